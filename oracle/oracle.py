@@ -1,0 +1,282 @@
+"""ctypes binding of the CPU oracle (oracle/librgc_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package.  PARITY UNPINNED (see rgc_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "librgc_oracle.so")
+
+DIRECT27, DIRECT7, DIRECT1 = 0, 1, 2
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("rgc_oracle.c", "rgc_oracle_aux.c", "rgc_oracle.h", "Makefile")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+class Params(C.Structure):
+    _fields_ = [("voxel_res", C.c_double), ("max_iterations", C.c_int), ("lm_max_iterations", C.c_int),
+                ("rotation_eps", C.c_double), ("translation_eps", C.c_double), ("lm_init_lambda_factor", C.c_double),
+                ("k_correspondences", C.c_int), ("neighbor_method", C.c_int), ("num_threads", C.c_int)]
+
+
+class LmTrace(C.Structure):
+    _fields_ = [("outer", C.c_int), ("inner", C.c_int), ("n_corr", C.c_int), ("y0", C.c_double), ("yi", C.c_double),
+                ("rho", C.c_double), ("lambda_before", C.c_double), ("lambda_after", C.c_double), ("accepted", C.c_int),
+                ("x", C.c_double * 16)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        fp, ip, dp, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p
+        L.orc_default_params.argtypes = [C.POINTER(Params)]
+        L.orc_knn.argtypes = [fp, C.c_int, C.c_int, C.c_int, ip, fp, C.c_int]
+        L.orc_covariances.argtypes = [fp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int]
+        L.orc_cov_from_neighbors.argtypes = [fp, C.c_int, ip, C.c_int, dp, dp]
+        L.orc_eig3.argtypes = [dp, dp, dp]
+        L.orc_voxelmap_create.argtypes = [fp, C.c_int, C.c_int, dp, C.c_double]
+        L.orc_voxelmap_create.restype = vp
+        L.orc_voxelmap_free.argtypes = [vp]
+        L.orc_voxelmap_size.argtypes = [vp]
+        L.orc_voxelmap_dump.argtypes = [vp, ip, ip, dp, dp]
+        L.orc_voxel_coord.argtypes = [dp, C.c_double, ip]
+        L.orc_reg_create.argtypes = [C.POINTER(Params)]
+        L.orc_reg_create.restype = vp
+        L.orc_reg_free.argtypes = [vp]
+        L.orc_reg_set_target.argtypes = [vp, fp, C.c_int, C.c_int]
+        L.orc_reg_set_source.argtypes = [vp, fp, C.c_int, C.c_int]
+        L.orc_reg_prepare.argtypes = [vp]
+        L.orc_reg_linearize.argtypes = [vp, dp, dp, dp]
+        L.orc_reg_linearize.restype = C.c_double
+        L.orc_reg_compute_error.argtypes = [vp, dp]
+        L.orc_reg_compute_error.restype = C.c_double
+        L.orc_reg_num_correspondences.argtypes = [vp]
+        L.orc_reg_align.argtypes = [vp, fp, fp, dp, ip, ip, C.POINTER(LmTrace), C.c_int]
+        L.orc_reg_num_linearize.argtypes = [vp]
+        L.orc_reg_num_error.argtypes = [vp]
+        L.orc_reg_fitness.argtypes = [vp, fp]
+        L.orc_reg_fitness.restype = C.c_double
+        L.orc_reg_source_cov.argtypes = [vp]
+        L.orc_reg_source_cov.restype = dp
+        L.orc_reg_target_cov.argtypes = [vp]
+        L.orc_reg_target_cov.restype = dp
+        L.orc_reg_voxelmap.argtypes = [vp]
+        L.orc_reg_voxelmap.restype = vp
+        L.orc_voxelgrid_filter.argtypes = [fp, C.c_int, C.c_float, fp]
+        L.orc_so3_exp.argtypes = [dp, dp]
+        L.orc_is_converged.argtypes = [dp, C.c_double, C.c_double]
+        L.orc_transform_f32.argtypes = [fp, C.c_int, C.c_int, fp, fp]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().orc_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def knn(xyz, k=20, threads=0):
+    a, ap = _f32(xyz)
+    n = a.shape[0]
+    idx = np.empty((n, k), np.int32)
+    d2 = np.empty((n, k), np.float32)
+    rc = lib().orc_knn(ap, n, a.shape[1], k, _ip(idx), d2.ctypes.data_as(C.POINTER(C.c_float)), threads)
+    if rc:
+        raise RuntimeError(f"orc_knn rc={rc}")
+    return idx, d2
+
+
+def covariances(xyz, k=20, threads=0):
+    a, ap = _f32(xyz)
+    n = a.shape[0]
+    cov = np.empty((n, 3, 3), np.float64)
+    nrm = np.empty((n, 3), np.float64)
+    rc = lib().orc_covariances(ap, n, a.shape[1], k, cov.ctypes.data_as(C.POINTER(C.c_double)),
+                               nrm.ctypes.data_as(C.POINTER(C.c_double)), threads)
+    if rc:
+        raise RuntimeError(f"orc_covariances rc={rc}")
+    return cov, nrm
+
+
+def eig3(A):
+    a, ap = _f64(A)
+    ev = np.empty(3)
+    V = np.empty((3, 3))
+    lib().orc_eig3(ap, ev.ctypes.data_as(C.POINTER(C.c_double)), V.ctypes.data_as(C.POINTER(C.c_double)))
+    return ev, V
+
+
+def _dump_vm(handle):
+    L = lib()
+    V = L.orc_voxelmap_size(handle)
+    coords = np.empty((V, 3), np.int32)
+    num = np.empty(V, np.int32)
+    mean = np.empty((V, 3))
+    cov = np.empty((V, 3, 3))
+    L.orc_voxelmap_dump(handle, _ip(coords), _ip(num), mean.ctypes.data_as(C.POINTER(C.c_double)),
+                        cov.ctypes.data_as(C.POINTER(C.c_double)))
+    return dict(coords=coords, num=num, mean=mean, cov=cov)
+
+
+def voxelmap(xyz, cov, res=1.0):
+    a, ap = _f32(xyz)
+    c, cp = _f64(cov)
+    h = lib().orc_voxelmap_create(ap, a.shape[0], a.shape[1], cp, res)
+    try:
+        return _dump_vm(h)
+    finally:
+        lib().orc_voxelmap_free(h)
+
+
+def voxel_coord(x, res=1.0):
+    a, ap = _f64(x)
+    c = np.empty(3, np.int32)
+    lib().orc_voxel_coord(ap, res, _ip(c))
+    return c
+
+
+def voxelgrid_filter(xyzi, leaf):
+    a, ap = _f32(xyzi)
+    assert a.shape[1] == 4
+    out = np.empty_like(a)
+    m = lib().orc_voxelgrid_filter(ap, a.shape[0], leaf, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if m < 0:
+        return a.copy()
+    return out[:m].copy()
+
+
+def so3_exp(w):
+    a, ap = _f64(w)
+    q = np.empty(4)
+    lib().orc_so3_exp(ap, q.ctypes.data_as(C.POINTER(C.c_double)))
+    return q
+
+
+def transform_f32(xyz, T):
+    a, ap = _f32(xyz)
+    t, tp = _f32(np.asarray(T).reshape(16))
+    out = np.empty((a.shape[0], 3), np.float32)
+    lib().orc_transform_f32(ap, a.shape[0], a.shape[1], tp, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+class Registration:
+    """Mirror of the FastVGICP call sequence at RGC_odometer.cpp:998-1011, CPU oracle backend."""
+
+    def __init__(self, **params):
+        self.params = default_params(**params)
+        self._h = lib().orc_reg_create(C.byref(self.params))
+        self._keep = {}
+        self.final_T = np.eye(4, dtype=np.float32)
+        self.final_H = np.eye(6)
+        self.converged = False
+        self.lm_failed = False
+        self.iterations = 0
+        self.trace = []
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_reg_free(self._h)
+            self._h = None
+
+    def set_target(self, xyz):
+        a, ap = _f32(xyz)
+        lib().orc_reg_set_target(self._h, ap, a.shape[0], a.shape[1])
+
+    def set_source(self, xyz):
+        a, ap = _f32(xyz)
+        lib().orc_reg_set_source(self._h, ap, a.shape[0], a.shape[1])
+
+    def prepare(self):
+        rc = lib().orc_reg_prepare(self._h)
+        if rc:
+            raise RuntimeError(f"orc_reg_prepare rc={rc}")
+
+    def linearize(self, T, want_H=True):
+        t, tp = _f64(np.asarray(T, dtype=np.float64).reshape(16))
+        if want_H:
+            H = np.empty((6, 6))
+            b = np.empty(6)
+            cost = lib().orc_reg_linearize(self._h, tp, H.ctypes.data_as(C.POINTER(C.c_double)),
+                                           b.ctypes.data_as(C.POINTER(C.c_double)))
+            return cost, H, b
+        return lib().orc_reg_linearize(self._h, tp, None, None), None, None
+
+    def compute_error(self, T):
+        t, tp = _f64(np.asarray(T, dtype=np.float64).reshape(16))
+        return lib().orc_reg_compute_error(self._h, tp)
+
+    @property
+    def num_correspondences(self):
+        return lib().orc_reg_num_correspondences(self._h)
+
+    def align(self, guess=None, max_trace=64):
+        g = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, dtype=np.float32)
+        g, gp = _f32(g.reshape(16))
+        fin = np.empty(16, np.float32)
+        H = np.empty((6, 6))
+        conv, fail = C.c_int(0), C.c_int(0)
+        tr = (LmTrace * max_trace)()
+        it = lib().orc_reg_align(self._h, gp, fin.ctypes.data_as(C.POINTER(C.c_float)),
+                                 H.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv), C.byref(fail), tr, max_trace)
+        if it < 0:
+            raise RuntimeError("orc_reg_align failed (need >= k points in both clouds)")
+        self.final_T = fin.reshape(4, 4)
+        self.final_H = H
+        self.converged, self.lm_failed, self.iterations = bool(conv.value), bool(fail.value), it
+        self.n_linearize = lib().orc_reg_num_linearize(self._h)
+        self.n_error = lib().orc_reg_num_error(self._h)
+        self.trace = [dict(outer=t.outer, inner=t.inner, n_corr=t.n_corr, y0=t.y0, yi=t.yi, rho=t.rho,
+                           lambda_before=t.lambda_before, lambda_after=t.lambda_after, accepted=t.accepted,
+                           x=np.array(t.x[:]).reshape(4, 4)) for t in tr[:min(it, max_trace)]]
+        return self.final_T
+
+    def fitness(self, T=None):
+        t = self.final_T if T is None else np.asarray(T, dtype=np.float32)
+        t, tp = _f32(t.reshape(16))
+        return lib().orc_reg_fitness(self._h, tp)
+
+    def source_cov(self, n):
+        p = lib().orc_reg_source_cov(self._h)
+        return np.ctypeslib.as_array(p, shape=(n, 3, 3)).copy()
+
+    def target_cov(self, n):
+        p = lib().orc_reg_target_cov(self._h)
+        return np.ctypeslib.as_array(p, shape=(n, 3, 3)).copy()
+
+    def voxelmap(self):
+        return _dump_vm(lib().orc_reg_voxelmap(self._h))

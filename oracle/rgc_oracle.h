@@ -1,0 +1,117 @@
+/*
+ * rgc_oracle.h -- CPU restatement of the RGC-SLAM scan-to-map registration path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle (and the timed CPU
+ * baseline) for the HIP path; the product library (librgc_hip.so) never links,
+ * loads or calls anything in this directory.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may use it.
+ *
+ * PARITY UNPINNED: the reference (ROBOT-WSC/RGC-SLAM @2024_10_08) ships no tests,
+ * golden vectors or fixtures for this path and cannot be compiled in this image
+ * (needs ROS1, PCL, Eigen, Ceres, Boost -- none installed, no network).  The
+ * oracle is therefore pinned only by (i) an independent numpy/scipy restatement
+ * (oracle/py_oracle.py -> tests/golden/), (ii) analytic known-answer cases and
+ * (iii) recovery of known SE(3) motions.  See DESIGN.md.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/rgc_slam/).
+ */
+#ifndef RGC_ORACLE_H
+#define RGC_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum order follows include/fast_gicp/gicp/gicp_settings.hpp:8 */
+enum { ORC_DIRECT27 = 0, ORC_DIRECT7 = 1, ORC_DIRECT1 = 2 };
+
+typedef struct {
+  double voxel_res;             /* RGC_odometer.cpp:308,1000  (1.0)                  */
+  int    max_iterations;        /* RGC_odometer.cpp:1001      (25)                   */
+  int    lm_max_iterations;     /* lsq_registration_impl.hpp:17 (10)                 */
+  double rotation_eps;          /* lsq_registration_impl.hpp:12 (2e-3)               */
+  double translation_eps;       /* RGC_odometer.cpp:1003      (1e-6)                 */
+  double lm_init_lambda_factor; /* lsq_registration_impl.hpp:18 (1e-9)               */
+  int    k_correspondences;     /* fast_gicp_impl.hpp:16      (20)                   */
+  int    neighbor_method;       /* fast_vgicp_impl.hpp:23     (ORC_DIRECT1)          */
+  int    num_threads;           /* RGC_odometer.cpp:1006      (14; 0 = omp max)      */
+} orc_params;
+
+void orc_default_params(orc_params* p);
+
+/* ---- C1/C2: exact kNN + PLANE-regularised covariance (fast_gicp_impl.hpp:241-298) ---- */
+/* pts: AoS floats, point i at pts + i*stride (x,y,z first).  idx_out: n*k ints sorted by
+ * (float squared distance, index); d2_out: n*k floats (may be NULL). returns 0 / <0 error. */
+int orc_knn(const float* pts, int n, int stride, int k, int* idx_out, float* d2_out, int num_threads);
+/* cov9_out: n*9 doubles row-major 3x3 (the block<3,3>(0,0) of the reference's Matrix4d);
+ * normal_out: n*3 unit eigenvector of the least eigenvalue (may be NULL). */
+int orc_covariances(const float* pts, int n, int stride, int k, double* cov9_out, double* normal_out, int num_threads);
+/* covariance of ONE neighbourhood given explicit indices (for known-answer tests) */
+void orc_cov_from_neighbors(const float* pts, int stride, const int* idx, int k, double cov9[9], double normal[3]);
+/* symmetric 3x3 eigen decomposition (cyclic Jacobi); evals descending, evecs columns row-major */
+void orc_eig3(const double A[9], double evals[3], double evecs[9]);
+
+/* ---- C3: Gaussian voxel map (fast_vgicp_voxel.hpp:105-182) ---- */
+typedef struct orc_voxelmap orc_voxelmap;
+orc_voxelmap* orc_voxelmap_create(const float* pts, int n, int stride, const double* cov9, double res);
+void orc_voxelmap_free(orc_voxelmap*);
+int  orc_voxelmap_size(const orc_voxelmap*);
+/* dump sorted by (cx,cy,cz): coords 3V ints, num V ints, mean 3V doubles, cov 9V doubles */
+void orc_voxelmap_dump(const orc_voxelmap*, int* coords, int* num, double* mean, double* cov9);
+/* voxel_coord (fast_vgicp_voxel.hpp:158-160) */
+void orc_voxel_coord(const double x[3], double res, int c[3]);
+
+/* ---- C4-C9: registration object mirroring FastVGICP as called at RGC_odometer.cpp:998-1011 ---- */
+typedef struct orc_reg orc_reg;
+orc_reg* orc_reg_create(const orc_params* p);
+void orc_reg_free(orc_reg*);
+int  orc_reg_set_target(orc_reg*, const float* pts, int n, int stride);   /* fast_vgicp_impl.hpp:56-63 */
+int  orc_reg_set_source(orc_reg*, const float* pts, int n, int stride);   /* fast_gicp_impl.hpp:72-80  */
+/* force covariance + voxel map computation now (otherwise lazily in align/linearize) */
+int  orc_reg_prepare(orc_reg*);
+/* fast_vgicp_impl.hpp:119-180.  T row-major 4x4 double.  H(36 row-major)/b(6) may be NULL. */
+double orc_reg_linearize(orc_reg*, const double T[16], double* H, double* b);
+/* fast_vgicp_impl.hpp:183-204 -- frozen correspondences + Mahalanobis of the last linearize */
+double orc_reg_compute_error(orc_reg*, const double T[16]);
+int  orc_reg_num_correspondences(const orc_reg*);
+
+typedef struct {
+  int    outer;        /* outer iteration index                       */
+  int    inner;        /* number of LM tries in this outer iteration  */
+  int    n_corr;
+  double y0, yi, rho, lambda_before, lambda_after;
+  int    accepted;     /* 1 = x updated, 0 = rho<0 && converged exit  */
+  double x[16];        /* pose after this outer iteration             */
+} orc_lm_trace;
+
+/* lsq_registration_impl.hpp:53-172.  guess/final row-major 4x4 float.  trace: up to
+ * max_trace entries (may be NULL).  returns number of outer iterations executed. */
+int orc_reg_align(orc_reg*, const float guess[16], float final_T[16], double final_H[36],
+                  int* converged, int* lm_failed, orc_lm_trace* trace, int max_trace);
+int orc_reg_num_linearize(const orc_reg*);   /* counters since last align start */
+int orc_reg_num_error(const orc_reg*);
+/* pcl::Registration::getFitnessScore (RGC_odometer.cpp:1010) */
+double orc_reg_fitness(orc_reg*, const float final_T[16]);
+/* access the lazily computed per-point results */
+const double* orc_reg_source_cov(orc_reg*);   /* n_s*9 */
+const double* orc_reg_target_cov(orc_reg*);   /* n_t*9 */
+const orc_voxelmap* orc_reg_voxelmap(orc_reg*);
+
+/* ---- B3: pcl::VoxelGrid<PointXYZI>::filter restatement (RGC_odometer.cpp:976-991) ---- */
+/* pts: n*4 floats (x,y,z,intensity). out: caller buffer n*4. returns number of output points,
+ * or -1 if the leaf grid overflows int (PCL then returns the input unfiltered). */
+int orc_voxelgrid_filter(const float* xyzi, int n, float leaf, float* out_xyzi);
+
+/* ---- C7 helpers ---- */
+void orc_so3_exp(const double omega[3], double q_wxyz[4]);                 /* so3/so3.hpp:58-77 */
+int  orc_is_converged(const double delta[16], double rot_eps, double trans_eps); /* lsq_registration_impl.hpp:82-91 */
+
+/* ---- point transforms ---- */
+/* pcl::transformPointCloud restated in fp32 (lsq_registration_impl.hpp:78) */
+void orc_transform_f32(const float* pts, int n, int stride, const float T[16], float* out_xyz /* n*3 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

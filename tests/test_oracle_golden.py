@@ -1,0 +1,140 @@
+"""C oracle (oracle/rgc_oracle.c) vs the golden fixtures produced by the independent numpy/scipy
+restatement (tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+
+from conftest import tri6
+
+
+def test_knn_sets(orc, fx_reg):
+    idx, d2 = orc.knn(fx_reg["src"], 20)
+    got = np.sort(idx, axis=1)
+    bad = np.sum(np.any(got != fx_reg["src_knn"], axis=1))
+    assert bad <= 2, f"{bad} source neighbourhoods differ (only float-vs-double near ties may)"
+    assert np.all(np.diff(d2, axis=1) >= 0)
+    assert np.all(d2[:, 0] == 0) and np.all(idx[:, 0] == np.arange(len(idx)))
+    idx_t, _ = orc.knn(fx_reg["tgt"], 20)
+    bad = np.sum(np.any(np.sort(idx_t[::8], axis=1) != fx_reg["tgt_knn_sub"], axis=1))
+    assert bad <= 2
+
+
+def test_covariances(orc, fx_reg):
+    cov, nrm = orc.covariances(fx_reg["src"], 20)
+    err = np.abs(tri6(cov) - fx_reg["src_cov6"]).max(axis=1)
+    assert np.sum(err > 1e-9) <= 2, err.max()
+    # PLANE regularisation: C = I - 0.999 n n^T, eigenvalues {1, 1, 1e-3}
+    ev = np.linalg.eigvalsh(cov)
+    assert np.allclose(ev, [1e-3, 1.0, 1.0], atol=1e-12)
+    rebuilt = np.eye(3)[None] - 0.999 * nrm[:, :, None] * nrm[:, None, :]
+    assert np.abs(rebuilt - cov).max() < 1e-12
+    cov_t, _ = orc.covariances(fx_reg["tgt"], 20)
+    err = np.abs(tri6(cov_t[::4]) - fx_reg["tgt_cov6_sub"]).max(axis=1)
+    assert np.sum(err > 1e-9) <= 2
+
+
+def test_eig3_known(orc):
+    A = np.diag([3.0, 1.0, 2.0])
+    ev, V = orc.eig3(A)
+    assert np.allclose(ev, [3, 2, 1])
+    assert np.allclose(np.abs(V), [[1, 0, 0], [0, 0, 1], [0, 1, 0]])
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        B = rng.normal(size=(3, 3))
+        S = B @ B.T
+        ev, V = orc.eig3(S)
+        assert np.allclose(V @ np.diag(ev) @ V.T, S, atol=1e-12)
+        assert np.allclose(np.sort(ev), np.linalg.eigvalsh(S), atol=1e-12)
+
+
+def test_voxelmap(orc, fx_reg):
+    cov, _ = orc.covariances(fx_reg["tgt"], 20)
+    vm = orc.voxelmap(fx_reg["tgt"], cov, 1.0)
+    assert np.array_equal(vm["coords"], fx_reg["vox_coords"])
+    assert np.array_equal(vm["num"], fx_reg["vox_num"])
+    assert np.abs(vm["mean"] - fx_reg["vox_mean"]).max() < 1e-12
+    assert np.abs(tri6(vm["cov"]) - fx_reg["vox_cov6"]).max() < 1e-9
+    assert vm["num"].sum() == len(fx_reg["tgt"])
+
+
+def test_voxel_coord_table(orc, fx_small):
+    for x, c1, c05 in zip(fx_small["vc_x"], fx_small["vc_res1"], fx_small["vc_res05"]):
+        assert np.array_equal(orc.voxel_coord(x, 1.0), c1)
+        assert np.array_equal(orc.voxel_coord(x, 0.5), c05)
+    # the -0.5 offset of fast_vgicp_voxel.hpp:158-160
+    assert list(orc.voxel_coord([0.5, -0.5, -1.5], 1.0)) == [0, -1, -2]
+    assert list(orc.voxel_coord([1.4999, 0.4999, -0.5001], 1.0)) == [0, -1, -2]
+
+
+def test_so3_exp(orc, fx_small):
+    for w, R in zip(fx_small["so3_w"], fx_small["so3_R"]):
+        q = orc.so3_exp(w)
+        qw, qx, qy, qz = q
+        Rq = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                       [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                       [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+        assert np.abs(Rq - R).max() < 1e-14
+
+
+def _reg(orc, fx, **kw):
+    r = orc.Registration(num_threads=4, **kw)
+    r.set_target(fx["tgt"])
+    r.set_source(fx["src"])
+    return r
+
+
+def test_linearize_direct1(orc, fx_reg):
+    r = _reg(orc, fx_reg)
+    cost, H, b = r.linearize(fx_reg["guess"])
+    assert r.num_correspondences == int(fx_reg["lin_ncorr"])
+    assert abs(cost - fx_reg["lin_cost"]) <= 1e-9 * abs(fx_reg["lin_cost"])
+    assert np.abs(H - fx_reg["lin_H"]).max() <= 1e-9 * np.abs(fx_reg["lin_H"]).max()
+    assert np.abs(b - fx_reg["lin_b"]).max() <= 1e-9 * np.abs(fx_reg["lin_b"]).max()
+    assert np.allclose(H, H.T, rtol=0, atol=1e-9 * np.abs(H).max())
+    assert np.linalg.eigvalsh(H).min() > 0
+    # frozen correspondences (fast_vgicp_impl.hpp:183-204)
+    e = r.compute_error(fx_reg["err_T"])
+    assert abs(e - fx_reg["err_cost"]) <= 1e-9 * abs(fx_reg["err_cost"])
+    # cost-only path returns the same cost
+    c2, _, _ = r.linearize(fx_reg["guess"], want_H=False)
+    assert abs(c2 - cost) <= 1e-12 * abs(cost)
+
+
+def test_linearize_direct7(orc, fx_reg):
+    r = _reg(orc, fx_reg, neighbor_method=orc.DIRECT7)
+    cost, H, b = r.linearize(fx_reg["guess"])
+    assert r.num_correspondences == int(fx_reg["lin7_ncorr"])
+    assert abs(cost - fx_reg["lin7_cost"]) <= 1e-9 * abs(fx_reg["lin7_cost"])
+    assert np.abs(H - fx_reg["lin7_H"]).max() <= 1e-9 * np.abs(fx_reg["lin7_H"]).max()
+    assert np.abs(b - fx_reg["lin7_b"]).max() <= 1e-9 * np.abs(fx_reg["lin7_b"]).max()
+
+
+def test_lm_trace_and_final(orc, fx_reg):
+    r = _reg(orc, fx_reg)
+    T = r.align(fx_reg["guess"])
+    n = len(fx_reg["lm_y0"])
+    assert r.iterations == n
+    assert r.converged == bool(fx_reg["converged"])
+    for k, t in enumerate(r.trace):
+        assert t["inner"] == fx_reg["lm_inner"][k]
+        assert t["accepted"] == fx_reg["lm_accepted"][k]
+        assert t["n_corr"] == fx_reg["lm_ncorr"][k]
+        assert abs(t["y0"] - fx_reg["lm_y0"][k]) <= 1e-7 * abs(fx_reg["lm_y0"][k])
+        assert np.abs(t["x"] - fx_reg["lm_x"][k]).max() < 1e-8
+    assert np.abs(T - fx_reg["final_T"]).max() < 1e-6
+    assert abs(r.fitness() - fx_reg["fitness"]) <= 1e-5 * fx_reg["fitness"]
+
+
+def test_identity_registration(orc, fx_reg):
+    """cloud against itself: every voxel's residuals sum to zero at identity, so the recovered motion is tiny
+    (not exactly zero: each residual is weighted by its own Mahalanobis matrix)"""
+    r = orc.Registration(num_threads=4)
+    r.set_target(fx_reg["tgt"])
+    r.set_source(fx_reg["tgt"])
+    T = r.align(np.eye(4))
+    assert np.abs(T - np.eye(4)).max() < 5e-3
+
+
+def test_voxelgrid(orc, fx_vg):
+    for leaf, key in ((0.2, "out_02"), (0.3, "out_03")):
+        out = orc.voxelgrid_filter(fx_vg["xyzi"], leaf)
+        assert out.shape == fx_vg[key].shape
+        assert np.abs(out - fx_vg[key]).max() < 1e-4
