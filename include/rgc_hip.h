@@ -1,0 +1,158 @@
+/*
+ * rgc_hip.h -- C-ABI of librgc_hip.so: the MI355X (gfx950) scan-to-map registration path of RGC-SLAM.
+ *
+ * Plain C: opaque context, plain pointers and sizes, int status codes.  No C++/PCL/Eigen/ROS/torch types.
+ * Every entry point names the reference interface it replaces; paths are relative to
+ * /root/reference/rgc_slam/ (ROBOT-WSC/RGC-SLAM @2024_10_08).
+ *
+ * Ownership: the caller owns every host buffer for the duration of the call only (inputs are copied to
+ *   the device before the call returns); the context owns all device memory, its HIP stream and events.
+ * Threading: a context is NOT thread-safe and is bound to one HIP device; use one context per
+ *   sequence / GPU, driven by one host thread (the reference drives registration from the single
+ *   ICP_thread, src/RGC_odometer.cpp:408).
+ * Errors: 0 = OK, negative = rgc_status; nothing aborts or throws across this boundary (the reference
+ *   prints "lm not converged!!" and carries on, lsq_registration_impl.hpp:69-72; here that is the
+ *   `lm_failed` output).  rgc_last_error() returns a human-readable message for the last failure.
+ * There is NO CPU fallback: if no HIP device / kernel image is available every call fails with
+ *   RGC_ERR_HIP.
+ *
+ * Matrices: 4x4 poses and 6x6 Hessians are ROW-MAJOR.  The 6-vector order is [rotation(3), translation(3)]
+ *   with a LEFT-multiplied perturbation, exactly as LsqRegistration (lsq_registration_impl.hpp:139-143).
+ */
+#ifndef RGC_HIP_H
+#define RGC_HIP_H
+
+#include <stddef.h>
+
+#if defined(__GNUC__) || defined(__clang__)
+#define RGC_API __attribute__((visibility("default")))
+#else
+#define RGC_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rgc_ctx rgc_ctx;
+
+typedef enum rgc_status {
+  RGC_OK = 0,
+  RGC_ERR_INVALID = -1,         /* bad argument / call order                                   */
+  RGC_ERR_HIP = -2,             /* HIP runtime error (no device, OOM, launch failure, ...)     */
+  RGC_ERR_TOO_FEW_POINTS = -3,  /* cloud has fewer than k_correspondences points (undefined in
+                                   the reference, fast_gicp_impl.hpp:256-259)      */
+  RGC_ERR_GRID_TOO_LARGE = -4,  /* bounding box / resolution needs more cells than max_cells   */
+  RGC_ERR_NO_INPUT = -5,        /* source or target not set                                    */
+  RGC_ERR_NONFINITE = -6        /* input contains NaN/Inf coordinates                          */
+} rgc_status;
+
+/* enum order = fast_gicp::NeighborSearchMethod, include/fast_gicp/gicp/gicp_settings.hpp:8 */
+typedef enum rgc_neighbor_method { RGC_DIRECT27 = 0, RGC_DIRECT7 = 1, RGC_DIRECT1 = 2 } rgc_neighbor_method;
+
+/* Parameter block = the setters the odometer calls on fast_gicp::FastVGICP (src/RGC_odometer.cpp:998-1006)
+ * plus the constructor defaults they leave untouched.  Defaults: rgc_default_params(). */
+typedef struct rgc_params {
+  double voxel_res;             /* setResolution(1.0)            RGC_odometer.cpp:308,1000; fast_vgicp_impl.hpp:32-34 */
+  int    max_iterations;        /* setMaximumIterations(25)      RGC_odometer.cpp:1001                                */
+  int    lm_max_iterations;     /* lm_max_iterations_ = 10       lsq_registration_impl.hpp:17                          */
+  double rotation_eps;          /* setRotationEpsilon (2e-3)     lsq_registration_impl.hpp:12,27-29                    */
+  double translation_eps;       /* setTransformationEpsilon(1e-6) RGC_odometer.cpp:1003                               */
+  double lm_init_lambda_factor; /* setInitialLambdaFactor (1e-9) lsq_registration_impl.hpp:18,32-34                    */
+  int    k_correspondences;     /* setCorrespondenceRandomness (20) fast_gicp_impl.hpp:16,41-43; 2..32 supported       */
+  int    neighbor_method;       /* setNeighborSearchMethod (RGC_DIRECT1) fast_vgicp_impl.hpp:23,37-39                  */
+  long long max_cells;          /* cap on dense grid cells per cloud (default 1<<29)                                  */
+} rgc_params;
+
+RGC_API void rgc_default_params(rgc_params* p);
+
+/* FastVGICP construction / destruction (a stack local re-created per frame at RGC_odometer.cpp:998;
+ * here the context is long-lived and re-used, device buffers grow on demand). */
+RGC_API int  rgc_create(int hip_device, const rgc_params* params /* NULL = defaults */, rgc_ctx** out);
+RGC_API void rgc_destroy(rgc_ctx* ctx);
+RGC_API int  rgc_set_params(rgc_ctx* ctx, const rgc_params* params);
+RGC_API int  rgc_get_params(const rgc_ctx* ctx, rgc_params* params);
+RGC_API const char* rgc_last_error(const rgc_ctx* ctx);
+RGC_API const char* rgc_status_string(int status);
+RGC_API const char* rgc_version(void);
+
+/* setInputTarget (fast_vgicp_impl.hpp:56-63) / setInputSource (fast_gicp_impl.hpp:72-80).
+ * xyz: first float of point 0; point i starts at (char*)xyz + i*stride_bytes (x,y,z consecutive floats;
+ * stride 16 or 32 = pcl::PointXYZI padding welcome).  Setting a cloud drops its covariances (and, for the
+ * target, the voxel map) exactly like the reference; the exact-kNN covariances (fast_gicp_impl.hpp:241-298),
+ * and for the target the Gaussian voxel map (fast_vgicp_voxel.hpp:129-156), are computed on the device
+ * (enqueued immediately on the context's stream). */
+RGC_API int rgc_set_target(rgc_ctx* ctx, const float* xyz, int n, int stride_bytes);
+RGC_API int rgc_set_source(rgc_ctx* ctx, const float* xyz, int n, int stride_bytes);
+/* same, but xyz is DEVICE memory on the context's device (cloud already resident in HBM). */
+RGC_API int rgc_set_target_device(rgc_ctx* ctx, const float* d_xyz, int n, int stride_bytes);
+RGC_API int rgc_set_source_device(rgc_ctx* ctx, const float* d_xyz, int n, int stride_bytes);
+
+/* LsqRegistration::linearize (lsq_registration.hpp:68; fast_vgicp_impl.hpp:119-180): rebuilds the voxel
+ * correspondences and Mahalanobis matrices at T, returns cost and (if both non-NULL) H, b. */
+RGC_API int rgc_linearize(rgc_ctx* ctx, const double T[16], double H[36], double b[6], double* cost);
+/* LsqRegistration::compute_error (lsq_registration.hpp:69; fast_vgicp_impl.hpp:183-204): cost at T with the
+ * correspondences and Mahalanobis matrices FROZEN at the last rgc_linearize. */
+RGC_API int rgc_compute_error(rgc_ctx* ctx, const double T[16], double* cost);
+RGC_API int rgc_num_correspondences(rgc_ctx* ctx, int* n_corr);
+
+/* pcl::Registration::align(out, guess) -> LsqRegistration::computeTransformation
+ * (lsq_registration_impl.hpp:53-79, LM step :125-172) + getFinalTransformation + getFinalHessian (:43-45)
+ * + getFitnessScore (RGC_odometer.cpp:1009-1011).  Any output pointer may be NULL.
+ *   final_T    : float 4x4 (final_transformation_ = x0.cast<float>(), :77)
+ *   final_H    : 6x6 of the last accepted LM step (identity if none, :21,167)
+ *   fitness    : mean squared 1-NN distance source->target (computed only if non-NULL)
+ *   iterations : outer iterations executed;  converged: hasConverged();  lm_failed: "lm not converged!!" */
+RGC_API int rgc_align(rgc_ctx* ctx, const float guess[16], float final_T[16], double final_H[36], double* fitness,
+              int* iterations, int* converged, int* lm_failed);
+/* pcl::Registration::getFitnessScore() for an arbitrary pose */
+RGC_API int rgc_fitness(rgc_ctx* ctx, const float T[16], double* fitness);
+/* the `output` cloud of align(): pcl::transformPointCloud(*input_, output, final_transformation_)
+ * (lsq_registration_impl.hpp:78) in the caller's point order; out stride in bytes (>= 12). */
+RGC_API int rgc_get_aligned(rgc_ctx* ctx, const float T[16], float* out_xyz, int stride_bytes);
+
+/* getSourceCovariances / getTargetCovariances analogue (fast_gicp.hpp): PLANE-regularised 3x3 covariances
+ * (row-major, n*9 doubles) and/or unit normals (n*3 doubles, sign arbitrary), caller point order. */
+RGC_API int rgc_get_source_covariances(rgc_ctx* ctx, double* cov9 /* may be NULL */, double* normals /* may be NULL */);
+RGC_API int rgc_get_target_covariances(rgc_ctx* ctx, double* cov9, double* normals);
+/* Gaussian voxel map dump (fast_vgicp_voxel.hpp:105-122): up to cap voxels, unordered.
+ * coords 3*cap ints, num cap ints, mean 3*cap doubles, cov9 9*cap doubles; *count = total voxels. */
+RGC_API int rgc_get_voxels(rgc_ctx* ctx, int cap, int* coords, int* num, double* mean, double* cov9, int* count);
+
+/* per-align statistics (reported by bench.py) */
+typedef struct rgc_stats {
+  int n_source, n_target, n_voxels, n_corr;
+  int outer_iterations, n_linearize, n_error;
+  long long target_cells, source_cells;
+} rgc_stats;
+RGC_API int rgc_get_stats(rgc_ctx* ctx, rgc_stats* out);
+
+/* ---- device plumbing for callers that keep clouds resident in HBM (bench, ROS adaptor) ---- */
+RGC_API int  rgc_device_alloc(rgc_ctx* ctx, size_t bytes, void** d_ptr);
+RGC_API int  rgc_device_free(rgc_ctx* ctx, void* d_ptr);
+RGC_API int  rgc_upload(rgc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* async on ctx stream */
+RGC_API int  rgc_download(rgc_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous          */
+RGC_API int  rgc_synchronize(rgc_ctx* ctx);
+RGC_API void* rgc_stream(rgc_ctx* ctx); /* the hipStream_t every kernel of this context is launched on */
+
+/* ---- in-library kernel timing with HIP events on the context's stream (bench.py roofline) ---- */
+enum {
+  RGC_K_GRID = 0,      /* bbox + count + scan + scatter + rank/gather                         */
+  RGC_K_KNN_COV = 1,   /* exact kNN + covariance + normal on the TARGET (the dominant kernel) */
+  RGC_K_VOXEL = 2,     /* Gaussian voxel map reduction                                        */
+  RGC_K_LINEARIZE = 3, /* correspondences + Mahalanobis + H/b/cost                            */
+  RGC_K_ERROR = 4,     /* frozen-correspondence cost                                          */
+  RGC_K_FITNESS = 5,   /* 1-NN fitness                                                        */
+  RGC_K_KNN_COV_SRC = 6, /* the same kernel on the (small) source cloud, separate instantiation */
+  RGC_K_COUNT = 7
+};
+RGC_API int rgc_profile_enable(rgc_ctx* ctx, int on);
+RGC_API int rgc_profile_reset(rgc_ctx* ctx);
+/* launches = timed regions of that kind; total_ms = summed hipEventElapsedTime; last_n = points of the last region */
+RGC_API int rgc_profile_get(rgc_ctx* ctx, int kind, long long* launches, double* total_ms, long long* total_points);
+RGC_API const char* rgc_profile_name(int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGC_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of librgc_hip.so (the C-ABI declared in include/rgc_hip.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is no CPU
+fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librgc_hip.so")
+
+DIRECT27, DIRECT7, DIRECT1 = 0, 1, 2
+
+K_GRID, K_KNN_COV, K_VOXEL, K_LINEARIZE, K_ERROR, K_FITNESS, K_KNN_COV_SRC, K_COUNT = range(8)
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_TOO_FEW_POINTS, ERR_GRID_TOO_LARGE, ERR_NO_INPUT, ERR_NONFINITE = -1, -2, -3, -4, -5, -6
+
+
+class Params(C.Structure):
+    _fields_ = [("voxel_res", C.c_double), ("max_iterations", C.c_int), ("lm_max_iterations", C.c_int),
+                ("rotation_eps", C.c_double), ("translation_eps", C.c_double), ("lm_init_lambda_factor", C.c_double),
+                ("k_correspondences", C.c_int), ("neighbor_method", C.c_int), ("max_cells", C.c_longlong)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_source", C.c_int), ("n_target", C.c_int), ("n_voxels", C.c_int), ("n_corr", C.c_int),
+                ("outer_iterations", C.c_int), ("n_linearize", C.c_int), ("n_error", C.c_int),
+                ("target_cells", C.c_longlong), ("source_cells", C.c_longlong)]
+
+
+class RgcError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"rgc_hip status {status}: {msg}")
+        self.status = status
+
+
+# every symbol include/rgc_hip.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "rgc_default_params", "rgc_create", "rgc_destroy", "rgc_set_params", "rgc_get_params", "rgc_last_error",
+    "rgc_status_string", "rgc_version", "rgc_set_target", "rgc_set_source", "rgc_set_target_device",
+    "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align",
+    "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
+    "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
+    "rgc_stream", "rgc_profile_enable", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+]
+
+_lib = None
+
+
+def load():
+    """Load librgc_hip.so and declare prototypes.  Raises if the library is missing (build with
+    `python rgc-slam_amd/build.py` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback); "
+                          f"run `python rgc-slam_amd/build.py`")
+    L = C.CDLL(LIB_PATH)
+    vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.rgc_default_params.argtypes = [C.POINTER(Params)]
+    L.rgc_default_params.restype = None
+    L.rgc_create.argtypes = [C.c_int, C.POINTER(Params), C.POINTER(vp)]
+    L.rgc_destroy.argtypes = [vp]
+    L.rgc_destroy.restype = None
+    L.rgc_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.rgc_get_params.argtypes = [vp, C.POINTER(Params)]
+    L.rgc_last_error.argtypes = [vp]
+    L.rgc_last_error.restype = C.c_char_p
+    L.rgc_status_string.argtypes = [C.c_int]
+    L.rgc_status_string.restype = C.c_char_p
+    L.rgc_version.restype = C.c_char_p
+    for f in (L.rgc_set_target, L.rgc_set_source, L.rgc_set_target_device, L.rgc_set_source_device):
+        f.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.rgc_linearize.argtypes = [vp, dp, dp, dp, dp]
+    L.rgc_compute_error.argtypes = [vp, dp, dp]
+    L.rgc_num_correspondences.argtypes = [vp, ip]
+    L.rgc_align.argtypes = [vp, fp, fp, dp, dp, ip, ip, ip]
+    L.rgc_fitness.argtypes = [vp, fp, dp]
+    L.rgc_get_aligned.argtypes = [vp, fp, fp, C.c_int]
+    L.rgc_get_source_covariances.argtypes = [vp, dp, dp]
+    L.rgc_get_target_covariances.argtypes = [vp, dp, dp]
+    L.rgc_get_voxels.argtypes = [vp, C.c_int, ip, ip, dp, dp, ip]
+    L.rgc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rgc_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.rgc_device_free.argtypes = [vp, vp]
+    L.rgc_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.rgc_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.rgc_synchronize.argtypes = [vp]
+    L.rgc_stream.argtypes = [vp]
+    L.rgc_stream.restype = vp
+    L.rgc_profile_enable.argtypes = [vp, C.c_int]
+    L.rgc_profile_reset.argtypes = [vp]
+    L.rgc_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, C.POINTER(C.c_longlong)]
+    L.rgc_profile_name.argtypes = [C.c_int]
+    L.rgc_profile_name.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load().rgc_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p

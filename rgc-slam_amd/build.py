@@ -1,0 +1,42 @@
+"""Builds librgc_hip.so (the product: HIP kernels + C-ABI) in-tree with hipcc for gfx950.
+
+    python rgc-slam_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: the exact-kNN parity with the CPU path
+depends on the fp32 squared distance not being FMA-contracted (see csrc/rgc_kernels.hip header).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librgc_hip.so")
+SRCS = ["rgc_api.hip", "rgc_kernels.hip"]
+DEPS = SRCS + ["rgc_kernels.h", os.path.join("..", "..", "include", "rgc_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden", "-DRGC_BUILD"]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    objs = []
+    for src in SRCS:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,811 @@
+// rgc_api.hip -- host side of librgc_hip.so: context, device buffers, the LM driver and the C-ABI of
+// include/rgc_hip.h.  The per-point work is in rgc_kernels.hip; this file holds the scalar control flow the
+// reference runs in LsqRegistration (lsq_registration_impl.hpp:53-172) and the buffer plumbing.
+//
+// No CPU fallback exists: every entry point fails with RGC_ERR_HIP when the HIP runtime / device is missing.
+// Reference citations are relative to /root/reference/rgc_slam/.
+#include "../../include/rgc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rgc_kernels.h"
+
+namespace {
+
+constexpr int kMaxK = 32;
+constexpr int kProfKinds = RGC_K_COUNT;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct Cloud {
+  // input (device copy owned by ctx, or caller's device pointer)
+  const float* in = nullptr;
+  int stride_f = 0;
+  int n = 0;
+  bool ready = false;  // grid + normals (+ voxels for the target) enqueued
+  DevBuf in_copy, cell_of, cnt, start, block_sums, order_tmp, order, xs, ys, zs, nx, ny, nz;
+  rgck::Grid grid{};
+  // target only
+  DevBuf cell_voxel, vox, vox_cell;
+  int nvox = -1;
+};
+
+struct ProfRegion {
+  hipEvent_t a, b;
+  int kind;
+  long long points;
+};
+
+}  // namespace
+
+struct rgc_ctx {
+  int device = 0;
+  rgc_params prm{};
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  Cloud src, tgt;
+  // per-correspondence state frozen by linearize (fast_vgicp_impl.hpp:104-115)
+  DevBuf corr_v, corr_M, partials, ipartials;
+  int corr_noff = 0, corr_n = 0;
+  bool corr_valid = false;
+  // small device scratch + pinned host mirrors
+  int* d_small = nullptr;     // [0..5] bbox, [6] flags, [7] nvox, [8] ncorr
+  double* d_out = nullptr;    // 28 doubles
+  int* h_small = nullptr;     // pinned
+  double* h_out = nullptr;    // pinned
+  DevBuf scratch;             // getters
+  rgc_stats stats{};
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRegion> prof_open;
+  std::vector<hipEvent_t> ev_pool;
+  long long prof_launches[kProfKinds] = {0};
+  double prof_ms[kProfKinds] = {0};
+  long long prof_points[kProfKinds] = {0};
+};
+
+namespace {
+
+int fail(rgc_ctx* c, int code, const char* fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                                    \
+  do {                                                                                                     \
+    hipError_t _e = (expr);                                                                                \
+    if (_e != hipSuccess) return fail((c), RGC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+int ensure(rgc_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return RGC_OK;
+  if (b.p) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;  // head-room: clouds of similar size arrive every frame
+  HIPCHK(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return RGC_OK;
+}
+
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+void release_cloud(Cloud& cl) {
+  for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.order, &cl.xs, &cl.ys,
+                    &cl.zs, &cl.nx, &cl.ny, &cl.nz, &cl.cell_voxel, &cl.vox, &cl.vox_cell})
+    release(*b);
+}
+
+// ---- profiling regions (HIP events on the context's stream) ----
+struct ProfScope {
+  rgc_ctx* c;
+  bool on;
+  ProfRegion r{};
+  ProfScope(rgc_ctx* ctx, int kind, long long points) : c(ctx), on(ctx->prof_on) {
+    if (!on) return;
+    auto get = [&](hipEvent_t* e) {
+      if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
+      return hipEventCreate(e) == hipSuccess;
+    };
+    if (!get(&r.a) || !get(&r.b)) { on = false; return; }
+    r.kind = kind;
+    r.points = points;
+    (void)hipEventRecord(r.a, c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, c->stream);
+    c->prof_open.push_back(r);
+  }
+};
+
+void prof_collect(rgc_ctx* c) {
+  for (auto& r : c->prof_open) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->prof_launches[r.kind]++;
+      c->prof_ms[r.kind] += (double)ms;
+      c->prof_points[r.kind] += r.points;
+    }
+    c->ev_pool.push_back(r.a);
+    c->ev_pool.push_back(r.b);
+  }
+  c->prof_open.clear();
+}
+
+int noff_of(int method) { return method == RGC_DIRECT1 ? 1 : (method == RGC_DIRECT7 ? 7 : 27); }
+
+int check_params(rgc_ctx* c, const rgc_params* p) {
+  if (!(p->voxel_res > 0.0) || !std::isfinite(p->voxel_res)) return fail(c, RGC_ERR_INVALID, "voxel_res must be > 0");
+  if (p->k_correspondences < 2 || p->k_correspondences > kMaxK) return fail(c, RGC_ERR_INVALID, "k_correspondences must be in [2,%d]", kMaxK);
+  if (p->neighbor_method < RGC_DIRECT27 || p->neighbor_method > RGC_DIRECT1) return fail(c, RGC_ERR_INVALID, "bad neighbor_method");
+  if (p->max_iterations < 0 || p->lm_max_iterations < 1) return fail(c, RGC_ERR_INVALID, "bad iteration limits");
+  if (!(p->rotation_eps > 0) || !(p->translation_eps > 0)) return fail(c, RGC_ERR_INVALID, "epsilons must be > 0");
+  if (p->max_cells < 1) return fail(c, RGC_ERR_INVALID, "max_cells must be >= 1");
+  return RGC_OK;
+}
+
+// C1-C3: grid + exact-kNN covariances (+ voxel map for the target), all enqueued on the stream.
+// One host<->device round trip: the 6-int bounding box (the dense grid is sized from it).
+int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
+  const int n = cl.n;
+  const int k = c->prm.k_correspondences;
+  hipStream_t s = c->stream;
+  {
+    ProfScope ps(c, RGC_K_GRID, n);
+    int init[7] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0};  // [7] nvox and [8] ncorr stay untouched
+    memcpy(c->h_small, init, sizeof(init));
+    HIPCHK(c, hipMemcpyAsync(c->d_small, c->h_small, sizeof(init), hipMemcpyHostToDevice, s));
+    rgck::bbox(s, cl.in, cl.stride_f, n, c->prm.voxel_res, c->d_small, c->d_small + 6);
+    HIPCHK(c, hipMemcpyAsync(c->h_small, c->d_small, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (c->h_small[6]) return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", is_target ? "target" : "source");
+    rgck::Grid g{};
+    double ncell = 1.0;
+    for (int a = 0; a < 3; a++) {
+      g.minc[a] = c->h_small[a];
+      g.dim[a] = c->h_small[3 + a] - c->h_small[a] + 1;
+      ncell *= (double)g.dim[a];
+    }
+    if (ncell > (double)c->prm.max_cells || ncell > 2.0e9)
+      return fail(c, RGC_ERR_GRID_TOO_LARGE, "%s grid %d x %d x %d exceeds max_cells", is_target ? "target" : "source", g.dim[0], g.dim[1], g.dim[2]);
+    g.res = c->prm.voxel_res;
+    g.ncell = (int)ncell;
+    cl.grid = g;
+    const size_t nc1 = (size_t)g.ncell + 1;
+    int rc;
+    if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
+    if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1))) return rc;
+    if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
+    if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nc1 / 2048 + 2)))) return rc;
+    if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
+    if ((rc = ensure(c, cl.order, sizeof(int) * n))) return rc;
+    if ((rc = ensure(c, cl.xs, sizeof(float) * n))) return rc;
+    if ((rc = ensure(c, cl.ys, sizeof(float) * n))) return rc;
+    if ((rc = ensure(c, cl.zs, sizeof(float) * n))) return rc;
+    if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
+    if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
+    if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
+    HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nc1, s));
+    rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.cnt.p);
+    rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, (int*)cl.block_sums.p);
+    rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
+    rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
+                      (int*)cl.order.p, (float*)cl.xs.p, (float*)cl.ys.p, (float*)cl.zs.p);
+  }
+  {
+    ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n);
+    rgck::knn_cov(s, is_target, (const float*)cl.xs.p, (const float*)cl.ys.p, (const float*)cl.zs.p, (const int*)cl.start.p,
+                  (const int*)cl.order.p, cl.grid, n, k, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
+  }
+  if (is_target) {
+    int rc;
+    if ((rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)cl.grid.ncell))) return rc;
+    const size_t vmax = (size_t)(n < cl.grid.ncell ? n : cl.grid.ncell);
+    if ((rc = ensure(c, cl.vox, sizeof(double) * rgck::kVoxRec * vmax))) return rc;
+    if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
+    ProfScope ps(c, RGC_K_VOXEL, n);
+    HIPCHK(c, hipMemsetAsync(c->d_small + 7, 0, sizeof(int), s));
+    rgck::voxel_build(s, (const float*)cl.xs.p, (const float*)cl.ys.p, (const float*)cl.zs.p, (const double*)cl.nx.p,
+                      (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p, cl.grid, (int*)cl.cell_voxel.p,
+                      (double*)cl.vox.p, (int*)cl.vox_cell.p, c->d_small + 7);
+    cl.nvox = -1;  // fetched lazily
+  }
+  HIPCHK(c, hipGetLastError());
+  cl.ready = true;
+  return RGC_OK;
+}
+
+int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, int stride_bytes, bool on_device) {
+  if (!c) return RGC_ERR_INVALID;
+  cl.ready = false;
+  cl.n = 0;
+  c->corr_valid = false;
+  if (!xyz || n < 0) return fail(c, RGC_ERR_INVALID, "null cloud");
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  if (n < c->prm.k_correspondences)
+    return fail(c, RGC_ERR_TOO_FEW_POINTS, "%s cloud has %d points, need >= k = %d", is_target ? "target" : "source", n, c->prm.k_correspondences);
+  HIPCHK(c, hipSetDevice(c->device));
+  const int stride_f = stride_bytes / 4;
+  if (on_device) {
+    cl.in = xyz;
+  } else {
+    const size_t bytes = (size_t)n * stride_bytes;
+    int rc = ensure(c, cl.in_copy, bytes);
+    if (rc) return rc;
+    // pageable host memory: hipMemcpyAsync stages and returns once the source has been consumed
+    HIPCHK(c, hipMemcpyAsync(cl.in_copy.p, xyz, bytes - (stride_bytes - 12), hipMemcpyHostToDevice, c->stream));
+    cl.in = (const float*)cl.in_copy.p;
+  }
+  cl.stride_f = stride_f;
+  cl.n = n;
+  int rc = prepare_cloud(c, cl, is_target);
+  if (rc) { cl.n = 0; return rc; }
+  if (is_target) { c->stats.n_target = n; c->stats.target_cells = cl.grid.ncell; }
+  else { c->stats.n_source = n; c->stats.source_cells = cl.grid.ncell; }
+  return RGC_OK;
+}
+
+rgck::Pose pose_from(const double T[16]) {
+  rgck::Pose P;
+  for (int a = 0; a < 3; a++) {
+    for (int b = 0; b < 3; b++) P.R[a * 3 + b] = T[a * 4 + b];
+    P.t[a] = T[a * 4 + 3];
+  }
+  return P;
+}
+rgck::PoseF posef_from(const float T[16]) {
+  rgck::PoseF P;
+  for (int a = 0; a < 12; a++) P.m[a] = T[a];
+  return P;
+}
+
+int need_inputs(rgc_ctx* c) {
+  if (!c) return RGC_ERR_INVALID;
+  if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
+  return RGC_OK;
+}
+
+int do_linearize(rgc_ctx* c, const double T[16], double* H, double* b, double* cost) {
+  int rc = need_inputs(c);
+  if (rc) return rc;
+  const int n = c->src.n, noff = noff_of(c->prm.neighbor_method);
+  if ((rc = ensure(c, c->corr_v, sizeof(int) * (size_t)n * noff))) return rc;
+  if ((rc = ensure(c, c->corr_M, sizeof(double) * 6 * (size_t)n * noff))) return rc;
+  const int nb = rgck::linearize_blocks(n);
+  if ((rc = ensure(c, c->partials, sizeof(double) * rgck::kAccum * (size_t)nb))) return rc;
+  if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
+  const int want = (H && b) ? 1 : 0;
+  {
+    ProfScope ps(c, RGC_K_LINEARIZE, n);
+    rgck::linearize(c->stream, (const float*)c->src.xs.p, (const float*)c->src.ys.p, (const float*)c->src.zs.p,
+                    (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n, pose_from(T), c->tgt.grid,
+                    (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p, want,
+                    (double*)c->partials.p, (int*)c->ipartials.p, c->d_out, c->d_small + 8);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double) * rgck::kAccum, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_small + 8, c->d_small + 8, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->corr_noff = noff;
+  c->corr_n = n;
+  c->corr_valid = true;
+  c->stats.n_corr = c->h_small[8];
+  c->stats.n_linearize++;
+  if (want) {
+    int u = 0;
+    for (int a = 0; a < 6; a++)
+      for (int d = a; d < 6; d++) {
+        H[a * 6 + d] = c->h_out[u];
+        H[d * 6 + a] = c->h_out[u];
+        u++;
+      }
+    for (int a = 0; a < 6; a++) b[a] = c->h_out[21 + a];
+  }
+  if (cost) *cost = c->h_out[27];
+  return RGC_OK;
+}
+
+int do_error(rgc_ctx* c, const double T[16], double* cost) {
+  int rc = need_inputs(c);
+  if (rc) return rc;
+  if (!c->corr_valid) return fail(c, RGC_ERR_INVALID, "rgc_compute_error needs a preceding rgc_linearize");
+  const int n = c->corr_n;
+  {
+    ProfScope ps(c, RGC_K_ERROR, n);
+    rgck::compute_error(c->stream, (const float*)c->src.xs.p, (const float*)c->src.ys.p, (const float*)c->src.zs.p, n, pose_from(T),
+                        (const double*)c->tgt.vox.p, c->corr_noff, (const int*)c->corr_v.p, (const double*)c->corr_M.p,
+                        (double*)c->partials.p, c->d_out);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->stats.n_error++;
+  *cost = c->h_out[0];
+  return RGC_OK;
+}
+
+int do_fitness(rgc_ctx* c, const float T[16], double* out) {
+  int rc = need_inputs(c);
+  if (rc) return rc;
+  const int n = c->src.n;
+  const int nb = rgck::linearize_blocks(n);
+  if ((rc = ensure(c, c->partials, sizeof(double) * rgck::kAccum * (size_t)nb))) return rc;
+  {
+    ProfScope ps(c, RGC_K_FITNESS, n);
+    rgck::fitness(c->stream, (const float*)c->src.xs.p, (const float*)c->src.ys.p, (const float*)c->src.zs.p, n, posef_from(T),
+                  (const float*)c->tgt.xs.p, (const float*)c->tgt.ys.p, (const float*)c->tgt.zs.p, (const int*)c->tgt.start.p, c->tgt.grid,
+                  (double*)c->partials.p, c->d_out);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  *out = c->h_out[0] / (double)n;
+  return RGC_OK;
+}
+
+// ---- scalar helpers of the LM driver ----
+// so3_exp (so3/so3.hpp:58-77) followed by Eigen's Quaterniond::toRotationMatrix()
+void so3_exp_R(const double w[3], double R[9]) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double imag, real;
+  if (th2 < 1e-10) {
+    const double th4 = th2 * th2;
+    imag = 0.5 - 1.0 / 48.0 * th2 + 1.0 / 3840.0 * th4;
+    real = 1.0 - 1.0 / 8.0 * th2 + 1.0 / 384.0 * th4;
+  } else {
+    const double th = std::sqrt(th2), half = 0.5 * th;
+    imag = std::sin(half) / th;
+    real = std::cos(half);
+  }
+  const double qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+// lsq_registration_impl.hpp:82-91
+bool is_converged(const double d[16], double rot_eps, double trans_eps) {
+  double m = 0;
+  for (int a = 0; a < 3; a++) {
+    for (int b = 0; b < 3; b++) m = std::fmax(m, std::fabs(d[a * 4 + b] - (a == b ? 1.0 : 0.0)) / rot_eps);
+    m = std::fmax(m, std::fabs(d[a * 4 + 3]) / trans_eps);
+  }
+  return m < 1;
+}
+
+// (H + lambda I) d = -b, symmetric 6x6 (Eigen::LDLT at lsq_registration_impl.hpp:136-137): LDL^T with
+// diagonal pivoting
+bool solve_ldlt6(const double Ain[36], const double rhs[6], double x[6]) {
+  double A[6][6];
+  int perm[6];
+  for (int i = 0; i < 6; i++) { perm[i] = i; for (int j = 0; j < 6; j++) A[i][j] = Ain[i * 6 + j]; }
+  for (int k = 0; k < 6; k++) {
+    int piv = k;
+    for (int i = k + 1; i < 6; i++) if (std::fabs(A[i][i]) > std::fabs(A[piv][piv])) piv = i;
+    if (piv != k) {
+      for (int j = 0; j < 6; j++) std::swap(A[k][j], A[piv][j]);
+      for (int i = 0; i < 6; i++) std::swap(A[i][k], A[i][piv]);
+      std::swap(perm[k], perm[piv]);
+    }
+    const double d = A[k][k];
+    if (d == 0.0 || !std::isfinite(d)) return false;
+    for (int i = k + 1; i < 6; i++) {
+      const double l = A[i][k] / d;
+      for (int j = k + 1; j <= i; j++) { A[i][j] -= l * A[j][k]; A[j][i] = A[i][j]; }
+      A[i][k] = l;
+    }
+  }
+  double y[6];
+  for (int i = 0; i < 6; i++) {
+    double s = rhs[perm[i]];
+    for (int j = 0; j < i; j++) s -= A[i][j] * y[j];
+    y[i] = s;
+  }
+  for (int i = 0; i < 6; i++) y[i] /= A[i][i];
+  double z[6];
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+    for (int j = i + 1; j < 6; j++) s -= A[j][i] * z[j];
+    z[i] = s;
+  }
+  for (int i = 0; i < 6; i++) x[perm[i]] = z[i];
+  return true;
+}
+
+void mul4(const double A[16], const double B[16], double C[16]) {
+  double t[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0;
+      for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j];
+      t[i * 4 + j] = s;
+    }
+  memcpy(C, t, sizeof(t));
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+void rgc_default_params(rgc_params* p) {
+  if (!p) return;
+  p->voxel_res = 1.0;
+  p->max_iterations = 25;
+  p->lm_max_iterations = 10;
+  p->rotation_eps = 2e-3;
+  p->translation_eps = 1e-6;
+  p->lm_init_lambda_factor = 1e-9;
+  p->k_correspondences = 20;
+  p->neighbor_method = RGC_DIRECT1;
+  p->max_cells = 1ll << 29;
+}
+
+const char* rgc_version(void) { return "rgc_hip 0.1 (gfx950)"; }
+
+const char* rgc_status_string(int s) {
+  switch (s) {
+    case RGC_OK: return "ok";
+    case RGC_ERR_INVALID: return "invalid argument";
+    case RGC_ERR_HIP: return "HIP runtime error";
+    case RGC_ERR_TOO_FEW_POINTS: return "too few points";
+    case RGC_ERR_GRID_TOO_LARGE: return "grid too large";
+    case RGC_ERR_NO_INPUT: return "no input cloud";
+    case RGC_ERR_NONFINITE: return "non-finite input";
+  }
+  return "unknown";
+}
+
+int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
+  if (!out) return RGC_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipSetDevice(hip_device) != hipSuccess) return RGC_ERR_HIP;
+  rgc_ctx* c = new (std::nothrow) rgc_ctx();
+  if (!c) return RGC_ERR_HIP;
+  c->device = hip_device;
+  rgc_default_params(&c->prm);
+  if (params) {
+    int rc = check_params(c, params);
+    if (rc) { delete c; return rc; }
+    c->prm = *params;
+  }
+  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_small, 16 * sizeof(int)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_out, 32 * sizeof(double)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->h_small, 16 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->h_out, 32 * sizeof(double), hipHostMallocDefault) == hipSuccess;
+  if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
+  *out = c;
+  return RGC_OK;
+}
+
+void rgc_destroy(rgc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  prof_collect(c);
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  release_cloud(c->src);
+  release_cloud(c->tgt);
+  for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->partials, &c->ipartials, &c->scratch}) release(*b);
+  if (c->d_small) (void)hipFree(c->d_small);
+  if (c->d_out) (void)hipFree(c->d_out);
+  if (c->h_small) (void)hipHostFree(c->h_small);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rgc_set_params(rgc_ctx* c, const rgc_params* p) {
+  if (!c || !p) return RGC_ERR_INVALID;
+  int rc = check_params(c, p);
+  if (rc) return rc;
+  const bool redo = p->voxel_res != c->prm.voxel_res || p->k_correspondences != c->prm.k_correspondences;
+  c->prm = *p;
+  c->corr_valid = false;
+  if (redo) {  // covariances / voxel map depend on these: recompute from the resident inputs
+    if (c->src.ready) { c->src.ready = false; if ((rc = prepare_cloud(c, c->src, false))) return rc; }
+    if (c->tgt.ready) { c->tgt.ready = false; if ((rc = prepare_cloud(c, c->tgt, true))) return rc; }
+  }
+  return RGC_OK;
+}
+
+int rgc_get_params(const rgc_ctx* c, rgc_params* p) {
+  if (!c || !p) return RGC_ERR_INVALID;
+  *p = c->prm;
+  return RGC_OK;
+}
+
+const char* rgc_last_error(const rgc_ctx* c) { return c ? c->err : "null context"; }
+
+int rgc_set_target(rgc_ctx* c, const float* xyz, int n, int stride_bytes) { return c ? set_cloud(c, c->tgt, true, xyz, n, stride_bytes, false) : RGC_ERR_INVALID; }
+int rgc_set_source(rgc_ctx* c, const float* xyz, int n, int stride_bytes) { return c ? set_cloud(c, c->src, false, xyz, n, stride_bytes, false) : RGC_ERR_INVALID; }
+int rgc_set_target_device(rgc_ctx* c, const float* xyz, int n, int stride_bytes) { return c ? set_cloud(c, c->tgt, true, xyz, n, stride_bytes, true) : RGC_ERR_INVALID; }
+int rgc_set_source_device(rgc_ctx* c, const float* xyz, int n, int stride_bytes) { return c ? set_cloud(c, c->src, false, xyz, n, stride_bytes, true) : RGC_ERR_INVALID; }
+
+int rgc_linearize(rgc_ctx* c, const double T[16], double H[36], double b[6], double* cost) {
+  if (!c || !T) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  return do_linearize(c, T, H, b, cost);
+}
+
+int rgc_compute_error(rgc_ctx* c, const double T[16], double* cost) {
+  if (!c || !T || !cost) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  return do_error(c, T, cost);
+}
+
+int rgc_num_correspondences(rgc_ctx* c, int* n) {
+  if (!c || !n) return RGC_ERR_INVALID;
+  if (!c->corr_valid) return fail(c, RGC_ERR_INVALID, "no linearisation yet");
+  *n = c->stats.n_corr;
+  return RGC_OK;
+}
+
+// lsq_registration_impl.hpp:53-79 (computeTransformation) + :125-172 (step_lm); SURVEY A.5
+int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final_H[36], double* fitness, int* iterations,
+              int* converged, int* lm_failed) {
+  if (!c || !guess) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = need_inputs(c);
+  if (rc) return rc;
+  const rgc_params& P = c->prm;
+  double x0[16];
+  for (int i = 0; i < 12; i++) x0[i] = (double)guess[i];
+  x0[12] = x0[13] = x0[14] = 0.0;
+  x0[15] = 1.0;
+  double lambda = -1.0;  // :56
+  bool conv = false, failed = false;
+  int iters = 0;
+  double Hfin[36];
+  memset(Hfin, 0, sizeof(Hfin));
+  for (int i = 0; i < 6; i++) Hfin[i * 7] = 1.0;  // final_hessian_.setIdentity(), :21
+  c->stats.n_linearize = c->stats.n_error = c->stats.outer_iterations = 0;
+
+  for (int it = 0; it < P.max_iterations && !conv; it++) {  // :65
+    iters = it + 1;
+    double H[36], b[6], y0, delta[16];
+    if ((rc = do_linearize(c, x0, H, b, &y0))) return rc;  // :128
+    if (lambda < 0.0) {                                     // :130-132
+      double m = 0;
+      for (int i = 0; i < 6; i++) m = std::fmax(m, std::fabs(H[i * 7]));
+      lambda = P.lm_init_lambda_factor * m;
+    }
+    double nu = 2.0;
+    bool ok = false;
+    for (int k = 0; k < P.lm_max_iterations; k++) {  // :135
+      double A[36], nb[6], d[6];
+      memcpy(A, H, sizeof(A));
+      for (int i = 0; i < 6; i++) { A[i * 7] += lambda; nb[i] = -b[i]; }
+      if (!solve_ldlt6(A, nb, d)) for (int i = 0; i < 6; i++) d[i] = NAN;
+      double R[9];
+      so3_exp_R(d, R);  // :139-141
+      memset(delta, 0, sizeof(delta));
+      for (int a = 0; a < 3; a++) { for (int e = 0; e < 3; e++) delta[a * 4 + e] = R[a * 3 + e]; delta[a * 4 + 3] = d[3 + a]; }
+      delta[15] = 1.0;
+      double xi[16], yi;
+      mul4(delta, x0, xi);                           // :143
+      if ((rc = do_error(c, xi, &yi))) return rc;    // :144
+      double den = 0;
+      for (int i = 0; i < 6; i++) den += d[i] * (lambda * d[i] - b[i]);
+      const double rho = (y0 - yi) / den;            // :145
+      if (rho < 0) {                                 // :155-163
+        if (is_converged(delta, P.rotation_eps, P.translation_eps)) { ok = true; break; }
+        lambda = nu * lambda;
+        nu = 2 * nu;
+        continue;
+      }
+      memcpy(x0, xi, sizeof(xi));                    // :165
+      lambda = lambda * std::fmax(1.0 / 3.0, 1 - std::pow(2 * rho - 1, 3));  // :166
+      memcpy(Hfin, H, sizeof(Hfin));                 // :167
+      ok = true;
+      break;
+    }
+    if (!ok) { failed = true; break; }               // :69-72 "lm not converged!!"
+    conv = is_converged(delta, P.rotation_eps, P.translation_eps);  // :74
+  }
+  c->stats.outer_iterations = iters;
+  float fin[16];
+  for (int i = 0; i < 16; i++) fin[i] = (float)x0[i];  // :77
+  if (final_T) memcpy(final_T, fin, sizeof(fin));
+  if (final_H) memcpy(final_H, Hfin, sizeof(Hfin));
+  if (iterations) *iterations = iters;
+  if (converged) *converged = conv ? 1 : 0;
+  if (lm_failed) *lm_failed = failed ? 1 : 0;
+  if (fitness) {
+    if ((rc = do_fitness(c, fin, fitness))) return rc;
+  }
+  return RGC_OK;
+}
+
+int rgc_fitness(rgc_ctx* c, const float T[16], double* fitness) {
+  if (!c || !T || !fitness) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  return do_fitness(c, T, fitness);
+}
+
+int rgc_get_aligned(rgc_ctx* c, const float T[16], float* out, int stride_bytes) {
+  if (!c || !T || !out) return RGC_ERR_INVALID;
+  if (!c->src.ready) return fail(c, RGC_ERR_NO_INPUT, "source not set");
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int n = c->src.n;
+  int rc = ensure(c, c->scratch, sizeof(float) * 3 * (size_t)n);
+  if (rc) return rc;
+  rgck::transform_f32(c->stream, c->src.in, c->src.stride_f, n, posef_from(T), (float*)c->scratch.p, 3);
+  if (stride_bytes == 12) {
+    HIPCHK(c, hipMemcpyAsync(out, c->scratch.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    HIPCHK(c, hipMemcpy2DAsync(out, stride_bytes, c->scratch.p, 12, 12, n, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RGC_OK;
+}
+
+static int get_covs(rgc_ctx* c, Cloud& cl, double* cov9, double* normals) {
+  if (!cl.ready) return fail(c, RGC_ERR_NO_INPUT, "cloud not set");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int n = cl.n;
+  int rc = ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n);
+  if (rc) return rc;
+  rgck::unsort3(c->stream, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.order.p, n, (double*)c->scratch.p);
+  std::vector<double> tmp;
+  double* dst = normals;
+  if (!dst) { tmp.resize((size_t)n * 3); dst = tmp.data(); }
+  HIPCHK(c, hipMemcpyAsync(dst, c->scratch.p, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (cov9) {
+    for (int i = 0; i < n; i++) {  // C = I - 0.999 n n^T  (fast_gicp_impl.hpp:281,293)
+      const double* v = dst + (size_t)i * 3;
+      double* C = cov9 + (size_t)i * 9;
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) C[a * 3 + b] = (a == b ? 1.0 : 0.0) - 0.999 * v[a] * v[b];
+    }
+  }
+  return RGC_OK;
+}
+
+int rgc_get_source_covariances(rgc_ctx* c, double* cov9, double* normals) { return c ? get_covs(c, c->src, cov9, normals) : RGC_ERR_INVALID; }
+int rgc_get_target_covariances(rgc_ctx* c, double* cov9, double* normals) { return c ? get_covs(c, c->tgt, cov9, normals) : RGC_ERR_INVALID; }
+
+static int fetch_nvox(rgc_ctx* c) {
+  if (c->tgt.nvox >= 0) return RGC_OK;
+  HIPCHK(c, hipMemcpyAsync(c->h_small + 7, c->d_small + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->tgt.nvox = c->h_small[7];
+  c->stats.n_voxels = c->tgt.nvox;
+  return RGC_OK;
+}
+
+int rgc_get_voxels(rgc_ctx* c, int cap, int* coords, int* num, double* mean, double* cov9, int* count) {
+  if (!c || !count) return RGC_ERR_INVALID;
+  if (!c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "target not set");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = fetch_nvox(c);
+  if (rc) return rc;
+  const int V = c->tgt.nvox;
+  *count = V;
+  const int m = V < cap ? V : cap;
+  if (m <= 0) return RGC_OK;
+  std::vector<double> rec((size_t)m * rgck::kVoxRec);
+  std::vector<int> cell((size_t)m);
+  HIPCHK(c, hipMemcpyAsync(rec.data(), c->tgt.vox.p, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cell.data(), c->tgt.vox_cell.p, sizeof(int) * cell.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const rgck::Grid& g = c->tgt.grid;
+  for (int v = 0; v < m; v++) {
+    const double* r = &rec[(size_t)v * rgck::kVoxRec];
+    const int ci = cell[v];
+    if (coords) {
+      coords[v * 3 + 0] = ci % g.dim[0] + g.minc[0];
+      coords[v * 3 + 1] = (ci / g.dim[0]) % g.dim[1] + g.minc[1];
+      coords[v * 3 + 2] = ci / (g.dim[0] * g.dim[1]) + g.minc[2];
+    }
+    if (num) num[v] = (int)r[9];
+    if (mean) { mean[v * 3] = r[0]; mean[v * 3 + 1] = r[1]; mean[v * 3 + 2] = r[2]; }
+    if (cov9) {
+      double* C = cov9 + (size_t)v * 9;
+      C[0] = r[3]; C[1] = r[4]; C[2] = r[5];
+      C[3] = r[4]; C[4] = r[6]; C[5] = r[7];
+      C[6] = r[5]; C[7] = r[7]; C[8] = r[8];
+    }
+  }
+  return RGC_OK;
+}
+
+int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
+  if (!c || !out) return RGC_ERR_INVALID;
+  if (c->tgt.ready) { int rc = fetch_nvox(c); if (rc) return rc; }
+  *out = c->stats;
+  return RGC_OK;
+}
+
+int rgc_device_alloc(rgc_ctx* c, size_t bytes, void** p) {
+  if (!c || !p) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMalloc(p, bytes));
+  return RGC_OK;
+}
+int rgc_device_free(rgc_ctx* c, void* p) {
+  if (!c) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipFree(p));
+  return RGC_OK;
+}
+int rgc_upload(rgc_ctx* c, void* d, const void* h, size_t bytes) {
+  if (!c || !d || !h) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  return RGC_OK;
+}
+int rgc_download(rgc_ctx* c, void* h, const void* d, size_t bytes) {
+  if (!c || !d || !h) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RGC_OK;
+}
+int rgc_synchronize(rgc_ctx* c) {
+  if (!c) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RGC_OK;
+}
+void* rgc_stream(rgc_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int rgc_profile_enable(rgc_ctx* c, int on) {
+  if (!c) return RGC_ERR_INVALID;
+  c->prof_on = on != 0;
+  return RGC_OK;
+}
+int rgc_profile_reset(rgc_ctx* c) {
+  if (!c) return RGC_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  for (int i = 0; i < kProfKinds; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_points[i] = 0; }
+  return RGC_OK;
+}
+int rgc_profile_get(rgc_ctx* c, int kind, long long* launches, double* total_ms, long long* total_points) {
+  if (!c || kind < 0 || kind >= kProfKinds) return RGC_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  if (launches) *launches = c->prof_launches[kind];
+  if (total_ms) *total_ms = c->prof_ms[kind];
+  if (total_points) *total_points = c->prof_points[kind];
+  return RGC_OK;
+}
+const char* rgc_profile_name(int kind) {
+  static const char* names[kProfKinds] = {"grid_build", "knn_cov_target", "voxel_build", "linearize", "compute_error", "fitness", "knn_cov_source"};
+  return (kind >= 0 && kind < kProfKinds) ? names[kind] : "?";
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// rgc_kernels.h -- launch wrappers of the gfx950 kernels (internal; the public boundary is include/rgc_hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rgck {
+
+// Dense voxel-aligned grid.  Cell c (per axis) covers [(c + minc + 0.5) * res, (c + minc + 1.5) * res):
+// this is fast_gicp's voxel_coord = floor(x / res - 0.5) (fast_vgicp_voxel.hpp:158-160) shifted by minc, so
+// the exact-kNN search grid and the Gaussian voxel map of the target are the SAME partition.
+struct Grid {
+  int minc[3];
+  int dim[3];
+  double res;
+  int ncell;
+};
+
+struct Pose {  // row-major rotation + translation, fp64 (Eigen::Isometry3d in the reference)
+  double R[9];
+  double t[3];
+};
+struct PoseF {  // fp32 4x4 rows 0..2 (pcl::transformPointCloud in the reference)
+  float m[12];
+};
+
+constexpr int kAccum = 28;  // 21 upper-triangular H + 6 b + 1 cost
+constexpr int kVoxRec = 10; // mean(3) cov6(6) num(1), doubles
+
+// ---- grid build ----
+void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags);
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt);
+void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */);
+void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp);
+void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
+                 const int* order_tmp, int* order, float* xs, float* ys, float* zs);
+// ---- C2: exact kNN + PLANE covariance -> unit normal ----
+void knn_cov(hipStream_t s, bool is_target, const float* xs, const float* ys, const float* zs, const int* start,
+             const int* order, Grid g, int n, int k, double* nx, double* ny, double* nz);
+// ---- C3: Gaussian voxel map ----
+void voxel_build(hipStream_t s, const float* xs, const float* ys, const float* zs, const double* nx, const double* ny,
+                 const double* nz, const int* start, Grid g, int* cell_voxel, double* vox, int* vox_cell, int* nvox);
+// ---- C4/C5/C6 ----
+void linearize(hipStream_t s, const float* xs, const float* ys, const float* zs, const double* nx, const double* ny,
+               const double* nz, int n, Pose T, Grid g, const int* cell_voxel, const double* vox, int noff,
+               int* corr_v, double* corr_M, int want_H, double* partials, int* ncorr_partials, double* out28,
+               int* out_ncorr);
+void compute_error(hipStream_t s, const float* xs, const float* ys, const float* zs, int n, Pose T, const double* vox,
+                   int noff, const int* corr_v, const double* corr_M, double* partials, double* out1);
+// ---- C8 ----
+void fitness(hipStream_t s, const float* sxs, const float* sys, const float* szs, int ns, PoseF T, const float* txs,
+             const float* tys, const float* tzs, const int* tstart, Grid g, double* partials, double* out1);
+// ---- misc ----
+void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f);
+void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const int* order, int n, double* out3);
+int  linearize_blocks(int n);
+
+}  // namespace rgck

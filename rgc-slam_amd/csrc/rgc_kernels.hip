@@ -1,0 +1,718 @@
+// rgc_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the RGC-SLAM scan-to-map registration path.
+//
+// Written for 64-wide wavefronts; compiled with -ffp-contract=off so the fp32 squared distance is the same
+// ((dx*dx + dy*dy) + dz*dz) FLANN's L2_Simple<float> produces on the reference's x86-64 build and the exact-kNN
+// neighbour SETS match the CPU path bit for bit (fast_gicp_impl.hpp:254).  Everything downstream of the raw fp32
+// points is fp64, like the reference (points are cast to double at fast_gicp_impl.hpp:258, fast_vgicp_impl.hpp:84).
+//
+// Reference citations are relative to /root/reference/rgc_slam/.
+#include "rgc_kernels.h"
+
+#include <limits.h>
+
+namespace rgck {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int voxel_coord1(float x, double res) { return (int)floor((double)x / res - 0.5); }
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid build
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bbox(const float* __restrict__ in, int stride_f, int n, double res, int* mm6, int* flags) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+  int bad = 0;
+  if (i < n) {
+    const float* p = in + (size_t)i * stride_f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      float v = p[a];
+      if (!isfinite(v) || fabsf(v) > 1.0e8f) { bad = 1; continue; }
+      int c = voxel_coord1(v, res);
+      lo[a] = c;
+      hi[a] = c;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    int l = wave_min(lo[a]), h = wave_max(hi[a]);
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+      if (l != INT_MAX) atomicMin(&mm6[a], l);
+      if (h != INT_MIN) atomicMax(&mm6[3 + a], h);
+    }
+  }
+  if (bad) atomicOr(flags, 1);
+}
+
+__device__ __forceinline__ int cell_index(const Grid& g, int cx, int cy, int cz) { return (cz * g.dim[1] + cy) * g.dim[0] + cx; }
+
+__global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* cnt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = in + (size_t)i * stride_f;
+  int cx = voxel_coord1(p[0], g.res) - g.minc[0];
+  int cy = voxel_coord1(p[1], g.res) - g.minc[1];
+  int cz = voxel_coord1(p[2], g.res) - g.minc[2];
+  int c = cell_index(g, cx, cy, cz);
+  cell_of[i] = c;
+  atomicAdd(&cnt[c], 1);
+}
+
+// three-kernel exclusive scan: 2048 items per block (256 threads x 8)
+constexpr int SCAN_T = 256, SCAN_V = 8, SCAN_B = SCAN_T * SCAN_V;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+  __shared__ int wsum[SCAN_T / WAVE];
+  int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == WAVE - 1) wsum[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_T / WAVE; j++) {
+    int s = wsum[j];
+    if (j < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void k_scan_block(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ block_sums) {
+  int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
+  int v[SCAN_V], s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++) {
+    v[j] = (base + j < n) ? in[base + j] : 0;
+    s += v[j];
+  }
+  int tot;
+  int ex = block_exclusive_scan(s, &tot);
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ void k_scan_sums(int* sums, int nb) {  // single block, in-place exclusive scan
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += SCAN_T) {
+    int i = base + threadIdx.x;
+    int v = i < nb ? sums[i] : 0;
+    int tot;
+    int ex = block_exclusive_scan(v, &tot);
+    int carry = carry_s;
+    if (i < nb) sums[i] = ex + carry;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+}
+
+__global__ void k_scan_add(int* out, int n, const int* __restrict__ block_sums) {
+  int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
+  int add = block_sums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++)
+    if (base + j < n) out[base + j] += add;
+}
+
+__global__ void k_scatter(int n, const int* __restrict__ cell_of, const int* __restrict__ start, int* cnt, int* __restrict__ order_tmp) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int c = cell_of[i];
+  int r = atomicSub(&cnt[c], 1) - 1;  // unordered slot inside the cell; k_rank_gather makes the order deterministic
+  order_tmp[start[c] + r] = i;
+}
+
+// deterministic placement: a point's final slot = cell start + number of same-cell points with a smaller index
+__global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
+                              const int* __restrict__ start, const int* __restrict__ order_tmp, int* __restrict__ order,
+                              float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ zs) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  int i = order_tmp[s];
+  int c = cell_of[i];
+  int s0 = start[c], s1 = start[c + 1];
+  int rank = 0;
+  for (int t = s0; t < s1; t++) rank += (order_tmp[t] < i);
+  int pos = s0 + rank;
+  const float* p = in + (size_t)i * stride_f;
+  order[pos] = i;
+  xs[pos] = p[0];
+  ys[pos] = p[1];
+  zs[pos] = p[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// symmetric 3x3 eigen solver (cyclic Jacobi, fp64) -> eigenvector of the smallest eigenvalue.
+// Stands in for Eigen::JacobiSVD on the symmetric PSD neighbourhood covariance (fast_gicp_impl.hpp:273):
+// U diag(1,1,1e-3) V^T = I - 0.999 n n^T with n that eigenvector.
+// ------------------------------------------------------------------------------------------------
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rot(double (&A)[3][3], double (&V)[3][3]) {
+  if (A[P][Q] == 0.0) return;
+  double theta = (A[Q][Q] - A[P][P]) / (2.0 * A[P][Q]);
+  double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double akp = A[k][P], akq = A[k][Q];
+    A[k][P] = c * akp - s * akq;
+    A[k][Q] = s * akp + c * akq;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double apk = A[P][k], aqk = A[Q][k];
+    A[P][k] = c * apk - s * aqk;
+    A[Q][k] = s * apk + c * aqk;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double vkp = V[k][P], vkq = V[k][Q];
+    V[k][P] = c * vkp - s * vkq;
+    V[k][Q] = s * vkp + c * vkq;
+  }
+}
+
+__device__ __forceinline__ void min_eigenvector(const double S[6], double n[3]) {
+  double A[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-40 * diag || off == 0.0) break;
+    jacobi_rot<0, 1>(A, V);
+    jacobi_rot<0, 2>(A, V);
+    jacobi_rot<1, 2>(A, V);
+  }
+  double e0 = A[0][0], e1 = A[1][1], e2 = A[2][2];
+  // column of the smallest eigenvalue; on exact ties take the LAST one in descending sort order like the
+  // oracle's stable selection (ord[] keeps index order for equal values, so the smallest is the highest index)
+  int m = 0;
+  double em = e0;
+  if (e1 <= em) { m = 1; em = e1; }
+  if (e2 <= em) { m = 2; em = e2; }
+  n[0] = m == 0 ? V[0][0] : (m == 1 ? V[0][1] : V[0][2]);
+  n[1] = m == 0 ? V[1][0] : (m == 1 ? V[1][1] : V[1][2]);
+  n[2] = m == 0 ? V[2][0] : (m == 1 ? V[2][1] : V[2][2]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C2  exact k-nearest neighbours + covariance + normal, one lane per query point (v1).
+// The per-lane candidate list lives in LDS as [slot][lane] columns (bank = lane -> conflict free).
+// fast_gicp_impl.hpp:241-298.
+// ------------------------------------------------------------------------------------------------
+constexpr int KNN_T = 256;
+
+// kTarget only separates the two instantiations by NAME (map cloud vs scan cloud) so that profiles report the
+// dominant launch (the map) on its own line.
+template <bool kTarget>
+__global__ void __launch_bounds__(KNN_T)
+k_knn_cov(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+          const int* __restrict__ start, const int* __restrict__ order, Grid g, int n, int k, double* __restrict__ nx,
+          double* __restrict__ ny, double* __restrict__ nz) {
+  extern __shared__ float smem[];
+  float* sd = smem;                       // [k][KNN_T]
+  int* si = (int*)(smem + k * KNN_T);     // [k][KNN_T]
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * KNN_T + tid;
+  if (i >= n) return;
+  const float px = xs[i], py = ys[i], pz = zs[i];
+  const int c0 = voxel_coord1(px, g.res) - g.minc[0];
+  const int c1 = voxel_coord1(py, g.res) - g.minc[1];
+  const int c2 = voxel_coord1(pz, g.res) - g.minc[2];
+  int rmax = max(max(max(c0, g.dim[0] - 1 - c0), max(c1, g.dim[1] - 1 - c1)), max(c2, g.dim[2] - 1 - c2));
+
+  int cnt = 0, wslot = 0;
+  float worst = 0.f;
+  for (int r = 0;; r++) {
+    const int z0 = max(c2 - r, 0), z1 = min(c2 + r, g.dim[2] - 1);
+    const int y0 = max(c1 - r, 0), y1 = min(c1 + r, g.dim[1] - 1);
+    for (int z = z0; z <= z1; z++) {
+      const int az = abs(z - c2);
+      for (int y = y0; y <= y1; y++) {
+        const bool face = (az == r) || (abs(y - c1) == r);
+        const int xstep = face ? 1 : max(2 * r, 1);
+        for (int x = c0 - r; x <= c0 + r; x += xstep) {
+          if (x < 0 || x >= g.dim[0]) continue;
+          const int cid = cell_index(g, x, y, z);
+          const int s0 = start[cid], s1 = start[cid + 1];
+          for (int s = s0; s < s1; s++) {
+            const float dx = px - xs[s], dy = py - ys[s], dz = pz - zs[s];
+            const float d2 = (dx * dx + dy * dy) + dz * dz;  // L2_Simple<float>; no contraction (-ffp-contract=off)
+            if (cnt < k) {
+              sd[cnt * KNN_T + tid] = d2;
+              si[cnt * KNN_T + tid] = s;
+              cnt++;
+              if (cnt < k) continue;
+            } else {
+              bool better = d2 < worst;
+              if (!better && d2 == worst) better = order[s] < order[si[wslot * KNN_T + tid]];
+              if (!better) continue;
+              sd[wslot * KNN_T + tid] = d2;
+              si[wslot * KNN_T + tid] = s;
+            }
+            // list is full: locate the worst kept neighbour (largest (d2, original index))
+            worst = sd[tid];
+            wslot = 0;
+            for (int j = 1; j < k; j++) {
+              const float dj = sd[j * KNN_T + tid];
+              if (dj > worst || (dj == worst && order[si[j * KNN_T + tid]] > order[si[wslot * KNN_T + tid]])) {
+                worst = dj;
+                wslot = j;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (r >= rmax) break;  // whole grid scanned
+    if (cnt == k) {
+      // every unscanned point lies outside the cube of cells [c-r, c+r]: its distance is at least the distance
+      // from the query to the cube faces that are not grid borders
+      double bound = 1.0e300;
+      const double q[3] = {(double)px, (double)py, (double)pz};
+      const int c[3] = {c0, c1, c2};
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        if (c[a] - r > 0) bound = fmin(bound, q[a] - ((double)(c[a] - r + g.minc[a]) + 0.5) * g.res);
+        if (c[a] + r < g.dim[a] - 1) bound = fmin(bound, ((double)(c[a] + r + g.minc[a]) + 1.5) * g.res - q[a]);
+      }
+      if (bound == 1.0e300) break;
+      if (bound > 0.0 && (double)worst < bound * bound * (1.0 - 1e-5)) break;
+    }
+  }
+
+  // neighbourhood mean and covariance in fp64 (fast_gicp_impl.hpp:256-262)
+  double mx = 0, my = 0, mz = 0;
+  for (int j = 0; j < k; j++) {
+    const int s = si[j * KNN_T + tid];
+    mx += (double)xs[s];
+    my += (double)ys[s];
+    mz += (double)zs[s];
+  }
+  const double inv_k = 1.0 / (double)k;
+  mx *= inv_k; my *= inv_k; mz *= inv_k;
+  double S[6] = {0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < k; j++) {
+    const int s = si[j * KNN_T + tid];
+    const double dx = (double)xs[s] - mx, dy = (double)ys[s] - my, dz = (double)zs[s] - mz;
+    S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz;
+    S[3] += dy * dy; S[4] += dy * dz; S[5] += dz * dz;
+  }
+#pragma unroll
+  for (int a = 0; a < 6; a++) S[a] *= inv_k;
+  double nrm[3];
+  min_eigenvector(S, nrm);
+  nx[i] = nrm[0];
+  ny[i] = nrm[1];
+  nz[i] = nrm[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// C3  Gaussian voxel map (ADDITIVE): one lane per grid cell; the cell's points are contiguous and in ascending
+// original index, so the fp64 sums run in the reference's cloud order (fast_vgicp_voxel.hpp:112-121,129-156).
+// record = { mean xyz, cov00 01 02 11 12 22, num }  (10 doubles).  C_i = I - 0.999 n_i n_i^T.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_voxel_build(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+                              const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
+                              const int* __restrict__ start, Grid g, int* __restrict__ cell_voxel, double* __restrict__ vox,
+                              int* __restrict__ vox_cell, int* nvox) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= g.ncell) return;
+  const int s0 = start[c], s1 = start[c + 1];
+  if (s0 == s1) { cell_voxel[c] = -1; return; }
+  double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
+  for (int s = s0; s < s1; s++) {
+    m[0] += (double)xs[s];
+    m[1] += (double)ys[s];
+    m[2] += (double)zs[s];
+    const double a = nx[s], b = ny[s], d = nz[s];
+    C[0] += 1.0 - 0.999 * a * a; C[1] += -0.999 * a * b; C[2] += -0.999 * a * d;
+    C[3] += 1.0 - 0.999 * b * b; C[4] += -0.999 * b * d; C[5] += 1.0 - 0.999 * d * d;
+  }
+  const double num = (double)(s1 - s0);
+  const int v = atomicAdd(nvox, 1);
+  cell_voxel[c] = v;
+  vox_cell[v] = c;
+  double* rec = vox + (size_t)v * kVoxRec;
+  rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
+#pragma unroll
+  for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
+  rec[9] = num;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C4 + C5  correspondences, Mahalanobis, residual, Jacobian, normal equations.
+// fast_vgicp_impl.hpp:73-116 (update_correspondences) + :119-180 (linearize); SURVEY A.4.
+// One lane per source point; 28 fp64 partials per lane -> wave __shfl reduction -> LDS across the block's waves
+// -> one partial row per block; a second single-block kernel folds the rows in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+constexpr int LIN_T = 256;
+int linearize_blocks(int n) { return (n + LIN_T - 1) / LIN_T; }
+
+__device__ __forceinline__ bool inv_sym3(const double S[6], double M[6]) {
+  const double a = S[0], b = S[1], c = S[2], d = S[3], e = S[4], f = S[5];
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  if (det == 0.0) return false;
+  const double id = 1.0 / det;
+  M[0] = c00 * id; M[1] = c01 * id; M[2] = c02 * id;
+  M[3] = (a * f - c * c) * id; M[4] = (b * c - a * e) * id; M[5] = (a * d - b * b) * id;
+  return true;
+}
+
+__device__ __forceinline__ void neighbor_offset(int noff, int o, int& ox, int& oy, int& oz) {
+  // fast_vgicp_voxel.hpp:10-44
+  if (noff == 1) { ox = oy = oz = 0; return; }
+  if (noff == 7) {
+    ox = (o == 1) - (o == 2);
+    oy = (o == 3) - (o == 4);
+    oz = (o == 5) - (o == 6);
+    return;
+  }
+  ox = o / 9 - 1; oy = (o / 3) % 3 - 1; oz = o % 3 - 1;
+}
+
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ row) {
+  __shared__ double red[LIN_T / WAVE][NACC];
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+  for (int a = 0; a < NACC; a++) {
+    double v = wave_sum(acc[a]);
+    if (lane == 0) red[w][a] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < LIN_T / WAVE; j++) s += red[j][threadIdx.x];
+    row[threadIdx.x] = s;
+  }
+}
+
+__global__ void __launch_bounds__(LIN_T)
+k_linearize(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+            const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Pose T, Grid g,
+            const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v,
+            double* __restrict__ corr_M, int want_H, double* __restrict__ partials, int* __restrict__ ncorr_partials) {
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[kAccum];
+#pragma unroll
+  for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
+  int ncorr = 0;
+  if (i < n) {
+    const double p0 = (double)xs[i], p1 = (double)ys[i], p2 = (double)zs[i];
+    const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
+    const double q1 = T.R[3] * p0 + T.R[4] * p1 + T.R[5] * p2 + T.t[1];
+    const double q2 = T.R[6] * p0 + T.R[7] * p1 + T.R[8] * p2 + T.t[2];
+    // R C_A R^T = I - 0.999 (R n)(R n)^T
+    const double a0 = nx[i], a1 = ny[i], a2 = nz[i];
+    const double r0 = T.R[0] * a0 + T.R[1] * a1 + T.R[2] * a2;
+    const double r1 = T.R[3] * a0 + T.R[4] * a1 + T.R[5] * a2;
+    const double r2 = T.R[6] * a0 + T.R[7] * a1 + T.R[8] * a2;
+    const double CA[6] = {1.0 - 0.999 * r0 * r0, -0.999 * r0 * r1, -0.999 * r0 * r2,
+                          1.0 - 0.999 * r1 * r1, -0.999 * r1 * r2, 1.0 - 0.999 * r2 * r2};
+    const int cx = (int)floor(q0 / g.res - 0.5) - g.minc[0];
+    const int cy = (int)floor(q1 / g.res - 0.5) - g.minc[1];
+    const int cz = (int)floor(q2 / g.res - 0.5) - g.minc[2];
+    for (int o = 0; o < noff; o++) {
+      int ox, oy, oz;
+      neighbor_offset(noff, o, ox, oy, oz);
+      const int x = cx + ox, y = cy + oy, z = cz + oz;
+      int v = -1;
+      if (x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) v = cell_voxel[cell_index(g, x, y, z)];
+      const size_t slot = (size_t)o * n + i;
+      corr_v[slot] = v;
+      if (v < 0) continue;
+      const double* rec = vox + (size_t)v * kVoxRec;
+      double S[6], M[6];
+#pragma unroll
+      for (int a = 0; a < 6; a++) S[a] = rec[3 + a] + CA[a];
+      if (!inv_sym3(S, M)) {
+#pragma unroll
+        for (int a = 0; a < 6; a++) M[a] = 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 6; a++) corr_M[((size_t)a * noff + o) * n + i] = M[a];
+      ncorr++;
+      const double e0 = rec[0] - q0, e1 = rec[1] - q1, e2 = rec[2] - q2;
+      const double w = sqrt(rec[9]);
+      const double Me0 = M[0] * e0 + M[1] * e1 + M[2] * e2;
+      const double Me1 = M[1] * e0 + M[3] * e1 + M[4] * e2;
+      const double Me2 = M[2] * e0 + M[4] * e1 + M[5] * e2;
+      acc[27] += w * (e0 * Me0 + e1 * Me1 + e2 * Me2);
+      if (!want_H) continue;
+      // J = [skew(q) | -I]  (3x6), columns [rot, trans]; H += w J^T M J, b += w J^T M e
+      const double J[3][6] = {{0.0, -q2, q1, -1.0, 0.0, 0.0}, {q2, 0.0, -q0, 0.0, -1.0, 0.0}, {-q1, q0, 0.0, 0.0, 0.0, -1.0}};
+      double MJ[3][6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        MJ[0][c] = M[0] * J[0][c] + M[1] * J[1][c] + M[2] * J[2][c];
+        MJ[1][c] = M[1] * J[0][c] + M[3] * J[1][c] + M[4] * J[2][c];
+        MJ[2][c] = M[2] * J[0][c] + M[4] * J[1][c] + M[5] * J[2][c];
+      }
+      int u = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int c = a; c < 6; c++) {
+          acc[u] += w * (J[0][a] * MJ[0][c] + J[1][a] * MJ[1][c] + J[2][a] * MJ[2][c]);
+          u++;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; a++) acc[21 + a] += w * (J[0][a] * Me0 + J[1][a] * Me1 + J[2][a] * Me2);
+    }
+  }
+  block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
+  // correspondence count (exact integer)
+  int c = ncorr;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  __shared__ int cred[LIN_T / WAVE];
+  if ((threadIdx.x & (WAVE - 1)) == 0) cred[threadIdx.x / WAVE] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int j = 0; j < LIN_T / WAVE; j++) s += cred[j];
+    ncorr_partials[blockIdx.x] = s;
+  }
+}
+
+// fold per-block rows in a fixed order: thread t sums rows t, t+256, ... then a fixed LDS tree
+template <int NACC>
+__global__ void __launch_bounds__(256) k_fold(const double* __restrict__ partials, int nrows, double* __restrict__ out,
+                                              const int* __restrict__ ipartials, int* __restrict__ iout) {
+  __shared__ double sh[256];
+  __shared__ int shi[256];
+  const int t = threadIdx.x;
+  for (int a = 0; a < NACC; a++) {
+    double s = 0;
+    for (int r = t; r < nrows; r += 256) s += partials[(size_t)r * NACC + a];
+    sh[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) sh[t] += sh[t + o];
+      __syncthreads();
+    }
+    if (t == 0) out[a] = sh[0];
+    __syncthreads();
+  }
+  if (ipartials) {
+    int s = 0;
+    for (int r = t; r < nrows; r += 256) s += ipartials[r];
+    shi[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) shi[t] += shi[t + o];
+      __syncthreads();
+    }
+    if (t == 0) *iout = shi[0];
+  }
+}
+
+// C6  fast_vgicp_impl.hpp:183-204: frozen correspondences and Mahalanobis
+__global__ void __launch_bounds__(LIN_T)
+k_error(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs, int n, Pose T,
+        const double* __restrict__ vox, int noff, const int* __restrict__ corr_v, const double* __restrict__ corr_M,
+        double* __restrict__ partials) {
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < n) {
+    const double p0 = (double)xs[i], p1 = (double)ys[i], p2 = (double)zs[i];
+    const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
+    const double q1 = T.R[3] * p0 + T.R[4] * p1 + T.R[5] * p2 + T.t[1];
+    const double q2 = T.R[6] * p0 + T.R[7] * p1 + T.R[8] * p2 + T.t[2];
+    for (int o = 0; o < noff; o++) {
+      const int v = corr_v[(size_t)o * n + i];
+      if (v < 0) continue;
+      const double* rec = vox + (size_t)v * kVoxRec;
+      double M[6];
+#pragma unroll
+      for (int a = 0; a < 6; a++) M[a] = corr_M[((size_t)a * noff + o) * n + i];
+      const double e0 = rec[0] - q0, e1 = rec[1] - q1, e2 = rec[2] - q2;
+      const double w = sqrt(rec[9]);
+      acc[0] += w * (e0 * (M[0] * e0 + M[1] * e1 + M[2] * e2) + e1 * (M[1] * e0 + M[3] * e1 + M[4] * e2) +
+                     e2 * (M[2] * e0 + M[4] * e1 + M[5] * e2));
+    }
+  }
+  block_reduce_store<1>(acc, partials + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C8  pcl::Registration::getFitnessScore: fp32 transform, exact 1-NN in the target grid, fp32 distances summed
+// in fp64.  One lane per source point.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(LIN_T)
+k_fitness(const float* __restrict__ sxs, const float* __restrict__ sys, const float* __restrict__ szs, int ns, PoseF T,
+          const float* __restrict__ txs, const float* __restrict__ tys, const float* __restrict__ tzs,
+          const int* __restrict__ tstart, Grid g, double* __restrict__ partials) {
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < ns) {
+    const float x = sxs[i], y = sys[i], z = szs[i];
+    const float px = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
+    const float py = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
+    const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
+    const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
+    const double q[3] = {(double)px, (double)py, (double)pz};
+    int rmax = 0, r0 = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
+      r0 = max(r0, max(-c[a], c[a] - (g.dim[a] - 1)));
+    }
+    float best = 3.0e38f;
+    bool have = false;
+    for (int r = r0;; r++) {
+      const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
+      const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
+      for (int zz = z0; zz <= z1; zz++) {
+        const int az = abs(zz - c[2]);
+        for (int yy = y0; yy <= y1; yy++) {
+          const bool face = (az == r) || (abs(yy - c[1]) == r);
+          const int xstep = face ? 1 : max(2 * r, 1);
+          for (int xx = c[0] - r; xx <= c[0] + r; xx += xstep) {
+            if (xx < 0 || xx >= g.dim[0]) continue;
+            const int cid = cell_index(g, xx, yy, zz);
+            for (int s = tstart[cid]; s < tstart[cid + 1]; s++) {
+              const float dx = px - txs[s], dy = py - tys[s], dz = pz - tzs[s];
+              const float d2 = (dx * dx + dy * dy) + dz * dz;
+              if (d2 < best) { best = d2; have = true; }
+            }
+          }
+        }
+      }
+      if (r >= rmax) break;
+      if (have) {
+        double bound = 1.0e300;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          if (c[a] - r > 0) bound = fmin(bound, q[a] - ((double)(c[a] - r + g.minc[a]) + 0.5) * g.res);
+          if (c[a] + r < g.dim[a] - 1) bound = fmin(bound, ((double)(c[a] + r + g.minc[a]) + 1.5) * g.res - q[a]);
+        }
+        if (bound == 1.0e300) break;
+        if (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5)) break;
+      }
+    }
+    acc[0] = (double)best;
+  }
+  block_reduce_store<1>(acc, partials + blockIdx.x);
+}
+
+__global__ void k_transform_f32(const float* __restrict__ in, int stride_f, int n, PoseF T, float* __restrict__ out, int ostride_f) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = in + (size_t)i * stride_f;
+  const float x = p[0], y = p[1], z = p[2];
+  float* o = out + (size_t)i * ostride_f;
+  o[0] = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
+  o[1] = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
+  o[2] = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
+}
+
+__global__ void k_unsort3(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c,
+                          const int* __restrict__ order, int n, double* __restrict__ out3) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int i = order[s];
+  out3[(size_t)i * 3 + 0] = a[s];
+  out3[(size_t)i * 3 + 1] = b[s];
+  out3[(size_t)i * 3 + 2] = c[s];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+static inline int nblk(long long n, int t) { return (int)((n + t - 1) / t); }
+
+void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags) {
+  hipLaunchKernelGGL(k_bbox, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags);
+}
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt) {
+  hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, cnt);
+}
+void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums) {
+  const int nb = nblk(n, SCAN_B);
+  hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(SCAN_T), 0, s, in, out, n, block_sums);
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, s, block_sums, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_T), 0, s, out, n, block_sums);
+  }
+}
+void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp) {
+  hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, start, cnt, order_tmp);
+}
+void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
+                 const int* order_tmp, int* order, float* xs, float* ys, float* zs) {
+  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, order, xs, ys, zs);
+}
+void knn_cov(hipStream_t s, bool is_target, const float* xs, const float* ys, const float* zs, const int* start,
+             const int* order, Grid g, int n, int k, double* nx, double* ny, double* nz) {
+  const size_t lds = (size_t)k * KNN_T * (sizeof(float) + sizeof(int));
+  if (is_target)
+    hipLaunchKernelGGL(k_knn_cov<true>, dim3(nblk(n, KNN_T)), dim3(KNN_T), lds, s, xs, ys, zs, start, order, g, n, k, nx, ny, nz);
+  else
+    hipLaunchKernelGGL(k_knn_cov<false>, dim3(nblk(n, KNN_T)), dim3(KNN_T), lds, s, xs, ys, zs, start, order, g, n, k, nx, ny, nz);
+}
+void voxel_build(hipStream_t s, const float* xs, const float* ys, const float* zs, const double* nx, const double* ny,
+                 const double* nz, const int* start, Grid g, int* cell_voxel, double* vox, int* vox_cell, int* nvox) {
+  hipLaunchKernelGGL(k_voxel_build, dim3(nblk(g.ncell, 256)), dim3(256), 0, s, xs, ys, zs, nx, ny, nz, start, g, cell_voxel, vox, vox_cell, nvox);
+}
+void linearize(hipStream_t s, const float* xs, const float* ys, const float* zs, const double* nx, const double* ny,
+               const double* nz, int n, Pose T, Grid g, const int* cell_voxel, const double* vox, int noff, int* corr_v,
+               double* corr_M, int want_H, double* partials, int* ncorr_partials, double* out28, int* out_ncorr) {
+  const int nb = linearize_blocks(n);
+  hipLaunchKernelGGL(k_linearize, dim3(nb), dim3(LIN_T), 0, s, xs, ys, zs, nx, ny, nz, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, want_H, partials, ncorr_partials);
+  hipLaunchKernelGGL(k_fold<kAccum>, dim3(1), dim3(256), 0, s, partials, nb, out28, ncorr_partials, out_ncorr);
+}
+void compute_error(hipStream_t s, const float* xs, const float* ys, const float* zs, int n, Pose T, const double* vox, int noff,
+                   const int* corr_v, const double* corr_M, double* partials, double* out1) {
+  const int nb = linearize_blocks(n);
+  hipLaunchKernelGGL(k_error, dim3(nb), dim3(LIN_T), 0, s, xs, ys, zs, n, T, vox, noff, corr_v, corr_M, partials);
+  hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(256), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
+}
+void fitness(hipStream_t s, const float* sxs, const float* sys, const float* szs, int ns, PoseF T, const float* txs,
+             const float* tys, const float* tzs, const int* tstart, Grid g, double* partials, double* out1) {
+  const int nb = linearize_blocks(ns);
+  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(LIN_T), 0, s, sxs, sys, szs, ns, T, txs, tys, tzs, tstart, g, partials);
+  hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(256), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
+}
+void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f) {
+  hipLaunchKernelGGL(k_transform_f32, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, out, out_stride_f);
+}
+void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const int* order, int n, double* out3) {
+  hipLaunchKernelGGL(k_unsort3, dim3(nblk(n, 256)), dim3(256), 0, s, a, b, c, order, n, out3);
+}
+
+}  // namespace rgck

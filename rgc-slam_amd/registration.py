@@ -1,0 +1,294 @@
+"""Host-side mirror of the registration operator the RGC-SLAM odometer programs against
+(``fast_gicp::FastVGICP<PointXYZI,PointXYZI>`` as driven at /root/reference/rgc_slam/src/RGC_odometer.cpp:998-1011),
+backed by the HIP library through the C-ABI (include/rgc_hip.h).  Same method names, argument meaning and
+error behaviour (no exceptions from the solver itself: "lm not converged" is a flag, hasConverged() like PCL);
+API misuse and HIP failures raise RgcError.
+
+This is a thin Python stand-in for the C++ adaptor (cpp/fast_vgicp_hip.hpp) so that the parity tests read like
+the reference's call site.  It never computes anything on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DIRECT1, DIRECT7, DIRECT27, Params, RgcError, Stats
+
+
+def _f32c(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+class NeighborSearchMethod:  # include/fast_gicp/gicp/gicp_settings.hpp:8
+    DIRECT27, DIRECT7, DIRECT1 = DIRECT27, DIRECT7, DIRECT1
+
+
+class FastVGICP:
+    """``vgicp = FastVGICP(); vgicp.setResolution(1.0); ... vgicp.setInputTarget(t); vgicp.setInputSource(s);
+    aligned = vgicp.align(T2); score = vgicp.getFitnessScore(); T = vgicp.getFinalTransformation()``"""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        # constructor defaults of LsqRegistration / FastGICP / FastVGICP
+        # (lsq_registration_impl.hpp:9-22, fast_gicp_impl.hpp:9-24, fast_vgicp_impl.hpp:18-25)
+        self._p = _lib.default_params(max_iterations=64, translation_eps=5e-4)
+        h = C.c_void_p()
+        rc = self._L.rgc_create(device, C.byref(self._p), C.byref(h))
+        if rc != 0:
+            raise RgcError(rc, self._L.rgc_status_string(rc).decode() + " (rgc_create: is a HIP device visible?)")
+        self._h = h
+        self._final = np.eye(4, dtype=np.float32)
+        self._H = np.eye(6)
+        self._converged = False
+        self._lm_failed = False
+        self._iterations = 0
+        self._fitness = None
+        self._n_src = self._n_tgt = 0
+        self._keep = {}
+
+    # -- lifetime --------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rgc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RgcError(rc, self._L.rgc_last_error(self._h).decode() or self._L.rgc_status_string(rc).decode())
+
+    def _push(self):
+        self._chk(self._L.rgc_set_params(self._h, C.byref(self._p)))
+
+    # -- setters (pcl::Registration / LsqRegistration / FastGICP / FastVGICP) ----------------------
+    def setResolution(self, r):                      # fast_vgicp_impl.hpp:32-34
+        self._p.voxel_res = float(r); self._push()
+
+    def setMaximumIterations(self, n):               # pcl::Registration
+        self._p.max_iterations = int(n); self._push()
+
+    def setTransformationEpsilon(self, e):           # pcl::Registration; used by is_converged (:82-91)
+        self._p.translation_eps = float(e); self._push()
+
+    def setRotationEpsilon(self, e):                 # lsq_registration_impl.hpp:27-29
+        self._p.rotation_eps = float(e); self._push()
+
+    def setInitialLambdaFactor(self, f):             # lsq_registration_impl.hpp:32-34
+        self._p.lm_init_lambda_factor = float(f); self._push()
+
+    def setCorrespondenceRandomness(self, k):        # fast_gicp_impl.hpp:41-43
+        self._p.k_correspondences = int(k); self._push()
+
+    def setNeighborSearchMethod(self, m):            # fast_vgicp_impl.hpp:37-39
+        self._p.neighbor_method = int(m); self._push()
+
+    # accepted and ignored, exactly like the reference for FastVGICP
+    def setMaxCorrespondenceDistance(self, d):       # unused by FastVGICP (only kd-tree FastGICP, fast_gicp_impl.hpp:136)
+        self._max_corr_dist = float(d)
+
+    def setEuclideanFitnessEpsilon(self, e):         # no-op in LsqRegistration
+        self._fitness_eps = float(e)
+
+    def setRANSACIterations(self, n):                # no-op
+        self._ransac = int(n)
+
+    def setNumThreads(self, n):                      # fast_gicp_impl.hpp:29-37: CPU threads; nothing to set on the GPU
+        self._num_threads = int(n)
+
+    # -- clouds ----------------------------------------------------------------------------------
+    def setInputTarget(self, cloud):                 # fast_vgicp_impl.hpp:56-63
+        a = _f32c(cloud)
+        if a.ndim != 2 or a.shape[1] < 3:
+            raise RgcError(_lib.ERR_INVALID, "cloud must be (n, >=3) float32")
+        self._chk(self._L.rgc_set_target(self._h, a.ctypes.data, a.shape[0], a.strides[0]))
+        self._n_tgt = a.shape[0]
+        self._fitness = None
+
+    def setInputSource(self, cloud):                 # fast_gicp_impl.hpp:72-80
+        a = _f32c(cloud)
+        if a.ndim != 2 or a.shape[1] < 3:
+            raise RgcError(_lib.ERR_INVALID, "cloud must be (n, >=3) float32")
+        self._chk(self._L.rgc_set_source(self._h, a.ctypes.data, a.shape[0], a.strides[0]))
+        self._n_src = a.shape[0]
+        self._fitness = None
+
+    def setInputTargetDevice(self, d_ptr: int, n: int, stride_bytes: int):
+        self._chk(self._L.rgc_set_target_device(self._h, C.c_void_p(d_ptr), n, stride_bytes))
+        self._n_tgt = n
+        self._fitness = None
+
+    def setInputSourceDevice(self, d_ptr: int, n: int, stride_bytes: int):
+        self._chk(self._L.rgc_set_source_device(self._h, C.c_void_p(d_ptr), n, stride_bytes))
+        self._n_src = n
+        self._fitness = None
+
+    # -- the operator ------------------------------------------------------------------------------
+    def align(self, guess=None, want_output=True, want_fitness=False):
+        """pcl::Registration::align(output, guess): returns the transformed source cloud (n,3) float32
+        (or None if want_output=False)."""
+        g = np.eye(4, dtype=np.float32) if guess is None else np.ascontiguousarray(guess, dtype=np.float32).reshape(4, 4)
+        fin = np.empty(16, np.float32)
+        H = np.empty(36)
+        fit = C.c_double(0)
+        it, conv, fail = C.c_int(0), C.c_int(0), C.c_int(0)
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        self._chk(self._L.rgc_align(self._h, g.ctypes.data_as(fp), fin.ctypes.data_as(fp), H.ctypes.data_as(dp),
+                                    C.byref(fit) if want_fitness else None, C.byref(it), C.byref(conv), C.byref(fail)))
+        self._final = fin.reshape(4, 4)
+        self._H = H.reshape(6, 6)
+        self._iterations, self._converged, self._lm_failed = it.value, bool(conv.value), bool(fail.value)
+        self._fitness = fit.value if want_fitness else None
+        if not want_output:
+            return None
+        out = np.empty((self._n_src, 3), np.float32)
+        self._chk(self._L.rgc_get_aligned(self._h, fin.ctypes.data_as(fp), out.ctypes.data_as(fp), 12))
+        return out
+
+    def getFinalTransformation(self):
+        return self._final.copy()
+
+    def getFinalHessian(self):                       # lsq_registration_impl.hpp:43-45
+        return self._H.copy()
+
+    def hasConverged(self):
+        return self._converged
+
+    @property
+    def lm_failed(self):                             # "lm not converged!!" lsq_registration_impl.hpp:69-72
+        return self._lm_failed
+
+    @property
+    def nr_iterations(self):                         # number of outer iterations executed
+        return self._iterations
+
+    def getFitnessScore(self):                       # RGC_odometer.cpp:1010
+        if self._fitness is None:
+            f = C.c_double(0)
+            t = np.ascontiguousarray(self._final, dtype=np.float32)
+            self._chk(self._L.rgc_fitness(self._h, t.ctypes.data_as(C.POINTER(C.c_float)), C.byref(f)))
+            self._fitness = f.value
+        return self._fitness
+
+    def evaluateCost(self, relative_pose, want_H=False):   # lsq_registration_impl.hpp:48-50
+        T = np.ascontiguousarray(np.asarray(relative_pose, dtype=np.float32).astype(np.float64)).reshape(16)
+        cost = C.c_double(0)
+        dp = C.POINTER(C.c_double)
+        if want_H:
+            H, b = np.empty(36), np.empty(6)
+            self._chk(self._L.rgc_linearize(self._h, T.ctypes.data_as(dp), H.ctypes.data_as(dp), b.ctypes.data_as(dp), C.byref(cost)))
+            return cost.value, H.reshape(6, 6), b
+        self._chk(self._L.rgc_linearize(self._h, T.ctypes.data_as(dp), None, None, C.byref(cost)))
+        return cost.value
+
+    # the two protected virtuals of LsqRegistration (lsq_registration.hpp:68-69), exposed for the parity tests
+    def linearize(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        cost = C.c_double(0)
+        H, b = np.empty(36), np.empty(6)
+        dp = C.POINTER(C.c_double)
+        self._chk(self._L.rgc_linearize(self._h, T.ctypes.data_as(dp), H.ctypes.data_as(dp), b.ctypes.data_as(dp), C.byref(cost)))
+        return cost.value, H.reshape(6, 6), b
+
+    def compute_error(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        cost = C.c_double(0)
+        self._chk(self._L.rgc_compute_error(self._h, T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cost)))
+        return cost.value
+
+    @property
+    def num_correspondences(self):
+        n = C.c_int(0)
+        self._chk(self._L.rgc_num_correspondences(self._h, C.byref(n)))
+        return n.value
+
+    # -- per-stage results ---------------------------------------------------------------------------
+    def getSourceCovariances(self):                  # fast_gicp.hpp:63-65 (3x3 block of the reference's Matrix4d)
+        cov = np.empty((self._n_src, 3, 3))
+        self._chk(self._L.rgc_get_source_covariances(self._h, cov.ctypes.data_as(C.POINTER(C.c_double)), None))
+        return cov
+
+    def getTargetCovariances(self):                  # fast_gicp.hpp:67-69
+        cov = np.empty((self._n_tgt, 3, 3))
+        self._chk(self._L.rgc_get_target_covariances(self._h, cov.ctypes.data_as(C.POINTER(C.c_double)), None))
+        return cov
+
+    def getSourceNormals(self):
+        n = np.empty((self._n_src, 3))
+        self._chk(self._L.rgc_get_source_covariances(self._h, None, n.ctypes.data_as(C.POINTER(C.c_double))))
+        return n
+
+    def getTargetNormals(self):
+        n = np.empty((self._n_tgt, 3))
+        self._chk(self._L.rgc_get_target_covariances(self._h, None, n.ctypes.data_as(C.POINTER(C.c_double))))
+        return n
+
+    def getVoxels(self):
+        """Gaussian voxel map sorted by (cx,cy,cz): dict(coords, num, mean, cov)."""
+        cnt = C.c_int(0)
+        self._chk(self._L.rgc_get_voxels(self._h, 0, None, None, None, None, C.byref(cnt)))
+        V = cnt.value
+        coords, num = np.empty((V, 3), np.int32), np.empty(V, np.int32)
+        mean, cov = np.empty((V, 3)), np.empty((V, 3, 3))
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        self._chk(self._L.rgc_get_voxels(self._h, V, coords.ctypes.data_as(ip), num.ctypes.data_as(ip), mean.ctypes.data_as(dp),
+                                         cov.ctypes.data_as(dp), C.byref(cnt)))
+        o = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+        return dict(coords=coords[o], num=num[o], mean=mean[o], cov=cov[o])
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._chk(self._L.rgc_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    # -- profiling plumbing ----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self._L.rgc_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self._L.rgc_profile_reset(self._h))
+
+    def profile(self) -> dict:
+        out = {}
+        for kind in range(_lib.K_COUNT):
+            n, ms, pts = C.c_longlong(0), C.c_double(0), C.c_longlong(0)
+            self._chk(self._L.rgc_profile_get(self._h, kind, C.byref(n), C.byref(ms), C.byref(pts)))
+            out[self._L.rgc_profile_name(kind).decode()] = dict(launches=n.value, total_ms=ms.value, points=pts.value)
+        return out
+
+    def synchronize(self):
+        self._chk(self._L.rgc_synchronize(self._h))
+
+    # device memory helpers (clouds resident in HBM)
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._chk(self._L.rgc_device_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr: int):
+        self._chk(self._L.rgc_device_free(self._h, C.c_void_p(ptr)))
+
+    def upload(self, ptr: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        self._chk(self._L.rgc_upload(self._h, C.c_void_p(ptr), a.ctypes.data, a.nbytes))
+        self._chk(self._L.rgc_synchronize(self._h))
+
+
+def odometer_vgicp(device: int = 0) -> FastVGICP:
+    """A FastVGICP configured exactly as the odometer does (RGC_odometer.cpp:998-1006)."""
+    v = FastVGICP(device)
+    v.setResolution(1.0)                 # down_simple_vgicp, :308,1000
+    v.setMaximumIterations(25)           # :1001
+    v.setMaxCorrespondenceDistance(2)    # :1002
+    v.setTransformationEpsilon(1e-6)     # :1003
+    v.setEuclideanFitnessEpsilon(1e-6)   # :1004
+    v.setRANSACIterations(0)             # :1005
+    v.setNumThreads(14)                  # :1006
+    return v

@@ -1,0 +1,224 @@
+"""HIP path (through the C-ABI) vs the golden fixtures and vs the CPU oracle.  Needs an MI355X: -m gpu.
+
+Tolerances: integer / index results exact; fp64 reductions relative 1e-9 (different summation order only);
+end-to-end pose delta <= 1e-4 m / 1e-4 rad (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from conftest import tri6
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reg_mod():
+    from rgc_slam_amd import registration
+    return registration
+
+
+def _odo(reg_mod):
+    return reg_mod.odometer_vgicp(0)
+
+
+def _rot_angle(Ra, Rb):
+    # angle of Ra Rb^T from its skew part (arccos of the trace is ill-conditioned near 0 for fp32 matrices)
+    R = Ra.astype(np.float64) @ Rb.astype(np.float64).T
+    w = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return float(np.arcsin(min(1.0, np.linalg.norm(w))))
+
+
+def _cov_from_normals(n):
+    return np.eye(3)[None] - 0.999 * n[:, :, None] * n[:, None, :]
+
+
+def test_golden_covariances_and_voxels(reg_mod, fx_reg):
+    v = _odo(reg_mod)
+    v.setInputTarget(fx_reg["tgt"])
+    v.setInputSource(fx_reg["src"])
+    cs = v.getSourceCovariances()
+    err = np.abs(tri6(cs) - fx_reg["src_cov6"]).max(axis=1)
+    assert np.sum(err > 1e-9) <= 2, f"{np.sum(err > 1e-9)} source covariances differ, max {err.max()}"
+    ct = v.getTargetCovariances()
+    err = np.abs(tri6(ct[::4]) - fx_reg["tgt_cov6_sub"]).max(axis=1)
+    assert np.sum(err > 1e-9) <= 2
+    n = v.getSourceNormals()
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-12)
+    vm = v.getVoxels()
+    assert np.array_equal(vm["coords"], fx_reg["vox_coords"])
+    assert np.array_equal(vm["num"], fx_reg["vox_num"])
+    assert np.abs(vm["mean"] - fx_reg["vox_mean"]).max() < 1e-12
+    assert np.abs(tri6(vm["cov"]) - fx_reg["vox_cov6"]).max() < 1e-9
+    v.close()
+
+
+def test_golden_linearize_and_error(reg_mod, fx_reg):
+    v = _odo(reg_mod)
+    v.setInputTarget(fx_reg["tgt"])
+    v.setInputSource(fx_reg["src"])
+    cost, H, b = v.linearize(fx_reg["guess"])
+    assert v.num_correspondences == int(fx_reg["lin_ncorr"])
+    assert abs(cost - fx_reg["lin_cost"]) <= 1e-9 * abs(fx_reg["lin_cost"])
+    assert np.abs(H - fx_reg["lin_H"]).max() <= 1e-9 * np.abs(fx_reg["lin_H"]).max()
+    assert np.abs(b - fx_reg["lin_b"]).max() <= 1e-9 * np.abs(fx_reg["lin_b"]).max()
+    assert np.array_equal(H, H.T)
+    assert np.linalg.eigvalsh(H).min() > 0
+    e = v.compute_error(fx_reg["err_T"])
+    assert abs(e - fx_reg["err_cost"]) <= 1e-9 * abs(fx_reg["err_cost"])
+    assert abs(v.evaluateCost(fx_reg["guess"]) - cost) <= 1e-12 * cost
+    v.setNeighborSearchMethod(reg_mod.NeighborSearchMethod.DIRECT7)
+    cost7, H7, b7 = v.linearize(fx_reg["guess"])
+    assert v.num_correspondences == int(fx_reg["lin7_ncorr"])
+    assert abs(cost7 - fx_reg["lin7_cost"]) <= 1e-9 * abs(fx_reg["lin7_cost"])
+    assert np.abs(H7 - fx_reg["lin7_H"]).max() <= 1e-9 * np.abs(fx_reg["lin7_H"]).max()
+    assert np.abs(b7 - fx_reg["lin7_b"]).max() <= 1e-9 * np.abs(fx_reg["lin7_b"]).max()
+    v.close()
+
+
+def test_golden_align(reg_mod, fx_reg):
+    v = _odo(reg_mod)
+    v.setInputTarget(fx_reg["tgt"])
+    v.setInputSource(fx_reg["src"])
+    out = v.align(fx_reg["guess"])
+    T = v.getFinalTransformation()
+    assert v.nr_iterations == len(fx_reg["lm_y0"])
+    assert v.hasConverged() == bool(fx_reg["converged"])
+    assert np.abs(T - fx_reg["final_T"]).max() < 1e-6
+    assert abs(v.getFitnessScore() - fx_reg["fitness"]) <= 1e-5 * fx_reg["fitness"]
+    # output cloud = pcl::transformPointCloud(input, final) in fp32
+    src = fx_reg["src"]
+    exp = np.stack([((T[r, 0] * src[:, 0] + T[r, 1] * src[:, 1]) + T[r, 2] * src[:, 2]) + T[r, 3] for r in range(3)], axis=1)
+    assert np.abs(out - exp).max() < 1e-5
+    v.close()
+
+
+@pytest.fixture(scope="module")
+def medium():
+    import rgc_slam_amd.synth as synth
+    world, tgt = synth.make_world_and_map(100000, seed=synth.SEED)
+    T_true = synth.se3(synth.rot_zyx(0.02, 0.003, -0.002), [0.15, 0.01, 0.002])
+    src = synth.make_scan_n(world, T_true, 30000, seed=synth.SEED)["xyz"]
+    return dict(world=world, tgt=tgt, src=src, T_true=T_true)
+
+
+def test_oracle_parity_c1(reg_mod, orc, medium):
+    """BASELINE config 1 (30 k scan vs 100 k map): every stage against the CPU oracle."""
+    v = _odo(reg_mod)
+    v.setInputTarget(medium["tgt"])
+    v.setInputSource(medium["src"])
+    o = orc.Registration(max_iterations=25, translation_eps=1e-6, num_threads=0)
+    o.set_target(medium["tgt"])
+    o.set_source(medium["src"])
+    o.prepare()
+    # C2: covariances (a handful of float near-tie neighbourhoods may differ)
+    cs, ct = v.getSourceCovariances(), v.getTargetCovariances()
+    es = np.abs(cs - o.source_cov(len(cs))).reshape(len(cs), -1).max(axis=1)
+    et = np.abs(ct - o.target_cov(len(ct))).reshape(len(ct), -1).max(axis=1)
+    assert np.sum(es > 1e-9) == 0 and np.sum(et > 1e-9) == 0, (np.sum(es > 1e-9), np.sum(et > 1e-9))
+    # C3: voxel map as a sorted table
+    vm, om = v.getVoxels(), o.voxelmap()
+    assert np.array_equal(vm["coords"], om["coords"]) and np.array_equal(vm["num"], om["num"])
+    assert np.abs(vm["mean"] - om["mean"]).max() < 1e-11
+    assert np.abs(vm["cov"] - om["cov"]).max() < 1e-9
+    # C4/C5 at the initial guess
+    g = np.eye(4)
+    cost, H, b = v.linearize(g)
+    ocost, oH, ob = o.linearize(g)
+    assert v.num_correspondences == o.num_correspondences
+    assert abs(cost - ocost) <= 1e-9 * abs(ocost)
+    assert np.abs(H - oH).max() <= 1e-9 * np.abs(oH).max()
+    assert np.abs(b - ob).max() <= 1e-9 * np.abs(ob).max()
+    # C7 end to end
+    v.align(g, want_output=False)
+    To = o.align(g)
+    T = v.getFinalTransformation()
+    assert np.abs(T[:3, 3] - To[:3, 3]).max() <= 1e-4
+    assert _rot_angle(T[:3, :3], To[:3, :3]) <= 1e-4
+    assert v.nr_iterations == o.iterations and v.hasConverged() == o.converged
+    # C8
+    assert abs(v.getFitnessScore() - o.fitness()) <= 1e-6 * o.fitness()
+    v.close()
+
+
+def test_determinism_and_layouts(reg_mod, medium):
+    """same inputs => bit-identical outputs; AoS strides 12/16/32 and device-resident inputs agree."""
+    tgt, src = medium["tgt"][:40000], medium["src"][:8000]
+    res = []
+    for rep in range(2):
+        v = _odo(reg_mod)
+        v.setInputTarget(tgt)
+        v.setInputSource(src)
+        v.align(np.eye(4), want_output=False)
+        res.append((v.getFinalTransformation(), v.getFinalHessian(), v.getFitnessScore()))
+        v.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    # stride 16 and 32 (pcl::PointXYZI is 32 bytes)
+    for width in (4, 8):
+        t = np.zeros((len(tgt), width), np.float32); t[:, :3] = tgt; t[:, 3] = 7.0
+        s = np.zeros((len(src), width), np.float32); s[:, :3] = src; s[:, 3] = 3.0
+        v = _odo(reg_mod)
+        v.setInputTarget(t)
+        v.setInputSource(s)
+        v.align(np.eye(4), want_output=False)
+        assert np.array_equal(v.getFinalTransformation(), res[0][0])
+        v.close()
+    # clouds already resident in HBM
+    v = _odo(reg_mod)
+    t4 = np.zeros((len(tgt), 4), np.float32); t4[:, :3] = tgt
+    s4 = np.zeros((len(src), 4), np.float32); s4[:, :3] = src
+    dt, ds = v.device_alloc(t4.nbytes), v.device_alloc(s4.nbytes)
+    v.upload(dt, t4); v.upload(ds, s4)
+    v.setInputTargetDevice(dt, len(tgt), 16)
+    v.setInputSourceDevice(ds, len(src), 16)
+    v.align(np.eye(4), want_output=False)
+    assert np.array_equal(v.getFinalTransformation(), res[0][0])
+    v.device_free(dt); v.device_free(ds)
+    v.close()
+
+
+def test_edge_cases(reg_mod, medium):
+    from rgc_slam_amd import _lib
+    v = _odo(reg_mod)
+    with pytest.raises(reg_mod.RgcError) as e:
+        v.setInputTarget(medium["tgt"][:19])          # < k points: undefined in the reference, an error here
+    assert e.value.status == _lib.ERR_TOO_FEW_POINTS
+    with pytest.raises(reg_mod.RgcError) as e:
+        v.align(np.eye(4))                            # nothing set
+    assert e.value.status == _lib.ERR_NO_INPUT
+    bad = medium["tgt"][:1000].copy(); bad[17, 1] = np.nan
+    with pytest.raises(reg_mod.RgcError) as e:
+        v.setInputTarget(bad)
+    assert e.value.status == _lib.ERR_NONFINITE
+    # exactly k points, all in one voxel; source far away => zero correspondences, no crash, no hang
+    rng = np.random.default_rng(3)
+    v.setInputTarget(rng.uniform(0.6, 1.4, (20, 3)).astype(np.float32))
+    v.setInputSource((rng.uniform(0.6, 1.4, (25, 3)) + 50.0).astype(np.float32))
+    cost, H, b = v.linearize(np.eye(4))
+    assert v.num_correspondences == 0 and cost == 0.0 and not H.any() and not b.any()
+    v.align(np.eye(4), want_output=False)
+    assert v.nr_iterations >= 1
+    # a cloud spread over many empty cells (ring search must widen): 64 points on a 40 m line
+    line = np.stack([np.linspace(0, 40, 64), np.zeros(64), np.zeros(64)], axis=1).astype(np.float32)
+    line += rng.normal(0, 0.01, line.shape).astype(np.float32)
+    v.setInputTarget(line)
+    n = v.getTargetNormals()
+    assert np.all(np.abs(n[:, 0]) < 0.05)             # normals are perpendicular to the line
+    v.close()
+
+
+def test_k_and_resolution_parameters(reg_mod, orc, fx_reg):
+    """setCorrespondenceRandomness / setResolution change the covariances and the voxel map like the oracle's"""
+    v = _odo(reg_mod)
+    v.setCorrespondenceRandomness(10)
+    v.setResolution(0.5)
+    v.setInputTarget(fx_reg["tgt"])
+    v.setInputSource(fx_reg["src"])
+    o = orc.Registration(k_correspondences=10, voxel_res=0.5, num_threads=0)
+    o.set_target(fx_reg["tgt"]); o.set_source(fx_reg["src"]); o.prepare()
+    cs = v.getSourceCovariances()
+    assert np.sum(np.abs(cs - o.source_cov(len(cs))).reshape(len(cs), -1).max(axis=1) > 1e-9) <= 2
+    vm, om = v.getVoxels(), o.voxelmap()
+    assert np.array_equal(vm["coords"], om["coords"]) and np.array_equal(vm["num"], om["num"])
+    cost, H, b = v.linearize(fx_reg["guess"])
+    ocost, oH, ob = o.linearize(fx_reg["guess"])
+    assert abs(cost - ocost) <= 1e-9 * abs(ocost) and np.abs(H - oH).max() <= 1e-9 * np.abs(oH).max()
+    v.close()
