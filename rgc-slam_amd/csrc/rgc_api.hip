@@ -33,7 +33,7 @@ struct Cloud {
   int stride_f = 0;
   int n = 0;
   bool ready = false;  // grid + normals (+ voxels for the target) enqueued
-  DevBuf in_copy, cell_of, cnt, start, block_sums, order_tmp, order, xs, ys, zs, nx, ny, nz;
+  DevBuf in_copy, cell_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
   rgck::Grid grid{};
   // target only
   DevBuf cell_voxel, vox, vox_cell;
@@ -113,8 +113,8 @@ void release(DevBuf& b) {
 }
 
 void release_cloud(Cloud& cl) {
-  for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.order, &cl.xs, &cl.ys,
-                    &cl.zs, &cl.nx, &cl.ny, &cl.nz, &cl.cell_voxel, &cl.vox, &cl.vox_cell})
+  for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz,
+                    &cl.cell_voxel, &cl.vox, &cl.vox_cell})
     release(*b);
 }
 
@@ -201,10 +201,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
     if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nc1 / 2048 + 2)))) return rc;
     if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, cl.order, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, cl.xs, sizeof(float) * n))) return rc;
-    if ((rc = ensure(c, cl.ys, sizeof(float) * n))) return rc;
-    if ((rc = ensure(c, cl.zs, sizeof(float) * n))) return rc;
+    if ((rc = ensure(c, cl.P, sizeof(float4) * n))) return rc;
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
@@ -213,12 +210,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, (int*)cl.block_sums.p);
     rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
-                      (int*)cl.order.p, (float*)cl.xs.p, (float*)cl.ys.p, (float*)cl.zs.p);
+                      (float4*)cl.P.p);
   }
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n);
-    rgck::knn_cov(s, is_target, (const float*)cl.xs.p, (const float*)cl.ys.p, (const float*)cl.zs.p, (const int*)cl.start.p,
-                  (const int*)cl.order.p, cl.grid, n, k, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
+    rgck::knn_cov(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, (double*)cl.nx.p, (double*)cl.ny.p,
+                  (double*)cl.nz.p);
   }
   if (is_target) {
     int rc;
@@ -228,9 +225,8 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
     ProfScope ps(c, RGC_K_VOXEL, n);
     HIPCHK(c, hipMemsetAsync(c->d_small + 7, 0, sizeof(int), s));
-    rgck::voxel_build(s, (const float*)cl.xs.p, (const float*)cl.ys.p, (const float*)cl.zs.p, (const double*)cl.nx.p,
-                      (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p, cl.grid, (int*)cl.cell_voxel.p,
-                      (double*)cl.vox.p, (int*)cl.vox_cell.p, c->d_small + 7);
+    rgck::voxel_build(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p,
+                      (const int*)cl.start.p, cl.grid, (int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, c->d_small + 7);
     cl.nvox = -1;  // fetched lazily
   }
   HIPCHK(c, hipGetLastError());
@@ -300,7 +296,7 @@ int do_linearize(rgc_ctx* c, const double T[16], double* H, double* b, double* c
   const int want = (H && b) ? 1 : 0;
   {
     ProfScope ps(c, RGC_K_LINEARIZE, n);
-    rgck::linearize(c->stream, (const float*)c->src.xs.p, (const float*)c->src.ys.p, (const float*)c->src.zs.p,
+    rgck::linearize(c->stream, (const float4*)c->src.P.p,
                     (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n, pose_from(T), c->tgt.grid,
                     (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p, want,
                     (double*)c->partials.p, (int*)c->ipartials.p, c->d_out, c->d_small + 8);
@@ -335,7 +331,7 @@ int do_error(rgc_ctx* c, const double T[16], double* cost) {
   const int n = c->corr_n;
   {
     ProfScope ps(c, RGC_K_ERROR, n);
-    rgck::compute_error(c->stream, (const float*)c->src.xs.p, (const float*)c->src.ys.p, (const float*)c->src.zs.p, n, pose_from(T),
+    rgck::compute_error(c->stream, (const float4*)c->src.P.p, n, pose_from(T),
                         (const double*)c->tgt.vox.p, c->corr_noff, (const int*)c->corr_v.p, (const double*)c->corr_M.p,
                         (double*)c->partials.p, c->d_out);
   }
@@ -355,9 +351,8 @@ int do_fitness(rgc_ctx* c, const float T[16], double* out) {
   if ((rc = ensure(c, c->partials, sizeof(double) * rgck::kAccum * (size_t)nb))) return rc;
   {
     ProfScope ps(c, RGC_K_FITNESS, n);
-    rgck::fitness(c->stream, (const float*)c->src.xs.p, (const float*)c->src.ys.p, (const float*)c->src.zs.p, n, posef_from(T),
-                  (const float*)c->tgt.xs.p, (const float*)c->tgt.ys.p, (const float*)c->tgt.zs.p, (const int*)c->tgt.start.p, c->tgt.grid,
-                  (double*)c->partials.p, c->d_out);
+    rgck::fitness(c->stream, (const float4*)c->src.P.p, n, posef_from(T), (const float4*)c->tgt.P.p, (const int*)c->tgt.start.p,
+                  c->tgt.grid, (double*)c->partials.p, c->d_out);
   }
   HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -676,7 +671,7 @@ static int get_covs(rgc_ctx* c, Cloud& cl, double* cov9, double* normals) {
   const int n = cl.n;
   int rc = ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n);
   if (rc) return rc;
-  rgck::unsort3(c->stream, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.order.p, n, (double*)c->scratch.p);
+  rgck::unsort3(c->stream, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const float4*)cl.P.p, n, (double*)c->scratch.p);
   std::vector<double> tmp;
   double* dst = normals;
   if (!dst) { tmp.resize((size_t)n * 3); dst = tmp.data(); }

@@ -25,32 +25,32 @@ struct PoseF {  // fp32 4x4 rows 0..2 (pcl::transformPointCloud in the reference
 constexpr int kAccum = 28;  // 21 upper-triangular H + 6 b + 1 cost
 constexpr int kVoxRec = 10; // mean(3) cov6(6) num(1), doubles
 
+// Sorted points are float4 {x, y, z, original index (int bits)} grouped by grid cell.
 // ---- grid build ----
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags);
 void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt);
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */);
 void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp);
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const int* order_tmp, int* order, float* xs, float* ys, float* zs);
+                 const int* order_tmp, float4* P);
 // ---- C2: exact kNN + PLANE covariance -> unit normal ----
-void knn_cov(hipStream_t s, bool is_target, const float* xs, const float* ys, const float* zs, const int* start,
-             const int* order, Grid g, int n, int k, double* nx, double* ny, double* nz);
+void knn_cov(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, double* nx, double* ny,
+             double* nz);
 // ---- C3: Gaussian voxel map ----
-void voxel_build(hipStream_t s, const float* xs, const float* ys, const float* zs, const double* nx, const double* ny,
-                 const double* nz, const int* start, Grid g, int* cell_voxel, double* vox, int* vox_cell, int* nvox);
+void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
+                 int* cell_voxel, double* vox, int* vox_cell, int* nvox);
 // ---- C4/C5/C6 ----
-void linearize(hipStream_t s, const float* xs, const float* ys, const float* zs, const double* nx, const double* ny,
-               const double* nz, int n, Pose T, Grid g, const int* cell_voxel, const double* vox, int noff,
-               int* corr_v, double* corr_M, int want_H, double* partials, int* ncorr_partials, double* out28,
-               int* out_ncorr);
-void compute_error(hipStream_t s, const float* xs, const float* ys, const float* zs, int n, Pose T, const double* vox,
-                   int noff, const int* corr_v, const double* corr_M, double* partials, double* out1);
+void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
+               const int* cell_voxel, const double* vox, int noff, int* corr_v, double* corr_M, int want_H, double* partials,
+               int* ncorr_partials, double* out28, int* out_ncorr);
+void compute_error(hipStream_t s, const float4* P, int n, Pose T, const double* vox, int noff, const int* corr_v,
+                   const double* corr_M, double* partials, double* out1);
 // ---- C8 ----
-void fitness(hipStream_t s, const float* sxs, const float* sys, const float* szs, int ns, PoseF T, const float* txs,
-             const float* tys, const float* tzs, const int* tstart, Grid g, double* partials, double* out1);
+void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials,
+             double* out1);
 // ---- misc ----
 void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f);
-void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const int* order, int n, double* out3);
+void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const float4* P, int n, double* out3);
 int  linearize_blocks(int n);
 
 }  // namespace rgck

@@ -35,28 +35,33 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ------------------------------------------------------------------------------------------------
 // grid build
 // ------------------------------------------------------------------------------------------------
-__global__ void k_bbox(const float* __restrict__ in, int stride_f, int n, double res, int* mm6, int* flags) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ in, int stride_f, int n, double res, int* mm6, int* flags) {
+  __shared__ int red[256 / WAVE][6];
   int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
   int bad = 0;
-  if (i < n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float* p = in + (size_t)i * stride_f;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      float v = p[a];
+      const float v = p[a];
       if (!isfinite(v) || fabsf(v) > 1.0e8f) { bad = 1; continue; }
-      int c = voxel_coord1(v, res);
-      lo[a] = c;
-      hi[a] = c;
+      const int c = voxel_coord1(v, res);
+      lo[a] = min(lo[a], c);
+      hi[a] = max(hi[a], c);
     }
   }
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    int l = wave_min(lo[a]), h = wave_max(hi[a]);
-    if ((threadIdx.x & (WAVE - 1)) == 0) {
-      if (l != INT_MAX) atomicMin(&mm6[a], l);
-      if (h != INT_MIN) atomicMax(&mm6[3 + a], h);
-    }
+    const int l = wave_min(lo[a]), h = wave_max(hi[a]);
+    if (lane == 0) { red[w][a] = l; red[w][3 + a] = h; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    int v = red[0][threadIdx.x];
+    for (int j = 1; j < 256 / WAVE; j++) v = threadIdx.x < 3 ? min(v, red[j][threadIdx.x]) : max(v, red[j][threadIdx.x]);
+    if (threadIdx.x < 3) { if (v != INT_MAX) atomicMin(&mm6[threadIdx.x], v); }
+    else { if (v != INT_MIN) atomicMax(&mm6[threadIdx.x], v); }
   }
   if (bad) atomicOr(flags, 1);
 }
@@ -152,10 +157,10 @@ __global__ void k_scatter(int n, const int* __restrict__ cell_of, const int* __r
   order_tmp[start[c] + r] = i;
 }
 
-// deterministic placement: a point's final slot = cell start + number of same-cell points with a smaller index
+// deterministic placement: a point's final slot = cell start + number of same-cell points with a smaller index.
+// Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate.
 __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
-                              const int* __restrict__ start, const int* __restrict__ order_tmp, int* __restrict__ order,
-                              float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ zs) {
+                              const int* __restrict__ start, const int* __restrict__ order_tmp, float4* __restrict__ P) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   int i = order_tmp[s];
@@ -163,12 +168,8 @@ __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n,
   int s0 = start[c], s1 = start[c + 1];
   int rank = 0;
   for (int t = s0; t < s1; t++) rank += (order_tmp[t] < i);
-  int pos = s0 + rank;
   const float* p = in + (size_t)i * stride_f;
-  order[pos] = i;
-  xs[pos] = p[0];
-  ys[pos] = p[1];
-  zs[pos] = p[2];
+  P[s0 + rank] = make_float4(p[0], p[1], p[2], __int_as_float(i));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -226,110 +227,168 @@ __device__ __forceinline__ void min_eigenvector(const double S[6], double n[3]) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// C2  exact k-nearest neighbours + covariance + normal, one lane per query point (v1).
-// The per-lane candidate list lives in LDS as [slot][lane] columns (bank = lane -> conflict free).
-// fast_gicp_impl.hpp:241-298.
+// C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298).
+// One lane per query point, queries in cell order so a wave's lanes walk (nearly) the same cells and their
+// 16-byte candidate loads coalesce to a handful of cache lines.
+//  pass 1: the K smallest squared distances are kept in REGISTERS as a sorted chain (v_min/v_max insertion,
+//          no indexing, no LDS); a wave-uniform __any() skips the chain when no lane can improve.  Shells of
+//          cells are added until the K-th distance is provably inside the scanned cube (exact search).
+//  pass 2: the same cells are re-scanned; candidates closer than the K-th distance are appended to a per-lane
+//          LDS column ([slot][lane], bank = lane), ties on the K-th distance are resolved by original index
+//          like the CPU path, then mean / covariance / smallest eigenvector in fp64.
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_T = 256;
 
-// kTarget only separates the two instantiations by NAME (map cloud vs scan cloud) so that profiles report the
-// dominant launch (the map) on its own line.
-template <bool kTarget>
+struct ShellIter {  // cells at Chebyshev distance exactly r from (c0,c1,c2), clipped to the grid
+  int r, z, y, x, z1, y0, y1, c0, c1, c2;
+};
+
+template <typename F>
+__device__ __forceinline__ void for_each_shell_cell(const Grid& g, int c0, int c1, int c2, int r, F&& f) {
+  const int z0 = max(c2 - r, 0), z1 = min(c2 + r, g.dim[2] - 1);
+  const int y0 = max(c1 - r, 0), y1 = min(c1 + r, g.dim[1] - 1);
+  for (int z = z0; z <= z1; z++) {
+    const int az = abs(z - c2);
+    for (int y = y0; y <= y1; y++) {
+      const bool face = (az == r) || (abs(y - c1) == r);
+      const int xstep = face ? 1 : max(2 * r, 1);
+      for (int x = c0 - r; x <= c0 + r; x += xstep) {
+        if (x < 0 || x >= g.dim[0]) continue;
+        f(cell_index(g, x, y, z));
+      }
+    }
+  }
+}
+
+// distance from the query to the faces of the cube of cells [c-r, c+r] that are not grid borders; 1e300 if none
+__device__ __forceinline__ double cube_bound(const Grid& g, const int c[3], const double q[3], int r) {
+  double bound = 1.0e300;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (c[a] - r > 0) bound = fmin(bound, q[a] - ((double)(c[a] - r + g.minc[a]) + 0.5) * g.res);
+    if (c[a] + r < g.dim[a] - 1) bound = fmin(bound, ((double)(c[a] + r + g.minc[a]) + 1.5) * g.res - q[a]);
+  }
+  return bound;
+}
+
+// KC = chain capacity (compile time, >= k).  kTarget only separates the two instantiations by NAME (map cloud
+// vs scan cloud) so that profiles report the dominant launch (the map) on its own line.
+template <int KC, bool kTarget>
 __global__ void __launch_bounds__(KNN_T)
-k_knn_cov(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
-          const int* __restrict__ start, const int* __restrict__ order, Grid g, int n, int k, double* __restrict__ nx,
+k_knn_cov(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, double* __restrict__ nx,
           double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ float smem[];
-  float* sd = smem;                       // [k][KNN_T]
-  int* si = (int*)(smem + k * KNN_T);     // [k][KNN_T]
+  extern __shared__ int slist[];  // [k][KNN_T] sorted-array positions of the selected neighbours
   const int tid = threadIdx.x;
   const int i = blockIdx.x * KNN_T + tid;
   if (i >= n) return;
-  const float px = xs[i], py = ys[i], pz = zs[i];
-  const int c0 = voxel_coord1(px, g.res) - g.minc[0];
-  const int c1 = voxel_coord1(py, g.res) - g.minc[1];
-  const int c2 = voxel_coord1(pz, g.res) - g.minc[2];
-  int rmax = max(max(max(c0, g.dim[0] - 1 - c0), max(c1, g.dim[1] - 1 - c1)), max(c2, g.dim[2] - 1 - c2));
+  const float4 pq = P[i];
+  const float px = pq.x, py = pq.y, pz = pq.z;
+  const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
+  const double q[3] = {(double)px, (double)py, (double)pz};
+  const int rmax = max(max(max(c[0], g.dim[0] - 1 - c[0]), max(c[1], g.dim[1] - 1 - c[1])), max(c[2], g.dim[2] - 1 - c[2]));
 
-  int cnt = 0, wslot = 0;
-  float worst = 0.f;
+  // ---- pass 1: K-th smallest squared distance ----
+  float a[KC];
+#pragma unroll
+  for (int j = 0; j < KC; j++) a[j] = INFINITY;
+  float thr = INFINITY;  // a[k-1]
+  int rfin = 0;
   for (int r = 0;; r++) {
-    const int z0 = max(c2 - r, 0), z1 = min(c2 + r, g.dim[2] - 1);
-    const int y0 = max(c1 - r, 0), y1 = min(c1 + r, g.dim[1] - 1);
-    for (int z = z0; z <= z1; z++) {
-      const int az = abs(z - c2);
-      for (int y = y0; y <= y1; y++) {
-        const bool face = (az == r) || (abs(y - c1) == r);
-        const int xstep = face ? 1 : max(2 * r, 1);
-        for (int x = c0 - r; x <= c0 + r; x += xstep) {
-          if (x < 0 || x >= g.dim[0]) continue;
-          const int cid = cell_index(g, x, y, z);
-          const int s0 = start[cid], s1 = start[cid + 1];
-          for (int s = s0; s < s1; s++) {
-            const float dx = px - xs[s], dy = py - ys[s], dz = pz - zs[s];
-            const float d2 = (dx * dx + dy * dy) + dz * dz;  // L2_Simple<float>; no contraction (-ffp-contract=off)
-            if (cnt < k) {
-              sd[cnt * KNN_T + tid] = d2;
-              si[cnt * KNN_T + tid] = s;
-              cnt++;
-              if (cnt < k) continue;
-            } else {
-              bool better = d2 < worst;
-              if (!better && d2 == worst) better = order[s] < order[si[wslot * KNN_T + tid]];
-              if (!better) continue;
-              sd[wslot * KNN_T + tid] = d2;
-              si[wslot * KNN_T + tid] = s;
-            }
-            // list is full: locate the worst kept neighbour (largest (d2, original index))
-            worst = sd[tid];
-            wslot = 0;
-            for (int j = 1; j < k; j++) {
-              const float dj = sd[j * KNN_T + tid];
-              if (dj > worst || (dj == worst && order[si[j * KNN_T + tid]] > order[si[wslot * KNN_T + tid]])) {
-                worst = dj;
-                wslot = j;
-              }
-            }
+    for_each_shell_cell(g, c[0], c[1], c[2], r, [&](int cid) {
+      const int s0 = start[cid], s1 = start[cid + 1];
+      for (int s = s0; s < s1; s++) {
+        const float4 cp = P[s];
+        const float dx = px - cp.x, dy = py - cp.y, dz = pz - cp.z;
+        float x = (dx * dx + dy * dy) + dz * dz;  // L2_Simple<float>; no contraction (-ffp-contract=off)
+        if (__any(x < a[KC - 1])) {
+#pragma unroll
+          for (int j = 0; j < KC; j++) {
+            const float lo = fminf(a[j], x);
+            x = fmaxf(a[j], x);
+            a[j] = lo;
           }
         }
       }
-    }
+    });
+    rfin = r;
     if (r >= rmax) break;  // whole grid scanned
-    if (cnt == k) {
-      // every unscanned point lies outside the cube of cells [c-r, c+r]: its distance is at least the distance
-      // from the query to the cube faces that are not grid borders
-      double bound = 1.0e300;
-      const double q[3] = {(double)px, (double)py, (double)pz};
-      const int c[3] = {c0, c1, c2};
+    thr = a[KC - 1];
 #pragma unroll
-      for (int a = 0; a < 3; a++) {
-        if (c[a] - r > 0) bound = fmin(bound, q[a] - ((double)(c[a] - r + g.minc[a]) + 0.5) * g.res);
-        if (c[a] + r < g.dim[a] - 1) bound = fmin(bound, ((double)(c[a] + r + g.minc[a]) + 1.5) * g.res - q[a]);
-      }
+    for (int j = 0; j < KC - 1; j++) thr = (j == k - 1) ? a[j] : thr;
+    if (thr < INFINITY) {
+      const double bound = cube_bound(g, c, q, r);
       if (bound == 1.0e300) break;
-      if (bound > 0.0 && (double)worst < bound * bound * (1.0 - 1e-5)) break;
+      if (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5)) break;
     }
   }
+  thr = a[KC - 1];
+#pragma unroll
+  for (int j = 0; j < KC - 1; j++) thr = (j == k - 1) ? a[j] : thr;
 
-  // neighbourhood mean and covariance in fp64 (fast_gicp_impl.hpp:256-262)
+  // ---- pass 2: collect the neighbours ----
+  int m = 0;            // strictly closer than thr (at most k-1 of them)
+  int ties = 0;         // candidates exactly at thr
+  int tie_s = -1, tie_o = INT_MAX;  // tie with the smallest original index
+  for (int r = 0; r <= rfin; r++) {
+    for_each_shell_cell(g, c[0], c[1], c[2], r, [&](int cid) {
+      const int s0 = start[cid], s1 = start[cid + 1];
+      for (int s = s0; s < s1; s++) {
+        const float4 cp = P[s];
+        const float dx = px - cp.x, dy = py - cp.y, dz = pz - cp.z;
+        const float x = (dx * dx + dy * dy) + dz * dz;
+        if (x < thr) {
+          if (m < k) slist[m * KNN_T + tid] = s;
+          m++;
+        } else if (x == thr) {
+          ties++;
+          const int o = __float_as_int(cp.w);
+          if (o < tie_o) { tie_o = o; tie_s = s; }
+        }
+      }
+    });
+  }
+  // ties on the K-th distance enter in ascending original index (the CPU path's (d2, index) order)
+  if (m < k && tie_s >= 0) { slist[m * KNN_T + tid] = tie_s; m++; }
+  while (m < k && ties > 1) {  // rare: several candidates exactly at thr are needed -> one rescan per extra tie
+    const int last_o = tie_o;
+    tie_o = INT_MAX;
+    tie_s = -1;
+    for (int r = 0; r <= rfin; r++) {
+      for_each_shell_cell(g, c[0], c[1], c[2], r, [&](int cid) {
+        const int s0 = start[cid], s1 = start[cid + 1];
+        for (int s = s0; s < s1; s++) {
+          const float4 cp = P[s];
+          const float dx = px - cp.x, dy = py - cp.y, dz = pz - cp.z;
+          const float x = (dx * dx + dy * dy) + dz * dz;
+          const int o = __float_as_int(cp.w);
+          if (x == thr && o > last_o && o < tie_o) { tie_o = o; tie_s = s; }
+        }
+      });
+    }
+    if (tie_s < 0) break;
+    slist[m * KNN_T + tid] = tie_s;
+    m++;
+  }
+
+  // ---- neighbourhood mean and covariance in fp64 (fast_gicp_impl.hpp:256-262) ----
   double mx = 0, my = 0, mz = 0;
   for (int j = 0; j < k; j++) {
-    const int s = si[j * KNN_T + tid];
-    mx += (double)xs[s];
-    my += (double)ys[s];
-    mz += (double)zs[s];
+    const float4 cp = P[slist[j * KNN_T + tid]];
+    mx += (double)cp.x;
+    my += (double)cp.y;
+    mz += (double)cp.z;
   }
   const double inv_k = 1.0 / (double)k;
   mx *= inv_k; my *= inv_k; mz *= inv_k;
   double S[6] = {0, 0, 0, 0, 0, 0};
   for (int j = 0; j < k; j++) {
-    const int s = si[j * KNN_T + tid];
-    const double dx = (double)xs[s] - mx, dy = (double)ys[s] - my, dz = (double)zs[s] - mz;
+    const float4 cp = P[slist[j * KNN_T + tid]];
+    const double dx = (double)cp.x - mx, dy = (double)cp.y - my, dz = (double)cp.z - mz;
     S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz;
     S[3] += dy * dy; S[4] += dy * dz; S[5] += dz * dz;
   }
 #pragma unroll
-  for (int a = 0; a < 6; a++) S[a] *= inv_k;
+  for (int e = 0; e < 6; e++) S[e] *= inv_k;
   double nrm[3];
   min_eigenvector(S, nrm);
   nx[i] = nrm[0];
@@ -342,7 +401,7 @@ k_knn_cov(const float* __restrict__ xs, const float* __restrict__ ys, const floa
 // original index, so the fp64 sums run in the reference's cloud order (fast_vgicp_voxel.hpp:112-121,129-156).
 // record = { mean xyz, cov00 01 02 11 12 22, num }  (10 doubles).  C_i = I - 0.999 n_i n_i^T.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_voxel_build(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+__global__ void k_voxel_build(const float4* __restrict__ P,
                               const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
                               const int* __restrict__ start, Grid g, int* __restrict__ cell_voxel, double* __restrict__ vox,
                               int* __restrict__ vox_cell, int* nvox) {
@@ -352,9 +411,10 @@ __global__ void k_voxel_build(const float* __restrict__ xs, const float* __restr
   if (s0 == s1) { cell_voxel[c] = -1; return; }
   double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
   for (int s = s0; s < s1; s++) {
-    m[0] += (double)xs[s];
-    m[1] += (double)ys[s];
-    m[2] += (double)zs[s];
+    const float4 cp = P[s];
+    m[0] += (double)cp.x;
+    m[1] += (double)cp.y;
+    m[2] += (double)cp.z;
     const double a = nx[s], b = ny[s], d = nz[s];
     C[0] += 1.0 - 0.999 * a * a; C[1] += -0.999 * a * b; C[2] += -0.999 * a * d;
     C[3] += 1.0 - 0.999 * b * b; C[4] += -0.999 * b * d; C[5] += 1.0 - 0.999 * d * d;
@@ -421,7 +481,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 }
 
 __global__ void __launch_bounds__(LIN_T)
-k_linearize(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+k_linearize(const float4* __restrict__ P,
             const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Pose T, Grid g,
             const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v,
             double* __restrict__ corr_M, int want_H, double* __restrict__ partials, int* __restrict__ ncorr_partials) {
@@ -431,7 +491,8 @@ k_linearize(const float* __restrict__ xs, const float* __restrict__ ys, const fl
   for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
   int ncorr = 0;
   if (i < n) {
-    const double p0 = (double)xs[i], p1 = (double)ys[i], p2 = (double)zs[i];
+    const float4 pp = P[i];
+    const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
     const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
     const double q1 = T.R[3] * p0 + T.R[4] * p1 + T.R[5] * p2 + T.t[1];
     const double q2 = T.R[6] * p0 + T.R[7] * p1 + T.R[8] * p2 + T.t[2];
@@ -509,47 +570,36 @@ k_linearize(const float* __restrict__ xs, const float* __restrict__ ys, const fl
   }
 }
 
-// fold per-block rows in a fixed order: thread t sums rows t, t+256, ... then a fixed LDS tree
+// fold per-block rows in a fixed order: block a (one wave) owns accumulator a; lane l sums rows l, l+64, ...
+// then a fixed shuffle tree (deterministic for a given row count).  Block NACC folds the integer counts.
 template <int NACC>
-__global__ void __launch_bounds__(256) k_fold(const double* __restrict__ partials, int nrows, double* __restrict__ out,
-                                              const int* __restrict__ ipartials, int* __restrict__ iout) {
-  __shared__ double sh[256];
-  __shared__ int shi[256];
-  const int t = threadIdx.x;
-  for (int a = 0; a < NACC; a++) {
+__global__ void __launch_bounds__(WAVE) k_fold(const double* __restrict__ partials, int nrows, double* __restrict__ out,
+                                                const int* __restrict__ ipartials, int* __restrict__ iout) {
+  const int a = blockIdx.x, lane = threadIdx.x;
+  if (a < NACC) {
     double s = 0;
-    for (int r = t; r < nrows; r += 256) s += partials[(size_t)r * NACC + a];
-    sh[t] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (t < o) sh[t] += sh[t + o];
-      __syncthreads();
-    }
-    if (t == 0) out[a] = sh[0];
-    __syncthreads();
-  }
-  if (ipartials) {
-    int s = 0;
-    for (int r = t; r < nrows; r += 256) s += ipartials[r];
-    shi[t] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (t < o) shi[t] += shi[t + o];
-      __syncthreads();
-    }
-    if (t == 0) *iout = shi[0];
+    for (int r = lane; r < nrows; r += WAVE) s += partials[(size_t)r * NACC + a];
+    s = wave_sum(s);
+    if (lane == 0) out[a] = s;
+  } else if (ipartials) {
+    int c = 0;
+    for (int r = lane; r < nrows; r += WAVE) c += ipartials[r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if (lane == 0) *iout = c;
   }
 }
 
 // C6  fast_vgicp_impl.hpp:183-204: frozen correspondences and Mahalanobis
 __global__ void __launch_bounds__(LIN_T)
-k_error(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs, int n, Pose T,
+k_error(const float4* __restrict__ P, int n, Pose T,
         const double* __restrict__ vox, int noff, const int* __restrict__ corr_v, const double* __restrict__ corr_M,
         double* __restrict__ partials) {
   const int i = blockIdx.x * LIN_T + threadIdx.x;
   double acc[1] = {0.0};
   if (i < n) {
-    const double p0 = (double)xs[i], p1 = (double)ys[i], p2 = (double)zs[i];
+    const float4 pp = P[i];
+    const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
     const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
     const double q1 = T.R[3] * p0 + T.R[4] * p1 + T.R[5] * p2 + T.t[1];
     const double q2 = T.R[6] * p0 + T.R[7] * p1 + T.R[8] * p2 + T.t[2];
@@ -574,13 +624,13 @@ k_error(const float* __restrict__ xs, const float* __restrict__ ys, const float*
 // in fp64.  One lane per source point.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(LIN_T)
-k_fitness(const float* __restrict__ sxs, const float* __restrict__ sys, const float* __restrict__ szs, int ns, PoseF T,
-          const float* __restrict__ txs, const float* __restrict__ tys, const float* __restrict__ tzs,
+k_fitness(const float4* __restrict__ SP, int ns, PoseF T, const float4* __restrict__ TP,
           const int* __restrict__ tstart, Grid g, double* __restrict__ partials) {
   const int i = blockIdx.x * LIN_T + threadIdx.x;
   double acc[1] = {0.0};
   if (i < ns) {
-    const float x = sxs[i], y = sys[i], z = szs[i];
+    const float4 sp = SP[i];
+    const float x = sp.x, y = sp.y, z = sp.z;
     const float px = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
     const float py = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
     const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
@@ -606,7 +656,8 @@ k_fitness(const float* __restrict__ sxs, const float* __restrict__ sys, const fl
             if (xx < 0 || xx >= g.dim[0]) continue;
             const int cid = cell_index(g, xx, yy, zz);
             for (int s = tstart[cid]; s < tstart[cid + 1]; s++) {
-              const float dx = px - txs[s], dy = py - tys[s], dz = pz - tzs[s];
+              const float4 cp = TP[s];
+              const float dx = px - cp.x, dy = py - cp.y, dz = pz - cp.z;
               const float d2 = (dx * dx + dy * dy) + dz * dz;
               if (d2 < best) { best = d2; have = true; }
             }
@@ -642,10 +693,10 @@ __global__ void k_transform_f32(const float* __restrict__ in, int stride_f, int 
 }
 
 __global__ void k_unsort3(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c,
-                          const int* __restrict__ order, int n, double* __restrict__ out3) {
+                          const float4* __restrict__ P, int n, double* __restrict__ out3) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  const int i = order[s];
+  const int i = __float_as_int(P[s].w);
   out3[(size_t)i * 3 + 0] = a[s];
   out3[(size_t)i * 3 + 1] = b[s];
   out3[(size_t)i * 3 + 2] = c[s];
@@ -657,7 +708,7 @@ __global__ void k_unsort3(const double* __restrict__ a, const double* __restrict
 static inline int nblk(long long n, int t) { return (int)((n + t - 1) / t); }
 
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags) {
-  hipLaunchKernelGGL(k_bbox, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags);
+  hipLaunchKernelGGL(k_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags);
 }
 void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt) {
   hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, cnt);
@@ -674,45 +725,48 @@ void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cn
   hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, start, cnt, order_tmp);
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const int* order_tmp, int* order, float* xs, float* ys, float* zs) {
-  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, order, xs, ys, zs);
+                 const int* order_tmp, float4* P) {
+  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P);
 }
-void knn_cov(hipStream_t s, bool is_target, const float* xs, const float* ys, const float* zs, const int* start,
-             const int* order, Grid g, int n, int k, double* nx, double* ny, double* nz) {
-  const size_t lds = (size_t)k * KNN_T * (sizeof(float) + sizeof(int));
+template <int KC>
+static void knn_cov_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, double* nx, double* ny, double* nz) {
+  const size_t lds = (size_t)k * KNN_T * sizeof(int);
   if (is_target)
-    hipLaunchKernelGGL(k_knn_cov<true>, dim3(nblk(n, KNN_T)), dim3(KNN_T), lds, s, xs, ys, zs, start, order, g, n, k, nx, ny, nz);
+    hipLaunchKernelGGL((k_knn_cov<KC, true>), dim3(nblk(n, KNN_T)), dim3(KNN_T), lds, s, P, start, g, n, k, nx, ny, nz);
   else
-    hipLaunchKernelGGL(k_knn_cov<false>, dim3(nblk(n, KNN_T)), dim3(KNN_T), lds, s, xs, ys, zs, start, order, g, n, k, nx, ny, nz);
+    hipLaunchKernelGGL((k_knn_cov<KC, false>), dim3(nblk(n, KNN_T)), dim3(KNN_T), lds, s, P, start, g, n, k, nx, ny, nz);
 }
-void voxel_build(hipStream_t s, const float* xs, const float* ys, const float* zs, const double* nx, const double* ny,
-                 const double* nz, const int* start, Grid g, int* cell_voxel, double* vox, int* vox_cell, int* nvox) {
-  hipLaunchKernelGGL(k_voxel_build, dim3(nblk(g.ncell, 256)), dim3(256), 0, s, xs, ys, zs, nx, ny, nz, start, g, cell_voxel, vox, vox_cell, nvox);
+void knn_cov(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, double* nx, double* ny, double* nz) {
+  if (k <= 20) knn_cov_kc<20>(s, is_target, P, start, g, n, k, nx, ny, nz);
+  else knn_cov_kc<32>(s, is_target, P, start, g, n, k, nx, ny, nz);
 }
-void linearize(hipStream_t s, const float* xs, const float* ys, const float* zs, const double* nx, const double* ny,
-               const double* nz, int n, Pose T, Grid g, const int* cell_voxel, const double* vox, int noff, int* corr_v,
-               double* corr_M, int want_H, double* partials, int* ncorr_partials, double* out28, int* out_ncorr) {
+void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
+                 int* cell_voxel, double* vox, int* vox_cell, int* nvox) {
+  hipLaunchKernelGGL(k_voxel_build, dim3(nblk(g.ncell, 256)), dim3(256), 0, s, P, nx, ny, nz, start, g, cell_voxel, vox, vox_cell, nvox);
+}
+void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
+               const int* cell_voxel, const double* vox, int noff, int* corr_v, double* corr_M, int want_H, double* partials,
+               int* ncorr_partials, double* out28, int* out_ncorr) {
   const int nb = linearize_blocks(n);
-  hipLaunchKernelGGL(k_linearize, dim3(nb), dim3(LIN_T), 0, s, xs, ys, zs, nx, ny, nz, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, want_H, partials, ncorr_partials);
-  hipLaunchKernelGGL(k_fold<kAccum>, dim3(1), dim3(256), 0, s, partials, nb, out28, ncorr_partials, out_ncorr);
+  hipLaunchKernelGGL(k_linearize, dim3(nb), dim3(LIN_T), 0, s, P, nx, ny, nz, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, want_H, partials, ncorr_partials);
+  hipLaunchKernelGGL(k_fold<kAccum>, dim3(kAccum + 1), dim3(WAVE), 0, s, partials, nb, out28, ncorr_partials, out_ncorr);
 }
-void compute_error(hipStream_t s, const float* xs, const float* ys, const float* zs, int n, Pose T, const double* vox, int noff,
-                   const int* corr_v, const double* corr_M, double* partials, double* out1) {
+void compute_error(hipStream_t s, const float4* P, int n, Pose T, const double* vox, int noff, const int* corr_v,
+                   const double* corr_M, double* partials, double* out1) {
   const int nb = linearize_blocks(n);
-  hipLaunchKernelGGL(k_error, dim3(nb), dim3(LIN_T), 0, s, xs, ys, zs, n, T, vox, noff, corr_v, corr_M, partials);
-  hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(256), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(k_error, dim3(nb), dim3(LIN_T), 0, s, P, n, T, vox, noff, corr_v, corr_M, partials);
+  hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
 }
-void fitness(hipStream_t s, const float* sxs, const float* sys, const float* szs, int ns, PoseF T, const float* txs,
-             const float* tys, const float* tzs, const int* tstart, Grid g, double* partials, double* out1) {
+void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials, double* out1) {
   const int nb = linearize_blocks(ns);
-  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(LIN_T), 0, s, sxs, sys, szs, ns, T, txs, tys, tzs, tstart, g, partials);
-  hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(256), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(LIN_T), 0, s, SP, ns, T, TP, tstart, g, partials);
+  hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
 }
 void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f) {
   hipLaunchKernelGGL(k_transform_f32, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, out, out_stride_f);
 }
-void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const int* order, int n, double* out3) {
-  hipLaunchKernelGGL(k_unsort3, dim3(nblk(n, 256)), dim3(256), 0, s, a, b, c, order, n, out3);
+void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const float4* P, int n, double* out3) {
+  hipLaunchKernelGGL(k_unsort3, dim3(nblk(n, 256)), dim3(256), 0, s, a, b, c, P, n, out3);
 }
 
 }  // namespace rgck
