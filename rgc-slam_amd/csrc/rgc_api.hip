@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -34,6 +35,7 @@ struct Cloud {
   int n = 0;
   bool ready = false;  // grid + normals (+ voxels for the target) enqueued
   DevBuf in_copy, cell_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
+  DevBuf segs, nseg;  // row segments of the tiled kNN kernel
   rgck::Grid grid{};
   // target only
   DevBuf cell_voxel, vox, vox_cell;
@@ -113,7 +115,7 @@ void release(DevBuf& b) {
 }
 
 void release_cloud(Cloud& cl) {
-  for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz,
+  for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs, &cl.nseg,
                     &cl.cell_voxel, &cl.vox, &cl.vox_cell})
     release(*b);
 }
@@ -202,6 +204,8 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nc1 / 2048 + 2)))) return rc;
     if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.P, sizeof(float4) * n))) return rc;
+    if ((rc = ensure(c, cl.segs, rgck::segment_bytes(n)))) return rc;
+    if ((rc = ensure(c, cl.nseg, 64))) return rc;
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
@@ -211,11 +215,15 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
                       (float4*)cl.P.p);
+    if (rgck::knn_impl() == 1) {
+      HIPCHK(c, hipMemsetAsync(cl.nseg.p, 0, sizeof(int), s));
+      rgck::segments(s, (const int*)cl.start.p, cl.grid, cl.segs.p, (int*)cl.nseg.p);
+    }
   }
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n);
-    rgck::knn_cov(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, (double*)cl.nx.p, (double*)cl.ny.p,
-                  (double*)cl.nz.p);
+    rgck::knn_cov(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (const int*)cl.nseg.p,
+                  (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
   }
   if (is_target) {
     int rc;
@@ -486,6 +494,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   rgc_ctx* c = new (std::nothrow) rgc_ctx();
   if (!c) return RGC_ERR_HIP;
   c->device = hip_device;
+  if (const char* e = getenv("RGC_KNN_IMPL")) rgck::set_knn_impl(strcmp(e, "tile") == 0 ? 1 : 0);
   rgc_default_params(&c->prm);
   if (params) {
     int rc = check_params(c, params);

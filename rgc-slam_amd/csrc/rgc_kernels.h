@@ -34,8 +34,13 @@ void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cn
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
                  const int* order_tmp, float4* P);
 // ---- C2: exact kNN + PLANE covariance -> unit normal ----
-void knn_cov(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, double* nx, double* ny,
-             double* nz);
+// row segments (work items of the tiled kNN kernel): segs needs segment_bytes(n) bytes, *nseg must be 0 on entry
+void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg);
+size_t segment_bytes(int n);
+void set_knn_impl(int impl);  // 0 = rows (default), 1 = LDS tile
+int knn_impl();
+void knn_cov(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
+             const int* nseg, double* nx, double* ny, double* nz);
 // ---- C3: Gaussian voxel map ----
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int* cell_voxel, double* vox, int* vox_cell, int* nvox);

@@ -237,12 +237,6 @@ __device__ __forceinline__ void min_eigenvector(const double S[6], double n[3]) 
 //          LDS column ([slot][lane], bank = lane), ties on the K-th distance are resolved by original index
 //          like the CPU path, then mean / covariance / smallest eigenvector in fp64.
 // ------------------------------------------------------------------------------------------------
-constexpr int KNN_T = 256;
-
-struct ShellIter {  // cells at Chebyshev distance exactly r from (c0,c1,c2), clipped to the grid
-  int r, z, y, x, z1, y0, y1, c0, c1, c2;
-};
-
 template <typename F>
 __device__ __forceinline__ void for_each_shell_cell(const Grid& g, int c0, int c1, int c2, int r, F&& f) {
   const int z0 = max(c2 - r, 0), z1 = min(c2 + r, g.dim[2] - 1);
@@ -271,109 +265,43 @@ __device__ __forceinline__ double cube_bound(const Grid& g, const int c[3], cons
   return bound;
 }
 
-// KC = chain capacity (compile time, >= k).  kTarget only separates the two instantiations by NAME (map cloud
-// vs scan cloud) so that profiles report the dominant launch (the map) on its own line.
-template <int KC, bool kTarget>
-__global__ void __launch_bounds__(KNN_T)
-k_knn_cov(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, double* __restrict__ nx,
-          double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ int slist[];  // [k][KNN_T] sorted-array positions of the selected neighbours
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * KNN_T + tid;
-  if (i >= n) return;
-  const float4 pq = P[i];
-  const float px = pq.x, py = pq.y, pz = pq.z;
-  const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
-  const double q[3] = {(double)px, (double)py, (double)pz};
-  const int rmax = max(max(max(c[0], g.dim[0] - 1 - c[0]), max(c[1], g.dim[1] - 1 - c[1])), max(c[2], g.dim[2] - 1 - c[2]));
-
-  // ---- pass 1: K-th smallest squared distance ----
+// ---- shared pieces of the exact search ----------------------------------------------------------------------
+template <int KC>
+struct TopK {  // the KC smallest squared distances, ascending, in registers (static indexing only)
   float a[KC];
+  __device__ __forceinline__ void init() {
 #pragma unroll
-  for (int j = 0; j < KC; j++) a[j] = INFINITY;
-  float thr = INFINITY;  // a[k-1]
-  int rfin = 0;
-  for (int r = 0;; r++) {
-    for_each_shell_cell(g, c[0], c[1], c[2], r, [&](int cid) {
-      const int s0 = start[cid], s1 = start[cid + 1];
-      for (int s = s0; s < s1; s++) {
-        const float4 cp = P[s];
-        const float dx = px - cp.x, dy = py - cp.y, dz = pz - cp.z;
-        float x = (dx * dx + dy * dy) + dz * dz;  // L2_Simple<float>; no contraction (-ffp-contract=off)
-        if (__any(x < a[KC - 1])) {
+    for (int j = 0; j < KC; j++) a[j] = INFINITY;
+  }
+  __device__ __forceinline__ void insert(float x) {
 #pragma unroll
-          for (int j = 0; j < KC; j++) {
-            const float lo = fminf(a[j], x);
-            x = fmaxf(a[j], x);
-            a[j] = lo;
-          }
-        }
-      }
-    });
-    rfin = r;
-    if (r >= rmax) break;  // whole grid scanned
-    thr = a[KC - 1];
-#pragma unroll
-    for (int j = 0; j < KC - 1; j++) thr = (j == k - 1) ? a[j] : thr;
-    if (thr < INFINITY) {
-      const double bound = cube_bound(g, c, q, r);
-      if (bound == 1.0e300) break;
-      if (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5)) break;
+    for (int j = 0; j < KC; j++) {
+      const float lo = fminf(a[j], x);
+      x = fmaxf(a[j], x);
+      a[j] = lo;
     }
   }
-  thr = a[KC - 1];
+  // a[k-1] without dynamic register indexing (a select chain is turned back into an indexed scratch access by
+  // the compiler): the chain is ascending, so a[k-1] is the maximum of the first k entries
+  __device__ __forceinline__ float kth(int k) const {
+    if (k == KC) return a[KC - 1];
+    float t = a[0];
 #pragma unroll
-  for (int j = 0; j < KC - 1; j++) thr = (j == k - 1) ? a[j] : thr;
-
-  // ---- pass 2: collect the neighbours ----
-  int m = 0;            // strictly closer than thr (at most k-1 of them)
-  int ties = 0;         // candidates exactly at thr
-  int tie_s = -1, tie_o = INT_MAX;  // tie with the smallest original index
-  for (int r = 0; r <= rfin; r++) {
-    for_each_shell_cell(g, c[0], c[1], c[2], r, [&](int cid) {
-      const int s0 = start[cid], s1 = start[cid + 1];
-      for (int s = s0; s < s1; s++) {
-        const float4 cp = P[s];
-        const float dx = px - cp.x, dy = py - cp.y, dz = pz - cp.z;
-        const float x = (dx * dx + dy * dy) + dz * dz;
-        if (x < thr) {
-          if (m < k) slist[m * KNN_T + tid] = s;
-          m++;
-        } else if (x == thr) {
-          ties++;
-          const int o = __float_as_int(cp.w);
-          if (o < tie_o) { tie_o = o; tie_s = s; }
-        }
-      }
-    });
+    for (int j = 1; j < KC; j++) t = (j < k) ? fmaxf(t, a[j]) : t;
+    return t;
   }
-  // ties on the K-th distance enter in ascending original index (the CPU path's (d2, index) order)
-  if (m < k && tie_s >= 0) { slist[m * KNN_T + tid] = tie_s; m++; }
-  while (m < k && ties > 1) {  // rare: several candidates exactly at thr are needed -> one rescan per extra tie
-    const int last_o = tie_o;
-    tie_o = INT_MAX;
-    tie_s = -1;
-    for (int r = 0; r <= rfin; r++) {
-      for_each_shell_cell(g, c[0], c[1], c[2], r, [&](int cid) {
-        const int s0 = start[cid], s1 = start[cid + 1];
-        for (int s = s0; s < s1; s++) {
-          const float4 cp = P[s];
-          const float dx = px - cp.x, dy = py - cp.y, dz = pz - cp.z;
-          const float x = (dx * dx + dy * dy) + dz * dz;
-          const int o = __float_as_int(cp.w);
-          if (x == thr && o > last_o && o < tie_o) { tie_o = o; tie_s = s; }
-        }
-      });
-    }
-    if (tie_s < 0) break;
-    slist[m * KNN_T + tid] = tie_s;
-    m++;
-  }
+};
 
-  // ---- neighbourhood mean and covariance in fp64 (fast_gicp_impl.hpp:256-262) ----
+__device__ __forceinline__ float dist2(float px, float py, float pz, const float4& c) {
+  const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
+  return (dx * dx + dy * dy) + dz * dz;  // flann::L2_Simple<float>; never contracted (-ffp-contract=off)
+}
+
+// neighbourhood mean / covariance in fp64 (fast_gicp_impl.hpp:256-262) and the PLANE normal
+__device__ __forceinline__ void normal_from_list(const float4* __restrict__ P, const int* list, int lstride, int k, double nrm[3]) {
   double mx = 0, my = 0, mz = 0;
   for (int j = 0; j < k; j++) {
-    const float4 cp = P[slist[j * KNN_T + tid]];
+    const float4 cp = P[list[j * lstride]];
     mx += (double)cp.x;
     my += (double)cp.y;
     mz += (double)cp.z;
@@ -382,15 +310,395 @@ k_knn_cov(const float4* __restrict__ P, const int* __restrict__ start, Grid g, i
   mx *= inv_k; my *= inv_k; mz *= inv_k;
   double S[6] = {0, 0, 0, 0, 0, 0};
   for (int j = 0; j < k; j++) {
-    const float4 cp = P[slist[j * KNN_T + tid]];
+    const float4 cp = P[list[j * lstride]];
     const double dx = (double)cp.x - mx, dy = (double)cp.y - my, dz = (double)cp.z - mz;
     S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz;
     S[3] += dy * dy; S[4] += dy * dz; S[5] += dz * dz;
   }
 #pragma unroll
   for (int e = 0; e < 6; e++) S[e] *= inv_k;
-  double nrm[3];
   min_eigenvector(S, nrm);
+}
+
+// ---- generic exact search by ROWS ---------------------------------------------------------------------------
+// Cells of one (y,z) grid row are consecutive in the sorted array, so the candidates of the cube of cells
+// [c-r, c+r]^3 are (2r+1)^2 CONTIGUOUS ranges: two start[] loads per row instead of two per cell, and no walk
+// through empty cells.  If the k-th distance found in cube(r) is not provably exact the search JUMPS to the
+// smallest cube that can prove it (restarting the chain), instead of growing shell by shell.
+template <typename F>
+__device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3], int r, const int* __restrict__ start, F&& f) {
+  const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
+  const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
+  const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
+  if (x0 > x1) return;
+  for (int z = z0; z <= z1; z++) {
+    int y = y0;
+    for (; y + 1 <= y1; y += 2) {  // two rows per step: four independent loads in flight
+      const int a0 = start[cell_index(g, x0, y, z)], b0 = start[cell_index(g, x1, y, z) + 1];
+      const int a1 = start[cell_index(g, x0, y + 1, z)], b1 = start[cell_index(g, x1, y + 1, z) + 1];
+      f(a0, b0);
+      f(a1, b1);
+    }
+    if (y <= y1) f(start[cell_index(g, x0, y, z)], start[cell_index(g, x1, y, z) + 1]);
+  }
+}
+
+template <int KC>
+__device__ __forceinline__ void scan_range_topk(const float4* __restrict__ P, int s0, int s1, float px, float py, float pz, TopK<KC>& top) {
+  for (int s = s0; s < s1; s += 4) {
+    const int e = s1 - 1;
+    const float4 c0 = P[s], c1 = P[min(s + 1, e)], c2 = P[min(s + 2, e)], c3 = P[min(s + 3, e)];
+    const float x0 = dist2(px, py, pz, c0);
+    const float x1 = (s + 1 < s1) ? dist2(px, py, pz, c1) : INFINITY;
+    const float x2 = (s + 2 < s1) ? dist2(px, py, pz, c2) : INFINITY;
+    const float x3 = (s + 3 < s1) ? dist2(px, py, pz, c3) : INFINITY;
+    if (__any(x0 < top.a[KC - 1])) top.insert(x0);
+    if (__any(x1 < top.a[KC - 1])) top.insert(x1);
+    if (__any(x2 < top.a[KC - 1])) top.insert(x2);
+    if (__any(x3 < top.a[KC - 1])) top.insert(x3);
+  }
+}
+
+// append neighbours strictly closer than thr; remember the candidate AT thr with the smallest original index
+__device__ __forceinline__ void collect_one(const float4& cp, int s, bool valid, float px, float py, float pz, float thr, int k, int* list,
+                                            int lstride, int& m, int& tie_s, int& tie_o) {
+  const float x = valid ? dist2(px, py, pz, cp) : INFINITY;
+  if (x < thr) {
+    if (m < k) list[m * lstride] = s;
+    m++;
+  } else if (x == thr) {
+    const int o = __float_as_int(cp.w);
+    if (o < tie_o) { tie_o = o; tie_s = s; }
+  }
+}
+__device__ __forceinline__ void scan_range_collect(const float4* __restrict__ P, int s0, int s1, float px, float py, float pz, float thr,
+                                                   int k, int* list, int lstride, int& m, int& tie_s, int& tie_o) {
+  for (int s = s0; s < s1; s += 4) {
+    const int e = s1 - 1;
+    const float4 c0 = P[s], c1 = P[min(s + 1, e)], c2 = P[min(s + 2, e)], c3 = P[min(s + 3, e)];
+    collect_one(c0, s, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+    collect_one(c1, s + 1, s + 1 < s1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+    collect_one(c2, s + 2, s + 2 < s1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+    collect_one(c3, s + 3, s + 3 < s1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+  }
+}
+
+// thr_hint: k-th distance already known from a smaller cube (INFINITY if fewer than k candidates were seen)
+template <int KC>
+__device__ __forceinline__ void generic_search_rows(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, float px,
+                                                    float py, float pz, const int c[3], int k, int r_done, float thr_hint, int* list,
+                                                    int lstride) {
+  const double q[3] = {(double)px, (double)py, (double)pz};
+  const int rmax = max(max(max(c[0], g.dim[0] - 1 - c[0]), max(c[1], g.dim[1] - 1 - c[1])), max(c[2], g.dim[2] - 1 - c[2]));
+  TopK<KC> top;
+  int r = r_done;
+  float thr = thr_hint;
+  for (;;) {
+    // next cube: the smallest one that can prove the current k-th distance, or twice the size if none is known
+    int rn;
+    if (thr < INFINITY) {
+      const double need = sqrt((double)thr) * (1.0 + 1e-5);
+      rn = r + 1;
+      while (rn < rmax) {
+        const double b = cube_bound(g, c, q, rn);
+        if (b == 1.0e300 || b > need) break;
+        rn++;
+      }
+    } else {
+      rn = 2 * r + 1;
+    }
+    r = min(rn, rmax);
+    top.init();
+    for_each_cube_row(g, c, r, start, [&](int s0, int s1) { scan_range_topk<KC>(P, s0, s1, px, py, pz, top); });
+    thr = top.kth(k);
+    if (r >= rmax) break;  // whole grid scanned
+    if (thr < INFINITY) {
+      const double bound = cube_bound(g, c, q, r);
+      if (bound == 1.0e300) break;
+      if (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5)) break;
+    }
+  }
+  int m = 0, tie_s = -1, tie_o = INT_MAX;
+  for_each_cube_row(g, c, r, start, [&](int s0, int s1) { scan_range_collect(P, s0, s1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o); });
+  if (m < k && tie_s >= 0) { list[m * lstride] = tie_s; m++; }
+  while (m < k) {  // rare: more than one candidate exactly at the k-th distance is needed; ascending original index
+    const int last_o = tie_o;
+    tie_s = -1;
+    tie_o = INT_MAX;
+    for_each_cube_row(g, c, r, start, [&](int s0, int s1) {
+      for (int s = s0; s < s1; s++) {
+        const float4 cp = P[s];
+        const int o = __float_as_int(cp.w);
+        if (dist2(px, py, pz, cp) == thr && o > last_o && o < tie_o) { tie_o = o; tie_s = s; }
+      }
+    });
+    if (tie_s < 0) break;  // cannot happen for n >= k
+    list[m * lstride] = tie_s;
+    m++;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298): one lane per query, queries in
+// cell order.  The 3x3x3 block of cells around a query is 9 contiguous ranges of the sorted array (one per row);
+// their 18 start[] loads are issued together and candidates are fetched four 16-byte loads at a time, so the lane
+// is not serialised on one memory round trip per candidate.  Neighbouring lanes share cells, hence cache lines.
+//  pass 1: k smallest squared distances in a register chain (v_min/v_max), wave-uniform __any() skip;
+//  pass 2: neighbours closer than the k-th distance appended to a per-lane LDS column ([slot][lane]);
+//  lanes whose k-th distance is not provably inside the 3x3x3 block fall back to generic_search_rows().
+// kTarget only separates the two instantiations by NAME (map vs scan) for the profiles.
+// ------------------------------------------------------------------------------------------------
+constexpr int KNN_T = 256;
+
+template <int KC, bool kTarget>
+__global__ void __launch_bounds__(KNN_T)
+k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, double* __restrict__ nx,
+           double* __restrict__ ny, double* __restrict__ nz) {
+  extern __shared__ int slist_rows[];  // [k][KNN_T]
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * KNN_T + tid;
+  if (i >= n) return;
+  const float4 pq = P[i];
+  const float px = pq.x, py = pq.y, pz = pq.z;
+  const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
+  const int xl = max(c[0] - 1, 0), xh = min(c[0] + 1, g.dim[0] - 1);
+  int lo[9], hi[9];
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
+    const bool in = (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]);
+    const int yy = in ? y : c[1], zz = in ? z : c[2];
+    const int a = start[cell_index(g, xl, yy, zz)], b = start[cell_index(g, xh, yy, zz) + 1];
+    lo[r] = in ? a : 0;
+    hi[r] = in ? b : 0;
+  }
+  TopK<KC> top;
+  top.init();
+#pragma unroll
+  for (int r = 0; r < 9; r++) scan_range_topk<KC>(P, lo[r], hi[r], px, py, pz, top);
+  const float thr = top.kth(k);
+  bool resolved = false;
+  if (thr < INFINITY) {
+    const double q[3] = {(double)px, (double)py, (double)pz};
+    const double bound = cube_bound(g, c, q, 1);
+    resolved = (bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5));
+  }
+  int* list = slist_rows + tid;
+  if (resolved) {
+    int m = 0, tie_s = -1, tie_o = INT_MAX;
+#pragma unroll
+    for (int r = 0; r < 9; r++) scan_range_collect(P, lo[r], hi[r], px, py, pz, thr, k, list, KNN_T, m, tie_s, tie_o);
+    if (m < k && tie_s >= 0) { list[m * KNN_T] = tie_s; m++; }
+    if (m < k) resolved = false;  // several candidates exactly at the k-th distance are needed: rare
+  }
+  if (!resolved) generic_search_rows<KC>(P, start, g, px, py, pz, c, k, 1, thr, list, KNN_T);
+  double nrm[3];
+  normal_from_list(P, list, KNN_T, k, nrm);
+  nx[i] = nrm[0];
+  ny[i] = nrm[1];
+  nz[i] = nrm[2];
+}
+
+// ---- work decomposition: row segments -----------------------------------------------------------------------
+// Sorted points of one (y,z) grid row are contiguous.  A segment = consecutive cells of one row holding at most TQ
+// query points (a cell with more than TQ points is split over several segments).  One workgroup per segment.
+constexpr int TQ = 256;     // queries per segment = threads per workgroup
+constexpr int TCH = 3584;   // candidates per LDS chunk (56 KiB of float4)
+constexpr int TXMAX = 32;   // max cells spanned by a segment
+
+struct Seg {
+  int cell0;  // linear index of the first cell
+  int ncell;  // cells spanned along x
+  int q0, q1; // query range in the sorted array
+};
+
+__global__ void k_segments(const int* __restrict__ start, Grid g, Seg* __restrict__ segs, int* nseg) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= g.dim[1] * g.dim[2]) return;
+  const int base = row * g.dim[0];
+  int x = 0;
+  int prev = start[base];
+  while (x < g.dim[0]) {
+    // skip empty cells
+    int e = start[base + x + 1];
+    if (e == prev) { x++; continue; }
+    const int xa = x, q0 = prev;
+    int q1 = e;
+    if (q1 - q0 > TQ) {  // one crowded cell -> several segments over sub-ranges of its points
+      for (int s = q0; s < q1; s += TQ) {
+        const int id = atomicAdd(nseg, 1);
+        segs[id] = Seg{base + xa, 1, s, min(s + TQ, q1)};
+      }
+      prev = q1;
+      x++;
+      continue;
+    }
+    x++;
+    while (x < g.dim[0] && x - xa < TXMAX) {
+      const int e2 = start[base + x + 1];
+      if (e2 - q0 > TQ) break;
+      q1 = e2;
+      x++;
+    }
+    // trim trailing empty cells
+    int xb = x - 1;
+    while (xb > xa && start[base + xb] == q1) xb--;
+    const int id = atomicAdd(nseg, 1);
+    segs[id] = Seg{base + xa, xb - xa + 1, q0, q1};
+    prev = q1;
+  }
+}
+
+int segment_bound(const Grid& g, int n) {
+  const long long rows = (long long)g.dim[1] * g.dim[2];
+  const long long b = 2ll * n / TQ + rows * (g.dim[0] / TXMAX + 2) + 16;
+  return (int)(b < n ? b : n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298), LDS-tiled.
+// One workgroup per row segment, one lane per query.  The candidates of the segment -- the 9 neighbouring grid
+// rows, each a CONTIGUOUS range of the sorted array -- are staged through LDS in coalesced 16-byte loads, in chunks
+// of TCH points, so the inner loops see LDS latency only and dense cells (hundreds of points) cost bandwidth, not
+// serialized global-memory round trips.
+//  pass 1: K smallest squared distances in a register chain (v_min/v_max), wave-uniform __any() skip;
+//          the lane is RESOLVED if the k-th distance is provably inside its 3x3x3 block of cells.
+//  pass 2: re-scan, append the neighbours closer than the k-th distance to a per-lane LDS column.
+//  Unresolved lanes (sparse areas) and tie overflows fall back to generic_search().
+// kTarget only separates the two instantiations by NAME (map vs scan) for the profiles.
+// ------------------------------------------------------------------------------------------------
+template <int KC, bool kTarget>
+__global__ void __launch_bounds__(TQ)
+k_knn_tile(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int k, const Seg* __restrict__ segs,
+           const int* __restrict__ nseg, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
+  extern __shared__ float4 smem4[];
+  float4* cand = smem4;                   // [TCH]
+  int* slist = (int*)(smem4 + TCH);       // [k][TQ]
+  __shared__ int row_p0[9], row_off[10];
+  if ((int)blockIdx.x >= *nseg) return;
+  const Seg sg = segs[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int i = sg.q0 + tid;
+  const bool active = i < sg.q1;
+  const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
+  const int sx0 = sg.cell0 % dimx, cy = (sg.cell0 / dimx) % dimy, cz = sg.cell0 / (dimx * dimy);
+  const int xa = max(sx0 - 1, 0), xb = min(sx0 + sg.ncell, dimx - 1);
+  if (tid < 9) {
+    const int y = cy + tid % 3 - 1, z = cz + tid / 3 - 1;
+    int lo = 0, hi = 0;
+    if (y >= 0 && y < dimy && z >= 0 && z < dimz) {
+      lo = start[cell_index(g, xa, y, z)];
+      hi = start[cell_index(g, xb, y, z) + 1];
+    }
+    row_p0[tid] = lo;
+    row_off[tid + 1] = hi - lo;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    row_off[0] = 0;
+    for (int r = 1; r <= 9; r++) row_off[r] += row_off[r - 1];
+  }
+  __syncthreads();
+  const int C = row_off[9];
+
+  float px = 0.f, py = 0.f, pz = 0.f;
+  int lo[9], hi[9];
+#pragma unroll
+  for (int r = 0; r < 9; r++) lo[r] = hi[r] = 0;
+  int cxq = 0;
+  if (active) {
+    const float4 pq = P[i];
+    px = pq.x; py = pq.y; pz = pq.z;
+    cxq = voxel_coord1(px, g.res) - g.minc[0];
+    const int xl = max(cxq - 1, 0), xh = min(cxq + 1, dimx - 1);
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+      const int y = cy + r % 3 - 1, z = cz + r / 3 - 1;
+      if (y >= 0 && y < dimy && z >= 0 && z < dimz) {
+        lo[r] = row_off[r] + (start[cell_index(g, xl, y, z)] - row_p0[r]);
+        hi[r] = row_off[r] + (start[cell_index(g, xh, y, z) + 1] - row_p0[r]);
+      }
+    }
+  }
+
+  auto stage = [&](int cbase) {
+    const int cnt = min(TCH, C - cbase);
+    for (int j = tid; j < cnt; j += TQ) {
+      const int jj = cbase + j;
+      int r = 0;
+#pragma unroll
+      for (int t = 1; t < 9; t++) r += (row_off[t] <= jj);
+      cand[j] = P[row_p0[r] + (jj - row_off[r])];
+    }
+  };
+
+  // ---- pass 1 ----
+  TopK<KC> top;
+  top.init();
+  for (int cbase = 0; cbase < C; cbase += TCH) {
+    if (cbase) __syncthreads();
+    stage(cbase);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+      const int l = max(lo[r], cbase) - cbase, h = min(hi[r], cbase + TCH) - cbase;
+      for (int j = l; j < h; j += 2) {
+        const float4 c0 = cand[j];
+        const float4 c1 = cand[min(j + 1, h - 1)];
+        const float x0 = dist2(px, py, pz, c0);
+        const float x1 = (j + 1 < h) ? dist2(px, py, pz, c1) : INFINITY;
+        if (__any(fminf(x0, x1) < top.a[KC - 1])) {
+          top.insert(x0);
+          top.insert(x1);
+        }
+      }
+    }
+  }
+  const float thr = top.kth(k);
+  bool resolved = false;
+  if (active && thr < INFINITY) {
+    const int c[3] = {cxq, cy, cz};
+    const double q[3] = {(double)px, (double)py, (double)pz};
+    const double bound = cube_bound(g, c, q, 1);
+    resolved = (bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5));
+  }
+
+  // ---- pass 2 ----
+  int m = 0, tie_s = -1, tie_o = INT_MAX;
+  for (int cbase = 0; cbase < C; cbase += TCH) {
+    __syncthreads();
+    stage(cbase);
+    __syncthreads();
+    if (resolved) {
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
+        const int l = max(lo[r], cbase) - cbase, h = min(hi[r], cbase + TCH) - cbase;
+        const int gbase = row_p0[r] + cbase - row_off[r];  // LDS slot j -> sorted-array position gbase + j
+        for (int j = l; j < h; j++) {
+          const float4 cp = cand[j];
+          const float x = dist2(px, py, pz, cp);
+          if (x < thr) {
+            if (m < k) slist[m * TQ + tid] = gbase + j;
+            m++;
+          } else if (x == thr) {
+            const int o = __float_as_int(cp.w);
+            if (o < tie_o) { tie_o = o; tie_s = gbase + j; }
+          }
+        }
+      }
+    }
+  }
+  if (!active) return;  // no barriers below
+  if (resolved) {
+    if (m < k && tie_s >= 0) { slist[m * TQ + tid] = tie_s; m++; }
+    if (m < k) resolved = false;  // several candidates exactly at the k-th distance are needed: rare, generic path
+  }
+  if (!resolved) {
+    const int c[3] = {cxq, cy, cz};
+    generic_search_rows<KC>(P, start, g, px, py, pz, c, k, 1, thr, slist + tid, TQ);
+  }
+  double nrm[3];
+  normal_from_list(P, slist + tid, TQ, k, nrm);
   nx[i] = nrm[0];
   ny[i] = nrm[1];
   nz[i] = nrm[2];
@@ -728,17 +1036,41 @@ void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int*
                  const int* order_tmp, float4* P) {
   hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P);
 }
-template <int KC>
-static void knn_cov_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, double* nx, double* ny, double* nz) {
-  const size_t lds = (size_t)k * KNN_T * sizeof(int);
-  if (is_target)
-    hipLaunchKernelGGL((k_knn_cov<KC, true>), dim3(nblk(n, KNN_T)), dim3(KNN_T), lds, s, P, start, g, n, k, nx, ny, nz);
-  else
-    hipLaunchKernelGGL((k_knn_cov<KC, false>), dim3(nblk(n, KNN_T)), dim3(KNN_T), lds, s, P, start, g, n, k, nx, ny, nz);
+void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg) {
+  hipLaunchKernelGGL(k_segments, dim3(nblk((long long)g.dim[1] * g.dim[2], 64)), dim3(64), 0, s, start, g, (Seg*)segs, nseg);
 }
-void knn_cov(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, double* nx, double* ny, double* nz) {
-  if (k <= 20) knn_cov_kc<20>(s, is_target, P, start, g, n, k, nx, ny, nz);
-  else knn_cov_kc<32>(s, is_target, P, start, g, n, k, nx, ny, nz);
+size_t segment_bytes(int n) { return sizeof(Seg) * (size_t)n; }
+static int g_knn_impl = 0;  // 0 = rows (default), 1 = LDS tile (experiment knob, RGC_KNN_IMPL=tile)
+void set_knn_impl(int impl) { g_knn_impl = impl; }
+int knn_impl() { return g_knn_impl; }
+template <int KC>
+static void knn_cov_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
+                       const int* nseg, double* nx, double* ny, double* nz) {
+  if (g_knn_impl == 0) {
+    const size_t ldsr = (size_t)k * KNN_T * sizeof(int);
+    if (is_target)
+      hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nblk(n, KNN_T)), dim3(KNN_T), ldsr, s, P, start, g, n, k, nx, ny, nz);
+    else
+      hipLaunchKernelGGL((k_knn_rows<KC, false>), dim3(nblk(n, KNN_T)), dim3(KNN_T), ldsr, s, P, start, g, n, k, nx, ny, nz);
+    return;
+  }
+  const size_t lds = sizeof(float4) * TCH + (size_t)k * TQ * sizeof(int);
+  const int nb = segment_bound(g, n);
+  static bool attr_done = false;
+  if (!attr_done) {  // dynamic LDS beyond 64 KiB must be opted into
+    (void)hipFuncSetAttribute((const void*)k_knn_tile<KC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute((const void*)k_knn_tile<KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    attr_done = true;
+  }
+  if (is_target)
+    hipLaunchKernelGGL((k_knn_tile<KC, true>), dim3(nb), dim3(TQ), lds, s, P, start, g, k, (const Seg*)segs, nseg, nx, ny, nz);
+  else
+    hipLaunchKernelGGL((k_knn_tile<KC, false>), dim3(nb), dim3(TQ), lds, s, P, start, g, k, (const Seg*)segs, nseg, nx, ny, nz);
+}
+void knn_cov(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
+             const int* nseg, double* nx, double* ny, double* nz) {
+  if (k <= 20) knn_cov_kc<20>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz);
+  else knn_cov_kc<32>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz);
 }
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int* cell_voxel, double* vox, int* vox_cell, int* nvox) {
