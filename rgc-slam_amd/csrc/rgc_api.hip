@@ -53,7 +53,10 @@ struct ProfRegion {
 struct rgc_ctx {
   int device = 0;
   rgc_params prm{};
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // main stream: target preprocessing, LM loop, fitness, getters
+  hipStream_t stream2 = nullptr;  // source preprocessing runs here, concurrently with the (much larger) target's
+  hipEvent_t src_ready = nullptr; // recorded on stream2 after the source is prepared
+  bool src_pending = false;       // main stream has not yet been ordered after src_ready
   char err[512] = {0};
   Cloud src, tgt;
   // per-correspondence state frozen by linearize (fast_vgicp_impl.hpp:104-115)
@@ -61,9 +64,9 @@ struct rgc_ctx {
   int corr_noff = 0, corr_n = 0;
   bool corr_valid = false;
   // small device scratch + pinned host mirrors
-  int* d_small = nullptr;     // [0..5] bbox, [6] flags, [7] nvox, [8] ncorr
+  int* d_small = nullptr;     // [0..5] target bbox, [6] flags, [7] nvox, [8] ncorr, [16..22] source bbox + flags
   double* d_out = nullptr;    // 28 doubles
-  int* h_small = nullptr;     // pinned
+  int* h_small = nullptr;     // pinned, same layout
   double* h_out = nullptr;    // pinned
   DevBuf scratch;             // getters
   rgc_stats stats{};
@@ -98,6 +101,7 @@ int ensure(rgc_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap && b.p) return RGC_OK;
   if (b.p) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
     HIPCHK(c, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -125,7 +129,8 @@ struct ProfScope {
   rgc_ctx* c;
   bool on;
   ProfRegion r{};
-  ProfScope(rgc_ctx* ctx, int kind, long long points) : c(ctx), on(ctx->prof_on) {
+  hipStream_t st;
+  ProfScope(rgc_ctx* ctx, int kind, long long points, hipStream_t stream = nullptr) : c(ctx), on(ctx->prof_on), st(stream ? stream : ctx->stream) {
     if (!on) return;
     auto get = [&](hipEvent_t* e) {
       if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
@@ -134,11 +139,11 @@ struct ProfScope {
     if (!get(&r.a) || !get(&r.b)) { on = false; return; }
     r.kind = kind;
     r.points = points;
-    (void)hipEventRecord(r.a, c->stream);
+    (void)hipEventRecord(r.a, st);
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(r.b, c->stream);
+    (void)hipEventRecord(r.b, st);
     c->prof_open.push_back(r);
   }
 };
@@ -174,21 +179,23 @@ int check_params(rgc_ctx* c, const rgc_params* p) {
 int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
   const int n = cl.n;
   const int k = c->prm.k_correspondences;
-  hipStream_t s = c->stream;
+  hipStream_t s = is_target ? c->stream : c->stream2;
+  int* dsm = c->d_small + (is_target ? 0 : 16);
+  int* hsm = c->h_small + (is_target ? 0 : 16);
   {
-    ProfScope ps(c, RGC_K_GRID, n);
+    ProfScope ps(c, RGC_K_GRID, n, s);
     int init[7] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0};  // [7] nvox and [8] ncorr stay untouched
-    memcpy(c->h_small, init, sizeof(init));
-    HIPCHK(c, hipMemcpyAsync(c->d_small, c->h_small, sizeof(init), hipMemcpyHostToDevice, s));
-    rgck::bbox(s, cl.in, cl.stride_f, n, c->prm.voxel_res, c->d_small, c->d_small + 6);
-    HIPCHK(c, hipMemcpyAsync(c->h_small, c->d_small, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
+    memcpy(hsm, init, sizeof(init));
+    HIPCHK(c, hipMemcpyAsync(dsm, hsm, sizeof(init), hipMemcpyHostToDevice, s));
+    rgck::bbox(s, cl.in, cl.stride_f, n, c->prm.voxel_res, dsm, dsm + 6);
+    HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (c->h_small[6]) return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", is_target ? "target" : "source");
+    if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", is_target ? "target" : "source");
     rgck::Grid g{};
     double ncell = 1.0;
     for (int a = 0; a < 3; a++) {
-      g.minc[a] = c->h_small[a];
-      g.dim[a] = c->h_small[3 + a] - c->h_small[a] + 1;
+      g.minc[a] = hsm[a];
+      g.dim[a] = hsm[3 + a] - hsm[a] + 1;
       ncell *= (double)g.dim[a];
     }
     if (ncell > (double)c->prm.max_cells || ncell > 2.0e9)
@@ -221,7 +228,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     }
   }
   {
-    ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n);
+    ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n, s);
     rgck::knn_cov(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (const int*)cl.nseg.p,
                   (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
   }
@@ -238,6 +245,10 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     cl.nvox = -1;  // fetched lazily
   }
   HIPCHK(c, hipGetLastError());
+  if (!is_target) {
+    HIPCHK(c, hipEventRecord(c->src_ready, s));
+    c->src_pending = true;
+  }
   cl.ready = true;
   return RGC_OK;
 }
@@ -260,7 +271,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
     int rc = ensure(c, cl.in_copy, bytes);
     if (rc) return rc;
     // pageable host memory: hipMemcpyAsync stages and returns once the source has been consumed
-    HIPCHK(c, hipMemcpyAsync(cl.in_copy.p, xyz, bytes - (stride_bytes - 12), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cl.in_copy.p, xyz, bytes - (stride_bytes - 12), hipMemcpyHostToDevice, is_target ? c->stream : c->stream2));
     cl.in = (const float*)cl.in_copy.p;
   }
   cl.stride_f = stride_f;
@@ -286,10 +297,19 @@ rgck::PoseF posef_from(const float T[16]) {
   return P;
 }
 
+// order the main stream after the source preprocessing (which runs on stream2)
+int join_source(rgc_ctx* c) {
+  if (c->src_pending) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->src_ready, 0));
+    c->src_pending = false;
+  }
+  return RGC_OK;
+}
+
 int need_inputs(rgc_ctx* c) {
   if (!c) return RGC_ERR_INVALID;
   if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
-  return RGC_OK;
+  return join_source(c);
 }
 
 int do_linearize(rgc_ctx* c, const double T[16], double* H, double* b, double* cost) {
@@ -502,9 +522,11 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
     c->prm = *params;
   }
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipMalloc((void**)&c->d_small, 16 * sizeof(int)) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_small, 32 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_out, 32 * sizeof(double)) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&c->h_small, 16 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->h_small, 32 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_out, 32 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   *out = c;
@@ -515,6 +537,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   prof_collect(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   release_cloud(c->src);
@@ -524,7 +547,9 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->src_ready) (void)hipEventDestroy(c->src_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
 
@@ -662,8 +687,9 @@ int rgc_get_aligned(rgc_ctx* c, const float T[16], float* out, int stride_bytes)
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
   HIPCHK(c, hipSetDevice(c->device));
   const int n = c->src.n;
-  int rc = ensure(c, c->scratch, sizeof(float) * 3 * (size_t)n);
+  int rc = join_source(c);
   if (rc) return rc;
+  if ((rc = ensure(c, c->scratch, sizeof(float) * 3 * (size_t)n))) return rc;
   rgck::transform_f32(c->stream, c->src.in, c->src.stride_f, n, posef_from(T), (float*)c->scratch.p, 3);
   if (stride_bytes == 12) {
     HIPCHK(c, hipMemcpyAsync(out, c->scratch.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -678,8 +704,9 @@ static int get_covs(rgc_ctx* c, Cloud& cl, double* cov9, double* normals) {
   if (!cl.ready) return fail(c, RGC_ERR_NO_INPUT, "cloud not set");
   HIPCHK(c, hipSetDevice(c->device));
   const int n = cl.n;
-  int rc = ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n);
+  int rc = join_source(c);
   if (rc) return rc;
+  if ((rc = ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n))) return rc;
   rgck::unsort3(c->stream, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const float4*)cl.P.p, n, (double*)c->scratch.p);
   std::vector<double> tmp;
   double* dst = normals;
@@ -761,6 +788,7 @@ int rgc_device_alloc(rgc_ctx* c, size_t bytes, void** p) {
 int rgc_device_free(rgc_ctx* c, void* p) {
   if (!c) return RGC_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipFree(p));
   return RGC_OK;
@@ -781,6 +809,7 @@ int rgc_download(rgc_ctx* c, void* h, const void* d, size_t bytes) {
 int rgc_synchronize(rgc_ctx* c) {
   if (!c) return RGC_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return RGC_OK;
 }
@@ -793,6 +822,7 @@ int rgc_profile_enable(rgc_ctx* c, int on) {
 }
 int rgc_profile_reset(rgc_ctx* c) {
   if (!c) return RGC_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
   for (int i = 0; i < kProfKinds; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_points[i] = 0; }
@@ -800,6 +830,7 @@ int rgc_profile_reset(rgc_ctx* c) {
 }
 int rgc_profile_get(rgc_ctx* c, int kind, long long* launches, double* total_ms, long long* total_points) {
   if (!c || kind < 0 || kind >= kProfKinds) return RGC_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
   if (launches) *launches = c->prof_launches[kind];

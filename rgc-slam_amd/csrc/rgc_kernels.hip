@@ -333,13 +333,17 @@ __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3],
   if (x0 > x1) return;
   for (int z = z0; z <= z1; z++) {
     int y = y0;
-    for (; y + 1 <= y1; y += 2) {  // two rows per step: four independent loads in flight
-      const int a0 = start[cell_index(g, x0, y, z)], b0 = start[cell_index(g, x1, y, z) + 1];
-      const int a1 = start[cell_index(g, x0, y + 1, z)], b1 = start[cell_index(g, x1, y + 1, z) + 1];
-      f(a0, b0);
-      f(a1, b1);
+    for (; y + 3 <= y1; y += 4) {  // four rows per step: eight independent start[] loads in flight
+      int a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        a[u] = start[cell_index(g, x0, y + u, z)];
+        b[u] = start[cell_index(g, x1, y + u, z) + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) f(a[u], b[u]);
     }
-    if (y <= y1) f(start[cell_index(g, x0, y, z)], start[cell_index(g, x1, y, z) + 1]);
+    for (; y <= y1; y++) f(start[cell_index(g, x0, y, z)], start[cell_index(g, x1, y, z) + 1]);
   }
 }
 
@@ -462,6 +466,8 @@ k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
   const int xl = max(c[0] - 1, 0), xh = min(c[0] + 1, g.dim[0] - 1);
+  const int own = cell_index(g, c[0], c[1], c[2]);
+  const int own0 = start[own], own1 = start[own + 1];
   int lo[9], hi[9];
 #pragma unroll
   for (int r = 0; r < 9; r++) {
@@ -472,26 +478,47 @@ k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
     lo[r] = in ? a : 0;
     hi[r] = in ? b : 0;
   }
+  const double q[3] = {(double)px, (double)py, (double)pz};
   TopK<KC> top;
   top.init();
-#pragma unroll
-  for (int r = 0; r < 9; r++) scan_range_topk<KC>(P, lo[r], hi[r], px, py, pz, top);
-  const float thr = top.kth(k);
-  bool resolved = false;
+  // cube r = 0: the query's own cell.  Crowded cells (raw scans near the sensor) resolve here without touching
+  // their 26 neighbours.
+  scan_range_topk<KC>(P, own0, own1, px, py, pz, top);
+  float thr = top.kth(k);
+  int rdone = -1;  // radius of the cube that proved the k-th distance
   if (thr < INFINITY) {
-    const double q[3] = {(double)px, (double)py, (double)pz};
-    const double bound = cube_bound(g, c, q, 1);
-    resolved = (bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5));
+    const double bound = cube_bound(g, c, q, 0);
+    if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) rdone = 0;
+  }
+  if (rdone < 0) {  // cube r = 1: nine row ranges; the middle one without the own cell (already in the chain)
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+      if (r == 4) {
+        scan_range_topk<KC>(P, lo[4], own0, px, py, pz, top);
+        scan_range_topk<KC>(P, own1, hi[4], px, py, pz, top);
+      } else {
+        scan_range_topk<KC>(P, lo[r], hi[r], px, py, pz, top);
+      }
+    }
+    thr = top.kth(k);
+    if (thr < INFINITY) {
+      const double bound = cube_bound(g, c, q, 1);
+      if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) rdone = 1;
+    }
   }
   int* list = slist_rows + tid;
-  if (resolved) {
+  if (rdone >= 0) {
     int m = 0, tie_s = -1, tie_o = INT_MAX;
+    if (rdone == 0) {
+      scan_range_collect(P, own0, own1, px, py, pz, thr, k, list, KNN_T, m, tie_s, tie_o);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 9; r++) scan_range_collect(P, lo[r], hi[r], px, py, pz, thr, k, list, KNN_T, m, tie_s, tie_o);
+      for (int r = 0; r < 9; r++) scan_range_collect(P, lo[r], hi[r], px, py, pz, thr, k, list, KNN_T, m, tie_s, tie_o);
+    }
     if (m < k && tie_s >= 0) { list[m * KNN_T] = tie_s; m++; }
-    if (m < k) resolved = false;  // several candidates exactly at the k-th distance are needed: rare
+    if (m < k) rdone = -1;  // several candidates exactly at the k-th distance are needed: rare
   }
-  if (!resolved) generic_search_rows<KC>(P, start, g, px, py, pz, c, k, 1, thr, list, KNN_T);
+  if (rdone < 0) generic_search_rows<KC>(P, start, g, px, py, pz, c, k, 1, thr, list, KNN_T);
   double nrm[3];
   normal_from_list(P, list, KNN_T, k, nrm);
   nx[i] = nrm[0];
