@@ -449,48 +449,74 @@ __device__ __forceinline__ void generic_search_rows(const float4* __restrict__ P
 // is not serialised on one memory round trip per candidate.  Neighbouring lanes share cells, hence cache lines.
 //  pass 1: k smallest squared distances in a register chain (v_min/v_max), wave-uniform __any() skip;
 //  pass 2: neighbours closer than the k-th distance appended to a per-lane LDS column ([slot][lane]);
-//  lanes whose k-th distance is not provably inside the 3x3x3 block fall back to generic_search_rows().
+//  lanes whose k-th distance is not provably inside the scanned block are DEFERRED to a follow-up launch
+//  (crowded own cell -> 3x3x3 block; 3x3x3 block -> generic_search_rows), keeping waves homogeneous.
 // kTarget only separates the two instantiations by NAME (map vs scan) for the profiles.
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_T = 256;
+constexpr int KNN_HEAVY = 640;  // candidates in the 3x3x3 block above which a query gets a whole wave
 
-template <int KC, bool kTarget>
-__global__ void __launch_bounds__(KNN_T)
-k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, double* __restrict__ nx,
-           double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ int slist_rows[];  // [k][KNN_T]
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * KNN_T + tid;
-  if (i >= n) return;
+// Queries that the lane-per-query kernel cannot finish cheaply -- a crowded own cell that is not decisive (its
+// 3x3x3 block holds thousands of candidates) or a sparse neighbourhood (the search cube must grow) -- are DEFERRED:
+// (query, k-th distance known so far, radius already proven insufficient) goes to a list that k_knn_coop handles
+// with one WAVE per query, so a wave never idles 63 lanes behind one expensive query.
+struct Deferred {
+  int* idx;    // query index i, or ~i when the 3x3x3 block (radius 1) has already been scanned
+  float* thr;  // k-th distance seen so far (INFINITY if fewer than k candidates)
+  int* cnt;
+};
+
+template <int KC>
+__device__ __forceinline__ void knn_point(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, int i,
+                                          int* list, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
+                                          double* __restrict__ nz) {
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
-  const int xl = max(c[0] - 1, 0), xh = min(c[0] + 1, g.dim[0] - 1);
+  const double q[3] = {(double)px, (double)py, (double)pz};
   const int own = cell_index(g, c[0], c[1], c[2]);
   const int own0 = start[own], own1 = start[own + 1];
-  int lo[9], hi[9];
-#pragma unroll
-  for (int r = 0; r < 9; r++) {
-    const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
-    const bool in = (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]);
-    const int yy = in ? y : c[1], zz = in ? z : c[2];
-    const int a = start[cell_index(g, xl, yy, zz)], b = start[cell_index(g, xh, yy, zz) + 1];
-    lo[r] = in ? a : 0;
-    hi[r] = in ? b : 0;
-  }
-  const double q[3] = {(double)px, (double)py, (double)pz};
   TopK<KC> top;
   top.init();
+  float thr = INFINITY;
+  int rdone = -1;
   // cube r = 0: the query's own cell.  Crowded cells (raw scans near the sensor) resolve here without touching
   // their 26 neighbours.
   scan_range_topk<KC>(P, own0, own1, px, py, pz, top);
-  float thr = top.kth(k);
-  int rdone = -1;  // radius of the cube that proved the k-th distance
-  if (thr < INFINITY) {
+  if (own1 - own0 >= k) {
+    thr = top.kth(k);
     const double bound = cube_bound(g, c, q, 0);
-    if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) rdone = 0;
+    if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) {
+      rdone = 0;
+    } else {  // crowded AND undecided
+      const int e = atomicAdd(df.cnt, 1);
+      df.idx[e] = i;
+      df.thr[e] = thr;
+      return;
+    }
   }
-  if (rdone < 0) {  // cube r = 1: nine row ranges; the middle one without the own cell (already in the chain)
+  int lo[9], hi[9];
+  if (rdone < 0) {
+    const int xl = max(c[0] - 1, 0), xh = min(c[0] + 1, g.dim[0] - 1);
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+      const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
+      const bool in = (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]);
+      const int yy = in ? y : c[1], zz = in ? z : c[2];
+      const int a = start[cell_index(g, xl, yy, zz)], b = start[cell_index(g, xh, yy, zz) + 1];
+      lo[r] = in ? a : 0;
+      hi[r] = in ? b : 0;
+    }
+    int tot = 0;
+#pragma unroll
+    for (int r = 0; r < 9; r++) tot += hi[r] - lo[r];
+    if (tot > KNN_HEAVY) {  // a sparse cell next to crowded ones: thousands of candidates -> one wave for this query
+      const int e = atomicAdd(df.cnt, 1);
+      df.idx[e] = i;
+      df.thr[e] = INFINITY;
+      return;
+    }
+    // cube r = 1: nine row ranges, the middle one without the own cell (already in the chain)
 #pragma unroll
     for (int r = 0; r < 9; r++) {
       if (r == 4) {
@@ -506,7 +532,7 @@ k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
       if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) rdone = 1;
     }
   }
-  int* list = slist_rows + tid;
+  bool done = false;
   if (rdone >= 0) {
     int m = 0, tie_s = -1, tie_o = INT_MAX;
     if (rdone == 0) {
@@ -516,14 +542,226 @@ k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
       for (int r = 0; r < 9; r++) scan_range_collect(P, lo[r], hi[r], px, py, pz, thr, k, list, KNN_T, m, tie_s, tie_o);
     }
     if (m < k && tie_s >= 0) { list[m * KNN_T] = tie_s; m++; }
-    if (m < k) rdone = -1;  // several candidates exactly at the k-th distance are needed: rare
+    done = (m >= k);  // else several candidates exactly at the k-th distance are needed: rare -> cooperative path
   }
-  if (rdone < 0) generic_search_rows<KC>(P, start, g, px, py, pz, c, k, 1, thr, list, KNN_T);
+  if (!done) {
+    const int e = atomicAdd(df.cnt, 1);
+    df.idx[e] = ~i;
+    df.thr[e] = thr;
+    return;
+  }
   double nrm[3];
   normal_from_list(P, list, KNN_T, k, nrm);
   nx[i] = nrm[0];
   ny[i] = nrm[1];
   nz[i] = nrm[2];
+}
+
+template <int KC, bool kTarget>
+__global__ void __launch_bounds__(KNN_T)
+k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df, double* __restrict__ nx,
+           double* __restrict__ ny, double* __restrict__ nz) {
+  extern __shared__ int slist_rows[];  // [k][KNN_T]
+  const int i = blockIdx.x * KNN_T + threadIdx.x;
+  if (i < n) knn_point<KC>(P, start, g, k, i, slist_rows + threadIdx.x, df, nx, ny, nz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cooperative exact search: ONE WAVE PER QUERY.  The (2r+1)^2 rows of the search cube are spread over the lanes
+// (their start[] loads overlap instead of forming a dependent chain), the candidates of each batch of 64 rows are
+// flattened and dealt round-robin to the lanes (a crowded row does not serialise on one lane), every lane keeps
+// the KC smallest distances of ITS candidates in a register chain, and the k-th smallest over the wave is found by
+// a bit-wise bisection on the fp32 pattern with per-lane counts + a wave sum.  Exactness and the jump to a larger
+// cube are decided once per wave.  Ties on the k-th distance: ascending original index, like the CPU path.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) { return wave_min(v); }
+
+struct CoopRows {  // per-wave LDS scratch
+  int pref[WAVE + 1];
+  int rowa[WAVE];
+  int nb[32];
+};
+
+__device__ __forceinline__ void wave_lds_fence() {  // LDS is in-order within a wave: only the compiler must not reorder
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int coop_locate(const CoopRows* sh, int j) {  // sorted-array position of flattened candidate j
+  int rr = 0;
+#pragma unroll
+  for (int step = 32; step > 0; step >>= 1) {  // last row whose prefix is <= j
+    const int probe = rr + step;
+    if (sh->pref[probe] <= j) rr = probe;
+  }
+  return sh->rowa[rr] + (j - sh->pref[rr]);
+}
+
+// f(s0, valid0, s1, valid1): two candidates per lane per step so that two searches / loads overlap
+template <typename F>
+__device__ __forceinline__ void coop_for_each_candidate(const Grid& g, const int c[3], int r, const int* __restrict__ start,
+                                                        CoopRows* sh, int lane, F&& f) {
+  const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
+  const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
+  const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
+  if (x0 > x1 || y0 > y1 || z0 > z1) return;
+  const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+  for (int rb = 0; rb < nrows; rb += WAVE) {
+    const int t = rb + lane;
+    int a = 0, b = 0;
+    if (t < nrows) {
+      const int y = y0 + t % ny, z = z0 + t / ny;
+      a = start[cell_index(g, x0, y, z)];
+      b = start[cell_index(g, x1, y, z) + 1];
+    }
+    const int len = b - a;
+    int inc = len;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+      const int u = __shfl_up(inc, o);
+      if (lane >= o) inc += u;
+    }
+    const int total = __shfl(inc, WAVE - 1);
+    wave_lds_fence();
+    sh->pref[lane] = inc - len;
+    sh->rowa[lane] = a;
+    if (lane == 0) sh->pref[WAVE] = INT_MAX;  // sentinel: probes never run past the last row
+    wave_lds_fence();
+    for (int jb = 0; jb < total; jb += 2 * WAVE) {
+      const int j0 = jb + lane, j1 = jb + WAVE + lane;
+      const bool v0 = j0 < total, v1 = j1 < total;
+      const int s0 = v0 ? coop_locate(sh, j0) : 0;
+      const int s1 = v1 ? coop_locate(sh, j1) : 0;
+      f(s0, v0, s1, v1);
+    }
+  }
+}
+
+template <int KC, bool kTarget>
+__global__ void __launch_bounds__(KNN_T)
+k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int k, Deferred df, double* __restrict__ nx,
+           double* __restrict__ ny, double* __restrict__ nz) {
+  __shared__ CoopRows shm[KNN_T / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), wib = threadIdx.x / WAVE;
+  CoopRows* sh = &shm[wib];
+  const int wave = blockIdx.x * (KNN_T / WAVE) + wib, nwaves = gridDim.x * (KNN_T / WAVE);
+  const int cnt = *df.cnt;
+  for (int e = wave; e < cnt; e += nwaves) {
+    const int enc = __builtin_amdgcn_readfirstlane(df.idx[e]);
+    const int i = enc < 0 ? ~enc : enc;
+    int r = enc < 0 ? 1 : 0;  // radius already known to be insufficient
+    float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(df.thr[e])));
+    const float4 pq = P[i];
+    const float px = pq.x, py = pq.y, pz = pq.z;
+    const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
+    const double q[3] = {(double)px, (double)py, (double)pz};
+    const int rmax = max(max(max(c[0], g.dim[0] - 1 - c[0]), max(c[1], g.dim[1] - 1 - c[1])), max(c[2], g.dim[2] - 1 - c[2]));
+    for (;;) {
+      // next cube: the smallest one that can prove the current k-th distance, or twice the size if none is known
+      int rn;
+      if (thr < INFINITY) {
+        const double need = sqrt((double)thr) * (1.0 + 1e-5);
+        rn = r + 1;
+        while (rn < rmax) {
+          const double b = cube_bound(g, c, q, rn);
+          if (b == 1.0e300 || b > need) break;
+          rn++;
+        }
+      } else {
+        rn = r + max(1, (r + 1) / 2);  // fewer than k candidates so far: grow geometrically (x1.5), not x2
+      }
+      r = min(rn, rmax);
+      TopK<KC> top;
+      top.init();
+      coop_for_each_candidate(g, c, r, start, sh, lane, [&](int s0, bool v0, int s1, bool v1) {
+        const float4 c0 = P[s0], c1 = P[s1];
+        const float x0 = v0 ? dist2(px, py, pz, c0) : INFINITY;
+        const float x1 = v1 ? dist2(px, py, pz, c1) : INFINITY;
+        if (x0 < top.a[KC - 1]) top.insert(x0);
+        if (x1 < top.a[KC - 1]) top.insert(x1);
+      });
+      // k-th smallest over the wave: largest bit pattern T with #(values < T) < k  ==  the k-th smallest value
+      unsigned T = 0;
+      for (int bit = 30; bit >= 0; bit--) {
+        const unsigned cand = T | (1u << bit);
+        const float tf = __uint_as_float(cand);
+        int cl = 0;
+#pragma unroll
+        for (int j = 0; j < KC; j++) cl += (top.a[j] < tf) ? 1 : 0;
+        if (cand <= 0x7F800000u && wave_sum_i(cl) < k) T = cand;
+      }
+      thr = (T >= 0x7F800000u) ? INFINITY : __uint_as_float(T);
+      if (r >= rmax) break;  // whole grid scanned
+      if (thr < INFINITY) {
+        const double bound = cube_bound(g, c, q, r);
+        if (bound == 1.0e300) break;
+        if (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5)) break;
+      }
+    }
+    // collect: strictly closer neighbours in wave order, then ties in ascending original index
+    int m = 0;
+    int tie_o = INT_MAX, tie_s = -1;
+    auto take = [&](int s, bool valid, const float4& cp) {
+      const float x = valid ? dist2(px, py, pz, cp) : INFINITY;
+      const unsigned long long mask = __ballot(x < thr);
+      if (x < thr) {
+        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < k) sh->nb[pos] = s;
+      }
+      m += __popcll(mask);
+      const int o = __float_as_int(cp.w);
+      if (x == thr && o < tie_o) { tie_o = o; tie_s = s; }
+    };
+    coop_for_each_candidate(g, c, r, start, sh, lane, [&](int s0, bool v0, int s1, bool v1) {
+      const float4 c0 = P[s0], c1 = P[s1];
+      take(s0, v0, c0);
+      take(s1, v1, c1);
+    });
+    int last_o = -1;
+    while (m < k) {
+      // smallest original index among the ties that is larger than the last one taken
+      int best_o = wave_min_i(tie_o);
+      if (best_o == INT_MAX) break;  // cannot happen for n >= k
+      if (tie_o == best_o) sh->nb[m] = tie_s;
+      m++;
+      last_o = best_o;
+      if (m >= k) break;
+      tie_o = INT_MAX;
+      tie_s = -1;
+      coop_for_each_candidate(g, c, r, start, sh, lane, [&](int s0, bool v0, int s1, bool v1) {
+        const float4 c0 = P[s0], c1 = P[s1];
+        const int o0 = __float_as_int(c0.w), o1 = __float_as_int(c1.w);
+        if (v0 && dist2(px, py, pz, c0) == thr && o0 > last_o && o0 < tie_o) { tie_o = o0; tie_s = s0; }
+        if (v1 && dist2(px, py, pz, c1) == thr && o1 > last_o && o1 < tie_o) { tie_o = o1; tie_s = s1; }
+      });
+    }
+    wave_lds_fence();
+    // neighbourhood mean / covariance in fp64 (fast_gicp_impl.hpp:256-262): lane j holds neighbour j
+    double vx = 0, vy = 0, vz = 0;
+    if (lane < k) {
+      const float4 cp = P[sh->nb[lane]];
+      vx = (double)cp.x; vy = (double)cp.y; vz = (double)cp.z;
+    }
+    const double inv_k = 1.0 / (double)k;
+    const double mx = __shfl(wave_sum(vx), 0) * inv_k, my = __shfl(wave_sum(vy), 0) * inv_k, mz = __shfl(wave_sum(vz), 0) * inv_k;
+    const double dx = lane < k ? vx - mx : 0.0, dy = lane < k ? vy - my : 0.0, dz = lane < k ? vz - mz : 0.0;
+    double S[6] = {wave_sum(dx * dx), wave_sum(dx * dy), wave_sum(dx * dz), wave_sum(dy * dy), wave_sum(dy * dz), wave_sum(dz * dz)};
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) S[a] *= inv_k;
+      double nrm[3];
+      min_eigenvector(S, nrm);
+      nx[i] = nrm[0];
+      ny[i] = nrm[1];
+      nz[i] = nrm[2];
+    }
+    wave_lds_fence();
+  }
 }
 
 // ---- work decomposition: row segments -----------------------------------------------------------------------
@@ -1066,7 +1304,7 @@ void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int*
 void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg) {
   hipLaunchKernelGGL(k_segments, dim3(nblk((long long)g.dim[1] * g.dim[2], 64)), dim3(64), 0, s, start, g, (Seg*)segs, nseg);
 }
-size_t segment_bytes(int n) { return sizeof(Seg) * (size_t)n; }
+size_t segment_bytes(int n) { return sizeof(Seg) * (size_t)n + 64; }  // also holds the deferred lists (3 n ints + header)
 static int g_knn_impl = 0;  // 0 = rows (default), 1 = LDS tile (experiment knob, RGC_KNN_IMPL=tile)
 void set_knn_impl(int impl) { g_knn_impl = impl; }
 int knn_impl() { return g_knn_impl; }
@@ -1075,10 +1313,19 @@ static void knn_cov_kc(hipStream_t s, bool is_target, const float4* P, const int
                        const int* nseg, double* nx, double* ny, double* nz) {
   if (g_knn_impl == 0) {
     const size_t ldsr = (size_t)k * KNN_T * sizeof(int);
-    if (is_target)
-      hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nblk(n, KNN_T)), dim3(KNN_T), ldsr, s, P, start, g, n, k, nx, ny, nz);
-    else
-      hipLaunchKernelGGL((k_knn_rows<KC, false>), dim3(nblk(n, KNN_T)), dim3(KNN_T), ldsr, s, P, start, g, n, k, nx, ny, nz);
+    // deferred list lives in the segment buffer (unused by this implementation): [cnt, pad x15][idx n][thr n]
+    int* base = (int*)const_cast<void*>(segs);
+    Deferred df{base + 16, (float*)(base + 16 + (size_t)n), base};
+    (void)hipMemsetAsync(base, 0, sizeof(int), s);
+    // the number of deferred queries is only known on the device: one wave each up to 8192 waves, idle blocks exit at once
+    const int nb = nblk(n, KNN_T), nbc = n < 2048 * (KNN_T / WAVE) ? nblk(n, KNN_T / WAVE) : 2048;
+    if (is_target) {
+      hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, df, nx, ny, nz);
+      hipLaunchKernelGGL((k_knn_coop<KC, true>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
+    } else {
+      hipLaunchKernelGGL((k_knn_rows<KC, false>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, df, nx, ny, nz);
+      hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
+    }
     return;
   }
   const size_t lds = sizeof(float4) * TCH + (size_t)k * TQ * sizeof(int);
