@@ -147,7 +147,7 @@ def main():
     # dominant kernel = the one with the largest summed HIP-event time in the timed region
     dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
     name, d = dom
-    per_unit = {"knn_cov_target": 36.0, "knn_cov_source": 36.0, "voxel_build": 36.0 + 40.0 * n_vox / args.n_target,
+    per_unit = {"knn_cov_target": 36.0, "knn_cov_source": 36.0, "knn_coop_target": 36.0, "knn_coop_source": 36.0, "voxel_build": 36.0 + 40.0 * n_vox / args.n_target,
                 "linearize": 36.0 + 40.0 * mean_corr / args.n_source, "compute_error": 36.0 + 40.0 * mean_corr / args.n_source,
                 "fitness": 24.0, "grid_build": 0.0}[name]
     avg_ms = d["total_ms"] / max(d["launches"], 1)

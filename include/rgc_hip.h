@@ -138,13 +138,15 @@ RGC_API void* rgc_stream(rgc_ctx* ctx); /* the hipStream_t every kernel of this 
 /* ---- in-library kernel timing with HIP events on the context's stream (bench.py roofline) ---- */
 enum {
   RGC_K_GRID = 0,      /* bbox + count + scan + scatter + rank/gather                         */
-  RGC_K_KNN_COV = 1,   /* exact kNN + covariance + normal on the TARGET (the dominant kernel) */
+  RGC_K_KNN_COV = 1,   /* exact kNN + covariance + normal, bulk kernel on the TARGET (dominant) */
   RGC_K_VOXEL = 2,     /* Gaussian voxel map reduction                                        */
   RGC_K_LINEARIZE = 3, /* correspondences + Mahalanobis + H/b/cost                            */
   RGC_K_ERROR = 4,     /* frozen-correspondence cost                                          */
   RGC_K_FITNESS = 5,   /* 1-NN fitness                                                        */
   RGC_K_KNN_COV_SRC = 6, /* the same kernel on the (small) source cloud, separate instantiation */
-  RGC_K_COUNT = 7
+  RGC_K_KNN_COOP = 7,    /* cooperative kernel (one wave per deferred query), target               */
+  RGC_K_KNN_COOP_SRC = 8,/* cooperative kernel, source                                             */
+  RGC_K_COUNT = 9
 };
 RGC_API int rgc_profile_enable(rgc_ctx* ctx, int on);
 RGC_API int rgc_profile_reset(rgc_ctx* ctx);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "librgc_hip.so")
 
 DIRECT27, DIRECT7, DIRECT1 = 0, 1, 2
 
-K_GRID, K_KNN_COV, K_VOXEL, K_LINEARIZE, K_ERROR, K_FITNESS, K_KNN_COV_SRC, K_COUNT = range(8)
+K_GRID, K_KNN_COV, K_VOXEL, K_LINEARIZE, K_ERROR, K_FITNESS, K_KNN_COV_SRC, K_KNN_COOP, K_KNN_COOP_SRC, K_COUNT = range(10)
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_TOO_FEW_POINTS, ERR_GRID_TOO_LARGE, ERR_NO_INPUT, ERR_NONFINITE = -1, -2, -3, -4, -5, -6

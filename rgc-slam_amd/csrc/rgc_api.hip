@@ -229,8 +229,13 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
   }
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n, s);
-    rgck::knn_cov(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (const int*)cl.nseg.p,
-                  (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
+    rgck::knn_rows(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (const int*)cl.nseg.p,
+                   (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
+  }
+  {
+    ProfScope ps(c, is_target ? RGC_K_KNN_COOP : RGC_K_KNN_COOP_SRC, n, s);
+    rgck::knn_coop(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p,
+                   (double*)cl.ny.p, (double*)cl.nz.p);
   }
   if (is_target) {
     int rc;
@@ -839,7 +844,8 @@ int rgc_profile_get(rgc_ctx* c, int kind, long long* launches, double* total_ms,
   return RGC_OK;
 }
 const char* rgc_profile_name(int kind) {
-  static const char* names[kProfKinds] = {"grid_build", "knn_cov_target", "voxel_build", "linearize", "compute_error", "fitness", "knn_cov_source"};
+  static const char* names[kProfKinds] = {"grid_build", "knn_cov_target", "voxel_build", "linearize", "compute_error", "fitness",
+                                          "knn_cov_source", "knn_coop_target", "knn_coop_source"};
   return (kind >= 0 && kind < kProfKinds) ? names[kind] : "?";
 }
 

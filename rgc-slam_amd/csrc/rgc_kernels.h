@@ -39,8 +39,11 @@ void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg);
 size_t segment_bytes(int n);
 void set_knn_impl(int impl);  // 0 = rows (default), 1 = LDS tile
 int knn_impl();
-void knn_cov(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-             const int* nseg, double* nx, double* ny, double* nz);
+// bulk kernel (one lane per query; defers expensive queries) then the cooperative kernel (one wave per deferred query)
+void knn_rows(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
+              const int* nseg, double* nx, double* ny, double* nz);
+void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
+              double* ny, double* nz);
 // ---- C3: Gaussian voxel map ----
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int* cell_voxel, double* vox, int* vox_cell, int* nvox);

@@ -1305,27 +1305,28 @@ void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg) {
   hipLaunchKernelGGL(k_segments, dim3(nblk((long long)g.dim[1] * g.dim[2], 64)), dim3(64), 0, s, start, g, (Seg*)segs, nseg);
 }
 size_t segment_bytes(int n) { return sizeof(Seg) * (size_t)n + 64; }  // also holds the deferred lists (3 n ints + header)
-static int g_knn_impl = 0;  // 0 = rows (default), 1 = LDS tile (experiment knob, RGC_KNN_IMPL=tile)
+static int g_knn_impl = 0;  // 0 = rows + cooperative (default), 1 = LDS tile (experiment knob, RGC_KNN_IMPL=tile)
 void set_knn_impl(int impl) { g_knn_impl = impl; }
 int knn_impl() { return g_knn_impl; }
+
+// deferred list lives in the segment buffer (unused by the default implementation): [cnt, pad x15][idx n][thr n]
+static Deferred deferred_of(const void* segs, int n) {
+  int* base = (int*)const_cast<void*>(segs);
+  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base};
+}
+
 template <int KC>
-static void knn_cov_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-                       const int* nseg, double* nx, double* ny, double* nz) {
+static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
+                        const int* nseg, double* nx, double* ny, double* nz) {
   if (g_knn_impl == 0) {
     const size_t ldsr = (size_t)k * KNN_T * sizeof(int);
-    // deferred list lives in the segment buffer (unused by this implementation): [cnt, pad x15][idx n][thr n]
-    int* base = (int*)const_cast<void*>(segs);
-    Deferred df{base + 16, (float*)(base + 16 + (size_t)n), base};
-    (void)hipMemsetAsync(base, 0, sizeof(int), s);
-    // the number of deferred queries is only known on the device: one wave each up to 8192 waves, idle blocks exit at once
-    const int nb = nblk(n, KNN_T), nbc = n < 2048 * (KNN_T / WAVE) ? nblk(n, KNN_T / WAVE) : 2048;
-    if (is_target) {
+    Deferred df = deferred_of(segs, n);
+    (void)hipMemsetAsync(df.cnt, 0, sizeof(int), s);
+    const int nb = nblk(n, KNN_T);
+    if (is_target)
       hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, df, nx, ny, nz);
-      hipLaunchKernelGGL((k_knn_coop<KC, true>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
-    } else {
+    else
       hipLaunchKernelGGL((k_knn_rows<KC, false>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, df, nx, ny, nz);
-      hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
-    }
     return;
   }
   const size_t lds = sizeof(float4) * TCH + (size_t)k * TQ * sizeof(int);
@@ -1341,10 +1342,27 @@ static void knn_cov_kc(hipStream_t s, bool is_target, const float4* P, const int
   else
     hipLaunchKernelGGL((k_knn_tile<KC, false>), dim3(nb), dim3(TQ), lds, s, P, start, g, k, (const Seg*)segs, nseg, nx, ny, nz);
 }
-void knn_cov(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-             const int* nseg, double* nx, double* ny, double* nz) {
-  if (k <= 20) knn_cov_kc<20>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz);
-  else knn_cov_kc<32>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz);
+template <int KC>
+static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
+                        double* nx, double* ny, double* nz) {
+  if (g_knn_impl != 0) return;
+  Deferred df = deferred_of(segs, n);
+  // the number of deferred queries is only known on the device: one wave each up to 8192 waves, idle blocks exit at once
+  const int nbc = n < 2048 * (KNN_T / WAVE) ? nblk(n, KNN_T / WAVE) : 2048;
+  if (is_target)
+    hipLaunchKernelGGL((k_knn_coop<KC, true>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
+  else
+    hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
+}
+void knn_rows(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
+              const int* nseg, double* nx, double* ny, double* nz) {
+  if (k <= 20) knn_rows_kc<20>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz);
+  else knn_rows_kc<32>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz);
+}
+void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
+              double* ny, double* nz) {
+  if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz);
+  else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz);
 }
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int* cell_voxel, double* vox, int* vox_cell, int* nvox) {
