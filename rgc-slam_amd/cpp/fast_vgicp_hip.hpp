@@ -1,0 +1,123 @@
+// fast_vgicp_hip.hpp -- header-only C++ adaptor over the C-ABI (include/rgc_hip.h) exposing the calls the RGC-SLAM
+// odometer makes on fast_gicp::FastVGICP (/root/reference/rgc_slam/src/RGC_odometer.cpp:998-1011), with the same
+// method names and argument meaning, WITHOUT requiring PCL/Eigen at build time:
+//
+//   rgc::FastVGICPHip vgicp;                          // fast_gicp::FastVGICP<pcl::PointXYZI, pcl::PointXYZI> vgicp;
+//   vgicp.setResolution(1.0); vgicp.setMaximumIterations(25); vgicp.setMaxCorrespondenceDistance(2);
+//   vgicp.setTransformationEpsilon(1e-6); vgicp.setEuclideanFitnessEpsilon(1e-6); vgicp.setRANSACIterations(0);
+//   vgicp.setNumThreads(14);
+//   vgicp.setInputTarget(target); vgicp.setInputSource(source);   // any cloud with ->points / ->size() (pcl::PointCloud::Ptr)
+//   vgicp.align(*aligned, T2);                                     // T2: anything with operator()(row, col) (Eigen::Matrix4f)
+//   double score = vgicp.getFitnessScore();  auto T = vgicp.getFinalTransformation<Eigen::Matrix4f>();
+//
+// Errors: like the reference, the solver itself never throws ("lm not converged" is lmFailed(), hasConverged() as in
+// PCL); API misuse and HIP failures throw std::runtime_error carrying rgc_last_error().  No CPU fallback exists.
+#pragma once
+#include <cstddef>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rgc_hip.h"
+
+namespace rgc {
+
+enum class NeighborSearchMethod { DIRECT27 = RGC_DIRECT27, DIRECT7 = RGC_DIRECT7, DIRECT1 = RGC_DIRECT1 };  // gicp_settings.hpp:8
+
+class FastVGICPHip {
+public:
+  explicit FastVGICPHip(int hip_device = 0) {
+    rgc_default_params(&p_);
+    p_.max_iterations = 64;       // LsqRegistration() default, lsq_registration_impl.hpp:11
+    p_.translation_eps = 5e-4;    // lsq_registration_impl.hpp:13
+    int rc = rgc_create(hip_device, &p_, &ctx_);
+    if (rc != RGC_OK) throw std::runtime_error(std::string("rgc_create: ") + rgc_status_string(rc));
+    set_identity(final_);
+  }
+  ~FastVGICPHip() { rgc_destroy(ctx_); }
+  FastVGICPHip(const FastVGICPHip&) = delete;
+  FastVGICPHip& operator=(const FastVGICPHip&) = delete;
+
+  // ---- setters: pcl::Registration / LsqRegistration / FastGICP / FastVGICP ----
+  void setResolution(double r) { p_.voxel_res = r; push(); }                       // fast_vgicp_impl.hpp:32-34
+  void setMaximumIterations(int n) { p_.max_iterations = n; push(); }
+  void setTransformationEpsilon(double e) { p_.translation_eps = e; push(); }
+  void setRotationEpsilon(double e) { p_.rotation_eps = e; push(); }               // lsq_registration_impl.hpp:27-29
+  void setInitialLambdaFactor(double f) { p_.lm_init_lambda_factor = f; push(); }  // lsq_registration_impl.hpp:32-34
+  void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; push(); }    // fast_gicp_impl.hpp:41-43
+  void setNeighborSearchMethod(NeighborSearchMethod m) { p_.neighbor_method = (int)m; push(); }
+  void setMaxCorrespondenceDistance(double) {}   // unused by FastVGICP
+  void setEuclideanFitnessEpsilon(double) {}     // no-op in LsqRegistration
+  void setRANSACIterations(int) {}               // no-op
+  void setNumThreads(int) {}                     // CPU threads of the reference; nothing to set on the GPU
+
+  // ---- clouds ----
+  void setInputTarget(const float* xyz, int n, int stride_bytes) { chk(rgc_set_target(ctx_, xyz, n, stride_bytes)); n_tgt_ = n; fit_valid_ = false; }
+  void setInputSource(const float* xyz, int n, int stride_bytes) { chk(rgc_set_source(ctx_, xyz, n, stride_bytes)); n_src_ = n; fit_valid_ = false; }
+  template <class CloudPtr>
+  void setInputTarget(const CloudPtr& cloud) { setInputTarget(&cloud->points[0].x, (int)cloud->points.size(), (int)sizeof(cloud->points[0])); }
+  template <class CloudPtr>
+  void setInputSource(const CloudPtr& cloud) { setInputSource(&cloud->points[0].x, (int)cloud->points.size(), (int)sizeof(cloud->points[0])); }
+  void setInputTargetDevice(const float* d_xyz, int n, int stride_bytes) { chk(rgc_set_target_device(ctx_, d_xyz, n, stride_bytes)); n_tgt_ = n; fit_valid_ = false; }
+  void setInputSourceDevice(const float* d_xyz, int n, int stride_bytes) { chk(rgc_set_source_device(ctx_, d_xyz, n, stride_bytes)); n_src_ = n; fit_valid_ = false; }
+
+  // ---- pcl::Registration::align(output, guess) ----
+  // guess: row-major float[16]
+  void align(const float guess[16]) {
+    int it = 0, conv = 0, fail = 0;
+    chk(rgc_align(ctx_, guess, final_, hessian_, nullptr, &it, &conv, &fail));
+    iterations_ = it; converged_ = conv != 0; lm_failed_ = fail != 0; fit_valid_ = false;
+  }
+  void align() { float I[16]; set_identity(I); align(I); }
+  // output: any cloud with .points (resized to the source size, x/y/z written); guess: operator()(r,c)
+  template <class Cloud, class Mat4>
+  void align(Cloud& output, const Mat4& guess) {
+    float g[16];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) g[r * 4 + c] = (float)guess(r, c);
+    align(g);
+    output.points.resize((size_t)n_src_);
+    if (n_src_ > 0) chk(rgc_get_aligned(ctx_, final_, &output.points[0].x, (int)sizeof(output.points[0])));
+  }
+  void getAligned(float* out_xyz, int stride_bytes) { chk(rgc_get_aligned(ctx_, final_, out_xyz, stride_bytes)); }
+
+  const float* getFinalTransformation() const { return final_; }  // row-major 4x4
+  template <class Mat4>
+  Mat4 getFinalTransformation() const { Mat4 m; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) m(r, c) = final_[r * 4 + c]; return m; }
+  const double* getFinalHessian() const { return hessian_; }      // row-major 6x6, lsq_registration_impl.hpp:43-45
+  bool hasConverged() const { return converged_; }
+  bool lmFailed() const { return lm_failed_; }                    // "lm not converged!!", lsq_registration_impl.hpp:69-72
+  int  iterations() const { return iterations_; }
+  double getFitnessScore() {                                      // RGC_odometer.cpp:1010
+    if (!fit_valid_) { chk(rgc_fitness(ctx_, final_, &fitness_)); fit_valid_ = true; }
+    return fitness_;
+  }
+  // LsqRegistration::evaluateCost (lsq_registration_impl.hpp:48-50); H (36) and b (6) may be null
+  double evaluateCost(const float pose[16], double* H = nullptr, double* b = nullptr) {
+    double T[16], cost = 0;
+    for (int i = 0; i < 16; i++) T[i] = (double)pose[i];
+    chk(rgc_linearize(ctx_, T, H, b, &cost));
+    return cost;
+  }
+  // the accelerator seam of LsqRegistration (lsq_registration.hpp:68-69)
+  double linearize(const double T[16], double H[36], double b[6]) { double c = 0; chk(rgc_linearize(ctx_, T, H, b, &c)); return c; }
+  double compute_error(const double T[16]) { double c = 0; chk(rgc_compute_error(ctx_, T, &c)); return c; }
+
+  std::vector<double> getSourceCovariances() { std::vector<double> c((size_t)n_src_ * 9); chk(rgc_get_source_covariances(ctx_, c.data(), nullptr)); return c; }
+  std::vector<double> getTargetCovariances() { std::vector<double> c((size_t)n_tgt_ * 9); chk(rgc_get_target_covariances(ctx_, c.data(), nullptr)); return c; }
+  rgc_ctx* context() { return ctx_; }
+
+private:
+  static void set_identity(float m[16]) { std::memset(m, 0, 16 * sizeof(float)); m[0] = m[5] = m[10] = m[15] = 1.f; }
+  void chk(int rc) { if (rc != RGC_OK) throw std::runtime_error(std::string(rgc_status_string(rc)) + ": " + rgc_last_error(ctx_)); }
+  void push() { chk(rgc_set_params(ctx_, &p_)); }
+  rgc_ctx* ctx_ = nullptr;
+  rgc_params p_{};
+  float final_[16];
+  double hessian_[36] = {0};
+  double fitness_ = 0;
+  bool fit_valid_ = false, converged_ = false, lm_failed_ = false;
+  int iterations_ = 0, n_src_ = 0, n_tgt_ = 0;
+};
+
+}  // namespace rgc

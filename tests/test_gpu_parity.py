@@ -224,3 +224,23 @@ def test_k_and_resolution_parameters(reg_mod, orc, fx_reg):
     ocost, oH, ob = o.linearize(fx_reg["guess"])
     assert abs(cost - ocost) <= 1e-9 * abs(ocost) and np.abs(H - oH).max() <= 1e-9 * np.abs(oH).max()
     v.close()
+
+
+def test_cpp_adaptor(reg_mod, fx_reg, tmp_path):
+    """the header-only C++ adaptor (rgc-slam_amd/cpp/fast_vgicp_hip.hpp), driven like RGC_odometer.cpp:998-1011 with
+    32-byte pcl::PointXYZI-shaped points, gives the same result as the golden fixture"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_adaptor")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", os.path.join(root, "tests", "cpp", "test_adaptor.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "rgc-slam_amd"), "-lrgc_hip", "-Wl,-rpath," + os.path.join(root, "rgc-slam_amd")])
+    for name in ("tgt", "src"):
+        with open(tmp_path / (name + ".bin"), "wb") as f:
+            a = np.ascontiguousarray(fx_reg[name], dtype=np.float32)
+            f.write(np.int32(len(a)).tobytes()); f.write(a.tobytes())
+    out = subprocess.run([exe, str(tmp_path / "tgt.bin"), str(tmp_path / "src.bin")], capture_output=True, text=True, timeout=300).stdout
+    lines = dict(l.split(" ", 1) for l in out.strip().splitlines())
+    T = np.array([float(x) for x in lines["T"].split()]).reshape(4, 4)
+    assert np.abs(T - fx_reg["final_T"]).max() < 1e-6, out
+    assert abs(float(lines["fitness"]) - fx_reg["fitness"]) <= 1e-5 * fx_reg["fitness"]
+    assert lines["converged"].startswith("1")
