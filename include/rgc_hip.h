@@ -119,6 +119,23 @@ RGC_API int rgc_get_target_covariances(rgc_ctx* ctx, double* cov9, double* norma
  * coords 3*cap ints, num cap ints, mean 3*cap doubles, cov9 9*cap doubles; *count = total voxels. */
 RGC_API int rgc_get_voxels(rgc_ctx* ctx, int cap, int* coords, int* num, double* mean, double* cov9, int* count);
 
+/* ---- stages either side of the operator in the odometer's per-frame body (vg_ICP::ICP_thread) ----
+ * on_device != 0: every cloud pointer of the call is device memory on the context's device. */
+/* B2  vg_ICP::adjustDistortion (src/RGC_odometer.cpp:1441-1481), in place.  Points are x,y,z,intensity with
+ * intensity = ring + 0.1 * relTime as the front-end encodes it (scanRegistration.cpp:207-210).
+ * q_last_curr_xyzw / t_last_curr: the motion guess (IMU pre-integration or previous delta, :929,993-996). */
+RGC_API int rgc_deskew(rgc_ctx* ctx, float* xyzi, int n, int stride_bytes, const double q_last_curr_xyzw[4],
+                       const double t_last_curr[3], int on_device);
+/* B3  pcl::VoxelGrid<PointXYZI>::filter with setLeafSize(leaf,leaf,leaf) (src/RGC_odometer.cpp:976-991).
+ * out_xyzi: n*4 floats capacity (x,y,z,intensity centroids, 16-byte stride, ordered by leaf index); *n_out = leaves.
+ * If the leaf grid would overflow int the input is returned unfiltered, like PCL. */
+RGC_API int rgc_voxelgrid(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, float leaf, float* out_xyzi, int* n_out,
+                          int on_device);
+/* B9  vg_ICP::transformPointCloud(cloud, q, t) (src/RGC_odometer.cpp:1495-1514): q * p + t in fp64, stored fp32,
+ * intensity copied; out_xyzi: n*4 floats. */
+RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, const double q_xyzw[4], const double t[3],
+                                float* out_xyzi, int on_device);
+
 /* per-align statistics (reported by bench.py) */
 typedef struct rgc_stats {
   int n_source, n_target, n_voxels, n_corr;

@@ -80,6 +80,8 @@ def lib():
         L.orc_reg_voxelmap.argtypes = [vp]
         L.orc_reg_voxelmap.restype = vp
         L.orc_voxelgrid_filter.argtypes = [fp, C.c_int, C.c_float, fp]
+        L.orc_deskew.argtypes = [fp, C.c_int, C.c_int, dp, dp]
+        L.orc_transform_cloud.argtypes = [fp, C.c_int, C.c_int, dp, dp, fp]
         L.orc_so3_exp.argtypes = [dp, dp]
         L.orc_is_converged.argtypes = [dp, C.c_double, C.c_double]
         L.orc_transform_f32.argtypes = [fp, C.c_int, C.c_int, fp, fp]
@@ -191,6 +193,23 @@ def transform_f32(xyz, T):
     t, tp = _f32(np.asarray(T).reshape(16))
     out = np.empty((a.shape[0], 3), np.float32)
     lib().orc_transform_f32(ap, a.shape[0], a.shape[1], tp, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def deskew(xyzi, q_xyzw, t):
+    a = np.array(xyzi, dtype=np.float32, order="C", copy=True)
+    q, qp = _f64(q_xyzw)
+    tt, tp = _f64(t)
+    lib().orc_deskew(a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0], a.shape[1], qp, tp)
+    return a
+
+
+def transform_cloud(xyzi, q_xyzw, t):
+    a, ap = _f32(xyzi)
+    q, qp = _f64(q_xyzw)
+    tt, tp = _f64(t)
+    out = np.empty((a.shape[0], 4), np.float32)
+    lib().orc_transform_cloud(ap, a.shape[0], a.shape[1], qp, tp, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
 
 

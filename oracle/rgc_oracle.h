@@ -103,6 +103,11 @@ const orc_voxelmap* orc_reg_voxelmap(orc_reg*);
  * or -1 if the leaf grid overflows int (PCL then returns the input unfiltered). */
 int orc_voxelgrid_filter(const float* xyzi, int n, float leaf, float* out_xyzi);
 
+/* ---- B2: vg_ICP::adjustDistortion (src/RGC_odometer.cpp:1441-1481), in place; quaternions are x,y,z,w ---- */
+void orc_deskew(float* xyzi, int n, int stride, const double q_last_curr_xyzw[4], const double t_last_curr[3]);
+/* ---- B9: vg_ICP::transformPointCloud (src/RGC_odometer.cpp:1495-1514); out: n*4 floats ---- */
+void orc_transform_cloud(const float* xyzi, int n, int stride, const double q_xyzw[4], const double t[3], float* out_xyzi);
+
 /* ---- C7 helpers ---- */
 void orc_so3_exp(const double omega[3], double q_wxyz[4]);                 /* so3/so3.hpp:58-77 */
 int  orc_is_converged(const double delta[16], double rot_eps, double trans_eps); /* lsq_registration_impl.hpp:82-91 */

@@ -44,7 +44,7 @@ SYMBOLS = [
     "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align",
     "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
-    "rgc_stream", "rgc_profile_enable", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+    "rgc_stream", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_profile_enable", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
 _lib = None
@@ -92,6 +92,9 @@ def load():
     L.rgc_synchronize.argtypes = [vp]
     L.rgc_stream.argtypes = [vp]
     L.rgc_stream.restype = vp
+    L.rgc_deskew.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, C.c_int]
+    L.rgc_voxelgrid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, ip, C.c_int]
+    L.rgc_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, vp, C.c_int]
     L.rgc_profile_enable.argtypes = [vp, C.c_int]
     L.rgc_profile_reset.argtypes = [vp]
     L.rgc_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), dp, C.POINTER(C.c_longlong)]

@@ -69,6 +69,8 @@ struct rgc_ctx {
   int* h_small = nullptr;     // pinned, same layout
   double* h_out = nullptr;    // pinned
   DevBuf scratch;             // getters
+  Cloud aux;                  // grid scratch of rgc_voxelgrid
+  DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos;  // B2/B3/B9 staging
   rgc_stats stats{};
   // profiling
   bool prof_on = false;
@@ -529,9 +531,9 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipMalloc((void**)&c->d_small, 32 * sizeof(int)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_small, 48 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_out, 32 * sizeof(double)) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&c->h_small, 32 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_out, 32 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   *out = c;
@@ -547,7 +549,8 @@ void rgc_destroy(rgc_ctx* c) {
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   release_cloud(c->src);
   release_cloud(c->tgt);
-  for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->partials, &c->ipartials, &c->scratch}) release(*b);
+  release_cloud(c->aux);
+  for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_first, &c->vg_pos}) release(*b);
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->h_small) (void)hipHostFree(c->h_small);
@@ -774,6 +777,120 @@ int rgc_get_voxels(rgc_ctx* c, int cap, int* coords, int* num, double* mean, dou
       C[6] = r[5]; C[7] = r[7]; C[8] = r[8];
     }
   }
+  return RGC_OK;
+}
+
+// ---- B2 / B3 / B9: the stages either side of the operator in the odometer's frame body ----
+static int stage_in(rgc_ctx* c, const float* p, int n, int stride_bytes, int on_device, const float** d_in) {
+  if (on_device) { *d_in = p; return RGC_OK; }
+  const size_t bytes = (size_t)n * stride_bytes;
+  int rc = ensure(c, c->pre_in, bytes);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->pre_in.p, p, bytes, hipMemcpyHostToDevice, c->stream));
+  *d_in = (const float*)c->pre_in.p;
+  return RGC_OK;
+}
+
+int rgc_deskew(rgc_ctx* c, float* xyzi, int n, int stride_bytes, const double q[4], const double t[3], int on_device) {
+  if (!c || !xyzi || !q || !t || n < 0) return RGC_ERR_INVALID;
+  if (stride_bytes < 16 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "de-skew needs x,y,z,intensity: stride_bytes >= 16");
+  if (n == 0) return RGC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const float* d_in;
+  int rc = stage_in(c, xyzi, n, stride_bytes, on_device, &d_in);
+  if (rc) return rc;
+  // q_last_curr.inverse() = conjugate / squaredNorm (Eigen), RGC_odometer.cpp:1444
+  const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (!(n2 > 0)) return fail(c, RGC_ERR_INVALID, "zero quaternion");
+  rgck::Quat qi{-q[0] / n2, -q[1] / n2, -q[2] / n2, q[3] / n2};
+  rgck::deskew(c->stream, (float*)d_in, stride_bytes / 4, n, qi, t);
+  if (!on_device) HIPCHK(c, hipMemcpyAsync(xyzi, d_in, (size_t)n * stride_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return RGC_OK;
+}
+
+int rgc_transform_cloud(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const double q[4], const double t[3], float* out_xyzi,
+                        int on_device) {
+  if (!c || !xyzi || !q || !t || !out_xyzi || n < 0) return RGC_ERR_INVALID;
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
+  if (n == 0) return RGC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const float* d_in;
+  int rc = stage_in(c, xyzi, n, stride_bytes, on_device, &d_in);
+  if (rc) return rc;
+  float* d_out = out_xyzi;
+  if (!on_device) {
+    if ((rc = ensure(c, c->pre_out, sizeof(float) * 4 * (size_t)n))) return rc;
+    d_out = (float*)c->pre_out.p;
+  }
+  rgck::transform_q(c->stream, d_in, stride_bytes / 4, n, rgck::Quat{q[0], q[1], q[2], q[3]}, t, d_out, 4);
+  if (!on_device) HIPCHK(c, hipMemcpyAsync(out_xyzi, d_out, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return RGC_OK;
+}
+
+int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float leaf, float* out_xyzi, int* n_out, int on_device) {
+  if (!c || !xyzi || !out_xyzi || !n_out || n < 0) return RGC_ERR_INVALID;
+  if (stride_bytes < 12 || (stride_bytes & 3) || !(leaf > 0.f)) return fail(c, RGC_ERR_INVALID, "bad stride or leaf size");
+  *n_out = 0;
+  if (n == 0) return RGC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const float* d_in;
+  int rc = stage_in(c, xyzi, n, stride_bytes, on_device, &d_in);
+  if (rc) return rc;
+  const int stride_f = stride_bytes / 4;
+  const float inv = 1.0f / leaf;  // inverse_leaf_size_
+  int* dsm = c->d_small + 24;
+  int* hsm = c->h_small + 24;
+  int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+  memcpy(hsm, init, sizeof(init));
+  HIPCHK(c, hipMemcpyAsync(dsm, hsm, sizeof(init), hipMemcpyHostToDevice, s));
+  rgck::vg_bbox(s, d_in, stride_f, n, inv, dsm, dsm + 6);
+  HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "cloud contains non-finite coordinates (PCL skips them; remove NaNs first)");
+  rgck::LeafGrid g{};
+  double ncell = 1.0;
+  for (int a = 0; a < 3; a++) { g.minb[a] = hsm[a]; g.div[a] = hsm[3 + a] - hsm[a] + 1; ncell *= (double)g.div[a]; }
+  float* d_out = out_xyzi;
+  if (!on_device) {
+    if ((rc = ensure(c, c->pre_out, sizeof(float) * 4 * (size_t)n))) return rc;
+    d_out = (float*)c->pre_out.p;
+  }
+  if (ncell > 2147483647.0) {
+    // PCL: "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
+    rgck::transform_q(s, d_in, stride_f, n, rgck::Quat{0, 0, 0, 1}, (const double[3]){0, 0, 0}, d_out, 4);
+    *n_out = n;
+  } else {
+    if (ncell > (double)c->prm.max_cells) return fail(c, RGC_ERR_GRID_TOO_LARGE, "leaf grid %d x %d x %d exceeds max_cells", g.div[0], g.div[1], g.div[2]);
+    Cloud& cl = c->aux;
+    const size_t nc1 = (size_t)ncell + 1;
+    if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
+    if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1))) return rc;
+    if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
+    if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nc1 / 2048 + (size_t)n / 2048 + 4)))) return rc;
+    if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
+    if ((rc = ensure(c, c->vg_order, sizeof(int) * n))) return rc;
+    if ((rc = ensure(c, c->vg_first, sizeof(int) * n))) return rc;
+    if ((rc = ensure(c, c->vg_pos, sizeof(int) * n))) return rc;
+    HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nc1, s));
+    rgck::vg_count(s, d_in, stride_f, n, inv, g, (int*)cl.cell_of.p, (int*)cl.cnt.p);
+    rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, (int*)cl.block_sums.p);
+    rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
+    rgck::vg_rank(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p, (int*)c->vg_order.p, (int*)c->vg_first.p);
+    rgck::exclusive_scan(s, (const int*)c->vg_first.p, (int*)c->vg_pos.p, n, (int*)cl.block_sums.p);
+    rgck::vg_centroid(s, d_in, stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)c->vg_order.p,
+                      (const int*)c->vg_first.p, (const int*)c->vg_pos.p, d_out, dsm + 7);
+    HIPCHK(c, hipMemcpyAsync(hsm + 7, dsm + 7, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *n_out = hsm[7];
+  }
+  if (!on_device) HIPCHK(c, hipMemcpyAsync(out_xyzi, d_out, sizeof(float) * 4 * (size_t)*n_out, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
   return RGC_OK;
 }
 

@@ -22,6 +22,9 @@ struct PoseF {  // fp32 4x4 rows 0..2 (pcl::transformPointCloud in the reference
   float m[12];
 };
 
+struct Quat { double x, y, z, w; };
+struct LeafGrid { int minb[3]; int div[3]; };  // pcl::VoxelGrid leaf grid
+
 constexpr int kAccum = 28;  // 21 upper-triangular H + 6 b + 1 cost
 constexpr int kVoxRec = 10; // mean(3) cov6(6) num(1), doubles
 
@@ -60,5 +63,13 @@ void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP,
 void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f);
 void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const float4* P, int n, double* out3);
 int  linearize_blocks(int n);
+// ---- B2 / B3 / B9 (rgc_pre.hip) ----
+void deskew(hipStream_t s, float* xyzi, int stride_f, int n, Quat qinv, const double t[3]);
+void transform_q(hipStream_t s, const float* in, int stride_f, int n, Quat q, const double t[3], float* out, int ostride_f);
+void vg_bbox(hipStream_t s, const float* in, int stride_f, int n, float inv, int* mm6, int* flags);
+void vg_count(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* cell_of, int* cnt);
+void vg_rank(hipStream_t s, int n, const int* cell_of, const int* start, const int* order_tmp, int* order, int* first);
+void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start, const int* order,
+                 const int* first, const int* outpos, float* out, int* n_out);
 
 }  // namespace rgck

@@ -1,0 +1,76 @@
+"""B2 de-skew, B3 VoxelGrid, B9 sub-map transform: HIP path vs the CPU oracle and the golden fixture.  -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pre():
+    from rgc_slam_amd import odometry
+    p = odometry.Preprocessor(0)
+    yield p
+    p.close()
+
+
+def _scan(n_az=1200, seed=3):
+    import rgc_slam_amd.synth as synth
+    w = synth.make_world(half_extent=40.0, seed=synth.SEED)
+    sc = synth.make_scan(w, np.eye(4), n_az=n_az, seed=synth.SEED + seed)
+    return np.concatenate([sc["xyz"], (sc["ring"] + 0.1 * sc["rel_time"])[:, None].astype(np.float32)], axis=1)
+
+
+def test_voxelgrid_golden(pre, fx_vg):
+    for leaf, key in ((0.2, "out_02"), (0.3, "out_03")):
+        out = pre.voxelGridFilter(fx_vg["xyzi"], leaf)
+        assert out.shape == fx_vg[key].shape
+        assert np.abs(out - fx_vg[key]).max() < 1e-4
+
+
+def test_voxelgrid_vs_oracle_bit_exact(pre, orc):
+    xyzi = _scan()
+    for leaf in (0.2, 0.3, 1.0):
+        got, exp = pre.voxelGridFilter(xyzi, leaf), orc.voxelgrid_filter(xyzi, leaf)
+        assert got.shape == exp.shape
+        assert np.array_equal(got, exp), np.abs(got - exp).max()   # same fp32 sums in the same order
+    # 32-byte stride (pcl::PointXYZI) and a single-leaf cloud
+    wide = np.zeros((len(xyzi), 8), np.float32); wide[:, :3] = xyzi[:, :3]; wide[:, 3] = xyzi[:, 3]
+    tight4 = np.concatenate([wide[:, :3], wide[:, 3:4]], axis=1)
+    assert np.array_equal(pre.voxelGridFilter(wide, 0.2), orc.voxelgrid_filter(tight4, 0.2))
+    one = pre.voxelGridFilter(xyzi[:50] * 1e-4, 1.0)
+    assert one.shape == (1, 4) or one.shape == (2, 4) or one.shape[0] <= 8
+
+
+def test_deskew_vs_oracle(pre, orc):
+    import rgc_slam_amd.synth as synth
+    xyzi = _scan()
+    R = synth.rot_zyx(0.02, 0.004, -0.003)
+    # quaternion x,y,z,w of R
+    qw = np.sqrt(1 + np.trace(R)) / 2
+    q = np.array([(R[2, 1] - R[1, 2]) / (4 * qw), (R[0, 2] - R[2, 0]) / (4 * qw), (R[1, 0] - R[0, 1]) / (4 * qw), qw])
+    t = np.array([0.15, -0.01, 0.004])
+    got, exp = pre.adjustDistortion(xyzi, q, t), orc.deskew(xyzi, q, t)
+    assert np.array_equal(got[:, 3], xyzi[:, 3])
+    assert np.abs(got[:, :3] - exp[:, :3]).max() <= 2e-6      # fp64 math, results rounded to fp32
+    # identity motion leaves the cloud unchanged; points at rel-time 1 (s = 0) do not move
+    same = pre.adjustDistortion(xyzi, [0, 0, 0, 1], [0, 0, 0])
+    assert np.abs(same[:, :3] - xyzi[:, :3]).max() <= 1e-6
+    moved = np.linalg.norm(got[:, :3] - xyzi[:, :3], axis=1)
+    rel = (xyzi[:, 3] - np.floor(xyzi[:, 3])) / 0.1
+    assert moved[rel > 0.98].max() < 0.02 and moved[rel < 0.05].max() > 0.1
+
+
+def test_transform_cloud_vs_oracle(pre, orc):
+    xyzi = _scan(n_az=400)
+    q = np.array([0.01, -0.02, 0.3, 0.95]); q /= np.linalg.norm(q)
+    t = np.array([12.5, -3.25, 0.75])
+    got, exp = pre.transformPointCloud(xyzi, q, t), orc.transform_cloud(xyzi, q, t)
+    assert np.array_equal(got[:, 3], xyzi[:, 3])
+    assert np.abs(got - exp).max() <= 4e-6
+    # B9 round trip (RGC_odometer.cpp:1250-1255): world -> body with (q^-1, -q^-1 t) undoes body -> world
+    qc = np.array([-q[0], -q[1], -q[2], q[3]])
+    R = np.array([[1 - 2 * (q[1] ** 2 + q[2] ** 2), 2 * (q[0] * q[1] - q[2] * q[3]), 2 * (q[0] * q[2] + q[1] * q[3])],
+                  [2 * (q[0] * q[1] + q[2] * q[3]), 1 - 2 * (q[0] ** 2 + q[2] ** 2), 2 * (q[1] * q[2] - q[0] * q[3])],
+                  [2 * (q[0] * q[2] - q[1] * q[3]), 2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[0] ** 2 + q[1] ** 2)]])
+    back = pre.transformPointCloud(got, qc, -(R.T @ t))
+    assert np.abs(back[:, :3] - xyzi[:, :3]).max() < 2e-5
