@@ -136,6 +136,41 @@ RGC_API int rgc_voxelgrid(rgc_ctx* ctx, const float* xyzi, int n, int stride_byt
 RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, const double q_xyzw[4], const double t[3],
                                 float* out_xyzi, int on_device);
 
+/* ---- scalar host stages of the frame body (no GPU needed; kept in the same library so the adaptor is complete) ----
+ * Quaternions are x,y,z,w.  ground[11] = ground_msg/groundparam order: norm xyz, vector1 xyz, vector2 xyz, distance,
+ * source (ground_msg/msg/groundparam.msg:2-12; ground_s, include/rgc_slam/utility.h:382-389). */
+/* C9  result extraction (src/RGC_odometer.cpp:1011-1016): Matrix4f -> (q_last_curr_l, t_last_curr_l) */
+RGC_API int rgc_extract_pose(const float T[16], double q_xyzw[4], double t[3]);
+/* B1  gyro-only delta-q guess + mid-point delta-p/delta-v (src/RGC_odometer.cpp:883-931,1418-1438) */
+RGC_API int rgc_imu_preintegrate(const double* stamps, const double* gyr3, const double* acc3 /* may be NULL */, int n,
+                                 double prev_time, double cur_time, double dq_xyzw[4], double dq2_xyzw[4] /* NULL ok */,
+                                 double dp[3] /* NULL ok */, double dv[3] /* NULL ok */);
+/* B7  the pose-fusion problem the reference builds for Ceres (src/RGC_odometer.cpp:1025-1032,1088-1119,1188-1193;
+ * factors src/lidarFactor.hpp:132-172,228-265,311-350) */
+typedef struct rgc_fuse_in {
+  double q_lidar_xyzw[4];    /* q_last_curr_l (:1016)                                              */
+  double t_lidar[3];         /* t_last_curr_l (:1015)                                              */
+  double fitness;            /* vgicp_source = getFitnessScore() (:1010)                           */
+  int    use_ground;         /* USE_GROUND && gflag == 0 (:1088)                                   */
+  double ground_last[11];    /* ground_last                                                        */
+  double ground_cur[11];     /* ground_cur                                                         */
+  double q_w_curr_f_xyzw[4]; /* q_w_curr_delta^-1 * q_w_curr, normalised (:1086-1087)              */
+  double ground_cov;         /* 0.2 (:1092)                                                        */
+  int    use_imu;            /* USE_IMU && imuflag == 1 (:1104)                                    */
+  double q_imu_xyzw[4];      /* delta_q_imu; its weight follows :1107-1116                         */
+  int    max_iterations;     /* 6 (:1190)                                                          */
+} rgc_fuse_in;
+RGC_API void rgc_default_fuse_in(rgc_fuse_in* in);
+RGC_API int rgc_fuse_pose(const rgc_fuse_in* in, double q_xyzw[4], double t[3], int* iterations /* NULL ok */);
+/* B8  pose composition + 0.95/0.05 pitch-roll blend in DEGREES (src/RGC_odometer.cpp:1194-1214);
+ * R_imu_wl = IMU.Rwi * R_il, row-major, only read when use_imu */
+RGC_API int rgc_compose_pose(const double q_w_curr[4], const double t_w_curr[3], const double q_fused[4], const double t_fused[3],
+                             const double t_lidar[3], int use_imu, const double R_imu_wl[9], double q_w_out[4], double t_w_out[3],
+                             double t_last_curr_out[3] /* NULL ok */);
+/* Utility::R2ypr / ypr2R (include/rgc_slam/utility.h:105-147): degrees, Rz*Ry*Rx, row-major 3x3 */
+RGC_API void rgc_R2ypr(const double R[9], double ypr_deg[3]);
+RGC_API void rgc_ypr2R(const double ypr_deg[3], double R[9]);
+
 /* per-align statistics (reported by bench.py) */
 typedef struct rgc_stats {
   int n_source, n_target, n_voxels, n_corr;

@@ -31,6 +31,12 @@ class Stats(C.Structure):
                 ("target_cells", C.c_longlong), ("source_cells", C.c_longlong)]
 
 
+class FuseIn(C.Structure):
+    _fields_ = [("q_lidar_xyzw", C.c_double * 4), ("t_lidar", C.c_double * 3), ("fitness", C.c_double), ("use_ground", C.c_int),
+                ("ground_last", C.c_double * 11), ("ground_cur", C.c_double * 11), ("q_w_curr_f_xyzw", C.c_double * 4),
+                ("ground_cov", C.c_double), ("use_imu", C.c_int), ("q_imu_xyzw", C.c_double * 4), ("max_iterations", C.c_int)]
+
+
 class RgcError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"rgc_hip status {status}: {msg}")
@@ -44,7 +50,8 @@ SYMBOLS = [
     "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align",
     "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
-    "rgc_stream", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_profile_enable", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+    "rgc_stream", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
+    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_profile_enable", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
 _lib = None
@@ -92,6 +99,16 @@ def load():
     L.rgc_synchronize.argtypes = [vp]
     L.rgc_stream.argtypes = [vp]
     L.rgc_stream.restype = vp
+    L.rgc_extract_pose.argtypes = [fp, dp, dp]
+    L.rgc_imu_preintegrate.argtypes = [dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp]
+    L.rgc_default_fuse_in.argtypes = [C.POINTER(FuseIn)]
+    L.rgc_default_fuse_in.restype = None
+    L.rgc_fuse_pose.argtypes = [C.POINTER(FuseIn), dp, dp, ip]
+    L.rgc_compose_pose.argtypes = [dp, dp, dp, dp, dp, C.c_int, dp, dp, dp, dp]
+    L.rgc_R2ypr.argtypes = [dp, dp]
+    L.rgc_R2ypr.restype = None
+    L.rgc_ypr2R.argtypes = [dp, dp]
+    L.rgc_ypr2R.restype = None
     L.rgc_deskew.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, C.c_int]
     L.rgc_voxelgrid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, ip, C.c_int]
     L.rgc_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, vp, C.c_int]

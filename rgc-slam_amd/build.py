@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librgc_hip.so")
-SRCS = ["rgc_api.hip", "rgc_kernels.hip", "rgc_pre.hip"]
+SRCS = ["rgc_api.hip", "rgc_kernels.hip", "rgc_pre.hip", "rgc_host.cpp"]
 DEPS = SRCS + ["rgc_kernels.h", os.path.join("..", "..", "include", "rgc_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
@@ -25,8 +25,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     objs = []
     for src in SRCS:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [HIPCC] + (FLAGS if src.endswith(".hip") else FLAGS[1:]) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
