@@ -136,6 +136,33 @@ RGC_API int rgc_voxelgrid(rgc_ctx* ctx, const float* xyzi, int n, int stride_byt
 RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, const double q_xyzw[4], const double t[3],
                                 float* out_xyzi, int on_device);
 
+/* ---- A1-A8  ScanRegistration::laserCloudHandler (src/scanRegistration.cpp:89-730): range/NaN filter, ring + rel-time
+ * assignment, curvature stencils, ground marking + weighted-PCA ground plane, occlusion mask, per-ring 6-sector
+ * selection of sharp / flat / intensity features.  Input: the raw sensor cloud x,y,z,intensity in firing order
+ * (what pcl::fromROSMsg yields from /velodyne_points, :107-108).  All output buffers are caller-allocated HOST memory.
+ * Outputs = the node's published topics (:689-727): cloud = /velodyne_cloud_2 (ring-major, intensity = ring +
+ * 0.1*relTime), sharp = /laser_cloud_sharp, inten = /laser_cloud_inten, flat = /laser_cloud_flat (features are
+ * x,y,z,intensity,normal_x with normal_x the weight of :501,554,609), ground_pts = /laser_cloud_ground,
+ * groundparam = /ground_param (ground_msg/groundparam.msg field order).  Per-point diagnostics may be NULL. */
+typedef struct rgc_fe_params {
+  int    n_scans;        /* scan_line: 16 / 32 / 64 (:57,69)          */
+  double min_range;      /* minimum_range 0.5 (:59)                    */
+  double max_range;      /* maxmum_range 80 (launch/run.launch:13)     */
+  int    use_intensity;  /* USE_intensity (:58,645)                    */
+} rgc_fe_params;
+typedef struct rgc_fe_out {
+  float* cloud; int cloud_cap; int n_cloud;                 /* cloud_cap points * 4 floats                        */
+  float* sharp; float* flat; float* inten; int feat_cap;    /* feat_cap features * 5 floats each                  */
+  int n_sharp, n_sharp_own, n_flat, n_inten;                /* n_sharp includes the appended intensity corners    */
+  float* ground_pts; int ground_cap; int n_ground;          /* ground_cap * 4 floats (may be NULL); n_ground total */
+  double groundparam[11]; int ground_valid;                 /* ground_valid = 0 <=> "groundsize0" (:354-357)      */
+  int ring_count[64];
+  float *curvature, *curvature2, *inten_curvature;          /* cloud_cap each, optional                           */
+  int *label, *inten_label, *picked, *ground_marked;        /* cloud_cap each, optional                           */
+} rgc_fe_out;
+RGC_API void rgc_default_fe_params(rgc_fe_params* p);
+RGC_API int rgc_frontend(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* params, rgc_fe_out* out);
+
 /* ---- scalar host stages of the frame body (no GPU needed; kept in the same library so the adaptor is complete) ----
  * Quaternions are x,y,z,w.  ground[11] = ground_msg/groundparam order: norm xyz, vector1 xyz, vector2 xyz, distance,
  * source (ground_msg/msg/groundparam.msg:2-12; ground_s, include/rgc_slam/utility.h:382-389). */

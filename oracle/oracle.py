@@ -30,6 +30,20 @@ class Params(C.Structure):
                 ("k_correspondences", C.c_int), ("neighbor_method", C.c_int), ("num_threads", C.c_int)]
 
 
+class FeParams(C.Structure):
+    _fields_ = [("n_scans", C.c_int), ("min_range", C.c_double), ("max_range", C.c_double), ("use_intensity", C.c_int)]
+
+
+class FeOut(C.Structure):
+    _fields_ = [("cloud", C.POINTER(C.c_float)), ("n_cloud", C.c_int), ("ring_count", C.c_int * 64), ("scan_start", C.c_int * 64),
+                ("scan_end", C.c_int * 64), ("curvature", C.POINTER(C.c_float)), ("curvature2", C.POINTER(C.c_float)),
+                ("inten_curvature", C.POINTER(C.c_float)), ("label", C.POINTER(C.c_int)), ("inten_label", C.POINTER(C.c_int)),
+                ("picked", C.POINTER(C.c_int)), ("ground_marked", C.POINTER(C.c_int)), ("sharp", C.POINTER(C.c_float)),
+                ("flat", C.POINTER(C.c_float)), ("inten", C.POINTER(C.c_float)), ("feat_cap", C.c_int), ("n_sharp", C.c_int),
+                ("n_sharp_own", C.c_int), ("n_flat", C.c_int), ("n_inten", C.c_int), ("ground_pts", C.POINTER(C.c_float)),
+                ("ground_cap", C.c_int), ("n_ground", C.c_int), ("groundparam", C.c_double * 11), ("ground_valid", C.c_int)]
+
+
 class LmTrace(C.Structure):
     _fields_ = [("outer", C.c_int), ("inner", C.c_int), ("n_corr", C.c_int), ("y0", C.c_double), ("yi", C.c_double),
                 ("rho", C.c_double), ("lambda_before", C.c_double), ("lambda_after", C.c_double), ("accepted", C.c_int),
@@ -82,6 +96,8 @@ def lib():
         L.orc_voxelgrid_filter.argtypes = [fp, C.c_int, C.c_float, fp]
         L.orc_deskew.argtypes = [fp, C.c_int, C.c_int, dp, dp]
         L.orc_transform_cloud.argtypes = [fp, C.c_int, C.c_int, dp, dp, fp]
+        L.orc_fe_default_params.argtypes = [C.POINTER(FeParams)]
+        L.orc_frontend.argtypes = [fp, C.c_int, C.c_int, C.POINTER(FeParams), C.POINTER(FeOut)]
         L.orc_so3_exp.argtypes = [dp, dp]
         L.orc_is_converged.argtypes = [dp, C.c_double, C.c_double]
         L.orc_transform_f32.argtypes = [fp, C.c_int, C.c_int, fp, fp]
@@ -210,6 +226,33 @@ def transform_cloud(xyzi, q_xyzw, t):
     tt, tp = _f64(t)
     out = np.empty((a.shape[0], 4), np.float32)
     lib().orc_transform_cloud(ap, a.shape[0], a.shape[1], qp, tp, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def frontend(xyzi, n_scans=16, min_range=0.5, max_range=80.0, use_intensity=1):
+    """ScanRegistration::laserCloudHandler restatement; returns a dict of numpy arrays."""
+    a, ap = _f32(xyzi)
+    n = a.shape[0]
+    prm = FeParams(n_scans, min_range, max_range, use_intensity)
+    fcap, gcap = max(n, 1), max(10 * n, 1)
+    bufs = dict(cloud=np.zeros((n, 4), np.float32), curvature=np.zeros(n, np.float32), curvature2=np.zeros(n, np.float32),
+                inten_curvature=np.zeros(n, np.float32), label=np.zeros(n, np.int32), inten_label=np.zeros(n, np.int32),
+                picked=np.zeros(n, np.int32), ground_marked=np.zeros(n, np.int32), sharp=np.zeros((fcap, 5), np.float32),
+                flat=np.zeros((fcap, 5), np.float32), inten=np.zeros((fcap, 5), np.float32), ground_pts=np.zeros((gcap, 4), np.float32))
+    o = FeOut()
+    for k, v in bufs.items():
+        setattr(o, k, v.ctypes.data_as(C.POINTER(C.c_int if v.dtype == np.int32 else C.c_float)))
+    o.feat_cap, o.ground_cap = fcap, gcap
+    rc = lib().orc_frontend(ap, n, a.shape[1], C.byref(prm), C.byref(o))
+    if rc:
+        raise RuntimeError(f"orc_frontend rc={rc}")
+    m = o.n_cloud
+    out = {k: (v[:m] if k in ("cloud", "curvature", "curvature2", "inten_curvature", "label", "inten_label", "picked", "ground_marked") else v)
+           for k, v in bufs.items()}
+    out["sharp"], out["flat"], out["inten"] = bufs["sharp"][:o.n_sharp], bufs["flat"][:o.n_flat], bufs["inten"][:o.n_inten]
+    out["ground_pts"] = bufs["ground_pts"][:o.n_ground]
+    out.update(n_cloud=m, n_sharp_own=o.n_sharp_own, ring_count=np.array(o.ring_count[:n_scans]), scan_start=np.array(o.scan_start[:n_scans]),
+               scan_end=np.array(o.scan_end[:n_scans]), groundparam=np.array(o.groundparam[:]), ground_valid=bool(o.ground_valid))
     return out
 
 

@@ -108,6 +108,23 @@ void orc_deskew(float* xyzi, int n, int stride, const double q_last_curr_xyzw[4]
 /* ---- B9: vg_ICP::transformPointCloud (src/RGC_odometer.cpp:1495-1514); out: n*4 floats ---- */
 void orc_transform_cloud(const float* xyzi, int n, int stride, const double q_xyzw[4], const double t[3], float* out_xyzi);
 
+/* ---- A1-A8: ScanRegistration::laserCloudHandler (src/scanRegistration.cpp:89-730) ---- */
+typedef struct { int n_scans; double min_range, max_range; int use_intensity; } orc_fe_params;
+typedef struct {
+  /* caller-allocated, capacity n (input size) unless noted */
+  float* cloud;            /* n*4: ring-major full cloud, intensity = ring + 0.1*relTime (/velodyne_cloud_2) */
+  int n_cloud;
+  int ring_count[64], scan_start[64], scan_end[64];
+  float *curvature, *curvature2, *inten_curvature;   /* n each */
+  int *label, *inten_label, *picked, *ground_marked; /* n each */
+  float *sharp, *flat, *inten;                       /* feat_cap*5: x,y,z,intensity,normal_x weight */
+  int feat_cap, n_sharp, n_sharp_own, n_flat, n_inten;
+  float* ground_pts; int ground_cap, n_ground;       /* ground_cap*4, pushed with duplicates in reference order */
+  double groundparam[11]; int ground_valid;          /* ground_msg/groundparam field order */
+} orc_fe_out;
+void orc_fe_default_params(orc_fe_params* p);
+int orc_frontend(const float* xyzi, int n, int stride, const orc_fe_params* prm, orc_fe_out* out);
+
 /* ---- C7 helpers ---- */
 void orc_so3_exp(const double omega[3], double q_wxyz[4]);                 /* so3/so3.hpp:58-77 */
 int  orc_is_converged(const double delta[16], double rot_eps, double trans_eps); /* lsq_registration_impl.hpp:82-91 */

@@ -37,6 +37,20 @@ class FuseIn(C.Structure):
                 ("ground_cov", C.c_double), ("use_imu", C.c_int), ("q_imu_xyzw", C.c_double * 4), ("max_iterations", C.c_int)]
 
 
+class FeParams(C.Structure):
+    _fields_ = [("n_scans", C.c_int), ("min_range", C.c_double), ("max_range", C.c_double), ("use_intensity", C.c_int)]
+
+
+class FeOut(C.Structure):
+    _fields_ = [("cloud", C.POINTER(C.c_float)), ("cloud_cap", C.c_int), ("n_cloud", C.c_int), ("sharp", C.POINTER(C.c_float)),
+                ("flat", C.POINTER(C.c_float)), ("inten", C.POINTER(C.c_float)), ("feat_cap", C.c_int), ("n_sharp", C.c_int),
+                ("n_sharp_own", C.c_int), ("n_flat", C.c_int), ("n_inten", C.c_int), ("ground_pts", C.POINTER(C.c_float)),
+                ("ground_cap", C.c_int), ("n_ground", C.c_int), ("groundparam", C.c_double * 11), ("ground_valid", C.c_int),
+                ("ring_count", C.c_int * 64), ("curvature", C.POINTER(C.c_float)), ("curvature2", C.POINTER(C.c_float)),
+                ("inten_curvature", C.POINTER(C.c_float)), ("label", C.POINTER(C.c_int)), ("inten_label", C.POINTER(C.c_int)),
+                ("picked", C.POINTER(C.c_int)), ("ground_marked", C.POINTER(C.c_int))]
+
+
 class RgcError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"rgc_hip status {status}: {msg}")
@@ -50,7 +64,7 @@ SYMBOLS = [
     "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align",
     "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
-    "rgc_stream", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
+    "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
     "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_profile_enable", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
@@ -99,6 +113,9 @@ def load():
     L.rgc_synchronize.argtypes = [vp]
     L.rgc_stream.argtypes = [vp]
     L.rgc_stream.restype = vp
+    L.rgc_default_fe_params.argtypes = [C.POINTER(FeParams)]
+    L.rgc_default_fe_params.restype = None
+    L.rgc_frontend.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(FeParams), C.POINTER(FeOut)]
     L.rgc_extract_pose.argtypes = [fp, dp, dp]
     L.rgc_imu_preintegrate.argtypes = [dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp]
     L.rgc_default_fuse_in.argtypes = [C.POINTER(FuseIn)]

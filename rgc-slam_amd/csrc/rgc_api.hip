@@ -71,6 +71,7 @@ struct rgc_ctx {
   DevBuf scratch;             // getters
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos;  // B2/B3/B9 staging
+  DevBuf fe[32];              // front-end buffers
   rgc_stats stats{};
   // profiling
   bool prof_on = false;
@@ -550,6 +551,7 @@ void rgc_destroy(rgc_ctx* c) {
   release_cloud(c->src);
   release_cloud(c->tgt);
   release_cloud(c->aux);
+  for (DevBuf& b : c->fe) release(b);
   for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_first, &c->vg_pos}) release(*b);
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->d_out) (void)hipFree(c->d_out);
@@ -891,6 +893,148 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
   if (!on_device) HIPCHK(c, hipMemcpyAsync(out_xyzi, d_out, sizeof(float) * 4 * (size_t)*n_out, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
+  return RGC_OK;
+}
+
+
+// ---- A1-A8: ScanRegistration::laserCloudHandler on the device (src/scanRegistration.cpp:89-730) ----
+static void host_eig3_sym(const double S[6], double ev[3], double V[9]) {  // Jacobi; eigenvalues ASCENDING, columns of V
+  double A[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}}, U[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 60; sweep++) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-40 * dg || off == 0.0) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cc = 1.0 / std::sqrt(t * t + 1.0), ss = t * cc;
+        for (int k = 0; k < 3; k++) { const double a = A[k][p], b = A[k][q]; A[k][p] = cc * a - ss * b; A[k][q] = ss * a + cc * b; }
+        for (int k = 0; k < 3; k++) { const double a = A[p][k], b = A[q][k]; A[p][k] = cc * a - ss * b; A[q][k] = ss * a + cc * b; }
+        for (int k = 0; k < 3; k++) { const double a = U[k][p], b = U[k][q]; U[k][p] = cc * a - ss * b; U[k][q] = ss * a + cc * b; }
+      }
+  }
+  int o[3] = {0, 1, 2};
+  const double e[3] = {A[0][0], A[1][1], A[2][2]};
+  for (int i = 0; i < 2; i++) for (int j = i + 1; j < 3; j++) if (e[o[j]] < e[o[i]]) std::swap(o[i], o[j]);
+  for (int j = 0; j < 3; j++) { ev[j] = e[o[j]]; for (int i = 0; i < 3; i++) V[i * 3 + j] = U[i][o[j]]; }
+}
+
+void rgc_default_fe_params(rgc_fe_params* p) {
+  if (!p) return;
+  p->n_scans = 16; p->min_range = 0.5; p->max_range = 80.0; p->use_intensity = 1;  // launch/run.launch:6,12-13,18
+}
+
+int rgc_frontend(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out) {
+  if (!c || !xyzi || !prm || !out || n < 0) return RGC_ERR_INVALID;
+  if (stride_bytes < 16 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "front-end needs x,y,z,intensity: stride_bytes >= 16");
+  const int NS = prm->n_scans;
+  if (NS != 16 && NS != 32 && NS != 64) return fail(c, RGC_ERR_INVALID, "only 16, 32 or 64 scan lines (scanRegistration.cpp:69-72)");
+  out->n_cloud = out->n_sharp = out->n_sharp_own = out->n_flat = out->n_inten = out->n_ground = 0;
+  out->ground_valid = 0;
+  memset(out->ring_count, 0, sizeof(out->ring_count));
+  if (n == 0) return RGC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int stride_f = stride_bytes / 4;
+  const float* d_in;
+  int rc = stage_in(c, xyzi, n, stride_bytes, 0, &d_in);
+  if (rc) return rc;
+  const int nb = rgck::fe_blocks(n);
+  enum { RING, RANK, HIST, META, ST, CL, INUM2, INUM, RANGE, ANGLE, CURV, CURV2, ICURV, DSRC, OSRC, PICK, IPICK, LAB, ILAB, GMARK, MULT, SCNT,
+         SPOS, PART, OUTD, SLOTS, FLAGS, SHARP, FLAT, INTEN, GLIST, BSUM };
+  const int nu = NS * 6, fcap = nu * 41;
+  const size_t sizes[32] = {4u * n, 4u * n, 4u * 64 * nb, 4u * 132, 4u * 8, 16u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n,
+                            4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 8u * 11 * nb, 8u * 16,
+                            4u * (size_t)nu * rgck::fe_slot_ints(), 4u * 8, 20u * fcap, 20u * fcap, 20u * fcap, 16u * 10 * (size_t)n, 4u * (n / 2048 + 4)};
+  for (int b = 0; b < 32; b++) if ((rc = ensure(c, c->fe[b], sizes[b] + 64))) return rc;
+#define FE(i, T) ((T*)c->fe[i].p)
+  int st_init[8] = {INT_MAX, -1, INT_MAX, 0, 0, 0, 0, 0};
+  memcpy(c->h_small + 32, st_init, sizeof(st_init));
+  HIPCHK(c, hipMemcpyAsync(FE(ST, int), c->h_small + 32, sizeof(st_init), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(FE(FLAGS, int), 0, 32, s));
+  rgck::FeParams fp{NS, prm->min_range, prm->max_range};
+  rgck::fe_filter(s, d_in, stride_f, n, fp, FE(RING, int), FE(ST, int));
+  rgck::fe_half(s, d_in, stride_f, n, FE(RING, int), FE(ST, int));
+  rgck::fe_bucket(s, d_in, stride_f, n, NS, FE(RING, int), FE(RANK, int), FE(HIST, int), FE(META, int), FE(ST, int), FE(CL, float4), FE(INUM2, int));
+  std::vector<int> meta(129);
+  HIPCHK(c, hipMemcpyAsync(meta.data(), FE(META, int), sizeof(int) * 129, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  const int cs = meta[128];
+  out->n_cloud = cs;
+  for (int r = 0; r < NS; r++) out->ring_count[r] = meta[r];
+  if (cs == 0) return RGC_OK;
+  if (out->cloud_cap < cs) return fail(c, RGC_ERR_INVALID, "cloud_cap %d < %d points", out->cloud_cap, cs);
+  for (int b : {PICK, IPICK, LAB, ILAB}) HIPCHK(c, hipMemsetAsync(c->fe[b].p, 0, sizeof(int) * (size_t)cs, s));
+  rgck::fe_stencils(s, FE(CL, float4), cs, FE(RANGE, float), FE(ANGLE, float), FE(INUM2, int), FE(INUM, int), FE(CURV, float), FE(CURV2, float),
+                    FE(ICURV, float), FE(DSRC, float), FE(OSRC, float), FE(PICK, int));
+  // A5: ground set (with multiplicities) -> weighted centroid / covariance -> plane (scanRegistration.cpp:308-431)
+  rgck::fe_ground(s, FE(CL, float4), cs, NS, FE(RANGE, float), FE(META, int), FE(GMARK, int), FE(MULT, int), FE(SCNT, int), FE(PART, double), FE(OUTD, double));
+  double g11[11];
+  HIPCHK(c, hipMemcpyAsync(g11, FE(OUTD, double), sizeof(g11), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  const long long gsize = (long long)(g11[10] + 0.5);
+  if (gsize > 0) {
+    const double W = g11[0];
+    const double ctr[3] = {g11[1] / W, g11[2] / W, g11[3] / W};
+    const double S6[6] = {g11[4] / W - ctr[0] * ctr[0], g11[5] / W - ctr[0] * ctr[1], g11[6] / W - ctr[0] * ctr[2],
+                          g11[7] / W - ctr[1] * ctr[1], g11[8] / W - ctr[1] * ctr[2], g11[9] / W - ctr[2] * ctr[2]};
+    double ev[3], V[9];
+    host_eig3_sym(S6, ev, V);  // ascending like Eigen::SelfAdjointEigenSolver (:371)
+    double nrm[3] = {V[0], V[3], V[6]};
+    const double nl = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    for (int a = 0; a < 3; a++) nrm[a] /= nl;
+    if (ctr[0] * nrm[0] + ctr[1] * nrm[1] + ctr[2] * nrm[2] < 0) for (int a = 0; a < 3; a++) nrm[a] = -nrm[a];  // :374-377
+    rgck::fe_ground_dist(s, FE(CL, float4), cs, FE(MULT, int), ctr, nrm, FE(PART, double), FE(OUTD, double));
+    double d2[2];
+    HIPCHK(c, hipMemcpyAsync(d2, FE(OUTD, double), sizeof(d2), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const double laderH = 0.56;  // :39
+    double distance = d2[1] / d2[0], src1 = d2[0] / (double)gsize;  // :403-404
+    if ((distance / laderH) > 1.1 || (distance / laderH) < 0.9) distance = laderH;  // :405-409
+    if (src1 < 0.9) distance = 0.9 * laderH + 0.1 * distance;                       // :410-413
+    double* g = out->groundparam;  // groundparam.msg order, :420-430
+    g[0] = nrm[0]; g[1] = nrm[1]; g[2] = nrm[2];
+    g[3] = V[1]; g[4] = V[4]; g[5] = V[7];
+    g[6] = V[2]; g[7] = V[5]; g[8] = V[8];
+    g[9] = distance; g[10] = 1 - src1;
+    out->ground_valid = 1;
+    // /laser_cloud_ground: pushes in reference order (with duplicates)
+    rgck::exclusive_scan(s, FE(SCNT, int), FE(SPOS, int), cs, FE(BSUM, int));
+    const int gcap_dev = 10 * n;
+    rgck::fe_ground_list(s, FE(CL, float4), cs, NS, FE(RANGE, float), FE(META, int), FE(SCNT, int), FE(SPOS, int), FE(GLIST, float4), gcap_dev);
+    out->n_ground = (int)gsize;
+    if (out->ground_pts && out->ground_cap > 0) {
+      const long long m = gsize < out->ground_cap ? gsize : out->ground_cap;
+      HIPCHK(c, hipMemcpyAsync(out->ground_pts, FE(GLIST, float4), sizeof(float) * 4 * (size_t)m, hipMemcpyDeviceToHost, s));
+    }
+  }
+  // A7 + A8
+  rgck::fe_select(s, FE(CL, float4), NS, FE(META, int), FE(CURV, float), FE(CURV2, float), FE(ICURV, float), FE(INUM, int), FE(GMARK, int),
+                  FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), FE(FLAGS, int));
+  rgck::fe_emit(s, FE(CL, float4), NS, FE(SLOTS, int), FE(DSRC, float), FE(OSRC, float), FE(SHARP, float), FE(FLAT, float), FE(INTEN, float), fcap,
+                FE(FLAGS, int) + 4);
+  int fl[8];
+  HIPCHK(c, hipMemcpyAsync(fl, FE(FLAGS, int), sizeof(fl), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(out->cloud, FE(CL, float4), sizeof(float) * 4 * (size_t)cs, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (fl[0] & 2) return fail(c, RGC_ERR_INVALID, "a ring sector holds more than 2048 points");
+  const int ns = fl[4], nf = fl[5], ni = fl[6];
+  out->n_sharp_own = ns; out->n_flat = nf; out->n_inten = ni;
+  const bool add_inten = prm->use_intensity && ((double)ns / (double)nf < 0.3);  // :645-656
+  out->n_sharp = ns + (add_inten ? ni : 0);
+  if (out->feat_cap < out->n_sharp || out->feat_cap < nf || out->feat_cap < ni) return fail(c, RGC_ERR_INVALID, "feat_cap too small");
+  if (ns) HIPCHK(c, hipMemcpyAsync(out->sharp, FE(SHARP, float), 20u * (size_t)ns, hipMemcpyDeviceToHost, s));
+  if (nf) HIPCHK(c, hipMemcpyAsync(out->flat, FE(FLAT, float), 20u * (size_t)nf, hipMemcpyDeviceToHost, s));
+  if (ni) HIPCHK(c, hipMemcpyAsync(out->inten, FE(INTEN, float), 20u * (size_t)ni, hipMemcpyDeviceToHost, s));
+  if (add_inten && ni) HIPCHK(c, hipMemcpyAsync(out->sharp + 5 * (size_t)ns, FE(INTEN, float), 20u * (size_t)ni, hipMemcpyDeviceToHost, s));
+  const struct { void* dst; int src; } diag[7] = {{out->curvature, CURV}, {out->curvature2, CURV2}, {out->inten_curvature, ICURV}, {out->label, LAB},
+                                                   {out->inten_label, ILAB}, {out->picked, PICK}, {out->ground_marked, GMARK}};
+  for (auto& d : diag) if (d.dst) HIPCHK(c, hipMemcpyAsync(d.dst, c->fe[d.src].p, 4u * (size_t)cs, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+#undef FE
   return RGC_OK;
 }
 

@@ -1,0 +1,553 @@
+// rgc_frontend.hip -- gfx950 kernels of the scan feature + ground front-end:
+// ScanRegistration::laserCloudHandler, /root/reference/rgc_slam/src/scanRegistration.cpp:89-730.
+// The reference is one sequential callback; here every stage is data-parallel except the greedy per-sector pick
+// (one lane per ring, after a cooperative LDS bitonic sort of each sector).
+//
+// fp32 stencils keep the reference's left-to-right association (compiled with -ffp-contract=off) so curvatures,
+// hence labels, are bit-identical to the CPU path.  Documented clean-ups of reference quirks: SURVEY A.8 and
+// oracle/rgc_oracle_aux.c (per-frame zero-initialised state, sort ties by index, no 30000-point cap).
+#include <limits.h>
+
+#include "rgc_kernels.h"
+
+namespace rgck {
+
+constexpr int WAVE = 64;
+constexpr int FE_T = 256;
+
+__device__ __forceinline__ double fe_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+
+// ---- A1 + A2a: validity, ring id (:111-113, :141-183, :732-763) ----
+__device__ __forceinline__ int ring_of(float x, float y, float z, int NS) {
+  const float verticalAngle = (float)(atanf(z / sqrtf(x * x + y * y)) * 180 / M_PI);
+  int scanID;
+  if (NS == 16) {
+    scanID = (int)((verticalAngle + 15) / 2 + 0.5);
+    if (scanID > (NS - 1) || scanID < 0) return -1;
+  } else if (NS == 32) {
+    scanID = (int)((verticalAngle + 92.0 / 3.0) * 3.0 / 4.0);
+    if (scanID > (NS - 1) || scanID < 0) return -1;
+  } else {
+    if (verticalAngle >= -8.83) scanID = (int)((2 - verticalAngle) * 3.0 + 0.5);
+    else scanID = NS / 2 + (int)((-8.83 - verticalAngle) * 2.0 + 0.5);
+    if (verticalAngle > 2 || verticalAngle < -24.33 || scanID > 50 || scanID < 0) return -1;
+  }
+  return scanID;
+}
+
+// ring[i] = -2: dropped by the NaN / range / self filter; -1: kept by them but outside the sensor's rings; >= 0: ring
+// st[0] = first kept index, st[1] = last kept index
+__global__ void k_fe_filter(const float* __restrict__ in, int stride_f, int n, FeParams p, int* __restrict__ ring, int* st) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* q = in + (size_t)i * stride_f;
+  const float x = q[0], y = q[1], z = q[2];
+  int r = -2;
+  if (isfinite(x) && isfinite(y) && isfinite(z)) {
+    const float dis = x * x + y * y + z * z;
+    const float th1 = (float)p.min_range, th2 = (float)p.max_range;
+    if (!(dis < th1 * th1) && !(dis > th2 * th2) && !(x < 0 && fabsf(y) < 0.5)) {
+      r = ring_of(x, y, z, p.n_scans);
+      atomicMin(&st[0], i);
+      atomicMax(&st[1], i);
+    }
+  }
+  ring[i] = r;
+}
+
+__device__ __forceinline__ void start_end_ori(const float* __restrict__ in, int stride_f, const int* st, float& startOri, float& endOri) {
+  const float* a = in + (size_t)st[0] * stride_f;
+  const float* b = in + (size_t)st[1] * stride_f;
+  startOri = -atan2f(a[1], a[0]);                                   // :117
+  endOri = (float)(-atan2f(b[1], b[0]) + 2 * M_PI);                 // :118
+  if (endOri - startOri > 3 * M_PI) endOri -= 2 * M_PI;             // :120-127
+  else if (endOri - startOri < M_PI) endOri += 2 * M_PI;
+}
+
+// A2b: halfPassed becomes true AFTER the first ring-valid point whose (unwrapped) ori - startOri exceeds pi (:186-194):
+// a prefix-OR, i.e. the minimum index satisfying the condition.  st[2] = that index (INT_MAX if none).
+__global__ void k_fe_half(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ ring, int* st) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || ring[i] < 0) return;
+  float startOri, endOri;
+  start_end_ori(in, stride_f, st, startOri, endOri);
+  const float* q = in + (size_t)i * stride_f;
+  float ori = -atan2f(q[1], q[0]);
+  if (ori < startOri - M_PI / 2) ori += 2 * M_PI;
+  else if (ori > startOri + M_PI * 3 / 2) ori -= 2 * M_PI;
+  if (ori - startOri > M_PI) atomicMin(&st[2], i);
+}
+
+// A2c: stable bucket by ring (:206-230).  Pass 1: rank of each point among the same-ring points of its block and the
+// block's per-ring histogram.
+__global__ void __launch_bounds__(FE_T) k_fe_rank(int n, const int* __restrict__ ring, int* __restrict__ rank_in_block, int* __restrict__ blk_hist) {
+  __shared__ int hist[FE_T / WAVE][64];
+  const int i = blockIdx.x * FE_T + threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  for (int t = threadIdx.x; t < (FE_T / WAVE) * 64; t += FE_T) (&hist[0][0])[t] = 0;
+  __syncthreads();
+  const int r = i < n ? ring[i] : -1;
+  int rk = 0;
+  unsigned long long todo = __ballot(r >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int rr = __shfl(r, leader);
+    const unsigned long long mask = __ballot(r == rr);
+    if (r == rr) rk = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == leader) hist[w][rr] = __popcll(mask);
+    todo &= ~mask;
+  }
+  __syncthreads();
+  if (r >= 0) {
+    for (int j = 0; j < w; j++) rk += hist[j][r];
+    rank_in_block[i] = rk;
+  }
+  if (threadIdx.x < 64) {
+    int s = 0;
+    for (int j = 0; j < FE_T / WAVE; j++) s += hist[j][threadIdx.x];
+    blk_hist[(size_t)blockIdx.x * 64 + threadIdx.x] = s;
+  }
+}
+
+// pass 2 (one block): exclusive prefix of the block histograms per ring, ring counts and ring starts.
+// meta: [0..63] ring_count, [64..128] ring_start (65 entries)
+__global__ void __launch_bounds__(64) k_fe_hist_scan(int nblocks, int NS, int* __restrict__ blk_hist, int* __restrict__ meta) {
+  __shared__ int cnt[64];
+  const int r = threadIdx.x;
+  int s = 0;
+  for (int b = 0; b < nblocks; b++) {
+    const int v = blk_hist[(size_t)b * 64 + r];
+    blk_hist[(size_t)b * 64 + r] = s;
+    s += v;
+  }
+  cnt[r] = r < NS ? s : 0;
+  meta[r] = cnt[r];
+  __syncthreads();
+  if (r == 0) {
+    int a = 0;
+    for (int j = 0; j < 64; j++) { meta[64 + j] = a; a += cnt[j]; }
+    meta[128] = a;
+  }
+}
+
+// pass 3: scatter into the ring-major cloud with intensity = ring + 0.1 * relTime (:196-213)
+__global__ void k_fe_scatter(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ ring, const int* __restrict__ rank_in_block,
+                             const int* __restrict__ blk_hist, const int* __restrict__ meta, const int* __restrict__ st,
+                             float4* __restrict__ C, int* __restrict__ inum2) {
+  const int i = blockIdx.x * FE_T + threadIdx.x;
+  if (i >= n) return;
+  const int r = ring[i];
+  if (r < 0) return;
+  float startOri, endOri;
+  start_end_ori(in, stride_f, st, startOri, endOri);
+  const float* q = in + (size_t)i * stride_f;
+  float ori = -atan2f(q[1], q[0]);
+  if (i <= st[2]) {  // !halfPassed (the point that flips the flag is still processed by this branch)
+    if (ori < startOri - M_PI / 2) ori += 2 * M_PI;
+    else if (ori > startOri + M_PI * 3 / 2) ori -= 2 * M_PI;
+  } else {
+    ori += 2 * M_PI;
+    if (ori < endOri - M_PI * 3 / 2) ori += 2 * M_PI;
+    else if (ori > endOri + M_PI / 2) ori -= 2 * M_PI;
+  }
+  const float relTime = (ori - startOri) / (endOri - startOri);
+  const int d = meta[64 + r] + blk_hist[(size_t)blockIdx.x * 64 + r] + rank_in_block[i];
+  C[d] = make_float4(q[0], q[1], q[2], (float)(r + 0.1 * relTime));  // scanPeriod = 0.1, :35
+  inum2[d] = stride_f > 3 ? (int)q[3] : 0;                             // int point_intensity, :132,140
+}
+
+// ---- A3: range, incidence angle (:234-255) ----
+__global__ void k_fe_range_angle(const float4* __restrict__ C, int cs, float* __restrict__ range_vec, float* __restrict__ scan_angle) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cs) return;
+  const float4 p4 = C[i];
+  const float rg = sqrtf(p4.x * p4.x + p4.y * p4.y + p4.z * p4.z);
+  range_vec[i] = rg;
+  float sa = 0.f;  // zero-initialised per frame (the reference leaks earlier frames' values here)
+  if (i >= 5 && i < cs - 5 && rg < 2) {
+    const float4 a4 = C[i + 5], b4 = C[i - 5];
+    const double a[3] = {a4.x, a4.y, a4.z}, b[3] = {b4.x, b4.y, b4.z}, p[3] = {p4.x, p4.y, p4.z};
+    const double c[3] = {(a[0] + b[0]) / 2, (a[1] + b[1]) / 2, (a[2] + b[2]) / 2};
+    const double u[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}, v[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+    const double nrm[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+    const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]), pn = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    sa = (float)((nrm[0] * p[0] + nrm[1] * p[1] + nrm[2] * p[2]) / (nn * pn));
+    if (sa < 0) sa = -sa;
+  }
+  scan_angle[i] = sa;
+}
+
+// near-range intensity smoothing on the int intensities, truncating on every store like the deque<int> (:257-268)
+__global__ void k_fe_smooth(int cs, const float* __restrict__ range_vec, const float* __restrict__ scan_angle, const int* __restrict__ inum2,
+                            int* __restrict__ inum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cs) return;
+  int v = inum2[i];
+  if (i >= 5 && i < cs - 5 && scan_angle[i] < 0.07 && range_vec[i] < 2) {
+    v = (int)(0.9 * inum2[i]);
+    for (int j = -5; j < 6; j++)
+      if (j != 0) v = (int)(v + 0.005 * inum2[i + j]);
+  }
+  inum[i] = v;
+}
+
+// ---- A4: curvature stencils (:270-306) ----
+__global__ void k_fe_curv(const float4* __restrict__ C, int cs, const float* __restrict__ range_vec, const float* __restrict__ scan_angle,
+                          const int* __restrict__ inum, float* __restrict__ curv, float* __restrict__ curv2, float* __restrict__ icurv,
+                          float* __restrict__ dsrc, float* __restrict__ osrc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cs) return;
+  float cv = 0.f, cv2 = 0.f, icv = 0.f, ds = 0.f, os = 0.f;
+  if (i >= 5 && i < cs - 5) {
+    float4 c = C[i - 5];
+    float dX = c.x, dY = c.y, dZ = c.z;
+#pragma unroll
+    for (int k = -4; k <= -1; k++) { c = C[i + k]; dX = dX + c.x; dY = dY + c.y; dZ = dZ + c.z; }
+    c = C[i];
+    dX = dX - 10 * c.x; dY = dY - 10 * c.y; dZ = dZ - 10 * c.z;
+#pragma unroll
+    for (int k = 1; k <= 5; k++) { c = C[i + k]; dX = dX + c.x; dY = dY + c.y; dZ = dZ + c.z; }
+    const int dIi = inum[i - 5] + inum[i - 4] + inum[i - 3] + inum[i - 2] + inum[i - 1] - 10 * inum[i] + inum[i + 1] + inum[i + 2] +
+                    inum[i + 3] + inum[i + 4] + inum[i + 5];
+    const float diffI = (float)dIi;
+    float dis_factor = (float)(2.0 / (1.0 + range_vec[i] / 20.0));
+    if (dis_factor < 0.2) dis_factor = 0.2f;
+    cv = (dX * dX + dY * dY + dZ * dZ) * dis_factor;
+    ds = (float)(0.5 + dis_factor);
+    if (scan_angle[i] < 0.07 && range_vec[i] < 2) {
+      os = (float)(scan_angle[i] * 10 + 0.6);
+      icv = (float)((scan_angle[i] + 0.3) * diffI);
+    } else {
+      os = 3;
+      icv = diffI;
+    }
+    const float dr = (float)(range_vec[i - 5] + range_vec[i - 4] + range_vec[i - 3] + range_vec[i - 2] + range_vec[i - 1] - 10.0 * range_vec[i] +
+                             range_vec[i + 1] + range_vec[i + 2] + range_vec[i + 3] + range_vec[i + 4] + range_vec[i + 5]);
+    cv2 = fabsf(dr * dis_factor);
+  }
+  curv[i] = cv; curv2[i] = cv2; icurv[i] = icv; dsrc[i] = ds; osrc[i] = os;
+}
+
+// ---- A6: occlusion / parallel-beam mask (:433-456); picked[] zeroed before ----
+__global__ void k_fe_occlusion(int cs, const float* __restrict__ range_vec, int* __restrict__ picked) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 5 || i >= cs - 5) return;
+  const float d1 = range_vec[i], d2 = range_vec[i + 1];
+  if (d1 - d2 > 0.04 * d2) {
+    for (int k = -5; k <= 0; k++) picked[i + k] = 1;
+  } else if (d2 - d1 > 0.04 * d1) {
+    for (int k = 1; k <= 6; k++) if (i + k < cs) picked[i + k] = 1;
+  }
+}
+
+// ---- A5: ground marking (:308-353) ----
+__device__ __forceinline__ int ring_of_index(const int* __restrict__ meta, int NS, int i) {  // meta[64..] ring starts
+  int r = 0;
+  for (int j = 1; j < NS; j++) r += (meta[64 + j] <= i);
+  return r;
+}
+__constant__ float kGroundScanRange[16] = {2.66f, 3.04f, 3.56f, 4.30f, 5.44f, 7.41f, 11.63f, 27.12f, 0, 0, 0, 0, 0, 0, 0, 0};  // :40
+
+__device__ __forceinline__ bool ground_seed(const float4* __restrict__ C, const float* __restrict__ range_vec, const int* __restrict__ meta,
+                                            int ring, int c) {
+  const int s0 = meta[64 + ring], sz = meta[ring];
+  const int col = c - s0;
+  if (sz < 11 || col < 5 || col >= sz - 5) return false;
+  const float th = (float)(0.8 * (1.0 + ring / 6));  // integer division, :323
+  const float dr = fabsf(range_vec[c] - kGroundScanRange[ring]);
+  return dr < th && C[c].z < 0.3;
+}
+
+// mult[j] = how many times point j is pushed into the ground set (seed c = j - n, n in [-5, 4]); seedcnt[c] = pushes
+// made by seed c (for the ordered ground list).  acc: block partial sums {W, Wx, Wy, Wz, Wxx, Wxy, Wxz, Wyy, Wyz, Wzz, count}
+__global__ void __launch_bounds__(FE_T)
+k_fe_ground(const float4* __restrict__ C, int cs, int NS, const float* __restrict__ range_vec, const int* __restrict__ meta,
+            int* __restrict__ gmark, int* __restrict__ mult_out, int* __restrict__ seedcnt, double* __restrict__ partials) {
+  const int j = blockIdx.x * FE_T + threadIdx.x;
+  double acc[11];
+#pragma unroll
+  for (int a = 0; a < 11; a++) acc[a] = 0.0;
+  int mult = 0, sc = 0;
+  const int gend = meta[64 + (NS < 7 ? NS : 7)];  // rings 0..6 only (groundScanInd = 7, :34)
+  if (j < cs && j < gend) {
+    const int ring = ring_of_index(meta, NS, j);
+    const float th = (float)(0.8 * (1.0 + ring / 6));
+    const float rj = range_vec[j];
+    for (int nn = -5; nn < 5; nn++) {       // j = c + nn
+      const int c = j - nn;
+      if (c < 0 || c >= cs) continue;
+      if (ground_seed(C, range_vec, meta, ring, c) && fabsf(rj - range_vec[c]) < th / 2) mult++;
+    }
+    if (ground_seed(C, range_vec, meta, ring, j)) {
+      for (int nn = -5; nn < 5; nn++)
+        if (fabsf(range_vec[j + nn] - rj) < th / 2) sc++;
+    }
+    if (mult > 0) {
+      const double w = (1.5 - ring / 6) * (double)mult;  // groundweight, :325
+      const float4 p = C[j];
+      const double x = p.x, y = p.y, z = p.z;
+      acc[0] = w; acc[1] = w * x; acc[2] = w * y; acc[3] = w * z;
+      acc[4] = w * x * x; acc[5] = w * x * y; acc[6] = w * x * z; acc[7] = w * y * y; acc[8] = w * y * z; acc[9] = w * z * z;
+      acc[10] = (double)mult;
+    }
+  }
+  if (j < cs) { gmark[j] = mult > 0 ? 1 : 0; mult_out[j] = mult; seedcnt[j] = sc; }
+  __shared__ double red[FE_T / WAVE][11];
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+  for (int a = 0; a < 11; a++) {
+    const double v = fe_wave_sum(acc[a]);
+    if (lane == 0) red[w][a] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 11) {
+    double s = 0;
+    for (int t = 0; t < FE_T / WAVE; t++) s += red[t][threadIdx.x];
+    partials[(size_t)blockIdx.x * 11 + threadIdx.x] = s;
+  }
+}
+
+// distance pass (:386-402): sums {sum dw, sum dw * n.p} with multiplicity
+__global__ void __launch_bounds__(FE_T)
+k_fe_ground_dist(const float4* __restrict__ C, int cs, const int* __restrict__ mult, double cx, double cy, double cz, double nx, double ny,
+                 double nz, double* __restrict__ partials) {
+  const int j = blockIdx.x * FE_T + threadIdx.x;
+  double a0 = 0, a1 = 0;
+  if (j < cs && mult[j] > 0) {
+    const float4 p = C[j];
+    const double d[3] = {(double)p.x - cx, (double)p.y - cy, (double)p.z - cz};
+    const double dl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    double dw = dl == 0 ? 1.0 : 1 - 100 * fabs((nx * d[0] + ny * d[1] + nz * d[2]) / dl);
+    if (dw < 0) dw = 0.1;
+    a0 = dw * mult[j];
+    a1 = dw * mult[j] * (nx * (double)p.x + ny * (double)p.y + nz * (double)p.z);
+  }
+  __shared__ double red[FE_T / WAVE][2];
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  a0 = fe_wave_sum(a0); a1 = fe_wave_sum(a1);
+  if (lane == 0) { red[w][0] = a0; red[w][1] = a1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double s = 0;
+    for (int t = 0; t < FE_T / WAVE; t++) s += red[t][threadIdx.x];
+    partials[(size_t)blockIdx.x * 2 + threadIdx.x] = s;
+  }
+}
+
+// fixed-order fold of per-block rows (deterministic)
+__global__ void __launch_bounds__(WAVE) k_fe_fold(const double* __restrict__ partials, int nrows, int ncols, double* __restrict__ out) {
+  const int a = blockIdx.x, lane = threadIdx.x;
+  double s = 0;
+  for (int r = lane; r < nrows; r += WAVE) s += partials[(size_t)r * ncols + a];
+  s = fe_wave_sum(s);
+  if (lane == 0) out[a] = s;
+}
+
+// ground points with duplicates in the reference's push order (/laser_cloud_ground, :336)
+__global__ void k_fe_ground_list(const float4* __restrict__ C, int cs, int NS, const float* __restrict__ range_vec, const int* __restrict__ meta,
+                                 const int* __restrict__ seedcnt, const int* __restrict__ seedpos, float4* __restrict__ out, int cap) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cs || seedcnt[c] == 0) return;
+  const int ring = ring_of_index(meta, NS, c);
+  const float th = (float)(0.8 * (1.0 + ring / 6));
+  int pos = seedpos[c];
+  const float rc = range_vec[c];
+  for (int nn = -5; nn < 5; nn++) {
+    if (fabsf(range_vec[c + nn] - rc) < th / 2) {
+      if (pos < cap) out[pos] = C[c + nn];
+      pos++;
+    }
+  }
+}
+
+// ---- A7: per ring, six sectors: sort by curvature / intensity curvature, greedy pick with +-5 suppression (:469-644) ----
+constexpr int SEC_MAX = 2048;   // points per sector (ring of <= 12288 points)
+constexpr int SEL_T = 256;
+
+struct Key { float v; int i; };
+__device__ __forceinline__ bool key_less(const Key& a, const Key& b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
+
+__device__ void bitonic_sort(Key* k, int n2) {  // ascending by (value, index); n2 power of two; whole block
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < n2 / 2; t += SEL_T) {
+        const int lo = (t / stride) * (stride * 2) + (t % stride), hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const Key a = k[lo], b = k[hi];
+        if (key_less(b, a) == up) { k[lo] = b; k[hi] = a; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float sq_gap(const float4* __restrict__ C, int l, int m) {
+  const float4 a = C[l], b = C[m];
+  const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// slots: per (ring, sector): sharp 20, flat 40, inten 20 indices + 3 counts (83 ints)
+constexpr int SLOT = 83;
+
+__global__ void __launch_bounds__(SEL_T)
+k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, const float* __restrict__ curv, const float* __restrict__ curv2,
+            const float* __restrict__ icurv, const int* __restrict__ inum, const int* __restrict__ gmark, int* __restrict__ picked,
+            int* __restrict__ ipicked, int* __restrict__ label, int* __restrict__ ilabel, int* __restrict__ slots, int* flags) {
+  __shared__ Key ks[SEC_MAX];
+  __shared__ Key ki[SEC_MAX];
+  const int ring = blockIdx.x;
+  const int S = meta[64 + ring] + 5, E = meta[64 + ring + 1] - 5;  // scanStartInd / scanEndInd, :223,229
+  for (int j = 0; j < 6; j++) {
+    int* sl = slots + ((size_t)ring * 6 + j) * SLOT;
+    if (threadIdx.x < 3) sl[80 + threadIdx.x] = 0;
+  }
+  if (E - S < 10) return;  // :471
+  for (int j = 0; j < 6; j++) {
+    const int sp = S + (E - S) * j / 6, ep = S + (E - S) * (j + 1) / 6 - 1;  // :478-480
+    const int cnt = ep - sp + 1;
+    if (cnt > SEC_MAX) { if (threadIdx.x == 0) atomicOr(flags, 2); return; }
+    int n2 = 1;
+    while (n2 < cnt) n2 <<= 1;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n2; t += SEL_T) {
+      if (t < cnt) { ks[t] = Key{curv[sp + t], sp + t}; ki[t] = Key{icurv[sp + t], sp + t}; }
+      else { ks[t] = Key{INFINITY, INT_MAX}; ki[t] = Key{INFINITY, INT_MAX}; }
+    }
+    bitonic_sort(ks, n2);
+    bitonic_sort(ki, n2);
+    if (threadIdx.x == 0) {
+      int* sl = slots + ((size_t)ring * 6 + j) * SLOT;
+      int largest = 0, nsh = 0;
+      for (int k = cnt - 1; k >= 0; k--) {  // :487-536
+        const int ind = ks[k].i;
+        if (picked[ind] == 0 && gmark[ind] != 1 && curv[ind] > 0.1 && curv2[ind] > 0.3) {
+          largest++;
+          if (largest <= 20) { label[ind] = 2; sl[nsh++] = ind; }
+          else if (largest <= 21) { label[ind] = 1; }
+          else break;
+          picked[ind] = 1;
+          for (int l = 1; l <= 5; l++) { if (sq_gap(C, ind + l, ind + l - 1) > 0.05) break; picked[ind + l] = 1; }
+          for (int l = -1; l >= -5; l--) { if (sq_gap(C, ind + l, ind + l + 1) > 0.05) break; picked[ind + l] = 1; }
+        }
+      }
+      int smallest = 0, nfl = 0;
+      for (int k = 0; k < cnt; k++) {  // :540-583
+        const int ind = ks[k].i;
+        if (picked[ind] == 0 && curv[ind] < 0.3 && curv2[ind] < 0.4) {
+          smallest++;
+          if (smallest <= 40) { label[ind] = -1; sl[20 + nfl++] = ind; }
+          else break;
+          picked[ind] = 1;
+          for (int l = 1; l <= 5; l++) { if (sq_gap(C, ind + l, ind + l - 1) > 0.05) break; picked[ind + l] = 1; }
+          for (int l = -1; l >= -5; l--) { if (sq_gap(C, ind + l, ind + l + 1) > 0.05) break; picked[ind + l] = 1; }
+        }
+      }
+      int largest2 = 0, nin = 0;
+      for (int k = cnt - 1; k >= 0; k--) {  // :594-641
+        const int ind = ki[k].i;
+        if (ipicked[ind] == 0 && gmark[ind] != 1 && icurv[ind] > 65 && label[ind] != 2 && label[ind] != 1) {
+          largest2++;
+          if (largest2 <= 20) { ilabel[ind] = 2; sl[60 + nin++] = ind; }
+          else if (largest2 <= 21) { ilabel[ind] = 1; }
+          else break;
+          ipicked[ind] = 1;
+          for (int l = 1; l <= 5; l++) { if (fabsf((float)(inum[ind + l] - inum[ind + l - 1])) > 35) break; ipicked[ind + l] = 1; }
+          for (int l = -1; l >= -5; l--) { if (fabsf((float)(inum[ind + l] - inum[ind + l + 1])) > 35) break; ipicked[ind + l] = 1; }
+        }
+      }
+      sl[80] = nsh; sl[81] = nfl; sl[82] = nin;
+    }
+    __syncthreads();
+  }
+}
+
+// A8: emit the feature clouds in the reference's order (ring, sector, pick order): x,y,z,intensity,normal_x weight.
+// counts: [0] sharp (own), [1] flat, [2] inten
+__global__ void __launch_bounds__(512) k_fe_emit(const float4* __restrict__ C, int NS, const int* __restrict__ slots, const float* __restrict__ dsrc,
+                                                 const float* __restrict__ osrc, float* __restrict__ sharp, float* __restrict__ flat,
+                                                 float* __restrict__ inten, int cap, int* __restrict__ counts) {
+  __shared__ int off[3][385];
+  const int nu = NS * 6, u = threadIdx.x;
+  if (u == 0) {
+    int a = 0, b = 0, c = 0;
+    for (int t = 0; t < nu; t++) {
+      off[0][t] = a; off[1][t] = b; off[2][t] = c;
+      a += slots[(size_t)t * SLOT + 80]; b += slots[(size_t)t * SLOT + 81]; c += slots[(size_t)t * SLOT + 82];
+    }
+    counts[0] = a; counts[1] = b; counts[2] = c;
+  }
+  __syncthreads();
+  if (u >= nu) return;
+  const int* sl = slots + (size_t)u * SLOT;
+  for (int k = 0; k < sl[80]; k++) {
+    const int ind = sl[k], d = off[0][u] + k;
+    if (d < cap) { const float4 p = C[ind]; float* f = sharp + (size_t)d * 5; f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w; f[4] = dsrc[ind] + 1; }  // :501
+  }
+  for (int k = 0; k < sl[81]; k++) {
+    const int ind = sl[20 + k], d = off[1][u] + k;
+    if (d < cap) { const float4 p = C[ind]; float* f = flat + (size_t)d * 5; f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w; f[4] = dsrc[ind]; }       // :554
+  }
+  for (int k = 0; k < sl[82]; k++) {
+    const int ind = sl[60 + k], d = off[2][u] + k;
+    if (d < cap) { const float4 p = C[ind]; float* f = inten + (size_t)d * 5; f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w; f[4] = osrc[ind]; }      // :609
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline int nblk(long long n, int t) { return (int)((n + t - 1) / t); }
+
+int fe_blocks(int n) { return nblk(n, FE_T); }
+int fe_slot_ints() { return SLOT; }
+
+void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st) {
+  hipLaunchKernelGGL(k_fe_filter, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, in, stride_f, n, p, ring, st);
+}
+void fe_half(hipStream_t s, const float* in, int stride_f, int n, const int* ring, int* st) {
+  hipLaunchKernelGGL(k_fe_half, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, in, stride_f, n, ring, st);
+}
+void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, const int* ring, int* rank_in_block, int* blk_hist, int* meta,
+               const int* st, float4* C, int* inum2) {
+  const int nb = nblk(n, FE_T);
+  hipLaunchKernelGGL(k_fe_rank, dim3(nb), dim3(FE_T), 0, s, n, ring, rank_in_block, blk_hist);
+  hipLaunchKernelGGL(k_fe_hist_scan, dim3(1), dim3(64), 0, s, nb, NS, blk_hist, meta);
+  hipLaunchKernelGGL(k_fe_scatter, dim3(nb), dim3(FE_T), 0, s, in, stride_f, n, ring, rank_in_block, blk_hist, meta, st, C, inum2);
+}
+void fe_stencils(hipStream_t s, const float4* C, int cs, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
+                 float* curv2, float* icurv, float* dsrc, float* osrc, int* picked) {
+  const int nb = nblk(cs, FE_T);
+  hipLaunchKernelGGL(k_fe_range_angle, dim3(nb), dim3(FE_T), 0, s, C, cs, range_vec, scan_angle);
+  hipLaunchKernelGGL(k_fe_smooth, dim3(nb), dim3(FE_T), 0, s, cs, range_vec, scan_angle, inum2, inum);
+  hipLaunchKernelGGL(k_fe_curv, dim3(nb), dim3(FE_T), 0, s, C, cs, range_vec, scan_angle, inum, curv, curv2, icurv, dsrc, osrc);
+  hipLaunchKernelGGL(k_fe_occlusion, dim3(nb), dim3(FE_T), 0, s, cs, range_vec, picked);
+}
+void fe_ground(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
+               double* partials, double* out11) {
+  const int nb = nblk(cs, FE_T);
+  hipLaunchKernelGGL(k_fe_ground, dim3(nb), dim3(FE_T), 0, s, C, cs, NS, range_vec, meta, gmark, mult, seedcnt, partials);
+  hipLaunchKernelGGL(k_fe_fold, dim3(11), dim3(WAVE), 0, s, partials, nb, 11, out11);
+}
+void fe_ground_dist(hipStream_t s, const float4* C, int cs, const int* mult, const double c[3], const double nrm[3], double* partials, double* out2) {
+  const int nb = nblk(cs, FE_T);
+  hipLaunchKernelGGL(k_fe_ground_dist, dim3(nb), dim3(FE_T), 0, s, C, cs, mult, c[0], c[1], c[2], nrm[0], nrm[1], nrm[2], partials);
+  hipLaunchKernelGGL(k_fe_fold, dim3(2), dim3(WAVE), 0, s, partials, nb, 2, out2);
+}
+void fe_ground_list(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, const int* seedcnt,
+                    const int* seedpos, float4* out, int cap) {
+  hipLaunchKernelGGL(k_fe_ground_list, dim3(nblk(cs, FE_T)), dim3(FE_T), 0, s, C, cs, NS, range_vec, meta, seedcnt, seedpos, out, cap);
+}
+void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const float* curv, const float* curv2, const float* icurv, const int* inum,
+               const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags) {
+  hipLaunchKernelGGL(k_fe_select, dim3(NS), dim3(SEL_T), 0, s, C, NS, meta, curv, curv2, icurv, inum, gmark, picked, ipicked, label, ilabel, slots, flags);
+}
+void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const float* dsrc, const float* osrc, float* sharp, float* flat, float* inten,
+             int cap, int* counts) {
+  hipLaunchKernelGGL(k_fe_emit, dim3(1), dim3(512), 0, s, C, NS, slots, dsrc, osrc, sharp, flat, inten, cap, counts);
+}
+
+}  // namespace rgck

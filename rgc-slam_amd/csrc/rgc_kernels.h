@@ -23,6 +23,7 @@ struct PoseF {  // fp32 4x4 rows 0..2 (pcl::transformPointCloud in the reference
 };
 
 struct Quat { double x, y, z, w; };
+struct FeParams { int n_scans; double min_range, max_range; };
 struct LeafGrid { int minb[3]; int div[3]; };  // pcl::VoxelGrid leaf grid
 
 constexpr int kAccum = 28;  // 21 upper-triangular H + 6 b + 1 cost
@@ -71,5 +72,24 @@ void vg_count(hipStream_t s, const float* in, int stride_f, int n, float inv, Le
 void vg_rank(hipStream_t s, int n, const int* cell_of, const int* start, const int* order_tmp, int* order, int* first);
 void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start, const int* order,
                  const int* first, const int* outpos, float* out, int* n_out);
+
+// ---- A1-A8 front-end (rgc_frontend.hip) ----
+int fe_blocks(int n);
+int fe_slot_ints();
+void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st);
+void fe_half(hipStream_t s, const float* in, int stride_f, int n, const int* ring, int* st);
+void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, const int* ring, int* rank_in_block, int* blk_hist, int* meta,
+               const int* st, float4* C, int* inum2);
+void fe_stencils(hipStream_t s, const float4* C, int cs, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
+                 float* curv2, float* icurv, float* dsrc, float* osrc, int* picked);
+void fe_ground(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
+               double* partials, double* out11);
+void fe_ground_dist(hipStream_t s, const float4* C, int cs, const int* mult, const double c[3], const double nrm[3], double* partials, double* out2);
+void fe_ground_list(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, const int* seedcnt,
+                    const int* seedpos, float4* out, int cap);
+void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const float* curv, const float* curv2, const float* icurv, const int* inum,
+               const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags);
+void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const float* dsrc, const float* osrc, float* sharp, float* flat, float* inten,
+             int cap, int* counts);
 
 }  // namespace rgck

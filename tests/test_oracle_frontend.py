@@ -1,0 +1,50 @@
+"""Oracle front-end (oracle/rgc_oracle_aux.c: orc_frontend) pinned by properties of the synthetic sensor model whose
+ground truth is known (ring ids, rel-time, ground plane), since the reference holds no fixtures for it.  CPU only."""
+import numpy as np
+
+
+def _scan(n_az=900, seed=1):
+    import rgc_slam_amd.synth as synth
+    w = synth.make_world(half_extent=50.0, seed=synth.SEED)
+    sc = synth.make_scan(w, np.eye(4), n_az=n_az, seed=synth.SEED + seed)
+    raw = np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32)
+    return raw, sc
+
+
+def test_ring_and_reltime(orc):
+    raw, sc = _scan()
+    o = orc.frontend(raw)
+    assert o["n_cloud"] == len(raw)                                           # generator already applies the range / self filter
+    assert np.array_equal(o["ring_count"], np.bincount(sc["ring"], minlength=16))
+    # stable bucket: ring-major, firing order inside a ring
+    order = np.argsort(sc["ring"], kind="stable")
+    assert np.array_equal(o["cloud"][:, :3], raw[order, :3])
+    enc = o["cloud"][:, 3]
+    assert np.array_equal(np.floor(enc).astype(int), sc["ring"][order])
+    rel = (enc - np.floor(enc)) / 0.1
+    assert np.abs(rel - sc["rel_time"][order]).max() < 2e-3                  # relTime from azimuth, scanRegistration.cpp:206
+
+
+def test_ground_plane_and_caps(orc):
+    raw, _ = _scan(n_az=1800, seed=4)
+    o = orc.frontend(raw)
+    g = o["groundparam"]
+    assert o["ground_valid"] and abs(abs(g[2]) - 1) < 1e-3 and abs(g[9] - 0.56) < 0.02 and 0 <= g[10] < 0.5
+    assert abs(np.linalg.norm(g[0:3]) - 1) < 1e-12 and abs(np.dot(g[0:3], g[3:6])) < 1e-9 and abs(np.dot(g[3:6], g[6:9])) < 1e-9
+    assert np.all(o["cloud"][o["ground_marked"] == 1, 2] < 0.0)              # marked points lie on the z = -0.56 floor
+    # per ring-sector caps (:493,546,601) and label bookkeeping
+    assert o["n_sharp_own"] <= 16 * 6 * 20 and len(o["flat"]) <= 16 * 6 * 40 and len(o["inten"]) <= 16 * 6 * 20
+    assert np.sum(o["label"] == 2) == o["n_sharp_own"] and np.sum(o["label"] == -1) == len(o["flat"])
+    assert np.sum(o["label"] == 1) <= 16 * 6 and np.sum(o["inten_label"] == 2) == len(o["inten"])
+    assert not np.any((o["label"] == 2) & (o["ground_marked"] == 1))         # ground points are never sharp (:490)
+    # weights carried in normal_x (:501,554): distance_source in [0.7, 2.5] (+1 for sharp)
+    assert np.all((o["flat"][:, 4] >= 0.7 - 1e-6) & (o["flat"][:, 4] <= 2.5 + 1e-6))
+    k = o["n_sharp_own"]
+    assert np.all((o["sharp"][:k, 4] >= 1.7 - 1e-6) & (o["sharp"][:k, 4] <= 3.5 + 1e-6))
+
+
+def test_filters(orc):
+    raw, _ = _scan(n_az=300, seed=2)
+    junk = np.array([[0.1, 0.1, 0.0, 5], [-1.0, 0.2, 0.0, 5], [100.0, 0, 0, 5], [np.nan, 1, 1, 5]], np.float32)
+    o1, o2 = orc.frontend(raw), orc.frontend(np.concatenate([raw[:100], junk, raw[100:]]))
+    assert o1["n_cloud"] == o2["n_cloud"] and np.array_equal(o1["cloud"], o2["cloud"])   # :112-113, :732-763
