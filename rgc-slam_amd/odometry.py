@@ -64,3 +64,175 @@ class Preprocessor:
         self._chk(self._L.rgc_transform_cloud(self._h, a.ctypes.data, a.shape[0], a.strides[0], q.ctypes.data_as(dp), tt.ctypes.data_as(dp),
                                               out.ctypes.data, 0))
         return out
+
+
+# ======================================================================================================================
+# vg_ICP::ICP_thread per-frame body (src/RGC_odometer.cpp:932-1322) as a host-side class.  The per-point work goes to the
+# HIP library; this class only holds the scalar state machine of the node (poses, ground_last, the 3-keyframe sub-map).
+# ======================================================================================================================
+class HipBackend:
+    """The operations the frame body needs, each one C-ABI call (or a few) into librgc_hip.so."""
+
+    def __init__(self, device: int = 0, scan_line: int = 16):
+        from . import frontend, registration
+        self.fe = frontend.ScanRegistration(scan_line, device=device)
+        self.pre = Preprocessor(device)
+        self.reg = registration.odometer_vgicp(device)
+        self._L = _lib.load()
+
+    def close(self):
+        self.fe.close(); self.pre.close(); self.reg.close()
+
+    def frontend(self, raw):
+        return self.fe.laserCloudHandler(raw, diagnostics=False)
+
+    def deskew(self, xyzi, q, t):
+        return self.pre.adjustDistortion(xyzi, q, t)
+
+    def voxelgrid(self, xyzi, leaf):
+        return self.pre.voxelGridFilter(xyzi, leaf)
+
+    def transform(self, xyzi, q, t):
+        return self.pre.transformPointCloud(xyzi, q, t)
+
+    def register(self, source, target, guess):
+        """-> (final 4x4 float32, fitness)  RGC_odometer.cpp:998-1011"""
+        self.reg.setInputTarget(target)
+        self.reg.setInputSource(source)
+        self.reg.align(guess, want_output=False, want_fitness=True)
+        return self.reg.getFinalTransformation(), self.reg.getFitnessScore()
+
+    def extract(self, T):
+        q, t = np.empty(4), np.empty(3)
+        dp = C.POINTER(C.c_double)
+        Tf = np.ascontiguousarray(T, dtype=np.float32)
+        rc = self._L.rgc_extract_pose(Tf.ctypes.data_as(C.POINTER(C.c_float)), q.ctypes.data_as(dp), t.ctypes.data_as(dp))
+        if rc:
+            raise RgcError(rc, "rgc_extract_pose")
+        return q, t
+
+    def fuse(self, q_l, t_l, fitness, use_ground, g_last, g_cur, q_wf):
+        fin = _lib.FuseIn()
+        self._L.rgc_default_fuse_in(C.byref(fin))
+        fin.q_lidar_xyzw[:] = list(q_l); fin.t_lidar[:] = list(t_l); fin.fitness = float(fitness)
+        fin.use_ground = int(use_ground)
+        if use_ground:
+            fin.ground_last[:] = list(g_last); fin.ground_cur[:] = list(g_cur); fin.q_w_curr_f_xyzw[:] = list(q_wf)
+        q, t = np.empty(4), np.empty(3)
+        dp = C.POINTER(C.c_double)
+        rc = self._L.rgc_fuse_pose(C.byref(fin), q.ctypes.data_as(dp), t.ctypes.data_as(dp), None)
+        if rc:
+            raise RgcError(rc, "rgc_fuse_pose")
+        return q, t
+
+    def compose(self, q_w, t_w, q_f, t_f, t_l):
+        qo, to, tl = np.empty(4), np.empty(3), np.empty(3)
+        dp = C.POINTER(C.c_double)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (q_w, t_w, q_f, t_f, t_l)]
+        rc = self._L.rgc_compose_pose(*[x.ctypes.data_as(dp) for x in a], 0, None, qo.ctypes.data_as(dp), to.ctypes.data_as(dp), tl.ctypes.data_as(dp))
+        if rc:
+            raise RgcError(rc, "rgc_compose_pose")
+        return qo, to, tl
+
+    def R2ypr(self, q):
+        x, y, z, w = q
+        R = np.ascontiguousarray([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=np.float64)
+        ypr = np.empty(3)
+        dp = C.POINTER(C.c_double)
+        self._L.rgc_R2ypr(R.ctypes.data_as(dp), ypr.ctypes.data_as(dp))
+        return ypr
+
+
+def _qconj(q):
+    return np.array([-q[0], -q[1], -q[2], q[3]])
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _qrot(q, v):
+    x, y, z, w = q
+    u = 2 * np.cross([x, y, z], v)
+    return v + w * u + np.cross([x, y, z], u)
+
+
+class Odometer:
+    """One sequence of the odometry node with USE_IMU = 0 (no IMU in the synthetic sequences; the IMU hooks of the
+    library -- rgc_imu_preintegrate, the IMU block of rgc_fuse_pose, the gravity blend of rgc_compose_pose -- are
+    exercised by tests/test_host_stages.py).  The ground-change detector (:1034-1085) needs the IMU pitch rate and is
+    therefore inactive: gflag stays 0.  Constants: RGC_odometer.cpp:280-310."""
+
+    keyframeAddingDistance, keyframeAddingAngle = 0.3, 0.2      # :280-281 (the angle is compared against DEGREES, SURVEY A.9)
+    slipwide = 3                                                # :299
+    planeResolution1, planeResolution2 = 0.2, 0.3               # :305-306
+
+    def __init__(self, backend, use_ground: bool = True):
+        self.b = backend
+        self.USE_GROUND = use_ground
+        self.q_w_curr, self.t_w_curr = np.array([0, 0, 0, 1.0]), np.zeros(3)
+        self.q_last_curr, self.t_last_curr = np.array([0, 0, 0, 1.0]), np.zeros(3)   # para_q / para_t, :26-34
+        self.q_w_curr_delta = np.array([0, 0, 0, 1.0])
+        self.full_last = None
+        self.ground_last = None
+        self.surrounding, self.surrounding_q, self.surrounding_t = [], [], []
+        self.submap = np.zeros((0, 4), np.float32)
+        self.submapflag = 0
+        self.fitness = 1.0
+        self.frames = 0
+
+    def process(self, raw_xyzi):
+        """One LiDAR message through front-end + frame body; returns (q_w_curr xyzw, t_w_curr)."""
+        b = self.b
+        fe = b.frontend(raw_xyzi)
+        full, ground_cur = fe["cloud"], fe["groundparam"]
+        full = b.deskew(full, self.q_last_curr, self.t_last_curr)                    # adjustDistortion, :958
+        if self.full_last is not None and len(self.full_last):
+            if self.submapflag == 0:                                                 # :963-972
+                self.surrounding.append(self.full_last)
+                self.surrounding_q.append(np.array([0, 0, 0, 1.0])); self.surrounding_t.append(np.zeros(3))
+                self.submap = np.concatenate([self.submap, self.full_last])
+            self.submapflag += 1
+            source = b.voxelgrid(full, self.planeResolution1)                        # :976-983
+            target = b.voxelgrid(self.submap, self.planeResolution2)                 # :985-991
+            T2 = np.eye(4, dtype=np.float32)                                         # :993-996
+            x, y, z, w = self.q_last_curr
+            T2[:3, :3] = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]).astype(np.float32)
+            T2[:3, 3] = self.t_last_curr.astype(np.float32)
+            T, self.fitness = b.register(source, target, T2)                         # :998-1010
+            q_l, t_l = b.extract(T)                                                  # :1011-1016
+            q_wf = _qmul(_qconj(self.q_w_curr_delta), self.q_w_curr)                 # :1086-1087
+            q_wf = q_wf / np.linalg.norm(q_wf)
+            use_ground = self.USE_GROUND and fe["ground_valid"] and self.ground_last is not None
+            q_f, t_f = b.fuse(q_l, t_l, self.fitness, use_ground, self.ground_last, ground_cur, q_wf)   # :1025-1193
+            self.q_w_curr, self.t_w_curr, t_lc = b.compose(self.q_w_curr, self.t_w_curr, q_f, t_f, t_l)  # :1194-1203
+            self.q_last_curr, self.t_last_curr = q_f, t_lc
+            # sub-map maintenance, :1218-1256
+            if self.surrounding:
+                yb, yc = b.R2ypr(self.surrounding_q[-1]), b.R2ypr(self.q_w_curr)
+                d = np.float32(self.surrounding_t[-1] - self.t_w_curr)
+                dy, dp_, dr = np.float32(yb[0] - yc[0]), np.float32(yb[1] - yc[1]), np.float32(yb[2] - yc[2])
+                if dy > np.pi: dy -= 2 * np.pi
+                if dy < -np.pi: dy += 2 * np.pi
+                if (abs(dr) > self.keyframeAddingAngle or abs(dp_) > self.keyframeAddingAngle or abs(dy) > self.keyframeAddingAngle or
+                        float(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])) > self.keyframeAddingDistance or self.submapflag < self.slipwide - 1):
+                    self.surrounding.append(b.transform(source, self.q_w_curr, self.t_w_curr))
+                    self.surrounding_q.append(self.q_w_curr.copy()); self.surrounding_t.append(self.t_w_curr.copy())
+            self.submap = np.zeros((0, 4), np.float32)
+            if len(self.surrounding) > self.slipwide:
+                self.surrounding.pop(0); self.surrounding_q.pop(0); self.surrounding_t.pop(0)
+            if len(self.surrounding) > 1:
+                qi = _qconj(self.q_w_curr)
+                ti = -_qrot(qi, self.t_w_curr)
+                self.submap = np.concatenate([b.transform(c, qi, ti) for c in self.surrounding])
+        self.full_last = full                                                        # :1319-1322
+        self.ground_last = ground_cur if fe["ground_valid"] else self.ground_last
+        self.frames += 1
+        return self.q_w_curr.copy(), self.t_w_curr.copy()

@@ -1,0 +1,55 @@
+"""CPU-oracle implementation of the backend interface rgc_slam_amd.odometry.Odometer expects -- used ONLY by the tests to
+produce the reference trajectory of a sequence (the product's HipBackend never touches the oracle)."""
+import numpy as np
+
+from oracle import oracle as orc
+from oracle import py_fusion as pf
+
+
+class OracleBackend:
+    def __init__(self, scan_line=16):
+        self.ns = scan_line
+
+    def close(self):
+        pass
+
+    def frontend(self, raw):
+        return orc.frontend(raw, n_scans=self.ns)
+
+    def deskew(self, xyzi, q, t):
+        return orc.deskew(xyzi, q, t)
+
+    def voxelgrid(self, xyzi, leaf):
+        return orc.voxelgrid_filter(np.ascontiguousarray(xyzi[:, :4]), leaf)
+
+    def transform(self, xyzi, q, t):
+        return orc.transform_cloud(xyzi, q, t)
+
+    def register(self, source, target, guess):
+        r = orc.Registration(num_threads=0)
+        r.set_target(target); r.set_source(source)
+        T = r.align(guess)
+        return T, r.fitness()
+
+    def extract(self, T):
+        T = np.asarray(T, dtype=np.float32)
+        U, _, Vt = np.linalg.svd(T[:3, :3].astype(np.float64))        # Affine3f::rotation(): polar part
+        R = (U @ Vt).astype(np.float32).astype(np.float64)
+        # quaternion from rotation matrix (w >= 0 branch is enough for the small inter-frame rotations)
+        w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+        q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+        return q.astype(np.float32).astype(np.float64), T[:3, 3].astype(np.float64)
+
+    def fuse(self, q_l, t_l, fitness, use_ground, g_last, g_cur, q_wf):
+        c = dict(q_lidar=np.asarray(q_l), t_lidar=np.asarray(t_l), fitness=float(fitness), use_ground=bool(use_ground),
+                 ground_last=np.asarray(g_last) if use_ground else None, ground_cur=np.asarray(g_cur) if use_ground else None,
+                 q_w_curr_f=np.asarray(q_wf), ground_cov=0.2, use_imu=False, q_imu=np.array([0, 0, 0, 1.0]))
+        return pf.fuse(c)
+
+    def compose(self, q_w, t_w, q_f, t_f, t_l):
+        R, t, tl = pf.compose(np.asarray(q_w), np.asarray(t_w), np.asarray(q_f), np.asarray(t_f), np.asarray(t_l), False, None)
+        q = pf.qmul(np.asarray(q_w), np.asarray(q_f))
+        return q / np.linalg.norm(q), t, tl
+
+    def R2ypr(self, q):
+        return pf.R2ypr(pf.q2R(np.asarray(q)))
