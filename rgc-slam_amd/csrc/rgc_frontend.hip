@@ -4,8 +4,8 @@
 // (one lane per ring, after a cooperative LDS bitonic sort of each sector).
 //
 // fp32 stencils keep the reference's left-to-right association (compiled with -ffp-contract=off) so curvatures,
-// hence labels, are bit-identical to the CPU path.  Documented clean-ups of reference quirks: SURVEY A.8 and
-// oracle/rgc_oracle_aux.c (per-frame zero-initialised state, sort ties by index, no 30000-point cap).
+// hence labels, are bit-identical to the CPU path.  Documented clean-ups of reference quirks:
+// per-frame zero-initialised state, sort ties broken by index, no 30000-point cap.
 #include <limits.h>
 
 #include "rgc_kernels.h"
