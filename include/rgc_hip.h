@@ -203,6 +203,7 @@ typedef struct rgc_stats {
   int n_source, n_target, n_voxels, n_corr;
   int outer_iterations, n_linearize, n_error;
   long long target_cells, source_cells;
+  int deferred_target, deferred_source; /* queries handled by the cooperative kNN kernel */
 } rgc_stats;
 RGC_API int rgc_get_stats(rgc_ctx* ctx, rgc_stats* out);
 

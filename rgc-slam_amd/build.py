@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librgc_hip.so")
 SRCS = ["rgc_api.hip", "rgc_kernels.hip", "rgc_pre.hip", "rgc_frontend.hip", "rgc_host.cpp"]
-DEPS = SRCS + ["rgc_kernels.h", os.path.join("..", "..", "include", "rgc_hip.h")]
+DEPS = SRCS + ["rgc_kernels.h", "rgc_lm.h", os.path.join("..", "..", "include", "rgc_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden", "-DRGC_BUILD"]

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rgc_kernels.h"
+#include "rgc_lm.h"
 
 namespace {
 
@@ -360,6 +361,55 @@ int do_linearize(rgc_ctx* c, const double T[16], double* H, double* b, double* c
   return RGC_OK;
 }
 
+// One enqueue per outer LM iteration: linearize at x0, fold, FIRST LM try on the device (solve, so3_exp, xi = delta*x0),
+// compute_error at xi, fold -- then a single 57-double read-back.  lambda < 0: lambda = factor * max|H_ii| on the device.
+int do_linearize_try(rgc_ctx* c, const double x0[16], double lambda, double H[36], double b[6], double* y0, double d[6], double xi[16],
+                     double* lambda_used, double* yi) {
+  int rc = need_inputs(c);
+  if (rc) return rc;
+  const int n = c->src.n, noff = noff_of(c->prm.neighbor_method);
+  if ((rc = ensure(c, c->corr_v, sizeof(int) * (size_t)n * noff))) return rc;
+  if ((rc = ensure(c, c->corr_M, sizeof(double) * 6 * (size_t)n * noff))) return rc;
+  const int nb = rgck::linearize_blocks(n);
+  if ((rc = ensure(c, c->partials, sizeof(double) * rgck::kAccum * (size_t)nb))) return rc;
+  if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
+  rgck::LmIn in;
+  for (int i = 0; i < 16; i++) in.x0[i] = x0[i];
+  in.lambda = lambda;
+  in.init_factor = c->prm.lm_init_lambda_factor;
+  {
+    ProfScope ps(c, RGC_K_LINEARIZE, n);
+    rgck::linearize(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
+                    pose_from(x0), c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p,
+                    (double*)c->corr_M.p, 1, (double*)c->partials.p, (int*)c->ipartials.p, c->d_out, c->d_small + 8);
+    rgck::lm_try(c->stream, c->d_out, c->d_small + 8, in);
+  }
+  {
+    ProfScope ps(c, RGC_K_ERROR, n);
+    rgck::compute_error_dev(c->stream, (const float4*)c->src.P.p, n, c->d_out + 38, (const double*)c->tgt.vox.p, noff, (const int*)c->corr_v.p,
+                            (const double*)c->corr_M.p, (double*)c->partials.p, c->d_out + 56);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double) * 57, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->corr_noff = noff;
+  c->corr_n = n;
+  c->corr_valid = true;
+  c->stats.n_corr = (int)c->h_out[28];
+  c->stats.n_linearize++;
+  c->stats.n_error++;
+  int u = 0;
+  for (int a = 0; a < 6; a++)
+    for (int e = a; e < 6; e++) { H[a * 6 + e] = c->h_out[u]; H[e * 6 + a] = c->h_out[u]; u++; }
+  for (int a = 0; a < 6; a++) b[a] = c->h_out[21 + a];
+  *y0 = c->h_out[27];
+  for (int a = 0; a < 6; a++) d[a] = c->h_out[32 + a];
+  for (int a = 0; a < 16; a++) xi[a] = c->h_out[38 + a];
+  *lambda_used = c->h_out[54];
+  *yi = c->h_out[56];
+  return RGC_OK;
+}
+
 int do_error(rgc_ctx* c, const double T[16], double* cost) {
   int rc = need_inputs(c);
   if (rc) return rc;
@@ -397,28 +447,7 @@ int do_fitness(rgc_ctx* c, const float T[16], double* out) {
   return RGC_OK;
 }
 
-// ---- scalar helpers of the LM driver ----
-// so3_exp (so3/so3.hpp:58-77) followed by Eigen's Quaterniond::toRotationMatrix()
-void so3_exp_R(const double w[3], double R[9]) {
-  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  double imag, real;
-  if (th2 < 1e-10) {
-    const double th4 = th2 * th2;
-    imag = 0.5 - 1.0 / 48.0 * th2 + 1.0 / 3840.0 * th4;
-    real = 1.0 - 1.0 / 8.0 * th2 + 1.0 / 384.0 * th4;
-  } else {
-    const double th = std::sqrt(th2), half = 0.5 * th;
-    imag = std::sin(half) / th;
-    real = std::cos(half);
-  }
-  const double qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
-  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
-  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
-  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
-  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
-}
-
+// ---- scalar helpers of the LM driver (so3_exp, LDLT solve, 4x4 product: rgc_lm.h, shared with the device) ----
 // lsq_registration_impl.hpp:82-91
 bool is_converged(const double d[16], double rot_eps, double trans_eps) {
   double m = 0;
@@ -427,56 +456,6 @@ bool is_converged(const double d[16], double rot_eps, double trans_eps) {
     m = std::fmax(m, std::fabs(d[a * 4 + 3]) / trans_eps);
   }
   return m < 1;
-}
-
-// (H + lambda I) d = -b, symmetric 6x6 (Eigen::LDLT at lsq_registration_impl.hpp:136-137): LDL^T with
-// diagonal pivoting
-bool solve_ldlt6(const double Ain[36], const double rhs[6], double x[6]) {
-  double A[6][6];
-  int perm[6];
-  for (int i = 0; i < 6; i++) { perm[i] = i; for (int j = 0; j < 6; j++) A[i][j] = Ain[i * 6 + j]; }
-  for (int k = 0; k < 6; k++) {
-    int piv = k;
-    for (int i = k + 1; i < 6; i++) if (std::fabs(A[i][i]) > std::fabs(A[piv][piv])) piv = i;
-    if (piv != k) {
-      for (int j = 0; j < 6; j++) std::swap(A[k][j], A[piv][j]);
-      for (int i = 0; i < 6; i++) std::swap(A[i][k], A[i][piv]);
-      std::swap(perm[k], perm[piv]);
-    }
-    const double d = A[k][k];
-    if (d == 0.0 || !std::isfinite(d)) return false;
-    for (int i = k + 1; i < 6; i++) {
-      const double l = A[i][k] / d;
-      for (int j = k + 1; j <= i; j++) { A[i][j] -= l * A[j][k]; A[j][i] = A[i][j]; }
-      A[i][k] = l;
-    }
-  }
-  double y[6];
-  for (int i = 0; i < 6; i++) {
-    double s = rhs[perm[i]];
-    for (int j = 0; j < i; j++) s -= A[i][j] * y[j];
-    y[i] = s;
-  }
-  for (int i = 0; i < 6; i++) y[i] /= A[i][i];
-  double z[6];
-  for (int i = 5; i >= 0; i--) {
-    double s = y[i];
-    for (int j = i + 1; j < 6; j++) s -= A[j][i] * z[j];
-    z[i] = s;
-  }
-  for (int i = 0; i < 6; i++) x[perm[i]] = z[i];
-  return true;
-}
-
-void mul4(const double A[16], const double B[16], double C[16]) {
-  double t[16];
-  for (int i = 0; i < 4; i++)
-    for (int j = 0; j < 4; j++) {
-      double s = 0;
-      for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j];
-      t[i * 4 + j] = s;
-    }
-  memcpy(C, t, sizeof(t));
 }
 
 }  // namespace
@@ -523,6 +502,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   if (!c) return RGC_ERR_HIP;
   c->device = hip_device;
   if (const char* e = getenv("RGC_KNN_IMPL")) rgck::set_knn_impl(strcmp(e, "tile") == 0 ? 1 : 0);
+  if (const char* e = getenv("RGC_KNN_HEAVY")) { const int v = atoi(e); if (v > 0) rgck::set_knn_heavy(v); }
   rgc_default_params(&c->prm);
   if (params) {
     int rc = check_params(c, params);
@@ -533,9 +513,9 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_small, 48 * sizeof(int)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&c->d_out, 32 * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&c->d_out, 64 * sizeof(double)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&c->h_out, 32 * sizeof(double), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   *out = c;
   return RGC_OK;
@@ -631,28 +611,23 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
 
   for (int it = 0; it < P.max_iterations && !conv; it++) {  // :65
     iters = it + 1;
-    double H[36], b[6], y0, delta[16];
-    if ((rc = do_linearize(c, x0, H, b, &y0))) return rc;  // :128
-    if (lambda < 0.0) {                                     // :130-132
-      double m = 0;
-      for (int i = 0; i < 6; i++) m = std::fmax(m, std::fabs(H[i * 7]));
-      lambda = P.lm_init_lambda_factor * m;
-    }
+    double H[36], b[6], y0, delta[16], d[6], xi[16], yi, lam_used;
+    // :128 linearize + the first try of :135-144 in one enqueue
+    if ((rc = do_linearize_try(c, x0, lambda, H, b, &y0, d, xi, &lam_used, &yi))) return rc;
+    lambda = lam_used;  // :130-132 (first call: lambda0 = factor * max|H_ii|, computed on the device)
     double nu = 2.0;
     bool ok = false;
     for (int k = 0; k < P.lm_max_iterations; k++) {  // :135
-      double A[36], nb[6], d[6];
-      memcpy(A, H, sizeof(A));
-      for (int i = 0; i < 6; i++) { A[i * 7] += lambda; nb[i] = -b[i]; }
-      if (!solve_ldlt6(A, nb, d)) for (int i = 0; i < 6; i++) d[i] = NAN;
+      if (k > 0) {  // further tries of this outer iteration (rho < 0): solve on the host, evaluate on the device
+        double dl[16];
+        rgclm::lm_try(H, b, lambda, x0, d, dl, xi);  // :136-143
+        if ((rc = do_error(c, xi, &yi))) return rc;  // :144
+      }
       double R[9];
-      so3_exp_R(d, R);  // :139-141
+      rgclm::so3_exp_R(d, R);
       memset(delta, 0, sizeof(delta));
       for (int a = 0; a < 3; a++) { for (int e = 0; e < 3; e++) delta[a * 4 + e] = R[a * 3 + e]; delta[a * 4 + 3] = d[3 + a]; }
       delta[15] = 1.0;
-      double xi[16], yi;
-      mul4(delta, x0, xi);                           // :143
-      if ((rc = do_error(c, xi, &yi))) return rc;    // :144
       double den = 0;
       for (int i = 0; i < 6; i++) den += d[i] * (lambda * d[i] - b[i]);
       const double rho = (y0 - yi) / den;            // :145
@@ -1041,6 +1016,14 @@ int rgc_frontend(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const r
 int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   if (!c || !out) return RGC_ERR_INVALID;
   if (c->tgt.ready) { int rc = fetch_nvox(c); if (rc) return rc; }
+  // queries the bulk kNN kernel handed to the cooperative kernel (first int of the deferred-list buffer)
+  c->stats.deferred_target = c->stats.deferred_source = 0;
+  if (rgck::knn_impl() == 0) {
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->tgt.ready && c->tgt.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_target, c->tgt.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (c->src.ready && c->src.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_source, c->src.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   *out = c->stats;
   return RGC_OK;
 }

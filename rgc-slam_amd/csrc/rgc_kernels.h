@@ -23,6 +23,7 @@ struct PoseF {  // fp32 4x4 rows 0..2 (pcl::transformPointCloud in the reference
 };
 
 struct Quat { double x, y, z, w; };
+struct LmIn { double x0[16]; double lambda; double init_factor; };
 struct FeParams { int n_scans; double min_range, max_range; };
 struct LeafGrid { int minb[3]; int div[3]; };  // pcl::VoxelGrid leaf grid
 
@@ -43,6 +44,7 @@ void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg);
 size_t segment_bytes(int n);
 void set_knn_impl(int impl);  // 0 = rows (default), 1 = LDS tile
 int knn_impl();
+void set_knn_heavy(int v);
 // bulk kernel (one lane per query; defers expensive queries) then the cooperative kernel (one wave per deferred query)
 void knn_rows(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
               const int* nseg, double* nx, double* ny, double* nz);
@@ -57,6 +59,9 @@ void linearize(hipStream_t s, const float4* P, const double* nx, const double* n
                int* ncorr_partials, double* out28, int* out_ncorr);
 void compute_error(hipStream_t s, const float4* P, int n, Pose T, const double* vox, int noff, const int* corr_v,
                    const double* corr_M, double* partials, double* out1);
+void lm_try(hipStream_t s, double* out, const int* ncorr, LmIn in);
+void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev, const double* vox, int noff, const int* corr_v,
+                       const double* corr_M, double* partials, double* out1);
 // ---- C8 ----
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials,
              double* out1);

@@ -7,6 +7,7 @@
 //
 // Reference citations are relative to /root/reference/rgc_slam/.
 #include "rgc_kernels.h"
+#include "rgc_lm.h"
 
 #include <limits.h>
 
@@ -454,7 +455,8 @@ __device__ __forceinline__ void generic_search_rows(const float4* __restrict__ P
 // kTarget only separates the two instantiations by NAME (map vs scan) for the profiles.
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_T = 256;
-constexpr int KNN_HEAVY = 640;  // candidates in the 3x3x3 block above which a query gets a whole wave
+static int g_knn_heavy = 640;     // candidates in the 3x3x3 block above which a query gets a whole wave (RGC_KNN_HEAVY)
+void set_knn_heavy(int v) { g_knn_heavy = v; }
 
 // Queries that the lane-per-query kernel cannot finish cheaply -- a crowded own cell that is not decisive (its
 // 3x3x3 block holds thousands of candidates) or a sparse neighbourhood (the search cube must grow) -- are DEFERRED:
@@ -467,7 +469,7 @@ struct Deferred {
 };
 
 template <int KC>
-__device__ __forceinline__ void knn_point(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, int i,
+__device__ __forceinline__ void knn_point(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, int heavy, int i,
                                           int* list, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
                                           double* __restrict__ nz) {
   const float4 pq = P[i];
@@ -486,14 +488,7 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
   if (own1 - own0 >= k) {
     thr = top.kth(k);
     const double bound = cube_bound(g, c, q, 0);
-    if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) {
-      rdone = 0;
-    } else {  // crowded AND undecided
-      const int e = atomicAdd(df.cnt, 1);
-      df.idx[e] = i;
-      df.thr[e] = thr;
-      return;
-    }
+    if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) rdone = 0;
   }
   int lo[9], hi[9];
   if (rdone < 0) {
@@ -510,10 +505,10 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
     int tot = 0;
 #pragma unroll
     for (int r = 0; r < 9; r++) tot += hi[r] - lo[r];
-    if (tot > KNN_HEAVY) {  // a sparse cell next to crowded ones: thousands of candidates -> one wave for this query
+    if (tot > heavy) {  // crowded neighbourhood: thousands of candidates -> one wave for this query
       const int e = atomicAdd(df.cnt, 1);
       df.idx[e] = i;
-      df.thr[e] = INFINITY;
+      df.thr[e] = thr;  // k-th distance inside the own cell if it holds >= k points, else INFINITY
       return;
     }
     // cube r = 1: nine row ranges, the middle one without the own cell (already in the chain)
@@ -559,11 +554,11 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
 
 template <int KC, bool kTarget>
 __global__ void __launch_bounds__(KNN_T)
-k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df, double* __restrict__ nx,
-           double* __restrict__ ny, double* __restrict__ nz) {
+k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, int heavy, Deferred df,
+           double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
   extern __shared__ int slist_rows[];  // [k][KNN_T]
   const int i = blockIdx.x * KNN_T + threadIdx.x;
-  if (i < n) knn_point<KC>(P, start, g, k, i, slist_rows + threadIdx.x, df, nx, ny, nz);
+  if (i < n) knn_point<KC>(P, start, g, k, heavy, i, slist_rows + threadIdx.x, df, nx, ny, nz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -685,15 +680,17 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
         if (x0 < top.a[KC - 1]) top.insert(x0);
         if (x1 < top.a[KC - 1]) top.insert(x1);
       });
-      // k-th smallest over the wave: largest bit pattern T with #(values < T) < k  ==  the k-th smallest value
+      // k-th smallest over the wave: largest bit pattern T with #(values < T) < k  ==  the k-th smallest value.
+      // The count is a sum of ballot popcounts: compares write SGPR masks, s_bcnt1 adds them -- no cross-lane traffic.
       unsigned T = 0;
       for (int bit = 30; bit >= 0; bit--) {
         const unsigned cand = T | (1u << bit);
+        if (cand > 0x7F800000u) continue;
         const float tf = __uint_as_float(cand);
-        int cl = 0;
+        int cnt_lt = 0;
 #pragma unroll
-        for (int j = 0; j < KC; j++) cl += (top.a[j] < tf) ? 1 : 0;
-        if (cand <= 0x7F800000u && wave_sum_i(cl) < k) T = cand;
+        for (int j = 0; j < KC; j++) cnt_lt += __popcll(__ballot(top.a[j] < tf));
+        if (cnt_lt < k) T = cand;
       }
       thr = (T >= 0x7F800000u) ? INFINITY : __uint_as_float(T);
       if (r >= rmax) break;  // whole grid scanned
@@ -1275,6 +1272,65 @@ __global__ void k_unsort3(const double* __restrict__ a, const double* __restrict
   out3[(size_t)i * 3 + 2] = c[s];
 }
 
+// First LM try of an outer iteration on the device (one lane): lsq_registration_impl.hpp:130-143.
+// acc = the 28 folded doubles of linearize; out layout (doubles): [28] ncorr, [32..37] d, [38..53] xi (row-major 4x4),
+// [54] lambda used, [55] 1 if the solve succeeded.
+__global__ void k_lm_try(double* __restrict__ out, const int* __restrict__ ncorr, LmIn in) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double H[36], b[6];
+  int u = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int e = a; e < 6; e++) { H[a * 6 + e] = out[u]; H[e * 6 + a] = out[u]; u++; }
+#pragma unroll
+  for (int a = 0; a < 6; a++) b[a] = out[21 + a];
+  double lambda = in.lambda;
+  if (lambda < 0.0) {
+    double m = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) m = fmax(m, fabs(H[i * 7]));
+    lambda = in.init_factor * m;
+  }
+  double d[6], delta[16], xi[16];
+  rgclm::lm_try(H, b, lambda, in.x0, d, delta, xi);
+  out[28] = (double)*ncorr;
+#pragma unroll
+  for (int a = 0; a < 6; a++) out[32 + a] = d[a];
+#pragma unroll
+  for (int a = 0; a < 16; a++) out[38 + a] = xi[a];
+  out[54] = lambda;
+  out[55] = 1.0;
+}
+
+// C6 with the trial pose read from device memory (written by k_lm_try in the same stream)
+__global__ void __launch_bounds__(LIN_T)
+k_error_dev(const float4* __restrict__ P, int n, const double* __restrict__ Tdev, const double* __restrict__ vox, int noff,
+            const int* __restrict__ corr_v, const double* __restrict__ corr_M, double* __restrict__ partials) {
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < n) {
+    const float4 pp = P[i];
+    const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
+    const double q0 = Tdev[0] * p0 + Tdev[1] * p1 + Tdev[2] * p2 + Tdev[3];
+    const double q1 = Tdev[4] * p0 + Tdev[5] * p1 + Tdev[6] * p2 + Tdev[7];
+    const double q2 = Tdev[8] * p0 + Tdev[9] * p1 + Tdev[10] * p2 + Tdev[11];
+    for (int o = 0; o < noff; o++) {
+      const int v = corr_v[(size_t)o * n + i];
+      if (v < 0) continue;
+      const double* rec = vox + (size_t)v * kVoxRec;
+      double M[6];
+#pragma unroll
+      for (int a = 0; a < 6; a++) M[a] = corr_M[((size_t)a * noff + o) * n + i];
+      const double e0 = rec[0] - q0, e1 = rec[1] - q1, e2 = rec[2] - q2;
+      const double w = sqrt(rec[9]);
+      acc[0] += w * (e0 * (M[0] * e0 + M[1] * e1 + M[2] * e2) + e1 * (M[1] * e0 + M[3] * e1 + M[4] * e2) +
+                     e2 * (M[2] * e0 + M[4] * e1 + M[5] * e2));
+    }
+  }
+  block_reduce_store<1>(acc, partials + blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
@@ -1324,9 +1380,9 @@ static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const in
     (void)hipMemsetAsync(df.cnt, 0, sizeof(int), s);
     const int nb = nblk(n, KNN_T);
     if (is_target)
-      hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, df, nx, ny, nz);
+      hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, df, nx, ny, nz);
     else
-      hipLaunchKernelGGL((k_knn_rows<KC, false>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, df, nx, ny, nz);
+      hipLaunchKernelGGL((k_knn_rows<KC, false>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, df, nx, ny, nz);
     return;
   }
   const size_t lds = sizeof(float4) * TCH + (size_t)k * TQ * sizeof(int);
@@ -1379,6 +1435,15 @@ void compute_error(hipStream_t s, const float4* P, int n, Pose T, const double* 
                    const double* corr_M, double* partials, double* out1) {
   const int nb = linearize_blocks(n);
   hipLaunchKernelGGL(k_error, dim3(nb), dim3(LIN_T), 0, s, P, n, T, vox, noff, corr_v, corr_M, partials);
+  hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
+}
+void lm_try(hipStream_t s, double* out, const int* ncorr, LmIn in) {
+  hipLaunchKernelGGL(k_lm_try, dim3(1), dim3(WAVE), 0, s, out, ncorr, in);
+}
+void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev, const double* vox, int noff, const int* corr_v,
+                       const double* corr_M, double* partials, double* out1) {
+  const int nb = linearize_blocks(n);
+  hipLaunchKernelGGL(k_error_dev, dim3(nb), dim3(LIN_T), 0, s, P, n, Tdev, vox, noff, corr_v, corr_M, partials);
   hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
 }
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials, double* out1) {
