@@ -70,6 +70,9 @@ struct rgc_ctx {
   int* h_small = nullptr;     // pinned, same layout
   double* h_out = nullptr;    // pinned
   DevBuf scratch;             // getters
+  DevBuf lm_state;            // device-chained LM state (rgck::LmState)
+  rgck::LmState* h_lm = nullptr;  // pinned mirror
+  bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop (A/B knob)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos;  // B2/B3/B9 staging
   DevBuf fe[32];              // front-end buffers
@@ -516,6 +519,8 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipMalloc((void**)&c->d_out, 64 * sizeof(double)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
+  if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   *out = c;
   return RGC_OK;
@@ -537,6 +542,8 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->h_lm) (void)hipHostFree(c->h_lm);
+  release(c->lm_state);
   if (c->src_ready) (void)hipEventDestroy(c->src_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -609,6 +616,47 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
   for (int i = 0; i < 6; i++) Hfin[i * 7] = 1.0;  // final_hessian_.setIdentity(), :21
   c->stats.n_linearize = c->stats.n_error = c->stats.outer_iterations = 0;
 
+  if (!c->lm_host) {
+    // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_A / k_lm_B);
+    // the host only enqueues slots and reads the state back once per batch.
+    const int n = c->src.n, noff = noff_of(P.neighbor_method);
+    if ((rc = ensure(c, c->corr_v, sizeof(int) * (size_t)n * noff))) return rc;
+    if ((rc = ensure(c, c->corr_M, sizeof(double) * 6 * (size_t)n * noff))) return rc;
+    const int nb = rgck::linearize_blocks(n);
+    if ((rc = ensure(c, c->partials, sizeof(double) * rgck::kAccum * (size_t)nb))) return rc;
+    if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
+    if ((rc = ensure(c, c->lm_state, sizeof(rgck::LmState)))) return rc;
+    rgck::LmState& S = *c->h_lm;
+    memset(&S, 0, sizeof(S));
+    memcpy(S.x0, x0, sizeof(x0));
+    S.lambda = -1.0; S.nu = 2.0;
+    memcpy(S.Hfin, Hfin, sizeof(Hfin));
+    S.rot_eps = P.rotation_eps; S.trans_eps = P.translation_eps; S.init_factor = P.lm_init_lambda_factor;
+    S.max_outer = P.max_iterations; S.max_inner = P.lm_max_iterations;
+    S.done = P.max_iterations <= 0 ? 1 : 0;
+    HIPCHK(c, hipMemcpyAsync(c->lm_state.p, &S, sizeof(S), hipMemcpyHostToDevice, c->stream));
+    int batch = 6;
+    for (int guard = 0; guard < 400; guard++) {
+      {
+        ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch);
+        for (int k = 0; k < batch; k++)
+          rgck::lm_slot(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
+                        c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
+                        (double*)c->partials.p, (int*)c->ipartials.p, (rgck::LmState*)c->lm_state.p);
+      }
+      HIPCHK(c, hipMemcpyAsync(&S, c->lm_state.p, sizeof(S), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipGetLastError());
+      if (S.done) break;
+      batch = 3;
+    }
+    c->corr_noff = noff; c->corr_n = n; c->corr_valid = S.n_lin > 0;
+    c->stats.n_corr = S.ncorr; c->stats.n_linearize = S.n_lin; c->stats.n_error = S.n_err;
+    memcpy(x0, S.x0, sizeof(x0));
+    memcpy(Hfin, S.Hfin, sizeof(Hfin));
+    conv = S.conv != 0; failed = S.failed != 0;
+    iters = S.failed ? S.outer + 1 : S.outer;  // iterations started, like nr_iterations_ + 1
+  } else
   for (int it = 0; it < P.max_iterations && !conv; it++) {  // :65
     iters = it + 1;
     double H[36], b[6], y0, delta[16], d[6], xi[16], yi, lam_used;

@@ -24,6 +24,11 @@ struct PoseF {  // fp32 4x4 rows 0..2 (pcl::transformPointCloud in the reference
 
 struct Quat { double x, y, z, w; };
 struct LmIn { double x0[16]; double lambda; double init_factor; };
+struct LmState {  // device-resident state of LsqRegistration::computeTransformation (lsq_registration_impl.hpp:53-172)
+  double x0[16], lambda, nu, y0, yi, H[36], b[6], d[6], delta[16], xi[16], Hfin[36];
+  double rot_eps, trans_eps, init_factor;
+  int phase, done, conv, failed, outer, inner, n_lin, n_err, ncorr, ticketA, ticketB, max_outer, max_inner, pad;
+};
 struct FeParams { int n_scans; double min_range, max_range; };
 struct LeafGrid { int minb[3]; int div[3]; };  // pcl::VoxelGrid leaf grid
 
@@ -62,6 +67,8 @@ void compute_error(hipStream_t s, const float4* P, int n, Pose T, const double* 
 void lm_try(hipStream_t s, double* out, const int* ncorr, LmIn in);
 void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev, const double* vox, int noff, const int* corr_v,
                        const double* corr_M, double* partials, double* out1);
+void lm_slot(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
+             const double* vox, int noff, int* corr_v, double* corr_M, double* partials, int* ncorr_partials, LmState* st);
 // ---- C8 ----
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials,
              double* out1);

@@ -1050,17 +1050,12 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
   }
 }
 
-__global__ void __launch_bounds__(LIN_T)
-k_linearize(const float4* __restrict__ P,
-            const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Pose T, Grid g,
-            const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v,
-            double* __restrict__ corr_M, int want_H, double* __restrict__ partials, int* __restrict__ ncorr_partials) {
-  const int i = blockIdx.x * LIN_T + threadIdx.x;
-  double acc[kAccum];
-#pragma unroll
-  for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
-  int ncorr = 0;
-  if (i < n) {
+// per-point work of FastVGICP::update_correspondences + linearize (fast_vgicp_impl.hpp:73-180) for sorted source point i
+__device__ __forceinline__ void linearize_point(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
+                                                const double* __restrict__ nz, int i, int n, const Pose& T, const Grid& g,
+                                                const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff,
+                                                int* __restrict__ corr_v, double* __restrict__ corr_M, int want_H, double (&acc)[kAccum],
+                                                int& ncorr) {
     const float4 pp = P[i];
     const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
     const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
@@ -1124,9 +1119,9 @@ k_linearize(const float4* __restrict__ P,
 #pragma unroll
       for (int a = 0; a < 6; a++) acc[21 + a] += w * (J[0][a] * Me0 + J[1][a] * Me1 + J[2][a] * Me2);
     }
-  }
-  block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
-  // correspondence count (exact integer)
+}
+
+__device__ __forceinline__ void block_count_store(int ncorr, int* __restrict__ dst) {  // exact integer block sum -> *dst
   int c = ncorr;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
@@ -1136,7 +1131,207 @@ k_linearize(const float4* __restrict__ P,
   if (threadIdx.x == 0) {
     int s = 0;
     for (int j = 0; j < LIN_T / WAVE; j++) s += cred[j];
-    ncorr_partials[blockIdx.x] = s;
+    *dst = s;
+  }
+}
+
+__global__ void __launch_bounds__(LIN_T)
+k_linearize(const float4* __restrict__ P,
+            const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Pose T, Grid g,
+            const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v,
+            double* __restrict__ corr_M, int want_H, double* __restrict__ partials, int* __restrict__ ncorr_partials) {
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[kAccum];
+#pragma unroll
+  for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
+  int ncorr = 0;
+  if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, want_H, acc, ncorr);
+  block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
+  block_count_store(ncorr, ncorr_partials + blockIdx.x);
+}
+
+// cost of sorted source point i with the correspondences and Mahalanobis matrices frozen by the last linearisation
+__device__ __forceinline__ double error_point(const float4* __restrict__ P, int i, int n, const double* __restrict__ T12 /* row-major 3x4 */,
+                                              const double* __restrict__ vox, int noff, const int* __restrict__ corr_v,
+                                              const double* __restrict__ corr_M) {
+  const float4 pp = P[i];
+  const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
+  const double q0 = T12[0] * p0 + T12[1] * p1 + T12[2] * p2 + T12[3];
+  const double q1 = T12[4] * p0 + T12[5] * p1 + T12[6] * p2 + T12[7];
+  const double q2 = T12[8] * p0 + T12[9] * p1 + T12[10] * p2 + T12[11];
+  double s = 0.0;
+  for (int o = 0; o < noff; o++) {
+    const int v = corr_v[(size_t)o * n + i];
+    if (v < 0) continue;
+    const double* rec = vox + (size_t)v * kVoxRec;
+    double M[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) M[a] = corr_M[((size_t)a * noff + o) * n + i];
+    const double e0 = rec[0] - q0, e1 = rec[1] - q1, e2 = rec[2] - q2;
+    const double w = sqrt(rec[9]);
+    s += w * (e0 * (M[0] * e0 + M[1] * e1 + M[2] * e2) + e1 * (M[1] * e0 + M[3] * e1 + M[4] * e2) + e2 * (M[2] * e0 + M[4] * e1 + M[5] * e2));
+  }
+  return s;
+}
+
+// ---- device-chained LM: the whole LsqRegistration::computeTransformation loop (lsq_registration_impl.hpp:53-172) as a
+// state machine in device memory.  One SLOT = kernel A (linearise at x0 unless this is a retry; the last-arriving block
+// folds the partial rows and performs the LM try) + kernel B (cost at the trial pose; the last block folds, computes
+// rho and accepts / rejects / terminates).  The host enqueues slots blindly and reads the state back once per batch.
+// Inter-block hand-off: plain stores, every wave drains vmcnt, workgroup barrier, one lane agent-scope RELEASE + ticket;
+// the last arriver does an agent-scope ACQUIRE before the workgroup reads the rows (cdna_hip_programming.md G16).
+__device__ __forceinline__ bool last_block_arrive(int* ticket) {
+  __shared__ int is_last_s;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == (int)gridDim.x - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    is_last_s = last;
+  }
+  __syncthreads();
+  return is_last_s != 0;
+}
+
+// same summation order as k_fold: lane l sums rows l, l+64, ... then the shuffle tree; wave w owns accumulators w, w+4, ...
+template <int NACC>
+__device__ __forceinline__ void block_fold_rows(const double* __restrict__ partials, int nrows, double* sh_out) {
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  for (int a = w; a < NACC; a += LIN_T / WAVE) {
+    double s = 0;
+    for (int r = lane; r < nrows; r += WAVE) s += partials[(size_t)r * NACC + a];
+    s = wave_sum(s);
+    if (lane == 0) sh_out[a] = s;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(LIN_T)
+k_lm_A(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
+       const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v, double* __restrict__ corr_M,
+       double* __restrict__ partials, int* __restrict__ ncorr_partials, LmState* __restrict__ st) {
+  if (st->done) return;
+  __shared__ double folded[kAccum];
+  if (st->phase == 0) {
+    Pose T;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int e = 0; e < 3; e++) T.R[a * 3 + e] = st->x0[a * 4 + e];
+      T.t[a] = st->x0[a * 4 + 3];
+    }
+    const int i = blockIdx.x * LIN_T + threadIdx.x;
+    double acc[kAccum];
+#pragma unroll
+    for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
+    int ncorr = 0;
+    if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, 1, acc, ncorr);
+    block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
+    block_count_store(ncorr, ncorr_partials + blockIdx.x);
+    if (!last_block_arrive(&st->ticketA)) return;
+    block_fold_rows<kAccum>(partials, gridDim.x, folded);
+    if (threadIdx.x == 0) {
+      int u = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int e = a; e < 6; e++) { st->H[a * 6 + e] = folded[u]; st->H[e * 6 + a] = folded[u]; u++; }
+#pragma unroll
+      for (int a = 0; a < 6; a++) st->b[a] = folded[21 + a];
+      st->y0 = folded[27];
+      int nc = 0;
+      for (int r = 0; r < (int)gridDim.x; r++) nc += ncorr_partials[r];
+      st->ncorr = nc;
+      st->n_lin++;
+      if (st->lambda < 0.0) {  // :130-132
+        double m = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) m = fmax(m, fabs(st->H[a * 7]));
+        st->lambda = st->init_factor * m;
+      }
+    }
+  } else if (blockIdx.x != 0) {
+    return;  // retry of the same linearisation: only the try below is needed
+  }
+  if (threadIdx.x == 0) {  // :136-143
+    double H[36], b[6], x0[16], d[6], delta[16], xi[16];
+#pragma unroll
+    for (int a = 0; a < 36; a++) H[a] = st->H[a];
+#pragma unroll
+    for (int a = 0; a < 6; a++) b[a] = st->b[a];
+#pragma unroll
+    for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
+    rgclm::lm_try(H, b, st->lambda, x0, d, delta, xi);
+#pragma unroll
+    for (int a = 0; a < 6; a++) st->d[a] = d[a];
+#pragma unroll
+    for (int a = 0; a < 16; a++) { st->delta[a] = delta[a]; st->xi[a] = xi[a]; }
+  }
+}
+
+__device__ __forceinline__ bool lm_is_converged(const double* d, double rot_eps, double trans_eps) {  // :82-91
+  double m = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int e = 0; e < 3; e++) m = fmax(m, fabs(d[a * 4 + e] - (a == e ? 1.0 : 0.0)) / rot_eps);
+    m = fmax(m, fabs(d[a * 4 + 3]) / trans_eps);
+  }
+  return m < 1;
+}
+
+__global__ void __launch_bounds__(LIN_T)
+k_lm_B(const float4* __restrict__ P, int n, const double* __restrict__ vox, int noff, const int* __restrict__ corr_v,
+       const double* __restrict__ corr_M, double* __restrict__ partials, LmState* __restrict__ st) {
+  if (st->done) return;
+  __shared__ double folded[1];
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < n) acc[0] = error_point(P, i, n, st->xi, vox, noff, corr_v, corr_M);
+  block_reduce_store<1>(acc, partials + blockIdx.x);
+  if (!last_block_arrive(&st->ticketB)) return;
+  block_fold_rows<1>(partials, gridDim.x, folded);
+  if (threadIdx.x != 0) return;
+  const double yi = folded[0];
+  st->yi = yi;
+  st->n_err++;
+  double den = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) den += st->d[a] * (st->lambda * st->d[a] - st->b[a]);
+  const double rho = (st->y0 - yi) / den;  // :145
+  bool outer_done = false;
+  if (rho < 0) {  // :155-163
+    if (lm_is_converged(st->delta, st->rot_eps, st->trans_eps)) {
+      outer_done = true;  // step_lm returns true with x unchanged
+    } else {
+      st->lambda = st->nu * st->lambda;
+      st->nu = 2 * st->nu;
+      st->inner++;
+      if (st->inner >= st->max_inner) { st->failed = 1; st->done = 1; }  // "lm not converged!!", :69-72
+      st->phase = 1;
+    }
+  } else {  // :165-168
+#pragma unroll
+    for (int a = 0; a < 16; a++) st->x0[a] = st->xi[a];
+    st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
+#pragma unroll
+    for (int a = 0; a < 36; a++) st->Hfin[a] = st->H[a];
+    outer_done = true;
+  }
+  if (outer_done) {
+    st->conv = lm_is_converged(st->delta, st->rot_eps, st->trans_eps) ? 1 : 0;  // :74
+    st->outer++;
+    st->phase = 0;
+    st->nu = 2.0;
+    st->inner = 0;
+    if (st->conv || st->outer >= st->max_outer) st->done = 1;  // :65
   }
 }
 
@@ -1162,30 +1357,12 @@ __global__ void __launch_bounds__(WAVE) k_fold(const double* __restrict__ partia
 
 // C6  fast_vgicp_impl.hpp:183-204: frozen correspondences and Mahalanobis
 __global__ void __launch_bounds__(LIN_T)
-k_error(const float4* __restrict__ P, int n, Pose T,
-        const double* __restrict__ vox, int noff, const int* __restrict__ corr_v, const double* __restrict__ corr_M,
-        double* __restrict__ partials) {
+k_error(const float4* __restrict__ P, int n, Pose T, const double* __restrict__ vox, int noff, const int* __restrict__ corr_v,
+        const double* __restrict__ corr_M, double* __restrict__ partials) {
   const int i = blockIdx.x * LIN_T + threadIdx.x;
   double acc[1] = {0.0};
-  if (i < n) {
-    const float4 pp = P[i];
-    const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
-    const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
-    const double q1 = T.R[3] * p0 + T.R[4] * p1 + T.R[5] * p2 + T.t[1];
-    const double q2 = T.R[6] * p0 + T.R[7] * p1 + T.R[8] * p2 + T.t[2];
-    for (int o = 0; o < noff; o++) {
-      const int v = corr_v[(size_t)o * n + i];
-      if (v < 0) continue;
-      const double* rec = vox + (size_t)v * kVoxRec;
-      double M[6];
-#pragma unroll
-      for (int a = 0; a < 6; a++) M[a] = corr_M[((size_t)a * noff + o) * n + i];
-      const double e0 = rec[0] - q0, e1 = rec[1] - q1, e2 = rec[2] - q2;
-      const double w = sqrt(rec[9]);
-      acc[0] += w * (e0 * (M[0] * e0 + M[1] * e1 + M[2] * e2) + e1 * (M[1] * e0 + M[3] * e1 + M[4] * e2) +
-                     e2 * (M[2] * e0 + M[4] * e1 + M[5] * e2));
-    }
-  }
+  const double T12[12] = {T.R[0], T.R[1], T.R[2], T.t[0], T.R[3], T.R[4], T.R[5], T.t[1], T.R[6], T.R[7], T.R[8], T.t[2]};
+  if (i < n) acc[0] = error_point(P, i, n, T12, vox, noff, corr_v, corr_M);
   block_reduce_store<1>(acc, partials + blockIdx.x);
 }
 
@@ -1206,45 +1383,38 @@ k_fitness(const float4* __restrict__ SP, int ns, PoseF T, const float4* __restri
     const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
     const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
     const double q[3] = {(double)px, (double)py, (double)pz};
-    int rmax = 0, r0 = 0;
+    int rmax = 0, r = 1;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
-      r0 = max(r0, max(-c[a], c[a] - (g.dim[a] - 1)));
+      r = max(r, max(-c[a], c[a] - (g.dim[a] - 1)));  // first cube that touches the grid when the query lies outside
     }
-    float best = 3.0e38f;
-    bool have = false;
-    for (int r = r0;; r++) {
-      const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
-      const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
-      for (int zz = z0; zz <= z1; zz++) {
-        const int az = abs(zz - c[2]);
-        for (int yy = y0; yy <= y1; yy++) {
-          const bool face = (az == r) || (abs(yy - c[1]) == r);
-          const int xstep = face ? 1 : max(2 * r, 1);
-          for (int xx = c[0] - r; xx <= c[0] + r; xx += xstep) {
-            if (xx < 0 || xx >= g.dim[0]) continue;
-            const int cid = cell_index(g, xx, yy, zz);
-            for (int s = tstart[cid]; s < tstart[cid + 1]; s++) {
-              const float4 cp = TP[s];
-              const float dx = px - cp.x, dy = py - cp.y, dz = pz - cp.z;
-              const float d2 = (dx * dx + dy * dy) + dz * dz;
-              if (d2 < best) { best = d2; have = true; }
-            }
-          }
+    float best = INFINITY;
+    for (;;) {
+      // cube [c-r, c+r]^3 as contiguous row ranges of the sorted target (the minimum only improves on re-scans)
+      for_each_cube_row(g, c, r, tstart, [&](int s0, int s1) {
+        for (int s = s0; s < s1; s += 4) {
+          const int e = s1 - 1;
+          const float4 c0 = TP[s], c1 = TP[min(s + 1, e)], c2 = TP[min(s + 2, e)], c3 = TP[min(s + 3, e)];
+          best = fminf(best, fminf(fminf(dist2(px, py, pz, c0), dist2(px, py, pz, c1)), fminf(dist2(px, py, pz, c2), dist2(px, py, pz, c3))));
         }
-      }
+      });
       if (r >= rmax) break;
-      if (have) {
-        double bound = 1.0e300;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-          if (c[a] - r > 0) bound = fmin(bound, q[a] - ((double)(c[a] - r + g.minc[a]) + 0.5) * g.res);
-          if (c[a] + r < g.dim[a] - 1) bound = fmin(bound, ((double)(c[a] + r + g.minc[a]) + 1.5) * g.res - q[a]);
+      int rn;
+      if (best < INFINITY) {
+        const double bound = cube_bound(g, c, q, r);
+        if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) break;
+        const double need = sqrt((double)best) * (1.0 + 1e-5);
+        rn = r + 1;
+        while (rn < rmax) {
+          const double b = cube_bound(g, c, q, rn);
+          if (b == 1.0e300 || b > need) break;
+          rn++;
         }
-        if (bound == 1.0e300) break;
-        if (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5)) break;
+      } else {
+        rn = r + max(1, (r + 1) / 2);
       }
+      r = min(rn, rmax);
     }
     acc[0] = (double)best;
   }
@@ -1309,25 +1479,7 @@ k_error_dev(const float4* __restrict__ P, int n, const double* __restrict__ Tdev
             const int* __restrict__ corr_v, const double* __restrict__ corr_M, double* __restrict__ partials) {
   const int i = blockIdx.x * LIN_T + threadIdx.x;
   double acc[1] = {0.0};
-  if (i < n) {
-    const float4 pp = P[i];
-    const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
-    const double q0 = Tdev[0] * p0 + Tdev[1] * p1 + Tdev[2] * p2 + Tdev[3];
-    const double q1 = Tdev[4] * p0 + Tdev[5] * p1 + Tdev[6] * p2 + Tdev[7];
-    const double q2 = Tdev[8] * p0 + Tdev[9] * p1 + Tdev[10] * p2 + Tdev[11];
-    for (int o = 0; o < noff; o++) {
-      const int v = corr_v[(size_t)o * n + i];
-      if (v < 0) continue;
-      const double* rec = vox + (size_t)v * kVoxRec;
-      double M[6];
-#pragma unroll
-      for (int a = 0; a < 6; a++) M[a] = corr_M[((size_t)a * noff + o) * n + i];
-      const double e0 = rec[0] - q0, e1 = rec[1] - q1, e2 = rec[2] - q2;
-      const double w = sqrt(rec[9]);
-      acc[0] += w * (e0 * (M[0] * e0 + M[1] * e1 + M[2] * e2) + e1 * (M[1] * e0 + M[3] * e1 + M[4] * e2) +
-                     e2 * (M[2] * e0 + M[4] * e1 + M[5] * e2));
-    }
-  }
+  if (i < n) acc[0] = error_point(P, i, n, Tdev, vox, noff, corr_v, corr_M);
   block_reduce_store<1>(acc, partials + blockIdx.x);
 }
 
@@ -1445,6 +1597,12 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
   const int nb = linearize_blocks(n);
   hipLaunchKernelGGL(k_error_dev, dim3(nb), dim3(LIN_T), 0, s, P, n, Tdev, vox, noff, corr_v, corr_M, partials);
   hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
+}
+void lm_slot(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
+             const double* vox, int noff, int* corr_v, double* corr_M, double* partials, int* ncorr_partials, LmState* st) {
+  const int nb = linearize_blocks(n);
+  hipLaunchKernelGGL(k_lm_A, dim3(nb), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v, corr_M, partials, ncorr_partials, st);
+  hipLaunchKernelGGL(k_lm_B, dim3(nb), dim3(LIN_T), 0, s, P, n, vox, noff, corr_v, corr_M, partials, st);
 }
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials, double* out1) {
   const int nb = linearize_blocks(ns);
