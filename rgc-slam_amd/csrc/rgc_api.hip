@@ -71,6 +71,8 @@ struct rgc_ctx {
   double* h_out = nullptr;    // pinned
   DevBuf scratch;             // getters
   DevBuf lm_state;            // device-chained LM state (rgck::LmState)
+  bool deferred_known = false;  // stats.deferred_* are those of the current clouds (carried home by the last align)
+  DevBuf fit_partials;        // fitness rows when it is chained behind the LM slots
   rgck::LmState* h_lm = nullptr;  // pinned mirror
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop (A/B knob)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
@@ -189,12 +191,13 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
   hipStream_t s = is_target ? c->stream : c->stream2;
   int* dsm = c->d_small + (is_target ? 0 : 16);
   int* hsm = c->h_small + (is_target ? 0 : 16);
+  const int hi = is_target ? 0 : 1;  // the scan's kernels share CUs with the map's kNN launch: raised wave priority
   {
     ProfScope ps(c, RGC_K_GRID, n, s);
     int init[7] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0};  // [7] nvox and [8] ncorr stay untouched
     memcpy(hsm, init, sizeof(init));
     HIPCHK(c, hipMemcpyAsync(dsm, hsm, sizeof(init), hipMemcpyHostToDevice, s));
-    rgck::bbox(s, cl.in, cl.stride_f, n, c->prm.voxel_res, dsm, dsm + 6);
+    rgck::bbox(s, cl.in, cl.stride_f, n, c->prm.voxel_res, dsm, dsm + 6, hi);
     HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", is_target ? "target" : "source");
@@ -224,11 +227,11 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
     HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nc1, s));
-    rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.cnt.p);
-    rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, (int*)cl.block_sums.p);
-    rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
+    rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.cnt.p, hi);
+    rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, (int*)cl.block_sums.p, hi);
+    rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p, hi);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
-                      (float4*)cl.P.p);
+                      (float4*)cl.P.p, hi);
     if (rgck::knn_impl() == 1) {
       HIPCHK(c, hipMemsetAsync(cl.nseg.p, 0, sizeof(int), s));
       rgck::segments(s, (const int*)cl.start.p, cl.grid, cl.segs.p, (int*)cl.nseg.p);
@@ -270,6 +273,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
   cl.ready = false;
   cl.n = 0;
   c->corr_valid = false;
+  c->deferred_known = false;
   if (!xyz || n < 0) return fail(c, RGC_ERR_INVALID, "null cloud");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
   if (n < c->prm.k_correspondences)
@@ -513,7 +517,11 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
     c->prm = *params;
   }
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+  {  // the source's small kernels must not queue behind the map's 15k-wave kNN launch: highest stream priority
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    ok = ok && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) == hipSuccess;
+  }
   ok = ok && hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_small, 48 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_out, 64 * sizeof(double)) == hipSuccess;
@@ -544,6 +552,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->h_lm) (void)hipHostFree(c->h_lm);
   release(c->lm_state);
+  release(c->fit_partials);
   if (c->src_ready) (void)hipEventDestroy(c->src_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -616,6 +625,8 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
   for (int i = 0; i < 6; i++) Hfin[i * 7] = 1.0;  // final_hessian_.setIdentity(), :21
   c->stats.n_linearize = c->stats.n_error = c->stats.outer_iterations = 0;
 
+  bool fitness_chained = false;
+  double fit_sum = 0.0;
   if (!c->lm_host) {
     // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_A / k_lm_B);
     // the host only enqueues slots and reads the state back once per batch.
@@ -623,18 +634,18 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     if ((rc = ensure(c, c->corr_v, sizeof(int) * (size_t)n * noff))) return rc;
     if ((rc = ensure(c, c->corr_M, sizeof(double) * 6 * (size_t)n * noff))) return rc;
     const int nb = rgck::linearize_blocks(n);
-    if ((rc = ensure(c, c->partials, sizeof(double) * rgck::kAccum * (size_t)nb))) return rc;
+    if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 1) * (size_t)nb))) return rc;
     if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
     if ((rc = ensure(c, c->lm_state, sizeof(rgck::LmState)))) return rc;
+    if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)nb + 64))) return rc;
     rgck::LmState& S = *c->h_lm;
-    memset(&S, 0, sizeof(S));
-    memcpy(S.x0, x0, sizeof(x0));
-    S.lambda = -1.0; S.nu = 2.0;
-    memcpy(S.Hfin, Hfin, sizeof(Hfin));
-    S.rot_eps = P.rotation_eps; S.trans_eps = P.translation_eps; S.init_factor = P.lm_init_lambda_factor;
-    S.max_outer = P.max_iterations; S.max_inner = P.lm_max_iterations;
-    S.done = P.max_iterations <= 0 ? 1 : 0;
-    HIPCHK(c, hipMemcpyAsync(c->lm_state.p, &S, sizeof(S), hipMemcpyHostToDevice, c->stream));
+    rgck::LmInit in;
+    memcpy(in.x0, x0, sizeof(x0));
+    in.rot_eps = P.rotation_eps; in.trans_eps = P.translation_eps; in.init_factor = P.lm_init_lambda_factor;
+    in.max_outer = P.max_iterations; in.max_inner = P.lm_max_iterations;
+    const bool rows_impl = rgck::knn_impl() == 0;
+    rgck::lm_init(c->stream, (rgck::LmState*)c->lm_state.p, in, c->d_small + 7, rows_impl ? c->tgt.segs.p : nullptr,
+                  rows_impl ? c->src.segs.p : nullptr);
     int batch = 6;
     for (int guard = 0; guard < 400; guard++) {
       {
@@ -644,14 +655,23 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
                         c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
                         (double*)c->partials.p, (int*)c->ipartials.p, (rgck::LmState*)c->lm_state.p);
       }
+      if (fitness) {  // getFitnessScore at the final pose, chained blindly: the kernel is a no-op unless the LM is done
+        ProfScope ps(c, RGC_K_FITNESS, n);
+        rgck::fitness_lm(c->stream, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
+                         (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p);
+      }
       HIPCHK(c, hipMemcpyAsync(&S, c->lm_state.p, sizeof(S), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       HIPCHK(c, hipGetLastError());
-      if (S.done) break;
+      if (S.done) { fitness_chained = S.has_fit != 0; break; }
       batch = 3;
     }
     c->corr_noff = noff; c->corr_n = n; c->corr_valid = S.n_lin > 0;
     c->stats.n_corr = S.ncorr; c->stats.n_linearize = S.n_lin; c->stats.n_error = S.n_err;
+    c->tgt.nvox = c->stats.n_voxels = S.nvox;
+    c->stats.deferred_target = S.def_t; c->stats.deferred_source = S.def_s;
+    c->deferred_known = true;
+    fit_sum = S.fit_sum;
     memcpy(x0, S.x0, sizeof(x0));
     memcpy(Hfin, S.Hfin, sizeof(Hfin));
     conv = S.conv != 0; failed = S.failed != 0;
@@ -703,7 +723,8 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
   if (converged) *converged = conv ? 1 : 0;
   if (lm_failed) *lm_failed = failed ? 1 : 0;
   if (fitness) {
-    if ((rc = do_fitness(c, fin, fitness))) return rc;
+    if (fitness_chained) *fitness = fit_sum / (double)c->src.n;
+    else if ((rc = do_fitness(c, fin, fitness))) return rc;
   }
   return RGC_OK;
 }
@@ -1065,8 +1086,8 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   if (!c || !out) return RGC_ERR_INVALID;
   if (c->tgt.ready) { int rc = fetch_nvox(c); if (rc) return rc; }
   // queries the bulk kNN kernel handed to the cooperative kernel (first int of the deferred-list buffer)
-  c->stats.deferred_target = c->stats.deferred_source = 0;
-  if (rgck::knn_impl() == 0) {
+  if (!c->deferred_known) c->stats.deferred_target = c->stats.deferred_source = 0;
+  if (!c->deferred_known && rgck::knn_impl() == 0) {
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     if (c->tgt.ready && c->tgt.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_target, c->tgt.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (c->src.ready && c->src.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_source, c->src.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -27,8 +27,11 @@ struct LmIn { double x0[16]; double lambda; double init_factor; };
 struct LmState {  // device-resident state of LsqRegistration::computeTransformation (lsq_registration_impl.hpp:53-172)
   double x0[16], lambda, nu, y0, yi, H[36], b[6], d[6], delta[16], xi[16], Hfin[36];
   double rot_eps, trans_eps, init_factor;
-  int phase, done, conv, failed, outer, inner, n_lin, n_err, ncorr, ticketA, ticketB, max_outer, max_inner, pad;
+  int phase, done, conv, failed, outer, inner, n_lin, n_err, ncorr, ticketA, ticketB, max_outer, max_inner, has_fit;
+  double fit_sum;                // sum of squared NN distances at the final pose (k_fitness_lm)
+  int nvox, def_t, def_s, pad;   // frame counters carried home with the state
 };
+struct LmInit { double x0[16], rot_eps, trans_eps, init_factor; int max_outer, max_inner; };
 struct FeParams { int n_scans; double min_range, max_range; };
 struct LeafGrid { int minb[3]; int div[3]; };  // pcl::VoxelGrid leaf grid
 
@@ -37,12 +40,12 @@ constexpr int kVoxRec = 10; // mean(3) cov6(6) num(1), doubles
 
 // Sorted points are float4 {x, y, z, original index (int bits)} grouped by grid cell.
 // ---- grid build ----
-void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags);
-void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt);
-void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */);
-void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp);
+void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi = 0);
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt, int hi = 0);
+void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */, int hi = 0);
+void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp, int hi = 0);
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const int* order_tmp, float4* P);
+                 const int* order_tmp, float4* P, int hi = 0);
 // ---- C2: exact kNN + PLANE covariance -> unit normal ----
 // row segments (work items of the tiled kNN kernel): segs needs segment_bytes(n) bytes, *nseg must be 0 on entry
 void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg);
@@ -69,6 +72,8 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
                        const double* corr_M, double* partials, double* out1);
 void lm_slot(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v, double* corr_M, double* partials, int* ncorr_partials, LmState* st);
+void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials);
+void lm_init(hipStream_t s, LmState* st, const LmInit& in, const int* nvox, const void* segs_t, const void* segs_s);
 // ---- C8 ----
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials,
              double* out1);

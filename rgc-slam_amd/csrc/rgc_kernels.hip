@@ -36,7 +36,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ------------------------------------------------------------------------------------------------
 // grid build
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ in, int stride_f, int n, double res, int* mm6, int* flags) {
+// The scan's (source) preprocessing runs on a second stream underneath the map's VALU-bound kNN launch; its waves share
+// CUs with that kernel and would get ~1/8 of the issue slots.  Raising the wave priority lets the small latency-chained
+// source kernels finish while the big kernel soaks up what is left.
+__device__ __forceinline__ void wave_prio(int hi) {
+  if (hi) __builtin_amdgcn_s_setprio(3);
+}
+
+__global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ in, int stride_f, int n, double res, int* mm6, int* flags, int prio) {
+  wave_prio(prio);
   __shared__ int red[256 / WAVE][6];
   int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
   int bad = 0;
@@ -69,7 +77,8 @@ __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ in, int 
 
 __device__ __forceinline__ int cell_index(const Grid& g, int cx, int cy, int cz) { return (cz * g.dim[1] + cy) * g.dim[0] + cx; }
 
-__global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* cnt) {
+__global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* cnt, int prio) {
+  wave_prio(prio);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* p = in + (size_t)i * stride_f;
@@ -107,7 +116,8 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
   return base + inc - v;
 }
 
-__global__ void k_scan_block(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ block_sums) {
+__global__ void k_scan_block(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ block_sums, int prio) {
+  wave_prio(prio);
   int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
   int v[SCAN_V], s = 0;
 #pragma unroll
@@ -125,7 +135,8 @@ __global__ void k_scan_block(const int* __restrict__ in, int* __restrict__ out, 
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ void k_scan_sums(int* sums, int nb) {  // single block, in-place exclusive scan
+__global__ void k_scan_sums(int* sums, int nb, int prio) {
+  wave_prio(prio);  // single block, in-place exclusive scan
   __shared__ int carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
@@ -142,7 +153,8 @@ __global__ void k_scan_sums(int* sums, int nb) {  // single block, in-place excl
   }
 }
 
-__global__ void k_scan_add(int* out, int n, const int* __restrict__ block_sums) {
+__global__ void k_scan_add(int* out, int n, const int* __restrict__ block_sums, int prio) {
+  wave_prio(prio);
   int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
   int add = block_sums[blockIdx.x];
 #pragma unroll
@@ -150,7 +162,8 @@ __global__ void k_scan_add(int* out, int n, const int* __restrict__ block_sums) 
     if (base + j < n) out[base + j] += add;
 }
 
-__global__ void k_scatter(int n, const int* __restrict__ cell_of, const int* __restrict__ start, int* cnt, int* __restrict__ order_tmp) {
+__global__ void k_scatter(int n, const int* __restrict__ cell_of, const int* __restrict__ start, int* cnt, int* __restrict__ order_tmp, int prio) {
+  wave_prio(prio);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int c = cell_of[i];
@@ -161,7 +174,8 @@ __global__ void k_scatter(int n, const int* __restrict__ cell_of, const int* __r
 // deterministic placement: a point's final slot = cell start + number of same-cell points with a smaller index.
 // Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate.
 __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
-                              const int* __restrict__ start, const int* __restrict__ order_tmp, float4* __restrict__ P) {
+                              const int* __restrict__ start, const int* __restrict__ order_tmp, float4* __restrict__ P, int prio) {
+  wave_prio(prio);
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   int i = order_tmp[s];
@@ -557,6 +571,7 @@ __global__ void __launch_bounds__(KNN_T)
 k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, int heavy, Deferred df,
            double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
   extern __shared__ int slist_rows[];  // [k][KNN_T]
+  wave_prio(!kTarget);
   const int i = blockIdx.x * KNN_T + threadIdx.x;
   if (i < n) knn_point<KC>(P, start, g, k, heavy, i, slist_rows + threadIdx.x, df, nx, ny, nz);
 }
@@ -642,6 +657,7 @@ __global__ void __launch_bounds__(KNN_T)
 k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int k, Deferred df, double* __restrict__ nx,
            double* __restrict__ ny, double* __restrict__ nz) {
   __shared__ CoopRows shm[KNN_T / WAVE];
+  wave_prio(!kTarget);
   const int lane = threadIdx.x & (WAVE - 1), wib = threadIdx.x / WAVE;
   CoopRows* sh = &shm[wib];
   const int wave = blockIdx.x * (KNN_T / WAVE) + wib, nwaves = gridDim.x * (KNN_T / WAVE);
@@ -1032,7 +1048,9 @@ __device__ __forceinline__ void neighbor_offset(int noff, int o, int& ox, int& o
   ox = o / 9 - 1; oy = (o / 3) % 3 - 1; oz = o % 3 - 1;
 }
 
-template <int NACC>
+// kWriteThrough: the row is handed to another workgroup of the SAME launch (last-block fold): agent-scope relaxed
+// atomic stores lower to write-through (sc1) stores, so no release fence (L2 write-back) is needed before the ticket.
+template <int NACC, bool kWriteThrough = false>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ row) {
   __shared__ double red[LIN_T / WAVE][NACC];
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
@@ -1046,7 +1064,8 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
     double s = 0;
 #pragma unroll
     for (int j = 0; j < LIN_T / WAVE; j++) s += red[j][threadIdx.x];
-    row[threadIdx.x] = s;
+    if (kWriteThrough) __hip_atomic_store(&row[threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else row[threadIdx.x] = s;
   }
 }
 
@@ -1178,15 +1197,14 @@ __device__ __forceinline__ double error_point(const float4* __restrict__ P, int 
 // state machine in device memory.  One SLOT = kernel A (linearise at x0 unless this is a retry; the last-arriving block
 // folds the partial rows and performs the LM try) + kernel B (cost at the trial pose; the last block folds, computes
 // rho and accepts / rejects / terminates).  The host enqueues slots blindly and reads the state back once per batch.
-// Inter-block hand-off: plain stores, every wave drains vmcnt, workgroup barrier, one lane agent-scope RELEASE + ticket;
-// the last arriver does an agent-scope ACQUIRE before the workgroup reads the rows (cdna_hip_programming.md G16).
+// Inter-block hand-off (cdna_hip_programming.md G16): write-through (sc1) row stores, every wave drains vmcnt, workgroup
+// barrier, one lane takes a ticket; the last arriver does an agent-scope ACQUIRE before its workgroup reads the rows.
 __device__ __forceinline__ bool last_block_arrive(int* ticket) {
   __shared__ int is_last_s;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the rows were written with write-through (sc1) stores and every storing wave has drained vmcnt: no release fence
     const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == (int)gridDim.x - 1);
     if (last) {
@@ -1213,12 +1231,37 @@ __device__ __forceinline__ void block_fold_rows(const double* __restrict__ parti
   __syncthreads();
 }
 
+// State of a fresh computeTransformation (lsq_registration_impl.hpp:53-63) from kernel arguments -- no H2D copy -- plus the
+// frame's counters (voxels, deferred kNN queries) so that ONE read-back of the state at the end carries every statistic.
+__global__ void __launch_bounds__(WAVE) k_lm_init(LmState* __restrict__ st, LmInit in, const int* __restrict__ nvox,
+                                                  const int* __restrict__ def_t, const int* __restrict__ def_s) {
+  int* w = reinterpret_cast<int*>(st);
+  for (int i = threadIdx.x; i < (int)(sizeof(LmState) / sizeof(int)); i += WAVE) w[i] = 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fill lands before lane 0's fields (same wave, in order)
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int a = 0; a < 16; a++) st->x0[a] = in.x0[a];
+  st->lambda = -1.0;  // :56
+  st->nu = 2.0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) st->Hfin[a * 7] = 1.0;  // final_hessian_.setIdentity(), :21
+  st->rot_eps = in.rot_eps;
+  st->trans_eps = in.trans_eps;
+  st->init_factor = in.init_factor;
+  st->max_outer = in.max_outer;
+  st->max_inner = in.max_inner;
+  st->done = in.max_outer <= 0 ? 1 : 0;
+  st->nvox = nvox ? *nvox : 0;
+  st->def_t = def_t ? *def_t : 0;
+  st->def_s = def_s ? *def_s : 0;
+}
+
 __global__ void __launch_bounds__(LIN_T)
 k_lm_A(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
        const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v, double* __restrict__ corr_M,
        double* __restrict__ partials, int* __restrict__ ncorr_partials, LmState* __restrict__ st) {
   if (st->done) return;
-  __shared__ double folded[kAccum];
+  __shared__ double folded[kAccum + 1];
   if (st->phase == 0) {
     Pose T;
 #pragma unroll
@@ -1233,10 +1276,13 @@ k_lm_A(const float4* __restrict__ P, const double* __restrict__ nx, const double
     for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
     int ncorr = 0;
     if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, 1, acc, ncorr);
-    block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
-    block_count_store(ncorr, ncorr_partials + blockIdx.x);
+    double acc2[kAccum + 1];
+#pragma unroll
+    for (int a = 0; a < kAccum; a++) acc2[a] = acc[a];
+    acc2[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
+    block_reduce_store<kAccum + 1, true>(acc2, partials + (size_t)blockIdx.x * (kAccum + 1));
     if (!last_block_arrive(&st->ticketA)) return;
-    block_fold_rows<kAccum>(partials, gridDim.x, folded);
+    block_fold_rows<kAccum + 1>(partials, gridDim.x, folded);
     if (threadIdx.x == 0) {
       int u = 0;
 #pragma unroll
@@ -1246,9 +1292,7 @@ k_lm_A(const float4* __restrict__ P, const double* __restrict__ nx, const double
 #pragma unroll
       for (int a = 0; a < 6; a++) st->b[a] = folded[21 + a];
       st->y0 = folded[27];
-      int nc = 0;
-      for (int r = 0; r < (int)gridDim.x; r++) nc += ncorr_partials[r];
-      st->ncorr = nc;
+      st->ncorr = (int)folded[kAccum];
       st->n_lin++;
       if (st->lambda < 0.0) {  // :130-132
         double m = 0;
@@ -1295,7 +1339,7 @@ k_lm_B(const float4* __restrict__ P, int n, const double* __restrict__ vox, int 
   const int i = blockIdx.x * LIN_T + threadIdx.x;
   double acc[1] = {0.0};
   if (i < n) acc[0] = error_point(P, i, n, st->xi, vox, noff, corr_v, corr_M);
-  block_reduce_store<1>(acc, partials + blockIdx.x);
+  block_reduce_store<1, true>(acc, partials + blockIdx.x);
   if (!last_block_arrive(&st->ticketB)) return;
   block_fold_rows<1>(partials, gridDim.x, folded);
   if (threadIdx.x != 0) return;
@@ -1421,6 +1465,66 @@ k_fitness(const float4* __restrict__ SP, int ns, PoseF T, const float4* __restri
   block_reduce_store<1>(acc, partials + blockIdx.x);
 }
 
+// the same with the final pose taken from the device-resident LM state
+__global__ void __launch_bounds__(LIN_T)
+k_fitness_lm(const float4* __restrict__ SP, int ns, LmState* __restrict__ st, const float4* __restrict__ TP,
+             const int* __restrict__ tstart, Grid g, double* __restrict__ partials) {
+  if (!st->done) return;  // enqueued blindly behind a batch of LM slots
+  PoseF T;
+#pragma unroll
+  for (int a = 0; a < 12; a++) T.m[a] = (float)st->x0[a];  // final_transformation_ = x0.cast<float>(), :77
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < ns) {
+    const float4 sp = SP[i];
+    const float x = sp.x, y = sp.y, z = sp.z;
+    const float px = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
+    const float py = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
+    const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
+    const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
+    const double q[3] = {(double)px, (double)py, (double)pz};
+    int rmax = 0, r = 1;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
+      r = max(r, max(-c[a], c[a] - (g.dim[a] - 1)));  // first cube that touches the grid when the query lies outside
+    }
+    float best = INFINITY;
+    for (;;) {
+      // cube [c-r, c+r]^3 as contiguous row ranges of the sorted target (the minimum only improves on re-scans)
+      for_each_cube_row(g, c, r, tstart, [&](int s0, int s1) {
+        for (int s = s0; s < s1; s += 4) {
+          const int e = s1 - 1;
+          const float4 c0 = TP[s], c1 = TP[min(s + 1, e)], c2 = TP[min(s + 2, e)], c3 = TP[min(s + 3, e)];
+          best = fminf(best, fminf(fminf(dist2(px, py, pz, c0), dist2(px, py, pz, c1)), fminf(dist2(px, py, pz, c2), dist2(px, py, pz, c3))));
+        }
+      });
+      if (r >= rmax) break;
+      int rn;
+      if (best < INFINITY) {
+        const double bound = cube_bound(g, c, q, r);
+        if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) break;
+        const double need = sqrt((double)best) * (1.0 + 1e-5);
+        rn = r + 1;
+        while (rn < rmax) {
+          const double b = cube_bound(g, c, q, rn);
+          if (b == 1.0e300 || b > need) break;
+          rn++;
+        }
+      } else {
+        rn = r + max(1, (r + 1) / 2);
+      }
+      r = min(rn, rmax);
+    }
+    acc[0] = (double)best;
+  }
+  block_reduce_store<1, true>(acc, partials + blockIdx.x);
+  if (!last_block_arrive(&st->ticketB)) return;  // the LM is over: its ticket is free
+  __shared__ double folded[1];
+  block_fold_rows<1>(partials, gridDim.x, folded);
+  if (threadIdx.x == 0) { st->fit_sum = folded[0]; st->has_fit = 1; }
+}
+
 __global__ void k_transform_f32(const float* __restrict__ in, int stride_f, int n, PoseF T, float* __restrict__ out, int ostride_f) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1488,26 +1592,26 @@ k_error_dev(const float4* __restrict__ P, int n, const double* __restrict__ Tdev
 // ------------------------------------------------------------------------------------------------
 static inline int nblk(long long n, int t) { return (int)((n + t - 1) / t); }
 
-void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags) {
-  hipLaunchKernelGGL(k_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags);
+void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi) {
+  hipLaunchKernelGGL(k_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags, hi);
 }
-void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt) {
-  hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, cnt);
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt, int hi) {
+  hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, cnt, hi);
 }
-void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums) {
+void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums, int hi) {
   const int nb = nblk(n, SCAN_B);
-  hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(SCAN_T), 0, s, in, out, n, block_sums);
+  hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(SCAN_T), 0, s, in, out, n, block_sums, hi);
   if (nb > 1) {
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, s, block_sums, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_T), 0, s, out, n, block_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, s, block_sums, nb, hi);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_T), 0, s, out, n, block_sums, hi);
   }
 }
-void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp) {
-  hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, start, cnt, order_tmp);
+void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp, int hi) {
+  hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, start, cnt, order_tmp, hi);
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const int* order_tmp, float4* P) {
-  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P);
+                 const int* order_tmp, float4* P, int hi) {
+  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, hi);
 }
 void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg) {
   hipLaunchKernelGGL(k_segments, dim3(nblk((long long)g.dim[1] * g.dim[2], 64)), dim3(64), 0, s, start, g, (Seg*)segs, nseg);
@@ -1603,6 +1707,12 @@ void lm_slot(hipStream_t s, const float4* P, const double* nx, const double* ny,
   const int nb = linearize_blocks(n);
   hipLaunchKernelGGL(k_lm_A, dim3(nb), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v, corr_M, partials, ncorr_partials, st);
   hipLaunchKernelGGL(k_lm_B, dim3(nb), dim3(LIN_T), 0, s, P, n, vox, noff, corr_v, corr_M, partials, st);
+}
+void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials) {
+  hipLaunchKernelGGL(k_fitness_lm, dim3(linearize_blocks(ns)), dim3(LIN_T), 0, s, SP, ns, st, TP, tstart, g, partials);
+}
+void lm_init(hipStream_t s, LmState* st, const LmInit& in, const int* nvox, const void* segs_t, const void* segs_s) {
+  hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(WAVE), 0, s, st, in, nvox, (const int*)segs_t, (const int*)segs_s);
 }
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials, double* out1) {
   const int nb = linearize_blocks(ns);
