@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librgc_hip.so")
+LIB_PATH = os.environ.get("RGC_HIP_LIB") or os.path.join(_HERE, "librgc_hip.so")  # RGC_HIP_LIB: developer override (A/B builds)
 
 DIRECT27, DIRECT7, DIRECT1 = 0, 1, 2
 

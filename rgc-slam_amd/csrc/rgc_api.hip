@@ -276,6 +276,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
   c->deferred_known = false;
   if (!xyz || n < 0) return fail(c, RGC_ERR_INVALID, "null cloud");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  if (n > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud has %d points, the limit is 2^27 (32-bit byte offsets into the sorted array)", n);
   if (n < c->prm.k_correspondences)
     return fail(c, RGC_ERR_TOO_FEW_POINTS, "%s cloud has %d points, need >= k = %d", is_target ? "target" : "source", n, c->prm.k_correspondences);
   HIPCHK(c, hipSetDevice(c->device));

@@ -283,33 +283,47 @@ __device__ __forceinline__ double cube_bound(const Grid& g, const int c[3], cons
 // ---- shared pieces of the exact search ----------------------------------------------------------------------
 template <int KC>
 struct TopK {  // the KC smallest squared distances, ascending, in registers (static indexing only)
-  float a[KC];
+  // Kept as fp32 BIT PATTERNS: squared distances are >= +0 (never -0, never NaN: non-finite input is rejected by k_bbox),
+  // so they order exactly like signed integers, and v_min_i32/v_max_i32 need none of the NaN-quieting v_max_f32 x,x
+  // that fminf/fmaxf cost on a loop-carried value (3 ops per slot instead of 2).
+  int a[KC];
   __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int j = 0; j < KC; j++) a[j] = INFINITY;
+    for (int j = 0; j < KC; j++) a[j] = 0x7f800000;  // +inf
   }
-  __device__ __forceinline__ void insert(float x) {
+  // One compare-exchange per slot, IN PLACE: the carried value ping-pongs between two registers and a[j] is a
+  // read-write operand, so the insert is exactly 2 KC VALU ops.  (Written in C++ the conditional insert becomes a phi
+  // per slot and the allocator materialises it as 20 extra v_mov.)
+  __device__ __forceinline__ void insert(float xf) {
+    int x = __float_as_int(xf), t;
 #pragma unroll
-    for (int j = 0; j < KC; j++) {
-      const float lo = fminf(a[j], x);
-      x = fmaxf(a[j], x);
-      a[j] = lo;
+    for (int j = 0; j < KC; j += 2) {
+      asm("v_max_i32 %2, %0, %1\n\tv_min_i32 %0, %0, %1" : "+v"(a[j]), "+v"(x), "=&v"(t));
+      if (j + 1 < KC) asm("v_max_i32 %2, %0, %1\n\tv_min_i32 %0, %0, %1" : "+v"(a[j + 1]), "+v"(t), "=&v"(x));
     }
   }
+  __device__ __forceinline__ bool improves(float x) const { return __float_as_int(x) < a[KC - 1]; }
+  __device__ __forceinline__ float at(int j) const { return __int_as_float(a[j]); }  // j must be a compile-time constant
   // a[k-1] without dynamic register indexing (a select chain is turned back into an indexed scratch access by
   // the compiler): the chain is ascending, so a[k-1] is the maximum of the first k entries
   __device__ __forceinline__ float kth(int k) const {
-    if (k == KC) return a[KC - 1];
-    float t = a[0];
+    if (k == KC) return __int_as_float(a[KC - 1]);
+    int t = a[0];
 #pragma unroll
-    for (int j = 1; j < KC; j++) t = (j < k) ? fmaxf(t, a[j]) : t;
-    return t;
+    for (int j = 1; j < KC; j++) t = (j < k) ? max(t, a[j]) : t;
+    return __int_as_float(t);
   }
 };
 
 __device__ __forceinline__ float dist2(float px, float py, float pz, const float4& c) {
   const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
   return (dx * dx + dy * dy) + dz * dz;  // flann::L2_Simple<float>; never contracted (-ffp-contract=off)
+}
+
+// sorted point at a 32-bit BYTE offset: base in SGPRs + one VGPR offset, no 64-bit address arithmetic per candidate
+// (n <= 2^27 points is enforced at the API, so 16 n fits)
+__device__ __forceinline__ float4 point_at(const float4* __restrict__ P, unsigned byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(P) + byte_off);
 }
 
 // neighbourhood mean / covariance in fp64 (fast_gicp_impl.hpp:256-262) and the PLANE normal
@@ -364,17 +378,33 @@ __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3],
 
 template <int KC>
 __device__ __forceinline__ void scan_range_topk(const float4* __restrict__ P, int s0, int s1, float px, float py, float pz, TopK<KC>& top) {
-  for (int s = s0; s < s1; s += 4) {
-    const int e = s1 - 1;
-    const float4 c0 = P[s], c1 = P[min(s + 1, e)], c2 = P[min(s + 2, e)], c3 = P[min(s + 3, e)];
+  int s = s0;
+  unsigned off = (unsigned)s0 << 4;
+  for (; s + 4 <= s1; s += 4, off += 64) {  // full quads: four independent 16-byte loads, no validity selects
+    const float4 c0 = point_at(P, off), c1 = point_at(P, off + 16), c2 = point_at(P, off + 32), c3 = point_at(P, off + 48);
+    const float x0 = dist2(px, py, pz, c0), x1 = dist2(px, py, pz, c1), x2 = dist2(px, py, pz, c2), x3 = dist2(px, py, pz, c3);
+#if defined(RGC_EXP) && RGC_EXP >= 3
+    top.a[KC - 1] = min(top.a[KC - 1], __float_as_int(fminf(fminf(x0, x1), fminf(x2, x3))));
+#else
+    if (__any(top.improves(x0))) top.insert(x0);
+    if (__any(top.improves(x1))) top.insert(x1);
+    if (__any(top.improves(x2))) top.insert(x2);
+    if (__any(top.improves(x3))) top.insert(x3);
+#endif
+  }
+  if (s < s1) {  // 1..3 left: clamped loads, +inf for the missing ones
+    const int rem = s1 - s;
+    const float4 c0 = point_at(P, off), c1 = point_at(P, off + (rem > 1 ? 16u : 0u)), c2 = point_at(P, off + (rem > 2 ? 32u : 0u));
     const float x0 = dist2(px, py, pz, c0);
-    const float x1 = (s + 1 < s1) ? dist2(px, py, pz, c1) : INFINITY;
-    const float x2 = (s + 2 < s1) ? dist2(px, py, pz, c2) : INFINITY;
-    const float x3 = (s + 3 < s1) ? dist2(px, py, pz, c3) : INFINITY;
-    if (__any(x0 < top.a[KC - 1])) top.insert(x0);
-    if (__any(x1 < top.a[KC - 1])) top.insert(x1);
-    if (__any(x2 < top.a[KC - 1])) top.insert(x2);
-    if (__any(x3 < top.a[KC - 1])) top.insert(x3);
+    const float d1 = dist2(px, py, pz, c1), d2 = dist2(px, py, pz, c2);
+    const float x1 = rem > 1 ? d1 : INFINITY, x2 = rem > 2 ? d2 : INFINITY;
+#if defined(RGC_EXP) && RGC_EXP >= 3
+    top.a[KC - 1] = min(top.a[KC - 1], __float_as_int(fminf(x0, fminf(x1, x2))));
+#else
+    if (__any(top.improves(x0))) top.insert(x0);
+    if (__any(top.improves(x1))) top.insert(x1);
+    if (__any(top.improves(x2))) top.insert(x2);
+#endif
   }
 }
 
@@ -392,13 +422,52 @@ __device__ __forceinline__ void collect_one(const float4& cp, int s, bool valid,
 }
 __device__ __forceinline__ void scan_range_collect(const float4* __restrict__ P, int s0, int s1, float px, float py, float pz, float thr,
                                                    int k, int* list, int lstride, int& m, int& tie_s, int& tie_o) {
-  for (int s = s0; s < s1; s += 4) {
-    const int e = s1 - 1;
-    const float4 c0 = P[s], c1 = P[min(s + 1, e)], c2 = P[min(s + 2, e)], c3 = P[min(s + 3, e)];
+  int s = s0;
+  unsigned off = (unsigned)s0 << 4;
+  for (; s + 4 <= s1; s += 4, off += 64) {
+    const float4 c0 = point_at(P, off), c1 = point_at(P, off + 16), c2 = point_at(P, off + 32), c3 = point_at(P, off + 48);
     collect_one(c0, s, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-    collect_one(c1, s + 1, s + 1 < s1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-    collect_one(c2, s + 2, s + 2 < s1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-    collect_one(c3, s + 3, s + 3 < s1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+    collect_one(c1, s + 1, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+    collect_one(c2, s + 2, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+    collect_one(c3, s + 3, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+  }
+  if (s < s1) {
+    const int rem = s1 - s;
+    const float4 c0 = point_at(P, off), c1 = point_at(P, off + (rem > 1 ? 16u : 0u)), c2 = point_at(P, off + (rem > 2 ? 32u : 0u));
+    collect_one(c0, s, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+    collect_one(c1, s + 1, rem > 1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+    collect_one(c2, s + 2, rem > 2, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
+  }
+}
+
+// Bulk-kernel collector: every candidate with d <= thr (thr = the exact k-th distance) is a neighbour unless MORE than
+// k candidates qualify, i.e. several sit exactly at the k-th distance and an index tie-break is needed -- the caller
+// sees m > k and hands the query to the cooperative kernel.  No tie bookkeeping, no .w load, one branch per candidate.
+__device__ __forceinline__ void collect_le(const float4& cp, int s, bool valid, float px, float py, float pz, float thr, int k, int* list,
+                                           int lstride, int& m) {
+  const float x = dist2(px, py, pz, cp);
+  if (valid && x <= thr) {
+    if (m < k) list[m * lstride] = s;
+    m++;
+  }
+}
+__device__ __forceinline__ void scan_range_collect_le(const float4* __restrict__ P, int s0, int s1, float px, float py, float pz, float thr,
+                                                      int k, int* list, int lstride, int& m) {
+  int s = s0;
+  unsigned off = (unsigned)s0 << 4;
+  for (; s + 4 <= s1; s += 4, off += 64) {
+    const float4 c0 = point_at(P, off), c1 = point_at(P, off + 16), c2 = point_at(P, off + 32), c3 = point_at(P, off + 48);
+    collect_le(c0, s, true, px, py, pz, thr, k, list, lstride, m);
+    collect_le(c1, s + 1, true, px, py, pz, thr, k, list, lstride, m);
+    collect_le(c2, s + 2, true, px, py, pz, thr, k, list, lstride, m);
+    collect_le(c3, s + 3, true, px, py, pz, thr, k, list, lstride, m);
+  }
+  if (s < s1) {
+    const int rem = s1 - s;
+    const float4 c0 = point_at(P, off), c1 = point_at(P, off + (rem > 1 ? 16u : 0u)), c2 = point_at(P, off + (rem > 2 ? 32u : 0u));
+    collect_le(c0, s, true, px, py, pz, thr, k, list, lstride, m);
+    collect_le(c1, s + 1, rem > 1, px, py, pz, thr, k, list, lstride, m);
+    collect_le(c2, s + 2, rem > 2, px, py, pz, thr, k, list, lstride, m);
   }
 }
 
@@ -542,16 +611,18 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
     }
   }
   bool done = false;
+#if defined(RGC_EXP) && RGC_EXP >= 2
+  if (rdone >= 0) { nx[i] = thr; ny[i] = thr; nz[i] = thr; return; }
+#endif
   if (rdone >= 0) {
-    int m = 0, tie_s = -1, tie_o = INT_MAX;
+    int m = 0;
     if (rdone == 0) {
-      scan_range_collect(P, own0, own1, px, py, pz, thr, k, list, KNN_T, m, tie_s, tie_o);
+      scan_range_collect_le(P, own0, own1, px, py, pz, thr, k, list, KNN_T, m);
     } else {
 #pragma unroll
-      for (int r = 0; r < 9; r++) scan_range_collect(P, lo[r], hi[r], px, py, pz, thr, k, list, KNN_T, m, tie_s, tie_o);
+      for (int r = 0; r < 9; r++) scan_range_collect_le(P, lo[r], hi[r], px, py, pz, thr, k, list, KNN_T, m);
     }
-    if (m < k && tie_s >= 0) { list[m * KNN_T] = tie_s; m++; }
-    done = (m >= k);  // else several candidates exactly at the k-th distance are needed: rare -> cooperative path
+    done = (m == k);  // m > k: several candidates exactly at the k-th distance, index tie-break -> cooperative path
   }
   if (!done) {
     const int e = atomicAdd(df.cnt, 1);
@@ -560,7 +631,11 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
     return;
   }
   double nrm[3];
+#if defined(RGC_EXP) && RGC_EXP >= 1
+  nrm[0] = list[0]; nrm[1] = list[(k - 1) * KNN_T]; nrm[2] = thr;
+#else
   normal_from_list(P, list, KNN_T, k, nrm);
+#endif
   nx[i] = nrm[0];
   ny[i] = nrm[1];
   nz[i] = nrm[2];
@@ -693,8 +768,8 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
         const float4 c0 = P[s0], c1 = P[s1];
         const float x0 = v0 ? dist2(px, py, pz, c0) : INFINITY;
         const float x1 = v1 ? dist2(px, py, pz, c1) : INFINITY;
-        if (x0 < top.a[KC - 1]) top.insert(x0);
-        if (x1 < top.a[KC - 1]) top.insert(x1);
+        if (top.improves(x0)) top.insert(x0);
+        if (top.improves(x1)) top.insert(x1);
       });
       // k-th smallest over the wave: largest bit pattern T with #(values < T) < k  ==  the k-th smallest value.
       // The count is a sum of ballot popcounts: compares write SGPR masks, s_bcnt1 adds them -- no cross-lane traffic.
@@ -702,10 +777,9 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
       for (int bit = 30; bit >= 0; bit--) {
         const unsigned cand = T | (1u << bit);
         if (cand > 0x7F800000u) continue;
-        const float tf = __uint_as_float(cand);
         int cnt_lt = 0;
 #pragma unroll
-        for (int j = 0; j < KC; j++) cnt_lt += __popcll(__ballot(top.a[j] < tf));
+        for (int j = 0; j < KC; j++) cnt_lt += __popcll(__ballot(top.a[j] < (int)cand));
         if (cnt_lt < k) T = cand;
       }
       thr = (T >= 0x7F800000u) ? INFINITY : __uint_as_float(T);
@@ -925,7 +999,7 @@ k_knn_tile(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
         const float4 c1 = cand[min(j + 1, h - 1)];
         const float x0 = dist2(px, py, pz, c0);
         const float x1 = (j + 1 < h) ? dist2(px, py, pz, c1) : INFINITY;
-        if (__any(fminf(x0, x1) < top.a[KC - 1])) {
+        if (__any(top.improves(fminf(x0, x1)))) {
           top.insert(x0);
           top.insert(x1);
         }
