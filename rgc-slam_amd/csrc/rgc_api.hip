@@ -35,7 +35,7 @@ struct Cloud {
   int stride_f = 0;
   int n = 0;
   bool ready = false;  // grid + normals (+ voxels for the target) enqueued
-  DevBuf in_copy, cell_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
+  DevBuf in_copy, cell_of, slot_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
   DevBuf segs, nseg;  // row segments of the tiled kNN kernel
   rgck::Grid grid{};
   // target only
@@ -128,7 +128,7 @@ void release(DevBuf& b) {
 }
 
 void release_cloud(Cloud& cl) {
-  for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs, &cl.nseg,
+  for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.slot_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs, &cl.nseg,
                     &cl.cell_voxel, &cl.vox, &cl.vox_cell})
     release(*b);
 }
@@ -194,9 +194,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
   const int hi = is_target ? 0 : 1;  // the scan's kernels share CUs with the map's kNN launch: raised wave priority
   {
     ProfScope ps(c, RGC_K_GRID, n, s);
-    int init[7] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0};  // [7] nvox and [8] ncorr stay untouched
-    memcpy(hsm, init, sizeof(init));
-    HIPCHK(c, hipMemcpyAsync(dsm, hsm, sizeof(init), hipMemcpyHostToDevice, s));
+    // bbox accumulators + flag; the map's copy also zeroes [7], its voxel counter ([8] ncorr stays untouched; the scan's
+    // block lives at +16 and must not touch the map's counter)
+    const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+    const size_t init_bytes = (is_target ? 8 : 7) * sizeof(int);
+    memcpy(hsm, init, init_bytes);
+    HIPCHK(c, hipMemcpyAsync(dsm, hsm, init_bytes, hipMemcpyHostToDevice, s));
     rgck::bbox(s, cl.in, cl.stride_f, n, c->prm.voxel_res, dsm, dsm + 6, hi);
     HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -216,9 +219,10 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     const size_t nc1 = (size_t)g.ncell + 1;
     int rc;
     if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1))) return rc;
+    if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;
+    if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1 + 256))) return rc;
     if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
-    if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nc1 / 2048 + 2)))) return rc;
+    if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (nc1 / 2048 + 2)))) return rc;
     if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.P, sizeof(float4) * n))) return rc;
     if ((rc = ensure(c, cl.segs, rgck::segment_bytes(n)))) return rc;
@@ -226,12 +230,14 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
-    HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nc1, s));
-    rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.cnt.p, hi);
-    rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, (int*)cl.block_sums.p, hi);
-    rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p, hi);
+    if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)g.ncell))) return rc;
+    HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, (sizeof(int) * nc1 + 255) & ~(size_t)255, s));  // whole 256-byte lines: one fill kernel
+    rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi);
+    rgck::scan_cells(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
+                     is_target ? c->d_small + 7 : nullptr, hi);
+    rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p, hi);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
-                      (float4*)cl.P.p, hi);
+                      (float4*)cl.P.p, rgck::knn_impl() == 0 ? (int*)cl.segs.p : nullptr, hi);
     if (rgck::knn_impl() == 1) {
       HIPCHK(c, hipMemsetAsync(cl.nseg.p, 0, sizeof(int), s));
       rgck::segments(s, (const int*)cl.start.p, cl.grid, cl.segs.p, (int*)cl.nseg.p);
@@ -249,14 +255,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
   }
   if (is_target) {
     int rc;
-    if ((rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)cl.grid.ncell))) return rc;
     const size_t vmax = (size_t)(n < cl.grid.ncell ? n : cl.grid.ncell);
     if ((rc = ensure(c, cl.vox, sizeof(double) * rgck::kVoxRec * vmax))) return rc;
     if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
     ProfScope ps(c, RGC_K_VOXEL, n);
-    HIPCHK(c, hipMemsetAsync(c->d_small + 7, 0, sizeof(int), s));
     rgck::voxel_build(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p,
-                      (const int*)cl.start.p, cl.grid, (int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, c->d_small + 7);
+                      (const int*)cl.start.p, cl.grid, n, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p);
     cl.nvox = -1;  // fetched lazily
   }
   HIPCHK(c, hipGetLastError());
@@ -441,8 +445,7 @@ int do_fitness(rgc_ctx* c, const float T[16], double* out) {
   int rc = need_inputs(c);
   if (rc) return rc;
   const int n = c->src.n;
-  const int nb = rgck::linearize_blocks(n);
-  if ((rc = ensure(c, c->partials, sizeof(double) * rgck::kAccum * (size_t)nb))) return rc;
+  if ((rc = ensure(c, c->partials, sizeof(double) * (size_t)rgck::fitness_blocks(n) + 64))) return rc;
   {
     ProfScope ps(c, RGC_K_FITNESS, n);
     rgck::fitness(c->stream, (const float4*)c->src.P.p, n, posef_from(T), (const float4*)c->tgt.P.p, (const int*)c->tgt.start.p,
@@ -638,7 +641,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 1) * (size_t)nb))) return rc;
     if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
     if ((rc = ensure(c, c->lm_state, sizeof(rgck::LmState)))) return rc;
-    if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)nb + 64))) return rc;
+    if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)rgck::fitness_blocks(n) + 64))) return rc;
     rgck::LmState& S = *c->h_lm;
     rgck::LmInit in;
     memcpy(in.x0, x0, sizeof(x0));

@@ -41,11 +41,14 @@ constexpr int kVoxRec = 10; // mean(3) cov6(6) num(1), doubles
 // Sorted points are float4 {x, y, z, original index (int bits)} grouped by grid cell.
 // ---- grid build ----
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi = 0);
-void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt, int hi = 0);
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi = 0);
+// cnt: n = cells + 1 entries; block_sums: >= 8 * (n / 2048 + 2) bytes; cell_voxel (n - 1 ints) and nvox may be null
+void scan_cells(hipStream_t s, const int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi = 0);
+void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi = 0);
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */, int hi = 0);
 void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp, int hi = 0);
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const int* order_tmp, float4* P, int hi = 0);
+                 const int* order_tmp, float4* P, int* zero_me = nullptr, int hi = 0);
 // ---- C2: exact kNN + PLANE covariance -> unit normal ----
 // row segments (work items of the tiled kNN kernel): segs needs segment_bytes(n) bytes, *nseg must be 0 on entry
 void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg);
@@ -60,7 +63,7 @@ void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, 
               double* ny, double* nz);
 // ---- C3: Gaussian voxel map ----
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
-                 int* cell_voxel, double* vox, int* vox_cell, int* nvox);
+                 int n, const int* cell_voxel, double* vox, int* vox_cell);
 // ---- C4/C5/C6 ----
 void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
                const int* cell_voxel, const double* vox, int noff, int* corr_v, double* corr_M, int want_H, double* partials,
@@ -81,6 +84,7 @@ void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP,
 void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f);
 void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const float4* P, int n, double* out3);
 int  linearize_blocks(int n);
+int  fitness_blocks(int n);
 // ---- B2 / B3 / B9 (rgc_pre.hip) ----
 void deskew(hipStream_t s, float* xyzi, int stride_f, int n, Quat qinv, const double t[3]);
 void transform_q(hipStream_t s, const float* in, int stride_f, int n, Quat q, const double t[3], float* out, int ostride_f);

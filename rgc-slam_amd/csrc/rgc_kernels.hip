@@ -43,21 +43,42 @@ __device__ __forceinline__ void wave_prio(int hi) {
   if (hi) __builtin_amdgcn_s_setprio(3);
 }
 
+// Bounding box in CELL coordinates.  voxel_coord1 is monotone, so the per-thread work is a float min/max (the fp64
+// division runs once per thread, not once per coordinate); four points are in flight per lane; a block only issues
+// its six same-address atomics when it would still move the global bound (a relaxed read first) -- with ~1000 blocks the
+// serialised atomics used to cost more than the 16 MB read.
 __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ in, int stride_f, int n, double res, int* mm6, int* flags, int prio) {
   wave_prio(prio);
   __shared__ int red[256 / WAVE][6];
-  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+  float flo[3] = {INFINITY, INFINITY, INFINITY}, fhi[3] = {-INFINITY, -INFINITY, -INFINITY};
   int bad = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float* p = in + (size_t)i * stride_f;
+  const int T = gridDim.x * blockDim.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  auto take = [&](float v, int a) {
+    bad |= !(fabsf(v) <= 1.0e8f);  // NaN, inf and absurd coordinates
+    flo[a] = fminf(flo[a], v);
+    fhi[a] = fmaxf(fhi[a], v);
+  };
+  for (; i + 3 * T < n; i += 4 * T) {
+    float v[4][3];
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const float v = p[a];
-      if (!isfinite(v) || fabsf(v) > 1.0e8f) { bad = 1; continue; }
-      const int c = voxel_coord1(v, res);
-      lo[a] = min(lo[a], c);
-      hi[a] = max(hi[a], c);
+    for (int u = 0; u < 4; u++) {
+      const float* p = in + (size_t)(i + u * T) * stride_f;
+      v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2];
     }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { take(v[u][0], 0); take(v[u][1], 1); take(v[u][2], 2); }
+  }
+  for (; i < n; i += T) {
+    const float* p = in + (size_t)i * stride_f;
+    take(p[0], 0); take(p[1], 1); take(p[2], 2);
+  }
+  int lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const bool any_pt = flo[a] <= fhi[a] && !bad;  // a flagged cloud is rejected by the host: its bounds do not matter
+    lo[a] = any_pt ? voxel_coord1(flo[a], res) : INT_MAX;
+    hi[a] = any_pt ? voxel_coord1(fhi[a], res) : INT_MIN;
   }
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
 #pragma unroll
@@ -69,15 +90,17 @@ __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ in, int 
   if (threadIdx.x < 6) {
     int v = red[0][threadIdx.x];
     for (int j = 1; j < 256 / WAVE; j++) v = threadIdx.x < 3 ? min(v, red[j][threadIdx.x]) : max(v, red[j][threadIdx.x]);
-    if (threadIdx.x < 3) { if (v != INT_MAX) atomicMin(&mm6[threadIdx.x], v); }
-    else { if (v != INT_MIN) atomicMax(&mm6[threadIdx.x], v); }
+    const int cur = __hip_atomic_load(&mm6[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 3) { if (v < cur) atomicMin(&mm6[threadIdx.x], v); }
+    else { if (v > cur) atomicMax(&mm6[threadIdx.x], v); }
   }
   if (bad) atomicOr(flags, 1);
 }
 
 __device__ __forceinline__ int cell_index(const Grid& g, int cx, int cy, int cz) { return (cz * g.dim[1] + cy) * g.dim[0] + cx; }
 
-__global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* cnt, int prio) {
+__global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* __restrict__ slot_of,
+                        int* cnt, int prio) {
   wave_prio(prio);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -87,7 +110,8 @@ __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid 
   int cz = voxel_coord1(p[2], g.res) - g.minc[2];
   int c = cell_index(g, cx, cy, cz);
   cell_of[i] = c;
-  atomicAdd(&cnt[c], 1);
+  // the returned count is this point's (arrival-order) slot inside its cell: the placement pass needs no second atomic
+  slot_of[i] = atomicAdd(&cnt[c], 1);
 }
 
 // three-kernel exclusive scan: 2048 items per block (256 threads x 8)
@@ -162,6 +186,108 @@ __global__ void k_scan_add(int* out, int n, const int* __restrict__ block_sums, 
     if (base + j < n) out[base + j] += add;
 }
 
+// ---- cell scan: start[] AND the dense voxel numbering in one pass --------------------------------------------------
+// value per cell = count | (occupied << 32): one 64-bit exclusive scan yields the cell's first sorted slot (low half) and
+// the number of occupied cells before it (high half) = its voxel id.  Voxel ids therefore come out dense, deterministic and
+// in cell order without a single atomic (one same-address atomic per wave used to bound the voxel kernel: ~12 ns each
+// across the 8 XCDs).  n <= 2^27 points: the halves cannot carry into each other.
+__device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned long long v, unsigned long long* total) {
+  __shared__ unsigned long long wsum64[SCAN_T / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const unsigned long long t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == WAVE - 1) wsum64[w] = inc;
+  __syncthreads();
+  unsigned long long base = 0, tot = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_T / WAVE; j++) {
+    const unsigned long long s = wsum64[j];
+    if (j < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// cnt has n entries (cells + 1 sentinel of 0); cell_voxel (nullable) has n - 1
+__global__ void k_cells_scan_block(const int* __restrict__ cnt, int* __restrict__ start, int n, unsigned long long* __restrict__ block_sums,
+                                   int* __restrict__ cell_voxel, int* __restrict__ nvox, int prio) {
+  wave_prio(prio);
+  const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
+  int v[SCAN_V];
+  unsigned long long s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++) {
+    v[j] = (base + j < n) ? cnt[base + j] : 0;
+    s += (unsigned long long)(unsigned)v[j] | ((unsigned long long)(v[j] > 0) << 32);
+  }
+  unsigned long long tot;
+  unsigned long long ex = block_exclusive_scan64(s, &tot);
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++) {
+    if (base + j < n) {
+      start[base + j] = (int)(unsigned)ex;
+      if (cell_voxel && base + j < n - 1) cell_voxel[base + j] = v[j] > 0 ? (int)(ex >> 32) : -1;
+    }
+    ex += (unsigned long long)(unsigned)v[j] | ((unsigned long long)(v[j] > 0) << 32);
+  }
+  if (threadIdx.x == 0) {
+    block_sums[blockIdx.x] = tot;
+    if (gridDim.x == 1 && nvox) *nvox = (int)(tot >> 32);
+  }
+}
+
+__global__ void k_cells_scan_sums(unsigned long long* sums, int nb, int* __restrict__ nvox, int prio) {
+  wave_prio(prio);  // single block, in-place exclusive scan
+  __shared__ unsigned long long carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += SCAN_T) {
+    const int i = base + threadIdx.x;
+    const unsigned long long v = i < nb ? sums[i] : 0;
+    unsigned long long tot;
+    const unsigned long long ex = block_exclusive_scan64(v, &tot);
+    const unsigned long long carry = carry_s;
+    if (i < nb) sums[i] = ex + carry;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && nvox) *nvox = (int)(carry_s >> 32);
+}
+
+__global__ void k_cells_scan_add(int* __restrict__ start, int n, const unsigned long long* __restrict__ block_sums, int* __restrict__ cell_voxel,
+                                 int prio) {
+  wave_prio(prio);
+  const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
+  const unsigned long long add = block_sums[blockIdx.x];
+  const int add_s = (int)(unsigned)add, add_v = (int)(add >> 32);
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++) {
+    if (base + j < n) {
+      start[base + j] += add_s;
+      if (cell_voxel && base + j < n - 1) {
+        const int cv = cell_voxel[base + j];
+        if (cv >= 0) cell_voxel[base + j] = cv + add_v;
+      }
+    }
+  }
+}
+
+// placement without atomics: slot_of[] came back from k_count's atomicAdd
+__global__ void k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of, const int* __restrict__ start,
+                        int* __restrict__ order_tmp, int prio) {
+  wave_prio(prio);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  order_tmp[start[cell_of[i]] + slot_of[i]] = i;  // unordered inside the cell; k_rank_gather makes the order deterministic
+}
+
 __global__ void k_scatter(int n, const int* __restrict__ cell_of, const int* __restrict__ start, int* cnt, int* __restrict__ order_tmp, int prio) {
   wave_prio(prio);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,9 +300,11 @@ __global__ void k_scatter(int n, const int* __restrict__ cell_of, const int* __r
 // deterministic placement: a point's final slot = cell start + number of same-cell points with a smaller index.
 // Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate.
 __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
-                              const int* __restrict__ start, const int* __restrict__ order_tmp, float4* __restrict__ P, int prio) {
+                              const int* __restrict__ start, const int* __restrict__ order_tmp, float4* __restrict__ P, int* zero_me,
+                              int prio) {
   wave_prio(prio);
   int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0 && zero_me) *zero_me = 0;  // the kNN launch that follows counts its deferred queries here
   if (s >= n) return;
   int i = order_tmp[s];
   int c = cell_of[i];
@@ -1057,31 +1185,67 @@ k_knn_tile(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// C3  Gaussian voxel map (ADDITIVE): one lane per grid cell; the cell's points are contiguous and in ascending
-// original index, so the fp64 sums run in the reference's cloud order (fast_vgicp_voxel.hpp:112-121,129-156).
-// record = { mean xyz, cov00 01 02 11 12 22, num }  (10 doubles).  C_i = I - 0.999 n_i n_i^T.
+// C3  Gaussian voxel map (ADDITIVE), fast_vgicp_voxel.hpp:112-121,129-156.  record = { mean xyz, cov00 01 02 11 12 22,
+// num } (10 doubles), C_i = I - 0.999 n_i n_i^T.
+// One lane per POINT (sorted order): every lane puts its point's nine fp64 terms into LDS; the lane holding the
+// FIRST point of a cell then adds the cell's terms in ascending order -- the sorted order inside a cell is ascending
+// original index, so the sums run in the reference's cloud order, bit for bit what a serial loop gives -- reading LDS
+// for the part inside this block and global memory for the few points that spill into the next block.
+// (A lane per grid cell, as before, spends 96 % of its lanes on empty cells and serialises one memory round trip per
+// point.)  The voxel id of a cell comes from the cell scan (cell_voxel, -1 for empty cells).
 // ------------------------------------------------------------------------------------------------
-__global__ void k_voxel_build(const float4* __restrict__ P,
-                              const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
-                              const int* __restrict__ start, Grid g, int* __restrict__ cell_voxel, double* __restrict__ vox,
-                              int* __restrict__ vox_cell, int* nvox) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= g.ncell) return;
-  const int s0 = start[c], s1 = start[c + 1];
-  if (s0 == s1) { cell_voxel[c] = -1; return; }
-  double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
-  for (int s = s0; s < s1; s++) {
+constexpr int VOX_T = 256;
+__global__ void __launch_bounds__(VOX_T)
+k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
+              const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
+              int* __restrict__ vox_cell) {
+  __shared__ double sh[9][VOX_T];
+  const int b0 = blockIdx.x * VOX_T, bend = min(b0 + VOX_T, n);
+  const int s = b0 + threadIdx.x;
+  int c = 0, s1 = 0;
+  bool head = false;
+  if (s < n) {
     const float4 cp = P[s];
-    m[0] += (double)cp.x;
-    m[1] += (double)cp.y;
-    m[2] += (double)cp.z;
     const double a = nx[s], b = ny[s], d = nz[s];
-    C[0] += 1.0 - 0.999 * a * a; C[1] += -0.999 * a * b; C[2] += -0.999 * a * d;
-    C[3] += 1.0 - 0.999 * b * b; C[4] += -0.999 * b * d; C[5] += 1.0 - 0.999 * d * d;
+    c = cell_index(g, voxel_coord1(cp.x, g.res) - g.minc[0], voxel_coord1(cp.y, g.res) - g.minc[1], voxel_coord1(cp.z, g.res) - g.minc[2]);
+    const int s0 = start[c];
+    s1 = start[c + 1];
+    head = (s0 == s);
+    sh[0][threadIdx.x] = (double)cp.x;
+    sh[1][threadIdx.x] = (double)cp.y;
+    sh[2][threadIdx.x] = (double)cp.z;
+    sh[3][threadIdx.x] = 1.0 - 0.999 * a * a;
+    sh[4][threadIdx.x] = -0.999 * a * b;
+    sh[5][threadIdx.x] = -0.999 * a * d;
+    sh[6][threadIdx.x] = 1.0 - 0.999 * b * b;
+    sh[7][threadIdx.x] = -0.999 * b * d;
+    sh[8][threadIdx.x] = 1.0 - 0.999 * d * d;
   }
-  const double num = (double)(s1 - s0);
-  const int v = atomicAdd(nvox, 1);
-  cell_voxel[c] = v;
+  __syncthreads();
+  if (!head) return;
+  double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
+  const int e_in = min(s1, bend);
+  for (int u = s; u < e_in; u++) {
+    const int t = u - b0;
+    m[0] += sh[0][t]; m[1] += sh[1][t]; m[2] += sh[2][t];
+#pragma unroll
+    for (int j = 0; j < 6; j++) C[j] += sh[3 + j][t];
+  }
+  for (int u = e_in; u < s1; u += 2) {  // the cell runs past this block: two points per step straight from memory
+    const int u1 = min(u + 1, s1 - 1);
+    const float4 p0 = P[u], p1 = P[u1];
+    const double a0 = nx[u], b0_ = ny[u], d0 = nz[u], a1 = nx[u1], b1 = ny[u1], d1 = nz[u1];
+    m[0] += (double)p0.x; m[1] += (double)p0.y; m[2] += (double)p0.z;
+    C[0] += 1.0 - 0.999 * a0 * a0; C[1] += -0.999 * a0 * b0_; C[2] += -0.999 * a0 * d0;
+    C[3] += 1.0 - 0.999 * b0_ * b0_; C[4] += -0.999 * b0_ * d0; C[5] += 1.0 - 0.999 * d0 * d0;
+    if (u + 1 < s1) {
+      m[0] += (double)p1.x; m[1] += (double)p1.y; m[2] += (double)p1.z;
+      C[0] += 1.0 - 0.999 * a1 * a1; C[1] += -0.999 * a1 * b1; C[2] += -0.999 * a1 * d1;
+      C[3] += 1.0 - 0.999 * b1 * b1; C[4] += -0.999 * b1 * d1; C[5] += 1.0 - 0.999 * d1 * d1;
+    }
+  }
+  const double num = (double)(s1 - s);
+  const int v = cell_voxel[c];  // dense id from the cell scan
   vox_cell[v] = c;
   double* rec = vox + (size_t)v * kVoxRec;
   rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
@@ -1488,115 +1652,93 @@ k_error(const float4* __restrict__ P, int n, Pose T, const double* __restrict__ 
 // C8  pcl::Registration::getFitnessScore: fp32 transform, exact 1-NN in the target grid, fp32 distances summed
 // in fp64.  One lane per source point.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(LIN_T)
-k_fitness(const float4* __restrict__ SP, int ns, PoseF T, const float4* __restrict__ TP,
-          const int* __restrict__ tstart, Grid g, double* __restrict__ partials) {
-  const int i = blockIdx.x * LIN_T + threadIdx.x;
-  double acc[1] = {0.0};
-  if (i < ns) {
-    const float4 sp = SP[i];
-    const float x = sp.x, y = sp.y, z = sp.z;
-    const float px = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
-    const float py = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
-    const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
-    const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
-    const double q[3] = {(double)px, (double)py, (double)pz};
-    int rmax = 0, r = 1;
+constexpr int FIT_T = 64;  // one wave per block: 30 k scan points spread over ~470 workgroups instead of 118
+int fitness_blocks(int n) { return (n + FIT_T - 1) / FIT_T; }
+
+// squared distance from the transformed source point i to its nearest target point (exact: the search cube grows until
+// the best distance is provably inside it)
+__device__ __forceinline__ float fitness_point(const float4* __restrict__ SP, int i, const PoseF& T, const float4* __restrict__ TP,
+                                               const int* __restrict__ tstart, const Grid& g) {
+  const float4 sp = SP[i];
+  const float x = sp.x, y = sp.y, z = sp.z;
+  const float px = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
+  const float py = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
+  const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
+  const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
+  const double q[3] = {(double)px, (double)py, (double)pz};
+  int rmax = 0, r = 1;
+  bool inside = true;
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
-      r = max(r, max(-c[a], c[a] - (g.dim[a] - 1)));  // first cube that touches the grid when the query lies outside
-    }
-    float best = INFINITY;
-    for (;;) {
-      // cube [c-r, c+r]^3 as contiguous row ranges of the sorted target (the minimum only improves on re-scans)
-      for_each_cube_row(g, c, r, tstart, [&](int s0, int s1) {
-        for (int s = s0; s < s1; s += 4) {
-          const int e = s1 - 1;
-          const float4 c0 = TP[s], c1 = TP[min(s + 1, e)], c2 = TP[min(s + 2, e)], c3 = TP[min(s + 3, e)];
-          best = fminf(best, fminf(fminf(dist2(px, py, pz, c0), dist2(px, py, pz, c1)), fminf(dist2(px, py, pz, c2), dist2(px, py, pz, c3))));
-        }
-      });
-      if (r >= rmax) break;
-      int rn;
-      if (best < INFINITY) {
-        const double bound = cube_bound(g, c, q, r);
-        if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) break;
-        const double need = sqrt((double)best) * (1.0 + 1e-5);
-        rn = r + 1;
-        while (rn < rmax) {
-          const double b = cube_bound(g, c, q, rn);
-          if (b == 1.0e300 || b > need) break;
-          rn++;
-        }
-      } else {
-        rn = r + max(1, (r + 1) / 2);
-      }
-      r = min(rn, rmax);
-    }
-    acc[0] = (double)best;
+  for (int a = 0; a < 3; a++) {
+    rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
+    r = max(r, max(-c[a], c[a] - (g.dim[a] - 1)));  // first cube that touches the grid when the query lies outside
+    inside = inside && c[a] >= 0 && c[a] < g.dim[a];
   }
-  block_reduce_store<1>(acc, partials + blockIdx.x);
+  float best = INFINITY;
+  auto scan = [&](int s0, int s1) {
+    int s = s0;
+    unsigned off = (unsigned)s0 << 4;
+    for (; s + 4 <= s1; s += 4, off += 64) {
+      const float4 c0 = point_at(TP, off), c1 = point_at(TP, off + 16), c2 = point_at(TP, off + 32), c3 = point_at(TP, off + 48);
+      best = fminf(best, fminf(fminf(dist2(px, py, pz, c0), dist2(px, py, pz, c1)), fminf(dist2(px, py, pz, c2), dist2(px, py, pz, c3))));
+    }
+    for (; s < s1; s++, off += 16) best = fminf(best, dist2(px, py, pz, point_at(TP, off)));
+  };
+  if (inside) {  // an aligned scan point usually has its nearest map point in its own cell, closer than the cell walls
+    const int own = cell_index(g, c[0], c[1], c[2]);
+    scan(tstart[own], tstart[own + 1]);
+    if (best < INFINITY) {
+      const double bound = cube_bound(g, c, q, 0);
+      if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) return best;
+    }
+  }
+  for (;;) {
+    // cube [c-r, c+r]^3 as contiguous row ranges of the sorted target (the minimum only improves on re-scans)
+    for_each_cube_row(g, c, r, tstart, scan);
+    if (r >= rmax) break;
+    int rn;
+    if (best < INFINITY) {
+      const double bound = cube_bound(g, c, q, r);
+      if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) break;
+      const double need = sqrt((double)best) * (1.0 + 1e-5);
+      rn = r + 1;
+      while (rn < rmax) {
+        const double b = cube_bound(g, c, q, rn);
+        if (b == 1.0e300 || b > need) break;
+        rn++;
+      }
+    } else {
+      rn = r + max(1, (r + 1) / 2);
+    }
+    r = min(rn, rmax);
+  }
+  return best;
 }
 
-// the same with the final pose taken from the device-resident LM state
-__global__ void __launch_bounds__(LIN_T)
+__global__ void __launch_bounds__(FIT_T)
+k_fitness(const float4* __restrict__ SP, int ns, PoseF T, const float4* __restrict__ TP,
+          const int* __restrict__ tstart, Grid g, double* __restrict__ partials) {
+  const int i = blockIdx.x * FIT_T + threadIdx.x;
+  const double v = wave_sum(i < ns ? (double)fitness_point(SP, i, T, TP, tstart, g) : 0.0);
+  if (threadIdx.x == 0) partials[blockIdx.x] = v;
+}
+
+// the same with the final pose taken from the device-resident LM state; the last block folds the rows into the state
+__global__ void __launch_bounds__(FIT_T)
 k_fitness_lm(const float4* __restrict__ SP, int ns, LmState* __restrict__ st, const float4* __restrict__ TP,
              const int* __restrict__ tstart, Grid g, double* __restrict__ partials) {
   if (!st->done) return;  // enqueued blindly behind a batch of LM slots
   PoseF T;
 #pragma unroll
   for (int a = 0; a < 12; a++) T.m[a] = (float)st->x0[a];  // final_transformation_ = x0.cast<float>(), :77
-  const int i = blockIdx.x * LIN_T + threadIdx.x;
-  double acc[1] = {0.0};
-  if (i < ns) {
-    const float4 sp = SP[i];
-    const float x = sp.x, y = sp.y, z = sp.z;
-    const float px = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
-    const float py = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
-    const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
-    const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
-    const double q[3] = {(double)px, (double)py, (double)pz};
-    int rmax = 0, r = 1;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
-      r = max(r, max(-c[a], c[a] - (g.dim[a] - 1)));  // first cube that touches the grid when the query lies outside
-    }
-    float best = INFINITY;
-    for (;;) {
-      // cube [c-r, c+r]^3 as contiguous row ranges of the sorted target (the minimum only improves on re-scans)
-      for_each_cube_row(g, c, r, tstart, [&](int s0, int s1) {
-        for (int s = s0; s < s1; s += 4) {
-          const int e = s1 - 1;
-          const float4 c0 = TP[s], c1 = TP[min(s + 1, e)], c2 = TP[min(s + 2, e)], c3 = TP[min(s + 3, e)];
-          best = fminf(best, fminf(fminf(dist2(px, py, pz, c0), dist2(px, py, pz, c1)), fminf(dist2(px, py, pz, c2), dist2(px, py, pz, c3))));
-        }
-      });
-      if (r >= rmax) break;
-      int rn;
-      if (best < INFINITY) {
-        const double bound = cube_bound(g, c, q, r);
-        if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) break;
-        const double need = sqrt((double)best) * (1.0 + 1e-5);
-        rn = r + 1;
-        while (rn < rmax) {
-          const double b = cube_bound(g, c, q, rn);
-          if (b == 1.0e300 || b > need) break;
-          rn++;
-        }
-      } else {
-        rn = r + max(1, (r + 1) / 2);
-      }
-      r = min(rn, rmax);
-    }
-    acc[0] = (double)best;
-  }
-  block_reduce_store<1, true>(acc, partials + blockIdx.x);
+  const int i = blockIdx.x * FIT_T + threadIdx.x;
+  const double v = wave_sum(i < ns ? (double)fitness_point(SP, i, T, TP, tstart, g) : 0.0);
+  if (threadIdx.x == 0) __hip_atomic_store(&partials[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through row
   if (!last_block_arrive(&st->ticketB)) return;  // the LM is over: its ticket is free
-  __shared__ double folded[1];
-  block_fold_rows<1>(partials, gridDim.x, folded);
-  if (threadIdx.x == 0) { st->fit_sum = folded[0]; st->has_fit = 1; }
+  double t = 0;
+  for (int r = threadIdx.x; r < (int)gridDim.x; r += FIT_T) t += partials[r];
+  t = wave_sum(t);
+  if (threadIdx.x == 0) { st->fit_sum = t; st->has_fit = 1; }
 }
 
 __global__ void k_transform_f32(const float* __restrict__ in, int stride_f, int n, PoseF T, float* __restrict__ out, int ostride_f) {
@@ -1669,8 +1811,20 @@ static inline int nblk(long long n, int t) { return (int)((n + t - 1) / t); }
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi) {
   hipLaunchKernelGGL(k_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags, hi);
 }
-void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* cnt, int hi) {
-  hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, cnt, hi);
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi) {
+  hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, hi);
+}
+void scan_cells(hipStream_t s, const int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi) {
+  const int nb = nblk(n, SCAN_B);
+  unsigned long long* bs = (unsigned long long*)block_sums;
+  hipLaunchKernelGGL(k_cells_scan_block, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, cell_voxel, nvox, hi);
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_cells_scan_sums, dim3(1), dim3(SCAN_T), 0, s, bs, nb, nvox, hi);
+    hipLaunchKernelGGL(k_cells_scan_add, dim3(nb), dim3(SCAN_T), 0, s, start, n, bs, cell_voxel, hi);
+  }
+}
+void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi) {
+  hipLaunchKernelGGL(k_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, slot_of, start, order_tmp, hi);
 }
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums, int hi) {
   const int nb = nblk(n, SCAN_B);
@@ -1684,8 +1838,8 @@ void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cn
   hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, start, cnt, order_tmp, hi);
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const int* order_tmp, float4* P, int hi) {
-  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, hi);
+                 const int* order_tmp, float4* P, int* zero_me, int hi) {
+  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi);
 }
 void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg) {
   hipLaunchKernelGGL(k_segments, dim3(nblk((long long)g.dim[1] * g.dim[2], 64)), dim3(64), 0, s, start, g, (Seg*)segs, nseg);
@@ -1706,8 +1860,7 @@ static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const in
                         const int* nseg, double* nx, double* ny, double* nz) {
   if (g_knn_impl == 0) {
     const size_t ldsr = (size_t)k * KNN_T * sizeof(int);
-    Deferred df = deferred_of(segs, n);
-    (void)hipMemsetAsync(df.cnt, 0, sizeof(int), s);
+    Deferred df = deferred_of(segs, n);  // df.cnt was zeroed by k_rank_gather
     const int nb = nblk(n, KNN_T);
     if (is_target)
       hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, df, nx, ny, nz);
@@ -1751,8 +1904,8 @@ void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, 
   else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz);
 }
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
-                 int* cell_voxel, double* vox, int* vox_cell, int* nvox) {
-  hipLaunchKernelGGL(k_voxel_build, dim3(nblk(g.ncell, 256)), dim3(256), 0, s, P, nx, ny, nz, start, g, cell_voxel, vox, vox_cell, nvox);
+                 int n, const int* cell_voxel, double* vox, int* vox_cell) {
+  hipLaunchKernelGGL(k_voxel_build, dim3(nblk(n, VOX_T)), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell);
 }
 void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
                const int* cell_voxel, const double* vox, int noff, int* corr_v, double* corr_M, int want_H, double* partials,
@@ -1783,14 +1936,14 @@ void lm_slot(hipStream_t s, const float4* P, const double* nx, const double* ny,
   hipLaunchKernelGGL(k_lm_B, dim3(nb), dim3(LIN_T), 0, s, P, n, vox, noff, corr_v, corr_M, partials, st);
 }
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials) {
-  hipLaunchKernelGGL(k_fitness_lm, dim3(linearize_blocks(ns)), dim3(LIN_T), 0, s, SP, ns, st, TP, tstart, g, partials);
+  hipLaunchKernelGGL(k_fitness_lm, dim3(fitness_blocks(ns)), dim3(FIT_T), 0, s, SP, ns, st, TP, tstart, g, partials);
 }
 void lm_init(hipStream_t s, LmState* st, const LmInit& in, const int* nvox, const void* segs_t, const void* segs_s) {
   hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(WAVE), 0, s, st, in, nvox, (const int*)segs_t, (const int*)segs_s);
 }
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials, double* out1) {
-  const int nb = linearize_blocks(ns);
-  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(LIN_T), 0, s, SP, ns, T, TP, tstart, g, partials);
+  const int nb = fitness_blocks(ns);
+  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(FIT_T), 0, s, SP, ns, T, TP, tstart, g, partials);
   hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
 }
 void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f) {
