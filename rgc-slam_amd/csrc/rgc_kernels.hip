@@ -421,14 +421,20 @@ struct TopK {  // the KC smallest squared distances, ascending, in registers (st
   }
   // One compare-exchange per slot, IN PLACE: the carried value ping-pongs between two registers and a[j] is a
   // read-write operand, so the insert is exactly 2 KC VALU ops.  (Written in C++ the conditional insert becomes a phi
-  // per slot and the allocator materialises it as 20 extra v_mov.)
+  // per slot and the allocator materialises it as 20 extra v_mov; one asm statement per slot gets an s_nop after each.)
+  static_assert(KC % 2 == 0, "the carried value must end up back in its first register");
   __device__ __forceinline__ void insert(float xf) {
     int x = __float_as_int(xf), t;
+    int j = 0;
 #pragma unroll
-    for (int j = 0; j < KC; j += 2) {
-      asm("v_max_i32 %2, %0, %1\n\tv_min_i32 %0, %0, %1" : "+v"(a[j]), "+v"(x), "=&v"(t));
-      if (j + 1 < KC) asm("v_max_i32 %2, %0, %1\n\tv_min_i32 %0, %0, %1" : "+v"(a[j + 1]), "+v"(t), "=&v"(x));
-    }
+    for (; j + 10 <= KC; j += 10)
+      asm("v_max_i32 %11, %0, %10\n\tv_min_i32 %0, %0, %10\n\tv_max_i32 %10, %1, %11\n\tv_min_i32 %1, %1, %11\n\tv_max_i32 %11, %2, %10\n\tv_min_i32 %2, %2, %10\n\tv_max_i32 %10, %3, %11\n\tv_min_i32 %3, %3, %11\n\tv_max_i32 %11, %4, %10\n\tv_min_i32 %4, %4, %10\n\tv_max_i32 %10, %5, %11\n\tv_min_i32 %5, %5, %11\n\tv_max_i32 %11, %6, %10\n\tv_min_i32 %6, %6, %10\n\tv_max_i32 %10, %7, %11\n\tv_min_i32 %7, %7, %11\n\tv_max_i32 %11, %8, %10\n\tv_min_i32 %8, %8, %10\n\tv_max_i32 %10, %9, %11\n\tv_min_i32 %9, %9, %11"
+          : "+v"(a[j]), "+v"(a[j + 1]), "+v"(a[j + 2]), "+v"(a[j + 3]), "+v"(a[j + 4]), "+v"(a[j + 5]), "+v"(a[j + 6]), "+v"(a[j + 7]),
+            "+v"(a[j + 8]), "+v"(a[j + 9]), "+v"(x), "=&v"(t));
+#pragma unroll
+    for (; j < KC; j += 2)
+      asm("v_max_i32 %3, %0, %2\n\tv_min_i32 %0, %0, %2\n\tv_max_i32 %2, %1, %3\n\tv_min_i32 %1, %1, %3"
+          : "+v"(a[j]), "+v"(a[j + 1]), "+v"(x), "=&v"(t));
   }
   __device__ __forceinline__ bool improves(float x) const { return __float_as_int(x) < a[KC - 1]; }
   __device__ __forceinline__ float at(int j) const { return __int_as_float(a[j]); }  // j must be a compile-time constant
@@ -501,6 +507,36 @@ __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3],
       for (int u = 0; u < 4; u++) f(a[u], b[u]);
     }
     for (; y <= y1; y++) f(start[cell_index(g, x0, y, z)], start[cell_index(g, x1, y, z) + 1]);
+  }
+}
+
+// The same walk with the row ranges parked in a per-lane LDS column (rng, stride lstride, >= 16 slots): eight rows =
+// sixteen start[] loads in flight per step, and f is instantiated ONCE (a loop over the parked rows) instead of once per
+// unrolled row -- the chain insert inside f is 160 instructions per candidate slot.
+template <typename F>
+__device__ __forceinline__ void for_each_cube_row_lds(const Grid& g, const int c[3], int r, const int* __restrict__ start, int* rng,
+                                                      int lstride, F&& f) {
+  const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
+  const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
+  const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
+  if (x0 > x1) return;
+  for (int z = z0; z <= z1; z++) {
+    for (int y = y0; y <= y1; y += 8) {
+      int a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int yy = min(y + u, y1);
+        a[u] = start[cell_index(g, x0, yy, z)];
+        b[u] = start[cell_index(g, x1, yy, z) + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        rng[(2 * u) * lstride] = a[u];
+        rng[(2 * u + 1) * lstride] = (y + u <= y1) ? b[u] : a[u];  // rows past the cube: empty
+      }
+#pragma unroll 1
+      for (int u = 0; u < 8; u++) f(rng[(2 * u) * lstride], rng[(2 * u + 1) * lstride]);
+    }
   }
 }
 
@@ -666,6 +702,7 @@ __device__ __forceinline__ void generic_search_rows(const float4* __restrict__ P
 // kTarget only separates the two instantiations by NAME (map vs scan) for the profiles.
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_T = 256;
+constexpr int kJumpMax = 3;  // largest cube radius (cells) the bulk kernel searches inside the lane before deferring
 static int g_knn_heavy = 640;     // candidates in the 3x3x3 block above which a query gets a whole wave (RGC_KNN_HEAVY)
 void set_knn_heavy(int v) { g_knn_heavy = v; }
 
@@ -681,7 +718,7 @@ struct Deferred {
 
 template <int KC>
 __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, int heavy, int i,
-                                          int* list, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
+                                          int* list, int* rng, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
                                           double* __restrict__ nz) {
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
@@ -701,13 +738,30 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
     const double bound = cube_bound(g, c, q, 0);
     if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) rdone = 0;
   }
-  int lo[9], hi[9];
+  // The nine row ranges live in a per-lane LDS column (rng[2 r] = first, rng[2 r + 1] = end, stride KNN_T) so that both
+  // passes are LOOPS over rows: unrolled nine-fold, with the 20-slot insert chain inlined at every candidate, the kernel
+  // was 100 KB of code against a 64 KB instruction cache.
   if (rdone < 0) {
-    const int xl = max(c[0] - 1, 0), xh = min(c[0] + 1, g.dim[0] - 1);
+    // Ball clipping: once the own cell holds >= k points its k-th distance bounds the search ball, and a neighbouring
+    // cell (row) that the ball cannot reach holds no neighbour and no tie -- in a crowded neighbourhood (raw scan near
+    // the sensor: hundreds of points per cell) that is most of the 26, so the query stays cheap instead of "heavy".
+    bool side_lo[3] = {true, true, true}, side_hi[3] = {true, true, true};
+    if (thr < INFINITY) {
+      const double rad = sqrt((double)thr) * (1.0 + 1e-5);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        side_lo[a] = q[a] - ((double)(c[a] + g.minc[a]) + 0.5) * g.res < rad;
+        side_hi[a] = ((double)(c[a] + g.minc[a]) + 1.5) * g.res - q[a] < rad;
+      }
+    }
+    const int xl = max(c[0] - (side_lo[0] ? 1 : 0), 0), xh = min(c[0] + (side_hi[0] ? 1 : 0), g.dim[0] - 1);
+    int lo[9], hi[9];  // registers only until they are parked in LDS: all 18 start[] loads are issued together
 #pragma unroll
     for (int r = 0; r < 9; r++) {
-      const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
-      const bool in = (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]);
+      const int dy = r % 3 - 1, dz = r / 3 - 1;
+      const int y = c[1] + dy, z = c[2] + dz;
+      const bool in = (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) && (dy >= 0 || side_lo[1]) && (dy <= 0 || side_hi[1]) &&
+                      (dz >= 0 || side_lo[2]) && (dz <= 0 || side_hi[2]);
       const int yy = in ? y : c[1], zz = in ? z : c[2];
       const int a = start[cell_index(g, xl, yy, zz)], b = start[cell_index(g, xh, yy, zz) + 1];
       lo[r] = in ? a : 0;
@@ -715,27 +769,57 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
     }
     int tot = 0;
 #pragma unroll
-    for (int r = 0; r < 9; r++) tot += hi[r] - lo[r];
+    for (int r = 0; r < 9; r++) {
+      tot += hi[r] - lo[r];
+      rng[(2 * r) * KNN_T] = lo[r];
+      rng[(2 * r + 1) * KNN_T] = hi[r];
+    }
     if (tot > heavy) {  // crowded neighbourhood: thousands of candidates -> one wave for this query
       const int e = atomicAdd(df.cnt, 1);
       df.idx[e] = i;
       df.thr[e] = thr;  // k-th distance inside the own cell if it holds >= k points, else INFINITY
       return;
     }
-    // cube r = 1: nine row ranges, the middle one without the own cell (already in the chain)
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-      if (r == 4) {
-        scan_range_topk<KC>(P, lo[4], own0, px, py, pz, top);
-        scan_range_topk<KC>(P, own1, hi[4], px, py, pz, top);
-      } else {
-        scan_range_topk<KC>(P, lo[r], hi[r], px, py, pz, top);
-      }
+    // cube r = 1: nine row ranges, the middle one in two pieces around the own cell (already in the chain)
+#pragma unroll 1
+    for (int r = 0; r < 10; r++) {
+      const int row = r - (r > 4 ? 1 : 0);
+      int a = rng[(2 * row) * KNN_T], b = rng[(2 * row + 1) * KNN_T];
+      if (r == 4) b = own0;
+      if (r == 5) a = own1;
+      scan_range_topk<KC>(P, a, b, px, py, pz, top);
     }
     thr = top.kth(k);
     if (thr < INFINITY) {
       const double bound = cube_bound(g, c, q, 1);
       if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) rdone = 1;
+    }
+    if (rdone < 0) {
+      // Sparse neighbourhood (far rings of a raw scan, map fringe): the block cannot prove the k-th distance.  JUMP to the
+      // smallest cube that can -- inside the lane while that cube is small: its rows are nearly empty, the cost is the
+      // start[] loads, and queries in sorted order are neighbours, so a wave's lanes jump together.  Larger jumps go to the
+      // cooperative kernel.
+      const int rmax = max(max(max(c[0], g.dim[0] - 1 - c[0]), max(c[1], g.dim[1] - 1 - c[1])), max(c[2], g.dim[2] - 1 - c[2]));
+      int rn = 2;
+      if (thr < INFINITY) {
+        const double need = sqrt((double)thr) * (1.0 + 1e-5);
+        while (rn < rmax) {
+          const double b = cube_bound(g, c, q, rn);
+          if (b == 1.0e300 || b > need) break;
+          rn++;
+        }
+      }
+      rn = min(rn, max(rmax, 1));
+      if (rn <= kJumpMax && rn >= 2) {
+        top.init();
+        for_each_cube_row_lds(g, c, rn, start, rng, KNN_T, [&](int s0, int s1) { scan_range_topk<KC>(P, s0, s1, px, py, pz, top); });
+        const float t2 = top.kth(k);
+        if (t2 < INFINITY) {
+          thr = t2;  // an upper bound of the k-th distance in any case
+          const double bound = cube_bound(g, c, q, rn);
+          if ((bound == 1.0e300) || (bound > 0.0 && (double)t2 < bound * bound * (1.0 - 1e-5))) rdone = rn;
+        }
+      }
     }
   }
   bool done = false;
@@ -746,9 +830,12 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
     int m = 0;
     if (rdone == 0) {
       scan_range_collect_le(P, own0, own1, px, py, pz, thr, k, list, KNN_T, m);
+    } else if (rdone == 1) {
+#pragma unroll 1
+      for (int r = 0; r < 9; r++) scan_range_collect_le(P, rng[(2 * r) * KNN_T], rng[(2 * r + 1) * KNN_T], px, py, pz, thr, k, list, KNN_T, m);
     } else {
-#pragma unroll
-      for (int r = 0; r < 9; r++) scan_range_collect_le(P, lo[r], hi[r], px, py, pz, thr, k, list, KNN_T, m);
+      for_each_cube_row_lds(g, c, rdone, start, rng, KNN_T,
+                            [&](int s0, int s1) { scan_range_collect_le(P, s0, s1, px, py, pz, thr, k, list, KNN_T, m); });
     }
     done = (m == k);  // m > k: several candidates exactly at the k-th distance, index tie-break -> cooperative path
   }
@@ -773,10 +860,10 @@ template <int KC, bool kTarget>
 __global__ void __launch_bounds__(KNN_T)
 k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, int heavy, Deferred df,
            double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ int slist_rows[];  // [k][KNN_T]
+  extern __shared__ int slist_rows[];  // [k][KNN_T] neighbour list, then [18][KNN_T] row ranges
   wave_prio(!kTarget);
   const int i = blockIdx.x * KNN_T + threadIdx.x;
-  if (i < n) knn_point<KC>(P, start, g, k, heavy, i, slist_rows + threadIdx.x, df, nx, ny, nz);
+  if (i < n) knn_point<KC>(P, start, g, k, heavy, i, slist_rows + threadIdx.x, slist_rows + k * KNN_T + threadIdx.x, df, nx, ny, nz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1859,7 +1946,7 @@ template <int KC>
 static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
                         const int* nseg, double* nx, double* ny, double* nz) {
   if (g_knn_impl == 0) {
-    const size_t ldsr = (size_t)k * KNN_T * sizeof(int);
+    const size_t ldsr = (size_t)(k + 18) * KNN_T * sizeof(int);
     Deferred df = deferred_of(segs, n);  // df.cnt was zeroed by k_rank_gather
     const int nb = nblk(n, KNN_T);
     if (is_target)
