@@ -514,6 +514,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   c->device = hip_device;
   if (const char* e = getenv("RGC_KNN_IMPL")) rgck::set_knn_impl(strcmp(e, "tile") == 0 ? 1 : 0);
   if (const char* e = getenv("RGC_KNN_HEAVY")) { const int v = atoi(e); if (v > 0) rgck::set_knn_heavy(v); }
+  if (const char* e = getenv("RGC_KNN_JUMP")) { const int v = atoi(e); if (v >= 0) rgck::set_knn_jump(v); }
   rgc_default_params(&c->prm);
   if (params) {
     int rc = check_params(c, params);

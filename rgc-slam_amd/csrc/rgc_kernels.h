@@ -56,6 +56,7 @@ size_t segment_bytes(int n);
 void set_knn_impl(int impl);  // 0 = rows (default), 1 = LDS tile
 int knn_impl();
 void set_knn_heavy(int v);
+void set_knn_jump(int v);
 // bulk kernel (one lane per query; defers expensive queries) then the cooperative kernel (one wave per deferred query)
 void knn_rows(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
               const int* nseg, double* nx, double* ny, double* nz);

@@ -513,13 +513,15 @@ __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3],
 // The same walk with the row ranges parked in a per-lane LDS column (rng, stride lstride, >= 16 slots): eight rows =
 // sixteen start[] loads in flight per step, and f is instantiated ONCE (a loop over the parked rows) instead of once per
 // unrolled row -- the chain insert inside f is 160 instructions per candidate slot.
+// Returns false -- the walk is abandoned -- as soon as the cube turns out to hold more than `budget` candidates.
 template <typename F>
-__device__ __forceinline__ void for_each_cube_row_lds(const Grid& g, const int c[3], int r, const int* __restrict__ start, int* rng,
-                                                      int lstride, F&& f) {
+__device__ __forceinline__ bool for_each_cube_row_lds(const Grid& g, const int c[3], int r, const int* __restrict__ start, int* rng,
+                                                      int lstride, int budget, F&& f) {
   const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
   const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
   const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
-  if (x0 > x1) return;
+  if (x0 > x1) return true;
+  int seen = 0;
   for (int z = z0; z <= z1; z++) {
     for (int y = y0; y <= y1; y += 8) {
       int a[8], b[8];
@@ -532,12 +534,16 @@ __device__ __forceinline__ void for_each_cube_row_lds(const Grid& g, const int c
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         rng[(2 * u) * lstride] = a[u];
-        rng[(2 * u + 1) * lstride] = (y + u <= y1) ? b[u] : a[u];  // rows past the cube: empty
+        const int e = (y + u <= y1) ? b[u] : a[u];  // rows past the cube: empty
+        rng[(2 * u + 1) * lstride] = e;
+        seen += e - a[u];
       }
+      if (seen > budget) return false;
 #pragma unroll 1
       for (int u = 0; u < 8; u++) f(rng[(2 * u) * lstride], rng[(2 * u + 1) * lstride]);
     }
   }
+  return true;
 }
 
 template <int KC>
@@ -702,9 +708,15 @@ __device__ __forceinline__ void generic_search_rows(const float4* __restrict__ P
 // kTarget only separates the two instantiations by NAME (map vs scan) for the profiles.
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_T = 256;
-constexpr int kJumpMax = 3;  // largest cube radius (cells) the bulk kernel searches inside the lane before deferring
+#ifdef RGC_EXP_NOJUMP
+constexpr int kJumpMax = 1;
+#else
+constexpr int kJumpMax = 3;
+#endif  // largest cube radius (cells) the bulk kernel searches inside the lane before deferring
 static int g_knn_heavy = 640;     // candidates in the 3x3x3 block above which a query gets a whole wave (RGC_KNN_HEAVY)
 void set_knn_heavy(int v) { g_knn_heavy = v; }
+static int g_knn_jump = 192;      // candidates an in-lane jump cube may hold before the query is deferred (RGC_KNN_JUMP)
+void set_knn_jump(int v) { g_knn_jump = v; }
 
 // Queries that the lane-per-query kernel cannot finish cheaply -- a crowded own cell that is not decisive (its
 // 3x3x3 block holds thousands of candidates) or a sparse neighbourhood (the search cube must grow) -- are DEFERRED:
@@ -717,8 +729,8 @@ struct Deferred {
 };
 
 template <int KC>
-__device__ __forceinline__ void knn_point(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, int heavy, int i,
-                                          int* list, int* rng, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
+__device__ __forceinline__ void knn_point(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, int heavy, int jump_budget,
+                                          int i, int* list, int* rng, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
                                           double* __restrict__ nz) {
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
@@ -746,6 +758,7 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
     // cell (row) that the ball cannot reach holds no neighbour and no tie -- in a crowded neighbourhood (raw scan near
     // the sensor: hundreds of points per cell) that is most of the 26, so the query stays cheap instead of "heavy".
     bool side_lo[3] = {true, true, true}, side_hi[3] = {true, true, true};
+#ifndef RGC_EXP_NOCLIP
     if (thr < INFINITY) {
       const double rad = sqrt((double)thr) * (1.0 + 1e-5);
 #pragma unroll
@@ -754,6 +767,7 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
         side_hi[a] = ((double)(c[a] + g.minc[a]) + 1.5) * g.res - q[a] < rad;
       }
     }
+#endif
     const int xl = max(c[0] - (side_lo[0] ? 1 : 0), 0), xh = min(c[0] + (side_hi[0] ? 1 : 0), g.dim[0] - 1);
     int lo[9], hi[9];  // registers only until they are parked in LDS: all 18 start[] loads are issued together
 #pragma unroll
@@ -812,8 +826,12 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
       rn = min(rn, max(rmax, 1));
       if (rn <= kJumpMax && rn >= 2) {
         top.init();
-        for_each_cube_row_lds(g, c, rn, start, rng, KNN_T, [&](int s0, int s1) { scan_range_topk<KC>(P, s0, s1, px, py, pz, top); });
-        const float t2 = top.kth(k);
+        // the cube of a sparse query is nearly empty; on the fringe of a dense map it is not (and a lane that chews through
+        // hundreds of candidates alone becomes the tail of the launch): past the budget the walk is abandoned and the query
+        // goes to the cooperative kernel
+        const bool walked = for_each_cube_row_lds(g, c, rn, start, rng, KNN_T, jump_budget,
+                                                  [&](int s0, int s1) { scan_range_topk<KC>(P, s0, s1, px, py, pz, top); });
+        const float t2 = walked ? top.kth(k) : INFINITY;
         if (t2 < INFINITY) {
           thr = t2;  // an upper bound of the k-th distance in any case
           const double bound = cube_bound(g, c, q, rn);
@@ -834,7 +852,7 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
 #pragma unroll 1
       for (int r = 0; r < 9; r++) scan_range_collect_le(P, rng[(2 * r) * KNN_T], rng[(2 * r + 1) * KNN_T], px, py, pz, thr, k, list, KNN_T, m);
     } else {
-      for_each_cube_row_lds(g, c, rdone, start, rng, KNN_T,
+      for_each_cube_row_lds(g, c, rdone, start, rng, KNN_T, INT_MAX,
                             [&](int s0, int s1) { scan_range_collect_le(P, s0, s1, px, py, pz, thr, k, list, KNN_T, m); });
     }
     done = (m == k);  // m > k: several candidates exactly at the k-th distance, index tie-break -> cooperative path
@@ -858,12 +876,12 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
 
 template <int KC, bool kTarget>
 __global__ void __launch_bounds__(KNN_T)
-k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, int heavy, Deferred df,
+k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, int heavy, int jump_budget, Deferred df,
            double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
   extern __shared__ int slist_rows[];  // [k][KNN_T] neighbour list, then [18][KNN_T] row ranges
   wave_prio(!kTarget);
   const int i = blockIdx.x * KNN_T + threadIdx.x;
-  if (i < n) knn_point<KC>(P, start, g, k, heavy, i, slist_rows + threadIdx.x, slist_rows + k * KNN_T + threadIdx.x, df, nx, ny, nz);
+  if (i < n) knn_point<KC>(P, start, g, k, heavy, jump_budget, i, slist_rows + threadIdx.x, slist_rows + k * KNN_T + threadIdx.x, df, nx, ny, nz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1950,9 +1968,9 @@ static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const in
     Deferred df = deferred_of(segs, n);  // df.cnt was zeroed by k_rank_gather
     const int nb = nblk(n, KNN_T);
     if (is_target)
-      hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, df, nx, ny, nz);
+      hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, g_knn_jump, df, nx, ny, nz);
     else
-      hipLaunchKernelGGL((k_knn_rows<KC, false>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, df, nx, ny, nz);
+      hipLaunchKernelGGL((k_knn_rows<KC, false>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, g_knn_jump, df, nx, ny, nz);
     return;
   }
   const size_t lds = sizeof(float4) * TCH + (size_t)k * TQ * sizeof(int);
