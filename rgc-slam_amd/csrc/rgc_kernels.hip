@@ -320,27 +320,31 @@ __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n,
 // Stands in for Eigen::JacobiSVD on the symmetric PSD neighbourhood covariance (fast_gicp_impl.hpp:273):
 // U diag(1,1,1e-3) V^T = I - 0.999 n n^T with n that eigenvector.
 // ------------------------------------------------------------------------------------------------
-template <int P, int Q>
+// One Jacobi rotation in the (P,Q) plane, R = the third index.  Same rotation as the textbook two-sided product
+// A <- G^T A G (t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (a_qq - a_pp) / (2 a_pq)) written in its closed
+// form: only the five entries that change are touched, and t comes from ONE division and ONE square root
+// (t = 2 |a_pq| sgn(theta) / (|d| + sqrt(d^2 + 4 a_pq^2)), d = a_qq - a_pp) -- fp64 divisions and roots are ~15 VALU ops each
+// and this routine runs once per point of the map.
+template <int P, int Q, int R>
 __device__ __forceinline__ void jacobi_rot(double (&A)[3][3], double (&V)[3][3]) {
-  if (A[P][Q] == 0.0) return;
-  double theta = (A[Q][Q] - A[P][P]) / (2.0 * A[P][Q]);
-  double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-  double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  const double apq = A[P][Q];
+  if (apq == 0.0) return;
+  const double d = A[Q][Q] - A[P][P];
+  const bool pos = (d == 0.0) || ((d > 0.0) == (apq > 0.0));  // sign of theta, with theta = 0 counted positive
+  const double t = (pos ? 2.0 : -2.0) * fabs(apq) / (fabs(d) + sqrt(d * d + 4.0 * apq * apq));
+  const double c = rsqrt(t * t + 1.0), s = t * c;
+  const double tap = t * apq;
+  A[P][P] -= tap;
+  A[Q][Q] += tap;
+  A[P][Q] = 0.0;
+  A[Q][P] = 0.0;
+  const double arp = A[R][P], arq = A[R][Q];
+  const double nrp = c * arp - s * arq, nrq = s * arp + c * arq;
+  A[R][P] = nrp; A[P][R] = nrp;
+  A[R][Q] = nrq; A[Q][R] = nrq;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    double akp = A[k][P], akq = A[k][Q];
-    A[k][P] = c * akp - s * akq;
-    A[k][Q] = s * akp + c * akq;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    double apk = A[P][k], aqk = A[Q][k];
-    A[P][k] = c * apk - s * aqk;
-    A[Q][k] = s * apk + c * aqk;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    double vkp = V[k][P], vkq = V[k][Q];
+    const double vkp = V[k][P], vkq = V[k][Q];
     V[k][P] = c * vkp - s * vkq;
     V[k][Q] = s * vkp + c * vkq;
   }
@@ -353,9 +357,9 @@ __device__ __forceinline__ void min_eigenvector(const double S[6], double n[3]) 
     double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
     double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
     if (off <= 1e-40 * diag || off == 0.0) break;
-    jacobi_rot<0, 1>(A, V);
-    jacobi_rot<0, 2>(A, V);
-    jacobi_rot<1, 2>(A, V);
+    jacobi_rot<0, 1, 2>(A, V);
+    jacobi_rot<0, 2, 1>(A, V);
+    jacobi_rot<1, 2, 0>(A, V);
   }
   double e0 = A[0][0], e1 = A[1][1], e2 = A[2][2];
   // column of the smallest eigenvalue; on exact ties take the LAST one in descending sort order like the
