@@ -112,7 +112,11 @@ def main():
     for i in range(W):
         guess = step(i, guess)
     v.synchronize()
+    # HIP-event regions cost two hipEventRecord each: in the timed loop only the dominant kernel (the map's bulk kNN +
+    # covariance launch -- rocprofv3 agrees, profiles/) is bracketed; the other stages are timed in a separate pass below.
+    DOMINANT = "knn_cov_target"
     v.profile_enable(True)
+    v.profile_select([DOMINANT])
     v.profile_reset()
     if world_size > 1:
         dist.barrier()
@@ -131,6 +135,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    prof_dom = v.profile()[DOMINANT]
+    # per-stage breakdown: a few more frames with every region bracketed (untimed, informational)
+    v.profile_select(None)
+    v.profile_reset()
+    KB = min(K, 5)
+    gb = guess
+    for i in range(W, W + KB):
+        gb = step(i, gb)
+    v.synchronize()
     prof = v.profile()
     v.profile_enable(False)
 
@@ -144,9 +157,11 @@ def main():
     scans_per_s = K * world_size / elapsed
     B = algorithmic_bytes(args.n_source, args.n_target, n_vox, mean_corr, mean_lin, mean_err)
 
-    # dominant kernel = the one with the largest summed HIP-event time in the timed region
-    dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-    name, d = dom
+    # dominant kernel: checked against the all-stages pass (largest summed HIP-event time), measured over the timed region
+    name = max(prof.items(), key=lambda kv: kv[1]["total_ms"])[0]
+    if name != DOMINANT:
+        log(f"warning: the breakdown pass names {name} as dominant, the timed region bracketed {DOMINANT}")
+    name, d = DOMINANT, prof_dom
     per_unit = {"knn_cov_target": 36.0, "knn_cov_source": 36.0, "knn_coop_target": 36.0, "knn_coop_source": 36.0, "voxel_build": 36.0 + 40.0 * n_vox / args.n_target,
                 "linearize": 36.0 + 40.0 * mean_corr / args.n_source, "compute_error": 36.0 + 40.0 * mean_corr / args.n_source,
                 "fitness": 24.0, "grid_build": 0.0}[name]
@@ -176,7 +191,7 @@ def main():
         "hbm_frac_whole_frame": round(B * scans_per_s / world_size / 1e9 / HBM_PEAK_GBS, 6),
         "mean_outer_iterations": round(mean_outer, 2), "mean_linearize": round(mean_lin, 2), "mean_compute_error": round(mean_err, 2),
         "mean_correspondences": round(mean_corr, 1), "n_voxels": int(n_vox),
-        "kernel_ms_per_step": {k: round(x["total_ms"] / K, 4) for k, x in prof.items()},
+        "kernel_ms_per_step": {k: round(x["total_ms"] / KB, 4) for k, x in prof.items()},
         "roofline": roofline,
     }
 

@@ -229,6 +229,9 @@ enum {
   RGC_K_COUNT = 9
 };
 RGC_API int rgc_profile_enable(rgc_ctx* ctx, int on);
+/* restrict the event regions to the kinds whose bit is set (bit k = kind k; default: all).  Each region costs two
+ * hipEventRecord calls, so a timed run that only needs one kernel's duration selects just that kind. */
+RGC_API int rgc_profile_select(rgc_ctx* ctx, unsigned kind_mask);
 RGC_API int rgc_profile_reset(rgc_ctx* ctx);
 /* launches = timed regions of that kind; total_ms = summed hipEventElapsedTime; last_n = points of the last region */
 RGC_API int rgc_profile_get(rgc_ctx* ctx, int kind, long long* launches, double* total_ms, long long* total_points);

@@ -71,6 +71,9 @@ struct rgc_ctx {
   double* h_out = nullptr;    // pinned
   DevBuf scratch;             // getters
   DevBuf lm_state;            // device-chained LM state (rgck::LmState)
+  bool lm_persist = false;    // RGC_LM_IMPL=persistent: the whole solve in one launch with grid-wide hand-offs (A/B knob;
+                              // measured 215 us against 160 us for the chained two-kernel slots on MI355X, so not the default)
+  int lm_gen = 0;             // hand-off generation the device state is at (read back with the state)
   bool deferred_known = false;  // stats.deferred_* are those of the current clouds (carried home by the last align)
   DevBuf fit_partials;        // fitness rows when it is chained behind the LM slots
   rgck::LmState* h_lm = nullptr;  // pinned mirror
@@ -81,6 +84,7 @@ struct rgc_ctx {
   rgc_stats stats{};
   // profiling
   bool prof_on = false;
+  unsigned prof_mask = ~0u;
   std::vector<ProfRegion> prof_open;
   std::vector<hipEvent_t> ev_pool;
   long long prof_launches[kProfKinds] = {0};
@@ -139,7 +143,7 @@ struct ProfScope {
   bool on;
   ProfRegion r{};
   hipStream_t st;
-  ProfScope(rgc_ctx* ctx, int kind, long long points, hipStream_t stream = nullptr) : c(ctx), on(ctx->prof_on), st(stream ? stream : ctx->stream) {
+  ProfScope(rgc_ctx* ctx, int kind, long long points, hipStream_t stream = nullptr) : c(ctx), on(ctx->prof_on && ((ctx->prof_mask >> kind) & 1u)), st(stream ? stream : ctx->stream) {
     if (!on) return;
     auto get = [&](hipEvent_t* e) {
       if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
@@ -533,7 +537,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
-  if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
+  if (const char* e = getenv("RGC_LM_IMPL")) { c->lm_host = strcmp(e, "host") == 0; c->lm_persist = strcmp(e, "persistent") == 0; }
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   *out = c;
   return RGC_OK;
@@ -641,7 +645,11 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     const int nb = rgck::linearize_blocks(n);
     if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 1) * (size_t)nb))) return rc;
     if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
-    if ((rc = ensure(c, c->lm_state, sizeof(rgck::LmState)))) return rc;
+    if (!c->lm_state.p) {
+      if ((rc = ensure(c, c->lm_state, 4096))) return rc;  // LmState + the persistent solve's mailbox lines at +2048
+      HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->stream));  // tickets and generation start at 0
+      c->lm_gen = 0;
+    }
     if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)rgck::fitness_blocks(n) + 64))) return rc;
     rgck::LmState& S = *c->h_lm;
     rgck::LmInit in;
@@ -649,10 +657,42 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     in.rot_eps = P.rotation_eps; in.trans_eps = P.translation_eps; in.init_factor = P.lm_init_lambda_factor;
     in.max_outer = P.max_iterations; in.max_inner = P.lm_max_iterations;
     const bool rows_impl = rgck::knn_impl() == 0;
-    rgck::lm_init(c->stream, (rgck::LmState*)c->lm_state.p, in, c->d_small + 7, rows_impl ? c->tgt.segs.p : nullptr,
-                  rows_impl ? c->src.segs.p : nullptr);
+    bool solved = false;
+    if (c->lm_persist && nb <= 256) {  // one workgroup per CU at most: co-residency is certain
+      // the whole solve (and the fitness behind it) in one enqueue, one read-back
+      {
+        ProfScope ps(c, RGC_K_LINEARIZE, n);
+        rgck::lm_run(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
+                     c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
+                     (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, in, c->lm_gen, c->d_small + 7,
+                     rows_impl ? c->tgt.segs.p : nullptr, rows_impl ? c->src.segs.p : nullptr);
+      }
+      if (fitness) {
+        ProfScope ps(c, RGC_K_FITNESS, n);
+        rgck::fitness_lm(c->stream, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
+                         (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p);
+      }
+      HIPCHK(c, hipMemcpyAsync(&S, c->lm_state.p, sizeof(S), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipGetLastError());
+      c->lm_gen = S.gen;
+      if (S.failed == 2) {
+        // a grid-wide hand-off timed out (workgroups not co-resident?): never again on this context; redo this solve with
+        // the two-kernel slots, which need no co-residency
+        c->lm_persist = false;
+        snprintf(c->err, sizeof(c->err), "persistent LM launch timed out; falling back to chained slots");
+      } else {
+        solved = true;
+        fitness_chained = S.has_fit != 0;
+      }
+    }
     int batch = 6;
-    for (int guard = 0; guard < 400; guard++) {
+    if (!solved) {
+      rgck::lm_init(c->stream, (rgck::LmState*)c->lm_state.p, in, c->d_small + 7, rows_impl ? c->tgt.segs.p : nullptr,
+                    rows_impl ? c->src.segs.p : nullptr);
+      c->lm_gen = 0;  // k_lm_init zeroes the whole state
+    }
+    for (int guard = 0; guard < 400 && !solved; guard++) {
       {
         ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch);
         for (int k = 0; k < batch; k++)
@@ -1141,6 +1181,11 @@ void* rgc_stream(rgc_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int rgc_profile_enable(rgc_ctx* c, int on) {
   if (!c) return RGC_ERR_INVALID;
   c->prof_on = on != 0;
+  return RGC_OK;
+}
+int rgc_profile_select(rgc_ctx* c, unsigned kind_mask) {
+  if (!c) return RGC_ERR_INVALID;
+  c->prof_mask = kind_mask;
   return RGC_OK;
 }
 int rgc_profile_reset(rgc_ctx* c) {

@@ -30,6 +30,7 @@ struct LmState {  // device-resident state of LsqRegistration::computeTransforma
   int phase, done, conv, failed, outer, inner, n_lin, n_err, ncorr, ticketA, ticketB, max_outer, max_inner, has_fit;
   double fit_sum;                // sum of squared NN distances at the final pose (k_fitness_lm)
   int nvox, def_t, def_s, pad;   // frame counters carried home with the state
+  int gen, cmd, pad2, pad3;      // persistent solve: hand-off generation and the command published with it
 };
 struct LmInit { double x0[16], rot_eps, trans_eps, init_factor; int max_outer, max_inner; };
 struct FeParams { int n_scans; double min_range, max_range; };
@@ -77,6 +78,10 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
 void lm_slot(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v, double* corr_M, double* partials, int* ncorr_partials, LmState* st);
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials);
+// the whole solve in one persistent launch (needs linearize_blocks(n) co-resident workgroups: callers keep it <= 256)
+void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
+            const double* vox, int noff, int* corr_v, double* corr_M, double* partials, LmState* st, const LmInit& in, int gen_base,
+            const int* nvox, const void* segs_t, const void* segs_s);
 void lm_init(hipStream_t s, LmState* st, const LmInit& in, const int* nvox, const void* segs_t, const void* segs_s);
 // ---- C8 ----
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials,

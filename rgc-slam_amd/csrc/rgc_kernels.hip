@@ -1726,6 +1726,245 @@ k_lm_B(const float4* __restrict__ P, int n, const double* __restrict__ vox, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT LM: the whole computeTransformation loop (lsq_registration_impl.hpp:53-172) in ONE launch.  Every workgroup
+// keeps its 256 source points for the whole solve; per outer iteration there are two grid-wide hand-offs instead of two
+// kernel boundaries:
+//   phase A  linearise at x0 -> partial row (write-through) -> ticket; the LAST arriver folds the rows, forms H, b, y0,
+//            performs the LM try (solve, so3_exp, xi = delta x0) and PUBLISHES xi by bumping st->gen;
+//   phase B  every workgroup evaluates the cost at xi over its frozen correspondences -> row -> ticket; the last arriver
+//            folds, computes rho and accepts (x0 = xi, next iteration), rejects (lambda up, NEW try, phase B again) or
+//            terminates, and publishes a command word with the next gen.
+// Waiting workgroups poll st->gen with agent-scope loads and s_sleep; the poll is BOUNDED (a lost hand-off ends the solve
+// with failed = 2 instead of hanging the GPU).  All state that crosses workgroups is written with write-through (sc1)
+// stores and read either after the last arriver's agent-scope acquire or with sc1 loads, so no release fence (L2
+// write-back) sits on the critical path.  MEASURED (MI355X, 30 k points, 118 workgroups): 42 us per outer iteration against
+// 30 us for the two-kernel slots -- a polled hand-off costs more here than a kernel boundary -- so this launch is an A/B
+// knob (RGC_LM_IMPL=persistent), not the default.  The launch needs its workgroups co-resident: the host only uses it when the
+// grid is at most one workgroup per CU (<= 256) and keeps the two-kernel slots for anything larger.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wt(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double rd(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int rd(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int LM_CMD_ACCEPT = 0, LM_CMD_RETRY = 1, LM_CMD_DONE = 2;
+constexpr int kLmSpinLimit = 1 << 21;  // polls of ~0.3-1 us: a second or two before giving up
+
+// thread 0 of every waiting workgroup; returns false if the hand-off never came
+__device__ __forceinline__ bool lm_wait_gen(const int* gen, int want) {
+  for (int spins = 0; spins < kLmSpinLimit; spins++) {
+    if (rd(gen) - want >= 0) return true;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  return false;
+}
+
+// LM try at the state's (H, b, lambda, x0) -> d, delta, xi written through; xi also returned
+__device__ __forceinline__ void lm_try_state(LmState* st, const double H[36], const double b[6], double lambda, const double x0[16], double xi[16]) {
+  double d[6], delta[16];
+  rgclm::lm_try(H, b, lambda, x0, d, delta, xi);
+#pragma unroll
+  for (int a = 0; a < 6; a++) wt(&st->d[a], d[a]);
+#pragma unroll
+  for (int a = 0; a < 16; a++) { wt(&st->delta[a], delta[a]); wt(&st->xi[a], xi[a]); }
+}
+
+__global__ void __launch_bounds__(LIN_T)
+k_lm_run(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
+         const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v, double* __restrict__ corr_M,
+         double* __restrict__ partials, LmState* __restrict__ st, int* __restrict__ mbox, LmInit in, int gen_base, const int* __restrict__ nvox,
+         const int* __restrict__ def_t, const int* __restrict__ def_s) {
+  __shared__ double folded[kAccum + 1];
+  __shared__ double pose_s[12];
+  __shared__ int cmd_s;
+  const bool lead = threadIdx.x == 0;
+  if (blockIdx.x == 0 && lead) {
+    // fresh state (:53-63).  Written before this workgroup takes its first ticket, hence visible to whichever workgroup
+    // arrives last.  gen continues from gen_base (the host carries it from the previous solve's read-back).
+#pragma unroll
+    for (int a = 0; a < 16; a++) wt(&st->x0[a], in.x0[a]);
+    wt(&st->lambda, -1.0);  // :56
+    wt(&st->nu, 2.0);
+#pragma unroll
+    for (int a = 0; a < 36; a++) wt(&st->Hfin[a], (a % 7 == 0) ? 1.0 : 0.0);  // final_hessian_.setIdentity(), :21
+    wt(&st->rot_eps, in.rot_eps);
+    wt(&st->trans_eps, in.trans_eps);
+    wt(&st->init_factor, in.init_factor);
+    wt(&st->max_outer, in.max_outer);
+    wt(&st->max_inner, in.max_inner);
+    wt(&st->phase, 0); wt(&st->conv, 0); wt(&st->failed, 0); wt(&st->outer, 0); wt(&st->inner, 0);
+    wt(&st->n_lin, 0); wt(&st->n_err, 0); wt(&st->ncorr, 0); wt(&st->has_fit, 0);
+    wt(&st->fit_sum, 0.0); wt(&st->y0, 0.0); wt(&st->yi, 0.0);
+    wt(&st->nvox, nvox ? *nvox : 0);
+    wt(&st->def_t, def_t ? *def_t : 0);
+    wt(&st->def_s, def_s ? *def_s : 0);
+    wt(&st->done, in.max_outer <= 0 ? 1 : 0);
+  }
+  if (in.max_outer <= 0) return;
+  if (threadIdx.x < 12) pose_s[threadIdx.x] = in.x0[threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  int gen = gen_base;
+  bool relinearize = true;
+  for (int guard = 0; guard < 100000; guard++) {
+    if (relinearize) {
+      // ---- phase A ------------------------------------------------------------------------------------------------
+      Pose T;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int e = 0; e < 3; e++) T.R[a * 3 + e] = pose_s[a * 4 + e];
+        T.t[a] = pose_s[a * 4 + 3];
+      }
+      double acc[kAccum];
+#pragma unroll
+      for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
+      int ncorr = 0;
+      if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, 1, acc, ncorr);
+      double acc2[kAccum + 1];
+#pragma unroll
+      for (int a = 0; a < kAccum; a++) acc2[a] = acc[a];
+      acc2[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
+      block_reduce_store<kAccum + 1, true>(acc2, partials + (size_t)blockIdx.x * (kAccum + 1));
+      gen++;
+      if (last_block_arrive(&st->ticketA)) {
+        block_fold_rows<kAccum + 1>(partials, gridDim.x, folded);
+        if (lead) {
+          double H[36], b[6], x0[16], xi[16];
+          int u = 0;
+#pragma unroll
+          for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int e = a; e < 6; e++) { H[a * 6 + e] = folded[u]; H[e * 6 + a] = folded[u]; u++; }
+#pragma unroll
+          for (int a = 0; a < 6; a++) b[a] = folded[21 + a];
+#pragma unroll
+          for (int a = 0; a < 36; a++) wt(&st->H[a], H[a]);
+#pragma unroll
+          for (int a = 0; a < 6; a++) wt(&st->b[a], b[a]);
+          wt(&st->y0, folded[27]);
+          wt(&st->ncorr, (int)folded[kAccum]);
+          wt(&st->n_lin, st->n_lin + 1);
+          double lambda = st->lambda;
+          if (lambda < 0.0) {  // :130-132
+            double m = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) m = fmax(m, fabs(H[a * 7]));
+            lambda = st->init_factor * m;
+            wt(&st->lambda, lambda);
+          }
+#pragma unroll
+          for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
+          lm_try_state(st, H, b, lambda, x0, xi);  // :136-143
+#pragma unroll
+          for (int a = 0; a < 12; a++) pose_s[a] = xi[a];
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          wt(&st->gen, gen);
+          wt(mbox, gen);  // publish xi
+        }
+        __syncthreads();
+      } else {
+        if (lead) cmd_s = lm_wait_gen(mbox, gen) ? 0 : -1;
+        __syncthreads();
+        if (cmd_s < 0) { if (lead) { wt(&st->failed, 2); wt(&st->done, 1); } return; }
+        if (threadIdx.x < 12) pose_s[threadIdx.x] = rd(&st->xi[threadIdx.x]);
+        __syncthreads();
+      }
+    }
+    // ---- phase B: cost at the trial pose (pose_s = xi) --------------------------------------------------------------
+    double accb[1] = {0.0};
+    if (i < n) accb[0] = error_point(P, i, n, pose_s, vox, noff, corr_v, corr_M);
+    block_reduce_store<1, true>(accb, partials + blockIdx.x);
+    gen++;
+    if (last_block_arrive(&st->ticketB)) {
+      block_fold_rows<1>(partials, gridDim.x, folded);
+      if (lead) {
+        const double yi = folded[0];
+        wt(&st->yi, yi);
+        wt(&st->n_err, st->n_err + 1);
+        double d[6], b[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) { d[a] = st->d[a]; b[a] = st->b[a]; }
+        double lambda = st->lambda;
+        double den = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) den += d[a] * (lambda * d[a] - b[a]);
+        const double rho = (st->y0 - yi) / den;  // :145
+        double delta[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) delta[a] = st->delta[a];
+        const bool conv_now = lm_is_converged(delta, st->rot_eps, st->trans_eps);
+        int cmd;
+        bool outer_done = false;
+        if (rho < 0) {  // :155-163
+          if (conv_now) {
+            outer_done = true;  // step_lm returns true with x unchanged: the next linearisation is again at x0
+          } else {
+            const double nu = st->nu;
+            lambda = nu * lambda;
+            wt(&st->lambda, lambda);
+            wt(&st->nu, 2 * nu);
+            const int inner = st->inner + 1;
+            wt(&st->inner, inner);
+            if (inner >= st->max_inner) {  // "lm not converged!!", :69-72
+              wt(&st->failed, 1);
+              wt(&st->done, 1);
+              cmd = LM_CMD_DONE;
+            } else {  // next try of the same linearisation, straight away
+              double H[36], x0[16], xi[16];
+#pragma unroll
+              for (int a = 0; a < 36; a++) H[a] = st->H[a];
+#pragma unroll
+              for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
+              lm_try_state(st, H, b, lambda, x0, xi);
+#pragma unroll
+              for (int a = 0; a < 12; a++) pose_s[a] = xi[a];
+              cmd = LM_CMD_RETRY;
+            }
+          }
+        } else {  // :165-168
+#pragma unroll
+          for (int a = 0; a < 16; a++) wt(&st->x0[a], st->xi[a]);
+          wt(&st->lambda, lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3)));
+#pragma unroll
+          for (int a = 0; a < 36; a++) wt(&st->Hfin[a], st->H[a]);
+          outer_done = true;
+        }
+        if (outer_done) {
+          const int outer = st->outer + 1;
+          wt(&st->conv, conv_now ? 1 : 0);  // :74
+          wt(&st->outer, outer);
+          wt(&st->nu, 2.0);
+          wt(&st->inner, 0);
+          const bool fin = conv_now || outer >= st->max_outer;  // :65
+          if (fin) wt(&st->done, 1);
+          // (rho < 0 reaches this point only when converged, so fin holds and x0 stays what it was)
+          cmd = fin ? LM_CMD_DONE : LM_CMD_ACCEPT;
+        }
+        cmd_s = cmd;
+        wt(mbox + 32, cmd);
+        wt(&st->gen, gen);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wt(mbox, gen);
+      }
+      __syncthreads();
+    } else {
+      if (lead) cmd_s = lm_wait_gen(mbox, gen) ? rd(mbox + 32) : -1;
+      __syncthreads();
+      if (cmd_s < 0) { if (lead) { wt(&st->failed, 2); wt(&st->done, 1); } return; }
+      if (cmd_s == LM_CMD_RETRY) {
+        if (threadIdx.x < 12) pose_s[threadIdx.x] = rd(&st->xi[threadIdx.x]);
+      }
+      __syncthreads();
+    }
+    const int cmd = cmd_s;
+    __syncthreads();  // everyone has read cmd_s / pose_s before the next round may overwrite them
+    if (cmd == LM_CMD_DONE) return;
+    relinearize = (cmd != LM_CMD_RETRY);  // ACCEPT: pose_s (= xi) is the new x0
+  }
+}
+
 // fold per-block rows in a fixed order: block a (one wave) owns accumulator a; lane l sums rows l, l+64, ...
 // then a fixed shuffle tree (deterministic for a given row count).  Block NACC folds the integer counts.
 template <int NACC>
@@ -2043,6 +2282,14 @@ void lm_slot(hipStream_t s, const float4* P, const double* nx, const double* ny,
   const int nb = linearize_blocks(n);
   hipLaunchKernelGGL(k_lm_A, dim3(nb), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v, corr_M, partials, ncorr_partials, st);
   hipLaunchKernelGGL(k_lm_B, dim3(nb), dim3(LIN_T), 0, s, P, n, vox, noff, corr_v, corr_M, partials, st);
+}
+void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
+            const double* vox, int noff, int* corr_v, double* corr_M, double* partials, LmState* st, const LmInit& in, int gen_base,
+            const int* nvox, const void* segs_t, const void* segs_s) {
+  int* mbox = reinterpret_cast<int*>(reinterpret_cast<char*>(st) + 2048);  // the state buffer is 4 KiB: mailbox lines after the struct
+  static_assert(sizeof(LmState) <= 2048, "LmState must leave room for the mailbox");
+  hipLaunchKernelGGL(k_lm_run, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v, corr_M, partials,
+                     st, mbox, in, gen_base, nvox, (const int*)segs_t, (const int*)segs_s);
 }
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials) {
   hipLaunchKernelGGL(k_fitness_lm, dim3(fitness_blocks(ns)), dim3(FIT_T), 0, s, SP, ns, st, TP, tstart, g, partials);

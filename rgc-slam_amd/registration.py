@@ -252,6 +252,16 @@ class FastVGICP:
     def profile_enable(self, on=True):
         self._chk(self._L.rgc_profile_enable(self._h, 1 if on else 0))
 
+    def profile_select(self, kinds=None):
+        """Only time the named kinds (e.g. ["knn_cov_target"]); None = all."""
+        mask = 0xFFFFFFFF
+        if kinds is not None:
+            names = [self._L.rgc_profile_name(k).decode() for k in range(9)]
+            mask = 0
+            for k in kinds:
+                mask |= 1 << names.index(k)
+        self._chk(self._L.rgc_profile_select(self._h, mask))
+
     def profile_reset(self):
         self._chk(self._L.rgc_profile_reset(self._h))
 

@@ -91,6 +91,27 @@ def test_golden_align(reg_mod, fx_reg):
     v.close()
 
 
+def test_lm_drivers_agree(reg_mod, fx_reg, monkeypatch):
+    """The LM loop has three drivers (RGC_LM_IMPL: default = two chained kernels per slot; host = host-driven;
+    persistent = one launch with grid-wide hand-offs).  Same arithmetic, same fold order: same trajectory."""
+    res = {}
+    for impl in (None, "host", "persistent"):
+        if impl is None:
+            monkeypatch.delenv("RGC_LM_IMPL", raising=False)
+        else:
+            monkeypatch.setenv("RGC_LM_IMPL", impl)
+        v = _odo(reg_mod)  # the knob is read when the context is created
+        v.setInputTarget(fx_reg["tgt"])
+        v.setInputSource(fx_reg["src"])
+        v.align(fx_reg["guess"], want_output=False)
+        res[impl] = (v.getFinalTransformation().copy(), v.nr_iterations, v.hasConverged(), v.getFitnessScore())
+        v.close()
+    for impl in ("host", "persistent"):
+        assert res[impl][1] == res[None][1] and res[impl][2] == res[None][2]
+        assert np.abs(res[impl][0] - res[None][0]).max() < 1e-7
+        assert abs(res[impl][3] - res[None][3]) <= 1e-9 * abs(res[None][3])
+
+
 @pytest.fixture(scope="module")
 def medium():
     import rgc_slam_amd.synth as synth
