@@ -62,6 +62,8 @@ struct rgc_ctx {
   Cloud src, tgt;
   // per-correspondence state frozen by linearize (fast_vgicp_impl.hpp:104-115)
   DevBuf corr_v, corr_M, partials, ipartials;
+  DevBuf corr_v2, corr_M2;    // second correspondence buffer of the chained LM (speculative linearisation); corr_v / corr_M
+                              // always name the VALID one after a solve
   int corr_noff = 0, corr_n = 0;
   bool corr_valid = false;
   // small device scratch + pinned host mirrors
@@ -554,7 +556,7 @@ void rgc_destroy(rgc_ctx* c) {
   release_cloud(c->tgt);
   release_cloud(c->aux);
   for (DevBuf& b : c->fe) release(b);
-  for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_first, &c->vg_pos}) release(*b);
+  for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->corr_v2, &c->corr_M2, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_first, &c->vg_pos}) release(*b);
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->h_small) (void)hipHostFree(c->h_small);
@@ -637,13 +639,15 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
   bool fitness_chained = false;
   double fit_sum = 0.0;
   if (!c->lm_host) {
-    // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_A / k_lm_B);
+    // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_step);
     // the host only enqueues slots and reads the state back once per batch.
     const int n = c->src.n, noff = noff_of(P.neighbor_method);
     if ((rc = ensure(c, c->corr_v, sizeof(int) * (size_t)n * noff))) return rc;
     if ((rc = ensure(c, c->corr_M, sizeof(double) * 6 * (size_t)n * noff))) return rc;
     const int nb = rgck::linearize_blocks(n);
-    if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 1) * (size_t)nb))) return rc;
+    if ((rc = ensure(c, c->corr_v2, sizeof(int) * (size_t)n * noff))) return rc;
+    if ((rc = ensure(c, c->corr_M2, sizeof(double) * 6 * (size_t)n * noff))) return rc;
+    if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 2) * (size_t)nb))) return rc;
     if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
     if (!c->lm_state.p) {
       if ((rc = ensure(c, c->lm_state, 4096))) return rc;  // LmState + the persistent solve's mailbox lines at +2048
@@ -686,7 +690,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
         fitness_chained = S.has_fit != 0;
       }
     }
-    int batch = 6;
+    int batch = 7;  // one linearisation + six fused cost/linearise steps: up to six outer iterations without a read-back
     if (!solved) {
       rgck::lm_init(c->stream, (rgck::LmState*)c->lm_state.p, in, c->d_small + 7, rows_impl ? c->tgt.segs.p : nullptr,
                     rows_impl ? c->src.segs.p : nullptr);
@@ -696,9 +700,9 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
       {
         ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch);
         for (int k = 0; k < batch; k++)
-          rgck::lm_slot(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
+          rgck::lm_step(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
                         c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
-                        (double*)c->partials.p, (int*)c->ipartials.p, (rgck::LmState*)c->lm_state.p);
+                        (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p);
       }
       if (fitness) {  // getFitnessScore at the final pose, chained blindly: the kernel is a no-op unless the LM is done
         ProfScope ps(c, RGC_K_FITNESS, n);
@@ -711,6 +715,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
       if (S.done) { fitness_chained = S.has_fit != 0; break; }
       batch = 3;
     }
+    if (!solved && S.cur) { std::swap(c->corr_v, c->corr_v2); std::swap(c->corr_M, c->corr_M2); }  // corr_v / corr_M = the valid buffer
     c->corr_noff = noff; c->corr_n = n; c->corr_valid = S.n_lin > 0;
     c->stats.n_corr = S.ncorr; c->stats.n_linearize = S.n_lin; c->stats.n_error = S.n_err;
     c->tgt.nvox = c->stats.n_voxels = S.nvox;

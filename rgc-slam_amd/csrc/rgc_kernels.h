@@ -30,7 +30,7 @@ struct LmState {  // device-resident state of LsqRegistration::computeTransforma
   int phase, done, conv, failed, outer, inner, n_lin, n_err, ncorr, ticketA, ticketB, max_outer, max_inner, has_fit;
   double fit_sum;                // sum of squared NN distances at the final pose (k_fitness_lm)
   int nvox, def_t, def_s, pad;   // frame counters carried home with the state
-  int gen, cmd, pad2, pad3;      // persistent solve: hand-off generation and the command published with it
+  int gen, cmd, mode, cur;       // persistent solve: hand-off generation + command; step kernels: mode, valid corr buffer
 };
 struct LmInit { double x0[16], rot_eps, trans_eps, init_factor; int max_outer, max_inner; };
 struct FeParams { int n_scans; double min_range, max_range; };
@@ -75,8 +75,9 @@ void compute_error(hipStream_t s, const float4* P, int n, Pose T, const double* 
 void lm_try(hipStream_t s, double* out, const int* ncorr, LmIn in);
 void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev, const double* vox, int noff, const int* corr_v,
                        const double* corr_M, double* partials, double* out1);
-void lm_slot(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
-             const double* vox, int noff, int* corr_v, double* corr_M, double* partials, int* ncorr_partials, LmState* st);
+// one step of the device-chained LM (see k_lm_step); corr_*0 / corr_*1 are the two correspondence buffers, st->cur the valid one
+void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
+             const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st);
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials);
 // the whole solve in one persistent launch (needs linearize_blocks(n) co-resident workgroups: callers keep it <= 256)
 void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,

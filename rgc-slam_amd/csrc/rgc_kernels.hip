@@ -1541,9 +1541,8 @@ __device__ __forceinline__ double error_point(const float4* __restrict__ P, int 
 }
 
 // ---- device-chained LM: the whole LsqRegistration::computeTransformation loop (lsq_registration_impl.hpp:53-172) as a
-// state machine in device memory.  One SLOT = kernel A (linearise at x0 unless this is a retry; the last-arriving block
-// folds the partial rows and performs the LM try) + kernel B (cost at the trial pose; the last block folds, computes
-// rho and accepts / rejects / terminates).  The host enqueues slots blindly and reads the state back once per batch.
+// state machine in device memory, advanced by STEP kernels (k_lm_step below) whose last-arriving workgroup folds the
+// partial rows and takes the decision.  The host enqueues steps blindly and reads the state back once per batch.
 // Inter-block hand-off (cdna_hip_programming.md G16): write-through (sc1) row stores, every wave drains vmcnt, workgroup
 // barrier, one lane takes a ticket; the last arriver does an agent-scope ACQUIRE before its workgroup reads the rows.
 __device__ __forceinline__ bool last_block_arrive(int* ticket) {
@@ -1565,15 +1564,25 @@ __device__ __forceinline__ bool last_block_arrive(int* ticket) {
   return is_last_s != 0;
 }
 
-// same summation order as k_fold: lane l sums rows l, l+64, ... then the shuffle tree; wave w owns accumulators w, w+4, ...
+// Fold of the per-workgroup rows by the last arriver, all LIN_T threads at once: thread t owns accumulator t % 32 and
+// the rows t / 32, t / 32 + 8, ... (summed in ascending order); the eight strided sums of an accumulator are then added in
+// ascending order from LDS.  Fixed order -> deterministic for a given row count; every load of a thread is independent,
+// so the fold costs about one memory round trip instead of one per accumulator.
 template <int NACC>
 __device__ __forceinline__ void block_fold_rows(const double* __restrict__ partials, int nrows, double* sh_out) {
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-  for (int a = w; a < NACC; a += LIN_T / WAVE) {
-    double s = 0;
-    for (int r = lane; r < nrows; r += WAVE) s += partials[(size_t)r * NACC + a];
-    s = wave_sum(s);
-    if (lane == 0) sh_out[a] = s;
+  static_assert(NACC <= 32 && LIN_T == 256, "thread -> (accumulator, row group) mapping");
+  __shared__ double grp[LIN_T / 32][32];
+  const int a = threadIdx.x & 31, gq = threadIdx.x >> 5;
+  double s = 0;
+  if (a < NACC)
+    for (int r = gq; r < nrows; r += LIN_T / 32) s += partials[(size_t)r * NACC + a];
+  grp[gq][a] = s;
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double t = grp[0][threadIdx.x];
+#pragma unroll
+    for (int j = 1; j < LIN_T / 32; j++) t += grp[j][threadIdx.x];
+    sh_out[threadIdx.x] = t;
   }
   __syncthreads();
 }
@@ -1603,70 +1612,6 @@ __global__ void __launch_bounds__(WAVE) k_lm_init(LmState* __restrict__ st, LmIn
   st->def_s = def_s ? *def_s : 0;
 }
 
-__global__ void __launch_bounds__(LIN_T)
-k_lm_A(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
-       const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v, double* __restrict__ corr_M,
-       double* __restrict__ partials, int* __restrict__ ncorr_partials, LmState* __restrict__ st) {
-  if (st->done) return;
-  __shared__ double folded[kAccum + 1];
-  if (st->phase == 0) {
-    Pose T;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-#pragma unroll
-      for (int e = 0; e < 3; e++) T.R[a * 3 + e] = st->x0[a * 4 + e];
-      T.t[a] = st->x0[a * 4 + 3];
-    }
-    const int i = blockIdx.x * LIN_T + threadIdx.x;
-    double acc[kAccum];
-#pragma unroll
-    for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
-    int ncorr = 0;
-    if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, 1, acc, ncorr);
-    double acc2[kAccum + 1];
-#pragma unroll
-    for (int a = 0; a < kAccum; a++) acc2[a] = acc[a];
-    acc2[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
-    block_reduce_store<kAccum + 1, true>(acc2, partials + (size_t)blockIdx.x * (kAccum + 1));
-    if (!last_block_arrive(&st->ticketA)) return;
-    block_fold_rows<kAccum + 1>(partials, gridDim.x, folded);
-    if (threadIdx.x == 0) {
-      int u = 0;
-#pragma unroll
-      for (int a = 0; a < 6; a++)
-#pragma unroll
-        for (int e = a; e < 6; e++) { st->H[a * 6 + e] = folded[u]; st->H[e * 6 + a] = folded[u]; u++; }
-#pragma unroll
-      for (int a = 0; a < 6; a++) st->b[a] = folded[21 + a];
-      st->y0 = folded[27];
-      st->ncorr = (int)folded[kAccum];
-      st->n_lin++;
-      if (st->lambda < 0.0) {  // :130-132
-        double m = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++) m = fmax(m, fabs(st->H[a * 7]));
-        st->lambda = st->init_factor * m;
-      }
-    }
-  } else if (blockIdx.x != 0) {
-    return;  // retry of the same linearisation: only the try below is needed
-  }
-  if (threadIdx.x == 0) {  // :136-143
-    double H[36], b[6], x0[16], d[6], delta[16], xi[16];
-#pragma unroll
-    for (int a = 0; a < 36; a++) H[a] = st->H[a];
-#pragma unroll
-    for (int a = 0; a < 6; a++) b[a] = st->b[a];
-#pragma unroll
-    for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
-    rgclm::lm_try(H, b, st->lambda, x0, d, delta, xi);
-#pragma unroll
-    for (int a = 0; a < 6; a++) st->d[a] = d[a];
-#pragma unroll
-    for (int a = 0; a < 16; a++) { st->delta[a] = delta[a]; st->xi[a] = xi[a]; }
-  }
-}
-
 __device__ __forceinline__ bool lm_is_converged(const double* d, double rot_eps, double trans_eps) {  // :82-91
   double m = 0;
 #pragma unroll
@@ -1678,52 +1623,154 @@ __device__ __forceinline__ bool lm_is_converged(const double* d, double rot_eps,
   return m < 1;
 }
 
+// One STEP kernel of the device-chained LM.  st->mode selects what the launch does:
+//   LM_MODE_LIN  linearise at x0 (correspondences -> buffer cur), fold, LM try -> xi;                    next: BA
+//   LM_MODE_BA   cost at the trial pose xi over the FROZEN correspondences of buffer cur (compute_error, :144) AND,
+//                speculatively, the next linearisation AT xi into buffer cur^1.  The last arriver folds both: rho >= 0
+//                (the usual case) accepts x0 = xi and -- unless the solve is over -- adopts the speculative H, b, y0 and
+//                correspondences (cur ^= 1) and performs the next LM try at once: ONE launch per outer iteration instead
+//                of two.  rho < 0 discards the speculation, raises lambda, retries with the old H, b;          next: B
+//   LM_MODE_B    cost only (a retry of the same linearisation); accept -> next: LIN, reject -> B again.
+// The arithmetic of each adopted linearisation / cost evaluation is exactly that of the two-kernel slots; the speculative
+// linearisation at the final pose is never adopted, so buffer cur holds what the reference's last linearize() left.
+constexpr int LM_MODE_LIN = 0, LM_MODE_BA = 1, LM_MODE_B = 2;
+constexpr int kStepAcc = kAccum + 2;  // 28 linearisation sums, the correspondence count, the trial cost
+
+__device__ __forceinline__ void lm_load_pose(const double* m16, Pose& T) {
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int e = 0; e < 3; e++) T.R[a * 3 + e] = m16[a * 4 + e];
+    T.t[a] = m16[a * 4 + 3];
+  }
+}
+
 __global__ void __launch_bounds__(LIN_T)
-k_lm_B(const float4* __restrict__ P, int n, const double* __restrict__ vox, int noff, const int* __restrict__ corr_v,
-       const double* __restrict__ corr_M, double* __restrict__ partials, LmState* __restrict__ st) {
+k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
+          const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v0, double* __restrict__ corr_M0,
+          int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st) {
   if (st->done) return;
-  __shared__ double folded[1];
+  __shared__ double folded[kStepAcc];
+  const int mode = st->mode, cur = st->cur;
+  int* cv_cur = cur ? corr_v1 : corr_v0;
+  double* cm_cur = cur ? corr_M1 : corr_M0;
+  int* cv_nxt = cur ? corr_v0 : corr_v1;
+  double* cm_nxt = cur ? corr_M0 : corr_M1;
   const int i = blockIdx.x * LIN_T + threadIdx.x;
-  double acc[1] = {0.0};
-  if (i < n) acc[0] = error_point(P, i, n, st->xi, vox, noff, corr_v, corr_M);
-  block_reduce_store<1, true>(acc, partials + blockIdx.x);
-  if (!last_block_arrive(&st->ticketB)) return;
-  block_fold_rows<1>(partials, gridDim.x, folded);
+  double acc[kStepAcc];
+#pragma unroll
+  for (int a = 0; a < kStepAcc; a++) acc[a] = 0.0;
+  if (mode != LM_MODE_LIN && i < n) acc[kAccum + 1] = error_point(P, i, n, st->xi, vox, noff, cv_cur, cm_cur);
+  if (mode != LM_MODE_B) {
+    Pose T;
+    lm_load_pose(mode == LM_MODE_LIN ? st->x0 : st->xi, T);
+    double lin[kAccum];
+#pragma unroll
+    for (int a = 0; a < kAccum; a++) lin[a] = 0.0;
+    int ncorr = 0;
+    if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, mode == LM_MODE_LIN ? cv_cur : cv_nxt,
+                               mode == LM_MODE_LIN ? cm_cur : cm_nxt, 1, lin, ncorr);
+#pragma unroll
+    for (int a = 0; a < kAccum; a++) acc[a] = lin[a];
+    acc[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
+  }
+  block_reduce_store<kStepAcc, true>(acc, partials + (size_t)blockIdx.x * kStepAcc);
+  if (!last_block_arrive(&st->ticketA)) return;
+  block_fold_rows<kStepAcc>(partials, gridDim.x, folded);
   if (threadIdx.x != 0) return;
-  const double yi = folded[0];
-  st->yi = yi;
-  st->n_err++;
-  double den = 0;
+
+  double H[36], b[6], x0[16], d[6], delta[16], xi[16];
+  double lambda = st->lambda;
+  bool have_lin = false;  // H, b (registers) hold a linearisation at the pose the next try starts from
+  auto adopt = [&]() {    // H, b, y0, ncorr of the linearisation just folded
+    int u = 0;
 #pragma unroll
-  for (int a = 0; a < 6; a++) den += st->d[a] * (st->lambda * st->d[a] - st->b[a]);
-  const double rho = (st->y0 - yi) / den;  // :145
-  bool outer_done = false;
-  if (rho < 0) {  // :155-163
-    if (lm_is_converged(st->delta, st->rot_eps, st->trans_eps)) {
-      outer_done = true;  // step_lm returns true with x unchanged
-    } else {
-      st->lambda = st->nu * st->lambda;
-      st->nu = 2 * st->nu;
-      st->inner++;
-      if (st->inner >= st->max_inner) { st->failed = 1; st->done = 1; }  // "lm not converged!!", :69-72
-      st->phase = 1;
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int e = a; e < 6; e++) { H[a * 6 + e] = folded[u]; H[e * 6 + a] = folded[u]; u++; }
+#pragma unroll
+    for (int a = 0; a < 6; a++) b[a] = folded[21 + a];
+#pragma unroll
+    for (int a = 0; a < 36; a++) st->H[a] = H[a];
+#pragma unroll
+    for (int a = 0; a < 6; a++) st->b[a] = b[a];
+    st->y0 = folded[27];
+    st->ncorr = (int)folded[kAccum];
+    st->n_lin++;
+    have_lin = true;
+  };
+  if (mode == LM_MODE_LIN) {
+    adopt();
+    if (lambda < 0.0) {  // :130-132
+      double m = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) m = fmax(m, fabs(H[a * 7]));
+      lambda = st->init_factor * m;
     }
-  } else {  // :165-168
 #pragma unroll
-    for (int a = 0; a < 16; a++) st->x0[a] = st->xi[a];
-    st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
+    for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
+    st->mode = LM_MODE_BA;
+  } else {
+    const double yi = folded[kAccum + 1];
+    st->yi = yi;
+    st->n_err++;
+    double den = 0;
 #pragma unroll
-    for (int a = 0; a < 36; a++) st->Hfin[a] = st->H[a];
-    outer_done = true;
+    for (int a = 0; a < 6; a++) den += st->d[a] * (lambda * st->d[a] - st->b[a]);
+    const double rho = (st->y0 - yi) / den;  // :145
+    const bool conv_now = lm_is_converged(st->delta, st->rot_eps, st->trans_eps);
+    bool outer_done = false;
+    if (rho < 0) {  // :155-163
+      if (conv_now) {
+        outer_done = true;  // step_lm returns true with x unchanged
+      } else {
+        lambda = st->nu * lambda;
+        st->nu = 2 * st->nu;
+        st->inner++;
+        if (st->inner >= st->max_inner) { st->failed = 1; st->done = 1; st->lambda = lambda; return; }  // "lm not converged!!", :69-72
+#pragma unroll
+        for (int a = 0; a < 36; a++) H[a] = st->H[a];
+#pragma unroll
+        for (int a = 0; a < 6; a++) b[a] = st->b[a];
+#pragma unroll
+        for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
+        have_lin = true;  // the same linearisation, a larger lambda
+        st->mode = LM_MODE_B;
+      }
+    } else {  // :165-168
+#pragma unroll
+      for (int a = 0; a < 16; a++) { x0[a] = st->xi[a]; st->x0[a] = x0[a]; }
+      lambda = lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
+#pragma unroll
+      for (int a = 0; a < 36; a++) st->Hfin[a] = st->H[a];
+      outer_done = true;
+    }
+    if (outer_done) {
+      st->conv = conv_now ? 1 : 0;  // :74
+      st->outer++;
+      st->nu = 2.0;
+      st->inner = 0;
+      if (conv_now || st->outer >= st->max_outer) {  // :65
+        st->done = 1;
+        st->lambda = lambda;
+        return;
+      }
+      // accepted and not finished (rho < 0 never gets here: it only ends an outer iteration when converged)
+      if (mode == LM_MODE_BA) {
+        adopt();          // the speculative linearisation was taken at xi = the new x0
+        st->cur = cur ^ 1;
+      } else {
+        st->mode = LM_MODE_LIN;  // retry path: the next launch linearises at the new x0
+      }
+    }
   }
-  if (outer_done) {
-    st->conv = lm_is_converged(st->delta, st->rot_eps, st->trans_eps) ? 1 : 0;  // :74
-    st->outer++;
-    st->phase = 0;
-    st->nu = 2.0;
-    st->inner = 0;
-    if (st->conv || st->outer >= st->max_outer) st->done = 1;  // :65
-  }
+  st->lambda = lambda;
+  if (!have_lin) return;
+  rgclm::lm_try(H, b, lambda, x0, d, delta, xi);  // :136-143
+#pragma unroll
+  for (int a = 0; a < 6; a++) st->d[a] = d[a];
+#pragma unroll
+  for (int a = 0; a < 16; a++) { st->delta[a] = delta[a]; st->xi[a] = xi[a]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2277,11 +2324,10 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
   hipLaunchKernelGGL(k_error_dev, dim3(nb), dim3(LIN_T), 0, s, P, n, Tdev, vox, noff, corr_v, corr_M, partials);
   hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
 }
-void lm_slot(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
-             const double* vox, int noff, int* corr_v, double* corr_M, double* partials, int* ncorr_partials, LmState* st) {
-  const int nb = linearize_blocks(n);
-  hipLaunchKernelGGL(k_lm_A, dim3(nb), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v, corr_M, partials, ncorr_partials, st);
-  hipLaunchKernelGGL(k_lm_B, dim3(nb), dim3(LIN_T), 0, s, P, n, vox, noff, corr_v, corr_M, partials, st);
+void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
+             const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st) {
+  hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
+                     corr_M1, partials, st);
 }
 void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
             const double* vox, int noff, int* corr_v, double* corr_M, double* partials, LmState* st, const LmInit& in, int gen_base,
