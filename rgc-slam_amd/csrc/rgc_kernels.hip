@@ -964,6 +964,37 @@ __device__ __forceinline__ void coop_for_each_candidate(const Grid& g, const int
   }
 }
 
+// k-th smallest squared distance (as an fp32 bit pattern) over the candidates of cube r, one wave.  Every lane keeps the KW
+// smallest of ITS candidates; the k-th smallest over the wave is the largest pattern T with #(values < T) < k, found by
+// bisection on the bits: the count is a sum of ballot popcounts (compares write SGPR masks, s_bcnt1 adds them, no
+// cross-lane traffic).  KW < k is a gamble that pays: candidates are dealt round-robin, so a lane holding more than KW of
+// the k nearest is rare (KW = 4, k = 20: ~1.5 % of queries); `overflow` reports that a lane's largest kept value lies
+// below T -- it may have dropped something below T -- and the caller repeats the sweep with full-width chains.
+template <int KW>
+__device__ __forceinline__ unsigned coop_kth(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, const int c[3], int r,
+                                             CoopRows* sh, int lane, float px, float py, float pz, int k, bool& overflow) {
+  TopK<KW> top;
+  top.init();
+  coop_for_each_candidate(g, c, r, start, sh, lane, [&](int s0, bool v0, int s1, bool v1) {
+    const float4 c0 = P[s0], c1 = P[s1];
+    const float x0 = v0 ? dist2(px, py, pz, c0) : INFINITY;
+    const float x1 = v1 ? dist2(px, py, pz, c1) : INFINITY;
+    if (top.improves(x0)) top.insert(x0);
+    if (top.improves(x1)) top.insert(x1);
+  });
+  unsigned T = 0;
+  for (int bit = 30; bit >= 0; bit--) {
+    const unsigned cand = T | (1u << bit);
+    if (cand > 0x7F800000u) continue;
+    int cnt_lt = 0;
+#pragma unroll
+    for (int j = 0; j < KW; j++) cnt_lt += __popcll(__ballot(top.a[j] < (int)cand));
+    if (cnt_lt < k) T = cand;
+  }
+  overflow = __any(top.a[KW - 1] < (int)T);
+  return T;
+}
+
 template <int KC, bool kTarget>
 __global__ void __launch_bounds__(KNN_T)
 k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int k, Deferred df, double* __restrict__ nx,
@@ -999,26 +1030,9 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
         rn = r + max(1, (r + 1) / 2);  // fewer than k candidates so far: grow geometrically (x1.5), not x2
       }
       r = min(rn, rmax);
-      TopK<KC> top;
-      top.init();
-      coop_for_each_candidate(g, c, r, start, sh, lane, [&](int s0, bool v0, int s1, bool v1) {
-        const float4 c0 = P[s0], c1 = P[s1];
-        const float x0 = v0 ? dist2(px, py, pz, c0) : INFINITY;
-        const float x1 = v1 ? dist2(px, py, pz, c1) : INFINITY;
-        if (top.improves(x0)) top.insert(x0);
-        if (top.improves(x1)) top.insert(x1);
-      });
-      // k-th smallest over the wave: largest bit pattern T with #(values < T) < k  ==  the k-th smallest value.
-      // The count is a sum of ballot popcounts: compares write SGPR masks, s_bcnt1 adds them -- no cross-lane traffic.
-      unsigned T = 0;
-      for (int bit = 30; bit >= 0; bit--) {
-        const unsigned cand = T | (1u << bit);
-        if (cand > 0x7F800000u) continue;
-        int cnt_lt = 0;
-#pragma unroll
-        for (int j = 0; j < KC; j++) cnt_lt += __popcll(__ballot(top.a[j] < (int)cand));
-        if (cnt_lt < k) T = cand;
-      }
+      bool overflow;
+      unsigned T = coop_kth<4>(P, start, g, c, r, sh, lane, px, py, pz, k, overflow);
+      if (overflow) T = coop_kth<KC>(P, start, g, c, r, sh, lane, px, py, pz, k, overflow);  // full width: nothing relevant can be dropped
       thr = (T >= 0x7F800000u) ? INFINITY : __uint_as_float(T);
       if (r >= rmax) break;  // whole grid scanned
       if (thr < INFINITY) {
@@ -2073,11 +2087,21 @@ __device__ __forceinline__ float fitness_point(const float4* __restrict__ SP, in
   auto scan = [&](int s0, int s1) {
     int s = s0;
     unsigned off = (unsigned)s0 << 4;
-    for (; s + 4 <= s1; s += 4, off += 64) {
-      const float4 c0 = point_at(TP, off), c1 = point_at(TP, off + 16), c2 = point_at(TP, off + 32), c3 = point_at(TP, off + 48);
-      best = fminf(best, fminf(fminf(dist2(px, py, pz, c0), dist2(px, py, pz, c1)), fminf(dist2(px, py, pz, c2), dist2(px, py, pz, c3))));
+    for (; s + 8 <= s1; s += 8, off += 128) {  // eight loads in flight: this kernel is a chain of memory round trips
+      float4 cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) cc[u] = point_at(TP, off + 16u * u);
+#pragma unroll
+      for (int u = 0; u < 8; u++) best = fminf(best, dist2(px, py, pz, cc[u]));
     }
-    for (; s < s1; s++, off += 16) best = fminf(best, dist2(px, py, pz, point_at(TP, off)));
+    if (s < s1) {  // 1..7 left: clamped loads (a repeated candidate does not change a minimum)
+      const unsigned last = (unsigned)(s1 - 1) << 4;
+      float4 cc[7];
+#pragma unroll
+      for (int u = 0; u < 7; u++) cc[u] = point_at(TP, min(off + 16u * u, last));
+#pragma unroll
+      for (int u = 0; u < 7; u++) best = fminf(best, dist2(px, py, pz, cc[u]));
+    }
   };
   if (inside) {  // an aligned scan point usually has its nearest map point in its own cell, closer than the cell walls
     const int own = cell_index(g, c[0], c[1], c[2]);
