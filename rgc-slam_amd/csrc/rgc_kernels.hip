@@ -453,9 +453,16 @@ struct TopK {  // the KC smallest squared distances, ascending, in registers (st
   }
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dist2(float px, float py, float pz, const float4& c) {
-  const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
-  return (dx * dx + dy * dy) + dz * dz;  // flann::L2_Simple<float>; never contracted (-ffp-contract=off)
+  // (dx*dx + dy*dy) + dz*dz like flann::L2_Simple<float>; never contracted (-ffp-contract=off).  x and y go through the
+  // packed fp32 pipe as ONE pair -- the loaded {x, y} already sits in an aligned register pair -- so the distance is
+  // v_pk_add, v_pk_mul, v_sub, v_mul, v_add, v_add: six VALU ops per candidate (each lane rounds exactly as before).
+  const f32x2 cxy = {c.x, c.y}, pxy = {px, py};
+  const f32x2 d = pxy - cxy;
+  const f32x2 dd = d * d;
+  const float dz = pz - c.z;
+  return (dd.x + dd.y) + dz * dz;
 }
 
 // sorted point at a 32-bit BYTE offset: base in SGPRs + one VGPR offset, no 64-bit address arithmetic per candidate
@@ -518,15 +525,28 @@ __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3],
 // sixteen start[] loads in flight per step, and f is instantiated ONCE (a loop over the parked rows) instead of once per
 // unrolled row -- the chain insert inside f is 160 instructions per candidate slot.
 // Returns false -- the walk is abandoned -- as soon as the cube turns out to hold more than `budget` candidates.
+// rad < inf clips the cube to the BALL of that radius around q: a row whose nearest wall is farther than rad, and the
+// cells of a row beyond the ball's x extent, hold neither a neighbour nor a tie when rad is (an upper bound of) the k-th
+// distance -- for a cube of radius 2 that is about half of its cells.
 template <typename F>
-__device__ __forceinline__ bool for_each_cube_row_lds(const Grid& g, const int c[3], int r, const int* __restrict__ start, int* rng,
-                                                      int lstride, int budget, F&& f) {
+__device__ __forceinline__ bool for_each_cube_row_lds(const Grid& g, const int c[3], const double q[3], double rad, int r,
+                                                      const int* __restrict__ start, int* rng, int lstride, int budget, F&& f) {
   const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
   const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
-  const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
+  int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
+  const bool clip = rad < 1.0e30;
+  const double rad2 = rad * rad;
+  if (clip) {  // floor() of a slightly-too-small / too-large coordinate only ever keeps an extra cell
+    x0 = max(x0, (int)floor((q[0] - rad) / g.res - 0.5) - g.minc[0]);
+    x1 = min(x1, (int)floor((q[0] + rad) / g.res - 0.5) - g.minc[0]);
+  }
   if (x0 > x1) return true;
   int seen = 0;
   for (int z = z0; z <= z1; z++) {
+    double dzw = 0.0;
+    if (z < c[2]) dzw = q[2] - ((double)(z + g.minc[2]) + 1.5) * g.res;
+    else if (z > c[2]) dzw = ((double)(z + g.minc[2]) + 0.5) * g.res - q[2];
+    if (clip && dzw > rad) continue;
     for (int y = y0; y <= y1; y += 8) {
       int a[8], b[8];
 #pragma unroll
@@ -534,6 +554,12 @@ __device__ __forceinline__ bool for_each_cube_row_lds(const Grid& g, const int c
         const int yy = min(y + u, y1);
         a[u] = start[cell_index(g, x0, yy, z)];
         b[u] = start[cell_index(g, x1, yy, z) + 1];
+        if (clip) {
+          double dyw = 0.0;
+          if (yy < c[1]) dyw = q[1] - ((double)(yy + g.minc[1]) + 1.5) * g.res;
+          else if (yy > c[1]) dyw = ((double)(yy + g.minc[1]) + 0.5) * g.res - q[1];
+          if (dyw > 0.0 && dyw * dyw + (dzw > 0.0 ? dzw * dzw : 0.0) > rad2) b[u] = a[u];  // the ball does not reach this row
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
@@ -833,7 +859,8 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
         // the cube of a sparse query is nearly empty; on the fringe of a dense map it is not (and a lane that chews through
         // hundreds of candidates alone becomes the tail of the launch): past the budget the walk is abandoned and the query
         // goes to the cooperative kernel
-        const bool walked = for_each_cube_row_lds(g, c, rn, start, rng, KNN_T, jump_budget,
+        const double rad = thr < INFINITY ? sqrt((double)thr) * (1.0 + 1e-5) : 1.0e300;
+        const bool walked = for_each_cube_row_lds(g, c, q, rad, rn, start, rng, KNN_T, jump_budget,
                                                   [&](int s0, int s1) { scan_range_topk<KC>(P, s0, s1, px, py, pz, top); });
         const float t2 = walked ? top.kth(k) : INFINITY;
         if (t2 < INFINITY) {
@@ -856,7 +883,7 @@ __device__ __forceinline__ void knn_point(const float4* __restrict__ P, const in
 #pragma unroll 1
       for (int r = 0; r < 9; r++) scan_range_collect_le(P, rng[(2 * r) * KNN_T], rng[(2 * r + 1) * KNN_T], px, py, pz, thr, k, list, KNN_T, m);
     } else {
-      for_each_cube_row_lds(g, c, rdone, start, rng, KNN_T, INT_MAX,
+      for_each_cube_row_lds(g, c, q, sqrt((double)thr) * (1.0 + 1e-5), rdone, start, rng, KNN_T, INT_MAX,
                             [&](int s0, int s1) { scan_range_collect_le(P, s0, s1, px, py, pz, thr, k, list, KNN_T, m); });
     }
     done = (m == k);  // m > k: several candidates exactly at the k-th distance, index tie-break -> cooperative path

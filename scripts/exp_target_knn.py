@@ -8,6 +8,7 @@ nt = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 world, tgt = synth.make_world_and_map(nt)
 v = registration.odometer_vgicp(0)
+if os.environ.get("RGC_EXP_RES"): v.setResolution(float(os.environ["RGC_EXP_RES"]))
 v.setInputTarget(tgt); v.synchronize()
 v.profile_enable(True); v.profile_reset()
 for _ in range(reps):
