@@ -81,7 +81,8 @@ RGC_API const char* rgc_version(void);
  * stride 16 or 32 = pcl::PointXYZI padding welcome).  Setting a cloud drops its covariances (and, for the
  * target, the voxel map) exactly like the reference; the exact-kNN covariances (fast_gicp_impl.hpp:241-298),
  * and for the target the Gaussian voxel map (fast_vgicp_voxel.hpp:129-156), are computed on the device
- * (enqueued immediately on the context's stream). */
+ * (enqueued immediately on the context's stream).  n <= 2^27 points per cloud (RGC_ERR_INVALID beyond: the kernels
+ * address the sorted 16-byte points with 32-bit byte offsets). */
 RGC_API int rgc_set_target(rgc_ctx* ctx, const float* xyz, int n, int stride_bytes);
 RGC_API int rgc_set_source(rgc_ctx* ctx, const float* xyz, int n, int stride_bytes);
 /* same, but xyz is DEVICE memory on the context's device (cloud already resident in HBM). */

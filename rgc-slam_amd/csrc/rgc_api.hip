@@ -691,18 +691,17 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
       }
     }
     int batch = 7;  // one linearisation + six fused cost/linearise steps: up to six outer iterations without a read-back
-    if (!solved) {
-      rgck::lm_init(c->stream, (rgck::LmState*)c->lm_state.p, in, c->d_small + 7, rows_impl ? c->tgt.segs.p : nullptr,
-                    rows_impl ? c->src.segs.p : nullptr);
-      c->lm_gen = 0;  // k_lm_init zeroes the whole state
-    }
+    bool first_step = true;
+    if (!solved) c->lm_gen = 0;  // the first step kernel rewrites the whole state
     for (int guard = 0; guard < 400 && !solved; guard++) {
       {
         ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch);
         for (int k = 0; k < batch; k++)
           rgck::lm_step(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
                         c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
-                        (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p);
+                        (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p,
+                        first_step ? &in : nullptr, c->d_small + 7, rows_impl ? c->tgt.segs.p : nullptr, rows_impl ? c->src.segs.p : nullptr),
+          first_step = false;
       }
       if (fitness) {  // getFitnessScore at the final pose, chained blindly: the kernel is a no-op unless the LM is done
         ProfScope ps(c, RGC_K_FITNESS, n);

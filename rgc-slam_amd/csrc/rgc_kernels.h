@@ -77,7 +77,8 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
                        const double* corr_M, double* partials, double* out1);
 // one step of the device-chained LM (see k_lm_step); corr_*0 / corr_*1 are the two correspondence buffers, st->cur the valid one
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
-             const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st);
+             const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
+             const LmInit* first /* non-null: this launch opens a solve */, const int* nvox, const void* segs_t, const void* segs_s);
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials);
 // the whole solve in one persistent launch (needs linearize_blocks(n) co-resident workgroups: callers keep it <= 256)
 void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,

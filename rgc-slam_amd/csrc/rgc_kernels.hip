@@ -1689,10 +1689,28 @@ __device__ __forceinline__ void lm_load_pose(const double* m16, Pose& T) {
 __global__ void __launch_bounds__(LIN_T)
 k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
           const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v0, double* __restrict__ corr_M0,
-          int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st) {
-  if (st->done) return;
+          int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st, int first,
+          LmInit in, const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s) {
+  // first != 0: this launch opens a solve.  Nobody reads the (stale) state: mode, buffer and pose come from the kernel
+  // arguments, and the last-arriving workgroup's lane 0 writes the fresh state (:53-63) before it uses it -- no separate
+  // initialisation launch, no H2D copy.  The tickets are 0 between launches by construction (the last arriver resets them).
+  if (first ? in.max_outer <= 0 : st->done != 0) {
+    if (first && blockIdx.x == 0 && threadIdx.x == 0) {  // max_iterations <= 0: the guess is the answer
+      int* w = reinterpret_cast<int*>(st);
+      for (int u = 0; u < (int)(sizeof(LmState) / sizeof(int)); u++) w[u] = 0;
+#pragma unroll
+      for (int a = 0; a < 16; a++) st->x0[a] = in.x0[a];
+#pragma unroll
+      for (int a = 0; a < 6; a++) st->Hfin[a * 7] = 1.0;
+      st->nvox = nvox ? *nvox : 0;
+      st->def_t = def_t ? *def_t : 0;
+      st->def_s = def_s ? *def_s : 0;
+      st->done = 1;
+    }
+    return;
+  }
   __shared__ double folded[kStepAcc];
-  const int mode = st->mode, cur = st->cur;
+  const int mode = first ? LM_MODE_LIN : st->mode, cur = first ? 0 : st->cur;
   int* cv_cur = cur ? corr_v1 : corr_v0;
   double* cm_cur = cur ? corr_M1 : corr_M0;
   int* cv_nxt = cur ? corr_v0 : corr_v1;
@@ -1704,7 +1722,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
   if (mode != LM_MODE_LIN && i < n) acc[kAccum + 1] = error_point(P, i, n, st->xi, vox, noff, cv_cur, cm_cur);
   if (mode != LM_MODE_B) {
     Pose T;
-    lm_load_pose(mode == LM_MODE_LIN ? st->x0 : st->xi, T);
+    lm_load_pose(first ? in.x0 : (mode == LM_MODE_LIN ? st->x0 : st->xi), T);
     double lin[kAccum];
 #pragma unroll
     for (int a = 0; a < kAccum; a++) lin[a] = 0.0;
@@ -1720,6 +1738,24 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
   block_fold_rows<kStepAcc>(partials, gridDim.x, folded);
   if (threadIdx.x != 0) return;
 
+  if (first) {  // fresh state (:53-63) plus the frame's counters, so that ONE read-back at the end carries every statistic
+    int* w = reinterpret_cast<int*>(st);
+    for (int u = 0; u < (int)(sizeof(LmState) / sizeof(int)); u++) w[u] = 0;  // (the ticket was already reset above)
+#pragma unroll
+    for (int a = 0; a < 16; a++) st->x0[a] = in.x0[a];
+    st->lambda = -1.0;  // :56
+    st->nu = 2.0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) st->Hfin[a * 7] = 1.0;  // final_hessian_.setIdentity(), :21
+    st->rot_eps = in.rot_eps;
+    st->trans_eps = in.trans_eps;
+    st->init_factor = in.init_factor;
+    st->max_outer = in.max_outer;
+    st->max_inner = in.max_inner;
+    st->nvox = nvox ? *nvox : 0;
+    st->def_t = def_t ? *def_t : 0;
+    st->def_s = def_s ? *def_s : 0;
+  }
   double H[36], b[6], x0[16], d[6], delta[16], xi[16];
   double lambda = st->lambda;
   bool have_lin = false;  // H, b (registers) hold a linearisation at the pose the next try starts from
@@ -2376,9 +2412,10 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
   hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
 }
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
-             const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st) {
+             const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
+             const LmInit* first, const int* nvox, const void* segs_t, const void* segs_s) {
   hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
-                     corr_M1, partials, st);
+                     corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s);
 }
 void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
             const double* vox, int noff, int* corr_v, double* corr_M, double* partials, LmState* st, const LmInit& in, int gen_base,

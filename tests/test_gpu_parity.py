@@ -244,6 +244,15 @@ def test_k_and_resolution_parameters(reg_mod, orc, fx_reg):
     cost, H, b = v.linearize(fx_reg["guess"])
     ocost, oH, ob = o.linearize(fx_reg["guess"])
     assert abs(cost - ocost) <= 1e-9 * abs(ocost) and np.abs(H - oH).max() <= 1e-9 * np.abs(oH).max()
+    # k > 20 runs the 32-slot instantiation of the neighbour chain (bulk and cooperative kernels)
+    v.setCorrespondenceRandomness(25)
+    v.setResolution(1.0)
+    v.setInputTarget(fx_reg["tgt"])
+    v.setInputSource(fx_reg["src"])
+    o = orc.Registration(k_correspondences=25, voxel_res=1.0, num_threads=0)
+    o.set_target(fx_reg["tgt"]); o.set_source(fx_reg["src"]); o.prepare()
+    for got, exp in ((v.getSourceCovariances(), o.source_cov), (v.getTargetCovariances(), o.target_cov)):
+        assert np.sum(np.abs(got - exp(len(got))).reshape(len(got), -1).max(axis=1) > 1e-9) <= 2
     v.close()
 
 
