@@ -226,6 +226,16 @@ def main():
         out["cpu_baseline"] = {"value": round(n_done / t_cpu, 4), "unit": "scans/s", "cores": cores, "kind": "port",
                                "sample": f"{n_done} frame(s) of the same workload (first timed frames), OpenMP x{cores}, "
                                          f"{t_cpu:.1f} s of CPU work"}
+        # the reference hard-codes 14 OpenMP threads (RGC_odometer.cpp:1006): one frame of the same workload at that setting
+        o14 = oracle.Registration(num_threads=min(14, cores))
+        c0 = time.perf_counter()
+        o14.set_target(tgt)
+        o14.set_source(scans[W])
+        o14.align(guess_in[0])
+        _ = o14.fitness()
+        t14 = time.perf_counter() - c0
+        out["cpu_baseline"]["value_14_threads"] = round(1.0 / t14, 4)
+        out["cpu_baseline"]["sample"] += f"; 1 frame at {min(14, cores)} threads (the reference's setNumThreads), {t14:.1f} s"
         out["pose_parity_vs_cpu"] = {"frames": n_done, "max_dt_m": max(dts), "max_dtheta_rad": max(dths),
                                      "rmse_dt_m": float(np.sqrt(np.mean(np.square(dts)))),
                                      "rmse_dtheta_rad": float(np.sqrt(np.mean(np.square(dths))))}

@@ -1628,31 +1628,6 @@ __device__ __forceinline__ void block_fold_rows(const double* __restrict__ parti
   __syncthreads();
 }
 
-// State of a fresh computeTransformation (lsq_registration_impl.hpp:53-63) from kernel arguments -- no H2D copy -- plus the
-// frame's counters (voxels, deferred kNN queries) so that ONE read-back of the state at the end carries every statistic.
-__global__ void __launch_bounds__(WAVE) k_lm_init(LmState* __restrict__ st, LmInit in, const int* __restrict__ nvox,
-                                                  const int* __restrict__ def_t, const int* __restrict__ def_s) {
-  int* w = reinterpret_cast<int*>(st);
-  for (int i = threadIdx.x; i < (int)(sizeof(LmState) / sizeof(int)); i += WAVE) w[i] = 0;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fill lands before lane 0's fields (same wave, in order)
-  if (threadIdx.x != 0) return;
-#pragma unroll
-  for (int a = 0; a < 16; a++) st->x0[a] = in.x0[a];
-  st->lambda = -1.0;  // :56
-  st->nu = 2.0;
-#pragma unroll
-  for (int a = 0; a < 6; a++) st->Hfin[a * 7] = 1.0;  // final_hessian_.setIdentity(), :21
-  st->rot_eps = in.rot_eps;
-  st->trans_eps = in.trans_eps;
-  st->init_factor = in.init_factor;
-  st->max_outer = in.max_outer;
-  st->max_inner = in.max_inner;
-  st->done = in.max_outer <= 0 ? 1 : 0;
-  st->nvox = nvox ? *nvox : 0;
-  st->def_t = def_t ? *def_t : 0;
-  st->def_s = def_s ? *def_s : 0;
-}
-
 __device__ __forceinline__ bool lm_is_converged(const double* d, double rot_eps, double trans_eps) {  // :82-91
   double m = 0;
 #pragma unroll
@@ -2427,9 +2402,6 @@ void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, 
 }
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials) {
   hipLaunchKernelGGL(k_fitness_lm, dim3(fitness_blocks(ns)), dim3(FIT_T), 0, s, SP, ns, st, TP, tstart, g, partials);
-}
-void lm_init(hipStream_t s, LmState* st, const LmInit& in, const int* nvox, const void* segs_t, const void* segs_s) {
-  hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(WAVE), 0, s, st, in, nvox, (const int*)segs_t, (const int*)segs_s);
 }
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials, double* out1) {
   const int nb = fitness_blocks(ns);

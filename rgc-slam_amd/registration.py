@@ -177,6 +177,13 @@ class FastVGICP:
             self._fitness = f.value
         return self._fitness
 
+    def fitnessAt(self, T):
+        """getFitnessScore's quantity at an arbitrary pose: mean squared 1-NN distance of the transformed source."""
+        f = C.c_double(0)
+        t = np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+        self._chk(self._L.rgc_fitness(self._h, t.ctypes.data_as(C.POINTER(C.c_float)), C.byref(f)))
+        return f.value
+
     def evaluateCost(self, relative_pose, want_H=False):   # lsq_registration_impl.hpp:48-50
         T = np.ascontiguousarray(np.asarray(relative_pose, dtype=np.float32).astype(np.float64)).reshape(16)
         cost = C.c_double(0)

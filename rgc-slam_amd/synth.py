@@ -251,7 +251,8 @@ def make_scan(world: World, T_ws: np.ndarray, elev_deg: np.ndarray = VLP16_ELEV,
         d_w = np.einsum("nij,nj->ni", Rm, d_s)
     t = _cast(world, o, d_w, max_range)
     t = t + rng.normal(0.0, sigma, t.shape)
-    p = d_s * t[:, None]
+    with np.errstate(invalid="ignore"):  # rays that hit nothing carry t = inf; they are dropped by `ok` below
+        p = d_s * t[:, None]
     ok = np.isfinite(t) & (t > min_range) & (t < max_range)
     ok &= ~((p[:, 0] < 0) & (np.abs(p[:, 1]) < 0.5))
     # per-surface albedo-like intensity with noise (uint8 range)

@@ -1,0 +1,119 @@
+"""BASELINE.json's configurations at FULL size on the MI355X (-m gpu): c-main 30 k vs 1 M, c3 130 k (HDL-64) vs 5 M,
+c5 250 k (two interleaved HDL-64 patterns) vs 20 M with an IMU-like prior.
+
+At these sizes the checks are (i) the CPU oracle itself on all host cores of the GPU box (it needs ~0.3 s per million map
+points there) with the path's tolerance -- pose delta <= 1e-4 m / 1e-4 rad -- and (ii) properties that do not depend on
+size: every regularised covariance has trace 2.001; the voxel table partitions the map (sum of counts = N_t, one voxel
+per occupied cell of floor(x/res - 0.5), counted independently with numpy); the known motion is recovered; aligning again
+from the result does not move (idempotence); the fitness is the mean squared 1-NN distance (checked on a sample)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot_angle(Ra, Rb):
+    R = Ra.astype(np.float64) @ Rb.astype(np.float64).T
+    w = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return float(np.arcsin(min(1.0, np.linalg.norm(w))))
+
+
+@pytest.fixture(scope="module")
+def synth():
+    import rgc_slam_amd.synth as s
+    return s
+
+
+@pytest.fixture(scope="module")
+def map5m(synth):
+    world, tgt = synth.make_world_and_map(5_000_000, seed=synth.SEED + 7)
+    return world, tgt
+
+
+def _properties(v, tgt, res=1.0):
+    n_t = len(tgt)
+    vm = v.getVoxels()
+    assert int(vm["num"].sum()) == n_t
+    c = np.floor(tgt.astype(np.float32).astype(np.float64) / res - 0.5).astype(np.int64)
+    c -= c.min(0)
+    key = (c[:, 2] * (c[:, 1].max() + 1) + c[:, 1]) * (c[:, 0].max() + 1) + c[:, 0]
+    assert len(vm["num"]) == len(np.unique(key)) == v.stats()["n_voxels"]
+    # C = I - 0.999 n n^T with |n| = 1: trace 2.001, on a strided sample of the map and on every source point
+    ct = v.getTargetCovariances()[:: max(1, n_t // 200000)]
+    assert np.abs(np.trace(ct, axis1=1, axis2=2) - 2.001).max() < 1e-9
+    cs = v.getSourceCovariances()
+    assert np.abs(np.trace(cs, axis1=1, axis2=2) - 2.001).max() < 1e-9
+
+
+def _check_case(synth, world, tgt, src, T_true, guess, oracle_pose_check=True, recover_tol=(0.03, 3e-3)):
+    from rgc_slam_amd import registration
+    from oracle import oracle
+    v = registration.odometer_vgicp(0)
+    v.setInputTarget(tgt)
+    v.setInputSource(src)
+    v.align(guess, want_output=False, want_fitness=True)
+    T = v.getFinalTransformation().copy()
+    fit = v.getFitnessScore()
+    assert v.hasConverged()
+    # known motion recovered (range noise 1 cm, map sampling 0.3 m)
+    assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < recover_tol[0] and _rot_angle(T[:3, :3], T_true[:3, :3]) < recover_tol[1]
+    _properties(v, tgt)
+    # idempotence: from the answer, the solver stays at the answer
+    v.align(T, want_output=False)
+    T2 = v.getFinalTransformation()
+    assert np.abs(T2[:3, 3] - T[:3, 3]).max() < 1e-4 and _rot_angle(T2[:3, :3], T[:3, :3]) < 1e-4
+    # fitness = mean squared nearest-neighbour distance: brute force on a sample of the scan against the map points near it
+    rng = np.random.default_rng(5)
+    sel = rng.choice(len(src), 64, replace=False)
+    p = (T[:3, :3].astype(np.float32) @ src[sel].T.astype(np.float32)).T + T[:3, 3].astype(np.float32)
+    near = tgt[(np.abs(tgt[:, 0] - T[0, 3]) < 130) & (np.abs(tgt[:, 1] - T[1, 3]) < 130)]
+    d2 = np.array([np.min(np.sum((near - q) ** 2, axis=1)) for q in p])
+    v2 = registration.odometer_vgicp(0)
+    v2.setInputTarget(tgt)
+    v2.setInputSource(np.ascontiguousarray(src[sel]))
+    assert abs(v2.fitnessAt(T) - float(d2.mean())) <= 1e-4 * float(d2.mean()) + 1e-9
+    v2.close()
+    if oracle_pose_check:
+        o = oracle.Registration(num_threads=0)
+        o.set_target(tgt)
+        o.set_source(src)
+        To = o.align(guess)
+        assert np.abs(T[:3, 3] - To[:3, 3]).max() <= 1e-4 and _rot_angle(T[:3, :3], To[:3, :3]) <= 1e-4
+        assert abs(fit - o.fitness()) <= 1e-5 * abs(o.fitness())
+    v.close()
+    return T
+
+
+def test_c_main_30k_vs_1M(synth):
+    world, tgt = synth.make_world_and_map(1_000_000, seed=synth.SEED)
+    T_true = synth.se3(synth.rot_zyx(0.015, 0.002, -0.001), [0.12, 0.01, 0.003])
+    src = synth.make_scan_n(world, T_true, 30000, seed=synth.SEED + 1)["xyz"]
+    _check_case(synth, world, tgt, src, T_true, np.eye(4, dtype=np.float32))
+
+
+def test_c3_hdl64_130k_vs_5M(synth, map5m):
+    world, tgt = map5m
+    T_true = synth.se3(synth.rot_zyx(-0.02, 0.001, 0.002), [0.18, -0.02, 0.004])
+    src = synth.make_scan_n(world, T_true, 130000, elev_deg=synth.hdl64_elev(), seed=synth.SEED + 2)["xyz"]
+    _check_case(synth, world, tgt, src, T_true, np.eye(4, dtype=np.float32))
+
+
+def test_c5_250k_vs_20M_with_prior(synth, map5m):
+    world, tile = map5m
+    # 20 M-point map: the 5 M world plus three translated copies (the scan only sees the original tile)
+    L = 2.0 * world.half_extent + 4.0
+    tgt = np.concatenate([tile, tile + np.float32([L, 0, 0]), tile + np.float32([0, L, 0]), tile + np.float32([L, L, 0])]).astype(np.float32)
+    assert len(tgt) == 20_000_000
+    T_true = synth.se3(synth.rot_zyx(0.03, -0.002, 0.001), [0.25, 0.02, -0.002])
+    e = synth.hdl64_elev()
+    a = synth.make_scan_n(world, T_true, 125000, elev_deg=e, seed=synth.SEED + 3)["xyz"]
+    b = synth.make_scan_n(world, T_true, 125000, elev_deg=e + 0.5 * float(np.abs(np.diff(np.sort(e))).min()), seed=synth.SEED + 4)["xyz"]
+    src = np.concatenate([a, b]).astype(np.float32)
+    # IMU-preintegrated prior (RGC_odometer.cpp:929,993-996): the true motion corrupted by ~0.5 degrees of rotation
+    rng = np.random.default_rng(11)
+    ang = np.deg2rad(0.5) * rng.standard_normal(3)
+    guess = (T_true @ synth.se3(synth.rot_zyx(*ang), [0, 0, 0])).astype(np.float32)
+    # the CPU oracle on 20 M points needs a many-core host and a few GB; keep it where it finishes in seconds
+    _check_case(synth, world, tgt, src, T_true, guess, oracle_pose_check=(os.cpu_count() or 1) >= 64)
