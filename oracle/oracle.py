@@ -18,7 +18,7 @@ DIRECT27, DIRECT7, DIRECT1 = 0, 1, 2
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("rgc_oracle.c", "rgc_oracle_aux.c", "rgc_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rgc_oracle.c", "rgc_oracle_aux.c", "rgc_oracle_map.c", "rgc_oracle.h", "Makefile")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
@@ -42,6 +42,20 @@ class FeOut(C.Structure):
                 ("flat", C.POINTER(C.c_float)), ("inten", C.POINTER(C.c_float)), ("feat_cap", C.c_int), ("n_sharp", C.c_int),
                 ("n_sharp_own", C.c_int), ("n_flat", C.c_int), ("n_inten", C.c_int), ("ground_pts", C.POINTER(C.c_float)),
                 ("ground_cap", C.c_int), ("n_ground", C.c_int), ("groundparam", C.c_double * 11), ("ground_valid", C.c_int)]
+
+
+class EdgeFactor(C.Structure):
+    _fields_ = [("valid", C.c_int), ("pad", C.c_int), ("a", C.c_double * 3), ("b", C.c_double * 3), ("var", C.c_double)]
+
+
+class PlaneFactor(C.Structure):
+    _fields_ = [("valid", C.c_int), ("pad", C.c_int), ("n", C.c_double * 3), ("d", C.c_double), ("var", C.c_double)]
+
+
+class MapregTrace(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("radius", C.c_double), ("iterations", C.c_int),
+                ("successful", C.c_int), ("n_edge_cur", C.c_int), ("n_edge_last", C.c_int), ("n_plane_cur", C.c_int),
+                ("n_plane_last", C.c_int), ("pad", C.c_int)]
 
 
 class LmTrace(C.Structure):
@@ -101,6 +115,12 @@ def lib():
         L.orc_so3_exp.argtypes = [dp, dp]
         L.orc_is_converged.argtypes = [dp, C.c_double, C.c_double]
         L.orc_transform_f32.argtypes = [fp, C.c_int, C.c_int, fp, fp]
+        L.orc_knn_query.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, ip, fp, C.c_int]
+        ef, pf, tr = C.POINTER(EdgeFactor), C.POINTER(PlaneFactor), C.POINTER(MapregTrace)
+        L.orc_mapreg_associate_edges.argtypes = [fp, C.c_int, dp, dp, fp, C.c_int, C.c_int, ef, C.c_int]
+        L.orc_mapreg_associate_planes.argtypes = [fp, C.c_int, dp, dp, fp, C.c_int, C.c_int, pf, C.c_int]
+        L.orc_mapreg_solve.argtypes = [fp, ef, C.c_int, fp, pf, C.c_int, fp, ef, C.c_int, fp, pf, C.c_int, dp, C.c_int, tr]
+        L.orc_mapreg_optimize.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, dp, tr, C.c_int]
         _lib = L
     return _lib
 
@@ -254,6 +274,67 @@ def frontend(xyzi, n_scans=16, min_range=0.5, max_range=80.0, use_intensity=1):
     out.update(n_cloud=m, n_sharp_own=o.n_sharp_own, ring_count=np.array(o.ring_count[:n_scans]), scan_start=np.array(o.scan_start[:n_scans]),
                scan_end=np.array(o.scan_end[:n_scans]), groundparam=np.array(o.groundparam[:]), ground_valid=bool(o.ground_valid))
     return out
+
+
+def knn_query(xyz, queries, k, threads=0):
+    """exact kNN of arbitrary queries (pcl::KdTreeFLANN::nearestKSearch restated): (idx (nq,k), d2 (nq,k) float32)"""
+    a, ap = _f32(xyz)
+    b, bp = _f32(queries)
+    idx = np.empty((b.shape[0], k), np.int32)
+    d2 = np.empty((b.shape[0], k), np.float32)
+    rc = lib().orc_knn_query(ap, a.shape[0], a.shape[1], bp, b.shape[0], b.shape[1], k, idx.ctypes.data_as(C.POINTER(C.c_int)),
+                             d2.ctypes.data_as(C.POINTER(C.c_float)), threads)
+    if rc:
+        raise RuntimeError(f"orc_knn_query rc={rc}")
+    return idx, d2
+
+
+def _factors_to_np(arr, kind):
+    n = len(arr)
+    valid = np.array([f.valid for f in arr], dtype=bool)
+    if kind == "edge":
+        return dict(valid=valid, a=np.array([list(f.a) for f in arr]).reshape(n, 3), b=np.array([list(f.b) for f in arr]).reshape(n, 3),
+                    var=np.array([f.var for f in arr]))
+    return dict(valid=valid, n=np.array([list(f.n) for f in arr]).reshape(n, 3), d=np.array([f.d for f in arr]),
+                var=np.array([f.var for f in arr]))
+
+
+def mapreg_associate(feat_xyzw, q_xyzw, t, map_xyz, kind, threads=0, raw=False):
+    """RGC_mapping.cpp:1092-1138 (kind='edge') / :1191-1236 (kind='plane'): per-feature factor parameters."""
+    f, fp_ = _f32(feat_xyzw)
+    m, mp = _f32(map_xyz)
+    q, qp = _f64(q_xyzw)
+    tt, tp = _f64(t)
+    arr = ((EdgeFactor if kind == "edge" else PlaneFactor) * max(f.shape[0], 1))()
+    fn = lib().orc_mapreg_associate_edges if kind == "edge" else lib().orc_mapreg_associate_planes
+    cnt = fn(fp_, f.shape[0], qp, tp, mp, m.shape[0], m.shape[1], arr, threads)
+    if cnt < 0:
+        raise RuntimeError(f"orc_mapreg_associate rc={cnt}")
+    return arr if raw else _factors_to_np(arr[: f.shape[0]], kind)
+
+
+def mapreg_solve(corner_cur, e_cur, surf_cur, p_cur, corner_last, e_last, surf_last, p_last, poses14, max_iterations=6):
+    """ceres::Solve restated (RGC_mapping.cpp:1333-1341); e_*/p_* are the RAW ctypes factor arrays of mapreg_associate(raw=True)."""
+    cc, ccp = _f32(corner_cur); sc, scp = _f32(surf_cur); cl, clp = _f32(corner_last); sl, slp = _f32(surf_last)
+    x = np.ascontiguousarray(poses14, dtype=np.float64).copy()
+    tr = MapregTrace()
+    lib().orc_mapreg_solve(ccp, e_cur, cc.shape[0], scp, p_cur, sc.shape[0], clp, e_last, cl.shape[0], slp, p_last, sl.shape[0],
+                           x.ctypes.data_as(C.POINTER(C.c_double)), max_iterations, C.byref(tr))
+    return x, {k: getattr(tr, k) for k, _ in MapregTrace._fields_ if k != "pad"}
+
+
+def mapreg_optimize(corner_cur, surf_cur, corner_last, surf_last, corner_map, surf_map, poses14, threads=0):
+    """The optimisation block of one mapping frame (2 x associate + solve, then quaternion normalisation)."""
+    cc, ccp = _f32(corner_cur); sc, scp = _f32(surf_cur); cl, clp = _f32(corner_last); sl, slp = _f32(surf_last)
+    cm, cmp_ = _f32(corner_map); sm, smp = _f32(surf_map)
+    assert cm.shape[1] == sm.shape[1]
+    x = np.ascontiguousarray(poses14, dtype=np.float64).copy()
+    tr = (MapregTrace * 2)()
+    rc = lib().orc_mapreg_optimize(ccp, cc.shape[0], scp, sc.shape[0], clp, cl.shape[0], slp, sl.shape[0], cmp_, cm.shape[0], smp, sm.shape[0],
+                                   cm.shape[1], x.ctypes.data_as(C.POINTER(C.c_double)), tr, threads)
+    if rc < 0:
+        raise RuntimeError(f"orc_mapreg_optimize rc={rc}")
+    return x, rc, [{k: getattr(t, k) for k, _ in MapregTrace._fields_ if k != "pad"} for t in tr]
 
 
 class Registration:

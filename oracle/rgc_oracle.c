@@ -262,6 +262,21 @@ int orc_knn(const float* pts, int n, int stride, int k, int* idx_out, float* d2_
   return 0;
 }
 
+/* exact kNN of ARBITRARY query points against a cloud (pcl::KdTreeFLANN::nearestKSearch restated: fp32 L2_Simple over
+ * x,y,z, ascending (distance, index)).  queries: nq points at qstride floats.  Fewer than k points in the cloud: -1. */
+int orc_knn_query(const float* pts, int n, int stride, const float* queries, int nq, int qstride, int k, int* idx_out, float* d2_out,
+                  int num_threads) {
+  if (k > ORC_MAXK || k <= 0 || n < k) return -1;
+  grid_t g;
+  if (grid_build(&g, pts, n, stride, k) < 0) return -2;
+  int nt = clip_threads(num_threads);
+  (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 256)
+  for (int i = 0; i < nq; i++) grid_knn(&g, queries + (size_t)i * qstride, k, idx_out + (size_t)i * k, d2_out ? d2_out + (size_t)i * k : NULL);
+  grid_free(&g);
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * symmetric 3x3 eigen decomposition, cyclic Jacobi.  Stands in for Eigen::JacobiSVD of the
  * symmetric PSD covariance (fast_gicp_impl.hpp:273): for such a matrix U = V = eigenvectors

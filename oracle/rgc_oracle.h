@@ -125,6 +125,31 @@ typedef struct {
 void orc_fe_default_params(orc_fe_params* p);
 int orc_frontend(const float* xyzi, int n, int stride, const orc_fe_params* prm, orc_fe_out* out);
 
+/* ---- exact kNN of arbitrary query points (pcl::KdTreeFLANN::nearestKSearch restated) ---- */
+int orc_knn_query(const float* pts, int n, int stride, const float* queries, int nq, int qstride, int k, int* idx_out, float* d2_out,
+                  int num_threads);
+
+/* ---- f1: scan-to-map FEATURE registration of the mapping node (src/RGC_mapping.cpp:1069-1358, src/lidarFactor.hpp:9-51,91-121) ---- */
+typedef struct { int valid; int pad; double a[3], b[3], var; } orc_edge_factor;   /* LidarEdgeFactor(curr, point_a, point_b, var) */
+typedef struct { int valid; int pad; double n[3], d, var; } orc_plane_factor;     /* LidarPlaneNormFactor(curr, norm, negative_OA_dot_norm, var) */
+typedef struct {
+  double initial_cost, final_cost, radius;
+  int iterations, successful, n_edge_cur, n_edge_last, n_plane_cur, n_plane_last, pad;
+} orc_mapreg_trace;
+/* features: nf x 4 floats (x, y, z, normal_x = the per-feature weight of scanRegistration.cpp:501,554,609); q = x,y,z,w */
+int orc_mapreg_associate_edges(const float* feat, int nf, const double q_xyzw[4], const double t[3], const float* map_xyz, int nmap,
+                               int mstride, orc_edge_factor* out, int num_threads);
+int orc_mapreg_associate_planes(const float* feat, int nf, const double q_xyzw[4], const double t[3], const float* map_xyz, int nmap,
+                                int mstride, orc_plane_factor* out, int num_threads);
+/* poses: q_cur[4] t_cur[3] q_last[4] t_last[3], in/out */
+int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int n_ccur, const float* surf_cur, const orc_plane_factor* p_cur,
+                     int n_scur, const float* corner_last, const orc_edge_factor* e_last, int n_clast, const float* surf_last,
+                     const orc_plane_factor* p_last, int n_slast, double poses[14], int max_iterations, orc_mapreg_trace* trace);
+/* returns 1 if the gate of RGC_mapping.cpp:1069 is not met (poses untouched), 0 on success */
+int orc_mapreg_optimize(const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur, const float* corner_last, int n_clast,
+                        const float* surf_last, int n_slast, const float* corner_map, int n_cmap, const float* surf_map, int n_smap,
+                        int mstride, double poses[14], orc_mapreg_trace trace[2], int num_threads);
+
 /* ---- C7 helpers ---- */
 void orc_so3_exp(const double omega[3], double q_wxyz[4]);                 /* so3/so3.hpp:58-77 */
 int  orc_is_converged(const double delta[16], double rot_eps, double trans_eps); /* lsq_registration_impl.hpp:82-91 */

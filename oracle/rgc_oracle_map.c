@@ -1,0 +1,405 @@
+/*
+ * rgc_oracle_map.c -- CPU restatement of the mapping node's scan-to-map FEATURE registration:
+ * RGC_mapping.cpp:1069-1358 with lidarFactor.hpp:9-51 (LidarEdgeFactor) and :91-121 (LidarPlaneNormFactor).
+ *
+ * TEST INFRASTRUCTURE ONLY (see rgc_oracle.h).  PARITY UNPINNED: the reference has no tests for this path and cannot be
+ * built here; the arithmetic that lives in third-party code is restated from its published algorithm --
+ *   pcl::KdTreeFLANN::nearestKSearch  -> exact fp32 kNN (orc_knn_query);
+ *   Eigen::SelfAdjointEigenSolver<3x3> -> cyclic Jacobi (orc_eig3);
+ *   Eigen colPivHouseholderQr().solve  -> Householder QR with column pivoting, least-squares solve (below);
+ *   ceres::Solve (trust region, LEVENBERG_MARQUARDT, DENSE_QR, HuberLoss(0.1), EigenQuaternionParameterization, <= 6
+ *   iterations, Ceres 1.14 defaults) -> the LM loop of orc_mapreg_solve below (robustification by the Triggs corrector,
+ *   which for Huber reduces to scaling residual and Jacobian by sqrt(rho'); damping diag(J^T J)/radius; step acceptance
+ *   and radius update of LevenbergMarquardtStrategy).  Pinned by oracle/py_mapreg.py (numpy/scipy).
+ * USE_IMU = 0 and no ground factor (the two optional blocks of :1283-1331) -- stated in DESIGN.md.
+ */
+#include "rgc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* q (x,y,z,w) applied to p: Eigen's quaternion * vector */
+static void quat_rot(const double q[4], const double p[3], double out[3]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  /* t = 2 * cross(q.xyz, p); out = p + w t + cross(q.xyz, t) */
+  const double tx = 2 * (y * p[2] - z * p[1]), ty = 2 * (z * p[0] - x * p[2]), tz = 2 * (x * p[1] - y * p[0]);
+  out[0] = p[0] + w * tx + (y * tz - z * ty);
+  out[1] = p[1] + w * ty + (z * tx - x * tz);
+  out[2] = p[2] + w * tz + (x * ty - y * tx);
+}
+
+/* pointAssociateToMap (RGC_mapping.cpp:1811-1820): double math, stored back into a float point */
+static void associate_points(const float* feat, int nf, const double q[4], const double t[3], float* sel /* nf*3 */) {
+  for (int i = 0; i < nf; i++) {
+    const double p[3] = {(double)feat[4 * i], (double)feat[4 * i + 1], (double)feat[4 * i + 2]};
+    double w[3];
+    quat_rot(q, p, w);
+    for (int a = 0; a < 3; a++) sel[3 * i + a] = (float)(w[a] + t[a]);
+  }
+}
+
+/* least-squares solution of A x = b for a 5x3 A: Householder QR with column pivoting (Eigen::ColPivHouseholderQR) */
+static void lstsq_5x3_colpiv(const double Ain[5][3], const double bin[5], double x[3]) {
+  double A[5][3], b[5];
+  int perm[3] = {0, 1, 2};
+  memcpy(A, Ain, sizeof(A));
+  memcpy(b, bin, sizeof(b));
+  int rank = 3;
+  for (int k = 0; k < 3; k++) {
+    /* pivot: remaining column with the largest norm */
+    int piv = k;
+    double best = -1.0;
+    for (int j = k; j < 3; j++) {
+      double s = 0;
+      for (int i = k; i < 5; i++) s += A[i][j] * A[i][j];
+      if (s > best) { best = s; piv = j; }
+    }
+    if (best <= 0.0) { rank = k; break; }
+    if (piv != k) {
+      for (int i = 0; i < 5; i++) { double tmp = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = tmp; }
+      int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+    }
+    /* Householder vector for column k */
+    double norm = 0;
+    for (int i = k; i < 5; i++) norm += A[i][k] * A[i][k];
+    norm = sqrt(norm);
+    const double alpha = A[k][k] > 0 ? -norm : norm;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int i = k; i < 5; i++) v[i] = A[i][k];
+    v[k] -= alpha;
+    double vv = 0;
+    for (int i = k; i < 5; i++) vv += v[i] * v[i];
+    if (vv > 0) {
+      for (int j = k; j < 3; j++) {
+        double d = 0;
+        for (int i = k; i < 5; i++) d += v[i] * A[i][j];
+        d = 2 * d / vv;
+        for (int i = k; i < 5; i++) A[i][j] -= d * v[i];
+      }
+      double d = 0;
+      for (int i = k; i < 5; i++) d += v[i] * b[i];
+      d = 2 * d / vv;
+      for (int i = k; i < 5; i++) b[i] -= d * v[i];
+    }
+  }
+  double y[3] = {0, 0, 0};
+  for (int k = rank - 1; k >= 0; k--) {
+    double s = b[k];
+    for (int j = k + 1; j < rank; j++) s -= A[k][j] * y[j];
+    y[k] = s / A[k][k];
+  }
+  for (int k = 0; k < 3; k++) x[perm[k]] = y[k];
+}
+
+/* RGC_mapping.cpp:1092-1138 (and :1144-1188 with the last pose): edge association + line test */
+int orc_mapreg_associate_edges(const float* feat, int nf, const double q_xyzw[4], const double t[3], const float* map_xyz, int nmap,
+                               int mstride, orc_edge_factor* out, int num_threads) {
+  if (nf <= 0) return 0;
+  float* sel = (float*)malloc(sizeof(float) * 3 * (size_t)nf);
+  int* idx = (int*)malloc(sizeof(int) * 5 * (size_t)nf);
+  float* d2 = (float*)malloc(sizeof(float) * 5 * (size_t)nf);
+  associate_points(feat, nf, q_xyzw, t, sel);
+  int rc = orc_knn_query(map_xyz, nmap, mstride, sel, nf, 3, 5, idx, d2, num_threads);
+  int count = 0;
+  if (rc == 0) {
+    for (int i = 0; i < nf; i++) {
+      orc_edge_factor* f = &out[i];
+      memset(f, 0, sizeof(*f));
+      if (!(d2[5 * i + 4] < 1.0f)) continue; /* :1098 */
+      double P[5][3], center[3] = {0, 0, 0};
+      for (int j = 0; j < 5; j++)
+        for (int a = 0; a < 3; a++) { P[j][a] = (double)map_xyz[(size_t)idx[5 * i + j] * mstride + a]; center[a] += P[j][a]; }
+      for (int a = 0; a < 3; a++) center[a] /= 5.0;
+      double cov[9] = {0};
+      for (int j = 0; j < 5; j++) {
+        const double z[3] = {P[j][0] - center[0], P[j][1] - center[1], P[j][2] - center[2]};
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) cov[a * 3 + b] += z[a] * z[b];
+      }
+      double ev[3], U[9];
+      orc_eig3(cov, ev, U); /* descending: ev[0] = the reference's eigenvalues()[2] */
+      if (!(ev[0] > 3 * ev[1])) continue; /* :1122 */
+      for (int a = 0; a < 3; a++) {
+        const double dir = U[a * 3 + 0];
+        f->a[a] = 0.1 * dir + center[a];
+        f->b[a] = -0.1 * dir + center[a];
+      }
+      f->var = (double)feat[4 * i + 3]; /* edge_var = pointOri.normal_x (float) */
+      f->valid = 1;
+      count++;
+    }
+  }
+  free(sel); free(idx); free(d2);
+  return rc < 0 ? rc : count;
+}
+
+/* RGC_mapping.cpp:1191-1236 (and :1238-1282): plane association + fit */
+int orc_mapreg_associate_planes(const float* feat, int nf, const double q_xyzw[4], const double t[3], const float* map_xyz, int nmap,
+                                int mstride, orc_plane_factor* out, int num_threads) {
+  if (nf <= 0) return 0;
+  float* sel = (float*)malloc(sizeof(float) * 3 * (size_t)nf);
+  int* idx = (int*)malloc(sizeof(int) * 5 * (size_t)nf);
+  float* d2 = (float*)malloc(sizeof(float) * 5 * (size_t)nf);
+  associate_points(feat, nf, q_xyzw, t, sel);
+  int rc = orc_knn_query(map_xyz, nmap, mstride, sel, nf, 3, 5, idx, d2, num_threads);
+  int count = 0;
+  if (rc == 0) {
+    for (int i = 0; i < nf; i++) {
+      orc_plane_factor* f = &out[i];
+      memset(f, 0, sizeof(*f));
+      if (!(d2[5 * i + 4] < 2.0f)) continue; /* :1200 */
+      double A[5][3];
+      const double b[5] = {-1, -1, -1, -1, -1};
+      for (int j = 0; j < 5; j++)
+        for (int a = 0; a < 3; a++) A[j][a] = (double)map_xyz[(size_t)idx[5 * i + j] * mstride + a];
+      double n[3];
+      lstsq_5x3_colpiv(A, b, n);
+      const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      if (!(nn > 0)) continue;
+      const double d = 1.0 / nn; /* negative_OA_dot_norm */
+      for (int a = 0; a < 3; a++) n[a] /= nn;
+      int ok = 1;
+      for (int j = 0; j < 5; j++)
+        if (fabs(n[0] * A[j][0] + n[1] * A[j][1] + n[2] * A[j][2] + d) > 0.2) { ok = 0; break; } /* :1218-1226 */
+      if (!ok) continue;
+      for (int a = 0; a < 3; a++) f->n[a] = n[a];
+      f->d = d;
+      f->var = (double)feat[4 * i + 3];
+      f->valid = 1;
+      count++;
+    }
+  }
+  free(sel); free(idx); free(d2);
+  return rc < 0 ? rc : count;
+}
+
+/* ---- residuals and Jacobians on the 6-dim local parameterisation of one pose ---------------------------------------
+ * EigenQuaternionParameterization::Plus: q' = dq (x) q with dq = (sin|d|/|d| d, cos|d|): a rotation by 2|d| about d, applied
+ * on the left, so d(R p)/dd = -2 [R p]x at d = 0.  Ceres multiplies the ambient (4-dim) autodiff Jacobian by the plus
+ * Jacobian, which is the same derivative. */
+static void skew_times(const double v[3], double M[9]) { /* M = [v]x */
+  M[0] = 0; M[1] = -v[2]; M[2] = v[1];
+  M[3] = v[2]; M[4] = 0; M[5] = -v[0];
+  M[6] = -v[1]; M[7] = v[0]; M[8] = 0;
+}
+
+/* accumulate one robustified residual block (dim rows) with Jacobian J (dim x 6) into H (21 upper), g (6), cost */
+static void accumulate_block(const double* r, const double* J, int dim, double huber_a, double* H21, double* g6, double* cost) {
+  double s = 0;
+  for (int a = 0; a < dim; a++) s += r[a] * r[a];
+  /* HuberLoss(a): rho(s) = s (s <= a^2), 2 a sqrt(s) - a^2 otherwise; rho' = 1 or a / sqrt(s); rho'' <= 0 -> Corrector scales
+   * residual and Jacobian by sqrt(rho') */
+  const double b = huber_a * huber_a;
+  double rho, rho1;
+  if (s > b) { const double sq = sqrt(s); rho = 2 * huber_a * sq - b; rho1 = huber_a / sq; }
+  else { rho = s; rho1 = 1.0; }
+  *cost += 0.5 * rho;
+  if (!H21) return;
+  const double w = rho1; /* (sqrt(rho1))^2 */
+  int u = 0;
+  for (int a = 0; a < 6; a++)
+    for (int c = a; c < 6; c++) {
+      double v = 0;
+      for (int k = 0; k < dim; k++) v += J[k * 6 + a] * J[k * 6 + c];
+      H21[u++] += w * v;
+    }
+  for (int a = 0; a < 6; a++) {
+    double v = 0;
+    for (int k = 0; k < dim; k++) v += J[k * 6 + a] * r[k];
+    g6[a] += w * v;
+  }
+}
+
+/* cost (and, if H21 != NULL, the normal equations) of one pose over its edge and plane factors */
+static void pose_terms(const float* cfeat, const orc_edge_factor* ef, int ne, const float* sfeat, const orc_plane_factor* pf, int np,
+                       const double q[4], const double t[3], double huber_a, double* H21, double* g6, double* cost) {
+  for (int i = 0; i < ne; i++) {
+    if (!ef[i].valid) continue;
+    const double p[3] = {(double)cfeat[4 * i], (double)cfeat[4 * i + 1], (double)cfeat[4 * i + 2]};
+    double Rp[3], lp[3];
+    quat_rot(q, p, Rp);
+    for (int a = 0; a < 3; a++) lp[a] = Rp[a] + t[a];
+    const double* A = ef[i].a; const double* B = ef[i].b;
+    const double u[3] = {lp[0] - A[0], lp[1] - A[1], lp[2] - A[2]}, v[3] = {lp[0] - B[0], lp[1] - B[1], lp[2] - B[2]};
+    const double nu[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+    const double de[3] = {A[0] - B[0], A[1] - B[1], A[2] - B[2]};
+    const double den = sqrt(de[0] * de[0] + de[1] * de[1] + de[2] * de[2]);
+    const double sc = ef[i].var / den;
+    const double r[3] = {nu[0] * sc, nu[1] * sc, nu[2] * sc};
+    double J[18];
+    if (H21) {
+      /* d nu / d lp = -[de]x ; d lp / d delta = -2 [Rp]x ; d lp / d t = I */
+      double Sde[9], SRp[9];
+      skew_times(de, Sde);
+      skew_times(Rp, SRp);
+      for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 3; c++) {
+          double m = 0;
+          for (int k = 0; k < 3; k++) m += Sde[a * 3 + k] * SRp[k * 3 + c];
+          J[a * 6 + c] = sc * 2.0 * m;          /* (-[de]x)(-2 [Rp]x) */
+          J[a * 6 + 3 + c] = -sc * Sde[a * 3 + c];
+        }
+    }
+    accumulate_block(r, J, 3, huber_a, H21, g6, cost);
+  }
+  for (int i = 0; i < np; i++) {
+    if (!pf[i].valid) continue;
+    const double p[3] = {(double)sfeat[4 * i], (double)sfeat[4 * i + 1], (double)sfeat[4 * i + 2]};
+    double Rp[3];
+    quat_rot(q, p, Rp);
+    const double* n = pf[i].n;
+    const double r[1] = {(n[0] * (Rp[0] + t[0]) + n[1] * (Rp[1] + t[1]) + n[2] * (Rp[2] + t[2]) + pf[i].d) * pf[i].var};
+    double J[6];
+    if (H21) {
+      /* n^T (-2 [Rp]x) = -2 (Rp x n)^T ... written out: (n^T [Rp]x)_c = (n x Rp)_c with a sign: n^T [v]x = (n x v)^T?  [v]x w = v x w,
+       * n^T [v]x = -(v x n)^T ... = (n x v)^T */
+      const double nxRp[3] = {n[1] * Rp[2] - n[2] * Rp[1], n[2] * Rp[0] - n[0] * Rp[2], n[0] * Rp[1] - n[1] * Rp[0]};
+      for (int c = 0; c < 3; c++) { J[c] = -2.0 * nxRp[c] * pf[i].var; J[3 + c] = n[c] * pf[i].var; }
+    }
+    accumulate_block(r, J, 1, huber_a, H21, g6, cost);
+  }
+}
+
+/* 6x6 symmetric positive definite solve (Cholesky) */
+static int chol_solve6(const double Ain[36], const double rhs[6], double x[6]) {
+  double L[36] = {0};
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = Ain[i * 6 + j];
+      for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+      if (i == j) { if (!(s > 0)) return -1; L[i * 6 + i] = sqrt(s); }
+      else L[i * 6 + j] = s / L[j * 6 + j];
+    }
+  double y[6];
+  for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
+  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+  return 0;
+}
+
+static void quat_plus(const double q[4], const double d[3], double out[4]) { /* EigenQuaternionParameterization::Plus */
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  double dq[4];
+  if (nd > 0.0) { const double s = sin(nd) / nd; dq[0] = s * d[0]; dq[1] = s * d[1]; dq[2] = s * d[2]; dq[3] = cos(nd); }
+  else { dq[0] = d[0]; dq[1] = d[1]; dq[2] = d[2]; dq[3] = 1.0; }
+  /* out = dq (x) q  (x,y,z,w) */
+  const double ax = dq[0], ay = dq[1], az = dq[2], aw = dq[3], bx = q[0], by = q[1], bz = q[2], bw = q[3];
+  out[0] = aw * bx + ax * bw + ay * bz - az * by;
+  out[1] = aw * by - ax * bz + ay * bw + az * bx;
+  out[2] = aw * bz + ax * by - ay * bx + az * bw;
+  out[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+
+/* ceres::Solve restated (see the header of this file).  poses: q_cur[4] t_cur[3] q_last[4] t_last[3] in/out. */
+int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int n_ccur, const float* surf_cur, const orc_plane_factor* p_cur,
+                     int n_scur, const float* corner_last, const orc_edge_factor* e_last, int n_clast, const float* surf_last,
+                     const orc_plane_factor* p_last, int n_slast, double poses[14], int max_iterations, orc_mapreg_trace* trace) {
+  const double huber_a = 0.1;
+  double radius = 1e4, decrease_factor = 2.0; /* initial_trust_region_radius, LevenbergMarquardtStrategy */
+  double* qc = poses; double* tc = poses + 4; double* ql = poses + 7; double* tl = poses + 11;
+  double H[2][21], g[2][6], cost = 0;
+  int it = 0, n_success = 0;
+  memset(H, 0, sizeof(H)); memset(g, 0, sizeof(g));
+  pose_terms(corner_cur, e_cur, n_ccur, surf_cur, p_cur, n_scur, qc, tc, huber_a, H[0], g[0], &cost);
+  pose_terms(corner_last, e_last, n_clast, surf_last, p_last, n_slast, ql, tl, huber_a, H[1], g[1], &cost);
+  if (trace) { trace->initial_cost = cost; trace->iterations = 0; trace->successful = 0; }
+  for (it = 0; it < max_iterations; it++) {
+    /* gradient tolerance (max-norm) */
+    double gmax = 0;
+    for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) if (fabs(g[b][a]) > gmax) gmax = fabs(g[b][a]);
+    if (gmax <= 1e-10) break;
+    /* LM step: (H + diag(clamp(diag H)) / radius) d = -g, block diagonal over the two poses */
+    double d[2][6], model = 0;
+    int ok = 1;
+    for (int b = 0; b < 2; b++) {
+      double A[36];
+      int u = 0;
+      for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { A[a * 6 + c] = H[b][u]; A[c * 6 + a] = H[b][u]; u++; }
+      for (int a = 0; a < 6; a++) {
+        double dg = A[a * 7];
+        if (dg < 1e-6) dg = 1e-6;   /* min_lm_diagonal */
+        if (dg > 1e32) dg = 1e32;   /* max_lm_diagonal */
+        A[a * 7] += dg / radius;
+      }
+      double rhs[6];
+      for (int a = 0; a < 6; a++) rhs[a] = -g[b][a];
+      if (chol_solve6(A, rhs, d[b]) != 0) { ok = 0; break; }
+      /* model cost change = -d^T (g + 0.5 H d) */
+      u = 0;
+      double Hd[6] = {0, 0, 0, 0, 0, 0};
+      double Hf[36];
+      for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { Hf[a * 6 + c] = H[b][u]; Hf[c * 6 + a] = H[b][u]; u++; }
+      for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) Hd[a] += Hf[a * 6 + c] * d[b][c];
+      for (int a = 0; a < 6; a++) model -= d[b][a] * (g[b][a] + 0.5 * Hd[a]);
+    }
+    double rho = -1.0, new_cost = cost;
+    double nq[2][4], nt[2][3];
+    if (ok && model > 0) {
+      quat_plus(qc, d[0], nq[0]);
+      quat_plus(ql, d[1], nq[1]);
+      for (int a = 0; a < 3; a++) { nt[0][a] = tc[a] + d[0][3 + a]; nt[1][a] = tl[a] + d[1][3 + a]; }
+      new_cost = 0;
+      pose_terms(corner_cur, e_cur, n_ccur, surf_cur, p_cur, n_scur, nq[0], nt[0], huber_a, NULL, NULL, &new_cost);
+      pose_terms(corner_last, e_last, n_clast, surf_last, p_last, n_slast, nq[1], nt[1], huber_a, NULL, NULL, &new_cost);
+      rho = (cost - new_cost) / model;
+    }
+    if (rho > 1e-3) { /* min_relative_decrease: successful step */
+      const double old_cost = cost;
+      memcpy(qc, nq[0], sizeof(double) * 4); memcpy(ql, nq[1], sizeof(double) * 4);
+      memcpy(tc, nt[0], sizeof(double) * 3); memcpy(tl, nt[1], sizeof(double) * 3);
+      double f = 1.0 - pow(2.0 * rho - 1.0, 3);
+      if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+      radius = radius / f;
+      if (radius > 1e16) radius = 1e16; /* max_trust_region_radius */
+      decrease_factor = 2.0;
+      n_success++;
+      memset(H, 0, sizeof(H)); memset(g, 0, sizeof(g));
+      cost = 0;
+      pose_terms(corner_cur, e_cur, n_ccur, surf_cur, p_cur, n_scur, qc, tc, huber_a, H[0], g[0], &cost);
+      pose_terms(corner_last, e_last, n_clast, surf_last, p_last, n_slast, ql, tl, huber_a, H[1], g[1], &cost);
+      double step2 = 0, x2 = 0;
+      for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) step2 += d[b][a] * d[b][a];
+      for (int a = 0; a < 14; a++) x2 += poses[a] * poses[a];
+      if (fabs(old_cost - cost) <= 1e-6 * old_cost) { it++; break; }                 /* function_tolerance */
+      if (sqrt(step2) <= 1e-8 * (sqrt(x2) + 1e-8)) { it++; break; }                  /* parameter_tolerance */
+    } else {
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      if (radius < 1e-32) { it++; break; } /* min_trust_region_radius */
+    }
+  }
+  if (trace) { trace->final_cost = cost; trace->iterations = it; trace->successful = n_success; trace->radius = radius; }
+  return 0;
+}
+
+/* the whole optimisation block of one mapping frame: 2 x (associate, solve) -- RGC_mapping.cpp:1076-1358 -- then the
+ * normalisation of :1375-1376 */
+int orc_mapreg_optimize(const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur, const float* corner_last, int n_clast,
+                        const float* surf_last, int n_slast, const float* corner_map, int n_cmap, const float* surf_map, int n_smap,
+                        int mstride, double poses[14], orc_mapreg_trace trace[2], int num_threads) {
+  /* the gate of :1069 */
+  if (!(n_ccur > 10 && n_scur > 50 && n_cmap > 10 && n_smap > 50)) return 1;
+  orc_edge_factor* ec = (orc_edge_factor*)malloc(sizeof(orc_edge_factor) * (size_t)(n_ccur > 0 ? n_ccur : 1));
+  orc_edge_factor* el = (orc_edge_factor*)malloc(sizeof(orc_edge_factor) * (size_t)(n_clast > 0 ? n_clast : 1));
+  orc_plane_factor* pc = (orc_plane_factor*)malloc(sizeof(orc_plane_factor) * (size_t)(n_scur > 0 ? n_scur : 1));
+  orc_plane_factor* pl = (orc_plane_factor*)malloc(sizeof(orc_plane_factor) * (size_t)(n_slast > 0 ? n_slast : 1));
+  int rc = 0;
+  for (int iter = 0; iter < 2 && rc == 0; iter++) { /* :1076 */
+    int a = orc_mapreg_associate_edges(corner_cur, n_ccur, poses, poses + 4, corner_map, n_cmap, mstride, ec, num_threads);
+    int b = orc_mapreg_associate_edges(corner_last, n_clast, poses + 7, poses + 11, corner_map, n_cmap, mstride, el, num_threads);
+    int c = orc_mapreg_associate_planes(surf_cur, n_scur, poses, poses + 4, surf_map, n_smap, mstride, pc, num_threads);
+    int d = orc_mapreg_associate_planes(surf_last, n_slast, poses + 7, poses + 11, surf_map, n_smap, mstride, pl, num_threads);
+    if (a < 0 || b < 0 || c < 0 || d < 0) { rc = -1; break; }
+    if (trace) { trace[iter].n_edge_cur = a; trace[iter].n_edge_last = b; trace[iter].n_plane_cur = c; trace[iter].n_plane_last = d; }
+    orc_mapreg_solve(corner_cur, ec, n_ccur, surf_cur, pc, n_scur, corner_last, el, n_clast, surf_last, pl, n_slast, poses, 6,
+                     trace ? &trace[iter] : NULL);
+  }
+  /* q_w_last.normalize(); q_w_curr.normalize(); (:1375-1376) */
+  for (int b = 0; b < 2; b++) {
+    double* q = poses + (b ? 7 : 0);
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n > 0) for (int a = 0; a < 4; a++) q[a] /= n;
+  }
+  free(ec); free(el); free(pc); free(pl);
+  return rc;
+}

@@ -1,0 +1,48 @@
+"""Synthetic input of the mapping node's feature registration (f1): corner / surf feature maps in the world frame built
+from the front-end's sharp / flat features of a few synthetic VLP-16 scans, plus the features of the two newest frames."""
+import numpy as np
+
+
+def rot_to_quat_xyzw(R):
+    w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+    x = (R[2, 1] - R[1, 2]) / (4 * w)
+    y = (R[0, 2] - R[2, 0]) / (4 * w)
+    z = (R[1, 0] - R[0, 1]) / (4 * w)
+    return np.array([x, y, z, w])
+
+
+def make_case(synth, frontend, n_map_frames=8, seed=None, n_az=1800):
+    """frontend(xyzi) -> dict with 'sharp' and 'flat' (n,5: x,y,z,intensity,normal_x).  Returns dict(corner_map, surf_map (n,4
+    float32: x,y,z,pad), corner_cur, surf_cur, corner_last, surf_last (n,4: x,y,z,weight), T_cur, T_last (true poses))."""
+    seed = synth.SEED if seed is None else seed
+    world = synth.make_world(seed=seed)
+    poses = synth.make_trajectory(n_map_frames + 2, seed=seed)
+    feats = []
+    for i, T in enumerate(poses):
+        sc = synth.make_scan(world, T, n_az=n_az, seed=seed + 10 + i)
+        xyzi = np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32)
+        fe = frontend(xyzi)
+        feats.append((fe["sharp"][:, [0, 1, 2, 4]].astype(np.float32), fe["flat"][:, [0, 1, 2, 4]].astype(np.float32)))
+    def to_world(f, T):
+        o = np.zeros((len(f), 4), np.float32)
+        o[:, :3] = (f[:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+        return o
+    corner_map = np.concatenate([to_world(feats[i][0], poses[i]) for i in range(n_map_frames)])
+    surf_map = np.concatenate([to_world(feats[i][1], poses[i]) for i in range(n_map_frames)])
+    return dict(corner_map=corner_map, surf_map=surf_map, corner_cur=feats[-1][0], surf_cur=feats[-1][1], corner_last=feats[-2][0],
+                surf_last=feats[-2][1], T_cur=poses[-1], T_last=poses[-2])
+
+
+def poses14(T_cur, T_last):
+    return np.concatenate([rot_to_quat_xyzw(T_cur[:3, :3]), T_cur[:3, 3], rot_to_quat_xyzw(T_last[:3, :3]), T_last[:3, 3]])
+
+
+def perturb(T, rng, ang=0.01, trans=0.05):
+    a = rng.normal(0, ang, 3)
+    th = np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(3) + (np.sin(th) / th) * K + ((1 - np.cos(th)) / th ** 2) * K @ K if th > 0 else np.eye(3)
+    o = T.copy()
+    o[:3, :3] = R @ T[:3, :3]
+    o[:3, 3] = T[:3, 3] + rng.normal(0, trans, 3)
+    return o

@@ -1,0 +1,108 @@
+"""f1 (mapping-node feature registration) oracle: oracle/rgc_oracle_map.c against the independent numpy/scipy restatement
+oracle/py_mapreg.py (cKDTree, eigh, lstsq, finite-difference Jacobians, scipy BFGS).  CPU only."""
+import numpy as np
+import pytest
+
+import mapreg_data as md
+
+
+@pytest.fixture(scope="module")
+def case():
+    import rgc_slam_amd.synth as synth
+    from oracle import oracle
+    c = md.make_case(synth, oracle.frontend, n_map_frames=4, n_az=600)
+    rng = np.random.default_rng(3)
+    c["x0"] = md.poses14(md.perturb(c["T_cur"], rng), md.perturb(c["T_last"], rng))
+    c["xt"] = md.poses14(c["T_cur"], c["T_last"])
+    return c
+
+
+def test_knn_query_matches_bruteforce(case):
+    from oracle import oracle
+    rng = np.random.default_rng(0)
+    m = case["surf_map"][:4000, :3]
+    qs = m[rng.choice(len(m), 200)] + rng.normal(0, 0.3, (200, 3)).astype(np.float32)
+    idx, d2 = oracle.knn_query(m, qs, 5)
+    for i in range(len(qs)):
+        d = ((m - qs[i]) ** 2).astype(np.float32)
+        full = (d[:, 0] + d[:, 1]) + d[:, 2]
+        ref = np.lexsort((np.arange(len(m)), full))[:5]
+        assert np.array_equal(idx[i], ref) and np.array_equal(d2[i], full[ref])
+
+
+@pytest.mark.parametrize("kind", ["edge", "plane"])
+def test_association_matches_numpy(case, kind):
+    from oracle import oracle, py_mapreg as pm
+    feat, mp = (case["corner_cur"], case["corner_map"]) if kind == "edge" else (case["surf_cur"], case["surf_map"])
+    q, t = case["x0"][0:4], case["x0"][4:7]
+    a = oracle.mapreg_associate(feat, q, t, mp, kind)
+    b = pm.associate(feat, q, t, mp, kind)
+    assert a["valid"].sum() > 50
+    assert (a["valid"] != b["valid"]).sum() <= 2          # a 5th-neighbour distance or eigenvalue ratio sitting on its threshold
+    both = a["valid"] & b["valid"]
+    if kind == "edge":
+        d1 = np.abs(a["a"][both] - b["a"][both]).max(axis=1)
+        d2 = np.abs(a["a"][both] - b["b"][both]).max(axis=1)  # the eigenvector's sign is free: a and b may be swapped
+        assert np.minimum(d1, d2).max() < 1e-9
+        assert np.allclose(np.linalg.norm(a["a"][both] - a["b"][both], axis=1), 0.2, atol=1e-12)
+    else:
+        assert np.abs(a["n"][both] - b["n"][both]).max() < 1e-8 and np.abs(a["d"][both] - b["d"][both]).max() < 1e-7
+        assert np.allclose(np.linalg.norm(a["n"][both], axis=1), 1.0, atol=1e-12)
+    assert np.array_equal(a["var"][both], feat[both, 3].astype(np.float64))
+
+
+def _frozen(case):
+    from oracle import oracle
+    x0 = case["x0"]
+    raw = {}
+    for key, feat, mp, kind, q, t in (("ec", case["corner_cur"], case["corner_map"], "edge", x0[0:4], x0[4:7]),
+                                      ("pc", case["surf_cur"], case["surf_map"], "plane", x0[0:4], x0[4:7]),
+                                      ("el", case["corner_last"], case["corner_map"], "edge", x0[7:11], x0[11:14]),
+                                      ("pl", case["surf_last"], case["surf_map"], "plane", x0[7:11], x0[11:14])):
+        raw[key] = (oracle.mapreg_associate(feat, q, t, mp, kind, raw=True), len(feat), kind)
+    npf = {k: oracle._factors_to_np(v[0][: v[1]], v[2]) for k, v in raw.items()}
+    sets = [(case["corner_cur"], npf["ec"], case["surf_cur"], npf["pc"]), (case["corner_last"], npf["el"], case["surf_last"], npf["pl"])]
+    return raw, sets
+
+
+def test_lm_trajectory_matches_numpy(case):
+    """same LM loop, finite-difference Jacobians instead of the analytic ones: the iterates agree"""
+    from oracle import oracle, py_mapreg as pm
+    raw, sets = _frozen(case)
+    for iters in (1, 3):
+        xc, trc = oracle.mapreg_solve(case["corner_cur"], raw["ec"][0], case["surf_cur"], raw["pc"][0], case["corner_last"], raw["el"][0],
+                                      case["surf_last"], raw["pl"][0], case["x0"], iters)
+        xn, trn = pm.lm_solve(sets, case["x0"], iters)
+        assert abs(trc["initial_cost"] - trn["initial_cost"]) <= 1e-10 * trn["initial_cost"]
+        assert abs(trc["final_cost"] - trn["final_cost"]) <= 1e-8 * trn["final_cost"]
+        assert trc["successful"] == trn["successful"] and np.abs(xc - xn).max() < 1e-8
+        assert trc["final_cost"] < trc["initial_cost"]
+
+
+def test_converged_solution_is_a_minimum(case):
+    """run to convergence: the gradient of the robust cost vanishes and a generic minimiser (scipy BFGS) cannot improve on it"""
+    from oracle import oracle, py_mapreg as pm
+    raw, sets = _frozen(case)
+    xc, trc = oracle.mapreg_solve(case["corner_cur"], raw["ec"][0], case["surf_cur"], raw["pc"][0], case["corner_last"], raw["el"][0],
+                                  case["surf_last"], raw["pl"][0], case["x0"], 60)
+    cc = pm.total_cost(sets, xc)
+    assert abs(cc - trc["final_cost"]) <= 1e-9 * cc and cc < 0.6 * trc["initial_cost"]
+    g0, g1 = np.abs(pm.fd_gradient(sets, case["x0"])).max(), np.abs(pm.fd_gradient(sets, xc)).max()
+    assert g1 < 2e-3 * g0
+    xs, cs = pm.polish(sets, xc)
+    assert cs <= cc * (1 + 1e-12) and (cc - cs) <= 1e-5 * cc   # Ceres' function tolerance (1e-6 per step) stops a little short
+
+
+def test_optimize_recovers_motion(case):
+    from oracle import oracle
+    x, rc, tr = oracle.mapreg_optimize(case["corner_cur"], case["surf_cur"], case["corner_last"], case["surf_last"], case["corner_map"],
+                                       case["surf_map"], case["x0"])
+    assert rc == 0 and tr[0]["iterations"] <= 6 and tr[1]["iterations"] <= 6
+    assert tr[1]["final_cost"] < tr[0]["initial_cost"]
+    e0, e1 = np.abs(case["x0"] - case["xt"]).max(), np.abs(x - case["xt"]).max()
+    assert e1 < 0.5 * e0
+    assert abs(np.linalg.norm(x[0:4]) - 1) < 1e-12 and abs(np.linalg.norm(x[7:11]) - 1) < 1e-12
+    # the gate of RGC_mapping.cpp:1069: too few features -> nothing happens
+    x2, rc2, _ = oracle.mapreg_optimize(case["corner_cur"][:5], case["surf_cur"], case["corner_last"], case["surf_last"], case["corner_map"],
+                                        case["surf_map"], case["x0"])
+    assert rc2 == 1 and np.array_equal(x2, case["x0"])
