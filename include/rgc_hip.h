@@ -216,6 +216,30 @@ RGC_API int  rgc_download(rgc_ctx* ctx, void* h_dst, const void* d_src, size_t b
 RGC_API int  rgc_synchronize(rgc_ctx* ctx);
 RGC_API void* rgc_stream(rgc_ctx* ctx); /* the hipStream_t every kernel of this context is launched on */
 
+/* ---- f1: scan-to-map FEATURE registration of the mapping node, src/RGC_mapping.cpp:1069-1358 ----
+ * Replaces, per mapping frame: kdtreeCornerFromMap/kdtreeSurfFromMap->setInputCloud (:1073-1074), the four association
+ * loops (:1092-1282: pointAssociateToMap, 5-NN, PCA line test / QR plane fit) and ceres::Solve over para_q/para_t and
+ * para_q_last/para_t_last with LidarEdgeFactor / LidarPlaneNormFactor under HuberLoss(0.1) (:1078-1341,
+ * src/lidarFactor.hpp:9-51,91-121), twice (:1076).  USE_IMU = 0, no ground factor (the optional blocks :1283-1331).
+ * Features are n x 4 floats {x, y, z, weight} (PointXYZINormal's x,y,z,normal_x); quaternions are x,y,z,w. */
+typedef struct rgc_mapreg_report {
+  double initial_cost, final_cost;  /* ceres Summary: 1/2 sum rho(|r|^2) before / after the solve */
+  int iterations, successful;       /* LM iterations run (<= 6) and accepted steps */
+  int n_edge_cur, n_plane_cur, n_edge_last, n_plane_last; /* residual blocks: corner_num, surf_num, cornerLast_num, surfLast_num */
+} rgc_mapreg_report;
+/* laserCloudCornerFromMapDS / laserCloudSurfFromMapDS (host AoS, x,y,z first; at least 5 points each) */
+RGC_API int rgc_mapreg_set_maps(rgc_ctx* ctx, const float* corner_map, int n_corner, const float* surf_map, int n_surf, int stride_bytes);
+/* association only (kind 0 = edge against the corner map, 1 = plane against the surf map): factors8 (nullable) receives
+ * n x 8 doubles: edge {point_a[3], point_b[3], var, valid}, plane {norm[3], negative_OA_dot_norm, 0, 0, var, valid} */
+RGC_API int rgc_mapreg_associate(rgc_ctx* ctx, int kind, const float* feat_xyzw, int n, const double q_xyzw[4], const double t[3],
+                                 double* factors8, int* n_valid);
+/* poses: q_w_curr[4] t_w_curr[3] q_w_last[4] t_w_last[3], in/out.  *gate_failed = 1 (poses untouched) when the size gate of
+ * :1069 is not met.  report: one entry per pass of the two-pass loop (nullable). */
+RGC_API int rgc_mapreg_optimize(rgc_ctx* ctx, const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur,
+                                const float* corner_last, int n_clast, const float* surf_last, int n_slast, double poses[14],
+                                rgc_mapreg_report report[2], int* gate_failed);
+
+
 /* ---- in-library kernel timing with HIP events on the context's stream (bench.py roofline) ---- */
 enum {
   RGC_K_GRID = 0,      /* bbox + count + scan + scatter + rank/gather                         */

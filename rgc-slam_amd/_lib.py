@@ -52,6 +52,11 @@ class FeOut(C.Structure):
                 ("picked", C.POINTER(C.c_int)), ("ground_marked", C.POINTER(C.c_int))]
 
 
+class MapregReport(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int), ("successful", C.c_int),
+                ("n_edge_cur", C.c_int), ("n_plane_cur", C.c_int), ("n_edge_last", C.c_int), ("n_plane_last", C.c_int)]
+
+
 class RgcError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"rgc_hip status {status}: {msg}")
@@ -66,7 +71,7 @@ SYMBOLS = [
     "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
-    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
 _lib = None
@@ -130,6 +135,9 @@ def load():
     L.rgc_deskew.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, C.c_int]
     L.rgc_voxelgrid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, ip, C.c_int]
     L.rgc_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, vp, C.c_int]
+    L.rgc_mapreg_set_maps.argtypes = [vp, fp, C.c_int, fp, C.c_int, C.c_int]
+    L.rgc_mapreg_associate.argtypes = [vp, C.c_int, fp, C.c_int, dp, dp, dp, ip]
+    L.rgc_mapreg_optimize.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, dp, C.POINTER(MapregReport), ip]
     L.rgc_profile_enable.argtypes = [vp, C.c_int]
     L.rgc_profile_select.argtypes = [vp, C.c_uint]
     L.rgc_profile_reset.argtypes = [vp]

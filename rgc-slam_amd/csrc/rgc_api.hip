@@ -76,6 +76,9 @@ struct rgc_ctx {
   bool lm_persist = false;    // RGC_LM_IMPL=persistent: the whole solve in one launch with grid-wide hand-offs (A/B knob;
                               // measured 215 us against 160 us for the chained two-kernel slots on MI355X, so not the default)
   int lm_gen = 0;             // hand-off generation the device state is at (read back with the state)
+  // f1: mapping-node feature registration (corner / surf feature maps: grid only, 1.5 m cells)
+  Cloud mr_map[2];
+  DevBuf mr_feat[4], mr_fac[4], mr_partials, mr_small;
   bool deferred_known = false;  // stats.deferred_* are those of the current clouds (carried home by the last align)
   DevBuf fit_partials;        // fitness rows when it is chained behind the LM slots
   rgck::LmState* h_lm = nullptr;  // pinned mirror
@@ -475,6 +478,95 @@ bool is_converged(const double d[16], double rot_eps, double trans_eps) {
   return m < 1;
 }
 
+// ---- f1: grid of a feature map (bbox -> counting sort; no covariances) and the host side of the robust LM ----------------
+constexpr double kMapregCell = 1.5;  // > sqrt(2) m, the largest 5th-neighbour distance that still yields a factor (:1200)
+
+int prepare_map_grid(rgc_ctx* c, Cloud& cl) {
+  const int n = cl.n;
+  hipStream_t s = c->stream;
+  int rc;
+  if ((rc = ensure(c, c->mr_small, 64))) return rc;
+  int* dsm = (int*)c->mr_small.p;
+  int hsm[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(dsm, hsm, 7 * sizeof(int), hipMemcpyHostToDevice, s));
+  rgck::bbox(s, cl.in, cl.stride_f, n, kMapregCell, dsm, dsm + 6);
+  HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "feature map contains non-finite or absurd coordinates");
+  rgck::Grid g{};
+  double ncell = 1.0;
+  for (int a = 0; a < 3; a++) {
+    g.minc[a] = hsm[a];
+    g.dim[a] = hsm[3 + a] - hsm[a] + 1;
+    ncell *= (double)g.dim[a];
+  }
+  if (ncell > (double)c->prm.max_cells || ncell > 2.0e9) return fail(c, RGC_ERR_GRID_TOO_LARGE, "feature-map grid exceeds max_cells");
+  g.res = kMapregCell;
+  g.ncell = (int)ncell;
+  cl.grid = g;
+  const size_t nc1 = (size_t)g.ncell + 1;
+  if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
+  if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;
+  if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1 + 256))) return rc;
+  if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
+  if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (nc1 / 2048 + 2)))) return rc;
+  if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
+  if ((rc = ensure(c, cl.P, sizeof(float4) * n))) return rc;
+  HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, (sizeof(int) * nc1 + 255) & ~(size_t)255, s));
+  rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p);
+  rgck::scan_cells(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, nullptr, nullptr);
+  rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p);
+  rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p, (float4*)cl.P.p);
+  HIPCHK(c, hipGetLastError());
+  cl.ready = true;
+  return RGC_OK;
+}
+
+// Cholesky solve of a symmetric positive definite 6x6 (the damped normal equations of one pose)
+bool chol_solve6(const double Ain[36], const double rhs[6], double x[6]) {
+  double L[36] = {0};
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = Ain[i * 6 + j];
+      for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+      if (i == j) { if (!(s > 0)) return false; L[i * 6 + i] = std::sqrt(s); }
+      else L[i * 6 + j] = s / L[j * 6 + j];
+    }
+  double y[6];
+  for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
+  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+  return true;
+}
+
+void quat_plus(const double q[4], const double d[3], double out[4]) {  // EigenQuaternionParameterization::Plus [3P-memory]
+  const double nd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  double dq[4];
+  if (nd > 0.0) { const double s = std::sin(nd) / nd; dq[0] = s * d[0]; dq[1] = s * d[1]; dq[2] = s * d[2]; dq[3] = std::cos(nd); }
+  else { dq[0] = d[0]; dq[1] = d[1]; dq[2] = d[2]; dq[3] = 1.0; }
+  const double ax = dq[0], ay = dq[1], az = dq[2], aw = dq[3], bx = q[0], by = q[1], bz = q[2], bw = q[3];
+  out[0] = aw * bx + ax * bw + ay * bz - az * by;
+  out[1] = aw * by - ax * bz + ay * bw + az * bx;
+  out[2] = aw * bz + ax * by - ay * bx + az * bw;
+  out[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+
+// sums of both poses at x (14 doubles): out[b][0..27] = 21 H, 6 g, cost; feature sets 0/1 = corner/surf of the current pose,
+// 2/3 = of the last pose
+int mapreg_eval(rgc_ctx* c, const int nfeat[4], const double x[14], bool want_H, double out[2][28]) {
+  for (int b = 0; b < 2; b++) {
+    const double* q = x + 7 * b;
+    const rgck::Quat Q{q[0], q[1], q[2], q[3]};
+    rgck::mapreg_terms(c->stream, (const float*)c->mr_feat[2 * b].p, (const double*)c->mr_fac[2 * b].p, nfeat[2 * b],
+                       (const float*)c->mr_feat[2 * b + 1].p, (const double*)c->mr_fac[2 * b + 1].p, nfeat[2 * b + 1], Q, q + 4, 0.1,
+                       want_H ? 1 : 0, (double*)c->mr_partials.p, c->d_out + 28 * b);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double) * 56, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  memcpy(out, c->h_out, sizeof(double) * 56);
+  return RGC_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -555,6 +647,12 @@ void rgc_destroy(rgc_ctx* c) {
   release_cloud(c->src);
   release_cloud(c->tgt);
   release_cloud(c->aux);
+  release_cloud(c->mr_map[0]);
+  release_cloud(c->mr_map[1]);
+  for (DevBuf& b : c->mr_feat) release(b);
+  for (DevBuf& b : c->mr_fac) release(b);
+  release(c->mr_partials);
+  release(c->mr_small);
   for (DevBuf& b : c->fe) release(b);
   for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->corr_v2, &c->corr_M2, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_first, &c->vg_pos}) release(*b);
   if (c->d_small) (void)hipFree(c->d_small);
@@ -1214,6 +1312,171 @@ const char* rgc_profile_name(int kind) {
   static const char* names[kProfKinds] = {"grid_build", "knn_cov_target", "voxel_build", "linearize", "compute_error", "fitness",
                                           "knn_cov_source", "knn_coop_target", "knn_coop_source"};
   return (kind >= 0 && kind < kProfKinds) ? names[kind] : "?";
+}
+
+// ---- f1: scan-to-map FEATURE registration of the mapping node (RGC_mapping.cpp:1069-1358) --------------------------------
+int rgc_mapreg_set_maps(rgc_ctx* c, const float* corner_map, int n_corner, const float* surf_map, int n_surf, int stride_bytes) {
+  if (!c || !corner_map || !surf_map) return RGC_ERR_INVALID;
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  if (n_corner < 5 || n_surf < 5) return fail(c, RGC_ERR_TOO_FEW_POINTS, "feature maps need at least 5 points each (5-NN)");
+  if (n_corner > (1 << 27) || n_surf > (1 << 27)) return fail(c, RGC_ERR_INVALID, "feature map larger than 2^27 points");
+  HIPCHK(c, hipSetDevice(c->device));
+  const float* src[2] = {corner_map, surf_map};
+  const int n[2] = {n_corner, n_surf};
+  for (int m = 0; m < 2; m++) {
+    Cloud& cl = c->mr_map[m];
+    cl.ready = false;
+    const size_t bytes = (size_t)n[m] * stride_bytes;
+    int rc = ensure(c, cl.in_copy, bytes);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(cl.in_copy.p, src[m], bytes - (stride_bytes - 12), hipMemcpyHostToDevice, c->stream));
+    cl.in = (const float*)cl.in_copy.p;
+    cl.stride_f = stride_bytes / 4;
+    cl.n = n[m];
+    if ((rc = prepare_map_grid(c, cl))) return rc;
+  }
+  return RGC_OK;
+}
+
+static int mapreg_upload_features(rgc_ctx* c, int slot, const float* feat, int n) {
+  int rc;
+  if ((rc = ensure(c, c->mr_feat[slot], sizeof(float) * 4 * (size_t)(n > 0 ? n : 1)))) return rc;
+  if ((rc = ensure(c, c->mr_fac[slot], sizeof(double) * 8 * (size_t)(n > 0 ? n : 1)))) return rc;
+  if (n > 0) HIPCHK(c, hipMemcpyAsync(c->mr_feat[slot].p, feat, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  return RGC_OK;
+}
+
+int rgc_mapreg_associate(rgc_ctx* c, int kind, const float* feat_xyzw, int n, const double q_xyzw[4], const double t[3], double* factors8,
+                         int* n_valid) {
+  if (!c || !feat_xyzw || !q_xyzw || !t || n < 0 || (kind != 0 && kind != 1)) return RGC_ERR_INVALID;
+  if (!c->mr_map[kind].ready) return fail(c, RGC_ERR_NO_INPUT, "rgc_mapreg_set_maps first");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = mapreg_upload_features(c, kind, feat_xyzw, n);
+  if (rc) return rc;
+  const Cloud& m = c->mr_map[kind];
+  rgck::mapreg_associate(c->stream, kind == 0, (const float*)c->mr_feat[kind].p, n, rgck::Quat{q_xyzw[0], q_xyzw[1], q_xyzw[2], q_xyzw[3]}, t,
+                         (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[kind].p);
+  std::vector<double> tmp;
+  double* dst = factors8;
+  if (!dst) { tmp.resize((size_t)8 * (n > 0 ? n : 1)); dst = tmp.data(); }
+  if (n > 0) HIPCHK(c, hipMemcpyAsync(dst, c->mr_fac[kind].p, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  if (n_valid) {
+    int cnt = 0;
+    for (int i = 0; i < n; i++) cnt += dst[(size_t)8 * i + 7] != 0.0;
+    *n_valid = cnt;
+  }
+  return RGC_OK;
+}
+
+int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur, const float* corner_last,
+                        int n_clast, const float* surf_last, int n_slast, double poses[14], rgc_mapreg_report report[2], int* gate_failed) {
+  if (!c || !poses || n_ccur < 0 || n_scur < 0 || n_clast < 0 || n_slast < 0) return RGC_ERR_INVALID;
+  if ((n_ccur && !corner_cur) || (n_scur && !surf_cur) || (n_clast && !corner_last) || (n_slast && !surf_last)) return RGC_ERR_INVALID;
+  if (!c->mr_map[0].ready || !c->mr_map[1].ready) return fail(c, RGC_ERR_NO_INPUT, "rgc_mapreg_set_maps first");
+  if (report) memset(report, 0, sizeof(rgc_mapreg_report) * 2);
+  // the gate of :1069 (laserCloudCornerDSNum > 10 && laserCloudSurfDSNum > 50 && map sizes likewise)
+  const bool gate = n_ccur > 10 && n_scur > 50 && c->mr_map[0].n > 10 && c->mr_map[1].n > 50;
+  if (gate_failed) *gate_failed = gate ? 0 : 1;
+  if (!gate) return RGC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const float* feat[4] = {corner_cur, surf_cur, corner_last, surf_last};
+  const int nfeat[4] = {n_ccur, n_scur, n_clast, n_slast};
+  int rc;
+  for (int s = 0; s < 4; s++)
+    if ((rc = mapreg_upload_features(c, s, feat[s], nfeat[s]))) return rc;
+  const int nb = std::max(rgck::mapreg_blocks(n_ccur, n_scur), rgck::mapreg_blocks(n_clast, n_slast));
+  if ((rc = ensure(c, c->mr_partials, sizeof(double) * rgck::kAccum * (size_t)(nb > 0 ? nb : 1)))) return rc;
+  std::vector<double> fac_host;
+  for (int iter = 0; iter < 2; iter++) {  // :1076
+    // association at the current estimate of both poses (frozen during the solve)
+    for (int s = 0; s < 4; s++) {
+      const double* q = poses + 7 * (s / 2);
+      const Cloud& m = c->mr_map[s & 1];
+      rgck::mapreg_associate(c->stream, (s & 1) == 0, (const float*)c->mr_feat[s].p, nfeat[s], rgck::Quat{q[0], q[1], q[2], q[3]}, q + 4,
+                             (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[s].p);
+    }
+    if (report) {  // factor counts (the reference's corner_num / surf_num ...)
+      int* cnt[4] = {&report[iter].n_edge_cur, &report[iter].n_plane_cur, &report[iter].n_edge_last, &report[iter].n_plane_last};
+      for (int s = 0; s < 4; s++) {
+        fac_host.resize((size_t)8 * (nfeat[s] > 0 ? nfeat[s] : 1));
+        if (nfeat[s] > 0) HIPCHK(c, hipMemcpyAsync(fac_host.data(), c->mr_fac[s].p, sizeof(double) * 8 * (size_t)nfeat[s], hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        int k = 0;
+        for (int i = 0; i < nfeat[s]; i++) k += fac_host[(size_t)8 * i + 7] != 0.0;
+        *cnt[s] = k;
+      }
+    }
+    // ceres::Solve restated: trust-region LM, <= 6 iterations (:1333-1341), Ceres 1.14 defaults: initial radius 1e4, damping diag(H)/radius clamped to [1e-6, 1e32], step accepted above a relative decrease of 1e-3
+    double radius = 1e4, decrease_factor = 2.0;
+    double S[2][28];
+    if ((rc = mapreg_eval(c, nfeat, poses, true, S))) return rc;
+    double cost = S[0][27] + S[1][27];
+    int it = 0, n_success = 0;
+    const double initial_cost = cost;
+    for (it = 0; it < 6; it++) {
+      double gmax = 0;
+      for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) gmax = std::fmax(gmax, std::fabs(S[b][21 + a]));
+      if (gmax <= 1e-10) break;
+      double d[2][6], model = 0;
+      bool ok = true;
+      for (int b = 0; b < 2 && ok; b++) {
+        double Hf[36], A[36];
+        int u = 0;
+        for (int a = 0; a < 6; a++) for (int e = a; e < 6; e++) { Hf[a * 6 + e] = S[b][u]; Hf[e * 6 + a] = S[b][u]; u++; }
+        memcpy(A, Hf, sizeof(A));
+        for (int a = 0; a < 6; a++) {
+          double dg = A[a * 7];
+          if (dg < 1e-6) dg = 1e-6;
+          if (dg > 1e32) dg = 1e32;
+          A[a * 7] += dg / radius;
+        }
+        double rhs[6];
+        for (int a = 0; a < 6; a++) rhs[a] = -S[b][21 + a];
+        if (!chol_solve6(A, rhs, d[b])) { ok = false; break; }
+        double Hd[6] = {0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < 6; a++) for (int e = 0; e < 6; e++) Hd[a] += Hf[a * 6 + e] * d[b][e];
+        for (int a = 0; a < 6; a++) model -= d[b][a] * (S[b][21 + a] + 0.5 * Hd[a]);
+      }
+      double rho = -1.0, xn[14];
+      memcpy(xn, poses, sizeof(xn));
+      if (ok && model > 0) {
+        for (int b = 0; b < 2; b++) {
+          quat_plus(poses + 7 * b, d[b], xn + 7 * b);
+          for (int a = 0; a < 3; a++) xn[7 * b + 4 + a] = poses[7 * b + 4 + a] + d[b][3 + a];
+        }
+        double Sn[2][28];
+        if ((rc = mapreg_eval(c, nfeat, xn, false, Sn))) return rc;
+        rho = (cost - (Sn[0][27] + Sn[1][27])) / model;
+      }
+      if (rho > 1e-3) {
+        const double old_cost = cost;
+        memcpy(poses, xn, sizeof(xn));
+        radius = std::fmin(radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e16);
+        decrease_factor = 2.0;
+        n_success++;
+        if ((rc = mapreg_eval(c, nfeat, poses, true, S))) return rc;
+        cost = S[0][27] + S[1][27];
+        double step2 = 0, x2 = 0;
+        for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) step2 += d[b][a] * d[b][a];
+        for (int a = 0; a < 14; a++) x2 += poses[a] * poses[a];
+        if (std::fabs(old_cost - cost) <= 1e-6 * old_cost) { it++; break; }
+        if (std::sqrt(step2) <= 1e-8 * (std::sqrt(x2) + 1e-8)) { it++; break; }
+      } else {
+        radius /= decrease_factor;
+        decrease_factor *= 2.0;
+        if (radius < 1e-32) { it++; break; }
+      }
+    }
+    if (report) { report[iter].initial_cost = initial_cost; report[iter].final_cost = cost; report[iter].iterations = it; report[iter].successful = n_success; }
+  }
+  for (int b = 0; b < 2; b++) {  // q_w_last.normalize(); q_w_curr.normalize(); (:1375-1376)
+    double* q = poses + 7 * b;
+    const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (nn > 0) for (int a = 0; a < 4; a++) q[a] /= nn;
+  }
+  return RGC_OK;
 }
 
 }  // extern "C"

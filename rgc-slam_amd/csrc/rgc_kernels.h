@@ -84,6 +84,14 @@ void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const floa
 void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
             const double* vox, int noff, int* corr_v, double* corr_M, double* partials, LmState* st, const LmInit& in, int gen_base,
             const int* nvox, const void* segs_t, const void* segs_s);
+// ---- f1: mapping-node feature registration (RGC_mapping.cpp:1069-1358) ----
+// factor record = 8 doubles per feature: edge {a[3], b[3], var, valid}, plane {n[3], d, 0, 0, var, valid}
+void mapreg_associate(hipStream_t s, bool edge, const float* feat /* n x 4: x,y,z,weight */, int n, Quat q, const double t[3], const float4* P,
+                      const int* start, Grid g, double* fac);
+int mapreg_blocks(int ne, int np);
+// out28 = 21 upper-triangular H, 6 g, robust cost (H, g only if want_H); partials: 28 * mapreg_blocks doubles
+void mapreg_terms(hipStream_t s, const float* cfeat, const double* efac, int ne, const float* sfeat, const double* pfac, int np, Quat q,
+                  const double t[3], double huber_a, int want_H, double* partials, double* out28);
 // ---- C8 ----
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials,
              double* out1);

@@ -2265,6 +2265,273 @@ k_error_dev(const float4* __restrict__ P, int n, const double* __restrict__ Tdev
 // ------------------------------------------------------------------------------------------------
 static inline int nblk(long long n, int t) { return (int)((n + t - 1) / t); }
 
+// ================================================================================================
+// f1  Scan-to-map FEATURE registration of the mapping node (src/RGC_mapping.cpp:1069-1358): association kernels and the
+// robustified normal equations of LidarEdgeFactor / LidarPlaneNormFactor (src/lidarFactor.hpp:9-51, 91-121).
+// Factor record = 8 doubles: edge {a[3], b[3], var, valid}, plane {n[3], d, 0, 0, var, valid}.
+// ================================================================================================
+__device__ __forceinline__ void quat_rot_d(const Quat& q, const double p[3], double out[3]) {  // Eigen: quaternion * vector
+  const double tx = 2 * (q.y * p[2] - q.z * p[1]), ty = 2 * (q.z * p[0] - q.x * p[2]), tz = 2 * (q.x * p[1] - q.y * p[0]);
+  out[0] = p[0] + q.w * tx + (q.y * tz - q.z * ty);
+  out[1] = p[1] + q.w * ty + (q.z * tx - q.x * tz);
+  out[2] = p[2] + q.w * tz + (q.x * ty - q.y * tx);
+}
+
+// all three eigenpairs of a symmetric 3x3 (same cyclic Jacobi as min_eigenvector); ord[] = indices by DESCENDING eigenvalue
+__device__ __forceinline__ void eig3_sym(const double S[6], double ev[3], double (&V)[3][3], int ord[3]) {
+  double A[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) V[a][b] = a == b ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-40 * diag || off == 0.0) break;
+    jacobi_rot<0, 1, 2>(A, V);
+    jacobi_rot<0, 2, 1>(A, V);
+    jacobi_rot<1, 2, 0>(A, V);
+  }
+  ev[0] = A[0][0]; ev[1] = A[1][1]; ev[2] = A[2][2];
+  ord[0] = 0; ord[1] = 1; ord[2] = 2;
+  for (int i = 0; i < 2; i++)
+    for (int j = i + 1; j < 3; j++)
+      if (ev[ord[j]] > ev[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+}
+
+// least-squares solution of the 5x3 system A x = b: Householder QR with column pivoting (Eigen::ColPivHouseholderQR)
+__device__ void lstsq_5x3_colpiv(double A[5][3], double b[5], double x[3]) {
+  int perm[3] = {0, 1, 2};
+  int rank = 3;
+  for (int k = 0; k < 3; k++) {
+    int piv = k;
+    double best = -1.0;
+    for (int j = k; j < 3; j++) {
+      double s = 0;
+      for (int i = k; i < 5; i++) s += A[i][j] * A[i][j];
+      if (s > best) { best = s; piv = j; }
+    }
+    if (best <= 0.0) { rank = k; break; }
+    if (piv != k) {
+      for (int i = 0; i < 5; i++) { const double t = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = t; }
+      const int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+    }
+    double norm = 0;
+    for (int i = k; i < 5; i++) norm += A[i][k] * A[i][k];
+    norm = sqrt(norm);
+    const double alpha = A[k][k] > 0 ? -norm : norm;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int i = k; i < 5; i++) v[i] = A[i][k];
+    v[k] -= alpha;
+    double vv = 0;
+    for (int i = k; i < 5; i++) vv += v[i] * v[i];
+    if (vv > 0) {
+      for (int j = k; j < 3; j++) {
+        double d = 0;
+        for (int i = k; i < 5; i++) d += v[i] * A[i][j];
+        d = 2 * d / vv;
+        for (int i = k; i < 5; i++) A[i][j] -= d * v[i];
+      }
+      double d = 0;
+      for (int i = k; i < 5; i++) d += v[i] * b[i];
+      d = 2 * d / vv;
+      for (int i = k; i < 5; i++) b[i] -= d * v[i];
+    }
+  }
+  double y[3] = {0, 0, 0};
+  for (int k = rank - 1; k >= 0; k--) {
+    double s = b[k];
+    for (int j = k + 1; j < rank; j++) s -= A[k][j] * y[j];
+    y[k] = s / A[k][k];
+  }
+  x[0] = x[1] = x[2] = 0.0;
+  for (int k = 0; k < 3; k++) x[perm[k]] = y[k];
+}
+
+// One lane per feature: pointAssociateToMap (:1811-1820, fp64 then stored as float), exact 5-NN in the map grid (the grid's
+// cell is 1.5 m, so the 3x3x3 block proves every 5th-neighbour distance below the thresholds 1 m / sqrt(2) m of :1098,:1200;
+// a farther 5th neighbour means "no factor" either way), then the line test (:1100-1138) or the plane fit (:1202-1236).
+template <bool kEdge>
+__global__ void k_mapreg_associate(const float* __restrict__ feat, int n, Quat q, double tx, double ty, double tz,
+                                   const float4* __restrict__ P, const int* __restrict__ start, Grid g, double* __restrict__ fac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double* f = fac + (size_t)i * 8;
+#pragma unroll
+  for (int a = 0; a < 8; a++) f[a] = 0.0;
+  const double p[3] = {(double)feat[4 * i], (double)feat[4 * i + 1], (double)feat[4 * i + 2]};
+  double w[3];
+  quat_rot_d(q, p, w);
+  const float sx = (float)(w[0] + tx), sy = (float)(w[1] + ty), sz = (float)(w[2] + tz);
+  const int c[3] = {voxel_coord1(sx, g.res) - g.minc[0], voxel_coord1(sy, g.res) - g.minc[1], voxel_coord1(sz, g.res) - g.minc[2]};
+  float bd[5];
+  int bs[5], bo[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) { bd[j] = INFINITY; bs[j] = -1; bo[j] = INT_MAX; }
+  const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, g.dim[0] - 1);
+  if (x0 <= x1) {
+    for (int z = max(c[2] - 1, 0); z <= min(c[2] + 1, g.dim[2] - 1); z++)
+      for (int y = max(c[1] - 1, 0); y <= min(c[1] + 1, g.dim[1] - 1); y++) {
+        const int s0 = start[cell_index(g, x0, y, z)], s1 = start[cell_index(g, x1, y, z) + 1];
+        for (int s = s0; s < s1; s++) {
+          const float4 cp = P[s];
+          float d = dist2(sx, sy, sz, cp);
+          int o = __float_as_int(cp.w), ss = s;
+          // insertion into the ascending (distance, original index) list
+#pragma unroll
+          for (int j = 0; j < 5; j++) {
+            const bool before = d < bd[j] || (d == bd[j] && o < bo[j]);
+            if (before) {
+              const float td = bd[j]; bd[j] = d; d = td;
+              const int ts = bs[j]; bs[j] = ss; ss = ts;
+              const int to = bo[j]; bo[j] = o; o = to;
+            }
+          }
+        }
+      }
+  }
+  const float limit = kEdge ? 1.0f : 2.0f;
+  if (!(bd[4] < limit)) return;  // :1098 / :1200 (also: fewer than five points in reach)
+  double Q[5][3];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const float4 cp = P[bs[j]];
+    Q[j][0] = (double)cp.x; Q[j][1] = (double)cp.y; Q[j][2] = (double)cp.z;
+  }
+  if (kEdge) {
+    double ctr[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; j++) { ctr[0] += Q[j][0]; ctr[1] += Q[j][1]; ctr[2] += Q[j][2]; }
+    ctr[0] /= 5.0; ctr[1] /= 5.0; ctr[2] /= 5.0;
+    double S[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const double zx = Q[j][0] - ctr[0], zy = Q[j][1] - ctr[1], zz = Q[j][2] - ctr[2];
+      S[0] += zx * zx; S[1] += zx * zy; S[2] += zx * zz; S[3] += zy * zy; S[4] += zy * zz; S[5] += zz * zz;
+    }
+    double ev[3], V[3][3];
+    int ord[3];
+    eig3_sym(S, ev, V, ord);
+    if (!(ev[ord[0]] > 3 * ev[ord[1]])) return;  // :1122 (Eigen sorts ascending: eigenvalues()[2] > 3 eigenvalues()[1])
+    const int m = ord[0];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const double dir = m == 0 ? V[a][0] : (m == 1 ? V[a][1] : V[a][2]);
+      f[a] = 0.1 * dir + ctr[a];       // point_a
+      f[3 + a] = -0.1 * dir + ctr[a];  // point_b
+    }
+  } else {
+    double A[5][3], b[5] = {-1, -1, -1, -1, -1};
+#pragma unroll
+    for (int j = 0; j < 5; j++) { A[j][0] = Q[j][0]; A[j][1] = Q[j][1]; A[j][2] = Q[j][2]; }
+    double nrm[3];
+    lstsq_5x3_colpiv(A, b, nrm);
+    const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    if (!(nn > 0)) return;
+    const double d = 1.0 / nn;  // negative_OA_dot_norm
+    nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn;
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+      if (fabs(nrm[0] * Q[j][0] + nrm[1] * Q[j][1] + nrm[2] * Q[j][2] + d) > 0.2) return;  // :1218-1226
+    f[0] = nrm[0]; f[1] = nrm[1]; f[2] = nrm[2]; f[3] = d;
+  }
+  f[6] = (double)feat[4 * i + 3];  // var = pointOri.normal_x
+  f[7] = 1.0;
+}
+
+// Robustified normal equations of ONE pose over its edge and plane factors (or the cost only): 21 + 6 + 1 sums per lane
+// -> the same block reduction and fixed-order fold as the registration's linearisation.  Local parameterisation =
+// EigenQuaternionParameterization (q' = dq (x) q, dq = (sin|d|/|d| d, cos|d|)): d(R p)/dd = -2 [R p]x.  HuberLoss(a) has
+// rho'' <= 0, so Ceres' corrector scales residual and Jacobian by sqrt(rho'): the sums carry the weight rho'.
+__global__ void __launch_bounds__(LIN_T)
+k_mapreg_terms(const float* __restrict__ cfeat, const double* __restrict__ efac, int ne, const float* __restrict__ sfeat,
+               const double* __restrict__ pfac, int np, Quat q, double tx, double ty, double tz, double huber_a, int want_H,
+               double* __restrict__ partials) {
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[kAccum];
+#pragma unroll
+  for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
+  const bool is_edge = i < ne;
+  const int j = is_edge ? i : i - ne;
+  if (i < ne + np) {
+    const double* f = (is_edge ? efac : pfac) + (size_t)j * 8;
+    if (f[7] != 0.0) {
+      const float* fp = (is_edge ? cfeat : sfeat) + 4 * (size_t)j;
+      const double p[3] = {(double)fp[0], (double)fp[1], (double)fp[2]};
+      double Rp[3];
+      quat_rot_d(q, p, Rp);
+      const double lp[3] = {Rp[0] + tx, Rp[1] + ty, Rp[2] + tz};
+      double r[3] = {0, 0, 0}, J[3][6];
+      int dim;
+      if (is_edge) {
+        dim = 3;
+        const double u[3] = {lp[0] - f[0], lp[1] - f[1], lp[2] - f[2]}, v[3] = {lp[0] - f[3], lp[1] - f[4], lp[2] - f[5]};
+        const double nu[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+        const double de[3] = {f[0] - f[3], f[1] - f[4], f[2] - f[5]};
+        const double sc = f[6] / sqrt(de[0] * de[0] + de[1] * de[1] + de[2] * de[2]);
+        r[0] = nu[0] * sc; r[1] = nu[1] * sc; r[2] = nu[2] * sc;
+        // d nu / d lp = -[de]x ; columns 0..2: (-[de]x)(-2 [Rp]x) = 2 [de]x [Rp]x ; columns 3..5: -[de]x
+        const double Sd[3][3] = {{0, -de[2], de[1]}, {de[2], 0, -de[0]}, {-de[1], de[0], 0}};
+        const double Sr[3][3] = {{0, -Rp[2], Rp[1]}, {Rp[2], 0, -Rp[0]}, {-Rp[1], Rp[0], 0}};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            J[a][c] = sc * 2.0 * (Sd[a][0] * Sr[0][c] + Sd[a][1] * Sr[1][c] + Sd[a][2] * Sr[2][c]);
+            J[a][3 + c] = -sc * Sd[a][c];
+          }
+      } else {
+        dim = 1;
+        r[0] = (f[0] * lp[0] + f[1] * lp[1] + f[2] * lp[2] + f[3]) * f[6];
+        const double nx_[3] = {f[1] * Rp[2] - f[2] * Rp[1], f[2] * Rp[0] - f[0] * Rp[2], f[0] * Rp[1] - f[1] * Rp[0]};  // n x Rp
+#pragma unroll
+        for (int c = 0; c < 3; c++) { J[0][c] = -2.0 * nx_[c] * f[6]; J[0][3 + c] = f[c] * f[6]; }
+#pragma unroll
+        for (int c = 0; c < 6; c++) { J[1][c] = 0.0; J[2][c] = 0.0; }
+      }
+      const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      const double b2 = huber_a * huber_a;
+      double rho, rho1;
+      if (s > b2) { const double sq = sqrt(s); rho = 2 * huber_a * sq - b2; rho1 = huber_a / sq; }
+      else { rho = s; rho1 = 1.0; }
+      acc[27] = 0.5 * rho;
+      if (want_H) {
+        int u = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int c = a; c < 6; c++) {
+            double v = J[0][a] * J[0][c];
+            if (dim == 3) v += J[1][a] * J[1][c] + J[2][a] * J[2][c];
+            acc[u++] = rho1 * v;
+          }
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          double v = J[0][a] * r[0];
+          if (dim == 3) v += J[1][a] * r[1] + J[2][a] * r[2];
+          acc[21 + a] = rho1 * v;
+        }
+      }
+    }
+  }
+  block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
+}
+
+void mapreg_associate(hipStream_t s, bool edge, const float* feat, int n, Quat q, const double t[3], const float4* P, const int* start, Grid g,
+                      double* fac) {
+  if (n <= 0) return;
+  if (edge) hipLaunchKernelGGL(k_mapreg_associate<true>, dim3(nblk(n, 128)), dim3(128), 0, s, feat, n, q, t[0], t[1], t[2], P, start, g, fac);
+  else hipLaunchKernelGGL(k_mapreg_associate<false>, dim3(nblk(n, 128)), dim3(128), 0, s, feat, n, q, t[0], t[1], t[2], P, start, g, fac);
+}
+int mapreg_blocks(int ne, int np) { return (ne + np + LIN_T - 1) / LIN_T; }
+void mapreg_terms(hipStream_t s, const float* cfeat, const double* efac, int ne, const float* sfeat, const double* pfac, int np, Quat q,
+                  const double t[3], double huber_a, int want_H, double* partials, double* out28) {
+  const int nb = mapreg_blocks(ne, np);
+  if (nb <= 0) { (void)hipMemsetAsync(out28, 0, sizeof(double) * kAccum, s); return; }
+  hipLaunchKernelGGL(k_mapreg_terms, dim3(nb), dim3(LIN_T), 0, s, cfeat, efac, ne, sfeat, pfac, np, q, t[0], t[1], t[2], huber_a, want_H, partials);
+  hipLaunchKernelGGL(k_fold<kAccum>, dim3(kAccum), dim3(WAVE), 0, s, partials, nb, out28, (const int*)nullptr, (int*)nullptr);
+}
+
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi) {
   hipLaunchKernelGGL(k_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags, hi);
 }
