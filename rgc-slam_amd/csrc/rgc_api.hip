@@ -479,9 +479,11 @@ bool is_converged(const double d[16], double rot_eps, double trans_eps) {
 }
 
 // ---- f1: grid of a feature map (bbox -> counting sort; no covariances) and the host side of the robust LM ----------------
-constexpr double kMapregCell = 1.5;  // > sqrt(2) m, the largest 5th-neighbour distance that still yields a factor (:1200)
+// grid cell of a feature map = the largest 5th-neighbour distance that still yields a factor (1 m for edges :1098, sqrt(2) m for
+// planes :1200): the 3x3x3 block of cells then proves every accepted neighbourhood, and holds as few candidates as possible
+constexpr double kMapregCell[2] = {1.0, 1.4143};
 
-int prepare_map_grid(rgc_ctx* c, Cloud& cl) {
+int prepare_map_grid(rgc_ctx* c, Cloud& cl, double cell) {
   const int n = cl.n;
   hipStream_t s = c->stream;
   int rc;
@@ -489,7 +491,7 @@ int prepare_map_grid(rgc_ctx* c, Cloud& cl) {
   int* dsm = (int*)c->mr_small.p;
   int hsm[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
   HIPCHK(c, hipMemcpyAsync(dsm, hsm, 7 * sizeof(int), hipMemcpyHostToDevice, s));
-  rgck::bbox(s, cl.in, cl.stride_f, n, kMapregCell, dsm, dsm + 6);
+  rgck::bbox(s, cl.in, cl.stride_f, n, cell, dsm, dsm + 6);
   HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "feature map contains non-finite or absurd coordinates");
@@ -501,7 +503,7 @@ int prepare_map_grid(rgc_ctx* c, Cloud& cl) {
     ncell *= (double)g.dim[a];
   }
   if (ncell > (double)c->prm.max_cells || ncell > 2.0e9) return fail(c, RGC_ERR_GRID_TOO_LARGE, "feature-map grid exceeds max_cells");
-  g.res = kMapregCell;
+  g.res = cell;
   g.ncell = (int)ncell;
   cl.grid = g;
   const size_t nc1 = (size_t)g.ncell + 1;
@@ -553,13 +555,10 @@ void quat_plus(const double q[4], const double d[3], double out[4]) {  // EigenQ
 // sums of both poses at x (14 doubles): out[b][0..27] = 21 H, 6 g, cost; feature sets 0/1 = corner/surf of the current pose,
 // 2/3 = of the last pose
 int mapreg_eval(rgc_ctx* c, const int nfeat[4], const double x[14], bool want_H, double out[2][28]) {
-  for (int b = 0; b < 2; b++) {
-    const double* q = x + 7 * b;
-    const rgck::Quat Q{q[0], q[1], q[2], q[3]};
-    rgck::mapreg_terms(c->stream, (const float*)c->mr_feat[2 * b].p, (const double*)c->mr_fac[2 * b].p, nfeat[2 * b],
-                       (const float*)c->mr_feat[2 * b + 1].p, (const double*)c->mr_fac[2 * b + 1].p, nfeat[2 * b + 1], Q, q + 4, 0.1,
-                       want_H ? 1 : 0, (double*)c->mr_partials.p, c->d_out + 28 * b);
-  }
+  const float* feat[4];
+  const double* fac[4];
+  for (int s = 0; s < 4; s++) { feat[s] = (const float*)c->mr_feat[s].p; fac[s] = (const double*)c->mr_fac[s].p; }
+  rgck::mapreg_terms(c->stream, feat, fac, nfeat, x, 0.1, want_H ? 1 : 0, (double*)c->mr_partials.p, c->d_out);
   HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double) * 56, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
@@ -1333,7 +1332,7 @@ int rgc_mapreg_set_maps(rgc_ctx* c, const float* corner_map, int n_corner, const
     cl.in = (const float*)cl.in_copy.p;
     cl.stride_f = stride_bytes / 4;
     cl.n = n[m];
-    if ((rc = prepare_map_grid(c, cl))) return rc;
+    if ((rc = prepare_map_grid(c, cl, kMapregCell[m]))) return rc;
   }
   return RGC_OK;
 }
@@ -1355,7 +1354,7 @@ int rgc_mapreg_associate(rgc_ctx* c, int kind, const float* feat_xyzw, int n, co
   if (rc) return rc;
   const Cloud& m = c->mr_map[kind];
   rgck::mapreg_associate(c->stream, kind == 0, (const float*)c->mr_feat[kind].p, n, rgck::Quat{q_xyzw[0], q_xyzw[1], q_xyzw[2], q_xyzw[3]}, t,
-                         (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[kind].p);
+                         (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[kind].p, nullptr);
   std::vector<double> tmp;
   double* dst = factors8;
   if (!dst) { tmp.resize((size_t)8 * (n > 0 ? n : 1)); dst = tmp.data(); }
@@ -1387,32 +1386,28 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
   for (int s = 0; s < 4; s++)
     if ((rc = mapreg_upload_features(c, s, feat[s], nfeat[s]))) return rc;
   const int nb = std::max(rgck::mapreg_blocks(n_ccur, n_scur), rgck::mapreg_blocks(n_clast, n_slast));
-  if ((rc = ensure(c, c->mr_partials, sizeof(double) * rgck::kAccum * (size_t)(nb > 0 ? nb : 1)))) return rc;
-  std::vector<double> fac_host;
+  if ((rc = ensure(c, c->mr_partials, sizeof(double) * 2 * rgck::kAccum * (size_t)(nb > 0 ? nb : 1)))) return rc;
   for (int iter = 0; iter < 2; iter++) {  // :1076
-    // association at the current estimate of both poses (frozen during the solve)
+    // association at the current estimate of both poses (frozen during the solve); the factor counts (the reference's
+    // corner_num / surf_num ...) ride home with the first evaluation's synchronisation
+    int* dcnt = (int*)c->mr_small.p + 8;
+    HIPCHK(c, hipMemsetAsync(dcnt, 0, 4 * sizeof(int), c->stream));
     for (int s = 0; s < 4; s++) {
       const double* q = poses + 7 * (s / 2);
       const Cloud& m = c->mr_map[s & 1];
       rgck::mapreg_associate(c->stream, (s & 1) == 0, (const float*)c->mr_feat[s].p, nfeat[s], rgck::Quat{q[0], q[1], q[2], q[3]}, q + 4,
-                             (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[s].p);
+                             (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[s].p, dcnt + s);
     }
-    if (report) {  // factor counts (the reference's corner_num / surf_num ...)
-      int* cnt[4] = {&report[iter].n_edge_cur, &report[iter].n_plane_cur, &report[iter].n_edge_last, &report[iter].n_plane_last};
-      for (int s = 0; s < 4; s++) {
-        fac_host.resize((size_t)8 * (nfeat[s] > 0 ? nfeat[s] : 1));
-        if (nfeat[s] > 0) HIPCHK(c, hipMemcpyAsync(fac_host.data(), c->mr_fac[s].p, sizeof(double) * 8 * (size_t)nfeat[s], hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        int k = 0;
-        for (int i = 0; i < nfeat[s]; i++) k += fac_host[(size_t)8 * i + 7] != 0.0;
-        *cnt[s] = k;
-      }
-    }
+    HIPCHK(c, hipMemcpyAsync(c->h_small + 40, dcnt, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // ceres::Solve restated: trust-region LM, <= 6 iterations (:1333-1341), Ceres 1.14 defaults: initial radius 1e4, damping diag(H)/radius clamped to [1e-6, 1e32], step accepted above a relative decrease of 1e-3
     double radius = 1e4, decrease_factor = 2.0;
     double S[2][28];
     if ((rc = mapreg_eval(c, nfeat, poses, true, S))) return rc;
     double cost = S[0][27] + S[1][27];
+    if (report) {
+      report[iter].n_edge_cur = c->h_small[40]; report[iter].n_plane_cur = c->h_small[41];
+      report[iter].n_edge_last = c->h_small[42]; report[iter].n_plane_last = c->h_small[43];
+    }
     int it = 0, n_success = 0;
     const double initial_cost = cost;
     for (it = 0; it < 6; it++) {
@@ -1439,15 +1434,16 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
         for (int a = 0; a < 6; a++) for (int e = 0; e < 6; e++) Hd[a] += Hf[a * 6 + e] * d[b][e];
         for (int a = 0; a < 6; a++) model -= d[b][a] * (S[b][21 + a] + 0.5 * Hd[a]);
       }
-      double rho = -1.0, xn[14];
+      double rho = -1.0, xn[14], Sn[2][28];
       memcpy(xn, poses, sizeof(xn));
       if (ok && model > 0) {
         for (int b = 0; b < 2; b++) {
           quat_plus(poses + 7 * b, d[b], xn + 7 * b);
           for (int a = 0; a < 3; a++) xn[7 * b + 4 + a] = poses[7 * b + 4 + a] + d[b][3 + a];
         }
-        double Sn[2][28];
-        if ((rc = mapreg_eval(c, nfeat, xn, false, Sn))) return rc;
+        // the candidate's cost AND its normal equations in one launch: nearly every step is accepted, and an accepted step
+        // needs them next (a rejected one just drops them)
+        if ((rc = mapreg_eval(c, nfeat, xn, true, Sn))) return rc;
         rho = (cost - (Sn[0][27] + Sn[1][27])) / model;
       }
       if (rho > 1e-3) {
@@ -1456,7 +1452,7 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
         radius = std::fmin(radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e16);
         decrease_factor = 2.0;
         n_success++;
-        if ((rc = mapreg_eval(c, nfeat, poses, true, S))) return rc;
+        memcpy(S, Sn, sizeof(S));
         cost = S[0][27] + S[1][27];
         double step2 = 0, x2 = 0;
         for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) step2 += d[b][a] * d[b][a];

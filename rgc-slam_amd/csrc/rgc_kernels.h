@@ -87,11 +87,12 @@ void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, 
 // ---- f1: mapping-node feature registration (RGC_mapping.cpp:1069-1358) ----
 // factor record = 8 doubles per feature: edge {a[3], b[3], var, valid}, plane {n[3], d, 0, 0, var, valid}
 void mapreg_associate(hipStream_t s, bool edge, const float* feat /* n x 4: x,y,z,weight */, int n, Quat q, const double t[3], const float4* P,
-                      const int* start, Grid g, double* fac);
+                      const int* start, Grid g, double* fac, int* nvalid /* nullable, += factors created */);
 int mapreg_blocks(int ne, int np);
-// out28 = 21 upper-triangular H, 6 g, robust cost (H, g only if want_H); partials: 28 * mapreg_blocks doubles
-void mapreg_terms(hipStream_t s, const float* cfeat, const double* efac, int ne, const float* sfeat, const double* pfac, int np, Quat q,
-                  const double t[3], double huber_a, int want_H, double* partials, double* out28);
+// both poses in one launch.  feat/fac/nfeat: {corner cur, surf cur, corner last, surf last}; x14 = q_cur t_cur q_last t_last;
+// out56 = per pose {21 upper-triangular H, 6 g, robust cost} (H, g only if want_H); partials: 2 * 28 * max mapreg_blocks doubles
+void mapreg_terms(hipStream_t s, const float* const feat[4], const double* const fac[4], const int nfeat[4], const double x14[14], double huber_a,
+                  int want_H, double* partials, double* out56);
 // ---- C8 ----
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials,
              double* out1);

@@ -2349,11 +2349,13 @@ __device__ void lstsq_5x3_colpiv(double A[5][3], double b[5], double x[3]) {
 }
 
 // One lane per feature: pointAssociateToMap (:1811-1820, fp64 then stored as float), exact 5-NN in the map grid (the grid's
-// cell is 1.5 m, so the 3x3x3 block proves every 5th-neighbour distance below the thresholds 1 m / sqrt(2) m of :1098,:1200;
-// a farther 5th neighbour means "no factor" either way), then the line test (:1100-1138) or the plane fit (:1202-1236).
+// cell is the threshold distance itself -- 1 m for edges :1098, sqrt(2) m for planes :1200 -- so the 3x3x3 block proves
+// every 5th-neighbour distance below the threshold; a farther 5th neighbour means "no factor" either way), then the line
+// test (:1100-1138) or the plane fit (:1202-1236).  *nvalid counts the factors created (corner_num, surf_num, ...).
 template <bool kEdge>
 __global__ void k_mapreg_associate(const float* __restrict__ feat, int n, Quat q, double tx, double ty, double tz,
-                                   const float4* __restrict__ P, const int* __restrict__ start, Grid g, double* __restrict__ fac) {
+                                   const float4* __restrict__ P, const int* __restrict__ start, Grid g, double* __restrict__ fac,
+                                   int* __restrict__ nvalid) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double* f = fac + (size_t)i * 8;
@@ -2437,16 +2439,26 @@ __global__ void k_mapreg_associate(const float* __restrict__ feat, int n, Quat q
   }
   f[6] = (double)feat[4 * i + 3];  // var = pointOri.normal_x
   f[7] = 1.0;
+  if (nvalid) atomicAdd(nvalid, 1);
 }
 
 // Robustified normal equations of ONE pose over its edge and plane factors (or the cost only): 21 + 6 + 1 sums per lane
 // -> the same block reduction and fixed-order fold as the registration's linearisation.  Local parameterisation =
 // EigenQuaternionParameterization (q' = dq (x) q, dq = (sin|d|/|d| d, cos|d|)): d(R p)/dd = -2 [R p]x.  HuberLoss(a) has
 // rho'' <= 0, so Ceres' corrector scales residual and Jacobian by sqrt(rho'): the sums carry the weight rho'.
+struct MapregPose {  // one pose's feature sets and estimate
+  const float* cfeat; const double* efac; int ne;
+  const float* sfeat; const double* pfac; int np;
+  Quat q; double t[3];
+};
 __global__ void __launch_bounds__(LIN_T)
-k_mapreg_terms(const float* __restrict__ cfeat, const double* __restrict__ efac, int ne, const float* __restrict__ sfeat,
-               const double* __restrict__ pfac, int np, Quat q, double tx, double ty, double tz, double huber_a, int want_H,
-               double* __restrict__ partials) {
+k_mapreg_terms(MapregPose pose0, MapregPose pose1, double huber_a, int want_H, double* __restrict__ partials) {
+  // blockIdx.y selects the pose (current / last): one launch and one fold for both
+  const MapregPose& ps = blockIdx.y ? pose1 : pose0;
+  const float* __restrict__ cfeat = ps.cfeat; const double* __restrict__ efac = ps.efac; const int ne = ps.ne;
+  const float* __restrict__ sfeat = ps.sfeat; const double* __restrict__ pfac = ps.pfac; const int np = ps.np;
+  const Quat q = ps.q;
+  const double tx = ps.t[0], ty = ps.t[1], tz = ps.t[2];
   const int i = blockIdx.x * LIN_T + threadIdx.x;
   double acc[kAccum];
 #pragma unroll
@@ -2514,22 +2526,37 @@ k_mapreg_terms(const float* __restrict__ cfeat, const double* __restrict__ efac,
       }
     }
   }
-  block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
+  block_reduce_store<kAccum>(acc, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kAccum);
+}
+
+// fold of the two poses' rows: blocks 0..27 -> pose 0, 28..55 -> pose 1
+__global__ void __launch_bounds__(WAVE) k_mapreg_fold(const double* __restrict__ partials, int nrows, double* __restrict__ out56) {
+  const int b = blockIdx.x / kAccum, a = blockIdx.x % kAccum, lane = threadIdx.x;
+  const double* base = partials + (size_t)b * nrows * kAccum;
+  double s = 0;
+  for (int r = lane; r < nrows; r += WAVE) s += base[(size_t)r * kAccum + a];
+  s = wave_sum(s);
+  if (lane == 0) out56[b * kAccum + a] = s;
 }
 
 void mapreg_associate(hipStream_t s, bool edge, const float* feat, int n, Quat q, const double t[3], const float4* P, const int* start, Grid g,
-                      double* fac) {
+                      double* fac, int* nvalid) {
   if (n <= 0) return;
-  if (edge) hipLaunchKernelGGL(k_mapreg_associate<true>, dim3(nblk(n, 128)), dim3(128), 0, s, feat, n, q, t[0], t[1], t[2], P, start, g, fac);
-  else hipLaunchKernelGGL(k_mapreg_associate<false>, dim3(nblk(n, 128)), dim3(128), 0, s, feat, n, q, t[0], t[1], t[2], P, start, g, fac);
+  if (edge) hipLaunchKernelGGL(k_mapreg_associate<true>, dim3(nblk(n, 64)), dim3(64), 0, s, feat, n, q, t[0], t[1], t[2], P, start, g, fac, nvalid);
+  else hipLaunchKernelGGL(k_mapreg_associate<false>, dim3(nblk(n, 64)), dim3(64), 0, s, feat, n, q, t[0], t[1], t[2], P, start, g, fac, nvalid);
 }
 int mapreg_blocks(int ne, int np) { return (ne + np + LIN_T - 1) / LIN_T; }
-void mapreg_terms(hipStream_t s, const float* cfeat, const double* efac, int ne, const float* sfeat, const double* pfac, int np, Quat q,
-                  const double t[3], double huber_a, int want_H, double* partials, double* out28) {
-  const int nb = mapreg_blocks(ne, np);
-  if (nb <= 0) { (void)hipMemsetAsync(out28, 0, sizeof(double) * kAccum, s); return; }
-  hipLaunchKernelGGL(k_mapreg_terms, dim3(nb), dim3(LIN_T), 0, s, cfeat, efac, ne, sfeat, pfac, np, q, t[0], t[1], t[2], huber_a, want_H, partials);
-  hipLaunchKernelGGL(k_fold<kAccum>, dim3(kAccum), dim3(WAVE), 0, s, partials, nb, out28, (const int*)nullptr, (int*)nullptr);
+void mapreg_terms(hipStream_t s, const float* const feat[4], const double* const fac[4], const int nfeat[4], const double x14[14], double huber_a,
+                  int want_H, double* partials, double* out56) {
+  MapregPose ps[2];
+  for (int b = 0; b < 2; b++) {
+    const double* q = x14 + 7 * b;
+    ps[b] = MapregPose{feat[2 * b], fac[2 * b], nfeat[2 * b], feat[2 * b + 1], fac[2 * b + 1], nfeat[2 * b + 1], Quat{q[0], q[1], q[2], q[3]},
+                       {q[4], q[5], q[6]}};
+  }
+  const int nb = max(max(mapreg_blocks(nfeat[0], nfeat[1]), mapreg_blocks(nfeat[2], nfeat[3])), 1);
+  hipLaunchKernelGGL(k_mapreg_terms, dim3(nb, 2), dim3(LIN_T), 0, s, ps[0], ps[1], huber_a, want_H, partials);
+  hipLaunchKernelGGL(k_mapreg_fold, dim3(2 * kAccum), dim3(WAVE), 0, s, partials, nb, out56);
 }
 
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi) {

@@ -11,9 +11,9 @@ def rot_to_quat_xyzw(R):
     return np.array([x, y, z, w])
 
 
-def make_case(synth, frontend, n_map_frames=8, seed=None, n_az=1800):
+def make_case(synth, frontend, n_map_frames=8, seed=None, n_az=1800, voxelgrid=None, corner_leaf=0.4, surf_leaf=0.8):
     """frontend(xyzi) -> dict with 'sharp' and 'flat' (n,5: x,y,z,intensity,normal_x).  Returns dict(corner_map, surf_map (n,4
-    float32: x,y,z,pad), corner_cur, surf_cur, corner_last, surf_last (n,4: x,y,z,weight), T_cur, T_last (true poses))."""
+    float32: x,y,z,pad; leaf-filtered when `voxelgrid(xyzi, leaf)` is given), corner_cur, surf_cur, corner_last, surf_last (n,4: x,y,z,weight), T_cur, T_last (true poses))."""
     seed = synth.SEED if seed is None else seed
     world = synth.make_world(seed=seed)
     poses = synth.make_trajectory(n_map_frames + 2, seed=seed)
@@ -29,6 +29,9 @@ def make_case(synth, frontend, n_map_frames=8, seed=None, n_az=1800):
         return o
     corner_map = np.concatenate([to_world(feats[i][0], poses[i]) for i in range(n_map_frames)])
     surf_map = np.concatenate([to_world(feats[i][1], poses[i]) for i in range(n_map_frames)])
+    if voxelgrid is not None:  # laserCloudCornerFromMapDS / laserCloudSurfFromMapDS are leaf-filtered in the reference
+        corner_map = np.ascontiguousarray(voxelgrid(corner_map, corner_leaf), dtype=np.float32)
+        surf_map = np.ascontiguousarray(voxelgrid(surf_map, surf_leaf), dtype=np.float32)
     return dict(corner_map=corner_map, surf_map=surf_map, corner_cur=feats[-1][0], surf_cur=feats[-1][1], corner_last=feats[-2][0],
                 surf_last=feats[-2][1], T_cur=poses[-1], T_last=poses[-2])
 

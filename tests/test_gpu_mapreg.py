@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def case():
     import rgc_slam_amd.synth as synth
     from oracle import oracle
-    c = md.make_case(synth, oracle.frontend, n_map_frames=8, n_az=1800)
+    c = md.make_case(synth, oracle.frontend, n_map_frames=12, n_az=1800, voxelgrid=oracle.voxelgrid_filter)
     rng = np.random.default_rng(3)
     c["x0"] = md.poses14(md.perturb(c["T_cur"], rng), md.perturb(c["T_last"], rng))
     c["xt"] = md.poses14(c["T_cur"], c["T_last"])
