@@ -220,13 +220,22 @@ RGC_API void* rgc_stream(rgc_ctx* ctx); /* the hipStream_t every kernel of this 
  * Replaces, per mapping frame: kdtreeCornerFromMap/kdtreeSurfFromMap->setInputCloud (:1073-1074), the four association
  * loops (:1092-1282: pointAssociateToMap, 5-NN, PCA line test / QR plane fit) and ceres::Solve over para_q/para_t and
  * para_q_last/para_t_last with LidarEdgeFactor / LidarPlaneNormFactor under HuberLoss(0.1) (:1078-1341,
- * src/lidarFactor.hpp:9-51,91-121), twice (:1076).  USE_IMU = 0, no ground factor (the optional blocks :1283-1331).
+ * src/lidarFactor.hpp:9-51,91-121), twice (:1076).  The ground block (:1314-1340, Ground_DeltaFactor_goable) is optional
+ * input; USE_IMU = 0 (the block :1283-1312 is not part of this entry point).
  * Features are n x 4 floats {x, y, z, weight} (PointXYZINormal's x,y,z,normal_x); quaternions are x,y,z,w. */
 typedef struct rgc_mapreg_report {
   double initial_cost, final_cost;  /* ceres Summary: 1/2 sum rho(|r|^2) before / after the solve */
   int iterations, successful;       /* LM iterations run (<= 6) and accepted steps */
   int n_edge_cur, n_plane_cur, n_edge_last, n_plane_last; /* residual blocks: corner_num, surf_num, cornerLast_num, surfLast_num */
 } rgc_mapreg_report;
+/* one Ground_DeltaFactor_goable (src/lidarFactor.hpp:352-403) as created at RGC_mapping.cpp:1326-1337, NULL loss */
+typedef struct rgc_mapreg_ground {
+  double last_v1[3], last_v2[3], last_norm[3], last_distance; /* g_last: vector_1, vector_2, vector_norm, distance */
+  double cur_norm[3], cur_distance;                          /* g_cur: vector_norm, distance */
+  double q_history[4];                                       /* histoary_q = q_w_curr_f (x,y,z,w) */
+  double last_q[4], last_t[3];                               /* last_q_q, last_t_t: the fixed previous pose */
+  double p_var;                                              /* ground_cov (0.2) */
+} rgc_mapreg_ground;
 /* laserCloudCornerFromMapDS / laserCloudSurfFromMapDS (host AoS, x,y,z first; at least 5 points each) */
 RGC_API int rgc_mapreg_set_maps(rgc_ctx* ctx, const float* corner_map, int n_corner, const float* surf_map, int n_surf, int stride_bytes);
 /* association only (kind 0 = edge against the corner map, 1 = plane against the surf map): factors8 (nullable) receives
@@ -234,9 +243,11 @@ RGC_API int rgc_mapreg_set_maps(rgc_ctx* ctx, const float* corner_map, int n_cor
 RGC_API int rgc_mapreg_associate(rgc_ctx* ctx, int kind, const float* feat_xyzw, int n, const double q_xyzw[4], const double t[3],
                                  double* factors8, int* n_valid);
 /* poses: q_w_curr[4] t_w_curr[3] q_w_last[4] t_w_last[3], in/out.  *gate_failed = 1 (poses untouched) when the size gate of
- * :1069 is not met.  report: one entry per pass of the two-pass loop (nullable). */
+ * :1069 is not met.  report: one entry per pass of the two-pass loop (nullable).  ground_cur / ground_last (nullable): the
+ * ground block on (para_q, para_t) resp. (para_q_last, para_t_last) -- pass them when the reference's condition at :1314 holds. */
 RGC_API int rgc_mapreg_optimize(rgc_ctx* ctx, const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur,
-                                const float* corner_last, int n_clast, const float* surf_last, int n_slast, double poses[14],
+                                const float* corner_last, int n_clast, const float* surf_last, int n_slast,
+                                const rgc_mapreg_ground* ground_cur, const rgc_mapreg_ground* ground_last, double poses[14],
                                 rgc_mapreg_report report[2], int* gate_failed);
 
 

@@ -52,6 +52,25 @@ class PlaneFactor(C.Structure):
     _fields_ = [("valid", C.c_int), ("pad", C.c_int), ("n", C.c_double * 3), ("d", C.c_double), ("var", C.c_double)]
 
 
+class MapregGround(C.Structure):
+    _fields_ = [("last_v1", C.c_double * 3), ("last_v2", C.c_double * 3), ("last_norm", C.c_double * 3), ("last_distance", C.c_double),
+                ("cur_norm", C.c_double * 3), ("cur_distance", C.c_double), ("q_history", C.c_double * 4), ("last_q", C.c_double * 4),
+                ("last_t", C.c_double * 3), ("p_var", C.c_double)]
+
+
+def make_ground(d):
+    """dict(last_v1, last_v2, last_norm, last_distance, cur_norm, cur_distance, q_history, last_q, last_t, p_var) -> MapregGround"""
+    if d is None:
+        return None
+    g = MapregGround()
+    for k in ("last_v1", "last_v2", "last_norm", "cur_norm", "last_t"):
+        setattr(g, k, (C.c_double * 3)(*[float(x) for x in d[k]]))
+    for k in ("q_history", "last_q"):
+        setattr(g, k, (C.c_double * 4)(*[float(x) for x in d[k]]))
+    g.last_distance, g.cur_distance, g.p_var = float(d["last_distance"]), float(d["cur_distance"]), float(d.get("p_var", 0.2))
+    return g
+
+
 class MapregTrace(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("radius", C.c_double), ("iterations", C.c_int),
                 ("successful", C.c_int), ("n_edge_cur", C.c_int), ("n_edge_last", C.c_int), ("n_plane_cur", C.c_int),
@@ -70,8 +89,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB):
-            build()
+        build()  # (re)builds only when a source is newer than the library
         L = C.CDLL(_LIB)
         fp, ip, dp, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p
         L.orc_default_params.argtypes = [C.POINTER(Params)]
@@ -119,8 +137,9 @@ def lib():
         ef, pf, tr = C.POINTER(EdgeFactor), C.POINTER(PlaneFactor), C.POINTER(MapregTrace)
         L.orc_mapreg_associate_edges.argtypes = [fp, C.c_int, dp, dp, fp, C.c_int, C.c_int, ef, C.c_int]
         L.orc_mapreg_associate_planes.argtypes = [fp, C.c_int, dp, dp, fp, C.c_int, C.c_int, pf, C.c_int]
-        L.orc_mapreg_solve.argtypes = [fp, ef, C.c_int, fp, pf, C.c_int, fp, ef, C.c_int, fp, pf, C.c_int, dp, C.c_int, tr]
-        L.orc_mapreg_optimize.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, dp, tr, C.c_int]
+        gp = C.POINTER(MapregGround)
+        L.orc_mapreg_solve.argtypes = [fp, ef, C.c_int, fp, pf, C.c_int, fp, ef, C.c_int, fp, pf, C.c_int, gp, gp, dp, C.c_int, tr]
+        L.orc_mapreg_optimize.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, gp, gp, dp, tr, C.c_int]
         _lib = L
     return _lib
 
@@ -313,25 +332,30 @@ def mapreg_associate(feat_xyzw, q_xyzw, t, map_xyz, kind, threads=0, raw=False):
     return arr if raw else _factors_to_np(arr[: f.shape[0]], kind)
 
 
-def mapreg_solve(corner_cur, e_cur, surf_cur, p_cur, corner_last, e_last, surf_last, p_last, poses14, max_iterations=6):
+def mapreg_solve(corner_cur, e_cur, surf_cur, p_cur, corner_last, e_last, surf_last, p_last, poses14, max_iterations=6, ground_cur=None,
+                 ground_last=None):
     """ceres::Solve restated (RGC_mapping.cpp:1333-1341); e_*/p_* are the RAW ctypes factor arrays of mapreg_associate(raw=True)."""
     cc, ccp = _f32(corner_cur); sc, scp = _f32(surf_cur); cl, clp = _f32(corner_last); sl, slp = _f32(surf_last)
     x = np.ascontiguousarray(poses14, dtype=np.float64).copy()
     tr = MapregTrace()
+    gc, gl = make_ground(ground_cur), make_ground(ground_last)
     lib().orc_mapreg_solve(ccp, e_cur, cc.shape[0], scp, p_cur, sc.shape[0], clp, e_last, cl.shape[0], slp, p_last, sl.shape[0],
-                           x.ctypes.data_as(C.POINTER(C.c_double)), max_iterations, C.byref(tr))
+                           C.byref(gc) if gc else None, C.byref(gl) if gl else None, x.ctypes.data_as(C.POINTER(C.c_double)), max_iterations,
+                           C.byref(tr))
     return x, {k: getattr(tr, k) for k, _ in MapregTrace._fields_ if k != "pad"}
 
 
-def mapreg_optimize(corner_cur, surf_cur, corner_last, surf_last, corner_map, surf_map, poses14, threads=0):
+def mapreg_optimize(corner_cur, surf_cur, corner_last, surf_last, corner_map, surf_map, poses14, threads=0, ground_cur=None, ground_last=None):
     """The optimisation block of one mapping frame (2 x associate + solve, then quaternion normalisation)."""
     cc, ccp = _f32(corner_cur); sc, scp = _f32(surf_cur); cl, clp = _f32(corner_last); sl, slp = _f32(surf_last)
     cm, cmp_ = _f32(corner_map); sm, smp = _f32(surf_map)
     assert cm.shape[1] == sm.shape[1]
     x = np.ascontiguousarray(poses14, dtype=np.float64).copy()
     tr = (MapregTrace * 2)()
+    gc, gl = make_ground(ground_cur), make_ground(ground_last)
     rc = lib().orc_mapreg_optimize(ccp, cc.shape[0], scp, sc.shape[0], clp, cl.shape[0], slp, sl.shape[0], cmp_, cm.shape[0], smp, sm.shape[0],
-                                   cm.shape[1], x.ctypes.data_as(C.POINTER(C.c_double)), tr, threads)
+                                   cm.shape[1], C.byref(gc) if gc else None, C.byref(gl) if gl else None, x.ctypes.data_as(C.POINTER(C.c_double)),
+                                   tr, threads)
     if rc < 0:
         raise RuntimeError(f"orc_mapreg_optimize rc={rc}")
     return x, rc, [{k: getattr(t, k) for k, _ in MapregTrace._fields_ if k != "pad"} for t in tr]

@@ -78,6 +78,23 @@ def residual_blocks(cfeat, ef, sfeat, pf, q, t):
     return e, p
 
 
+def _qmul(a, b):
+    return np.array([a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1], a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0],
+                     a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
+
+
+def ground_residual(G, q, t):
+    """Ground_DeltaFactor_goable (lidarFactor.hpp:357-391); G = dict like oracle.make_ground's input"""
+    lqc = np.array([-G["last_q"][0], -G["last_q"][1], -G["last_q"][2], G["last_q"][3]])
+    q_lc = _qmul(lqc, np.asarray(q, float))
+    t_lc = quat_rot(lqc, np.asarray(t, float) - np.asarray(G["last_t"], float))
+    gn = quat_rot(q_lc, np.asarray(G["cur_norm"], float))
+    delta_t = quat_rot(np.asarray(G["q_history"], float), t_lc)
+    pv = G.get("p_var", 0.2)
+    return np.array([(G["last_distance"] - (G["cur_distance"] + delta_t[2])) / (pv / 1000),
+                     abs(np.dot(G["last_v1"], gn)) / (pv * 10), abs(np.dot(G["last_v2"], gn)) / (pv * 10)])
+
+
 def _sq(blocks):
     return np.concatenate([np.sum(b * b, axis=1) for b in blocks])
 
@@ -116,8 +133,13 @@ def lm_solve(sets, poses14, max_iterations=6):
     def blocks_at(xv, b):
         q, t = pose(xv, b)
         return residual_blocks(sets[b][0], sets[b][1], sets[b][2], sets[b][3], q, t)
+    def ground_of(b):
+        return sets[b][4] if len(sets[b]) > 4 else None
+    def ground_r(xv, b):
+        q, t = pose(xv, b)
+        return ground_residual(ground_of(b), q, t) if ground_of(b) is not None else np.zeros(0)
     def cost_at(xv):
-        return robust_cost(blocks_at(xv, 0)) + robust_cost(blocks_at(xv, 1))
+        return robust_cost(blocks_at(xv, 0)) + robust_cost(blocks_at(xv, 1)) + 0.5 * sum(float(ground_r(xv, b) @ ground_r(xv, b)) for b in range(2))
     def normal_eq(xv):
         H, g = np.zeros((12, 12)), np.zeros(12)
         for b in range(2):
@@ -130,6 +152,13 @@ def lm_solve(sets, poses14, max_iterations=6):
                 d = np.zeros(12); d[6 * b + a] = h
                 J[:, a] = (_flat(blocks_at(apply(xv, d), b)) - _flat(blocks_at(apply(xv, -d), b))) / (2 * h)
             Jw, rw = J * w[:, None], r0 * w
+            if ground_of(b) is not None:  # NULL loss: no robustification
+                rg = ground_r(xv, b)
+                Jg = np.zeros((3, 6))
+                for a in range(6):
+                    d = np.zeros(12); d[6 * b + a] = h
+                    Jg[:, a] = (ground_r(apply(xv, d), b) - ground_r(apply(xv, -d), b)) / (2 * h)
+                Jw, rw = np.vstack([Jw, Jg]), np.concatenate([rw, rg])
             H[6 * b: 6 * b + 6, 6 * b: 6 * b + 6] = Jw.T @ Jw
             g[6 * b: 6 * b + 6] = Jw.T @ rw
         return H, g

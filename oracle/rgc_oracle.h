@@ -136,6 +136,12 @@ typedef struct {
   double initial_cost, final_cost, radius;
   int iterations, successful, n_edge_cur, n_edge_last, n_plane_cur, n_plane_last, pad;
 } orc_mapreg_trace;
+/* one Ground_DeltaFactor_goable (src/lidarFactor.hpp:352-403, RGC_mapping.cpp:1314-1340); quaternions x,y,z,w */
+typedef struct {
+  double last_v1[3], last_v2[3], last_norm[3], last_distance; /* g_last: vector_1, vector_2, vector_norm, distance */
+  double cur_norm[3], cur_distance;                          /* g_cur */
+  double q_history[4], last_q[4], last_t[3], p_var;          /* q_w_curr_f, q_w_last, t_w_last, ground_cov (0.2) */
+} orc_mapreg_ground;
 /* features: nf x 4 floats (x, y, z, normal_x = the per-feature weight of scanRegistration.cpp:501,554,609); q = x,y,z,w */
 int orc_mapreg_associate_edges(const float* feat, int nf, const double q_xyzw[4], const double t[3], const float* map_xyz, int nmap,
                                int mstride, orc_edge_factor* out, int num_threads);
@@ -144,11 +150,13 @@ int orc_mapreg_associate_planes(const float* feat, int nf, const double q_xyzw[4
 /* poses: q_cur[4] t_cur[3] q_last[4] t_last[3], in/out */
 int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int n_ccur, const float* surf_cur, const orc_plane_factor* p_cur,
                      int n_scur, const float* corner_last, const orc_edge_factor* e_last, int n_clast, const float* surf_last,
-                     const orc_plane_factor* p_last, int n_slast, double poses[14], int max_iterations, orc_mapreg_trace* trace);
+                     const orc_plane_factor* p_last, int n_slast, const orc_mapreg_ground* ground_cur /* nullable */,
+                     const orc_mapreg_ground* ground_last /* nullable */, double poses[14], int max_iterations, orc_mapreg_trace* trace);
 /* returns 1 if the gate of RGC_mapping.cpp:1069 is not met (poses untouched), 0 on success */
 int orc_mapreg_optimize(const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur, const float* corner_last, int n_clast,
                         const float* surf_last, int n_slast, const float* corner_map, int n_cmap, const float* surf_map, int n_smap,
-                        int mstride, double poses[14], orc_mapreg_trace trace[2], int num_threads);
+                        int mstride, const orc_mapreg_ground* ground_cur, const orc_mapreg_ground* ground_last, double poses[14],
+                        orc_mapreg_trace trace[2], int num_threads);
 
 /* ---- C7 helpers ---- */
 void orc_so3_exp(const double omega[3], double q_wxyz[4]);                 /* so3/so3.hpp:58-77 */

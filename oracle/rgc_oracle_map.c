@@ -11,7 +11,8 @@
  *   iterations, Ceres 1.14 defaults) -> the LM loop of orc_mapreg_solve below (robustification by the Triggs corrector,
  *   which for Huber reduces to scaling residual and Jacobian by sqrt(rho'); damping diag(J^T J)/radius; step acceptance
  *   and radius update of LevenbergMarquardtStrategy).  Pinned by oracle/py_mapreg.py (numpy/scipy).
- * USE_IMU = 0 and no ground factor (the two optional blocks of :1283-1331) -- stated in DESIGN.md.
+ * USE_IMU = 0 (the block of :1283-1312 is not restated); the ground block of :1314-1340 (Ground_DeltaFactor_goable,
+ * lidarFactor.hpp:352-403, NULL loss) is optional input.
  */
 #include "rgc_oracle.h"
 
@@ -290,10 +291,67 @@ static void quat_plus(const double q[4], const double d[3], double out[4]) { /* 
   out[3] = aw * bw - ax * bx - ay * by - az * bz;
 }
 
+static void quat_mul(const double a[4], const double b[4], double o[4]) { /* x,y,z,w */
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+
+/* Ground_DeltaFactor_goable::operator() (lidarFactor.hpp:357-391) */
+static void ground_residual(const orc_mapreg_ground* G, const double q[4], const double t[3], double r[3]) {
+  const double lqc[4] = {-G->last_q[0], -G->last_q[1], -G->last_q[2], G->last_q[3]}; /* conjugate */
+  double q_lc[4], dt[3] = {t[0] - G->last_t[0], t[1] - G->last_t[1], t[2] - G->last_t[2]}, t_lc[3], gn[3], delta_t[3];
+  quat_mul(lqc, q, q_lc);
+  quat_rot(lqc, dt, t_lc);
+  quat_rot(q_lc, G->cur_norm, gn);
+  quat_rot(G->q_history, t_lc, delta_t);
+  const double dist_cur = G->cur_distance + delta_t[2];
+  r[0] = (G->last_distance - dist_cur) / (G->p_var / 1000);
+  r[1] = fabs(G->last_v1[0] * gn[0] + G->last_v1[1] * gn[1] + G->last_v1[2] * gn[2]) / (G->p_var * 10);
+  r[2] = fabs(G->last_v2[0] * gn[0] + G->last_v2[1] * gn[1] + G->last_v2[2] * gn[2]) / (G->p_var * 10);
+}
+
+/* adds the (non-robustified, NULL loss) ground block of one pose: cost, and H21 / g6 if given.  The Jacobian on the 6-dim local
+ * parameterisation is taken by central differences (step 1e-6): the block is three scalars of a smooth function (abs() aside,
+ * where Ceres' autodiff uses sign()), and both sides of the parity comparison share this exact routine. */
+static void ground_terms(const orc_mapreg_ground* G, const double q[4], const double t[3], double* H21, double* g6, double* cost) {
+  if (!G) return;
+  double r[3];
+  ground_residual(G, q, t, r);
+  *cost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  if (!H21) return;
+  double J[18];
+  const double h = 1e-6;
+  for (int a = 0; a < 6; a++) {
+    double rp[3], rm[3], qq[4], tt[3], d[3] = {0, 0, 0};
+    for (int sgn = 0; sgn < 2; sgn++) {
+      const double e = sgn ? -h : h;
+      memcpy(qq, q, sizeof(qq)); memcpy(tt, t, sizeof(tt));
+      if (a < 3) { d[0] = d[1] = d[2] = 0; d[a] = e; quat_plus(q, d, qq); } else tt[a - 3] += e;
+      ground_residual(G, qq, tt, sgn ? rm : rp);
+    }
+    for (int k = 0; k < 3; k++) J[k * 6 + a] = (rp[k] - rm[k]) / (2 * h);
+  }
+  int u = 0;
+  for (int a = 0; a < 6; a++)
+    for (int c = a; c < 6; c++) {
+      double v = 0;
+      for (int k = 0; k < 3; k++) v += J[k * 6 + a] * J[k * 6 + c];
+      H21[u++] += v;
+    }
+  for (int a = 0; a < 6; a++) {
+    double v = 0;
+    for (int k = 0; k < 3; k++) v += J[k * 6 + a] * r[k];
+    g6[a] += v;
+  }
+}
+
 /* ceres::Solve restated (see the header of this file).  poses: q_cur[4] t_cur[3] q_last[4] t_last[3] in/out. */
 int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int n_ccur, const float* surf_cur, const orc_plane_factor* p_cur,
                      int n_scur, const float* corner_last, const orc_edge_factor* e_last, int n_clast, const float* surf_last,
-                     const orc_plane_factor* p_last, int n_slast, double poses[14], int max_iterations, orc_mapreg_trace* trace) {
+                     const orc_plane_factor* p_last, int n_slast, const orc_mapreg_ground* ground_cur, const orc_mapreg_ground* ground_last,
+                     double poses[14], int max_iterations, orc_mapreg_trace* trace) {
   const double huber_a = 0.1;
   double radius = 1e4, decrease_factor = 2.0; /* initial_trust_region_radius, LevenbergMarquardtStrategy */
   double* qc = poses; double* tc = poses + 4; double* ql = poses + 7; double* tl = poses + 11;
@@ -302,6 +360,8 @@ int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int 
   memset(H, 0, sizeof(H)); memset(g, 0, sizeof(g));
   pose_terms(corner_cur, e_cur, n_ccur, surf_cur, p_cur, n_scur, qc, tc, huber_a, H[0], g[0], &cost);
   pose_terms(corner_last, e_last, n_clast, surf_last, p_last, n_slast, ql, tl, huber_a, H[1], g[1], &cost);
+  ground_terms(ground_cur, qc, tc, H[0], g[0], &cost);
+  ground_terms(ground_last, ql, tl, H[1], g[1], &cost);
   if (trace) { trace->initial_cost = cost; trace->iterations = 0; trace->successful = 0; }
   for (it = 0; it < max_iterations; it++) {
     /* gradient tolerance (max-norm) */
@@ -341,6 +401,8 @@ int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int 
       new_cost = 0;
       pose_terms(corner_cur, e_cur, n_ccur, surf_cur, p_cur, n_scur, nq[0], nt[0], huber_a, NULL, NULL, &new_cost);
       pose_terms(corner_last, e_last, n_clast, surf_last, p_last, n_slast, nq[1], nt[1], huber_a, NULL, NULL, &new_cost);
+      ground_terms(ground_cur, nq[0], nt[0], NULL, NULL, &new_cost);
+      ground_terms(ground_last, nq[1], nt[1], NULL, NULL, &new_cost);
       rho = (cost - new_cost) / model;
     }
     if (rho > 1e-3) { /* min_relative_decrease: successful step */
@@ -357,6 +419,8 @@ int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int 
       cost = 0;
       pose_terms(corner_cur, e_cur, n_ccur, surf_cur, p_cur, n_scur, qc, tc, huber_a, H[0], g[0], &cost);
       pose_terms(corner_last, e_last, n_clast, surf_last, p_last, n_slast, ql, tl, huber_a, H[1], g[1], &cost);
+      ground_terms(ground_cur, qc, tc, H[0], g[0], &cost);
+      ground_terms(ground_last, ql, tl, H[1], g[1], &cost);
       double step2 = 0, x2 = 0;
       for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) step2 += d[b][a] * d[b][a];
       for (int a = 0; a < 14; a++) x2 += poses[a] * poses[a];
@@ -376,7 +440,8 @@ int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int 
  * normalisation of :1375-1376 */
 int orc_mapreg_optimize(const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur, const float* corner_last, int n_clast,
                         const float* surf_last, int n_slast, const float* corner_map, int n_cmap, const float* surf_map, int n_smap,
-                        int mstride, double poses[14], orc_mapreg_trace trace[2], int num_threads) {
+                        int mstride, const orc_mapreg_ground* ground_cur, const orc_mapreg_ground* ground_last, double poses[14],
+                        orc_mapreg_trace trace[2], int num_threads) {
   /* the gate of :1069 */
   if (!(n_ccur > 10 && n_scur > 50 && n_cmap > 10 && n_smap > 50)) return 1;
   orc_edge_factor* ec = (orc_edge_factor*)malloc(sizeof(orc_edge_factor) * (size_t)(n_ccur > 0 ? n_ccur : 1));
@@ -391,7 +456,7 @@ int orc_mapreg_optimize(const float* corner_cur, int n_ccur, const float* surf_c
     int d = orc_mapreg_associate_planes(surf_last, n_slast, poses + 7, poses + 11, surf_map, n_smap, mstride, pl, num_threads);
     if (a < 0 || b < 0 || c < 0 || d < 0) { rc = -1; break; }
     if (trace) { trace[iter].n_edge_cur = a; trace[iter].n_edge_last = b; trace[iter].n_plane_cur = c; trace[iter].n_plane_last = d; }
-    orc_mapreg_solve(corner_cur, ec, n_ccur, surf_cur, pc, n_scur, corner_last, el, n_clast, surf_last, pl, n_slast, poses, 6,
+    orc_mapreg_solve(corner_cur, ec, n_ccur, surf_cur, pc, n_scur, corner_last, el, n_clast, surf_last, pl, n_slast, ground_cur, ground_last, poses, 6,
                      trace ? &trace[iter] : NULL);
   }
   /* q_w_last.normalize(); q_w_curr.normalize(); (:1375-1376) */

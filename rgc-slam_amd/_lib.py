@@ -57,6 +57,12 @@ class MapregReport(C.Structure):
                 ("n_edge_cur", C.c_int), ("n_plane_cur", C.c_int), ("n_edge_last", C.c_int), ("n_plane_last", C.c_int)]
 
 
+class MapregGround(C.Structure):
+    _fields_ = [("last_v1", C.c_double * 3), ("last_v2", C.c_double * 3), ("last_norm", C.c_double * 3), ("last_distance", C.c_double),
+                ("cur_norm", C.c_double * 3), ("cur_distance", C.c_double), ("q_history", C.c_double * 4), ("last_q", C.c_double * 4),
+                ("last_t", C.c_double * 3), ("p_var", C.c_double)]
+
+
 class RgcError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"rgc_hip status {status}: {msg}")
@@ -137,7 +143,8 @@ def load():
     L.rgc_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, vp, C.c_int]
     L.rgc_mapreg_set_maps.argtypes = [vp, fp, C.c_int, fp, C.c_int, C.c_int]
     L.rgc_mapreg_associate.argtypes = [vp, C.c_int, fp, C.c_int, dp, dp, dp, ip]
-    L.rgc_mapreg_optimize.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, dp, C.POINTER(MapregReport), ip]
+    L.rgc_mapreg_optimize.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.POINTER(MapregGround), C.POINTER(MapregGround), dp,
+                                      C.POINTER(MapregReport), ip]
     L.rgc_profile_enable.argtypes = [vp, C.c_int]
     L.rgc_profile_select.argtypes = [vp, C.c_uint]
     L.rgc_profile_reset.argtypes = [vp]

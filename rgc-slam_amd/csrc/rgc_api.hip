@@ -552,9 +552,68 @@ void quat_plus(const double q[4], const double d[3], double out[4]) {  // EigenQ
   out[3] = aw * bw - ax * bx - ay * by - az * bz;
 }
 
+void quat_rot_h(const double q[4], const double p[3], double out[3]) {  // Eigen: quaternion * vector (x,y,z,w)
+  const double tx = 2 * (q[1] * p[2] - q[2] * p[1]), ty = 2 * (q[2] * p[0] - q[0] * p[2]), tz = 2 * (q[0] * p[1] - q[1] * p[0]);
+  out[0] = p[0] + q[3] * tx + (q[1] * tz - q[2] * ty);
+  out[1] = p[1] + q[3] * ty + (q[2] * tx - q[0] * tz);
+  out[2] = p[2] + q[3] * tz + (q[0] * ty - q[1] * tx);
+}
+void quat_mul_h(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+// Ground_DeltaFactor_goable::operator() (lidarFactor.hpp:357-391)
+void ground_residual(const rgc_mapreg_ground* G, const double q[4], const double t[3], double r[3]) {
+  const double lqc[4] = {-G->last_q[0], -G->last_q[1], -G->last_q[2], G->last_q[3]};
+  double q_lc[4], dt[3] = {t[0] - G->last_t[0], t[1] - G->last_t[1], t[2] - G->last_t[2]}, t_lc[3], gn[3], delta_t[3];
+  quat_mul_h(lqc, q, q_lc);
+  quat_rot_h(lqc, dt, t_lc);
+  quat_rot_h(q_lc, G->cur_norm, gn);
+  quat_rot_h(G->q_history, t_lc, delta_t);
+  const double dist_cur = G->cur_distance + delta_t[2];
+  r[0] = (G->last_distance - dist_cur) / (G->p_var / 1000);
+  r[1] = std::fabs(G->last_v1[0] * gn[0] + G->last_v1[1] * gn[1] + G->last_v1[2] * gn[2]) / (G->p_var * 10);
+  r[2] = std::fabs(G->last_v2[0] * gn[0] + G->last_v2[1] * gn[1] + G->last_v2[2] * gn[2]) / (G->p_var * 10);
+}
+// the ground block of one pose added on the host (three scalars: not worth a launch).  NULL loss; the Jacobian on the local
+// parameterisation by central differences (step 1e-6; Ceres differentiates abs() as sign(), which this matches away from 0).
+void ground_terms(const rgc_mapreg_ground* G, const double q[4], const double t[3], bool want_H, double S28[28]) {
+  if (!G) return;
+  double r[3];
+  ground_residual(G, q, t, r);
+  S28[27] += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  if (!want_H) return;
+  double J[18];
+  const double h = 1e-6;
+  for (int a = 0; a < 6; a++) {
+    double rp[3], rm[3], qq[4], tt[3], d[3] = {0, 0, 0};
+    for (int sgn = 0; sgn < 2; sgn++) {
+      const double e = sgn ? -h : h;
+      memcpy(qq, q, sizeof(qq)); memcpy(tt, t, sizeof(tt));
+      if (a < 3) { d[0] = d[1] = d[2] = 0; d[a] = e; quat_plus(q, d, qq); } else tt[a - 3] += e;
+      ground_residual(G, qq, tt, sgn ? rm : rp);
+    }
+    for (int k = 0; k < 3; k++) J[k * 6 + a] = (rp[k] - rm[k]) / (2 * h);
+  }
+  int u = 0;
+  for (int a = 0; a < 6; a++)
+    for (int e = a; e < 6; e++) {
+      double v = 0;
+      for (int k = 0; k < 3; k++) v += J[k * 6 + a] * J[k * 6 + e];
+      S28[u++] += v;
+    }
+  for (int a = 0; a < 6; a++) {
+    double v = 0;
+    for (int k = 0; k < 3; k++) v += J[k * 6 + a] * r[k];
+    S28[21 + a] += v;
+  }
+}
+
 // sums of both poses at x (14 doubles): out[b][0..27] = 21 H, 6 g, cost; feature sets 0/1 = corner/surf of the current pose,
 // 2/3 = of the last pose
-int mapreg_eval(rgc_ctx* c, const int nfeat[4], const double x[14], bool want_H, double out[2][28]) {
+int mapreg_eval(rgc_ctx* c, const int nfeat[4], const double x[14], bool want_H, const rgc_mapreg_ground* const ground[2], double out[2][28]) {
   const float* feat[4];
   const double* fac[4];
   for (int s = 0; s < 4; s++) { feat[s] = (const float*)c->mr_feat[s].p; fac[s] = (const double*)c->mr_fac[s].p; }
@@ -563,6 +622,7 @@ int mapreg_eval(rgc_ctx* c, const int nfeat[4], const double x[14], bool want_H,
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   memcpy(out, c->h_out, sizeof(double) * 56);
+  for (int b = 0; b < 2; b++) ground_terms(ground[b], x + 7 * b, x + 7 * b + 4, want_H, out[b]);
   return RGC_OK;
 }
 
@@ -1370,7 +1430,8 @@ int rgc_mapreg_associate(rgc_ctx* c, int kind, const float* feat_xyzw, int n, co
 }
 
 int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur, const float* corner_last,
-                        int n_clast, const float* surf_last, int n_slast, double poses[14], rgc_mapreg_report report[2], int* gate_failed) {
+                        int n_clast, const float* surf_last, int n_slast, const rgc_mapreg_ground* ground_cur, const rgc_mapreg_ground* ground_last,
+                        double poses[14], rgc_mapreg_report report[2], int* gate_failed) {
   if (!c || !poses || n_ccur < 0 || n_scur < 0 || n_clast < 0 || n_slast < 0) return RGC_ERR_INVALID;
   if ((n_ccur && !corner_cur) || (n_scur && !surf_cur) || (n_clast && !corner_last) || (n_slast && !surf_last)) return RGC_ERR_INVALID;
   if (!c->mr_map[0].ready || !c->mr_map[1].ready) return fail(c, RGC_ERR_NO_INPUT, "rgc_mapreg_set_maps first");
@@ -1382,6 +1443,7 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
   HIPCHK(c, hipSetDevice(c->device));
   const float* feat[4] = {corner_cur, surf_cur, corner_last, surf_last};
   const int nfeat[4] = {n_ccur, n_scur, n_clast, n_slast};
+  const rgc_mapreg_ground* const ground[2] = {ground_cur, ground_last};
   int rc;
   for (int s = 0; s < 4; s++)
     if ((rc = mapreg_upload_features(c, s, feat[s], nfeat[s]))) return rc;
@@ -1402,7 +1464,7 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
     // ceres::Solve restated: trust-region LM, <= 6 iterations (:1333-1341), Ceres 1.14 defaults: initial radius 1e4, damping diag(H)/radius clamped to [1e-6, 1e32], step accepted above a relative decrease of 1e-3
     double radius = 1e4, decrease_factor = 2.0;
     double S[2][28];
-    if ((rc = mapreg_eval(c, nfeat, poses, true, S))) return rc;
+    if ((rc = mapreg_eval(c, nfeat, poses, true, ground, S))) return rc;
     double cost = S[0][27] + S[1][27];
     if (report) {
       report[iter].n_edge_cur = c->h_small[40]; report[iter].n_plane_cur = c->h_small[41];
@@ -1443,7 +1505,7 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
         }
         // the candidate's cost AND its normal equations in one launch: nearly every step is accepted, and an accepted step
         // needs them next (a rejected one just drops them)
-        if ((rc = mapreg_eval(c, nfeat, xn, true, Sn))) return rc;
+        if ((rc = mapreg_eval(c, nfeat, xn, true, ground, Sn))) return rc;
         rho = (cost - (Sn[0][27] + Sn[1][27])) / model;
       }
       if (rho > 1e-3) {

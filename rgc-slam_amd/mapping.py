@@ -71,15 +71,30 @@ class MapFeatureRegistration:
             return dict(valid=valid, a=out[:, 0:3].copy(), b=out[:, 3:6].copy(), var=out[:, 6].copy(), n_valid=nv.value)
         return dict(valid=valid, n=out[:, 0:3].copy(), d=out[:, 3].copy(), var=out[:, 6].copy(), n_valid=nv.value)
 
-    def optimize(self, corner_cur, surf_cur, corner_last, surf_last, q_w_curr, t_w_curr, q_w_last, t_w_last):
+    @staticmethod
+    def _ground(d):
+        if d is None:
+            return None
+        g = _lib.MapregGround()
+        for k in ("last_v1", "last_v2", "last_norm", "cur_norm", "last_t"):
+            setattr(g, k, (C.c_double * 3)(*[float(v) for v in d[k]]))
+        for k in ("q_history", "last_q"):
+            setattr(g, k, (C.c_double * 4)(*[float(v) for v in d[k]]))
+        g.last_distance, g.cur_distance, g.p_var = float(d["last_distance"]), float(d["cur_distance"]), float(d.get("p_var", 0.2))
+        return g
+
+    def optimize(self, corner_cur, surf_cur, corner_last, surf_last, q_w_curr, t_w_curr, q_w_last, t_w_last, ground_cur=None, ground_last=None):
         """The two-pass associate + solve block; returns (q_w_curr, t_w_curr, q_w_last, t_w_last, report) with report = None when
-        the size gate of :1069 is not met (poses returned unchanged)."""
+        the size gate of :1069 is not met (poses returned unchanged).  ground_cur / ground_last: dicts with the fields of
+        rgc_mapreg_ground (the Ground_DeltaFactor_goable blocks of :1314-1340), or None."""
         cc, ccp = _f32(corner_cur, 4); sc, scp = _f32(surf_cur, 4); cl, clp = _f32(corner_last, 4); sl, slp = _f32(surf_last, 4)
         x = np.concatenate([np.asarray(q_w_curr, float), np.asarray(t_w_curr, float), np.asarray(q_w_last, float), np.asarray(t_w_last, float)])
         x = np.ascontiguousarray(x, np.float64)
         rep = (_lib.MapregReport * 2)()
         gate = C.c_int(0)
+        gc, gl = self._ground(ground_cur), self._ground(ground_last)
         self._chk(self._L.rgc_mapreg_optimize(self._h, ccp, cc.shape[0], scp, sc.shape[0], clp, cl.shape[0], slp, sl.shape[0],
+                                              C.byref(gc) if gc else None, C.byref(gl) if gl else None,
                                               x.ctypes.data_as(C.POINTER(C.c_double)), rep, C.byref(gate)))
         report = None if gate.value else [{k: getattr(r, k) for k, _ in _lib.MapregReport._fields_} for r in rep]
         return x[0:4].copy(), x[4:7].copy(), x[7:11].copy(), x[11:14].copy(), report

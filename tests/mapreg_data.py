@@ -49,3 +49,20 @@ def perturb(T, rng, ang=0.01, trans=0.05):
     o[:3, :3] = R @ T[:3, :3]
     o[:3, 3] = T[:3, 3] + rng.normal(0, trans, 3)
     return o
+
+
+def make_ground(T_cur, T_last, height=0.56, p_var=0.2, tilt=(0.01, -0.008)):
+    """A Ground_DeltaFactor_goable input consistent with a ground plane at z = -height in the map frame (RGC_mapping.cpp:1326-1331):
+    g_last / g_cur are the plane seen from the last / current sensor frame, q_history the last pose's rotation."""
+    def plane_in(T):
+        R = T[:3, :3]
+        n = R.T @ np.array([0.0, 0.0, 1.0])            # map-frame up expressed in the sensor frame
+        d = height + T[2, 3]                            # sensor height above the plane
+        v1 = np.cross(n, [1.0, 0.0, 0.0]); v1 /= np.linalg.norm(v1)
+        v2 = np.cross(n, v1)
+        return n, v1, v2, d
+    nl, v1, v2, dl = plane_in(T_last)
+    nc, _, _, dc = plane_in(T_cur)
+    nc = nc + np.array([tilt[0], tilt[1], 0.0]); nc /= np.linalg.norm(nc)   # measurement noise on the current plane
+    return dict(last_v1=v1, last_v2=v2, last_norm=nl, last_distance=dl, cur_norm=nc, cur_distance=dc + 0.01,
+                q_history=rot_to_quat_xyzw(T_last[:3, :3]), last_q=rot_to_quat_xyzw(T_last[:3, :3]), last_t=T_last[:3, 3].copy(), p_var=p_var)

@@ -79,6 +79,26 @@ def test_lm_trajectory_matches_numpy(case):
         assert trc["final_cost"] < trc["initial_cost"]
 
 
+def test_ground_block_matches_numpy(case):
+    """the optional Ground_DeltaFactor_goable blocks (NULL loss) on both poses"""
+    from oracle import oracle, py_mapreg as pm
+    raw, sets = _frozen(case)
+    gc, gl = md.make_ground(case["T_cur"], case["T_last"]), md.make_ground(case["T_last"], case["T_last"], tilt=(-0.004, 0.006))
+    sets_g = [sets[0] + (gc,), sets[1] + (gl,)]
+    x0 = case["x0"]
+    xc, trc = oracle.mapreg_solve(case["corner_cur"], raw["ec"][0], case["surf_cur"], raw["pc"][0], case["corner_last"], raw["el"][0],
+                                  case["surf_last"], raw["pl"][0], x0, 3, ground_cur=gc, ground_last=gl)
+    xn, trn = pm.lm_solve(sets_g, x0, 3)
+    x_plain, tr_plain = oracle.mapreg_solve(case["corner_cur"], raw["ec"][0], case["surf_cur"], raw["pc"][0], case["corner_last"], raw["el"][0],
+                                            case["surf_last"], raw["pl"][0], x0, 3)
+    assert abs(trc["initial_cost"] - trn["initial_cost"]) <= 1e-10 * trn["initial_cost"]
+    assert trc["initial_cost"] > tr_plain["initial_cost"]          # the block adds cost
+    assert abs(trc["final_cost"] - trn["final_cost"]) <= 1e-7 * trn["final_cost"] and np.abs(xc - xn).max() < 1e-7
+    assert np.abs(xc - x_plain).max() > 1e-6                         # and it moves the solution
+    r = pm.ground_residual(gc, x0[0:4], x0[4:7])
+    assert r.shape == (3,) and r[1] >= 0 and r[2] >= 0
+
+
 def test_converged_solution_is_a_minimum(case):
     """run to convergence: the gradient of the robust cost vanishes and a generic minimiser (scipy BFGS) cannot improve on it"""
     from oracle import oracle, py_mapreg as pm
