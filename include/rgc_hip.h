@@ -216,6 +216,36 @@ RGC_API int  rgc_download(rgc_ctx* ctx, void* h_dst, const void* d_src, size_t b
 RGC_API int  rgc_synchronize(rgc_ctx* ctx);
 RGC_API void* rgc_stream(rgc_ctx* ctx); /* the hipStream_t every kernel of this context is launched on */
 
+/* ---- f3: wire and disk formats at the edges of the path ----
+ * sensor_msgs/PointCloud2 <-> device arrays without PCL: pcl::fromROSMsg (src/scanRegistration.cpp:107-108) and pcl::toROSMsg
+ * (:689-727, src/RGC_odometer.cpp:1348).  Fields in the order x, y, z, intensity, ring, time; offset < 0 = the message has
+ * no such field (-> 0, ring -> -1).  datatype = sensor_msgs/PointField constants (INT8 1 ... FLOAT32 7, FLOAT64 8).
+ * strict != 0 reproduces fromROSMsg<PointXYZI>'s field matching: a field whose datatype is not FLOAT32 is NOT mapped (stays
+ * 0); strict = 0 converts any numeric type. */
+typedef struct rgc_pc2_layout {
+  int point_step;
+  int offset[6];
+  int datatype[6];
+  int is_bigendian;
+  int strict;
+} rgc_pc2_layout;
+/* data: width*height points of point_step bytes (host).  xyzi_out: n x 4 floats (host, or device if out_on_device);
+ * ring_out / time_out: n ints / floats, nullable (same residency). */
+RGC_API int rgc_pc2_unpack(rgc_ctx* ctx, const void* data, int n_points, const rgc_pc2_layout* layout, float* xyzi_out, int* ring_out,
+                           float* time_out, int out_on_device);
+/* kind 0: PointXYZI message (point_step 32), in = n x 4 {x,y,z,intensity}; kind 1: PointXYZINormal message (point_step 48),
+ * in = n x 5 {x,y,z,intensity,normal_x}.  data_out: n * point_step bytes (host). */
+RGC_API int rgc_pc2_pack(rgc_ctx* ctx, int kind, const float* in, int n, int in_on_device, void* data_out);
+typedef struct rgc_pc2_field { char name[16]; int offset; int datatype; int count; } rgc_pc2_field;
+/* the PointField table pcl::toROSMsg emits for that point type; returns the number of fields (<= cap), *point_step set */
+RGC_API int rgc_pc2_point_fields(int kind, rgc_pc2_field* out, int cap, int* point_step);
+/* one line of the TUM trajectory file f_save_pose_evo (src/RGC_odometer.cpp:1315-1316): "stamp tx ty tz qx qy qz qw\n" with
+ * std::fixed, 6 decimals for the stamp and 9 for the rest.  Returns the length written (excluding the NUL) or < 0. */
+RGC_API int rgc_tum_line(double stamp, const double t[3], const double q_xyzw[4], char* buf, int cap);
+/* key-frame cloud to a .pcd file (src/RGC_odometer.cpp:1353-1354 writes ASCII): binary = 0 -> DATA ascii like
+ * pcl::io::savePCDFileASCII (precision 8), binary = 1 -> DATA binary, 16 bytes per point (FIELDS x y z intensity). */
+RGC_API int rgc_pcd_write(const char* path, const float* xyzi, int n, int binary);
+
 /* ---- f1: scan-to-map FEATURE registration of the mapping node, src/RGC_mapping.cpp:1069-1358 ----
  * Replaces, per mapping frame: kdtreeCornerFromMap/kdtreeSurfFromMap->setInputCloud (:1073-1074), the four association
  * loops (:1092-1282: pointAssociateToMap, 5-NN, PCA line test / QR plane fit) and ceres::Solve over para_q/para_t and

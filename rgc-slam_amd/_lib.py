@@ -57,6 +57,14 @@ class MapregReport(C.Structure):
                 ("n_edge_cur", C.c_int), ("n_plane_cur", C.c_int), ("n_edge_last", C.c_int), ("n_plane_last", C.c_int)]
 
 
+class Pc2Layout(C.Structure):
+    _fields_ = [("point_step", C.c_int), ("offset", C.c_int * 6), ("datatype", C.c_int * 6), ("is_bigendian", C.c_int), ("strict", C.c_int)]
+
+
+class Pc2Field(C.Structure):
+    _fields_ = [("name", C.c_char * 16), ("offset", C.c_int), ("datatype", C.c_int), ("count", C.c_int)]
+
+
 class MapregGround(C.Structure):
     _fields_ = [("last_v1", C.c_double * 3), ("last_v2", C.c_double * 3), ("last_norm", C.c_double * 3), ("last_distance", C.c_double),
                 ("cur_norm", C.c_double * 3), ("cur_distance", C.c_double), ("q_history", C.c_double * 4), ("last_q", C.c_double * 4),
@@ -77,7 +85,7 @@ SYMBOLS = [
     "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
-    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
 _lib = None
@@ -141,6 +149,11 @@ def load():
     L.rgc_deskew.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, C.c_int]
     L.rgc_voxelgrid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, ip, C.c_int]
     L.rgc_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, vp, C.c_int]
+    L.rgc_pc2_unpack.argtypes = [vp, vp, C.c_int, C.POINTER(Pc2Layout), vp, vp, vp, C.c_int]
+    L.rgc_pc2_pack.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp]
+    L.rgc_pc2_point_fields.argtypes = [C.c_int, C.POINTER(Pc2Field), C.c_int, ip]
+    L.rgc_tum_line.argtypes = [C.c_double, dp, dp, C.c_char_p, C.c_int]
+    L.rgc_pcd_write.argtypes = [C.c_char_p, fp, C.c_int, C.c_int]
     L.rgc_mapreg_set_maps.argtypes = [vp, fp, C.c_int, fp, C.c_int, C.c_int]
     L.rgc_mapreg_associate.argtypes = [vp, C.c_int, fp, C.c_int, dp, dp, dp, ip]
     L.rgc_mapreg_optimize.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.POINTER(MapregGround), C.POINTER(MapregGround), dp,

@@ -1537,4 +1537,69 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
   return RGC_OK;
 }
 
+// ---- f3: PointCloud2 <-> device arrays ---------------------------------------------------------------------------------
+int rgc_pc2_unpack(rgc_ctx* c, const void* data, int n, const rgc_pc2_layout* L, float* xyzi_out, int* ring_out, float* time_out,
+                   int out_on_device) {
+  if (!c || !data || !L || !xyzi_out || n < 0) return RGC_ERR_INVALID;
+  if (L->point_step <= 0) return fail(c, RGC_ERR_INVALID, "point_step must be positive");
+  rgck::Pc2Layout K{};
+  K.point_step = L->point_step;
+  K.big_endian = L->is_bigendian ? 1 : 0;
+  for (int f = 0; f < 6; f++) {
+    int off = L->offset[f], ty = L->datatype[f];
+    if (off >= 0) {
+      if (ty < 1 || ty > 8) return fail(c, RGC_ERR_INVALID, "field %d: unknown PointField datatype %d", f, ty);
+      const int size = (ty == 1 || ty == 2) ? 1 : (ty == 3 || ty == 4) ? 2 : (ty == 8 ? 8 : 4);
+      if (off + size > L->point_step) return fail(c, RGC_ERR_INVALID, "field %d runs past point_step", f);
+      // fromROSMsg<PointXYZI> maps x, y, z, intensity only from FLOAT32 fields (a mismatching datatype leaves the default)
+      if (L->strict && f < 4 && ty != 7) off = -1;
+    }
+    K.off[f] = off;
+    K.type[f] = ty;
+  }
+  if (n == 0) return RGC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t bytes = (size_t)n * L->point_step;
+  int rc;
+  if ((rc = ensure(c, c->pre_in, bytes))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->pre_in.p, data, bytes, hipMemcpyHostToDevice, s));
+  float4* d_xyzi;
+  int* d_ring = nullptr;
+  float* d_time = nullptr;
+  if (out_on_device) {
+    d_xyzi = (float4*)xyzi_out; d_ring = ring_out; d_time = time_out;
+  } else {
+    if ((rc = ensure(c, c->pre_out, (size_t)n * 24))) return rc;
+    d_xyzi = (float4*)c->pre_out.p;
+    if (ring_out) d_ring = (int*)((char*)c->pre_out.p + (size_t)n * 16);
+    if (time_out) d_time = (float*)((char*)c->pre_out.p + (size_t)n * 20);
+  }
+  rgck::pc2_unpack(s, (const unsigned char*)c->pre_in.p, n, K, d_xyzi, d_ring, d_time);
+  if (!out_on_device) {
+    HIPCHK(c, hipMemcpyAsync(xyzi_out, d_xyzi, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+    if (ring_out) HIPCHK(c, hipMemcpyAsync(ring_out, d_ring, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (time_out) HIPCHK(c, hipMemcpyAsync(time_out, d_time, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return RGC_OK;
+}
+
+int rgc_pc2_pack(rgc_ctx* c, int kind, const float* in, int n, int in_on_device, void* data_out) {
+  if (!c || !in || !data_out || n < 0 || (kind != 0 && kind != 1)) return RGC_ERR_INVALID;
+  if (n == 0) return RGC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int cols = kind == 0 ? 4 : 5, step = kind == 0 ? 32 : 48;
+  const float* d_in;
+  int rc = stage_in(c, in, n, cols * 4, in_on_device, &d_in);
+  if (rc) return rc;
+  if ((rc = ensure(c, c->pre_out, (size_t)n * step))) return rc;
+  rgck::pc2_pack(c->stream, d_in, cols, n, kind, (unsigned char*)c->pre_out.p);
+  HIPCHK(c, hipMemcpyAsync(data_out, c->pre_out.p, (size_t)n * step, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return RGC_OK;
+}
+
 }  // extern "C"

@@ -3,6 +3,7 @@
 // and the pose composition + gravity blend (B8).  Part of librgc_hip.so (C-ABI in include/rgc_hip.h); needs no GPU.
 // Reference citations are relative to /root/reference/rgc_slam/.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 #include "../../include/rgc_hip.h"
@@ -338,6 +339,63 @@ int rgc_extract_pose(const float T[16], double q_xyzw[4], double t[3]) {
   for (int a = 0; a < 4; a++) q_xyzw[a] = (double)qf[a];
   t[0] = (double)T[3]; t[1] = (double)T[7]; t[2] = (double)T[11];
   return RGC_OK;
+}
+
+// ---- f3: the message field tables and the two files the odometer writes ------------------------------------------------
+// pcl::toROSMsg -> pcl::toPCLPointCloud2 emits one PointField per registered field of the point type [3P-memory: PCL
+// point_types.hpp]: PointXYZI = x y z intensity (offsets 0 4 8 16, 32-byte points), PointXYZINormal = x y z intensity
+// normal_x normal_y normal_z curvature (offsets 0 4 8 32 16 20 24 36, 48-byte points); all FLOAT32, count 1.
+int rgc_pc2_point_fields(int kind, rgc_pc2_field* out, int cap, int* point_step) {
+  static const struct { const char* name; int off; } xyzi[4] = {{"x", 0}, {"y", 4}, {"z", 8}, {"intensity", 16}};
+  static const struct { const char* name; int off; } xyzin[8] = {{"x", 0}, {"y", 4}, {"z", 8}, {"intensity", 32}, {"normal_x", 16},
+                                                                {"normal_y", 20}, {"normal_z", 24}, {"curvature", 36}};
+  if (kind != 0 && kind != 1) return RGC_ERR_INVALID;
+  const int nf = kind == 0 ? 4 : 8;
+  if (point_step) *point_step = kind == 0 ? 32 : 48;
+  if (!out) return nf;
+  if (cap < nf) return RGC_ERR_INVALID;
+  for (int i = 0; i < nf; i++) {
+    const char* nm = kind == 0 ? xyzi[i].name : xyzin[i].name;
+    memset(out[i].name, 0, sizeof(out[i].name));
+    strncpy(out[i].name, nm, sizeof(out[i].name) - 1);
+    out[i].offset = kind == 0 ? xyzi[i].off : xyzin[i].off;
+    out[i].datatype = 7;
+    out[i].count = 1;
+  }
+  return nf;
+}
+
+// RGC_odometer.cpp:1315-1316: std::fixed << setprecision(6) << stamp << " " << setprecision(9) << t ... q (x y z w) << endl
+int rgc_tum_line(double stamp, const double t[3], const double q[4], char* buf, int cap) {
+  if (!t || !q || !buf || cap <= 0) return RGC_ERR_INVALID;
+  const int n = snprintf(buf, (size_t)cap, "%.6f %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", stamp, t[0], t[1], t[2], q[0], q[1], q[2], q[3]);
+  return (n < 0 || n >= cap) ? RGC_ERR_INVALID : n;
+}
+
+// pcl::io::savePCDFileASCII(file, cloud) = PCDWriter::writeASCII(..., precision 8) [3P-memory: PCL pcd_io]: header lines
+// exactly as below, then one "x y z intensity" line per point written through an ostream with precision(8) and the default
+// (%g-like) float format; NaN is written as "nan".  binary = 1: the same header with DATA binary and 16 raw bytes per point.
+int rgc_pcd_write(const char* path, const float* xyzi, int n, int binary) {
+  if (!path || (!xyzi && n > 0) || n < 0) return RGC_ERR_INVALID;
+  FILE* f = fopen(path, "wb");
+  if (!f) return RGC_ERR_INVALID;
+  fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+             "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n", n, n, binary ? "binary" : "ascii");
+  int ok = 1;
+  if (binary) {
+    if (n > 0) ok = fwrite(xyzi, 16, (size_t)n, f) == (size_t)n;
+  } else {
+    for (int i = 0; i < n && ok; i++) {
+      for (int a = 0; a < 4; a++) {
+        const float v = xyzi[4 * (size_t)i + a];
+        if (std::isnan(v)) ok = ok && fputs("nan", f) >= 0;
+        else ok = ok && fprintf(f, "%.8g", (double)v) > 0;
+        ok = ok && fputc(a == 3 ? '\n' : ' ', f) != EOF;
+      }
+    }
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? RGC_OK : RGC_ERR_INVALID;
 }
 
 }  // extern "C"

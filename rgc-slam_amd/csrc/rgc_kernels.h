@@ -102,6 +102,10 @@ void unsort3(hipStream_t s, const double* a, const double* b, const double* c, c
 int  linearize_blocks(int n);
 int  fitness_blocks(int n);
 // ---- B2 / B3 / B9 (rgc_pre.hip) ----
+// ---- f3: sensor_msgs/PointCloud2 <-> device arrays; fields in the order x, y, z, intensity, ring, time (offset < 0: absent) ----
+struct Pc2Layout { int point_step; int off[6]; int type[6]; int big_endian; };
+void pc2_unpack(hipStream_t s, const unsigned char* data, int n, const Pc2Layout& L, float4* xyzi, int* ring, float* time);
+void pc2_pack(hipStream_t s, const float* in, int cols, int n, int kind, unsigned char* out);
 void deskew(hipStream_t s, float* xyzi, int stride_f, int n, Quat qinv, const double t[3]);
 void transform_q(hipStream_t s, const float* in, int stride_f, int n, Quat q, const double t[3], float* out, int ostride_f);
 void vg_bbox(hipStream_t s, const float* in, int stride_f, int n, float inv, int* mm6, int* flags);

@@ -170,4 +170,71 @@ void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int*
   hipLaunchKernelGGL(k_vg_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order, first, outpos, out, n_out);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// f3  sensor_msgs/PointCloud2 <-> device arrays (pcl::fromROSMsg at src/scanRegistration.cpp:107-108, pcl::toROSMsg at
+// :689-727 and src/RGC_odometer.cpp:1348).  One lane per point: the fields are gathered from the message's byte layout
+// (offset + PointField datatype per field, either endianness) straight into the float4 {x, y, z, intensity} the front-end
+// consumes, plus the Velodyne driver's `ring` / `time` fields when present -- no PCL, no host-side repacking.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pc2_load(const unsigned char* p, int type, int big) {
+  unsigned char b[8];
+  const int size = (type == 1 || type == 2) ? 1 : (type == 3 || type == 4) ? 2 : (type == 8 ? 8 : 4);
+  for (int i = 0; i < size; i++) b[i] = big ? p[size - 1 - i] : p[i];
+  switch (type) {  // sensor_msgs/PointField: INT8=1 UINT8=2 INT16=3 UINT16=4 INT32=5 UINT32=6 FLOAT32=7 FLOAT64=8
+    case 1: return (double)(signed char)b[0];
+    case 2: return (double)b[0];
+    case 3: return (double)(short)(b[0] | (b[1] << 8));
+    case 4: return (double)(unsigned short)(b[0] | (b[1] << 8));
+    case 5: return (double)(int)(b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24));
+    case 6: return (double)(unsigned)(b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24));
+    case 7: return (double)__uint_as_float(b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24));
+    case 8: {
+      unsigned long long u = 0;
+      for (int i = 0; i < 8; i++) u |= (unsigned long long)b[i] << (8 * i);
+      return __longlong_as_double((long long)u);
+    }
+  }
+  return 0.0;
+}
+
+__global__ void k_pc2_unpack(const unsigned char* __restrict__ data, int n, Pc2Layout L, float4* __restrict__ xyzi, int* __restrict__ ring,
+                             float* __restrict__ time) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* p = data + (size_t)i * L.point_step;
+  float v[4];
+#pragma unroll
+  for (int f = 0; f < 4; f++) v[f] = L.off[f] >= 0 ? (float)pc2_load(p + L.off[f], L.type[f], L.big_endian) : 0.0f;
+  xyzi[i] = make_float4(v[0], v[1], v[2], v[3]);
+  if (ring) ring[i] = L.off[4] >= 0 ? (int)pc2_load(p + L.off[4], L.type[4], L.big_endian) : -1;
+  if (time) time[i] = L.off[5] >= 0 ? (float)pc2_load(p + L.off[5], L.type[5], L.big_endian) : 0.0f;
+}
+
+// pcl::toROSMsg of a PointXYZI (kind 0: 32-byte points, x y z @0 4 8, data[3] = 1.0f @12, intensity @16) or PointXYZINormal
+// cloud (kind 1: 48-byte points, normal_x y z @16 20 24, intensity @32, curvature @36); in = cols floats per point:
+// x, y, z, intensity[, normal_x]
+__global__ void k_pc2_pack(const float* __restrict__ in, int cols, int n, int kind, unsigned char* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* q = in + (size_t)i * cols;
+  const int step = kind == 0 ? 32 : 48;
+  float* o = reinterpret_cast<float*>(out + (size_t)i * step);
+  for (int w = 0; w < step / 4; w++) o[w] = 0.0f;
+  o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = 1.0f;
+  if (kind == 0) {
+    o[4] = q[3];
+  } else {
+    o[4] = cols > 4 ? q[4] : 0.0f;  // normal_x carries the feature weight (scanRegistration.cpp:501,554,609)
+    o[8] = q[3];                    // intensity
+  }
+}
+
+void pc2_unpack(hipStream_t s, const unsigned char* data, int n, const Pc2Layout& L, float4* xyzi, int* ring, float* time) {
+  if (n > 0) hipLaunchKernelGGL(k_pc2_unpack, dim3((n + 255) / 256), dim3(256), 0, s, data, n, L, xyzi, ring, time);
+}
+void pc2_pack(hipStream_t s, const float* in, int cols, int n, int kind, unsigned char* out) {
+  if (n > 0) hipLaunchKernelGGL(k_pc2_pack, dim3((n + 255) / 256), dim3(256), 0, s, in, cols, n, kind, out);
+}
+
 }  // namespace rgck
