@@ -246,6 +246,27 @@ RGC_API int rgc_tum_line(double stamp, const double t[3], const double q_xyzw[4]
  * pcl::io::savePCDFileASCII (precision 8), binary = 1 -> DATA binary, 16 bytes per point (FIELDS x y z intensity). */
 RGC_API int rgc_pcd_write(const char* path, const float* xyzi, int n, int binary);
 
+/* ---- f4: loop-closure ICP = pcl::IterativeClosestPoint<PointType2,PointType2> as configured and used at
+ * src/RGC_mapping.cpp:2050-2069: setMaxCorrespondenceDistance, setMaximumIterations(100), setTransformationEpsilon(1e-6),
+ * setEuclideanFitnessEpsilon(1e-6), setRANSACIterations(0); setInputSource(latestKeyFrameCloud), setInputTarget(
+ * nearHistoryKeyFrameCloud), align() with the identity guess, hasConverged(), getFitnessScore(), getFinalTransformation(). */
+typedef struct rgc_icp_params {
+  int max_iterations;                 /* 100 */
+  double max_correspondence_distance; /* poseGraphSearchRadius * 2 */
+  double transformation_epsilon;      /* 1e-6: translation^2 <= eps and cos(angle) >= 1 - eps */
+  double euclidean_fitness_epsilon;   /* 1e-6: relative change of the correspondence MSE */
+} rgc_icp_params;
+enum { RGC_ICP_NOT_CONVERGED = 0, RGC_ICP_ITERATIONS = 1, RGC_ICP_TRANSFORM = 2, RGC_ICP_ABS_MSE = 3, RGC_ICP_REL_MSE = 4,
+       RGC_ICP_NO_CORRESPONDENCES = 5 };   /* pcl::registration::DefaultConvergenceCriteria::ConvergenceState */
+typedef struct rgc_icp_result {
+  int iterations, converged, state, n_correspondences;
+  double fitness;                     /* getFitnessScore(): mean squared nearest-neighbour distance at the final transformation */
+} rgc_icp_result;
+RGC_API void rgc_default_icp_params(rgc_icp_params* p);
+/* source / target: host AoS, x,y,z first, same stride.  final_T: row-major 4x4 float (getFinalTransformation()). */
+RGC_API int rgc_icp_align(rgc_ctx* ctx, const float* source, int n_source, const float* target, int n_target, int stride_bytes,
+                          const rgc_icp_params* params, float final_T[16], rgc_icp_result* result);
+
 /* ---- f1: scan-to-map FEATURE registration of the mapping node, src/RGC_mapping.cpp:1069-1358 ----
  * Replaces, per mapping frame: kdtreeCornerFromMap/kdtreeSurfFromMap->setInputCloud (:1073-1074), the four association
  * loops (:1092-1282: pointAssociateToMap, 5-NN, PCA line test / QR plane fit) and ceres::Solve over para_q/para_t and

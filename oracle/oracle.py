@@ -52,6 +52,15 @@ class PlaneFactor(C.Structure):
     _fields_ = [("valid", C.c_int), ("pad", C.c_int), ("n", C.c_double * 3), ("d", C.c_double), ("var", C.c_double)]
 
 
+class IcpParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("pad", C.c_int), ("max_corr_dist", C.c_double), ("transformation_eps", C.c_double),
+                ("fitness_eps", C.c_double)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("state", C.c_int), ("n_correspondences", C.c_int), ("fitness", C.c_double)]
+
+
 class MapregGround(C.Structure):
     _fields_ = [("last_v1", C.c_double * 3), ("last_v2", C.c_double * 3), ("last_norm", C.c_double * 3), ("last_distance", C.c_double),
                 ("cur_norm", C.c_double * 3), ("cur_distance", C.c_double), ("q_history", C.c_double * 4), ("last_q", C.c_double * 4),
@@ -133,6 +142,8 @@ def lib():
         L.orc_so3_exp.argtypes = [dp, dp]
         L.orc_is_converged.argtypes = [dp, C.c_double, C.c_double]
         L.orc_transform_f32.argtypes = [fp, C.c_int, C.c_int, fp, fp]
+        L.orc_icp_align.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.POINTER(IcpParams), fp, C.POINTER(IcpResult), C.c_int]
+        L.orc_rigid_from_sums.argtypes = [C.c_double, dp, dp, dp, dp, dp]
         L.orc_knn_query.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, ip, fp, C.c_int]
         ef, pf, tr = C.POINTER(EdgeFactor), C.POINTER(PlaneFactor), C.POINTER(MapregTrace)
         L.orc_mapreg_associate_edges.argtypes = [fp, C.c_int, dp, dp, fp, C.c_int, C.c_int, ef, C.c_int]
@@ -359,6 +370,20 @@ def mapreg_optimize(corner_cur, surf_cur, corner_last, surf_last, corner_map, su
     if rc < 0:
         raise RuntimeError(f"orc_mapreg_optimize rc={rc}")
     return x, rc, [{k: getattr(t, k) for k, _ in MapregTrace._fields_ if k != "pad"} for t in tr]
+
+
+def icp_align(source, target, max_corr_dist=10.0, max_iterations=100, transformation_eps=1e-6, fitness_eps=1e-6, threads=0):
+    """pcl::IterativeClosestPoint as configured at RGC_mapping.cpp:2050-2069 -> (final_T (4,4) float32, dict)"""
+    s, sp = _f32(source)
+    g, gp = _f32(target)
+    prm = IcpParams(max_iterations, 0, max_corr_dist, transformation_eps, fitness_eps)
+    T = np.zeros(16, np.float32)
+    res = IcpResult()
+    rc = lib().orc_icp_align(sp, s.shape[0], s.shape[1], gp, g.shape[0], g.shape[1], C.byref(prm), T.ctypes.data_as(C.POINTER(C.c_float)),
+                             C.byref(res), threads)
+    if rc:
+        raise RuntimeError(f"orc_icp_align rc={rc}")
+    return T.reshape(4, 4), {k: getattr(res, k) for k, _ in IcpResult._fields_}
 
 
 class Registration:

@@ -999,3 +999,143 @@ int orc_voxelgrid_filter(const float* p, int n, float leaf, float* out) {
   free(pr);
   return no;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * f4: loop-closure ICP, pcl::IterativeClosestPoint as configured at src/RGC_mapping.cpp:2050-2069
+ * (setMaxCorrespondenceDistance, setMaximumIterations(100), setTransformationEpsilon(1e-6),
+ * setEuclideanFitnessEpsilon(1e-6), setRANSACIterations(0)), align() with the identity guess and getFitnessScore().
+ * PCL is not installable here: the loop below restates IterativeClosestPoint::computeTransformation,
+ * CorrespondenceEstimation::determineCorrespondences (1-NN, kept if d^2 <= max_dist^2), TransformationEstimationSVD
+ * (Umeyama without scale) and DefaultConvergenceCriteria::hasConverged (PCL 1.8-1.10) [3P-memory].  PCL accumulates the
+ * centroids and the 3x3 correlation in float in cloud order; here they are accumulated in fp64 (the GPU path sums in a
+ * different order anyway) and the per-iteration transform is cast to float like PCL's Matrix4f.
+ * ------------------------------------------------------------------------------------------ */
+static void mat4f_mul(const float A[16], const float B[16], float C[16]) {
+  float t[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      float s = 0.0f;
+      for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j];
+      t[i * 4 + j] = s;
+    }
+  memcpy(C, t, sizeof(t));
+}
+
+/* rotation R and translation t minimising sum |R p + t - q|^2 from the sums n, sum p, sum q, sum p q^T (Kabsch / Umeyama) */
+void orc_rigid_from_sums(double n, const double sp[3], const double sq[3], const double spq[9], double R[9], double t[3]) {
+  double cp[3], cq[3], H[9];
+  for (int a = 0; a < 3; a++) { cp[a] = sp[a] / n; cq[a] = sq[a] / n; }
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) H[a * 3 + b] = spq[a * 3 + b] - n * cp[a] * cq[b]; /* sum (p - cp)(q - cq)^T */
+  /* SVD of H through the eigen decomposition of H^T H: H = U S V^T, R = V diag(1, 1, det) U^T */
+  double HtH[9] = {0}, ev[3], V[9];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++)
+      for (int k = 0; k < 3; k++) HtH[a * 3 + b] += H[k * 3 + a] * H[k * 3 + b];
+  orc_eig3(HtH, ev, V); /* descending, V columns */
+  double U[9];
+  for (int j = 0; j < 2; j++) {
+    double u[3] = {0, 0, 0};
+    for (int a = 0; a < 3; a++)
+      for (int k = 0; k < 3; k++) u[a] += H[a * 3 + k] * V[k * 3 + j];
+    double nn = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    if (!(nn > 1e-300)) { /* rank deficient: any unit vector orthogonal to the previous columns */
+      if (j == 0) { u[0] = 1; u[1] = 0; u[2] = 0; }
+      else {
+        const double a0 = fabs(U[0]), a1 = fabs(U[3]), a2 = fabs(U[6]);
+        double e[3] = {a0 <= a1 && a0 <= a2 ? 1.0 : 0.0, a1 < a0 && a1 <= a2 ? 1.0 : 0.0, 0.0};
+        if (e[0] == 0.0 && e[1] == 0.0) e[2] = 1.0;
+        u[0] = U[3] * e[2] - U[6] * e[1]; u[1] = U[6] * e[0] - U[0] * e[2]; u[2] = U[0] * e[1] - U[3] * e[0];
+      }
+      nn = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    }
+    for (int a = 0; a < 3; a++) U[a * 3 + j] = u[a] / nn;
+  }
+  /* third columns complete right-handed bases; the reflection fix of Umeyama is then implicit: R = V' U'^T with
+   * V' = [v0 v1 v0 x v1], U' = [u0 u1 u0 x u1] is a proper rotation that agrees with V diag(1,1,det) U^T */
+  U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
+  double Vp[9];
+  memcpy(Vp, V, sizeof(Vp));
+  Vp[2] = V[3] * V[7] - V[6] * V[4]; Vp[5] = V[6] * V[1] - V[0] * V[7]; Vp[8] = V[0] * V[4] - V[3] * V[1];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double v = 0;
+      for (int k = 0; k < 3; k++) v += Vp[a * 3 + k] * U[b * 3 + k];
+      R[a * 3 + b] = v;
+    }
+  for (int a = 0; a < 3; a++) t[a] = cq[a] - (R[a * 3] * cp[0] + R[a * 3 + 1] * cp[1] + R[a * 3 + 2] * cp[2]);
+}
+
+int orc_icp_align(const float* src, int ns, int sstride, const float* tgt, int nt_, int tstride, const orc_icp_params* prm, float final_T[16],
+                  orc_icp_result* res, int num_threads) {
+  if (!src || !tgt || !prm || !final_T || !res || ns < 1 || nt_ < 1) return -1;
+  grid_t g;
+  if (grid_build(&g, tgt, nt_, tstride, 1) < 0) return -2;
+  int nth = clip_threads(num_threads);
+  (void)nth;
+  float* cur = (float*)malloc(sizeof(float) * 3 * (size_t)ns);
+  int* nn = (int*)malloc(sizeof(int) * (size_t)ns);
+  float* d2 = (float*)malloc(sizeof(float) * (size_t)ns);
+  for (int i = 0; i < ns; i++)
+    for (int a = 0; a < 3; a++) cur[3 * i + a] = src[(size_t)i * sstride + a];
+  float fin[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const double max_d2 = prm->max_corr_dist * prm->max_corr_dist;
+  const double rot_thr = 1.0 - prm->transformation_eps, trans_thr = prm->transformation_eps;
+  double prev_mse = DBL_MAX;
+  memset(res, 0, sizeof(*res));
+  for (;;) {
+#pragma omp parallel for num_threads(nth) schedule(dynamic, 256)
+    for (int i = 0; i < ns; i++) grid_knn(&g, cur + 3 * (size_t)i, 1, &nn[i], &d2[i]);
+    double cnt = 0, sp[3] = {0, 0, 0}, sq[3] = {0, 0, 0}, spq[9] = {0}, sd = 0;
+    for (int i = 0; i < ns; i++) {
+      if ((double)d2[i] > max_d2) continue;
+      const float* p = cur + 3 * (size_t)i;
+      const float* q = tgt + (size_t)nn[i] * tstride;
+      cnt += 1;
+      sd += (double)d2[i];
+      for (int a = 0; a < 3; a++) {
+        sp[a] += (double)p[a]; sq[a] += (double)q[a];
+        for (int b = 0; b < 3; b++) spq[a * 3 + b] += (double)p[a] * (double)q[b];
+      }
+    }
+    res->n_correspondences = (int)cnt;
+    if (cnt < 3) { res->converged = 0; res->state = ORC_ICP_NO_CORRESPONDENCES; break; }
+    double R[9], t[3];
+    orc_rigid_from_sums(cnt, sp, sq, spq, R, t);
+    float T[16] = {(float)R[0], (float)R[1], (float)R[2], (float)t[0], (float)R[3], (float)R[4], (float)R[5], (float)t[1],
+                   (float)R[6], (float)R[7], (float)R[8], (float)t[2], 0, 0, 0, 1};
+    float* nxt = (float*)malloc(sizeof(float) * 3 * (size_t)ns);
+    orc_transform_f32(cur, ns, 3, T, nxt);
+    free(cur);
+    cur = nxt;
+    mat4f_mul(T, fin, fin);
+    res->iterations++;
+    /* DefaultConvergenceCriteria::hasConverged */
+    if (res->iterations >= prm->max_iterations) { res->converged = 1; res->state = ORC_ICP_ITERATIONS; break; }
+    const double cos_angle = 0.5 * ((double)T[0] + (double)T[5] + (double)T[10] - 1.0);
+    const double tr2 = (double)T[3] * T[3] + (double)T[7] * T[7] + (double)T[11] * T[11];
+    if (cos_angle >= rot_thr && tr2 <= trans_thr) { res->converged = 1; res->state = ORC_ICP_TRANSFORM; break; }
+    const double mse = sd / cnt;
+    if (fabs(mse - prev_mse) < 1e-12) { res->converged = 1; res->state = ORC_ICP_ABS_MSE; break; }
+    if (fabs(mse - prev_mse) / prev_mse < prm->fitness_eps) { res->converged = 1; res->state = ORC_ICP_REL_MSE; break; }
+    prev_mse = mse;
+  }
+  /* getFitnessScore(): the source transformed by the final transformation (fp32), mean squared 1-NN distance */
+  {
+    float* tmp = (float*)malloc(sizeof(float) * 3 * (size_t)ns);
+    float* s3 = (float*)malloc(sizeof(float) * 3 * (size_t)ns);
+    for (int i = 0; i < ns; i++)
+      for (int a = 0; a < 3; a++) s3[3 * i + a] = src[(size_t)i * sstride + a];
+    orc_transform_f32(s3, ns, 3, fin, tmp);
+#pragma omp parallel for num_threads(nth) schedule(dynamic, 256)
+    for (int i = 0; i < ns; i++) grid_knn(&g, tmp + 3 * (size_t)i, 1, &nn[i], &d2[i]);
+    double s = 0;
+    for (int i = 0; i < ns; i++) s += (double)d2[i];
+    res->fitness = s / (double)ns;
+    free(tmp); free(s3);
+  }
+  memcpy(final_T, fin, sizeof(fin));
+  free(cur); free(nn); free(d2);
+  grid_free(&g);
+  return 0;
+}

@@ -158,6 +158,15 @@ int orc_mapreg_optimize(const float* corner_cur, int n_ccur, const float* surf_c
                         int mstride, const orc_mapreg_ground* ground_cur, const orc_mapreg_ground* ground_last, double poses[14],
                         orc_mapreg_trace trace[2], int num_threads);
 
+/* ---- f4: loop-closure ICP = pcl::IterativeClosestPoint as used at src/RGC_mapping.cpp:2050-2069 (restated, see rgc_oracle.c) ---- */
+enum { ORC_ICP_NOT_CONVERGED = 0, ORC_ICP_ITERATIONS = 1, ORC_ICP_TRANSFORM = 2, ORC_ICP_ABS_MSE = 3, ORC_ICP_REL_MSE = 4, ORC_ICP_NO_CORRESPONDENCES = 5 };
+typedef struct { int max_iterations; int pad; double max_corr_dist, transformation_eps, fitness_eps; } orc_icp_params;
+typedef struct { int iterations, converged, state, n_correspondences; double fitness; } orc_icp_result;
+/* source -> target, identity guess; final_T row-major 4x4 float (icp.getFinalTransformation()); result.fitness = getFitnessScore() */
+int orc_icp_align(const float* src, int ns, int sstride, const float* tgt, int nt, int tstride, const orc_icp_params* prm, float final_T[16],
+                  orc_icp_result* res, int num_threads);
+void orc_rigid_from_sums(double n, const double sp[3], const double sq[3], const double spq[9], double R[9], double t[3]);
+
 /* ---- C7 helpers ---- */
 void orc_so3_exp(const double omega[3], double q_wxyz[4]);                 /* so3/so3.hpp:58-77 */
 int  orc_is_converged(const double delta[16], double rot_eps, double trans_eps); /* lsq_registration_impl.hpp:82-91 */

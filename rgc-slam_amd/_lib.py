@@ -57,6 +57,15 @@ class MapregReport(C.Structure):
                 ("n_edge_cur", C.c_int), ("n_plane_cur", C.c_int), ("n_edge_last", C.c_int), ("n_plane_last", C.c_int)]
 
 
+class IcpParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("max_correspondence_distance", C.c_double), ("transformation_epsilon", C.c_double),
+                ("euclidean_fitness_epsilon", C.c_double)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("state", C.c_int), ("n_correspondences", C.c_int), ("fitness", C.c_double)]
+
+
 class Pc2Layout(C.Structure):
     _fields_ = [("point_step", C.c_int), ("offset", C.c_int * 6), ("datatype", C.c_int * 6), ("is_bigendian", C.c_int), ("strict", C.c_int)]
 
@@ -85,7 +94,7 @@ SYMBOLS = [
     "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
-    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
 _lib = None
@@ -149,6 +158,9 @@ def load():
     L.rgc_deskew.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, C.c_int]
     L.rgc_voxelgrid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, ip, C.c_int]
     L.rgc_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, vp, C.c_int]
+    L.rgc_default_icp_params.argtypes = [C.POINTER(IcpParams)]
+    L.rgc_default_icp_params.restype = None
+    L.rgc_icp_align.argtypes = [vp, fp, C.c_int, fp, C.c_int, C.c_int, C.POINTER(IcpParams), fp, C.POINTER(IcpResult)]
     L.rgc_pc2_unpack.argtypes = [vp, vp, C.c_int, C.POINTER(Pc2Layout), vp, vp, vp, C.c_int]
     L.rgc_pc2_pack.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp]
     L.rgc_pc2_point_fields.argtypes = [C.c_int, C.POINTER(Pc2Field), C.c_int, ip]

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1599,6 +1600,141 @@ int rgc_pc2_pack(rgc_ctx* c, int kind, const float* in, int n, int in_on_device,
   HIPCHK(c, hipMemcpyAsync(data_out, c->pre_out.p, (size_t)n * step, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
+  return RGC_OK;
+}
+
+// ---- f4: loop-closure ICP (pcl::IterativeClosestPoint as configured at RGC_mapping.cpp:2050-2069) -----------------------------
+// R, t minimising sum |R p + t - q|^2 from n, sum p, sum q, sum p q^T (TransformationEstimationSVD = Umeyama without scale): SVD of
+// the centred correlation through the eigen decomposition of H^T H
+static void rigid_from_sums(double n, const double sp[3], const double sq[3], const double spq[9], double R[9], double t[3]) {
+  double cp[3], cq[3], H[9];
+  for (int a = 0; a < 3; a++) { cp[a] = sp[a] / n; cq[a] = sq[a] / n; }
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) H[a * 3 + b] = spq[a * 3 + b] - n * cp[a] * cq[b];
+  double HtH[9] = {0};
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++)
+      for (int k = 0; k < 3; k++) HtH[a * 3 + b] += H[k * 3 + a] * H[k * 3 + b];
+  const double S6[6] = {HtH[0], 0.5 * (HtH[1] + HtH[3]), 0.5 * (HtH[2] + HtH[6]), HtH[4], 0.5 * (HtH[5] + HtH[7]), HtH[8]};
+  double ev[3], Va[9], V[9];
+  host_eig3_sym(S6, ev, Va);  // ascending
+  for (int a = 0; a < 3; a++) { V[a * 3 + 0] = Va[a * 3 + 2]; V[a * 3 + 1] = Va[a * 3 + 1]; V[a * 3 + 2] = Va[a * 3 + 0]; }  // descending
+  double U[9];
+  for (int j = 0; j < 2; j++) {
+    double w[3] = {0, 0, 0};
+    for (int a = 0; a < 3; a++)
+      for (int k = 0; k < 3; k++) w[a] += H[a * 3 + k] * V[k * 3 + j];
+    double nn = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (!(nn > 1e-300)) {  // rank deficient: any unit vector orthogonal to the previous column
+      if (j == 0) { w[0] = 1; w[1] = 0; w[2] = 0; }
+      else {
+        const double a0 = std::fabs(U[0]), a1 = std::fabs(U[3]), a2 = std::fabs(U[6]);
+        double e[3] = {a0 <= a1 && a0 <= a2 ? 1.0 : 0.0, a1 < a0 && a1 <= a2 ? 1.0 : 0.0, 0.0};
+        if (e[0] == 0.0 && e[1] == 0.0) e[2] = 1.0;
+        w[0] = U[3] * e[2] - U[6] * e[1]; w[1] = U[6] * e[0] - U[0] * e[2]; w[2] = U[0] * e[1] - U[3] * e[0];
+      }
+      nn = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    }
+    for (int a = 0; a < 3; a++) U[a * 3 + j] = w[a] / nn;
+  }
+  // right-handed completions: R = [v0 v1 v0xv1] [u0 u1 u0xu1]^T is the proper rotation V diag(1, 1, det) U^T
+  U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
+  V[2] = V[3] * V[7] - V[6] * V[4]; V[5] = V[6] * V[1] - V[0] * V[7]; V[8] = V[0] * V[4] - V[3] * V[1];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double v = 0;
+      for (int k = 0; k < 3; k++) v += V[a * 3 + k] * U[b * 3 + k];
+      R[a * 3 + b] = v;
+    }
+  for (int a = 0; a < 3; a++) t[a] = cq[a] - (R[a * 3] * cp[0] + R[a * 3 + 1] * cp[1] + R[a * 3 + 2] * cp[2]);
+}
+
+void rgc_default_icp_params(rgc_icp_params* p) {
+  if (!p) return;
+  p->max_iterations = 100;                    // :2053
+  p->max_correspondence_distance = 10.0;      // poseGraphSearchRadius * 2 with historyKeyframeSearchRadius = 5 (:155, :2052)
+  p->transformation_epsilon = 1e-6;           // :2054
+  p->euclidean_fitness_epsilon = 1e-6;        // :2055
+}
+
+int rgc_icp_align(rgc_ctx* c, const float* source, int ns, const float* target, int nt, int stride_bytes, const rgc_icp_params* prm,
+                  float final_T[16], rgc_icp_result* res) {
+  if (!c || !source || !target || !prm || !final_T || !res) return RGC_ERR_INVALID;
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  if (ns < 1 || nt < 1) return fail(c, RGC_ERR_TOO_FEW_POINTS, "ICP needs a non-empty source and target");
+  if (ns > (1 << 27) || nt > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud larger than 2^27 points");
+  if (!(prm->max_correspondence_distance > 0) || prm->max_iterations < 1) return fail(c, RGC_ERR_INVALID, "bad ICP parameters");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  memset(res, 0, sizeof(*res));
+  int rc;
+  // target grid (icp.setInputTarget builds a kd-tree, :2066)
+  Cloud& tg = c->aux;
+  tg.ready = false;
+  {
+    const size_t bytes = (size_t)nt * stride_bytes;
+    if ((rc = ensure(c, tg.in_copy, bytes))) return rc;
+    HIPCHK(c, hipMemcpyAsync(tg.in_copy.p, target, bytes - (stride_bytes - 12), hipMemcpyHostToDevice, s));
+    tg.in = (const float*)tg.in_copy.p;
+    tg.stride_f = stride_bytes / 4;
+    tg.n = nt;
+    if ((rc = prepare_map_grid(c, tg, 1.0))) return rc;
+  }
+  // the source as float4, transformed in place every iteration (pcl::transformPointCloud, fp32)
+  const float* d_src;
+  if ((rc = stage_in(c, source, ns, stride_bytes, 0, &d_src))) return rc;  // the raw source, kept for the fitness score
+  if ((rc = ensure(c, c->pre_out, sizeof(float4) * (size_t)ns))) return rc;
+  float4* cur = (float4*)c->pre_out.p;
+  const rgck::PoseF I{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}};
+  rgck::transform_f32(s, d_src, stride_bytes / 4, ns, I, (float*)cur, 4);  // identity guess: a plain copy to 16-byte points
+  const int nb = rgck::linearize_blocks(ns);
+  if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 2) * (size_t)(nb > 0 ? nb : 1)))) return rc;
+  float fin[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const double rot_thr = 1.0 - prm->transformation_epsilon, trans_thr = prm->transformation_epsilon;
+  double prev_mse = DBL_MAX;
+  for (;;) {
+    rgck::icp_accumulate(s, cur, ns, (const float4*)tg.P.p, (const int*)tg.start.p, tg.grid, prm->max_correspondence_distance,
+                         (double*)c->partials.p, c->d_out);
+    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double) * 17, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    const double* S = c->h_out;
+    const double cnt = S[0];
+    res->n_correspondences = (int)cnt;
+    if (cnt < 3) { res->converged = 0; res->state = RGC_ICP_NO_CORRESPONDENCES; break; }  // min_number_correspondences_
+    double R[9], t[3];
+    rigid_from_sums(cnt, S + 1, S + 4, S + 7, R, t);
+    float T[16] = {(float)R[0], (float)R[1], (float)R[2], (float)t[0], (float)R[3], (float)R[4], (float)R[5], (float)t[1],
+                   (float)R[6], (float)R[7], (float)R[8], (float)t[2], 0, 0, 0, 1};
+    rgck::transform_f32(s, (const float*)cur, 4, ns, posef_from(T), (float*)cur, 4);
+    float nf[16];
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        float v = 0.0f;
+        for (int k = 0; k < 4; k++) v += T[i * 4 + k] * fin[k * 4 + j];
+        nf[i * 4 + j] = v;
+      }
+    memcpy(fin, nf, sizeof(fin));
+    res->iterations++;
+    // DefaultConvergenceCriteria::hasConverged [3P-memory]
+    if (res->iterations >= prm->max_iterations) { res->converged = 1; res->state = RGC_ICP_ITERATIONS; break; }
+    const double cos_angle = 0.5 * ((double)T[0] + (double)T[5] + (double)T[10] - 1.0);
+    const double tr2 = (double)T[3] * T[3] + (double)T[7] * T[7] + (double)T[11] * T[11];
+    if (cos_angle >= rot_thr && tr2 <= trans_thr) { res->converged = 1; res->state = RGC_ICP_TRANSFORM; break; }
+    const double mse = S[16] / cnt;
+    if (std::fabs(mse - prev_mse) < 1e-12) { res->converged = 1; res->state = RGC_ICP_ABS_MSE; break; }
+    if (std::fabs(mse - prev_mse) / prev_mse < prm->euclidean_fitness_epsilon) { res->converged = 1; res->state = RGC_ICP_REL_MSE; break; }
+    prev_mse = mse;
+  }
+  // getFitnessScore(): the ORIGINAL source through the final transformation (fp32), mean squared 1-NN distance
+  rgck::transform_f32(s, d_src, stride_bytes / 4, ns, posef_from(fin), (float*)cur, 4);
+  if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)rgck::fitness_blocks(ns) + 64))) return rc;
+  rgck::fitness(s, cur, ns, I, (const float4*)tg.P.p, (const int*)tg.start.p, tg.grid, (double*)c->fit_partials.p, c->d_out);
+  HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  res->fitness = c->h_out[0] / (double)ns;
+  memcpy(final_T, fin, sizeof(fin));
   return RGC_OK;
 }
 

@@ -93,6 +93,9 @@ int mapreg_blocks(int ne, int np);
 // out56 = per pose {21 upper-triangular H, 6 g, robust cost} (H, g only if want_H); partials: 2 * 28 * max mapreg_blocks doubles
 void mapreg_terms(hipStream_t s, const float* const feat[4], const double* const fac[4], const int nfeat[4], const double x14[14], double huber_a,
                   int want_H, double* partials, double* out56);
+// ---- f4: one ICP iteration (1-NN correspondences within max_dist + the sums of the rigid fit); out28[0..16] = n, sum p, sum q, sum p q^T, sum d^2
+void icp_accumulate(hipStream_t s, const float4* SP, int ns, const float4* TP, const int* tstart, Grid g, double max_dist, double* partials,
+                    double* out28);
 // ---- C8 ----
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials,
              double* out1);

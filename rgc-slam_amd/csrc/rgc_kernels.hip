@@ -2102,15 +2102,12 @@ k_error(const float4* __restrict__ P, int n, Pose T, const double* __restrict__ 
 constexpr int FIT_T = 64;  // one wave per block: 30 k scan points spread over ~470 workgroups instead of 118
 int fitness_blocks(int n) { return (n + FIT_T - 1) / FIT_T; }
 
-// squared distance from the transformed source point i to its nearest target point (exact: the search cube grows until
-// the best distance is provably inside it)
-__device__ __forceinline__ float fitness_point(const float4* __restrict__ SP, int i, const PoseF& T, const float4* __restrict__ TP,
-                                               const int* __restrict__ tstart, const Grid& g) {
-  const float4 sp = SP[i];
-  const float x = sp.x, y = sp.y, z = sp.z;
-  const float px = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
-  const float py = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
-  const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
+// Exact nearest neighbour of (px,py,pz) in the sorted target: own cell first (an aligned point's nearest map point is usually
+// closer than its cell walls), else a cube of cells that grows until the best distance is provably inside it -- or until the
+// unscanned region is farther than cap_r (then nothing within cap_r is missing).  Ties: smaller original index.
+// best = squared distance (INFINITY if none found), bs = position in the sorted array (-1 if none).
+__device__ __forceinline__ void nn_search(float px, float py, float pz, const float4* __restrict__ TP, const int* __restrict__ tstart,
+                                          const Grid& g, double cap_r, float& best, int& bs) {
   const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
   const double q[3] = {(double)px, (double)py, (double)pz};
   int rmax = 0, r = 1;
@@ -2121,42 +2118,51 @@ __device__ __forceinline__ float fitness_point(const float4* __restrict__ SP, in
     r = max(r, max(-c[a], c[a] - (g.dim[a] - 1)));  // first cube that touches the grid when the query lies outside
     inside = inside && c[a] >= 0 && c[a] < g.dim[a];
   }
-  float best = INFINITY;
+  best = INFINITY;
+  bs = -1;
+  int bo = INT_MAX;
+  auto take = [&](const float4& cp, int s) {
+    const float d = dist2(px, py, pz, cp);
+    const int o = __float_as_int(cp.w);
+    if (d < best || (d == best && o < bo)) { best = d; bs = s; bo = o; }
+  };
   auto scan = [&](int s0, int s1) {
     int s = s0;
     unsigned off = (unsigned)s0 << 4;
-    for (; s + 8 <= s1; s += 8, off += 128) {  // eight loads in flight: this kernel is a chain of memory round trips
+    for (; s + 8 <= s1; s += 8, off += 128) {  // eight loads in flight: this search is a chain of memory round trips
       float4 cc[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) cc[u] = point_at(TP, off + 16u * u);
 #pragma unroll
-      for (int u = 0; u < 8; u++) best = fminf(best, dist2(px, py, pz, cc[u]));
+      for (int u = 0; u < 8; u++) take(cc[u], s + u);
     }
-    if (s < s1) {  // 1..7 left: clamped loads (a repeated candidate does not change a minimum)
-      const unsigned last = (unsigned)(s1 - 1) << 4;
+    if (s < s1) {  // 1..7 left: clamped loads (a repeated candidate changes neither the minimum nor its index)
+      const int last = s1 - 1;
       float4 cc[7];
 #pragma unroll
-      for (int u = 0; u < 7; u++) cc[u] = point_at(TP, min(off + 16u * u, last));
+      for (int u = 0; u < 7; u++) cc[u] = point_at(TP, (unsigned)min(s + u, last) << 4);
 #pragma unroll
-      for (int u = 0; u < 7; u++) best = fminf(best, dist2(px, py, pz, cc[u]));
+      for (int u = 0; u < 7; u++) take(cc[u], min(s + u, last));
     }
   };
-  if (inside) {  // an aligned scan point usually has its nearest map point in its own cell, closer than the cell walls
+  if (inside) {
     const int own = cell_index(g, c[0], c[1], c[2]);
     scan(tstart[own], tstart[own + 1]);
     if (best < INFINITY) {
       const double bound = cube_bound(g, c, q, 0);
-      if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) return best;
+      if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) return;
     }
   }
   for (;;) {
     // cube [c-r, c+r]^3 as contiguous row ranges of the sorted target (the minimum only improves on re-scans)
     for_each_cube_row(g, c, r, tstart, scan);
     if (r >= rmax) break;
+    const double bound = cube_bound(g, c, q, r);
+    if (bound == 1.0e300) break;
+    if (bound > cap_r) break;  // everything unscanned is farther than the cap
     int rn;
     if (best < INFINITY) {
-      const double bound = cube_bound(g, c, q, r);
-      if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) break;
+      if (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5)) break;
       const double need = sqrt((double)best) * (1.0 + 1e-5);
       rn = r + 1;
       while (rn < rmax) {
@@ -2169,7 +2175,53 @@ __device__ __forceinline__ float fitness_point(const float4* __restrict__ SP, in
     }
     r = min(rn, rmax);
   }
+}
+
+// squared distance from the transformed source point i to its nearest target point
+__device__ __forceinline__ float fitness_point(const float4* __restrict__ SP, int i, const PoseF& T, const float4* __restrict__ TP,
+                                               const int* __restrict__ tstart, const Grid& g) {
+  const float4 sp = SP[i];
+  const float x = sp.x, y = sp.y, z = sp.z;
+  const float px = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
+  const float py = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
+  const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
+  float best;
+  int bs;
+  nn_search(px, py, pz, TP, tstart, g, 1.0e300, best, bs);
   return best;
+}
+
+// f4  one ICP iteration's correspondences and sums (pcl::IterativeClosestPoint as used at RGC_mapping.cpp:2050-2069):
+// nearest target point of every (already transformed) source point, kept if d^2 <= max_d2
+// (CorrespondenceEstimation::determineCorrespondences), then the sums TransformationEstimationSVD needs --
+// n, sum p, sum q, sum p q^T -- and sum d^2 for the convergence criteria: 17 of the 28 accumulators.
+__global__ void __launch_bounds__(LIN_T)
+k_icp_accumulate(const float4* __restrict__ SP, int ns, const float4* __restrict__ TP, const int* __restrict__ tstart, Grid g, double max_dist,
+                 double max_d2, double* __restrict__ partials) {
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[kAccum];
+#pragma unroll
+  for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
+  if (i < ns) {
+    const float4 sp = SP[i];
+    float best;
+    int bs;
+    nn_search(sp.x, sp.y, sp.z, TP, tstart, g, max_dist * (1.0 + 1e-5), best, bs);
+    if (bs >= 0 && (double)best <= max_d2) {
+      const float4 tq = TP[bs];
+      const double p[3] = {(double)sp.x, (double)sp.y, (double)sp.z}, q[3] = {(double)tq.x, (double)tq.y, (double)tq.z};
+      acc[0] = 1.0;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        acc[1 + a] = p[a];
+        acc[4 + a] = q[a];
+#pragma unroll
+        for (int b = 0; b < 3; b++) acc[7 + a * 3 + b] = p[a] * q[b];
+      }
+      acc[16] = (double)best;
+    }
+  }
+  block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
 }
 
 __global__ void __launch_bounds__(FIT_T)
@@ -2701,6 +2753,12 @@ void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP,
   const int nb = fitness_blocks(ns);
   hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(FIT_T), 0, s, SP, ns, T, TP, tstart, g, partials);
   hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
+}
+void icp_accumulate(hipStream_t s, const float4* SP, int ns, const float4* TP, const int* tstart, Grid g, double max_dist, double* partials,
+                    double* out28) {
+  const int nb = linearize_blocks(ns);
+  hipLaunchKernelGGL(k_icp_accumulate, dim3(nb), dim3(LIN_T), 0, s, SP, ns, TP, tstart, g, max_dist, max_dist * max_dist, partials);
+  hipLaunchKernelGGL(k_fold<kAccum>, dim3(kAccum), dim3(WAVE), 0, s, partials, nb, out28, (const int*)nullptr, (int*)nullptr);
 }
 void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f) {
   hipLaunchKernelGGL(k_transform_f32, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, out, out_stride_f);
