@@ -2105,7 +2105,9 @@ int fitness_blocks(int n) { return (n + FIT_T - 1) / FIT_T; }
 // Exact nearest neighbour of (px,py,pz) in the sorted target: own cell first (an aligned point's nearest map point is usually
 // closer than its cell walls), else a cube of cells that grows until the best distance is provably inside it -- or until the
 // unscanned region is farther than cap_r (then nothing within cap_r is missing).  Ties: smaller original index.
-// best = squared distance (INFINITY if none found), bs = position in the sorted array (-1 if none).
+// best = squared distance (INFINITY if none found), bs = position in the sorted array (-1 if none; only tracked if kIndex:
+// the fitness score needs the distance alone, and the index bookkeeping costs it a third of its time).
+template <bool kIndex>
 __device__ __forceinline__ void nn_search(float px, float py, float pz, const float4* __restrict__ TP, const int* __restrict__ tstart,
                                           const Grid& g, double cap_r, float& best, int& bs) {
   const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
@@ -2123,8 +2125,12 @@ __device__ __forceinline__ void nn_search(float px, float py, float pz, const fl
   int bo = INT_MAX;
   auto take = [&](const float4& cp, int s) {
     const float d = dist2(px, py, pz, cp);
-    const int o = __float_as_int(cp.w);
-    if (d < best || (d == best && o < bo)) { best = d; bs = s; bo = o; }
+    if (kIndex) {
+      const int o = __float_as_int(cp.w);
+      if (d < best || (d == best && o < bo)) { best = d; bs = s; bo = o; }
+    } else {
+      best = fminf(best, d);
+    }
   };
   auto scan = [&](int s0, int s1) {
     int s = s0;
@@ -2187,7 +2193,7 @@ __device__ __forceinline__ float fitness_point(const float4* __restrict__ SP, in
   const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
   float best;
   int bs;
-  nn_search(px, py, pz, TP, tstart, g, 1.0e300, best, bs);
+  nn_search<false>(px, py, pz, TP, tstart, g, 1.0e300, best, bs);
   return best;
 }
 
@@ -2206,7 +2212,7 @@ k_icp_accumulate(const float4* __restrict__ SP, int ns, const float4* __restrict
     const float4 sp = SP[i];
     float best;
     int bs;
-    nn_search(sp.x, sp.y, sp.z, TP, tstart, g, max_dist * (1.0 + 1e-5), best, bs);
+    nn_search<true>(sp.x, sp.y, sp.z, TP, tstart, g, max_dist * (1.0 + 1e-5), best, bs);
     if (bs >= 0 && (double)best <= max_d2) {
       const float4 tq = TP[bs];
       const double p[3] = {(double)sp.x, (double)sp.y, (double)sp.z}, q[3] = {(double)tq.x, (double)tq.y, (double)tq.z};
