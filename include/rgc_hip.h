@@ -163,6 +163,9 @@ typedef struct rgc_fe_out {
 } rgc_fe_out;
 RGC_API void rgc_default_fe_params(rgc_fe_params* p);
 RGC_API int rgc_frontend(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* params, rgc_fe_out* out);
+/* the same with the sweep already resident on the device (a pointer from rgc_device_alloc, e.g. filled by
+ * rgc_pc2_unpack(..., out_on_device = 1)): the message bytes are the only thing that crosses PCIe */
+RGC_API int rgc_frontend_device(rgc_ctx* ctx, const float* d_xyzi, int n, int stride_bytes, const rgc_fe_params* params, rgc_fe_out* out);
 
 /* ---- scalar host stages of the frame body (no GPU needed; kept in the same library so the adaptor is complete) ----
  * Quaternions are x,y,z,w.  ground[11] = ground_msg/groundparam order: norm xyz, vector1 xyz, vector2 xyz, distance,

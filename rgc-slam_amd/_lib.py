@@ -94,7 +94,7 @@ SYMBOLS = [
     "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
-    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_frontend_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
 _lib = None
@@ -145,6 +145,7 @@ def load():
     L.rgc_default_fe_params.argtypes = [C.POINTER(FeParams)]
     L.rgc_default_fe_params.restype = None
     L.rgc_frontend.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(FeParams), C.POINTER(FeOut)]
+    L.rgc_frontend_device.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(FeParams), C.POINTER(FeOut)]
     L.rgc_extract_pose.argtypes = [fp, dp, dp]
     L.rgc_imu_preintegrate.argtypes = [dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp]
     L.rgc_default_fuse_in.argtypes = [C.POINTER(FuseIn)]

@@ -1177,7 +1177,15 @@ void rgc_default_fe_params(rgc_fe_params* p) {
   p->n_scans = 16; p->min_range = 0.5; p->max_range = 80.0; p->use_intensity = 1;  // launch/run.launch:6,12-13,18
 }
 
+static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out, int on_device);
 int rgc_frontend(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out) {
+  return frontend_impl(c, xyzi, n, stride_bytes, prm, out, 0);
+}
+// the same with the sweep already on the device (e.g. rgc_pc2_unpack(..., out_on_device = 1)): no host copy of the input
+int rgc_frontend_device(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out) {
+  return frontend_impl(c, d_xyzi, n, stride_bytes, prm, out, 1);
+}
+static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out, int on_device) {
   if (!c || !xyzi || !prm || !out || n < 0) return RGC_ERR_INVALID;
   if (stride_bytes < 16 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "front-end needs x,y,z,intensity: stride_bytes >= 16");
   const int NS = prm->n_scans;
@@ -1190,7 +1198,7 @@ int rgc_frontend(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const r
   hipStream_t s = c->stream;
   const int stride_f = stride_bytes / 4;
   const float* d_in;
-  int rc = stage_in(c, xyzi, n, stride_bytes, 0, &d_in);
+  int rc = stage_in(c, xyzi, n, stride_bytes, on_device, &d_in);
   if (rc) return rc;
   const int nb = rgck::fe_blocks(n);
   enum { RING, RANK, HIST, META, ST, CL, INUM2, INUM, RANGE, ANGLE, CURV, CURV2, ICURV, DSRC, OSRC, PICK, IPICK, LAB, ILAB, GMARK, MULT, SCNT,

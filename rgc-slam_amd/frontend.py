@@ -32,12 +32,32 @@ class ScanRegistration:
         except Exception:
             pass
 
+    def laserCloudHandlerMsg(self, data: bytes, n_points: int, layout, diagnostics: bool = True) -> dict:
+        """The callback on the raw sensor_msgs/PointCloud2 bytes (scanRegistration.cpp:89-730 including fromROSMsg at :107-108):
+        the message is unpacked by a kernel and the sweep never exists on the host.  layout: rgc_slam_amd.wire.layout(...)."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        if buf.size < n_points * layout.point_step:
+            raise RgcError(_lib.ERR_INVALID, "data shorter than n_points * point_step")
+        d = C.c_void_p()
+        rc = self._L.rgc_device_alloc(self._h, max(n_points, 1) * 16, C.byref(d))
+        if rc != 0:
+            raise RgcError(rc, self._L.rgc_last_error(self._h).decode())
+        try:
+            rc = self._L.rgc_pc2_unpack(self._h, buf.ctypes.data, n_points, C.byref(layout), d, None, None, 1)
+            if rc != 0:
+                raise RgcError(rc, self._L.rgc_last_error(self._h).decode())
+            return self._run(d, n_points, 16, diagnostics, on_device=True)
+        finally:
+            self._L.rgc_device_free(self._h, d)
+
     def laserCloudHandler(self, xyzi, diagnostics: bool = True) -> dict:
         """scanRegistration.cpp:89-730.  xyzi: raw cloud (n, >=4) float32 in firing order."""
         a = np.ascontiguousarray(xyzi, dtype=np.float32)
         if a.ndim != 2 or a.shape[1] < 4:
             raise RgcError(_lib.ERR_INVALID, "cloud must be (n, >=4) float32: x, y, z, intensity")
-        n = a.shape[0]
+        return self._run(a.ctypes.data, a.shape[0], a.strides[0], diagnostics, on_device=False, keepalive=a)
+
+    def _run(self, ptr, n, stride, diagnostics, on_device, keepalive=None) -> dict:
         ns = self.params.n_scans
         fcap, gcap = ns * 6 * 41, max(10 * n, 1)
         f32, i32 = C.POINTER(C.c_float), C.POINTER(C.c_int)
@@ -52,7 +72,8 @@ class ScanRegistration:
         for k, v in {**bufs, **diag}.items():
             setattr(o, k, v.ctypes.data_as(i32 if v.dtype == np.int32 else f32))
         o.cloud_cap, o.feat_cap, o.ground_cap = max(n, 1), fcap, gcap
-        rc = self._L.rgc_frontend(self._h, a.ctypes.data, n, a.strides[0], C.byref(self.params), C.byref(o))
+        fn = self._L.rgc_frontend_device if on_device else self._L.rgc_frontend
+        rc = fn(self._h, ptr, n, stride, C.byref(self.params), C.byref(o))
         if rc != 0:
             raise RgcError(rc, self._L.rgc_last_error(self._h).decode())
         m = o.n_cloud

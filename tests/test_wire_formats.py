@@ -125,3 +125,22 @@ def test_pc2_pack_matches_pcl_layouts_and_round_trips():
     assert np.array_equal(np.stack([a["x"], a["y"], a["z"], a["intensity"], a["normal_x"]], axis=1), p5)
     assert np.all(a["normal_y"] == 0) and np.all(a["curvature"] == 0)
     w.close()
+
+
+@pytest.mark.gpu
+def test_frontend_on_message_bytes_matches_host_path():
+    """PointCloud2 bytes -> unpack kernel -> front-end, all on the device, equals the front-end on the host array"""
+    import rgc_slam_amd.synth as synth
+    from rgc_slam_amd import wire, frontend
+    w_ = synth.make_world(seed=synth.SEED)
+    sc = synth.make_scan(w_, np.eye(4), n_az=900, seed=synth.SEED + 3)
+    xyzi = np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32)
+    dt = np.dtype({"names": ["x", "y", "z", "intensity", "ring"], "formats": ["<f4", "<f4", "<f4", "<f4", "<u2"], "offsets": [0, 4, 8, 16, 20], "itemsize": 32})
+    msg = np.zeros(len(xyzi), dt)
+    msg["x"], msg["y"], msg["z"], msg["intensity"] = xyzi[:, 0], xyzi[:, 1], xyzi[:, 2], xyzi[:, 3]
+    lay = wire.layout(32, dict(x=(0, 7), y=(4, 7), z=(8, 7), intensity=(16, 7), ring=(20, 4)), strict=True)
+    fe = frontend.ScanRegistration(device=0)
+    a = fe.laserCloudHandler(xyzi)
+    b = fe.laserCloudHandlerMsg(msg.tobytes(), len(xyzi), lay)
+    for k in ("cloud", "sharp", "flat", "inten", "label", "curvature", "groundparam"):
+        assert np.array_equal(a[k], b[k]), k
