@@ -228,6 +228,34 @@ def test_edge_cases(reg_mod, medium):
     v.close()
 
 
+def test_exact_ties_follow_the_oracle_order(reg_mod, orc):
+    """Lattice points and duplicates: many candidates at EXACTLY the k-th distance.  The neighbour set is then decided by the
+    tie rule (ascending original index), which the bulk kernel hands to the cooperative kernel (more than k candidates <= the
+    k-th distance).  With an anisotropic lattice the neighbourhood covariances are non-degenerate, so every one must match."""
+    rng = np.random.default_rng(9)
+    for spacing, strict in (((0.25, 0.27, 0.31), True), ((0.25, 0.25, 0.25), False)):
+        g = np.stack(np.meshgrid(np.arange(14), np.arange(14), np.arange(5), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float32)
+        g = g * np.float32(spacing)
+        pts = np.concatenate([g, g[rng.choice(len(g), 150, replace=False)]])      # 150 exact duplicates
+        pts = pts[rng.permutation(len(pts))] + np.float32([3.0, -2.0, 0.5])
+        v = _odo(reg_mod)
+        v.setInputTarget(pts)
+        v.setInputSource(pts[:400])
+        ct, cs = v.getTargetCovariances(), v.getSourceCovariances()
+        assert v.stats()["deferred_target"] > 100                                  # the tie path really ran
+        o = orc.Registration(num_threads=0)
+        o.set_target(pts); o.set_source(pts[:400]); o.prepare()
+        dt = np.abs(ct - o.target_cov(len(pts))).reshape(len(pts), -1).max(axis=1)
+        ds = np.abs(cs - o.source_cov(400)).reshape(400, -1).max(axis=1)
+        if strict:
+            assert dt.max() < 1e-9 and ds.max() < 1e-9
+        else:   # cubic lattice: symmetric neighbourhoods have degenerate eigen-spaces, their normal is not unique
+            assert np.mean(dt < 1e-9) > 0.85
+        vm, om = v.getVoxels(), o.voxelmap()
+        assert np.array_equal(vm["coords"], om["coords"]) and np.array_equal(vm["num"], om["num"])
+        v.close()
+
+
 def test_k_and_resolution_parameters(reg_mod, orc, fx_reg):
     """setCorrespondenceRandomness / setResolution change the covariances and the voxel map like the oracle's"""
     v = _odo(reg_mod)
