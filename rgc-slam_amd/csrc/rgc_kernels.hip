@@ -6,6 +6,19 @@
 // points is fp64, like the reference (points are cast to double at fast_gicp_impl.hpp:258, fast_vgicp_impl.hpp:84).
 //
 // Reference citations are relative to /root/reference/rgc_slam/.
+//
+// Contents, in file order (one translation unit on purpose: the device helpers -- wave reductions, the register top-k chain,
+// the row walkers, the Jacobi solver, the block reduction -- are shared by nearly every kernel and stay inlinable):
+//   grid build      k_bbox, k_count, k_cells_scan_{block,sums,add}, k_place, k_rank_gather (+ k_scan_*, k_scatter for the
+//                   pcl::VoxelGrid path of rgc_pre.hip)
+//   C2 kNN + cov    TopK, scan_range_*, for_each_cube_row(_lds), knn_point, k_knn_rows (bulk, one lane per query),
+//                   coop_kth, k_knn_coop (deferred queries, one wave per query), k_segments / k_knn_tile (A/B knob)
+//   C3 voxel map    k_voxel_build
+//   C4-C7 solve     linearize_point, error_point, block_reduce_store, last_block_arrive, block_fold_rows, k_lm_step (default
+//                   driver), k_lm_run (persistent A/B knob), k_linearize / k_error / k_fold / k_lm_try (public fine seam)
+//   C8, f4          nn_search, k_fitness(_lm), k_icp_accumulate, k_transform_f32
+//   f1              k_mapreg_associate, k_mapreg_terms, k_mapreg_fold
+//   launch wrappers at the end (namespace rgck, declared in rgc_kernels.h)
 #include "rgc_kernels.h"
 #include "rgc_lm.h"
 
