@@ -1422,8 +1422,9 @@ int rgc_mapreg_associate(rgc_ctx* c, int kind, const float* feat_xyzw, int n, co
   int rc = mapreg_upload_features(c, kind, feat_xyzw, n);
   if (rc) return rc;
   const Cloud& m = c->mr_map[kind];
-  rgck::mapreg_associate(c->stream, kind == 0, (const float*)c->mr_feat[kind].p, n, rgck::Quat{q_xyzw[0], q_xyzw[1], q_xyzw[2], q_xyzw[3]}, t,
-                         (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[kind].p, nullptr);
+  const rgck::MapregAssoc one{(const float*)c->mr_feat[kind].p, n, kind == 0 ? 1 : 0, rgck::Quat{q_xyzw[0], q_xyzw[1], q_xyzw[2], q_xyzw[3]},
+                              {t[0], t[1], t[2]}, (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[kind].p, nullptr};
+  rgck::mapreg_associate(c->stream, &one, 1);
   std::vector<double> tmp;
   double* dst = factors8;
   if (!dst) { tmp.resize((size_t)8 * (n > 0 ? n : 1)); dst = tmp.data(); }
@@ -1463,12 +1464,14 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
     // corner_num / surf_num ...) ride home with the first evaluation's synchronisation
     int* dcnt = (int*)c->mr_small.p + 8;
     HIPCHK(c, hipMemsetAsync(dcnt, 0, 4 * sizeof(int), c->stream));
+    rgck::MapregAssoc sets[4];
     for (int s = 0; s < 4; s++) {
       const double* q = poses + 7 * (s / 2);
       const Cloud& m = c->mr_map[s & 1];
-      rgck::mapreg_associate(c->stream, (s & 1) == 0, (const float*)c->mr_feat[s].p, nfeat[s], rgck::Quat{q[0], q[1], q[2], q[3]}, q + 4,
-                             (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[s].p, dcnt + s);
+      sets[s] = rgck::MapregAssoc{(const float*)c->mr_feat[s].p, nfeat[s], (s & 1) == 0 ? 1 : 0, rgck::Quat{q[0], q[1], q[2], q[3]}, {q[4], q[5], q[6]},
+                                  (const float4*)m.P.p, (const int*)m.start.p, m.grid, (double*)c->mr_fac[s].p, dcnt + s};
     }
+    rgck::mapreg_associate(c->stream, sets, 4);  // the four loops of :1092-1282 side by side
     HIPCHK(c, hipMemcpyAsync(c->h_small + 40, dcnt, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // ceres::Solve restated: trust-region LM, <= 6 iterations (:1333-1341), Ceres 1.14 defaults: initial radius 1e4, damping diag(H)/radius clamped to [1e-6, 1e32], step accepted above a relative decrease of 1e-3
     double radius = 1e4, decrease_factor = 2.0;

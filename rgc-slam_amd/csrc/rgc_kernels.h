@@ -86,8 +86,13 @@ void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, 
             const int* nvox, const void* segs_t, const void* segs_s);
 // ---- f1: mapping-node feature registration (RGC_mapping.cpp:1069-1358) ----
 // factor record = 8 doubles per feature: edge {a[3], b[3], var, valid}, plane {n[3], d, 0, 0, var, valid}
-void mapreg_associate(hipStream_t s, bool edge, const float* feat /* n x 4: x,y,z,weight */, int n, Quat q, const double t[3], const float4* P,
-                      const int* start, Grid g, double* fac, int* nvalid /* nullable, += factors created */);
+struct MapregAssoc {  // one association loop: feature set (n x 4: x,y,z,weight), its pose, the map grid it is matched against
+  const float* feat; int n; int edge;
+  Quat q; double t[3];
+  const float4* P; const int* start; Grid g;
+  double* fac; int* nvalid;  // nvalid nullable: += factors created
+};
+void mapreg_associate(hipStream_t s, const MapregAssoc* sets, int nsets /* <= 4, one launch */);
 int mapreg_blocks(int ne, int np);
 // both poses in one launch.  feat/fac/nfeat: {corner cur, surf cur, corner last, surf last}; x14 = q_cur t_cur q_last t_last;
 // out56 = per pose {21 upper-triangular H, 6 g, robust cost} (H, g only if want_H); partials: 2 * 28 * max mapreg_blocks doubles

@@ -2424,10 +2424,9 @@ __device__ void lstsq_5x3_colpiv(double A[5][3], double b[5], double x[3]) {
 // every 5th-neighbour distance below the threshold; a farther 5th neighbour means "no factor" either way), then the line
 // test (:1100-1138) or the plane fit (:1202-1236).  *nvalid counts the factors created (corner_num, surf_num, ...).
 template <bool kEdge>
-__global__ void k_mapreg_associate(const float* __restrict__ feat, int n, Quat q, double tx, double ty, double tz,
-                                   const float4* __restrict__ P, const int* __restrict__ start, Grid g, double* __restrict__ fac,
-                                   int* __restrict__ nvalid) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void mapreg_associate_one(const float* __restrict__ feat, int n, Quat q, double tx, double ty, double tz,
+                                                     const float4* __restrict__ P, const int* __restrict__ start, const Grid& g,
+                                                     double* __restrict__ fac, int* __restrict__ nvalid, int i) {
   if (i >= n) return;
   double* f = fac + (size_t)i * 8;
 #pragma unroll
@@ -2511,6 +2510,15 @@ __global__ void k_mapreg_associate(const float* __restrict__ feat, int n, Quat q
   f[6] = (double)feat[4 * i + 3];  // var = pointOri.normal_x
   f[7] = 1.0;
   if (nvalid) atomicAdd(nvalid, 1);
+}
+
+// up to four association loops in ONE launch (blockIdx.y selects the loop): they are independent, each is a few thousand
+// lanes of latency-bound search, and side by side they cost the longest one instead of the sum
+__global__ void k_mapreg_associate(MapregAssoc a0, MapregAssoc a1, MapregAssoc a2, MapregAssoc a3) {
+  const MapregAssoc& a = blockIdx.y == 0 ? a0 : (blockIdx.y == 1 ? a1 : (blockIdx.y == 2 ? a2 : a3));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.edge) mapreg_associate_one<true>(a.feat, a.n, a.q, a.t[0], a.t[1], a.t[2], a.P, a.start, a.g, a.fac, a.nvalid, i);
+  else mapreg_associate_one<false>(a.feat, a.n, a.q, a.t[0], a.t[1], a.t[2], a.P, a.start, a.g, a.fac, a.nvalid, i);
 }
 
 // Robustified normal equations of ONE pose over its edge and plane factors (or the cost only): 21 + 6 + 1 sums per lane
@@ -2610,11 +2618,15 @@ __global__ void __launch_bounds__(WAVE) k_mapreg_fold(const double* __restrict__
   if (lane == 0) out56[b * kAccum + a] = s;
 }
 
-void mapreg_associate(hipStream_t s, bool edge, const float* feat, int n, Quat q, const double t[3], const float4* P, const int* start, Grid g,
-                      double* fac, int* nvalid) {
-  if (n <= 0) return;
-  if (edge) hipLaunchKernelGGL(k_mapreg_associate<true>, dim3(nblk(n, 64)), dim3(64), 0, s, feat, n, q, t[0], t[1], t[2], P, start, g, fac, nvalid);
-  else hipLaunchKernelGGL(k_mapreg_associate<false>, dim3(nblk(n, 64)), dim3(64), 0, s, feat, n, q, t[0], t[1], t[2], P, start, g, fac, nvalid);
+void mapreg_associate(hipStream_t s, const MapregAssoc* sets, int nsets) {
+  MapregAssoc a[4] = {};
+  int nmax = 0;
+  for (int k = 0; k < 4; k++) {
+    if (k < nsets) a[k] = sets[k];
+    nmax = max(nmax, a[k].n);
+  }
+  if (nmax <= 0 || nsets <= 0) return;
+  hipLaunchKernelGGL(k_mapreg_associate, dim3(nblk(nmax, 64), nsets), dim3(64), 0, s, a[0], a[1], a[2], a[3]);
 }
 int mapreg_blocks(int ne, int np) { return (ne + np + LIN_T - 1) / LIN_T; }
 void mapreg_terms(hipStream_t s, const float* const feat[4], const double* const fac[4], const int nfeat[4], const double x14[14], double huber_a,
