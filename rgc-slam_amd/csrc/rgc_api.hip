@@ -1222,7 +1222,8 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   HIPCHK(c, hipStreamSynchronize(s));
   const int cs = meta[128];
   out->n_cloud = cs;
-  for (int r = 0; r < NS; r++) out->ring_count[r] = meta[r];
+  int max_ring = 0;
+  for (int r = 0; r < NS; r++) { out->ring_count[r] = meta[r]; max_ring = std::max(max_ring, meta[r]); }
   if (cs == 0) return RGC_OK;
   if (out->cloud_cap < cs) return fail(c, RGC_ERR_INVALID, "cloud_cap %d < %d points", out->cloud_cap, cs);
   for (int b : {PICK, IPICK, LAB, ILAB}) HIPCHK(c, hipMemsetAsync(c->fe[b].p, 0, sizeof(int) * (size_t)cs, s));
@@ -1271,7 +1272,7 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   }
   // A7 + A8
   rgck::fe_select(s, FE(CL, float4), NS, FE(META, int), FE(CURV, float), FE(CURV2, float), FE(ICURV, float), FE(INUM, int), FE(GMARK, int),
-                  FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), FE(FLAGS, int));
+                  FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), FE(FLAGS, int), max_ring);
   rgck::fe_emit(s, FE(CL, float4), NS, FE(SLOTS, int), FE(DSRC, float), FE(OSRC, float), FE(SHARP, float), FE(FLAT, float), FE(INTEN, float), fcap,
                 FE(FLAGS, int) + 4);
   int fl[8];

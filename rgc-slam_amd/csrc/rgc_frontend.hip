@@ -386,21 +386,38 @@ __device__ void bitonic_sort(Key* k, int n2) {  // ascending by (value, index); 
   __syncthreads();
 }
 
-__device__ __forceinline__ float sq_gap(const float4* __restrict__ C, int l, int m) {
-  const float4 a = C[l], b = C[m];
-  const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-  return dx * dx + dy * dy + dz * dz;
-}
-
 // slots: per (ring, sector): sharp 20, flat 40, inten 20 indices + 3 counts (83 ints)
 constexpr int SLOT = 83;
+constexpr int SEL_MARGIN = 5;  // a pick touches ind +- 5 (and compares ind + l with ind + l -+ 1, both inside +- 5)
 
+// One workgroup per ring; the sectors of a ring are processed in order (a pick suppresses up to five neighbours, possibly
+// across a sector border).  Per sector: every lane stages the sector's window (points, curvatures, flags; +-5 points of
+// margin) in LDS and the block sorts the two key arrays; then ONE lane runs the three greedy passes of :487-641 entirely out of
+// LDS -- the passes are inherently sequential (each pick changes what the next candidate may be), and run from global memory
+// they were a chain of ~10 dependent loads per pick (1.4 ms per sweep); finally the block writes the flags back.
+// Dynamic LDS: n2 keys x 2, then the window arrays (host sizes it from the largest ring).
 __global__ void __launch_bounds__(SEL_T)
 k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, const float* __restrict__ curv, const float* __restrict__ curv2,
             const float* __restrict__ icurv, const int* __restrict__ inum, const int* __restrict__ gmark, int* __restrict__ picked,
-            int* __restrict__ ipicked, int* __restrict__ label, int* __restrict__ ilabel, int* __restrict__ slots, int* flags) {
-  __shared__ Key ks[SEC_MAX];
-  __shared__ Key ki[SEC_MAX];
+            int* __restrict__ ipicked, int* __restrict__ label, int* __restrict__ ilabel, int* __restrict__ slots, int* flags, int sec_cap) {
+  extern __shared__ __align__(16) unsigned char sel_lds[];
+  int n2cap = 1;
+  while (n2cap < sec_cap) n2cap <<= 1;
+  const int wcap = sec_cap + 2 * SEL_MARGIN;
+  Key* ks = reinterpret_cast<Key*>(sel_lds);
+  Key* ki = ks + n2cap;
+  float* wx = reinterpret_cast<float*>(ki + n2cap);
+  float* wy = wx + wcap;
+  float* wz = wy + wcap;
+  float* wc = wz + wcap;    // curvature
+  float* wc2 = wc + wcap;   // curvature2
+  float* wic = wc2 + wcap;  // intensity curvature
+  int* wnum = reinterpret_cast<int*>(wic + wcap);
+  signed char* wpick = reinterpret_cast<signed char*>(wnum + wcap);
+  signed char* wipick = wpick + wcap;
+  signed char* wgm = wipick + wcap;
+  signed char* wlab = wgm + wcap;
+  signed char* wilab = wlab + wcap;
   const int ring = blockIdx.x;
   const int S = meta[64 + ring] + 5, E = meta[64 + ring + 1] - 5;  // scanStartInd / scanEndInd, :223,229
   for (int j = 0; j < 6; j++) {
@@ -411,59 +428,101 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
   for (int j = 0; j < 6; j++) {
     const int sp = S + (E - S) * j / 6, ep = S + (E - S) * (j + 1) / 6 - 1;  // :478-480
     const int cnt = ep - sp + 1;
-    if (cnt > SEC_MAX) { if (threadIdx.x == 0) atomicOr(flags, 2); return; }
+    if (cnt > sec_cap || cnt > SEC_MAX) { if (threadIdx.x == 0) atomicOr(flags, 2); return; }
     int n2 = 1;
     while (n2 < cnt) n2 <<= 1;
+    const int w0 = sp - SEL_MARGIN, wn = cnt + 2 * SEL_MARGIN;  // window [w0, w0 + wn): inside this ring (S = start + 5)
     __syncthreads();
+    for (int t = threadIdx.x; t < wn; t += SEL_T) {
+      const int g = w0 + t;
+      const float4 p = C[g];
+      wx[t] = p.x; wy[t] = p.y; wz[t] = p.z;
+      wc[t] = curv[g]; wc2[t] = curv2[g]; wic[t] = icurv[g];
+      wnum[t] = inum[g];
+      wpick[t] = (signed char)picked[g]; wipick[t] = (signed char)ipicked[g];
+      wgm[t] = (signed char)(gmark[g] == 1);
+      wlab[t] = (signed char)label[g]; wilab[t] = (signed char)ilabel[g];
+    }
     for (int t = threadIdx.x; t < n2; t += SEL_T) {
       if (t < cnt) { ks[t] = Key{curv[sp + t], sp + t}; ki[t] = Key{icurv[sp + t], sp + t}; }
       else { ks[t] = Key{INFINITY, INT_MAX}; ki[t] = Key{INFINITY, INT_MAX}; }
     }
     bitonic_sort(ks, n2);
     bitonic_sort(ki, n2);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < WAVE) {
+      // The three greedy passes of :487-641 by ONE WAVE.  A pass walks the sorted candidates in order and a pick suppresses
+      // up to ten neighbours, so picks are sequential -- but only picks: 64 candidates at a time, every lane tests the
+      // static conditions of its candidate, then the earliest candidate that is still unsuppressed is picked (ballot +
+      // find-first), its lane marks the neighbours in LDS, and the remaining lanes look again.  Serial steps = picks
+      // (<= 21 / 40 / 21 per sector), not candidates (hundreds).
+      const int lane = threadIdx.x;
       int* sl = slots + ((size_t)ring * 6 + j) * SLOT;
-      int largest = 0, nsh = 0;
-      for (int k = cnt - 1; k >= 0; k--) {  // :487-536
-        const int ind = ks[k].i;
-        if (picked[ind] == 0 && gmark[ind] != 1 && curv[ind] > 0.1 && curv2[ind] > 0.3) {
-          largest++;
-          if (largest <= 20) { label[ind] = 2; sl[nsh++] = ind; }
-          else if (largest <= 21) { label[ind] = 1; }
-          else break;
-          picked[ind] = 1;
-          for (int l = 1; l <= 5; l++) { if (sq_gap(C, ind + l, ind + l - 1) > 0.05) break; picked[ind + l] = 1; }
-          for (int l = -1; l >= -5; l--) { if (sq_gap(C, ind + l, ind + l + 1) > 0.05) break; picked[ind + l] = 1; }
+      auto gap2 = [&](int a, int b) {  // squared distance between window points a and b
+        const float dx = wx[a] - wx[b], dy = wy[a] - wy[b], dz = wz[a] - wz[b];
+        return dx * dx + dy * dy + dz * dz;
+      };
+      auto wave_fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      };
+      // returns the number of picks that produced an output slot
+      auto greedy = [&](const Key* keys, bool descending, signed char* flag, int limit, auto&& static_ok, auto&& on_pick) {
+        int count = 0;
+        bool stop = false;
+        for (int base = 0; base < cnt && !stop; base += WAVE) {
+          const int kk = base + lane;
+          const bool valid = kk < cnt;
+          const int k = valid ? (descending ? cnt - 1 - kk : kk) : 0;
+          const int ind = keys[k].i, w = ind - w0;
+          bool ok = valid && static_ok(w);
+          for (;;) {
+            const unsigned long long mask = __ballot(ok && flag[w] == 0);
+            if (!mask) break;
+            count++;
+            if (count > limit) { stop = true; break; }  // the reference's `else break`: not even marked
+            const int b = __ffsll((long long)mask) - 1;
+            if (lane == b) {
+              on_pick(count, ind, w);
+              flag[w] = 1;
+              ok = false;
+            }
+            wave_fence();
+          }
         }
-      }
-      int smallest = 0, nfl = 0;
-      for (int k = 0; k < cnt; k++) {  // :540-583
-        const int ind = ks[k].i;
-        if (picked[ind] == 0 && curv[ind] < 0.3 && curv2[ind] < 0.4) {
-          smallest++;
-          if (smallest <= 40) { label[ind] = -1; sl[20 + nfl++] = ind; }
-          else break;
-          picked[ind] = 1;
-          for (int l = 1; l <= 5; l++) { if (sq_gap(C, ind + l, ind + l - 1) > 0.05) break; picked[ind + l] = 1; }
-          for (int l = -1; l >= -5; l--) { if (sq_gap(C, ind + l, ind + l + 1) > 0.05) break; picked[ind + l] = 1; }
-        }
-      }
-      int largest2 = 0, nin = 0;
-      for (int k = cnt - 1; k >= 0; k--) {  // :594-641
-        const int ind = ki[k].i;
-        if (ipicked[ind] == 0 && gmark[ind] != 1 && icurv[ind] > 65 && label[ind] != 2 && label[ind] != 1) {
-          largest2++;
-          if (largest2 <= 20) { ilabel[ind] = 2; sl[60 + nin++] = ind; }
-          else if (largest2 <= 21) { ilabel[ind] = 1; }
-          else break;
-          ipicked[ind] = 1;
-          for (int l = 1; l <= 5; l++) { if (fabsf((float)(inum[ind + l] - inum[ind + l - 1])) > 35) break; ipicked[ind + l] = 1; }
-          for (int l = -1; l >= -5; l--) { if (fabsf((float)(inum[ind + l] - inum[ind + l + 1])) > 35) break; ipicked[ind + l] = 1; }
-        }
-      }
-      sl[80] = nsh; sl[81] = nfl; sl[82] = nin;
+        return count > limit ? limit : count;
+      };
+      // sharp: largest curvature first (:487-536); the 21st pick is labelled "less sharp" and gets no slot
+      const int nsh_picks = greedy(ks, true, wpick, 21, [&](int w) { return wgm[w] == 0 && wc[w] > 0.1 && wc2[w] > 0.3; },
+                                   [&](int count, int ind, int w) {
+                                     if (count <= 20) { wlab[w] = 2; sl[count - 1] = ind; } else { wlab[w] = 1; }
+                                     for (int l = 1; l <= 5; l++) { if (gap2(w + l, w + l - 1) > 0.05) break; wpick[w + l] = 1; }
+                                     for (int l = -1; l >= -5; l--) { if (gap2(w + l, w + l + 1) > 0.05) break; wpick[w + l] = 1; }
+                                   });
+      const int nsh = nsh_picks > 20 ? 20 : nsh_picks;
+      wave_fence();
+      // flat: smallest curvature first (:540-583)
+      const int nfl = greedy(ks, false, wpick, 40, [&](int w) { return wc[w] < 0.3 && wc2[w] < 0.4; },
+                             [&](int count, int ind, int w) {
+                               wlab[w] = -1; sl[20 + count - 1] = ind;
+                               for (int l = 1; l <= 5; l++) { if (gap2(w + l, w + l - 1) > 0.05) break; wpick[w + l] = 1; }
+                               for (int l = -1; l >= -5; l--) { if (gap2(w + l, w + l + 1) > 0.05) break; wpick[w + l] = 1; }
+                             });
+      wave_fence();
+      // intensity: largest intensity curvature first, not on points already labelled sharp (:594-641)
+      int nin_picks = greedy(ki, true, wipick, 21, [&](int w) { return wgm[w] == 0 && wic[w] > 65 && wlab[w] != 2 && wlab[w] != 1; },
+                             [&](int count, int ind, int w) {
+                               if (count <= 20) { wilab[w] = 2; sl[60 + count - 1] = ind; } else { wilab[w] = 1; }
+                               for (int l = 1; l <= 5; l++) { if (fabsf((float)(wnum[w + l] - wnum[w + l - 1])) > 35) break; wipick[w + l] = 1; }
+                               for (int l = -1; l >= -5; l--) { if (fabsf((float)(wnum[w + l] - wnum[w + l + 1])) > 35) break; wipick[w + l] = 1; }
+                             });
+      if (lane == 0) { sl[80] = nsh; sl[81] = nfl; sl[82] = nin_picks > 20 ? 20 : nin_picks; }
     }
     __syncthreads();
+    for (int t = threadIdx.x; t < wn; t += SEL_T) {  // flags back to memory: the next sector's window overlaps this one's margin
+      const int g = w0 + t;
+      picked[g] = wpick[t]; ipicked[g] = wipick[t];
+      label[g] = wlab[t]; ilabel[g] = wilab[t];
+    }
   }
 }
 
@@ -542,8 +601,20 @@ void fe_ground_list(hipStream_t s, const float4* C, int cs, int NS, const float*
   hipLaunchKernelGGL(k_fe_ground_list, dim3(nblk(cs, FE_T)), dim3(FE_T), 0, s, C, cs, NS, range_vec, meta, seedcnt, seedpos, out, cap);
 }
 void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const float* curv, const float* curv2, const float* icurv, const int* inum,
-               const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags) {
-  hipLaunchKernelGGL(k_fe_select, dim3(NS), dim3(SEL_T), 0, s, C, NS, meta, curv, curv2, icurv, inum, gmark, picked, ipicked, label, ilabel, slots, flags);
+               const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags, int max_ring) {
+  // LDS sized from the largest ring: two key arrays (power of two) + the per-sector window arrays
+  int sec_cap = max_ring / 6 + 2;
+  if (sec_cap > SEC_MAX) sec_cap = SEC_MAX;
+  int n2 = 1;
+  while (n2 < sec_cap) n2 <<= 1;
+  const size_t lds = sizeof(Key) * 2 * (size_t)n2 + (size_t)(sec_cap + 2 * SEL_MARGIN) * (7 * 4 + 5) + 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k_fe_select, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_fe_select, dim3(NS), dim3(SEL_T), lds, s, C, NS, meta, curv, curv2, icurv, inum, gmark, picked, ipicked, label, ilabel, slots, flags,
+                     sec_cap);
 }
 void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const float* dsrc, const float* osrc, float* sharp, float* flat, float* inten,
              int cap, int* counts) {
