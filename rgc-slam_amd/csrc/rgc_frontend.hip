@@ -465,8 +465,8 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       };
-      // returns the number of picks that produced an output slot
-      auto greedy = [&](const Key* keys, bool descending, signed char* flag, int limit, auto&& static_ok, auto&& on_pick) {
+      // near(a, b): the suppression keeps spreading from a to its neighbour b (:517-533 and twins).  Returns the picks made.
+      auto greedy = [&](const Key* keys, bool descending, signed char* flag, int limit, auto&& static_ok, auto&& on_pick, auto&& near) {
         int count = 0;
         bool stop = false;
         for (int base = 0; base < cnt && !stop; base += WAVE) {
@@ -481,40 +481,40 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
             count++;
             if (count > limit) { stop = true; break; }  // the reference's `else break`: not even marked
             const int b = __ffsll((long long)mask) - 1;
+            const int wb = __shfl(w, b);
             if (lane == b) {
               on_pick(count, ind, w);
               flag[w] = 1;
               ok = false;
             }
+            // the ten neighbours side by side: lanes 0..4 test wb+1..wb+5 against their predecessor, lanes 5..9 test
+            // wb-1..wb-5; the suppression runs up to the first failing gap on each side
+            const int l = lane < 5 ? lane + 1 : -(lane - 4);
+            const bool cont = lane < 10 && near(wb + l, wb + l - (l > 0 ? 1 : -1));
+            const unsigned long long m = __ballot(cont);
+            const int np = __builtin_ctzll(~(m & 31ull)), nm = __builtin_ctzll(~((m >> 5) & 31ull));
+            if (lane < 5 ? lane < np : (lane < 10 && lane - 5 < nm)) flag[wb + l] = 1;
             wave_fence();
           }
         }
         return count > limit ? limit : count;
       };
+      auto near_pts = [&](int a, int b2) { return !(gap2(a, b2) > 0.05); };
+      auto near_int = [&](int a, int b2) { return !(fabsf((float)(wnum[a] - wnum[b2])) > 35); };
       // sharp: largest curvature first (:487-536); the 21st pick is labelled "less sharp" and gets no slot
       const int nsh_picks = greedy(ks, true, wpick, 21, [&](int w) { return wgm[w] == 0 && wc[w] > 0.1 && wc2[w] > 0.3; },
-                                   [&](int count, int ind, int w) {
-                                     if (count <= 20) { wlab[w] = 2; sl[count - 1] = ind; } else { wlab[w] = 1; }
-                                     for (int l = 1; l <= 5; l++) { if (gap2(w + l, w + l - 1) > 0.05) break; wpick[w + l] = 1; }
-                                     for (int l = -1; l >= -5; l--) { if (gap2(w + l, w + l + 1) > 0.05) break; wpick[w + l] = 1; }
-                                   });
+                                   [&](int count, int ind, int w) { if (count <= 20) { wlab[w] = 2; sl[count - 1] = ind; } else { wlab[w] = 1; } },
+                                   near_pts);
       const int nsh = nsh_picks > 20 ? 20 : nsh_picks;
       wave_fence();
       // flat: smallest curvature first (:540-583)
       const int nfl = greedy(ks, false, wpick, 40, [&](int w) { return wc[w] < 0.3 && wc2[w] < 0.4; },
-                             [&](int count, int ind, int w) {
-                               wlab[w] = -1; sl[20 + count - 1] = ind;
-                               for (int l = 1; l <= 5; l++) { if (gap2(w + l, w + l - 1) > 0.05) break; wpick[w + l] = 1; }
-                               for (int l = -1; l >= -5; l--) { if (gap2(w + l, w + l + 1) > 0.05) break; wpick[w + l] = 1; }
-                             });
+                             [&](int count, int ind, int w) { wlab[w] = -1; sl[20 + count - 1] = ind; }, near_pts);
       wave_fence();
       // intensity: largest intensity curvature first, not on points already labelled sharp (:594-641)
-      int nin_picks = greedy(ki, true, wipick, 21, [&](int w) { return wgm[w] == 0 && wic[w] > 65 && wlab[w] != 2 && wlab[w] != 1; },
-                             [&](int count, int ind, int w) {
-                               if (count <= 20) { wilab[w] = 2; sl[60 + count - 1] = ind; } else { wilab[w] = 1; }
-                               for (int l = 1; l <= 5; l++) { if (fabsf((float)(wnum[w + l] - wnum[w + l - 1])) > 35) break; wipick[w + l] = 1; }
-                               for (int l = -1; l >= -5; l--) { if (fabsf((float)(wnum[w + l] - wnum[w + l + 1])) > 35) break; wipick[w + l] = 1; }
-                             });
+      const int nin_picks = greedy(ki, true, wipick, 21, [&](int w) { return wgm[w] == 0 && wic[w] > 65 && wlab[w] != 2 && wlab[w] != 1; },
+                                   [&](int count, int ind, int w) { if (count <= 20) { wilab[w] = 2; sl[60 + count - 1] = ind; } else { wilab[w] = 1; } },
+                                   near_int);
       if (lane == 0) { sl[80] = nsh; sl[81] = nfl; sl[82] = nin_picks > 20 ? 20 : nin_picks; }
     }
     __syncthreads();
