@@ -870,7 +870,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
       HIPCHK(c, hipStreamSynchronize(c->stream));
       HIPCHK(c, hipGetLastError());
       if (S.done) { fitness_chained = S.has_fit != 0; break; }
-      batch = 3;
+      batch = 6;  // a solve that is still running after six outer iterations usually runs many more (up to 25): fewer read-backs
     }
     if (!solved && S.cur) { std::swap(c->corr_v, c->corr_v2); std::swap(c->corr_M, c->corr_M2); }  // corr_v / corr_M = the valid buffer
     c->corr_noff = noff; c->corr_n = n; c->corr_valid = S.n_lin > 0;
