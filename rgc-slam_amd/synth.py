@@ -140,15 +140,24 @@ def make_world_and_map(n_points: int, seed: int = SEED, leaf: float = 0.3):
     """World sized so that its leaf-filtered map holds a little over n_points (<= 15 % excess, trimmed
     uniformly at random so no region loses its map).  Returns (world, float32 map (n_points,3))."""
     L = max(12.0, math.sqrt(1.07 * n_points / (100.0 * (0.3 / leaf) ** 2)))
+    best = None  # smallest world seen that holds at least n_points (the count moves in steps: whole boxes enter with L)
+
+    def trimmed(world, cen):
+        rng = np.random.default_rng(seed + 2)
+        keep = np.sort(rng.choice(cen.shape[0], n_points, replace=False))
+        return world, np.ascontiguousarray(cen[keep])
+
     for _ in range(12):
         world = make_world(half_extent=L, seed=seed)
         cen = make_map(world, None, leaf=leaf, seed=seed)
         c = cen.shape[0]
         if n_points <= c <= 1.15 * n_points:
-            rng = np.random.default_rng(seed + 2)
-            keep = np.sort(rng.choice(c, n_points, replace=False))
-            return world, np.ascontiguousarray(cen[keep])
+            return trimmed(world, cen)
+        if c >= n_points and (best is None or c < best[1].shape[0]):
+            best = (world, cen)
         L *= math.sqrt(1.07 * n_points / c)
+    if best is not None:  # never inside the 15 % window: take the tightest overshoot and trim more
+        return trimmed(*best)
     raise RuntimeError("could not size the world")
 
 
