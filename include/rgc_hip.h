@@ -274,8 +274,8 @@ RGC_API int rgc_icp_align(rgc_ctx* ctx, const float* source, int n_source, const
  * Replaces, per mapping frame: kdtreeCornerFromMap/kdtreeSurfFromMap->setInputCloud (:1073-1074), the four association
  * loops (:1092-1282: pointAssociateToMap, 5-NN, PCA line test / QR plane fit) and ceres::Solve over para_q/para_t and
  * para_q_last/para_t_last with LidarEdgeFactor / LidarPlaneNormFactor under HuberLoss(0.1) (:1078-1341,
- * src/lidarFactor.hpp:9-51,91-121), twice (:1076).  The ground block (:1314-1340, Ground_DeltaFactor_goable) is optional
- * input; USE_IMU = 0 (the block :1283-1312 is not part of this entry point).
+ * src/lidarFactor.hpp:9-51,91-121), twice (:1076).  The ground block (:1314-1340, Ground_DeltaFactor_goable) and the IMU
+ * block (:1285-1312, RelativeRFactor + two PitchRollFactor) are optional inputs.
  * Features are n x 4 floats {x, y, z, weight} (PointXYZINormal's x,y,z,normal_x); quaternions are x,y,z,w. */
 typedef struct rgc_mapreg_report {
   double initial_cost, final_cost;  /* ceres Summary: 1/2 sum rho(|r|^2) before / after the solve */
@@ -290,6 +290,17 @@ typedef struct rgc_mapreg_ground {
   double last_q[4], last_t[3];                               /* last_q_q, last_t_t: the fixed previous pose */
   double p_var;                                              /* ground_cov (0.2) */
 } rgc_mapreg_ground;
+/* the IMU block of RGC_mapping.cpp:1285-1312 (USE_IMU == 1 && map_update != 0), NULL loss: RelativeRFactor::Create(delta_q_imu,
+ * imu_cov) on (para_q_last, para_q) (src/lidarFactor.hpp:174-226) and PitchRollFactor::Create(pitch, roll, 0.02) on para_q and
+ * on para_q_last (:434-468).  The caller computes imu_cov (0.004 / 0.4, :1288-1293) and the pitch / roll targets in radians
+ * (ypr of IMUTemp.Rwi * R_il and of IMULast.Rwi * R_il, :1299-1310) as the reference does. */
+typedef struct rgc_mapreg_imu {
+  double delta_q[4];             /* delta_q_imu (x,y,z,w) */
+  double imu_cov;                /* q_var of the RelativeRFactor */
+  double pitch_cur, roll_cur;    /* pl_tmp, rl_tmp */
+  double pitch_last, roll_last;  /* pl_last, rl_last */
+  double pr_var;                 /* q_var of both PitchRollFactor (0.02) */
+} rgc_mapreg_imu;
 /* laserCloudCornerFromMapDS / laserCloudSurfFromMapDS (host AoS, x,y,z first; at least 5 points each) */
 RGC_API int rgc_mapreg_set_maps(rgc_ctx* ctx, const float* corner_map, int n_corner, const float* surf_map, int n_surf, int stride_bytes);
 /* association only (kind 0 = edge against the corner map, 1 = plane against the surf map): factors8 (nullable) receives
@@ -298,11 +309,12 @@ RGC_API int rgc_mapreg_associate(rgc_ctx* ctx, int kind, const float* feat_xyzw,
                                  double* factors8, int* n_valid);
 /* poses: q_w_curr[4] t_w_curr[3] q_w_last[4] t_w_last[3], in/out.  *gate_failed = 1 (poses untouched) when the size gate of
  * :1069 is not met.  report: one entry per pass of the two-pass loop (nullable).  ground_cur / ground_last (nullable): the
- * ground block on (para_q, para_t) resp. (para_q_last, para_t_last) -- pass them when the reference's condition at :1314 holds. */
+ * ground block on (para_q, para_t) resp. (para_q_last, para_t_last) -- pass them when the reference's condition at :1314 holds.
+ * imu (nullable): the IMU block -- pass it when the condition at :1285 holds. */
 RGC_API int rgc_mapreg_optimize(rgc_ctx* ctx, const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur,
                                 const float* corner_last, int n_clast, const float* surf_last, int n_slast,
-                                const rgc_mapreg_ground* ground_cur, const rgc_mapreg_ground* ground_last, double poses[14],
-                                rgc_mapreg_report report[2], int* gate_failed);
+                                const rgc_mapreg_ground* ground_cur, const rgc_mapreg_ground* ground_last,
+                                const rgc_mapreg_imu* imu, double poses[14], rgc_mapreg_report report[2], int* gate_failed);
 
 
 /* ---- in-library kernel timing with HIP events on the context's stream (bench.py roofline) ---- */

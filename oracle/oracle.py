@@ -80,6 +80,22 @@ def make_ground(d):
     return g
 
 
+class MapregImu(C.Structure):
+    _fields_ = [("delta_q", C.c_double * 4), ("imu_cov", C.c_double), ("pitch_cur", C.c_double), ("roll_cur", C.c_double),
+                ("pitch_last", C.c_double), ("roll_last", C.c_double), ("pr_var", C.c_double)]
+
+
+def make_imu(d):
+    """dict(delta_q (x,y,z,w), imu_cov, pitch_cur, roll_cur, pitch_last, roll_last, pr_var=0.02) -> MapregImu"""
+    if d is None:
+        return None
+    m = MapregImu()
+    m.delta_q = (C.c_double * 4)(*[float(x) for x in d["delta_q"]])
+    m.imu_cov, m.pr_var = float(d["imu_cov"]), float(d.get("pr_var", 0.02))
+    m.pitch_cur, m.roll_cur, m.pitch_last, m.roll_last = (float(d[k]) for k in ("pitch_cur", "roll_cur", "pitch_last", "roll_last"))
+    return m
+
+
 class MapregTrace(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("radius", C.c_double), ("iterations", C.c_int),
                 ("successful", C.c_int), ("n_edge_cur", C.c_int), ("n_edge_last", C.c_int), ("n_plane_cur", C.c_int),
@@ -149,8 +165,9 @@ def lib():
         L.orc_mapreg_associate_edges.argtypes = [fp, C.c_int, dp, dp, fp, C.c_int, C.c_int, ef, C.c_int]
         L.orc_mapreg_associate_planes.argtypes = [fp, C.c_int, dp, dp, fp, C.c_int, C.c_int, pf, C.c_int]
         gp = C.POINTER(MapregGround)
-        L.orc_mapreg_solve.argtypes = [fp, ef, C.c_int, fp, pf, C.c_int, fp, ef, C.c_int, fp, pf, C.c_int, gp, gp, dp, C.c_int, tr]
-        L.orc_mapreg_optimize.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, gp, gp, dp, tr, C.c_int]
+        mi = C.POINTER(MapregImu)
+        L.orc_mapreg_solve.argtypes = [fp, ef, C.c_int, fp, pf, C.c_int, fp, ef, C.c_int, fp, pf, C.c_int, gp, gp, mi, dp, C.c_int, tr]
+        L.orc_mapreg_optimize.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int, gp, gp, mi, dp, tr, C.c_int]
         _lib = L
     return _lib
 
@@ -344,29 +361,30 @@ def mapreg_associate(feat_xyzw, q_xyzw, t, map_xyz, kind, threads=0, raw=False):
 
 
 def mapreg_solve(corner_cur, e_cur, surf_cur, p_cur, corner_last, e_last, surf_last, p_last, poses14, max_iterations=6, ground_cur=None,
-                 ground_last=None):
+                 ground_last=None, imu=None):
     """ceres::Solve restated (RGC_mapping.cpp:1333-1341); e_*/p_* are the RAW ctypes factor arrays of mapreg_associate(raw=True)."""
     cc, ccp = _f32(corner_cur); sc, scp = _f32(surf_cur); cl, clp = _f32(corner_last); sl, slp = _f32(surf_last)
     x = np.ascontiguousarray(poses14, dtype=np.float64).copy()
     tr = MapregTrace()
-    gc, gl = make_ground(ground_cur), make_ground(ground_last)
+    gc, gl, im = make_ground(ground_cur), make_ground(ground_last), make_imu(imu)
     lib().orc_mapreg_solve(ccp, e_cur, cc.shape[0], scp, p_cur, sc.shape[0], clp, e_last, cl.shape[0], slp, p_last, sl.shape[0],
-                           C.byref(gc) if gc else None, C.byref(gl) if gl else None, x.ctypes.data_as(C.POINTER(C.c_double)), max_iterations,
-                           C.byref(tr))
+                           C.byref(gc) if gc else None, C.byref(gl) if gl else None, C.byref(im) if im else None,
+                           x.ctypes.data_as(C.POINTER(C.c_double)), max_iterations, C.byref(tr))
     return x, {k: getattr(tr, k) for k, _ in MapregTrace._fields_ if k != "pad"}
 
 
-def mapreg_optimize(corner_cur, surf_cur, corner_last, surf_last, corner_map, surf_map, poses14, threads=0, ground_cur=None, ground_last=None):
+def mapreg_optimize(corner_cur, surf_cur, corner_last, surf_last, corner_map, surf_map, poses14, threads=0, ground_cur=None, ground_last=None,
+                    imu=None):
     """The optimisation block of one mapping frame (2 x associate + solve, then quaternion normalisation)."""
     cc, ccp = _f32(corner_cur); sc, scp = _f32(surf_cur); cl, clp = _f32(corner_last); sl, slp = _f32(surf_last)
     cm, cmp_ = _f32(corner_map); sm, smp = _f32(surf_map)
     assert cm.shape[1] == sm.shape[1]
     x = np.ascontiguousarray(poses14, dtype=np.float64).copy()
     tr = (MapregTrace * 2)()
-    gc, gl = make_ground(ground_cur), make_ground(ground_last)
+    gc, gl, im = make_ground(ground_cur), make_ground(ground_last), make_imu(imu)
     rc = lib().orc_mapreg_optimize(ccp, cc.shape[0], scp, sc.shape[0], clp, cl.shape[0], slp, sl.shape[0], cmp_, cm.shape[0], smp, sm.shape[0],
-                                   cm.shape[1], C.byref(gc) if gc else None, C.byref(gl) if gl else None, x.ctypes.data_as(C.POINTER(C.c_double)),
-                                   tr, threads)
+                                   cm.shape[1], C.byref(gc) if gc else None, C.byref(gl) if gl else None, C.byref(im) if im else None,
+                                   x.ctypes.data_as(C.POINTER(C.c_double)), tr, threads)
     if rc < 0:
         raise RuntimeError(f"orc_mapreg_optimize rc={rc}")
     return x, rc, [{k: getattr(t, k) for k, _ in MapregTrace._fields_ if k != "pad"} for t in tr]

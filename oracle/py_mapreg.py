@@ -95,6 +95,25 @@ def ground_residual(G, q, t):
                      abs(np.dot(G["last_v1"], gn)) / (pv * 10), abs(np.dot(G["last_v2"], gn)) / (pv * 10)])
 
 
+def pitch_roll(q):
+    """Quaternion2EulerAngle (lidarFactor.hpp:405-433), q = x,y,z,w"""
+    x, y, z, w = q
+    sinp = 2 * (w * y - x * z)
+    return (np.pi / 2 if sinp >= 1 else (-np.pi / 2 if sinp <= -1 else np.arcsin(sinp))), np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))
+
+
+def imu_residual(I, qc, ql):
+    """RelativeRFactor on (q_last, q_cur) + PitchRollFactor on each (lidarFactor.hpp:174-226, 434-468); I = dict like oracle.make_imu's input"""
+    qli = np.array([-ql[0], -ql[1], -ql[2], ql[3]])
+    rqi = np.array([-I["delta_q"][0], -I["delta_q"][1], -I["delta_q"][2], I["delta_q"][3]])
+    e = _qmul(rqi, _qmul(qli, np.asarray(qc, float)))
+    pv = I.get("pr_var", 0.02)
+    pc, rc = pitch_roll(qc)
+    pl, rl = pitch_roll(ql)
+    return np.concatenate([2 * e[:3] / I["imu_cov"], [2 * (pc - I["pitch_cur"]) / pv, 2 * (rc - I["roll_cur"]) / pv,
+                                                      2 * (pl - I["pitch_last"]) / pv, 2 * (rl - I["roll_last"]) / pv]])
+
+
 def _sq(blocks):
     return np.concatenate([np.sum(b * b, axis=1) for b in blocks])
 
@@ -118,7 +137,7 @@ def _flat(blocks):
     return np.concatenate([b.reshape(-1) for b in blocks])
 
 
-def lm_solve(sets, poses14, max_iterations=6):
+def lm_solve(sets, poses14, max_iterations=6, imu=None):
     """Ceres-style LM (the loop restated in rgc_oracle_map.c) with finite-difference Jacobians; sets = [(cfeat, ef, sfeat, pf)] x 2."""
     x = np.array(poses14, float)
     def pose(xv, b):
@@ -138,8 +157,11 @@ def lm_solve(sets, poses14, max_iterations=6):
     def ground_r(xv, b):
         q, t = pose(xv, b)
         return ground_residual(ground_of(b), q, t) if ground_of(b) is not None else np.zeros(0)
+    def imu_r(xv):
+        return imu_residual(imu, xv[0:4], xv[7:11]) if imu is not None else np.zeros(0)
     def cost_at(xv):
-        return robust_cost(blocks_at(xv, 0)) + robust_cost(blocks_at(xv, 1)) + 0.5 * sum(float(ground_r(xv, b) @ ground_r(xv, b)) for b in range(2))
+        return (robust_cost(blocks_at(xv, 0)) + robust_cost(blocks_at(xv, 1)) + 0.5 * sum(float(ground_r(xv, b) @ ground_r(xv, b)) for b in range(2))
+                + 0.5 * float(imu_r(xv) @ imu_r(xv)))
     def normal_eq(xv):
         H, g = np.zeros((12, 12)), np.zeros(12)
         for b in range(2):
@@ -161,6 +183,14 @@ def lm_solve(sets, poses14, max_iterations=6):
                 Jw, rw = np.vstack([Jw, Jg]), np.concatenate([rw, rg])
             H[6 * b: 6 * b + 6, 6 * b: 6 * b + 6] = Jw.T @ Jw
             g[6 * b: 6 * b + 6] = Jw.T @ rw
+        if imu is not None:  # couples the two rotations: a full 12-column Jacobian
+            ri = imu_r(xv)
+            Ji = np.zeros((7, 12))
+            for a in range(12):
+                d = np.zeros(12); d[a] = 1e-6
+                Ji[:, a] = (imu_r(apply(xv, d)) - imu_r(apply(xv, -d))) / 2e-6
+            H += Ji.T @ Ji
+            g += Ji.T @ ri
         return H, g
     radius, dec = 1e4, 2.0
     cost = cost_at(x)

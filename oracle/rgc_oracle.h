@@ -142,6 +142,9 @@ typedef struct {
   double cur_norm[3], cur_distance;                          /* g_cur */
   double q_history[4], last_q[4], last_t[3], p_var;          /* q_w_curr_f, q_w_last, t_w_last, ground_cov (0.2) */
 } orc_mapreg_ground;
+/* the IMU block of RGC_mapping.cpp:1285-1312: RelativeRFactor(delta_q_imu, imu_cov) on (q_last, q_cur) and PitchRollFactor(pitch, roll,
+ * pr_var) on each pose (src/lidarFactor.hpp:174-226, 434-468) */
+typedef struct { double delta_q[4], imu_cov, pitch_cur, roll_cur, pitch_last, roll_last, pr_var; } orc_mapreg_imu;
 /* features: nf x 4 floats (x, y, z, normal_x = the per-feature weight of scanRegistration.cpp:501,554,609); q = x,y,z,w */
 int orc_mapreg_associate_edges(const float* feat, int nf, const double q_xyzw[4], const double t[3], const float* map_xyz, int nmap,
                                int mstride, orc_edge_factor* out, int num_threads);
@@ -151,12 +154,13 @@ int orc_mapreg_associate_planes(const float* feat, int nf, const double q_xyzw[4
 int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int n_ccur, const float* surf_cur, const orc_plane_factor* p_cur,
                      int n_scur, const float* corner_last, const orc_edge_factor* e_last, int n_clast, const float* surf_last,
                      const orc_plane_factor* p_last, int n_slast, const orc_mapreg_ground* ground_cur /* nullable */,
-                     const orc_mapreg_ground* ground_last /* nullable */, double poses[14], int max_iterations, orc_mapreg_trace* trace);
+                     const orc_mapreg_ground* ground_last /* nullable */, const orc_mapreg_imu* imu /* nullable */, double poses[14],
+                     int max_iterations, orc_mapreg_trace* trace);
 /* returns 1 if the gate of RGC_mapping.cpp:1069 is not met (poses untouched), 0 on success */
 int orc_mapreg_optimize(const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur, const float* corner_last, int n_clast,
                         const float* surf_last, int n_slast, const float* corner_map, int n_cmap, const float* surf_map, int n_smap,
-                        int mstride, const orc_mapreg_ground* ground_cur, const orc_mapreg_ground* ground_last, double poses[14],
-                        orc_mapreg_trace trace[2], int num_threads);
+                        int mstride, const orc_mapreg_ground* ground_cur, const orc_mapreg_ground* ground_last, const orc_mapreg_imu* imu,
+                        double poses[14], orc_mapreg_trace trace[2], int num_threads);
 
 /* ---- f4: loop-closure ICP = pcl::IterativeClosestPoint as used at src/RGC_mapping.cpp:2050-2069 (restated, see rgc_oracle.c) ---- */
 enum { ORC_ICP_NOT_CONVERGED = 0, ORC_ICP_ITERATIONS = 1, ORC_ICP_TRANSFORM = 2, ORC_ICP_ABS_MSE = 3, ORC_ICP_REL_MSE = 4, ORC_ICP_NO_CORRESPONDENCES = 5 };

@@ -11,8 +11,8 @@
  *   iterations, Ceres 1.14 defaults) -> the LM loop of orc_mapreg_solve below (robustification by the Triggs corrector,
  *   which for Huber reduces to scaling residual and Jacobian by sqrt(rho'); damping diag(J^T J)/radius; step acceptance
  *   and radius update of LevenbergMarquardtStrategy).  Pinned by oracle/py_mapreg.py (numpy/scipy).
- * USE_IMU = 0 (the block of :1283-1312 is not restated); the ground block of :1314-1340 (Ground_DeltaFactor_goable,
- * lidarFactor.hpp:352-403, NULL loss) is optional input.
+ * The IMU block of :1285-1312 (RelativeRFactor, PitchRollFactor) and the ground block of :1314-1340
+ * (Ground_DeltaFactor_goable), both NULL loss, are optional inputs.
  */
 #include "rgc_oracle.h"
 
@@ -262,22 +262,6 @@ static void pose_terms(const float* cfeat, const orc_edge_factor* ef, int ne, co
   }
 }
 
-/* 6x6 symmetric positive definite solve (Cholesky) */
-static int chol_solve6(const double Ain[36], const double rhs[6], double x[6]) {
-  double L[36] = {0};
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j <= i; j++) {
-      double s = Ain[i * 6 + j];
-      for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
-      if (i == j) { if (!(s > 0)) return -1; L[i * 6 + i] = sqrt(s); }
-      else L[i * 6 + j] = s / L[j * 6 + j];
-    }
-  double y[6];
-  for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
-  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
-  return 0;
-}
-
 static void quat_plus(const double q[4], const double d[3], double out[4]) { /* EigenQuaternionParameterization::Plus */
   const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   double dq[4];
@@ -347,82 +331,166 @@ static void ground_terms(const orc_mapreg_ground* G, const double q[4], const do
   }
 }
 
+/* ---- the IMU block of RGC_mapping.cpp:1285-1312 (USE_IMU = 1, the launch file's default): RelativeRFactor on (q_last, q_cur)
+ * (lidarFactor.hpp:174-226) and a PitchRollFactor on each pose (:434-468), all with NULL loss: seven residuals that couple
+ * the two rotations. */
+static void quat_to_pitch_roll(const double q[4], double* pitch, double* roll) { /* Quaternion2EulerAngle, :405-433; q = x,y,z,w */
+  const double w = q[3], x = q[0], y = q[1], z = q[2];
+  *roll = atan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y));
+  const double sinp = 2 * (w * y - x * z);
+  *pitch = sinp >= 1 ? M_PI / 2 : (sinp <= -1 ? -M_PI / 2 : asin(sinp));
+}
+
+static void imu_residual(const orc_mapreg_imu* I, const double qc[4], const double ql[4], double r[7]) {
+  const double qli[4] = {-ql[0], -ql[1], -ql[2], ql[3]};       /* QuaternionInverse(w_q_i) */
+  const double rqi[4] = {-I->delta_q[0], -I->delta_q[1], -I->delta_q[2], I->delta_q[3]};
+  double q_ij[4], e[4];
+  quat_mul(qli, qc, q_ij);                                       /* q_i^-1 (x) q_j  with i = last, j = cur */
+  quat_mul(rqi, q_ij, e);                                        /* relative_q^-1 (x) q_i_j */
+  for (int a = 0; a < 3; a++) r[a] = 2 * e[a] / I->imu_cov;
+  double p, ro;
+  quat_to_pitch_roll(qc, &p, &ro);
+  r[3] = 2 * (p - I->pitch_cur) / I->pr_var; r[4] = 2 * (ro - I->roll_cur) / I->pr_var;
+  quat_to_pitch_roll(ql, &p, &ro);
+  r[5] = 2 * (p - I->pitch_last) / I->pr_var; r[6] = 2 * (ro - I->roll_last) / I->pr_var;
+}
+
+/* adds the IMU block: cost, and the full 12x12 H / 12-vector g if given (central differences on the tangent, step 1e-6) */
+static void imu_terms(const orc_mapreg_imu* I, const double x[14], double* H144, double* g12, double* cost) {
+  if (!I) return;
+  double r[7];
+  imu_residual(I, x, x + 7, r);
+  for (int k = 0; k < 7; k++) *cost += 0.5 * r[k] * r[k];
+  if (!H144) return;
+  double J[7 * 12];
+  const double h = 1e-6;
+  for (int a = 0; a < 12; a++) {
+    double rp[7], rm[7];
+    if (a % 6 >= 3) { for (int k = 0; k < 7; k++) J[k * 12 + a] = 0.0; continue; } /* translations do not enter */
+    for (int sgn = 0; sgn < 2; sgn++) {
+      double qc[4], ql[4], d[3] = {0, 0, 0};
+      memcpy(qc, x, sizeof(qc)); memcpy(ql, x + 7, sizeof(ql));
+      d[a % 6] = sgn ? -h : h;
+      if (a < 6) quat_plus(x, d, qc); else quat_plus(x + 7, d, ql);
+      imu_residual(I, qc, ql, sgn ? rm : rp);
+    }
+    for (int k = 0; k < 7; k++) J[k * 12 + a] = (rp[k] - rm[k]) / (2 * h);
+  }
+  for (int a = 0; a < 12; a++) {
+    for (int c = 0; c < 12; c++) {
+      double v = 0;
+      for (int k = 0; k < 7; k++) v += J[k * 12 + a] * J[k * 12 + c];
+      H144[a * 12 + c] += v;
+    }
+    double v = 0;
+    for (int k = 0; k < 7; k++) v += J[k * 12 + a] * r[k];
+    g12[a] += v;
+  }
+}
+
+/* Cholesky solve of a symmetric positive definite n x n system (n <= 12) */
+static int chol_solve_n(const double* Ain, const double* rhs, double* x, int n) {
+  double L[144] = {0}, y[12];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = Ain[i * n + j];
+      for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
+      if (i == j) { if (!(s > 0)) return -1; L[i * n + i] = sqrt(s); }
+      else L[i * n + j] = s / L[j * n + j];
+    }
+  for (int i = 0; i < n; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * y[k]; y[i] = s / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
+  return 0;
+}
+
+typedef struct {
+  const float *corner_cur, *surf_cur, *corner_last, *surf_last;
+  const orc_edge_factor *e_cur, *e_last;
+  const orc_plane_factor *p_cur, *p_last;
+  int n_ccur, n_scur, n_clast, n_slast;
+  const orc_mapreg_ground *ground_cur, *ground_last;
+  const orc_mapreg_imu* imu;
+} mapreg_problem;
+
+/* robust cost at x and, if H144 != NULL, the 12x12 normal equations (two 6x6 pose blocks + the IMU coupling) */
+static double mapreg_evaluate(const mapreg_problem* P, const double x[14], double* H144, double* g12) {
+  const double huber_a = 0.1;
+  double H[2][21], g[2][6], cost = 0;
+  memset(H, 0, sizeof(H)); memset(g, 0, sizeof(g));
+  pose_terms(P->corner_cur, P->e_cur, P->n_ccur, P->surf_cur, P->p_cur, P->n_scur, x, x + 4, huber_a, H144 ? H[0] : NULL, H144 ? g[0] : NULL, &cost);
+  pose_terms(P->corner_last, P->e_last, P->n_clast, P->surf_last, P->p_last, P->n_slast, x + 7, x + 11, huber_a, H144 ? H[1] : NULL,
+             H144 ? g[1] : NULL, &cost);
+  ground_terms(P->ground_cur, x, x + 4, H144 ? H[0] : NULL, H144 ? g[0] : NULL, &cost);
+  ground_terms(P->ground_last, x + 7, x + 11, H144 ? H[1] : NULL, H144 ? g[1] : NULL, &cost);
+  if (H144) {
+    memset(H144, 0, sizeof(double) * 144);
+    for (int b = 0; b < 2; b++) {
+      int u = 0;
+      for (int a = 0; a < 6; a++)
+        for (int c = a; c < 6; c++) { H144[(6 * b + a) * 12 + 6 * b + c] = H[b][u]; H144[(6 * b + c) * 12 + 6 * b + a] = H[b][u]; u++; }
+      for (int a = 0; a < 6; a++) g12[6 * b + a] = g[b][a];
+    }
+  }
+  imu_terms(P->imu, x, H144, g12, &cost);
+  return cost;
+}
+
 /* ceres::Solve restated (see the header of this file).  poses: q_cur[4] t_cur[3] q_last[4] t_last[3] in/out. */
 int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int n_ccur, const float* surf_cur, const orc_plane_factor* p_cur,
                      int n_scur, const float* corner_last, const orc_edge_factor* e_last, int n_clast, const float* surf_last,
                      const orc_plane_factor* p_last, int n_slast, const orc_mapreg_ground* ground_cur, const orc_mapreg_ground* ground_last,
-                     double poses[14], int max_iterations, orc_mapreg_trace* trace) {
-  const double huber_a = 0.1;
+                     const orc_mapreg_imu* imu, double poses[14], int max_iterations, orc_mapreg_trace* trace) {
+  const mapreg_problem P = {corner_cur, surf_cur, corner_last, surf_last, e_cur, e_last, p_cur, p_last, n_ccur, n_scur, n_clast, n_slast,
+                            ground_cur, ground_last, imu};
   double radius = 1e4, decrease_factor = 2.0; /* initial_trust_region_radius, LevenbergMarquardtStrategy */
-  double* qc = poses; double* tc = poses + 4; double* ql = poses + 7; double* tl = poses + 11;
-  double H[2][21], g[2][6], cost = 0;
+  double H[144], g[12];
   int it = 0, n_success = 0;
-  memset(H, 0, sizeof(H)); memset(g, 0, sizeof(g));
-  pose_terms(corner_cur, e_cur, n_ccur, surf_cur, p_cur, n_scur, qc, tc, huber_a, H[0], g[0], &cost);
-  pose_terms(corner_last, e_last, n_clast, surf_last, p_last, n_slast, ql, tl, huber_a, H[1], g[1], &cost);
-  ground_terms(ground_cur, qc, tc, H[0], g[0], &cost);
-  ground_terms(ground_last, ql, tl, H[1], g[1], &cost);
+  double cost = mapreg_evaluate(&P, poses, H, g);
   if (trace) { trace->initial_cost = cost; trace->iterations = 0; trace->successful = 0; }
   for (it = 0; it < max_iterations; it++) {
-    /* gradient tolerance (max-norm) */
-    double gmax = 0;
-    for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) if (fabs(g[b][a]) > gmax) gmax = fabs(g[b][a]);
+    double gmax = 0; /* gradient tolerance (max-norm) */
+    for (int a = 0; a < 12; a++) if (fabs(g[a]) > gmax) gmax = fabs(g[a]);
     if (gmax <= 1e-10) break;
-    /* LM step: (H + diag(clamp(diag H)) / radius) d = -g, block diagonal over the two poses */
-    double d[2][6], model = 0;
-    int ok = 1;
-    for (int b = 0; b < 2; b++) {
-      double A[36];
-      int u = 0;
-      for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { A[a * 6 + c] = H[b][u]; A[c * 6 + a] = H[b][u]; u++; }
-      for (int a = 0; a < 6; a++) {
-        double dg = A[a * 7];
-        if (dg < 1e-6) dg = 1e-6;   /* min_lm_diagonal */
-        if (dg > 1e32) dg = 1e32;   /* max_lm_diagonal */
-        A[a * 7] += dg / radius;
-      }
-      double rhs[6];
-      for (int a = 0; a < 6; a++) rhs[a] = -g[b][a];
-      if (chol_solve6(A, rhs, d[b]) != 0) { ok = 0; break; }
-      /* model cost change = -d^T (g + 0.5 H d) */
-      u = 0;
-      double Hd[6] = {0, 0, 0, 0, 0, 0};
-      double Hf[36];
-      for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { Hf[a * 6 + c] = H[b][u]; Hf[c * 6 + a] = H[b][u]; u++; }
-      for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) Hd[a] += Hf[a * 6 + c] * d[b][c];
-      for (int a = 0; a < 6; a++) model -= d[b][a] * (g[b][a] + 0.5 * Hd[a]);
+    /* LM step: (H + diag(clamp(diag H)) / radius) d = -g */
+    double A[144], rhs[12], d[12], model = 0;
+    memcpy(A, H, sizeof(A));
+    for (int a = 0; a < 12; a++) {
+      double dg = H[a * 13];
+      if (dg < 1e-6) dg = 1e-6;   /* min_lm_diagonal */
+      if (dg > 1e32) dg = 1e32;   /* max_lm_diagonal */
+      A[a * 13] += dg / radius;
+      rhs[a] = -g[a];
     }
-    double rho = -1.0, new_cost = cost;
-    double nq[2][4], nt[2][3];
+    const int ok = chol_solve_n(A, rhs, d, 12) == 0;
+    if (ok)
+      for (int a = 0; a < 12; a++) { /* model cost change = -d^T (g + 0.5 H d) */
+        double Hd = 0;
+        for (int c = 0; c < 12; c++) Hd += H[a * 12 + c] * d[c];
+        model -= d[a] * (g[a] + 0.5 * Hd);
+      }
+    double rho = -1.0, xn[14], Hn[144], gn[12], new_cost = cost;
+    memcpy(xn, poses, sizeof(xn));
     if (ok && model > 0) {
-      quat_plus(qc, d[0], nq[0]);
-      quat_plus(ql, d[1], nq[1]);
-      for (int a = 0; a < 3; a++) { nt[0][a] = tc[a] + d[0][3 + a]; nt[1][a] = tl[a] + d[1][3 + a]; }
-      new_cost = 0;
-      pose_terms(corner_cur, e_cur, n_ccur, surf_cur, p_cur, n_scur, nq[0], nt[0], huber_a, NULL, NULL, &new_cost);
-      pose_terms(corner_last, e_last, n_clast, surf_last, p_last, n_slast, nq[1], nt[1], huber_a, NULL, NULL, &new_cost);
-      ground_terms(ground_cur, nq[0], nt[0], NULL, NULL, &new_cost);
-      ground_terms(ground_last, nq[1], nt[1], NULL, NULL, &new_cost);
+      for (int b = 0; b < 2; b++) {
+        quat_plus(poses + 7 * b, d + 6 * b, xn + 7 * b);
+        for (int a = 0; a < 3; a++) xn[7 * b + 4 + a] = poses[7 * b + 4 + a] + d[6 * b + 3 + a];
+      }
+      new_cost = mapreg_evaluate(&P, xn, Hn, gn);
       rho = (cost - new_cost) / model;
     }
     if (rho > 1e-3) { /* min_relative_decrease: successful step */
       const double old_cost = cost;
-      memcpy(qc, nq[0], sizeof(double) * 4); memcpy(ql, nq[1], sizeof(double) * 4);
-      memcpy(tc, nt[0], sizeof(double) * 3); memcpy(tl, nt[1], sizeof(double) * 3);
+      memcpy(poses, xn, sizeof(xn));
       double f = 1.0 - pow(2.0 * rho - 1.0, 3);
       if (f < 1.0 / 3.0) f = 1.0 / 3.0;
       radius = radius / f;
       if (radius > 1e16) radius = 1e16; /* max_trust_region_radius */
       decrease_factor = 2.0;
       n_success++;
-      memset(H, 0, sizeof(H)); memset(g, 0, sizeof(g));
-      cost = 0;
-      pose_terms(corner_cur, e_cur, n_ccur, surf_cur, p_cur, n_scur, qc, tc, huber_a, H[0], g[0], &cost);
-      pose_terms(corner_last, e_last, n_clast, surf_last, p_last, n_slast, ql, tl, huber_a, H[1], g[1], &cost);
-      ground_terms(ground_cur, qc, tc, H[0], g[0], &cost);
-      ground_terms(ground_last, ql, tl, H[1], g[1], &cost);
+      memcpy(H, Hn, sizeof(H)); memcpy(g, gn, sizeof(g));
+      cost = new_cost;
       double step2 = 0, x2 = 0;
-      for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) step2 += d[b][a] * d[b][a];
+      for (int a = 0; a < 12; a++) step2 += d[a] * d[a];
       for (int a = 0; a < 14; a++) x2 += poses[a] * poses[a];
       if (fabs(old_cost - cost) <= 1e-6 * old_cost) { it++; break; }                 /* function_tolerance */
       if (sqrt(step2) <= 1e-8 * (sqrt(x2) + 1e-8)) { it++; break; }                  /* parameter_tolerance */
@@ -440,8 +508,8 @@ int orc_mapreg_solve(const float* corner_cur, const orc_edge_factor* e_cur, int 
  * normalisation of :1375-1376 */
 int orc_mapreg_optimize(const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur, const float* corner_last, int n_clast,
                         const float* surf_last, int n_slast, const float* corner_map, int n_cmap, const float* surf_map, int n_smap,
-                        int mstride, const orc_mapreg_ground* ground_cur, const orc_mapreg_ground* ground_last, double poses[14],
-                        orc_mapreg_trace trace[2], int num_threads) {
+                        int mstride, const orc_mapreg_ground* ground_cur, const orc_mapreg_ground* ground_last, const orc_mapreg_imu* imu,
+                        double poses[14], orc_mapreg_trace trace[2], int num_threads) {
   /* the gate of :1069 */
   if (!(n_ccur > 10 && n_scur > 50 && n_cmap > 10 && n_smap > 50)) return 1;
   orc_edge_factor* ec = (orc_edge_factor*)malloc(sizeof(orc_edge_factor) * (size_t)(n_ccur > 0 ? n_ccur : 1));
@@ -456,7 +524,7 @@ int orc_mapreg_optimize(const float* corner_cur, int n_ccur, const float* surf_c
     int d = orc_mapreg_associate_planes(surf_last, n_slast, poses + 7, poses + 11, surf_map, n_smap, mstride, pl, num_threads);
     if (a < 0 || b < 0 || c < 0 || d < 0) { rc = -1; break; }
     if (trace) { trace[iter].n_edge_cur = a; trace[iter].n_edge_last = b; trace[iter].n_plane_cur = c; trace[iter].n_plane_last = d; }
-    orc_mapreg_solve(corner_cur, ec, n_ccur, surf_cur, pc, n_scur, corner_last, el, n_clast, surf_last, pl, n_slast, ground_cur, ground_last, poses, 6,
+    orc_mapreg_solve(corner_cur, ec, n_ccur, surf_cur, pc, n_scur, corner_last, el, n_clast, surf_last, pl, n_slast, ground_cur, ground_last, imu, poses, 6,
                      trace ? &trace[iter] : NULL);
   }
   /* q_w_last.normalize(); q_w_curr.normalize(); (:1375-1376) */

@@ -80,6 +80,11 @@ class MapregGround(C.Structure):
                 ("last_t", C.c_double * 3), ("p_var", C.c_double)]
 
 
+class MapregImu(C.Structure):
+    _fields_ = [("delta_q", C.c_double * 4), ("imu_cov", C.c_double), ("pitch_cur", C.c_double), ("roll_cur", C.c_double),
+                ("pitch_last", C.c_double), ("roll_last", C.c_double), ("pr_var", C.c_double)]
+
+
 class RgcError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"rgc_hip status {status}: {msg}")
@@ -169,8 +174,8 @@ def load():
     L.rgc_pcd_write.argtypes = [C.c_char_p, fp, C.c_int, C.c_int]
     L.rgc_mapreg_set_maps.argtypes = [vp, fp, C.c_int, fp, C.c_int, C.c_int]
     L.rgc_mapreg_associate.argtypes = [vp, C.c_int, fp, C.c_int, dp, dp, dp, ip]
-    L.rgc_mapreg_optimize.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.POINTER(MapregGround), C.POINTER(MapregGround), dp,
-                                      C.POINTER(MapregReport), ip]
+    L.rgc_mapreg_optimize.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.POINTER(MapregGround), C.POINTER(MapregGround),
+                                      C.POINTER(MapregImu), dp, C.POINTER(MapregReport), ip]
     L.rgc_profile_enable.argtypes = [vp, C.c_int]
     L.rgc_profile_select.argtypes = [vp, C.c_uint]
     L.rgc_profile_reset.argtypes = [vp]

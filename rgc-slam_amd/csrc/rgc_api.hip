@@ -525,19 +525,19 @@ int prepare_map_grid(rgc_ctx* c, Cloud& cl, double cell) {
   return RGC_OK;
 }
 
-// Cholesky solve of a symmetric positive definite 6x6 (the damped normal equations of one pose)
-bool chol_solve6(const double Ain[36], const double rhs[6], double x[6]) {
-  double L[36] = {0};
-  for (int i = 0; i < 6; i++)
+// Cholesky solve of a symmetric positive definite n x n, n <= 12 (the damped normal equations of the two poses: block
+// diagonal unless the IMU block couples the rotations)
+bool chol_solve(const double* A, const double* rhs, double* x, int n) {
+  double L[144] = {0}, y[12];
+  for (int i = 0; i < n; i++)
     for (int j = 0; j <= i; j++) {
-      double s = Ain[i * 6 + j];
-      for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
-      if (i == j) { if (!(s > 0)) return false; L[i * 6 + i] = std::sqrt(s); }
-      else L[i * 6 + j] = s / L[j * 6 + j];
+      double s = A[i * n + j];
+      for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
+      if (i == j) { if (!(s > 0)) return false; L[i * n + i] = std::sqrt(s); }
+      else L[i * n + j] = s / L[j * n + j];
     }
-  double y[6];
-  for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
-  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+  for (int i = 0; i < n; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * y[k]; y[i] = s / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
   return true;
 }
 
@@ -612,9 +612,68 @@ void ground_terms(const rgc_mapreg_ground* G, const double q[4], const double t[
   }
 }
 
-// sums of both poses at x (14 doubles): out[b][0..27] = 21 H, 6 g, cost; feature sets 0/1 = corner/surf of the current pose,
-// 2/3 = of the last pose
-int mapreg_eval(rgc_ctx* c, const int nfeat[4], const double x[14], bool want_H, const rgc_mapreg_ground* const ground[2], double out[2][28]) {
+// Quaternion2EulerAngle (lidarFactor.hpp:405-433) on x,y,z,w: pitch and roll only
+void pitch_roll(const double q[4], double* pitch, double* roll) {
+  const double sinp = 2 * (q[3] * q[1] - q[0] * q[2]);
+  *pitch = sinp >= 1 ? M_PI / 2 : (sinp <= -1 ? -M_PI / 2 : std::asin(sinp));
+  *roll = std::atan2(2 * (q[3] * q[0] + q[1] * q[2]), 1 - 2 * (q[0] * q[0] + q[1] * q[1]));
+}
+// RelativeRFactor on (q_last, q_cur) (lidarFactor.hpp:174-226; QuaternionInverse = conjugate, :124-130) followed by the
+// PitchRollFactor of the current and of the last pose (:434-468): 3 + 2 + 2 residuals
+void imu_residual(const rgc_mapreg_imu* I, const double q_cur[4], const double q_last[4], double r[7]) {
+  const double li[4] = {-q_last[0], -q_last[1], -q_last[2], q_last[3]};
+  const double di[4] = {-I->delta_q[0], -I->delta_q[1], -I->delta_q[2], I->delta_q[3]};
+  double q_ij[4], e[4], p, ro;
+  quat_mul_h(li, q_cur, q_ij);
+  quat_mul_h(di, q_ij, e);
+  for (int a = 0; a < 3; a++) r[a] = 2 * e[a] / I->imu_cov;
+  pitch_roll(q_cur, &p, &ro);
+  r[3] = 2 * (p - I->pitch_cur) / I->pr_var;
+  r[4] = 2 * (ro - I->roll_cur) / I->pr_var;
+  pitch_roll(q_last, &p, &ro);
+  r[5] = 2 * (p - I->pitch_last) / I->pr_var;
+  r[6] = 2 * (ro - I->roll_last) / I->pr_var;
+}
+// the IMU block (RGC_mapping.cpp:1285-1312) added on the host: seven scalars over the two rotations, NULL loss, Jacobian
+// on the local parameterisation by central differences (step 1e-6) like the ground block.  H is the full 12 x 12.
+void imu_terms(const rgc_mapreg_imu* I, const double x[14], bool want_H, double H[144], double g[12], double* cost) {
+  if (!I) return;
+  double r[7];
+  imu_residual(I, x, x + 7, r);
+  for (int k = 0; k < 7; k++) *cost += 0.5 * r[k] * r[k];
+  if (!want_H) return;
+  double J[7][12] = {};
+  const double h = 1e-6;
+  for (int b = 0; b < 2; b++)
+    for (int a = 0; a < 3; a++) {  // the translations do not enter
+      double rp[7], rm[7];
+      for (int sgn = 0; sgn < 2; sgn++) {
+        double qc[4], ql[4], d[3] = {0, 0, 0};
+        memcpy(qc, x, sizeof(qc)); memcpy(ql, x + 7, sizeof(ql));
+        d[a] = sgn ? -h : h;
+        quat_plus(x + 7 * b, d, b ? ql : qc);
+        imu_residual(I, qc, ql, sgn ? rm : rp);
+      }
+      for (int k = 0; k < 7; k++) J[k][6 * b + a] = (rp[k] - rm[k]) / (2 * h);
+    }
+  for (int a = 0; a < 12; a++) {
+    for (int e = 0; e < 12; e++) {
+      double v = 0;
+      for (int k = 0; k < 7; k++) v += J[k][a] * J[k][e];
+      H[a * 12 + e] += v;
+    }
+    double v = 0;
+    for (int k = 0; k < 7; k++) v += J[k][a] * r[k];
+    g[a] += v;
+  }
+}
+
+// the robustified normal equations of both poses at x (14 doubles): H 12 x 12 (two 6 x 6 pose blocks, plus the IMU block's
+// coupling of the rotations), g 12, the cost.  Feature sets 0/1 = corner/surf of the current pose, 2/3 = of the last pose;
+// the kernels return 21 H + 6 g + cost per pose.
+struct MapregSystem { double H[144], g[12], cost; };
+int mapreg_eval(rgc_ctx* c, const int nfeat[4], const double x[14], bool want_H, const rgc_mapreg_ground* const ground[2],
+                const rgc_mapreg_imu* imu, MapregSystem* out) {
   const float* feat[4];
   const double* fac[4];
   for (int s = 0; s < 4; s++) { feat[s] = (const float*)c->mr_feat[s].p; fac[s] = (const double*)c->mr_fac[s].p; }
@@ -622,8 +681,19 @@ int mapreg_eval(rgc_ctx* c, const int nfeat[4], const double x[14], bool want_H,
   HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double) * 56, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
-  memcpy(out, c->h_out, sizeof(double) * 56);
-  for (int b = 0; b < 2; b++) ground_terms(ground[b], x + 7 * b, x + 7 * b + 4, want_H, out[b]);
+  double S[2][28];
+  memcpy(S, c->h_out, sizeof(S));
+  for (int b = 0; b < 2; b++) ground_terms(ground[b], x + 7 * b, x + 7 * b + 4, want_H, S[b]);
+  memset(out->H, 0, sizeof(out->H));
+  memset(out->g, 0, sizeof(out->g));
+  for (int b = 0; b < 2 && want_H; b++) {
+    int u = 0;
+    for (int a = 0; a < 6; a++)
+      for (int e = a; e < 6; e++, u++) out->H[(6 * b + a) * 12 + 6 * b + e] = out->H[(6 * b + e) * 12 + 6 * b + a] = S[b][u];
+    for (int a = 0; a < 6; a++) out->g[6 * b + a] = S[b][21 + a];
+  }
+  out->cost = S[0][27] + S[1][27];
+  imu_terms(imu, x, want_H, out->H, out->g, &out->cost);
   return RGC_OK;
 }
 
@@ -1442,7 +1512,7 @@ int rgc_mapreg_associate(rgc_ctx* c, int kind, const float* feat_xyzw, int n, co
 
 int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const float* surf_cur, int n_scur, const float* corner_last,
                         int n_clast, const float* surf_last, int n_slast, const rgc_mapreg_ground* ground_cur, const rgc_mapreg_ground* ground_last,
-                        double poses[14], rgc_mapreg_report report[2], int* gate_failed) {
+                        const rgc_mapreg_imu* imu, double poses[14], rgc_mapreg_report report[2], int* gate_failed) {
   if (!c || !poses || n_ccur < 0 || n_scur < 0 || n_clast < 0 || n_slast < 0) return RGC_ERR_INVALID;
   if ((n_ccur && !corner_cur) || (n_scur && !surf_cur) || (n_clast && !corner_last) || (n_slast && !surf_last)) return RGC_ERR_INVALID;
   if (!c->mr_map[0].ready || !c->mr_map[1].ready) return fail(c, RGC_ERR_NO_INPUT, "rgc_mapreg_set_maps first");
@@ -1476,63 +1546,53 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
     HIPCHK(c, hipMemcpyAsync(c->h_small + 40, dcnt, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // ceres::Solve restated: trust-region LM, <= 6 iterations (:1333-1341), Ceres 1.14 defaults: initial radius 1e4, damping diag(H)/radius clamped to [1e-6, 1e32], step accepted above a relative decrease of 1e-3
     double radius = 1e4, decrease_factor = 2.0;
-    double S[2][28];
-    if ((rc = mapreg_eval(c, nfeat, poses, true, ground, S))) return rc;
-    double cost = S[0][27] + S[1][27];
+    MapregSystem S, Sn;
+    if ((rc = mapreg_eval(c, nfeat, poses, true, ground, imu, &S))) return rc;
     if (report) {
       report[iter].n_edge_cur = c->h_small[40]; report[iter].n_plane_cur = c->h_small[41];
       report[iter].n_edge_last = c->h_small[42]; report[iter].n_plane_last = c->h_small[43];
     }
     int it = 0, n_success = 0;
-    const double initial_cost = cost;
+    const double initial_cost = S.cost;
     for (it = 0; it < 6; it++) {
       double gmax = 0;
-      for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) gmax = std::fmax(gmax, std::fabs(S[b][21 + a]));
+      for (int a = 0; a < 12; a++) gmax = std::fmax(gmax, std::fabs(S.g[a]));
       if (gmax <= 1e-10) break;
-      double d[2][6], model = 0;
-      bool ok = true;
-      for (int b = 0; b < 2 && ok; b++) {
-        double Hf[36], A[36];
-        int u = 0;
-        for (int a = 0; a < 6; a++) for (int e = a; e < 6; e++) { Hf[a * 6 + e] = S[b][u]; Hf[e * 6 + a] = S[b][u]; u++; }
-        memcpy(A, Hf, sizeof(A));
-        for (int a = 0; a < 6; a++) {
-          double dg = A[a * 7];
-          if (dg < 1e-6) dg = 1e-6;
-          if (dg > 1e32) dg = 1e32;
-          A[a * 7] += dg / radius;
-        }
-        double rhs[6];
-        for (int a = 0; a < 6; a++) rhs[a] = -S[b][21 + a];
-        if (!chol_solve6(A, rhs, d[b])) { ok = false; break; }
-        double Hd[6] = {0, 0, 0, 0, 0, 0};
-        for (int a = 0; a < 6; a++) for (int e = 0; e < 6; e++) Hd[a] += Hf[a * 6 + e] * d[b][e];
-        for (int a = 0; a < 6; a++) model -= d[b][a] * (S[b][21 + a] + 0.5 * Hd[a]);
+      double A[144], rhs[12], d[12], model = 0;
+      memcpy(A, S.H, sizeof(A));
+      for (int a = 0; a < 12; a++) {
+        A[a * 13] += std::fmin(std::fmax(S.H[a * 13], 1e-6), 1e32) / radius;  // min / max_lm_diagonal
+        rhs[a] = -S.g[a];
       }
-      double rho = -1.0, xn[14], Sn[2][28];
+      const bool ok = chol_solve(A, rhs, d, 12);
+      for (int a = 0; a < 12 && ok; a++) {  // model cost change = -d^T (g + H d / 2)
+        double Hd = 0;
+        for (int e = 0; e < 12; e++) Hd += S.H[a * 12 + e] * d[e];
+        model -= d[a] * (S.g[a] + 0.5 * Hd);
+      }
+      double rho = -1.0, xn[14];
       memcpy(xn, poses, sizeof(xn));
       if (ok && model > 0) {
         for (int b = 0; b < 2; b++) {
-          quat_plus(poses + 7 * b, d[b], xn + 7 * b);
-          for (int a = 0; a < 3; a++) xn[7 * b + 4 + a] = poses[7 * b + 4 + a] + d[b][3 + a];
+          quat_plus(poses + 7 * b, d + 6 * b, xn + 7 * b);
+          for (int a = 0; a < 3; a++) xn[7 * b + 4 + a] = poses[7 * b + 4 + a] + d[6 * b + 3 + a];
         }
         // the candidate's cost AND its normal equations in one launch: nearly every step is accepted, and an accepted step
         // needs them next (a rejected one just drops them)
-        if ((rc = mapreg_eval(c, nfeat, xn, true, ground, Sn))) return rc;
-        rho = (cost - (Sn[0][27] + Sn[1][27])) / model;
+        if ((rc = mapreg_eval(c, nfeat, xn, true, ground, imu, &Sn))) return rc;
+        rho = (S.cost - Sn.cost) / model;
       }
       if (rho > 1e-3) {
-        const double old_cost = cost;
+        const double old_cost = S.cost;
         memcpy(poses, xn, sizeof(xn));
         radius = std::fmin(radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e16);
         decrease_factor = 2.0;
         n_success++;
-        memcpy(S, Sn, sizeof(S));
-        cost = S[0][27] + S[1][27];
+        S = Sn;
         double step2 = 0, x2 = 0;
-        for (int b = 0; b < 2; b++) for (int a = 0; a < 6; a++) step2 += d[b][a] * d[b][a];
+        for (int a = 0; a < 12; a++) step2 += d[a] * d[a];
         for (int a = 0; a < 14; a++) x2 += poses[a] * poses[a];
-        if (std::fabs(old_cost - cost) <= 1e-6 * old_cost) { it++; break; }
+        if (std::fabs(old_cost - S.cost) <= 1e-6 * old_cost) { it++; break; }
         if (std::sqrt(step2) <= 1e-8 * (std::sqrt(x2) + 1e-8)) { it++; break; }
       } else {
         radius /= decrease_factor;
@@ -1540,6 +1600,7 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
         if (radius < 1e-32) { it++; break; }
       }
     }
+    const double cost = S.cost;
     if (report) { report[iter].initial_cost = initial_cost; report[iter].final_cost = cost; report[iter].iterations = it; report[iter].successful = n_success; }
   }
   for (int b = 0; b < 2; b++) {  // q_w_last.normalize(); q_w_curr.normalize(); (:1375-1376)

@@ -83,18 +83,30 @@ class MapFeatureRegistration:
         g.last_distance, g.cur_distance, g.p_var = float(d["last_distance"]), float(d["cur_distance"]), float(d.get("p_var", 0.2))
         return g
 
-    def optimize(self, corner_cur, surf_cur, corner_last, surf_last, q_w_curr, t_w_curr, q_w_last, t_w_last, ground_cur=None, ground_last=None):
+    @staticmethod
+    def _imu(d):
+        if d is None:
+            return None
+        m = _lib.MapregImu()
+        m.delta_q = (C.c_double * 4)(*[float(v) for v in d["delta_q"]])
+        m.imu_cov, m.pr_var = float(d["imu_cov"]), float(d.get("pr_var", 0.02))
+        m.pitch_cur, m.roll_cur, m.pitch_last, m.roll_last = (float(d[k]) for k in ("pitch_cur", "roll_cur", "pitch_last", "roll_last"))
+        return m
+
+    def optimize(self, corner_cur, surf_cur, corner_last, surf_last, q_w_curr, t_w_curr, q_w_last, t_w_last, ground_cur=None, ground_last=None,
+                 imu=None):
         """The two-pass associate + solve block; returns (q_w_curr, t_w_curr, q_w_last, t_w_last, report) with report = None when
         the size gate of :1069 is not met (poses returned unchanged).  ground_cur / ground_last: dicts with the fields of
-        rgc_mapreg_ground (the Ground_DeltaFactor_goable blocks of :1314-1340), or None."""
+        rgc_mapreg_ground (the Ground_DeltaFactor_goable blocks of :1314-1340), or None.  imu: dict with the fields of
+        rgc_mapreg_imu (the RelativeRFactor / PitchRollFactor block of :1285-1312), or None."""
         cc, ccp = _f32(corner_cur, 4); sc, scp = _f32(surf_cur, 4); cl, clp = _f32(corner_last, 4); sl, slp = _f32(surf_last, 4)
         x = np.concatenate([np.asarray(q_w_curr, float), np.asarray(t_w_curr, float), np.asarray(q_w_last, float), np.asarray(t_w_last, float)])
         x = np.ascontiguousarray(x, np.float64)
         rep = (_lib.MapregReport * 2)()
         gate = C.c_int(0)
-        gc, gl = self._ground(ground_cur), self._ground(ground_last)
+        gc, gl, im = self._ground(ground_cur), self._ground(ground_last), self._imu(imu)
         self._chk(self._L.rgc_mapreg_optimize(self._h, ccp, cc.shape[0], scp, sc.shape[0], clp, cl.shape[0], slp, sl.shape[0],
                                               C.byref(gc) if gc else None, C.byref(gl) if gl else None,
-                                              x.ctypes.data_as(C.POINTER(C.c_double)), rep, C.byref(gate)))
+                                              C.byref(im) if im else None, x.ctypes.data_as(C.POINTER(C.c_double)), rep, C.byref(gate)))
         report = None if gate.value else [{k: getattr(r, k) for k, _ in _lib.MapregReport._fields_} for r in rep]
         return x[0:4].copy(), x[4:7].copy(), x[7:11].copy(), x[11:14].copy(), report

@@ -66,3 +66,18 @@ def make_ground(T_cur, T_last, height=0.56, p_var=0.2, tilt=(0.01, -0.008)):
     nc = nc + np.array([tilt[0], tilt[1], 0.0]); nc /= np.linalg.norm(nc)   # measurement noise on the current plane
     return dict(last_v1=v1, last_v2=v2, last_norm=nl, last_distance=dl, cur_norm=nc, cur_distance=dc + 0.01,
                 q_history=rot_to_quat_xyzw(T_last[:3, :3]), last_q=rot_to_quat_xyzw(T_last[:3, :3]), last_t=T_last[:3, 3].copy(), p_var=p_var)
+
+
+def make_imu(T_cur, T_last, noise=(0.004, -0.003, 0.002), imu_cov=0.4, pr_var=0.02):
+    """The IMU block's inputs (RGC_mapping.cpp:1285-1312) consistent with the true poses: delta_q_imu = q_last^-1 (x) q_cur with a
+    small gyro error, pitch / roll targets = those of each pose's rotation (Quaternion2EulerAngle convention) with an offset."""
+    def pr(q):
+        x, y, z, w = q
+        return np.arcsin(np.clip(2 * (w * y - x * z), -1, 1)), np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))
+    Rd = T_last[:3, :3].T @ T_cur[:3, :3]
+    e = perturb(np.eye(4), np.random.default_rng(5), ang=0.003, trans=0.0)[:3, :3]
+    dq = rot_to_quat_xyzw(e @ Rd)
+    pc, rc = pr(rot_to_quat_xyzw(T_cur[:3, :3]))
+    pl, rl = pr(rot_to_quat_xyzw(T_last[:3, :3]))
+    return dict(delta_q=dq, imu_cov=imu_cov, pitch_cur=pc + noise[0], roll_cur=rc + noise[1], pitch_last=pl + noise[2], roll_last=rl - noise[0],
+                pr_var=pr_var)

@@ -87,6 +87,28 @@ def test_optimize_with_ground_block_vs_oracle(case, reg):
     assert np.abs(x - plain).max() > 1e-6   # the block is really in the problem
 
 
+def test_optimize_with_imu_block_vs_oracle(case, reg):
+    """the IMU block couples the two rotations: a 12 x 12 solve, alone and together with the ground block"""
+    from oracle import oracle
+    x0 = case["x0"]
+    gc, gl = md.make_ground(case["T_cur"], case["T_last"]), md.make_ground(case["T_last"], case["T_last"], tilt=(-0.004, 0.006))
+    plain = np.concatenate(reg.optimize(case["corner_cur"], case["surf_cur"], case["corner_last"], case["surf_last"], x0[0:4], x0[4:7], x0[7:11], x0[11:14])[:4])
+    for imu_cov, ground in ((0.4, False), (0.004, False), (0.4, True)):
+        im = md.make_imu(case["T_cur"], case["T_last"], imu_cov=imu_cov)
+        kw = dict(ground_cur=gc, ground_last=gl) if ground else {}
+        qc, tc, ql, tl, rep = reg.optimize(case["corner_cur"], case["surf_cur"], case["corner_last"], case["surf_last"], x0[0:4], x0[4:7], x0[7:11],
+                                           x0[11:14], imu=im, **kw)
+        xo, rc, tr = oracle.mapreg_optimize(case["corner_cur"], case["surf_cur"], case["corner_last"], case["surf_last"], case["corner_map"],
+                                            case["surf_map"], x0, imu=im, **kw)
+        x = np.concatenate([qc, tc, ql, tl])
+        for i in range(2):
+            assert rep[i]["iterations"] == tr[i]["iterations"] and rep[i]["successful"] == tr[i]["successful"]
+            assert abs(rep[i]["initial_cost"] - tr[i]["initial_cost"]) <= 1e-9 * tr[i]["initial_cost"]
+            assert abs(rep[i]["final_cost"] - tr[i]["final_cost"]) <= 1e-9 * tr[i]["final_cost"]
+        assert np.abs(x - xo).max() < 1e-7
+        assert np.abs(x - plain).max() > 1e-6
+
+
 def test_gate_and_errors(case, reg):
     x0 = case["x0"]
     out = reg.optimize(case["corner_cur"][:5], case["surf_cur"], case["corner_last"], case["surf_last"], x0[0:4], x0[4:7], x0[7:11], x0[11:14])

@@ -99,6 +99,49 @@ def test_ground_block_matches_numpy(case):
     assert r.shape == (3,) and r[1] >= 0 and r[2] >= 0
 
 
+def test_imu_block_matches_numpy(case):
+    """the optional IMU block (RelativeRFactor on both rotations + a PitchRollFactor on each, NULL loss): it couples the two
+    poses, so the normal equations are a full 12 x 12"""
+    from oracle import oracle, py_mapreg as pm
+    raw, sets = _frozen(case)
+    x0 = case["x0"]
+    for imu_cov in (0.4, 0.004):     # the two values of RGC_mapping.cpp:1288-1293
+        im = md.make_imu(case["T_cur"], case["T_last"], imu_cov=imu_cov)
+        xc, trc = oracle.mapreg_solve(case["corner_cur"], raw["ec"][0], case["surf_cur"], raw["pc"][0], case["corner_last"], raw["el"][0],
+                                      case["surf_last"], raw["pl"][0], x0, 3, imu=im)
+        xn, trn = pm.lm_solve(sets, x0, 3, imu=im)
+        x_plain, tr_plain = oracle.mapreg_solve(case["corner_cur"], raw["ec"][0], case["surf_cur"], raw["pc"][0], case["corner_last"], raw["el"][0],
+                                                case["surf_last"], raw["pl"][0], x0, 3)
+        assert abs(trc["initial_cost"] - trn["initial_cost"]) <= 1e-10 * trn["initial_cost"]
+        assert trc["initial_cost"] > tr_plain["initial_cost"]
+        assert trc["successful"] == trn["successful"]
+        assert abs(trc["final_cost"] - trn["final_cost"]) <= 1e-7 * trn["final_cost"] and np.abs(xc - xn).max() < 1e-7
+        assert np.abs(xc - x_plain).max() > 1e-6
+    # known answers: at the exact relative rotation and the exact pitch / roll the seven residuals vanish
+    q = md.rot_to_quat_xyzw
+    exact = md.make_imu(case["T_cur"], case["T_last"], noise=(0, 0, 0))
+    exact["delta_q"] = q(case["T_last"][:3, :3].T @ case["T_cur"][:3, :3])
+    xt = md.poses14(case["T_cur"], case["T_last"])
+    assert np.abs(pm.imu_residual(exact, xt[0:4], xt[7:11])).max() < 1e-12
+    # a pure pitch of 0.1 rad about y: pitch residual = 2 * 0.1 / 0.02, roll residual 0
+    qy = np.array([0, np.sin(0.05), 0, np.cos(0.05)])
+    flat = dict(delta_q=[0, 0, 0, 1], imu_cov=0.4, pitch_cur=0, roll_cur=0, pitch_last=0, roll_last=0, pr_var=0.02)
+    r = pm.imu_residual(flat, qy, np.array([0, 0, 0, 1.0]))
+    assert np.allclose(r, [0, 2 * np.sin(0.05) / 0.4, 0, 10.0, 0, 0, 0], atol=1e-12)
+
+
+def test_imu_and_ground_together(case):
+    from oracle import oracle, py_mapreg as pm
+    raw, sets = _frozen(case)
+    gc, gl = md.make_ground(case["T_cur"], case["T_last"]), md.make_ground(case["T_last"], case["T_last"], tilt=(-0.004, 0.006))
+    im = md.make_imu(case["T_cur"], case["T_last"])
+    xc, trc = oracle.mapreg_solve(case["corner_cur"], raw["ec"][0], case["surf_cur"], raw["pc"][0], case["corner_last"], raw["el"][0],
+                                  case["surf_last"], raw["pl"][0], case["x0"], 4, ground_cur=gc, ground_last=gl, imu=im)
+    xn, trn = pm.lm_solve([sets[0] + (gc,), sets[1] + (gl,)], case["x0"], 4, imu=im)
+    assert trc["successful"] == trn["successful"] and abs(trc["final_cost"] - trn["final_cost"]) <= 1e-7 * trn["final_cost"]
+    assert np.abs(xc - xn).max() < 1e-7
+
+
 def test_converged_solution_is_a_minimum(case):
     """run to convergence: the gradient of the robust cost vanishes and a generic minimiser (scipy BFGS) cannot improve on it"""
     from oracle import oracle, py_mapreg as pm
