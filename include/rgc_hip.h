@@ -317,6 +317,42 @@ RGC_API int rgc_mapreg_optimize(rgc_ctx* ctx, const float* corner_cur, int n_ccu
                                 const rgc_mapreg_imu* imu, double poses[14], rgc_mapreg_report report[2], int* gate_failed);
 
 
+/* ---- f2: rolling local map resident on the device ----
+ * The odometer keeps a deque of <= slipwide (3) keyframe clouds in the WORLD frame (src/RGC_odometer.cpp:1237-1247), and every
+ * frame re-expresses all of them in the new body frame (:1248-1256), VoxelGrid-filters the concatenation (:985-991) and hands it
+ * to a fresh FastVGICP (:998,1007): 3 kd-trees, N_t covariances and the voxel map are rebuilt per FRAME even when no keyframe
+ * changed.  Here the keyframes stay in HBM in a map frame (world minus an origin that the caller keeps near the sensor so that
+ * fp32 coordinates stay small), the registration runs in that frame (guess = T_w_curr * T_last_curr, result = the new world pose)
+ * and the target (filter + grid + covariances + voxels) is rebuilt, on the device, only when a keyframe was inserted or evicted.
+ * Numerics differ from the reference by the frame the 0.3 m leaf lattice and the 1 m voxel lattice are aligned to (map axes
+ * instead of the previous body axes); see DESIGN.md 6e for the parity definition of this row. */
+typedef struct rgc_map_info {
+  int n_keyframes;
+  long long n_points;            /* world-frame points held (before the leaf filter) */
+  int n_target;                  /* points of the committed target, -1 if the map changed since the last commit */
+  unsigned long long revision;   /* bumped by every insert / evict / rebase / reset */
+  int oldest_id, newest_id;      /* -1 when empty */
+  double origin[3];
+} rgc_map_info;
+/* drops every keyframe; origin (nullable = 0,0,0): the world point the map frame is centred on */
+RGC_API int rgc_map_reset(rgc_ctx* ctx, const double origin[3]);
+/* surroundingCloud.push_back(transformPointCloud(cloud, q_w_curr, t_w_curr)) (:1237): q * p + (t - origin) in fp64, stored fp32,
+ * intensity copied.  xyzi: x,y,z,intensity (stride >= 16), host or (on_device) device memory.  *keyframe_id (nullable): its id. */
+RGC_API int rgc_map_insert(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, const double q_w_xyzw[4], const double t_w[3],
+                           int on_device, int* keyframe_id);
+/* eviction: first every keyframe whose pose is farther than radius from center (skipped when center is NULL or radius <= 0), then
+ * the oldest ones until at most max_keyframes remain (pop_front, :1242-1247; skipped when max_keyframes <= 0) */
+RGC_API int rgc_map_evict(rgc_ctx* ctx, int max_keyframes, const double center[3], double radius, int* n_evicted);
+/* moves the map frame's origin (every stored point shifts by old - new, fp64 -> fp32) */
+RGC_API int rgc_map_rebase(rgc_ctx* ctx, const double new_origin[3]);
+/* makes the map the registration target: pcl::VoxelGrid(leaf) over the keyframes in insertion order (:985-991) + setInputTarget
+ * (:1007), all on the device.  A no-op when nothing changed since the last commit and the target is still bound (rgc_set_target*
+ * unbinds it).  Poses passed to rgc_align / rgc_linearize are then map-frame poses (world translation minus origin). */
+RGC_API int rgc_map_commit(rgc_ctx* ctx, float leaf, int* n_target);
+RGC_API int rgc_map_get_info(rgc_ctx* ctx, rgc_map_info* out);
+/* which = 0: the stored keyframe points, 1: the committed target; up to cap points (x,y,z,intensity) to the host, *n = total */
+RGC_API int rgc_map_download(rgc_ctx* ctx, int which, float* out_xyzi, int cap, int* n);
+
 /* ---- in-library kernel timing with HIP events on the context's stream (bench.py roofline) ---- */
 enum {
   RGC_K_GRID = 0,      /* bbox + count + scan + scatter + rank/gather                         */

@@ -85,6 +85,11 @@ class MapregImu(C.Structure):
                 ("pitch_last", C.c_double), ("roll_last", C.c_double), ("pr_var", C.c_double)]
 
 
+class MapInfo(C.Structure):
+    _fields_ = [("n_keyframes", C.c_int), ("n_points", C.c_longlong), ("n_target", C.c_int), ("revision", C.c_ulonglong),
+                ("oldest_id", C.c_int), ("newest_id", C.c_int), ("origin", C.c_double * 3)]
+
+
 class RgcError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"rgc_hip status {status}: {msg}")
@@ -99,7 +104,7 @@ SYMBOLS = [
     "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
-    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_frontend_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_frontend_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_map_reset", "rgc_map_insert", "rgc_map_evict", "rgc_map_rebase", "rgc_map_commit", "rgc_map_get_info", "rgc_map_download", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
 _lib = None
@@ -176,6 +181,13 @@ def load():
     L.rgc_mapreg_associate.argtypes = [vp, C.c_int, fp, C.c_int, dp, dp, dp, ip]
     L.rgc_mapreg_optimize.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.POINTER(MapregGround), C.POINTER(MapregGround),
                                       C.POINTER(MapregImu), dp, C.POINTER(MapregReport), ip]
+    L.rgc_map_reset.argtypes = [vp, dp]
+    L.rgc_map_insert.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, C.c_int, ip]
+    L.rgc_map_evict.argtypes = [vp, C.c_int, dp, C.c_double, ip]
+    L.rgc_map_rebase.argtypes = [vp, dp]
+    L.rgc_map_commit.argtypes = [vp, C.c_float, ip]
+    L.rgc_map_get_info.argtypes = [vp, C.POINTER(MapInfo)]
+    L.rgc_map_download.argtypes = [vp, C.c_int, vp, C.c_int, ip]
     L.rgc_profile_enable.argtypes = [vp, C.c_int]
     L.rgc_profile_select.argtypes = [vp, C.c_uint]
     L.rgc_profile_reset.argtypes = [vp]

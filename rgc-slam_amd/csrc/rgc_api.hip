@@ -87,6 +87,20 @@ struct rgc_ctx {
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos;  // B2/B3/B9 staging
   DevBuf fe[32];              // front-end buffers
+  // f2: rolling local map.  World-frame points (relative to map_origin, x,y,z,intensity, 16 B) of the live keyframes as
+  // contiguous segments in insertion order in map_store[map_cur]; the other buffer is the compaction / re-basing target.
+  struct MapKf { int id; size_t off; int n; double t[3]; };
+  DevBuf map_store[2], map_target;
+  int map_cur = 0;
+  size_t map_n = 0;
+  std::vector<MapKf> map_kf;
+  int map_next_id = 0;
+  double map_origin[3] = {0, 0, 0};
+  bool map_dirty = false;     // keyframes changed since the last commit
+  bool map_bound = false;     // the context's target IS the committed map (rgc_set_target* unbinds it)
+  float map_leaf = 0.f;
+  int map_ntarget = 0;
+  unsigned long long map_rev = 0;
   rgc_stats stats{};
   // profiling
   bool prof_on = false;
@@ -288,6 +302,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
   cl.n = 0;
   c->corr_valid = false;
   c->deferred_known = false;
+  if (is_target) c->map_bound = false;
   if (!xyz || n < 0) return fail(c, RGC_ERR_INVALID, "null cloud");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
   if (n > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud has %d points, the limit is 2^27 (32-bit byte offsets into the sorted array)", n);
@@ -784,6 +799,7 @@ void rgc_destroy(rgc_ctx* c) {
   release(c->mr_partials);
   release(c->mr_small);
   for (DevBuf& b : c->fe) release(b);
+  for (DevBuf* b : {&c->map_store[0], &c->map_store[1], &c->map_target}) release(*b);
   for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->corr_v2, &c->corr_M2, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_first, &c->vg_pos}) release(*b);
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->d_out) (void)hipFree(c->d_out);
@@ -1607,6 +1623,172 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
     double* q = poses + 7 * b;
     const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (nn > 0) for (int a = 0; a < 4; a++) q[a] /= nn;
+  }
+  return RGC_OK;
+}
+
+// ---- f2: rolling local map resident on the device (replaces the keyframe deque + per-frame re-framing + re-upload of
+// src/RGC_odometer.cpp:1218-1256, 985-991, 1007) ----------------------------------------------------------------------------
+static int map_reserve(rgc_ctx* c, int which, size_t points, bool preserve) {
+  DevBuf& b = c->map_store[which];
+  const size_t bytes = points * 16;
+  if (bytes <= b.cap && b.p) return RGC_OK;
+  void* np = nullptr;
+  const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 20);
+  HIPCHK(c, hipMalloc(&np, want));
+  if (b.p) {
+    if (preserve && c->map_n) HIPCHK(c, hipMemcpyAsync(np, b.p, c->map_n * 16, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(b.p));
+  }
+  b.p = np;
+  b.cap = want;
+  return RGC_OK;
+}
+
+int rgc_map_reset(rgc_ctx* c, const double origin[3]) {
+  if (!c) return RGC_ERR_INVALID;
+  c->map_kf.clear();
+  c->map_n = 0;
+  c->map_dirty = true;
+  c->map_ntarget = 0;
+  if (c->map_bound) { c->tgt.ready = false; c->tgt.n = 0; c->corr_valid = false; c->map_bound = false; }
+  for (int a = 0; a < 3; a++) c->map_origin[a] = origin ? origin[a] : 0.0;
+  c->map_rev++;
+  return RGC_OK;
+}
+
+int rgc_map_insert(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const double q[4], const double t[3], int on_device, int* keyframe_id) {
+  if (!c || !xyzi || !q || !t || n <= 0) return RGC_ERR_INVALID;
+  if (stride_bytes < 16 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "a keyframe is x,y,z,intensity: stride_bytes >= 16");
+  if (c->map_n + (size_t)n > ((size_t)1 << 27)) return fail(c, RGC_ERR_INVALID, "the map would exceed 2^27 points");
+  HIPCHK(c, hipSetDevice(c->device));
+  const float* d_in;
+  int rc = stage_in(c, xyzi, n, stride_bytes, on_device, &d_in);
+  if (rc) return rc;
+  if ((rc = map_reserve(c, c->map_cur, c->map_n + n, true))) return rc;
+  // surroundingCloud.push_back(transformPointCloud(FullPointsLessFlat, q_w_curr, t_w_curr)) (:1237), relative to the origin
+  const double tr[3] = {t[0] - c->map_origin[0], t[1] - c->map_origin[1], t[2] - c->map_origin[2]};
+  rgck::transform_q(c->stream, d_in, stride_bytes / 4, n, rgck::Quat{q[0], q[1], q[2], q[3]}, tr, (float*)c->map_store[c->map_cur].p + 4 * c->map_n, 4);
+  if (!on_device) HIPCHK(c, hipStreamSynchronize(c->stream));  // pre_in is re-used by the next staged call
+  HIPCHK(c, hipGetLastError());
+  rgc_ctx::MapKf kf{c->map_next_id++, c->map_n, n, {t[0], t[1], t[2]}};
+  c->map_kf.push_back(kf);
+  c->map_n += n;
+  c->map_dirty = true;
+  c->map_rev++;
+  if (keyframe_id) *keyframe_id = kf.id;
+  return RGC_OK;
+}
+
+int rgc_map_evict(rgc_ctx* c, int max_keyframes, const double center[3], double radius, int* n_evicted) {
+  if (!c) return RGC_ERR_INVALID;
+  if (n_evicted) *n_evicted = 0;
+  std::vector<rgc_ctx::MapKf> keep;
+  for (const auto& k : c->map_kf) {
+    bool far = false;
+    if (center && radius > 0) {
+      const double dx = k.t[0] - center[0], dy = k.t[1] - center[1], dz = k.t[2] - center[2];
+      far = std::sqrt(dx * dx + dy * dy + dz * dz) > radius;
+    }
+    if (!far) keep.push_back(k);
+  }
+  if (max_keyframes > 0 && (int)keep.size() > max_keyframes) keep.erase(keep.begin(), keep.end() - max_keyframes);  // pop_front, :1242-1247
+  const int gone = (int)c->map_kf.size() - (int)keep.size();
+  if (!gone) return RGC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t total = 0;
+  for (const auto& k : keep) total += k.n;
+  const int other = c->map_cur ^ 1;
+  int rc = map_reserve(c, other, std::max(total, (size_t)1), false);
+  if (rc) return rc;
+  size_t off = 0;
+  for (size_t i = 0; i < keep.size();) {  // runs of surviving neighbours move with one copy
+    size_t j = i, run = 0;
+    const size_t base = keep[i].off;
+    while (j < keep.size() && keep[j].off == base + run) { run += keep[j].n; j++; }
+    HIPCHK(c, hipMemcpyAsync((char*)c->map_store[other].p + off * 16, (const char*)c->map_store[c->map_cur].p + base * 16, run * 16,
+                             hipMemcpyDeviceToDevice, c->stream));
+    for (size_t k = i; k < j; k++) keep[k].off = off + (keep[k].off - base);
+    off += run;
+    i = j;
+  }
+  c->map_cur = other;
+  c->map_kf.swap(keep);
+  c->map_n = total;
+  c->map_dirty = true;
+  c->map_rev++;
+  if (n_evicted) *n_evicted = gone;
+  return RGC_OK;
+}
+
+int rgc_map_rebase(rgc_ctx* c, const double new_origin[3]) {
+  if (!c || !new_origin) return RGC_ERR_INVALID;
+  const double d[3] = {c->map_origin[0] - new_origin[0], c->map_origin[1] - new_origin[1], c->map_origin[2] - new_origin[2]};
+  if (c->map_n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const int other = c->map_cur ^ 1;
+    int rc = map_reserve(c, other, c->map_n, false);
+    if (rc) return rc;
+    rgck::transform_q(c->stream, (const float*)c->map_store[c->map_cur].p, 4, (int)c->map_n, rgck::Quat{0, 0, 0, 1}, d, (float*)c->map_store[other].p, 4);
+    HIPCHK(c, hipGetLastError());
+    c->map_cur = other;
+  }
+  for (int a = 0; a < 3; a++) c->map_origin[a] = new_origin[a];
+  c->map_dirty = true;
+  c->map_rev++;
+  return RGC_OK;
+}
+
+int rgc_map_commit(rgc_ctx* c, float leaf, int* n_target) {
+  if (!c || !(leaf > 0.f)) return RGC_ERR_INVALID;
+  if (c->map_bound && !c->map_dirty && leaf == c->map_leaf && c->tgt.ready) {  // nothing changed: the resident target stands
+    if (n_target) *n_target = c->map_ntarget;
+    return RGC_OK;
+  }
+  if (!c->map_n) return fail(c, RGC_ERR_NO_INPUT, "the map holds no keyframe");
+  int rc = ensure(c, c->map_target, c->map_n * 16);
+  if (rc) return rc;
+  int nt = 0;
+  // downSizeFilter2.setInputCloud(laserCloudsubmap); filter (:985-991) -- on the resident store, nothing crosses PCIe
+  if ((rc = rgc_voxelgrid(c, (const float*)c->map_store[c->map_cur].p, (int)c->map_n, 16, leaf, (float*)c->map_target.p, &nt, 1))) return rc;
+  // setInputTarget (:1007): grid, exact-kNN covariances, Gaussian voxel map
+  if ((rc = set_cloud(c, c->tgt, true, (const float*)c->map_target.p, nt, 16, true))) return rc;
+  c->map_bound = true;
+  c->map_dirty = false;
+  c->map_leaf = leaf;
+  c->map_ntarget = nt;
+  if (n_target) *n_target = nt;
+  return RGC_OK;
+}
+
+int rgc_map_get_info(rgc_ctx* c, rgc_map_info* out) {
+  if (!c || !out) return RGC_ERR_INVALID;
+  out->n_keyframes = (int)c->map_kf.size();
+  out->n_points = (long long)c->map_n;
+  out->n_target = c->map_bound && !c->map_dirty ? c->map_ntarget : -1;
+  out->revision = c->map_rev;
+  out->oldest_id = c->map_kf.empty() ? -1 : c->map_kf.front().id;
+  out->newest_id = c->map_kf.empty() ? -1 : c->map_kf.back().id;
+  for (int a = 0; a < 3; a++) out->origin[a] = c->map_origin[a];
+  return RGC_OK;
+}
+
+int rgc_map_download(rgc_ctx* c, int which, float* out_xyzi, int cap, int* n) {
+  if (!c || !n || cap < 0 || (cap && !out_xyzi)) return RGC_ERR_INVALID;
+  const void* src = nullptr;
+  int have = 0;
+  if (which == 0) { src = c->map_store[c->map_cur].p; have = (int)c->map_n; }
+  else if (which == 1) {
+    if (!c->map_bound || c->map_dirty) return fail(c, RGC_ERR_NO_INPUT, "rgc_map_commit first");
+    src = c->map_target.p; have = c->map_ntarget;
+  } else return RGC_ERR_INVALID;
+  *n = have;
+  const int m = std::min(have, cap);
+  if (m > 0) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out_xyzi, src, (size_t)m * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return RGC_OK;
 }

@@ -74,10 +74,11 @@ class HipBackend:
     """The operations the frame body needs, each one C-ABI call (or a few) into librgc_hip.so."""
 
     def __init__(self, device: int = 0, scan_line: int = 16):
-        from . import frontend, registration
+        from . import frontend, local_map, registration
         self.fe = frontend.ScanRegistration(scan_line, device=device)
         self.pre = Preprocessor(device)
         self.reg = registration.odometer_vgicp(device)
+        self.map = local_map.RollingLocalMap(self.reg)
         self._L = _lib.load()
 
     def close(self):
@@ -98,6 +99,26 @@ class HipBackend:
     def register(self, source, target, guess):
         """-> (final 4x4 float32, fitness)  RGC_odometer.cpp:998-1011"""
         self.reg.setInputTarget(target)
+        self.reg.setInputSource(source)
+        self.reg.align(guess, want_output=False, want_fitness=True)
+        return self.reg.getFinalTransformation(), self.reg.getFitnessScore()
+
+    # f2: the local map resident on the device (rgc_map_*), registration in the map frame
+    def map_reset(self, origin):
+        self.map.reset(origin)
+
+    def map_insert(self, xyzi, q, t):
+        return self.map.insert(xyzi, q, t)
+
+    def map_evict(self, max_keyframes, center=None, radius=0.0):
+        return self.map.evict(max_keyframes, center, radius)
+
+    def map_rebase(self, origin):
+        self.map.rebase(origin)
+
+    def map_register(self, source, guess, leaf):
+        """-> (final 4x4 float32 in the map frame, fitness); the target is rebuilt only if a keyframe changed"""
+        self.map.commit(leaf)
         self.reg.setInputSource(source)
         self.reg.align(guess, want_output=False, want_fitness=True)
         return self.reg.getFinalTransformation(), self.reg.getFitnessScore()
@@ -232,6 +253,81 @@ class Odometer:
                 qi = _qconj(self.q_w_curr)
                 ti = -_qrot(qi, self.t_w_curr)
                 self.submap = np.concatenate([b.transform(c, qi, ti) for c in self.surrounding])
+        self.full_last = full                                                        # :1319-1322
+        self.ground_last = ground_cur if fe["ground_valid"] else self.ground_last
+        self.frames += 1
+        return self.q_w_curr.copy(), self.t_w_curr.copy()
+
+
+def _q2R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+class RollingOdometer(Odometer):
+    """f2: the same frame body with the local map resident on the device in a MAP frame (world minus an origin
+    kept near the sensor) instead of a host deque that is re-framed, re-filtered and re-uploaded per frame (:1218-1256,
+    985-991, 1007).  The registration runs in the map frame: guess = T_w_curr * T_last_curr, result = the scan's new world pose,
+    from which the reference's lidar delta (q_last_curr_l, t_last_curr_l) is recovered for the fusion.  Keyframe test, deque
+    length and the first-keyframe rule are the reference's; eviction may additionally be by distance (radius > 0)."""
+
+    rebase_distance = 50.0   # the origin follows the sensor so that fp32 map coordinates stay < ~64 m (ulp 4e-6 m)
+
+    def __init__(self, backend, use_ground: bool = True, max_keyframes=None, radius: float = 0.0):
+        super().__init__(backend, use_ground)
+        self.max_keyframes = self.slipwide if max_keyframes is None else max_keyframes
+        self.radius = radius
+        self.origin = np.zeros(3)
+        self.kf_q, self.kf_t = None, None
+        self.n_commits = 0
+
+    def process(self, raw_xyzi):
+        b = self.b
+        fe = b.frontend(raw_xyzi)
+        full, ground_cur = fe["cloud"], fe["groundparam"]
+        full = b.deskew(full, self.q_last_curr, self.t_last_curr)                    # adjustDistortion, :958
+        if self.full_last is not None and len(self.full_last):
+            if self.submapflag == 0:                                                 # :963-972: the previous sweep is keyframe 0
+                self.origin = self.t_w_curr.copy()
+                b.map_reset(self.origin)
+                b.map_insert(self.full_last, np.array([0, 0, 0, 1.0]), np.zeros(3))
+                self.kf_q, self.kf_t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+            self.submapflag += 1
+            source = b.voxelgrid(full, self.planeResolution1)                        # :976-983
+            # the guess of :993-996 moved into the map frame: T_w_curr * T_last_curr
+            q_g = _qmul(self.q_w_curr, self.q_last_curr)
+            t_g = _qrot(self.q_w_curr, self.t_last_curr) + self.t_w_curr - self.origin
+            T2 = np.eye(4, dtype=np.float32)
+            T2[:3, :3] = _q2R(q_g / np.linalg.norm(q_g)).astype(np.float32)
+            T2[:3, 3] = t_g.astype(np.float32)
+            T, self.fitness = b.map_register(source, T2, self.planeResolution2)      # :985-991, 998-1010
+            q_m, t_m = b.extract(T)                                                  # :1011-1016, map-frame pose of the scan
+            qi = _qconj(self.q_w_curr)
+            q_l = _qmul(qi, q_m)                                                     # back to the delta the fusion expects
+            t_l = _qrot(qi, t_m + self.origin - self.t_w_curr)
+            q_wf = _qmul(_qconj(self.q_w_curr_delta), self.q_w_curr)                 # :1086-1087
+            q_wf = q_wf / np.linalg.norm(q_wf)
+            use_ground = self.USE_GROUND and fe["ground_valid"] and self.ground_last is not None
+            q_f, t_f = b.fuse(q_l, t_l, self.fitness, use_ground, self.ground_last, ground_cur, q_wf)   # :1025-1193
+            self.q_w_curr, self.t_w_curr, t_lc = b.compose(self.q_w_curr, self.t_w_curr, q_f, t_f, t_l)  # :1194-1203
+            self.q_last_curr, self.t_last_curr = q_f, t_lc
+            # keyframe test of :1218-1239 against the newest keyframe's pose
+            yb, yc = b.R2ypr(self.kf_q), b.R2ypr(self.q_w_curr)
+            d = np.float32(self.kf_t - self.t_w_curr)
+            dy, dp_, dr = np.float32(yb[0] - yc[0]), np.float32(yb[1] - yc[1]), np.float32(yb[2] - yc[2])
+            if dy > np.pi: dy -= 2 * np.pi
+            if dy < -np.pi: dy += 2 * np.pi
+            if (abs(dr) > self.keyframeAddingAngle or abs(dp_) > self.keyframeAddingAngle or abs(dy) > self.keyframeAddingAngle or
+                    float(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])) > self.keyframeAddingDistance or self.submapflag < self.slipwide - 1):
+                b.map_insert(source, self.q_w_curr, self.t_w_curr)                   # :1237, once, never re-framed
+                self.kf_q, self.kf_t = self.q_w_curr.copy(), self.t_w_curr.copy()
+                b.map_evict(self.max_keyframes, self.t_w_curr if self.radius > 0 else None, self.radius)   # :1242-1247
+                self.n_commits += 1
+            if np.linalg.norm(self.t_w_curr - self.origin) > self.rebase_distance:
+                self.origin = self.t_w_curr.copy()
+                b.map_rebase(self.origin)
         self.full_last = full                                                        # :1319-1322
         self.ground_last = ground_cur if fe["ground_valid"] else self.ground_last
         self.frames += 1

@@ -1,0 +1,119 @@
+"""f2 measurement: the local map resident on the device (rgc_map_*) against the reference's per-frame rebuild.
+
+(A) c-main size (30 k-pt scans, 1 M-pt map): registered scans/s when the target is rebuilt every frame (the reference's
+    semantics, what bench.py times), when it stays resident (no keyframe change), and amortised over a keyframe every
+    KF_EVERY frames (the device-side rebuild: VoxelGrid 0.3 over the store + grid + exact-kNN covariances + voxel map).
+(B) the config-2 stand-in sequence (front-end + frame body): frames/s of odometry.Odometer (re-frame, re-filter, re-upload per
+    frame) against odometry.RollingOdometer on the same sweeps, and the distance between the two trajectories.
+"""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401  (first: its HIP runtime is the one the library must bind to)
+import rgc_slam_amd.synth as synth
+from rgc_slam_amd import registration, local_map, odometry
+
+N_T = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+N_S, FRAMES, KF_EVERY, N_KF = 30000, 20, 3, 32
+
+world, tgt = synth.make_world_and_map(N_T, seed=synth.SEED)
+poses = synth.make_trajectory(FRAMES + 4, seed=synth.SEED)
+scans = [synth.make_scan_n(world, poses[i + 1], N_S, seed=synth.SEED + 100 + i)["xyz"] for i in range(FRAMES + 3)]
+v = registration.odometer_vgicp(0)
+m = local_map.RollingLocalMap(v)
+
+
+def to_dev(xyz):
+    a = np.zeros((xyz.shape[0], 4), np.float32)
+    a[:, :3] = xyz
+    p = v.device_alloc(a.nbytes)
+    v.upload(p, a)
+    return p
+
+
+d_scans = [to_dev(s) for s in scans]
+d_tgt = to_dev(tgt)
+# the map as N_KF keyframes already in the world frame (identity poses): chunks of the map cloud
+m.reset(None)
+tgt4 = np.zeros((len(tgt), 4), np.float32); tgt4[:, :3] = tgt
+for ch in np.array_split(tgt4, N_KF):
+    m.insert(ch, [0, 0, 0, 1.0], [0, 0, 0])
+n_target = m.commit(0.3)
+v.synchronize()
+
+
+def run(mode):
+    guess = poses[0].astype(np.float32)
+    out = []
+    t0 = None
+    per = []
+    for i in range(3 + FRAMES):
+        if i == 3:
+            v.synchronize(); t0 = time.perf_counter()
+        tf = time.perf_counter()
+        if mode == "rebuild":
+            v.setInputTargetDevice(d_tgt, len(tgt), 16)
+        elif mode == "keyframes" and i % KF_EVERY == 0:
+            # a keyframe changed: (here the newest chunk is evicted and re-inserted so that the map content stays comparable)
+            ch = np.array_split(tgt4, N_KF)[i % N_KF]
+            m.insert(ch, [0, 0, 0, 1.0], [0, 0, 0]); m.evict(N_KF)
+            m.commit(0.3)
+        else:
+            m.commit(0.3)          # resident: no-op
+        v.setInputSourceDevice(d_scans[i], N_S, 16)
+        v.align(guess, want_output=False, want_fitness=True)
+        guess = v.getFinalTransformation()
+        out.append(guess)
+        per.append(round(1e3 * (time.perf_counter() - tf), 3))
+    v.synchronize()
+    print(mode, per, file=sys.stderr)
+    return (time.perf_counter() - t0) / FRAMES, out
+
+
+res = {}
+run("rebuild")
+t_rebuild, T_a = run("rebuild")
+m.commit(0.3)
+t_res, T_b = run("resident")
+t_kf, T_c = run("keyframes")
+# commit alone
+t0 = time.perf_counter(); reps = 10
+for r in range(reps):
+    m.insert(np.array_split(tgt4, N_KF)[r], [0, 0, 0, 1.0], [0, 0, 0]); m.evict(N_KF)
+    v.synchronize(); t1 = time.perf_counter()
+    m.commit(0.3); v.synchronize()
+    res.setdefault("commit_ms", []).append(1e3 * (time.perf_counter() - t1))
+res_A = {"workload": f"c-main: {N_S}-pt scans vs a {len(tgt)}-pt map held as {N_KF} keyframes on the device ({n_target} target points after the 0.3 m filter)",
+         "rebuild_every_frame_scans_per_s": round(1 / t_rebuild, 1), "resident_scans_per_s": round(1 / t_res, 1),
+         f"keyframe_every_{KF_EVERY}_frames_scans_per_s": round(1 / t_kf, 1), "commit_ms_median": round(float(np.median(res["commit_ms"])), 3),
+         "ms_per_frame": {"rebuild": round(1e3 * t_rebuild, 3), "resident": round(1e3 * t_res, 3), "keyframes": round(1e3 * t_kf, 3)},
+         "max_translation_diff_resident_vs_rebuild_m": float(max(np.abs(a[:3, 3] - b[:3, 3]).max() for a, b in zip(T_a, T_b)))}
+
+# (B) the sequence
+world2 = synth.make_world(half_extent=45.0, seed=synth.SEED)
+poses2 = synth.make_trajectory(25, seed=synth.SEED)
+raws = []
+for k in range(24):
+    sc = synth.make_scan(world2, poses2[k], n_az=1800, seed=synth.SEED + 50 + k, T_ws_end=poses2[k + 1])
+    raws.append(np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32))
+tim = {}
+traj = {}
+for name, cls in (("reference_semantics", odometry.Odometer), ("rolling", odometry.RollingOdometer)):
+    hb = odometry.HipBackend(0)
+    od = cls(hb)
+    for raw in raws[:4]:
+        od.process(raw)
+    t0 = time.perf_counter()
+    tr = []
+    for raw in raws[4:]:
+        q, t = od.process(raw); tr.append(t)
+    tim[name] = (time.perf_counter() - t0) / (len(raws) - 4)
+    traj[name] = np.array(tr)
+    if name == "rolling":
+        tim["keyframes_inserted"] = od.n_commits
+    hb.close()
+res_B = {"workload": "config-2 stand-in: 24 VLP-16 sweeps (28.8 k points) through front-end + frame body, 3-keyframe local map",
+         "ms_per_frame": {k: round(1e3 * x, 3) for k, x in tim.items() if k != "keyframes_inserted"}, "keyframes_inserted": tim["keyframes_inserted"],
+         "max_trajectory_distance_m": float(np.linalg.norm(traj["rolling"] - traj["reference_semantics"], axis=1).max()),
+         "path_length_m": float(np.linalg.norm(traj["rolling"][-1]))}
+print(json.dumps({"A": res_A, "B": res_B}))

@@ -53,3 +53,44 @@ class OracleBackend:
 
     def R2ypr(self, q):
         return pf.R2ypr(pf.q2R(np.asarray(q)))
+
+    # ---- f2: the rolling local map composed from the oracle's own pieces (transform, VoxelGrid, registration), on the host ----
+    def map_reset(self, origin):
+        self._origin = np.asarray(origin, float).copy()
+        self._kf = []                                   # [(id, points in the map frame, world translation)]
+        self._next = 0
+        self._target, self._leaf = None, None
+
+    def map_insert(self, xyzi, q, t):
+        pts = orc.transform_cloud(np.ascontiguousarray(xyzi, np.float32)[:, :4], q, np.asarray(t, float) - self._origin)
+        self._kf.append((self._next, pts, np.asarray(t, float).copy()))
+        self._next += 1
+        self._target = None
+        return self._next - 1
+
+    def map_evict(self, max_keyframes, center=None, radius=0.0):
+        n0 = len(self._kf)
+        if center is not None and radius > 0:
+            self._kf = [k for k in self._kf if np.linalg.norm(k[2] - np.asarray(center, float)) <= radius]
+        if max_keyframes > 0 and len(self._kf) > max_keyframes:
+            self._kf = self._kf[-max_keyframes:]
+        if len(self._kf) != n0:
+            self._target = None
+        return n0 - len(self._kf)
+
+    def map_rebase(self, origin):
+        d = self._origin - np.asarray(origin, float)
+        self._kf = [(i, orc.transform_cloud(p, np.array([0, 0, 0, 1.0]), d), t) for i, p, t in self._kf]
+        self._origin = np.asarray(origin, float).copy()
+        self._target = None
+
+    def map_points(self):
+        return np.concatenate([p for _, p, _ in self._kf]) if self._kf else np.zeros((0, 4), np.float32)
+
+    def map_target(self, leaf):
+        if self._target is None or self._leaf != leaf:
+            self._target, self._leaf = orc.voxelgrid_filter(np.ascontiguousarray(self.map_points()), leaf), leaf
+        return self._target
+
+    def map_register(self, source, guess, leaf):
+        return self.register(source, self.map_target(leaf), guess)
