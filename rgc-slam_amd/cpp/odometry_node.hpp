@@ -1,0 +1,274 @@
+// odometry_node.hpp -- header-only C++ host side of the odometry path over the C-ABI (include/rgc_hip.h): what the two ROS
+// nodes on the path do per LiDAR message, WITHOUT ROS/PCL/Eigen/Ceres at build time:
+//
+//   ScanRegistration::laserCloudHandler   /root/reference/rgc_slam/src/scanRegistration.cpp:89-730   (sensor_msgs::PointCloud2 in)
+//   vg_ICP::ICP_thread frame body         /root/reference/rgc_slam/src/RGC_odometer.cpp:932-1322     (nav_msgs::Odometry out)
+//
+//   rgc::OdometryNode node(opt);
+//   rgc::OdometryMsg odom; rgc::GroundMsg ground;
+//   node.handlePointCloud2(msg.data.data(), msg.width * msg.height, layout, stamp, &odom, &ground);   // the subscriber callback
+//   // odom -> nav_msgs::Odometry (frame_id "camera_init", child "laser_odom", pose only: RGC_odometer.cpp:1264-1275)
+//   // ground -> ground_msg::groundparam (field order of ground_msg/msg/groundparam.msg:1-12)
+//
+// Every per-point stage is a call into librgc_hip.so (front-end, de-skew, VoxelGrid, registration, fitness, transforms); this class
+// only holds the node's scalar state (poses, ground_last, the keyframe bookkeeping).  Two local-map modes:
+//   resident_map = false : the reference's semantics -- keyframe deque on the host, re-framed / re-filtered / re-uploaded per frame
+//                          (:1218-1256, 985-991, 1007)
+//   resident_map = true  : SURVEY 8f row f2 -- keyframes stay on the device in a map frame, target rebuilt only on a keyframe change
+// USE_IMU = 0 (no IMU stream in this class; the IMU hooks of the library are separate entry points).
+// Errors: std::runtime_error carrying rgc_last_error(); there is no CPU fallback.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rgc_hip.h"
+
+namespace rgc {
+
+struct OdometryMsg {             // the pose part of nav_msgs::Odometry as filled at RGC_odometer.cpp:1264-1275
+  double stamp = 0;
+  double position[3] = {0, 0, 0};
+  double orientation_xyzw[4] = {0, 0, 0, 1};
+  static const char* frame_id() { return "camera_init"; }
+  static const char* child_frame_id() { return "laser_odom"; }
+};
+struct GroundMsg {               // ground_msg::groundparam, scanRegistration.cpp:420-430
+  double param[11] = {0};
+  bool valid = false;
+};
+
+class OdometryNode {
+public:
+  struct Options {
+    int hip_device = 0;
+    int scan_line = 16;                    // launch/run.launch scan_line
+    double minimum_range = 0.5, maxmum_range = 80.0;
+    bool use_ground = true;                // USE_GROUND
+    bool resident_map = false;
+    int max_keyframes = 3;                 // slipwide, RGC_odometer.cpp:299
+    double evict_radius = 0.0;             // resident map only: additionally evict keyframes farther than this (0 = off)
+    double rebase_distance = 50.0;         // resident map only: the map origin follows the sensor
+  };
+
+  explicit OdometryNode(const Options& o) : opt_(o) {
+    rgc_params p;
+    rgc_default_params(&p);                // = the setters of RGC_odometer.cpp:998-1006 (resolution 1.0, 25 iterations, eps 1e-6)
+    int rc = rgc_create(o.hip_device, &p, &ctx_);
+    if (rc != RGC_OK) throw std::runtime_error(std::string("rgc_create: ") + rgc_status_string(rc));
+    rgc_default_fe_params(&fe_);
+    fe_.n_scans = o.scan_line; fe_.min_range = o.minimum_range; fe_.max_range = o.maxmum_range;
+  }
+  ~OdometryNode() { rgc_destroy(ctx_); }
+  OdometryNode(const OdometryNode&) = delete;
+  OdometryNode& operator=(const OdometryNode&) = delete;
+
+  // the /velodyne_points subscriber on the raw message bytes (pcl::fromROSMsg becomes a kernel, scanRegistration.cpp:107-108)
+  void handlePointCloud2(const void* data, int n_points, const rgc_pc2_layout& layout, double stamp, OdometryMsg* odom, GroundMsg* ground) {
+    raw_.resize((size_t)4 * (size_t)(n_points > 0 ? n_points : 1));
+    chk(rgc_pc2_unpack(ctx_, data, n_points, &layout, raw_.data(), nullptr, nullptr, 0));
+    handleCloud(raw_.data(), n_points, 16, stamp, odom, ground);
+  }
+
+  // the same on an already converted cloud: x,y,z,intensity in firing order
+  void handleCloud(const float* xyzi, int n, int stride_bytes, double stamp, OdometryMsg* odom, GroundMsg* ground) {
+    // ---- ScanRegistration::laserCloudHandler ----
+    const int fcap = fe_.n_scans * 6 * 41;
+    full_.resize((size_t)4 * (size_t)(n > 0 ? n : 1));
+    sharp_.resize((size_t)5 * fcap); flat_.resize((size_t)5 * fcap); inten_.resize((size_t)5 * fcap);
+    rgc_fe_out fo;
+    std::memset(&fo, 0, sizeof(fo));
+    fo.cloud = full_.data(); fo.cloud_cap = n > 0 ? n : 1;
+    fo.sharp = sharp_.data(); fo.flat = flat_.data(); fo.inten = inten_.data(); fo.feat_cap = fcap;
+    chk(rgc_frontend(ctx_, xyzi, n, stride_bytes, &fe_, &fo));
+    const int n_full = fo.n_cloud;
+    n_sharp_ = fo.n_sharp; n_flat_ = fo.n_flat;
+    if (ground) { std::memcpy(ground->param, fo.groundparam, sizeof(ground->param)); ground->valid = fo.ground_valid != 0; }
+    // ---- vg_ICP::ICP_thread ----
+    if (n_full > 0) chk(rgc_deskew(ctx_, full_.data(), n_full, 16, q_last_curr_, t_last_curr_, 0));   // adjustDistortion, :958
+    if (!full_last_.empty()) {
+      if (submapflag_ == 0) first_keyframe();                                                   // :963-972
+      submapflag_++;
+      int n_src = 0;
+      source_.resize((size_t)4 * n_full);
+      chk(rgc_voxelgrid(ctx_, full_.data(), n_full, 16, 0.2f, source_.data(), &n_src, 0));       // :976-983, planeResolution1
+      float guess[16], T[16];
+      double fitness = 1.0;
+      if (opt_.resident_map) {
+        // the guess of :993-996 moved into the map frame: T_w_curr * T_last_curr
+        double qg[4], tg[3];
+        qmul(q_w_, q_last_curr_, qg); qnormalize(qg);
+        qrot(q_w_, t_last_curr_, tg);
+        for (int a = 0; a < 3; a++) tg[a] += t_w_[a] - origin_[a];
+        pose_to_mat(qg, tg, guess);
+        chk(rgc_map_commit(ctx_, 0.3f, nullptr));                                              // :985-991, 1007 (only if a keyframe changed)
+      } else {
+        int n_tgt = 0;
+        target_.resize(submap_.size());
+        chk(rgc_voxelgrid(ctx_, submap_.data(), (int)(submap_.size() / 4), 16, 0.3f, target_.data(), &n_tgt, 0));   // :985-991
+        pose_to_mat(q_last_curr_, t_last_curr_, guess);                                         // :993-996
+        chk(rgc_set_target(ctx_, target_.data(), n_tgt, 16));                                   // :1007
+      }
+      chk(rgc_set_source(ctx_, source_.data(), n_src, 16));                                      // :1008
+      int it = 0, conv = 0, lmf = 0;
+      chk(rgc_align(ctx_, guess, T, nullptr, &fitness, &it, &conv, &lmf));                       // :1009-1010
+      double q_l[4], t_l[3];
+      chk(rgc_extract_pose(T, q_l, t_l));                                                       // :1011-1016
+      if (opt_.resident_map) {   // T is the scan's map-frame pose: back to the delta the fusion expects, T_w_curr^-1 * T
+        double qi[4] = {-q_w_[0], -q_w_[1], -q_w_[2], q_w_[3]}, qd[4], d[3];
+        qmul(qi, q_l, qd);
+        for (int a = 0; a < 3; a++) d[a] = t_l[a] + origin_[a] - t_w_[a];
+        qrot(qi, d, t_l);
+        std::memcpy(q_l, qd, sizeof(qd));
+      }
+      // pose fusion, :1025-1193
+      rgc_fuse_in fin;
+      rgc_default_fuse_in(&fin);
+      std::memcpy(fin.q_lidar_xyzw, q_l, sizeof(q_l)); std::memcpy(fin.t_lidar, t_l, sizeof(t_l));
+      fin.fitness = fitness;
+      const bool use_ground = opt_.use_ground && fo.ground_valid && have_ground_last_;
+      fin.use_ground = use_ground ? 1 : 0;
+      if (use_ground) {
+        std::memcpy(fin.ground_last, ground_last_, sizeof(ground_last_));
+        std::memcpy(fin.ground_cur, fo.groundparam, sizeof(ground_last_));
+        double qdi[4] = {-q_w_delta_[0], -q_w_delta_[1], -q_w_delta_[2], q_w_delta_[3]};
+        qmul(qdi, q_w_, fin.q_w_curr_f_xyzw);                                                  // :1086-1087
+        qnormalize(fin.q_w_curr_f_xyzw);
+      }
+      double q_f[4], t_f[3], q_new[4], t_new[3], t_lc[3];
+      chk(rgc_fuse_pose(&fin, q_f, t_f, nullptr));
+      chk(rgc_compose_pose(q_w_, t_w_, q_f, t_f, t_l, 0, nullptr, q_new, t_new, t_lc));          // :1194-1203
+      std::memcpy(q_w_, q_new, sizeof(q_new)); std::memcpy(t_w_, t_new, sizeof(t_new));
+      std::memcpy(q_last_curr_, q_f, sizeof(q_f)); std::memcpy(t_last_curr_, t_lc, sizeof(t_lc));
+      maintain_map(n_src);                                                                      // :1218-1256
+    }
+    full_last_.assign(full_.begin(), full_.begin() + (size_t)4 * n_full);                         // :1319-1322
+    if (fo.ground_valid) { std::memcpy(ground_last_, fo.groundparam, sizeof(ground_last_)); have_ground_last_ = true; }
+    frames_++;
+    if (odom) {
+      odom->stamp = stamp;
+      std::memcpy(odom->position, t_w_, sizeof(t_w_));
+      std::memcpy(odom->orientation_xyzw, q_w_, sizeof(q_w_));
+    }
+  }
+
+  // what the node publishes besides the odometry (:689-727): feature clouds of the last sweep, x,y,z,intensity,normal_x
+  const float* cornerPointsSharp(int* n) const { *n = n_sharp_; return sharp_.data(); }
+  const float* surfPointsFlat(int* n) const { *n = n_flat_; return flat_.data(); }
+  int frames() const { return frames_; }
+  int keyframesInserted() const { return kf_inserted_; }
+  rgc_ctx* context() { return ctx_; }
+
+private:
+  void chk(int rc) { if (rc != RGC_OK) throw std::runtime_error(std::string(rgc_status_string(rc)) + ": " + rgc_last_error(ctx_)); }
+
+  static void qmul(const double a[4], const double b[4], double o[4]) {
+    const double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1], y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    const double z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3], w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+  }
+  static void qnormalize(double q[4]) {
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int a = 0; a < 4; a++) q[a] /= n;
+  }
+  static void qrot(const double q[4], const double v[3], double o[3]) {
+    const double ux = 2 * (q[1] * v[2] - q[2] * v[1]), uy = 2 * (q[2] * v[0] - q[0] * v[2]), uz = 2 * (q[0] * v[1] - q[1] * v[0]);
+    const double x = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy), y = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+    const double z = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+    o[0] = x; o[1] = y; o[2] = z;
+  }
+  static void q2R(const double q[4], double R[9]) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+  }
+  static void pose_to_mat(const double q[4], const double t[3], float M[16]) {   // Matrix4f from Quaterniond / Vector3d
+    double R[9];
+    q2R(q, R);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M[r * 4 + c] = (float)R[r * 3 + c]; M[r * 4 + 3] = (float)t[r]; }
+    M[12] = M[13] = M[14] = 0.f; M[15] = 1.f;
+  }
+
+  void first_keyframe() {   // the previous sweep is keyframe 0 at the identity pose, :963-972
+    const double I[4] = {0, 0, 0, 1}, Z[3] = {0, 0, 0};
+    if (opt_.resident_map) {
+      std::memcpy(origin_, t_w_, sizeof(origin_));
+      chk(rgc_map_reset(ctx_, origin_));
+      chk(rgc_map_insert(ctx_, full_last_.data(), (int)(full_last_.size() / 4), 16, I, Z, 0, nullptr));
+    } else {
+      kf_cloud_.push_back(full_last_);
+      submap_.insert(submap_.end(), full_last_.begin(), full_last_.end());
+    }
+    std::memcpy(kf_q_, I, sizeof(I)); std::memcpy(kf_t_, Z, sizeof(Z));
+    have_kf_ = true;
+  }
+
+  void maintain_map(int n_src) {
+    if (have_kf_) {
+      double Rb[9], Rc[9], yb[3], yc[3];
+      q2R(kf_q_, Rb); q2R(q_w_, Rc);
+      rgc_R2ypr(Rb, yb); rgc_R2ypr(Rc, yc);
+      const float dx = (float)(kf_t_[0] - t_w_[0]), dy = (float)(kf_t_[1] - t_w_[1]), dz = (float)(kf_t_[2] - t_w_[2]);
+      float dyaw = (float)(yb[0] - yc[0]);
+      const float dpitch = (float)(yb[1] - yc[1]), droll = (float)(yb[2] - yc[2]);
+      if (dyaw > M_PI) dyaw = (float)(dyaw - M_PI * 2);
+      if (dyaw < -M_PI) dyaw = (float)(dyaw + M_PI * 2);
+      const float kAngle = 0.2f, kDist = 0.3f;   // keyframeAddingAngle / keyframeAddingDistance, :280-281 (the angle meets DEGREES)
+      if (std::fabs(droll) > kAngle || std::fabs(dpitch) > kAngle || std::fabs(dyaw) > kAngle || std::sqrt(dx * dx + dy * dy + dz * dz) > kDist ||
+          submapflag_ < kSlipwide - 1) {
+        if (opt_.resident_map) {
+          chk(rgc_map_insert(ctx_, source_.data(), n_src, 16, q_w_, t_w_, 0, nullptr));           // :1237, once, never re-framed
+          chk(rgc_map_evict(ctx_, opt_.max_keyframes, opt_.evict_radius > 0 ? t_w_ : nullptr, opt_.evict_radius, nullptr));   // :1242-1247
+        } else {
+          std::vector<float> w((size_t)4 * n_src);
+          chk(rgc_transform_cloud(ctx_, source_.data(), n_src, 16, q_w_, t_w_, w.data(), 0));
+          kf_cloud_.push_back(std::move(w));
+        }
+        std::memcpy(kf_q_, q_w_, sizeof(kf_q_)); std::memcpy(kf_t_, t_w_, sizeof(kf_t_));
+        kf_inserted_++;
+      }
+    }
+    if (opt_.resident_map) {
+      const double ddx = t_w_[0] - origin_[0], ddy = t_w_[1] - origin_[1], ddz = t_w_[2] - origin_[2];
+      if (std::sqrt(ddx * ddx + ddy * ddy + ddz * ddz) > opt_.rebase_distance) {
+        std::memcpy(origin_, t_w_, sizeof(origin_));
+        chk(rgc_map_rebase(ctx_, origin_));
+      }
+      return;
+    }
+    submap_.clear();
+    if ((int)kf_cloud_.size() > opt_.max_keyframes) kf_cloud_.pop_front();                       // :1242-1247
+    if (kf_cloud_.size() > 1) {                                                                  // :1248-1256: every keyframe into the new body frame
+      const double qi[4] = {-q_w_[0], -q_w_[1], -q_w_[2], q_w_[3]};
+      double ti[3];
+      qrot(qi, t_w_, ti);
+      for (int a = 0; a < 3; a++) ti[a] = -ti[a];
+      for (const auto& kf : kf_cloud_) {
+        const size_t at = submap_.size();
+        submap_.resize(at + kf.size());
+        chk(rgc_transform_cloud(ctx_, kf.data(), (int)(kf.size() / 4), 16, qi, ti, submap_.data() + at, 0));
+      }
+    }
+  }
+
+  static constexpr int kSlipwide = 3;   // slipwide, RGC_odometer.cpp:299 (the first keyframes are forced, :1233)
+  Options opt_;
+  rgc_ctx* ctx_ = nullptr;
+  rgc_fe_params fe_{};
+  std::vector<float> raw_, full_, full_last_, sharp_, flat_, inten_, source_, target_, submap_;
+  std::deque<std::vector<float>> kf_cloud_;
+  int n_sharp_ = 0, n_flat_ = 0;
+  double q_w_[4] = {0, 0, 0, 1}, t_w_[3] = {0, 0, 0};                 // q_w_curr, t_w_curr
+  double q_last_curr_[4] = {0, 0, 0, 1}, t_last_curr_[3] = {0, 0, 0};  // para_q, para_t
+  double q_w_delta_[4] = {0, 0, 0, 1};                                 // q_w_curr_delta (ground-change detector inactive without IMU)
+  double ground_last_[11] = {0};
+  bool have_ground_last_ = false, have_kf_ = false;
+  double kf_q_[4] = {0, 0, 0, 1}, kf_t_[3] = {0, 0, 0}, origin_[3] = {0, 0, 0};
+  int submapflag_ = 0, frames_ = 0, kf_inserted_ = 0;
+};
+
+}  // namespace rgc

@@ -1,0 +1,53 @@
+"""Frame rate of the C++ host side (rgc-slam_amd/cpp/odometry_node.hpp through tests/cpp/test_odometry_node.cpp): 24 synthetic VLP-16
+sweeps (28.8 k points, packed 22-byte Velodyne records) through PointCloud2 unpacking + front-end + frame body, in the
+reference's local-map semantics and with the map resident on the device; the Python mirrors on the same sweeps beside it."""
+import sys, os, json, subprocess, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401
+import rgc_slam_amd.synth as synth
+from rgc_slam_amd import odometry
+
+world = synth.make_world(half_extent=45.0, seed=synth.SEED)
+poses = synth.make_trajectory(25, seed=synth.SEED)
+raws = []
+for k in range(24):
+    sc = synth.make_scan(world, poses[k], n_az=1800, seed=synth.SEED + 50 + k, T_ws_end=poses[k + 1])
+    raws.append(np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32))
+tmp = tempfile.mkdtemp()
+path = os.path.join(tmp, "sweeps.bin")
+dt = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4"), ("ring", "<u2"), ("time", "<f4")])
+with open(path, "wb") as f:
+    f.write(np.int32(len(raws)).tobytes())
+    for r in raws:
+        rec = np.zeros(len(r), dt)
+        rec["x"], rec["y"], rec["z"], rec["intensity"] = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+        f.write(np.int32(len(r)).tobytes()); f.write(rec.tobytes())
+exe = os.path.join(tmp, "node")
+subprocess.check_call(["g++", "-std=c++14", "-O2", os.path.join(ROOT, "tests", "cpp", "test_odometry_node.cpp"), "-o", exe,
+                       "-L", os.path.join(ROOT, "rgc-slam_amd"), "-lrgc_hip", "-Wl,-rpath," + os.path.join(ROOT, "rgc-slam_amd")])
+res = {"workload": "24 VLP-16 sweeps x 28.8 k points, PointCloud2 bytes in -> odometry pose out (front-end + frame body, 3-keyframe local map); first 4 frames untimed"}
+final = {}
+for name, resident in (("cpp_reference_semantics", 0), ("cpp_resident_map", 1)):
+    best = None
+    for rep in range(2):
+        out = subprocess.run([exe, path, str(resident), "1"], capture_output=True, text=True, timeout=600).stdout
+        last = out.strip().splitlines()[-1].split()
+        s = dict(zip(last[1::2], last[2::2]))
+        best = float(s["ms_per_frame"]) if best is None else min(best, float(s["ms_per_frame"]))
+        final[name] = [float(x) for x in out.strip().splitlines()[-2].split()[6:9]]
+    res[name + "_ms_per_frame"] = best
+for name, cls in (("python_reference_semantics", odometry.Odometer), ("python_resident_map", odometry.RollingOdometer)):
+    hb = odometry.HipBackend(0)
+    od = cls(hb)
+    for r in raws[:4]:
+        od.process(r)
+    t0 = time.perf_counter()
+    for r in raws[4:]:
+        q, t = od.process(r)
+    res[name + "_ms_per_frame"] = round(1e3 * (time.perf_counter() - t0) / 20, 3)
+    final[name] = [float(x) for x in t]
+    hb.close()
+res["final_position_m"] = final
+print(json.dumps(res))

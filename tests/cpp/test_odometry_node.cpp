@@ -1,0 +1,64 @@
+// Drives rgc::OdometryNode (rgc-slam_amd/cpp/odometry_node.hpp) like the two ROS nodes drive their callbacks: one
+// sensor_msgs::PointCloud2-shaped message per sweep in, one odometry pose + ground message out.  Sweeps come from a file
+// written by the Python test: int32 n_sweeps, then per sweep int32 n_points followed by n_points records of the Velodyne
+// point layout {float x, y, z, intensity; uint16 ring; float time} packed to 22 bytes.
+//   test_odometry_node <sweeps.bin> <resident_map 0|1> <as_message 0|1> [rebase_distance]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../rgc-slam_amd/cpp/odometry_node.hpp"
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) { perror(argv[1]); return 2; }
+  int n_sweeps = 0;
+  if (fread(&n_sweeps, 4, 1, f) != 1) return 2;
+  std::vector<std::vector<unsigned char>> msgs(n_sweeps);
+  std::vector<int> counts(n_sweeps);
+  for (int s = 0; s < n_sweeps; s++) {
+    if (fread(&counts[s], 4, 1, f) != 1) return 2;
+    msgs[s].resize((size_t)counts[s] * 22);
+    if (fread(msgs[s].data(), 1, msgs[s].size(), f) != msgs[s].size()) return 2;
+  }
+  fclose(f);
+  rgc_pc2_layout L{};
+  L.point_step = 22; L.is_bigendian = 0; L.strict = 1;
+  const int off[6] = {0, 4, 8, 12, 16, 18}, ty[6] = {7, 7, 7, 7, 4, 7};   // FLOAT32 x4, UINT16 ring, FLOAT32 time
+  for (int k = 0; k < 6; k++) { L.offset[k] = off[k]; L.datatype[k] = ty[k]; }
+  try {
+    rgc::OdometryNode::Options opt;
+    opt.resident_map = atoi(argv[2]) != 0;
+    if (argc > 4) opt.rebase_distance = atof(argv[4]);
+    const bool as_message = atoi(argv[3]) != 0;
+    rgc::OdometryNode node(opt);
+    std::vector<float> xyzi;
+    double total = 0;
+    for (int s = 0; s < n_sweeps; s++) {
+      rgc::OdometryMsg odom; rgc::GroundMsg ground;
+      const auto t0 = std::chrono::steady_clock::now();
+      if (as_message) {
+        node.handlePointCloud2(msgs[s].data(), counts[s], L, 0.1 * s, &odom, &ground);
+      } else {   // the cloud converted on the host, as pcl::fromROSMsg would
+        xyzi.resize((size_t)4 * counts[s]);
+        for (int i = 0; i < counts[s]; i++) memcpy(&xyzi[4 * (size_t)i], &msgs[s][22 * (size_t)i], 16);
+        node.handleCloud(xyzi.data(), counts[s], 16, 0.1 * s, &odom, &ground);
+      }
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (s >= 4) total += ms;
+      printf("pose %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g ground %d %.17g %.17g ms %.3f\n", s, odom.orientation_xyzw[0], odom.orientation_xyzw[1],
+             odom.orientation_xyzw[2], odom.orientation_xyzw[3], odom.position[0], odom.position[1], odom.position[2], (int)ground.valid, ground.param[2],
+             ground.param[9], ms);
+    }
+    int ns = 0, nf = 0;
+    node.cornerPointsSharp(&ns); node.surfPointsFlat(&nf);
+    printf("summary frames %d keyframes %d sharp %d flat %d ms_per_frame %.4f\n", node.frames(), node.keyframesInserted(), ns, nf,
+           n_sweeps > 4 ? total / (n_sweeps - 4) : 0.0);
+  } catch (const std::exception& e) {
+    printf("EXCEPTION %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
