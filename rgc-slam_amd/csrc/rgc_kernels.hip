@@ -115,16 +115,32 @@ __device__ __forceinline__ int cell_index(const Grid& g, int cx, int cy, int cz)
 __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* __restrict__ slot_of,
                         int* cnt, int prio) {
   wave_prio(prio);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* p = in + (size_t)i * stride_f;
-  int cx = voxel_coord1(p[0], g.res) - g.minc[0];
-  int cy = voxel_coord1(p[1], g.res) - g.minc[1];
-  int cz = voxel_coord1(p[2], g.res) - g.minc[2];
-  int c = cell_index(g, cx, cy, cz);
-  cell_of[i] = c;
-  // the returned count is this point's (arrival-order) slot inside its cell: the placement pass needs no second atomic
-  slot_of[i] = atomicAdd(&cnt[c], 1);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  const int lane = threadIdx.x & (WAVE - 1);
+  int c = -1 - lane;  // lanes past the end: distinct negative keys, so they never extend a neighbour's run
+  if (valid) {
+    const float* p = in + (size_t)i * stride_f;
+    const int cx = voxel_coord1(p[0], g.res) - g.minc[0];
+    const int cy = voxel_coord1(p[1], g.res) - g.minc[1];
+    const int cz = voxel_coord1(p[2], g.res) - g.minc[2];
+    c = cell_index(g, cx, cy, cz);
+    cell_of[i] = c;
+  }
+  // Clouds arrive spatially coherent (ring order, leaf order): consecutive lanes that fall into the same cell form a RUN, and
+  // only the run's first lane goes to memory -- one atomicAdd(run length) instead of one per point.  A crowded cell near the
+  // sensor used to serialise hundreds of same-address atomics (~12 ns each across the XCDs).
+  // The returned count is the run's first (arrival-order) slot inside its cell: the placement pass needs no second atomic.
+  const int prev = __shfl_up(c, 1);
+  const bool head = lane == 0 || c != prev;
+  const unsigned long long hm = __ballot(head);
+  const int head_lane = 63 - __clzll(hm & ((2ull << lane) - 1ull));            // highest head at or below this lane
+  const unsigned long long above = head_lane == 63 ? 0ull : (hm >> (head_lane + 1));
+  const int run_len = above ? __ffsll((long long)above) : WAVE - head_lane;      // distance to the next head
+  int base = 0;
+  if (head && valid) base = atomicAdd(&cnt[c], run_len);
+  base = __shfl(base, head_lane);
+  if (valid) slot_of[i] = base + (lane - head_lane);
 }
 
 // three-kernel exclusive scan: 2048 items per block (256 threads x 8)
@@ -323,7 +339,15 @@ __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n,
   int c = cell_of[i];
   int s0 = start[c], s1 = start[c + 1];
   int rank = 0;
-  for (int t = s0; t < s1; t++) rank += (order_tmp[t] < i);
+  int t = s0;
+  for (; t + 8 <= s1; t += 8) {  // eight independent loads in flight: a crowded cell (hundreds of members) is a long serial loop otherwise
+    int o[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) o[u] = order_tmp[t + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) rank += (o[u] < i);
+  }
+  for (; t < s1; t++) rank += (order_tmp[t] < i);
   const float* p = in + (size_t)i * stride_f;
   P[s0 + rank] = make_float4(p[0], p[1], p[2], __int_as_float(i));
 }
