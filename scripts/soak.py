@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import rgc_slam_amd.synth as synth
-from rgc_slam_amd import registration, mapping, loop_closure, wire
+from rgc_slam_amd import registration, mapping, loop_closure, wire, local_map
 world, tgt = synth.make_world_and_map(100000)
 scan = synth.make_scan_n(world, np.eye(4), 20000)["xyz"]
 free0 = torch.cuda.mem_get_info()[0]
@@ -16,6 +16,16 @@ for it in range(40):
     v.align(np.eye(4, dtype=np.float32), want_output=False, want_fitness=True)
     if it % 5 == 0:
         v.setResolution(0.5 + 0.1 * (it % 3))
+        v.align(np.eye(4, dtype=np.float32), want_output=False)
+    if it % 4 == 0:   # f2: the resident map through inserts, evictions, a re-base and commits, then destroyed with the context
+        m = local_map.RollingLocalMap(v)
+        m.reset([1.0, 2.0, 0.0])
+        s4 = np.zeros((ns, 4), np.float32); s4[:, :3] = scan[:ns]
+        for k in range(6):
+            m.insert(s4, [0, 0, 0, 1.0], [1.0 + 0.2 * k, 2.0, 0.0])
+            m.evict(3)
+            m.commit(0.3)
+        m.rebase([1.5, 2.0, 0.0]); m.commit(0.3)
         v.align(np.eye(4, dtype=np.float32), want_output=False)
     v.close()
     icp = loop_closure.IterativeClosestPoint(0)

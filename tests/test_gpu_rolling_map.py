@@ -146,3 +146,52 @@ def test_rolling_sequence_vs_oracle_and_vs_reference_semantics():
     assert np.linalg.norm(og.t_w_curr - oref.t_w_curr) < 0.05, (og.t_w_curr, oref.t_w_curr)
     assert max(err_roll) < max(0.05, 1.5 * max(err_ref)) + 0.5
     hb.close(); hb2.close()
+
+
+def test_map_edge_cases_and_growth(clouds):
+    import ctypes as C
+    from rgc_slam_amd import registration, local_map, _lib
+    from oracle_backend import OracleBackend
+    scans, _ = clouds
+    reg = registration.odometer_vgicp(0)
+    m = local_map.RollingLocalMap(reg)
+    L, h = reg._L, reg._h
+    q, t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    dp = C.POINTER(C.c_double)
+    a = np.ascontiguousarray(scans[0])
+    # bad arguments: empty keyframe, x,y,z-only stride, null pose
+    assert L.rgc_map_insert(h, a.ctypes.data, 0, 16, q.ctypes.data_as(dp), t.ctypes.data_as(dp), 0, None) == _lib.ERR_INVALID
+    assert L.rgc_map_insert(h, a.ctypes.data, 10, 12, q.ctypes.data_as(dp), t.ctypes.data_as(dp), 0, None) == _lib.ERR_INVALID
+    assert L.rgc_map_insert(h, a.ctypes.data, 10, 16, None, t.ctypes.data_as(dp), 0, None) == _lib.ERR_INVALID
+    assert L.rgc_map_commit(h, C.c_float(-1.0), None) == _lib.ERR_INVALID
+    # a map with fewer points than k: the commit fails like setInputTarget on such a cloud, and nothing is bound
+    m.reset(None)
+    m.insert(scans[0][:7], q, t)
+    with pytest.raises(_lib.RgcError) as e:
+        m.commit(0.3)
+    assert e.value.status == -3 and m.info()["n_target"] == -1          # RGC_ERR_TOO_FEW_POINTS
+    # reset drops the bound target: align has no input any more
+    m.reset(None)
+    m.insert(scans[0], q, t); m.commit(0.3)
+    reg.setInputSource(scans[1][:, :3])
+    reg.align(np.eye(4, dtype=np.float32), want_output=False)
+    m.reset(None)
+    with pytest.raises(_lib.RgcError):
+        reg.align(np.eye(4, dtype=np.float32), want_output=False)
+    # a keyframe already resident on the device, and growth of the store across many inserts (the content must survive)
+    ob = OracleBackend(); ob.map_reset(np.zeros(3))
+    d = reg.device_alloc(a.nbytes); reg.upload(d, a)
+    kid = C.c_int(-1)
+    assert L.rgc_map_insert(h, C.c_void_p(d), len(a), 16, q.ctypes.data_as(dp), t.ctypes.data_as(dp), 1, C.byref(kid)) == 0 and kid.value >= 0
+    ob.map_insert(a, q, t)
+    rng = np.random.default_rng(9)
+    for k in range(40):                                   # 41 keyframes x ~14 k points: several re-allocations of the store
+        tk = rng.normal(0, 2.0, 3)
+        m.insert(scans[k % 5], q, tk); ob.map_insert(scans[k % 5], q, tk)
+    assert np.array_equal(m.points(), ob.map_points())
+    assert m.evict(0, np.zeros(3), 2.0) == ob.map_evict(0, np.zeros(3), 2.0)   # scattered survivors: several compaction runs
+    assert np.array_equal(m.points(), ob.map_points())
+    n = m.commit(0.3)
+    assert n == len(ob.map_target(0.3)) and np.array_equal(m.target(), ob.map_target(0.3))
+    reg.device_free(d)
+    reg.close()
