@@ -152,7 +152,7 @@ typedef struct rgc_fe_params {
   int    use_intensity;  /* USE_intensity (:58,645)                    */
 } rgc_fe_params;
 typedef struct rgc_fe_out {
-  float* cloud; int cloud_cap; int n_cloud;                 /* cloud_cap points * 4 floats                        */
+  float* cloud; int cloud_cap; int n_cloud;                 /* cloud_cap points * 4 floats (NULL: not downloaded) */
   float* sharp; float* flat; float* inten; int feat_cap;    /* feat_cap features * 5 floats each                  */
   int n_sharp, n_sharp_own, n_flat, n_inten;                /* n_sharp includes the appended intensity corners    */
   float* ground_pts; int ground_cap; int n_ground;          /* ground_cap * 4 floats (may be NULL); n_ground total */
@@ -166,6 +166,10 @@ RGC_API int rgc_frontend(rgc_ctx* ctx, const float* xyzi, int n, int stride_byte
 /* the same with the sweep already resident on the device (a pointer from rgc_device_alloc, e.g. filled by
  * rgc_pc2_unpack(..., out_on_device = 1)): the message bytes are the only thing that crosses PCIe */
 RGC_API int rgc_frontend_device(rgc_ctx* ctx, const float* d_xyzi, int n, int stride_bytes, const rgc_fe_params* params, rgc_fe_out* out);
+/* the ring-major cloud of the LAST front-end call where it lies on the device (n x {x, y, z, ring + 0.1 relTime}, 16-byte stride), so
+ * that de-skew / VoxelGrid / setInputSource can follow without a PCIe round trip (pass out->cloud = NULL to skip its download).
+ * The pointer belongs to the context and is valid until the next front-end call; rgc_deskew(..., on_device = 1) may modify it in place. */
+RGC_API int rgc_frontend_cloud_device(rgc_ctx* ctx, float** d_cloud, int* n);
 
 /* ---- scalar host stages of the frame body (no GPU needed; kept in the same library so the adaptor is complete) ----
  * Quaternions are x,y,z,w.  ground[11] = ground_msg/groundparam order: norm xyz, vector1 xyz, vector2 xyz, distance,

@@ -104,7 +104,7 @@ SYMBOLS = [
     "rgc_fitness", "rgc_get_aligned", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
-    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_frontend_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_map_reset", "rgc_map_insert", "rgc_map_evict", "rgc_map_rebase", "rgc_map_commit", "rgc_map_get_info", "rgc_map_download", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_frontend_device", "rgc_frontend_cloud_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_map_reset", "rgc_map_insert", "rgc_map_evict", "rgc_map_rebase", "rgc_map_commit", "rgc_map_get_info", "rgc_map_download", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
 _lib = None
@@ -181,6 +181,7 @@ def load():
     L.rgc_mapreg_associate.argtypes = [vp, C.c_int, fp, C.c_int, dp, dp, dp, ip]
     L.rgc_mapreg_optimize.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, C.POINTER(MapregGround), C.POINTER(MapregGround),
                                       C.POINTER(MapregImu), dp, C.POINTER(MapregReport), ip]
+    L.rgc_frontend_cloud_device.argtypes = [vp, C.POINTER(C.c_void_p), ip]
     L.rgc_map_reset.argtypes = [vp, dp]
     L.rgc_map_insert.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, C.c_int, ip]
     L.rgc_map_evict.argtypes = [vp, C.c_int, dp, C.c_double, ip]

@@ -15,6 +15,9 @@
 //   resident_map = false : the reference's semantics -- keyframe deque on the host, re-framed / re-filtered / re-uploaded per frame
 //                          (:1218-1256, 985-991, 1007)
 //   resident_map = true  : SURVEY 8f row f2 -- keyframes stay on the device in a map frame, target rebuilt only on a keyframe change
+//   device_chain = true  : (with resident_map) the sweep never returns to the host between the stages: message bytes -> unpack kernel ->
+//                          front-end -> de-skew -> VoxelGrid -> setInputSource / keyframe insert all read the previous stage's DEVICE
+//                          buffer; only the message goes up and features, ground parameters and the pose come down
 // USE_IMU = 0 (no IMU stream in this class; the IMU hooks of the library are separate entry points).
 // Errors: std::runtime_error carrying rgc_last_error(); there is no CPU fallback.
 #pragma once
@@ -52,49 +55,97 @@ public:
     int max_keyframes = 3;                 // slipwide, RGC_odometer.cpp:299
     double evict_radius = 0.0;             // resident map only: additionally evict keyframes farther than this (0 = off)
     double rebase_distance = 50.0;         // resident map only: the map origin follows the sensor
+    bool device_chain = false;             // resident map only: keep the sweep on the device between the stages
   };
 
   explicit OdometryNode(const Options& o) : opt_(o) {
     rgc_params p;
     rgc_default_params(&p);                // = the setters of RGC_odometer.cpp:998-1006 (resolution 1.0, 25 iterations, eps 1e-6)
+    if (o.device_chain && !o.resident_map) throw std::runtime_error("device_chain needs resident_map");
     int rc = rgc_create(o.hip_device, &p, &ctx_);
     if (rc != RGC_OK) throw std::runtime_error(std::string("rgc_create: ") + rgc_status_string(rc));
     rgc_default_fe_params(&fe_);
     fe_.n_scans = o.scan_line; fe_.min_range = o.minimum_range; fe_.max_range = o.maxmum_range;
   }
-  ~OdometryNode() { rgc_destroy(ctx_); }
+  ~OdometryNode() {
+    for (DevBuf* b : {&d_raw_, &d_source_, &d_last_}) if (b->p) rgc_device_free(ctx_, b->p);
+    rgc_destroy(ctx_);
+  }
   OdometryNode(const OdometryNode&) = delete;
   OdometryNode& operator=(const OdometryNode&) = delete;
 
   // the /velodyne_points subscriber on the raw message bytes (pcl::fromROSMsg becomes a kernel, scanRegistration.cpp:107-108)
   void handlePointCloud2(const void* data, int n_points, const rgc_pc2_layout& layout, double stamp, OdometryMsg* odom, GroundMsg* ground) {
+    if (opt_.device_chain) {
+      reserve(d_raw_, (size_t)16 * (size_t)(n_points > 0 ? n_points : 1));
+      chk(rgc_pc2_unpack(ctx_, data, n_points, &layout, d_raw_.p, nullptr, nullptr, 1));
+      process(d_raw_.p, n_points, 16, true, stamp, odom, ground);
+      return;
+    }
     raw_.resize((size_t)4 * (size_t)(n_points > 0 ? n_points : 1));
     chk(rgc_pc2_unpack(ctx_, data, n_points, &layout, raw_.data(), nullptr, nullptr, 0));
-    handleCloud(raw_.data(), n_points, 16, stamp, odom, ground);
+    process(raw_.data(), n_points, 16, false, stamp, odom, ground);
   }
 
   // the same on an already converted cloud: x,y,z,intensity in firing order
   void handleCloud(const float* xyzi, int n, int stride_bytes, double stamp, OdometryMsg* odom, GroundMsg* ground) {
+    if (opt_.device_chain && n > 0) {
+      reserve(d_raw_, (size_t)stride_bytes * (size_t)n);
+      chk(rgc_upload(ctx_, d_raw_.p, xyzi, (size_t)stride_bytes * (size_t)n));
+      process(d_raw_.p, n, stride_bytes, true, stamp, odom, ground);
+      return;
+    }
+    process(xyzi, n, stride_bytes, false, stamp, odom, ground);
+  }
+
+  // what the node publishes besides the odometry (:689-727): feature clouds of the last sweep, x,y,z,intensity,normal_x
+  const float* cornerPointsSharp(int* n) const { *n = n_sharp_; return sharp_.data(); }
+  const float* surfPointsFlat(int* n) const { *n = n_flat_; return flat_.data(); }
+  int frames() const { return frames_; }
+  int keyframesInserted() const { return kf_inserted_; }
+  rgc_ctx* context() { return ctx_; }
+
+private:
+  struct DevBuf { float* p = nullptr; size_t cap = 0; };
+  void reserve(DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return;
+    if (b.p) chk(rgc_device_free(ctx_, b.p));
+    b.p = nullptr; b.cap = 0;
+    void* np = nullptr;
+    chk(rgc_device_alloc(ctx_, bytes + bytes / 4, &np));
+    b.p = (float*)np; b.cap = bytes + bytes / 4;
+  }
+
+  // in: host memory, or (on_device) device memory of this context's GPU
+  void process(const float* xyzi, int n, int stride_bytes, bool on_device, double stamp, OdometryMsg* odom, GroundMsg* ground) {
+    const bool chain = opt_.device_chain;
     // ---- ScanRegistration::laserCloudHandler ----
     const int fcap = fe_.n_scans * 6 * 41;
     full_.resize((size_t)4 * (size_t)(n > 0 ? n : 1));
     sharp_.resize((size_t)5 * fcap); flat_.resize((size_t)5 * fcap); inten_.resize((size_t)5 * fcap);
     rgc_fe_out fo;
     std::memset(&fo, 0, sizeof(fo));
-    fo.cloud = full_.data(); fo.cloud_cap = n > 0 ? n : 1;
+    fo.cloud = chain ? nullptr : full_.data(); fo.cloud_cap = n > 0 ? n : 1;
     fo.sharp = sharp_.data(); fo.flat = flat_.data(); fo.inten = inten_.data(); fo.feat_cap = fcap;
-    chk(rgc_frontend(ctx_, xyzi, n, stride_bytes, &fe_, &fo));
+    chk(on_device ? rgc_frontend_device(ctx_, xyzi, n, stride_bytes, &fe_, &fo) : rgc_frontend(ctx_, xyzi, n, stride_bytes, &fe_, &fo));
     const int n_full = fo.n_cloud;
+    float* d_full = nullptr;   // chain: the ring-major sweep where the front-end left it
+    if (chain) { int nn = 0; chk(rgc_frontend_cloud_device(ctx_, &d_full, &nn)); }
     n_sharp_ = fo.n_sharp; n_flat_ = fo.n_flat;
     if (ground) { std::memcpy(ground->param, fo.groundparam, sizeof(ground->param)); ground->valid = fo.ground_valid != 0; }
     // ---- vg_ICP::ICP_thread ----
-    if (n_full > 0) chk(rgc_deskew(ctx_, full_.data(), n_full, 16, q_last_curr_, t_last_curr_, 0));   // adjustDistortion, :958
-    if (!full_last_.empty()) {
+    if (n_full > 0) chk(rgc_deskew(ctx_, chain ? d_full : full_.data(), n_full, 16, q_last_curr_, t_last_curr_, chain ? 1 : 0));   // adjustDistortion, :958
+    if (have_last_) {
       if (submapflag_ == 0) first_keyframe();                                                   // :963-972
       submapflag_++;
       int n_src = 0;
-      source_.resize((size_t)4 * n_full);
-      chk(rgc_voxelgrid(ctx_, full_.data(), n_full, 16, 0.2f, source_.data(), &n_src, 0));       // :976-983, planeResolution1
+      if (chain) {
+        reserve(d_source_, (size_t)16 * (size_t)(n_full > 0 ? n_full : 1));
+        chk(rgc_voxelgrid(ctx_, d_full, n_full, 16, 0.2f, d_source_.p, &n_src, 1));
+      } else {
+        source_.resize((size_t)4 * n_full);
+        chk(rgc_voxelgrid(ctx_, full_.data(), n_full, 16, 0.2f, source_.data(), &n_src, 0));     // :976-983, planeResolution1
+      }
       float guess[16], T[16];
       double fitness = 1.0;
       if (opt_.resident_map) {
@@ -112,7 +163,7 @@ public:
         pose_to_mat(q_last_curr_, t_last_curr_, guess);                                         // :993-996
         chk(rgc_set_target(ctx_, target_.data(), n_tgt, 16));                                   // :1007
       }
-      chk(rgc_set_source(ctx_, source_.data(), n_src, 16));                                      // :1008
+      chk(chain ? rgc_set_source_device(ctx_, d_source_.p, n_src, 16) : rgc_set_source(ctx_, source_.data(), n_src, 16));   // :1008
       int it = 0, conv = 0, lmf = 0;
       chk(rgc_align(ctx_, guess, T, nullptr, &fitness, &it, &conv, &lmf));                       // :1009-1010
       double q_l[4], t_l[3];
@@ -145,7 +196,19 @@ public:
       std::memcpy(q_last_curr_, q_f, sizeof(q_f)); std::memcpy(t_last_curr_, t_lc, sizeof(t_lc));
       maintain_map(n_src);                                                                      // :1218-1256
     }
-    full_last_.assign(full_.begin(), full_.begin() + (size_t)4 * n_full);                         // :1319-1322
+    // :1319-1322 -- the previous sweep is only ever read to make keyframe 0
+    if (chain) {
+      if (submapflag_ == 0 && n_full > 0) {
+        const double I[4] = {0, 0, 0, 1}, Z[3] = {0, 0, 0};
+        reserve(d_last_, (size_t)16 * n_full);
+        chk(rgc_transform_cloud(ctx_, d_full, n_full, 16, I, Z, d_last_.p, 1));   // identity = a device-to-device copy
+        n_last_ = n_full;
+      }
+    } else {
+      full_last_.assign(full_.begin(), full_.begin() + (size_t)4 * n_full);
+      n_last_ = n_full;
+    }
+    have_last_ = n_full > 0;
     if (fo.ground_valid) { std::memcpy(ground_last_, fo.groundparam, sizeof(ground_last_)); have_ground_last_ = true; }
     frames_++;
     if (odom) {
@@ -155,14 +218,6 @@ public:
     }
   }
 
-  // what the node publishes besides the odometry (:689-727): feature clouds of the last sweep, x,y,z,intensity,normal_x
-  const float* cornerPointsSharp(int* n) const { *n = n_sharp_; return sharp_.data(); }
-  const float* surfPointsFlat(int* n) const { *n = n_flat_; return flat_.data(); }
-  int frames() const { return frames_; }
-  int keyframesInserted() const { return kf_inserted_; }
-  rgc_ctx* context() { return ctx_; }
-
-private:
   void chk(int rc) { if (rc != RGC_OK) throw std::runtime_error(std::string(rgc_status_string(rc)) + ": " + rgc_last_error(ctx_)); }
 
   static void qmul(const double a[4], const double b[4], double o[4]) {
@@ -198,7 +253,8 @@ private:
     if (opt_.resident_map) {
       std::memcpy(origin_, t_w_, sizeof(origin_));
       chk(rgc_map_reset(ctx_, origin_));
-      chk(rgc_map_insert(ctx_, full_last_.data(), (int)(full_last_.size() / 4), 16, I, Z, 0, nullptr));
+      if (opt_.device_chain) chk(rgc_map_insert(ctx_, d_last_.p, n_last_, 16, I, Z, 1, nullptr));
+      else chk(rgc_map_insert(ctx_, full_last_.data(), n_last_, 16, I, Z, 0, nullptr));
     } else {
       kf_cloud_.push_back(full_last_);
       submap_.insert(submap_.end(), full_last_.begin(), full_last_.end());
@@ -221,7 +277,8 @@ private:
       if (std::fabs(droll) > kAngle || std::fabs(dpitch) > kAngle || std::fabs(dyaw) > kAngle || std::sqrt(dx * dx + dy * dy + dz * dz) > kDist ||
           submapflag_ < kSlipwide - 1) {
         if (opt_.resident_map) {
-          chk(rgc_map_insert(ctx_, source_.data(), n_src, 16, q_w_, t_w_, 0, nullptr));           // :1237, once, never re-framed
+          chk(opt_.device_chain ? rgc_map_insert(ctx_, d_source_.p, n_src, 16, q_w_, t_w_, 1, nullptr)
+                                : rgc_map_insert(ctx_, source_.data(), n_src, 16, q_w_, t_w_, 0, nullptr));   // :1237, once, never re-framed
           chk(rgc_map_evict(ctx_, opt_.max_keyframes, opt_.evict_radius > 0 ? t_w_ : nullptr, opt_.evict_radius, nullptr));   // :1242-1247
         } else {
           std::vector<float> w((size_t)4 * n_src);
@@ -261,6 +318,9 @@ private:
   rgc_fe_params fe_{};
   std::vector<float> raw_, full_, full_last_, sharp_, flat_, inten_, source_, target_, submap_;
   std::deque<std::vector<float>> kf_cloud_;
+  DevBuf d_raw_, d_source_, d_last_;     // device_chain: the unpacked message, the 0.2 m-filtered sweep, the previous sweep (keyframe 0)
+  int n_last_ = 0;
+  bool have_last_ = false;
   int n_sharp_ = 0, n_flat_ = 0;
   double q_w_[4] = {0, 0, 0, 1}, t_w_[3] = {0, 0, 0};                 // q_w_curr, t_w_curr
   double q_last_curr_[4] = {0, 0, 0, 1}, t_last_curr_[3] = {0, 0, 0};  // para_q, para_t

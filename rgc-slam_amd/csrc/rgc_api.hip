@@ -87,6 +87,9 @@ struct rgc_ctx {
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos;  // B2/B3/B9 staging
   DevBuf fe[32];              // front-end buffers
+  unsigned char* h_stage = nullptr;  // pinned staging of the front-end's small read-backs and feature clouds (a copy into pageable
+  size_t h_stage_cap = 0;            // memory is staged by the runtime anyway, one blocking hop per call)
+  int fe_n_cloud = 0;         // points of the last front-end's ring-major cloud (fe[5]), for rgc_frontend_cloud_device
   // f2: rolling local map.  World-frame points (relative to map_origin, x,y,z,intensity, 16 B) of the live keyframes as
   // contiguous segments in insertion order in map_store[map_cur]; the other buffer is the compaction / re-basing target.
   struct MapKf { int id; size_t off; int n; double t[3]; };
@@ -806,6 +809,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->h_lm) (void)hipHostFree(c->h_lm);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   release(c->lm_state);
   release(c->fit_partials);
   if (c->src_ready) (void)hipEventDestroy(c->src_ready);
@@ -1278,6 +1282,7 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   if (NS != 16 && NS != 32 && NS != 64) return fail(c, RGC_ERR_INVALID, "only 16, 32 or 64 scan lines (scanRegistration.cpp:69-72)");
   out->n_cloud = out->n_sharp = out->n_sharp_own = out->n_flat = out->n_inten = out->n_ground = 0;
   out->ground_valid = 0;
+  c->fe_n_cloud = 0;
   memset(out->ring_count, 0, sizeof(out->ring_count));
   if (n == 0) return RGC_OK;
   HIPCHK(c, hipSetDevice(c->device));
@@ -1303,22 +1308,34 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   rgck::fe_filter(s, d_in, stride_f, n, fp, FE(RING, int), FE(ST, int));
   rgck::fe_half(s, d_in, stride_f, n, FE(RING, int), FE(ST, int));
   rgck::fe_bucket(s, d_in, stride_f, n, NS, FE(RING, int), FE(RANK, int), FE(HIST, int), FE(META, int), FE(ST, int), FE(CL, float4), FE(INUM2, int));
-  std::vector<int> meta(129);
-  HIPCHK(c, hipMemcpyAsync(meta.data(), FE(META, int), sizeof(int) * 129, hipMemcpyDeviceToHost, s));
+  // pinned staging: [0, 1024) meta + ground sums + flags, then the three feature clouds
+  const size_t stage_need = 1024 + 3 * 20u * (size_t)fcap;
+  if (c->h_stage_cap < stage_need) {
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, stage_need, hipHostMallocDefault));
+    c->h_stage_cap = stage_need;
+  }
+  int* meta = (int*)c->h_stage;                       // 129 ints
+  double* g11 = (double*)(c->h_stage + 640);          // 11 doubles
+  double* d2 = (double*)(c->h_stage + 768);           // 2 doubles
+  int* fl = (int*)(c->h_stage + 832);                 // 8 ints
+  unsigned char* h_feat = c->h_stage + 1024;
+  HIPCHK(c, hipMemcpyAsync(meta, FE(META, int), sizeof(int) * 129, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   const int cs = meta[128];
   out->n_cloud = cs;
   int max_ring = 0;
   for (int r = 0; r < NS; r++) { out->ring_count[r] = meta[r]; max_ring = std::max(max_ring, meta[r]); }
   if (cs == 0) return RGC_OK;
-  if (out->cloud_cap < cs) return fail(c, RGC_ERR_INVALID, "cloud_cap %d < %d points", out->cloud_cap, cs);
-  for (int b : {PICK, IPICK, LAB, ILAB}) HIPCHK(c, hipMemsetAsync(c->fe[b].p, 0, sizeof(int) * (size_t)cs, s));
+  c->fe_n_cloud = cs;
+  if (out->cloud && out->cloud_cap < cs) return fail(c, RGC_ERR_INVALID, "cloud_cap %d < %d points", out->cloud_cap, cs);
+  rgck::fe_zero4(s, FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), cs);
   rgck::fe_stencils(s, FE(CL, float4), cs, FE(RANGE, float), FE(ANGLE, float), FE(INUM2, int), FE(INUM, int), FE(CURV, float), FE(CURV2, float),
                     FE(ICURV, float), FE(DSRC, float), FE(OSRC, float), FE(PICK, int));
   // A5: ground set (with multiplicities) -> weighted centroid / covariance -> plane (scanRegistration.cpp:308-431)
   rgck::fe_ground(s, FE(CL, float4), cs, NS, FE(RANGE, float), FE(META, int), FE(GMARK, int), FE(MULT, int), FE(SCNT, int), FE(PART, double), FE(OUTD, double));
-  double g11[11];
-  HIPCHK(c, hipMemcpyAsync(g11, FE(OUTD, double), sizeof(g11), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(g11, FE(OUTD, double), sizeof(double) * 11, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   const long long gsize = (long long)(g11[10] + 0.5);
   if (gsize > 0) {
@@ -1333,8 +1350,7 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
     for (int a = 0; a < 3; a++) nrm[a] /= nl;
     if (ctr[0] * nrm[0] + ctr[1] * nrm[1] + ctr[2] * nrm[2] < 0) for (int a = 0; a < 3; a++) nrm[a] = -nrm[a];  // :374-377
     rgck::fe_ground_dist(s, FE(CL, float4), cs, FE(MULT, int), ctr, nrm, FE(PART, double), FE(OUTD, double));
-    double d2[2];
-    HIPCHK(c, hipMemcpyAsync(d2, FE(OUTD, double), sizeof(d2), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(d2, FE(OUTD, double), sizeof(double) * 2, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const double laderH = 0.56;  // :39
     double distance = d2[1] / d2[0], src1 = d2[0] / (double)gsize;  // :403-404
@@ -1361,9 +1377,13 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
                   FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), FE(FLAGS, int), max_ring);
   rgck::fe_emit(s, FE(CL, float4), NS, FE(SLOTS, int), FE(DSRC, float), FE(OSRC, float), FE(SHARP, float), FE(FLAT, float), FE(INTEN, float), fcap,
                 FE(FLAGS, int) + 4);
-  int fl[8];
-  HIPCHK(c, hipMemcpyAsync(fl, FE(FLAGS, int), sizeof(fl), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(out->cloud, FE(CL, float4), sizeof(float) * 4 * (size_t)cs, hipMemcpyDeviceToHost, s));
+  // flags and the three feature clouds (at their capacity: ~80 kB each for 16 rings) come down together into pinned memory, one
+  // synchronisation; the counts decide how much of each is handed to the caller
+  HIPCHK(c, hipMemcpyAsync(fl, FE(FLAGS, int), sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(h_feat, FE(SHARP, float), 20u * (size_t)fcap, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(h_feat + 20u * (size_t)fcap, FE(FLAT, float), 20u * (size_t)fcap, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(h_feat + 40u * (size_t)fcap, FE(INTEN, float), 20u * (size_t)fcap, hipMemcpyDeviceToHost, s));
+  if (out->cloud) HIPCHK(c, hipMemcpyAsync(out->cloud, FE(CL, float4), sizeof(float) * 4 * (size_t)cs, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (fl[0] & 2) return fail(c, RGC_ERR_INVALID, "a ring sector holds more than 2048 points");
   const int ns = fl[4], nf = fl[5], ni = fl[6];
@@ -1371,16 +1391,23 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   const bool add_inten = prm->use_intensity && ((double)ns / (double)nf < 0.3);  // :645-656
   out->n_sharp = ns + (add_inten ? ni : 0);
   if (out->feat_cap < out->n_sharp || out->feat_cap < nf || out->feat_cap < ni) return fail(c, RGC_ERR_INVALID, "feat_cap too small");
-  if (ns) HIPCHK(c, hipMemcpyAsync(out->sharp, FE(SHARP, float), 20u * (size_t)ns, hipMemcpyDeviceToHost, s));
-  if (nf) HIPCHK(c, hipMemcpyAsync(out->flat, FE(FLAT, float), 20u * (size_t)nf, hipMemcpyDeviceToHost, s));
-  if (ni) HIPCHK(c, hipMemcpyAsync(out->inten, FE(INTEN, float), 20u * (size_t)ni, hipMemcpyDeviceToHost, s));
-  if (add_inten && ni) HIPCHK(c, hipMemcpyAsync(out->sharp + 5 * (size_t)ns, FE(INTEN, float), 20u * (size_t)ni, hipMemcpyDeviceToHost, s));
+  if (ns) memcpy(out->sharp, h_feat, 20u * (size_t)ns);
+  if (nf) memcpy(out->flat, h_feat + 20u * (size_t)fcap, 20u * (size_t)nf);
+  if (ni) memcpy(out->inten, h_feat + 40u * (size_t)fcap, 20u * (size_t)ni);
+  if (add_inten && ni) memcpy(out->sharp + 5 * (size_t)ns, h_feat + 40u * (size_t)fcap, 20u * (size_t)ni);
   const struct { void* dst; int src; } diag[7] = {{out->curvature, CURV}, {out->curvature2, CURV2}, {out->inten_curvature, ICURV}, {out->label, LAB},
                                                    {out->inten_label, ILAB}, {out->picked, PICK}, {out->ground_marked, GMARK}};
   for (auto& d : diag) if (d.dst) HIPCHK(c, hipMemcpyAsync(d.dst, c->fe[d.src].p, 4u * (size_t)cs, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
 #undef FE
+  return RGC_OK;
+}
+
+int rgc_frontend_cloud_device(rgc_ctx* c, float** d_cloud, int* n) {
+  if (!c || !d_cloud || !n) return RGC_ERR_INVALID;
+  *d_cloud = c->fe_n_cloud > 0 ? (float*)c->fe[5].p : nullptr;  // CL: float4 {x, y, z, ring + 0.1 relTime}, ring-major
+  *n = c->fe_n_cloud;
   return RGC_OK;
 }
 

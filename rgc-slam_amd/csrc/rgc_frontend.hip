@@ -531,17 +531,18 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
 __global__ void __launch_bounds__(512) k_fe_emit(const float4* __restrict__ C, int NS, const int* __restrict__ slots, const float* __restrict__ dsrc,
                                                  const float* __restrict__ osrc, float* __restrict__ sharp, float* __restrict__ flat,
                                                  float* __restrict__ inten, int cap, int* __restrict__ counts) {
-  __shared__ int off[3][385];
+  __shared__ int off[3][385], cnt_s[3][385];
   const int nu = NS * 6, u = threadIdx.x;
-  if (u == 0) {
-    int a = 0, b = 0, c = 0;
-    for (int t = 0; t < nu; t++) {
-      off[0][t] = a; off[1][t] = b; off[2][t] = c;
-      a += slots[(size_t)t * SLOT + 80]; b += slots[(size_t)t * SLOT + 81]; c += slots[(size_t)t * SLOT + 82];
-    }
-    counts[0] = a; counts[1] = b; counts[2] = c;
-  }
+  // exclusive prefix of the per-(ring, sector) counts: every thread loads its unit's three counts (one round trip instead of
+  // 3 * nu dependent loads by one lane), then each thread sums the units before it out of LDS
+  if (u < nu) { cnt_s[0][u] = slots[(size_t)u * SLOT + 80]; cnt_s[1][u] = slots[(size_t)u * SLOT + 81]; cnt_s[2][u] = slots[(size_t)u * SLOT + 82]; }
   __syncthreads();
+  if (u <= nu) {  // thread nu computes the totals
+    int a = 0, b = 0, c = 0;
+    for (int t = 0; t < u; t++) { a += cnt_s[0][t]; b += cnt_s[1][t]; c += cnt_s[2][t]; }
+    if (u < nu) { off[0][u] = a; off[1][u] = b; off[2][u] = c; }
+    else { counts[0] = a; counts[1] = b; counts[2] = c; }
+  }
   if (u >= nu) return;
   const int* sl = slots + (size_t)u * SLOT;
   for (int k = 0; k < sl[80]; k++) {
@@ -564,6 +565,13 @@ static inline int nblk(long long n, int t) { return (int)((n + t - 1) / t); }
 int fe_blocks(int n) { return nblk(n, FE_T); }
 int fe_slot_ints() { return SLOT; }
 
+__global__ void k_fe_zero4(int* __restrict__ a, int* __restrict__ b, int* __restrict__ c, int* __restrict__ d, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { a[i] = 0; b[i] = 0; c[i] = 0; d[i] = 0; }
+}
+void fe_zero4(hipStream_t s, int* a, int* b, int* c, int* d, int n) {
+  if (n > 0) hipLaunchKernelGGL(k_fe_zero4, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, a, b, c, d, n);
+}
 void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st) {
   hipLaunchKernelGGL(k_fe_filter, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, in, stride_f, n, p, ring, st);
 }

@@ -125,6 +125,7 @@ void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int*
 // ---- A1-A8 front-end (rgc_frontend.hip) ----
 int fe_blocks(int n);
 int fe_slot_ints();
+void fe_zero4(hipStream_t s, int* a, int* b, int* c, int* d, int n);  // four per-point flag arrays in one launch
 void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st);
 void fe_half(hipStream_t s, const float* in, int stride_f, int n, const int* ring, int* st);
 void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, const int* ring, int* rank_in_block, int* blk_hist, int* meta,

@@ -2,7 +2,7 @@
 // sensor_msgs::PointCloud2-shaped message per sweep in, one odometry pose + ground message out.  Sweeps come from a file
 // written by the Python test: int32 n_sweeps, then per sweep int32 n_points followed by n_points records of the Velodyne
 // point layout {float x, y, z, intensity; uint16 ring; float time} packed to 22 bytes.
-//   test_odometry_node <sweeps.bin> <resident_map 0|1> <as_message 0|1> [rebase_distance]
+//   test_odometry_node <sweeps.bin> <resident_map 0|1> <as_message 0|1> [rebase_distance] [device_chain 0|1]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
     opt.resident_map = atoi(argv[2]) != 0;
     if (argc > 4) opt.rebase_distance = atof(argv[4]);
     const bool as_message = atoi(argv[3]) != 0;
+    if (argc > 5) opt.device_chain = atoi(argv[5]) != 0;
     rgc::OdometryNode node(opt);
     std::vector<float> xyzi;
     double total = 0;

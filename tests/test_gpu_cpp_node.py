@@ -41,8 +41,8 @@ def sweeps(tmp_path_factory):
     return raws, path
 
 
-def _run(exe, path, resident, as_message, rebase=None):
-    args = [exe, path, str(int(resident)), str(int(as_message))] + ([str(rebase)] if rebase is not None else [])
+def _run(exe, path, resident, as_message, rebase=None, chain=False):
+    args = [exe, path, str(int(resident)), str(int(as_message)), str(rebase if rebase is not None else 50.0), str(int(chain))]
     out = subprocess.run(args, capture_output=True, text=True, timeout=600).stdout
     assert "EXCEPTION" not in out, out
     poses, ground = [], []
@@ -72,3 +72,17 @@ def test_cpp_node_matches_python_frame_body(exe, sweeps, resident):
         assert all(g[0] == 1 for g in ground) and all(abs(abs(g[2]) - 0.56) < 0.1 for g in ground)   # ground plane: normal z ~ 1, distance ~ laderH
         assert int(summary["sharp"]) > 100 and int(summary["flat"]) > 100
     assert np.linalg.norm(ref[-1, 4:7]) > 0.3
+
+
+def test_cpp_node_device_chain(exe, sweeps):
+    """the sweep stays on the device between unpack, front-end, de-skew, VoxelGrid and setInputSource / keyframe insert: the same
+    kernels on the same data, so the poses equal the host-staged run exactly"""
+    raws, path = sweeps
+    for as_message in (True, False):
+        a, ga, sa = _run(exe, path, True, as_message, 0.5, chain=False)
+        b, gb, sb = _run(exe, path, True, as_message, 0.5, chain=True)
+        assert np.array_equal(a, b) and ga == gb
+        assert sa["keyframes"] == sb["keyframes"] and sa["sharp"] == sb["sharp"] and sa["flat"] == sb["flat"]
+    # reference semantics keep their keyframes on the host: the option is refused
+    out = subprocess.run([exe, path, "0", "1", "50", "1"], capture_output=True, text=True, timeout=600).stdout
+    assert "EXCEPTION" in out and "device_chain" in out
