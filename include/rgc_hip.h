@@ -82,7 +82,12 @@ RGC_API const char* rgc_version(void);
  * target, the voxel map) exactly like the reference; the exact-kNN covariances (fast_gicp_impl.hpp:241-298),
  * and for the target the Gaussian voxel map (fast_vgicp_voxel.hpp:129-156), are computed on the device
  * (enqueued immediately on the context's stream).  n <= 2^27 points per cloud (RGC_ERR_INVALID beyond: the kernels
- * address the sorted 16-byte points with 32-bit byte offsets). */
+ * address the sorted 16-byte points with 32-bit byte offsets).
+ * From its second cloud on a context re-uses the previous cloud's (widened) grid instead of measuring the bounding box first
+ * -- the one host round trip of these calls; results are unaffected.  A cloud that does not fit is prepared again, transparently,
+ * when the first call that consumes it finds out; by the same token RGC_ERR_NONFINITE / RGC_ERR_GRID_TOO_LARGE for such a cloud
+ * may be returned by that consuming call (rgc_align, rgc_linearize, a getter ...) instead of by rgc_set_*.  RGC_SPEC_GRID=0 in
+ * the environment restores the immediate check. */
 RGC_API int rgc_set_target(rgc_ctx* ctx, const float* xyz, int n, int stride_bytes);
 RGC_API int rgc_set_source(rgc_ctx* ctx, const float* xyz, int n, int stride_bytes);
 /* same, but xyz is DEVICE memory on the context's device (cloud already resident in HBM). */

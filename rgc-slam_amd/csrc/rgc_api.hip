@@ -39,6 +39,10 @@ struct Cloud {
   DevBuf in_copy, cell_of, slot_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
   DevBuf segs, nseg;  // row segments of the tiled kNN kernel
   rgck::Grid grid{};
+  // speculative grid: the previous cloud's grid, widened, re-used without the bounding-box round trip; k_count guards it
+  rgck::Grid spec_grid{};
+  bool spec_ok = false;    // spec_grid is usable
+  bool spec_used = false;  // this cloud was prepared on spec_grid and its guard has not been read yet
   // target only
   DevBuf cell_voxel, vox, vox_cell;
   int nvox = -1;
@@ -84,6 +88,7 @@ struct rgc_ctx {
   DevBuf fit_partials;        // fitness rows when it is chained behind the LM slots
   rgck::LmState* h_lm = nullptr;  // pinned mirror
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop (A/B knob)
+  bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos;  // B2/B3/B9 staging
   DevBuf fe[32];              // front-end buffers
@@ -212,7 +217,7 @@ int check_params(rgc_ctx* c, const rgc_params* p) {
 
 // C1-C3: grid + exact-kNN covariances (+ voxel map for the target), all enqueued on the stream.
 // One host<->device round trip: the 6-int bounding box (the dense grid is sized from it).
-int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
+int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false) {
   const int n = cl.n;
   const int k = c->prm.k_correspondences;
   hipStream_t s = is_target ? c->stream : c->stream2;
@@ -227,21 +232,40 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     const size_t init_bytes = (is_target ? 8 : 7) * sizeof(int);
     memcpy(hsm, init, init_bytes);
     HIPCHK(c, hipMemcpyAsync(dsm, hsm, init_bytes, hipMemcpyHostToDevice, s));
-    rgck::bbox(s, cl.in, cl.stride_f, n, c->prm.voxel_res, dsm, dsm + 6, hi);
-    HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", is_target ? "target" : "source");
+    // Speculative grid: consecutive clouds of a sequence cover (almost) the same cells, so the previous grid -- widened by two
+    // cells in x and y, one in z -- is re-used WITHOUT the bounding-box kernel and its host round trip (the only synchronisation
+    // between setInputTarget and the end of align).  A larger bounding grid changes nothing in the results: cells keep their
+    // relative order (voxel ids come from the cell scan), neighbourhoods are the same.  k_count guards it; the guard comes home
+    // with the LM state (or is read by the first other consumer) and a miss re-prepares the cloud on its own bounding box.
+    const bool spec = c->spec_on && !c->lm_host && rgck::knn_impl() == 0 && cl.spec_ok && cl.spec_grid.res == c->prm.voxel_res && !force_bbox;
     rgck::Grid g{};
-    double ncell = 1.0;
-    for (int a = 0; a < 3; a++) {
-      g.minc[a] = hsm[a];
-      g.dim[a] = hsm[3 + a] - hsm[a] + 1;
-      ncell *= (double)g.dim[a];
+    if (spec) {
+      g = cl.spec_grid;
+      cl.spec_used = true;
+    } else {
+      cl.spec_used = false;
+      rgck::bbox(s, cl.in, cl.stride_f, n, c->prm.voxel_res, dsm, dsm + 6, hi);
+      HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", is_target ? "target" : "source");
+      double ncell = 1.0;
+      for (int a = 0; a < 3; a++) {
+        g.minc[a] = hsm[a];
+        g.dim[a] = hsm[3 + a] - hsm[a] + 1;
+        ncell *= (double)g.dim[a];
+      }
+      if (ncell > (double)c->prm.max_cells || ncell > 2.0e9)
+        return fail(c, RGC_ERR_GRID_TOO_LARGE, "%s grid %d x %d x %d exceeds max_cells", is_target ? "target" : "source", g.dim[0], g.dim[1], g.dim[2]);
+      g.res = c->prm.voxel_res;
+      g.ncell = (int)ncell;
+      // the grid the NEXT cloud will try
+      rgck::Grid w = g;
+      double wcell = 1.0;
+      for (int a = 0; a < 3; a++) { const int m = a < 2 ? 2 : 1; w.minc[a] -= m; w.dim[a] += 2 * m; wcell *= (double)w.dim[a]; }
+      w.ncell = (int)wcell;
+      cl.spec_ok = wcell <= (double)c->prm.max_cells && wcell <= 2.0e9;
+      cl.spec_grid = w;
     }
-    if (ncell > (double)c->prm.max_cells || ncell > 2.0e9)
-      return fail(c, RGC_ERR_GRID_TOO_LARGE, "%s grid %d x %d x %d exceeds max_cells", is_target ? "target" : "source", g.dim[0], g.dim[1], g.dim[2]);
-    g.res = c->prm.voxel_res;
-    g.ncell = (int)ncell;
     cl.grid = g;
     const size_t nc1 = (size_t)g.ncell + 1;
     int rc;
@@ -259,7 +283,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
     if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)g.ncell))) return rc;
     HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, (sizeof(int) * nc1 + 255) & ~(size_t)255, s));  // whole 256-byte lines: one fill kernel
-    rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi);
+    rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi, spec ? dsm + 6 : nullptr);
     rgck::scan_cells(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
                      is_target ? c->d_small + 7 : nullptr, hi);
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p, hi);
@@ -273,12 +297,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target) {
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n, s);
     rgck::knn_rows(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (const int*)cl.nseg.p,
-                   (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
+                   (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr);
   }
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COOP : RGC_K_KNN_COOP_SRC, n, s);
     rgck::knn_coop(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p,
-                   (double*)cl.ny.p, (double*)cl.nz.p);
+                   (double*)cl.ny.p, (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr);
   }
   if (is_target) {
     int rc;
@@ -355,9 +379,46 @@ int join_source(rgc_ctx* c) {
   return RGC_OK;
 }
 
-int need_inputs(rgc_ctx* c) {
+// Guards of speculative grids (bit 0: non-finite point, bit 1: point outside the grid).  Returns < 0 on error, 1 if a cloud had
+// to be prepared again on its own bounding box (whatever was computed from it must be redone), 0 if everything stands.
+int resolve_guards(rgc_ctx* c, int guard_t, int guard_s) {
+  int redo = 0;
+  Cloud* cl[2] = {&c->tgt, &c->src};
+  const int gd[2] = {guard_t, guard_s};
+  for (int a = 0; a < 2; a++) {
+    if (!cl[a]->spec_used) continue;
+    cl[a]->spec_used = false;
+    if (!gd[a]) continue;
+    cl[a]->ready = false;
+    c->corr_valid = false;
+    c->deferred_known = false;
+    if (gd[a] & 1) { cl[a]->n = 0; return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", a == 0 ? "target" : "source"); }
+    int rc = prepare_cloud(c, *cl[a], a == 0, /*force_bbox=*/true);
+    if (rc) { cl[a]->n = 0; return rc; }
+    redo = 1;
+  }
+  return redo;
+}
+
+// for every consumer except rgc_align (which gets the guards with its state read-back): one synchronisation, once per cloud
+int validate_clouds(rgc_ctx* c) {
+  if (!((c->tgt.ready && c->tgt.spec_used) || (c->src.ready && c->src.spec_used))) return RGC_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipMemcpyAsync(c->h_small + 6, c->d_small + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_small + 22, c->d_small + 22, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int r = resolve_guards(c, c->tgt.spec_used ? c->h_small[6] : 0, c->src.spec_used ? c->h_small[22] : 0);
+  return r < 0 ? r : RGC_OK;
+}
+
+int need_inputs(rgc_ctx* c, bool validate = true) {
   if (!c) return RGC_ERR_INVALID;
   if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
+  if (validate) {
+    int rc = validate_clouds(c);
+    if (rc) return rc;
+    if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
+  }
   return join_source(c);
 }
 
@@ -779,6 +840,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
+  if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_LM_IMPL")) { c->lm_host = strcmp(e, "host") == 0; c->lm_persist = strcmp(e, "persistent") == 0; }
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   *out = c;
@@ -869,7 +931,8 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
               int* converged, int* lm_failed) {
   if (!c || !guess) return RGC_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = need_inputs(c);
+  // the guards of speculative grids come home with the LM state below: no extra synchronisation here
+  int rc = need_inputs(c, /*validate=*/c->lm_host);
   if (rc) return rc;
   const rgc_params& P = c->prm;
   double x0[16];
@@ -961,6 +1024,11 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
       HIPCHK(c, hipGetLastError());
       if (S.done) { fitness_chained = S.has_fit != 0; break; }
       batch = 6;  // a solve that is still running after six outer iterations usually runs many more (up to 25): fewer read-backs
+    }
+    {  // a cloud that did not fit its speculative grid: everything above ran on a parked cloud -- prepare it properly, solve again
+      const int r = resolve_guards(c, S.pad & 0xff, (S.pad >> 8) & 0xff);
+      if (r < 0) return r;
+      if (r > 0) return rgc_align(c, guess, final_T, final_H, fitness, iterations, converged, lm_failed);
     }
     if (!solved && S.cur) { std::swap(c->corr_v, c->corr_v2); std::swap(c->corr_M, c->corr_M2); }  // corr_v / corr_M = the valid buffer
     c->corr_noff = noff; c->corr_n = n; c->corr_valid = S.n_lin > 0;
@@ -1054,9 +1122,11 @@ int rgc_get_aligned(rgc_ctx* c, const float T[16], float* out, int stride_bytes)
 static int get_covs(rgc_ctx* c, Cloud& cl, double* cov9, double* normals) {
   if (!cl.ready) return fail(c, RGC_ERR_NO_INPUT, "cloud not set");
   HIPCHK(c, hipSetDevice(c->device));
-  const int n = cl.n;
-  int rc = join_source(c);
+  int rc = validate_clouds(c);
   if (rc) return rc;
+  if (!cl.ready) return fail(c, RGC_ERR_NO_INPUT, "cloud not set");
+  const int n = cl.n;
+  if ((rc = join_source(c))) return rc;
   if ((rc = ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n))) return rc;
   rgck::unsort3(c->stream, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const float4*)cl.P.p, n, (double*)c->scratch.p);
   std::vector<double> tmp;
@@ -1091,8 +1161,10 @@ int rgc_get_voxels(rgc_ctx* c, int cap, int* coords, int* num, double* mean, dou
   if (!c || !count) return RGC_ERR_INVALID;
   if (!c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "target not set");
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = fetch_nvox(c);
+  int rc = validate_clouds(c);
   if (rc) return rc;
+  if (!c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "target not set");
+  if ((rc = fetch_nvox(c))) return rc;
   const int V = c->tgt.nvox;
   *count = V;
   const int m = V < cap ? V : cap;
@@ -1413,6 +1485,7 @@ int rgc_frontend_cloud_device(rgc_ctx* c, float** d_cloud, int* n) {
 
 int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   if (!c || !out) return RGC_ERR_INVALID;
+  { int rc = validate_clouds(c); if (rc) return rc; }
   if (c->tgt.ready) { int rc = fetch_nvox(c); if (rc) return rc; }
   // queries the bulk kNN kernel handed to the cooperative kernel (first int of the deferred-list buffer)
   if (!c->deferred_known) c->stats.deferred_target = c->stats.deferred_source = 0;

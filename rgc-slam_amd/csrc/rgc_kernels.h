@@ -29,7 +29,7 @@ struct LmState {  // device-resident state of LsqRegistration::computeTransforma
   double rot_eps, trans_eps, init_factor;
   int phase, done, conv, failed, outer, inner, n_lin, n_err, ncorr, ticketA, ticketB, max_outer, max_inner, has_fit;
   double fit_sum;                // sum of squared NN distances at the final pose (k_fitness_lm)
-  int nvox, def_t, def_s, pad;   // frame counters carried home with the state
+  int nvox, def_t, def_s, pad;   // frame counters carried home with the state; pad = grid guards, map | scan << 8
   int gen, cmd, mode, cur;       // persistent solve: hand-off generation + command; step kernels: mode, valid corr buffer
 };
 struct LmInit { double x0[16], rot_eps, trans_eps, init_factor; int max_outer, max_inner; };
@@ -42,7 +42,7 @@ constexpr int kVoxRec = 10; // mean(3) cov6(6) num(1), doubles
 // Sorted points are float4 {x, y, z, original index (int bits)} grouped by grid cell.
 // ---- grid build ----
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi = 0);
-void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi = 0);
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi = 0, int* guard = nullptr);
 // cnt: n = cells + 1 entries; block_sums: >= 8 * (n / 2048 + 2) bytes; cell_voxel (n - 1 ints) and nvox may be null
 void scan_cells(hipStream_t s, const int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi = 0);
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi = 0);
@@ -60,9 +60,9 @@ void set_knn_heavy(int v);
 void set_knn_jump(int v);
 // bulk kernel (one lane per query; defers expensive queries) then the cooperative kernel (one wave per deferred query)
 void knn_rows(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-              const int* nseg, double* nx, double* ny, double* nz);
+              const int* nseg, double* nx, double* ny, double* nz, const int* guard = nullptr);
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
-              double* ny, double* nz);
+              double* ny, double* nz, const int* guard = nullptr);
 // ---- C3: Gaussian voxel map ----
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int n, const int* cell_voxel, double* vox, int* vox_cell);

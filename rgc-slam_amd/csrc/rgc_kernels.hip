@@ -112,8 +112,11 @@ __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ in, int 
 
 __device__ __forceinline__ int cell_index(const Grid& g, int cx, int cy, int cz) { return (cz * g.dim[1] + cy) * g.dim[0] + cx; }
 
+// guard (nullable): the grid was NOT derived from this cloud (a speculative grid kept from the previous one): a point with
+// non-finite / absurd coordinates sets bit 0, a point outside the grid bit 1 -- the host re-prepares the cloud when it
+// learns of it; such a point is parked in cell 0 so that nothing is written out of bounds meanwhile.
 __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* __restrict__ slot_of,
-                        int* cnt, int prio) {
+                        int* cnt, int* guard, int prio) {
   wave_prio(prio);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < n;
@@ -121,9 +124,20 @@ __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid 
   int c = -1 - lane;  // lanes past the end: distinct negative keys, so they never extend a neighbour's run
   if (valid) {
     const float* p = in + (size_t)i * stride_f;
-    const int cx = voxel_coord1(p[0], g.res) - g.minc[0];
-    const int cy = voxel_coord1(p[1], g.res) - g.minc[1];
-    const int cz = voxel_coord1(p[2], g.res) - g.minc[2];
+    int cx, cy, cz;
+    if (guard) {
+      const float x = p[0], y = p[1], z = p[2];
+      const bool fin = fabsf(x) <= 1.0e8f && fabsf(y) <= 1.0e8f && fabsf(z) <= 1.0e8f;  // false for NaN too
+      cx = fin ? voxel_coord1(x, g.res) - g.minc[0] : 0;
+      cy = fin ? voxel_coord1(y, g.res) - g.minc[1] : 0;
+      cz = fin ? voxel_coord1(z, g.res) - g.minc[2] : 0;
+      const bool inside = cx >= 0 && cx < g.dim[0] && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
+      if (!fin || !inside) { atomicOr(guard, fin ? 2 : 1); cx = cy = cz = 0; }
+    } else {
+      cx = voxel_coord1(p[0], g.res) - g.minc[0];
+      cy = voxel_coord1(p[1], g.res) - g.minc[1];
+      cz = voxel_coord1(p[2], g.res) - g.minc[2];
+    }
     c = cell_index(g, cx, cy, cz);
     cell_of[i] = c;
   }
@@ -793,6 +807,7 @@ struct Deferred {
   int* idx;    // query index i, or ~i when the 3x3x3 block (radius 1) has already been scanned
   float* thr;  // k-th distance seen so far (INFINITY if fewer than k candidates)
   int* cnt;
+  const int* guard;  // speculative grid only: non-zero = some point did not fit the grid, the cloud will be prepared again -- do nothing
 };
 
 template <int KC>
@@ -948,6 +963,7 @@ k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
            double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
   extern __shared__ int slist_rows[];  // [k][KNN_T] neighbour list, then [18][KNN_T] row ranges
   wave_prio(!kTarget);
+  if (df.guard && *df.guard) return;  // points outside a speculative grid were parked in cell 0: their cells must not be looked up
   const int i = blockIdx.x * KNN_T + threadIdx.x;
   if (i < n) knn_point<KC>(P, start, g, k, heavy, jump_budget, i, slist_rows + threadIdx.x, slist_rows + k * KNN_T + threadIdx.x, df, nx, ny, nz);
 }
@@ -1065,6 +1081,7 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
            double* __restrict__ ny, double* __restrict__ nz) {
   __shared__ CoopRows shm[KNN_T / WAVE];
   wave_prio(!kTarget);
+  if (df.guard && *df.guard) return;
   const int lane = threadIdx.x & (WAVE - 1), wib = threadIdx.x / WAVE;
   CoopRows* sh = &shm[wib];
   const int wave = blockIdx.x * (KNN_T / WAVE) + wib, nwaves = gridDim.x * (KNN_T / WAVE);
@@ -1715,6 +1732,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
 #pragma unroll
       for (int a = 0; a < 6; a++) st->Hfin[a * 7] = 1.0;
       st->nvox = nvox ? *nvox : 0;
+      st->pad = nvox ? (nvox[-1] | (nvox[15] << 8)) : 0;  // grid guards of map and scan (d_small[6], [22])
       st->def_t = def_t ? *def_t : 0;
       st->def_s = def_s ? *def_s : 0;
       st->done = 1;
@@ -1765,6 +1783,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     st->max_outer = in.max_outer;
     st->max_inner = in.max_inner;
     st->nvox = nvox ? *nvox : 0;
+    st->pad = nvox ? (nvox[-1] | (nvox[15] << 8)) : 0;
     st->def_t = def_t ? *def_t : 0;
     st->def_s = def_s ? *def_s : 0;
   }
@@ -1933,6 +1952,7 @@ k_lm_run(const float4* __restrict__ P, const double* __restrict__ nx, const doub
     wt(&st->n_lin, 0); wt(&st->n_err, 0); wt(&st->ncorr, 0); wt(&st->has_fit, 0);
     wt(&st->fit_sum, 0.0); wt(&st->y0, 0.0); wt(&st->yi, 0.0);
     wt(&st->nvox, nvox ? *nvox : 0);
+    wt(&st->pad, nvox ? (nvox[-1] | (nvox[15] << 8)) : 0);
     wt(&st->def_t, def_t ? *def_t : 0);
     wt(&st->def_s, def_s ? *def_s : 0);
     wt(&st->done, in.max_outer <= 0 ? 1 : 0);
@@ -2669,8 +2689,8 @@ void mapreg_terms(hipStream_t s, const float* const feat[4], const double* const
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi) {
   hipLaunchKernelGGL(k_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags, hi);
 }
-void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi) {
-  hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, hi);
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi, int* guard) {
+  hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi);
 }
 void scan_cells(hipStream_t s, const int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi) {
   const int nb = nblk(n, SCAN_B);
@@ -2710,15 +2730,16 @@ int knn_impl() { return g_knn_impl; }
 // deferred list lives in the segment buffer (unused by the default implementation): [cnt, pad x15][idx n][thr n]
 static Deferred deferred_of(const void* segs, int n) {
   int* base = (int*)const_cast<void*>(segs);
-  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base};
+  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr};
 }
 
 template <int KC>
 static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-                        const int* nseg, double* nx, double* ny, double* nz) {
+                        const int* nseg, double* nx, double* ny, double* nz, const int* guard) {
   if (g_knn_impl == 0) {
     const size_t ldsr = (size_t)(k + 18) * KNN_T * sizeof(int);
     Deferred df = deferred_of(segs, n);  // df.cnt was zeroed by k_rank_gather
+    df.guard = guard;
     const int nb = nblk(n, KNN_T);
     if (is_target)
       hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, g_knn_jump, df, nx, ny, nz);
@@ -2741,9 +2762,10 @@ static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const in
 }
 template <int KC>
 static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-                        double* nx, double* ny, double* nz) {
+                        double* nx, double* ny, double* nz, const int* guard) {
   if (g_knn_impl != 0) return;
   Deferred df = deferred_of(segs, n);
+  df.guard = guard;
   // the number of deferred queries is only known on the device: one wave each up to 8192 waves, idle blocks exit at once
   const int nbc = n < 2048 * (KNN_T / WAVE) ? nblk(n, KNN_T / WAVE) : 2048;
   if (is_target)
@@ -2752,14 +2774,14 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
     hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
 }
 void knn_rows(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-              const int* nseg, double* nx, double* ny, double* nz) {
-  if (k <= 20) knn_rows_kc<20>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz);
-  else knn_rows_kc<32>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz);
+              const int* nseg, double* nx, double* ny, double* nz, const int* guard) {
+  if (k <= 20) knn_rows_kc<20>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz, guard);
+  else knn_rows_kc<32>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz, guard);
 }
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
-              double* ny, double* nz) {
-  if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz);
-  else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz);
+              double* ny, double* nz, const int* guard) {
+  if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard);
+  else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard);
 }
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int n, const int* cell_voxel, double* vox, int* vox_cell) {

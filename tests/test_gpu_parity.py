@@ -302,3 +302,63 @@ def test_cpp_adaptor(reg_mod, fx_reg, tmp_path):
     assert np.abs(T - fx_reg["final_T"]).max() < 1e-6, out
     assert abs(float(lines["fitness"]) - fx_reg["fitness"]) <= 1e-5 * fx_reg["fitness"]
     assert lines["converged"].startswith("1")
+
+
+def test_speculative_grid_hit_miss_and_late_errors(reg_mod, medium):
+    """From the second cloud on, a context re-uses the previous cloud's (widened) grid without the bounding-box round trip.  A hit
+    must give bit-identical results (a larger bounding grid changes neither neighbourhoods nor the order of the voxels); a miss -- the
+    new cloud does not fit -- must be detected (by align through its state read-back, by any other consumer through its own check) and
+    give the result of a fresh context; a non-finite cloud is then reported by the first call that consumes it."""
+    from rgc_slam_amd import _lib
+    tgt, src = medium["tgt"], medium["src"]
+    eye = np.eye(4, dtype=np.float32)
+    fresh = _odo(reg_mod)
+    fresh.setInputTarget(tgt); fresh.setInputSource(src)
+    fresh.align(eye, want_output=False, want_fitness=True)
+    T0, f0, vm0, ct0 = fresh.getFinalTransformation(), fresh.getFitnessScore(), fresh.getVoxels(), fresh.getTargetCovariances()
+    fresh.close()
+
+    def same(v):
+        v.align(eye, want_output=False, want_fitness=True)
+        vm = v.getVoxels()
+        return (np.array_equal(v.getFinalTransformation(), T0) and v.getFitnessScore() == f0 and np.array_equal(vm["coords"], vm0["coords"]) and
+                np.array_equal(vm["num"], vm0["num"]) and np.array_equal(vm["mean"], vm0["mean"]) and np.array_equal(vm["cov"], vm0["cov"]) and
+                np.array_equal(v.getTargetCovariances(), ct0))
+    v = _odo(reg_mod)
+    # hit: the same clouds a second and third time (speculative grid = first grid widened)
+    for _ in range(3):
+        v.setInputTarget(tgt); v.setInputSource(src)
+        assert same(v)
+    # miss seen by align: a small target first, then the full one (its bounding box is far larger than the widened small grid)
+    c = tgt.mean(axis=0)
+    small = tgt[np.abs(tgt - c).max(axis=1) < 6.0]
+    assert 100 < len(small) < len(tgt) // 2
+    v.setInputTarget(small); v.setInputSource(src); v.align(eye, want_output=False)
+    v.setInputTarget(tgt); v.setInputSource(src)
+    assert same(v)
+    # miss seen by a getter (no align in between)
+    v.setInputTarget(small); v.getTargetCovariances()
+    v.setInputTarget(tgt)
+    assert np.array_equal(v.getTargetCovariances(), ct0)
+    v.setInputSource(src)
+    assert same(v)
+    # a shifted source (speculative source grid misses) and back
+    v.setInputSource(src + np.float32([40.0, -30.0, 5.0])); v.align(eye, want_output=False)
+    v.setInputSource(src)
+    assert same(v)
+    # non-finite input under a speculative grid: reported by the first consumer, and the context stays usable
+    bad = tgt.copy(); bad[17, 1] = np.nan
+    v.setInputTarget(bad)
+    with pytest.raises(reg_mod.RgcError) as e:
+        v.align(eye, want_output=False)
+    assert e.value.status == _lib.ERR_NONFINITE
+    with pytest.raises(reg_mod.RgcError) as e:
+        v.align(eye, want_output=False)
+    assert e.value.status == _lib.ERR_NO_INPUT             # the bad target was dropped
+    v.setInputTarget(bad)
+    with pytest.raises(reg_mod.RgcError) as e:
+        v.getTargetNormals()
+    assert e.value.status == _lib.ERR_NONFINITE
+    v.setInputTarget(tgt); v.setInputSource(src)
+    assert same(v)
+    v.close()
