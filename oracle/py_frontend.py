@@ -1,0 +1,165 @@
+"""TEST INFRASTRUCTURE -- a second, deliberately literal restatement of the per-point stages of the scan front-end
+(/root/reference/rgc_slam/src/scanRegistration.cpp), written from the reference text line by line in numpy float32 / Python
+scalars, to pin oracle/rgc_oracle_aux.c (orc_frontend): A3 range / incidence / near-intensity smoothing (:234-268), A4 curvature
+stencils (:270-306), A6 occlusion mask (:433-456), A7 per-sector sort and greedy selection (:469-644) and the intensity append of
+:645-656.  The ring bucket (A2) and the ground marking (A5) are inputs here (they are pinned by the sensor-model properties in
+tests/test_oracle_frontend.py).  Plain loops: use on small sweeps only.  Per-frame arrays start at zero and
+std::sort's unspecified tie order is fixed as ascending index (item 10), like every other implementation in this repository.
+"""
+import numpy as np
+
+f32 = np.float32
+
+
+def stencils(cloud_xyz, intensity_num_in):
+    """:234-306.  cloud_xyz: (n,3) float32 ring-major; intensity_num_in: (n,) ints (deque<int> intensity_num2).  Returns a dict."""
+    P = np.asarray(cloud_xyz, np.float32)
+    n = len(P)
+    num2 = [int(v) for v in intensity_num_in]
+    num = list(num2)
+    rng = np.zeros(n, np.float32)
+    ang = np.zeros(n, np.float32)
+    for i in range(n):  # :235-238 float expression, sqrt of a float
+        x, y, z = P[i]
+        rng[i] = np.sqrt(f32(f32(f32(x * x) + f32(y * y)) + f32(z * z)))
+    for i in range(5, n - 5):  # :240-255, Eigen::Vector3d arithmetic
+        if rng[i] < 2:
+            a, b, now = P[i + 5].astype(np.float64), P[i - 5].astype(np.float64), P[i].astype(np.float64)
+            c = (a + b) / 2
+            nrm = np.cross(a - b, now - c)
+            v = f32(np.dot(nrm, now) / (np.linalg.norm(nrm) * np.linalg.norm(now)))
+            ang[i] = -v if v < 0 else v
+    for i in range(5, n - 5):  # :257-268, every store truncates to int
+        if ang[i] < 0.07 and rng[i] < 2:
+            num[i] = int(0.9 * num2[i])
+            for j in range(-5, 6):
+                if j != 0:
+                    num[i] = int(num[i] + 0.005 * num2[i + j])
+    curv, curv2, icurv = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    dsrc, osrc = np.zeros(n, np.float32), np.zeros(n, np.float32)
+
+    def lap(col, i):  # p[i-5] + ... + p[i-1] - 10 p[i] + p[i+1] + ... + p[i+5], float, left to right
+        s = col[i - 5]
+        for k in (-4, -3, -2, -1):
+            s = f32(s + col[i + k])
+        s = f32(s - f32(f32(10) * col[i]))
+        for k in (1, 2, 3, 4, 5):
+            s = f32(s + col[i + k])
+        return s
+    for i in range(5, n - 5):
+        dx, dy, dz = lap(P[:, 0], i), lap(P[:, 1], i), lap(P[:, 2], i)
+        di = f32(num[i - 5] + num[i - 4] + num[i - 3] + num[i - 2] + num[i - 1] - 10 * num[i] + num[i + 1] + num[i + 2] + num[i + 3] + num[i + 4] + num[i + 5])
+        dis = f32(2.0 / (1.0 + float(rng[i]) / 20.0))  # double expression stored in a float
+        if dis < 0.2:
+            dis = f32(0.2)
+        curv[i] = f32(f32(f32(f32(dx * dx) + f32(dy * dy)) + f32(dz * dz)) * dis)
+        dsrc[i] = f32(0.5 + float(dis))
+        if ang[i] < 0.07 and rng[i] < 2:
+            osrc[i] = f32(float(f32(ang[i] * f32(10))) + 0.6)
+            icurv[i] = f32((float(ang[i]) + 0.3) * float(di))
+        else:
+            osrc[i] = f32(3)
+            icurv[i] = di
+        # float sum of the first five, then double from "- 10.0 * range" on; stored in a float
+        s = rng[i - 5]
+        for k in (-4, -3, -2, -1):
+            s = f32(s + rng[i + k])
+        d = float(s) - 10.0 * float(rng[i])
+        for k in (1, 2, 3, 4, 5):
+            d = d + float(rng[i + k])
+        dr = f32(d)
+        curv2[i] = abs(f32(dr * dis))
+    return dict(range=rng, angle=ang, intensity_num=np.array(num, np.int64), curvature=curv, curvature2=curv2, inten_curvature=icurv,
+                distance_source=dsrc, other_source=osrc)
+
+
+def occlusion(rng):
+    """:433-456 on zeroed cloudNeighborPicked"""
+    n = len(rng)
+    picked = np.zeros(n + 8, np.int32)
+    for i in range(5, n - 5):
+        d1, d2 = rng[i], rng[i + 1]
+        if f32(d1 - d2) > 0.04 * float(d2):
+            picked[i - 5:i + 1] = 1
+        elif f32(d2 - d1) > 0.04 * float(d1):
+            picked[i + 1:i + 7] = 1
+    return picked[:n]
+
+
+def select(cloud, st, picked_in, ground_marked, scan_start, scan_end, use_intensity=1):
+    """:458-656.  cloud: (n,4) ring-major with encoded intensity; st: stencils() output; scan_start / scan_end = scanStartInd / scanEndInd."""
+    P = np.asarray(cloud, np.float32)
+    n = len(P)
+    curv, curv2, icurv, num = st["curvature"], st["curvature2"], st["inten_curvature"], st["intensity_num"]
+    picked = np.array(picked_in, np.int32).copy()
+    ipicked = np.zeros(n, np.int32)
+    label, ilabel = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    sharp, flat, inten = [], [], []
+
+    def gap(a, b):
+        d = P[a, :3] - P[b, :3]
+        return f32(f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2]))
+
+    def suppress(ind, flags, far):
+        for l in range(1, 6):
+            if far(ind + l, ind + l - 1):
+                break
+            flags[ind + l] = 1
+        for l in range(-1, -6, -1):
+            if far(ind + l, ind + l + 1):
+                break
+            flags[ind + l] = 1
+    far_pts = lambda a, b: gap(a, b) > 0.05
+    far_int = lambda a, b: abs(f32(int(num[a]) - int(num[b]))) > 35
+    for i in range(len(scan_start)):
+        S, E = int(scan_start[i]), int(scan_end[i])
+        if E - S < 10:
+            continue
+        for j in range(6):
+            sp = S + (E - S) * j // 6
+            ep = S + (E - S) * (j + 1) // 6 - 1
+            by_curv = sorted(range(sp, ep + 1), key=lambda t: (curv[t], t))
+            by_int = sorted(range(sp, ep + 1), key=lambda t: (icurv[t], t))
+            k = 0
+            for ind in reversed(by_curv):
+                if picked[ind] == 0 and ground_marked[ind] != 1 and curv[ind] > 0.1 and curv2[ind] > 0.3:
+                    k += 1
+                    if k <= 20:
+                        label[ind] = 2
+                        sharp.append((P[ind, 0], P[ind, 1], P[ind, 2], P[ind, 3], f32(st["distance_source"][ind] + f32(1))))
+                    elif k <= 21:
+                        label[ind] = 1
+                    else:
+                        break
+                    picked[ind] = 1
+                    suppress(ind, picked, far_pts)
+            k = 0
+            for ind in by_curv:
+                if picked[ind] == 0 and curv[ind] < 0.3 and curv2[ind] < 0.4:
+                    k += 1
+                    if k <= 40:
+                        label[ind] = -1
+                        flat.append((P[ind, 0], P[ind, 1], P[ind, 2], P[ind, 3], st["distance_source"][ind]))
+                    else:
+                        break
+                    picked[ind] = 1
+                    suppress(ind, picked, far_pts)
+            k = 0
+            for ind in reversed(by_int):
+                if ipicked[ind] == 0 and ground_marked[ind] != 1 and icurv[ind] > 65 and label[ind] != 2 and label[ind] != 1:
+                    k += 1
+                    if k <= 20:
+                        ilabel[ind] = 2
+                        inten.append((P[ind, 0], P[ind, 1], P[ind, 2], P[ind, 3], st["other_source"][ind]))
+                    elif k <= 21:
+                        ilabel[ind] = 1
+                    else:
+                        break
+                    ipicked[ind] = 1
+                    suppress(ind, ipicked, far_int)
+    n_sharp_own = len(sharp)
+    if use_intensity and len(flat) and n_sharp_own / len(flat) < 0.3:   # :645-656
+        sharp = sharp + inten
+    arr = lambda v: np.array(v, np.float32).reshape(-1, 5)
+    return dict(label=label, inten_label=ilabel, picked=picked, ipicked=ipicked, sharp=arr(sharp), flat=arr(flat), inten=arr(inten),
+                n_sharp_own=n_sharp_own)

@@ -48,3 +48,38 @@ def test_filters(orc):
     junk = np.array([[0.1, 0.1, 0.0, 5], [-1.0, 0.2, 0.0, 5], [100.0, 0, 0, 5], [np.nan, 1, 1, 5]], np.float32)
     o1, o2 = orc.frontend(raw), orc.frontend(np.concatenate([raw[:100], junk, raw[100:]]))
     assert o1["n_cloud"] == o2["n_cloud"] and np.array_equal(o1["cloud"], o2["cloud"])   # :112-113, :732-763
+
+
+def test_stencils_occlusion_and_selection_match_the_literal_restatement(orc):
+    """A3 / A4 / A6 / A7 of the C oracle against oracle/py_frontend.py, written separately from the reference text: curvatures to the
+    last bit, labels, suppression flags and the three feature clouds (points, order and weights) identical.  Two sweeps: plain, and
+    one with near, grazing returns (the intensity smoothing branch) and strong intensity edges (the intensity corners)."""
+    from oracle import py_frontend as pf
+    for n_az, seed, near in ((420, 2, False), (360, 6, True)):
+        raw, sc = _scan(n_az=n_az, seed=seed)
+        if near:  # pull a stretch of ground returns close to the sensor and paint intensity stripes on the walls
+            rng = np.random.default_rng(8)
+            m = (sc["ring"] >= 5) & (sc["ring"] <= 6)
+            raw[m, :3] *= np.float32(0.12)
+            raw[:, 3] = np.where((np.arange(len(raw)) // 7) % 2 == 0, 20.0, 200.0).astype(np.float32) + rng.integers(0, 5, len(raw)).astype(np.float32)
+            keep = (np.linalg.norm(raw[:, :3], axis=1) > 0.55) & ~((raw[:, 0] < 0) & (np.abs(raw[:, 1]) < 0.5))   # range and self filter
+            raw, ring = raw[keep], sc["ring"][keep]
+        else:
+            ring = sc["ring"]
+        o = orc.frontend(raw)
+        assert o["n_cloud"] == len(raw)
+        order = np.argsort(ring, kind="stable")
+        assert np.array_equal(o["cloud"][:, :3], raw[order, :3])
+        st = pf.stencils(o["cloud"][:, :3], raw[order, 3].astype(np.int64))       # deque<int>: truncation of the float intensity
+        assert np.array_equal(st["curvature"], o["curvature"])
+        assert np.array_equal(st["curvature2"], o["curvature2"])
+        assert np.array_equal(st["inten_curvature"], o["inten_curvature"])
+        if near:
+            assert np.any((st["angle"] < 0.07) & (st["range"] < 2) & (st["angle"] > 0))   # the smoothing branch really ran
+        sel = pf.select(o["cloud"], st, pf.occlusion(st["range"]), o["ground_marked"], o["scan_start"], o["scan_end"])
+        assert np.array_equal(sel["label"], o["label"]) and np.array_equal(sel["inten_label"], o["inten_label"])
+        assert np.array_equal(sel["picked"], o["picked"])
+        assert sel["n_sharp_own"] == o["n_sharp_own"] and len(sel["flat"]) == len(o["flat"]) > 50 and len(sel["inten"]) == len(o["inten"])
+        assert np.array_equal(sel["sharp"], o["sharp"]) and np.array_equal(sel["flat"], o["flat"]) and np.array_equal(sel["inten"], o["inten"])
+        if near:
+            assert len(o["inten"]) > 0
