@@ -83,3 +83,29 @@ def test_stencils_occlusion_and_selection_match_the_literal_restatement(orc):
         assert np.array_equal(sel["sharp"], o["sharp"]) and np.array_equal(sel["flat"], o["flat"]) and np.array_equal(sel["inten"], o["inten"])
         if near:
             assert len(o["inten"]) > 0
+
+
+def test_deskew_and_transform_match_scipy(orc):
+    """B2 adjustDistortion (RGC_odometer.cpp:1441-1481) and B9 transformPointCloud (:1495-1514) of the C oracle against scipy's
+    Rotation / Slerp: s = 1 - frac(intensity) / 0.1, q_s = slerp(identity, q^-1, s), p' = q_s (p - s t), in double, stored float."""
+    from scipy.spatial.transform import Rotation as R, Slerp
+    rng = np.random.default_rng(12)
+    n = 400
+    pts = rng.normal(0, 10, (n, 3)).astype(np.float32)
+    ring = rng.integers(0, 16, n)
+    rel = rng.uniform(0, 1, n)
+    inten = (ring + 0.1 * rel).astype(np.float32)
+    cloud = np.concatenate([pts, inten[:, None]], axis=1).astype(np.float32)
+    q = R.from_rotvec([0.02, -0.015, 0.05])
+    t = np.array([0.12, -0.03, 0.01])
+    out = orc.deskew(cloud, q.as_quat(), t)
+    s = 1.0 - (inten.astype(np.float64) - np.floor(inten.astype(np.float64))) / 0.1
+    key = R.from_quat(np.stack([[0, 0, 0, 1.0], q.inv().as_quat()]))
+    qs = Slerp([0.0, 1.0], key)(np.clip(s, 0.0, 1.0))
+    exp = qs.apply(pts.astype(np.float64) - s[:, None] * t)
+    assert np.abs(out[:, :3] - exp.astype(np.float32)).max() < 2e-6 and np.array_equal(out[:, 3], inten)
+    assert np.all((s >= -1e-6) & (s <= 1 + 1e-6))
+    # transformPointCloud: q * p + t
+    tw = orc.transform_cloud(cloud, q.as_quat(), t)
+    assert np.abs(tw[:, :3] - (q.apply(pts.astype(np.float64)) + t).astype(np.float32)).max() < 2e-6
+    assert np.array_equal(tw[:, 3], inten)
