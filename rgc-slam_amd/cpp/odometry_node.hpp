@@ -21,11 +21,16 @@
 // USE_IMU = 0 (no IMU stream in this class; the IMU hooks of the library are separate entry points).
 // Errors: std::runtime_error carrying rgc_last_error(); there is no CPU fallback.
 #pragma once
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rgc_hip.h"
@@ -98,6 +103,13 @@ public:
     process(xyzi, n, stride_bytes, false, stamp, odom, ground);
   }
 
+  // the frame body alone (device_chain): the sweep already went through a front-end -- on another context / thread, see
+  // ReplayPipeline -- and lies on this GPU, ring-major with the encoded intensity; it is de-skewed in place
+  void handleFrontEndOutput(float* d_full, int n_full, const double groundparam[11], bool ground_valid, double stamp, OdometryMsg* odom) {
+    if (!opt_.device_chain) throw std::runtime_error("handleFrontEndOutput needs device_chain");
+    body(d_full, n_full, groundparam, ground_valid, stamp, odom);
+  }
+
   // what the node publishes besides the odometry (:689-727): feature clouds of the last sweep, x,y,z,intensity,normal_x
   const float* cornerPointsSharp(int* n) const { *n = n_sharp_; return sharp_.data(); }
   const float* surfPointsFlat(int* n) const { *n = n_flat_; return flat_.data(); }
@@ -133,7 +145,13 @@ private:
     if (chain) { int nn = 0; chk(rgc_frontend_cloud_device(ctx_, &d_full, &nn)); }
     n_sharp_ = fo.n_sharp; n_flat_ = fo.n_flat;
     if (ground) { std::memcpy(ground->param, fo.groundparam, sizeof(ground->param)); ground->valid = fo.ground_valid != 0; }
-    // ---- vg_ICP::ICP_thread ----
+    body(d_full, n_full, fo.groundparam, fo.ground_valid != 0, stamp, odom);
+  }
+
+  // ---- vg_ICP::ICP_thread: one frame body on a sweep that has been through the front-end (d_full: its device copy when chained,
+  // else full_ holds it on the host) ----
+  void body(float* d_full, int n_full, const double groundparam[11], bool ground_valid, double stamp, OdometryMsg* odom) {
+    const bool chain = opt_.device_chain;
     if (n_full > 0) chk(rgc_deskew(ctx_, chain ? d_full : full_.data(), n_full, 16, q_last_curr_, t_last_curr_, chain ? 1 : 0));   // adjustDistortion, :958
     if (have_last_) {
       if (submapflag_ == 0) first_keyframe();                                                   // :963-972
@@ -180,11 +198,11 @@ private:
       rgc_default_fuse_in(&fin);
       std::memcpy(fin.q_lidar_xyzw, q_l, sizeof(q_l)); std::memcpy(fin.t_lidar, t_l, sizeof(t_l));
       fin.fitness = fitness;
-      const bool use_ground = opt_.use_ground && fo.ground_valid && have_ground_last_;
+      const bool use_ground = opt_.use_ground && ground_valid && have_ground_last_;
       fin.use_ground = use_ground ? 1 : 0;
       if (use_ground) {
         std::memcpy(fin.ground_last, ground_last_, sizeof(ground_last_));
-        std::memcpy(fin.ground_cur, fo.groundparam, sizeof(ground_last_));
+        std::memcpy(fin.ground_cur, groundparam, sizeof(ground_last_));
         double qdi[4] = {-q_w_delta_[0], -q_w_delta_[1], -q_w_delta_[2], q_w_delta_[3]};
         qmul(qdi, q_w_, fin.q_w_curr_f_xyzw);                                                  // :1086-1087
         qnormalize(fin.q_w_curr_f_xyzw);
@@ -209,7 +227,7 @@ private:
       n_last_ = n_full;
     }
     have_last_ = n_full > 0;
-    if (fo.ground_valid) { std::memcpy(ground_last_, fo.groundparam, sizeof(ground_last_)); have_ground_last_ = true; }
+    if (ground_valid) { std::memcpy(ground_last_, groundparam, sizeof(ground_last_)); have_ground_last_ = true; }
     frames_++;
     if (odom) {
       odom->stamp = stamp;
@@ -329,6 +347,116 @@ private:
   bool have_ground_last_ = false, have_kf_ = false;
   double kf_q_[4] = {0, 0, 0, 1}, kf_t_[3] = {0, 0, 0}, origin_[3] = {0, 0, 0};
   int submapflag_ = 0, frames_ = 0, kf_inserted_ = 0;
+};
+
+// Bag replay at full rate: the reference runs scanRegistration and the odometry as two ROS nodes, i.e. concurrently.  Here the
+// front-end of sweep k+1 (own context, own stream, own host thread) overlaps the frame body of sweep k; the sweep is handed over
+// on the device through two slots.  Poses are those of the unpipelined node (the stages see the same data in the same order).
+class ReplayPipeline {
+public:
+  explicit ReplayPipeline(OdometryNode::Options o) : body_((o.resident_map = true, o.device_chain = true, o)), opt_(o) {
+    int rc = rgc_create(o.hip_device, nullptr, &fe_ctx_);
+    if (rc != RGC_OK) throw std::runtime_error(std::string("rgc_create: ") + rgc_status_string(rc));
+    rgc_default_fe_params(&fe_);
+    fe_.n_scans = o.scan_line; fe_.min_range = o.minimum_range; fe_.max_range = o.maxmum_range;
+  }
+  ~ReplayPipeline() {
+    for (Slot& s : slot_) if (s.d) rgc_device_free(fe_ctx_, s.d);
+    if (d_raw_) rgc_device_free(fe_ctx_, d_raw_);
+    rgc_destroy(fe_ctx_);
+  }
+  ReplayPipeline(const ReplayPipeline&) = delete;
+  ReplayPipeline& operator=(const ReplayPipeline&) = delete;
+
+  // messages[k]: n_points[k] records of `layout`; stamps[k] their time stamps.  Fills one pose and one ground message per sweep.
+  // done_ms (nullable): wall time, from the call, at which each pose was ready.
+  void run(const std::vector<const void*>& messages, const std::vector<int>& n_points, const rgc_pc2_layout& layout, const std::vector<double>& stamps,
+           std::vector<OdometryMsg>* odom, std::vector<GroundMsg>* ground, std::vector<double>* done_ms = nullptr) {
+    const size_t N = messages.size();
+    const auto t_call = std::chrono::steady_clock::now();
+    if (done_ms) done_ms->assign(N, 0.0);
+    odom->assign(N, OdometryMsg());
+    ground->assign(N, GroundMsg());
+    std::exception_ptr front_error;
+    std::thread front([&]() {
+      try {
+        for (size_t k = 0; k < N; k++) {
+          Slot& s = slot_[k & 1];
+          { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return !s.full || stop_; }); if (stop_) return; }
+          front_stage(messages[k], n_points[k], layout, s);
+          { std::lock_guard<std::mutex> lk(m_); s.full = true; }
+          cv_.notify_all();
+        }
+      } catch (...) {
+        front_error = std::current_exception();
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+      }
+    });
+    try {
+      for (size_t k = 0; k < N; k++) {
+        Slot& s = slot_[k & 1];
+        { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return s.full || stop_; }); if (stop_ && !s.full) break; }
+        body_.handleFrontEndOutput(s.d, s.n, s.ground.param, s.ground.valid, stamps[k], &(*odom)[k]);
+        (*ground)[k] = s.ground;
+        if (done_ms) (*done_ms)[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        { std::lock_guard<std::mutex> lk(m_); s.full = false; }
+        cv_.notify_all();
+      }
+    } catch (...) {
+      { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+      cv_.notify_all();
+      front.join();
+      throw;
+    }
+    front.join();
+    if (front_error) std::rethrow_exception(front_error);
+  }
+  OdometryNode& node() { return body_; }
+
+private:
+  struct Slot { float* d = nullptr; size_t cap = 0; int n = 0; GroundMsg ground; bool full = false; };
+  void chk(int rc) { if (rc != RGC_OK) throw std::runtime_error(std::string(rgc_status_string(rc)) + ": " + rgc_last_error(fe_ctx_)); }
+  void grow(float*& p, size_t& cap, size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) chk(rgc_device_free(fe_ctx_, p));
+    p = nullptr; cap = 0;
+    void* np = nullptr;
+    chk(rgc_device_alloc(fe_ctx_, bytes + bytes / 4, &np));
+    p = (float*)np; cap = bytes + bytes / 4;
+  }
+  void front_stage(const void* data, int n, const rgc_pc2_layout& layout, Slot& s) {   // ScanRegistration::laserCloudHandler
+    grow(d_raw_, raw_cap_, (size_t)16 * (size_t)(n > 0 ? n : 1));
+    chk(rgc_pc2_unpack(fe_ctx_, data, n, &layout, d_raw_, nullptr, nullptr, 1));
+    const int fcap = fe_.n_scans * 6 * 41;
+    sharp_.resize((size_t)5 * fcap); flat_.resize((size_t)5 * fcap); inten_.resize((size_t)5 * fcap);
+    rgc_fe_out fo;
+    std::memset(&fo, 0, sizeof(fo));
+    fo.cloud = nullptr; fo.cloud_cap = n > 0 ? n : 1;
+    fo.sharp = sharp_.data(); fo.flat = flat_.data(); fo.inten = inten_.data(); fo.feat_cap = fcap;
+    chk(rgc_frontend_device(fe_ctx_, d_raw_, n, 16, &fe_, &fo));
+    float* d_full = nullptr; int nn = 0;
+    chk(rgc_frontend_cloud_device(fe_ctx_, &d_full, &nn));
+    s.n = fo.n_cloud;
+    if (s.n > 0) {
+      const double I[4] = {0, 0, 0, 1}, Z[3] = {0, 0, 0};
+      grow(s.d, s.cap, (size_t)16 * (size_t)s.n);
+      chk(rgc_transform_cloud(fe_ctx_, d_full, s.n, 16, I, Z, s.d, 1));   // identity = device-to-device copy into the hand-over slot
+    }
+    std::memcpy(s.ground.param, fo.groundparam, sizeof(s.ground.param));
+    s.ground.valid = fo.ground_valid != 0;
+  }
+
+  OdometryNode body_;
+  OdometryNode::Options opt_;
+  rgc_ctx* fe_ctx_ = nullptr;
+  rgc_fe_params fe_{};
+  float* d_raw_ = nullptr; size_t raw_cap_ = 0;
+  std::vector<float> sharp_, flat_, inten_;
+  Slot slot_[2];
+  std::mutex m_;
+  std::condition_variable cv_;
+  bool stop_ = false;
 };
 
 }  // namespace rgc

@@ -25,14 +25,15 @@ with open(path, "wb") as f:
         rec["x"], rec["y"], rec["z"], rec["intensity"] = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
         f.write(np.int32(len(r)).tobytes()); f.write(rec.tobytes())
 exe = os.path.join(tmp, "node")
-subprocess.check_call(["g++", "-std=c++14", "-O2", os.path.join(ROOT, "tests", "cpp", "test_odometry_node.cpp"), "-o", exe,
+subprocess.check_call(["g++", "-std=c++14", "-O2", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_odometry_node.cpp"), "-o", exe,
                        "-L", os.path.join(ROOT, "rgc-slam_amd"), "-lrgc_hip", "-Wl,-rpath," + os.path.join(ROOT, "rgc-slam_amd")])
 res = {"workload": "24 VLP-16 sweeps x 28.8 k points, PointCloud2 bytes in -> odometry pose out (front-end + frame body, 3-keyframe local map); first 4 frames untimed"}
 final = {}
-for name, resident, chain in (("cpp_reference_semantics", 0, 0), ("cpp_resident_map", 1, 0), ("cpp_resident_map_device_chain", 1, 1)):
+for name, resident, chain, pipe in (("cpp_reference_semantics", 0, 0, 0), ("cpp_resident_map", 1, 0, 0), ("cpp_resident_map_device_chain", 1, 1, 0),
+                                    ("cpp_replay_pipeline", 1, 1, 1)):
     best = None
     for rep in range(2):
-        out = subprocess.run([exe, path, str(resident), "1", "50", str(chain)], capture_output=True, text=True, timeout=600).stdout
+        out = subprocess.run([exe, path, str(resident), "1", "50", str(chain), str(pipe)], capture_output=True, text=True, timeout=600).stdout
         last = out.strip().splitlines()[-1].split()
         s = dict(zip(last[1::2], last[2::2]))
         best = float(s["ms_per_frame"]) if best is None else min(best, float(s["ms_per_frame"]))

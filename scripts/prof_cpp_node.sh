@@ -18,7 +18,7 @@ with open("/tmp/sweeps.bin", "wb") as f:
         rec["x"], rec["y"], rec["z"], rec["intensity"] = sc["xyz"][:, 0], sc["xyz"][:, 1], sc["xyz"][:, 2], sc["intensity"]
         f.write(np.int32(len(rec)).tobytes()); f.write(rec.tobytes())
 PY
-g++ -std=c++14 -O2 tests/cpp/test_odometry_node.cpp -o /tmp/node -L rgc-slam_amd -lrgc_hip -Wl,-rpath,$GRAFT_REPO_ROOT/rgc-slam_amd
+g++ -std=c++14 -O2 -pthread tests/cpp/test_odometry_node.cpp -o /tmp/node -L rgc-slam_amd -lrgc_hip -Wl,-rpath,$GRAFT_REPO_ROOT/rgc-slam_amd
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/tl_node -o runc --output-format csv -- /tmp/node /tmp/sweeps.bin 1 1 50 1 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT && python scripts/timeline_any.py gpurun_out/tl_node k_pc2_unpack
