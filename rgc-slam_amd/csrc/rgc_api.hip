@@ -91,7 +91,7 @@ struct rgc_ctx {
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos;  // B2/B3/B9 staging
-  DevBuf fe[32];              // front-end buffers
+  DevBuf fe[34];              // front-end buffers
   unsigned char* h_stage = nullptr;  // pinned staging of the front-end's small read-backs and feature clouds (a copy into pageable
   size_t h_stage_cap = 0;            // memory is staged by the runtime anyway, one blocking hop per call)
   int fe_n_cloud = 0;         // points of the last front-end's ring-major cloud (fe[5]), for rgc_frontend_cloud_device
@@ -1365,12 +1365,12 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   if (rc) return rc;
   const int nb = rgck::fe_blocks(n);
   enum { RING, RANK, HIST, META, ST, CL, INUM2, INUM, RANGE, ANGLE, CURV, CURV2, ICURV, DSRC, OSRC, PICK, IPICK, LAB, ILAB, GMARK, MULT, SCNT,
-         SPOS, PART, OUTD, SLOTS, FLAGS, SHARP, FLAT, INTEN, GLIST, BSUM };
+         SPOS, PART, OUTD, SLOTS, FLAGS, SHARP, FLAT, INTEN, GLIST, BSUM, SORTC, SORTI };
   const int nu = NS * 6, fcap = nu * 41;
-  const size_t sizes[32] = {4u * n, 4u * n, 4u * 64 * nb, 4u * 132, 4u * 8, 16u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n,
+  const size_t sizes[34] = {4u * n, 4u * n, 4u * 64 * nb, 4u * 132, 4u * 8, 16u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n,
                             4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 8u * 11 * nb, 8u * 16,
-                            4u * (size_t)nu * rgck::fe_slot_ints(), 4u * 8, 20u * fcap, 20u * fcap, 20u * fcap, 16u * 10 * (size_t)n, 4u * (n / 2048 + 4)};
-  for (int b = 0; b < 32; b++) if ((rc = ensure(c, c->fe[b], sizes[b] + 64))) return rc;
+                            4u * (size_t)nu * rgck::fe_slot_ints(), 4u * 8, 20u * fcap, 20u * fcap, 20u * fcap, 16u * 10 * (size_t)n, 4u * (n / 2048 + 4), 4u * n, 4u * n};
+  for (int b = 0; b < 34; b++) if ((rc = ensure(c, c->fe[b], sizes[b] + 64))) return rc;
 #define FE(i, T) ((T*)c->fe[i].p)
   int st_init[8] = {INT_MAX, -1, INT_MAX, 0, 0, 0, 0, 0};
   memcpy(c->h_small + 32, st_init, sizeof(st_init));
@@ -1446,7 +1446,7 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   }
   // A7 + A8
   rgck::fe_select(s, FE(CL, float4), NS, FE(META, int), FE(CURV, float), FE(CURV2, float), FE(ICURV, float), FE(INUM, int), FE(GMARK, int),
-                  FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), FE(FLAGS, int), max_ring);
+                  FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), FE(FLAGS, int), max_ring, FE(SORTC, int), FE(SORTI, int));
   rgck::fe_emit(s, FE(CL, float4), NS, FE(SLOTS, int), FE(DSRC, float), FE(OSRC, float), FE(SHARP, float), FE(FLAT, float), FE(INTEN, float), fcap,
                 FE(FLAGS, int) + 4);
   // flags and the three feature clouds (at their capacity: ~80 kB each for 16 rings) come down together into pinned memory, one

@@ -386,6 +386,28 @@ __device__ void bitonic_sort(Key* k, int n2) {  // ascending by (value, index); 
   __syncthreads();
 }
 
+// The two sorts of every (ring, sector) -- by curvature and by intensity curvature (:482-483) -- depend on nothing the greedy passes
+// change, so they do not belong on the 16 workgroups that must walk their ring's sectors in order: one workgroup per (ring, sector,
+// array), all at once, the sorted point indices left in memory for k_fe_select (the two sorts used to be half of that kernel's time).
+__global__ void __launch_bounds__(SEL_T)
+k_fe_sort(int NS, const int* __restrict__ meta, const float* __restrict__ curv, const float* __restrict__ icurv, int* __restrict__ sorted_curv,
+          int* __restrict__ sorted_icurv) {
+  __shared__ Key k[SEC_MAX];
+  const int ring = blockIdx.x / 6, j = blockIdx.x % 6;
+  const int S = meta[64 + ring] + 5, E = meta[64 + ring + 1] - 5;
+  if (E - S < 10) return;
+  const int sp = S + (E - S) * j / 6, ep = S + (E - S) * (j + 1) / 6 - 1;
+  const int cnt = ep - sp + 1;
+  if (cnt > SEC_MAX || cnt <= 0) return;  // k_fe_select reports the oversize sector
+  const float* __restrict__ key = blockIdx.y ? icurv : curv;
+  int* __restrict__ out = blockIdx.y ? sorted_icurv : sorted_curv;
+  int n2 = 1;
+  while (n2 < cnt) n2 <<= 1;
+  for (int t = threadIdx.x; t < n2; t += SEL_T) k[t] = t < cnt ? Key{key[sp + t], sp + t} : Key{INFINITY, INT_MAX};
+  bitonic_sort(k, n2);
+  for (int t = threadIdx.x; t < cnt; t += SEL_T) out[sp + t] = k[t].i;
+}
+
 // slots: per (ring, sector): sharp 20, flat 40, inten 20 indices + 3 counts (83 ints)
 constexpr int SLOT = 83;
 constexpr int SEL_MARGIN = 5;  // a pick touches ind +- 5 (and compares ind + l with ind + l -+ 1, both inside +- 5)
@@ -399,14 +421,13 @@ constexpr int SEL_MARGIN = 5;  // a pick touches ind +- 5 (and compares ind + l 
 __global__ void __launch_bounds__(SEL_T)
 k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, const float* __restrict__ curv, const float* __restrict__ curv2,
             const float* __restrict__ icurv, const int* __restrict__ inum, const int* __restrict__ gmark, int* __restrict__ picked,
-            int* __restrict__ ipicked, int* __restrict__ label, int* __restrict__ ilabel, int* __restrict__ slots, int* flags, int sec_cap) {
+            int* __restrict__ ipicked, int* __restrict__ label, int* __restrict__ ilabel, int* __restrict__ slots, int* flags, int sec_cap,
+            const int* __restrict__ sorted_curv, const int* __restrict__ sorted_icurv) {
   extern __shared__ __align__(16) unsigned char sel_lds[];
-  int n2cap = 1;
-  while (n2cap < sec_cap) n2cap <<= 1;
   const int wcap = sec_cap + 2 * SEL_MARGIN;
-  Key* ks = reinterpret_cast<Key*>(sel_lds);
-  Key* ki = ks + n2cap;
-  float* wx = reinterpret_cast<float*>(ki + n2cap);
+  int* ks = reinterpret_cast<int*>(sel_lds);   // point indices of the sector in ascending curvature (k_fe_sort)
+  int* ki = ks + sec_cap;                      // ... in ascending intensity curvature
+  float* wx = reinterpret_cast<float*>(ki + sec_cap);
   float* wy = wx + wcap;
   float* wz = wy + wcap;
   float* wc = wz + wcap;    // curvature
@@ -429,8 +450,6 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
     const int sp = S + (E - S) * j / 6, ep = S + (E - S) * (j + 1) / 6 - 1;  // :478-480
     const int cnt = ep - sp + 1;
     if (cnt > sec_cap || cnt > SEC_MAX) { if (threadIdx.x == 0) atomicOr(flags, 2); return; }
-    int n2 = 1;
-    while (n2 < cnt) n2 <<= 1;
     const int w0 = sp - SEL_MARGIN, wn = cnt + 2 * SEL_MARGIN;  // window [w0, w0 + wn): inside this ring (S = start + 5)
     __syncthreads();
     for (int t = threadIdx.x; t < wn; t += SEL_T) {
@@ -443,12 +462,8 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
       wgm[t] = (signed char)(gmark[g] == 1);
       wlab[t] = (signed char)label[g]; wilab[t] = (signed char)ilabel[g];
     }
-    for (int t = threadIdx.x; t < n2; t += SEL_T) {
-      if (t < cnt) { ks[t] = Key{curv[sp + t], sp + t}; ki[t] = Key{icurv[sp + t], sp + t}; }
-      else { ks[t] = Key{INFINITY, INT_MAX}; ki[t] = Key{INFINITY, INT_MAX}; }
-    }
-    bitonic_sort(ks, n2);
-    bitonic_sort(ki, n2);
+    for (int t = threadIdx.x; t < cnt; t += SEL_T) { ks[t] = sorted_curv[sp + t]; ki[t] = sorted_icurv[sp + t]; }
+    __syncthreads();
     if (threadIdx.x < WAVE) {
       // The three greedy passes of :487-641 by ONE WAVE.  A pass walks the sorted candidates in order and a pick suppresses
       // up to ten neighbours, so picks are sequential -- but only picks: 64 candidates at a time, every lane tests the
@@ -466,14 +481,14 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
         __builtin_amdgcn_wave_barrier();
       };
       // near(a, b): the suppression keeps spreading from a to its neighbour b (:517-533 and twins).  Returns the picks made.
-      auto greedy = [&](const Key* keys, bool descending, signed char* flag, int limit, auto&& static_ok, auto&& on_pick, auto&& near) {
+      auto greedy = [&](const int* keys, bool descending, signed char* flag, int limit, auto&& static_ok, auto&& on_pick, auto&& near) {
         int count = 0;
         bool stop = false;
         for (int base = 0; base < cnt && !stop; base += WAVE) {
           const int kk = base + lane;
           const bool valid = kk < cnt;
           const int k = valid ? (descending ? cnt - 1 - kk : kk) : 0;
-          const int ind = keys[k].i, w = ind - w0;
+          const int ind = keys[k], w = ind - w0;
           bool ok = valid && static_ok(w);
           for (;;) {
             const unsigned long long mask = __ballot(ok && flag[w] == 0);
@@ -528,34 +543,35 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
 
 // A8: emit the feature clouds in the reference's order (ring, sector, pick order): x,y,z,intensity,normal_x weight.
 // counts: [0] sharp (own), [1] flat, [2] inten
-__global__ void __launch_bounds__(512) k_fe_emit(const float4* __restrict__ C, int NS, const int* __restrict__ slots, const float* __restrict__ dsrc,
+__global__ void __launch_bounds__(128) k_fe_emit(const float4* __restrict__ C, int NS, const int* __restrict__ slots, const float* __restrict__ dsrc,
                                                  const float* __restrict__ osrc, float* __restrict__ sharp, float* __restrict__ flat,
                                                  float* __restrict__ inten, int cap, int* __restrict__ counts) {
-  __shared__ int off[3][385], cnt_s[3][385];
-  const int nu = NS * 6, u = threadIdx.x;
-  // exclusive prefix of the per-(ring, sector) counts: every thread loads its unit's three counts (one round trip instead of
-  // 3 * nu dependent loads by one lane), then each thread sums the units before it out of LDS
-  if (u < nu) { cnt_s[0][u] = slots[(size_t)u * SLOT + 80]; cnt_s[1][u] = slots[(size_t)u * SLOT + 81]; cnt_s[2][u] = slots[(size_t)u * SLOT + 82]; }
+  // one workgroup per (ring, sector) unit, one lane per pick (20 sharp + 40 flat + 20 intensity slots); the unit's output offsets =
+  // the picks of the units before it, summed by the workgroup itself (<= 383 units x 3 counts, strided loads + one reduction)
+  __shared__ int red[3][128 / WAVE];
+  __shared__ int off[3];
+  const int nu = NS * 6, u = blockIdx.x, t = threadIdx.x;
+  int a = 0, b = 0, c = 0;
+  for (int v = t; v < u; v += 128) { a += slots[(size_t)v * SLOT + 80]; b += slots[(size_t)v * SLOT + 81]; c += slots[(size_t)v * SLOT + 82]; }
+  for (int o = WAVE / 2; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); }
+  if ((t & (WAVE - 1)) == 0) { red[0][t / WAVE] = a; red[1][t / WAVE] = b; red[2][t / WAVE] = c; }
   __syncthreads();
-  if (u <= nu) {  // thread nu computes the totals
-    int a = 0, b = 0, c = 0;
-    for (int t = 0; t < u; t++) { a += cnt_s[0][t]; b += cnt_s[1][t]; c += cnt_s[2][t]; }
-    if (u < nu) { off[0][u] = a; off[1][u] = b; off[2][u] = c; }
-    else { counts[0] = a; counts[1] = b; counts[2] = c; }
-  }
-  if (u >= nu) return;
+  if (t < 3) { int v = 0; for (int w = 0; w < 128 / WAVE; w++) v += red[t][w]; off[t] = v; }
+  __syncthreads();
   const int* sl = slots + (size_t)u * SLOT;
-  for (int k = 0; k < sl[80]; k++) {
-    const int ind = sl[k], d = off[0][u] + k;
-    if (d < cap) { const float4 p = C[ind]; float* f = sharp + (size_t)d * 5; f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w; f[4] = dsrc[ind] + 1; }  // :501
-  }
-  for (int k = 0; k < sl[81]; k++) {
-    const int ind = sl[20 + k], d = off[1][u] + k;
-    if (d < cap) { const float4 p = C[ind]; float* f = flat + (size_t)d * 5; f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w; f[4] = dsrc[ind]; }       // :554
-  }
-  for (int k = 0; k < sl[82]; k++) {
-    const int ind = sl[60 + k], d = off[2][u] + k;
-    if (d < cap) { const float4 p = C[ind]; float* f = inten + (size_t)d * 5; f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w; f[4] = osrc[ind]; }      // :609
+  const int ns = sl[80], nf = sl[81], ni = sl[82];
+  if (u == nu - 1 && t == 0) { counts[0] = off[0] + ns; counts[1] = off[1] + nf; counts[2] = off[2] + ni; }
+  if (t < 20) {
+    if (t < ns) { const int ind = sl[t], d = off[0] + t;
+      if (d < cap) { const float4 p = C[ind]; float* f = sharp + (size_t)d * 5; f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w; f[4] = dsrc[ind] + 1; } }  // :501
+  } else if (t < 60) {
+    const int k = t - 20;
+    if (k < nf) { const int ind = sl[20 + k], d = off[1] + k;
+      if (d < cap) { const float4 p = C[ind]; float* f = flat + (size_t)d * 5; f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w; f[4] = dsrc[ind]; } }     // :554
+  } else if (t < 80) {
+    const int k = t - 60;
+    if (k < ni) { const int ind = sl[60 + k], d = off[2] + k;
+      if (d < cap) { const float4 p = C[ind]; float* f = inten + (size_t)d * 5; f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w; f[4] = osrc[ind]; } }    // :609
   }
 }
 
@@ -609,24 +625,24 @@ void fe_ground_list(hipStream_t s, const float4* C, int cs, int NS, const float*
   hipLaunchKernelGGL(k_fe_ground_list, dim3(nblk(cs, FE_T)), dim3(FE_T), 0, s, C, cs, NS, range_vec, meta, seedcnt, seedpos, out, cap);
 }
 void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const float* curv, const float* curv2, const float* icurv, const int* inum,
-               const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags, int max_ring) {
-  // LDS sized from the largest ring: two key arrays (power of two) + the per-sector window arrays
+               const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags, int max_ring, int* sorted_curv,
+               int* sorted_icurv) {
+  hipLaunchKernelGGL(k_fe_sort, dim3(NS * 6, 2), dim3(SEL_T), 0, s, NS, meta, curv, icurv, sorted_curv, sorted_icurv);
+  // LDS sized from the largest ring: the two sorted index lists of a sector + the per-sector window arrays
   int sec_cap = max_ring / 6 + 2;
   if (sec_cap > SEC_MAX) sec_cap = SEC_MAX;
-  int n2 = 1;
-  while (n2 < sec_cap) n2 <<= 1;
-  const size_t lds = sizeof(Key) * 2 * (size_t)n2 + (size_t)(sec_cap + 2 * SEL_MARGIN) * (7 * 4 + 5) + 64;
+  const size_t lds = sizeof(int) * 2 * (size_t)sec_cap + (size_t)(sec_cap + 2 * SEL_MARGIN) * (7 * 4 + 5) + 64;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k_fe_select, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_done = true;
   }
   hipLaunchKernelGGL(k_fe_select, dim3(NS), dim3(SEL_T), lds, s, C, NS, meta, curv, curv2, icurv, inum, gmark, picked, ipicked, label, ilabel, slots, flags,
-                     sec_cap);
+                     sec_cap, sorted_curv, sorted_icurv);
 }
 void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const float* dsrc, const float* osrc, float* sharp, float* flat, float* inten,
              int cap, int* counts) {
-  hipLaunchKernelGGL(k_fe_emit, dim3(1), dim3(512), 0, s, C, NS, slots, dsrc, osrc, sharp, flat, inten, cap, counts);
+  hipLaunchKernelGGL(k_fe_emit, dim3(NS * 6), dim3(128), 0, s, C, NS, slots, dsrc, osrc, sharp, flat, inten, cap, counts);
 }
 
 }  // namespace rgck

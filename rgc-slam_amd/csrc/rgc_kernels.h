@@ -138,7 +138,8 @@ void fe_ground_dist(hipStream_t s, const float4* C, int cs, const int* mult, con
 void fe_ground_list(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, const int* seedcnt,
                     const int* seedpos, float4* out, int cap);
 void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const float* curv, const float* curv2, const float* icurv, const int* inum,
-               const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags, int max_ring /* points in the largest ring: sizes the LDS window */);
+               const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags, int max_ring /* points in the largest ring: sizes the LDS window */,
+               int* sorted_curv, int* sorted_icurv /* cs ints each: per-sector sorted point indices (scratch) */);
 void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const float* dsrc, const float* osrc, float* sharp, float* flat, float* inten,
              int cap, int* counts);
 
