@@ -439,6 +439,8 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
   signed char* wgm = wipick + wcap;
   signed char* wlab = wgm + wcap;
   signed char* wilab = wlab + wcap;
+  signed char* wrun = wilab + wcap;   // how far a pick at this point suppresses: points to the right | points to the left << 4 (:517-533)
+  signed char* wirun = wrun + wcap;   // the same for the intensity pass (:625-639)
   const int ring = blockIdx.x;
   const int S = meta[64 + ring] + 5, E = meta[64 + ring + 1] - 5;  // scanStartInd / scanEndInd, :223,229
   for (int j = 0; j < 6; j++) {
@@ -464,6 +466,24 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
     }
     for (int t = threadIdx.x; t < cnt; t += SEL_T) { ks[t] = sorted_curv[sp + t]; ki[t] = sorted_icurv[sp + t]; }
     __syncthreads();
+    // The reach of a pick's suppression is a property of the points alone (consecutive gaps <= 0.05 m^2, resp. intensity steps <= 35,
+    // up to five on each side): computed here for every point of the sector by the whole workgroup, so that the serial pick loop
+    // below reads one byte instead of testing ten gaps per pick.
+    for (int t = SEL_MARGIN + threadIdx.x; t < SEL_MARGIN + cnt; t += SEL_T) {
+      auto far_p = [&](int a, int b) {
+        const float dx = wx[a] - wx[b], dy = wy[a] - wy[b], dz = wz[a] - wz[b];
+        return dx * dx + dy * dy + dz * dz > 0.05;
+      };
+      auto far_i = [&](int a, int b) { return fabsf((float)(wnum[a] - wnum[b])) > 35; };
+      int rp = 0, rm = 0, ip = 0, im = 0;
+      while (rp < 5 && !far_p(t + rp + 1, t + rp)) rp++;
+      while (rm < 5 && !far_p(t - rm - 1, t - rm)) rm++;
+      while (ip < 5 && !far_i(t + ip + 1, t + ip)) ip++;
+      while (im < 5 && !far_i(t - im - 1, t - im)) im++;
+      wrun[t] = (signed char)(rp | (rm << 4));
+      wirun[t] = (signed char)(ip | (im << 4));
+    }
+    __syncthreads();
     if (threadIdx.x < WAVE) {
       // The three greedy passes of :487-641 by ONE WAVE.  A pass walks the sorted candidates in order and a pick suppresses
       // up to ten neighbours, so picks are sequential -- but only picks: 64 candidates at a time, every lane tests the
@@ -472,16 +492,12 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
       // (<= 21 / 40 / 21 per sector), not candidates (hundreds).
       const int lane = threadIdx.x;
       int* sl = slots + ((size_t)ring * 6 + j) * SLOT;
-      auto gap2 = [&](int a, int b) {  // squared distance between window points a and b
-        const float dx = wx[a] - wx[b], dy = wy[a] - wy[b], dz = wz[a] - wz[b];
-        return dx * dx + dy * dy + dz * dz;
-      };
       auto wave_fence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       };
-      // near(a, b): the suppression keeps spreading from a to its neighbour b (:517-533 and twins).  Returns the picks made.
-      auto greedy = [&](const int* keys, bool descending, signed char* flag, int limit, auto&& static_ok, auto&& on_pick, auto&& near) {
+      // run: the precomputed reach of a pick's suppression at every window point (:517-533 and twins).  Returns the picks made.
+      auto greedy = [&](const int* keys, bool descending, signed char* flag, int limit, auto&& static_ok, auto&& on_pick, const signed char* run) {
         int count = 0;
         bool stop = false;
         for (int base = 0; base < cnt && !stop; base += WAVE) {
@@ -490,46 +506,43 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
           const int k = valid ? (descending ? cnt - 1 - kk : kk) : 0;
           const int ind = keys[k], w = ind - w0;
           bool ok = valid && static_ok(w);
+          const int reach = run[w];
           for (;;) {
             const unsigned long long mask = __ballot(ok && flag[w] == 0);
             if (!mask) break;
             count++;
             if (count > limit) { stop = true; break; }  // the reference's `else break`: not even marked
-            const int b = __ffsll((long long)mask) - 1;
-            const int wb = __shfl(w, b);
+            const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);  // wave-uniform: v_readlane, not an LDS permute
+            const int wb = __builtin_amdgcn_readlane(w, b);
             if (lane == b) {
               on_pick(count, ind, w);
               flag[w] = 1;
               ok = false;
             }
-            // the ten neighbours side by side: lanes 0..4 test wb+1..wb+5 against their predecessor, lanes 5..9 test
-            // wb-1..wb-5; the suppression runs up to the first failing gap on each side
+            // the ten neighbours side by side: lanes 0..4 mark wb+1..wb+5, lanes 5..9 wb-1..wb-5, as far as the pick reaches
+            const int rb = __builtin_amdgcn_readlane(reach, b);
+            const int np = rb & 15, nm = rb >> 4;
             const int l = lane < 5 ? lane + 1 : -(lane - 4);
-            const bool cont = lane < 10 && near(wb + l, wb + l - (l > 0 ? 1 : -1));
-            const unsigned long long m = __ballot(cont);
-            const int np = __builtin_ctzll(~(m & 31ull)), nm = __builtin_ctzll(~((m >> 5) & 31ull));
             if (lane < 5 ? lane < np : (lane < 10 && lane - 5 < nm)) flag[wb + l] = 1;
             wave_fence();
           }
         }
         return count > limit ? limit : count;
       };
-      auto near_pts = [&](int a, int b2) { return !(gap2(a, b2) > 0.05); };
-      auto near_int = [&](int a, int b2) { return !(fabsf((float)(wnum[a] - wnum[b2])) > 35); };
       // sharp: largest curvature first (:487-536); the 21st pick is labelled "less sharp" and gets no slot
       const int nsh_picks = greedy(ks, true, wpick, 21, [&](int w) { return wgm[w] == 0 && wc[w] > 0.1 && wc2[w] > 0.3; },
                                    [&](int count, int ind, int w) { if (count <= 20) { wlab[w] = 2; sl[count - 1] = ind; } else { wlab[w] = 1; } },
-                                   near_pts);
+                                   wrun);
       const int nsh = nsh_picks > 20 ? 20 : nsh_picks;
       wave_fence();
       // flat: smallest curvature first (:540-583)
       const int nfl = greedy(ks, false, wpick, 40, [&](int w) { return wc[w] < 0.3 && wc2[w] < 0.4; },
-                             [&](int count, int ind, int w) { wlab[w] = -1; sl[20 + count - 1] = ind; }, near_pts);
+                             [&](int count, int ind, int w) { wlab[w] = -1; sl[20 + count - 1] = ind; }, wrun);
       wave_fence();
       // intensity: largest intensity curvature first, not on points already labelled sharp (:594-641)
       const int nin_picks = greedy(ki, true, wipick, 21, [&](int w) { return wgm[w] == 0 && wic[w] > 65 && wlab[w] != 2 && wlab[w] != 1; },
                                    [&](int count, int ind, int w) { if (count <= 20) { wilab[w] = 2; sl[60 + count - 1] = ind; } else { wilab[w] = 1; } },
-                                   near_int);
+                                   wirun);
       if (lane == 0) { sl[80] = nsh; sl[81] = nfl; sl[82] = nin_picks > 20 ? 20 : nin_picks; }
     }
     __syncthreads();
@@ -631,7 +644,7 @@ void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const fl
   // LDS sized from the largest ring: the two sorted index lists of a sector + the per-sector window arrays
   int sec_cap = max_ring / 6 + 2;
   if (sec_cap > SEC_MAX) sec_cap = SEC_MAX;
-  const size_t lds = sizeof(int) * 2 * (size_t)sec_cap + (size_t)(sec_cap + 2 * SEL_MARGIN) * (7 * 4 + 5) + 64;
+  const size_t lds = sizeof(int) * 2 * (size_t)sec_cap + (size_t)(sec_cap + 2 * SEL_MARGIN) * (7 * 4 + 7) + 64;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k_fe_select, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
