@@ -1368,7 +1368,7 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
          SPOS, PART, OUTD, SLOTS, FLAGS, SHARP, FLAT, INTEN, GLIST, BSUM, SORTC, SORTI };
   const int nu = NS * 6, fcap = nu * 41;
   const size_t sizes[34] = {4u * n, 4u * n, 4u * 64 * nb, 4u * 132, 4u * 8, 16u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n,
-                            4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 8u * 11 * nb, 8u * 16,
+                            4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 8u * 11 * nb, 8u * 48,
                             4u * (size_t)nu * rgck::fe_slot_ints(), 4u * 8, 20u * fcap, 20u * fcap, 20u * fcap, 16u * 10 * (size_t)n, 4u * (n / 2048 + 4), 4u * n, 4u * n};
   for (int b = 0; b < 34; b++) if ((rc = ensure(c, c->fe[b], sizes[b] + 64))) return rc;
 #define FE(i, T) ((T*)c->fe[i].p)
@@ -1389,9 +1389,7 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
     c->h_stage_cap = stage_need;
   }
   int* meta = (int*)c->h_stage;                       // 129 ints
-  double* g11 = (double*)(c->h_stage + 640);          // 11 doubles
-  double* d2 = (double*)(c->h_stage + 768);           // 2 doubles
-  int* fl = (int*)(c->h_stage + 832);                 // 8 ints
+  int* fl = (int*)(c->h_stage + 832);                 // 8 ints ([528, 800): the ground sums, fit and distance sums)
   unsigned char* h_feat = c->h_stage + 1024;
   HIPCHK(c, hipMemcpyAsync(meta, FE(META, int), sizeof(int) * 129, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
@@ -1407,43 +1405,12 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
                     FE(ICURV, float), FE(DSRC, float), FE(OSRC, float), FE(PICK, int));
   // A5: ground set (with multiplicities) -> weighted centroid / covariance -> plane (scanRegistration.cpp:308-431)
   rgck::fe_ground(s, FE(CL, float4), cs, NS, FE(RANGE, float), FE(META, int), FE(GMARK, int), FE(MULT, int), FE(SCNT, int), FE(PART, double), FE(OUTD, double));
-  HIPCHK(c, hipMemcpyAsync(g11, FE(OUTD, double), sizeof(double) * 11, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  const long long gsize = (long long)(g11[10] + 0.5);
-  if (gsize > 0) {
-    const double W = g11[0];
-    const double ctr[3] = {g11[1] / W, g11[2] / W, g11[3] / W};
-    const double S6[6] = {g11[4] / W - ctr[0] * ctr[0], g11[5] / W - ctr[0] * ctr[1], g11[6] / W - ctr[0] * ctr[2],
-                          g11[7] / W - ctr[1] * ctr[1], g11[8] / W - ctr[1] * ctr[2], g11[9] / W - ctr[2] * ctr[2]};
-    double ev[3], V[9];
-    host_eig3_sym(S6, ev, V);  // ascending like Eigen::SelfAdjointEigenSolver (:371)
-    double nrm[3] = {V[0], V[3], V[6]};
-    const double nl = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-    for (int a = 0; a < 3; a++) nrm[a] /= nl;
-    if (ctr[0] * nrm[0] + ctr[1] * nrm[1] + ctr[2] * nrm[2] < 0) for (int a = 0; a < 3; a++) nrm[a] = -nrm[a];  // :374-377
-    rgck::fe_ground_dist(s, FE(CL, float4), cs, FE(MULT, int), ctr, nrm, FE(PART, double), FE(OUTD, double));
-    HIPCHK(c, hipMemcpyAsync(d2, FE(OUTD, double), sizeof(double) * 2, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    const double laderH = 0.56;  // :39
-    double distance = d2[1] / d2[0], src1 = d2[0] / (double)gsize;  // :403-404
-    if ((distance / laderH) > 1.1 || (distance / laderH) < 0.9) distance = laderH;  // :405-409
-    if (src1 < 0.9) distance = 0.9 * laderH + 0.1 * distance;                       // :410-413
-    double* g = out->groundparam;  // groundparam.msg order, :420-430
-    g[0] = nrm[0]; g[1] = nrm[1]; g[2] = nrm[2];
-    g[3] = V[1]; g[4] = V[4]; g[5] = V[7];
-    g[6] = V[2]; g[7] = V[5]; g[8] = V[8];
-    g[9] = distance; g[10] = 1 - src1;
-    out->ground_valid = 1;
-    // /laser_cloud_ground: pushes in reference order (with duplicates)
-    rgck::exclusive_scan(s, FE(SCNT, int), FE(SPOS, int), cs, FE(BSUM, int));
-    const int gcap_dev = 10 * n;
-    rgck::fe_ground_list(s, FE(CL, float4), cs, NS, FE(RANGE, float), FE(META, int), FE(SCNT, int), FE(SPOS, int), FE(GLIST, float4), gcap_dev);
-    out->n_ground = (int)gsize;
-    if (out->ground_pts && out->ground_cap > 0) {
-      const long long m = gsize < out->ground_cap ? gsize : out->ground_cap;
-      HIPCHK(c, hipMemcpyAsync(out->ground_pts, FE(GLIST, float4), sizeof(float) * 4 * (size_t)m, hipMemcpyDeviceToHost, s));
-    }
-  }
+  // OUTD: [0..10] the ground sums, [16..31] the plane fit, [32..33] the distance sums -- fitted on the device, read back with the features
+  rgck::fe_ground_fit_dist(s, FE(CL, float4), cs, FE(MULT, int), FE(OUTD, double), FE(OUTD, double) + 16, FE(PART, double), FE(OUTD, double) + 32);
+  // /laser_cloud_ground: pushes in reference order (with duplicates); empty when no ground seed was found
+  rgck::exclusive_scan(s, FE(SCNT, int), FE(SPOS, int), cs, FE(BSUM, int));
+  const int gcap_dev = 10 * n;
+  rgck::fe_ground_list(s, FE(CL, float4), cs, NS, FE(RANGE, float), FE(META, int), FE(SCNT, int), FE(SPOS, int), FE(GLIST, float4), gcap_dev);
   // A7 + A8
   rgck::fe_select(s, FE(CL, float4), NS, FE(META, int), FE(CURV, float), FE(CURV2, float), FE(ICURV, float), FE(INUM, int), FE(GMARK, int),
                   FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), FE(FLAGS, int), max_ring, FE(SORTC, int), FE(SORTI, int));
@@ -1451,6 +1418,8 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
                 FE(FLAGS, int) + 4);
   // flags and the three feature clouds (at their capacity: ~80 kB each for 16 rings) come down together into pinned memory, one
   // synchronisation; the counts decide how much of each is handed to the caller
+  double* gd = (double*)(c->h_stage + 528);            // 34 doubles behind the 129 meta ints
+  HIPCHK(c, hipMemcpyAsync(gd, FE(OUTD, double), sizeof(double) * 34, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(fl, FE(FLAGS, int), sizeof(int) * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(h_feat, FE(SHARP, float), 20u * (size_t)fcap, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(h_feat + 20u * (size_t)fcap, FE(FLAT, float), 20u * (size_t)fcap, hipMemcpyDeviceToHost, s));
@@ -1458,6 +1427,29 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   if (out->cloud) HIPCHK(c, hipMemcpyAsync(out->cloud, FE(CL, float4), sizeof(float) * 4 * (size_t)cs, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (fl[0] & 2) return fail(c, RGC_ERR_INVALID, "a ring sector holds more than 2048 points");
+  {  // ground message (:403-430) from the sums, the fit and the distance sums that just came down
+    const long long gsize = (long long)(gd[10] + 0.5);
+    if (gsize > 0) {
+      const double* nrm = gd + 19;
+      const double* V = gd + 22;
+      const double* d2 = gd + 32;
+      const double laderH = 0.56;  // :39
+      double distance = d2[1] / d2[0], src1 = d2[0] / (double)gsize;  // :403-404
+      if ((distance / laderH) > 1.1 || (distance / laderH) < 0.9) distance = laderH;  // :405-409
+      if (src1 < 0.9) distance = 0.9 * laderH + 0.1 * distance;                       // :410-413
+      double* g = out->groundparam;  // groundparam.msg order, :420-430
+      g[0] = nrm[0]; g[1] = nrm[1]; g[2] = nrm[2];
+      g[3] = V[1]; g[4] = V[4]; g[5] = V[7];
+      g[6] = V[2]; g[7] = V[5]; g[8] = V[8];
+      g[9] = distance; g[10] = 1 - src1;
+      out->ground_valid = 1;
+      out->n_ground = (int)gsize;
+      if (out->ground_pts && out->ground_cap > 0) {
+        const long long m = gsize < out->ground_cap ? gsize : out->ground_cap;
+        HIPCHK(c, hipMemcpyAsync(out->ground_pts, FE(GLIST, float4), sizeof(float) * 4 * (size_t)m, hipMemcpyDeviceToHost, s));
+      }
+    }
+  }
   const int ns = fl[4], nf = fl[5], ni = fl[6];
   out->n_sharp_own = ns; out->n_flat = nf; out->n_inten = ni;
   const bool add_inten = prm->use_intensity && ((double)ns / (double)nf < 0.3);  // :645-656

@@ -313,11 +313,12 @@ k_fe_ground(const float4* __restrict__ C, int cs, int NS, const float* __restric
 
 // distance pass (:386-402): sums {sum dw, sum dw * n.p} with multiplicity
 __global__ void __launch_bounds__(FE_T)
-k_fe_ground_dist(const float4* __restrict__ C, int cs, const int* __restrict__ mult, double cx, double cy, double cz, double nx, double ny,
-                 double nz, double* __restrict__ partials) {
+k_fe_ground_dist(const float4* __restrict__ C, int cs, const int* __restrict__ mult, const double* __restrict__ fit, double* __restrict__ partials) {
+  // fit: centre (3), normal (3), eigenvectors (9), ground present (1) -- written by k_fe_ground_fit, never seen by the host in between
   const int j = blockIdx.x * FE_T + threadIdx.x;
   double a0 = 0, a1 = 0;
-  if (j < cs && mult[j] > 0) {
+  if (fit[15] != 0.0 && j < cs && mult[j] > 0) {
+    const double cx = fit[0], cy = fit[1], cz = fit[2], nx = fit[3], ny = fit[4], nz = fit[5];
     const float4 p = C[j];
     const double d[3] = {(double)p.x - cx, (double)p.y - cy, (double)p.z - cz};
     const double dl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -336,6 +337,54 @@ k_fe_ground_dist(const float4* __restrict__ C, int cs, const int* __restrict__ m
     for (int t = 0; t < FE_T / WAVE; t++) s += red[t][threadIdx.x];
     partials[(size_t)blockIdx.x * 2 + threadIdx.x] = s;
   }
+}
+
+// Plane through the weighted ground set (:358-377) on the device, so that the host does not have to see the sums before the distance
+// pass can start: weighted centroid, covariance, symmetric eigen-decomposition (cyclic Jacobi, eigenvalues ascending like
+// Eigen::SelfAdjointEigenSolver), normal = the smallest eigenvector oriented towards the centroid.  One lane; ~2 us.
+// g11: {W, Wx, Wy, Wz, Wxx, Wxy, Wxz, Wyy, Wyz, Wzz, count};  fit: centre (3), normal (3), V row-major (9), present (1)
+__global__ void k_fe_ground_fit(const double* __restrict__ g11, double* __restrict__ fit) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long gsize = (long long)(g11[10] + 0.5);
+  fit[15] = gsize > 0 ? 1.0 : 0.0;
+  if (gsize <= 0) return;
+  const double W = g11[0];
+  const double ctr[3] = {g11[1] / W, g11[2] / W, g11[3] / W};
+  double A[3][3], U[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  A[0][0] = g11[4] / W - ctr[0] * ctr[0]; A[0][1] = A[1][0] = g11[5] / W - ctr[0] * ctr[1]; A[0][2] = A[2][0] = g11[6] / W - ctr[0] * ctr[2];
+  A[1][1] = g11[7] / W - ctr[1] * ctr[1]; A[1][2] = A[2][1] = g11[8] / W - ctr[1] * ctr[2]; A[2][2] = g11[9] / W - ctr[2] * ctr[2];
+  for (int sweep = 0; sweep < 60; sweep++) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-40 * dg || off == 0.0) break;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int q = p + 1; q < 3; q++) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cc = 1.0 / sqrt(t * t + 1.0), ss = t * cc;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double a = A[k][p], b = A[k][q]; A[k][p] = cc * a - ss * b; A[k][q] = ss * a + cc * b; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double a = A[p][k], b = A[q][k]; A[p][k] = cc * a - ss * b; A[q][k] = ss * a + cc * b; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double a = U[k][p], b = U[k][q]; U[k][p] = cc * a - ss * b; U[k][q] = ss * a + cc * b; }
+      }
+  }
+  // columns in ascending eigenvalue order (a three-element sorting network on the column indices, static indexing only)
+  double e0 = A[0][0], e1 = A[1][1], e2 = A[2][2];
+  double c0[3] = {U[0][0], U[1][0], U[2][0]}, c1[3] = {U[0][1], U[1][1], U[2][1]}, c2[3] = {U[0][2], U[1][2], U[2][2]};
+  auto cswap = [](double& ea, double& eb, double (&ca)[3], double (&cb)[3]) {
+    if (eb < ea) { double t = ea; ea = eb; eb = t; for (int k = 0; k < 3; k++) { t = ca[k]; ca[k] = cb[k]; cb[k] = t; } }
+  };
+  cswap(e0, e1, c0, c1); cswap(e0, e2, c0, c2); cswap(e1, e2, c1, c2);
+  double nrm[3] = {c0[0], c0[1], c0[2]};
+  const double nl = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+  for (int a = 0; a < 3; a++) nrm[a] /= nl;
+  if (ctr[0] * nrm[0] + ctr[1] * nrm[1] + ctr[2] * nrm[2] < 0) for (int a = 0; a < 3; a++) nrm[a] = -nrm[a];  // :374-377
+  for (int a = 0; a < 3; a++) { fit[a] = ctr[a]; fit[3 + a] = nrm[a]; fit[6 + a * 3] = c0[a]; fit[6 + a * 3 + 1] = c1[a]; fit[6 + a * 3 + 2] = c2[a]; }
 }
 
 // fixed-order fold of per-block rows (deterministic)
@@ -628,9 +677,10 @@ void fe_ground(hipStream_t s, const float4* C, int cs, int NS, const float* rang
   hipLaunchKernelGGL(k_fe_ground, dim3(nb), dim3(FE_T), 0, s, C, cs, NS, range_vec, meta, gmark, mult, seedcnt, partials);
   hipLaunchKernelGGL(k_fe_fold, dim3(11), dim3(WAVE), 0, s, partials, nb, 11, out11);
 }
-void fe_ground_dist(hipStream_t s, const float4* C, int cs, const int* mult, const double c[3], const double nrm[3], double* partials, double* out2) {
+void fe_ground_fit_dist(hipStream_t s, const float4* C, int cs, const int* mult, const double* g11, double* fit, double* partials, double* out2) {
   const int nb = nblk(cs, FE_T);
-  hipLaunchKernelGGL(k_fe_ground_dist, dim3(nb), dim3(FE_T), 0, s, C, cs, mult, c[0], c[1], c[2], nrm[0], nrm[1], nrm[2], partials);
+  hipLaunchKernelGGL(k_fe_ground_fit, dim3(1), dim3(WAVE), 0, s, g11, fit);
+  hipLaunchKernelGGL(k_fe_ground_dist, dim3(nb), dim3(FE_T), 0, s, C, cs, mult, fit, partials);
   hipLaunchKernelGGL(k_fe_fold, dim3(2), dim3(WAVE), 0, s, partials, nb, 2, out2);
 }
 void fe_ground_list(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, const int* seedcnt,

@@ -134,7 +134,8 @@ void fe_stencils(hipStream_t s, const float4* C, int cs, float* range_vec, float
                  float* curv2, float* icurv, float* dsrc, float* osrc, int* picked);
 void fe_ground(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
                double* partials, double* out11);
-void fe_ground_dist(hipStream_t s, const float4* C, int cs, const int* mult, const double c[3], const double nrm[3], double* partials, double* out2);
+// plane fit of the ground sums (g11) into fit[16] on the device, then the distance sums into out2[2]
+void fe_ground_fit_dist(hipStream_t s, const float4* C, int cs, const int* mult, const double* g11, double* fit, double* partials, double* out2);
 void fe_ground_list(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, const int* seedcnt,
                     const int* seedpos, float4* out, int cap);
 void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const float* curv, const float* curv2, const float* icurv, const int* inum,
