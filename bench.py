@@ -184,6 +184,20 @@ def main():
             traffic = json.load(open(tfile)).get(name)
         except Exception:
             traffic = None
+    # the same kernel against the roof that actually binds it -- VALU instruction issue: wave-instructions per query from the
+    # committed PMC pass (profiles/r01_pmc_issue.json, rocprofv3 --pmc SQ_INSTS_VALU) / this run's launch duration, against
+    # 256 CUs x 4 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz
+    issue = None
+    ifile = os.path.join(ROOT, "profiles", "r01_pmc_issue.json")
+    if name == "knn_cov_target" and os.path.exists(ifile) and avg_ms > 0:
+        try:
+            per_q = float(json.load(open(ifile))["valu_wave_instructions_per_query"])
+            ach = per_q * units / (avg_ms * 1e-3) / 1e9
+            peak = 256 * 4 * 2.4 / 4.0
+            issue = {"bound": "valu_issue", "kernel": name, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                     "frac": round(ach / peak, 4), "valu_wave_instructions_per_query": per_q}
+        except Exception:
+            issue = None
     roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": per_unit * units}
@@ -201,7 +215,7 @@ def main():
         "mean_outer_iterations": round(mean_outer, 2), "mean_linearize": round(mean_lin, 2), "mean_compute_error": round(mean_err, 2),
         "mean_correspondences": round(mean_corr, 1), "n_voxels": int(n_vox),
         "kernel_ms_per_step": {k: round(x["total_ms"] / KB, 4) for k, x in prof.items()},
-        "roofline": roofline, "spinup_frames": SPINUP,
+        "roofline": roofline, "issue_roofline": issue, "spinup_frames": SPINUP,
     }
 
     if world_size == 1 and not args.no_cpu_baseline:
