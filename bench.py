@@ -111,7 +111,7 @@ def main():
     # Process spin-up, untimed and outside W: a fresh process pays ONE ~40 ms stall inside the HIP runtime at its ~84th frame
     # (a runtime pool growing once; measured with scripts/exp_bench_overhead.py: frame 83 exactly, never again in 600 frames).
     # A 10 Hz node never notices it; a 20-step timed loop would report it as a 3x slowdown if it fell inside.
-    SPINUP = 96
+    SPINUP = int(os.environ.get("RGC_BENCH_SPINUP", "96"))
     g0 = poses[0].astype(np.float32)
     for j in range(SPINUP):
         step(j % max(W, 1), g0)

@@ -147,9 +147,14 @@ int ensure(rgc_ctx* c, DevBuf& b, size_t bytes) {
     b.p = nullptr;
     b.cap = 0;
   }
-  size_t want = bytes + bytes / 8 + 256;  // head-room: clouds of similar size arrive every frame
+  // head-room: clouds of similar size arrive every frame, and a re-allocation costs a device synchronisation plus hipFree /
+  // hipMalloc (hundreds of microseconds: 10 % of the first 20 frames of a sequence when buffers crept up by 1/8 at a time).
+  // HBM is not the scarce resource here: half again for anything below 256 MB, an eighth above.
+  size_t want = bytes + (bytes < ((size_t)256 << 20) ? bytes / 2 : bytes / 8) + 256;
   HIPCHK(c, hipMalloc(&b.p, want));
   b.cap = want;
+  static const bool trace = getenv("RGC_TRACE_ALLOC") != nullptr;  // developer aid: which buffer grew, and when
+  if (trace) fprintf(stderr, "[rgc] buffer at ctx+%ld grew to %zu bytes (asked %zu)\n", (long)((char*)&b - (char*)c), want, bytes);
   return RGC_OK;
 }
 
@@ -258,13 +263,37 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
         return fail(c, RGC_ERR_GRID_TOO_LARGE, "%s grid %d x %d x %d exceeds max_cells", is_target ? "target" : "source", g.dim[0], g.dim[1], g.dim[2]);
       g.res = c->prm.voxel_res;
       g.ncell = (int)ncell;
-      // the grid the NEXT cloud will try
+      // The grid the NEXT cloud will try.  The map's box is stable and its grid large: 2 / 2 / 1 cells of margin.  A raw scan's box
+      // jumps with every far return, but it stays inside the sensor's range envelope and its grid is small: 16 / 16 / 4 cells of
+      // margin, united with the box tried before (a miss costs the scan's whole preparation and a second solve, so the box only
+      // ever grows -- at most to four times the measured one).
       rgck::Grid w = g;
       double wcell = 1.0;
-      for (int a = 0; a < 3; a++) { const int m = a < 2 ? 2 : 1; w.minc[a] -= m; w.dim[a] += 2 * m; wcell *= (double)w.dim[a]; }
+      for (int a = 0; a < 3; a++) {
+        const int m = is_target ? (a < 2 ? 2 : 1) : (a < 2 ? 16 : 4);
+        int lo = g.minc[a] - m, hi = g.minc[a] + g.dim[a] - 1 + m;
+        if (!is_target && cl.spec_ok && cl.spec_grid.res == g.res) {
+          lo = std::min(lo, cl.spec_grid.minc[a]);
+          hi = std::max(hi, cl.spec_grid.minc[a] + cl.spec_grid.dim[a] - 1);
+        }
+        w.minc[a] = lo; w.dim[a] = hi - lo + 1;
+        wcell *= (double)w.dim[a];
+      }
+      if (!is_target && wcell > 4.0 * ncell + 1.0e6) {  // the union ran away (a sequence that really moves its box): start over from this cloud
+        wcell = 1.0;
+        for (int a = 0; a < 3; a++) { const int m = a < 2 ? 16 : 4; w.minc[a] = g.minc[a] - m; w.dim[a] = g.dim[a] + 2 * m; wcell *= (double)w.dim[a]; }
+      }
       w.ncell = (int)wcell;
       cl.spec_ok = wcell <= (double)c->prm.max_cells && wcell <= 2.0e9;
       cl.spec_grid = w;
+      if (cl.spec_ok) {  // its cell arrays now, in the frame that is slow anyway, not in the next one
+        const size_t wc1 = (size_t)w.ncell + 1;
+        int rc;
+        if ((rc = ensure(c, cl.cnt, sizeof(int) * wc1 + 256))) return rc;
+        if ((rc = ensure(c, cl.start, sizeof(int) * wc1))) return rc;
+        if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (wc1 / 2048 + 2)))) return rc;
+        if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)w.ncell))) return rc;
+      }
     }
     cl.grid = g;
     const size_t nc1 = (size_t)g.ncell + 1;
@@ -393,6 +422,8 @@ int resolve_guards(rgc_ctx* c, int guard_t, int guard_s) {
     c->corr_valid = false;
     c->deferred_known = false;
     if (gd[a] & 1) { cl[a]->n = 0; return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", a == 0 ? "target" : "source"); }
+    static const bool trace = getenv("RGC_TRACE_ALLOC") != nullptr;
+    if (trace) fprintf(stderr, "[rgc] %s cloud left its speculative grid: prepared again\n", a == 0 ? "target" : "source");
     int rc = prepare_cloud(c, *cl[a], a == 0, /*force_bbox=*/true);
     if (rc) { cl[a]->n = 0; return rc; }
     redo = 1;
