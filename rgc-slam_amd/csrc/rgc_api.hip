@@ -43,6 +43,8 @@ struct Cloud {
   rgck::Grid spec_grid{};
   bool spec_ok = false;    // spec_grid is usable
   bool spec_used = false;  // this cloud was prepared on spec_grid and its guard has not been read yet
+  size_t cnt_clean = 0;    // cnt[0 .. cnt_clean) is known to be zero (the cell scan leaves the counters it consumed at zero)
+  const void* cnt_seen = nullptr;  // the allocation cnt_clean refers to
   // target only
   DevBuf cell_voxel, vox, vox_cell;
   int nvox = -1;
@@ -311,9 +313,14 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
     if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)g.ncell))) return rc;
-    HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, (sizeof(int) * nc1 + 255) & ~(size_t)255, s));  // whole 256-byte lines: one fill kernel
+    if (cl.cnt.p != cl.cnt_seen) { cl.cnt_clean = 0; cl.cnt_seen = cl.cnt.p; }  // re-allocated: contents unknown
+    if (cl.cnt_clean < nc1) {  // first use or a larger grid; afterwards the scan leaves the counters clean: no fill kernel per frame
+      const size_t fill = std::min(cl.cnt.cap, (sizeof(int) * nc1 + 255) & ~(size_t)255);
+      HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, fill, s));
+    }
+    cl.cnt_clean = nc1;
     rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi, spec ? dsm + 6 : nullptr);
-    rgck::scan_cells(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
+    rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
                      is_target ? c->d_small + 7 : nullptr, hi);
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p, hi);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
@@ -627,7 +634,7 @@ int prepare_map_grid(rgc_ctx* c, Cloud& cl, double cell) {
   if ((rc = ensure(c, cl.P, sizeof(float4) * n))) return rc;
   HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, (sizeof(int) * nc1 + 255) & ~(size_t)255, s));
   rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p);
-  rgck::scan_cells(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, nullptr, nullptr);
+  rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, nullptr, nullptr);
   rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p);
   rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p, (float4*)cl.P.p);
   HIPCHK(c, hipGetLastError());

@@ -258,7 +258,7 @@ __device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned lo
 }
 
 // cnt has n entries (cells + 1 sentinel of 0); cell_voxel (nullable) has n - 1
-__global__ void k_cells_scan_block(const int* __restrict__ cnt, int* __restrict__ start, int n, unsigned long long* __restrict__ block_sums,
+__global__ void k_cells_scan_block(int* __restrict__ cnt, int* __restrict__ start, int n, unsigned long long* __restrict__ block_sums,
                                    int* __restrict__ cell_voxel, int* __restrict__ nvox, int prio) {
   wave_prio(prio);
   const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
@@ -267,6 +267,7 @@ __global__ void k_cells_scan_block(const int* __restrict__ cnt, int* __restrict_
 #pragma unroll
   for (int j = 0; j < SCAN_V; j++) {
     v[j] = (base + j < n) ? cnt[base + j] : 0;
+    if (base + j < n && v[j]) cnt[base + j] = 0;  // the counters are consumed here: left clean for the next cloud, no fill kernel per frame
     s += (unsigned long long)(unsigned)v[j] | ((unsigned long long)(v[j] > 0) << 32);
   }
   unsigned long long tot;
@@ -302,6 +303,41 @@ __global__ void k_cells_scan_sums(unsigned long long* sums, int nb, int* __restr
     __syncthreads();
   }
   if (threadIdx.x == 0 && nvox) *nvox = (int)(carry_s >> 32);
+}
+
+// k_cells_scan_sums + k_cells_scan_add in one launch for grids of up to a few thousand scan blocks: every workgroup sums the
+// totals of the workgroups before it itself (<= 4096 values, strided loads + one reduction) instead of waiting for a
+// single-workgroup kernel to do it for all.
+__global__ void __launch_bounds__(SCAN_T) k_cells_scan_add_self(int* __restrict__ start, int n, const unsigned long long* __restrict__ block_sums,
+                                                                int nb, int* __restrict__ cell_voxel, int* __restrict__ nvox, int prio) {
+  wave_prio(prio);
+  __shared__ unsigned long long part[SCAN_T / WAVE];
+  __shared__ unsigned long long pre_s;
+  unsigned long long acc = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_T) acc += block_sums[j];
+  for (int o = WAVE / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & (WAVE - 1)) == 0) part[threadIdx.x / WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < SCAN_T / WAVE; w++) t += part[w];
+    pre_s = t;
+    if ((int)blockIdx.x == nb - 1 && nvox) *nvox = (int)((t + block_sums[nb - 1]) >> 32);
+  }
+  __syncthreads();
+  const unsigned long long add = pre_s;
+  const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
+  const int add_s = (int)(unsigned)add, add_v = (int)(add >> 32);
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++) {
+    if (base + j < n) {
+      start[base + j] += add_s;
+      if (cell_voxel && base + j < n - 1) {
+        const int cv = cell_voxel[base + j];
+        if (cv >= 0) cell_voxel[base + j] = cv + add_v;
+      }
+    }
+  }
 }
 
 __global__ void k_cells_scan_add(int* __restrict__ start, int n, const unsigned long long* __restrict__ block_sums, int* __restrict__ cell_voxel,
@@ -2692,11 +2728,13 @@ void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* 
 void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi, int* guard) {
   hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi);
 }
-void scan_cells(hipStream_t s, const int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi) {
+void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi) {
   const int nb = nblk(n, SCAN_B);
   unsigned long long* bs = (unsigned long long*)block_sums;
   hipLaunchKernelGGL(k_cells_scan_block, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, cell_voxel, nvox, hi);
-  if (nb > 1) {
+  if (nb > 1 && nb <= 4096) {
+    hipLaunchKernelGGL(k_cells_scan_add_self, dim3(nb), dim3(SCAN_T), 0, s, start, n, bs, nb, cell_voxel, nvox, hi);
+  } else if (nb > 1) {
     hipLaunchKernelGGL(k_cells_scan_sums, dim3(1), dim3(SCAN_T), 0, s, bs, nb, nvox, hi);
     hipLaunchKernelGGL(k_cells_scan_add, dim3(nb), dim3(SCAN_T), 0, s, start, n, bs, cell_voxel, hi);
   }
