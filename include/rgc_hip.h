@@ -217,6 +217,7 @@ typedef struct rgc_stats {
   int outer_iterations, n_linearize, n_error;
   long long target_cells, source_cells;
   int deferred_target, deferred_source; /* queries handled by the cooperative kNN kernel */
+  double source_crowding;               /* mean number of points in a scan point's own kNN-grid cell (sum count^2 / n) */
 } rgc_stats;
 RGC_API int rgc_get_stats(rgc_ctx* ctx, rgc_stats* out);
 

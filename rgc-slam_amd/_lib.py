@@ -29,7 +29,7 @@ class Stats(C.Structure):
     _fields_ = [("n_source", C.c_int), ("n_target", C.c_int), ("n_voxels", C.c_int), ("n_corr", C.c_int),
                 ("outer_iterations", C.c_int), ("n_linearize", C.c_int), ("n_error", C.c_int),
                 ("target_cells", C.c_longlong), ("source_cells", C.c_longlong),
-                ("deferred_target", C.c_int), ("deferred_source", C.c_int)]
+                ("deferred_target", C.c_int), ("deferred_source", C.c_int), ("source_crowding", C.c_double)]
 
 
 class FuseIn(C.Structure):

@@ -91,6 +91,8 @@ struct rgc_ctx {
   rgck::LmState* h_lm = nullptr;  // pinned mirror
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop (A/B knob)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
+  double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
+  double src_res_auto = 0.0;  // adaptive cell size of the scan's kNN grid, steered by how crowded its cells were in the previous frame (0 = voxel_res)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos;  // B2/B3/B9 staging
   DevBuf fe[34];              // front-end buffers
@@ -236,7 +238,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     // bbox accumulators + flag; the map's copy also zeroes [7], its voxel counter ([8] ncorr stays untouched; the scan's
     // block lives at +16 and must not touch the map's counter)
     const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
-    const size_t init_bytes = (is_target ? 8 : 7) * sizeof(int);
+    const size_t init_bytes = 8 * sizeof(int);  // the scan's eighth int (d_small[23]) is its sum of count^2, a float accumulated by the cell scan
     memcpy(hsm, init, init_bytes);
     HIPCHK(c, hipMemcpyAsync(dsm, hsm, init_bytes, hipMemcpyHostToDevice, s));
     // Speculative grid: consecutive clouds of a sequence cover (almost) the same cells, so the previous grid -- widened by two
@@ -244,14 +246,18 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     // between setInputTarget and the end of align).  A larger bounding grid changes nothing in the results: cells keep their
     // relative order (voxel ids come from the cell scan), neighbourhoods are the same.  k_count guards it; the guard comes home
     // with the LM state (or is read by the first other consumer) and a miss re-prepares the cloud on its own bounding box.
-    const bool spec = c->spec_on && !c->lm_host && rgck::knn_impl() == 0 && cl.spec_ok && cl.spec_grid.res == c->prm.voxel_res && !force_bbox;
+    // The scan's kNN grid need not be the voxel grid (only the map's doubles as the voxel map), and the exact search returns the
+    // same neighbours on any grid: a raw 64-beam sweep puts thousands of points into the 1 m cells near the sensor (every query
+    // scans its whole cell: O(c^2)), so its cell size follows the crowding measured on the previous frame of the sequence.
+    const double res = is_target ? c->prm.voxel_res : (c->src_res > 0.0 ? c->src_res : (c->src_res_auto > 0.0 ? c->src_res_auto : c->prm.voxel_res));
+    const bool spec = c->spec_on && !c->lm_host && rgck::knn_impl() == 0 && cl.spec_ok && cl.spec_grid.res == res && !force_bbox;
     rgck::Grid g{};
     if (spec) {
       g = cl.spec_grid;
       cl.spec_used = true;
     } else {
       cl.spec_used = false;
-      rgck::bbox(s, cl.in, cl.stride_f, n, c->prm.voxel_res, dsm, dsm + 6, hi);
+      rgck::bbox(s, cl.in, cl.stride_f, n, res, dsm, dsm + 6, hi);
       HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
       HIPCHK(c, hipStreamSynchronize(s));
       if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", is_target ? "target" : "source");
@@ -263,7 +269,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       }
       if (ncell > (double)c->prm.max_cells || ncell > 2.0e9)
         return fail(c, RGC_ERR_GRID_TOO_LARGE, "%s grid %d x %d x %d exceeds max_cells", is_target ? "target" : "source", g.dim[0], g.dim[1], g.dim[2]);
-      g.res = c->prm.voxel_res;
+      g.res = res;
       g.ncell = (int)ncell;
       // The grid the NEXT cloud will try.  The map's box is stable and its grid large: 2 / 2 / 1 cells of margin.  A raw scan's box
       // jumps with every far return, but it stays inside the sensor's range envelope and its grid is small: 16 / 16 / 4 cells of
@@ -321,7 +327,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     cl.cnt_clean = nc1;
     rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi, spec ? dsm + 6 : nullptr);
     rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
-                     is_target ? c->d_small + 7 : nullptr, hi);
+                     is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23));
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p, hi);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
                       (float4*)cl.P.p, rgck::knn_impl() == 0 ? (int*)cl.segs.p : nullptr, hi);
@@ -879,6 +885,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
+  if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
   if (const char* e = getenv("RGC_LM_IMPL")) { c->lm_host = strcmp(e, "host") == 0; c->lm_persist = strcmp(e, "persistent") == 0; }
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   *out = c;
@@ -923,6 +930,7 @@ int rgc_set_params(rgc_ctx* c, const rgc_params* p) {
   int rc = check_params(c, p);
   if (rc) return rc;
   const bool redo = p->voxel_res != c->prm.voxel_res || p->k_correspondences != c->prm.k_correspondences;
+  if (p->voxel_res != c->prm.voxel_res) c->src_res_auto = 0.0;
   c->prm = *p;
   c->corr_valid = false;
   if (redo) {  // covariances / voxel map depend on these: recompute from the resident inputs
@@ -1073,6 +1081,14 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     c->stats.n_corr = S.ncorr; c->stats.n_linearize = S.n_lin; c->stats.n_error = S.n_err;
     c->tgt.nvox = c->stats.n_voxels = S.nvox;
     c->stats.deferred_target = S.def_t; c->stats.deferred_source = S.def_s;
+    c->stats.source_crowding = c->src.n > 0 ? (double)S.src_sq / (double)c->src.n : 0.0;
+    if (c->src_res <= 0.0 && c->src.n > 0) {  // steer the next scan's cell size: halve above 300 points per own cell, double below 40
+      const double cur = c->src.grid.res, crowd = c->stats.source_crowding;
+      double next = cur;
+      if (crowd > 300.0 && cur > 0.26 * c->prm.voxel_res) next = cur * 0.5;
+      else if (crowd < 40.0 && cur < c->prm.voxel_res) next = std::fmin(cur * 2.0, c->prm.voxel_res);
+      c->src_res_auto = next;
+    }
     c->deferred_known = true;
     fit_sum = S.fit_sum;
     memcpy(x0, S.x0, sizeof(x0));

@@ -31,6 +31,7 @@ struct LmState {  // device-resident state of LsqRegistration::computeTransforma
   double fit_sum;                // sum of squared NN distances at the final pose (k_fitness_lm)
   int nvox, def_t, def_s, pad;   // frame counters carried home with the state; pad = grid guards, map | scan << 8
   int gen, cmd, mode, cur;       // persistent solve: hand-off generation + command; step kernels: mode, valid corr buffer
+  float src_sq; int pad2;        // sum over the scan's grid cells of count^2 (how crowded its cells are; steers the scan's cell size)
 };
 struct LmInit { double x0[16], rot_eps, trans_eps, init_factor; int max_outer, max_inner; };
 struct FeParams { int n_scans; double min_range, max_range; };
@@ -45,7 +46,8 @@ void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* 
 void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi = 0, int* guard = nullptr);
 // cnt: n = cells + 1 entries; block_sums: >= 8 * (n / 2048 + 2) bytes; cell_voxel (n - 1 ints) and nvox may be null
 // consumes the counters: cnt[0..n) is left ZERO
-void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi = 0);
+void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi = 0,
+                float* sum_sq = nullptr /* += sum of count^2, nullable */);
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi = 0);
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */, int hi = 0);
 void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp, int hi = 0);

@@ -259,7 +259,7 @@ __device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned lo
 
 // cnt has n entries (cells + 1 sentinel of 0); cell_voxel (nullable) has n - 1
 __global__ void k_cells_scan_block(int* __restrict__ cnt, int* __restrict__ start, int n, unsigned long long* __restrict__ block_sums,
-                                   int* __restrict__ cell_voxel, int* __restrict__ nvox, int prio) {
+                                   int* __restrict__ cell_voxel, int* __restrict__ nvox, int prio, float* __restrict__ sum_sq) {
   wave_prio(prio);
   const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
   int v[SCAN_V];
@@ -269,6 +269,13 @@ __global__ void k_cells_scan_block(int* __restrict__ cnt, int* __restrict__ star
     v[j] = (base + j < n) ? cnt[base + j] : 0;
     if (base + j < n && v[j]) cnt[base + j] = 0;  // the counters are consumed here: left clean for the next cloud, no fill kernel per frame
     s += (unsigned long long)(unsigned)v[j] | ((unsigned long long)(v[j] > 0) << 32);
+  }
+  if (sum_sq) {  // sum of count^2 = the work of every point scanning its own cell: how crowded the cells are (a heuristic, float is plenty)
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < SCAN_V; j++) q += (float)v[j] * (float)v[j];
+    for (int o = WAVE / 2; o > 0; o >>= 1) q += __shfl_down(q, o);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && q > 0.f) atomicAdd(sum_sq, q);
   }
   unsigned long long tot;
   unsigned long long ex = block_exclusive_scan64(s, &tot);
@@ -1771,6 +1778,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
       st->pad = nvox ? (nvox[-1] | (nvox[15] << 8)) : 0;  // grid guards of map and scan (d_small[6], [22])
       st->def_t = def_t ? *def_t : 0;
       st->def_s = def_s ? *def_s : 0;
+      st->src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;  // d_small[23]
       st->done = 1;
     }
     return;
@@ -1822,6 +1830,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     st->pad = nvox ? (nvox[-1] | (nvox[15] << 8)) : 0;
     st->def_t = def_t ? *def_t : 0;
     st->def_s = def_s ? *def_s : 0;
+    st->src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;
   }
   double H[36], b[6], x0[16], d[6], delta[16], xi[16];
   double lambda = st->lambda;
@@ -1991,6 +2000,7 @@ k_lm_run(const float4* __restrict__ P, const double* __restrict__ nx, const doub
     wt(&st->pad, nvox ? (nvox[-1] | (nvox[15] << 8)) : 0);
     wt(&st->def_t, def_t ? *def_t : 0);
     wt(&st->def_s, def_s ? *def_s : 0);
+    st->src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;
     wt(&st->done, in.max_outer <= 0 ? 1 : 0);
   }
   if (in.max_outer <= 0) return;
@@ -2728,10 +2738,10 @@ void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* 
 void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi, int* guard) {
   hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi);
 }
-void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi) {
+void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi, float* sum_sq) {
   const int nb = nblk(n, SCAN_B);
   unsigned long long* bs = (unsigned long long*)block_sums;
-  hipLaunchKernelGGL(k_cells_scan_block, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, cell_voxel, nvox, hi);
+  hipLaunchKernelGGL(k_cells_scan_block, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, cell_voxel, nvox, hi, sum_sq);
   if (nb > 1 && nb <= 4096) {
     hipLaunchKernelGGL(k_cells_scan_add_self, dim3(nb), dim3(SCAN_T), 0, s, start, n, bs, nb, cell_voxel, nvox, hi);
   } else if (nb > 1) {
