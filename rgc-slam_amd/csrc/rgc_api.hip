@@ -1334,25 +1334,46 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
     rgck::transform_q(s, d_in, stride_f, n, rgck::Quat{0, 0, 0, 1}, (const double[3]){0, 0, 0}, d_out, 4);
     *n_out = n;
   } else {
-    if (ncell > (double)c->prm.max_cells) return fail(c, RGC_ERR_GRID_TOO_LARGE, "leaf grid %d x %d x %d exceeds max_cells", g.div[0], g.div[1], g.div[2]);
     Cloud& cl = c->aux;
-    const size_t nc1 = (size_t)ncell + 1;
     if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1))) return rc;
-    if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
-    if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nc1 / 2048 + (size_t)n / 2048 + 4)))) return rc;
     if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, c->vg_order, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, c->vg_first, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, c->vg_pos, sizeof(int) * n))) return rc;
-    HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nc1, s));
-    rgck::vg_count(s, d_in, stride_f, n, inv, g, (int*)cl.cell_of.p, (int*)cl.cnt.p);
-    rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, (int*)cl.block_sums.p);
-    rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
-    rgck::vg_rank(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p, (int*)c->vg_order.p, (int*)c->vg_first.p);
-    rgck::exclusive_scan(s, (const int*)c->vg_first.p, (int*)c->vg_pos.p, n, (int*)cl.block_sums.p);
-    rgck::vg_centroid(s, d_in, stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)c->vg_order.p,
-                      (const int*)c->vg_first.p, (const int*)c->vg_pos.p, d_out, dsm + 7);
+    const double nrows = (double)g.div[1] * (double)g.div[2];
+    if (ncell > 64.0 * (double)n && nrows <= 64.0e6) {
+      // sparse leaf grid: counting sort over the (y, z) rows, rank by (leaf x, point index) inside a row
+      const size_t nr1 = (size_t)nrows + 1;
+      if ((rc = ensure(c, cl.cnt, sizeof(int) * nr1))) return rc;
+      if ((rc = ensure(c, cl.start, sizeof(int) * nr1))) return rc;
+      if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nr1 / 2048 + (size_t)n / 2048 + 4)))) return rc;
+      if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;   // leaf x of every point
+      if ((rc = ensure(c, cl.P, sizeof(int) * n))) return rc;         // leaf x in sorted order
+      cl.cnt_clean = 0;
+      HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nr1, s));
+      rgck::vg_count_rows(s, d_in, stride_f, n, inv, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p);
+      rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nr1, (int*)cl.block_sums.p);
+      rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
+      rgck::vg_rank_rows(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
+                         (int*)c->vg_order.p, (int*)cl.P.p, (int*)c->vg_first.p);
+      rgck::exclusive_scan(s, (const int*)c->vg_first.p, (int*)c->vg_pos.p, n, (int*)cl.block_sums.p);
+      rgck::vg_centroid_rows(s, d_in, stride_f, n, (const int*)c->vg_order.p, (const int*)c->vg_first.p, (const int*)c->vg_pos.p, d_out, dsm + 7);
+    } else {
+      if (ncell > (double)c->prm.max_cells) return fail(c, RGC_ERR_GRID_TOO_LARGE, "leaf grid %d x %d x %d exceeds max_cells", g.div[0], g.div[1], g.div[2]);
+      const size_t nc1 = (size_t)ncell + 1;
+      if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1))) return rc;
+      if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
+      if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nc1 / 2048 + (size_t)n / 2048 + 4)))) return rc;
+      cl.cnt_clean = 0;
+      HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nc1, s));
+      rgck::vg_count(s, d_in, stride_f, n, inv, g, (int*)cl.cell_of.p, (int*)cl.cnt.p);
+      rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, (int*)cl.block_sums.p);
+      rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
+      rgck::vg_rank(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p, (int*)c->vg_order.p, (int*)c->vg_first.p);
+      rgck::exclusive_scan(s, (const int*)c->vg_first.p, (int*)c->vg_pos.p, n, (int*)cl.block_sums.p);
+      rgck::vg_centroid(s, d_in, stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)c->vg_order.p,
+                        (const int*)c->vg_first.p, (const int*)c->vg_pos.p, d_out, dsm + 7);
+    }
     HIPCHK(c, hipMemcpyAsync(hsm + 7, dsm + 7, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     *n_out = hsm[7];
