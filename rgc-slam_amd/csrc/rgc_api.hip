@@ -1351,9 +1351,9 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
       if ((rc = ensure(c, cl.P, sizeof(int) * n))) return rc;         // leaf x in sorted order
       cl.cnt_clean = 0;
       HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nr1, s));
-      rgck::vg_count_rows(s, d_in, stride_f, n, inv, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p);
+      rgck::vg_count_rows(s, d_in, stride_f, n, inv, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, (int*)c->vg_pos.p);
       rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nr1, (int*)cl.block_sums.p);
-      rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
+      rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)c->vg_pos.p, (const int*)cl.start.p, (int*)cl.order_tmp.p);
       rgck::vg_rank_rows(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
                          (int*)c->vg_order.p, (int*)cl.P.p, (int*)c->vg_first.p);
       rgck::exclusive_scan(s, (const int*)c->vg_first.p, (int*)c->vg_pos.p, n, (int*)cl.block_sums.p);

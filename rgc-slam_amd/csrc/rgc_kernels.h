@@ -123,7 +123,7 @@ void vg_bbox(hipStream_t s, const float* in, int stride_f, int n, float inv, int
 void vg_count(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* cell_of, int* cnt);
 void vg_rank(hipStream_t s, int n, const int* cell_of, const int* start, const int* order_tmp, int* order, int* first);
 // sparse leaf grids: counting sort over (y, z) rows, rank by (leaf x, index) inside a row; key = n ints of scratch
-void vg_count_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* row_of, int* lx, int* cnt);
+void vg_count_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* row_of, int* lx, int* cnt, int* slot);
 void vg_rank_rows(hipStream_t s, int n, const int* row_of, const int* lx, const int* start, const int* order_tmp, int* order, int* key, int* first);
 void vg_centroid_rows(hipStream_t s, const float* in, int stride_f, int n, const int* order, const int* first, const int* outpos, float* out,
                       int* n_out);

@@ -153,14 +153,14 @@ __global__ void k_vg_centroid(const float* __restrict__ in, int stride_f, int n,
 // inside the row: the counting sort runs over the ROWS (dy x dz entries, tens of thousands), and inside a row the points are ranked by
 // (i, point index) -- rows hold few points when the grid is sparse.  Same output, bit for bit.
 __global__ void k_vg_count_rows(const float* __restrict__ in, int stride_f, int n, float inv, LeafGrid g, int* __restrict__ row_of,
-                                int* __restrict__ lx, int* cnt) {
+                                int* __restrict__ lx, int* cnt, int* __restrict__ slot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* p = in + (size_t)i * stride_f;
   const int r = (leaf_coord(p[1], inv) - g.minb[1]) + (leaf_coord(p[2], inv) - g.minb[2]) * g.div[1];
   row_of[i] = r;
   lx[i] = leaf_coord(p[0], inv) - g.minb[0];
-  atomicAdd(&cnt[r], 1);
+  slot[i] = atomicAdd(&cnt[r], 1);  // arrival order inside the row: the placement needs no second atomic
 }
 // final slot of a point = row start + number of same-row points that precede it in (leaf x, point index) order; key[slot] = its leaf x
 __global__ void k_vg_rank_rows(int n, const int* __restrict__ row_of, const int* __restrict__ lx, const int* __restrict__ start,
@@ -221,8 +221,8 @@ void vg_count(hipStream_t s, const float* in, int stride_f, int n, float inv, Le
 void vg_rank(hipStream_t s, int n, const int* cell_of, const int* start, const int* order_tmp, int* order, int* first) {
   hipLaunchKernelGGL(k_vg_rank, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, start, order_tmp, order, first);
 }
-void vg_count_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* row_of, int* lx, int* cnt) {
-  hipLaunchKernelGGL(k_vg_count_rows, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, inv, g, row_of, lx, cnt);
+void vg_count_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* row_of, int* lx, int* cnt, int* slot) {
+  hipLaunchKernelGGL(k_vg_count_rows, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, inv, g, row_of, lx, cnt, slot);
 }
 void vg_rank_rows(hipStream_t s, int n, const int* row_of, const int* lx, const int* start, const int* order_tmp, int* order, int* key, int* first) {
   hipLaunchKernelGGL(k_vg_rank_rows, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, lx, start, order_tmp, order, key);
