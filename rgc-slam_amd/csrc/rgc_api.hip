@@ -225,7 +225,8 @@ int check_params(rgc_ctx* c, const rgc_params* p) {
 }
 
 // C1-C3: grid + exact-kNN covariances (+ voxel map for the target), all enqueued on the stream.
-// One host<->device round trip: the 6-int bounding box (the dense grid is sized from it).
+// The first cloud of a context costs one host<->device round trip -- the 6-int bounding box the dense grid is sized from; later
+// clouds re-use the previous (widened) grid speculatively and need none (see `spec` below).
 int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false) {
   const int n = cl.n;
   const int k = c->prm.k_correspondences;
