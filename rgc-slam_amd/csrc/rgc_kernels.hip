@@ -832,6 +832,9 @@ __device__ __forceinline__ void generic_search_rows(const float4* __restrict__ P
 // kTarget only separates the two instantiations by NAME (map vs scan) for the profiles.
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_T = 256;
+#ifndef RGC_XCD_RUN
+#define RGC_XCD_RUN 16
+#endif
 #ifdef RGC_EXP_NOJUMP
 constexpr int kJumpMax = 1;
 #else
@@ -1012,7 +1015,12 @@ k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
   extern __shared__ int slist_rows[];  // [k][KNN_T] neighbour list, then [18][KNN_T] row ranges
   wave_prio(!kTarget);
   if (df.guard && *df.guard) return;  // points outside a speculative grid were parked in cell 0: their cells must not be looked up
-  const int i = blockIdx.x * KNN_T + threadIdx.x;
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one) and queries are in cell order.
+  // Each XCD takes runs of kXcdRun CONSECUTIVE query blocks (neighbouring cells: their candidates are re-used out of that XCD's L2),
+  // the runs themselves dealt round-robin (whole contiguous eighths of the map differ too much in work: 7 % slower).
+  constexpr int kXcdRun = RGC_XCD_RUN;
+  const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
+  const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * KNN_T + threadIdx.x;
   if (i < n) knn_point<KC>(P, start, g, k, heavy, jump_budget, i, slist_rows + threadIdx.x, slist_rows + k * KNN_T + threadIdx.x, df, nx, ny, nz);
 }
 
@@ -2793,7 +2801,7 @@ static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const in
     const size_t ldsr = (size_t)(k + 18) * KNN_T * sizeof(int);
     Deferred df = deferred_of(segs, n);  // df.cnt was zeroed by k_rank_gather
     df.guard = guard;
-    const int nb = nblk(n, KNN_T);
+    const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, KNN_T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
     if (is_target)
       hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, g_knn_jump, df, nx, ny, nz);
     else
