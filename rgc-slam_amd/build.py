@@ -16,7 +16,7 @@ SRCS = ["rgc_api.hip", "rgc_kernels.hip", "rgc_pre.hip", "rgc_frontend.hip", "rg
 DEPS = SRCS + ["rgc_kernels.h", "rgc_lm.h", os.path.join("..", "..", "include", "rgc_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-         "-fvisibility=hidden", "-DRGC_BUILD"]
+         "-fvisibility=hidden", "-DRGC_BUILD"] + os.environ.get("RGC_EXTRA_FLAGS", "").split()  # e.g. -DRGC_LAB: developer-only exports
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

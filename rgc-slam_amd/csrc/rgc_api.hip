@@ -251,7 +251,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     // same neighbours on any grid: a raw 64-beam sweep puts thousands of points into the 1 m cells near the sensor (every query
     // scans its whole cell: O(c^2)), so its cell size follows the crowding measured on the previous frame of the sequence.
     const double res = is_target ? c->prm.voxel_res : (c->src_res > 0.0 ? c->src_res : (c->src_res_auto > 0.0 ? c->src_res_auto : c->prm.voxel_res));
-    const bool spec = c->spec_on && !c->lm_host && rgck::knn_impl() == 0 && cl.spec_ok && cl.spec_grid.res == res && !force_bbox;
+    const bool spec = c->spec_on && !c->lm_host && rgck::knn_impl() != 1 && cl.spec_ok && cl.spec_grid.res == res && !force_bbox;
     rgck::Grid g{};
     if (spec) {
       g = cl.spec_grid;
@@ -271,6 +271,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       if (ncell > (double)c->prm.max_cells || ncell > 2.0e9)
         return fail(c, RGC_ERR_GRID_TOO_LARGE, "%s grid %d x %d x %d exceeds max_cells", is_target ? "target" : "source", g.dim[0], g.dim[1], g.dim[2]);
       g.res = res;
+      g.inv_res = rgck::grid_inv_res(res);
       g.ncell = (int)ncell;
       // The grid the NEXT cloud will try.  The map's box is stable and its grid large: 2 / 2 / 1 cells of margin.  A raw scan's box
       // jumps with every far return, but it stays inside the sensor's range envelope and its grid is small: 16 / 16 / 4 cells of
@@ -313,7 +314,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
     if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (nc1 / 2048 + 2)))) return rc;
     if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, cl.P, sizeof(float4) * n))) return rc;
+    if ((rc = ensure(c, cl.P, sizeof(float4) * ((size_t)n + 4)))) return rc;
     if ((rc = ensure(c, cl.segs, rgck::segment_bytes(n)))) return rc;
     if ((rc = ensure(c, cl.nseg, 64))) return rc;
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
@@ -331,7 +332,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
                      is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23));
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p, hi);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
-                      (float4*)cl.P.p, rgck::knn_impl() == 0 ? (int*)cl.segs.p : nullptr, hi);
+                      (float4*)cl.P.p, rgck::knn_impl() != 1 ? (int*)cl.segs.p : nullptr, hi);
     if (rgck::knn_impl() == 1) {
       HIPCHK(c, hipMemsetAsync(cl.nseg.p, 0, sizeof(int), s));
       rgck::segments(s, (const int*)cl.start.p, cl.grid, cl.segs.p, (int*)cl.nseg.p);
@@ -629,6 +630,7 @@ int prepare_map_grid(rgc_ctx* c, Cloud& cl, double cell) {
   }
   if (ncell > (double)c->prm.max_cells || ncell > 2.0e9) return fail(c, RGC_ERR_GRID_TOO_LARGE, "feature-map grid exceeds max_cells");
   g.res = cell;
+  g.inv_res = rgck::grid_inv_res(cell);
   g.ncell = (int)ncell;
   cl.grid = g;
   const size_t nc1 = (size_t)g.ncell + 1;
@@ -638,7 +640,7 @@ int prepare_map_grid(rgc_ctx* c, Cloud& cl, double cell) {
   if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
   if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (nc1 / 2048 + 2)))) return rc;
   if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
-  if ((rc = ensure(c, cl.P, sizeof(float4) * n))) return rc;
+  if ((rc = ensure(c, cl.P, sizeof(float4) * ((size_t)n + 4)))) return rc;
   HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, (sizeof(int) * nc1 + 255) & ~(size_t)255, s));
   rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p);
   rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, nullptr, nullptr);
@@ -864,7 +866,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   rgc_ctx* c = new (std::nothrow) rgc_ctx();
   if (!c) return RGC_ERR_HIP;
   c->device = hip_device;
-  if (const char* e = getenv("RGC_KNN_IMPL")) rgck::set_knn_impl(strcmp(e, "tile") == 0 ? 1 : 0);
+  if (const char* e = getenv("RGC_KNN_IMPL")) rgck::set_knn_impl(strcmp(e, "tile") == 0 ? 1 : (strcmp(e, "sp") == 0 ? 2 : 0));
   if (const char* e = getenv("RGC_KNN_HEAVY")) { const int v = atoi(e); if (v > 0) rgck::set_knn_heavy(v); }
   if (const char* e = getenv("RGC_KNN_JUMP")) { const int v = atoi(e); if (v >= 0) rgck::set_knn_jump(v); }
   rgc_default_params(&c->prm);
@@ -1018,7 +1020,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     memcpy(in.x0, x0, sizeof(x0));
     in.rot_eps = P.rotation_eps; in.trans_eps = P.translation_eps; in.init_factor = P.lm_init_lambda_factor;
     in.max_outer = P.max_iterations; in.max_inner = P.lm_max_iterations;
-    const bool rows_impl = rgck::knn_impl() == 0;
+    const bool rows_impl = rgck::knn_impl() != 1;
     bool solved = false;
     if (c->lm_persist && nb <= 256) {  // one workgroup per CU at most: co-residency is certain
       // the whole solve (and the fitness behind it) in one enqueue, one read-back
@@ -1557,7 +1559,7 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   if (c->tgt.ready) { int rc = fetch_nvox(c); if (rc) return rc; }
   // queries the bulk kNN kernel handed to the cooperative kernel (first int of the deferred-list buffer)
   if (!c->deferred_known) c->stats.deferred_target = c->stats.deferred_source = 0;
-  if (!c->deferred_known && rgck::knn_impl() == 0) {
+  if (!c->deferred_known && rgck::knn_impl() != 1) {
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     if (c->tgt.ready && c->tgt.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_target, c->tgt.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (c->src.ready && c->src.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_source, c->src.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1566,6 +1568,22 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   *out = c->stats;
   return RGC_OK;
 }
+
+#ifdef RGC_LAB
+// developer build only (-DRGC_LAB): the deferred-query list of a cloud as the bulk kNN kernel left it
+RGC_API int rgc_lab_deferred(rgc_ctx* c, int is_target, int* idx, float* thr, int cap, int* count) {
+  Cloud& cl = is_target ? c->tgt : c->src;
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int cnt = 0;
+  HIPCHK(c, hipMemcpy(&cnt, cl.segs.p, sizeof(int), hipMemcpyDeviceToHost));
+  *count = cnt;
+  const int m = cnt < cap ? cnt : cap;
+  HIPCHK(c, hipMemcpy(idx, (const int*)cl.segs.p + 16, sizeof(int) * m, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(thr, (const int*)cl.segs.p + 16 + cl.n, sizeof(float) * m, hipMemcpyDeviceToHost));
+  return RGC_OK;
+}
+#endif
 
 int rgc_device_alloc(rgc_ctx* c, size_t bytes, void** p) {
   if (!c || !p) return RGC_ERR_INVALID;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 namespace rgck {
 
 // Dense voxel-aligned grid.  Cell c (per axis) covers [(c + minc + 0.5) * res, (c + minc + 1.5) * res):
@@ -12,7 +14,12 @@ struct Grid {
   int dim[3];
   double res;
   int ncell;
+  double inv_res;  // 1 / res when res is a power of two (x / res == x * inv_res bit for bit), else 0: see grid_inv_res()
 };
+inline double grid_inv_res(double res) {
+  int e;
+  return std::frexp(res, &e) == 0.5 ? 1.0 / res : 0.0;
+}
 
 struct Pose {  // row-major rotation + translation, fp64 (Eigen::Isometry3d in the reference)
   double R[9];
@@ -61,6 +68,7 @@ void set_knn_impl(int impl);  // 0 = rows (default), 1 = LDS tile
 int knn_impl();
 void set_knn_heavy(int v);
 void set_knn_jump(int v);
+void set_sp_heavy(int v);
 // bulk kernel (one lane per query; defers expensive queries) then the cooperative kernel (one wave per deferred query)
 void knn_rows(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
               const int* nseg, double* nx, double* ny, double* nz, const int* guard = nullptr);

@@ -24,11 +24,17 @@
 
 #include <limits.h>
 
+#include <type_traits>
+
 namespace rgck {
 
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ int voxel_coord1(float x, double res) { return (int)floor((double)x / res - 0.5); }
+// the same cell, without the fp64 division when the cell size is a power of two (the product is then the same double)
+__device__ __forceinline__ int voxel_coord_g(float x, const Grid& g) {
+  return g.inv_res != 0.0 ? (int)floor((double)x * g.inv_res - 0.5) : (int)floor((double)x / g.res - 0.5);
+}
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -384,13 +390,14 @@ __global__ void k_scatter(int n, const int* __restrict__ cell_of, const int* __r
 }
 
 // deterministic placement: a point's final slot = cell start + number of same-cell points with a smaller index.
-// Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate.
+// Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate; P holds n + 4 entries.
 __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
                               const int* __restrict__ start, const int* __restrict__ order_tmp, float4* __restrict__ P, int* zero_me,
                               int prio) {
   wave_prio(prio);
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s == 0 && zero_me) *zero_me = 0;  // the kNN launch that follows counts its deferred queries here
+  if (s < 4) P[n + s] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __int_as_float(-1));  // sentinels: infinitely far from every query (k_knn_sp's last quad)
   if (s >= n) return;
   int i = order_tmp[s];
   int c = cell_of[i];
@@ -465,6 +472,51 @@ __device__ __forceinline__ void min_eigenvector(const double S[6], double n[3]) 
   n[0] = m == 0 ? V[0][0] : (m == 1 ? V[0][1] : V[0][2]);
   n[1] = m == 0 ? V[1][0] : (m == 1 ? V[1][1] : V[1][2]);
   n[2] = m == 0 ? V[2][0] : (m == 1 ? V[2][1] : V[2][2]);
+}
+
+// The same eigenvector without sweeps, for the bulk kernel (one call per map point): the smallest root of the characteristic
+// polynomial by Newton's iteration from 0 -- for a symmetric positive semi-definite matrix all three roots are real and
+// non-negative, so the iteration climbs monotonically to the smallest one, quadratically once it is close (a planar
+// neighbourhood: lambda_3 << lambda_2, four or five steps) -- then the null vector of S - lambda I as the largest cross
+// product of two of its rows.  About 150 fp64 instructions instead of the ~1700 of five or six Jacobi sweeps.
+// Returns false -- the caller falls back to min_eigenvector -- when the iteration does not settle or the two smallest
+// eigenvalues are closer than ~1e-3 of the trace (rank of S - lambda I drops to 1, the cross products vanish): there the
+// eigenvector is ill-conditioned and only the SAME algorithm reproduces the oracle's choice.
+__device__ __forceinline__ bool min_eigenvector_direct(const double S[6], double n[3]) {
+  const double tr = S[0] + S[3] + S[5];
+  if (!(tr > 0.0)) return false;
+  const double inv = 1.0 / tr;  // scaled to trace 1: every entry and every eigenvalue is in [0, 1]
+  const double a = S[0] * inv, b = S[1] * inv, c = S[2] * inv, d = S[3] * inv, e = S[4] * inv, f = S[5] * inv;
+  const double m0 = d * f - e * e, m1 = b * f - c * e, m2 = b * e - c * d;
+  const double c1 = (a * d - b * b) + (a * f - c * c) + m0;  // sum of the principal 2x2 minors
+  const double c0 = a * m0 - b * m1 + c * m2;                // determinant
+  // p(x) = x^3 - x^2 + c1 x - c0
+  double x = 0.0;
+  bool settled = false;
+  for (int it = 0; it < 12; it++) {
+    const double pv = ((x - 1.0) * x + c1) * x - c0;
+    const double dp = (3.0 * x - 2.0) * x + c1;
+    const double dx = pv * __builtin_amdgcn_rcp(dp);  // an approximate reciprocal is enough: the iteration corrects itself
+    x -= dx;
+    // a step this small is the last one that matters (the next would be ~dx^2 / gap); the rounding noise of pv / dp stays below
+    // it while the two smallest eigenvalues are at least ~1e-3 apart, which the cross-product test below insists on
+    if (!(fabs(dx) > 1.0e-13)) { settled = dp > 0.0; break; }  // also leaves on NaN
+  }
+  if (!settled) return false;
+  const double r0[3] = {a - x, b, c}, r1[3] = {b, d - x, e}, r2[3] = {c, e, f - x};
+  const double u[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+  const double v[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+  const double w[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+  const double nu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2], nv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2],
+               nw = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const bool pu = nu >= nv && nu >= nw, pv2 = !pu && nv >= nw;
+  const double best = pu ? nu : (pv2 ? nv : nw);
+  if (!(best >= 1.0e-7)) return false;  // |cross| ~ (lambda_1 - lambda_3)(lambda_2 - lambda_3) / 2 at trace 1
+  const double s = rsqrt(best);
+  n[0] = (pu ? u[0] : (pv2 ? v[0] : w[0])) * s;
+  n[1] = (pu ? u[1] : (pv2 ? v[1] : w[1])) * s;
+  n[2] = (pu ? u[2] : (pv2 ? v[2] : w[2])) * s;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1022,6 +1074,320 @@ k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
   const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
   const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * KNN_T + threadIdx.x;
   if (i < n) knn_point<KC>(P, start, g, k, heavy, jump_budget, i, slist_rows + threadIdx.x, slist_rows + k * KNN_T + threadIdx.x, df, nx, ny, nz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C2, single pass (fast_gicp_impl.hpp:241-298): one lane per query, queries in cell order, the 3x3x3 block as <= 9 row
+// ranges -- like k_knn_rows -- but every candidate is looked at ONCE and the selection costs a few instructions per candidate:
+//  * key = fp32 bit pattern of the squared distance with its low kKeyBits replaced by the candidate's ORDINAL in the lane's
+//    candidate stream.  Keys order like distances (up to 2^-13 relative), and the winning keys name the neighbours: no second
+//    pass over the candidates to collect them.
+//  * the k + 2 smallest keys live in a sorted register chain whose insert is ONE v_med3_i32 per slot
+//    (new a[j] = med3(a[j-1], a[j], x): the slots do not depend on each other), half of the compare-exchange form.
+//  * LAZY insertion: a candidate whose key is below the chain's tail is only APPENDED to a small per-lane LDS buffer
+//    (compare + masked store); the buffers are drained into the chains when one fills up.  A wave then pays one insert per
+//    buffered key of its fullest lane -- not one per candidate that improves ANY of its 64 lanes, which is nearly every one.
+//  * the distance may use FMA here: keys only have to ORDER candidates that are at least two key buckets apart.  Where the k-th
+//    and (k+1)-th keys are closer than that the two candidates are compared by their exact, uncontracted distances
+//    (flann::L2_Simple's expression); a third contender or an exact tie (index order decides) sends the query to the
+//    cooperative kernel, as do blocks that cannot prove the k-th distance, crowded blocks and blocks whose rows touch in memory.
+// Rows are walked as ONE per-lane stream of quads (a lane moves to its next row when the current one is exhausted), so a
+// wave's trip count is its longest lane's total, not the sum of the per-row maxima.  A row's last quad may read up to three
+// points past the row: they are real points of cells outside the block (the row table is rejected otherwise), so they are
+// legitimate candidates and need no masking.
+// ------------------------------------------------------------------------------------------------
+constexpr int kKeyBits = 10;
+constexpr int kKeyOrd = (1 << kKeyBits) - 1;
+constexpr int kSpBuf = 12;   // keys waiting to enter the chain, per lane
+constexpr int kSpCum = 16;   // ordinal of each row's first candidate, padded with INT_MAX for the ordinal -> row search
+constexpr int kSpRows = 9;
+constexpr int kSpLds = kSpBuf + kSpCum + kSpRows;  // ints of LDS per lane, as columns [slot][lane]
+static int g_sp_heavy = 1000;  // candidates (rows rounded up to quads) above which a query goes to the cooperative kernel; < 2^kKeyBits
+void set_sp_heavy(int v) { g_sp_heavy = v < kKeyOrd - 3 * kSpRows ? v : kKeyOrd - 3 * kSpRows; }
+
+// a = med3(below, a, x), IN PLACE: the chain's registers stay where they are across the loops they are carried through (with a
+// separate output operand the compiler shuffles all of them at every loop boundary)
+__device__ __forceinline__ void med3_inplace(int& a, int below, int x) { asm("v_med3_i32 %0, %1, %0, %2" : "+v"(a) : "v"(below), "v"(x)); }
+
+template <int L>
+struct Chain {  // the L smallest keys, ascending, in registers
+  int a[L];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < L; j++) a[j] = INT_MAX;
+  }
+  __device__ __forceinline__ void insert(int x) {  // INT_MAX is a no-op
+#pragma unroll
+    for (int j = L - 1; j >= 1; j--) med3_inplace(a[j], a[j - 1], x);
+    asm("v_min_i32 %0, %0, %1" : "+v"(a[0]) : "v"(x));
+  }
+  // a[idx] for a run-time idx, without indexing (an indexed private array goes to scratch memory): the chain is ascending,
+  // so a[idx] is the largest of the first idx + 1 entries
+  __device__ __forceinline__ int at(int idx) const {
+    int t = a[0];
+#pragma unroll
+    for (int j = 1; j < L; j++) t = (j <= idx) ? max(t, a[j]) : t;
+    return t;
+  }
+};
+
+__device__ __forceinline__ float dist2_fma(float px, float py, float pz, float cx, float cy, float cz) {
+  const float dx = px - cx, dy = py - cy, dz = pz - cz;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+template <int KC>
+__device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k, int heavy,
+                                             int i, int* lds, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
+                                             double* __restrict__ nz) {
+  constexpr int L = KC + 2;
+  int* const buf = lds;                              // [kSpBuf][KNN_T]
+  int* const tcum = lds + kSpBuf * KNN_T;            // [kSpCum][KNN_T]
+  int* const tlo = lds + (kSpBuf + kSpCum) * KNN_T;  // [kSpRows][KNN_T]
+  const float4 pq = P[i];
+  const float px = pq.x, py = pq.y, pz = pq.z;
+  const int c[3] = {voxel_coord_g(px, g) - g.minc[0], voxel_coord_g(py, g) - g.minc[1], voxel_coord_g(pz, g) - g.minc[2]};
+  auto defer = [&](int enc, float thr) {
+    const int e = atomicAdd(df.cnt, 1);
+    df.idx[e] = enc;
+    df.thr[e] = thr;
+  };
+  // ---- the block's rows, in memory order (r = 3 (dz + 1) + (dy + 1)) ----
+  const int xl = max(c[0] - 1, 0), xh = min(c[0] + 1, g.dim[0] - 1);
+  int lo[kSpRows], hi[kSpRows];
+#pragma unroll
+  for (int r = 0; r < kSpRows; r++) {
+    const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
+    const bool in = y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2];
+    const int yy = in ? y : c[1], zz = in ? z : c[2];
+    const int a = start[cell_index(g, xl, yy, zz)], b = start[cell_index(g, xh, yy, zz) + 1];
+    lo[r] = in ? a : 0;
+    hi[r] = in ? b : 0;
+  }
+  // A row's last quad may read up to 3 points past the row.  Where the next row of this block (in memory order) starts closer than
+  // that -- sparse layers: a wall's cells are all a grid row holds -- the row keeps whole quads only and its tail, together with the
+  // points in between (real points: harmless candidates), is handed to the next row, so no point is ever seen twice.  Past the end
+  // of the array sit four sentinel points (k_rank_gather).
+  {
+    int next_lo[kSpRows];
+    int nl = INT_MAX;
+#pragma unroll
+    for (int r = kSpRows - 1; r >= 0; r--) {
+      next_lo[r] = nl;
+      if (hi[r] > lo[r]) nl = lo[r];
+    }
+    int carry = -1;
+#pragma unroll
+    for (int r = 0; r < kSpRows; r++) {
+      if (hi[r] > lo[r]) {
+        const int a = carry >= 0 ? carry : lo[r];
+        const int len = hi[r] - a;
+        const bool tight = next_lo[r] - hi[r] < 3;
+        const int keep = tight ? (len & ~3) : len;
+        lo[r] = a;
+        hi[r] = a + keep;
+        carry = tight ? a + keep : -1;
+      }
+    }
+  }
+  // ---- row table, nearest rows first (own row, the four face neighbours, the four diagonal ones) ----
+#pragma unroll
+  for (int j = 0; j < kSpCum; j++) tcum[j * KNN_T] = INT_MAX;
+  int nr = 0, acc = 0;
+  constexpr unsigned long long kOrder = 0x620817354ull;  // r = 4, 5, 3, 7, 1, 8, 0, 2, 6
+#pragma unroll
+  for (int it = 0; it < kSpRows; it++) {
+    const int r = (int)((kOrder >> (4 * it)) & 15ull);
+    const int len = hi[r] - lo[r];
+    if (len > 0) {
+      tlo[nr * KNN_T] = lo[r];
+      tcum[nr * KNN_T] = acc;
+      acc += (len + 3) & ~3;
+      nr++;
+    }
+  }
+  tcum[nr * KNN_T] = acc;
+  if (acc > heavy) {
+    defer(i, INFINITY);
+    return;
+  }
+#if defined(RGC_ABLATE) && RGC_ABLATE == 3  // scripts/ablate_knn.sh: the row table alone
+  nx[i] = (double)acc; ny[i] = (double)nr; nz[i] = 0.0;
+  return;
+#endif
+  // ---- one pass over the candidate stream ----
+  Chain<L> top;
+  top.init();
+  int tau = INT_MAX, ri = 0, ordn = 0;
+  unsigned off = 0, end = 0;
+  int* bp = buf;  // one past the newest buffered key (a column: stride KNN_T)
+  int* const bp_full = buf + (kSpBuf - 4) * KNN_T;
+  auto pop = [&]() {
+    int key = INT_MAX;
+    if (bp != buf) {
+      bp -= KNN_T;
+      key = *bp;
+    }
+    return key;
+  };
+  auto drain = [&]() {  // the next key is on its way from LDS while the current one walks down the chain
+    int key = pop();
+    for (;;) {
+      const int nkey = pop();
+#if defined(RGC_ABLATE) && RGC_ABLATE == 1  // scan + appends + pops, no chain insert (the first slot keeps the tail moving)
+      top.a[L - 1] = min(top.a[L - 1], key ^ 0x40000000);
+#else
+      top.insert(key);
+#endif
+      if (!__any(nkey != INT_MAX)) break;
+      key = nkey;
+    }
+    tau = top.a[L - 1];
+  };
+  // Software pipeline: the loads of quad q + 1 are issued before quad q is processed, so a wave waits for memory once, not once
+  // per quad; two register sets take turns (copying one into the other would wait for the loads just issued).
+  // (off, end, ri, ordn) always describe the NEXT quad to fetch.
+  struct Quad { float4 p0, p1, p2, p3; int ord; bool on; };
+  auto fetch = [&](Quad& q) {
+    if (off >= end && ri < nr) {
+      const int l0 = tlo[ri * KNN_T], c0 = tcum[ri * KNN_T], c1 = tcum[(ri + 1) * KNN_T];
+      off = (unsigned)l0 << 4;
+      end = off + ((unsigned)(c1 - c0) << 4);
+      ordn = c0;
+      ri++;
+    }
+    q.on = off < end;
+    q.ord = ordn;
+    // unconditional loads (a lane that has run out of rows reads the sentinels): a load under a branch is waited for at the
+    // end of its block, which would put the memory latency back into every iteration
+    const unsigned a = q.on ? off : (unsigned)n << 4;
+    q.p0 = point_at(P, a); q.p1 = point_at(P, a + 16); q.p2 = point_at(P, a + 32); q.p3 = point_at(P, a + 48);
+    off += q.on ? 64u : 0u;
+    ordn += q.on ? 4 : 0;
+  };
+  auto process = [&](const Quad& q) {
+    if (q.on) {
+      const int k0 = (__float_as_int(dist2_fma(px, py, pz, q.p0.x, q.p0.y, q.p0.z)) & ~kKeyOrd) | q.ord;
+      const int k1 = (__float_as_int(dist2_fma(px, py, pz, q.p1.x, q.p1.y, q.p1.z)) & ~kKeyOrd) | (q.ord + 1);
+      const int k2 = (__float_as_int(dist2_fma(px, py, pz, q.p2.x, q.p2.y, q.p2.z)) & ~kKeyOrd) | (q.ord + 2);
+      const int k3 = (__float_as_int(dist2_fma(px, py, pz, q.p3.x, q.p3.y, q.p3.z)) & ~kKeyOrd) | (q.ord + 3);
+      if (k0 < tau) { *bp = k0; bp += KNN_T; }
+      if (k1 < tau) { *bp = k1; bp += KNN_T; }
+      if (k2 < tau) { *bp = k2; bp += KNN_T; }
+      if (k3 < tau) { *bp = k3; bp += KNN_T; }
+    }
+    if (__any(bp > bp_full)) drain();
+  };
+  Quad qa, qb;
+  fetch(qa);
+  for (;;) {
+    if (!__any(qa.on)) break;
+    fetch(qb);
+    process(qa);
+    if (!__any(qb.on)) break;
+    fetch(qa);
+    process(qb);
+  }
+  if (__any(bp != buf)) drain();
+#if defined(RGC_ABLATE) && (RGC_ABLATE == 1 || RGC_ABLATE == 2)  // everything up to the end of the scan
+  nx[i] = (double)top.a[0]; ny[i] = (double)top.a[L - 1]; nz[i] = (double)top.a[L / 2];
+  return;
+#endif
+  // ---- the k-th neighbour: is it decided by the keys, and is it provably inside the block? ----
+  int a_km2, a_km1, a_k, a_kp1;
+  if (k == KC) {
+    a_km2 = top.a[KC - 2]; a_km1 = top.a[KC - 1]; a_k = top.a[KC]; a_kp1 = top.a[KC + 1];
+  } else {
+    a_km2 = k >= 2 ? top.at(k - 2) : -(4 << kKeyBits);
+    a_km1 = top.at(k - 1); a_k = top.at(k); a_kp1 = top.at(k + 1);
+  }
+  if (a_km1 >= 0x7f800000) {  // fewer than k candidates in the block (INT_MAX: empty slot; infinite distance: a sentinel point)
+    defer(~i, INFINITY);
+    return;
+  }
+  auto index_of = [&](int key) {  // ordinal -> position in the sorted array: last row whose first ordinal is <= the ordinal
+    const int o = key & kKeyOrd;
+    int r = tcum[8 * KNN_T] <= o ? 8 : 0;
+#pragma unroll
+    for (int s = 4; s > 0; s >>= 1)
+      if (tcum[(r + s) * KNN_T] <= o) r += s;
+    return tlo[r * KNN_T] + (o - tcum[r * KNN_T]);
+  };
+  bool decided = true, swap = false;
+  int kth_key = a_km1;
+  if ((a_k >> kKeyBits) - (a_km1 >> kKeyBits) < 2) {
+    // the k-th and (k+1)-th candidates are less than two key buckets apart: the truncated (and FMA-rounded) keys cannot order them
+    decided = false;
+    if ((a_kp1 >> kKeyBits) - (a_k >> kKeyBits) >= 2 && (a_km1 >> kKeyBits) - (a_km2 >> kKeyBits) >= 2) {  // exactly two contenders
+      const float4 p1 = P[index_of(a_km1)], p2 = P[index_of(a_k)];
+      const float d1 = dist2(px, py, pz, p1), d2 = dist2(px, py, pz, p2);  // the reference's expression, uncontracted
+      decided = d1 != d2;  // an exact tie is decided by the original index: cooperative kernel
+      swap = d2 < d1;
+      if (swap) kth_key = a_k;
+    }
+  }
+  const float thr_up = __int_as_float(kth_key | kKeyOrd);  // upper bound of the k-th squared distance
+  const double q[3] = {(double)px, (double)py, (double)pz};
+  const double bound = cube_bound(g, c, q, 1);
+  const bool proven = (bound == 1.0e300) || (bound > 0.0 && (double)thr_up < bound * bound * (1.0 - 1e-5));
+  if (!proven) {
+    // a k-th "neighbour" farther than the block reaches is one of the stray points behind a row: it says nothing about where to look
+    defer(~i, (double)thr_up < 12.0 * g.res * g.res ? thr_up : INFINITY);
+    return;
+  }
+  if (!decided) {
+    defer(i, thr_up);
+    return;
+  }
+  // ---- neighbour positions replace the keys, then mean / covariance (fast_gicp_impl.hpp:256-262) / normal ----
+  // One pass: with u_j = p_j - q (exact in fp64: both are fp32 values), cov = sum u u^T / k - ubar ubar^T -- the reference's
+  // centred sum up to rounding (|u| <= a few cells, so nothing cancels badly), half the gathers of the two-pass form.
+  // k == KC (the reference's k = 20) runs without per-neighbour guards: a load under a branch is waited for where the branch
+  // ends, which would serialise the gathers.
+  const int idx_k = swap ? index_of(a_k) : 0;
+  double S[6] = {0, 0, 0, 0, 0, 0};
+  auto moments = [&](auto full_tag) {
+    constexpr bool kFull = decltype(full_tag)::value;
+#pragma unroll
+    for (int j = 0; j < KC; j++)
+      if (kFull || j < k) top.a[j] = (swap && j == k - 1) ? idx_k : index_of(top.a[j]);
+    const double qx = (double)px, qy = (double)py, qz = (double)pz;
+    double mx = 0, my = 0, mz = 0;
+#pragma unroll
+    for (int j = 0; j < KC; j++) {
+      if (kFull || j < k) {
+        const float4 cp = P[top.a[j]];
+        const double dx = (double)cp.x - qx, dy = (double)cp.y - qy, dz = (double)cp.z - qz;
+        mx += dx; my += dy; mz += dz;
+        S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz;
+        S[3] += dy * dy; S[4] += dy * dz; S[5] += dz * dz;
+      }
+    }
+    const double inv_k = 1.0 / (double)k;
+    mx *= inv_k; my *= inv_k; mz *= inv_k;
+    S[0] = S[0] * inv_k - mx * mx; S[1] = S[1] * inv_k - mx * my; S[2] = S[2] * inv_k - mx * mz;
+    S[3] = S[3] * inv_k - my * my; S[4] = S[4] * inv_k - my * mz; S[5] = S[5] * inv_k - mz * mz;
+  };
+  if (k == KC) moments(std::true_type{});
+  else moments(std::false_type{});
+  double nrm[3];
+  if (!min_eigenvector_direct(S, nrm)) min_eigenvector(S, nrm);
+  nx[i] = nrm[0];
+  ny[i] = nrm[1];
+  nz[i] = nrm[2];
+}
+
+template <int KC, bool kTarget>
+__global__ void __launch_bounds__(KNN_T)
+k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, int heavy, Deferred df,
+         double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
+  extern __shared__ int slist_sp[];  // [kSpLds][KNN_T]
+  wave_prio(!kTarget);
+  if (df.guard && *df.guard) return;
+  constexpr int kXcdRun = RGC_XCD_RUN;  // XCD-aware block order, as in k_knn_rows
+  const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
+  const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * KNN_T + threadIdx.x;
+  if (i < n) knn_point_sp<KC>(P, start, g, n, k, heavy, i, slist_sp + threadIdx.x, df, nx, ny, nz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2797,6 +3163,17 @@ static Deferred deferred_of(const void* segs, int n) {
 template <int KC>
 static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
                         const int* nseg, double* nx, double* ny, double* nz, const int* guard) {
+  if (g_knn_impl == 2) {
+    Deferred df = deferred_of(segs, n);  // df.cnt was zeroed by k_rank_gather
+    df.guard = guard;
+    const size_t lds = (size_t)kSpLds * KNN_T * sizeof(int);
+    const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, KNN_T), 8 * RGC_XCD_RUN);
+    if (is_target)
+      hipLaunchKernelGGL((k_knn_sp<KC, true>), dim3(nb), dim3(KNN_T), lds, s, P, start, g, n, k, g_sp_heavy, df, nx, ny, nz);
+    else
+      hipLaunchKernelGGL((k_knn_sp<KC, false>), dim3(nb), dim3(KNN_T), lds, s, P, start, g, n, k, g_sp_heavy, df, nx, ny, nz);
+    return;
+  }
   if (g_knn_impl == 0) {
     const size_t ldsr = (size_t)(k + 18) * KNN_T * sizeof(int);
     Deferred df = deferred_of(segs, n);  // df.cnt was zeroed by k_rank_gather
@@ -2824,7 +3201,7 @@ static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const in
 template <int KC>
 static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
                         double* nx, double* ny, double* nz, const int* guard) {
-  if (g_knn_impl != 0) return;
+  if (g_knn_impl == 1) return;
   Deferred df = deferred_of(segs, n);
   df.guard = guard;
   // the number of deferred queries is only known on the device: one wave each up to 8192 waves, idle blocks exit at once
