@@ -37,7 +37,7 @@ struct Cloud {
   int n = 0;
   bool ready = false;  // grid + normals (+ voxels for the target) enqueued
   DevBuf in_copy, cell_of, slot_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
-  DevBuf segs, nseg;  // row segments of the tiled kNN kernel
+  DevBuf segs;  // deferred-query list of the bulk kNN kernel: [count, pad x15][query n][bound n]
   rgck::Grid grid{};
   // speculative grid: the previous cloud's grid, widened, re-used without the bounding-box round trip; k_count guards it
   rgck::Grid spec_grid{};
@@ -169,7 +169,7 @@ void release(DevBuf& b) {
 }
 
 void release_cloud(Cloud& cl) {
-  for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.slot_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs, &cl.nseg,
+  for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.slot_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs,
                     &cl.cell_voxel, &cl.vox, &cl.vox_cell})
     release(*b);
 }
@@ -251,7 +251,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     // same neighbours on any grid: a raw 64-beam sweep puts thousands of points into the 1 m cells near the sensor (every query
     // scans its whole cell: O(c^2)), so its cell size follows the crowding measured on the previous frame of the sequence.
     const double res = is_target ? c->prm.voxel_res : (c->src_res > 0.0 ? c->src_res : (c->src_res_auto > 0.0 ? c->src_res_auto : c->prm.voxel_res));
-    const bool spec = c->spec_on && !c->lm_host && rgck::knn_impl() != 1 && cl.spec_ok && cl.spec_grid.res == res && !force_bbox;
+    const bool spec = c->spec_on && !c->lm_host && cl.spec_ok && cl.spec_grid.res == res && !force_bbox;
     rgck::Grid g{};
     if (spec) {
       g = cl.spec_grid;
@@ -315,8 +315,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (nc1 / 2048 + 2)))) return rc;
     if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.P, sizeof(float4) * ((size_t)n + 4)))) return rc;
-    if ((rc = ensure(c, cl.segs, rgck::segment_bytes(n)))) return rc;
-    if ((rc = ensure(c, cl.nseg, 64))) return rc;
+    if ((rc = ensure(c, cl.segs, rgck::deferred_bytes(n)))) return rc;
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
@@ -332,16 +331,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
                      is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23));
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p, hi);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
-                      (float4*)cl.P.p, rgck::knn_impl() != 1 ? (int*)cl.segs.p : nullptr, hi);
-    if (rgck::knn_impl() == 1) {
-      HIPCHK(c, hipMemsetAsync(cl.nseg.p, 0, sizeof(int), s));
-      rgck::segments(s, (const int*)cl.start.p, cl.grid, cl.segs.p, (int*)cl.nseg.p);
-    }
+                      (float4*)cl.P.p, (int*)cl.segs.p, hi);
   }
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n, s);
-    rgck::knn_rows(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (const int*)cl.nseg.p,
-                   (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr);
+    rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
+                   (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr);
   }
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COOP : RGC_K_KNN_COOP_SRC, n, s);
@@ -866,9 +861,6 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   rgc_ctx* c = new (std::nothrow) rgc_ctx();
   if (!c) return RGC_ERR_HIP;
   c->device = hip_device;
-  if (const char* e = getenv("RGC_KNN_IMPL")) rgck::set_knn_impl(strcmp(e, "tile") == 0 ? 1 : (strcmp(e, "sp") == 0 ? 2 : 0));
-  if (const char* e = getenv("RGC_KNN_HEAVY")) { const int v = atoi(e); if (v > 0) rgck::set_knn_heavy(v); }
-  if (const char* e = getenv("RGC_KNN_JUMP")) { const int v = atoi(e); if (v >= 0) rgck::set_knn_jump(v); }
   rgc_default_params(&c->prm);
   if (params) {
     int rc = check_params(c, params);
@@ -1020,7 +1012,6 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     memcpy(in.x0, x0, sizeof(x0));
     in.rot_eps = P.rotation_eps; in.trans_eps = P.translation_eps; in.init_factor = P.lm_init_lambda_factor;
     in.max_outer = P.max_iterations; in.max_inner = P.lm_max_iterations;
-    const bool rows_impl = rgck::knn_impl() != 1;
     bool solved = false;
     if (c->lm_persist && nb <= 256) {  // one workgroup per CU at most: co-residency is certain
       // the whole solve (and the fitness behind it) in one enqueue, one read-back
@@ -1029,7 +1020,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
         rgck::lm_run(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
                      c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
                      (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, in, c->lm_gen, c->d_small + 7,
-                     rows_impl ? c->tgt.segs.p : nullptr, rows_impl ? c->src.segs.p : nullptr);
+                     c->tgt.segs.p, c->src.segs.p);
       }
       if (fitness) {
         ProfScope ps(c, RGC_K_FITNESS, n);
@@ -1060,7 +1051,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
           rgck::lm_step(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
                         c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
                         (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p,
-                        first_step ? &in : nullptr, c->d_small + 7, rows_impl ? c->tgt.segs.p : nullptr, rows_impl ? c->src.segs.p : nullptr),
+                        first_step ? &in : nullptr, c->d_small + 7, c->tgt.segs.p, c->src.segs.p),
           first_step = false;
       }
       if (fitness) {  // getFitnessScore at the final pose, chained blindly: the kernel is a no-op unless the LM is done
@@ -1559,7 +1550,7 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   if (c->tgt.ready) { int rc = fetch_nvox(c); if (rc) return rc; }
   // queries the bulk kNN kernel handed to the cooperative kernel (first int of the deferred-list buffer)
   if (!c->deferred_known) c->stats.deferred_target = c->stats.deferred_source = 0;
-  if (!c->deferred_known && rgck::knn_impl() != 1) {
+  if (!c->deferred_known) {
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     if (c->tgt.ready && c->tgt.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_target, c->tgt.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (c->src.ready && c->src.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_source, c->src.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -61,18 +61,12 @@ void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cn
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
                  const int* order_tmp, float4* P, int* zero_me = nullptr, int hi = 0);
 // ---- C2: exact kNN + PLANE covariance -> unit normal ----
-// row segments (work items of the tiled kNN kernel): segs needs segment_bytes(n) bytes, *nseg must be 0 on entry
-void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg);
-size_t segment_bytes(int n);
-void set_knn_impl(int impl);  // 0 = rows (default), 1 = LDS tile
-int knn_impl();
-void set_knn_heavy(int v);
-void set_knn_jump(int v);
-void set_sp_heavy(int v);
-// bulk kernel (one lane per query; defers expensive queries) then the cooperative kernel (one wave per deferred query)
-void knn_rows(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-              const int* nseg, double* nx, double* ny, double* nz, const int* guard = nullptr);
-void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
+// bulk kernel (one lane per query; defers what it cannot finish) then the cooperative kernel (one wave per deferred query).
+// deferred: deferred_bytes(n) bytes, whose first int (the count) must be 0 on entry (rank_gather's zero_me)
+size_t deferred_bytes(int n);
+void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
+              double* ny, double* nz, const int* guard = nullptr);
+void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard = nullptr);
 // ---- C3: Gaussian voxel map ----
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,

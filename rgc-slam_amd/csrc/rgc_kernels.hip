@@ -11,8 +11,8 @@
 // the row walkers, the Jacobi solver, the block reduction -- are shared by nearly every kernel and stay inlinable):
 //   grid build      k_bbox, k_count, k_cells_scan_{block,sums,add}, k_place, k_rank_gather (+ k_scan_*, k_scatter for the
 //                   pcl::VoxelGrid path of rgc_pre.hip)
-//   C2 kNN + cov    TopK, scan_range_*, for_each_cube_row(_lds), knn_point, k_knn_rows (bulk, one lane per query),
-//                   coop_kth, k_knn_coop (deferred queries, one wave per query), k_segments / k_knn_tile (A/B knob)
+//   C2 kNN + cov    Chain, knn_point_sp, k_knn_sp (bulk, one lane per query, one pass), TopK, coop_kth, k_knn_coop (deferred
+//                   queries, one wave per query)
 //   C3 voxel map    k_voxel_build
 //   C4-C7 solve     linearize_point, error_point, block_reduce_store, last_block_arrive, block_fold_rows, k_lm_step (default
 //                   driver), k_lm_run (persistent A/B knob), k_linearize / k_error / k_fold / k_lm_try (public fine seam)
@@ -617,34 +617,9 @@ __device__ __forceinline__ float4 point_at(const float4* __restrict__ P, unsigne
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(P) + byte_off);
 }
 
-// neighbourhood mean / covariance in fp64 (fast_gicp_impl.hpp:256-262) and the PLANE normal
-__device__ __forceinline__ void normal_from_list(const float4* __restrict__ P, const int* list, int lstride, int k, double nrm[3]) {
-  double mx = 0, my = 0, mz = 0;
-  for (int j = 0; j < k; j++) {
-    const float4 cp = P[list[j * lstride]];
-    mx += (double)cp.x;
-    my += (double)cp.y;
-    mz += (double)cp.z;
-  }
-  const double inv_k = 1.0 / (double)k;
-  mx *= inv_k; my *= inv_k; mz *= inv_k;
-  double S[6] = {0, 0, 0, 0, 0, 0};
-  for (int j = 0; j < k; j++) {
-    const float4 cp = P[list[j * lstride]];
-    const double dx = (double)cp.x - mx, dy = (double)cp.y - my, dz = (double)cp.z - mz;
-    S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz;
-    S[3] += dy * dy; S[4] += dy * dz; S[5] += dz * dz;
-  }
-#pragma unroll
-  for (int e = 0; e < 6; e++) S[e] *= inv_k;
-  min_eigenvector(S, nrm);
-}
-
-// ---- generic exact search by ROWS ---------------------------------------------------------------------------
 // Cells of one (y,z) grid row are consecutive in the sorted array, so the candidates of the cube of cells
 // [c-r, c+r]^3 are (2r+1)^2 CONTIGUOUS ranges: two start[] loads per row instead of two per cell, and no walk
-// through empty cells.  If the k-th distance found in cube(r) is not provably exact the search JUMPS to the
-// smallest cube that can prove it (restarting the chain), instead of growing shell by shell.
+// through empty cells (the 1-NN searches of C8 / f4).
 template <typename F>
 __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3], int r, const int* __restrict__ start, F&& f) {
   const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
@@ -667,240 +642,15 @@ __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3],
   }
 }
 
-// The same walk with the row ranges parked in a per-lane LDS column (rng, stride lstride, >= 16 slots): eight rows =
-// sixteen start[] loads in flight per step, and f is instantiated ONCE (a loop over the parked rows) instead of once per
-// unrolled row -- the chain insert inside f is 160 instructions per candidate slot.
-// Returns false -- the walk is abandoned -- as soon as the cube turns out to hold more than `budget` candidates.
-// rad < inf clips the cube to the BALL of that radius around q: a row whose nearest wall is farther than rad, and the
-// cells of a row beyond the ball's x extent, hold neither a neighbour nor a tie when rad is (an upper bound of) the k-th
-// distance -- for a cube of radius 2 that is about half of its cells.
-template <typename F>
-__device__ __forceinline__ bool for_each_cube_row_lds(const Grid& g, const int c[3], const double q[3], double rad, int r,
-                                                      const int* __restrict__ start, int* rng, int lstride, int budget, F&& f) {
-  const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
-  const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
-  int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
-  const bool clip = rad < 1.0e30;
-  const double rad2 = rad * rad;
-  if (clip) {  // floor() of a slightly-too-small / too-large coordinate only ever keeps an extra cell
-    x0 = max(x0, (int)floor((q[0] - rad) / g.res - 0.5) - g.minc[0]);
-    x1 = min(x1, (int)floor((q[0] + rad) / g.res - 0.5) - g.minc[0]);
-  }
-  if (x0 > x1) return true;
-  int seen = 0;
-  for (int z = z0; z <= z1; z++) {
-    double dzw = 0.0;
-    if (z < c[2]) dzw = q[2] - ((double)(z + g.minc[2]) + 1.5) * g.res;
-    else if (z > c[2]) dzw = ((double)(z + g.minc[2]) + 0.5) * g.res - q[2];
-    if (clip && dzw > rad) continue;
-    for (int y = y0; y <= y1; y += 8) {
-      int a[8], b[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int yy = min(y + u, y1);
-        a[u] = start[cell_index(g, x0, yy, z)];
-        b[u] = start[cell_index(g, x1, yy, z) + 1];
-        if (clip) {
-          double dyw = 0.0;
-          if (yy < c[1]) dyw = q[1] - ((double)(yy + g.minc[1]) + 1.5) * g.res;
-          else if (yy > c[1]) dyw = ((double)(yy + g.minc[1]) + 0.5) * g.res - q[1];
-          if (dyw > 0.0 && dyw * dyw + (dzw > 0.0 ? dzw * dzw : 0.0) > rad2) b[u] = a[u];  // the ball does not reach this row
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        rng[(2 * u) * lstride] = a[u];
-        const int e = (y + u <= y1) ? b[u] : a[u];  // rows past the cube: empty
-        rng[(2 * u + 1) * lstride] = e;
-        seen += e - a[u];
-      }
-      if (seen > budget) return false;
-#pragma unroll 1
-      for (int u = 0; u < 8; u++) f(rng[(2 * u) * lstride], rng[(2 * u + 1) * lstride]);
-    }
-  }
-  return true;
-}
-
-template <int KC>
-__device__ __forceinline__ void scan_range_topk(const float4* __restrict__ P, int s0, int s1, float px, float py, float pz, TopK<KC>& top) {
-  int s = s0;
-  unsigned off = (unsigned)s0 << 4;
-  for (; s + 4 <= s1; s += 4, off += 64) {  // full quads: four independent 16-byte loads, no validity selects
-    const float4 c0 = point_at(P, off), c1 = point_at(P, off + 16), c2 = point_at(P, off + 32), c3 = point_at(P, off + 48);
-    const float x0 = dist2(px, py, pz, c0), x1 = dist2(px, py, pz, c1), x2 = dist2(px, py, pz, c2), x3 = dist2(px, py, pz, c3);
-#if defined(RGC_EXP) && RGC_EXP >= 3
-    top.a[KC - 1] = min(top.a[KC - 1], __float_as_int(fminf(fminf(x0, x1), fminf(x2, x3))));
-#else
-    if (__any(top.improves(x0))) top.insert(x0);
-    if (__any(top.improves(x1))) top.insert(x1);
-    if (__any(top.improves(x2))) top.insert(x2);
-    if (__any(top.improves(x3))) top.insert(x3);
-#endif
-  }
-  if (s < s1) {  // 1..3 left: clamped loads, +inf for the missing ones
-    const int rem = s1 - s;
-    const float4 c0 = point_at(P, off), c1 = point_at(P, off + (rem > 1 ? 16u : 0u)), c2 = point_at(P, off + (rem > 2 ? 32u : 0u));
-    const float x0 = dist2(px, py, pz, c0);
-    const float d1 = dist2(px, py, pz, c1), d2 = dist2(px, py, pz, c2);
-    const float x1 = rem > 1 ? d1 : INFINITY, x2 = rem > 2 ? d2 : INFINITY;
-#if defined(RGC_EXP) && RGC_EXP >= 3
-    top.a[KC - 1] = min(top.a[KC - 1], __float_as_int(fminf(x0, fminf(x1, x2))));
-#else
-    if (__any(top.improves(x0))) top.insert(x0);
-    if (__any(top.improves(x1))) top.insert(x1);
-    if (__any(top.improves(x2))) top.insert(x2);
-#endif
-  }
-}
-
-// append neighbours strictly closer than thr; remember the candidate AT thr with the smallest original index
-__device__ __forceinline__ void collect_one(const float4& cp, int s, bool valid, float px, float py, float pz, float thr, int k, int* list,
-                                            int lstride, int& m, int& tie_s, int& tie_o) {
-  const float x = valid ? dist2(px, py, pz, cp) : INFINITY;
-  if (x < thr) {
-    if (m < k) list[m * lstride] = s;
-    m++;
-  } else if (x == thr) {
-    const int o = __float_as_int(cp.w);
-    if (o < tie_o) { tie_o = o; tie_s = s; }
-  }
-}
-__device__ __forceinline__ void scan_range_collect(const float4* __restrict__ P, int s0, int s1, float px, float py, float pz, float thr,
-                                                   int k, int* list, int lstride, int& m, int& tie_s, int& tie_o) {
-  int s = s0;
-  unsigned off = (unsigned)s0 << 4;
-  for (; s + 4 <= s1; s += 4, off += 64) {
-    const float4 c0 = point_at(P, off), c1 = point_at(P, off + 16), c2 = point_at(P, off + 32), c3 = point_at(P, off + 48);
-    collect_one(c0, s, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-    collect_one(c1, s + 1, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-    collect_one(c2, s + 2, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-    collect_one(c3, s + 3, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-  }
-  if (s < s1) {
-    const int rem = s1 - s;
-    const float4 c0 = point_at(P, off), c1 = point_at(P, off + (rem > 1 ? 16u : 0u)), c2 = point_at(P, off + (rem > 2 ? 32u : 0u));
-    collect_one(c0, s, true, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-    collect_one(c1, s + 1, rem > 1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-    collect_one(c2, s + 2, rem > 2, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o);
-  }
-}
-
-// Bulk-kernel collector: every candidate with d <= thr (thr = the exact k-th distance) is a neighbour unless MORE than
-// k candidates qualify, i.e. several sit exactly at the k-th distance and an index tie-break is needed -- the caller
-// sees m > k and hands the query to the cooperative kernel.  No tie bookkeeping, no .w load, one branch per candidate.
-__device__ __forceinline__ void collect_le(const float4& cp, int s, bool valid, float px, float py, float pz, float thr, int k, int* list,
-                                           int lstride, int& m) {
-  const float x = dist2(px, py, pz, cp);
-  if (valid && x <= thr) {
-    if (m < k) list[m * lstride] = s;
-    m++;
-  }
-}
-__device__ __forceinline__ void scan_range_collect_le(const float4* __restrict__ P, int s0, int s1, float px, float py, float pz, float thr,
-                                                      int k, int* list, int lstride, int& m) {
-  int s = s0;
-  unsigned off = (unsigned)s0 << 4;
-  for (; s + 4 <= s1; s += 4, off += 64) {
-    const float4 c0 = point_at(P, off), c1 = point_at(P, off + 16), c2 = point_at(P, off + 32), c3 = point_at(P, off + 48);
-    collect_le(c0, s, true, px, py, pz, thr, k, list, lstride, m);
-    collect_le(c1, s + 1, true, px, py, pz, thr, k, list, lstride, m);
-    collect_le(c2, s + 2, true, px, py, pz, thr, k, list, lstride, m);
-    collect_le(c3, s + 3, true, px, py, pz, thr, k, list, lstride, m);
-  }
-  if (s < s1) {
-    const int rem = s1 - s;
-    const float4 c0 = point_at(P, off), c1 = point_at(P, off + (rem > 1 ? 16u : 0u)), c2 = point_at(P, off + (rem > 2 ? 32u : 0u));
-    collect_le(c0, s, true, px, py, pz, thr, k, list, lstride, m);
-    collect_le(c1, s + 1, rem > 1, px, py, pz, thr, k, list, lstride, m);
-    collect_le(c2, s + 2, rem > 2, px, py, pz, thr, k, list, lstride, m);
-  }
-}
-
-// thr_hint: k-th distance already known from a smaller cube (INFINITY if fewer than k candidates were seen)
-template <int KC>
-__device__ __forceinline__ void generic_search_rows(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, float px,
-                                                    float py, float pz, const int c[3], int k, int r_done, float thr_hint, int* list,
-                                                    int lstride) {
-  const double q[3] = {(double)px, (double)py, (double)pz};
-  const int rmax = max(max(max(c[0], g.dim[0] - 1 - c[0]), max(c[1], g.dim[1] - 1 - c[1])), max(c[2], g.dim[2] - 1 - c[2]));
-  TopK<KC> top;
-  int r = r_done;
-  float thr = thr_hint;
-  for (;;) {
-    // next cube: the smallest one that can prove the current k-th distance, or twice the size if none is known
-    int rn;
-    if (thr < INFINITY) {
-      const double need = sqrt((double)thr) * (1.0 + 1e-5);
-      rn = r + 1;
-      while (rn < rmax) {
-        const double b = cube_bound(g, c, q, rn);
-        if (b == 1.0e300 || b > need) break;
-        rn++;
-      }
-    } else {
-      rn = 2 * r + 1;
-    }
-    r = min(rn, rmax);
-    top.init();
-    for_each_cube_row(g, c, r, start, [&](int s0, int s1) { scan_range_topk<KC>(P, s0, s1, px, py, pz, top); });
-    thr = top.kth(k);
-    if (r >= rmax) break;  // whole grid scanned
-    if (thr < INFINITY) {
-      const double bound = cube_bound(g, c, q, r);
-      if (bound == 1.0e300) break;
-      if (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5)) break;
-    }
-  }
-  int m = 0, tie_s = -1, tie_o = INT_MAX;
-  for_each_cube_row(g, c, r, start, [&](int s0, int s1) { scan_range_collect(P, s0, s1, px, py, pz, thr, k, list, lstride, m, tie_s, tie_o); });
-  if (m < k && tie_s >= 0) { list[m * lstride] = tie_s; m++; }
-  while (m < k) {  // rare: more than one candidate exactly at the k-th distance is needed; ascending original index
-    const int last_o = tie_o;
-    tie_s = -1;
-    tie_o = INT_MAX;
-    for_each_cube_row(g, c, r, start, [&](int s0, int s1) {
-      for (int s = s0; s < s1; s++) {
-        const float4 cp = P[s];
-        const int o = __float_as_int(cp.w);
-        if (dist2(px, py, pz, cp) == thr && o > last_o && o < tie_o) { tie_o = o; tie_s = s; }
-      }
-    });
-    if (tie_s < 0) break;  // cannot happen for n >= k
-    list[m * lstride] = tie_s;
-    m++;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298): one lane per query, queries in
-// cell order.  The 3x3x3 block of cells around a query is 9 contiguous ranges of the sorted array (one per row);
-// their 18 start[] loads are issued together and candidates are fetched four 16-byte loads at a time, so the lane
-// is not serialised on one memory round trip per candidate.  Neighbouring lanes share cells, hence cache lines.
-//  pass 1: k smallest squared distances in a register chain (v_min/v_max), wave-uniform __any() skip;
-//  pass 2: neighbours closer than the k-th distance appended to a per-lane LDS column ([slot][lane]);
-//  lanes whose k-th distance is not provably inside the scanned block are DEFERRED to a follow-up launch
-//  (crowded own cell -> 3x3x3 block; 3x3x3 block -> generic_search_rows), keeping waves homogeneous.
-// kTarget only separates the two instantiations by NAME (map vs scan) for the profiles.
-// ------------------------------------------------------------------------------------------------
 constexpr int KNN_T = 256;
 #ifndef RGC_XCD_RUN
 #define RGC_XCD_RUN 16
 #endif
-#ifdef RGC_EXP_NOJUMP
-constexpr int kJumpMax = 1;
-#else
-constexpr int kJumpMax = 3;
-#endif  // largest cube radius (cells) the bulk kernel searches inside the lane before deferring
-static int g_knn_heavy = 640;     // candidates in the 3x3x3 block above which a query gets a whole wave (RGC_KNN_HEAVY)
-void set_knn_heavy(int v) { g_knn_heavy = v; }
-static int g_knn_jump = 192;      // candidates an in-lane jump cube may hold before the query is deferred (RGC_KNN_JUMP)
-void set_knn_jump(int v) { g_knn_jump = v; }
 
-// Queries that the lane-per-query kernel cannot finish cheaply -- a crowded own cell that is not decisive (its
-// 3x3x3 block holds thousands of candidates) or a sparse neighbourhood (the search cube must grow) -- are DEFERRED:
-// (query, k-th distance known so far, radius already proven insufficient) goes to a list that k_knn_coop handles
-// with one WAVE per query, so a wave never idles 63 lanes behind one expensive query.
+// Queries the lane-per-query kernel cannot finish -- a sparse neighbourhood whose k-th neighbour is not provably inside the 3x3x3
+// block (the search cube must grow), several candidates at exactly the k-th distance (the original index decides), more candidates
+// than the keys can number -- are DEFERRED: (query, an upper bound of the k-th distance if one is known, whether the block has been
+// scanned) goes to a list that k_knn_coop handles with one WAVE per query, so a wave never idles 63 lanes behind one expensive query.
 struct Deferred {
   int* idx;    // query index i, or ~i when the 3x3x3 block (radius 1) has already been scanned
   float* thr;  // k-th distance seen so far (INFINITY if fewer than k candidates)
@@ -908,202 +658,40 @@ struct Deferred {
   const int* guard;  // speculative grid only: non-zero = some point did not fit the grid, the cloud will be prepared again -- do nothing
 };
 
-template <int KC>
-__device__ __forceinline__ void knn_point(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, int heavy, int jump_budget,
-                                          int i, int* list, int* rng, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
-                                          double* __restrict__ nz) {
-  const float4 pq = P[i];
-  const float px = pq.x, py = pq.y, pz = pq.z;
-  const int c[3] = {voxel_coord1(px, g.res) - g.minc[0], voxel_coord1(py, g.res) - g.minc[1], voxel_coord1(pz, g.res) - g.minc[2]};
-  const double q[3] = {(double)px, (double)py, (double)pz};
-  const int own = cell_index(g, c[0], c[1], c[2]);
-  const int own0 = start[own], own1 = start[own + 1];
-  TopK<KC> top;
-  top.init();
-  float thr = INFINITY;
-  int rdone = -1;
-  // cube r = 0: the query's own cell.  Crowded cells (raw scans near the sensor) resolve here without touching
-  // their 26 neighbours.
-  scan_range_topk<KC>(P, own0, own1, px, py, pz, top);
-  if (own1 - own0 >= k) {
-    thr = top.kth(k);
-    const double bound = cube_bound(g, c, q, 0);
-    if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) rdone = 0;
-  }
-  // The nine row ranges live in a per-lane LDS column (rng[2 r] = first, rng[2 r + 1] = end, stride KNN_T) so that both
-  // passes are LOOPS over rows: unrolled nine-fold, with the 20-slot insert chain inlined at every candidate, the kernel
-  // was 100 KB of code against a 64 KB instruction cache.
-  if (rdone < 0) {
-    // Ball clipping: once the own cell holds >= k points its k-th distance bounds the search ball, and a neighbouring
-    // cell (row) that the ball cannot reach holds no neighbour and no tie -- in a crowded neighbourhood (raw scan near
-    // the sensor: hundreds of points per cell) that is most of the 26, so the query stays cheap instead of "heavy".
-    bool side_lo[3] = {true, true, true}, side_hi[3] = {true, true, true};
-#ifndef RGC_EXP_NOCLIP
-    if (thr < INFINITY) {
-      const double rad = sqrt((double)thr) * (1.0 + 1e-5);
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        side_lo[a] = q[a] - ((double)(c[a] + g.minc[a]) + 0.5) * g.res < rad;
-        side_hi[a] = ((double)(c[a] + g.minc[a]) + 1.5) * g.res - q[a] < rad;
-      }
-    }
-#endif
-    const int xl = max(c[0] - (side_lo[0] ? 1 : 0), 0), xh = min(c[0] + (side_hi[0] ? 1 : 0), g.dim[0] - 1);
-    int lo[9], hi[9];  // registers only until they are parked in LDS: all 18 start[] loads are issued together
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-      const int dy = r % 3 - 1, dz = r / 3 - 1;
-      const int y = c[1] + dy, z = c[2] + dz;
-      const bool in = (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) && (dy >= 0 || side_lo[1]) && (dy <= 0 || side_hi[1]) &&
-                      (dz >= 0 || side_lo[2]) && (dz <= 0 || side_hi[2]);
-      const int yy = in ? y : c[1], zz = in ? z : c[2];
-      const int a = start[cell_index(g, xl, yy, zz)], b = start[cell_index(g, xh, yy, zz) + 1];
-      lo[r] = in ? a : 0;
-      hi[r] = in ? b : 0;
-    }
-    int tot = 0;
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-      tot += hi[r] - lo[r];
-      rng[(2 * r) * KNN_T] = lo[r];
-      rng[(2 * r + 1) * KNN_T] = hi[r];
-    }
-    if (tot > heavy) {  // crowded neighbourhood: thousands of candidates -> one wave for this query
-      const int e = atomicAdd(df.cnt, 1);
-      df.idx[e] = i;
-      df.thr[e] = thr;  // k-th distance inside the own cell if it holds >= k points, else INFINITY
-      return;
-    }
-    // cube r = 1: nine row ranges, the middle one in two pieces around the own cell (already in the chain)
-    // nearest rows first -- the two pieces of the own row, the four face neighbours, the four diagonal ones: the chain's k-th distance
-    // tightens before the far rows are scanned, so fewer of their candidates improve ANY lane of the wave (the 40-op insert is
-    // wave-uniform).  The order changes neither the set nor the k-th distance.
-    constexpr unsigned long long kRowOrder = 0x9720816354ull;  // r = 4, 5, 3, 6, 1, 8, 0, 2, 7, 9 (one nibble each, low first)
-#pragma unroll 1
-    for (int it = 0; it < 10; it++) {
-      const int r = (int)((kRowOrder >> (4 * it)) & 15ull);
-      const int row = r - (r > 4 ? 1 : 0);
-      int a = rng[(2 * row) * KNN_T], b = rng[(2 * row + 1) * KNN_T];
-      if (r == 4) b = own0;
-      if (r == 5) a = own1;
-      scan_range_topk<KC>(P, a, b, px, py, pz, top);
-    }
-    thr = top.kth(k);
-    if (thr < INFINITY) {
-      const double bound = cube_bound(g, c, q, 1);
-      if ((bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5))) rdone = 1;
-    }
-    if (rdone < 0) {
-      // Sparse neighbourhood (far rings of a raw scan, map fringe): the block cannot prove the k-th distance.  JUMP to the
-      // smallest cube that can -- inside the lane while that cube is small: its rows are nearly empty, the cost is the
-      // start[] loads, and queries in sorted order are neighbours, so a wave's lanes jump together.  Larger jumps go to the
-      // cooperative kernel.
-      const int rmax = max(max(max(c[0], g.dim[0] - 1 - c[0]), max(c[1], g.dim[1] - 1 - c[1])), max(c[2], g.dim[2] - 1 - c[2]));
-      int rn = 2;
-      if (thr < INFINITY) {
-        const double need = sqrt((double)thr) * (1.0 + 1e-5);
-        while (rn < rmax) {
-          const double b = cube_bound(g, c, q, rn);
-          if (b == 1.0e300 || b > need) break;
-          rn++;
-        }
-      }
-      rn = min(rn, max(rmax, 1));
-      if (rn <= kJumpMax && rn >= 2) {
-        top.init();
-        // the cube of a sparse query is nearly empty; on the fringe of a dense map it is not (and a lane that chews through
-        // hundreds of candidates alone becomes the tail of the launch): past the budget the walk is abandoned and the query
-        // goes to the cooperative kernel
-        const double rad = thr < INFINITY ? sqrt((double)thr) * (1.0 + 1e-5) : 1.0e300;
-        const bool walked = for_each_cube_row_lds(g, c, q, rad, rn, start, rng, KNN_T, jump_budget,
-                                                  [&](int s0, int s1) { scan_range_topk<KC>(P, s0, s1, px, py, pz, top); });
-        const float t2 = walked ? top.kth(k) : INFINITY;
-        if (t2 < INFINITY) {
-          thr = t2;  // an upper bound of the k-th distance in any case
-          const double bound = cube_bound(g, c, q, rn);
-          if ((bound == 1.0e300) || (bound > 0.0 && (double)t2 < bound * bound * (1.0 - 1e-5))) rdone = rn;
-        }
-      }
-    }
-  }
-  bool done = false;
-#if defined(RGC_EXP) && RGC_EXP >= 2
-  if (rdone >= 0) { nx[i] = thr; ny[i] = thr; nz[i] = thr; return; }
-#endif
-  if (rdone >= 0) {
-    int m = 0;
-    if (rdone == 0) {
-      scan_range_collect_le(P, own0, own1, px, py, pz, thr, k, list, KNN_T, m);
-    } else if (rdone == 1) {
-#pragma unroll 1
-      for (int r = 0; r < 9; r++) scan_range_collect_le(P, rng[(2 * r) * KNN_T], rng[(2 * r + 1) * KNN_T], px, py, pz, thr, k, list, KNN_T, m);
-    } else {
-      for_each_cube_row_lds(g, c, q, sqrt((double)thr) * (1.0 + 1e-5), rdone, start, rng, KNN_T, INT_MAX,
-                            [&](int s0, int s1) { scan_range_collect_le(P, s0, s1, px, py, pz, thr, k, list, KNN_T, m); });
-    }
-    done = (m == k);  // m > k: several candidates exactly at the k-th distance, index tie-break -> cooperative path
-  }
-  if (!done) {
-    const int e = atomicAdd(df.cnt, 1);
-    df.idx[e] = ~i;
-    df.thr[e] = thr;
-    return;
-  }
-  double nrm[3];
-#if defined(RGC_EXP) && RGC_EXP >= 1
-  nrm[0] = list[0]; nrm[1] = list[(k - 1) * KNN_T]; nrm[2] = thr;
-#else
-  normal_from_list(P, list, KNN_T, k, nrm);
-#endif
-  nx[i] = nrm[0];
-  ny[i] = nrm[1];
-  nz[i] = nrm[2];
-}
-
-template <int KC, bool kTarget>
-__global__ void __launch_bounds__(KNN_T)
-k_knn_rows(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, int heavy, int jump_budget, Deferred df,
-           double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ int slist_rows[];  // [k][KNN_T] neighbour list, then [18][KNN_T] row ranges
-  wave_prio(!kTarget);
-  if (df.guard && *df.guard) return;  // points outside a speculative grid were parked in cell 0: their cells must not be looked up
-  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one) and queries are in cell order.
-  // Each XCD takes runs of kXcdRun CONSECUTIVE query blocks (neighbouring cells: their candidates are re-used out of that XCD's L2),
-  // the runs themselves dealt round-robin (whole contiguous eighths of the map differ too much in work: 7 % slower, DESIGN.md).
-  constexpr int kXcdRun = RGC_XCD_RUN;
-  const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
-  const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * KNN_T + threadIdx.x;
-  if (i < n) knn_point<KC>(P, start, g, k, heavy, jump_budget, i, slist_rows + threadIdx.x, slist_rows + k * KNN_T + threadIdx.x, df, nx, ny, nz);
-}
-
 // ------------------------------------------------------------------------------------------------
-// C2, single pass (fast_gicp_impl.hpp:241-298): one lane per query, queries in cell order, the 3x3x3 block as <= 9 row
-// ranges -- like k_knn_rows -- but every candidate is looked at ONCE and the selection costs a few instructions per candidate:
-//  * key = fp32 bit pattern of the squared distance with its low kKeyBits replaced by the candidate's ORDINAL in the lane's
-//    candidate stream.  Keys order like distances (up to 2^-13 relative), and the winning keys name the neighbours: no second
-//    pass over the candidates to collect them.
+// C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298), the bulk kernel: one lane per query, queries
+// in cell order (neighbouring lanes share cells, hence cache lines).  A query's 3x3x3 block of cells is 11 PIECES -- contiguous
+// ranges of the sorted array: eight grid rows of three cells and the own row cut into the own cell and its two neighbours -- each
+// with a lower bound of the distance to anything in it.  Every candidate is looked at ONCE and the selection costs a few
+// instructions per candidate:
+//  * key = fp32 bit pattern of the squared distance with its low KB bits replaced by the candidate's ORDINAL in the lane's
+//    candidate stream.  Keys order like distances (up to 2^-13 relative at KB = 10), and the winning keys name the neighbours: no
+//    second pass over the candidates to collect them.
 //  * the k + 2 smallest keys live in a sorted register chain whose insert is ONE v_med3_i32 per slot
 //    (new a[j] = med3(a[j-1], a[j], x): the slots do not depend on each other), half of the compare-exchange form.
 //  * LAZY insertion: a candidate whose key is below the chain's tail is only APPENDED to a small per-lane LDS buffer
 //    (compare + masked store); the buffers are drained into the chains when one fills up.  A wave then pays one insert per
 //    buffered key of its fullest lane -- not one per candidate that improves ANY of its 64 lanes, which is nearly every one.
+//    (min / max / med3 / compare / select are HALF-rate instructions on gfx950 -- profiles/r02_valu_issue.jsonl -- so the insert is
+//    what the kernel must ration.)
+//  * pieces are visited nearest first and one whose distance bound is not below the chain's tail is skipped: the ball clipping of
+//    an exact search, decided with the bound the scan has reached.  A crowded cell next to the sensor is done after its own piece.
 //  * the distance may use FMA here: keys only have to ORDER candidates that are at least two key buckets apart.  Where the k-th
 //    and (k+1)-th keys are closer than that the two candidates are compared by their exact, uncontracted distances
 //    (flann::L2_Simple's expression); a third contender or an exact tie (index order decides) sends the query to the
-//    cooperative kernel, as do blocks that cannot prove the k-th distance, crowded blocks and blocks whose rows touch in memory.
-// Rows are walked as ONE per-lane stream of quads (a lane moves to its next row when the current one is exhausted), so a
-// wave's trip count is its longest lane's total, not the sum of the per-row maxima.  A row's last quad may read up to three
-// points past the row: they are real points of cells outside the block (the row table is rejected otherwise), so they are
-// legitimate candidates and need no masking.
+//    cooperative kernel, as do blocks that cannot prove the k-th distance and blocks with more candidates than ordinals.
+//  * the loads of the next four candidates are in flight while four are processed (two register sets taking turns).
+// Pieces are walked as ONE per-lane stream of quads (a lane moves to its next piece when the current one is exhausted), so a
+// wave's trip count is its longest lane's total, not the sum of per-piece maxima.  A piece's last quad may read up to three
+// points past the piece: real points of cells outside the block (pieces that touch in memory hand their tails over, below), so
+// they are legitimate candidates and need no masking.
+// kTarget separates the two instantiations by NAME (map vs scan) for the profiles and picks the ordinal width.
 // ------------------------------------------------------------------------------------------------
-constexpr int kKeyBits = 10;
-constexpr int kKeyOrd = (1 << kKeyBits) - 1;
+constexpr int kPieceQuads = 1023;  // a piece's length in quads shares its table entry with the piece's distance bound (fp32, low 10 bits cut)
 constexpr int kSpBuf = 12;   // keys waiting to enter the chain, per lane
-constexpr int kSpCum = 16;   // ordinal of each row's first candidate, padded with INT_MAX for the ordinal -> row search
-constexpr int kSpRows = 9;
+constexpr int kSpCum = 16;   // piece table (first ordinals once visited), padded with INT_MAX for the ordinal -> piece search
+constexpr int kSpRows = 11;  // pieces of a 3x3x3 block: 8 rows + the own row in three parts
 constexpr int kSpLds = kSpBuf + kSpCum + kSpRows;  // ints of LDS per lane, as columns [slot][lane]
-static int g_sp_heavy = 1000;  // candidates (rows rounded up to quads) above which a query goes to the cooperative kernel; < 2^kKeyBits
-void set_sp_heavy(int v) { g_sp_heavy = v < kKeyOrd - 3 * kSpRows ? v : kKeyOrd - 3 * kSpRows; }
 
 // a = med3(below, a, x), IN PLACE: the chain's registers stay where they are across the loops they are carried through (with a
 // separate output operand the compiler shuffles all of them at every loop boundary)
@@ -1136,83 +724,114 @@ __device__ __forceinline__ float dist2_fma(float px, float py, float pz, float c
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
-template <int KC>
-__device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k, int heavy,
+template <int KC, int KB>  // KB: low key bits that hold the candidate's ordinal (ordinals < 2^KB)
+__device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
                                              int i, int* lds, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
                                              double* __restrict__ nz) {
   constexpr int L = KC + 2;
+  constexpr int kKeyOrd = (1 << KB) - 1;
+  constexpr int kKeyBits = KB;
   int* const buf = lds;                              // [kSpBuf][KNN_T]
-  int* const tcum = lds + kSpBuf * KNN_T;            // [kSpCum][KNN_T]
+  int* const tmix = lds + kSpBuf * KNN_T;            // [kSpCum][KNN_T]: before a piece is reached {min distance^2 (fp32, low byte cut) | quads}, after: its first ordinal
   int* const tlo = lds + (kSpBuf + kSpCum) * KNN_T;  // [kSpRows][KNN_T]
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int c[3] = {voxel_coord_g(px, g) - g.minc[0], voxel_coord_g(py, g) - g.minc[1], voxel_coord_g(pz, g) - g.minc[2]};
+  const double q[3] = {(double)px, (double)py, (double)pz};
   auto defer = [&](int enc, float thr) {
     const int e = atomicAdd(df.cnt, 1);
     df.idx[e] = enc;
     df.thr[e] = thr;
   };
-  // ---- the block's rows, in memory order (r = 3 (dz + 1) + (dy + 1)) ----
+  // ---- the block's pieces in MEMORY order: rows r = 3 (dz + 1) + (dy + 1) for r != 4 (pieces 0..3, 7..10); the own row (r = 4) as
+  // three pieces cut at multiples of four points from its start: left of the own cell (4), the own cell (5), right of it (6) ----
   const int xl = max(c[0] - 1, 0), xh = min(c[0] + 1, g.dim[0] - 1);
-  int lo[kSpRows], hi[kSpRows];
+  // squared distance from the query to each wall of its cell (rounded down a little: the pieces' lower bounds must never be too high)
+  float wlo2[3], whi2[3];
 #pragma unroll
-  for (int r = 0; r < kSpRows; r++) {
-    const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
+  for (int a = 0; a < 3; a++) {
+    const double wall = ((double)(c[a] + g.minc[a]) + 0.5) * g.res;
+    const double dl = fmax(q[a] - wall, 0.0), dh = fmax(wall + g.res - q[a], 0.0);
+    wlo2[a] = (float)(dl * dl * (1.0 - 1.0e-6));
+    whi2[a] = (float)(dh * dh * (1.0 - 1.0e-6));
+  }
+  int lo[kSpRows], hi[kSpRows];
+  float min2[kSpRows];
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const int dy = r % 3 - 1, dz = r / 3 - 1;
+    const int y = c[1] + dy, z = c[2] + dz;
     const bool in = y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2];
     const int yy = in ? y : c[1], zz = in ? z : c[2];
     const int a = start[cell_index(g, xl, yy, zz)], b = start[cell_index(g, xh, yy, zz) + 1];
-    lo[r] = in ? a : 0;
-    hi[r] = in ? b : 0;
+    const float m = (dy < 0 ? wlo2[1] : (dy > 0 ? whi2[1] : 0.f)) + (dz < 0 ? wlo2[2] : (dz > 0 ? whi2[2] : 0.f));
+    if (r == 4) {
+      const int own = cell_index(g, c[0], c[1], c[2]);
+      const int o0 = start[own], o1 = start[own + 1];
+      const int a1 = a + ((o0 - a) & ~3), a2 = min(a + ((o1 - a + 3) & ~3), b);
+      lo[4] = a;  hi[4] = a1; min2[4] = wlo2[0];
+      lo[5] = a1; hi[5] = a2; min2[5] = 0.f;
+      lo[6] = a2; hi[6] = b;  min2[6] = whi2[0];
+    } else {
+      const int p = r < 4 ? r : r + 2;
+      lo[p] = in ? a : 0;
+      hi[p] = in ? b : 0;
+      min2[p] = m;
+    }
   }
-  // A row's last quad may read up to 3 points past the row.  Where the next row of this block (in memory order) starts closer than
-  // that -- sparse layers: a wall's cells are all a grid row holds -- the row keeps whole quads only and its tail, together with the
-  // points in between (real points: harmless candidates), is handed to the next row, so no point is ever seen twice.  Past the end
-  // of the array sit four sentinel points (k_rank_gather).
+  // A piece's last quad may read up to 3 points past the piece.  Where the next piece of this block (in memory order) starts closer
+  // than that -- sparse layers: a wall's cells are all a grid row holds -- the piece keeps whole quads only and its tail, together
+  // with the points in between (real points: harmless candidates), is handed to the next piece (which inherits its distance bound),
+  // so no point is ever seen twice.  Past the end of the array sit four sentinel points (k_rank_gather).
   {
     int next_lo[kSpRows];
     int nl = INT_MAX;
 #pragma unroll
-    for (int r = kSpRows - 1; r >= 0; r--) {
-      next_lo[r] = nl;
-      if (hi[r] > lo[r]) nl = lo[r];
+    for (int p = kSpRows - 1; p >= 0; p--) {
+      next_lo[p] = nl;
+      if (hi[p] > lo[p]) nl = lo[p];
     }
     int carry = -1;
+    float carry_min2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < kSpRows; r++) {
-      if (hi[r] > lo[r]) {
-        const int a = carry >= 0 ? carry : lo[r];
-        const int len = hi[r] - a;
-        const bool tight = next_lo[r] - hi[r] < 3;
+    for (int p = 0; p < kSpRows; p++) {
+      if (hi[p] > lo[p]) {
+        const int a = carry >= 0 ? carry : lo[p];
+        if (carry >= 0 && carry < lo[p]) min2[p] = fminf(min2[p], carry_min2);
+        const int len = hi[p] - a;
+        const bool tight = next_lo[p] - hi[p] < 3;
         const int keep = tight ? (len & ~3) : len;
-        lo[r] = a;
-        hi[r] = a + keep;
+        lo[p] = a;
+        hi[p] = a + keep;
         carry = tight ? a + keep : -1;
+        carry_min2 = min2[p];
       }
     }
   }
-  // ---- row table, nearest rows first (own row, the four face neighbours, the four diagonal ones) ----
+  // ---- piece table, nearest first: the own cell, its two neighbours in the row, the four face rows, the four diagonal ones ----
 #pragma unroll
-  for (int j = 0; j < kSpCum; j++) tcum[j * KNN_T] = INT_MAX;
-  int nr = 0, acc = 0;
-  constexpr unsigned long long kOrder = 0x620817354ull;  // r = 4, 5, 3, 7, 1, 8, 0, 2, 6
+  for (int j = 0; j < kSpCum; j++) tmix[j * KNN_T] = INT_MAX;
+  int nr = 0;
+  bool heavy_piece = false;
+  constexpr unsigned long long kOrder = 0x820a1937645ull;  // p = 5, 4, 6, 7, 3, 9, 1, 10, 0, 2, 8 (one nibble each, low first)
 #pragma unroll
   for (int it = 0; it < kSpRows; it++) {
-    const int r = (int)((kOrder >> (4 * it)) & 15ull);
-    const int len = hi[r] - lo[r];
+    const int p = (int)((kOrder >> (4 * it)) & 15ull);
+    const int len = hi[p] - lo[p];
     if (len > 0) {
-      tlo[nr * KNN_T] = lo[r];
-      tcum[nr * KNN_T] = acc;
-      acc += (len + 3) & ~3;
+      const int quads = (len + 3) >> 2;
+      heavy_piece |= quads > kPieceQuads;
+      tlo[nr * KNN_T] = lo[p];
+      tmix[nr * KNN_T] = (__float_as_int(min2[p]) & ~kPieceQuads) | quads;
       nr++;
     }
   }
-  tcum[nr * KNN_T] = acc;
-  if (acc > heavy) {
+  if (heavy_piece) {  // a piece of more than 4092 points does not fit the table entry
     defer(i, INFINITY);
     return;
   }
-#if defined(RGC_ABLATE) && RGC_ABLATE == 3  // scripts/ablate_knn.sh: the row table alone
-  nx[i] = (double)acc; ny[i] = (double)nr; nz[i] = 0.0;
+#if defined(RGC_ABLATE) && RGC_ABLATE == 3  // scripts/ablate_knn.sh: the piece table alone
+  nx[i] = (double)nr; ny[i] = 0.0; nz[i] = 0.0;
   return;
 #endif
   // ---- one pass over the candidate stream ----
@@ -1220,6 +839,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   top.init();
   int tau = INT_MAX, ri = 0, ordn = 0;
   unsigned off = 0, end = 0;
+  bool overflow = false;  // more candidates than the keys' ordinals can number: the query goes to the cooperative kernel
   int* bp = buf;  // one past the newest buffered key (a column: stride KNN_T)
   int* const bp_full = buf + (kSpBuf - 4) * KNN_T;
   auto pop = [&]() {
@@ -1249,11 +869,24 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   // (off, end, ri, ordn) always describe the NEXT quad to fetch.
   struct Quad { float4 p0, p1, p2, p3; int ord; bool on; };
   auto fetch = [&](Quad& q) {
-    if (off >= end && ri < nr) {
-      const int l0 = tlo[ri * KNN_T], c0 = tcum[ri * KNN_T], c1 = tcum[(ri + 1) * KNN_T];
-      off = (unsigned)l0 << 4;
-      end = off + ((unsigned)(c1 - c0) << 4);
-      ordn = c0;
+    while (off >= end && ri < nr) {
+      // next piece -- unless nothing in it can be among the k + 2 nearest any more: its lower distance bound is not below (an
+      // upper bound of) the chain's tail: a crowded cell near the sensor is done after its own piece, its 26 neighbours are never
+      // touched.
+      // The piece's table entry is replaced by its first ordinal (skipped pieces: zero length), which index_of() searches.
+      const int mix = tmix[ri * KNN_T];
+      tmix[ri * KNN_T] = ordn;
+      const int quads = mix & kPieceQuads;
+      const bool reach = !(__int_as_float(mix & ~kPieceQuads) >= __int_as_float(tau | kKeyOrd));  // tau == INT_MAX (chain not full): NaN, no skip
+      if (reach) {
+        if (ordn + 4 * quads > kKeyOrd) {
+          overflow = true;
+          ri = nr;
+          break;
+        }
+        off = (unsigned)tlo[ri * KNN_T] << 4;
+        end = off + ((unsigned)quads << 6);
+      }
       ri++;
     }
     q.on = off < end;
@@ -1289,6 +922,10 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     process(qb);
   }
   if (__any(bp != buf)) drain();
+  if (overflow) {
+    defer(i, INFINITY);
+    return;
+  }
 #if defined(RGC_ABLATE) && (RGC_ABLATE == 1 || RGC_ABLATE == 2)  // everything up to the end of the scan
   nx[i] = (double)top.a[0]; ny[i] = (double)top.a[L - 1]; nz[i] = (double)top.a[L / 2];
   return;
@@ -1305,13 +942,13 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     defer(~i, INFINITY);
     return;
   }
-  auto index_of = [&](int key) {  // ordinal -> position in the sorted array: last row whose first ordinal is <= the ordinal
+  auto index_of = [&](int key) {  // ordinal -> position in the sorted array: the last piece whose first ordinal is <= the ordinal
     const int o = key & kKeyOrd;
-    int r = tcum[8 * KNN_T] <= o ? 8 : 0;
+    int r = tmix[8 * KNN_T] <= o ? 8 : 0;
 #pragma unroll
     for (int s = 4; s > 0; s >>= 1)
-      if (tcum[(r + s) * KNN_T] <= o) r += s;
-    return tlo[r * KNN_T] + (o - tcum[r * KNN_T]);
+      if (tmix[(r + s) * KNN_T] <= o) r += s;
+    return tlo[r * KNN_T] + (o - tmix[r * KNN_T]);
   };
   bool decided = true, swap = false;
   int kth_key = a_km1;
@@ -1327,7 +964,6 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     }
   }
   const float thr_up = __int_as_float(kth_key | kKeyOrd);  // upper bound of the k-th squared distance
-  const double q[3] = {(double)px, (double)py, (double)pz};
   const double bound = cube_bound(g, c, q, 1);
   const bool proven = (bound == 1.0e300) || (bound > 0.0 && (double)thr_up < bound * bound * (1.0 - 1e-5));
   if (!proven) {
@@ -1379,15 +1015,20 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
 
 template <int KC, bool kTarget>
 __global__ void __launch_bounds__(KNN_T)
-k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, int heavy, Deferred df,
+k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
          double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
   extern __shared__ int slist_sp[];  // [kSpLds][KNN_T]
   wave_prio(!kTarget);
   if (df.guard && *df.guard) return;
-  constexpr int kXcdRun = RGC_XCD_RUN;  // XCD-aware block order, as in k_knn_rows
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one) and queries are in cell order.
+  // Each XCD takes runs of kXcdRun CONSECUTIVE query blocks (neighbouring cells: their candidates are re-used out of that XCD's L2),
+  // the runs themselves dealt round-robin (whole contiguous eighths of the map differ too much in work: 7 % slower, DESIGN.md).
+  constexpr int kXcdRun = RGC_XCD_RUN;
   const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
   const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * KNN_T + threadIdx.x;
-  if (i < n) knn_point_sp<KC>(P, start, g, n, k, heavy, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+  // the map's keys keep 10 bits for the ordinal (blocks of up to 1023 candidates; one query in ~100 needs the exact tie-break of two
+  // contenders); a raw scan's crowded cells need 12 (4095 candidates, four times as many tie-breaks: cheap for 30 k points)
+  if (i < n) knn_point_sp<KC, kTarget ? 10 : 12>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1603,211 +1244,6 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
     }
     wave_lds_fence();
   }
-}
-
-// ---- work decomposition: row segments -----------------------------------------------------------------------
-// Sorted points of one (y,z) grid row are contiguous.  A segment = consecutive cells of one row holding at most TQ
-// query points (a cell with more than TQ points is split over several segments).  One workgroup per segment.
-constexpr int TQ = 256;     // queries per segment = threads per workgroup
-constexpr int TCH = 3584;   // candidates per LDS chunk (56 KiB of float4)
-constexpr int TXMAX = 32;   // max cells spanned by a segment
-
-struct Seg {
-  int cell0;  // linear index of the first cell
-  int ncell;  // cells spanned along x
-  int q0, q1; // query range in the sorted array
-};
-
-__global__ void k_segments(const int* __restrict__ start, Grid g, Seg* __restrict__ segs, int* nseg) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= g.dim[1] * g.dim[2]) return;
-  const int base = row * g.dim[0];
-  int x = 0;
-  int prev = start[base];
-  while (x < g.dim[0]) {
-    // skip empty cells
-    int e = start[base + x + 1];
-    if (e == prev) { x++; continue; }
-    const int xa = x, q0 = prev;
-    int q1 = e;
-    if (q1 - q0 > TQ) {  // one crowded cell -> several segments over sub-ranges of its points
-      for (int s = q0; s < q1; s += TQ) {
-        const int id = atomicAdd(nseg, 1);
-        segs[id] = Seg{base + xa, 1, s, min(s + TQ, q1)};
-      }
-      prev = q1;
-      x++;
-      continue;
-    }
-    x++;
-    while (x < g.dim[0] && x - xa < TXMAX) {
-      const int e2 = start[base + x + 1];
-      if (e2 - q0 > TQ) break;
-      q1 = e2;
-      x++;
-    }
-    // trim trailing empty cells
-    int xb = x - 1;
-    while (xb > xa && start[base + xb] == q1) xb--;
-    const int id = atomicAdd(nseg, 1);
-    segs[id] = Seg{base + xa, xb - xa + 1, q0, q1};
-    prev = q1;
-  }
-}
-
-int segment_bound(const Grid& g, int n) {
-  const long long rows = (long long)g.dim[1] * g.dim[2];
-  const long long b = 2ll * n / TQ + rows * (g.dim[0] / TXMAX + 2) + 16;
-  return (int)(b < n ? b : n);
-}
-
-// ------------------------------------------------------------------------------------------------
-// C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298), LDS-tiled.
-// One workgroup per row segment, one lane per query.  The candidates of the segment -- the 9 neighbouring grid
-// rows, each a CONTIGUOUS range of the sorted array -- are staged through LDS in coalesced 16-byte loads, in chunks
-// of TCH points, so the inner loops see LDS latency only and dense cells (hundreds of points) cost bandwidth, not
-// serialized global-memory round trips.
-//  pass 1: K smallest squared distances in a register chain (v_min/v_max), wave-uniform __any() skip;
-//          the lane is RESOLVED if the k-th distance is provably inside its 3x3x3 block of cells.
-//  pass 2: re-scan, append the neighbours closer than the k-th distance to a per-lane LDS column.
-//  Unresolved lanes (sparse areas) and tie overflows fall back to generic_search().
-// kTarget only separates the two instantiations by NAME (map vs scan) for the profiles.
-// ------------------------------------------------------------------------------------------------
-template <int KC, bool kTarget>
-__global__ void __launch_bounds__(TQ)
-k_knn_tile(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int k, const Seg* __restrict__ segs,
-           const int* __restrict__ nseg, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ float4 smem4[];
-  float4* cand = smem4;                   // [TCH]
-  int* slist = (int*)(smem4 + TCH);       // [k][TQ]
-  __shared__ int row_p0[9], row_off[10];
-  if ((int)blockIdx.x >= *nseg) return;
-  const Seg sg = segs[blockIdx.x];
-  const int tid = threadIdx.x;
-  const int i = sg.q0 + tid;
-  const bool active = i < sg.q1;
-  const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
-  const int sx0 = sg.cell0 % dimx, cy = (sg.cell0 / dimx) % dimy, cz = sg.cell0 / (dimx * dimy);
-  const int xa = max(sx0 - 1, 0), xb = min(sx0 + sg.ncell, dimx - 1);
-  if (tid < 9) {
-    const int y = cy + tid % 3 - 1, z = cz + tid / 3 - 1;
-    int lo = 0, hi = 0;
-    if (y >= 0 && y < dimy && z >= 0 && z < dimz) {
-      lo = start[cell_index(g, xa, y, z)];
-      hi = start[cell_index(g, xb, y, z) + 1];
-    }
-    row_p0[tid] = lo;
-    row_off[tid + 1] = hi - lo;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    row_off[0] = 0;
-    for (int r = 1; r <= 9; r++) row_off[r] += row_off[r - 1];
-  }
-  __syncthreads();
-  const int C = row_off[9];
-
-  float px = 0.f, py = 0.f, pz = 0.f;
-  int lo[9], hi[9];
-#pragma unroll
-  for (int r = 0; r < 9; r++) lo[r] = hi[r] = 0;
-  int cxq = 0;
-  if (active) {
-    const float4 pq = P[i];
-    px = pq.x; py = pq.y; pz = pq.z;
-    cxq = voxel_coord1(px, g.res) - g.minc[0];
-    const int xl = max(cxq - 1, 0), xh = min(cxq + 1, dimx - 1);
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-      const int y = cy + r % 3 - 1, z = cz + r / 3 - 1;
-      if (y >= 0 && y < dimy && z >= 0 && z < dimz) {
-        lo[r] = row_off[r] + (start[cell_index(g, xl, y, z)] - row_p0[r]);
-        hi[r] = row_off[r] + (start[cell_index(g, xh, y, z) + 1] - row_p0[r]);
-      }
-    }
-  }
-
-  auto stage = [&](int cbase) {
-    const int cnt = min(TCH, C - cbase);
-    for (int j = tid; j < cnt; j += TQ) {
-      const int jj = cbase + j;
-      int r = 0;
-#pragma unroll
-      for (int t = 1; t < 9; t++) r += (row_off[t] <= jj);
-      cand[j] = P[row_p0[r] + (jj - row_off[r])];
-    }
-  };
-
-  // ---- pass 1 ----
-  TopK<KC> top;
-  top.init();
-  for (int cbase = 0; cbase < C; cbase += TCH) {
-    if (cbase) __syncthreads();
-    stage(cbase);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-      const int l = max(lo[r], cbase) - cbase, h = min(hi[r], cbase + TCH) - cbase;
-      for (int j = l; j < h; j += 2) {
-        const float4 c0 = cand[j];
-        const float4 c1 = cand[min(j + 1, h - 1)];
-        const float x0 = dist2(px, py, pz, c0);
-        const float x1 = (j + 1 < h) ? dist2(px, py, pz, c1) : INFINITY;
-        if (__any(top.improves(fminf(x0, x1)))) {
-          top.insert(x0);
-          top.insert(x1);
-        }
-      }
-    }
-  }
-  const float thr = top.kth(k);
-  bool resolved = false;
-  if (active && thr < INFINITY) {
-    const int c[3] = {cxq, cy, cz};
-    const double q[3] = {(double)px, (double)py, (double)pz};
-    const double bound = cube_bound(g, c, q, 1);
-    resolved = (bound == 1.0e300) || (bound > 0.0 && (double)thr < bound * bound * (1.0 - 1e-5));
-  }
-
-  // ---- pass 2 ----
-  int m = 0, tie_s = -1, tie_o = INT_MAX;
-  for (int cbase = 0; cbase < C; cbase += TCH) {
-    __syncthreads();
-    stage(cbase);
-    __syncthreads();
-    if (resolved) {
-#pragma unroll
-      for (int r = 0; r < 9; r++) {
-        const int l = max(lo[r], cbase) - cbase, h = min(hi[r], cbase + TCH) - cbase;
-        const int gbase = row_p0[r] + cbase - row_off[r];  // LDS slot j -> sorted-array position gbase + j
-        for (int j = l; j < h; j++) {
-          const float4 cp = cand[j];
-          const float x = dist2(px, py, pz, cp);
-          if (x < thr) {
-            if (m < k) slist[m * TQ + tid] = gbase + j;
-            m++;
-          } else if (x == thr) {
-            const int o = __float_as_int(cp.w);
-            if (o < tie_o) { tie_o = o; tie_s = gbase + j; }
-          }
-        }
-      }
-    }
-  }
-  if (!active) return;  // no barriers below
-  if (resolved) {
-    if (m < k && tie_s >= 0) { slist[m * TQ + tid] = tie_s; m++; }
-    if (m < k) resolved = false;  // several candidates exactly at the k-th distance are needed: rare, generic path
-  }
-  if (!resolved) {
-    const int c[3] = {cxq, cy, cz};
-    generic_search_rows<KC>(P, start, g, px, py, pz, c, k, 1, thr, slist + tid, TQ);
-  }
-  double nrm[3];
-  normal_from_list(P, slist + tid, TQ, k, nrm);
-  nx[i] = nrm[0];
-  ny[i] = nrm[1];
-  nz[i] = nrm[2];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3146,62 +2582,27 @@ void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int*
                  const int* order_tmp, float4* P, int* zero_me, int hi) {
   hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi);
 }
-void segments(hipStream_t s, const int* start, Grid g, void* segs, int* nseg) {
-  hipLaunchKernelGGL(k_segments, dim3(nblk((long long)g.dim[1] * g.dim[2], 64)), dim3(64), 0, s, start, g, (Seg*)segs, nseg);
-}
-size_t segment_bytes(int n) { return sizeof(Seg) * (size_t)n + 64; }  // also holds the deferred lists (3 n ints + header)
-static int g_knn_impl = 0;  // 0 = rows + cooperative (default), 1 = LDS tile (experiment knob, RGC_KNN_IMPL=tile)
-void set_knn_impl(int impl) { g_knn_impl = impl; }
-int knn_impl() { return g_knn_impl; }
+size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 
-// deferred list lives in the segment buffer (unused by the default implementation): [cnt, pad x15][idx n][thr n]
-static Deferred deferred_of(const void* segs, int n) {
-  int* base = (int*)const_cast<void*>(segs);
+// deferred list: [cnt, pad x15][idx n][thr n]
+static Deferred deferred_of(const void* buf, int n) {
+  int* base = (int*)const_cast<void*>(buf);
   return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr};
 }
 
 template <int KC>
-static void knn_rows_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-                        const int* nseg, double* nx, double* ny, double* nz, const int* guard) {
-  if (g_knn_impl == 2) {
-    Deferred df = deferred_of(segs, n);  // df.cnt was zeroed by k_rank_gather
-    df.guard = guard;
-    const size_t lds = (size_t)kSpLds * KNN_T * sizeof(int);
-    const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, KNN_T), 8 * RGC_XCD_RUN);
-    if (is_target)
-      hipLaunchKernelGGL((k_knn_sp<KC, true>), dim3(nb), dim3(KNN_T), lds, s, P, start, g, n, k, g_sp_heavy, df, nx, ny, nz);
-    else
-      hipLaunchKernelGGL((k_knn_sp<KC, false>), dim3(nb), dim3(KNN_T), lds, s, P, start, g, n, k, g_sp_heavy, df, nx, ny, nz);
-    return;
-  }
-  if (g_knn_impl == 0) {
-    const size_t ldsr = (size_t)(k + 18) * KNN_T * sizeof(int);
-    Deferred df = deferred_of(segs, n);  // df.cnt was zeroed by k_rank_gather
-    df.guard = guard;
-    const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, KNN_T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
-    if (is_target)
-      hipLaunchKernelGGL((k_knn_rows<KC, true>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, g_knn_jump, df, nx, ny, nz);
-    else
-      hipLaunchKernelGGL((k_knn_rows<KC, false>), dim3(nb), dim3(KNN_T), ldsr, s, P, start, g, n, k, g_knn_heavy, g_knn_jump, df, nx, ny, nz);
-    return;
-  }
-  const size_t lds = sizeof(float4) * TCH + (size_t)k * TQ * sizeof(int);
-  const int nb = segment_bound(g, n);
-  static bool attr_done = false;
-  if (!attr_done) {  // dynamic LDS beyond 64 KiB must be opted into
-    (void)hipFuncSetAttribute((const void*)k_knn_tile<KC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute((const void*)k_knn_tile<KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    attr_done = true;
-  }
-  if (is_target)
-    hipLaunchKernelGGL((k_knn_tile<KC, true>), dim3(nb), dim3(TQ), lds, s, P, start, g, k, (const Seg*)segs, nseg, nx, ny, nz);
-  else
-    hipLaunchKernelGGL((k_knn_tile<KC, false>), dim3(nb), dim3(TQ), lds, s, P, start, g, k, (const Seg*)segs, nseg, nx, ny, nz);
+static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred,
+                        double* nx, double* ny, double* nz, const int* guard) {
+  Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
+  df.guard = guard;
+  const size_t lds = (size_t)kSpLds * KNN_T * sizeof(int);
+  const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, KNN_T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
+  if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true>), dim3(nb), dim3(KNN_T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+  else hipLaunchKernelGGL((k_knn_sp<KC, false>), dim3(nb), dim3(KNN_T), lds, s, P, start, g, n, k, df, nx, ny, nz);
 }
 template <int KC>
 static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
                         double* nx, double* ny, double* nz, const int* guard) {
-  if (g_knn_impl == 1) return;
   Deferred df = deferred_of(segs, n);
   df.guard = guard;
   // the number of deferred queries is only known on the device: one wave each up to 8192 waves, idle blocks exit at once
@@ -3211,10 +2612,10 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
   else
     hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
 }
-void knn_rows(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-              const int* nseg, double* nx, double* ny, double* nz, const int* guard) {
-  if (k <= 20) knn_rows_kc<20>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz, guard);
-  else knn_rows_kc<32>(s, is_target, P, start, g, n, k, segs, nseg, nx, ny, nz, guard);
+void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
+              double* ny, double* nz, const int* guard) {
+  if (k <= 20) knn_bulk_kc<20>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard);
+  else knn_bulk_kc<32>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard);
 }
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
               double* ny, double* nz, const int* guard) {

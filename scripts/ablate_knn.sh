@@ -6,10 +6,10 @@ cd "$GRAFT_REPO_ROOT"
 : > gpurun_out/ablate_knn.jsonl
 for n in 0 1 2 3; do
   RGC_EXTRA_FLAGS="-DRGC_ABLATE=$n" python3 rgc-slam_amd/build.py --force > /dev/null 2>&1
-  t=$(RGC_KNN_IMPL=sp python3 scripts/lab_knn.py 1000000 5 sp 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['target']['knn_cov_target'])")
+  t=$(python3 scripts/lab_knn.py 1000000 5 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['target']['knn_cov_target'])")
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/abl_$n
-  RGC_KNN_IMPL=sp rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU -d /tmp/abl_$n -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prof_frame.py 1000000 3 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU -d /tmp/abl_$n -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prof_frame.py 1000000 3 > /dev/null 2>&1
   cd "$GRAFT_REPO_ROOT"
   python3 - <<PY >> gpurun_out/ablate_knn.jsonl
 import csv, glob, json, collections

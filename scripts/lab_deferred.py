@@ -1,22 +1,27 @@
-"""Developer aid (library built with RGC_EXTRA_FLAGS=-DRGC_LAB): which queries the bulk kNN kernel deferred, and why they are slow."""
+"""Developer aid (library built with RGC_EXTRA_FLAGS=-DRGC_LAB): which queries the bulk kNN kernel deferred, for the map and the scan."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import rgc_slam_amd.synth as synth
 from rgc_slam_amd import registration, _lib
-world, tgt = synth.make_world_and_map(1000000, seed=synth.SEED)
-v = registration.odometer_vgicp(0)
-v.setInputTarget(tgt); v.synchronize()
+world, tgt = synth.make_world_and_map(int(sys.argv[1]) if len(sys.argv) > 1 else 1000000, seed=synth.SEED)
+poses = synth.make_trajectory(4, seed=synth.SEED)
+src = synth.make_scan_n(world, poses[1], 30000, seed=synth.SEED + 100)["xyz"]
 lib = _lib.load()
-cap = 100000
-idx = np.zeros(cap, np.int32); thr = np.zeros(cap, np.float32); cnt = C.c_int(0)
 lib.rgc_lab_deferred.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
-h = v._h if hasattr(v, "_h") else v.ctx
-rc = lib.rgc_lab_deferred(h, 1, idx.ctypes.data, thr.ctypes.data, cap, C.byref(cnt))
-n = cnt.value
-print("rc", rc, "deferred", n)
-idx, thr = idx[:n], thr[:n]
-neg = idx < 0
-print("scanned-but-unproven (~i):", int(neg.sum()), " not scanned / undecided (i):", int((~neg).sum()), " thr=inf:", int(np.isinf(thr).sum()), "nan:", int(np.isnan(thr).sum()))
-print("thr (finite) percentiles", np.percentile(thr[np.isfinite(thr)], [0, 50, 90, 100]) if np.isfinite(thr).any() else None)
-print(list(zip(idx[:40].tolist(), thr[:40].tolist())))
+for res in [None] + [float(a) for a in sys.argv[2:]]:
+    if res is not None: os.environ["RGC_SRC_RES"] = str(res)
+    v = registration.odometer_vgicp(0)
+    v.setInputTarget(tgt); v.setInputSource(src); v.synchronize()
+    for which, cloud in ((1, tgt), (0, src)):
+        if res is not None and which == 1: continue
+        cap = len(cloud)
+        idx = np.zeros(cap, np.int32); thr = np.zeros(cap, np.float32); cnt = C.c_int(0)
+        lib.rgc_lab_deferred(v._h, which, idx.ctypes.data, thr.ctypes.data, cap, C.byref(cnt))
+        n = cnt.value; idx, thr = idx[:n], thr[:n]
+        neg = idx < 0
+        rng = np.linalg.norm(cloud[np.where(neg, ~idx, idx)], axis=1) if n else np.zeros(0)
+        print("src_res", res, "target" if which else "source", "n", len(cloud), "deferred", n, "| unproven (~i):", int(neg.sum()), "of which thr=inf", int((neg & np.isinf(thr)).sum()),
+              "| heavy/unsafe (i, inf):", int((~neg & np.isinf(thr)).sum()), "| undecided (i, finite):", int((~neg & np.isfinite(thr)).sum()),
+              "| range of deferred pts pcts", np.percentile(rng, [10, 50, 90]).round(1) if n else None, flush=True)
+    v.close()

@@ -5,7 +5,7 @@
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and gfx950's FETCH_SIZE reports half of
 wide (16 B per lane) reads (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Gather-shaped reads are uncalibrated: an upper estimate."""
 import csv, glob, json, os, sys, collections
-KIND = [("k_knn_rows<20, true>", "knn_cov_target"), ("k_knn_rows<20, false>", "knn_cov_source"), ("k_knn_coop<20, true>", "knn_coop_target"),
+KIND = [("k_knn_sp<20, true>", "knn_cov_target"), ("k_knn_sp<20, false>", "knn_cov_source"), ("k_knn_coop<20, true>", "knn_coop_target"),
         ("k_knn_coop<20, false>", "knn_coop_source"), ("k_voxel_build", "voxel_build"), ("k_lm_step", "linearize"), ("k_fitness_lm", "fitness")]
 def mean_per_kernel(d, counter):
     acc = collections.defaultdict(list)
