@@ -90,7 +90,13 @@ RGC_API const char* rgc_version(void);
  * the environment restores the immediate check. */
 RGC_API int rgc_set_target(rgc_ctx* ctx, const float* xyz, int n, int stride_bytes);
 RGC_API int rgc_set_source(rgc_ctx* ctx, const float* xyz, int n, int stride_bytes);
-/* same, but xyz is DEVICE memory on the context's device (cloud already resident in HBM). */
+/* same, but xyz is DEVICE memory on the context's device (cloud already resident in HBM).
+ * Streams: the target is prepared on rgc_stream(ctx); the SOURCE is prepared on a second, internal stream so that it overlaps the
+ * (much larger) target's preparation, and rgc_align joins the two.  That internal stream is ordered after everything that was
+ * enqueued on rgc_stream(ctx) before this frame's rgc_set_target* call (or before rgc_set_source* itself when no target preparation
+ * is in flight): a source buffer written by rgc_upload, by the front-end or by the caller's own kernels on rgc_stream(ctx) is safe
+ * to hand over without synchronising, provided those writes were enqueued before rgc_set_target*.  Writes enqueued between
+ * rgc_set_target* and rgc_set_source_device must be complete (synchronised) first. */
 RGC_API int rgc_set_target_device(rgc_ctx* ctx, const float* d_xyz, int n, int stride_bytes);
 RGC_API int rgc_set_source_device(rgc_ctx* ctx, const float* d_xyz, int n, int stride_bytes);
 
@@ -116,6 +122,9 @@ RGC_API int rgc_fitness(rgc_ctx* ctx, const float T[16], double* fitness);
 /* the `output` cloud of align(): pcl::transformPointCloud(*input_, output, final_transformation_)
  * (lsq_registration_impl.hpp:78) in the caller's point order; out stride in bytes (>= 12). */
 RGC_API int rgc_get_aligned(rgc_ctx* ctx, const float T[16], float* out_xyz, int stride_bytes);
+/* the same cloud left on the device: d_out_xyz is a device pointer (n_source * stride_bytes bytes); enqueued on the context's
+ * stream, no synchronisation, no copy -- for callers that consume the aligned cloud on the GPU (the odometer's sub-map insert) */
+RGC_API int rgc_get_aligned_device(rgc_ctx* ctx, const float T[16], float* d_out_xyz, int stride_bytes);
 
 /* getSourceCovariances / getTargetCovariances analogue (fast_gicp.hpp): PLANE-regularised 3x3 covariances
  * (row-major, n*9 doubles) and/or unit normals (n*3 doubles, sign arbitrary), caller point order. */
@@ -227,7 +236,7 @@ RGC_API int  rgc_device_free(rgc_ctx* ctx, void* d_ptr);
 RGC_API int  rgc_upload(rgc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* async on ctx stream */
 RGC_API int  rgc_download(rgc_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous          */
 RGC_API int  rgc_synchronize(rgc_ctx* ctx);
-RGC_API void* rgc_stream(rgc_ctx* ctx); /* the hipStream_t every kernel of this context is launched on */
+RGC_API void* rgc_stream(rgc_ctx* ctx); /* the context's main hipStream_t (everything except the source's preparation, see rgc_set_source_device) */
 
 /* ---- f3: wire and disk formats at the edges of the path ----
  * sensor_msgs/PointCloud2 <-> device arrays without PCL: pcl::fromROSMsg (src/scanRegistration.cpp:107-108) and pcl::toROSMsg

@@ -64,7 +64,9 @@ struct rgc_ctx {
   hipStream_t stream = nullptr;   // main stream: target preprocessing, LM loop, fitness, getters
   hipStream_t stream2 = nullptr;  // source preprocessing runs here, concurrently with the (much larger) target's
   hipEvent_t src_ready = nullptr; // recorded on stream2 after the source is prepared
+  hipEvent_t main_mark = nullptr; // recorded on the main stream before a source is prepared: stream2 waits for it (producers on rgc_stream())
   bool src_pending = false;       // main stream has not yet been ordered after src_ready
+  bool mark_valid = false, main_has_target_prep = false;  // main_mark recorded; a map preparation was enqueued after it and may still run
   char err[512] = {0};
   Cloud src, tgt;
   // per-correspondence state frozen by linearize (fast_vgicp_impl.hpp:104-115)
@@ -234,6 +236,17 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   int* dsm = c->d_small + (is_target ? 0 : 16);
   int* hsm = c->h_small + (is_target ? 0 : 16);
   const int hi = is_target ? 0 : 1;  // the scan's kernels share CUs with the map's kNN launch: raised wave priority
+  // The scan is prepared on stream2, concurrently with the map's preparation on the main stream.  Whatever produced the scan was
+  // enqueued on the main stream (rgc_upload, the front-end, a caller's own kernels on rgc_stream()): stream2 waits for a mark
+  // recorded on the main stream BEFORE this frame's map preparation was enqueued (waiting for the map's kNN launch would serialise
+  // the two) -- i.e. at rgc_set_target*, or here when no map preparation is pending.  See rgc_set_source_device in rgc_hip.h.
+  if (!is_target && c->main_has_target_prep && hipStreamQuery(c->stream) == hipSuccess) c->main_has_target_prep = false;  // it has drained
+  if (is_target || !c->main_has_target_prep) {
+    HIPCHK(c, hipEventRecord(c->main_mark, c->stream));
+    c->mark_valid = true;
+  }
+  if (is_target) c->main_has_target_prep = true;
+  else if (c->mark_valid) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->main_mark, 0));
   {
     ProfScope ps(c, RGC_K_GRID, n, s);
     // bbox accumulators + flag; the map's copy also zeroes [7], its voxel counter ([8] ncorr stays untouched; the scan's
@@ -874,6 +887,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
     ok = ok && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) == hipSuccess;
   }
   ok = ok && hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->main_mark, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_small, 48 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_out, 64 * sizeof(double)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
@@ -916,6 +930,7 @@ void rgc_destroy(rgc_ctx* c) {
   release(c->fit_partials);
   if (c->src_ready) (void)hipEventDestroy(c->src_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->main_mark) (void)hipEventDestroy(c->main_mark);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
@@ -1146,6 +1161,18 @@ int rgc_fitness(rgc_ctx* c, const float T[16], double* fitness) {
   if (!c || !T || !fitness) return RGC_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   return do_fitness(c, T, fitness);
+}
+
+int rgc_get_aligned_device(rgc_ctx* c, const float T[16], float* d_out, int stride_bytes) {
+  if (!c || !T || !d_out) return RGC_ERR_INVALID;
+  if (!c->src.ready) return fail(c, RGC_ERR_NO_INPUT, "source not set");
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = join_source(c);
+  if (rc) return rc;
+  rgck::transform_f32(c->stream, c->src.in, c->src.stride_f, c->src.n, posef_from(T), d_out, stride_bytes / 4);
+  HIPCHK(c, hipGetLastError());
+  return RGC_OK;
 }
 
 int rgc_get_aligned(rgc_ctx* c, const float T[16], float* out, int stride_bytes) {
@@ -1608,6 +1635,7 @@ int rgc_synchronize(rgc_ctx* c) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->main_has_target_prep = false;
   return RGC_OK;
 }
 void* rgc_stream(rgc_ctx* c) { return c ? (void*)c->stream : nullptr; }

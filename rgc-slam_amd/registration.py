@@ -152,6 +152,11 @@ class FastVGICP:
         self._chk(self._L.rgc_get_aligned(self._h, fin.ctypes.data_as(fp), out.ctypes.data_as(fp), 12))
         return out
 
+    def alignedToDevice(self, d_out, stride_bytes=16, T=None):
+        """the `output` cloud of align() written to a device buffer (no copy to the host, no synchronisation)"""
+        t = np.ascontiguousarray(self._final if T is None else T, dtype=np.float32).reshape(16)
+        self._chk(self._L.rgc_get_aligned_device(self._h, t.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(d_out), stride_bytes))
+
     def getFinalTransformation(self):
         return self._final.copy()
 
