@@ -194,6 +194,43 @@ RGC_API int rgc_extract_pose(const float T[16], double q_xyzw[4], double t[3]);
 RGC_API int rgc_imu_preintegrate(const double* stamps, const double* gyr3, const double* acc3 /* may be NULL */, int n,
                                  double prev_time, double cur_time, double dq_xyzw[4], double dq2_xyzw[4] /* NULL ok */,
                                  double dp[3] /* NULL ok */, double dv[3] /* NULL ok */);
+/* B1  the IMU side of the odometer's callbacks: vg_ICP::imu_callback (src/RGC_odometer.cpp:444-486: the first 100 messages are
+ * dropped, biases removed) and ComplementaryFilter (:545-625: median filters over 201 / 41 / 41 accelerometer samples --
+ * Mid_Filter, include/rgc_slam/utility.h -- complementary roll / pitch, integrated yaw) -> IMU.Rwi, the attitude the frame body
+ * initialises the pose from (:866-871) and blends pitch / roll towards (:1206-1214).  Plain host code, no GPU. */
+typedef struct rgc_imu_filter {
+  double ba[3], bg[3];          /* imu_s::ba / bg (utility.h:253-254), subtracted from every sample */
+  int    dropped;               /* of the first 100 messages (:446-451) */
+  int    count;                 /* IMU.count: samples accepted */
+  double t_last;                /* imu_last.t */
+  double roll, pitch, yaw;      /* rad */
+  double roll_last, pitch_last; /* imu_last.roll / pitch */
+  double Rwi[9];                /* IMU.Rwi, row-major */
+  double mf_buf[3][201];        /* Mid_Filter::data_buf of accx_MF(201), accy_MF(41), accz_MF(41) (:39) */
+  int    mf_count[3];
+} rgc_imu_filter;
+RGC_API void rgc_imu_filter_init(rgc_imu_filter* f);
+/* one sensor_msgs/Imu message.  Returns 1 and the bias-free sample (what the callback pushes into accBuf / gyrBuf for
+ * rgc_imu_preintegrate) when the message is accepted, 0 while the first 100 are being dropped, < 0 on error. */
+RGC_API int rgc_imu_filter_push(rgc_imu_filter* f, double stamp, const double acc[3], const double gyr[3], double acc_out[3], double gyr_out[3]);
+
+/* B7  the ground-change detector in front of the fusion (src/RGC_odometer.cpp:1034-1087): a plane mismatch while the IMU pitches
+ * (>= 0.02 twice and |pitch of delta_q_imu| > 0.5 deg) switches the ground factor off for 25 frames, after which the new plane is
+ * re-associated with a remembered one (pitch / roll within 4 deg) or remembered itself.  Plain host code. */
+typedef struct rgc_ground_gate {
+  int    gflag;                 /* :328 */
+  int    changegroundflag;      /* :327, starts at 25 */
+  double q_w_curr_delta[4];     /* :20, x y z w */
+  int    n_history;
+  double history[64][4];        /* histoary_pose (:298); the oldest entry is overwritten beyond 64 */
+} rgc_ground_gate;
+RGC_API void rgc_ground_gate_init(rgc_ground_gate* g);
+RGC_API void rgc_ground_gate_remember(rgc_ground_gate* g);  /* histoary_pose.push_back(q_w_curr_delta) of the first sub-map frame (:969) */
+/* one frame: returns the new gflag (the ground factor is used when USE_GROUND && gflag == 0, :1088) and q_w_curr_f (:1086-1087) */
+RGC_API int rgc_ground_gate_step(rgc_ground_gate* g, const double ground_last[11], const double ground_cur[11], const double q_lidar_xyzw[4],
+                                 const double t_lidar[3], const double dq_imu_xyzw[4] /* NULL: identity */, const double q_w_curr_xyzw[4],
+                                 double q_w_curr_f_xyzw[4]);
+
 /* B7  the pose-fusion problem the reference builds for Ceres (src/RGC_odometer.cpp:1025-1032,1088-1119,1188-1193;
  * factors src/lidarFactor.hpp:132-172,228-265,311-350) */
 typedef struct rgc_fuse_in {

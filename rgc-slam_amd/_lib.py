@@ -38,6 +38,17 @@ class FuseIn(C.Structure):
                 ("ground_cov", C.c_double), ("use_imu", C.c_int), ("q_imu_xyzw", C.c_double * 4), ("max_iterations", C.c_int)]
 
 
+class ImuFilter(C.Structure):
+    _fields_ = [("ba", C.c_double * 3), ("bg", C.c_double * 3), ("dropped", C.c_int), ("count", C.c_int), ("t_last", C.c_double),
+                ("roll", C.c_double), ("pitch", C.c_double), ("yaw", C.c_double), ("roll_last", C.c_double), ("pitch_last", C.c_double),
+                ("Rwi", C.c_double * 9), ("mf_buf", (C.c_double * 201) * 3), ("mf_count", C.c_int * 3)]
+
+
+class GroundGate(C.Structure):
+    _fields_ = [("gflag", C.c_int), ("changegroundflag", C.c_int), ("q_w_curr_delta", C.c_double * 4), ("n_history", C.c_int),
+                ("history", (C.c_double * 4) * 64)]
+
+
 class FeParams(C.Structure):
     _fields_ = [("n_scans", C.c_int), ("min_range", C.c_double), ("max_range", C.c_double), ("use_intensity", C.c_int)]
 
@@ -103,7 +114,7 @@ SYMBOLS = [
     "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align",
     "rgc_fitness", "rgc_get_aligned", "rgc_get_aligned_device", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
-    "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
+    "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_imu_filter_init", "rgc_imu_filter_push", "rgc_ground_gate_init", "rgc_ground_gate_remember", "rgc_ground_gate_step", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
     "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_frontend_device", "rgc_frontend_cloud_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_map_reset", "rgc_map_insert", "rgc_map_evict", "rgc_map_rebase", "rgc_map_commit", "rgc_map_get_info", "rgc_map_download", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
@@ -159,6 +170,14 @@ def load():
     L.rgc_frontend_device.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(FeParams), C.POINTER(FeOut)]
     L.rgc_extract_pose.argtypes = [fp, dp, dp]
     L.rgc_imu_preintegrate.argtypes = [dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp]
+    L.rgc_imu_filter_init.argtypes = [C.POINTER(ImuFilter)]
+    L.rgc_imu_filter_init.restype = None
+    L.rgc_imu_filter_push.argtypes = [C.POINTER(ImuFilter), C.c_double, dp, dp, dp, dp]
+    L.rgc_ground_gate_init.argtypes = [C.POINTER(GroundGate)]
+    L.rgc_ground_gate_init.restype = None
+    L.rgc_ground_gate_remember.argtypes = [C.POINTER(GroundGate)]
+    L.rgc_ground_gate_remember.restype = None
+    L.rgc_ground_gate_step.argtypes = [C.POINTER(GroundGate), dp, dp, dp, dp, dp, dp, dp]
     L.rgc_default_fuse_in.argtypes = [C.POINTER(FuseIn)]
     L.rgc_default_fuse_in.restype = None
     L.rgc_fuse_pose.argtypes = [C.POINTER(FuseIn), dp, dp, ip]

@@ -2,6 +2,7 @@
 // SURVEY.md §7.1 step 7): IMU rotation pre-integration (B1), the pose-fusion solve the reference hands to Ceres (B7)
 // and the pose composition + gravity blend (B8).  Part of librgc_hip.so (C-ABI in include/rgc_hip.h); needs no GPU.
 // Reference citations are relative to /root/reference/rgc_slam/.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -187,6 +188,156 @@ int rgc_imu_preintegrate(const double* stamps, const double* gyr3, const double*
   if (dp) std::memcpy(dp, p, sizeof(p));
   if (dv) std::memcpy(dv, v, sizeof(v));
   return RGC_OK;
+}
+
+// vg_ICP::imu_callback + ComplementaryFilter (src/RGC_odometer.cpp:444-486, 545-625), Mid_Filter (include/rgc_slam/utility.h)
+void rgc_imu_filter_init(rgc_imu_filter* f) {
+  if (!f) return;
+  std::memset(f, 0, sizeof(*f));
+  const double ba[3] = {0.23054, -0.22046, -0.14313}, bg[3] = {0.00127, -0.00061, -0.00267};  // utility.h:253-254
+  std::memcpy(f->ba, ba, sizeof(ba));
+  std::memcpy(f->bg, bg, sizeof(bg));
+  f->Rwi[0] = f->Rwi[4] = f->Rwi[8] = 1.0;
+}
+
+namespace {
+const int kMfSize[3] = {201, 41, 41};  // accx_MF(201), accy_MF(41), accz_MF(41), RGC_odometer.cpp:39
+double mid_filter(rgc_imu_filter* f, int axis, double data) {  // Mid_Filter::MFilter: median of the ring buffer (zeros until it has filled)
+  const int n = kMfSize[axis];
+  f->mf_buf[axis][f->mf_count[axis]] = data;
+  if (++f->mf_count[axis] >= n) f->mf_count[axis] = 0;
+  double tmp[201];
+  std::memcpy(tmp, f->mf_buf[axis], sizeof(double) * n);
+  std::nth_element(tmp, tmp + (n - 1) / 2, tmp + n);  // the bubble sort's element (n - 1) / 2
+  return tmp[(n - 1) / 2];
+}
+double norm_angle(double a) { return a > M_PI ? a - 2 * M_PI : (a < -M_PI ? a + 2 * M_PI : a); }               // utility.h:82-90
+double norm_rp(double a) { return a > M_PI / 2 ? a - M_PI : (a < -M_PI / 2 ? a + M_PI : a); }                   // utility.h:92-100
+}  // namespace
+
+int rgc_imu_filter_push(rgc_imu_filter* f, double t, const double acc[3], const double gyr[3], double acc_out[3], double gyr_out[3]) {
+  if (!f || !acc || !gyr) return RGC_ERR_INVALID;
+  if (f->dropped < 100) {  // :446-451
+    f->dropped++;
+    return 0;
+  }
+  const double rad2deg = 180.0 / M_PI;
+  double a[3], g[3];
+  for (int i = 0; i < 3; i++) { a[i] = acc[i] - f->ba[i]; g[i] = gyr[i] - f->bg[i]; }  // :470-471
+  if (acc_out) std::memcpy(acc_out, a, sizeof(a));
+  if (gyr_out) std::memcpy(gyr_out, g, sizeof(g));
+  f->count++;  // :484
+  // ---- ComplementaryFilter, :545-625 ----
+  double d_t = t - f->t_last;
+  if (f->count == 1) d_t = 0.005;  // first_flag, :554-559 (imu_last = t_imu: the last roll / pitch are this sample's, i.e. still 0)
+  double ax = mid_filter(f, 0, a[0]), ay = mid_filter(f, 1, a[1]), az = mid_filter(f, 2, a[2]);  // :561-563
+  const double k = f->count < 300 ? 0.9 : 0.002;                                                 // :565-572
+  double gx = g[0], gy = g[1], gz = g[2];
+  if (std::fabs(gz * rad2deg) < 0.2) gz = 0;                                                     // :574-577
+  if (f->count > 300) {                                                                           // :579-597
+    double R[9];
+    const double ypr[3] = {0.0, f->pitch * rad2deg, f->roll * rad2deg};
+    ypr2R(ypr, R);
+    const double mx = R[2] * 9.81, my = R[5] * 9.81;  // Rimu * (0, 0, 9.81)
+    const double rx = std::fabs(mx) / std::fabs(ax);
+    if (std::fabs(ax) > 0.3 && rx < 0.8) ax = rx * ax + (1 - rx) * mx;
+    const double ry = std::fabs(my) / std::fabs(ay);
+    if (std::fabs(ay) > 0.3 && ry < 0.8) ay = ry * ay + (1 - ry) * my;
+  }
+  const double roll_acc = std::atan2(ay, az), pitch_acc = -std::atan2(ax, az);                    // :598-599
+  {  // body rates -> Euler rates: inverse of eulerRates2bodyRates(roll, pitch), :206-220, 601-605
+    const double cr = std::cos(f->roll), sr = std::sin(f->roll), cp = std::cos(f->pitch), sp = std::sin(f->pitch);
+    double M[9] = {1, 0, -sp, 0, cr, sr * cp, 0, -sr, cr * cp};
+    double b[3] = {gx, gy, gz};
+    if (solve_sym(M, b, 3)) { gx = b[0]; gy = b[1]; gz = b[2]; }
+  }
+  double roll = k * roll_acc + (1.0 - k) * (f->roll + gx * d_t);                                  // :607-609
+  double pitch = k * pitch_acc + (1.0 - k) * (f->pitch + gy * d_t);
+  double yaw = f->yaw + gz / 0.9998 * d_t;
+  if (std::fabs(gz * rad2deg) > 5.0) {                                                            // :611-616
+    const double low = 0.005;
+    roll = low * roll + (1 - low) * f->roll_last;
+    pitch = low * pitch + (1 - low) * f->pitch_last;
+  }
+  f->roll = norm_rp(roll);                                                                        // :618-621
+  f->pitch = norm_rp(pitch);
+  f->yaw = norm_angle(yaw);
+  const double ypr[3] = {f->yaw * rad2deg, f->pitch * rad2deg, f->roll * rad2deg};
+  ypr2R(ypr, f->Rwi);
+  f->t_last = t;                                                                                  // imu_last = t_imu, :623
+  f->roll_last = f->roll;
+  f->pitch_last = f->pitch;
+  return 1;
+}
+
+// the ground-change detector, src/RGC_odometer.cpp:1034-1087
+void rgc_ground_gate_init(rgc_ground_gate* g) {
+  if (!g) return;
+  std::memset(g, 0, sizeof(*g));
+  g->changegroundflag = 25;  // :327
+  g->q_w_curr_delta[3] = 1.0;  // :20
+}
+namespace {
+void gate_remember(rgc_ground_gate* g, const double q[4]) {
+  const int slot = g->n_history < 64 ? g->n_history++ : 0;
+  std::memcpy(g->history[slot], q, sizeof(double) * 4);
+}
+}  // namespace
+void rgc_ground_gate_remember(rgc_ground_gate* g) {
+  if (g) gate_remember(g, g->q_w_curr_delta);
+}
+int rgc_ground_gate_step(rgc_ground_gate* g, const double gl[11], const double gc[11], const double q_lidar[4], const double t_lidar[3],
+                         const double dq_imu[4], const double q_w_curr[4], double q_w_curr_f[4]) {
+  if (!g || !q_w_curr || !q_w_curr_f) return RGC_ERR_INVALID;
+  const Q qw{q_w_curr[0], q_w_curr[1], q_w_curr[2], q_w_curr[3]};
+  if (gl && gc && q_lidar && t_lidar) {
+    const Q ql{q_lidar[0], q_lidar[1], q_lidar[2], q_lidar[3]};
+    double nc[3];
+    qrot(ql, gc, nc);                                                                  // ground_norm_cur, :1034
+    const double dcur = gc[9] + nc[0] * t_lidar[0] + nc[1] * t_lidar[1] + nc[2] * t_lidar[2];  // :1035
+    double e1 = 0;
+    for (int a = 0; a < 3; a++) { const double d = gl[9] * gl[a] - dcur * nc[a]; e1 += d * d; }
+    e1 = std::sqrt(e1);                                                                // :1036
+    const double e2 = std::fabs(gl[3] * nc[0] + gl[4] * nc[1] + gl[5] * nc[2]);        // :1037
+    double pitch_deg = 0.0;
+    if (dq_imu) {
+      double R[9], ypr[3];
+      q2R(Q{dq_imu[0], dq_imu[1], dq_imu[2], dq_imu[3]}, R);
+      R2ypr(R, ypr);                                                                   // d_ypr, :1039
+      pitch_deg = ypr[1];
+    }
+    if (e1 >= 0.02 && e2 >= 0.02 && std::fabs(pitch_deg) > 0.5) {                      // :1042-1048
+      g->changegroundflag = 0;
+      g->gflag = 1;
+    }
+  }
+  if (g->gflag == 1 && g->changegroundflag < 25) {                                     // :1049-1085
+    g->changegroundflag++;
+    if (g->changegroundflag == 25) {
+      double R[9], now[3], tmp[3], best = 1000.0;
+      q2R(qw, R);
+      R2ypr(R, now);
+      int pick = -1;
+      for (int i = 0; i < g->n_history; i++) {
+        q2R(Q{g->history[i][0], g->history[i][1], g->history[i][2], g->history[i][3]}, R);
+        R2ypr(R, tmp);
+        const double pe = tmp[1] - now[1], re = tmp[2] - now[2];
+        const double e = std::sqrt(pe * pe + re * re);
+        if (e < best) { best = e; pick = i; }
+      }
+      if (best < 4 && pick >= 0) {
+        std::memcpy(g->q_w_curr_delta, g->history[pick], sizeof(double) * 4);
+      } else {
+        std::memcpy(g->q_w_curr_delta, q_w_curr, sizeof(double) * 4);
+        gate_remember(g, g->q_w_curr_delta);
+      }
+      g->gflag = 0;
+    }
+  }
+  const Q qd{g->q_w_curr_delta[0], g->q_w_curr_delta[1], g->q_w_curr_delta[2], g->q_w_curr_delta[3]};
+  const Q qf = qnormalized(qmul(qconj(qd), qw));                                       // :1086-1087
+  q_w_curr_f[0] = qf.x; q_w_curr_f[1] = qf.y; q_w_curr_f[2] = qf.z; q_w_curr_f[3] = qf.w;
+  return g->gflag;
 }
 
 void rgc_default_fuse_in(rgc_fuse_in* in) {

@@ -132,13 +132,16 @@ class HipBackend:
             raise RgcError(rc, "rgc_extract_pose")
         return q, t
 
-    def fuse(self, q_l, t_l, fitness, use_ground, g_last, g_cur, q_wf):
+    def fuse(self, q_l, t_l, fitness, use_ground, g_last, g_cur, q_wf, q_imu=None):
         fin = _lib.FuseIn()
         self._L.rgc_default_fuse_in(C.byref(fin))
         fin.q_lidar_xyzw[:] = list(q_l); fin.t_lidar[:] = list(t_l); fin.fitness = float(fitness)
         fin.use_ground = int(use_ground)
         if use_ground:
             fin.ground_last[:] = list(g_last); fin.ground_cur[:] = list(g_cur); fin.q_w_curr_f_xyzw[:] = list(q_wf)
+        if q_imu is not None:                                                        # USE_IMU && imuflag == 1, :1104-1119
+            fin.use_imu = 1
+            fin.q_imu_xyzw[:] = list(q_imu)
         q, t = np.empty(4), np.empty(3)
         dp = C.POINTER(C.c_double)
         rc = self._L.rgc_fuse_pose(C.byref(fin), q.ctypes.data_as(dp), t.ctypes.data_as(dp), None)
@@ -146,14 +149,84 @@ class HipBackend:
             raise RgcError(rc, "rgc_fuse_pose")
         return q, t
 
-    def compose(self, q_w, t_w, q_f, t_f, t_l):
+    def compose(self, q_w, t_w, q_f, t_f, t_l, R_imu_wl=None):
         qo, to, tl = np.empty(4), np.empty(3), np.empty(3)
         dp = C.POINTER(C.c_double)
         a = [np.ascontiguousarray(x, dtype=np.float64) for x in (q_w, t_w, q_f, t_f, t_l)]
-        rc = self._L.rgc_compose_pose(*[x.ctypes.data_as(dp) for x in a], 0, None, qo.ctypes.data_as(dp), to.ctypes.data_as(dp), tl.ctypes.data_as(dp))
+        R = None if R_imu_wl is None else np.ascontiguousarray(R_imu_wl, dtype=np.float64).reshape(9)
+        rc = self._L.rgc_compose_pose(*[x.ctypes.data_as(dp) for x in a], 0 if R is None else 1, None if R is None else R.ctypes.data_as(dp),
+                                      qo.ctypes.data_as(dp), to.ctypes.data_as(dp), tl.ctypes.data_as(dp))
         if rc:
             raise RgcError(rc, "rgc_compose_pose")
         return qo, to, tl
+
+    # B1: the IMU side (rgc_imu_filter_*, rgc_imu_preintegrate) and the ground-change detector (rgc_ground_gate_*)
+    def imu_filter(self):
+        L, dp = self._L, C.POINTER(C.c_double)
+
+        class _Filter:
+            def __init__(self):
+                self.s = _lib.ImuFilter()
+                L.rgc_imu_filter_init(C.byref(self.s))
+
+            def push(self, t, acc, gyr):
+                a, g = np.ascontiguousarray(acc, np.float64), np.ascontiguousarray(gyr, np.float64)
+                ao, go = np.empty(3), np.empty(3)
+                rc = L.rgc_imu_filter_push(C.byref(self.s), float(t), a.ctypes.data_as(dp), g.ctypes.data_as(dp), ao.ctypes.data_as(dp), go.ctypes.data_as(dp))
+                if rc < 0:
+                    raise RgcError(rc, "rgc_imu_filter_push")
+                return (ao, go) if rc == 1 else None
+
+            @property
+            def Rwi(self):
+                return np.array(self.s.Rwi[:]).reshape(3, 3)
+        return _Filter()
+
+    def imu_preintegrate(self, stamps, gyr, acc, prev_time, cur_time):
+        st, g, a = (np.ascontiguousarray(x, np.float64) for x in (stamps, gyr, acc))
+        dq = np.empty(4)
+        dp = C.POINTER(C.c_double)
+        rc = self._L.rgc_imu_preintegrate(st.ctypes.data_as(dp), g.ctypes.data_as(dp), a.ctypes.data_as(dp), len(st), float(prev_time), float(cur_time),
+                                          dq.ctypes.data_as(dp), None, None, None)
+        if rc:
+            raise RgcError(rc, "rgc_imu_preintegrate")
+        return dq
+
+    def ground_gate(self):
+        L, dp = self._L, C.POINTER(C.c_double)
+
+        class _Gate:
+            def __init__(self):
+                self.s = _lib.GroundGate()
+                L.rgc_ground_gate_init(C.byref(self.s))
+
+            def remember(self):
+                L.rgc_ground_gate_remember(C.byref(self.s))
+
+            def step(self, g_last, g_cur, q_l, t_l, dq_imu, q_w):
+                def p(x):
+                    return None if x is None else np.ascontiguousarray(x, np.float64).ctypes.data_as(dp)
+                keep = [None if x is None else np.ascontiguousarray(x, np.float64) for x in (g_last, g_cur, q_l, t_l, dq_imu, q_w)]
+                qf = np.empty(4)
+                have = g_last is not None and g_cur is not None
+                rc = L.rgc_ground_gate_step(C.byref(self.s), *[None if (x is None or (i < 4 and not have)) else x.ctypes.data_as(dp) for i, x in enumerate(keep)],
+                                            qf.ctypes.data_as(dp))
+                if rc < 0:
+                    raise RgcError(rc, "rgc_ground_gate_step")
+                return rc, qf
+        return _Gate()
+
+    def ypr2R(self, ypr_deg):
+        R, y = np.empty(9), np.ascontiguousarray(ypr_deg, np.float64)
+        dp = C.POINTER(C.c_double)
+        self._L.rgc_ypr2R(y.ctypes.data_as(dp), R.ctypes.data_as(dp))
+        return R.reshape(3, 3)
+
+    def R2ypr_m(self, R):
+        ypr, Rc = np.empty(3), np.ascontiguousarray(R, np.float64).reshape(9)
+        dp = C.POINTER(C.c_double)
+        self._L.rgc_R2ypr(Rc.ctypes.data_as(dp), ypr.ctypes.data_as(dp))
+        return ypr
 
     def R2ypr(self, q):
         x, y, z, w = q
@@ -184,21 +257,25 @@ def _qrot(q, v):
 
 
 class Odometer:
-    """One sequence of the odometry node with USE_IMU = 0 (no IMU in the synthetic sequences; the IMU hooks of the
-    library -- rgc_imu_preintegrate, the IMU block of rgc_fuse_pose, the gravity blend of rgc_compose_pose -- are
-    exercised by tests/test_host_stages.py).  The ground-change detector (:1034-1085) needs the IMU pitch rate and is
-    therefore inactive: gflag stays 0.  Constants: RGC_odometer.cpp:280-310."""
+    """One sequence of the odometry node (vg_ICP: the callbacks' buffering + ICP_thread's frame body), USE_IMU = 0 or 1 like the
+    launch file's switch (launch/run.launch:18).  With the IMU: imu_callback feeds the attitude filter and the sample buffer
+    (:444-486), the gyro's pre-integrated rotation is the registration's initial guess (:883-931, 993-996) and a factor of the
+    fusion (:1104-1119), pitch / roll are blended towards the filter's attitude (:1206-1214) and the first `first_frames` sweeps
+    only initialise the pose from it (:857-882).  The ground-change detector (:1034-1087) runs in both modes (without an IMU its
+    pitch-rate condition never fires).  Not mirrored: the two gravity-direction solves of the first frame (:1121-1186), whose
+    results (g_init, q_body2world) do not enter the pose.  Constants: RGC_odometer.cpp:280-310, 387-393."""
 
     keyframeAddingDistance, keyframeAddingAngle = 0.3, 0.2      # :280-281 (the angle is compared against DEGREES, SURVEY A.9)
     slipwide = 3                                                # :299
     planeResolution1, planeResolution2 = 0.2, 0.3               # :305-306
+    R_il_ypr = (-1.29, -0.15, 0.65)                             # :387, degrees
 
-    def __init__(self, backend, use_ground: bool = True):
+    def __init__(self, backend, use_ground: bool = True, use_imu: bool = False, first_frames: int = 0, init_yaw: float = 0.0):
         self.b = backend
-        self.USE_GROUND = use_ground
+        self.USE_GROUND, self.USE_IMU = use_ground, use_imu
+        self.first_frames, self.init_yaw = first_frames, init_yaw                    # firstflagnum (:303), init_yaw (:358)
         self.q_w_curr, self.t_w_curr = np.array([0, 0, 0, 1.0]), np.zeros(3)
         self.q_last_curr, self.t_last_curr = np.array([0, 0, 0, 1.0]), np.zeros(3)   # para_q / para_t, :26-34
-        self.q_w_curr_delta = np.array([0, 0, 0, 1.0])
         self.full_last = None
         self.ground_last = None
         self.surrounding, self.surrounding_q, self.surrounding_t = [], [], []
@@ -206,10 +283,71 @@ class Odometer:
         self.submapflag = 0
         self.fitness = 1.0
         self.frames = 0
+        self.gate = backend.ground_gate()
+        self.gflag = 0
+        self.prev_time = 0.0
+        self.delta_q_imu = None
+        if use_imu:
+            self.imu = backend.imu_filter()
+            self.imu_buf = []                                                         # accBuf / gyrBuf: (t, acc, gyr), bias-free
+            self.R_il = backend.ypr2R(self.R_il_ypr)
 
-    def process(self, raw_xyzi):
-        """One LiDAR message through front-end + frame body; returns (q_w_curr xyzw, t_w_curr)."""
+    # ---- callbacks' side ----
+    def imu_callback(self, stamp, acc, gyr):
+        """sensor_msgs/Imu -> attitude filter + sample buffer (:444-486)"""
+        s = self.imu.push(stamp, acc, gyr)
+        if s is not None:
+            self.imu_buf.append((float(stamp), s[0], s[1]))
+
+    def _imu_interval(self, t0, t1):
+        """getIMUInterval, :1376-1416"""
+        buf = self.imu_buf
+        if not buf or (t0 <= buf[0][0] and t1 <= buf[0][0]) or not (t1 <= buf[-1][0]):
+            return None
+        while buf[0][0] <= t0:
+            buf.pop(0)
+        out = []
+        while buf[0][0] < t1:
+            out.append(buf.pop(0))
+        out.append(buf[0])
+        return out
+
+    def _begin_frame(self, stamp):
+        """:857-931, 955-956: pose initialisation of the first sweeps and the IMU guess; False = this sweep is dropped"""
+        if self.frames < self.first_frames:
+            self.frames += 1
+            self.prev_time = stamp
+            self.t_w_curr = np.zeros(3)
+            if self.USE_IMU:
+                y = self.b.R2ypr_m(self.imu.Rwi @ self.R_il) + np.array([self.init_yaw, 0.0, 0.0])
+                self.q_w_curr = _R2q(self.b.ypr2R(y))
+            return False
+        if self.USE_IMU:
+            iv = self._imu_interval(self.prev_time, stamp)
+            if iv is None:
+                return False
+            self.delta_q_imu = self.b.imu_preintegrate([x[0] for x in iv], [x[2] for x in iv], [x[1] for x in iv], self.prev_time, stamp)
+            self.q_last_curr = self.delta_q_imu.copy()                               # :929-930
+        self.prev_time = stamp
+        return True
+
+    def _fuse_and_compose(self, q_l, t_l, ground_cur, ground_valid):
+        """:1025-1214: ground-change detector, fusion, composition, gravity blend"""
         b = self.b
+        have = ground_valid and self.ground_last is not None
+        self.gflag, q_wf = self.gate.step(self.ground_last if have else None, ground_cur if have else None, q_l, t_l, self.delta_q_imu, self.q_w_curr)
+        use_ground = self.USE_GROUND and have and self.gflag == 0                    # :1088
+        q_f, t_f = b.fuse(q_l, t_l, self.fitness, use_ground, self.ground_last, ground_cur, q_wf, self.delta_q_imu if self.USE_IMU else None)
+        R_imu = self.imu.Rwi @ self.R_il if self.USE_IMU else None                   # :1209
+        self.q_w_curr, self.t_w_curr, t_lc = b.compose(self.q_w_curr, self.t_w_curr, q_f, t_f, t_l, R_imu)   # :1194-1214
+        self.q_last_curr, self.t_last_curr = q_f, t_lc
+
+    def process(self, raw_xyzi, stamp=None):
+        """One LiDAR message through front-end + frame body; returns (q_w_curr xyzw, t_w_curr), or None for a dropped sweep."""
+        b = self.b
+        stamp = 0.1 * self.frames if stamp is None else float(stamp)
+        if not self._begin_frame(stamp):
+            return None
         fe = b.frontend(raw_xyzi)
         full, ground_cur = fe["cloud"], fe["groundparam"]
         full = b.deskew(full, self.q_last_curr, self.t_last_curr)                    # adjustDistortion, :958
@@ -217,24 +355,17 @@ class Odometer:
             if self.submapflag == 0:                                                 # :963-972
                 self.surrounding.append(self.full_last)
                 self.surrounding_q.append(np.array([0, 0, 0, 1.0])); self.surrounding_t.append(np.zeros(3))
+                self.gate.remember()
                 self.submap = np.concatenate([self.submap, self.full_last])
             self.submapflag += 1
             source = b.voxelgrid(full, self.planeResolution1)                        # :976-983
             target = b.voxelgrid(self.submap, self.planeResolution2)                 # :985-991
             T2 = np.eye(4, dtype=np.float32)                                         # :993-996
-            x, y, z, w = self.q_last_curr
-            T2[:3, :3] = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]).astype(np.float32)
+            T2[:3, :3] = _q2R(self.q_last_curr).astype(np.float32)
             T2[:3, 3] = self.t_last_curr.astype(np.float32)
             T, self.fitness = b.register(source, target, T2)                         # :998-1010
             q_l, t_l = b.extract(T)                                                  # :1011-1016
-            q_wf = _qmul(_qconj(self.q_w_curr_delta), self.q_w_curr)                 # :1086-1087
-            q_wf = q_wf / np.linalg.norm(q_wf)
-            use_ground = self.USE_GROUND and fe["ground_valid"] and self.ground_last is not None
-            q_f, t_f = b.fuse(q_l, t_l, self.fitness, use_ground, self.ground_last, ground_cur, q_wf)   # :1025-1193
-            self.q_w_curr, self.t_w_curr, t_lc = b.compose(self.q_w_curr, self.t_w_curr, q_f, t_f, t_l)  # :1194-1203
-            self.q_last_curr, self.t_last_curr = q_f, t_lc
+            self._fuse_and_compose(q_l, t_l, ground_cur, fe["ground_valid"])         # :1025-1214
             # sub-map maintenance, :1218-1256
             if self.surrounding:
                 yb, yc = b.R2ypr(self.surrounding_q[-1]), b.R2ypr(self.q_w_curr)
@@ -259,6 +390,13 @@ class Odometer:
         return self.q_w_curr.copy(), self.t_w_curr.copy()
 
 
+def _R2q(R):
+    """Eigen's quaternion-from-matrix, positive-trace branch (the attitudes met here are near the identity)"""
+    w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+    return q / np.linalg.norm(q)
+
+
 def _q2R(q):
     x, y, z, w = q
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
@@ -275,16 +413,19 @@ class RollingOdometer(Odometer):
 
     rebase_distance = 50.0   # the origin follows the sensor so that fp32 map coordinates stay < ~64 m (ulp 4e-6 m)
 
-    def __init__(self, backend, use_ground: bool = True, max_keyframes=None, radius: float = 0.0):
-        super().__init__(backend, use_ground)
+    def __init__(self, backend, use_ground: bool = True, max_keyframes=None, radius: float = 0.0, **kw):
+        super().__init__(backend, use_ground, **kw)
         self.max_keyframes = self.slipwide if max_keyframes is None else max_keyframes
         self.radius = radius
         self.origin = np.zeros(3)
         self.kf_q, self.kf_t = None, None
         self.n_commits = 0
 
-    def process(self, raw_xyzi):
+    def process(self, raw_xyzi, stamp=None):
         b = self.b
+        stamp = 0.1 * self.frames if stamp is None else float(stamp)
+        if not self._begin_frame(stamp):
+            return None
         fe = b.frontend(raw_xyzi)
         full, ground_cur = fe["cloud"], fe["groundparam"]
         full = b.deskew(full, self.q_last_curr, self.t_last_curr)                    # adjustDistortion, :958
@@ -294,6 +435,7 @@ class RollingOdometer(Odometer):
                 b.map_reset(self.origin)
                 b.map_insert(self.full_last, np.array([0, 0, 0, 1.0]), np.zeros(3))
                 self.kf_q, self.kf_t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+                self.gate.remember()
             self.submapflag += 1
             source = b.voxelgrid(full, self.planeResolution1)                        # :976-983
             # the guess of :993-996 moved into the map frame: T_w_curr * T_last_curr
@@ -307,12 +449,7 @@ class RollingOdometer(Odometer):
             qi = _qconj(self.q_w_curr)
             q_l = _qmul(qi, q_m)                                                     # back to the delta the fusion expects
             t_l = _qrot(qi, t_m + self.origin - self.t_w_curr)
-            q_wf = _qmul(_qconj(self.q_w_curr_delta), self.q_w_curr)                 # :1086-1087
-            q_wf = q_wf / np.linalg.norm(q_wf)
-            use_ground = self.USE_GROUND and fe["ground_valid"] and self.ground_last is not None
-            q_f, t_f = b.fuse(q_l, t_l, self.fitness, use_ground, self.ground_last, ground_cur, q_wf)   # :1025-1193
-            self.q_w_curr, self.t_w_curr, t_lc = b.compose(self.q_w_curr, self.t_w_curr, q_f, t_f, t_l)  # :1194-1203
-            self.q_last_curr, self.t_last_curr = q_f, t_lc
+            self._fuse_and_compose(q_l, t_l, ground_cur, fe["ground_valid"])         # :1025-1214
             # keyframe test of :1218-1239 against the newest keyframe's pose
             yb, yc = b.R2ypr(self.kf_q), b.R2ypr(self.q_w_curr)
             d = np.float32(self.kf_t - self.t_w_curr)

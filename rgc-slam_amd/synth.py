@@ -312,6 +312,42 @@ def make_trajectory(n_frames: int, seed: int = SEED, dt: float = 0.1):
     return poses
 
 
+def make_imu(poses, dt: float = 0.1, rate: float = 200.0, lead_s: float = 2.5, seed: int = SEED, gyro_sigma: float = 2e-4,
+             acc_sigma: float = 5e-3, ba=(0.23054, -0.22046, -0.14313), bg=(0.00127, -0.00061, -0.00267)):
+    """sensor_msgs/Imu samples for a trajectory of make_trajectory(): (stamps, acc (n,3), gyr (n,3)), raw -- i.e. INCLUDING the biases
+    the odometer subtracts (include/rgc_slam/utility.h:253-254).  Pose k holds at t = k * dt; between poses the body turns at a
+    constant rate (the trajectory's constant-twist segments); the accelerometer sees gravity only (specific force of a platform
+    that does not accelerate; +z up, /root/reference/rgc_slam/src/RGC_odometer.cpp:598-599 reads roll / pitch off it); the platform
+    rests at pose 0 for lead_s seconds first, long enough for the node to drop its first 100 messages and for the attitude filter's
+    fast phase (300 samples, :565-572)."""
+    rng = np.random.default_rng(seed + 17)
+    n_lead = int(round(lead_s * rate))
+    n_move = int(round((len(poses) - 1) * dt * rate))
+    stamps = (np.arange(-n_lead, n_move + 2) / rate).astype(np.float64)
+    acc = np.zeros((len(stamps), 3)); gyr = np.zeros((len(stamps), 3))
+    def log_so3(R):
+        c = min(1.0, max(-1.0, (np.trace(R) - 1) / 2)); th = math.acos(c)
+        w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        return w * (0.5 if th < 1e-9 else th / (2 * math.sin(th)))
+    def exp_so3(w):
+        th = np.linalg.norm(w)
+        if th < 1e-12:
+            return np.eye(3)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+        return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
+    for j, t in enumerate(stamps):
+        k = int(math.floor(t / dt)) if t > 0 else -1
+        if k < 0 or k >= len(poses) - 1:
+            R = poses[0][:3, :3] if k < 0 else poses[-1][:3, :3]
+            w = np.zeros(3)
+        else:
+            w = log_so3(poses[k][:3, :3].T @ poses[k + 1][:3, :3]) / dt
+            R = poses[k][:3, :3] @ exp_so3(w * (t - k * dt))
+        acc[j] = R.T @ np.array([0.0, 0.0, 9.81]) + np.asarray(ba) + rng.normal(0, acc_sigma, 3)
+        gyr[j] = w + np.asarray(bg) + rng.normal(0, gyro_sigma, 3)
+    return stamps, acc, gyr
+
+
 def perturb(T: np.ndarray, rng, trans_sigma: float, rot_sigma_rad: float) -> np.ndarray:
     w = rng.normal(0, rot_sigma_rad, 3)
     th = np.linalg.norm(w)

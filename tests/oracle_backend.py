@@ -40,16 +40,37 @@ class OracleBackend:
         q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
         return q.astype(np.float32).astype(np.float64), T[:3, 3].astype(np.float64)
 
-    def fuse(self, q_l, t_l, fitness, use_ground, g_last, g_cur, q_wf):
+    def fuse(self, q_l, t_l, fitness, use_ground, g_last, g_cur, q_wf, q_imu=None):
         c = dict(q_lidar=np.asarray(q_l), t_lidar=np.asarray(t_l), fitness=float(fitness), use_ground=bool(use_ground),
                  ground_last=np.asarray(g_last) if use_ground else None, ground_cur=np.asarray(g_cur) if use_ground else None,
-                 q_w_curr_f=np.asarray(q_wf), ground_cov=0.2, use_imu=False, q_imu=np.array([0, 0, 0, 1.0]))
+                 q_w_curr_f=np.asarray(q_wf), ground_cov=0.2, use_imu=q_imu is not None,
+                 q_imu=np.asarray(q_imu) if q_imu is not None else np.array([0, 0, 0, 1.0]))
         return pf.fuse(c)
 
-    def compose(self, q_w, t_w, q_f, t_f, t_l):
-        R, t, tl = pf.compose(np.asarray(q_w), np.asarray(t_w), np.asarray(q_f), np.asarray(t_f), np.asarray(t_l), False, None)
+    def compose(self, q_w, t_w, q_f, t_f, t_l, R_imu_wl=None):
+        R, t, tl = pf.compose(np.asarray(q_w), np.asarray(t_w), np.asarray(q_f), np.asarray(t_f), np.asarray(t_l), R_imu_wl is not None, R_imu_wl)
+        if R_imu_wl is not None:                      # the blended attitude comes back as a matrix
+            w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+            q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+            return q / np.linalg.norm(q), t, tl
         q = pf.qmul(np.asarray(q_w), np.asarray(q_f))
         return q / np.linalg.norm(q), t, tl
+
+    # B1: IMU attitude filter, gyro pre-integration, ground-change detector -- the numpy restatements of oracle/py_fusion.py
+    def imu_filter(self):
+        return pf.ImuFilter()
+
+    def imu_preintegrate(self, stamps, gyr, acc, prev_time, cur_time):
+        return pf.imu_delta_q(np.asarray(stamps, float), np.asarray(gyr, float), prev_time, cur_time)
+
+    def ground_gate(self):
+        return pf.GroundGate()
+
+    def ypr2R(self, ypr_deg):
+        return pf.ypr2R(np.asarray(ypr_deg, float))
+
+    def R2ypr_m(self, R):
+        return pf.R2ypr(np.asarray(R, float))
 
     def R2ypr(self, q):
         return pf.R2ypr(pf.q2R(np.asarray(q)))

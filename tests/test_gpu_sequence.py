@@ -41,3 +41,53 @@ def test_sequence_with_ground_constraint():
     # and the estimate follows the true motion (sensor frame of pose 8 vs pose 1 ... coarse sanity, not parity)
     true = np.linalg.inv(poses[1]) @ poses[8]
     assert np.linalg.norm(og.t_w_curr - true[:3, 3]) < 0.5
+
+
+def test_sequence_with_imu():
+    """The launch file's default, USE_IMU = 1 (launch/run.launch:18): imu_callback -> attitude filter + gyro pre-integration as the
+    registration's guess (RGC_odometer.cpp:883-931, 993-996), the IMU factor of the fusion (:1104-1119), the gravity blend
+    (:1206-1214), the pose initialised from the filter's attitude during the first sweeps (:857-882) and the ground-change detector
+    (:1034-1087) -- GPU frame body vs the same frame body on the CPU oracle, per-frame pose deltas within 1e-4 m / 1e-4 rad."""
+    import rgc_slam_amd.synth as synth
+    from rgc_slam_amd import odometry
+    from oracle_backend import OracleBackend
+    world = synth.make_world(half_extent=45.0, seed=synth.SEED)
+    poses = synth.make_trajectory(11, seed=synth.SEED + 2)
+    stamps, acc, gyr = synth.make_imu(poses, seed=synth.SEED + 2)
+    raws = []
+    for k in range(10):
+        sc = synth.make_scan(world, poses[k], n_az=1200, seed=synth.SEED + 70 + k, T_ws_end=poses[k + 1])
+        raws.append(np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32))
+    hb = odometry.HipBackend(0)
+    og = odometry.Odometer(hb, use_imu=True, first_frames=2)
+    oc = odometry.Odometer(OracleBackend(), use_imu=True, first_frames=2)
+    j = 0
+    prev_g = prev_c = None
+    worst_t = worst_r = 0.0
+    n_done = 0
+    for k, raw in enumerate(raws):
+        t_k = 0.1 * (k + 1)                                   # the sweep ends at pose k + 1
+        while j < len(stamps) and stamps[j] <= t_k + 0.011:   # the IMU messages that arrived before the cloud (one past its stamp, :1405-1406)
+            og.imu_callback(stamps[j], acc[j], gyr[j]); oc.imu_callback(stamps[j], acc[j], gyr[j]); j += 1
+        rg, rc = og.process(raw, t_k), oc.process(raw, t_k)
+        assert (rg is None) == (rc is None) == (k < 2)
+        if rg is None:
+            assert np.abs(og.q_w_curr - oc.q_w_curr).max() < 1e-12          # pose initialised from IMU.Rwi * R_il
+            continue
+        (qg, tg), (qc, tc) = rg, rc
+        if prev_g is not None:
+            worst_t = max(worst_t, float(np.abs((tg - prev_g[1]) - (tc - prev_c[1])).max()))
+            worst_r = max(worst_r, abs(_angle(qg, prev_g[0]) - _angle(qc, prev_c[0])))
+        worst_r = max(worst_r, _angle(qg, qc) if n_done < 3 else 0.0)
+        prev_g, prev_c = (qg, tg), (qc, tc)
+        n_done += 1
+    hb.close()
+    assert n_done == 8 and og.delta_q_imu is not None
+    assert worst_t <= 1e-4 and worst_r <= 1e-4, (worst_t, worst_r)
+    # the gyro's pre-integrated rotation of the last sweep is the true one to within the sensor noise (it is the registration's guess)
+    true_dq = poses[9][:3, :3].T @ poses[10][:3, :3]
+    Rg = odometry._q2R(og.delta_q_imu)
+    assert np.abs(Rg - true_dq).max() < 2e-3
+    # and the estimate follows the true motion from the first processed sweep on (coarse sanity, not parity)
+    true = np.linalg.inv(poses[3]) @ poses[10]
+    assert np.linalg.norm(og.t_w_curr - true[:3, 3]) < 0.6

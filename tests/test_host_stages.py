@@ -128,3 +128,72 @@ def test_extract_pose(L):
         if np.dot(qo, q) < 0:
             qo = -qo
         assert np.abs(qo - q).max() < 2e-7 and np.array_equal(to, T[:3, 3].astype(np.float64))
+
+
+def test_imu_filter_vs_restatement(L):
+    """vg_ICP::imu_callback + ComplementaryFilter (RGC_odometer.cpp:444-486, 545-625): the library against oracle/py_fusion.ImuFilter on a
+    synthetic stream -- a resting lead-in (first 100 messages dropped, fast phase of 300), then a turning platform; and a known answer:
+    at rest on a tilted platform the filter settles on the tilt the accelerometer shows."""
+    import rgc_slam_amd.synth as synth
+    from oracle import py_fusion as pf
+    lib, h = L
+    poses = synth.make_trajectory(12, seed=synth.SEED)
+    stamps, acc, gyr = synth.make_imu(poses, seed=synth.SEED)
+    f = lib.ImuFilter(); h.rgc_imu_filter_init(C.byref(f))
+    ref = pf.ImuFilter()
+    ao, go = np.empty(3), np.empty(3)
+    worst, accepted = 0.0, 0
+    for t, a, g in zip(stamps, acc, gyr):
+        rc = h.rgc_imu_filter_push(C.byref(f), float(t), _dp(np.ascontiguousarray(a)), _dp(np.ascontiguousarray(g)), _dp(ao), _dp(go))
+        r = ref.push(float(t), a, g)
+        assert (rc == 1) == (r is not None)
+        if rc == 1:
+            accepted += 1
+            assert np.abs(ao - r[0]).max() < 1e-15 and np.abs(go - r[1]).max() < 1e-15
+            worst = max(worst, float(np.abs(np.array(f.Rwi[:]).reshape(3, 3) - ref.Rwi).max()))
+    assert accepted == len(stamps) - 100 and f.count == accepted
+    assert worst < 1e-12, worst
+    # known answer: 4 s at rest, pitched by 3 degrees and rolled by -2 (accelerometer = R^T g): the filter reports that attitude
+    R = pf.ypr2R(np.array([0.0, 3.0, -2.0]))
+    f2 = lib.ImuFilter(); h.rgc_imu_filter_init(C.byref(f2))
+    a = R.T @ np.array([0, 0, 9.81]) + np.array(f2.ba[:]); g = np.array(f2.bg[:])
+    for j in range(800):
+        h.rgc_imu_filter_push(C.byref(f2), 0.005 * j, _dp(a), _dp(g), None, None)
+    ypr = np.empty(3); h.rgc_R2ypr(_dp(np.array(f2.Rwi[:])), _dp(ypr))
+    assert abs(ypr[1] - 3.0) < 0.05 and abs(ypr[2] + 2.0) < 0.05 and abs(ypr[0]) < 1e-9, ypr
+
+
+def test_ground_gate_vs_restatement(L):
+    """The ground-change detector (RGC_odometer.cpp:1034-1087): a plane mismatch while the IMU pitches switches the ground factor off
+    for 25 frames, then the plane is re-associated with a remembered attitude (or remembered).  Library vs oracle/py_fusion.GroundGate
+    over a scripted drive: flat, a ramp (new plane remembered), flat again (the first plane is found in the history)."""
+    from oracle import py_fusion as pf
+    lib, h = L
+    rng = np.random.default_rng(5)
+    g = lib.GroundGate(); h.rgc_ground_gate_init(C.byref(g))
+    ref = pf.GroundGate()
+    h.rgc_ground_gate_remember(C.byref(g)); ref.remember()
+
+    def plane(pitch_deg):
+        n = pf.ypr2R(np.array([0.0, pitch_deg, 0.0])) @ np.array([0, 0, 1.0])
+        v1 = np.cross(n, [0, 1.0, 0]); v1 /= np.linalg.norm(v1)
+        return np.array([*n, *v1, *np.cross(n, v1), 0.56, 0.01])
+    flags, q_w = [], np.array([0, 0, 0, 1.0])
+    for k in range(90):
+        on_ramp = 20 <= k < 55
+        change = k in (20, 55)                       # the frames in which the plane under the sensor changes
+        g_last, g_cur = plane(6.0 if (on_ramp and not change) or k == 55 else 0.0), plane(6.0 if on_ramp else 0.0)
+        dq_imu = _rand_q(rng, 0.0005) if not change else np.array([0, math.sin(math.radians(0.6)), 0, math.cos(math.radians(0.6))])
+        q_l, t_l = _rand_q(rng, 0.002), np.array([0.1, 0.0, 0.0])
+        q_w = pf.qmul(q_w, pf.qmul(np.array([0, math.sin(math.radians(3.0 if k == 20 else (-3.0 if k == 55 else 0.0))), 0,
+                                             math.cos(math.radians(3.0 if k == 20 else (-3.0 if k == 55 else 0.0)))]), q_l))
+        q_w /= np.linalg.norm(q_w)
+        qf = np.empty(4)
+        rc = h.rgc_ground_gate_step(C.byref(g), _dp(g_last), _dp(g_cur), _dp(q_l), _dp(t_l), _dp(dq_imu), _dp(q_w), _dp(qf))
+        rf, qfr = ref.step(g_last, g_cur, q_l, t_l, dq_imu, q_w)
+        assert rc == rf and np.abs(qf - qfr).max() < 1e-14
+        flags.append(rc)
+    assert flags[19] == 0 and all(f == 1 for f in flags[20:44]) and flags[44] == 0      # 25-frame hold-off after the ramp's foot
+    assert all(f == 1 for f in flags[55:79]) and flags[79] == 0                          # and after its top
+    assert g.n_history == len(ref.history) == 2                                          # flat, ramp; the second flat was FOUND, not added
+    assert np.abs(np.array(g.q_w_curr_delta[:]) - ref.q_delta).max() < 1e-14
