@@ -18,7 +18,12 @@
 //   device_chain = true  : (with resident_map) the sweep never returns to the host between the stages: message bytes -> unpack kernel ->
 //                          front-end -> de-skew -> VoxelGrid -> setInputSource / keyframe insert all read the previous stage's DEVICE
 //                          buffer; only the message goes up and features, ground parameters and the pose come down
-// USE_IMU = 0 (no IMU stream in this class; the IMU hooks of the library are separate entry points).
+// use_imu (launch/run.launch:18, the reference's default): imuCallback() feeds the attitude filter and the sample buffer
+//   (vg_ICP::imu_callback, :444-486); the gyro's pre-integrated rotation is the registration's guess (:883-931, 993-996) and a factor
+//   of the fusion (:1104-1119); pitch / roll are blended towards the filter's attitude (:1206-1214); the first `first_frames` sweeps
+//   only initialise the pose from it (:857-882); a sweep without IMU coverage is dropped (:885-891).  The ground-change detector
+//   (:1034-1087) runs in both modes.  Not mirrored: the two gravity-direction solves of the first frame (:1121-1186), whose results
+//   do not enter the pose.
 // Errors: std::runtime_error carrying rgc_last_error(); there is no CPU fallback.
 #pragma once
 #include <chrono>
@@ -61,6 +66,9 @@ public:
     double evict_radius = 0.0;             // resident map only: additionally evict keyframes farther than this (0 = off)
     double rebase_distance = 50.0;         // resident map only: the map origin follows the sensor
     bool device_chain = false;             // resident map only: keep the sweep on the device between the stages
+    bool use_imu = false;                  // USE_IMU (launch/run.launch:18)
+    int first_frames = 0;                  // firstflagnum, RGC_odometer.cpp:303 (the reference: 10)
+    double init_yaw = 0.0;                 // init_yaw, :358 (degrees)
   };
 
   explicit OdometryNode(const Options& o) : opt_(o) {
@@ -71,7 +79,19 @@ public:
     if (rc != RGC_OK) throw std::runtime_error(std::string("rgc_create: ") + rgc_status_string(rc));
     rgc_default_fe_params(&fe_);
     fe_.n_scans = o.scan_line; fe_.min_range = o.minimum_range; fe_.max_range = o.maxmum_range;
+    rgc_imu_filter_init(&imu_);
+    rgc_ground_gate_init(&gate_);
+    const double ril[3] = {-1.29, -0.15, 0.65};   // R_il, :387 (degrees)
+    rgc_ypr2R(ril, R_il_);
   }
+
+  // the /mynteye/imu/data_raw subscriber (vg_ICP::imu_callback, :444-486): attitude filter + the buffer the frame body integrates
+  void imuCallback(double stamp, const double acc[3], const double gyr[3]) {
+    ImuSample s;
+    s.t = stamp;
+    if (rgc_imu_filter_push(&imu_, stamp, acc, gyr, s.acc, s.gyr) == 1) imu_buf_.push_back(s);
+  }
+  int groundFlag() const { return gate_.gflag; }
   ~OdometryNode() {
     for (DevBuf* b : {&d_raw_, &d_source_, &d_last_}) if (b->p) rgc_device_free(ctx_, b->p);
     rgc_destroy(ctx_);
@@ -107,6 +127,7 @@ public:
   // ReplayPipeline -- and lies on this GPU, ring-major with the encoded intensity; it is de-skewed in place
   void handleFrontEndOutput(float* d_full, int n_full, const double groundparam[11], bool ground_valid, double stamp, OdometryMsg* odom) {
     if (!opt_.device_chain) throw std::runtime_error("handleFrontEndOutput needs device_chain");
+    if (!begin_frame(stamp)) { publish(stamp, odom); return; }
     body(d_full, n_full, groundparam, ground_valid, stamp, odom);
   }
 
@@ -131,6 +152,7 @@ private:
   // in: host memory, or (on_device) device memory of this context's GPU
   void process(const float* xyzi, int n, int stride_bytes, bool on_device, double stamp, OdometryMsg* odom, GroundMsg* ground) {
     const bool chain = opt_.device_chain;
+    if (!begin_frame(stamp)) { publish(stamp, odom); return; }
     // ---- ScanRegistration::laserCloudHandler ----
     const int fcap = fe_.n_scans * 6 * 41;
     full_.resize((size_t)4 * (size_t)(n > 0 ? n : 1));
@@ -193,23 +215,26 @@ private:
         qrot(qi, d, t_l);
         std::memcpy(q_l, qd, sizeof(qd));
       }
-      // pose fusion, :1025-1193
+      // ground-change detector + pose fusion + composition + gravity blend, :1025-1214
+      const bool have_ground = ground_valid && have_ground_last_;
       rgc_fuse_in fin;
       rgc_default_fuse_in(&fin);
       std::memcpy(fin.q_lidar_xyzw, q_l, sizeof(q_l)); std::memcpy(fin.t_lidar, t_l, sizeof(t_l));
       fin.fitness = fitness;
-      const bool use_ground = opt_.use_ground && ground_valid && have_ground_last_;
+      const int gflag = rgc_ground_gate_step(&gate_, have_ground ? ground_last_ : nullptr, have_ground ? groundparam : nullptr, q_l, t_l,
+                                             have_dq_imu_ ? dq_imu_ : nullptr, q_w_, fin.q_w_curr_f_xyzw);   // :1034-1087
+      if (gflag < 0) chk(gflag);
+      const bool use_ground = opt_.use_ground && have_ground && gflag == 0;                     // :1088
       fin.use_ground = use_ground ? 1 : 0;
       if (use_ground) {
         std::memcpy(fin.ground_last, ground_last_, sizeof(ground_last_));
         std::memcpy(fin.ground_cur, groundparam, sizeof(ground_last_));
-        double qdi[4] = {-q_w_delta_[0], -q_w_delta_[1], -q_w_delta_[2], q_w_delta_[3]};
-        qmul(qdi, q_w_, fin.q_w_curr_f_xyzw);                                                  // :1086-1087
-        qnormalize(fin.q_w_curr_f_xyzw);
       }
-      double q_f[4], t_f[3], q_new[4], t_new[3], t_lc[3];
+      if (opt_.use_imu && have_dq_imu_) { fin.use_imu = 1; std::memcpy(fin.q_imu_xyzw, dq_imu_, sizeof(dq_imu_)); }   // :1104-1119
+      double q_f[4], t_f[3], q_new[4], t_new[3], t_lc[3], R_imu[9];
       chk(rgc_fuse_pose(&fin, q_f, t_f, nullptr));
-      chk(rgc_compose_pose(q_w_, t_w_, q_f, t_f, t_l, 0, nullptr, q_new, t_new, t_lc));          // :1194-1203
+      if (opt_.use_imu) matmul3(imu_.Rwi, R_il_, R_imu);                                         // IMU.Rwi * R_il, :1209
+      chk(rgc_compose_pose(q_w_, t_w_, q_f, t_f, t_l, opt_.use_imu ? 1 : 0, opt_.use_imu ? R_imu : nullptr, q_new, t_new, t_lc));   // :1194-1214
       std::memcpy(q_w_, q_new, sizeof(q_new)); std::memcpy(t_w_, t_new, sizeof(t_new));
       std::memcpy(q_last_curr_, q_f, sizeof(q_f)); std::memcpy(t_last_curr_, t_lc, sizeof(t_lc));
       maintain_map(n_src);                                                                      // :1218-1256
@@ -229,11 +254,57 @@ private:
     have_last_ = n_full > 0;
     if (ground_valid) { std::memcpy(ground_last_, groundparam, sizeof(ground_last_)); have_ground_last_ = true; }
     frames_++;
-    if (odom) {
-      odom->stamp = stamp;
-      std::memcpy(odom->position, t_w_, sizeof(t_w_));
-      std::memcpy(odom->orientation_xyzw, q_w_, sizeof(q_w_));
+    publish(stamp, odom);
+  }
+
+  void publish(double stamp, OdometryMsg* odom) const {
+    if (!odom) return;
+    odom->stamp = stamp;
+    std::memcpy(odom->position, t_w_, sizeof(t_w_));
+    std::memcpy(odom->orientation_xyzw, q_w_, sizeof(q_w_));
+  }
+
+  // :857-931, 955-956: the first sweeps only initialise the pose (from IMU.Rwi * R_il with the IMU); afterwards the gyro samples
+  // between the previous sweep and this one give delta_q_imu = q_last_curr, the registration's rotation guess.  false = the sweep is
+  // dropped (initialisation, or no IMU coverage: getIMUInterval, :1376-1416).
+  bool begin_frame(double stamp) {
+    if (frames_seen_ < opt_.first_frames) {
+      frames_seen_++;
+      prev_time_ = stamp;
+      t_w_[0] = t_w_[1] = t_w_[2] = 0.0;
+      if (opt_.use_imu) {
+        double R[9], ypr[3];
+        matmul3(imu_.Rwi, R_il_, R);
+        rgc_R2ypr(R, ypr);
+        ypr[0] += opt_.init_yaw;
+        rgc_ypr2R(ypr, R);
+        R2q(R, q_w_);
+      }
+      return false;
     }
+    if (opt_.use_imu) {
+      if (imu_buf_.empty() || (prev_time_ <= imu_buf_.front().t && stamp <= imu_buf_.front().t) || !(stamp <= imu_buf_.back().t)) return false;
+      while (imu_buf_.front().t <= prev_time_) imu_buf_.pop_front();
+      st_.clear(); ga_.clear(); aa_.clear();
+      auto take = [&](const ImuSample& m) { st_.push_back(m.t); for (int a = 0; a < 3; a++) { ga_.push_back(m.gyr[a]); aa_.push_back(m.acc[a]); } };
+      while (imu_buf_.front().t < stamp) { take(imu_buf_.front()); imu_buf_.pop_front(); }
+      take(imu_buf_.front());
+      chk(rgc_imu_preintegrate(st_.data(), ga_.data(), aa_.data(), (int)st_.size(), prev_time_, stamp, dq_imu_, nullptr, nullptr, nullptr));
+      have_dq_imu_ = true;
+      std::memcpy(q_last_curr_, dq_imu_, sizeof(dq_imu_));                                       // :929-930
+    }
+    prev_time_ = stamp;
+    frames_seen_++;
+    return true;
+  }
+
+  static void matmul3(const double A[9], const double B[9], double C[9]) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+  }
+  static void R2q(const double R[9], double q[4]) {   // positive-trace branch (attitudes near the identity)
+    const double w = std::sqrt(std::fmax(0.0, 1.0 + R[0] + R[4] + R[8])) / 2;
+    q[0] = (R[7] - R[5]) / (4 * w); q[1] = (R[2] - R[6]) / (4 * w); q[2] = (R[3] - R[1]) / (4 * w); q[3] = w;
+    qnormalize(q);
   }
 
   void chk(int rc) { if (rc != RGC_OK) throw std::runtime_error(std::string(rgc_status_string(rc)) + ": " + rgc_last_error(ctx_)); }
@@ -279,6 +350,7 @@ private:
     }
     std::memcpy(kf_q_, I, sizeof(I)); std::memcpy(kf_t_, Z, sizeof(Z));
     have_kf_ = true;
+    rgc_ground_gate_remember(&gate_);   // histoary_pose.push_back(q_w_curr_delta), :969
   }
 
   void maintain_map(int n_src) {
@@ -342,7 +414,16 @@ private:
   int n_sharp_ = 0, n_flat_ = 0;
   double q_w_[4] = {0, 0, 0, 1}, t_w_[3] = {0, 0, 0};                 // q_w_curr, t_w_curr
   double q_last_curr_[4] = {0, 0, 0, 1}, t_last_curr_[3] = {0, 0, 0};  // para_q, para_t
-  double q_w_delta_[4] = {0, 0, 0, 1};                                 // q_w_curr_delta (ground-change detector inactive without IMU)
+  rgc_ground_gate gate_;                                               // gflag, changegroundflag, q_w_curr_delta, histoary_pose (:1034-1087)
+  rgc_imu_filter imu_;                                                 // IMU (imu_s) + ComplementaryFilter state
+  struct ImuSample { double t, acc[3], gyr[3]; };
+  std::deque<ImuSample> imu_buf_;                                      // accBuf / gyrBuf
+  std::vector<double> st_, ga_, aa_;                                   // the interval handed to rgc_imu_preintegrate
+  double R_il_[9];
+  double dq_imu_[4] = {0, 0, 0, 1};                                    // delta_q_imu
+  bool have_dq_imu_ = false;
+  double prev_time_ = 0.0;
+  int frames_seen_ = 0;
   double ground_last_[11] = {0};
   bool have_ground_last_ = false, have_kf_ = false;
   double kf_q_[4] = {0, 0, 0, 1}, kf_t_[3] = {0, 0, 0}, origin_[3] = {0, 0, 0};
@@ -360,6 +441,8 @@ public:
     rgc_default_fe_params(&fe_);
     fe_.n_scans = o.scan_line; fe_.min_range = o.minimum_range; fe_.max_range = o.maxmum_range;
   }
+  // IMU messages go to the frame body's node (deliver them before run(): the replay has every message up front)
+  void imuCallback(double stamp, const double acc[3], const double gyr[3]) { body_.imuCallback(stamp, acc, gyr); }
   ~ReplayPipeline() {
     for (Slot& s : slot_) if (s.d) rgc_device_free(fe_ctx_, s.d);
     if (d_raw_) rgc_device_free(fe_ctx_, d_raw_);
@@ -377,6 +460,8 @@ public:
     if (done_ms) done_ms->assign(N, 0.0);
     odom->assign(N, OdometryMsg());
     ground->assign(N, GroundMsg());
+    stop_ = false;                                   // a run that failed must not poison the next one
+    for (Slot& s : slot_) s.full = false;
     std::exception_ptr front_error;
     std::thread front([&]() {
       try {

@@ -1445,6 +1445,7 @@ int rgc_frontend_device(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes
 }
 static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out, int on_device) {
   if (!c || !xyzi || !prm || !out || n < 0) return RGC_ERR_INVALID;
+  if (n > (1 << 24)) return fail(c, RGC_ERR_INVALID, "sweep has %d points, the front-end's limit is 2^24", n);  // 32-bit sizes and candidate lists below
   if (stride_bytes < 16 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "front-end needs x,y,z,intensity: stride_bytes >= 16");
   const int NS = prm->n_scans;
   if (NS != 16 && NS != 32 && NS != 64) return fail(c, RGC_ERR_INVALID, "only 16, 32 or 64 scan lines (scanRegistration.cpp:69-72)");
@@ -1463,9 +1464,10 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   enum { RING, RANK, HIST, META, ST, CL, INUM2, INUM, RANGE, ANGLE, CURV, CURV2, ICURV, DSRC, OSRC, PICK, IPICK, LAB, ILAB, GMARK, MULT, SCNT,
          SPOS, PART, OUTD, SLOTS, FLAGS, SHARP, FLAT, INTEN, GLIST, BSUM, SORTC, SORTI };
   const int nu = NS * 6, fcap = nu * 41;
-  const size_t sizes[34] = {4u * n, 4u * n, 4u * 64 * nb, 4u * 132, 4u * 8, 16u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n,
-                            4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 4u * n, 8u * 11 * nb, 8u * 48,
-                            4u * (size_t)nu * rgck::fe_slot_ints(), 4u * 8, 20u * fcap, 20u * fcap, 20u * fcap, 16u * 10 * (size_t)n, 4u * (n / 2048 + 4), 4u * n, 4u * n};
+  const size_t n4 = (size_t)4 * n;
+  const size_t sizes[34] = {n4, n4, (size_t)4 * 64 * nb, 4u * 132, 4u * 8, 4 * n4, n4, n4, n4, n4, n4, n4, n4, n4,
+                            n4, n4, n4, n4, n4, n4, n4, n4, n4, (size_t)8 * 11 * nb, 8u * 48,
+                            4u * (size_t)nu * rgck::fe_slot_ints(), 4u * 8, 20u * fcap, 20u * fcap, 20u * fcap, 16u * 10 * (size_t)n, 4u * ((size_t)n / 2048 + 4), n4, n4};
   for (int b = 0; b < 34; b++) if ((rc = ensure(c, c->fe[b], sizes[b] + 64))) return rc;
 #define FE(i, T) ((T*)c->fe[i].p)
   int st_init[8] = {INT_MAX, -1, INT_MAX, 0, 0, 0, 0, 0};
@@ -1892,7 +1894,7 @@ int rgc_map_evict(rgc_ctx* c, int max_keyframes, const double center[3], double 
   std::vector<rgc_ctx::MapKf> keep;
   for (const auto& k : c->map_kf) {
     bool far = false;
-    if (center && radius > 0) {
+    if (center && radius > 0 && &k != &c->map_kf.back()) {  // the newest keyframe always stays: an empty map cannot be committed
       const double dx = k.t[0] - center[0], dy = k.t[1] - center[1], dz = k.t[2] - center[2];
       far = std::sqrt(dx * dx + dy * dy + dz * dz) > radius;
     }
@@ -1942,6 +1944,10 @@ int rgc_map_rebase(rgc_ctx* c, const double new_origin[3]) {
   for (int a = 0; a < 3; a++) c->map_origin[a] = new_origin[a];
   c->map_dirty = true;
   c->map_rev++;
+  if (c->map_bound) {  // the committed target is in the OLD origin's coordinates: an align before the next rgc_map_commit must fail, not drift
+    c->tgt.ready = false;
+    c->corr_valid = false;
+  }
   return RGC_OK;
 }
 
@@ -2003,6 +2009,7 @@ int rgc_pc2_unpack(rgc_ctx* c, const void* data, int n, const rgc_pc2_layout* L,
                    int out_on_device) {
   if (!c || !data || !L || !xyzi_out || n < 0) return RGC_ERR_INVALID;
   if (L->point_step <= 0) return fail(c, RGC_ERR_INVALID, "point_step must be positive");
+  if (n > (1 << 24)) return fail(c, RGC_ERR_INVALID, "message has %d points, the limit is 2^24", n);
   rgck::Pc2Layout K{};
   K.point_step = L->point_step;
   K.big_endian = L->is_bigendian ? 1 : 0;

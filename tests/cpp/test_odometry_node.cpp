@@ -2,7 +2,9 @@
 // sensor_msgs::PointCloud2-shaped message per sweep in, one odometry pose + ground message out.  Sweeps come from a file
 // written by the Python test: int32 n_sweeps, then per sweep int32 n_points followed by n_points records of the Velodyne
 // point layout {float x, y, z, intensity; uint16 ring; float time} packed to 22 bytes.
-//   test_odometry_node <sweeps.bin> <resident_map 0|1> <as_message 0|1> [rebase_distance] [device_chain 0|1] [pipeline 0|1]
+//   test_odometry_node <sweeps.bin> <resident_map 0|1> <as_message 0|1> [rebase_distance] [device_chain 0|1] [pipeline 0|1] [imu.bin first_frames]
+// imu.bin (USE_IMU = 1): int32 n, then n records of 7 doubles {stamp, acc xyz, gyr xyz}; sweep s then carries the stamp 0.1 (s + 1) and the
+// messages up to 11 ms past it are delivered before it.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -52,18 +54,32 @@ int main(int argc, char** argv) {
       printf("summary frames %d keyframes %d sharp %d flat %d ms_per_frame %.4f\n", pipe.node().frames(), pipe.node().keyframesInserted(), 0, 0, ms / n_sweeps);
       return 0;
     }
+    std::vector<double> imu;
+    if (argc > 8) {
+      FILE* fi = fopen(argv[7], "rb");
+      int ni = 0;
+      if (!fi || fread(&ni, 4, 1, fi) != 1) return 2;
+      imu.resize((size_t)7 * ni);
+      if (fread(imu.data(), 8, imu.size(), fi) != imu.size()) return 2;
+      fclose(fi);
+      opt.use_imu = true;
+      opt.first_frames = atoi(argv[8]);
+    }
     rgc::OdometryNode node(opt);
     std::vector<float> xyzi;
     double total = 0;
+    size_t ji = 0;
     for (int s = 0; s < n_sweeps; s++) {
       rgc::OdometryMsg odom; rgc::GroundMsg ground;
+      const double stamp = imu.empty() ? 0.1 * s : 0.1 * (s + 1);
+      for (; ji < imu.size() / 7 && imu[7 * ji] <= stamp + 0.011; ji++) node.imuCallback(imu[7 * ji], &imu[7 * ji + 1], &imu[7 * ji + 4]);
       const auto t0 = std::chrono::steady_clock::now();
       if (as_message) {
-        node.handlePointCloud2(msgs[s].data(), counts[s], L, 0.1 * s, &odom, &ground);
+        node.handlePointCloud2(msgs[s].data(), counts[s], L, stamp, &odom, &ground);
       } else {   // the cloud converted on the host, as pcl::fromROSMsg would
         xyzi.resize((size_t)4 * counts[s]);
         for (int i = 0; i < counts[s]; i++) memcpy(&xyzi[4 * (size_t)i], &msgs[s][22 * (size_t)i], 16);
-        node.handleCloud(xyzi.data(), counts[s], 16, 0.1 * s, &odom, &ground);
+        node.handleCloud(xyzi.data(), counts[s], 16, stamp, &odom, &ground);
       }
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (s >= 4) total += ms;

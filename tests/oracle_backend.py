@@ -92,7 +92,8 @@ class OracleBackend:
     def map_evict(self, max_keyframes, center=None, radius=0.0):
         n0 = len(self._kf)
         if center is not None and radius > 0:
-            self._kf = [k for k in self._kf if np.linalg.norm(k[2] - np.asarray(center, float)) <= radius]
+            # the newest keyframe always stays (an empty map cannot be committed)
+            self._kf = [k for i, k in enumerate(self._kf) if i == len(self._kf) - 1 or np.linalg.norm(k[2] - np.asarray(center, float)) <= radius]
         if max_keyframes > 0 and len(self._kf) > max_keyframes:
             self._kf = self._kf[-max_keyframes:]
         if len(self._kf) != n0:

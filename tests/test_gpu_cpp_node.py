@@ -41,8 +41,10 @@ def sweeps(tmp_path_factory):
     return raws, path
 
 
-def _run(exe, path, resident, as_message, rebase=None, chain=False, pipeline=False):
+def _run(exe, path, resident, as_message, rebase=None, chain=False, pipeline=False, imu=None, first_frames=0):
     args = [exe, path, str(int(resident)), str(int(as_message)), str(rebase if rebase is not None else 50.0), str(int(chain)), str(int(pipeline))]
+    if imu is not None:
+        args += [imu, str(first_frames)]
     out = subprocess.run(args, capture_output=True, text=True, timeout=600).stdout
     assert "EXCEPTION" not in out, out
     poses, ground = [], []
@@ -96,3 +98,44 @@ def test_cpp_replay_pipeline(exe, sweeps):
     for _ in range(2):
         b, gb, sb = _run(exe, path, True, True, 0.5, chain=True, pipeline=True)
         assert np.array_equal(a, b) and ga == gb and sa["frames"] == sb["frames"] and sa["keyframes"] == sb["keyframes"]
+
+
+def test_cpp_node_with_imu(exe, tmp_path):
+    """USE_IMU = 1 (launch/run.launch:18) in the C++ node: imuCallback -> attitude filter / gyro guess / IMU factor / gravity blend /
+    ground-change detector, the first sweeps initialising the pose -- same poses as the Python mirror of the frame body, which
+    tests/test_gpu_sequence.py::test_sequence_with_imu holds against the CPU oracle"""
+    import rgc_slam_amd.synth as synth
+    from rgc_slam_amd import odometry
+    world = synth.make_world(half_extent=45.0, seed=synth.SEED)
+    poses = synth.make_trajectory(9, seed=synth.SEED + 2)
+    stamps, acc, gyr = synth.make_imu(poses, seed=synth.SEED + 2)
+    raws = []
+    for k in range(8):
+        sc = synth.make_scan(world, poses[k], n_az=1200, seed=synth.SEED + 70 + k, T_ws_end=poses[k + 1])
+        raws.append(np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32))
+    path, ipath = str(tmp_path / "sweeps.bin"), str(tmp_path / "imu.bin")
+    dt = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4"), ("ring", "<u2"), ("time", "<f4")])
+    with open(path, "wb") as f:
+        f.write(np.int32(len(raws)).tobytes())
+        for r in raws:
+            rec = np.zeros(len(r), dt)
+            rec["x"], rec["y"], rec["z"], rec["intensity"] = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+            f.write(np.int32(len(r)).tobytes()); f.write(rec.tobytes())
+    with open(ipath, "wb") as f:
+        f.write(np.int32(len(stamps)).tobytes())
+        f.write(np.concatenate([stamps[:, None], acc, gyr], axis=1).astype("<f8").tobytes())
+    hb = odometry.HipBackend(0)
+    od = odometry.Odometer(hb, use_imu=True, first_frames=2)
+    ref, j = [], 0
+    for k, raw in enumerate(raws):
+        t_k = 0.1 * (k + 1)
+        while j < len(stamps) and stamps[j] <= t_k + 0.011:
+            od.imu_callback(stamps[j], acc[j], gyr[j]); j += 1
+        od.process(raw, t_k)
+        ref.append(np.concatenate([od.q_w_curr, od.t_w_curr]))
+    hb.close()
+    ref = np.array(ref)
+    poses_cpp, ground, summary = _run(exe, path, False, True, imu=ipath, first_frames=2)
+    assert len(poses_cpp) == len(raws) and int(summary["frames"]) == len(raws) - 2      # two sweeps only initialised the pose
+    assert np.abs(poses_cpp - ref).max() < 1e-9, np.abs(poses_cpp - ref).max()
+    assert np.linalg.norm(ref[-1, 4:7]) > 0.2
