@@ -38,6 +38,7 @@ struct Cloud {
   bool ready = false;  // grid + normals (+ voxels for the target) enqueued
   DevBuf in_copy, cell_of, slot_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
   DevBuf segs;  // deferred-query list of the bulk kNN kernel: [count, pad x15][query n][bound n]
+  int deferred_seen = -1;  // deferred count of the last cloud whose count came home (sizes the next cooperative launch)
   rgck::Grid grid{};
   // speculative grid: the previous cloud's grid, widened, re-used without the bounding-box round trip; k_count guards it
   rgck::Grid spec_grid{};
@@ -353,8 +354,11 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   }
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COOP : RGC_K_KNN_COOP_SRC, n, s);
+    // grid of the cooperative launch: twice the deferred count of the previous cloud prepared here (consecutive clouds of a sequence
+    // defer about the same queries), n / 64 for the first one
+    const int waves = cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 32 : n / 64 + 32;
     rgck::knn_coop(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p,
-                   (double*)cl.ny.p, (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr);
+                   (double*)cl.ny.p, (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, waves);
   }
   if (is_target) {
     int rc;
@@ -1090,6 +1094,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     c->stats.n_corr = S.ncorr; c->stats.n_linearize = S.n_lin; c->stats.n_error = S.n_err;
     c->tgt.nvox = c->stats.n_voxels = S.nvox;
     c->stats.deferred_target = S.def_t; c->stats.deferred_source = S.def_s;
+    c->tgt.deferred_seen = S.def_t; c->src.deferred_seen = S.def_s;
     c->stats.source_crowding = c->src.n > 0 ? (double)S.src_sq / (double)c->src.n : 0.0;
     if (c->src_res <= 0.0 && c->src.n > 0) {  // steer the next scan's cell size: halve above 300 points per own cell, double below 40
       const double cur = c->src.grid.res, crowd = c->stats.source_crowding;

@@ -66,8 +66,9 @@ void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int*
 size_t deferred_bytes(int n);
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard = nullptr);
+// waves: one-wave workgroups that share the deferred list (clamped to [32, 8192])
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
-              double* ny, double* nz, const int* guard = nullptr);
+              double* ny, double* nz, const int* guard, int waves);
 // ---- C3: Gaussian voxel map ----
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int n, const int* cell_voxel, double* vox, int* vox_cell);

@@ -689,9 +689,40 @@ struct Deferred {
 // ------------------------------------------------------------------------------------------------
 constexpr int kPieceQuads = 1023;  // a piece's length in quads shares its table entry with the piece's distance bound (fp32, low 10 bits cut)
 constexpr int kSpBuf = 12;   // keys waiting to enter the chain, per lane
-constexpr int kSpCum = 16;   // piece table (first ordinals once visited), padded with INT_MAX for the ordinal -> piece search
-constexpr int kSpRows = 11;  // pieces of a 3x3x3 block: 8 rows + the own row in three parts
-constexpr int kSpLds = kSpBuf + kSpCum + kSpRows;  // ints of LDS per lane, as columns [slot][lane]
+// Block geometry and LDS layout of one instantiation.  R = block radius in cells, kClip as described at knn_point_sp.
+// LDS per lane, as columns [slot][lane]: the append buffer, the piece table (padded with INT_MAX for the ordinal -> piece search)
+// and the pieces' first positions in the sorted array.
+template <int R, bool kClip>
+struct SpShape {
+  static constexpr int D = 2 * R + 1;
+  static constexpr int NROW = D * D;               // grid rows of the block
+  static constexpr int NP = kClip ? NROW + 2 : NROW;  // pieces: the own row in three parts when clipping
+  static constexpr int CUM = NP < 16 ? 16 : (NP < 32 ? 32 : 64);  // searchable table size (a power of two > NP)
+  static constexpr int LDS = kSpBuf + CUM + NP;    // ints per lane
+};
+// visiting order, nearest first: the own cell and its row, then the other rows by the Chebyshev ring and the distance of their offset
+template <int R, bool kClip>
+struct SpOrder {
+  int p[SpShape<R, kClip>::NP];
+  constexpr SpOrder() : p{} {
+    constexpr int D = 2 * R + 1, NROW = D * D, OWN = NROW / 2;
+    int n = 0;
+    if (kClip) { p[n++] = OWN + 1; p[n++] = OWN; p[n++] = OWN + 2; }
+    else p[n++] = OWN;
+    for (int ring = 1; ring <= R; ring++)
+      for (int d2 = 1; d2 <= 2 * R * R; d2++)
+        for (int r = 0; r < NROW; r++) {
+          const int dy = r % D - R, dz = r / D - R;
+          const int ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
+          if ((ay > az ? ay : az) == ring && dy * dy + dz * dz == d2) p[n++] = (kClip && r > OWN) ? r + 2 : r;
+        }
+  }
+};
+
+// Batcher's odd-even merge sort for 32 inputs with the comparators that touch wires >= 24 removed (those wires would hold +inf):
+// 132 compare-exchanges sort 24 values (checked on all 2^24 zero-one inputs).  (a << 5 | b), a < b.
+constexpr int kSort24N = 132;
+__device__ constexpr unsigned short kSort24[kSort24N] = {1, 67, 2, 35, 34, 133, 199, 134, 167, 166, 4, 70, 68, 37, 103, 101, 34, 100, 166, 265, 331, 266, 299, 298, 397, 463, 398, 431, 430, 268, 334, 332, 301, 367, 365, 298, 364, 430, 8, 140, 136, 74, 206, 202, 68, 200, 332, 41, 173, 169, 107, 239, 235, 101, 233, 365, 34, 100, 166, 232, 298, 364, 430, 529, 595, 530, 563, 562, 661, 727, 662, 695, 694, 532, 598, 596, 565, 631, 629, 562, 628, 694, 596, 629, 562, 628, 694, 16, 272, 148, 404, 136, 400, 82, 338, 214, 470, 202, 466, 68, 200, 332, 464, 596, 49, 305, 181, 437, 169, 433, 115, 371, 247, 503, 235, 499, 101, 233, 365, 497, 629, 34, 100, 166, 232, 298, 364, 430, 496, 562, 628, 694};
 
 // a = med3(below, a, x), IN PLACE: the chain's registers stay where they are across the loops they are carried through (with a
 // separate output operand the compiler shuffles all of them at every loop boundary)
@@ -724,16 +755,21 @@ __device__ __forceinline__ float dist2_fma(float px, float py, float pz, float c
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
-template <int KC, int KB>  // KB: low key bits that hold the candidate's ordinal (ordinals < 2^KB)
+// KB: low key bits that hold the candidate's ordinal (ordinals < 2^KB).  kClip: pieces carry distance bounds and are skipped once the
+// scan's bound excludes them, the own row is cut in three, ordinals are handed out as pieces are entered (a raw scan's crowded
+// cells); without it the block is nine whole rows numbered up front (a leaf-filtered map: nothing to skip, less bookkeeping).
+template <int KC, int KB, bool kClip, int R, int T>  // T: threads per workgroup = stride of the per-lane LDS columns
 __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
                                              int i, int* lds, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
                                              double* __restrict__ nz) {
+  using Shape = SpShape<R, kClip>;
   constexpr int L = KC + 2;
   constexpr int kKeyOrd = (1 << KB) - 1;
   constexpr int kKeyBits = KB;
-  int* const buf = lds;                              // [kSpBuf][KNN_T]
-  int* const tmix = lds + kSpBuf * KNN_T;            // [kSpCum][KNN_T]: before a piece is reached {min distance^2 (fp32, low byte cut) | quads}, after: its first ordinal
-  int* const tlo = lds + (kSpBuf + kSpCum) * KNN_T;  // [kSpRows][KNN_T]
+  constexpr int D = Shape::D, NROW = Shape::NROW, NP = Shape::NP, OWN = NROW / 2;
+  int* const buf = lds;                                   // [kSpBuf][T]
+  int* const tmix = lds + kSpBuf * T;                 // [CUM][T]: before a piece is reached {min distance^2 (fp32, low bits cut) | quads}, after: its first ordinal
+  int* const tlo = lds + (kSpBuf + Shape::CUM) * T;   // [NP][T]
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int c[3] = {voxel_coord_g(px, g) - g.minc[0], voxel_coord_g(py, g) - g.minc[1], voxel_coord_g(pz, g) - g.minc[2]};
@@ -743,40 +779,43 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     df.idx[e] = enc;
     df.thr[e] = thr;
   };
-  // ---- the block's pieces in MEMORY order: rows r = 3 (dz + 1) + (dy + 1) for r != 4 (pieces 0..3, 7..10); the own row (r = 4) as
-  // three pieces cut at multiples of four points from its start: left of the own cell (4), the own cell (5), right of it (6) ----
-  const int xl = max(c[0] - 1, 0), xh = min(c[0] + 1, g.dim[0] - 1);
-  // squared distance from the query to each wall of its cell (rounded down a little: the pieces' lower bounds must never be too high)
-  float wlo2[3], whi2[3];
+  // ---- the block's pieces in MEMORY order: the D x D grid rows r = D (dz + R) + (dy + R), each the cells cx - R .. cx + R.  kClip: the
+  // own row (r = OWN) as three pieces cut at multiples of four points from its start -- left of the own cell, the own cell, right
+  // of it -- so pieces OWN, OWN + 1, OWN + 2, and the rows behind it shifted by two. ----
+  const int xl = max(c[0] - R, 0), xh = min(c[0] + R, g.dim[0] - 1);
+  // distance from the query to the walls of its cell; a row / piece at offset d cells is at least (|d| - 1) cells + that away
+  double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
+  if (kClip) {
 #pragma unroll
-  for (int a = 0; a < 3; a++) {
-    const double wall = ((double)(c[a] + g.minc[a]) + 0.5) * g.res;
-    const double dl = fmax(q[a] - wall, 0.0), dh = fmax(wall + g.res - q[a], 0.0);
-    wlo2[a] = (float)(dl * dl * (1.0 - 1.0e-6));
-    whi2[a] = (float)(dh * dh * (1.0 - 1.0e-6));
+    for (int a = 0; a < 3; a++) {
+      const double wall = ((double)(c[a] + g.minc[a]) + 0.5) * g.res;
+      wlo[a] = fmax(q[a] - wall, 0.0);
+      whi[a] = fmax(wall + g.res - q[a], 0.0);
+    }
   }
-  int lo[kSpRows], hi[kSpRows];
-  float min2[kSpRows];
+  auto axis_gap = [&](int a, int d) { return d == 0 ? 0.0 : (d < 0 ? wlo[a] + (double)(-d - 1) * g.res : whi[a] + (double)(d - 1) * g.res); };
+  auto bound2 = [&](double gy, double gz) { return (float)((gy * gy + gz * gz) * (1.0 - 1.0e-6)); };  // rounded down a little: never too high
+  int lo[NP], hi[NP];
+  float min2[NP];
 #pragma unroll
-  for (int r = 0; r < 9; r++) {
-    const int dy = r % 3 - 1, dz = r / 3 - 1;
+  for (int r = 0; r < NROW; r++) {
+    const int dy = r % D - R, dz = r / D - R;
     const int y = c[1] + dy, z = c[2] + dz;
     const bool in = y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2];
     const int yy = in ? y : c[1], zz = in ? z : c[2];
     const int a = start[cell_index(g, xl, yy, zz)], b = start[cell_index(g, xh, yy, zz) + 1];
-    const float m = (dy < 0 ? wlo2[1] : (dy > 0 ? whi2[1] : 0.f)) + (dz < 0 ? wlo2[2] : (dz > 0 ? whi2[2] : 0.f));
-    if (r == 4) {
+    if (kClip && r == OWN) {
       const int own = cell_index(g, c[0], c[1], c[2]);
       const int o0 = start[own], o1 = start[own + 1];
       const int a1 = a + ((o0 - a) & ~3), a2 = min(a + ((o1 - a + 3) & ~3), b);
-      lo[4] = a;  hi[4] = a1; min2[4] = wlo2[0];
-      lo[5] = a1; hi[5] = a2; min2[5] = 0.f;
-      lo[6] = a2; hi[6] = b;  min2[6] = whi2[0];
+      lo[OWN] = a;      hi[OWN] = a1;     min2[OWN] = bound2(wlo[0], 0.0);
+      lo[OWN + 1] = a1; hi[OWN + 1] = a2; min2[OWN + 1] = 0.f;
+      lo[OWN + 2] = a2; hi[OWN + 2] = b;  min2[OWN + 2] = bound2(whi[0], 0.0);
     } else {
-      const int p = r < 4 ? r : r + 2;
+      const int p = (!kClip || r < OWN) ? r : r + 2;
       lo[p] = in ? a : 0;
       hi[p] = in ? b : 0;
-      min2[p] = m;
+      min2[p] = kClip ? bound2(axis_gap(1, dy), axis_gap(2, dz)) : 0.f;
     }
   }
   // A piece's last quad may read up to 3 points past the piece.  Where the next piece of this block (in memory order) starts closer
@@ -784,20 +823,20 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   // with the points in between (real points: harmless candidates), is handed to the next piece (which inherits its distance bound),
   // so no point is ever seen twice.  Past the end of the array sit four sentinel points (k_rank_gather).
   {
-    int next_lo[kSpRows];
+    int next_lo[NP];
     int nl = INT_MAX;
 #pragma unroll
-    for (int p = kSpRows - 1; p >= 0; p--) {
+    for (int p = NP - 1; p >= 0; p--) {
       next_lo[p] = nl;
       if (hi[p] > lo[p]) nl = lo[p];
     }
     int carry = -1;
     float carry_min2 = 0.f;
 #pragma unroll
-    for (int p = 0; p < kSpRows; p++) {
+    for (int p = 0; p < NP; p++) {
       if (hi[p] > lo[p]) {
         const int a = carry >= 0 ? carry : lo[p];
-        if (carry >= 0 && carry < lo[p]) min2[p] = fminf(min2[p], carry_min2);
+        if (kClip && carry >= 0 && carry < lo[p]) min2[p] = fminf(min2[p], carry_min2);
         const int len = hi[p] - a;
         const bool tight = next_lo[p] - hi[p] < 3;
         const int keep = tight ? (len & ~3) : len;
@@ -808,25 +847,31 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
       }
     }
   }
-  // ---- piece table, nearest first: the own cell, its two neighbours in the row, the four face rows, the four diagonal ones ----
+  // ---- piece table, nearest first (SpOrder).  Entry: kClip {distance bound | quads} until the piece is entered, then its first
+  // ordinal; otherwise the first ordinal at once. ----
 #pragma unroll
-  for (int j = 0; j < kSpCum; j++) tmix[j * KNN_T] = INT_MAX;
-  int nr = 0;
+  for (int j = 0; j < Shape::CUM; j++) tmix[j * T] = INT_MAX;
+  int nr = 0, acc = 0;
   bool heavy_piece = false;
-  constexpr unsigned long long kOrder = 0x820a1937645ull;  // p = 5, 4, 6, 7, 3, 9, 1, 10, 0, 2, 8 (one nibble each, low first)
+  constexpr SpOrder<R, kClip> kOrder{};
 #pragma unroll
-  for (int it = 0; it < kSpRows; it++) {
-    const int p = (int)((kOrder >> (4 * it)) & 15ull);
+  for (int it = 0; it < NP; it++) {
+    const int p = kOrder.p[it];
     const int len = hi[p] - lo[p];
     if (len > 0) {
       const int quads = (len + 3) >> 2;
       heavy_piece |= quads > kPieceQuads;
-      tlo[nr * KNN_T] = lo[p];
-      tmix[nr * KNN_T] = (__float_as_int(min2[p]) & ~kPieceQuads) | quads;
+      tlo[nr * T] = lo[p];
+      tmix[nr * T] = kClip ? ((__float_as_int(min2[p]) & ~kPieceQuads) | quads) : acc;
+      acc += 4 * quads;
       nr++;
     }
   }
-  if (heavy_piece) {  // a piece of more than 4092 points does not fit the table entry
+  if (!kClip) {
+    tmix[nr * T] = acc;
+    heavy_piece |= acc > kKeyOrd;  // more candidates than ordinals
+  }
+  if (heavy_piece) {  // (kClip: a piece of more than 4092 points does not fit the table entry)
     defer(i, INFINITY);
     return;
   }
@@ -840,12 +885,12 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   int tau = INT_MAX, ri = 0, ordn = 0;
   unsigned off = 0, end = 0;
   bool overflow = false;  // more candidates than the keys' ordinals can number: the query goes to the cooperative kernel
-  int* bp = buf;  // one past the newest buffered key (a column: stride KNN_T)
-  int* const bp_full = buf + (kSpBuf - 4) * KNN_T;
+  int* bp = buf;  // one past the newest buffered key (a column: stride T)
+  int* const bp_full = buf + (kSpBuf - 4) * T;
   auto pop = [&]() {
     int key = INT_MAX;
     if (bp != buf) {
-      bp -= KNN_T;
+      bp -= T;
       key = *bp;
     }
     return key;
@@ -869,24 +914,31 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   // (off, end, ri, ordn) always describe the NEXT quad to fetch.
   struct Quad { float4 p0, p1, p2, p3; int ord; bool on; };
   auto fetch = [&](Quad& q) {
-    while (off >= end && ri < nr) {
-      // next piece -- unless nothing in it can be among the k + 2 nearest any more: its lower distance bound is not below (an
-      // upper bound of) the chain's tail: a crowded cell near the sensor is done after its own piece, its 26 neighbours are never
-      // touched.
-      // The piece's table entry is replaced by its first ordinal (skipped pieces: zero length), which index_of() searches.
-      const int mix = tmix[ri * KNN_T];
-      tmix[ri * KNN_T] = ordn;
-      const int quads = mix & kPieceQuads;
-      const bool reach = !(__int_as_float(mix & ~kPieceQuads) >= __int_as_float(tau | kKeyOrd));  // tau == INT_MAX (chain not full): NaN, no skip
-      if (reach) {
-        if (ordn + 4 * quads > kKeyOrd) {
-          overflow = true;
-          ri = nr;
-          break;
+    if (kClip) {
+      while (off >= end && ri < nr) {
+        // next piece -- unless nothing in it can be among the k + 2 nearest any more: its lower distance bound is not below (an
+        // upper bound of) the chain's tail: a crowded cell near the sensor is done after its own piece, its 26 neighbours are never
+        // touched.  The piece's table entry is replaced by its first ordinal (skipped pieces: zero length), which index_of() searches.
+        const int mix = tmix[ri * T];
+        tmix[ri * T] = ordn;
+        const int quads = mix & kPieceQuads;
+        const bool reach = !(__int_as_float(mix & ~kPieceQuads) >= __int_as_float(tau | kKeyOrd));  // tau == INT_MAX (chain not full): NaN, no skip
+        if (reach) {
+          if (ordn + 4 * quads > kKeyOrd) {
+            overflow = true;
+            ri = nr;
+            break;
+          }
+          off = (unsigned)tlo[ri * T] << 4;
+          end = off + ((unsigned)quads << 6);
         }
-        off = (unsigned)tlo[ri * KNN_T] << 4;
-        end = off + ((unsigned)quads << 6);
+        ri++;
       }
+    } else if (off >= end && ri < nr) {
+      const int l0 = tlo[ri * T], c0 = tmix[ri * T], c1 = tmix[(ri + 1) * T];
+      off = (unsigned)l0 << 4;
+      end = off + ((unsigned)(c1 - c0) << 4);
+      ordn = c0;
       ri++;
     }
     q.on = off < end;
@@ -904,14 +956,38 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
       const int k1 = (__float_as_int(dist2_fma(px, py, pz, q.p1.x, q.p1.y, q.p1.z)) & ~kKeyOrd) | (q.ord + 1);
       const int k2 = (__float_as_int(dist2_fma(px, py, pz, q.p2.x, q.p2.y, q.p2.z)) & ~kKeyOrd) | (q.ord + 2);
       const int k3 = (__float_as_int(dist2_fma(px, py, pz, q.p3.x, q.p3.y, q.p3.z)) & ~kKeyOrd) | (q.ord + 3);
-      if (k0 < tau) { *bp = k0; bp += KNN_T; }
-      if (k1 < tau) { *bp = k1; bp += KNN_T; }
-      if (k2 < tau) { *bp = k2; bp += KNN_T; }
-      if (k3 < tau) { *bp = k3; bp += KNN_T; }
+      if (k0 < tau) { *bp = k0; bp += T; }
+      if (k1 < tau) { *bp = k1; bp += T; }
+      if (k2 < tau) { *bp = k2; bp += T; }
+      if (k3 < tau) { *bp = k3; bp += T; }
     }
     if (__any(bp > bp_full)) drain();
   };
   Quad qa, qb;
+  if (L <= 24) {
+    // The first 24 candidates fill the chain whatever they are: instead of 24 appends and as many inserts (the tail is +inf) they go
+    // straight into registers -- six quads' loads in flight at once -- and through a fixed sorting network (132 compare-exchanges
+    // against ~24 x 22 med3); the 22 smallest become the chain.
+    int w[24];
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      fetch(qa);
+      w[4 * t + 0] = qa.on ? ((__float_as_int(dist2_fma(px, py, pz, qa.p0.x, qa.p0.y, qa.p0.z)) & ~kKeyOrd) | qa.ord) : INT_MAX;
+      w[4 * t + 1] = qa.on ? ((__float_as_int(dist2_fma(px, py, pz, qa.p1.x, qa.p1.y, qa.p1.z)) & ~kKeyOrd) | (qa.ord + 1)) : INT_MAX;
+      w[4 * t + 2] = qa.on ? ((__float_as_int(dist2_fma(px, py, pz, qa.p2.x, qa.p2.y, qa.p2.z)) & ~kKeyOrd) | (qa.ord + 2)) : INT_MAX;
+      w[4 * t + 3] = qa.on ? ((__float_as_int(dist2_fma(px, py, pz, qa.p3.x, qa.p3.y, qa.p3.z)) & ~kKeyOrd) | (qa.ord + 3)) : INT_MAX;
+    }
+#pragma unroll
+    for (int e = 0; e < kSort24N; e++) {
+      const int a = kSort24[e] >> 5, b = kSort24[e] & 31;
+      const int lo_ = min(w[a], w[b]);
+      w[b] = max(w[a], w[b]);
+      w[a] = lo_;
+    }
+#pragma unroll
+    for (int j = 0; j < L && j < 24; j++) top.a[j] = w[j];
+    tau = top.a[L - 1];
+  }
   fetch(qa);
   for (;;) {
     if (!__any(qa.on)) break;
@@ -944,11 +1020,11 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   }
   auto index_of = [&](int key) {  // ordinal -> position in the sorted array: the last piece whose first ordinal is <= the ordinal
     const int o = key & kKeyOrd;
-    int r = tmix[8 * KNN_T] <= o ? 8 : 0;
+    int r = 0;
 #pragma unroll
-    for (int s = 4; s > 0; s >>= 1)
-      if (tmix[(r + s) * KNN_T] <= o) r += s;
-    return tlo[r * KNN_T] + (o - tmix[r * KNN_T]);
+    for (int s = Shape::CUM / 2; s > 0; s >>= 1)
+      if (tmix[(r + s) * T] <= o) r += s;
+    return tlo[r * T] + (o - tmix[r * T]);
   };
   bool decided = true, swap = false;
   int kth_key = a_km1;
@@ -964,11 +1040,11 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     }
   }
   const float thr_up = __int_as_float(kth_key | kKeyOrd);  // upper bound of the k-th squared distance
-  const double bound = cube_bound(g, c, q, 1);
+  const double bound = cube_bound(g, c, q, R);
   const bool proven = (bound == 1.0e300) || (bound > 0.0 && (double)thr_up < bound * bound * (1.0 - 1e-5));
   if (!proven) {
     // a k-th "neighbour" farther than the block reaches is one of the stray points behind a row: it says nothing about where to look
-    defer(~i, (double)thr_up < 12.0 * g.res * g.res ? thr_up : INFINITY);
+    defer(~i, (double)thr_up < 3.0 * (R + 1) * (R + 1) * g.res * g.res ? thr_up : INFINITY);
     return;
   }
   if (!decided) {
@@ -1013,11 +1089,25 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   nz[i] = nrm[2];
 }
 
+// kTarget names the two instantiations (map vs scan) for the profiles and picks their shape:
+//   map  : 3x3x3 block, nine whole rows, 10 ordinal bits (blocks of up to 1023 candidates; one query in ~100 needs the exact
+//          tie-break of two contenders) -- a leaf-filtered cloud, nothing to clip;
+//   scan : 3x3x3 block as 11 pieces with distance bounds, 12 ordinal bits (4095 candidates) -- a raw sweep: hundreds of points per
+//          cell next to the sensor (done after the own piece), metres between neighbours on its far rings (cooperative kernel).
+template <bool kTarget> struct SpConfig {
+  static constexpr int KB = kTarget ? 10 : 12, R = 1;  // (R = 2, 3 work; for a VLP-16 sweep beside the map's launch they lose to R = 1 at 1 m cells)
+  static constexpr bool kClip = !kTarget;
+  // The scan's launch runs beside the map's, which fills every CU's LDS with four 256-thread workgroups: one-wave workgroups
+  // (18 KiB of LDS each) are admitted as soon as ONE of those retires, a 256-thread one (73 KiB) would wait for two.
+  static constexpr int T = kTarget ? KNN_T : WAVE;
+};
+
 template <int KC, bool kTarget>
-__global__ void __launch_bounds__(KNN_T)
+__global__ void __launch_bounds__(SpConfig<kTarget>::T)
 k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
          double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ int slist_sp[];  // [kSpLds][KNN_T]
+  extern __shared__ int slist_sp[];  // [SpShape::LDS][T]
+  using Cfg = SpConfig<kTarget>;
   wave_prio(!kTarget);
   if (df.guard && *df.guard) return;
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one) and queries are in cell order.
@@ -1025,10 +1115,8 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
   // the runs themselves dealt round-robin (whole contiguous eighths of the map differ too much in work: 7 % slower).
   constexpr int kXcdRun = RGC_XCD_RUN;
   const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
-  const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * KNN_T + threadIdx.x;
-  // the map's keys keep 10 bits for the ordinal (blocks of up to 1023 candidates; one query in ~100 needs the exact tie-break of two
-  // contenders); a raw scan's crowded cells need 12 (4095 candidates, four times as many tie-breaks: cheap for 30 k points)
-  if (i < n) knn_point_sp<KC, kTarget ? 10 : 12>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+  const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
+  if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::kClip, Cfg::R, Cfg::T>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1138,16 +1226,19 @@ __device__ __forceinline__ unsigned coop_kth(const float4* __restrict__ P, const
   return T;
 }
 
+// One-wave workgroups: the launch runs beside other kernels of the frame (the map's bulk launch fills every CU), and a single wave is
+// admitted wherever one SIMD has a slot; the grid is sized by the caller from the previous cloud's deferred count (idle workgroups
+// still have to be dispatched: 2048 four-wave workgroups cost 0.25 ms of the scan's critical path when 200 queries were waiting).
 template <int KC, bool kTarget>
-__global__ void __launch_bounds__(KNN_T)
+__global__ void __launch_bounds__(WAVE)
 k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int k, Deferred df, double* __restrict__ nx,
            double* __restrict__ ny, double* __restrict__ nz) {
-  __shared__ CoopRows shm[KNN_T / WAVE];
+  __shared__ CoopRows shm[1];
   wave_prio(!kTarget);
   if (df.guard && *df.guard) return;
-  const int lane = threadIdx.x & (WAVE - 1), wib = threadIdx.x / WAVE;
-  CoopRows* sh = &shm[wib];
-  const int wave = blockIdx.x * (KNN_T / WAVE) + wib, nwaves = gridDim.x * (KNN_T / WAVE);
+  const int lane = threadIdx.x;
+  CoopRows* sh = &shm[0];
+  const int wave = blockIdx.x, nwaves = gridDim.x;
   const int cnt = *df.cnt;
   for (int e = wave; e < cnt; e += nwaves) {
     const int enc = __builtin_amdgcn_readfirstlane(df.idx[e]);
@@ -2595,22 +2686,26 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
                         double* nx, double* ny, double* nz, const int* guard) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
-  const size_t lds = (size_t)kSpLds * KNN_T * sizeof(int);
-  const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, KNN_T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
-  if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true>), dim3(nb), dim3(KNN_T), lds, s, P, start, g, n, k, df, nx, ny, nz);
-  else hipLaunchKernelGGL((k_knn_sp<KC, false>), dim3(nb), dim3(KNN_T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+  using CT = SpConfig<true>;
+  using CS = SpConfig<false>;
+  const int T = is_target ? CT::T : CS::T;
+  const size_t lds = (size_t)(is_target ? SpShape<CT::R, CT::kClip>::LDS : SpShape<CS::R, CS::kClip>::LDS) * T * sizeof(int);
+  const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
+  if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+  else hipLaunchKernelGGL((k_knn_sp<KC, false>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
 }
 template <int KC>
 static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-                        double* nx, double* ny, double* nz, const int* guard) {
+                        double* nx, double* ny, double* nz, const int* guard, int waves) {
   Deferred df = deferred_of(segs, n);
   df.guard = guard;
-  // the number of deferred queries is only known on the device: one wave each up to 8192 waves, idle blocks exit at once
-  const int nbc = n < 2048 * (KNN_T / WAVE) ? nblk(n, KNN_T / WAVE) : 2048;
+  // the number of deferred queries is only known on the device: `waves` one-wave workgroups share the list (each takes every
+  // waves-th entry); the caller sizes it from the previous cloud of the sequence
+  const int nbc = waves < 32 ? 32 : (waves > 8192 ? 8192 : waves);
   if (is_target)
-    hipLaunchKernelGGL((k_knn_coop<KC, true>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
+    hipLaunchKernelGGL((k_knn_coop<KC, true>), dim3(nbc), dim3(WAVE), 0, s, P, start, g, k, df, nx, ny, nz);
   else
-    hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(KNN_T), 0, s, P, start, g, k, df, nx, ny, nz);
+    hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(WAVE), 0, s, P, start, g, k, df, nx, ny, nz);
 }
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard) {
@@ -2618,9 +2713,9 @@ void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, 
   else knn_bulk_kc<32>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard);
 }
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
-              double* ny, double* nz, const int* guard) {
-  if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard);
-  else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard);
+              double* ny, double* nz, const int* guard, int waves) {
+  if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
+  else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
 }
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int n, const int* cell_voxel, double* vox, int* vox_cell) {
