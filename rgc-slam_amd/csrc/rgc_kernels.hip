@@ -2162,10 +2162,48 @@ __device__ __forceinline__ void nn_search(float px, float py, float pz, const fl
   };
   if (inside) {
     const int own = cell_index(g, c[0], c[1], c[2]);
-    scan(tstart[own], tstart[own + 1]);
+    const int o0 = tstart[own], o1 = tstart[own + 1];
+    scan(o0, o1);
     if (best < INFINITY) {
       const double bound = cube_bound(g, c, q, 0);
       if (bound == 1.0e300 || (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5))) return;
+      // The nearest point of the own cell bounds the search ball: of the 26 neighbouring cells only those the ball reaches can hold
+      // anything nearer (or an equal-distance tie) -- usually one to three of them, not the whole 3x3x3 block.  All their row ranges
+      // are fetched together (one round trip), then scanned.  If the ball pokes out of the block the general loop below takes over.
+      const double b1 = cube_bound(g, c, q, 1);
+      if (b1 == 1.0e300 || (b1 > 0.0 && (double)best < b1 * b1 * (1.0 - 1e-5))) {
+        const double rad2 = (double)best * (1.0 + 1e-5);
+        double wl[3], wh[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const double wall = ((double)(c[a] + g.minc[a]) + 0.5) * g.res;
+          wl[a] = q[a] - wall;
+          wh[a] = wall + g.res - q[a];
+        }
+        int ra[9], rb[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+          const int dy = r % 3 - 1, dz = r / 3 - 1;
+          const int y = c[1] + dy, z = c[2] + dz;
+          const double gy = dy < 0 ? wl[1] : (dy > 0 ? wh[1] : 0.0), gz = dz < 0 ? wl[2] : (dz > 0 ? wh[2] : 0.0);
+          const double m = gy * gy + gz * gz;
+          const bool need = y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && m <= rad2;
+          const int xa = (c[0] > 0 && wl[0] * wl[0] + m <= rad2) ? c[0] - 1 : c[0];
+          const int xb = (c[0] < g.dim[0] - 1 && wh[0] * wh[0] + m <= rad2) ? c[0] + 1 : c[0];
+          ra[r] = need ? tstart[cell_index(g, xa, y, z)] : 0;
+          rb[r] = need ? tstart[cell_index(g, xb, y, z) + 1] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+          if (r == 4) {  // the own row: its own cell has been scanned
+            if (ra[4] < o0) scan(ra[4], o0);
+            if (rb[4] > o1) scan(o1, rb[4]);
+          } else if (rb[r] > ra[r]) {
+            scan(ra[r], rb[r]);
+          }
+        }
+        return;
+      }
     }
   }
   for (;;) {

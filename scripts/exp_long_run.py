@@ -1,7 +1,9 @@
 """Steady state over a long sequence: 3000 c-main frames (23 scans cycled forward and backward so that consecutive frames are consecutive
-poses), per-frame wall time statistics, drift of the rate, device memory before / after."""
+poses), per-frame wall time statistics, drift of the rate, and device memory sampled before the first frame, at frame 200 (the working set
+is allocated by then) and at the end: working set and steady-state growth are separate numbers."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gc
 import numpy as np, torch
 import rgc_slam_amd.synth as synth
 from rgc_slam_amd import registration
@@ -16,6 +18,8 @@ def to_dev(xyz):
 d_tgt = to_dev(tgt); d_s = [to_dev(s) for s in scans]
 order = list(range(23)) + list(range(21, 0, -1))     # 0..22..1, repeated: neighbours in the order are neighbours in space
 free0 = torch.cuda.mem_get_info()[0]
+free200 = None
+gc.collect(); gc.freeze()   # CPython's full collections over torch's object graph are 40 ms pauses of this harness (scripts/exp_stall.py)
 g = poses[0].astype(np.float32)
 per = np.empty(N)
 ref = {}
@@ -26,6 +30,7 @@ for f in range(N):
     v.align(poses[i].astype(np.float32), want_output=False, want_fitness=True)
     T = v.getFinalTransformation()
     per[f] = 1e3 * (time.perf_counter() - t0)
+    if f == 199: v.synchronize(); free200 = torch.cuda.mem_get_info()[0]
     if i in ref: assert np.array_equal(ref[i], T), f"frame {f}: scan {i} gave a different pose than the first time"   # same inputs, same guess
     else: ref[i] = T
 v.synchronize()
@@ -33,4 +38,5 @@ free1 = torch.cuda.mem_get_info()[0]
 q = np.percentile(per[200:], [50, 90, 99, 100])
 print({"frames": N, "ms_median": round(float(q[0]), 4), "ms_p90": round(float(q[1]), 4), "ms_p99": round(float(q[2]), 4), "ms_max": round(float(q[3]), 3),
        "first_500_median": round(float(np.median(per[200:700])), 4), "last_500_median": round(float(np.median(per[-500:])), 4),
-       "frames_over_1ms": int((per[200:] > 1.0).sum()), "device_memory_delta_MiB": round((free0 - free1) / 2**20, 1), "identical_results": True})
+       "frames_over_1ms": int((per[200:] > 1.0).sum()), "working_set_MiB": round((free0 - free200) / 2**20, 1),
+       "steady_state_growth_MiB_frames_200_to_end": round((free200 - free1) / 2**20, 2), "identical_results": True})
