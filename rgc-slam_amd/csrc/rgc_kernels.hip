@@ -697,7 +697,7 @@ struct SpShape {
   static constexpr int D = 2 * R + 1;
   static constexpr int NROW = D * D;               // grid rows of the block
   static constexpr int NP = kClip ? NROW + 2 : NROW;  // pieces: the own row in three parts when clipping
-  static constexpr int CUM = NP < 16 ? 16 : (NP < 32 ? 32 : 64);  // searchable table size (a power of two > NP)
+  static constexpr int CUM = !kClip ? NP : (NP < 16 ? 16 : (NP < 32 ? 32 : 64));  // table size; with clipping searchable: a power of two > NP
   static constexpr int LDS = kSpBuf + CUM + NP;    // ints per lane
 };
 // visiting order, nearest first: the own cell and its row, then the other rows by the Chebyshev ring and the distance of their offset
@@ -766,10 +766,16 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   constexpr int L = KC + 2;
   constexpr int kKeyOrd = (1 << KB) - 1;
   constexpr int kKeyBits = KB;
+  // without clipping the ordinal is {table row (high bits) | position in the row (low 7 bits)}: the winning keys give their
+  // neighbours' positions with ONE table read; with clipping ordinals are handed out as pieces are entered and searched for
+  constexpr int kRowRel = 127;
+  static_assert(kClip || (SpShape<R, kClip>::NP << 7) <= (1 << KB), "ordinal bits: rows x 128");
   constexpr int D = Shape::D, NROW = Shape::NROW, NP = Shape::NP, OWN = NROW / 2;
-  int* const buf = lds;                                   // [kSpBuf][T]
-  int* const tmix = lds + kSpBuf * T;                 // [CUM][T]: before a piece is reached {min distance^2 (fp32, low bits cut) | quads}, after: its first ordinal
-  int* const tlo = lds + (kSpBuf + Shape::CUM) * T;   // [NP][T]
+  // LDS-address-space pointers (32 bits): through a generic int* every address computation is a 64-bit add
+  typedef __attribute__((address_space(3))) int lds_int;
+  lds_int* const buf = (lds_int*)lds;                   // [kSpBuf][T]
+  lds_int* const tmix = buf + kSpBuf * T;               // [CUM][T]: before a piece is reached {min distance^2 (fp32, low bits cut) | quads}, after: its first ordinal
+  lds_int* const tlo = buf + (kSpBuf + Shape::CUM) * T; // [NP][T]
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int c[3] = {voxel_coord_g(px, g) - g.minc[0], voxel_coord_g(py, g) - g.minc[1], voxel_coord_g(pz, g) - g.minc[2]};
@@ -851,7 +857,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   // ordinal; otherwise the first ordinal at once. ----
 #pragma unroll
   for (int j = 0; j < Shape::CUM; j++) tmix[j * T] = INT_MAX;
-  int nr = 0, acc = 0;
+  int nr = 0;
   bool heavy_piece = false;
   constexpr SpOrder<R, kClip> kOrder{};
 #pragma unroll
@@ -861,15 +867,11 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     if (len > 0) {
       const int quads = (len + 3) >> 2;
       heavy_piece |= quads > kPieceQuads;
+      if (!kClip) heavy_piece |= quads > (kRowRel + 1) / 4;  // the row's candidates must fit the ordinal's row-relative part
       tlo[nr * T] = lo[p];
-      tmix[nr * T] = kClip ? ((__float_as_int(min2[p]) & ~kPieceQuads) | quads) : acc;
-      acc += 4 * quads;
+      tmix[nr * T] = kClip ? ((__float_as_int(min2[p]) & ~kPieceQuads) | quads) : quads;
       nr++;
     }
-  }
-  if (!kClip) {
-    tmix[nr * T] = acc;
-    heavy_piece |= acc > kKeyOrd;  // more candidates than ordinals
   }
   if (heavy_piece) {  // (kClip: a piece of more than 4092 points does not fit the table entry)
     defer(i, INFINITY);
@@ -885,8 +887,8 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   int tau = INT_MAX, ri = 0, ordn = 0;
   unsigned off = 0, end = 0;
   bool overflow = false;  // more candidates than the keys' ordinals can number: the query goes to the cooperative kernel
-  int* bp = buf;  // one past the newest buffered key (a column: stride T)
-  int* const bp_full = buf + (kSpBuf - 4) * T;
+  lds_int* bp = buf;  // one past the newest buffered key of this lane's column (stride T)
+  lds_int* const bp_full = buf + (kSpBuf - 4) * T;
   auto pop = [&]() {
     int key = INT_MAX;
     if (bp != buf) {
@@ -935,10 +937,9 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
         ri++;
       }
     } else if (off >= end && ri < nr) {
-      const int l0 = tlo[ri * T], c0 = tmix[ri * T], c1 = tmix[(ri + 1) * T];
-      off = (unsigned)l0 << 4;
-      end = off + ((unsigned)(c1 - c0) << 4);
-      ordn = c0;
+      off = (unsigned)tlo[ri * T] << 4;
+      end = off + ((unsigned)tmix[ri * T] << 6);
+      ordn = ri << 7;
       ri++;
     }
     q.on = off < end;
@@ -1018,9 +1019,10 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     defer(~i, INFINITY);
     return;
   }
-  auto index_of = [&](int key) {  // ordinal -> position in the sorted array: the last piece whose first ordinal is <= the ordinal
+  auto index_of = [&](int key) {  // ordinal -> position in the sorted array
     const int o = key & kKeyOrd;
-    int r = 0;
+    if (!kClip) return tlo[(o >> 7) * T] + (o & kRowRel);
+    int r = 0;  // the last piece whose first ordinal is <= the ordinal
 #pragma unroll
     for (int s = Shape::CUM / 2; s > 0; s >>= 1)
       if (tmix[(r + s) * T] <= o) r += s;
@@ -1090,12 +1092,12 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
 }
 
 // kTarget names the two instantiations (map vs scan) for the profiles and picks their shape:
-//   map  : 3x3x3 block, nine whole rows, 10 ordinal bits (blocks of up to 1023 candidates; one query in ~100 needs the exact
-//          tie-break of two contenders) -- a leaf-filtered cloud, nothing to clip;
+//   map  : 3x3x3 block, nine whole rows of at most 128 candidates, 11 ordinal bits {row | position} (one query in ~50 needs the
+//          exact tie-break of two contenders) -- a leaf-filtered cloud, nothing to clip;
 //   scan : 3x3x3 block as 11 pieces with distance bounds, 12 ordinal bits (4095 candidates) -- a raw sweep: hundreds of points per
 //          cell next to the sensor (done after the own piece), metres between neighbours on its far rings (cooperative kernel).
 template <bool kTarget> struct SpConfig {
-  static constexpr int KB = kTarget ? 10 : 12, R = 1;  // (R = 2, 3 work; for a VLP-16 sweep beside the map's launch they lose to R = 1 at 1 m cells)
+  static constexpr int KB = kTarget ? 11 : 12, R = 1;  // (R = 2, 3 work; for a VLP-16 sweep beside the map's launch they lose to R = 1 at 1 m cells)
   static constexpr bool kClip = !kTarget;
   // The scan's launch runs beside the map's, which fills every CU's LDS with four 256-thread workgroups: one-wave workgroups
   // (18 KiB of LDS each) are admitted as soon as ONE of those retires, a 256-thread one (73 KiB) would wait for two.
