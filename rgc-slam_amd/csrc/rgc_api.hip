@@ -1595,6 +1595,7 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
 }
 
 #ifdef RGC_LAB
+RGC_API int rgc_lab_lm_ts(rgc_ctx* c, unsigned long long* out16) { rgck::lab_lm_ts(out16, c->stream); return RGC_OK; }
 // developer build only (-DRGC_LAB): the deferred-query list of a cloud as the bulk kNN kernel left it
 RGC_API int rgc_lab_deferred(rgc_ctx* c, int is_target, int* idx, float* thr, int cap, int* count) {
   Cloud& cl = is_target ? c->tgt : c->src;

@@ -155,4 +155,7 @@ void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const fl
 void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const float* dsrc, const float* osrc, float* sharp, float* flat, float* inten,
              int cap, int* counts);
 
+#ifdef RGC_LAB
+void lab_lm_ts(unsigned long long* out16, hipStream_t s);  // developer build: phase timestamps of k_lm_step
+#endif
 }  // namespace rgck

@@ -1443,22 +1443,65 @@ __device__ __forceinline__ void neighbor_offset(int noff, int o, int& ox, int& o
 
 // kWriteThrough: the row is handed to another workgroup of the SAME launch (last-block fold): agent-scope relaxed
 // atomic stores lower to write-through (sc1) stores, so no release fence (L2 write-back) is needed before the ticket.
+//
+// Sum of NACC fp64 accumulators over the workgroup in a FIXED order: ((t0 + t1) + (t2 + t3)) inside every quad of lanes with
+// two DPP quad permutes (registers only), the quad sums parked in LDS as [quad][accumulator], then thread (accumulator, eighth)
+// adds its eight quads in ascending order and thread `accumulator` the eight eighths.  The former version reduced every
+// accumulator across the wave with six dependent 64-bit shuffles (two ds_bpermute each): 7.6 us of the LM step's 20
+// (scripts/lab_lm.py); this one moves 4 x fewer values through LDS once.
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_f64(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 template <int NACC, bool kWriteThrough = false>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ row) {
-  __shared__ double red[LIN_T / WAVE][NACC];
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  static_assert(NACC <= 32 && LIN_T == 256, "thread -> (accumulator, eighth) mapping");
+  if constexpr (NACC <= 2) {
+    __shared__ double red[LIN_T / WAVE][NACC];
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
 #pragma unroll
-  for (int a = 0; a < NACC; a++) {
-    double v = wave_sum(acc[a]);
-    if (lane == 0) red[w][a] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < NACC) {
-    double s = 0;
+    for (int a = 0; a < NACC; a++) {
+      double v = wave_sum(acc[a]);
+      if (lane == 0) red[w][a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+      double s = 0;
 #pragma unroll
-    for (int j = 0; j < LIN_T / WAVE; j++) s += red[j][threadIdx.x];
-    if (kWriteThrough) __hip_atomic_store(&row[threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else row[threadIdx.x] = s;
+      for (int j = 0; j < LIN_T / WAVE; j++) s += red[j][threadIdx.x];
+      if (kWriteThrough) __hip_atomic_store(&row[threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else row[threadIdx.x] = s;
+    }
+  } else {
+    constexpr int PITCH = NACC | 1;  // odd pitch: the quads of a wave spread over the banks
+    __shared__ double quads[LIN_T / 4][PITCH];
+    __shared__ double eighths[8][32];
+    const int q = threadIdx.x >> 2;
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+      double v = acc[a];
+      v += quad_perm_f64<0xB1>(v);  // lanes 0<->1, 2<->3
+      v += quad_perm_f64<0x4E>(v);  // lanes 0,1<->2,3: lane 0 of the quad holds (t0 + t1) + (t2 + t3)
+      if ((threadIdx.x & 3) == 0) quads[q][a] = v;
+    }
+    __syncthreads();
+    const int a = threadIdx.x & 31, e = threadIdx.x >> 5;
+    if (a < NACC) {
+      double t = quads[e * 8][a];
+#pragma unroll
+      for (int j = 1; j < 8; j++) t += quads[e * 8 + j][a];
+      eighths[e][a] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+      double t = eighths[0][threadIdx.x];
+#pragma unroll
+      for (int j = 1; j < 8; j++) t += eighths[j][threadIdx.x];
+      if (kWriteThrough) __hip_atomic_store(&row[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else row[threadIdx.x] = t;
+    }
   }
 }
 
@@ -1612,16 +1655,23 @@ __device__ __forceinline__ bool last_block_arrive(int* ticket) {
 
 // Fold of the per-workgroup rows by the last arriver, all LIN_T threads at once: thread t owns accumulator t % 32 and
 // the rows t / 32, t / 32 + 8, ... (summed in ascending order); the eight strided sums of an accumulator are then added in
-// ascending order from LDS.  Fixed order -> deterministic for a given row count; every load of a thread is independent,
-// so the fold costs about one memory round trip instead of one per accumulator.
+// ascending order from LDS.  Fixed order -> deterministic for a given row count.  The rows of a thread are fetched EIGHT at a time
+// before any is added (the loop used to wait for each load in turn: 15 dependent L2 / fabric round trips for a 30 k-point scan).
 template <int NACC>
 __device__ __forceinline__ void block_fold_rows(const double* __restrict__ partials, int nrows, double* sh_out) {
   static_assert(NACC <= 32 && LIN_T == 256, "thread -> (accumulator, row group) mapping");
   __shared__ double grp[LIN_T / 32][32];
   const int a = threadIdx.x & 31, gq = threadIdx.x >> 5;
   double s = 0;
-  if (a < NACC)
-    for (int r = gq; r < nrows; r += LIN_T / 32) s += partials[(size_t)r * NACC + a];
+  if (a < NACC) {
+    for (int r0 = gq; r0 < nrows; r0 += 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = (r0 + 8 * u < nrows) ? partials[(size_t)(r0 + 8 * u) * NACC + a] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];  // (+0.0 past the end: no effect on a sum that starts at +0.0)
+    }
+  }
   grp[gq][a] = s;
   __syncthreads();
   if (threadIdx.x < NACC) {
@@ -1666,6 +1716,142 @@ __device__ __forceinline__ void lm_load_pose(const double* m16, Pose& T) {
   }
 }
 
+#ifdef RGC_LAB
+__device__ unsigned long long g_lab_ts[16];  // developer build: phase timestamps (100 MHz) of the last active k_lm_step
+#define LAB_TS(k) do { if (threadIdx.x == 0) g_lab_ts[(first ? 0 : 8) + k] = wall_clock64(); } while (0)
+#define LAB_TS_MIN(k) do { if (threadIdx.x == 0) atomicMin(&g_lab_ts[(first ? 0 : 8) + k], (unsigned long long)wall_clock64()); } while (0)
+void lab_lm_ts(unsigned long long* out, hipStream_t s) {
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lab_ts), sizeof(g_lab_ts));
+  unsigned long long init[16];
+  for (int i = 0; i < 16; i++) init[i] = ~0ull;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_ts), init, sizeof(init));
+}
+#else
+#define LAB_TS(k)
+#define LAB_TS_MIN(k)
+#endif
+
+// The decision of one STEP launch, taken by lane 0 of the last-arriving workgroup on the LDS copy `ls` of the state: what the
+// folded sums mean in this mode, accept / reject / terminate, and the next LM try (lsq_registration_impl.hpp:125-172).
+__device__ __forceinline__ void lm_step_decide(LmState& ls, const double* folded, int first, const LmInit& in, int mode, int cur,
+                                               const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s) {
+  if (first) {  // fresh state (:53-63) plus the frame's counters, so that ONE read-back at the end carries every statistic
+#pragma unroll
+    for (int a = 0; a < 16; a++) ls.x0[a] = in.x0[a];
+    ls.lambda = -1.0;  // :56
+    ls.nu = 2.0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) ls.Hfin[a * 7] = 1.0;  // final_hessian_.setIdentity(), :21
+    ls.rot_eps = in.rot_eps;
+    ls.trans_eps = in.trans_eps;
+    ls.init_factor = in.init_factor;
+    ls.max_outer = in.max_outer;
+    ls.max_inner = in.max_inner;
+    ls.nvox = nvox ? *nvox : 0;
+    ls.pad = nvox ? (nvox[-1] | (nvox[15] << 8)) : 0;
+    ls.def_t = def_t ? *def_t : 0;
+    ls.def_s = def_s ? *def_s : 0;
+    ls.src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;
+  }
+  double H[36], b[6], x0[16], d[6], delta[16], xi[16];
+  double lambda = ls.lambda;
+  bool have_lin = false;  // H, b (registers) hold a linearisation at the pose the next try starts from
+  auto adopt = [&]() {    // H, b, y0, ncorr of the linearisation just folded
+    int u = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int e = a; e < 6; e++) { H[a * 6 + e] = folded[u]; H[e * 6 + a] = folded[u]; u++; }
+#pragma unroll
+    for (int a = 0; a < 6; a++) b[a] = folded[21 + a];
+#pragma unroll
+    for (int a = 0; a < 36; a++) ls.H[a] = H[a];
+#pragma unroll
+    for (int a = 0; a < 6; a++) ls.b[a] = b[a];
+    ls.y0 = folded[27];
+    ls.ncorr = (int)folded[kAccum];
+    ls.n_lin++;
+    have_lin = true;
+  };
+  if (mode == LM_MODE_LIN) {
+    adopt();
+    if (lambda < 0.0) {  // :130-132
+      double m = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) m = fmax(m, fabs(H[a * 7]));
+      lambda = ls.init_factor * m;
+    }
+#pragma unroll
+    for (int a = 0; a < 16; a++) x0[a] = ls.x0[a];
+    ls.mode = LM_MODE_BA;
+  } else {
+    const double yi = folded[kAccum + 1];
+    ls.yi = yi;
+    ls.n_err++;
+    double den = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) den += ls.d[a] * (lambda * ls.d[a] - ls.b[a]);
+    const double rho = (ls.y0 - yi) / den;  // :145
+    const bool conv_now = lm_is_converged(ls.delta, ls.rot_eps, ls.trans_eps);
+    bool outer_done = false;
+    if (rho < 0) {  // :155-163
+      if (conv_now) {
+        outer_done = true;  // step_lm returns true with x unchanged
+      } else {
+        lambda = ls.nu * lambda;
+        ls.nu = 2 * ls.nu;
+        ls.inner++;
+        if (ls.inner >= ls.max_inner) { ls.failed = 1; ls.done = 1; ls.lambda = lambda; return; }  // "lm not converged!!", :69-72
+#pragma unroll
+        for (int a = 0; a < 36; a++) H[a] = ls.H[a];
+#pragma unroll
+        for (int a = 0; a < 6; a++) b[a] = ls.b[a];
+#pragma unroll
+        for (int a = 0; a < 16; a++) x0[a] = ls.x0[a];
+        have_lin = true;  // the same linearisation, a larger lambda
+        ls.mode = LM_MODE_B;
+      }
+    } else {  // :165-168
+#pragma unroll
+      for (int a = 0; a < 16; a++) { x0[a] = ls.xi[a]; ls.x0[a] = x0[a]; }
+      const double r21 = 2 * rho - 1;
+      lambda = lambda * fmax(1.0 / 3.0, 1 - r21 * r21 * r21);
+#pragma unroll
+      for (int a = 0; a < 36; a++) ls.Hfin[a] = ls.H[a];
+      outer_done = true;
+    }
+    if (outer_done) {
+      ls.conv = conv_now ? 1 : 0;  // :74
+      ls.outer++;
+      ls.nu = 2.0;
+      ls.inner = 0;
+      if (conv_now || ls.outer >= ls.max_outer) {  // :65
+        ls.done = 1;
+        ls.lambda = lambda;
+        return;
+      }
+      // accepted and not finished (rho < 0 never gets here: it only ends an outer iteration when converged)
+      if (mode == LM_MODE_BA) {
+        adopt();          // the speculative linearisation was taken at xi = the new x0
+        ls.cur = cur ^ 1;
+      } else {
+        ls.mode = LM_MODE_LIN;  // retry path: the next launch linearises at the new x0
+      }
+    }
+  }
+  ls.lambda = lambda;
+  if (!have_lin) return;
+  LAB_TS(5);
+  rgclm::lm_try(H, b, lambda, x0, d, delta, xi);  // :136-143
+  LAB_TS(6);
+#pragma unroll
+  for (int a = 0; a < 6; a++) ls.d[a] = d[a];
+#pragma unroll
+  for (int a = 0; a < 16; a++) { ls.delta[a] = delta[a]; ls.xi[a] = xi[a]; }
+  LAB_TS(7);
+}
+
 __global__ void __launch_bounds__(LIN_T)
 k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
           const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v0, double* __restrict__ corr_M0,
@@ -1692,6 +1878,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     return;
   }
   __shared__ double folded[kStepAcc];
+  LAB_TS_MIN(0);
   const int mode = first ? LM_MODE_LIN : st->mode, cur = first ? 0 : st->cur;
   int* cv_cur = cur ? corr_v1 : corr_v0;
   double* cm_cur = cur ? corr_M1 : corr_M0;
@@ -1715,123 +1902,33 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     for (int a = 0; a < kAccum; a++) acc[a] = lin[a];
     acc[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
   }
+  LAB_TS_MIN(1);
   block_reduce_store<kStepAcc, true>(acc, partials + (size_t)blockIdx.x * kStepAcc);
+  LAB_TS_MIN(2);
   if (!last_block_arrive(&st->ticketA)) return;
-  block_fold_rows<kStepAcc>(partials, gridDim.x, folded);
-  if (threadIdx.x != 0) return;
-
-  if (first) {  // fresh state (:53-63) plus the frame's counters, so that ONE read-back at the end carries every statistic
-    int* w = reinterpret_cast<int*>(st);
-    for (int u = 0; u < (int)(sizeof(LmState) / sizeof(int)); u++) w[u] = 0;  // (the ticket was already reset above)
-#pragma unroll
-    for (int a = 0; a < 16; a++) st->x0[a] = in.x0[a];
-    st->lambda = -1.0;  // :56
-    st->nu = 2.0;
-#pragma unroll
-    for (int a = 0; a < 6; a++) st->Hfin[a * 7] = 1.0;  // final_hessian_.setIdentity(), :21
-    st->rot_eps = in.rot_eps;
-    st->trans_eps = in.trans_eps;
-    st->init_factor = in.init_factor;
-    st->max_outer = in.max_outer;
-    st->max_inner = in.max_inner;
-    st->nvox = nvox ? *nvox : 0;
-    st->pad = nvox ? (nvox[-1] | (nvox[15] << 8)) : 0;
-    st->def_t = def_t ? *def_t : 0;
-    st->def_s = def_s ? *def_s : 0;
-    st->src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;
+  LAB_TS(3);
+  // The last arriver works on an LDS copy of the state: all threads fetch it in the same memory round trip as the rows of the
+  // fold, lane 0 takes the decision at LDS latency (the former global-memory accesses were ~2 us of dependent round trips per
+  // step), and all threads write the copy back.
+  __shared__ LmState ls;
+  constexpr int kStateWords = (int)(sizeof(LmState) / sizeof(int));
+  {
+    int* lw = reinterpret_cast<int*>(&ls);
+    const int* gw = reinterpret_cast<const int*>(st);
+    for (int u = threadIdx.x; u < kStateWords; u += LIN_T) lw[u] = first ? 0 : gw[u];
   }
-  double H[36], b[6], x0[16], d[6], delta[16], xi[16];
-  double lambda = st->lambda;
-  bool have_lin = false;  // H, b (registers) hold a linearisation at the pose the next try starts from
-  auto adopt = [&]() {    // H, b, y0, ncorr of the linearisation just folded
-    int u = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int e = a; e < 6; e++) { H[a * 6 + e] = folded[u]; H[e * 6 + a] = folded[u]; u++; }
-#pragma unroll
-    for (int a = 0; a < 6; a++) b[a] = folded[21 + a];
-#pragma unroll
-    for (int a = 0; a < 36; a++) st->H[a] = H[a];
-#pragma unroll
-    for (int a = 0; a < 6; a++) st->b[a] = b[a];
-    st->y0 = folded[27];
-    st->ncorr = (int)folded[kAccum];
-    st->n_lin++;
-    have_lin = true;
-  };
-  if (mode == LM_MODE_LIN) {
-    adopt();
-    if (lambda < 0.0) {  // :130-132
-      double m = 0;
-#pragma unroll
-      for (int a = 0; a < 6; a++) m = fmax(m, fabs(H[a * 7]));
-      lambda = st->init_factor * m;
-    }
-#pragma unroll
-    for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
-    st->mode = LM_MODE_BA;
-  } else {
-    const double yi = folded[kAccum + 1];
-    st->yi = yi;
-    st->n_err++;
-    double den = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++) den += st->d[a] * (lambda * st->d[a] - st->b[a]);
-    const double rho = (st->y0 - yi) / den;  // :145
-    const bool conv_now = lm_is_converged(st->delta, st->rot_eps, st->trans_eps);
-    bool outer_done = false;
-    if (rho < 0) {  // :155-163
-      if (conv_now) {
-        outer_done = true;  // step_lm returns true with x unchanged
-      } else {
-        lambda = st->nu * lambda;
-        st->nu = 2 * st->nu;
-        st->inner++;
-        if (st->inner >= st->max_inner) { st->failed = 1; st->done = 1; st->lambda = lambda; return; }  // "lm not converged!!", :69-72
-#pragma unroll
-        for (int a = 0; a < 36; a++) H[a] = st->H[a];
-#pragma unroll
-        for (int a = 0; a < 6; a++) b[a] = st->b[a];
-#pragma unroll
-        for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
-        have_lin = true;  // the same linearisation, a larger lambda
-        st->mode = LM_MODE_B;
-      }
-    } else {  // :165-168
-#pragma unroll
-      for (int a = 0; a < 16; a++) { x0[a] = st->xi[a]; st->x0[a] = x0[a]; }
-      lambda = lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
-#pragma unroll
-      for (int a = 0; a < 36; a++) st->Hfin[a] = st->H[a];
-      outer_done = true;
-    }
-    if (outer_done) {
-      st->conv = conv_now ? 1 : 0;  // :74
-      st->outer++;
-      st->nu = 2.0;
-      st->inner = 0;
-      if (conv_now || st->outer >= st->max_outer) {  // :65
-        st->done = 1;
-        st->lambda = lambda;
-        return;
-      }
-      // accepted and not finished (rho < 0 never gets here: it only ends an outer iteration when converged)
-      if (mode == LM_MODE_BA) {
-        adopt();          // the speculative linearisation was taken at xi = the new x0
-        st->cur = cur ^ 1;
-      } else {
-        st->mode = LM_MODE_LIN;  // retry path: the next launch linearises at the new x0
-      }
-    }
+  block_fold_rows<kStepAcc>(partials, gridDim.x, folded);  // (its barriers also publish ls)
+  if (threadIdx.x == 0) {
+    LAB_TS(4);
+    ls.ticketA = 0;  // (already reset in memory by last_block_arrive)
+    lm_step_decide(ls, folded, first, in, mode, cur, nvox, def_t, def_s);
   }
-  st->lambda = lambda;
-  if (!have_lin) return;
-  rgclm::lm_try(H, b, lambda, x0, d, delta, xi);  // :136-143
-#pragma unroll
-  for (int a = 0; a < 6; a++) st->d[a] = d[a];
-#pragma unroll
-  for (int a = 0; a < 16; a++) { st->delta[a] = delta[a]; st->xi[a] = xi[a]; }
+  __syncthreads();
+  {
+    const int* lw = reinterpret_cast<const int*>(&ls);
+    int* gw = reinterpret_cast<int*>(st);
+    for (int u = threadIdx.x; u < kStateWords; u += LIN_T) gw[u] = lw[u];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ __host__ __device__ inline void so3_exp_R(const double w[3], double R[9]) {
 // lives in scratch memory and costs ~10 us per call).  H + lambda I is positive definite whenever there are
 // correspondences; a zero pivot reports failure (d = NaN upstream, like a failed Eigen solve would propagate).
 __host__ __device__ inline bool solve_ldlt6(const double Ain[36], const double rhs[6], double x[6]) {
-  double L[6][6], D[6];
+  double L[6][6], D[6], invD[6];  // one division per pivot (an fp64 division is ~40 dependent instructions on the device lane)
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
@@ -43,6 +43,7 @@ __host__ __device__ inline bool solve_ldlt6(const double Ain[36], const double r
       if (j < k) dk -= L[k][j] * L[k][j] * D[j];
     D[k] = dk;
     if (dk == 0.0 || !(fabs(dk) < 1.0e300)) ok = false;
+    invD[k] = 1.0 / dk;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
       if (i > k) {
@@ -50,7 +51,7 @@ __host__ __device__ inline bool solve_ldlt6(const double Ain[36], const double r
 #pragma unroll
         for (int j = 0; j < 6; j++)
           if (j < k) v -= L[i][j] * L[k][j] * D[j];
-        L[i][k] = v / dk;
+        L[i][k] = v * invD[k];
       }
     }
   }
@@ -65,7 +66,7 @@ __host__ __device__ inline bool solve_ldlt6(const double Ain[36], const double r
     y[i] = s;
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) y[i] /= D[i];
+  for (int i = 0; i < 6; i++) y[i] *= invD[i];
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
     double s = y[i];
