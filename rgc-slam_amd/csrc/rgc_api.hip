@@ -83,16 +83,13 @@ struct rgc_ctx {
   double* h_out = nullptr;    // pinned
   DevBuf scratch;             // getters
   DevBuf lm_state;            // device-chained LM state (rgck::LmState)
-  bool lm_persist = false;    // RGC_LM_IMPL=persistent: the whole solve in one launch with grid-wide hand-offs (A/B knob;
-                              // measured 215 us against 160 us for the chained two-kernel slots on MI355X, so not the default)
-  int lm_gen = 0;             // hand-off generation the device state is at (read back with the state)
   // f1: mapping-node feature registration (corner / surf feature maps: grid only, 1.5 m cells)
   Cloud mr_map[2];
   DevBuf mr_feat[4], mr_fac[4], mr_partials, mr_small;
   bool deferred_known = false;  // stats.deferred_* are those of the current clouds (carried home by the last align)
   DevBuf fit_partials;        // fitness rows when it is chained behind the LM slots
   rgck::LmState* h_lm = nullptr;  // pinned mirror
-  bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop (A/B knob)
+  bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
   double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
   double src_res_auto = 0.0;  // adaptive cell size of the scan's kNN grid, steered by how crowded its cells were in the previous frame (0 = voxel_res)
@@ -899,7 +896,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
-  if (const char* e = getenv("RGC_LM_IMPL")) { c->lm_host = strcmp(e, "host") == 0; c->lm_persist = strcmp(e, "persistent") == 0; }
+  if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   *out = c;
   return RGC_OK;
@@ -1021,9 +1018,8 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 2) * (size_t)nb))) return rc;
     if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
     if (!c->lm_state.p) {
-      if ((rc = ensure(c, c->lm_state, 4096))) return rc;  // LmState + the persistent solve's mailbox lines at +2048
-      HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->stream));  // tickets and generation start at 0
-      c->lm_gen = 0;
+      if ((rc = ensure(c, c->lm_state, 4096))) return rc;
+      HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->stream));  // tickets start at 0
     }
     if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)rgck::fitness_blocks(n) + 64))) return rc;
     rgck::LmState& S = *c->h_lm;
@@ -1031,39 +1027,9 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
     memcpy(in.x0, x0, sizeof(x0));
     in.rot_eps = P.rotation_eps; in.trans_eps = P.translation_eps; in.init_factor = P.lm_init_lambda_factor;
     in.max_outer = P.max_iterations; in.max_inner = P.lm_max_iterations;
-    bool solved = false;
-    if (c->lm_persist && nb <= 256) {  // one workgroup per CU at most: co-residency is certain
-      // the whole solve (and the fitness behind it) in one enqueue, one read-back
-      {
-        ProfScope ps(c, RGC_K_LINEARIZE, n);
-        rgck::lm_run(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
-                     c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
-                     (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, in, c->lm_gen, c->d_small + 7,
-                     c->tgt.segs.p, c->src.segs.p);
-      }
-      if (fitness) {
-        ProfScope ps(c, RGC_K_FITNESS, n);
-        rgck::fitness_lm(c->stream, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
-                         (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p);
-      }
-      HIPCHK(c, hipMemcpyAsync(&S, c->lm_state.p, sizeof(S), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      HIPCHK(c, hipGetLastError());
-      c->lm_gen = S.gen;
-      if (S.failed == 2) {
-        // a grid-wide hand-off timed out (workgroups not co-resident?): never again on this context; redo this solve with
-        // the two-kernel slots, which need no co-residency
-        c->lm_persist = false;
-        snprintf(c->err, sizeof(c->err), "persistent LM launch timed out; falling back to chained slots");
-      } else {
-        solved = true;
-        fitness_chained = S.has_fit != 0;
-      }
-    }
     int batch = 7;  // one linearisation + six fused cost/linearise steps: up to six outer iterations without a read-back
     bool first_step = true;
-    if (!solved) c->lm_gen = 0;  // the first step kernel rewrites the whole state
-    for (int guard = 0; guard < 400 && !solved; guard++) {
+    for (int guard = 0; guard < 400; guard++) {
       {
         ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch);
         for (int k = 0; k < batch; k++)
@@ -1089,7 +1055,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
       if (r < 0) return r;
       if (r > 0) return rgc_align(c, guess, final_T, final_H, fitness, iterations, converged, lm_failed);
     }
-    if (!solved && S.cur) { std::swap(c->corr_v, c->corr_v2); std::swap(c->corr_M, c->corr_M2); }  // corr_v / corr_M = the valid buffer
+    if (S.cur) { std::swap(c->corr_v, c->corr_v2); std::swap(c->corr_M, c->corr_M2); }  // corr_v / corr_M = the valid buffer
     c->corr_noff = noff; c->corr_n = n; c->corr_valid = S.n_lin > 0;
     c->stats.n_corr = S.ncorr; c->stats.n_linearize = S.n_lin; c->stats.n_error = S.n_err;
     c->tgt.nvox = c->stats.n_voxels = S.nvox;
@@ -1596,6 +1562,7 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
 
 #ifdef RGC_LAB
 RGC_API int rgc_lab_lm_ts(rgc_ctx* c, unsigned long long* out16) { rgck::lab_lm_ts(out16, c->stream); return RGC_OK; }
+RGC_API int rgc_lab_wave_ts(rgc_ctx* c, long long* out16384) { (void)hipStreamSynchronize(c->stream); rgck::lab_wave_ts(out16384, c->stream2); return RGC_OK; }
 // developer build only (-DRGC_LAB): the deferred-query list of a cloud as the bulk kNN kernel left it
 RGC_API int rgc_lab_deferred(rgc_ctx* c, int is_target, int* idx, float* thr, int cap, int* count) {
   Cloud& cl = is_target ? c->tgt : c->src;

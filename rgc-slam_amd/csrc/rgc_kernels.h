@@ -37,7 +37,7 @@ struct LmState {  // device-resident state of LsqRegistration::computeTransforma
   int phase, done, conv, failed, outer, inner, n_lin, n_err, ncorr, ticketA, ticketB, max_outer, max_inner, has_fit;
   double fit_sum;                // sum of squared NN distances at the final pose (k_fitness_lm)
   int nvox, def_t, def_s, pad;   // frame counters carried home with the state; pad = grid guards, map | scan << 8
-  int gen, cmd, mode, cur;       // persistent solve: hand-off generation + command; step kernels: mode, valid corr buffer
+  int gen, cmd, mode, cur;       // step kernels: mode, valid correspondence buffer (gen, cmd: unused, kept for the layout)
   float src_sq; int pad2;        // sum over the scan's grid cells of count^2 (how crowded its cells are; steers the scan's cell size)
 };
 struct LmInit { double x0[16], rot_eps, trans_eps, init_factor; int max_outer, max_inner; };
@@ -86,10 +86,6 @@ void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
              const LmInit* first /* non-null: this launch opens a solve */, const int* nvox, const void* segs_t, const void* segs_s);
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials);
-// the whole solve in one persistent launch (needs linearize_blocks(n) co-resident workgroups: callers keep it <= 256)
-void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
-            const double* vox, int noff, int* corr_v, double* corr_M, double* partials, LmState* st, const LmInit& in, int gen_base,
-            const int* nvox, const void* segs_t, const void* segs_s);
 // ---- f1: mapping-node feature registration (RGC_mapping.cpp:1069-1358) ----
 // factor record = 8 doubles per feature: edge {a[3], b[3], var, valid}, plane {n[3], d, 0, 0, var, valid}
 struct MapregAssoc {  // one association loop: feature set (n x 4: x,y,z,weight), its pose, the map grid it is matched against
@@ -157,5 +153,6 @@ void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const flo
 
 #ifdef RGC_LAB
 void lab_lm_ts(unsigned long long* out16, hipStream_t s);  // developer build: phase timestamps of k_lm_step
+void lab_wave_ts(long long* out16384, hipStream_t s);       // developer build: start / end of the scan kNN launch's waves
 #endif
 }  // namespace rgck

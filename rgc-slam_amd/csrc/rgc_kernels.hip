@@ -15,7 +15,7 @@
 //                   queries, one wave per query)
 //   C3 voxel map    k_voxel_build
 //   C4-C7 solve     linearize_point, error_point, block_reduce_store, last_block_arrive, block_fold_rows, k_lm_step (default
-//                   driver), k_lm_run (persistent A/B knob), k_linearize / k_error / k_fold / k_lm_try (public fine seam)
+//                   driver), k_linearize / k_error / k_fold / k_lm_try (public fine seam)
 //   C8, f4          nn_search, k_fitness(_lm), k_icp_accumulate, k_transform_f32
 //   f1              k_mapreg_associate, k_mapreg_terms, k_mapreg_fold
 //   launch wrappers at the end (namespace rgck, declared in rgc_kernels.h)
@@ -50,6 +50,29 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
   return v;
+}
+
+// DPP quad permutes (registers only): lane l of every quad of lanes reads lane (CTRL >> 2 l) & 3 of its quad
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_f64(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int kQuadSwap1 = 0xB1, kQuadSwap2 = 0x4E;  // lanes 0<->1, 2<->3 / lanes 0,1<->2,3
+__device__ __forceinline__ int quad_max_i(int v) {
+  v = max(v, quad_perm_i<kQuadSwap1>(v));
+  return max(v, quad_perm_i<kQuadSwap2>(v));
+}
+__device__ __forceinline__ int quad_or_i(int v) {
+  v |= quad_perm_i<kQuadSwap1>(v);
+  return v | quad_perm_i<kQuadSwap2>(v);
+}
+__device__ __forceinline__ double quad_sum_f64(double v) {  // (l0 + l1) + (l2 + l3) in every lane of the quad... up to the order of each pair
+  v += quad_perm_f64<kQuadSwap1>(v);
+  return v + quad_perm_f64<kQuadSwap2>(v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -755,36 +778,17 @@ __device__ __forceinline__ float dist2_fma(float px, float py, float pz, float c
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
-// KB: low key bits that hold the candidate's ordinal (ordinals < 2^KB).  kClip: pieces carry distance bounds and are skipped once the
-// scan's bound excludes them, the own row is cut in three, ordinals are handed out as pieces are entered (a raw scan's crowded
-// cells); without it the block is nine whole rows numbered up front (a leaf-filtered map: nothing to skip, less bookkeeping).
-template <int KC, int KB, bool kClip, int R, int T>  // T: threads per workgroup = stride of the per-lane LDS columns
-__device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
-                                             int i, int* lds, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
-                                             double* __restrict__ nz) {
+// LDS-address-space pointers (32 bits): through a generic int* every address computation is a 64-bit add
+typedef __attribute__((address_space(3))) int lds_int;
+
+// The piece table of query (c, q) in the lane's LDS columns tmix / tlo (stride T), nearest first; returns the number of pieces.
+// heavy_piece: some piece is too long for its table entry (or, without clipping, for the row-relative ordinal).
+template <bool kClip, int R, int T>
+__device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, const Grid& g, const int (&c)[3], const double (&q)[3],
+                                              lds_int* const tmix, lds_int* const tlo, bool& heavy_piece) {
   using Shape = SpShape<R, kClip>;
-  constexpr int L = KC + 2;
-  constexpr int kKeyOrd = (1 << KB) - 1;
-  constexpr int kKeyBits = KB;
-  // without clipping the ordinal is {table row (high bits) | position in the row (low 7 bits)}: the winning keys give their
-  // neighbours' positions with ONE table read; with clipping ordinals are handed out as pieces are entered and searched for
   constexpr int kRowRel = 127;
-  static_assert(kClip || (SpShape<R, kClip>::NP << 7) <= (1 << KB), "ordinal bits: rows x 128");
   constexpr int D = Shape::D, NROW = Shape::NROW, NP = Shape::NP, OWN = NROW / 2;
-  // LDS-address-space pointers (32 bits): through a generic int* every address computation is a 64-bit add
-  typedef __attribute__((address_space(3))) int lds_int;
-  lds_int* const buf = (lds_int*)lds;                   // [kSpBuf][T]
-  lds_int* const tmix = buf + kSpBuf * T;               // [CUM][T]: before a piece is reached {min distance^2 (fp32, low bits cut) | quads}, after: its first ordinal
-  lds_int* const tlo = buf + (kSpBuf + Shape::CUM) * T; // [NP][T]
-  const float4 pq = P[i];
-  const float px = pq.x, py = pq.y, pz = pq.z;
-  const int c[3] = {voxel_coord_g(px, g) - g.minc[0], voxel_coord_g(py, g) - g.minc[1], voxel_coord_g(pz, g) - g.minc[2]};
-  const double q[3] = {(double)px, (double)py, (double)pz};
-  auto defer = [&](int enc, float thr) {
-    const int e = atomicAdd(df.cnt, 1);
-    df.idx[e] = enc;
-    df.thr[e] = thr;
-  };
   // ---- the block's pieces in MEMORY order: the D x D grid rows r = D (dz + R) + (dy + R), each the cells cx - R .. cx + R.  kClip: the
   // own row (r = OWN) as three pieces cut at multiples of four points from its start -- left of the own cell, the own cell, right
   // of it -- so pieces OWN, OWN + 1, OWN + 2, and the rows behind it shifted by two. ----
@@ -858,7 +862,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
 #pragma unroll
   for (int j = 0; j < Shape::CUM; j++) tmix[j * T] = INT_MAX;
   int nr = 0;
-  bool heavy_piece = false;
+  heavy_piece = false;
   constexpr SpOrder<R, kClip> kOrder{};
 #pragma unroll
   for (int it = 0; it < NP; it++) {
@@ -873,6 +877,38 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
       nr++;
     }
   }
+  return nr;
+}
+
+// KB: low key bits that hold the candidate's ordinal (ordinals < 2^KB).  kClip: pieces carry distance bounds and are skipped once the
+// scan's bound excludes them, the own row is cut in three, ordinals are handed out as pieces are entered (a raw scan's crowded
+// cells); without it the block is nine whole rows numbered up front (a leaf-filtered map: nothing to skip, less bookkeeping).
+template <int KC, int KB, bool kClip, int R, int T>  // T: threads per workgroup = stride of the per-lane LDS columns
+__device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
+                                             int i, int* lds, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
+                                             double* __restrict__ nz) {
+  using Shape = SpShape<R, kClip>;
+  constexpr int L = KC + 2;
+  constexpr int kKeyOrd = (1 << KB) - 1;
+  constexpr int kKeyBits = KB;
+  // without clipping the ordinal is {table row (high bits) | position in the row (low 7 bits)}: the winning keys give their
+  // neighbours' positions with ONE table read; with clipping ordinals are handed out as pieces are entered and searched for
+  constexpr int kRowRel = 127;
+  static_assert(kClip || (SpShape<R, kClip>::NP << 7) <= (1 << KB), "ordinal bits: rows x 128");
+  lds_int* const buf = (lds_int*)lds;                   // [kSpBuf][T]
+  lds_int* const tmix = buf + kSpBuf * T;               // [CUM][T]: before a piece is reached {min distance^2 (fp32, low bits cut) | quads}, after: its first ordinal
+  lds_int* const tlo = buf + (kSpBuf + Shape::CUM) * T; // [NP][T]
+  const float4 pq = P[i];
+  const float px = pq.x, py = pq.y, pz = pq.z;
+  const int c[3] = {voxel_coord_g(px, g) - g.minc[0], voxel_coord_g(py, g) - g.minc[1], voxel_coord_g(pz, g) - g.minc[2]};
+  const double q[3] = {(double)px, (double)py, (double)pz};
+  auto defer = [&](int enc, float thr) {
+    const int e = atomicAdd(df.cnt, 1);
+    df.idx[e] = enc;
+    df.thr[e] = thr;
+  };
+  bool heavy_piece = false;
+  const int nr = sp_piece_table<kClip, R, T>(start, g, c, q, tmix, tlo, heavy_piece);
   if (heavy_piece) {  // (kClip: a piece of more than 4092 points does not fit the table entry)
     defer(i, INFINITY);
     return;
@@ -1091,6 +1127,275 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   nz[i] = nrm[2];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same search with FOUR LANES PER QUERY, for clouds too small to fill the chip with one lane per query (a raw sweep: ~470
+// waves for 1024 SIMDs, and the launch lasts as long as its slowest wave -- the 64 queries of a crowded cell next to the sensor,
+// 185 us against a median of 34, scripts/lab_wave.py).  The four lanes of a quad walk the SAME pieces in lock-step and take every
+// fourth quad of candidates each (a piece is padded to a multiple of four quads, so they reach its end together):
+//  * ordinals number the query's whole candidate stream, as if one lane had walked it: keys of the four lanes merge directly;
+//  * each lane keeps the Ls = (k + 2) / 2 + 1 smallest keys of ITS candidates.  If every lane holds b = ceil((k + 2) / 4) keys
+//    <= X then k + 2 keys of the union are <= X: the largest of the four lanes' b-th keys (two DPP quad permutes, after every
+//    drain) bounds what can still matter -- appends and piece skipping use it, so pruning is as sharp as with one chain;
+//    the skip decision uses ONLY this shared bound: the four lanes take it alike, their tables stay identical;
+//  * at the end every lane merges the four chains (quad broadcasts) into the k + 2 smallest of the union.  A lane whose chain was
+//    full and whose tail is below the (k + 2)-th merged key may have dropped a needed key: the query is deferred (never seen
+//    with an interleaved split; the cooperative kernel is exact for anything);
+//  * the neighbours' moments are gathered five per lane and summed over the quad; the eigenvector is solved in all four.
+// ------------------------------------------------------------------------------------------------
+template <int KC, int KB, int T>
+__device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
+                                                int i, int sub, int* lds, const Deferred& df, double* __restrict__ nx,
+                                                double* __restrict__ ny, double* __restrict__ nz) {
+  constexpr bool kClip = true;
+  constexpr int R = 1, S = 4;
+  using Shape = SpShape<R, kClip>;
+  constexpr int L = KC + 2, Ls = (KC + 2) / 2 + 1;
+  static_assert(Ls <= 24 && KC % S == 0, "initial fill by the 24-input network; neighbours dealt evenly to the quad");
+  constexpr int kKeyOrd = (1 << KB) - 1;
+  constexpr int kKeyBits = KB;
+  lds_int* const buf = (lds_int*)lds;                   // [kSpBuf][T]
+  lds_int* const tmix = buf + kSpBuf * T;               // [CUM][T]
+  lds_int* const tlo = buf + (kSpBuf + Shape::CUM) * T; // [NP][T]
+  const float4 pq = P[i];
+  const float px = pq.x, py = pq.y, pz = pq.z;
+  const int c[3] = {voxel_coord_g(px, g) - g.minc[0], voxel_coord_g(py, g) - g.minc[1], voxel_coord_g(pz, g) - g.minc[2]};
+  const double q[3] = {(double)px, (double)py, (double)pz};
+  auto defer = [&](int enc, float thr) {  // (the four lanes of a query take every branch alike: one of them reports)
+    if (sub == 0) {
+      const int e = atomicAdd(df.cnt, 1);
+      df.idx[e] = enc;
+      df.thr[e] = thr;
+    }
+  };
+  bool heavy_piece = false;
+  const int nr = sp_piece_table<kClip, R, T>(start, g, c, q, tmix, tlo, heavy_piece);
+  if (heavy_piece) {
+    defer(i, INFINITY);
+    return;
+  }
+  // ---- one pass over this lane's quarter of the candidate stream ----
+  Chain<Ls> top;
+  top.init();
+  const int bi = (k + 2 + S - 1) / S - 1;
+  int shared = INT_MAX;  // upper bound of the (k + 2)-th smallest key of the union, the same in the four lanes
+  int tau = INT_MAX;     // min(own tail, shared): what an append must beat
+  auto refresh = [&]() {
+    shared = quad_max_i(k == KC ? top.a[(KC + 2 + S - 1) / S - 1] : top.at(bi));
+    tau = min(top.a[Ls - 1], shared);
+  };
+  int ri = 0, ordn = 0, ord = 0, jleft = 0;  // next piece, its first ordinal; this lane's next quad: ordinal, slots left in the piece
+  unsigned off = 0, end = 0;
+  bool overflow = false;
+  lds_int* bp = buf;
+  lds_int* const bp_full = buf + (kSpBuf - 4) * T;
+  auto pop = [&]() {
+    int key = INT_MAX;
+    if (bp != buf) {
+      bp -= T;
+      key = *bp;
+    }
+    return key;
+  };
+  auto drain = [&]() {
+    int key = pop();
+    for (;;) {
+      const int nkey = pop();
+      top.insert(key);
+      if (!__any(nkey != INT_MAX)) break;
+      key = nkey;
+    }
+    refresh();
+  };
+  struct Quad { float4 p0, p1, p2, p3; int ord; bool on, live; };
+  auto fetch = [&](Quad& qd) {
+    while (jleft == 0 && ri < nr) {
+      const int mix = tmix[ri * T];
+      tmix[ri * T] = ordn;
+      const int quads = mix & kPieceQuads;
+      const bool reach = !(__int_as_float(mix & ~kPieceQuads) >= __int_as_float(shared | kKeyOrd));  // INT_MAX: NaN, no skip
+      if (reach) {
+        if (ordn + 4 * quads > kKeyOrd) {
+          overflow = true;
+          ri = nr;
+          break;
+        }
+        const unsigned base = (unsigned)tlo[ri * T] << 4;
+        off = base + 64u * (unsigned)sub;
+        end = base + ((unsigned)quads << 6);
+        ord = ordn + 4 * sub;
+        jleft = (quads + S - 1) / S;
+        ordn += 4 * quads;
+      }
+      ri++;
+    }
+    qd.live = jleft > 0;
+    qd.on = qd.live && off < end;
+    qd.ord = ord;
+    const unsigned a = qd.on ? off : (unsigned)n << 4;  // unconditional loads (the sentinels), as in knn_point_sp
+    qd.p0 = point_at(P, a); qd.p1 = point_at(P, a + 16); qd.p2 = point_at(P, a + 32); qd.p3 = point_at(P, a + 48);
+    off += qd.live ? 64u * S : 0u;
+    ord += qd.live ? 4 * S : 0;
+    jleft -= qd.live ? 1 : 0;
+  };
+  auto key_of = [&](const float4& cp, int o) { return (__float_as_int(dist2_fma(px, py, pz, cp.x, cp.y, cp.z)) & ~kKeyOrd) | o; };
+  auto process = [&](const Quad& qd) {
+    if (qd.on) {
+      const int k0 = key_of(qd.p0, qd.ord), k1 = key_of(qd.p1, qd.ord + 1), k2 = key_of(qd.p2, qd.ord + 2), k3 = key_of(qd.p3, qd.ord + 3);
+      if (k0 < tau) { *bp = k0; bp += T; }
+      if (k1 < tau) { *bp = k1; bp += T; }
+      if (k2 < tau) { *bp = k2; bp += T; }
+      if (k3 < tau) { *bp = k3; bp += T; }
+    }
+    if (__any(bp > bp_full)) drain();
+  };
+  Quad qa, qb;
+  {  // this lane's first 24 candidates through the sorting network (knn_point_sp); the Ls smallest become its chain
+    int w[24];
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      fetch(qa);
+      w[4 * t + 0] = qa.on ? key_of(qa.p0, qa.ord) : INT_MAX;
+      w[4 * t + 1] = qa.on ? key_of(qa.p1, qa.ord + 1) : INT_MAX;
+      w[4 * t + 2] = qa.on ? key_of(qa.p2, qa.ord + 2) : INT_MAX;
+      w[4 * t + 3] = qa.on ? key_of(qa.p3, qa.ord + 3) : INT_MAX;
+    }
+#pragma unroll
+    for (int e = 0; e < kSort24N; e++) {
+      const int a = kSort24[e] >> 5, b = kSort24[e] & 31;
+      const int lo_ = min(w[a], w[b]);
+      w[b] = max(w[a], w[b]);
+      w[a] = lo_;
+    }
+#pragma unroll
+    for (int j = 0; j < Ls; j++) top.a[j] = w[j];
+    refresh();
+  }
+  fetch(qa);
+  for (;;) {
+    if (!__any(qa.live)) break;
+    fetch(qb);
+    process(qa);
+    if (!__any(qb.live)) break;
+    fetch(qa);
+    process(qb);
+  }
+  if (__any(bp != buf)) drain();
+  if (overflow) {
+    defer(i, INFINITY);
+    return;
+  }
+  // ---- the k + 2 smallest keys of the union, in every lane of the quad ----
+  Chain<L> all;
+#pragma unroll
+  for (int j = 0; j < L; j++) all.a[j] = j < Ls ? quad_perm_i<0x00>(top.a[j]) : INT_MAX;
+  auto merge_from = [&](auto ctrl_tag) {
+    constexpr int kCtrl = decltype(ctrl_tag)::value;
+    bool more = true;  // a chain is ascending: once one of its keys is not below any lane's merged tail, none of the rest is
+#pragma unroll
+    for (int j = 0; j < Ls; j++) {
+      const int x = quad_perm_i<kCtrl>(top.a[j]);
+      if (more) {
+        more = __any(x < all.a[L - 1]);
+        if (more) all.insert(x);
+      }
+    }
+  };
+  merge_from(std::integral_constant<int, 0x55>{});
+  merge_from(std::integral_constant<int, 0xAA>{});
+  merge_from(std::integral_constant<int, 0xFF>{});
+  int a_km2, a_km1, a_k, a_kp1;
+  if (k == KC) {
+    a_km2 = all.a[KC - 2]; a_km1 = all.a[KC - 1]; a_k = all.a[KC]; a_kp1 = all.a[KC + 1];
+  } else {
+    a_km2 = k >= 2 ? all.at(k - 2) : -(4 << kKeyBits);
+    a_km1 = all.at(k - 1); a_k = all.at(k); a_kp1 = all.at(k + 1);
+  }
+  if (quad_or_i(top.a[Ls - 1] < a_kp1 ? 1 : 0)) {  // a full chain whose tail ranks inside the merged k + 2: a needed key may have been dropped
+    defer(i, INFINITY);
+    return;
+  }
+  if (a_km1 >= 0x7f800000) {  // fewer than k candidates in the block
+    defer(~i, INFINITY);
+    return;
+  }
+  auto index_of = [&](int key) {  // ordinal -> position in the sorted array (the lanes' tables are identical)
+    const int o = key & kKeyOrd;
+    int r = 0;
+#pragma unroll
+    for (int st = Shape::CUM / 2; st > 0; st >>= 1)
+      if (tmix[(r + st) * T] <= o) r += st;
+    return tlo[r * T] + (o - tmix[r * T]);
+  };
+  bool decided = true, swap = false;
+  int kth_key = a_km1;
+  if ((a_k >> kKeyBits) - (a_km1 >> kKeyBits) < 2) {  // as in knn_point_sp: two contenders are compared exactly, more are deferred
+    decided = false;
+    if ((a_kp1 >> kKeyBits) - (a_k >> kKeyBits) >= 2 && (a_km1 >> kKeyBits) - (a_km2 >> kKeyBits) >= 2) {
+      const float4 p1 = P[index_of(a_km1)], p2 = P[index_of(a_k)];
+      const float d1 = dist2(px, py, pz, p1), d2 = dist2(px, py, pz, p2);
+      decided = d1 != d2;
+      swap = d2 < d1;
+      if (swap) kth_key = a_k;
+    }
+  }
+  const float thr_up = __int_as_float(kth_key | kKeyOrd);
+  const double bound = cube_bound(g, c, q, R);
+  const bool proven = (bound == 1.0e300) || (bound > 0.0 && (double)thr_up < bound * bound * (1.0 - 1e-5));
+  if (!proven) {
+    defer(~i, (double)thr_up < 3.0 * (R + 1) * (R + 1) * g.res * g.res ? thr_up : INFINITY);
+    return;
+  }
+  if (!decided) {
+    defer(i, thr_up);
+    return;
+  }
+  // ---- moments of neighbours sub, sub + 4, ... in this lane, summed over the quad (one-pass form of knn_point_sp) ----
+  const int idx_k = swap ? index_of(a_k) : 0;
+  double S6[6] = {0, 0, 0, 0, 0, 0}, m3[3] = {0, 0, 0};
+  // this lane's pick of four registers by bit masks (a select chain on `sub` is turned into an indexed stack array by the compiler)
+  const int m_lo = -(sub & 1), m_hi = -(sub >> 1);
+  auto pick4 = [](int mlo, int mhi, int a0, int a1, int a2, int a3) {
+    const int x = a0 ^ ((a0 ^ a1) & mlo), y = a2 ^ ((a2 ^ a3) & mlo);
+    return x ^ ((x ^ y) & mhi);
+  };
+  auto moments = [&](auto full_tag) {
+    constexpr bool kFull = decltype(full_tag)::value;
+    const double qx = (double)px, qy = (double)py, qz = (double)pz;
+#pragma unroll
+    for (int t = 0; t < KC / S; t++) {  // positions replace the keys (slots 0 .. KC / S - 1: the keys there have been read by then)
+      const int key = pick4(m_lo, m_hi, all.a[S * t], all.a[S * t + 1], all.a[S * t + 2], all.a[S * t + 3]);
+      const int j = S * t + sub;
+      all.a[t] = (swap && j == k - 1) ? idx_k : ((kFull || j < k) ? index_of(key) : 0);
+    }
+#pragma unroll
+    for (int t = 0; t < KC / S; t++) {
+      const float4 cp = P[all.a[t]];  // (unconditional: position 0 is a valid point; its terms are masked below)
+      const bool use = kFull || S * t + sub < k;
+      const double dx = use ? (double)cp.x - qx : 0.0, dy = use ? (double)cp.y - qy : 0.0, dz = use ? (double)cp.z - qz : 0.0;
+      m3[0] += dx; m3[1] += dy; m3[2] += dz;
+      S6[0] += dx * dx; S6[1] += dx * dy; S6[2] += dx * dz;
+      S6[3] += dy * dy; S6[4] += dy * dz; S6[5] += dz * dz;
+    }
+  };
+  if (k == KC) moments(std::true_type{});
+  else moments(std::false_type{});
+#pragma unroll
+  for (int a = 0; a < 3; a++) m3[a] = quad_sum_f64(m3[a]);
+#pragma unroll
+  for (int a = 0; a < 6; a++) S6[a] = quad_sum_f64(S6[a]);
+  const double inv_k = 1.0 / (double)k;
+  const double mx = m3[0] * inv_k, my = m3[1] * inv_k, mz = m3[2] * inv_k;
+  double Sc[6] = {S6[0] * inv_k - mx * mx, S6[1] * inv_k - mx * my, S6[2] * inv_k - mx * mz,
+                  S6[3] * inv_k - my * my, S6[4] * inv_k - my * mz, S6[5] * inv_k - mz * mz};
+  double nrm[3];
+  if (!min_eigenvector_direct(Sc, nrm)) min_eigenvector(Sc, nrm);
+  if (sub == 0) {
+    nx[i] = nrm[0];
+    ny[i] = nrm[1];
+    nz[i] = nrm[2];
+  }
+}
+
 // kTarget names the two instantiations (map vs scan) for the profiles and picks their shape:
 //   map  : 3x3x3 block, nine whole rows of at most 128 candidates, 11 ordinal bits {row | position} (one query in ~50 needs the
 //          exact tie-break of two contenders) -- a leaf-filtered cloud, nothing to clip;
@@ -1104,6 +1409,13 @@ template <bool kTarget> struct SpConfig {
   static constexpr int T = kTarget ? KNN_T : WAVE;
 };
 
+#ifdef RGC_LAB
+__device__ long long g_lab_wave[2 * 8192];  // developer build: start / end (100 MHz) of every wave of the scan's bulk kNN launch
+void lab_wave_ts(long long* out, hipStream_t s) {
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lab_wave), sizeof(g_lab_wave));
+}
+#endif
 template <int KC, bool kTarget>
 __global__ void __launch_bounds__(SpConfig<kTarget>::T)
 k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
@@ -1117,6 +1429,18 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
   // the runs themselves dealt round-robin (whole contiguous eighths of the map differ too much in work: 7 % slower).
   constexpr int kXcdRun = RGC_XCD_RUN;
   const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
+  if constexpr (!kTarget) {  // four lanes per query, queries in cell order
+    const int t = b * Cfg::T + (int)threadIdx.x;
+    const int i = t >> 2;
+#ifdef RGC_LAB
+    const long long lab_t0 = wall_clock64();
+#endif
+    if (i < n) knn_point_split<KC, Cfg::KB, Cfg::T>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz);
+#ifdef RGC_LAB
+    if (threadIdx.x == 0 && b < 8192) { g_lab_wave[2 * b] = lab_t0; g_lab_wave[2 * b + 1] = wall_clock64(); }
+#endif
+    return;
+  }
   const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
   if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::kClip, Cfg::R, Cfg::T>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
 }
@@ -1449,12 +1773,6 @@ __device__ __forceinline__ void neighbor_offset(int noff, int o, int& ox, int& o
 // adds its eight quads in ascending order and thread `accumulator` the eight eighths.  The former version reduced every
 // accumulator across the wave with six dependent 64-bit shuffles (two ds_bpermute each): 7.6 us of the LM step's 20
 // (scripts/lab_lm.py); this one moves 4 x fewer values through LDS once.
-template <int CTRL>
-__device__ __forceinline__ double quad_perm_f64(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
 template <int NACC, bool kWriteThrough = false>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ row) {
   static_assert(NACC <= 32 && LIN_T == 256, "thread -> (accumulator, eighth) mapping");
@@ -1928,247 +2246,6 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     const int* lw = reinterpret_cast<const int*>(&ls);
     int* gw = reinterpret_cast<int*>(st);
     for (int u = threadIdx.x; u < kStateWords; u += LIN_T) gw[u] = lw[u];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// PERSISTENT LM: the whole computeTransformation loop (lsq_registration_impl.hpp:53-172) in ONE launch.  Every workgroup
-// keeps its 256 source points for the whole solve; per outer iteration there are two grid-wide hand-offs instead of two
-// kernel boundaries:
-//   phase A  linearise at x0 -> partial row (write-through) -> ticket; the LAST arriver folds the rows, forms H, b, y0,
-//            performs the LM try (solve, so3_exp, xi = delta x0) and PUBLISHES xi by bumping st->gen;
-//   phase B  every workgroup evaluates the cost at xi over its frozen correspondences -> row -> ticket; the last arriver
-//            folds, computes rho and accepts (x0 = xi, next iteration), rejects (lambda up, NEW try, phase B again) or
-//            terminates, and publishes a command word with the next gen.
-// Waiting workgroups poll st->gen with agent-scope loads and s_sleep; the poll is BOUNDED (a lost hand-off ends the solve
-// with failed = 2 instead of hanging the GPU).  All state that crosses workgroups is written with write-through (sc1)
-// stores and read either after the last arriver's agent-scope acquire or with sc1 loads, so no release fence (L2
-// write-back) sits on the critical path.  MEASURED (MI355X, 30 k points, 118 workgroups): 42 us per outer iteration against
-// 30 us for the two-kernel slots -- a polled hand-off costs more here than a kernel boundary -- so this launch is an A/B
-// knob (RGC_LM_IMPL=persistent), not the default.  The launch needs its workgroups co-resident: the host only uses it when the
-// grid is at most one workgroup per CU (<= 256) and keeps the two-kernel slots for anything larger.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void wt(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double rd(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int rd(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-constexpr int LM_CMD_ACCEPT = 0, LM_CMD_RETRY = 1, LM_CMD_DONE = 2;
-constexpr int kLmSpinLimit = 1 << 21;  // polls of ~0.3-1 us: a second or two before giving up
-
-// thread 0 of every waiting workgroup; returns false if the hand-off never came
-__device__ __forceinline__ bool lm_wait_gen(const int* gen, int want) {
-  for (int spins = 0; spins < kLmSpinLimit; spins++) {
-    if (rd(gen) - want >= 0) return true;
-    __builtin_amdgcn_s_sleep(16);
-  }
-  return false;
-}
-
-// LM try at the state's (H, b, lambda, x0) -> d, delta, xi written through; xi also returned
-__device__ __forceinline__ void lm_try_state(LmState* st, const double H[36], const double b[6], double lambda, const double x0[16], double xi[16]) {
-  double d[6], delta[16];
-  rgclm::lm_try(H, b, lambda, x0, d, delta, xi);
-#pragma unroll
-  for (int a = 0; a < 6; a++) wt(&st->d[a], d[a]);
-#pragma unroll
-  for (int a = 0; a < 16; a++) { wt(&st->delta[a], delta[a]); wt(&st->xi[a], xi[a]); }
-}
-
-__global__ void __launch_bounds__(LIN_T)
-k_lm_run(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
-         const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v, double* __restrict__ corr_M,
-         double* __restrict__ partials, LmState* __restrict__ st, int* __restrict__ mbox, LmInit in, int gen_base, const int* __restrict__ nvox,
-         const int* __restrict__ def_t, const int* __restrict__ def_s) {
-  __shared__ double folded[kAccum + 1];
-  __shared__ double pose_s[12];
-  __shared__ int cmd_s;
-  const bool lead = threadIdx.x == 0;
-  if (blockIdx.x == 0 && lead) {
-    // fresh state (:53-63).  Written before this workgroup takes its first ticket, hence visible to whichever workgroup
-    // arrives last.  gen continues from gen_base (the host carries it from the previous solve's read-back).
-#pragma unroll
-    for (int a = 0; a < 16; a++) wt(&st->x0[a], in.x0[a]);
-    wt(&st->lambda, -1.0);  // :56
-    wt(&st->nu, 2.0);
-#pragma unroll
-    for (int a = 0; a < 36; a++) wt(&st->Hfin[a], (a % 7 == 0) ? 1.0 : 0.0);  // final_hessian_.setIdentity(), :21
-    wt(&st->rot_eps, in.rot_eps);
-    wt(&st->trans_eps, in.trans_eps);
-    wt(&st->init_factor, in.init_factor);
-    wt(&st->max_outer, in.max_outer);
-    wt(&st->max_inner, in.max_inner);
-    wt(&st->phase, 0); wt(&st->conv, 0); wt(&st->failed, 0); wt(&st->outer, 0); wt(&st->inner, 0);
-    wt(&st->n_lin, 0); wt(&st->n_err, 0); wt(&st->ncorr, 0); wt(&st->has_fit, 0);
-    wt(&st->fit_sum, 0.0); wt(&st->y0, 0.0); wt(&st->yi, 0.0);
-    wt(&st->nvox, nvox ? *nvox : 0);
-    wt(&st->pad, nvox ? (nvox[-1] | (nvox[15] << 8)) : 0);
-    wt(&st->def_t, def_t ? *def_t : 0);
-    wt(&st->def_s, def_s ? *def_s : 0);
-    st->src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;
-    wt(&st->done, in.max_outer <= 0 ? 1 : 0);
-  }
-  if (in.max_outer <= 0) return;
-  if (threadIdx.x < 12) pose_s[threadIdx.x] = in.x0[threadIdx.x];
-  __syncthreads();
-  const int i = blockIdx.x * LIN_T + threadIdx.x;
-  int gen = gen_base;
-  bool relinearize = true;
-  for (int guard = 0; guard < 100000; guard++) {
-    if (relinearize) {
-      // ---- phase A ------------------------------------------------------------------------------------------------
-      Pose T;
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-#pragma unroll
-        for (int e = 0; e < 3; e++) T.R[a * 3 + e] = pose_s[a * 4 + e];
-        T.t[a] = pose_s[a * 4 + 3];
-      }
-      double acc[kAccum];
-#pragma unroll
-      for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
-      int ncorr = 0;
-      if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, 1, acc, ncorr);
-      double acc2[kAccum + 1];
-#pragma unroll
-      for (int a = 0; a < kAccum; a++) acc2[a] = acc[a];
-      acc2[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
-      block_reduce_store<kAccum + 1, true>(acc2, partials + (size_t)blockIdx.x * (kAccum + 1));
-      gen++;
-      if (last_block_arrive(&st->ticketA)) {
-        block_fold_rows<kAccum + 1>(partials, gridDim.x, folded);
-        if (lead) {
-          double H[36], b[6], x0[16], xi[16];
-          int u = 0;
-#pragma unroll
-          for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int e = a; e < 6; e++) { H[a * 6 + e] = folded[u]; H[e * 6 + a] = folded[u]; u++; }
-#pragma unroll
-          for (int a = 0; a < 6; a++) b[a] = folded[21 + a];
-#pragma unroll
-          for (int a = 0; a < 36; a++) wt(&st->H[a], H[a]);
-#pragma unroll
-          for (int a = 0; a < 6; a++) wt(&st->b[a], b[a]);
-          wt(&st->y0, folded[27]);
-          wt(&st->ncorr, (int)folded[kAccum]);
-          wt(&st->n_lin, st->n_lin + 1);
-          double lambda = st->lambda;
-          if (lambda < 0.0) {  // :130-132
-            double m = 0;
-#pragma unroll
-            for (int a = 0; a < 6; a++) m = fmax(m, fabs(H[a * 7]));
-            lambda = st->init_factor * m;
-            wt(&st->lambda, lambda);
-          }
-#pragma unroll
-          for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
-          lm_try_state(st, H, b, lambda, x0, xi);  // :136-143
-#pragma unroll
-          for (int a = 0; a < 12; a++) pose_s[a] = xi[a];
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          wt(&st->gen, gen);
-          wt(mbox, gen);  // publish xi
-        }
-        __syncthreads();
-      } else {
-        if (lead) cmd_s = lm_wait_gen(mbox, gen) ? 0 : -1;
-        __syncthreads();
-        if (cmd_s < 0) { if (lead) { wt(&st->failed, 2); wt(&st->done, 1); } return; }
-        if (threadIdx.x < 12) pose_s[threadIdx.x] = rd(&st->xi[threadIdx.x]);
-        __syncthreads();
-      }
-    }
-    // ---- phase B: cost at the trial pose (pose_s = xi) --------------------------------------------------------------
-    double accb[1] = {0.0};
-    if (i < n) accb[0] = error_point(P, i, n, pose_s, vox, noff, corr_v, corr_M);
-    block_reduce_store<1, true>(accb, partials + blockIdx.x);
-    gen++;
-    if (last_block_arrive(&st->ticketB)) {
-      block_fold_rows<1>(partials, gridDim.x, folded);
-      if (lead) {
-        const double yi = folded[0];
-        wt(&st->yi, yi);
-        wt(&st->n_err, st->n_err + 1);
-        double d[6], b[6];
-#pragma unroll
-        for (int a = 0; a < 6; a++) { d[a] = st->d[a]; b[a] = st->b[a]; }
-        double lambda = st->lambda;
-        double den = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++) den += d[a] * (lambda * d[a] - b[a]);
-        const double rho = (st->y0 - yi) / den;  // :145
-        double delta[16];
-#pragma unroll
-        for (int a = 0; a < 16; a++) delta[a] = st->delta[a];
-        const bool conv_now = lm_is_converged(delta, st->rot_eps, st->trans_eps);
-        int cmd;
-        bool outer_done = false;
-        if (rho < 0) {  // :155-163
-          if (conv_now) {
-            outer_done = true;  // step_lm returns true with x unchanged: the next linearisation is again at x0
-          } else {
-            const double nu = st->nu;
-            lambda = nu * lambda;
-            wt(&st->lambda, lambda);
-            wt(&st->nu, 2 * nu);
-            const int inner = st->inner + 1;
-            wt(&st->inner, inner);
-            if (inner >= st->max_inner) {  // "lm not converged!!", :69-72
-              wt(&st->failed, 1);
-              wt(&st->done, 1);
-              cmd = LM_CMD_DONE;
-            } else {  // next try of the same linearisation, straight away
-              double H[36], x0[16], xi[16];
-#pragma unroll
-              for (int a = 0; a < 36; a++) H[a] = st->H[a];
-#pragma unroll
-              for (int a = 0; a < 16; a++) x0[a] = st->x0[a];
-              lm_try_state(st, H, b, lambda, x0, xi);
-#pragma unroll
-              for (int a = 0; a < 12; a++) pose_s[a] = xi[a];
-              cmd = LM_CMD_RETRY;
-            }
-          }
-        } else {  // :165-168
-#pragma unroll
-          for (int a = 0; a < 16; a++) wt(&st->x0[a], st->xi[a]);
-          wt(&st->lambda, lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3)));
-#pragma unroll
-          for (int a = 0; a < 36; a++) wt(&st->Hfin[a], st->H[a]);
-          outer_done = true;
-        }
-        if (outer_done) {
-          const int outer = st->outer + 1;
-          wt(&st->conv, conv_now ? 1 : 0);  // :74
-          wt(&st->outer, outer);
-          wt(&st->nu, 2.0);
-          wt(&st->inner, 0);
-          const bool fin = conv_now || outer >= st->max_outer;  // :65
-          if (fin) wt(&st->done, 1);
-          // (rho < 0 reaches this point only when converged, so fin holds and x0 stays what it was)
-          cmd = fin ? LM_CMD_DONE : LM_CMD_ACCEPT;
-        }
-        cmd_s = cmd;
-        wt(mbox + 32, cmd);
-        wt(&st->gen, gen);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wt(mbox, gen);
-      }
-      __syncthreads();
-    } else {
-      if (lead) cmd_s = lm_wait_gen(mbox, gen) ? rd(mbox + 32) : -1;
-      __syncthreads();
-      if (cmd_s < 0) { if (lead) { wt(&st->failed, 2); wt(&st->done, 1); } return; }
-      if (cmd_s == LM_CMD_RETRY) {
-        if (threadIdx.x < 12) pose_s[threadIdx.x] = rd(&st->xi[threadIdx.x]);
-      }
-      __syncthreads();
-    }
-    const int cmd = cmd_s;
-    __syncthreads();  // everyone has read cmd_s / pose_s before the next round may overwrite them
-    if (cmd == LM_CMD_DONE) return;
-    relinearize = (cmd != LM_CMD_RETRY);  // ACCEPT: pose_s (= xi) is the new x0
   }
 }
 
@@ -2829,7 +2906,7 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   const size_t lds = (size_t)(is_target ? SpShape<CT::R, CT::kClip>::LDS : SpShape<CS::R, CS::kClip>::LDS) * T * sizeof(int);
   const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
   if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
-  else hipLaunchKernelGGL((k_knn_sp<KC, false>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+  else hipLaunchKernelGGL((k_knn_sp<KC, false>), dim3(nblk(n, T / 4)), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);  // four lanes per query
 }
 template <int KC>
 static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
@@ -2885,14 +2962,6 @@ void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny,
              const LmInit* first, const int* nvox, const void* segs_t, const void* segs_s) {
   hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
                      corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s);
-}
-void lm_run(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
-            const double* vox, int noff, int* corr_v, double* corr_M, double* partials, LmState* st, const LmInit& in, int gen_base,
-            const int* nvox, const void* segs_t, const void* segs_s) {
-  int* mbox = reinterpret_cast<int*>(reinterpret_cast<char*>(st) + 2048);  // the state buffer is 4 KiB: mailbox lines after the struct
-  static_assert(sizeof(LmState) <= 2048, "LmState must leave room for the mailbox");
-  hipLaunchKernelGGL(k_lm_run, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v, corr_M, partials,
-                     st, mbox, in, gen_base, nvox, (const int*)segs_t, (const int*)segs_s);
 }
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials) {
   hipLaunchKernelGGL(k_fitness_lm, dim3(fitness_blocks(ns)), dim3(FIT_T), 0, s, SP, ns, st, TP, tstart, g, partials);
