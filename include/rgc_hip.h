@@ -117,6 +117,15 @@ RGC_API int rgc_num_correspondences(rgc_ctx* ctx, int* n_corr);
  *   iterations : outer iterations executed;  converged: hasConverged();  lm_failed: "lm not converged!!" */
 RGC_API int rgc_align(rgc_ctx* ctx, const float guess[16], float final_T[16], double final_H[36], double* fitness,
               int* iterations, int* converged, int* lm_failed);
+/* rgc_align in two halves (rgc_align == begin + end).  rgc_align_begin enqueues the solve behind the clouds' preparation and
+ * returns without waiting; rgc_align_end waits for it and returns what rgc_align returns.  Between the two the caller may do
+ * anything that does not touch THIS context -- in particular prepare the next frame's clouds on a second context, so that
+ * the preparation of frame i + 1 runs on the GPU while frame i is being solved (rgc_slam_amd.registration.PipelinedVGICP,
+ * rgc::OdometryNode's replay).  want_fitness != 0 chains getFitnessScore behind the solve (rgc_align_end's `fitness` then costs
+ * nothing extra).  Errors that a speculative grid defers (rgc_set_* above) may surface in rgc_align_end. */
+RGC_API int rgc_align_begin(rgc_ctx* ctx, const float guess[16], int want_fitness);
+RGC_API int rgc_align_end(rgc_ctx* ctx, float final_T[16], double final_H[36], double* fitness, int* iterations, int* converged,
+                          int* lm_failed);
 /* pcl::Registration::getFitnessScore() for an arbitrary pose */
 RGC_API int rgc_fitness(rgc_ctx* ctx, const float T[16], double* fitness);
 /* the `output` cloud of align(): pcl::transformPointCloud(*input_, output, final_transformation_)

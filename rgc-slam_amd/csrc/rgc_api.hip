@@ -89,6 +89,7 @@ struct rgc_ctx {
   bool deferred_known = false;  // stats.deferred_* are those of the current clouds (carried home by the last align)
   DevBuf fit_partials;        // fitness rows when it is chained behind the LM slots
   rgck::LmState* h_lm = nullptr;  // pinned mirror
+  struct { bool active = false; bool want_fitness = false; float guess[16]; } pend;  // rgc_align_begin .. rgc_align_end
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
   double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
@@ -983,13 +984,138 @@ int rgc_num_correspondences(rgc_ctx* c, int* n) {
   return RGC_OK;
 }
 
+// One batch of blind LM steps (the first launch of a solve opens it), the fitness kernel behind them and the state's read-back:
+// enqueued, not waited for.
+static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, bool want_fitness) {
+  const int n = c->src.n, noff = noff_of(c->prm.neighbor_method);
+  {
+    ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch);
+    for (int k = 0; k < batch; k++) {
+      rgck::lm_step(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
+                    c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
+                    (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, open, c->d_small + 7,
+                    c->tgt.segs.p, c->src.segs.p);
+      open = nullptr;
+    }
+  }
+  if (want_fitness) {  // getFitnessScore at the final pose, chained blindly: the kernel is a no-op unless the LM is done
+    ProfScope ps(c, RGC_K_FITNESS, n);
+    rgck::fitness_lm(c->stream, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
+                     (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, c->stream));
+  return RGC_OK;
+}
+
+// The solve in two halves, so that a caller with two contexts can prepare the clouds of the next frame (on the other context)
+// while this one's LM runs: rgc_align_begin enqueues the device-chained LM behind the clouds' preparation and returns;
+// rgc_align_end waits for it (and enqueues further batches if the solve needs more than six outer iterations).
+int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
+  if (!c || !guess) return RGC_ERR_INVALID;
+  if (c->lm_host) return fail(c, RGC_ERR_INVALID, "the host-driven LM loop (RGC_LM_IMPL=host) has no asynchronous form");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->pend.active = false;
+  // the guards of speculative grids come home with the LM state: no synchronisation here
+  int rc = need_inputs(c, /*validate=*/false);
+  if (rc) return rc;
+  const rgc_params& P = c->prm;
+  // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_step);
+  // the host only enqueues slots and reads the state back once per batch.
+  const int n = c->src.n, noff = noff_of(P.neighbor_method);
+  if ((rc = ensure(c, c->corr_v, sizeof(int) * (size_t)n * noff))) return rc;
+  if ((rc = ensure(c, c->corr_M, sizeof(double) * 6 * (size_t)n * noff))) return rc;
+  const int nb = rgck::linearize_blocks(n);
+  if ((rc = ensure(c, c->corr_v2, sizeof(int) * (size_t)n * noff))) return rc;
+  if ((rc = ensure(c, c->corr_M2, sizeof(double) * 6 * (size_t)n * noff))) return rc;
+  if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 2) * (size_t)nb))) return rc;
+  if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
+  if (!c->lm_state.p) {
+    if ((rc = ensure(c, c->lm_state, 4096))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->stream));  // tickets start at 0
+  }
+  if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)rgck::fitness_blocks(n) + 64))) return rc;
+  rgck::LmInit in;
+  for (int i = 0; i < 12; i++) in.x0[i] = (double)guess[i];
+  in.x0[12] = in.x0[13] = in.x0[14] = 0.0;
+  in.x0[15] = 1.0;
+  in.rot_eps = P.rotation_eps; in.trans_eps = P.translation_eps; in.init_factor = P.lm_init_lambda_factor;
+  in.max_outer = P.max_iterations; in.max_inner = P.lm_max_iterations;
+  c->stats.n_linearize = c->stats.n_error = c->stats.outer_iterations = 0;
+  // one linearisation + six fused cost/linearise steps: up to six outer iterations without a read-back
+  if ((rc = lm_enqueue_batch(c, 7, &in, want_fitness != 0))) return rc;
+  memcpy(c->pend.guess, guess, sizeof(c->pend.guess));
+  c->pend.want_fitness = want_fitness != 0;
+  c->pend.active = true;
+  return RGC_OK;
+}
+
+int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fitness, int* iterations, int* converged, int* lm_failed) {
+  if (!c) return RGC_ERR_INVALID;
+  if (!c->pend.active) return fail(c, RGC_ERR_INVALID, "rgc_align_end without rgc_align_begin");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->pend.active = false;
+  int rc;
+  const bool want_fitness = c->pend.want_fitness;
+  rgck::LmState& S = *c->h_lm;
+  for (int guard = 0;; guard++) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (S.done || guard >= 400) break;
+    // a solve that is still running after six outer iterations usually runs many more (up to 25): batches of six, fewer read-backs
+    if ((rc = lm_enqueue_batch(c, 6, nullptr, want_fitness))) return rc;
+  }
+  {  // a cloud that did not fit its speculative grid: everything above ran on a parked cloud -- prepare it properly, solve again
+    const int r = resolve_guards(c, S.pad & 0xff, (S.pad >> 8) & 0xff);
+    if (r < 0) return r;
+    if (r > 0) {
+      float guess[16];
+      memcpy(guess, c->pend.guess, sizeof(guess));
+      return rgc_align(c, guess, final_T, final_H, fitness, iterations, converged, lm_failed);
+    }
+  }
+  const int n = c->src.n, noff = noff_of(c->prm.neighbor_method);
+  if (S.cur) { std::swap(c->corr_v, c->corr_v2); std::swap(c->corr_M, c->corr_M2); }  // corr_v / corr_M = the valid buffer
+  c->corr_noff = noff; c->corr_n = n; c->corr_valid = S.n_lin > 0;
+  c->stats.n_corr = S.ncorr; c->stats.n_linearize = S.n_lin; c->stats.n_error = S.n_err;
+  c->tgt.nvox = c->stats.n_voxels = S.nvox;
+  c->stats.deferred_target = S.def_t; c->stats.deferred_source = S.def_s;
+  c->tgt.deferred_seen = S.def_t; c->src.deferred_seen = S.def_s;
+  c->stats.source_crowding = c->src.n > 0 ? (double)S.src_sq / (double)c->src.n : 0.0;
+  if (c->src_res <= 0.0 && c->src.n > 0) {  // steer the next scan's cell size: halve above 300 points per own cell, double below 40
+    const double cur = c->src.grid.res, crowd = c->stats.source_crowding;
+    double next = cur;
+    if (crowd > 300.0 && cur > 0.26 * c->prm.voxel_res) next = cur * 0.5;
+    else if (crowd < 40.0 && cur < c->prm.voxel_res) next = std::fmin(cur * 2.0, c->prm.voxel_res);
+    c->src_res_auto = next;
+  }
+  c->deferred_known = true;
+  const int iters = S.failed ? S.outer + 1 : S.outer;  // iterations started, like nr_iterations_ + 1
+  c->stats.outer_iterations = iters;
+  float fin[16];
+  for (int i = 0; i < 16; i++) fin[i] = (float)S.x0[i];  // :77
+  if (final_T) memcpy(final_T, fin, sizeof(fin));
+  if (final_H) memcpy(final_H, S.Hfin, sizeof(double) * 36);
+  if (iterations) *iterations = iters;
+  if (converged) *converged = S.conv != 0 ? 1 : 0;
+  if (lm_failed) *lm_failed = S.failed != 0 ? 1 : 0;
+  if (fitness) {
+    if (want_fitness && S.has_fit) *fitness = S.fit_sum / (double)n;
+    else if ((rc = do_fitness(c, fin, fitness))) return rc;
+  }
+  return RGC_OK;
+}
+
 // lsq_registration_impl.hpp:53-79 (computeTransformation) + :125-172 (step_lm); SURVEY A.5
 int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final_H[36], double* fitness, int* iterations,
               int* converged, int* lm_failed) {
   if (!c || !guess) return RGC_ERR_INVALID;
+  if (!c->lm_host) {
+    const int rc0 = rgc_align_begin(c, guess, fitness != nullptr);
+    return rc0 ? rc0 : rgc_align_end(c, final_T, final_H, fitness, iterations, converged, lm_failed);
+  }
+  // ---- RGC_LM_IMPL=host: the loop on the host over the public fine-seam kernels (cross-check of the device-chained driver) ----
   HIPCHK(c, hipSetDevice(c->device));
-  // the guards of speculative grids come home with the LM state below: no extra synchronisation here
-  int rc = need_inputs(c, /*validate=*/c->lm_host);
+  int rc = need_inputs(c, /*validate=*/true);
   if (rc) return rc;
   const rgc_params& P = c->prm;
   double x0[16];
@@ -1003,79 +1129,6 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
   memset(Hfin, 0, sizeof(Hfin));
   for (int i = 0; i < 6; i++) Hfin[i * 7] = 1.0;  // final_hessian_.setIdentity(), :21
   c->stats.n_linearize = c->stats.n_error = c->stats.outer_iterations = 0;
-
-  bool fitness_chained = false;
-  double fit_sum = 0.0;
-  if (!c->lm_host) {
-    // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_step);
-    // the host only enqueues slots and reads the state back once per batch.
-    const int n = c->src.n, noff = noff_of(P.neighbor_method);
-    if ((rc = ensure(c, c->corr_v, sizeof(int) * (size_t)n * noff))) return rc;
-    if ((rc = ensure(c, c->corr_M, sizeof(double) * 6 * (size_t)n * noff))) return rc;
-    const int nb = rgck::linearize_blocks(n);
-    if ((rc = ensure(c, c->corr_v2, sizeof(int) * (size_t)n * noff))) return rc;
-    if ((rc = ensure(c, c->corr_M2, sizeof(double) * 6 * (size_t)n * noff))) return rc;
-    if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 2) * (size_t)nb))) return rc;
-    if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
-    if (!c->lm_state.p) {
-      if ((rc = ensure(c, c->lm_state, 4096))) return rc;
-      HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->stream));  // tickets start at 0
-    }
-    if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)rgck::fitness_blocks(n) + 64))) return rc;
-    rgck::LmState& S = *c->h_lm;
-    rgck::LmInit in;
-    memcpy(in.x0, x0, sizeof(x0));
-    in.rot_eps = P.rotation_eps; in.trans_eps = P.translation_eps; in.init_factor = P.lm_init_lambda_factor;
-    in.max_outer = P.max_iterations; in.max_inner = P.lm_max_iterations;
-    int batch = 7;  // one linearisation + six fused cost/linearise steps: up to six outer iterations without a read-back
-    bool first_step = true;
-    for (int guard = 0; guard < 400; guard++) {
-      {
-        ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch);
-        for (int k = 0; k < batch; k++)
-          rgck::lm_step(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
-                        c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
-                        (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p,
-                        first_step ? &in : nullptr, c->d_small + 7, c->tgt.segs.p, c->src.segs.p),
-          first_step = false;
-      }
-      if (fitness) {  // getFitnessScore at the final pose, chained blindly: the kernel is a no-op unless the LM is done
-        ProfScope ps(c, RGC_K_FITNESS, n);
-        rgck::fitness_lm(c->stream, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
-                         (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p);
-      }
-      HIPCHK(c, hipMemcpyAsync(&S, c->lm_state.p, sizeof(S), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      HIPCHK(c, hipGetLastError());
-      if (S.done) { fitness_chained = S.has_fit != 0; break; }
-      batch = 6;  // a solve that is still running after six outer iterations usually runs many more (up to 25): fewer read-backs
-    }
-    {  // a cloud that did not fit its speculative grid: everything above ran on a parked cloud -- prepare it properly, solve again
-      const int r = resolve_guards(c, S.pad & 0xff, (S.pad >> 8) & 0xff);
-      if (r < 0) return r;
-      if (r > 0) return rgc_align(c, guess, final_T, final_H, fitness, iterations, converged, lm_failed);
-    }
-    if (S.cur) { std::swap(c->corr_v, c->corr_v2); std::swap(c->corr_M, c->corr_M2); }  // corr_v / corr_M = the valid buffer
-    c->corr_noff = noff; c->corr_n = n; c->corr_valid = S.n_lin > 0;
-    c->stats.n_corr = S.ncorr; c->stats.n_linearize = S.n_lin; c->stats.n_error = S.n_err;
-    c->tgt.nvox = c->stats.n_voxels = S.nvox;
-    c->stats.deferred_target = S.def_t; c->stats.deferred_source = S.def_s;
-    c->tgt.deferred_seen = S.def_t; c->src.deferred_seen = S.def_s;
-    c->stats.source_crowding = c->src.n > 0 ? (double)S.src_sq / (double)c->src.n : 0.0;
-    if (c->src_res <= 0.0 && c->src.n > 0) {  // steer the next scan's cell size: halve above 300 points per own cell, double below 40
-      const double cur = c->src.grid.res, crowd = c->stats.source_crowding;
-      double next = cur;
-      if (crowd > 300.0 && cur > 0.26 * c->prm.voxel_res) next = cur * 0.5;
-      else if (crowd < 40.0 && cur < c->prm.voxel_res) next = std::fmin(cur * 2.0, c->prm.voxel_res);
-      c->src_res_auto = next;
-    }
-    c->deferred_known = true;
-    fit_sum = S.fit_sum;
-    memcpy(x0, S.x0, sizeof(x0));
-    memcpy(Hfin, S.Hfin, sizeof(Hfin));
-    conv = S.conv != 0; failed = S.failed != 0;
-    iters = S.failed ? S.outer + 1 : S.outer;  // iterations started, like nr_iterations_ + 1
-  } else
   for (int it = 0; it < P.max_iterations && !conv; it++) {  // :65
     iters = it + 1;
     double H[36], b[6], y0, delta[16], d[6], xi[16], yi, lam_used;
@@ -1121,10 +1174,7 @@ int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final
   if (iterations) *iterations = iters;
   if (converged) *converged = conv ? 1 : 0;
   if (lm_failed) *lm_failed = failed ? 1 : 0;
-  if (fitness) {
-    if (fitness_chained) *fitness = fit_sum / (double)c->src.n;
-    else if ((rc = do_fitness(c, fin, fitness))) return rc;
-  }
+  if (fitness && (rc = do_fitness(c, fin, fitness))) return rc;
   return RGC_OK;
 }
 
@@ -1562,6 +1612,7 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
 
 #ifdef RGC_LAB
 RGC_API int rgc_lab_lm_ts(rgc_ctx* c, unsigned long long* out16) { rgck::lab_lm_ts(out16, c->stream); return RGC_OK; }
+RGC_API int rgc_lab_why(rgc_ctx*, int* out8) { rgck::lab_why(out8); return RGC_OK; }
 RGC_API int rgc_lab_wave_ts(rgc_ctx* c, long long* out16384) { (void)hipStreamSynchronize(c->stream); rgck::lab_wave_ts(out16384, c->stream2); return RGC_OK; }
 // developer build only (-DRGC_LAB): the deferred-query list of a cloud as the bulk kNN kernel left it
 RGC_API int rgc_lab_deferred(rgc_ctx* c, int is_target, int* idx, float* thr, int cap, int* count) {

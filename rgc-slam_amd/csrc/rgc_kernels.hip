@@ -1138,16 +1138,25 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
 //    drain) bounds what can still matter -- appends and piece skipping use it, so pruning is as sharp as with one chain;
 //    the skip decision uses ONLY this shared bound: the four lanes take it alike, their tables stay identical;
 //  * at the end every lane merges the four chains (quad broadcasts) into the k + 2 smallest of the union.  A lane whose chain was
-//    full and whose tail is below the (k + 2)-th merged key may have dropped a needed key: the query is deferred (never seen
-//    with an interleaved split; the cooperative kernel is exact for anything);
+//    full and whose tail is below the (k + 2)-th merged key may have dropped a needed key: the query is deferred (rare with the
+//    quads dealt round-robin and the deal rotated from piece to piece; the cooperative kernel is exact for anything);
 //  * the neighbours' moments are gathered five per lane and summed over the quad; the eigenvector is solved in all four.
 // ------------------------------------------------------------------------------------------------
-template <int KC, int KB, int T>
+#ifdef RGC_LAB
+__device__ int g_lab_why[8];  // developer build: why the scan's bulk kernel deferred (1 piece too long, 2 ordinals, 3 dropped key, 4 < k, 5 unproven, 6 tie)
+void lab_why(int* out8) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lab_why), sizeof(g_lab_why));
+  int z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_why), z, sizeof(z));
+}
+#endif
+template <int KC, int KB, int R, int T>
 __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
                                                 int i, int sub, int* lds, const Deferred& df, double* __restrict__ nx,
                                                 double* __restrict__ ny, double* __restrict__ nz) {
   constexpr bool kClip = true;
-  constexpr int R = 1, S = 4;
+  constexpr int S = 4;
   using Shape = SpShape<R, kClip>;
   constexpr int L = KC + 2, Ls = (KC + 2) / 2 + 1;
   static_assert(Ls <= 24 && KC % S == 0, "initial fill by the 24-input network; neighbours dealt evenly to the quad");
@@ -1160,8 +1169,11 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int c[3] = {voxel_coord_g(px, g) - g.minc[0], voxel_coord_g(py, g) - g.minc[1], voxel_coord_g(pz, g) - g.minc[2]};
   const double q[3] = {(double)px, (double)py, (double)pz};
-  auto defer = [&](int enc, float thr) {  // (the four lanes of a query take every branch alike: one of them reports)
+  auto defer = [&](int enc, float thr, int why = 0) {  // (the four lanes of a query take every branch alike: one of them reports)
     if (sub == 0) {
+#ifdef RGC_LAB
+      atomicAdd(&g_lab_why[why], 1);
+#endif
       const int e = atomicAdd(df.cnt, 1);
       df.idx[e] = enc;
       df.thr[e] = thr;
@@ -1170,7 +1182,7 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   bool heavy_piece = false;
   const int nr = sp_piece_table<kClip, R, T>(start, g, c, q, tmix, tlo, heavy_piece);
   if (heavy_piece) {
-    defer(i, INFINITY);
+    defer(i, INFINITY, 1);
     return;
   }
   // ---- one pass over this lane's quarter of the candidate stream ----
@@ -1219,10 +1231,13 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
           ri = nr;
           break;
         }
+        // quad j of the piece goes to lane (j + piece number) & 3: the far field is many pieces of one or two quads, which would
+        // otherwise all land on lane 0 (and overflow its chain)
+        const int first = (sub - ri) & (S - 1);
         const unsigned base = (unsigned)tlo[ri * T] << 4;
-        off = base + 64u * (unsigned)sub;
+        off = base + 64u * (unsigned)first;
         end = base + ((unsigned)quads << 6);
-        ord = ordn + 4 * sub;
+        ord = ordn + 4 * first;
         jleft = (quads + S - 1) / S;
         ordn += 4 * quads;
       }
@@ -1281,7 +1296,7 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   }
   if (__any(bp != buf)) drain();
   if (overflow) {
-    defer(i, INFINITY);
+    defer(i, INFINITY, 2);
     return;
   }
   // ---- the k + 2 smallest keys of the union, in every lane of the quad ----
@@ -1311,11 +1326,11 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
     a_km1 = all.at(k - 1); a_k = all.at(k); a_kp1 = all.at(k + 1);
   }
   if (quad_or_i(top.a[Ls - 1] < a_kp1 ? 1 : 0)) {  // a full chain whose tail ranks inside the merged k + 2: a needed key may have been dropped
-    defer(i, INFINITY);
+    defer(i, INFINITY, 3);
     return;
   }
   if (a_km1 >= 0x7f800000) {  // fewer than k candidates in the block
-    defer(~i, INFINITY);
+    defer(~i, INFINITY, 4);
     return;
   }
   auto index_of = [&](int key) {  // ordinal -> position in the sorted array (the lanes' tables are identical)
@@ -1342,11 +1357,11 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   const double bound = cube_bound(g, c, q, R);
   const bool proven = (bound == 1.0e300) || (bound > 0.0 && (double)thr_up < bound * bound * (1.0 - 1e-5));
   if (!proven) {
-    defer(~i, (double)thr_up < 3.0 * (R + 1) * (R + 1) * g.res * g.res ? thr_up : INFINITY);
+    defer(~i, (double)thr_up < 3.0 * (R + 1) * (R + 1) * g.res * g.res ? thr_up : INFINITY, 5);
     return;
   }
   if (!decided) {
-    defer(i, thr_up);
+    defer(i, thr_up, 6);
     return;
   }
   // ---- moments of neighbours sub, sub + 4, ... in this lane, summed over the quad (one-pass form of knn_point_sp) ----
@@ -1402,7 +1417,13 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
 //   scan : 3x3x3 block as 11 pieces with distance bounds, 12 ordinal bits (4095 candidates) -- a raw sweep: hundreds of points per
 //          cell next to the sensor (done after the own piece), metres between neighbours on its far rings (cooperative kernel).
 template <bool kTarget> struct SpConfig {
-  static constexpr int KB = kTarget ? 11 : 12, R = 1;  // (R = 2, 3 work; for a VLP-16 sweep beside the map's launch they lose to R = 1 at 1 m cells)
+#ifndef RGC_SCAN_KB
+#define RGC_SCAN_KB 12
+#endif
+#ifndef RGC_SCAN_R
+#define RGC_SCAN_R 1
+#endif
+  static constexpr int KB = kTarget ? 11 : RGC_SCAN_KB, R = kTarget ? 1 : RGC_SCAN_R;  // (R = 2, 3 work; for a VLP-16 sweep beside the map's launch they lose to R = 1 at 1 m cells)
   static constexpr bool kClip = !kTarget;
   // The scan's launch runs beside the map's, which fills every CU's LDS with four 256-thread workgroups: one-wave workgroups
   // (18 KiB of LDS each) are admitted as soon as ONE of those retires, a 256-thread one (73 KiB) would wait for two.
@@ -1435,7 +1456,7 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
 #ifdef RGC_LAB
     const long long lab_t0 = wall_clock64();
 #endif
-    if (i < n) knn_point_split<KC, Cfg::KB, Cfg::T>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz);
+    if (i < n) knn_point_split<KC, Cfg::KB, Cfg::R, Cfg::T>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz);
 #ifdef RGC_LAB
     if (threadIdx.x == 0 && b < 8192) { g_lab_wave[2 * b] = lab_t0; g_lab_wave[2 * b + 1] = wall_clock64(); }
 #endif
@@ -1567,6 +1588,10 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
   const int wave = blockIdx.x, nwaves = gridDim.x;
   const int cnt = *df.cnt;
   for (int e = wave; e < cnt; e += nwaves) {
+#ifdef RGC_LAB
+    const long long lab_t0 = wall_clock64();
+    int lab_rounds = 0;
+#endif
     const int enc = __builtin_amdgcn_readfirstlane(df.idx[e]);
     const int i = enc < 0 ? ~enc : enc;
     int r = enc < 0 ? 1 : 0;  // radius already known to be insufficient
@@ -1592,6 +1617,9 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
       }
       r = min(rn, rmax);
       bool overflow;
+#ifdef RGC_LAB
+      lab_rounds++;
+#endif
       unsigned T = coop_kth<4>(P, start, g, c, r, sh, lane, px, py, pz, k, overflow);
       if (overflow) T = coop_kth<KC>(P, start, g, c, r, sh, lane, px, py, pz, k, overflow);  // full width: nothing relevant can be dropped
       thr = (T >= 0x7F800000u) ? INFINITY : __uint_as_float(T);
@@ -1658,6 +1686,9 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
       nx[i] = nrm[0];
       ny[i] = nrm[1];
       nz[i] = nrm[2];
+#ifdef RGC_LAB
+      if (!kTarget && e < 8192) { g_lab_wave[2 * e] = lab_t0 | ((long long)r << 56) | ((long long)lab_rounds << 48); g_lab_wave[2 * e + 1] = wall_clock64(); }
+#endif
     }
     wave_lds_fence();
   }

@@ -152,6 +152,29 @@ class FastVGICP:
         self._chk(self._L.rgc_get_aligned(self._h, fin.ctypes.data_as(fp), out.ctypes.data_as(fp), 12))
         return out
 
+    def align_begin(self, guess=None, want_fitness=False):
+        """First half of align(): enqueue the solve and return (rgc_align_begin).  align_end() collects the result; in between the
+        caller may prepare the next frame on ANOTHER FastVGICP (PipelinedVGICP below does)."""
+        g = np.eye(4, dtype=np.float32) if guess is None else np.ascontiguousarray(guess, dtype=np.float32).reshape(4, 4)
+        self._chk(self._L.rgc_align_begin(self._h, g.ctypes.data_as(C.POINTER(C.c_float)), 1 if want_fitness else 0))
+        self._pending_fitness = want_fitness
+
+    def align_end(self):
+        """Second half of align(): waits for the solve; getFinalTransformation() etc. are valid afterwards."""
+        want_fitness = self._pending_fitness
+        fin = np.empty(16, np.float32)
+        H = np.empty(36)
+        fit = C.c_double(0)
+        it, conv, fail = C.c_int(0), C.c_int(0), C.c_int(0)
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        self._chk(self._L.rgc_align_end(self._h, fin.ctypes.data_as(fp), H.ctypes.data_as(dp), C.byref(fit) if want_fitness else None,
+                                        C.byref(it), C.byref(conv), C.byref(fail)))
+        self._final = fin.reshape(4, 4)
+        self._H = H.reshape(6, 6)
+        self._iterations, self._converged, self._lm_failed = it.value, bool(conv.value), bool(fail.value)
+        self._fitness = fit.value if want_fitness else None
+        return self._final.copy()
+
     def alignedToDevice(self, d_out, stride_bytes=16, T=None):
         """the `output` cloud of align() written to a device buffer (no copy to the host, no synchronisation)"""
         t = np.ascontiguousarray(self._final if T is None else T, dtype=np.float32).reshape(16)
@@ -314,3 +337,44 @@ def odometer_vgicp(device: int = 0) -> FastVGICP:
     v.setRANSACIterations(0)             # :1005
     v.setNumThreads(14)                  # :1006
     return v
+
+
+class PipelinedVGICP:
+    """Scan-to-map registration of a SEQUENCE on two contexts taking turns.  A frame is cloud preparation (grids, kNN covariances,
+    voxel map: throughput-bound, most of the frame) followed by the LM solve (a chain of short launches that leaves the chip mostly
+    idle) -- and only the solve needs the previous frame's pose.  So while frame i is being solved on one context the clouds of frame
+    i + 1 are prepared on the other; every frame runs the same kernels on the same inputs as FastVGICP.align() one frame at a time:
+    results are identical, the frames just overlap on the GPU (align_begin / align_end, include/rgc_hip.h)."""
+
+    def __init__(self, device: int = 0, make=odometer_vgicp):
+        self.v = [make(device), make(device)]
+
+    def close(self):
+        for v in self.v:
+            v.close()
+
+    def synchronize(self):
+        for v in self.v:
+            v.synchronize()
+
+    def run(self, n_frames, set_clouds, guess0, want_fitness=False, next_guess=None, on_result=None):
+        """set_clouds(i, v): set target and source of frame i on the FastVGICP `v` (device-resident or host clouds).
+        The guess of frame 0 is guess0; that of frame i + 1 is next_guess(i, T_i) (default: T_i, frame i's final transformation).
+        on_result(i, v) is called when frame i is done (v holds its results until frame i + 2 is set).  Returns the final
+        transformations."""
+        out = []
+        if n_frames <= 0:
+            return out
+        set_clouds(0, self.v[0])
+        g = guess0
+        for i in range(n_frames):
+            cur = self.v[i & 1]
+            cur.align_begin(g, want_fitness)
+            if i + 1 < n_frames:
+                set_clouds(i + 1, self.v[(i + 1) & 1])   # the next frame's preparation: on the GPU while this frame is solved
+            T = cur.align_end()
+            if on_result is not None:
+                on_result(i, cur)
+            g = T if next_guess is None else next_guess(i, T)
+            out.append(T)
+        return out

@@ -9,10 +9,14 @@ poses = synth.make_trajectory(4, seed=synth.SEED)
 src = synth.make_scan_n(world, poses[1], 30000, seed=synth.SEED + 100)["xyz"]
 lib = _lib.load()
 lib.rgc_lab_deferred.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+lib.rgc_lab_why.argtypes = [C.c_void_p, C.c_void_p]
 for res in [None] + [float(a) for a in sys.argv[2:]]:
     if res is not None: os.environ["RGC_SRC_RES"] = str(res)
     v = registration.odometer_vgicp(0)
-    v.setInputTarget(tgt); v.setInputSource(src); v.synchronize()
+    why = np.zeros(8, np.int32)
+    v.setInputTarget(tgt); v.synchronize(); lib.rgc_lab_why(v._h, why.ctypes.data)
+    v.setInputSource(src); v.synchronize(); lib.rgc_lab_why(v._h, why.ctypes.data)
+    print("scan bulk kernel deferred because: piece too long", why[1], "ordinals", why[2], "dropped key", why[3], "< k in block", why[4], "unproven", why[5], "tie", why[6])
     for which, cloud in ((1, tgt), (0, src)):
         if res is not None and which == 1: continue
         cap = len(cloud)
