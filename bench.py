@@ -87,9 +87,11 @@ def shifted(T, d, sign):
 
 
 def time_config(registration, oracle, name, tgt, scans, guess0, prior=None):
-    """scans[i] registered to tgt (rebuilt per frame, inputs resident); frame 0 is the warm-up; frame 1 is checked against the CPU oracle"""
+    """scans[i] registered to tgt (rebuilt per frame, inputs resident); frame 0 is the warm-up (once per context); frame 1 is checked against
+    the CPU oracle.  Timed twice: the two-context pipeline (the figure) and one frame at a time."""
     import numpy as np
-    v = registration.odometer_vgicp(int(os.environ.get("LOCAL_RANK", "0")))
+    pv = registration.PipelinedVGICP(int(os.environ.get("LOCAL_RANK", "0")), depth=2)
+    v = pv.v[0]
 
     def to_dev(xyz):
         a = np.zeros((xyz.shape[0], 4), np.float32)
@@ -99,25 +101,33 @@ def time_config(registration, oracle, name, tgt, scans, guess0, prior=None):
         return p
     d_tgt, d_s = to_dev(tgt), [to_dev(s) for s in scans]
 
-    def step(i, g):
-        v.setInputTargetDevice(d_tgt, len(tgt), 16)
-        v.setInputSourceDevice(d_s[i], len(scans[i]), 16)
-        v.align(g, want_output=False, want_fitness=True)
-        return v.getFinalTransformation()
+    def setc(i, w):
+        w.setInputTargetDevice(d_tgt, len(tgt), 16)
+        w.setInputSourceDevice(d_s[i], len(scans[i]), 16)
     frames = len(scans) - 1
-    g = step(0, prior[0] if prior else guess0)
-    v.synchronize()
-    g_in1 = prior[1] if prior else g
+    for w in pv.v:
+        setc(0, w)
+        w.align(prior[0] if prior else guess0, want_output=False, want_fitness=True)
+    g_in1 = prior[1] if prior else v.getFinalTransformation()
+    pv.synchronize()
     t1 = time.perf_counter()
-    fin = []
+    g, fin_seq = g_in1, []
     for i in range(1, frames + 1):
-        g = step(i, prior[i] if prior else g)
-        fin.append(g)
+        setc(i, v)
+        v.align(prior[i] if prior else g, want_output=False, want_fitness=True)
+        g = v.getFinalTransformation()
+        fin_seq.append(g)
     v.synchronize()
+    el_seq = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    fin = pv.run(frames, lambda j, w: setc(j + 1, w), g_in1, want_fitness=True,
+                 next_guess=(lambda j, T: prior[min(j + 2, frames)]) if prior else None)
+    pv.synchronize()
     el = time.perf_counter() - t1
-    st = v.stats()
+    st = pv.v[(frames - 1) % 2].stats()
     out = {"config": name, "n_source": int(len(scans[0])), "n_target": int(len(tgt)), "frames": frames, "scans_per_s": round(frames / el, 2),
-           "ms_per_scan": round(1e3 * el / frames, 3), "outer_iterations_last": st["outer_iterations"]}
+           "ms_per_scan": round(1e3 * el / frames, 3), "one_frame_at_a_time_scans_per_s": round(frames / el_seq, 2),
+           "same_poses_both_ways": bool(all(np.array_equal(x, y) for x, y in zip(fin, fin_seq))), "outer_iterations_last": st["outer_iterations"]}
     if oracle is not None:
         o = oracle.Registration(num_threads=os.cpu_count() or 1)
         c0 = time.perf_counter()
@@ -128,7 +138,7 @@ def time_config(registration, oracle, name, tgt, scans, guess0, prior=None):
         out["cpu_oracle_scans_per_s"] = round(1.0 / (time.perf_counter() - c0), 4)
         out["max_dt_m"] = float(np.abs(fin[0][:3, 3] - To[:3, 3]).max())
         out["max_dtheta_rad"] = rot_angle(fin[0][:3, :3], To[:3, :3])
-    v.close()
+    pv.close()
     return out
 
 
@@ -188,8 +198,8 @@ def run_extra_configs(registration, synth, oracle, keys):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--n-target", type=int, default=N_TARGET)
     ap.add_argument("--n-source", type=int, default=N_SOURCE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -231,7 +241,10 @@ def main():
     log(f"[rank {rank}] synthetic data: map {tgt.shape} x {len(maps)} copies, {len(scans)} scans of {scans[0].shape[0]} pts, world half-extent "
         f"{world.half_extent:.1f} m, {time.time() - t0:.1f} s, NUMA node {numa}")
 
-    v = registration.odometer_vgicp(local_rank)
+    # Two contexts take turns (registration.PipelinedVGICP): while frame i is solved on one, frame i + 1's clouds are prepared on the
+    # other.  Same kernels, same inputs, same poses as one frame at a time (measured below as well, and compared).
+    pv = registration.PipelinedVGICP(local_rank, depth=2)
+    v = pv.v[0]
     # inputs resident in HBM (x,y,z,pad; 16-byte stride) before anything is timed
     def to_dev(xyz):
         a = np.zeros((xyz.shape[0], 4), np.float32)
@@ -241,32 +254,52 @@ def main():
         return p
     d_maps = [to_dev(m) for m in maps]
     d_scans = [to_dev(s) for s in scans]
-    # the second loop's inputs: every scan in pinned host memory (x,y,z,pad), one device buffer for align()'s output cloud
+    # the second loop's inputs: every scan in pinned host memory (x,y,z,pad), one device buffer per context for align()'s output cloud
     pinned = []
     for s in scans:
         t = torch.zeros((s.shape[0], 4), dtype=torch.float32).pin_memory()
         t[:, :3] = torch.from_numpy(s)
         pinned.append(t)
-    d_aligned = v.device_alloc(16 * args.n_source)
+    d_aligned = {id(w): w.device_alloc(16 * args.n_source) for w in pv.v}
+
+    def to_map(i, T_world):   # world pose -> pose in the (translated) map copy frame i registers to
+        return shifted(T_world, MAP_SHIFTS[i % len(maps)], -1.0)
+
+    def to_world(i, T):
+        return shifted(T, MAP_SHIFTS[i % len(maps)], +1.0)
+
+    def set_clouds(i, w, from_host=False):
+        w.setInputTargetDevice(d_maps[i % len(maps)], tgt.shape[0], 16)   # full per-frame rebuild, like the reference
+        if from_host:
+            w.setInputSource(pinned[i].numpy())                           # H2D inside the step (pinned host memory)
+        else:
+            w.setInputSourceDevice(d_scans[i], scans[i].shape[0], 16)
+
+    def run_pipelined(first, count, guess_world, from_host=False, collect=None):
+        """frames first .. first + count - 1 through the pipeline; returns the world poses"""
+        def done(j, w):
+            if from_host:
+                w.alignedToDevice(d_aligned[id(w)], 16)                   # pcl::transformPointCloud(*input_, output, final), left on the device
+            if collect is not None:
+                st = w.stats()
+                collect.append((st["outer_iterations"], st["n_linearize"], st["n_error"], st["n_corr"], st["n_voxels"]))
+        Ts = pv.run(count, lambda j, w: set_clouds(first + j, w, from_host), to_map(first, guess_world), want_fitness=True,
+                    next_guess=lambda j, T: to_map(first + j + 1, to_world(first + j, T)), on_result=done)
+        return [to_world(first + j, T) for j, T in enumerate(Ts)]
+
+    def step(i, guess_world):   # one frame at a time on one context
+        set_clouds(i, v)
+        v.align(to_map(i, guess_world), want_output=False, want_fitness=True)
+        return to_world(i, v.getFinalTransformation())
 
     finals, per_frame = [], []
-
-    def step(i, guess_world, from_host=False):
-        m = i % len(maps)
-        v.setInputTargetDevice(d_maps[m], tgt.shape[0], 16)          # full per-frame rebuild, like the reference
-        if from_host:
-            v.setInputSource(pinned[i].numpy())                      # H2D inside the step (pinned host memory)
-        else:
-            v.setInputSourceDevice(d_scans[i], scans[i].shape[0], 16)
-        v.align(shifted(guess_world, MAP_SHIFTS[m], -1.0), want_output=False, want_fitness=True)
-        if from_host:
-            v.alignedToDevice(d_aligned, 16)                         # pcl::transformPointCloud(*input_, output, final), left on the device
-        return shifted(v.getFinalTransformation(), MAP_SHIFTS[m], +1.0)
-
     guess = poses[0].astype(np.float32)
-    for i in range(W):
-        guess = step(i, guess)
-    v.synchronize()
+    for w in pv.v:   # context start-up (first allocations, the first cloud's bounding-box round trip): frame 0 once on each, untimed
+        set_clouds(0, w)
+        w.align(to_map(0, guess), want_output=False, want_fitness=True)
+    if W > 0:
+        guess = run_pipelined(0, W, guess)[-1]
+    pv.synchronize()
     # The one-off ~40 ms stall that earlier rounds hid behind 96 untimed frames is CPython's cyclic garbage collector doing a full
     # collection over torch's object graph (scripts/exp_stall.py: gone with gc.freeze(), unmoved by anything done to the HIP
     # runtime): it belongs to this harness, not to the path.  Freeze what exists; the loop below allocates nothing cyclic.
@@ -275,40 +308,57 @@ def main():
     # HIP-event regions cost two hipEventRecord each: in the timed loop only the dominant kernel (the map's bulk kNN +
     # covariance launch -- rocprofv3 agrees, profiles/) is bracketed; the other stages are timed in a separate pass below.
     DOMINANT = "knn_cov_target"
-    v.profile_enable(True)
-    v.profile_select([DOMINANT])
-    v.profile_reset()
+    for w in pv.v:
+        w.profile_enable(True)
+        w.profile_select([DOMINANT])
+        w.profile_reset()
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    guess_in = []
-    for i in range(W, W + K):
-        guess_in.append(guess)
-        guess = step(i, guess)
-        finals.append(guess)
-        st = v.stats()
-        per_frame.append((st["outer_iterations"], st["n_linearize"], st["n_error"], st["n_corr"], st["n_voxels"]))
-    v.synchronize()
+    finals = run_pipelined(W, K, guess, collect=per_frame)
+    pv.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    guess_in = [guess] + finals[:-1]
     if world_size > 1:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    prof_dom = v.profile()[DOMINANT]
-    v.profile_enable(False)
+    prof_dom = {"total_ms": 0.0, "launches": 0, "points": 0}
+    for w in pv.v:
+        d = w.profile()[DOMINANT]
+        for kk in prof_dom:
+            prof_dom[kk] += d[kk]
+        w.profile_enable(False)
+    # the same K frames one at a time on one context (what a caller of the blocking align() gets: the frame's latency)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    g1, seq_finals = guess_in[0], []
+    for i in range(W, W + K):
+        g1 = step(i, g1)
+        seq_finals.append(g1)
+    v.synchronize()
+    elapsed_seq = time.perf_counter() - t1
+    seq_same = bool(all(np.array_equal(a_, b_) for a_, b_ in zip(finals, seq_finals)))
     # the same K steps with the scan crossing PCIe inside the step and the output cloud produced (device-resident): an extra key
-    g2 = guess_in[0]
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    for i in range(W, W + K):
-        g2 = step(i, g2, from_host=True)
-    v.synchronize()
+    g2 = run_pipelined(W, K, guess_in[0], from_host=True)[-1]
+    pv.synchronize()
     elapsed_h2d = time.perf_counter() - t2
     h2d_same = bool(np.array_equal(g2, finals[-1]))
-    # per-stage breakdown: a few more frames with every region bracketed (untimed, informational)
+    # the dominant kernel by itself (nothing else on the GPU): what the kernel costs, as opposed to what it costs while it shares the chip
+    v.profile_enable(True)
+    v.profile_select([DOMINANT])
+    v.profile_reset()
+    for j in range(5):
+        v.setInputTargetDevice(d_maps[j % len(maps)], tgt.shape[0], 16)
+        v.synchronize()
+    dom_alone = v.profile()[DOMINANT]
+    v.profile_enable(False)
+    # per-stage breakdown: a few more frames, one at a time, with every region bracketed (untimed, informational)
     v.profile_enable(True)
     v.profile_select(None)
     v.profile_reset()
@@ -362,6 +412,10 @@ def main():
     roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": per_unit * units}
+    alone_ms = dom_alone["total_ms"] / max(dom_alone["launches"], 1)
+    if alone_ms > 0:  # the timed region runs the launch beside another frame's kernels; alone it is shorter
+        roofline["launch_alone_ms"] = round(alone_ms, 4)
+        roofline["frac_launch_alone"] = round(per_unit * units / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
 
     out = {
         "metric": "registered scans/sec (16-beam -> 1M-pt map)", "value": round(scans_per_s, 3), "unit": "scans/s",
@@ -369,7 +423,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 points and neighbour search, f64 covariances and solve",
         "data": "synthetic",
         "config": {"workload": f"c-main: synthetic VLP-16 {args.n_source}-pt scans registered to a {args.n_target}-pt local map, rebuilt every step, "
-                               f"{len(maps)} translated map copies in turn (BASELINE.md c-main; one independent sequence per GPU)",
+                               f"{len(maps)} translated map copies in turn (BASELINE.md c-main; one independent sequence per GPU; two contexts "
+                               f"take turns so that a frame's preparation overlaps the previous frame's solve)",
                    "n_source": args.n_source, "n_target": args.n_target, "voxel_res": 1.0, "k": 20, "max_iterations": 25,
                    "parallelism": f"sequences x{world_size}"},
         "algorithmic_bytes_per_scan": round(B), "hbm_gbps_algorithmic": round(B * scans_per_s / world_size / 1e9, 3),
@@ -378,6 +433,8 @@ def main():
         "mean_correspondences": round(mean_corr, 1), "n_voxels": int(n_vox),
         "kernel_ms_per_step": {k: round(x["total_ms"] / KB, 4) for k, x in prof.items()},
         "roofline": roofline, "issue_roofline": issue,
+        "one_frame_at_a_time": {"scans_per_s": round(K / elapsed_seq, 3), "ms_per_step": round(1e3 * elapsed_seq / K, 3), "same_poses": seq_same,
+                                "what": "the same K frames through the blocking align() on one context: a frame's latency"},
         "scan_h2d_and_output": {"scans_per_s": round(K / elapsed_h2d, 3), "ms_per_step": round(1e3 * elapsed_h2d / K, 3), "same_final_pose": h2d_same,
                                 "what": "same steps; each scan uploaded from pinned host memory inside the step, align()'s output cloud written to a device buffer"},
         "final_pose_checksum": float(np.sum(np.abs(np.asarray(finals, np.float64)))),
@@ -422,7 +479,7 @@ def main():
         out["pose_parity_vs_cpu"] = {"frames": n_done, "max_dt_m": max(dts), "max_dtheta_rad": max(dths),
                                      "rmse_dt_m": float(np.sqrt(np.mean(np.square(dts)))),
                                      "rmse_dtheta_rad": float(np.sqrt(np.mean(np.square(dths))))}
-    v.close()
+    pv.close()
 
     if world_size == 1 and args.configs != "none":
         out["configs"] = run_extra_configs(registration, synth, oracle, [c.strip() for c in args.configs.split(",") if c.strip()])

@@ -65,6 +65,7 @@ struct rgc_ctx {
   hipStream_t stream = nullptr;   // main stream: target preprocessing, LM loop, fitness, getters
   hipStream_t stream2 = nullptr;  // source preprocessing runs here, concurrently with the (much larger) target's
   hipEvent_t src_ready = nullptr; // recorded on stream2 after the source is prepared
+  hipEvent_t tgt_ready = nullptr; // recorded on the main stream at rgc_align_begin: the solve (on stream2) waits for the map's preparation
   hipEvent_t main_mark = nullptr; // recorded on the main stream before a source is prepared: stream2 waits for it (producers on rgc_stream())
   bool src_pending = false;       // main stream has not yet been ordered after src_ready
   bool mark_valid = false, main_has_target_prep = false;  // main_mark recorded; a map preparation was enqueued after it and may still run
@@ -890,6 +891,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   }
   ok = ok && hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->main_mark, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->tgt_ready, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_small, 48 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_out, 64 * sizeof(double)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
@@ -933,6 +935,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->src_ready) (void)hipEventDestroy(c->src_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->main_mark) (void)hipEventDestroy(c->main_mark);
+  if (c->tgt_ready) (void)hipEventDestroy(c->tgt_ready);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
@@ -988,10 +991,11 @@ int rgc_num_correspondences(rgc_ctx* c, int* n) {
 // enqueued, not waited for.
 static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, bool want_fitness) {
   const int n = c->src.n, noff = noff_of(c->prm.neighbor_method);
+  hipStream_t s = c->stream2;  // see rgc_align_begin
   {
-    ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch);
+    ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch, s);
     for (int k = 0; k < batch; k++) {
-      rgck::lm_step(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
+      rgck::lm_step(s, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
                     c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
                     (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, open, c->d_small + 7,
                     c->tgt.segs.p, c->src.segs.p);
@@ -999,11 +1003,11 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
     }
   }
   if (want_fitness) {  // getFitnessScore at the final pose, chained blindly: the kernel is a no-op unless the LM is done
-    ProfScope ps(c, RGC_K_FITNESS, n);
-    rgck::fitness_lm(c->stream, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
+    ProfScope ps(c, RGC_K_FITNESS, n, s);
+    rgck::fitness_lm(s, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
                      (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p);
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, s));
   return RGC_OK;
 }
 
@@ -1016,8 +1020,14 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   HIPCHK(c, hipSetDevice(c->device));
   c->pend.active = false;
   // the guards of speculative grids come home with the LM state: no synchronisation here
-  int rc = need_inputs(c, /*validate=*/false);
-  if (rc) return rc;
+  if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
+  // The solve is a chain of short launches: it runs on the HIGH-PRIORITY stream -- the one the scan was prepared on, so it is already
+  // behind that -- ordered after the map's preparation on the main stream by one event.  With a second context preparing the next
+  // frame's map meanwhile (15 k waves that fill every CU), the dispatcher places the solve's ~100 workgroups as soon as slots free up
+  // instead of behind that launch.
+  HIPCHK(c, hipEventRecord(c->tgt_ready, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->tgt_ready, 0));
+  int rc;
   const rgc_params& P = c->prm;
   // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_step);
   // the host only enqueues slots and reads the state back once per batch.
@@ -1031,7 +1041,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
   if (!c->lm_state.p) {
     if ((rc = ensure(c, c->lm_state, 4096))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->stream));  // tickets start at 0
+    HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->stream2));  // tickets start at 0
   }
   if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)rgck::fitness_blocks(n) + 64))) return rc;
   rgck::LmInit in;
@@ -1058,12 +1068,13 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
   const bool want_fitness = c->pend.want_fitness;
   rgck::LmState& S = *c->h_lm;
   for (int guard = 0;; guard++) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
     HIPCHK(c, hipGetLastError());
     if (S.done || guard >= 400) break;
     // a solve that is still running after six outer iterations usually runs many more (up to 25): batches of six, fewer read-backs
     if ((rc = lm_enqueue_batch(c, 6, nullptr, want_fitness))) return rc;
   }
+  c->src_pending = false;  // stream2 has drained, and it was behind the main stream: nothing of this frame is in flight
   {  // a cloud that did not fit its speculative grid: everything above ran on a parked cloud -- prepare it properly, solve again
     const int r = resolve_guards(c, S.pad & 0xff, (S.pad >> 8) & 0xff);
     if (r < 0) return r;

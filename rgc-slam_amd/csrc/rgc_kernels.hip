@@ -2206,6 +2206,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
           const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v0, double* __restrict__ corr_M0,
           int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st, int first,
           LmInit in, const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s) {
+  wave_prio(1);  // a latency chain: issue ahead of whatever throughput-bound launch shares the CU (the other context's kNN)
   // first != 0: this launch opens a solve.  Nobody reads the (stale) state: mode, buffer and pose come from the kernel
   // arguments, and the last-arriving workgroup's lane 0 writes the fresh state (:53-63) before it uses it -- no separate
   // initialisation launch, no H2D copy.  The tickets are 0 between launches by construction (the last arriver resets them).
@@ -2497,6 +2498,7 @@ __global__ void __launch_bounds__(FIT_T)
 k_fitness_lm(const float4* __restrict__ SP, int ns, LmState* __restrict__ st, const float4* __restrict__ TP,
              const int* __restrict__ tstart, Grid g, double* __restrict__ partials) {
   if (!st->done) return;  // enqueued blindly behind a batch of LM slots
+  wave_prio(1);
   PoseF T;
 #pragma unroll
   for (int a = 0; a < 12; a++) T.m[a] = (float)st->x0[a];  // final_transformation_ = x0.cast<float>(), :77

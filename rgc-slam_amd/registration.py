@@ -161,7 +161,7 @@ class FastVGICP:
 
     def align_end(self):
         """Second half of align(): waits for the solve; getFinalTransformation() etc. are valid afterwards."""
-        want_fitness = self._pending_fitness
+        want_fitness = getattr(self, "_pending_fitness", False)
         fin = np.empty(16, np.float32)
         H = np.empty(36)
         fit = C.c_double(0)
@@ -340,14 +340,16 @@ def odometer_vgicp(device: int = 0) -> FastVGICP:
 
 
 class PipelinedVGICP:
-    """Scan-to-map registration of a SEQUENCE on two contexts taking turns.  A frame is cloud preparation (grids, kNN covariances,
+    """Scan-to-map registration of a SEQUENCE on `depth` contexts taking turns.  A frame is cloud preparation (grids, kNN covariances,
     voxel map: throughput-bound, most of the frame) followed by the LM solve (a chain of short launches that leaves the chip mostly
-    idle) -- and only the solve needs the previous frame's pose.  So while frame i is being solved on one context the clouds of frame
-    i + 1 are prepared on the other; every frame runs the same kernels on the same inputs as FastVGICP.align() one frame at a time:
-    results are identical, the frames just overlap on the GPU (align_begin / align_end, include/rgc_hip.h)."""
+    idle) -- and only the solve needs the previous frame's pose.  So while frame i is being solved on one context the clouds of frames
+    i + 1 .. i + depth - 1 are being prepared on the others; every frame runs the same kernels on the same inputs as FastVGICP.align()
+    one frame at a time: results are identical, the frames just overlap on the GPU (align_begin / align_end, include/rgc_hip.h)."""
 
-    def __init__(self, device: int = 0, make=odometer_vgicp):
-        self.v = [make(device), make(device)]
+    def __init__(self, device: int = 0, make=odometer_vgicp, depth: int = 3):
+        if depth < 2:
+            raise ValueError("depth >= 2")
+        self.v = [make(device) for _ in range(depth)]
 
     def close(self):
         for v in self.v:
@@ -360,18 +362,19 @@ class PipelinedVGICP:
     def run(self, n_frames, set_clouds, guess0, want_fitness=False, next_guess=None, on_result=None):
         """set_clouds(i, v): set target and source of frame i on the FastVGICP `v` (device-resident or host clouds).
         The guess of frame 0 is guess0; that of frame i + 1 is next_guess(i, T_i) (default: T_i, frame i's final transformation).
-        on_result(i, v) is called when frame i is done (v holds its results until frame i + 2 is set).  Returns the final
+        on_result(i, v) is called when frame i is done (v holds its results until it is given frame i + depth).  Returns the final
         transformations."""
         out = []
-        if n_frames <= 0:
-            return out
-        set_clouds(0, self.v[0])
+        D = len(self.v)
+        for j in range(min(D - 1, n_frames)):
+            set_clouds(j, self.v[j % D])
         g = guess0
         for i in range(n_frames):
-            cur = self.v[i & 1]
+            cur = self.v[i % D]
             cur.align_begin(g, want_fitness)
-            if i + 1 < n_frames:
-                set_clouds(i + 1, self.v[(i + 1) & 1])   # the next frame's preparation: on the GPU while this frame is solved
+            j = i + D - 1                       # the context of frame i - 1 is free: the frame D - 1 ahead goes there
+            if j < n_frames:
+                set_clouds(j, self.v[j % D])    # ... and is prepared on the GPU while this frame (and the next) are solved
             T = cur.align_end()
             if on_result is not None:
                 on_result(i, cur)

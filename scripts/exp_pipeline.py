@@ -24,7 +24,7 @@ def seq(n_rep):
             g = v.getFinalTransformation(); out.append(g)
     v.synchronize()
     return out
-pv = registration.PipelinedVGICP(0)
+pv = registration.PipelinedVGICP(0, depth=int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 def setc(j, w):
     w.setInputTargetDevice(d_tgt, len(tgt), 16)
     w.setInputSourceDevice(d_s[j % frames], 30000, 16)

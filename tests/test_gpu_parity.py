@@ -362,3 +362,52 @@ def test_speculative_grid_hit_miss_and_late_errors(reg_mod, medium):
     v.setInputTarget(tgt); v.setInputSource(src)
     assert same(v)
     v.close()
+
+
+def test_align_in_two_halves_and_pipelined_sequence(reg_mod, orc):
+    """rgc_align_begin + rgc_align_end == rgc_align, and a sequence through PipelinedVGICP (two or three contexts taking turns, the next
+    frames' clouds prepared while a frame is solved) gives exactly the poses of one frame at a time -- which follow the CPU oracle."""
+    import rgc_slam_amd.synth as synth
+    world, tgt = synth.make_world_and_map(60000, seed=synth.SEED + 7)
+    poses = synth.make_trajectory(7, seed=synth.SEED + 7)
+    scans = [synth.make_scan_n(world, poses[i + 1], 12000, seed=synth.SEED + 300 + i)["xyz"] for i in range(6)]
+    v = _odo(reg_mod)
+    with pytest.raises(reg_mod.RgcError):
+        v.align_end()                                # nothing begun
+    g = poses[0].astype(np.float32)
+    seq, fits = [], []
+    for s in scans:
+        v.setInputTarget(tgt)
+        v.setInputSource(s)
+        v.align(g, want_output=False, want_fitness=True)
+        g = v.getFinalTransformation()
+        seq.append(g)
+        fits.append(v.getFitnessScore())
+    # the two halves on one context
+    v.setInputTarget(tgt)
+    v.setInputSource(scans[0])
+    v.align_begin(poses[0].astype(np.float32), want_fitness=True)
+    T = v.align_end()
+    assert np.array_equal(T, seq[0]) and v.getFitnessScore() == fits[0]
+    with pytest.raises(reg_mod.RgcError):
+        v.align_end()                                # already collected
+    v.close()
+    for depth in (2, 3):
+        pv = reg_mod.PipelinedVGICP(0, depth=depth)
+        got_fit = []
+        def setc(i, w):
+            w.setInputTarget(tgt)
+            w.setInputSource(scans[i])
+        out = pv.run(len(scans), setc, poses[0].astype(np.float32), want_fitness=True, on_result=lambda i, w: got_fit.append(w.getFitnessScore()))
+        assert all(np.array_equal(a, b) for a, b in zip(out, seq)), depth
+        assert got_fit == fits
+        pv.close()
+    # and the sequence follows the oracle (frame by frame from the GPU path's own guesses)
+    o = orc.Registration(max_iterations=25, translation_eps=1e-6, num_threads=0)
+    g = poses[0].astype(np.float32)
+    for s, T in zip(scans[:3], seq[:3]):
+        o.set_target(tgt)
+        o.set_source(s)
+        To = o.align(g)
+        assert np.abs(T[:3, 3] - To[:3, 3]).max() <= 1e-4 and _rot_angle(T[:3, :3], To[:3, :3]) <= 1e-4
+        g = T
