@@ -9,7 +9,7 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 world, tgt = synth.make_world_and_map(nt)
 poses = synth.make_trajectory(frames + 1)
 scans = [synth.make_scan_n(world, poses[i + 1], 30000, seed=synth.SEED + 100 + i)["xyz"] for i in range(frames)]
-pv = registration.PipelinedVGICP(0)
+pv = registration.PipelinedVGICP(0, depth=int(sys.argv[3]) if len(sys.argv) > 3 else 2)
 v = pv.v[0]
 def to_dev(xyz):
     a = np.zeros((xyz.shape[0], 4), np.float32); a[:, :3] = xyz
