@@ -1,7 +1,7 @@
 #!/bin/bash
 # Instruction-issue / memory counters of ONE kernel (name substring $1, e.g. "k_knn_sp<20, true>"): separate rocprofv3 --pmc passes over
-# scripts/prof_frame.py (30 k-point scan vs 1 M-point map), summarised into gpurun_out/pmc_$2.json.   usage: pmc_kernel.sh <pattern> <tag>
-PAT="$1"; TAG="${2:-kernel}"
+# scripts/prof_frame.py (30 k-point scan vs 1 M-point map), summarised into gpurun_out/pmc_$2.json.   usage: pmc_kernel.sh <pattern> <tag> [queries per launch, default 1000000]
+PAT="$1"; TAG="${2:-kernel}"; NQ="${3:-1000000}"
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 rm -rf $O; mkdir -p $O
@@ -10,7 +10,7 @@ for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "
   rocprofv3 --pmc $set -d $d -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prof_frame.py 1000000 4 > /dev/null 2>&1
 done
 cd $GRAFT_REPO_ROOT
-PAT="$PAT" TAG="$TAG" python3 - <<'PY'
+PAT="$PAT" TAG="$TAG" NQ="$NQ" python3 - <<'PY'
 import csv, glob, json, collections, os
 O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_" + os.environ["TAG"])
 pat = os.environ["PAT"]
@@ -20,8 +20,8 @@ for f in glob.glob(os.path.join(O, "**", "*counter_collection.csv"), recursive=T
         if pat in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
-out = {"kernel": pat + " (1 M queries per launch)", "per_launch": m}
-q = 1.0e6
+q = float(os.environ["NQ"])
+out = {"kernel": pat + " (%d queries per launch)" % int(q), "per_launch": m}
 if "SQ_INSTS_VALU" in m: out["valu_wave_instructions_per_query"] = round(m["SQ_INSTS_VALU"] / q, 1)
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m: out["hbm_bytes_per_launch"] = int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)
 for a, b, name in (("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "valu_active_per_busy_cycle"), ("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "wave_cycles_waiting_on_issue_frac"),

@@ -13,7 +13,7 @@ find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_s
 find $O/stats -name "*domain_stats.csv" | head -1 | xargs -I{} cp {} $O/domain_stats.csv
 rm -rf $O/stats
 scripts/pmc_kernel.sh "k_knn_sp<20, true>" knn > /dev/null 2>&1; cp gpurun_out/pmc_knn.json $O/pmc_knn.json
-scripts/pmc_kernel.sh "k_knn_sp<20, false>" knn_src > /dev/null 2>&1; cp gpurun_out/pmc_knn_src.json $O/pmc_knn_src.json
+scripts/pmc_kernel.sh "k_knn_sp<20, false>" knn_src 30000 > /dev/null 2>&1; cp gpurun_out/pmc_knn_src.json $O/pmc_knn_src.json
 timeout 120 scripts/ubench/valu_issue > $O/valu_issue.jsonl 2> /dev/null
 python scripts/exp_stall.py 300 > $O/stall.txt 2>&1; EXP_GC=freeze python scripts/exp_stall.py 300 >> $O/stall.txt 2>&1
 if [ "$1" != quick ]; then
