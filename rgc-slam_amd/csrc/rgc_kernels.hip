@@ -2201,10 +2201,7 @@ __device__ __forceinline__ void lm_step_decide(LmState& ls, const double* folded
   LAB_TS(7);
 }
 
-#ifndef RGC_LM_WAVES
-#define RGC_LM_WAVES 1
-#endif
-__global__ void __launch_bounds__(LIN_T, RGC_LM_WAVES)
+__global__ void __launch_bounds__(LIN_T)
 k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
           const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v0, double* __restrict__ corr_M0,
           int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st, int first,
@@ -2941,10 +2938,7 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   const int T = is_target ? CT::T : CS::T;
   const size_t lds = (size_t)(is_target ? SpShape<CT::R, CT::kClip>::LDS : SpShape<CS::R, CS::kClip>::LDS) * T * sizeof(int);
   const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
-#ifndef RGC_KNN_PAD
-#define RGC_KNN_PAD 0
-#endif
-  if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true>), dim3(nb), dim3(T), lds + RGC_KNN_PAD, s, P, start, g, n, k, df, nx, ny, nz);
+  if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
   else hipLaunchKernelGGL((k_knn_sp<KC, false>), dim3(nblk(n, T / 4)), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);  // four lanes per query
 }
 template <int KC>
