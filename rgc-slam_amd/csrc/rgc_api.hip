@@ -1287,8 +1287,13 @@ int rgc_get_voxels(rgc_ctx* c, int cap, int* coords, int* num, double* mean, dou
     const int ci = cell[v];
     if (coords) {
       coords[v * 3 + 0] = ci % g.dim[0] + g.minc[0];
+#if defined(RGC_Y_SLOWEST) && RGC_Y_SLOWEST  // the cell order of rgck::cell_index
+      coords[v * 3 + 2] = (ci / g.dim[0]) % g.dim[2] + g.minc[2];
+      coords[v * 3 + 1] = ci / (g.dim[0] * g.dim[2]) + g.minc[1];
+#else
       coords[v * 3 + 1] = (ci / g.dim[0]) % g.dim[1] + g.minc[1];
       coords[v * 3 + 2] = ci / (g.dim[0] * g.dim[1]) + g.minc[2];
+#endif
     }
     if (num) num[v] = (int)r[9];
     if (mean) { mean[v * 3] = r[0]; mean[v * 3 + 1] = r[1]; mean[v * 3 + 2] = r[2]; }

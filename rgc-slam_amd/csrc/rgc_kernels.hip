@@ -139,7 +139,22 @@ __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ in, int 
   if (bad) atomicOr(flags, 1);
 }
 
-__device__ __forceinline__ int cell_index(const Grid& g, int cx, int cy, int cz) { return (cz * g.dim[1] + cy) * g.dim[0] + cx; }
+// Cell order: x fastest (a grid row = the cells of one (y, z) = one contiguous range of the sorted array), then y, then z.
+// -DRGC_Y_SLOWEST=1 makes it x, z, y: a lidar map is flat (hundreds of cells in x and y, ten or twenty in z), so with y slowest a
+// contiguous run of queries keeps its candidates in a ~0.5 MB window of the array, and with one long run per XCD (-DRGC_XCD_RUN=496)
+// the bulk kNN launch re-reads almost nothing: 43 MB of HBM traffic per 1 M-query launch instead of 73 (algorithmic 36) -- but the
+// launch is 3 % SLOWER (0.163-0.169 ms against 0.157: the populated neighbour rows of a surface are the y-neighbours, which that
+// order moves apart) and the frame 2-3 % (scripts/exp_xcd_run.sh).  The kernel is bound by instruction issue, not bytes: the default
+// keeps the faster order.
+#ifndef RGC_Y_SLOWEST
+#define RGC_Y_SLOWEST 0
+#endif
+__device__ __forceinline__ int cell_index(const Grid& g, int cx, int cy, int cz) {
+  return RGC_Y_SLOWEST ? (cy * g.dim[2] + cz) * g.dim[0] + cx : (cz * g.dim[1] + cy) * g.dim[0] + cx;
+}
+// which (dy, dz) the r-th row of a D x D block is, rows counted in MEMORY order
+__device__ __forceinline__ constexpr int row_dy(int r, int D, int R) { return (RGC_Y_SLOWEST ? r / D : r % D) - R; }
+__device__ __forceinline__ constexpr int row_dz(int r, int D, int R) { return (RGC_Y_SLOWEST ? r % D : r / D) - R; }
 
 // guard (nullable): the grid was NOT derived from this cloud (a speculative grid kept from the previous one): a point with
 // non-finite / absurd coordinates sets bit 0, a point outside the grid bit 1 -- the host re-prepares the cloud when it
@@ -735,7 +750,7 @@ struct SpOrder {
     for (int ring = 1; ring <= R; ring++)
       for (int d2 = 1; d2 <= 2 * R * R; d2++)
         for (int r = 0; r < NROW; r++) {
-          const int dy = r % D - R, dz = r / D - R;
+          const int dy = row_dy(r, D, R), dz = row_dz(r, D, R);
           const int ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
           if ((ay > az ? ay : az) == ring && dy * dy + dz * dz == d2) p[n++] = (kClip && r > OWN) ? r + 2 : r;
         }
@@ -789,7 +804,7 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
   using Shape = SpShape<R, kClip>;
   constexpr int kRowRel = 127;
   constexpr int D = Shape::D, NROW = Shape::NROW, NP = Shape::NP, OWN = NROW / 2;
-  // ---- the block's pieces in MEMORY order: the D x D grid rows r = D (dz + R) + (dy + R), each the cells cx - R .. cx + R.  kClip: the
+  // ---- the block's pieces in MEMORY order: the D x D grid rows in the order of cell_index (row_dy / row_dz), each the cells cx - R .. cx + R.  kClip: the
   // own row (r = OWN) as three pieces cut at multiples of four points from its start -- left of the own cell, the own cell, right
   // of it -- so pieces OWN, OWN + 1, OWN + 2, and the rows behind it shifted by two. ----
   const int xl = max(c[0] - R, 0), xh = min(c[0] + R, g.dim[0] - 1);
@@ -809,7 +824,7 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
   float min2[NP];
 #pragma unroll
   for (int r = 0; r < NROW; r++) {
-    const int dy = r % D - R, dz = r / D - R;
+    const int dy = row_dy(r, D, R), dz = row_dz(r, D, R);
     const int y = c[1] + dy, z = c[2] + dz;
     const bool in = y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2];
     const int yy = in ? y : c[1], zz = in ? z : c[2];
