@@ -435,18 +435,28 @@ private:
 // on the device through two slots.  Poses are those of the unpipelined node (the stages see the same data in the same order).
 class ReplayPipeline {
 public:
-  explicit ReplayPipeline(OdometryNode::Options o) : body_((o.resident_map = true, o.device_chain = true, o)), opt_(o) {
-    int rc = rgc_create(o.hip_device, nullptr, &fe_ctx_);
-    if (rc != RGC_OK) throw std::runtime_error(std::string("rgc_create: ") + rgc_status_string(rc));
+  // front_workers: how many sweeps are in the front-end at once (each worker = one host thread + one context; workers take alternate
+  // sweeps, the frame body consumes them in order).  The front-end of a sweep (0.56 ms, two host round trips) is longer than the frame
+  // body and sweeps are independent there -- yet MEASURED on MI355X / ROCm 7.2 a second worker makes the replay slower (0.65 ms per
+  // sweep with one, 0.98 with two, 0.85 with three: three host threads that synchronise with the device several times per sweep
+  // contend inside the runtime), so the default is one.
+  explicit ReplayPipeline(OdometryNode::Options o, int front_workers = 1)
+      : body_((o.resident_map = true, o.device_chain = true, o)), opt_(o), front_(front_workers < 1 ? 1 : front_workers), slot_(2 * front_.size()) {
+    for (Front& f : front_) {
+      int rc = rgc_create(o.hip_device, nullptr, &f.ctx);
+      if (rc != RGC_OK) throw std::runtime_error(std::string("rgc_create: ") + rgc_status_string(rc));
+    }
     rgc_default_fe_params(&fe_);
     fe_.n_scans = o.scan_line; fe_.min_range = o.minimum_range; fe_.max_range = o.maxmum_range;
   }
   // IMU messages go to the frame body's node (deliver them before run(): the replay has every message up front)
   void imuCallback(double stamp, const double acc[3], const double gyr[3]) { body_.imuCallback(stamp, acc, gyr); }
   ~ReplayPipeline() {
-    for (Slot& s : slot_) if (s.d) rgc_device_free(fe_ctx_, s.d);
-    if (d_raw_) rgc_device_free(fe_ctx_, d_raw_);
-    rgc_destroy(fe_ctx_);
+    for (Slot& s : slot_) if (s.d) rgc_device_free(front_[0].ctx, s.d);
+    for (Front& f : front_) {
+      if (f.d_raw) rgc_device_free(f.ctx, f.d_raw);
+      if (f.ctx) rgc_destroy(f.ctx);
+    }
   }
   ReplayPipeline(const ReplayPipeline&) = delete;
   ReplayPipeline& operator=(const ReplayPipeline&) = delete;
@@ -455,7 +465,7 @@ public:
   // done_ms (nullable): wall time, from the call, at which each pose was ready.
   void run(const std::vector<const void*>& messages, const std::vector<int>& n_points, const rgc_pc2_layout& layout, const std::vector<double>& stamps,
            std::vector<OdometryMsg>* odom, std::vector<GroundMsg>* ground, std::vector<double>* done_ms = nullptr) {
-    const size_t N = messages.size();
+    const size_t N = messages.size(), F = front_.size(), NS = slot_.size();
     const auto t_call = std::chrono::steady_clock::now();
     if (done_ms) done_ms->assign(N, 0.0);
     odom->assign(N, OdometryMsg());
@@ -463,24 +473,26 @@ public:
     stop_ = false;                                   // a run that failed must not poison the next one
     for (Slot& s : slot_) s.full = false;
     std::exception_ptr front_error;
-    std::thread front([&]() {
-      try {
-        for (size_t k = 0; k < N; k++) {
-          Slot& s = slot_[k & 1];
-          { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return !s.full || stop_; }); if (stop_) return; }
-          front_stage(messages[k], n_points[k], layout, s);
-          { std::lock_guard<std::mutex> lk(m_); s.full = true; }
+    std::vector<std::thread> workers;
+    for (size_t w = 0; w < F; w++)
+      workers.emplace_back([&, w]() {
+        try {
+          for (size_t k = w; k < N; k += F) {        // sweep k always lands in slot k % NS: the body takes the slots in sweep order
+            Slot& s = slot_[k % NS];
+            { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return !s.full || stop_; }); if (stop_) return; }
+            front_stage(front_[w], messages[k], n_points[k], layout, s);
+            { std::lock_guard<std::mutex> lk(m_); s.full = true; }
+            cv_.notify_all();
+          }
+        } catch (...) {
+          { std::lock_guard<std::mutex> lk(m_); if (!front_error) front_error = std::current_exception(); stop_ = true; }
           cv_.notify_all();
         }
-      } catch (...) {
-        front_error = std::current_exception();
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        cv_.notify_all();
-      }
-    });
+      });
+    auto join_all = [&]() { for (std::thread& t : workers) t.join(); };
     try {
       for (size_t k = 0; k < N; k++) {
-        Slot& s = slot_[k & 1];
+        Slot& s = slot_[k % NS];
         { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return s.full || stop_; }); if (stop_ && !s.full) break; }
         body_.handleFrontEndOutput(s.d, s.n, s.ground.param, s.ground.valid, stamps[k], &(*odom)[k]);
         (*ground)[k] = s.ground;
@@ -491,42 +503,47 @@ public:
     } catch (...) {
       { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
       cv_.notify_all();
-      front.join();
+      join_all();
       throw;
     }
-    front.join();
+    join_all();
     if (front_error) std::rethrow_exception(front_error);
   }
   OdometryNode& node() { return body_; }
 
 private:
   struct Slot { float* d = nullptr; size_t cap = 0; int n = 0; GroundMsg ground; bool full = false; };
-  void chk(int rc) { if (rc != RGC_OK) throw std::runtime_error(std::string(rgc_status_string(rc)) + ": " + rgc_last_error(fe_ctx_)); }
-  void grow(float*& p, size_t& cap, size_t bytes) {
+  struct Front {                                     // one front-end worker: its context, its raw-sweep buffer, its feature staging
+    rgc_ctx* ctx = nullptr;
+    float* d_raw = nullptr; size_t raw_cap = 0;
+    std::vector<float> sharp, flat, inten;
+  };
+  static void chk(rgc_ctx* c, int rc) { if (rc != RGC_OK) throw std::runtime_error(std::string(rgc_status_string(rc)) + ": " + rgc_last_error(c)); }
+  static void grow(rgc_ctx* c, float*& p, size_t& cap, size_t bytes) {
     if (bytes <= cap) return;
-    if (p) chk(rgc_device_free(fe_ctx_, p));
+    if (p) chk(c, rgc_device_free(c, p));
     p = nullptr; cap = 0;
     void* np = nullptr;
-    chk(rgc_device_alloc(fe_ctx_, bytes + bytes / 4, &np));
+    chk(c, rgc_device_alloc(c, bytes + bytes / 4, &np));
     p = (float*)np; cap = bytes + bytes / 4;
   }
-  void front_stage(const void* data, int n, const rgc_pc2_layout& layout, Slot& s) {   // ScanRegistration::laserCloudHandler
-    grow(d_raw_, raw_cap_, (size_t)16 * (size_t)(n > 0 ? n : 1));
-    chk(rgc_pc2_unpack(fe_ctx_, data, n, &layout, d_raw_, nullptr, nullptr, 1));
+  void front_stage(Front& f, const void* data, int n, const rgc_pc2_layout& layout, Slot& s) {   // ScanRegistration::laserCloudHandler
+    grow(f.ctx, f.d_raw, f.raw_cap, (size_t)16 * (size_t)(n > 0 ? n : 1));
+    chk(f.ctx, rgc_pc2_unpack(f.ctx, data, n, &layout, f.d_raw, nullptr, nullptr, 1));
     const int fcap = fe_.n_scans * 6 * 41;
-    sharp_.resize((size_t)5 * fcap); flat_.resize((size_t)5 * fcap); inten_.resize((size_t)5 * fcap);
+    f.sharp.resize((size_t)5 * fcap); f.flat.resize((size_t)5 * fcap); f.inten.resize((size_t)5 * fcap);
     rgc_fe_out fo;
     std::memset(&fo, 0, sizeof(fo));
     fo.cloud = nullptr; fo.cloud_cap = n > 0 ? n : 1;
-    fo.sharp = sharp_.data(); fo.flat = flat_.data(); fo.inten = inten_.data(); fo.feat_cap = fcap;
-    chk(rgc_frontend_device(fe_ctx_, d_raw_, n, 16, &fe_, &fo));
+    fo.sharp = f.sharp.data(); fo.flat = f.flat.data(); fo.inten = f.inten.data(); fo.feat_cap = fcap;
+    chk(f.ctx, rgc_frontend_device(f.ctx, f.d_raw, n, 16, &fe_, &fo));
     float* d_full = nullptr; int nn = 0;
-    chk(rgc_frontend_cloud_device(fe_ctx_, &d_full, &nn));
+    chk(f.ctx, rgc_frontend_cloud_device(f.ctx, &d_full, &nn));
     s.n = fo.n_cloud;
     if (s.n > 0) {
       const double I[4] = {0, 0, 0, 1}, Z[3] = {0, 0, 0};
-      grow(s.d, s.cap, (size_t)16 * (size_t)s.n);
-      chk(rgc_transform_cloud(fe_ctx_, d_full, s.n, 16, I, Z, s.d, 1));   // identity = device-to-device copy into the hand-over slot
+      grow(f.ctx, s.d, s.cap, (size_t)16 * (size_t)s.n);   // (device memory is not tied to the context that allocated it)
+      chk(f.ctx, rgc_transform_cloud(f.ctx, d_full, s.n, 16, I, Z, s.d, 1));   // identity = device-to-device copy into the hand-over slot
     }
     std::memcpy(s.ground.param, fo.groundparam, sizeof(s.ground.param));
     s.ground.valid = fo.ground_valid != 0;
@@ -534,11 +551,9 @@ private:
 
   OdometryNode body_;
   OdometryNode::Options opt_;
-  rgc_ctx* fe_ctx_ = nullptr;
+  std::vector<Front> front_;
   rgc_fe_params fe_{};
-  float* d_raw_ = nullptr; size_t raw_cap_ = 0;
-  std::vector<float> sharp_, flat_, inten_;
-  Slot slot_[2];
+  std::vector<Slot> slot_;
   std::mutex m_;
   std::condition_variable cv_;
   bool stop_ = false;

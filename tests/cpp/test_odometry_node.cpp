@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     const bool as_message = atoi(argv[3]) != 0;
     if (argc > 5) opt.device_chain = atoi(argv[5]) != 0;
     if (argc > 6 && atoi(argv[6]) != 0) {   // front-end of sweep k+1 overlapped with the frame body of sweep k
-      rgc::ReplayPipeline pipe(opt);
+      rgc::ReplayPipeline pipe(opt, getenv("RGC_FRONT_WORKERS") ? atoi(getenv("RGC_FRONT_WORKERS")) : 1);
       std::vector<const void*> data;
       std::vector<double> stamps;
       for (int s = 0; s < n_sweeps; s++) { data.push_back(msgs[s].data()); stamps.push_back(0.1 * s); }
