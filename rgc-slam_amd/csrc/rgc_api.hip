@@ -91,6 +91,7 @@ struct rgc_ctx {
   DevBuf fit_partials;        // fitness rows when it is chained behind the LM slots
   rgck::LmState* h_lm = nullptr;  // pinned mirror
   struct { bool active = false; bool want_fitness = false; float guess[16]; } pend;  // rgc_align_begin .. rgc_align_end
+  int lm_last_outer = 0;      // outer iterations of the previous solve: sizes the next blind batch
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
   double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
@@ -1051,8 +1052,14 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   in.rot_eps = P.rotation_eps; in.trans_eps = P.translation_eps; in.init_factor = P.lm_init_lambda_factor;
   in.max_outer = P.max_iterations; in.max_inner = P.lm_max_iterations;
   c->stats.n_linearize = c->stats.n_error = c->stats.outer_iterations = 0;
-  // one linearisation + six fused cost/linearise steps: up to six outer iterations without a read-back
-  if ((rc = lm_enqueue_batch(c, 7, &in, want_fitness != 0))) return rc;
+  // One linearisation + fused cost / linearise steps, enqueued blind: enough for the outer iterations the PREVIOUS solve on this context
+  // took plus two (consecutive frames of a sequence need about the same number; a launch on a finished solve costs ~2 us, a
+  // read-back and a second batch ~40), at least the six that cover a tracking frame, at most what max_iterations allows.
+  int batch = 7;
+  if (c->lm_last_outer + 3 > batch) batch = c->lm_last_outer + 3;
+  if (batch > P.max_iterations + 1) batch = P.max_iterations + 1;
+  if (batch < 2) batch = 2;
+  if ((rc = lm_enqueue_batch(c, batch, &in, want_fitness != 0))) return rc;
   memcpy(c->pend.guess, guess, sizeof(c->pend.guess));
   c->pend.want_fitness = want_fitness != 0;
   c->pend.active = true;
@@ -1101,6 +1108,7 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
   }
   c->deferred_known = true;
   const int iters = S.failed ? S.outer + 1 : S.outer;  // iterations started, like nr_iterations_ + 1
+  c->lm_last_outer = S.outer;
   c->stats.outer_iterations = iters;
   float fin[16];
   for (int i = 0; i < 16; i++) fin[i] = (float)S.x0[i];  // :77
