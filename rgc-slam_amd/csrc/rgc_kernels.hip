@@ -2522,7 +2522,13 @@ k_fitness_lm(const float4* __restrict__ SP, int ns, LmState* __restrict__ st, co
   if (threadIdx.x == 0) __hip_atomic_store(&partials[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through row
   if (!last_block_arrive(&st->ticketB)) return;  // the LM is over: its ticket is free
   double t = 0;
-  for (int r = threadIdx.x; r < (int)gridDim.x; r += FIT_T) t += partials[r];
+  for (int r0 = threadIdx.x; r0 < (int)gridDim.x; r0 += 8 * FIT_T) {  // eight rows per lane fetched before any is added (one round trip, not eight)
+    double v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v8[u] = (r0 + u * FIT_T < (int)gridDim.x) ? partials[r0 + u * FIT_T] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) t += v8[u];
+  }
   t = wave_sum(t);
   if (threadIdx.x == 0) { st->fit_sum = t; st->has_fit = 1; }
 }
