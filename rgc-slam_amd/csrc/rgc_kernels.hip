@@ -1,8 +1,9 @@
 // rgc_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the RGC-SLAM scan-to-map registration path.
 //
-// Written for 64-wide wavefronts; compiled with -ffp-contract=off so the fp32 squared distance is the same
-// ((dx*dx + dy*dy) + dz*dz) FLANN's L2_Simple<float> produces on the reference's x86-64 build and the exact-kNN
-// neighbour SETS match the CPU path bit for bit (fast_gicp_impl.hpp:254).  Everything downstream of the raw fp32
+// Written for 64-wide wavefronts; compiled with -ffp-contract=off so that dist2() is the same ((dx*dx + dy*dy) + dz*dz) FLANN's
+// L2_Simple<float> produces on the reference's x86-64 build: wherever the ORDER of two candidates decides a neighbour set it is
+// decided by that expression (the bulk kNN kernels rank by FMA-contracted keys and fall back to it when two keys are too close
+// to tell), so the exact-kNN neighbour sets match the CPU path (fast_gicp_impl.hpp:254).  Everything downstream of the raw fp32
 // points is fp64, like the reference (points are cast to double at fast_gicp_impl.hpp:258, fast_vgicp_impl.hpp:84).
 //
 // Reference citations are relative to /root/reference/rgc_slam/.
@@ -11,8 +12,8 @@
 // the row walkers, the Jacobi solver, the block reduction -- are shared by nearly every kernel and stay inlinable):
 //   grid build      k_bbox, k_count, k_cells_scan_{block,sums,add}, k_place, k_rank_gather (+ k_scan_*, k_scatter for the
 //                   pcl::VoxelGrid path of rgc_pre.hip)
-//   C2 kNN + cov    Chain, knn_point_sp, k_knn_sp (bulk, one lane per query, one pass), TopK, coop_kth, k_knn_coop (deferred
-//                   queries, one wave per query)
+//   C2 kNN + cov    Chain, sp_piece_table, knn_point_sp (map: one lane per query, one pass), knn_point_split (scan: four lanes per
+//                   query), k_knn_sp (the bulk launch of either), TopK, coop_kth, k_knn_coop (deferred queries, one wave per query)
 //   C3 voxel map    k_voxel_build
 //   C4-C7 solve     linearize_point, error_point, block_reduce_store, last_block_arrive, block_fold_rows, k_lm_step (default
 //                   driver), k_linearize / k_error / k_fold / k_lm_try (public fine seam)
