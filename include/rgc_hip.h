@@ -126,6 +126,13 @@ RGC_API int rgc_align(rgc_ctx* ctx, const float guess[16], float final_T[16], do
 RGC_API int rgc_align_begin(rgc_ctx* ctx, const float guess[16], int want_fitness);
 RGC_API int rgc_align_end(rgc_ctx* ctx, float final_T[16], double final_H[36], double* fitness, int* iterations, int* converged,
                           int* lm_failed);
+/* ctx registers its scans to the target `owner` has prepared (rgc_set_target*, or rgc_map_commit: the resident local map), without
+ * preparing or copying it: ctx's target becomes a non-owning alias of the owner's device buffers.  Two contexts can then take turns
+ * on a sequence whose map does not change every frame (the next scan is prepared on one while the current one is solved on the
+ * other).  The owner must stay alive and must not be destroyed while ctx uses the target; when the owner prepares a new target
+ * (rgc_set_target*, a commit that rebuilds) ctx's next rgc_align* fails with RGC_ERR_INVALID until the target is shared again.
+ * Synchronises both contexts.  No reference counterpart (the reference builds one FastVGICP per frame). */
+RGC_API int rgc_share_target(rgc_ctx* ctx, rgc_ctx* owner);
 /* pcl::Registration::getFitnessScore() for an arbitrary pose */
 RGC_API int rgc_fitness(rgc_ctx* ctx, const float T[16], double* fitness);
 /* the `output` cloud of align(): pcl::transformPointCloud(*input_, output, final_transformation_)

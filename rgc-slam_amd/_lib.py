@@ -111,7 +111,7 @@ class RgcError(RuntimeError):
 SYMBOLS = [
     "rgc_default_params", "rgc_create", "rgc_destroy", "rgc_set_params", "rgc_get_params", "rgc_last_error",
     "rgc_status_string", "rgc_version", "rgc_set_target", "rgc_set_source", "rgc_set_target_device",
-    "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align", "rgc_align_begin", "rgc_align_end",
+    "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align", "rgc_align_begin", "rgc_align_end", "rgc_share_target",
     "rgc_fitness", "rgc_get_aligned", "rgc_get_aligned_device", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_imu_filter_init", "rgc_imu_filter_push", "rgc_ground_gate_init", "rgc_ground_gate_remember", "rgc_ground_gate_step", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
@@ -152,6 +152,7 @@ def load():
     L.rgc_align.argtypes = [vp, fp, fp, dp, dp, ip, ip, ip]
     L.rgc_align_begin.argtypes = [vp, fp, C.c_int]
     L.rgc_align_end.argtypes = [vp, fp, dp, dp, ip, ip, ip]
+    L.rgc_share_target.argtypes = [vp, vp]
     L.rgc_fitness.argtypes = [vp, fp, dp]
     L.rgc_get_aligned.argtypes = [vp, fp, fp, C.c_int]
     L.rgc_get_aligned_device.argtypes = [vp, fp, vp, C.c_int]

@@ -28,6 +28,7 @@ constexpr int kProfKinds = RGC_K_COUNT;
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool borrowed = false;  // p belongs to another context (rgc_share_target): never freed, never grown here
 };
 
 struct Cloud {
@@ -113,6 +114,9 @@ struct rgc_ctx {
   double map_origin[3] = {0, 0, 0};
   bool map_dirty = false;     // keyframes changed since the last commit
   bool map_bound = false;     // the context's target IS the committed map (rgc_set_target* unbinds it)
+  unsigned long long tgt_generation = 0;   // bumped whenever this context prepares a target (what borrowers check)
+  const rgc_ctx* tgt_owner = nullptr;      // rgc_share_target: whose target this context aliases, and at which generation
+  unsigned long long tgt_owner_gen = 0;
   float map_leaf = 0.f;
   int map_ntarget = 0;
   unsigned long long map_rev = 0;
@@ -146,6 +150,7 @@ int fail(rgc_ctx* c, int code, const char* fmt, ...) {
   } while (0)
 
 int ensure(rgc_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.borrowed) { b.p = nullptr; b.cap = 0; b.borrowed = false; }  // an alias is dropped, never resized: this context gets its own buffer
   if (bytes <= b.cap && b.p) return RGC_OK;
   if (b.p) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -166,9 +171,10 @@ int ensure(rgc_ctx* c, DevBuf& b, size_t bytes) {
 }
 
 void release(DevBuf& b) {
-  if (b.p) (void)hipFree(b.p);
+  if (b.p && !b.borrowed) (void)hipFree(b.p);
   b.p = nullptr;
   b.cap = 0;
+  b.borrowed = false;
 }
 
 void release_cloud(Cloud& cl) {
@@ -232,6 +238,10 @@ int check_params(rgc_ctx* c, const rgc_params* p) {
 // clouds re-use the previous (widened) grid speculatively and need none (see `spec` below).
 int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false) {
   const int n = cl.n;
+  if (is_target && &cl == &c->tgt) {
+    c->tgt_generation++;       // borrowers of the previous target must share again
+    c->tgt_owner = nullptr;    // (a borrowed target's aliases are dropped buffer by buffer in ensure())
+  }
   const int k = c->prm.k_correspondences;
   hipStream_t s = is_target ? c->stream : c->stream2;
   int* dsm = c->d_small + (is_target ? 0 : 16);
@@ -969,6 +979,48 @@ int rgc_set_source(rgc_ctx* c, const float* xyz, int n, int stride_bytes) { retu
 int rgc_set_target_device(rgc_ctx* c, const float* xyz, int n, int stride_bytes) { return c ? set_cloud(c, c->tgt, true, xyz, n, stride_bytes, true) : RGC_ERR_INVALID; }
 int rgc_set_source_device(rgc_ctx* c, const float* xyz, int n, int stride_bytes) { return c ? set_cloud(c, c->src, false, xyz, n, stride_bytes, true) : RGC_ERR_INVALID; }
 
+static int fetch_nvox(rgc_ctx* c);
+
+// A second context registers scans to the SAME prepared target (a resident map) without preparing or copying it: its target
+// becomes a non-owning alias of the owner's buffers.  What it is for: two contexts taking turns on a sequence whose map does not
+// change from frame to frame -- the next scan is prepared on one while the current one is solved on the other (PipelinedVGICP).
+int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
+  if (!c || !owner || c == owner) return RGC_ERR_INVALID;
+  if (c->device != owner->device) return fail(c, RGC_ERR_INVALID, "rgc_share_target: the contexts are on different devices");
+  if (c->lm_host || owner->lm_host) return fail(c, RGC_ERR_INVALID, "rgc_share_target is not available with RGC_LM_IMPL=host");
+  if (!owner->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "rgc_share_target: the owner has no target");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = validate_clouds(owner);  // a speculative grid the owner's target did not fit is resolved now (one synchronisation)
+  if (rc) return fail(c, rc, "rgc_share_target: %s", owner->err);
+  if (!owner->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "rgc_share_target: the owner has no target");
+  if ((rc = fetch_nvox(owner))) return fail(c, rc, "rgc_share_target: %s", owner->err);
+  HIPCHK(c, hipStreamSynchronize(owner->stream2));
+  HIPCHK(c, hipStreamSynchronize(owner->stream));   // the target is complete in memory
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->stream));       // nothing of this context still reads its old target
+  Cloud& d = c->tgt;
+  const Cloud& o = owner->tgt;
+  release_cloud(d);
+  DevBuf* db[] = {&d.in_copy, &d.cell_of, &d.slot_of, &d.cnt, &d.start, &d.block_sums, &d.order_tmp, &d.P, &d.nx, &d.ny, &d.nz, &d.segs,
+                  &d.cell_voxel, &d.vox, &d.vox_cell};
+  const DevBuf* ob[] = {&o.in_copy, &o.cell_of, &o.slot_of, &o.cnt, &o.start, &o.block_sums, &o.order_tmp, &o.P, &o.nx, &o.ny, &o.nz, &o.segs,
+                        &o.cell_voxel, &o.vox, &o.vox_cell};
+  for (size_t k = 0; k < sizeof(db) / sizeof(db[0]); k++) { db[k]->p = ob[k]->p; db[k]->cap = ob[k]->cap; db[k]->borrowed = ob[k]->p != nullptr; }
+  d.in = o.in; d.stride_f = o.stride_f; d.n = o.n; d.grid = o.grid; d.nvox = o.nvox; d.deferred_seen = o.deferred_seen;
+  d.spec_ok = false; d.spec_used = false; d.cnt_clean = 0; d.cnt_seen = nullptr;
+  d.ready = true;
+  const int small[2] = {0, o.nvox};  // this context's copy of the target's guard (clear) and voxel count, which the solve reads
+  HIPCHK(c, hipMemcpy(c->d_small + 6, small, sizeof(small), hipMemcpyHostToDevice));
+  c->tgt_owner = owner;
+  c->tgt_owner_gen = owner->tgt_generation;
+  c->map_bound = false;
+  c->corr_valid = false;
+  c->deferred_known = false;
+  c->main_has_target_prep = false;
+  c->stats.n_target = o.n; c->stats.target_cells = o.grid.ncell; c->stats.n_voxels = o.nvox;
+  return RGC_OK;
+}
+
 int rgc_linearize(rgc_ctx* c, const double T[16], double H[36], double b[6], double* cost) {
   if (!c || !T) return RGC_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
@@ -1022,6 +1074,8 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   c->pend.active = false;
   // the guards of speculative grids come home with the LM state: no synchronisation here
   if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
+  if (c->tgt_owner && c->tgt_owner->tgt_generation != c->tgt_owner_gen)
+    return fail(c, RGC_ERR_INVALID, "the shared target was rebuilt by its owner: rgc_share_target again");
   // The solve is a chain of short launches: it runs on the HIGH-PRIORITY stream -- the one the scan was prepared on, so it is already
   // behind that -- ordered after the map's preparation on the main stream by one event.  With a second context preparing the next
   // frame's map meanwhile (15 k waves that fill every CU), the dispatcher places the solve's ~100 workgroups as soon as slots free up

@@ -152,6 +152,12 @@ class FastVGICP:
         self._chk(self._L.rgc_get_aligned(self._h, fin.ctypes.data_as(fp), out.ctypes.data_as(fp), 12))
         return out
 
+    def shareTargetFrom(self, owner: "FastVGICP"):
+        """Register to the target `owner` has prepared (setInputTarget*, or a committed RollingLocalMap) without preparing or copying it
+        (rgc_share_target).  Share again whenever the owner prepares a new target."""
+        self._chk(self._L.rgc_share_target(self._h, owner._h))
+        self._n_tgt = getattr(owner, "_n_tgt", None)
+
     def align_begin(self, guess=None, want_fitness=False):
         """First half of align(): enqueue the solve and return (rgc_align_begin).  align_end() collects the result; in between the
         caller may prepare the next frame on ANOTHER FastVGICP (PipelinedVGICP below does)."""
@@ -346,18 +352,28 @@ class PipelinedVGICP:
     i + 1 .. i + depth - 1 are being prepared on the others; every frame runs the same kernels on the same inputs as FastVGICP.align()
     one frame at a time: results are identical, the frames just overlap on the GPU (align_begin / align_end, include/rgc_hip.h)."""
 
-    def __init__(self, device: int = 0, make=odometer_vgicp, depth: int = 3):
+    def __init__(self, device: int = 0, make=odometer_vgicp, depth: int = 2, contexts=None):
+        """contexts: FastVGICP objects to use as the first contexts (e.g. the one a RollingLocalMap lives on); they are not closed here"""
         if depth < 2:
             raise ValueError("depth >= 2")
-        self.v = [make(device) for _ in range(depth)]
+        given = list(contexts or [])
+        self._owned = [make(device) for _ in range(depth - len(given))]
+        self.v = given + self._owned
 
     def close(self):
-        for v in self.v:
+        for v in self._owned:
             v.close()
 
     def synchronize(self):
         for v in self.v:
             v.synchronize()
+
+    def share_target(self):
+        """The other contexts register to the target context 0 holds (setInputTarget* or a committed RollingLocalMap on self.v[0]) without
+        preparing it again: for sequences whose map does not change every frame; then set_clouds of run() sets only the source.
+        Call again after context 0 prepared a new target."""
+        for w in self.v[1:]:
+            w.shareTargetFrom(self.v[0])
 
     def run(self, n_frames, set_clouds, guess0, want_fitness=False, next_guess=None, on_result=None):
         """set_clouds(i, v): set target and source of frame i on the FastVGICP `v` (device-resident or host clouds).

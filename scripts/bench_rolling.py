@@ -34,12 +34,32 @@ def to_dev(xyz):
 d_scans = [to_dev(s) for s in scans]
 d_tgt = to_dev(tgt)
 # the map as N_KF keyframes already in the world frame (identity poses): chunks of the map cloud
-m.reset(None)
 tgt4 = np.zeros((len(tgt), 4), np.float32); tgt4[:, :3] = tgt
-for ch in np.array_split(tgt4, N_KF):
-    m.insert(ch, [0, 0, 0, 1.0], [0, 0, 0])
-n_target = m.commit(0.3)
-v.synchronize()
+chunks = np.array_split(tgt4, N_KF)
+kf_changes = 0
+
+
+def reset_map():
+    global kf_changes
+    m.reset(None)
+    for ch in chunks:
+        m.insert(ch, [0, 0, 0, 1.0], [0, 0, 0])
+    kf_changes = 0
+    n = m.commit(0.3)
+    v.synchronize()
+    return n
+
+
+def change_keyframe():
+    """a keyframe arrives and the oldest one leaves; here the arriving one is a copy of the leaving one, so that the map's content (and with
+    it the registration problem) stays the same while all of the device-side work of a keyframe change is done"""
+    global kf_changes
+    m.insert(chunks[kf_changes % N_KF], [0, 0, 0, 1.0], [0, 0, 0])
+    m.evict(N_KF)
+    kf_changes += 1
+
+
+n_target = reset_map()
 
 
 def run(mode):
@@ -54,9 +74,7 @@ def run(mode):
         if mode == "rebuild":
             v.setInputTargetDevice(d_tgt, len(tgt), 16)
         elif mode == "keyframes" and i % KF_EVERY == 0:
-            # a keyframe changed: (here the newest chunk is evicted and re-inserted so that the map content stays comparable)
-            ch = np.array_split(tgt4, N_KF)[i % N_KF]
-            m.insert(ch, [0, 0, 0, 1.0], [0, 0, 0]); m.evict(N_KF)
+            change_keyframe()
             m.commit(0.3)
         else:
             m.commit(0.3)          # resident: no-op
@@ -70,22 +88,70 @@ def run(mode):
     return (time.perf_counter() - t0) / FRAMES, out
 
 
+def run_resident_pipelined(pv):
+    """the resident frames with two contexts taking turns: the second registers to the first one's committed map (rgc_share_target), the
+    next scan is prepared on one while the current one is solved on the other"""
+    m.commit(0.3)
+    pv.share_target()
+    def setc(i, w):
+        w.setInputSourceDevice(d_scans[i], N_S, 16)
+    g0 = poses[0].astype(np.float32)
+    pv.run(3, setc, g0, want_fitness=True)
+    pv.synchronize()
+    t0 = time.perf_counter()
+    out = pv.run(FRAMES, lambda j, w: setc(3 + j, w), out_seed[0], want_fitness=True)
+    pv.synchronize()
+    return (time.perf_counter() - t0) / FRAMES, out
+
+
+def run_keyframes_pipelined(pv):
+    """a keyframe change every KF_EVERY frames with two contexts: the pipeline drains, the map is committed on the owner and shared again,
+    the next KF_EVERY frames overlap"""
+    def setc(i, w):
+        w.setInputSourceDevice(d_scans[i], N_S, 16)
+    g = poses[0].astype(np.float32)
+    out, t0 = [], None
+    for i0 in range(0, 3 + FRAMES, KF_EVERY):
+        if i0 == 3:
+            pv.synchronize(); t0 = time.perf_counter()
+        change_keyframe()
+        m.commit(0.3)
+        pv.share_target()
+        cnt = min(KF_EVERY, 3 + FRAMES - i0)
+        Ts = pv.run(cnt, lambda j, w: setc(i0 + j, w), g, want_fitness=True)
+        g = Ts[-1]
+        out += Ts
+    pv.synchronize()
+    return (time.perf_counter() - t0) / FRAMES, out
+
+
 res = {}
 run("rebuild")
 t_rebuild, T_a = run("rebuild")
 m.commit(0.3)
 t_res, T_b = run("resident")
+out_seed = [T_b[2]]                      # the guess the timed frames of run() started from
+pv = registration.PipelinedVGICP(0, depth=2, contexts=[v])
+t_res_p, T_bp = run_resident_pipelined(pv)
+same_p = bool(all(np.array_equal(a, b) for a, b in zip(T_b[3:], T_bp)))
+reset_map()
 t_kf, T_c = run("keyframes")
+reset_map()
+t_kf_p, T_cp = run_keyframes_pipelined(pv)
+same_kf = bool(all(np.array_equal(a, b) for a, b in zip(T_c, T_cp)))
 # commit alone
 t0 = time.perf_counter(); reps = 10
+reset_map()
 for r in range(reps):
-    m.insert(np.array_split(tgt4, N_KF)[r], [0, 0, 0, 1.0], [0, 0, 0]); m.evict(N_KF)
+    change_keyframe()
     v.synchronize(); t1 = time.perf_counter()
     m.commit(0.3); v.synchronize()
     res.setdefault("commit_ms", []).append(1e3 * (time.perf_counter() - t1))
 res_A = {"workload": f"c-main: {N_S}-pt scans vs a {len(tgt)}-pt map held as {N_KF} keyframes on the device ({n_target} target points after the 0.3 m filter)",
          "rebuild_every_frame_scans_per_s": round(1 / t_rebuild, 1), "resident_scans_per_s": round(1 / t_res, 1),
-         f"keyframe_every_{KF_EVERY}_frames_scans_per_s": round(1 / t_kf, 1), "commit_ms_median": round(float(np.median(res["commit_ms"])), 3),
+         "resident_two_contexts_scans_per_s": round(1 / t_res_p, 1), "resident_two_contexts_same_poses": same_p,
+         f"keyframe_every_{KF_EVERY}_frames_scans_per_s": round(1 / t_kf, 1),
+         f"keyframe_every_{KF_EVERY}_frames_two_contexts_scans_per_s": round(1 / t_kf_p, 1), "keyframes_two_contexts_same_poses": same_kf, "commit_ms_median": round(float(np.median(res["commit_ms"])), 3),
          "ms_per_frame": {"rebuild": round(1e3 * t_rebuild, 3), "resident": round(1e3 * t_res, 3), "keyframes": round(1e3 * t_kf, 3)},
          "max_translation_diff_resident_vs_rebuild_m": float(max(np.abs(a[:3, 3] - b[:3, 3]).max() for a, b in zip(T_a, T_b)))}
 

@@ -411,3 +411,55 @@ def test_align_in_two_halves_and_pipelined_sequence(reg_mod, orc):
         To = o.align(g)
         assert np.abs(T[:3, 3] - To[:3, 3]).max() <= 1e-4 and _rot_angle(T[:3, :3], To[:3, :3]) <= 1e-4
         g = T
+
+
+def test_shared_target(reg_mod, medium):
+    """rgc_share_target: a second context registers to the owner's prepared target (no second preparation): same pose, fitness and target
+    covariances as the owner itself; stale after the owner prepares a new target; a sequence on two contexts sharing one target gives the
+    poses of one context."""
+    import rgc_slam_amd.synth as synth
+    a, b = _odo(reg_mod), _odo(reg_mod)
+    with pytest.raises(reg_mod.RgcError):
+        b.shareTargetFrom(a)                              # the owner has no target yet
+    a.setInputTarget(medium["tgt"])
+    b.shareTargetFrom(a)
+    g = np.eye(4, dtype=np.float32)
+    res = []
+    for v in (a, b):
+        v.setInputSource(medium["src"])
+        v.align(g, want_output=False, want_fitness=True)
+        res.append((v.getFinalTransformation(), v.getFitnessScore(), v.nr_iterations))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert np.array_equal(a.getTargetCovariances(), b.getTargetCovariances())
+    assert b.stats()["n_voxels"] == a.stats()["n_voxels"] > 0
+    # a sequence: two contexts, one target
+    poses = synth.make_trajectory(6, seed=synth.SEED + 3)
+    scans = [synth.make_scan_n(medium["world"], poses[i + 1], 15000, seed=synth.SEED + 500 + i)["xyz"] for i in range(5)]
+    seq, gg = [], poses[0].astype(np.float32)
+    for s in scans:
+        a.setInputSource(s)
+        a.align(gg, want_output=False)
+        gg = a.getFinalTransformation()
+        seq.append(gg)
+    pv = reg_mod.PipelinedVGICP(0, depth=2, contexts=[a, b])
+    pv.share_target()
+    out = pv.run(len(scans), lambda i, w: w.setInputSource(scans[i]), poses[0].astype(np.float32))
+    assert all(np.array_equal(x, y) for x, y in zip(out, seq))
+    # the owner prepares a new target: the borrower must notice
+    a.setInputTarget(medium["tgt"][: len(medium["tgt"]) // 2])
+    b.setInputSource(medium["src"])
+    with pytest.raises(reg_mod.RgcError):
+        b.align(g, want_output=False)
+    b.shareTargetFrom(a)
+    b.align(g, want_output=False)
+    a.setInputSource(medium["src"])
+    a.align(g, want_output=False)
+    assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())
+    # the borrower gets a target of its own again: the alias is dropped, the owner's buffers stay intact
+    b.setInputTarget(medium["tgt"])
+    b.align(g, want_output=False)
+    assert np.array_equal(b.getFinalTransformation(), res[0][0])
+    a.align(g, want_output=False)
+    pv.close()
+    b.close()
+    a.close()
