@@ -463,3 +463,24 @@ def test_shared_target(reg_mod, medium):
     pv.close()
     b.close()
     a.close()
+
+
+def test_fitness_with_points_far_from_the_map(reg_mod, orc, medium):
+    """getFitnessScore when much of the scan has no map nearby (the map covers a corner of the scene, and the pose is off by metres):
+    every point's exact nearest neighbour, however far, equals the oracle's (slow there -- scripts/exp_fitness_far.py -- but exact)."""
+    tgt = medium["tgt"]
+    part = tgt[(tgt[:, 0] > 5.0) & (tgt[:, 1] > 5.0)]
+    assert 2000 < len(part) < len(tgt) // 2
+    v = _odo(reg_mod)
+    v.setInputTarget(part)
+    v.setInputSource(medium["src"])
+    o = orc.Registration(max_iterations=25, translation_eps=1e-6, num_threads=0)
+    o.set_target(part)
+    o.set_source(medium["src"])
+    o.prepare()
+    for T in (np.eye(4, dtype=np.float32), np.array([[1, 0, 0, -40.0], [0, 1, 0, 25.0], [0, 0, 1, 3.0], [0, 0, 0, 1]], np.float32)):
+        f = v.fitnessAt(T)
+        fo = o.fitness(T)
+        assert abs(f - fo) <= 1e-6 * fo, (f, fo)
+        assert f > 1.0                                     # metres away on average: growing search cubes were exercised
+    v.close()
