@@ -17,6 +17,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/rgc_hip.h"
@@ -70,6 +71,19 @@ public:
     iterations_ = it; converged_ = conv != 0; lm_failed_ = fail != 0; fit_valid_ = false;
   }
   void align() { float I[16]; set_identity(I); align(I); }
+  // align() in two halves (rgc_align_begin / rgc_align_end): between them the caller may prepare the next frame's clouds on ANOTHER
+  // FastVGICPHip (rgc::PipelinedVGICP below); want_fitness chains getFitnessScore behind the solve
+  void alignBegin(const float guess[16], bool want_fitness = false) {
+    chk(rgc_align_begin(ctx_, guess, want_fitness ? 1 : 0));
+    pending_fitness_ = want_fitness;
+  }
+  void alignEnd() {
+    int it = 0, conv = 0, fail = 0;
+    chk(rgc_align_end(ctx_, final_, hessian_, pending_fitness_ ? &fitness_ : nullptr, &it, &conv, &fail));
+    iterations_ = it; converged_ = conv != 0; lm_failed_ = fail != 0; fit_valid_ = pending_fitness_;
+  }
+  // register to the target `owner` has prepared, without preparing or copying it (rgc_share_target)
+  void shareTargetFrom(FastVGICPHip& owner) { chk(rgc_share_target(ctx_, owner.ctx_)); n_tgt_ = owner.n_tgt_; fit_valid_ = false; }
   // output: any cloud with .points (resized to the source size, x/y/z written); guess: operator()(r,c)
   template <class Cloud, class Mat4>
   void align(Cloud& output, const Mat4& guess) {
@@ -116,8 +130,50 @@ private:
   float final_[16];
   double hessian_[36] = {0};
   double fitness_ = 0;
-  bool fit_valid_ = false, converged_ = false, lm_failed_ = false;
+  bool fit_valid_ = false, converged_ = false, lm_failed_ = false, pending_fitness_ = false;
   int iterations_ = 0, n_src_ = 0, n_tgt_ = 0;
+};
+
+// A SEQUENCE of registrations on `depth` contexts taking turns (the C++ twin of rgc_slam_amd.registration.PipelinedVGICP): while frame
+// i is being solved on one context the clouds of the next frames are prepared on the others -- only the solve needs the previous
+// frame's pose.  Same kernels, same inputs, same order per frame: the poses are those of align() one frame at a time.
+//   set_clouds(i, reg)    set target and source of frame i on `reg` (or only the source after shareTarget())
+//   next_guess(i, T_i, g) write frame i + 1's guess into g (default: T_i)
+//   on_result(i, reg)     frame i is done; `reg` holds its results until it is given frame i + depth
+class PipelinedVGICP {
+public:
+  explicit PipelinedVGICP(int hip_device = 0, int depth = 2) {
+    if (depth < 2) depth = 2;
+    for (int k = 0; k < depth; k++) regs_.emplace_back(new FastVGICPHip(hip_device));
+  }
+  FastVGICPHip& context(int k) { return *regs_[(size_t)k]; }
+  int depth() const { return (int)regs_.size(); }
+  // the other contexts register to the target context(0) holds (a resident map): call again after context(0) prepared a new one
+  void shareTarget() { for (size_t k = 1; k < regs_.size(); k++) regs_[k]->shareTargetFrom(*regs_[0]); }
+
+  template <class SetClouds, class NextGuess, class OnResult>
+  void run(int n_frames, SetClouds&& set_clouds, const float guess0[16], bool want_fitness, NextGuess&& next_guess, OnResult&& on_result) {
+    const int D = depth();
+    for (int j = 0; j < D - 1 && j < n_frames; j++) set_clouds(j, *regs_[(size_t)(j % D)]);
+    float g[16];
+    std::memcpy(g, guess0, sizeof(g));
+    for (int i = 0; i < n_frames; i++) {
+      FastVGICPHip& cur = *regs_[(size_t)(i % D)];
+      cur.alignBegin(g, want_fitness);
+      const int j = i + D - 1;                    // the context of frame i - 1 is free: the frame D - 1 ahead goes there
+      if (j < n_frames) set_clouds(j, *regs_[(size_t)(j % D)]);
+      cur.alignEnd();
+      on_result(i, cur);
+      next_guess(i, cur.getFinalTransformation(), g);
+    }
+  }
+  template <class SetClouds, class OnResult>
+  void run(int n_frames, SetClouds&& set_clouds, const float guess0[16], bool want_fitness, OnResult&& on_result) {
+    run(n_frames, set_clouds, guess0, want_fitness, [](int, const float* T, float* g) { std::memcpy(g, T, 16 * sizeof(float)); }, on_result);
+  }
+
+private:
+  std::vector<std::unique_ptr<FastVGICPHip>> regs_;
 };
 
 }  // namespace rgc

@@ -20,6 +20,7 @@ if [ "$1" != quick ]; then
   python scripts/exp_long_run.py 3000 2>/dev/null | tail -1 > $O/long_run.json
   python scripts/bench_rolling.py > $O/rolling.json 2> /dev/null
   python scripts/bench_cpp_node.py > $O/cpp_node.json 2> /dev/null
+  python scripts/bench_cpp_pipeline.py 2>/dev/null | tail -1 > $O/cpp_pipeline.json
   python scripts/bench_frontend.py 2>/dev/null | tail -1 > $O/frontend.json
   python scripts/bench_mapreg.py > $O/mapreg.json 2> /dev/null
   python scripts/bench_icp.py 2>/dev/null | tail -1 > $O/icp.json

@@ -484,3 +484,44 @@ def test_fitness_with_points_far_from_the_map(reg_mod, orc, medium):
         assert abs(f - fo) <= 1e-6 * fo, (f, fo)
         assert f > 1.0                                     # metres away on average: growing search cubes were exercised
     v.close()
+
+
+def _build_cpp(root, tmp_path, name):
+    import os, subprocess
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-std=c++14", "-O2", os.path.join(root, "tests", "cpp", name + ".cpp"), "-o", exe,
+                           "-L", os.path.join(root, "rgc-slam_amd"), "-lrgc_hip", "-Wl,-rpath," + os.path.join(root, "rgc-slam_amd")])
+    return exe
+
+
+def test_cpp_pipelined_sequence(reg_mod, tmp_path):
+    """rgc::PipelinedVGICP (C++, two contexts taking turns) gives the poses and fitness scores of one frame at a time, and those of the
+    Python mirror."""
+    import os, subprocess
+    import rgc_slam_amd.synth as synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = _build_cpp(root, tmp_path, "test_pipelined")
+    world, tgt = synth.make_world_and_map(80000, seed=synth.SEED + 11)
+    poses = synth.make_trajectory(6, seed=synth.SEED + 11)
+    scans = [synth.make_scan_n(world, poses[i + 1], 12000, seed=synth.SEED + 700 + i)["xyz"] for i in range(5)]
+    def dump(a, path):
+        with open(path, "wb") as f:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            f.write(np.int32(len(a)).tobytes()); f.write(a.tobytes())
+    dump(tgt, tmp_path / "tgt.bin")
+    for i, s in enumerate(scans):
+        dump(s, tmp_path / f"s{i}.bin")
+    out = subprocess.run([exe, str(tmp_path / "tgt.bin"), str(len(scans))] + [str(tmp_path / f"s{i}.bin") for i in range(len(scans))],
+                         capture_output=True, text=True, timeout=600).stdout
+    lines = dict(l.split(" ", 1) for l in out.strip().splitlines())
+    assert lines.get("same") == "1", out
+    v = _odo(reg_mod)
+    g = np.eye(4, dtype=np.float32)
+    for i, s in enumerate(scans):
+        v.setInputTarget(tgt)
+        v.setInputSource(s)
+        v.align(g, want_output=False)
+        g = v.getFinalTransformation()
+        T = np.array([float(x) for x in lines[f"T{i}"].split()], np.float32).reshape(4, 4)
+        assert np.array_equal(T, g), (i, T, g)
+    v.close()
