@@ -56,3 +56,14 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "rgc_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_null_arguments_are_rejected_without_a_gpu(lib):
+    """the entry points that take contexts check them before touching HIP: a null context is RGC_ERR_INVALID (-1), not a crash"""
+    import ctypes as C
+    L = lib.load()
+    g = (C.c_float * 16)(*([0.0] * 16))
+    assert L.rgc_align_begin(None, g, 0) == -1
+    assert L.rgc_align_end(None, None, None, None, None, None, None) == -1
+    assert L.rgc_share_target(None, None) == -1
+    assert L.rgc_align(None, g, None, None, None, None, None, None) == -1
