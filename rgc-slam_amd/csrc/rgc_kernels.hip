@@ -559,33 +559,10 @@ __device__ __forceinline__ bool min_eigenvector_direct(const double S[6], double
 }
 
 // ------------------------------------------------------------------------------------------------
-// C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298).
-// One lane per query point, queries in cell order so a wave's lanes walk (nearly) the same cells and their
-// 16-byte candidate loads coalesce to a handful of cache lines.
-//  pass 1: the K smallest squared distances are kept in REGISTERS as a sorted chain (v_min/v_max insertion,
-//          no indexing, no LDS); a wave-uniform __any() skips the chain when no lane can improve.  Shells of
-//          cells are added until the K-th distance is provably inside the scanned cube (exact search).
-//  pass 2: the same cells are re-scanned; candidates closer than the K-th distance are appended to a per-lane
-//          LDS column ([slot][lane], bank = lane), ties on the K-th distance are resolved by original index
-//          like the CPU path, then mean / covariance / smallest eigenvector in fp64.
+// C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298): helpers shared by the bulk kernels (knn_point_sp,
+// knn_point_split: one or four lanes per query, one pass, below), the cooperative kernel (one wave per deferred query) and the
+// nearest-neighbour search of the fitness score / ICP.
 // ------------------------------------------------------------------------------------------------
-template <typename F>
-__device__ __forceinline__ void for_each_shell_cell(const Grid& g, int c0, int c1, int c2, int r, F&& f) {
-  const int z0 = max(c2 - r, 0), z1 = min(c2 + r, g.dim[2] - 1);
-  const int y0 = max(c1 - r, 0), y1 = min(c1 + r, g.dim[1] - 1);
-  for (int z = z0; z <= z1; z++) {
-    const int az = abs(z - c2);
-    for (int y = y0; y <= y1; y++) {
-      const bool face = (az == r) || (abs(y - c1) == r);
-      const int xstep = face ? 1 : max(2 * r, 1);
-      for (int x = c0 - r; x <= c0 + r; x += xstep) {
-        if (x < 0 || x >= g.dim[0]) continue;
-        f(cell_index(g, x, y, z));
-      }
-    }
-  }
-}
-
 // distance from the query to the faces of the cube of cells [c-r, c+r] that are not grid borders; 1e300 if none
 __device__ __forceinline__ double cube_bound(const Grid& g, const int c[3], const double q[3], int r) {
   double bound = 1.0e300;
@@ -699,10 +676,10 @@ struct Deferred {
 
 // ------------------------------------------------------------------------------------------------
 // C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298), the bulk kernel: one lane per query, queries
-// in cell order (neighbouring lanes share cells, hence cache lines).  A query's 3x3x3 block of cells is 11 PIECES -- contiguous
-// ranges of the sorted array: eight grid rows of three cells and the own row cut into the own cell and its two neighbours -- each
-// with a lower bound of the distance to anything in it.  Every candidate is looked at ONCE and the selection costs a few
-// instructions per candidate:
+// in cell order (neighbouring lanes share cells, hence cache lines).  A query's 3x3x3 block of cells is a handful of PIECES --
+// contiguous ranges of the sorted array: the nine grid rows of three cells (map), or eight rows and the own row cut into the own
+// cell and its two neighbours (scan: 11 pieces) -- each with a lower bound of the distance to anything in it.  Every candidate is
+// looked at ONCE and the selection costs a few instructions per candidate:
 //  * key = fp32 bit pattern of the squared distance with its low KB bits replaced by the candidate's ORDINAL in the lane's
 //    candidate stream.  Keys order like distances (up to 2^-13 relative at KB = 10), and the winning keys name the neighbours: no
 //    second pass over the candidates to collect them.
@@ -726,6 +703,10 @@ struct Deferred {
 // they are legitimate candidates and need no masking.
 // kTarget separates the two instantiations by NAME (map vs scan) for the profiles and picks the ordinal width.
 // ------------------------------------------------------------------------------------------------
+#ifndef RGC_ROW_SKIP
+#define RGC_ROW_SKIP 1
+#endif
+constexpr bool kRowSkip = RGC_ROW_SKIP != 0;  // the map's search (whole rows, no piece machinery) skips rows by their distance bound
 constexpr int kPieceQuads = 1023;  // a piece's length in quads shares its table entry with the piece's distance bound (fp32, low 10 bits cut)
 constexpr int kSpBuf = 12;   // keys waiting to enter the chain, per lane
 // Block geometry and LDS layout of one instantiation.  R = block radius in cells, kClip as described at knn_point_sp.
@@ -811,7 +792,7 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
   const int xl = max(c[0] - R, 0), xh = min(c[0] + R, g.dim[0] - 1);
   // distance from the query to the walls of its cell; a row / piece at offset d cells is at least (|d| - 1) cells + that away
   double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
-  if (kClip) {
+  if (kClip || kRowSkip) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const double wall = ((double)(c[a] + g.minc[a]) + 0.5) * g.res;
@@ -841,7 +822,7 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
       const int p = (!kClip || r < OWN) ? r : r + 2;
       lo[p] = in ? a : 0;
       hi[p] = in ? b : 0;
-      min2[p] = kClip ? bound2(axis_gap(1, dy), axis_gap(2, dz)) : 0.f;
+      min2[p] = (kClip || kRowSkip) ? bound2(axis_gap(1, dy), axis_gap(2, dz)) : 0.f;
     }
   }
   // A piece's last quad may read up to 3 points past the piece.  Where the next piece of this block (in memory order) starts closer
@@ -862,7 +843,7 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
     for (int p = 0; p < NP; p++) {
       if (hi[p] > lo[p]) {
         const int a = carry >= 0 ? carry : lo[p];
-        if (kClip && carry >= 0 && carry < lo[p]) min2[p] = fminf(min2[p], carry_min2);
+        if ((kClip || kRowSkip) && carry >= 0 && carry < lo[p]) min2[p] = fminf(min2[p], carry_min2);
         const int len = hi[p] - a;
         const bool tight = next_lo[p] - hi[p] < 3;
         const int keep = tight ? (len & ~3) : len;
@@ -889,20 +870,23 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
       heavy_piece |= quads > kPieceQuads;
       if (!kClip) heavy_piece |= quads > (kRowRel + 1) / 4;  // the row's candidates must fit the ordinal's row-relative part
       tlo[nr * T] = lo[p];
-      tmix[nr * T] = kClip ? ((__float_as_int(min2[p]) & ~kPieceQuads) | quads) : quads;
+      // (whole rows: at most 32 quads, six bits; the row's distance bound, rounded down, in the rest)
+      tmix[nr * T] = kClip ? ((__float_as_int(min2[p]) & ~kPieceQuads) | quads) : (kRowSkip ? ((__float_as_int(min2[p]) & ~63) | quads) : quads);
       nr++;
     }
   }
   return nr;
 }
 
-// KB: low key bits that hold the candidate's ordinal (ordinals < 2^KB).  kClip: pieces carry distance bounds and are skipped once the
-// scan's bound excludes them, the own row is cut in three, ordinals are handed out as pieces are entered (a raw scan's crowded
-// cells); without it the block is nine whole rows numbered up front (a leaf-filtered map: nothing to skip, less bookkeeping).
-template <int KC, int KB, bool kClip, int R, int T>  // T: threads per workgroup = stride of the per-lane LDS columns
+// The MAP's search (a leaf-filtered cloud: nothing crowded, the block is nine whole rows).  KB: low key bits that hold the candidate's
+// ordinal {table row (high bits) | position in the row (low 7 bits)}: the winning keys give their neighbours' positions with ONE table
+// read, and a skipped row renumbers nothing.  (The raw scan's search -- pieces with lazily numbered ordinals, four lanes per query -- is
+// knn_point_split below.)
+template <int KC, int KB, int R, int T>  // T: threads per workgroup = stride of the per-lane LDS columns
 __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
                                              int i, int* lds, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
                                              double* __restrict__ nz) {
+  constexpr bool kClip = false;
   using Shape = SpShape<R, kClip>;
   constexpr int L = KC + 2;
   constexpr int kKeyOrd = (1 << KB) - 1;
@@ -910,7 +894,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   // without clipping the ordinal is {table row (high bits) | position in the row (low 7 bits)}: the winning keys give their
   // neighbours' positions with ONE table read; with clipping ordinals are handed out as pieces are entered and searched for
   constexpr int kRowRel = 127;
-  static_assert(kClip || (SpShape<R, kClip>::NP << 7) <= (1 << KB), "ordinal bits: rows x 128");
+  static_assert((SpShape<R, kClip>::NP << 7) <= (1 << KB), "ordinal bits: rows x 128");
   lds_int* const buf = (lds_int*)lds;                   // [kSpBuf][T]
   lds_int* const tmix = buf + kSpBuf * T;               // [CUM][T]: before a piece is reached {min distance^2 (fp32, low bits cut) | quads}, after: its first ordinal
   lds_int* const tlo = buf + (kSpBuf + Shape::CUM) * T; // [NP][T]
@@ -925,7 +909,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   };
   bool heavy_piece = false;
   const int nr = sp_piece_table<kClip, R, T>(start, g, c, q, tmix, tlo, heavy_piece);
-  if (heavy_piece) {  // (kClip: a piece of more than 4092 points does not fit the table entry)
+  if (heavy_piece) {  // a row of more than 128 candidates does not fit the ordinal's row-relative part
     defer(i, INFINITY);
     return;
   }
@@ -938,7 +922,6 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   top.init();
   int tau = INT_MAX, ri = 0, ordn = 0;
   unsigned off = 0, end = 0;
-  bool overflow = false;  // more candidates than the keys' ordinals can number: the query goes to the cooperative kernel
   lds_int* bp = buf;  // one past the newest buffered key of this lane's column (stride T)
   lds_int* const bp_full = buf + (kSpBuf - 4) * T;
   auto pop = [&]() {
@@ -966,35 +949,20 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   // Software pipeline: the loads of quad q + 1 are issued before quad q is processed, so a wave waits for memory once, not once
   // per quad; two register sets take turns (copying one into the other would wait for the loads just issued).
   // (off, end, ri, ordn) always describe the NEXT quad to fetch.
-  struct Quad { float4 p0, p1, p2, p3; int ord; bool on; };
+  struct Quad { float4 p0, p1, p2, p3; int ord; bool on, live; };  // live: the lane's stream is not exhausted (a skipped row gives on = false)
   auto fetch = [&](Quad& q) {
-    if (kClip) {
-      while (off >= end && ri < nr) {
-        // next piece -- unless nothing in it can be among the k + 2 nearest any more: its lower distance bound is not below (an
-        // upper bound of) the chain's tail: a crowded cell near the sensor is done after its own piece, its 26 neighbours are never
-        // touched.  The piece's table entry is replaced by its first ordinal (skipped pieces: zero length), which index_of() searches.
-        const int mix = tmix[ri * T];
-        tmix[ri * T] = ordn;
-        const int quads = mix & kPieceQuads;
-        const bool reach = !(__int_as_float(mix & ~kPieceQuads) >= __int_as_float(tau | kKeyOrd));  // tau == INT_MAX (chain not full): NaN, no skip
-        if (reach) {
-          if (ordn + 4 * quads > kKeyOrd) {
-            overflow = true;
-            ri = nr;
-            break;
-          }
-          off = (unsigned)tlo[ri * T] << 4;
-          end = off + ((unsigned)quads << 6);
-        }
-        ri++;
-      }
-    } else if (off >= end && ri < nr) {
+    if (off >= end && ri < nr) {
+      // next row -- as an EMPTY one if nothing in it can be among the k + 2 nearest any more (its distance bound is not below the
+      // chain's tail): the lane idles for this quad and moves on with the next; ordinals are {row, position}, so skipping renumbers nothing
+      const int mix = tmix[ri * T];
+      const int quads = kRowSkip ? ((__int_as_float(mix & ~63) >= __int_as_float(tau | kKeyOrd)) ? 0 : (mix & 63)) : mix;
       off = (unsigned)tlo[ri * T] << 4;
-      end = off + ((unsigned)tmix[ri * T] << 6);
+      end = off + ((unsigned)quads << 6);
       ordn = ri << 7;
       ri++;
     }
     q.on = off < end;
+    q.live = q.on || ri < nr;
     q.ord = ordn;
     // unconditional loads (a lane that has run out of rows reads the sentinels): a load under a branch is waited for at the
     // end of its block, which would put the memory latency back into every iteration
@@ -1043,18 +1011,14 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   }
   fetch(qa);
   for (;;) {
-    if (!__any(qa.on)) break;
+    if (!__any(qa.live)) break;
     fetch(qb);
     process(qa);
-    if (!__any(qb.on)) break;
+    if (!__any(qb.live)) break;
     fetch(qa);
     process(qb);
   }
   if (__any(bp != buf)) drain();
-  if (overflow) {
-    defer(i, INFINITY);
-    return;
-  }
 #if defined(RGC_ABLATE) && (RGC_ABLATE == 1 || RGC_ABLATE == 2)  // everything up to the end of the scan
   nx[i] = (double)top.a[0]; ny[i] = (double)top.a[L - 1]; nz[i] = (double)top.a[L / 2];
   return;
@@ -1073,12 +1037,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   }
   auto index_of = [&](int key) {  // ordinal -> position in the sorted array
     const int o = key & kKeyOrd;
-    if (!kClip) return tlo[(o >> 7) * T] + (o & kRowRel);
-    int r = 0;  // the last piece whose first ordinal is <= the ordinal
-#pragma unroll
-    for (int s = Shape::CUM / 2; s > 0; s >>= 1)
-      if (tmix[(r + s) * T] <= o) r += s;
-    return tlo[r * T] + (o - tmix[r * T]);
+    return tlo[(o >> 7) * T] + (o & kRowRel);
   };
   bool decided = true, swap = false;
   int kth_key = a_km1;
@@ -1479,7 +1438,7 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
     return;
   }
   const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
-  if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::kClip, Cfg::R, Cfg::T>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+  if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
 }
 
 // ------------------------------------------------------------------------------------------------
