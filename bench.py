@@ -181,16 +181,18 @@ def run_extra_configs(registration, synth, oracle, keys):
                 L = 2.0 * world.half_extent + 4.0
                 tgt = np.concatenate([tile, tile + np.float32([L, 0, 0]), tile + np.float32([0, L, 0]), tile + np.float32([L, L, 0])]).astype(np.float32)
                 poses = synth.make_trajectory(6, seed=synth.SEED + 9)
-                rng = np.random.default_rng(11)
+                from rgc_slam_amd import odometry
+                # the guesses the odometer forms with USE_IMU = 1 (RGC_odometer.cpp:929-931, 993-996): the gyro's pre-integrated rotation over
+                # the sweep (synthetic 200 Hz IMU stream through rgc_imu_preintegrate) and the previous sweep's translation
+                imu_prior = odometry.imu_rotation_priors(poses)
                 scans, prior = [], []
                 for i in range(4):
                     a = synth.make_scan_n(world, poses[i + 1], 125000, elev_deg=e64, seed=synth.SEED + 300 + i)["xyz"]
                     b = synth.make_scan_n(world, poses[i + 1], 125000, elev_deg=e64 + 0.5 * float(np.abs(np.diff(np.sort(e64))).min()),
                                           seed=synth.SEED + 400 + i)["xyz"]
                     scans.append(np.concatenate([a, b]).astype(np.float32))
-                    ang = np.deg2rad(0.5) * rng.standard_normal(3)
-                    prior.append((poses[i + 1] @ synth.se3(synth.rot_zyx(*ang), [0, 0, 0])).astype(np.float32))
-                return time_config(registration, oracle, "c5: 2 x 64-beam 250 k-pt scans vs 20 M-pt map, rotation prior", tgt, scans, None, prior=prior)
+                    prior.append(imu_prior[i + 1])
+                return time_config(registration, oracle, "c5: 2 x 64-beam 250 k-pt scans vs 20 M-pt map, IMU-preintegrated prior", tgt, scans, None, prior=prior)
             guarded("c5", c5)
     return res
 

@@ -183,14 +183,7 @@ class HipBackend:
         return _Filter()
 
     def imu_preintegrate(self, stamps, gyr, acc, prev_time, cur_time):
-        st, g, a = (np.ascontiguousarray(x, np.float64) for x in (stamps, gyr, acc))
-        dq = np.empty(4)
-        dp = C.POINTER(C.c_double)
-        rc = self._L.rgc_imu_preintegrate(st.ctypes.data_as(dp), g.ctypes.data_as(dp), a.ctypes.data_as(dp), len(st), float(prev_time), float(cur_time),
-                                          dq.ctypes.data_as(dp), None, None, None)
-        if rc:
-            raise RgcError(rc, "rgc_imu_preintegrate")
-        return dq
+        return imu_preintegrate(stamps, gyr, acc, prev_time, cur_time)
 
     def ground_gate(self):
         L, dp = self._L, C.POINTER(C.c_double)
@@ -395,6 +388,43 @@ def _R2q(R):
     w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
     q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
     return q / np.linalg.norm(q)
+
+
+def imu_preintegrate(stamps, gyr, acc, prev_time, cur_time):
+    """IMU_preintegration (RGC_odometer.cpp:883-931): the gyro's rotation between two sweeps as a quaternion xyzw (rgc_imu_preintegrate, host code
+    of the library: no context needed); samples = those of getIMUInterval, bias-corrected"""
+    L = _lib.load()
+    st, g, a = (np.ascontiguousarray(x, np.float64) for x in (stamps, gyr, acc))
+    dq = np.empty(4)
+    dp = C.POINTER(C.c_double)
+    rc = L.rgc_imu_preintegrate(st.ctypes.data_as(dp), g.ctypes.data_as(dp), a.ctypes.data_as(dp), len(st), float(prev_time), float(cur_time),
+                                dq.ctypes.data_as(dp), None, None, None)
+    if rc:
+        raise RgcError(rc, "rgc_imu_preintegrate")
+    return dq
+
+
+def imu_rotation_priors(poses, dt=0.1, **imu_kw):
+    """Initial guesses of a sequence the way the odometer forms them with USE_IMU = 1 (RGC_odometer.cpp:929-931, 993-996), from a
+    synthetic IMU stream of the trajectory: guess_k = pose_{k-1} * [R(gyro delta over sweep k) | translation delta of sweep k - 1] for
+    k >= 1 (world frame; pose_{k-1} is the true one, so every frame's prior stands alone).  Returns {k: 4x4 float32}."""
+    from . import synth
+    stamps, acc, gyr = synth.make_imu(poses, dt=dt, **imu_kw)
+    bg = np.asarray(imu_kw.get("bg", (0.00127, -0.00061, -0.00267)))
+    ba = np.asarray(imu_kw.get("ba", (0.23054, -0.22046, -0.14313)))
+    gyr, acc = gyr - bg, acc - ba                      # the odometer subtracts its calibrated biases (utility.h:253-254)
+    out = {}
+    for k in range(1, len(poses)):
+        t0, t1 = (k - 1) * dt, k * dt
+        sel = np.where((stamps > t0) & (stamps < t1))[0]
+        sel = np.append(sel, sel[-1] + 1)               # getIMUInterval keeps the first sample at or after t1 as well
+        dq = imu_preintegrate(stamps[sel], gyr[sel], acc[sel], t0, t1)
+        T2 = np.eye(4)
+        T2[:3, :3] = _q2R(dq)
+        if k >= 2:
+            T2[:3, 3] = (np.linalg.inv(poses[k - 2]) @ poses[k - 1])[:3, 3]
+        out[k] = (np.asarray(poses[k - 1], np.float64) @ T2).astype(np.float32)
+    return out
 
 
 def _q2R(q):

@@ -111,9 +111,9 @@ def test_c5_250k_vs_20M_with_prior(synth, map5m):
     a = synth.make_scan_n(world, T_true, 125000, elev_deg=e, seed=synth.SEED + 3)["xyz"]
     b = synth.make_scan_n(world, T_true, 125000, elev_deg=e + 0.5 * float(np.abs(np.diff(np.sort(e))).min()), seed=synth.SEED + 4)["xyz"]
     src = np.concatenate([a, b]).astype(np.float32)
-    # IMU-preintegrated prior (RGC_odometer.cpp:929,993-996): the true motion corrupted by ~0.5 degrees of rotation
-    rng = np.random.default_rng(11)
-    ang = np.deg2rad(0.5) * rng.standard_normal(3)
-    guess = (T_true @ synth.se3(synth.rot_zyx(*ang), [0, 0, 0])).astype(np.float32)
+    # IMU-preintegrated prior (RGC_odometer.cpp:929-931, 993-996): the rotation the gyro measured over the sweep -- a synthetic 200 Hz
+    # IMU stream of the motion through rgc_imu_preintegrate -- and no translation (the first frame of a sequence has no previous delta)
+    from rgc_slam_amd import odometry
+    guess = odometry.imu_rotation_priors([np.eye(4), T_true])[1]
     # the CPU oracle on 20 M points needs a many-core host and a few GB; keep it where it finishes in seconds
     _check_case(synth, world, tgt, src, T_true, guess, oracle_pose_check=(os.cpu_count() or 1) >= 64)
