@@ -49,7 +49,7 @@ under the profiler the host is slower and the frames overlap less); alone the la
 (`rgc::PipelinedVGICP`, `profiles/r02_cpp_pipeline_bench.json`) measures the same: {pipe["pipelined_scans_per_s"]:.0f} pipelined / {pipe["one_at_a_time_scans_per_s"]:.0f} one at a time — the host
 language is not what bounds the loop. (Box to box these figures move by ±3 %.)
 
-Steady state (`profiles/r02_long_run.json`, {longr["frames"]} consecutive frames one at a time): median {longr["ms_median"]:.3f} ms, p99 {longr["ms_p99"]:.3f}, maximum {longr["ms_max"]:.2f}, {longr["frames_over_1ms"]} frames
+Steady state (`profiles/r02_long_run.json`, {longr["frames"]} consecutive frames one at a time): median {longr["ms_median"]:.3f} ms, p99 {longr["ms_p99"]:.3f}, maximum {longr["ms_max"]:.2f}, {longr["frames_over_1ms"]} frame(s)
 over 1 ms, working set {longr["working_set_MiB"]:.0f} MiB with {longr["steady_state_growth_MiB_frames_200_to_end"]} MiB growth between frame 200 and the end, every repetition of an input gives the bit-identical
 pose (fixed-order folds, deterministic cell order).
 
