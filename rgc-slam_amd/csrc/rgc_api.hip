@@ -93,6 +93,8 @@ struct rgc_ctx {
   rgck::LmState* h_lm = nullptr;  // pinned mirror
   struct { bool active = false; bool want_fitness = false; float guess[16]; } pend;  // rgc_align_begin .. rgc_align_end
   int lm_last_outer = 0;      // outer iterations of the previous solve: sizes the next blind batch
+  bool small_copy_always = false;  // RGC_SMALL_COPY=1: the 32-byte copy in front of every preparation, as before (A/B knob)
+  bool small_clean[2] = {false, false};  // d_small block of the map / the scan holds its initial image (the last solve's first step restored it)
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
   double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
@@ -262,10 +264,14 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     ProfScope ps(c, RGC_K_GRID, n, s);
     // bbox accumulators + flag; the map's copy also zeroes [7], its voxel counter ([8] ncorr stays untouched; the scan's
     // block lives at +16 and must not touch the map's counter)
-    const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
-    const size_t init_bytes = 8 * sizeof(int);  // the scan's eighth int (d_small[23]) is its sum of count^2, a float accumulated by the cell scan
-    memcpy(hsm, init, init_bytes);
-    HIPCHK(c, hipMemcpyAsync(dsm, hsm, init_bytes, hipMemcpyHostToDevice, s));
+    // ... unless the previous solve's first step has already put the block back to this image on the device (reinit_small_blocks)
+    if (!c->small_clean[is_target ? 0 : 1] || c->small_copy_always) {
+      const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+      const size_t init_bytes = 8 * sizeof(int);  // the scan's eighth int (d_small[23]) is its sum of count^2, a float accumulated by the cell scan
+      memcpy(hsm, init, init_bytes);
+      HIPCHK(c, hipMemcpyAsync(dsm, hsm, init_bytes, hipMemcpyHostToDevice, s));
+    }
+    c->small_clean[is_target ? 0 : 1] = false;  // this preparation uses it
     // Speculative grid: consecutive clouds of a sequence cover (almost) the same cells, so the previous grid -- widened by two
     // cells in x and y, one in z -- is re-used WITHOUT the bounding-box kernel and its host round trip (the only synchronisation
     // between setInputTarget and the end of align).  A larger bounding grid changes nothing in the results: cells keep their
@@ -909,6 +915,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
+  if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
   if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
   if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
@@ -1136,6 +1143,7 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
     if ((rc = lm_enqueue_batch(c, 6, nullptr, want_fitness))) return rc;
   }
   c->src_pending = false;  // stream2 has drained, and it was behind the main stream: nothing of this frame is in flight
+  c->small_clean[0] = c->small_clean[1] = true;  // the solve's first step re-initialised both blocks after capturing them
   {  // a cloud that did not fit its speculative grid: everything above ran on a parked cloud -- prepare it properly, solve again
     const int r = resolve_guards(c, S.pad & 0xff, (S.pad >> 8) & 0xff);
     if (r < 0) return r;
@@ -1152,8 +1160,10 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
   c->tgt.nvox = c->stats.n_voxels = S.nvox;
   c->stats.deferred_target = S.def_t; c->stats.deferred_source = S.def_s;
   c->tgt.deferred_seen = S.def_t; c->src.deferred_seen = S.def_s;
-  c->stats.source_crowding = c->src.n > 0 ? (double)S.src_sq / (double)c->src.n : 0.0;
-  if (c->src_res <= 0.0 && c->src.n > 0) {  // steer the next scan's cell size: halve above 300 points per own cell, double below 40
+  // (S.src_sq == 0: this scan's figure was consumed by an earlier solve on the same clouds -- the first step hands the counter back
+  // zeroed -- and the steering it caused stands)
+  if (S.src_sq > 0.f) c->stats.source_crowding = c->src.n > 0 ? (double)S.src_sq / (double)c->src.n : 0.0;
+  if (S.src_sq > 0.f && c->src_res <= 0.0 && c->src.n > 0) {  // steer the next scan's cell size: halve above 300 points per own cell, double below 40
     const double cur = c->src.grid.res, crowd = c->stats.source_crowding;
     double next = cur;
     if (crowd > 300.0 && cur > 0.26 * c->prm.voxel_res) next = cur * 0.5;

@@ -2056,6 +2056,22 @@ void lab_lm_ts(unsigned long long* out, hipStream_t s) {
 #define LAB_TS_MIN(k)
 #endif
 
+// The frame's small counters have been captured into the LM state: put both clouds' blocks of d_small back to their initial image
+// (bounding-box accumulators, guard, the scan's sum of count^2), so that the NEXT preparation of either cloud needs no 32-byte
+// H2D copy in front of its first kernel (3.5 us of copy kernel + 4 us of gap at the head of each preparation chain).  The map's voxel
+// count (nvox[0]) and the correspondence count behind it stay: a resident target is solved against again.
+__device__ __forceinline__ void reinit_small_blocks(const int* nvox) {
+  int* t = const_cast<int*>(nvox) - 7;  // d_small: [0..5] map bbox, [6] map guard, [7] nvox; [16..21] scan bbox, [22] scan guard, [23] scan sum count^2
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    int* m = t + 16 * b;
+    m[0] = m[1] = m[2] = INT_MAX;
+    m[3] = m[4] = m[5] = INT_MIN;
+    m[6] = 0;
+  }
+  t[23] = 0;
+}
+
 // The decision of one STEP launch, taken by lane 0 of the last-arriving workgroup on the LDS copy `ls` of the state: what the
 // folded sums mean in this mode, accept / reject / terminate, and the next LM try (lsq_registration_impl.hpp:125-172).
 __device__ __forceinline__ void lm_step_decide(LmState& ls, const double* folded, int first, const LmInit& in, int mode, int cur,
@@ -2077,6 +2093,7 @@ __device__ __forceinline__ void lm_step_decide(LmState& ls, const double* folded
     ls.def_t = def_t ? *def_t : 0;
     ls.def_s = def_s ? *def_s : 0;
     ls.src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;
+    if (nvox) reinit_small_blocks(nvox);
   }
   double H[36], b[6], x0[16], d[6], delta[16], xi[16];
   double lambda = ls.lambda;
@@ -2198,6 +2215,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
       st->def_t = def_t ? *def_t : 0;
       st->def_s = def_s ? *def_s : 0;
       st->src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;  // d_small[23]
+      if (nvox) reinit_small_blocks(nvox);
       st->done = 1;
     }
     return;
