@@ -65,6 +65,12 @@ checked against the CPU oracle; pipelined / one at a time):
 
 '''
 s = sub_block(s, "Round-2 numbers (MI355X, `profiles/r02_*`", "History (scans/s on c-main", new)
+# the same figures where §5 and §6e quote them
+s = re.sub(r"\d+ → \d+ scans/s in `bench.py` \(\d+ → [\d–]+ in the bare drivers `scripts/exp_pipeline.py` and `bench_cpp_pipeline.py`\); c1 \(30 k vs\n100 k, 15 outer iterations\): \d+ → \d+; c3: \d+ → \d+; c5: \d+ → \d+\.",
+           f"{O['scans_per_s']:.0f} → {d['value']:.0f} scans/s in `bench.py` ({pipe['one_at_a_time_scans_per_s']:.0f} → {pipe['pipelined_scans_per_s']:.0f} in the bare drivers `scripts/exp_pipeline.py` and `bench_cpp_pipeline.py`); c1 (30 k vs\n"
+           f"100 k, 15 outer iterations): {c['c1']['one_frame_at_a_time_scans_per_s']:.0f} → {c['c1']['scans_per_s']:.0f}; c3: {c['c3']['one_frame_at_a_time_scans_per_s']:.0f} → {c['c3']['scans_per_s']:.0f}; c5: {c['c5']['one_frame_at_a_time_scans_per_s']:.0f} → {c['c5']['scans_per_s']:.0f}.", s)
+s = re.sub(r"source: \*\*\d+ scans/s against \d+ on one context\*\*", f"source: **{roll['resident_two_contexts_scans_per_s']:.0f} scans/s against {roll['resident_scans_per_s']:.0f} on one context**", s)
+s = re.sub(r"three frames\): \d+ against \d+ scans/s\.", f"three frames): {roll['keyframe_every_3_frames_two_contexts_scans_per_s']:.0f} against {roll['keyframe_every_3_frames_scans_per_s']:.0f} scans/s.", s)
 open(P("DESIGN.md"), "w").write(s)
 
 # ---------------- BASELINE.md §4
@@ -127,5 +133,25 @@ new = f'''* Measured on MI355X (`profiles/r02_*`, one run): **{d["value"]:.0f} r
   {100 * issue_alone / 595:.0f} % of the measured half-rate VALU issue roof (DESIGN.md §5).
 '''
 s = sub_block(s, "* Measured on MI355X (`profiles/r02_*`, one run):", "* The host side in the reference's language:", new)
+open(P("README.md"), "w").write(s)
+# ---------------- profiles/README.md: the figures quoted in its table
+s = open(P("profiles", "README.md")).read()
+s = re.sub(r"pose parity of \d+ frames", f"pose parity of {pp['frames']} frames", s)
+s = re.sub(r"average, \d+ µs, against \d+ µs from the library's own HIP events in that run; \d+ µs in the unprofiled run:",
+           f"average, {knn_prof_us:.0f} µs, against {u['roofline']['avg_launch_ms'] * 1e3:.0f} µs from the library's own HIP events in that run; {R['avg_launch_ms'] * 1e3:.0f} µs in the unprofiled run:", s)
+s = re.sub(r"→ [\d.]+ VALU wave-instructions per map query, [\d.]+ MB per 1 M-query launch", f"→ {valu:.1f} VALU wave-instructions per map query, {traffic_mb:.1f} MB per 1 M-query launch", s)
+s = re.sub(r"median [\d.]+ ms, p99 [\d.]+, max [\d.]+[^,]*,", f"median {longr['ms_median']:.3f} ms, p99 {longr['ms_p99']:.3f}, max {longr['ms_max']:.2f} ({longr['frames_over_1ms']} frame(s) over 1 ms),", s, count=1)
+s = re.sub(r"rebuilt every frame \d+ scans/s, resident \d+ on one context and \d+ on two sharing the map \(`rgc_share_target`\), a keyframe every 3rd frame \d+ / \d+ \(commit [\d.]+ ms\);",
+           f"rebuilt every frame {roll['rebuild_every_frame_scans_per_s']:.0f} scans/s, resident {roll['resident_scans_per_s']:.0f} on one context and {roll['resident_two_contexts_scans_per_s']:.0f} on two sharing the map (`rgc_share_target`), a keyframe every 3rd frame {roll['keyframe_every_3_frames_scans_per_s']:.0f} / {roll['keyframe_every_3_frames_two_contexts_scans_per_s']:.0f} (commit {roll['commit_ms_median']:.2f} ms);", s)
+s = re.sub(r"[\d.]+ / [\d.]+ / [\d.]+ ms per frame \(reference semantics / resident map / device chain\), [\d.]+ ms through `ReplayPipeline`",
+           f"{node['cpp_reference_semantics_ms_per_frame']:.2f} / {node['cpp_resident_map_ms_per_frame']:.2f} / {node['cpp_resident_map_device_chain_ms_per_frame']:.2f} ms per frame (reference semantics / resident map / device chain), {node['cpp_replay_pipeline_ms_per_frame']:.2f} ms through `ReplayPipeline`", s)
+s = re.sub(r"\d+ scans/s pipelined, \d+ one at a time, same poses and fitness", f"{pipe['pipelined_scans_per_s']:.0f} scans/s pipelined, {pipe['one_at_a_time_scans_per_s']:.0f} one at a time, same poses and fitness", s)
+open(P("profiles", "README.md"), "w").write(s)
+# ---------------- README.md: the C++ node line
+s = open(P("README.md")).read()
+s = re.sub(r"[\d.]+ ms per 28\.8 k-point sweep with the sweep kept on the device between the stages, [\d.]+ ms in",
+           f"{node['cpp_resident_map_device_chain_ms_per_frame']:.2f} ms per 28.8 k-point sweep with the sweep kept on the device between the stages, {node['cpp_replay_pipeline_ms_per_frame']:.2f} ms in", s)
+s = re.sub(r"\d+ scans/s against a\n  resident 1 M-point map with two contexts sharing it, \d+ with one\)",
+           f"{roll['resident_two_contexts_scans_per_s']:.0f} scans/s against a\n  resident 1 M-point map with two contexts sharing it, {roll['resident_scans_per_s']:.0f} with one)", s)
 open(P("README.md"), "w").write(s)
 print("synced:", d["value"], O["scans_per_s"], [x["scans_per_s"] for x in d["configs"]])
