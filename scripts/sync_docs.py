@@ -40,7 +40,7 @@ def cfg_row(key, label, r1):
 s = open(P("DESIGN.md")).read()
 new = f'''Round-2 numbers (MI355X, `profiles/r02_*`, all from one `scripts/refresh_profiles.sh` run): **{d["value"]:.0f} scans/s ({d["ms_per_step"]} ms/step) pipelined**,
 {O["scans_per_s"]:.0f} scans/s ({O["ms_per_step"]} ms) one frame at a time (round 1: 1497), {H["scans_per_s"]:.0f} scans/s with the scan's H2D and the output cloud inside the step; pose
-parity vs CPU over {pp["frames"]} timed frames ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad; CPU port {cb["value"]:.2f} scans/s on {cb["cores"]} host threads, {cb["value_14_threads"]:.1f} at the reference's 14 threads
+parity vs CPU over {pp["frames"]} timed frames ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad; CPU port {cb["value"]:.2f} scans/s at the reference's {cb["cores"]} OpenMP threads ({cb.get("value_all_cores", 0):.2f} on all host cores: more threads make it slower)
 (a reported baseline, not a target). Per step, one frame at a time (HIP events, separate pass with every stage bracketed): grid build
 {k["grid_build"]:.3f} ms (both clouds), kNN map {k["knn_cov_target"]:.3f} + {k["knn_coop_target"]:.3f} ms, kNN scan {k["knn_cov_source"]:.3f} + {k["knn_coop_source"]:.3f} ms (second stream, overlapped), voxel map {k["voxel_build"]:.3f}, LM {k["linearize"]:.3f}
 ({d["mean_outer_iterations"]} outer iterations), fitness {k["fitness"]:.3f}. `profiles/r02_kernel_stats.csv` (rocprofv3 `--kernel-trace --stats` of the same
@@ -56,10 +56,10 @@ pose (fixed-order folds, deterministic cell order).
 All configurations of BASELINE.json (`profiles/r02_bench.json` → `configs`; target rebuilt every frame, inputs resident, first frame
 checked against the CPU oracle; pipelined / one at a time):
 
-| config | scans/s | ms/scan | round 1 | CPU oracle scans/s ({cb["cores"]} threads) | max Δt (m) / Δθ (rad) vs oracle |
+| config | scans/s | ms/scan | round 1 | CPU oracle scans/s | max Δt (m) / Δθ (rad) vs oracle |
 |---|---|---|---|---|---|
 ''' + cfg_row("c1", "c1 30 k vs 100 k (15 outer iterations from the identity)", 1386) + \
-    f'''| c-main 30 k vs 1 M | {d["value"]:.0f} / {O["scans_per_s"]:.0f} | {d["ms_per_step"]} / {O["ms_per_step"]} | 1497 | {cb["value"]:.2f} ({cb["value_14_threads"]:.1f} at 14 threads) | {pp["max_dt_m"]:.1e} / {pp["max_dtheta_rad"]:.1e} |
+    f'''| c-main 30 k vs 1 M | {d["value"]:.0f} / {O["scans_per_s"]:.0f} | {d["ms_per_step"]} / {O["ms_per_step"]} | 1497 | {cb["value"]:.2f} at {cb["cores"]} threads ({cb.get("value_all_cores", 0):.2f} on all cores) | {pp["max_dt_m"]:.1e} / {pp["max_dtheta_rad"]:.1e} |
 ''' + cfg_row("c3", "c3 HDL-64 130 k vs 5 M", 351) + cfg_row("c5", "c5 250 k vs 20 M, IMU-preintegrated prior", 113) + \
     f'''| c-main, map resident on the device (`profiles/r02_rolling_bench.json`) | {roll["resident_two_contexts_scans_per_s"]:.0f} resident on two contexts, {roll["resident_scans_per_s"]:.0f} on one; {roll["keyframe_every_3_frames_two_contexts_scans_per_s"]:.0f} / {roll["keyframe_every_3_frames_scans_per_s"]:.0f} with a keyframe every 3rd frame | {1e3 / roll["resident_two_contexts_scans_per_s"]:.3f}, {roll["ms_per_frame"]["resident"]}; {1e3 / roll["keyframe_every_3_frames_two_contexts_scans_per_s"]:.3f} / {roll["ms_per_frame"]["keyframes"]} | 2061, 1402 | | {roll["max_translation_diff_resident_vs_rebuild_m"]:.1e} vs rebuild |
 
@@ -80,7 +80,7 @@ B = d["algorithmic_bytes_per_scan"] / 1e6
 
 def brow(key, label, r1):
     x = c[key]
-    return (f"| {label} | CPU | {cb['cores']} | {x['cpu_oracle_scans_per_s']:.2f} | | | |\n"
+    return (f"| {label} | CPU | all cores | {x['cpu_oracle_scans_per_s']:.2f} | | | |\n"
             f"| {label} | HIP | 1 GPU | **{x['scans_per_s']:.0f}** pipelined / {x['one_frame_at_a_time_scans_per_s']:.0f} one at a time (round 1: {r1}) | "
             f"{x['ms_per_scan']:.3g} / {1e3 / x['one_frame_at_a_time_scans_per_s']:.3g} | {x['max_dt_m']:.1e} | {x['max_dtheta_rad']:.1e} |\n")
 
@@ -92,14 +92,14 @@ run of `scripts/refresh_profiles.sh`; this section is generated from those files
 gfx950 path, target rebuilt every frame, inputs resident in HBM; two figures per configuration: **pipelined** (two contexts take turns:
 frame i + 1's clouds are prepared while frame i is solved — the throughput of a replayed sequence, `value` of the bench line) and **one
 frame at a time** (the blocking `align()`: a frame's latency). Both give bit-identical poses (checked in every run). CPU = the C/OpenMP
-restatement (`oracle/`, the parity checker) on the GPU box's host at {cb["cores"]} threads (the reference's 14 threads in brackets). The reference
-itself cannot be built (section 2), so there is no reference row.
+restatement (`oracle/`, the parity checker) on the GPU box's host: c-main at the reference's {cb["cores"]} OpenMP threads (all cores in brackets:
+slower), the other configurations on all cores. The reference itself cannot be built (section 2), so there is no reference row.
 
 | Config | Backend | Threads / GPUs | scans/s | ms/scan | max Δt (m) vs CPU | max Δθ (rad) |
 |---|---|---|---|---|---|---|
 ''' + brow("c1", "c1 30 k vs 100 k", 1386) + \
     f'''| c2 sequence stand-in (24 sweeps × 28.8 k pts, front-end + frame body + ground factor, 3 keyframes) | HIP, C++ node | 1 GPU | {1e3 / node["cpp_reference_semantics_ms_per_frame"]:.0f} (reference semantics) / {1e3 / node["cpp_resident_map_device_chain_ms_per_frame"]:.0f} (resident map, device chain) / {1e3 / node["cpp_replay_pipeline_ms_per_frame"]:.0f} (replay pipeline) (`profiles/r02_cpp_node_bench.json`) | {node["cpp_reference_semantics_ms_per_frame"]:.2f} / {node["cpp_resident_map_device_chain_ms_per_frame"]:.2f} / {node["cpp_replay_pipeline_ms_per_frame"]:.2f} | ≤ 1e-4 vs the oracle frame body, with and without the IMU path (`tests/test_gpu_sequence.py`, `tests/test_gpu_cpp_node.py`) | ≤ 1e-4 |
-| c-main 30 k vs 1 M | CPU | {cb["cores"]} (14) | {cb["value"]:.2f} ({cb["value_14_threads"]:.1f}) | | | |
+| c-main 30 k vs 1 M | CPU | {cb["cores"]} (all cores) | {cb["value"]:.2f} ({cb.get("value_all_cores", 0):.2f}) | | | |
 | c-main 30 k vs 1 M | HIP | 1 GPU | **{d["value"]:.0f}** pipelined / {O["scans_per_s"]:.0f} one at a time / {H["scans_per_s"]:.0f} pipelined with the scan uploaded from pinned memory inside the step (round 1: 1497) | {d["ms_per_step"]} / {O["ms_per_step"]} / {H["ms_per_step"]} | {pp["max_dt_m"]:.1e} ({pp["frames"]} frames) | {pp["max_dtheta_rad"]:.1e} |
 | c-main, C++ host (`rgc::PipelinedVGICP`) | HIP | 1 GPU | {pipe["pipelined_scans_per_s"]:.0f} pipelined / {pipe["one_at_a_time_scans_per_s"]:.0f} one at a time (`profiles/r02_cpp_pipeline_bench.json`) | {pipe["pipelined_ms_per_frame"]:.3f} / {pipe["one_at_a_time_ms_per_frame"]:.3f} | identical to the Python mirror | |
 | c-main, map resident (SURVEY §8f f2) | HIP | 1 GPU | {roll["resident_two_contexts_scans_per_s"]:.0f} resident on two contexts sharing the map / {roll["resident_scans_per_s"]:.0f} on one / {roll["rebuild_every_frame_scans_per_s"]:.0f} rebuilt per frame / {roll["keyframe_every_3_frames_two_contexts_scans_per_s"]:.0f} with a keyframe every 3rd frame (`profiles/r02_rolling_bench.json`) | {1e3 / roll["resident_two_contexts_scans_per_s"]:.3f} / {roll["ms_per_frame"]["resident"]} / {roll["ms_per_frame"]["rebuild"]} / {1e3 / roll["keyframe_every_3_frames_two_contexts_scans_per_s"]:.3f} | {roll["max_translation_diff_resident_vs_rebuild_m"]:.1e} vs rebuild | |
@@ -127,8 +127,8 @@ s = open(P("README.md")).read()
 new = f'''* Measured on MI355X (`profiles/r02_*`, one run): **{d["value"]:.0f} registered scans/s** on the headline workload (30 k-point scan against a
   1 M-point map, everything rebuilt per frame) with two contexts taking turns (`registration.PipelinedVGICP`: the next frame's clouds are
   prepared while a frame is solved; identical poses; `rgc::PipelinedVGICP` in C++ measures the same), {O["scans_per_s"]:.0f} scans/s one frame at a time
-  (round 1: 1497); pose parity against the CPU oracle ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad over {pp["frames"]} timed frames; the CPU port runs {cb["value"]:.2f} scans/s on
-  {cb["cores"]} host threads ({cb["value_14_threads"]:.1f} at the reference's 14). c1 {c["c1"]["scans_per_s"]:.0f}, c3 {c["c3"]["scans_per_s"]:.0f}, c5 {c["c5"]["scans_per_s"]:.0f} scans/s; {roll["resident_two_contexts_scans_per_s"]:.0f} scans/s against a map resident on the device.
+  (round 1: 1497); pose parity against the CPU oracle ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad over {pp["frames"]} timed frames; the CPU port runs {cb["value"]:.2f} scans/s at
+  the reference's {cb["cores"]} OpenMP threads ({cb.get("value_all_cores", 0):.2f} on all host cores). c1 {c["c1"]["scans_per_s"]:.0f}, c3 {c["c3"]["scans_per_s"]:.0f}, c5 {c["c5"]["scans_per_s"]:.0f} scans/s; {roll["resident_two_contexts_scans_per_s"]:.0f} scans/s against a map resident on the device.
   The dominant kernel (exact 20-NN + covariance of the 1 M-point map) takes {alone_us:.0f} µs alone, {valu:.0f} VALU wave-instructions per query, at
   {100 * issue_alone / 595:.0f} % of the measured half-rate VALU issue roof (DESIGN.md §5).
 '''
