@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_set>
 #include <vector>
 
 #include "rgc_kernels.h"
@@ -59,6 +61,15 @@ struct ProfRegion {
 };
 
 }  // namespace
+
+// Contexts alive in this process: a context that borrows another one's target (rgc_share_target) checks its owner here before every
+// solve, so that an owner destroyed too early is an error message and not a read of freed memory.
+static std::mutex g_live_mutex;
+static std::unordered_set<const rgc_ctx*> g_live;
+static bool ctx_alive(const rgc_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_live_mutex);
+  return g_live.count(c) != 0;
+}
 
 struct rgc_ctx {
   int device = 0;
@@ -919,12 +930,14 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
   if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
+  { std::lock_guard<std::mutex> lk(g_live_mutex); g_live.insert(c); }
   *out = c;
   return RGC_OK;
 }
 
 void rgc_destroy(rgc_ctx* c) {
   if (!c) return;
+  { std::lock_guard<std::mutex> lk(g_live_mutex); g_live.erase(c); }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -1081,8 +1094,19 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   c->pend.active = false;
   // the guards of speculative grids come home with the LM state: no synchronisation here
   if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
-  if (c->tgt_owner && c->tgt_owner->tgt_generation != c->tgt_owner_gen)
-    return fail(c, RGC_ERR_INVALID, "the shared target was rebuilt by its owner: rgc_share_target again");
+  if (c->tgt_owner) {
+    if (!ctx_alive(c->tgt_owner)) {  // its device buffers are gone with it
+      c->tgt_owner = nullptr;
+      for (DevBuf* b : {&c->tgt.in_copy, &c->tgt.cell_of, &c->tgt.slot_of, &c->tgt.cnt, &c->tgt.start, &c->tgt.block_sums, &c->tgt.order_tmp, &c->tgt.P,
+                        &c->tgt.nx, &c->tgt.ny, &c->tgt.nz, &c->tgt.segs, &c->tgt.cell_voxel, &c->tgt.vox, &c->tgt.vox_cell})
+        release(*b);
+      c->tgt.ready = false;
+      c->tgt.n = 0;
+      return fail(c, RGC_ERR_NO_INPUT, "the context whose target this one shared has been destroyed");
+    }
+    if (c->tgt_owner->tgt_generation != c->tgt_owner_gen)
+      return fail(c, RGC_ERR_INVALID, "the shared target was rebuilt by its owner: rgc_share_target again");
+  }
   // The solve is a chain of short launches: it runs on the HIGH-PRIORITY stream -- the one the scan was prepared on, so it is already
   // behind that -- ordered after the map's preparation on the main stream by one event.  With a second context preparing the next
   // frame's map meanwhile (15 k waves that fill every CU), the dispatcher places the solve's ~100 workgroups as soon as slots free up

@@ -462,7 +462,17 @@ def test_shared_target(reg_mod, medium):
     a.align(g, want_output=False)
     pv.close()
     b.close()
+    # an owner destroyed while its target is still borrowed: an error, not a read of freed memory
+    c = _odo(reg_mod)
+    c.shareTargetFrom(a)
+    c.setInputSource(medium["src"])
     a.close()
+    with pytest.raises(reg_mod.RgcError):
+        c.align(g, want_output=False)
+    c.setInputTarget(medium["tgt"])
+    c.align(g, want_output=False)
+    assert np.array_equal(c.getFinalTransformation(), res[0][0])
+    c.close()
 
 
 def test_fitness_with_points_far_from_the_map(reg_mod, orc, medium):
