@@ -129,7 +129,7 @@ def time_config(registration, oracle, name, tgt, scans, guess0, prior=None):
            "ms_per_scan": round(1e3 * el / frames, 3), "one_frame_at_a_time_scans_per_s": round(frames / el_seq, 2),
            "same_poses_both_ways": bool(all(np.array_equal(x, y) for x, y in zip(fin, fin_seq))), "outer_iterations_last": st["outer_iterations"]}
     if oracle is not None:
-        o = oracle.Registration(num_threads=os.cpu_count() or 1)
+        o = oracle.Registration(num_threads=min(14, os.cpu_count() or 1))  # the reference's setNumThreads(14): also the oracle's faster setting
         c0 = time.perf_counter()
         o.set_target(tgt)
         o.set_source(scans[1])

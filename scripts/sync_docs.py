@@ -80,7 +80,7 @@ B = d["algorithmic_bytes_per_scan"] / 1e6
 
 def brow(key, label, r1):
     x = c[key]
-    return (f"| {label} | CPU | all cores | {x['cpu_oracle_scans_per_s']:.2f} | | | |\n"
+    return (f"| {label} | CPU | 14 | {x['cpu_oracle_scans_per_s']:.2f} | | | |\n"
             f"| {label} | HIP | 1 GPU | **{x['scans_per_s']:.0f}** pipelined / {x['one_frame_at_a_time_scans_per_s']:.0f} one at a time (round 1: {r1}) | "
             f"{x['ms_per_scan']:.3g} / {1e3 / x['one_frame_at_a_time_scans_per_s']:.3g} | {x['max_dt_m']:.1e} | {x['max_dtheta_rad']:.1e} |\n")
 
@@ -92,8 +92,8 @@ run of `scripts/refresh_profiles.sh`; this section is generated from those files
 gfx950 path, target rebuilt every frame, inputs resident in HBM; two figures per configuration: **pipelined** (two contexts take turns:
 frame i + 1's clouds are prepared while frame i is solved — the throughput of a replayed sequence, `value` of the bench line) and **one
 frame at a time** (the blocking `align()`: a frame's latency). Both give bit-identical poses (checked in every run). CPU = the C/OpenMP
-restatement (`oracle/`, the parity checker) on the GPU box's host: c-main at the reference's {cb["cores"]} OpenMP threads (all cores in brackets:
-slower), the other configurations on all cores. The reference itself cannot be built (section 2), so there is no reference row.
+restatement (`oracle/`, the parity checker) on the GPU box's host at the reference's {cb["cores"]} OpenMP threads (c-main also on all cores, in
+brackets: slower). The reference itself cannot be built (section 2), so there is no reference row.
 
 | Config | Backend | Threads / GPUs | scans/s | ms/scan | max Δt (m) vs CPU | max Δθ (rad) |
 |---|---|---|---|---|---|---|
