@@ -115,19 +115,38 @@ __global__ void __launch_bounds__(FE_T) k_fe_rank(int n, const int* __restrict__
 
 // pass 2 (one block): exclusive prefix of the block histograms per ring, ring counts and ring starts.
 // meta: [0..63] ring_count, [64..128] ring_start (65 entries)
-__global__ void __launch_bounds__(64) k_fe_hist_scan(int nblocks, int NS, int* __restrict__ blk_hist, int* __restrict__ meta) {
+// 64 rings x 16 chunks of blocks: a thread sums its chunk's histogram entries (independent loads), the chunk totals are prefixed per
+// ring through LDS, then the thread writes its entries' exclusive prefixes.  (One thread per ring walking all ~110 blocks with a
+// dependent load-store chain took 21 us of the front-end's 570.)
+constexpr int HS_CH = 16;
+__global__ void __launch_bounds__(64 * HS_CH) k_fe_hist_scan(int nblocks, int NS, int* __restrict__ blk_hist, int* __restrict__ meta) {
+  __shared__ int part[HS_CH][64];
   __shared__ int cnt[64];
-  const int r = threadIdx.x;
+  const int r = threadIdx.x & 63, ch = threadIdx.x >> 6;
+  const int per = (nblocks + HS_CH - 1) / HS_CH, b0 = ch * per, b1 = min(b0 + per, nblocks);
   int s = 0;
-  for (int b = 0; b < nblocks; b++) {
-    const int v = blk_hist[(size_t)b * 64 + r];
-    blk_hist[(size_t)b * 64 + r] = s;
-    s += v;
-  }
-  cnt[r] = r < NS ? s : 0;
-  meta[r] = cnt[r];
+  for (int b = b0; b < b1; b++) s += blk_hist[(size_t)b * 64 + r];
+  part[ch][r] = s;
   __syncthreads();
-  if (r == 0) {
+  int before = 0, total = 0;
+#pragma unroll
+  for (int j = 0; j < HS_CH; j++) {
+    const int v = part[j][r];
+    before += j < ch ? v : 0;
+    total += v;
+  }
+  int run = before;
+  for (int b = b0; b < b1; b++) {
+    const int v = blk_hist[(size_t)b * 64 + r];
+    blk_hist[(size_t)b * 64 + r] = run;
+    run += v;
+  }
+  if (ch == 0) {
+    cnt[r] = r < NS ? total : 0;
+    meta[r] = cnt[r];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     int a = 0;
     for (int j = 0; j < 64; j++) { meta[64 + j] = a; a += cnt[j]; }
     meta[128] = a;
@@ -660,7 +679,7 @@ void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, cons
                const int* st, float4* C, int* inum2) {
   const int nb = nblk(n, FE_T);
   hipLaunchKernelGGL(k_fe_rank, dim3(nb), dim3(FE_T), 0, s, n, ring, rank_in_block, blk_hist);
-  hipLaunchKernelGGL(k_fe_hist_scan, dim3(1), dim3(64), 0, s, nb, NS, blk_hist, meta);
+  hipLaunchKernelGGL(k_fe_hist_scan, dim3(1), dim3(64 * HS_CH), 0, s, nb, NS, blk_hist, meta);
   hipLaunchKernelGGL(k_fe_scatter, dim3(nb), dim3(FE_T), 0, s, in, stride_f, n, ring, rank_in_block, blk_hist, meta, st, C, inum2);
 }
 void fe_stencils(hipStream_t s, const float4* C, int cs, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
