@@ -1597,20 +1597,29 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   enum { RING, RANK, HIST, META, ST, CL, INUM2, INUM, RANGE, ANGLE, CURV, CURV2, ICURV, DSRC, OSRC, PICK, IPICK, LAB, ILAB, GMARK, MULT, SCNT,
          SPOS, PART, OUTD, SLOTS, FLAGS, SHARP, FLAT, INTEN, GLIST, BSUM, SORTC, SORTI };
   const int nu = NS * 6, fcap = nu * 41;
+  constexpr size_t kTailFlags = 304, kTailSt = 336, kTailFeat = 496;  // see OUTD below
   const size_t n4 = (size_t)4 * n;
   const size_t sizes[34] = {n4, n4, (size_t)4 * 64 * nb, 4u * 132, 4u * 8, 4 * n4, n4, n4, n4, n4, n4, n4, n4, n4,
-                            n4, n4, n4, n4, n4, n4, n4, n4, n4, (size_t)8 * 11 * nb, 8u * 48,
-                            4u * (size_t)nu * rgck::fe_slot_ints(), 4u * 8, 20u * fcap, 20u * fcap, 20u * fcap, 16u * 10 * (size_t)n, 4u * ((size_t)n / 2048 + 4), n4, n4};
+                            n4, n4, n4, n4, n4, n4, n4, n4, n4, (size_t)8 * 11 * nb, kTailFeat + 60u * (size_t)fcap,
+                            4u * (size_t)nu * rgck::fe_slot_ints(), 4u * 8, 64u, 64u, 64u, 16u * 10 * (size_t)n, 4u * ((size_t)n / 2048 + 4), n4, n4};
+  // OUTD is the sweep's "tail": ground sums / fit / distance sums (doubles 0..33), the flags, the filter's start-end state and the three
+  // feature clouds in ONE buffer laid out like the pinned staging area behind the meta block, so that everything the host needs at the
+  // end of the sweep comes down in ONE copy and the two small blocks are initialised by ONE
   for (int b = 0; b < 34; b++) if ((rc = ensure(c, c->fe[b], sizes[b] + 64))) return rc;
 #define FE(i, T) ((T*)c->fe[i].p)
-  int st_init[8] = {INT_MAX, -1, INT_MAX, 0, 0, 0, 0, 0};
-  memcpy(c->h_small + 32, st_init, sizeof(st_init));
-  HIPCHK(c, hipMemcpyAsync(FE(ST, int), c->h_small + 32, sizeof(st_init), hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemsetAsync(FE(FLAGS, int), 0, 32, s));
+  unsigned char* const tail = (unsigned char*)c->fe[OUTD].p;
+  int* const d_flags = (int*)(tail + kTailFlags);
+  int* const d_st = (int*)(tail + kTailSt);
+  float* const d_sharp = (float*)(tail + kTailFeat);
+  float* const d_flat = d_sharp + 5 * (size_t)fcap;
+  float* const d_inten = d_flat + 5 * (size_t)fcap;
+  const int init16[16] = {0, 0, 0, 0, 0, 0, 0, 0, INT_MAX, -1, INT_MAX, 0, 0, 0, 0, 0};  // flags (zero) + the filter's state
+  memcpy(c->h_small + 32, init16, sizeof(init16));
+  HIPCHK(c, hipMemcpyAsync(d_flags, c->h_small + 32, sizeof(init16), hipMemcpyHostToDevice, s));
   rgck::FeParams fp{NS, prm->min_range, prm->max_range};
-  rgck::fe_filter(s, d_in, stride_f, n, fp, FE(RING, int), FE(ST, int));
-  rgck::fe_half(s, d_in, stride_f, n, FE(RING, int), FE(ST, int));
-  rgck::fe_bucket(s, d_in, stride_f, n, NS, FE(RING, int), FE(RANK, int), FE(HIST, int), FE(META, int), FE(ST, int), FE(CL, float4), FE(INUM2, int));
+  rgck::fe_filter(s, d_in, stride_f, n, fp, FE(RING, int), d_st);
+  rgck::fe_half(s, d_in, stride_f, n, FE(RING, int), d_st);
+  rgck::fe_bucket(s, d_in, stride_f, n, NS, FE(RING, int), FE(RANK, int), FE(HIST, int), FE(META, int), d_st, FE(CL, float4), FE(INUM2, int));
   // pinned staging: [0, 1024) meta + ground sums + flags, then the three feature clouds
   const size_t stage_need = 1024 + 3 * 20u * (size_t)fcap;
   if (c->h_stage_cap < stage_need) {
@@ -1644,17 +1653,14 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   rgck::fe_ground_list(s, FE(CL, float4), cs, NS, FE(RANGE, float), FE(META, int), FE(SCNT, int), FE(SPOS, int), FE(GLIST, float4), gcap_dev);
   // A7 + A8
   rgck::fe_select(s, FE(CL, float4), NS, FE(META, int), FE(CURV, float), FE(CURV2, float), FE(ICURV, float), FE(INUM, int), FE(GMARK, int),
-                  FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), FE(FLAGS, int), max_ring, FE(SORTC, int), FE(SORTI, int));
-  rgck::fe_emit(s, FE(CL, float4), NS, FE(SLOTS, int), FE(DSRC, float), FE(OSRC, float), FE(SHARP, float), FE(FLAT, float), FE(INTEN, float), fcap,
-                FE(FLAGS, int) + 4);
+                  FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), d_flags, max_ring, FE(SORTC, int), FE(SORTI, int));
+  rgck::fe_emit(s, FE(CL, float4), NS, FE(SLOTS, int), FE(DSRC, float), FE(OSRC, float), d_sharp, d_flat, d_inten, fcap,
+                d_flags + 4);
   // flags and the three feature clouds (at their capacity: ~80 kB each for 16 rings) come down together into pinned memory, one
   // synchronisation; the counts decide how much of each is handed to the caller
   double* gd = (double*)(c->h_stage + 528);            // 34 doubles behind the 129 meta ints
-  HIPCHK(c, hipMemcpyAsync(gd, FE(OUTD, double), sizeof(double) * 34, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(fl, FE(FLAGS, int), sizeof(int) * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(h_feat, FE(SHARP, float), 20u * (size_t)fcap, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(h_feat + 20u * (size_t)fcap, FE(FLAT, float), 20u * (size_t)fcap, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(h_feat + 40u * (size_t)fcap, FE(INTEN, float), 20u * (size_t)fcap, hipMemcpyDeviceToHost, s));
+  static_assert(528 + kTailFlags == 832 && 528 + kTailFeat == 1024, "the device tail mirrors the staging area from gd on");
+  HIPCHK(c, hipMemcpyAsync(gd, tail, kTailFeat + 60u * (size_t)fcap, hipMemcpyDeviceToHost, s));
   if (out->cloud) HIPCHK(c, hipMemcpyAsync(out->cloud, FE(CL, float4), sizeof(float) * 4 * (size_t)cs, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (fl[0] & 2) return fail(c, RGC_ERR_INVALID, "a ring sector holds more than 2048 points");
