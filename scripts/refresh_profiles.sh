@@ -18,6 +18,7 @@ timeout 120 scripts/ubench/valu_issue > $O/valu_issue.jsonl 2> /dev/null
 python scripts/exp_stall.py 300 > $O/stall.txt 2>&1; EXP_GC=freeze python scripts/exp_stall.py 300 >> $O/stall.txt 2>&1
 if [ "$1" != quick ]; then
   python scripts/exp_long_run.py 3000 2>/dev/null | tail -1 > $O/long_run.json
+  python scripts/exp_long_run_pipelined.py 6000 2>/dev/null | tail -1 > $O/long_run_pipelined.json
   python scripts/bench_rolling.py > $O/rolling.json 2> /dev/null
   python scripts/bench_cpp_node.py > $O/cpp_node.json 2> /dev/null
   python scripts/bench_cpp_pipeline.py 2>/dev/null | tail -1 > $O/cpp_pipeline.json

@@ -11,6 +11,7 @@ node = json.load(open(P("profiles", "r02_cpp_node_bench.json")))
 pipe = json.load(open(P("profiles", "r02_cpp_pipeline_bench.json")))
 longr = json.load(open(P("profiles", "r02_long_run.json"))) if open(P("profiles", "r02_long_run.json")).read().strip().startswith("{\"") else eval(open(P("profiles", "r02_long_run.json")).read())
 pmc = json.load(open(P("profiles", "r02_pmc_knn.json")))
+lp = json.load(open(P("profiles", "r02_long_run_pipelined.json")))
 knn_prof_us = None
 for r in csv.DictReader(open(P("profiles", "r02_kernel_stats.csv"))):
     if "k_knn_sp<20, true>" in r["Name"]:
@@ -51,7 +52,8 @@ language is not what bounds the loop. (Box to box these figures move by ±3 %.)
 
 Steady state (`profiles/r02_long_run.json`, {longr["frames"]} consecutive frames one at a time): median {longr["ms_median"]:.3f} ms, p99 {longr["ms_p99"]:.3f}, maximum {longr["ms_max"]:.2f}, {longr["frames_over_1ms"]} frame(s)
 over 1 ms, working set {longr["working_set_MiB"]:.0f} MiB with {longr["steady_state_growth_MiB_frames_200_to_end"]} MiB growth between frame 200 and the end, every repetition of an input gives the bit-identical
-pose (fixed-order folds, deterministic cell order).
+pose (fixed-order folds, deterministic cell order). Through the two-context pipeline (`profiles/r02_long_run_pipelined.json`, {lp["frames"]} frames):
+{lp["scans_per_s_overall"]:.0f} scans/s overall, {lp["scans_per_s_per_500_frames_min_max"][0]:.0f}–{lp["scans_per_s_per_500_frames_min_max"][1]:.0f} per block of 500 frames, {lp["working_set_MiB"]:.0f} MiB for the two contexts, {"no" if lp["growth_MiB_frames_400_to_end"] == 0 else str(lp["growth_MiB_frames_400_to_end"]) + " MiB of"} growth, identical poses on every repetition.
 
 All configurations of BASELINE.json (`profiles/r02_bench.json` → `configs`; target rebuilt every frame, inputs resident, first frame
 checked against the CPU oracle; pipelined / one at a time):
