@@ -516,6 +516,12 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
     if (threadIdx.x < 3) sl[80 + threadIdx.x] = 0;
   }
   if (E - S < 10) return;  // :471
+#ifdef RGC_LAB
+  long long lab_t[5] = {0, 0, 0, 0, 0}, lab_prev = wall_clock64();
+#define FE_LAB(k) do { const long long now_ = wall_clock64(); lab_t[k] += now_ - lab_prev; lab_prev = now_; } while (0)
+#else
+#define FE_LAB(k)
+#endif
   for (int j = 0; j < 6; j++) {
     const int sp = S + (E - S) * j / 6, ep = S + (E - S) * (j + 1) / 6 - 1;  // :478-480
     const int cnt = ep - sp + 1;
@@ -534,6 +540,7 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
     }
     for (int t = threadIdx.x; t < cnt; t += SEL_T) { ks[t] = sorted_curv[sp + t]; ki[t] = sorted_icurv[sp + t]; }
     __syncthreads();
+    FE_LAB(0);
     // The reach of a pick's suppression is a property of the points alone (consecutive gaps <= 0.05 m^2, resp. intensity steps <= 35,
     // up to five on each side): computed here for every point of the sector by the whole workgroup, so that the serial pick loop
     // below reads one byte instead of testing ten gaps per pick.
@@ -552,6 +559,7 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
       wirun[t] = (signed char)(ip | (im << 4));
     }
     __syncthreads();
+    FE_LAB(1);
     if (threadIdx.x < WAVE) {
       // The three greedy passes of :487-641 by ONE WAVE.  A pass walks the sorted candidates in order and a pick suppresses
       // up to ten neighbours, so picks are sequential -- but only picks: 64 candidates at a time, every lane tests the
@@ -565,6 +573,9 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
         __builtin_amdgcn_wave_barrier();
       };
       // run: the precomputed reach of a pick's suppression at every window point (:517-533 and twins).  Returns the picks made.
+      const bool mark_right = lane < 5;
+      const int mark_off = lane < 5 ? lane + 1 : -(lane - 4);           // lanes 0..4: +1..+5, lanes 5..9: -1..-5
+      const int mark_rank = lane < 5 ? lane : (lane < 10 ? lane - 5 : 99);  // how far out this lane's mark is (99: this lane marks nothing)
       auto greedy = [&](const int* keys, bool descending, signed char* flag, int limit, auto&& static_ok, auto&& on_pick, const signed char* run) {
         int count = 0;
         bool stop = false;
@@ -573,10 +584,15 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
           const bool valid = kk < cnt;
           const int k = valid ? (descending ? cnt - 1 - kk : kk) : 0;
           const int ind = keys[k], w = ind - w0;
-          bool ok = valid && static_ok(w);
+          const bool ok = valid && static_ok(w);
           const int reach = run[w];
+          // This candidate's suppression state lives in a REGISTER for the batch: a pick marks window positions wb - nm .. wb + np, and
+          // every lane sees whether its own candidate is among them by comparing -- no LDS read (and no wait for the marks to land)
+          // inside the pick loop, which was two LDS round trips per pick (~340 cycles; 70 of the kernel's 138 us were this loop).
+          // The marks still go to LDS for the following batches and passes; one fence per batch.
+          int mine = flag[w];
           for (;;) {
-            const unsigned long long mask = __ballot(ok && flag[w] == 0);
+            const unsigned long long mask = __ballot(ok && mine == 0);
             if (!mask) break;
             count++;
             if (count > limit) { stop = true; break; }  // the reference's `else break`: not even marked
@@ -585,15 +601,15 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
             if (lane == b) {
               on_pick(count, ind, w);
               flag[w] = 1;
-              ok = false;
             }
             // the ten neighbours side by side: lanes 0..4 mark wb+1..wb+5, lanes 5..9 wb-1..wb-5, as far as the pick reaches
+            // (mark_off / mark_rank are per-lane constants: one select, one compare and one masked byte store per pick)
             const int rb = __builtin_amdgcn_readlane(reach, b);
             const int np = rb & 15, nm = rb >> 4;
-            const int l = lane < 5 ? lane + 1 : -(lane - 4);
-            if (lane < 5 ? lane < np : (lane < 10 && lane - 5 < nm)) flag[wb + l] = 1;
-            wave_fence();
+            if (mark_rank < (mark_right ? np : nm)) flag[wb + mark_off] = 1;
+            if (w >= wb - nm && w <= wb + np) mine = 1;
           }
+          wave_fence();
         }
         return count > limit ? limit : count;
       };
@@ -614,12 +630,17 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
       if (lane == 0) { sl[80] = nsh; sl[81] = nfl; sl[82] = nin_picks > 20 ? 20 : nin_picks; }
     }
     __syncthreads();
+    FE_LAB(2);
     for (int t = threadIdx.x; t < wn; t += SEL_T) {  // flags back to memory: the next sector's window overlaps this one's margin
       const int g = w0 + t;
       picked[g] = wpick[t]; ipicked[g] = wipick[t];
       label[g] = wlab[t]; ilabel[g] = wilab[t];
     }
+    FE_LAB(3);
   }
+#ifdef RGC_LAB
+  if (threadIdx.x == 0 && ring == 3) printf("k_fe_select ring 3 (10 ns units): load %lld reach %lld greedy %lld writeback %lld\n", lab_t[0], lab_t[1], lab_t[2], lab_t[3]);
+#endif
 }
 
 // A8: emit the feature clouds in the reference's order (ring, sector, pick order): x,y,z,intensity,normal_x weight.
