@@ -535,3 +535,33 @@ def test_cpp_pipelined_sequence(reg_mod, tmp_path):
         T = np.array([float(x) for x in lines[f"T{i}"].split()], np.float32).reshape(4, 4)
         assert np.array_equal(T, g), (i, T, g)
     v.close()
+
+
+def test_pipelined_sequence_with_speculative_grid_misses(reg_mod):
+    """A scan that leaves the speculative grid of its context (a far stray return) in the middle of a pipelined sequence: the solve is
+    redone on the scan's own bounding box inside align_end, while the other context's preparation is in flight; poses equal one frame at
+    a time on a fresh context that measures every bounding box (RGC_SPEC_GRID=0 semantics are the same results by construction)."""
+    import rgc_slam_amd.synth as synth
+    world, tgt = synth.make_world_and_map(60000, seed=synth.SEED + 21)
+    poses = synth.make_trajectory(9, seed=synth.SEED + 21)
+    scans = [synth.make_scan_n(world, poses[i + 1], 10000, seed=synth.SEED + 900 + i)["xyz"] for i in range(8)]
+    for i, far in ((3, [400.0, -350.0, 20.0]), (4, [-500.0, 10.0, -30.0]), (6, [0.0, 600.0, 5.0])):
+        scans[i] = np.concatenate([scans[i], np.asarray([far], np.float32)]).astype(np.float32)
+    v = _odo(reg_mod)
+    g, seq = poses[0].astype(np.float32), []
+    for s in scans:
+        v.setInputTarget(tgt)
+        v.setInputSource(s)
+        v.align(g, want_output=False, want_fitness=True)
+        g = v.getFinalTransformation()
+        seq.append((g, v.getFitnessScore()))
+    v.close()
+    pv = reg_mod.PipelinedVGICP(0, depth=2)
+    fits = []
+    def setc(i, w):
+        w.setInputTarget(tgt)
+        w.setInputSource(scans[i])
+    out = pv.run(len(scans), setc, poses[0].astype(np.float32), want_fitness=True, on_result=lambda i, w: fits.append(w.getFitnessScore()))
+    pv.close()
+    for i, (T, f) in enumerate(zip(out, fits)):
+        assert np.array_equal(T, seq[i][0]) and f == seq[i][1], i
