@@ -1187,10 +1187,14 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
   // (S.src_sq == 0: this scan's figure was consumed by an earlier solve on the same clouds -- the first step hands the counter back
   // zeroed -- and the steering it caused stands)
   if (S.src_sq > 0.f) c->stats.source_crowding = c->src.n > 0 ? (double)S.src_sq / (double)c->src.n : 0.0;
-  if (S.src_sq > 0.f && c->src_res <= 0.0 && c->src.n > 0) {  // steer the next scan's cell size: halve above 300 points per own cell, double below 40
+  // steer the next scan's cell size: halve above 500 points per own cell, double below 40.  (With four lanes per query a crowded cell is
+  // cheap and a fine grid's far field -- every sparse query deferred to the cooperative kernel -- is what costs: an HDL-64 sweep,
+  // 1270 / 380 / 107 at 1 / 0.5 / 0.25 m, is fastest at 0.5 m (c3 529 -> 594 scans/s against the former threshold of 300, which took it
+  // to 0.25 m); two fused 64-beam sweeps, 2420 / 720 / 201, still want 0.25 m (184 against 139 scans/s at 0.5 m).)
+  if (S.src_sq > 0.f && c->src_res <= 0.0 && c->src.n > 0) {
     const double cur = c->src.grid.res, crowd = c->stats.source_crowding;
     double next = cur;
-    if (crowd > 300.0 && cur > 0.26 * c->prm.voxel_res) next = cur * 0.5;
+    if (crowd > 500.0 && cur > 0.26 * c->prm.voxel_res) next = cur * 0.5;
     else if (crowd < 40.0 && cur < c->prm.voxel_res) next = std::fmin(cur * 2.0, c->prm.voxel_res);
     c->src_res_auto = next;
   }
