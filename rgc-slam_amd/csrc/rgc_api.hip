@@ -111,7 +111,10 @@ struct rgc_ctx {
   double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
   double src_res_auto = 0.0;  // adaptive cell size of the scan's kNN grid, steered by how crowded its cells were in the previous frame (0 = voxel_res)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
-  DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos;  // B2/B3/B9 staging
+  DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos, vg_tmp, vg_leaf;  // B2/B3/B9 staging
+  struct VgBox { float leaf = 0.f; bool valid = false; rgck::LeafGrid g{}; } vg_box[4];  // padded leaf boxes of earlier clouds, by leaf size
+  int vg_box_next = 0;
+  bool vg_flags_clean = false;  // d_small[24 + 6] is known to be zero (a finished rows chain leaves it so)
   DevBuf fe[34];              // front-end buffers
   unsigned char* h_stage = nullptr;  // pinned staging of the front-end's small read-backs and feature clouds (a copy into pageable
   size_t h_stage_cap = 0;            // memory is staged by the runtime anyway, one blocking hop per call)
@@ -954,7 +957,7 @@ void rgc_destroy(rgc_ctx* c) {
   release(c->mr_small);
   for (DevBuf& b : c->fe) release(b);
   for (DevBuf* b : {&c->map_store[0], &c->map_store[1], &c->map_target}) release(*b);
-  for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->corr_v2, &c->corr_M2, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_first, &c->vg_pos}) release(*b);
+  for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->corr_v2, &c->corr_M2, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_first, &c->vg_pos, &c->vg_tmp, &c->vg_leaf}) release(*b);
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1458,6 +1461,48 @@ int rgc_transform_cloud(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, 
   return RGC_OK;
 }
 
+// The rows chain of the leaf filter on box g (rgc_pre.hip); one read-back: *flags (bits as rgck::vg_rows documents) and *n_out.
+static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, float inv, const rgck::LeafGrid& g, int edge, float* d_out, int* flags,
+                          int* n_out) {
+  hipStream_t s = c->stream;
+  int* dsm = c->d_small + 24;
+  int* hsm = c->h_small + 24;
+  Cloud& cl = c->aux;
+  int rc;
+  const size_t nr1 = (size_t)g.div[1] * (size_t)g.div[2] + 1;
+  if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;                                                    // row of every point
+  if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;                                                    // leaf x of every point
+  if ((rc = ensure(c, c->vg_pos, sizeof(int) * n))) return rc;                                                     // arrival slot, then output number
+  if ((rc = ensure(c, c->vg_order, sizeof(int) * n))) return rc;
+  if ((rc = ensure(c, c->vg_tmp, sizeof(long long) * n))) return rc;
+  if ((rc = ensure(c, c->vg_leaf, sizeof(long long) * n))) return rc;
+  if ((rc = ensure(c, cl.cnt, sizeof(int) * nr1))) return rc;
+  if ((rc = ensure(c, cl.start, sizeof(int) * nr1))) return rc;
+  const size_t row_bs = sizeof(long long) * (nr1 / 2048 + 2);
+  if ((rc = ensure(c, cl.block_sums, row_bs + sizeof(int) * ((size_t)n / 2048 + 2)))) return rc;
+  if (cl.cnt.p != cl.cnt_seen) { cl.cnt_clean = 0; cl.cnt_seen = cl.cnt.p; }
+  if (cl.cnt_clean < nr1) {  // afterwards the scan leaves the counters it consumed at zero: no fill per call
+    const size_t fill = std::min(cl.cnt.cap, (sizeof(int) * nr1 + 255) & ~(size_t)255);
+    HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, fill, s));
+  }
+  cl.cnt_clean = nr1;
+  if (!c->vg_flags_clean) HIPCHK(c, hipMemsetAsync(dsm + 6, 0, sizeof(int), s));
+  c->vg_flags_clean = false;
+  rgck::vg_rows(s, d_in, stride_f, n, inv, g, edge, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)c->vg_pos.p, (int*)cl.cnt.p, (int*)cl.start.p,
+                cl.block_sums.p, (unsigned long long*)c->vg_tmp.p, (int*)c->vg_order.p, (unsigned long long*)c->vg_leaf.p,
+                (int*)((char*)cl.block_sums.p + row_bs), d_out, dsm + 5);
+  HIPCHK(c, hipMemcpyAsync(hsm + 5, dsm + 5, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  c->vg_flags_clean = true;
+  *flags = hsm[5];
+  *n_out = hsm[7];
+  return RGC_OK;
+}
+static bool vg_rows_fit(const rgck::LeafGrid& g, int n) {  // sparse enough for the rows chain, small enough for its one-level block sums
+  const double ncell = (double)g.div[0] * (double)g.div[1] * (double)g.div[2], nrows = (double)g.div[1] * (double)g.div[2];
+  return ncell <= 2147483647.0 && ncell > 64.0 * (double)n && nrows <= 64.0e6 && n <= 2048 * 4096;
+}
+
 int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float leaf, float* out_xyzi, int* n_out, int on_device) {
   if (!c || !xyzi || !out_xyzi || !n_out || n < 0) return RGC_ERR_INVALID;
   if (stride_bytes < 12 || (stride_bytes & 3) || !(leaf > 0.f)) return fail(c, RGC_ERR_INVALID, "bad stride or leaf size");
@@ -1472,52 +1517,64 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
   const float inv = 1.0f / leaf;  // inverse_leaf_size_
   int* dsm = c->d_small + 24;
   int* hsm = c->h_small + 24;
-  int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
-  memcpy(hsm, init, sizeof(init));
-  HIPCHK(c, hipMemcpyAsync(dsm, hsm, sizeof(init), hipMemcpyHostToDevice, s));
-  rgck::vg_bbox(s, d_in, stride_f, n, inv, dsm, dsm + 6);
-  HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "cloud contains non-finite coordinates (PCL skips them; remove NaNs first)");
-  rgck::LeafGrid g{};
-  double ncell = 1.0;
-  for (int a = 0; a < 3; a++) { g.minb[a] = hsm[a]; g.div[a] = hsm[3 + a] - hsm[a] + 1; ncell *= (double)g.div[a]; }
   float* d_out = out_xyzi;
   if (!on_device) {
     if ((rc = ensure(c, c->pre_out, sizeof(float) * 4 * (size_t)n))) return rc;
     d_out = (float*)c->pre_out.p;
   }
-  if (ncell > 2147483647.0) {
-    // PCL: "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
-    rgck::transform_q(s, d_in, stride_f, n, rgck::Quat{0, 0, 0, 1}, (const double[3]){0, 0, 0}, d_out, 4);
-    *n_out = n;
-  } else {
-    Cloud& cl = c->aux;
-    if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, c->vg_order, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, c->vg_first, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, c->vg_pos, sizeof(int) * n))) return rc;
-    const double nrows = (double)g.div[1] * (double)g.div[2];
-    if (ncell > 64.0 * (double)n && nrows <= 64.0e6) {
-      // sparse leaf grid: counting sort over the (y, z) rows, rank by (leaf x, point index) inside a row
-      const size_t nr1 = (size_t)nrows + 1;
-      if ((rc = ensure(c, cl.cnt, sizeof(int) * nr1))) return rc;
-      if ((rc = ensure(c, cl.start, sizeof(int) * nr1))) return rc;
-      if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nr1 / 2048 + (size_t)n / 2048 + 4)))) return rc;
-      if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;   // leaf x of every point
-      if ((rc = ensure(c, cl.P, sizeof(int) * n))) return rc;         // leaf x in sorted order
-      cl.cnt_clean = 0;
-      HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nr1, s));
-      rgck::vg_count_rows(s, d_in, stride_f, n, inv, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, (int*)c->vg_pos.p);
-      rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nr1, (int*)cl.block_sums.p);
-      rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)c->vg_pos.p, (const int*)cl.start.p, (int*)cl.order_tmp.p);
-      rgck::vg_rank_rows(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
-                         (int*)c->vg_order.p, (int*)cl.P.p, (int*)c->vg_first.p);
-      rgck::exclusive_scan(s, (const int*)c->vg_first.p, (int*)c->vg_pos.p, n, (int*)cl.block_sums.p);
-      rgck::vg_centroid_rows(s, d_in, stride_f, n, (const int*)c->vg_order.p, (const int*)c->vg_first.p, (const int*)c->vg_pos.p, d_out, dsm + 7);
+  constexpr int kPad = 32;  // leaves added on every side of a measured box when it is kept for the next cloud of this leaf size
+  rgc_ctx::VgBox* box = nullptr;
+  for (auto& b : c->vg_box) if (b.leaf == leaf) box = &b;
+  bool done = false;
+  if (box && box->valid && vg_rows_fit(box->g, n)) {
+    // the box of an earlier cloud: no bounding-box pass, no read-back before the filter (the frames of a sequence span the same volume)
+    int flags = 0, no = 0;
+    if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, box->g, kPad / 2, d_out, &flags, &no))) return rc;
+    if (flags & 1) return fail(c, RGC_ERR_NONFINITE, "cloud contains non-finite coordinates (PCL skips them; remove NaNs first)");
+    if (flags & 6) box->valid = false;  // outside: measure and repeat now; near a face: measure at the next call
+    if (!(flags & 2)) { *n_out = no; done = true; }
+  }
+  if (!done) {
+    int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+    memcpy(hsm, init, sizeof(init));
+    c->vg_flags_clean = false;
+    HIPCHK(c, hipMemcpyAsync(dsm, hsm, sizeof(init), hipMemcpyHostToDevice, s));
+    rgck::vg_bbox(s, d_in, stride_f, n, inv, dsm, dsm + 6);
+    HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (hsm[6]) return fail(c, RGC_ERR_NONFINITE, "cloud contains non-finite coordinates (PCL skips them; remove NaNs first)");
+    c->vg_flags_clean = true;
+    rgck::LeafGrid g{};
+    double ncell = 1.0;
+    for (int a = 0; a < 3; a++) { g.minb[a] = hsm[a]; g.div[a] = hsm[3 + a] - hsm[a] + 1; ncell *= (double)g.div[a]; }
+    {  // keep the padded box for the next cloud of this leaf size
+      if (!box) { box = &c->vg_box[c->vg_box_next]; c->vg_box_next = (c->vg_box_next + 1) % 4; box->leaf = leaf; }
+      rgck::LeafGrid pg{};
+      bool ok = true;
+      for (int a = 0; a < 3; a++) {
+        if (g.minb[a] < -1000000000 || g.div[a] > 1000000000) ok = false;
+        pg.minb[a] = g.minb[a] - kPad;
+        pg.div[a] = g.div[a] + 2 * kPad;
+      }
+      box->g = pg;
+      box->valid = ok && vg_rows_fit(pg, n);
+    }
+    if (ncell > 2147483647.0) {
+      // PCL: "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
+      rgck::transform_q(s, d_in, stride_f, n, rgck::Quat{0, 0, 0, 1}, (const double[3]){0, 0, 0}, d_out, 4);
+      *n_out = n;
+      HIPCHK(c, hipStreamSynchronize(s));
+    } else if (vg_rows_fit(g, n)) {
+      int flags = 0;
+      if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, g, 0, d_out, &flags, n_out))) return rc;
     } else {
+      Cloud& cl = c->aux;
       if (ncell > (double)c->prm.max_cells) return fail(c, RGC_ERR_GRID_TOO_LARGE, "leaf grid %d x %d x %d exceeds max_cells", g.div[0], g.div[1], g.div[2]);
+      if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
+      if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
+      if ((rc = ensure(c, c->vg_order, sizeof(int) * n))) return rc;
+      if ((rc = ensure(c, c->vg_first, sizeof(int) * n))) return rc;
+      if ((rc = ensure(c, c->vg_pos, sizeof(int) * n))) return rc;
       const size_t nc1 = (size_t)ncell + 1;
       if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1))) return rc;
       if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
@@ -1531,13 +1588,15 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
       rgck::exclusive_scan(s, (const int*)c->vg_first.p, (int*)c->vg_pos.p, n, (int*)cl.block_sums.p);
       rgck::vg_centroid(s, d_in, stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)c->vg_order.p,
                         (const int*)c->vg_first.p, (const int*)c->vg_pos.p, d_out, dsm + 7);
+      HIPCHK(c, hipMemcpyAsync(hsm + 7, dsm + 7, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      *n_out = hsm[7];
     }
-    HIPCHK(c, hipMemcpyAsync(hsm + 7, dsm + 7, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    *n_out = hsm[7];
   }
-  if (!on_device) HIPCHK(c, hipMemcpyAsync(out_xyzi, d_out, sizeof(float) * 4 * (size_t)*n_out, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
+  if (!on_device) {
+    HIPCHK(c, hipMemcpyAsync(out_xyzi, d_out, sizeof(float) * 4 * (size_t)*n_out, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
   HIPCHK(c, hipGetLastError());
   return RGC_OK;
 }

@@ -121,11 +121,13 @@ void transform_q(hipStream_t s, const float* in, int stride_f, int n, Quat q, co
 void vg_bbox(hipStream_t s, const float* in, int stride_f, int n, float inv, int* mm6, int* flags);
 void vg_count(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* cell_of, int* cnt);
 void vg_rank(hipStream_t s, int n, const int* cell_of, const int* start, const int* order_tmp, int* order, int* first);
-// sparse leaf grids: counting sort over (y, z) rows, rank by (leaf x, index) inside a row; key = n ints of scratch
-void vg_count_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* row_of, int* lx, int* cnt, int* slot);
-void vg_rank_rows(hipStream_t s, int n, const int* row_of, const int* lx, const int* start, const int* order_tmp, int* order, int* key, int* first);
-void vg_centroid_rows(hipStream_t s, const float* in, int stride_f, int n, const int* order, const int* first, const int* outpos, float* out,
-                      int* n_out);
+// sparse leaf grids: counting sort over (y, z) rows, rank by (leaf x, index) inside a row -- the whole filter as one chain of launches.
+// edge > 0: g is a box kept from an earlier cloud (see rgc_pre.hip).  res[0] <- flags of this run (1 non-finite point, 2 point outside g,
+// 4 point within `edge` leaves of g's faces), res[1] = the live flag word (must be 0 on entry, is 0 on exit), res[2] <- number of leaves.
+// row_block_sums: 8 bytes x (rows / 2048 + 2); head_block_sums: n / 2048 + 2 ints (n <= 2048 * 4096); cnt: rows + 1 zeros, left at zero.
+void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int* row_of, int* lx, int* slot_then_pos, int* cnt,
+             int* start, void* row_block_sums, unsigned long long* tmp, int* order, unsigned long long* leaf, int* head_block_sums, float* out,
+             int* res);
 void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start, const int* order,
                  const int* first, const int* outpos, float* out, int* n_out);
 

@@ -152,55 +152,161 @@ __global__ void k_vg_centroid(const float* __restrict__ in, int stride_f, int n,
 // dense leaf array was most of the filter's time).  Leaves are ordered by idx = i + j dx + k dx dy, i.e. by (k, j) row first and by i
 // inside the row: the counting sort runs over the ROWS (dy x dz entries, tens of thousands), and inside a row the points are ranked by
 // (i, point index) -- rows hold few points when the grid is sparse.  Same output, bit for bit.
-__global__ void k_vg_count_rows(const float* __restrict__ in, int stride_f, int n, float inv, LeafGrid g, int* __restrict__ row_of,
-                                int* __restrict__ lx, int* cnt, int* __restrict__ slot) {
+//
+// The order of the leaves -- (k, j, i) lexicographic -- does not depend on WHICH box the grid spans, only that it holds every point: the
+// filter may therefore run on a box kept from the previous cloud of the same leaf size (padded), without asking the host for this
+// cloud's bounding box first.  `edge` > 0 marks such a speculative box: a point outside it sets flag bit 1 (the host repeats the filter
+// with the exact box), a point within `edge` leaves of its faces sets bit 2 (the next call measures the box again); a non-finite point
+// sets bit 0 in either mode.  Seven launches, one read-back: count, scan of the rows (two launches, the counters are left at zero for
+// the next cloud), placement, rank, leaf heads + their block scan, centroids.
+constexpr int VG_SCAN_T = 256, VG_SCAN_V = 8, VG_SCAN_B = VG_SCAN_T * VG_SCAN_V;
+
+__global__ void __launch_bounds__(256)
+k_vg_rows_count(const float* __restrict__ in, int stride_f, int n, float inv, LeafGrid g, int edge, int* __restrict__ row_of, int* __restrict__ lx,
+                int* cnt, int* __restrict__ slot, int* flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const bool valid = i < n;
+  int r = -1 - lane;  // lanes past the end: distinct negative keys, they never extend a neighbour's run
+  bool near = false;
+  if (valid) {
+    const float* p = in + (size_t)i * stride_f;
+    const float x = p[0], y = p[1], z = p[2];
+    const bool fin = fabsf(x * inv) <= 1.0e9f && fabsf(y * inv) <= 1.0e9f && fabsf(z * inv) <= 1.0e9f;  // false for NaN / inf too
+    int cx = fin ? leaf_coord(x, inv) - g.minb[0] : 0, cy = fin ? leaf_coord(y, inv) - g.minb[1] : 0, cz = fin ? leaf_coord(z, inv) - g.minb[2] : 0;
+    const bool inside = cx >= 0 && cx < g.div[0] && cy >= 0 && cy < g.div[1] && cz >= 0 && cz < g.div[2];
+    if (!fin || !inside) {  // parked in leaf 0 so that nothing is written out of bounds; the host discards the result
+      atomicOr(flags, fin ? 2 : 1);
+      cx = cy = cz = 0;
+    } else {
+      near = cx < edge || cx >= g.div[0] - edge || cy < edge || cy >= g.div[1] - edge || cz < edge || cz >= g.div[2] - edge;
+    }
+    r = cy + cz * g.div[1];
+    row_of[i] = r;
+    lx[i] = cx;
+  }
+  const unsigned long long nm = __ballot(near);
+  if (nm && lane == __ffsll((long long)nm) - 1) atomicOr(flags, 4);
+  // consecutive points of a sweep fall into the same row: one atomicAdd per RUN of equal rows inside the wave, not one per point
+  // (same-address atomics cost ~12 ns each on this part); the returned count is the run's first arrival-order slot inside its row.
+  const int prev = __shfl_up(r, 1);
+  const bool head = lane == 0 || r != prev;
+  const unsigned long long hm = __ballot(head);
+  const int head_lane = 63 - __clzll(hm & ((2ull << lane) - 1ull));
+  const unsigned long long above = head_lane == 63 ? 0ull : (hm >> (head_lane + 1));
+  const int run_len = above ? __ffsll((long long)above) : WAVE - head_lane;
+  int base = 0;
+  if (head && valid) base = atomicAdd(&cnt[r], run_len);
+  base = __shfl(base, head_lane);
+  if (valid) slot[i] = base + (lane - head_lane);
+}
+// arrival-order placement: tmp[row start + slot] = (leaf x, point index) packed, the key the rank compares
+__global__ void k_vg_rows_place(int n, const int* __restrict__ row_of, const int* __restrict__ lx, const int* __restrict__ slot,
+                                const int* __restrict__ start, unsigned long long* __restrict__ tmp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float* p = in + (size_t)i * stride_f;
-  const int r = (leaf_coord(p[1], inv) - g.minb[1]) + (leaf_coord(p[2], inv) - g.minb[2]) * g.div[1];
-  row_of[i] = r;
-  lx[i] = leaf_coord(p[0], inv) - g.minb[0];
-  slot[i] = atomicAdd(&cnt[r], 1);  // arrival order inside the row: the placement needs no second atomic
+  tmp[start[row_of[i]] + slot[i]] = ((unsigned long long)(unsigned)lx[i] << 32) | (unsigned)i;
 }
-// final slot of a point = row start + number of same-row points that precede it in (leaf x, point index) order; key[slot] = its leaf x
-__global__ void k_vg_rank_rows(int n, const int* __restrict__ row_of, const int* __restrict__ lx, const int* __restrict__ start,
-                               const int* __restrict__ order_tmp, int* __restrict__ order, int* __restrict__ key) {
+// final slot of a point = row start + number of same-row points that precede it in (leaf x, point index) order;
+// order[slot] = point index, leaf[slot] = (row, leaf x) packed: equal values = same leaf
+__global__ void k_vg_rows_rank(int n, const int* __restrict__ row_of, const int* __restrict__ start, const unsigned long long* __restrict__ tmp,
+                               int* __restrict__ order, unsigned long long* __restrict__ leaf) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  const int i = order_tmp[s];
-  const int r = row_of[i], x = lx[i];
+  const unsigned long long me = tmp[s];
+  const int i = (int)(unsigned)me;
+  const int r = row_of[i];
   const int s0 = start[r], s1 = start[r + 1];
-  int rank = 0;
-  for (int t = s0; t < s1; t++) {
-    const int j = order_tmp[t], xj = lx[j];
-    rank += (xj < x || (xj == x && j < i)) ? 1 : 0;
+  int rank = 0, t = s0;
+  for (; t + 8 <= s1; t += 8) {  // eight independent loads in flight: a ring of the sweep inside one row is hundreds of members
+    unsigned long long o[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) o[u] = tmp[t + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) rank += (o[u] < me);
   }
+  for (; t < s1; t++) rank += (tmp[t] < me);
   order[s0 + rank] = i;
-  key[s0 + rank] = x;
+  leaf[s0 + rank] = ((unsigned long long)(unsigned)r << 32) | (me >> 32);
 }
-// first[s] = 1 where a new leaf begins in the sorted order (new row or new leaf x)
-__global__ void k_vg_first_rows(int n, const int* __restrict__ row_of, const int* __restrict__ order, const int* __restrict__ key,
-                                int* __restrict__ first) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  first[s] = (s == 0 || key[s] != key[s - 1] || row_of[order[s]] != row_of[order[s - 1]]) ? 1 : 0;
+// pos[s] = number of leaf heads before s inside this block of 2048 sorted slots; block_sums[b] = heads in block b
+__global__ void __launch_bounds__(VG_SCAN_T)
+k_vg_rows_heads(const unsigned long long* __restrict__ leaf, int n, int* __restrict__ pos, int* __restrict__ block_sums) {
+  __shared__ int wsum[VG_SCAN_T / WAVE];
+  const int base = blockIdx.x * VG_SCAN_B + threadIdx.x * VG_SCAN_V;
+  unsigned long long prev = (base > 0 && base <= n) ? leaf[base - 1] : ~0ull;
+  int v[VG_SCAN_V], sum = 0;
+#pragma unroll
+  for (int j = 0; j < VG_SCAN_V; j++) {
+    v[j] = 0;
+    if (base + j < n) {
+      const unsigned long long cur = leaf[base + j];
+      v[j] = (base + j == 0 || cur != prev) ? 1 : 0;
+      prev = cur;
+    }
+    sum += v[j];
+  }
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == WAVE - 1) wsum[w] = inc;
+  __syncthreads();
+  int before = 0, tot = 0;
+#pragma unroll
+  for (int j = 0; j < VG_SCAN_T / WAVE; j++) {
+    if (j < w) before += wsum[j];
+    tot += wsum[j];
+  }
+  int ex = before + inc - sum;
+#pragma unroll
+  for (int j = 0; j < VG_SCAN_V; j++) {
+    if (base + j < n) pos[base + j] = ex;
+    ex += v[j];
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
-__global__ void k_vg_centroid_rows(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ order, const int* __restrict__ first,
-                                   const int* __restrict__ outpos, float* __restrict__ out, int* n_out) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+// one lane per sorted slot; the head of a leaf sums its points in ascending point index (fp32, like the dense path) and writes output
+// number pos + (heads in the scan blocks before this one), which every workgroup adds up for itself (<= 4096 values).
+// res[0] = the flags of this run (and the live word res[1] goes back to zero for the next run), res[2] = number of leaves.
+__global__ void __launch_bounds__(256)
+k_vg_rows_centroid(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ order, const unsigned long long* __restrict__ leaf,
+                   const int* __restrict__ pos, const int* __restrict__ block_sums, float* __restrict__ out, int* res) {
+  __shared__ int part[256 / WAVE];
+  const int sb = (int)((blockIdx.x * 256u) / VG_SCAN_B);
+  int acc = 0;
+  for (int j = threadIdx.x; j < sb; j += 256) acc += block_sums[j];
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & (WAVE - 1)) == 0) part[threadIdx.x / WAVE] = acc;
+  __syncthreads();
+  int pre = 0;
+#pragma unroll
+  for (int w = 0; w < 256 / WAVE; w++) pre += part[w];
+  const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= n) return;
-  if (s == n - 1) *n_out = outpos[s] + first[s];
-  if (!first[s]) return;
+  const unsigned long long me = leaf[s];
+  const bool head = s == 0 || leaf[s - 1] != me;
+  const int op = pos[s] + pre;
+  if (s == n - 1) {
+    res[2] = op + (head ? 1 : 0);
+    res[0] = res[1];
+    res[1] = 0;
+  }
+  if (!head) return;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int t = s;
-  do {  // the leaf's points in ascending point index, like the dense path
+  do {
     const float* p = in + (size_t)order[t] * stride_f;
     a0 += p[0]; a1 += p[1]; a2 += p[2];
     a3 += stride_f > 3 ? p[3] : 0.f;
     t++;
-  } while (t < n && !first[t]);
+  } while (t < n && leaf[t] == me);
   const float cnt = (float)(t - s);
-  float* o = out + (size_t)outpos[s] * 4;
+  float* o = out + (size_t)op * 4;
   o[0] = a0 / cnt; o[1] = a1 / cnt; o[2] = a2 / cnt; o[3] = a3 / cnt;
 }
 
@@ -221,16 +327,16 @@ void vg_count(hipStream_t s, const float* in, int stride_f, int n, float inv, Le
 void vg_rank(hipStream_t s, int n, const int* cell_of, const int* start, const int* order_tmp, int* order, int* first) {
   hipLaunchKernelGGL(k_vg_rank, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, start, order_tmp, order, first);
 }
-void vg_count_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* row_of, int* lx, int* cnt, int* slot) {
-  hipLaunchKernelGGL(k_vg_count_rows, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, inv, g, row_of, lx, cnt, slot);
-}
-void vg_rank_rows(hipStream_t s, int n, const int* row_of, const int* lx, const int* start, const int* order_tmp, int* order, int* key, int* first) {
-  hipLaunchKernelGGL(k_vg_rank_rows, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, lx, start, order_tmp, order, key);
-  hipLaunchKernelGGL(k_vg_first_rows, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, order, key, first);
-}
-void vg_centroid_rows(hipStream_t s, const float* in, int stride_f, int n, const int* order, const int* first, const int* outpos, float* out,
-                      int* n_out) {
-  hipLaunchKernelGGL(k_vg_centroid_rows, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, order, first, outpos, out, n_out);
+void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int* row_of, int* lx, int* slot_then_pos, int* cnt,
+             int* start, void* row_block_sums, unsigned long long* tmp, int* order, unsigned long long* leaf, int* head_block_sums, float* out,
+             int* res) {
+  const int nr1 = g.div[1] * g.div[2] + 1;
+  hipLaunchKernelGGL(k_vg_rows_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, inv, g, edge, row_of, lx, cnt, slot_then_pos, res + 1);
+  scan_cells(s, cnt, start, nr1, row_block_sums, nullptr, nullptr, 0, nullptr);
+  hipLaunchKernelGGL(k_vg_rows_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, lx, slot_then_pos, start, tmp);
+  hipLaunchKernelGGL(k_vg_rows_rank, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, start, tmp, order, leaf);
+  hipLaunchKernelGGL(k_vg_rows_heads, dim3(nblk(n, VG_SCAN_B)), dim3(VG_SCAN_T), 0, s, leaf, n, slot_then_pos, head_block_sums);
+  hipLaunchKernelGGL(k_vg_rows_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, order, leaf, slot_then_pos, head_block_sums, out, res);
 }
 void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start, const int* order,
                  const int* first, const int* outpos, float* out, int* n_out) {

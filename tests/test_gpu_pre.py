@@ -41,6 +41,41 @@ def test_voxelgrid_vs_oracle_bit_exact(pre, orc):
     assert one.shape == (1, 4) or one.shape == (2, 4) or one.shape[0] <= 8
 
 
+def test_voxelgrid_box_kept_from_the_previous_cloud(orc):
+    """The filter re-uses the (padded) leaf box of the previous cloud of the same leaf size: clouds that stay inside it, drift to its
+    faces, jump out of it, carry a NaN, or turn dense must all give the oracle's output bit for bit."""
+    from rgc_slam_amd import odometry, _lib
+    p = odometry.Preprocessor(0)
+    try:
+        base = _scan()
+        rng = np.random.default_rng(5)
+        def check(xyzi, leaf):
+            got, exp = p.voxelGridFilter(xyzi, leaf), orc.voxelgrid_filter(xyzi, leaf)
+            assert got.shape == exp.shape and np.array_equal(got, exp)
+        for leaf in (0.2, 0.3):
+            check(base, leaf)                       # measures the box
+            check(base, leaf)                       # inside the kept box
+            check(_scan(seed=4), leaf)              # another sweep of the same volume
+        shift = base.copy(); shift[:, 0] += 4.5     # 22 leaves of 0.2 m: inside the padded box, within 16 leaves of its face
+        check(shift, 0.2); check(shift, 0.2)
+        far = base.copy(); far[:, :3] += np.float32([60.0, -35.0, 8.0])   # outside the kept box: repeated with the measured one
+        check(far, 0.2); check(far, 0.2)
+        check(base, 0.3)                            # the other leaf size kept its own box
+        bad = base.copy(); bad[7, 1] = np.nan
+        with pytest.raises(_lib.RgcError):
+            p.voxelGridFilter(bad, 0.2)
+        check(far, 0.2)                             # the error left nothing behind
+        dense = (rng.random((200000, 4)) * np.float32([6.0, 6.0, 2.0, 1.0])).astype(np.float32)   # 30 x 30 x 10 leaves: the dense path
+        check(dense, 0.2)
+        check(base, 0.2)
+        few = base[:40]                             # fewer points than one wave
+        check(few, 0.2)
+        big = np.concatenate([base + np.float32([0.01 * k, 0, 0, 0]) for k in range(12)])          # 12 sweeps on top of each other: crowded rows
+        check(big, 0.2)
+    finally:
+        p.close()
+
+
 def test_deskew_vs_oracle(pre, orc):
     import rgc_slam_amd.synth as synth
     xyzi = _scan()
