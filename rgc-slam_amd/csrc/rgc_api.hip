@@ -109,6 +109,8 @@ struct rgc_ctx {
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
   double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
+  int map_wide_r = 2;             // RGC_MAP_WIDE_R (0 = off, 2, 3): block radius of the bulk kNN launch for a sparse map
+  double map_wide_density = 0.25; // RGC_MAP_WIDE: ... when the map has fewer points per grid cell than this
   double src_res_auto = 0.0;  // adaptive cell size of the scan's kNN grid, steered by how crowded its cells were in the previous frame (0 = voxel_res)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos, vg_tmp, vg_leaf;  // B2/B3/B9 staging
@@ -379,8 +381,10 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   }
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n, s);
+    // a sparse map (points per cell of its grid below map_wide_density): the wider block, see k_knn_sp_wide
+    const int wide_r = (is_target && c->map_wide_r > 0 && (double)n < c->map_wide_density * (double)cl.grid.ncell) ? c->map_wide_r : 0;
     rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
-                   (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr);
+                   (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r);
   }
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COOP : RGC_K_KNN_COOP_SRC, n, s);
@@ -930,6 +934,8 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
+  if (const char* e = getenv("RGC_MAP_WIDE_R")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 3) c->map_wide_r = v; }
+  if (const char* e = getenv("RGC_MAP_WIDE")) { const double v = atof(e); if (v >= 0.0 && std::isfinite(v)) c->map_wide_density = v; }
   if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
   if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
@@ -1190,7 +1196,10 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
   // (S.src_sq == 0: this scan's figure was consumed by an earlier solve on the same clouds -- the first step hands the counter back
   // zeroed -- and the steering it caused stands)
   if (S.src_sq > 0.f) c->stats.source_crowding = c->src.n > 0 ? (double)S.src_sq / (double)c->src.n : 0.0;
-  // steer the next scan's cell size: halve above 500 points per own cell, double below 40.  (With four lanes per query a crowded cell is
+  // steer the next scan's cell size: halve above 500 points per own cell, double below 40 -- up to twice the voxel size, which is where a
+  // 0.2 m leaf-filtered VLP-16 sweep (the odometer's source cloud) ends up: fewer of its far-field queries go to the cooperative
+  // kernel (frame body 0.76 -> 0.73 ms); a raw VLP-16 sweep (117) stays at the voxel size (2837 scans/s against 2683 at twice that).
+  // (With four lanes per query a crowded cell is
   // cheap and a fine grid's far field -- every sparse query deferred to the cooperative kernel -- is what costs: an HDL-64 sweep,
   // 1270 / 380 / 107 at 1 / 0.5 / 0.25 m, is fastest at 0.5 m (c3 529 -> 594 scans/s against the former threshold of 300, which took it
   // to 0.25 m); two fused 64-beam sweeps, 2420 / 720 / 201, still want 0.25 m (184 against 139 scans/s at 0.5 m).)
@@ -1198,7 +1207,7 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
     const double cur = c->src.grid.res, crowd = c->stats.source_crowding;
     double next = cur;
     if (crowd > 500.0 && cur > 0.26 * c->prm.voxel_res) next = cur * 0.5;
-    else if (crowd < 40.0 && cur < c->prm.voxel_res) next = std::fmin(cur * 2.0, c->prm.voxel_res);
+    else if (crowd < 40.0 && cur < 2.0 * c->prm.voxel_res) next = std::fmin(cur * 2.0, 2.0 * c->prm.voxel_res);  // a leaf-filtered sweep: 2 x voxel size
     c->src_res_auto = next;
   }
   c->deferred_known = true;

@@ -1441,6 +1441,20 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
   if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
 }
 
+// The bulk launch for a SPARSE map (a few keyframes of a 16-beam sensor after the leaf filter: 0.1 points per 1 m cell, where the 3x3x3
+// block of the dense-map kernel holds fewer than k points for most queries and 85 % of them went to the cooperative kernel): the
+// scan's four-lanes-per-query search on the (2R+1)^3 block.  Same neighbours, same tie rule; the grid stays the voxel grid.
+template <int KC, int R>
+__global__ void __launch_bounds__(WAVE)
+k_knn_sp_wide(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df, double* __restrict__ nx,
+              double* __restrict__ ny, double* __restrict__ nz) {
+  extern __shared__ int slist_wide[];
+  if (df.guard && *df.guard) return;
+  const int t = (int)blockIdx.x * WAVE + (int)threadIdx.x;
+  const int i = t >> 2;
+  if (i < n) knn_point_split<KC, SpConfig<false>::KB, R, WAVE>(P, start, g, n, k, i, t & 3, slist_wide + threadIdx.x, df, nx, ny, nz);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cooperative exact search: ONE WAVE PER QUERY.  The (2r+1)^2 rows of the search cube are spread over the lanes
 // (their start[] loads overlap instead of forming a dependent chain), the candidates of each batch of 64 rows are
@@ -2929,9 +2943,15 @@ static Deferred deferred_of(const void* buf, int n) {
 
 template <int KC>
 static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred,
-                        double* nx, double* ny, double* nz, const int* guard) {
+                        double* nx, double* ny, double* nz, const int* guard, int wide_r) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
+  if (wide_r == 2 || wide_r == 3) {
+    const size_t ldsw = (size_t)(wide_r == 2 ? SpShape<2, true>::LDS : SpShape<3, true>::LDS) * WAVE * sizeof(int);
+    if (wide_r == 2) hipLaunchKernelGGL((k_knn_sp_wide<KC, 2>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
+    else hipLaunchKernelGGL((k_knn_sp_wide<KC, 3>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
+    return;
+  }
   using CT = SpConfig<true>;
   using CS = SpConfig<false>;
   const int T = is_target ? CT::T : CS::T;
@@ -2954,9 +2974,9 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
     hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(WAVE), 0, s, P, start, g, k, df, nx, ny, nz);
 }
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
-              double* ny, double* nz, const int* guard) {
-  if (k <= 20) knn_bulk_kc<20>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard);
-  else knn_bulk_kc<32>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard);
+              double* ny, double* nz, const int* guard, int wide_r) {
+  if (k <= 20) knn_bulk_kc<20>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
+  else knn_bulk_kc<32>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
 }
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
               double* ny, double* nz, const int* guard, int waves) {

@@ -256,6 +256,42 @@ def test_exact_ties_follow_the_oracle_order(reg_mod, orc):
         v.close()
 
 
+def test_sparse_map_takes_the_wide_block(reg_mod, orc, monkeypatch):
+    """A map of three leaf-filtered 16-beam sweeps (0.1 points per 1 m cell): the bulk launch searches the 5^3 block with four lanes per
+    query (k_knn_sp_wide) instead of sending most queries to the cooperative kernel.  Covariances, voxel table and pose against the
+    oracle, and the same against the dense-map kernel (RGC_MAP_WIDE_R=0)."""
+    import rgc_slam_amd.synth as synth
+    world = synth.make_world(half_extent=45.0, seed=synth.SEED)
+    poses = synth.make_trajectory(5, seed=synth.SEED)
+    sweeps = [synth.make_scan(world, poses[i], n_az=900, seed=synth.SEED + 70 + i)["xyz"] for i in range(4)]
+    def to_world(xyz, T):
+        return (xyz.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    tgt = orc.voxelgrid_filter(np.concatenate([np.c_[to_world(sweeps[i], poses[i]), np.zeros(len(sweeps[i]), np.float32)] for i in range(3)]), 0.3)[:, :3].copy()
+    src = orc.voxelgrid_filter(np.c_[sweeps[3], np.zeros(len(sweeps[3]), np.float32)], 0.2)[:, :3].copy()
+    o = orc.Registration(max_iterations=25, translation_eps=1e-6, num_threads=0)
+    o.set_target(tgt); o.set_source(src); o.prepare()
+    To = o.align(poses[3])
+    res = {}
+    for wide in ("2", "0"):
+        monkeypatch.setenv("RGC_MAP_WIDE_R", wide)
+        v = _odo(reg_mod)
+        v.setInputTarget(tgt); v.setInputSource(src)
+        ct = v.getTargetCovariances()
+        st = v.stats()
+        assert st["n_target"] < 0.25 * st["target_cells"]
+        res[wide] = st["deferred_target"]
+        et = np.abs(ct - o.target_cov(len(ct))).reshape(len(ct), -1).max(axis=1)
+        assert np.sum(et > 1e-9) == 0, np.sum(et > 1e-9)
+        vm, om = v.getVoxels(), o.voxelmap()
+        assert np.array_equal(vm["coords"], om["coords"]) and np.array_equal(vm["num"], om["num"])
+        assert np.abs(vm["cov"] - om["cov"]).max() < 1e-9
+        v.align(poses[3], want_output=False)
+        T = v.getFinalTransformation()
+        assert np.abs(T[:3, 3] - To[:3, 3]).max() <= 1e-4 and _rot_angle(T[:3, :3], To[:3, :3]) <= 1e-4
+        v.close()
+    assert res["2"] < 0.35 * res["0"], res          # the wide block really ran and left far fewer queries to the cooperative kernel
+
+
 def test_k_and_resolution_parameters(reg_mod, orc, fx_reg):
     """setCorrespondenceRandomness / setResolution change the covariances and the voxel map like the oracle's"""
     v = _odo(reg_mod)
