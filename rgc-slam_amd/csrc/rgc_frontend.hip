@@ -435,6 +435,7 @@ __global__ void k_fe_ground_list(const float4* __restrict__ C, int cs, int NS, c
 // ---- A7: per ring, six sectors: sort by curvature / intensity curvature, greedy pick with +-5 suppression (:469-644) ----
 constexpr int SEC_MAX = 2048;   // points per sector (ring of <= 12288 points)
 constexpr int SEL_T = 256;
+constexpr int SELP_T = 384;  // k_fe_select: six waves, one per sector of the ring
 
 struct Key { float v; int i; };
 __device__ __forceinline__ bool key_less(const Key& a, const Key& b) { return a.v < b.v || (a.v == b.v && a.i < b.i); }
@@ -486,11 +487,13 @@ constexpr int SEL_MARGIN = 5;  // a pick touches ind +- 5 (and compares ind + l 
 // LDS -- the passes are inherently sequential (each pick changes what the next candidate may be), and run from global memory
 // they were a chain of ~10 dependent loads per pick (1.4 ms per sweep); finally the block writes the flags back.
 // Dynamic LDS: n2 keys x 2, then the window arrays (host sizes it from the largest ring).
-__global__ void __launch_bounds__(SEL_T)
+__global__ void __launch_bounds__(SELP_T)
 k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, const float* __restrict__ curv, const float* __restrict__ curv2,
             const float* __restrict__ icurv, const int* __restrict__ inum, const int* __restrict__ gmark, int* __restrict__ picked,
             int* __restrict__ ipicked, int* __restrict__ label, int* __restrict__ ilabel, int* __restrict__ slots, int* flags, int sec_cap,
-            const int* __restrict__ sorted_curv, const int* __restrict__ sorted_icurv) {
+            const int* __restrict__ sorted_curv, const int* __restrict__ sorted_icurv, int group) {
+  // sec_cap: points of `group` consecutive sectors (6, 3, 2 or 1: as many as the LDS holds) -- their window is staged, and written
+  // back, ONCE, and the serial passes walk the group's sectors in order out of it (staging per sector was a third of the kernel)
   extern __shared__ __align__(16) unsigned char sel_lds[];
   const int wcap = sec_cap + 2 * SEL_MARGIN;
   int* ks = reinterpret_cast<int*>(sel_lds);   // point indices of the sector in ascending curvature (k_fe_sort)
@@ -509,6 +512,10 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
   signed char* wilab = wlab + wcap;
   signed char* wrun = wilab + wcap;   // how far a pick at this point suppresses: points to the right | points to the left << 4 (:517-533)
   signed char* wirun = wrun + wcap;   // the same for the intensity pass (:625-639)
+  signed char* wpick0 = wirun + wcap;  // the two flag arrays as staged (six sectors at once: a sector that must start over)
+  signed char* wipick0 = wpick0 + wcap;
+  signed char* xp = wipick0 + wcap;    // marks dropped outside the marking wave's sector
+  signed char* xip = xp + wcap;
   const int ring = blockIdx.x;
   const int S = meta[64 + ring] + 5, E = meta[64 + ring + 1] - 5;  // scanStartInd / scanEndInd, :223,229
   for (int j = 0; j < 6; j++) {
@@ -518,17 +525,21 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
   if (E - S < 10) return;  // :471
 #ifdef RGC_LAB
   long long lab_t[5] = {0, 0, 0, 0, 0}, lab_prev = wall_clock64();
+  __shared__ int lab_redo;
+  if (threadIdx.x == 0) lab_redo = 0;
 #define FE_LAB(k) do { const long long now_ = wall_clock64(); lab_t[k] += now_ - lab_prev; lab_prev = now_; } while (0)
 #else
 #define FE_LAB(k)
 #endif
-  for (int j = 0; j < 6; j++) {
-    const int sp = S + (E - S) * j / 6, ep = S + (E - S) * (j + 1) / 6 - 1;  // :478-480
-    const int cnt = ep - sp + 1;
-    if (cnt > sec_cap || cnt > SEC_MAX) { if (threadIdx.x == 0) atomicOr(flags, 2); return; }
-    const int w0 = sp - SEL_MARGIN, wn = cnt + 2 * SEL_MARGIN;  // window [w0, w0 + wn): inside this ring (S = start + 5)
+  for (int j0 = 0; j0 < 6; j0 += group) {
+    const int sp0 = S + (E - S) * j0 / 6, epl = S + (E - S) * (j0 + group) / 6 - 1;  // the group's first and last point
+    const int gcnt = epl - sp0 + 1;
+    bool oversize = gcnt > sec_cap;
+    for (int j = j0; j < j0 + group; j++) oversize |= (S + (E - S) * (j + 1) / 6 - 1) - (S + (E - S) * j / 6) + 1 > SEC_MAX;
+    if (oversize) { if (threadIdx.x == 0) atomicOr(flags, 2); return; }
+    const int w0 = sp0 - SEL_MARGIN, wn = gcnt + 2 * SEL_MARGIN;  // window [w0, w0 + wn): inside this ring (S = start + 5)
     __syncthreads();
-    for (int t = threadIdx.x; t < wn; t += SEL_T) {
+    for (int t = threadIdx.x; t < wn; t += SELP_T) {
       const int g = w0 + t;
       const float4 p = C[g];
       wx[t] = p.x; wy[t] = p.y; wz[t] = p.z;
@@ -538,13 +549,13 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
       wgm[t] = (signed char)(gmark[g] == 1);
       wlab[t] = (signed char)label[g]; wilab[t] = (signed char)ilabel[g];
     }
-    for (int t = threadIdx.x; t < cnt; t += SEL_T) { ks[t] = sorted_curv[sp + t]; ki[t] = sorted_icurv[sp + t]; }
+    for (int t = threadIdx.x; t < gcnt; t += SELP_T) { ks[t] = sorted_curv[sp0 + t]; ki[t] = sorted_icurv[sp0 + t]; }  // sorted sector by sector
     __syncthreads();
     FE_LAB(0);
     // The reach of a pick's suppression is a property of the points alone (consecutive gaps <= 0.05 m^2, resp. intensity steps <= 35,
     // up to five on each side): computed here for every point of the sector by the whole workgroup, so that the serial pick loop
     // below reads one byte instead of testing ten gaps per pick.
-    for (int t = SEL_MARGIN + threadIdx.x; t < SEL_MARGIN + cnt; t += SEL_T) {
+    for (int t = SEL_MARGIN + threadIdx.x; t < SEL_MARGIN + gcnt; t += SELP_T) {
       auto far_p = [&](int a, int b) {
         const float dx = wx[a] - wx[b], dy = wy[a] - wy[b], dz = wz[a] - wz[b];
         return dx * dx + dy * dy + dz * dz > 0.05;
@@ -560,13 +571,19 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
     }
     __syncthreads();
     FE_LAB(1);
-    if (threadIdx.x < WAVE) {
+    // one sector's three passes by the calling wave; own_only: marks that fall outside the sector go to xp / xip instead of the flags
+    auto run_sector = [&](int j, bool own_only) {
+      const int sp = S + (E - S) * j / 6, ep = S + (E - S) * (j + 1) / 6 - 1;  // :478-480
+      const int cnt = ep - sp + 1;
+      const int* const ksj = ks + (sp - sp0);
+      const int* const kij = ki + (sp - sp0);
       // The three greedy passes of :487-641 by ONE WAVE.  A pass walks the sorted candidates in order and a pick suppresses
       // up to ten neighbours, so picks are sequential -- but only picks: 64 candidates at a time, every lane tests the
       // static conditions of its candidate, then the earliest candidate that is still unsuppressed is picked (ballot +
       // find-first), its lane marks the neighbours in LDS, and the remaining lanes look again.  Serial steps = picks
       // (<= 21 / 40 / 21 per sector), not candidates (hundreds).
-      const int lane = threadIdx.x;
+      const int lane = threadIdx.x & (WAVE - 1);
+      const int tlo = own_only ? sp - w0 : 0, thi = own_only ? ep - w0 : wn - 1;   // the window positions whose flags this wave owns
       int* sl = slots + ((size_t)ring * 6 + j) * SLOT;
       auto wave_fence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -576,7 +593,7 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
       const bool mark_right = lane < 5;
       const int mark_off = lane < 5 ? lane + 1 : -(lane - 4);           // lanes 0..4: +1..+5, lanes 5..9: -1..-5
       const int mark_rank = lane < 5 ? lane : (lane < 10 ? lane - 5 : 99);  // how far out this lane's mark is (99: this lane marks nothing)
-      auto greedy = [&](const int* keys, bool descending, signed char* flag, int limit, auto&& static_ok, auto&& on_pick, const signed char* run) {
+      auto greedy = [&](const int* keys, bool descending, signed char* flag, signed char* xflag, int limit, auto&& static_ok, auto&& on_pick, const signed char* run) {
         int count = 0;
         bool stop = false;
         for (int base = 0; base < cnt && !stop; base += WAVE) {
@@ -591,6 +608,9 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
           // inside the pick loop, which was two LDS round trips per pick (~340 cycles; 70 of the kernel's 138 us were this loop).
           // The marks still go to LDS for the following batches and passes; one fence per batch.
           int mine = flag[w];
+          // (the LDS reads above are waited for HERE: left to the compiler, the wait lands in the loop header below and every pick then
+          // also waits for the previous pick's LDS stores to land)
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
           for (;;) {
             const unsigned long long mask = __ballot(ok && mine == 0);
             if (!mask) break;
@@ -606,7 +626,10 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
             // (mark_off / mark_rank are per-lane constants: one select, one compare and one masked byte store per pick)
             const int rb = __builtin_amdgcn_readlane(reach, b);
             const int np = rb & 15, nm = rb >> 4;
-            if (mark_rank < (mark_right ? np : nm)) flag[wb + mark_off] = 1;
+            if (mark_rank < (mark_right ? np : nm)) {
+              const int q = wb + mark_off;
+              if (q >= tlo && q <= thi) flag[q] = 1; else xflag[q] = 1;
+            }
             if (w >= wb - nm && w <= wb + np) mine = 1;
           }
           wave_fence();
@@ -614,24 +637,67 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
         return count > limit ? limit : count;
       };
       // sharp: largest curvature first (:487-536); the 21st pick is labelled "less sharp" and gets no slot
-      const int nsh_picks = greedy(ks, true, wpick, 21, [&](int w) { return wgm[w] == 0 && wc[w] > 0.1 && wc2[w] > 0.3; },
+      const int nsh_picks = greedy(ksj, true, wpick, xp, 21, [&](int w) { return wgm[w] == 0 && wc[w] > 0.1 && wc2[w] > 0.3; },
                                    [&](int count, int ind, int w) { if (count <= 20) { wlab[w] = 2; sl[count - 1] = ind; } else { wlab[w] = 1; } },
                                    wrun);
       const int nsh = nsh_picks > 20 ? 20 : nsh_picks;
       wave_fence();
       // flat: smallest curvature first (:540-583)
-      const int nfl = greedy(ks, false, wpick, 40, [&](int w) { return wc[w] < 0.3 && wc2[w] < 0.4; },
+      const int nfl = greedy(ksj, false, wpick, xp, 40, [&](int w) { return wc[w] < 0.3 && wc2[w] < 0.4; },
                              [&](int count, int ind, int w) { wlab[w] = -1; sl[20 + count - 1] = ind; }, wrun);
       wave_fence();
       // intensity: largest intensity curvature first, not on points already labelled sharp (:594-641)
-      const int nin_picks = greedy(ki, true, wipick, 21, [&](int w) { return wgm[w] == 0 && wic[w] > 65 && wlab[w] != 2 && wlab[w] != 1; },
+      const int nin_picks = greedy(kij, true, wipick, xip, 21, [&](int w) { return wgm[w] == 0 && wic[w] > 65 && wlab[w] != 2 && wlab[w] != 1; },
                                    [&](int count, int ind, int w) { if (count <= 20) { wilab[w] = 2; sl[60 + count - 1] = ind; } else { wilab[w] = 1; } },
                                    wirun);
       if (lane == 0) { sl[80] = nsh; sl[81] = nfl; sl[82] = nin_picks > 20 ? 20 : nin_picks; }
+      wave_fence();
+    };
+    const int wv = threadIdx.x / WAVE, ln = threadIdx.x & (WAVE - 1);
+    bool parallel = group == 6;
+    for (int j = 0; j < 6 && parallel; j++) parallel = (S + (E - S) * (j + 1) / 6 - 1) - (S + (E - S) * j / 6) + 1 >= 12;  // marks reach one sector only
+    if (!parallel) {
+      if (wv == 0) for (int j = j0; j < j0 + group; j++) run_sector(j, false);
+    } else {
+      // THE SIX SECTORS AT ONCE, one wave each.  A sector's passes depend on the sectors before it only through the marks their picks
+      // drop on its first five points, and such a mark changes the outcome only if it lands on a point this sector picked (a point
+      // that was not picked -- failed the thresholds, already suppressed, behind the quota -- stays unpicked).  So: every wave runs its
+      // sector on the flags as staged, marks that leave the sector are kept aside (xp / xip); then, in ring order, a sector that finds
+      // one of its picks marked by its (final) predecessor starts over from the staged flags plus those marks.  Same picks, same
+      // order, same flags as the serial walk; a 16-beam ring of six sectors takes one sector's time plus the repeats (about a third).
+      for (int t = threadIdx.x; t < wn; t += SELP_T) { wpick0[t] = wpick[t]; wipick0[t] = wipick[t]; xp[t] = 0; xip[t] = 0; }
+      __syncthreads();
+      if (wv < 6) run_sector(wv, true);
+      __syncthreads();
+      FE_LAB(4);
+      for (int j = 1; j < 6; j++) {
+        if (wv == j) {
+          const int sp = S + (E - S) * j / 6, ep = S + (E - S) * (j + 1) / 6 - 1;
+          const int tlo = sp - w0, thi = ep - w0;
+          const int q = tlo + (ln < 5 ? ln : 0);
+          const bool hit = ln < 5 && ((xp[q] && !wpick0[q] && wlab[q] != 0) || (xip[q] && !wipick0[q] && wilab[q] != 0));
+          const bool redo = __any(hit);
+          if (redo) {
+            for (int t = tlo + ln; t <= thi; t += WAVE) { wpick[t] = wpick0[t]; wipick[t] = wipick0[t]; wlab[t] = 0; wilab[t] = 0; }
+            if (ln < 5) { xp[thi + 1 + ln] = 0; xip[thi + 1 + ln] = 0; xp[tlo - 1 - ln] = 0; xip[tlo - 1 - ln] = 0; }   // this sector's own marks outside it
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+          if (ln < 5) { wpick[q] |= xp[q]; wipick[q] |= xip[q]; }   // the predecessor's marks
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (redo) run_sector(j, true);
+#ifdef RGC_LAB
+          if (redo && ln == 0) atomicAdd(&lab_redo, 1);
+#endif
+        }
+        __syncthreads();
+      }
+      for (int t = threadIdx.x; t < wn; t += SELP_T) { wpick[t] |= xp[t]; wipick[t] |= xip[t]; }   // every mark that left its sector
     }
     __syncthreads();
     FE_LAB(2);
-    for (int t = threadIdx.x; t < wn; t += SEL_T) {  // flags back to memory: the next sector's window overlaps this one's margin
+    for (int t = threadIdx.x; t < wn; t += SELP_T) {  // flags back to memory: the next sector's window overlaps this one's margin
       const int g = w0 + t;
       picked[g] = wpick[t]; ipicked[g] = wipick[t];
       label[g] = wlab[t]; ilabel[g] = wilab[t];
@@ -639,7 +705,7 @@ k_fe_select(const float4* __restrict__ C, int NS, const int* __restrict__ meta, 
     FE_LAB(3);
   }
 #ifdef RGC_LAB
-  if (threadIdx.x == 0 && ring == 3) printf("k_fe_select ring 3 (10 ns units): load %lld reach %lld greedy %lld writeback %lld\n", lab_t[0], lab_t[1], lab_t[2], lab_t[3]);
+  if (threadIdx.x == 0 && (ring == 3 || ring == 12)) printf("k_fe_select ring 3 / 12 (10 ns units): load %lld reach %lld six sectors at once %lld in-order pass %lld (%d sectors started over) writeback %lld\n", lab_t[0], lab_t[1], lab_t[4], lab_t[2], lab_redo, lab_t[3]);
 #endif
 }
 
@@ -732,16 +798,23 @@ void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const fl
                int* sorted_icurv) {
   hipLaunchKernelGGL(k_fe_sort, dim3(NS * 6, 2), dim3(SEL_T), 0, s, NS, meta, curv, icurv, sorted_curv, sorted_icurv);
   // LDS sized from the largest ring: the two sorted index lists of a sector + the per-sector window arrays
-  int sec_cap = max_ring / 6 + 2;
-  if (sec_cap > SEC_MAX) sec_cap = SEC_MAX;
-  const size_t lds = sizeof(int) * 2 * (size_t)sec_cap + (size_t)(sec_cap + 2 * SEL_MARGIN) * (7 * 4 + 7) + 64;
+  // as many consecutive sectors per staging as fit (a 16- or 64-beam ring of ~2000 points: all six)
+  int group = 6, sec_cap = 0;
+  size_t lds = 0;
+  for (;;) {
+    sec_cap = (int)(((long long)max_ring * group + 5) / 6) + 2;
+    if (sec_cap > SEC_MAX * group) sec_cap = SEC_MAX * group;
+    lds = sizeof(int) * 2 * (size_t)sec_cap + (size_t)(sec_cap + 2 * SEL_MARGIN) * (7 * 4 + 11) + 64;
+    if (lds <= 150 * 1024 || group == 1) break;
+    group = group == 6 ? 3 : (group == 3 ? 2 : 1);
+  }
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k_fe_select, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_fe_select, dim3(NS), dim3(SEL_T), lds, s, C, NS, meta, curv, curv2, icurv, inum, gmark, picked, ipicked, label, ilabel, slots, flags,
-                     sec_cap, sorted_curv, sorted_icurv);
+  hipLaunchKernelGGL(k_fe_select, dim3(NS), dim3(SELP_T), lds, s, C, NS, meta, curv, curv2, icurv, inum, gmark, picked, ipicked, label, ilabel, slots, flags,
+                     sec_cap, sorted_curv, sorted_icurv, group);
 }
 void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const float* dsrc, const float* osrc, float* sharp, float* flat, float* inten,
              int cap, int* counts) {
