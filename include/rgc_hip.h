@@ -159,7 +159,9 @@ RGC_API int rgc_deskew(rgc_ctx* ctx, float* xyzi, int n, int stride_bytes, const
                        const double t_last_curr[3], int on_device);
 /* B3  pcl::VoxelGrid<PointXYZI>::filter with setLeafSize(leaf,leaf,leaf) (src/RGC_odometer.cpp:976-991).
  * out_xyzi: n*4 floats capacity (x,y,z,intensity centroids, 16-byte stride, ordered by leaf index); *n_out = leaves.
- * If the leaf grid would overflow int the input is returned unfiltered, like PCL. */
+ * If the leaf grid would overflow int the input is returned unfiltered, like PCL.
+ * (A context remembers the leaf box of the last cloud per leaf size and filters the next one on it without measuring its bounding
+ * box first; the output does not depend on the box, and a cloud that leaves it is filtered again on its own.) */
 RGC_API int rgc_voxelgrid(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, float leaf, float* out_xyzi, int* n_out,
                           int on_device);
 /* B9  vg_ICP::transformPointCloud(cloud, q, t) (src/RGC_odometer.cpp:1495-1514): q * p + t in fp64, stored fp32,

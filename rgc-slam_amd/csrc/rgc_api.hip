@@ -1494,7 +1494,7 @@ static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, fl
     const size_t fill = std::min(cl.cnt.cap, (sizeof(int) * nr1 + 255) & ~(size_t)255);
     HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, fill, s));
   }
-  cl.cnt_clean = nr1;
+  cl.cnt_clean = std::max(cl.cnt_clean, nr1);  // (what lies beyond this call's rows was not touched: the scan's and the map's filter take turns)
   if (!c->vg_flags_clean) HIPCHK(c, hipMemsetAsync(dsm + 6, 0, sizeof(int), s));
   c->vg_flags_clean = false;
   rgck::vg_rows(s, d_in, stride_f, n, inv, g, edge, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)c->vg_pos.p, (int*)cl.cnt.p, (int*)cl.start.p,

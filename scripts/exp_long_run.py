@@ -1,7 +1,7 @@
 """Steady state over a long sequence: 3000 c-main frames (23 scans cycled forward and backward so that consecutive frames are consecutive
 poses), per-frame wall time statistics, drift of the rate, and device memory sampled before the first frame, at frame 200 (the working set
 is allocated by then) and at the end: working set and steady-state growth are separate numbers."""
-import sys, os, time
+import sys, json, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gc
 import numpy as np, torch
@@ -36,7 +36,7 @@ for f in range(N):
 v.synchronize()
 free1 = torch.cuda.mem_get_info()[0]
 q = np.percentile(per[200:], [50, 90, 99, 100])
-print({"frames": N, "ms_median": round(float(q[0]), 4), "ms_p90": round(float(q[1]), 4), "ms_p99": round(float(q[2]), 4), "ms_max": round(float(q[3]), 3),
+print(json.dumps({"frames": N, "ms_median": round(float(q[0]), 4), "ms_p90": round(float(q[1]), 4), "ms_p99": round(float(q[2]), 4), "ms_max": round(float(q[3]), 3),
        "first_500_median": round(float(np.median(per[200:700])), 4), "last_500_median": round(float(np.median(per[-500:])), 4),
        "frames_over_1ms": int((per[200:] > 1.0).sum()), "working_set_MiB": round((free0 - free200) / 2**20, 1),
-       "steady_state_growth_MiB_frames_200_to_end": round((free200 - free1) / 2**20, 2), "identical_results": True})
+       "steady_state_growth_MiB_frames_200_to_end": round((free200 - free1) / 2**20, 2), "identical_results": True}))
