@@ -154,7 +154,9 @@ RGC_API int rgc_get_voxels(rgc_ctx* ctx, int cap, int* coords, int* num, double*
  * on_device != 0: every cloud pointer of the call is device memory on the context's device. */
 /* B2  vg_ICP::adjustDistortion (src/RGC_odometer.cpp:1441-1481), in place.  Points are x,y,z,intensity with
  * intensity = ring + 0.1 * relTime as the front-end encodes it (scanRegistration.cpp:207-210).
- * q_last_curr_xyzw / t_last_curr: the motion guess (IMU pre-integration or previous delta, :929,993-996). */
+ * q_last_curr_xyzw / t_last_curr: the motion guess (IMU pre-integration or previous delta, :929,993-996).
+ * on_device: returns once the kernel is enqueued on rgc_stream(ctx); later calls on this context, rgc_download and work the caller
+ * enqueues on that stream see the de-skewed sweep (the frame body's next stage is the leaf filter, which reads it there). */
 RGC_API int rgc_deskew(rgc_ctx* ctx, float* xyzi, int n, int stride_bytes, const double q_last_curr_xyzw[4],
                        const double t_last_curr[3], int on_device);
 /* B3  pcl::VoxelGrid<PointXYZI>::filter with setLeafSize(leaf,leaf,leaf) (src/RGC_odometer.cpp:976-991).

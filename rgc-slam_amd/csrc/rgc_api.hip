@@ -109,7 +109,7 @@ struct rgc_ctx {
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
   double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
-  int map_wide_r = 2;             // RGC_MAP_WIDE_R (0 = off, 2, 3): block radius of the bulk kNN launch for a sparse map
+  int map_wide_r = 2;             // RGC_MAP_WIDE_R (0 = off, 2): block radius of the bulk kNN launch for a sparse map
   double map_wide_density = 0.25; // RGC_MAP_WIDE: ... when the map has fewer points per grid cell than this
   double src_res_auto = 0.0;  // adaptive cell size of the scan's kNN grid, steered by how crowded its cells were in the previous frame (0 = voxel_res)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
@@ -934,7 +934,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
-  if (const char* e = getenv("RGC_MAP_WIDE_R")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 3) c->map_wide_r = v; }
+  if (const char* e = getenv("RGC_MAP_WIDE_R")) { const int v = atoi(e); if (v == 0 || v == 2) c->map_wide_r = v; }
   if (const char* e = getenv("RGC_MAP_WIDE")) { const double v = atof(e); if (v >= 0.0 && std::isfinite(v)) c->map_wide_density = v; }
   if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
   if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
@@ -1443,8 +1443,10 @@ int rgc_deskew(rgc_ctx* c, float* xyzi, int n, int stride_bytes, const double q[
   if (!(n2 > 0)) return fail(c, RGC_ERR_INVALID, "zero quaternion");
   rgck::Quat qi{-q[0] / n2, -q[1] / n2, -q[2] / n2, q[3] / n2};
   rgck::deskew(c->stream, (float*)d_in, stride_bytes / 4, n, qi, t);
-  if (!on_device) HIPCHK(c, hipMemcpyAsync(xyzi, d_in, (size_t)n * stride_bytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!on_device) {
+    HIPCHK(c, hipMemcpyAsync(xyzi, d_in, (size_t)n * stride_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }  // (device memory: in place and stream-ordered -- whatever reads the sweep next is enqueued behind it, see the header)
   HIPCHK(c, hipGetLastError());
   return RGC_OK;
 }

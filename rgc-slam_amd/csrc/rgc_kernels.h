@@ -64,7 +64,7 @@ void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int*
 // bulk kernel (one lane per query; defers what it cannot finish) then the cooperative kernel (one wave per deferred query).
 // deferred: deferred_bytes(n) bytes, whose first int (the count) must be 0 on entry (rank_gather's zero_me)
 size_t deferred_bytes(int n);
-// wide_r = 2 or 3: the four-lanes-per-query search on the 5^3 / 7^3 block whatever the cloud (a sparse map)
+// wide_r = 2: the four-lanes-per-query search on the 5^3 block whatever the cloud (a sparse map)
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard = nullptr, int wide_r = 0);
 // waves: one-wave workgroups that share the deferred list (clamped to [32, 8192])

@@ -2946,10 +2946,9 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
                         double* nx, double* ny, double* nz, const int* guard, int wide_r) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
-  if (wide_r == 2 || wide_r == 3) {
-    const size_t ldsw = (size_t)(wide_r == 2 ? SpShape<2, true>::LDS : SpShape<3, true>::LDS) * WAVE * sizeof(int);
-    if (wide_r == 2) hipLaunchKernelGGL((k_knn_sp_wide<KC, 2>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
-    else hipLaunchKernelGGL((k_knn_sp_wide<KC, 3>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
+  if (wide_r == 2) {
+    const size_t ldsw = (size_t)SpShape<2, true>::LDS * WAVE * sizeof(int);
+    hipLaunchKernelGGL((k_knn_sp_wide<KC, 2>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
     return;
   }
   using CT = SpConfig<true>;
