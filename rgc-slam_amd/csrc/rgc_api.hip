@@ -1442,11 +1442,13 @@ int rgc_deskew(rgc_ctx* c, float* xyzi, int n, int stride_bytes, const double q[
   const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
   if (!(n2 > 0)) return fail(c, RGC_ERR_INVALID, "zero quaternion");
   rgck::Quat qi{-q[0] / n2, -q[1] / n2, -q[2] / n2, q[3] / n2};
+  if (c->main_has_target_prep && hipStreamQuery(c->stream) == hipSuccess) c->main_has_target_prep = false;  // it has drained
   rgck::deskew(c->stream, (float*)d_in, stride_bytes / 4, n, qi, t);
-  if (!on_device) {
-    HIPCHK(c, hipMemcpyAsync(xyzi, d_in, (size_t)n * stride_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }  // (device memory: in place and stream-ordered -- whatever reads the sweep next is enqueued behind it, see the header)
+  if (!on_device) HIPCHK(c, hipMemcpyAsync(xyzi, d_in, (size_t)n * stride_bytes, hipMemcpyDeviceToHost, c->stream));
+  // device memory: in place and stream-ordered, whatever reads the sweep next on the main stream is enqueued behind it -- unless a map
+  // preparation is still pending there: rgc_set_source_device orders the scan's stream after a mark recorded BEFORE that preparation
+  // (see prepare_cloud), which this kernel would then lie behind
+  if (!on_device || c->main_has_target_prep) HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   return RGC_OK;
 }

@@ -76,6 +76,44 @@ def test_voxelgrid_box_kept_from_the_previous_cloud(orc):
         p.close()
 
 
+def test_deskew_on_device_between_set_target_and_set_source(pre):
+    """rgc_deskew on device memory does not synchronise -- except when a map preparation is pending on the main stream: the scan's
+    preparation (second stream) is ordered after a mark recorded BEFORE that preparation, so a de-skew enqueued behind it must have
+    finished when rgc_set_source_device is called.  Same pose, bit for bit, as de-skewing on the host first."""
+    import ctypes as C
+    import rgc_slam_amd.synth as synth
+    from rgc_slam_amd import registration
+    world, tgt = synth.make_world_and_map(300000, seed=synth.SEED + 3)
+    poses = synth.make_trajectory(3, seed=synth.SEED + 3)
+    sc = synth.make_scan(world, poses[1], n_az=1800, seed=synth.SEED + 9)
+    scan = np.concatenate([sc["xyz"], (sc["ring"] + 0.1 * sc["rel_time"])[:, None].astype(np.float32)], axis=1)
+    q, t = np.float64([0.0, 0.0, 0.01, 1.0]), np.float64([0.3, 0.02, 0.0])
+    q /= np.linalg.norm(q)
+    expect = pre.adjustDistortion(scan, q, t)
+    t4 = np.zeros((len(tgt), 4), np.float32); t4[:, :3] = tgt
+    v = registration.odometer_vgicp(0)
+    try:
+        d_t = v.device_alloc(t4.nbytes); v.upload(d_t, t4)
+        d_s = v.device_alloc(scan.nbytes)
+        dp = C.POINTER(C.c_double)
+        res = []
+        for on_device in (True, False):
+            v.upload(d_s, scan if on_device else expect)
+            v.setInputTargetDevice(d_t, len(t4), 16)          # map preparation pending on the main stream
+            if on_device:
+                rc = v._L.rgc_deskew(v._h, C.c_void_p(d_s), len(scan), 16, q.ctypes.data_as(dp), t.ctypes.data_as(dp), 1)
+                assert rc == 0
+            v.setInputSourceDevice(d_s, len(scan), 16)
+            v.align(poses[1].astype(np.float32), want_output=False)
+            res.append(v.getFinalTransformation().copy())
+            got = np.empty_like(scan)
+            assert v._L.rgc_download(v._h, got.ctypes.data, C.c_void_p(d_s), got.nbytes) == 0
+            assert np.array_equal(got, expect)
+        assert np.array_equal(res[0], res[1])
+    finally:
+        v.close()
+
+
 def test_deskew_vs_oracle(pre, orc):
     import rgc_slam_amd.synth as synth
     xyzi = _scan()
