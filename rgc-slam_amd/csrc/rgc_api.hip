@@ -120,6 +120,8 @@ struct rgc_ctx {
   DevBuf fe[34];              // front-end buffers
   unsigned char* h_stage = nullptr;  // pinned staging of the front-end's small read-backs and feature clouds (a copy into pageable
   size_t h_stage_cap = 0;            // memory is staged by the runtime anyway, one blocking hop per call)
+  bool fe_spec_on = true;    // RGC_FE_SPEC=0: read every sweep's size back before its stencil kernels
+  int fe_last_ns = 0, fe_last_max_ring = 0;  // the previous sweep's scan lines and largest ring: sizes the next sweep's launches without a read-back
   int fe_n_cloud = 0;         // points of the last front-end's ring-major cloud (fe[5]), for rgc_frontend_cloud_device
   // f2: rolling local map.  World-frame points (relative to map_origin, x,y,z,intensity, 16 B) of the live keyframes as
   // contiguous segments in insertion order in map_store[map_cur]; the other buffer is the compaction / re-basing target.
@@ -934,6 +936,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
+  if (const char* e = getenv("RGC_FE_SPEC")) c->fe_spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_MAP_WIDE_R")) { const int v = atoi(e); if (v == 0 || v == 2) c->map_wide_r = v; }
   if (const char* e = getenv("RGC_MAP_WIDE")) { const double v = atof(e); if (v >= 0.0 && std::isfinite(v)) c->map_wide_density = v; }
   if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
@@ -1644,7 +1647,7 @@ void rgc_default_fe_params(rgc_fe_params* p) {
   p->n_scans = 16; p->min_range = 0.5; p->max_range = 80.0; p->use_intensity = 1;  // launch/run.launch:6,12-13,18
 }
 
-static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out, int on_device);
+static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out, int on_device, bool allow_spec = true);
 int rgc_frontend(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out) {
   return frontend_impl(c, xyzi, n, stride_bytes, prm, out, 0);
 }
@@ -1652,7 +1655,7 @@ int rgc_frontend(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const r
 int rgc_frontend_device(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out) {
   return frontend_impl(c, d_xyzi, n, stride_bytes, prm, out, 1);
 }
-static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out, int on_device) {
+static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out, int on_device, bool allow_spec) {
   if (!c || !xyzi || !prm || !out || n < 0) return RGC_ERR_INVALID;
   if (n > (1 << 24)) return fail(c, RGC_ERR_INVALID, "sweep has %d points, the front-end's limit is 2^24", n);  // 32-bit sizes and candidate lists below
   if (stride_bytes < 16 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "front-end needs x,y,z,intensity: stride_bytes >= 16");
@@ -1707,26 +1710,36 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   int* meta = (int*)c->h_stage;                       // 129 ints
   int* fl = (int*)(c->h_stage + 832);                 // 8 ints ([528, 800): the ground sums, fit and distance sums)
   unsigned char* h_feat = c->h_stage + 1024;
-  HIPCHK(c, hipMemcpyAsync(meta, FE(META, int), sizeof(int) * 129, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  const int cs = meta[128];
-  out->n_cloud = cs;
-  int max_ring = 0;
-  for (int r = 0; r < NS; r++) { out->ring_count[r] = meta[r]; max_ring = std::max(max_ring, meta[r]); }
-  if (cs == 0) return RGC_OK;
-  c->fe_n_cloud = cs;
-  if (out->cloud && out->cloud_cap < cs) return fail(c, RGC_ERR_INVALID, "cloud_cap %d < %d points", out->cloud_cap, cs);
+  // The sweep's size after the range filter and its ring sizes are known on the device (k_fe_hist_scan); the host needs them only to
+  // size launches and the selection kernel's LDS.  From the second sweep of a sequence on it does not wait for them: launches are sized
+  // by the raw point count, the kernels read the size themselves (csp), the selection kernel's window by the largest ring of the
+  // PREVIOUS sweep plus a quarter -- if a ring outgrows that (flag bit 1), the sweep is done again the slow way.
+  const bool spec = allow_spec && c->fe_spec_on && c->fe_last_ns == NS && c->fe_last_max_ring > 0 && !out->cloud;
+  int cs = n, max_ring = 0;
+  const int* csp = nullptr;
+  if (spec) {
+    csp = FE(META, int) + 128;
+    max_ring = std::min(n, c->fe_last_max_ring + c->fe_last_max_ring / 4 + 64);
+  } else {
+    HIPCHK(c, hipMemcpyAsync(meta, FE(META, int), sizeof(int) * 129, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    cs = meta[128];
+    out->n_cloud = cs;
+    for (int r = 0; r < NS; r++) { out->ring_count[r] = meta[r]; max_ring = std::max(max_ring, meta[r]); }
+    if (cs == 0) return RGC_OK;
+    if (out->cloud && out->cloud_cap < cs) return fail(c, RGC_ERR_INVALID, "cloud_cap %d < %d points", out->cloud_cap, cs);
+  }
   rgck::fe_zero4(s, FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), cs);
-  rgck::fe_stencils(s, FE(CL, float4), cs, FE(RANGE, float), FE(ANGLE, float), FE(INUM2, int), FE(INUM, int), FE(CURV, float), FE(CURV2, float),
+  rgck::fe_stencils(s, FE(CL, float4), cs, csp, FE(RANGE, float), FE(ANGLE, float), FE(INUM2, int), FE(INUM, int), FE(CURV, float), FE(CURV2, float),
                     FE(ICURV, float), FE(DSRC, float), FE(OSRC, float), FE(PICK, int));
   // A5: ground set (with multiplicities) -> weighted centroid / covariance -> plane (scanRegistration.cpp:308-431)
-  rgck::fe_ground(s, FE(CL, float4), cs, NS, FE(RANGE, float), FE(META, int), FE(GMARK, int), FE(MULT, int), FE(SCNT, int), FE(PART, double), FE(OUTD, double));
+  rgck::fe_ground(s, FE(CL, float4), cs, csp, NS, FE(RANGE, float), FE(META, int), FE(GMARK, int), FE(MULT, int), FE(SCNT, int), FE(PART, double), FE(OUTD, double));
   // OUTD: [0..10] the ground sums, [16..31] the plane fit, [32..33] the distance sums -- fitted on the device, read back with the features
-  rgck::fe_ground_fit_dist(s, FE(CL, float4), cs, FE(MULT, int), FE(OUTD, double), FE(OUTD, double) + 16, FE(PART, double), FE(OUTD, double) + 32);
+  rgck::fe_ground_fit_dist(s, FE(CL, float4), cs, csp, FE(MULT, int), FE(OUTD, double), FE(OUTD, double) + 16, FE(PART, double), FE(OUTD, double) + 32);
   // /laser_cloud_ground: pushes in reference order (with duplicates); empty when no ground seed was found
   rgck::exclusive_scan(s, FE(SCNT, int), FE(SPOS, int), cs, FE(BSUM, int));
   const int gcap_dev = 10 * n;
-  rgck::fe_ground_list(s, FE(CL, float4), cs, NS, FE(RANGE, float), FE(META, int), FE(SCNT, int), FE(SPOS, int), FE(GLIST, float4), gcap_dev);
+  rgck::fe_ground_list(s, FE(CL, float4), cs, csp, NS, FE(RANGE, float), FE(META, int), FE(SCNT, int), FE(SPOS, int), FE(GLIST, float4), gcap_dev);
   // A7 + A8
   rgck::fe_select(s, FE(CL, float4), NS, FE(META, int), FE(CURV, float), FE(CURV2, float), FE(ICURV, float), FE(INUM, int), FE(GMARK, int),
                   FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), d_flags, max_ring, FE(SORTC, int), FE(SORTI, int));
@@ -1737,9 +1750,23 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   double* gd = (double*)(c->h_stage + 528);            // 34 doubles behind the 129 meta ints
   static_assert(528 + kTailFlags == 832 && 528 + kTailFeat == 1024, "the device tail mirrors the staging area from gd on");
   HIPCHK(c, hipMemcpyAsync(gd, tail, kTailFeat + 60u * (size_t)fcap, hipMemcpyDeviceToHost, s));
+  if (spec) HIPCHK(c, hipMemcpyAsync(meta, FE(META, int), sizeof(int) * 129, hipMemcpyDeviceToHost, s));
   if (out->cloud) HIPCHK(c, hipMemcpyAsync(out->cloud, FE(CL, float4), sizeof(float) * 4 * (size_t)cs, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
+  if (spec) {
+    if (fl[0] & 2) {  // a ring outgrew the window sized from the previous sweep (or really holds an oversize sector): the slow way decides
+      c->fe_last_max_ring = 0;
+      return frontend_impl(c, xyzi, n, stride_bytes, prm, out, on_device, false);
+    }
+    cs = meta[128];
+    out->n_cloud = cs;
+    max_ring = 0;
+    for (int r = 0; r < NS; r++) { out->ring_count[r] = meta[r]; max_ring = std::max(max_ring, meta[r]); }
+    if (cs == 0) return RGC_OK;
+  }
   if (fl[0] & 2) return fail(c, RGC_ERR_INVALID, "a ring sector holds more than 2048 points");
+  c->fe_n_cloud = cs;
+  c->fe_last_ns = NS; c->fe_last_max_ring = max_ring;
   {  // ground message (:403-430) from the sums, the fit and the distance sums that just came down
     const long long gsize = (long long)(gd[10] + 0.5);
     if (gsize > 0) {

@@ -180,7 +180,9 @@ __global__ void k_fe_scatter(const float* __restrict__ in, int stride_f, int n, 
 }
 
 // ---- A3: range, incidence angle (:234-255) ----
-__global__ void k_fe_range_angle(const float4* __restrict__ C, int cs, float* __restrict__ range_vec, float* __restrict__ scan_angle) {
+__global__ void k_fe_range_angle(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp, float* __restrict__ range_vec,
+                                 float* __restrict__ scan_angle) {
+  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cs) return;
   const float4 p4 = C[i];
@@ -201,8 +203,9 @@ __global__ void k_fe_range_angle(const float4* __restrict__ C, int cs, float* __
 }
 
 // near-range intensity smoothing on the int intensities, truncating on every store like the deque<int> (:257-268)
-__global__ void k_fe_smooth(int cs, const float* __restrict__ range_vec, const float* __restrict__ scan_angle, const int* __restrict__ inum2,
+__global__ void k_fe_smooth(int cs_in, const int* __restrict__ csp, const float* __restrict__ range_vec, const float* __restrict__ scan_angle, const int* __restrict__ inum2,
                             int* __restrict__ inum) {
+  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cs) return;
   int v = inum2[i];
@@ -215,9 +218,10 @@ __global__ void k_fe_smooth(int cs, const float* __restrict__ range_vec, const f
 }
 
 // ---- A4: curvature stencils (:270-306) ----
-__global__ void k_fe_curv(const float4* __restrict__ C, int cs, const float* __restrict__ range_vec, const float* __restrict__ scan_angle,
+__global__ void k_fe_curv(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp, const float* __restrict__ range_vec, const float* __restrict__ scan_angle,
                           const int* __restrict__ inum, float* __restrict__ curv, float* __restrict__ curv2, float* __restrict__ icurv,
                           float* __restrict__ dsrc, float* __restrict__ osrc) {
+  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cs) return;
   float cv = 0.f, cv2 = 0.f, icv = 0.f, ds = 0.f, os = 0.f;
@@ -252,7 +256,8 @@ __global__ void k_fe_curv(const float4* __restrict__ C, int cs, const float* __r
 }
 
 // ---- A6: occlusion / parallel-beam mask (:433-456); picked[] zeroed before ----
-__global__ void k_fe_occlusion(int cs, const float* __restrict__ range_vec, int* __restrict__ picked) {
+__global__ void k_fe_occlusion(int cs_in, const int* __restrict__ csp, const float* __restrict__ range_vec, int* __restrict__ picked) {
+  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 5 || i >= cs - 5) return;
   const float d1 = range_vec[i], d2 = range_vec[i + 1];
@@ -284,8 +289,9 @@ __device__ __forceinline__ bool ground_seed(const float4* __restrict__ C, const 
 // mult[j] = how many times point j is pushed into the ground set (seed c = j - n, n in [-5, 4]); seedcnt[c] = pushes
 // made by seed c (for the ordered ground list).  acc: block partial sums {W, Wx, Wy, Wz, Wxx, Wxy, Wxz, Wyy, Wyz, Wzz, count}
 __global__ void __launch_bounds__(FE_T)
-k_fe_ground(const float4* __restrict__ C, int cs, int NS, const float* __restrict__ range_vec, const int* __restrict__ meta,
+k_fe_ground(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp, int NS, const float* __restrict__ range_vec, const int* __restrict__ meta,
             int* __restrict__ gmark, int* __restrict__ mult_out, int* __restrict__ seedcnt, double* __restrict__ partials) {
+  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
   const int j = blockIdx.x * FE_T + threadIdx.x;
   double acc[11];
 #pragma unroll
@@ -315,6 +321,7 @@ k_fe_ground(const float4* __restrict__ C, int cs, int NS, const float* __restric
     }
   }
   if (j < cs) { gmark[j] = mult > 0 ? 1 : 0; mult_out[j] = mult; seedcnt[j] = sc; }
+  else if (j < cs_in) seedcnt[j] = 0;  // the scan of the seed counts runs over the launch's bound
   __shared__ double red[FE_T / WAVE][11];
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
 #pragma unroll
@@ -332,8 +339,9 @@ k_fe_ground(const float4* __restrict__ C, int cs, int NS, const float* __restric
 
 // distance pass (:386-402): sums {sum dw, sum dw * n.p} with multiplicity
 __global__ void __launch_bounds__(FE_T)
-k_fe_ground_dist(const float4* __restrict__ C, int cs, const int* __restrict__ mult, const double* __restrict__ fit, double* __restrict__ partials) {
+k_fe_ground_dist(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp, const int* __restrict__ mult, const double* __restrict__ fit, double* __restrict__ partials) {
   // fit: centre (3), normal (3), eigenvectors (9), ground present (1) -- written by k_fe_ground_fit, never seen by the host in between
+  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
   const int j = blockIdx.x * FE_T + threadIdx.x;
   double a0 = 0, a1 = 0;
   if (fit[15] != 0.0 && j < cs && mult[j] > 0) {
@@ -416,8 +424,9 @@ __global__ void __launch_bounds__(WAVE) k_fe_fold(const double* __restrict__ par
 }
 
 // ground points with duplicates in the reference's push order (/laser_cloud_ground, :336)
-__global__ void k_fe_ground_list(const float4* __restrict__ C, int cs, int NS, const float* __restrict__ range_vec, const int* __restrict__ meta,
+__global__ void k_fe_ground_list(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp, int NS, const float* __restrict__ range_vec, const int* __restrict__ meta,
                                  const int* __restrict__ seedcnt, const int* __restrict__ seedpos, float4* __restrict__ out, int cap) {
+  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cs || seedcnt[c] == 0) return;
   const int ring = ring_of_index(meta, NS, c);
@@ -769,29 +778,29 @@ void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, cons
   hipLaunchKernelGGL(k_fe_hist_scan, dim3(1), dim3(64 * HS_CH), 0, s, nb, NS, blk_hist, meta);
   hipLaunchKernelGGL(k_fe_scatter, dim3(nb), dim3(FE_T), 0, s, in, stride_f, n, ring, rank_in_block, blk_hist, meta, st, C, inum2);
 }
-void fe_stencils(hipStream_t s, const float4* C, int cs, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
+void fe_stencils(hipStream_t s, const float4* C, int cs, const int* csp, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
                  float* curv2, float* icurv, float* dsrc, float* osrc, int* picked) {
   const int nb = nblk(cs, FE_T);
-  hipLaunchKernelGGL(k_fe_range_angle, dim3(nb), dim3(FE_T), 0, s, C, cs, range_vec, scan_angle);
-  hipLaunchKernelGGL(k_fe_smooth, dim3(nb), dim3(FE_T), 0, s, cs, range_vec, scan_angle, inum2, inum);
-  hipLaunchKernelGGL(k_fe_curv, dim3(nb), dim3(FE_T), 0, s, C, cs, range_vec, scan_angle, inum, curv, curv2, icurv, dsrc, osrc);
-  hipLaunchKernelGGL(k_fe_occlusion, dim3(nb), dim3(FE_T), 0, s, cs, range_vec, picked);
+  hipLaunchKernelGGL(k_fe_range_angle, dim3(nb), dim3(FE_T), 0, s, C, cs, csp, range_vec, scan_angle);
+  hipLaunchKernelGGL(k_fe_smooth, dim3(nb), dim3(FE_T), 0, s, cs, csp, range_vec, scan_angle, inum2, inum);
+  hipLaunchKernelGGL(k_fe_curv, dim3(nb), dim3(FE_T), 0, s, C, cs, csp, range_vec, scan_angle, inum, curv, curv2, icurv, dsrc, osrc);
+  hipLaunchKernelGGL(k_fe_occlusion, dim3(nb), dim3(FE_T), 0, s, cs, csp, range_vec, picked);
 }
-void fe_ground(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
+void fe_ground(hipStream_t s, const float4* C, int cs, const int* csp, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
                double* partials, double* out11) {
   const int nb = nblk(cs, FE_T);
-  hipLaunchKernelGGL(k_fe_ground, dim3(nb), dim3(FE_T), 0, s, C, cs, NS, range_vec, meta, gmark, mult, seedcnt, partials);
+  hipLaunchKernelGGL(k_fe_ground, dim3(nb), dim3(FE_T), 0, s, C, cs, csp, NS, range_vec, meta, gmark, mult, seedcnt, partials);
   hipLaunchKernelGGL(k_fe_fold, dim3(11), dim3(WAVE), 0, s, partials, nb, 11, out11);
 }
-void fe_ground_fit_dist(hipStream_t s, const float4* C, int cs, const int* mult, const double* g11, double* fit, double* partials, double* out2) {
+void fe_ground_fit_dist(hipStream_t s, const float4* C, int cs, const int* csp, const int* mult, const double* g11, double* fit, double* partials, double* out2) {
   const int nb = nblk(cs, FE_T);
   hipLaunchKernelGGL(k_fe_ground_fit, dim3(1), dim3(WAVE), 0, s, g11, fit);
-  hipLaunchKernelGGL(k_fe_ground_dist, dim3(nb), dim3(FE_T), 0, s, C, cs, mult, fit, partials);
+  hipLaunchKernelGGL(k_fe_ground_dist, dim3(nb), dim3(FE_T), 0, s, C, cs, csp, mult, fit, partials);
   hipLaunchKernelGGL(k_fe_fold, dim3(2), dim3(WAVE), 0, s, partials, nb, 2, out2);
 }
-void fe_ground_list(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, const int* seedcnt,
+void fe_ground_list(hipStream_t s, const float4* C, int cs, const int* csp, int NS, const float* range_vec, const int* meta, const int* seedcnt,
                     const int* seedpos, float4* out, int cap) {
-  hipLaunchKernelGGL(k_fe_ground_list, dim3(nblk(cs, FE_T)), dim3(FE_T), 0, s, C, cs, NS, range_vec, meta, seedcnt, seedpos, out, cap);
+  hipLaunchKernelGGL(k_fe_ground_list, dim3(nblk(cs, FE_T)), dim3(FE_T), 0, s, C, cs, csp, NS, range_vec, meta, seedcnt, seedpos, out, cap);
 }
 void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const float* curv, const float* curv2, const float* icurv, const int* inum,
                const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags, int max_ring, int* sorted_curv,

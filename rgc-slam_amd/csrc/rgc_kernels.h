@@ -140,13 +140,14 @@ void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, 
 void fe_half(hipStream_t s, const float* in, int stride_f, int n, const int* ring, int* st);
 void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, const int* ring, int* rank_in_block, int* blk_hist, int* meta,
                const int* st, float4* C, int* inum2);
-void fe_stencils(hipStream_t s, const float4* C, int cs, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
+// cs: the launch's bound; csp (nullable): the sweep's size on the device (meta[128]), read by the kernels -- the host need not know it
+void fe_stencils(hipStream_t s, const float4* C, int cs, const int* csp, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
                  float* curv2, float* icurv, float* dsrc, float* osrc, int* picked);
-void fe_ground(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
+void fe_ground(hipStream_t s, const float4* C, int cs, const int* csp, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
                double* partials, double* out11);
 // plane fit of the ground sums (g11) into fit[16] on the device, then the distance sums into out2[2]
-void fe_ground_fit_dist(hipStream_t s, const float4* C, int cs, const int* mult, const double* g11, double* fit, double* partials, double* out2);
-void fe_ground_list(hipStream_t s, const float4* C, int cs, int NS, const float* range_vec, const int* meta, const int* seedcnt,
+void fe_ground_fit_dist(hipStream_t s, const float4* C, int cs, const int* csp, const int* mult, const double* g11, double* fit, double* partials, double* out2);
+void fe_ground_list(hipStream_t s, const float4* C, int cs, const int* csp, int NS, const float* range_vec, const int* meta, const int* seedcnt,
                     const int* seedpos, float4* out, int cap);
 void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const float* curv, const float* curv2, const float* icurv, const int* inum,
                const int* gmark, int* picked, int* ipicked, int* label, int* ilabel, int* slots, int* flags, int max_ring /* points in the largest ring: sizes the LDS window */,

@@ -50,14 +50,15 @@ class ScanRegistration:
         finally:
             self._L.rgc_device_free(self._h, d)
 
-    def laserCloudHandler(self, xyzi, diagnostics: bool = True) -> dict:
-        """scanRegistration.cpp:89-730.  xyzi: raw cloud (n, >=4) float32 in firing order."""
+    def laserCloudHandler(self, xyzi, diagnostics: bool = True, cloud: bool = True) -> dict:
+        """scanRegistration.cpp:89-730.  xyzi: raw cloud (n, >=4) float32 in firing order.  cloud=False: the ring-major sweep stays on the
+        device (rgc_frontend_cloud_device), as in the chained frame body -- the library then sizes the sweep's launches from the previous one."""
         a = np.ascontiguousarray(xyzi, dtype=np.float32)
         if a.ndim != 2 or a.shape[1] < 4:
             raise RgcError(_lib.ERR_INVALID, "cloud must be (n, >=4) float32: x, y, z, intensity")
-        return self._run(a.ctypes.data, a.shape[0], a.strides[0], diagnostics, on_device=False, keepalive=a)
+        return self._run(a.ctypes.data, a.shape[0], a.strides[0], diagnostics, on_device=False, keepalive=a, want_cloud=cloud)
 
-    def _run(self, ptr, n, stride, diagnostics, on_device, keepalive=None) -> dict:
+    def _run(self, ptr, n, stride, diagnostics, on_device, keepalive=None, want_cloud=True) -> dict:
         ns = self.params.n_scans
         fcap, gcap = ns * 6 * 41, max(10 * n, 1)
         f32, i32 = C.POINTER(C.c_float), C.POINTER(C.c_int)
@@ -72,6 +73,8 @@ class ScanRegistration:
         for k, v in {**bufs, **diag}.items():
             setattr(o, k, v.ctypes.data_as(i32 if v.dtype == np.int32 else f32))
         o.cloud_cap, o.feat_cap, o.ground_cap = max(n, 1), fcap, gcap
+        if not want_cloud:
+            o.cloud = None
         fn = self._L.rgc_frontend_device if on_device else self._L.rgc_frontend
         rc = fn(self._h, ptr, n, stride, C.byref(self.params), C.byref(o))
         if rc != 0:

@@ -88,3 +88,25 @@ def test_edge_cases(fe16, orc):
     high = raw[raw[:, 2] > 0.4]
     gh, oh = _compare(fe16, orc, high, 16)
     assert not gh["ground_valid"] and gh["n_ground"] == 0
+
+
+def test_sweeps_sized_from_the_previous_one(fe16):
+    """With the ring-major sweep left on the device (the chained frame body) the library does not read the sweep's size back before the
+    stencil / ground / selection kernels from the second sweep on: launches are sized from the raw count, the selection window from the
+    previous sweep's largest ring.  Same labels, flags and feature clouds as the synchronous path -- also when a ring outgrows the guess
+    (a sparse sweep followed by a dense one) and for an empty sweep in between."""
+    from rgc_slam_amd import frontend
+    spec = frontend.ScanRegistration(16)
+    try:
+        T = np.eye(4); T[:3, 3] = [1.0, -0.5, 0.0]
+        sweeps = [_raw(), _raw(), _raw(seed=5, pose=T), _raw(n_az=500, seed=6), _raw(n_az=1800, seed=7), np.full((300, 4), 1000.0, np.float32), _raw(seed=8)]
+        for raw in sweeps:
+            a = spec.laserCloudHandler(raw, cloud=False)
+            b = fe16.laserCloudHandler(raw)
+            assert a["n_cloud"] == b["n_cloud"] and np.array_equal(a["ring_count"], b["ring_count"])
+            for k in ("curvature", "curvature2", "inten_curvature", "ground_marked", "picked", "label", "inten_label", "sharp", "flat", "inten", "ground_pts"):
+                assert np.array_equal(a[k], b[k]), k
+            assert a["n_sharp_own"] == b["n_sharp_own"] and a["n_ground"] == b["n_ground"] and a["ground_valid"] == b["ground_valid"]
+            assert np.array_equal(a["groundparam"], b["groundparam"])
+    finally:
+        spec.close()
