@@ -110,13 +110,23 @@ def time_config(registration, oracle, name, tgt, scans, guess0, prior=None):
         w.align(prior[0] if prior else guess0, want_output=False, want_fitness=True)
     g_in1 = prior[1] if prior else v.getFinalTransformation()
     pv.synchronize()
+    # a cyclic-GC pass over torch's object graph (40-65 ms, scripts/exp_stall.py) inside a 3-frame timed region quarters the figure:
+    # the garbage made so far (data generation, the oracle's arrays) is collected here and the survivors are frozen, as before the main loop
+    import gc
+    gc.collect()
+    gc.freeze()
     t1 = time.perf_counter()
     g, fin_seq = g_in1, []
+    trace = os.environ.get("RGC_BENCH_TRACE")  # developer aid: where a frame's time goes, per call
     for i in range(1, frames + 1):
+        ta = time.perf_counter()
         setc(i, v)
+        tb = time.perf_counter()
         v.align(prior[i] if prior else g, want_output=False, want_fitness=True)
         g = v.getFinalTransformation()
         fin_seq.append(g)
+        if trace:
+            print(f"[bench] {name[:2]} frame {i}: set clouds {1e3 * (tb - ta):.2f} ms, align {1e3 * (time.perf_counter() - tb):.2f} ms", file=sys.stderr)
     v.synchronize()
     el_seq = time.perf_counter() - t1
     t1 = time.perf_counter()

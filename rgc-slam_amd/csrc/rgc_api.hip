@@ -351,6 +351,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
         if ((rc = ensure(c, cl.start, sizeof(int) * wc1))) return rc;
         if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (wc1 / 2048 + 2)))) return rc;
         if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)w.ncell))) return rc;
+        if (is_target) {  // ... and the voxel table (80 B per cell of a map denser than its grid: 1.3 GB at 16 M cells -- growing it in the next
+                          // frame, when the widened grid is first used, was a 77 ms allocation inside c5's three timed frames on a fresh box)
+          const size_t vw = (size_t)(n < w.ncell ? n : w.ncell);
+          if ((rc = ensure(c, cl.vox, sizeof(double) * rgck::kVoxRec * vw))) return rc;
+          if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vw))) return rc;
+        }
       }
     }
     cl.grid = g;
