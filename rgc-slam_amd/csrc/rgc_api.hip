@@ -1743,9 +1743,12 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   // OUTD: [0..10] the ground sums, [16..31] the plane fit, [32..33] the distance sums -- fitted on the device, read back with the features
   rgck::fe_ground_fit_dist(s, FE(CL, float4), cs, csp, FE(MULT, int), FE(OUTD, double), FE(OUTD, double) + 16, FE(PART, double), FE(OUTD, double) + 32);
   // /laser_cloud_ground: pushes in reference order (with duplicates); empty when no ground seed was found
-  rgck::exclusive_scan(s, FE(SCNT, int), FE(SPOS, int), cs, FE(BSUM, int));
-  const int gcap_dev = 10 * n;
-  rgck::fe_ground_list(s, FE(CL, float4), cs, csp, NS, FE(RANGE, float), FE(META, int), FE(SCNT, int), FE(SPOS, int), FE(GLIST, float4), gcap_dev);
+  // (only when the caller takes the list: the chained frame body does not, and these are four launches)
+  if (out->ground_pts && out->ground_cap > 0) {
+    rgck::exclusive_scan(s, FE(SCNT, int), FE(SPOS, int), cs, FE(BSUM, int));
+    const int gcap_dev = 10 * n;
+    rgck::fe_ground_list(s, FE(CL, float4), cs, csp, NS, FE(RANGE, float), FE(META, int), FE(SCNT, int), FE(SPOS, int), FE(GLIST, float4), gcap_dev);
+  }
   // A7 + A8
   rgck::fe_select(s, FE(CL, float4), NS, FE(META, int), FE(CURV, float), FE(CURV2, float), FE(ICURV, float), FE(INUM, int), FE(GMARK, int),
                   FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), FE(SLOTS, int), d_flags, max_ring, FE(SORTC, int), FE(SORTI, int));
