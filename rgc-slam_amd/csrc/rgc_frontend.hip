@@ -180,92 +180,99 @@ __global__ void k_fe_scatter(const float* __restrict__ in, int stride_f, int n, 
 }
 
 // ---- A3: range, incidence angle (:234-255) ----
-__global__ void k_fe_range_angle(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp, float* __restrict__ range_vec,
-                                 float* __restrict__ scan_angle) {
+// A3 / A4 / A6 in ONE launch (they were four: range + incidence angle, intensity smoothing, the curvature stencils, the occlusion mask --
+// each a few microseconds of work behind a dependent-launch gap).  A workgroup stages its 256 points and ten neighbours on either side
+// in LDS; the +-5 stencils of the smoothed intensity need the smoothing -- itself a +-5 stencil gated by the incidence angle, a +-5
+// construction -- of the five points past the tile, hence ten.  Every value is computed by the expression the separate kernels used, in
+// the same order; halo values are recomputed by the neighbouring workgroup for its own tile, identically.
+//   range / incidence angle (:234-255), near-range intensity smoothing on the int intensities, truncating on every store like the
+//   deque<int> (:257-268), curvature stencils (:270-306), occlusion / parallel-beam mask (:433-456; picked[] zeroed before)
+__global__ void __launch_bounds__(FE_T)
+k_fe_stencils(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp, const int* __restrict__ inum2, float* __restrict__ range_vec,
+              float* __restrict__ scan_angle, int* __restrict__ inum, float* __restrict__ curv, float* __restrict__ curv2, float* __restrict__ icurv,
+              float* __restrict__ dsrc, float* __restrict__ osrc, int* __restrict__ picked) {
+  constexpr int H = 10, W = FE_T + 2 * H;
+  __shared__ float sx[W], sy[W], sz[W], sr[W], sa[W];
+  __shared__ int si2[W], si[W];
   const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cs) return;
-  const float4 p4 = C[i];
-  const float rg = sqrtf(p4.x * p4.x + p4.y * p4.y + p4.z * p4.z);
-  range_vec[i] = rg;
-  float sa = 0.f;  // zero-initialised per frame (the reference leaks earlier frames' values here)
-  if (i >= 5 && i < cs - 5 && rg < 2) {
-    const float4 a4 = C[i + 5], b4 = C[i - 5];
-    const double a[3] = {a4.x, a4.y, a4.z}, b[3] = {b4.x, b4.y, b4.z}, p[3] = {p4.x, p4.y, p4.z};
-    const double c[3] = {(a[0] + b[0]) / 2, (a[1] + b[1]) / 2, (a[2] + b[2]) / 2};
-    const double u[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}, v[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
-    const double nrm[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
-    const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]), pn = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-    sa = (float)((nrm[0] * p[0] + nrm[1] * p[1] + nrm[2] * p[2]) / (nn * pn));
-    if (sa < 0) sa = -sa;
+  const int b0 = blockIdx.x * FE_T;
+  if (b0 >= cs) return;
+  for (int t = threadIdx.x; t < W; t += FE_T) {
+    const int g = b0 - H + t;
+    float x = 0.f, y = 0.f, z = 0.f, rg = 0.f;
+    int iv = 0;
+    if (g >= 0 && g < cs) {
+      const float4 p4 = C[g];
+      x = p4.x; y = p4.y; z = p4.z;
+      rg = sqrtf(p4.x * p4.x + p4.y * p4.y + p4.z * p4.z);
+      iv = inum2[g];
+    }
+    sx[t] = x; sy[t] = y; sz[t] = z; sr[t] = rg; si2[t] = iv;
   }
-  scan_angle[i] = sa;
-}
-
-// near-range intensity smoothing on the int intensities, truncating on every store like the deque<int> (:257-268)
-__global__ void k_fe_smooth(int cs_in, const int* __restrict__ csp, const float* __restrict__ range_vec, const float* __restrict__ scan_angle, const int* __restrict__ inum2,
-                            int* __restrict__ inum) {
-  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cs) return;
-  int v = inum2[i];
-  if (i >= 5 && i < cs - 5 && scan_angle[i] < 0.07 && range_vec[i] < 2) {
-    v = (int)(0.9 * inum2[i]);
-    for (int j = -5; j < 6; j++)
-      if (j != 0) v = (int)(v + 0.005 * inum2[i + j]);
+  __syncthreads();
+  for (int t = 5 + threadIdx.x; t < W - 5; t += FE_T) {
+    const int g = b0 - H + t;
+    float v = 0.f;  // zero-initialised per frame (the reference leaks earlier frames' values here)
+    if (g >= 5 && g < cs - 5 && sr[t] < 2) {
+      const double a[3] = {sx[t + 5], sy[t + 5], sz[t + 5]}, b[3] = {sx[t - 5], sy[t - 5], sz[t - 5]}, p[3] = {sx[t], sy[t], sz[t]};
+      const double c[3] = {(a[0] + b[0]) / 2, (a[1] + b[1]) / 2, (a[2] + b[2]) / 2};
+      const double u[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}, w[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+      const double nrm[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
+      const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]), pn = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+      v = (float)((nrm[0] * p[0] + nrm[1] * p[1] + nrm[2] * p[2]) / (nn * pn));
+      if (v < 0) v = -v;
+    }
+    sa[t] = v;
   }
-  inum[i] = v;
-}
-
-// ---- A4: curvature stencils (:270-306) ----
-__global__ void k_fe_curv(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp, const float* __restrict__ range_vec, const float* __restrict__ scan_angle,
-                          const int* __restrict__ inum, float* __restrict__ curv, float* __restrict__ curv2, float* __restrict__ icurv,
-                          float* __restrict__ dsrc, float* __restrict__ osrc) {
-  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __syncthreads();
+  for (int t = 5 + threadIdx.x; t < W - 5; t += FE_T) {
+    const int g = b0 - H + t;
+    int v = si2[t];
+    if (g >= 5 && g < cs - 5 && sa[t] < 0.07 && sr[t] < 2) {
+      v = (int)(0.9 * si2[t]);
+      for (int j = -5; j < 6; j++)
+        if (j != 0) v = (int)(v + 0.005 * si2[t + j]);
+    }
+    si[t] = v;
+  }
+  __syncthreads();
+  const int i = b0 + threadIdx.x, t = H + threadIdx.x;
   if (i >= cs) return;
+  range_vec[i] = sr[t];
+  scan_angle[i] = sa[t];
+  inum[i] = si[t];
   float cv = 0.f, cv2 = 0.f, icv = 0.f, ds = 0.f, os = 0.f;
   if (i >= 5 && i < cs - 5) {
-    float4 c = C[i - 5];
-    float dX = c.x, dY = c.y, dZ = c.z;
+    float dX = sx[t - 5], dY = sy[t - 5], dZ = sz[t - 5];
 #pragma unroll
-    for (int k = -4; k <= -1; k++) { c = C[i + k]; dX = dX + c.x; dY = dY + c.y; dZ = dZ + c.z; }
-    c = C[i];
-    dX = dX - 10 * c.x; dY = dY - 10 * c.y; dZ = dZ - 10 * c.z;
+    for (int k = -4; k <= -1; k++) { dX = dX + sx[t + k]; dY = dY + sy[t + k]; dZ = dZ + sz[t + k]; }
+    dX = dX - 10 * sx[t]; dY = dY - 10 * sy[t]; dZ = dZ - 10 * sz[t];
 #pragma unroll
-    for (int k = 1; k <= 5; k++) { c = C[i + k]; dX = dX + c.x; dY = dY + c.y; dZ = dZ + c.z; }
-    const int dIi = inum[i - 5] + inum[i - 4] + inum[i - 3] + inum[i - 2] + inum[i - 1] - 10 * inum[i] + inum[i + 1] + inum[i + 2] +
-                    inum[i + 3] + inum[i + 4] + inum[i + 5];
+    for (int k = 1; k <= 5; k++) { dX = dX + sx[t + k]; dY = dY + sy[t + k]; dZ = dZ + sz[t + k]; }
+    const int dIi = si[t - 5] + si[t - 4] + si[t - 3] + si[t - 2] + si[t - 1] - 10 * si[t] + si[t + 1] + si[t + 2] + si[t + 3] + si[t + 4] + si[t + 5];
     const float diffI = (float)dIi;
-    float dis_factor = (float)(2.0 / (1.0 + range_vec[i] / 20.0));
+    float dis_factor = (float)(2.0 / (1.0 + sr[t] / 20.0));
     if (dis_factor < 0.2) dis_factor = 0.2f;
     cv = (dX * dX + dY * dY + dZ * dZ) * dis_factor;
     ds = (float)(0.5 + dis_factor);
-    if (scan_angle[i] < 0.07 && range_vec[i] < 2) {
-      os = (float)(scan_angle[i] * 10 + 0.6);
-      icv = (float)((scan_angle[i] + 0.3) * diffI);
+    if (sa[t] < 0.07 && sr[t] < 2) {
+      os = (float)(sa[t] * 10 + 0.6);
+      icv = (float)((sa[t] + 0.3) * diffI);
     } else {
       os = 3;
       icv = diffI;
     }
-    const float dr = (float)(range_vec[i - 5] + range_vec[i - 4] + range_vec[i - 3] + range_vec[i - 2] + range_vec[i - 1] - 10.0 * range_vec[i] +
-                             range_vec[i + 1] + range_vec[i + 2] + range_vec[i + 3] + range_vec[i + 4] + range_vec[i + 5]);
+    const float dr = (float)(sr[t - 5] + sr[t - 4] + sr[t - 3] + sr[t - 2] + sr[t - 1] - 10.0 * sr[t] + sr[t + 1] + sr[t + 2] + sr[t + 3] + sr[t + 4] + sr[t + 5]);
     cv2 = fabsf(dr * dis_factor);
+    // occlusion / parallel beams
+    const float d1 = sr[t], d2 = sr[t + 1];
+    if (d1 - d2 > 0.04 * d2) {
+      for (int k = -5; k <= 0; k++) picked[i + k] = 1;
+    } else if (d2 - d1 > 0.04 * d1) {
+      for (int k = 1; k <= 6; k++) if (i + k < cs) picked[i + k] = 1;
+    }
   }
   curv[i] = cv; curv2[i] = cv2; icurv[i] = icv; dsrc[i] = ds; osrc[i] = os;
-}
-
-// ---- A6: occlusion / parallel-beam mask (:433-456); picked[] zeroed before ----
-__global__ void k_fe_occlusion(int cs_in, const int* __restrict__ csp, const float* __restrict__ range_vec, int* __restrict__ picked) {
-  const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 5 || i >= cs - 5) return;
-  const float d1 = range_vec[i], d2 = range_vec[i + 1];
-  if (d1 - d2 > 0.04 * d2) {
-    for (int k = -5; k <= 0; k++) picked[i + k] = 1;
-  } else if (d2 - d1 > 0.04 * d1) {
-    for (int k = 1; k <= 6; k++) if (i + k < cs) picked[i + k] = 1;
-  }
 }
 
 // ---- A5: ground marking (:308-353) ----
@@ -780,11 +787,8 @@ void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, cons
 }
 void fe_stencils(hipStream_t s, const float4* C, int cs, const int* csp, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
                  float* curv2, float* icurv, float* dsrc, float* osrc, int* picked) {
-  const int nb = nblk(cs, FE_T);
-  hipLaunchKernelGGL(k_fe_range_angle, dim3(nb), dim3(FE_T), 0, s, C, cs, csp, range_vec, scan_angle);
-  hipLaunchKernelGGL(k_fe_smooth, dim3(nb), dim3(FE_T), 0, s, cs, csp, range_vec, scan_angle, inum2, inum);
-  hipLaunchKernelGGL(k_fe_curv, dim3(nb), dim3(FE_T), 0, s, C, cs, csp, range_vec, scan_angle, inum, curv, curv2, icurv, dsrc, osrc);
-  hipLaunchKernelGGL(k_fe_occlusion, dim3(nb), dim3(FE_T), 0, s, cs, csp, range_vec, picked);
+  hipLaunchKernelGGL(k_fe_stencils, dim3(nblk(cs, FE_T)), dim3(FE_T), 0, s, C, cs, csp, inum2, range_vec, scan_angle, inum, curv, curv2, icurv, dsrc, osrc,
+                     picked);
 }
 void fe_ground(hipStream_t s, const float4* C, int cs, const int* csp, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
                double* partials, double* out11) {
