@@ -1704,7 +1704,8 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   rgck::FeParams fp{NS, prm->min_range, prm->max_range};
   rgck::fe_filter(s, d_in, stride_f, n, fp, FE(RING, int), d_st);
   rgck::fe_half(s, d_in, stride_f, n, FE(RING, int), d_st);
-  rgck::fe_bucket(s, d_in, stride_f, n, NS, FE(RING, int), FE(RANK, int), FE(HIST, int), FE(META, int), d_st, FE(CL, float4), FE(INUM2, int));
+  rgck::fe_bucket(s, d_in, stride_f, n, NS, FE(RING, int), FE(RANK, int), FE(HIST, int), FE(META, int), d_st, FE(CL, float4), FE(INUM2, int),
+                  FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int));
   // pinned staging: [0, 1024) meta + ground sums + flags, then the three feature clouds
   const size_t stage_need = 1024 + 3 * 20u * (size_t)fcap;
   if (c->h_stage_cap < stage_need) {
@@ -1735,13 +1736,13 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
     if (cs == 0) return RGC_OK;
     if (out->cloud && out->cloud_cap < cs) return fail(c, RGC_ERR_INVALID, "cloud_cap %d < %d points", out->cloud_cap, cs);
   }
-  rgck::fe_zero4(s, FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int), cs);
   rgck::fe_stencils(s, FE(CL, float4), cs, csp, FE(RANGE, float), FE(ANGLE, float), FE(INUM2, int), FE(INUM, int), FE(CURV, float), FE(CURV2, float),
                     FE(ICURV, float), FE(DSRC, float), FE(OSRC, float), FE(PICK, int));
   // A5: ground set (with multiplicities) -> weighted centroid / covariance -> plane (scanRegistration.cpp:308-431)
-  rgck::fe_ground(s, FE(CL, float4), cs, csp, NS, FE(RANGE, float), FE(META, int), FE(GMARK, int), FE(MULT, int), FE(SCNT, int), FE(PART, double), FE(OUTD, double));
+  rgck::fe_ground(s, FE(CL, float4), cs, csp, NS, FE(RANGE, float), FE(META, int), FE(GMARK, int), FE(MULT, int), FE(SCNT, int), FE(PART, double), FE(OUTD, double),
+                  FE(OUTD, double) + 16);
   // OUTD: [0..10] the ground sums, [16..31] the plane fit, [32..33] the distance sums -- fitted on the device, read back with the features
-  rgck::fe_ground_fit_dist(s, FE(CL, float4), cs, csp, FE(MULT, int), FE(OUTD, double), FE(OUTD, double) + 16, FE(PART, double), FE(OUTD, double) + 32);
+  rgck::fe_ground_dist(s, FE(CL, float4), cs, csp, FE(MULT, int), FE(OUTD, double) + 16, FE(PART, double), FE(OUTD, double) + 32);
   // /laser_cloud_ground: pushes in reference order (with duplicates); empty when no ground seed was found
   // (only when the caller takes the list: the chained frame body does not, and these are four launches)
   if (out->ground_pts && out->ground_cap > 0) {

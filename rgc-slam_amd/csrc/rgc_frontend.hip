@@ -156,9 +156,11 @@ __global__ void __launch_bounds__(64 * HS_CH) k_fe_hist_scan(int nblocks, int NS
 // pass 3: scatter into the ring-major cloud with intensity = ring + 0.1 * relTime (:196-213)
 __global__ void k_fe_scatter(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ ring, const int* __restrict__ rank_in_block,
                              const int* __restrict__ blk_hist, const int* __restrict__ meta, const int* __restrict__ st,
-                             float4* __restrict__ C, int* __restrict__ inum2) {
+                             float4* __restrict__ C, int* __restrict__ inum2, int* __restrict__ z0, int* __restrict__ z1, int* __restrict__ z2,
+                             int* __restrict__ z3) {
   const int i = blockIdx.x * FE_T + threadIdx.x;
   if (i >= n) return;
+  z0[i] = 0; z1[i] = 0; z2[i] = 0; z3[i] = 0;  // the selection's flag and label arrays, zeroed per sweep (the sweep holds at most n points)
   const int r = ring[i];
   if (r < 0) return;
   float startOri, endOri;
@@ -347,7 +349,7 @@ k_fe_ground(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp
 // distance pass (:386-402): sums {sum dw, sum dw * n.p} with multiplicity
 __global__ void __launch_bounds__(FE_T)
 k_fe_ground_dist(const float4* __restrict__ C, int cs_in, const int* __restrict__ csp, const int* __restrict__ mult, const double* __restrict__ fit, double* __restrict__ partials) {
-  // fit: centre (3), normal (3), eigenvectors (9), ground present (1) -- written by k_fe_ground_fit, never seen by the host in between
+  // fit: centre (3), normal (3), eigenvectors (9), ground present (1) -- written by k_fe_fold_fit, never seen by the host in between
   const int cs = csp ? min(cs_in, *csp) : cs_in;  // the sweep's size on the device (k_fe_hist_scan), cs_in = the launch's bound
   const int j = blockIdx.x * FE_T + threadIdx.x;
   double a0 = 0, a1 = 0;
@@ -377,8 +379,7 @@ k_fe_ground_dist(const float4* __restrict__ C, int cs_in, const int* __restrict_
 // pass can start: weighted centroid, covariance, symmetric eigen-decomposition (cyclic Jacobi, eigenvalues ascending like
 // Eigen::SelfAdjointEigenSolver), normal = the smallest eigenvector oriented towards the centroid.  One lane; ~2 us.
 // g11: {W, Wx, Wy, Wz, Wxx, Wxy, Wxz, Wyy, Wyz, Wzz, count};  fit: centre (3), normal (3), V row-major (9), present (1)
-__global__ void k_fe_ground_fit(const double* __restrict__ g11, double* __restrict__ fit) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void fe_ground_fit(const double* g11, double* __restrict__ fit) {
   const long long gsize = (long long)(g11[10] + 0.5);
   fit[15] = gsize > 0 ? 1.0 : 0.0;
   if (gsize <= 0) return;
@@ -419,6 +420,18 @@ __global__ void k_fe_ground_fit(const double* __restrict__ g11, double* __restri
   for (int a = 0; a < 3; a++) nrm[a] /= nl;
   if (ctr[0] * nrm[0] + ctr[1] * nrm[1] + ctr[2] * nrm[2] < 0) for (int a = 0; a < 3; a++) nrm[a] = -nrm[a];  // :374-377
   for (int a = 0; a < 3; a++) { fit[a] = ctr[a]; fit[3 + a] = nrm[a]; fit[6 + a * 3] = c0[a]; fit[6 + a * 3 + 1] = c1[a]; fit[6 + a * 3 + 2] = c2[a]; }
+}
+
+// the fold of k_fe_ground's block sums (eleven columns, one wave each, the fixed order of k_fe_fold) and the plane fit in ONE launch
+__global__ void __launch_bounds__(11 * WAVE) k_fe_fold_fit(const double* __restrict__ partials, int nrows, double* __restrict__ out11, double* __restrict__ fit) {
+  __shared__ double g[11];
+  const int a = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  double sum = 0;
+  for (int r = lane; r < nrows; r += WAVE) sum += partials[(size_t)r * 11 + a];
+  sum = fe_wave_sum(sum);
+  if (lane == 0) { out11[a] = sum; g[a] = sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) fe_ground_fit(g, fit);
 }
 
 // fixed-order fold of per-block rows (deterministic)
@@ -765,13 +778,6 @@ static inline int nblk(long long n, int t) { return (int)((n + t - 1) / t); }
 int fe_blocks(int n) { return nblk(n, FE_T); }
 int fe_slot_ints() { return SLOT; }
 
-__global__ void k_fe_zero4(int* __restrict__ a, int* __restrict__ b, int* __restrict__ c, int* __restrict__ d, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { a[i] = 0; b[i] = 0; c[i] = 0; d[i] = 0; }
-}
-void fe_zero4(hipStream_t s, int* a, int* b, int* c, int* d, int n) {
-  if (n > 0) hipLaunchKernelGGL(k_fe_zero4, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, a, b, c, d, n);
-}
 void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st) {
   hipLaunchKernelGGL(k_fe_filter, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, in, stride_f, n, p, ring, st);
 }
@@ -779,11 +785,11 @@ void fe_half(hipStream_t s, const float* in, int stride_f, int n, const int* rin
   hipLaunchKernelGGL(k_fe_half, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, in, stride_f, n, ring, st);
 }
 void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, const int* ring, int* rank_in_block, int* blk_hist, int* meta,
-               const int* st, float4* C, int* inum2) {
+               const int* st, float4* C, int* inum2, int* z0, int* z1, int* z2, int* z3) {
   const int nb = nblk(n, FE_T);
   hipLaunchKernelGGL(k_fe_rank, dim3(nb), dim3(FE_T), 0, s, n, ring, rank_in_block, blk_hist);
   hipLaunchKernelGGL(k_fe_hist_scan, dim3(1), dim3(64 * HS_CH), 0, s, nb, NS, blk_hist, meta);
-  hipLaunchKernelGGL(k_fe_scatter, dim3(nb), dim3(FE_T), 0, s, in, stride_f, n, ring, rank_in_block, blk_hist, meta, st, C, inum2);
+  hipLaunchKernelGGL(k_fe_scatter, dim3(nb), dim3(FE_T), 0, s, in, stride_f, n, ring, rank_in_block, blk_hist, meta, st, C, inum2, z0, z1, z2, z3);
 }
 void fe_stencils(hipStream_t s, const float4* C, int cs, const int* csp, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
                  float* curv2, float* icurv, float* dsrc, float* osrc, int* picked) {
@@ -791,14 +797,13 @@ void fe_stencils(hipStream_t s, const float4* C, int cs, const int* csp, float* 
                      picked);
 }
 void fe_ground(hipStream_t s, const float4* C, int cs, const int* csp, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
-               double* partials, double* out11) {
+               double* partials, double* out11, double* fit) {
   const int nb = nblk(cs, FE_T);
   hipLaunchKernelGGL(k_fe_ground, dim3(nb), dim3(FE_T), 0, s, C, cs, csp, NS, range_vec, meta, gmark, mult, seedcnt, partials);
-  hipLaunchKernelGGL(k_fe_fold, dim3(11), dim3(WAVE), 0, s, partials, nb, 11, out11);
+  hipLaunchKernelGGL(k_fe_fold_fit, dim3(1), dim3(11 * WAVE), 0, s, partials, nb, out11, fit);
 }
-void fe_ground_fit_dist(hipStream_t s, const float4* C, int cs, const int* csp, const int* mult, const double* g11, double* fit, double* partials, double* out2) {
+void fe_ground_dist(hipStream_t s, const float4* C, int cs, const int* csp, const int* mult, const double* fit, double* partials, double* out2) {
   const int nb = nblk(cs, FE_T);
-  hipLaunchKernelGGL(k_fe_ground_fit, dim3(1), dim3(WAVE), 0, s, g11, fit);
   hipLaunchKernelGGL(k_fe_ground_dist, dim3(nb), dim3(FE_T), 0, s, C, cs, csp, mult, fit, partials);
   hipLaunchKernelGGL(k_fe_fold, dim3(2), dim3(WAVE), 0, s, partials, nb, 2, out2);
 }

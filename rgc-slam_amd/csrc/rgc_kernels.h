@@ -135,18 +135,17 @@ void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int*
 // ---- A1-A8 front-end (rgc_frontend.hip) ----
 int fe_blocks(int n);
 int fe_slot_ints();
-void fe_zero4(hipStream_t s, int* a, int* b, int* c, int* d, int n);  // four per-point flag arrays in one launch
 void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st);
 void fe_half(hipStream_t s, const float* in, int stride_f, int n, const int* ring, int* st);
 void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, const int* ring, int* rank_in_block, int* blk_hist, int* meta,
-               const int* st, float4* C, int* inum2);
+               const int* st, float4* C, int* inum2, int* z0, int* z1, int* z2, int* z3);  // z0..z3: four per-point arrays zeroed on the way (n ints each)
 // cs: the launch's bound; csp (nullable): the sweep's size on the device (meta[128]), read by the kernels -- the host need not know it
 void fe_stencils(hipStream_t s, const float4* C, int cs, const int* csp, float* range_vec, float* scan_angle, const int* inum2, int* inum, float* curv,
                  float* curv2, float* icurv, float* dsrc, float* osrc, int* picked);
 void fe_ground(hipStream_t s, const float4* C, int cs, const int* csp, int NS, const float* range_vec, const int* meta, int* gmark, int* mult, int* seedcnt,
-               double* partials, double* out11);
-// plane fit of the ground sums (g11) into fit[16] on the device, then the distance sums into out2[2]
-void fe_ground_fit_dist(hipStream_t s, const float4* C, int cs, const int* csp, const int* mult, const double* g11, double* fit, double* partials, double* out2);
+               double* partials, double* out11, double* fit);   // ... the ground sums into out11 and their plane fit into fit[16], on the device
+// the distance sums into out2[2]
+void fe_ground_dist(hipStream_t s, const float4* C, int cs, const int* csp, const int* mult, const double* fit, double* partials, double* out2);
 void fe_ground_list(hipStream_t s, const float4* C, int cs, const int* csp, int NS, const float* range_vec, const int* meta, const int* seedcnt,
                     const int* seedpos, float4* out, int cap);
 void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const float* curv, const float* curv2, const float* icurv, const int* inum,
