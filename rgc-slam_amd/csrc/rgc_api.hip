@@ -1702,7 +1702,7 @@ static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes,
   memcpy(c->h_small + 32, init16, sizeof(init16));
   HIPCHK(c, hipMemcpyAsync(d_flags, c->h_small + 32, sizeof(init16), hipMemcpyHostToDevice, s));
   rgck::FeParams fp{NS, prm->min_range, prm->max_range};
-  rgck::fe_filter(s, d_in, stride_f, n, fp, FE(RING, int), d_st);
+  rgck::fe_filter(s, d_in, stride_f, n, fp, FE(RING, int), d_st, FE(RANK, int), FE(HIST, int));
   rgck::fe_half(s, d_in, stride_f, n, FE(RING, int), d_st);
   rgck::fe_bucket(s, d_in, stride_f, n, NS, FE(RING, int), FE(RANK, int), FE(HIST, int), FE(META, int), d_st, FE(CL, float4), FE(INUM2, int),
                   FE(PICK, int), FE(IPICK, int), FE(LAB, int), FE(ILAB, int));

@@ -40,23 +40,55 @@ __device__ __forceinline__ int ring_of(float x, float y, float z, int NS) {
 }
 
 // ring[i] = -2: dropped by the NaN / range / self filter; -1: kept by them but outside the sensor's rings; >= 0: ring
-// st[0] = first kept index, st[1] = last kept index
-__global__ void k_fe_filter(const float* __restrict__ in, int stride_f, int n, FeParams p, int* __restrict__ ring, int* st) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* q = in + (size_t)i * stride_f;
-  const float x = q[0], y = q[1], z = q[2];
+// st[0] = first kept index, st[1] = last kept index (one atomicMin / atomicMax per WAVE: the first and last kept lane of its ballot --
+// one pair per kept point was 23 k same-address atomics, most of this kernel's time)
+// ... and, in the same launch, A2c pass 1 of the stable bucket by ring (:206-230): the rank of each point among the same-ring points of
+// its block and the block's per-ring histogram.
+__global__ void __launch_bounds__(FE_T)
+k_fe_filter(const float* __restrict__ in, int stride_f, int n, FeParams p, int* __restrict__ ring, int* st, int* __restrict__ rank_in_block,
+            int* __restrict__ blk_hist) {
+  __shared__ int hist[FE_T / WAVE][64];
+  const int i = blockIdx.x * FE_T + threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  for (int t = threadIdx.x; t < (FE_T / WAVE) * 64; t += FE_T) (&hist[0][0])[t] = 0;
   int r = -2;
-  if (isfinite(x) && isfinite(y) && isfinite(z)) {
-    const float dis = x * x + y * y + z * z;
-    const float th1 = (float)p.min_range, th2 = (float)p.max_range;
-    if (!(dis < th1 * th1) && !(dis > th2 * th2) && !(x < 0 && fabsf(y) < 0.5)) {
-      r = ring_of(x, y, z, p.n_scans);
-      atomicMin(&st[0], i);
-      atomicMax(&st[1], i);
+  if (i < n) {
+    const float* q = in + (size_t)i * stride_f;
+    const float x = q[0], y = q[1], z = q[2];
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      const float dis = x * x + y * y + z * z;
+      const float th1 = (float)p.min_range, th2 = (float)p.max_range;
+      if (!(dis < th1 * th1) && !(dis > th2 * th2) && !(x < 0 && fabsf(y) < 0.5)) r = ring_of(x, y, z, p.n_scans);
     }
+    ring[i] = r;
   }
-  ring[i] = r;
+  const unsigned long long kept = __ballot(r != -2);
+  if (kept && lane == 0) {
+    const int base = i;  // lane 0's index
+    atomicMin(&st[0], base + __ffsll((long long)kept) - 1);
+    atomicMax(&st[1], base + 63 - __clzll(kept));
+  }
+  __syncthreads();
+  int rk = 0;
+  unsigned long long todo = __ballot(r >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int rr = __shfl(r, leader);
+    const unsigned long long mask = __ballot(r == rr);
+    if (r == rr) rk = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == leader) hist[w][rr] = __popcll(mask);
+    todo &= ~mask;
+  }
+  __syncthreads();
+  if (r >= 0) {
+    for (int j = 0; j < w; j++) rk += hist[j][r];
+    rank_in_block[i] = rk;
+  }
+  if (threadIdx.x < 64) {
+    int sum = 0;
+    for (int j = 0; j < FE_T / WAVE; j++) sum += hist[j][threadIdx.x];
+    blk_hist[(size_t)blockIdx.x * 64 + threadIdx.x] = sum;
+  }
 }
 
 __device__ __forceinline__ void start_end_ori(const float* __restrict__ in, int stride_f, const int* st, float& startOri, float& endOri) {
@@ -80,37 +112,6 @@ __global__ void k_fe_half(const float* __restrict__ in, int stride_f, int n, con
   if (ori < startOri - M_PI / 2) ori += 2 * M_PI;
   else if (ori > startOri + M_PI * 3 / 2) ori -= 2 * M_PI;
   if (ori - startOri > M_PI) atomicMin(&st[2], i);
-}
-
-// A2c: stable bucket by ring (:206-230).  Pass 1: rank of each point among the same-ring points of its block and the
-// block's per-ring histogram.
-__global__ void __launch_bounds__(FE_T) k_fe_rank(int n, const int* __restrict__ ring, int* __restrict__ rank_in_block, int* __restrict__ blk_hist) {
-  __shared__ int hist[FE_T / WAVE][64];
-  const int i = blockIdx.x * FE_T + threadIdx.x;
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-  for (int t = threadIdx.x; t < (FE_T / WAVE) * 64; t += FE_T) (&hist[0][0])[t] = 0;
-  __syncthreads();
-  const int r = i < n ? ring[i] : -1;
-  int rk = 0;
-  unsigned long long todo = __ballot(r >= 0);
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int rr = __shfl(r, leader);
-    const unsigned long long mask = __ballot(r == rr);
-    if (r == rr) rk = __popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == leader) hist[w][rr] = __popcll(mask);
-    todo &= ~mask;
-  }
-  __syncthreads();
-  if (r >= 0) {
-    for (int j = 0; j < w; j++) rk += hist[j][r];
-    rank_in_block[i] = rk;
-  }
-  if (threadIdx.x < 64) {
-    int s = 0;
-    for (int j = 0; j < FE_T / WAVE; j++) s += hist[j][threadIdx.x];
-    blk_hist[(size_t)blockIdx.x * 64 + threadIdx.x] = s;
-  }
 }
 
 // pass 2 (one block): exclusive prefix of the block histograms per ring, ring counts and ring starts.
@@ -778,8 +779,8 @@ static inline int nblk(long long n, int t) { return (int)((n + t - 1) / t); }
 int fe_blocks(int n) { return nblk(n, FE_T); }
 int fe_slot_ints() { return SLOT; }
 
-void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st) {
-  hipLaunchKernelGGL(k_fe_filter, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, in, stride_f, n, p, ring, st);
+void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st, int* rank_in_block, int* blk_hist) {
+  hipLaunchKernelGGL(k_fe_filter, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, in, stride_f, n, p, ring, st, rank_in_block, blk_hist);
 }
 void fe_half(hipStream_t s, const float* in, int stride_f, int n, const int* ring, int* st) {
   hipLaunchKernelGGL(k_fe_half, dim3(nblk(n, FE_T)), dim3(FE_T), 0, s, in, stride_f, n, ring, st);
@@ -787,7 +788,6 @@ void fe_half(hipStream_t s, const float* in, int stride_f, int n, const int* rin
 void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, const int* ring, int* rank_in_block, int* blk_hist, int* meta,
                const int* st, float4* C, int* inum2, int* z0, int* z1, int* z2, int* z3) {
   const int nb = nblk(n, FE_T);
-  hipLaunchKernelGGL(k_fe_rank, dim3(nb), dim3(FE_T), 0, s, n, ring, rank_in_block, blk_hist);
   hipLaunchKernelGGL(k_fe_hist_scan, dim3(1), dim3(64 * HS_CH), 0, s, nb, NS, blk_hist, meta);
   hipLaunchKernelGGL(k_fe_scatter, dim3(nb), dim3(FE_T), 0, s, in, stride_f, n, ring, rank_in_block, blk_hist, meta, st, C, inum2, z0, z1, z2, z3);
 }

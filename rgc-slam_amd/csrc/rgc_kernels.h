@@ -135,7 +135,7 @@ void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int*
 // ---- A1-A8 front-end (rgc_frontend.hip) ----
 int fe_blocks(int n);
 int fe_slot_ints();
-void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st);
+void fe_filter(hipStream_t s, const float* in, int stride_f, int n, FeParams p, int* ring, int* st, int* rank_in_block, int* blk_hist);  // + per-block ring ranks / histograms
 void fe_half(hipStream_t s, const float* in, int stride_f, int n, const int* ring, int* st);
 void fe_bucket(hipStream_t s, const float* in, int stride_f, int n, int NS, const int* ring, int* rank_in_block, int* blk_hist, int* meta,
                const int* st, float4* C, int* inum2, int* z0, int* z1, int* z2, int* z3);  // z0..z3: four per-point arrays zeroed on the way (n ints each)
