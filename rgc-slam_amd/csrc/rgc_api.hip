@@ -113,7 +113,7 @@ struct rgc_ctx {
   double map_wide_density = 0.25; // RGC_MAP_WIDE: ... when the map has fewer points per grid cell than this
   double src_res_auto = 0.0;  // adaptive cell size of the scan's kNN grid, steered by how crowded its cells were in the previous frame (0 = voxel_res)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
-  DevBuf pre_in, pre_out, vg_order, vg_first, vg_pos, vg_tmp, vg_leaf;  // B2/B3/B9 staging
+  DevBuf pre_in, pre_out, vg_order, vg_pos, vg_tmp, vg_leaf;  // B2/B3/B9 staging
   struct VgBox { float leaf = 0.f; bool valid = false; rgck::LeafGrid g{}; } vg_box[4];  // padded leaf boxes of earlier clouds, by leaf size
   int vg_box_next = 0;
   bool vg_flags_clean = false;  // d_small[24 + 6] is known to be zero (a finished rows chain leaves it so)
@@ -972,7 +972,7 @@ void rgc_destroy(rgc_ctx* c) {
   release(c->mr_small);
   for (DevBuf& b : c->fe) release(b);
   for (DevBuf* b : {&c->map_store[0], &c->map_store[1], &c->map_target}) release(*b);
-  for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->corr_v2, &c->corr_M2, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_first, &c->vg_pos, &c->vg_tmp, &c->vg_leaf}) release(*b);
+  for (DevBuf* b : {&c->corr_v, &c->corr_M, &c->corr_v2, &c->corr_M2, &c->partials, &c->ipartials, &c->scratch, &c->pre_in, &c->pre_out, &c->vg_order, &c->vg_pos, &c->vg_tmp, &c->vg_leaf}) release(*b);
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1484,14 +1484,14 @@ int rgc_transform_cloud(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, 
 }
 
 // The rows chain of the leaf filter on box g (rgc_pre.hip); one read-back: *flags (bits as rgck::vg_rows documents) and *n_out.
-static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, float inv, const rgck::LeafGrid& g, int edge, float* d_out, int* flags,
-                          int* n_out) {
+static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, float inv, const rgck::LeafGrid& g, int edge, bool dense, float* d_out,
+                          int* flags, int* n_out) {
   hipStream_t s = c->stream;
   int* dsm = c->d_small + 24;
   int* hsm = c->h_small + 24;
   Cloud& cl = c->aux;
   int rc;
-  const size_t nr1 = (size_t)g.div[1] * (size_t)g.div[2] + 1;
+  const size_t nr1 = (size_t)g.div[1] * (size_t)g.div[2] * (dense ? (size_t)g.div[0] : 1) + 1;   // rows, or leaves for a dense cloud
   if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;                                                    // row of every point
   if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;                                                    // leaf x of every point
   if ((rc = ensure(c, c->vg_pos, sizeof(int) * n))) return rc;                                                     // arrival slot, then output number
@@ -1510,7 +1510,7 @@ static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, fl
   cl.cnt_clean = std::max(cl.cnt_clean, nr1);  // (what lies beyond this call's rows was not touched: the scan's and the map's filter take turns)
   if (!c->vg_flags_clean) HIPCHK(c, hipMemsetAsync(dsm + 6, 0, sizeof(int), s));
   c->vg_flags_clean = false;
-  rgck::vg_rows(s, d_in, stride_f, n, inv, g, edge, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)c->vg_pos.p, (int*)cl.cnt.p, (int*)cl.start.p,
+  rgck::vg_rows(s, d_in, stride_f, n, inv, g, edge, dense ? 1 : 0, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)c->vg_pos.p, (int*)cl.cnt.p, (int*)cl.start.p,
                 cl.block_sums.p, (unsigned long long*)c->vg_tmp.p, (int*)c->vg_order.p, (unsigned long long*)c->vg_leaf.p,
                 (int*)((char*)cl.block_sums.p + row_bs), d_out, dsm + 5);
   HIPCHK(c, hipMemcpyAsync(hsm + 5, dsm + 5, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1520,9 +1520,9 @@ static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, fl
   *n_out = hsm[7];
   return RGC_OK;
 }
-static bool vg_rows_fit(const rgck::LeafGrid& g, int n) {  // sparse enough for the rows chain, small enough for its one-level block sums
+static bool vg_rows_fit(const rgck::LeafGrid& g, int n) {  // sparse enough for the sort over rows (else: over the leaves)
   const double ncell = (double)g.div[0] * (double)g.div[1] * (double)g.div[2], nrows = (double)g.div[1] * (double)g.div[2];
-  return ncell <= 2147483647.0 && ncell > 64.0 * (double)n && nrows <= 64.0e6 && n <= 2048 * 4096;
+  return ncell <= 2147483647.0 && ncell > 64.0 * (double)n && nrows <= 64.0e6;
 }
 
 int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float leaf, float* out_xyzi, int* n_out, int on_device) {
@@ -1551,7 +1551,7 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
   if (box && box->valid && vg_rows_fit(box->g, n)) {
     // the box of an earlier cloud: no bounding-box pass, no read-back before the filter (the frames of a sequence span the same volume)
     int flags = 0, no = 0;
-    if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, box->g, kPad / 2, d_out, &flags, &no))) return rc;
+    if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, box->g, kPad / 2, false, d_out, &flags, &no))) return rc;
     if (flags & 1) return fail(c, RGC_ERR_NONFINITE, "cloud contains non-finite coordinates (PCL skips them; remove NaNs first)");
     if (flags & 6) box->valid = false;  // outside: measure and repeat now; near a face: measure at the next call
     if (!(flags & 2)) { *n_out = no; done = true; }
@@ -1588,31 +1588,12 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
       HIPCHK(c, hipStreamSynchronize(s));
     } else if (vg_rows_fit(g, n)) {
       int flags = 0;
-      if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, g, 0, d_out, &flags, n_out))) return rc;
+      if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, g, 0, false, d_out, &flags, n_out))) return rc;
     } else {
-      Cloud& cl = c->aux;
+      // a dense cloud: the same chain with the leaves themselves as the sort's buckets
       if (ncell > (double)c->prm.max_cells) return fail(c, RGC_ERR_GRID_TOO_LARGE, "leaf grid %d x %d x %d exceeds max_cells", g.div[0], g.div[1], g.div[2]);
-      if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
-      if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
-      if ((rc = ensure(c, c->vg_order, sizeof(int) * n))) return rc;
-      if ((rc = ensure(c, c->vg_first, sizeof(int) * n))) return rc;
-      if ((rc = ensure(c, c->vg_pos, sizeof(int) * n))) return rc;
-      const size_t nc1 = (size_t)ncell + 1;
-      if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1))) return rc;
-      if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
-      if ((rc = ensure(c, cl.block_sums, sizeof(int) * (nc1 / 2048 + (size_t)n / 2048 + 4)))) return rc;
-      cl.cnt_clean = 0;
-      HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, sizeof(int) * nc1, s));
-      rgck::vg_count(s, d_in, stride_f, n, inv, g, (int*)cl.cell_of.p, (int*)cl.cnt.p);
-      rgck::exclusive_scan(s, (const int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, (int*)cl.block_sums.p);
-      rgck::scatter(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (int*)cl.cnt.p, (int*)cl.order_tmp.p);
-      rgck::vg_rank(s, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p, (int*)c->vg_order.p, (int*)c->vg_first.p);
-      rgck::exclusive_scan(s, (const int*)c->vg_first.p, (int*)c->vg_pos.p, n, (int*)cl.block_sums.p);
-      rgck::vg_centroid(s, d_in, stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)c->vg_order.p,
-                        (const int*)c->vg_first.p, (const int*)c->vg_pos.p, d_out, dsm + 7);
-      HIPCHK(c, hipMemcpyAsync(hsm + 7, dsm + 7, sizeof(int), hipMemcpyDeviceToHost, s));
-      HIPCHK(c, hipStreamSynchronize(s));
-      *n_out = hsm[7];
+      int flags = 0;
+      if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, g, 0, true, d_out, &flags, n_out))) return rc;
     }
   }
   if (!on_device) {

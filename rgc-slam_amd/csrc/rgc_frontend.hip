@@ -104,14 +104,18 @@ __device__ __forceinline__ void start_end_ori(const float* __restrict__ in, int 
 // a prefix-OR, i.e. the minimum index satisfying the condition.  st[2] = that index (INT_MAX if none).
 __global__ void k_fe_half(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ ring, int* st) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || ring[i] < 0) return;
-  float startOri, endOri;
-  start_end_ori(in, stride_f, st, startOri, endOri);
-  const float* q = in + (size_t)i * stride_f;
-  float ori = -atan2f(q[1], q[0]);
-  if (ori < startOri - M_PI / 2) ori += 2 * M_PI;
-  else if (ori > startOri + M_PI * 3 / 2) ori -= 2 * M_PI;
-  if (ori - startOri > M_PI) atomicMin(&st[2], i);
+  bool past = false;
+  if (i < n && ring[i] >= 0) {
+    float startOri, endOri;
+    start_end_ori(in, stride_f, st, startOri, endOri);
+    const float* q = in + (size_t)i * stride_f;
+    float ori = -atan2f(q[1], q[0]);
+    if (ori < startOri - M_PI / 2) ori += 2 * M_PI;
+    else if (ori > startOri + M_PI * 3 / 2) ori -= 2 * M_PI;
+    past = ori - startOri > M_PI;
+  }
+  const unsigned long long m = __ballot(past);  // the wave's minimum is its first such lane: one atomic per wave, not one per point of the second half
+  if (m && (int)(threadIdx.x & (WAVE - 1)) == __ffsll((long long)m) - 1) atomicMin(&st[2], i);
 }
 
 // pass 2 (one block): exclusive prefix of the block histograms per ring, ring counts and ring starts.

@@ -57,7 +57,6 @@ void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, in
                 float* sum_sq = nullptr /* += sum of count^2, nullable */);
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi = 0);
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */, int hi = 0);
-void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp, int hi = 0);
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
                  const int* order_tmp, float4* P, int* zero_me = nullptr, int hi = 0);
 // ---- C2: exact kNN + PLANE covariance -> unit normal ----
@@ -120,17 +119,14 @@ void pc2_pack(hipStream_t s, const float* in, int cols, int n, int kind, unsigne
 void deskew(hipStream_t s, float* xyzi, int stride_f, int n, Quat qinv, const double t[3]);
 void transform_q(hipStream_t s, const float* in, int stride_f, int n, Quat q, const double t[3], float* out, int ostride_f);
 void vg_bbox(hipStream_t s, const float* in, int stride_f, int n, float inv, int* mm6, int* flags);
-void vg_count(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* cell_of, int* cnt);
-void vg_rank(hipStream_t s, int n, const int* cell_of, const int* start, const int* order_tmp, int* order, int* first);
 // sparse leaf grids: counting sort over (y, z) rows, rank by (leaf x, index) inside a row -- the whole filter as one chain of launches.
 // edge > 0: g is a box kept from an earlier cloud (see rgc_pre.hip).  res[0] <- flags of this run (1 non-finite point, 2 point outside g,
 // 4 point within `edge` leaves of g's faces), res[1] = the live flag word (must be 0 on entry, is 0 on exit), res[2] <- number of leaves.
-// row_block_sums: 8 bytes x (rows / 2048 + 2); head_block_sums: n / 2048 + 2 ints (n <= 2048 * 4096); cnt: rows + 1 zeros, left at zero.
-void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int* row_of, int* lx, int* slot_then_pos, int* cnt,
+// dense != 0: the counting sort runs over the leaves themselves ("rows" below = leaves; dense clouds).
+// row_block_sums: 8 bytes x (rows / 2048 + 2); head_block_sums: n / 2048 + 2 ints; cnt: rows + 1 zeros, left at zero.
+void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int dense, int* row_of, int* lx, int* slot_then_pos, int* cnt,
              int* start, void* row_block_sums, unsigned long long* tmp, int* order, unsigned long long* leaf, int* head_block_sums, float* out,
              int* res);
-void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start, const int* order,
-                 const int* first, const int* outpos, float* out, int* n_out);
 
 // ---- A1-A8 front-end (rgc_frontend.hip) ----
 int fe_blocks(int n);

@@ -10,7 +10,7 @@
 //
 // Contents, in file order (one translation unit on purpose: the device helpers -- wave reductions, the register top-k chain,
 // the row walkers, the Jacobi solver, the block reduction -- are shared by nearly every kernel and stay inlinable):
-//   grid build      k_bbox, k_count, k_cells_scan_{block,sums,add}, k_place, k_rank_gather (+ k_scan_*, k_scatter for the
+//   grid build      k_bbox, k_count, k_cells_scan_{block,sums,add}, k_place, k_rank_gather (+ k_scan_* for the
 //                   pcl::VoxelGrid path of rgc_pre.hip)
 //   C2 kNN + cov    Chain, sp_piece_table, knn_point_sp (map: one lane per query, one pass), knn_point_split (scan: four lanes per
 //                   query), k_knn_sp (the bulk launch of either), TopK, coop_kth, k_knn_coop (deferred queries, one wave per query)
@@ -417,15 +417,6 @@ __global__ void k_place(int n, const int* __restrict__ cell_of, const int* __res
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   order_tmp[start[cell_of[i]] + slot_of[i]] = i;  // unordered inside the cell; k_rank_gather makes the order deterministic
-}
-
-__global__ void k_scatter(int n, const int* __restrict__ cell_of, const int* __restrict__ start, int* cnt, int* __restrict__ order_tmp, int prio) {
-  wave_prio(prio);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int c = cell_of[i];
-  int r = atomicSub(&cnt[c], 1) - 1;  // unordered slot inside the cell; k_rank_gather makes the order deterministic
-  order_tmp[start[c] + r] = i;
 }
 
 // deterministic placement: a point's final slot = cell start + number of same-cell points with a smaller index.
@@ -2925,9 +2916,6 @@ void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_su
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, s, block_sums, nb, hi);
     hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_T), 0, s, out, n, block_sums, hi);
   }
-}
-void scatter(hipStream_t s, int n, const int* cell_of, const int* start, int* cnt, int* order_tmp, int hi) {
-  hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, start, cnt, order_tmp, hi);
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
                  const int* order_tmp, float4* P, int* zero_me, int hi) {

@@ -103,51 +103,6 @@ __global__ void __launch_bounds__(256) k_vg_bbox(const float* __restrict__ in, i
   if (bad) atomicOr(flags, 1);
 }
 
-__global__ void k_vg_count(const float* __restrict__ in, int stride_f, int n, float inv, LeafGrid g, int* __restrict__ cell_of, int* cnt) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* p = in + (size_t)i * stride_f;
-  const int c = (leaf_coord(p[0], inv) - g.minb[0]) + (leaf_coord(p[1], inv) - g.minb[1]) * g.div[0] +
-                (leaf_coord(p[2], inv) - g.minb[2]) * g.div[0] * g.div[1];
-  cell_of[i] = c;
-  atomicAdd(&cnt[c], 1);
-}
-
-// final slot of a point = leaf start + number of same-leaf points with a smaller index (deterministic);
-// order[slot] = original index, first[slot] = 1 for the first point of each leaf
-__global__ void k_vg_rank(int n, const int* __restrict__ cell_of, const int* __restrict__ start, const int* __restrict__ order_tmp,
-                          int* __restrict__ order, int* __restrict__ first) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  const int i = order_tmp[s];
-  const int c = cell_of[i];
-  const int s0 = start[c], s1 = start[c + 1];
-  int rank = 0;
-  for (int t = s0; t < s1; t++) rank += (order_tmp[t] < i);
-  order[s0 + rank] = i;
-  first[s0 + rank] = (rank == 0) ? 1 : 0;
-}
-
-__global__ void k_vg_centroid(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
-                              const int* __restrict__ start, const int* __restrict__ order, const int* __restrict__ first,
-                              const int* __restrict__ outpos, float* __restrict__ out, int* n_out) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  if (s == n - 1) *n_out = outpos[s] + first[s];
-  if (!first[s]) return;
-  const int c = cell_of[order[s]];
-  const int s1 = start[c + 1];
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  for (int t = s; t < s1; t++) {
-    const float* p = in + (size_t)order[t] * stride_f;
-    a0 += p[0]; a1 += p[1]; a2 += p[2];
-    a3 += stride_f > 3 ? p[3] : 0.f;
-  }
-  const float cnt = (float)(s1 - s);
-  float* o = out + (size_t)outpos[s] * 4;
-  o[0] = a0 / cnt; o[1] = a1 / cnt; o[2] = a2 / cnt; o[3] = a3 / cnt;
-}
-
 // ---- the same filter for SPARSE leaf grids (a 30 k-point sweep at 0.2 m leaves spans ten million leaves: zero-filling and scanning the
 // dense leaf array was most of the filter's time).  Leaves are ordered by idx = i + j dx + k dx dy, i.e. by (k, j) row first and by i
 // inside the row: the counting sort runs over the ROWS (dy x dz entries, tens of thousands), and inside a row the points are ranked by
@@ -162,8 +117,8 @@ __global__ void k_vg_centroid(const float* __restrict__ in, int stride_f, int n,
 constexpr int VG_SCAN_T = 256, VG_SCAN_V = 8, VG_SCAN_B = VG_SCAN_T * VG_SCAN_V;
 
 __global__ void __launch_bounds__(256)
-k_vg_rows_count(const float* __restrict__ in, int stride_f, int n, float inv, LeafGrid g, int edge, int* __restrict__ row_of, int* __restrict__ lx,
-                int* cnt, int* __restrict__ slot, int* flags) {
+k_vg_rows_count(const float* __restrict__ in, int stride_f, int n, float inv, LeafGrid g, int edge, int dense, int* __restrict__ row_of,
+                int* __restrict__ lx, int* cnt, int* __restrict__ slot, int* flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1);
   const bool valid = i < n;
@@ -181,9 +136,11 @@ k_vg_rows_count(const float* __restrict__ in, int stride_f, int n, float inv, Le
     } else {
       near = cx < edge || cx >= g.div[0] - edge || cy < edge || cy >= g.div[1] - edge || cz < edge || cz >= g.div[2] - edge;
     }
-    r = cy + cz * g.div[1];
+    // dense clouds (a keyframe store: several points per leaf, a few million leaves) sort over the LEAVES themselves: the "row" is the
+    // leaf, every leaf x is 0, and the rest of the chain is the same
+    r = dense ? cx + (cy + cz * g.div[1]) * g.div[0] : cy + cz * g.div[1];
     row_of[i] = r;
-    lx[i] = cx;
+    lx[i] = dense ? 0 : cx;
   }
   const unsigned long long nm = __ballot(near);
   if (nm && lane == __ffsll((long long)nm) - 1) atomicOr(flags, 4);
@@ -321,26 +278,16 @@ void transform_q(hipStream_t s, const float* in, int stride_f, int n, Quat q, co
 void vg_bbox(hipStream_t s, const float* in, int stride_f, int n, float inv, int* mm6, int* flags) {
   hipLaunchKernelGGL(k_vg_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, inv, mm6, flags);
 }
-void vg_count(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int* cell_of, int* cnt) {
-  hipLaunchKernelGGL(k_vg_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, inv, g, cell_of, cnt);
-}
-void vg_rank(hipStream_t s, int n, const int* cell_of, const int* start, const int* order_tmp, int* order, int* first) {
-  hipLaunchKernelGGL(k_vg_rank, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, start, order_tmp, order, first);
-}
-void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int* row_of, int* lx, int* slot_then_pos, int* cnt,
+void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int dense, int* row_of, int* lx, int* slot_then_pos, int* cnt,
              int* start, void* row_block_sums, unsigned long long* tmp, int* order, unsigned long long* leaf, int* head_block_sums, float* out,
              int* res) {
-  const int nr1 = g.div[1] * g.div[2] + 1;
-  hipLaunchKernelGGL(k_vg_rows_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, inv, g, edge, row_of, lx, cnt, slot_then_pos, res + 1);
+  const int nr1 = g.div[1] * g.div[2] * (dense ? g.div[0] : 1) + 1;
+  hipLaunchKernelGGL(k_vg_rows_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, inv, g, edge, dense, row_of, lx, cnt, slot_then_pos, res + 1);
   scan_cells(s, cnt, start, nr1, row_block_sums, nullptr, nullptr, 0, nullptr);
   hipLaunchKernelGGL(k_vg_rows_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, lx, slot_then_pos, start, tmp);
   hipLaunchKernelGGL(k_vg_rows_rank, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, start, tmp, order, leaf);
   hipLaunchKernelGGL(k_vg_rows_heads, dim3(nblk(n, VG_SCAN_B)), dim3(VG_SCAN_T), 0, s, leaf, n, slot_then_pos, head_block_sums);
   hipLaunchKernelGGL(k_vg_rows_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, order, leaf, slot_then_pos, head_block_sums, out, res);
-}
-void vg_centroid(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start, const int* order,
-                 const int* first, const int* outpos, float* out, int* n_out) {
-  hipLaunchKernelGGL(k_vg_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order, first, outpos, out, n_out);
 }
 
 
