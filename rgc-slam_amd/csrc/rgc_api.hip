@@ -114,7 +114,7 @@ struct rgc_ctx {
   double src_res_auto = 0.0;  // adaptive cell size of the scan's kNN grid, steered by how crowded its cells were in the previous frame (0 = voxel_res)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_pos, vg_tmp, vg_leaf;  // B2/B3/B9 staging
-  struct VgBox { float leaf = 0.f; bool valid = false; rgck::LeafGrid g{}; } vg_box[4];  // padded leaf boxes of earlier clouds, by leaf size
+  struct VgBox { float leaf = 0.f; bool valid = false; rgck::LeafGrid g{}; } vg_box[4];  // measured leaf boxes of earlier clouds, by leaf size
   int vg_box_next = 0;
   bool vg_flags_clean = false;  // d_small[24 + 6] is known to be zero (a finished rows chain leaves it so)
   DevBuf fe[34];              // front-end buffers
@@ -1544,17 +1544,29 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
     if ((rc = ensure(c, c->pre_out, sizeof(float) * 4 * (size_t)n))) return rc;
     d_out = (float*)c->pre_out.p;
   }
-  constexpr int kPad = 32;  // leaves added on every side of a measured box when it is kept for the next cloud of this leaf size
+  // leaves added on every side of a measured box when the next cloud of this leaf size is filtered on it: 32 for a sweep (its rows are
+  // what is counted and scanned), 8 for a dense cloud (its leaves are: a wider box is a longer scan)
+  constexpr int kPadSparse = 32, kPadDense = 8;
+  auto padded = [](const rgck::LeafGrid& g, int pad) {
+    rgck::LeafGrid p = g;
+    for (int a = 0; a < 3; a++) { p.minb[a] -= pad; p.div[a] += 2 * pad; }
+    return p;
+  };
   rgc_ctx::VgBox* box = nullptr;
   for (auto& b : c->vg_box) if (b.leaf == leaf) box = &b;
   bool done = false;
-  if (box && box->valid && vg_rows_fit(box->g, n)) {
+  if (box && box->valid) {
     // the box of an earlier cloud: no bounding-box pass, no read-back before the filter (the frames of a sequence span the same volume)
-    int flags = 0, no = 0;
-    if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, box->g, kPad / 2, false, d_out, &flags, &no))) return rc;
-    if (flags & 1) return fail(c, RGC_ERR_NONFINITE, "cloud contains non-finite coordinates (PCL skips them; remove NaNs first)");
-    if (flags & 6) box->valid = false;  // outside: measure and repeat now; near a face: measure at the next call
-    if (!(flags & 2)) { *n_out = no; done = true; }
+    const rgck::LeafGrid ps = padded(box->g, kPadSparse), pd = padded(box->g, kPadDense);
+    const bool sparse = vg_rows_fit(ps, n);
+    const double dcell = (double)pd.div[0] * (double)pd.div[1] * (double)pd.div[2];
+    if (sparse || dcell <= (double)c->prm.max_cells) {
+      int flags = 0, no = 0;
+      if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, sparse ? ps : pd, (sparse ? kPadSparse : kPadDense) / 2, !sparse, d_out, &flags, &no))) return rc;
+      if (flags & 1) return fail(c, RGC_ERR_NONFINITE, "cloud contains non-finite coordinates (PCL skips them; remove NaNs first)");
+      if (flags & 6) box->valid = false;  // outside: measure and repeat now; near a face: measure at the next call
+      if (!(flags & 2)) { *n_out = no; done = true; }
+    }
   }
   if (!done) {
     int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
@@ -1569,17 +1581,12 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
     rgck::LeafGrid g{};
     double ncell = 1.0;
     for (int a = 0; a < 3; a++) { g.minb[a] = hsm[a]; g.div[a] = hsm[3 + a] - hsm[a] + 1; ncell *= (double)g.div[a]; }
-    {  // keep the padded box for the next cloud of this leaf size
+    {  // keep the measured box for the next cloud of this leaf size
       if (!box) { box = &c->vg_box[c->vg_box_next]; c->vg_box_next = (c->vg_box_next + 1) % 4; box->leaf = leaf; }
-      rgck::LeafGrid pg{};
-      bool ok = true;
-      for (int a = 0; a < 3; a++) {
-        if (g.minb[a] < -1000000000 || g.div[a] > 1000000000) ok = false;
-        pg.minb[a] = g.minb[a] - kPad;
-        pg.div[a] = g.div[a] + 2 * kPad;
-      }
-      box->g = pg;
-      box->valid = ok && vg_rows_fit(pg, n);
+      bool ok = ncell <= 2.0e9;
+      for (int a = 0; a < 3; a++) if (g.minb[a] < -1000000000 || g.div[a] > 1000000000) ok = false;
+      box->g = g;
+      box->valid = ok;
     }
     if (ncell > 2147483647.0) {
       // PCL: "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
