@@ -10,8 +10,8 @@
 //
 // Contents, in file order (one translation unit on purpose: the device helpers -- wave reductions, the register top-k chain,
 // the row walkers, the Jacobi solver, the block reduction -- are shared by nearly every kernel and stay inlinable):
-//   grid build      k_bbox, k_count, k_cells_scan_{block,sums,add}, k_place, k_rank_gather (+ k_scan_* for the
-//                   pcl::VoxelGrid path of rgc_pre.hip)
+//   grid build      k_bbox, k_count, k_cells_scan_{block,sums,add}, k_place, k_rank_gather (+ k_scan_*, a plain 32-bit
+//                   exclusive scan: the front-end's ground list; the leaf filter of rgc_pre.hip uses the cell scan)
 //   C2 kNN + cov    Chain, sp_piece_table, knn_point_sp (map: one lane per query, one pass), knn_point_split (scan: four lanes per
 //                   query), k_knn_sp (the bulk launch of either), TopK, coop_kth, k_knn_coop (deferred queries, one wave per query)
 //   C3 voxel map    k_voxel_build

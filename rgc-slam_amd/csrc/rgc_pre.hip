@@ -66,7 +66,8 @@ __global__ void k_transform_q(const float* __restrict__ in, int stride_f, int n,
 // B3  pcl::VoxelGrid<PointXYZI>::filter (src/RGC_odometer.cpp:976-991; SURVEY A.6 [3P-memory]):
 //   ijk = floor(p * inv_leaf) - min_b ; idx = i + j*dx + k*dx*dy ; one output per occupied leaf = mean of ALL fields
 //   (fp32 running sum / count) ; output ordered by idx.  Inside a leaf the sum runs in ascending point index (PCL's
-//   std::sort leaves that order unspecified).  Counting sort over the dense leaf grid + first-in-leaf compaction.
+//   std::sort leaves that order unspecified).  Counting sort over the rows of the leaf grid (over the leaves themselves for a dense
+//   cloud) + compaction by leaf heads; see the chain below.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int leaf_coord(float x, float inv) { return (int)floorf(x * inv); }
 
@@ -103,8 +104,8 @@ __global__ void __launch_bounds__(256) k_vg_bbox(const float* __restrict__ in, i
   if (bad) atomicOr(flags, 1);
 }
 
-// ---- the same filter for SPARSE leaf grids (a 30 k-point sweep at 0.2 m leaves spans ten million leaves: zero-filling and scanning the
-// dense leaf array was most of the filter's time).  Leaves are ordered by idx = i + j dx + k dx dy, i.e. by (k, j) row first and by i
+// ---- the filter as ONE chain of launches.  A 30 k-point sweep at 0.2 m leaves spans ten million leaves (zero-filling and scanning a
+// dense leaf array was most of the filter's time):  Leaves are ordered by idx = i + j dx + k dx dy, i.e. by (k, j) row first and by i
 // inside the row: the counting sort runs over the ROWS (dy x dz entries, tens of thousands), and inside a row the points are ranked by
 // (i, point index) -- rows hold few points when the grid is sparse.  Same output, bit for bit.
 //
