@@ -42,8 +42,9 @@ struct Cloud {
   DevBuf in_copy, cell_of, slot_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
   DevBuf segs;  // deferred-query list of the bulk kNN kernel: [count, pad x15][query n][bound n]
   int deferred_seen = -1;  // deferred count of the last cloud whose count came home (sizes the next cooperative launch)
-  rgck::Grid grid{};
-  // speculative grid: the previous cloud's grid, widened, re-used without the bounding-box round trip; k_count guards it
+  rgck::Grid grid{};   // the search grid: sorted array P, start[]
+  rgck::Grid vgrid{};  // target: the voxel grid cell_voxel[] is laid out on -- `grid` itself, or the voxel grid that goes with a half-size search grid
+  // speculative grid (voxel level): the previous cloud's grid, widened, re-used without the bounding-box round trip; k_count guards it
   rgck::Grid spec_grid{};
   bool spec_ok = false;    // spec_grid is usable
   bool spec_used = false;  // this cloud was prepared on spec_grid and its guard has not been read yet
@@ -111,6 +112,8 @@ struct rgc_ctx {
   double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
   int map_wide_r = 2;             // RGC_MAP_WIDE_R (0 = off, 2): block radius of the bulk kNN launch for a sparse map
   double map_wide_density = 0.25; // RGC_MAP_WIDE: ... when the map has fewer points per grid cell than this
+  bool map_half = false;          // RGC_MAP_HALF=1: a dense map is searched on a half-size grid nested in the voxel grid (k_knn_h, 5x5x5 half cells) instead of
+                                  // the voxel grid's 3x3x3 block -- measured in round 3 and parked: no faster, and its grid costs more (profiles/r03_pmc_knn_half_grid.json)
   double src_res_auto = 0.0;  // adaptive cell size of the scan's kNN grid, steered by how crowded its cells were in the previous frame (0 = voxel_res)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_pos, vg_tmp, vg_leaf;  // B2/B3/B9 staging
@@ -253,6 +256,16 @@ int check_params(rgc_ctx* c, const rgc_params* p) {
   return RGC_OK;
 }
 
+// Which layout a map of n points on voxel-level box v gets: the half-size search grid (k_knn_h: k <= 20, a dense map -- a sparse one
+// takes the wide-block launch on the voxel grid -- and cell arrays that still fit), or the voxel grid itself.
+bool half_layout(const rgc_ctx* c, bool is_target, int n, const rgck::Grid& v) {
+  if (!is_target || !c->map_half || c->prm.k_correspondences > 20) return false;
+  if (c->map_wide_r > 0 && (double)n < c->map_wide_density * (double)v.ncell) return false;
+  double hc = 8.0;
+  for (int a = 0; a < 3; a++) hc *= (double)(v.dim[a] + 2);
+  return hc <= 1.0e9 && hc <= 8.0 * (double)c->prm.max_cells;  // (k_knn_h addresses start[] with 32-bit byte offsets)
+}
+
 // C1-C3: grid + exact-kNN covariances (+ voxel map for the target), all enqueued on the stream.
 // The first cloud of a context costs one host<->device round trip -- the 6-int bounding box the dense grid is sized from; later
 // clouds re-use the previous (widened) grid speculatively and need none (see `spec` below).
@@ -319,6 +332,9 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       if (ncell > (double)c->prm.max_cells || ncell > 2.0e9)
         return fail(c, RGC_ERR_GRID_TOO_LARGE, "%s grid %d x %d x %d exceeds max_cells", is_target ? "target" : "source", g.dim[0], g.dim[1], g.dim[2]);
       g.res = res;
+      g.vres = res;
+      g.sub = 1;
+      g.pad = 0;
       g.inv_res = rgck::grid_inv_res(res);
       g.ncell = (int)ncell;
       // The grid the NEXT cloud will try.  The map's box is stable and its grid large: 2 / 2 / 1 cells of margin.  A raw scan's box
@@ -345,12 +361,14 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       cl.spec_ok = wcell <= (double)c->prm.max_cells && wcell <= 2.0e9;
       cl.spec_grid = w;
       if (cl.spec_ok) {  // its cell arrays now, in the frame that is slow anyway, not in the next one
-        const size_t wc1 = (size_t)w.ncell + 1;
+        rgck::Grid wv = w;
+        const rgck::Grid ws = half_layout(c, is_target, n, w) ? rgck::half_grid_of(w, &wv) : w;
+        const size_t wc1 = (size_t)ws.ncell + 1, wtot = wc1 + (ws.sub == 2 ? (size_t)wv.ncell : 0);
         int rc;
-        if ((rc = ensure(c, cl.cnt, sizeof(int) * wc1 + 256))) return rc;
+        if ((rc = ensure(c, cl.cnt, sizeof(int) * wtot + 256))) return rc;
         if ((rc = ensure(c, cl.start, sizeof(int) * wc1))) return rc;
-        if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (wc1 / 2048 + 2)))) return rc;
-        if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)w.ncell))) return rc;
+        if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (wtot / 2048 + 2)))) return rc;
+        if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)wv.ncell))) return rc;
         if (is_target) {  // ... and the voxel table (80 B per cell of a map denser than its grid: 1.3 GB at 16 M cells -- growing it in the next
                           // frame, when the widened grid is first used, was a 77 ms allocation inside c5's three timed frames on a fresh box)
           const size_t vw = (size_t)(n < w.ncell ? n : w.ncell);
@@ -359,30 +377,43 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
         }
       }
     }
+    // A dense map is searched on cells of HALF the voxel size nested in the voxels (k_knn_h); g stays the voxel-level box, the
+    // search grid and the voxel grid cell_voxel[] lives on are derived from it (two cells / one voxel of padding).
+    const bool half = half_layout(c, is_target, n, g);
+    rgck::Grid vg = g;
+    if (half) g = rgck::half_grid_of(g, &vg);
     cl.grid = g;
+    cl.vgrid = vg;
     const size_t nc1 = (size_t)g.ncell + 1;
+    const size_t ntot = nc1 + (half ? (size_t)vg.ncell : 0);  // counters (+ sentinel), then the voxel occupancy flags
     int rc;
     if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1 + 256))) return rc;
+    if ((rc = ensure(c, cl.cnt, sizeof(int) * ntot + 256))) return rc;
     if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
-    if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (nc1 / 2048 + 2)))) return rc;
+    if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (ntot / 2048 + 2)))) return rc;
     if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.P, sizeof(float4) * ((size_t)n + 4)))) return rc;
     if ((rc = ensure(c, cl.segs, rgck::deferred_bytes(n)))) return rc;
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
-    if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)g.ncell))) return rc;
+    if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)vg.ncell))) return rc;
+    if (half) {  // (vox_cell is written by the cell scan in this layout)
+      const size_t vmax = (size_t)(n < vg.ncell ? n : vg.ncell);
+      if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
+    }
     if (cl.cnt.p != cl.cnt_seen) { cl.cnt_clean = 0; cl.cnt_seen = cl.cnt.p; }  // re-allocated: contents unknown
-    if (cl.cnt_clean < nc1) {  // first use or a larger grid; afterwards the scan leaves the counters clean: no fill kernel per frame
-      const size_t fill = std::min(cl.cnt.cap, (sizeof(int) * nc1 + 255) & ~(size_t)255);
+    if (cl.cnt_clean < ntot) {  // first use or a larger grid; afterwards the scan leaves the counters clean: no fill kernel per frame
+      const size_t fill = std::min(cl.cnt.cap, (sizeof(int) * ntot + 255) & ~(size_t)255);
       HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, fill, s));
     }
-    cl.cnt_clean = nc1;
-    rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi, spec ? dsm + 6 : nullptr);
-    rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
-                     is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23));
+    cl.cnt_clean = ntot;
+    rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi, spec ? dsm + 6 : nullptr,
+                      half ? (int*)cl.cnt.p + nc1 : nullptr);
+    rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)ntot, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
+                     is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23), half ? (int)nc1 : -1,
+                     half ? (int*)cl.vox_cell.p : nullptr);
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p, hi);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
                       (float4*)cl.P.p, (int*)cl.segs.p, hi);
@@ -390,7 +421,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   {
     ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n, s);
     // a sparse map (points per cell of its grid below map_wide_density): the wider block, see k_knn_sp_wide
-    const int wide_r = (is_target && c->map_wide_r > 0 && (double)n < c->map_wide_density * (double)cl.grid.ncell) ? c->map_wide_r : 0;
+    const int wide_r = (is_target && c->map_wide_r > 0 && (double)n < c->map_wide_density * (double)cl.vgrid.ncell) ? c->map_wide_r : 0;
     rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
                    (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r);
   }
@@ -404,12 +435,16 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   }
   if (is_target) {
     int rc;
-    const size_t vmax = (size_t)(n < cl.grid.ncell ? n : cl.grid.ncell);
+    const size_t vmax = (size_t)(n < cl.vgrid.ncell ? n : cl.vgrid.ncell);
     if ((rc = ensure(c, cl.vox, sizeof(double) * rgck::kVoxRec * vmax))) return rc;
     if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
     ProfScope ps(c, RGC_K_VOXEL, n);
-    rgck::voxel_build(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p,
-                      (const int*)cl.start.p, cl.grid, n, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p);
+    if (cl.grid.sub == 2)
+      rgck::voxel_build_h(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p,
+                          (const int*)cl.start.p, cl.grid, (int)vmax, c->d_small + 7, (const int*)cl.vox_cell.p, (double*)cl.vox.p);
+    else
+      rgck::voxel_build(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p,
+                        (const int*)cl.start.p, cl.grid, n, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p);
     cl.nvox = -1;  // fetched lazily
   }
   HIPCHK(c, hipGetLastError());
@@ -535,7 +570,7 @@ int do_linearize(rgc_ctx* c, const double T[16], double* H, double* b, double* c
   {
     ProfScope ps(c, RGC_K_LINEARIZE, n);
     rgck::linearize(c->stream, (const float4*)c->src.P.p,
-                    (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n, pose_from(T), c->tgt.grid,
+                    (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n, pose_from(T), c->tgt.vgrid,
                     (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p, want,
                     (double*)c->partials.p, (int*)c->ipartials.p, c->d_out, c->d_small + 8);
   }
@@ -581,7 +616,7 @@ int do_linearize_try(rgc_ctx* c, const double x0[16], double lambda, double H[36
   {
     ProfScope ps(c, RGC_K_LINEARIZE, n);
     rgck::linearize(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
-                    pose_from(x0), c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p,
+                    pose_from(x0), c->tgt.vgrid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p,
                     (double*)c->corr_M.p, 1, (double*)c->partials.p, (int*)c->ipartials.p, c->d_out, c->d_small + 8);
     rgck::lm_try(c->stream, c->d_out, c->d_small + 8, in);
   }
@@ -684,9 +719,13 @@ int prepare_map_grid(rgc_ctx* c, Cloud& cl, double cell) {
   }
   if (ncell > (double)c->prm.max_cells || ncell > 2.0e9) return fail(c, RGC_ERR_GRID_TOO_LARGE, "feature-map grid exceeds max_cells");
   g.res = cell;
+  g.vres = cell;
+  g.sub = 1;
+  g.pad = 0;
   g.inv_res = rgck::grid_inv_res(cell);
   g.ncell = (int)ncell;
   cl.grid = g;
+  cl.vgrid = g;
   const size_t nc1 = (size_t)g.ncell + 1;
   if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
   if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;
@@ -943,6 +982,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
   if (const char* e = getenv("RGC_FE_SPEC")) c->fe_spec_on = atoi(e) != 0;
+  if (const char* e = getenv("RGC_MAP_HALF")) c->map_half = atoi(e) != 0;
   if (const char* e = getenv("RGC_MAP_WIDE_R")) { const int v = atoi(e); if (v == 0 || v == 2) c->map_wide_r = v; }
   if (const char* e = getenv("RGC_MAP_WIDE")) { const double v = atof(e); if (v >= 0.0 && std::isfinite(v)) c->map_wide_density = v; }
   if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
@@ -1044,7 +1084,7 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
   const DevBuf* ob[] = {&o.in_copy, &o.cell_of, &o.slot_of, &o.cnt, &o.start, &o.block_sums, &o.order_tmp, &o.P, &o.nx, &o.ny, &o.nz, &o.segs,
                         &o.cell_voxel, &o.vox, &o.vox_cell};
   for (size_t k = 0; k < sizeof(db) / sizeof(db[0]); k++) { db[k]->p = ob[k]->p; db[k]->cap = ob[k]->cap; db[k]->borrowed = ob[k]->p != nullptr; }
-  d.in = o.in; d.stride_f = o.stride_f; d.n = o.n; d.grid = o.grid; d.nvox = o.nvox; d.deferred_seen = o.deferred_seen;
+  d.in = o.in; d.stride_f = o.stride_f; d.n = o.n; d.grid = o.grid; d.vgrid = o.vgrid; d.nvox = o.nvox; d.deferred_seen = o.deferred_seen;
   d.spec_ok = false; d.spec_used = false; d.cnt_clean = 0; d.cnt_seen = nullptr;
   d.ready = true;
   const int small[2] = {0, o.nvox};  // this context's copy of the target's guard (clear) and voxel count, which the solve reads
@@ -1087,7 +1127,7 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
     ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch, s);
     for (int k = 0; k < batch; k++) {
       rgck::lm_step(s, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
-                    c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
+                    c->tgt.vgrid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
                     (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, open, c->d_small + 7,
                     c->tgt.segs.p, c->src.segs.p);
       open = nullptr;
@@ -1402,7 +1442,7 @@ int rgc_get_voxels(rgc_ctx* c, int cap, int* coords, int* num, double* mean, dou
   HIPCHK(c, hipMemcpyAsync(rec.data(), c->tgt.vox.p, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(cell.data(), c->tgt.vox_cell.p, sizeof(int) * cell.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const rgck::Grid& g = c->tgt.grid;
+  const rgck::Grid& g = c->tgt.vgrid;
   for (int v = 0; v < m; v++) {
     const double* r = &rec[(size_t)v * rgck::kVoxRec];
     const int ci = cell[v];
