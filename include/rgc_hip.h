@@ -167,7 +167,8 @@ RGC_API int rgc_deskew(rgc_ctx* ctx, float* xyzi, int n, int stride_bytes, const
 RGC_API int rgc_voxelgrid(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, float leaf, float* out_xyzi, int* n_out,
                           int on_device);
 /* B9  vg_ICP::transformPointCloud(cloud, q, t) (src/RGC_odometer.cpp:1495-1514): q * p + t in fp64, stored fp32,
- * intensity copied; out_xyzi: n*4 floats. */
+ * intensity copied; out_xyzi: n*4 floats.  on_device: both pointers are device memory and the call returns once the kernel is enqueued
+ * on rgc_stream(ctx), like rgc_deskew -- a sub-map re-framed by the new pose (:1248-1256) goes straight to rgc_set_target_device. */
 RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, const double q_xyzw[4], const double t[3],
                                 float* out_xyzi, int on_device);
 

@@ -119,6 +119,12 @@ struct rgc_ctx {
   DevBuf pre_in, pre_out, vg_order, vg_pos, vg_tmp, vg_leaf;  // B2/B3/B9 staging
   struct VgBox { float leaf = 0.f; bool valid = false; rgck::LeafGrid g{}; } vg_box[4];  // measured leaf boxes of earlier clouds, by leaf size
   int vg_box_next = 0;
+  // Bounding boxes the library knows WITHOUT measuring: rgc_transform_cloud on device memory maps the input's box (measured once per
+  // input buffer) through the transform it applies -- the box of a sub-map re-framed by a new pose (RGC_odometer.cpp:1248-1256) follows
+  // from the pose.  rgc_set_target_device of such a buffer takes its grid from the hint: no bounding-box kernel, no host round trip,
+  // and no speculative-grid miss when the re-framed map's box swings with the vehicle's yaw.  k_count's guard still checks it.
+  struct BoxHint { const void* p = nullptr; int n = 0; double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; } box_hint[4];
+  int box_hint_next = 0;
   bool vg_flags_clean = false;  // d_small[24 + 6] is known to be zero (a finished rows chain leaves it so)
   DevBuf fe[34];              // front-end buffers
   unsigned char* h_stage = nullptr;  // pinned staging of the front-end's small read-backs and feature clouds (a copy into pageable
@@ -256,6 +262,23 @@ int check_params(rgc_ctx* c, const rgc_params* p) {
   return RGC_OK;
 }
 
+const rgc_ctx::BoxHint* find_hint(const rgc_ctx* c, const void* p, int n) {
+  for (const auto& h : c->box_hint)
+    if (h.p == p && h.n == n && p) return &h;
+  return nullptr;
+}
+void put_hint(rgc_ctx* c, const void* p, int n, const double lo[3], const double hi[3]) {
+  rgc_ctx::BoxHint* h = nullptr;
+  for (auto& e : c->box_hint)
+    if (e.p == p) h = &e;  // a buffer has one box
+  if (!h) { h = &c->box_hint[c->box_hint_next]; c->box_hint_next = (c->box_hint_next + 1) % 4; }
+  h->p = p; h->n = n;
+  for (int a = 0; a < 3; a++) { h->lo[a] = lo[a]; h->hi[a] = hi[a]; }
+}
+void drop_hints(rgc_ctx* c) {
+  for (auto& e : c->box_hint) e.p = nullptr;
+}
+
 // Which layout a map of n points on voxel-level box v gets: the half-size search grid (k_knn_h: k <= 20, a dense map -- a sparse one
 // takes the wide-block launch on the voxel grid -- and cell arrays that still fit), or the voxel grid itself.
 bool half_layout(const rgc_ctx* c, bool is_target, int n, const rgck::Grid& v) {
@@ -312,9 +335,26 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     // same neighbours on any grid: a raw 64-beam sweep puts thousands of points into the 1 m cells near the sensor (every query
     // scans its whole cell: O(c^2)), so its cell size follows the crowding measured on the previous frame of the sequence.
     const double res = is_target ? c->prm.voxel_res : (c->src_res > 0.0 ? c->src_res : (c->src_res_auto > 0.0 ? c->src_res_auto : c->prm.voxel_res));
-    const bool spec = c->spec_on && !c->lm_host && cl.spec_ok && cl.spec_grid.res == res && !force_bbox;
+    bool spec = c->spec_on && !c->lm_host && cl.spec_ok && cl.spec_grid.res == res && !force_bbox;
+    const rgc_ctx::BoxHint* hint = (is_target && c->spec_on && !c->lm_host && !force_bbox) ? find_hint(c, cl.in, n) : nullptr;
     rgck::Grid g{};
-    if (spec) {
+    if (hint) {  // the box is known (rgc_transform_cloud): its cells plus one on every side, guarded like a speculative grid
+      int lo[3], dm[3];
+      double ncell = 1.0;
+      for (int a = 0; a < 3; a++) {
+        lo[a] = (int)std::floor(hint->lo[a] / res - 0.5) - 1;
+        dm[a] = (int)std::floor(hint->hi[a] / res - 0.5) + 1 - lo[a] + 1;
+        ncell *= (double)dm[a];
+      }
+      if (ncell <= (double)c->prm.max_cells && ncell <= 2.0e9) g = rgck::make_grid(lo, dm, res);
+      else hint = nullptr;
+    }
+    if (hint) {
+      spec = true;
+      cl.spec_used = true;
+      cl.spec_ok = true;
+      cl.spec_grid = g;
+    } else if (spec) {
       g = cl.spec_grid;
       cl.spec_used = true;
     } else {
@@ -389,16 +429,19 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     int rc;
     if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;
-    if ((rc = ensure(c, cl.cnt, sizeof(int) * ntot + 256))) return rc;
-    if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
-    if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (ntot / 2048 + 2)))) return rc;
+    // (a hinted box is that of a map re-framed by the vehicle's pose: as the yaw changes it swings between the map's own box and one
+    // with twice the cells -- when the cell arrays have to grow, they grow for that at once, not a few per cent per frame)
+    const size_t cell_slack = (hint && (cl.cnt.cap < sizeof(int) * ntot + 256 || cl.start.cap < sizeof(int) * nc1)) ? 3 : 2;
+    if ((rc = ensure(c, cl.cnt, sizeof(int) * ntot * cell_slack / 2 + 256))) return rc;
+    if ((rc = ensure(c, cl.start, sizeof(int) * nc1 * cell_slack / 2))) return rc;
+    if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (ntot * cell_slack / 2 / 2048 + 2)))) return rc;
     if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.P, sizeof(float4) * ((size_t)n + 4)))) return rc;
     if ((rc = ensure(c, cl.segs, rgck::deferred_bytes(n)))) return rc;
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
-    if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)vg.ncell))) return rc;
+    if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)vg.ncell * cell_slack / 2))) return rc;
     if (half) {  // (vox_cell is written by the cell scan in this layout)
       const size_t vmax = (size_t)(n < vg.ncell ? n : vg.ncell);
       if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
@@ -528,6 +571,7 @@ int resolve_guards(rgc_ctx* c, int guard_t, int guard_s) {
     if (gd[a] & 1) { cl[a]->n = 0; return fail(c, RGC_ERR_NONFINITE, "%s cloud contains non-finite or absurd coordinates", a == 0 ? "target" : "source"); }
     static const bool trace = getenv("RGC_TRACE_ALLOC") != nullptr;
     if (trace) fprintf(stderr, "[rgc] %s cloud left its speculative grid: prepared again\n", a == 0 ? "target" : "source");
+    if (a == 0) drop_hints(c);  // (a hinted box that did not hold: its buffer was rewritten behind the library's back -- measure again)
     int rc = prepare_cloud(c, *cl[a], a == 0, /*force_bbox=*/true);
     if (rc) { cl[a]->n = 0; return rc; }
     redo = 1;
@@ -1516,9 +1560,46 @@ int rgc_transform_cloud(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, 
     if ((rc = ensure(c, c->pre_out, sizeof(float) * 4 * (size_t)n))) return rc;
     d_out = (float*)c->pre_out.p;
   }
+  if (on_device && c->spec_on) {
+    // the output's bounding box from the input's: measured once per input buffer (whole cells of 1 m, k_bbox), then the eight
+    // corners through q * p + t in fp64, a millimetre added for the fp32 rounding of the stored points
+    const rgc_ctx::BoxHint* hin = find_hint(c, xyzi, n);
+    if (!hin) {
+      int* dsm = c->d_small + 32;
+      int* hsm = c->h_small + 32;
+      const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+      memcpy(hsm, init, sizeof(init));
+      HIPCHK(c, hipMemcpyAsync(dsm, hsm, sizeof(init), hipMemcpyHostToDevice, c->stream));
+      rgck::bbox(c->stream, d_in, stride_bytes / 4, n, 1.0, dsm, dsm + 6);
+      HIPCHK(c, hipMemcpyAsync(hsm, dsm, 7 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (!hsm[6]) {
+        const double lo[3] = {hsm[0] + 0.5, hsm[1] + 0.5, hsm[2] + 0.5}, hi[3] = {hsm[3] + 1.5, hsm[4] + 1.5, hsm[5] + 1.5};
+        put_hint(c, xyzi, n, lo, hi);
+        hin = find_hint(c, xyzi, n);
+      }
+    }
+    if (hin) {
+      const double x = q[0], y = q[1], z = q[2], w = q[3];
+      const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                           2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+      for (int k = 0; k < 8; k++) {
+        const double p[3] = {(k & 1) ? hin->hi[0] : hin->lo[0], (k & 2) ? hin->hi[1] : hin->lo[1], (k & 4) ? hin->hi[2] : hin->lo[2]};
+        for (int a = 0; a < 3; a++) {
+          const double v = R[3 * a] * p[0] + R[3 * a + 1] * p[1] + R[3 * a + 2] * p[2] + t[a];
+          lo[a] = std::min(lo[a], v - 1.0e-3);
+          hi[a] = std::max(hi[a], v + 1.0e-3);
+        }
+      }
+      put_hint(c, out_xyzi, n, lo, hi);
+    }
+  }
   rgck::transform_q(c->stream, d_in, stride_bytes / 4, n, rgck::Quat{q[0], q[1], q[2], q[3]}, t, d_out, 4);
   if (!on_device) HIPCHK(c, hipMemcpyAsync(out_xyzi, d_out, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // device memory: stream-ordered like rgc_deskew -- a sub-map re-framed here and handed to rgc_set_target_device needs no host round trip
+  // (RGC_odometer.cpp:1248-1256 followed by :998); the one exception is the same as there (a pending map preparation, see rgc_deskew)
+  if (!on_device || c->main_has_target_prep) HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   return RGC_OK;
 }

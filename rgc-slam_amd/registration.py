@@ -326,6 +326,19 @@ class FastVGICP:
     def device_free(self, ptr: int):
         self._chk(self._L.rgc_device_free(self._h, C.c_void_p(ptr)))
 
+    def transformCloudDevice(self, d_in: int, n: int, stride_bytes: int, q_xyzw, t, d_out: int):
+        """B9 on device-resident clouds (RGC_odometer.cpp:1495-1514): q * p + t in fp64 -> n x 4 floats at d_out, stream-ordered."""
+        q = np.ascontiguousarray(q_xyzw, dtype=np.float64)
+        tt = np.ascontiguousarray(t, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._chk(self._L.rgc_transform_cloud(self._h, C.c_void_p(d_in), n, stride_bytes, q.ctypes.data_as(dp), tt.ctypes.data_as(dp),
+                                              C.c_void_p(d_out), 1))
+
+    def download(self, ptr: int, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        self._chk(self._L.rgc_download(self._h, out.ctypes.data, C.c_void_p(ptr), out.nbytes))
+        return out
+
     def upload(self, ptr: int, arr: np.ndarray):
         a = np.ascontiguousarray(arr)
         self._chk(self._L.rgc_upload(self._h, C.c_void_p(ptr), a.ctypes.data, a.nbytes))
