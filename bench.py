@@ -40,7 +40,7 @@ N_SOURCE = 30000
 N_TARGET = 1000000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 MAP_SHIFTS = ((0.0, 0.0, 0.0), (0.37, -0.23, 0.011), (-0.29, 0.41, -0.007))  # m: the map copies `replay_of_preframed_maps` alternates between
-PMC_FILE = "r02_pmc_knn.json"      # counters of the dominant kernel (scripts/pmc_kernel.sh)
+PMC_FILE = "r03_pmc_knn.json"      # counters of the dominant kernel (scripts/pmc_kernel.sh)
 MIX_FILE = "r03_knn_isa_mix.json"  # its full- / half-rate instruction mix (scripts/isa_mix.py)
 
 

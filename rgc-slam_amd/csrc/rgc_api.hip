@@ -1953,6 +1953,7 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
 #ifdef RGC_LAB
 RGC_API int rgc_lab_lm_ts(rgc_ctx* c, unsigned long long* out16) { rgck::lab_lm_ts(out16, c->stream); return RGC_OK; }
 RGC_API int rgc_lab_why(rgc_ctx*, int* out8) { rgck::lab_why(out8); return RGC_OK; }
+RGC_API int rgc_lab_iters(rgc_ctx*, unsigned long long* out8) { rgck::lab_iters(out8); return RGC_OK; }
 RGC_API int rgc_lab_wave_ts(rgc_ctx* c, long long* out16384) { (void)hipStreamSynchronize(c->stream); rgck::lab_wave_ts(out16384, c->stream2); return RGC_OK; }
 // developer build only (-DRGC_LAB): the deferred-query list of a cloud as the bulk kNN kernel left it
 RGC_API int rgc_lab_deferred(rgc_ctx* c, int is_target, int* idx, float* thr, int cap, int* count) {

@@ -192,6 +192,7 @@ void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const flo
 #ifdef RGC_LAB
 void lab_lm_ts(unsigned long long* out16, hipStream_t s);  // developer build: phase timestamps of k_lm_step
 void lab_why(int* out8);
+void lab_iters(unsigned long long* out8);                   // developer build: wave-level loop counts of the map's bulk kNN kernel (and resets them)
 void lab_wave_ts(long long* out16384, hipStream_t s);       // developer build: start / end of the scan kNN launch's waves
 #endif
 }  // namespace rgck

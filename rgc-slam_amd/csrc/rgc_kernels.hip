@@ -91,6 +91,25 @@ __device__ __forceinline__ void wave_prio(int hi) {
   if (hi) __builtin_amdgcn_s_setprio(3);
 }
 
+// Developer build (-DRGC_LAB): how often the wave-level loops of the map's bulk kNN kernel run -- with the kernel's ISA that gives the
+// executed instruction mix (scripts/isa_mix.py).  One count per WAVE (its first active lane).  Compiled out of the product.
+#ifdef RGC_LAB
+__device__ unsigned long long g_lab_iter[8];  // 0 waves, 1 quads processed in the scan loop, 2 chain inserts (drain rounds), 3 Newton steps, 4 Jacobi fallbacks, 5 exact tie-breaks
+#define LAB_COUNT(slot)                                                                                    \
+  do {                                                                                                     \
+    const unsigned long long m_ = __ballot(true);                                                          \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&g_lab_iter[slot], 1ull);         \
+  } while (0)
+void lab_iters(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lab_iter), sizeof(g_lab_iter));
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_iter), z, sizeof(z));
+}
+#else
+#define LAB_COUNT(slot) do {} while (0)
+#endif
+
 // Bounding box in CELL coordinates.  voxel_coord1 is monotone, so the per-thread work is a float min/max (the fp64
 // division runs once per thread, not once per coordinate); four points are in flight per lane; a block only issues
 // its six same-address atomics when it would still move the global bound (a relaxed read first) -- with ~1000 blocks the
@@ -562,6 +581,7 @@ __device__ __forceinline__ bool min_eigenvector_direct(const double S[6], double
   double x = 0.0;
   bool settled = false;
   for (int it = 0; it < 12; it++) {
+    LAB_COUNT(3);
     const double pv = ((x - 1.0) * x + c1) * x - c0;
     const double dp = (3.0 * x - 2.0) * x + c1;
     const double dx = pv * __builtin_amdgcn_rcp(dp);  // an approximate reciprocal is enough: the iteration corrects itself
@@ -737,7 +757,10 @@ struct Deferred {
 #endif
 constexpr bool kRowSkip = RGC_ROW_SKIP != 0;  // the map's search (whole rows, no piece machinery) skips rows by their distance bound
 constexpr int kPieceQuads = 1023;  // a piece's length in quads shares its table entry with the piece's distance bound (fp32, low 10 bits cut)
-constexpr int kSpBuf = 12;   // keys waiting to enter the chain, per lane
+#ifndef RGC_SPBUF
+#define RGC_SPBUF 12
+#endif
+constexpr int kSpBuf = RGC_SPBUF;   // keys waiting to enter the chain, per lane
 // Block geometry and LDS layout of one instantiation.  R = block radius in cells, kClip as described at knn_point_sp.
 // LDS per lane, as columns [slot][lane]: the append buffer, the piece table (padded with INT_MAX for the ordinal -> piece search)
 // and the pieces' first positions in the sorted array.
@@ -911,7 +934,8 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
 // ordinal {table row (high bits) | position in the row (low 7 bits)}: the winning keys give their neighbours' positions with ONE table
 // read, and a skipped row renumbers nothing.  (The raw scan's search -- pieces with lazily numbered ordinals, four lanes per query -- is
 // knn_point_split below.)
-template <int KC, int KB, int R, int T>  // T: threads per workgroup = stride of the per-lane LDS columns
+// kExact: the launch is for k == KC (the reference's k = 20): the general-k branches are not even compiled into that instance
+template <int KC, int KB, int R, int T, bool kExact>  // T: threads per workgroup = stride of the per-lane LDS columns
 __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
                                              int i, int* lds, const Deferred& df, double* __restrict__ nx, double* __restrict__ ny,
                                              double* __restrict__ nz) {
@@ -942,10 +966,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     defer(i, INFINITY);
     return;
   }
-#if defined(RGC_ABLATE) && RGC_ABLATE == 3  // scripts/ablate_knn.sh: the piece table alone
-  nx[i] = (double)nr; ny[i] = 0.0; nz[i] = 0.0;
-  return;
-#endif
+  LAB_COUNT(0);
   // ---- one pass over the candidate stream ----
   Chain<L> top;
   top.init();
@@ -965,11 +986,8 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     int key = pop();
     for (;;) {
       const int nkey = pop();
-#if defined(RGC_ABLATE) && RGC_ABLATE == 1  // scan + appends + pops, no chain insert (the first slot keeps the tail moving)
-      top.a[L - 1] = min(top.a[L - 1], key ^ 0x40000000);
-#else
+      LAB_COUNT(2);
       top.insert(key);
-#endif
       if (!__any(nkey != INT_MAX)) break;
       key = nkey;
     }
@@ -1001,6 +1019,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     ordn += q.on ? 4 : 0;
   };
   auto process = [&](const Quad& q) {
+    LAB_COUNT(1);
     if (q.on) {
       const int k0 = (__float_as_int(dist2_fma(px, py, pz, q.p0.x, q.p0.y, q.p0.z)) & ~kKeyOrd) | q.ord;
       const int k1 = (__float_as_int(dist2_fma(px, py, pz, q.p1.x, q.p1.y, q.p1.z)) & ~kKeyOrd) | (q.ord + 1);
@@ -1048,13 +1067,9 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     process(qb);
   }
   if (__any(bp != buf)) drain();
-#if defined(RGC_ABLATE) && (RGC_ABLATE == 1 || RGC_ABLATE == 2)  // everything up to the end of the scan
-  nx[i] = (double)top.a[0]; ny[i] = (double)top.a[L - 1]; nz[i] = (double)top.a[L / 2];
-  return;
-#endif
   // ---- the k-th neighbour: is it decided by the keys, and is it provably inside the block? ----
   int a_km2, a_km1, a_k, a_kp1;
-  if (k == KC) {
+  if (kExact || k == KC) {
     a_km2 = top.a[KC - 2]; a_km1 = top.a[KC - 1]; a_k = top.a[KC]; a_kp1 = top.a[KC + 1];
   } else {
     a_km2 = k >= 2 ? top.at(k - 2) : -(4 << kKeyBits);
@@ -1074,6 +1089,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     // the k-th and (k+1)-th candidates are less than two key buckets apart: the truncated (and FMA-rounded) keys cannot order them
     decided = false;
     if ((a_kp1 >> kKeyBits) - (a_k >> kKeyBits) >= 2 && (a_km1 >> kKeyBits) - (a_km2 >> kKeyBits) >= 2) {  // exactly two contenders
+      LAB_COUNT(5);
       const float4 p1 = P[index_of(a_km1)], p2 = P[index_of(a_k)];
       const float d1 = dist2(px, py, pz, p1), d2 = dist2(px, py, pz, p2);  // the reference's expression, uncontracted
       decided = d1 != d2;  // an exact tie is decided by the original index: cooperative kernel
@@ -1110,11 +1126,12 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
 #pragma unroll
     for (int j = 0; j < KC; j++) {
       if (kFull || j < k) {
-        const float4 cp = P[top.a[j]];
+        const float4 cp = point_at(P, (unsigned)top.a[j] << 4);
         const double dx = (double)cp.x - qx, dy = (double)cp.y - qy, dz = (double)cp.z - qz;
         mx += dx; my += dy; mz += dz;
-        S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz;
-        S[3] += dy * dy; S[4] += dy * dz; S[5] += dz * dz;
+        // (explicit fma: the file is compiled without contraction for the sake of dist2(); these sums have no such constraint)
+        S[0] = fma(dx, dx, S[0]); S[1] = fma(dx, dy, S[1]); S[2] = fma(dx, dz, S[2]);
+        S[3] = fma(dy, dy, S[3]); S[4] = fma(dy, dz, S[4]); S[5] = fma(dz, dz, S[5]);
       }
     }
     const double inv_k = 1.0 / (double)k;
@@ -1122,10 +1139,13 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     S[0] = S[0] * inv_k - mx * mx; S[1] = S[1] * inv_k - mx * my; S[2] = S[2] * inv_k - mx * mz;
     S[3] = S[3] * inv_k - my * my; S[4] = S[4] * inv_k - my * mz; S[5] = S[5] * inv_k - mz * mz;
   };
-  if (k == KC) moments(std::true_type{});
+  if (kExact || k == KC) moments(std::true_type{});
   else moments(std::false_type{});
   double nrm[3];
-  if (!min_eigenvector_direct(S, nrm)) min_eigenvector(S, nrm);
+  if (!min_eigenvector_direct(S, nrm)) {
+    LAB_COUNT(4);
+    min_eigenvector(S, nrm);
+  }
   nx[i] = nrm[0];
   ny[i] = nrm[1];
   nz[i] = nrm[2];
@@ -1155,7 +1175,7 @@ void lab_why(int* out8) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_why), z, sizeof(z));
 }
 #endif
-template <int KC, int KB, int R, int T>
+template <int KC, int KB, int R, int T, bool kExact>
 __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
                                                 int i, int sub, int* lds, const Deferred& df, double* __restrict__ nx,
                                                 double* __restrict__ ny, double* __restrict__ nz) {
@@ -1196,7 +1216,7 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   int shared = INT_MAX;  // upper bound of the (k + 2)-th smallest key of the union, the same in the four lanes
   int tau = INT_MAX;     // min(own tail, shared): what an append must beat
   auto refresh = [&]() {
-    shared = quad_max_i(k == KC ? top.a[(KC + 2 + S - 1) / S - 1] : top.at(bi));
+    shared = quad_max_i((kExact || k == KC) ? top.a[(KC + 2 + S - 1) / S - 1] : top.at(bi));
     tau = min(top.a[Ls - 1], shared);
   };
   int ri = 0, ordn = 0, ord = 0, jleft = 0;  // next piece, its first ordinal; this lane's next quad: ordinal, slots left in the piece
@@ -1323,7 +1343,7 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   merge_from(std::integral_constant<int, 0xAA>{});
   merge_from(std::integral_constant<int, 0xFF>{});
   int a_km2, a_km1, a_k, a_kp1;
-  if (k == KC) {
+  if (kExact || k == KC) {
     a_km2 = all.a[KC - 2]; a_km1 = all.a[KC - 1]; a_k = all.a[KC]; a_kp1 = all.a[KC + 1];
   } else {
     a_km2 = k >= 2 ? all.at(k - 2) : -(4 << kKeyBits);
@@ -1392,11 +1412,11 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
       const bool use = kFull || S * t + sub < k;
       const double dx = use ? (double)cp.x - qx : 0.0, dy = use ? (double)cp.y - qy : 0.0, dz = use ? (double)cp.z - qz : 0.0;
       m3[0] += dx; m3[1] += dy; m3[2] += dz;
-      S6[0] += dx * dx; S6[1] += dx * dy; S6[2] += dx * dz;
-      S6[3] += dy * dy; S6[4] += dy * dz; S6[5] += dz * dz;
+      S6[0] = fma(dx, dx, S6[0]); S6[1] = fma(dx, dy, S6[1]); S6[2] = fma(dx, dz, S6[2]);
+      S6[3] = fma(dy, dy, S6[3]); S6[4] = fma(dy, dz, S6[4]); S6[5] = fma(dz, dz, S6[5]);
     }
   };
-  if (k == KC) moments(std::true_type{});
+  if (kExact || k == KC) moments(std::true_type{});
   else moments(std::false_type{});
 #pragma unroll
   for (int a = 0; a < 3; a++) m3[a] = quad_sum_f64(m3[a]);
@@ -1441,7 +1461,7 @@ void lab_wave_ts(long long* out, hipStream_t s) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lab_wave), sizeof(g_lab_wave));
 }
 #endif
-template <int KC, bool kTarget>
+template <int KC, bool kTarget, bool kExact>
 __global__ void __launch_bounds__(SpConfig<kTarget>::T)
 k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
          double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
@@ -1460,20 +1480,20 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
 #ifdef RGC_LAB
     const long long lab_t0 = wall_clock64();
 #endif
-    if (i < n) knn_point_split<KC, Cfg::KB, Cfg::R, Cfg::T>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz);
+    if (i < n) knn_point_split<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz);
 #ifdef RGC_LAB
     if (threadIdx.x == 0 && b < 8192) { g_lab_wave[2 * b] = lab_t0; g_lab_wave[2 * b + 1] = wall_clock64(); }
 #endif
     return;
   }
   const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
-  if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+  if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
 }
 
 // The bulk launch for a SPARSE map (a few keyframes of a 16-beam sensor after the leaf filter: 0.1 points per 1 m cell, where the 3x3x3
 // block of the dense-map kernel holds fewer than k points for most queries and 85 % of them went to the cooperative kernel): the
 // scan's four-lanes-per-query search on the (2R+1)^3 block.  Same neighbours, same tie rule; the grid stays the voxel grid.
-template <int KC, int R>
+template <int KC, int R, bool kExact>
 __global__ void __launch_bounds__(WAVE)
 k_knn_sp_wide(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df, double* __restrict__ nx,
               double* __restrict__ ny, double* __restrict__ nz) {
@@ -1481,7 +1501,7 @@ k_knn_sp_wide(const float4* __restrict__ P, const int* __restrict__ start, Grid 
   if (df.guard && *df.guard) return;
   const int t = (int)blockIdx.x * WAVE + (int)threadIdx.x;
   const int i = t >> 2;
-  if (i < n) knn_point_split<KC, SpConfig<false>::KB, R, WAVE>(P, start, g, n, k, i, t & 3, slist_wide + threadIdx.x, df, nx, ny, nz);
+  if (i < n) knn_point_split<KC, SpConfig<false>::KB, R, WAVE, kExact>(P, start, g, n, k, i, t & 3, slist_wide + threadIdx.x, df, nx, ny, nz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3384,7 +3404,7 @@ static Deferred deferred_of(const void* buf, int n) {
   return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr};
 }
 
-template <int KC>
+template <int KC, bool kExact>
 static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred,
                         double* nx, double* ny, double* nz, const int* guard, int wide_r) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
@@ -3399,7 +3419,7 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   }
   if (wide_r == 2) {
     const size_t ldsw = (size_t)SpShape<2, true>::LDS * WAVE * sizeof(int);
-    hipLaunchKernelGGL((k_knn_sp_wide<KC, 2>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
+    hipLaunchKernelGGL((k_knn_sp_wide<KC, 2, kExact>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
     return;
   }
   using CT = SpConfig<true>;
@@ -3407,8 +3427,8 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   const int T = is_target ? CT::T : CS::T;
   const size_t lds = (size_t)(is_target ? SpShape<CT::R, CT::kClip>::LDS : SpShape<CS::R, CS::kClip>::LDS) * T * sizeof(int);
   const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
-  if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
-  else hipLaunchKernelGGL((k_knn_sp<KC, false>), dim3(nblk(n, T / 4)), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);  // four lanes per query
+  if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+  else hipLaunchKernelGGL((k_knn_sp<KC, false, kExact>), dim3(nblk(n, T / 4)), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);  // four lanes per query
 }
 template <int KC>
 static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
@@ -3425,8 +3445,10 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
 }
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard, int wide_r) {
-  if (k <= 20) knn_bulk_kc<20>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
-  else knn_bulk_kc<32>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
+  // (k == 20, the reference's setting, gets an instance without the general-k branches)
+  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
+  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
+  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
 }
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
               double* ny, double* nz, const int* guard, int waves) {
