@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <unordered_set>
@@ -67,6 +68,7 @@ struct ProfRegion {
 // solve, so that an owner destroyed too early is an error message and not a read of freed memory.
 static std::mutex g_live_mutex;
 static std::unordered_set<const rgc_ctx*> g_live;
+static std::atomic<unsigned long long> g_next_uid{1};  // contexts are told apart by this, not by their address (an address is re-used)
 static bool ctx_alive(const rgc_ctx* c) {
   std::lock_guard<std::mutex> lk(g_live_mutex);
   return g_live.count(c) != 0;
@@ -82,6 +84,7 @@ struct rgc_ctx {
   hipEvent_t main_mark = nullptr; // recorded on the main stream before a source is prepared: stream2 waits for it (producers on rgc_stream())
   bool src_pending = false;       // main stream has not yet been ordered after src_ready
   bool mark_valid = false, main_has_target_prep = false;  // main_mark recorded; a map preparation was enqueued after it and may still run
+  bool main_late_producer = false;  // ... and something that may WRITE a scan buffer (rgc_upload) was enqueued on the main stream behind it
   char err[512] = {0};
   Cloud src, tgt;
   // per-correspondence state frozen by linearize (fast_vgicp_impl.hpp:104-115)
@@ -145,7 +148,10 @@ struct rgc_ctx {
   bool map_bound = false;     // the context's target IS the committed map (rgc_set_target* unbinds it)
   unsigned long long tgt_generation = 0;   // bumped whenever this context prepares a target (what borrowers check)
   const rgc_ctx* tgt_owner = nullptr;      // rgc_share_target: whose target this context aliases, and at which generation
-  unsigned long long tgt_owner_gen = 0;
+  unsigned long long tgt_owner_gen = 0, tgt_owner_uid = 0;
+  unsigned long long uid = 0;              // process-wide, never re-used
+  hipEvent_t src_read_done = nullptr;      // recorded on the main stream behind a kernel that reads the source's INPUT buffer (rgc_get_aligned*)
+  bool src_read_pending = false;           // ... and not yet waited for by the stream a host source is copied on
   float map_leaf = 0.f;
   int map_ntarget = 0;
   unsigned long long map_rev = 0;
@@ -308,9 +314,10 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   // recorded on the main stream BEFORE this frame's map preparation was enqueued (waiting for the map's kNN launch would serialise
   // the two) -- i.e. at rgc_set_target*, or here when no map preparation is pending.  See rgc_set_source_device in rgc_hip.h.
   if (!is_target && c->main_has_target_prep && hipStreamQuery(c->stream) == hipSuccess) c->main_has_target_prep = false;  // it has drained
-  if (is_target || !c->main_has_target_prep) {
+  if (is_target || !c->main_has_target_prep || c->main_late_producer) {
     HIPCHK(c, hipEventRecord(c->main_mark, c->stream));
     c->mark_valid = true;
+    c->main_late_producer = false;
   }
   if (is_target) c->main_has_target_prep = true;
   else if (c->mark_valid) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->main_mark, 0));
@@ -501,6 +508,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
 
 int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, int stride_bytes, bool on_device) {
   if (!c) return RGC_ERR_INVALID;
+  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   cl.ready = false;
   cl.n = 0;
   c->corr_valid = false;
@@ -519,6 +527,10 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
     const size_t bytes = (size_t)n * stride_bytes;
     int rc = ensure(c, cl.in_copy, bytes);
     if (rc) return rc;
+    if (!is_target && c->src_read_pending) {  // a kernel on the main stream still reads the previous scan out of this buffer (rgc_get_aligned_device)
+      HIPCHK(c, hipStreamWaitEvent(c->stream2, c->src_read_done, 0));
+      c->src_read_pending = false;
+    }
     // pageable host memory: hipMemcpyAsync stages and returns once the source has been consumed
     HIPCHK(c, hipMemcpyAsync(cl.in_copy.p, xyz, bytes - (stride_bytes - 12), hipMemcpyHostToDevice, is_target ? c->stream : c->stream2));
     cl.in = (const float*)cl.in_copy.p;
@@ -579,8 +591,33 @@ int resolve_guards(rgc_ctx* c, int guard_t, int guard_s) {
   return redo;
 }
 
+// A borrowed target (rgc_share_target) is only as good as its owner: alive (the same context, not a new one at its address) and not
+// prepared again since.  Called by EVERY consumer of c->tgt -- the solve, the fine seam, the fitness score, the getters.
+int check_target_owner(rgc_ctx* c) {
+  if (!c->tgt_owner) return RGC_OK;
+  bool alive;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mutex);
+    alive = g_live.count(c->tgt_owner) != 0 && c->tgt_owner->uid == c->tgt_owner_uid;
+  }
+  if (!alive) {  // its device buffers are gone with it
+    c->tgt_owner = nullptr;
+    for (DevBuf* b : {&c->tgt.in_copy, &c->tgt.cell_of, &c->tgt.slot_of, &c->tgt.cnt, &c->tgt.start, &c->tgt.block_sums, &c->tgt.order_tmp, &c->tgt.P,
+                      &c->tgt.nx, &c->tgt.ny, &c->tgt.nz, &c->tgt.segs, &c->tgt.cell_voxel, &c->tgt.vox, &c->tgt.vox_cell})
+      release(*b);
+    c->tgt.ready = false;
+    c->tgt.n = 0;
+    return fail(c, RGC_ERR_NO_INPUT, "the context whose target this one shared has been destroyed");
+  }
+  if (c->tgt_owner->tgt_generation != c->tgt_owner_gen)
+    return fail(c, RGC_ERR_INVALID, "the shared target was rebuilt by its owner: rgc_share_target again");
+  return RGC_OK;
+}
+
 // for every consumer except rgc_align (which gets the guards with its state read-back): one synchronisation, once per cloud
 int validate_clouds(rgc_ctx* c) {
+  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  { int rc = check_target_owner(c); if (rc) return rc; }
   if (!((c->tgt.ready && c->tgt.spec_used) || (c->src.ready && c->src.spec_used))) return RGC_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipMemcpyAsync(c->h_small + 6, c->d_small + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1023,6 +1060,8 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
+  c->uid = g_next_uid.fetch_add(1);
+  ok = ok && hipEventCreateWithFlags(&c->src_read_done, hipEventDisableTiming) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
   if (const char* e = getenv("RGC_FE_SPEC")) c->fe_spec_on = atoi(e) != 0;
@@ -1069,6 +1108,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->main_mark) (void)hipEventDestroy(c->main_mark);
   if (c->tgt_ready) (void)hipEventDestroy(c->tgt_ready);
+  if (c->src_read_done) (void)hipEventDestroy(c->src_read_done);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
@@ -1135,6 +1175,7 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
   HIPCHK(c, hipMemcpy(c->d_small + 6, small, sizeof(small), hipMemcpyHostToDevice));
   c->tgt_owner = owner;
   c->tgt_owner_gen = owner->tgt_generation;
+  c->tgt_owner_uid = owner->uid;
   c->map_bound = false;
   c->corr_valid = false;
   c->deferred_known = false;
@@ -1196,19 +1237,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   c->pend.active = false;
   // the guards of speculative grids come home with the LM state: no synchronisation here
   if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
-  if (c->tgt_owner) {
-    if (!ctx_alive(c->tgt_owner)) {  // its device buffers are gone with it
-      c->tgt_owner = nullptr;
-      for (DevBuf* b : {&c->tgt.in_copy, &c->tgt.cell_of, &c->tgt.slot_of, &c->tgt.cnt, &c->tgt.start, &c->tgt.block_sums, &c->tgt.order_tmp, &c->tgt.P,
-                        &c->tgt.nx, &c->tgt.ny, &c->tgt.nz, &c->tgt.segs, &c->tgt.cell_voxel, &c->tgt.vox, &c->tgt.vox_cell})
-        release(*b);
-      c->tgt.ready = false;
-      c->tgt.n = 0;
-      return fail(c, RGC_ERR_NO_INPUT, "the context whose target this one shared has been destroyed");
-    }
-    if (c->tgt_owner->tgt_generation != c->tgt_owner_gen)
-      return fail(c, RGC_ERR_INVALID, "the shared target was rebuilt by its owner: rgc_share_target again");
-  }
+  { int rc = check_target_owner(c); if (rc) return rc; }
   // The solve is a chain of short launches: it runs on the HIGH-PRIORITY stream -- the one the scan was prepared on, so it is already
   // behind that -- ordered after the map's preparation on the main stream by one event.  With a second context preparing the next
   // frame's map meanwhile (15 k waves that fill every CU), the dispatcher places the solve's ~100 workgroups as soon as slots free up
@@ -1408,6 +1437,10 @@ int rgc_get_aligned_device(rgc_ctx* c, const float T[16], float* d_out, int stri
   int rc = join_source(c);
   if (rc) return rc;
   rgck::transform_f32(c->stream, c->src.in, c->src.stride_f, c->src.n, posef_from(T), d_out, stride_bytes / 4);
+  // the kernel reads the source's input buffer on the MAIN stream and nothing here waits for it: the next host source is copied into
+  // that buffer on the scan's stream, which must queue behind this read (set_cloud)
+  HIPCHK(c, hipEventRecord(c->src_read_done, c->stream));
+  c->src_read_pending = true;
   HIPCHK(c, hipGetLastError());
   return RGC_OK;
 }
@@ -1988,6 +2021,9 @@ int rgc_upload(rgc_ctx* c, void* d, const void* h, size_t bytes) {
   if (!c || !d || !h) return RGC_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  // behind a pending map preparation this copy is NOT covered by the mark the scan's stream waits for (rgc_set_source_device in rgc_hip.h):
+  // remembered, so that a source set next is ordered behind it -- at the price of that one frame's overlap -- instead of racing it
+  if (c->main_has_target_prep) c->main_late_producer = true;
   return RGC_OK;
 }
 int rgc_download(rgc_ctx* c, void* h, const void* d, size_t bytes) {

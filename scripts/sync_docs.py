@@ -1,6 +1,6 @@
 """Rewrite the number-bearing passages of DESIGN.md (§8), BASELINE.md (§4), README.md and profiles/README.md from the files under
 profiles/r02_* (one refresh = one run of scripts/refresh_profiles.sh), so that the prose cannot drift from the measurements."""
-import csv, json, os, re
+import ast, csv, json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda *a: os.path.join(ROOT, *a)
 J = lambda name: json.loads(open(P("profiles", name)).readline()) if name.endswith("bench.json") and "rolling" not in name and "cpp" not in name and "frontend" not in name and "mapreg" not in name and "icp" not in name and "pre_" not in name else json.load(open(P("profiles", name)))
@@ -9,7 +9,7 @@ u = json.loads(open(P("profiles", "r02_bench_under_rocprof.json")).readline())
 roll = json.load(open(P("profiles", "r02_rolling_bench.json")))["A"]
 node = json.load(open(P("profiles", "r02_cpp_node_bench.json")))
 pipe = json.load(open(P("profiles", "r02_cpp_pipeline_bench.json")))
-longr = json.load(open(P("profiles", "r02_long_run.json"))) if open(P("profiles", "r02_long_run.json")).read().strip().startswith("{\"") else eval(open(P("profiles", "r02_long_run.json")).read())
+longr = json.load(open(P("profiles", "r02_long_run.json"))) if open(P("profiles", "r02_long_run.json")).read().strip().startswith("{\"") else ast.literal_eval(open(P("profiles", "r02_long_run.json")).read())
 pmc = json.load(open(P("profiles", "r02_pmc_knn.json")))
 lp = json.load(open(P("profiles", "r02_long_run_pipelined.json")))
 knn_prof_us = None

@@ -481,11 +481,14 @@ def test_shared_target(reg_mod, medium):
     pv.share_target()
     out = pv.run(len(scans), lambda i, w: w.setInputSource(scans[i]), poses[0].astype(np.float32))
     assert all(np.array_equal(x, y) for x, y in zip(out, seq))
-    # the owner prepares a new target: the borrower must notice
+    # the owner prepares a new target: the borrower must notice -- in the solve and in EVERY other consumer of the aliased buffers
     a.setInputTarget(medium["tgt"][: len(medium["tgt"]) // 2])
     b.setInputSource(medium["src"])
     with pytest.raises(reg_mod.RgcError):
         b.align(g, want_output=False)
+    for stale in (lambda: b.fitnessAt(g), lambda: b.linearize(np.eye(4)), lambda: b.compute_error(np.eye(4)), b.getTargetCovariances, b.getVoxels):
+        with pytest.raises(reg_mod.RgcError):
+            stale()
     b.shareTargetFrom(a)
     b.align(g, want_output=False)
     a.setInputSource(medium["src"])
@@ -503,6 +506,12 @@ def test_shared_target(reg_mod, medium):
     c.shareTargetFrom(a)
     c.setInputSource(medium["src"])
     a.close()
+    d = _odo(reg_mod)   # (a new context, possibly at the dead owner's address: contexts are told apart by a process-wide id)
+    d.setInputTarget(medium["tgt"])
+    with pytest.raises(reg_mod.RgcError):
+        c.getTargetCovariances()
+    c.shareTargetFrom(d)
+    d.close()
     with pytest.raises(reg_mod.RgcError):
         c.align(g, want_output=False)
     c.setInputTarget(medium["tgt"])
@@ -601,3 +610,104 @@ def test_pipelined_sequence_with_speculative_grid_misses(reg_mod):
     pv.close()
     for i, (T, f) in enumerate(zip(out, fits)):
         assert np.array_equal(T, seq[i][0]) and f == seq[i][1], i
+
+
+def test_output_cloud_on_the_device_with_host_sources_in_a_pipeline(reg_mod, orc, medium):
+    """rgc_get_aligned_device reads the scan's input buffer on the main stream and returns at once; the next HOST source is copied into that
+    buffer on the scan's stream, which must queue behind the read.  Two contexts taking turns, host sources, the output cloud of every
+    frame left on the device: each equals pcl::transformPointCloud(*input_, output, final) of ITS scan (lsq_registration_impl.hpp:78)."""
+    import rgc_slam_amd.synth as synth
+    poses = synth.make_trajectory(7, seed=synth.SEED + 5)
+    scans = [synth.make_scan_n(medium["world"], poses[i + 1], 15000, seed=synth.SEED + 700 + i)["xyz"] for i in range(6)]
+    pv = reg_mod.PipelinedVGICP(0, depth=2)
+    d_out = [pv.v[0].device_alloc(16 * len(s)) for s in scans]
+
+    def setc(i, w):
+        w.setInputTarget(medium["tgt"])
+        w.setInputSource(scans[i])
+    Ts = pv.run(len(scans), setc, poses[0].astype(np.float32), on_result=lambda i, w: w.alignedToDevice(d_out[i], 16))
+    pv.synchronize()
+    for i, s in enumerate(scans):
+        got = pv.v[0].download(d_out[i], (len(s), 4))[:, :3]
+        exp = orc.transform_f32(s, Ts[i])
+        assert np.abs(got - exp).max() <= 2e-6 * max(1.0, np.abs(exp).max()), i
+    for p in d_out:
+        pv.v[0].device_free(p)
+    pv.close()
+
+
+def test_a_context_with_a_solve_in_flight_refuses_new_clouds(reg_mod, medium):
+    v = _odo(reg_mod)
+    v.setInputTarget(medium["tgt"])
+    v.setInputSource(medium["src"])
+    v.align_begin(np.eye(4, dtype=np.float32))
+    for bad in (lambda: v.setInputSource(medium["src"]), lambda: v.setInputTarget(medium["tgt"]), lambda: v.fitnessAt(np.eye(4, dtype=np.float32)),
+                v.getTargetCovariances):
+        with pytest.raises(reg_mod.RgcError):
+            bad()
+    T = v.align_end()
+    w = _odo(reg_mod)
+    w.setInputTarget(medium["tgt"])
+    w.setInputSource(medium["src"])
+    w.align(np.eye(4, dtype=np.float32), want_output=False)
+    assert np.array_equal(T, w.getFinalTransformation())
+    v.close()
+    w.close()
+
+
+def test_half_size_search_grid_layout(reg_mod, orc, medium, monkeypatch):
+    """RGC_MAP_HALF=1 (k_knn_h, parked in round 3: no faster): the map searched on cells of half the voxel size nested in the voxels.  Same
+    neighbours -- every target covariance as the CPU oracle's and as the default layout's -- the same voxel table, the same pose."""
+    base = _odo(reg_mod)
+    base.setInputTarget(medium["tgt"])
+    cov0, vox0 = base.getTargetCovariances(), base.getVoxels()
+    base.setInputSource(medium["src"])
+    base.align(np.eye(4, dtype=np.float32), want_output=False)
+    T0 = base.getFinalTransformation()
+    base.close()
+    monkeypatch.setenv("RGC_MAP_HALF", "1")
+    v = _odo(reg_mod)
+    v.setInputTarget(medium["tgt"])
+    assert v.stats()["target_cells"] > 4 * len(vox0["num"])          # (it really is the finer grid)
+    cov1, vox1 = v.getTargetCovariances(), v.getVoxels()
+    assert np.abs(cov1 - cov0).max() <= 1e-12
+    ocov, _ = orc.covariances(medium["tgt"], k=20)
+    assert np.abs(cov1 - ocov).max() <= 1e-9
+    k0 = np.lexsort(vox0["coords"].T[::-1]); k1 = np.lexsort(vox1["coords"].T[::-1])
+    assert np.array_equal(vox0["coords"][k0], vox1["coords"][k1]) and np.array_equal(vox0["num"][k0], vox1["num"][k1])
+    assert np.abs(vox0["mean"][k0] - vox1["mean"][k1]).max() <= 1e-12 and np.abs(vox0["cov"][k0] - vox1["cov"][k1]).max() <= 1e-12
+    v.setInputSource(medium["src"])
+    v.align(np.eye(4, dtype=np.float32), want_output=False)
+    assert np.abs(v.getFinalTransformation() - T0).max() <= 1e-6
+    v.close()
+
+
+@pytest.mark.parametrize("knob,value", [("RGC_SRC_RES", "0.5"), ("RGC_SRC_RES", "2.0"), ("RGC_SMALL_COPY", "1"), ("RGC_SPEC_GRID", "0"),
+                                        ("RGC_MAP_WIDE", "0"), ("RGC_MAP_WIDE", "1000"), ("RGC_MAP_WIDE_R", "0"), ("RGC_MAP_HALF", "1")])
+def test_developer_knobs_change_no_result(reg_mod, medium, monkeypatch, knob, value):
+    """Every environment knob read by rgc_create (README) selects another route to the SAME result: a short sequence gives the default's
+    poses bit for bit (the map's layout knobs: to 1e-6, their fp64 sums run in another order), iterations and fitness included."""
+    import rgc_slam_amd.synth as synth
+    poses = synth.make_trajectory(4, seed=synth.SEED + 11)
+    scans = [synth.make_scan_n(medium["world"], poses[i + 1], 12000, seed=synth.SEED + 900 + i)["xyz"] for i in range(3)]
+
+    def run():
+        v = _odo(reg_mod)
+        g, out = poses[0].astype(np.float32), []
+        for s_ in scans:
+            v.setInputTarget(medium["tgt"])
+            v.setInputSource(s_)
+            v.align(g, want_output=False, want_fitness=True)
+            g = v.getFinalTransformation()
+            out.append((g, v.nr_iterations, v.getFitnessScore()))
+        v.close()
+        return out
+    ref = run()
+    monkeypatch.setenv(knob, value)
+    got = run()
+    exact = knob not in ("RGC_MAP_HALF", "RGC_MAP_WIDE", "RGC_MAP_WIDE_R")
+    for (Ta, ia, fa), (Tb, ib, fb) in zip(ref, got):
+        if exact:
+            assert np.array_equal(Ta, Tb) and ia == ib and fa == fb
+        else:
+            assert np.abs(Ta - Tb).max() <= 1e-6 and abs(fa - fb) <= 1e-6 * fa
