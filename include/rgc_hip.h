@@ -146,6 +146,17 @@ RGC_API int rgc_get_aligned_device(rgc_ctx* ctx, const float T[16], float* d_out
  * (row-major, n*9 doubles) and/or unit normals (n*3 doubles, sign arbitrary), caller point order. */
 RGC_API int rgc_get_source_covariances(rgc_ctx* ctx, double* cov9 /* may be NULL */, double* normals /* may be NULL */);
 RGC_API int rgc_get_target_covariances(rgc_ctx* ctx, double* cov9, double* normals);
+/* FastGICP::setSourceCovariances / setTargetCovariances (include/fast_gicp/gicp/fast_gicp.hpp:58-61, impl/fast_gicp_impl.hpp:93-100):
+ * n*9 doubles, row-major, caller point order, for the cloud set before.  Only covariances of the plane-regularised form
+ * I - 0.999 n n^T (what this path and the reference's odometer produce, fast_gicp_impl.hpp:280-293) are representable here: any other
+ * matrix is RGC_ERR_INVALID.  The target's voxel map is rebuilt from them. */
+RGC_API int rgc_set_source_covariances(rgc_ctx* ctx, const double* cov9, int n);
+RGC_API int rgc_set_target_covariances(rgc_ctx* ctx, const double* cov9, int n);
+/* FastGICP::clearSource / clearTarget (fast_gicp.hpp:56-57, fast_gicp_impl.hpp:60-69) and FastVGICP::swapSourceAndTarget
+ * (fast_vgicp_impl.hpp:46-53: the clouds change roles, the voxel map is rebuilt from the new target). */
+RGC_API int rgc_clear_source(rgc_ctx* ctx);
+RGC_API int rgc_clear_target(rgc_ctx* ctx);
+RGC_API int rgc_swap_source_and_target(rgc_ctx* ctx);
 /* Gaussian voxel map dump (fast_vgicp_voxel.hpp:105-122): up to cap voxels, unordered.
  * coords 3*cap ints, num cap ints, mean 3*cap doubles, cov9 9*cap doubles; *count = total voxels. */
 RGC_API int rgc_get_voxels(rgc_ctx* ctx, int cap, int* coords, int* num, double* mean, double* cov9, int* count);

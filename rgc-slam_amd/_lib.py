@@ -112,7 +112,8 @@ SYMBOLS = [
     "rgc_default_params", "rgc_create", "rgc_destroy", "rgc_set_params", "rgc_get_params", "rgc_last_error",
     "rgc_status_string", "rgc_version", "rgc_set_target", "rgc_set_source", "rgc_set_target_device",
     "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align", "rgc_align_begin", "rgc_align_end", "rgc_share_target",
-    "rgc_fitness", "rgc_get_aligned", "rgc_get_aligned_device", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_get_voxels",
+    "rgc_fitness", "rgc_get_aligned", "rgc_get_aligned_device", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_set_source_covariances", "rgc_set_target_covariances",
+    "rgc_clear_source", "rgc_clear_target", "rgc_swap_source_and_target", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_imu_filter_init", "rgc_imu_filter_push", "rgc_ground_gate_init", "rgc_ground_gate_remember", "rgc_ground_gate_step", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
     "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_frontend_device", "rgc_frontend_cloud_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_map_reset", "rgc_map_insert", "rgc_map_evict", "rgc_map_rebase", "rgc_map_commit", "rgc_map_get_info", "rgc_map_download", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
@@ -157,6 +158,11 @@ def load():
     L.rgc_get_aligned.argtypes = [vp, fp, fp, C.c_int]
     L.rgc_get_aligned_device.argtypes = [vp, fp, vp, C.c_int]
     L.rgc_get_source_covariances.argtypes = [vp, dp, dp]
+    L.rgc_set_source_covariances.argtypes = [vp, dp, C.c_int]
+    L.rgc_set_target_covariances.argtypes = [vp, dp, C.c_int]
+    L.rgc_clear_source.argtypes = [vp]
+    L.rgc_clear_target.argtypes = [vp]
+    L.rgc_swap_source_and_target.argtypes = [vp]
     L.rgc_get_target_covariances.argtypes = [vp, dp, dp]
     L.rgc_get_voxels.argtypes = [vp, C.c_int, ip, ip, dp, dp, ip]
     L.rgc_get_stats.argtypes = [vp, C.POINTER(Stats)]

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <memory>
 #include <vector>
 
@@ -25,6 +26,8 @@
 namespace rgc {
 
 enum class NeighborSearchMethod { DIRECT27 = RGC_DIRECT27, DIRECT7 = RGC_DIRECT7, DIRECT1 = RGC_DIRECT1 };  // gicp_settings.hpp:8
+enum class RegularizationMethod { NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS };                    // gicp_settings.hpp:6
+enum class VoxelAccumulationMode { ADDITIVE, ADDITIVE_WEIGHTED, MULTIPLICATIVE };                            // gicp_settings.hpp:10
 
 class FastVGICPHip {
 public:
@@ -48,6 +51,9 @@ public:
   void setInitialLambdaFactor(double f) { p_.lm_init_lambda_factor = f; push(); }  // lsq_registration_impl.hpp:32-34
   void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; push(); }    // fast_gicp_impl.hpp:41-43
   void setNeighborSearchMethod(NeighborSearchMethod m) { p_.neighbor_method = (int)m; push(); }
+  // the odometer leaves both at the constructor's values (PLANE, fast_gicp_impl.hpp:20; ADDITIVE, fast_vgicp_impl.hpp:24): the only ones built here
+  void setRegularizationMethod(RegularizationMethod m) { if (m != RegularizationMethod::PLANE) throw std::runtime_error("rgc: only RegularizationMethod::PLANE is implemented"); }
+  void setVoxelAccumulationMode(VoxelAccumulationMode m) { if (m != VoxelAccumulationMode::ADDITIVE) throw std::runtime_error("rgc: only VoxelAccumulationMode::ADDITIVE is implemented"); }
   void setMaxCorrespondenceDistance(double) {}   // unused by FastVGICP
   void setEuclideanFitnessEpsilon(double) {}     // no-op in LsqRegistration
   void setRANSACIterations(int) {}               // no-op
@@ -62,6 +68,14 @@ public:
   void setInputSource(const CloudPtr& cloud) { setInputSource(&cloud->points[0].x, (int)cloud->points.size(), (int)sizeof(cloud->points[0])); }
   void setInputTargetDevice(const float* d_xyz, int n, int stride_bytes) { chk(rgc_set_target_device(ctx_, d_xyz, n, stride_bytes)); n_tgt_ = n; fit_valid_ = false; }
   void setInputSourceDevice(const float* d_xyz, int n, int stride_bytes) { chk(rgc_set_source_device(ctx_, d_xyz, n, stride_bytes)); n_src_ = n; fit_valid_ = false; }
+
+  // fast_gicp.hpp:55-61: the clouds change roles (fast_vgicp_impl.hpp:46-53) / are dropped / get covariances from the caller (n*9 doubles,
+  // row-major, plane-regularised form only -- see rgc_set_source_covariances)
+  void swapSourceAndTarget() { chk(rgc_swap_source_and_target(ctx_)); std::swap(n_src_, n_tgt_); fit_valid_ = false; }
+  void clearSource() { chk(rgc_clear_source(ctx_)); n_src_ = 0; fit_valid_ = false; }
+  void clearTarget() { chk(rgc_clear_target(ctx_)); n_tgt_ = 0; fit_valid_ = false; }
+  void setSourceCovariances(const std::vector<double>& cov9) { chk(rgc_set_source_covariances(ctx_, cov9.data(), (int)(cov9.size() / 9))); fit_valid_ = false; }
+  void setTargetCovariances(const std::vector<double>& cov9) { chk(rgc_set_target_covariances(ctx_, cov9.data(), (int)(cov9.size() / 9))); fit_valid_ = false; }
 
   // ---- pcl::Registration::align(output, guess) ----
   // guess: row-major float[16]

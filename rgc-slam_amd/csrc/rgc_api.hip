@@ -1493,6 +1493,96 @@ static int get_covs(rgc_ctx* c, Cloud& cl, double* cov9, double* normals) {
 int rgc_get_source_covariances(rgc_ctx* c, double* cov9, double* normals) { return c ? get_covs(c, c->src, cov9, normals) : RGC_ERR_INVALID; }
 int rgc_get_target_covariances(rgc_ctx* c, double* cov9, double* normals) { return c ? get_covs(c, c->tgt, cov9, normals) : RGC_ERR_INVALID; }
 
+// FastGICP::setSourceCovariances / setTargetCovariances (fast_gicp_impl.hpp:93-100): covariances given by the caller replace the ones
+// computed from the 20 nearest neighbours.  This path keeps a covariance as its unit normal (C = I - 0.999 n n^T, the PLANE
+// regularisation, fast_gicp_impl.hpp:280-293 -- the only form the reference's odometer produces): matrices of that form are
+// accepted (to 1e-9), anything else is RGC_ERR_INVALID.  The target's voxel map is rebuilt from the new covariances.
+static int set_covs(rgc_ctx* c, Cloud& cl, bool is_target, const double* cov9, int n) {
+  if (!cov9) return RGC_ERR_INVALID;
+  if (!cl.ready) return fail(c, RGC_ERR_NO_INPUT, "cloud not set");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = validate_clouds(c);
+  if (rc) return rc;
+  if (!cl.ready) return fail(c, RGC_ERR_NO_INPUT, "cloud not set");
+  if (is_target && c->tgt_owner) return fail(c, RGC_ERR_INVALID, "the target is borrowed (rgc_share_target): its covariances belong to the owner");
+  if (n != cl.n) return fail(c, RGC_ERR_INVALID, "%d covariances for a cloud of %d points", n, cl.n);
+  std::vector<double> nrm((size_t)n * 3);
+  for (int i = 0; i < n; i++) {
+    const double* C9 = cov9 + (size_t)i * 9;
+    double M[9];
+    for (int a = 0; a < 9; a++) M[a] = ((a % 4 == 0 ? 1.0 : 0.0) - C9[a]) / 0.999;   // n n^T
+    const int d = (M[0] >= M[4] && M[0] >= M[8]) ? 0 : (M[4] >= M[8] ? 1 : 2);
+    const double len = std::sqrt(M[4 * d]);
+    double v[3] = {0, 0, 0};
+    bool ok = len > 0.0 && std::isfinite(len);
+    if (ok) {
+      for (int a = 0; a < 3; a++) v[a] = M[3 * a + d] / len;
+      for (int a = 0; a < 3 && ok; a++)
+        for (int b = 0; b < 3; b++)
+          if (!(std::fabs(M[3 * a + b] - v[a] * v[b]) <= 1.0e-9)) { ok = false; break; }
+    }
+    if (!ok) return fail(c, RGC_ERR_INVALID, "covariance %d is not of the plane-regularised form I - 0.999 n n^T: not supported", i);
+    nrm[(size_t)i * 3] = v[0]; nrm[(size_t)i * 3 + 1] = v[1]; nrm[(size_t)i * 3 + 2] = v[2];
+  }
+  if ((rc = join_source(c))) return rc;
+  if ((rc = ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->scratch.p, nrm.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  rgck::sort3(c->stream, (const double*)c->scratch.p, (const float4*)cl.P.p, n, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
+  if (is_target) {
+    if (cl.grid.sub == 2)
+      rgck::voxel_build_h(c->stream, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
+                          cl.grid, (int)(n < cl.vgrid.ncell ? n : cl.vgrid.ncell), c->d_small + 7, (const int*)cl.vox_cell.p, (double*)cl.vox.p);
+    else
+      rgck::voxel_build(c->stream, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
+                        cl.grid, n, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p);
+    c->tgt_generation++;   // borrowers of this target must share again
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // (the host vector goes out of scope)
+  HIPCHK(c, hipGetLastError());
+  c->corr_valid = false;
+  return RGC_OK;
+}
+int rgc_set_source_covariances(rgc_ctx* c, const double* cov9, int n) { return c ? set_covs(c, c->src, false, cov9, n) : RGC_ERR_INVALID; }
+int rgc_set_target_covariances(rgc_ctx* c, const double* cov9, int n) { return c ? set_covs(c, c->tgt, true, cov9, n) : RGC_ERR_INVALID; }
+
+// pcl::Registration / FastGICP::clearSource, clearTarget (fast_gicp_impl.hpp:60-69): the cloud and its covariances are dropped
+int rgc_clear_source(rgc_ctx* c) {
+  if (!c) return RGC_ERR_INVALID;
+  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  c->src.ready = false; c->src.n = 0; c->corr_valid = false; c->deferred_known = false;
+  return RGC_OK;
+}
+int rgc_clear_target(rgc_ctx* c) {
+  if (!c) return RGC_ERR_INVALID;
+  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  c->tgt.ready = false; c->tgt.n = 0; c->corr_valid = false; c->deferred_known = false; c->map_bound = false;
+  return RGC_OK;
+}
+
+// FastVGICP::swapSourceAndTarget (fast_vgicp_impl.hpp:46-53): the clouds change roles; the voxel map is rebuilt.  Each cloud is
+// prepared again in its new role (the source's search grid is not the voxel grid): the covariances are the same function of the cloud.
+int rgc_swap_source_and_target(rgc_ctx* c) {
+  if (!c) return RGC_ERR_INVALID;
+  if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
+  if (c->tgt_owner) return fail(c, RGC_ERR_INVALID, "the target is borrowed (rgc_share_target): it cannot become the source");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = validate_clouds(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::swap(c->src.in_copy, c->tgt.in_copy);
+  std::swap(c->src.in, c->tgt.in);
+  std::swap(c->src.stride_f, c->tgt.stride_f);
+  std::swap(c->src.n, c->tgt.n);
+  c->src.ready = c->tgt.ready = false;
+  c->corr_valid = false; c->deferred_known = false; c->map_bound = false;
+  if ((rc = prepare_cloud(c, c->tgt, true, /*force_bbox=*/true))) return rc;
+  if ((rc = prepare_cloud(c, c->src, false, /*force_bbox=*/true))) return rc;
+  c->stats.n_target = c->tgt.n; c->stats.target_cells = c->tgt.grid.ncell;
+  c->stats.n_source = c->src.n; c->stats.source_cells = c->src.grid.ncell;
+  return RGC_OK;
+}
+
 static int fetch_nvox(rgc_ctx* c) {
   if (c->tgt.nvox >= 0) return RGC_OK;
   HIPCHK(c, hipMemcpyAsync(c->h_small + 7, c->d_small + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -148,6 +148,7 @@ void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP,
 // ---- misc ----
 void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f);
 void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const float4* P, int n, double* out3);
+void sort3(hipStream_t s, const double* in3, const float4* P, int n, double* a, double* b, double* c);
 int  linearize_blocks(int n);
 int  fitness_blocks(int n);
 // ---- B2 / B3 / B9 (rgc_pre.hip) ----

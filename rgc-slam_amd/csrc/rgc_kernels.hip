@@ -3010,6 +3010,17 @@ __global__ void k_unsort3(const double* __restrict__ a, const double* __restrict
   out3[(size_t)i * 3 + 2] = c[s];
 }
 
+// the inverse: three values per point given in the caller's order go to the sorted positions (setSource/TargetCovariances)
+__global__ void k_sort3(const double* __restrict__ in3, const float4* __restrict__ P, int n, double* __restrict__ a, double* __restrict__ b,
+                        double* __restrict__ c) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int i = __float_as_int(P[s].w);
+  a[s] = in3[(size_t)i * 3 + 0];
+  b[s] = in3[(size_t)i * 3 + 1];
+  c[s] = in3[(size_t)i * 3 + 2];
+}
+
 // First LM try of an outer iteration on the device (one lane): lsq_registration_impl.hpp:130-143.
 // acc = the 28 folded doubles of linearize; out layout (doubles): [28] ncorr, [32..37] d, [38..53] xi (row-major 4x4),
 // [54] lambda used, [55] 1 if the solve succeeded.
@@ -3510,6 +3521,9 @@ void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T,
 }
 void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const float4* P, int n, double* out3) {
   hipLaunchKernelGGL(k_unsort3, dim3(nblk(n, 256)), dim3(256), 0, s, a, b, c, P, n, out3);
+}
+void sort3(hipStream_t s, const double* in3, const float4* P, int n, double* a, double* b, double* c) {
+  hipLaunchKernelGGL(k_sort3, dim3(nblk(n, 256)), dim3(256), 0, s, in3, P, n, a, b, c);
 }
 
 }  // namespace rgck

@@ -261,6 +261,24 @@ class FastVGICP:
         self._chk(self._L.rgc_get_target_covariances(self._h, cov.ctypes.data_as(C.POINTER(C.c_double)), None))
         return cov
 
+    def setSourceCovariances(self, cov):             # fast_gicp_impl.hpp:93-95 (plane-regularised covariances only, see rgc_hip.h)
+        c = np.ascontiguousarray(cov, dtype=np.float64).reshape(-1, 9)
+        self._chk(self._L.rgc_set_source_covariances(self._h, c.ctypes.data_as(C.POINTER(C.c_double)), c.shape[0]))
+
+    def setTargetCovariances(self, cov):             # fast_gicp_impl.hpp:98-100
+        c = np.ascontiguousarray(cov, dtype=np.float64).reshape(-1, 9)
+        self._chk(self._L.rgc_set_target_covariances(self._h, c.ctypes.data_as(C.POINTER(C.c_double)), c.shape[0]))
+
+    def swapSourceAndTarget(self):                   # fast_vgicp_impl.hpp:46-53
+        self._chk(self._L.rgc_swap_source_and_target(self._h))
+        self._n_src, self._n_tgt = self._n_tgt, self._n_src
+
+    def clearSource(self):                           # fast_gicp_impl.hpp:60-63
+        self._chk(self._L.rgc_clear_source(self._h))
+
+    def clearTarget(self):                           # fast_gicp_impl.hpp:66-69
+        self._chk(self._L.rgc_clear_target(self._h))
+
     def getSourceNormals(self):
         n = np.empty((self._n_src, 3))
         self._chk(self._L.rgc_get_source_covariances(self._h, None, n.ctypes.data_as(C.POINTER(C.c_double))))

@@ -49,6 +49,30 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 16; i++) printf(" %.9g", T.m[i]);
     printf("\nfitness %.17g\nconverged %d iterations %d aligned %zu first %.9g %.9g %.9g\n", score, (int)vgicp.hasConverged(),
            vgicp.iterations(), aligned.points.size(), aligned.points[0].x, aligned.points[0].y, aligned.points[0].z);
+    // fast_gicp.hpp:55-61 -- the rest of the coarse interface: covariances handed back in, roles swapped twice, clouds dropped
+    const float* Tf = vgicp.getFinalTransformation();
+    float T1[16];
+    for (int i = 0; i < 16; i++) T1[i] = Tf[i];
+    vgicp.setRegularizationMethod(rgc::RegularizationMethod::PLANE);
+    vgicp.setVoxelAccumulationMode(rgc::VoxelAccumulationMode::ADDITIVE);
+    vgicp.setSourceCovariances(vgicp.getSourceCovariances());
+    vgicp.setTargetCovariances(vgicp.getTargetCovariances());
+    vgicp.align(aligned, T2);
+    int same = 1;
+    for (int i = 0; i < 16; i++) same &= vgicp.getFinalTransformation()[i] == T1[i];
+    vgicp.swapSourceAndTarget();
+    vgicp.swapSourceAndTarget();
+    vgicp.align(aligned, T2);
+    for (int i = 0; i < 16; i++) same &= vgicp.getFinalTransformation()[i] == T1[i];
+    int refused = 0;
+    try { std::vector<double> bad((size_t)source->points.size() * 9, 0.25); vgicp.setSourceCovariances(bad); } catch (const std::exception&) { refused++; }
+    try { vgicp.setRegularizationMethod(rgc::RegularizationMethod::FROBENIUS); } catch (const std::exception&) { refused++; }
+    vgicp.clearSource();
+    try { vgicp.align(aligned, T2); } catch (const std::exception&) { refused++; }
+    vgicp.setInputSource(source);
+    vgicp.clearTarget();
+    try { vgicp.align(aligned, T2); } catch (const std::exception&) { refused++; }
+    printf("leftovers same %d refused %d\n", same, refused);
   } catch (const std::exception& e) {
     printf("EXCEPTION %s\n", e.what());
     return 1;

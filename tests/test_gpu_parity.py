@@ -338,6 +338,48 @@ def test_cpp_adaptor(reg_mod, fx_reg, tmp_path):
     assert np.abs(T - fx_reg["final_T"]).max() < 1e-6, out
     assert abs(float(lines["fitness"]) - fx_reg["fitness"]) <= 1e-5 * fx_reg["fitness"]
     assert lines["converged"].startswith("1")
+    # setSource/TargetCovariances with the path's own covariances and two role swaps change nothing; a non-plane covariance, another
+    # regularisation, an align() after clearSource / clearTarget are refused (fast_gicp.hpp:55-61)
+    assert lines["leftovers"] == "same 1 refused 4", out
+
+
+def test_swap_clear_and_caller_covariances(reg_mod, orc, medium):
+    """FastVGICP::swapSourceAndTarget (fast_vgicp_impl.hpp:46-53), clearSource / clearTarget and setSource / setTargetCovariances
+    (fast_gicp_impl.hpp:60-69, 93-100) through the C-ABI: after a swap the registration is that of a fresh object with the clouds the
+    other way round; covariances handed in replace the computed ones (plane-regularised form only)."""
+    a = _odo(reg_mod)
+    a.setInputTarget(medium["src"])
+    a.setInputSource(medium["tgt"][:20000])
+    a.swapSourceAndTarget()
+    b = _odo(reg_mod)
+    b.setInputTarget(medium["tgt"][:20000])
+    b.setInputSource(medium["src"])
+    assert np.array_equal(a.getTargetCovariances(), b.getTargetCovariances()) and np.array_equal(a.getSourceCovariances(), b.getSourceCovariances())
+    g = np.eye(4, dtype=np.float32)
+    a.align(g, want_output=False); b.align(g, want_output=False)
+    assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())
+    # the oracle's covariances of the source, handed in: the same solve to rounding
+    ocov, _ = orc.covariances(medium["src"], k=20)
+    b.setSourceCovariances(ocov)
+    assert np.abs(b.getSourceCovariances() - ocov).max() <= 1e-9
+    b.align(g, want_output=False)
+    assert np.abs(b.getFinalTransformation() - a.getFinalTransformation()).max() <= 1e-6
+    # every target covariance replaced by the horizontal plane's: the voxel map follows
+    flat = np.tile(np.diag([1.0, 1.0, 1e-3]), (20000, 1, 1))
+    b.setTargetCovariances(flat)
+    assert np.abs(b.getVoxels()["cov"] - np.diag([1.0, 1.0, 1e-3])).max() <= 1e-12
+    with pytest.raises(reg_mod.RgcError):
+        b.setSourceCovariances(np.tile(np.eye(3) * 0.5, (len(medium["src"]), 1, 1)))   # not of the plane form
+    with pytest.raises(reg_mod.RgcError):
+        b.setTargetCovariances(flat[:10])                                             # wrong count
+    b.clearSource()
+    with pytest.raises(reg_mod.RgcError):
+        b.align(g, want_output=False)
+    b.setInputSource(medium["src"])
+    b.clearTarget()
+    with pytest.raises(reg_mod.RgcError):
+        b.align(g, want_output=False)
+    a.close(); b.close()
 
 
 def test_speculative_grid_hit_miss_and_late_errors(reg_mod, medium):
