@@ -164,7 +164,8 @@ class DependentSequence:
                 self.frame_source(first + j, cur, from_host)
             cur.align_begin(g, True)
             if overlap and j + 1 < count:
-                self.frame_source(first + j + 1, v[(j + 1) % D], from_host)   # under this frame's map preparation and solve
+                v[(j + 1) % D].holdSourceUntilTargetOf(cur)                   # ... held back until this frame's map is ready:
+                self.frame_source(first + j + 1, v[(j + 1) % D], from_host)   # the next scan is prepared under this frame's SOLVE
             T = cur.align_end()
             if from_host and self.d_aligned is not None:
                 cur.alignedToDevice(self.d_aligned[id(cur)], 16)              # pcl::transformPointCloud(*input_, output, final), left on the device

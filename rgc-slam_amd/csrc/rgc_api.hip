@@ -150,6 +150,8 @@ struct rgc_ctx {
   const rgc_ctx* tgt_owner = nullptr;      // rgc_share_target: whose target this context aliases, and at which generation
   unsigned long long tgt_owner_gen = 0, tgt_owner_uid = 0;
   unsigned long long uid = 0;              // process-wide, never re-used
+  hipEvent_t src_hold = nullptr;           // rgc_hold_source_until_target_of: recorded on ANOTHER context's main stream; the next source preparation waits for it
+  bool src_hold_pending = false;
   hipEvent_t src_read_done = nullptr;      // recorded on the main stream behind a kernel that reads the source's INPUT buffer (rgc_get_aligned*)
   bool src_read_pending = false;           // ... and not yet waited for by the stream a host source is copied on
   float map_leaf = 0.f;
@@ -321,6 +323,10 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   }
   if (is_target) c->main_has_target_prep = true;
   else if (c->mark_valid) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->main_mark, 0));
+  if (!is_target && c->src_hold_pending) {  // rgc_hold_source_until_target_of: this scan's small kernels start when the other context's map is ready
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->src_hold, 0));
+    c->src_hold_pending = false;
+  }
   {
     ProfScope ps(c, RGC_K_GRID, n, s);
     // bbox accumulators + flag; the map's copy also zeroes [7], its voxel counter ([8] ncorr stays untouched; the scan's
@@ -475,13 +481,17 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
                    (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r);
   }
-  {
+  // The map's deferred queries (~100 of a million, one wave each: 20 us of latency) are resolved in the SAME launch as the voxel map's
+  // build (k_voxel_build_coop); the few voxels that hold one are recomputed behind it (k_voxel_patch).  The scan has no voxel map, the
+  // half-size layout keeps its own voxel kernel: their chains stay serial.
+  const bool coop_beside = is_target && cl.grid.sub == 1;
+  // grid of the cooperative launch: twice the deferred count of the previous cloud prepared here (consecutive clouds of a sequence
+  // defer about the same queries), n / 64 for the first one
+  const int coop_waves = cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 32 : n / 64 + 32;
+  if (!coop_beside) {
     ProfScope ps(c, is_target ? RGC_K_KNN_COOP : RGC_K_KNN_COOP_SRC, n, s);
-    // grid of the cooperative launch: twice the deferred count of the previous cloud prepared here (consecutive clouds of a sequence
-    // defer about the same queries), n / 64 for the first one
-    const int waves = cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 32 : n / 64 + 32;
     rgck::knn_coop(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p,
-                   (double*)cl.ny.p, (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, waves);
+                   (double*)cl.ny.p, (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves);
   }
   if (is_target) {
     int rc;
@@ -493,8 +503,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       rgck::voxel_build_h(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p,
                           (const int*)cl.start.p, cl.grid, (int)vmax, c->d_small + 7, (const int*)cl.vox_cell.p, (double*)cl.vox.p);
     else
-      rgck::voxel_build(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p,
-                        (const int*)cl.start.p, cl.grid, n, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p);
+    {
+      rgck::voxel_build_coop(s, (const float4*)cl.P.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p, (const int*)cl.start.p, cl.grid, n,
+                             (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves);
+      rgck::voxel_patch(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
+                        cl.grid, cl.segs.p, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 64 : n);
+    }
     cl.nvox = -1;  // fetched lazily
   }
   HIPCHK(c, hipGetLastError());
@@ -1062,6 +1076,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
   c->uid = g_next_uid.fetch_add(1);
   ok = ok && hipEventCreateWithFlags(&c->src_read_done, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->src_hold, hipEventDisableTiming) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
   if (const char* e = getenv("RGC_FE_SPEC")) c->fe_spec_on = atoi(e) != 0;
@@ -1109,6 +1124,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->main_mark) (void)hipEventDestroy(c->main_mark);
   if (c->tgt_ready) (void)hipEventDestroy(c->tgt_ready);
   if (c->src_read_done) (void)hipEventDestroy(c->src_read_done);
+  if (c->src_hold) (void)hipEventDestroy(c->src_hold);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
@@ -1181,6 +1197,19 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
   c->deferred_known = false;
   c->main_has_target_prep = false;
   c->stats.n_target = o.n; c->stats.target_cells = o.grid.ncell; c->stats.n_voxels = o.nvox;
+  return RGC_OK;
+}
+
+// Two contexts taking turns on a DEPENDENT sequence (each frame's target is a function of the previous pose, RGC_odometer.cpp:1248-1256):
+// the next scan can be prepared ahead -- it depends on no pose -- but enqueued beside the current frame's map preparation its small
+// kernels share the chip with the 15 k-wave kNN launch the frame is waiting for (207 us instead of 155).  Held back until that
+// preparation is done, they run under the current frame's SOLVE, a chain of short launches that leaves the chip mostly idle.
+int rgc_hold_source_until_target_of(rgc_ctx* c, rgc_ctx* other) {
+  if (!c || !other) return RGC_ERR_INVALID;
+  if (c->device != other->device) return fail(c, RGC_ERR_INVALID, "rgc_hold_source_until_target_of: the contexts are on different devices");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->src_hold, other->stream));   // behind everything enqueued on the other context's main stream so far
+  c->src_hold_pending = true;
   return RGC_OK;
 }
 

@@ -107,6 +107,13 @@ void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, 
 // ---- C3: Gaussian voxel map ----
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int n, const int* cell_voxel, double* vox, int* vox_cell);
+// voxel_build and knn_coop (target) in one launch, followed by voxel_patch: see k_voxel_build_coop
+void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves);
+// the voxels that hold a deferred query, recomputed (sub = 1 layout): lets the cooperative search run BESIDE voxel_build; lanes: about
+// the number of deferred queries (grid-stride loop)
+void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g, const void* deferred,
+                 const int* cell_voxel, double* vox, int lanes);
 // the same from a half-size search grid (g.sub == 2, k <= 20 only in knn_bulk): one lane per voxel id < *nvox (launch sized by max_vox);
 // vox_cell from scan_cells
 void voxel_build_h(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,

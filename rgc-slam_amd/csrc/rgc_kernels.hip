@@ -707,7 +707,7 @@ __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3],
   }
 }
 
-constexpr int KNN_T = 256;
+constexpr int KNN_T = 256;  // (64- and 128-thread workgroups: the same launch time, round 3)
 #ifndef RGC_XCD_RUN
 #define RGC_XCD_RUN 16
 #endif
@@ -1971,16 +1971,11 @@ __device__ __forceinline__ unsigned coop_kth(const float4* __restrict__ P, const
 // One-wave workgroups: the launch runs beside other kernels of the frame (the map's bulk launch fills every CU), and a single wave is
 // admitted wherever one SIMD has a slot; the grid is sized by the caller from the previous cloud's deferred count (idle workgroups
 // still have to be dispatched: 2048 four-wave workgroups cost 0.25 ms of the scan's critical path when 200 queries were waiting).
+// (the body: wave `wave` of `nwaves` takes every nwaves-th entry of the deferred list; sh: this wave's LDS scratch)
 template <int KC, bool kTarget>
-__global__ void __launch_bounds__(WAVE)
-k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int k, Deferred df, double* __restrict__ nx,
-           double* __restrict__ ny, double* __restrict__ nz) {
-  __shared__ CoopRows shm[1];
-  wave_prio(!kTarget);
-  if (df.guard && *df.guard) return;
-  const int lane = threadIdx.x;
-  CoopRows* sh = &shm[0];
-  const int wave = blockIdx.x, nwaves = gridDim.x;
+__device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, const Deferred& df,
+                                         double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz, CoopRows* sh, int lane,
+                                         int wave, int nwaves) {
   const int cnt = *df.cnt;
   for (int e = wave; e < cnt; e += nwaves) {
 #ifdef RGC_LAB
@@ -2089,6 +2084,16 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
   }
 }
 
+template <int KC, bool kTarget>
+__global__ void __launch_bounds__(WAVE)
+k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int k, Deferred df, double* __restrict__ nx,
+           double* __restrict__ ny, double* __restrict__ nz) {
+  __shared__ CoopRows shm[1];
+  wave_prio(!kTarget);
+  if (df.guard && *df.guard) return;
+  coop_run<KC, kTarget>(P, start, g, k, df, nx, ny, nz, &shm[0], (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // C3  Gaussian voxel map (ADDITIVE), fast_vgicp_voxel.hpp:112-121,129-156.  record = { mean xyz, cov00 01 02 11 12 22,
 // num } (10 doubles), C_i = I - 0.999 n_i n_i^T.
@@ -2100,12 +2105,11 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
 // point.)  The voxel id of a cell comes from the cell scan (cell_voxel, -1 for empty cells).
 // ------------------------------------------------------------------------------------------------
 constexpr int VOX_T = 256;
-__global__ void __launch_bounds__(VOX_T)
-k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
-              const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
-              int* __restrict__ vox_cell) {
-  __shared__ double sh[9][VOX_T];
-  const int b0 = blockIdx.x * VOX_T, bend = min(b0 + VOX_T, n);
+__device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
+                                                  const double* __restrict__ nz, const int* __restrict__ start, const Grid& g, int n,
+                                                  const int* __restrict__ cell_voxel, double* __restrict__ vox, int* __restrict__ vox_cell,
+                                                  double (*sh)[VOX_T], int block) {
+  const int b0 = block * VOX_T, bend = min(b0 + VOX_T, n);
   const int s = b0 + threadIdx.x;
   int c = 0, s1 = 0;
   bool head = false;
@@ -2157,6 +2161,67 @@ k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const
 #pragma unroll
   for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
   rec[9] = num;
+}
+__global__ void __launch_bounds__(VOX_T)
+k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
+              const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
+              int* __restrict__ vox_cell) {
+  __shared__ double sh[9][VOX_T];
+  voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x);
+}
+// k_voxel_build and the map's cooperative kNN kernel in ONE launch: the FIRST nb_coop workgroups resolve the deferred queries -- four waves
+// each, a wave per query; first, because workgroups are dispatched in order and a query is 20 us of latency -- the workgroups behind them
+// build the voxel map (from the normals the bulk kernel wrote) at the same time.  The voxels that hold a deferred query are recomputed
+// afterwards (k_voxel_patch).  Two streams and events did the same 20 us SLOWER than the serial chain (a cross-stream dependency costs
+// ~10 us here); one launch has no such hop.
+template <int KC>
+__global__ void __launch_bounds__(VOX_T)
+k_voxel_build_coop(const float4* __restrict__ P, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz,
+                   const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
+                   int* __restrict__ vox_cell, int nb_coop, int k, Deferred df) {
+  __shared__ double sh[9][VOX_T];
+  __shared__ CoopRows shm[VOX_T / WAVE];
+  if ((int)blockIdx.x >= nb_coop) {
+    voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x - nb_coop);
+    return;
+  }
+  if (df.guard && *df.guard) return;
+  const int w = (int)threadIdx.x / WAVE;
+  coop_run<KC, true>(P, start, g, k, df, nx, ny, nz, &shm[w], (int)threadIdx.x & (WAVE - 1), (int)blockIdx.x * (VOX_T / WAVE) + w,
+                     nb_coop * (VOX_T / WAVE));
+}
+
+// The voxels of the DEFERRED queries once more.  The cooperative search (one wave per deferred query: ~100 of a million, 20 us of
+// latency) runs beside the voxel map's build in the same launch (k_voxel_build_coop) instead of in front of it; the voxel records
+// computed meanwhile from those points' stale normals are recomputed here, behind it -- the same sums in the same order (ascending
+// sorted position = the cloud's order), so the table is bit for bit what the serial chain gave.  Several deferred queries of one
+// voxel write the same values.
+__global__ void __launch_bounds__(WAVE)
+k_voxel_patch(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
+              const int* __restrict__ start, Grid g, const int* __restrict__ deferred, const int* __restrict__ cell_voxel, double* __restrict__ vox) {
+  const int cnt = deferred[0];
+  const int* idx = deferred + 16;
+  for (int e = blockIdx.x * WAVE + threadIdx.x; e < cnt; e += gridDim.x * WAVE) {
+    const int enc = idx[e];
+    const int i = enc < 0 ? ~enc : enc;
+    const float4 cp = P[i];
+    const int c = cell_index(g, cell_coord(cp.x, g) - g.minc[0], cell_coord(cp.y, g) - g.minc[1], cell_coord(cp.z, g) - g.minc[2]);
+    const int s0 = start[c], s1 = start[c + 1];
+    double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
+    for (int u = s0; u < s1; u++) {
+      const float4 p0 = P[u];
+      const double a = nx[u], b = ny[u], d = nz[u];
+      m[0] += (double)p0.x; m[1] += (double)p0.y; m[2] += (double)p0.z;
+      C[0] += 1.0 - 0.999 * a * a; C[1] += -0.999 * a * b; C[2] += -0.999 * a * d;
+      C[3] += 1.0 - 0.999 * b * b; C[4] += -0.999 * b * d; C[5] += 1.0 - 0.999 * d * d;
+    }
+    const double num = (double)(s1 - s0);
+    double* rec = vox + (size_t)cell_voxel[c] * kVoxRec;
+    rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
+#pragma unroll
+    for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
+    rec[9] = num;
+  }
 }
 
 // The same voxel map from the half-size search grid (Grid::sub == 2): a voxel's points are no longer one contiguous run of the
@@ -3469,6 +3534,20 @@ void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, 
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int n, const int* cell_voxel, double* vox, int* vox_cell) {
   hipLaunchKernelGGL(k_voxel_build, dim3(nblk(n, VOX_T)), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell);
+}
+void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves) {
+  Deferred df = deferred_of(deferred, n);
+  df.guard = guard;
+  const int nbv = nblk(n, VOX_T);
+  const int nbc = nblk(waves < 32 ? 32 : (waves > 8192 ? 8192 : waves), VOX_T / WAVE);
+  if (k <= 20) hipLaunchKernelGGL((k_voxel_build_coop<20>), dim3(nbv + nbc), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, nbc, k, df);
+  else hipLaunchKernelGGL((k_voxel_build_coop<32>), dim3(nbv + nbc), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, nbc, k, df);
+}
+void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g, const void* deferred,
+                 const int* cell_voxel, double* vox, int lanes) {
+  const int nb = lanes < 64 ? 1 : (lanes > 65536 ? 1024 : nblk(lanes, WAVE));
+  hipLaunchKernelGGL(k_voxel_patch, dim3(nb), dim3(WAVE), 0, s, P, nx, ny, nz, start, g, (const int*)deferred, cell_voxel, vox);
 }
 void voxel_build_h(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                    int max_vox, const int* nvox, const int* vox_cell, double* vox) {

@@ -158,6 +158,10 @@ class FastVGICP:
         self._chk(self._L.rgc_share_target(self._h, owner._h))
         self._n_tgt = getattr(owner, "_n_tgt", None)
 
+    def holdSourceUntilTargetOf(self, other: "FastVGICP"):
+        """the next setInputSource* here starts on the GPU when `other`'s target preparation (as enqueued so far) is done (rgc_hip.h)"""
+        self._chk(self._L.rgc_hold_source_until_target_of(self._h, other._h))
+
     def align_begin(self, guess=None, want_fitness=False):
         """First half of align(): enqueue the solve and return (rgc_align_begin).  align_end() collects the result; in between the
         caller may prepare the next frame on ANOTHER FastVGICP (PipelinedVGICP below does)."""

@@ -37,7 +37,9 @@ for overlap in (False, True, False, True):
         if not overlap: seq.frame_source(1 + j, cur)
         t4 = T(); cur.align_begin(g, True)
         t5 = T()
-        if overlap and j + 1 < K: seq.frame_source(2 + j, vv[(j + 1) % 2])
+        if overlap and j + 1 < K:
+            if os.environ.get("RGC_EXP_HOLD", "1") == "1": vv[(j + 1) % 2].holdSourceUntilTargetOf(cur)
+            seq.frame_source(2 + j, vv[(j + 1) % 2])
         t6 = T(); Tm = cur.align_end()
         t7 = T(); Tw = Tw @ Tm.astype(np.float64); g = Tm
         rows.append([t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6, T() - t7])
