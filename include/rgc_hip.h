@@ -144,8 +144,8 @@ RGC_API int rgc_get_aligned_device(rgc_ctx* ctx, const float T[16], float* d_out
 
 /* Scheduling hint for two contexts taking turns on a dependent sequence -- every frame's target is the sub-map re-framed by the previous
  * pose (src/RGC_odometer.cpp:1248-1256), so only the NEXT scan can be prepared ahead: the next rgc_set_source* on ctx starts on the
- * GPU only when everything enqueued on other's main stream up to this call (its target preparation) has finished, i.e. under
- * other's solve instead of beside its map's kNN launch.  Results are unaffected. */
+ * GPU only when the target preparation other has enqueued last (rgc_set_target*) has finished, i.e. under other's solve instead of
+ * beside its map's kNN launch.  Results are unaffected. */
 RGC_API int rgc_hold_source_until_target_of(rgc_ctx* ctx, rgc_ctx* other);
 
 /* getSourceCovariances / getTargetCovariances analogue (fast_gicp.hpp): PLANE-regularised 3x3 covariances

@@ -105,11 +105,17 @@ struct rgc_ctx {
   DevBuf mr_feat[4], mr_fac[4], mr_partials, mr_small;
   bool deferred_known = false;  // stats.deferred_* are those of the current clouds (carried home by the last align)
   DevBuf fit_partials;        // fitness rows when it is chained behind the LM slots
-  rgck::LmState* h_lm = nullptr;  // pinned mirror
+  rgck::LmState* h_lm = nullptr;  // pinned mirror (the stream-ordered copy behind every batch of LM launches)
+  rgck::LmState* h_post = nullptr; // mapped host memory the DEVICE writes a finished solve's state into, then the solve's number into its `gen`
+  rgck::LmState* d_post = nullptr; // ... its device address
+  int lm_seq = 0;                  // number of the pending solve (1, 2, ...)
+  bool post_on = true;             // RGC_LM_POST=0: always wait for the stream and its copy, as in round 2
   struct { bool active = false; bool want_fitness = false; float guess[16]; } pend;  // rgc_align_begin .. rgc_align_end
   int lm_last_outer = 0;      // outer iterations of the previous solve: sizes the next blind batch
   bool small_copy_always = false;  // RGC_SMALL_COPY=1: the 32-byte copy in front of every preparation, as before (A/B knob)
   bool small_clean[2] = {false, false};  // d_small block of the map / the scan holds its initial image (the last solve's first step restored it)
+  hipStream_t solve_stream = nullptr;  // where the pending solve was enqueued (rgc_align_begin)
+  bool solve_behind_map = true;  // RGC_SOLVE_BEHIND_MAP=0: the solve always on the scan's (high-priority) stream, as in round 2
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
   double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
@@ -150,8 +156,7 @@ struct rgc_ctx {
   const rgc_ctx* tgt_owner = nullptr;      // rgc_share_target: whose target this context aliases, and at which generation
   unsigned long long tgt_owner_gen = 0, tgt_owner_uid = 0;
   unsigned long long uid = 0;              // process-wide, never re-used
-  hipEvent_t src_hold = nullptr;           // rgc_hold_source_until_target_of: recorded on ANOTHER context's main stream; the next source preparation waits for it
-  bool src_hold_pending = false;
+  hipEvent_t tgt_prepared = nullptr;       // recorded on the main stream behind every target preparation (rgc_hold_source_until_target_of of another context waits for it)
   hipEvent_t src_read_done = nullptr;      // recorded on the main stream behind a kernel that reads the source's INPUT buffer (rgc_get_aligned*)
   bool src_read_pending = false;           // ... and not yet waited for by the stream a host source is copied on
   float map_leaf = 0.f;
@@ -323,10 +328,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   }
   if (is_target) c->main_has_target_prep = true;
   else if (c->mark_valid) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->main_mark, 0));
-  if (!is_target && c->src_hold_pending) {  // rgc_hold_source_until_target_of: this scan's small kernels start when the other context's map is ready
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->src_hold, 0));
-    c->src_hold_pending = false;
-  }
+
   {
     ProfScope ps(c, RGC_K_GRID, n, s);
     // bbox accumulators + flag; the map's copy also zeroes [7], its voxel counter ([8] ncorr stays untouched; the scan's
@@ -515,6 +517,8 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   if (!is_target) {
     HIPCHK(c, hipEventRecord(c->src_ready, s));
     c->src_pending = true;
+  } else {
+    HIPCHK(c, hipEventRecord(c->tgt_prepared, s));
   }
   cl.ready = true;
   return RGC_OK;
@@ -1074,13 +1078,20 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_lm, sizeof(rgck::LmState), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->h_post, sizeof(rgck::LmState), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+  if (ok) {
+    memset(c->h_post, 0, sizeof(rgck::LmState));
+    if (hipHostGetDevicePointer((void**)&c->d_post, c->h_post, 0) != hipSuccess) c->d_post = nullptr;  // (no fast path then)
+  }
+  if (const char* e = getenv("RGC_LM_POST")) c->post_on = atoi(e) != 0;
   c->uid = g_next_uid.fetch_add(1);
   ok = ok && hipEventCreateWithFlags(&c->src_read_done, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->src_hold, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->tgt_prepared, hipEventDisableTiming) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
   if (const char* e = getenv("RGC_FE_SPEC")) c->fe_spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_MAP_HALF")) c->map_half = atoi(e) != 0;
+  if (const char* e = getenv("RGC_SOLVE_BEHIND_MAP")) c->solve_behind_map = atoi(e) != 0;
   if (const char* e = getenv("RGC_MAP_WIDE_R")) { const int v = atoi(e); if (v == 0 || v == 2) c->map_wide_r = v; }
   if (const char* e = getenv("RGC_MAP_WIDE")) { const double v = atof(e); if (v >= 0.0 && std::isfinite(v)) c->map_wide_density = v; }
   if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
@@ -1116,6 +1127,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->h_lm) (void)hipHostFree(c->h_lm);
+  if (c->h_post) (void)hipHostFree(c->h_post);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   release(c->lm_state);
   release(c->fit_partials);
@@ -1124,7 +1136,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->main_mark) (void)hipEventDestroy(c->main_mark);
   if (c->tgt_ready) (void)hipEventDestroy(c->tgt_ready);
   if (c->src_read_done) (void)hipEventDestroy(c->src_read_done);
-  if (c->src_hold) (void)hipEventDestroy(c->src_hold);
+  if (c->tgt_prepared) (void)hipEventDestroy(c->tgt_prepared);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
@@ -1208,8 +1220,8 @@ int rgc_hold_source_until_target_of(rgc_ctx* c, rgc_ctx* other) {
   if (!c || !other) return RGC_ERR_INVALID;
   if (c->device != other->device) return fail(c, RGC_ERR_INVALID, "rgc_hold_source_until_target_of: the contexts are on different devices");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipEventRecord(c->src_hold, other->stream));   // behind everything enqueued on the other context's main stream so far
-  c->src_hold_pending = true;
+  // the scan's stream waits for the end of other's latest target preparation (a wait on an event nobody recorded yet is no wait)
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, other->tgt_prepared, 0));
   return RGC_OK;
 }
 
@@ -1236,21 +1248,23 @@ int rgc_num_correspondences(rgc_ctx* c, int* n) {
 // enqueued, not waited for.
 static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, bool want_fitness) {
   const int n = c->src.n, noff = noff_of(c->prm.neighbor_method);
-  hipStream_t s = c->stream2;  // see rgc_align_begin
+  hipStream_t s = c->solve_stream;  // see rgc_align_begin
+  rgck::LmState* post = (c->post_on && c->d_post) ? c->d_post : nullptr;
+  const int seq = want_fitness ? -c->lm_seq : c->lm_seq;  // who posts the finished state: the fitness kernel, or the deciding step
   {
     ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch, s);
     for (int k = 0; k < batch; k++) {
       rgck::lm_step(s, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
                     c->tgt.vgrid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
                     (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, open, c->d_small + 7,
-                    c->tgt.segs.p, c->src.segs.p);
+                    c->tgt.segs.p, c->src.segs.p, post, seq);
       open = nullptr;
     }
   }
   if (want_fitness) {  // getFitnessScore at the final pose, chained blindly: the kernel is a no-op unless the LM is done
     ProfScope ps(c, RGC_K_FITNESS, n, s);
     rgck::fitness_lm(s, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
-                     (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p);
+                     (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p, post, c->lm_seq);
   }
   HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, s));
   return RGC_OK;
@@ -1271,9 +1285,18 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   // behind that -- ordered after the map's preparation on the main stream by one event.  With a second context preparing the next
   // frame's map meanwhile (15 k waves that fill every CU), the dispatcher places the solve's ~100 workgroups as soon as slots free up
   // instead of behind that launch.
-  HIPCHK(c, hipEventRecord(c->tgt_ready, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->tgt_ready, 0));
   int rc;
+  if (c->solve_behind_map && c->main_has_target_prep && hipStreamQuery(c->stream) != hipSuccess) {
+    // the map is still being prepared (a dependent sequence: it could only start when the previous pose was known): the solve goes
+    // directly behind it on the main stream -- a dependency that resolves across streams costs ~10 us on this runtime, and the scan's
+    // preparation, which the solve also waits for, has long finished
+    c->solve_stream = c->stream;
+    if ((rc = join_source(c))) return rc;
+  } else {
+    c->solve_stream = c->stream2;
+    HIPCHK(c, hipEventRecord(c->tgt_ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->tgt_ready, 0));
+  }
   const rgc_params& P = c->prm;
   // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_step);
   // the host only enqueues slots and reads the state back once per batch.
@@ -1287,7 +1310,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
   if (!c->lm_state.p) {
     if ((rc = ensure(c, c->lm_state, 4096))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->stream2));  // tickets start at 0
+    HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->solve_stream));  // tickets start at 0
   }
   if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)rgck::fitness_blocks(n) + 64))) return rc;
   rgck::LmInit in;
@@ -1304,6 +1327,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   if (c->lm_last_outer + 3 > batch) batch = c->lm_last_outer + 3;
   if (batch > P.max_iterations + 1) batch = P.max_iterations + 1;
   if (batch < 2) batch = 2;
+  c->lm_seq = c->lm_seq >= 0x3fffffff ? 1 : c->lm_seq + 1;
   if ((rc = lm_enqueue_batch(c, batch, &in, want_fitness != 0))) return rc;
   memcpy(c->pend.guess, guess, sizeof(c->pend.guess));
   c->pend.want_fitness = want_fitness != 0;
@@ -1320,7 +1344,24 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
   const bool want_fitness = c->pend.want_fitness;
   rgck::LmState& S = *c->h_lm;
   for (int guard = 0;; guard++) {
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    // The device posts a finished solve's state into mapped host memory and then the solve's number: the host spins on that word and
+    // leaves as soon as it shows up -- the blind launches behind the deciding one and the stream's copy drain in the background.
+    // A batch that ends without a finished solve shows up as a drained stream: then the copy has landed and more launches are enqueued.
+    bool posted = false;
+    if (c->post_on && c->d_post) {
+      volatile int* gen = &c->h_post->gen;
+      for (;;) {
+        if (*gen == c->lm_seq) { posted = true; break; }
+        const hipError_t q = hipStreamQuery(c->solve_stream);
+        if (q == hipSuccess) { posted = *gen == c->lm_seq; break; }
+        if (q != hipErrorNotReady) return fail(c, RGC_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+      }
+      if (posted) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        memcpy(&S, c->h_post, sizeof(S));
+      }
+    }
+    if (!posted) HIPCHK(c, hipStreamSynchronize(c->solve_stream));
     HIPCHK(c, hipGetLastError());
     if (S.done || guard >= 400) break;
     // a solve that is still running after six outer iterations usually runs many more (up to 25): batches of six, fewer read-backs

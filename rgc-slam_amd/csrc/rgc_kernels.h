@@ -130,8 +130,10 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
 // one step of the device-chained LM (see k_lm_step); corr_*0 / corr_*1 are the two correspondence buffers, st->cur the valid one
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
-             const LmInit* first /* non-null: this launch opens a solve */, const int* nvox, const void* segs_t, const void* segs_s);
-void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials);
+             const LmInit* first /* non-null: this launch opens a solve */, const int* nvox, const void* segs_t, const void* segs_s,
+             LmState* h_post = nullptr /* mapped host memory: a finished state is posted there, then seq in its `gen` */, int seq = 0 /* > 0: post when done; < 0: fitness_lm posts */);
+void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials,
+                LmState* h_post = nullptr, int seq = 0);
 // ---- f1: mapping-node feature registration (RGC_mapping.cpp:1069-1358) ----
 // factor record = 8 doubles per feature: edge {a[3], b[3], var, valid}, plane {n[3], d, 0, 0, var, valid}
 struct MapregAssoc {  // one association loop: feature set (n x 4: x,y,z,weight), its pose, the map grid it is matched against

@@ -24,6 +24,7 @@
 #include "rgc_lm.h"
 
 #include <limits.h>
+#include <stddef.h>
 
 #include <type_traits>
 
@@ -2736,11 +2737,31 @@ __device__ __forceinline__ void lm_step_decide(LmState& ls, const double* folded
   LAB_TS(7);
 }
 
+// The finished solve's state goes straight into MAPPED HOST memory, followed by the solve's sequence number in `gen`: the host thread
+// spins on that word instead of waiting for the stream to drain (the blind launches enqueued behind the deciding one, the copy of
+// the state, the wake-up of a blocked hipStreamSynchronize: ~20 us at the end of every frame of a dependent sequence).
+// src: the state (LDS or device memory); every thread of the workgroup takes part; skip_fit: the fitness words are written by the caller.
+__device__ __forceinline__ void post_state_to_host(const LmState* src, LmState* __restrict__ h_post, int seq, int nthreads, bool skip_fit) {
+  constexpr int kWords = (int)(sizeof(LmState) / sizeof(int));
+  constexpr int kGen = (int)(offsetof(LmState, gen) / sizeof(int));
+  constexpr int kFit0 = (int)(offsetof(LmState, fit_sum) / sizeof(int)), kHas = (int)(offsetof(LmState, has_fit) / sizeof(int));
+  const int* sw = reinterpret_cast<const int*>(src);
+  int* hw = reinterpret_cast<int*>(h_post);
+  for (int u = threadIdx.x; u < kWords; u += nthreads) {
+    if (u == kGen || (skip_fit && (u == kFit0 || u == kFit0 + 1 || u == kHas))) continue;
+    __hip_atomic_store(&hw[u], sw[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this thread's words are on their way to the host before the barrier
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&hw[kGen], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void __launch_bounds__(LIN_T)
 k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
           const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v0, double* __restrict__ corr_M0,
           int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st, int first,
-          LmInit in, const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s) {
+          LmInit in, const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s, LmState* __restrict__ h_post,
+          int seq) {
   wave_prio(1);  // a latency chain: issue ahead of whatever throughput-bound launch shares the CU (the other context's kNN)
   // first != 0: this launch opens a solve.  Nobody reads the (stale) state: mode, buffer and pose come from the kernel
   // arguments, and the last-arriving workgroup's lane 0 writes the fresh state (:53-63) before it uses it -- no separate
@@ -2815,6 +2836,8 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     int* gw = reinterpret_cast<int*>(st);
     for (int u = threadIdx.x; u < kStateWords; u += LIN_T) gw[u] = lw[u];
   }
+  // seq > 0: no fitness score is chained behind this solve -- a finished state is the frame's result (seq < 0: the fitness kernel posts it)
+  if (h_post && seq > 0 && ls.done) post_state_to_host(&ls, h_post, seq, LIN_T, false);
 }
 
 // fold per-block rows in a fixed order: block a (one wave) owns accumulator a; lane l sums rows l, l+64, ...
@@ -3032,8 +3055,8 @@ k_fitness(const float4* __restrict__ SP, int ns, PoseF T, const float4* __restri
 // the same with the final pose taken from the device-resident LM state; the last block folds the rows into the state
 __global__ void __launch_bounds__(FIT_T)
 k_fitness_lm(const float4* __restrict__ SP, int ns, LmState* __restrict__ st, const float4* __restrict__ TP,
-             const int* __restrict__ tstart, Grid g, double* __restrict__ partials) {
-  if (!st->done) return;  // enqueued blindly behind a batch of LM slots
+             const int* __restrict__ tstart, Grid g, double* __restrict__ partials, LmState* __restrict__ h_post, int seq) {
+  if (!st->done || st->has_fit) return;  // enqueued blindly behind a batch of LM slots (and once more behind a later batch)
   wave_prio(1);
   PoseF T;
 #pragma unroll
@@ -3051,7 +3074,15 @@ k_fitness_lm(const float4* __restrict__ SP, int ns, LmState* __restrict__ st, co
     for (int u = 0; u < 8; u++) t += v8[u];
   }
   t = wave_sum(t);
-  if (threadIdx.x == 0) { st->fit_sum = t; st->has_fit = 1; }
+  if (threadIdx.x == 0) {
+    st->fit_sum = t;
+    st->has_fit = 1;
+    if (h_post) {
+      __hip_atomic_store(&h_post->fit_sum, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&h_post->has_fit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (h_post) post_state_to_host(st, h_post, seq, FIT_T, true);
 }
 
 __global__ void k_transform_f32(const float* __restrict__ in, int stride_f, int n, PoseF T, float* __restrict__ out, int ostride_f) {
@@ -3577,12 +3608,13 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
 }
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
-             const LmInit* first, const int* nvox, const void* segs_t, const void* segs_s) {
+             const LmInit* first, const int* nvox, const void* segs_t, const void* segs_s, LmState* h_post, int seq) {
   hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
-                     corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s);
+                     corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s, h_post, seq);
 }
-void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials) {
-  hipLaunchKernelGGL(k_fitness_lm, dim3(fitness_blocks(ns)), dim3(FIT_T), 0, s, SP, ns, st, TP, tstart, g, partials);
+void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials, LmState* h_post,
+                int seq) {
+  hipLaunchKernelGGL(k_fitness_lm, dim3(fitness_blocks(ns)), dim3(FIT_T), 0, s, SP, ns, st, TP, tstart, g, partials, h_post, seq);
 }
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials, double* out1) {
   const int nb = fitness_blocks(ns);

@@ -22,7 +22,7 @@ for w in pv.v:
     seq.v = [w]; seq.run(0, 1, poses[0], I4, False)
 seq.v = pv.v
 T = time.perf_counter
-for overlap in (False, True, False, True):
+for overlap in (False, True) * int(os.environ.get('RGC_EXP_PASSES', '2')):
     vv = pv.v if overlap else pv.v[:1]
     Tw, g = np.asarray(poses[0], np.float64), I4
     rows = []
