@@ -139,3 +139,34 @@ def test_cpp_node_with_imu(exe, tmp_path):
     assert len(poses_cpp) == len(raws) and int(summary["frames"]) == len(raws) - 2      # two sweeps only initialised the pose
     assert np.abs(poses_cpp - ref).max() < 1e-9, np.abs(poses_cpp - ref).max()
     assert np.linalg.norm(ref[-1, 4:7]) > 0.2
+
+
+def test_cpp_node_against_the_literal_frame_body(exe, tmp_path):
+    """rgc::OdometryNode (the frame body in the reference's language) on the ten sweeps + IMU stream of tests/golden/fx_sequence.npz: the
+    poses of oracle/py_odometer.py -- the line by line restatement of vg_ICP::ICP_thread on the CPU oracle's stages -- sweep by sweep,
+    pose deltas within 1e-4 m / 1e-4 rad."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import gen_sequence
+    fx = np.load(os.path.join(root, "tests", "golden", "fx_sequence.npz"))
+    raws, sweep_stamps, (stamps, acc, gyr) = gen_sequence.inputs()
+    path, ipath = str(tmp_path / "sweeps.bin"), str(tmp_path / "imu.bin")
+    dt = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4"), ("ring", "<u2"), ("time", "<f4")])
+    with open(path, "wb") as f:
+        f.write(np.int32(len(raws)).tobytes())
+        for r in raws:
+            rec = np.zeros(len(r), dt)
+            rec["x"], rec["y"], rec["z"], rec["intensity"] = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+            f.write(np.int32(len(r)).tobytes()); f.write(rec.tobytes())
+    with open(ipath, "wb") as f:
+        f.write(np.int32(len(stamps)).tobytes())
+        f.write(np.concatenate([stamps[:, None], acc, gyr], axis=1).astype("<f8").tobytes())
+    poses_cpp, ground, summary = _run(exe, path, False, True, imu=ipath, first_frames=2)
+    assert len(poses_cpp) == len(raws) and int(summary["frames"]) == int(np.sum(fx["produced"]))
+    q, t = poses_cpp[:, :4], poses_cpp[:, 4:7]
+    ang = lambda a, b: 2 * np.arccos(min(1.0, abs(float(np.dot(a, b)))))
+    for i in range(1, len(raws)):
+        assert np.abs((t[i] - t[i - 1]) - (fx["t"][i] - fx["t"][i - 1])).max() <= 1e-4, i
+        assert abs(ang(q[i], q[i - 1]) - ang(fx["q"][i], fx["q"][i - 1])) <= 1e-4, i
+    assert np.abs(t - fx["t"]).max() <= 5e-4 and max(ang(a, b) for a, b in zip(q, fx["q"])) <= 5e-4

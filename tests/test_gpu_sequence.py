@@ -91,3 +91,38 @@ def test_sequence_with_imu():
     # and the estimate follows the true motion from the first processed sweep on (coarse sanity, not parity)
     true = np.linalg.inv(poses[3]) @ poses[10]
     assert np.linalg.norm(og.t_w_curr - true[:3, 3]) < 0.6
+
+
+def test_sequence_against_the_literal_frame_body():
+    """The independent pin of the frame body: tests/golden/fx_sequence.npz is what oracle/py_odometer.py -- a line by
+    line restatement of vg_ICP::ICP_thread (RGC_odometer.cpp:848-1256, USE_IMU = 1, USE_GROUND = 1) that shares no code with the mirrors --
+    produced on the CPU oracle's stages.  The Python mirror on the HIP library follows it sweep by sweep: pose deltas within 1e-4 m /
+    1e-4 rad, the same ground flag, the same number of keyframes in the window, the same sub-map size."""
+    import os, sys
+    from rgc_slam_amd import odometry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import gen_sequence
+    fx = np.load(os.path.join(root, "tests", "golden", "fx_sequence.npz"))
+    raws, sweep_stamps, imu = gen_sequence.inputs()
+    assert gen_sequence.digest(raws, imu) == str(fx["inputs_sha256"])
+    hb = odometry.HipBackend(0)
+    od = odometry.Odometer(hb, use_imu=True, first_frames=2)
+    rows = []
+
+    def handle(raw, t_k):
+        r = od.process(raw, t_k)
+        rows.append((r is not None, od.q_w_curr.copy(), od.t_w_curr.copy(), od.gflag, len(od.surrounding), len(od.submap)))
+        return r
+    gen_sequence.feed(od, raws, sweep_stamps, imu, od.imu_callback, handle)
+    hb.close()
+    assert [r[0] for r in rows] == list(fx["produced"])
+    worst_t = worst_r = 0.0
+    for i in range(1, len(rows)):
+        dq_g, dq_f = _angle(rows[i][1], rows[i - 1][1]), _angle(fx["q"][i], fx["q"][i - 1])
+        worst_t = max(worst_t, float(np.abs((rows[i][2] - rows[i - 1][2]) - (fx["t"][i] - fx["t"][i - 1])).max()))
+        worst_r = max(worst_r, abs(dq_g - dq_f))
+    assert worst_t <= 1e-4 and worst_r <= 1e-4, (worst_t, worst_r)
+    assert max(_angle(r[1], q) for r, q in zip(rows, fx["q"])) <= 5e-4 and max(np.abs(r[2] - t).max() for r, t in zip(rows, fx["t"])) <= 5e-4
+    assert [r[3] for r in rows] == list(fx["gflag"]) and [r[4] for r in rows] == list(fx["keyframes"])
+    assert [r[5] for r in rows] == list(fx["submap"])     # the leaf filters' output sizes: the same clouds went in
