@@ -120,8 +120,8 @@ def world_to_body(Tw):
 
 class DependentSequence:
     """The odometer's frame loop on device-resident clouds (RGC_odometer.cpp:976-1023, 1201-1203, 1248-1256):
-    frame i: target = the local map re-expressed in the body frame of world pose i - 1 (rgc_transform_cloud on the device, then a full
-    rgc_set_target_device), source = scan i, guess = frame i - 1's motion (or a prior), result = the motion of frame i; the world
+    frame i: target = the local map re-expressed in the body frame of world pose i - 1 and rebuilt in full (rgc_set_target_reframed,
+    on the device), source = scan i, guess = frame i - 1's motion (or a prior), result = the motion of frame i; the world
     pose accumulates in fp64.  overlap: two contexts -- the next scan's preparation (it depends on no pose) is enqueued under the solve."""
 
     def __init__(self, contexts, d_map, n_map, d_scans, n_scans, pinned=None, d_aligned=None):
@@ -135,8 +135,7 @@ class DependentSequence:
 
     def frame_target(self, w, Tw_prev):
         q, t = world_to_body(Tw_prev)
-        w.transformCloudDevice(self.d_map, self.n_map, 16, q, t, self.d_body[id(w)])   # B9
-        w.setInputTargetDevice(self.d_body[id(w)], self.n_map, 16)                     # full per-frame rebuild, like the reference
+        w.setInputTargetReframed(self.d_map, self.n_map, 16, q, t, self.d_body[id(w)])   # B9 + a full per-frame rebuild, like the reference
 
     def frame_source(self, i, w, from_host=False):
         if from_host:

@@ -185,9 +185,17 @@ RGC_API int rgc_voxelgrid(rgc_ctx* ctx, const float* xyzi, int n, int stride_byt
                           int on_device);
 /* B9  vg_ICP::transformPointCloud(cloud, q, t) (src/RGC_odometer.cpp:1495-1514): q * p + t in fp64, stored fp32,
  * intensity copied; out_xyzi: n*4 floats.  on_device: both pointers are device memory and the call returns once the kernel is enqueued
- * on rgc_stream(ctx), like rgc_deskew -- a sub-map re-framed by the new pose (:1248-1256) goes straight to rgc_set_target_device. */
+ * on rgc_stream(ctx), like rgc_deskew. */
 RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, const double q_xyzw[4], const double t[3],
                                 float* out_xyzi, int on_device);
+
+/* B9 + setInputTarget in one call, for a sub-map that lives on the device (src/RGC_odometer.cpp:1248-1256 then :998-1007): d_xyzi (n
+ * points, fixed between calls) re-expressed by q * p + t into d_scratch (n*4 floats, device) and prepared as the registration's target
+ * -- grid, exact-kNN covariances, voxel map, like rgc_set_target_device -- without a host round trip: the re-framed cloud's bounding
+ * box is derived from the input's (measured on the first call with a given d_xyzi, n) and the transform.  What a dependent sequence
+ * does every frame with the pose the previous frame returned. */
+RGC_API int rgc_set_target_reframed(rgc_ctx* ctx, const float* d_xyzi, int n, int stride_bytes, const double q_xyzw[4], const double t[3],
+                                    float* d_scratch);
 
 /* ---- A1-A8  ScanRegistration::laserCloudHandler (src/scanRegistration.cpp:89-730): range/NaN filter, ring + rel-time
  * assignment, curvature stencils, ground marking + weighted-PCA ground plane, occlusion mask, per-ring 6-sector

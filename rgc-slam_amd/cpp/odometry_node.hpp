@@ -15,9 +15,12 @@
 //   resident_map = false : the reference's semantics -- keyframe deque on the host, re-framed / re-filtered / re-uploaded per frame
 //                          (:1218-1256, 985-991, 1007)
 //   resident_map = true  : SURVEY 8f row f2 -- keyframes stay on the device in a map frame, target rebuilt only on a keyframe change
-//   device_chain = true  : (with resident_map) the sweep never returns to the host between the stages: message bytes -> unpack kernel ->
-//                          front-end -> de-skew -> VoxelGrid -> setInputSource / keyframe insert all read the previous stage's DEVICE
-//                          buffer; only the message goes up and features, ground parameters and the pose come down
+//   device_chain = true  : the sweep never returns to the host between the stages: message bytes -> unpack kernel -> front-end ->
+//                          de-skew -> VoxelGrid -> setInputSource / keyframe insert all read the previous stage's DEVICE buffer; only
+//                          the message goes up and features, ground parameters and the pose come down.  With resident_map = false the
+//                          reference's keyframe window lives on the device too: every frame its (at most three) world-frame clouds are
+//                          re-expressed in the new body frame, concatenated, leaf-filtered and set as the target there (:1248-1256,
+//                          985-991, 1007) -- the reference's semantics, bit for bit the host-staged mode's poses, without its PCIe traffic
 // use_imu (launch/run.launch:18, the reference's default): imuCallback() feeds the attitude filter and the sample buffer
 //   (vg_ICP::imu_callback, :444-486); the gyro's pre-integrated rotation is the registration's guess (:883-931, 993-996) and a factor
 //   of the fusion (:1104-1119); pitch / roll are blended towards the filter's attitude (:1206-1214); the first `first_frames` sweeps
@@ -65,7 +68,7 @@ public:
     int max_keyframes = 3;                 // slipwide, RGC_odometer.cpp:299
     double evict_radius = 0.0;             // resident map only: additionally evict keyframes farther than this (0 = off)
     double rebase_distance = 50.0;         // resident map only: the map origin follows the sensor
-    bool device_chain = false;             // resident map only: keep the sweep on the device between the stages
+    bool device_chain = false;             // keep the sweep -- and, without resident_map, the reference's keyframe window and its re-framed sub-map -- on the device between the stages
     bool use_imu = false;                  // USE_IMU (launch/run.launch:18)
     int first_frames = 0;                  // firstflagnum, RGC_odometer.cpp:303 (the reference: 10)
     double init_yaw = 0.0;                 // init_yaw, :358 (degrees)
@@ -74,7 +77,6 @@ public:
   explicit OdometryNode(const Options& o) : opt_(o) {
     rgc_params p;
     rgc_default_params(&p);                // = the setters of RGC_odometer.cpp:998-1006 (resolution 1.0, 25 iterations, eps 1e-6)
-    if (o.device_chain && !o.resident_map) throw std::runtime_error("device_chain needs resident_map");
     int rc = rgc_create(o.hip_device, &p, &ctx_);
     if (rc != RGC_OK) throw std::runtime_error(std::string("rgc_create: ") + rgc_status_string(rc));
     rgc_default_fe_params(&fe_);
@@ -93,7 +95,9 @@ public:
   }
   int groundFlag() const { return gate_.gflag; }
   ~OdometryNode() {
-    for (DevBuf* b : {&d_raw_, &d_source_, &d_last_}) if (b->p) rgc_device_free(ctx_, b->p);
+    for (DevBuf* b : {&d_raw_, &d_source_, &d_last_, &d_submap_, &d_target_}) if (b->p) rgc_device_free(ctx_, b->p);
+    for (auto& k : d_kf_) if (k.p) rgc_device_free(ctx_, k.p);
+    for (auto& k : d_kf_free_) if (k.p) rgc_device_free(ctx_, k.p);
     rgc_destroy(ctx_);
   }
   OdometryNode(const OdometryNode&) = delete;
@@ -196,6 +200,12 @@ private:
         for (int a = 0; a < 3; a++) tg[a] += t_w_[a] - origin_[a];
         pose_to_mat(qg, tg, guess);
         chk(rgc_map_commit(ctx_, 0.3f, nullptr));                                              // :985-991, 1007 (only if a keyframe changed)
+      } else if (chain) {   // the reference's local map, kept on the device: the re-framed keyframes -> leaf filter -> target, no PCIe crossing
+        int n_tgt = 0;
+        reserve(d_target_, (size_t)16 * (size_t)(n_submap_ > 0 ? n_submap_ : 1));
+        chk(rgc_voxelgrid(ctx_, d_submap_.p, n_submap_, 16, 0.3f, d_target_.p, &n_tgt, 1));       // :985-991
+        pose_to_mat(q_last_curr_, t_last_curr_, guess);                                         // :993-996
+        chk(rgc_set_target_device(ctx_, d_target_.p, n_tgt, 16));                               // :1007
       } else {
         int n_tgt = 0;
         target_.resize(submap_.size());
@@ -344,6 +354,13 @@ private:
       chk(rgc_map_reset(ctx_, origin_));
       if (opt_.device_chain) chk(rgc_map_insert(ctx_, d_last_.p, n_last_, 16, I, Z, 1, nullptr));
       else chk(rgc_map_insert(ctx_, full_last_.data(), n_last_, 16, I, Z, 0, nullptr));
+    } else if (opt_.device_chain) {   // *laserCloudsubmap += *laserCloudFullLast, on the device (an identity transform is a copy)
+      DevKf kf = new_keyframe(n_last_);
+      chk(rgc_transform_cloud(ctx_, d_last_.p, n_last_, 16, I, Z, kf.p, 1));
+      d_kf_.push_back(kf);
+      reserve(d_submap_, (size_t)16 * (size_t)n_last_);
+      chk(rgc_transform_cloud(ctx_, d_last_.p, n_last_, 16, I, Z, d_submap_.p, 1));
+      n_submap_ = n_last_;
     } else {
       kf_cloud_.push_back(full_last_);
       submap_.insert(submap_.end(), full_last_.begin(), full_last_.end());
@@ -370,6 +387,10 @@ private:
           chk(opt_.device_chain ? rgc_map_insert(ctx_, d_source_.p, n_src, 16, q_w_, t_w_, 1, nullptr)
                                 : rgc_map_insert(ctx_, source_.data(), n_src, 16, q_w_, t_w_, 0, nullptr));   // :1237, once, never re-framed
           chk(rgc_map_evict(ctx_, opt_.max_keyframes, opt_.evict_radius > 0 ? t_w_ : nullptr, opt_.evict_radius, nullptr));   // :1242-1247
+        } else if (opt_.device_chain) {
+          DevKf kf = new_keyframe(n_src);
+          chk(rgc_transform_cloud(ctx_, d_source_.p, n_src, 16, q_w_, t_w_, kf.p, 1));           // :1237
+          d_kf_.push_back(kf);
         } else {
           std::vector<float> w((size_t)4 * n_src);
           chk(rgc_transform_cloud(ctx_, source_.data(), n_src, 16, q_w_, t_w_, w.data(), 0));
@@ -384,6 +405,24 @@ private:
       if (std::sqrt(ddx * ddx + ddy * ddy + ddz * ddz) > opt_.rebase_distance) {
         std::memcpy(origin_, t_w_, sizeof(origin_));
         chk(rgc_map_rebase(ctx_, origin_));
+      }
+      return;
+    }
+    if (opt_.device_chain) {   // :1241-1256 on the device: the window slides, every keyframe is re-expressed in the new body frame
+      n_submap_ = 0;
+      if ((int)d_kf_.size() > opt_.max_keyframes) { d_kf_free_.push_back(d_kf_.front()); d_kf_.pop_front(); }
+      if (d_kf_.size() > 1) {
+        const double qi[4] = {-q_w_[0], -q_w_[1], -q_w_[2], q_w_[3]};
+        double ti[3];
+        qrot(qi, t_w_, ti);
+        for (int a = 0; a < 3; a++) ti[a] = -ti[a];
+        size_t total = 0;
+        for (const auto& kf : d_kf_) total += (size_t)kf.n;
+        reserve(d_submap_, (size_t)16 * (total > 0 ? total : 1));
+        for (const auto& kf : d_kf_) {
+          chk(rgc_transform_cloud(ctx_, kf.p, kf.n, 16, qi, ti, d_submap_.p + (size_t)4 * (size_t)n_submap_, 1));
+          n_submap_ += kf.n;
+        }
       }
       return;
     }
@@ -409,6 +448,22 @@ private:
   std::vector<float> raw_, full_, full_last_, sharp_, flat_, inten_, source_, target_, submap_;
   std::deque<std::vector<float>> kf_cloud_;
   DevBuf d_raw_, d_source_, d_last_;     // device_chain: the unpacked message, the 0.2 m-filtered sweep, the previous sweep (keyframe 0)
+  // device_chain without the resident map: the reference's keyframe window (world-frame clouds) and its re-framed concatenation on the device
+  struct DevKf { float* p = nullptr; size_t cap = 0; int n = 0; };
+  std::deque<DevKf> d_kf_;
+  std::vector<DevKf> d_kf_free_;         // buffers of keyframes that left the window, re-used
+  DevBuf d_submap_, d_target_;
+  int n_submap_ = 0;
+  DevKf new_keyframe(int n) {
+    const size_t need = (size_t)16 * (size_t)(n > 0 ? n : 1);
+    for (size_t i = 0; i < d_kf_free_.size(); i++)
+      if (d_kf_free_[i].cap >= need) { DevKf k = d_kf_free_[i]; d_kf_free_.erase(d_kf_free_.begin() + (long)i); k.n = n; return k; }
+    DevKf k;
+    void* np = nullptr;
+    chk(rgc_device_alloc(ctx_, need + need / 4, &np));
+    k.p = (float*)np; k.cap = need + need / 4; k.n = n;
+    return k;
+  }
   int n_last_ = 0;
   bool have_last_ = false;
   int n_sharp_ = 0, n_flat_ = 0;

@@ -128,10 +128,10 @@ struct rgc_ctx {
   DevBuf pre_in, pre_out, vg_order, vg_pos, vg_tmp, vg_leaf;  // B2/B3/B9 staging
   struct VgBox { float leaf = 0.f; bool valid = false; rgck::LeafGrid g{}; } vg_box[4];  // measured leaf boxes of earlier clouds, by leaf size
   int vg_box_next = 0;
-  // Bounding boxes the library knows WITHOUT measuring: rgc_transform_cloud on device memory maps the input's box (measured once per
-  // input buffer) through the transform it applies -- the box of a sub-map re-framed by a new pose (RGC_odometer.cpp:1248-1256) follows
-  // from the pose.  rgc_set_target_device of such a buffer takes its grid from the hint: no bounding-box kernel, no host round trip,
-  // and no speculative-grid miss when the re-framed map's box swings with the vehicle's yaw.  k_count's guard still checks it.
+  // Bounding boxes the library knows WITHOUT measuring: rgc_set_target_reframed maps the input's box (measured once per input buffer)
+  // through the transform it applies -- the box of a sub-map re-framed by a new pose (RGC_odometer.cpp:1248-1256) follows from the
+  // pose.  The target's preparation takes its grid from the hint: no bounding-box kernel, no host round trip, and no speculative-grid
+  // miss when the re-framed map's box swings with the vehicle's yaw.  k_count's guard still checks it.
   struct BoxHint { const void* p = nullptr; int n = 0; double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; } box_hint[4];
   int box_hint_next = 0;
   bool vg_flags_clean = false;  // d_small[24 + 6] is known to be zero (a finished rows chain leaves it so)
@@ -1753,6 +1753,28 @@ int rgc_transform_cloud(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, 
     if ((rc = ensure(c, c->pre_out, sizeof(float) * 4 * (size_t)n))) return rc;
     d_out = (float*)c->pre_out.p;
   }
+  rgck::transform_q(c->stream, d_in, stride_bytes / 4, n, rgck::Quat{q[0], q[1], q[2], q[3]}, t, d_out, 4);
+  if (!on_device) HIPCHK(c, hipMemcpyAsync(out_xyzi, d_out, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  // device memory: stream-ordered like rgc_deskew; the one exception is the same as there (a pending map preparation, see rgc_deskew)
+  if (!on_device || c->main_has_target_prep) HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return RGC_OK;
+}
+
+// B9 followed by setInputTarget, in one call and without a host round trip: the sub-map (device memory, fixed between calls) re-expressed
+// by (q, t) into d_scratch and handed to the registration as its new target (RGC_odometer.cpp:1248-1256, 998, 1007).  The output's
+// bounding box follows from the input's -- measured once per input buffer (whole 1 m cells, k_bbox) -- and the transform: its eight
+// corners through q * p + t in fp64, a millimetre added for the fp32 rounding of the stored points.  rgc_set_target_device takes its grid
+// from that box: no bounding-box kernel, no read-back, and no speculative-grid miss when the re-framed map's box swings with the yaw.
+int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, const double q[4], const double t[3], float* d_scratch) {
+  if (!c || !d_xyzi || !q || !t || !d_scratch || n <= 0) return RGC_ERR_INVALID;
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
+  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  HIPCHK(c, hipSetDevice(c->device));
+  const float* xyzi = d_xyzi;
+  const float* d_in = d_xyzi;
+  float* out_xyzi = d_scratch;
+  const int on_device = 1;
   if (on_device && c->spec_on) {
     // the output's bounding box from the input's: measured once per input buffer (whole cells of 1 m, k_bbox), then the eight
     // corners through q * p + t in fp64, a millimetre added for the fp32 rounding of the stored points
@@ -1788,13 +1810,9 @@ int rgc_transform_cloud(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, 
       put_hint(c, out_xyzi, n, lo, hi);
     }
   }
-  rgck::transform_q(c->stream, d_in, stride_bytes / 4, n, rgck::Quat{q[0], q[1], q[2], q[3]}, t, d_out, 4);
-  if (!on_device) HIPCHK(c, hipMemcpyAsync(out_xyzi, d_out, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  // device memory: stream-ordered like rgc_deskew -- a sub-map re-framed here and handed to rgc_set_target_device needs no host round trip
-  // (RGC_odometer.cpp:1248-1256 followed by :998); the one exception is the same as there (a pending map preparation, see rgc_deskew)
-  if (!on_device || c->main_has_target_prep) HIPCHK(c, hipStreamSynchronize(c->stream));
+  rgck::transform_q(c->stream, d_in, stride_bytes / 4, n, rgck::Quat{q[0], q[1], q[2], q[3]}, t, d_scratch, 4);
   HIPCHK(c, hipGetLastError());
-  return RGC_OK;
+  return set_cloud(c, c->tgt, true, d_scratch, n, 16, true);
 }
 
 // The rows chain of the leaf filter on box g (rgc_pre.hip); one read-back: *flags (bits as rgck::vg_rows documents) and *n_out.

@@ -356,6 +356,15 @@ class FastVGICP:
         self._chk(self._L.rgc_transform_cloud(self._h, C.c_void_p(d_in), n, stride_bytes, q.ctypes.data_as(dp), tt.ctypes.data_as(dp),
                                               C.c_void_p(d_out), 1))
 
+    def setInputTargetReframed(self, d_map: int, n: int, stride_bytes: int, q_xyzw, t, d_scratch: int):
+        """B9 + setInputTarget on the device in one call (rgc_set_target_reframed): the sub-map at d_map re-expressed by (q, t) into
+        d_scratch and prepared as the target, its bounding box derived from the map's and the transform (RGC_odometer.cpp:1248-1256, 998-1007)"""
+        q = np.ascontiguousarray(q_xyzw, dtype=np.float64)
+        tt = np.ascontiguousarray(t, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._chk(self._L.rgc_set_target_reframed(self._h, C.c_void_p(d_map), n, stride_bytes, q.ctypes.data_as(dp), tt.ctypes.data_as(dp), C.c_void_p(d_scratch)))
+        self._n_tgt = n
+
     def download(self, ptr: int, shape, dtype=np.float32) -> np.ndarray:
         out = np.empty(shape, dtype)
         self._chk(self._L.rgc_download(self._h, out.ctypes.data, C.c_void_p(ptr), out.nbytes))

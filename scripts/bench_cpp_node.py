@@ -29,7 +29,8 @@ subprocess.check_call(["g++", "-std=c++14", "-O2", "-pthread", os.path.join(ROOT
                        "-L", os.path.join(ROOT, "rgc-slam_amd"), "-lrgc_hip", "-Wl,-rpath," + os.path.join(ROOT, "rgc-slam_amd")])
 res = {"workload": "24 VLP-16 sweeps x 28.8 k points, PointCloud2 bytes in -> odometry pose out (front-end + frame body, 3-keyframe local map); first 4 frames untimed"}
 final = {}
-for name, resident, chain, pipe in (("cpp_reference_semantics", 0, 0, 0), ("cpp_resident_map", 1, 0, 0), ("cpp_resident_map_device_chain", 1, 1, 0),
+for name, resident, chain, pipe in (("cpp_reference_semantics", 0, 0, 0), ("cpp_reference_semantics_device_chain", 0, 1, 0), ("cpp_resident_map", 1, 0, 0),
+                                    ("cpp_resident_map_device_chain", 1, 1, 0),
                                     ("cpp_replay_pipeline", 1, 1, 1)):
     best = None
     for rep in range(2):

@@ -31,8 +31,8 @@ for overlap in (False, True) * int(os.environ.get('RGC_EXP_PASSES', '2')):
     for j in range(K):
         cur = vv[j % len(vv)]
         t0 = T(); q, t = bench.world_to_body(Tw)
-        t1 = T(); cur.transformCloudDevice(d_map, len(tgt), 16, q, t, seq.d_body[id(cur)])
-        t2 = T(); cur.setInputTargetDevice(seq.d_body[id(cur)], len(tgt), 16)
+        t1 = T()
+        t2 = T(); cur.setInputTargetReframed(d_map, len(tgt), 16, q, t, seq.d_body[id(cur)])
         t3 = T()
         if not overlap: seq.frame_source(1 + j, cur)
         t4 = T(); cur.align_begin(g, True)

@@ -85,9 +85,7 @@ def test_cpp_node_device_chain(exe, sweeps):
         b, gb, sb = _run(exe, path, True, as_message, 0.5, chain=True)
         assert np.array_equal(a, b) and ga == gb
         assert sa["keyframes"] == sb["keyframes"] and sa["sharp"] == sb["sharp"] and sa["flat"] == sb["flat"]
-    # reference semantics keep their keyframes on the host: the option is refused
-    out = subprocess.run([exe, path, "0", "1", "50", "1"], capture_output=True, text=True, timeout=600).stdout
-    assert "EXCEPTION" in out and "device_chain" in out
+    # (reference semantics on the device: test_cpp_node_reference_semantics_on_the_device)
 
 
 def test_cpp_replay_pipeline(exe, sweeps):
@@ -170,3 +168,13 @@ def test_cpp_node_against_the_literal_frame_body(exe, tmp_path):
         assert np.abs((t[i] - t[i - 1]) - (fx["t"][i] - fx["t"][i - 1])).max() <= 1e-4, i
         assert abs(ang(q[i], q[i - 1]) - ang(fx["q"][i], fx["q"][i - 1])) <= 1e-4, i
     assert np.abs(t - fx["t"]).max() <= 5e-4 and max(ang(a, b) for a, b in zip(q, fx["q"])) <= 5e-4
+
+
+def test_cpp_node_reference_semantics_on_the_device(exe, sweeps):
+    """device_chain without the resident map: the reference's keyframe window, its re-framing and both leaf filters stay on the device --
+    the same poses, to the last bit, as the host-staged reference-semantics mode (which the frame-body tests hold against the oracle)."""
+    raws, path = sweeps
+    host, _, s0 = _run(exe, path, False, True)
+    dev, _, s1 = _run(exe, path, False, True, chain=True)
+    assert len(host) == len(dev) == len(raws) and s0["keyframes"] == s1["keyframes"]
+    assert np.array_equal(host, dev)
