@@ -132,7 +132,7 @@ struct rgc_ctx {
   // through the transform it applies -- the box of a sub-map re-framed by a new pose (RGC_odometer.cpp:1248-1256) follows from the
   // pose.  The target's preparation takes its grid from the hint: no bounding-box kernel, no host round trip, and no speculative-grid
   // miss when the re-framed map's box swings with the vehicle's yaw.  k_count's guard still checks it.
-  struct BoxHint { const void* p = nullptr; int n = 0; double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; } box_hint[4];
+  struct BoxHint { const void* p = nullptr; int n = 0; double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; double reach_xy = 0, reach_z = 0; } box_hint[4];
   int box_hint_next = 0;
   bool vg_flags_clean = false;  // d_small[24 + 6] is known to be zero (a finished rows chain leaves it so)
   DevBuf fe[34];              // front-end buffers
@@ -280,12 +280,13 @@ const rgc_ctx::BoxHint* find_hint(const rgc_ctx* c, const void* p, int n) {
     if (h.p == p && h.n == n && p) return &h;
   return nullptr;
 }
-void put_hint(rgc_ctx* c, const void* p, int n, const double lo[3], const double hi[3]) {
+void put_hint(rgc_ctx* c, const void* p, int n, const double lo[3], const double hi[3], double reach_xy = 0, double reach_z = 0) {
   rgc_ctx::BoxHint* h = nullptr;
   for (auto& e : c->box_hint)
     if (e.p == p) h = &e;  // a buffer has one box
   if (!h) { h = &c->box_hint[c->box_hint_next]; c->box_hint_next = (c->box_hint_next + 1) % 4; }
   h->p = p; h->n = n;
+  h->reach_xy = reach_xy; h->reach_z = reach_z;
   for (int a = 0; a < 3; a++) { h->lo[a] = lo[a]; h->hi[a] = hi[a]; }
 }
 void drop_hints(rgc_ctx* c) {
@@ -445,18 +446,25 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;
     // (a hinted box is that of a map re-framed by the vehicle's pose: as the yaw changes it swings between the map's own box and one
-    // with twice the cells -- when the cell arrays have to grow, they grow for that at once, not a few per cent per frame)
-    const size_t cell_slack = (hint && (cl.cnt.cap < sizeof(int) * ntot + 256 || cl.start.cap < sizeof(int) * nc1)) ? 3 : 2;
-    if ((rc = ensure(c, cl.cnt, sizeof(int) * ntot * cell_slack / 2 + 256))) return rc;
-    if ((rc = ensure(c, cl.start, sizeof(int) * nc1 * cell_slack / 2))) return rc;
-    if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (ntot * cell_slack / 2 / 2048 + 2)))) return rc;
+    // with twice the cells -- the cell arrays are sized for the largest it can get, once, not grown a few per cent per frame)
+    size_t want_cells = ntot;
+    if (hint && hint->reach_xy > 0) {
+      const double e = hint->reach_xy / res + 6.0, ez = hint->reach_z / res + 6.0;
+      const double cells = e * e * ez * (half ? 8.0 : 1.0) * 1.05;
+      if (cells < 2.0e9 && cells <= 8.0 * (double)c->prm.max_cells && (size_t)cells > want_cells) want_cells = (size_t)cells;
+    }
+    const size_t cell_slack = 2;
+    if ((rc = ensure(c, cl.cnt, sizeof(int) * std::max(ntot, want_cells) + 256))) return rc;
+    if ((rc = ensure(c, cl.start, sizeof(int) * std::max(nc1, want_cells)))) return rc;
+    if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (std::max(ntot, want_cells) / 2048 + 2)))) return rc;
     if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.P, sizeof(float4) * ((size_t)n + 4)))) return rc;
     if ((rc = ensure(c, cl.segs, rgck::deferred_bytes(n)))) return rc;
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
-    if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)vg.ncell * cell_slack / 2))) return rc;
+    if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * std::max((size_t)vg.ncell, half ? want_cells / 8 : want_cells)))) return rc;
+    (void)cell_slack;
     if (half) {  // (vox_cell is written by the cell scan in this layout)
       const size_t vmax = (size_t)(n < vg.ncell ? n : vg.ncell);
       if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
@@ -1807,7 +1815,10 @@ int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_b
           hi[a] = std::max(hi[a], v + 1.0e-3);
         }
       }
-      put_hint(c, out_xyzi, n, lo, hi);
+      // how large the re-framed box can get as the vehicle turns: under any yaw its x / y extents stay within the horizontal diagonal of
+      // the map's own box; pitch and roll of a ground vehicle tilt it by a few cells.  The cell arrays are sized for that ONCE.
+      const double dxy = std::hypot(hin->hi[0] - hin->lo[0], hin->hi[1] - hin->lo[1]);
+      put_hint(c, out_xyzi, n, lo, hi, dxy, (hi[2] - lo[2]) + 0.08 * dxy);
     }
   }
   rgck::transform_q(c->stream, d_in, stride_bytes / 4, n, rgck::Quat{q[0], q[1], q[2], q[3]}, t, d_scratch, 4);
