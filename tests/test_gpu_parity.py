@@ -725,7 +725,8 @@ def test_half_size_search_grid_layout(reg_mod, orc, medium, monkeypatch):
 
 
 @pytest.mark.parametrize("knob,value", [("RGC_SRC_RES", "0.5"), ("RGC_SRC_RES", "2.0"), ("RGC_SMALL_COPY", "1"), ("RGC_SPEC_GRID", "0"),
-                                        ("RGC_MAP_WIDE", "0"), ("RGC_MAP_WIDE", "1000"), ("RGC_MAP_WIDE_R", "0"), ("RGC_MAP_HALF", "1")])
+                                        ("RGC_MAP_WIDE", "0"), ("RGC_MAP_WIDE", "1000"), ("RGC_MAP_WIDE_R", "0"), ("RGC_MAP_HALF", "1"),
+                                        ("RGC_LM_POST", "0"), ("RGC_SOLVE_BEHIND_MAP", "0")])
 def test_developer_knobs_change_no_result(reg_mod, medium, monkeypatch, knob, value):
     """Every environment knob read by rgc_create (README) selects another route to the SAME result: a short sequence gives the default's
     poses bit for bit (the map's layout knobs: to 1e-6, their fp64 sums run in another order), iterations and fitness included."""
