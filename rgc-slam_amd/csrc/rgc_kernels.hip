@@ -762,6 +762,11 @@ constexpr int kPieceQuads = 1023;  // a piece's length in quads shares its table
 #define RGC_SPBUF 12
 #endif
 constexpr int kSpBuf = RGC_SPBUF;   // keys waiting to enter the chain, per lane
+#ifndef RGC_SPLOW
+#define RGC_SPLOW 8
+#endif
+constexpr int kSpLow = RGC_SPLOW;   // the map's kernel drains a full buffer down to this many keys (0: to the bottom), knn_point_sp
+static_assert(kSpLow >= 0 && kSpLow <= kSpBuf - 4, "a quad of four keys must fit above the drained level");
 // Block geometry and LDS layout of one instantiation.  R = block radius in cells, kClip as described at knn_point_sp.
 // LDS per lane, as columns [slot][lane]: the append buffer, the piece table (padded with INT_MAX for the ordinal -> piece search)
 // and the pieces' first positions in the sorted array.
@@ -983,17 +988,23 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     }
     return key;
   };
-  auto drain = [&]() {  // the next key is on its way from LDS while the current one walks down the chain
+  // An insert round costs the wave the same whether one lane or all 64 hold a key.  Buffers are therefore drained only DOWN TO
+  // kSpLow keys when one runs full (the tail of a full drain is rounds in which the fullest lane works alone, and at any time some
+  // lane of the 64 is in its loose-tail phase), and to the bottom once, at the end of the stream: 65 -> 47 rounds per wave on the
+  // c-main map for 1 % more appended keys (scripts/sim_drain.py; counted on the device: profiles/r03_knn_isa_mix.json).
+  auto drain = [&](lds_int* floor) {  // the next key is on its way from LDS while the current one walks down the chain
     int key = pop();
     for (;;) {
-      const int nkey = pop();
+      const bool more = __any(bp > floor);
+      const int nkey = more ? pop() : INT_MAX;
       LAB_COUNT(2);
       top.insert(key);
-      if (!__any(nkey != INT_MAX)) break;
+      if (!more) break;
       key = nkey;
     }
     tau = top.a[L - 1];
   };
+  lds_int* const bp_low = buf + kSpLow * T;
   // Software pipeline: the loads of quad q + 1 are issued before quad q is processed, so a wave waits for memory once, not once
   // per quad; two register sets take turns (copying one into the other would wait for the loads just issued).
   // (off, end, ri, ordn) always describe the NEXT quad to fetch.
@@ -1031,7 +1042,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
       if (k2 < tau) { *bp = k2; bp += T; }
       if (k3 < tau) { *bp = k3; bp += T; }
     }
-    if (__any(bp > bp_full)) drain();
+    if (__any(bp > bp_full)) drain(bp_low);
   };
   Quad qa, qb;
   if (L <= 24) {
@@ -1067,7 +1078,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     fetch(qa);
     process(qb);
   }
-  if (__any(bp != buf)) drain();
+  if (__any(bp != buf)) drain(buf);
   // ---- the k-th neighbour: is it decided by the keys, and is it provably inside the block? ----
   int a_km2, a_km1, a_k, a_kp1;
   if (kExact || k == KC) {
