@@ -91,31 +91,32 @@ def shifted(T, d, sign):
 
 
 def quat_of(R):
-    """unit quaternion (x, y, z, w) of a rotation matrix, fp64 (Shepperd's branches)"""
-    import numpy as np
-    R = np.asarray(R, np.float64)
-    tr = R[0, 0] + R[1, 1] + R[2, 2]
+    """unit quaternion (x, y, z, w) of a rotation matrix given as nested lists, fp64 (Shepperd's branches).  Plain Python floats: this
+    runs on the host between a frame's result and the next frame's first launch, where a numpy call costs more than the arithmetic"""
+    import math
+    tr = R[0][0] + R[1][1] + R[2][2]
     if tr > 0:
-        s = 2.0 * np.sqrt(tr + 1.0)
-        q = [(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s]
+        s = 2.0 * math.sqrt(tr + 1.0)
+        q = [(R[2][1] - R[1][2]) / s, (R[0][2] - R[2][0]) / s, (R[1][0] - R[0][1]) / s, 0.25 * s]
     else:
-        i = int(np.argmax([R[0, 0], R[1, 1], R[2, 2]]))
+        i = 0 if (R[0][0] >= R[1][1] and R[0][0] >= R[2][2]) else (1 if R[1][1] >= R[2][2] else 2)
         j, k = (i + 1) % 3, (i + 2) % 3
-        s = 2.0 * np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k])
-        q = [0.0, 0.0, 0.0, (R[k, j] - R[j, k]) / s]
+        s = 2.0 * math.sqrt(1.0 + R[i][i] - R[j][j] - R[k][k])
+        q = [0.0, 0.0, 0.0, (R[k][j] - R[j][k]) / s]
         q[i] = 0.25 * s
-        q[j] = (R[j, i] + R[i, j]) / s
-        q[k] = (R[k, i] + R[i, k]) / s
-    q = np.asarray(q, np.float64)
-    return q / np.linalg.norm(q)
+        q[j] = (R[j][i] + R[i][j]) / s
+        q[k] = (R[k][i] + R[i][k]) / s
+    nrm = math.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    return [q[0] / nrm, q[1] / nrm, q[2] / nrm, q[3] / nrm]
 
 
 def world_to_body(Tw):
     """(q, t) of the transform that re-expresses world-frame points in the body frame of pose Tw (RGC_odometer.cpp:1250-1255)"""
-    import numpy as np
-    Tw = np.asarray(Tw, np.float64)
-    Rt = Tw[:3, :3].T
-    return quat_of(Rt), -(Rt @ Tw[:3, 3])
+    M = Tw.tolist() if hasattr(Tw, "tolist") else Tw
+    Rt = [[M[0][0], M[1][0], M[2][0]], [M[0][1], M[1][1], M[2][1]], [M[0][2], M[1][2], M[2][2]]]
+    tx, ty, tz = M[0][3], M[1][3], M[2][3]
+    return quat_of(Rt), [-(Rt[0][0] * tx + Rt[0][1] * ty + Rt[0][2] * tz), -(Rt[1][0] * tx + Rt[1][1] * ty + Rt[1][2] * tz),
+                        -(Rt[2][0] * tx + Rt[2][1] * ty + Rt[2][2] * tz)]
 
 
 class DependentSequence:

@@ -473,8 +473,8 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     if (cl.cnt_clean < ntot) {  // first use or a larger grid; afterwards the scan leaves the counters clean: no fill kernel per frame
       const size_t fill = std::min(cl.cnt.cap, (sizeof(int) * ntot + 255) & ~(size_t)255);
       HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, fill, s));
-    }
-    cl.cnt_clean = ntot;
+      cl.cnt_clean = fill / sizeof(int);
+    }  // (a smaller grid leaves the counters beyond it as clean as they were: a re-framed map's box breathes with the yaw)
     rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi, spec ? dsm + 6 : nullptr,
                       half ? (int*)cl.cnt.p + nc1 : nullptr);
     rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)ntot, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
@@ -497,7 +497,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   const bool coop_beside = is_target && cl.grid.sub == 1;
   // grid of the cooperative launch: twice the deferred count of the previous cloud prepared here (consecutive clouds of a sequence
   // defer about the same queries), n / 64 for the first one
-  const int coop_waves = cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 32 : n / 64 + 32;
+  const int coop_waves = cl.deferred_seen >= 0 ? cl.deferred_seen + cl.deferred_seen / 4 + 32 : n / 64 + 32;
   if (!coop_beside) {
     ProfScope ps(c, is_target ? RGC_K_KNN_COOP : RGC_K_KNN_COOP_SRC, n, s);
     rgck::knn_coop(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p,
@@ -1259,20 +1259,39 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
   hipStream_t s = c->solve_stream;  // see rgc_align_begin
   rgck::LmState* post = (c->post_on && c->d_post) ? c->d_post : nullptr;
   const int seq = want_fitness ? -c->lm_seq : c->lm_seq;  // who posts the finished state: the fitness kernel, or the deciding step
-  {
-    ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch, s);
-    for (int k = 0; k < batch; k++) {
-      rgck::lm_step(s, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
-                    c->tgt.vgrid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
-                    (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, open, c->d_small + 7,
-                    c->tgt.segs.p, c->src.segs.p, post, seq);
-      open = nullptr;
-    }
-  }
-  if (want_fitness) {  // getFitnessScore at the final pose, chained blindly: the kernel is a no-op unless the LM is done
-    ProfScope ps(c, RGC_K_FITNESS, n, s);
+  // The batch is sized for a few steps more than the solve should need (rgc_align_begin), and the fitness kernel must not wait
+  // behind the spare ones (a launch on a finished solve still costs its ~2 us and the gap to the next): it is enqueued behind EACH of
+  // the last kTail steps -- it does nothing unless the solve is done and has no score yet, so the first one behind the deciding step
+  // does the work and posts the result, the others fall through.
+  constexpr int kTail = 3;
+  auto step = [&](const rgck::LmInit* op) {
+    rgck::lm_step(s, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
+                  c->tgt.vgrid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
+                  (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, op, c->d_small + 7,
+                  c->tgt.segs.p, c->src.segs.p, post, seq);
+  };
+  auto score = [&]() {  // getFitnessScore at the final pose, chained blindly
     rgck::fitness_lm(s, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
                      (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p, post, c->lm_seq);
+  };
+  // the stage-by-stage pass (events around the solve's regions) keeps the two apart: all steps, then the score
+  const bool staged = c->prof_on && ((c->prof_mask >> RGC_K_LINEARIZE) & 1u || (c->prof_mask >> RGC_K_FITNESS) & 1u);
+  if (staged) {
+    {
+      ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch, s);
+      for (int k = 0; k < batch; k++) { step(open); open = nullptr; }
+    }
+    if (want_fitness) {
+      ProfScope ps(c, RGC_K_FITNESS, n, s);
+      score();
+    }
+  } else {
+    for (int k = 0; k < batch; k++) {
+      step(open);
+      open = nullptr;
+      if (want_fitness && k >= batch - kTail) score();
+    }
+    if (want_fitness && batch <= 0) score();
   }
   HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, s));
   return RGC_OK;

@@ -2084,7 +2084,7 @@ __device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int
 #pragma unroll
       for (int a = 0; a < 6; a++) S[a] *= inv_k;
       double nrm[3];
-      min_eigenvector(S, nrm);
+      if (!min_eigenvector_direct(S, nrm)) min_eigenvector(S, nrm);  // (one lane, ~150 dependent fp64 instructions instead of the sweeps' ~1700: 5 us of a query's 16)
       nx[i] = nrm[0];
       ny[i] = nrm[1];
       nz[i] = nrm[2];

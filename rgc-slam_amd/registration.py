@@ -359,10 +359,14 @@ class FastVGICP:
     def setInputTargetReframed(self, d_map: int, n: int, stride_bytes: int, q_xyzw, t, d_scratch: int):
         """B9 + setInputTarget on the device in one call (rgc_set_target_reframed): the sub-map at d_map re-expressed by (q, t) into
         d_scratch and prepared as the target, its bounding box derived from the map's and the transform (RGC_odometer.cpp:1248-1256, 998-1007)"""
-        q = np.ascontiguousarray(q_xyzw, dtype=np.float64)
-        tt = np.ascontiguousarray(t, dtype=np.float64)
-        dp = C.POINTER(C.c_double)
-        self._chk(self._L.rgc_set_target_reframed(self._h, C.c_void_p(d_map), n, stride_bytes, q.ctypes.data_as(dp), tt.ctypes.data_as(dp), C.c_void_p(d_scratch)))
+        qt = getattr(self, "_qt7", None)
+        if qt is None:
+            qt = self._qt7 = (C.c_double * 7)()   # (the call sits on a sequence's critical path: no numpy temporaries)
+            self._qt7_q = C.cast(qt, C.POINTER(C.c_double))
+            self._qt7_t = C.cast(C.byref(qt, 4 * C.sizeof(C.c_double)), C.POINTER(C.c_double))
+        qt[0], qt[1], qt[2], qt[3] = float(q_xyzw[0]), float(q_xyzw[1]), float(q_xyzw[2]), float(q_xyzw[3])
+        qt[4], qt[5], qt[6] = float(t[0]), float(t[1]), float(t[2])
+        self._chk(self._L.rgc_set_target_reframed(self._h, C.c_void_p(d_map), n, stride_bytes, self._qt7_q, self._qt7_t, C.c_void_p(d_scratch)))
         self._n_tgt = n
 
     def download(self, ptr: int, shape, dtype=np.float32) -> np.ndarray:
