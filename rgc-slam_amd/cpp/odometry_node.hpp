@@ -183,9 +183,13 @@ private:
       if (submapflag_ == 0) first_keyframe();                                                   // :963-972
       submapflag_++;
       int n_src = 0;
+      bool source_set = false;
       if (chain) {
         reserve(d_source_, (size_t)16 * (size_t)(n_full > 0 ? n_full : 1));
         chk(rgc_voxelgrid(ctx_, d_full, n_full, 16, 0.2f, d_source_.p, &n_src, 1));
+        // (reference semantics: the scan is prepared on its own stream while the sub-map goes through its leaf filter -- it depends
+        // on neither; with the resident map the commit is usually a no-op and the order makes no difference)
+        if (!opt_.resident_map) { chk(rgc_set_source_device(ctx_, d_source_.p, n_src, 16)); source_set = true; }   // :1008
       } else {
         source_.resize((size_t)4 * n_full);
         chk(rgc_voxelgrid(ctx_, full_.data(), n_full, 16, 0.2f, source_.data(), &n_src, 0));     // :976-983, planeResolution1
@@ -213,7 +217,7 @@ private:
         pose_to_mat(q_last_curr_, t_last_curr_, guess);                                         // :993-996
         chk(rgc_set_target(ctx_, target_.data(), n_tgt, 16));                                   // :1007
       }
-      chk(chain ? rgc_set_source_device(ctx_, d_source_.p, n_src, 16) : rgc_set_source(ctx_, source_.data(), n_src, 16));   // :1008
+      if (!source_set) chk(chain ? rgc_set_source_device(ctx_, d_source_.p, n_src, 16) : rgc_set_source(ctx_, source_.data(), n_src, 16));   // :1008
       int it = 0, conv = 0, lmf = 0;
       chk(rgc_align(ctx_, guess, T, nullptr, &fitness, &it, &conv, &lmf));                       // :1009-1010
       double q_l[4], t_l[3];

@@ -1395,6 +1395,7 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
     if ((rc = lm_enqueue_batch(c, 6, nullptr, want_fitness))) return rc;
   }
   c->src_pending = false;  // stream2 has drained, and it was behind the main stream: nothing of this frame is in flight
+  c->main_has_target_prep = false;  // (the solve came after the map's preparation)
   c->small_clean[0] = c->small_clean[1] = true;  // the solve's first step re-initialised both blocks after capturing them
   {  // a cloud that did not fit its speculative grid: everything above ran on a parked cloud -- prepare it properly, solve again
     const int r = resolve_guards(c, S.pad & 0xff, (S.pad >> 8) & 0xff);
@@ -2483,6 +2484,9 @@ int rgc_map_insert(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const
   int rc = stage_in(c, xyzi, n, stride_bytes, on_device, &d_in);
   if (rc) return rc;
   if ((rc = map_reserve(c, c->map_cur, c->map_n + n, true))) return rc;
+  // (the other buffer -- where the first eviction or re-basing compacts to -- grows with it: a first hipMalloc of that size is 9 ms in
+  // whichever frame it falls)
+  if ((rc = map_reserve(c, c->map_cur ^ 1, c->map_n + n, false))) return rc;
   // surroundingCloud.push_back(transformPointCloud(FullPointsLessFlat, q_w_curr, t_w_curr)) (:1237), relative to the origin
   const double tr[3] = {t[0] - c->map_origin[0], t[1] - c->map_origin[1], t[2] - c->map_origin[2]};
   rgck::transform_q(c->stream, d_in, stride_bytes / 4, n, rgck::Quat{q[0], q[1], q[2], q[3]}, tr, (float*)c->map_store[c->map_cur].p + 4 * c->map_n, 4);

@@ -1,10 +1,13 @@
 #!/bin/bash
-# Copy the outputs of scripts/refresh_profiles.sh (gpurun_out/r02f/) into profiles/r02_* and regenerate the figures the documents quote.
+# Copy the outputs of scripts/refresh_profiles.sh (gpurun_out/${TAG}f/) into profiles/${TAG}_* and regenerate the figures the documents quote.
+TAG=${RGC_ROUND_TAG:-r03}
 cd "$(dirname "$0")/.." || exit 1
-S=gpurun_out/r02f
-for f in bench.json bench_under_rocprof.json kernel_stats.csv domain_stats.csv pmc_knn.json pmc_knn_src.json valu_issue.jsonl stall.txt long_run.json; do cp $S/$f profiles/r02_$f; done
-[ -s $S/long_run_pipelined.json ] && cp $S/long_run_pipelined.json profiles/r02_long_run_pipelined.json
-cp $S/rolling.json profiles/r02_rolling_bench.json; cp $S/cpp_node.json profiles/r02_cpp_node_bench.json; cp $S/cpp_pipeline.json profiles/r02_cpp_pipeline_bench.json
-cp $S/frontend.json profiles/r02_frontend_bench.json; cp $S/mapreg.json profiles/r02_mapreg_bench.json; cp $S/icp.json profiles/r02_icp_bench.json; cp $S/pre.json profiles/r02_pre_bench.json
-cp $S/f_kernel_stats.csv profiles/r02_frontend_kernel_stats.csv; cp $S/m_kernel_stats.csv profiles/r02_mapreg_kernel_stats.csv; cp $S/i_kernel_stats.csv profiles/r02_icp_kernel_stats.csv
+S=gpurun_out/${TAG}f
+for f in bench.json bench_under_rocprof.json kernel_stats.csv domain_stats.csv dependent_frame_kernels.txt dependent_frame_timeline.txt pmc_knn.json pmc_knn_src.json lab_iters.json knn_isa_mix.json long_run.json; do
+  [ -s $S/$f ] && cp $S/$f profiles/${TAG}_$f
+done
+for p in rolling:rolling_bench cpp_node:cpp_node_bench cpp_pipeline:cpp_pipeline_bench frontend:frontend_bench mapreg:mapreg_bench icp:icp_bench pre:pre_bench; do
+  [ -s $S/${p%%:*}.json ] && cp $S/${p%%:*}.json profiles/${TAG}_${p##*:}.json
+done
+[ -s $S/f_kernel_stats.csv ] && cp $S/f_kernel_stats.csv profiles/${TAG}_frontend_kernel_stats.csv
 python3 scripts/sync_docs.py
