@@ -49,6 +49,8 @@ struct Cloud {
   rgck::Grid spec_grid{};
   bool spec_ok = false;    // spec_grid is usable
   bool spec_used = false;  // this cloud was prepared on spec_grid and its guard has not been read yet
+  bool reframe_pending = false;  // in[] has not been written yet: the next preparation produces it from rf (rgc_set_target_reframed)
+  rgck::Reframe rf{};
   size_t cnt_clean = 0;    // cnt[0 .. cnt_clean) is known to be zero (the cell scan leaves the counters it consumed at zero)
   const void* cnt_seen = nullptr;  // the allocation cnt_clean refers to
   // target only
@@ -365,6 +367,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       if (ncell <= (double)c->prm.max_cells && ncell <= 2.0e9) g = rgck::make_grid(lo, dm, res);
       else hint = nullptr;
     }
+    // A re-framed map (rgc_set_target_reframed) has not been written yet.  With its box known the counting pass below produces it on
+    // the way (one pass over the map and one launch less); any other route measures the cloud first and needs it in memory.
+    const bool fuse_reframe = cl.reframe_pending && hint != nullptr && cl.stride_f == 4;
+    if (cl.reframe_pending && !fuse_reframe)
+      rgck::transform_q(s, cl.rf.src, cl.rf.src_stride_f, n, cl.rf.q, cl.rf.t, const_cast<float*>(cl.in), 4);
+    cl.reframe_pending = false;
     if (hint) {
       spec = true;
       cl.spec_used = true;
@@ -476,7 +484,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       cl.cnt_clean = fill / sizeof(int);
     }  // (a smaller grid leaves the counters beyond it as clean as they were: a re-framed map's box breathes with the yaw)
     rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi, spec ? dsm + 6 : nullptr,
-                      half ? (int*)cl.cnt.p + nc1 : nullptr);
+                      half ? (int*)cl.cnt.p + nc1 : nullptr, fuse_reframe ? &cl.rf : nullptr);
     rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)ntot, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
                      is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23), half ? (int)nc1 : -1,
                      half ? (int*)cl.vox_cell.p : nullptr);
@@ -532,8 +540,10 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   return RGC_OK;
 }
 
-int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, int stride_bytes, bool on_device) {
+// rf (nullable, device clouds only): xyz has not been written yet -- the preparation produces it from rf (rgc_set_target_reframed)
+int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, int stride_bytes, bool on_device, const rgck::Reframe* rf = nullptr) {
   if (!c) return RGC_ERR_INVALID;
+  cl.reframe_pending = false;
   if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   cl.ready = false;
   cl.n = 0;
@@ -563,6 +573,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
   }
   cl.stride_f = stride_f;
   cl.n = n;
+  if (rf && on_device) { cl.rf = *rf; cl.reframe_pending = true; }
   int rc = prepare_cloud(c, cl, is_target);
   if (rc) { cl.n = 0; return rc; }
   if (is_target) { c->stats.n_target = n; c->stats.target_cells = cl.grid.ncell; }
@@ -1841,9 +1852,10 @@ int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_b
       put_hint(c, out_xyzi, n, lo, hi, dxy, (hi[2] - lo[2]) + 0.08 * dxy);
     }
   }
-  rgck::transform_q(c->stream, d_in, stride_bytes / 4, n, rgck::Quat{q[0], q[1], q[2], q[3]}, t, d_scratch, 4);
+  // (the re-framing itself is left to the preparation: its counting pass writes d_scratch on the way, prepare_cloud)
+  const rgck::Reframe rf{d_in, stride_bytes / 4, rgck::Quat{q[0], q[1], q[2], q[3]}, {t[0], t[1], t[2]}};
   HIPCHK(c, hipGetLastError());
-  return set_cloud(c, c->tgt, true, d_scratch, n, 16, true);
+  return set_cloud(c, c->tgt, true, d_scratch, n, 16, true, &rf);
 }
 
 // The rows chain of the leaf filter on box g (rgc_pre.hip); one read-back: *flags (bits as rgck::vg_rows documents) and *n_out.

@@ -61,6 +61,9 @@ struct PoseF {  // fp32 4x4 rows 0..2 (pcl::transformPointCloud in the reference
 };
 
 struct Quat { double x, y, z, w; };
+// B9 folded into the counting pass of a cloud's preparation (count_cells): point i is read from src, re-expressed as q * p + t with
+// k_transform_q's arithmetic, stored to the cloud's own buffer (x, y, z, intensity) and counted -- one pass over the map less
+struct Reframe { const float* src; int src_stride_f; Quat q; double t[3]; };
 struct LmIn { double x0[16]; double lambda; double init_factor; };
 struct LmState {  // device-resident state of LsqRegistration::computeTransformation (lsq_registration_impl.hpp:53-172)
   double x0[16], lambda, nu, y0, yi, H[36], b[6], d[6], delta[16], xi[16], Hfin[36];
@@ -82,8 +85,9 @@ constexpr int kVoxRec = 10; // mean(3) cov6(6) num(1), doubles
 // ---- grid build ----
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi = 0);
 // vocc (g.sub == 2 only, nullable): occupancy flags of the voxel grid that goes with g (half_grid_of), set to 1 where a point falls
+// rf (nullable): in[] is first WRITTEN from rf->src (see Reframe; in must then be a 16-byte-stride device buffer this call may write)
 void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi = 0, int* guard = nullptr,
-                 int* vocc = nullptr);
+                 int* vocc = nullptr, const Reframe* rf = nullptr);
 // cnt: n = cells + 1 entries; block_sums: >= 8 * (n / 2048 + 2) bytes; cell_voxel (n - 1 ints) and nvox may be null
 // consumes the counters: cnt[0..n) is left ZERO
 // nsplit >= 0: cnt[0..nsplit) are cell counters (+ sentinel) and get start[]; cnt[nsplit..n) are voxel occupancy flags (count_cells'

@@ -190,15 +190,36 @@ __device__ __forceinline__ constexpr int row_dz(int r, int D, int R) { return (R
 // guard (nullable): the grid was NOT derived from this cloud (a speculative grid kept from the previous one): a point with
 // non-finite / absurd coordinates sets bit 0, a point outside the grid bit 1 -- the host re-prepares the cloud when it
 // learns of it; such a point is parked in cell 0 so that nothing is written out of bounds meanwhile.
+// q * p + t, the arithmetic of k_transform_q (rgc_pre.hip; vg_ICP::transformPointCloud, src/RGC_odometer.cpp:1495-1514)
+__device__ __forceinline__ float4 reframe_point(const Reframe& rf, int i) {
+  const float* p = rf.src + (size_t)i * rf.src_stride_f;
+  const Quat& q = rf.q;
+  const double vx = (double)p[0], vy = (double)p[1], vz = (double)p[2];
+  double ux = q.y * vz - q.z * vy, uy = q.z * vx - q.x * vz, uz = q.x * vy - q.y * vx;
+  ux += ux; uy += uy; uz += uz;
+  return make_float4((float)(vx + q.w * ux + (q.y * uz - q.z * uy) + rf.t[0]), (float)(vy + q.w * uy + (q.z * ux - q.x * uz) + rf.t[1]),
+                     (float)(vz + q.w * uz + (q.x * uy - q.y * ux) + rf.t[2]), rf.src_stride_f > 3 ? p[3] : 0.f);
+}
+
+template <bool kReframe>
 __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* __restrict__ slot_of,
-                        int* cnt, int* guard, int prio, int* __restrict__ vocc) {
+                        int* cnt, int* guard, int prio, int* __restrict__ vocc, Reframe rf) {
   wave_prio(prio);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < n;
   const int lane = threadIdx.x & (WAVE - 1);
   int c = -1 - lane;  // lanes past the end: distinct negative keys, so they never extend a neighbour's run
   if (valid) {
-    const float* p = in + (size_t)i * stride_f;
+    float pt[3];
+    if (kReframe) {  // the cloud is produced here (stride 4 floats) and counted from registers
+      const float4 w = reframe_point(rf, i);
+      *reinterpret_cast<float4*>(const_cast<float*>(in) + (size_t)i * 4) = w;
+      pt[0] = w.x; pt[1] = w.y; pt[2] = w.z;
+    } else {
+      const float* pp = in + (size_t)i * stride_f;
+      pt[0] = pp[0]; pt[1] = pp[1]; pt[2] = pp[2];
+    }
+    const float* p = pt;
     int cx, cy, cz;
     if (guard) {
       const float x = p[0], y = p[1], z = p[2];
@@ -3483,8 +3504,10 @@ void mapreg_terms(hipStream_t s, const float* const feat[4], const double* const
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi) {
   hipLaunchKernelGGL(k_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags, hi);
 }
-void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi, int* guard, int* vocc) {
-  hipLaunchKernelGGL(k_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi, vocc);
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi, int* guard, int* vocc,
+                 const Reframe* rf) {
+  if (rf) hipLaunchKernelGGL(k_count<true>, dim3(nblk(n, 256)), dim3(256), 0, s, in, 4, n, g, cell_of, slot_of, cnt, guard, hi, vocc, *rf);
+  else hipLaunchKernelGGL(k_count<false>, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi, vocc, Reframe{});
 }
 void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi, float* sum_sq, int nsplit,
                 int* vox_cell) {

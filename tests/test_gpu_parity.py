@@ -754,3 +754,45 @@ def test_developer_knobs_change_no_result(reg_mod, medium, monkeypatch, knob, va
             assert np.array_equal(Ta, Tb) and ia == ib and fa == fb
         else:
             assert np.abs(Ta - Tb).max() <= 1e-6 and abs(fa - fb) <= 1e-6 * fa
+
+
+def test_reframed_target_equals_transform_then_set(reg_mod, orc, medium):
+    """rgc_set_target_reframed (B9 folded into the preparation's counting pass, the box derived from the input's box and the transform)
+    prepares the SAME target as rgc_transform_cloud followed by rgc_set_target_device -- every covariance and the voxel table bit for bit,
+    the re-framed cloud left in the scratch buffer -- and both equal the oracle's transform_cloud + covariances.  Three poses in a row on
+    one context: the second and third calls take the hinted grid (no measuring pass), a yaw of 40 degrees swings the box."""
+    import rgc_slam_amd.synth as synth
+    import bench
+    tgt = medium["tgt"]
+    n = len(tgt)
+    a = np.zeros((n, 4), np.float32)
+    a[:, :3] = tgt
+    a[:, 3] = np.arange(n, dtype=np.float32) % 7
+    v, w = _odo(reg_mod), _odo(reg_mod)
+    d_map = v.device_alloc(a.nbytes); v.upload(d_map, a)
+    d_body, d_ref = v.device_alloc(a.nbytes), v.device_alloc(a.nbytes)
+    d_map_w = w.device_alloc(a.nbytes); w.upload(d_map_w, a)
+    d_out_w = w.device_alloc(a.nbytes)
+    for yaw, t in ((0.0, [0.0, 0.0, 0.0]), (0.7, [3.0, -2.0, 0.1]), (-0.2, [-1.0, 4.0, 0.0])):
+        Tw = synth.se3(synth.rot_zyx(yaw, 0.01, -0.02), t)
+        q, tt = bench.world_to_body(Tw)          # world -> body of pose Tw (RGC_odometer.cpp:1250-1255)
+        v.setInputTargetReframed(d_map, n, 16, q, tt, d_body)
+        w.transformCloudDevice(d_map_w, n, 16, q, tt, d_out_w)
+        w.setInputTargetDevice(d_out_w, n, 16)
+        cv, cw = v.getTargetCovariances(), w.getTargetCovariances()
+        assert np.array_equal(cv, cw)
+        xv, xw = v.getVoxels(), w.getVoxels()
+        kv, kw = np.lexsort(xv["coords"].T[::-1]), np.lexsort(xw["coords"].T[::-1])
+        assert np.array_equal(xv["coords"][kv], xw["coords"][kw]) and np.array_equal(xv["num"][kv], xw["num"][kw])
+        assert np.array_equal(xv["mean"][kv], xw["mean"][kw]) and np.array_equal(xv["cov"][kv], xw["cov"][kw])
+        body = v.download(d_body, (n, 4))
+        assert np.array_equal(body, w.download(d_out_w, (n, 4)))
+        ob = orc.transform_cloud(a, q, tt)
+        assert np.array_equal(body, ob)                                   # B9 itself: the oracle's fp64 expression, stored fp32
+    ocov, _ = orc.covariances(body[:, :3].copy(), k=20)
+    assert np.abs(cv - ocov).max() <= 1e-9
+    for p in (d_map, d_body, d_ref):
+        v.device_free(p)
+    for p in (d_map_w, d_out_w):
+        w.device_free(p)
+    v.close(); w.close()
