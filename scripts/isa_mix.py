@@ -163,7 +163,10 @@ def main():
                 return True
             seen |= front
         return False
-    drain_blocks = [i for i, b in enumerate(blocks) if sum(o == "v_med3_i32" for o in b["ops"]) >= 15 and returns_soon(i)]
+    # (a drain call's first insert may be peeled out of its self-loop and then sits in the scan loop's component: every block that
+    # holds a chain insert -- 22 v_med3_i32 -- is one copy of the same body, and LAB_COUNT(2) counts the inserts of all of them)
+    drain_blocks = [i for i, b in enumerate(blocks) if sum(o == "v_med3_i32" for o in b["ops"]) >= 15]
+    looping_drain_blocks = [i for i in drain_blocks if returns_soon(i)]
     weight = [1.0] * n
     kinds = {}
     for c_, m in cyclic.items():
@@ -172,7 +175,7 @@ def main():
             k = "scan"
         elif any(o.startswith("v_rcp_f64") for o in ops) and not any(o.startswith(("v_sqrt_f64", "v_rsq_f64")) for o in ops):
             k = "newton"   # (a rolled Newton loop; the Jacobi fallback's sweeps also divide, but take roots as well)
-        elif len(m) == 1 and m[0] in drain_blocks:
+        elif len(m) == 1 and m[0] in looping_drain_blocks:
             k = "drain"
         else:
             k = "other"
@@ -201,6 +204,13 @@ def main():
             d = per_op.setdefault(o, [c, 0, 0.0])
             d[1] += 1
             d[2] += w
+    if os.environ.get("ISA_MIX_DEBUG"):   # where the weight goes: blocks by weighted VALU count
+        rows = sorted(((w * len(b["ops"]), w, len(b["ops"]), b["label"], kinds.get(comp[i] if comp[i] in cyclic else -1, "-"))
+                       for i, (b, w) in enumerate(zip(blocks, weight)) if b["ops"]), reverse=True)
+        for r in rows[:40]:
+            print("%9.1f = %7.2f x %4d  %-22s %s" % r, file=sys.stderr)
+        print("once-per-wave blocks: %.1f VALU in %d blocks" % (sum(len(b["ops"]) for b, w in zip(blocks, weight) if w == 1.0),
+                                                                 sum(1 for b, w in zip(blocks, weight) if w == 1.0 and b["ops"])), file=sys.stderr)
     executed = sum(tot.values())
     h_lo = tot["half"] / executed                      # unknown opcodes priced at full rate
     h_hi = (tot["half"] + tot["unknown"]) / executed   # ... at half rate
@@ -217,7 +227,8 @@ def main():
            "unmeasured_opcodes": {o: round(d[2], 1) for o, d in sorted(per_op.items()) if d[0] == "unknown"},
            "top_opcodes_executed_per_wave": {o: [d[0], round(d[2], 1)] for o, d in sorted(per_op.items(), key=lambda kv: -kv[1][2])[:24]},
            "note": "blocks outside the wave-level loops are weighted 1 per wave (the rare paths -- deferral, exact tie-break, Jacobi set-up -- are a few "
-                   "dozen instructions: a slight over-count); fp64 transcendental helpers (v_rcp_f64, v_rsq_f64, v_sqrt_f64) are priced at half rate, "
+                   "dozen instructions: a slight over-count) and blocks inside a loop by the loop's trip count although a wave skips them when no lane needs them "
+                   "(a new piece, a drain): executed_over_pmc is the size of both effects; fp64 transcendental helpers (v_rcp_f64, v_rsq_f64, v_sqrt_f64) are priced at half rate, "
                    "they are slower: the true mix-weighted peak is a little LOWER than printed"}
     if args.pmc and os.path.exists(args.pmc):
         pmc = json.load(open(args.pmc))
