@@ -10,7 +10,7 @@
 //
 // Contents, in file order (one translation unit on purpose: the device helpers -- wave reductions, the register top-k chain,
 // the row walkers, the Jacobi solver, the block reduction -- are shared by nearly every kernel and stay inlinable):
-//   grid build      k_bbox, k_count, k_cells_scan_{block,sums,add}, k_place, k_rank_gather (+ k_scan_*, a plain 32-bit
+//   grid build      k_bbox, k_count, k_cells_reduce + k_cells_scan_{write,sums}, k_place, k_rank_gather (+ k_scan_*, a plain 32-bit
 //                   exclusive scan: the front-end's ground list; the leaf filter of rgc_pre.hip uses the cell scan)
 //   C2 kNN + cov    Chain, sp_piece_table, knn_point_sp (map: one lane per query, one pass), knn_point_split (scan: four lanes per
 //                   query), k_knn_sp (the bulk launch of either), TopK, coop_kth, k_knn_coop (deferred queries, one wave per query)
@@ -370,16 +370,23 @@ __device__ __forceinline__ unsigned long long scan_value(int v, int i, int nspli
   if (nsplit < 0) return (unsigned long long)(unsigned)v | ((unsigned long long)(v > 0) << 32);
   return i < nsplit ? (unsigned long long)(unsigned)v : ((unsigned long long)(v != 0) << 32);
 }
-__global__ void k_cells_scan_block(int* __restrict__ cnt, int* __restrict__ start, int n, unsigned long long* __restrict__ block_sums,
-                                   int* __restrict__ cell_voxel, int* __restrict__ nvox, int prio, float* __restrict__ sum_sq, ScanSplit sp) {
+// Reduce, then scan (round 3; the first pass used to write provisional start[] / cell_voxel[] that the second read, corrected and
+// wrote again: 58 MB of traffic for a 2.4 M-cell grid, now 38):
+//   pass 1 (k_cells_reduce): every workgroup's total of its SCAN_B entries -- reads only (and the scan grid's crowding figure);
+//   pass 2 (k_cells_scan_write): the totals of the workgroups before this one (summed by the workgroup itself for <= 4096 of them,
+//           else taken from k_cells_scan_sums), the entries once more, their exclusive scan, and start[] / cell_voxel[] / vox_cell[]
+//           written ONCE with their final values; the counters are consumed here (left at zero for the next cloud).
+// A grid of one workgroup needs pass 2 only.
+__global__ void __launch_bounds__(SCAN_T) k_cells_reduce(const int* __restrict__ cnt, int n, unsigned long long* __restrict__ block_sums, int prio,
+                                                         float* __restrict__ sum_sq, ScanSplit sp) {
   wave_prio(prio);
+  __shared__ unsigned long long part[SCAN_T / WAVE];
   const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
   int v[SCAN_V];
   unsigned long long s = 0;
 #pragma unroll
   for (int j = 0; j < SCAN_V; j++) {
     v[j] = (base + j < n) ? cnt[base + j] : 0;
-    if (base + j < n && v[j]) cnt[base + j] = 0;  // the counters are consumed here: left clean for the next cloud, no fill kernel per frame
     s += scan_value(v[j], base + j, sp.nsplit);
   }
   if (sum_sq) {  // sum of count^2 = the work of every point scanning its own cell: how crowded the cells are (a heuristic, float is plenty)
@@ -389,29 +396,14 @@ __global__ void k_cells_scan_block(int* __restrict__ cnt, int* __restrict__ star
     for (int o = WAVE / 2; o > 0; o >>= 1) q += __shfl_down(q, o);
     if ((threadIdx.x & (WAVE - 1)) == 0 && q > 0.f) atomicAdd(sum_sq, q);
   }
-  unsigned long long tot;
-  unsigned long long ex = block_exclusive_scan64(s, &tot);
-  const bool final_ids = gridDim.x == 1;
-#pragma unroll
-  for (int j = 0; j < SCAN_V; j++) {
-    const int i = base + j;
-    if (i < n) {
-      if (sp.nsplit < 0) {
-        start[i] = (int)(unsigned)ex;
-        if (cell_voxel && i < n - 1) cell_voxel[i] = v[j] > 0 ? (int)(ex >> 32) : -1;
-      } else if (i < sp.nsplit) {
-        start[i] = (int)(unsigned)ex;
-      } else {
-        const int id = v[j] != 0 ? (int)(ex >> 32) : -1;
-        cell_voxel[i - sp.nsplit] = id;
-        if (final_ids && id >= 0) sp.vox_cell[id] = i - sp.nsplit;
-      }
-    }
-    ex += scan_value(v[j], i, sp.nsplit);
-  }
+  for (int o = WAVE / 2; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & (WAVE - 1)) == 0) part[threadIdx.x / WAVE] = s;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    block_sums[blockIdx.x] = tot;
-    if (gridDim.x == 1 && nvox) *nvox = (int)(tot >> 32);
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_T / WAVE; w++) t += part[w];
+    block_sums[blockIdx.x] = t;
   }
 }
 
@@ -434,59 +426,62 @@ __global__ void k_cells_scan_sums(unsigned long long* sums, int nb, int* __restr
   if (threadIdx.x == 0 && nvox) *nvox = (int)(carry_s >> 32);
 }
 
-// the second pass over one thread's SCAN_V entries: the sums of the workgroups before this one are added
-__device__ __forceinline__ void cells_scan_add(int* __restrict__ start, int n, int base, unsigned long long add, int* __restrict__ cell_voxel,
-                                               const ScanSplit& sp) {
-  const int add_s = (int)(unsigned)add, add_v = (int)(add >> 32);
-#pragma unroll
-  for (int j = 0; j < SCAN_V; j++) {
-    const int i = base + j;
-    if (i >= n) continue;
-    if (sp.nsplit < 0) {
-      start[i] += add_s;
-      if (cell_voxel && i < n - 1) {
-        const int cv = cell_voxel[i];
-        if (cv >= 0) cell_voxel[i] = cv + add_v;
-      }
-    } else if (i < sp.nsplit) {
-      start[i] += add_s;
-    } else {
-      const int cv = cell_voxel[i - sp.nsplit];
-      if (cv >= 0) {
-        cell_voxel[i - sp.nsplit] = cv + add_v;
-        sp.vox_cell[cv + add_v] = i - sp.nsplit;
-      }
-    }
-  }
-}
-
-// k_cells_scan_sums + k_cells_scan_add in one launch for grids of up to a few thousand scan blocks: every workgroup sums the
-// totals of the workgroups before it itself (<= 4096 values, strided loads + one reduction) instead of waiting for a
-// single-workgroup kernel to do it for all.
-__global__ void __launch_bounds__(SCAN_T) k_cells_scan_add_self(int* __restrict__ start, int n, const unsigned long long* __restrict__ block_sums,
-                                                                int nb, int* __restrict__ cell_voxel, int* __restrict__ nvox, int prio, ScanSplit sp) {
+// kSelf: block_sums holds the workgroups' TOTALS and this workgroup sums those before it itself (strided loads + one reduction: no
+// single-workgroup kernel in between); else block_sums has been scanned in place (k_cells_scan_sums) and holds the prefix.
+template <bool kSelf>
+__global__ void __launch_bounds__(SCAN_T) k_cells_scan_write(int* __restrict__ cnt, int* __restrict__ start, int n,
+                                                             const unsigned long long* __restrict__ block_sums, int nb, int* __restrict__ cell_voxel,
+                                                             int* __restrict__ nvox, int prio, ScanSplit sp) {
   wave_prio(prio);
   __shared__ unsigned long long part[SCAN_T / WAVE];
   __shared__ unsigned long long pre_s;
-  unsigned long long acc = 0;
-  for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_T) acc += block_sums[j];
-  for (int o = WAVE / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-  if ((threadIdx.x & (WAVE - 1)) == 0) part[threadIdx.x / WAVE] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long t = 0;
-    for (int w = 0; w < SCAN_T / WAVE; w++) t += part[w];
-    pre_s = t;
-    if ((int)blockIdx.x == nb - 1 && nvox) *nvox = (int)((t + block_sums[nb - 1]) >> 32);
+  const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
+  int v[SCAN_V];  // the entries are fetched first: their loads overlap the prefix of the totals
+  unsigned long long s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++) {
+    v[j] = (base + j < n) ? cnt[base + j] : 0;
+    s += scan_value(v[j], base + j, sp.nsplit);
   }
-  __syncthreads();
-  cells_scan_add(start, n, blockIdx.x * SCAN_B + threadIdx.x * SCAN_V, pre_s, cell_voxel, sp);
-}
-
-__global__ void k_cells_scan_add(int* __restrict__ start, int n, const unsigned long long* __restrict__ block_sums, int* __restrict__ cell_voxel,
-                                 int prio, ScanSplit sp) {
-  wave_prio(prio);
-  cells_scan_add(start, n, blockIdx.x * SCAN_B + threadIdx.x * SCAN_V, block_sums[blockIdx.x], cell_voxel, sp);
+  if (kSelf) {
+    unsigned long long acc = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_T) acc += block_sums[j];
+    for (int o = WAVE / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & (WAVE - 1)) == 0) part[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long t = 0;
+      for (int w = 0; w < SCAN_T / WAVE; w++) t += part[w];
+      pre_s = t;
+    }
+    __syncthreads();
+  } else if (threadIdx.x == 0) {
+    pre_s = block_sums[blockIdx.x];
+  }
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++)
+    if (base + j < n && v[j]) cnt[base + j] = 0;  // consumed: left clean for the next cloud, no fill kernel per frame
+  unsigned long long tot;
+  unsigned long long ex = block_exclusive_scan64(s, &tot);  // (its barriers publish pre_s)
+  ex += pre_s;
+  if (kSelf && threadIdx.x == 0 && (int)blockIdx.x == nb - 1 && nvox) *nvox = (int)((pre_s + tot) >> 32);
+#pragma unroll
+  for (int j = 0; j < SCAN_V; j++) {
+    const int i = base + j;
+    if (i < n) {
+      if (sp.nsplit < 0) {
+        start[i] = (int)(unsigned)ex;
+        if (cell_voxel && i < n - 1) cell_voxel[i] = v[j] > 0 ? (int)(ex >> 32) : -1;
+      } else if (i < sp.nsplit) {
+        start[i] = (int)(unsigned)ex;
+      } else {
+        const int id = v[j] != 0 ? (int)(ex >> 32) : -1;
+        cell_voxel[i - sp.nsplit] = id;
+        if (id >= 0) sp.vox_cell[id] = i - sp.nsplit;
+      }
+    }
+    ex += scan_value(v[j], i, sp.nsplit);
+  }
 }
 
 // placement without atomics: slot_of[] came back from k_count's atomicAdd
@@ -3514,12 +3509,12 @@ void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, in
   const int nb = nblk(n, SCAN_B);
   unsigned long long* bs = (unsigned long long*)block_sums;
   const ScanSplit sp{nsplit, vox_cell};
-  hipLaunchKernelGGL(k_cells_scan_block, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, cell_voxel, nvox, hi, sum_sq, sp);
-  if (nb > 1 && nb <= 4096) {
-    hipLaunchKernelGGL(k_cells_scan_add_self, dim3(nb), dim3(SCAN_T), 0, s, start, n, bs, nb, cell_voxel, nvox, hi, sp);
-  } else if (nb > 1) {
+  if (nb > 1 || sum_sq) hipLaunchKernelGGL(k_cells_reduce, dim3(nb), dim3(SCAN_T), 0, s, cnt, n, bs, hi, sum_sq, sp);
+  if (nb <= 4096) {
+    hipLaunchKernelGGL(k_cells_scan_write<true>, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, nb, cell_voxel, nvox, hi, sp);
+  } else {
     hipLaunchKernelGGL(k_cells_scan_sums, dim3(1), dim3(SCAN_T), 0, s, bs, nb, nvox, hi);
-    hipLaunchKernelGGL(k_cells_scan_add, dim3(nb), dim3(SCAN_T), 0, s, start, n, bs, cell_voxel, hi, sp);
+    hipLaunchKernelGGL(k_cells_scan_write<false>, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, nb, cell_voxel, nvox, hi, sp);
   }
 }
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi) {
