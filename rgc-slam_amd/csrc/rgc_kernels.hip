@@ -88,8 +88,11 @@ __device__ __forceinline__ double quad_sum_f64(double v) {  // (l0 + l1) + (l2 +
 // The scan's (source) preprocessing runs on a second stream underneath the map's VALU-bound kNN launch; its waves share
 // CUs with that kernel and would get ~1/8 of the issue slots.  Raising the wave priority lets the small latency-chained
 // source kernels finish while the big kernel soaks up what is left.
+// Three levels: the map's throughput kernels stay at 0, the scan's preparation runs at 2, the solve's steps and the score -- the
+// frame's critical chain, which with two contexts share the chip with the NEXT scan's preparation -- at 3.
 __device__ __forceinline__ void wave_prio(int hi) {
-  if (hi) __builtin_amdgcn_s_setprio(3);
+  if (hi >= 2) __builtin_amdgcn_s_setprio(3);
+  else if (hi) __builtin_amdgcn_s_setprio(2);
 }
 
 // Developer build (-DRGC_LAB): how often the wave-level loops of the map's bulk kNN kernel run -- with the kernel's ISA that gives the
@@ -2789,7 +2792,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
           int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st, int first,
           LmInit in, const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s, LmState* __restrict__ h_post,
           int seq) {
-  wave_prio(1);  // a latency chain: issue ahead of whatever throughput-bound launch shares the CU (the other context's kNN)
+  wave_prio(2);  // a latency chain: issue ahead of whatever shares the CU (the other context's kNN, the next scan's preparation)
   // first != 0: this launch opens a solve.  Nobody reads the (stale) state: mode, buffer and pose come from the kernel
   // arguments, and the last-arriving workgroup's lane 0 writes the fresh state (:53-63) before it uses it -- no separate
   // initialisation launch, no H2D copy.  The tickets are 0 between launches by construction (the last arriver resets them).
@@ -3084,7 +3087,7 @@ __global__ void __launch_bounds__(FIT_T)
 k_fitness_lm(const float4* __restrict__ SP, int ns, LmState* __restrict__ st, const float4* __restrict__ TP,
              const int* __restrict__ tstart, Grid g, double* __restrict__ partials, LmState* __restrict__ h_post, int seq) {
   if (!st->done || st->has_fit) return;  // enqueued blindly behind a batch of LM slots (and once more behind a later batch)
-  wave_prio(1);
+  wave_prio(2);
   PoseF T;
 #pragma unroll
   for (int a = 0; a < 12; a++) T.m[a] = (float)st->x0[a];  // final_transformation_ = x0.cast<float>(), :77
