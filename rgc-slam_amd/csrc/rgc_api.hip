@@ -791,7 +791,7 @@ int do_fitness(rgc_ctx* c, const float T[16], double* out) {
   {
     ProfScope ps(c, RGC_K_FITNESS, n);
     rgck::fitness(c->stream, (const float4*)c->src.P.p, n, posef_from(T), (const float4*)c->tgt.P.p, (const int*)c->tgt.start.p,
-                  c->tgt.grid, (double*)c->partials.p, c->d_out);
+                  c->tgt.grid, (double*)c->partials.p, c->d_out, c->tgt.n);
   }
   HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1283,7 +1283,7 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
   };
   auto score = [&]() {  // getFitnessScore at the final pose, chained blindly
     rgck::fitness_lm(s, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
-                     (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p, post, c->lm_seq);
+                     (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p, post, c->lm_seq, c->tgt.n);
   };
   // the stage-by-stage pass (events around the solve's regions) keeps the two apart: all steps, then the score
   const bool staged = c->prof_on && ((c->prof_mask >> RGC_K_LINEARIZE) & 1u || (c->prof_mask >> RGC_K_FITNESS) & 1u);

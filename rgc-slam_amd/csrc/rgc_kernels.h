@@ -136,8 +136,9 @@ void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
              const LmInit* first /* non-null: this launch opens a solve */, const int* nvox, const void* segs_t, const void* segs_s,
              LmState* h_post = nullptr /* mapped host memory: a finished state is posted there, then seq in its `gen` */, int seq = 0 /* > 0: post when done; < 0: fitness_lm posts */);
+// nt: the target's point count (a small map is scanned whole by the wave for a query its first cube does not settle; 0: never)
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials,
-                LmState* h_post = nullptr, int seq = 0);
+                LmState* h_post = nullptr, int seq = 0, int nt = 0);
 // ---- f1: mapping-node feature registration (RGC_mapping.cpp:1069-1358) ----
 // factor record = 8 doubles per feature: edge {a[3], b[3], var, valid}, plane {n[3], d, 0, 0, var, valid}
 struct MapregAssoc {  // one association loop: feature set (n x 4: x,y,z,weight), its pose, the map grid it is matched against
@@ -157,7 +158,7 @@ void icp_accumulate(hipStream_t s, const float4* SP, int ns, const float4* TP, c
                     double* out28);
 // ---- C8 ----
 void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials,
-             double* out1);
+             double* out1, int nt = 0);
 // ---- misc ----
 void transform_f32(hipStream_t s, const float* in, int stride_f, int n, PoseF T, float* out, int out_stride_f);
 void unsort3(hipStream_t s, const double* a, const double* b, const double* c, const float4* P, int n, double* out3);

@@ -2913,9 +2913,11 @@ int fitness_blocks(int n) { return (n + FIT_T - 1) / FIT_T; }
 // unscanned region is farther than cap_r (then nothing within cap_r is missing).  Ties: smaller original index.
 // best = squared distance (INFINITY if none found), bs = position in the sorted array (-1 if none; only tracked if kIndex:
 // the fitness score needs the distance alone, and the index bookkeeping costs it a third of its time).
+// unresolved (nullable): instead of growing the cube beyond its first size the search gives up and sets the flag -- the caller has a
+// cheaper way for what is left (a small map: the whole wave scans all of it, fitness_wave)
 template <bool kIndex>
 __device__ __forceinline__ void nn_search(float px, float py, float pz, const float4* __restrict__ TP, const int* __restrict__ tstart,
-                                          const Grid& g, double cap_r, float& best, int& bs) {
+                                          const Grid& g, double cap_r, float& best, int& bs, bool* unresolved = nullptr) {
   const int c[3] = {cell_coord(px, g) - g.minc[0], cell_coord(py, g) - g.minc[1], cell_coord(pz, g) - g.minc[2]};
   const double q[3] = {(double)px, (double)py, (double)pz};
   int rmax = 0, r = 1;
@@ -3013,6 +3015,12 @@ __device__ __forceinline__ void nn_search(float px, float py, float pz, const fl
     int rn;
     if (best < INFINITY) {
       if (bound > 0.0 && (double)best < bound * bound * (1.0 - 1e-5)) break;
+    }
+    if (unresolved) {
+      *unresolved = true;
+      return;
+    }
+    if (best < INFINITY) {
       const double need = sqrt((double)best) * (1.0 + 1e-5);
       rn = r + 1;
       while (rn < rmax) {
@@ -3029,7 +3037,7 @@ __device__ __forceinline__ void nn_search(float px, float py, float pz, const fl
 
 // squared distance from the transformed source point i to its nearest target point
 __device__ __forceinline__ float fitness_point(const float4* __restrict__ SP, int i, const PoseF& T, const float4* __restrict__ TP,
-                                               const int* __restrict__ tstart, const Grid& g) {
+                                               const int* __restrict__ tstart, const Grid& g, bool* unresolved = nullptr, float* moved = nullptr) {
   const float4 sp = SP[i];
   const float x = sp.x, y = sp.y, z = sp.z;
   const float px = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
@@ -3037,7 +3045,8 @@ __device__ __forceinline__ float fitness_point(const float4* __restrict__ SP, in
   const float pz = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
   float best;
   int bs;
-  nn_search<false>(px, py, pz, TP, tstart, g, 1.0e300, best, bs);
+  nn_search<false>(px, py, pz, TP, tstart, g, 1.0e300, best, bs, unresolved);
+  if (moved) { moved[0] = px; moved[1] = py; moved[2] = pz; }
   return best;
 }
 
@@ -3074,25 +3083,66 @@ k_icp_accumulate(const float4* __restrict__ SP, int ns, const float4* __restrict
   block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
 }
 
+// One wave's share of the scan against the map (FIT_T == WAVE); returns the wave's sum of squared nearest distances.
+// n_all > 0 -- a SMALL map, the odometer's own three keyframes: ~11 k points, one per ten cells of its grid, and of a sweep's 11 k
+// points several hundred lie 1-7 m from it (the keyframes hold the less-flat feature cloud, not whole sweeps).  Growing the cube for
+// those is (2r+1)^2 mostly empty rows per level, and the launch lasted as long as its farthest lanes: 84 us.  Instead
+//   * a query that its own cell and the first cube around it do not settle is handed to the WHOLE WAVE, which scans all n_all map points
+//     for it (n_all / 64 coalesced loads per lane, the same dist2(), the minimum over the lanes: the exact nearest distance again), and
+//   * the wave takes every (number of waves)-th point of the cell-sorted scan, not 64 consecutive ones: a sweep's far points are
+//     neighbours, and a wave that holds 64 of them scans the map 64 times while the others idle.
+__device__ __forceinline__ double fitness_wave(const float4* __restrict__ SP, int ns, const PoseF& T, const float4* __restrict__ TP,
+                                               const int* __restrict__ tstart, const Grid& g, int n_all) {
+  static_assert(FIT_T == WAVE, "one wave per workgroup");
+  const int lane = (int)threadIdx.x;
+  const int i = n_all > 0 ? lane * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * FIT_T + lane;
+  float best = 0.f, q[3] = {0.f, 0.f, 0.f};
+  bool unresolved = false;
+  if (i < ns) best = fitness_point(SP, i, T, TP, tstart, g, n_all > 0 ? &unresolved : nullptr, q);
+  if (n_all > 0) {
+    unsigned long long todo = __ballot(unresolved);
+    while (todo) {
+      const int l = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const float qx = __shfl(q[0], l), qy = __shfl(q[1], l), qz = __shfl(q[2], l);
+      float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+      int s = lane;
+      for (; s + 7 * WAVE < n_all; s += 8 * WAVE) {  // eight loads in flight per lane
+        float4 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) c[u] = TP[s + u * WAVE];
+#pragma unroll
+        for (int u = 0; u < 8; u += 4) {
+          m0 = fminf(m0, dist2(qx, qy, qz, c[u])); m1 = fminf(m1, dist2(qx, qy, qz, c[u + 1]));
+          m2 = fminf(m2, dist2(qx, qy, qz, c[u + 2])); m3 = fminf(m3, dist2(qx, qy, qz, c[u + 3]));
+        }
+      }
+      for (; s < n_all; s += WAVE) m0 = fminf(m0, dist2(qx, qy, qz, TP[s]));
+      const float mine = fminf(fminf(m0, m1), fminf(m2, m3));
+      const float all = __int_as_float(wave_min(__float_as_int(mine)));  // (squared distances are >= +0: they order like their bit patterns)
+      if (lane == l) best = all;
+    }
+  }
+  return wave_sum(i < ns ? (double)best : 0.0);
+}
+
 __global__ void __launch_bounds__(FIT_T)
 k_fitness(const float4* __restrict__ SP, int ns, PoseF T, const float4* __restrict__ TP,
-          const int* __restrict__ tstart, Grid g, double* __restrict__ partials) {
-  const int i = blockIdx.x * FIT_T + threadIdx.x;
-  const double v = wave_sum(i < ns ? (double)fitness_point(SP, i, T, TP, tstart, g) : 0.0);
+          const int* __restrict__ tstart, Grid g, double* __restrict__ partials, int n_all) {
+  const double v = fitness_wave(SP, ns, T, TP, tstart, g, n_all);
   if (threadIdx.x == 0) partials[blockIdx.x] = v;
 }
 
 // the same with the final pose taken from the device-resident LM state; the last block folds the rows into the state
 __global__ void __launch_bounds__(FIT_T)
 k_fitness_lm(const float4* __restrict__ SP, int ns, LmState* __restrict__ st, const float4* __restrict__ TP,
-             const int* __restrict__ tstart, Grid g, double* __restrict__ partials, LmState* __restrict__ h_post, int seq) {
+             const int* __restrict__ tstart, Grid g, double* __restrict__ partials, LmState* __restrict__ h_post, int seq, int n_all) {
   if (!st->done || st->has_fit) return;  // enqueued blindly behind a batch of LM slots (and once more behind a later batch)
   wave_prio(2);
   PoseF T;
 #pragma unroll
   for (int a = 0; a < 12; a++) T.m[a] = (float)st->x0[a];  // final_transformation_ = x0.cast<float>(), :77
-  const int i = blockIdx.x * FIT_T + threadIdx.x;
-  const double v = wave_sum(i < ns ? (double)fitness_point(SP, i, T, TP, tstart, g) : 0.0);
+  const double v = fitness_wave(SP, ns, T, TP, tstart, g, n_all);
   if (threadIdx.x == 0) __hip_atomic_store(&partials[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through row
   if (!last_block_arrive(&st->ticketB)) return;  // the LM is over: its ticket is free
   double t = 0;
@@ -3644,13 +3694,15 @@ void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny,
   hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
                      corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s, h_post, seq);
 }
+// a map of at most this many points is scanned whole by the wave for a query its first cube does not settle (fitness_wave)
+static int fitness_scan_all(int nt) { return nt > 0 && nt <= 32768 ? nt : 0; }
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials, LmState* h_post,
-                int seq) {
-  hipLaunchKernelGGL(k_fitness_lm, dim3(fitness_blocks(ns)), dim3(FIT_T), 0, s, SP, ns, st, TP, tstart, g, partials, h_post, seq);
+                int seq, int nt) {
+  hipLaunchKernelGGL(k_fitness_lm, dim3(fitness_blocks(ns)), dim3(FIT_T), 0, s, SP, ns, st, TP, tstart, g, partials, h_post, seq, fitness_scan_all(nt));
 }
-void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials, double* out1) {
+void fitness(hipStream_t s, const float4* SP, int ns, PoseF T, const float4* TP, const int* tstart, Grid g, double* partials, double* out1, int nt) {
   const int nb = fitness_blocks(ns);
-  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(FIT_T), 0, s, SP, ns, T, TP, tstart, g, partials);
+  hipLaunchKernelGGL(k_fitness, dim3(nb), dim3(FIT_T), 0, s, SP, ns, T, TP, tstart, g, partials, fitness_scan_all(nt));
   hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
 }
 void icp_accumulate(hipStream_t s, const float4* SP, int ns, const float4* TP, const int* tstart, Grid g, double max_dist, double* partials,
