@@ -796,3 +796,29 @@ def test_reframed_target_equals_transform_then_set(reg_mod, orc, medium):
     for p in (d_map_w, d_out_w):
         w.device_free(p)
     v.close(); w.close()
+
+
+def test_fitness_on_a_small_sparse_map(reg_mod, orc, medium):
+    """The score against a map of a few thousand points (the odometer's own kind of sub-map: <= 32 k points take the path in which a whole
+    wave scans the map for the queries their first search cube does not settle, and waves take every n-th scan point): the separate
+    launch (rgc_fitness) and the one chained behind the solve both equal the oracle's, with the scan on the map, metres off it, and with
+    a part of the scan that has no map within metres."""
+    tgt = medium["tgt"][::12].copy()
+    assert 5000 < len(tgt) < 32768
+    src = medium["src"]
+    v = _odo(reg_mod)
+    o = orc.Registration(max_iterations=25, translation_eps=1e-6, num_threads=0)
+    for T_map in (tgt, tgt[tgt[:, 0] > -10.0]):                     # the whole thinned map; the same with a side of the scene cut away
+        v.setInputTarget(T_map); v.setInputSource(src)
+        o.set_target(T_map); o.set_source(src); o.prepare()
+        for T in (np.eye(4, dtype=np.float32), medium["T_true"].astype(np.float32),
+                  np.array([[1, 0, 0, 6.0], [0, 1, 0, -4.0], [0, 0, 1, 0.5], [0, 0, 0, 1]], np.float32)):
+            f, fo = v.fitnessAt(T), o.fitness(T)
+            assert abs(f - fo) <= 1e-6 * fo, (f, fo)
+        Tg = v.align(np.eye(4, dtype=np.float32), want_output=False, want_fitness=True)     # k_fitness_lm behind the solve
+        Tg = v.getFinalTransformation()
+        f_chain, f_sep = v.getFitnessScore(), v.fitnessAt(Tg)
+        assert f_chain == f_sep, (f_chain, f_sep)                    # same kernel body, same partial sums, same fold
+        fo = o.fitness(Tg)
+        assert abs(f_chain - fo) <= 1e-6 * fo
+    v.close()
