@@ -29,6 +29,7 @@ bash scripts/prof_dependent.sh 40 0 > $O/dependent_frame_kernels.txt 2>&1
 python3 scripts/timeline_window.py gpurun_out/prof_dep 1100 3000 > $O/dependent_frame_timeline.txt 2>&1
 if [ "$1" != quick ]; then
   python scripts/exp_long_run.py 3000 2>/dev/null | tail -1 > $O/long_run.json
+  python scripts/exp_long_run_dependent.py 50 2>/dev/null | tail -1 > $O/long_run_dependent.json
   python scripts/bench_rolling.py > $O/rolling.json 2> /dev/null
   python scripts/bench_cpp_node.py > $O/cpp_node.json 2> /dev/null
   python scripts/bench_cpp_pipeline.py 2>/dev/null | tail -1 > $O/cpp_pipeline.json

@@ -100,6 +100,13 @@ if longr:
     numbers += (f"Steady state (`profiles/{TAG}_long_run.json`, {longr['frames']} consecutive frames of the replay, one at a time): median {longr['ms_median']:.3f} ms, p99 {longr['ms_p99']:.3f}, "
                 f"maximum {longr['ms_max']:.2f}, {longr['frames_over_1ms']} frame(s) over 1 ms, working set {longr['working_set_MiB']:.0f} MiB with "
                 f"{longr['steady_state_growth_MiB_frames_200_to_end']} MiB growth between frame 200 and the end, every repetition of an input gives the bit-identical pose.\n")
+ld = load("long_run_dependent.json")
+if ld:
+    a, b = ld["one_context"], ld["two_contexts"]
+    numbers += (f"The dependent sequence itself (`profiles/{TAG}_long_run_dependent.json`: the same {ld['frames_per_repetition']} frames {ld['repetitions']} times over from the same start): "
+                f"{a['scans_per_s_median']:.0f} scans/s on one context (median {a['ms_per_frame_median']:.3f} ms per frame, {a['ms_per_frame_min_max'][0]:.3f}–{a['ms_per_frame_min_max'][1]:.3f} per repetition), "
+                f"{b['scans_per_s_median']:.0f} on two ({b['ms_per_frame_median']:.3f} ms), every repetition and both modes bit-identical poses, "
+                f"{a['growth_MiB_after_the_second_repetition']} / {b['growth_MiB_after_the_second_repetition']} MiB of growth after the second repetition.\n")
 if node:
     numbers += (f"\nThe C++ node (`profiles/{TAG}_cpp_node_bench.json`, 24 sweeps × 28.8 k points, message bytes in → pose out; mean / median of the timed sweeps): "
                 f"reference semantics {node['cpp_reference_semantics_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_median_ms', float('nan')):.2f} ms host-staged and "
