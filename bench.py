@@ -21,7 +21,8 @@ Extra keys beside the contract's: `one_frame_at_a_time` (the same steps on one c
 `replay_of_preframed_maps` (round 2's figure: targets that do NOT depend on the previous pose -- three translated copies of the map in
 turn -- so that a whole frame's preparation overlaps the previous solve; what a replay of pre-framed sub-maps reaches, not a live
 sequence), `scan_h2d_and_output` (the dependent steps with each scan uploaded from pinned host memory inside the step and align()'s
-output cloud produced on the device), `issue_roofline` (the dominant kernel against the measured VALU issue rates), `configs`
+output cloud produced on the device), `steady_state` (the K timed steps repeated ten times back to back without HIP events in the
+loop: what a sequence that keeps running sustains), `issue_roofline` (the dominant kernel against the measured VALU issue rates), `configs`
 (BASELINE.json's other single-GPU configurations, a few frames each, with their own hbm_frac_whole_frame).
 """
 import argparse
@@ -478,6 +479,24 @@ def main():
     pv.synchronize()
     elapsed_replay = time.perf_counter() - t3
     replay_err = float(max(np.abs(to_world(W + j, T).astype(np.float64) - worlds[j]).max() for j, T in enumerate(Ts)))
+    # The K timed steps are ~18 ms of GPU work behind a warm-up of W steps, with the dominant kernel bracketed by HIP events (two records per
+    # frame: ~3 % of a frame).  The same K steps repeated back to back without the events (an extra key, not `value`): what a sequence
+    # that keeps running sustains, and a check that every repetition gives the timed run's poses bit for bit.
+    REPS = 10
+    steady = {}
+    for mode, overlap in (("two_contexts", True), ("one_frame_at_a_time", False)):
+        per, same = [], True
+        for r in range(REPS):
+            pv.synchronize()
+            tr = time.perf_counter()
+            mr, _, _ = seq.run(W, K, Tw_start, g_start, overlap)
+            pv.synchronize()
+            per.append(time.perf_counter() - tr)
+            same = same and all(np.array_equal(a_, b_) for a_, b_ in zip(motions, mr))
+        med = float(np.median(per[2:]))
+        steady[mode] = {"scans_per_s": round(K / med, 3), "ms_per_step": round(1e3 * med / K, 4), "same_poses_every_repetition": bool(same)}
+    steady["what"] = (f"the K timed steps repeated {REPS} times back to back with no HIP events in the loop, median of the last {REPS - 2} repetitions: the "
+                      f"rate of a sequence that keeps running, beside `value` (first pass behind W warm-up steps, dominant kernel bracketed by events)")
     # the dominant kernel by itself (nothing else on the GPU): what the kernel costs, as opposed to what it costs while it shares the chip
     v.profile_enable(True)
     v.profile_select([DOMINANT])
@@ -584,6 +603,7 @@ def main():
                                              "preparation overlaps the previous solve -- round 2's `value`; a replay of pre-framed sub-maps, not a live sequence"},
         "scan_h2d_and_output": {"scans_per_s": round(K / elapsed_h2d, 3), "ms_per_step": round(1e3 * elapsed_h2d / K, 3), "same_final_pose": h2d_same,
                                 "what": "the dependent steps; each scan uploaded from pinned host memory inside the step, align()'s output cloud written to a device buffer"},
+        "steady_state": steady,
         "final_pose_checksum": float(np.sum(np.abs(np.asarray(worlds, np.float64)))),
     }
 

@@ -100,6 +100,10 @@ if longr:
     numbers += (f"Steady state (`profiles/{TAG}_long_run.json`, {longr['frames']} consecutive frames of the replay, one at a time): median {longr['ms_median']:.3f} ms, p99 {longr['ms_p99']:.3f}, "
                 f"maximum {longr['ms_max']:.2f}, {longr['frames_over_1ms']} frame(s) over 1 ms, working set {longr['working_set_MiB']:.0f} MiB with "
                 f"{longr['steady_state_growth_MiB_frames_200_to_end']} MiB growth between frame 200 and the end, every repetition of an input gives the bit-identical pose.\n")
+ss = d.get("steady_state")
+if ss:
+    numbers += (f"Repeated back to back without the HIP events around the dominant kernel (`steady_state` in the bench line: the K timed steps ten times over, median of the "
+                f"last eight): {ss['two_contexts']['scans_per_s']:.0f} scans/s on two contexts, {ss['one_frame_at_a_time']['scans_per_s']:.0f} one frame at a time, the timed run's poses on every repetition.\n")
 ld = load("long_run_dependent.json")
 if ld:
     a, b = ld["one_context"], ld["two_contexts"]
