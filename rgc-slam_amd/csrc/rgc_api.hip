@@ -493,11 +493,31 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
                       (float4*)cl.P.p, (int*)cl.segs.p, hi);
   }
   {
-    ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n, s);
     // a sparse map (points per cell of its grid below map_wide_density): the wider block, see k_knn_sp_wide
     const int wide_r = (is_target && c->map_wide_r > 0 && (double)n < c->map_wide_density * (double)cl.vgrid.ncell) ? c->map_wide_r : 0;
-    rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
-                   (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r);
+    const int kind = is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC;
+    // The dense map's launch (the dominant kernel) is timed by ITS OWN start / stop times (hipExtLaunchKernelGGL fills the two events):
+    // two hipEventRecord packets around it cost ~3 % of a frame of a dependent sequence on two contexts (bench.py's timed region).
+    ProfRegion own{};
+    bool self_timed = false;
+    if (c->prof_on && ((c->prof_mask >> kind) & 1u) && rgck::knn_bulk_times_itself(is_target, cl.grid, wide_r)) {
+      auto get = [&](hipEvent_t* e) {
+        if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
+        return hipEventCreate(e) == hipSuccess;
+      };
+      self_timed = get(&own.a) && get(&own.b);
+      own.kind = kind;
+      own.points = n;
+    }
+    if (self_timed) {
+      rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
+                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, own.a, own.b);
+      c->prof_open.push_back(own);
+    } else {
+      ProfScope ps(c, kind, n, s);
+      rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
+                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r);
+    }
   }
   // The map's deferred queries (~100 of a million, one wave each: 20 us of latency) are resolved in the SAME launch as the voxel map's
   // build (k_voxel_build_coop); the few voxels that hold one are recomputed behind it (k_voxel_patch).  The scan has no voxel map, the

@@ -104,7 +104,9 @@ void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int*
 size_t deferred_bytes(int n);
 // wide_r = 2: the four-lanes-per-query search on the 5^3 block whatever the cloud (a sparse map)
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
-              double* ny, double* nz, const int* guard = nullptr, int wide_r = 0);
+              double* ny, double* nz, const int* guard = nullptr, int wide_r = 0,
+              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* dense-map launch only (knn_bulk_times_itself): the launch's own start / stop times */);
+bool knn_bulk_times_itself(bool is_target, Grid g, int wide_r);
 // waves: one-wave workgroups that share the deferred list (clamped to [32, 8192])
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard, int waves);

@@ -22,6 +22,7 @@
 //   launch wrappers at the end (namespace rgck, declared in rgc_kernels.h)
 #include "rgc_kernels.h"
 #include "rgc_lm.h"
+#include <hip/hip_ext.h>
 
 #include <limits.h>
 #include <stddef.h>
@@ -3595,7 +3596,7 @@ static Deferred deferred_of(const void* buf, int n) {
 
 template <int KC, bool kExact>
 static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred,
-                        double* nx, double* ny, double* nz, const int* guard, int wide_r) {
+                        double* nx, double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
   if (g.sub == 2) {  // the dense map's half-size search grid
@@ -3616,7 +3617,9 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   const int T = is_target ? CT::T : CS::T;
   const size_t lds = (size_t)(is_target ? SpShape<CT::R, CT::kClip>::LDS : SpShape<CS::R, CS::kClip>::LDS) * T * sizeof(int);
   const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
-  if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+  // (ev0 / ev1: the launch's own start / stop times go into the caller's events -- no separate record packets around it)
+  if (is_target && ev0 && ev1) hipExtLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), (std::uint32_t)lds, s, ev0, ev1, 0u, P, start, g, n, k, df, nx, ny, nz);
+  else if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
   else hipLaunchKernelGGL((k_knn_sp<KC, false, kExact>), dim3(nblk(n, T / 4)), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);  // four lanes per query
 }
 template <int KC>
@@ -3632,12 +3635,13 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
   else
     hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(WAVE), 0, s, P, start, g, k, df, nx, ny, nz);
 }
+bool knn_bulk_times_itself(bool is_target, Grid g, int wide_r) { return is_target && g.sub == 1 && wide_r != 2; }
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
-              double* ny, double* nz, const int* guard, int wide_r) {
+              double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1) {
   // (k == 20, the reference's setting, gets an instance without the general-k branches)
-  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
-  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
-  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r);
+  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1);
+  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1);
+  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1);
 }
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
               double* ny, double* nz, const int* guard, int waves) {
