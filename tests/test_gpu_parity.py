@@ -822,3 +822,46 @@ def test_fitness_on_a_small_sparse_map(reg_mod, orc, medium):
         fo = o.fitness(Tg)
         assert abs(f_chain - fo) <= 1e-6 * fo
     v.close()
+
+
+def test_reframed_target_with_a_stale_box(reg_mod, orc, medium):
+    """The box rgc_set_target_reframed derives for the re-framed map comes from the INPUT buffer's box, measured once per buffer.  If the
+    caller rewrites that buffer with a larger cloud behind the library's back the derived box no longer holds every point: the counting
+    pass's guard reports it with the solve's state, the target is prepared again on its own bounding box (from the re-framed cloud the
+    counting pass has written meanwhile) and the solve repeated -- the pose and the covariances of transform + set on the new cloud."""
+    import bench
+    import rgc_slam_amd.synth as synth
+    tgt = medium["tgt"]
+    n = len(tgt)
+    small = tgt.copy()
+    small[:, :2] *= 0.5                                   # the same points pulled towards the origin: a box of half the extent
+    a_small, a_big = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+    a_small[:, :3], a_big[:, :3] = small, tgt
+    v, w = _odo(reg_mod), _odo(reg_mod)
+    d_map, d_body = v.device_alloc(a_big.nbytes), v.device_alloc(a_big.nbytes)
+    d_map_w, d_out_w = w.device_alloc(a_big.nbytes), w.device_alloc(a_big.nbytes)
+    Tw = synth.se3(synth.rot_zyx(0.3, 0.0, 0.01), [1.0, -0.5, 0.0])
+    q, t = bench.world_to_body(Tw)
+    v.upload(d_map, a_small)
+    v.setInputTargetReframed(d_map, n, 16, q, t, d_body)  # the box of the SMALL cloud is remembered for this buffer
+    v.setInputSource(medium["src"])
+    v.align(np.eye(4, dtype=np.float32), want_output=False)
+    v.upload(d_map, a_big)                                # same buffer, same count, twice the extent
+    v.setInputTargetReframed(d_map, n, 16, q, t, d_body)
+    v.setInputSource(medium["src"])
+    v.align(np.eye(4, dtype=np.float32), want_output=False, want_fitness=True)
+    w.upload(d_map_w, a_big)
+    w.transformCloudDevice(d_map_w, n, 16, q, t, d_out_w)
+    w.setInputTargetDevice(d_out_w, n, 16)
+    w.setInputSource(medium["src"])
+    w.align(np.eye(4, dtype=np.float32), want_output=False, want_fitness=True)
+    assert np.array_equal(v.getFinalTransformation(), w.getFinalTransformation()) and v.getFitnessScore() == w.getFitnessScore()
+    assert np.array_equal(v.getTargetCovariances(), w.getTargetCovariances())
+    assert np.array_equal(v.download(d_body, (n, 4)), w.download(d_out_w, (n, 4)))
+    v.setInputTargetReframed(d_map, n, 16, q, t, d_body)  # and the buffer's box has been measured again: no second miss
+    assert np.array_equal(v.getTargetCovariances(), w.getTargetCovariances())
+    for p in (d_map, d_body):
+        v.device_free(p)
+    for p in (d_map_w, d_out_w):
+        w.device_free(p)
+    v.close(); w.close()
