@@ -183,6 +183,13 @@ RGC_API int rgc_deskew(rgc_ctx* ctx, float* xyzi, int n, int stride_bytes, const
  * box first; the output does not depend on the box, and a cloud that leaves it is filtered again on its own.) */
 RGC_API int rgc_voxelgrid(rgc_ctx* ctx, const float* xyzi, int n, int stride_bytes, float leaf, float* out_xyzi, int* n_out,
                           int on_device);
+/* The same filter for a DEVICE cloud in two halves: begin enqueues it (on the leaf box kept from the previous cloud of this leaf size) and
+ * returns, end waits and returns the point count -- repeating the filter when the kept box did not hold the cloud, so d_xyzi and d_out must
+ * stay untouched in between.  The odometer's sub-map filter (src/RGC_odometer.cpp:985-991) depends only on the previous frame's pose: begun
+ * when that frame ends and ended after the next sweep's own filter, it is off the frame's critical path.  Other rgc_voxelgrid calls may run
+ * in between; one begin may be open per context. */
+RGC_API int rgc_voxelgrid_begin(rgc_ctx* ctx, const float* d_xyzi, int n, int stride_bytes, float leaf, float* d_out);
+RGC_API int rgc_voxelgrid_end(rgc_ctx* ctx, int* n_out);
 /* B9  vg_ICP::transformPointCloud(cloud, q, t) (src/RGC_odometer.cpp:1495-1514): q * p + t in fp64, stored fp32,
  * intensity copied; out_xyzi: n*4 floats.  on_device: both pointers are device memory and the call returns once the kernel is enqueued
  * on rgc_stream(ctx), like rgc_deskew. */

@@ -116,7 +116,7 @@ SYMBOLS = [
     "rgc_clear_source", "rgc_clear_target", "rgc_swap_source_and_target", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_imu_filter_init", "rgc_imu_filter_push", "rgc_ground_gate_init", "rgc_ground_gate_remember", "rgc_ground_gate_step", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
-    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_transform_cloud", "rgc_set_target_reframed", "rgc_frontend_device", "rgc_frontend_cloud_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_map_reset", "rgc_map_insert", "rgc_map_evict", "rgc_map_rebase", "rgc_map_commit", "rgc_map_get_info", "rgc_map_download", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
+    "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_voxelgrid_begin", "rgc_voxelgrid_end", "rgc_transform_cloud", "rgc_set_target_reframed", "rgc_frontend_device", "rgc_frontend_cloud_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_map_reset", "rgc_map_insert", "rgc_map_evict", "rgc_map_rebase", "rgc_map_commit", "rgc_map_get_info", "rgc_map_download", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
 
 _lib = None
@@ -198,6 +198,8 @@ def load():
     L.rgc_ypr2R.restype = None
     L.rgc_deskew.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, C.c_int]
     L.rgc_voxelgrid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, ip, C.c_int]
+    L.rgc_voxelgrid_begin.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp]
+    L.rgc_voxelgrid_end.argtypes = [vp, ip]
     L.rgc_transform_cloud.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, vp, C.c_int]
     L.rgc_set_target_reframed.argtypes = [vp, vp, C.c_int, C.c_int, dp, dp, vp]
     L.rgc_default_icp_params.argtypes = [C.POINTER(IcpParams)]

@@ -206,8 +206,13 @@ private:
         chk(rgc_map_commit(ctx_, 0.3f, nullptr));                                              // :985-991, 1007 (only if a keyframe changed)
       } else if (chain) {   // the reference's local map, kept on the device: the re-framed keyframes -> leaf filter -> target, no PCIe crossing
         int n_tgt = 0;
-        reserve(d_target_, (size_t)16 * (size_t)(n_submap_ > 0 ? n_submap_ : 1));
-        chk(rgc_voxelgrid(ctx_, d_submap_.p, n_submap_, 16, 0.3f, d_target_.p, &n_tgt, 1));       // :985-991
+        if (target_begun_) {   // the sub-map's filter was started when the previous frame ended (maintain_map): only its count is fetched here
+          chk(rgc_voxelgrid_end(ctx_, &n_tgt));                                                  // :985-991
+          target_begun_ = false;
+        } else {
+          reserve(d_target_, (size_t)16 * (size_t)(n_submap_ > 0 ? n_submap_ : 1));
+          chk(rgc_voxelgrid(ctx_, d_submap_.p, n_submap_, 16, 0.3f, d_target_.p, &n_tgt, 1));     // :985-991
+        }
         pose_to_mat(q_last_curr_, t_last_curr_, guess);                                         // :993-996
         chk(rgc_set_target_device(ctx_, d_target_.p, n_tgt, 16));                               // :1007
       } else {
@@ -420,13 +425,25 @@ private:
         double ti[3];
         qrot(qi, t_w_, ti);
         for (int a = 0; a < 3; a++) ti[a] = -ti[a];
-        size_t total = 0;
-        for (const auto& kf : d_kf_) total += (size_t)kf.n;
-        reserve(d_submap_, (size_t)16 * (total > 0 ? total : 1));
+        size_t total = 0, largest = 0;
+        for (const auto& kf : d_kf_) { total += (size_t)kf.n; largest = std::max(largest, (size_t)kf.n); }
+        // (sized for a full window of keyframes at once: growing it when the third keyframe arrives is a hipFree + hipMalloc, several ms
+        // in whichever frame that is)
+        const size_t window = std::max(total, (size_t)opt_.max_keyframes * largest);
+        reserve(d_submap_, (size_t)16 * (window > 0 ? window : 1));
+        reserve(d_target_, (size_t)16 * (window > 0 ? window : 1));
         for (const auto& kf : d_kf_) {
           chk(rgc_transform_cloud(ctx_, kf.p, kf.n, 16, qi, ti, d_submap_.p + (size_t)4 * (size_t)n_submap_, 1));
           n_submap_ += kf.n;
         }
+      }
+      // The next frame's target is this sub-map through the 0.3 m leaf filter (:985-991), which depends on nothing of the next sweep:
+      // it is started now -- the filter's kernels run while the host returns and the next message goes up -- and its count is fetched
+      // behind the next sweep's own filter (rgc_voxelgrid_begin / _end): 55 us of kernels and a read-back off the frame's critical path.
+      if (n_submap_ > 0) {
+        reserve(d_target_, (size_t)16 * (size_t)n_submap_);
+        chk(rgc_voxelgrid_begin(ctx_, d_submap_.p, n_submap_, 16, 0.3f, d_target_.p));
+        target_begun_ = true;
       }
       return;
     }
@@ -458,6 +475,7 @@ private:
   std::vector<DevKf> d_kf_free_;         // buffers of keyframes that left the window, re-used
   DevBuf d_submap_, d_target_;
   int n_submap_ = 0;
+  bool target_begun_ = false;   // rgc_voxelgrid_begin(d_submap_ -> d_target_) is open
   DevKf new_keyframe(int n) {
     const size_t need = (size_t)16 * (size_t)(n > 0 ? n : 1);
     for (size_t i = 0; i < d_kf_free_.size(); i++)

@@ -137,6 +137,11 @@ struct rgc_ctx {
   struct BoxHint { const void* p = nullptr; int n = 0; double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; double reach_xy = 0, reach_z = 0; } box_hint[4];
   int box_hint_next = 0;
   bool vg_flags_clean = false;  // d_small[24 + 6] is known to be zero (a finished rows chain leaves it so)
+  // rgc_voxelgrid_begin / _end: one filter of a device cloud in flight (enqueued on its kept box, result not yet looked at)
+  struct VgPending { bool active = false, ready = false; const float* d_in = nullptr; int n = 0, stride_bytes = 0; float leaf = 0.f; float* d_out = nullptr;
+                     int n_out = 0; } vg_pend;
+  hipEvent_t vg_done = nullptr;
+  int* h_vg = nullptr;  // pinned: the pending filter's three result ints (h_small's words are all taken: the front-end stages 16 ints at +32)
   DevBuf fe[34];              // front-end buffers
   unsigned char* h_stage = nullptr;  // pinned staging of the front-end's small read-backs and feature clouds (a copy into pageable
   size_t h_stage_cap = 0;            // memory is staged by the runtime anyway, one blocking hop per call)
@@ -1126,6 +1131,8 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   c->uid = g_next_uid.fetch_add(1);
   ok = ok && hipEventCreateWithFlags(&c->src_read_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->tgt_prepared, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->vg_done, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->h_vg, 4 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
   if (const char* e = getenv("RGC_FE_SPEC")) c->fe_spec_on = atoi(e) != 0;
@@ -1170,6 +1177,8 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   release(c->lm_state);
   release(c->fit_partials);
+  if (c->vg_done) (void)hipEventDestroy(c->vg_done);
+  if (c->h_vg) (void)hipHostFree(c->h_vg);
   if (c->src_ready) (void)hipEventDestroy(c->src_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->main_mark) (void)hipEventDestroy(c->main_mark);
@@ -1879,8 +1888,10 @@ int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_b
 }
 
 // The rows chain of the leaf filter on box g (rgc_pre.hip); one read-back: *flags (bits as rgck::vg_rows documents) and *n_out.
+// h_result (nullable): the chain is only ENQUEUED -- its three result ints go to h_result (pinned), c->vg_done is recorded behind the
+// copy, and the caller picks them up later (rgc_voxelgrid_begin / _end); flags / n_out are not written then.
 static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, float inv, const rgck::LeafGrid& g, int edge, bool dense, float* d_out,
-                          int* flags, int* n_out) {
+                          int* flags, int* n_out, int* h_result = nullptr) {
   hipStream_t s = c->stream;
   int* dsm = c->d_small + 24;
   int* hsm = c->h_small + 24;
@@ -1908,6 +1919,12 @@ static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, fl
   rgck::vg_rows(s, d_in, stride_f, n, inv, g, edge, dense ? 1 : 0, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)c->vg_pos.p, (int*)cl.cnt.p, (int*)cl.start.p,
                 cl.block_sums.p, (unsigned long long*)c->vg_tmp.p, (int*)c->vg_order.p, (unsigned long long*)c->vg_leaf.p,
                 (int*)((char*)cl.block_sums.p + row_bs), d_out, dsm + 5);
+  if (h_result) {  // (the finished chain leaves the flag word zeroed: the next chain on this stream finds it so)
+    HIPCHK(c, hipMemcpyAsync(h_result, dsm + 5, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->vg_done, s));
+    c->vg_flags_clean = true;
+    return RGC_OK;
+  }
   HIPCHK(c, hipMemcpyAsync(hsm + 5, dsm + 5, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   c->vg_flags_clean = true;
@@ -2004,6 +2021,63 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
   }
   HIPCHK(c, hipGetLastError());
   return RGC_OK;
+}
+
+// rgc_voxelgrid for a DEVICE cloud in two halves.  begin enqueues the filter on the box kept from the previous cloud of this leaf size and
+// returns; end waits for it, looks at its flags and returns the point count -- repeating the filter through rgc_voxelgrid when the kept box
+// did not hold the cloud (the input must therefore stay untouched in between).  Without a kept box begin is the whole rgc_voxelgrid.
+// What it is for: the odometer's sub-map filter (RGC_odometer.cpp:985-991) depends on the pose of the PREVIOUS frame only, so a caller
+// can start it when that frame ends and collect the result after the next sweep's own filter -- its 55 us of kernels and the read-back
+// of its count are off the frame's critical path.  Other rgc_voxelgrid calls may run in between (they come later in stream order and
+// use other result words); only ONE begin may be open per context.
+int rgc_voxelgrid_begin(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, float leaf, float* d_out) {
+  if (!c || !d_xyzi || !d_out || n < 0) return RGC_ERR_INVALID;
+  if (stride_bytes < 12 || (stride_bytes & 3) || !(leaf > 0.f)) return fail(c, RGC_ERR_INVALID, "bad stride or leaf size");
+  if (c->vg_pend.active) return fail(c, RGC_ERR_INVALID, "rgc_voxelgrid_begin: the previous one has not been ended");
+  HIPCHK(c, hipSetDevice(c->device));
+  rgc_ctx::VgPending& pd_ = c->vg_pend;
+  pd_ = rgc_ctx::VgPending{};
+  pd_.d_in = d_xyzi; pd_.n = n; pd_.stride_bytes = stride_bytes; pd_.leaf = leaf; pd_.d_out = d_out;
+  rgc_ctx::VgBox* box = nullptr;
+  for (auto& b : c->vg_box) if (b.leaf == leaf) box = &b;
+  bool enqueued = false;
+  if (n > 0 && box && box->valid) {
+    constexpr int kPadSparse = 32, kPadDense = 8;   // as in rgc_voxelgrid
+    rgck::LeafGrid ps = box->g, pdg = box->g;
+    for (int a = 0; a < 3; a++) { ps.minb[a] -= kPadSparse; ps.div[a] += 2 * kPadSparse; pdg.minb[a] -= kPadDense; pdg.div[a] += 2 * kPadDense; }
+    const bool sparse = vg_rows_fit(ps, n);
+    const double dcell = (double)pdg.div[0] * (double)pdg.div[1] * (double)pdg.div[2];
+    if (sparse || dcell <= (double)c->prm.max_cells) {
+      int rc = voxelgrid_rows(c, d_xyzi, stride_bytes / 4, n, 1.0f / leaf, sparse ? ps : pdg, (sparse ? kPadSparse : kPadDense) / 2, !sparse, d_out, nullptr,
+                              nullptr, c->h_vg);
+      if (rc) return rc;
+      enqueued = true;
+    }
+  }
+  if (!enqueued) {  // no box to trust yet: the whole filter now
+    int rc = rgc_voxelgrid(c, d_xyzi, n, stride_bytes, leaf, d_out, &pd_.n_out, 1);
+    if (rc) return rc;
+    pd_.ready = true;
+  }
+  pd_.active = true;
+  return RGC_OK;
+}
+
+int rgc_voxelgrid_end(rgc_ctx* c, int* n_out) {
+  if (!c || !n_out) return RGC_ERR_INVALID;
+  rgc_ctx::VgPending& pd_ = c->vg_pend;
+  if (!pd_.active) return fail(c, RGC_ERR_INVALID, "rgc_voxelgrid_end without rgc_voxelgrid_begin");
+  pd_.active = false;
+  if (pd_.ready) { *n_out = pd_.n_out; return RGC_OK; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(c->vg_done));
+  const int flags = c->h_vg[0], no = c->h_vg[2];
+  if (flags & 1) return fail(c, RGC_ERR_NONFINITE, "cloud contains non-finite coordinates (PCL skips them; remove NaNs first)");
+  rgc_ctx::VgBox* box = nullptr;
+  for (auto& b : c->vg_box) if (b.leaf == pd_.leaf) box = &b;
+  if (box && (flags & 6)) box->valid = false;  // outside: measure and repeat now; near a face: measure at the next call
+  if (!(flags & 2)) { *n_out = no; return RGC_OK; }
+  return rgc_voxelgrid(c, pd_.d_in, pd_.n, pd_.stride_bytes, pd_.leaf, pd_.d_out, n_out, 1);
 }
 
 
