@@ -147,3 +147,49 @@ def test_transform_cloud_vs_oracle(pre, orc):
                   [2 * (q[0] * q[2] - q[1] * q[3]), 2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[0] ** 2 + q[1] ** 2)]])
     back = pre.transformPointCloud(got, qc, -(R.T @ t))
     assert np.abs(back[:, :3] - xyzi[:, :3]).max() < 2e-5
+
+
+def test_voxelgrid_in_two_halves(orc):
+    """rgc_voxelgrid_begin / rgc_voxelgrid_end on device clouds: the oracle's output bit for bit -- without a kept box (begin is the whole
+    filter), on a kept box with another filter of another leaf size and of the SAME leaf size running in between, and for a cloud that has
+    left the kept box (end repeats the filter); a second begin before the end is refused."""
+    import ctypes as C
+    from rgc_slam_amd import registration, _lib
+    lib = _lib.load()
+    v = registration.odometer_vgicp(0)
+    try:
+        base, other = _scan(), _scan(seed=4)
+        far = base.copy(); far[:, :3] += np.float32([60.0, -35.0, 8.0])
+        cap = max(len(base), len(other), len(far))
+        d_a, d_b, d_oa, d_ob = (v.device_alloc(16 * cap) for _ in range(4))
+        def begin(xyzi, d_in, d_out, leaf):
+            v.upload(d_in, np.ascontiguousarray(xyzi, np.float32))
+            rc = lib.rgc_voxelgrid_begin(v._h, C.c_void_p(d_in), len(xyzi), 16, C.c_float(leaf), C.c_void_p(d_out))
+            return rc
+        def end(d_out):
+            n = C.c_int(0)
+            assert lib.rgc_voxelgrid_end(v._h, C.byref(n)) == 0
+            return v.download(d_out, (n.value, 4))
+        def blocking(xyzi, d_in, d_out, leaf):
+            v.upload(d_in, np.ascontiguousarray(xyzi, np.float32))
+            n = C.c_int(0)
+            assert lib.rgc_voxelgrid(v._h, C.c_void_p(d_in), len(xyzi), 16, C.c_float(leaf), C.c_void_p(d_out), C.byref(n), 1) == 0
+            return v.download(d_out, (n.value, 4))
+        assert begin(base, d_a, d_oa, 0.3) == 0                       # no box for 0.3 m yet: the whole filter inside begin
+        assert np.array_equal(end(d_oa), orc.voxelgrid_filter(base, 0.3))
+        assert begin(other, d_a, d_oa, 0.3) == 0                      # on the kept box, enqueued only
+        assert begin(base, d_b, d_ob, 0.3) != 0                       # one at a time
+        got_b = blocking(base, d_b, d_ob, 0.2)                        # another leaf size in between (its own box, the same scratch)
+        got_c = blocking(base, d_b, d_ob, 0.3)                        # ... and the same leaf size
+        assert np.array_equal(end(d_oa), orc.voxelgrid_filter(other, 0.3))
+        assert np.array_equal(got_b, orc.voxelgrid_filter(base, 0.2))
+        v.upload(d_b, base)
+        assert np.array_equal(got_c, orc.voxelgrid_filter(base, 0.3))
+        assert begin(far, d_a, d_oa, 0.3) == 0                        # outside the kept box: end repeats it on the measured one
+        assert np.array_equal(end(d_oa), orc.voxelgrid_filter(far, 0.3))
+        n = C.c_int(0)
+        assert lib.rgc_voxelgrid_end(v._h, C.byref(n)) != 0           # nothing open
+        for p in (d_a, d_b, d_oa, d_ob):
+            v.device_free(p)
+    finally:
+        v.close()
