@@ -111,7 +111,7 @@ public:
       process(d_raw_.p, n_points, 16, true, stamp, odom, ground);
       return;
     }
-    raw_.resize((size_t)4 * (size_t)(n_points > 0 ? n_points : 1));
+    fit(raw_, (size_t)4 * (size_t)(n_points > 0 ? n_points : 1));
     chk(rgc_pc2_unpack(ctx_, data, n_points, &layout, raw_.data(), nullptr, nullptr, 0));
     process(raw_.data(), n_points, 16, false, stamp, odom, ground);
   }
@@ -144,6 +144,12 @@ public:
 
 private:
   struct DevBuf { float* p = nullptr; size_t cap = 0; };
+  // Host staging vectors grow with headroom: a sweep a few points larger than any before would otherwise move the vector, and the
+  // first copy to the device out of fresh pageable memory costs milliseconds on this runtime (a 9 ms frame in the host-staged modes).
+  static void fit(std::vector<float>& v, size_t n) {
+    if (n > v.capacity()) v.reserve(n + n / 2);
+    v.resize(n);
+  }
   void reserve(DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return;
     if (b.p) chk(rgc_device_free(ctx_, b.p));
@@ -159,7 +165,7 @@ private:
     if (!begin_frame(stamp)) { publish(stamp, odom); return; }
     // ---- ScanRegistration::laserCloudHandler ----
     const int fcap = fe_.n_scans * 6 * 41;
-    full_.resize((size_t)4 * (size_t)(n > 0 ? n : 1));
+    fit(full_, (size_t)4 * (size_t)(n > 0 ? n : 1));
     sharp_.resize((size_t)5 * fcap); flat_.resize((size_t)5 * fcap); inten_.resize((size_t)5 * fcap);
     rgc_fe_out fo;
     std::memset(&fo, 0, sizeof(fo));
@@ -191,7 +197,7 @@ private:
         // on neither; with the resident map the commit is usually a no-op and the order makes no difference)
         if (!opt_.resident_map) { chk(rgc_set_source_device(ctx_, d_source_.p, n_src, 16)); source_set = true; }   // :1008
       } else {
-        source_.resize((size_t)4 * n_full);
+        fit(source_, (size_t)4 * n_full);
         chk(rgc_voxelgrid(ctx_, full_.data(), n_full, 16, 0.2f, source_.data(), &n_src, 0));     // :976-983, planeResolution1
       }
       float guess[16], T[16];
@@ -217,7 +223,7 @@ private:
         chk(rgc_set_target_device(ctx_, d_target_.p, n_tgt, 16));                               // :1007
       } else {
         int n_tgt = 0;
-        target_.resize(submap_.size());
+        fit(target_, submap_.size());
         chk(rgc_voxelgrid(ctx_, submap_.data(), (int)(submap_.size() / 4), 16, 0.3f, target_.data(), &n_tgt, 0));   // :985-991
         pose_to_mat(q_last_curr_, t_last_curr_, guess);                                         // :993-996
         chk(rgc_set_target(ctx_, target_.data(), n_tgt, 16));                                   // :1007
@@ -456,7 +462,7 @@ private:
       for (int a = 0; a < 3; a++) ti[a] = -ti[a];
       for (const auto& kf : kf_cloud_) {
         const size_t at = submap_.size();
-        submap_.resize(at + kf.size());
+        fit(submap_, at + kf.size());
         chk(rgc_transform_cloud(ctx_, kf.data(), (int)(kf.size() / 4), 16, qi, ti, submap_.data() + at, 0));
       }
     }

@@ -26,6 +26,12 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 t0 = int(rows[0]["Start_Timestamp"])
 big = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), (int(r["Start_Timestamp"]) - t0) / 1e6, r["Function"]) for r in rows]
 big.sort(reverse=True)
-for d, t, fn in big[:25]:
+for d, t, fn in big[:8]:
     print("%9.3f ms at %9.3f ms  %s" % (d / 1e6, t, fn))
+# the calls around the slow copies that are not part of the start-up
+slow = [i for i, r in enumerate(rows) if r["Function"] == "hipMemcpyAsync" and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 2000000]
+for i in slow[1:3]:
+    print("---- around call", i)
+    for r in rows[max(0, i - 14):i + 4]:
+        print("   %9.3f ms  +%8.3f ms  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r["Function"]))
 PY

@@ -116,7 +116,7 @@ if node:
                 f"reference semantics {node['cpp_reference_semantics_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_median_ms', float('nan')):.2f} ms host-staged and "
                 f"**{node['cpp_reference_semantics_device_chain_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_device_chain_median_ms', float('nan')):.2f} ms on the device** (round 2: 1.08); "
                 f"resident map {node['cpp_resident_map_ms_per_frame']:.2f} / {node.get('cpp_resident_map_median_ms', float('nan')):.2f} host-staged "
-                f"(slowest timed frame {node.get('cpp_resident_map_slowest_timed_frame_ms', float('nan')):.1f} ms: a first-use pageable copy), "
+                f"(slowest timed frame {node.get('cpp_resident_map_slowest_timed_frame_ms', float('nan')):.1f} ms: one `hipMemcpyAsync` of a filter's output into pageable host memory takes 7 ms once per process, `scripts/prof_node_hip_api.sh`), "
                 f"{node['cpp_resident_map_device_chain_ms_per_frame']:.2f} / {node.get('cpp_resident_map_device_chain_median_ms', float('nan')):.2f} with `device_chain`; "
                 f"`ReplayPipeline` {node['cpp_replay_pipeline_ms_per_frame']:.2f} ms per sweep.")
     if pipe:
