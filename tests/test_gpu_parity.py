@@ -756,13 +756,16 @@ def test_developer_knobs_change_no_result(reg_mod, medium, monkeypatch, knob, va
             assert np.abs(Ta - Tb).max() <= 1e-6 and abs(fa - fb) <= 1e-6 * fa
 
 
-def test_reframed_target_equals_transform_then_set(reg_mod, orc, medium):
+@pytest.mark.parametrize("spec_grid", ["1", "0"])
+def test_reframed_target_equals_transform_then_set(reg_mod, orc, medium, monkeypatch, spec_grid):
     """rgc_set_target_reframed (B9 folded into the preparation's counting pass, the box derived from the input's box and the transform)
     prepares the SAME target as rgc_transform_cloud followed by rgc_set_target_device -- every covariance and the voxel table bit for bit,
     the re-framed cloud left in the scratch buffer -- and both equal the oracle's transform_cloud + covariances.  Three poses in a row on
-    one context: the second and third calls take the hinted grid (no measuring pass), a yaw of 40 degrees swings the box."""
+    one context: the second and third calls take the hinted grid (no measuring pass), a yaw of 40 degrees swings the box.
+    RGC_SPEC_GRID=0: no derived box -- the re-framed cloud is written by its own launch and measured like any other."""
     import rgc_slam_amd.synth as synth
     import bench
+    monkeypatch.setenv("RGC_SPEC_GRID", spec_grid)
     tgt = medium["tgt"]
     n = len(tgt)
     a = np.zeros((n, 4), np.float32)
