@@ -147,8 +147,7 @@ configuration: two contexts taking turns (`value` of the bench line) / one frame
 bit-identical poses (checked in every run). CPU = the C/OpenMP restatement (`oracle/`, the parity checker) on the GPU box's host at the
 reference's {cb["cores"]} OpenMP threads. The reference itself cannot be built (section 2), so there is no reference row.
 
-{table}
-| c2 sequence stand-in (24 sweeps × 28.8 k pts, front-end + frame body + ground factor, 3 keyframes), C++ node | reference semantics on the device {1e3 / node["cpp_reference_semantics_device_chain_ms_per_frame"]:.0f} sweeps/s, resident map + device chain {1e3 / node["cpp_resident_map_device_chain_ms_per_frame"]:.0f}, replay pipeline {1e3 / node["cpp_replay_pipeline_ms_per_frame"]:.0f} (`profiles/{TAG}_cpp_node_bench.json`) | {node["cpp_reference_semantics_device_chain_ms_per_frame"]:.2f} / {node["cpp_resident_map_device_chain_ms_per_frame"]:.2f} / {node["cpp_replay_pipeline_ms_per_frame"]:.2f} | | | ≤ 1e-4 vs the oracle frame body and vs the literal `ICP_thread` restatement (`tests/test_gpu_cpp_node.py`) |
+{table}| c2 sequence stand-in (24 sweeps × 28.8 k pts, front-end + frame body + ground factor, 3 keyframes), C++ node | reference semantics on the device {1e3 / node["cpp_reference_semantics_device_chain_ms_per_frame"]:.0f} sweeps/s, resident map + device chain {1e3 / node["cpp_resident_map_device_chain_ms_per_frame"]:.0f}, replay pipeline {1e3 / node["cpp_replay_pipeline_ms_per_frame"]:.0f} (`profiles/{TAG}_cpp_node_bench.json`) | {node["cpp_reference_semantics_device_chain_ms_per_frame"]:.2f} / {node["cpp_resident_map_device_chain_ms_per_frame"]:.2f} / {node["cpp_replay_pipeline_ms_per_frame"]:.2f} | | | ≤ 1e-4 vs the oracle frame body and vs the literal `ICP_thread` restatement (`tests/test_gpu_cpp_node.py`) |
 | c4 8 × (30 k vs 1 M) | measured by the driver (`bench.py --gpus 8`, one sequence and two contexts per rank, no collective) | | | | |
 | c-main, replay of pre-framed maps (round 2's headline: targets that do not depend on a pose) | {RP["scans_per_s"]:.0f} (round 2: 2781) | {RP["ms_per_step"]} | | | |
 
@@ -161,9 +160,10 @@ The north star's "≥ 50 % of HBM roofline" is the yardstick of a streaming kern
 query it looks at ≈ 105 candidates (3×3×3 cells of a 1 m grid) and keeps the 22 best, which costs {valu:.0f} VALU wave-instructions per query,
 {100 * mix["half_rate_fraction"]:.0f} % of them compare / select / `med3` / fp64, which gfx950 issues at HALF rate (measured: 595 G wave-instr/s against 1060 for
 add / mul / fma, `profiles/r02_valu_issue.jsonl`). Against the peak weighted by that executed mix ({mix["peak_mix_weighted"]:.0f} G/s,
-`profiles/{TAG}_knn_isa_mix.json`) the launch alone runs at {100 * issue_alone / mix["peak_mix_weighted"]:.0f} %; what moves the number is fewer instructions per query
-(173 → 87.9 → {valu:.0f} over three rounds; a half-resolution search grid that cuts the candidates by a third was built, measured and
-parked this round — DESIGN.md §5), not bytes.
+`profiles/{TAG}_knn_isa_mix.json`) the launch alone runs at {100 * issue_alone / mix["peak_mix_weighted"]:.0f} %, with the vector-memory pipe about half busy beside it. What moves the number is
+fewer instructions AND fewer candidate loads per query (173 → 87.9 → {valu:.0f} instructions over three rounds; this round a half-resolution search
+grid that cuts the candidates by a third and two re-orderings of the block that cut only the selection work were built, measured and
+dropped — DESIGN.md §5), not bytes.
 '''
 s = open(P("BASELINE.md")).read()
 open(P("BASELINE.md"), "w").write(put(s, base + "\n"))
