@@ -117,3 +117,47 @@ def test_c5_250k_vs_20M_with_prior(synth, map5m):
     guess = odometry.imu_rotation_priors([np.eye(4), T_true])[1]
     # the CPU oracle on 20 M points needs a many-core host and a few GB; keep it where it finishes in seconds
     _check_case(synth, world, tgt, src, T_true, guess, oracle_pose_check=(os.cpu_count() or 1) >= 64)
+
+
+def test_c_main_dependent_sequence_vs_oracle(synth):
+    """The headline workload as bench.py runs it, at full size: six frames of the DEPENDENT c-main sequence -- every 30 k-point scan
+    registered to the 1 M-point map re-expressed on the device in the previous pose's body frame (rgc_set_target_reframed) -- on one
+    context and on two taking turns.  Each frame's motion against the CPU oracle started from the SAME previous pose and guess (its
+    own transform_cloud of the map, its own registration): <= 1e-4 m / 1e-4 rad; the re-framed cloud itself equals the oracle's to the
+    last bit; both modes give bit-identical motions; the accumulated world pose follows the known trajectory."""
+    import bench
+    from oracle import oracle as orc
+    from rgc_slam_amd import registration
+    K = 6
+    world, tgt = synth.make_world_and_map(1_000_000, seed=synth.SEED)
+    poses = synth.make_trajectory(K + 2, seed=synth.SEED)
+    scans = [synth.make_scan_n(world, poses[i + 1], 30000, seed=synth.SEED + 100 + i)["xyz"] for i in range(K + 1)]
+    pv = registration.PipelinedVGICP(0, depth=2)
+    v = pv.v[0]
+    def to_dev(xyz):
+        a = np.zeros((xyz.shape[0], 4), np.float32); a[:, :3] = xyz
+        p = v.device_alloc(a.nbytes); v.upload(p, a); return p, a
+    (d_map, map4), d_scans = to_dev(tgt), [to_dev(s)[0] for s in scans]
+    seq = bench.DependentSequence(pv.v, d_map, len(tgt), d_scans, [len(s) for s in scans])
+    I4 = np.eye(4, dtype=np.float32)
+    Tw0 = np.asarray(poses[0], np.float64)
+    for w in pv.v:
+        seq.v = [w]; _, w0, _ = seq.run(0, 1, Tw0, I4, False)
+    seq.v = pv.v
+    m1, worlds, guesses = seq.run(1, K, w0[0], I4, False)
+    m2, _, _ = seq.run(1, K, w0[0], I4, True)
+    assert all(np.array_equal(a, b) for a, b in zip(m1, m2))
+    o = orc.Registration(num_threads=min(14, os.cpu_count() or 1))
+    for j in range(K):
+        Tw_prev = w0[0] if j == 0 else worlds[j - 1]
+        q, t = bench.world_to_body(Tw_prev)
+        body = orc.transform_cloud(map4, q, t)
+        if j in (0, K - 1):
+            v.transformCloudDevice(d_map, len(tgt), 16, q, t, seq.d_body[id(v)])
+            assert np.array_equal(v.download(seq.d_body[id(v)], (len(tgt), 4)), body)
+        o.set_target(body[:, :3].copy()); o.set_source(scans[1 + j])
+        To = o.align(guesses[j])
+        assert np.abs(m1[j][:3, 3] - To[:3, 3]).max() <= 1e-4 and _rot_angle(m1[j][:3, :3], To[:3, :3]) <= 1e-4, j
+    assert np.abs(worlds[-1][:3, 3] - poses[K + 1][:3, 3]).max() < 0.05      # the synthetic trajectory is recovered (metres travelled: ~1)
+    seq.close()
+    pv.close()
