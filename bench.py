@@ -344,6 +344,7 @@ def main():
     ap.add_argument("--n-source", type=int, default=N_SOURCE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--configs", default="c1,c3,c5", help="extra single-GPU configurations of BASELINE.json to run after the metric (c1,c3,c5 or 'none')")
+    ap.add_argument("--sequence", type=int, default=0, help="number of the first rank's sequence (rank r runs sequence --sequence + r: seed offset)")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -362,17 +363,25 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    numa = pin_to_gpu_numa_node(local_rank)
+    # RGC_BENCH_DEVICE: every rank on THIS device (tests/test_gpu_bench_contract.py runs two ranks on a one-GPU box: the N > 1 control flow
+    # with real HIP contexts in more than one process; RCCL cannot span two ranks of one device, so the barrier / MAX-reduce then go over
+    # gloo -- RGC_BENCH_DIST_BACKEND).  Unset (the driver's runs): rank r on device r, RCCL.
+    device_index = int(os.environ.get("RGC_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("RGC_BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
+    numa = pin_to_gpu_numa_node(device_index)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world_size)
 
     import rgc_slam_amd.synth as synth
     from rgc_slam_amd import registration
 
     K, W = args.steps, args.warmup
-    seed = synth.SEED + rank  # one independent sequence per rank
+    seed = synth.SEED + args.sequence + rank  # one independent sequence per rank
     t0 = time.time()
     world, tgt = synth.make_world_and_map(args.n_target, seed=seed)
     poses = synth.make_trajectory(K + W + 1, seed=seed)
@@ -381,7 +390,7 @@ def main():
     log(f"[rank {rank}] synthetic data: map {tgt.shape}, {len(scans)} scans of {scans[0].shape[0]} pts, world half-extent "
         f"{world.half_extent:.1f} m, {time.time() - t0:.1f} s, NUMA node {numa}")
 
-    pv = registration.PipelinedVGICP(local_rank, depth=2)
+    pv = registration.PipelinedVGICP(device_index, depth=2)
     v = pv.v[0]
     # inputs resident in HBM (x,y,z,pad; 16-byte stride) before anything is timed
     def to_dev(xyz):
@@ -441,7 +450,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     if world_size > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof_dom = {"total_ms": 0.0, "launches": 0, "points": 0}
@@ -516,6 +525,11 @@ def main():
     prof = v.profile()
     v.profile_enable(False)
 
+    checksum = float(np.sum(np.abs(np.asarray(worlds, np.float64))))
+    rank_checksums = [checksum]
+    if world_size > 1:  # (after every timed region: one small object per rank, for the record that the ranks ran DIFFERENT sequences)
+        rank_checksums = [None] * world_size
+        dist.all_gather_object(rank_checksums, checksum)
     if rank != 0:
         if world_size > 1:
             dist.destroy_process_group()
@@ -604,7 +618,9 @@ def main():
         "scan_h2d_and_output": {"scans_per_s": round(K / elapsed_h2d, 3), "ms_per_step": round(1e3 * elapsed_h2d / K, 3), "same_final_pose": h2d_same,
                                 "what": "the dependent steps; each scan uploaded from pinned host memory inside the step, align()'s output cloud written to a device buffer"},
         "steady_state": steady,
-        "final_pose_checksum": float(np.sum(np.abs(np.asarray(worlds, np.float64)))),
+        "final_pose_checksum": checksum,
+        "final_pose_checksum_per_rank": rank_checksums,
+        "sequence_of_rank0": args.sequence,
     }
 
     oracle = None

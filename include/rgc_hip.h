@@ -159,7 +159,9 @@ RGC_API int rgc_get_target_covariances(rgc_ctx* ctx, double* cov9, double* norma
 RGC_API int rgc_set_source_covariances(rgc_ctx* ctx, const double* cov9, int n);
 RGC_API int rgc_set_target_covariances(rgc_ctx* ctx, const double* cov9, int n);
 /* FastGICP::clearSource / clearTarget (fast_gicp.hpp:56-57, fast_gicp_impl.hpp:60-69) and FastVGICP::swapSourceAndTarget
- * (fast_vgicp_impl.hpp:46-53: the clouds change roles, the voxel map is rebuilt from the new target). */
+ * (fast_vgicp_impl.hpp:46-53: the clouds change roles, the voxel map is rebuilt from the new target; covariances the caller set with
+ * rgc_set_source/target_covariances travel with their cloud, like the reference's swap of source_covs_ / target_covs_ -- computed
+ * ones are the same function of the cloud in either role). */
 RGC_API int rgc_clear_source(rgc_ctx* ctx);
 RGC_API int rgc_clear_target(rgc_ctx* ctx);
 RGC_API int rgc_swap_source_and_target(rgc_ctx* ctx);
@@ -200,7 +202,10 @@ RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stri
  * points, fixed between calls) re-expressed by q * p + t into d_scratch (n*4 floats, device) and prepared as the registration's target
  * -- grid, exact-kNN covariances, voxel map, like rgc_set_target_device -- without a host round trip: the re-framed cloud's bounding
  * box is derived from the input's (measured on the first call with a given d_xyzi, n) and the transform.  What a dependent sequence
- * does every frame with the pose the previous frame returned. */
+ * does every frame with the pose the previous frame returned.
+ * Preconditions: d_scratch must not overlap d_xyzi (RGC_ERR_INVALID: the input is read while the output is written, and a buffer has
+ * one bounding-box hint); a d_scratch that is 16-byte aligned (anything hipMalloc / rgc_device_alloc returns) takes the fused path
+ * -- re-framing inside the preparation's counting pass -- any other 4-byte aligned address the re-framing runs as its own launch. */
 RGC_API int rgc_set_target_reframed(rgc_ctx* ctx, const float* d_xyzi, int n, int stride_bytes, const double q_xyzw[4], const double t[3],
                                     float* d_scratch);
 
@@ -323,6 +328,12 @@ RGC_API int rgc_get_stats(rgc_ctx* ctx, rgc_stats* out);
 /* ---- device plumbing for callers that keep clouds resident in HBM (bench, ROS adaptor) ---- */
 RGC_API int  rgc_device_alloc(rgc_ctx* ctx, size_t bytes, void** d_ptr);
 RGC_API int  rgc_device_free(rgc_ctx* ctx, void* d_ptr);
+/* Page-locked HOST memory (hipHostMalloc, visible to every device) for a caller's staging buffers: a copy between the device and
+ * pageable memory is staged by the runtime in a blocking hop, and the first touch of fresh pageable pages costs milliseconds (the
+ * host-staged node's one 8.8 ms frame in round 3); out of these buffers the copies of rgc_set_*, rgc_voxelgrid, rgc_frontend run at
+ * PCIe rate.  No context needed; rgc_host_free(NULL) is a no-op. */
+RGC_API int  rgc_host_alloc(size_t bytes, void** h_ptr);
+RGC_API int  rgc_host_free(void* h_ptr);
 RGC_API int  rgc_upload(rgc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* async on ctx stream */
 RGC_API int  rgc_download(rgc_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous          */
 RGC_API int  rgc_synchronize(rgc_ctx* ctx);

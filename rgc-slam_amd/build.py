@@ -1,6 +1,8 @@
 """Builds librgc_hip.so (the product: HIP kernels + C-ABI) in-tree with hipcc for gfx950.
 
     python rgc-slam_amd/build.py [--force]
+    RGC_EXTRA_FLAGS="-DRGC_LM_POST=0" RGC_LIB_OUT=/tmp/librgc_alt.so python rgc-slam_amd/build.py   # an A/B build beside the product
+                                                                                                     # (RGC_HIP_LIB=/tmp/librgc_alt.so loads it)
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: the exact-kNN parity with the CPU path
 depends on the fp32 squared distance not being FMA-contracted (see csrc/rgc_kernels.hip header).
@@ -11,7 +13,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "librgc_hip.so")
+LIB = os.environ.get("RGC_LIB_OUT") or os.path.join(HERE, "librgc_hip.so")
+OBJDIR = CSRC if not os.environ.get("RGC_LIB_OUT") else os.path.splitext(LIB)[0] + "_obj"
 SRCS = ["rgc_api.hip", "rgc_kernels.hip", "rgc_pre.hip", "rgc_frontend.hip", "rgc_host.cpp"]
 DEPS = SRCS + ["rgc_kernels.h", "rgc_lm.h", os.path.join("..", "..", "include", "rgc_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -25,7 +28,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     objs = []
     for src in SRCS:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        os.makedirs(OBJDIR, exist_ok=True)
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
         cmd = [HIPCC] + (FLAGS if src.endswith(".hip") else FLAGS[1:]) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -36,6 +36,7 @@
 #include <deque>
 #include <exception>
 #include <mutex>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -44,6 +45,23 @@
 #include "../../include/rgc_hip.h"
 
 namespace rgc {
+
+// std::allocator over page-locked host memory (rgc_host_alloc): what the node's host staging vectors are made of
+template <typename T>
+struct PinnedAllocator {
+  using value_type = T;
+  PinnedAllocator() = default;
+  template <typename U> PinnedAllocator(const PinnedAllocator<U>&) {}
+  T* allocate(std::size_t n) {
+    void* p = nullptr;
+    if (rgc_host_alloc(n * sizeof(T), &p) != RGC_OK || !p) throw std::bad_alloc();
+    return static_cast<T*>(p);
+  }
+  void deallocate(T* p, std::size_t) noexcept { (void)rgc_host_free(p); }
+  template <typename U> bool operator==(const PinnedAllocator<U>&) const { return true; }
+  template <typename U> bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+using HostVec = std::vector<float, PinnedAllocator<float>>;
 
 struct OdometryMsg {             // the pose part of nav_msgs::Odometry as filled at RGC_odometer.cpp:1264-1275
   double stamp = 0;
@@ -144,9 +162,9 @@ public:
 
 private:
   struct DevBuf { float* p = nullptr; size_t cap = 0; };
-  // Host staging vectors grow with headroom: a sweep a few points larger than any before would otherwise move the vector, and the
-  // first copy to the device out of fresh pageable memory costs milliseconds on this runtime (a 9 ms frame in the host-staged modes).
-  static void fit(std::vector<float>& v, size_t n) {
+  // Host staging vectors live in PAGE-LOCKED memory (rgc_host_alloc) and grow with headroom: a copy between the device and pageable
+  // memory is staged by the runtime, and the first one out of fresh pages cost 7 ms (round 3's one 8.8 ms frame of the host-staged modes).
+  static void fit(HostVec& v, size_t n) {
     if (n > v.capacity()) v.reserve(n + n / 2);
     v.resize(n);
   }
@@ -407,7 +425,7 @@ private:
           chk(rgc_transform_cloud(ctx_, d_source_.p, n_src, 16, q_w_, t_w_, kf.p, 1));           // :1237
           d_kf_.push_back(kf);
         } else {
-          std::vector<float> w((size_t)4 * n_src);
+          HostVec w((size_t)4 * n_src);
           chk(rgc_transform_cloud(ctx_, source_.data(), n_src, 16, q_w_, t_w_, w.data(), 0));
           kf_cloud_.push_back(std::move(w));
         }
@@ -472,8 +490,8 @@ private:
   Options opt_;
   rgc_ctx* ctx_ = nullptr;
   rgc_fe_params fe_{};
-  std::vector<float> raw_, full_, full_last_, sharp_, flat_, inten_, source_, target_, submap_;
-  std::deque<std::vector<float>> kf_cloud_;
+  HostVec raw_, full_, full_last_, sharp_, flat_, inten_, source_, target_, submap_;
+  std::deque<HostVec> kf_cloud_;
   DevBuf d_raw_, d_source_, d_last_;     // device_chain: the unpacked message, the 0.2 m-filtered sweep, the previous sweep (keyframe 0)
   // device_chain without the resident map: the reference's keyframe window (world-frame clouds) and its re-framed concatenation on the device
   struct DevKf { float* p = nullptr; size_t cap = 0; int n = 0; };
@@ -599,7 +617,7 @@ private:
   struct Front {                                     // one front-end worker: its context, its raw-sweep buffer, its feature staging
     rgc_ctx* ctx = nullptr;
     float* d_raw = nullptr; size_t raw_cap = 0;
-    std::vector<float> sharp, flat, inten;
+    HostVec sharp, flat, inten;
   };
   static void chk(rgc_ctx* c, int rc) { if (rc != RGC_OK) throw std::runtime_error(std::string(rgc_status_string(rc)) + ": " + rgc_last_error(c)); }
   static void grow(rgc_ctx* c, float*& p, size_t& cap, size_t bytes) {

@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,30 @@
 namespace {
 
 constexpr int kMaxK = 32;
+// Build-time switches (RGC_EXTRA_FLAGS=-D...): alternative routes to the SAME results, kept for A/B measurements.  A caller's
+// process reads only RGC_LM_IMPL, RGC_SPEC_GRID and RGC_TRACE_ALLOC from the environment (rgc_create).
+#ifndef RGC_LM_POST
+#define RGC_LM_POST 1          // 0: rgc_align_end always waits for the stream and its copy of the state (round 2)
+#endif
+#ifndef RGC_SMALL_COPY
+#define RGC_SMALL_COPY 0       // 1: the 32-byte host-to-device copy in front of every preparation
+#endif
+#ifndef RGC_FE_SPEC
+#define RGC_FE_SPEC 1          // 0: the front-end reads every sweep's size back before its stencil kernels
+#endif
+#ifndef RGC_SOLVE_BEHIND_MAP
+#define RGC_SOLVE_BEHIND_MAP 1 // 0: the solve always on the scan's (high-priority) stream (round 2)
+#endif
+#ifndef RGC_MAP_WIDE_R
+#define RGC_MAP_WIDE_R 2       // block radius of the bulk kNN launch for a sparse map (0 = off, 2)
+#endif
+#ifndef RGC_MAP_WIDE
+#define RGC_MAP_WIDE 0.25      // ... taken when the map has fewer points per grid cell than this
+#endif
+#ifndef RGC_SRC_RES
+#define RGC_SRC_RES 0.0        // fixed cell size of the scan's kNN grid (0 = adaptive)
+#endif
+static_assert(RGC_MAP_WIDE_R == 0 || RGC_MAP_WIDE_R == 2, "RGC_MAP_WIDE_R: 0 or 2");
 constexpr int kProfKinds = RGC_K_COUNT;
 
 struct DevBuf {
@@ -40,11 +65,11 @@ struct Cloud {
   int stride_f = 0;
   int n = 0;
   bool ready = false;  // grid + normals (+ voxels for the target) enqueued
+  bool covs_user = false;  // the normals were given by the caller (rgc_set_source/target_covariances), not computed from the neighbours
   DevBuf in_copy, cell_of, slot_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
   DevBuf segs;  // deferred-query list of the bulk kNN kernel: [count, pad x15][query n][bound n]
   int deferred_seen = -1;  // deferred count of the last cloud whose count came home (sizes the next cooperative launch)
-  rgck::Grid grid{};   // the search grid: sorted array P, start[]
-  rgck::Grid vgrid{};  // target: the voxel grid cell_voxel[] is laid out on -- `grid` itself, or the voxel grid that goes with a half-size search grid
+  rgck::Grid grid{};   // the search grid: sorted array P, start[]; for the target also the voxel grid cell_voxel[] is laid out on
   // speculative grid (voxel level): the previous cloud's grid, widened, re-used without the bounding-box round trip; k_count guards it
   rgck::Grid spec_grid{};
   bool spec_ok = false;    // spec_grid is usable
@@ -111,20 +136,21 @@ struct rgc_ctx {
   rgck::LmState* h_post = nullptr; // mapped host memory the DEVICE writes a finished solve's state into, then the solve's number into its `gen`
   rgck::LmState* d_post = nullptr; // ... its device address
   int lm_seq = 0;                  // number of the pending solve (1, 2, ...)
-  bool post_on = true;             // RGC_LM_POST=0: always wait for the stream and its copy, as in round 2
+  rgck::LmState lm_res{};          // the finished solve's state as rgc_align_end took it (from h_post or h_lm): nothing writes it asynchronously
+  hipEvent_t lm_tail = nullptr;    // recorded behind every batch of LM launches (and its copy into h_lm) on the stream they went to
+  hipStream_t lm_tail_stream = nullptr;  // ... that stream: a solve enqueued on the OTHER stream waits for lm_tail first
+  bool post_on = RGC_LM_POST != 0; // (build flag) 0: always wait for the stream and its copy, as in round 2
   struct { bool active = false; bool want_fitness = false; float guess[16]; } pend;  // rgc_align_begin .. rgc_align_end
   int lm_last_outer = 0;      // outer iterations of the previous solve: sizes the next blind batch
-  bool small_copy_always = false;  // RGC_SMALL_COPY=1: the 32-byte copy in front of every preparation, as before (A/B knob)
+  bool small_copy_always = RGC_SMALL_COPY != 0;  // (build flag) 1: the 32-byte copy in front of every preparation, as before
   bool small_clean[2] = {false, false};  // d_small block of the map / the scan holds its initial image (the last solve's first step restored it)
   hipStream_t solve_stream = nullptr;  // where the pending solve was enqueued (rgc_align_begin)
-  bool solve_behind_map = true;  // RGC_SOLVE_BEHIND_MAP=0: the solve always on the scan's (high-priority) stream, as in round 2
+  bool solve_behind_map = RGC_SOLVE_BEHIND_MAP != 0;  // (build flag) 0: the solve always on the scan's (high-priority) stream, as in round 2
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
-  double src_res = 0.0;       // RGC_SRC_RES: fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
-  int map_wide_r = 2;             // RGC_MAP_WIDE_R (0 = off, 2): block radius of the bulk kNN launch for a sparse map
-  double map_wide_density = 0.25; // RGC_MAP_WIDE: ... when the map has fewer points per grid cell than this
-  bool map_half = false;          // RGC_MAP_HALF=1: a dense map is searched on a half-size grid nested in the voxel grid (k_knn_h, 5x5x5 half cells) instead of
-                                  // the voxel grid's 3x3x3 block -- measured in round 3 and parked: no faster, and its grid costs more (profiles/r03_pmc_knn_half_grid.json)
+  double src_res = RGC_SRC_RES;  // (build flag) fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
+  int map_wide_r = RGC_MAP_WIDE_R;          // (build flag; 0 = off, 2) block radius of the bulk kNN launch for a sparse map
+  double map_wide_density = RGC_MAP_WIDE;   // (build flag) ... when the map has fewer points per grid cell than this
   double src_res_auto = 0.0;  // adaptive cell size of the scan's kNN grid, steered by how crowded its cells were in the previous frame (0 = voxel_res)
   Cloud aux;                  // grid scratch of rgc_voxelgrid
   DevBuf pre_in, pre_out, vg_order, vg_pos, vg_tmp, vg_leaf;  // B2/B3/B9 staging
@@ -145,7 +171,7 @@ struct rgc_ctx {
   DevBuf fe[34];              // front-end buffers
   unsigned char* h_stage = nullptr;  // pinned staging of the front-end's small read-backs and feature clouds (a copy into pageable
   size_t h_stage_cap = 0;            // memory is staged by the runtime anyway, one blocking hop per call)
-  bool fe_spec_on = true;    // RGC_FE_SPEC=0: read every sweep's size back before its stencil kernels
+  bool fe_spec_on = RGC_FE_SPEC != 0;  // (build flag) 0: read every sweep's size back before its stencil kernels
   int fe_last_ns = 0, fe_last_max_ring = 0;  // the previous sweep's scan lines and largest ring: sizes the next sweep's launches without a read-back
   int fe_n_cloud = 0;         // points of the last front-end's ring-major cloud (fe[5]), for rgc_frontend_cloud_device
   // f2: rolling local map.  World-frame points (relative to map_origin, x,y,z,intensity, 16 B) of the live keyframes as
@@ -244,7 +270,8 @@ struct ProfScope {
       if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
       return hipEventCreate(e) == hipSuccess;
     };
-    if (!get(&r.a) || !get(&r.b)) { on = false; return; }
+    if (!get(&r.a)) { on = false; return; }
+    if (!get(&r.b)) { c->ev_pool.push_back(r.a); on = false; return; }
     r.kind = kind;
     r.points = points;
     (void)hipEventRecord(r.a, st);
@@ -300,21 +327,12 @@ void drop_hints(rgc_ctx* c) {
   for (auto& e : c->box_hint) e.p = nullptr;
 }
 
-// Which layout a map of n points on voxel-level box v gets: the half-size search grid (k_knn_h: k <= 20, a dense map -- a sparse one
-// takes the wide-block launch on the voxel grid -- and cell arrays that still fit), or the voxel grid itself.
-bool half_layout(const rgc_ctx* c, bool is_target, int n, const rgck::Grid& v) {
-  if (!is_target || !c->map_half || c->prm.k_correspondences > 20) return false;
-  if (c->map_wide_r > 0 && (double)n < c->map_wide_density * (double)v.ncell) return false;
-  double hc = 8.0;
-  for (int a = 0; a < 3; a++) hc *= (double)(v.dim[a] + 2);
-  return hc <= 1.0e9 && hc <= 8.0 * (double)c->prm.max_cells;  // (k_knn_h addresses start[] with 32-bit byte offsets)
-}
-
 // C1-C3: grid + exact-kNN covariances (+ voxel map for the target), all enqueued on the stream.
 // The first cloud of a context costs one host<->device round trip -- the 6-int bounding box the dense grid is sized from; later
 // clouds re-use the previous (widened) grid speculatively and need none (see `spec` below).
 int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false) {
   const int n = cl.n;
+  cl.covs_user = false;
   if (is_target && &cl == &c->tgt) {
     c->tgt_generation++;       // borrowers of the previous target must share again
     c->tgt_owner = nullptr;    // (a borrowed target's aliases are dropped buffer by buffer in ensure())
@@ -361,7 +379,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     bool spec = c->spec_on && !c->lm_host && cl.spec_ok && cl.spec_grid.res == res && !force_bbox;
     const rgc_ctx::BoxHint* hint = (is_target && c->spec_on && !c->lm_host && !force_bbox) ? find_hint(c, cl.in, n) : nullptr;
     rgck::Grid g{};
-    if (hint) {  // the box is known (rgc_transform_cloud): its cells plus one on every side, guarded like a speculative grid
+    if (hint) {  // the box is known (rgc_set_target_reframed / rgc_transform_cloud): its cells plus one on every side, guarded like a speculative grid
       int lo[3], dm[3];
       double ncell = 1.0;
       for (int a = 0; a < 3; a++) {
@@ -374,7 +392,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     }
     // A re-framed map (rgc_set_target_reframed) has not been written yet.  With its box known the counting pass below produces it on
     // the way (one pass over the map and one launch less); any other route measures the cloud first and needs it in memory.
-    const bool fuse_reframe = cl.reframe_pending && hint != nullptr && cl.stride_f == 4;
+    const bool fuse_reframe = cl.reframe_pending && hint != nullptr && cl.stride_f == 4 && ((uintptr_t)cl.in & 15) == 0;  // (k_count<true> stores float4)
     if (cl.reframe_pending && !fuse_reframe)
       rgck::transform_q(s, cl.rf.src, cl.rf.src_stride_f, n, cl.rf.q, cl.rf.t, const_cast<float*>(cl.in), 4);
     cl.reframe_pending = false;
@@ -401,9 +419,6 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       if (ncell > (double)c->prm.max_cells || ncell > 2.0e9)
         return fail(c, RGC_ERR_GRID_TOO_LARGE, "%s grid %d x %d x %d exceeds max_cells", is_target ? "target" : "source", g.dim[0], g.dim[1], g.dim[2]);
       g.res = res;
-      g.vres = res;
-      g.sub = 1;
-      g.pad = 0;
       g.inv_res = rgck::grid_inv_res(res);
       g.ncell = (int)ncell;
       // The grid the NEXT cloud will try.  The map's box is stable and its grid large: 2 / 2 / 1 cells of margin.  A raw scan's box
@@ -430,14 +445,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       cl.spec_ok = wcell <= (double)c->prm.max_cells && wcell <= 2.0e9;
       cl.spec_grid = w;
       if (cl.spec_ok) {  // its cell arrays now, in the frame that is slow anyway, not in the next one
-        rgck::Grid wv = w;
-        const rgck::Grid ws = half_layout(c, is_target, n, w) ? rgck::half_grid_of(w, &wv) : w;
-        const size_t wc1 = (size_t)ws.ncell + 1, wtot = wc1 + (ws.sub == 2 ? (size_t)wv.ncell : 0);
+        const size_t wc1 = (size_t)w.ncell + 1;
         int rc;
-        if ((rc = ensure(c, cl.cnt, sizeof(int) * wtot + 256))) return rc;
+        if ((rc = ensure(c, cl.cnt, sizeof(int) * wc1 + 256))) return rc;
         if ((rc = ensure(c, cl.start, sizeof(int) * wc1))) return rc;
-        if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (wtot / 2048 + 2)))) return rc;
-        if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)wv.ncell))) return rc;
+        if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (wc1 / 2048 + 2)))) return rc;
+        if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * (size_t)w.ncell))) return rc;
         if (is_target) {  // ... and the voxel table (80 B per cell of a map denser than its grid: 1.3 GB at 16 M cells -- growing it in the next
                           // frame, when the widened grid is first used, was a 77 ms allocation inside c5's three timed frames on a fresh box)
           const size_t vw = (size_t)(n < w.ncell ? n : w.ncell);
@@ -446,15 +459,9 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
         }
       }
     }
-    // A dense map is searched on cells of HALF the voxel size nested in the voxels (k_knn_h); g stays the voxel-level box, the
-    // search grid and the voxel grid cell_voxel[] lives on are derived from it (two cells / one voxel of padding).
-    const bool half = half_layout(c, is_target, n, g);
-    rgck::Grid vg = g;
-    if (half) g = rgck::half_grid_of(g, &vg);
     cl.grid = g;
-    cl.vgrid = vg;
-    const size_t nc1 = (size_t)g.ncell + 1;
-    const size_t ntot = nc1 + (half ? (size_t)vg.ncell : 0);  // counters (+ sentinel), then the voxel occupancy flags
+    const size_t nc1 = (size_t)g.ncell + 1;  // counters (+ sentinel)
+    const size_t ntot = nc1;
     int rc;
     if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
     if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;
@@ -463,10 +470,9 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     size_t want_cells = ntot;
     if (hint && hint->reach_xy > 0) {
       const double e = hint->reach_xy / res + 6.0, ez = hint->reach_z / res + 6.0;
-      const double cells = e * e * ez * (half ? 8.0 : 1.0) * 1.05;
-      if (cells < 2.0e9 && cells <= 8.0 * (double)c->prm.max_cells && (size_t)cells > want_cells) want_cells = (size_t)cells;
+      const double cells = e * e * ez * 1.05;
+      if (cells < 2.0e9 && cells <= (double)c->prm.max_cells && (size_t)cells > want_cells) want_cells = (size_t)cells;
     }
-    const size_t cell_slack = 2;
     if ((rc = ensure(c, cl.cnt, sizeof(int) * std::max(ntot, want_cells) + 256))) return rc;
     if ((rc = ensure(c, cl.start, sizeof(int) * std::max(nc1, want_cells)))) return rc;
     if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (std::max(ntot, want_cells) / 2048 + 2)))) return rc;
@@ -476,12 +482,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.ny, sizeof(double) * n))) return rc;
     if ((rc = ensure(c, cl.nz, sizeof(double) * n))) return rc;
-    if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * std::max((size_t)vg.ncell, half ? want_cells / 8 : want_cells)))) return rc;
-    (void)cell_slack;
-    if (half) {  // (vox_cell is written by the cell scan in this layout)
-      const size_t vmax = (size_t)(n < vg.ncell ? n : vg.ncell);
-      if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
-    }
+    if (is_target && (rc = ensure(c, cl.cell_voxel, sizeof(int) * std::max((size_t)g.ncell, want_cells)))) return rc;
     if (cl.cnt.p != cl.cnt_seen) { cl.cnt_clean = 0; cl.cnt_seen = cl.cnt.p; }  // re-allocated: contents unknown
     if (cl.cnt_clean < ntot) {  // first use or a larger grid; afterwards the scan leaves the counters clean: no fill kernel per frame
       const size_t fill = std::min(cl.cnt.cap, (sizeof(int) * ntot + 255) & ~(size_t)255);
@@ -489,28 +490,28 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       cl.cnt_clean = fill / sizeof(int);
     }  // (a smaller grid leaves the counters beyond it as clean as they were: a re-framed map's box breathes with the yaw)
     rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi, spec ? dsm + 6 : nullptr,
-                      half ? (int*)cl.cnt.p + nc1 : nullptr, fuse_reframe ? &cl.rf : nullptr);
+                      fuse_reframe ? &cl.rf : nullptr);
     rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)ntot, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
-                     is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23), half ? (int)nc1 : -1,
-                     half ? (int*)cl.vox_cell.p : nullptr);
+                     is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23));
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p, hi);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
                       (float4*)cl.P.p, (int*)cl.segs.p, hi);
   }
   {
     // a sparse map (points per cell of its grid below map_wide_density): the wider block, see k_knn_sp_wide
-    const int wide_r = (is_target && c->map_wide_r > 0 && (double)n < c->map_wide_density * (double)cl.vgrid.ncell) ? c->map_wide_r : 0;
+    const int wide_r = (is_target && c->map_wide_r > 0 && (double)n < c->map_wide_density * (double)cl.grid.ncell) ? c->map_wide_r : 0;
     const int kind = is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC;
     // The dense map's launch (the dominant kernel) is timed by ITS OWN start / stop times (hipExtLaunchKernelGGL fills the two events):
     // two hipEventRecord packets around it cost ~3 % of a frame of a dependent sequence on two contexts (bench.py's timed region).
     ProfRegion own{};
     bool self_timed = false;
-    if (c->prof_on && ((c->prof_mask >> kind) & 1u) && rgck::knn_bulk_times_itself(is_target, cl.grid, wide_r)) {
+    if (c->prof_on && ((c->prof_mask >> kind) & 1u) && rgck::knn_bulk_times_itself(is_target, wide_r)) {
       auto get = [&](hipEvent_t* e) {
         if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); return true; }
         return hipEventCreate(e) == hipSuccess;
       };
-      self_timed = get(&own.a) && get(&own.b);
+      self_timed = get(&own.a);
+      if (self_timed && !get(&own.b)) { c->ev_pool.push_back(own.a); self_timed = false; }
       own.kind = kind;
       own.points = n;
     }
@@ -525,9 +526,9 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     }
   }
   // The map's deferred queries (~100 of a million, one wave each: 20 us of latency) are resolved in the SAME launch as the voxel map's
-  // build (k_voxel_build_coop); the few voxels that hold one are recomputed behind it (k_voxel_patch).  The scan has no voxel map, the
-  // half-size layout keeps its own voxel kernel: their chains stay serial.
-  const bool coop_beside = is_target && cl.grid.sub == 1;
+  // build (k_voxel_build_coop); the few voxels that hold one are recomputed behind it (k_voxel_patch).  The scan has no voxel map:
+  // its chain stays serial.
+  const bool coop_beside = is_target;
   // grid of the cooperative launch: twice the deferred count of the previous cloud prepared here (consecutive clouds of a sequence
   // defer about the same queries), n / 64 for the first one
   const int coop_waves = cl.deferred_seen >= 0 ? cl.deferred_seen + cl.deferred_seen / 4 + 32 : n / 64 + 32;
@@ -538,14 +539,10 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   }
   if (is_target) {
     int rc;
-    const size_t vmax = (size_t)(n < cl.vgrid.ncell ? n : cl.vgrid.ncell);
+    const size_t vmax = (size_t)(n < cl.grid.ncell ? n : cl.grid.ncell);
     if ((rc = ensure(c, cl.vox, sizeof(double) * rgck::kVoxRec * vmax))) return rc;
     if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
     ProfScope ps(c, RGC_K_VOXEL, n);
-    if (cl.grid.sub == 2)
-      rgck::voxel_build_h(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p,
-                          (const int*)cl.start.p, cl.grid, (int)vmax, c->d_small + 7, (const int*)cl.vox_cell.p, (double*)cl.vox.p);
-    else
     {
       rgck::voxel_build_coop(s, (const float4*)cl.P.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p, (const int*)cl.start.p, cl.grid, n,
                              (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves);
@@ -658,9 +655,11 @@ int resolve_guards(rgc_ctx* c, int guard_t, int guard_s) {
 int check_target_owner(rgc_ctx* c) {
   if (!c->tgt_owner) return RGC_OK;
   bool alive;
+  unsigned long long owner_gen = 0;
   {
-    std::lock_guard<std::mutex> lk(g_live_mutex);
+    std::lock_guard<std::mutex> lk(g_live_mutex);  // (the owner is only looked at while it cannot be destroyed)
     alive = g_live.count(c->tgt_owner) != 0 && c->tgt_owner->uid == c->tgt_owner_uid;
+    if (alive) owner_gen = c->tgt_owner->tgt_generation;
   }
   if (!alive) {  // its device buffers are gone with it
     c->tgt_owner = nullptr;
@@ -671,7 +670,7 @@ int check_target_owner(rgc_ctx* c) {
     c->tgt.n = 0;
     return fail(c, RGC_ERR_NO_INPUT, "the context whose target this one shared has been destroyed");
   }
-  if (c->tgt_owner->tgt_generation != c->tgt_owner_gen)
+  if (owner_gen != c->tgt_owner_gen)
     return fail(c, RGC_ERR_INVALID, "the shared target was rebuilt by its owner: rgc_share_target again");
   return RGC_OK;
 }
@@ -713,7 +712,7 @@ int do_linearize(rgc_ctx* c, const double T[16], double* H, double* b, double* c
   {
     ProfScope ps(c, RGC_K_LINEARIZE, n);
     rgck::linearize(c->stream, (const float4*)c->src.P.p,
-                    (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n, pose_from(T), c->tgt.vgrid,
+                    (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n, pose_from(T), c->tgt.grid,
                     (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p, want,
                     (double*)c->partials.p, (int*)c->ipartials.p, c->d_out, c->d_small + 8);
   }
@@ -759,7 +758,7 @@ int do_linearize_try(rgc_ctx* c, const double x0[16], double lambda, double H[36
   {
     ProfScope ps(c, RGC_K_LINEARIZE, n);
     rgck::linearize(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
-                    pose_from(x0), c->tgt.vgrid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p,
+                    pose_from(x0), c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p,
                     (double*)c->corr_M.p, 1, (double*)c->partials.p, (int*)c->ipartials.p, c->d_out, c->d_small + 8);
     rgck::lm_try(c->stream, c->d_out, c->d_small + 8, in);
   }
@@ -862,13 +861,9 @@ int prepare_map_grid(rgc_ctx* c, Cloud& cl, double cell) {
   }
   if (ncell > (double)c->prm.max_cells || ncell > 2.0e9) return fail(c, RGC_ERR_GRID_TOO_LARGE, "feature-map grid exceeds max_cells");
   g.res = cell;
-  g.vres = cell;
-  g.sub = 1;
-  g.pad = 0;
   g.inv_res = rgck::grid_inv_res(cell);
   g.ncell = (int)ncell;
   cl.grid = g;
-  cl.vgrid = g;
   const size_t nc1 = (size_t)g.ncell + 1;
   if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;
   if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;
@@ -1127,20 +1122,13 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
     memset(c->h_post, 0, sizeof(rgck::LmState));
     if (hipHostGetDevicePointer((void**)&c->d_post, c->h_post, 0) != hipSuccess) c->d_post = nullptr;  // (no fast path then)
   }
-  if (const char* e = getenv("RGC_LM_POST")) c->post_on = atoi(e) != 0;
   c->uid = g_next_uid.fetch_add(1);
   ok = ok && hipEventCreateWithFlags(&c->src_read_done, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->lm_tail, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->tgt_prepared, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->vg_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_vg, 4 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
-  if (const char* e = getenv("RGC_SMALL_COPY")) c->small_copy_always = atoi(e) != 0;
-  if (const char* e = getenv("RGC_FE_SPEC")) c->fe_spec_on = atoi(e) != 0;
-  if (const char* e = getenv("RGC_MAP_HALF")) c->map_half = atoi(e) != 0;
-  if (const char* e = getenv("RGC_SOLVE_BEHIND_MAP")) c->solve_behind_map = atoi(e) != 0;
-  if (const char* e = getenv("RGC_MAP_WIDE_R")) { const int v = atoi(e); if (v == 0 || v == 2) c->map_wide_r = v; }
-  if (const char* e = getenv("RGC_MAP_WIDE")) { const double v = atof(e); if (v >= 0.0 && std::isfinite(v)) c->map_wide_density = v; }
-  if (const char* e = getenv("RGC_SRC_RES")) { const double v = atof(e); if (v > 0.0 && std::isfinite(v)) c->src_res = v; }
   if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   { std::lock_guard<std::mutex> lk(g_live_mutex); g_live.insert(c); }
@@ -1184,6 +1172,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->main_mark) (void)hipEventDestroy(c->main_mark);
   if (c->tgt_ready) (void)hipEventDestroy(c->tgt_ready);
   if (c->src_read_done) (void)hipEventDestroy(c->src_read_done);
+  if (c->lm_tail) (void)hipEventDestroy(c->lm_tail);
   if (c->tgt_prepared) (void)hipEventDestroy(c->tgt_prepared);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -1244,7 +1233,7 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
   const DevBuf* ob[] = {&o.in_copy, &o.cell_of, &o.slot_of, &o.cnt, &o.start, &o.block_sums, &o.order_tmp, &o.P, &o.nx, &o.ny, &o.nz, &o.segs,
                         &o.cell_voxel, &o.vox, &o.vox_cell};
   for (size_t k = 0; k < sizeof(db) / sizeof(db[0]); k++) { db[k]->p = ob[k]->p; db[k]->cap = ob[k]->cap; db[k]->borrowed = ob[k]->p != nullptr; }
-  d.in = o.in; d.stride_f = o.stride_f; d.n = o.n; d.grid = o.grid; d.vgrid = o.vgrid; d.nvox = o.nvox; d.deferred_seen = o.deferred_seen;
+  d.in = o.in; d.stride_f = o.stride_f; d.n = o.n; d.grid = o.grid; d.grid = o.grid; d.nvox = o.nvox; d.deferred_seen = o.deferred_seen;
   d.spec_ok = false; d.spec_used = false; d.cnt_clean = 0; d.cnt_seen = nullptr;
   d.ready = true;
   const int small[2] = {0, o.nvox};  // this context's copy of the target's guard (clear) and voxel count, which the solve reads
@@ -1266,6 +1255,9 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
 // preparation is done, they run under the current frame's SOLVE, a chain of short launches that leaves the chip mostly idle.
 int rgc_hold_source_until_target_of(rgc_ctx* c, rgc_ctx* other) {
   if (!c || !other) return RGC_ERR_INVALID;
+  // (the other context must be alive while its event is handed to the runtime: checked and used under the registry's lock)
+  std::lock_guard<std::mutex> lk(g_live_mutex);
+  if (!g_live.count(other)) return fail(c, RGC_ERR_INVALID, "rgc_hold_source_until_target_of: the other context has been destroyed");
   if (c->device != other->device) return fail(c, RGC_ERR_INVALID, "rgc_hold_source_until_target_of: the contexts are on different devices");
   HIPCHK(c, hipSetDevice(c->device));
   // the scan's stream waits for the end of other's latest target preparation (a wait on an event nobody recorded yet is no wait)
@@ -1306,7 +1298,7 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
   constexpr int kTail = 3;
   auto step = [&](const rgck::LmInit* op) {
     rgck::lm_step(s, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
-                  c->tgt.vgrid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
+                  c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
                   (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, op, c->d_small + 7,
                   c->tgt.segs.p, c->src.segs.p, post, seq);
   };
@@ -1334,6 +1326,8 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
     if (want_fitness && batch <= 0) score();
   }
   HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipEventRecord(c->lm_tail, s));
+  c->lm_tail_stream = s;
   return RGC_OK;
 }
 
@@ -1364,6 +1358,10 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
     HIPCHK(c, hipEventRecord(c->tgt_ready, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->tgt_ready, 0));
   }
+  // rgc_align_end returns as soon as the device POSTS the finished state: the previous solve's spare steps, score launches and the copy
+  // into h_lm may still be queued on the stream they were enqueued on.  A solve that goes to the other stream is ordered behind them
+  // (they work on the same LM state and tickets); a wait on an event that has already fired costs nothing.
+  if (c->lm_tail_stream && c->lm_tail_stream != c->solve_stream) HIPCHK(c, hipStreamWaitEvent(c->solve_stream, c->lm_tail, 0));
   const rgc_params& P = c->prm;
   // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_step);
   // the host only enqueues slots and reads the state back once per batch.
@@ -1409,7 +1407,7 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
   c->pend.active = false;
   int rc;
   const bool want_fitness = c->pend.want_fitness;
-  rgck::LmState& S = *c->h_lm;
+  rgck::LmState& S = c->lm_res;  // (not h_lm itself: the stream's copy into it may still be in flight when a posted state is taken)
   for (int guard = 0;; guard++) {
     // The device posts a finished solve's state into mapped host memory and then the solve's number: the host spins on that word and
     // leaves as soon as it shows up -- the blind launches behind the deciding one and the stream's copy drain in the background.
@@ -1428,13 +1426,16 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
         memcpy(&S, c->h_post, sizeof(S));
       }
     }
-    if (!posted) HIPCHK(c, hipStreamSynchronize(c->solve_stream));
+    if (!posted) {
+      HIPCHK(c, hipStreamSynchronize(c->solve_stream));
+      memcpy(&S, c->h_lm, sizeof(S));
+    }
     HIPCHK(c, hipGetLastError());
     if (S.done || guard >= 400) break;
     // a solve that is still running after six outer iterations usually runs many more (up to 25): batches of six, fewer read-backs
     if ((rc = lm_enqueue_batch(c, 6, nullptr, want_fitness))) return rc;
   }
-  c->src_pending = false;  // stream2 has drained, and it was behind the main stream: nothing of this frame is in flight
+  c->src_pending = false;  // the solve came after the scan's preparation and has finished (its spare launches may still drain: lm_tail)
   c->main_has_target_prep = false;  // (the solve came after the map's preparation)
   c->small_clean[0] = c->small_clean[1] = true;  // the solve's first step re-initialised both blocks after capturing them
   {  // a cloud that did not fit its speculative grid: everything above ran on a parked cloud -- prepare it properly, solve again
@@ -1667,17 +1668,14 @@ static int set_covs(rgc_ctx* c, Cloud& cl, bool is_target, const double* cov9, i
   HIPCHK(c, hipMemcpyAsync(c->scratch.p, nrm.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
   rgck::sort3(c->stream, (const double*)c->scratch.p, (const float4*)cl.P.p, n, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
   if (is_target) {
-    if (cl.grid.sub == 2)
-      rgck::voxel_build_h(c->stream, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
-                          cl.grid, (int)(n < cl.vgrid.ncell ? n : cl.vgrid.ncell), c->d_small + 7, (const int*)cl.vox_cell.p, (double*)cl.vox.p);
-    else
-      rgck::voxel_build(c->stream, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
-                        cl.grid, n, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p);
+    rgck::voxel_build(c->stream, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
+                      cl.grid, n, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p);
     c->tgt_generation++;   // borrowers of this target must share again
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));   // (the host vector goes out of scope)
   HIPCHK(c, hipGetLastError());
   c->corr_valid = false;
+  cl.covs_user = true;
   return RGC_OK;
 }
 int rgc_set_source_covariances(rgc_ctx* c, const double* cov9, int n) { return c ? set_covs(c, c->src, false, cov9, n) : RGC_ERR_INVALID; }
@@ -1708,14 +1706,49 @@ int rgc_swap_source_and_target(rgc_ctx* c) {
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  // Covariances the CALLER set travel with their cloud (the reference swaps source_covs_ and target_covs_, fast_vgicp_impl.hpp:46-53):
+  // taken out in the caller's point order here, put back into the new ordering behind the preparation (computed ones are simply
+  // computed again: the same function of the cloud).
+  struct Kept { bool on = false; void* p = nullptr; } kept[2];  // [0]: the old source's (-> new target), [1]: the old target's (-> new source)
+  auto drop_kept = [&]() { for (auto& k : kept) if (k.p) { (void)hipFree(k.p); k.p = nullptr; } };
+  {
+    Cloud* from[2] = {&c->src, &c->tgt};
+    for (int a = 0; a < 2; a++) {
+      if (!from[a]->covs_user) continue;
+      kept[a].on = true;
+      if (hipMalloc(&kept[a].p, sizeof(double) * 3 * (size_t)from[a]->n) != hipSuccess) { drop_kept(); return fail(c, RGC_ERR_HIP, "hipMalloc failed (swap)"); }
+      rgck::unsort3(c->stream, (const double*)from[a]->nx.p, (const double*)from[a]->ny.p, (const double*)from[a]->nz.p, (const float4*)from[a]->P.p,
+                    from[a]->n, (double*)kept[a].p);
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { drop_kept(); return fail(c, RGC_ERR_HIP, "hipStreamSynchronize failed (swap)"); }
+  }
   std::swap(c->src.in_copy, c->tgt.in_copy);
   std::swap(c->src.in, c->tgt.in);
   std::swap(c->src.stride_f, c->tgt.stride_f);
   std::swap(c->src.n, c->tgt.n);
   c->src.ready = c->tgt.ready = false;
   c->corr_valid = false; c->deferred_known = false; c->map_bound = false;
-  if ((rc = prepare_cloud(c, c->tgt, true, /*force_bbox=*/true))) return rc;
-  if ((rc = prepare_cloud(c, c->src, false, /*force_bbox=*/true))) return rc;
+  if ((rc = prepare_cloud(c, c->tgt, true, /*force_bbox=*/true))) { drop_kept(); return rc; }
+  if ((rc = prepare_cloud(c, c->src, false, /*force_bbox=*/true))) { drop_kept(); return rc; }
+  if (kept[0].on || kept[1].on) {
+    hipError_t e = hipStreamSynchronize(c->stream2);
+    if (e == hipSuccess && kept[0].on) {  // the old source's covariances on the new target: normals, then its voxel map from them
+      Cloud& cl = c->tgt;
+      rgck::sort3(c->stream, (const double*)kept[0].p, (const float4*)cl.P.p, cl.n, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
+      rgck::voxel_build(c->stream, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
+                        cl.grid, cl.n, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p);
+      cl.covs_user = true;
+    }
+    if (e == hipSuccess && kept[1].on) {
+      Cloud& cl = c->src;
+      rgck::sort3(c->stream, (const double*)kept[1].p, (const float4*)cl.P.p, cl.n, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
+      cl.covs_user = true;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    drop_kept();
+    if (e != hipSuccess) return fail(c, RGC_ERR_HIP, "swap: %s", hipGetErrorString(e));
+    c->src_pending = false;  // (both streams have drained)
+  }
   c->stats.n_target = c->tgt.n; c->stats.target_cells = c->tgt.grid.ncell;
   c->stats.n_source = c->src.n; c->stats.source_cells = c->src.grid.ncell;
   return RGC_OK;
@@ -1747,7 +1780,7 @@ int rgc_get_voxels(rgc_ctx* c, int cap, int* coords, int* num, double* mean, dou
   HIPCHK(c, hipMemcpyAsync(rec.data(), c->tgt.vox.p, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(cell.data(), c->tgt.vox_cell.p, sizeof(int) * cell.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const rgck::Grid& g = c->tgt.vgrid;
+  const rgck::Grid& g = c->tgt.grid;
   for (int v = 0; v < m; v++) {
     const double* r = &rec[(size_t)v * rgck::kVoxRec];
     const int ci = cell[v];
@@ -1838,6 +1871,11 @@ int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_b
   if (!c || !d_xyzi || !q || !t || !d_scratch || n <= 0) return RGC_ERR_INVALID;
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
   if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  {  // the re-framed cloud is WRITTEN to d_scratch while d_xyzi is read: they must not overlap (and one buffer has one bounding-box hint)
+    const char* a0 = (const char*)d_xyzi; const char* a1 = a0 + (size_t)n * stride_bytes;
+    const char* b0 = (const char*)d_scratch; const char* b1 = b0 + (size_t)n * 16;
+    if (a0 < b1 && b0 < a1) return fail(c, RGC_ERR_INVALID, "rgc_set_target_reframed: d_scratch overlaps d_xyzi");
+  }
   HIPCHK(c, hipSetDevice(c->device));
   const float* xyzi = d_xyzi;
   const float* d_in = d_xyzi;
@@ -2332,6 +2370,16 @@ int rgc_device_free(rgc_ctx* c, void* p) {
   HIPCHK(c, hipFree(p));
   return RGC_OK;
 }
+int rgc_host_alloc(size_t bytes, void** p) {
+  if (!p) return RGC_ERR_INVALID;
+  *p = nullptr;
+  return hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable) == hipSuccess ? RGC_OK : RGC_ERR_HIP;
+}
+int rgc_host_free(void* p) {
+  if (!p) return RGC_OK;
+  return hipHostFree(p) == hipSuccess ? RGC_OK : RGC_ERR_HIP;
+}
+
 int rgc_upload(rgc_ctx* c, void* d, const void* h, size_t bytes) {
   if (!c || !d || !h) return RGC_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));

@@ -6,50 +6,28 @@
 
 namespace rgck {
 
-// Dense voxel-aligned grid.  sub = 1: cell c (per axis) covers [(c + minc + 0.5) * res, (c + minc + 1.5) * res):
-// this is fast_gicp's voxel_coord = floor(x / res - 0.5) (fast_vgicp_voxel.hpp:158-160) shifted by minc, so
-// the exact-kNN search grid and the Gaussian voxel map of the target are the SAME partition.
-// sub = 2 (the dense map's search grid): cells of HALF the voxel size nested in the voxels -- cell = floor(2 u) with
-// u = x / vres - 0.5 the voxel coordinate before the floor, so voxel = cell >> 1 exactly (2 u is exact in fp64) and
-// cell c covers [(c + minc + 1) * res, (c + minc + 2) * res).  pad: empty cells kept on every side of the cloud's box, so that
-// the (2 pad + 1)^3 block of any point's cell lies inside the arrays (no clamping in the search).
+// Dense voxel-aligned grid: cell c (per axis) covers [(c + minc + 0.5) * res, (c + minc + 1.5) * res): this is fast_gicp's
+// voxel_coord = floor(x / res - 0.5) (fast_vgicp_voxel.hpp:158-160) shifted by minc, so the exact-kNN search grid and the Gaussian
+// voxel map of the target are the SAME partition.
 struct Grid {
   int minc[3];
   int dim[3];
   double res;      // cell size
   int ncell;
-  double inv_res;  // 1 / vres when vres is a power of two (x / vres == x * inv_res bit for bit), else 0: see grid_inv_res()
-  double vres;     // voxel size = res * sub
-  int sub, pad;
+  double inv_res;  // 1 / res when res is a power of two (x / res == x * inv_res bit for bit), else 0: see grid_inv_res()
 };
 inline double grid_inv_res(double res) {
   int e;
   return std::frexp(res, &e) == 0.5 ? 1.0 / res : 0.0;
 }
-inline Grid make_grid(const int minc[3], const int dim[3], double res) {  // sub = 1, no padding: cells = voxels of size res
+inline Grid make_grid(const int minc[3], const int dim[3], double res) {
   Grid g{};
   double nc = 1.0;
   for (int a = 0; a < 3; a++) { g.minc[a] = minc[a]; g.dim[a] = dim[a]; nc *= (double)dim[a]; }
-  g.res = res; g.vres = res; g.sub = 1; g.pad = 0;
+  g.res = res;
   g.inv_res = grid_inv_res(res);
   g.ncell = nc <= 2.0e9 ? (int)nc : -1;
   return g;
-}
-// the half-size search grid nested in voxel grid v (sub = 1), padded by two cells (= one voxel) on every side, and the voxel
-// grid that goes with it (v grown by that voxel: its relative coordinates are the search grid's >> 1)
-inline Grid half_grid_of(const Grid& v, Grid* vox_padded) {
-  Grid h{}, w = v;
-  double nc = 1.0, nw = 1.0;
-  for (int a = 0; a < 3; a++) {
-    w.minc[a] = v.minc[a] - 1; w.dim[a] = v.dim[a] + 2; nw *= (double)w.dim[a];
-    h.minc[a] = 2 * w.minc[a]; h.dim[a] = 2 * w.dim[a]; nc *= (double)h.dim[a];
-  }
-  w.ncell = nw <= 2.0e9 ? (int)nw : -1;
-  h.res = v.res * 0.5; h.vres = v.res; h.sub = 2; h.pad = 2;
-  h.inv_res = v.inv_res;
-  h.ncell = nc <= 2.0e9 ? (int)nc : -1;
-  if (vox_padded) *vox_padded = w;
-  return h;
 }
 
 struct Pose {  // row-major rotation + translation, fp64 (Eigen::Isometry3d in the reference)
@@ -84,16 +62,13 @@ constexpr int kVoxRec = 10; // mean(3) cov6(6) num(1), doubles
 // Sorted points are float4 {x, y, z, original index (int bits)} grouped by grid cell.
 // ---- grid build ----
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi = 0);
-// vocc (g.sub == 2 only, nullable): occupancy flags of the voxel grid that goes with g (half_grid_of), set to 1 where a point falls
 // rf (nullable): in[] is first WRITTEN from rf->src (see Reframe; in must then be a 16-byte-stride device buffer this call may write)
 void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi = 0, int* guard = nullptr,
-                 int* vocc = nullptr, const Reframe* rf = nullptr);
+                 const Reframe* rf = nullptr);
 // cnt: n = cells + 1 entries; block_sums: >= 8 * (n / 2048 + 2) bytes; cell_voxel (n - 1 ints) and nvox may be null
 // consumes the counters: cnt[0..n) is left ZERO
-// nsplit >= 0: cnt[0..nsplit) are cell counters (+ sentinel) and get start[]; cnt[nsplit..n) are voxel occupancy flags (count_cells'
-// vocc) and get cell_voxel[i - nsplit] = dense voxel id or -1, vox_cell[id] = i - nsplit, *nvox = number of voxels
 void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi = 0,
-                float* sum_sq = nullptr /* += sum of count^2, nullable */, int nsplit = -1, int* vox_cell = nullptr);
+                float* sum_sq = nullptr /* += sum of count^2, nullable */);
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi = 0);
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */, int hi = 0);
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
@@ -106,7 +81,7 @@ size_t deferred_bytes(int n);
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard = nullptr, int wide_r = 0,
               hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* dense-map launch only (knn_bulk_times_itself): the launch's own start / stop times */);
-bool knn_bulk_times_itself(bool is_target, Grid g, int wide_r);
+bool knn_bulk_times_itself(bool is_target, int wide_r);
 // waves: one-wave workgroups that share the deferred list (clamped to [32, 8192])
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard, int waves);
@@ -116,14 +91,10 @@ void voxel_build(hipStream_t s, const float4* P, const double* nx, const double*
 // voxel_build and knn_coop (target) in one launch, followed by voxel_patch: see k_voxel_build_coop
 void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
                       double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves);
-// the voxels that hold a deferred query, recomputed (sub = 1 layout): lets the cooperative search run BESIDE voxel_build; lanes: about
+// the voxels that hold a deferred query, recomputed: lets the cooperative search run BESIDE voxel_build; lanes: about
 // the number of deferred queries (grid-stride loop)
 void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g, const void* deferred,
                  const int* cell_voxel, double* vox, int lanes);
-// the same from a half-size search grid (g.sub == 2, k <= 20 only in knn_bulk): one lane per voxel id < *nvox (launch sized by max_vox);
-// vox_cell from scan_cells
-void voxel_build_h(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
-                   int max_vox, const int* nvox, const int* vox_cell, double* vox);
 // ---- C4/C5/C6 ----
 void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
                const int* cell_voxel, const double* vox, int noff, int* corr_v, double* corr_M, int want_H, double* partials,

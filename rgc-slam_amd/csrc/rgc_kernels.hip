@@ -34,15 +34,14 @@ namespace rgck {
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ int voxel_coord1(float x, double res) { return (int)floor((double)x / res - 0.5); }
-// Cell of grid g (absolute, before - minc) along one axis.  u = the voxel coordinate before the floor, without the fp64 division
-// when the voxel size is a power of two (the product is then the same double); sub = 2: the half cell floor(2 u) -- 2 u is exact,
-// so (cell >> 1) == floor(u) == the voxel, point by point (Grid in rgc_kernels.h).
+// Cell of grid g (absolute, before - minc) along one axis: floor(x / res - 0.5), without the fp64 division when the cell size is a
+// power of two (the product is then the same double).
 __device__ __forceinline__ int cell_coord(float x, const Grid& g) {
-  const double u = g.inv_res != 0.0 ? (double)x * g.inv_res - 0.5 : (double)x / g.vres - 0.5;
-  return g.sub == 1 ? (int)floor(u) : (int)floor(2.0 * u);
+  const double u = g.inv_res != 0.0 ? (double)x * g.inv_res - 0.5 : (double)x / g.res - 0.5;
+  return (int)floor(u);
 }
 // lower wall of cell c (relative) along axis a; the upper wall is + g.res
-__device__ __forceinline__ double cell_wall(const Grid& g, int a, int c) { return ((double)(c + g.minc[a]) + 0.5 * (double)g.sub) * g.res; }
+__device__ __forceinline__ double cell_wall(const Grid& g, int a, int c) { return ((double)(c + g.minc[a]) + 0.5) * g.res; }
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -182,11 +181,6 @@ __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ in, int 
 __device__ __forceinline__ int cell_index(const Grid& g, int cx, int cy, int cz) {
   return RGC_Y_SLOWEST ? (cy * g.dim[2] + cz) * g.dim[0] + cx : (cz * g.dim[1] + cy) * g.dim[0] + cx;
 }
-// the voxel grid that goes with a half-size search grid g (Grid::sub == 2, half_grid_of): dims g.dim / 2, same cell order
-__device__ __forceinline__ int voxel_index_h(const Grid& g, int vx, int vy, int vz) {
-  const int d0 = g.dim[0] >> 1, d1 = g.dim[1] >> 1, d2 = g.dim[2] >> 1;
-  return RGC_Y_SLOWEST ? (vy * d2 + vz) * d0 + vx : (vz * d1 + vy) * d0 + vx;
-}
 // which (dy, dz) the r-th row of a D x D block is, rows counted in MEMORY order
 __device__ __forceinline__ constexpr int row_dy(int r, int D, int R) { return (RGC_Y_SLOWEST ? r / D : r % D) - R; }
 __device__ __forceinline__ constexpr int row_dz(int r, int D, int R) { return (RGC_Y_SLOWEST ? r % D : r / D) - R; }
@@ -207,7 +201,7 @@ __device__ __forceinline__ float4 reframe_point(const Reframe& rf, int i) {
 
 template <bool kReframe>
 __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* __restrict__ slot_of,
-                        int* cnt, int* guard, int prio, int* __restrict__ vocc, Reframe rf) {
+                        int* cnt, int* guard, int prio, Reframe rf) {
   wave_prio(prio);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < n;
@@ -231,9 +225,8 @@ __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid 
       cx = fin ? cell_coord(x, g) - g.minc[0] : 0;
       cy = fin ? cell_coord(y, g) - g.minc[1] : 0;
       cz = fin ? cell_coord(z, g) - g.minc[2] : 0;
-      // (a padded grid keeps g.pad empty cells on every side: a point there is outside the box the grid was made for)
-      const bool inside = cx >= g.pad && cx < g.dim[0] - g.pad && cy >= g.pad && cy < g.dim[1] - g.pad && cz >= g.pad && cz < g.dim[2] - g.pad;
-      if (!fin || !inside) { atomicOr(guard, fin ? 2 : 1); cx = cy = cz = g.pad; }
+      const bool inside = cx >= 0 && cx < g.dim[0] && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
+      if (!fin || !inside) { atomicOr(guard, fin ? 2 : 1); cx = cy = cz = 0; }
     } else {
       cx = cell_coord(p[0], g) - g.minc[0];
       cy = cell_coord(p[1], g) - g.minc[1];
@@ -241,9 +234,6 @@ __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid 
     }
     c = cell_index(g, cx, cy, cz);
     cell_of[i] = c;
-    // sub = 2: the voxel of this cell is occupied (plain stores of the same value: no atomic needed); vocc is laid out like the
-    // voxel grid that goes with g (half_grid_of: relative voxel coordinates = cell coordinates >> 1) and scanned with the counters
-    if (vocc) vocc[voxel_index_h(g, cx >> 1, cy >> 1, cz >> 1)] = 1;
   }
   // Clouds arrive spatially coherent (ring order, leaf order): consecutive lanes that fall into the same cell form a RUN, and
   // only the run's first lane goes to memory -- one atomicAdd(run length) instead of one per point.  A crowded cell near the
@@ -362,27 +352,16 @@ __device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned lo
 }
 
 // cnt has n entries (cells + 1 sentinel of 0); cell_voxel (nullable) has n - 1.
-// nsplit >= 0 (the dense map's half-size search grid): entries [0, nsplit) are the cells' counters (+ sentinel) and only get their
-// start[]; entries [nsplit, n) are the OCCUPANCY flags of the voxel grid that goes with it (k_count's vocc): they count in the high
-// half only and get cell_voxel[i - nsplit] (and, once final, vox_cell[id] = i - nsplit) -- the voxel numbering of a grid whose
-// voxels are not contiguous in the cell order still falls out of the one scan.
-struct ScanSplit {
-  int nsplit;     // < 0: every cell is a voxel (sub = 1)
-  int* vox_cell;  // nsplit >= 0 only
-};
-__device__ __forceinline__ unsigned long long scan_value(int v, int i, int nsplit) {
-  if (nsplit < 0) return (unsigned long long)(unsigned)v | ((unsigned long long)(v > 0) << 32);
-  return i < nsplit ? (unsigned long long)(unsigned)v : ((unsigned long long)(v != 0) << 32);
-}
+__device__ __forceinline__ unsigned long long scan_value(int v) { return (unsigned long long)(unsigned)v | ((unsigned long long)(v > 0) << 32); }
 // Reduce, then scan (round 3; the first pass used to write provisional start[] / cell_voxel[] that the second read, corrected and
 // wrote again: 58 MB of traffic for a 2.4 M-cell grid, now 38):
 //   pass 1 (k_cells_reduce): every workgroup's total of its SCAN_B entries -- reads only (and the scan grid's crowding figure);
 //   pass 2 (k_cells_scan_write): the totals of the workgroups before this one (summed by the workgroup itself for <= 4096 of them,
-//           else taken from k_cells_scan_sums), the entries once more, their exclusive scan, and start[] / cell_voxel[] / vox_cell[]
+//           else taken from k_cells_scan_sums), the entries once more, their exclusive scan, and start[] / cell_voxel[]
 //           written ONCE with their final values; the counters are consumed here (left at zero for the next cloud).
 // A grid of one workgroup needs pass 2 only.
 __global__ void __launch_bounds__(SCAN_T) k_cells_reduce(const int* __restrict__ cnt, int n, unsigned long long* __restrict__ block_sums, int prio,
-                                                         float* __restrict__ sum_sq, ScanSplit sp) {
+                                                         float* __restrict__ sum_sq) {
   wave_prio(prio);
   __shared__ unsigned long long part[SCAN_T / WAVE];
   const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
@@ -391,7 +370,7 @@ __global__ void __launch_bounds__(SCAN_T) k_cells_reduce(const int* __restrict__
 #pragma unroll
   for (int j = 0; j < SCAN_V; j++) {
     v[j] = (base + j < n) ? cnt[base + j] : 0;
-    s += scan_value(v[j], base + j, sp.nsplit);
+    s += scan_value(v[j]);
   }
   if (sum_sq) {  // sum of count^2 = the work of every point scanning its own cell: how crowded the cells are (a heuristic, float is plenty)
     float q = 0.f;
@@ -435,7 +414,7 @@ __global__ void k_cells_scan_sums(unsigned long long* sums, int nb, int* __restr
 template <bool kSelf>
 __global__ void __launch_bounds__(SCAN_T) k_cells_scan_write(int* __restrict__ cnt, int* __restrict__ start, int n,
                                                              const unsigned long long* __restrict__ block_sums, int nb, int* __restrict__ cell_voxel,
-                                                             int* __restrict__ nvox, int prio, ScanSplit sp) {
+                                                             int* __restrict__ nvox, int prio) {
   wave_prio(prio);
   __shared__ unsigned long long part[SCAN_T / WAVE];
   __shared__ unsigned long long pre_s;
@@ -445,7 +424,7 @@ __global__ void __launch_bounds__(SCAN_T) k_cells_scan_write(int* __restrict__ c
 #pragma unroll
   for (int j = 0; j < SCAN_V; j++) {
     v[j] = (base + j < n) ? cnt[base + j] : 0;
-    s += scan_value(v[j], base + j, sp.nsplit);
+    s += scan_value(v[j]);
   }
   if (kSelf) {
     unsigned long long acc = 0;
@@ -473,18 +452,10 @@ __global__ void __launch_bounds__(SCAN_T) k_cells_scan_write(int* __restrict__ c
   for (int j = 0; j < SCAN_V; j++) {
     const int i = base + j;
     if (i < n) {
-      if (sp.nsplit < 0) {
-        start[i] = (int)(unsigned)ex;
-        if (cell_voxel && i < n - 1) cell_voxel[i] = v[j] > 0 ? (int)(ex >> 32) : -1;
-      } else if (i < sp.nsplit) {
-        start[i] = (int)(unsigned)ex;
-      } else {
-        const int id = v[j] != 0 ? (int)(ex >> 32) : -1;
-        cell_voxel[i - sp.nsplit] = id;
-        if (id >= 0) sp.vox_cell[id] = i - sp.nsplit;
-      }
+      start[i] = (int)(unsigned)ex;
+      if (cell_voxel && i < n - 1) cell_voxel[i] = v[j] > 0 ? (int)(ex >> 32) : -1;
     }
-    ex += scan_value(v[j], i, sp.nsplit);
+    ex += scan_value(v[j]);
   }
 }
 
@@ -1537,363 +1508,6 @@ k_knn_sp_wide(const float4* __restrict__ P, const int* __restrict__ start, Grid 
 }
 
 // ------------------------------------------------------------------------------------------------
-// C2 for a DENSE map, on the half-size search grid (Grid::sub == 2: cells of half the voxel size nested in the voxels, two empty
-// cells of padding on every side): knn_point_h / k_knn_h.  One lane per query and the selection machinery of knn_point_sp (packed
-// distance | ordinal keys, lazy append buffer, sorted register chain, sorting-network fill); what changes is WHICH candidates a
-// query looks at and in which order.  On the voxel grid the 3x3x3 block is nine rows of 3 m: ~105 candidates per query of a
-// 0.3 m-filtered map, the first 24 of them from a 3 m x 1 m strip -- a poor first bound, so ~18 more enter the chain later.
-// Here the 5x5x5 block of half cells proves the same radius (>= one voxel), and it is walked in two phases:
-//  1. the INNER 3x3x3 half cells (nine rows of three cells, 1.5 voxels across): about k + 2 points of a surface, the nearest
-//     ones -- after them the chain's tail is close to the final k-th distance;
-//  2. the SHELL, with that bound known: the inner rows' cells -2 / +2 and the sixteen outer rows, each entered only if its
-//     distance bound (cell walls) is below the tail.  On the c-main map: 49 candidates and 6 late insertions per query
-//     (scripts/sim_candidates.py).
-// A piece's last quad reads up to three points past it; those lanes are MASKED (one subtraction and three compares per quad):
-// with pieces this short the next piece of the block often begins right there -- a wall's cells are all a grid row holds -- and
-// a point seen twice would sit in the chain twice.
-// Ordinal of a candidate = {row of the 5x5 (y, z) rows (5 bits) | position - start of the row's cell -2 (6 bits)}: the winning
-// keys name their neighbours with one start[] load each, no per-lane table survives the scan.  Rows spanning more than 63 points
-// are left to the cooperative kernel (a leaf-filtered map has <= ~30).
-// LDS per lane: the append buffer and ONE piece table (12 entries) used by phase 1, then refilled by phase 2.
-// ------------------------------------------------------------------------------------------------
-constexpr int kHT = 256;                       // threads per workgroup
-constexpr int kHNT = 12;                       // piece-table entries per lane and phase
-constexpr int kHLds = kSpBuf + 2 * kHNT;       // ints of LDS per lane
-constexpr int kHPosBits = 6, kHSpanMax = (1 << kHPosBits) - 1;  // position field; rows longer than this are deferred
-
-struct HRow { signed char dy, dz; };
-// visiting order: the own row, the four rows sharing a face with it, the four diagonal ones; then ring 2 by distance
-__device__ constexpr HRow kHInner[9] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
-__device__ constexpr HRow kHOuter[16] = {{-2, 0}, {2, 0}, {0, -2}, {0, 2}, {-2, -1}, {2, -1}, {-2, 1}, {2, 1}, {-1, -2}, {1, -2}, {-1, 2}, {1, 2},
-                                          {-2, -2}, {2, -2}, {-2, 2}, {2, 2}};
-__device__ __forceinline__ constexpr int hrow_id(int dy, int dz) { return (dz + 2) * 5 + (dy + 2); }
-
-__device__ __forceinline__ int2 load_int2(const int* __restrict__ p) {  // 4-byte aligned pair (global memory: any dword alignment)
-  int2 v;
-  __builtin_memcpy(&v, p, sizeof(v));
-  return v;
-}
-
-template <int KC, int T>
-__device__ __forceinline__ void knn_point_h(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k, int i,
-                                            int* lds, const int* rowoff, const Deferred& df, double* __restrict__ nx,
-                                            double* __restrict__ ny, double* __restrict__ nz) {
-  constexpr int L = KC + 2;
-  constexpr int KB = 5 + kHPosBits;
-  constexpr int kKeyOrd = (1 << KB) - 1;
-  constexpr int kPosMask = (1 << kHPosBits) - 1;
-  static_assert(L <= 24, "initial fill by the 24-input network");
-  lds_int* const buf = (lds_int*)lds;          // [kSpBuf][T]
-  lds_int* const tmix = buf + kSpBuf * T;      // [kHNT][T]: {distance bound (fp32, low 17 bits cut) | first ordinal (11 bits) | length (6 bits)}
-  lds_int* const tlo = tmix + kHNT * T;        // [kHNT][T]: first position
-  const float4 pq = P[i];
-  const float px = pq.x, py = pq.y, pz = pq.z;
-  const int c[3] = {cell_coord(px, g) - g.minc[0], cell_coord(py, g) - g.minc[1], cell_coord(pz, g) - g.minc[2]};
-  const double q[3] = {(double)px, (double)py, (double)pz};
-  const int rb0 = cell_index(g, c[0], c[1], c[2]);
-  const int sy = cell_index(g, 0, 1, 0) - cell_index(g, 0, 0, 0), sz = cell_index(g, 0, 0, 1) - cell_index(g, 0, 0, 0);  // row strides (uniform)
-  auto defer = [&](int enc, float thr, int why = 0) {
-#ifdef RGC_LAB
-    atomicAdd(&g_lab_why[why], 1);  // 1 row too long, 2 table full, 4 < k, 5 unproven, 6 tie
-#endif
-    const int e = atomicAdd(df.cnt, 1);
-    df.idx[e] = enc;
-    df.thr[e] = thr;
-  };
-  // distance from the query to the walls of its cell, rounded DOWN a little (every bound below must never be too high)
-  float wl[3], wh[3];
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    const double wall = cell_wall(g, a, c[a]);
-    wl[a] = (float)(fmax(q[a] - wall, 0.0) * (1.0 - 1.0e-6));
-    wh[a] = (float)(fmax(wall + g.res - q[a], 0.0) * (1.0 - 1.0e-6));
-  }
-  const float hres = (float)(g.res * (1.0 - 1.0e-6));
-  auto gap = [&](int a, int d) { return d == 0 ? 0.f : (d == -1 ? wl[a] : (d == 1 ? wh[a] : (d < 0 ? wl[a] + hres : wh[a] + hres))); };
-  auto sq = [](float v) { return v * v * (1.f - 1.0e-6f); };
-  auto row_bound = [&](int dy, int dz) { return sq(gap(1, dy)) + sq(gap(2, dz)); };
-  const float gxl2 = sq(wl[0] + hres), gxr2 = sq(wh[0] + hres);  // to the cells -2 / +2 of a row, along x
-
-  // ---- piece table of the current phase ----
-  int nr = 0;
-  bool heavy = false;
-  lds_int* tp = tmix;  // next free entry of this lane's column
-  auto put = [&](bool cond, int lo, float bound, int row, int pos0, int len) {
-    if (cond) {
-      if (nr < kHNT) {
-        tp[0] = (__float_as_int(bound) & 0xFFFE0000) | (((row << kHPosBits) | pos0) << 6) | len;
-        tp[kHNT * T] = lo;
-        tp += T;
-        nr++;
-      } else {
-        heavy = true;  // more pieces than the table holds
-      }
-    }
-  };
-  {  // phase 1: the inner rows' cells -1 .. +1
-    int2 lf[9], rt[9];
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-      const int rb = rb0 + kHInner[r].dy * sy + kHInner[r].dz * sz;
-      lf[r] = load_int2(start + rb - 2);  // starts of the cells -2, -1
-      rt[r] = load_int2(start + rb + 2);  // starts of the cells +2, +3
-    }
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-      heavy |= rt[r].y - lf[r].x > kHSpanMax;
-      put(rt[r].x > lf[r].y, lf[r].y, row_bound(kHInner[r].dy, kHInner[r].dz), hrow_id(kHInner[r].dy, kHInner[r].dz), lf[r].y - lf[r].x,
-          rt[r].x - lf[r].y);
-    }
-  }
-  if (heavy) {
-    defer(i, INFINITY, 1);
-    return;
-  }
-  // ---- one pass over the candidate stream (the machinery of knn_point_sp) ----
-  Chain<L> top;
-  top.init();
-  int tau = INT_MAX, ri = 0, ordn = 0;
-  unsigned off = 0, end = 0;
-  lds_int* bp = buf;
-  lds_int* const bp_full = buf + (kSpBuf - 4) * T;
-  auto pop = [&]() {
-    int key = INT_MAX;
-    if (bp != buf) {
-      bp -= T;
-      key = *bp;
-    }
-    return key;
-  };
-  auto drain = [&]() {
-    int key = pop();
-    for (;;) {
-      const int nkey = pop();
-      top.insert(key);
-      if (!__any(nkey != INT_MAX)) break;
-      key = nkey;
-    }
-    tau = top.a[L - 1];
-  };
-  struct Quad { float4 p0, p1, p2, p3; int ord; unsigned rem; bool live; };  // rem: bytes of the piece left at this quad (0: no quad)
-  auto fetch = [&](Quad& qd) {
-    if (off >= end && ri < nr) {
-      // next piece -- as an EMPTY one if its distance bound is not below the chain's tail any more
-      const int mix = tmix[ri * T];
-      const int len = (__int_as_float(mix & 0xFFFE0000) >= __int_as_float(tau | kKeyOrd)) ? 0 : (mix & 63);
-      off = (unsigned)tlo[ri * T] << 4;
-      end = off + ((unsigned)len << 4);
-      ordn = (mix >> 6) & kKeyOrd;
-      ri++;
-    }
-    const bool on = off < end;
-    qd.rem = on ? end - off : 0u;
-    qd.live = on || ri < nr;
-    qd.ord = ordn;
-    const unsigned a = on ? off : (unsigned)n << 4;  // unconditional loads (the sentinels behind the array), as in knn_point_sp
-    qd.p0 = point_at(P, a); qd.p1 = point_at(P, a + 16); qd.p2 = point_at(P, a + 32); qd.p3 = point_at(P, a + 48);
-    off += on ? 64u : 0u;
-    ordn += on ? 4 : 0;
-  };
-  auto key_of = [&](const float4& cp, int o) { return (__float_as_int(dist2_fma(px, py, pz, cp.x, cp.y, cp.z)) & ~kKeyOrd) | o; };
-  auto process = [&](const Quad& qd) {
-    if (qd.rem) {
-      const int k0 = key_of(qd.p0, qd.ord), k1 = key_of(qd.p1, qd.ord + 1), k2 = key_of(qd.p2, qd.ord + 2), k3 = key_of(qd.p3, qd.ord + 3);
-      if (k0 < tau) { *bp = k0; bp += T; }
-      if (k1 < tau && qd.rem > 16u) { *bp = k1; bp += T; }
-      if (k2 < tau && qd.rem > 32u) { *bp = k2; bp += T; }
-      if (k3 < tau && qd.rem > 48u) { *bp = k3; bp += T; }
-    }
-    if (__any(bp > bp_full)) drain();
-  };
-  Quad qa, qb;
-  auto stream = [&]() {  // the rest of the current table
-    fetch(qa);
-    for (;;) {
-      if (!__any(qa.live)) break;
-      fetch(qb);
-      process(qa);
-      if (!__any(qb.live)) break;
-      fetch(qa);
-      process(qb);
-    }
-    if (__any(bp != buf)) drain();
-  };
-  {  // the first 24 candidates through the sorting network (knn_point_sp)
-    int w[24];
-#pragma unroll
-    for (int t = 0; t < 6; t++) {
-      fetch(qa);
-      w[4 * t + 0] = qa.rem > 0u ? key_of(qa.p0, qa.ord) : INT_MAX;
-      w[4 * t + 1] = qa.rem > 16u ? key_of(qa.p1, qa.ord + 1) : INT_MAX;
-      w[4 * t + 2] = qa.rem > 32u ? key_of(qa.p2, qa.ord + 2) : INT_MAX;
-      w[4 * t + 3] = qa.rem > 48u ? key_of(qa.p3, qa.ord + 3) : INT_MAX;
-    }
-#pragma unroll
-    for (int e = 0; e < kSort24N; e++) {
-      const int a = kSort24[e] >> 5, b = kSort24[e] & 31;
-      const int lo_ = min(w[a], w[b]);
-      w[b] = max(w[a], w[b]);
-      w[a] = lo_;
-    }
-#pragma unroll
-    for (int j = 0; j < L; j++) top.a[j] = w[j];
-    tau = top.a[L - 1];
-  }
-  stream();
-  // ---- phase 2: the shell, against the bound phase 1 has reached ----
-  {
-    const float tau_f = __int_as_float(tau | kKeyOrd);  // (INT_MAX: NaN -- every comparison below is false, nothing is skipped)
-    nr = 0;
-    ri = 0;
-    tp = tmix;
-    off = end = 0;
-    bool want[9][2];
-    int2 lf[9], rt[9];
-#pragma unroll
-    for (int r = 0; r < 9; r++) {  // the inner rows' cells -2 and +2
-      const float rem = tau_f - row_bound(kHInner[r].dy, kHInner[r].dz);
-      want[r][0] = !(gxl2 >= rem);
-      want[r][1] = !(gxr2 >= rem);
-      const int rb = rb0 + kHInner[r].dy * sy + kHInner[r].dz * sz;
-      lf[r] = make_int2(0, 0);
-      rt[r] = make_int2(0, 0);
-      if (want[r][0] || want[r][1]) {
-        lf[r] = load_int2(start + rb - 2);
-        rt[r] = load_int2(start + rb + 2);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-      const int row = hrow_id(kHInner[r].dy, kHInner[r].dz);
-      const float rbnd = row_bound(kHInner[r].dy, kHInner[r].dz);
-      const int llen = lf[r].y - lf[r].x, rlen = rt[r].y - rt[r].x;
-      put(want[r][0] && llen > 0, lf[r].x, rbnd + gxl2, row, 0, llen);
-      put(want[r][1] && rlen > 0, rt[r].x, rbnd + gxr2, row, rt[r].x - lf[r].x, rlen);
-    }
-#pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 4) {  // the outer rows, whole (cells -2 .. +2), four at a time
-      int a0[4], b0[4];
-      bool w4[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const HRow hr = kHOuter[r0 + u];
-        w4[u] = !(row_bound(hr.dy, hr.dz) >= tau_f);
-        const int rb = rb0 + hr.dy * sy + hr.dz * sz;
-        a0[u] = b0[u] = 0;
-        if (w4[u]) {
-          a0[u] = start[rb - 2];
-          b0[u] = start[rb + 3];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const HRow hr = kHOuter[r0 + u];
-        const int len = b0[u] - a0[u];
-        heavy |= len > kHSpanMax;
-        put(w4[u] && len > 0, a0[u], row_bound(hr.dy, hr.dz), hrow_id(hr.dy, hr.dz), 0, len);
-      }
-    }
-  }
-  stream();
-  if (heavy) {  // a row too long for its ordinals, or more shell pieces than the table holds: the cooperative kernel
-    defer(i, INFINITY, 2);
-    return;
-  }
-  // ---- the k-th neighbour: is it decided by the keys, and is it provably inside the block? (as in knn_point_sp) ----
-  int a_km2, a_km1, a_k, a_kp1;
-  if (k == KC) {
-    a_km2 = top.a[KC - 2]; a_km1 = top.a[KC - 1]; a_k = top.a[KC]; a_kp1 = top.a[KC + 1];
-  } else {
-    a_km2 = k >= 2 ? top.at(k - 2) : -(4 << KB);
-    a_km1 = top.at(k - 1); a_k = top.at(k); a_kp1 = top.at(k + 1);
-  }
-  if (a_km1 >= 0x7f800000) {  // fewer than k candidates in the block
-    defer(~i, INFINITY, 4);
-    return;
-  }
-  const unsigned sbase = (unsigned)(rb0 - 2) << 2;  // byte offset of start[own cell - 2]
-  auto index_of = [&](int key) {  // ordinal -> position in the sorted array: the row's base is start[row's cell -2]
-    const int row = (key >> kHPosBits) & 31;
-    const int base = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(start) + (sbase + (unsigned)(rowoff[row] << 2)));
-    return base + (key & kPosMask);
-  };
-  bool decided = true, swap = false;
-  int kth_key = a_km1;
-  if ((a_k >> KB) - (a_km1 >> KB) < 2) {
-    decided = false;
-    if ((a_kp1 >> KB) - (a_k >> KB) >= 2 && (a_km1 >> KB) - (a_km2 >> KB) >= 2) {  // exactly two contenders: the reference's expression decides
-      const float4 p1 = P[index_of(a_km1)], p2 = P[index_of(a_k)];
-      const float d1 = dist2(px, py, pz, p1), d2 = dist2(px, py, pz, p2);
-      decided = d1 != d2;  // an exact tie is decided by the original index: cooperative kernel
-      swap = d2 < d1;
-      if (swap) kth_key = a_k;
-    }
-  }
-  const float thr_up = __int_as_float(kth_key | kKeyOrd);
-  const double bound = cube_bound(g, c, q, 2);
-  const bool proven = (bound == 1.0e300) || (bound > 0.0 && (double)thr_up < bound * bound * (1.0 - 1e-5));
-  if (!proven) {
-    defer(~i, (double)thr_up < 27.0 * g.res * g.res ? thr_up : INFINITY, 5);
-    return;
-  }
-  if (!decided) {
-    defer(i, thr_up, 6);
-    return;
-  }
-  // ---- neighbour positions replace the keys, then the one-pass moments about the query (knn_point_sp) and the normal ----
-  const int idx_k = swap ? index_of(a_k) : 0;
-  double S[6] = {0, 0, 0, 0, 0, 0};
-  auto moments = [&](auto full_tag) {
-    constexpr bool kFull = decltype(full_tag)::value;
-#pragma unroll
-    for (int j = 0; j < KC; j++)
-      if (kFull || j < k) top.a[j] = (swap && j == k - 1) ? idx_k : index_of(top.a[j]);
-    const double qx = (double)px, qy = (double)py, qz = (double)pz;
-    double mx = 0, my = 0, mz = 0;
-#pragma unroll
-    for (int j = 0; j < KC; j++) {
-      if (kFull || j < k) {
-        const float4 cp = point_at(P, (unsigned)top.a[j] << 4);
-        const double dx = (double)cp.x - qx, dy = (double)cp.y - qy, dz = (double)cp.z - qz;
-        mx += dx; my += dy; mz += dz;
-        S[0] = fma(dx, dx, S[0]); S[1] = fma(dx, dy, S[1]); S[2] = fma(dx, dz, S[2]);
-        S[3] = fma(dy, dy, S[3]); S[4] = fma(dy, dz, S[4]); S[5] = fma(dz, dz, S[5]);
-      }
-    }
-    const double inv_k = 1.0 / (double)k;
-    mx *= inv_k; my *= inv_k; mz *= inv_k;
-    S[0] = S[0] * inv_k - mx * mx; S[1] = S[1] * inv_k - mx * my; S[2] = S[2] * inv_k - mx * mz;
-    S[3] = S[3] * inv_k - my * my; S[4] = S[4] * inv_k - my * mz; S[5] = S[5] * inv_k - mz * mz;
-  };
-  if (k == KC) moments(std::true_type{});
-  else moments(std::false_type{});
-  double nrm[3];
-  if (!min_eigenvector_direct(S, nrm)) min_eigenvector(S, nrm);
-  nx[i] = nrm[0];
-  ny[i] = nrm[1];
-  nz[i] = nrm[2];
-}
-
-template <int KC>
-__global__ void __launch_bounds__(kHT, 4)
-k_knn_h(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df, double* __restrict__ nx,
-        double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ int slist_h[];  // [kHLds][kHT], then the 25 row offsets
-  if (df.guard && *df.guard) return;
-  int* const rowoff = slist_h + kHLds * kHT;
-  if (threadIdx.x < 25) {
-    const int dy = (int)threadIdx.x % 5 - 2, dz = (int)threadIdx.x / 5 - 2;
-    rowoff[threadIdx.x] = cell_index(g, 0, dy, dz) - cell_index(g, 0, 0, 0);
-  }
-  __syncthreads();
-  // XCD-aware block order, as k_knn_sp: runs of RGC_XCD_RUN consecutive query blocks per XCD, the runs dealt round-robin
-  constexpr int kXcdRun = RGC_XCD_RUN;
-  const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
-  const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * kHT + threadIdx.x;
-  if (i < n) knn_point_h<KC, kHT>(P, start, g, n, k, i, slist_h + threadIdx.x, rowoff, df, nx, ny, nz);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Cooperative exact search: ONE WAVE PER QUERY.  The (2r+1)^2 rows of the search cube are spread over the lanes
 // (their start[] loads overlap instead of forming a dependent chain), the candidates of each batch of 64 rows are
 // flattened and dealt round-robin to the lanes (a crowded row does not serialise on one lane), every lane keeps
@@ -2016,7 +1630,7 @@ __device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int
 #endif
     const int enc = __builtin_amdgcn_readfirstlane(df.idx[e]);
     const int i = enc < 0 ? ~enc : enc;
-    int r = enc < 0 ? (g.sub == 2 ? 2 : 1) : 0;  // radius already known to be insufficient (the half-size grid's bulk kernel scans 5x5x5)
+    int r = enc < 0 ? 1 : 0;  // radius already known to be insufficient
     float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(df.thr[e])));
     const float4 pq = P[i];
     const float px = pq.x, py = pq.y, pz = pq.z;
@@ -2254,64 +1868,6 @@ k_voxel_patch(const float4* __restrict__ P, const double* __restrict__ nx, const
     for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
     rec[9] = num;
   }
-}
-
-// The same voxel map from the half-size search grid (Grid::sub == 2): a voxel's points are no longer one contiguous run of the
-// sorted array but FOUR -- the x pairs of half cells of its four (y, z) half rows -- each in ascending original index.  One lane per
-// voxel (dense ids and vox_cell come from the cell scan) merges the four runs by original index, so the sums still run in the
-// cloud's order, bit for bit what k_voxel_build and a serial loop give.  The four run heads (point + normal) are kept in registers:
-// one load latency per point, every voxel of the map in flight at once.
-__global__ void __launch_bounds__(VOX_T)
-k_voxel_build_h(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
-                const int* __restrict__ start, Grid g, const int* __restrict__ nvox, const int* __restrict__ vox_cell, double* __restrict__ vox) {
-  const int v = blockIdx.x * VOX_T + threadIdx.x;
-  if (v >= *nvox) return;
-  const int vc = vox_cell[v];
-  const int d0 = g.dim[0] >> 1, dm = RGC_Y_SLOWEST ? (g.dim[2] >> 1) : (g.dim[1] >> 1);
-  const int vx = vc % d0, vm = (vc / d0) % dm, vs = vc / (d0 * dm);  // (x, middle, slowest) axis of the cell order
-  const int vy = RGC_Y_SLOWEST ? vs : vm, vz = RGC_Y_SLOWEST ? vm : vs;
-  int h[4], e[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int cell = cell_index(g, 2 * vx, 2 * vy + (r & 1), 2 * vz + (r >> 1));
-    h[r] = start[cell];
-    e[r] = start[cell + 2];
-  }
-  const int total = (e[0] - h[0]) + (e[1] - h[1]) + (e[2] - h[2]) + (e[3] - h[3]);
-  float4 hp[4];
-  double ha[4], hb[4], hd[4];
-  int key[4];
-  auto load_head = [&](int r) {  // r is a compile-time constant at every call
-    const bool live = h[r] < e[r];
-    const int s = live ? h[r] : 0;
-    hp[r] = P[s];
-    ha[r] = nx[s]; hb[r] = ny[s]; hd[r] = nz[s];
-    key[r] = live ? __float_as_int(hp[r].w) : INT_MAX;
-  };
-#pragma unroll
-  for (int r = 0; r < 4; r++) load_head(r);
-  double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
-  for (int t = 0; t < total; t++) {
-    const int kmin = min(min(key[0], key[1]), min(key[2], key[3]));
-    const int r = key[0] == kmin ? 0 : (key[1] == kmin ? 1 : (key[2] == kmin ? 2 : 3));  // original indices are distinct
-    const float4 cp = r == 0 ? hp[0] : (r == 1 ? hp[1] : (r == 2 ? hp[2] : hp[3]));
-    const double a = r == 0 ? ha[0] : (r == 1 ? ha[1] : (r == 2 ? ha[2] : ha[3]));
-    const double b = r == 0 ? hb[0] : (r == 1 ? hb[1] : (r == 2 ? hb[2] : hb[3]));
-    const double d = r == 0 ? hd[0] : (r == 1 ? hd[1] : (r == 2 ? hd[2] : hd[3]));
-    m[0] += (double)cp.x; m[1] += (double)cp.y; m[2] += (double)cp.z;
-    C[0] += 1.0 - 0.999 * a * a; C[1] += -0.999 * a * b; C[2] += -0.999 * a * d;
-    C[3] += 1.0 - 0.999 * b * b; C[4] += -0.999 * b * d; C[5] += 1.0 - 0.999 * d * d;
-    if (r == 0) { h[0]++; load_head(0); }
-    else if (r == 1) { h[1]++; load_head(1); }
-    else if (r == 2) { h[2]++; load_head(2); }
-    else { h[3]++; load_head(3); }
-  }
-  const double num = (double)total;
-  double* rec = vox + (size_t)v * kVoxRec;
-  rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
-#pragma unroll
-  for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
-  rec[9] = num;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3553,22 +3109,20 @@ void mapreg_terms(hipStream_t s, const float* const feat[4], const double* const
 void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* mm6, int* flags, int hi) {
   hipLaunchKernelGGL(k_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, res, mm6, flags, hi);
 }
-void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi, int* guard, int* vocc,
+void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi, int* guard,
                  const Reframe* rf) {
-  if (rf) hipLaunchKernelGGL(k_count<true>, dim3(nblk(n, 256)), dim3(256), 0, s, in, 4, n, g, cell_of, slot_of, cnt, guard, hi, vocc, *rf);
-  else hipLaunchKernelGGL(k_count<false>, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi, vocc, Reframe{});
+  if (rf) hipLaunchKernelGGL(k_count<true>, dim3(nblk(n, 256)), dim3(256), 0, s, in, 4, n, g, cell_of, slot_of, cnt, guard, hi, *rf);
+  else hipLaunchKernelGGL(k_count<false>, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi, Reframe{});
 }
-void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi, float* sum_sq, int nsplit,
-                int* vox_cell) {
+void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi, float* sum_sq) {
   const int nb = nblk(n, SCAN_B);
   unsigned long long* bs = (unsigned long long*)block_sums;
-  const ScanSplit sp{nsplit, vox_cell};
-  if (nb > 1 || sum_sq) hipLaunchKernelGGL(k_cells_reduce, dim3(nb), dim3(SCAN_T), 0, s, cnt, n, bs, hi, sum_sq, sp);
+  if (nb > 1 || sum_sq) hipLaunchKernelGGL(k_cells_reduce, dim3(nb), dim3(SCAN_T), 0, s, cnt, n, bs, hi, sum_sq);
   if (nb <= 4096) {
-    hipLaunchKernelGGL(k_cells_scan_write<true>, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, nb, cell_voxel, nvox, hi, sp);
+    hipLaunchKernelGGL(k_cells_scan_write<true>, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, nb, cell_voxel, nvox, hi);
   } else {
     hipLaunchKernelGGL(k_cells_scan_sums, dim3(1), dim3(SCAN_T), 0, s, bs, nb, nvox, hi);
-    hipLaunchKernelGGL(k_cells_scan_write<false>, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, nb, cell_voxel, nvox, hi, sp);
+    hipLaunchKernelGGL(k_cells_scan_write<false>, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, nb, cell_voxel, nvox, hi);
   }
 }
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi) {
@@ -3599,14 +3153,6 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
                         double* nx, double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
-  if (g.sub == 2) {  // the dense map's half-size search grid
-    if constexpr (KC + 2 <= 24) {
-      const size_t ldsh = ((size_t)kHLds * kHT + 32) * sizeof(int);
-      const int nbh = 8 * RGC_XCD_RUN * nblk(nblk(n, kHT), 8 * RGC_XCD_RUN);
-      hipLaunchKernelGGL((k_knn_h<KC>), dim3(nbh), dim3(kHT), ldsh, s, P, start, g, n, k, df, nx, ny, nz);
-    }
-    return;
-  }
   if (wide_r == 2) {
     const size_t ldsw = (size_t)SpShape<2, true>::LDS * WAVE * sizeof(int);
     hipLaunchKernelGGL((k_knn_sp_wide<KC, 2, kExact>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
@@ -3635,7 +3181,7 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
   else
     hipLaunchKernelGGL((k_knn_coop<KC, false>), dim3(nbc), dim3(WAVE), 0, s, P, start, g, k, df, nx, ny, nz);
 }
-bool knn_bulk_times_itself(bool is_target, Grid g, int wide_r) { return is_target && g.sub == 1 && wide_r != 2; }
+bool knn_bulk_times_itself(bool is_target, int wide_r) { return is_target && wide_r != 2; }
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1) {
   // (k == 20, the reference's setting, gets an instance without the general-k branches)
@@ -3665,10 +3211,6 @@ void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double*
                  const int* cell_voxel, double* vox, int lanes) {
   const int nb = lanes < 64 ? 1 : (lanes > 65536 ? 1024 : nblk(lanes, WAVE));
   hipLaunchKernelGGL(k_voxel_patch, dim3(nb), dim3(WAVE), 0, s, P, nx, ny, nz, start, g, (const int*)deferred, cell_voxel, vox);
-}
-void voxel_build_h(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
-                   int max_vox, const int* nvox, const int* vox_cell, double* vox) {
-  hipLaunchKernelGGL(k_voxel_build_h, dim3(nblk(max_vox, VOX_T)), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, nvox, vox_cell, vox);
 }
 void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
                const int* cell_voxel, const double* vox, int noff, int* corr_v, double* corr_M, int want_H, double* partials,

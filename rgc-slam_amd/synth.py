@@ -32,6 +32,12 @@ def hdl64_elev() -> np.ndarray:
     return np.concatenate([up, lo])
 
 
+def hdl32_elev() -> np.ndarray:
+    """32 elevations consistent with the N_SCANS==32 ring formula (scanRegistration.cpp:154-162): scanID = int((angle + 92/3) * 3/4)
+    TRUNCATES, so ring k is the band [-92/3 + 4k/3, -92/3 + 4(k+1)/3) degrees; the beams sit in the middle of their bands."""
+    return -92.0 / 3.0 + (np.arange(32) + 0.5) * 4.0 / 3.0
+
+
 @dataclass
 class World:
     half_extent: float

@@ -34,3 +34,26 @@ def test_bench_line_direct_and_under_torchrun():
                "--master-port", "29611", "bench.py", "--gpus", "1"] + ARGS)
     assert b["n_gpus"] == 1
     assert b["final_pose_checksum"] == a["final_pose_checksum"]
+
+
+def test_two_ranks_with_real_hip_contexts_on_one_device():
+    """The N > 1 control flow with the HIP path in MORE THAN ONE process (the driver's 2/4/8-GPU runs; here both ranks share device 0 of a
+    one-GPU box -- RGC_BENCH_DEVICE -- and the barrier / MAX-reduce go over gloo): each rank runs its own sequence (two different
+    checksums), each equal to the `--gpus 1` run of that sequence, and `value` is the whole job's 2 K steps over the slower rank's time.
+    No scaling claim: the two ranks share one GPU."""
+    args = ["--steps", "4", "--warmup", "2", "--n-target", "150000", "--no-cpu-baseline", "--configs", "none"]
+    env2 = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RGC_BENCH_DEVICE="0", RGC_BENCH_DIST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29613", "bench.py", "--gpus", "2"] + args, cwd=ROOT, env=env2, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines                                   # rank 0 prints the ONE line
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["steps"] == 4 and two["scaling"] == "weak"
+    cs = two["final_pose_checksum_per_rank"]
+    assert len(cs) == 2 and cs[0] != cs[1] and cs[0] == two["final_pose_checksum"]
+    assert abs(two["value"] - 2 * 4 / (two["ms_per_step"] * 4 * 1e-3)) <= 1e-2 * two["value"]    # 2 K steps / MAX-over-ranks elapsed
+    assert two["one_frame_at_a_time"]["same_poses"]
+    for r in (0, 1):
+        one = _line([sys.executable, "bench.py", "--gpus", "1", "--sequence", str(r)] + args)
+        assert one["final_pose_checksum"] == cs[r], (r, one["final_pose_checksum"], cs)

@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 def _raw(n_az=1800, beams=16, seed=0, half=60.0, pose=None):
     import rgc_slam_amd.synth as synth
     w = synth.make_world(half_extent=half, seed=synth.SEED)
-    elev = synth.VLP16_ELEV if beams == 16 else synth.hdl64_elev()
+    elev = synth.VLP16_ELEV if beams == 16 else (synth.hdl32_elev() if beams == 32 else synth.hdl64_elev())
     T = np.eye(4) if pose is None else pose
     sc = synth.make_scan(w, T, elev_deg=elev, n_az=n_az, seed=synth.SEED + seed)
     return np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32)
@@ -67,6 +67,20 @@ def test_hdl64_vs_oracle(orc):
     f = frontend.ScanRegistration(64)
     g, o = _compare(f, orc, _raw(n_az=2083, beams=64, seed=2), 64)     # ~130k points: beyond the reference's 30000 cap
     assert g["n_cloud"] > 60000
+    f.close()
+
+
+def test_hdl32_vs_oracle(orc):
+    """N_SCANS == 32 (scanRegistration.cpp:154-162: the truncating ring formula): every stage against the oracle, at rest and on a
+    moving, tilted pose."""
+    import rgc_slam_amd.synth as synth
+    from rgc_slam_amd import frontend
+    f = frontend.ScanRegistration(32)
+    g, o = _compare(f, orc, _raw(n_az=1500, beams=32, seed=3), 32)
+    assert g["n_cloud"] > 25000 and len(g["sharp"]) > 100 and len(g["flat"]) > 1000 and g["ground_valid"]
+    assert np.count_nonzero(g["ring_count"][:32]) >= 20
+    assert np.array_equal(np.floor(g["cloud"][:, 3]).astype(int), np.repeat(np.arange(32), g["ring_count"][:32]))
+    _compare(f, orc, _raw(n_az=1200, beams=32, seed=4, pose=synth.se3(synth.rot_zyx(1.1, 0.02, -0.01), [2.0, 3.0, 0.03])), 32)
     f.close()
 
 

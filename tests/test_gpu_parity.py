@@ -256,10 +256,10 @@ def test_exact_ties_follow_the_oracle_order(reg_mod, orc):
         v.close()
 
 
-def test_sparse_map_takes_the_wide_block(reg_mod, orc, monkeypatch):
+def test_sparse_map_takes_the_wide_block(reg_mod, orc):
     """A map of three leaf-filtered 16-beam sweeps (0.1 points per 1 m cell): the bulk launch searches the 5^3 block with four lanes per
-    query (k_knn_sp_wide) instead of sending most queries to the cooperative kernel.  Covariances, voxel table and pose against the
-    oracle, and the same against the dense-map kernel (RGC_MAP_WIDE_R=0)."""
+    query (k_knn_sp_wide) instead of sending most queries to the cooperative kernel (the dense-map kernel deferred 85 % of them: a
+    -DRGC_MAP_WIDE_R=0 build).  Covariances, voxel table and pose against the oracle."""
     import rgc_slam_amd.synth as synth
     world = synth.make_world(half_extent=45.0, seed=synth.SEED)
     poses = synth.make_trajectory(5, seed=synth.SEED)
@@ -271,15 +271,13 @@ def test_sparse_map_takes_the_wide_block(reg_mod, orc, monkeypatch):
     o = orc.Registration(max_iterations=25, translation_eps=1e-6, num_threads=0)
     o.set_target(tgt); o.set_source(src); o.prepare()
     To = o.align(poses[3])
-    res = {}
-    for wide in ("2", "0"):
-        monkeypatch.setenv("RGC_MAP_WIDE_R", wide)
+    for _ in range(1):
         v = _odo(reg_mod)
         v.setInputTarget(tgt); v.setInputSource(src)
         ct = v.getTargetCovariances()
         st = v.stats()
         assert st["n_target"] < 0.25 * st["target_cells"]
-        res[wide] = st["deferred_target"]
+        assert st["deferred_target"] < 0.2 * st["n_target"], st      # the wide block really ran: the 3^3 block leaves ~85 % to the cooperative kernel
         et = np.abs(ct - o.target_cov(len(ct))).reshape(len(ct), -1).max(axis=1)
         assert np.sum(et > 1e-9) == 0, np.sum(et > 1e-9)
         vm, om = v.getVoxels(), o.voxelmap()
@@ -289,7 +287,6 @@ def test_sparse_map_takes_the_wide_block(reg_mod, orc, monkeypatch):
         T = v.getFinalTransformation()
         assert np.abs(T[:3, 3] - To[:3, 3]).max() <= 1e-4 and _rot_angle(T[:3, :3], To[:3, :3]) <= 1e-4
         v.close()
-    assert res["2"] < 0.35 * res["0"], res          # the wide block really ran and left far fewer queries to the cooperative kernel
 
 
 def test_k_and_resolution_parameters(reg_mod, orc, fx_reg):
@@ -372,6 +369,18 @@ def test_swap_clear_and_caller_covariances(reg_mod, orc, medium):
         b.setSourceCovariances(np.tile(np.eye(3) * 0.5, (len(medium["src"]), 1, 1)))   # not of the plane form
     with pytest.raises(reg_mod.RgcError):
         b.setTargetCovariances(flat[:10])                                             # wrong count
+    # caller-set covariances TRAVEL with their cloud through a swap (the reference swaps source_covs_ / target_covs_): b's target holds the
+    # flat covariances, its source the oracle's; swapped, the new source is flat and the new target carries the oracle's -- voxel map included
+    b.swapSourceAndTarget()
+    assert np.abs(b.getSourceCovariances() - np.diag([1.0, 1.0, 1e-3])).max() <= 1e-12
+    assert np.abs(b.getTargetCovariances() - ocov).max() <= 1e-9
+    c2 = _odo(reg_mod)
+    c2.setInputTarget(medium["src"]); c2.setTargetCovariances(ocov)
+    vb, vc = b.getVoxels(), c2.getVoxels()
+    assert np.array_equal(vb["coords"], vc["coords"]) and np.abs(vb["cov"] - vc["cov"]).max() <= 1e-12
+    c2.close()
+    b.swapSourceAndTarget()
+    assert np.abs(b.getVoxels()["cov"] - np.diag([1.0, 1.0, 1e-3])).max() <= 1e-12 and np.abs(b.getSourceCovariances() - ocov).max() <= 1e-9
     b.clearSource()
     with pytest.raises(reg_mod.RgcError):
         b.align(g, want_output=False)
@@ -697,39 +706,11 @@ def test_a_context_with_a_solve_in_flight_refuses_new_clouds(reg_mod, medium):
     w.close()
 
 
-def test_half_size_search_grid_layout(reg_mod, orc, medium, monkeypatch):
-    """RGC_MAP_HALF=1 (k_knn_h, parked in round 3: no faster): the map searched on cells of half the voxel size nested in the voxels.  Same
-    neighbours -- every target covariance as the CPU oracle's and as the default layout's -- the same voxel table, the same pose."""
-    base = _odo(reg_mod)
-    base.setInputTarget(medium["tgt"])
-    cov0, vox0 = base.getTargetCovariances(), base.getVoxels()
-    base.setInputSource(medium["src"])
-    base.align(np.eye(4, dtype=np.float32), want_output=False)
-    T0 = base.getFinalTransformation()
-    base.close()
-    monkeypatch.setenv("RGC_MAP_HALF", "1")
-    v = _odo(reg_mod)
-    v.setInputTarget(medium["tgt"])
-    assert v.stats()["target_cells"] > 4 * len(vox0["num"])          # (it really is the finer grid)
-    cov1, vox1 = v.getTargetCovariances(), v.getVoxels()
-    assert np.abs(cov1 - cov0).max() <= 1e-12
-    ocov, _ = orc.covariances(medium["tgt"], k=20)
-    assert np.abs(cov1 - ocov).max() <= 1e-9
-    k0 = np.lexsort(vox0["coords"].T[::-1]); k1 = np.lexsort(vox1["coords"].T[::-1])
-    assert np.array_equal(vox0["coords"][k0], vox1["coords"][k1]) and np.array_equal(vox0["num"][k0], vox1["num"][k1])
-    assert np.abs(vox0["mean"][k0] - vox1["mean"][k1]).max() <= 1e-12 and np.abs(vox0["cov"][k0] - vox1["cov"][k1]).max() <= 1e-12
-    v.setInputSource(medium["src"])
-    v.align(np.eye(4, dtype=np.float32), want_output=False)
-    assert np.abs(v.getFinalTransformation() - T0).max() <= 1e-6
-    v.close()
-
-
-@pytest.mark.parametrize("knob,value", [("RGC_SRC_RES", "0.5"), ("RGC_SRC_RES", "2.0"), ("RGC_SMALL_COPY", "1"), ("RGC_SPEC_GRID", "0"),
-                                        ("RGC_MAP_WIDE", "0"), ("RGC_MAP_WIDE", "1000"), ("RGC_MAP_WIDE_R", "0"), ("RGC_MAP_HALF", "1"),
-                                        ("RGC_LM_POST", "0"), ("RGC_SOLVE_BEHIND_MAP", "0")])
-def test_developer_knobs_change_no_result(reg_mod, medium, monkeypatch, knob, value):
-    """Every environment knob read by rgc_create (README) selects another route to the SAME result: a short sequence gives the default's
-    poses bit for bit (the map's layout knobs: to 1e-6, their fp64 sums run in another order), iterations and fitness included."""
+@pytest.mark.parametrize("knob,value", [("RGC_SPEC_GRID", "0"), ("RGC_TRACE_ALLOC", "1")])
+def test_environment_knobs_change_no_result(reg_mod, medium, monkeypatch, knob, value):
+    """The environment knobs read by rgc_create (README; RGC_LM_IMPL has test_lm_drivers_agree) select another route to the SAME result: a
+    short sequence gives the default's poses bit for bit, iterations and fitness included.  (The A/B routes of earlier rounds are build
+    flags since round 4: scripts/exp_build_flags.sh runs this sequence on each of those builds.)"""
     import rgc_slam_amd.synth as synth
     poses = synth.make_trajectory(4, seed=synth.SEED + 11)
     scans = [synth.make_scan_n(medium["world"], poses[i + 1], 12000, seed=synth.SEED + 900 + i)["xyz"] for i in range(3)]
@@ -748,12 +729,8 @@ def test_developer_knobs_change_no_result(reg_mod, medium, monkeypatch, knob, va
     ref = run()
     monkeypatch.setenv(knob, value)
     got = run()
-    exact = knob not in ("RGC_MAP_HALF", "RGC_MAP_WIDE", "RGC_MAP_WIDE_R")
     for (Ta, ia, fa), (Tb, ib, fb) in zip(ref, got):
-        if exact:
-            assert np.array_equal(Ta, Tb) and ia == ib and fa == fb
-        else:
-            assert np.abs(Ta - Tb).max() <= 1e-6 and abs(fa - fb) <= 1e-6 * fa
+        assert np.array_equal(Ta, Tb) and ia == ib and fa == fb
 
 
 @pytest.mark.parametrize("spec_grid", ["1", "0"])
@@ -863,6 +840,17 @@ def test_reframed_target_with_a_stale_box(reg_mod, orc, medium):
     assert np.array_equal(v.download(d_body, (n, 4)), w.download(d_out_w, (n, 4)))
     v.setInputTargetReframed(d_map, n, 16, q, t, d_body)  # and the buffer's box has been measured again: no second miss
     assert np.array_equal(v.getTargetCovariances(), w.getTargetCovariances())
+    # preconditions of the call (rgc_hip.h): an output that overlaps the input is refused; an output that is only 4-byte aligned takes
+    # the un-fused route (its own re-framing launch) and gives the same target
+    with pytest.raises(reg_mod.RgcError):
+        v.setInputTargetReframed(d_map, n, 16, q, t, d_map)
+    with pytest.raises(reg_mod.RgcError):
+        v.setInputTargetReframed(d_map, n - 8, 16, q, t, d_map + 64)
+    d_odd = v.device_alloc(a_big.nbytes + 16)
+    v.setInputTargetReframed(d_map, n, 16, q, t, d_odd + 4)
+    assert np.array_equal(v.getTargetCovariances(), w.getTargetCovariances())
+    assert np.array_equal(v.download(d_odd + 4, (n, 4)), w.download(d_out_w, (n, 4)))
+    v.device_free(d_odd)
     for p in (d_map, d_body):
         v.device_free(p)
     for p in (d_map_w, d_out_w):

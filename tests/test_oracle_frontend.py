@@ -25,6 +25,33 @@ def test_ring_and_reltime(orc):
     assert np.abs(rel - sc["rel_time"][order]).max() < 2e-3                  # relTime from azimuth, scanRegistration.cpp:206
 
 
+def test_ring_and_reltime_32_beams(orc):
+    """N_SCANS == 32 (scanRegistration.cpp:154-162): the truncating ring formula, the stable ring bucket and the per ring-sector caps on a
+    synthetic 32-beam sweep whose ring ids are known."""
+    import rgc_slam_amd.synth as synth
+    w = synth.make_world(half_extent=50.0, seed=synth.SEED)
+    sc = synth.make_scan(w, np.eye(4), elev_deg=synth.hdl32_elev(), n_az=700, seed=synth.SEED + 3)
+    raw = np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32)
+    o = orc.frontend(raw, n_scans=32)
+    assert o["n_cloud"] == len(raw)
+    assert np.array_equal(o["ring_count"][:32], np.bincount(sc["ring"], minlength=32)) and o["ring_count"][:32].min() >= 0
+    assert np.count_nonzero(o["ring_count"][:32]) >= 20                     # (the top beams of a 32-beam head see sky)
+    order = np.argsort(sc["ring"], kind="stable")
+    assert np.array_equal(o["cloud"][:, :3], raw[order, :3])
+    enc = o["cloud"][:, 3]
+    assert np.array_equal(np.floor(enc).astype(int), sc["ring"][order])
+    assert np.abs((enc - np.floor(enc)) / 0.1 - sc["rel_time"][order]).max() < 2e-3
+    assert o["n_sharp_own"] <= 32 * 6 * 20 and len(o["flat"]) <= 32 * 6 * 40 and len(o["inten"]) <= 32 * 6 * 20
+    assert np.sum(o["label"] == 2) == o["n_sharp_own"] > 50 and np.sum(o["label"] == -1) == len(o["flat"]) > 500
+    # the literal restatement on the same sweep: curvatures, labels, feature clouds
+    from oracle import py_frontend as pf
+    st = pf.stencils(o["cloud"][:, :3], raw[order, 3].astype(np.int64))
+    assert np.array_equal(st["curvature"], o["curvature"]) and np.array_equal(st["inten_curvature"], o["inten_curvature"])
+    sel = pf.select(o["cloud"], st, pf.occlusion(st["range"]), o["ground_marked"], o["scan_start"], o["scan_end"])
+    assert np.array_equal(sel["label"], o["label"]) and np.array_equal(sel["picked"], o["picked"])
+    assert np.array_equal(sel["sharp"], o["sharp"]) and np.array_equal(sel["flat"], o["flat"]) and np.array_equal(sel["inten"], o["inten"])
+
+
 def test_ground_plane_and_caps(orc):
     raw, _ = _scan(n_az=1800, seed=4)
     o = orc.frontend(raw)
