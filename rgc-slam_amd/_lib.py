@@ -114,7 +114,7 @@ SYMBOLS = [
     "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align", "rgc_align_begin", "rgc_align_end", "rgc_share_target", "rgc_hold_source_until_target_of",
     "rgc_fitness", "rgc_get_aligned", "rgc_get_aligned_device", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_set_source_covariances", "rgc_set_target_covariances",
     "rgc_clear_source", "rgc_clear_target", "rgc_swap_source_and_target", "rgc_get_voxels",
-    "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_upload", "rgc_download", "rgc_synchronize",
+    "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_host_alloc", "rgc_host_free", "rgc_upload", "rgc_download", "rgc_synchronize",
     "rgc_stream", "rgc_default_fe_params", "rgc_frontend", "rgc_extract_pose", "rgc_imu_preintegrate", "rgc_imu_filter_init", "rgc_imu_filter_push", "rgc_ground_gate_init", "rgc_ground_gate_remember", "rgc_ground_gate_step", "rgc_default_fuse_in", "rgc_fuse_pose", "rgc_compose_pose",
     "rgc_R2ypr", "rgc_ypr2R", "rgc_deskew", "rgc_voxelgrid", "rgc_voxelgrid_begin", "rgc_voxelgrid_end", "rgc_transform_cloud", "rgc_set_target_reframed", "rgc_frontend_device", "rgc_frontend_cloud_device", "rgc_default_icp_params", "rgc_icp_align", "rgc_pc2_unpack", "rgc_pc2_pack", "rgc_pc2_point_fields", "rgc_tum_line", "rgc_pcd_write", "rgc_mapreg_set_maps", "rgc_mapreg_associate", "rgc_mapreg_optimize", "rgc_map_reset", "rgc_map_insert", "rgc_map_evict", "rgc_map_rebase", "rgc_map_commit", "rgc_map_get_info", "rgc_map_download", "rgc_profile_enable", "rgc_profile_select", "rgc_profile_reset", "rgc_profile_get", "rgc_profile_name",
 ]
@@ -169,6 +169,8 @@ def load():
     L.rgc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rgc_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.rgc_device_free.argtypes = [vp, vp]
+    L.rgc_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.rgc_host_free.argtypes = [vp]
     L.rgc_upload.argtypes = [vp, vp, vp, C.c_size_t]
     L.rgc_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.rgc_synchronize.argtypes = [vp]
