@@ -41,8 +41,24 @@ N_SOURCE = 30000
 N_TARGET = 1000000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 MAP_SHIFTS = ((0.0, 0.0, 0.0), (0.37, -0.23, 0.011), (-0.29, 0.41, -0.007))  # m: the map copies `replay_of_preframed_maps` alternates between
-PMC_FILE = "r03_pmc_knn.json"      # counters of the dominant kernel (scripts/pmc_kernel.sh)
-MIX_FILE = "r03_knn_isa_mix.json"  # its full- / half-rate instruction mix (scripts/isa_mix.py)
+# Constants of this line that are NOT measured in this run: they are read from committed profile summaries (separate rocprofv3 --pmc passes
+# cannot run inside a timed bench) and every one is stamped with its file and the commit it was collected at (`*_source` keys): a kernel
+# change that was not followed by scripts/refresh_profiles.sh shows up as a stale stamp, not as a silently wrong number.
+PMC_FILE = "r04_pmc_knn.json"      # counters of the dominant kernel (scripts/pmc_kernel.sh)
+MIX_FILE = "r04_knn_isa_mix.json"  # its full- / half-rate instruction mix (scripts/isa_mix.py)
+FRAME_TRAFFIC_FILE = "r04_frame_traffic.json"  # measured HBM bytes of a whole dependent frame, every kernel (scripts/frame_traffic.sh)
+
+
+def profile_json(name):
+    """(contents, source stamp) of a committed profile summary, or (None, None)"""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, None
+    return d, f"profiles/{name}@{d.get('commit') or 'unstamped'}"
 
 
 def log(*a):
@@ -152,28 +168,33 @@ class DependentSequence:
         import numpy as np
         v = self.v if overlap else self.v[:1]
         D = len(v)
-        Tw, g = np.asarray(Tw0, np.float64), np.asarray(g0, np.float32)
+        Tw, g = np.array(Tw0, dtype=np.float64, order="C"), np.asarray(g0, np.float32)
         motions, worlds, guesses = [], [], []
         if overlap:
             self.frame_source(first, v[0], from_host)
+        self.frame_target(v[0], Tw)                   # the first frame's target; every later one is enqueued by align_end_reframe below
         for j in range(count):
-            cur = v[j % D]
+            cur, nxt = v[j % D], v[(j + 1) % D]
             if prior_world is not None:
                 g = (np.linalg.inv(Tw) @ np.asarray(prior_world[first + j], np.float64)).astype(np.float32)
-            self.frame_target(cur, Tw)
             if not overlap:
                 self.frame_source(first + j, cur, from_host)
             cur.align_begin(g, True)
             if overlap and j + 1 < count:
-                v[(j + 1) % D].holdSourceUntilTargetOf(cur)                   # ... held back until this frame's map is ready:
-                self.frame_source(first + j + 1, v[(j + 1) % D], from_host)   # the next scan is prepared under this frame's SOLVE
-            T = cur.align_end()
+                nxt.holdSourceUntilTargetOf(cur)                              # ... held back until this frame's map is ready:
+                self.frame_source(first + j + 1, nxt, from_host)              # the next scan is prepared under this frame's SOLVE
+            if j + 1 < count:
+                # the result, the world pose (Tw <- Tw * T, fp64) and the NEXT frame's target -- the map re-expressed in the new body frame,
+                # rebuilt in full like the reference does -- in one call: the host's turn-around is on the sequence's critical path
+                T = cur.align_end_reframe(nxt, Tw, self.d_map, self.n_map, 16, self.d_body[id(nxt)])
+            else:
+                T = cur.align_end()
+                Tw[:] = Tw @ T.astype(np.float64)
             if from_host and self.d_aligned is not None:
                 cur.alignedToDevice(self.d_aligned[id(cur)], 16)              # pcl::transformPointCloud(*input_, output, final), left on the device
             if on_result is not None:
                 on_result(first + j, cur)
             guesses.append(g)
-            Tw = Tw @ T.astype(np.float64)
             g = T
             motions.append(T)
             worlds.append(Tw.copy())
@@ -549,15 +570,8 @@ def main():
     avg_ms = d["total_ms"] / max(d["launches"], 1)
     units = d["points"] / max(d["launches"], 1)
     achieved = per_unit * units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
-    pmc = None
-    pfile = os.path.join(ROOT, "profiles", PMC_FILE)  # rocprofv3 --pmc passes of this kernel (scripts/pmc_kernel.sh), if committed
-    if os.path.exists(pfile):
-        try:
-            pmc = json.load(open(pfile))
-            traffic = pmc.get("hbm_bytes_per_launch")
-        except Exception:
-            pmc = None
+    pmc, pmc_src = profile_json(PMC_FILE)  # rocprofv3 --pmc passes of this kernel (scripts/pmc_kernel.sh), if committed
+    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
     # The same kernel against the roof that binds it -- VALU instruction issue.  Peaks are MEASURED (scripts/ubench/valu_issue.hip,
     # profiles/r02_valu_issue.jsonl, 8 waves per SIMD, every CU): add / sub / mul / fma / and / or / mov issue at ~1060 G
     # wave-instructions/s chip-wide (the 2-cycles-per-wave64 figure of the guide, 1229 G/s at 2.4 GHz, less the clock held under
@@ -570,21 +584,24 @@ def main():
         ach = per_q * units / (avg_ms * 1e-3) / 1e9
         issue = {"bound": "valu_issue", "kernel": name, "achieved": round(ach, 1), "unit": "G wave-instr/s", "valu_wave_instructions_per_query": per_q,
                  "peak_full_rate_measured": 1060.0, "peak_half_rate_measured": 595.0, "peak_2cyc_at_2.4GHz": 1228.8}
-        mix = None
-        mfile = os.path.join(ROOT, "profiles", MIX_FILE)
-        if os.path.exists(mfile):
-            try:
-                mix = json.load(open(mfile))
-            except Exception:
-                mix = None
+        issue["valu_per_query_source"] = pmc_src
+        mix, mix_src = profile_json(MIX_FILE)
         if mix and mix.get("half_rate_fraction") is not None:
+            issue["half_rate_fraction_source"] = mix_src
             h = float(mix["half_rate_fraction"])
             peak = 1.0 / (h / 595.0 + (1.0 - h) / 1060.0)
             issue.update({"half_rate_fraction": round(h, 4), "peak_mix_weighted": round(peak, 1), "frac_of_mix_weighted_peak": round(ach / peak, 4),
                           "frac_of_mix_weighted_peak_launch_alone": None})
     roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": pmc_src,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": per_unit * units}
+    # the whole frame's MEASURED HBM bytes (every kernel of a dependent frame, FETCH_SIZE x 2 + WRITE_SIZE) against the algorithmic B
+    ft, ft_src = profile_json(FRAME_TRAFFIC_FILE)
+    frame_traffic = None
+    if ft and ft.get("bytes_per_frame_measured"):
+        frame_traffic = {"bytes_per_frame_measured": int(ft["bytes_per_frame_measured"]), "algorithmic_bytes_per_scan": round(B),
+                         "measured_over_algorithmic": round(float(ft["bytes_per_frame_measured"]) / B, 3), "source": ft_src,
+                         "largest": [{k: r[k] for k in ("kernel", "MB_per_frame")} for r in ft.get("per_kernel", [])[:5]]}
     alone_ms = dom_alone["total_ms"] / max(dom_alone["launches"], 1)
     if alone_ms > 0:  # the timed region runs the launch beside the next scan's kernels; alone it is shorter
         roofline["launch_alone_ms"] = round(alone_ms, 4)
@@ -608,7 +625,7 @@ def main():
         "mean_outer_iterations": round(mean_outer, 2), "mean_linearize": round(mean_lin, 2), "mean_compute_error": round(mean_err, 2),
         "mean_correspondences": round(mean_corr, 1), "n_voxels": int(n_vox),
         "kernel_ms_per_step": {k: round(x["total_ms"] / KB, 4) for k, x in prof.items()},
-        "roofline": roofline, "issue_roofline": issue,
+        "roofline": roofline, "issue_roofline": issue, "frame_traffic": frame_traffic,
         "one_frame_at_a_time": {"scans_per_s": round(K / elapsed_seq, 3), "ms_per_step": round(1e3 * elapsed_seq / K, 3), "same_poses": seq_same,
                                 "what": "the same K dependent steps on one context through the blocking calls: a frame's latency"},
         "replay_of_preframed_maps": {"scans_per_s": round(K / elapsed_replay, 3), "ms_per_step": round(1e3 * elapsed_replay / K, 3),

@@ -126,6 +126,16 @@ RGC_API int rgc_align(rgc_ctx* ctx, const float guess[16], float final_T[16], do
 RGC_API int rgc_align_begin(rgc_ctx* ctx, const float guess[16], int want_fitness);
 RGC_API int rgc_align_end(rgc_ctx* ctx, float final_T[16], double final_H[36], double* fitness, int* iterations, int* converged,
                           int* lm_failed);
+/* rgc_align_end on `solve`, then -- without going back to the caller -- the two steps a frame loop WITHOUT a fusion stage does with the
+ * result: the world pose composed in fp64, world_T <- world_T * final_T (t_w_curr / q_w_curr, src/RGC_odometer.cpp:1201-1203), and the
+ * next frame's target enqueued on `next` (the same context or the other one of a pair taking turns): the sub-map d_map re-expressed in
+ * the new body frame, q = inverse rotation of world_T, t = -q * translation (:1250-1255), exactly rgc_set_target_reframed(next, d_map,
+ * n, stride_bytes, q, t, d_scratch).  The host's turn-around between a frame's result and the next frame's first launch is on the
+ * critical path of a dependent sequence; here it is a few microseconds of C instead of the caller's pose arithmetic and a second call.
+ * world_T: 16 doubles, row-major 4x4, in: the world pose before this frame, out: after it.  Outputs as rgc_align_end. */
+RGC_API int rgc_align_end_reframe(rgc_ctx* solve, rgc_ctx* next, double world_T[16], const float* d_map, int n, int stride_bytes,
+                                  float* d_scratch, float final_T[16], double final_H[36], double* fitness, int* iterations,
+                                  int* converged, int* lm_failed);
 /* ctx registers its scans to the target `owner` has prepared (rgc_set_target*, or rgc_map_commit: the resident local map), without
  * preparing or copying it: ctx's target becomes a non-owning alias of the owner's device buffers.  Two contexts can then take turns
  * on a sequence whose map does not change every frame (the next scan is prepared on one while the current one is solved on the

@@ -41,6 +41,9 @@ constexpr int kMaxK = 32;
 #ifndef RGC_SOLVE_BEHIND_MAP
 #define RGC_SOLVE_BEHIND_MAP 1 // 0: the solve always on the scan's (high-priority) stream (round 2)
 #endif
+#ifndef RGC_LM_SPARE_ASIDE
+#define RGC_LM_SPARE_ASIDE 1   // 0: a solve's spare step launches stay on its own stream, in front of whatever comes next there (round 3)
+#endif
 #ifndef RGC_MAP_WIDE_R
 #define RGC_MAP_WIDE_R 2       // block radius of the bulk kNN launch for a sparse map (0 = off, 2)
 #endif
@@ -137,6 +140,7 @@ struct rgc_ctx {
   rgck::LmState* d_post = nullptr; // ... its device address
   int lm_seq = 0;                  // number of the pending solve (1, 2, ...)
   rgck::LmState lm_res{};          // the finished solve's state as rgc_align_end took it (from h_post or h_lm): nothing writes it asynchronously
+  hipEvent_t lm_mid = nullptr;     // recorded on the solve's stream behind its expected launches: the spare ones, on the context's other stream, wait for it
   hipEvent_t lm_tail = nullptr;    // recorded behind every batch of LM launches (and its copy into h_lm) on the stream they went to
   hipStream_t lm_tail_stream = nullptr;  // ... that stream: a solve enqueued on the OTHER stream waits for lm_tail first
   bool post_on = RGC_LM_POST != 0; // (build flag) 0: always wait for the stream and its copy, as in round 2
@@ -476,7 +480,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     if ((rc = ensure(c, cl.cnt, sizeof(int) * std::max(ntot, want_cells) + 256))) return rc;
     if ((rc = ensure(c, cl.start, sizeof(int) * std::max(nc1, want_cells)))) return rc;
     if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (std::max(ntot, want_cells) / 2048 + 2)))) return rc;
-    if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
+    if ((rc = ensure(c, cl.order_tmp, sizeof(long long) * n))) return rc;
     if ((rc = ensure(c, cl.P, sizeof(float4) * ((size_t)n + 4)))) return rc;
     if ((rc = ensure(c, cl.segs, rgck::deferred_bytes(n)))) return rc;
     if ((rc = ensure(c, cl.nx, sizeof(double) * n))) return rc;
@@ -493,8 +497,8 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
                       fuse_reframe ? &cl.rf : nullptr);
     rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)ntot, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
                      is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23));
-    rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p, hi);
-    rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p,
+    rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (unsigned long long*)cl.order_tmp.p, hi);
+    rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const unsigned long long*)cl.order_tmp.p,
                       (float4*)cl.P.p, (int*)cl.segs.p, hi);
   }
   {
@@ -870,13 +874,13 @@ int prepare_map_grid(rgc_ctx* c, Cloud& cl, double cell) {
   if ((rc = ensure(c, cl.cnt, sizeof(int) * nc1 + 256))) return rc;
   if ((rc = ensure(c, cl.start, sizeof(int) * nc1))) return rc;
   if ((rc = ensure(c, cl.block_sums, sizeof(long long) * (nc1 / 2048 + 2)))) return rc;
-  if ((rc = ensure(c, cl.order_tmp, sizeof(int) * n))) return rc;
+  if ((rc = ensure(c, cl.order_tmp, sizeof(long long) * n))) return rc;
   if ((rc = ensure(c, cl.P, sizeof(float4) * ((size_t)n + 4)))) return rc;
   HIPCHK(c, hipMemsetAsync(cl.cnt.p, 0, (sizeof(int) * nc1 + 255) & ~(size_t)255, s));
   rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p);
   rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)nc1, cl.block_sums.p, nullptr, nullptr);
-  rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (int*)cl.order_tmp.p);
-  rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const int*)cl.order_tmp.p, (float4*)cl.P.p);
+  rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (unsigned long long*)cl.order_tmp.p);
+  rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const unsigned long long*)cl.order_tmp.p, (float4*)cl.P.p);
   HIPCHK(c, hipGetLastError());
   cl.ready = true;
   return RGC_OK;
@@ -1109,6 +1113,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     ok = ok && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) == hipSuccess;
   }
+  ok = ok && hipEventCreateWithFlags(&c->lm_mid, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->main_mark, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->tgt_ready, hipEventDisableTiming) == hipSuccess;
@@ -1173,6 +1178,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->tgt_ready) (void)hipEventDestroy(c->tgt_ready);
   if (c->src_read_done) (void)hipEventDestroy(c->src_read_done);
   if (c->lm_tail) (void)hipEventDestroy(c->lm_tail);
+  if (c->lm_mid) (void)hipEventDestroy(c->lm_mid);
   if (c->tgt_prepared) (void)hipEventDestroy(c->tgt_prepared);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -1290,44 +1296,54 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
   const int n = c->src.n, noff = noff_of(c->prm.neighbor_method);
   hipStream_t s = c->solve_stream;  // see rgc_align_begin
   rgck::LmState* post = (c->post_on && c->d_post) ? c->d_post : nullptr;
-  const int seq = want_fitness ? -c->lm_seq : c->lm_seq;  // who posts the finished state: the fitness kernel, or the deciding step
-  // The batch is sized for a few steps more than the solve should need (rgc_align_begin), and the fitness kernel must not wait
-  // behind the spare ones (a launch on a finished solve still costs its ~2 us and the gap to the next): it is enqueued behind EACH of
-  // the last kTail steps -- it does nothing unless the solve is done and has no score yet, so the first one behind the deciding step
-  // does the work and posts the result, the others fall through.
-  constexpr int kTail = 3;
-  auto step = [&](const rgck::LmInit* op) {
-    rgck::lm_step(s, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
+  const int seq = want_fitness ? -c->lm_seq : c->lm_seq;  // what is posted: a finished state (> 0), or a finished state with its score (< 0)
+  constexpr int kSpare = 2;
+  // the stage-by-stage pass (events around the solve's regions) keeps the two apart: all steps, then the score
+  const bool staged = c->prof_on && ((c->prof_mask >> RGC_K_LINEARIZE) & 1u || (c->prof_mask >> RGC_K_FITNESS) & 1u);
+  // The score is chained INTO the steps: the solve's last step (known in advance: a try below the convergence thresholds ends the solve
+  // either way) scores the pose it accepts and posts the result; if the solve ends otherwise, the next launch -- a blind one on a
+  // finished solve -- computes the score (k_lm_step).  No separate score launches, no blind steps between the deciding step and the score.
+  const bool fit_in_steps = want_fitness && !staged;
+  auto step = [&](const rgck::LmInit* op, hipStream_t on) {
+    rgck::lm_step(on, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
                   c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
                   (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, op, c->d_small + 7,
-                  c->tgt.segs.p, c->src.segs.p, post, seq);
+                  c->tgt.segs.p, c->src.segs.p, post, seq, fit_in_steps ? (const float4*)c->tgt.P.p : nullptr,
+                  fit_in_steps ? (const int*)c->tgt.start.p : nullptr, fit_in_steps ? (double*)c->fit_partials.p : nullptr, c->tgt.n);
   };
   auto score = [&]() {  // getFitnessScore at the final pose, chained blindly
     rgck::fitness_lm(s, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
                      (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p, post, c->lm_seq, c->tgt.n);
   };
-  // the stage-by-stage pass (events around the solve's regions) keeps the two apart: all steps, then the score
-  const bool staged = c->prof_on && ((c->prof_mask >> RGC_K_LINEARIZE) & 1u || (c->prof_mask >> RGC_K_FITNESS) & 1u);
+  hipStream_t tail = s;
   if (staged) {
     {
       ProfScope ps(c, RGC_K_LINEARIZE, (long long)n * batch, s);
-      for (int k = 0; k < batch; k++) { step(open); open = nullptr; }
+      for (int k = 0; k < batch; k++) { step(open, s); open = nullptr; }
     }
     if (want_fitness) {
       ProfScope ps(c, RGC_K_FITNESS, n, s);
       score();
     }
   } else {
-    for (int k = 0; k < batch; k++) {
-      step(open);
-      open = nullptr;
-      if (want_fitness && k >= batch - kTail) score();
+    // The launches a solve is EXPECTED to need go to the solve's stream; the spare ones -- enqueued blind in case it needs more: each costs
+    // ~5 us of its stream's time even when it finds the solve finished -- go to the context's OTHER stream behind an event, where they
+    // drain beside whatever the caller enqueues next on the solve's stream (the next frame's map preparation) instead of in front of it.
+    // (Not a third stream: two contexts with three streams each outnumber the hardware queues, and streams that share a queue serialise --
+    // the two-context sequence lost 130 us per frame that way.)
+    const int spare = (RGC_LM_SPARE_ASIDE && batch > kSpare + 1) ? kSpare : 0;
+    hipStream_t other = s == c->stream ? c->stream2 : c->stream;
+    for (int k = 0; k < batch - spare; k++) { step(open, s); open = nullptr; }
+    if (spare > 0) {
+      HIPCHK(c, hipEventRecord(c->lm_mid, s));
+      HIPCHK(c, hipStreamWaitEvent(other, c->lm_mid, 0));
+      for (int k = 0; k < spare; k++) step(nullptr, other);
+      tail = other;
     }
-    if (want_fitness && batch <= 0) score();
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipEventRecord(c->lm_tail, s));
-  c->lm_tail_stream = s;
+  HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, tail));
+  HIPCHK(c, hipEventRecord(c->lm_tail, tail));
+  c->lm_tail_stream = tail;
   return RGC_OK;
 }
 
@@ -1388,8 +1404,10 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   // One linearisation + fused cost / linearise steps, enqueued blind: enough for the outer iterations the PREVIOUS solve on this context
   // took plus two (consecutive frames of a sequence need about the same number; a launch on a finished solve costs ~2 us, a
   // read-back and a second batch ~40), at least the six that cover a tracking frame, at most what max_iterations allows.
-  int batch = 7;
-  if (c->lm_last_outer + 3 > batch) batch = c->lm_last_outer + 3;
+  // (a solve of o outer iterations needs o + 1 launches: the opening linearisation and one step per try; the previous solve's count plus
+  // one stay on the solve's stream, two more go aside as spares -- lm_enqueue_batch)
+  int batch = 8;
+  if (c->lm_last_outer + 4 > batch) batch = c->lm_last_outer + 4;
   if (batch > P.max_iterations + 1) batch = P.max_iterations + 1;
   if (batch < 2) batch = 2;
   c->lm_seq = c->lm_seq >= 0x3fffffff ? 1 : c->lm_seq + 1;
@@ -1417,7 +1435,7 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
       volatile int* gen = &c->h_post->gen;
       for (;;) {
         if (*gen == c->lm_seq) { posted = true; break; }
-        const hipError_t q = hipStreamQuery(c->solve_stream);
+        const hipError_t q = hipStreamQuery(c->lm_tail_stream);  // (the batch's last launches and its copy of the state: the solve's stream, or the other one when spare launches went there)
         if (q == hipSuccess) { posted = *gen == c->lm_seq; break; }
         if (q != hipErrorNotReady) return fail(c, RGC_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
       }
@@ -1427,7 +1445,7 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
       }
     }
     if (!posted) {
-      HIPCHK(c, hipStreamSynchronize(c->solve_stream));
+      HIPCHK(c, hipStreamSynchronize(c->lm_tail_stream));
       memcpy(&S, c->h_lm, sizeof(S));
     }
     HIPCHK(c, hipGetLastError());
@@ -1923,6 +1941,48 @@ int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_b
   const rgck::Reframe rf{d_in, stride_bytes / 4, rgck::Quat{q[0], q[1], q[2], q[3]}, {t[0], t[1], t[2]}};
   HIPCHK(c, hipGetLastError());
   return set_cloud(c, c->tgt, true, d_scratch, n, 16, true, &rf);
+}
+
+int rgc_align_end_reframe(rgc_ctx* c, rgc_ctx* next, double Tw[16], const float* d_map, int n, int stride_bytes, float* d_scratch,
+                          float final_T[16], double final_H[36], double* fitness, int* iterations, int* converged, int* lm_failed) {
+  if (!c || !next || !Tw) return RGC_ERR_INVALID;
+  float T[16];
+  int rc = rgc_align_end(c, T, final_H, fitness, iterations, converged, lm_failed);
+  if (rc) return rc;
+  if (final_T) memcpy(final_T, T, sizeof(T));
+  // world_T <- world_T * T in fp64, rows in ascending k (the composition of :1201-1203 on matrices)
+  double W[16];
+  for (int a = 0; a < 4; a++)
+    for (int b = 0; b < 4; b++) {
+      double v = 0.0;
+      for (int k = 0; k < 4; k++) v += Tw[a * 4 + k] * (double)T[k * 4 + b];
+      W[a * 4 + b] = v;
+    }
+  memcpy(Tw, W, sizeof(W));
+  // world -> body of the new pose: R^T and -R^T t; the unit quaternion of R^T by Shepperd's branches (:1250-1255)
+  const double Rt[3][3] = {{W[0], W[4], W[8]}, {W[1], W[5], W[9]}, {W[2], W[6], W[10]}};
+  double q[4];
+  const double tr = Rt[0][0] + Rt[1][1] + Rt[2][2];
+  if (tr > 0) {
+    const double s4 = 2.0 * std::sqrt(tr + 1.0);
+    q[0] = (Rt[2][1] - Rt[1][2]) / s4; q[1] = (Rt[0][2] - Rt[2][0]) / s4; q[2] = (Rt[1][0] - Rt[0][1]) / s4; q[3] = 0.25 * s4;
+  } else {
+    const int i = (Rt[0][0] >= Rt[1][1] && Rt[0][0] >= Rt[2][2]) ? 0 : (Rt[1][1] >= Rt[2][2] ? 1 : 2);
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    const double s4 = 2.0 * std::sqrt(1.0 + Rt[i][i] - Rt[j][j] - Rt[k][k]);
+    q[3] = (Rt[k][j] - Rt[j][k]) / s4;
+    q[i] = 0.25 * s4;
+    q[j] = (Rt[j][i] + Rt[i][j]) / s4;
+    q[k] = (Rt[k][i] + Rt[i][k]) / s4;
+  }
+  const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int a = 0; a < 4; a++) q[a] /= nrm;
+  const double tx = W[3], ty = W[7], tz = W[11];
+  const double t[3] = {-(Rt[0][0] * tx + Rt[0][1] * ty + Rt[0][2] * tz), -(Rt[1][0] * tx + Rt[1][1] * ty + Rt[1][2] * tz),
+                       -(Rt[2][0] * tx + Rt[2][1] * ty + Rt[2][2] * tz)};
+  rc = rgc_set_target_reframed(next, d_map, n, stride_bytes, q, t, d_scratch);
+  if (rc && next != c) fail(c, rc, "rgc_align_end_reframe: %s", next->err);
+  return rc;
 }
 
 // The rows chain of the leaf filter on box g (rgc_pre.hip); one read-back: *flags (bits as rgck::vg_rows documents) and *n_out.

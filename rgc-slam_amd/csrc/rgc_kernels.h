@@ -69,10 +69,11 @@ void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, in
 // consumes the counters: cnt[0..n) is left ZERO
 void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi = 0,
                 float* sum_sq = nullptr /* += sum of count^2, nullable */);
-void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi = 0);
+// order_tmp: n 64-bit records {original index, position in the cell, cell population} (k_place)
+void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi = 0);
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */, int hi = 0);
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const int* order_tmp, float4* P, int* zero_me = nullptr, int hi = 0);
+                 const unsigned long long* order_tmp, float4* P, int* zero_me = nullptr, int hi = 0);
 // ---- C2: exact kNN + PLANE covariance -> unit normal ----
 // bulk kernel (one lane per query; defers what it cannot finish) then the cooperative kernel (one wave per deferred query).
 // deferred: deferred_bytes(n) bytes, whose first int (the count) must be 0 on entry (rank_gather's zero_me)
@@ -108,7 +109,11 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
              const LmInit* first /* non-null: this launch opens a solve */, const int* nvox, const void* segs_t, const void* segs_s,
-             LmState* h_post = nullptr /* mapped host memory: a finished state is posted there, then seq in its `gen` */, int seq = 0 /* > 0: post when done; < 0: fitness_lm posts */);
+             LmState* h_post = nullptr /* mapped host memory: a finished state is posted there, then seq in its `gen` */,
+             int seq = 0 /* > 0: post when done; < 0: post when done AND scored (by this kernel or fitness_lm) */,
+             // the fitness score chained to the solve (all non-null): the solve's LAST step scores the pose it accepts, a launch on a finished
+             // solve without a score computes it; TP / tstart: the map's sorted points and cell starts, nt its point count
+             const float4* TP = nullptr, const int* tstart = nullptr, double* fit_partials = nullptr, int nt = 0);
 // nt: the target's point count (a small map is scanned whole by the wave for a query its first cube does not settle; 0: never)
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials,
                 LmState* h_post = nullptr, int seq = 0, int nt = 0);

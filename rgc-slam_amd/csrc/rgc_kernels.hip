@@ -235,20 +235,31 @@ __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid 
     c = cell_index(g, cx, cy, cz);
     cell_of[i] = c;
   }
-  // Clouds arrive spatially coherent (ring order, leaf order): consecutive lanes that fall into the same cell form a RUN, and
-  // only the run's first lane goes to memory -- one atomicAdd(run length) instead of one per point.  A crowded cell near the
-  // sensor used to serialise hundreds of same-address atomics (~12 ns each across the XCDs).
-  // The returned count is the run's first (arrival-order) slot inside its cell: the placement pass needs no second atomic.
-  const int prev = __shfl_up(c, 1);
-  const bool head = lane == 0 || c != prev;
-  const unsigned long long hm = __ballot(head);
-  const int head_lane = 63 - __clzll(hm & ((2ull << lane) - 1ull));            // highest head at or below this lane
-  const unsigned long long above = head_lane == 63 ? 0ull : (hm >> (head_lane + 1));
-  const int run_len = above ? __ffsll((long long)above) : WAVE - head_lane;      // distance to the next head
+  // One atomicAdd per DISTINCT cell of the wave, not per point: the lanes that fall into the same cell are found with one ballot per
+  // distinct cell (the first lane still unassigned names the cell, every lane compares), the first of them adds the group's size and the
+  // returned count is the group's first (arrival-order) slot inside its cell -- the placement pass needs no second atomic.
+  // Same-address atomics are what this pass costs (~12 ns each across the XCDs, serialised per address): a leaf-ordered map puts a wave
+  // into ~6 cells; a raw sweep arrives in FIRING order -- consecutive points are the 16 lasers of one azimuth, 16 different cells, and
+  // the next azimuth hits the same 16 again -- so grouping only CONSECUTIVE lanes (round 1-3) left it one atomic per point, hundreds of
+  // them on the crowded cells next to the sensor: the 30 k-point scan's pass took as long as the 1 M-point map's (21 us) and slowed
+  // every other kernel that was waiting for an atomic meanwhile (the solve's tickets).
+  unsigned long long todo = __ballot(valid);
+  int lead = lane, rank = 0, group = 1;
+  while (todo) {
+    const int l0 = __ffsll((long long)todo) - 1;
+    const int cl = __shfl(c, l0);
+    const unsigned long long same = __ballot(valid && c == cl);
+    if (valid && c == cl) {
+      lead = l0;
+      rank = __popcll(same & ((1ull << lane) - 1ull));
+      group = __popcll(same);
+    }
+    todo &= ~same;
+  }
   int base = 0;
-  if (head && valid) base = atomicAdd(&cnt[c], run_len);
-  base = __shfl(base, head_lane);
-  if (valid) slot_of[i] = base + (lane - head_lane);
+  if (valid && lane == lead) base = atomicAdd(&cnt[c], group);
+  base = __shfl(base, lead);
+  if (valid) slot_of[i] = base + rank;
 }
 
 // three-kernel exclusive scan: 2048 items per block (256 threads x 8)
@@ -351,6 +362,20 @@ __device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned lo
   return base + inc - v;
 }
 
+// A thread's SCAN_V = 8 consecutive entries as two 16-byte accesses where the whole group lies inside the array and the array is 16-byte
+// aligned (hipMalloc's are): eight 4-byte accesses per thread at a stride of 32 bytes touch every cache line of the wave's 2 KB four
+// times over and cost four times the instructions.  Past the end: zeros.
+__device__ __forceinline__ void load_cells8(const int* __restrict__ a, int base, int n, bool wide, int (&v)[8]) {
+  if (wide && base + 8 <= n) {
+    const int4 lo = *reinterpret_cast<const int4*>(a + base), hi = *reinterpret_cast<const int4*>(a + base + 4);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (base + j < n) ? a[base + j] : 0;
+  }
+}
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<unsigned long long>(p) & 15ull) == 0ull; }
+
 // cnt has n entries (cells + 1 sentinel of 0); cell_voxel (nullable) has n - 1.
 __device__ __forceinline__ unsigned long long scan_value(int v) { return (unsigned long long)(unsigned)v | ((unsigned long long)(v > 0) << 32); }
 // Reduce, then scan (round 3; the first pass used to write provisional start[] / cell_voxel[] that the second read, corrected and
@@ -364,14 +389,13 @@ __global__ void __launch_bounds__(SCAN_T) k_cells_reduce(const int* __restrict__
                                                          float* __restrict__ sum_sq) {
   wave_prio(prio);
   __shared__ unsigned long long part[SCAN_T / WAVE];
+  static_assert(SCAN_V == 8, "load_cells8");
   const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
   int v[SCAN_V];
   unsigned long long s = 0;
+  load_cells8(cnt, base, n, aligned16(cnt), v);
 #pragma unroll
-  for (int j = 0; j < SCAN_V; j++) {
-    v[j] = (base + j < n) ? cnt[base + j] : 0;
-    s += scan_value(v[j]);
-  }
+  for (int j = 0; j < SCAN_V; j++) s += scan_value(v[j]);
   if (sum_sq) {  // sum of count^2 = the work of every point scanning its own cell: how crowded the cells are (a heuristic, float is plenty)
     float q = 0.f;
 #pragma unroll
@@ -421,11 +445,10 @@ __global__ void __launch_bounds__(SCAN_T) k_cells_scan_write(int* __restrict__ c
   const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_V;
   int v[SCAN_V];  // the entries are fetched first: their loads overlap the prefix of the totals
   unsigned long long s = 0;
+  const bool wide = aligned16(cnt) && aligned16(start) && (!cell_voxel || aligned16(cell_voxel));
+  load_cells8(cnt, base, n, wide, v);
 #pragma unroll
-  for (int j = 0; j < SCAN_V; j++) {
-    v[j] = (base + j < n) ? cnt[base + j] : 0;
-    s += scan_value(v[j]);
-  }
+  for (int j = 0; j < SCAN_V; j++) s += scan_value(v[j]);
   if (kSelf) {
     unsigned long long acc = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_T) acc += block_sums[j];
@@ -441,13 +464,37 @@ __global__ void __launch_bounds__(SCAN_T) k_cells_scan_write(int* __restrict__ c
   } else if (threadIdx.x == 0) {
     pre_s = block_sums[blockIdx.x];
   }
+  const bool whole = wide && base + SCAN_V <= n - 1;  // all eight entries are cells (the sentinel, entry n - 1, has no cell_voxel)
+  // consumed: the counters are left clean for the next cloud, no fill kernel per frame
+  if (whole) {
+    const int4 z = make_int4(0, 0, 0, 0);
+    if (v[0] | v[1] | v[2] | v[3]) *reinterpret_cast<int4*>(cnt + base) = z;
+    if (v[4] | v[5] | v[6] | v[7]) *reinterpret_cast<int4*>(cnt + base + 4) = z;
+  } else {
 #pragma unroll
-  for (int j = 0; j < SCAN_V; j++)
-    if (base + j < n && v[j]) cnt[base + j] = 0;  // consumed: left clean for the next cloud, no fill kernel per frame
+    for (int j = 0; j < SCAN_V; j++)
+      if (base + j < n && v[j]) cnt[base + j] = 0;
+  }
   unsigned long long tot;
   unsigned long long ex = block_exclusive_scan64(s, &tot);  // (its barriers publish pre_s)
   ex += pre_s;
   if (kSelf && threadIdx.x == 0 && (int)blockIdx.x == nb - 1 && nvox) *nvox = (int)((pre_s + tot) >> 32);
+  if (whole) {
+    int st8[SCAN_V], vx8[SCAN_V];
+#pragma unroll
+    for (int j = 0; j < SCAN_V; j++) {
+      st8[j] = (int)(unsigned)ex;
+      vx8[j] = v[j] > 0 ? (int)(ex >> 32) : -1;
+      ex += scan_value(v[j]);
+    }
+    *reinterpret_cast<int4*>(start + base) = make_int4(st8[0], st8[1], st8[2], st8[3]);
+    *reinterpret_cast<int4*>(start + base + 4) = make_int4(st8[4], st8[5], st8[6], st8[7]);
+    if (cell_voxel) {
+      *reinterpret_cast<int4*>(cell_voxel + base) = make_int4(vx8[0], vx8[1], vx8[2], vx8[3]);
+      *reinterpret_cast<int4*>(cell_voxel + base + 4) = make_int4(vx8[4], vx8[5], vx8[6], vx8[7]);
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < SCAN_V; j++) {
     const int i = base + j;
@@ -459,40 +506,70 @@ __global__ void __launch_bounds__(SCAN_T) k_cells_scan_write(int* __restrict__ c
   }
 }
 
-// placement without atomics: slot_of[] came back from k_count's atomicAdd
+// placement without atomics: slot_of[] came back from k_count's atomicAdd.  The record left at the point's (arrival-order) position in its
+// cell carries everything the ranking pass needs -- the original index, this position inside the cell and the cell's population -- so
+// that k_rank_gather finds its cell's extent WITHOUT going back to cell_of[] and start[] (two dependent memory round trips of its five;
+// the pass is a chain of round trips, not bandwidth: 27 -> us at 1 M points):
+//   bits 0..26 original index (n <= 2^27), 27..44 position in the cell, 45..62 population; a cell of 2^18 points or more (a degenerate
+//   cloud) stores population 0 and the ranking pass takes the long way for it.
+constexpr int kOrdIdxBits = 27, kOrdCntBits = 18;
+constexpr unsigned long long kOrdIdxMask = (1ull << kOrdIdxBits) - 1ull;
+constexpr int kOrdCntMax = (1 << kOrdCntBits) - 1;
 __global__ void k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of, const int* __restrict__ start,
-                        int* __restrict__ order_tmp, int prio) {
+                        unsigned long long* __restrict__ order_tmp, int prio) {
   wave_prio(prio);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  order_tmp[start[cell_of[i]] + slot_of[i]] = i;  // unordered inside the cell; k_rank_gather makes the order deterministic
+  const int c = cell_of[i], slot = slot_of[i];
+  const int s0 = start[c], cnt = start[c + 1] - s0;
+  const bool big = cnt > kOrdCntMax;
+  order_tmp[s0 + slot] = (unsigned long long)(unsigned)i | ((unsigned long long)(big ? 0 : slot) << kOrdIdxBits) |
+                         ((unsigned long long)(big ? 0 : cnt) << (kOrdIdxBits + kOrdCntBits));  // unordered inside the cell; k_rank_gather makes the order deterministic
 }
 
 // deterministic placement: a point's final slot = cell start + number of same-cell points with a smaller index.
 // Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate; P holds n + 4 entries.
 __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
-                              const int* __restrict__ start, const int* __restrict__ order_tmp, float4* __restrict__ P, int* zero_me,
+                              const int* __restrict__ start, const unsigned long long* __restrict__ order_tmp, float4* __restrict__ P, int* zero_me,
                               int prio) {
   wave_prio(prio);
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s == 0 && zero_me) *zero_me = 0;  // the kNN launch that follows counts its deferred queries here
   if (s < 4) P[n + s] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __int_as_float(-1));  // sentinels: infinitely far from every query (k_knn_sp's last quad)
   if (s >= n) return;
-  int i = order_tmp[s];
-  int c = cell_of[i];
-  int s0 = start[c], s1 = start[c + 1];
+  const unsigned long long rec = order_tmp[s];
+  const int i = (int)(rec & kOrdIdxMask);
+  const int cnt = (int)(rec >> (kOrdIdxBits + kOrdCntBits)) & kOrdCntMax;
+  int s0, s1;
+  if (cnt > 0) {
+    s0 = s - ((int)(rec >> kOrdIdxBits) & kOrdCntMax);
+    s1 = s0 + cnt;
+  } else {  // a cell too crowded for the record's fields
+    const int c = cell_of[i];
+    s0 = start[c];
+    s1 = start[c + 1];
+  }
+  const float* p = in + (size_t)i * stride_f;
+  const float px = p[0], py = p[1], pz = p[2];  // (issued beside the members' loads: nothing below depends on them until the store)
+  const unsigned* lo = reinterpret_cast<const unsigned*>(order_tmp);  // the records' low words: index bits 0..26, position bits above
+  constexpr unsigned kLoMask = (unsigned)kOrdIdxMask;
   int rank = 0;
   int t = s0;
   for (; t + 8 <= s1; t += 8) {  // eight independent loads in flight: a crowded cell (hundreds of members) is a long serial loop otherwise
-    int o[8];
+    unsigned o[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) o[u] = order_tmp[t + u];
+    for (int u = 0; u < 8; u++) o[u] = lo[2 * (size_t)(t + u)];
 #pragma unroll
-    for (int u = 0; u < 8; u++) rank += (o[u] < i);
+    for (int u = 0; u < 8; u++) rank += ((int)(o[u] & kLoMask) < i);
   }
-  for (; t < s1; t++) rank += (order_tmp[t] < i);
-  const float* p = in + (size_t)i * stride_f;
-  P[s0 + rank] = make_float4(p[0], p[1], p[2], __int_as_float(i));
+  if (t < s1) {  // 1..7 left: clamped loads (the last member counted again would be wrong: masked by position)
+    unsigned o[7];
+#pragma unroll
+    for (int u = 0; u < 7; u++) o[u] = lo[2 * (size_t)min(t + u, s1 - 1)];
+#pragma unroll
+    for (int u = 0; u < 7; u++) rank += (t + u < s1 && (int)(o[u] & kLoMask) < i);
+  }
+  P[s0 + rank] = make_float4(px, py, pz, __int_as_float(i));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2206,7 +2283,8 @@ __device__ __forceinline__ void reinit_small_blocks(const int* nvox) {
 // The decision of one STEP launch, taken by lane 0 of the last-arriving workgroup on the LDS copy `ls` of the state: what the
 // folded sums mean in this mode, accept / reject / terminate, and the next LM try (lsq_registration_impl.hpp:125-172).
 __device__ __forceinline__ void lm_step_decide(LmState& ls, const double* folded, int first, const LmInit& in, int mode, int cur,
-                                               const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s) {
+                                               const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s,
+                                               bool* took_xi) {
   if (first) {  // fresh state (:53-63) plus the frame's counters, so that ONE read-back at the end carries every statistic
 #pragma unroll
     for (int a = 0; a < 16; a++) ls.x0[a] = in.x0[a];
@@ -2285,6 +2363,7 @@ __device__ __forceinline__ void lm_step_decide(LmState& ls, const double* folded
         ls.mode = LM_MODE_B;
       }
     } else {  // :165-168
+      *took_xi = true;
 #pragma unroll
       for (int a = 0; a < 16; a++) { x0[a] = ls.xi[a]; ls.x0[a] = x0[a]; }
       const double r21 = 2 * rho - 1;
@@ -2343,17 +2422,60 @@ __device__ __forceinline__ void post_state_to_host(const LmState* src, LmState* 
   if (threadIdx.x == 0) __hip_atomic_store(&hw[kGen], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// (defined with the score's kernels below)
+constexpr int FIT_T = 64;
+int fitness_blocks(int n) { return (n + FIT_T - 1) / FIT_T; }
+__device__ __forceinline__ int fitness_blocks_dev(int n) { return (n + FIT_T - 1) / FIT_T; }
+__device__ __forceinline__ double fitness_wave(const float4* __restrict__ SP, int ns, const PoseF& T, const float4* __restrict__ TP,
+                                               const int* __restrict__ tstart, const Grid& g, int n_all, int w, int W);
+__device__ __forceinline__ double fitness_fold(const double* __restrict__ partials, int W);
+
+// What the score needs beside the solve's own arguments (k_lm_step): the map's sorted points and cell starts, the rows of the per-wave
+// sums, and whether a small map is scanned whole (fitness_wave).  on == 0: no score is chained to this solve.
+struct FitArgs { const float4* TP; const int* tstart; double* partials; int n_all; int on; };
+
+// this wave's share of getFitnessScore at pose m16 (cast to float like final_transformation_, :77), as a write-through row
+__device__ __forceinline__ void step_fitness_rows(const float4* __restrict__ SP, int n, const double* m16, const Grid& g, const FitArgs& fa) {
+  const int W = (n + FIT_T - 1) / FIT_T, w = (int)blockIdx.x * (LIN_T / WAVE) + ((int)threadIdx.x >> 6);
+  if (w >= W) return;
+  PoseF T;
+#pragma unroll
+  for (int a = 0; a < 12; a++) T.m[a] = (float)m16[a];
+  const double v = fitness_wave(SP, n, T, fa.TP, fa.tstart, g, fa.n_all, w, W);
+  if (((int)threadIdx.x & (WAVE - 1)) == 0) __hip_atomic_store(&fa.partials[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void __launch_bounds__(LIN_T)
 k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
           const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v0, double* __restrict__ corr_M0,
           int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st, int first,
           LmInit in, const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s, LmState* __restrict__ h_post,
-          int seq) {
+          int seq, FitArgs fa) {
   wave_prio(2);  // a latency chain: issue ahead of whatever shares the CU (the other context's kNN, the next scan's preparation)
   // first != 0: this launch opens a solve.  Nobody reads the (stale) state: mode, buffer and pose come from the kernel
   // arguments, and the last-arriving workgroup's lane 0 writes the fresh state (:53-63) before it uses it -- no separate
   // initialisation launch, no H2D copy.  The tickets are 0 between launches by construction (the last arriver resets them).
   if (first ? in.max_outer <= 0 : st->done != 0) {
+    if (!first && fa.on && !st->has_fit) {
+      // A launch on a FINISHED solve that has no score yet computes the score (the same grid covers the scan: one thread per point).
+      // The usual frame never gets here -- its last step already scored the pose it accepted (below); this is the solve that ended
+      // on a rejected try (the final pose is the previous x0), on max_iterations, or with "lm not converged".
+      step_fitness_rows(P, n, st->x0, g, fa);
+      if (!last_block_arrive(&st->ticketB)) return;  // the LM is over: its second ticket is free
+      if (threadIdx.x < WAVE) {
+        const double t = fitness_fold(fa.partials, fitness_blocks_dev(n));
+        if (threadIdx.x == 0) {
+          st->fit_sum = t;
+          st->has_fit = 1;
+          if (h_post) {
+            __hip_atomic_store(&h_post->fit_sum, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&h_post->has_fit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+      }
+      if (h_post) post_state_to_host(st, h_post, seq < 0 ? -seq : seq, LIN_T, true);
+      return;
+    }
     if (first && blockIdx.x == 0 && threadIdx.x == 0) {  // max_iterations <= 0: the guess is the answer
       int* w = reinterpret_cast<int*>(st);
       for (int u = 0; u < (int)(sizeof(LmState) / sizeof(int)); u++) w[u] = 0;
@@ -2374,6 +2496,13 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
   __shared__ double folded[kStepAcc];
   LAB_TS_MIN(0);
   const int mode = first ? LM_MODE_LIN : st->mode, cur = first ? 0 : st->cur;
+  // A try whose delta is already below the convergence thresholds ENDS the solve whatever its cost turns out to be (rho >= 0: x0 = xi,
+  // converged; rho < 0: step_lm returns true with x unchanged, :155-158 -- lm_step_decide below): every workgroup can tell from the
+  // state that this launch is the last one.  It then skips the speculative linearisation (nobody would adopt it) and computes the
+  // fitness score at xi instead -- in the usual case (accepted) that IS the final pose, and the frame's result leaves with this launch:
+  // no blind steps in front of a separate score launch, no second kernel.
+  const bool final_try = !first && mode != LM_MODE_LIN && lm_is_converged(st->delta, st->rot_eps, st->trans_eps);
+  const bool score_here = final_try && fa.on != 0;
   int* cv_cur = cur ? corr_v1 : corr_v0;
   double* cm_cur = cur ? corr_M1 : corr_M0;
   int* cv_nxt = cur ? corr_v0 : corr_v1;
@@ -2383,7 +2512,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
 #pragma unroll
   for (int a = 0; a < kStepAcc; a++) acc[a] = 0.0;
   if (mode != LM_MODE_LIN && i < n) acc[kAccum + 1] = error_point(P, i, n, st->xi, vox, noff, cv_cur, cm_cur);
-  if (mode != LM_MODE_B) {
+  if (mode != LM_MODE_B && !final_try) {
     Pose T;
     lm_load_pose(first ? in.x0 : (mode == LM_MODE_LIN ? st->x0 : st->xi), T);
     double lin[kAccum];
@@ -2396,6 +2525,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     for (int a = 0; a < kAccum; a++) acc[a] = lin[a];
     acc[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
   }
+  if (score_here) step_fitness_rows(P, n, st->xi, g, fa);
   LAB_TS_MIN(1);
   block_reduce_store<kStepAcc, true>(acc, partials + (size_t)blockIdx.x * kStepAcc);
   LAB_TS_MIN(2);
@@ -2412,19 +2542,31 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     for (int u = threadIdx.x; u < kStateWords; u += LIN_T) lw[u] = first ? 0 : gw[u];
   }
   block_fold_rows<kStepAcc>(partials, gridDim.x, folded);  // (its barriers also publish ls)
+  __shared__ int took_xi_s;
   if (threadIdx.x == 0) {
     LAB_TS(4);
     ls.ticketA = 0;  // (already reset in memory by last_block_arrive)
-    lm_step_decide(ls, folded, first, in, mode, cur, nvox, def_t, def_s);
+    bool took_xi = false;
+    lm_step_decide(ls, folded, first, in, mode, cur, nvox, def_t, def_s, &took_xi);
+    took_xi_s = took_xi ? 1 : 0;
   }
   __syncthreads();
+  if (score_here && ls.done && took_xi_s) {  // the accepted pose is the one the score was taken at: fold it into the state
+    if (threadIdx.x < WAVE) {
+      const double t = fitness_fold(fa.partials, fitness_blocks_dev(n));
+      if (threadIdx.x == 0) { ls.fit_sum = t; ls.has_fit = 1; }
+    }
+    __syncthreads();
+  }
   {
     const int* lw = reinterpret_cast<const int*>(&ls);
     int* gw = reinterpret_cast<int*>(st);
     for (int u = threadIdx.x; u < kStateWords; u += LIN_T) gw[u] = lw[u];
   }
-  // seq > 0: no fitness score is chained behind this solve -- a finished state is the frame's result (seq < 0: the fitness kernel posts it)
-  if (h_post && seq > 0 && ls.done) post_state_to_host(&ls, h_post, seq, LIN_T, false);
+  // seq > 0: no fitness score is chained to this solve -- a finished state is the frame's result; seq < 0: a finished state WITH its
+  // score is (from here when the last step scored the pose it accepted, else from whoever computes the score: a later step launch or
+  // k_fitness_lm)
+  if (h_post && ls.done && (seq > 0 || ls.has_fit)) post_state_to_host(&ls, h_post, seq < 0 ? -seq : seq, LIN_T, false);
 }
 
 // fold per-block rows in a fixed order: block a (one wave) owns accumulator a; lane l sums rows l, l+64, ...
@@ -2462,8 +2604,7 @@ k_error(const float4* __restrict__ P, int n, Pose T, const double* __restrict__ 
 // C8  pcl::Registration::getFitnessScore: fp32 transform, exact 1-NN in the target grid, fp32 distances summed
 // in fp64.  One lane per source point.
 // ------------------------------------------------------------------------------------------------
-constexpr int FIT_T = 64;  // one wave per block: 30 k scan points spread over ~470 workgroups instead of 118
-int fitness_blocks(int n) { return (n + FIT_T - 1) / FIT_T; }
+// (FIT_T = 64, fitness_blocks: above k_lm_step -- one wave per row of the score's partial sums)
 
 // Exact nearest neighbour of (px,py,pz) in the sorted target: own cell first (an aligned point's nearest map point is usually
 // closer than its cell walls), else a cube of cells that grows until the best distance is provably inside it -- or until the
@@ -2640,6 +2781,21 @@ k_icp_accumulate(const float4* __restrict__ SP, int ns, const float4* __restrict
   block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
 }
 
+// The fold of the per-wave sums by ONE wave, in a fixed order (lane l: rows l, l + 64, ... ascending, eight fetched before any is added --
+// one round trip, not eight; then the wave's shuffle tree): the score is the same bits wherever it is folded.
+__device__ __forceinline__ double fitness_fold(const double* __restrict__ partials, int W) {
+  const int lane = (int)threadIdx.x & (WAVE - 1);
+  double t = 0;
+  for (int r0 = lane; r0 < W; r0 += 8 * FIT_T) {
+    double v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v8[u] = (r0 + u * FIT_T < W) ? partials[r0 + u * FIT_T] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) t += v8[u];
+  }
+  return wave_sum(t);
+}
+
 // One wave's share of the scan against the map (FIT_T == WAVE); returns the wave's sum of squared nearest distances.
 // n_all > 0 -- a SMALL map, the odometer's own three keyframes: ~11 k points, one per ten cells of its grid, and of a sweep's 11 k
 // points several hundred lie 1-7 m from it (the keyframes hold the less-flat feature cloud, not whole sweeps).  Growing the cube for
@@ -2648,11 +2804,14 @@ k_icp_accumulate(const float4* __restrict__ SP, int ns, const float4* __restrict
 //     for it (n_all / 64 coalesced loads per lane, the same dist2(), the minimum over the lanes: the exact nearest distance again), and
 //   * the wave takes every (number of waves)-th point of the cell-sorted scan, not 64 consecutive ones: a sweep's far points are
 //     neighbours, and a wave that holds 64 of them scans the map 64 times while the others idle.
+// (w, W): this wave's number and the number of waves the scan is dealt to -- fitness_blocks(ns) everywhere, so that the per-wave sums and
+// their fold (fitness_fold) are the same numbers whichever kernel computes them: k_fitness / k_fitness_lm (one-wave workgroups) or a step
+// launch of the solve (k_lm_step: four waves per workgroup).
 __device__ __forceinline__ double fitness_wave(const float4* __restrict__ SP, int ns, const PoseF& T, const float4* __restrict__ TP,
-                                               const int* __restrict__ tstart, const Grid& g, int n_all) {
-  static_assert(FIT_T == WAVE, "one wave per workgroup");
-  const int lane = (int)threadIdx.x;
-  const int i = n_all > 0 ? lane * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * FIT_T + lane;
+                                               const int* __restrict__ tstart, const Grid& g, int n_all, int w, int W) {
+  static_assert(FIT_T == WAVE, "one wave per row");
+  const int lane = (int)threadIdx.x & (WAVE - 1);
+  const int i = n_all > 0 ? lane * W + w : w * FIT_T + lane;
   float best = 0.f, q[3] = {0.f, 0.f, 0.f};
   bool unresolved = false;
   if (i < ns) best = fitness_point(SP, i, T, TP, tstart, g, n_all > 0 ? &unresolved : nullptr, q);
@@ -2686,7 +2845,7 @@ __device__ __forceinline__ double fitness_wave(const float4* __restrict__ SP, in
 __global__ void __launch_bounds__(FIT_T)
 k_fitness(const float4* __restrict__ SP, int ns, PoseF T, const float4* __restrict__ TP,
           const int* __restrict__ tstart, Grid g, double* __restrict__ partials, int n_all) {
-  const double v = fitness_wave(SP, ns, T, TP, tstart, g, n_all);
+  const double v = fitness_wave(SP, ns, T, TP, tstart, g, n_all, (int)blockIdx.x, (int)gridDim.x);
   if (threadIdx.x == 0) partials[blockIdx.x] = v;
 }
 
@@ -2699,18 +2858,10 @@ k_fitness_lm(const float4* __restrict__ SP, int ns, LmState* __restrict__ st, co
   PoseF T;
 #pragma unroll
   for (int a = 0; a < 12; a++) T.m[a] = (float)st->x0[a];  // final_transformation_ = x0.cast<float>(), :77
-  const double v = fitness_wave(SP, ns, T, TP, tstart, g, n_all);
+  const double v = fitness_wave(SP, ns, T, TP, tstart, g, n_all, (int)blockIdx.x, (int)gridDim.x);
   if (threadIdx.x == 0) __hip_atomic_store(&partials[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through row
   if (!last_block_arrive(&st->ticketB)) return;  // the LM is over: its ticket is free
-  double t = 0;
-  for (int r0 = threadIdx.x; r0 < (int)gridDim.x; r0 += 8 * FIT_T) {  // eight rows per lane fetched before any is added (one round trip, not eight)
-    double v8[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v8[u] = (r0 + u * FIT_T < (int)gridDim.x) ? partials[r0 + u * FIT_T] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; u++) t += v8[u];
-  }
-  t = wave_sum(t);
+  const double t = fitness_fold(partials, (int)gridDim.x);
   if (threadIdx.x == 0) {
     st->fit_sum = t;
     st->has_fit = 1;
@@ -3125,7 +3276,7 @@ void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, in
     hipLaunchKernelGGL(k_cells_scan_write<false>, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, nb, cell_voxel, nvox, hi);
   }
 }
-void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, int* order_tmp, int hi) {
+void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi) {
   hipLaunchKernelGGL(k_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, slot_of, start, order_tmp, hi);
 }
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums, int hi) {
@@ -3137,7 +3288,7 @@ void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_su
   }
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const int* order_tmp, float4* P, int* zero_me, int hi) {
+                 const unsigned long long* order_tmp, float4* P, int* zero_me, int hi) {
   hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi);
 }
 size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
@@ -3234,14 +3385,16 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
   hipLaunchKernelGGL(k_error_dev, dim3(nb), dim3(LIN_T), 0, s, P, n, Tdev, vox, noff, corr_v, corr_M, partials);
   hipLaunchKernelGGL(k_fold<1>, dim3(1), dim3(WAVE), 0, s, partials, nb, out1, (const int*)nullptr, (int*)nullptr);
 }
-void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
-             const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
-             const LmInit* first, const int* nvox, const void* segs_t, const void* segs_s, LmState* h_post, int seq) {
-  hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
-                     corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s, h_post, seq);
-}
 // a map of at most this many points is scanned whole by the wave for a query its first cube does not settle (fitness_wave)
 static int fitness_scan_all(int nt) { return nt > 0 && nt <= 32768 ? nt : 0; }
+void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
+             const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
+             const LmInit* first, const int* nvox, const void* segs_t, const void* segs_s, LmState* h_post, int seq, const float4* TP,
+             const int* tstart, double* fit_partials, int nt) {
+  const FitArgs fa{TP, tstart, fit_partials, fitness_scan_all(nt), (TP && tstart && fit_partials) ? 1 : 0};
+  hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
+                     corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s, h_post, seq, fa);
+}
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials, LmState* h_post,
                 int seq, int nt) {
   hipLaunchKernelGGL(k_fitness_lm, dim3(fitness_blocks(ns)), dim3(FIT_T), 0, s, SP, ns, st, TP, tstart, g, partials, h_post, seq, fitness_scan_all(nt));

@@ -185,6 +185,27 @@ class FastVGICP:
         self._fitness = fit.value if want_fitness else None
         return self._final.copy()
 
+    def align_end_reframe(self, nxt, Tw, d_map: int, n: int, stride_bytes: int, d_scratch: int):
+        """align_end(), the world pose composed (Tw <- Tw * T, in place: a C-contiguous float64 4x4) and the NEXT frame's target -- the map at
+        d_map re-expressed in the new body frame -- enqueued on context `nxt` in ONE call (rgc_align_end_reframe): a dependent sequence's
+        turn-around between a frame's result and the next frame's first launch without Python in it.  Returns the frame's motion."""
+        want_fitness = getattr(self, "_pending_fitness", False)
+        fin = np.empty(16, np.float32)
+        H = np.empty(36)
+        fit = C.c_double(0)
+        it, conv, fail = C.c_int(0), C.c_int(0), C.c_int(0)
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        assert Tw.dtype == np.float64 and Tw.flags["C_CONTIGUOUS"] and Tw.size == 16
+        self._chk(self._L.rgc_align_end_reframe(self._h, nxt._h, Tw.ctypes.data_as(dp), C.c_void_p(d_map), n, stride_bytes, C.c_void_p(d_scratch),
+                                                fin.ctypes.data_as(fp), H.ctypes.data_as(dp), C.byref(fit) if want_fitness else None,
+                                                C.byref(it), C.byref(conv), C.byref(fail)))
+        self._final = fin.reshape(4, 4)
+        self._H = H.reshape(6, 6)
+        self._iterations, self._converged, self._lm_failed = it.value, bool(conv.value), bool(fail.value)
+        self._fitness = fit.value if want_fitness else None
+        nxt._n_tgt = n
+        return self._final.copy()
+
     def alignedToDevice(self, d_out, stride_bytes=16, T=None):
         """the `output` cloud of align() written to a device buffer (no copy to the host, no synchronisation)"""
         t = np.ascontiguousarray(self._final if T is None else T, dtype=np.float32).reshape(16)

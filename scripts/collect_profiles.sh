@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the outputs of scripts/refresh_profiles.sh (gpurun_out/${TAG}f/) into profiles/${TAG}_* and regenerate the figures the documents quote.
-TAG=${RGC_ROUND_TAG:-r03}
+TAG=${RGC_ROUND_TAG:-r04}
 cd "$(dirname "$0")/.." || exit 1
 S=gpurun_out/${TAG}f
 for f in bench.json bench_under_rocprof.json kernel_stats.csv domain_stats.csv dependent_frame_kernels.txt dependent_frame_timeline.txt pmc_knn.json pmc_knn_src.json lab_iters.json knn_isa_mix.json long_run.json long_run_dependent.json; do

@@ -214,7 +214,9 @@ def main():
     executed = sum(tot.values())
     h_lo = tot["half"] / executed                      # unknown opcodes priced at full rate
     h_hi = (tot["half"] + tot["unknown"]) / executed   # ... at half rate
+    hc = os.path.join(ROOT, ".head_commit")   # written beside the snapshot before the GPU call (there is no .git on the box)
     out = {"kernel": "k_knn_sp<20, true, true> (the map's bulk kNN + covariance launch, k = 20)",
+           "commit": open(hc).read().strip() if os.path.exists(hc) else None,
            "static_valu_instructions": static, "executed_valu_per_wave": {k: round(v, 1) for k, v in tot.items()},
            "executed_valu_per_query": round(executed / 64.0, 2),
            "trip_counts_per_wave": {k: round(v, 2) for k, v in trips.items()}, "lab": lab,

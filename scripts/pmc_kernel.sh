@@ -21,7 +21,8 @@ for f in glob.glob(os.path.join(O, "**", "*counter_collection.csv"), recursive=T
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
 q = float(os.environ["NQ"])
-out = {"kernel": pat + " (%d queries per launch)" % int(q), "per_launch": m}
+hc = os.path.join(os.environ["GRAFT_REPO_ROOT"], ".head_commit")   # written beside the snapshot before the GPU call (there is no .git on the box)
+out = {"kernel": pat + " (%d queries per launch)" % int(q), "commit": open(hc).read().strip() if os.path.exists(hc) else None, "per_launch": m}
 if "SQ_INSTS_VALU" in m: out["valu_wave_instructions_per_query"] = round(m["SQ_INSTS_VALU"] / q, 1)
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m: out["hbm_bytes_per_launch"] = int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)
 for a, b, name in (("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "valu_active_per_busy_cycle"), ("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "wave_cycles_waiting_on_issue_frac"),

@@ -3,7 +3,7 @@
 # and the executed instruction mix of the dominant kernel, the side benches.  Outputs under gpurun_out/${TAG}f/ ; scripts/collect_profiles.sh
 # copies what should be judged into profiles/${TAG}_*.
 #   usage: scripts/refresh_profiles.sh [quick]     (quick: skip the long runs and the side benches)
-TAG=${RGC_ROUND_TAG:-r03}
+TAG=${RGC_ROUND_TAG:-r04}
 cd "$GRAFT_REPO_ROOT"
 O=$GRAFT_REPO_ROOT/gpurun_out/${TAG}f
 rm -rf $O; mkdir -p $O
