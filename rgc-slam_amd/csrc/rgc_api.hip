@@ -624,7 +624,12 @@ rgck::PoseF posef_from(const float T[16]) {
 // order the main stream after the source preprocessing (which runs on stream2)
 int join_source(rgc_ctx* c) {
   if (c->src_pending) {
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->src_ready, 0));
+    // (a scan prepared ahead -- two contexts taking turns -- has usually finished by now: then no barrier packet goes into the main
+    // stream at all; a dependency that has to be resolved across streams costs ~10 us in front of the kernel behind it, even a met one)
+    if (hipEventQuery(c->src_ready) != hipSuccess) {
+      (void)hipGetLastError();  // ("not ready" is an answer, not an error to be found by a later check)
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->src_ready, 0));
+    }
     c->src_pending = false;
   }
   return RGC_OK;
@@ -1297,7 +1302,7 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
   hipStream_t s = c->solve_stream;  // see rgc_align_begin
   rgck::LmState* post = (c->post_on && c->d_post) ? c->d_post : nullptr;
   const int seq = want_fitness ? -c->lm_seq : c->lm_seq;  // what is posted: a finished state (> 0), or a finished state with its score (< 0)
-  constexpr int kSpare = 2;
+  constexpr int kSpare = 3;
   // the stage-by-stage pass (events around the solve's regions) keeps the two apart: all steps, then the score
   const bool staged = c->prof_on && ((c->prof_mask >> RGC_K_LINEARIZE) & 1u || (c->prof_mask >> RGC_K_FITNESS) & 1u);
   // The score is chained INTO the steps: the solve's last step (known in advance: a try below the convergence thresholds ends the solve
@@ -1377,7 +1382,10 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   // rgc_align_end returns as soon as the device POSTS the finished state: the previous solve's spare steps, score launches and the copy
   // into h_lm may still be queued on the stream they were enqueued on.  A solve that goes to the other stream is ordered behind them
   // (they work on the same LM state and tickets); a wait on an event that has already fired costs nothing.
-  if (c->lm_tail_stream && c->lm_tail_stream != c->solve_stream) HIPCHK(c, hipStreamWaitEvent(c->solve_stream, c->lm_tail, 0));
+  if (c->lm_tail_stream && c->lm_tail_stream != c->solve_stream && hipEventQuery(c->lm_tail) != hipSuccess) {
+    (void)hipGetLastError();
+    HIPCHK(c, hipStreamWaitEvent(c->solve_stream, c->lm_tail, 0));
+  }
   const rgc_params& P = c->prm;
   // device-chained LM: the loop of :65-75 / :125-172 runs as a state machine on the device (k_lm_step);
   // the host only enqueues slots and reads the state back once per batch.
@@ -1404,8 +1412,9 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   // One linearisation + fused cost / linearise steps, enqueued blind: enough for the outer iterations the PREVIOUS solve on this context
   // took plus two (consecutive frames of a sequence need about the same number; a launch on a finished solve costs ~2 us, a
   // read-back and a second batch ~40), at least the six that cover a tracking frame, at most what max_iterations allows.
-  // (a solve of o outer iterations needs o + 1 launches: the opening linearisation and one step per try; the previous solve's count plus
-  // one stay on the solve's stream, two more go aside as spares -- lm_enqueue_batch)
+  // (a solve of o outer iterations needs o + 1 launches: the opening linearisation and one step per try; as many as the previous solve
+  // needed stay on the solve's stream -- a launch too many there costs ~5 us in front of the next frame --, three more go aside as
+  // spares: lm_enqueue_batch)
   int batch = 8;
   if (c->lm_last_outer + 4 > batch) batch = c->lm_last_outer + 4;
   if (batch > P.max_iterations + 1) batch = P.max_iterations + 1;
