@@ -199,126 +199,67 @@ __device__ __forceinline__ float4 reframe_point(const Reframe& rf, int i) {
                      (float)(vz + q.w * uz + (q.x * uy - q.y * ux) + rf.t[2]), rf.src_stride_f > 3 ? p[3] : 0.f);
 }
 
-// kCountPts points per thread, a workgroup of 256 threads takes 256 * kCountPts CONSECUTIVE points (thread t: t, t + 256, ...: every
-// wave-wide access stays coalesced).  The pass is two dependent memory round trips per point -- the point, then the atomic's returned
-// count -- and little else: with one point per thread a 1 M-point cloud is two residency rounds of them (17-19 us); four points per
-// thread put four round trips in flight at once.  It also lets a wave group the same-cell points of 256 points, not 64.
-constexpr int kCountPts = 4;
 template <bool kReframe>
-__global__ void __launch_bounds__(256) k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of,
-                                               int* __restrict__ slot_of, int* cnt, int* guard, int prio, Reframe rf) {
+__global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid g, int* __restrict__ cell_of, int* __restrict__ slot_of,
+                        int* cnt, int* guard, int prio, Reframe rf) {
   wave_prio(prio);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
   const int lane = threadIdx.x & (WAVE - 1);
-  const int i0 = blockIdx.x * (256 * kCountPts) + threadIdx.x;
-  int c[kCountPts];
-  bool valid[kCountPts];
-  float4 pt[kCountPts];
-#pragma unroll
-  for (int u = 0; u < kCountPts; u++) {  // the loads first: all of them in flight together
-    const int i = i0 + u * 256;
-    valid[u] = i < n;
-    pt[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid[u]) {
-      if (kReframe) {  // the cloud is produced here (stride 4 floats) and counted from registers
-        pt[u] = reframe_point(rf, i);
-      } else {
-        const float* pp = in + (size_t)i * stride_f;
-        pt[u].x = pp[0]; pt[u].y = pp[1]; pt[u].z = pp[2];
-      }
+  int c = -1 - lane;  // lanes past the end: distinct negative keys, so they never extend a neighbour's run
+  if (valid) {
+    float pt[3];
+    if (kReframe) {  // the cloud is produced here (stride 4 floats) and counted from registers
+      const float4 w = reframe_point(rf, i);
+      *reinterpret_cast<float4*>(const_cast<float*>(in) + (size_t)i * 4) = w;
+      pt[0] = w.x; pt[1] = w.y; pt[2] = w.z;
+    } else {
+      const float* pp = in + (size_t)i * stride_f;
+      pt[0] = pp[0]; pt[1] = pp[1]; pt[2] = pp[2];
     }
-  }
-#pragma unroll
-  for (int u = 0; u < kCountPts; u++) {
-    const int i = i0 + u * 256;
-    c[u] = -1;
-    if (valid[u]) {
-      if (kReframe) *reinterpret_cast<float4*>(const_cast<float*>(in) + (size_t)i * 4) = pt[u];
-      int cx, cy, cz;
-      if (guard) {
-        const float x = pt[u].x, y = pt[u].y, z = pt[u].z;
-        const bool fin = fabsf(x) <= 1.0e8f && fabsf(y) <= 1.0e8f && fabsf(z) <= 1.0e8f;  // false for NaN too
-        cx = fin ? cell_coord(x, g) - g.minc[0] : 0;
-        cy = fin ? cell_coord(y, g) - g.minc[1] : 0;
-        cz = fin ? cell_coord(z, g) - g.minc[2] : 0;
-        const bool inside = cx >= 0 && cx < g.dim[0] && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
-        if (!fin || !inside) { atomicOr(guard, fin ? 2 : 1); cx = cy = cz = 0; }
-      } else {
-        cx = cell_coord(pt[u].x, g) - g.minc[0];
-        cy = cell_coord(pt[u].y, g) - g.minc[1];
-        cz = cell_coord(pt[u].z, g) - g.minc[2];
-      }
-      c[u] = cell_index(g, cx, cy, cz);
-      cell_of[i] = c[u];
+    const float* p = pt;
+    int cx, cy, cz;
+    if (guard) {
+      const float x = p[0], y = p[1], z = p[2];
+      const bool fin = fabsf(x) <= 1.0e8f && fabsf(y) <= 1.0e8f && fabsf(z) <= 1.0e8f;  // false for NaN too
+      cx = fin ? cell_coord(x, g) - g.minc[0] : 0;
+      cy = fin ? cell_coord(y, g) - g.minc[1] : 0;
+      cz = fin ? cell_coord(z, g) - g.minc[2] : 0;
+      const bool inside = cx >= 0 && cx < g.dim[0] && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
+      if (!fin || !inside) { atomicOr(guard, fin ? 2 : 1); cx = cy = cz = 0; }
+    } else {
+      cx = cell_coord(p[0], g) - g.minc[0];
+      cy = cell_coord(p[1], g) - g.minc[1];
+      cz = cell_coord(p[2], g) - g.minc[2];
     }
+    c = cell_index(g, cx, cy, cz);
+    cell_of[i] = c;
   }
-  // One atomicAdd per DISTINCT cell among the wave's 64 * kCountPts points, not per point: the points that fall into the same cell are
-  // found with kCountPts ballots per distinct cell (the first point still unassigned names the cell, every lane compares its points),
-  // the first of them adds the group's size and the returned count is the group's first (arrival-order) slot inside its cell -- the
-  // placement pass needs no second atomic.  Same-address atomics are what this pass costs (~12 ns each across the XCDs, serialised per
-  // address): a leaf-ordered map puts a wave into a handful of cells; a raw sweep arrives in FIRING order -- consecutive points are
-  // the 16 lasers of one azimuth, 16 different cells, and the next azimuth hits the same 16 again -- so grouping only CONSECUTIVE lanes
-  // (rounds 1-3) left it one atomic per point, hundreds of them on the crowded cells next to the sensor: the 30 k-point scan's pass took
-  // as long as the 1 M-point map's (21 us) and slowed every other kernel that was waiting for an atomic meanwhile (the solve's tickets).
-  unsigned long long todo[kCountPts];
-  int lead[kCountPts], rank[kCountPts], group[kCountPts];
-  bool any_todo = false;
-#pragma unroll
-  for (int u = 0; u < kCountPts; u++) {
-    todo[u] = __ballot(valid[u]);
-    any_todo = any_todo || todo[u] != 0;
-    lead[u] = 0; rank[u] = 0; group[u] = 0;
-  }
-  const unsigned long long below = (1ull << lane) - 1ull;
-  while (any_todo) {
-    // the first unassigned point in (u, lane) order = ascending point index
-    int u0 = 0;
-#pragma unroll
-    for (int u = kCountPts - 1; u >= 0; u--) u0 = todo[u] ? u : u0;
-    unsigned long long t0 = todo[0];
-    int cu = c[0];
-#pragma unroll
-    for (int u = 1; u < kCountPts; u++) { t0 = u == u0 ? todo[u] : t0; cu = u == u0 ? c[u] : cu; }
-    const int l0 = __ffsll((long long)t0) - 1;
-    const int cl = __shfl(cu, l0);
-    unsigned long long same[kCountPts];
-    int total = 0;
-#pragma unroll
-    for (int u = 0; u < kCountPts; u++) {
-      same[u] = __ballot(valid[u] && c[u] == cl);
-      total += __popcll(same[u]);
+  // One atomicAdd per DISTINCT cell of the wave, not per point: the lanes that fall into the same cell are found with one ballot per
+  // distinct cell (the first lane still unassigned names the cell, every lane compares), the first of them adds the group's size and the
+  // returned count is the group's first (arrival-order) slot inside its cell -- the placement pass needs no second atomic.
+  // Same-address atomics are what this pass costs (~12 ns each across the XCDs, serialised per address): a leaf-ordered map puts a wave
+  // into ~6 cells; a raw sweep arrives in FIRING order -- consecutive points are the 16 lasers of one azimuth, 16 different cells, and
+  // the next azimuth hits the same 16 again -- so grouping only CONSECUTIVE lanes (round 1-3) left it one atomic per point, hundreds of
+  // them on the crowded cells next to the sensor: the 30 k-point scan's pass took as long as the 1 M-point map's (21 us) and slowed
+  // every other kernel that was waiting for an atomic meanwhile (the solve's tickets).
+  unsigned long long todo = __ballot(valid);
+  int lead = lane, rank = 0, group = 1;
+  while (todo) {
+    const int l0 = __ffsll((long long)todo) - 1;
+    const int cl = __shfl(c, l0);
+    const unsigned long long same = __ballot(valid && c == cl);
+    if (valid && c == cl) {
+      lead = l0;
+      rank = __popcll(same & ((1ull << lane) - 1ull));
+      group = __popcll(same);
     }
-    int before = 0;
-    any_todo = false;
-#pragma unroll
-    for (int u = 0; u < kCountPts; u++) {
-      if (valid[u] && c[u] == cl) {
-        lead[u] = u0 * WAVE + l0;
-        rank[u] = before + __popcll(same[u] & below);
-        group[u] = total;
-      }
-      before += __popcll(same[u]);
-      todo[u] &= ~same[u];
-      any_todo = any_todo || todo[u] != 0;
-    }
+    todo &= ~same;
   }
-  int base[kCountPts];
-#pragma unroll
-  for (int u = 0; u < kCountPts; u++) {
-    base[u] = 0;
-    if (valid[u] && lead[u] == u * WAVE + lane) base[u] = atomicAdd(&cnt[c[u]], group[u]);
-  }
-#pragma unroll
-  for (int u = 0; u < kCountPts; u++) {
-    // the group's first slot sits with its leader (set lu, lane ll): fetched from whichever set holds it
-    const int lu = lead[u] >> 6, ll = lead[u] & (WAVE - 1);
-    int b = 0;
-#pragma unroll
-    for (int w = 0; w < kCountPts; w++) {
-      const int bw = __shfl(base[w], ll);
-      b = lu == w ? bw : b;
-    }
-    if (valid[u]) slot_of[i0 + u * 256] = b + rank[u];
-  }
+  int base = 0;
+  if (valid && lane == lead) base = atomicAdd(&cnt[c], group);
+  base = __shfl(base, lead);
+  if (valid) slot_of[i] = base + rank;
 }
 
 // three-kernel exclusive scan: 2048 items per block (256 threads x 8)
@@ -574,97 +515,61 @@ __global__ void __launch_bounds__(SCAN_T) k_cells_scan_write(int* __restrict__ c
 constexpr int kOrdIdxBits = 27, kOrdCntBits = 18;
 constexpr unsigned long long kOrdIdxMask = (1ull << kOrdIdxBits) - 1ull;
 constexpr int kOrdCntMax = (1 << kOrdCntBits) - 1;
-constexpr int kPlacePts = 4;  // points per thread (thread t of a workgroup: t, t + 256, ...): four chains of two round trips in flight, as in k_count
-__global__ void __launch_bounds__(256) k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of, const int* __restrict__ start,
-                                               unsigned long long* __restrict__ order_tmp, int prio) {
+__global__ void k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of, const int* __restrict__ start,
+                        unsigned long long* __restrict__ order_tmp, int prio) {
   wave_prio(prio);
-  const int i0 = blockIdx.x * (256 * kPlacePts) + threadIdx.x;
-  int c[kPlacePts], slot[kPlacePts], s0[kPlacePts], s1[kPlacePts];
-#pragma unroll
-  for (int u = 0; u < kPlacePts; u++) {
-    const int i = min(i0 + u * 256, n - 1);  // (clamped: the loads stay unconditional, the store below is guarded)
-    c[u] = cell_of[i];
-    slot[u] = slot_of[i];
-  }
-#pragma unroll
-  for (int u = 0; u < kPlacePts; u++) { s0[u] = start[c[u]]; s1[u] = start[c[u] + 1]; }
-#pragma unroll
-  for (int u = 0; u < kPlacePts; u++) {
-    const int i = i0 + u * 256;
-    if (i >= n) continue;
-    const int cnt = s1[u] - s0[u];
-    const bool big = cnt > kOrdCntMax;
-    order_tmp[s0[u] + slot[u]] = (unsigned long long)(unsigned)i | ((unsigned long long)(big ? 0 : slot[u]) << kOrdIdxBits) |
-                                 ((unsigned long long)(big ? 0 : cnt) << (kOrdIdxBits + kOrdCntBits));  // unordered inside the cell; k_rank_gather makes the order deterministic
-  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell_of[i], slot = slot_of[i];
+  const int s0 = start[c], cnt = start[c + 1] - s0;
+  const bool big = cnt > kOrdCntMax;
+  order_tmp[s0 + slot] = (unsigned long long)(unsigned)i | ((unsigned long long)(big ? 0 : slot) << kOrdIdxBits) |
+                         ((unsigned long long)(big ? 0 : cnt) << (kOrdIdxBits + kOrdCntBits));  // unordered inside the cell; k_rank_gather makes the order deterministic
 }
 
 // deterministic placement: a point's final slot = cell start + number of same-cell points with a smaller index.
 // Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate; P holds n + 4 entries.
-constexpr int kRankPts = 2;     // sorted slots per thread (thread t of a workgroup: t, t + 256): two chains of round trips in flight
-constexpr int kRankFirst = 16;  // members of a cell compared in the first, unconditional batch (a leaf-filtered map has ~11 per cell)
-__global__ void __launch_bounds__(256) k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
-                                                     const int* __restrict__ start, const unsigned long long* __restrict__ order_tmp,
-                                                     float4* __restrict__ P, int* zero_me, int prio) {
+__global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
+                              const int* __restrict__ start, const unsigned long long* __restrict__ order_tmp, float4* __restrict__ P, int* zero_me,
+                              int prio) {
   wave_prio(prio);
-  const int sb = blockIdx.x * (256 * kRankPts) + threadIdx.x;
-  if (sb == 0 && zero_me) *zero_me = 0;  // the kNN launch that follows counts its deferred queries here
-  if (sb < 4) P[n + sb] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __int_as_float(-1));  // sentinels: infinitely far from every query (k_knn_sp's last quad)
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0 && zero_me) *zero_me = 0;  // the kNN launch that follows counts its deferred queries here
+  if (s < 4) P[n + s] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __int_as_float(-1));  // sentinels: infinitely far from every query (k_knn_sp's last quad)
+  if (s >= n) return;
+  const unsigned long long rec = order_tmp[s];
+  const int i = (int)(rec & kOrdIdxMask);
+  const int cnt = (int)(rec >> (kOrdIdxBits + kOrdCntBits)) & kOrdCntMax;
+  int s0, s1;
+  if (cnt > 0) {
+    s0 = s - ((int)(rec >> kOrdIdxBits) & kOrdCntMax);
+    s1 = s0 + cnt;
+  } else {  // a cell too crowded for the record's fields
+    const int c = cell_of[i];
+    s0 = start[c];
+    s1 = start[c + 1];
+  }
+  const float* p = in + (size_t)i * stride_f;
+  const float px = p[0], py = p[1], pz = p[2];  // (issued beside the members' loads: nothing below depends on them until the store)
   const unsigned* lo = reinterpret_cast<const unsigned*>(order_tmp);  // the records' low words: index bits 0..26, position bits above
   constexpr unsigned kLoMask = (unsigned)kOrdIdxMask;
-  unsigned long long rec[kRankPts];
+  int rank = 0;
+  int t = s0;
+  for (; t + 8 <= s1; t += 8) {  // eight independent loads in flight: a crowded cell (hundreds of members) is a long serial loop otherwise
+    unsigned o[8];
 #pragma unroll
-  for (int u = 0; u < kRankPts; u++) rec[u] = order_tmp[min(sb + u * 256, n - 1)];
-  int i[kRankPts], s0[kRankPts], s1[kRankPts], rank[kRankPts];
-  float px[kRankPts], py[kRankPts], pz[kRankPts];
+    for (int u = 0; u < 8; u++) o[u] = lo[2 * (size_t)(t + u)];
 #pragma unroll
-  for (int u = 0; u < kRankPts; u++) {
-    const int s = min(sb + u * 256, n - 1);
-    i[u] = (int)(rec[u] & kOrdIdxMask);
-    const int cnt = (int)(rec[u] >> (kOrdIdxBits + kOrdCntBits)) & kOrdCntMax;
-    if (cnt > 0) {
-      s0[u] = s - ((int)(rec[u] >> kOrdIdxBits) & kOrdCntMax);
-      s1[u] = s0[u] + cnt;
-    } else {  // a cell too crowded for the record's fields
-      const int c = cell_of[i[u]];
-      s0[u] = start[c];
-      s1[u] = start[c + 1];
-    }
-    const float* p = in + (size_t)i[u] * stride_f;
-    px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];  // (issued beside the members' loads: nothing depends on them until the store)
+    for (int u = 0; u < 8; u++) rank += ((int)(o[u] & kLoMask) < i);
   }
-  unsigned o[kRankPts][kRankFirst];
+  if (t < s1) {  // 1..7 left: clamped loads (the last member counted again would be wrong: masked by position)
+    unsigned o[7];
 #pragma unroll
-  for (int u = 0; u < kRankPts; u++)
+    for (int u = 0; u < 7; u++) o[u] = lo[2 * (size_t)min(t + u, s1 - 1)];
 #pragma unroll
-    for (int k = 0; k < kRankFirst; k++) o[u][k] = lo[2 * (size_t)min(s0[u] + k, s1[u] - 1)];  // clamped: unconditional loads, all in flight together
-#pragma unroll
-  for (int u = 0; u < kRankPts; u++) {
-    rank[u] = 0;
-#pragma unroll
-    for (int k = 0; k < kRankFirst; k++) rank[u] += (s0[u] + k < s1[u] && (int)(o[u][k] & kLoMask) < i[u]);
+    for (int u = 0; u < 7; u++) rank += (t + u < s1 && (int)(o[u] & kLoMask) < i);
   }
-#pragma unroll
-  for (int u = 0; u < kRankPts; u++) {
-    int t = s0[u] + kRankFirst;
-    for (; t + 8 <= s1[u]; t += 8) {  // a crowded cell (a raw sweep next to the sensor: hundreds of members): eight independent loads in flight
-      unsigned m[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) m[k] = lo[2 * (size_t)(t + k)];
-#pragma unroll
-      for (int k = 0; k < 8; k++) rank[u] += ((int)(m[k] & kLoMask) < i[u]);
-    }
-    if (t < s1[u]) {  // 1..7 left
-      unsigned m[7];
-#pragma unroll
-      for (int k = 0; k < 7; k++) m[k] = lo[2 * (size_t)min(t + k, s1[u] - 1)];
-#pragma unroll
-      for (int k = 0; k < 7; k++) rank[u] += (t + k < s1[u] && (int)(m[k] & kLoMask) < i[u]);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < kRankPts; u++)
-    if (sb + u * 256 < n) P[s0[u] + rank[u]] = make_float4(px[u], py[u], pz[u], __int_as_float(i[u]));
+  P[s0 + rank] = make_float4(px, py, pz, __int_as_float(i));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2736,15 +2641,6 @@ __device__ __forceinline__ void nn_search(float px, float py, float pz, const fl
   auto scan = [&](int s0, int s1) {
     int s = s0;
     unsigned off = (unsigned)s0 << 4;
-    if (s1 - s0 > 8 && s1 - s0 <= 16) {  // 9..16 points (a leaf-filtered map's cell holds ~11): ONE batch of sixteen clamped loads, not two dependent ones
-      const int last = s1 - 1;
-      float4 cc[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) cc[u] = point_at(TP, (unsigned)min(s0 + u, last) << 4);
-#pragma unroll
-      for (int u = 0; u < 16; u++) take(cc[u], min(s0 + u, last));
-      return;
-    }
     for (; s + 8 <= s1; s += 8, off += 128) {  // eight loads in flight: this search is a chain of memory round trips
       float4 cc[8];
 #pragma unroll
@@ -2764,17 +2660,6 @@ __device__ __forceinline__ void nn_search(float px, float py, float pz, const fl
   if (inside) {
     const int own = cell_index(g, c[0], c[1], c[2]);
     const int o0 = tstart[own], o1 = tstart[own + 1];
-    // the nine rows of the 3x3x3 block, each in its three x-extents' end points (cx - 1, cx, cx + 1, cx + 2), fetched in the SAME round trip
-    // as the own cell's range: whichever of them the ball around the own cell's nearest point reaches are scanned without asking again
-    int rs[9][4];
-    const int xm = max(c[0] - 1, 0), xp = min(c[0] + 1, g.dim[0] - 1);
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-      const int dy = r % 3 - 1, dz = r / 3 - 1;
-      const int y = min(max(c[1] + dy, 0), g.dim[1] - 1), z = min(max(c[2] + dz, 0), g.dim[2] - 1);   // (clamped: a row outside the grid is not used below)
-      const int base = cell_index(g, 0, y, z);
-      rs[r][0] = tstart[base + xm]; rs[r][1] = tstart[base + c[0]]; rs[r][2] = tstart[base + c[0] + 1]; rs[r][3] = tstart[base + xp + 1];
-    }
     scan(o0, o1);
     if (best < INFINITY) {
       const double bound = cube_bound(g, c, q, 0);
@@ -2800,9 +2685,10 @@ __device__ __forceinline__ void nn_search(float px, float py, float pz, const fl
           const double gy = dy < 0 ? wl[1] : (dy > 0 ? wh[1] : 0.0), gz = dz < 0 ? wl[2] : (dz > 0 ? wh[2] : 0.0);
           const double m = gy * gy + gz * gz;
           const bool need = y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && m <= rad2;
-          const bool left = c[0] > 0 && wl[0] * wl[0] + m <= rad2, right = c[0] < g.dim[0] - 1 && wh[0] * wh[0] + m <= rad2;
-          ra[r] = need ? (left ? rs[r][0] : rs[r][1]) : 0;     // start of cell cx - 1 or cx of that row
-          rb[r] = need ? (right ? rs[r][3] : rs[r][2]) : 0;    // end of cell cx + 1 or cx
+          const int xa = (c[0] > 0 && wl[0] * wl[0] + m <= rad2) ? c[0] - 1 : c[0];
+          const int xb = (c[0] < g.dim[0] - 1 && wh[0] * wh[0] + m <= rad2) ? c[0] + 1 : c[0];
+          ra[r] = need ? tstart[cell_index(g, xa, y, z)] : 0;
+          rb[r] = need ? tstart[cell_index(g, xb, y, z) + 1] : 0;
         }
 #pragma unroll
         for (int r = 0; r < 9; r++) {
@@ -3376,8 +3262,8 @@ void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* 
 }
 void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi, int* guard,
                  const Reframe* rf) {
-  if (rf) hipLaunchKernelGGL(k_count<true>, dim3(nblk(n, 256 * kCountPts)), dim3(256), 0, s, in, 4, n, g, cell_of, slot_of, cnt, guard, hi, *rf);
-  else hipLaunchKernelGGL(k_count<false>, dim3(nblk(n, 256 * kCountPts)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi, Reframe{});
+  if (rf) hipLaunchKernelGGL(k_count<true>, dim3(nblk(n, 256)), dim3(256), 0, s, in, 4, n, g, cell_of, slot_of, cnt, guard, hi, *rf);
+  else hipLaunchKernelGGL(k_count<false>, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi, Reframe{});
 }
 void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi, float* sum_sq) {
   const int nb = nblk(n, SCAN_B);
@@ -3391,7 +3277,7 @@ void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, in
   }
 }
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi) {
-  if (n > 0) hipLaunchKernelGGL(k_place, dim3(nblk(n, 256 * kPlacePts)), dim3(256), 0, s, n, cell_of, slot_of, start, order_tmp, hi);
+  hipLaunchKernelGGL(k_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, slot_of, start, order_tmp, hi);
 }
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums, int hi) {
   const int nb = nblk(n, SCAN_B);
@@ -3403,7 +3289,7 @@ void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_su
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
                  const unsigned long long* order_tmp, float4* P, int* zero_me, int hi) {
-  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256 * kRankPts)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi);
+  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi);
 }
 size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 
