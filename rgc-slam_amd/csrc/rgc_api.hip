@@ -27,6 +27,9 @@
 namespace {
 
 constexpr int kMaxK = 32;
+// Events that only order streams of ONE device against each other: no timing, and a device-scope release when recorded (the default is a
+// system-scope one -- the L2s written back so that the HOST may read what came before; nobody's host does behind these).
+constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 // Build-time switches (RGC_EXTRA_FLAGS=-D...): alternative routes to the SAME results, kept for A/B measurements.  A caller's
 // process reads only RGC_LM_IMPL, RGC_SPEC_GRID and RGC_TRACE_ALLOC from the environment (rgc_create).
 #ifndef RGC_LM_POST
@@ -331,6 +334,15 @@ void drop_hints(rgc_ctx* c) {
   for (auto& e : c->box_hint) e.p = nullptr;
 }
 
+// Has the map preparation enqueued last on the main stream finished?  Asked of the event recorded behind it -- NOT of the stream:
+// hipStreamQuery on a stream whose last command is a kernel puts a marker packet with a completion signal behind it (a system-scope
+// release in front of whatever is enqueued next: ~10 us between the map's last kernel and the solve's first step, every frame).
+bool map_prep_finished(rgc_ctx* c) {
+  const hipError_t q = hipEventQuery(c->tgt_prepared);
+  if (q != hipSuccess) (void)hipGetLastError();  // ("not ready" is an answer, not an error to be found by a later check)
+  return q == hipSuccess;
+}
+
 // C1-C3: grid + exact-kNN covariances (+ voxel map for the target), all enqueued on the stream.
 // The first cloud of a context costs one host<->device round trip -- the 6-int bounding box the dense grid is sized from; later
 // clouds re-use the previous (widened) grid speculatively and need none (see `spec` below).
@@ -350,7 +362,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   // enqueued on the main stream (rgc_upload, the front-end, a caller's own kernels on rgc_stream()): stream2 waits for a mark
   // recorded on the main stream BEFORE this frame's map preparation was enqueued (waiting for the map's kNN launch would serialise
   // the two) -- i.e. at rgc_set_target*, or here when no map preparation is pending.  See rgc_set_source_device in rgc_hip.h.
-  if (!is_target && c->main_has_target_prep && hipStreamQuery(c->stream) == hipSuccess) c->main_has_target_prep = false;  // it has drained
+  if (!is_target && c->main_has_target_prep && map_prep_finished(c)) c->main_has_target_prep = false;  // it has drained
   if (is_target || !c->main_has_target_prep || c->main_late_producer) {
     HIPCHK(c, hipEventRecord(c->main_mark, c->stream));
     c->mark_valid = true;
@@ -1118,10 +1130,10 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     ok = ok && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) == hipSuccess;
   }
-  ok = ok && hipEventCreateWithFlags(&c->lm_mid, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->main_mark, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->tgt_ready, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->lm_mid, kDevEvent) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->src_ready, kDevEvent) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->main_mark, kDevEvent) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->tgt_ready, kDevEvent) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_small, 48 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&c->d_out, 64 * sizeof(double)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_small, 48 * sizeof(int), hipHostMallocDefault) == hipSuccess;
@@ -1133,9 +1145,9 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
     if (hipHostGetDevicePointer((void**)&c->d_post, c->h_post, 0) != hipSuccess) c->d_post = nullptr;  // (no fast path then)
   }
   c->uid = g_next_uid.fetch_add(1);
-  ok = ok && hipEventCreateWithFlags(&c->src_read_done, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->lm_tail, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->tgt_prepared, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->src_read_done, kDevEvent) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->lm_tail, kDevEvent) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->tgt_prepared, kDevEvent) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->vg_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_vg, 4 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
@@ -1368,7 +1380,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   // frame's map meanwhile (15 k waves that fill every CU), the dispatcher places the solve's ~100 workgroups as soon as slots free up
   // instead of behind that launch.
   int rc;
-  if (c->solve_behind_map && c->main_has_target_prep && hipStreamQuery(c->stream) != hipSuccess) {
+  if (c->solve_behind_map && c->main_has_target_prep && !map_prep_finished(c)) {
     // the map is still being prepared (a dependent sequence: it could only start when the previous pose was known): the solve goes
     // directly behind it on the main stream -- a dependency that resolves across streams costs ~10 us on this runtime, and the scan's
     // preparation, which the solve also waits for, has long finished
@@ -1444,9 +1456,10 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
       volatile int* gen = &c->h_post->gen;
       for (;;) {
         if (*gen == c->lm_seq) { posted = true; break; }
-        const hipError_t q = hipStreamQuery(c->lm_tail_stream);  // (the batch's last launches and its copy of the state: the solve's stream, or the other one when spare launches went there)
+        const hipError_t q = hipEventQuery(c->lm_tail);  // (recorded behind the batch's last launch and its copy of the state, on whichever stream they went to)
         if (q == hipSuccess) { posted = *gen == c->lm_seq; break; }
-        if (q != hipErrorNotReady) return fail(c, RGC_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        if (q != hipErrorNotReady) return fail(c, RGC_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        (void)hipGetLastError();
       }
       if (posted) {
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -1856,7 +1869,7 @@ int rgc_deskew(rgc_ctx* c, float* xyzi, int n, int stride_bytes, const double q[
   const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
   if (!(n2 > 0)) return fail(c, RGC_ERR_INVALID, "zero quaternion");
   rgck::Quat qi{-q[0] / n2, -q[1] / n2, -q[2] / n2, q[3] / n2};
-  if (c->main_has_target_prep && hipStreamQuery(c->stream) == hipSuccess) c->main_has_target_prep = false;  // it has drained
+  if (c->main_has_target_prep && map_prep_finished(c)) c->main_has_target_prep = false;  // it has drained
   rgck::deskew(c->stream, (float*)d_in, stride_bytes / 4, n, qi, t);
   if (!on_device) HIPCHK(c, hipMemcpyAsync(xyzi, d_in, (size_t)n * stride_bytes, hipMemcpyDeviceToHost, c->stream));
   // device memory: in place and stream-ordered, whatever reads the sweep next on the main stream is enqueued behind it -- unless a map

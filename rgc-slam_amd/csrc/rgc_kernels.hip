@@ -1919,31 +1919,51 @@ k_voxel_build_coop(const float4* __restrict__ P, double* __restrict__ nx, double
 // computed meanwhile from those points' stale normals are recomputed here, behind it -- the same sums in the same order (ascending
 // sorted position = the cloud's order), so the table is bit for bit what the serial chain gave.  Several deferred queries of one
 // voxel write the same values.
+// One WAVE per deferred query's voxel: the lanes fetch the cell's points and normals in ONE round trip (a lane per point, 64 at a time)
+// and lane 0 adds the nine terms in ascending position from LDS.  (A lane per voxel walking its ~11 points was eleven dependent round
+// trips: 10 us of pure latency for ~100 voxels, on every frame's critical path.)
 __global__ void __launch_bounds__(WAVE)
 k_voxel_patch(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
               const int* __restrict__ start, Grid g, const int* __restrict__ deferred, const int* __restrict__ cell_voxel, double* __restrict__ vox) {
+  __shared__ double term[9][WAVE];
   const int cnt = deferred[0];
   const int* idx = deferred + 16;
-  for (int e = blockIdx.x * WAVE + threadIdx.x; e < cnt; e += gridDim.x * WAVE) {
+  const int lane = (int)threadIdx.x;
+  for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
     const int enc = idx[e];
     const int i = enc < 0 ? ~enc : enc;
     const float4 cp = P[i];
     const int c = cell_index(g, cell_coord(cp.x, g) - g.minc[0], cell_coord(cp.y, g) - g.minc[1], cell_coord(cp.z, g) - g.minc[2]);
     const int s0 = start[c], s1 = start[c + 1];
     double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
-    for (int u = s0; u < s1; u++) {
-      const float4 p0 = P[u];
-      const double a = nx[u], b = ny[u], d = nz[u];
-      m[0] += (double)p0.x; m[1] += (double)p0.y; m[2] += (double)p0.z;
-      C[0] += 1.0 - 0.999 * a * a; C[1] += -0.999 * a * b; C[2] += -0.999 * a * d;
-      C[3] += 1.0 - 0.999 * b * b; C[4] += -0.999 * b * d; C[5] += 1.0 - 0.999 * d * d;
+    for (int b0 = s0; b0 < s1; b0 += WAVE) {
+      const int u = b0 + lane;
+      if (u < s1) {
+        const float4 p0 = P[u];
+        const double a = nx[u], b = ny[u], d = nz[u];
+        term[0][lane] = (double)p0.x; term[1][lane] = (double)p0.y; term[2][lane] = (double)p0.z;
+        term[3][lane] = 1.0 - 0.999 * a * a; term[4][lane] = -0.999 * a * b; term[5][lane] = -0.999 * a * d;
+        term[6][lane] = 1.0 - 0.999 * b * b; term[7][lane] = -0.999 * b * d; term[8][lane] = 1.0 - 0.999 * d * d;
+      }
+      wave_lds_fence();
+      if (lane == 0) {
+        const int nb = min(WAVE, s1 - b0);
+        for (int t = 0; t < nb; t++) {  // ascending sorted position = the cloud's order, like k_voxel_build
+          m[0] += term[0][t]; m[1] += term[1][t]; m[2] += term[2][t];
+          C[0] += term[3][t]; C[1] += term[4][t]; C[2] += term[5][t];
+          C[3] += term[6][t]; C[4] += term[7][t]; C[5] += term[8][t];
+        }
+      }
+      wave_lds_fence();
     }
-    const double num = (double)(s1 - s0);
-    double* rec = vox + (size_t)cell_voxel[c] * kVoxRec;
-    rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
+    if (lane == 0) {
+      const double num = (double)(s1 - s0);
+      double* rec = vox + (size_t)cell_voxel[c] * kVoxRec;
+      rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
 #pragma unroll
-    for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
-    rec[9] = num;
+      for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
+      rec[9] = num;
+    }
   }
 }
 
@@ -3360,7 +3380,7 @@ void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, do
 }
 void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g, const void* deferred,
                  const int* cell_voxel, double* vox, int lanes) {
-  const int nb = lanes < 64 ? 1 : (lanes > 65536 ? 1024 : nblk(lanes, WAVE));
+  const int nb = lanes < 64 ? 64 : (lanes > 4096 ? 4096 : lanes);  // one-wave workgroups, one deferred entry each (grid-stride beyond)
   hipLaunchKernelGGL(k_voxel_patch, dim3(nb), dim3(WAVE), 0, s, P, nx, ny, nz, start, g, (const int*)deferred, cell_voxel, vox);
 }
 void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
