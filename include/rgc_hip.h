@@ -152,6 +152,17 @@ RGC_API int rgc_get_aligned(rgc_ctx* ctx, const float T[16], float* out_xyz, int
  * stream, no synchronisation, no copy -- for callers that consume the aligned cloud on the GPU (the odometer's sub-map insert) */
 RGC_API int rgc_get_aligned_device(rgc_ctx* ctx, const float T[16], float* d_out_xyz, int stride_bytes);
 
+/* Lazy target.  Only the voxels the solve LOOKS UP enter its cost (update_correspondences, impl/fast_vgicp_impl.hpp:73-116: one voxel per
+ * source point with DIRECT1), and a voxel's covariance needs the 20-NN covariances of that voxel's points only -- yet the reference builds
+ * every covariance of the map every frame (setInputTarget, src/RGC_odometer.cpp:1007), and so does this library by default.  With
+ * margin_cells > 0 a target set afterwards gets its grid at rgc_set_target* and the rest at rgc_align / rgc_align_begin, for the cells
+ * within margin_cells voxels (Chebyshev) of a voxel the scan falls into at the guess: 8 % of the c-main map at a margin of 2.  Every
+ * look-up of the solve is checked; one that lands on an occupied voxel outside the built part (the pose moved more than the margin
+ * covers) makes rgc_align_end complete the map and solve again, and any other consumer of the target (getters, the fine seam,
+ * rgc_share_target, a second solve on the same target) completes it first: results are those of the full build, bit for bit, always.
+ * 0 (default): off.  rgc_stats::lazy_misses counts the solves that had to be repeated. */
+RGC_API int rgc_set_target_lazy(rgc_ctx* ctx, int margin_cells);
+
 /* Scheduling hint for two contexts taking turns on a dependent sequence -- every frame's target is the sub-map re-framed by the previous
  * pose (src/RGC_odometer.cpp:1248-1256), so only the NEXT scan can be prepared ahead: the next rgc_set_source* on ctx starts on the
  * GPU only when the target preparation other has enqueued last (rgc_set_target*) has finished, i.e. under other's solve instead of
@@ -332,6 +343,7 @@ typedef struct rgc_stats {
   long long target_cells, source_cells;
   int deferred_target, deferred_source; /* queries handled by the cooperative kNN kernel */
   double source_crowding;               /* mean number of points in a scan point's own kNN-grid cell (sum count^2 / n) */
+  int lazy_misses;                      /* lazy target: solves repeated on the completed map since the context was created */
 } rgc_stats;
 RGC_API int rgc_get_stats(rgc_ctx* ctx, rgc_stats* out);
 

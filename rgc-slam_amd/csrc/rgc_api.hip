@@ -87,6 +87,12 @@ struct Cloud {
   // target only
   DevBuf cell_voxel, vox, vox_cell;
   int nvox = -1;
+  // lazy target (rgc_set_target_lazy): 0 = covariances and voxel map complete; 1 = the grid is built, nothing else (the solve's guess
+  // decides which part is needed); 2 = built for the cells stamped need_stamp in `need` only
+  int lazy = 0;
+  DevBuf need;              // one 16-bit stamp per grid cell (k_footprint)
+  int need_stamp = 0;
+  const void* need_seen = nullptr;  // the allocation the stamps refer to
 };
 
 struct ProfRegion {
@@ -141,6 +147,9 @@ struct rgc_ctx {
   rgck::LmState* h_lm = nullptr;  // pinned mirror (the stream-ordered copy behind every batch of LM launches)
   rgck::LmState* h_post = nullptr; // mapped host memory the DEVICE writes a finished solve's state into, then the solve's number into its `gen`
   rgck::LmState* d_post = nullptr; // ... its device address
+  int lazy_margin = 0;             // rgc_set_target_lazy: > 0 = the target's covariances / voxels are built only where the solve can look (cells of margin)
+  hipEvent_t src_in_ready = nullptr;  // recorded on stream2 behind a HOST scan's upload: the lazy target's footprint pass (main stream) reads the scan's input
+  bool src_in_pending = false;
   int lm_seq = 0;                  // number of the pending solve (1, 2, ...)
   rgck::LmState lm_res{};          // the finished solve's state as rgc_align_end took it (from h_post or h_lm): nothing writes it asynchronously
   hipEvent_t lm_mid = nullptr;     // recorded on the solve's stream behind its expected launches: the spare ones, on the context's other stream, wait for it
@@ -261,7 +270,7 @@ void release(DevBuf& b) {
 
 void release_cloud(Cloud& cl) {
   for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.slot_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs,
-                    &cl.cell_voxel, &cl.vox, &cl.vox_cell})
+                    &cl.cell_voxel, &cl.vox, &cl.vox_cell, &cl.need})
     release(*b);
 }
 
@@ -341,6 +350,12 @@ bool map_prep_finished(rgc_ctx* c) {
   const hipError_t q = hipEventQuery(c->tgt_prepared);
   if (q != hipSuccess) (void)hipGetLastError();  // ("not ready" is an answer, not an error to be found by a later check)
   return q == hipSuccess;
+}
+
+int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target, const unsigned short* need, int stamp);
+// a sparse map (points per cell of its grid below map_wide_density) takes the wider block of the bulk kNN launch, see k_knn_sp_wide
+int map_wide_r_of(const rgc_ctx* c, const Cloud& cl) {
+  return (c->map_wide_r > 0 && (double)cl.n < c->map_wide_density * (double)cl.grid.ncell) ? c->map_wide_r : 0;
 }
 
 // C1-C3: grid + exact-kNN covariances (+ voxel map for the target), all enqueued on the stream.
@@ -513,9 +528,45 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const unsigned long long*)cl.order_tmp.p,
                       (float4*)cl.P.p, (int*)cl.segs.p, hi);
   }
+  cl.lazy = 0;
+  if (is_target && &cl == &c->tgt && c->lazy_margin > 0 && !c->lm_host && map_wide_r_of(c, cl) == 0) {
+    // lazy target: which part of the map needs covariances and voxels is decided by the solve's guess (rgc_align_begin: lazy_build);
+    // any other consumer completes the map first (validate_clouds)
+    int rc;
+    const size_t vmax = (size_t)(n < cl.grid.ncell ? n : cl.grid.ncell);
+    if ((rc = ensure(c, cl.vox, sizeof(double) * rgck::kVoxRec * vmax))) return rc;
+    if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
+    cl.lazy = 1;
+    cl.nvox = -1;
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->tgt_prepared, s));
+    cl.ready = true;
+    return RGC_OK;
+  }
+  {
+    int rc = cloud_covariances(c, cl, is_target, nullptr, 0);
+    if (rc) return rc;
+  }
+  HIPCHK(c, hipGetLastError());
+  if (!is_target) {
+    HIPCHK(c, hipEventRecord(c->src_ready, s));
+    c->src_pending = true;
+  } else {
+    HIPCHK(c, hipEventRecord(c->tgt_prepared, s));
+  }
+  cl.ready = true;
+  return RGC_OK;
+}
+
+// C2 / C3 of a cloud whose grid is built: exact-kNN covariances (+ the Gaussian voxel map for the target), enqueued on the cloud's stream.
+// need / stamp (target only, lazy): only the queries and voxels of the cells stamped `stamp` are built (rgck::footprint).
+int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target, const unsigned short* need, int stamp) {
+  const int n = cl.n, k = c->prm.k_correspondences;
+  hipStream_t s = is_target ? c->stream : c->stream2;
+  int* dsm = c->d_small + (is_target ? 0 : 16);
   {
     // a sparse map (points per cell of its grid below map_wide_density): the wider block, see k_knn_sp_wide
-    const int wide_r = (is_target && c->map_wide_r > 0 && (double)n < c->map_wide_density * (double)cl.grid.ncell) ? c->map_wide_r : 0;
+    const int wide_r = is_target ? map_wide_r_of(c, cl) : 0;
     const int kind = is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC;
     // The dense map's launch (the dominant kernel) is timed by ITS OWN start / stop times (hipExtLaunchKernelGGL fills the two events):
     // two hipEventRecord packets around it cost ~3 % of a frame of a dependent sequence on two contexts (bench.py's timed region).
@@ -533,12 +584,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     }
     if (self_timed) {
       rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
-                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, own.a, own.b);
+                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, own.a, own.b, need, stamp);
       c->prof_open.push_back(own);
     } else {
       ProfScope ps(c, kind, n, s);
       rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
-                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r);
+                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, nullptr, nullptr, need, stamp);
     }
   }
   // The map's deferred queries (~100 of a million, one wave each: 20 us of latency) are resolved in the SAME launch as the voxel map's
@@ -561,20 +612,60 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     ProfScope ps(c, RGC_K_VOXEL, n);
     {
       rgck::voxel_build_coop(s, (const float4*)cl.P.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p, (const int*)cl.start.p, cl.grid, n,
-                             (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves);
+                             (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves,
+                             need, stamp);
       rgck::voxel_patch(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
                         cl.grid, cl.segs.p, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 64 : n);
     }
     cl.nvox = -1;  // fetched lazily
   }
-  HIPCHK(c, hipGetLastError());
-  if (!is_target) {
-    HIPCHK(c, hipEventRecord(c->src_ready, s));
-    c->src_pending = true;
-  } else {
-    HIPCHK(c, hipEventRecord(c->tgt_prepared, s));
+  return RGC_OK;
+}
+
+// Lazy target, at rgc_align_begin: the cells within lazy_margin cells of where the scan falls at the guess are stamped (the look-up's own
+// arithmetic), and covariances + voxels are built for those only -- at c-main 8 % of the map's points at a margin of two cells.  The
+// solve checks every look-up (linearize_point): one that lands on an occupied voxel outside the stamped set makes rgc_align_end
+// complete the map and solve again, so the result is the full build's bit for bit either way.
+rgck::Pose pose_from(const double T[16]);
+int lazy_build(rgc_ctx* c, const float guess[16]) {
+  Cloud& cl = c->tgt;
+  hipStream_t s = c->stream;
+  int rc;
+  const size_t cells = (size_t)cl.grid.ncell;
+  if ((rc = ensure(c, cl.need, sizeof(unsigned short) * cells + 256))) return rc;
+  cl.need_stamp++;
+  if (cl.need.p != cl.need_seen || cl.need_stamp > 65535) {  // a new allocation, or the 16-bit stamps wrapped: start over from a clean array
+    HIPCHK(c, hipMemsetAsync(cl.need.p, 0, cl.need.cap, s));
+    cl.need_seen = cl.need.p;
+    cl.need_stamp = 1;
   }
-  cl.ready = true;
+  if (c->src_in_pending) {  // the scan came from the host: its upload ran on stream2
+    HIPCHK(c, hipStreamWaitEvent(s, c->src_in_ready, 0));
+    c->src_in_pending = false;
+  }
+  double T[16];
+  for (int i = 0; i < 16; i++) T[i] = (double)guess[i];
+  rgck::footprint(s, c->src.in, c->src.stride_f, c->src.n, pose_from(T), cl.grid, (unsigned short*)cl.need.p, cl.need_stamp, c->lazy_margin);
+  if ((rc = cloud_covariances(c, cl, true, (const unsigned short*)cl.need.p, cl.need_stamp))) return rc;
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->tgt_prepared, s));  // (the map's preparation ends HERE now: what the solve goes behind, what another context's held scan waits for)
+  cl.lazy = 2;
+  return RGC_OK;
+}
+
+// every consumer of the target other than the chained solve: the whole map, as without the lazy mode
+int complete_target(rgc_ctx* c) {
+  Cloud& cl = c->tgt;
+  if (!cl.ready || cl.lazy == 0 || c->tgt_owner) return RGC_OK;
+  HIPCHK(c, hipMemsetAsync(cl.segs.p, 0, sizeof(int), c->stream));  // the deferred-query counter of the bulk launch
+  int rc = cloud_covariances(c, cl, true, nullptr, 0);
+  if (rc) return rc;
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->tgt_prepared, c->stream));
+  cl.lazy = 0;
+  c->corr_valid = false;
+  c->deferred_known = false;
+  c->main_has_target_prep = true;
   return RGC_OK;
 }
 
@@ -607,6 +698,10 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
     }
     // pageable host memory: hipMemcpyAsync stages and returns once the source has been consumed
     HIPCHK(c, hipMemcpyAsync(cl.in_copy.p, xyz, bytes - (stride_bytes - 12), hipMemcpyHostToDevice, is_target ? c->stream : c->stream2));
+    if (!is_target && c->lazy_margin > 0) {  // (the lazy target's footprint pass reads the scan's input on the main stream)
+      HIPCHK(c, hipEventRecord(c->src_in_ready, c->stream2));
+      c->src_in_pending = true;
+    }
     cl.in = (const float*)cl.in_copy.p;
   }
   cl.stride_f = stride_f;
@@ -697,9 +792,10 @@ int check_target_owner(rgc_ctx* c) {
 }
 
 // for every consumer except rgc_align (which gets the guards with its state read-back): one synchronisation, once per cloud
-int validate_clouds(rgc_ctx* c) {
+int validate_clouds(rgc_ctx* c, bool whole_target = true) {
   if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   { int rc = check_target_owner(c); if (rc) return rc; }
+  if (whole_target) { int rc = complete_target(c); if (rc) return rc; }  // (lazy target: whoever comes this way reads covariances or voxels the solve may not have needed)
   if (!((c->tgt.ready && c->tgt.spec_used) || (c->src.ready && c->src.spec_used))) return RGC_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipMemcpyAsync(c->h_small + 6, c->d_small + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1131,6 +1227,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
     ok = ok && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) == hipSuccess;
   }
   ok = ok && hipEventCreateWithFlags(&c->lm_mid, kDevEvent) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->src_in_ready, kDevEvent) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->src_ready, kDevEvent) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->main_mark, kDevEvent) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->tgt_ready, kDevEvent) == hipSuccess;
@@ -1196,6 +1293,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->src_read_done) (void)hipEventDestroy(c->src_read_done);
   if (c->lm_tail) (void)hipEventDestroy(c->lm_tail);
   if (c->lm_mid) (void)hipEventDestroy(c->lm_mid);
+  if (c->src_in_ready) (void)hipEventDestroy(c->src_in_ready);
   if (c->tgt_prepared) (void)hipEventDestroy(c->tgt_prepared);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -1257,7 +1355,7 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
                         &o.cell_voxel, &o.vox, &o.vox_cell};
   for (size_t k = 0; k < sizeof(db) / sizeof(db[0]); k++) { db[k]->p = ob[k]->p; db[k]->cap = ob[k]->cap; db[k]->borrowed = ob[k]->p != nullptr; }
   d.in = o.in; d.stride_f = o.stride_f; d.n = o.n; d.grid = o.grid; d.grid = o.grid; d.nvox = o.nvox; d.deferred_seen = o.deferred_seen;
-  d.spec_ok = false; d.spec_used = false; d.cnt_clean = 0; d.cnt_seen = nullptr;
+  d.spec_ok = false; d.spec_used = false; d.cnt_clean = 0; d.cnt_seen = nullptr; d.lazy = 0;
   d.ready = true;
   const int small[2] = {0, o.nvox};  // this context's copy of the target's guard (clear) and voxel count, which the solve reads
   HIPCHK(c, hipMemcpy(c->d_small + 6, small, sizeof(small), hipMemcpyHostToDevice));
@@ -1276,6 +1374,14 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
 // the next scan can be prepared ahead -- it depends on no pose -- but enqueued beside the current frame's map preparation its small
 // kernels share the chip with the 15 k-wave kNN launch the frame is waiting for (207 us instead of 155).  Held back until that
 // preparation is done, they run under the current frame's SOLVE, a chain of short launches that leaves the chip mostly idle.
+int rgc_set_target_lazy(rgc_ctx* c, int margin_cells) {
+  if (!c) return RGC_ERR_INVALID;
+  if (margin_cells < 0 || margin_cells > 16) return fail(c, RGC_ERR_INVALID, "rgc_set_target_lazy: margin_cells must be in [0, 16]");
+  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  c->lazy_margin = margin_cells;  // (takes effect with the next target; one already set keeps the state it is in)
+  return RGC_OK;
+}
+
 int rgc_hold_source_until_target_of(rgc_ctx* c, rgc_ctx* other) {
   if (!c || !other) return RGC_ERR_INVALID;
   // (the other context must be alive while its event is handed to the runtime: checked and used under the registry's lock)
@@ -1326,7 +1432,8 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
                   c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
                   (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, op, c->d_small + 7,
                   c->tgt.segs.p, c->src.segs.p, post, seq, fit_in_steps ? (const float4*)c->tgt.P.p : nullptr,
-                  fit_in_steps ? (const int*)c->tgt.start.p : nullptr, fit_in_steps ? (double*)c->fit_partials.p : nullptr, c->tgt.n);
+                  fit_in_steps ? (const int*)c->tgt.start.p : nullptr, fit_in_steps ? (double*)c->fit_partials.p : nullptr, c->tgt.n,
+                  c->tgt.lazy == 2 ? 1 : 0);
   };
   auto score = [&]() {  // getFitnessScore at the final pose, chained blindly
     rgck::fitness_lm(s, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
@@ -1375,6 +1482,8 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   // the guards of speculative grids come home with the LM state: no synchronisation here
   if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
   { int rc = check_target_owner(c); if (rc) return rc; }
+  if (c->tgt.lazy == 1) { int rc = lazy_build(c, guess); if (rc) return rc; }        // lazy target: built where this solve can look
+  else if (c->tgt.lazy == 2) { int rc = complete_target(c); if (rc) return rc; }      // ... a second solve on the same target: all of it
   // The solve is a chain of short launches: it runs on the HIGH-PRIORITY stream -- the one the scan was prepared on, so it is already
   // behind that -- ordered after the map's preparation on the main stream by one event.  With a second context preparing the next
   // frame's map meanwhile (15 k waves that fill every CU), the dispatcher places the solve's ~100 workgroups as soon as slots free up
@@ -1424,11 +1533,12 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   // One linearisation + fused cost / linearise steps, enqueued blind: enough for the outer iterations the PREVIOUS solve on this context
   // took plus two (consecutive frames of a sequence need about the same number; a launch on a finished solve costs ~2 us, a
   // read-back and a second batch ~40), at least the six that cover a tracking frame, at most what max_iterations allows.
-  // (a solve of o outer iterations needs o + 1 launches: the opening linearisation and one step per try; as many as the previous solve
-  // needed stay on the solve's stream -- a launch too many there costs ~5 us in front of the next frame --, three more go aside as
-  // spares: lm_enqueue_batch)
-  int batch = 8;
-  if (c->lm_last_outer + 4 > batch) batch = c->lm_last_outer + 4;
+  // (a solve of o outer iterations needs o + 1 launches: the opening linearisation and one step per try -- and one more when its last try
+  // is rejected: the score is then computed by the launch behind it.  As many as the previous solve needed plus that one stay on the
+  // solve's stream -- a launch too many there costs ~5 us in front of the next frame, one too few a ~13 us hop to the other stream --,
+  // three more go aside as spares: lm_enqueue_batch)
+  int batch = 9;
+  if (c->lm_last_outer + 5 > batch) batch = c->lm_last_outer + 5;
   if (batch > P.max_iterations + 1) batch = P.max_iterations + 1;
   if (batch < 2) batch = 2;
   c->lm_seq = c->lm_seq >= 0x3fffffff ? 1 : c->lm_seq + 1;
@@ -1486,6 +1596,16 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
       memcpy(guess, c->pend.guess, sizeof(guess));
       return rgc_align(c, guess, final_T, final_H, fitness, iterations, converged, lm_failed);
     }
+  }
+  if (c->tgt.lazy == 2 && S.pad2) {
+    // lazy target: a look-up landed on an occupied voxel outside the part that was built (the pose moved further from the guess than the
+    // margin covers).  The map is completed and the solve repeated from the same guess: the full build's result, bit for bit.
+    c->stats.lazy_misses++;
+    int rc2 = complete_target(c);
+    if (rc2) return rc2;
+    float guess[16];
+    memcpy(guess, c->pend.guess, sizeof(guess));
+    return rgc_align(c, guess, final_T, final_H, fitness, iterations, converged, lm_failed);
   }
   const int n = c->src.n, noff = noff_of(c->prm.neighbor_method);
   if (S.cur) { std::swap(c->corr_v, c->corr_v2); std::swap(c->corr_M, c->corr_M2); }  // corr_v / corr_M = the valid buffer
@@ -2404,7 +2524,7 @@ int rgc_frontend_cloud_device(rgc_ctx* c, float** d_cloud, int* n) {
 
 int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   if (!c || !out) return RGC_ERR_INVALID;
-  { int rc = validate_clouds(c); if (rc) return rc; }
+  { int rc = validate_clouds(c, /*whole_target=*/false); if (rc) return rc; }
   if (c->tgt.ready) { int rc = fetch_nvox(c); if (rc) return rc; }
   // queries the bulk kNN kernel handed to the cooperative kernel (first int of the deferred-list buffer)
   if (!c->deferred_known) c->stats.deferred_target = c->stats.deferred_source = 0;

@@ -81,7 +81,11 @@ size_t deferred_bytes(int n);
 // wide_r = 2: the four-lanes-per-query search on the 5^3 block whatever the cloud (a sparse map)
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard = nullptr, int wide_r = 0,
-              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* dense-map launch only (knn_bulk_times_itself): the launch's own start / stop times */);
+              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* dense-map launch only (knn_bulk_times_itself): the launch's own start / stop times */,
+              // lazy target (dense-map launch only): the queries whose cell carries `stamp` in need[] are searched, the others left alone
+              const unsigned short* need = nullptr, int stamp = 0);
+// lazy target: stamp the cells of grid g within `margin` cells of the cell each point of the cloud falls into under T (k_footprint)
+void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, unsigned short* need, int stamp, int margin);
 bool knn_bulk_times_itself(bool is_target, int wide_r);
 // waves: one-wave workgroups that share the deferred list (clamped to [32, 8192])
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
@@ -91,7 +95,8 @@ void voxel_build(hipStream_t s, const float4* P, const double* nx, const double*
                  int n, const int* cell_voxel, double* vox, int* vox_cell);
 // voxel_build and knn_coop (target) in one launch, followed by voxel_patch: see k_voxel_build_coop
 void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
-                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves);
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves,
+                      const unsigned short* need = nullptr, int stamp = 0 /* lazy target: voxels of unstamped cells are marked num = -1, not built */);
 // the voxels that hold a deferred query, recomputed: lets the cooperative search run BESIDE voxel_build; lanes: about
 // the number of deferred queries (grid-stride loop)
 void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g, const void* deferred,
@@ -113,7 +118,8 @@ void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny,
              int seq = 0 /* > 0: post when done; < 0: post when done AND scored (by this kernel or fitness_lm) */,
              // the fitness score chained to the solve (all non-null): the solve's LAST step scores the pose it accepts, a launch on a finished
              // solve without a score computes it; TP / tstart: the map's sorted points and cell starts, nt its point count
-             const float4* TP = nullptr, const int* tstart = nullptr, double* fit_partials = nullptr, int nt = 0);
+             const float4* TP = nullptr, const int* tstart = nullptr, double* fit_partials = nullptr, int nt = 0,
+             int lazy = 0 /* the target is partly built (lazy target): a look-up of an un-built voxel raises LmState::pad2 */);
 // nt: the target's point count (a small map is scanned whole by the wave for a query its first cube does not settle; 0: never)
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials,
                 LmState* h_post = nullptr, int seq = 0, int nt = 0);

@@ -790,7 +790,12 @@ struct Deferred {
   float* thr;  // k-th distance seen so far (INFINITY if fewer than k candidates)
   int* cnt;
   const int* guard;  // speculative grid only: non-zero = some point did not fit the grid, the cloud will be prepared again -- do nothing
+  // lazy target (rgc_set_target_lazy): only the queries whose cell carries this frame's stamp are searched -- the cells within the margin
+  // of a cell the scan falls into at the guess (k_footprint); null: every query
+  const unsigned short* need;
+  int stamp;
 };
+__device__ __forceinline__ bool cell_needed(const unsigned short* __restrict__ need, int stamp, int cell) { return !need || (int)need[cell] == stamp; }
 
 // ------------------------------------------------------------------------------------------------
 // C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298), the bulk kernel: one lane per query, queries
@@ -1028,6 +1033,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int c[3] = {cell_coord(px, g) - g.minc[0], cell_coord(py, g) - g.minc[1], cell_coord(pz, g) - g.minc[2]};
+  if (!cell_needed(df.need, df.stamp, cell_index(g, c[0], c[1], c[2]))) return;  // lazy target: the solve cannot look this point's voxel up
   const double q[3] = {(double)px, (double)py, (double)pz};
   auto defer = [&](int enc, float thr) {
     const int e = atomicAdd(df.cnt, 1);
@@ -1827,19 +1833,43 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
 // (A lane per grid cell, as before, spends 96 % of its lanes on empty cells and serialises one memory round trip per
 // point.)  The voxel id of a cell comes from the cell scan (cell_voxel, -1 for empty cells).
 // ------------------------------------------------------------------------------------------------
+// Lazy target: the cells of the map's grid the solve can look up -- every cell within `margin` cells (Chebyshev) of the cell a scan point
+// falls into at the guess (the look-up's own arithmetic, linearize_point) -- get this frame's stamp.  Stamps, not flags: nothing is cleared
+// between frames (a 16-bit stamp: the array is zeroed when it wraps, by the host).
+__global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, Pose T, Grid g, unsigned short* __restrict__ need, int stamp, int margin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* pp = in + (size_t)i * stride_f;
+  const double p0 = (double)pp[0], p1 = (double)pp[1], p2 = (double)pp[2];
+  const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
+  const double q1 = T.R[3] * p0 + T.R[4] * p1 + T.R[5] * p2 + T.t[1];
+  const double q2 = T.R[6] * p0 + T.R[7] * p1 + T.R[8] * p2 + T.t[2];
+  if (!(fabs(q0) <= 1.0e8 && fabs(q1) <= 1.0e8 && fabs(q2) <= 1.0e8)) return;
+  const int cx = (int)floor(q0 / g.res - 0.5) - g.minc[0];
+  const int cy = (int)floor(q1 / g.res - 0.5) - g.minc[1];
+  const int cz = (int)floor(q2 / g.res - 0.5) - g.minc[2];
+  const int x0 = max(cx - margin, 0), x1 = min(cx + margin, g.dim[0] - 1);
+  const int y0 = max(cy - margin, 0), y1 = min(cy + margin, g.dim[1] - 1);
+  const int z0 = max(cz - margin, 0), z1 = min(cz + margin, g.dim[2] - 1);
+  for (int z = z0; z <= z1; z++)
+    for (int y = y0; y <= y1; y++)
+      for (int x = x0; x <= x1; x++) need[cell_index(g, x, y, z)] = (unsigned short)stamp;
+}
+
 constexpr int VOX_T = 256;
 __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
                                                   const double* __restrict__ nz, const int* __restrict__ start, const Grid& g, int n,
                                                   const int* __restrict__ cell_voxel, double* __restrict__ vox, int* __restrict__ vox_cell,
-                                                  double (*sh)[VOX_T], int block) {
+                                                  double (*sh)[VOX_T], int block, const unsigned short* __restrict__ need = nullptr, int stamp = 0) {
   const int b0 = block * VOX_T, bend = min(b0 + VOX_T, n);
   const int s = b0 + threadIdx.x;
   int c = 0, s1 = 0;
-  bool head = false;
+  bool head = false, built = true;
   if (s < n) {
     const float4 cp = P[s];
-    const double a = nx[s], b = ny[s], d = nz[s];
     c = cell_index(g, cell_coord(cp.x, g) - g.minc[0], cell_coord(cp.y, g) - g.minc[1], cell_coord(cp.z, g) - g.minc[2]);
+    built = cell_needed(need, stamp, c);  // lazy target: a voxel outside the scan's footprint has no normals -- it is marked, not summed
+    const double a = built ? nx[s] : 0.0, b = built ? ny[s] : 0.0, d = built ? nz[s] : 0.0;
     const int s0 = start[c];
     s1 = start[c + 1];
     head = (s0 == s);
@@ -1855,6 +1885,12 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
   }
   __syncthreads();
   if (!head) return;
+  if (!built) {  // num < 0: "not built" -- a look-up that lands here makes the solve complete the map and start over (linearize_point)
+    const int v = cell_voxel[c];
+    vox_cell[v] = c;
+    vox[(size_t)v * kVoxRec + 9] = -1.0;
+    return;
+  }
   double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
   const int e_in = min(s1, bend);
   for (int u = s; u < e_in; u++) {
@@ -1905,7 +1941,7 @@ k_voxel_build_coop(const float4* __restrict__ P, double* __restrict__ nx, double
   __shared__ double sh[9][VOX_T];
   __shared__ CoopRows shm[VOX_T / WAVE];
   if ((int)blockIdx.x >= nb_coop) {
-    voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x - nb_coop);
+    voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x - nb_coop, df.need, df.stamp);
     return;
   }
   if (df.guard && *df.guard) return;
@@ -2062,7 +2098,7 @@ __device__ __forceinline__ void linearize_point(const float4* __restrict__ P, co
                                                 const double* __restrict__ nz, int i, int n, const Pose& T, const Grid& g,
                                                 const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff,
                                                 int* __restrict__ corr_v, double* __restrict__ corr_M, int want_H, double (&acc)[kAccum],
-                                                int& ncorr) {
+                                                int& ncorr, int* __restrict__ miss = nullptr) {
     const float4 pp = P[i];
     const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
     const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
@@ -2085,6 +2121,12 @@ __device__ __forceinline__ void linearize_point(const float4* __restrict__ P, co
       int v = -1;
       if (x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) v = cell_voxel[cell_index(g, x, y, z)];
       const size_t slot = (size_t)o * n + i;
+      if (v >= 0 && miss && vox[(size_t)v * kVoxRec + 9] < 0.0) {
+        // lazy target: an occupied voxel the footprint did not cover.  The solve's result will be thrown away -- the caller completes the
+        // map and solves again -- so the correspondence is simply dropped here (write-through flag: another XCD's workgroup reads it)
+        __hip_atomic_store(miss, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = -1;
+      }
       corr_v[slot] = v;
       if (v < 0) continue;
       const double* rec = vox + (size_t)v * kVoxRec;
@@ -2452,7 +2494,7 @@ __device__ __forceinline__ double fitness_fold(const double* __restrict__ partia
 
 // What the score needs beside the solve's own arguments (k_lm_step): the map's sorted points and cell starts, the rows of the per-wave
 // sums, and whether a small map is scanned whole (fitness_wave).  on == 0: no score is chained to this solve.
-struct FitArgs { const float4* TP; const int* tstart; double* partials; int n_all; int on; };
+struct FitArgs { const float4* TP; const int* tstart; double* partials; int n_all; int on; int lazy /* the target is partly built: look-ups are checked */; };
 
 // this wave's share of getFitnessScore at pose m16 (cast to float like final_transformation_, :77), as a write-through row
 __device__ __forceinline__ void step_fitness_rows(const float4* __restrict__ SP, int n, const double* m16, const Grid& g, const FitArgs& fa) {
@@ -2540,7 +2582,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     for (int a = 0; a < kAccum; a++) lin[a] = 0.0;
     int ncorr = 0;
     if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, mode == LM_MODE_LIN ? cv_cur : cv_nxt,
-                               mode == LM_MODE_LIN ? cm_cur : cm_nxt, 1, lin, ncorr);
+                               mode == LM_MODE_LIN ? cm_cur : cm_nxt, 1, lin, ncorr, fa.lazy ? &st->cmd : nullptr);
 #pragma unroll
     for (int a = 0; a < kAccum; a++) acc[a] = lin[a];
     acc[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
@@ -2559,7 +2601,10 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
   {
     int* lw = reinterpret_cast<int*>(&ls);
     const int* gw = reinterpret_cast<const int*>(st);
-    for (int u = threadIdx.x; u < kStateWords; u += LIN_T) lw[u] = first ? 0 : gw[u];
+    // (cmd = the lazy target's "a look-up hit an un-built voxel" flag: set by ANY workgroup of ANY launch of this solve, the opening one
+    // included -- it is taken from memory even then; a finished solve hands it on in pad2 and leaves it cleared for the next one)
+    constexpr int kCmdWord = (int)(offsetof(LmState, cmd) / sizeof(int));
+    for (int u = threadIdx.x; u < kStateWords; u += LIN_T) lw[u] = (first && u != kCmdWord) ? 0 : gw[u];
   }
   block_fold_rows<kStepAcc>(partials, gridDim.x, folded);  // (its barriers also publish ls)
   __shared__ int took_xi_s;
@@ -2578,6 +2623,8 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     }
     __syncthreads();
   }
+  if (threadIdx.x == 0 && ls.done) { ls.pad2 = ls.cmd; ls.cmd = 0; }
+  __syncthreads();
   {
     const int* lw = reinterpret_cast<const int*>(&ls);
     int* gw = reinterpret_cast<int*>(st);
@@ -3316,14 +3363,16 @@ size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 // deferred list: [cnt, pad x15][idx n][thr n]
 static Deferred deferred_of(const void* buf, int n) {
   int* base = (int*)const_cast<void*>(buf);
-  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr};
+  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, 0};
 }
 
 template <int KC, bool kExact>
 static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred,
-                        double* nx, double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1) {
+                        double* nx, double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1,
+                        const unsigned short* need, int stamp) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
+  df.need = need; df.stamp = stamp;
   if (wide_r == 2) {
     const size_t ldsw = (size_t)SpShape<2, true>::LDS * WAVE * sizeof(int);
     hipLaunchKernelGGL((k_knn_sp_wide<KC, 2, kExact>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
@@ -3354,25 +3403,29 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
 }
 bool knn_bulk_times_itself(bool is_target, int wide_r) { return is_target && wide_r != 2; }
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
-              double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1) {
+              double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1, const unsigned short* need, int stamp) {
   // (k == 20, the reference's setting, gets an instance without the general-k branches)
-  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1);
-  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1);
-  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1);
+  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, need, stamp);
+  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, need, stamp);
+  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, need, stamp);
 }
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
               double* ny, double* nz, const int* guard, int waves) {
   if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
   else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
 }
+void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, unsigned short* need, int stamp, int margin) {
+  if (n > 0) hipLaunchKernelGGL(k_footprint, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, g, need, stamp, margin);
+}
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int n, const int* cell_voxel, double* vox, int* vox_cell) {
   hipLaunchKernelGGL(k_voxel_build, dim3(nblk(n, VOX_T)), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell);
 }
 void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
-                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves) {
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const unsigned short* need, int stamp) {
   Deferred df = deferred_of(deferred, n);
   df.guard = guard;
+  df.need = need; df.stamp = stamp;
   const int nbv = nblk(n, VOX_T);
   const int nbc = nblk(waves < 32 ? 32 : (waves > 8192 ? 8192 : waves), VOX_T / WAVE);
   if (k <= 20) hipLaunchKernelGGL((k_voxel_build_coop<20>), dim3(nbv + nbc), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, nbc, k, df);
@@ -3410,8 +3463,8 @@ static int fitness_scan_all(int nt) { return nt > 0 && nt <= 32768 ? nt : 0; }
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
              const LmInit* first, const int* nvox, const void* segs_t, const void* segs_s, LmState* h_post, int seq, const float4* TP,
-             const int* tstart, double* fit_partials, int nt) {
-  const FitArgs fa{TP, tstart, fit_partials, fitness_scan_all(nt), (TP && tstart && fit_partials) ? 1 : 0};
+             const int* tstart, double* fit_partials, int nt, int lazy) {
+  const FitArgs fa{TP, tstart, fit_partials, fitness_scan_all(nt), (TP && tstart && fit_partials) ? 1 : 0, lazy};
   hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
                      corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s, h_post, seq, fa);
 }

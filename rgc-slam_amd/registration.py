@@ -158,6 +158,11 @@ class FastVGICP:
         self._chk(self._L.rgc_share_target(self._h, owner._h))
         self._n_tgt = getattr(owner, "_n_tgt", None)
 
+    def setLazyTarget(self, margin_cells: int):
+        """rgc_set_target_lazy: targets set from now on get covariances and voxels only within margin_cells voxels of where the scan falls
+        at the solve's guess (0: everywhere, the default); results are the full build's bit for bit (a look-up outside repeats the solve)."""
+        self._chk(self._L.rgc_set_target_lazy(self._h, int(margin_cells)))
+
     def holdSourceUntilTargetOf(self, other: "FastVGICP"):
         """the next setInputSource* here starts on the GPU when `other`'s target preparation (as enqueued so far) is done (rgc_hip.h)"""
         self._chk(self._L.rgc_hold_source_until_target_of(self._h, other._h))

@@ -778,6 +778,65 @@ def test_reframed_target_equals_transform_then_set(reg_mod, orc, medium, monkeyp
     v.close(); w.close()
 
 
+def test_lazy_target_gives_the_full_builds_result(reg_mod, medium):
+    """rgc_set_target_lazy: covariances and voxels only within two voxels of where the scan falls at the guess.  Pose, iterations, final
+    Hessian and fitness are the full build's bit for bit -- with a guess near the truth (no look-up leaves the built part) and with one 6 m
+    off (look-ups land outside: the solve is repeated on the completed map, rgc_stats::lazy_misses counts it); the getters, a second solve
+    on the same target and the fine seam complete the map on demand; a sequence of re-framed targets on two contexts likewise."""
+    import bench
+    import rgc_slam_amd.synth as synth
+    tgt, src = medium["tgt"], medium["src"]
+    full, lazy = _odo(reg_mod), _odo(reg_mod)
+    lazy.setLazyTarget(2)
+    off = np.eye(4, dtype=np.float32); off[:3, 3] = [6.0, -3.0, 0.2]
+    for k, guess in enumerate((np.eye(4, dtype=np.float32), off)):
+        for v in (full, lazy):
+            v.setInputTarget(tgt); v.setInputSource(src)
+            v.align(guess, want_output=False, want_fitness=True)
+        assert np.array_equal(full.getFinalTransformation(), lazy.getFinalTransformation()), k
+        assert full.nr_iterations == lazy.nr_iterations and full.getFitnessScore() == lazy.getFitnessScore()
+        assert np.array_equal(full.getFinalHessian(), lazy.getFinalHessian())
+        if k == 0:
+            assert lazy.stats()["lazy_misses"] == 0
+    assert lazy.stats()["lazy_misses"] >= 1                       # the far guess left the built part
+    # completed on demand: the getters, then a second solve on the SAME target, then the fine seam
+    cov_full, vox_full = full.getTargetCovariances(), full.getVoxels()
+    lazy.setInputTarget(tgt)
+    assert np.array_equal(lazy.getTargetCovariances(), cov_full)
+    vl = lazy.getVoxels()
+    assert np.array_equal(vl["coords"], vox_full["coords"]) and np.array_equal(vl["cov"], vox_full["cov"]) and np.array_equal(vl["mean"], vox_full["mean"])
+    lazy.setInputTarget(tgt); lazy.setInputSource(src)
+    eye = np.eye(4, dtype=np.float32)
+    lazy.align(eye, want_output=False)
+    T1 = lazy.getFinalTransformation()
+    lazy.align(T1, want_output=False)                             # the same target again, another guess: the whole map is built first
+    full.setInputTarget(tgt); full.setInputSource(src); full.align(eye, want_output=False); full.align(T1, want_output=False)
+    assert np.array_equal(lazy.getFinalTransformation(), full.getFinalTransformation())
+    lazy.setInputTarget(tgt); lazy.setInputSource(src)
+    cl_, Hl, bl = lazy.linearize(np.eye(4))
+    cf, Hf, bf = full.linearize(np.eye(4))
+    assert np.array_equal(Hl, Hf) and np.array_equal(bl, bf) and cl_ == cf
+    full.close(); lazy.close()
+    # a dependent sequence on two contexts (re-framed targets, the next frame's target enqueued by rgc_align_end_reframe)
+    pv = reg_mod.PipelinedVGICP(0, depth=2)
+    v = pv.v[0]
+    poses = synth.make_trajectory(6, seed=synth.SEED + 3)
+    scans = [synth.make_scan_n(medium["world"], poses[i + 1], 12000, seed=synth.SEED + 700 + i)["xyz"] for i in range(5)]
+    def to_dev(xyz):
+        a = np.zeros((xyz.shape[0], 4), np.float32); a[:, :3] = xyz
+        p = v.device_alloc(a.nbytes); v.upload(p, a); return p
+    d_map, d_scans = to_dev(tgt), [to_dev(s_) for s_ in scans]
+    seq = bench.DependentSequence(pv.v, d_map, len(tgt), d_scans, [len(s_) for s_ in scans])
+    Tw0 = np.asarray(poses[0], np.float64)
+    m_full, _, _ = seq.run(0, 5, Tw0, eye, True)
+    for w in pv.v:
+        w.setLazyTarget(2)
+    m_lazy2, _, _ = seq.run(0, 5, Tw0, eye, True)
+    m_lazy1, _, _ = seq.run(0, 5, Tw0, eye, False)
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(m_full, m_lazy2)) and all(np.array_equal(a_, b_) for a_, b_ in zip(m_full, m_lazy1))
+    seq.close(); pv.close()
+
+
 def test_fitness_on_a_small_sparse_map(reg_mod, orc, medium):
     """The score against a map of a few thousand points (the odometer's own kind of sub-map: <= 32 k points take the path in which a whole
     wave scans the map for the queries their first search cube does not settle, and waves take every n-th scan point): the separate
