@@ -245,6 +245,19 @@ def time_config(registration, oracle, name, tgt, scans, pose0, prior=None, depen
         el = time.perf_counter() - t1
         fin, fin_seq, g_in1 = m_pipe, m_seq, g_seq[0]
         st = pv.v[(frames - 1) % 2].stats()
+        # the same frames with the lazy target (covariances and voxels only where the solve can look; bench.py's `lazy_target` key)
+        for w in pv.v:
+            w.setLazyTarget(2)
+        seq.run(1, frames, Tw1, I4, True, prior_world=prior)   # (once untimed: the stamp array's allocation)
+        pv.synchronize()
+        t1 = time.perf_counter()
+        m_lazy, _, _ = seq.run(1, frames, Tw1, I4, True, prior_world=prior)
+        pv.synchronize()
+        el_lazy = time.perf_counter() - t1
+        lazy_info = {"lazy_target_scans_per_s": round(frames / el_lazy, 2), "lazy_target_same_poses": bool(all(np.array_equal(x, y) for x, y in zip(m_pipe, m_lazy))),
+                     "lazy_target_solves_repeated": int(sum(w.stats()["lazy_misses"] for w in pv.v))}
+        for w in pv.v:
+            w.setLazyTarget(0)
     else:
         def setc(i, w):
             w.setInputTargetDevice(d_tgt, len(tgt), 16)
@@ -273,6 +286,7 @@ def time_config(registration, oracle, name, tgt, scans, pose0, prior=None, depen
         pv.synchronize()
         el = time.perf_counter() - t1
         st = pv.v[(frames - 1) % 2].stats()
+        lazy_info = {}
     B = frame_bytes(st, len(scans[0]), len(tgt))
     out = {"config": name, "n_source": int(len(scans[0])), "n_target": int(len(tgt)), "frames": frames,
            "sequence": "dependent (target re-framed by the previous pose)" if dependent else "fixed map",
@@ -280,6 +294,7 @@ def time_config(registration, oracle, name, tgt, scans, pose0, prior=None, depen
            "one_frame_at_a_time_scans_per_s": round(frames / el_seq, 2),
            "same_poses_both_ways": bool(all(np.array_equal(x, y) for x, y in zip(fin, fin_seq))), "outer_iterations_last": st["outer_iterations"],
            "algorithmic_bytes_per_scan": round(B), "hbm_frac_whole_frame": round(B * frames / el / 1e9 / HBM_PEAK_GBS, 6)}
+    out.update(lazy_info)
     if oracle is not None:
         o = oracle.Registration(num_threads=min(14, os.cpu_count() or 1))  # the reference's setNumThreads(14): also the oracle's faster setting
         if dependent:   # identical input clouds: the target the GPU path registered frame 1 to

@@ -368,7 +368,6 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     c->tgt_generation++;       // borrowers of the previous target must share again
     c->tgt_owner = nullptr;    // (a borrowed target's aliases are dropped buffer by buffer in ensure())
   }
-  const int k = c->prm.k_correspondences;
   hipStream_t s = is_target ? c->stream : c->stream2;
   int* dsm = c->d_small + (is_target ? 0 : 16);
   int* hsm = c->h_small + (is_target ? 0 : 16);

@@ -1,4 +1,4 @@
-"""Small driver for rocprofv3: N dependent steps (bench.DependentSequence, one context), nothing else.  python scripts/prof_dependent.py [frames] [overlap 0|1] [cmain|c3|c5]"""
+"""Small driver for rocprofv3: N dependent steps (bench.DependentSequence, one context), nothing else.  python scripts/prof_dependent.py [frames] [overlap 0|1] [cmain|c3|c5] [lazy margin]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,6 +8,7 @@ from rgc_slam_amd import registration
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 overlap = len(sys.argv) > 2 and sys.argv[2] == "1"
 cfg = sys.argv[3] if len(sys.argv) > 3 else "cmain"   # cmain | c3 | c5 (bench.py's configurations)
+lazy_margin = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # > 0: rgc_set_target_lazy
 prior = None
 if cfg == "cmain":
     world, tgt = synth.make_world_and_map(1000000, seed=synth.SEED)
@@ -34,6 +35,8 @@ else:
             prior[i] = imu_prior[i + 1]
 pv = registration.PipelinedVGICP(0, depth=2)
 v = pv.v[0]
+for w in pv.v:
+    w.setLazyTarget(lazy_margin)
 def to_dev(xyz):
     a = np.zeros((xyz.shape[0], 4), np.float32); a[:, :3] = xyz
     p = v.device_alloc(a.nbytes); v.upload(p, a); return p

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Developer aid (GPU box): rocprofv3 kernel statistics of scripts/prof_dependent.py.   bash scripts/prof_dependent.sh [frames] [overlap 0|1]
+# Developer aid (GPU box): rocprofv3 kernel statistics of scripts/prof_dependent.py.   bash scripts/prof_dependent.sh [frames] [overlap 0|1] [cmain|c3|c5] [lazy margin]
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_dep
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O -o dep --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prof_dependent.py ${1:-40} ${2:-0} > $O/run.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O -o dep --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prof_dependent.py ${1:-40} ${2:-0} ${3:-cmain} ${4:-0} > $O/run.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$O/**/*kernel_stats.csv", recursive=True)[0]

@@ -788,17 +788,23 @@ def test_lazy_target_gives_the_full_builds_result(reg_mod, medium):
     tgt, src = medium["tgt"], medium["src"]
     full, lazy = _odo(reg_mod), _odo(reg_mod)
     lazy.setLazyTarget(2)
-    off = np.eye(4, dtype=np.float32); off[:3, 3] = [6.0, -3.0, 0.2]
-    for k, guess in enumerate((np.eye(4, dtype=np.float32), off)):
+    def both(guess):
         for v in (full, lazy):
             v.setInputTarget(tgt); v.setInputSource(src)
             v.align(guess, want_output=False, want_fitness=True)
-        assert np.array_equal(full.getFinalTransformation(), lazy.getFinalTransformation()), k
+        assert np.array_equal(full.getFinalTransformation(), lazy.getFinalTransformation()), guess[:3, 3]
         assert full.nr_iterations == lazy.nr_iterations and full.getFitnessScore() == lazy.getFitnessScore()
         assert np.array_equal(full.getFinalHessian(), lazy.getFinalHessian())
-        if k == 0:
-            assert lazy.stats()["lazy_misses"] == 0
-    assert lazy.stats()["lazy_misses"] >= 1                       # the far guess left the built part
+    both(np.eye(4, dtype=np.float32))
+    assert lazy.stats()["lazy_misses"] == 0                       # a guess near the truth: every look-up stays inside the built part
+    # guesses a metre or two off that the solve recovers from: the scan's points travel further than the margin covers and some land on
+    # occupied voxels outside the stamped cells (the ground between two rings' footprints) -- the solve is repeated on the completed map
+    lazy.setLazyTarget(1)
+    for d in ([6.0, -3.0, 0.2], [1.6, 0.9, 0.0], [-1.2, 1.4, 0.05], [2.2, 0.0, 0.0], [0.0, -2.4, 0.0]):
+        off = np.eye(4, dtype=np.float32); off[:3, 3] = d
+        both(off)
+    assert lazy.stats()["lazy_misses"] >= 1, lazy.stats()
+    lazy.setLazyTarget(2)
     # completed on demand: the getters, then a second solve on the SAME target, then the fine seam
     cov_full, vox_full = full.getTargetCovariances(), full.getVoxels()
     lazy.setInputTarget(tgt)
