@@ -1856,6 +1856,9 @@ __global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, P
       for (int x = x0; x <= x1; x++) need[cell_index(g, x, y, z)] = (unsigned short)stamp;
 }
 
+#ifndef RGC_VOX_SERIAL
+#define RGC_VOX_SERIAL 0  // 1: the head lane of a cell adds all nine terms itself (rounds 1-3)
+#endif
 constexpr int VOX_T = 256;
 __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
                                                   const double* __restrict__ nz, const int* __restrict__ start, const Grid& g, int n,
@@ -1883,6 +1886,46 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
     sh[7][threadIdx.x] = -0.999 * b * d;
     sh[8][threadIdx.x] = 1.0 - 0.999 * d * d;
   }
+#if RGC_VOX_SERIAL
+  __syncthreads();
+  if (!head) return;
+  if (!built) {  // num < 0: "not built" -- a look-up that lands here makes the solve complete the map and start over (linearize_point)
+    const int v = cell_voxel[c];
+    vox_cell[v] = c;
+    vox[(size_t)v * kVoxRec + 9] = -1.0;
+    return;
+  }
+  double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
+  const int e_in = min(s1, bend);
+  for (int u = s; u < e_in; u++) {
+    const int t = u - b0;
+    m[0] += sh[0][t]; m[1] += sh[1][t]; m[2] += sh[2][t];
+#pragma unroll
+    for (int j = 0; j < 6; j++) C[j] += sh[3 + j][t];
+  }
+  for (int u = e_in; u < s1; u += 2) {  // the cell runs past this block: two points per step straight from memory
+    const int u1 = min(u + 1, s1 - 1);
+    const float4 p0 = P[u], p1 = P[u1];
+    const double a0 = nx[u], b0_ = ny[u], d0 = nz[u], a1 = nx[u1], b1 = ny[u1], d1 = nz[u1];
+    m[0] += (double)p0.x; m[1] += (double)p0.y; m[2] += (double)p0.z;
+    C[0] += 1.0 - 0.999 * a0 * a0; C[1] += -0.999 * a0 * b0_; C[2] += -0.999 * a0 * d0;
+    C[3] += 1.0 - 0.999 * b0_ * b0_; C[4] += -0.999 * b0_ * d0; C[5] += 1.0 - 0.999 * d0 * d0;
+    if (u + 1 < s1) {
+      m[0] += (double)p1.x; m[1] += (double)p1.y; m[2] += (double)p1.z;
+      C[0] += 1.0 - 0.999 * a1 * a1; C[1] += -0.999 * a1 * b1; C[2] += -0.999 * a1 * d1;
+      C[3] += 1.0 - 0.999 * b1 * b1; C[4] += -0.999 * b1 * d1; C[5] += 1.0 - 0.999 * d1 * d1;
+    }
+  }
+  const double num = (double)(s1 - s);
+  const int v = cell_voxel[c];  // dense id from the cell scan
+  vox_cell[v] = c;
+  double* rec = vox + (size_t)v * kVoxRec;
+  rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
+#pragma unroll
+  for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
+  rec[9] = num;
+}
+#else
   __syncthreads();
   if (s >= n) return;
   if (!built) {  // num < 0: "not built" -- a look-up that lands here makes the solve complete the map and start over (linearize_point)
@@ -1899,6 +1942,9 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
   // launch was the sum of those chains, not its 47 MB).  Points of the cell past this block come straight from memory.
   const int s0 = head ? s : start[c];
   if (s0 < b0) return;  // the cell began in the previous block: that block's lanes sum it (and read this block's points from memory)
+  // (a cloud PARKED on a speculative grid it did not fit -- k_count's guard: every point in cell 0 whatever its coordinates -- is not
+  // sorted by the cells computed here; it will be prepared again, nothing of this launch is used: such a lane does nothing)
+  if (s0 > s || s1 <= s) return;
   const int e_in = min(s1, bend), W = e_in - s0, t = s - s0;
   const double num = (double)(s1 - s0);
   double* rec = vox + (size_t)cell_voxel[c] * kVoxRec;  // dense id from the cell scan
@@ -1924,6 +1970,7 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
     rec[j] = acc / num;
   }
 }
+#endif
 __global__ void __launch_bounds__(VOX_T)
 k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
               const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
