@@ -1863,7 +1863,7 @@ constexpr int VOX_T = 256;
 __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
                                                   const double* __restrict__ nz, const int* __restrict__ start, const Grid& g, int n,
                                                   const int* __restrict__ cell_voxel, double* __restrict__ vox, int* __restrict__ vox_cell,
-                                                  double (*sh)[VOX_T], int block, const unsigned short* __restrict__ need = nullptr, int stamp = 0) {
+                                                  double (*sh)[9], int block, const unsigned short* __restrict__ need = nullptr, int stamp = 0) {
   const int b0 = block * VOX_T, bend = min(b0 + VOX_T, n);
   const int s = b0 + threadIdx.x;
   int c = 0, s1 = 0;
@@ -1876,15 +1876,15 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
     const int s0 = start[c];
     s1 = start[c + 1];
     head = (s0 == s);
-    sh[0][threadIdx.x] = (double)cp.x;
-    sh[1][threadIdx.x] = (double)cp.y;
-    sh[2][threadIdx.x] = (double)cp.z;
-    sh[3][threadIdx.x] = 1.0 - 0.999 * a * a;
-    sh[4][threadIdx.x] = -0.999 * a * b;
-    sh[5][threadIdx.x] = -0.999 * a * d;
-    sh[6][threadIdx.x] = 1.0 - 0.999 * b * b;
-    sh[7][threadIdx.x] = -0.999 * b * d;
-    sh[8][threadIdx.x] = 1.0 - 0.999 * d * d;
+    sh[threadIdx.x][0] = (double)cp.x;
+    sh[threadIdx.x][1] = (double)cp.y;
+    sh[threadIdx.x][2] = (double)cp.z;
+    sh[threadIdx.x][3] = 1.0 - 0.999 * a * a;
+    sh[threadIdx.x][4] = -0.999 * a * b;
+    sh[threadIdx.x][5] = -0.999 * a * d;
+    sh[threadIdx.x][6] = 1.0 - 0.999 * b * b;
+    sh[threadIdx.x][7] = -0.999 * b * d;
+    sh[threadIdx.x][8] = 1.0 - 0.999 * d * d;
   }
 #if RGC_VOX_SERIAL
   __syncthreads();
@@ -1899,9 +1899,9 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
   const int e_in = min(s1, bend);
   for (int u = s; u < e_in; u++) {
     const int t = u - b0;
-    m[0] += sh[0][t]; m[1] += sh[1][t]; m[2] += sh[2][t];
+    m[0] += sh[t][0]; m[1] += sh[t][1]; m[2] += sh[t][2];
 #pragma unroll
-    for (int j = 0; j < 6; j++) C[j] += sh[3 + j][t];
+    for (int j = 0; j < 6; j++) C[j] += sh[t][3 + j];
   }
   for (int u = e_in; u < s1; u += 2) {  // the cell runs past this block: two points per step straight from memory
     const int u1 = min(u + 1, s1 - 1);
@@ -1954,7 +1954,7 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
   }
   for (int j = t; j < 9; j += W) {
     double acc = 0.0;
-    for (int u = s0; u < e_in; u++) acc += sh[j][u - b0];
+    for (int u = s0; u < e_in; u++) acc += sh[u - b0][j];
     for (int u = e_in; u < s1; u++) {  // the cell runs past this block
       double term;
       if (j < 3) {
@@ -1975,7 +1975,7 @@ __global__ void __launch_bounds__(VOX_T)
 k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
               const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
               int* __restrict__ vox_cell) {
-  __shared__ double sh[9][VOX_T];
+  __shared__ double sh[VOX_T][9];
   voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x);
 }
 // k_voxel_build and the map's cooperative kNN kernel in ONE launch: the FIRST nb_coop workgroups resolve the deferred queries -- four waves
@@ -1988,7 +1988,7 @@ __global__ void __launch_bounds__(VOX_T)
 k_voxel_build_coop(const float4* __restrict__ P, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz,
                    const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
                    int* __restrict__ vox_cell, int nb_coop, int k, Deferred df) {
-  __shared__ double sh[9][VOX_T];
+  __shared__ double sh[VOX_T][9];  // (point-major: the lanes of a cell read nine different terms of the SAME point -- nine banks, not one)
   __shared__ CoopRows shm[VOX_T / WAVE];
   if ((int)blockIdx.x >= nb_coop) {
     voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x - nb_coop, df.need, df.stamp);
