@@ -1826,6 +1826,9 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
 // ------------------------------------------------------------------------------------------------
 // C3  Gaussian voxel map (ADDITIVE), fast_vgicp_voxel.hpp:112-121,129-156.  record = { mean xyz, cov00 01 02 11 12 22,
 // num } (10 doubles), C_i = I - 0.999 n_i n_i^T.
+// (Round 4, measured and dropped: the nine sums of a cell dealt to the cell's lanes instead of all added by its first lane -- each term
+// still in the cloud's order -- made the launch 29 -> 60 us with the term-major LDS rows (the lanes of a cell read nine rows at the same
+// column: one bank) and 29 -> 53 us with point-major rows; the serial head loop is not what the launch waits for.)
 // One lane per POINT (sorted order): every lane puts its point's nine fp64 terms into LDS; the lane holding the
 // FIRST point of a cell then adds the cell's terms in ascending order -- the sorted order inside a cell is ascending
 // original index, so the sums run in the reference's cloud order, bit for bit what a serial loop gives -- reading LDS
@@ -1856,14 +1859,11 @@ __global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, P
       for (int x = x0; x <= x1; x++) need[cell_index(g, x, y, z)] = (unsigned short)stamp;
 }
 
-#ifndef RGC_VOX_SERIAL
-#define RGC_VOX_SERIAL 0  // 1: the head lane of a cell adds all nine terms itself (rounds 1-3)
-#endif
 constexpr int VOX_T = 256;
 __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
                                                   const double* __restrict__ nz, const int* __restrict__ start, const Grid& g, int n,
                                                   const int* __restrict__ cell_voxel, double* __restrict__ vox, int* __restrict__ vox_cell,
-                                                  double (*sh)[9], int block, const unsigned short* __restrict__ need = nullptr, int stamp = 0) {
+                                                  double (*sh)[VOX_T], int block, const unsigned short* __restrict__ need = nullptr, int stamp = 0) {
   const int b0 = block * VOX_T, bend = min(b0 + VOX_T, n);
   const int s = b0 + threadIdx.x;
   int c = 0, s1 = 0;
@@ -1876,17 +1876,16 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
     const int s0 = start[c];
     s1 = start[c + 1];
     head = (s0 == s);
-    sh[threadIdx.x][0] = (double)cp.x;
-    sh[threadIdx.x][1] = (double)cp.y;
-    sh[threadIdx.x][2] = (double)cp.z;
-    sh[threadIdx.x][3] = 1.0 - 0.999 * a * a;
-    sh[threadIdx.x][4] = -0.999 * a * b;
-    sh[threadIdx.x][5] = -0.999 * a * d;
-    sh[threadIdx.x][6] = 1.0 - 0.999 * b * b;
-    sh[threadIdx.x][7] = -0.999 * b * d;
-    sh[threadIdx.x][8] = 1.0 - 0.999 * d * d;
+    sh[0][threadIdx.x] = (double)cp.x;
+    sh[1][threadIdx.x] = (double)cp.y;
+    sh[2][threadIdx.x] = (double)cp.z;
+    sh[3][threadIdx.x] = 1.0 - 0.999 * a * a;
+    sh[4][threadIdx.x] = -0.999 * a * b;
+    sh[5][threadIdx.x] = -0.999 * a * d;
+    sh[6][threadIdx.x] = 1.0 - 0.999 * b * b;
+    sh[7][threadIdx.x] = -0.999 * b * d;
+    sh[8][threadIdx.x] = 1.0 - 0.999 * d * d;
   }
-#if RGC_VOX_SERIAL
   __syncthreads();
   if (!head) return;
   if (!built) {  // num < 0: "not built" -- a look-up that lands here makes the solve complete the map and start over (linearize_point)
@@ -1899,9 +1898,9 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
   const int e_in = min(s1, bend);
   for (int u = s; u < e_in; u++) {
     const int t = u - b0;
-    m[0] += sh[t][0]; m[1] += sh[t][1]; m[2] += sh[t][2];
+    m[0] += sh[0][t]; m[1] += sh[1][t]; m[2] += sh[2][t];
 #pragma unroll
-    for (int j = 0; j < 6; j++) C[j] += sh[t][3 + j];
+    for (int j = 0; j < 6; j++) C[j] += sh[3 + j][t];
   }
   for (int u = e_in; u < s1; u += 2) {  // the cell runs past this block: two points per step straight from memory
     const int u1 = min(u + 1, s1 - 1);
@@ -1925,57 +1924,11 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
   for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
   rec[9] = num;
 }
-#else
-  __syncthreads();
-  if (s >= n) return;
-  if (!built) {  // num < 0: "not built" -- a look-up that lands here makes the solve complete the map and start over (linearize_point)
-    if (head) {
-      const int v = cell_voxel[c];
-      vox_cell[v] = c;
-      vox[(size_t)v * kVoxRec + 9] = -1.0;
-    }
-    return;
-  }
-  // EVERY lane of the cell that sits in the block of the cell's first point works: lane t of them adds terms t, t + W, ... (of the nine)
-  // over the cell's points in ascending position -- each term's sum still runs in the cloud's order, bit for bit what one lane adding
-  // all nine gives, in a ninth of the serial steps (the head lane alone was 99 dependent LDS reads and adds for an 11-point cell: the
-  // launch was the sum of those chains, not its 47 MB).  Points of the cell past this block come straight from memory.
-  const int s0 = head ? s : start[c];
-  if (s0 < b0) return;  // the cell began in the previous block: that block's lanes sum it (and read this block's points from memory)
-  // (a cloud PARKED on a speculative grid it did not fit -- k_count's guard: every point in cell 0 whatever its coordinates -- is not
-  // sorted by the cells computed here; it will be prepared again, nothing of this launch is used: such a lane does nothing)
-  if (s0 > s || s1 <= s) return;
-  const int e_in = min(s1, bend), W = e_in - s0, t = s - s0;
-  const double num = (double)(s1 - s0);
-  double* rec = vox + (size_t)cell_voxel[c] * kVoxRec;  // dense id from the cell scan
-  if (head) {
-    vox_cell[cell_voxel[c]] = c;
-    rec[9] = num;
-  }
-  for (int j = t; j < 9; j += W) {
-    double acc = 0.0;
-    for (int u = s0; u < e_in; u++) acc += sh[u - b0][j];
-    for (int u = e_in; u < s1; u++) {  // the cell runs past this block
-      double term;
-      if (j < 3) {
-        const float4 p0 = P[u];
-        term = j == 0 ? (double)p0.x : (j == 1 ? (double)p0.y : (double)p0.z);
-      } else {
-        const double a0 = nx[u], b0_ = ny[u], d0 = nz[u];
-        term = j == 3 ? 1.0 - 0.999 * a0 * a0 : (j == 4 ? -0.999 * a0 * b0_ : (j == 5 ? -0.999 * a0 * d0 : (j == 6 ? 1.0 - 0.999 * b0_ * b0_ :
-               (j == 7 ? -0.999 * b0_ * d0 : 1.0 - 0.999 * d0 * d0))));
-      }
-      acc += term;
-    }
-    rec[j] = acc / num;
-  }
-}
-#endif
 __global__ void __launch_bounds__(VOX_T)
 k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
               const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
               int* __restrict__ vox_cell) {
-  __shared__ double sh[VOX_T][9];
+  __shared__ double sh[9][VOX_T];
   voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x);
 }
 // k_voxel_build and the map's cooperative kNN kernel in ONE launch: the FIRST nb_coop workgroups resolve the deferred queries -- four waves
@@ -1988,7 +1941,7 @@ __global__ void __launch_bounds__(VOX_T)
 k_voxel_build_coop(const float4* __restrict__ P, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz,
                    const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
                    int* __restrict__ vox_cell, int nb_coop, int k, Deferred df) {
-  __shared__ double sh[VOX_T][9];  // (point-major: the lanes of a cell read nine different terms of the SAME point -- nine banks, not one)
+  __shared__ double sh[9][VOX_T];
   __shared__ CoopRows shm[VOX_T / WAVE];
   if ((int)blockIdx.x >= nb_coop) {
     voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x - nb_coop, df.need, df.stamp);
