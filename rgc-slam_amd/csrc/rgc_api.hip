@@ -90,9 +90,10 @@ struct Cloud {
   // lazy target (rgc_set_target_lazy): 0 = covariances and voxel map complete; 1 = the grid is built, nothing else (the solve's guess
   // decides which part is needed); 2 = built for the cells stamped need_stamp in `need` only
   int lazy = 0;
-  DevBuf need;              // one 16-bit stamp per grid cell (k_footprint)
+  DevBuf need, qlist, cell_list;  // one stamp per grid cell; the listed queries (points) and cells of this frame (k_footprint)
   int need_stamp = 0;
   const void* need_seen = nullptr;  // the allocation the stamps refer to
+  int lazy_nq_seen = -1, lazy_ncell_seen = -1;  // the previous frame's list sizes (they size this frame's launches)
 };
 
 struct ProfRegion {
@@ -270,7 +271,7 @@ void release(DevBuf& b) {
 
 void release_cloud(Cloud& cl) {
   for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.slot_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs,
-                    &cl.cell_voxel, &cl.vox, &cl.vox_cell, &cl.need})
+                    &cl.cell_voxel, &cl.vox, &cl.vox_cell, &cl.need, &cl.qlist, &cl.cell_list})
     release(*b);
 }
 
@@ -352,7 +353,7 @@ bool map_prep_finished(rgc_ctx* c) {
   return q == hipSuccess;
 }
 
-int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target, const unsigned short* need, int stamp);
+int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target);
 // a sparse map (points per cell of its grid below map_wide_density) takes the wider block of the bulk kNN launch, see k_knn_sp_wide
 int map_wide_r_of(const rgc_ctx* c, const Cloud& cl) {
   return (c->map_wide_r > 0 && (double)cl.n < c->map_wide_density * (double)cl.grid.ncell) ? c->map_wide_r : 0;
@@ -543,7 +544,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     return RGC_OK;
   }
   {
-    int rc = cloud_covariances(c, cl, is_target, nullptr, 0);
+    int rc = cloud_covariances(c, cl, is_target);
     if (rc) return rc;
   }
   HIPCHK(c, hipGetLastError());
@@ -558,8 +559,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
 }
 
 // C2 / C3 of a cloud whose grid is built: exact-kNN covariances (+ the Gaussian voxel map for the target), enqueued on the cloud's stream.
-// need / stamp (target only, lazy): only the queries and voxels of the cells stamped `stamp` are built (rgck::footprint).
-int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target, const unsigned short* need, int stamp) {
+int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
   const int n = cl.n, k = c->prm.k_correspondences;
   hipStream_t s = is_target ? c->stream : c->stream2;
   int* dsm = c->d_small + (is_target ? 0 : 16);
@@ -583,12 +583,12 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target, const unsigned shor
     }
     if (self_timed) {
       rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
-                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, own.a, own.b, need, stamp);
+                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, own.a, own.b);
       c->prof_open.push_back(own);
     } else {
       ProfScope ps(c, kind, n, s);
       rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
-                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, nullptr, nullptr, need, stamp);
+                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r);
     }
   }
   // The map's deferred queries (~100 of a million, one wave each: 20 us of latency) are resolved in the SAME launch as the voxel map's
@@ -611,8 +611,7 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target, const unsigned shor
     ProfScope ps(c, RGC_K_VOXEL, n);
     {
       rgck::voxel_build_coop(s, (const float4*)cl.P.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p, (const int*)cl.start.p, cl.grid, n,
-                             (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves,
-                             need, stamp);
+                             (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves);
       rgck::voxel_patch(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
                         cl.grid, cl.segs.p, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 64 : n);
     }
@@ -630,10 +629,13 @@ int lazy_build(rgc_ctx* c, const float guess[16]) {
   Cloud& cl = c->tgt;
   hipStream_t s = c->stream;
   int rc;
+  const int n = cl.n, k = c->prm.k_correspondences;
   const size_t cells = (size_t)cl.grid.ncell;
-  if ((rc = ensure(c, cl.need, sizeof(unsigned short) * cells + 256))) return rc;
+  if ((rc = ensure(c, cl.need, sizeof(int) * cells + 256))) return rc;
+  if ((rc = ensure(c, cl.qlist, sizeof(int) * (size_t)n + 256))) return rc;
+  if ((rc = ensure(c, cl.cell_list, sizeof(int) * (size_t)n + 256))) return rc;
   cl.need_stamp++;
-  if (cl.need.p != cl.need_seen || cl.need_stamp > 65535) {  // a new allocation, or the 16-bit stamps wrapped: start over from a clean array
+  if (cl.need.p != cl.need_seen || cl.need_stamp > 0x3fffffff) {  // a new allocation (or the stamps ran out): start over from a clean array
     HIPCHK(c, hipMemsetAsync(cl.need.p, 0, cl.need.cap, s));
     cl.need_seen = cl.need.p;
     cl.need_stamp = 1;
@@ -644,8 +646,26 @@ int lazy_build(rgc_ctx* c, const float guess[16]) {
   }
   double T[16];
   for (int i = 0; i < 16; i++) T[i] = (double)guess[i];
-  rgck::footprint(s, c->src.in, c->src.stride_f, c->src.n, pose_from(T), cl.grid, (unsigned short*)cl.need.p, cl.need_stamp, c->lazy_margin);
-  if ((rc = cloud_covariances(c, cl, true, (const unsigned short*)cl.need.p, cl.need_stamp))) return rc;
+  int* counts = (int*)cl.segs.p + 1;  // [0] listed queries, [1] listed cells: behind the deferred-query counter, zeroed with it by k_rank_gather
+  rgck::footprint(s, c->src.in, c->src.stride_f, c->src.n, pose_from(T), cl.grid, (const int*)cl.start.p, (int*)cl.need.p, cl.need_stamp, c->lazy_margin,
+                  (int*)cl.qlist.p, (int*)cl.cell_list.p, counts);
+  const int q_est = cl.lazy_nq_seen >= 0 ? cl.lazy_nq_seen + cl.lazy_nq_seen / 4 + 4096 : n;
+  const int c_est = cl.lazy_ncell_seen >= 0 ? cl.lazy_ncell_seen + cl.lazy_ncell_seen / 4 + 1024 : n / 8 + 1024;
+  const int* guard = cl.spec_used ? c->d_small + 6 : nullptr;
+  {
+    ProfScope ps(c, RGC_K_KNN_COV, n, s);
+    rgck::knn_bulk(s, true, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p,
+                   guard, 0, nullptr, nullptr, (const int*)cl.qlist.p, counts, q_est);
+  }
+  {
+    const int coop_waves = cl.deferred_seen >= 0 ? cl.deferred_seen + cl.deferred_seen / 4 + 32 : n / 64 + 32;
+    ProfScope ps(c, RGC_K_VOXEL, n);
+    rgck::voxel_cells_coop(s, (const float4*)cl.P.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p, (const int*)cl.start.p, cl.grid, n,
+                           (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, guard, coop_waves, (const int*)cl.cell_list.p,
+                           counts + 1, c_est);
+    rgck::voxel_patch(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
+                      cl.grid, cl.segs.p, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 64 : n);
+  }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->tgt_prepared, s));  // (the map's preparation ends HERE now: what the solve goes behind, what another context's held scan waits for)
   cl.lazy = 2;
@@ -657,7 +677,7 @@ int complete_target(rgc_ctx* c) {
   Cloud& cl = c->tgt;
   if (!cl.ready || cl.lazy == 0 || c->tgt_owner) return RGC_OK;
   HIPCHK(c, hipMemsetAsync(cl.segs.p, 0, sizeof(int), c->stream));  // the deferred-query counter of the bulk launch
-  int rc = cloud_covariances(c, cl, true, nullptr, 0);
+  int rc = cloud_covariances(c, cl, true);
   if (rc) return rc;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->tgt_prepared, c->stream));
@@ -1432,7 +1452,7 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
                   (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, op, c->d_small + 7,
                   c->tgt.segs.p, c->src.segs.p, post, seq, fit_in_steps ? (const float4*)c->tgt.P.p : nullptr,
                   fit_in_steps ? (const int*)c->tgt.start.p : nullptr, fit_in_steps ? (double*)c->fit_partials.p : nullptr, c->tgt.n,
-                  c->tgt.lazy == 2 ? 1 : 0);
+                  c->tgt.lazy == 2 ? (const int*)c->tgt.need.p : nullptr, c->tgt.need_stamp, c->tgt.lazy == 2 ? (const int*)c->tgt.segs.p + 1 : nullptr);
   };
   auto score = [&]() {  // getFitnessScore at the final pose, chained blindly
     rgck::fitness_lm(s, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
@@ -1613,6 +1633,7 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
   c->tgt.nvox = c->stats.n_voxels = S.nvox;
   c->stats.deferred_target = S.def_t; c->stats.deferred_source = S.def_s;
   c->tgt.deferred_seen = S.def_t; c->src.deferred_seen = S.def_s;
+  if (c->tgt.lazy == 2) { c->tgt.lazy_nq_seen = S.lazy_nq; c->tgt.lazy_ncell_seen = S.lazy_ncell; }
   // (S.src_sq == 0: this scan's figure was consumed by an earlier solve on the same clouds -- the first step hands the counter back
   // zeroed -- and the steering it caused stands)
   if (S.src_sq > 0.f) c->stats.source_crowding = c->src.n > 0 ? (double)S.src_sq / (double)c->src.n : 0.0;

@@ -50,7 +50,8 @@ struct LmState {  // device-resident state of LsqRegistration::computeTransforma
   double fit_sum;                // sum of squared NN distances at the final pose (k_fitness_lm)
   int nvox, def_t, def_s, pad;   // frame counters carried home with the state; pad = grid guards, map | scan << 8
   int gen, cmd, mode, cur;       // step kernels: mode, valid correspondence buffer (gen, cmd: unused, kept for the layout)
-  float src_sq; int pad2;        // sum over the scan's grid cells of count^2 (how crowded its cells are; steers the scan's cell size)
+  float src_sq; int pad2;        // sum over the scan's grid cells of count^2 (how crowded its cells are; steers the scan's cell size); pad2: the lazy target's miss flag
+  int lazy_nq, lazy_ncell;       // lazy target: listed queries / cells of this frame (size the next frame's launches)
 };
 struct LmInit { double x0[16], rot_eps, trans_eps, init_factor; int max_outer, max_inner; };
 struct FeParams { int n_scans; double min_range, max_range; };
@@ -82,10 +83,16 @@ size_t deferred_bytes(int n);
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard = nullptr, int wide_r = 0,
               hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* dense-map launch only (knn_bulk_times_itself): the launch's own start / stop times */,
-              // lazy target (dense-map launch only): the queries whose cell carries `stamp` in need[] are searched, the others left alone
-              const unsigned short* need = nullptr, int stamp = 0);
-// lazy target: stamp the cells of grid g within `margin` cells of the cell each point of the cloud falls into under T (k_footprint)
-void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, unsigned short* need, int stamp, int margin);
+              // lazy target (dense-map launch only): the queries listed in qlist[0 .. *nq) are searched, nothing else; q_est sizes the launch
+              const int* qlist = nullptr, const int* nq = nullptr, int q_est = 0);
+// lazy target: stamp the cells of grid g within `margin` cells of the cell each point of the cloud falls into under T and list the occupied
+// ones (cell_list: their first sorted point; qlist: all their points; counts[0] / [1]: the lists' sizes, zeroed by rank_gather)
+void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, const int* start, int* need, int stamp, int margin, int* qlist,
+               int* cell_list, int* counts);
+// ... and the voxel pass over the listed cells, the map's deferred queries resolved beside it (k_voxel_cells_coop); voxel_patch follows
+void voxel_cells_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const int* cell_list, const int* ncells,
+                      int cells_est);
 bool knn_bulk_times_itself(bool is_target, int wide_r);
 // waves: one-wave workgroups that share the deferred list (clamped to [32, 8192])
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
@@ -95,8 +102,7 @@ void voxel_build(hipStream_t s, const float4* P, const double* nx, const double*
                  int n, const int* cell_voxel, double* vox, int* vox_cell);
 // voxel_build and knn_coop (target) in one launch, followed by voxel_patch: see k_voxel_build_coop
 void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
-                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves,
-                      const unsigned short* need = nullptr, int stamp = 0 /* lazy target: voxels of unstamped cells are marked num = -1, not built */);
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves);
 // the voxels that hold a deferred query, recomputed: lets the cooperative search run BESIDE voxel_build; lanes: about
 // the number of deferred queries (grid-stride loop)
 void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g, const void* deferred,
@@ -119,7 +125,9 @@ void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny,
              // the fitness score chained to the solve (all non-null): the solve's LAST step scores the pose it accepts, a launch on a finished
              // solve without a score computes it; TP / tstart: the map's sorted points and cell starts, nt its point count
              const float4* TP = nullptr, const int* tstart = nullptr, double* fit_partials = nullptr, int nt = 0,
-             int lazy = 0 /* the target is partly built (lazy target): a look-up of an un-built voxel raises LmState::pad2 */);
+             // lazy target: the target is built for the cells stamped lazy_stamp in lazy_need[] only -- a look-up of any other occupied voxel
+             // raises LmState::pad2; lazy_counts: the lists' sizes, carried home in LmState::lazy_nq / lazy_ncell
+             const int* lazy_need = nullptr, int lazy_stamp = 0, const int* lazy_counts = nullptr);
 // nt: the target's point count (a small map is scanned whole by the wave for a query its first cube does not settle; 0: never)
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials,
                 LmState* h_post = nullptr, int seq = 0, int nt = 0);

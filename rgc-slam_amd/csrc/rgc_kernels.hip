@@ -534,7 +534,7 @@ __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n,
                               int prio) {
   wave_prio(prio);
   int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s == 0 && zero_me) *zero_me = 0;  // the kNN launch that follows counts its deferred queries here
+  if (s == 0 && zero_me) { zero_me[0] = 0; zero_me[1] = 0; zero_me[2] = 0; }  // the deferred-query counter of the kNN launch that follows, and the lazy target's two list sizes behind it
   if (s < 4) P[n + s] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __int_as_float(-1));  // sentinels: infinitely far from every query (k_knn_sp's last quad)
   if (s >= n) return;
   const unsigned long long rec = order_tmp[s];
@@ -790,12 +790,11 @@ struct Deferred {
   float* thr;  // k-th distance seen so far (INFINITY if fewer than k candidates)
   int* cnt;
   const int* guard;  // speculative grid only: non-zero = some point did not fit the grid, the cloud will be prepared again -- do nothing
-  // lazy target (rgc_set_target_lazy): only the queries whose cell carries this frame's stamp are searched -- the cells within the margin
-  // of a cell the scan falls into at the guess (k_footprint); null: every query
-  const unsigned short* need;
-  int stamp;
+  // lazy target (rgc_set_target_lazy): the map's bulk launch searches only the queries LISTED here -- the points of the cells within the
+  // margin of a cell the scan falls into at the guess, compacted by k_footprint (qlist[0 .. *nq)); null: every query, in cell order
+  const int* qlist;
+  const int* nq;
 };
-__device__ __forceinline__ bool cell_needed(const unsigned short* __restrict__ need, int stamp, int cell) { return !need || (int)need[cell] == stamp; }
 
 // ------------------------------------------------------------------------------------------------
 // C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298), the bulk kernel: one lane per query, queries
@@ -1033,7 +1032,6 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int c[3] = {cell_coord(px, g) - g.minc[0], cell_coord(py, g) - g.minc[1], cell_coord(pz, g) - g.minc[2]};
-  if (!cell_needed(df.need, df.stamp, cell_index(g, c[0], c[1], c[2]))) return;  // lazy target: the solve cannot look this point's voxel up
   const double q[3] = {(double)px, (double)py, (double)pz};
   auto defer = [&](int enc, float thr) {
     const int e = atomicAdd(df.cnt, 1);
@@ -1576,6 +1574,21 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
   if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
 }
 
+// Lazy target: the map's search for the LISTED queries only (df.qlist: whole cells, a cell's points are consecutive entries) instead of
+// all of them in cell order.  The launch is sized from the previous frame's list and strides over this one's whatever its length.  (Its own
+// kernel: the stride loop around the search costs registers -- 107 against 86 -- that the full launch, five waves per SIMD, cannot spare.)
+template <int KC, bool kExact>
+__global__ void __launch_bounds__(SpConfig<true>::T)
+k_knn_sp_listed(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
+                double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
+  extern __shared__ int slist_spl[];
+  using Cfg = SpConfig<true>;
+  if (df.guard && *df.guard) return;
+  const int nq = *df.nq;
+  for (int t = (int)blockIdx.x * Cfg::T + (int)threadIdx.x; t < nq; t += (int)gridDim.x * Cfg::T)
+    knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, df.qlist[t], slist_spl + threadIdx.x, df, nx, ny, nz);
+}
+
 // The bulk launch for a SPARSE map (a few keyframes of a 16-beam sensor after the leaf filter: 0.1 points per 1 m cell, where the 3x3x3
 // block of the dense-map kernel holds fewer than k points for most queries and 85 % of them went to the cooperative kernel): the
 // scan's four-lanes-per-query search on the (2R+1)^3 block.  Same neighbours, same tie rule; the grid stays the voxel grid.
@@ -1837,9 +1850,12 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
 // point.)  The voxel id of a cell comes from the cell scan (cell_voxel, -1 for empty cells).
 // ------------------------------------------------------------------------------------------------
 // Lazy target: the cells of the map's grid the solve can look up -- every cell within `margin` cells (Chebyshev) of the cell a scan point
-// falls into at the guess (the look-up's own arithmetic, linearize_point) -- get this frame's stamp.  Stamps, not flags: nothing is cleared
-// between frames (a 16-bit stamp: the array is zeroed when it wraps, by the host).
-__global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, Pose T, Grid g, unsigned short* __restrict__ need, int stamp, int margin) {
+// falls into at the guess (the look-up's own arithmetic, linearize_point) -- get this frame's stamp, and whoever stamps an OCCUPIED cell
+// first puts it on two lists: the cell (by its first point) for the voxel pass, its points for the bulk kNN launch.  Stamps, not flags:
+// nothing is cleared between frames.  counts: [0] listed queries, [1] listed cells (zeroed by k_rank_gather).  The lists' order is the
+// order of arrival; every listed query and cell is computed independently of the others, so the results do not depend on it.
+__global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, Pose T, Grid g, const int* __restrict__ start, int* __restrict__ need,
+                            int stamp, int margin, int* __restrict__ qlist, int* __restrict__ cell_list, int* __restrict__ counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* pp = in + (size_t)i * stride_f;
@@ -1856,23 +1872,31 @@ __global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, P
   const int z0 = max(cz - margin, 0), z1 = min(cz + margin, g.dim[2] - 1);
   for (int z = z0; z <= z1; z++)
     for (int y = y0; y <= y1; y++)
-      for (int x = x0; x <= x1; x++) need[cell_index(g, x, y, z)] = (unsigned short)stamp;
+      for (int x = x0; x <= x1; x++) {
+        const int c = cell_index(g, x, y, z);
+        if (need[c] == stamp) continue;                   // (most of a sweep's look-ups: somebody was here before)
+        if (atomicExch(&need[c], stamp) == stamp) continue;  // ... or is, at this moment: exactly one thread lists the cell
+        const int s0 = start[c], cnt = start[c + 1] - s0;
+        if (cnt <= 0) continue;
+        cell_list[atomicAdd(&counts[1], 1)] = s0;
+        const int at = atomicAdd(&counts[0], cnt);
+        for (int u = 0; u < cnt; u++) qlist[at + u] = s0 + u;
+      }
 }
 
 constexpr int VOX_T = 256;
 __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
                                                   const double* __restrict__ nz, const int* __restrict__ start, const Grid& g, int n,
                                                   const int* __restrict__ cell_voxel, double* __restrict__ vox, int* __restrict__ vox_cell,
-                                                  double (*sh)[VOX_T], int block, const unsigned short* __restrict__ need = nullptr, int stamp = 0) {
+                                                  double (*sh)[VOX_T], int block) {
   const int b0 = block * VOX_T, bend = min(b0 + VOX_T, n);
   const int s = b0 + threadIdx.x;
   int c = 0, s1 = 0;
-  bool head = false, built = true;
+  bool head = false;
   if (s < n) {
     const float4 cp = P[s];
+    const double a = nx[s], b = ny[s], d = nz[s];
     c = cell_index(g, cell_coord(cp.x, g) - g.minc[0], cell_coord(cp.y, g) - g.minc[1], cell_coord(cp.z, g) - g.minc[2]);
-    built = cell_needed(need, stamp, c);  // lazy target: a voxel outside the scan's footprint has no normals -- it is marked, not summed
-    const double a = built ? nx[s] : 0.0, b = built ? ny[s] : 0.0, d = built ? nz[s] : 0.0;
     const int s0 = start[c];
     s1 = start[c + 1];
     head = (s0 == s);
@@ -1888,12 +1912,6 @@ __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, 
   }
   __syncthreads();
   if (!head) return;
-  if (!built) {  // num < 0: "not built" -- a look-up that lands here makes the solve complete the map and start over (linearize_point)
-    const int v = cell_voxel[c];
-    vox_cell[v] = c;
-    vox[(size_t)v * kVoxRec + 9] = -1.0;
-    return;
-  }
   double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
   const int e_in = min(s1, bend);
   for (int u = s; u < e_in; u++) {
@@ -1944,7 +1962,7 @@ k_voxel_build_coop(const float4* __restrict__ P, double* __restrict__ nx, double
   __shared__ double sh[9][VOX_T];
   __shared__ CoopRows shm[VOX_T / WAVE];
   if ((int)blockIdx.x >= nb_coop) {
-    voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x - nb_coop, df.need, df.stamp);
+    voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x - nb_coop);
     return;
   }
   if (df.guard && *df.guard) return;
@@ -1961,6 +1979,45 @@ k_voxel_build_coop(const float4* __restrict__ P, double* __restrict__ nx, double
 // One WAVE per deferred query's voxel: the lanes fetch the cell's points and normals in ONE round trip (a lane per point, 64 at a time)
 // and lane 0 adds the nine terms in ascending position from LDS.  (A lane per voxel walking its ~11 points was eleven dependent round
 // trips: 10 us of pure latency for ~100 voxels, on every frame's critical path.)
+// the voxel record of cell c by ONE wave (term: its nine LDS rows): the cell's points and normals fetched a lane per point, the nine sums
+// added by lane 0 in ascending sorted position = the cloud's order, like k_voxel_build -- the same bits
+__device__ __forceinline__ void voxel_of_cell_wave(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
+                                                   const double* __restrict__ nz, const int* __restrict__ start, int c, const int* __restrict__ cell_voxel,
+                                                   double* __restrict__ vox, int* __restrict__ vox_cell, double (*term)[WAVE], int lane) {
+  const int s0 = start[c], s1 = start[c + 1];
+  double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
+  for (int b0 = s0; b0 < s1; b0 += WAVE) {
+    const int u = b0 + lane;
+    if (u < s1) {
+      const float4 p0 = P[u];
+      const double a = nx[u], b = ny[u], d = nz[u];
+      term[0][lane] = (double)p0.x; term[1][lane] = (double)p0.y; term[2][lane] = (double)p0.z;
+      term[3][lane] = 1.0 - 0.999 * a * a; term[4][lane] = -0.999 * a * b; term[5][lane] = -0.999 * a * d;
+      term[6][lane] = 1.0 - 0.999 * b * b; term[7][lane] = -0.999 * b * d; term[8][lane] = 1.0 - 0.999 * d * d;
+    }
+    wave_lds_fence();
+    if (lane == 0) {
+      const int nb = min(WAVE, s1 - b0);
+      for (int t = 0; t < nb; t++) {
+        m[0] += term[0][t]; m[1] += term[1][t]; m[2] += term[2][t];
+        C[0] += term[3][t]; C[1] += term[4][t]; C[2] += term[5][t];
+        C[3] += term[6][t]; C[4] += term[7][t]; C[5] += term[8][t];
+      }
+    }
+    wave_lds_fence();
+  }
+  if (lane == 0) {
+    const double num = (double)(s1 - s0);
+    const int v = cell_voxel[c];
+    if (vox_cell) vox_cell[v] = c;
+    double* rec = vox + (size_t)v * kVoxRec;
+    rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
+#pragma unroll
+    for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
+    rec[9] = num;
+  }
+}
+
 __global__ void __launch_bounds__(WAVE)
 k_voxel_patch(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
               const int* __restrict__ start, Grid g, const int* __restrict__ deferred, const int* __restrict__ cell_voxel, double* __restrict__ vox) {
@@ -1973,36 +2030,31 @@ k_voxel_patch(const float4* __restrict__ P, const double* __restrict__ nx, const
     const int i = enc < 0 ? ~enc : enc;
     const float4 cp = P[i];
     const int c = cell_index(g, cell_coord(cp.x, g) - g.minc[0], cell_coord(cp.y, g) - g.minc[1], cell_coord(cp.z, g) - g.minc[2]);
-    const int s0 = start[c], s1 = start[c + 1];
-    double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
-    for (int b0 = s0; b0 < s1; b0 += WAVE) {
-      const int u = b0 + lane;
-      if (u < s1) {
-        const float4 p0 = P[u];
-        const double a = nx[u], b = ny[u], d = nz[u];
-        term[0][lane] = (double)p0.x; term[1][lane] = (double)p0.y; term[2][lane] = (double)p0.z;
-        term[3][lane] = 1.0 - 0.999 * a * a; term[4][lane] = -0.999 * a * b; term[5][lane] = -0.999 * a * d;
-        term[6][lane] = 1.0 - 0.999 * b * b; term[7][lane] = -0.999 * b * d; term[8][lane] = 1.0 - 0.999 * d * d;
-      }
-      wave_lds_fence();
-      if (lane == 0) {
-        const int nb = min(WAVE, s1 - b0);
-        for (int t = 0; t < nb; t++) {  // ascending sorted position = the cloud's order, like k_voxel_build
-          m[0] += term[0][t]; m[1] += term[1][t]; m[2] += term[2][t];
-          C[0] += term[3][t]; C[1] += term[4][t]; C[2] += term[5][t];
-          C[3] += term[6][t]; C[4] += term[7][t]; C[5] += term[8][t];
-        }
-      }
-      wave_lds_fence();
-    }
-    if (lane == 0) {
-      const double num = (double)(s1 - s0);
-      double* rec = vox + (size_t)cell_voxel[c] * kVoxRec;
-      rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
-#pragma unroll
-      for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
-      rec[9] = num;
-    }
+    voxel_of_cell_wave(P, nx, ny, nz, start, c, cell_voxel, vox, nullptr, term, lane);
+  }
+}
+
+// Lazy target: the voxel pass over the LISTED cells (k_footprint's cell_list: the first sorted point of each occupied cell the solve can
+// look up), a wave per cell -- and, as in k_voxel_build_coop, the map's deferred queries resolved by the first nb_coop workgroups of the
+// same launch (k_voxel_patch behind it redoes the voxels that hold one).
+template <int KC>
+__global__ void __launch_bounds__(VOX_T)
+k_voxel_cells_coop(const float4* __restrict__ P, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz,
+                   const int* __restrict__ start, Grid g, const int* __restrict__ cell_voxel, double* __restrict__ vox, int* __restrict__ vox_cell,
+                   int nb_coop, int k, Deferred df, const int* __restrict__ cell_list, const int* __restrict__ ncells) {
+  __shared__ double term[VOX_T / WAVE][9][WAVE];
+  __shared__ CoopRows shm[VOX_T / WAVE];
+  const int w = (int)threadIdx.x / WAVE, lane = (int)threadIdx.x & (WAVE - 1);
+  if ((int)blockIdx.x < nb_coop) {
+    if (df.guard && *df.guard) return;
+    coop_run<KC, true>(P, start, g, k, df, nx, ny, nz, &shm[w], lane, (int)blockIdx.x * (VOX_T / WAVE) + w, nb_coop * (VOX_T / WAVE));
+    return;
+  }
+  const int nc = *ncells, nwaves = ((int)gridDim.x - nb_coop) * (VOX_T / WAVE);
+  for (int e = ((int)blockIdx.x - nb_coop) * (VOX_T / WAVE) + w; e < nc; e += nwaves) {
+    const float4 cp = P[cell_list[e]];
+    const int c = cell_index(g, cell_coord(cp.x, g) - g.minc[0], cell_coord(cp.y, g) - g.minc[1], cell_coord(cp.z, g) - g.minc[2]);
+    voxel_of_cell_wave(P, nx, ny, nz, start, c, cell_voxel, vox, vox_cell, term[w], lane);
   }
 }
 
@@ -2101,7 +2153,7 @@ __device__ __forceinline__ void linearize_point(const float4* __restrict__ P, co
                                                 const double* __restrict__ nz, int i, int n, const Pose& T, const Grid& g,
                                                 const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff,
                                                 int* __restrict__ corr_v, double* __restrict__ corr_M, int want_H, double (&acc)[kAccum],
-                                                int& ncorr, int* __restrict__ miss = nullptr) {
+                                                int& ncorr, int* __restrict__ miss = nullptr, const int* __restrict__ need = nullptr, int stamp = 0) {
     const float4 pp = P[i];
     const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
     const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
@@ -2124,9 +2176,10 @@ __device__ __forceinline__ void linearize_point(const float4* __restrict__ P, co
       int v = -1;
       if (x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) v = cell_voxel[cell_index(g, x, y, z)];
       const size_t slot = (size_t)o * n + i;
-      if (v >= 0 && miss && vox[(size_t)v * kVoxRec + 9] < 0.0) {
-        // lazy target: an occupied voxel the footprint did not cover.  The solve's result will be thrown away -- the caller completes the
-        // map and solves again -- so the correspondence is simply dropped here (write-through flag: another XCD's workgroup reads it)
+      if (v >= 0 && miss && need[cell_index(g, x, y, z)] != stamp) {
+        // lazy target: an occupied voxel the footprint did not cover (its cell does not carry this frame's stamp: nothing was built for
+        // it).  The solve's result will be thrown away -- the caller completes the map and solves again -- so the correspondence is
+        // simply dropped here (write-through flag: another XCD's workgroup reads it)
         __hip_atomic_store(miss, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         v = -1;
       }
@@ -2497,7 +2550,11 @@ __device__ __forceinline__ double fitness_fold(const double* __restrict__ partia
 
 // What the score needs beside the solve's own arguments (k_lm_step): the map's sorted points and cell starts, the rows of the per-wave
 // sums, and whether a small map is scanned whole (fitness_wave).  on == 0: no score is chained to this solve.
-struct FitArgs { const float4* TP; const int* tstart; double* partials; int n_all; int on; int lazy /* the target is partly built: look-ups are checked */; };
+struct FitArgs {
+  const float4* TP; const int* tstart; double* partials; int n_all; int on;
+  const int* need; int stamp;  // lazy target: the target is built only for the cells stamped `stamp` in need[]: every look-up is checked
+  const int* counts;           // ... and its list sizes ([0] queries, [1] cells) ride home with the state
+};
 
 // this wave's share of getFitnessScore at pose m16 (cast to float like final_transformation_, :77), as a write-through row
 __device__ __forceinline__ void step_fitness_rows(const float4* __restrict__ SP, int n, const double* m16, const Grid& g, const FitArgs& fa) {
@@ -2585,7 +2642,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     for (int a = 0; a < kAccum; a++) lin[a] = 0.0;
     int ncorr = 0;
     if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, mode == LM_MODE_LIN ? cv_cur : cv_nxt,
-                               mode == LM_MODE_LIN ? cm_cur : cm_nxt, 1, lin, ncorr, fa.lazy ? &st->cmd : nullptr);
+                               mode == LM_MODE_LIN ? cm_cur : cm_nxt, 1, lin, ncorr, fa.need ? &st->cmd : nullptr, fa.need, fa.stamp);
 #pragma unroll
     for (int a = 0; a < kAccum; a++) acc[a] = lin[a];
     acc[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
@@ -2617,6 +2674,7 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     bool took_xi = false;
     lm_step_decide(ls, folded, first, in, mode, cur, nvox, def_t, def_s, &took_xi);
     took_xi_s = took_xi ? 1 : 0;
+    if (first) { ls.lazy_nq = fa.counts ? fa.counts[0] : 0; ls.lazy_ncell = fa.counts ? fa.counts[1] : 0; }
   }
   __syncthreads();
   if (score_here && ls.done && took_xi_s) {  // the accepted pose is the one the score was taken at: fold it into the state
@@ -3366,16 +3424,16 @@ size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 // deferred list: [cnt, pad x15][idx n][thr n]
 static Deferred deferred_of(const void* buf, int n) {
   int* base = (int*)const_cast<void*>(buf);
-  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, 0};
+  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, nullptr};
 }
 
 template <int KC, bool kExact>
 static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred,
                         double* nx, double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1,
-                        const unsigned short* need, int stamp) {
+                        const int* qlist, const int* nq, int q_est) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
-  df.need = need; df.stamp = stamp;
+  df.qlist = qlist; df.nq = nq;
   if (wide_r == 2) {
     const size_t ldsw = (size_t)SpShape<2, true>::LDS * WAVE * sizeof(int);
     hipLaunchKernelGGL((k_knn_sp_wide<KC, 2, kExact>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
@@ -3385,9 +3443,13 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   using CS = SpConfig<false>;
   const int T = is_target ? CT::T : CS::T;
   const size_t lds = (size_t)(is_target ? SpShape<CT::R, CT::kClip>::LDS : SpShape<CS::R, CS::kClip>::LDS) * T * sizeof(int);
-  const int nb = 8 * RGC_XCD_RUN * nblk(nblk(n, T), 8 * RGC_XCD_RUN);  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n)
+  // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n); lazy target: as many blocks as the listed queries are
+  // expected to fill (the kernel strides over the list whatever its true length)
+  const int n_launch = (is_target && qlist) ? (q_est < T ? T : (q_est > n ? n : q_est)) : n;
+  const int nb = (is_target && qlist) ? nblk(n_launch, T) : 8 * RGC_XCD_RUN * nblk(nblk(n, T), 8 * RGC_XCD_RUN);
   // (ev0 / ev1: the launch's own start / stop times go into the caller's events -- no separate record packets around it)
-  if (is_target && ev0 && ev1) hipExtLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), (std::uint32_t)lds, s, ev0, ev1, 0u, P, start, g, n, k, df, nx, ny, nz);
+  if (is_target && qlist) hipLaunchKernelGGL((k_knn_sp_listed<KC, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+  else if (is_target && ev0 && ev1) hipExtLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), (std::uint32_t)lds, s, ev0, ev1, 0u, P, start, g, n, k, df, nx, ny, nz);
   else if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
   else hipLaunchKernelGGL((k_knn_sp<KC, false, kExact>), dim3(nblk(n, T / 4)), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);  // four lanes per query
 }
@@ -3406,29 +3468,39 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
 }
 bool knn_bulk_times_itself(bool is_target, int wide_r) { return is_target && wide_r != 2; }
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
-              double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1, const unsigned short* need, int stamp) {
+              double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1, const int* qlist, const int* nq, int q_est) {
   // (k == 20, the reference's setting, gets an instance without the general-k branches)
-  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, need, stamp);
-  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, need, stamp);
-  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, need, stamp);
+  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est);
+  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est);
+  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est);
 }
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
               double* ny, double* nz, const int* guard, int waves) {
   if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
   else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
 }
-void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, unsigned short* need, int stamp, int margin) {
-  if (n > 0) hipLaunchKernelGGL(k_footprint, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, g, need, stamp, margin);
+void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, const int* start, int* need, int stamp, int margin, int* qlist,
+               int* cell_list, int* counts) {
+  if (n > 0) hipLaunchKernelGGL(k_footprint, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, g, start, need, stamp, margin, qlist, cell_list, counts);
+}
+void voxel_cells_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const int* cell_list, const int* ncells,
+                      int cells_est) {
+  Deferred df = deferred_of(deferred, n);
+  df.guard = guard;
+  const int nbc = nblk(waves < 32 ? 32 : (waves > 8192 ? 8192 : waves), VOX_T / WAVE);
+  const int nbv = nblk(cells_est < 256 ? 256 : (cells_est > (1 << 20) ? (1 << 20) : cells_est), VOX_T / WAVE);  // a wave per listed cell (grid-stride beyond the estimate)
+  if (k <= 20) hipLaunchKernelGGL((k_voxel_cells_coop<20>), dim3(nbc + nbv), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, cell_voxel, vox, vox_cell, nbc, k, df, cell_list, ncells);
+  else hipLaunchKernelGGL((k_voxel_cells_coop<32>), dim3(nbc + nbv), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, cell_voxel, vox, vox_cell, nbc, k, df, cell_list, ncells);
 }
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int n, const int* cell_voxel, double* vox, int* vox_cell) {
   hipLaunchKernelGGL(k_voxel_build, dim3(nblk(n, VOX_T)), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell);
 }
 void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
-                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const unsigned short* need, int stamp) {
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves) {
   Deferred df = deferred_of(deferred, n);
   df.guard = guard;
-  df.need = need; df.stamp = stamp;
   const int nbv = nblk(n, VOX_T);
   const int nbc = nblk(waves < 32 ? 32 : (waves > 8192 ? 8192 : waves), VOX_T / WAVE);
   if (k <= 20) hipLaunchKernelGGL((k_voxel_build_coop<20>), dim3(nbv + nbc), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, nbc, k, df);
@@ -3466,8 +3538,8 @@ static int fitness_scan_all(int nt) { return nt > 0 && nt <= 32768 ? nt : 0; }
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
              const LmInit* first, const int* nvox, const void* segs_t, const void* segs_s, LmState* h_post, int seq, const float4* TP,
-             const int* tstart, double* fit_partials, int nt, int lazy) {
-  const FitArgs fa{TP, tstart, fit_partials, fitness_scan_all(nt), (TP && tstart && fit_partials) ? 1 : 0, lazy};
+             const int* tstart, double* fit_partials, int nt, const int* lazy_need, int lazy_stamp, const int* lazy_counts) {
+  const FitArgs fa{TP, tstart, fit_partials, fitness_scan_all(nt), (TP && tstart && fit_partials) ? 1 : 0, lazy_need, lazy_stamp, lazy_counts};
   hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
                      corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s, h_post, seq, fa);
 }

@@ -1,10 +1,10 @@
 """Regenerate the number-bearing blocks of DESIGN.md (§8), BASELINE.md (§4), README.md and profiles/README.md from the files under
-profiles/r03_* (one refresh = one run of scripts/refresh_profiles.sh + scripts/collect_profiles.sh), so that the prose cannot drift from
-the measurements.  A block lives between two HTML comments, `<!-- r03-numbers:begin ... -->` and `<!-- r03-numbers:end -->`; everything
+profiles/r04_* (one refresh = one run of scripts/refresh_profiles.sh + scripts/collect_profiles.sh), so that the prose cannot drift from
+the measurements.  A block lives between two HTML comments, `<!-- r04-numbers:begin ... -->` and `<!-- r04-numbers:end -->`; everything
 else in those documents is written by hand and quotes the same files."""
 import csv, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r03"
+TAG = "r04"
 P = lambda *a: os.path.join(ROOT, *a)
 
 
@@ -38,6 +38,8 @@ u = load("bench_under_rocprof.json", first_line=True)
 pmc, mix, lab = load("pmc_knn.json"), load("knn_isa_mix.json"), load("lab_iters.json")
 roll, node, pipe, longr = load("rolling_bench.json"), load("cpp_node_bench.json"), load("cpp_pipeline_bench.json"), load("long_run.json")
 fe, mr, ic = load("frontend_bench.json"), load("mapreg_bench.json"), load("icp_bench.json")
+ft, ft3, ft5 = load("frame_traffic.json"), load("frame_traffic_c3.json"), load("frame_traffic_c5.json")
+LZ = d.get("lazy_target") or {}
 R, IR, O, RP, H, pp, cb, k = (d["roofline"], d["issue_roofline"], d["one_frame_at_a_time"], d["replay_of_preframed_maps"], d["scan_h2d_and_output"],
                               d["pose_parity_vs_cpu"], d["cpu_baseline"], d["kernel_ms_per_step"])
 c = {x["config"][:2]: x for x in d.get("configs", [])}
@@ -54,22 +56,23 @@ def cfg_line(key, label):
     x = c.get(key)
     if not x:
         return ""
+    lz = f"{x['lazy_target_scans_per_s']:.0f}" if x.get("lazy_target_scans_per_s") else "—"
     return (f"| {label} | {x['scans_per_s']:.0f} / {x['one_frame_at_a_time_scans_per_s']:.0f} | {x['ms_per_scan']:.3g} / "
-            f"{1e3 / x['one_frame_at_a_time_scans_per_s']:.3g} | {100 * x['hbm_frac_whole_frame']:.2f} % | {x.get('cpu_oracle_scans_per_s', float('nan')):.2f} | "
+            f"{1e3 / x['one_frame_at_a_time_scans_per_s']:.3g} | {lz} | {100 * x['hbm_frac_whole_frame']:.2f} % | {x.get('cpu_oracle_scans_per_s', float('nan')):.2f} | "
             f"{x.get('max_dt_m', float('nan')):.1e} / {x.get('max_dtheta_rad', float('nan')):.1e} |\n")
 
 
-table = ("| config | scans/s, two contexts / one frame at a time | ms/scan | algorithmic bytes ÷ time ÷ 8 TB/s | CPU oracle scans/s | max Δt (m) / Δθ (rad) vs oracle |\n"
-         "|---|---|---|---|---|---|\n"
+table = ("| config | scans/s, two contexts / one frame at a time | ms/scan | scans/s with the lazy target (two contexts) | algorithmic bytes ÷ time ÷ 8 TB/s | CPU oracle scans/s | max Δt (m) / Δθ (rad) vs oracle |\n"
+         "|---|---|---|---|---|---|---|\n"
          + cfg_line("c1", "c1 30 k vs 100 k, fixed map (15 outer iterations from the identity)")
-         + f"| c-main 30 k vs 1 M, dependent | {d['value']:.0f} / {O['scans_per_s']:.0f} | {d['ms_per_step']} / {O['ms_per_step']} | {100 * d['hbm_frac_whole_frame']:.2f} % | "
+         + f"| c-main 30 k vs 1 M, dependent | {d['value']:.0f} / {O['scans_per_s']:.0f} | {d['ms_per_step']} / {O['ms_per_step']} | {LZ.get('two_contexts', {}).get('scans_per_s', float('nan')):.0f} | {100 * d['hbm_frac_whole_frame']:.2f} % | "
            f"{cb['value']:.2f} at {cb['cores']} threads | {pp['max_dt_m']:.1e} / {pp['max_dtheta_rad']:.1e} ({pp['frames']} frames) |\n"
          + cfg_line("c3", "c3 HDL-64 130 k vs 5 M, dependent") + cfg_line("c5", "c5 250 k vs 20 M, dependent, IMU-like prior"))
 if roll:
     A = roll["A"]
     table += (f"| c-main, map resident on the device (`profiles/{TAG}_rolling_bench.json`) | {A['resident_two_contexts_scans_per_s']:.0f} on two contexts sharing the map, "
               f"{A['resident_scans_per_s']:.0f} on one; {A['keyframe_every_3_frames_two_contexts_scans_per_s']:.0f} / {A['keyframe_every_3_frames_scans_per_s']:.0f} with a keyframe every 3rd frame | "
-              f"{1e3 / A['resident_two_contexts_scans_per_s']:.3f}, {A['ms_per_frame']['resident']}; {1e3 / A['keyframe_every_3_frames_two_contexts_scans_per_s']:.3f} / {A['ms_per_frame']['keyframes']} | | | "
+              f"{1e3 / A['resident_two_contexts_scans_per_s']:.3f}, {A['ms_per_frame']['resident']}; {1e3 / A['keyframe_every_3_frames_two_contexts_scans_per_s']:.3f} / {A['ms_per_frame']['keyframes']} | | | | "
               f"{A['max_translation_diff_resident_vs_rebuild_m']:.1e} vs rebuild |\n")
 
 numbers = f'''Round-3 numbers (MI355X, `profiles/{TAG}_*`, all from one `scripts/refresh_profiles.sh` run): **{d["value"]:.0f} scans/s ({d["ms_per_step"]} ms/step)** for the
