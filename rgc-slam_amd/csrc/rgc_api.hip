@@ -647,8 +647,8 @@ int lazy_build(rgc_ctx* c, const float guess[16]) {
   double T[16];
   for (int i = 0; i < 16; i++) T[i] = (double)guess[i];
   int* counts = (int*)cl.segs.p + 1;  // [0] listed queries, [1] listed cells: behind the deferred-query counter, zeroed with it by k_rank_gather
-  rgck::footprint(s, c->src.in, c->src.stride_f, c->src.n, pose_from(T), cl.grid, (const int*)cl.start.p, (int*)cl.need.p, cl.need_stamp, c->lazy_margin,
-                  (int*)cl.qlist.p, (int*)cl.cell_list.p, counts);
+  rgck::footprint(s, c->src.in, c->src.stride_f, c->src.n, pose_from(T), cl.grid, (int*)cl.need.p, cl.need_stamp, c->lazy_margin, (const float4*)cl.P.p, n,
+                  (const int*)cl.start.p, (int*)cl.qlist.p, (int*)cl.cell_list.p, counts);
   const int q_est = cl.lazy_nq_seen >= 0 ? cl.lazy_nq_seen + cl.lazy_nq_seen / 4 + 4096 : n;
   const int c_est = cl.lazy_ncell_seen >= 0 ? cl.lazy_ncell_seen + cl.lazy_ncell_seen / 4 + 1024 : n / 8 + 1024;
   const int* guard = cl.spec_used ? c->d_small + 6 : nullptr;

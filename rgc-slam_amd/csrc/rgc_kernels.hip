@@ -1849,13 +1849,15 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
 // (A lane per grid cell, as before, spends 96 % of its lanes on empty cells and serialises one memory round trip per
 // point.)  The voxel id of a cell comes from the cell scan (cell_voxel, -1 for empty cells).
 // ------------------------------------------------------------------------------------------------
-// Lazy target: the cells of the map's grid the solve can look up -- every cell within `margin` cells (Chebyshev) of the cell a scan point
-// falls into at the guess (the look-up's own arithmetic, linearize_point) -- get this frame's stamp, and whoever stamps an OCCUPIED cell
-// first puts it on two lists: the cell (by its first point) for the voxel pass, its points for the bulk kNN launch.  Stamps, not flags:
-// nothing is cleared between frames.  counts: [0] listed queries, [1] listed cells (zeroed by k_rank_gather).  The lists' order is the
-// order of arrival; every listed query and cell is computed independently of the others, so the results do not depend on it.
-__global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, Pose T, Grid g, const int* __restrict__ start, int* __restrict__ need,
-                            int stamp, int margin, int* __restrict__ qlist, int* __restrict__ cell_list, int* __restrict__ counts) {
+// Lazy target, two passes.  k_footprint: the cells of the map's grid the solve can look up -- every cell within `margin` cells (Chebyshev)
+// of the cell a scan point falls into at the guess (the look-up's own arithmetic, linearize_point) -- get this frame's stamp: plain stores,
+// nothing is read and nothing cleared between frames (stamps, not flags).  k_lazy_lists: every sorted map point whose cell carries the
+// stamp puts itself on the query list of the bulk kNN launch, the first point of such a cell its cell on the list of the voxel pass (one
+// atomicAdd per wave and list; counts: [0] listed queries, [1] listed cells, zeroed by k_rank_gather).  The lists' order is the order of
+// arrival of the waves; every listed query and cell is computed independently of the others, so the results do not depend on it.
+// (Listing from inside the stamping pass -- whoever stamps a cell first appends its points -- made that pass read every cell it visits and
+// serialised the appends on a few thousand threads: 8 -> 220 us.)
+__global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, Pose T, Grid g, int* __restrict__ need, int stamp, int margin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* pp = in + (size_t)i * stride_f;
@@ -1872,16 +1874,30 @@ __global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, P
   const int z0 = max(cz - margin, 0), z1 = min(cz + margin, g.dim[2] - 1);
   for (int z = z0; z <= z1; z++)
     for (int y = y0; y <= y1; y++)
-      for (int x = x0; x <= x1; x++) {
-        const int c = cell_index(g, x, y, z);
-        if (need[c] == stamp) continue;                   // (most of a sweep's look-ups: somebody was here before)
-        if (atomicExch(&need[c], stamp) == stamp) continue;  // ... or is, at this moment: exactly one thread lists the cell
-        const int s0 = start[c], cnt = start[c + 1] - s0;
-        if (cnt <= 0) continue;
-        cell_list[atomicAdd(&counts[1], 1)] = s0;
-        const int at = atomicAdd(&counts[0], cnt);
-        for (int u = 0; u < cnt; u++) qlist[at + u] = s0 + u;
-      }
+      for (int x = x0; x <= x1; x++) need[cell_index(g, x, y, z)] = stamp;
+}
+__global__ void __launch_bounds__(256) k_lazy_lists(const float4* __restrict__ P, int n, Grid g, const int* __restrict__ start, const int* __restrict__ need,
+                                                    int stamp, int* __restrict__ qlist, int* __restrict__ cell_list, int* __restrict__ counts) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  bool want = false, head = false;
+  if (s < n) {
+    const float4 cp = P[s];
+    const int c = cell_index(g, cell_coord(cp.x, g) - g.minc[0], cell_coord(cp.y, g) - g.minc[1], cell_coord(cp.z, g) - g.minc[2]);
+    want = need[c] == stamp;
+    head = want && start[c] == s;
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned long long mw = __ballot(want), mh = __ballot(head);
+  int bq = 0, bc = 0;
+  if (lane == 0) {
+    if (mw) bq = atomicAdd(&counts[0], __popcll(mw));
+    if (mh) bc = atomicAdd(&counts[1], __popcll(mh));
+  }
+  bq = __shfl(bq, 0);
+  bc = __shfl(bc, 0);
+  if (want) qlist[bq + __popcll(mw & below)] = s;
+  if (head) cell_list[bc + __popcll(mh & below)] = s;
 }
 
 constexpr int VOX_T = 256;
@@ -3479,9 +3495,10 @@ void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, 
   if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
   else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
 }
-void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, const int* start, int* need, int stamp, int margin, int* qlist,
-               int* cell_list, int* counts) {
-  if (n > 0) hipLaunchKernelGGL(k_footprint, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, g, start, need, stamp, margin, qlist, cell_list, counts);
+void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, int* need, int stamp, int margin, const float4* P, int n_map,
+               const int* start, int* qlist, int* cell_list, int* counts) {
+  if (n > 0) hipLaunchKernelGGL(k_footprint, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, g, need, stamp, margin);
+  if (n_map > 0) hipLaunchKernelGGL(k_lazy_lists, dim3(nblk(n_map, 256)), dim3(256), 0, s, P, n_map, g, start, need, stamp, qlist, cell_list, counts);
 }
 void voxel_cells_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
                       double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const int* cell_list, const int* ncells,

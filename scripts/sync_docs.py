@@ -75,18 +75,33 @@ if roll:
               f"{1e3 / A['resident_two_contexts_scans_per_s']:.3f}, {A['ms_per_frame']['resident']}; {1e3 / A['keyframe_every_3_frames_two_contexts_scans_per_s']:.3f} / {A['ms_per_frame']['keyframes']} | | | | "
               f"{A['max_translation_diff_resident_vs_rebuild_m']:.1e} vs rebuild |\n")
 
-numbers = f'''Round-3 numbers (MI355X, `profiles/{TAG}_*`, all from one `scripts/refresh_profiles.sh` run): **{d["value"]:.0f} scans/s ({d["ms_per_step"]} ms/step)** for the
-dependent c-main sequence on two contexts, {O["scans_per_s"]:.0f} ({O["ms_per_step"]} ms) one frame at a time, {H["scans_per_s"]:.0f} with the scan's H2D and the output
-cloud inside the step; the replay of pre-framed maps (round 2's headline, 2781 then) {RP["scans_per_s"]:.0f}; pose parity vs CPU over {pp["frames"]}
+def traffic_line(name, f, alg):
+    if not f or not alg:
+        return ""
+    top = "; ".join(f"`{r['kernel']}` {r['MB_per_frame']:.0f}" for r in f["per_kernel"][:4])
+    return f"{name} {f['bytes_per_frame_measured'] / 1e6:.0f} MB measured / {alg / 1e6:.0f} MB algorithmic = **{f['bytes_per_frame_measured'] / alg:.2f} ×** (largest, MB per frame: {top})"
+tl = [traffic_line("c-main", ft, d["algorithmic_bytes_per_scan"]), traffic_line("c3", ft3, c.get("c3", {}).get("algorithmic_bytes_per_scan")),
+      traffic_line("c5", ft5, c.get("c5", {}).get("algorithmic_bytes_per_scan"))]
+traffic_txt = ("Frame-level HBM traffic, measured (`profiles/" + TAG + "_frame_traffic*.json`: one `rocprofv3 --pmc FETCH_SIZE` and one `WRITE_SIZE` pass over a dependent "
+               "sequence, EVERY kernel of a frame, 2 × FETCH_SIZE + WRITE_SIZE): " + "; ".join(x for x in tl if x) + ".\n") if any(tl) else ""
+lazy_txt = ""
+if LZ:
+    lazy_txt = (f"Lazy target (`lazy_target` in the bench line; `value` stays the full rebuild): covariances and voxels only within {LZ.get('margin_cells')} voxels of where the "
+                f"scan falls at the guess -- **{LZ['two_contexts']['scans_per_s']:.0f} scans/s** on two contexts ({LZ['two_contexts']['ms_per_step']} ms), "
+                f"{LZ['one_frame_at_a_time']['scans_per_s']:.0f} one frame at a time, the full rebuild's poses bit for bit, {LZ.get('solves_repeated_on_the_completed_map')} solve(s) repeated on the completed map.\n")
+
+numbers = f'''Round-4 numbers (MI355X, `profiles/{TAG}_*`, all from one `scripts/refresh_profiles.sh` run): **{d["value"]:.0f} scans/s ({d["ms_per_step"]} ms/step)** for the
+dependent c-main sequence on two contexts (round 3: 2301 in its own refresh run, 2399 in the driver's), {O["scans_per_s"]:.0f} ({O["ms_per_step"]} ms) one frame at a time, {H["scans_per_s"]:.0f} with the scan's H2D and the output
+cloud inside the step; the replay of pre-framed maps (round 2's headline, 2781 then; 3049 in round 3) {RP["scans_per_s"]:.0f}; pose parity vs CPU over {pp["frames"]}
 timed frames ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad; CPU port {cb["value"]:.2f} scans/s at the reference's {cb["cores"]} OpenMP threads (a reported
 baseline, not a target). Per step, one frame at a time (HIP events, separate pass with every stage bracketed): grid build
 {k["grid_build"]:.3f} ms (both clouds), kNN map {k["knn_cov_target"]:.3f} ms, voxel map + the map's deferred queries {k["voxel_build"]:.3f}, kNN scan {k["knn_cov_source"]:.3f} + {k["knn_coop_source"]:.3f}
 (second stream, overlapped), LM {k["linearize"]:.3f} ({d["mean_outer_iterations"]} outer iterations), fitness {k["fitness"]:.3f}.
 `profiles/{TAG}_kernel_stats.csv` (rocprofv3 `--kernel-trace --stats` of the same command): `k_knn_sp<20, true, true>` {knn_prof_us:.0f} µs average under
 the profiler, {u["roofline"]["avg_launch_ms"] * 1e3:.0f} µs from the library's events in that run, {R["avg_launch_ms"] * 1e3:.0f} µs unprofiled; alone the launch takes **{alone_us:.0f} µs**
-= {100 * R["frac_launch_alone"]:.2f} % of 8 TB/s on its 36 algorithmic MB ({100 * R["frac"]:.2f} % in the timed region; round 2: 156 µs, 2.85 %).
-
-The dominant kernel by the counters (`profiles/{TAG}_pmc_knn.json`, per 1 M-query launch): **{valu:.1f} VALU wave-instructions per query** (87.9 in
+= {100 * R["frac_launch_alone"]:.2f} % of 8 TB/s on its 36 algorithmic MB ({100 * R["frac"]:.2f} % in the timed region; round 3: 141 µs alone, 2.83 % in the timed region; round 2: 156 µs).
+{lazy_txt}{traffic_txt}
+The dominant kernel by the counters (`profiles/{TAG}_pmc_knn.json`, per 1 M-query launch): **{valu:.1f} VALU wave-instructions per query** (76.2 in round 3, 87.9 in
 round 2, 173 in round 1), {vmem_m:.2f} M vector loads, HBM traffic {traffic_mb:.1f} MB = {traffic_mb / 36:.1f} × algorithmic. Per wave of 64 queries
 (`profiles/{TAG}_lab_iters.json`): {lab["quads_in_scan_loop"] / w:.1f} trips of the scan loop, **{lab["chain_inserts"] / w:.1f} chain insert rounds** (65.1 before the
 buffers were drained only down to 8 keys), {lab["newton_steps"] / w:.1f} Newton steps, {lab["jacobi_fallbacks"]} Jacobi fallbacks and {lab["exact_tie_breaks"]} exact tie-breaks per launch.
@@ -141,22 +156,25 @@ open(P("DESIGN.md"), "w").write(put(s, numbers + "\n"))
 
 # ---------------- BASELINE.md §4
 B = d["algorithmic_bytes_per_scan"] / 1e6
-base = f'''Round 3, one MI355X, `python bench.py` (`profiles/{TAG}_bench.json`; everything under `profiles/{TAG}_*` is from the same run of
+base = f'''Round 4, one MI355X, `python bench.py` (`profiles/{TAG}_bench.json`; everything under `profiles/{TAG}_*` is from the same run of
 `scripts/refresh_profiles.sh`; this block is generated from those files by `scripts/sync_docs.py`). HIP = this repository's gfx950 path,
 target rebuilt every frame, inputs resident in HBM. c-main, c3 and c5 run as **dependent sequences** — frame i's target is the map
 re-expressed on the device in the body frame of the pose frame i − 1 produced (`RGC_odometer.cpp:1248-1256`), so only the scan's
 preparation can overlap the previous solve; c1, the reference's CPU-runnable case, registers against a fixed map. Two figures per
 configuration: two contexts taking turns (`value` of the bench line) / one frame at a time through the blocking `align()`; both give
 bit-identical poses (checked in every run). CPU = the C/OpenMP restatement (`oracle/`, the parity checker) on the GPU box's host at the
-reference's {cb["cores"]} OpenMP threads. The reference itself cannot be built (section 2), so there is no reference row.
+reference's {cb["cores"]} OpenMP threads. The reference itself cannot be built (section 2), so there is no reference row. The lazy-target
+column is `rgc_set_target_lazy(2)` -- covariances and voxels only where the solve can look, same poses bit for bit (DESIGN.md §5); the
+headline and every other column rebuild the whole target every frame like the reference.
 
 {table}| c2 sequence stand-in (24 sweeps × 28.8 k pts, front-end + frame body + ground factor, 3 keyframes), C++ node | reference semantics on the device {1e3 / node["cpp_reference_semantics_device_chain_ms_per_frame"]:.0f} sweeps/s, resident map + device chain {1e3 / node["cpp_resident_map_device_chain_ms_per_frame"]:.0f}, replay pipeline {1e3 / node["cpp_replay_pipeline_ms_per_frame"]:.0f} (`profiles/{TAG}_cpp_node_bench.json`) | {node["cpp_reference_semantics_device_chain_ms_per_frame"]:.2f} / {node["cpp_resident_map_device_chain_ms_per_frame"]:.2f} / {node["cpp_replay_pipeline_ms_per_frame"]:.2f} | | | ≤ 1e-4 vs the oracle frame body and vs the literal `ICP_thread` restatement (`tests/test_gpu_cpp_node.py`) |
 | c4 8 × (30 k vs 1 M) | measured by the driver (`bench.py --gpus 8`, one sequence and two contexts per rank, no collective) | | | | |
 | c-main, replay of pre-framed maps (round 2's headline: targets that do not depend on a pose) | {RP["scans_per_s"]:.0f} (round 2: 2781) | {RP["ms_per_step"]} | | | |
 
 Algorithmic bytes of a c-main scan (the formula above): B = {B:.1f} MB ⇒ {d["hbm_gbps_algorithmic"]:.0f} GB/s = {100 * d["hbm_frac_whole_frame"]:.1f} % of 8 TB/s for the whole frame.
+{traffic_txt}
 The dominant kernel (the map's bulk kNN + covariance launch, 36 B per point): {R["avg_launch_ms"] * 1e3:.0f} µs per launch in the timed region =
-{100 * R["frac"]:.2f} % of 8 TB/s; {alone_us:.0f} µs alone = {100 * R["frac_launch_alone"]:.2f} % (round 2: 156 µs, 2.85 %; round 1: 353 µs, 1.27 %); measured HBM traffic
+{100 * R["frac"]:.2f} % of 8 TB/s; {alone_us:.0f} µs alone = {100 * R["frac_launch_alone"]:.2f} % (round 3: 141 µs; round 2: 156 µs, 2.85 %; round 1: 353 µs, 1.27 %); measured HBM traffic
 {traffic_mb:.1f} MB per launch = {traffic_mb / 36:.1f} × algorithmic (`profiles/{TAG}_pmc_knn.json`).
 
 The north star's "≥ 50 % of HBM roofline" is the yardstick of a streaming kernel. This path's dominant kernel is an exact 20-NN: per
@@ -164,9 +182,9 @@ query it looks at ≈ 105 candidates (3×3×3 cells of a 1 m grid) and keeps the
 {100 * mix["half_rate_fraction"]:.0f} % of them compare / select / `med3` / fp64, which gfx950 issues at HALF rate (measured: 595 G wave-instr/s against 1060 for
 add / mul / fma, `profiles/r02_valu_issue.jsonl`). Against the peak weighted by that executed mix ({mix["peak_mix_weighted"]:.0f} G/s,
 `profiles/{TAG}_knn_isa_mix.json`) the launch alone runs at {100 * issue_alone / mix["peak_mix_weighted"]:.0f} %, with the vector-memory pipe about half busy beside it. What moves the number is
-fewer instructions AND fewer candidate loads per query (173 → 87.9 → {valu:.0f} instructions over three rounds; this round a half-resolution search
-grid that cuts the candidates by a third and two re-orderings of the block that cut only the selection work were built, measured and
-dropped — DESIGN.md §5), not bytes.
+fewer instructions AND fewer candidate loads per query (173 → 87.9 → 76.2 → {valu:.0f} instructions over four rounds), not bytes. Round 4
+left the kernel itself alone -- a simulation of lane-homogeneous waves put their gain at 2-6 % (`profiles/r04_knn_grouping_sim.json`) -- and
+went for what surrounds it and for work that need not be done: the lazy target computes {100 * 0.08:.0f} % of these queries.
 '''
 s = open(P("BASELINE.md")).read()
 open(P("BASELINE.md"), "w").write(put(s, base + "\n"))
@@ -174,7 +192,8 @@ open(P("BASELINE.md"), "w").write(put(s, base + "\n"))
 # ---------------- README.md
 readme = f'''* Measured on MI355X (`profiles/{TAG}_*`, one run): **{d["value"]:.0f} registered scans/s** on the headline workload — a DEPENDENT sequence: every
   30 k-point scan is registered to the 1 M-point map re-expressed in the previous pose's body frame on the device and rebuilt in full
-  (`RGC_odometer.cpp:1248-1256`) — on two contexts, {O["scans_per_s"]:.0f} one frame at a time; {RP["scans_per_s"]:.0f} for round 2's headline, the replay of pre-framed
+  (`RGC_odometer.cpp:1248-1256`) — on two contexts, {O["scans_per_s"]:.0f} one frame at a time; **{LZ.get("two_contexts", {{}}).get("scans_per_s", float("nan")):.0f}** with the lazy target (covariances and
+  voxels only where the solve can look, the same poses bit for bit); {RP["scans_per_s"]:.0f} for round 2's headline, the replay of pre-framed
   maps (2781 then); pose parity against the CPU oracle ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad over {pp["frames"]} timed frames; the CPU port runs
   {cb["value"]:.2f} scans/s at the reference's {cb["cores"]} OpenMP threads. c1 {c["c1"]["scans_per_s"]:.0f}, c3 {c["c3"]["scans_per_s"]:.0f}, c5 {c["c5"]["scans_per_s"]:.0f} scans/s{f"; {roll['A']['resident_two_contexts_scans_per_s']:.0f} scans/s against a map resident on the device" if roll else ""}.
   The dominant kernel (exact 20-NN + covariance of the 1 M-point map) takes {alone_us:.0f} µs alone, {valu:.0f} VALU wave-instructions per query, at
