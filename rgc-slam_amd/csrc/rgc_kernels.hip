@@ -1876,10 +1876,13 @@ __global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, P
     for (int y = y0; y <= y1; y++)
       for (int x = x0; x <= x1; x++) need[cell_index(g, x, y, z)] = stamp;
 }
-__global__ void __launch_bounds__(256) k_lazy_lists(const float4* __restrict__ P, int n, Grid g, const int* __restrict__ start, const int* __restrict__ need,
-                                                    int stamp, int* __restrict__ qlist, int* __restrict__ cell_list, int* __restrict__ counts) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & (WAVE - 1);
+constexpr int kListT = 1024;  // sixteen waves per workgroup: ONE atomicAdd per workgroup and list (same-address atomics cost ~12 ns each across the XCDs --
+                              // one per wave was 6 000 of them on one word: 63 us for a pass that moves 20 MB)
+__global__ void __launch_bounds__(kListT) k_lazy_lists(const float4* __restrict__ P, int n, Grid g, const int* __restrict__ start, const int* __restrict__ need,
+                                                       int stamp, int* __restrict__ qlist, int* __restrict__ cell_list, int* __restrict__ counts) {
+  __shared__ int wq[kListT / WAVE], wc[kListT / WAVE], base_s[2];
+  const int s = blockIdx.x * kListT + threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
   bool want = false, head = false;
   if (s < n) {
     const float4 cp = P[s];
@@ -1889,15 +1892,18 @@ __global__ void __launch_bounds__(256) k_lazy_lists(const float4* __restrict__ P
   }
   const unsigned long long below = (1ull << lane) - 1ull;
   const unsigned long long mw = __ballot(want), mh = __ballot(head);
-  int bq = 0, bc = 0;
-  if (lane == 0) {
-    if (mw) bq = atomicAdd(&counts[0], __popcll(mw));
-    if (mh) bc = atomicAdd(&counts[1], __popcll(mh));
+  if (lane == 0) { wq[w] = __popcll(mw); wc[w] = __popcll(mh); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tq = 0, tc = 0;
+#pragma unroll
+    for (int j = 0; j < kListT / WAVE; j++) { const int a = wq[j], b = wc[j]; wq[j] = tq; wc[j] = tc; tq += a; tc += b; }  // counts -> offsets inside the workgroup
+    base_s[0] = tq ? atomicAdd(&counts[0], tq) : 0;
+    base_s[1] = tc ? atomicAdd(&counts[1], tc) : 0;
   }
-  bq = __shfl(bq, 0);
-  bc = __shfl(bc, 0);
-  if (want) qlist[bq + __popcll(mw & below)] = s;
-  if (head) cell_list[bc + __popcll(mh & below)] = s;
+  __syncthreads();
+  if (want) qlist[base_s[0] + wq[w] + __popcll(mw & below)] = s;
+  if (head) cell_list[base_s[1] + wc[w] + __popcll(mh & below)] = s;
 }
 
 constexpr int VOX_T = 256;
@@ -3498,7 +3504,7 @@ void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, 
 void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, int* need, int stamp, int margin, const float4* P, int n_map,
                const int* start, int* qlist, int* cell_list, int* counts) {
   if (n > 0) hipLaunchKernelGGL(k_footprint, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, g, need, stamp, margin);
-  if (n_map > 0) hipLaunchKernelGGL(k_lazy_lists, dim3(nblk(n_map, 256)), dim3(256), 0, s, P, n_map, g, start, need, stamp, qlist, cell_list, counts);
+  if (n_map > 0) hipLaunchKernelGGL(k_lazy_lists, dim3(nblk(n_map, kListT)), dim3(kListT), 0, s, P, n_map, g, start, need, stamp, qlist, cell_list, counts);
 }
 void voxel_cells_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
                       double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const int* cell_list, const int* ncells,
