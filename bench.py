@@ -161,7 +161,7 @@ class DependentSequence:
         else:
             w.setInputSourceDevice(self.d_scans[i], self.n_scans[i], 16)
 
-    def run(self, first, count, Tw0, g0, overlap, from_host=False, on_result=None, prior_world=None):
+    def run(self, first, count, Tw0, g0, overlap, from_host=False, on_result=None, prior_world=None, stamps=None):
         """frames first .. first + count - 1.  Tw0: world pose before frame `first` (4x4 fp64), g0: its guess (relative, 4x4 fp32).
         prior_world[i]: a world-frame guess of frame i (an IMU-like prior) instead of the previous motion.
         Returns (motions [fp32 4x4], world poses [fp64 4x4], guesses used)."""
@@ -194,6 +194,8 @@ class DependentSequence:
                 cur.alignedToDevice(self.d_aligned[id(cur)], 16)              # pcl::transformPointCloud(*input_, output, final), left on the device
             if on_result is not None:
                 on_result(first + j, cur)
+            if stamps is not None:
+                stamps.append(time.perf_counter())      # (when this frame's result was in the host's hands)
             guesses.append(g)
             g = T
             motions.append(T)
@@ -480,7 +482,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    motions, worlds, guesses = seq.run(W, K, Tw_start, g_start, True)   # (per-frame counters are read in an untimed repetition below: 5 us of Python per frame)
+    step_stamps = [t_start]
+    motions, worlds, guesses = seq.run(W, K, Tw_start, g_start, True, stamps=step_stamps)   # (per-frame counters are read in an untimed repetition below: 5 us of Python per frame)
     pv.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
@@ -654,6 +657,9 @@ def main():
     out = {
         "metric": "registered scans/sec (16-beam -> 1M-pt map)", "value": round(scans_per_s, 3), "unit": "scans/s",
         "n_gpus": world_size, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
+        "timed_steps_ms": {"median": round(1e3 * float(np.median(np.diff(step_stamps))), 4), "max": round(1e3 * float(np.max(np.diff(step_stamps))), 4),
+                           "slowest_step": int(np.argmax(np.diff(step_stamps))),
+                           "what": "host time between consecutive results inside the timed region of rank 0 (a one-off stall -- an allocation, a speculative-grid miss -- shows here, not in the kernels)"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 points and neighbour search, f64 covariances and solve",
         "data": "synthetic",
         "config": {"workload": f"c-main: a dependent sequence of synthetic VLP-16 {args.n_source}-pt scans, each registered to the {args.n_target}-pt local "

@@ -40,6 +40,7 @@ roll, node, pipe, longr = load("rolling_bench.json"), load("cpp_node_bench.json"
 fe, mr, ic = load("frontend_bench.json"), load("mapreg_bench.json"), load("icp_bench.json")
 ft, ft3, ft5 = load("frame_traffic.json"), load("frame_traffic_c3.json"), load("frame_traffic_c5.json")
 LZ = d.get("lazy_target") or {}
+LZ2 = (LZ.get("two_contexts") or {}).get("scans_per_s", float("nan"))
 R, IR, O, RP, H, pp, cb, k = (d["roofline"], d["issue_roofline"], d["one_frame_at_a_time"], d["replay_of_preframed_maps"], d["scan_h2d_and_output"],
                               d["pose_parity_vs_cpu"], d["cpu_baseline"], d["kernel_ms_per_step"])
 c = {x["config"][:2]: x for x in d.get("configs", [])}
@@ -134,7 +135,7 @@ if node:
                 f"reference semantics {node['cpp_reference_semantics_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_median_ms', float('nan')):.2f} ms host-staged and "
                 f"**{node['cpp_reference_semantics_device_chain_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_device_chain_median_ms', float('nan')):.2f} ms on the device** (round 2: 1.08); "
                 f"resident map {node['cpp_resident_map_ms_per_frame']:.2f} / {node.get('cpp_resident_map_median_ms', float('nan')):.2f} host-staged "
-                f"(slowest timed frame {node.get('cpp_resident_map_slowest_timed_frame_ms', float('nan')):.1f} ms: one `hipMemcpyAsync` of a filter's output into pageable host memory takes 7 ms once per process, `scripts/prof_node_hip_api.sh`), "
+                f"(slowest timed frame {node.get('cpp_resident_map_slowest_timed_frame_ms', float('nan')):.1f} ms; round 3: 8.8 ms, one copy of a filter's output into pageable host memory -- the node's staging vectors are page-locked since round 4, `rgc::PinnedAllocator`), "
                 f"{node['cpp_resident_map_device_chain_ms_per_frame']:.2f} / {node.get('cpp_resident_map_device_chain_median_ms', float('nan')):.2f} with `device_chain`; "
                 f"`ReplayPipeline` {node['cpp_replay_pipeline_ms_per_frame']:.2f} ms per sweep.")
     if pipe:
@@ -192,7 +193,7 @@ open(P("BASELINE.md"), "w").write(put(s, base + "\n"))
 # ---------------- README.md
 readme = f'''* Measured on MI355X (`profiles/{TAG}_*`, one run): **{d["value"]:.0f} registered scans/s** on the headline workload — a DEPENDENT sequence: every
   30 k-point scan is registered to the 1 M-point map re-expressed in the previous pose's body frame on the device and rebuilt in full
-  (`RGC_odometer.cpp:1248-1256`) — on two contexts, {O["scans_per_s"]:.0f} one frame at a time; **{LZ.get("two_contexts", {{}}).get("scans_per_s", float("nan")):.0f}** with the lazy target (covariances and
+  (`RGC_odometer.cpp:1248-1256`) — on two contexts, {O["scans_per_s"]:.0f} one frame at a time; **{LZ2:.0f}** with the lazy target (covariances and
   voxels only where the solve can look, the same poses bit for bit); {RP["scans_per_s"]:.0f} for round 2's headline, the replay of pre-framed
   maps (2781 then); pose parity against the CPU oracle ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad over {pp["frames"]} timed frames; the CPU port runs
   {cb["value"]:.2f} scans/s at the reference's {cb["cores"]} OpenMP threads. c1 {c["c1"]["scans_per_s"]:.0f}, c3 {c["c3"]["scans_per_s"]:.0f}, c5 {c["c5"]["scans_per_s"]:.0f} scans/s{f"; {roll['A']['resident_two_contexts_scans_per_s']:.0f} scans/s against a map resident on the device" if roll else ""}.
