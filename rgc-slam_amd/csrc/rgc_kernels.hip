@@ -1259,8 +1259,11 @@ void lab_why(int* out8) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_why), z, sizeof(z));
 }
 #endif
-template <int KC, int KB, int R, int T, bool kExact>
-__device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
+// kFinal = false (the scan's bulk launch, block radius R): a query whose block holds fewer than k points, or whose k-th neighbour is not
+// provably inside the block, is NOT deferred: the function returns true and the caller runs the search again on the next larger block
+// (k_knn_sp: R = 1, then R = 2 -- the same four lanes, at once) before anything goes to the cooperative kernel.
+template <int KC, int KB, int R, int T, bool kExact, bool kFinal = true>
+__device__ __forceinline__ bool knn_point_split(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int k,
                                                 int i, int sub, int* lds, const Deferred& df, double* __restrict__ nx,
                                                 double* __restrict__ ny, double* __restrict__ nz) {
   constexpr bool kClip = true;
@@ -1291,7 +1294,7 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   const int nr = sp_piece_table<kClip, R, T>(start, g, c, q, tmix, tlo, heavy_piece);
   if (heavy_piece) {
     defer(i, INFINITY, 1);
-    return;
+    return false;
   }
   // ---- one pass over this lane's quarter of the candidate stream ----
   Chain<Ls> top;
@@ -1405,7 +1408,7 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   if (__any(bp != buf)) drain();
   if (overflow) {
     defer(i, INFINITY, 2);
-    return;
+    return false;
   }
   // ---- the k + 2 smallest keys of the union, in every lane of the quad ----
   Chain<L> all;
@@ -1435,11 +1438,12 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   }
   if (quad_or_i(top.a[Ls - 1] < a_kp1 ? 1 : 0)) {  // a full chain whose tail ranks inside the merged k + 2: a needed key may have been dropped
     defer(i, INFINITY, 3);
-    return;
+    return false;
   }
   if (a_km1 >= 0x7f800000) {  // fewer than k candidates in the block
+    if (!kFinal) return true;  // fewer than k candidates in this block: the next larger one
     defer(~i, INFINITY, 4);
-    return;
+    return false;
   }
   auto index_of = [&](int key) {  // ordinal -> position in the sorted array (the lanes' tables are identical)
     const int o = key & kKeyOrd;
@@ -1465,12 +1469,13 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
   const double bound = cube_bound(g, c, q, R);
   const bool proven = (bound == 1.0e300) || (bound > 0.0 && (double)thr_up < bound * bound * (1.0 - 1e-5));
   if (!proven) {
+    if (!kFinal) return true;  // the k-th neighbour found may not be the true one: the next larger block decides
     defer(~i, (double)thr_up < 3.0 * (R + 1) * (R + 1) * g.res * g.res ? thr_up : INFINITY, 5);
-    return;
+    return false;
   }
   if (!decided) {
     defer(i, thr_up, 6);
-    return;
+    return false;
   }
   // ---- moments of neighbours sub, sub + 4, ... in this lane, summed over the quad (one-pass form of knn_point_sp) ----
   const int idx_k = swap ? index_of(a_k) : 0;
@@ -1517,6 +1522,7 @@ __device__ __forceinline__ void knn_point_split(const float4* __restrict__ P, co
     ny[i] = nrm[1];
     nz[i] = nrm[2];
   }
+  return false;
 }
 
 // kTarget names the two instantiations (map vs scan) for the profiles and picks their shape:
@@ -1564,7 +1570,13 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
 #ifdef RGC_LAB
     const long long lab_t0 = wall_clock64();
 #endif
-    if (i < n) knn_point_split<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz);
+    // A query the 3x3x3 block does not settle -- too few points in it, or a k-th neighbour that a closer point outside it could
+    // displace: the sparse far field of a sweep, 12 % of a VLP-16's queries -- is searched again on the 5x5x5 block by the same four lanes,
+    // at once: 97 % of them settle there, and a wave of the far field has few candidates either way.  (They used to go to the
+    // cooperative kernel, a wave per query and four dependent passes each: the longest launch of the scan's preparation.)
+    if (i < n && knn_point_split<KC, Cfg::KB, Cfg::R, Cfg::T, kExact, Cfg::R >= 2>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz)) {
+      if constexpr (Cfg::R < 2) knn_point_split<KC, Cfg::KB, 2, Cfg::T, kExact, true>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz);
+    }
 #ifdef RGC_LAB
     if (threadIdx.x == 0 && b < 8192) { g_lab_wave[2 * b] = lab_t0; g_lab_wave[2 * b + 1] = wall_clock64(); }
 #endif
@@ -3464,7 +3476,8 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   using CT = SpConfig<true>;
   using CS = SpConfig<false>;
   const int T = is_target ? CT::T : CS::T;
-  const size_t lds = (size_t)(is_target ? SpShape<CT::R, CT::kClip>::LDS : SpShape<CS::R, CS::kClip>::LDS) * T * sizeof(int);
+  // (the scan's launch lays its per-lane LDS columns out for the 3x3x3 block and again, for the queries that block does not settle, for the 5x5x5 one)
+  const size_t lds = (size_t)(is_target ? SpShape<CT::R, CT::kClip>::LDS : std::max(SpShape<CS::R, CS::kClip>::LDS, SpShape<2, CS::kClip>::LDS)) * T * sizeof(int);
   // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n); lazy target: as many blocks as the listed queries are
   // expected to fill (the kernel strides over the list whatever its true length)
   const int n_launch = (is_target && qlist) ? (q_est < T ? T : (q_est > n ? n : q_est)) : n;
