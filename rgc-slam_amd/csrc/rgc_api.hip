@@ -378,8 +378,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   // recorded on the main stream BEFORE this frame's map preparation was enqueued (waiting for the map's kNN launch would serialise
   // the two) -- i.e. at rgc_set_target*, or here when no map preparation is pending.  See rgc_set_source_device in rgc_hip.h.
   if (!is_target && c->main_has_target_prep && map_prep_finished(c)) c->main_has_target_prep = false;  // it has drained
+  // (the map's own mark goes BEHIND its counting pass: the record is a call of its own in front of the dependent sequence's first launch, and
+  // a scan that waits for one 17 us kernel more has lost nothing -- its preparation is enqueued after the map's whole chain anyway)
+  bool mark_behind_count = false;
   if (is_target || !c->main_has_target_prep || c->main_late_producer) {
-    HIPCHK(c, hipEventRecord(c->main_mark, c->stream));
+    if (is_target) mark_behind_count = true;
+    else HIPCHK(c, hipEventRecord(c->main_mark, c->stream));
     c->mark_valid = true;
     c->main_late_producer = false;
   }
@@ -522,6 +526,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     }  // (a smaller grid leaves the counters beyond it as clean as they were: a re-framed map's box breathes with the yaw)
     rgck::count_cells(s, cl.in, cl.stride_f, n, g, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)cl.cnt.p, hi, spec ? dsm + 6 : nullptr,
                       fuse_reframe ? &cl.rf : nullptr);
+    if (mark_behind_count) HIPCHK(c, hipEventRecord(c->main_mark, c->stream));
     rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)ntot, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
                      is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23));
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (unsigned long long*)cl.order_tmp.p, hi);
@@ -1484,7 +1489,9 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
       tail = other;
     }
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, tail));
+  // (a solve that POSTS its finished state needs no stream-ordered copy of it: the one case that reads the state otherwise -- a batch that
+  // ends without a finished solve -- fetches it with a blocking copy once the stream has drained, rgc_align_end)
+  if (!post) HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, tail));
   HIPCHK(c, hipEventRecord(c->lm_tail, tail));
   c->lm_tail_stream = tail;
   return RGC_OK;
@@ -1583,8 +1590,9 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
     bool posted = false;
     if (c->post_on && c->d_post) {
       volatile int* gen = &c->h_post->gen;
-      for (;;) {
+      for (unsigned spin = 0;; spin++) {
         if (*gen == c->lm_seq) { posted = true; break; }
+        if (spin & 31u) continue;  // the posted word is the usual way out: look at it often, at the event now and then
         const hipError_t q = hipEventQuery(c->lm_tail);  // (recorded behind the batch's last launch and its copy of the state, on whichever stream they went to)
         if (q == hipSuccess) { posted = *gen == c->lm_seq; break; }
         if (q != hipErrorNotReady) return fail(c, RGC_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
@@ -1597,6 +1605,7 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
     }
     if (!posted) {
       HIPCHK(c, hipStreamSynchronize(c->lm_tail_stream));
+      if (c->post_on && c->d_post) HIPCHK(c, hipMemcpy(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost));  // (no copy was chained)
       memcpy(&S, c->h_lm, sizeof(S));
     }
     HIPCHK(c, hipGetLastError());
