@@ -152,6 +152,7 @@ struct rgc_ctx {
   hipEvent_t src_in_ready = nullptr;  // recorded on stream2 behind a HOST scan's upload: the lazy target's footprint pass (main stream) reads the scan's input
   bool src_in_pending = false;
   int lm_seq = 0;                  // number of the pending solve (1, 2, ...)
+  int lm_j = 0;                    // launches enqueued for it so far (rgck::lm_step's launch number: the state image alternates with it)
   rgck::LmState lm_res{};          // the finished solve's state as rgc_align_end took it (from h_post or h_lm): nothing writes it asynchronously
   hipEvent_t lm_mid = nullptr;     // recorded on the solve's stream behind its expected launches: the spare ones, on the context's other stream, wait for it
   hipEvent_t lm_tail = nullptr;    // recorded behind every batch of LM launches (and its copy into h_lm) on the stream they went to
@@ -1447,20 +1448,20 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
   constexpr int kSpare = 3;
   // the stage-by-stage pass (events around the solve's regions) keeps the two apart: all steps, then the score
   const bool staged = c->prof_on && ((c->prof_mask >> RGC_K_LINEARIZE) & 1u || (c->prof_mask >> RGC_K_FITNESS) & 1u);
-  // The score is chained INTO the steps: the solve's last step (known in advance: a try below the convergence thresholds ends the solve
-  // either way) scores the pose it accepts and posts the result; if the solve ends otherwise, the next launch -- a blind one on a
-  // finished solve -- computes the score (k_lm_step).  No separate score launches, no blind steps between the deciding step and the score.
+  // The score is chained INTO the steps: the launch whose decision ends the solve scores the final pose and posts the result (k_lm_step).
+  // No separate score launches, no blind steps between the deciding launch and the score.
   const bool fit_in_steps = want_fitness && !staged;
+  if (open) c->lm_j = 0;
   auto step = [&](const rgck::LmInit* op, hipStream_t on) {
     rgck::lm_step(on, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
                   c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p,
-                  (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, op, c->d_small + 7,
+                  (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, c->lm_j++, op, c->d_small + 7,
                   c->tgt.segs.p, c->src.segs.p, post, seq, fit_in_steps ? (const float4*)c->tgt.P.p : nullptr,
                   fit_in_steps ? (const int*)c->tgt.start.p : nullptr, fit_in_steps ? (double*)c->fit_partials.p : nullptr, c->tgt.n,
                   c->tgt.lazy == 2 ? (const int*)c->tgt.need.p : nullptr, c->tgt.need_stamp, c->tgt.lazy == 2 ? (const int*)c->tgt.segs.p + 1 : nullptr);
   };
-  auto score = [&]() {  // getFitnessScore at the final pose, chained blindly
-    rgck::fitness_lm(s, (const float4*)c->src.P.p, n, (rgck::LmState*)c->lm_state.p, (const float4*)c->tgt.P.p,
+  auto score = [&]() {  // getFitnessScore at the final pose, chained blindly (on the image the last launch left)
+    rgck::fitness_lm(s, (const float4*)c->src.P.p, n, rgck::lm_image((rgck::LmState*)c->lm_state.p, c->lm_j - 1), (const float4*)c->tgt.P.p,
                      (const int*)c->tgt.start.p, c->tgt.grid, (double*)c->fit_partials.p, post, c->lm_seq, c->tgt.n);
   };
   hipStream_t tail = s;
@@ -1491,7 +1492,7 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
   }
   // (a solve that POSTS its finished state needs no stream-ordered copy of it: the one case that reads the state otherwise -- a batch that
   // ends without a finished solve -- fetches it with a blocking copy once the stream has drained, rgc_align_end)
-  if (!post) HIPCHK(c, hipMemcpyAsync(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost, tail));
+  if (!post) HIPCHK(c, hipMemcpyAsync(c->h_lm, rgck::lm_image((rgck::LmState*)c->lm_state.p, c->lm_j - 1), sizeof(rgck::LmState), hipMemcpyDeviceToHost, tail));
   HIPCHK(c, hipEventRecord(c->lm_tail, tail));
   c->lm_tail_stream = tail;
   return RGC_OK;
@@ -1542,7 +1543,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   const int nb = rgck::linearize_blocks(n);
   if ((rc = ensure(c, c->corr_v2, sizeof(int) * (size_t)n * noff))) return rc;
   if ((rc = ensure(c, c->corr_M2, sizeof(double) * 6 * (size_t)n * noff))) return rc;
-  if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 2) * (size_t)nb))) return rc;
+  if ((rc = ensure(c, c->partials, sizeof(double) * (rgck::kAccum + 2) * (size_t)nb * 2))) return rc;  // (two halves: rgck::lm_step)
   if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
   if (!c->lm_state.p) {
     if ((rc = ensure(c, c->lm_state, 4096))) return rc;
@@ -1556,16 +1557,15 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   in.rot_eps = P.rotation_eps; in.trans_eps = P.translation_eps; in.init_factor = P.lm_init_lambda_factor;
   in.max_outer = P.max_iterations; in.max_inner = P.lm_max_iterations;
   c->stats.n_linearize = c->stats.n_error = c->stats.outer_iterations = 0;
-  // One linearisation + fused cost / linearise steps, enqueued blind: enough for the outer iterations the PREVIOUS solve on this context
-  // took plus two (consecutive frames of a sequence need about the same number; a launch on a finished solve costs ~2 us, a
-  // read-back and a second batch ~40), at least the six that cover a tracking frame, at most what max_iterations allows.
-  // (a solve of o outer iterations needs o + 1 launches: the opening linearisation and one step per try -- and one more when its last try
-  // is rejected: the score is then computed by the launch behind it.  As many as the previous solve needed plus that one stay on the
-  // solve's stream -- a launch too many there costs ~5 us in front of the next frame, one too few a ~13 us hop to the other stream --,
-  // three more go aside as spares: lm_enqueue_batch)
+  // The launches are enqueued blind: enough for the outer iterations the PREVIOUS solve on this context took (consecutive frames of a
+  // sequence need about the same number; a launch on a finished solve costs ~5 us of its stream's time, a read-back and a second batch
+  // ~40), at least the six that cover a tracking frame, at most what max_iterations allows.
+  // (a solve of o outer iterations without a rejected try needs o + 2 launches: the opening linearisation, one per try, and the one
+  // whose decision ends it and scores the pose.  That many plus one stay on the solve's stream -- a launch too many there costs ~5 us in
+  // front of the next frame, one too few a ~13 us hop to the other stream --, three more go aside as spares: lm_enqueue_batch)
   int batch = 9;
-  if (c->lm_last_outer + 5 > batch) batch = c->lm_last_outer + 5;
-  if (batch > P.max_iterations + 1) batch = P.max_iterations + 1;
+  if (c->lm_last_outer + 6 > batch) batch = c->lm_last_outer + 6;
+  if (batch > P.max_iterations + 2) batch = P.max_iterations + 2;
   if (batch < 2) batch = 2;
   c->lm_seq = c->lm_seq >= 0x3fffffff ? 1 : c->lm_seq + 1;
   if ((rc = lm_enqueue_batch(c, batch, &in, want_fitness != 0))) return rc;
@@ -1605,7 +1605,8 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
     }
     if (!posted) {
       HIPCHK(c, hipStreamSynchronize(c->lm_tail_stream));
-      if (c->post_on && c->d_post) HIPCHK(c, hipMemcpy(c->h_lm, c->lm_state.p, sizeof(rgck::LmState), hipMemcpyDeviceToHost));  // (no copy was chained)
+      if (c->post_on && c->d_post)  // (no copy was chained)
+        HIPCHK(c, hipMemcpy(c->h_lm, rgck::lm_image((rgck::LmState*)c->lm_state.p, c->lm_j - 1), sizeof(rgck::LmState), hipMemcpyDeviceToHost));
       memcpy(&S, c->h_lm, sizeof(S));
     }
     HIPCHK(c, hipGetLastError());

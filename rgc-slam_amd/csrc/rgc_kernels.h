@@ -49,7 +49,7 @@ struct LmState {  // device-resident state of LsqRegistration::computeTransforma
   int phase, done, conv, failed, outer, inner, n_lin, n_err, ncorr, ticketA, ticketB, max_outer, max_inner, has_fit;
   double fit_sum;                // sum of squared NN distances at the final pose (k_fitness_lm)
   int nvox, def_t, def_s, pad;   // frame counters carried home with the state; pad = grid guards, map | scan << 8
-  int gen, cmd, mode, cur;       // step kernels: mode, valid correspondence buffer (gen, cmd: unused, kept for the layout)
+  int gen, cmd, mode, cur;       // step kernels: mode, valid correspondence buffer; gen: the posted solve's number (host image); cmd, ticketA: unused
   float src_sq; int pad2;        // sum over the scan's grid cells of count^2 (how crowded its cells are; steers the scan's cell size); pad2: the lazy target's miss flag
   int lazy_nq, lazy_ncell;       // lazy target: listed queries / cells of this frame (size the next frame's launches)
 };
@@ -116,14 +116,18 @@ void compute_error(hipStream_t s, const float4* P, int n, Pose T, const double* 
 void lm_try(hipStream_t s, double* out, const int* ncorr, LmIn in);
 void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev, const double* vox, int noff, const int* corr_v,
                        const double* corr_M, double* partials, double* out1);
-// one step of the device-chained LM (see k_lm_step); corr_*0 / corr_*1 are the two correspondence buffers, st->cur the valid one
+// launch number j of a solve of the device-chained LM (see k_lm_step; 0 opens the solve and takes *open); corr_*0 / corr_*1 are the two
+// correspondence buffers, the finished state's `cur` the valid one.  st: the 4096-byte LM area, zeroed once -- two state images (launch j
+// reads image (j - 1) & 1 and leaves image j & 1: lm_image(st, j_last) is the latest) and the loose words behind them.  partials:
+// 2 * linearize_blocks(n) rows of kAccum + 2 doubles (the launches alternate between the halves).
+inline LmState* lm_image(LmState* st, int j_last) { return st + (j_last & 1); }
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
-             const LmInit* first /* non-null: this launch opens a solve */, const int* nvox, const void* segs_t, const void* segs_s,
+             int j, const LmInit* open, const int* nvox, const void* segs_t, const void* segs_s,
              LmState* h_post = nullptr /* mapped host memory: a finished state is posted there, then seq in its `gen` */,
              int seq = 0 /* > 0: post when done; < 0: post when done AND scored (by this kernel or fitness_lm) */,
-             // the fitness score chained to the solve (all non-null): the solve's LAST step scores the pose it accepts, a launch on a finished
-             // solve without a score computes it; TP / tstart: the map's sorted points and cell starts, nt its point count
+             // the fitness score chained to the solve (all non-null): the launch whose decision ends the solve scores the final pose (as does a
+             // launch on a finished solve without a score); TP / tstart: the map's sorted points and cell starts, nt its point count
              const float4* TP = nullptr, const int* tstart = nullptr, double* fit_partials = nullptr, int nt = 0,
              // lazy target: the target is built for the cells stamped lazy_stamp in lazy_need[] only -- a look-up of any other occupied voxel
              // raises LmState::pad2; lazy_counts: the lists' sizes, carried home in LmState::lazy_nq / lazy_ncell

@@ -2378,16 +2378,7 @@ __device__ __forceinline__ bool lm_is_converged(const double* d, double rot_eps,
   return m < 1;
 }
 
-// One STEP kernel of the device-chained LM.  st->mode selects what the launch does:
-//   LM_MODE_LIN  linearise at x0 (correspondences -> buffer cur), fold, LM try -> xi;                    next: BA
-//   LM_MODE_BA   cost at the trial pose xi over the FROZEN correspondences of buffer cur (compute_error, :144) AND,
-//                speculatively, the next linearisation AT xi into buffer cur^1.  The last arriver folds both: rho >= 0
-//                (the usual case) accepts x0 = xi and -- unless the solve is over -- adopts the speculative H, b, y0 and
-//                correspondences (cur ^= 1) and performs the next LM try at once: ONE launch per outer iteration instead
-//                of two.  rho < 0 discards the speculation, raises lambda, retries with the old H, b;          next: B
-//   LM_MODE_B    cost only (a retry of the same linearisation); accept -> next: LIN, reject -> B again.
-// The arithmetic of each adopted linearisation / cost evaluation is exactly that of the two-kernel slots; the speculative
-// linearisation at the final pose is never adopted, so buffer cur holds what the reference's last linearize() left.
+// The modes of a launch of the device-chained LM (k_lm_step below):
 constexpr int LM_MODE_LIN = 0, LM_MODE_BA = 1, LM_MODE_B = 2;
 constexpr int kStepAcc = kAccum + 2;  // 28 linearisation sums, the correspondence count, the trial cost
 
@@ -2432,30 +2423,33 @@ __device__ __forceinline__ void reinit_small_blocks(const int* nvox) {
   t[23] = 0;
 }
 
-// The decision of one STEP launch, taken by lane 0 of the last-arriving workgroup on the LDS copy `ls` of the state: what the
-// folded sums mean in this mode, accept / reject / terminate, and the next LM try (lsq_registration_impl.hpp:125-172).
-__device__ __forceinline__ void lm_step_decide(LmState& ls, const double* folded, int first, const LmInit& in, int mode, int cur,
-                                               const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s,
-                                               bool* took_xi) {
-  if (first) {  // fresh state (:53-63) plus the frame's counters, so that ONE read-back at the end carries every statistic
+// The fresh state of a solve (:53-63) plus the frame's counters, on a zeroed image (k_lm_step's opening launch, lane 0 of workgroup 0).
+__device__ __forceinline__ void lm_state_open(LmState& ls, const LmInit& in, const int* __restrict__ nvox, const int* __restrict__ def_t,
+                                              const int* __restrict__ def_s) {
 #pragma unroll
-    for (int a = 0; a < 16; a++) ls.x0[a] = in.x0[a];
-    ls.lambda = -1.0;  // :56
-    ls.nu = 2.0;
+  for (int a = 0; a < 16; a++) ls.x0[a] = in.x0[a];
+  ls.lambda = -1.0;  // :56
+  ls.nu = 2.0;
 #pragma unroll
-    for (int a = 0; a < 6; a++) ls.Hfin[a * 7] = 1.0;  // final_hessian_.setIdentity(), :21
-    ls.rot_eps = in.rot_eps;
-    ls.trans_eps = in.trans_eps;
-    ls.init_factor = in.init_factor;
-    ls.max_outer = in.max_outer;
-    ls.max_inner = in.max_inner;
-    ls.nvox = nvox ? *nvox : 0;
-    ls.pad = nvox ? (nvox[-1] | (nvox[15] << 8)) : 0;
-    ls.def_t = def_t ? *def_t : 0;
-    ls.def_s = def_s ? *def_s : 0;
-    ls.src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;
-    if (nvox) reinit_small_blocks(nvox);
-  }
+  for (int a = 0; a < 6; a++) ls.Hfin[a * 7] = 1.0;  // final_hessian_.setIdentity(), :21
+  ls.rot_eps = in.rot_eps;
+  ls.trans_eps = in.trans_eps;
+  ls.init_factor = in.init_factor;
+  ls.max_outer = in.max_outer;
+  ls.max_inner = in.max_inner;
+  ls.nvox = nvox ? *nvox : 0;
+  ls.pad = nvox ? (nvox[-1] | (nvox[15] << 8)) : 0;  // grid guards of map and scan (d_small[6], [22])
+  ls.def_t = def_t ? *def_t : 0;
+  ls.def_s = def_s ? *def_s : 0;
+  ls.src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;  // d_small[23]
+  if (nvox) reinit_small_blocks(nvox);
+}
+
+// The decision the sums of one launch call for, taken by lane 0 of a workgroup on its LDS copy `ls` of the state the launch ran from:
+// what the folded sums mean in that launch's mode, accept / reject / terminate, and the next LM try (lsq_registration_impl.hpp:125-172).
+__device__ __forceinline__ void lm_step_decide(LmState& ls, const double* folded, int mode, int cur, bool* took_xi) {
+  const int first = 0;  // (the developer build's timestamps: slot of a launch that decides)
+  (void)first;
   double H[36], b[6], x0[16], d[6], delta[16], xi[16];
   double lambda = ls.lambda;
   bool have_lin = false;  // H, b (registers) hold a linearisation at the pose the next try starts from
@@ -2601,64 +2595,125 @@ __device__ __forceinline__ void step_fitness_rows(const float4* __restrict__ SP,
   if (((int)threadIdx.x & (WAVE - 1)) == 0) __hip_atomic_store(&fa.partials[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The words of the LM area that are NOT part of either state image (rgc_api.hip allocates 4096 bytes and zeroes them once):
+//   +3072  the lazy target's miss flag ("a look-up hit an occupied voxel outside the part that was built"), set by any workgroup of any
+//          launch of a solve, taken into the finished state (pad2) and cleared by whoever finishes it
+//   +3076  the ticket of the score's fold (the one launch of a solve whose workgroups hand rows to each other)
+static_assert(2 * sizeof(LmState) <= 3072, "two state images in front of the area's loose words");
+__device__ __forceinline__ int* lm_area_miss(LmState* st) { return reinterpret_cast<int*>(reinterpret_cast<char*>(st) + 3072); }
+__device__ __forceinline__ int* lm_area_ticket(LmState* st) { return reinterpret_cast<int*>(reinterpret_cast<char*>(st) + 3076); }
+
+// One launch of the device-chained LM, launch number j of its solve (the host counts; 0 opens the solve).
+//
+// EVERY workgroup takes the decision the previous launch's sums call for, by itself: it reads the state image the previous launch
+// left (st[(j-1) & 1]) and that launch's rows, folds them in the fixed order, and its lane 0 runs accept / reject / terminate and the
+// next LM try (lm_step_decide) on an LDS copy -- the same inputs and the same code in every workgroup, hence the same state.  Then it
+// does this launch's per-point work at the pose that decision produced and stores its row; workgroup 0 also stores the state image
+// (st[j & 1]: never the one the launch reads).  No workgroup waits for another inside a step: the kernel boundary is the only
+// synchronisation (the former step had both -- a ticket, a last arriver that fetched everyone's rows, decided and tried alone while
+// the launch's other 117 workgroups had left: ~2.8 us of a 14 us step).
+//
+// What a launch does at the pose it arrives at (ls.mode, after the decision):
+//   LM_MODE_LIN  linearise at x0 (correspondences -> buffer cur);                                                          next: BA
+//   LM_MODE_BA   cost at the trial pose xi over the FROZEN correspondences of buffer cur (compute_error, :144) AND, speculatively, the
+//                next linearisation AT xi into buffer cur^1.  The next launch's decision: rho >= 0 (the usual case) accepts x0 = xi
+//                and -- unless the solve is over -- adopts the speculative H, b, y0 and correspondences (cur ^= 1) and tries again at
+//                once: ONE launch per outer iteration.  rho < 0 discards the speculation, raises lambda, retries with the old H, b;   next: B
+//   LM_MODE_B    cost only (a retry of the same linearisation); accept -> next: LIN, reject -> B again.
+// A try whose delta is already below the convergence thresholds ends the solve whatever its cost turns out to be: its launch skips the
+// speculative linearisation.  The arithmetic of each adopted linearisation / cost evaluation is exactly that of the two-kernel slots; the
+// speculative linearisation at the final pose is never adopted, so buffer cur holds what the reference's last linearize() left.
+//
+// The launch whose decision ENDS the solve computes getFitnessScore at the final pose (fa.on; the same grid covers the scan: four
+// waves per workgroup, one row per wave), its last-arriving workgroup folds the rows into the state and posts it to the host.  A
+// launch on a finished solve only hands the state image on (workgroup 0: st[(j-1) & 1] -> st[j & 1]) so that the host finds the
+// latest image behind its last launch whatever their number.
 __global__ void __launch_bounds__(LIN_T)
 k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz, int n, Grid g,
           const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff, int* __restrict__ corr_v0, double* __restrict__ corr_M0,
-          int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st, int first,
+          int* __restrict__ corr_v1, double* __restrict__ corr_M1, double* __restrict__ partials, LmState* __restrict__ st, int j,
           LmInit in, const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s, LmState* __restrict__ h_post,
           int seq, FitArgs fa) {
   wave_prio(2);  // a latency chain: issue ahead of whatever shares the CU (the other context's kNN, the next scan's preparation)
-  // first != 0: this launch opens a solve.  Nobody reads the (stale) state: mode, buffer and pose come from the kernel
-  // arguments, and the last-arriving workgroup's lane 0 writes the fresh state (:53-63) before it uses it -- no separate
-  // initialisation launch, no H2D copy.  The tickets are 0 between launches by construction (the last arriver resets them).
-  if (first ? in.max_outer <= 0 : st->done != 0) {
-    if (!first && fa.on && !st->has_fit) {
-      // A launch on a FINISHED solve that has no score yet computes the score (the same grid covers the scan: one thread per point).
-      // The usual frame never gets here -- its last step already scored the pose it accepted (below); this is the solve that ended
-      // on a rejected try (the final pose is the previous x0), on max_iterations, or with "lm not converged".
-      step_fitness_rows(P, n, st->x0, g, fa);
-      if (!last_block_arrive(&st->ticketB)) return;  // the LM is over: its second ticket is free
-      if (threadIdx.x < WAVE) {
-        const double t = fitness_fold(fa.partials, fitness_blocks_dev(n));
-        if (threadIdx.x == 0) {
-          st->fit_sum = t;
-          st->has_fit = 1;
-          if (h_post) {
-            __hip_atomic_store(&h_post->fit_sum, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&h_post->has_fit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-        }
+  constexpr int kStateWords = (int)(sizeof(LmState) / sizeof(int));
+  __shared__ LmState ls;
+  __shared__ double folded[kStepAcc];
+  const int first = j == 0;
+  (void)first;
+  LmState* const sn = st + (j & 1);                                  // the image this launch leaves
+  double* const rows_out = partials + (size_t)(j & 1) * gridDim.x * kStepAcc;
+  int* const miss = lm_area_miss(st);
+  auto store_image = [&](LmState* dst) {
+    const int* lw = reinterpret_cast<const int*>(&ls);
+    int* gw = reinterpret_cast<int*>(dst);
+    for (int u = threadIdx.x; u < kStateWords; u += LIN_T) gw[u] = lw[u];
+  };
+  LAB_TS_MIN(0);
+  if (j == 0) {
+    // The opening launch: nobody reads the (stale) images; pose and thresholds come from the kernel arguments.  Workgroup 0 builds the
+    // fresh state (:53-63) with the frame's counters, so that ONE read-back at the end carries every statistic.
+    if (blockIdx.x == 0) {
+      int* lw = reinterpret_cast<int*>(&ls);
+      for (int u = threadIdx.x; u < kStateWords; u += LIN_T) lw[u] = 0;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        lm_state_open(ls, in, nvox, def_t, def_s);
+        ls.lazy_nq = fa.counts ? fa.counts[0] : 0;
+        ls.lazy_ncell = fa.counts ? fa.counts[1] : 0;
+        ls.mode = LM_MODE_LIN;
+        if (in.max_outer <= 0) ls.done = 1;  // max_iterations <= 0: the guess is the answer (a later launch scores it if asked to)
       }
-      if (h_post) post_state_to_host(st, h_post, seq < 0 ? -seq : seq, LIN_T, true);
+      __syncthreads();
+      store_image(sn);
+      if (in.max_outer <= 0 && h_post && seq > 0) post_state_to_host(&ls, h_post, seq, LIN_T, false);
+    }
+    if (in.max_outer <= 0) return;
+  } else {
+    {
+      int* lw = reinterpret_cast<int*>(&ls);
+      const int* gw = reinterpret_cast<const int*>(st + ((j - 1) & 1));
+      for (int u = threadIdx.x; u < kStateWords; u += LIN_T) lw[u] = gw[u];
+    }
+    __syncthreads();
+    const bool was_done = ls.done != 0;
+    if (!was_done) {
+      block_fold_rows<kStepAcc>(partials + (size_t)((j - 1) & 1) * gridDim.x * kStepAcc, gridDim.x, folded);
+      LAB_TS(4);
+      if (threadIdx.x == 0) {
+        bool took_xi = false;
+        lm_step_decide(ls, folded, ls.mode, ls.cur, &took_xi);
+      }
+      __syncthreads();
+    }
+    if (ls.done) {
+      const bool score = fa.on && !ls.has_fit;
+      if (score) {
+        // the solve ended with this launch's decision (or earlier, unscored: max_iterations <= 0): the score at the final pose, every
+        // wave its row; the last arriver folds them
+        step_fitness_rows(P, n, ls.x0, g, fa);
+        if (!last_block_arrive(lm_area_ticket(st))) return;
+        if (threadIdx.x < WAVE) {
+          const double t = fitness_fold(fa.partials, fitness_blocks_dev(n));
+          if (threadIdx.x == 0) { ls.fit_sum = t; ls.has_fit = 1; }
+        }
+      } else if (blockIdx.x != 0) {
+        return;
+      }
+      if (threadIdx.x == 0 && !was_done) {  // the lazy target's miss flag rides home with the state and is left cleared for the next solve
+        ls.pad2 = __hip_atomic_load(miss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(miss, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      store_image(sn);
+      // seq > 0: no score is chained to this solve -- a finished state is the frame's result; seq < 0: a finished state WITH its score is
+      // (from here, or from k_fitness_lm when the caller keeps the score apart)
+      if (h_post && (!was_done || score) && (seq > 0 || ls.has_fit)) post_state_to_host(&ls, h_post, seq < 0 ? -seq : seq, LIN_T, false);
       return;
     }
-    if (first && blockIdx.x == 0 && threadIdx.x == 0) {  // max_iterations <= 0: the guess is the answer
-      int* w = reinterpret_cast<int*>(st);
-      for (int u = 0; u < (int)(sizeof(LmState) / sizeof(int)); u++) w[u] = 0;
-#pragma unroll
-      for (int a = 0; a < 16; a++) st->x0[a] = in.x0[a];
-#pragma unroll
-      for (int a = 0; a < 6; a++) st->Hfin[a * 7] = 1.0;
-      st->nvox = nvox ? *nvox : 0;
-      st->pad = nvox ? (nvox[-1] | (nvox[15] << 8)) : 0;  // grid guards of map and scan (d_small[6], [22])
-      st->def_t = def_t ? *def_t : 0;
-      st->def_s = def_s ? *def_s : 0;
-      st->src_sq = nvox ? __int_as_float(nvox[16]) : 0.f;  // d_small[23]
-      if (nvox) reinit_small_blocks(nvox);
-      st->done = 1;
-    }
-    return;
   }
-  __shared__ double folded[kStepAcc];
-  LAB_TS_MIN(0);
-  const int mode = first ? LM_MODE_LIN : st->mode, cur = first ? 0 : st->cur;
-  // A try whose delta is already below the convergence thresholds ENDS the solve whatever its cost turns out to be (rho >= 0: x0 = xi,
-  // converged; rho < 0: step_lm returns true with x unchanged, :155-158 -- lm_step_decide below): every workgroup can tell from the
-  // state that this launch is the last one.  It then skips the speculative linearisation (nobody would adopt it) and computes the
-  // fitness score at xi instead -- in the usual case (accepted) that IS the final pose, and the frame's result leaves with this launch:
-  // no blind steps in front of a separate score launch, no second kernel.
-  const bool final_try = !first && mode != LM_MODE_LIN && lm_is_converged(st->delta, st->rot_eps, st->trans_eps);
-  const bool score_here = final_try && fa.on != 0;
+  // ---- this launch's per-point work, at the pose the decision above arrived at ----
+  const int mode = j == 0 ? LM_MODE_LIN : ls.mode, cur = j == 0 ? 0 : ls.cur;
+  const bool final_try = mode != LM_MODE_LIN && lm_is_converged(ls.delta, ls.rot_eps, ls.trans_eps);
   int* cv_cur = cur ? corr_v1 : corr_v0;
   double* cm_cur = cur ? corr_M1 : corr_M0;
   int* cv_nxt = cur ? corr_v0 : corr_v1;
@@ -2667,68 +2722,25 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
   double acc[kStepAcc];
 #pragma unroll
   for (int a = 0; a < kStepAcc; a++) acc[a] = 0.0;
-  if (mode != LM_MODE_LIN && i < n) acc[kAccum + 1] = error_point(P, i, n, st->xi, vox, noff, cv_cur, cm_cur);
+  if (mode != LM_MODE_LIN && i < n) acc[kAccum + 1] = error_point(P, i, n, ls.xi, vox, noff, cv_cur, cm_cur);
   if (mode != LM_MODE_B && !final_try) {
     Pose T;
-    lm_load_pose(first ? in.x0 : (mode == LM_MODE_LIN ? st->x0 : st->xi), T);
+    if (j == 0) lm_load_pose(in.x0, T);
+    else lm_load_pose(mode == LM_MODE_LIN ? ls.x0 : ls.xi, T);
     double lin[kAccum];
 #pragma unroll
     for (int a = 0; a < kAccum; a++) lin[a] = 0.0;
     int ncorr = 0;
     if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, mode == LM_MODE_LIN ? cv_cur : cv_nxt,
-                               mode == LM_MODE_LIN ? cm_cur : cm_nxt, 1, lin, ncorr, fa.need ? &st->cmd : nullptr, fa.need, fa.stamp);
+                               mode == LM_MODE_LIN ? cm_cur : cm_nxt, 1, lin, ncorr, fa.need ? miss : nullptr, fa.need, fa.stamp);
 #pragma unroll
     for (int a = 0; a < kAccum; a++) acc[a] = lin[a];
     acc[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
   }
-  if (score_here) step_fitness_rows(P, n, st->xi, g, fa);
   LAB_TS_MIN(1);
-  block_reduce_store<kStepAcc, true>(acc, partials + (size_t)blockIdx.x * kStepAcc);
+  block_reduce_store<kStepAcc>(acc, rows_out + (size_t)blockIdx.x * kStepAcc);  // (read by the NEXT launch: plain stores)
   LAB_TS_MIN(2);
-  if (!last_block_arrive(&st->ticketA)) return;
-  LAB_TS(3);
-  // The last arriver works on an LDS copy of the state: all threads fetch it in the same memory round trip as the rows of the
-  // fold, lane 0 takes the decision at LDS latency (the former global-memory accesses were ~2 us of dependent round trips per
-  // step), and all threads write the copy back.
-  __shared__ LmState ls;
-  constexpr int kStateWords = (int)(sizeof(LmState) / sizeof(int));
-  {
-    int* lw = reinterpret_cast<int*>(&ls);
-    const int* gw = reinterpret_cast<const int*>(st);
-    // (cmd = the lazy target's "a look-up hit an un-built voxel" flag: set by ANY workgroup of ANY launch of this solve, the opening one
-    // included -- it is taken from memory even then; a finished solve hands it on in pad2 and leaves it cleared for the next one)
-    constexpr int kCmdWord = (int)(offsetof(LmState, cmd) / sizeof(int));
-    for (int u = threadIdx.x; u < kStateWords; u += LIN_T) lw[u] = (first && u != kCmdWord) ? 0 : gw[u];
-  }
-  block_fold_rows<kStepAcc>(partials, gridDim.x, folded);  // (its barriers also publish ls)
-  __shared__ int took_xi_s;
-  if (threadIdx.x == 0) {
-    LAB_TS(4);
-    ls.ticketA = 0;  // (already reset in memory by last_block_arrive)
-    bool took_xi = false;
-    lm_step_decide(ls, folded, first, in, mode, cur, nvox, def_t, def_s, &took_xi);
-    took_xi_s = took_xi ? 1 : 0;
-    if (first) { ls.lazy_nq = fa.counts ? fa.counts[0] : 0; ls.lazy_ncell = fa.counts ? fa.counts[1] : 0; }
-  }
-  __syncthreads();
-  if (score_here && ls.done && took_xi_s) {  // the accepted pose is the one the score was taken at: fold it into the state
-    if (threadIdx.x < WAVE) {
-      const double t = fitness_fold(fa.partials, fitness_blocks_dev(n));
-      if (threadIdx.x == 0) { ls.fit_sum = t; ls.has_fit = 1; }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && ls.done) { ls.pad2 = ls.cmd; ls.cmd = 0; }
-  __syncthreads();
-  {
-    const int* lw = reinterpret_cast<const int*>(&ls);
-    int* gw = reinterpret_cast<int*>(st);
-    for (int u = threadIdx.x; u < kStateWords; u += LIN_T) gw[u] = lw[u];
-  }
-  // seq > 0: no fitness score is chained to this solve -- a finished state is the frame's result; seq < 0: a finished state WITH its
-  // score is (from here when the last step scored the pose it accepted, else from whoever computes the score: a later step launch or
-  // k_fitness_lm)
-  if (h_post && ls.done && (seq > 0 || ls.has_fit)) post_state_to_host(&ls, h_post, seq < 0 ? -seq : seq, LIN_T, false);
+  if (j > 0 && blockIdx.x == 0) store_image(sn);
 }
 
 // fold per-block rows in a fixed order: block a (one wave) owns accumulator a; lane l sums rows l, l+64, ...
@@ -3573,11 +3585,11 @@ void compute_error_dev(hipStream_t s, const float4* P, int n, const double* Tdev
 static int fitness_scan_all(int nt) { return nt > 0 && nt <= 32768 ? nt : 0; }
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
-             const LmInit* first, const int* nvox, const void* segs_t, const void* segs_s, LmState* h_post, int seq, const float4* TP,
+             int j, const LmInit* open, const int* nvox, const void* segs_t, const void* segs_s, LmState* h_post, int seq, const float4* TP,
              const int* tstart, double* fit_partials, int nt, const int* lazy_need, int lazy_stamp, const int* lazy_counts) {
   const FitArgs fa{TP, tstart, fit_partials, fitness_scan_all(nt), (TP && tstart && fit_partials) ? 1 : 0, lazy_need, lazy_stamp, lazy_counts};
   hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
-                     corr_M1, partials, st, first ? 1 : 0, first ? *first : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s, h_post, seq, fa);
+                     corr_M1, partials, st, j, (j == 0 && open) ? *open : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s, h_post, seq, fa);
 }
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials, LmState* h_post,
                 int seq, int nt) {
