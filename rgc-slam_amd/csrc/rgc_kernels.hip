@@ -2182,19 +2182,16 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
   }
 }
 
-// per-point work of FastVGICP::update_correspondences + linearize (fast_vgicp_impl.hpp:73-180) for sorted source point i
-__device__ __forceinline__ void linearize_point(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
-                                                const double* __restrict__ nz, int i, int n, const Pose& T, const Grid& g,
-                                                const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff,
-                                                int* __restrict__ corr_v, double* __restrict__ corr_M, int want_H, double (&acc)[kAccum],
-                                                int& ncorr, int* __restrict__ miss = nullptr, const int* __restrict__ need = nullptr, int stamp = 0) {
-    const float4 pp = P[i];
+// (the body, with the point and its normal already in registers: k_lm_step fetches them before it takes the previous launch's decision)
+__device__ __forceinline__ void linearize_point_pre(const float4 pp, const double a0, const double a1, const double a2, int i, int n, const Pose& T,
+                                                    const Grid& g, const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff,
+                                                    int* __restrict__ corr_v, double* __restrict__ corr_M, int want_H, double (&acc)[kAccum],
+                                                    int& ncorr, int* __restrict__ miss = nullptr, const int* __restrict__ need = nullptr, int stamp = 0) {
     const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
     const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
     const double q1 = T.R[3] * p0 + T.R[4] * p1 + T.R[5] * p2 + T.t[1];
     const double q2 = T.R[6] * p0 + T.R[7] * p1 + T.R[8] * p2 + T.t[2];
     // R C_A R^T = I - 0.999 (R n)(R n)^T
-    const double a0 = nx[i], a1 = ny[i], a2 = nz[i];
     const double r0 = T.R[0] * a0 + T.R[1] * a1 + T.R[2] * a2;
     const double r1 = T.R[3] * a0 + T.R[4] * a1 + T.R[5] * a2;
     const double r2 = T.R[6] * a0 + T.R[7] * a1 + T.R[8] * a2;
@@ -2260,6 +2257,15 @@ __device__ __forceinline__ void linearize_point(const float4* __restrict__ P, co
     }
 }
 
+// per-point work of FastVGICP::update_correspondences + linearize (fast_vgicp_impl.hpp:73-180) for sorted source point i
+__device__ __forceinline__ void linearize_point(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
+                                                const double* __restrict__ nz, int i, int n, const Pose& T, const Grid& g,
+                                                const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff,
+                                                int* __restrict__ corr_v, double* __restrict__ corr_M, int want_H, double (&acc)[kAccum],
+                                                int& ncorr, int* __restrict__ miss = nullptr, const int* __restrict__ need = nullptr, int stamp = 0) {
+  linearize_point_pre(P[i], nx[i], ny[i], nz[i], i, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, want_H, acc, ncorr, miss, need, stamp);
+}
+
 __device__ __forceinline__ void block_count_store(int ncorr, int* __restrict__ dst) {  // exact integer block sum -> *dst
   int c = ncorr;
 #pragma unroll
@@ -2290,10 +2296,9 @@ k_linearize(const float4* __restrict__ P,
 }
 
 // cost of sorted source point i with the correspondences and Mahalanobis matrices frozen by the last linearisation
-__device__ __forceinline__ double error_point(const float4* __restrict__ P, int i, int n, const double* __restrict__ T12 /* row-major 3x4 */,
-                                              const double* __restrict__ vox, int noff, const int* __restrict__ corr_v,
-                                              const double* __restrict__ corr_M) {
-  const float4 pp = P[i];
+__device__ __forceinline__ double error_point_pre(const float4 pp, int i, int n, const double* __restrict__ T12 /* row-major 3x4 */,
+                                                  const double* __restrict__ vox, int noff, const int* __restrict__ corr_v,
+                                                  const double* __restrict__ corr_M) {
   const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
   const double q0 = T12[0] * p0 + T12[1] * p1 + T12[2] * p2 + T12[3];
   const double q1 = T12[4] * p0 + T12[5] * p1 + T12[6] * p2 + T12[7];
@@ -2311,6 +2316,10 @@ __device__ __forceinline__ double error_point(const float4* __restrict__ P, int 
     s += w * (e0 * (M[0] * e0 + M[1] * e1 + M[2] * e2) + e1 * (M[1] * e0 + M[3] * e1 + M[4] * e2) + e2 * (M[2] * e0 + M[4] * e1 + M[5] * e2));
   }
   return s;
+}
+__device__ __forceinline__ double error_point(const float4* __restrict__ P, int i, int n, const double* __restrict__ T12, const double* __restrict__ vox,
+                                              int noff, const int* __restrict__ corr_v, const double* __restrict__ corr_M) {
+  return error_point_pre(P[i], i, n, T12, vox, noff, corr_v, corr_M);
 }
 
 // ---- device-chained LM: the whole LsqRegistration::computeTransformation loop (lsq_registration_impl.hpp:53-172) as a
@@ -2354,6 +2363,43 @@ __device__ __forceinline__ void block_fold_rows(const double* __restrict__ parti
       for (int u = 0; u < 8; u++) v[u] = (r0 + 8 * u < nrows) ? partials[(size_t)(r0 + 8 * u) * NACC + a] : 0.0;
 #pragma unroll
       for (int u = 0; u < 8; u++) s += v[u];  // (+0.0 past the end: no effect on a sum that starts at +0.0)
+    }
+  }
+  grp[gq][a] = s;
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double t = grp[0][threadIdx.x];
+#pragma unroll
+    for (int j = 1; j < LIN_T / 32; j++) t += grp[j][threadIdx.x];
+    sh_out[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// The same fold with the thread's first sixteen rows (t / 32 + 8 u, u < 16) already in registers: k_lm_step issues those loads together
+// with its other loads at the top of the launch -- one round trip instead of one for the state and two for the rows.  Same additions in the
+// same order as block_fold_rows (a missing row is +0.0).
+template <int NACC>
+__device__ __forceinline__ void block_fold_rows_load16(const double* __restrict__ partials, int nrows, double (&v)[16]) {
+  const int a = threadIdx.x & 31, gq = threadIdx.x >> 5;
+#pragma unroll
+  for (int u = 0; u < 16; u++) v[u] = (a < NACC && gq + 8 * u < nrows) ? partials[(size_t)(gq + 8 * u) * NACC + a] : 0.0;
+}
+template <int NACC>
+__device__ __forceinline__ void block_fold_rows_pre(const double* __restrict__ partials, int nrows, const double (&v)[16], double* sh_out) {
+  static_assert(NACC <= 32 && LIN_T == 256, "thread -> (accumulator, row group) mapping");
+  __shared__ double grp[LIN_T / 32][32];
+  const int a = threadIdx.x & 31, gq = threadIdx.x >> 5;
+  double s = 0;
+  if (a < NACC) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) s += v[u];
+    for (int r0 = gq + 128; r0 < nrows; r0 += 64) {
+      double w[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) w[u] = (r0 + 8 * u < nrows) ? partials[(size_t)(r0 + 8 * u) * NACC + a] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += w[u];
     }
   }
   grp[gq][a] = s;
@@ -2649,6 +2695,12 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     for (int u = threadIdx.x; u < kStateWords; u += LIN_T) gw[u] = lw[u];
   };
   LAB_TS_MIN(0);
+  // Everything this launch will need from memory that does not depend on the decision is asked for NOW, in one round trip: the state image,
+  // this thread's rows of the previous launch, its scan point and normal.
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+  double pn0 = 0.0, pn1 = 0.0, pn2 = 0.0;
+  if (i < n) { pp = P[i]; pn0 = nx[i]; pn1 = ny[i]; pn2 = nz[i]; }
   if (j == 0) {
     // The opening launch: nobody reads the (stale) images; pose and thresholds come from the kernel arguments.  Workgroup 0 builds the
     // fresh state (:53-63) with the frame's counters, so that ONE read-back at the end carries every statistic.
@@ -2669,15 +2721,22 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
     }
     if (in.max_outer <= 0) return;
   } else {
+    const double* const rows_in = partials + (size_t)((j - 1) & 1) * gridDim.x * kStepAcc;
+    double rv[16];
     {
+      static_assert(kStateWords <= 2 * LIN_T, "two words of the image per thread");
       int* lw = reinterpret_cast<int*>(&ls);
       const int* gw = reinterpret_cast<const int*>(st + ((j - 1) & 1));
-      for (int u = threadIdx.x; u < kStateWords; u += LIN_T) lw[u] = gw[u];
+      const int u0 = threadIdx.x, u1 = threadIdx.x + LIN_T;
+      const int w0 = gw[u0], w1 = u1 < kStateWords ? gw[u1] : 0;
+      block_fold_rows_load16<kStepAcc>(rows_in, gridDim.x, rv);  // (rows of a finished solve are stale but valid memory; they are not used then)
+      lw[u0] = w0;
+      if (u1 < kStateWords) lw[u1] = w1;
     }
     __syncthreads();
     const bool was_done = ls.done != 0;
     if (!was_done) {
-      block_fold_rows<kStepAcc>(partials + (size_t)((j - 1) & 1) * gridDim.x * kStepAcc, gridDim.x, folded);
+      block_fold_rows_pre<kStepAcc>(rows_in, gridDim.x, rv, folded);
       LAB_TS(4);
       if (threadIdx.x == 0) {
         bool took_xi = false;
@@ -2718,11 +2777,10 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
   double* cm_cur = cur ? corr_M1 : corr_M0;
   int* cv_nxt = cur ? corr_v0 : corr_v1;
   double* cm_nxt = cur ? corr_M0 : corr_M1;
-  const int i = blockIdx.x * LIN_T + threadIdx.x;
   double acc[kStepAcc];
 #pragma unroll
   for (int a = 0; a < kStepAcc; a++) acc[a] = 0.0;
-  if (mode != LM_MODE_LIN && i < n) acc[kAccum + 1] = error_point(P, i, n, ls.xi, vox, noff, cv_cur, cm_cur);
+  if (mode != LM_MODE_LIN && i < n) acc[kAccum + 1] = error_point_pre(pp, i, n, ls.xi, vox, noff, cv_cur, cm_cur);
   if (mode != LM_MODE_B && !final_try) {
     Pose T;
     if (j == 0) lm_load_pose(in.x0, T);
@@ -2731,8 +2789,8 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
 #pragma unroll
     for (int a = 0; a < kAccum; a++) lin[a] = 0.0;
     int ncorr = 0;
-    if (i < n) linearize_point(P, nx, ny, nz, i, n, T, g, cell_voxel, vox, noff, mode == LM_MODE_LIN ? cv_cur : cv_nxt,
-                               mode == LM_MODE_LIN ? cm_cur : cm_nxt, 1, lin, ncorr, fa.need ? miss : nullptr, fa.need, fa.stamp);
+    if (i < n) linearize_point_pre(pp, pn0, pn1, pn2, i, n, T, g, cell_voxel, vox, noff, mode == LM_MODE_LIN ? cv_cur : cv_nxt,
+                                   mode == LM_MODE_LIN ? cm_cur : cm_nxt, 1, lin, ncorr, fa.need ? miss : nullptr, fa.need, fa.stamp);
 #pragma unroll
     for (int a = 0; a < kAccum; a++) acc[a] = lin[a];
     acc[kAccum] = (double)ncorr;  // exact: counts are far below 2^53
