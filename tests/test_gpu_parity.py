@@ -112,6 +112,53 @@ def test_lm_drivers_agree(reg_mod, fx_reg, monkeypatch):
         assert abs(res[impl][3] - res[None][3]) <= 1e-9 * abs(res[None][3])
 
 
+@pytest.mark.parametrize("max_it,lm_it,far", [(0, 10, False), (1, 10, False), (2, 10, False), (3, 10, False), (25, 1, True), (25, 2, True),
+                                              (40, 10, True)])
+def test_lm_edge_settings(reg_mod, orc, fx_reg, monkeypatch, max_it, lm_it, far):
+    """The solve's ends: max_iterations 0 (the guess is the answer), 1..3 (the iteration cap ends it), lm_max_iterations 1 / 2 from a
+    guess well off (every outer iteration gives up: "lm not converged", lsq_registration_impl.hpp:69-72), and a long solve from that
+    guess (more launches than one batch holds).  The device-chained driver against the host-driven one (same kernels' arithmetic, the
+    host's control flow) -- pose, iteration count, flags and score -- and both against the CPU oracle."""
+    import rgc_slam_amd.synth as synth
+    guess = fx_reg["guess"].astype(np.float64)
+    if far:
+        guess = synth.se3(synth.rot_zyx(0.06, 0.0, 0.0), [0.9, -0.5, 0.05]) @ guess
+    guess = guess.astype(np.float32)
+    res = {}
+    for impl in (None, "host"):
+        if impl is None:
+            monkeypatch.delenv("RGC_LM_IMPL", raising=False)
+        else:
+            monkeypatch.setenv("RGC_LM_IMPL", impl)
+        v = _odo(reg_mod)
+        v.setMaximumIterations(max_it)
+        v._p.lm_max_iterations = lm_it
+        v._push()
+        v.setInputTarget(fx_reg["tgt"])
+        v.setInputSource(fx_reg["src"])
+        for rep in range(2):  # (the second solve sizes its batch from the first one's iteration count)
+            v.align(guess, want_output=False)
+        res[impl] = (v.getFinalTransformation().copy(), v.nr_iterations, v.hasConverged(), v.lm_failed, v.getFitnessScore(), v.getFinalHessian().copy())
+        v.close()
+    a, b = res[None], res["host"]
+    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3], (a[1:4], b[1:4])
+    assert np.abs(a[0] - b[0]).max() < 1e-7
+    assert abs(a[4] - b[4]) <= 1e-9 * abs(b[4])
+    assert np.abs(a[5] - b[5]).max() <= 1e-9 * np.abs(b[5]).max()
+    o = orc.Registration(max_iterations=max_it, lm_max_iterations=lm_it, num_threads=0)
+    o.set_target(fx_reg["tgt"])
+    o.set_source(fx_reg["src"])
+    o.prepare()
+    To = o.align(guess)
+    assert a[2] == o.converged and a[3] == o.lm_failed
+    if max_it <= 3 or lm_it <= 2:  # (a long solve's iteration count may differ by the sign of a rho decided by summation order)
+        assert a[1] == o.iterations, (a[1], o.iterations)
+    assert np.abs(a[0][:3, 3] - To[:3, 3]).max() <= 1e-4 and _rot_angle(a[0][:3, :3], To[:3, :3]) <= 1e-4
+    assert abs(a[4] - o.fitness()) <= 1e-6 * o.fitness()
+    if max_it == 0:
+        assert np.array_equal(a[0], guess) and np.array_equal(a[5], np.eye(6))
+
+
 @pytest.fixture(scope="module")
 def medium():
     import rgc_slam_amd.synth as synth
