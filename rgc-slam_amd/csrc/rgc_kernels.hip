@@ -3048,27 +3048,42 @@ __device__ __forceinline__ double fitness_wave(const float4* __restrict__ SP, in
   bool unresolved = false;
   if (i < ns) best = fitness_point(SP, i, T, TP, tstart, g, n_all > 0 ? &unresolved : nullptr, q);
   if (n_all > 0) {
+    // (up to FOUR unsettled queries share one pass over the map: the pass is a chain of load round trips -- 21 of them for a 10 k-point
+    // map, ~17 us -- and a sweep's far points come three or four to a wave: one pass instead of three or four.  A minimum does not depend
+    // on the order it is taken in: the same bits.)
     unsigned long long todo = __ballot(unresolved);
     while (todo) {
-      const int l = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const float qx = __shfl(q[0], l), qy = __shfl(q[1], l), qz = __shfl(q[2], l);
-      float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+      int l[4];
+      float qx[4], qy[4], qz[4], m[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        l[a] = todo ? __ffsll((long long)todo) - 1 : -1;
+        todo &= todo - 1;  // (0 stays 0)
+        const int src = l[a] < 0 ? 0 : l[a];
+        qx[a] = __shfl(q[0], src); qy[a] = __shfl(q[1], src); qz[a] = __shfl(q[2], src);
+        m[a] = INFINITY;
+      }
       int s = lane;
-      for (; s + 7 * WAVE < n_all; s += 8 * WAVE) {  // eight loads in flight per lane
+      for (; s + 7 * WAVE < n_all; s += 8 * WAVE) {  // eight loads in flight per lane (sixteen: the same 46 us -- four queries per candidate is arithmetic, not round trips)
         float4 c[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) c[u] = TP[s + u * WAVE];
 #pragma unroll
-        for (int u = 0; u < 8; u += 4) {
-          m0 = fminf(m0, dist2(qx, qy, qz, c[u])); m1 = fminf(m1, dist2(qx, qy, qz, c[u + 1]));
-          m2 = fminf(m2, dist2(qx, qy, qz, c[u + 2])); m3 = fminf(m3, dist2(qx, qy, qz, c[u + 3]));
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+          for (int a = 0; a < 4; a++) m[a] = fminf(m[a], dist2(qx[a], qy[a], qz[a], c[u]));
         }
       }
-      for (; s < n_all; s += WAVE) m0 = fminf(m0, dist2(qx, qy, qz, TP[s]));
-      const float mine = fminf(fminf(m0, m1), fminf(m2, m3));
-      const float all = __int_as_float(wave_min(__float_as_int(mine)));  // (squared distances are >= +0: they order like their bit patterns)
-      if (lane == l) best = all;
+      for (; s < n_all; s += WAVE) {
+        const float4 c = TP[s];
+#pragma unroll
+        for (int a = 0; a < 4; a++) m[a] = fminf(m[a], dist2(qx[a], qy[a], qz[a], c));
+      }
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        const float all = __int_as_float(wave_min(__float_as_int(m[a])));  // (squared distances are >= +0: they order like their bit patterns)
+        if (lane == l[a]) best = all;
+      }
     }
   }
   return wave_sum(i < ns ? (double)best : 0.0);
