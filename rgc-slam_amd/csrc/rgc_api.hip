@@ -1529,7 +1529,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   }
   // rgc_align_end returns as soon as the device POSTS the finished state: the previous solve's spare steps, score launches and the copy
   // into h_lm may still be queued on the stream they were enqueued on.  A solve that goes to the other stream is ordered behind them
-  // (they work on the same LM state and tickets); a wait on an event that has already fired costs nothing.
+  // (they work on the same LM state images and rows); a wait on an event that has already fired costs nothing.
   if (c->lm_tail_stream && c->lm_tail_stream != c->solve_stream && hipEventQuery(c->lm_tail) != hipSuccess) {
     (void)hipGetLastError();
     HIPCHK(c, hipStreamWaitEvent(c->solve_stream, c->lm_tail, 0));
@@ -1547,7 +1547,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   if ((rc = ensure(c, c->ipartials, sizeof(int) * (size_t)nb))) return rc;
   if (!c->lm_state.p) {
     if ((rc = ensure(c, c->lm_state, 4096))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->solve_stream));  // tickets start at 0
+    HIPCHK(c, hipMemsetAsync(c->lm_state.p, 0, 4096, c->solve_stream));  // the score's ticket and the lazy target's miss flag start at 0
   }
   if ((rc = ensure(c, c->fit_partials, sizeof(double) * (size_t)rgck::fitness_blocks(n) + 64))) return rc;
   rgck::LmInit in;

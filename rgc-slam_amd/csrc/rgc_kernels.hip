@@ -15,7 +15,7 @@
 //   C2 kNN + cov    Chain, sp_piece_table, knn_point_sp (map: one lane per query, one pass), knn_point_split (scan: four lanes per
 //                   query), k_knn_sp (the bulk launch of either), TopK, coop_kth, k_knn_coop (deferred queries, one wave per query)
 //   C3 voxel map    k_voxel_build
-//   C4-C7 solve     linearize_point, error_point, block_reduce_store, last_block_arrive, block_fold_rows, k_lm_step (default
+//   C4-C7 solve     linearize_point, error_point, block_reduce_store, block_fold_rows_pre, lm_step_decide, k_lm_step (default
 //                   driver), k_linearize / k_error / k_fold / k_lm_try (public fine seam)
 //   C8, f4          nn_search, k_fitness(_lm), k_icp_accumulate, k_transform_f32
 //   f1              k_mapreg_associate, k_mapreg_terms, k_mapreg_fold
@@ -2323,10 +2323,11 @@ __device__ __forceinline__ double error_point(const float4* __restrict__ P, int 
 }
 
 // ---- device-chained LM: the whole LsqRegistration::computeTransformation loop (lsq_registration_impl.hpp:53-172) as a
-// state machine in device memory, advanced by STEP kernels (k_lm_step below) whose last-arriving workgroup folds the
-// partial rows and takes the decision.  The host enqueues steps blindly and reads the state back once per batch.
-// Inter-block hand-off (cdna_hip_programming.md G16): write-through (sc1) row stores, every wave drains vmcnt, workgroup
-// barrier, one lane takes a ticket; the last arriver does an agent-scope ACQUIRE before its workgroup reads the rows.
+// state machine in device memory, advanced by STEP kernels (k_lm_step below): every workgroup of a launch folds the rows the
+// previous launch left and takes its decision; the host enqueues launches blindly and spins on the posted result.
+// The one hand-off between workgroups of a launch that is left is the score's fold (and the separate score kernels'), through
+// last_block_arrive (cdna_hip_programming.md G16): write-through (sc1) row stores, every wave drains vmcnt, workgroup barrier,
+// one lane takes a ticket; the last arriver does an agent-scope ACQUIRE before its workgroup reads the rows.
 __device__ __forceinline__ bool last_block_arrive(int* ticket) {
   __shared__ int is_last_s;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2346,39 +2347,12 @@ __device__ __forceinline__ bool last_block_arrive(int* ticket) {
   return is_last_s != 0;
 }
 
-// Fold of the per-workgroup rows by the last arriver, all LIN_T threads at once: thread t owns accumulator t % 32 and
-// the rows t / 32, t / 32 + 8, ... (summed in ascending order); the eight strided sums of an accumulator are then added in
-// ascending order from LDS.  Fixed order -> deterministic for a given row count.  The rows of a thread are fetched EIGHT at a time
-// before any is added (the loop used to wait for each load in turn: 15 dependent L2 / fabric round trips for a 30 k-point scan).
-template <int NACC>
-__device__ __forceinline__ void block_fold_rows(const double* __restrict__ partials, int nrows, double* sh_out) {
-  static_assert(NACC <= 32 && LIN_T == 256, "thread -> (accumulator, row group) mapping");
-  __shared__ double grp[LIN_T / 32][32];
-  const int a = threadIdx.x & 31, gq = threadIdx.x >> 5;
-  double s = 0;
-  if (a < NACC) {
-    for (int r0 = gq; r0 < nrows; r0 += 64) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = (r0 + 8 * u < nrows) ? partials[(size_t)(r0 + 8 * u) * NACC + a] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 8; u++) s += v[u];  // (+0.0 past the end: no effect on a sum that starts at +0.0)
-    }
-  }
-  grp[gq][a] = s;
-  __syncthreads();
-  if (threadIdx.x < NACC) {
-    double t = grp[0][threadIdx.x];
-#pragma unroll
-    for (int j = 1; j < LIN_T / 32; j++) t += grp[j][threadIdx.x];
-    sh_out[threadIdx.x] = t;
-  }
-  __syncthreads();
-}
-
-// The same fold with the thread's first sixteen rows (t / 32 + 8 u, u < 16) already in registers: k_lm_step issues those loads together
-// with its other loads at the top of the launch -- one round trip instead of one for the state and two for the rows.  Same additions in the
-// same order as block_fold_rows (a missing row is +0.0).
+// Fold of the per-workgroup rows, all LIN_T threads at once: thread t owns accumulator t % 32 and the rows t / 32, t / 32 + 8, ... (summed
+// in ascending order); the eight strided sums of an accumulator are then added in ascending order from LDS.  Fixed order -> deterministic
+// for a given row count, and the same in every workgroup that folds the same rows.  The thread's first sixteen rows (t / 32 + 8 u, u < 16)
+// are fetched by block_fold_rows_load16 -- k_lm_step issues those loads together with its other loads at the top of the launch: one round
+// trip instead of one for the state and two for the rows -- any further ones eight at a time (a missing row is +0.0: no effect on a sum
+// that starts at +0.0).
 template <int NACC>
 __device__ __forceinline__ void block_fold_rows_load16(const double* __restrict__ partials, int nrows, double (&v)[16]) {
   const int a = threadIdx.x & 31, gq = threadIdx.x >> 5;
