@@ -1919,68 +1919,98 @@ __global__ void __launch_bounds__(kListT) k_lazy_lists(const float4* __restrict_
 }
 
 constexpr int VOX_T = 256;
+// LDS of a voxel-building workgroup: the nine terms of its points (rows one element longer than the block: the nine rows of one point
+// fall into nine different bank pairs) and the list of the cells that START in the block.
+struct VoxLds {
+  double t[9][VOX_T + 1];
+  int head_t[VOX_T + 1], head_c[VOX_T];  // per listed cell: its first point (index in the block), its cell
+  int wcnt[VOX_T / WAVE];
+};
+// term k of sorted point u straight from memory (a cell that runs past its block's end): the expressions of the staging pass below
+__device__ __forceinline__ double voxel_term(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
+                                             const double* __restrict__ nz, int k, int u) {
+  if (k < 3) { const float4 p = P[u]; return (double)(k == 0 ? p.x : (k == 1 ? p.y : p.z)); }
+  const double a = nx[u], b = ny[u], d = nz[u];
+  switch (k) {
+    case 3: return 1.0 - 0.999 * a * a;
+    case 4: return -0.999 * a * b;
+    case 5: return -0.999 * a * d;
+    case 6: return 1.0 - 0.999 * b * b;
+    case 7: return -0.999 * b * d;
+    default: return 1.0 - 0.999 * d * d;
+  }
+}
+// One lane per POINT stages the point's nine terms in LDS; then one lane per (cell that starts in the block, term) adds that term over the
+// cell's points in ascending sorted position -- the cloud's order, the very additions a serial loop makes, so the same bits -- divides
+// and stores its entry of the record.  (Until round 4 the lane of a cell's FIRST point added all nine terms and every lane looked its
+// cell's bounds up: three dependent round trips per workgroup, now two.  The pass is bound by memory LATENCY at the parallelism its
+// waves offer -- 64 % of its wave cycles wait on memory counters with 22 waves per CU in flight, 2 TB/s: scripts/pmc_kernel.sh -- not by
+// the additions: the per-term lanes alone changed nothing, dropping the bounds look-up gave 36 -> 33 us.  Measured and dropped: workgroups
+// that walk several tiles with the next tile's loads in flight during the sums (36.7 us: the barrier at the end of a tile waits for
+// them anyway); dealing the terms to the cell's own lanes (round 4, earlier: it indexes the accumulators dynamically).)
 __device__ __forceinline__ void voxel_build_block(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny,
                                                   const double* __restrict__ nz, const int* __restrict__ start, const Grid& g, int n,
                                                   const int* __restrict__ cell_voxel, double* __restrict__ vox, int* __restrict__ vox_cell,
-                                                  double (*sh)[VOX_T], int block) {
+                                                  VoxLds& sh, int block) {
   const int b0 = block * VOX_T, bend = min(b0 + VOX_T, n);
   const int s = b0 + threadIdx.x;
-  int c = 0, s1 = 0;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  int c = 0;
   bool head = false;
   if (s < n) {
-    const float4 cp = P[s];
+    // a cell STARTS at this point iff the point before it (sorted order) lies in another cell: the neighbour's coordinates come with the
+    // point's own in one round trip -- no look-up of the cell's bounds (a second, dependent round trip for every lane of the pass)
+    const float4 cp = P[s], pv = P[s > 0 ? s - 1 : 0];
     const double a = nx[s], b = ny[s], d = nz[s];
     c = cell_index(g, cell_coord(cp.x, g) - g.minc[0], cell_coord(cp.y, g) - g.minc[1], cell_coord(cp.z, g) - g.minc[2]);
-    const int s0 = start[c];
-    s1 = start[c + 1];
-    head = (s0 == s);
-    sh[0][threadIdx.x] = (double)cp.x;
-    sh[1][threadIdx.x] = (double)cp.y;
-    sh[2][threadIdx.x] = (double)cp.z;
-    sh[3][threadIdx.x] = 1.0 - 0.999 * a * a;
-    sh[4][threadIdx.x] = -0.999 * a * b;
-    sh[5][threadIdx.x] = -0.999 * a * d;
-    sh[6][threadIdx.x] = 1.0 - 0.999 * b * b;
-    sh[7][threadIdx.x] = -0.999 * b * d;
-    sh[8][threadIdx.x] = 1.0 - 0.999 * d * d;
+    const int cprev = cell_index(g, cell_coord(pv.x, g) - g.minc[0], cell_coord(pv.y, g) - g.minc[1], cell_coord(pv.z, g) - g.minc[2]);
+    head = s == 0 || cprev != c;
+    sh.t[0][threadIdx.x] = (double)cp.x;
+    sh.t[1][threadIdx.x] = (double)cp.y;
+    sh.t[2][threadIdx.x] = (double)cp.z;
+    sh.t[3][threadIdx.x] = 1.0 - 0.999 * a * a;
+    sh.t[4][threadIdx.x] = -0.999 * a * b;
+    sh.t[5][threadIdx.x] = -0.999 * a * d;
+    sh.t[6][threadIdx.x] = 1.0 - 0.999 * b * b;
+    sh.t[7][threadIdx.x] = -0.999 * b * d;
+    sh.t[8][threadIdx.x] = 1.0 - 0.999 * d * d;
+  }
+  const unsigned long long mh = __ballot(head);
+  if (lane == 0) sh.wcnt[w] = __popcll(mh);
+  __syncthreads();
+  int base = 0, H = 0;
+#pragma unroll
+  for (int j = 0; j < VOX_T / WAVE; j++) { const int q = sh.wcnt[j]; base += j < w ? q : 0; H += q; }
+  if (head) {
+    const int h = base + __popcll(mh & ((1ull << lane) - 1ull));
+    sh.head_t[h] = threadIdx.x; sh.head_c[h] = c;
   }
   __syncthreads();
-  if (!head) return;
-  double m[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
-  const int e_in = min(s1, bend);
-  for (int u = s; u < e_in; u++) {
-    const int t = u - b0;
-    m[0] += sh[0][t]; m[1] += sh[1][t]; m[2] += sh[2][t];
-#pragma unroll
-    for (int j = 0; j < 6; j++) C[j] += sh[3 + j][t];
-  }
-  for (int u = e_in; u < s1; u += 2) {  // the cell runs past this block: two points per step straight from memory
-    const int u1 = min(u + 1, s1 - 1);
-    const float4 p0 = P[u], p1 = P[u1];
-    const double a0 = nx[u], b0_ = ny[u], d0 = nz[u], a1 = nx[u1], b1 = ny[u1], d1 = nz[u1];
-    m[0] += (double)p0.x; m[1] += (double)p0.y; m[2] += (double)p0.z;
-    C[0] += 1.0 - 0.999 * a0 * a0; C[1] += -0.999 * a0 * b0_; C[2] += -0.999 * a0 * d0;
-    C[3] += 1.0 - 0.999 * b0_ * b0_; C[4] += -0.999 * b0_ * d0; C[5] += 1.0 - 0.999 * d0 * d0;
-    if (u + 1 < s1) {
-      m[0] += (double)p1.x; m[1] += (double)p1.y; m[2] += (double)p1.z;
-      C[0] += 1.0 - 0.999 * a1 * a1; C[1] += -0.999 * a1 * b1; C[2] += -0.999 * a1 * d1;
-      C[3] += 1.0 - 0.999 * b1 * b1; C[4] += -0.999 * b1 * d1; C[5] += 1.0 - 0.999 * d1 * d1;
+  for (int idx = threadIdx.x; idx < 9 * H; idx += VOX_T) {
+    const int h = idx / 9, k = idx - 9 * h;
+    const int t0 = sh.head_t[h], cc = sh.head_c[h];
+    const int vv = cell_voxel[cc];  // dense id from the cell scan: asked for now, needed behind the loop
+    // the cell ends where the next one starts; the block's last cell may run past the block: its end is the one look-up of the cell table
+    const bool last = h == H - 1;
+    const int e_in = last ? bend - b0 : sh.head_t[h + 1];
+    const int e1 = last ? start[cc + 1] : b0 + e_in;
+    const double* __restrict__ row = sh.t[k];
+    double acc = 0.0;
+    for (int u = t0; u < e_in; u++) acc += row[u];
+    for (int u = b0 + e_in; u < e1; u++) acc += voxel_term(P, nx, ny, nz, k, u);  // the cell runs past this block
+    const double num = (double)(e1 - (b0 + t0));
+    vox[(size_t)vv * kVoxRec + k] = acc / num;
+    if (k == 0) {
+      vox[(size_t)vv * kVoxRec + 9] = num;
+      vox_cell[vv] = cc;
     }
   }
-  const double num = (double)(s1 - s);
-  const int v = cell_voxel[c];  // dense id from the cell scan
-  vox_cell[v] = c;
-  double* rec = vox + (size_t)v * kVoxRec;
-  rec[0] = m[0] / num; rec[1] = m[1] / num; rec[2] = m[2] / num;
-#pragma unroll
-  for (int a = 0; a < 6; a++) rec[3 + a] = C[a] / num;
-  rec[9] = num;
 }
 __global__ void __launch_bounds__(VOX_T)
 k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
               const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
               int* __restrict__ vox_cell) {
-  __shared__ double sh[9][VOX_T];
+  __shared__ VoxLds sh;
   voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x);
 }
 // k_voxel_build and the map's cooperative kNN kernel in ONE launch: the FIRST nb_coop workgroups resolve the deferred queries -- four waves
@@ -1989,17 +2019,17 @@ k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const
 // afterwards (k_voxel_patch).  Two streams and events did the same 20 us SLOWER than the serial chain (a cross-stream dependency costs
 // ~10 us here); one launch has no such hop.
 template <int KC>
-__global__ void __launch_bounds__(VOX_T)
+__global__ void __launch_bounds__(VOX_T, 6)
 k_voxel_build_coop(const float4* __restrict__ P, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz,
                    const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
                    int* __restrict__ vox_cell, int nb_coop, int k, Deferred df) {
-  __shared__ double sh[9][VOX_T];
+  __shared__ VoxLds sh;
   __shared__ CoopRows shm[VOX_T / WAVE];
+  if (df.guard && *df.guard) return;  // (a cloud parked on a grid it does not fit: its points' cells are not the sorted order's)
   if ((int)blockIdx.x >= nb_coop) {
     voxel_build_block(P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, sh, (int)blockIdx.x - nb_coop);
     return;
   }
-  if (df.guard && *df.guard) return;
   const int w = (int)threadIdx.x / WAVE;
   coop_run<KC, true>(P, start, g, k, df, nx, ny, nz, &shm[w], (int)threadIdx.x & (WAVE - 1), (int)blockIdx.x * (VOX_T / WAVE) + w,
                      nb_coop * (VOX_T / WAVE));
