@@ -1,19 +1,31 @@
 #!/bin/bash
 # The A/B routes that were environment knobs until round 3 are build flags now.  This builds the library once per flag beside the
 # product (RGC_LIB_OUT) and runs the short knob sequence of tests/test_gpu_parity.py on each build through RGC_HIP_LIB: every route
-# must give the default build's poses.  GPU box:  bash scripts/exp_build_flags.sh
+# must give the default build's poses.  GPU box:  bash scripts/exp_build_flags.sh        (builds there), or in two halves -- the builds
+# where there is no GPU (hipcc cross-compiles), the runs on the GPU box:  bash scripts/exp_build_flags.sh build ; ... exp_build_flags.sh run
+# (libraries in $RGC_FLAG_LIB_DIR, default exp_flags/ in the tree: git-ignored, shipped with the snapshot)
 set -e
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out
+MODE=${1:-both}
+D=${RGC_FLAG_LIB_DIR:-$PWD/exp_flags}
+mkdir -p gpurun_out "$D"
+FLAGS="-DRGC_SMALL_COPY=1 -DRGC_SRC_RES=0.5 -DRGC_SRC_RES=2.0 -DRGC_MAP_WIDE=0 -DRGC_MAP_WIDE=1000 -DRGC_MAP_WIDE_R=0 -DRGC_LM_POST=0 -DRGC_SOLVE_BEHIND_MAP=0 -DRGC_FE_SPEC=0 -DRGC_LM_SPARE_ASIDE=0"
+if [ $MODE != run ]; then
+  for flag in $FLAGS; do
+    out=$D/librgc_alt_$(echo "$flag" | tr -c 'A-Za-z0-9' '_').so
+    RGC_EXTRA_FLAGS="$flag" RGC_LIB_OUT="$out" python rgc-slam_amd/build.py > /dev/null
+    rm -rf "${out%.so}_obj"
+  done
+fi
+[ $MODE = build ] && exit 0
 python - <<'PY' > gpurun_out/ref_poses.json
 import json, sys, numpy as np
 sys.path.insert(0, "scripts")
 from knob_sequence import run
 print(json.dumps([[T.tolist(), it, fit] for T, it, fit in run()]))
 PY
-for flag in -DRGC_SMALL_COPY=1 -DRGC_SRC_RES=0.5 -DRGC_SRC_RES=2.0 -DRGC_MAP_WIDE=0 -DRGC_MAP_WIDE=1000 -DRGC_MAP_WIDE_R=0 -DRGC_LM_POST=0 -DRGC_SOLVE_BEHIND_MAP=0 -DRGC_FE_SPEC=0; do
-  out=/tmp/librgc_alt_$(echo "$flag" | tr -c 'A-Za-z0-9' '_').so
-  RGC_EXTRA_FLAGS="$flag" RGC_LIB_OUT="$out" python rgc-slam_amd/build.py > /dev/null
+for flag in $FLAGS; do
+  out=$D/librgc_alt_$(echo "$flag" | tr -c 'A-Za-z0-9' '_').so
   RGC_HIP_LIB="$out" python - "$flag" <<'PY'
 import json, sys, numpy as np
 sys.path.insert(0, "scripts")
