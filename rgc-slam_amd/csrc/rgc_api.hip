@@ -2167,7 +2167,18 @@ static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, fl
   int* hsm = c->h_small + 24;
   Cloud& cl = c->aux;
   int rc;
-  const size_t nr1 = (size_t)g.div[1] * (size_t)g.div[2] * (dense ? (size_t)g.div[0] : 1) + 1;   // rows, or leaves for a dense cloud
+  // the sort's buckets: leaves for a dense cloud, whole grid rows for a sweep, and for a LARGE cloud in a box too big for leaf buckets
+  // segments of a row, as many as keep the table near 4 n entries (the ranking pass is quadratic in a bucket's population: a ground-level
+  // row of a 1.3 M-point keyframe store holds thousands of points)
+  int seg_shift = dense ? 0 : 31;
+  if (!dense) {
+    const double rows = (double)g.div[1] * (double)g.div[2], nseg_max = 4.0 * (double)n / rows;
+    if (nseg_max >= 2.0) {
+      seg_shift = 3;
+      while (seg_shift < 30 && (double)(((long long)g.div[0] + (1ll << seg_shift) - 1) >> seg_shift) > nseg_max) seg_shift++;
+    }
+  }
+  const size_t nr1 = (size_t)g.div[1] * (size_t)g.div[2] * (size_t)rgck::vg_segments(g, seg_shift) + 1;   // buckets
   if ((rc = ensure(c, cl.cell_of, sizeof(int) * n))) return rc;                                                    // row of every point
   if ((rc = ensure(c, cl.slot_of, sizeof(int) * n))) return rc;                                                    // leaf x of every point
   if ((rc = ensure(c, c->vg_pos, sizeof(int) * n))) return rc;                                                     // arrival slot, then output number
@@ -2186,7 +2197,7 @@ static int voxelgrid_rows(rgc_ctx* c, const float* d_in, int stride_f, int n, fl
   cl.cnt_clean = std::max(cl.cnt_clean, nr1);  // (what lies beyond this call's rows was not touched: the scan's and the map's filter take turns)
   if (!c->vg_flags_clean) HIPCHK(c, hipMemsetAsync(dsm + 6, 0, sizeof(int), s));
   c->vg_flags_clean = false;
-  rgck::vg_rows(s, d_in, stride_f, n, inv, g, edge, dense ? 1 : 0, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)c->vg_pos.p, (int*)cl.cnt.p, (int*)cl.start.p,
+  rgck::vg_rows(s, d_in, stride_f, n, inv, g, edge, seg_shift, (int*)cl.cell_of.p, (int*)cl.slot_of.p, (int*)c->vg_pos.p, (int*)cl.cnt.p, (int*)cl.start.p,
                 cl.block_sums.p, (unsigned long long*)c->vg_tmp.p, (int*)c->vg_order.p, (unsigned long long*)c->vg_leaf.p,
                 (int*)((char*)cl.block_sums.p + row_bs), d_out, dsm + 5);
   if (h_result) {  // (the finished chain leaves the flag word zeroed: the next chain on this stream finds it so)

@@ -174,7 +174,9 @@ void vg_bbox(hipStream_t s, const float* in, int stride_f, int n, float inv, int
 // 4 point within `edge` leaves of g's faces), res[1] = the live flag word (must be 0 on entry, is 0 on exit), res[2] <- number of leaves.
 // dense != 0: the counting sort runs over the leaves themselves ("rows" below = leaves; dense clouds).
 // row_block_sums: 8 bytes x (rows / 2048 + 2); head_block_sums: n / 2048 + 2 ints; cnt: rows + 1 zeros, left at zero.
-void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int dense, int* row_of, int* lx, int* slot_then_pos, int* cnt,
+// seg_shift: the counting sort's bucket is 2^seg_shift leaves of a grid row (0: the leaf itself, 31: the whole row); cnt / start: rows x vg_segments() + 1 entries
+int vg_segments(const LeafGrid& g, int seg_shift);
+void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int seg_shift, int* row_of, int* lx, int* slot_then_pos, int* cnt,
              int* start, void* row_block_sums, unsigned long long* tmp, int* order, unsigned long long* leaf, int* head_block_sums, float* out,
              int* res);
 

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) k_vg_bbox(const float* __restrict__ in, i
 constexpr int VG_SCAN_T = 256, VG_SCAN_V = 8, VG_SCAN_B = VG_SCAN_T * VG_SCAN_V;
 
 __global__ void __launch_bounds__(256)
-k_vg_rows_count(const float* __restrict__ in, int stride_f, int n, float inv, LeafGrid g, int edge, int dense, int* __restrict__ row_of,
+k_vg_rows_count(const float* __restrict__ in, int stride_f, int n, float inv, LeafGrid g, int edge, int seg_shift, int nseg, int* __restrict__ row_of,
                 int* __restrict__ lx, int* cnt, int* __restrict__ slot, int* flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -137,11 +137,14 @@ k_vg_rows_count(const float* __restrict__ in, int stride_f, int n, float inv, Le
     } else {
       near = cx < edge || cx >= g.div[0] - edge || cy < edge || cy >= g.div[1] - edge || cz < edge || cz >= g.div[2] - edge;
     }
-    // dense clouds (a keyframe store: several points per leaf, a few million leaves) sort over the LEAVES themselves: the "row" is the
-    // leaf, every leaf x is 0, and the rest of the chain is the same
-    r = dense ? cx + (cy + cz * g.div[1]) * g.div[0] : cy + cz * g.div[1];
+    // The counting sort's bucket is a SEGMENT of 2^seg_shift leaves of a grid row: the whole row for a sweep (seg_shift = 31: tens of
+    // thousands of buckets, a few hundred points in the fullest), the leaf itself for a dense cloud (seg_shift = 0), and in between for a
+    // large cloud in a box too big for leaf buckets (a keyframe store: the ranking pass below is quadratic in a bucket's population, and
+    // a ground-level row of such a store holds thousands of points -- 140 us of a 0.19 ms filter).  Buckets in (k, j, segment) order and
+    // points by (leaf x, index) inside one give the order of idx = i + j dx + k dx dy whatever the segment length.
+    r = (cy + cz * g.div[1]) * nseg + (cx >> seg_shift);
     row_of[i] = r;
-    lx[i] = dense ? 0 : cx;
+    lx[i] = seg_shift >= 13 ? cx : (cx & ((1 << seg_shift) - 1));
   }
   const unsigned long long nm = __ballot(near);
   if (nm && lane == __ffsll((long long)nm) - 1) atomicOr(flags, 4);
@@ -158,34 +161,60 @@ k_vg_rows_count(const float* __restrict__ in, int stride_f, int n, float inv, Le
   base = __shfl(base, head_lane);
   if (valid) slot[i] = base + (lane - head_lane);
 }
-// arrival-order placement: tmp[row start + slot] = (leaf x, point index) packed, the key the rank compares
+// arrival-order placement: tmp[row start + slot] = one 64-bit record per point.  kVgPacked (leaf x < 2^13: the host checks the grid):
+//   {leaf x : 13 | point index : 27 | arrival slot in the row : 12 | row population : 12}  -- its top 40 bits are the key the rank compares,
+//   and the ranking pass finds the row's extent in the record itself (s - slot, + population) instead of looking the point's row and the
+//   row's bounds up: two dependent random reads per point into tables of millions of entries, which is what that pass cost (60 us of a
+//   1.3 M-point keyframe store's filter).  A row of more than 4095 points leaves the population field 0: looked up as before.
+// otherwise {leaf x : 32 | point index : 32}.
+constexpr int kVgIdxBits = 27, kVgCntBits = 12;
+constexpr unsigned long long kVgCntMask = (1ull << kVgCntBits) - 1ull;
+template <bool kVgPacked>
 __global__ void k_vg_rows_place(int n, const int* __restrict__ row_of, const int* __restrict__ lx, const int* __restrict__ slot,
                                 const int* __restrict__ start, unsigned long long* __restrict__ tmp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  tmp[start[row_of[i]] + slot[i]] = ((unsigned long long)(unsigned)lx[i] << 32) | (unsigned)i;
+  const int r = row_of[i], s0 = start[r], sl = slot[i];
+  if (kVgPacked) {
+    const int cnt = start[r + 1] - s0;
+    const unsigned long long tail = cnt <= (int)kVgCntMask ? (((unsigned long long)(unsigned)sl << kVgCntBits) | (unsigned)cnt) : 0ull;
+    tmp[s0 + sl] = ((unsigned long long)(unsigned)lx[i] << (kVgIdxBits + 2 * kVgCntBits)) | ((unsigned long long)(unsigned)i << (2 * kVgCntBits)) | tail;
+  } else {
+    tmp[s0 + sl] = ((unsigned long long)(unsigned)lx[i] << 32) | (unsigned)i;
+  }
 }
 // final slot of a point = row start + number of same-row points that precede it in (leaf x, point index) order;
-// order[slot] = point index, leaf[slot] = (row, leaf x) packed: equal values = same leaf
+// order[slot] = point index, leaf[slot] = (row start, leaf x) packed: equal values = same leaf
+template <bool kVgPacked>
 __global__ void k_vg_rows_rank(int n, const int* __restrict__ row_of, const int* __restrict__ start, const unsigned long long* __restrict__ tmp,
                                int* __restrict__ order, unsigned long long* __restrict__ leaf) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const unsigned long long me = tmp[s];
-  const int i = (int)(unsigned)me;
-  const int r = row_of[i];
-  const int s0 = start[r], s1 = start[r + 1];
+  constexpr int kKeyShift = kVgPacked ? 2 * kVgCntBits : 0;
+  const int i = kVgPacked ? (int)((me >> kKeyShift) & ((1ull << kVgIdxBits) - 1ull)) : (int)(unsigned)me;
+  const unsigned lxv = kVgPacked ? (unsigned)(me >> (kVgIdxBits + kKeyShift)) : (unsigned)(me >> 32);
+  int s0, s1;
+  if (kVgPacked && (me & kVgCntMask) != 0) {
+    s0 = s - (int)((me >> kVgCntBits) & kVgCntMask);
+    s1 = s0 + (int)(me & kVgCntMask);
+  } else {
+    const int r = row_of[i];
+    s0 = start[r];
+    s1 = start[r + 1];
+  }
+  const unsigned long long key = me >> kKeyShift;
   int rank = 0, t = s0;
   for (; t + 8 <= s1; t += 8) {  // eight independent loads in flight: a ring of the sweep inside one row is hundreds of members
     unsigned long long o[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) o[u] = tmp[t + u];
 #pragma unroll
-    for (int u = 0; u < 8; u++) rank += (o[u] < me);
+    for (int u = 0; u < 8; u++) rank += ((o[u] >> kKeyShift) < key);
   }
-  for (; t < s1; t++) rank += (tmp[t] < me);
+  for (; t < s1; t++) rank += ((tmp[t] >> kKeyShift) < key);
   order[s0 + rank] = i;
-  leaf[s0 + rank] = ((unsigned long long)(unsigned)r << 32) | (me >> 32);
+  leaf[s0 + rank] = ((unsigned long long)(unsigned)s0 << 32) | lxv;
 }
 // pos[s] = number of leaf heads before s inside this block of 2048 sorted slots; block_sums[b] = heads in block b
 __global__ void __launch_bounds__(VG_SCAN_T)
@@ -279,14 +308,21 @@ void transform_q(hipStream_t s, const float* in, int stride_f, int n, Quat q, co
 void vg_bbox(hipStream_t s, const float* in, int stride_f, int n, float inv, int* mm6, int* flags) {
   hipLaunchKernelGGL(k_vg_bbox, dim3(min(nblk(n, 256), 1024)), dim3(256), 0, s, in, stride_f, n, inv, mm6, flags);
 }
-void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int dense, int* row_of, int* lx, int* slot_then_pos, int* cnt,
+int vg_segments(const LeafGrid& g, int seg_shift) { return seg_shift >= 31 ? 1 : (int)(((long long)g.div[0] + (1ll << seg_shift) - 1) >> seg_shift); }
+void vg_rows(hipStream_t s, const float* in, int stride_f, int n, float inv, LeafGrid g, int edge, int seg_shift, int* row_of, int* lx, int* slot_then_pos, int* cnt,
              int* start, void* row_block_sums, unsigned long long* tmp, int* order, unsigned long long* leaf, int* head_block_sums, float* out,
              int* res) {
-  const int nr1 = g.div[1] * g.div[2] * (dense ? g.div[0] : 1) + 1;
-  hipLaunchKernelGGL(k_vg_rows_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, inv, g, edge, dense, row_of, lx, cnt, slot_then_pos, res + 1);
+  const int nseg = vg_segments(g, seg_shift);
+  const int nr1 = g.div[1] * g.div[2] * nseg + 1;
+  hipLaunchKernelGGL(k_vg_rows_count, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, inv, g, edge, seg_shift, nseg, row_of, lx, cnt, slot_then_pos, res + 1);
   scan_cells(s, cnt, start, nr1, row_block_sums, nullptr, nullptr, 0, nullptr);
-  hipLaunchKernelGGL(k_vg_rows_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, lx, slot_then_pos, start, tmp);
-  hipLaunchKernelGGL(k_vg_rows_rank, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, start, tmp, order, leaf);
+  if ((seg_shift <= 13 || g.div[0] <= (1 << 13)) && n <= (1 << kVgIdxBits)) {  // (the packed record holds 13 bits of leaf x inside the bucket and 27 of point index)
+    hipLaunchKernelGGL(k_vg_rows_place<true>, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, lx, slot_then_pos, start, tmp);
+    hipLaunchKernelGGL(k_vg_rows_rank<true>, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, start, tmp, order, leaf);
+  } else {
+    hipLaunchKernelGGL(k_vg_rows_place<false>, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, lx, slot_then_pos, start, tmp);
+    hipLaunchKernelGGL(k_vg_rows_rank<false>, dim3(nblk(n, 256)), dim3(256), 0, s, n, row_of, start, tmp, order, leaf);
+  }
   hipLaunchKernelGGL(k_vg_rows_heads, dim3(nblk(n, VG_SCAN_B)), dim3(VG_SCAN_T), 0, s, leaf, n, slot_then_pos, head_block_sums);
   hipLaunchKernelGGL(k_vg_rows_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, order, leaf, slot_then_pos, head_block_sums, out, res);
 }
