@@ -31,7 +31,7 @@ constexpr int kMaxK = 32;
 // system-scope one -- the L2s written back so that the HOST may read what came before; nobody's host does behind these).
 constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 // Build-time switches (RGC_EXTRA_FLAGS=-D...): alternative routes to the SAME results, kept for A/B measurements.  A caller's
-// process reads only RGC_LM_IMPL, RGC_SPEC_GRID and RGC_TRACE_ALLOC from the environment (rgc_create).
+// process reads only RGC_LM_IMPL, RGC_SPEC_GRID, RGC_KNN_SEEDS and RGC_TRACE_ALLOC from the environment (rgc_create).
 #ifndef RGC_LM_POST
 #define RGC_LM_POST 1          // 0: rgc_align_end always waits for the stream and its copy of the state (round 2)
 #endif
@@ -46,6 +46,9 @@ constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 #endif
 #ifndef RGC_LM_SPARE_ASIDE
 #define RGC_LM_SPARE_ASIDE 1   // 0: a solve's spare step launches stay on its own stream, in front of whatever comes next there (round 3)
+#endif
+#ifndef RGC_KNN_SEEDS
+#define RGC_KNN_SEEDS 1        // 0: the map's exact search never starts from the previous search's k-th distances (round 4)
 #endif
 #ifndef RGC_MAP_WIDE_R
 #define RGC_MAP_WIDE_R 2       // block radius of the bulk kNN launch for a sparse map (0 = off, 2)
@@ -94,6 +97,14 @@ struct Cloud {
   int need_stamp = 0;
   const void* need_seen = nullptr;  // the allocation the stamps refer to
   int lazy_nq_seen = -1, lazy_ncell_seen = -1;  // the previous frame's list sizes (they size this frame's launches)
+  // seeds of the exact search (rgck::KnnSeeds): kept while the target is a re-expression of the SAME buffer (rgc_set_target_reframed: the
+  // key is the buffer it re-frames), one float per original point
+  DevBuf seed;
+  const void* seed_key = nullptr;
+  int seed_n = 0;
+  bool seed_on = false;    // this cloud's searches read and write them
+  bool seed_warm = false;  // ... and some search has written them
+  float seed_slack = 0.f;
 };
 
 struct ProfRegion {
@@ -166,6 +177,7 @@ struct rgc_ctx {
   bool solve_behind_map = RGC_SOLVE_BEHIND_MAP != 0;  // (build flag) 0: the solve always on the scan's (high-priority) stream, as in round 2
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
+  bool seeds_on = RGC_KNN_SEEDS != 0;  // (build flag; RGC_KNN_SEEDS=0 in the environment) 0: every search of a re-framed map starts without a bound, as before round 5
   double src_res = RGC_SRC_RES;  // (build flag) fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
   int map_wide_r = RGC_MAP_WIDE_R;          // (build flag; 0 = off, 2) block radius of the bulk kNN launch for a sparse map
   double map_wide_density = RGC_MAP_WIDE;   // (build flag) ... when the map has fewer points per grid cell than this
@@ -272,7 +284,7 @@ void release(DevBuf& b) {
 
 void release_cloud(Cloud& cl) {
   for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.slot_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs,
-                    &cl.cell_voxel, &cl.vox, &cl.vox_cell, &cl.need, &cl.qlist, &cl.cell_list})
+                    &cl.cell_voxel, &cl.vox, &cl.vox_cell, &cl.need, &cl.qlist, &cl.cell_list, &cl.seed})
     release(*b);
 }
 
@@ -431,6 +443,29 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     const bool fuse_reframe = cl.reframe_pending && hint != nullptr && cl.stride_f == 4 && ((uintptr_t)cl.in & 15) == 0;  // (k_count<true> stores float4)
     if (cl.reframe_pending && !fuse_reframe)
       rgck::transform_q(s, cl.rf.src, cl.rf.src_stride_f, n, cl.rf.q, cl.rf.t, const_cast<float*>(cl.in), 4);
+    // Seeds of the exact search: a re-framed map is the point set of cl.rf.src moved rigidly, so what the last search of that buffer found
+    // bounds this one (rgck::KnnSeeds; exactness does not depend on it).  Any other target: no seeds.
+    cl.seed_on = false;
+    if (is_target && &cl == &c->tgt && cl.reframe_pending && c->seeds_on && rgck::knn_seeds_apply(n, c->prm.k_correspondences)) {
+      int rc;
+      if (cl.seed_key != (const void*)cl.rf.src || cl.seed_n != n || !cl.seed.p) {
+        if ((rc = ensure(c, cl.seed, sizeof(float) * (size_t)n))) return rc;
+        HIPCHK(c, hipMemsetAsync(cl.seed.p, 0x7f, sizeof(float) * (size_t)n, s));  // 3.4e38: "no seed"
+        cl.seed_key = cl.rf.src;
+        cl.seed_n = n;
+        cl.seed_warm = false;
+      }
+      cl.seed_on = true;
+      // the coordinates' fp32 rounding, twice (two frames), on either end of a distance: 4 ulp of the largest coordinate of the box
+      double maxabs = 1.0;
+      if (hint) for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::max(std::fabs(hint->lo[a]), std::fabs(hint->hi[a])));
+      else maxabs = 1024.0;
+      int e2;
+      (void)std::frexp(1.5 * maxabs, &e2);
+      cl.seed_slack = (float)(4.0 * std::ldexp(1.0, e2 - 24));
+    } else if (is_target && &cl == &c->tgt) {
+      cl.seed_key = nullptr;
+    }
     cl.reframe_pending = false;
     if (hint) {
       spec = true;
@@ -564,6 +599,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   return RGC_OK;
 }
 
+rgck::KnnSeeds cloud_seeds(const Cloud& cl, bool is_target) {
+  rgck::KnnSeeds sd;
+  if (is_target && cl.seed_on) { sd.seed = (float*)cl.seed.p; sd.slack = cl.seed_slack; sd.warm = cl.seed_warm; }
+  return sd;
+}
+
 // C2 / C3 of a cloud whose grid is built: exact-kNN covariances (+ the Gaussian voxel map for the target), enqueued on the cloud's stream.
 int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
   const int n = cl.n, k = c->prm.k_correspondences;
@@ -587,15 +628,17 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
       own.kind = kind;
       own.points = n;
     }
+    const rgck::KnnSeeds seeds = cloud_seeds(cl, is_target);
     if (self_timed) {
       rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
-                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, own.a, own.b);
+                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, own.a, own.b, nullptr, nullptr, 0, seeds);
       c->prof_open.push_back(own);
     } else {
       ProfScope ps(c, kind, n, s);
       rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
-                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r);
+                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, nullptr, nullptr, nullptr, nullptr, 0, seeds);
     }
+    if (seeds.seed && wide_r == 0) cl.seed_warm = true;
   }
   // The map's deferred queries (~100 of a million, one wave each: 20 us of latency) are resolved in the SAME launch as the voxel map's
   // build (k_voxel_build_coop); the few voxels that hold one are recomputed behind it (k_voxel_patch).  The scan has no voxel map:
@@ -661,7 +704,8 @@ int lazy_build(rgc_ctx* c, const float guess[16]) {
   {
     ProfScope ps(c, RGC_K_KNN_COV, n, s);
     rgck::knn_bulk(s, true, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p,
-                   guard, 0, nullptr, nullptr, (const int*)cl.qlist.p, counts, q_est);
+                   guard, 0, nullptr, nullptr, (const int*)cl.qlist.p, counts, q_est, cloud_seeds(cl, true));
+    if (cl.seed_on) cl.seed_warm = true;
   }
   {
     const int coop_waves = cl.deferred_seen >= 0 ? cl.deferred_seen + cl.deferred_seen / 4 + 32 : n / 64 + 32;
@@ -1273,6 +1317,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipEventCreateWithFlags(&c->vg_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_vg, 4 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
+  if (const char* e = getenv("RGC_KNN_SEEDS")) c->seeds_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   { std::lock_guard<std::mutex> lk(g_live_mutex); g_live.insert(c); }
@@ -2579,9 +2624,13 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   return RGC_OK;
 }
 
+#if defined(RGC_LAB) || defined(RGC_LAB_BLK)
+RGC_API int rgc_lab_blocks(rgc_ctx*, long long* out65536) { rgck::lab_blocks(out65536); return RGC_OK; }
+#endif
 #ifdef RGC_LAB
 RGC_API int rgc_lab_lm_ts(rgc_ctx* c, unsigned long long* out16) { rgck::lab_lm_ts(out16, c->stream); return RGC_OK; }
 RGC_API int rgc_lab_why(rgc_ctx*, int* out8) { rgck::lab_why(out8); return RGC_OK; }
+RGC_API int rgc_lab_declines(rgc_ctx*, int* out16) { rgck::lab_declines(out16); return RGC_OK; }
 RGC_API int rgc_lab_iters(rgc_ctx*, unsigned long long* out8) { rgck::lab_iters(out8); return RGC_OK; }
 RGC_API int rgc_lab_wave_ts(rgc_ctx* c, long long* out16384) { (void)hipStreamSynchronize(c->stream); rgck::lab_wave_ts(out16384, c->stream2); return RGC_OK; }
 // developer build only (-DRGC_LAB): the deferred-query list of a cloud as the bulk kNN kernel left it

@@ -79,12 +79,21 @@ void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int*
 // bulk kernel (one lane per query; defers what it cannot finish) then the cooperative kernel (one wave per deferred query).
 // deferred: deferred_bytes(n) bytes, whose first int (the count) must be 0 on entry (rank_gather's zero_me)
 size_t deferred_bytes(int n);
+// Seeds of the map's search (knn_point_seeded): seed[original point index] = an upper bound of the k-th squared distance the last search
+// of that point found (>= 1e30: none); slack = how much a k-th distance may have grown since, in metres; warm = a search has written
+// them.  Results do not depend on the seeds' values (a search they do not serve runs again without them).
+struct KnnSeeds {
+  float* seed = nullptr;
+  float slack = 0.f;
+  bool warm = false;
+};
+bool knn_seeds_apply(int n, int k);  // the seeded search exists for this cloud size and k
 // wide_r = 2: the four-lanes-per-query search on the 5^3 block whatever the cloud (a sparse map)
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard = nullptr, int wide_r = 0,
               hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* dense-map launch only (knn_bulk_times_itself): the launch's own start / stop times */,
               // lazy target (dense-map launch only): the queries listed in qlist[0 .. *nq) are searched, nothing else; q_est sizes the launch
-              const int* qlist = nullptr, const int* nq = nullptr, int q_est = 0);
+              const int* qlist = nullptr, const int* nq = nullptr, int q_est = 0, const KnnSeeds& seeds = KnnSeeds{});
 // lazy target: stamp the cells of grid g within `margin` cells of the cell each point of the cloud falls into under T and list the occupied
 // ones (cell_list: their first sorted point; qlist: all their points; counts[0] / [1]: the lists' sizes, zeroed by rank_gather)
 void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, int* need, int stamp, int margin, const float4* P, int n_map,
@@ -202,9 +211,13 @@ void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const fl
 void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const float* dsrc, const float* osrc, float* sharp, float* flat, float* inten,
              int cap, int* counts);
 
+#if defined(RGC_LAB) || defined(RGC_LAB_BLK)
+void lab_blocks(long long* out65536);  // developer build: {start, end, XCC, first query} of every workgroup of the map's bulk kNN launch
+#endif
 #ifdef RGC_LAB
 void lab_lm_ts(unsigned long long* out16, hipStream_t s);  // developer build: phase timestamps of k_lm_step
 void lab_why(int* out8);
+void lab_declines(int* out16);                              // developer build: why knn_point_seeded declined, per lane (and resets)
 void lab_iters(unsigned long long* out8);                   // developer build: wave-level loop counts of the map's bulk kNN kernel (and resets them)
 void lab_wave_ts(long long* out16384, hipStream_t s);       // developer build: start / end of the scan kNN launch's waves
 #endif

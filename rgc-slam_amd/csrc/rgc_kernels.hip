@@ -110,8 +110,22 @@ void lab_iters(unsigned long long* out8) {
   unsigned long long z[8] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_iter), z, sizeof(z));
 }
+__device__ int g_lab_decl[16];  // developer build: why knn_point_seeded declined, per LANE (1 no seed, 2 crowded row, 3 fewer than k, 4 more than k + 1, 5 k keys undecided, 6 k + 2 may contend, 7 three contenders, 8 exact tie)
+#define LAB_DECLINE(r) atomicAdd(&g_lab_decl[r], 1)
+void lab_declines(int* out16) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lab_decl), sizeof(g_lab_decl));
+  int z[16] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_decl), z, sizeof(z));
+}
 #else
 #define LAB_COUNT(slot) do {} while (0)
+#ifdef RGC_LAB_BLK
+__device__ int g_lab_blk_why[16384];  // developer build: OR of (1 << reason) over the lanes of a workgroup whose seeded search declined
+#define LAB_DECLINE(r) atomicOr(&g_lab_blk_why[blockIdx.x < 16384 ? blockIdx.x : 0], 1 << (r))
+#else
+#define LAB_DECLINE(r) do {} while (0)
+#endif
 #endif
 
 // Bounding box in CELL coordinates.  voxel_coord1 is monotone, so the per-thread work is a float min/max (the fp64
@@ -776,7 +790,10 @@ __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3],
   }
 }
 
-constexpr int KNN_T = 256;  // (64- and 128-thread workgroups: the same launch time, round 3)
+#ifndef RGC_KNN_T
+#define RGC_KNN_T 256
+#endif
+constexpr int KNN_T = RGC_KNN_T;  // (64- and 128-thread workgroups: the same launch time, round 3)
 #ifndef RGC_XCD_RUN
 #define RGC_XCD_RUN 16
 #endif
@@ -794,6 +811,11 @@ struct Deferred {
   // margin of a cell the scan falls into at the guess, compacted by k_footprint (qlist[0 .. *nq)); null: every query, in cell order
   const int* qlist;
   const int* nq;
+  // seeds (nullable; a map that is a rigid re-expression of a buffer seen before, rgc_set_target_reframed): per ORIGINAL point index an
+  // upper bound of the k-th squared distance the last search of that point found -- where the next search starts pruning (knn_point_seeded).
+  // Any value is safe: a search that does not find its k neighbours under the bound runs again without it.
+  float* seed;
+  float seed_slack;  // how much a k-th distance may have grown since (the coordinates' fp32 rounding in two different frames), metres
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -874,6 +896,11 @@ struct SpOrder {
 constexpr int kSort24N = 132;
 __device__ constexpr unsigned short kSort24[kSort24N] = {1, 67, 2, 35, 34, 133, 199, 134, 167, 166, 4, 70, 68, 37, 103, 101, 34, 100, 166, 265, 331, 266, 299, 298, 397, 463, 398, 431, 430, 268, 334, 332, 301, 367, 365, 298, 364, 430, 8, 140, 136, 74, 206, 202, 68, 200, 332, 41, 173, 169, 107, 239, 235, 101, 233, 365, 34, 100, 166, 232, 298, 364, 430, 529, 595, 530, 563, 562, 661, 727, 662, 695, 694, 532, 598, 596, 565, 631, 629, 562, 628, 694, 596, 629, 562, 628, 694, 16, 272, 148, 404, 136, 400, 82, 338, 214, 470, 202, 466, 68, 200, 332, 464, 596, 49, 305, 181, 437, 169, 433, 115, 371, 247, 503, 235, 499, 101, 233, 365, 497, 629, 34, 100, 166, 232, 298, 364, 430, 496, 562, 628, 694};
 
+// The same network cut to 20 wires: 101 compare-exchanges (checked on all 2^20 zero-one inputs).  It puts the k = 20 winning ordinals of
+// the map's search into ascending order: the order the moments are summed in (below).
+constexpr int kSort20N = 101;
+__device__ constexpr unsigned short kSort20[kSort20N] = {1, 67, 2, 35, 34, 133, 199, 134, 167, 166, 4, 70, 68, 37, 103, 101, 34, 100, 166, 265, 331, 266, 299, 298, 397, 463, 398, 431, 430, 268, 334, 332, 301, 367, 365, 298, 364, 430, 8, 140, 136, 74, 206, 202, 68, 200, 332, 41, 173, 169, 107, 239, 235, 101, 233, 365, 34, 100, 166, 232, 298, 364, 430, 529, 595, 530, 563, 562, 16, 272, 136, 400, 82, 338, 202, 466, 68, 200, 332, 464, 49, 305, 169, 433, 115, 371, 235, 499, 101, 233, 365, 497, 34, 100, 166, 232, 298, 364, 430, 496, 562};
+
 // a = med3(below, a, x), IN PLACE: the chain's registers stay where they are across the loops they are carried through (with a
 // separate output operand the compiler shuffles all of them at every loop boundary)
 __device__ __forceinline__ void med3_inplace(int& a, int below, int x) { asm("v_med3_i32 %0, %1, %0, %2" : "+v"(a) : "v"(below), "v"(x)); }
@@ -908,13 +935,12 @@ __device__ __forceinline__ float dist2_fma(float px, float py, float pz, float c
 // LDS-address-space pointers (32 bits): through a generic int* every address computation is a 64-bit add
 typedef __attribute__((address_space(3))) int lds_int;
 
-// The piece table of query (c, q) in the lane's LDS columns tmix / tlo (stride T), nearest first; returns the number of pieces.
-// heavy_piece: some piece is too long for its table entry (or, without clipping, for the row-relative ordinal).
-template <bool kClip, int R, int T>
-__device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, const Grid& g, const int (&c)[3], const double (&q)[3],
-                                              lds_int* const tmix, lds_int* const tlo, bool& heavy_piece) {
+// The pieces of query (c, q)'s block, in registers and in MEMORY order: [lo, hi) of the sorted array and a lower bound of the squared
+// distance from the query to anything in the piece (rounded down a little).
+template <bool kClip, int R>
+__device__ __forceinline__ void sp_pieces(const int* __restrict__ start, const Grid& g, const int (&c)[3], const double (&q)[3],
+                                          int (&lo)[SpShape<R, kClip>::NP], int (&hi)[SpShape<R, kClip>::NP], float (&min2)[SpShape<R, kClip>::NP]) {
   using Shape = SpShape<R, kClip>;
-  constexpr int kRowRel = 127;
   constexpr int D = Shape::D, NROW = Shape::NROW, NP = Shape::NP, OWN = NROW / 2;
   // ---- the block's pieces in MEMORY order: the D x D grid rows in the order of cell_index (row_dy / row_dz), each the cells cx - R .. cx + R.  kClip: the
   // own row (r = OWN) as three pieces cut at multiples of four points from its start -- left of the own cell, the own cell, right
@@ -932,8 +958,6 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
   }
   auto axis_gap = [&](int a, int d) { return d == 0 ? 0.0 : (d < 0 ? wlo[a] + (double)(-d - 1) * g.res : whi[a] + (double)(d - 1) * g.res); };
   auto bound2 = [&](double gy, double gz) { return (float)((gy * gy + gz * gz) * (1.0 - 1.0e-6)); };  // rounded down a little: never too high
-  int lo[NP], hi[NP];
-  float min2[NP];
 #pragma unroll
   for (int r = 0; r < NROW; r++) {
     const int dy = row_dy(r, D, R), dz = row_dz(r, D, R);
@@ -984,6 +1008,19 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
       }
     }
   }
+}
+
+// The piece table of query (c, q) in the lane's LDS columns tmix / tlo (stride T), nearest first; returns the number of pieces.
+// heavy_piece: some piece is too long for its table entry (or, without clipping, for the row-relative ordinal).
+template <bool kClip, int R, int T>
+__device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, const Grid& g, const int (&c)[3], const double (&q)[3],
+                                              lds_int* const tmix, lds_int* const tlo, bool& heavy_piece) {
+  using Shape = SpShape<R, kClip>;
+  constexpr int kRowRel = 127;
+  constexpr int NP = Shape::NP;
+  int lo[NP], hi[NP];
+  float min2[NP];
+  sp_pieces<kClip, R>(start, g, c, q, lo, hi, min2);
   // ---- piece table, nearest first (SpOrder).  Entry: kClip {distance bound | quads} until the piece is entered, then its first
   // ordinal; otherwise the first ordinal at once. ----
 #pragma unroll
@@ -1006,6 +1043,42 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
     }
   }
   return nr;
+}
+
+// Mean / covariance (fast_gicp_impl.hpp:256-262) / normal of query (px, py, pz) from its neighbours' positions idx[0 .. k) in the sorted
+// array.  One pass: with u_j = p_j - q (exact in fp64: both are fp32 values), cov = sum u u^T / k - ubar ubar^T -- the reference's
+// centred sum up to rounding (|u| <= a few cells, so nothing cancels badly), half the gathers of the two-pass form.
+// kFull (k == KC, the reference's k = 20) runs without per-neighbour guards: a load under a branch is waited for where the branch
+// ends, which would serialise the gathers.
+template <int KC, bool kFull>
+__device__ __forceinline__ void sp_normal_of(const float4* __restrict__ P, const int (&idx)[KC], float px, float py, float pz, int k, int i,
+                                             double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
+  double S[6] = {0, 0, 0, 0, 0, 0};
+  const double qx = (double)px, qy = (double)py, qz = (double)pz;
+  double mx = 0, my = 0, mz = 0;
+#pragma unroll
+  for (int j = 0; j < KC; j++) {
+    if (kFull || j < k) {
+      const float4 cp = point_at(P, (unsigned)idx[j] << 4);
+      const double dx = (double)cp.x - qx, dy = (double)cp.y - qy, dz = (double)cp.z - qz;
+      mx += dx; my += dy; mz += dz;
+      // (explicit fma: the file is compiled without contraction for the sake of dist2(); these sums have no such constraint)
+      S[0] = fma(dx, dx, S[0]); S[1] = fma(dx, dy, S[1]); S[2] = fma(dx, dz, S[2]);
+      S[3] = fma(dy, dy, S[3]); S[4] = fma(dy, dz, S[4]); S[5] = fma(dz, dz, S[5]);
+    }
+  }
+  const double inv_k = 1.0 / (double)k;
+  mx *= inv_k; my *= inv_k; mz *= inv_k;
+  S[0] = S[0] * inv_k - mx * mx; S[1] = S[1] * inv_k - mx * my; S[2] = S[2] * inv_k - mx * mz;
+  S[3] = S[3] * inv_k - my * my; S[4] = S[4] * inv_k - my * mz; S[5] = S[5] * inv_k - mz * mz;
+  double nrm[3];
+  if (!min_eigenvector_direct(S, nrm)) {
+    LAB_COUNT(4);
+    min_eigenvector(S, nrm);
+  }
+  nx[i] = nrm[0];
+  ny[i] = nrm[1];
+  nz[i] = nrm[2];
 }
 
 // The MAP's search (a leaf-filtered cloud: nothing crowded, the block is nine whole rows).  KB: low key bits that hold the candidate's
@@ -1141,12 +1214,13 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     for (int j = 0; j < L && j < 24; j++) top.a[j] = w[j];
     tau = top.a[L - 1];
   }
+  // (one exit, at the head: with a second one between the halves the compiler waits for ALL loads at the head of the loop -- see
+  // knn_point_seeded; a wave may run one trip more than its longest lane needs)
   fetch(qa);
   for (;;) {
     if (!__any(qa.live)) break;
     fetch(qb);
     process(qa);
-    if (!__any(qb.live)) break;
     fetch(qa);
     process(qb);
   }
@@ -1194,45 +1268,245 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     return;
   }
   // ---- neighbour positions replace the keys, then mean / covariance (fast_gicp_impl.hpp:256-262) / normal ----
-  // One pass: with u_j = p_j - q (exact in fp64: both are fp32 values), cov = sum u u^T / k - ubar ubar^T -- the reference's
-  // centred sum up to rounding (|u| <= a few cells, so nothing cancels badly), half the gathers of the two-pass form.
-  // k == KC (the reference's k = 20) runs without per-neighbour guards: a load under a branch is waited for where the branch
-  // ends, which would serialise the gathers.
-  const int idx_k = swap ? index_of(a_k) : 0;
-  double S[6] = {0, 0, 0, 0, 0, 0};
-  auto moments = [&](auto full_tag) {
-    constexpr bool kFull = decltype(full_tag)::value;
+  // k == KC (the reference's k = 20): the neighbours are summed in ascending ORDINAL order -- the order the candidates were streamed in,
+  // which a seeded search (knn_point_seeded, no chain) has for free: both routes give the same bits.
+  int idx[KC];
+  if constexpr (kExact) {
+    static_assert(KC == 20, "the ordinal sort is a 20-input network");
+    int o[KC];
 #pragma unroll
-    for (int j = 0; j < KC; j++)
-      if (kFull || j < k) top.a[j] = (swap && j == k - 1) ? idx_k : index_of(top.a[j]);
-    const double qx = (double)px, qy = (double)py, qz = (double)pz;
-    double mx = 0, my = 0, mz = 0;
+    for (int j = 0; j < KC; j++) o[j] = top.a[j] & kKeyOrd;
+    if (swap) o[KC - 1] = a_k & kKeyOrd;
 #pragma unroll
-    for (int j = 0; j < KC; j++) {
-      if (kFull || j < k) {
-        const float4 cp = point_at(P, (unsigned)top.a[j] << 4);
-        const double dx = (double)cp.x - qx, dy = (double)cp.y - qy, dz = (double)cp.z - qz;
-        mx += dx; my += dy; mz += dz;
-        // (explicit fma: the file is compiled without contraction for the sake of dist2(); these sums have no such constraint)
-        S[0] = fma(dx, dx, S[0]); S[1] = fma(dx, dy, S[1]); S[2] = fma(dx, dz, S[2]);
-        S[3] = fma(dy, dy, S[3]); S[4] = fma(dy, dz, S[4]); S[5] = fma(dz, dz, S[5]);
+    for (int e = 0; e < kSort20N; e++) {
+      const int a = kSort20[e] >> 5, b = kSort20[e] & 31;
+      const int lo_ = min(o[a], o[b]);
+      o[b] = max(o[a], o[b]);
+      o[a] = lo_;
+    }
+#pragma unroll
+    for (int j = 0; j < KC; j++) idx[j] = tlo[(o[j] >> 7) * T] + (o[j] & kRowRel);
+  } else {
+    const int idx_k = swap ? index_of(a_k) : 0;
+#pragma unroll
+    for (int j = 0; j < KC; j++) idx[j] = j < k ? ((swap && j == k - 1) ? idx_k : index_of(top.a[j])) : 0;
+  }
+  if (kExact || k == KC) sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz);
+  else sp_normal_of<KC, false>(P, idx, px, py, pz, k, i, nx, ny, nz);
+  if (df.seed) df.seed[__float_as_int(pq.w)] = thr_up;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The map's search SEEDED with a bound (round 5).  A map handed over by rgc_set_target_reframed is the same point set as last time, rigidly
+// moved: a point's k-th neighbour distance is what the last search found, up to the fp32 rounding of the coordinates in the two frames
+// (df.seed_slack).  With the pruning bound known BEFORE the first candidate is fetched
+//  * a grid row whose distance bound is not below it never enters the table (knn_point_sp learns its bound from the candidates: it
+//    visits the nearest rows in full and sorts its first 24 candidates whatever they are),
+//  * a candidate is admitted iff its key is below the bound -- about k of them: they are APPENDED to the lane's LDS column and that is
+//    all; no sorted chain, no insert rounds, no sorting network.  The covariance is a sum over the neighbour SET
+//    (fast_gicp_impl.hpp:256-262) and is taken in the order the candidates were streamed in, which is the order knn_point_sp sorts
+//    its winners into: the two routes give the same bits.
+// Exactness does not rest on the seed.  The bound admits keys up to three buckets above the seeded distance; exactly k admitted keys
+// whose largest lies two buckets below the bound ARE the k nearest (everything not admitted is two buckets farther: the keys decide,
+// as in knn_point_sp); k + 1 admitted keys: the largest goes, or the exact distances decide between the two largest as there; fewer
+// than k (a stale seed: the caller overwrote the map in place), more than k + 1, a third contender or an exact tie: the lane returns
+// false and runs knn_point_sp, which also makes every deferral decision but "the block cannot prove the k-th distance" (made here from
+// the same k-th key, hence the same way).
+// LDS per lane: k + 6 key slots (a quad of candidates appends up to four before the count is looked at) and nine table entries
+// {first position << 6 | quads} of the rows to visit.
+// ------------------------------------------------------------------------------------------------
+template <int KC>
+struct SeedShape {
+  static constexpr int BUF = KC + 6;
+  static constexpr int LDS = BUF + SpShape<1, false>::NP;  // ints per lane
+};
+#ifndef RGC_SEED_ROW_SKIP
+#define RGC_SEED_ROW_SKIP 1
+#endif
+constexpr bool kSeedRowSkip = RGC_SEED_ROW_SKIP != 0;
+// a candidate's coordinates: the first 12 bytes of its 16-byte record (global_load_dwordx3: three quarters of the vector-memory
+// pipe's cycles of a 16-byte load; the original index is only needed of the query itself)
+#ifndef RGC_SEED_X3
+#define RGC_SEED_X3 1
+#endif
+#if RGC_SEED_X3
+struct Cand { float x, y, z; };
+__device__ __forceinline__ Cand cand_at(const float4* __restrict__ P, unsigned byte_off) {
+  typedef float f32x3 __attribute__((ext_vector_type(3)));
+  const f32x3 v = *reinterpret_cast<const f32x3*>(reinterpret_cast<const char*>(P) + byte_off);
+  return Cand{v.x, v.y, v.z};
+}
+#else
+typedef float4 Cand;
+__device__ __forceinline__ Cand cand_at(const float4* __restrict__ P, unsigned byte_off) { return point_at(P, byte_off); }
+#endif
+#ifndef RGC_SEED_DEPTH
+#define RGC_SEED_DEPTH 2
+#endif
+constexpr int kSeedDepth = RGC_SEED_DEPTH;  // quads of candidates in flight (2: one being processed, one loading; 3)
+constexpr int kSeedMaxPoints = (1 << 26) - 8;  // a table entry holds a position in 26 bits
+
+template <int KC, int KB, int T>
+__device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int n, int i, int* lds,
+                                                 const Deferred& df, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
+  constexpr int R = 1;
+  using Shape = SpShape<R, false>;
+  constexpr int NP = Shape::NP;
+  constexpr int kKeyOrd = (1 << KB) - 1;
+  constexpr int kRowRel = 127;
+  static_assert((NP << 7) <= (1 << KB), "ordinal bits: rows x 128");
+  lds_int* const buf = (lds_int*)lds;              // [KC + 6][T] admitted keys, in stream order
+  lds_int* const tab = buf + SeedShape<KC>::BUF * T;  // [NP][T]
+  const float4 pq = P[i];
+  const float px = pq.x, py = pq.y, pz = pq.z;
+  const int orig = __float_as_int(pq.w);
+  const float seed = df.seed[orig];
+  if (!(seed < 1.0e30f)) { LAB_DECLINE(1); return false; }  // never searched (or deferred every time)
+  // keys below tkey are admitted: the seeded k-th distance, grown by the slack, rounded up, plus three key buckets
+  const float rs = __builtin_sqrtf(seed) + df.seed_slack;
+  const int tkey = ((__float_as_int(rs * rs * 1.000001f) >> KB) + 3) << KB;
+  const float tauf = __int_as_float(tkey);
+  const int c[3] = {cell_coord(px, g) - g.minc[0], cell_coord(py, g) - g.minc[1], cell_coord(pz, g) - g.minc[2]};
+  const double q[3] = {(double)px, (double)py, (double)pz};
+  int nv = 0;
+  {
+    int lo[NP], hi[NP];
+    float min2[NP];
+    sp_pieces<false, R>(start, g, c, q, lo, hi, min2);
+    bool heavy = false;
+    constexpr SpOrder<R, false> kOrder{};
+#pragma unroll
+    for (int it = 0; it < NP; it++) {
+      const int p = kOrder.p[it];
+      const int len = hi[p] - lo[p];
+      const int quads = (len + 3) >> 2;
+      heavy |= quads > (kRowRel + 1) / 4;
+      if (len > 0 && (!kSeedRowSkip || min2[p] < tauf)) {  // (a row handed a neighbour's tail inherited its bound: sp_pieces)
+        tab[nv * T] = (lo[p] << 6) | quads;
+        nv++;
       }
     }
-    const double inv_k = 1.0 / (double)k;
-    mx *= inv_k; my *= inv_k; mz *= inv_k;
-    S[0] = S[0] * inv_k - mx * mx; S[1] = S[1] * inv_k - mx * my; S[2] = S[2] * inv_k - mx * mz;
-    S[3] = S[3] * inv_k - my * my; S[4] = S[4] * inv_k - my * mz; S[5] = S[5] * inv_k - mz * mz;
-  };
-  if (kExact || k == KC) moments(std::true_type{});
-  else moments(std::false_type{});
-  double nrm[3];
-  if (!min_eigenvector_direct(S, nrm)) {
-    LAB_COUNT(4);
-    min_eigenvector(S, nrm);
+    if (heavy) { LAB_DECLINE(2); return false; }  // a row of more than 128 candidates: knn_point_sp defers the query
   }
-  nx[i] = nrm[0];
-  ny[i] = nrm[1];
-  nz[i] = nrm[2];
+  // ---- one pass over the candidate stream: the loads of quad q + 1 in flight while quad q is processed, as in knn_point_sp ----
+  int ri = 0, ordn = 0;
+  unsigned off = 0, end = 0;
+  lds_int* bp = buf;
+  lds_int* const bp_cap = buf + (KC + 2) * T;  // k + 2 keys: "too many" whatever follows
+  struct Quad { Cand p0, p1, p2, p3; int ord; bool on, live; };
+  auto fetch = [&](Quad& qd) {
+    if (off >= end && ri < nv) {
+      const int e = tab[ri * T];
+      off = ((unsigned)e >> 6) << 4;
+      end = off + ((unsigned)(e & 63) << 6);
+      ordn = ri << 7;
+      ri++;
+    }
+    qd.on = off < end;
+    qd.live = qd.on || ri < nv;
+    qd.ord = ordn;
+    const unsigned a = qd.on ? off : (unsigned)n << 4;  // (unconditional loads: a lane that has run out of rows reads the sentinels)
+    qd.p0 = cand_at(P, a); qd.p1 = cand_at(P, a + 16); qd.p2 = cand_at(P, a + 32); qd.p3 = cand_at(P, a + 48);
+    off += qd.on ? 64u : 0u;
+    ordn += qd.on ? 4 : 0;
+  };
+  auto process = [&](const Quad& qd) {
+    LAB_COUNT(7);
+    if (qd.on) {
+      const int k0 = (__float_as_int(dist2_fma(px, py, pz, qd.p0.x, qd.p0.y, qd.p0.z)) & ~kKeyOrd) | qd.ord;
+      const int k1 = (__float_as_int(dist2_fma(px, py, pz, qd.p1.x, qd.p1.y, qd.p1.z)) & ~kKeyOrd) | (qd.ord + 1);
+      const int k2 = (__float_as_int(dist2_fma(px, py, pz, qd.p2.x, qd.p2.y, qd.p2.z)) & ~kKeyOrd) | (qd.ord + 2);
+      const int k3 = (__float_as_int(dist2_fma(px, py, pz, qd.p3.x, qd.p3.y, qd.p3.z)) & ~kKeyOrd) | (qd.ord + 3);
+      if (k0 < tkey) { *bp = k0; bp += T; }
+      if (k1 < tkey) { *bp = k1; bp += T; }
+      if (k2 < tkey) { *bp = k2; bp += T; }
+      if (k3 < tkey) { *bp = k3; bp += T; }
+      bp = bp < bp_cap ? bp : bp_cap;
+    }
+  };
+  // ONE exit, at the head of the loop: a second one between the two halves makes the structurizer route both through a common latch
+  // block, where the compiler's scoreboard merges "the first set's loads are pending" with "the second set's are" and puts an
+  // s_waitcnt vmcnt(0) at the loop's head -- every other trip waited for the loads it had just issued (the loop of rounds 2-4 did).
+  // A wave may run one trip more than its longest lane needs (sentinel loads, nothing appended).
+  if constexpr (kSeedDepth == 3) {  // two quads' loads in flight behind the one being processed
+    Quad qa, qb, qc;
+    fetch(qa);
+    fetch(qb);
+    for (;;) {
+      if (!__any(qa.live)) break;
+      fetch(qc);
+      process(qa);
+      fetch(qa);
+      process(qb);
+      fetch(qb);
+      process(qc);
+    }
+  } else {
+    Quad qa, qb;
+    fetch(qa);
+    for (;;) {
+      if (!__any(qa.live)) break;
+      fetch(qb);
+      process(qa);
+      fetch(qa);
+      process(qb);
+    }
+  }
+  const int m = (int)(bp - buf) / T;
+  if (m < KC || m > KC + 1) { LAB_DECLINE(m < KC ? 3 : 4); return false; }
+  const bool extra = m > KC;
+  // ---- the admitted keys, their largest two and where the largest sits ----
+  int w[KC + 1];
+#pragma unroll
+  for (int j = 0; j <= KC; j++) w[j] = buf[j * T];
+  if (!extra) w[KC] = -1;  // (keys are non-negative)
+  int mx = w[0], mx2 = -1, pos = 0;
+#pragma unroll
+  for (int j = 1; j <= KC; j++) {
+    const bool gt = w[j] > mx;
+    const int t2 = max(mx2, w[j]);
+    mx2 = gt ? mx : t2;
+    pos = gt ? j : pos;
+    mx = max(mx, w[j]);
+  }
+  int kth_key = extra ? mx2 : mx;
+  int drop = extra ? pos : KC;  // the slot that is not a neighbour
+  const int next_bucket = extra ? (mx >> KB) : (tkey >> KB);  // of the (k+1)-th key, or below it
+  auto index_of = [&](int key) {
+    const int o = key & kKeyOrd;
+    return (int)((unsigned)tab[(o >> 7) * T] >> 6) + (o & kRowRel);
+  };
+  if (next_bucket - (kth_key >> KB) < 2) {  // the keys cannot order the k-th and the (k+1)-th candidate
+    if (!extra) { LAB_DECLINE(5); return false; }  // (the seed was too tight to tell)
+    if ((tkey >> KB) - (mx >> KB) < 2) { LAB_DECLINE(6); return false; }  // the (k+2)-th may be a contender too
+    int mx3 = -1, pos2 = 0;
+#pragma unroll
+    for (int j = 0; j <= KC; j++) {
+      pos2 = w[j] == mx2 ? j : pos2;
+      mx3 = (w[j] != mx && w[j] != mx2) ? max(mx3, w[j]) : mx3;
+    }
+    if ((mx2 >> KB) - (mx3 >> KB) < 2) { LAB_DECLINE(7); return false; }  // three contenders
+    LAB_COUNT(5);
+    const float4 p1 = P[index_of(mx2)], p2 = P[index_of(mx)];
+    const float d1 = dist2(px, py, pz, p1), d2 = dist2(px, py, pz, p2);  // the reference's expression, uncontracted
+    if (d1 == d2) { LAB_DECLINE(8); return false; }  // an exact tie: the original index decides (cooperative kernel)
+    if (d2 < d1) { kth_key = mx; drop = pos2; }
+  }
+  const float thr_up = __int_as_float(kth_key | kKeyOrd);  // upper bound of the k-th squared distance
+  const double bound = cube_bound(g, c, q, R);
+  const bool proven = (bound == 1.0e300) || (bound > 0.0 && (double)thr_up < bound * bound * (1.0 - 1e-5));
+  if (!proven) {  // (knn_point_sp's decision and its entry)
+    const int e = atomicAdd(df.cnt, 1);
+    df.idx[e] = ~i;
+    df.thr[e] = (double)thr_up < 3.0 * (R + 1) * (R + 1) * g.res * g.res ? thr_up : INFINITY;
+    return true;
+  }
+  int idx[KC];
+#pragma unroll
+  for (int j = 0; j < KC; j++) idx[j] = index_of(j >= drop ? w[j + 1] : w[j]);
+  sp_normal_of<KC, true>(P, idx, px, py, pz, KC, i, nx, ny, nz);
+  df.seed[orig] = thr_up;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1397,11 +1671,10 @@ __device__ __forceinline__ bool knn_point_split(const float4* __restrict__ P, co
     refresh();
   }
   fetch(qa);
-  for (;;) {
+  for (;;) {  // (one exit, at the head: see knn_point_seeded)
     if (!__any(qa.live)) break;
     fetch(qb);
     process(qa);
-    if (!__any(qb.live)) break;
     fetch(qa);
     process(qb);
   }
@@ -1544,6 +1817,14 @@ template <bool kTarget> struct SpConfig {
   static constexpr int T = kTarget ? KNN_T : WAVE;
 };
 
+#if defined(RGC_LAB) || defined(RGC_LAB_BLK)
+#define RGC_LAB_BLOCKS 1
+__device__ long long g_lab_blk[4 * 16384];  // developer build: {start, end (100 MHz), XCC id, first query} of every workgroup of the MAP's bulk kNN launch
+void lab_blocks(long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lab_blk), sizeof(g_lab_blk));
+}
+#endif
 #ifdef RGC_LAB
 __device__ long long g_lab_wave[2 * 8192];  // developer build: start / end (100 MHz) of every wave of the scan's bulk kNN launch
 void lab_wave_ts(long long* out, hipStream_t s) {
@@ -1551,12 +1832,15 @@ void lab_wave_ts(long long* out, hipStream_t s) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lab_wave), sizeof(g_lab_wave));
 }
 #endif
-template <int KC, bool kTarget, bool kExact>
+// kSeeded (the map, k == KC): every query first tries the seeded search (knn_point_seeded: df.seed holds a bound per original point
+// index) and runs the full one where that declines.
+template <int KC, bool kTarget, bool kExact, bool kSeeded = false>
 __global__ void __launch_bounds__(SpConfig<kTarget>::T)
 k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
          double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
   extern __shared__ int slist_sp[];  // [SpShape::LDS][T]
   using Cfg = SpConfig<kTarget>;
+  static_assert(!kSeeded || (kTarget && kExact), "seeds: the map's search at k == KC");
   wave_prio(!kTarget);
   if (df.guard && *df.guard) return;
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one) and queries are in cell order.
@@ -1583,22 +1867,51 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
     return;
   }
   const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
-  if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+#ifdef RGC_LAB_BLOCKS
+  const long long lab_b0 = wall_clock64();
+#endif
+  if constexpr (kSeeded) {
+    const bool done = i >= n || knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+    if (!done) {
+      LAB_COUNT(6);
+      knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+    }
+  } else {
+    if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+  }
+#ifdef RGC_LAB_BLOCKS
+  if (Cfg::T > WAVE) __syncthreads();
+  if (threadIdx.x == 0 && b < 16384) {
+    g_lab_blk[4 * b] = lab_b0; g_lab_blk[4 * b + 1] = wall_clock64();
+    g_lab_blk[4 * b + 2] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, bits 0..3
+    g_lab_blk[4 * b + 3] = i;
+#ifdef RGC_LAB_BLK
+    g_lab_blk[4 * b + 3] |= (long long)g_lab_blk_why[b] << 32;
+    g_lab_blk_why[b] = 0;
+#endif
+  }
+#endif
 }
 
 // Lazy target: the map's search for the LISTED queries only (df.qlist: whole cells, a cell's points are consecutive entries) instead of
 // all of them in cell order.  The launch is sized from the previous frame's list and strides over this one's whatever its length.  (Its own
 // kernel: the stride loop around the search costs registers -- 107 against 86 -- that the full launch, five waves per SIMD, cannot spare.)
-template <int KC, bool kExact>
+template <int KC, bool kExact, bool kSeeded = false>
 __global__ void __launch_bounds__(SpConfig<true>::T)
 k_knn_sp_listed(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
                 double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
   extern __shared__ int slist_spl[];
   using Cfg = SpConfig<true>;
+  static_assert(!kSeeded || kExact, "seeds: the map's search at k == KC");
   if (df.guard && *df.guard) return;
   const int nq = *df.nq;
-  for (int t = (int)blockIdx.x * Cfg::T + (int)threadIdx.x; t < nq; t += (int)gridDim.x * Cfg::T)
-    knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, df.qlist[t], slist_spl + threadIdx.x, df, nx, ny, nz);
+  for (int t = (int)blockIdx.x * Cfg::T + (int)threadIdx.x; t < nq; t += (int)gridDim.x * Cfg::T) {
+    const int i = df.qlist[t];
+    if constexpr (kSeeded) {
+      if (knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, i, slist_spl + threadIdx.x, df, nx, ny, nz)) continue;
+    }
+    knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_spl + threadIdx.x, df, nx, ny, nz);
+  }
 }
 
 // The bulk launch for a SPARSE map (a few keyframes of a 16-beam sensor after the leaf filter: 0.1 points per 1 m cell, where the 3x3x3
@@ -3547,16 +3860,21 @@ size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 // deferred list: [cnt, pad x15][idx n][thr n]
 static Deferred deferred_of(const void* buf, int n) {
   int* base = (int*)const_cast<void*>(buf);
-  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, nullptr};
+  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, nullptr, nullptr, 0.f};
 }
 
 template <int KC, bool kExact>
 static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred,
                         double* nx, double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1,
-                        const int* qlist, const int* nq, int q_est) {
+                        const int* qlist, const int* nq, int q_est, const KnnSeeds& seeds) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
   df.qlist = qlist; df.nq = nq;
+  // seeds: the map's dense search at k == KC only; `warm` = some search has written them (the seeded kernel is worth launching)
+  const bool seeds_ok = is_target && kExact && wide_r != 2 && seeds.seed && n <= kSeedMaxPoints;
+  df.seed = seeds_ok ? seeds.seed : nullptr;
+  df.seed_slack = seeds.slack;
+  const bool seeded = seeds_ok && seeds.warm;
   if (wide_r == 2) {
     const size_t ldsw = (size_t)SpShape<2, true>::LDS * WAVE * sizeof(int);
     hipLaunchKernelGGL((k_knn_sp_wide<KC, 2, kExact>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
@@ -3566,12 +3884,21 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   using CS = SpConfig<false>;
   const int T = is_target ? CT::T : CS::T;
   // (the scan's launch lays its per-lane LDS columns out for the 3x3x3 block and again, for the queries that block does not settle, for the 5x5x5 one)
-  const size_t lds = (size_t)(is_target ? SpShape<CT::R, CT::kClip>::LDS : std::max(SpShape<CS::R, CS::kClip>::LDS, SpShape<2, CS::kClip>::LDS)) * T * sizeof(int);
+  const size_t lds = (size_t)(is_target ? (seeded ? std::max(SpShape<CT::R, CT::kClip>::LDS, SeedShape<KC>::LDS) : SpShape<CT::R, CT::kClip>::LDS)
+                                        : std::max(SpShape<CS::R, CS::kClip>::LDS, SpShape<2, CS::kClip>::LDS)) * T * sizeof(int);
   // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n); lazy target: as many blocks as the listed queries are
   // expected to fill (the kernel strides over the list whatever its true length)
   const int n_launch = (is_target && qlist) ? (q_est < T ? T : (q_est > n ? n : q_est)) : n;
   const int nb = (is_target && qlist) ? nblk(n_launch, T) : 8 * RGC_XCD_RUN * nblk(nblk(n, T), 8 * RGC_XCD_RUN);
   // (ev0 / ev1: the launch's own start / stop times go into the caller's events -- no separate record packets around it)
+  if constexpr (kExact) {
+    if (seeded) {
+      if (qlist) hipLaunchKernelGGL((k_knn_sp_listed<KC, true, true>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+      else if (ev0 && ev1) hipExtLaunchKernelGGL((k_knn_sp<KC, true, true, true>), dim3(nb), dim3(T), (std::uint32_t)lds, s, ev0, ev1, 0u, P, start, g, n, k, df, nx, ny, nz);
+      else hipLaunchKernelGGL((k_knn_sp<KC, true, true, true>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+      return;
+    }
+  }
   if (is_target && qlist) hipLaunchKernelGGL((k_knn_sp_listed<KC, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
   else if (is_target && ev0 && ev1) hipExtLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), (std::uint32_t)lds, s, ev0, ev1, 0u, P, start, g, n, k, df, nx, ny, nz);
   else if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
@@ -3592,12 +3919,14 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
 }
 bool knn_bulk_times_itself(bool is_target, int wide_r) { return is_target && wide_r != 2; }
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
-              double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1, const int* qlist, const int* nq, int q_est) {
+              double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1, const int* qlist, const int* nq, int q_est,
+              const KnnSeeds& seeds) {
   // (k == 20, the reference's setting, gets an instance without the general-k branches)
-  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est);
-  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est);
-  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est);
+  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds);
+  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds);
+  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds);
 }
+bool knn_seeds_apply(int n, int k) { return k == 20 && n <= kSeedMaxPoints; }
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
               double* ny, double* nz, const int* guard, int waves) {
   if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);

@@ -968,3 +968,55 @@ def test_reframed_target_with_a_stale_box(reg_mod, orc, medium):
     for p in (d_map_w, d_out_w):
         w.device_free(p)
     v.close(); w.close()
+
+
+def test_seeded_search_is_exact_whatever_the_seeds(reg_mod, orc, medium, monkeypatch):
+    """Round 5: a re-framed map's exact search starts from the k-th distances the previous search of the same buffer found (knn_point_seeded).
+    The result must not depend on what the seeds hold.  Two contexts are fed the same calls on the same data -- one keeps seeds, the
+    other (created under RGC_KNN_SEEDS=0) never does: every covariance, the voxel table and the deferred-query count bit for bit, and the
+    oracle's covariances to 1e-9 --
+      * two poses in a row (the seeds fit),
+      * the buffer overwritten IN PLACE by a permutation of itself (same pointer, same n: every seed now belongs to some other point),
+      * ... by the cloud pulled together (k-th distances shrink: the seeds admit too many keys), pushed apart (too few), and by a lattice
+        with duplicates, where the k-th distance is an exact tie nearly everywhere (the seeded search declines, the tie rule decides)."""
+    import bench
+    import rgc_slam_amd.synth as synth
+    tgt = medium["tgt"]
+    n = len(tgt)
+    rng = np.random.default_rng(11)
+    def cloud(xyz):
+        a = np.zeros((n, 4), np.float32); a[:, :3] = xyz[:n]; return a
+    side = int(np.ceil(np.sqrt(n / 8.0)))
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side + 1), np.arange(8), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float32)
+    lattice = (g * np.float32((0.25, 0.27, 0.31)))[rng.permutation(len(g))][:n]     # (the points left out are random holes)
+    lattice[-300:] = lattice[:300]                                                   # ... and 300 exact duplicates
+    assert len(lattice) == n
+    clouds = [("first", tgt), ("second pose", tgt), ("third pose", tgt), ("permuted", tgt[rng.permutation(n)]), ("pulled together", tgt * np.float32(0.6)),
+              ("pushed apart", tgt * np.float32(1.5)), ("lattice", lattice), ("lattice again", lattice), ("back", tgt)]
+    v = _odo(reg_mod)
+    monkeypatch.setenv("RGC_KNN_SEEDS", "0")
+    w = _odo(reg_mod)
+    monkeypatch.delenv("RGC_KNN_SEEDS")
+    d_map, d_body = v.device_alloc(16 * n), v.device_alloc(16 * n)
+    d_map_w, d_body_w = w.device_alloc(16 * n), w.device_alloc(16 * n)
+    for j, (what, xyz) in enumerate(clouds):
+        a = cloud(xyz)
+        Tw = synth.se3(synth.rot_zyx(0.3 * j - 0.5, 0.01 * j, -0.02), [1.5 * j, -0.7 * j, 0.05 * j])
+        q, t = bench.world_to_body(Tw)
+        v.upload(d_map, a); w.upload(d_map_w, a)
+        v.setInputTargetReframed(d_map, n, 16, q, t, d_body)
+        w.setInputTargetReframed(d_map_w, n, 16, q, t, d_body_w)
+        cv, cw = v.getTargetCovariances(), w.getTargetCovariances()
+        assert np.array_equal(cv, cw), what
+        xv, xw = v.getVoxels(), w.getVoxels()
+        assert np.array_equal(xv["coords"], xw["coords"]) and np.array_equal(xv["cov"], xw["cov"]) and np.array_equal(xv["mean"], xw["mean"]), what
+        assert v.stats()["deferred_target"] == w.stats()["deferred_target"], what
+        if what in ("third pose", "permuted", "pushed apart"):
+            body = v.download(d_body, (n, 4))
+            ocov, _ = orc.covariances(body[:, :3].copy(), k=20)
+            assert np.abs(cv - ocov).max() <= 1e-9, what
+    for p in (d_map, d_body):
+        v.device_free(p)
+    for p in (d_map_w, d_body_w):
+        w.device_free(p)
+    v.close(); w.close()
