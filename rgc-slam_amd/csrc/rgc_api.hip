@@ -660,7 +660,8 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
     ProfScope ps(c, RGC_K_VOXEL, n);
     {
       rgck::voxel_build_coop(s, (const float4*)cl.P.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p, (const int*)cl.start.p, cl.grid, n,
-                             (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves);
+                             (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves,
+                             cloud_seeds(cl, true));
       rgck::voxel_patch(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
                         cl.grid, cl.segs.p, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 64 : n);
     }
@@ -712,7 +713,7 @@ int lazy_build(rgc_ctx* c, const float guess[16]) {
     ProfScope ps(c, RGC_K_VOXEL, n);
     rgck::voxel_cells_coop(s, (const float4*)cl.P.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p, (const int*)cl.start.p, cl.grid, n,
                            (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, guard, coop_waves, (const int*)cl.cell_list.p,
-                           counts + 1, c_est);
+                           counts + 1, c_est, cloud_seeds(cl, true));
     rgck::voxel_patch(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
                       cl.grid, cl.segs.p, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 64 : n);
   }

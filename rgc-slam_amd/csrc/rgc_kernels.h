@@ -101,17 +101,17 @@ void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid
 // ... and the voxel pass over the listed cells, the map's deferred queries resolved beside it (k_voxel_cells_coop); voxel_patch follows
 void voxel_cells_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
                       double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const int* cell_list, const int* ncells,
-                      int cells_est);
+                      int cells_est, const KnnSeeds& seeds = KnnSeeds{});
 bool knn_bulk_times_itself(bool is_target, int wide_r);
 // waves: one-wave workgroups that share the deferred list (clamped to [32, 8192])
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
-              double* ny, double* nz, const int* guard, int waves);
+              double* ny, double* nz, const int* guard, int waves, const KnnSeeds& seeds = KnnSeeds{});
 // ---- C3: Gaussian voxel map ----
 void voxel_build(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g,
                  int n, const int* cell_voxel, double* vox, int* vox_cell);
 // voxel_build and knn_coop (target) in one launch, followed by voxel_patch: see k_voxel_build_coop
 void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
-                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves);
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const KnnSeeds& seeds = KnnSeeds{});
 // the voxels that hold a deferred query, recomputed: lets the cooperative search run BESIDE voxel_build; lanes: about
 // the number of deferred queries (grid-stride loop)
 void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g, const void* deferred,

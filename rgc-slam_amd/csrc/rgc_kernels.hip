@@ -1312,12 +1312,13 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
 // than k (a stale seed: the caller overwrote the map in place), more than k + 1, a third contender or an exact tie: the lane returns
 // false and runs knn_point_sp, which also makes every deferral decision but "the block cannot prove the k-th distance" (made here from
 // the same k-th key, hence the same way).
-// LDS per lane: k + 6 key slots (a quad of candidates appends up to four before the count is looked at) and nine table entries
+// LDS per lane: k + 8 key slots (up to k + 3 keys are sorted out here; a quad of candidates appends up to four before the count is looked at) and nine table entries
 // {first position << 6 | quads} of the rows to visit.
 // ------------------------------------------------------------------------------------------------
+constexpr int kSeedExtra = 3;  // keys beyond k the seeded search sorts out itself (more: the full search)
 template <int KC>
 struct SeedShape {
-  static constexpr int BUF = KC + 6;
+  static constexpr int BUF = KC + kSeedExtra + 5;  // k + kSeedExtra + 1 = "too many", and a quad appends up to four before the count is clamped
   static constexpr int LDS = BUF + SpShape<1, false>::NP;  // ints per lane
 };
 #ifndef RGC_SEED_ROW_SKIP
@@ -1392,7 +1393,7 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
   int ri = 0, ordn = 0;
   unsigned off = 0, end = 0;
   lds_int* bp = buf;
-  lds_int* const bp_cap = buf + (KC + 2) * T;  // k + 2 keys: "too many" whatever follows
+  lds_int* const bp_cap = buf + (KC + kSeedExtra + 1) * T;  // that many keys: "too many" whatever follows
   struct Quad { Cand p0, p1, p2, p3; int ord; bool on, live; };
   auto fetch = [&](Quad& qd) {
     if (off >= end && ri < nv) {
@@ -1417,10 +1418,11 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
       const int k1 = (__float_as_int(dist2_fma(px, py, pz, qd.p1.x, qd.p1.y, qd.p1.z)) & ~kKeyOrd) | (qd.ord + 1);
       const int k2 = (__float_as_int(dist2_fma(px, py, pz, qd.p2.x, qd.p2.y, qd.p2.z)) & ~kKeyOrd) | (qd.ord + 2);
       const int k3 = (__float_as_int(dist2_fma(px, py, pz, qd.p3.x, qd.p3.y, qd.p3.z)) & ~kKeyOrd) | (qd.ord + 3);
-      if (k0 < tkey) { *bp = k0; bp += T; }
-      if (k1 < tkey) { *bp = k1; bp += T; }
-      if (k2 < tkey) { *bp = k2; bp += T; }
-      if (k3 < tkey) { *bp = k3; bp += T; }
+      // (the pointer is bumped in place: written as bp += T the compiler adds into a fresh register and moves it back, a VALU instruction per candidate)
+      if (k0 < tkey) { *bp = k0; asm("v_add_u32 %0, %1, %0" : "+v"(bp) : "n"(T * 4)); }
+      if (k1 < tkey) { *bp = k1; asm("v_add_u32 %0, %1, %0" : "+v"(bp) : "n"(T * 4)); }
+      if (k2 < tkey) { *bp = k2; asm("v_add_u32 %0, %1, %0" : "+v"(bp) : "n"(T * 4)); }
+      if (k3 < tkey) { *bp = k3; asm("v_add_u32 %0, %1, %0" : "+v"(bp) : "n"(T * 4)); }
       bp = bp < bp_cap ? bp : bp_cap;
     }
   };
@@ -1452,8 +1454,38 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
       process(qb);
     }
   }
-  const int m = (int)(bp - buf) / T;
-  if (m < KC || m > KC + 1) { LAB_DECLINE(m < KC ? 3 : 4); return false; }
+  int m = (int)(bp - buf) / T;
+  if (m < KC) {
+    // Fewer than k candidates under the bound.  If the bound is not below what the block can prove (a query at the map's sparse border,
+    // deferred last time too: its seed is the k-th distance the cooperative search found, beyond the block), the full search would find a
+    // k-th key >= tkey, hence a k-th distance it cannot prove either, and defer the query as "block scanned, not enough": so does this.
+    // (Its hint -- the k-th candidate of the block -- is not known here; the seeded distance serves: the cooperative search re-derives
+    // its bound from what it finds, and its result does not depend on the hint.)
+    const double bound = cube_bound(g, c, q, R);
+    if (bound != 1.0e300 && !((double)tauf < bound * bound * (1.0 - 1e-5))) {
+      const int e = atomicAdd(df.cnt, 1);
+      df.idx[e] = ~i;
+      df.thr[e] = rs * rs * 1.000001f;
+      return true;
+    }
+    LAB_DECLINE(3);
+    return false;
+  }
+  if (m > KC + kSeedExtra) { LAB_DECLINE(4); return false; }
+  // two or three keys too many (a lane in ten thousand): the largest go, in LDS, until k + 1 are left; the last one taken out is the (k+2)-th
+  int kp2 = tkey;  // the (k+2)-th smallest key, or (nothing taken out) a lower bound of it
+  bool kp2_known = false;
+  while (m > KC + 1) {
+    int mxv = -1, mxj = 0;
+    for (int j = 0; j < m; j++) {
+      const int x = buf[j * T];
+      if (x > mxv) { mxv = x; mxj = j; }
+    }
+    for (int j = mxj; j + 1 < m; j++) buf[j * T] = buf[(j + 1) * T];
+    m--;
+    kp2 = mxv;
+    kp2_known = true;
+  }
   const bool extra = m > KC;
   // ---- the admitted keys, their largest two and where the largest sits ----
   int w[KC + 1];
@@ -1476,21 +1508,29 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
     const int o = key & kKeyOrd;
     return (int)((unsigned)tab[(o >> 7) * T] >> 6) + (o & kRowRel);
   };
+  // undecided: knn_point_sp's verdict on the same four keys around the k-th (a third contender, an exact tie) -- the cooperative kernel's
+  // tie rule decides, from the same entry (query, its k-th key as the bound) the full search would have made
+  bool undecided = false;
   if (next_bucket - (kth_key >> KB) < 2) {  // the keys cannot order the k-th and the (k+1)-th candidate
     if (!extra) { LAB_DECLINE(5); return false; }  // (the seed was too tight to tell)
-    if ((tkey >> KB) - (mx >> KB) < 2) { LAB_DECLINE(6); return false; }  // the (k+2)-th may be a contender too
     int mx3 = -1, pos2 = 0;
 #pragma unroll
     for (int j = 0; j <= KC; j++) {
       pos2 = w[j] == mx2 ? j : pos2;
       mx3 = (w[j] != mx && w[j] != mx2) ? max(mx3, w[j]) : mx3;
     }
-    if ((mx2 >> KB) - (mx3 >> KB) < 2) { LAB_DECLINE(7); return false; }  // three contenders
-    LAB_COUNT(5);
-    const float4 p1 = P[index_of(mx2)], p2 = P[index_of(mx)];
-    const float d1 = dist2(px, py, pz, p1), d2 = dist2(px, py, pz, p2);  // the reference's expression, uncontracted
-    if (d1 == d2) { LAB_DECLINE(8); return false; }  // an exact tie: the original index decides (cooperative kernel)
-    if (d2 < d1) { kth_key = mx; drop = pos2; }
+    if ((kp2 >> KB) - (mx >> KB) < 2) {  // the (k+2)-th contends too -- if that is what kp2 is
+      if (!kp2_known) { LAB_DECLINE(6); return false; }
+      undecided = true;
+    } else if ((mx2 >> KB) - (mx3 >> KB) < 2) {  // ... or the (k-1)-th
+      undecided = true;
+    } else {
+      LAB_COUNT(5);
+      const float4 p1 = P[index_of(mx2)], p2 = P[index_of(mx)];
+      const float d1 = dist2(px, py, pz, p1), d2 = dist2(px, py, pz, p2);  // the reference's expression, uncontracted
+      undecided = d1 == d2;  // an exact tie: the original index decides
+      if (d2 < d1) { kth_key = mx; drop = pos2; }
+    }
   }
   const float thr_up = __int_as_float(kth_key | kKeyOrd);  // upper bound of the k-th squared distance
   const double bound = cube_bound(g, c, q, R);
@@ -1499,6 +1539,12 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
     const int e = atomicAdd(df.cnt, 1);
     df.idx[e] = ~i;
     df.thr[e] = (double)thr_up < 3.0 * (R + 1) * (R + 1) * g.res * g.res ? thr_up : INFINITY;
+    return true;
+  }
+  if (undecided) {
+    const int e = atomicAdd(df.cnt, 1);
+    df.idx[e] = i;
+    df.thr[e] = thr_up;
     return true;
   }
   int idx[KC];
@@ -2125,6 +2171,18 @@ __device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int
       });
     }
     wave_lds_fence();
+    // The neighbour SET is what the search decides; the order it was collected in depends on the cube the search ended on, hence on the
+    // hint (thr) the bulk kernel passed.  Lanes take the neighbours in ascending position in the sorted array: the sums below -- a
+    // fixed tree over the lanes -- are then a function of the set alone, whichever route deferred the query (knn_point_seeded passes
+    // other hints than knn_point_sp).
+    {
+      const int mine = lane < k ? sh->nb[lane] : INT_MAX;
+      int rank = 0;
+      for (int j = 0; j < k; j++) rank += sh->nb[j] < mine;
+      wave_lds_fence();
+      if (lane < k) sh->nb[rank] = mine;
+      wave_lds_fence();
+    }
     // neighbourhood mean / covariance in fp64 (fast_gicp_impl.hpp:256-262): lane j holds neighbour j
     double vx = 0, vy = 0, vz = 0;
     if (lane < k) {
@@ -2143,6 +2201,7 @@ __device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int
       nx[i] = nrm[0];
       ny[i] = nrm[1];
       nz[i] = nrm[2];
+      if (kTarget && df.seed) df.seed[__float_as_int(pq.w)] = thr;  // the k-th squared distance itself: where this point's next search starts (knn_point_seeded)
 #ifdef RGC_LAB
       if (!kTarget && e < 8192) { g_lab_wave[2 * e] = lab_t0 | ((long long)r << 56) | ((long long)lab_rounds << 48); g_lab_wave[2 * e + 1] = wall_clock64(); }
 #endif
@@ -3904,11 +3963,16 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   else if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
   else hipLaunchKernelGGL((k_knn_sp<KC, false, kExact>), dim3(nblk(n, T / 4)), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);  // four lanes per query
 }
+bool knn_seeds_apply(int n, int k) { return k == 20 && n <= kSeedMaxPoints; }
+static void deferred_seeds(Deferred& df, const KnnSeeds& seeds, int n, int k) {  // the cooperative search leaves its k-th distance as the point's seed
+  if (seeds.seed && knn_seeds_apply(n, k)) { df.seed = seeds.seed; df.seed_slack = seeds.slack; }
+}
 template <int KC>
 static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs,
-                        double* nx, double* ny, double* nz, const int* guard, int waves) {
+                        double* nx, double* ny, double* nz, const int* guard, int waves, const KnnSeeds& seeds) {
   Deferred df = deferred_of(segs, n);
   df.guard = guard;
+  if (is_target) deferred_seeds(df, seeds, n, k);
   // the number of deferred queries is only known on the device: `waves` one-wave workgroups share the list (each takes every
   // waves-th entry); the caller sizes it from the previous cloud of the sequence
   const int nbc = waves < 32 ? 32 : (waves > 8192 ? 8192 : waves);
@@ -3926,11 +3990,11 @@ void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, 
   else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds);
   else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds);
 }
-bool knn_seeds_apply(int n, int k) { return k == 20 && n <= kSeedMaxPoints; }
+
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
-              double* ny, double* nz, const int* guard, int waves) {
-  if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
-  else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves);
+              double* ny, double* nz, const int* guard, int waves, const KnnSeeds& seeds) {
+  if (k <= 20) knn_coop_kc<20>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves, seeds);
+  else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves, seeds);
 }
 void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, int* need, int stamp, int margin, const float4* P, int n_map,
                const int* start, int* qlist, int* cell_list, int* counts) {
@@ -3939,9 +4003,10 @@ void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid
 }
 void voxel_cells_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
                       double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const int* cell_list, const int* ncells,
-                      int cells_est) {
+                      int cells_est, const KnnSeeds& seeds) {
   Deferred df = deferred_of(deferred, n);
   df.guard = guard;
+  deferred_seeds(df, seeds, n, k);
   const int nbc = nblk(waves < 32 ? 32 : (waves > 8192 ? 8192 : waves), VOX_T / WAVE);
   const int nbv = nblk(cells_est < 256 ? 256 : (cells_est > (1 << 20) ? (1 << 20) : cells_est), VOX_T / WAVE);  // a wave per listed cell (grid-stride beyond the estimate)
   if (k <= 20) hipLaunchKernelGGL((k_voxel_cells_coop<20>), dim3(nbc + nbv), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, cell_voxel, vox, vox_cell, nbc, k, df, cell_list, ncells);
@@ -3952,9 +4017,10 @@ void voxel_build(hipStream_t s, const float4* P, const double* nx, const double*
   hipLaunchKernelGGL(k_voxel_build, dim3(nblk(n, VOX_T)), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell);
 }
 void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
-                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves) {
+                      double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const KnnSeeds& seeds) {
   Deferred df = deferred_of(deferred, n);
   df.guard = guard;
+  deferred_seeds(df, seeds, n, k);
   const int nbv = nblk(n, VOX_T);
   const int nbc = nblk(waves < 32 ? 32 : (waves > 8192 ? 8192 : waves), VOX_T / WAVE);
   if (k <= 20) hipLaunchKernelGGL((k_voxel_build_coop<20>), dim3(nbv + nbc), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, nbc, k, df);
