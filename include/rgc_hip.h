@@ -132,7 +132,11 @@ RGC_API int rgc_align_end(rgc_ctx* ctx, float final_T[16], double final_H[36], d
  * the new body frame, q = inverse rotation of world_T, t = -q * translation (:1250-1255), exactly rgc_set_target_reframed(next, d_map,
  * n, stride_bytes, q, t, d_scratch).  The host's turn-around between a frame's result and the next frame's first launch is on the
  * critical path of a dependent sequence; here it is a few microseconds of C instead of the caller's pose arithmetic and a second call.
- * world_T: 16 doubles, row-major 4x4, in: the world pose before this frame, out: after it.  Outputs as rgc_align_end. */
+ * world_T: 16 doubles, row-major 4x4, in: the world pose before this frame, out: after it.  Outputs as rgc_align_end.
+ * Failure is all or nothing for the caller's arguments: `next` (alive, no solve in flight), d_map / n / stride_bytes / d_scratch are
+ * checked as rgc_set_target_reframed checks them BEFORE the solve is consumed -- such an error leaves the solve pending and world_T
+ * untouched, and the call may be repeated with corrected arguments.  (A HIP or allocation failure inside the next target's preparation
+ * is reported after the outputs and world_T have been written; rgc_last_error names the failing call.) */
 RGC_API int rgc_align_end_reframe(rgc_ctx* solve, rgc_ctx* next, double world_T[16], const float* d_map, int n, int stride_bytes,
                                   float* d_scratch, float final_T[16], double final_H[36], double* fitness, int* iterations,
                                   int* converged, int* lm_failed);

@@ -13,6 +13,7 @@
 // Errors: like the reference, the solver itself never throws ("lm not converged" is lmFailed(), hasConverged() as in
 // PCL); API misuse and HIP failures throw std::runtime_error carrying rgc_last_error().  No CPU fallback exists.
 #pragma once
+#include <cmath>
 #include <cstddef>
 #include <cstring>
 #include <stdexcept>
@@ -69,6 +70,21 @@ public:
   void setInputTargetDevice(const float* d_xyz, int n, int stride_bytes) { chk(rgc_set_target_device(ctx_, d_xyz, n, stride_bytes)); n_tgt_ = n; fit_valid_ = false; }
   void setInputSourceDevice(const float* d_xyz, int n, int stride_bytes) { chk(rgc_set_source_device(ctx_, d_xyz, n, stride_bytes)); n_src_ = n; fit_valid_ = false; }
 
+  // The odometer's sub-map re-framing and setInputTarget in one call on device memory (RGC_odometer.cpp:1248-1256, 1007;
+  // rgc_set_target_reframed): the map at d_map (x,y,z,intensity..., fixed between calls) re-expressed by q (x,y,z,w) and t into d_scratch
+  // (n * 16 bytes) and prepared as the target.  A map handed over like this again and again is searched from what the last search found
+  // (rgc_hip.h: seeds) -- same results, a shorter kNN launch.
+  void setInputTargetReframed(const float* d_map, int n, int stride_bytes, const double q_xyzw[4], const double t[3], float* d_scratch) {
+    chk(rgc_set_target_reframed(ctx_, d_map, n, stride_bytes, q_xyzw, t, d_scratch));
+    n_tgt_ = n; fit_valid_ = false;
+  }
+  // Opt-in (rgc_set_target_lazy): covariances and voxels of a target are built only within margin_cells voxels of where the scan falls at
+  // align()'s guess -- only the voxels a solve looks up enter its cost (fast_vgicp_impl.hpp:73-116).  Every look-up is checked and a solve
+  // that leaves the built part is repeated on the completed map: results are the full build's bit for bit.  0 switches it off.
+  void setLazyTarget(int margin_cells) { chk(rgc_set_target_lazy(ctx_, margin_cells)); }
+  // two contexts taking turns on a dependent sequence: this context's scan preparation (enqueued now) is held back until `other`'s map
+  // preparation has finished, so that it runs under other's solve instead of beside the launch other's frame is waiting for
+  void holdSourceUntilTargetOf(FastVGICPHip& other) { chk(rgc_hold_source_until_target_of(ctx_, other.ctx_)); }
   // fast_gicp.hpp:55-61: the clouds change roles (fast_vgicp_impl.hpp:46-53) / are dropped / get covariances from the caller (n*9 doubles,
   // row-major, plane-regularised form only -- see rgc_set_source_covariances)
   void swapSourceAndTarget() { chk(rgc_swap_source_and_target(ctx_)); std::swap(n_src_, n_tgt_); fit_valid_ = false; }
@@ -95,6 +111,16 @@ public:
     int it = 0, conv = 0, fail = 0;
     chk(rgc_align_end(ctx_, final_, hessian_, pending_fitness_ ? &fitness_ : nullptr, &it, &conv, &fail));
     iterations_ = it; converged_ = conv != 0; lm_failed_ = fail != 0; fit_valid_ = pending_fitness_;
+  }
+  // alignEnd() and, in the same call, the two steps a frame loop without a fusion stage takes with the result (rgc_align_end_reframe):
+  // world_T <- world_T * final (fp64, row-major 4x4; RGC_odometer.cpp:1201-1203) and the NEXT frame's target on `next` (this object or
+  // the other one of a pair) -- the map re-expressed in the new body frame (:1250-1255), as setInputTargetReframed would.
+  void alignEndReframe(FastVGICPHip& next, double world_T[16], const float* d_map, int n, int stride_bytes, float* d_scratch) {
+    int it = 0, conv = 0, fail = 0;
+    chk(rgc_align_end_reframe(ctx_, next.ctx_, world_T, d_map, n, stride_bytes, d_scratch, final_, hessian_, pending_fitness_ ? &fitness_ : nullptr, &it,
+                              &conv, &fail));
+    iterations_ = it; converged_ = conv != 0; lm_failed_ = fail != 0; fit_valid_ = pending_fitness_;
+    next.n_tgt_ = n; next.fit_valid_ = false;
   }
   // register to the target `owner` has prepared, without preparing or copying it (rgc_share_target)
   void shareTargetFrom(FastVGICPHip& owner) { chk(rgc_share_target(ctx_, owner.ctx_)); n_tgt_ = owner.n_tgt_; fit_valid_ = false; }
@@ -134,6 +160,7 @@ public:
   std::vector<double> getSourceCovariances() { std::vector<double> c((size_t)n_src_ * 9); chk(rgc_get_source_covariances(ctx_, c.data(), nullptr)); return c; }
   std::vector<double> getTargetCovariances() { std::vector<double> c((size_t)n_tgt_ * 9); chk(rgc_get_target_covariances(ctx_, c.data(), nullptr)); return c; }
   rgc_ctx* context() { return ctx_; }
+  rgc_stats stats() { rgc_stats st; chk(rgc_get_stats(ctx_, &st)); return st; }   // (lazy_misses: solves repeated on the completed map)
 
 private:
   static void set_identity(float m[16]) { std::memset(m, 0, 16 * sizeof(float)); m[0] = m[5] = m[10] = m[15] = 1.f; }
@@ -188,6 +215,93 @@ public:
 
 private:
   std::vector<std::unique_ptr<FastVGICPHip>> regs_;
+};
+
+// The odometer's frame loop on device-resident clouds (RGC_odometer.cpp:976-1023, 1201-1203, 1248-1256; the C++ twin of bench.py's
+// DependentSequence): frame i registers scan i to the local map re-expressed in the body frame of world pose i - 1 -- nothing of frame
+// i's map can be prepared before frame i - 1 is solved.  With two registrations taking turns the next scan's preparation (it depends on
+// no pose) runs under the current solve; the result, the pose composition and the next frame's target are one call (alignEndReframe).
+//   rgc::DependentSequence seq(reg_a, &reg_b, d_map, n_map, 16);     // or (reg_a, nullptr, ...): one frame at a time
+//   seq.run(n_frames, world_T, guess0, set_source, on_result);        // set_source(i, reg): reg.setInputSourceDevice(scan i ...)
+class DependentSequence {
+public:
+  DependentSequence(FastVGICPHip& a, FastVGICPHip* b, const float* d_map, int n_map, int stride_bytes) : d_map_(d_map), n_(n_map), stride_(stride_bytes) {
+    regs_[0] = &a; regs_[1] = b;
+    for (int k = 0; k < 2; k++) {
+      if (!regs_[k]) continue;
+      void* p = nullptr;
+      if (rgc_device_alloc(regs_[k]->context(), (size_t)n_map * 16, &p) != RGC_OK) throw std::runtime_error("rgc::DependentSequence: device allocation failed");
+      scratch_[k] = (float*)p;
+    }
+  }
+  ~DependentSequence() {
+    for (int k = 0; k < 2; k++) if (scratch_[k]) rgc_device_free(regs_[k]->context(), scratch_[k]);
+  }
+  DependentSequence(const DependentSequence&) = delete;
+  DependentSequence& operator=(const DependentSequence&) = delete;
+
+  // world -> body of pose Tw (row-major 4x4, fp64): q = the rotation's inverse as a unit quaternion (x,y,z,w), t = -R^T t_w (:1250-1255)
+  static void worldToBody(const double Tw[16], double q[4], double t[3]) {
+    const double R[3][3] = {{Tw[0], Tw[4], Tw[8]}, {Tw[1], Tw[5], Tw[9]}, {Tw[2], Tw[6], Tw[10]}};   // R^T
+    const double tr = R[0][0] + R[1][1] + R[2][2];
+    if (tr > 0) {
+      const double s4 = 2.0 * std::sqrt(tr + 1.0);
+      q[0] = (R[2][1] - R[1][2]) / s4; q[1] = (R[0][2] - R[2][0]) / s4; q[2] = (R[1][0] - R[0][1]) / s4; q[3] = 0.25 * s4;
+    } else {
+      const int i = (R[0][0] >= R[1][1] && R[0][0] >= R[2][2]) ? 0 : (R[1][1] >= R[2][2] ? 1 : 2);
+      const int j = (i + 1) % 3, k = (i + 2) % 3;
+      const double s4 = 2.0 * std::sqrt(1.0 + R[i][i] - R[j][j] - R[k][k]);
+      q[3] = (R[k][j] - R[j][k]) / s4; q[i] = 0.25 * s4; q[j] = (R[j][i] + R[i][j]) / s4; q[k] = (R[k][i] + R[i][k]) / s4;
+    }
+    const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int a = 0; a < 4; a++) q[a] /= nrm;
+    for (int a = 0; a < 3; a++) t[a] = -(R[a][0] * Tw[3] + R[a][1] * Tw[7] + R[a][2] * Tw[11]);
+  }
+
+  // world_T: in the pose before the first frame, out the pose after the last.  guess0: the first frame's guess (row-major float[16]);
+  // every later frame starts from the previous frame's motion.  on_result(i, reg): frame i is done, reg holds its results.
+  template <class SetSource, class OnResult>
+  void run(int n_frames, double world_T[16], const float guess0[16], bool want_fitness, SetSource&& set_source, OnResult&& on_result) {
+    const int D = regs_[1] ? 2 : 1;
+    float g[16];
+    std::memcpy(g, guess0, sizeof(g));
+    if (D == 2) set_source(0, *regs_[0]);
+    double q[4], t[3];
+    worldToBody(world_T, q, t);
+    regs_[0]->setInputTargetReframed(d_map_, n_, stride_, q, t, scratch_[0]);
+    for (int i = 0; i < n_frames; i++) {
+      FastVGICPHip& cur = *regs_[i % D];
+      FastVGICPHip& nxt = *regs_[(i + 1) % D];
+      if (D == 1) set_source(i, cur);
+      cur.alignBegin(g, want_fitness);
+      if (D == 2 && i + 1 < n_frames) {
+        nxt.holdSourceUntilTargetOf(cur);
+        set_source(i + 1, nxt);
+      }
+      if (i + 1 < n_frames) {
+        cur.alignEndReframe(nxt, world_T, d_map_, n_, stride_, scratch_[(i + 1) % D]);
+      } else {
+        cur.alignEnd();
+        double W[16];
+        const float* T = cur.getFinalTransformation();
+        for (int a = 0; a < 4; a++)
+          for (int b = 0; b < 4; b++) {
+            double v = 0.0;
+            for (int k = 0; k < 4; k++) v += world_T[a * 4 + k] * (double)T[k * 4 + b];
+            W[a * 4 + b] = v;
+          }
+        std::memcpy(world_T, W, sizeof(W));
+      }
+      on_result(i, cur);
+      std::memcpy(g, cur.getFinalTransformation(), sizeof(g));
+    }
+  }
+
+private:
+  FastVGICPHip* regs_[2] = {nullptr, nullptr};
+  float* scratch_[2] = {nullptr, nullptr};
+  const float* d_map_;
+  int n_, stride_;
 };
 
 }  // namespace rgc

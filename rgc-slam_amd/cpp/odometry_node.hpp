@@ -90,6 +90,7 @@ public:
     bool use_imu = false;                  // USE_IMU (launch/run.launch:18)
     int first_frames = 0;                  // firstflagnum, RGC_odometer.cpp:303 (the reference: 10)
     double init_yaw = 0.0;                 // init_yaw, :358 (degrees)
+    int lazy_target_margin = 0;            // > 0: the map's covariances / voxels only within this many voxels of where the sweep falls at the guess (rgc_set_target_lazy: same poses)
   };
 
   explicit OdometryNode(const Options& o) : opt_(o) {
@@ -97,6 +98,8 @@ public:
     rgc_default_params(&p);                // = the setters of RGC_odometer.cpp:998-1006 (resolution 1.0, 25 iterations, eps 1e-6)
     int rc = rgc_create(o.hip_device, &p, &ctx_);
     if (rc != RGC_OK) throw std::runtime_error(std::string("rgc_create: ") + rgc_status_string(rc));
+    if (o.lazy_target_margin > 0 && (rc = rgc_set_target_lazy(ctx_, o.lazy_target_margin)) != RGC_OK)
+      throw std::runtime_error(std::string("rgc_set_target_lazy: ") + rgc_last_error(ctx_));
     rgc_default_fe_params(&fe_);
     fe_.n_scans = o.scan_line; fe_.min_range = o.minimum_range; fe_.max_range = o.maxmum_range;
     rgc_imu_filter_init(&imu_);
@@ -425,7 +428,11 @@ private:
           chk(rgc_transform_cloud(ctx_, d_source_.p, n_src, 16, q_w_, t_w_, kf.p, 1));           // :1237
           d_kf_.push_back(kf);
         } else {
-          HostVec w((size_t)4 * n_src);
+          // (a recycled buffer of an evicted keyframe: a fresh page-locked vector is a hipHostMalloc inside the frame, and freeing one when
+          // the window slides synchronises the device -- the kind of stall the page-locked staging was introduced to remove)
+          HostVec w;
+          if (!kf_free_.empty()) { w = std::move(kf_free_.back()); kf_free_.pop_back(); }
+          fit(w, (size_t)4 * n_src);
           chk(rgc_transform_cloud(ctx_, source_.data(), n_src, 16, q_w_, t_w_, w.data(), 0));
           kf_cloud_.push_back(std::move(w));
         }
@@ -472,7 +479,7 @@ private:
       return;
     }
     submap_.clear();
-    if ((int)kf_cloud_.size() > opt_.max_keyframes) kf_cloud_.pop_front();                       // :1242-1247
+    if ((int)kf_cloud_.size() > opt_.max_keyframes) { kf_free_.push_back(std::move(kf_cloud_.front())); kf_cloud_.pop_front(); }   // :1242-1247
     if (kf_cloud_.size() > 1) {                                                                  // :1248-1256: every keyframe into the new body frame
       const double qi[4] = {-q_w_[0], -q_w_[1], -q_w_[2], q_w_[3]};
       double ti[3];
@@ -492,6 +499,7 @@ private:
   rgc_fe_params fe_{};
   HostVec raw_, full_, full_last_, sharp_, flat_, inten_, source_, target_, submap_;
   std::deque<HostVec> kf_cloud_;
+  std::vector<HostVec> kf_free_;   // buffers of evicted keyframes, taken again by the next one
   DevBuf d_raw_, d_source_, d_last_;     // device_chain: the unpacked message, the 0.2 m-filtered sweep, the previous sweep (keyframe 0)
   // device_chain without the resident map: the reference's keyframe window (world-frame clouds) and its re-framed concatenation on the device
   struct DevKf { float* p = nullptr; size_t cap = 0; int n = 0; };

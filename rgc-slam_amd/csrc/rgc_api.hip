@@ -697,11 +697,11 @@ int lazy_build(rgc_ctx* c, const float guess[16]) {
   double T[16];
   for (int i = 0; i < 16; i++) T[i] = (double)guess[i];
   int* counts = (int*)cl.segs.p + 1;  // [0] listed queries, [1] listed cells: behind the deferred-query counter, zeroed with it by k_rank_gather
+  const int* guard = cl.spec_used ? c->d_small + 6 : nullptr;
   rgck::footprint(s, c->src.in, c->src.stride_f, c->src.n, pose_from(T), cl.grid, (int*)cl.need.p, cl.need_stamp, c->lazy_margin, (const float4*)cl.P.p, n,
-                  (const int*)cl.start.p, (int*)cl.qlist.p, (int*)cl.cell_list.p, counts);
+                  (const int*)cl.start.p, (int*)cl.qlist.p, (int*)cl.cell_list.p, counts, guard);
   const int q_est = cl.lazy_nq_seen >= 0 ? cl.lazy_nq_seen + cl.lazy_nq_seen / 4 + 4096 : n;
   const int c_est = cl.lazy_ncell_seen >= 0 ? cl.lazy_ncell_seen + cl.lazy_ncell_seen / 4 + 1024 : n / 8 + 1024;
-  const int* guard = cl.spec_used ? c->d_small + 6 : nullptr;
   {
     ProfScope ps(c, RGC_K_KNN_COV, n, s);
     rgck::knn_bulk(s, true, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p,
@@ -733,7 +733,8 @@ int complete_target(rgc_ctx* c) {
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->tgt_prepared, c->stream));
   cl.lazy = 0;
-  c->corr_valid = false;
+  // (corr_valid stays as it is: the completed map has the voxel ids and records of the part a solve has used, bit for bit, so the
+  // correspondences that solve froze are still the ones rgc_compute_error needs -- as after a solve on a fully built target)
   c->deferred_known = false;
   c->main_has_target_prep = true;
   return RGC_OK;
@@ -758,6 +759,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
   const int stride_f = stride_bytes / 4;
   if (on_device) {
     cl.in = xyz;
+    if (!is_target) c->src_in_pending = false;  // (no upload of this scan to wait for)
   } else {
     const size_t bytes = (size_t)n * stride_bytes;
     int rc = ensure(c, cl.in_copy, bytes);
@@ -768,7 +770,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
     }
     // pageable host memory: hipMemcpyAsync stages and returns once the source has been consumed
     HIPCHK(c, hipMemcpyAsync(cl.in_copy.p, xyz, bytes - (stride_bytes - 12), hipMemcpyHostToDevice, is_target ? c->stream : c->stream2));
-    if (!is_target && c->lazy_margin > 0) {  // (the lazy target's footprint pass reads the scan's input on the main stream)
+    if (!is_target) {  // (a lazy target's footprint pass reads the scan's input on the main stream -- whenever rgc_set_target_lazy was called)
       HIPCHK(c, hipEventRecord(c->src_in_ready, c->stream2));
       c->src_in_pending = true;
     }
@@ -2103,14 +2105,25 @@ int rgc_transform_cloud(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, 
 // bounding box follows from the input's -- measured once per input buffer (whole 1 m cells, k_bbox) -- and the transform: its eight
 // corners through q * p + t in fp64, a millimetre added for the fp32 rounding of the stored points.  rgc_set_target_device takes its grid
 // from that box: no bounding-box kernel, no read-back, and no speculative-grid miss when the re-framed map's box swings with the yaw.
-int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, const double q[4], const double t[3], float* d_scratch) {
-  if (!c || !d_xyzi || !q || !t || !d_scratch || n <= 0) return RGC_ERR_INVALID;
+// the argument checks of rgc_set_target_reframed (also made by rgc_align_end_reframe BEFORE it consumes the solve)
+static int reframe_args_ok(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, const float* d_scratch) {
+  if (!d_xyzi || !d_scratch || n <= 0) return fail(c, RGC_ERR_INVALID, "rgc_set_target_reframed: null buffer or no points");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
+  if (n > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud has %d points, the limit is 2^27 (32-bit byte offsets into the sorted array)", n);
+  if (n < c->prm.k_correspondences) return fail(c, RGC_ERR_TOO_FEW_POINTS, "target cloud has %d points, need >= k = %d", n, c->prm.k_correspondences);
+  // the re-framed cloud is WRITTEN to d_scratch while d_xyzi is read: they must not overlap (and one buffer has one bounding-box hint)
+  const char* a0 = (const char*)d_xyzi; const char* a1 = a0 + (size_t)n * stride_bytes;
+  const char* b0 = (const char*)d_scratch; const char* b1 = b0 + (size_t)n * 16;
+  if (a0 < b1 && b0 < a1) return fail(c, RGC_ERR_INVALID, "rgc_set_target_reframed: d_scratch overlaps d_xyzi");
+  return RGC_OK;
+}
+
+int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, const double q[4], const double t[3], float* d_scratch) {
+  if (!c || !q || !t) return RGC_ERR_INVALID;
   if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
-  {  // the re-framed cloud is WRITTEN to d_scratch while d_xyzi is read: they must not overlap (and one buffer has one bounding-box hint)
-    const char* a0 = (const char*)d_xyzi; const char* a1 = a0 + (size_t)n * stride_bytes;
-    const char* b0 = (const char*)d_scratch; const char* b1 = b0 + (size_t)n * 16;
-    if (a0 < b1 && b0 < a1) return fail(c, RGC_ERR_INVALID, "rgc_set_target_reframed: d_scratch overlaps d_xyzi");
+  {
+    const int rc = reframe_args_ok(c, d_xyzi, n, stride_bytes, d_scratch);
+    if (rc) return rc;
   }
   HIPCHK(c, hipSetDevice(c->device));
   const float* xyzi = d_xyzi;
@@ -2164,6 +2177,18 @@ int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_b
 int rgc_align_end_reframe(rgc_ctx* c, rgc_ctx* next, double Tw[16], const float* d_map, int n, int stride_bytes, float* d_scratch,
                           float final_T[16], double final_H[36], double* fitness, int* iterations, int* converged, int* lm_failed) {
   if (!c || !next || !Tw) return RGC_ERR_INVALID;
+  // Everything that could make the second half (the next frame's target) fail for the caller's arguments is checked BEFORE the solve is
+  // consumed: a non-OK return then means "nothing happened" (the solve is still pending, Tw untouched) -- or, past this point, a HIP /
+  // allocation failure inside the preparation, with the solve's outputs and Tw already valid (the message says which call failed).
+  if (next != c) {
+    if (!ctx_alive(next)) return fail(c, RGC_ERR_INVALID, "rgc_align_end_reframe: the next context is not alive");
+    if (next->pend.active) return fail(c, RGC_ERR_INVALID, "rgc_align_end_reframe: a solve is in flight on the next context");
+  }
+  if (!c->pend.active) return fail(c, RGC_ERR_INVALID, "rgc_align_end without rgc_align_begin");
+  {
+    const int rc0 = reframe_args_ok(next, d_map, n, stride_bytes, d_scratch);
+    if (rc0) { if (next != c) fail(c, rc0, "rgc_align_end_reframe: %s", next->err); return rc0; }
+  }
   float T[16];
   int rc = rgc_align_end(c, T, final_H, fitness, iterations, converged, lm_failed);
   if (rc) return rc;

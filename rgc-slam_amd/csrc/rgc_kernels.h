@@ -96,8 +96,9 @@ void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, 
               const int* qlist = nullptr, const int* nq = nullptr, int q_est = 0, const KnnSeeds& seeds = KnnSeeds{});
 // lazy target: stamp the cells of grid g within `margin` cells of the cell each point of the cloud falls into under T and list the occupied
 // ones (cell_list: their first sorted point; qlist: all their points; counts[0] / [1]: the lists' sizes, zeroed by rank_gather)
+// guard (nullable): the speculative grid's flag -- set: the map's points may lie outside the grid, nothing is listed
 void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, int* need, int stamp, int margin, const float4* P, int n_map,
-               const int* start, int* qlist, int* cell_list, int* counts);
+               const int* start, int* qlist, int* cell_list, int* counts, const int* guard = nullptr);
 // ... and the voxel pass over the listed cells, the map's deferred queries resolved beside it (k_voxel_cells_coop); voxel_patch follows
 void voxel_cells_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
                       double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const int* cell_list, const int* ncells,

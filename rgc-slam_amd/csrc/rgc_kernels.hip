@@ -793,6 +793,9 @@ __device__ __forceinline__ void for_each_cube_row(const Grid& g, const int c[3],
 #ifndef RGC_KNN_T
 #define RGC_KNN_T 256
 #endif
+#ifndef RGC_SP_ONE_EXIT
+#define RGC_SP_ONE_EXIT 0  // (1: the unseeded search's candidate loop with one exit like the seeded one's -- 0.172 against 0.156 ms per 1 M-query launch: it loses there)
+#endif
 constexpr int KNN_T = RGC_KNN_T;  // (64- and 128-thread workgroups: the same launch time, round 3)
 #ifndef RGC_XCD_RUN
 #define RGC_XCD_RUN 16
@@ -1214,13 +1217,16 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     for (int j = 0; j < L && j < 24; j++) top.a[j] = w[j];
     tau = top.a[L - 1];
   }
-  // (one exit, at the head: with a second one between the halves the compiler waits for ALL loads at the head of the loop -- see
-  // knn_point_seeded; a wave may run one trip more than its longest lane needs)
+  // (two exits.  The compiler then waits for ALL loads at the head of the loop -- see knn_point_seeded, whose loop has one exit -- but this
+  // kernel, five waves per SIMD and bound by instruction issue, is 10 % FASTER that way than with the one-exit loop: measured, not understood)
   fetch(qa);
   for (;;) {
     if (!__any(qa.live)) break;
     fetch(qb);
     process(qa);
+#if !RGC_SP_ONE_EXIT
+    if (!__any(qb.live)) break;
+#endif
     fetch(qa);
     process(qb);
   }
@@ -1717,10 +1723,11 @@ __device__ __forceinline__ bool knn_point_split(const float4* __restrict__ P, co
     refresh();
   }
   fetch(qa);
-  for (;;) {  // (one exit, at the head: see knn_point_seeded)
+  for (;;) {
     if (!__any(qa.live)) break;
     fetch(qb);
     process(qa);
+    if (!__any(qb.live)) break;
     fetch(qa);
     process(qb);
   }
@@ -2262,9 +2269,13 @@ __global__ void k_footprint(const float* __restrict__ in, int stride_f, int n, P
 }
 constexpr int kListT = 1024;  // sixteen waves per workgroup: ONE atomicAdd per workgroup and list (same-address atomics cost ~12 ns each across the XCDs --
                               // one per wave was 6 000 of them on one word: 63 us for a pass that moves 20 MB)
+// guard (nullable, as in k_knn_sp): the grid was not derived from this cloud and some point did not fit it -- k_count parked that point in cell 0 while P
+// keeps its coordinates, so a cell computed from them may lie outside need[] / start[]: nothing is listed, the cloud will be prepared again
 __global__ void __launch_bounds__(kListT) k_lazy_lists(const float4* __restrict__ P, int n, Grid g, const int* __restrict__ start, const int* __restrict__ need,
-                                                       int stamp, int* __restrict__ qlist, int* __restrict__ cell_list, int* __restrict__ counts) {
+                                                       int stamp, int* __restrict__ qlist, int* __restrict__ cell_list, int* __restrict__ counts,
+                                                       const int* __restrict__ guard) {
   __shared__ int wq[kListT / WAVE], wc[kListT / WAVE], base_s[2];
+  if (guard && *guard) return;
   const int s = blockIdx.x * kListT + threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
   bool want = false, head = false;
@@ -2486,6 +2497,7 @@ k_voxel_cells_coop(const float4* __restrict__ P, double* __restrict__ nx, double
     coop_run<KC, true>(P, start, g, k, df, nx, ny, nz, &shm[w], lane, (int)blockIdx.x * (VOX_T / WAVE) + w, nb_coop * (VOX_T / WAVE));
     return;
   }
+  if (df.guard && *df.guard) return;  // (a point outside the speculative grid: nothing was listed, the cloud will be prepared again)
   const int nc = *ncells, nwaves = ((int)gridDim.x - nb_coop) * (VOX_T / WAVE);
   for (int e = ((int)blockIdx.x - nb_coop) * (VOX_T / WAVE) + w; e < nc; e += nwaves) {
     const float4 cp = P[cell_list[e]];
@@ -3997,9 +4009,9 @@ void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, 
   else knn_coop_kc<32>(s, is_target, P, start, g, n, k, segs, nx, ny, nz, guard, waves, seeds);
 }
 void footprint(hipStream_t s, const float* in, int stride_f, int n, Pose T, Grid g, int* need, int stamp, int margin, const float4* P, int n_map,
-               const int* start, int* qlist, int* cell_list, int* counts) {
+               const int* start, int* qlist, int* cell_list, int* counts, const int* guard) {
   if (n > 0) hipLaunchKernelGGL(k_footprint, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, T, g, need, stamp, margin);
-  if (n_map > 0) hipLaunchKernelGGL(k_lazy_lists, dim3(nblk(n_map, kListT)), dim3(kListT), 0, s, P, n_map, g, start, need, stamp, qlist, cell_list, counts);
+  if (n_map > 0) hipLaunchKernelGGL(k_lazy_lists, dim3(nblk(n_map, kListT)), dim3(kListT), 0, s, P, n_map, g, start, need, stamp, qlist, cell_list, counts, guard);
 }
 void voxel_cells_coop(hipStream_t s, const float4* P, double* nx, double* ny, double* nz, const int* start, Grid g, int n, const int* cell_voxel,
                       double* vox, int* vox_cell, int k, const void* deferred, const int* guard, int waves, const int* cell_list, const int* ncells,

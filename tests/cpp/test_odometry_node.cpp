@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
     if (argc > 4) opt.rebase_distance = atof(argv[4]);
     const bool as_message = atoi(argv[3]) != 0;
     if (argc > 5) opt.device_chain = atoi(argv[5]) != 0;
+    if (getenv("RGC_NODE_LAZY_MARGIN")) opt.lazy_target_margin = atoi(getenv("RGC_NODE_LAZY_MARGIN"));   // (this driver's switch for Options::lazy_target_margin)
     if (argc > 6 && atoi(argv[6]) != 0) {   // front-end of sweep k+1 overlapped with the frame body of sweep k
       rgc::ReplayPipeline pipe(opt, getenv("RGC_FRONT_WORKERS") ? atoi(getenv("RGC_FRONT_WORKERS")) : 1);
       std::vector<const void*> data;

@@ -178,3 +178,16 @@ def test_cpp_node_reference_semantics_on_the_device(exe, sweeps):
     dev, _, s1 = _run(exe, path, False, True, chain=True)
     assert len(host) == len(dev) == len(raws) and s0["keyframes"] == s1["keyframes"]
     assert np.array_equal(host, dev)
+
+
+@pytest.mark.parametrize("resident,chain", [(False, False), (False, True), (True, True)])
+def test_cpp_node_with_the_lazy_target(exe, sweeps, monkeypatch, resident, chain):
+    """rgc::OdometryNode::Options::lazy_target_margin (rgc_set_target_lazy: the map's covariances and voxels only where the sweep can look):
+    the poses and ground messages of the node without it, bit for bit, in the reference's map semantics (host-staged and on the device)
+    and with the resident map."""
+    _, path = sweeps
+    ref = _run(exe, path, resident, True, chain=chain)
+    monkeypatch.setenv("RGC_NODE_LAZY_MARGIN", "2")
+    got = _run(exe, path, resident, True, chain=chain)
+    assert np.array_equal(ref[0], got[0]) and ref[1] == got[1]
+    assert ref[2]["keyframes"] == got[2]["keyframes"]

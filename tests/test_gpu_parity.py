@@ -1020,3 +1020,115 @@ def test_seeded_search_is_exact_whatever_the_seeds(reg_mod, orc, medium, monkeyp
     for p in (d_map_w, d_body_w):
         w.device_free(p)
     v.close(); w.close()
+
+
+def test_lazy_target_behind_a_tripped_guard_and_errors_of_the_fused_call(reg_mod, medium):
+    """(a) A lazy target prepared on the PREVIOUS cloud's (speculative) grid with a point far outside it: the counting pass parks that point
+    and raises the guard; the lazy kernels must stand still like every other consumer (no cell computed from the parked point's coordinates),
+    the target is prepared again on its own box and the result is the full build's.  (b) rgc_compute_error straight after a solve on a
+    lazy target: the completed map keeps the solve's correspondences.  (c) rgc_align_end_reframe checks its second half's arguments
+    before it consumes the solve: a bad call changes nothing and can be repeated."""
+    import bench
+    import rgc_slam_amd.synth as synth
+    tgt, src = medium["tgt"], medium["src"]
+    eye = np.eye(4, dtype=np.float32)
+    far = tgt.copy()
+    far[7] = np.float32([9.0e4, -3.0e4, 2.0e3])              # thousands of cells outside the grid of the cloud before it
+    far[11] = np.float32([3.0e7, 1.0e7, -5.0e6])             # ... and one whose cell index would not fit an int
+    full, lazy = _odo(reg_mod), _odo(reg_mod)
+    lazy.setLazyTarget(2)
+    for v in (full, lazy):
+        v.setInputTarget(tgt); v.setInputSource(src)
+        v.align(eye, want_output=False)                      # (the next target takes this one's grid, widened, without measuring)
+    out = []
+    for v in (full, lazy):
+        try:
+            v.setInputTarget(far); v.setInputSource(src)
+            v.align(eye, want_output=False, want_fitness=True)
+            out.append((v.getFinalTransformation(), v.nr_iterations, v.getFitnessScore()))
+        except reg_mod.RgcError as e:                        # (a grid over such a box may exceed max_cells: then both must say so)
+            out.append(str(e))
+    if isinstance(out[0], str):
+        assert isinstance(out[1], str)
+    else:
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:]
+    # (b)
+    for v in (full, lazy):
+        v.setInputTarget(tgt); v.setInputSource(src)
+        v.align(eye, want_output=False)
+    Tf = full.getFinalTransformation()
+    assert np.array_equal(Tf, lazy.getFinalTransformation())
+    assert full.compute_error(Tf) == lazy.compute_error(Tf)
+    full.close(); lazy.close()
+    # (c)
+    pv = reg_mod.PipelinedVGICP(0, depth=2)
+    a, b = pv.v
+    n = len(tgt)
+    m4 = np.zeros((n, 4), np.float32); m4[:, :3] = tgt
+    s4 = np.zeros((len(src), 4), np.float32); s4[:, :3] = src
+    d_map, d_src = a.device_alloc(m4.nbytes), a.device_alloc(s4.nbytes)
+    d_body = {id(w): w.device_alloc(m4.nbytes) for w in pv.v}
+    a.upload(d_map, m4); a.upload(d_src, s4)
+    Tw = np.eye(4)
+    q, t = bench.world_to_body(Tw)
+    a.setInputTargetReframed(d_map, n, 16, q, t, d_body[id(a)])
+    a.setInputSourceDevice(d_src, len(src), 16)
+    a.align_begin(eye, True)
+    Tw_before = Tw.copy()
+    with pytest.raises(reg_mod.RgcError):
+        a.align_end_reframe(b, Tw, d_map, n, 16, d_map)      # the scratch buffer IS the map: refused ...
+    assert np.array_equal(Tw, Tw_before)                     # ... with the world pose untouched and the solve still pending:
+    T = a.align_end_reframe(b, Tw, d_map, n, 16, d_body[id(b)])
+    assert np.array_equal(Tw, Tw_before @ T.astype(np.float64))
+    ref = _odo(reg_mod)
+    ref.setInputTarget(tgt); ref.setInputSource(src)
+    ref.align(eye, want_output=False)
+    assert np.abs(ref.getFinalTransformation() - T).max() <= 1e-6
+    b.setInputSourceDevice(d_src, len(src), 16)
+    b.align(eye, want_output=False)                          # the target the fused call enqueued on the other context is usable
+    for w in pv.v:
+        w.device_free(d_body[id(w)])
+    a.device_free(d_map); a.device_free(d_src)
+    ref.close(); pv.close()
+
+
+def test_cpp_dependent_sequence_through_the_device_entry_points(reg_mod, tmp_path):
+    """The C++ adaptor's device-side entry points (rgc::FastVGICPHip::setInputTargetReframed / alignEndReframe / holdSourceUntilTargetOf /
+    setLazyTarget, rgc::DependentSequence): the odometer's dependent frame loop one frame at a time through the reference's call sequence,
+    on two registrations taking turns, and with the lazy target -- the same motions, fitness scores and world pose bit for bit, and the
+    motions of the Python mirror's DependentSequence."""
+    import os, subprocess
+    import bench
+    import rgc_slam_amd.synth as synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = _build_cpp(root, tmp_path, "test_dependent")
+    world, tgt = synth.make_world_and_map(80000, seed=synth.SEED + 11)
+    poses = synth.make_trajectory(6, seed=synth.SEED + 11)
+    scans = [synth.make_scan_n(world, poses[i + 1], 12000, seed=synth.SEED + 700 + i)["xyz"] for i in range(5)]
+    def dump(a, path):
+        with open(path, "wb") as f:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            f.write(np.int32(len(a)).tobytes()); f.write(a.tobytes())
+    dump(tgt, tmp_path / "map.bin")
+    for i, s in enumerate(scans):
+        dump(s, tmp_path / f"s{i}.bin")
+    Tw0 = np.ascontiguousarray(poses[0], np.float64)
+    (tmp_path / "pose0.bin").write_bytes(Tw0.tobytes())
+    out = subprocess.run([exe, str(tmp_path / "map.bin"), str(tmp_path / "pose0.bin"), str(len(scans))] + [str(tmp_path / f"s{i}.bin") for i in range(len(scans))],
+                         capture_output=True, text=True, timeout=600).stdout
+    lines = dict(l.split(" ", 1) for l in out.strip().splitlines())
+    assert lines.get("same_two_contexts") == "1" and lines.get("same_lazy") == "1", out
+    pv = reg_mod.PipelinedVGICP(0, depth=2)
+    v = pv.v[0]
+    def to_dev(xyz):
+        a = np.zeros((xyz.shape[0], 4), np.float32); a[:, :3] = xyz
+        p = v.device_alloc(a.nbytes); v.upload(p, a); return p
+    d_map, d_scans = to_dev(tgt), [to_dev(s_) for s_ in scans]
+    seq = bench.DependentSequence(pv.v, d_map, len(tgt), d_scans, [len(s_) for s_ in scans])
+    motions, worlds, _ = seq.run(0, len(scans), Tw0, np.eye(4, dtype=np.float32), True)
+    for i, T in enumerate(motions):
+        Tc = np.array([float(x) for x in lines[f"T{i}"].split()], np.float32).reshape(4, 4)
+        assert np.array_equal(Tc, T), (i, Tc, T)
+    Wc = np.array([float(x) for x in lines["world"].split()]).reshape(4, 4)
+    assert np.array_equal(Wc, worlds[-1])
+    seq.close(); pv.close()
