@@ -228,6 +228,12 @@ RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stri
  * -- grid, exact-kNN covariances, voxel map, like rgc_set_target_device -- without a host round trip: the re-framed cloud's bounding
  * box is derived from the input's (measured on the first call with a given d_xyzi, n) and the transform.  What a dependent sequence
  * does every frame with the pose the previous frame returned.
+ * Seeds (round 5): while consecutive calls name the same (d_xyzi, n), the map's exact 20-NN search (fast_gicp_impl.hpp:241-298) starts
+ * from what the last search of each point found -- its k-th neighbour distance, kept per ORIGINAL point (4 bytes each) and widened by the
+ * fp32 rounding of the coordinates in two frames: only candidates under that bound are looked at, no running top-k is kept.  The result
+ * does NOT depend on what the seeds hold: a search that does not find exactly its k neighbours under the bound (a buffer rewritten in
+ * place, a different cloud at the same address) is repeated without it, so "fixed between calls" is what makes the call fast, not what
+ * makes it right.  Covariances are bit-identical with and without seeds (RGC_KNN_SEEDS=0 in the environment switches them off).
  * Preconditions: d_scratch must not overlap d_xyzi (RGC_ERR_INVALID: the input is read while the output is written, and a buffer has
  * one bounding-box hint); a d_scratch that is 16-byte aligned (anything hipMalloc / rgc_device_alloc returns) takes the fused path
  * -- re-framing inside the preparation's counting pass -- any other 4-byte aligned address the re-framing runs as its own launch. */
