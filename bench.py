@@ -203,6 +203,82 @@ class DependentSequence:
         return motions, worlds, guesses
 
 
+def two_sequences_per_gpu(registration, synth, np, device_index, seq_a, pv_a, n_target, n_source, seed, W, K2, Tw_init, I4):
+    """An extra key: TWO independent dependent sequences on one GPU, each on its own pair of contexts and its own host thread -- what a
+    node with more bags than GPUs would do (BASELINE config 4 with fewer than 8 GPUs).  A dependent frame leaves the chip mostly idle
+    while it solves (a chain of short launches on 118 workgroups); the other sequence's map preparation fits there.  `value` stays one
+    sequence per GPU (north_star).  Each sequence's motions must be those of its solo run, bit for bit."""
+    import threading
+    t0 = time.time()
+    world_b, tgt_b = synth.make_world_and_map(n_target, seed=seed + 1)
+    poses_b = synth.make_trajectory(K2 + W + 1, seed=seed + 1)
+    scans_b = [synth.make_scan_n(world_b, poses_b[i + 1], n_source, seed=seed + 1 + 100 + i)["xyz"] for i in range(K2 + W)]
+    pv_b = registration.PipelinedVGICP(device_index, depth=2)
+    vb = pv_b.v[0]
+    def to_dev(xyz):
+        a = np.zeros((xyz.shape[0], 4), np.float32)
+        a[:, :3] = xyz
+        p = vb.device_alloc(a.nbytes)
+        vb.upload(p, a)
+        return p
+    d_map_b, d_scans_b = to_dev(tgt_b), [to_dev(s_) for s_ in scans_b]
+    seq_b = DependentSequence(pv_b.v, d_map_b, tgt_b.shape[0], d_scans_b, [s_.shape[0] for s_ in scans_b])
+    for w in pv_b.v:   # context start-up, as for the first sequence
+        seq_b.v = [w]
+        seq_b.run(0, 1, np.asarray(poses_b[0], np.float64), I4, False)
+    seq_b.v = pv_b.v
+    starts = {}
+    for name, sq, p0 in (("a", seq_a, Tw_init), ("b", seq_b, np.asarray(poses_b[0], np.float64))):
+        Tw_s, g_s = p0, I4
+        if W > 0:
+            m, wd, _ = sq.run(0, W, p0, I4, True)
+            Tw_s, g_s = wd[-1], m[-1]
+        starts[name] = (Tw_s, g_s)
+    REPS = 6
+    def solo(sq, name):
+        per, ref = [], None
+        for r in range(REPS):
+            for w in sq.v:
+                w.synchronize()
+            tr = time.perf_counter()
+            m, _, _ = sq.run(W, K2, starts[name][0], starts[name][1], True)
+            for w in sq.v:
+                w.synchronize()
+            per.append(time.perf_counter() - tr)
+            ref = m if ref is None else ref
+        return ref, float(np.median(per[1:]))
+    ref_a, t_a = solo(seq_a, "a")
+    ref_b, t_b = solo(seq_b, "b")
+    # together: both threads leave a barrier at once and run their K2 frames REPS times; the job is done when the slower one is
+    gate = threading.Barrier(3)
+    same = {"a": True, "b": True}
+    def worker(sq, name, ref):
+        gate.wait()
+        for r in range(REPS):
+            m, _, _ = sq.run(W, K2, starts[name][0], starts[name][1], True)
+            same[name] = same[name] and all(np.array_equal(x, y) for x, y in zip(ref, m))
+        for w in sq.v:
+            w.synchronize()
+    th = [threading.Thread(target=worker, args=(seq_a, "a", ref_a)), threading.Thread(target=worker, args=(seq_b, "b", ref_b))]
+    for t_ in th:
+        t_.start()
+    gate.wait()
+    tr = time.perf_counter()
+    for t_ in th:
+        t_.join()
+    wall = time.perf_counter() - tr
+    seq_b.close()
+    for p in [d_map_b] + d_scans_b:
+        vb.device_free(p)
+    pv_b.close()
+    return {"aggregate_scans_per_s": round(2 * K2 * REPS / wall, 3), "ms_per_step_per_sequence": round(1e3 * wall / (K2 * REPS), 4),
+            "solo_scans_per_s": [round(K2 / t_a, 3), round(K2 / t_b, 3)], "frames_per_sequence": K2 * REPS,
+            "same_poses_as_each_sequence_alone": bool(same["a"] and same["b"]), "seeds": [int(seed), int(seed + 1)],
+            "wall_s_incl_datagen": round(time.time() - t0, 1),
+            "what": "two independent dependent sequences (two maps, two trajectories) on ONE GPU, each on its own two contexts and host thread, "
+                    "full rebuild per frame; aggregate = frames of both / wall time of the slower; `value` stays one sequence per GPU"}
+
+
 def frame_bytes(st, n_s, n_t):
     """SURVEY §8d's yardstick from one frame's counters"""
     return algorithmic_bytes(n_s, n_t, st["n_voxels"], st["n_corr"], st["n_linearize"], st["n_error"])
@@ -382,6 +458,7 @@ def main():
     ap.add_argument("--n-source", type=int, default=N_SOURCE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--configs", default="c1,c3,c5", help="extra single-GPU configurations of BASELINE.json to run after the metric (c1,c3,c5 or 'none')")
+    ap.add_argument("--no-two-sequences", action="store_true", help="skip the extra key two_sequences_per_gpu (a second sequence's data and contexts)")
     ap.add_argument("--sequence", type=int, default=0, help="number of the first rank's sequence (rank r runs sequence --sequence + r: seed offset)")
     args = ap.parse_args()
 
@@ -750,6 +827,9 @@ def main():
         out["pose_parity_vs_cpu"] = {"frames": n_done, "max_dt_m": max(dts), "max_dtheta_rad": max(dths),
                                      "rmse_dt_m": float(np.sqrt(np.mean(np.square(dts)))),
                                      "rmse_dtheta_rad": float(np.sqrt(np.mean(np.square(dths))))}
+    if world_size == 1 and not args.no_two_sequences:
+        out["two_sequences_per_gpu"] = two_sequences_per_gpu(registration, synth, np, device_index, seq, pv, tgt.shape[0], args.n_source, seed, W,
+                                                             min(K, 20), Tw_init, I4)
     seq.close()
     pv.close()
 
