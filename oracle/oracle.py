@@ -12,7 +12,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "librgc_oracle.so")
+# RGC_ORACLE_ASAN=1 (tests/test_sanitizers.py, a child process with libasan preloaded): the AddressSanitizer / UBSan build of the same sources
+_ASAN = os.environ.get("RGC_ORACLE_ASAN") == "1"
+_LIB = os.path.join(_HERE, "librgc_oracle_asan.so" if _ASAN else "librgc_oracle.so")
 
 DIRECT27, DIRECT7, DIRECT1 = 0, 1, 2
 
@@ -20,7 +22,7 @@ DIRECT27, DIRECT7, DIRECT1 = 0, 1, 2
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("rgc_oracle.c", "rgc_oracle_aux.c", "rgc_oracle_map.c", "rgc_oracle.h", "Makefile")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _ASAN else []))
     return _LIB
 
 

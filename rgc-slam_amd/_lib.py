@@ -123,6 +123,32 @@ SYMBOLS = [
 _lib = None
 
 
+class _PartialLibrary:
+    """RGC_HIP_LIB_PARTIAL=1: LIB_PATH names a library built from a SUBSET of the sources -- csrc/rgc_host.cpp alone under
+    -fsanitize=address,undefined (tests/test_sanitizers.py: the scalar host stages need no HIP).  A symbol it lacks becomes a stand-in
+    that takes the prototype declarations below and raises when called; the product library is never loaded this way."""
+
+    class _Missing:
+        def __init__(self, name):
+            object.__setattr__(self, "_name", name)
+
+        def __setattr__(self, k, v):
+            pass
+
+        def __call__(self, *a, **kw):
+            raise RuntimeError(f"{self._name} is not in the partial library {LIB_PATH}")
+
+    def __init__(self, real):
+        self._real = real
+        self._missing = {}
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._real, name)
+        except AttributeError:
+            return self._missing.setdefault(name, _PartialLibrary._Missing(name))
+
+
 def load():
     """Load librgc_hip.so and declare prototypes.  Raises if the library is missing (build with
     `python rgc-slam_amd/build.py` or __graft_entry__.build())."""
@@ -133,6 +159,8 @@ def load():
         raise ImportError(f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback); "
                           f"run `python rgc-slam_amd/build.py`")
     L = C.CDLL(LIB_PATH)
+    if os.environ.get("RGC_HIP_LIB_PARTIAL") == "1":
+        L = _PartialLibrary(L)
     vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)
     L.rgc_default_params.argtypes = [C.POINTER(Params)]
     L.rgc_default_params.restype = None
