@@ -15,6 +15,22 @@ __host__ __device__ inline void so3_exp_R(const double w[3], double R[9]) {
     const double th4 = th2 * th2;
     imag = 0.5 - 1.0 / 48.0 * th2 + 1.0 / 3840.0 * th4;
     real = 1.0 - 1.0 / 8.0 * th2 + 1.0 / 384.0 * th4;
+#ifdef __HIP_DEVICE_COMPILE__
+  } else if (th2 < 0.25) {
+    // The device's one deciding lane: sin(th/2)/th and cos(th/2) as series in u = (th/2)^2 (an LM step of a scan-to-map registration
+    // turns by well under half a radian) -- fourteen dependent fma instead of a square root, a division and libm's sin and cos with their
+    // range reduction (~300 dependent fp64 instructions).  Truncation below 1e-19 relative at u = 1/16: the same double as the closed
+    // form up to its own rounding.  (The host driver keeps the closed form: the two agree to 1e-15, tests/test_gpu_parity.py.)
+    const double u = 0.25 * th2;
+    double sc = -1.0 / 1307674368000.0;                       // sin(x)/x = sum (-u)^k / (2k+1)!
+    sc = fma(sc, u, 1.0 / 6227020800.0); sc = fma(sc, u, -1.0 / 39916800.0); sc = fma(sc, u, 1.0 / 362880.0);
+    sc = fma(sc, u, -1.0 / 5040.0); sc = fma(sc, u, 1.0 / 120.0); sc = fma(sc, u, -1.0 / 6.0); sc = fma(sc, u, 1.0);
+    double cs = 1.0 / 87178291200.0;                          // cos(x) = sum (-u)^k / (2k)!
+    cs = fma(cs, u, -1.0 / 479001600.0); cs = fma(cs, u, 1.0 / 3628800.0); cs = fma(cs, u, -1.0 / 40320.0);
+    cs = fma(cs, u, 1.0 / 720.0); cs = fma(cs, u, -1.0 / 24.0); cs = fma(cs, u, 0.5); cs = fma(-cs, u, 1.0);
+    imag = 0.5 * sc;
+    real = cs;
+#endif
   } else {
     const double th = sqrt(th2), half = 0.5 * th;
     imag = sin(half) / th;
@@ -43,7 +59,16 @@ __host__ __device__ inline bool solve_ldlt6(const double Ain[36], const double r
       if (j < k) dk -= L[k][j] * L[k][j] * D[j];
     D[k] = dk;
     if (dk == 0.0 || !(fabs(dk) < 1.0e300)) ok = false;
+#ifdef __HIP_DEVICE_COMPILE__
+    {  // v_rcp_f64 and two Newton steps (five dependent instructions; the compiler's IEEE division is ~40): within an ulp or two of 1 / dk
+      double r = __builtin_amdgcn_rcp(dk);
+      r = fma(fma(-dk, r, 1.0), r, r);
+      r = fma(fma(-dk, r, 1.0), r, r);
+      invD[k] = r;
+    }
+#else
     invD[k] = 1.0 / dk;
+#endif
 #pragma unroll
     for (int i = 0; i < 6; i++) {
       if (i > k) {
