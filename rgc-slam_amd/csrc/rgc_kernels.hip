@@ -1887,19 +1887,28 @@ void lab_wave_ts(long long* out, hipStream_t s) {
 #endif
 // kSeeded (the map, k == KC): every query first tries the seeded search (knn_point_seeded: df.seed holds a bound per original point
 // index) and runs the full one where that declines.
+// The seeded launch runs in smaller workgroups (kSeedT threads): its per-lane LDS columns (37 ints) admit four 256-thread workgroups per CU,
+// and a slot freed by a finished wave is refilled only when a whole workgroup's worth is free; smaller ones refill sooner.  128, not 64:
+// one-wave workgroups refill so promptly that the SCAN's one-wave kernels, which run beside this launch on the other stream, no longer
+// get in -- a frame one at a time 0.354 -> 0.394 ms (the launch alone 0.122 -> 0.120; 256: 0.123 / 0.361).
+#ifndef RGC_SEED_T
+#define RGC_SEED_T 128
+#endif
+constexpr int kSeedT = RGC_SEED_T;
+template <bool kTarget, bool kSeeded> struct SpLaunch : SpConfig<kTarget> { static constexpr int T = kSeeded ? kSeedT : SpConfig<kTarget>::T; };
 template <int KC, bool kTarget, bool kExact, bool kSeeded = false>
-__global__ void __launch_bounds__(SpConfig<kTarget>::T)
+__global__ void __launch_bounds__((SpLaunch<kTarget, kSeeded>::T))
 k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
          double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
   extern __shared__ int slist_sp[];  // [SpShape::LDS][T]
-  using Cfg = SpConfig<kTarget>;
+  using Cfg = SpLaunch<kTarget, kSeeded>;
   static_assert(!kSeeded || (kTarget && kExact), "seeds: the map's search at k == KC");
   wave_prio(!kTarget);
   if (df.guard && *df.guard) return;
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one) and queries are in cell order.
   // Each XCD takes runs of kXcdRun CONSECUTIVE query blocks (neighbouring cells: their candidates are re-used out of that XCD's L2),
   // the runs themselves dealt round-robin (whole contiguous eighths of the map differ too much in work: 7 % slower).
-  constexpr int kXcdRun = RGC_XCD_RUN;
+  constexpr int kXcdRun = RGC_XCD_RUN * KNN_T / Cfg::T;  // (a run is RGC_XCD_RUN x 256 consecutive queries whatever the workgroup size)
   const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
   if constexpr (!kTarget) {  // four lanes per query, queries in cell order
     const int t = b * Cfg::T + (int)threadIdx.x;
@@ -3953,14 +3962,15 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   }
   using CT = SpConfig<true>;
   using CS = SpConfig<false>;
-  const int T = is_target ? CT::T : CS::T;
+  const int T = is_target ? (seeded && !qlist ? kSeedT : CT::T) : CS::T;
   // (the scan's launch lays its per-lane LDS columns out for the 3x3x3 block and again, for the queries that block does not settle, for the 5x5x5 one)
   const size_t lds = (size_t)(is_target ? (seeded ? std::max(SpShape<CT::R, CT::kClip>::LDS, SeedShape<KC>::LDS) : SpShape<CT::R, CT::kClip>::LDS)
                                         : std::max(SpShape<CS::R, CS::kClip>::LDS, SpShape<2, CS::kClip>::LDS)) * T * sizeof(int);
   // whole rounds of 8 XCDs x RGC_XCD_RUN blocks (excess blocks fall out at i >= n); lazy target: as many blocks as the listed queries are
   // expected to fill (the kernel strides over the list whatever its true length)
   const int n_launch = (is_target && qlist) ? (q_est < T ? T : (q_est > n ? n : q_est)) : n;
-  const int nb = (is_target && qlist) ? nblk(n_launch, T) : 8 * RGC_XCD_RUN * nblk(nblk(n, T), 8 * RGC_XCD_RUN);
+  const int xcd_run = RGC_XCD_RUN * KNN_T / T;
+  const int nb = (is_target && qlist) ? nblk(n_launch, T) : 8 * xcd_run * nblk(nblk(n, T), 8 * xcd_run);
   // (ev0 / ev1: the launch's own start / stop times go into the caller's events -- no separate record packets around it)
   if constexpr (kExact) {
     if (seeded) {

@@ -1,4 +1,7 @@
-"""Executed VALU instruction mix of the map's bulk kNN kernel (k_knn_sp<20, true, true>): full-rate vs half-rate classes.
+"""Executed VALU instruction mix of the map's bulk kNN kernel: full-rate vs half-rate classes.  Two instances: k_knn_sp<20, true, true, false>
+(the full search: a map the library has not seen) and, with --seeded, k_knn_sp<20, true, true, true> (round 5: the search that starts from
+the previous search's k-th distances, what a re-framed persistent map runs from its second frame on; the full search inlined behind it
+for the lanes the seeded one declines is weighted by how many waves took it).
 
 The kernel's ISA comes from the product's own compile flags (hipcc --save-temps, gfx950); every v_* instruction is put into the issue
 class MEASURED for it by scripts/ubench/valu_issue.hip (profiles/r02_valu_issue.jsonl: add / sub / mul / fma / fmac f32, add / sub u32,
@@ -14,7 +17,8 @@ is checked against SQ_INSTS_VALU of the rocprofv3 --pmc pass.
 import argparse, json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN4rgck8k_knn_spILi20ELb1ELb1E"
+KERNEL = "_ZN4rgck8k_knn_spILi20ELb1ELb1ELb0E"
+KERNEL_SEEDED = "_ZN4rgck8k_knn_spILi20ELb1ELb1ELb1E"
 FULL = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_add_u32", "v_sub_u32", "v_subrev_u32",
         "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32"}
 HALF_PREFIX = ("v_min", "v_max", "v_med3", "v_cmp", "v_cndmask", "v_lshl", "v_lshr", "v_ashr", "v_and_or", "v_bfi", "v_bfe", "v_add3", "v_mad_",
@@ -40,13 +44,27 @@ def collect():
     lib.rgc_lab_iters(v._h, it.ctypes.data)
     out = {"n_target": int(len(tgt)), "waves": int(it[0]), "quads_in_scan_loop": int(it[1]), "chain_inserts": int(it[2]), "newton_steps": int(it[3]),
            "jacobi_fallbacks": int(it[4]), "exact_tie_breaks": int(it[5])}
+    # the seeded search: the same map handed over by rgc_set_target_reframed three times (poses of the bench's trajectory), the third counted
+    import bench
+    a = np.zeros((len(tgt), 4), np.float32); a[:, :3] = tgt
+    d_map, d_body = v.device_alloc(a.nbytes), v.device_alloc(a.nbytes)
+    v.upload(d_map, a)
+    poses = synth.make_trajectory(4, seed=synth.SEED)
+    for f in range(3):
+        q, t = bench.world_to_body(np.asarray(poses[f], np.float64))
+        lib.rgc_lab_iters(v._h, it.ctypes.data)
+        v.setInputTargetReframed(d_map, len(tgt), 16, q, t, d_body); v.synchronize()
+    lib.rgc_lab_iters(v._h, it.ctypes.data)
+    out["seeded"] = {"waves": (len(tgt) + 63) // 64, "waves_that_ran_the_full_search_too": int(it[6]), "quads_in_seeded_scan_loop": int(it[7]),
+                     "quads_in_scan_loop": int(it[1]), "chain_inserts": int(it[2]), "newton_steps": int(it[3]), "jacobi_fallbacks": int(it[4]),
+                     "exact_tie_breaks": int(it[5])}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "lab_iters.json"), "w"))
     print(json.dumps(out))
     v.close()
 
 
-def kernel_isa():
+def kernel_isa(KERNEL=KERNEL):
     d = tempfile.mkdtemp(prefix="rgc_isa_")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-DRGC_BUILD", "--save-temps"]
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", os.path.join(ROOT, "rgc-slam_amd", "csrc", "rgc_kernels.hip"), "-o", os.path.join(d, "k.o")],
@@ -72,12 +90,15 @@ def main():
     ap.add_argument("--collect", action="store_true")
     ap.add_argument("--lab", default=os.path.join(ROOT, "gpurun_out", "lab_iters.json"))
     ap.add_argument("--pmc", default=None)
+    ap.add_argument("--seeded", action="store_true", help="the seeded instance (k_knn_sp<20, true, true, true>), lab counts from lab['seeded']")
     args = ap.parse_args()
     if args.collect:
         return collect()
     lab = json.load(open(args.lab))
+    if args.seeded:
+        lab = lab["seeded"]
     W = float(lab["waves"])
-    isa = kernel_isa()
+    isa = kernel_isa(KERNEL_SEEDED if args.seeded else KERNEL)
     # ---- basic blocks ----
     blocks, cur = [], {"label": "entry", "ops": [], "branches": [], "line": 0}
     for ln, l in enumerate(isa):
@@ -155,6 +176,16 @@ def main():
     # Newton steps to the loop with v_rcp_f64; the Jacobi fallback's sweeps (a handful of waves) six per fallback
     trips = {"scan": lab["quads_in_scan_loop"] / W / 2.0, "drain": lab["chain_inserts"] / W, "newton": lab["newton_steps"] / W,
              "other": 6.0 * lab["jacobi_fallbacks"] / W}
+    # The seeded instance: its own candidate loop fetches 12-byte records (global_load_dwordx3), the full search inlined behind it 16-byte
+    # ones; everything from the full search's entry on (the second group of cell_coord blocks) runs for the waves that took it only.
+    fallback_from, fallback_w = len(blocks), 0.0
+    if args.seeded:
+        trips["scan_seeded"] = lab["quads_in_seeded_scan_loop"] / W / 2.0
+        fallback_w = lab["waves_that_ran_the_full_search_too"] / W
+        cc = [i for i, b in enumerate(blocks) if "cell_coord" in isa[b["line"]]]
+        groups = [i for j, i in enumerate(cc) if j == 0 or i - cc[j - 1] > 40]
+        if len(groups) >= 2:
+            fallback_from = groups[1] - 8   # (the full search's prologue: a few blocks before its first cell_coord block)
     def returns_soon(i):   # back at block i within three hops: the one-block body of a drain loop (split at its own branches)
         seen, front = set(), {i}
         for _ in range(3):
@@ -171,7 +202,9 @@ def main():
     kinds = {}
     for c_, m in cyclic.items():
         ops = [o for i in m for o in blocks[i]["ops"]]
-        if has_mem(m, "global_load_dwordx3") or has_mem(m, "global_load_dwordx4"):
+        if args.seeded and has_mem(m, "global_load_dwordx3") and min(m) < fallback_from:
+            k = "scan_seeded"
+        elif has_mem(m, "global_load_dwordx3") or has_mem(m, "global_load_dwordx4"):
             k = "scan"
         elif any(o.startswith("v_rcp_f64") for o in ops) and not any(o.startswith(("v_sqrt_f64", "v_rsq_f64")) for o in ops):
             k = "newton"   # (a rolled Newton loop; the Jacobi fallback's sweeps also divide, but take roots as well)
@@ -184,6 +217,10 @@ def main():
             weight[i] = trips[k] if k != "drain" else 0.0
     for i in drain_blocks:
         weight[i] = trips["drain"] / len(drain_blocks)
+    if args.seeded:   # the inlined full search: its once-per-wave blocks run for the waves that took it; its loops are weighted by their own counts (of those waves)
+        for i in range(max(fallback_from, 0), n):
+            if weight[i] == 1.0:
+                weight[i] = fallback_w
     # The Newton iteration of min_eigenvector_direct is fully unrolled (twelve steps, each leaving through an exec-mask branch): step j of the
     # chain runs for the waves that still have an unsettled lane; with `newton` steps per wave on average, step j gets clamp(newton - j, 0, 1)
     chain = [i for i, b in enumerate(blocks) if sum(o.startswith("v_rcp_f64") for o in b["ops"]) == 1 and b["branches"] and comp[i] not in cyclic
@@ -215,12 +252,13 @@ def main():
     h_lo = tot["half"] / executed                      # unknown opcodes priced at full rate
     h_hi = (tot["half"] + tot["unknown"]) / executed   # ... at half rate
     hc = os.path.join(ROOT, ".head_commit")   # written beside the snapshot before the GPU call (there is no .git on the box)
-    out = {"kernel": "k_knn_sp<20, true, true> (the map's bulk kNN + covariance launch, k = 20)",
+    out = {"kernel": ("k_knn_sp<20, true, true, true> (the map's bulk kNN + covariance launch, k = 20, seeded: a re-framed persistent map)" if args.seeded else
+                      "k_knn_sp<20, true, true, false> (the map's bulk kNN + covariance launch, k = 20, the full search)"),
            "commit": open(hc).read().strip() if os.path.exists(hc) else None,
            "static_valu_instructions": static, "executed_valu_per_wave": {k: round(v, 1) for k, v in tot.items()},
            "executed_valu_per_query": round(executed / 64.0, 2),
            "trip_counts_per_wave": {k: round(v, 2) for k, v in trips.items()}, "lab": lab,
-           "loops_found": {k: sum(1 for x in kinds.values() if x == k) for k in ("scan", "drain", "newton", "other")}, "drain_loop_copies": len(drain_blocks),
+           "loops_found": {k: sum(1 for x in kinds.values() if x == k) for k in ("scan", "scan_seeded", "drain", "newton", "other")}, "drain_loop_copies": len(drain_blocks),
            "unrolled_newton_steps_found": len(chain),
            "half_rate_fraction": round(h_hi, 4), "half_rate_fraction_if_unmeasured_opcodes_are_full_rate": round(h_lo, 4),
            "peak_full_rate_measured": 1060.0, "peak_half_rate_measured": 595.0,
