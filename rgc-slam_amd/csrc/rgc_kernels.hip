@@ -899,8 +899,8 @@ struct SpOrder {
 constexpr int kSort24N = 132;
 __device__ constexpr unsigned short kSort24[kSort24N] = {1, 67, 2, 35, 34, 133, 199, 134, 167, 166, 4, 70, 68, 37, 103, 101, 34, 100, 166, 265, 331, 266, 299, 298, 397, 463, 398, 431, 430, 268, 334, 332, 301, 367, 365, 298, 364, 430, 8, 140, 136, 74, 206, 202, 68, 200, 332, 41, 173, 169, 107, 239, 235, 101, 233, 365, 34, 100, 166, 232, 298, 364, 430, 529, 595, 530, 563, 562, 661, 727, 662, 695, 694, 532, 598, 596, 565, 631, 629, 562, 628, 694, 596, 629, 562, 628, 694, 16, 272, 148, 404, 136, 400, 82, 338, 214, 470, 202, 466, 68, 200, 332, 464, 596, 49, 305, 181, 437, 169, 433, 115, 371, 247, 503, 235, 499, 101, 233, 365, 497, 629, 34, 100, 166, 232, 298, 364, 430, 496, 562, 628, 694};
 
-// The same network cut to 20 wires: 101 compare-exchanges (checked on all 2^20 zero-one inputs).  It puts the k = 20 winning ordinals of
-// the map's search into ascending order: the order the moments are summed in (below).
+// The same network cut to 20 wires: 101 compare-exchanges (checked on all 2^20 zero-one inputs).  It puts the k = 20 winners of the map's
+// full search into ascending position in the sorted array: the order the moments are summed in (below).
 constexpr int kSort20N = 101;
 __device__ constexpr unsigned short kSort20[kSort20N] = {1, 67, 2, 35, 34, 133, 199, 134, 167, 166, 4, 70, 68, 37, 103, 101, 34, 100, 166, 265, 331, 266, 299, 298, 397, 463, 398, 431, 430, 268, 334, 332, 301, 367, 365, 298, 364, 430, 8, 140, 136, 74, 206, 202, 68, 200, 332, 41, 173, 169, 107, 239, 235, 101, 233, 365, 34, 100, 166, 232, 298, 364, 430, 529, 595, 530, 563, 562, 16, 272, 136, 400, 82, 338, 202, 466, 68, 200, 332, 464, 49, 305, 169, 433, 115, 371, 235, 499, 101, 233, 365, 497, 34, 100, 166, 232, 298, 364, 430, 496, 562};
 
@@ -940,9 +940,14 @@ typedef __attribute__((address_space(3))) int lds_int;
 
 // The pieces of query (c, q)'s block, in registers and in MEMORY order: [lo, hi) of the sorted array and a lower bound of the squared
 // distance from the query to anything in the piece (rounded down a little).
-template <bool kClip, int R>
+// kXCut (the seeded search, R = 1, whole rows): tauf is known before the first candidate is fetched, so a row is also cut in x -- the cell
+// left (right) of the query's is dropped when nothing in it can be below tauf (its x gap and the row's y / z gaps together): two more
+// start[] look-ups per row, a quarter fewer candidates.
+template <bool kClip, int R, bool kXCut = false>
 __device__ __forceinline__ void sp_pieces(const int* __restrict__ start, const Grid& g, const int (&c)[3], const double (&q)[3],
-                                          int (&lo)[SpShape<R, kClip>::NP], int (&hi)[SpShape<R, kClip>::NP], float (&min2)[SpShape<R, kClip>::NP]) {
+                                          int (&lo)[SpShape<R, kClip>::NP], int (&hi)[SpShape<R, kClip>::NP], float (&min2)[SpShape<R, kClip>::NP],
+                                          float tauf = 0.f) {
+  static_assert(!kXCut || (!kClip && R == 1), "the x cut: whole rows of three cells");
   using Shape = SpShape<R, kClip>;
   constexpr int D = Shape::D, NROW = Shape::NROW, NP = Shape::NP, OWN = NROW / 2;
   // ---- the block's pieces in MEMORY order: the D x D grid rows in the order of cell_index (row_dy / row_dz), each the cells cx - R .. cx + R.  kClip: the
@@ -951,7 +956,7 @@ __device__ __forceinline__ void sp_pieces(const int* __restrict__ start, const G
   const int xl = max(c[0] - R, 0), xh = min(c[0] + R, g.dim[0] - 1);
   // distance from the query to the walls of its cell; a row / piece at offset d cells is at least (|d| - 1) cells + that away
   double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
-  if (kClip || kRowSkip) {
+  if (kClip || kRowSkip || kXCut) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const double wall = cell_wall(g, a, c[a]);
@@ -967,7 +972,18 @@ __device__ __forceinline__ void sp_pieces(const int* __restrict__ start, const G
     const int y = c[1] + dy, z = c[2] + dz;
     const bool in = y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2];
     const int yy = in ? y : c[1], zz = in ? z : c[2];
-    const int a = start[cell_index(g, xl, yy, zz)], b = start[cell_index(g, xh, yy, zz) + 1];
+    int a, b;
+    if constexpr (kXCut) {
+      const int own = cell_index(g, c[0], yy, zz);
+      const int a0 = start[own - (c[0] > 0 ? 1 : 0)], m1 = start[own], m2 = start[own + 1], b0 = start[own + 1 + (c[0] < g.dim[0] - 1 ? 1 : 0)];
+      const double g2 = axis_gap(1, dy) * axis_gap(1, dy) + axis_gap(2, dz) * axis_gap(2, dz);
+      const bool left = (float)((g2 + wlo[0] * wlo[0]) * (1.0 - 1.0e-6)) < tauf, right = (float)((g2 + whi[0] * whi[0]) * (1.0 - 1.0e-6)) < tauf;
+      a = left ? a0 : m1;
+      b = right ? b0 : m2;
+    } else {
+      a = start[cell_index(g, xl, yy, zz)];
+      b = start[cell_index(g, xh, yy, zz) + 1];
+    }
     if (kClip && r == OWN) {
       const int own = cell_index(g, c[0], c[1], c[2]);
       const int o0 = start[own], o1 = start[own + 1];
@@ -1274,24 +1290,22 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     return;
   }
   // ---- neighbour positions replace the keys, then mean / covariance (fast_gicp_impl.hpp:256-262) / normal ----
-  // k == KC (the reference's k = 20): the neighbours are summed in ascending ORDINAL order -- the order the candidates were streamed in,
-  // which a seeded search (knn_point_seeded, no chain) has for free: both routes give the same bits.
+  // k == KC (the reference's k = 20): the neighbours are summed in ascending POSITION in the sorted array -- a property of the neighbour
+  // set alone, and the order a seeded search (knn_point_seeded: no chain, rows walked in memory order) admits its keys in: both routes
+  // give the same bits.
   int idx[KC];
   if constexpr (kExact) {
-    static_assert(KC == 20, "the ordinal sort is a 20-input network");
-    int o[KC];
+    static_assert(KC == 20, "the position sort is a 20-input network");
 #pragma unroll
-    for (int j = 0; j < KC; j++) o[j] = top.a[j] & kKeyOrd;
-    if (swap) o[KC - 1] = a_k & kKeyOrd;
+    for (int j = 0; j < KC; j++) idx[j] = index_of(top.a[j]);
+    if (swap) idx[KC - 1] = index_of(a_k);
 #pragma unroll
     for (int e = 0; e < kSort20N; e++) {
       const int a = kSort20[e] >> 5, b = kSort20[e] & 31;
-      const int lo_ = min(o[a], o[b]);
-      o[b] = max(o[a], o[b]);
-      o[a] = lo_;
+      const int lo_ = min(idx[a], idx[b]);
+      idx[b] = max(idx[a], idx[b]);
+      idx[a] = lo_;
     }
-#pragma unroll
-    for (int j = 0; j < KC; j++) idx[j] = tlo[(o[j] >> 7) * T] + (o[j] & kRowRel);
   } else {
     const int idx_k = swap ? index_of(a_k) : 0;
 #pragma unroll
@@ -1310,8 +1324,8 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
 //    visits the nearest rows in full and sorts its first 24 candidates whatever they are),
 //  * a candidate is admitted iff its key is below the bound -- about k of them: they are APPENDED to the lane's LDS column and that is
 //    all; no sorted chain, no insert rounds, no sorting network.  The covariance is a sum over the neighbour SET
-//    (fast_gicp_impl.hpp:256-262) and is taken in the order the candidates were streamed in, which is the order knn_point_sp sorts
-//    its winners into: the two routes give the same bits.
+//    (fast_gicp_impl.hpp:256-262) and is taken in ascending position in the sorted array -- the order the rows, walked in memory
+//    order, deliver the keys in, and the order knn_point_sp sorts its winners into: the two routes give the same bits.
 // Exactness does not rest on the seed.  The bound admits keys up to three buckets above the seeded distance; exactly k admitted keys
 // whose largest lies two buckets below the bound ARE the k nearest (everything not admitted is two buckets farther: the keys decide,
 // as in knn_point_sp); k + 1 admitted keys: the largest goes, or the exact distances decide between the two largest as there; fewer
@@ -1347,6 +1361,10 @@ __device__ __forceinline__ Cand cand_at(const float4* __restrict__ P, unsigned b
 typedef float4 Cand;
 __device__ __forceinline__ Cand cand_at(const float4* __restrict__ P, unsigned byte_off) { return point_at(P, byte_off); }
 #endif
+#ifndef RGC_SEED_XCUT
+#define RGC_SEED_XCUT 1
+#endif
+constexpr bool kSeedXCut = RGC_SEED_XCUT != 0;  // rows also cut in x (sp_pieces)
 #ifndef RGC_SEED_DEPTH
 #define RGC_SEED_DEPTH 2
 #endif
@@ -1379,12 +1397,12 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
   {
     int lo[NP], hi[NP];
     float min2[NP];
-    sp_pieces<false, R>(start, g, c, q, lo, hi, min2);
+    sp_pieces<false, R, kSeedXCut>(start, g, c, q, lo, hi, min2, tauf);
     bool heavy = false;
-    constexpr SpOrder<R, false> kOrder{};
+    // rows in MEMORY order (the bound is known: nothing is gained by visiting the nearest first): the admitted keys then come out in
+    // ascending position in the sorted array -- the order the moments are summed in on every route
 #pragma unroll
-    for (int it = 0; it < NP; it++) {
-      const int p = kOrder.p[it];
+    for (int p = 0; p < NP; p++) {
       const int len = hi[p] - lo[p];
       const int quads = (len + 3) >> 2;
       heavy |= quads > (kRowRel + 1) / 4;
@@ -2188,9 +2206,8 @@ __device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int
     }
     wave_lds_fence();
     // The neighbour SET is what the search decides; the order it was collected in depends on the cube the search ended on, hence on the
-    // hint (thr) the bulk kernel passed.  Lanes take the neighbours in ascending position in the sorted array: the sums below -- a
-    // fixed tree over the lanes -- are then a function of the set alone, whichever route deferred the query (knn_point_seeded passes
-    // other hints than knn_point_sp).
+    // hint (thr) the bulk kernel passed.  The neighbours are put into ascending position in the sorted array: the sums below are then a
+    // function of the set alone, whichever route deferred the query (knn_point_seeded passes other hints than knn_point_sp).
     {
       const int mine = lane < k ? sh->nb[lane] : INT_MAX;
       int rank = 0;
@@ -2199,24 +2216,16 @@ __device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int
       if (lane < k) sh->nb[rank] = mine;
       wave_lds_fence();
     }
-    // neighbourhood mean / covariance in fp64 (fast_gicp_impl.hpp:256-262): lane j holds neighbour j
-    double vx = 0, vy = 0, vz = 0;
-    if (lane < k) {
-      const float4 cp = P[sh->nb[lane]];
-      vx = (double)cp.x; vy = (double)cp.y; vz = (double)cp.z;
-    }
-    const double inv_k = 1.0 / (double)k;
-    const double mx = __shfl(wave_sum(vx), 0) * inv_k, my = __shfl(wave_sum(vy), 0) * inv_k, mz = __shfl(wave_sum(vz), 0) * inv_k;
-    const double dx = lane < k ? vx - mx : 0.0, dy = lane < k ? vy - my : 0.0, dz = lane < k ? vz - mz : 0.0;
-    double S[6] = {wave_sum(dx * dx), wave_sum(dx * dy), wave_sum(dx * dz), wave_sum(dy * dy), wave_sum(dy * dz), wave_sum(dz * dz)};
+    // neighbourhood mean / covariance / normal (fast_gicp_impl.hpp:256-262): lane 0 evaluates the bulk kernels' expression (sp_normal_of: one
+    // pass, neighbours in ascending position) -- a query's covariance is then the same bits whichever kernel ends up computing it, so
+    // WHICH queries a launch defers (that depends on the grid's extent, on stray candidates behind a row, on the seeds) cannot show in
+    // the results.  (~600 instructions on one lane, 3 us of a deferred query's 15; the lanes' tree sums of rounds 1-4 were another order.)
     if (lane == 0) {
+      int idx[KC];
 #pragma unroll
-      for (int a = 0; a < 6; a++) S[a] *= inv_k;
-      double nrm[3];
-      if (!min_eigenvector_direct(S, nrm)) min_eigenvector(S, nrm);  // (one lane, ~150 dependent fp64 instructions instead of the sweeps' ~1700: 5 us of a query's 16)
-      nx[i] = nrm[0];
-      ny[i] = nrm[1];
-      nz[i] = nrm[2];
+      for (int j = 0; j < KC; j++) idx[j] = j < k ? sh->nb[j] : 0;
+      if (k == KC) sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz);
+      else sp_normal_of<KC, false>(P, idx, px, py, pz, k, i, nx, ny, nz);
       if (kTarget && df.seed) df.seed[__float_as_int(pq.w)] = thr;  // the k-th squared distance itself: where this point's next search starts (knn_point_seeded)
 #ifdef RGC_LAB
       if (!kTarget && e < 8192) { g_lab_wave[2 * e] = lab_t0 | ((long long)r << 56) | ((long long)lab_rounds << 48); g_lab_wave[2 * e + 1] = wall_clock64(); }

@@ -973,8 +973,8 @@ def test_reframed_target_with_a_stale_box(reg_mod, orc, medium):
 def test_seeded_search_is_exact_whatever_the_seeds(reg_mod, orc, medium, monkeypatch):
     """Round 5: a re-framed map's exact search starts from the k-th distances the previous search of the same buffer found (knn_point_seeded).
     The result must not depend on what the seeds hold.  Two contexts are fed the same calls on the same data -- one keeps seeds, the
-    other (created under RGC_KNN_SEEDS=0) never does: every covariance, the voxel table and the deferred-query count bit for bit, and the
-    oracle's covariances to 1e-9 --
+    other (created under RGC_KNN_SEEDS=0) never does: every covariance and the voxel table bit for bit, and the oracle's covariances to
+    1e-9 --
       * two poses in a row (the seeds fit),
       * the buffer overwritten IN PLACE by a permutation of itself (same pointer, same n: every seed now belongs to some other point),
       * ... by the cloud pulled together (k-th distances shrink: the seeds admit too many keys), pushed apart (too few), and by a lattice
@@ -1010,7 +1010,9 @@ def test_seeded_search_is_exact_whatever_the_seeds(reg_mod, orc, medium, monkeyp
         assert np.array_equal(cv, cw), what
         xv, xw = v.getVoxels(), w.getVoxels()
         assert np.array_equal(xv["coords"], xw["coords"]) and np.array_equal(xv["cov"], xw["cov"]) and np.array_equal(xv["mean"], xw["mean"]), what
-        assert v.stats()["deferred_target"] == w.stats()["deferred_target"], what
+        # (HOW MANY queries the bulk launch hands to the cooperative kernel differs between the routes -- a stray candidate behind a row that
+        # one route reads and the other does not can be a third contender; on the lattice, where every stray sits at a lattice distance, by a
+        # quarter -- and does not show: every route evaluates the same expression on the same, unique, neighbour set)
         if what in ("third pose", "permuted", "pushed apart"):
             body = v.download(d_body, (n, 4))
             ocov, _ = orc.covariances(body[:, :3].copy(), k=20)
