@@ -44,9 +44,9 @@ MAP_SHIFTS = ((0.0, 0.0, 0.0), (0.37, -0.23, 0.011), (-0.29, 0.41, -0.007))  # m
 # Constants of this line that are NOT measured in this run: they are read from committed profile summaries (separate rocprofv3 --pmc passes
 # cannot run inside a timed bench) and every one is stamped with its file and the commit it was collected at (`*_source` keys): a kernel
 # change that was not followed by scripts/refresh_profiles.sh shows up as a stale stamp, not as a silently wrong number.
-PMC_FILE = "r04_pmc_knn.json"      # counters of the dominant kernel (scripts/pmc_kernel.sh)
-MIX_FILE = "r04_knn_isa_mix.json"  # its full- / half-rate instruction mix (scripts/isa_mix.py)
-FRAME_TRAFFIC_FILE = "r04_frame_traffic.json"  # measured HBM bytes of a whole dependent frame, every kernel (scripts/frame_traffic.sh)
+PMC_FILE = "r05_pmc_knn.json"      # counters of the dominant kernel (scripts/pmc_kernel.sh)
+MIX_FILE = "r05_knn_isa_mix.json"  # its full- / half-rate instruction mix (scripts/isa_mix.py)
+FRAME_TRAFFIC_FILE = "r05_frame_traffic.json"  # measured HBM bytes of a whole dependent frame, every kernel (scripts/frame_traffic.sh)
 
 
 def profile_json(name):

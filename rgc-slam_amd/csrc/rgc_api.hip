@@ -195,6 +195,7 @@ struct rgc_ctx {
   bool vg_flags_clean = false;  // d_small[24 + 6] is known to be zero (a finished rows chain leaves it so)
   // rgc_voxelgrid_begin / _end: one filter of a device cloud in flight (enqueued on its kept box, result not yet looked at)
   struct VgPending { bool active = false, ready = false; const float* d_in = nullptr; int n = 0, stride_bytes = 0; float leaf = 0.f; float* d_out = nullptr;
+                     rgck::LeafGrid g{};  // the leaf grid the pending filter was enqueued on
                      int n_out = 0; } vg_pend;
   hipEvent_t vg_done = nullptr;
   int* h_vg = nullptr;  // pinned: the pending filter's three result ints (h_small's words are all taken: the front-end stages 16 ints at +32)
@@ -355,6 +356,19 @@ void put_hint(rgc_ctx* c, const void* p, int n, const double lo[3], const double
 }
 void drop_hints(rgc_ctx* c) {
   for (auto& e : c->box_hint) e.p = nullptr;
+}
+// The leaf filter's output lies inside the leaf grid it was sorted on (a leaf's centroid lies in the leaf): a box the library knows without
+// measuring.  rgc_set_target_device on that buffer takes its grid from it -- the node's sub-map (three keyframes through the 0.3 m filter)
+// changes its bounding box with every keyframe, and a target that left the previous target's widened grid cost a second preparation and a
+// second solve (the node's 1.4 ms frames among 0.63 ms ones).
+void hint_from_leaf_grid(rgc_ctx* c, const float* out /* device, or the caller's host buffer */, int n_out, const rgck::LeafGrid& g, float leaf) {
+  if (!c->spec_on || n_out <= 0) return;
+  double lo[3], hi[3];
+  for (int a = 0; a < 3; a++) {
+    lo[a] = (double)g.minb[a] * (double)leaf - 1.0e-3;
+    hi[a] = ((double)g.minb[a] + (double)g.div[a]) * (double)leaf + 1.0e-3;
+  }
+  put_hint(c, out, n_out, lo, hi);
 }
 
 // Has the map preparation enqueued last on the main stream finished?  Asked of the event recorded behind it -- NOT of the stream:
@@ -775,6 +789,11 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
       c->src_in_pending = true;
     }
     cl.in = (const float*)cl.in_copy.p;
+    // (a box known for the caller's HOST buffer -- the leaf filter's output, rgc_voxelgrid -- goes with the cloud to its device copy)
+    if (is_target) {
+      if (const rgc_ctx::BoxHint* h = find_hint(c, xyz, n)) { const rgc_ctx::BoxHint hh = *h; put_hint(c, cl.in, n, hh.lo, hh.hi); }
+      else for (auto& e : c->box_hint) if (e.p == (const void*)cl.in) e.p = nullptr;  // (the staging buffer's last cloud's box says nothing about this one)
+    }
   }
   cl.stride_f = stride_f;
   cl.n = n;
@@ -1431,7 +1450,8 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
   d.spec_ok = false; d.spec_used = false; d.cnt_clean = 0; d.cnt_seen = nullptr; d.lazy = 0;
   d.ready = true;
   const int small[2] = {0, o.nvox};  // this context's copy of the target's guard (clear) and voxel count, which the solve reads
-  HIPCHK(c, hipMemcpy(c->d_small + 6, small, sizeof(small), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpyAsync(c->d_small + 6, small, sizeof(small), hipMemcpyHostToDevice, c->stream));  // (not the blocking form: it goes through the NULL stream)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->tgt_owner = owner;
   c->tgt_owner_gen = owner->tgt_generation;
   c->tgt_owner_uid = owner->uid;
@@ -1653,8 +1673,14 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
     }
     if (!posted) {
       HIPCHK(c, hipStreamSynchronize(c->lm_tail_stream));
-      if (c->post_on && c->d_post)  // (no copy was chained)
-        HIPCHK(c, hipMemcpy(c->h_lm, rgck::lm_image((rgck::LmState*)c->lm_state.p, c->lm_j - 1), sizeof(rgck::LmState), hipMemcpyDeviceToHost));
+      if (c->post_on && c->d_post) {  // (no copy was chained)
+        // on the solve's own stream, never with the blocking hipMemcpy: that one goes through the NULL stream, whose hardware queue the
+        // runtime creates at its first use -- 9 ms inside whichever frame first needed more launches than its batch held (the node's
+        // "one slow frame" of rounds 3 and 4: frame 14 of the c2 stand-in)
+        HIPCHK(c, hipMemcpyAsync(c->h_lm, rgck::lm_image((rgck::LmState*)c->lm_state.p, c->lm_j - 1), sizeof(rgck::LmState), hipMemcpyDeviceToHost,
+                                 c->lm_tail_stream));
+        HIPCHK(c, hipStreamSynchronize(c->lm_tail_stream));
+      }
       memcpy(&S, c->h_lm, sizeof(S));
     }
     HIPCHK(c, hipGetLastError());
@@ -2329,7 +2355,7 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
       if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, sparse ? ps : pd, (sparse ? kPadSparse : kPadDense) / 2, !sparse, d_out, &flags, &no))) return rc;
       if (flags & 1) return fail(c, RGC_ERR_NONFINITE, "cloud contains non-finite coordinates (PCL skips them; remove NaNs first)");
       if (flags & 6) box->valid = false;  // outside: measure and repeat now; near a face: measure at the next call
-      if (!(flags & 2)) { *n_out = no; done = true; }
+      if (!(flags & 2)) { *n_out = no; done = true; hint_from_leaf_grid(c, out_xyzi, no, sparse ? ps : pd, leaf); }
     }
   }
   if (!done) {
@@ -2360,11 +2386,13 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
     } else if (vg_rows_fit(g, n)) {
       int flags = 0;
       if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, g, 0, false, d_out, &flags, n_out))) return rc;
+      hint_from_leaf_grid(c, out_xyzi, *n_out, g, leaf);
     } else {
       // a dense cloud: the same chain with the leaves themselves as the sort's buckets
       if (ncell > (double)c->prm.max_cells) return fail(c, RGC_ERR_GRID_TOO_LARGE, "leaf grid %d x %d x %d exceeds max_cells", g.div[0], g.div[1], g.div[2]);
       int flags = 0;
       if ((rc = voxelgrid_rows(c, d_in, stride_f, n, inv, g, 0, true, d_out, &flags, n_out))) return rc;
+      hint_from_leaf_grid(c, out_xyzi, *n_out, g, leaf);
     }
   }
   if (!on_device) {
@@ -2403,6 +2431,7 @@ int rgc_voxelgrid_begin(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes
       int rc = voxelgrid_rows(c, d_xyzi, stride_bytes / 4, n, 1.0f / leaf, sparse ? ps : pdg, (sparse ? kPadSparse : kPadDense) / 2, !sparse, d_out, nullptr,
                               nullptr, c->h_vg);
       if (rc) return rc;
+      pd_.g = sparse ? ps : pdg;
       enqueued = true;
     }
   }
@@ -2428,7 +2457,7 @@ int rgc_voxelgrid_end(rgc_ctx* c, int* n_out) {
   rgc_ctx::VgBox* box = nullptr;
   for (auto& b : c->vg_box) if (b.leaf == pd_.leaf) box = &b;
   if (box && (flags & 6)) box->valid = false;  // outside: measure and repeat now; near a face: measure at the next call
-  if (!(flags & 2)) { *n_out = no; return RGC_OK; }
+  if (!(flags & 2)) { *n_out = no; hint_from_leaf_grid(c, pd_.d_out, no, pd_.g, pd_.leaf); return RGC_OK; }
   return rgc_voxelgrid(c, pd_.d_in, pd_.n, pd_.stride_bytes, pd_.leaf, pd_.d_out, n_out, 1);
 }
 

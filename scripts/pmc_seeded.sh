@@ -32,6 +32,12 @@ for which, cs in acc.items():
                        ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "vmem_rd_per_valu"), ("SQ_INST_CYCLES_VMEM", "SQ_BUSY_CYCLES", "vmem_inst_cycles_per_busy_cycle")):
         if a in m and b in m and m[b]: o[name] = round(m[a] / m[b], 4)
     out[which] = o
+# the seeded launch (what a re-framed persistent map runs from its second frame on: the bench's dominant kernel) at the top level, in the
+# layout bench.py / sync_docs.py read; the full search of the same map beside it under "unseeded"
+if "seeded" in out:
+    top = dict(out.pop("seeded"))
+    top["kernel"] = "k_knn_sp<20, true, true, true> (1000000 queries per launch; seeded: scripts/prof_frame_reframed.py, launches 2..5)"
+    out = {**top, **out}
 json.dump(out, open(os.path.join(root, "gpurun_out", "pmc_seeded.json"), "w"), indent=1)
 print(json.dumps(out))
 PY
