@@ -47,6 +47,11 @@ constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 #ifndef RGC_LM_SPARE_ASIDE
 #define RGC_LM_SPARE_ASIDE 1   // 0: a solve's spare step launches stay on its own stream, in front of whatever comes next there (round 3)
 #endif
+#ifndef RGC_MARK_BEHIND_COUNT
+#define RGC_MARK_BEHIND_COUNT 0  // 1: the map's stream mark is recorded BEHIND its counting pass (round 4).  An event record between two kernels of one
+                                 // stream holds the second one back ~5.8 us (the timeline of round 5); in front of the frame's first launch the record is
+                                 // processed while the GPU waits for the host anyway: two contexts steady 0.340 -> 0.334 ms per frame
+#endif
 #ifndef RGC_KNN_SEEDS
 #define RGC_KNN_SEEDS 1        // 0: the map's exact search never starts from the previous search's k-th distances (round 4)
 #endif
@@ -405,11 +410,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   // recorded on the main stream BEFORE this frame's map preparation was enqueued (waiting for the map's kNN launch would serialise
   // the two) -- i.e. at rgc_set_target*, or here when no map preparation is pending.  See rgc_set_source_device in rgc_hip.h.
   if (!is_target && c->main_has_target_prep && map_prep_finished(c)) c->main_has_target_prep = false;  // it has drained
-  // (the map's own mark goes BEHIND its counting pass: the record is a call of its own in front of the dependent sequence's first launch, and
-  // a scan that waits for one 17 us kernel more has lost nothing -- its preparation is enqueued after the map's whole chain anyway)
+  // (RGC_MARK_BEHIND_COUNT=1, round 4: the map's own mark BEHIND its counting pass -- the record is a call of its own in front of the dependent
+  // sequence's first launch, and a scan that waits for one 17 us kernel more has lost nothing; round 5 measured the record's cost on the
+  // GPU between the two kernels and put it back in front)
   bool mark_behind_count = false;
   if (is_target || !c->main_has_target_prep || c->main_late_producer) {
-    if (is_target) mark_behind_count = true;
+    if (is_target && RGC_MARK_BEHIND_COUNT) mark_behind_count = true;
     else HIPCHK(c, hipEventRecord(c->main_mark, c->stream));
     c->mark_valid = true;
     c->main_late_producer = false;

@@ -1,10 +1,10 @@
 """Regenerate the number-bearing blocks of DESIGN.md (§8), BASELINE.md (§4), README.md and profiles/README.md from the files under
-profiles/r04_* (one refresh = one run of scripts/refresh_profiles.sh + scripts/collect_profiles.sh), so that the prose cannot drift from
-the measurements.  A block lives between two HTML comments, `<!-- r04-numbers:begin ... -->` and `<!-- r04-numbers:end -->`; everything
+profiles/r05_* (one refresh = one run of scripts/refresh_profiles.sh + scripts/collect_profiles.sh), so that the prose cannot drift from
+the measurements.  A block lives between two HTML comments, `<!-- r05-numbers:begin ... -->` and `<!-- r05-numbers:end -->`; everything
 else in those documents is written by hand and quotes the same files."""
 import csv, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r04"
+TAG = "r05"
 P = lambda *a: os.path.join(ROOT, *a)
 
 
@@ -44,13 +44,16 @@ LZ2 = (LZ.get("two_contexts") or {}).get("scans_per_s", float("nan"))
 R, IR, O, RP, H, pp, cb, k = (d["roofline"], d["issue_roofline"], d["one_frame_at_a_time"], d["replay_of_preframed_maps"], d["scan_h2d_and_output"],
                               d["pose_parity_vs_cpu"], d["cpu_baseline"], d["kernel_ms_per_step"])
 c = {x["config"][:2]: x for x in d.get("configs", [])}
-knn_prof_us = kernel_avg_us("kernel_stats.csv", "k_knn_sp<20, true, true>")
+knn_prof_us = kernel_avg_us("kernel_stats.csv", "k_knn_sp<20, true, true, true>")
 valu = pmc["valu_wave_instructions_per_query"]
 traffic_mb = pmc["hbm_bytes_per_launch"] / 1e6
 vmem_m = pmc["per_launch"].get("SQ_INSTS_VMEM_RD", 0) / 1e6
 alone_us = R["launch_alone_ms"] * 1e3
 issue_alone = valu * 1e6 / (R["launch_alone_ms"] * 1e-3) / 1e9
 w = lab["waves"]
+SD = lab.get("seeded") or {}
+U = pmc.get("unseeded") or {}
+ws = float(SD.get("waves", 1))
 
 
 def cfg_line(key, label):
@@ -91,24 +94,25 @@ if LZ:
                 f"scan falls at the guess -- **{LZ['two_contexts']['scans_per_s']:.0f} scans/s** on two contexts ({LZ['two_contexts']['ms_per_step']} ms), "
                 f"{LZ['one_frame_at_a_time']['scans_per_s']:.0f} one frame at a time, the full rebuild's poses bit for bit, {LZ.get('solves_repeated_on_the_completed_map')} solve(s) repeated on the completed map.\n")
 
-numbers = f'''Round-4 numbers (MI355X, `profiles/{TAG}_*`, all from one `scripts/refresh_profiles.sh` run): **{d["value"]:.0f} scans/s ({d["ms_per_step"]} ms/step)** for the
-dependent c-main sequence on two contexts (round 3: 2301 in its own refresh run, 2399 in the driver's), {O["scans_per_s"]:.0f} ({O["ms_per_step"]} ms) one frame at a time, {H["scans_per_s"]:.0f} with the scan's H2D and the output
-cloud inside the step; the replay of pre-framed maps (round 2's headline, 2781 then; 3049 in round 3) {RP["scans_per_s"]:.0f}; pose parity vs CPU over {pp["frames"]}
+numbers = f'''Round-5 numbers (MI355X, `profiles/{TAG}_*`, all from one `scripts/refresh_profiles.sh` run): **{d["value"]:.0f} scans/s ({d["ms_per_step"]} ms/step)** for the
+dependent c-main sequence on two contexts (round 4: 2618 in its own refresh run, 2668 in the driver's), {O["scans_per_s"]:.0f} ({O["ms_per_step"]} ms) one frame at a time, {H["scans_per_s"]:.0f} with the scan's H2D and the output
+cloud inside the step; the replay of pre-framed maps (round 2's headline: targets the library has not seen, hence unseeded) {RP["scans_per_s"]:.0f}; pose parity vs CPU over {pp["frames"]}
 timed frames ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad; CPU port {cb["value"]:.2f} scans/s at the reference's {cb["cores"]} OpenMP threads (a reported
-baseline, not a target). Per step, one frame at a time (HIP events, separate pass with every stage bracketed): grid build
+baseline, not a target).  Two independent sequences on ONE GPU (`two_sequences_per_gpu`): {d.get("two_sequences_per_gpu", {}).get("aggregate_scans_per_s", float("nan")):.0f} scans/s together
+({", ".join("%.0f" % x for x in d.get("two_sequences_per_gpu", {}).get("solo_scans_per_s", []))} alone), each sequence's poses those of its solo run.  Per step, one frame at a time (HIP events, separate pass with every stage bracketed): grid build
 {k["grid_build"]:.3f} ms (both clouds), kNN map {k["knn_cov_target"]:.3f} ms, voxel map + the map's deferred queries {k["voxel_build"]:.3f}, kNN scan {k["knn_cov_source"]:.3f} + {k["knn_coop_source"]:.3f}
 (second stream, overlapped), LM {k["linearize"]:.3f} ({d["mean_outer_iterations"]} outer iterations), fitness {k["fitness"]:.3f}.
-`profiles/{TAG}_kernel_stats.csv` (rocprofv3 `--kernel-trace --stats` of the same command): `k_knn_sp<20, true, true>` {knn_prof_us:.0f} µs average under
+`profiles/{TAG}_kernel_stats.csv` (rocprofv3 `--kernel-trace --stats` of the same command): `k_knn_sp<20, true, true, true>` {knn_prof_us:.0f} µs average under
 the profiler, {u["roofline"]["avg_launch_ms"] * 1e3:.0f} µs from the library's events in that run, {R["avg_launch_ms"] * 1e3:.0f} µs unprofiled; alone the launch takes **{alone_us:.0f} µs**
-= {100 * R["frac_launch_alone"]:.2f} % of 8 TB/s on its 36 algorithmic MB ({100 * R["frac"]:.2f} % in the timed region; round 3: 141 µs alone, 2.83 % in the timed region; round 2: 156 µs).
+= {100 * R["frac_launch_alone"]:.2f} % of 8 TB/s on its 36 algorithmic MB ({100 * R["frac"]:.2f} % in the timed region; unseeded, a map the library has not seen: {R.get("launch_alone_unseeded_ms", float("nan")) * 1e3:.0f} µs; round 4: 149 µs alone, 2.81 % in the timed region).
 {lazy_txt}{traffic_txt}
-The dominant kernel by the counters (`profiles/{TAG}_pmc_knn.json`, per 1 M-query launch): **{valu:.1f} VALU wave-instructions per query** (76.2 in round 3, 87.9 in
-round 2, 173 in round 1), {vmem_m:.2f} M vector loads, HBM traffic {traffic_mb:.1f} MB = {traffic_mb / 36:.1f} × algorithmic. Per wave of 64 queries
-(`profiles/{TAG}_lab_iters.json`): {lab["quads_in_scan_loop"] / w:.1f} trips of the scan loop, **{lab["chain_inserts"] / w:.1f} chain insert rounds** (65.1 before the
-buffers were drained only down to 8 keys), {lab["newton_steps"] / w:.1f} Newton steps, {lab["jacobi_fallbacks"]} Jacobi fallbacks and {lab["exact_tie_breaks"]} exact tie-breaks per launch.
+The dominant kernel by the counters (`profiles/{TAG}_pmc_knn.json`, per 1 M-query launch, seeded): **{valu:.1f} VALU wave-instructions per query** ({U.get("valu_wave_instructions_per_query", float("nan")):.1f} for the
+full search of the same map; 75.9 in round 4, 87.9 in round 2, 173 in round 1), {vmem_m:.2f} M vector loads, HBM traffic {traffic_mb:.1f} MB = {traffic_mb / 36:.1f} × algorithmic. Per wave of 64 queries
+(`profiles/{TAG}_lab_iters.json`): {SD.get("quads_in_seeded_scan_loop", 0) / ws:.1f} trips of the seeded candidate loop (the full search: {lab["quads_in_scan_loop"] / w:.1f} trips and
+{lab["chain_inserts"] / w:.1f} chain insert rounds), no insert rounds, {SD.get("waves_that_ran_the_full_search_too", 0)} of {int(ws)} waves ran the full search behind the seeded one, {SD.get("newton_steps", 0) / ws:.1f} Newton steps.
 Executed mix (`profiles/{TAG}_knn_isa_mix.json`): {100 * mix["half_rate_fraction"]:.0f} % of the instructions in the half-rate class ⇒ mix-weighted peak
 {mix["peak_mix_weighted"]:.0f} G wave-instr/s; the launch alone sustains {valu:.1f} M / {R["launch_alone_ms"]:.4f} ms = {issue_alone:.0f} G/s = **{100 * issue_alone / mix["peak_mix_weighted"]:.0f} % of it**
-({100 * IR["frac_of_mix_weighted_peak"]:.0f} % in the timed region; ISA count ÷ PMC count = {mix.get("executed_over_pmc", float("nan")):.3f}).
+({100 * IR["frac_of_mix_weighted_peak"]:.0f} % in the timed region; ISA count ÷ PMC count = {mix.get("executed_over_pmc", float("nan")):.3f}): the launch is no longer bound by instruction issue but by its waves' lifetime and ramp-down (§5.1).
 
 All configurations of BASELINE.json (`profiles/{TAG}_bench.json` → `configs`; target rebuilt every frame, inputs resident, first frame
 checked against the CPU oracle):
@@ -133,9 +137,9 @@ if ld:
 if node:
     numbers += (f"\nThe C++ node (`profiles/{TAG}_cpp_node_bench.json`, 24 sweeps × 28.8 k points, message bytes in → pose out; mean / median of the timed sweeps): "
                 f"reference semantics {node['cpp_reference_semantics_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_median_ms', float('nan')):.2f} ms host-staged and "
-                f"**{node['cpp_reference_semantics_device_chain_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_device_chain_median_ms', float('nan')):.2f} ms on the device** (round 2: 1.08); "
+                f"**{node['cpp_reference_semantics_device_chain_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_device_chain_median_ms', float('nan')):.2f} ms on the device** (round 4: 1.09 / 0.62); "
                 f"resident map {node['cpp_resident_map_ms_per_frame']:.2f} / {node.get('cpp_resident_map_median_ms', float('nan')):.2f} host-staged "
-                f"(slowest timed frame {node.get('cpp_resident_map_slowest_timed_frame_ms', float('nan')):.1f} ms; round 3: 8.8 ms, one copy of a filter's output into pageable host memory -- the node's staging vectors are page-locked since round 4, `rgc::PinnedAllocator`), "
+                f"(slowest timed frames {node.get('cpp_reference_semantics_slowest_timed_frame_ms', float('nan')):.2f} / {node.get('cpp_reference_semantics_device_chain_slowest_timed_frame_ms', float('nan')):.2f} / {node.get('cpp_resident_map_slowest_timed_frame_ms', float('nan')):.2f} / {node.get('cpp_resident_map_device_chain_slowest_timed_frame_ms', float('nan')):.2f} ms in the four modes; round 4: 9.6 / 9.0 / 8.0 -- a blocking hipMemcpy through the NULL stream, whose queue is created at its first use, and speculative-grid misses of the sub-map), "
                 f"{node['cpp_resident_map_device_chain_ms_per_frame']:.2f} / {node.get('cpp_resident_map_device_chain_median_ms', float('nan')):.2f} with `device_chain`; "
                 f"`ReplayPipeline` {node['cpp_replay_pipeline_ms_per_frame']:.2f} ms per sweep.")
     if pipe:
@@ -157,7 +161,7 @@ open(P("DESIGN.md"), "w").write(put(s, numbers + "\n"))
 
 # ---------------- BASELINE.md §4
 B = d["algorithmic_bytes_per_scan"] / 1e6
-base = f'''Round 4, one MI355X, `python bench.py` (`profiles/{TAG}_bench.json`; everything under `profiles/{TAG}_*` is from the same run of
+base = f'''Round 5, one MI355X, `python bench.py` (`profiles/{TAG}_bench.json`; everything under `profiles/{TAG}_*` is from the same run of
 `scripts/refresh_profiles.sh`; this block is generated from those files by `scripts/sync_docs.py`). HIP = this repository's gfx950 path,
 target rebuilt every frame, inputs resident in HBM. c-main, c3 and c5 run as **dependent sequences** — frame i's target is the map
 re-expressed on the device in the body frame of the pose frame i − 1 produced (`RGC_odometer.cpp:1248-1256`), so only the scan's
@@ -165,8 +169,9 @@ preparation can overlap the previous solve; c1, the reference's CPU-runnable cas
 configuration: two contexts taking turns (`value` of the bench line) / one frame at a time through the blocking `align()`; both give
 bit-identical poses (checked in every run). CPU = the C/OpenMP restatement (`oracle/`, the parity checker) on the GPU box's host at the
 reference's {cb["cores"]} OpenMP threads. The reference itself cannot be built (section 2), so there is no reference row. The lazy-target
-column is `rgc_set_target_lazy(2)` -- covariances and voxels only where the solve can look, same poses bit for bit (DESIGN.md §5); the
-headline and every other column rebuild the whole target every frame like the reference.
+column is `rgc_set_target_lazy(2)` -- covariances and voxels only where the solve can look, same poses bit for bit (DESIGN.md §5.2); the
+headline and every other column rebuild the whole target every frame like the reference.  Since round 5 the exact 20-NN of a re-framed
+map starts from the k-th distances its previous search found (DESIGN.md §5.1; exact whatever the seeds hold, bit-identical results).
 
 {table}| c2 sequence stand-in (24 sweeps × 28.8 k pts, front-end + frame body + ground factor, 3 keyframes), C++ node | reference semantics on the device {1e3 / node["cpp_reference_semantics_device_chain_ms_per_frame"]:.0f} sweeps/s, resident map + device chain {1e3 / node["cpp_resident_map_device_chain_ms_per_frame"]:.0f}, replay pipeline {1e3 / node["cpp_replay_pipeline_ms_per_frame"]:.0f} (`profiles/{TAG}_cpp_node_bench.json`) | {node["cpp_reference_semantics_device_chain_ms_per_frame"]:.2f} / {node["cpp_resident_map_device_chain_ms_per_frame"]:.2f} / {node["cpp_replay_pipeline_ms_per_frame"]:.2f} | | | ≤ 1e-4 vs the oracle frame body and vs the literal `ICP_thread` restatement (`tests/test_gpu_cpp_node.py`) |
 | c4 8 × (30 k vs 1 M) | measured by the driver (`bench.py --gpus 8`, one sequence and two contexts per rank, no collective) | | | | |
@@ -175,17 +180,16 @@ headline and every other column rebuild the whole target every frame like the re
 Algorithmic bytes of a c-main scan (the formula above): B = {B:.1f} MB ⇒ {d["hbm_gbps_algorithmic"]:.0f} GB/s = {100 * d["hbm_frac_whole_frame"]:.1f} % of 8 TB/s for the whole frame.
 {traffic_txt}
 The dominant kernel (the map's bulk kNN + covariance launch, 36 B per point): {R["avg_launch_ms"] * 1e3:.0f} µs per launch in the timed region =
-{100 * R["frac"]:.2f} % of 8 TB/s; {alone_us:.0f} µs alone = {100 * R["frac_launch_alone"]:.2f} % (round 3: 141 µs; round 2: 156 µs, 2.85 %; round 1: 353 µs, 1.27 %); measured HBM traffic
+{100 * R["frac"]:.2f} % of 8 TB/s; {alone_us:.0f} µs alone = {100 * R["frac_launch_alone"]:.2f} % (round 4: 149 µs, 3.0 %; round 3: 141 µs; round 2: 156 µs; round 1: 353 µs, 1.27 %); measured HBM traffic
 {traffic_mb:.1f} MB per launch = {traffic_mb / 36:.1f} × algorithmic (`profiles/{TAG}_pmc_knn.json`).
 
 The north star's "≥ 50 % of HBM roofline" is the yardstick of a streaming kernel. This path's dominant kernel is an exact 20-NN: per
-query it looks at ≈ 105 candidates (3×3×3 cells of a 1 m grid) and keeps the 22 best, which costs {valu:.0f} VALU wave-instructions per query,
-{100 * mix["half_rate_fraction"]:.0f} % of them compare / select / `med3` / fp64, which gfx950 issues at HALF rate (measured: 595 G wave-instr/s against 1060 for
-add / mul / fma, `profiles/r02_valu_issue.jsonl`). Against the peak weighted by that executed mix ({mix["peak_mix_weighted"]:.0f} G/s,
-`profiles/{TAG}_knn_isa_mix.json`) the launch alone runs at {100 * issue_alone / mix["peak_mix_weighted"]:.0f} %, with the vector-memory pipe about half busy beside it. What moves the number is
-fewer instructions AND fewer candidate loads per query (173 → 87.9 → 76.2 → {valu:.0f} instructions over four rounds), not bytes. Round 4
-left the kernel itself alone -- a simulation of lane-homogeneous waves put their gain at 2-6 % (`profiles/r04_knn_grouping_sim.json`) -- and
-went for what surrounds it and for work that need not be done: the lazy target computes {100 * 0.08:.0f} % of these queries.
+query it looks at ≈ 85 candidates (3×3×3 cells of a 1 m grid, rows cut to what the seeded bound leaves) to find 20, which costs {valu:.0f} VALU
+wave-instructions per query ({U.get("valu_wave_instructions_per_query", float("nan")):.0f} without seeds), {100 * mix["half_rate_fraction"]:.0f} % of them compare / select / fp64, which gfx950 issues at HALF rate
+(measured: 595 G wave-instr/s against 1060 for add / mul / fma, `profiles/r02_valu_issue.jsonl`). Against the peak weighted by that executed mix
+({mix["peak_mix_weighted"]:.0f} G/s, `profiles/{TAG}_knn_isa_mix.json`) the launch alone runs at {100 * issue_alone / mix["peak_mix_weighted"]:.0f} %: since round 5 the bound is no longer instruction issue
+but the lifetime of a wave (≈ 26 µs of a ≈ {alone_us:.0f} µs launch: the last third of the launch is a ramp-down at falling occupancy, `scripts/lab_blocks.py`).
+Instructions per query over five rounds: 173 → 87.9 → 76.2 → 75.9 → {valu:.0f}.
 '''
 s = open(P("BASELINE.md")).read()
 open(P("BASELINE.md"), "w").write(put(s, base + "\n"))
@@ -194,11 +198,11 @@ open(P("BASELINE.md"), "w").write(put(s, base + "\n"))
 readme = f'''* Measured on MI355X (`profiles/{TAG}_*`, one run): **{d["value"]:.0f} registered scans/s** on the headline workload — a DEPENDENT sequence: every
   30 k-point scan is registered to the 1 M-point map re-expressed in the previous pose's body frame on the device and rebuilt in full
   (`RGC_odometer.cpp:1248-1256`) — on two contexts, {O["scans_per_s"]:.0f} one frame at a time; **{LZ2:.0f}** with the lazy target (covariances and
-  voxels only where the solve can look, the same poses bit for bit); {RP["scans_per_s"]:.0f} for round 2's headline, the replay of pre-framed
-  maps (2781 then); pose parity against the CPU oracle ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad over {pp["frames"]} timed frames; the CPU port runs
+  voxels only where the solve can look, the same poses bit for bit); {RP["scans_per_s"]:.0f} for the replay of pre-framed
+  maps (round 2's headline); pose parity against the CPU oracle ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad over {pp["frames"]} timed frames; the CPU port runs
   {cb["value"]:.2f} scans/s at the reference's {cb["cores"]} OpenMP threads. c1 {c["c1"]["scans_per_s"]:.0f}, c3 {c["c3"]["scans_per_s"]:.0f}, c5 {c["c5"]["scans_per_s"]:.0f} scans/s{f"; {roll['A']['resident_two_contexts_scans_per_s']:.0f} scans/s against a map resident on the device" if roll else ""}.
-  The dominant kernel (exact 20-NN + covariance of the 1 M-point map) takes {alone_us:.0f} µs alone, {valu:.0f} VALU wave-instructions per query, at
-  {100 * issue_alone / mix["peak_mix_weighted"]:.0f} % of the VALU issue peak weighted by its executed full- / half-rate mix (DESIGN.md §8).
+  The dominant kernel (exact 20-NN + covariance of the 1 M-point map, seeded with the previous search's k-th distances: DESIGN.md §5.1) takes
+  {alone_us:.0f} µs alone ({R.get("launch_alone_unseeded_ms", float("nan")) * 1e3:.0f} µs unseeded), {valu:.0f} VALU wave-instructions per query; two sequences on one GPU reach {d.get("two_sequences_per_gpu", {}).get("aggregate_scans_per_s", float("nan")):.0f} scans/s together.
 '''
 s = open(P("README.md")).read()
 open(P("README.md"), "w").write(put(s, readme))
@@ -207,7 +211,7 @@ open(P("README.md"), "w").write(put(s, readme))
 s = open(P("profiles", "README.md")).read()
 prof = f'''(figures of this run: headline {d["value"]:.0f} scans/s on two contexts, {O["scans_per_s"]:.0f} one frame at a time, replay {RP["scans_per_s"]:.0f}; the map's bulk kNN launch
 {alone_us:.0f} µs alone, {R["avg_launch_ms"] * 1e3:.0f} µs in the timed region, {knn_prof_us:.0f} µs average under rocprofv3; {valu:.1f} VALU wave-instructions per map query,
-{traffic_mb:.1f} MB per 1 M-query launch, {lab["chain_inserts"] / w:.1f} insert rounds per wave, mix-weighted issue peak {mix["peak_mix_weighted"]:.0f} G wave-instr/s)
+{traffic_mb:.1f} MB per 1 M-query launch, {SD.get("quads_in_seeded_scan_loop", 0) / ws:.1f} trips per wave, mix-weighted issue peak {mix["peak_mix_weighted"]:.0f} G wave-instr/s)
 '''
 open(P("profiles", "README.md"), "w").write(put(s, prof))
 print("synced:", d["value"], O["scans_per_s"], RP["scans_per_s"], [x["scans_per_s"] for x in d.get("configs", [])])
