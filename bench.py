@@ -252,6 +252,8 @@ def two_sequences_per_gpu(registration, synth, np, device_index, seq_a, pv_a, n_
     # together: both threads leave a barrier at once and run their K2 frames REPS times; the job is done when the slower one is
     gate = threading.Barrier(3)
     same = {"a": True, "b": True}
+    switch0 = sys.getswitchinterval()
+    sys.setswitchinterval(2.0e-5)   # two Python threads drive the two sequences: the interpreter lock changes hands at this interval (default 5 ms) when both want it
     def worker(sq, name, ref):
         gate.wait()
         for r in range(REPS):
@@ -267,6 +269,7 @@ def two_sequences_per_gpu(registration, synth, np, device_index, seq_a, pv_a, n_
     for t_ in th:
         t_.join()
     wall = time.perf_counter() - tr
+    sys.setswitchinterval(switch0)
     seq_b.close()
     for p in [d_map_b] + d_scans_b:
         vb.device_free(p)
