@@ -975,7 +975,12 @@ __device__ __forceinline__ void sp_pieces(const int* __restrict__ start, const G
     int a, b;
     if constexpr (kXCut) {
       const int own = cell_index(g, c[0], yy, zz);
-      const int a0 = start[own - (c[0] > 0 ? 1 : 0)], m1 = start[own], m2 = start[own + 1], b0 = start[own + 1 + (c[0] < g.dim[0] - 1 ? 1 : 0)];
+      // start[own - 1 .. own + 2] in ONE 16-byte load (the vector-memory pipe works per lane and instruction, not per byte: four dword
+      // gathers cost four times this); at the grid's x borders the window is shifted and the missing neighbour's range is empty
+      const bool has_l = c[0] > 0, has_r = c[0] < g.dim[0] - 1;
+      typedef int i32x4 __attribute__((ext_vector_type(4), aligned(4)));
+      const i32x4 s4 = *reinterpret_cast<const i32x4*>(start + (own - (has_l ? 1 : 0)));   // (start[] has ncell + 1 entries and slack behind them)
+      const int m1 = has_l ? s4.y : s4.x, m2 = has_l ? s4.z : s4.y, a0 = has_l ? s4.x : m1, b0 = has_r ? (has_l ? s4.w : s4.z) : m2;
       const double g2 = axis_gap(1, dy) * axis_gap(1, dy) + axis_gap(2, dz) * axis_gap(2, dz);
       const bool left = (float)((g2 + wlo[0] * wlo[0]) * (1.0 - 1.0e-6)) < tauf, right = (float)((g2 + whi[0] * whi[0]) * (1.0 - 1.0e-6)) < tauf;
       a = left ? a0 : m1;
