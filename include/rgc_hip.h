@@ -354,6 +354,8 @@ typedef struct rgc_stats {
   int deferred_target, deferred_source; /* queries handled by the cooperative kNN kernel */
   double source_crowding;               /* mean number of points in a scan point's own kNN-grid cell (sum count^2 / n) */
   int lazy_misses;                      /* lazy target: solves repeated on the completed map since the context was created */
+  int searched_target;                  /* queries of the target's last preparation whose k neighbours were SEARCHED: n_target, or -- a map handed
+                                         * over again by rgc_set_target_reframed, unchanged -- the few whose neighbour list carries no certificate */
 } rgc_stats;
 RGC_API int rgc_get_stats(rgc_ctx* ctx, rgc_stats* out);
 

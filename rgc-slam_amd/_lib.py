@@ -30,7 +30,7 @@ class Stats(C.Structure):
                 ("outer_iterations", C.c_int), ("n_linearize", C.c_int), ("n_error", C.c_int),
                 ("target_cells", C.c_longlong), ("source_cells", C.c_longlong),
                 ("deferred_target", C.c_int), ("deferred_source", C.c_int), ("source_crowding", C.c_double),
-                ("lazy_misses", C.c_int)]
+                ("lazy_misses", C.c_int), ("searched_target", C.c_int)]
 
 
 class FuseIn(C.Structure):

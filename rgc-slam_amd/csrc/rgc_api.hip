@@ -55,6 +55,9 @@ constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 #ifndef RGC_KNN_SEEDS
 #define RGC_KNN_SEEDS 1        // 0: the map's exact search never starts from the previous search's k-th distances (round 4)
 #endif
+#ifndef RGC_KNN_CACHE
+#define RGC_KNN_CACHE 1        // 0: no neighbour lists (rgck::KnnCache): every frame searches the whole map, seeded
+#endif
 #ifndef RGC_MAP_WIDE_R
 #define RGC_MAP_WIDE_R 2       // block radius of the bulk kNN launch for a sparse map (0 = off, 2)
 #endif
@@ -110,6 +113,15 @@ struct Cloud {
   bool seed_on = false;    // this cloud's searches read and write them
   bool seed_warm = false;  // ... and some search has written them
   float seed_slack = 0.f;
+  // the neighbour-list cache on top of the seeds (rgck::KnnCache): the same key, the same life
+  DevBuf nbr, pos_of, map_copy, todo, cache_small;  // cache_small: kTodoLists list lengths, then the epoch word
+  bool cache_on = false;    // this preparation compares the map with map_copy and its searches read / write the lists
+  bool cache_live = false;  // the LAST preparation's searches ran with the lists attached (otherwise they are stale: the next frame starts over)
+  int cache_frame = 0;
+  int cache_e2 = 0;         // binary exponent of the largest coordinate the certificates were issued for
+  int cache_e2_low = 0;     // frames in a row whose coordinates stayed below it
+  int todo_cap = 0;
+  bool cache_searched_lists = false;  // the last preparation's search was the seeded launch that reads the lists (rgc_stats::searched_target)
 };
 
 struct ProfRegion {
@@ -182,6 +194,7 @@ struct rgc_ctx {
   bool solve_behind_map = RGC_SOLVE_BEHIND_MAP != 0;  // (build flag) 0: the solve always on the scan's (high-priority) stream, as in round 2
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
+  bool cache_on = RGC_KNN_CACHE != 0;  // (build flag; RGC_KNN_CACHE=0 in the environment) the neighbour lists of an unchanged map on top of the seeds
   bool seeds_on = RGC_KNN_SEEDS != 0;  // (build flag; RGC_KNN_SEEDS=0 in the environment) 0: every search of a re-framed map starts without a bound, as before round 5
   double src_res = RGC_SRC_RES;  // (build flag) fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
   int map_wide_r = RGC_MAP_WIDE_R;          // (build flag; 0 = off, 2) block radius of the bulk kNN launch for a sparse map
@@ -394,6 +407,8 @@ int map_wide_r_of(const rgc_ctx* c, const Cloud& cl) {
 // C1-C3: grid + exact-kNN covariances (+ voxel map for the target), all enqueued on the stream.
 // The first cloud of a context costs one host<->device round trip -- the 6-int bounding box the dense grid is sized from; later
 // clouds re-use the previous (widened) grid speculatively and need none (see `spec` below).
+rgck::KnnSeeds cloud_seeds(const Cloud& cl, bool is_target);
+
 int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false) {
   const int n = cl.n;
   cl.covs_user = false;
@@ -483,8 +498,40 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       int e2;
       (void)std::frexp(1.5 * maxabs, &e2);
       cl.seed_slack = (float)(4.0 * std::ldexp(1.0, e2 - 24));
+      // The neighbour lists on top (rgck::KnnCache): the counting pass that produces the map compares it with the library's copy on the
+      // way, so only that route has them; a lazy target searches a part of the map per frame and keeps none.
+      const double qn = cl.rf.q.x * cl.rf.q.x + cl.rf.q.y * cl.rf.q.y + cl.rf.q.z * cl.rf.q.z + cl.rf.q.w * cl.rf.q.w;
+      cl.cache_on = false;
+      if (c->cache_on && fuse_reframe && c->lazy_margin <= 0 && std::fabs(qn - 1.0) < 1.0e-6) {
+        bool fresh = !cl.seed_warm || !cl.cache_live || !cl.nbr.p;
+        const size_t cap = (size_t)std::max(256, n / (4 * rgck::kTodoLists) + 1);
+        if ((rc = ensure(c, cl.nbr, sizeof(int) * (size_t)n * 20))) return rc;
+        if ((rc = ensure(c, cl.pos_of, sizeof(int) * (size_t)n))) return rc;
+        if ((rc = ensure(c, cl.map_copy, sizeof(float4) * (size_t)n))) return rc;
+        if ((rc = ensure(c, cl.todo, sizeof(int) * cap * rgck::kTodoLists))) return rc;
+        if ((rc = ensure(c, cl.cache_small, sizeof(int) * (rgck::kTodoLists + 16)))) return rc;
+        cl.todo_cap = (int)cap;
+        int ce2;  // (a cell of margin around the box, as the grid has)
+        (void)std::frexp(1.5 * maxabs + 2.0 * res, &ce2);
+        // larger coordinates than the certificates allow for: issue them again.  Smaller ones for sixteen frames in a row: new certificates
+        // need the smaller gap only (the old ones, issued for a wider one, stand).
+        if (fresh || ce2 > cl.cache_e2) { cl.cache_e2 = ce2; fresh = true; }
+        cl.cache_e2_low = ce2 < cl.cache_e2 ? cl.cache_e2_low + 1 : 0;
+        if (cl.cache_e2_low >= 16) { cl.cache_e2--; cl.cache_e2_low = 0; }
+        cl.cache_frame = cl.cache_frame >= (1 << 30) ? 1 : cl.cache_frame + 1;
+        cl.rf.copy = (float4*)cl.map_copy.p;
+        cl.rf.epoch = (int*)cl.cache_small.p + rgck::kTodoLists;
+        cl.rf.frame = cl.cache_frame;
+        cl.rf.force = fresh ? 1 : 0;
+        cl.cache_on = true;
+      }
     } else if (is_target && &cl == &c->tgt) {
       cl.seed_key = nullptr;
+      cl.cache_on = false;
+    }
+    if (is_target && &cl == &c->tgt) {
+      cl.cache_live = false;  // (set again by the search that attaches the lists, cloud_covariances)
+      if (!cl.cache_on) { cl.rf.copy = nullptr; cl.rf.epoch = nullptr; }
     }
     cl.reframe_pending = false;
     if (hint) {
@@ -585,9 +632,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     if (mark_behind_count) HIPCHK(c, hipEventRecord(c->main_mark, c->stream));
     rgck::scan_cells(s, (int*)cl.cnt.p, (int*)cl.start.p, (int)ntot, cl.block_sums.p, is_target ? (int*)cl.cell_voxel.p : nullptr,
                      is_target ? c->d_small + 7 : nullptr, hi, is_target ? nullptr : (float*)(c->d_small + 23));
-    rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (unsigned long long*)cl.order_tmp.p, hi);
+    const bool with_cache = is_target && &cl == &c->tgt && cl.cache_on;
+    const rgck::KnnSeeds sd = cloud_seeds(cl, is_target);
+    rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (unsigned long long*)cl.order_tmp.p, hi,
+                with_cache ? (int*)cl.cache_small.p : nullptr);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const unsigned long long*)cl.order_tmp.p,
-                      (float4*)cl.P.p, (int*)cl.segs.p, hi);
+                      (float4*)cl.P.p, (int*)cl.segs.p, hi, with_cache ? &sd.cache : nullptr, (with_cache && cl.seed_warm) ? sd.seed : nullptr);
   }
   cl.lazy = 0;
   if (is_target && &cl == &c->tgt && c->lazy_margin > 0 && !c->lm_host && map_wide_r_of(c, cl) == 0) {
@@ -621,7 +671,22 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
 
 rgck::KnnSeeds cloud_seeds(const Cloud& cl, bool is_target) {
   rgck::KnnSeeds sd;
-  if (is_target && cl.seed_on) { sd.seed = (float*)cl.seed.p; sd.slack = cl.seed_slack; sd.warm = cl.seed_warm; }
+  if (is_target && cl.seed_on) {
+    sd.seed = (float*)cl.seed.p; sd.slack = cl.seed_slack; sd.warm = cl.seed_warm;
+    if (cl.cache_on) {
+      rgck::KnnCache& kc = sd.cache;
+      kc.nbr = (int*)cl.nbr.p;
+      kc.pos_of = (int*)cl.pos_of.p;
+      kc.todo = (int*)cl.todo.p;
+      kc.todo_cnt = (int*)cl.cache_small.p;
+      kc.epoch_w = (int*)cl.cache_small.p + rgck::kTodoLists;
+      kc.epoch = kc.epoch_w;
+      kc.frame = cl.cache_frame;
+      kc.todo_cap = cl.todo_cap;
+      // what the coordinates' fp32 rounding in two frames can move a distance by, twice: 4 sqrt(3) ulp of the largest coordinate, and a tenth
+      kc.cert_slack = (float)(4.0 * 1.7320508 * 1.1 * std::ldexp(1.0, cl.cache_e2 - 24));
+    }
+  }
   return sd;
 }
 
@@ -658,7 +723,11 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
       rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
                      (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, nullptr, nullptr, nullptr, nullptr, 0, seeds);
     }
-    if (seeds.seed && wide_r == 0) cl.seed_warm = true;
+    if (is_target) cl.cache_searched_lists = seeds.cache.nbr && seeds.warm && wide_r == 0;
+    if (seeds.seed && wide_r == 0) {
+      cl.seed_warm = true;
+      if (seeds.cache.nbr) cl.cache_live = true;
+    }
   }
   // The map's deferred queries (~100 of a million, one wave each: 20 us of latency) are resolved in the SAME launch as the voxel map's
   // build (k_voxel_build_coop); the few voxels that hold one are recomputed behind it (k_voxel_patch).  The scan has no voxel map:
@@ -1346,6 +1415,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   ok = ok && hipHostMalloc((void**)&c->h_vg, 4 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_KNN_SEEDS")) c->seeds_on = atoi(e) != 0;
+  if (const char* e = getenv("RGC_KNN_CACHE")) c->cache_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   { std::lock_guard<std::mutex> lk(g_live_mutex); g_live.insert(c); }
@@ -2680,6 +2750,18 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
     if (c->tgt.ready && c->tgt.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_target, c->tgt.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (c->src.ready && c->src.segs.p) HIPCHK(c, hipMemcpyAsync(&c->stats.deferred_source, c->src.segs.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  c->stats.searched_target = c->tgt.ready ? c->tgt.n : 0;
+  if (c->tgt.ready && c->tgt.cache_on && c->tgt.seed_warm && c->tgt.cache_small.p) {
+    // the neighbour-list cache's list lengths and its epoch word (== the frame: everything was searched)
+    int h[rgck::kTodoLists + 1];
+    HIPCHK(c, hipMemcpyAsync(h, c->tgt.cache_small.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h[rgck::kTodoLists] != c->tgt.cache_frame && c->tgt.cache_searched_lists) {
+      int sum = 0;
+      for (int l = 0; l < rgck::kTodoLists; l++) sum += h[l];
+      c->stats.searched_target = sum;
+    }
   }
   *out = c->stats;
   return RGC_OK;

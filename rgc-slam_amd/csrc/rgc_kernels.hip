@@ -224,6 +224,15 @@ __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid 
   if (valid) {
     float pt[3];
     if (kReframe) {  // the cloud is produced here (stride 4 floats) and counted from registers
+      if (rf.copy) {  // the neighbour-list cache's guard: is this still the map its lists were made for?  (x, y, z, bit for bit)
+        const float* sp = rf.src + (size_t)i * rf.src_stride_f;
+        const float4 old = rf.copy[i];
+        if (__float_as_int(old.x) != __float_as_int(sp[0]) || __float_as_int(old.y) != __float_as_int(sp[1]) || __float_as_int(old.z) != __float_as_int(sp[2])) {
+          rf.copy[i] = make_float4(sp[0], sp[1], sp[2], 0.f);
+          *rf.epoch = rf.frame;  // (every thread that finds a difference stores the same value)
+        }
+        if (rf.force && i == 0) *rf.epoch = rf.frame;
+      }
       const float4 w = reframe_point(rf, i);
       *reinterpret_cast<float4*>(const_cast<float*>(in) + (size_t)i * 4) = w;
       pt[0] = w.x; pt[1] = w.y; pt[2] = w.z;
@@ -530,9 +539,10 @@ constexpr int kOrdIdxBits = 27, kOrdCntBits = 18;
 constexpr unsigned long long kOrdIdxMask = (1ull << kOrdIdxBits) - 1ull;
 constexpr int kOrdCntMax = (1 << kOrdCntBits) - 1;
 __global__ void k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of, const int* __restrict__ start,
-                        unsigned long long* __restrict__ order_tmp, int prio) {
+                        unsigned long long* __restrict__ order_tmp, int prio, int* __restrict__ zero64) {
   wave_prio(prio);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (zero64 && i < kTodoLists) zero64[i] = 0;  // the neighbour-list cache's todo counters (k_rank_gather, the next launch, adds to them)
   if (i >= n) return;
   const int c = cell_of[i], slot = slot_of[i];
   const int s0 = start[c], cnt = start[c + 1] - s0;
@@ -545,14 +555,23 @@ __global__ void k_place(int n, const int* __restrict__ cell_of, const int* __res
 // Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate; P holds n + 4 entries.
 __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
                               const int* __restrict__ start, const unsigned long long* __restrict__ order_tmp, float4* __restrict__ P, int* zero_me,
-                              int prio) {
+                              int prio, KnnCache kc, const float* __restrict__ seed) {
   wave_prio(prio);
   int s = blockIdx.x * blockDim.x + threadIdx.x;
+  // the neighbour-list cache (nullable): an unchanged map's queries WITHOUT a certificate are listed for the search (kTodoLists lists, a
+  // workgroup adds to list blockIdx % kTodoLists: one same-address atomic per wave that has any, spread over 64 words)
+  const bool listing = kc.nbr && seed && *kc.epoch != kc.frame;
+  bool todo_me = false;
   if (s == 0 && zero_me) { zero_me[0] = 0; zero_me[1] = 0; zero_me[2] = 0; }  // the deferred-query counter of the kNN launch that follows, and the lazy target's two list sizes behind it
   if (s < 4) P[n + s] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __int_as_float(-1));  // sentinels: infinitely far from every query (k_knn_sp's last quad)
-  if (s >= n) return;
-  const unsigned long long rec = order_tmp[s];
+  const bool live = s < n;
+  const unsigned long long rec = live ? order_tmp[s] : 0ull;
   const int i = (int)(rec & kOrdIdxMask);
+  float my_seed = 1.f;
+  if (live && listing) my_seed = seed[i];  // (its round trip overlaps the cell members' below)
+  if (!live && !listing) return;
+  int final_pos = 0;
+  if (live) {
   const int cnt = (int)(rec >> (kOrdIdxBits + kOrdCntBits)) & kOrdCntMax;
   int s0, s1;
   if (cnt > 0) {
@@ -584,6 +603,25 @@ __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n,
     for (int u = 0; u < 7; u++) rank += (t + u < s1 && (int)(o[u] & kLoMask) < i);
   }
   P[s0 + rank] = make_float4(px, py, pz, __int_as_float(i));
+  final_pos = s0 + rank;
+  if (kc.pos_of) kc.pos_of[i] = final_pos;
+  todo_me = listing && !(my_seed < 0.f);
+  }
+  if (listing) {
+    const unsigned long long m = __ballot(todo_me);
+    if (m) {
+      const int lane = threadIdx.x & (WAVE - 1), lead = __ffsll((long long)m) - 1;
+      const int l = (int)(blockIdx.x % kTodoLists);
+      int base = 0;
+      if (lane == lead) base = atomicAdd(&kc.todo_cnt[l], __popcll(m));
+      base = __shfl(base, lead);
+      if (todo_me) {
+        const int e = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (e < kc.todo_cap) kc.todo[(size_t)l * kc.todo_cap + e] = final_pos;
+        else *kc.epoch_w = kc.frame;  // a list is full: "search everything" (as if the map had changed)
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -819,6 +857,10 @@ struct Deferred {
   // Any value is safe: a search that does not find its k neighbours under the bound runs again without it.
   float* seed;
   float seed_slack;  // how much a k-th distance may have grown since (the coordinates' fp32 rounding in two different frames), metres
+  // the neighbour-list cache (KnnCache, rgc_kernels.h; nbr == nullptr: none).  seed < 0: the list of that point is CERTIFIED (|seed| is
+  // the bound as before); the exact searches write the lists and the certificates, knn_point_cached reads them.
+  KnnCache cache;
+  int cache_nb;  // workgroups at the end of the map's bulk launch that search the listed (uncertified) queries
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1074,21 +1116,30 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
 // centred sum up to rounding (|u| <= a few cells, so nothing cancels badly), half the gathers of the two-pass form.
 // kFull (k == KC, the reference's k = 20) runs without per-neighbour guards: a load under a branch is waited for where the branch
 // ends, which would serialise the gathers.
+// nbr_out (nullable, kFull only): the neighbours' ORIGINAL indices (P.w) are stored there, 16 bytes at a time (the cache's list of this query)
 template <int KC, bool kFull>
 __device__ __forceinline__ void sp_normal_of(const float4* __restrict__ P, const int (&idx)[KC], float px, float py, float pz, int k, int i,
-                                             double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
+                                             double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz, int* __restrict__ nbr_out = nullptr) {
   double S[6] = {0, 0, 0, 0, 0, 0};
+  int ow[KC];
   const double qx = (double)px, qy = (double)py, qz = (double)pz;
   double mx = 0, my = 0, mz = 0;
 #pragma unroll
   for (int j = 0; j < KC; j++) {
     if (kFull || j < k) {
       const float4 cp = point_at(P, (unsigned)idx[j] << 4);
+      ow[j] = __float_as_int(cp.w);
       const double dx = (double)cp.x - qx, dy = (double)cp.y - qy, dz = (double)cp.z - qz;
       mx += dx; my += dy; mz += dz;
       // (explicit fma: the file is compiled without contraction for the sake of dist2(); these sums have no such constraint)
       S[0] = fma(dx, dx, S[0]); S[1] = fma(dx, dy, S[1]); S[2] = fma(dx, dz, S[2]);
       S[3] = fma(dy, dy, S[3]); S[4] = fma(dy, dz, S[4]); S[5] = fma(dz, dz, S[5]);
+    }
+  }
+  if constexpr (kFull && KC % 4 == 0) {
+    if (nbr_out) {
+#pragma unroll
+      for (int j = 0; j < KC; j += 4) *reinterpret_cast<int4*>(nbr_out + j) = make_int4(ow[j], ow[j + 1], ow[j + 2], ow[j + 3]);
     }
   }
   const double inv_k = 1.0 / (double)k;
@@ -1103,6 +1154,19 @@ __device__ __forceinline__ void sp_normal_of(const float4* __restrict__ P, const
   nx[i] = nrm[0];
   ny[i] = nrm[1];
   nz[i] = nrm[2];
+}
+
+// The certificate of a query's neighbour list (KnnCache): a_up = upper bound of the k-th squared distance as computed in this frame,
+// b_lo = lower bound of the (k+1)-th candidate's, bound = distance to the nearest face of the block that is not a grid border (what the
+// search proved: every point outside the block is at least that far).  With D the true (frame-independent) distances and e the largest
+// error of a computed distance against D in any frame (two points rounded to fp32 in that frame: <= sqrt(3) ulp of the largest coordinate,
+// plus the 4e-7 relative of the fp32 expression): members have D <= sqrt(a_up) + e, everything else D >= sqrt(min(b_lo, bound^2)) - e;
+// in another frame the computed distances keep their order when the two are more than 2 e apart, i.e. when
+//     sqrt(min(b_lo, bound^2)) - sqrt(a_up) > 4 e         (cert_slack = 4 sqrt(3) ulp, times 1.1; the relative part added here).
+__device__ __forceinline__ bool list_certified(float a_up, float b_lo, double bound, float cert_slack) {
+  const float lim = bound == 1.0e300 ? b_lo : fminf(b_lo, (float)(bound * bound * (1.0 - 1e-5)));
+  const float ra = __builtin_sqrtf(a_up), rb = __builtin_sqrtf(lim);
+  return rb - ra > cert_slack + 4.0e-6f * rb;
 }
 
 // The MAP's search (a leaf-filtered cloud: nothing crowded, the block is nine whole rows).  KB: low key bits that hold the candidate's
@@ -1316,9 +1380,15 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
 #pragma unroll
     for (int j = 0; j < KC; j++) idx[j] = j < k ? ((swap && j == k - 1) ? idx_k : index_of(top.a[j])) : 0;
   }
-  if (kExact || k == KC) sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz);
+  const int orig = __float_as_int(pq.w);
+  int* const nbr_out = (kExact && df.cache.nbr) ? df.cache.nbr + (size_t)orig * KC : nullptr;
+  if (kExact || k == KC) sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz, nbr_out);
   else sp_normal_of<KC, false>(P, idx, px, py, pz, k, i, nx, ny, nz);
-  if (df.seed) df.seed[__float_as_int(pq.w)] = thr_up;
+  if (df.seed) {
+    // (the (k+1)-th candidate is a_k; when the exact distances swapped the two the gap is a key bucket or two: no certificate)
+    const bool cert = nbr_out && !swap && list_certified(thr_up, __int_as_float(a_k & ~kKeyOrd), bound, df.cache.cert_slack);
+    df.seed[orig] = cert ? -thr_up : thr_up;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1390,7 +1460,7 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int orig = __float_as_int(pq.w);
-  const float seed = df.seed[orig];
+  const float seed = fabsf(df.seed[orig]);  // (the sign is the neighbour list's certificate, KnnCache)
   if (!(seed < 1.0e30f)) { LAB_DECLINE(1); return false; }  // never searched (or deferred every time)
   // keys below tkey are admitted: the seeded k-th distance, grown by the slack, rounded up, plus three key buckets
   const float rs = __builtin_sqrtf(seed) + df.seed_slack;
@@ -1579,8 +1649,46 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
   int idx[KC];
 #pragma unroll
   for (int j = 0; j < KC; j++) idx[j] = index_of(j >= drop ? w[j + 1] : w[j]);
-  sp_normal_of<KC, true>(P, idx, px, py, pz, KC, i, nx, ny, nz);
-  df.seed[orig] = thr_up;
+  int* const nbr_out = df.cache.nbr ? df.cache.nbr + (size_t)orig * KC : nullptr;
+  sp_normal_of<KC, true>(P, idx, px, py, pz, KC, i, nx, ny, nz, nbr_out);
+  // the (k+1)-th candidate: exactly k admitted -- anything not admitted, >= tkey; k + 1 admitted -- the dropped key, mx (when the exact
+  // distances made mx the k-th instead, the two are a key bucket or two apart: no certificate)
+  const bool cert = nbr_out && (!extra || kth_key == mx2) &&
+                    list_certified(thr_up, __int_as_float((extra ? mx : tkey) & ~kKeyOrd), bound, df.cache.cert_slack);
+  df.seed[orig] = cert ? -thr_up : thr_up;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A certified query of an unchanged map (KnnCache): its k neighbours are the ones its last exact search found -- their ORIGINAL indices
+// are in the list, their positions in this frame's sorted array in pos_of[].  No search: twenty look-ups, the positions put into ascending
+// order (the order every route sums the moments in: the same bits as a search would give), the moments.  Returns false -- nothing done --
+// for a query without a certificate (seed >= 0: searched by the launch's other workgroups, k_knn_sp).
+// ------------------------------------------------------------------------------------------------
+template <int KC>
+__device__ __forceinline__ bool knn_point_cached(const float4* __restrict__ P, int i, const Deferred& df, double* __restrict__ nx,
+                                                 double* __restrict__ ny, double* __restrict__ nz) {
+  static_assert(KC == 20, "the position sort is a 20-input network");
+  const float4 pq = P[i];
+  const int orig = __float_as_int(pq.w);
+  if (!(df.seed[orig] < 0.f)) return false;
+  const int4* const L = reinterpret_cast<const int4*>(df.cache.nbr + (size_t)orig * KC);
+  int idx[KC];
+#pragma unroll
+  for (int j = 0; j < KC; j += 4) {
+    const int4 o = L[j >> 2];
+    idx[j] = o.x; idx[j + 1] = o.y; idx[j + 2] = o.z; idx[j + 3] = o.w;
+  }
+#pragma unroll
+  for (int j = 0; j < KC; j++) idx[j] = df.cache.pos_of[idx[j]];
+#pragma unroll
+  for (int e = 0; e < kSort20N; e++) {
+    const int a = kSort20[e] >> 5, b = kSort20[e] & 31;
+    const int lo_ = min(idx[a], idx[b]);
+    idx[b] = max(idx[a], idx[b]);
+    idx[a] = lo_;
+  }
+  sp_normal_of<KC, true>(P, idx, pq.x, pq.y, pq.z, KC, i, nx, ny, nz);
   return true;
 }
 
@@ -1932,7 +2040,8 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
   // Each XCD takes runs of kXcdRun CONSECUTIVE query blocks (neighbouring cells: their candidates are re-used out of that XCD's L2),
   // the runs themselves dealt round-robin (whole contiguous eighths of the map differ too much in work: 7 % slower).
   constexpr int kXcdRun = RGC_XCD_RUN * KNN_T / Cfg::T;  // (a run is RGC_XCD_RUN x 256 consecutive queries whatever the workgroup size)
-  const int b = (int)blockIdx.x, slot = b >> 3, x = b & 7;
+  int b = (int)blockIdx.x, slot = b >> 3;
+  const int x = b & 7;
   if constexpr (!kTarget) {  // four lanes per query, queries in cell order
     const int t = b * Cfg::T + (int)threadIdx.x;
     const int i = t >> 2;
@@ -1951,11 +2060,40 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
 #endif
     return;
   }
+  bool cached = false;
+  if constexpr (kSeeded) {
+    // The neighbour-list cache (KnnCache).  An unchanged map: the launch's FIRST cache_nb workgroups search the queries k_rank_gather
+    // listed (the ones without a certificate: whole waves of them, started first because they live ten times longer), the others take
+    // the certified queries' neighbours from their lists (knn_point_cached) and skip the rest.  A map that changed this frame (its first
+    // frame, a buffer rewritten in place): everything is searched by the workgroups behind the first cache_nb, as without the cache.
+    if (df.cache.nbr) {
+      const bool changed = *df.cache.epoch == df.cache.frame;
+      if (b < df.cache_nb) {
+        if (changed) return;
+        // list l = b % kTodoLists, T entries at a time, dealt to the list's workgroups
+        const int l = b % kTodoLists, per = df.cache_nb / kTodoLists;
+        const int cnt = df.cache.todo_cnt[l];  // (<= todo_cap: an overflow has set `changed`, k_rank_gather)
+        for (int e = (b / kTodoLists) * Cfg::T + (int)threadIdx.x; e < cnt; e += per * Cfg::T) {
+          const int q = df.cache.todo[(size_t)l * df.cache.todo_cap + e];
+          if (!knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, q, slist_sp + threadIdx.x, df, nx, ny, nz))
+            knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, q, slist_sp + threadIdx.x, df, nx, ny, nz);
+        }
+        return;
+      }
+      b -= df.cache_nb;  // (a multiple of 8: the XCD of a workgroup is still b & 7)
+      slot = b >> 3;
+      cached = !changed;
+    }
+  }
   const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
 #ifdef RGC_LAB_BLOCKS
   const long long lab_b0 = wall_clock64();
 #endif
   if constexpr (kSeeded) {
+    if (cached) {
+      if (i < n) knn_point_cached<KC>(P, i, df, nx, ny, nz);
+      return;
+    }
     const bool done = i >= n || knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, i, slist_sp + threadIdx.x, df, nx, ny, nz);
     if (!done) {
       LAB_COUNT(6);
@@ -3934,8 +4072,8 @@ void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, in
     hipLaunchKernelGGL(k_cells_scan_write<false>, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, nb, cell_voxel, nvox, hi);
   }
 }
-void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi) {
-  hipLaunchKernelGGL(k_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, slot_of, start, order_tmp, hi);
+void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi, int* zero64) {
+  hipLaunchKernelGGL(k_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, slot_of, start, order_tmp, hi, zero64);
 }
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums, int hi) {
   const int nb = nblk(n, SCAN_B);
@@ -3946,15 +4084,16 @@ void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_su
   }
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const unsigned long long* order_tmp, float4* P, int* zero_me, int hi) {
-  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi);
+                 const unsigned long long* order_tmp, float4* P, int* zero_me, int hi, const KnnCache* cache, const float* seed) {
+  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi,
+                     cache ? *cache : KnnCache{}, seed);
 }
 size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 
 // deferred list: [cnt, pad x15][idx n][thr n]
 static Deferred deferred_of(const void* buf, int n) {
   int* base = (int*)const_cast<void*>(buf);
-  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, nullptr, nullptr, 0.f};
+  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, nullptr, nullptr, 0.f, KnnCache{}, 0};
 }
 
 template <int KC, bool kExact>
@@ -3969,6 +4108,7 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   df.seed = seeds_ok ? seeds.seed : nullptr;
   df.seed_slack = seeds.slack;
   const bool seeded = seeds_ok && seeds.warm;
+  if (seeds_ok && seeds.cache.nbr) df.cache = seeds.cache;  // (the searches write the lists and certificates from the first launch on)
   if (wide_r == 2) {
     const size_t ldsw = (size_t)SpShape<2, true>::LDS * WAVE * sizeof(int);
     hipLaunchKernelGGL((k_knn_sp_wide<KC, 2, kExact>), dim3(nblk(n, WAVE / 4)), dim3(WAVE), ldsw, s, P, start, g, n, k, df, nx, ny, nz);
@@ -3984,7 +4124,12 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   // expected to fill (the kernel strides over the list whatever its true length)
   const int n_launch = (is_target && qlist) ? (q_est < T ? T : (q_est > n ? n : q_est)) : n;
   const int xcd_run = RGC_XCD_RUN * KNN_T / T;
-  const int nb = (is_target && qlist) ? nblk(n_launch, T) : 8 * xcd_run * nblk(nblk(n, T), 8 * xcd_run);
+  int nb = (is_target && qlist) ? nblk(n_launch, T) : 8 * xcd_run * nblk(nblk(n, T), 8 * xcd_run);
+  if (seeded && !qlist && df.cache.nbr) {
+    // the workgroups in front of the bulk ones search the listed queries: sized for 4 % of the map (they stride over longer lists)
+    df.cache_nb = kTodoLists * std::max(1, nblk((int)(0.04 * (double)n / kTodoLists) + 1, T));
+    nb += df.cache_nb;
+  }
   // (ev0 / ev1: the launch's own start / stop times go into the caller's events -- no separate record packets around it)
   if constexpr (kExact) {
     if (seeded) {

@@ -1024,6 +1024,87 @@ def test_seeded_search_is_exact_whatever_the_seeds(reg_mod, orc, medium, monkeyp
     v.close(); w.close()
 
 
+def test_neighbour_lists_of_an_unchanged_map(reg_mod, orc, medium, monkeypatch):
+    """Round 5, second half: a map handed over again by rgc_set_target_reframed, bit for bit the one of the frame before, keeps the
+    neighbour LISTS of its last exact search; a query whose list carries a certificate (the gap behind its k-th neighbour is wider than
+    fp32 rounding in any two frames can bridge) is not searched again (knn_point_cached).  "Unchanged" is verified by the library (the
+    counting pass compares the map with its own copy), never assumed.  Against a context that never keeps anything (RGC_KNN_SEEDS=0),
+    fed the same calls, every covariance and the voxel table bit for bit --
+      * a dozen poses all over the place (yaw through the full circle, tens of metres), most queries taken from their lists,
+      * ONE point of the buffer moved in place -- by a third of a metre, then by one ulp: everything is searched again,
+      * a pose that puts the map two kilometres from the origin (coarser fp32 coordinates than the certificates allow for: issued again,
+        for the wider gap; and for the narrower one some frames after the map is back),
+      * a quaternion that is not a unit one (no rigid motion: no lists that frame, and none trusted after it)."""
+    import bench
+    import rgc_slam_amd.synth as synth
+    tgt = medium["tgt"]
+    n = len(tgt)
+    rng = np.random.default_rng(23)
+    a = np.zeros((n, 4), np.float32); a[:, :3] = tgt
+    v = _odo(reg_mod)
+    monkeypatch.setenv("RGC_KNN_SEEDS", "0")
+    w = _odo(reg_mod)
+    monkeypatch.delenv("RGC_KNN_SEEDS")
+    d_map, d_body = v.device_alloc(16 * n), v.device_alloc(16 * n)
+    d_map_w, d_body_w = w.device_alloc(16 * n), w.device_alloc(16 * n)
+    v.upload(d_map, a); w.upload(d_map_w, a)
+
+    def frame(what, q, t, searched):
+        v.setInputTargetReframed(d_map, n, 16, q, t, d_body)
+        w.setInputTargetReframed(d_map_w, n, 16, q, t, d_body_w)
+        cv, cw = v.getTargetCovariances(), w.getTargetCovariances()
+        assert np.array_equal(cv, cw), what
+        xv, xw = v.getVoxels(), w.getVoxels()
+        assert np.array_equal(xv["coords"], xw["coords"]) and np.array_equal(xv["cov"], xw["cov"]) and np.array_equal(xv["mean"], xw["mean"]), what
+        got = v.stats()["searched_target"]
+        if searched == "all":
+            assert got == n, (what, got)
+        elif searched == "few":
+            assert got <= 0.15 * n, (what, got, n)
+        return cv
+
+    def pose(j):
+        Tw = synth.se3(synth.rot_zyx(0.55 * j - 0.5, 0.03 * np.sin(j), -0.02 * np.cos(j)), [7.5 * np.cos(j), -11.0 * np.sin(1.3 * j), 0.3 * j])
+        return bench.world_to_body(Tw)
+
+    q, t = pose(0)
+    frame("first", q, t, "all")
+    frame("second (the unseeded search wrote the lists)", *pose(1), "few")
+    for j in range(2, 14):
+        cv = frame("pose %d" % j, *pose(j), "few")
+    body = v.download(d_body, (n, 4))
+    ocov, _ = orc.covariances(body[:, :3].copy(), k=20)
+    assert np.abs(cv - ocov).max() <= 1e-9
+    # one point moved in place
+    b = a.copy(); b[n // 3, :3] += np.float32([0.3, -0.1, 0.05])
+    v.upload(d_map, b); w.upload(d_map_w, b)
+    frame("one point moved", *pose(14), "all")
+    frame("... and left there", *pose(15), "few")
+    b[n // 2, 0] = np.nextafter(b[n // 2, 0], np.float32(1e9))
+    v.upload(d_map, b); w.upload(d_map_w, b)
+    frame("one point moved by an ulp", *pose(16), "all")
+    frame("... and left there", *pose(17), "few")
+    # far from the origin
+    q, t = pose(18)
+    t_far = np.asarray(t, np.float64) + np.array([2000.0, -900.0, 10.0])
+    frame("two kilometres out", q, t_far, "all")
+    frame("... again", q, t_far + 0.25, None)        # (certificates need a gap of 2 mm there: few queries have one, the lists overflow)
+    for j in range(100, 180):                        # back: sixteen frames per binary order of magnitude until certificates are cheap again
+        frame("back", *pose(j), None)
+    frame("back for good", *pose(19), "few")
+    # not a rigid motion
+    q, t = pose(20)
+    q_bad = np.asarray(q, np.float64) * 1.0005
+    frame("scaled quaternion", q_bad, t, "all")
+    frame("after it", *pose(21), "all")
+    frame("... and then", *pose(22), "few")
+    for p in (d_map, d_body):
+        v.device_free(p)
+    for p in (d_map_w, d_body_w):
+        w.device_free(p)
+    v.close(); w.close()
+
+
 def test_lazy_target_behind_a_tripped_guard_and_errors_of_the_fused_call(reg_mod, medium):
     """(a) A lazy target prepared on the PREVIOUS cloud's (speculative) grid with a point far outside it: the counting pass parks that point
     and raises the guard; the lazy kernels must stand still like every other consumer (no cell computed from the parked point's coordinates),
