@@ -114,7 +114,7 @@ struct Cloud {
   bool seed_warm = false;  // ... and some search has written them
   float seed_slack = 0.f;
   // the neighbour-list cache on top of the seeds (rgck::KnnCache): the same key, the same life
-  DevBuf nbr, pos_of, map_copy, todo, cache_small;  // cache_small: kTodoLists list lengths, then the epoch word
+  DevBuf nbr, pos_of, map_copy, todo, cache_small;  // cache_small: kTodoLists list lengths, the epoch word, the overflow word
   bool cache_on = false;    // this preparation compares the map with map_copy and its searches read / write the lists
   bool cache_live = false;  // the LAST preparation's searches ran with the lists attached (otherwise they are stale: the next frame starts over)
   int cache_frame = 0;
@@ -518,7 +518,9 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
         if (fresh || ce2 > cl.cache_e2) { cl.cache_e2 = ce2; fresh = true; }
         cl.cache_e2_low = ce2 < cl.cache_e2 ? cl.cache_e2_low + 1 : 0;
         if (cl.cache_e2_low >= 16) { cl.cache_e2--; cl.cache_e2_low = 0; }
-        cl.cache_frame = cl.cache_frame >= (1 << 30) ? 1 : cl.cache_frame + 1;
+        if (cl.cache_frame >= (1 << 30)) { cl.cache_frame = 0; fresh = true; }
+        cl.cache_frame++;
+        if (fresh) HIPCHK(c, hipMemsetAsync(cl.cache_small.p, 0, sizeof(int) * (rgck::kTodoLists + 16), s));  // (list lengths, epoch, overflow)
         cl.rf.copy = (float4*)cl.map_copy.p;
         cl.rf.epoch = (int*)cl.cache_small.p + rgck::kTodoLists;
         cl.rf.frame = cl.cache_frame;
@@ -635,9 +637,9 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     const bool with_cache = is_target && &cl == &c->tgt && cl.cache_on;
     const rgck::KnnSeeds sd = cloud_seeds(cl, is_target);
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (unsigned long long*)cl.order_tmp.p, hi,
-                with_cache ? (int*)cl.cache_small.p : nullptr);
+                with_cache ? &sd.cache : nullptr);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const unsigned long long*)cl.order_tmp.p,
-                      (float4*)cl.P.p, (int*)cl.segs.p, hi, with_cache ? &sd.cache : nullptr, (with_cache && cl.seed_warm) ? sd.seed : nullptr);
+                      (float4*)cl.P.p, (int*)cl.segs.p, hi, with_cache ? sd.cache.pos_of : nullptr);
   }
   cl.lazy = 0;
   if (is_target && &cl == &c->tgt && c->lazy_margin > 0 && !c->lm_host && map_wide_r_of(c, cl) == 0) {
@@ -679,8 +681,8 @@ rgck::KnnSeeds cloud_seeds(const Cloud& cl, bool is_target) {
       kc.pos_of = (int*)cl.pos_of.p;
       kc.todo = (int*)cl.todo.p;
       kc.todo_cnt = (int*)cl.cache_small.p;
-      kc.epoch_w = (int*)cl.cache_small.p + rgck::kTodoLists;
-      kc.epoch = kc.epoch_w;
+      kc.epoch = (int*)cl.cache_small.p + rgck::kTodoLists;
+      kc.overflow = (int*)cl.cache_small.p + rgck::kTodoLists + 1;
       kc.frame = cl.cache_frame;
       kc.todo_cap = cl.todo_cap;
       // what the coordinates' fp32 rounding in two frames can move a distance by, twice: 4 sqrt(3) ulp of the largest coordinate, and a tenth
@@ -2754,12 +2756,13 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   c->stats.searched_target = c->tgt.ready ? c->tgt.n : 0;
   if (c->tgt.ready && c->tgt.cache_on && c->tgt.seed_warm && c->tgt.cache_small.p) {
     // the neighbour-list cache's list lengths and its epoch word (== the frame: everything was searched)
-    int h[rgck::kTodoLists + 1];
+    int h[rgck::kTodoLists + 2];
     HIPCHK(c, hipMemcpyAsync(h, c->tgt.cache_small.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (h[rgck::kTodoLists] != c->tgt.cache_frame && c->tgt.cache_searched_lists) {
+    const bool redo = h[rgck::kTodoLists] == c->tgt.cache_frame || h[rgck::kTodoLists + 1] == c->tgt.cache_frame - 1;
+    if (!redo && c->tgt.cache_searched_lists) {
       int sum = 0;
-      for (int l = 0; l < rgck::kTodoLists; l++) sum += h[l];
+      for (int l = 0; l < rgck::kTodoLists; l++) sum += std::min(h[l], c->tgt.todo_cap);
       c->stats.searched_target = sum;
     }
   }

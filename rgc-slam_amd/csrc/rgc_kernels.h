@@ -48,20 +48,21 @@ struct Reframe { const float* src; int src_stride_f; Quat q; double t[3]; float4
 // The neighbour-list cache of a map that is handed over by rgc_set_target_reframed again and again (round 5, second half).  A rigid
 // re-expression does not change who a point's k nearest neighbours are -- only the fp32 rounding of the coordinates can, and only where
 // the k-th and the (k+1)-th neighbour (or the edge of what the 3x3x3 block proves) are that close.  Per ORIGINAL point: the k neighbours'
-// original indices as the last exact search found them (nbr, 4 k bytes) and, in the sign of its seed, a CERTIFICATE: the gap behind the
-// k-th neighbour exceeded what rounding in any two frames can bridge.  A certified query of an unchanged map takes its neighbours from the
-// list (knn_point_cached: no search); every other one is searched exactly as before.  "Unchanged" is verified, not assumed: the
-// counting pass compares the map with the library's own copy, bit for bit (Reframe).
+// original indices as the last exact search found them (nbr, 4 k bytes), the top bit of the first one a CERTIFICATE: the gap behind the
+// k-th neighbour exceeded what rounding in any two frames can bridge (list_certified).  A certified query of an unchanged map takes its
+// neighbours from the list (knn_point_cached: no search); the others -- on the todo lists since the frame that built the lists -- are
+// searched exactly as before.  "Unchanged" is verified, not assumed: the counting pass compares the map with the library's own copy, bit
+// for bit (Reframe); a frame that finds a difference searches everything and builds the lists again.
 struct KnnCache {
-  int* nbr = nullptr;        // [n][k] original indices of the k nearest neighbours of original point o (any order)
+  int* nbr = nullptr;        // [n][k] original indices of the k nearest neighbours of original point o, in no particular order
   int* pos_of = nullptr;     // [n] this frame's position of original point o in the sorted array (k_rank_gather)
-  const int* epoch = nullptr;  // *epoch == frame: the map changed this frame (or the lists are not trusted): search everything
-  int* epoch_w = nullptr;    // (the same word, for k_rank_gather: a todo list that overflows says "search everything" too)
+  const int* epoch = nullptr;  // *epoch == frame: the map changed this frame (or the lists are not trusted)
+  int* overflow = nullptr;   // *overflow == frame - 1: the previous frame's rebuild ran out of room in a todo list: rebuild again
   int frame = 0;
-  int* todo = nullptr;       // kTodoLists lists of sorted positions of this frame's UNcertified queries, todo_cap entries each (k_rank_gather)
-  int* todo_cnt = nullptr;   // ... their lengths (zeroed by k_place)
+  int* todo = nullptr;       // kTodoLists lists of ORIGINAL indices of the queries without a certificate, todo_cap entries each
+  int* todo_cnt = nullptr;   // ... their lengths (emptied by k_place in a frame that rebuilds)
   int todo_cap = 0;
-  float cert_slack = 0.f;    // metres: what the coordinates' fp32 rounding in two frames can move a distance by (4 sqrt(3) ulp of the largest coordinate)
+  float cert_slack = 0.f;    // metres: what the coordinates' fp32 rounding in two frames can move a distance by, twice (4 sqrt(3) ulp of the largest coordinate)
 };
 constexpr int kTodoLists = 64;
 struct LmIn { double x0[16]; double lambda; double init_factor; };
@@ -94,12 +95,11 @@ void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, in
                 float* sum_sq = nullptr /* += sum of count^2, nullable */);
 // order_tmp: n 64-bit records {original index, position in the cell, cell population} (k_place)
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi = 0,
-           int* zero64 = nullptr /* the neighbour-list cache's todo counters, zeroed on the way */);
+           const KnnCache* cache = nullptr /* its todo lists are emptied on the way in a frame that rebuilds them */);
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */, int hi = 0);
-// cache (nullable) + seed: pos_of[] is written and the uncertified queries of an unchanged map are listed (KnnCache::todo)
+// pos_of (nullable): KnnCache::pos_of, written on the way
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const unsigned long long* order_tmp, float4* P, int* zero_me = nullptr, int hi = 0, const KnnCache* cache = nullptr,
-                 const float* seed = nullptr);
+                 const unsigned long long* order_tmp, float4* P, int* zero_me = nullptr, int hi = 0, int* pos_of = nullptr);
 // ---- C2: exact kNN + PLANE covariance -> unit normal ----
 // bulk kernel (one lane per query; defers what it cannot finish) then the cooperative kernel (one wave per deferred query).
 // deferred: deferred_bytes(n) bytes, whose first int (the count) must be 0 on entry (rank_gather's zero_me)

@@ -538,11 +538,15 @@ __global__ void __launch_bounds__(SCAN_T) k_cells_scan_write(int* __restrict__ c
 constexpr int kOrdIdxBits = 27, kOrdCntBits = 18;
 constexpr unsigned long long kOrdIdxMask = (1ull << kOrdIdxBits) - 1ull;
 constexpr int kOrdCntMax = (1 << kOrdCntBits) - 1;
+// The neighbour-list cache (KnnCache): does this frame search every query and rebuild the lists?  The map changed (k_count<true> found a
+// point that differs from the library's copy, or was told not to trust it), or the previous rebuild ran out of room in a todo list.
+__device__ __forceinline__ bool cache_redo(const KnnCache& kc) { return *kc.epoch == kc.frame || *kc.overflow == kc.frame - 1; }
 __global__ void k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of, const int* __restrict__ start,
-                        unsigned long long* __restrict__ order_tmp, int prio, int* __restrict__ zero64) {
+                        unsigned long long* __restrict__ order_tmp, int prio, KnnCache kc) {
   wave_prio(prio);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (zero64 && i < kTodoLists) zero64[i] = 0;  // the neighbour-list cache's todo counters (k_rank_gather, the next launch, adds to them)
+  // the neighbour-list cache's todo lists are rebuilt by a frame that searches everything (k_knn_sp, the launch after the next): emptied here
+  if (kc.nbr && i < kTodoLists && cache_redo(kc)) kc.todo_cnt[i] = 0;
   if (i >= n) return;
   const int c = cell_of[i], slot = slot_of[i];
   const int s0 = start[c], cnt = start[c + 1] - s0;
@@ -555,23 +559,14 @@ __global__ void k_place(int n, const int* __restrict__ cell_of, const int* __res
 // Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate; P holds n + 4 entries.
 __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
                               const int* __restrict__ start, const unsigned long long* __restrict__ order_tmp, float4* __restrict__ P, int* zero_me,
-                              int prio, KnnCache kc, const float* __restrict__ seed) {
+                              int prio, int* __restrict__ pos_of) {
   wave_prio(prio);
   int s = blockIdx.x * blockDim.x + threadIdx.x;
-  // the neighbour-list cache (nullable): an unchanged map's queries WITHOUT a certificate are listed for the search (kTodoLists lists, a
-  // workgroup adds to list blockIdx % kTodoLists: one same-address atomic per wave that has any, spread over 64 words)
-  const bool listing = kc.nbr && seed && *kc.epoch != kc.frame;
-  bool todo_me = false;
   if (s == 0 && zero_me) { zero_me[0] = 0; zero_me[1] = 0; zero_me[2] = 0; }  // the deferred-query counter of the kNN launch that follows, and the lazy target's two list sizes behind it
   if (s < 4) P[n + s] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __int_as_float(-1));  // sentinels: infinitely far from every query (k_knn_sp's last quad)
-  const bool live = s < n;
-  const unsigned long long rec = live ? order_tmp[s] : 0ull;
+  if (s >= n) return;
+  const unsigned long long rec = order_tmp[s];
   const int i = (int)(rec & kOrdIdxMask);
-  float my_seed = 1.f;
-  if (live && listing) my_seed = seed[i];  // (its round trip overlaps the cell members' below)
-  if (!live && !listing) return;
-  int final_pos = 0;
-  if (live) {
   const int cnt = (int)(rec >> (kOrdIdxBits + kOrdCntBits)) & kOrdCntMax;
   int s0, s1;
   if (cnt > 0) {
@@ -603,25 +598,7 @@ __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n,
     for (int u = 0; u < 7; u++) rank += (t + u < s1 && (int)(o[u] & kLoMask) < i);
   }
   P[s0 + rank] = make_float4(px, py, pz, __int_as_float(i));
-  final_pos = s0 + rank;
-  if (kc.pos_of) kc.pos_of[i] = final_pos;
-  todo_me = listing && !(my_seed < 0.f);
-  }
-  if (listing) {
-    const unsigned long long m = __ballot(todo_me);
-    if (m) {
-      const int lane = threadIdx.x & (WAVE - 1), lead = __ffsll((long long)m) - 1;
-      const int l = (int)(blockIdx.x % kTodoLists);
-      int base = 0;
-      if (lane == lead) base = atomicAdd(&kc.todo_cnt[l], __popcll(m));
-      base = __shfl(base, lead);
-      if (todo_me) {
-        const int e = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (e < kc.todo_cap) kc.todo[(size_t)l * kc.todo_cap + e] = final_pos;
-        else *kc.epoch_w = kc.frame;  // a list is full: "search everything" (as if the map had changed)
-      }
-    }
-  }
+  if (pos_of) pos_of[i] = s0 + rank;  // the neighbour-list cache (KnnCache): where original point i sits this frame
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1116,10 +1093,12 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
 // centred sum up to rounding (|u| <= a few cells, so nothing cancels badly), half the gathers of the two-pass form.
 // kFull (k == KC, the reference's k = 20) runs without per-neighbour guards: a load under a branch is waited for where the branch
 // ends, which would serialise the gathers.
-// nbr_out (nullable, kFull only): the neighbours' ORIGINAL indices (P.w) are stored there, 16 bytes at a time (the cache's list of this query)
+// nbr_out (nullable, kFull only): the neighbours' ORIGINAL indices (P.w) are stored there, 16 bytes at a time (the cache's list of this
+// query), nbr_flag (0 or kListCertified) in the first one's top bit
 template <int KC, bool kFull>
 __device__ __forceinline__ void sp_normal_of(const float4* __restrict__ P, const int (&idx)[KC], float px, float py, float pz, int k, int i,
-                                             double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz, int* __restrict__ nbr_out = nullptr) {
+                                             double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz, int* __restrict__ nbr_out = nullptr,
+                                             int nbr_flag = 0) {
   double S[6] = {0, 0, 0, 0, 0, 0};
   int ow[KC];
   const double qx = (double)px, qy = (double)py, qz = (double)pz;
@@ -1138,6 +1117,7 @@ __device__ __forceinline__ void sp_normal_of(const float4* __restrict__ P, const
   }
   if constexpr (kFull && KC % 4 == 0) {
     if (nbr_out) {
+      ow[0] |= nbr_flag;
 #pragma unroll
       for (int j = 0; j < KC; j += 4) *reinterpret_cast<int4*>(nbr_out + j) = make_int4(ow[j], ow[j + 1], ow[j + 2], ow[j + 3]);
     }
@@ -1169,6 +1149,20 @@ __device__ __forceinline__ bool list_certified(float a_up, float b_lo, double bo
   return rb - ra > cert_slack + 4.0e-6f * rb;
 }
 
+// A query that ends without a certificate -- no gap, or handed to the cooperative kernel -- while the lists are attached (a frame that
+// searches everything): its list says so, and it goes onto the todo list the later frames search (original index: the lists outlive the
+// frame's order).  ~3 % of the queries, an atomic each on one of kTodoLists words.
+constexpr int kListCertified = (int)0x80000000;
+template <int KC>
+__device__ __forceinline__ void cache_uncertified(const Deferred& df, int orig) {
+  if (!df.cache.nbr) return;
+  df.cache.nbr[(size_t)orig * KC] = 0;
+  const int l = (int)(blockIdx.x % kTodoLists);
+  const int e = atomicAdd(&df.cache.todo_cnt[l], 1);
+  if (e < df.cache.todo_cap) df.cache.todo[(size_t)l * df.cache.todo_cap + e] = orig;
+  else *df.cache.overflow = df.cache.frame;  // no room: the next frame searches everything again (cache_redo)
+}
+
 // The MAP's search (a leaf-filtered cloud: nothing crowded, the block is nine whole rows).  KB: low key bits that hold the candidate's
 // ordinal {table row (high bits) | position in the row (low 7 bits)}: the winning keys give their neighbours' positions with ONE table
 // read, and a skipped row renumbers nothing.  (The raw scan's search -- pieces with lazily numbered ordinals, four lanes per query -- is
@@ -1198,6 +1192,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     const int e = atomicAdd(df.cnt, 1);
     df.idx[e] = enc;
     df.thr[e] = thr;
+    if constexpr (kExact && KC == 20) cache_uncertified<KC>(df, __float_as_int(pq.w));
   };
   bool heavy_piece = false;
   const int nr = sp_piece_table<kClip, R, T>(start, g, c, q, tmix, tlo, heavy_piece);
@@ -1381,14 +1376,17 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     for (int j = 0; j < KC; j++) idx[j] = j < k ? ((swap && j == k - 1) ? idx_k : index_of(top.a[j])) : 0;
   }
   const int orig = __float_as_int(pq.w);
-  int* const nbr_out = (kExact && df.cache.nbr) ? df.cache.nbr + (size_t)orig * KC : nullptr;
-  if (kExact || k == KC) sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz, nbr_out);
-  else sp_normal_of<KC, false>(P, idx, px, py, pz, k, i, nx, ny, nz);
-  if (df.seed) {
+  if constexpr (kExact && KC == 20) {
     // (the (k+1)-th candidate is a_k; when the exact distances swapped the two the gap is a key bucket or two: no certificate)
+    int* const nbr_out = df.cache.nbr ? df.cache.nbr + (size_t)orig * KC : nullptr;
     const bool cert = nbr_out && !swap && list_certified(thr_up, __int_as_float(a_k & ~kKeyOrd), bound, df.cache.cert_slack);
-    df.seed[orig] = cert ? -thr_up : thr_up;
+    sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz, cert ? nbr_out : nullptr, kListCertified);
+    if (!cert) cache_uncertified<KC>(df, orig);
+  } else {
+    if (kExact || k == KC) sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz);
+    else sp_normal_of<KC, false>(P, idx, px, py, pz, k, i, nx, ny, nz);
   }
+  if (df.seed) df.seed[orig] = thr_up;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1460,7 +1458,7 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
   const float4 pq = P[i];
   const float px = pq.x, py = pq.y, pz = pq.z;
   const int orig = __float_as_int(pq.w);
-  const float seed = fabsf(df.seed[orig]);  // (the sign is the neighbour list's certificate, KnnCache)
+  const float seed = df.seed[orig];
   if (!(seed < 1.0e30f)) { LAB_DECLINE(1); return false; }  // never searched (or deferred every time)
   // keys below tkey are admitted: the seeded k-th distance, grown by the slack, rounded up, plus three key buckets
   const float rs = __builtin_sqrtf(seed) + df.seed_slack;
@@ -1565,6 +1563,7 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
       const int e = atomicAdd(df.cnt, 1);
       df.idx[e] = ~i;
       df.thr[e] = rs * rs * 1.000001f;
+      cache_uncertified<KC>(df, orig);
       return true;
     }
     LAB_DECLINE(3);
@@ -1638,24 +1637,27 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
     const int e = atomicAdd(df.cnt, 1);
     df.idx[e] = ~i;
     df.thr[e] = (double)thr_up < 3.0 * (R + 1) * (R + 1) * g.res * g.res ? thr_up : INFINITY;
+    cache_uncertified<KC>(df, orig);
     return true;
   }
   if (undecided) {
     const int e = atomicAdd(df.cnt, 1);
     df.idx[e] = i;
     df.thr[e] = thr_up;
+    cache_uncertified<KC>(df, orig);
     return true;
   }
   int idx[KC];
 #pragma unroll
   for (int j = 0; j < KC; j++) idx[j] = index_of(j >= drop ? w[j + 1] : w[j]);
-  int* const nbr_out = df.cache.nbr ? df.cache.nbr + (size_t)orig * KC : nullptr;
-  sp_normal_of<KC, true>(P, idx, px, py, pz, KC, i, nx, ny, nz, nbr_out);
   // the (k+1)-th candidate: exactly k admitted -- anything not admitted, >= tkey; k + 1 admitted -- the dropped key, mx (when the exact
   // distances made mx the k-th instead, the two are a key bucket or two apart: no certificate)
+  int* const nbr_out = df.cache.nbr ? df.cache.nbr + (size_t)orig * KC : nullptr;
   const bool cert = nbr_out && (!extra || kth_key == mx2) &&
                     list_certified(thr_up, __int_as_float((extra ? mx : tkey) & ~kKeyOrd), bound, df.cache.cert_slack);
-  df.seed[orig] = cert ? -thr_up : thr_up;
+  sp_normal_of<KC, true>(P, idx, px, py, pz, KC, i, nx, ny, nz, cert ? nbr_out : nullptr, kListCertified);
+  if (!cert) cache_uncertified<KC>(df, orig);
+  df.seed[orig] = thr_up;
   return true;
 }
 
@@ -1663,7 +1665,7 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
 // A certified query of an unchanged map (KnnCache): its k neighbours are the ones its last exact search found -- their ORIGINAL indices
 // are in the list, their positions in this frame's sorted array in pos_of[].  No search: twenty look-ups, the positions put into ascending
 // order (the order every route sums the moments in: the same bits as a search would give), the moments.  Returns false -- nothing done --
-// for a query without a certificate (seed >= 0: searched by the launch's other workgroups, k_knn_sp).
+// for a query without a certificate (it is on a todo list: searched by the launch's first workgroups, k_knn_sp).
 // ------------------------------------------------------------------------------------------------
 template <int KC>
 __device__ __forceinline__ bool knn_point_cached(const float4* __restrict__ P, int i, const Deferred& df, double* __restrict__ nx,
@@ -1671,7 +1673,6 @@ __device__ __forceinline__ bool knn_point_cached(const float4* __restrict__ P, i
   static_assert(KC == 20, "the position sort is a 20-input network");
   const float4 pq = P[i];
   const int orig = __float_as_int(pq.w);
-  if (!(df.seed[orig] < 0.f)) return false;
   const int4* const L = reinterpret_cast<const int4*>(df.cache.nbr + (size_t)orig * KC);
   int idx[KC];
 #pragma unroll
@@ -1679,6 +1680,8 @@ __device__ __forceinline__ bool knn_point_cached(const float4* __restrict__ P, i
     const int4 o = L[j >> 2];
     idx[j] = o.x; idx[j + 1] = o.y; idx[j + 2] = o.z; idx[j + 3] = o.w;
   }
+  if (idx[0] >= 0) return false;  // no certificate (kListCertified): on the todo list
+  idx[0] &= ~kListCertified;
 #pragma unroll
   for (int j = 0; j < KC; j++) idx[j] = df.cache.pos_of[idx[j]];
 #pragma unroll
@@ -2062,27 +2065,30 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
   }
   bool cached = false;
   if constexpr (kSeeded) {
-    // The neighbour-list cache (KnnCache).  An unchanged map: the launch's FIRST cache_nb workgroups search the queries k_rank_gather
-    // listed (the ones without a certificate: whole waves of them, started first because they live ten times longer), the others take
-    // the certified queries' neighbours from their lists (knn_point_cached) and skip the rest.  A map that changed this frame (its first
-    // frame, a buffer rewritten in place): everything is searched by the workgroups behind the first cache_nb, as without the cache.
+    // The neighbour-list cache (KnnCache).  An unchanged map: the launch's FIRST cache_nb workgroups search the queries on the todo lists
+    // (the ones without a certificate: whole waves of them, started first because they live ten times longer), the others take the
+    // certified queries' neighbours from their lists (knn_point_cached) and skip the rest.  A frame that rebuilds the lists (cache_redo:
+    // the map's first frame, a buffer rewritten in place): everything is searched by the workgroups behind the first cache_nb, as
+    // without the cache, and every search leaves its list and certificate -- or its query on a todo list.
     if (df.cache.nbr) {
-      const bool changed = *df.cache.epoch == df.cache.frame;
+      const bool redo = cache_redo(df.cache);
       if (b < df.cache_nb) {
-        if (changed) return;
+        if (redo) return;
+        Deferred dfb = df;
+        dfb.cache.nbr = nullptr;  // (these searches leave the lists alone: who is on a todo list stays there until the next rebuild)
         // list l = b % kTodoLists, T entries at a time, dealt to the list's workgroups
         const int l = b % kTodoLists, per = df.cache_nb / kTodoLists;
-        const int cnt = df.cache.todo_cnt[l];  // (<= todo_cap: an overflow has set `changed`, k_rank_gather)
+        const int cnt = min(df.cache.todo_cnt[l], df.cache.todo_cap);
         for (int e = (b / kTodoLists) * Cfg::T + (int)threadIdx.x; e < cnt; e += per * Cfg::T) {
-          const int q = df.cache.todo[(size_t)l * df.cache.todo_cap + e];
-          if (!knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, q, slist_sp + threadIdx.x, df, nx, ny, nz))
-            knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, q, slist_sp + threadIdx.x, df, nx, ny, nz);
+          const int q = df.cache.pos_of[df.cache.todo[(size_t)l * df.cache.todo_cap + e]];
+          if (!knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, q, slist_sp + threadIdx.x, dfb, nx, ny, nz))
+            knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, q, slist_sp + threadIdx.x, dfb, nx, ny, nz);
         }
         return;
       }
       b -= df.cache_nb;  // (a multiple of 8: the XCD of a workgroup is still b & 7)
       slot = b >> 3;
-      cached = !changed;
+      cached = !redo;
     }
   }
   const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
@@ -4072,8 +4078,8 @@ void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, in
     hipLaunchKernelGGL(k_cells_scan_write<false>, dim3(nb), dim3(SCAN_T), 0, s, cnt, start, n, bs, nb, cell_voxel, nvox, hi);
   }
 }
-void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi, int* zero64) {
-  hipLaunchKernelGGL(k_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, slot_of, start, order_tmp, hi, zero64);
+void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi, const KnnCache* cache) {
+  hipLaunchKernelGGL(k_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, slot_of, start, order_tmp, hi, cache ? *cache : KnnCache{});
 }
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums, int hi) {
   const int nb = nblk(n, SCAN_B);
@@ -4084,9 +4090,8 @@ void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_su
   }
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const unsigned long long* order_tmp, float4* P, int* zero_me, int hi, const KnnCache* cache, const float* seed) {
-  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi,
-                     cache ? *cache : KnnCache{}, seed);
+                 const unsigned long long* order_tmp, float4* P, int* zero_me, int hi, int* pos_of) {
+  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi, pos_of);
 }
 size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 

@@ -7,6 +7,6 @@ for v in 0 1; do
 RGC_KNN_CACHE=$v timeout 200 python scripts/lab_seeded.py 1000000 6 2>/dev/null | python -c "
 import sys, json
 rows=[json.loads(l) for l in sys.stdin if l.startswith('{')]
-print('cache=$v', 'first', rows[0]['ms']['knn_cov_target'], 'later', [r['ms']['knn_cov_target'] for r in rows[2:]], 'grid', [r['ms'].get('grid') for r in rows[2:4]])"
+print('cache=$v', 'searched', [r.get('searched') for r in rows[:3]], 'first', rows[0]['ms']['knn_cov_target'], 'later', [r['ms']['knn_cov_target'] for r in rows[2:]], 'grid', [r['ms'].get('grid') for r in rows[1:4]])"
 done
 done

@@ -31,7 +31,7 @@ for f in range(frames):
     v.setInputTargetReframed(d_map, nt, 16, q, t, d_body)
     v.synchronize()
     p = v.profile()
-    row = {"frame": f, "ms": {k: round(x["total_ms"], 4) for k, x in p.items() if x["launches"]}, "deferred": v.stats()["deferred_target"]}
+    row = {"frame": f, "ms": {k: round(x["total_ms"], 4) for k, x in p.items() if x["launches"]}, "deferred": v.stats()["deferred_target"], "searched": v.stats()["searched_target"]}
     if lab:
         lib.rgc_lab_iters(v._h, it.ctypes.data)
         lib.rgc_lab_declines(v._h, decl.ctypes.data)
