@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <unordered_set>
@@ -54,6 +55,12 @@ constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 #endif
 #ifndef RGC_KNN_SEEDS
 #define RGC_KNN_SEEDS 1        // 0: the map's exact search never starts from the previous search's k-th distances (round 4)
+#endif
+#ifndef RGC_PREP_EVENT_EXT
+#define RGC_PREP_EVENT_EXT 1
+#endif
+#ifndef RGC_JOIN_SPIN_US
+#define RGC_JOIN_SPIN_US 300
 #endif
 #ifndef RGC_KNN_CACHE
 #define RGC_KNN_CACHE 1        // 0: no neighbour lists (rgck::KnnCache): every frame searches the whole map, seeded
@@ -114,13 +121,14 @@ struct Cloud {
   bool seed_warm = false;  // ... and some search has written them
   float seed_slack = 0.f;
   // the neighbour-list cache on top of the seeds (rgck::KnnCache): the same key, the same life
-  DevBuf nbr, pos_of, map_copy, todo, cache_small;  // cache_small: kTodoLists list lengths, the epoch word, the overflow word
+  DevBuf nbr, rank_of, pos_of, qrank, map_copy, todo, cache_small;  // cache_small: kTodoLists list lengths, the epoch word, the overflow word
   bool cache_on = false;    // this preparation compares the map with map_copy and its searches read / write the lists
   bool cache_live = false;  // the LAST preparation's searches ran with the lists attached (otherwise they are stale: the next frame starts over)
   int cache_frame = 0;
   int cache_e2 = 0;         // binary exponent of the largest coordinate the certificates were issued for
   int cache_e2_low = 0;     // frames in a row whose coordinates stayed below it
   int todo_cap = 0;
+  bool prepared_recorded = false;  // the preparation's last launch carried the context's tgt_prepared event (no record packet behind it)
   bool cache_searched_lists = false;  // the last preparation's search was the seeded launch that reads the lists (rgc_stats::searched_target)
 };
 
@@ -194,6 +202,8 @@ struct rgc_ctx {
   bool solve_behind_map = RGC_SOLVE_BEHIND_MAP != 0;  // (build flag) 0: the solve always on the scan's (high-priority) stream, as in round 2
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
+  bool prep_event_ext = RGC_PREP_EVENT_EXT != 0;  // (build flag; RGC_PREP_EVENT_EXT in the environment) the map's last launch signals tgt_prepared itself
+  int join_spin_us = RGC_JOIN_SPIN_US;  // (build flag; RGC_JOIN_SPIN_US in the environment) how long the host waits for an almost-ready scan instead of putting a barrier into the map's stream (join_source)
   bool cache_on = RGC_KNN_CACHE != 0;  // (build flag; RGC_KNN_CACHE=0 in the environment) the neighbour lists of an unchanged map on top of the seeds
   bool seeds_on = RGC_KNN_SEEDS != 0;  // (build flag; RGC_KNN_SEEDS=0 in the environment) 0: every search of a re-framed map starts without a bound, as before round 5
   double src_res = RGC_SRC_RES;  // (build flag) fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
@@ -507,6 +517,8 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
         const size_t cap = (size_t)std::max(256, n / (4 * rgck::kTodoLists) + 1);
         if ((rc = ensure(c, cl.nbr, sizeof(int) * (size_t)n * 20))) return rc;
         if ((rc = ensure(c, cl.pos_of, sizeof(int) * (size_t)n))) return rc;
+        if ((rc = ensure(c, cl.rank_of, sizeof(int) * (size_t)n))) return rc;
+        if ((rc = ensure(c, cl.qrank, sizeof(int) * (size_t)n))) return rc;
         if ((rc = ensure(c, cl.map_copy, sizeof(float4) * (size_t)n))) return rc;
         if ((rc = ensure(c, cl.todo, sizeof(int) * cap * rgck::kTodoLists))) return rc;
         if ((rc = ensure(c, cl.cache_small, sizeof(int) * (rgck::kTodoLists + 16)))) return rc;
@@ -639,7 +651,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     rgck::place(s, n, (const int*)cl.cell_of.p, (const int*)cl.slot_of.p, (const int*)cl.start.p, (unsigned long long*)cl.order_tmp.p, hi,
                 with_cache ? &sd.cache : nullptr);
     rgck::rank_gather(s, cl.in, cl.stride_f, n, (const int*)cl.cell_of.p, (const int*)cl.start.p, (const unsigned long long*)cl.order_tmp.p,
-                      (float4*)cl.P.p, (int*)cl.segs.p, hi, with_cache ? sd.cache.pos_of : nullptr);
+                      (float4*)cl.P.p, (int*)cl.segs.p, hi, with_cache ? &sd.cache : nullptr);
   }
   cl.lazy = 0;
   if (is_target && &cl == &c->tgt && c->lazy_margin > 0 && !c->lm_host && map_wide_r_of(c, cl) == 0) {
@@ -656,6 +668,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     cl.ready = true;
     return RGC_OK;
   }
+  cl.prepared_recorded = false;
   {
     int rc = cloud_covariances(c, cl, is_target);
     if (rc) return rc;
@@ -664,7 +677,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
   if (!is_target) {
     HIPCHK(c, hipEventRecord(c->src_ready, s));
     c->src_pending = true;
-  } else {
+  } else if (!cl.prepared_recorded) {  // (otherwise the map's last launch carries the event, cloud_covariances)
     HIPCHK(c, hipEventRecord(c->tgt_prepared, s));
   }
   cl.ready = true;
@@ -679,6 +692,8 @@ rgck::KnnSeeds cloud_seeds(const Cloud& cl, bool is_target) {
       rgck::KnnCache& kc = sd.cache;
       kc.nbr = (int*)cl.nbr.p;
       kc.pos_of = (int*)cl.pos_of.p;
+      kc.rank_of = (int*)cl.rank_of.p;
+      kc.qrank = (int*)cl.qrank.p;
       kc.todo = (int*)cl.todo.p;
       kc.todo_cnt = (int*)cl.cache_small.p;
       kc.epoch = (int*)cl.cache_small.p + rgck::kTodoLists;
@@ -754,7 +769,9 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
                              (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p, k, cl.segs.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves,
                              cloud_seeds(cl, true));
       rgck::voxel_patch(s, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
-                        cl.grid, cl.segs.p, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 64 : n);
+                        cl.grid, cl.segs.p, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, cl.deferred_seen >= 0 ? 2 * cl.deferred_seen + 64 : n,
+                        (c->prep_event_ext && &cl == &c->tgt) ? c->tgt_prepared : nullptr);
+      cl.prepared_recorded = c->prep_event_ext && &cl == &c->tgt;
     }
     cl.nvox = -1;  // fetched lazily
   }
@@ -901,7 +918,20 @@ int join_source(rgc_ctx* c) {
   if (c->src_pending) {
     // (a scan prepared ahead -- two contexts taking turns -- has usually finished by now: then no barrier packet goes into the main
     // stream at all; a dependency that has to be resolved across streams costs ~10 us in front of the kernel behind it, even a met one)
-    if (hipEventQuery(c->src_ready) != hipSuccess) {
+    // A scan that is ALMOST ready -- two contexts taking turns: its cooperative search is still running beside the map's preparation --
+    // is waited for here, on the host, for as long as the map's preparation is still running anyway (bounded: join_spin_us): the solve's
+    // launches are not needed in the queue before that, and the host has nothing else to do until the solve ends.
+    bool ready = hipEventQuery(c->src_ready) == hipSuccess;
+    if (!ready && c->join_spin_us > 0) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        (void)hipGetLastError();
+        if (hipEventQuery(c->src_ready) == hipSuccess) { ready = true; break; }
+        if (map_prep_finished(c)) break;
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > (double)c->join_spin_us) break;
+      }
+    }
+    if (!ready) {
       (void)hipGetLastError();  // ("not ready" is an answer, not an error to be found by a later check)
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->src_ready, 0));
     }
@@ -1418,6 +1448,8 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_KNN_SEEDS")) c->seeds_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_KNN_CACHE")) c->cache_on = atoi(e) != 0;
+  if (const char* e = getenv("RGC_JOIN_SPIN_US")) c->join_spin_us = atoi(e);
+  if (const char* e = getenv("RGC_PREP_EVENT_EXT")) c->prep_event_ext = atoi(e) != 0;
   if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   { std::lock_guard<std::mutex> lk(g_live_mutex); g_live.insert(c); }

@@ -47,19 +47,23 @@ struct Quat { double x, y, z, w; };
 struct Reframe { const float* src; int src_stride_f; Quat q; double t[3]; float4* copy; int* epoch; int frame; int force; };
 // The neighbour-list cache of a map that is handed over by rgc_set_target_reframed again and again (round 5, second half).  A rigid
 // re-expression does not change who a point's k nearest neighbours are -- only the fp32 rounding of the coordinates can, and only where
-// the k-th and the (k+1)-th neighbour (or the edge of what the 3x3x3 block proves) are that close.  Per ORIGINAL point: the k neighbours'
-// original indices as the last exact search found them (nbr, 4 k bytes), the top bit of the first one a CERTIFICATE: the gap behind the
+// the k-th and the (k+1)-th neighbour (or the edge of what the 3x3x3 block proves) are that close.  Points are named by their RANK: the
+// position in the sorted array of the frame that built the lists (neighbours have nearby ranks in every later frame too: look-ups by rank
+// are as local as look-ups by position).  Per rank: the k neighbours' ranks as that frame's exact search found them (nbr, 4 k bytes), the
+// top bit of the first one a CERTIFICATE: the gap behind the
 // k-th neighbour exceeded what rounding in any two frames can bridge (list_certified).  A certified query of an unchanged map takes its
 // neighbours from the list (knn_point_cached: no search); the others -- on the todo lists since the frame that built the lists -- are
 // searched exactly as before.  "Unchanged" is verified, not assumed: the counting pass compares the map with the library's own copy, bit
 // for bit (Reframe); a frame that finds a difference searches everything and builds the lists again.
 struct KnnCache {
-  int* nbr = nullptr;        // [n][k] original indices of the k nearest neighbours of original point o, in no particular order
-  int* pos_of = nullptr;     // [n] this frame's position of original point o in the sorted array (k_rank_gather)
+  int* nbr = nullptr;        // [n][k] ranks of the k nearest neighbours of the point of rank r, in no particular order
+  int* rank_of = nullptr;    // [n] rank of original point o (written by the frame that builds the lists, k_rank_gather)
+  int* pos_of = nullptr;     // [n] this frame's position of rank r in the sorted array (k_rank_gather)
+  int* qrank = nullptr;      // [n] ... and the rank of the point at position i
   const int* epoch = nullptr;  // *epoch == frame: the map changed this frame (or the lists are not trusted)
   int* overflow = nullptr;   // *overflow == frame - 1: the previous frame's rebuild ran out of room in a todo list: rebuild again
   int frame = 0;
-  int* todo = nullptr;       // kTodoLists lists of ORIGINAL indices of the queries without a certificate, todo_cap entries each
+  int* todo = nullptr;       // kTodoLists lists of ranks of the queries without a certificate, todo_cap entries each
   int* todo_cnt = nullptr;   // ... their lengths (emptied by k_place in a frame that rebuilds)
   int todo_cap = 0;
   float cert_slack = 0.f;    // metres: what the coordinates' fp32 rounding in two frames can move a distance by, twice (4 sqrt(3) ulp of the largest coordinate)
@@ -97,9 +101,9 @@ void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, in
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi = 0,
            const KnnCache* cache = nullptr /* its todo lists are emptied on the way in a frame that rebuilds them */);
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums /* >= n/2048+2 */, int hi = 0);
-// pos_of (nullable): KnnCache::pos_of, written on the way
+// cache (nullable): KnnCache::rank_of (a frame that builds the lists) or pos_of and qrank (any other), written on the way
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const unsigned long long* order_tmp, float4* P, int* zero_me = nullptr, int hi = 0, int* pos_of = nullptr);
+                 const unsigned long long* order_tmp, float4* P, int* zero_me = nullptr, int hi = 0, const KnnCache* cache = nullptr);
 // ---- C2: exact kNN + PLANE covariance -> unit normal ----
 // bulk kernel (one lane per query; defers what it cannot finish) then the cooperative kernel (one wave per deferred query).
 // deferred: deferred_bytes(n) bytes, whose first int (the count) must be 0 on entry (rank_gather's zero_me)
@@ -142,7 +146,7 @@ void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, do
 // the voxels that hold a deferred query, recomputed: lets the cooperative search run BESIDE voxel_build; lanes: about
 // the number of deferred queries (grid-stride loop)
 void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g, const void* deferred,
-                 const int* cell_voxel, double* vox, int lanes);
+                 const int* cell_voxel, double* vox, int lanes, hipEvent_t done = nullptr /* signalled by the launch's own completion */);
 // ---- C4/C5/C6 ----
 void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
                const int* cell_voxel, const double* vox, int noff, int* corr_v, double* corr_M, int want_H, double* partials,

@@ -559,7 +559,7 @@ __global__ void k_place(int n, const int* __restrict__ cell_of, const int* __res
 // Sorted points are stored as float4 {x, y, z, original index (int bits)}: one 16-byte load per candidate; P holds n + 4 entries.
 __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n, const int* __restrict__ cell_of,
                               const int* __restrict__ start, const unsigned long long* __restrict__ order_tmp, float4* __restrict__ P, int* zero_me,
-                              int prio, int* __restrict__ pos_of) {
+                              int prio, KnnCache kc) {
   wave_prio(prio);
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s == 0 && zero_me) { zero_me[0] = 0; zero_me[1] = 0; zero_me[2] = 0; }  // the deferred-query counter of the kNN launch that follows, and the lazy target's two list sizes behind it
@@ -567,6 +567,11 @@ __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n,
   if (s >= n) return;
   const unsigned long long rec = order_tmp[s];
   const int i = (int)(rec & kOrdIdxMask);
+  // the neighbour-list cache (nullable): a frame that rebuilds the lists makes this frame's position the point's RANK; any other frame
+  // says where each rank sits now (pos_of) and which rank each position holds (qrank)
+  const bool ranked = kc.nbr && !cache_redo(kc);
+  int my_rank = 0;
+  if (ranked) my_rank = kc.rank_of[i];  // (its round trip overlaps the cell members' below)
   const int cnt = (int)(rec >> (kOrdIdxBits + kOrdCntBits)) & kOrdCntMax;
   int s0, s1;
   if (cnt > 0) {
@@ -598,7 +603,10 @@ __global__ void k_rank_gather(const float* __restrict__ in, int stride_f, int n,
     for (int u = 0; u < 7; u++) rank += (t + u < s1 && (int)(o[u] & kLoMask) < i);
   }
   P[s0 + rank] = make_float4(px, py, pz, __int_as_float(i));
-  if (pos_of) pos_of[i] = s0 + rank;  // the neighbour-list cache (KnnCache): where original point i sits this frame
+  if (kc.nbr) {
+    if (ranked) { kc.pos_of[my_rank] = s0 + rank; kc.qrank[s0 + rank] = my_rank; }
+    else kc.rank_of[i] = s0 + rank;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1093,33 +1101,30 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
 // centred sum up to rounding (|u| <= a few cells, so nothing cancels badly), half the gathers of the two-pass form.
 // kFull (k == KC, the reference's k = 20) runs without per-neighbour guards: a load under a branch is waited for where the branch
 // ends, which would serialise the gathers.
-// nbr_out (nullable, kFull only): the neighbours' ORIGINAL indices (P.w) are stored there, 16 bytes at a time (the cache's list of this
-// query), nbr_flag (0 or kListCertified) in the first one's top bit
+// nbr_out (nullable, kFull only): the neighbours' positions are stored there, 16 bytes at a time (the cache's list of this query: in the
+// frame that builds the lists a point's position is its RANK, KnnCache), nbr_flag (0 or kListCertified) in the first one's top bit
 template <int KC, bool kFull>
 __device__ __forceinline__ void sp_normal_of(const float4* __restrict__ P, const int (&idx)[KC], float px, float py, float pz, int k, int i,
                                              double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz, int* __restrict__ nbr_out = nullptr,
                                              int nbr_flag = 0) {
   double S[6] = {0, 0, 0, 0, 0, 0};
-  int ow[KC];
+  if constexpr (kFull && KC % 4 == 0) {
+    if (nbr_out) {
+#pragma unroll
+      for (int j = 0; j < KC; j += 4) *reinterpret_cast<int4*>(nbr_out + j) = make_int4(idx[j] | (j == 0 ? nbr_flag : 0), idx[j + 1], idx[j + 2], idx[j + 3]);
+    }
+  }
   const double qx = (double)px, qy = (double)py, qz = (double)pz;
   double mx = 0, my = 0, mz = 0;
 #pragma unroll
   for (int j = 0; j < KC; j++) {
     if (kFull || j < k) {
       const float4 cp = point_at(P, (unsigned)idx[j] << 4);
-      ow[j] = __float_as_int(cp.w);
       const double dx = (double)cp.x - qx, dy = (double)cp.y - qy, dz = (double)cp.z - qz;
       mx += dx; my += dy; mz += dz;
       // (explicit fma: the file is compiled without contraction for the sake of dist2(); these sums have no such constraint)
       S[0] = fma(dx, dx, S[0]); S[1] = fma(dx, dy, S[1]); S[2] = fma(dx, dz, S[2]);
       S[3] = fma(dy, dy, S[3]); S[4] = fma(dy, dz, S[4]); S[5] = fma(dz, dz, S[5]);
-    }
-  }
-  if constexpr (kFull && KC % 4 == 0) {
-    if (nbr_out) {
-      ow[0] |= nbr_flag;
-#pragma unroll
-      for (int j = 0; j < KC; j += 4) *reinterpret_cast<int4*>(nbr_out + j) = make_int4(ow[j], ow[j + 1], ow[j + 2], ow[j + 3]);
     }
   }
   const double inv_k = 1.0 / (double)k;
@@ -1150,16 +1155,16 @@ __device__ __forceinline__ bool list_certified(float a_up, float b_lo, double bo
 }
 
 // A query that ends without a certificate -- no gap, or handed to the cooperative kernel -- while the lists are attached (a frame that
-// searches everything): its list says so, and it goes onto the todo list the later frames search (original index: the lists outlive the
-// frame's order).  ~3 % of the queries, an atomic each on one of kTodoLists words.
+// searches everything): its list says so, and it goes onto the todo list the later frames search (by rank = its position in this frame:
+// the lists outlive the frame's order).  ~1 % of the queries, an atomic each on one of kTodoLists words.
 constexpr int kListCertified = (int)0x80000000;
 template <int KC>
-__device__ __forceinline__ void cache_uncertified(const Deferred& df, int orig) {
+__device__ __forceinline__ void cache_uncertified(const Deferred& df, int rank) {
   if (!df.cache.nbr) return;
-  df.cache.nbr[(size_t)orig * KC] = 0;
+  df.cache.nbr[(size_t)rank * KC] = 0;
   const int l = (int)(blockIdx.x % kTodoLists);
   const int e = atomicAdd(&df.cache.todo_cnt[l], 1);
-  if (e < df.cache.todo_cap) df.cache.todo[(size_t)l * df.cache.todo_cap + e] = orig;
+  if (e < df.cache.todo_cap) df.cache.todo[(size_t)l * df.cache.todo_cap + e] = rank;
   else *df.cache.overflow = df.cache.frame;  // no room: the next frame searches everything again (cache_redo)
 }
 
@@ -1192,7 +1197,7 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
     const int e = atomicAdd(df.cnt, 1);
     df.idx[e] = enc;
     df.thr[e] = thr;
-    if constexpr (kExact && KC == 20) cache_uncertified<KC>(df, __float_as_int(pq.w));
+    if constexpr (kExact && KC == 20) cache_uncertified<KC>(df, i);
   };
   bool heavy_piece = false;
   const int nr = sp_piece_table<kClip, R, T>(start, g, c, q, tmix, tlo, heavy_piece);
@@ -1378,10 +1383,10 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
   const int orig = __float_as_int(pq.w);
   if constexpr (kExact && KC == 20) {
     // (the (k+1)-th candidate is a_k; when the exact distances swapped the two the gap is a key bucket or two: no certificate)
-    int* const nbr_out = df.cache.nbr ? df.cache.nbr + (size_t)orig * KC : nullptr;
+    int* const nbr_out = df.cache.nbr ? df.cache.nbr + (size_t)i * KC : nullptr;
     const bool cert = nbr_out && !swap && list_certified(thr_up, __int_as_float(a_k & ~kKeyOrd), bound, df.cache.cert_slack);
     sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz, cert ? nbr_out : nullptr, kListCertified);
-    if (!cert) cache_uncertified<KC>(df, orig);
+    if (!cert) cache_uncertified<KC>(df, i);
   } else {
     if (kExact || k == KC) sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz);
     else sp_normal_of<KC, false>(P, idx, px, py, pz, k, i, nx, ny, nz);
@@ -1563,7 +1568,7 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
       const int e = atomicAdd(df.cnt, 1);
       df.idx[e] = ~i;
       df.thr[e] = rs * rs * 1.000001f;
-      cache_uncertified<KC>(df, orig);
+      cache_uncertified<KC>(df, i);
       return true;
     }
     LAB_DECLINE(3);
@@ -1637,14 +1642,14 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
     const int e = atomicAdd(df.cnt, 1);
     df.idx[e] = ~i;
     df.thr[e] = (double)thr_up < 3.0 * (R + 1) * (R + 1) * g.res * g.res ? thr_up : INFINITY;
-    cache_uncertified<KC>(df, orig);
+    cache_uncertified<KC>(df, i);
     return true;
   }
   if (undecided) {
     const int e = atomicAdd(df.cnt, 1);
     df.idx[e] = i;
     df.thr[e] = thr_up;
-    cache_uncertified<KC>(df, orig);
+    cache_uncertified<KC>(df, i);
     return true;
   }
   int idx[KC];
@@ -1652,18 +1657,18 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
   for (int j = 0; j < KC; j++) idx[j] = index_of(j >= drop ? w[j + 1] : w[j]);
   // the (k+1)-th candidate: exactly k admitted -- anything not admitted, >= tkey; k + 1 admitted -- the dropped key, mx (when the exact
   // distances made mx the k-th instead, the two are a key bucket or two apart: no certificate)
-  int* const nbr_out = df.cache.nbr ? df.cache.nbr + (size_t)orig * KC : nullptr;
+  int* const nbr_out = df.cache.nbr ? df.cache.nbr + (size_t)i * KC : nullptr;
   const bool cert = nbr_out && (!extra || kth_key == mx2) &&
                     list_certified(thr_up, __int_as_float((extra ? mx : tkey) & ~kKeyOrd), bound, df.cache.cert_slack);
   sp_normal_of<KC, true>(P, idx, px, py, pz, KC, i, nx, ny, nz, cert ? nbr_out : nullptr, kListCertified);
-  if (!cert) cache_uncertified<KC>(df, orig);
+  if (!cert) cache_uncertified<KC>(df, i);
   df.seed[orig] = thr_up;
   return true;
 }
 
 // ------------------------------------------------------------------------------------------------
 // A certified query of an unchanged map (KnnCache): its k neighbours are the ones its last exact search found -- their ORIGINAL indices
-// are in the list, their positions in this frame's sorted array in pos_of[].  No search: twenty look-ups, the positions put into ascending
+// -- by rank -- are in the list, their positions in this frame's sorted array in pos_of[].  No search: twenty look-ups, the positions put into ascending
 // order (the order every route sums the moments in: the same bits as a search would give), the moments.  Returns false -- nothing done --
 // for a query without a certificate (it is on a todo list: searched by the launch's first workgroups, k_knn_sp).
 // ------------------------------------------------------------------------------------------------
@@ -1672,8 +1677,7 @@ __device__ __forceinline__ bool knn_point_cached(const float4* __restrict__ P, i
                                                  double* __restrict__ ny, double* __restrict__ nz) {
   static_assert(KC == 20, "the position sort is a 20-input network");
   const float4 pq = P[i];
-  const int orig = __float_as_int(pq.w);
-  const int4* const L = reinterpret_cast<const int4*>(df.cache.nbr + (size_t)orig * KC);
+  const int4* const L = reinterpret_cast<const int4*>(df.cache.nbr + (size_t)df.cache.qrank[i] * KC);
   int idx[KC];
 #pragma unroll
   for (int j = 0; j < KC; j += 4) {
@@ -4090,8 +4094,9 @@ void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_su
   }
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
-                 const unsigned long long* order_tmp, float4* P, int* zero_me, int hi, int* pos_of) {
-  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi, pos_of);
+                 const unsigned long long* order_tmp, float4* P, int* zero_me, int hi, const KnnCache* cache) {
+  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi,
+                     cache ? *cache : KnnCache{});
 }
 size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 
@@ -4213,9 +4218,11 @@ void voxel_build_coop(hipStream_t s, const float4* P, double* nx, double* ny, do
   else hipLaunchKernelGGL((k_voxel_build_coop<32>), dim3(nbv + nbc), dim3(VOX_T), 0, s, P, nx, ny, nz, start, g, n, cell_voxel, vox, vox_cell, nbc, k, df);
 }
 void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, const int* start, Grid g, const void* deferred,
-                 const int* cell_voxel, double* vox, int lanes) {
+                 const int* cell_voxel, double* vox, int lanes, hipEvent_t done) {
   const int nb = lanes < 64 ? 64 : (lanes > 4096 ? 4096 : lanes);  // one-wave workgroups, one deferred entry each (grid-stride beyond)
-  hipLaunchKernelGGL(k_voxel_patch, dim3(nb), dim3(WAVE), 0, s, P, nx, ny, nz, start, g, (const int*)deferred, cell_voxel, vox);
+  // (done: the launch's own completion is the event -- no record packet between the map's last kernel and the solve's first step)
+  if (done) hipExtLaunchKernelGGL(k_voxel_patch, dim3(nb), dim3(WAVE), 0u, s, nullptr, done, 0u, P, nx, ny, nz, start, g, (const int*)deferred, cell_voxel, vox);
+  else hipLaunchKernelGGL(k_voxel_patch, dim3(nb), dim3(WAVE), 0, s, P, nx, ny, nz, start, g, (const int*)deferred, cell_voxel, vox);
 }
 void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
                const int* cell_voxel, const double* vox, int noff, int* corr_v, double* corr_M, int want_H, double* partials,
