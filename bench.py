@@ -664,6 +664,19 @@ def main():
         seq.frame_target(v, worlds[j % len(worlds)])
         v.synchronize()
     dom_alone = v.profile()[DOMINANT]
+    searched_alone = int(v.stats()["searched_target"])
+    # ... the same launch when the map's buffer has changed since the frame before (one coordinate of one point, in place: the library
+    # compares the map with its own copy, every query is searched again -- seeded -- and the neighbour lists are rebuilt)
+    v.profile_reset()
+    one = np.zeros((1, 4), np.float32); one[0, :3] = maps[0][7]
+    orig_one = one.copy()
+    for j in range(5):
+        one[0, 2] = np.nextafter(one[0, 2], np.float32(1e9))
+        v.upload(seq.d_map + 7 * 16, one)
+        seq.frame_target(v, worlds[j % len(worlds)])
+        v.synchronize()
+    dom_alone_changed = v.profile()[DOMINANT]
+    v.upload(seq.d_map + 7 * 16, orig_one)
     v.profile_reset()
     for j in range(5):
         v.setInputTargetDevice(d_maps[j % len(maps)], tgt.shape[0], 16)
@@ -720,6 +733,10 @@ def main():
                  "peak_full_rate_measured": 1060.0, "peak_half_rate_measured": 595.0, "peak_2cyc_at_2.4GHz": 1228.8}
         issue["valu_per_query_source"] = pmc_src
         mix, mix_src = profile_json(MIX_FILE)
+        if pmc.get("launch") == "lists":  # (the committed mix describes the seeded SEARCH; the timed launch mostly reads neighbour lists: no mix-weighted peak for it)
+            mix = None
+            issue["what"] = ("VALU wave-instructions per query of the timed launch (certified queries from their neighbour lists, the rest searched) "
+                             "against the measured full-rate issue peak; the executed mix of the searches is in profiles/*_knn_isa_mix*.json")
         if mix and mix.get("half_rate_fraction") is not None:
             issue["half_rate_fraction_source"] = mix_src
             h = float(mix["half_rate_fraction"])
@@ -740,10 +757,16 @@ def main():
     if alone_ms > 0:  # the timed region runs the launch beside the next scan's kernels; alone it is shorter
         roofline["launch_alone_ms"] = round(alone_ms, 4)
         roofline["frac_launch_alone"] = round(per_unit * units / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+        roofline["launch_alone_changed_map_ms"] = round(dom_alone_changed["total_ms"] / max(dom_alone_changed["launches"], 1), 4)
         roofline["launch_alone_unseeded_ms"] = round(dom_alone_unseeded["total_ms"] / max(dom_alone_unseeded["launches"], 1), 4)
-        roofline["what"] = ("the map's bulk 20-NN + covariance launch; the timed region re-frames one persistent map, so every search but a point's first "
-                            "starts from the k-th distance its last search found (knn_point_seeded, exact whatever the seed); launch_alone_unseeded_ms is "
-                            "the same launch for a map the library has not seen before")
+        roofline["queries_searched_per_launch"] = searched_alone
+        roofline["what"] = ("the map's bulk 20-NN + covariance launch; the timed region re-frames one persistent map, which the library verifies to be "
+                            "bit for bit the map of the frame before (its counting pass compares it with its own copy): a query whose neighbour list "
+                            "carries a certificate -- the gap behind its 20th neighbour exceeds what fp32 rounding in two frames can bridge -- takes its "
+                            "neighbours from the list (knn_point_cached), the others (queries_searched_per_launch) are searched, seeded with the k-th "
+                            "distance their last search found (knn_point_seeded, exact whatever the seed); launch_alone_changed_map_ms is the launch after "
+                            "the buffer was written to (everything searched, seeded, lists rebuilt), launch_alone_unseeded_ms the launch for a map the "
+                            "library has not seen before")
         if issue and issue.get("peak_mix_weighted"):
             issue["frac_of_mix_weighted_peak_launch_alone"] = round(issue["valu_wave_instructions_per_query"] * units / (alone_ms * 1e-3) / 1e9
                                                                     / issue["peak_mix_weighted"], 4)

@@ -234,6 +234,13 @@ RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stri
  * does NOT depend on what the seeds hold: a search that does not find exactly its k neighbours under the bound (a buffer rewritten in
  * place, a different cloud at the same address) is repeated without it, so "fixed between calls" is what makes the call fast, not what
  * makes it right.  Covariances are bit-identical with and without seeds (RGC_KNN_SEEDS=0 in the environment switches them off).
+ * Neighbour lists (round 5): on top of the seeds the library keeps, per point, the 20 neighbours its last exact search found and its OWN
+ * COPY of the map (112 bytes per point in all).  Every call compares d_xyzi with that copy, bit for bit, in the pass that re-frames it;
+ * when nothing differs (and q is a unit quaternion to 2.5e-7), a point whose list carries a certificate -- the gap behind its 20th
+ * neighbour is wider than the fp32 rounding of the coordinates in any two frames can bridge -- takes its neighbours from the list instead
+ * of searching (about 99 % of a map; rgc_stats::searched_target counts the rest); one differing coordinate and the call searches every
+ * point again and rebuilds the lists.  The result is the search's, bit for bit, either way (RGC_KNN_CACHE=0 switches the lists off).
+ * A lazy target (rgc_set_target_lazy) keeps seeds but no lists.
  * Preconditions: d_scratch must not overlap d_xyzi (RGC_ERR_INVALID: the input is read while the output is written, and a buffer has
  * one bounding-box hint); a d_scratch that is 16-byte aligned (anything hipMalloc / rgc_device_alloc returns) takes the fused path
  * -- re-framing inside the preparation's counting pass -- any other 4-byte aligned address the re-framing runs as its own launch. */

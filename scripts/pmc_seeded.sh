@@ -1,25 +1,36 @@
 #!/bin/bash
-# Counters of the map's bulk kNN launch, unseeded and seeded, over scripts/prof_frame_reframed.py: separate rocprofv3 --pmc passes,
+# Counters of the map's bulk kNN launch -- with the neighbour lists (the product), seeded without them, unseeded -- over scripts/prof_frame_reframed.py: separate rocprofv3 --pmc passes,
 # per-kernel averages into gpurun_out/pmc_seeded.json.      usage: bash scripts/pmc_seeded.sh ["extra counter sets" ...]
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc_seeded
 rm -rf $O; mkdir -p $O
 SETS=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "$@")
-for set in "${SETS[@]}"; do
-  d=$O/$(echo $set | tr ' ' '_')
-  rocprofv3 --pmc $set -d $d -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prof_frame_reframed.py 1000000 5 > $d.log 2>&1 || tail -3 $d.log
+# two sweeps: the product as it runs (neighbour lists on: launches 2..5 take certified queries' neighbours from their lists and search the
+# rest), and with RGC_KNN_CACHE=0 (every launch searches every query, seeded: what a frame runs after the map's buffer was written to)
+for mode in lists nolists; do
+  if [ $mode = nolists ]; then export RGC_KNN_CACHE=0; else unset RGC_KNN_CACHE; fi
+  for set in "${SETS[@]}"; do
+    d=$O/$mode/$(echo $set | tr ' ' '_')
+    mkdir -p $O/$mode
+    rocprofv3 --pmc $set -d $d -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prof_frame_reframed.py 1000000 5 > $d.log 2>&1 || tail -3 $d.log
+  done
 done
+unset RGC_KNN_CACHE
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, json, collections, os
 root = os.environ["GRAFT_REPO_ROOT"]
 O = os.path.join(root, "gpurun_out", "pmc_seeded")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(O, "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        kn = r["Kernel_Name"]
-        if "k_knn_sp<20, true, true" in kn:
-            acc["seeded" if "true, true, true" in kn else "unseeded"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for mode in ("lists", "nolists"):
+    for f in glob.glob(os.path.join(O, mode, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            kn = r["Kernel_Name"]
+            if "k_knn_sp<20, true, true" in kn:
+                if "true, true, true" in kn:
+                    acc["lists" if mode == "lists" else "seeded"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                elif mode == "lists":
+                    acc["unseeded"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 hc = os.path.join(root, ".head_commit")
 out = {"commit": open(hc).read().strip() if os.path.exists(hc) else None, "queries_per_launch": 1000000}
 for which, cs in acc.items():
@@ -32,11 +43,13 @@ for which, cs in acc.items():
                        ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "vmem_rd_per_valu"), ("SQ_INST_CYCLES_VMEM", "SQ_BUSY_CYCLES", "vmem_inst_cycles_per_busy_cycle")):
         if a in m and b in m and m[b]: o[name] = round(m[a] / m[b], 4)
     out[which] = o
-# the seeded launch (what a re-framed persistent map runs from its second frame on: the bench's dominant kernel) at the top level, in the
-# layout bench.py / sync_docs.py read; the full search of the same map beside it under "unseeded"
-if "seeded" in out:
-    top = dict(out.pop("seeded"))
-    top["kernel"] = "k_knn_sp<20, true, true, true> (1000000 queries per launch; seeded: scripts/prof_frame_reframed.py, launches 2..5)"
+# the launch of the bench's timed region (a re-framed persistent map from its second frame on: neighbour lists + the search of the
+# uncertified queries) at the top level, in the layout bench.py / sync_docs.py read; beside it "seeded" (the same kernel with the lists
+# off: every query searched, what a frame runs after a write to the map) and "unseeded" (the full search: a map the library has not seen)
+if "lists" in out:
+    top = dict(out.pop("lists"))
+    top["launch"] = "lists"
+    top["kernel"] = "k_knn_sp<20, true, true, true> (1000000 queries per launch; scripts/prof_frame_reframed.py, launches 2..5: certified queries from their neighbour lists, the rest searched)"
     out = {**top, **out}
 json.dump(out, open(os.path.join(root, "gpurun_out", "pmc_seeded.json"), "w"), indent=1)
 print(json.dumps(out))

@@ -10,13 +10,15 @@ rm -rf $O; mkdir -p $O
 # 1. counters and executed instruction mix of the dominant kernel FIRST: bench.py quotes them (traffic, VALU per query, mix-weighted peak)
 #    (round 5: the dominant launch is the SEEDED search of the re-framed map -- scripts/pmc_seeded.sh over scripts/prof_frame_reframed.py; the full
 #    search of the same map, a map the library has not seen, is in the same file under "unseeded")
-timeout 1200 bash scripts/pmc_seeded.sh "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum" > /dev/null 2>&1; cp gpurun_out/pmc_seeded.json $O/pmc_knn.json
-timeout 900 scripts/pmc_kernel.sh "k_knn_sp<20, false, true>" knn_src 30000 > /dev/null 2>&1; cp gpurun_out/pmc_knn_src.json $O/pmc_knn_src.json
+timeout 1800 bash scripts/pmc_seeded.sh "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum" > /dev/null 2>&1; cp gpurun_out/pmc_seeded.json $O/pmc_knn.json
+timeout 900 scripts/pmc_kernel.sh "k_knn_sp<20, false, true" knn_src 30000 > /dev/null 2>&1; cp gpurun_out/pmc_knn_src.json $O/pmc_knn_src.json
 #    loop trip counts from a developer build (-DRGC_LAB) beside the product, weights from the ISA of the product build
 RGC_EXTRA_FLAGS="-DRGC_LAB" RGC_LIB_OUT=/tmp/librgc_lab.so timeout 600 python3 rgc-slam_amd/build.py > /dev/null 2>&1
-RGC_HIP_LIB=/tmp/librgc_lab.so timeout 300 python3 scripts/isa_mix.py --collect > $O/lab_iters.log 2>&1; cp gpurun_out/lab_iters.json $O/lab_iters.json
-timeout 600 python3 scripts/isa_mix.py --seeded --lab $O/lab_iters.json --pmc $O/pmc_knn.json > $O/knn_isa_mix.json 2> $O/isa_mix.log
-python3 -c "import json; d=json.load(open('$O/pmc_knn.json')); json.dump(d['unseeded'], open('$O/pmc_knn_unseeded.json','w'), indent=1)"
+#    (the loop counts and the mix describe the SEARCHES -- seeded with the lists off, and unseeded; the launch with the lists on is
+#    straight-line code per certified query: its counters are in pmc_knn.json's top level)
+RGC_KNN_CACHE=0 RGC_HIP_LIB=/tmp/librgc_lab.so timeout 300 python3 scripts/isa_mix.py --collect > $O/lab_iters.log 2>&1; cp gpurun_out/lab_iters.json $O/lab_iters.json
+python3 -c "import json; d=json.load(open('$O/pmc_knn.json')); json.dump(d['seeded'], open('$O/pmc_knn_seeded.json','w'), indent=1); json.dump(d['unseeded'], open('$O/pmc_knn_unseeded.json','w'), indent=1)"
+timeout 600 python3 scripts/isa_mix.py --seeded --lab $O/lab_iters.json --pmc $O/pmc_knn_seeded.json > $O/knn_isa_mix.json 2> $O/isa_mix.log
 timeout 600 python3 scripts/isa_mix.py --lab $O/lab_iters.json --pmc $O/pmc_knn_unseeded.json > $O/knn_isa_mix_unseeded.json 2>> $O/isa_mix.log
 RGC_HIP_LIB=/tmp/librgc_lab.so timeout 300 python3 scripts/lab_seeded.py 1000000 4 > $O/lab_seeded.jsonl 2>&1
 # 2. frame-level traffic, measured (every kernel of a dependent frame): c-main always, c3 / c5 in the full run

@@ -66,15 +66,15 @@ def cfg_line(key, label):
             f"{x.get('max_dt_m', float('nan')):.1e} / {x.get('max_dtheta_rad', float('nan')):.1e} |\n")
 
 
-table = ("| config | scans/s, two contexts / one frame at a time | ms/scan | scans/s with the lazy target (two contexts) | algorithmic bytes ÷ time ÷ 8 TB/s | CPU oracle scans/s | max Δt (m) / Δθ (rad) vs oracle |\n"
+table = ("| config | scans/s: two contexts / one frame at a time | ms/scan | lazy target, scans/s | bytes ÷ time ÷ 8 TB/s | CPU oracle scans/s | max Δt (m) / Δθ (rad) vs oracle |\n"
          "|---|---|---|---|---|---|---|\n"
-         + cfg_line("c1", "c1 30 k vs 100 k, fixed map (15 outer iterations from the identity)")
+         + cfg_line("c1", "c1 30 k vs 100 k, fixed map")
          + f"| c-main 30 k vs 1 M, dependent | {d['value']:.0f} / {O['scans_per_s']:.0f} | {d['ms_per_step']} / {O['ms_per_step']} | {LZ.get('two_contexts', {}).get('scans_per_s', float('nan')):.0f} | {100 * d['hbm_frac_whole_frame']:.2f} % | "
            f"{cb['value']:.2f} at {cb['cores']} threads | {pp['max_dt_m']:.1e} / {pp['max_dtheta_rad']:.1e} ({pp['frames']} frames) |\n"
          + cfg_line("c3", "c3 HDL-64 130 k vs 5 M, dependent") + cfg_line("c5", "c5 250 k vs 20 M, dependent, IMU-like prior"))
 if roll:
     A = roll["A"]
-    table += (f"| c-main, map resident on the device (`profiles/{TAG}_rolling_bench.json`) | {A['resident_two_contexts_scans_per_s']:.0f} on two contexts sharing the map, "
+    table += (f"| c-main, map resident (`{TAG}_rolling_bench.json`) | {A['resident_two_contexts_scans_per_s']:.0f} on two contexts sharing the map, "
               f"{A['resident_scans_per_s']:.0f} on one; {A['keyframe_every_3_frames_two_contexts_scans_per_s']:.0f} / {A['keyframe_every_3_frames_scans_per_s']:.0f} with a keyframe every 3rd frame | "
               f"{1e3 / A['resident_two_contexts_scans_per_s']:.3f}, {A['ms_per_frame']['resident']}; {1e3 / A['keyframe_every_3_frames_two_contexts_scans_per_s']:.3f} / {A['ms_per_frame']['keyframes']} | | | | "
               f"{A['max_translation_diff_resident_vs_rebuild_m']:.1e} vs rebuild |\n")
@@ -82,70 +82,72 @@ if roll:
 def traffic_line(name, f, alg):
     if not f or not alg:
         return ""
-    top = "; ".join(f"`{r['kernel']}` {r['MB_per_frame']:.0f}" for r in f["per_kernel"][:4])
+    top = "; ".join(f"`{r['kernel'][:24]}` {r['MB_per_frame']:.0f}" for r in f["per_kernel"][:4])
     return f"{name} {f['bytes_per_frame_measured'] / 1e6:.0f} MB measured / {alg / 1e6:.0f} MB algorithmic = **{f['bytes_per_frame_measured'] / alg:.2f} ×** (largest, MB per frame: {top})"
-tl = [traffic_line("c-main", ft, d["algorithmic_bytes_per_scan"]), traffic_line("c3", ft3, c.get("c3", {}).get("algorithmic_bytes_per_scan")),
-      traffic_line("c5", ft5, c.get("c5", {}).get("algorithmic_bytes_per_scan"))]
-traffic_txt = ("Frame-level HBM traffic, measured (`profiles/" + TAG + "_frame_traffic*.json`: one `rocprofv3 --pmc FETCH_SIZE` and one `WRITE_SIZE` pass over a dependent "
-               "sequence, EVERY kernel of a frame, 2 × FETCH_SIZE + WRITE_SIZE): " + "; ".join(x for x in tl if x) + ".\n") if any(tl) else ""
+tl = [traffic_line("c-main", ft, d["algorithmic_bytes_per_scan"])]
+tl_more = [traffic_line("c3", ft3, c.get("c3", {}).get("algorithmic_bytes_per_scan")), traffic_line("c5", ft5, c.get("c5", {}).get("algorithmic_bytes_per_scan"))]
+traffic_txt = ("Frame-level HBM traffic, measured (`profiles/" + TAG + "_frame_traffic*.json`: `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over a dependent "
+               "sequence, every kernel of a frame): " + "; ".join(x for x in tl if x) + "; c3, c5: `profiles/README.md`.\n") if any(tl) else ""
 lazy_txt = ""
 if LZ:
     lazy_txt = (f"Lazy target (`lazy_target` in the bench line; `value` stays the full rebuild): covariances and voxels only within {LZ.get('margin_cells')} voxels of where the "
                 f"scan falls at the guess -- **{LZ['two_contexts']['scans_per_s']:.0f} scans/s** on two contexts ({LZ['two_contexts']['ms_per_step']} ms), "
                 f"{LZ['one_frame_at_a_time']['scans_per_s']:.0f} one frame at a time, the full rebuild's poses bit for bit, {LZ.get('solves_repeated_on_the_completed_map')} solve(s) repeated on the completed map.\n")
 
+SE = pmc.get("seeded") or {}
+TS = d.get("two_sequences_per_gpu", {})
 numbers = f'''Round-5 numbers (MI355X, `profiles/{TAG}_*`, all from one `scripts/refresh_profiles.sh` run): **{d["value"]:.0f} scans/s ({d["ms_per_step"]} ms/step)** for the
-dependent c-main sequence on two contexts (round 4: 2618 in its own refresh run, 2668 in the driver's), {O["scans_per_s"]:.0f} ({O["ms_per_step"]} ms) one frame at a time, {H["scans_per_s"]:.0f} with the scan's H2D and the output
-cloud inside the step; the replay of pre-framed maps (round 2's headline: targets the library has not seen, hence unseeded) {RP["scans_per_s"]:.0f}; pose parity vs CPU over {pp["frames"]}
-timed frames ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad; CPU port {cb["value"]:.2f} scans/s at the reference's {cb["cores"]} OpenMP threads (a reported
-baseline, not a target).  Two independent sequences on ONE GPU (`two_sequences_per_gpu`): {d.get("two_sequences_per_gpu", {}).get("aggregate_scans_per_s", float("nan")):.0f} scans/s together
-({", ".join("%.0f" % x for x in d.get("two_sequences_per_gpu", {}).get("solo_scans_per_s", []))} alone), each sequence's poses those of its solo run.  Per step, one frame at a time (HIP events, separate pass with every stage bracketed): grid build
-{k["grid_build"]:.3f} ms (both clouds), kNN map {k["knn_cov_target"]:.3f} ms, voxel map + the map's deferred queries {k["voxel_build"]:.3f}, kNN scan {k["knn_cov_source"]:.3f} + {k["knn_coop_source"]:.3f}
-(second stream, overlapped), LM {k["linearize"]:.3f} ({d["mean_outer_iterations"]} outer iterations), fitness {k["fitness"]:.3f}.
-`profiles/{TAG}_kernel_stats.csv` (rocprofv3 `--kernel-trace --stats` of the same command): `k_knn_sp<20, true, true, true>` {knn_prof_us:.0f} µs average under
-the profiler, {u["roofline"]["avg_launch_ms"] * 1e3:.0f} µs from the library's events in that run, {R["avg_launch_ms"] * 1e3:.0f} µs unprofiled; alone the launch takes **{alone_us:.0f} µs**
-= {100 * R["frac_launch_alone"]:.2f} % of 8 TB/s on its 36 algorithmic MB ({100 * R["frac"]:.2f} % in the timed region; unseeded, a map the library has not seen: {R.get("launch_alone_unseeded_ms", float("nan")) * 1e3:.0f} µs; round 4: 149 µs alone, 2.81 % in the timed region).
-{lazy_txt}{traffic_txt}
-The dominant kernel by the counters (`profiles/{TAG}_pmc_knn.json`, per 1 M-query launch, seeded): **{valu:.1f} VALU wave-instructions per query** ({U.get("valu_wave_instructions_per_query", float("nan")):.1f} for the
-full search of the same map; 75.9 in round 4, 87.9 in round 2, 173 in round 1), {vmem_m:.2f} M vector loads, HBM traffic {traffic_mb:.1f} MB = {traffic_mb / 36:.1f} × algorithmic. Per wave of 64 queries
-(`profiles/{TAG}_lab_iters.json`): {SD.get("quads_in_seeded_scan_loop", 0) / ws:.1f} trips of the seeded candidate loop (the full search: {lab["quads_in_scan_loop"] / w:.1f} trips and
-{lab["chain_inserts"] / w:.1f} chain insert rounds), no insert rounds, {SD.get("waves_that_ran_the_full_search_too", 0)} of {int(ws)} waves ran the full search behind the seeded one, {SD.get("newton_steps", 0) / ws:.1f} Newton steps.
-Executed mix (`profiles/{TAG}_knn_isa_mix.json`): {100 * mix["half_rate_fraction"]:.0f} % of the instructions in the half-rate class ⇒ mix-weighted peak
-{mix["peak_mix_weighted"]:.0f} G wave-instr/s; the launch alone sustains {valu:.1f} M / {R["launch_alone_ms"]:.4f} ms = {issue_alone:.0f} G/s = **{100 * issue_alone / mix["peak_mix_weighted"]:.0f} % of it**
-({100 * IR["frac_of_mix_weighted_peak"]:.0f} % in the timed region; ISA count ÷ PMC count = {mix.get("executed_over_pmc", float("nan")):.3f}): the launch is no longer bound by instruction issue but by its waves' lifetime and ramp-down (§5.1).
+dependent c-main sequence on two contexts (round 4: 2668 in the driver's run), {O["scans_per_s"]:.0f} ({O["ms_per_step"]} ms) one frame at a
+time, {H["scans_per_s"]:.0f} with the scan's H2D and the output cloud inside the step; the replay of pre-framed maps (round 2's headline: targets the library has
+not seen -- no seeds, no lists) {RP["scans_per_s"]:.0f}; pose parity vs CPU over {pp["frames"]} timed frames ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad; CPU port {cb["value"]:.2f} scans/s
+at the reference's {cb["cores"]} OpenMP threads .  Two independent sequences on ONE GPU: {TS.get("aggregate_scans_per_s", float("nan")):.0f} scans/s together
+({", ".join("%.0f" % x for x in TS.get("solo_scans_per_s", []))} alone), each sequence's poses those of its solo run.  Per step, one frame at a time (HIP events around every
+stage, separate pass): grid build {k["grid_build"]:.3f} ms (both clouds), kNN map {k["knn_cov_target"]:.3f}, voxel map + the map's deferred queries {k["voxel_build"]:.3f}, kNN scan
+{k["knn_cov_source"]:.3f} + {k["knn_coop_source"]:.3f} (second stream, overlapped), LM {k["linearize"]:.3f} ({d["mean_outer_iterations"]} outer iterations), fitness {k["fitness"]:.3f}.
 
+The dominant kernel, `k_knn_sp<20, true, true, true>`: {knn_prof_us:.0f} µs average under rocprofv3 (`profiles/{TAG}_kernel_stats.csv`), {u["roofline"]["avg_launch_ms"] * 1e3:.0f} µs from
+the library's events in that run, {R["avg_launch_ms"] * 1e3:.0f} µs unprofiled; alone **{alone_us:.0f} µs** = {100 * R["frac_launch_alone"]:.2f} % of 8 TB/s on its 36 algorithmic MB
+({100 * R["frac"]:.2f} % in the timed region) with {R.get("queries_searched_per_launch", float("nan"))} of the 1 M queries searched and the others taken from their neighbour lists; after a
+write to the map's buffer (every query searched, seeded, lists rebuilt) {R.get("launch_alone_changed_map_ms", float("nan")) * 1e3:.0f} µs; a map the library has not seen {R.get("launch_alone_unseeded_ms", float("nan")) * 1e3:.0f} µs
+(round 4: 149 µs, 2.81 % in the timed region).  Counters per 1 M-query launch (`profiles/{TAG}_pmc_knn.json`): **{valu:.1f} VALU wave-instructions per query** with the
+lists ({SE.get("valu_wave_instructions_per_query", float("nan")):.1f} seeded without them, {U.get("valu_wave_instructions_per_query", float("nan")):.1f} unseeded; 75.9 in round 4, 173 in round 1), {vmem_m:.2f} M vector loads,
+HBM traffic {traffic_mb:.1f} MB = {traffic_mb / 36:.1f} × algorithmic.  The searches' executed mix (`profiles/{TAG}_knn_isa_mix*.json`): {100 * mix["half_rate_fraction"]:.0f} % of the seeded search's
+instructions in the half-rate class.
+{lazy_txt}{traffic_txt}
 All configurations of BASELINE.json (`profiles/{TAG}_bench.json` → `configs`; target rebuilt every frame, inputs resident, first frame
 checked against the CPU oracle):
 
 {table}
 '''
-if longr:
-    numbers += (f"Steady state (`profiles/{TAG}_long_run.json`, {longr['frames']} consecutive frames of the replay, one at a time): median {longr['ms_median']:.3f} ms, p99 {longr['ms_p99']:.3f}, "
-                f"maximum {longr['ms_max']:.2f}, {longr['frames_over_1ms']} frame(s) over 1 ms, working set {longr['working_set_MiB']:.0f} MiB with "
-                f"{longr['steady_state_growth_MiB_frames_200_to_end']} MiB growth between frame 200 and the end, every repetition of an input gives the bit-identical pose.\n")
 ss = d.get("steady_state")
 if ss:
-    numbers += (f"Repeated back to back without the HIP events around the dominant kernel (`steady_state` in the bench line: the K timed steps ten times over, median of the "
-                f"last eight): {ss['two_contexts']['scans_per_s']:.0f} scans/s on two contexts, {ss['one_frame_at_a_time']['scans_per_s']:.0f} one frame at a time, the timed run's poses on every repetition.\n")
+    numbers += (f"Repeated back to back without the HIP events around the dominant kernel (`steady_state`: the K timed steps ten times over, median of the "
+                f"last eight): {ss['two_contexts']['scans_per_s']:.0f} scans/s on two contexts, {ss['one_frame_at_a_time']['scans_per_s']:.0f} one frame at a time, the timed run's poses on every repetition.  "
+                f"Long runs, the C++ node and the side benches of the same run: `profiles/README.md`.\n")
+extra = ""
+if longr:
+    extra += (f"Steady state (`{TAG}_long_run.json`, {longr['frames']} consecutive frames of the replay, one at a time): median {longr['ms_median']:.3f} ms, p99 {longr['ms_p99']:.3f}, "
+              f"maximum {longr['ms_max']:.2f}, {longr['frames_over_1ms']} frame(s) over 1 ms, working set {longr['working_set_MiB']:.0f} MiB with "
+              f"{longr['steady_state_growth_MiB_frames_200_to_end']} MiB growth between frame 200 and the end, every repetition of an input gives the bit-identical pose.\n")
 ld = load("long_run_dependent.json")
 if ld:
     a, b = ld["one_context"], ld["two_contexts"]
-    numbers += (f"The dependent sequence itself (`profiles/{TAG}_long_run_dependent.json`: the same {ld['frames_per_repetition']} frames {ld['repetitions']} times over from the same start): "
-                f"{a['scans_per_s_median']:.0f} scans/s on one context (median {a['ms_per_frame_median']:.3f} ms per frame, {a['ms_per_frame_min_max'][0]:.3f}–{a['ms_per_frame_min_max'][1]:.3f} per repetition), "
-                f"{b['scans_per_s_median']:.0f} on two ({b['ms_per_frame_median']:.3f} ms), every repetition and both modes bit-identical poses, "
-                f"{a['growth_MiB_after_the_second_repetition']} / {b['growth_MiB_after_the_second_repetition']} MiB of growth after the second repetition.\n")
+    extra += (f"The dependent sequence itself (`{TAG}_long_run_dependent.json`: the same {ld['frames_per_repetition']} frames {ld['repetitions']} times over from the same start): "
+              f"{a['scans_per_s_median']:.0f} scans/s on one context (median {a['ms_per_frame_median']:.3f} ms per frame, {a['ms_per_frame_min_max'][0]:.3f}–{a['ms_per_frame_min_max'][1]:.3f} per repetition), "
+              f"{b['scans_per_s_median']:.0f} on two ({b['ms_per_frame_median']:.3f} ms), every repetition and both modes bit-identical poses, "
+              f"{a['growth_MiB_after_the_second_repetition']} / {b['growth_MiB_after_the_second_repetition']} MiB of growth after the second repetition.\n")
 if node:
-    numbers += (f"\nThe C++ node (`profiles/{TAG}_cpp_node_bench.json`, 24 sweeps × 28.8 k points, message bytes in → pose out; mean / median of the timed sweeps): "
-                f"reference semantics {node['cpp_reference_semantics_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_median_ms', float('nan')):.2f} ms host-staged and "
-                f"**{node['cpp_reference_semantics_device_chain_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_device_chain_median_ms', float('nan')):.2f} ms on the device** (round 4: 1.09 / 0.62); "
-                f"resident map {node['cpp_resident_map_ms_per_frame']:.2f} / {node.get('cpp_resident_map_median_ms', float('nan')):.2f} host-staged "
-                f"(slowest timed frames {node.get('cpp_reference_semantics_slowest_timed_frame_ms', float('nan')):.2f} / {node.get('cpp_reference_semantics_device_chain_slowest_timed_frame_ms', float('nan')):.2f} / {node.get('cpp_resident_map_slowest_timed_frame_ms', float('nan')):.2f} / {node.get('cpp_resident_map_device_chain_slowest_timed_frame_ms', float('nan')):.2f} ms in the four modes; round 4: 9.6 / 9.0 / 8.0 -- a blocking hipMemcpy through the NULL stream, whose queue is created at its first use, and speculative-grid misses of the sub-map), "
-                f"{node['cpp_resident_map_device_chain_ms_per_frame']:.2f} / {node.get('cpp_resident_map_device_chain_median_ms', float('nan')):.2f} with `device_chain`; "
-                f"`ReplayPipeline` {node['cpp_replay_pipeline_ms_per_frame']:.2f} ms per sweep.")
+    extra += (f"The C++ node (`{TAG}_cpp_node_bench.json`, 24 sweeps × 28.8 k points, message bytes in → pose out; mean / median of the timed sweeps): "
+              f"reference semantics {node['cpp_reference_semantics_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_median_ms', float('nan')):.2f} ms host-staged and "
+              f"**{node['cpp_reference_semantics_device_chain_ms_per_frame']:.2f} / {node.get('cpp_reference_semantics_device_chain_median_ms', float('nan')):.2f} ms on the device** (round 4: 1.09 / 0.62); "
+              f"resident map {node['cpp_resident_map_ms_per_frame']:.2f} / {node.get('cpp_resident_map_median_ms', float('nan')):.2f} host-staged "
+              f"(slowest timed frames {node.get('cpp_reference_semantics_slowest_timed_frame_ms', float('nan')):.2f} / {node.get('cpp_reference_semantics_device_chain_slowest_timed_frame_ms', float('nan')):.2f} / {node.get('cpp_resident_map_slowest_timed_frame_ms', float('nan')):.2f} / {node.get('cpp_resident_map_device_chain_slowest_timed_frame_ms', float('nan')):.2f} ms in the four modes; round 4: 9.6 / 9.0 / 8.0 -- a blocking hipMemcpy through the NULL stream, whose queue is created at its first use, and speculative-grid misses of the sub-map), "
+              f"{node['cpp_resident_map_device_chain_ms_per_frame']:.2f} / {node.get('cpp_resident_map_device_chain_median_ms', float('nan')):.2f} with `device_chain`; "
+              f"`ReplayPipeline` {node['cpp_replay_pipeline_ms_per_frame']:.2f} ms per sweep.")
     if pipe:
-        numbers += (f" `rgc::PipelinedVGICP` on the replay workload (`profiles/{TAG}_cpp_pipeline_bench.json`): {pipe['pipelined_scans_per_s']:.0f} scans/s pipelined, "
-                    f"{pipe['one_at_a_time_scans_per_s']:.0f} one at a time.")
-    numbers += "\n"
+        extra += (f" `rgc::PipelinedVGICP` on the replay workload (`{TAG}_cpp_pipeline_bench.json`): {pipe['pipelined_scans_per_s']:.0f} scans/s pipelined, "
+                  f"{pipe['one_at_a_time_scans_per_s']:.0f} one at a time.")
+    extra += "\n"
 side = []
 if fe:
     side.append(f"front-end {fe['gpu_ms']:.2f} ms per VLP-16 sweep (CPU oracle, one thread: {fe['cpu_oracle_ms_1_thread']:.1f} ms)")
@@ -154,7 +156,7 @@ if mr:
 if ic:
     side.append(f"f4 {ic['gpu_ms']:.1f} ms per loop-closure ICP (CPU oracle: {ic['cpu_oracle_ms_14_threads']:.1f} ms)")
 if side:
-    numbers += "Side benches of the same run (`profiles/" + TAG + "_frontend_bench.json`, `_mapreg_bench.json`, `_icp_bench.json`): " + "; ".join(side) + ".\n"
+    extra += "Side benches of the same run (`" + TAG + "_frontend_bench.json`, `_mapreg_bench.json`, `_icp_bench.json`): " + "; ".join(side) + ".\n"
 
 s = open(P("DESIGN.md")).read()
 open(P("DESIGN.md"), "w").write(put(s, numbers + "\n"))
@@ -201,8 +203,9 @@ readme = f'''* Measured on MI355X (`profiles/{TAG}_*`, one run): **{d["value"]:.
   voxels only where the solve can look, the same poses bit for bit); {RP["scans_per_s"]:.0f} for the replay of pre-framed
   maps (round 2's headline); pose parity against the CPU oracle ≤ {pp["max_dt_m"]:.1e} m / {pp["max_dtheta_rad"]:.1e} rad over {pp["frames"]} timed frames; the CPU port runs
   {cb["value"]:.2f} scans/s at the reference's {cb["cores"]} OpenMP threads. c1 {c["c1"]["scans_per_s"]:.0f}, c3 {c["c3"]["scans_per_s"]:.0f}, c5 {c["c5"]["scans_per_s"]:.0f} scans/s{f"; {roll['A']['resident_two_contexts_scans_per_s']:.0f} scans/s against a map resident on the device" if roll else ""}.
-  The dominant kernel (exact 20-NN + covariance of the 1 M-point map, seeded with the previous search's k-th distances: DESIGN.md §5.1) takes
-  {alone_us:.0f} µs alone ({R.get("launch_alone_unseeded_ms", float("nan")) * 1e3:.0f} µs unseeded), {valu:.0f} VALU wave-instructions per query; two sequences on one GPU reach {d.get("two_sequences_per_gpu", {}).get("aggregate_scans_per_s", float("nan")):.0f} scans/s together.
+  The dominant kernel (exact 20-NN + covariance of the 1 M-point map; on a map that is bit for bit last frame's, certified queries take their
+  neighbours from last search's lists and the rest are searched, seeded: DESIGN.md §5.1) takes {alone_us:.0f} µs alone ({R.get("launch_alone_changed_map_ms", float("nan")) * 1e3:.0f} µs after a write to the
+  map, {R.get("launch_alone_unseeded_ms", float("nan")) * 1e3:.0f} µs for a map the library has not seen); two sequences on one GPU reach {d.get("two_sequences_per_gpu", {}).get("aggregate_scans_per_s", float("nan")):.0f} scans/s together.
 '''
 s = open(P("README.md")).read()
 open(P("README.md"), "w").write(put(s, readme))
@@ -210,8 +213,9 @@ open(P("README.md"), "w").write(put(s, readme))
 # ---------------- profiles/README.md
 s = open(P("profiles", "README.md")).read()
 prof = f'''(figures of this run: headline {d["value"]:.0f} scans/s on two contexts, {O["scans_per_s"]:.0f} one frame at a time, replay {RP["scans_per_s"]:.0f}; the map's bulk kNN launch
-{alone_us:.0f} µs alone, {R["avg_launch_ms"] * 1e3:.0f} µs in the timed region, {knn_prof_us:.0f} µs average under rocprofv3; {valu:.1f} VALU wave-instructions per map query,
-{traffic_mb:.1f} MB per 1 M-query launch, {SD.get("quads_in_seeded_scan_loop", 0) / ws:.1f} trips per wave, mix-weighted issue peak {mix["peak_mix_weighted"]:.0f} G wave-instr/s)
-'''
+{alone_us:.0f} µs alone, {R["avg_launch_ms"] * 1e3:.0f} µs in the timed region, {knn_prof_us:.0f} µs average under rocprofv3; {valu:.1f} VALU wave-instructions per map query with the
+neighbour lists, {SE.get("valu_wave_instructions_per_query", float("nan")):.1f} seeded without them, {U.get("valu_wave_instructions_per_query", float("nan")):.1f} unseeded; {traffic_mb:.1f} MB per 1 M-query launch)
+
+''' + extra + ("Frame-level HBM traffic of the larger configurations: " + "; ".join(x for x in tl_more if x) + ".\n" if any(tl_more) else "")
 open(P("profiles", "README.md"), "w").write(put(s, prof))
 print("synced:", d["value"], O["scans_per_s"], RP["scans_per_s"], [x["scans_per_s"] for x in d.get("configs", [])])
