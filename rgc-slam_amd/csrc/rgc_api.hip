@@ -313,7 +313,8 @@ void release(DevBuf& b) {
 
 void release_cloud(Cloud& cl) {
   for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.slot_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs,
-                    &cl.cell_voxel, &cl.vox, &cl.vox_cell, &cl.need, &cl.qlist, &cl.cell_list, &cl.seed})
+                    &cl.cell_voxel, &cl.vox, &cl.vox_cell, &cl.need, &cl.qlist, &cl.cell_list, &cl.seed, &cl.nbr, &cl.rank_of, &cl.pos_of, &cl.qrank,
+                    &cl.map_copy, &cl.todo, &cl.cache_small})
     release(*b);
 }
 

@@ -1158,6 +1158,12 @@ __device__ __forceinline__ bool list_certified(float a_up, float b_lo, double bo
 // searches everything): its list says so, and it goes onto the todo list the later frames search (by rank = its position in this frame:
 // the lists outlive the frame's order).  ~1 % of the queries, an atomic each on one of kTodoLists words.
 constexpr int kListCertified = (int)0x80000000;
+#ifndef RGC_CACHE_XCD_EIGHTHS
+#define RGC_CACHE_XCD_EIGHTHS 0  // 1: the list look-ups of each XCD cover one contiguous eighth of the map (measured: 2 % slower than the searches' runs)
+#endif
+#ifndef RGC_KNN_CACHE
+#define RGC_KNN_CACHE 1  // 0: the neighbour-list workgroups are not compiled into k_knn_sp (rgc_api.hip's flag of the same name keeps the host from asking for them)
+#endif
 template <int KC>
 __device__ __forceinline__ void cache_uncertified(const Deferred& df, int rank) {
   if (!df.cache.nbr) return;
@@ -2068,7 +2074,7 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
     return;
   }
   bool cached = false;
-  if constexpr (kSeeded) {
+  if constexpr (kSeeded && RGC_KNN_CACHE != 0) {
     // The neighbour-list cache (KnnCache).  An unchanged map: the launch's FIRST cache_nb workgroups search the queries on the todo lists
     // (the ones without a certificate: whole waves of them, started first because they live ten times longer), the others take the
     // certified queries' neighbours from their lists (knn_point_cached) and skip the rest.  A frame that rebuilds the lists (cache_redo:
@@ -2095,12 +2101,17 @@ k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, in
       cached = !redo;
     }
   }
-  const int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
+  int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
 #ifdef RGC_LAB_BLOCKS
   const long long lab_b0 = wall_clock64();
 #endif
   if constexpr (kSeeded) {
     if (cached) {
+#if RGC_CACHE_XCD_EIGHTHS
+      // every list look-up costs the same: each XCD takes one contiguous eighth of the map (the searches' runs are dealt round-robin because
+      // their work differs from region to region) -- neighbouring queries' look-ups then stay in ONE XCD's L2
+      i = (x * (((int)gridDim.x - df.cache_nb) >> 3) + slot) * Cfg::T + (int)threadIdx.x;
+#endif
       if (i < n) knn_point_cached<KC>(P, i, df, nx, ny, nz);
       return;
     }

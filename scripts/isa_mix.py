@@ -64,9 +64,9 @@ def collect():
     v.close()
 
 
-def kernel_isa(KERNEL=KERNEL):
+def kernel_isa(KERNEL=KERNEL, extra=()):
     d = tempfile.mkdtemp(prefix="rgc_isa_")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-DRGC_BUILD", "--save-temps"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-DRGC_BUILD", "--save-temps"] + list(extra)
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", os.path.join(ROOT, "rgc-slam_amd", "csrc", "rgc_kernels.hip"), "-o", os.path.join(d, "k.o")],
                           cwd=d, stderr=subprocess.DEVNULL)
     lines = open(os.path.join(d, "rgc_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
@@ -98,7 +98,9 @@ def main():
     if args.seeded:
         lab = lab["seeded"]
     W = float(lab["waves"])
-    isa = kernel_isa(KERNEL_SEEDED if args.seeded else KERNEL)
+    # (the seeded SEARCH by itself: the neighbour-list workgroups compiled out -- with them the search is instantiated twice, once inside
+    # the loop over the todo lists, and a map that is searched in full runs the copy outside it; lab counts collected under RGC_KNN_CACHE=0)
+    isa = kernel_isa(KERNEL_SEEDED, ["-DRGC_KNN_CACHE=0"]) if args.seeded else kernel_isa(KERNEL)
     # ---- basic blocks ----
     blocks, cur = [], {"label": "entry", "ops": [], "branches": [], "line": 0}
     for ln, l in enumerate(isa):
