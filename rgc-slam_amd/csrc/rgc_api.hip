@@ -56,6 +56,10 @@ constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 #ifndef RGC_KNN_SEEDS
 #define RGC_KNN_SEEDS 1        // 0: the map's exact search never starts from the previous search's k-th distances (round 4)
 #endif
+#ifndef RGC_COOP_STREAM
+#define RGC_COOP_STREAM 0      // 1: the scan's deferred queries are resolved by waiting waves at the end of its bulk kNN launch (coop_stream): a frame at a time
+                               // 3 % faster, a sequence on two contexts 9 % slower (the waiting waves hold slots the other context's map wants); measured, off
+#endif
 #ifndef RGC_PREP_EVENT_EXT
 #define RGC_PREP_EVENT_EXT 1
 #endif
@@ -128,6 +132,8 @@ struct Cloud {
   int cache_e2 = 0;         // binary exponent of the largest coordinate the certificates were issued for
   int cache_e2_low = 0;     // frames in a row whose coordinates stayed below it
   int todo_cap = 0;
+  bool slots_clean = false;        // segs' entry words hold the "empty slot" pattern (the scan's deferred queries resolved inside its bulk launch)
+  const void* slots_seen = nullptr;  // ... of this allocation
   bool prepared_recorded = false;  // the preparation's last launch carried the context's tgt_prepared event (no record packet behind it)
   bool cache_searched_lists = false;  // the last preparation's search was the seeded launch that reads the lists (rgc_stats::searched_target)
 };
@@ -202,6 +208,7 @@ struct rgc_ctx {
   bool solve_behind_map = RGC_SOLVE_BEHIND_MAP != 0;  // (build flag) 0: the solve always on the scan's (high-priority) stream, as in round 2
   bool lm_host = false;       // RGC_LM_IMPL=host: host-driven LM loop over the public fine-seam kernels (cross-check of the device-chained one)
   bool spec_on = true;        // RGC_SPEC_GRID=0 turns the speculative grid off
+  bool coop_stream_on = RGC_COOP_STREAM != 0;  // (build flag; RGC_COOP_STREAM in the environment) the scan's deferred queries inside its bulk kNN launch
   bool prep_event_ext = RGC_PREP_EVENT_EXT != 0;  // (build flag; RGC_PREP_EVENT_EXT in the environment) the map's last launch signals tgt_prepared itself
   int join_spin_us = RGC_JOIN_SPIN_US;  // (build flag; RGC_JOIN_SPIN_US in the environment) how long the host waits for an almost-ready scan instead of putting a barrier into the map's stream (join_source)
   bool cache_on = RGC_KNN_CACHE != 0;  // (build flag; RGC_KNN_CACHE=0 in the environment) the neighbour lists of an unchanged map on top of the seeds
@@ -713,6 +720,7 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
   const int n = cl.n, k = c->prm.k_correspondences;
   hipStream_t s = is_target ? c->stream : c->stream2;
   int* dsm = c->d_small + (is_target ? 0 : 16);
+  bool stream_coop = false;
   {
     // a sparse map (points per cell of its grid below map_wide_density): the wider block, see k_knn_sp_wide
     const int wide_r = is_target ? map_wide_r_of(c, cl) : 0;
@@ -732,14 +740,25 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
       own.points = n;
     }
     const rgck::KnnSeeds seeds = cloud_seeds(cl, is_target);
+    if (is_target) cl.slots_clean = false;
     if (self_timed) {
       rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
                      (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, own.a, own.b, nullptr, nullptr, 0, seeds);
       c->prof_open.push_back(own);
     } else {
+      // the scan: its deferred queries are resolved by the last workgroups of the same launch (coop_stream) -- unless the stage-by-stage
+      // profile wants the two apart.  The entry words must be "empty" on entry: filled once per allocation, the readers put it back.
+      const int coop_waves_s = cl.deferred_seen >= 0 ? cl.deferred_seen + cl.deferred_seen / 4 + 32 : n / 64 + 32;
+      stream_coop = !is_target && c->coop_stream_on && k <= 32 && !(c->prof_on && ((c->prof_mask >> RGC_K_KNN_COOP_SRC) & 1u));
+      if (stream_coop && (!cl.slots_clean || cl.slots_seen != cl.segs.p)) {
+        HIPCHK(c, hipMemsetAsync((int*)cl.segs.p + 16, rgck::kDeferredSlotEmptyByte, sizeof(int) * 2 * (size_t)n, s));
+        cl.slots_clean = true;
+        cl.slots_seen = cl.segs.p;
+      }
+      if (!stream_coop) cl.slots_clean = false;  // (the plain list will be written over the slots; a cloud can change roles: rgc_swap_source_and_target)
       ProfScope ps(c, kind, n, s);
       rgck::knn_bulk(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p, (double*)cl.ny.p,
-                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, nullptr, nullptr, nullptr, nullptr, 0, seeds);
+                     (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, wide_r, nullptr, nullptr, nullptr, nullptr, 0, seeds, stream_coop ? coop_waves_s : 0);
     }
     if (is_target) cl.cache_searched_lists = seeds.cache.nbr && seeds.warm && wide_r == 0;
     if (seeds.seed && wide_r == 0) {
@@ -754,7 +773,7 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
   // grid of the cooperative launch: twice the deferred count of the previous cloud prepared here (consecutive clouds of a sequence
   // defer about the same queries), n / 64 for the first one
   const int coop_waves = cl.deferred_seen >= 0 ? cl.deferred_seen + cl.deferred_seen / 4 + 32 : n / 64 + 32;
-  if (!coop_beside) {
+  if (!coop_beside && !stream_coop) {
     ProfScope ps(c, is_target ? RGC_K_KNN_COOP : RGC_K_KNN_COOP_SRC, n, s);
     rgck::knn_coop(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, cl.segs.p, (double*)cl.nx.p,
                    (double*)cl.ny.p, (double*)cl.nz.p, cl.spec_used ? dsm + 6 : nullptr, coop_waves);
@@ -1451,6 +1470,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   if (const char* e = getenv("RGC_KNN_CACHE")) c->cache_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_JOIN_SPIN_US")) c->join_spin_us = atoi(e);
   if (const char* e = getenv("RGC_PREP_EVENT_EXT")) c->prep_event_ext = atoi(e) != 0;
+  if (const char* e = getenv("RGC_COOP_STREAM")) c->coop_stream_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_LM_IMPL")) c->lm_host = strcmp(e, "host") == 0;
   if (!ok) { rgc_destroy(c); return RGC_ERR_HIP; }
   { std::lock_guard<std::mutex> lk(g_live_mutex); g_live.insert(c); }

@@ -123,7 +123,11 @@ void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, 
               double* ny, double* nz, const int* guard = nullptr, int wide_r = 0,
               hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* dense-map launch only (knn_bulk_times_itself): the launch's own start / stop times */,
               // lazy target (dense-map launch only): the queries listed in qlist[0 .. *nq) are searched, nothing else; q_est sizes the launch
-              const int* qlist = nullptr, const int* nq = nullptr, int q_est = 0, const KnnSeeds& seeds = KnnSeeds{});
+              const int* qlist = nullptr, const int* nq = nullptr, int q_est = 0, const KnnSeeds& seeds = KnnSeeds{},
+              // the scan's launch only: > 0 = that many waves at the end of the launch resolve the deferred queries as they are published
+              // (no knn_coop launch behind it); the deferred buffer's entry words must hold kDeferredSlotEmptyByte bytes on entry
+              int stream_coop_waves = 0);
+constexpr int kDeferredSlotEmptyByte = 0x80;
 // lazy target: stamp the cells of grid g within `margin` cells of the cell each point of the cloud falls into under T and list the occupied
 // ones (cell_list: their first sorted point; qlist: all their points; counts[0] / [1]: the lists' sizes, zeroed by rank_gather)
 // guard (nullable): the speculative grid's flag -- set: the map's points may lie outside the grid, nothing is listed

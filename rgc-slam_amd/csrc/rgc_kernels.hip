@@ -846,7 +846,15 @@ struct Deferred {
   // the bound as before); the exact searches write the lists and the certificates, knn_point_cached reads them.
   KnnCache cache;
   int cache_nb;  // workgroups at the end of the map's bulk launch that search the listed (uncertified) queries
+  // the scan's deferred queries resolved INSIDE its bulk launch (coop_stream): the launch's last coop_blocks workgroups take entries as
+  // they are published -- slot e = {enc, thr} in one 64-bit word (kSlotEmpty until then, put back by the reader) -- and leave when all
+  // bulk workgroups have counted themselves out (*done) and the list is exhausted.  coop_blocks == 0: the lists above, a launch of its own.
+  int coop_blocks;
+  int* done;
+  unsigned long long* slots;
 };
+constexpr unsigned long long kSlotEnd = 0x8080808080808081ull;    // "no entry will ever appear here": written behind the list by the last bulk workgroup
+constexpr unsigned long long kSlotEmpty = 0x8080808080808080ull;  // (what hipMemset can write; its low word is no valid entry: |enc| <= 2^27)
 
 // ------------------------------------------------------------------------------------------------
 // C2  exact k-nearest neighbours + covariance + normal (fast_gicp_impl.hpp:241-298), the bulk kernel: one lane per query, queries
@@ -1756,8 +1764,14 @@ __device__ __forceinline__ bool knn_point_split(const float4* __restrict__ P, co
       atomicAdd(&g_lab_why[why], 1);
 #endif
       const int e = atomicAdd(df.cnt, 1);
-      df.idx[e] = enc;
-      df.thr[e] = thr;
+      if (df.coop_blocks > 0) {  // published to the waves that resolve the deferred queries inside this launch: one 64-bit word, nothing to order
+        __hip_atomic_store(&df.slots[e], (unsigned long long)(unsigned)enc | ((unsigned long long)(unsigned)__float_as_int(thr) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the word has arrived before this wave goes on (and, at the launch's end, counts itself out)
+      } else {
+        df.idx[e] = enc;
+        df.thr[e] = thr;
+      }
     }
   };
   bool heavy_piece = false;
@@ -2040,123 +2054,11 @@ void lab_wave_ts(long long* out, hipStream_t s) {
 #endif
 constexpr int kSeedT = RGC_SEED_T;
 template <bool kTarget, bool kSeeded> struct SpLaunch : SpConfig<kTarget> { static constexpr int T = kSeeded ? kSeedT : SpConfig<kTarget>::T; };
-template <int KC, bool kTarget, bool kExact, bool kSeeded = false>
-__global__ void __launch_bounds__((SpLaunch<kTarget, kSeeded>::T))
-k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
-         double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ int slist_sp[];  // [SpShape::LDS][T]
-  using Cfg = SpLaunch<kTarget, kSeeded>;
-  static_assert(!kSeeded || (kTarget && kExact), "seeds: the map's search at k == KC");
-  wave_prio(!kTarget);
-  if (df.guard && *df.guard) return;
-  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one) and queries are in cell order.
-  // Each XCD takes runs of kXcdRun CONSECUTIVE query blocks (neighbouring cells: their candidates are re-used out of that XCD's L2),
-  // the runs themselves dealt round-robin (whole contiguous eighths of the map differ too much in work: 7 % slower, DESIGN.md).
-  constexpr int kXcdRun = RGC_XCD_RUN * KNN_T / Cfg::T;  // (a run is RGC_XCD_RUN x 256 consecutive queries whatever the workgroup size)
-  int b = (int)blockIdx.x, slot = b >> 3;
-  const int x = b & 7;
-  if constexpr (!kTarget) {  // four lanes per query, queries in cell order
-    const int t = b * Cfg::T + (int)threadIdx.x;
-    const int i = t >> 2;
-#ifdef RGC_LAB
-    const long long lab_t0 = wall_clock64();
-#endif
-    // A query the 3x3x3 block does not settle -- too few points in it, or a k-th neighbour that a closer point outside it could
-    // displace: the sparse far field of a sweep, 12 % of a VLP-16's queries -- is searched again on the 5x5x5 block by the same four lanes,
-    // at once: 97 % of them settle there, and a wave of the far field has few candidates either way.  (They used to go to the
-    // cooperative kernel, a wave per query and four dependent passes each: the longest launch of the scan's preparation.)
-    if (i < n && knn_point_split<KC, Cfg::KB, Cfg::R, Cfg::T, kExact, Cfg::R >= 2>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz)) {
-      if constexpr (Cfg::R < 2) knn_point_split<KC, Cfg::KB, 2, Cfg::T, kExact, true>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz);
-    }
-#ifdef RGC_LAB
-    if (threadIdx.x == 0 && b < 8192) { g_lab_wave[2 * b] = lab_t0; g_lab_wave[2 * b + 1] = wall_clock64(); }
-#endif
-    return;
-  }
-  bool cached = false;
-  if constexpr (kSeeded && RGC_KNN_CACHE != 0) {
-    // The neighbour-list cache (KnnCache).  An unchanged map: the launch's FIRST cache_nb workgroups search the queries on the todo lists
-    // (the ones without a certificate: whole waves of them, started first because they live ten times longer), the others take the
-    // certified queries' neighbours from their lists (knn_point_cached) and skip the rest.  A frame that rebuilds the lists (cache_redo:
-    // the map's first frame, a buffer rewritten in place): everything is searched by the workgroups behind the first cache_nb, as
-    // without the cache, and every search leaves its list and certificate -- or its query on a todo list.
-    if (df.cache.nbr) {
-      const bool redo = cache_redo(df.cache);
-      if (b < df.cache_nb) {
-        if (redo) return;
-        Deferred dfb = df;
-        dfb.cache.nbr = nullptr;  // (these searches leave the lists alone: who is on a todo list stays there until the next rebuild)
-        // list l = b % kTodoLists, T entries at a time, dealt to the list's workgroups
-        const int l = b % kTodoLists, per = df.cache_nb / kTodoLists;
-        const int cnt = min(df.cache.todo_cnt[l], df.cache.todo_cap);
-        for (int e = (b / kTodoLists) * Cfg::T + (int)threadIdx.x; e < cnt; e += per * Cfg::T) {
-          const int q = df.cache.pos_of[df.cache.todo[(size_t)l * df.cache.todo_cap + e]];
-          if (!knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, q, slist_sp + threadIdx.x, dfb, nx, ny, nz))
-            knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, q, slist_sp + threadIdx.x, dfb, nx, ny, nz);
-        }
-        return;
-      }
-      b -= df.cache_nb;  // (a multiple of 8: the XCD of a workgroup is still b & 7)
-      slot = b >> 3;
-      cached = !redo;
-    }
-  }
-  int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
-#ifdef RGC_LAB_BLOCKS
-  const long long lab_b0 = wall_clock64();
-#endif
-  if constexpr (kSeeded) {
-    if (cached) {
-#if RGC_CACHE_XCD_EIGHTHS
-      // every list look-up costs the same: each XCD takes one contiguous eighth of the map (the searches' runs are dealt round-robin because
-      // their work differs from region to region) -- neighbouring queries' look-ups then stay in ONE XCD's L2
-      i = (x * (((int)gridDim.x - df.cache_nb) >> 3) + slot) * Cfg::T + (int)threadIdx.x;
-#endif
-      if (i < n) knn_point_cached<KC>(P, i, df, nx, ny, nz);
-      return;
-    }
-    const bool done = i >= n || knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, i, slist_sp + threadIdx.x, df, nx, ny, nz);
-    if (!done) {
-      LAB_COUNT(6);
-      knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
-    }
-  } else {
-    if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
-  }
-#ifdef RGC_LAB_BLOCKS
-  if (Cfg::T > WAVE) __syncthreads();
-  if (threadIdx.x == 0 && b < 16384) {
-    g_lab_blk[4 * b] = lab_b0; g_lab_blk[4 * b + 1] = wall_clock64();
-    g_lab_blk[4 * b + 2] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, bits 0..3
-    g_lab_blk[4 * b + 3] = i;
-#ifdef RGC_LAB_BLK
-    g_lab_blk[4 * b + 3] |= (long long)g_lab_blk_why[b] << 32;
-    g_lab_blk_why[b] = 0;
-#endif
-  }
-#endif
-}
-
-// Lazy target: the map's search for the LISTED queries only (df.qlist: whole cells, a cell's points are consecutive entries) instead of
-// all of them in cell order.  The launch is sized from the previous frame's list and strides over this one's whatever its length.  (Its own
-// kernel: the stride loop around the search costs registers -- 107 against 86 -- that the full launch, five waves per SIMD, cannot spare.)
-template <int KC, bool kExact, bool kSeeded = false>
-__global__ void __launch_bounds__(SpConfig<true>::T)
-k_knn_sp_listed(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
-                double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
-  extern __shared__ int slist_spl[];
-  using Cfg = SpConfig<true>;
-  static_assert(!kSeeded || kExact, "seeds: the map's search at k == KC");
-  if (df.guard && *df.guard) return;
-  const int nq = *df.nq;
-  for (int t = (int)blockIdx.x * Cfg::T + (int)threadIdx.x; t < nq; t += (int)gridDim.x * Cfg::T) {
-    const int i = df.qlist[t];
-    if constexpr (kSeeded) {
-      if (knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, i, slist_spl + threadIdx.x, df, nx, ny, nz)) continue;
-    }
-    knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_spl + threadIdx.x, df, nx, ny, nz);
-  }
-}
+struct CoopRows {  // per-wave LDS scratch of the cooperative search (coop_run)
+  int pref[WAVE + 1];
+  int rowa[WAVE];
+  int nb[32];
+};
 
 // The bulk launch for a SPARSE map (a few keyframes of a 16-beam sensor after the leaf filter: 0.1 points per 1 m cell, where the 3x3x3
 // block of the dense-map kernel holds fewer than k points for most queries and 85 % of them went to the cooperative kernel): the
@@ -2187,11 +2089,6 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 }
 __device__ __forceinline__ int wave_min_i(int v) { return wave_min(v); }
 
-struct CoopRows {  // per-wave LDS scratch
-  int pref[WAVE + 1];
-  int rowa[WAVE];
-  int nb[32];
-};
 
 __device__ __forceinline__ void wave_lds_fence() {  // LDS is in-order within a wave: only the compiler must not reorder
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2283,20 +2180,18 @@ __device__ __forceinline__ unsigned coop_kth(const float4* __restrict__ P, const
 // admitted wherever one SIMD has a slot; the grid is sized by the caller from the previous cloud's deferred count (idle workgroups
 // still have to be dispatched: 2048 four-wave workgroups cost 0.25 ms of the scan's critical path when 200 queries were waiting).
 // (the body: wave `wave` of `nwaves` takes every nwaves-th entry of the deferred list; sh: this wave's LDS scratch)
+// one deferred entry (enc: the query, or ~query when radius 1 is known to be insufficient; thr: the k-th distance seen so far), one wave
 template <int KC, bool kTarget>
-__device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, const Deferred& df,
+__device__ __forceinline__ void coop_one(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, const Deferred& df,
                                          double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz, CoopRows* sh, int lane,
-                                         int wave, int nwaves) {
-  const int cnt = *df.cnt;
-  for (int e = wave; e < cnt; e += nwaves) {
+                                         int e, int enc, float thr) {
+  {
 #ifdef RGC_LAB
     const long long lab_t0 = wall_clock64();
     int lab_rounds = 0;
 #endif
-    const int enc = __builtin_amdgcn_readfirstlane(df.idx[e]);
     const int i = enc < 0 ? ~enc : enc;
     int r = enc < 0 ? 1 : 0;  // radius already known to be insufficient
-    float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(df.thr[e])));
     const float4 pq = P[i];
     const float px = pq.x, py = pq.y, pz = pq.z;
     const int c[3] = {cell_coord(px, g) - g.minc[0], cell_coord(py, g) - g.minc[1], cell_coord(pz, g) - g.minc[2]};
@@ -2400,6 +2295,42 @@ __device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int
 }
 
 template <int KC, bool kTarget>
+__device__ __forceinline__ void coop_run(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, const Deferred& df,
+                                         double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz, CoopRows* sh, int lane,
+                                         int wave, int nwaves) {
+  const int cnt = *df.cnt;
+  for (int e = wave; e < cnt; e += nwaves) {
+    const int enc = __builtin_amdgcn_readfirstlane(df.idx[e]);
+    const float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(df.thr[e])));
+    coop_one<KC, kTarget>(P, start, g, k, df, nx, ny, nz, sh, lane, e, enc, thr);
+  }
+}
+// The scan's deferred queries INSIDE its bulk launch (round 5): wave `wave` of the launch's last workgroups takes entries wave, wave +
+// nwaves, ... as they appear.  An entry is one 64-bit atomic word {enc, thr}; empty slots hold kSlotEmpty and the reader puts that back,
+// so the list is clean for the next cloud.  The last bulk workgroup to count itself out (*done) writes kSlotEnd into the first slot behind
+// the list for every waiting wave: a wave that reads it leaves.  Workgroups are dispatched in order, so every bulk workgroup is running
+// or finished when the first of these starts: the wait cannot deadlock.  (A launch of its own
+// behind the bulk one started 45 us of latency-bound work only when the last bulk wave had left.)
+template <int KC>
+__device__ __forceinline__ void coop_stream(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, const Deferred& df,
+                            double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz, CoopRows* sh, int lane, int wave, int nwaves,
+                            int bulk_blocks, int nslots) {
+  for (int e = wave;; e += nwaves) {
+    if (e >= nslots) return;  // (more waves than the cloud has points)
+    unsigned long long v;
+    for (;;) {
+      v = __hip_atomic_load(&df.slots[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v != kSlotEmpty) break;
+      __builtin_amdgcn_s_sleep(20);
+    }
+    if (lane == 0) __hip_atomic_store(&df.slots[e], kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v == kSlotEnd) return;
+    const int enc = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const float thr = __int_as_float(__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)));
+    coop_one<KC, false>(P, start, g, k, df, nx, ny, nz, sh, lane, e, enc, thr);
+  }
+}
+template <int KC, bool kTarget>
 __global__ void __launch_bounds__(WAVE)
 k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int k, Deferred df, double* __restrict__ nx,
            double* __restrict__ ny, double* __restrict__ nz) {
@@ -2407,6 +2338,146 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
   wave_prio(!kTarget);
   if (df.guard && *df.guard) return;
   coop_run<KC, kTarget>(P, start, g, k, df, nx, ny, nz, &shm[0], (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int KC, bool kTarget, bool kExact, bool kSeeded = false>
+__global__ void __launch_bounds__((SpLaunch<kTarget, kSeeded>::T))
+k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
+         double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
+  extern __shared__ int slist_sp[];  // [SpShape::LDS][T]
+  using Cfg = SpLaunch<kTarget, kSeeded>;
+  static_assert(!kSeeded || (kTarget && kExact), "seeds: the map's search at k == KC");
+  wave_prio(!kTarget);
+  if (df.guard && *df.guard) return;
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one) and queries are in cell order.
+  // Each XCD takes runs of kXcdRun CONSECUTIVE query blocks (neighbouring cells: their candidates are re-used out of that XCD's L2),
+  // the runs themselves dealt round-robin (whole contiguous eighths of the map differ too much in work: 7 % slower, DESIGN.md).
+  constexpr int kXcdRun = RGC_XCD_RUN * KNN_T / Cfg::T;  // (a run is RGC_XCD_RUN x 256 consecutive queries whatever the workgroup size)
+  int b = (int)blockIdx.x, slot = b >> 3;
+  const int x = b & 7;
+  if constexpr (!kTarget) {  // four lanes per query, queries in cell order
+    if (df.coop_blocks > 0 && b >= (int)gridDim.x - df.coop_blocks) {
+      // the launch's last workgroups: a wave per deferred query, taken as the searches in front publish them (coop_stream below)
+      const int bulk = (int)gridDim.x - df.coop_blocks;
+      coop_stream<KC>(P, start, g, k, df, nx, ny, nz, reinterpret_cast<CoopRows*>(slist_sp) + (threadIdx.x / WAVE), (int)threadIdx.x & (WAVE - 1),
+                      (b - bulk) * (Cfg::T / WAVE) + (int)threadIdx.x / WAVE, df.coop_blocks * (Cfg::T / WAVE), bulk, n);
+      return;
+    }
+    const int t = b * Cfg::T + (int)threadIdx.x;
+    const int i = t >> 2;
+#ifdef RGC_LAB
+    const long long lab_t0 = wall_clock64();
+#endif
+    // A query the 3x3x3 block does not settle -- too few points in it, or a k-th neighbour that a closer point outside it could
+    // displace: the sparse far field of a sweep, 12 % of a VLP-16's queries -- is searched again on the 5x5x5 block by the same four lanes,
+    // at once: 97 % of them settle there, and a wave of the far field has few candidates either way.  (They used to go to the
+    // cooperative kernel, a wave per query and four dependent passes each: the longest launch of the scan's preparation.)
+    if (i < n && knn_point_split<KC, Cfg::KB, Cfg::R, Cfg::T, kExact, Cfg::R >= 2>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz)) {
+      if constexpr (Cfg::R < 2) knn_point_split<KC, Cfg::KB, 2, Cfg::T, kExact, true>(P, start, g, n, k, i, t & 3, slist_sp + threadIdx.x, df, nx, ny, nz);
+    }
+#ifdef RGC_LAB
+    if (threadIdx.x == 0 && b < 8192) { g_lab_wave[2 * b] = lab_t0; g_lab_wave[2 * b + 1] = wall_clock64(); }
+#endif
+    if (df.coop_blocks > 0) {  // counted out: everything this workgroup deferred has arrived (each publishing wave waited for its word).
+      // No fence: an agent-scope release writes this XCD's whole L2 back and invalidates it -- under the searches still running on it
+      // The LAST workgroup to count itself out tells the waiting waves: an "end" word in the first slot behind the list for each of them
+      // (they watch their own slots only -- hundreds of waves polling ONE word queue up at its memory channel, in front of the searches'
+      // own atomics on the list's counter: the launch took 145 us instead of 55).
+      __syncthreads();
+      if (threadIdx.x == 0) slist_sp[0] = __hip_atomic_fetch_add(df.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - df.coop_blocks - 1;
+      __syncthreads();
+      if (slist_sp[0]) {
+        const int cnt = __hip_atomic_load(df.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nwaves = df.coop_blocks * (Cfg::T / WAVE);
+        for (int j = (int)threadIdx.x; j < nwaves; j += Cfg::T)
+          if (cnt + j < n) __hip_atomic_store(&df.slots[cnt + j], kSlotEnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  bool cached = false;
+  if constexpr (kSeeded && RGC_KNN_CACHE != 0) {
+    // The neighbour-list cache (KnnCache).  An unchanged map: the launch's FIRST cache_nb workgroups search the queries on the todo lists
+    // (the ones without a certificate: whole waves of them, started first because they live ten times longer), the others take the
+    // certified queries' neighbours from their lists (knn_point_cached) and skip the rest.  A frame that rebuilds the lists (cache_redo:
+    // the map's first frame, a buffer rewritten in place): everything is searched by the workgroups behind the first cache_nb, as
+    // without the cache, and every search leaves its list and certificate -- or its query on a todo list.
+    if (df.cache.nbr) {
+      const bool redo = cache_redo(df.cache);
+      if (b < df.cache_nb) {
+        if (redo) return;
+        Deferred dfb = df;
+        dfb.cache.nbr = nullptr;  // (these searches leave the lists alone: who is on a todo list stays there until the next rebuild)
+        // list l = b % kTodoLists, T entries at a time, dealt to the list's workgroups
+        const int l = b % kTodoLists, per = df.cache_nb / kTodoLists;
+        const int cnt = min(df.cache.todo_cnt[l], df.cache.todo_cap);
+        for (int e = (b / kTodoLists) * Cfg::T + (int)threadIdx.x; e < cnt; e += per * Cfg::T) {
+          const int q = df.cache.pos_of[df.cache.todo[(size_t)l * df.cache.todo_cap + e]];
+          if (!knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, q, slist_sp + threadIdx.x, dfb, nx, ny, nz))
+            knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, q, slist_sp + threadIdx.x, dfb, nx, ny, nz);
+        }
+        return;
+      }
+      b -= df.cache_nb;  // (a multiple of 8: the XCD of a workgroup is still b & 7)
+      slot = b >> 3;
+      cached = !redo;
+    }
+  }
+  int i = (((slot / kXcdRun) * 8 + x) * kXcdRun + slot % kXcdRun) * Cfg::T + threadIdx.x;
+#ifdef RGC_LAB_BLOCKS
+  const long long lab_b0 = wall_clock64();
+#endif
+  if constexpr (kSeeded) {
+    if (cached) {
+#if RGC_CACHE_XCD_EIGHTHS
+      // every list look-up costs the same: each XCD takes one contiguous eighth of the map (the searches' runs are dealt round-robin because
+      // their work differs from region to region) -- neighbouring queries' look-ups then stay in ONE XCD's L2
+      i = (x * (((int)gridDim.x - df.cache_nb) >> 3) + slot) * Cfg::T + (int)threadIdx.x;
+#endif
+      if (i < n) knn_point_cached<KC>(P, i, df, nx, ny, nz);
+      return;
+    }
+    const bool done = i >= n || knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+    if (!done) {
+      LAB_COUNT(6);
+      knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+    }
+  } else {
+    if (i < n) knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_sp + threadIdx.x, df, nx, ny, nz);
+  }
+#ifdef RGC_LAB_BLOCKS
+  if (Cfg::T > WAVE) __syncthreads();
+  if (threadIdx.x == 0 && b < 16384) {
+    g_lab_blk[4 * b] = lab_b0; g_lab_blk[4 * b + 1] = wall_clock64();
+    g_lab_blk[4 * b + 2] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, bits 0..3
+    g_lab_blk[4 * b + 3] = i;
+#ifdef RGC_LAB_BLK
+    g_lab_blk[4 * b + 3] |= (long long)g_lab_blk_why[b] << 32;
+    g_lab_blk_why[b] = 0;
+#endif
+  }
+#endif
+}
+
+// Lazy target: the map's search for the LISTED queries only (df.qlist: whole cells, a cell's points are consecutive entries) instead of
+// all of them in cell order.  The launch is sized from the previous frame's list and strides over this one's whatever its length.  (Its own
+// kernel: the stride loop around the search costs registers -- 107 against 86 -- that the full launch, five waves per SIMD, cannot spare.)
+template <int KC, bool kExact, bool kSeeded = false>
+__global__ void __launch_bounds__(SpConfig<true>::T)
+k_knn_sp_listed(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
+                double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
+  extern __shared__ int slist_spl[];
+  using Cfg = SpConfig<true>;
+  static_assert(!kSeeded || kExact, "seeds: the map's search at k == KC");
+  if (df.guard && *df.guard) return;
+  const int nq = *df.nq;
+  for (int t = (int)blockIdx.x * Cfg::T + (int)threadIdx.x; t < nq; t += (int)gridDim.x * Cfg::T) {
+    const int i = df.qlist[t];
+    if constexpr (kSeeded) {
+      if (knn_point_seeded<KC, Cfg::KB, Cfg::T>(P, start, g, n, i, slist_spl + threadIdx.x, df, nx, ny, nz)) continue;
+    }
+    knn_point_sp<KC, Cfg::KB, Cfg::R, Cfg::T, kExact>(P, start, g, n, k, i, slist_spl + threadIdx.x, df, nx, ny, nz);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4114,13 +4185,14 @@ size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 // deferred list: [cnt, pad x15][idx n][thr n]
 static Deferred deferred_of(const void* buf, int n) {
   int* base = (int*)const_cast<void*>(buf);
-  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, nullptr, nullptr, 0.f, KnnCache{}, 0};
+  return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, nullptr, nullptr, 0.f, KnnCache{}, 0,
+                  0, base + 1, reinterpret_cast<unsigned long long*>(base + 16)};
 }
 
 template <int KC, bool kExact>
 static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred,
                         double* nx, double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1,
-                        const int* qlist, const int* nq, int q_est, const KnnSeeds& seeds) {
+                        const int* qlist, const int* nq, int q_est, const KnnSeeds& seeds, int stream_coop_waves) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
   df.qlist = qlist; df.nq = nq;
@@ -4163,7 +4235,11 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
   if (is_target && qlist) hipLaunchKernelGGL((k_knn_sp_listed<KC, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
   else if (is_target && ev0 && ev1) hipExtLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), (std::uint32_t)lds, s, ev0, ev1, 0u, P, start, g, n, k, df, nx, ny, nz);
   else if (is_target) hipLaunchKernelGGL((k_knn_sp<KC, true, kExact>), dim3(nb), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
-  else hipLaunchKernelGGL((k_knn_sp<KC, false, kExact>), dim3(nblk(n, T / 4)), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);  // four lanes per query
+  else {  // four lanes per query; the deferred queries resolved by the launch's last workgroups (coop_stream) when the caller asks for it
+    if (stream_coop_waves > 0) df.coop_blocks = nblk(stream_coop_waves < 32 ? 32 : (stream_coop_waves > 8192 ? 8192 : stream_coop_waves), T / WAVE);
+    static_assert(sizeof(CoopRows) * (CS::T / WAVE) <= (size_t)SpShape<CS::R, CS::kClip>::LDS * CS::T * sizeof(int), "the cooperative waves' scratch fits the bulk launch's LDS");
+    hipLaunchKernelGGL((k_knn_sp<KC, false, kExact>), dim3(nblk(n, T / 4) + df.coop_blocks), dim3(T), lds, s, P, start, g, n, k, df, nx, ny, nz);
+  }
 }
 bool knn_seeds_apply(int n, int k) { return k == 20 && n <= kSeedMaxPoints; }
 static void deferred_seeds(Deferred& df, const KnnSeeds& seeds, int n, int k) {  // the cooperative search leaves its k-th distance as the point's seed
@@ -4186,11 +4262,12 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
 bool knn_bulk_times_itself(bool is_target, int wide_r) { return is_target && wide_r != 2; }
 void knn_bulk(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* deferred, double* nx,
               double* ny, double* nz, const int* guard, int wide_r, hipEvent_t ev0, hipEvent_t ev1, const int* qlist, const int* nq, int q_est,
-              const KnnSeeds& seeds) {
+              const KnnSeeds& seeds, int stream_coop_waves) {
+  if (is_target || wide_r == 2) stream_coop_waves = 0;  // (the scan's four-lane search only)
   // (k == 20, the reference's setting, gets an instance without the general-k branches)
-  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds);
-  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds);
-  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds);
+  if (k == 20) knn_bulk_kc<20, true>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds, stream_coop_waves);
+  else if (k < 20) knn_bulk_kc<20, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds, stream_coop_waves);
+  else knn_bulk_kc<32, false>(s, is_target, P, start, g, n, k, deferred, nx, ny, nz, guard, wide_r, ev0, ev1, qlist, nq, q_est, seeds, stream_coop_waves);
 }
 
 void knn_coop(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, const void* segs, double* nx,
