@@ -131,6 +131,7 @@ struct Cloud {
   int cache_frame = 0;
   int cache_e2 = 0;         // binary exponent of the largest coordinate the certificates were issued for
   int cache_e2_low = 0;     // frames in a row whose coordinates stayed below it
+  int cache_e2_low_max = 0; // ... and the largest exponent among them
   int todo_cap = 0;
   bool slots_clean = false;        // segs' entry words hold the "empty slot" pattern (the scan's deferred queries resolved inside its bulk launch)
   const void* slots_seen = nullptr;  // ... of this allocation
@@ -536,8 +537,12 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
         // larger coordinates than the certificates allow for: issue them again.  Smaller ones for sixteen frames in a row: new certificates
         // need the smaller gap only (the old ones, issued for a wider one, stand).
         if (fresh || ce2 > cl.cache_e2) { cl.cache_e2 = ce2; fresh = true; }
-        cl.cache_e2_low = ce2 < cl.cache_e2 ? cl.cache_e2_low + 1 : 0;
-        if (cl.cache_e2_low >= 16) { cl.cache_e2--; cl.cache_e2_low = 0; }
+        if (ce2 < cl.cache_e2) {
+          cl.cache_e2_low_max = cl.cache_e2_low ? std::max(cl.cache_e2_low_max, ce2) : ce2;
+          if (++cl.cache_e2_low >= 16) { cl.cache_e2 = cl.cache_e2_low_max; cl.cache_e2_low = 0; }  // (the largest of those sixteen frames)
+        } else {
+          cl.cache_e2_low = 0;
+        }
         if (cl.cache_frame >= (1 << 30)) { cl.cache_frame = 0; fresh = true; }
         cl.cache_frame++;
         if (fresh) HIPCHK(c, hipMemsetAsync(cl.cache_small.p, 0, sizeof(int) * (rgck::kTodoLists + 16), s));  // (list lengths, epoch, overflow)
@@ -2809,10 +2814,16 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   c->stats.searched_target = c->tgt.ready ? c->tgt.n : 0;
   if (c->tgt.ready && c->tgt.cache_on && c->tgt.seed_warm && c->tgt.cache_small.p) {
     // the neighbour-list cache's list lengths and its epoch word (== the frame: everything was searched)
-    int h[rgck::kTodoLists + 2];
+    int h[rgck::kTodoLists + 3];
     HIPCHK(c, hipMemcpyAsync(h, c->tgt.cache_small.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const bool redo = h[rgck::kTodoLists] == c->tgt.cache_frame || h[rgck::kTodoLists + 1] == c->tgt.cache_frame - 1;
+    const bool redo = h[rgck::kTodoLists] == c->tgt.cache_frame || h[rgck::kTodoLists + 1 + ((c->tgt.cache_frame - 1) & 1)] == c->tgt.cache_frame - 1;
+    if (getenv("RGC_TRACE_CACHE")) {
+      int mx = 0; long long sm = 0;
+      for (int l = 0; l < rgck::kTodoLists; l++) { mx = std::max(mx, h[l]); sm += h[l]; }
+      fprintf(stderr, "[rgc] cache: frame %d epoch %d overflow %d %d lists sum %lld max %d cap %d e2 %d slack %g searched_lists %d\n", c->tgt.cache_frame, h[rgck::kTodoLists],
+              h[rgck::kTodoLists + 1], h[rgck::kTodoLists + 2], sm, mx, c->tgt.todo_cap, c->tgt.cache_e2, 4.0 * 1.7320508 * 1.1 * std::ldexp(1.0, c->tgt.cache_e2 - 24), (int)c->tgt.cache_searched_lists);
+    }
     if (!redo && c->tgt.cache_searched_lists) {
       int sum = 0;
       for (int l = 0; l < rgck::kTodoLists; l++) sum += std::min(h[l], c->tgt.todo_cap);

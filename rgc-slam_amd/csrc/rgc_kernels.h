@@ -61,7 +61,7 @@ struct KnnCache {
   int* pos_of = nullptr;     // [n] this frame's position of rank r in the sorted array (k_rank_gather)
   int* qrank = nullptr;      // [n] ... and the rank of the point at position i
   const int* epoch = nullptr;  // *epoch == frame: the map changed this frame (or the lists are not trusted)
-  int* overflow = nullptr;   // *overflow == frame - 1: the previous frame's rebuild ran out of room in a todo list: rebuild again
+  int* overflow = nullptr;   // overflow[(frame - 1) & 1] == frame - 1: the previous frame's rebuild ran out of room in a todo list: rebuild again
   int frame = 0;
   int* todo = nullptr;       // kTodoLists lists of ranks of the queries without a certificate, todo_cap entries each
   int* todo_cnt = nullptr;   // ... their lengths (emptied by k_place in a frame that rebuilds)

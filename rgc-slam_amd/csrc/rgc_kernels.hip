@@ -540,7 +540,9 @@ constexpr unsigned long long kOrdIdxMask = (1ull << kOrdIdxBits) - 1ull;
 constexpr int kOrdCntMax = (1 << kOrdCntBits) - 1;
 // The neighbour-list cache (KnnCache): does this frame search every query and rebuild the lists?  The map changed (k_count<true> found a
 // point that differs from the library's copy, or was told not to trust it), or the previous rebuild ran out of room in a todo list.
-__device__ __forceinline__ bool cache_redo(const KnnCache& kc) { return *kc.epoch == kc.frame || *kc.overflow == kc.frame - 1; }
+// (overflow: two words, written by frame f at [f & 1] and read by frame f + 1 there: a rebuild that overflows again must not change what the
+// workgroups of its own launch that start later read)
+__device__ __forceinline__ bool cache_redo(const KnnCache& kc) { return *kc.epoch == kc.frame || kc.overflow[(kc.frame - 1) & 1] == kc.frame - 1; }
 __global__ void k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of, const int* __restrict__ start,
                         unsigned long long* __restrict__ order_tmp, int prio, KnnCache kc) {
   wave_prio(prio);
@@ -1179,7 +1181,7 @@ __device__ __forceinline__ void cache_uncertified(const Deferred& df, int rank) 
   const int l = (int)(blockIdx.x % kTodoLists);
   const int e = atomicAdd(&df.cache.todo_cnt[l], 1);
   if (e < df.cache.todo_cap) df.cache.todo[(size_t)l * df.cache.todo_cap + e] = rank;
-  else *df.cache.overflow = df.cache.frame;  // no room: the next frame searches everything again (cache_redo)
+  else df.cache.overflow[df.cache.frame & 1] = df.cache.frame;  // no room: the next frame searches everything again (cache_redo)
 }
 
 // The MAP's search (a leaf-filtered cloud: nothing crowded, the block is nine whole rows).  KB: low key bits that hold the candidate's
@@ -1480,7 +1482,9 @@ __device__ __forceinline__ bool knn_point_seeded(const float4* __restrict__ P, c
   const float seed = df.seed[orig];
   if (!(seed < 1.0e30f)) { LAB_DECLINE(1); return false; }  // never searched (or deferred every time)
   // keys below tkey are admitted: the seeded k-th distance, grown by the slack, rounded up, plus three key buckets
-  const float rs = __builtin_sqrtf(seed) + df.seed_slack;
+  // (a search that also issues the certificates -- a frame that rebuilds the neighbour lists -- admits a little more: exactly k keys
+  // under the bound then PROVES the gap a certificate needs, instead of leaving it undecided for every other query)
+  const float rs = __builtin_sqrtf(seed) + df.seed_slack + (df.cache.nbr ? 1.5f * df.cache.cert_slack + 8.0e-6f * __builtin_sqrtf(seed) : 0.f);
   const int tkey = ((__float_as_int(rs * rs * 1.000001f) >> KB) + 3) << KB;
   const float tauf = __int_as_float(tkey);
   const int c[3] = {cell_coord(px, g) - g.minc[0], cell_coord(py, g) - g.minc[1], cell_coord(pz, g) - g.minc[2]};
@@ -2053,7 +2057,13 @@ void lab_wave_ts(long long* out, hipStream_t s) {
 #define RGC_SEED_T 128
 #endif
 constexpr int kSeedT = RGC_SEED_T;
-template <bool kTarget, bool kSeeded> struct SpLaunch : SpConfig<kTarget> { static constexpr int T = kSeeded ? kSeedT : SpConfig<kTarget>::T; };
+#ifndef RGC_SEED_WAVES
+#define RGC_SEED_WAVES 1
+#endif
+template <bool kTarget, bool kSeeded> struct SpLaunch : SpConfig<kTarget> {
+  static constexpr int T = kSeeded ? kSeedT : SpConfig<kTarget>::T;
+  static constexpr int W = kSeeded ? RGC_SEED_WAVES : 1;  // waves per SIMD the register allocation must leave room for (1: whatever it takes)
+};
 struct CoopRows {  // per-wave LDS scratch of the cooperative search (coop_run)
   int pref[WAVE + 1];
   int rowa[WAVE];
@@ -2341,7 +2351,7 @@ k_knn_coop(const float4* __restrict__ P, const int* __restrict__ start, Grid g, 
 }
 
 template <int KC, bool kTarget, bool kExact, bool kSeeded = false>
-__global__ void __launch_bounds__((SpLaunch<kTarget, kSeeded>::T))
+__global__ void __launch_bounds__((SpLaunch<kTarget, kSeeded>::T), (SpLaunch<kTarget, kSeeded>::W))
 k_knn_sp(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, Deferred df,
          double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz) {
   extern __shared__ int slist_sp[];  // [SpShape::LDS][T]

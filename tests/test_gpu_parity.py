@@ -1089,7 +1089,7 @@ def test_neighbour_lists_of_an_unchanged_map(reg_mod, orc, medium, monkeypatch):
     t_far = np.asarray(t, np.float64) + np.array([2000.0, -900.0, 10.0])
     frame("two kilometres out", q, t_far, "all")
     frame("... again", q, t_far + 0.25, None)        # (certificates need a gap of 2 mm there: few queries have one, the lists overflow)
-    for j in range(100, 180):                        # back: sixteen frames per binary order of magnitude until certificates are cheap again
+    for j in range(100, 120):                        # back: sixteen frames until certificates are issued for the smaller coordinates again
         frame("back", *pose(j), None)
     frame("back for good", *pose(19), "few")
     # not a rigid motion
@@ -1098,6 +1098,41 @@ def test_neighbour_lists_of_an_unchanged_map(reg_mod, orc, medium, monkeypatch):
     frame("scaled quaternion", q_bad, t, "all")
     frame("after it", *pose(21), "all")
     frame("... and then", *pose(22), "few")
+    for p in (d_map, d_body):
+        v.device_free(p)
+    for p in (d_map_w, d_body_w):
+        w.device_free(p)
+    v.close(); w.close()
+
+
+def test_neighbour_lists_when_the_todo_lists_overflow(reg_mod, monkeypatch):
+    """A rebuild of the neighbour lists that runs out of room for the queries without a certificate -- a 1 M-point map twenty-five kilometres from
+    its frame's origin: the certificates need a 2 cm gap, most queries have none -- must make the NEXT frame search everything again, for
+    every workgroup of that frame's launch alike, including those that start after the rebuild has overflowed once more (round 5: the
+    first version kept ONE overflow word, which the overflowing launch itself overwrote under its later workgroups; scripts/soak_lists.py
+    found it).  Four frames far out, then back: bit for bit the covariances of a context that keeps nothing."""
+    import bench
+    import rgc_slam_amd.synth as synth
+    n = 1000000
+    _, tgt = synth.make_world_and_map(n, seed=synth.SEED)
+    a = np.zeros((n, 4), np.float32); a[:, :3] = tgt
+    v = _odo(reg_mod)
+    monkeypatch.setenv("RGC_KNN_SEEDS", "0")
+    w = _odo(reg_mod)
+    monkeypatch.delenv("RGC_KNN_SEEDS")
+    d_map, d_body = v.device_alloc(16 * n), v.device_alloc(16 * n)
+    d_map_w, d_body_w = w.device_alloc(16 * n), w.device_alloc(16 * n)
+    v.upload(d_map, a); w.upload(d_map_w, a)
+    searched = []
+    for j, far in enumerate([0, 0, 1, 1, 1, 1, 0, 0]):
+        Tw = synth.se3(synth.rot_zyx(0.4 * j, 0.01, -0.01), [3.0 * j + 20000.0 * far, -2.0 * j - 15000.0 * far, 0.1 * j])
+        q, t = bench.world_to_body(Tw)
+        v.setInputTargetReframed(d_map, n, 16, q, t, d_body)
+        w.setInputTargetReframed(d_map_w, n, 16, q, t, d_body_w)
+        assert np.array_equal(v.getTargetCovariances(), w.getTargetCovariances()), (j, far)
+        searched.append(v.stats()["searched_target"])
+    assert searched[1] < 0.05 * n, searched                # near the origin: the lists serve
+    assert searched[3] == n and searched[4] == n, searched  # far out: every rebuild overflows, every frame searches everything
     for p in (d_map, d_body):
         v.device_free(p)
     for p in (d_map_w, d_body_w):
