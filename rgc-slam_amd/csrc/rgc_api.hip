@@ -521,7 +521,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       // way, so only that route has them; a lazy target searches a part of the map per frame and keeps none.
       const double qn = cl.rf.q.x * cl.rf.q.x + cl.rf.q.y * cl.rf.q.y + cl.rf.q.z * cl.rf.q.z + cl.rf.q.w * cl.rf.q.w;
       cl.cache_on = false;
-      if (c->cache_on && fuse_reframe && c->lazy_margin <= 0 && std::fabs(qn - 1.0) < 1.0e-6) {
+      if (c->cache_on && fuse_reframe && c->lazy_margin <= 0 && std::fabs(qn - 1.0) < 2.5e-7) {
         bool fresh = !cl.seed_warm || !cl.cache_live || !cl.nbr.p;
         const size_t cap = (size_t)std::max(256, n / (4 * rgck::kTodoLists) + 1);
         if ((rc = ensure(c, cl.nbr, sizeof(int) * (size_t)n * 20))) return rc;
