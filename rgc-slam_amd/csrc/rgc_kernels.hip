@@ -844,8 +844,8 @@ struct Deferred {
   // Any value is safe: a search that does not find its k neighbours under the bound runs again without it.
   float* seed;
   float seed_slack;  // how much a k-th distance may have grown since (the coordinates' fp32 rounding in two different frames), metres
-  // the neighbour-list cache (KnnCache, rgc_kernels.h; nbr == nullptr: none).  seed < 0: the list of that point is CERTIFIED (|seed| is
-  // the bound as before); the exact searches write the lists and the certificates, knn_point_cached reads them.
+  // the neighbour-list cache (KnnCache, rgc_kernels.h; nbr == nullptr: none): the exact searches of a frame that rebuilds the lists write
+  // them (the certificate is the top bit of a list's first entry), knn_point_cached reads them
   KnnCache cache;
   int cache_nb;  // workgroups at the end of the map's bulk launch that search the listed (uncertified) queries
   // the scan's deferred queries resolved INSIDE its bulk launch (coop_stream): the launch's last coop_blocks workgroups take entries as
