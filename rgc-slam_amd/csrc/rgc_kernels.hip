@@ -847,7 +847,7 @@ struct Deferred {
   // the neighbour-list cache (KnnCache, rgc_kernels.h; nbr == nullptr: none): the exact searches of a frame that rebuilds the lists write
   // them (the certificate is the top bit of a list's first entry), knn_point_cached reads them
   KnnCache cache;
-  int cache_nb;  // workgroups at the end of the map's bulk launch that search the listed (uncertified) queries
+  int cache_nb;  // workgroups at the FRONT of the map's bulk launch that search the queries on the todo lists (no certificate)
   // the scan's deferred queries resolved INSIDE its bulk launch (coop_stream): the launch's last coop_blocks workgroups take entries as
   // they are published -- slot e = {enc, thr} in one 64-bit word (kSlotEmpty until then, put back by the reader) -- and leave when all
   // bulk workgroups have counted themselves out (*done) and the list is exhausted.  coop_blocks == 0: the lists above, a launch of its own.
