@@ -2565,6 +2565,11 @@ __global__ void __launch_bounds__(kListT) k_lazy_lists(const float4* __restrict_
 }
 
 constexpr int VOX_T = 256;
+#ifndef RGC_VOX_WAVES
+#define RGC_VOX_WAVES 1  // waves per SIMD k_voxel_build_coop's register allocation must leave room for.  6 (rounds 3-5) held the launch to 80
+                         // VGPRs -- and its cooperative half, the deferred queries everything behind the launch waits for, to 180 bytes of
+                         // scratch spills; without the cap (128 VGPRs, no scratch) a frame is 8 us shorter
+#endif
 // LDS of a voxel-building workgroup: the nine terms of its points (rows one element longer than the block: the nine rows of one point
 // fall into nine different bank pairs) and the list of the cells that START in the block.
 struct VoxLds {
@@ -2665,7 +2670,7 @@ k_voxel_build(const float4* __restrict__ P, const double* __restrict__ nx, const
 // afterwards (k_voxel_patch).  Two streams and events did the same 20 us SLOWER than the serial chain (a cross-stream dependency costs
 // ~10 us here); one launch has no such hop.
 template <int KC>
-__global__ void __launch_bounds__(VOX_T, 6)
+__global__ void __launch_bounds__(VOX_T, RGC_VOX_WAVES)
 k_voxel_build_coop(const float4* __restrict__ P, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz,
                    const int* __restrict__ start, Grid g, int n, const int* __restrict__ cell_voxel, double* __restrict__ vox,
                    int* __restrict__ vox_cell, int nb_coop, int k, Deferred df) {
