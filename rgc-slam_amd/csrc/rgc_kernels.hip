@@ -2564,7 +2564,13 @@ __global__ void __launch_bounds__(kListT) k_lazy_lists(const float4* __restrict_
   if (head) cell_list[base_s[1] + wc[w] + __popcll(mh & below)] = s;
 }
 
-constexpr int VOX_T = 256;
+#ifndef RGC_GRID_T
+#define RGC_GRID_T 256  // workgroup size of the grid build's per-point passes (k_count, k_place, k_rank_gather)
+#endif
+#ifndef RGC_VOX_T
+#define RGC_VOX_T 256
+#endif
+constexpr int VOX_T = RGC_VOX_T;
 #ifndef RGC_VOX_WAVES
 #define RGC_VOX_WAVES 1  // waves per SIMD k_voxel_build_coop's register allocation must leave room for.  6 (rounds 3-5) held the launch to 80
                          // VGPRs -- and its cooperative half, the deferred queries everything behind the launch waits for, to 180 bytes of
@@ -4165,8 +4171,8 @@ void bbox(hipStream_t s, const float* in, int stride_f, int n, double res, int* 
 }
 void count_cells(hipStream_t s, const float* in, int stride_f, int n, Grid g, int* cell_of, int* slot_of, int* cnt, int hi, int* guard,
                  const Reframe* rf) {
-  if (rf) hipLaunchKernelGGL(k_count<true>, dim3(nblk(n, 256)), dim3(256), 0, s, in, 4, n, g, cell_of, slot_of, cnt, guard, hi, *rf);
-  else hipLaunchKernelGGL(k_count<false>, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi, Reframe{});
+  if (rf) hipLaunchKernelGGL(k_count<true>, dim3(nblk(n, RGC_GRID_T)), dim3(RGC_GRID_T), 0, s, in, 4, n, g, cell_of, slot_of, cnt, guard, hi, *rf);
+  else hipLaunchKernelGGL(k_count<false>, dim3(nblk(n, RGC_GRID_T)), dim3(RGC_GRID_T), 0, s, in, stride_f, n, g, cell_of, slot_of, cnt, guard, hi, Reframe{});
 }
 void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, int* cell_voxel, int* nvox, int hi, float* sum_sq) {
   const int nb = nblk(n, SCAN_B);
@@ -4180,7 +4186,7 @@ void scan_cells(hipStream_t s, int* cnt, int* start, int n, void* block_sums, in
   }
 }
 void place(hipStream_t s, int n, const int* cell_of, const int* slot_of, const int* start, unsigned long long* order_tmp, int hi, const KnnCache* cache) {
-  hipLaunchKernelGGL(k_place, dim3(nblk(n, 256)), dim3(256), 0, s, n, cell_of, slot_of, start, order_tmp, hi, cache ? *cache : KnnCache{});
+  hipLaunchKernelGGL(k_place, dim3(nblk(n, RGC_GRID_T)), dim3(RGC_GRID_T), 0, s, n, cell_of, slot_of, start, order_tmp, hi, cache ? *cache : KnnCache{});
 }
 void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_sums, int hi) {
   const int nb = nblk(n, SCAN_B);
@@ -4192,7 +4198,7 @@ void exclusive_scan(hipStream_t s, const int* in, int* out, int n, int* block_su
 }
 void rank_gather(hipStream_t s, const float* in, int stride_f, int n, const int* cell_of, const int* start,
                  const unsigned long long* order_tmp, float4* P, int* zero_me, int hi, const KnnCache* cache) {
-  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, 256)), dim3(256), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi,
+  hipLaunchKernelGGL(k_rank_gather, dim3(nblk(n, RGC_GRID_T)), dim3(RGC_GRID_T), 0, s, in, stride_f, n, cell_of, start, order_tmp, P, zero_me, hi,
                      cache ? *cache : KnnCache{});
 }
 size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
