@@ -3707,8 +3707,13 @@ __device__ __forceinline__ double fitness_wave(const float4* __restrict__ SP, in
   const int lane = (int)threadIdx.x & (WAVE - 1);
   const int i = n_all > 0 ? lane * W + w : w * FIT_T + lane;
   float best = 0.f, q[3] = {0.f, 0.f, 0.f};
+  // (two calls, not one with a conditional pointer: a flag whose address is passed "maybe" lives in scratch memory -- one byte of it made
+  // every launch of the solve a kernel with a private segment)
   bool unresolved = false;
-  if (i < ns) best = fitness_point(SP, i, T, TP, tstart, g, n_all > 0 ? &unresolved : nullptr, q);
+  if (i < ns) {
+    if (n_all > 0) best = fitness_point(SP, i, T, TP, tstart, g, &unresolved, q);
+    else best = fitness_point(SP, i, T, TP, tstart, g, nullptr, q);
+  }
   if (n_all > 0) {
     // (up to FOUR unsettled queries share one pass over the map: the pass is a chain of load round trips -- 21 of them for a 10 k-point
     // map, ~17 us -- and a sweep's far points come three or four to a wave: one pass instead of three or four.  A minimum does not depend
