@@ -774,7 +774,9 @@ def main():
                             "neighbours from the list (knn_point_cached), the others (queries_searched_per_launch) are searched, seeded with the k-th "
                             "distance their last search found (knn_point_seeded, exact whatever the seed); launch_alone_changed_map_ms is the launch after "
                             "the buffer was written to (everything searched, seeded, lists rebuilt), launch_alone_unseeded_ms the launch for a map the "
-                            "library has not seen before")
+                            "library has not seen before.  Since the lists this is no longer the longest launch of a frame -- the scan's two search "
+                            "launches on the second stream (off the critical path of a sequence on two contexts) and the solve's chain of short "
+                            "launches take more time each (profiles/*_kernel_stats.csv); it stays the kernel SURVEY 8d's bytes are defined for")
         if issue and issue.get("peak_mix_weighted"):
             issue["frac_of_mix_weighted_peak_launch_alone"] = round(issue["valu_wave_instructions_per_query"] * units / (alone_ms * 1e-3) / 1e9
                                                                     / issue["peak_mix_weighted"], 4)
