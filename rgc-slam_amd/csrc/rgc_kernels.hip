@@ -90,9 +90,12 @@ __device__ __forceinline__ double quad_sum_f64(double v) {  // (l0 + l1) + (l2 +
 // source kernels finish while the big kernel soaks up what is left.
 // Three levels: the map's throughput kernels stay at 0, the scan's preparation runs at 2, the solve's steps and the score -- the
 // frame's critical chain, which with two contexts share the chip with the NEXT scan's preparation -- at 3.
+#ifndef RGC_SCAN_PRIO
+#define RGC_SCAN_PRIO 2
+#endif
 __device__ __forceinline__ void wave_prio(int hi) {
   if (hi >= 2) __builtin_amdgcn_s_setprio(3);
-  else if (hi) __builtin_amdgcn_s_setprio(2);
+  else if (hi) __builtin_amdgcn_s_setprio(RGC_SCAN_PRIO);
 }
 
 // Developer build (-DRGC_LAB): how often the wave-level loops of the map's bulk kNN kernel run -- with the kernel's ISA that gives the
