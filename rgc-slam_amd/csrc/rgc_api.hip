@@ -1720,12 +1720,13 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   // frame's map meanwhile (15 k waves that fill every CU), the dispatcher places the solve's ~100 workgroups as soon as slots free up
   // instead of behind that launch.
   int rc;
+  bool join_late = false;
   if (c->solve_behind_map && c->main_has_target_prep && !map_prep_finished(c)) {
     // the map is still being prepared (a dependent sequence: it could only start when the previous pose was known): the solve goes
     // directly behind it on the main stream -- a dependency that resolves across streams costs ~10 us on this runtime, and the scan's
     // preparation, which the solve also waits for, has long finished
     c->solve_stream = c->stream;
-    if ((rc = join_source(c))) return rc;
+    join_late = true;  // (join_source may wait on the host for an almost-ready scan: done last, right in front of the first launch)
   } else {
     c->solve_stream = c->stream2;
     HIPCHK(c, hipEventRecord(c->tgt_ready, c->stream));
@@ -1772,6 +1773,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   if (batch > P.max_iterations + 2) batch = P.max_iterations + 2;
   if (batch < 2) batch = 2;
   c->lm_seq = c->lm_seq >= 0x3fffffff ? 1 : c->lm_seq + 1;
+  if (join_late && (rc = join_source(c))) return rc;
   if ((rc = lm_enqueue_batch(c, batch, &in, want_fitness != 0))) return rc;
   memcpy(c->pend.guess, guess, sizeof(c->pend.guess));
   c->pend.want_fitness = want_fitness != 0;
