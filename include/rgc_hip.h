@@ -236,16 +236,33 @@ RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stri
  * makes it right.  Covariances are bit-identical with and without seeds (RGC_KNN_SEEDS=0 in the environment switches them off).
  * Neighbour lists (round 5): on top of the seeds the library keeps, per point, the 20 neighbours its last exact search found and its OWN
  * COPY of the map (112 bytes per point in all).  Every call compares d_xyzi with that copy, bit for bit, in the pass that re-frames it;
- * when nothing differs (and q is a unit quaternion to 2.5e-7), a point whose list carries a certificate -- the gap behind its 20th
+ * when nothing differs (and |q|^2 is within 1e-9 of 1: any quaternion normalised in fp64), a point whose list carries a certificate -- the gap behind its 20th
  * neighbour is wider than the fp32 rounding of the coordinates in any two frames can bridge -- takes its neighbours from the list instead
  * of searching (about 99 % of a map; rgc_stats::searched_target counts the rest); one differing coordinate and the call searches every
  * point again and rebuilds the lists.  The result is the search's, bit for bit, either way (RGC_KNN_CACHE=0 switches the lists off).
  * A lazy target (rgc_set_target_lazy) keeps seeds but no lists.
+ * WHEN THIS HELPS, AND WHEN IT CANNOT: seeds and lists belong to point IDENTITIES.  They serve a caller that keeps its sub-map in the world
+ * frame on the device and hands the same points over every frame -- i.e. one that has dropped the reference's per-frame body-frame leaf filter
+ * (pcl::VoxelGrid over the re-framed sub-map, src/RGC_odometer.cpp:985-991: its centroids are a new point set every frame) and filters once
+ * per keyframe instead (rgc_map_commit does).  A caller that keeps the reference's frame body (rgc::OdometryNode does) never hits them: its
+ * target is a map the library has not seen, every frame, and costs the full search.  rgc_set_knn_reuse(ctx, RGC_REUSE_NONE) gives exactly
+ * that cost for any map, and is what bench.py's `value` is timed with.
  * Preconditions: d_scratch must not overlap d_xyzi (RGC_ERR_INVALID: the input is read while the output is written, and a buffer has
  * one bounding-box hint); a d_scratch that is 16-byte aligned (anything hipMalloc / rgc_device_alloc returns) takes the fused path
  * -- re-framing inside the preparation's counting pass -- any other 4-byte aligned address the re-framing runs as its own launch. */
 RGC_API int rgc_set_target_reframed(rgc_ctx* ctx, const float* d_xyzi, int n, int stride_bytes, const double q_xyzw[4], const double t[3],
                                     float* d_scratch);
+/* What a context keeps between the targets rgc_set_target_reframed prepares (no reference counterpart: the reference keeps nothing, it
+ * builds a FastVGICP per frame, src/RGC_odometer.cpp:998).  Results never depend on the mode, bit for bit.
+ *   RGC_REUSE_NONE   nothing: every target is searched like a map the library has not seen (no per-point state, no copy of the map)
+ *   RGC_REUSE_SEEDS  the k-th distances of the last search (4 bytes per point)
+ *   RGC_REUSE_LISTS  seeds + neighbour lists + the library's copy of the map (112 bytes per point; the default).  If the device cannot hold
+ *                    them the context drops to RGC_REUSE_SEEDS by itself and carries on (rgc_get_knn_reuse tells).
+ * Takes effect with the next rgc_set_target_reframed; lowering the mode frees the buffers it no longer needs (synchronises the context).
+ * RGC_KNN_SEEDS=0 / RGC_KNN_CACHE=0 in the environment set a context's INITIAL mode to NONE / SEEDS (rgc_create). */
+typedef enum rgc_knn_reuse { RGC_REUSE_NONE = 0, RGC_REUSE_SEEDS = 1, RGC_REUSE_LISTS = 2 } rgc_knn_reuse;
+RGC_API int rgc_set_knn_reuse(rgc_ctx* ctx, int mode);
+RGC_API int rgc_get_knn_reuse(const rgc_ctx* ctx, int* mode);
 
 /* ---- A1-A8  ScanRegistration::laserCloudHandler (src/scanRegistration.cpp:89-730): range/NaN filter, ring + rel-time
  * assignment, curvature stencils, ground marking + weighted-PCA ground plane, occlusion mask, per-ring 6-sector
@@ -486,7 +503,7 @@ RGC_API int rgc_mapreg_optimize(rgc_ctx* ctx, const float* corner_cur, int n_ccu
  * fp32 coordinates stay small), the registration runs in that frame (guess = T_w_curr * T_last_curr, result = the new world pose)
  * and the target (filter + grid + covariances + voxels) is rebuilt, on the device, only when a keyframe was inserted or evicted.
  * Numerics differ from the reference by the frame the 0.3 m leaf lattice and the 1 m voxel lattice are aligned to (map axes
- * instead of the previous body axes); see DESIGN.md 6e for the parity definition of this row. */
+ * instead of the previous body axes); the parity definition of this row: DESIGN.md section 6 (f2) and EXPERIMENTS.md "6e". */
 typedef struct rgc_map_info {
   int n_keyframes;
   long long n_points;            /* world-frame points held (before the leaf filter) */

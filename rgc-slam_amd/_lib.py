@@ -112,7 +112,7 @@ class RgcError(RuntimeError):
 SYMBOLS = [
     "rgc_default_params", "rgc_create", "rgc_destroy", "rgc_set_params", "rgc_get_params", "rgc_last_error",
     "rgc_status_string", "rgc_version", "rgc_set_target", "rgc_set_source", "rgc_set_target_device",
-    "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align", "rgc_align_begin", "rgc_align_end", "rgc_align_end_reframe", "rgc_share_target", "rgc_hold_source_until_target_of", "rgc_set_target_lazy",
+    "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align", "rgc_align_begin", "rgc_align_end", "rgc_align_end_reframe", "rgc_share_target", "rgc_hold_source_until_target_of", "rgc_set_target_lazy", "rgc_set_knn_reuse", "rgc_get_knn_reuse",
     "rgc_fitness", "rgc_get_aligned", "rgc_get_aligned_device", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_set_source_covariances", "rgc_set_target_covariances",
     "rgc_clear_source", "rgc_clear_target", "rgc_swap_source_and_target", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_host_alloc", "rgc_host_free", "rgc_upload", "rgc_download", "rgc_synchronize",
@@ -191,6 +191,8 @@ def load():
     L.rgc_set_target_covariances.argtypes = [vp, dp, C.c_int]
     L.rgc_hold_source_until_target_of.argtypes = [vp, vp]
     L.rgc_set_target_lazy.argtypes = [vp, C.c_int]
+    L.rgc_set_knn_reuse.argtypes = [vp, C.c_int]
+    L.rgc_get_knn_reuse.argtypes = [vp, ip]
     L.rgc_clear_source.argtypes = [vp]
     L.rgc_clear_target.argtypes = [vp]
     L.rgc_swap_source_and_target.argtypes = [vp]

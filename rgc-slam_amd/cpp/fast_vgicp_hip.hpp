@@ -82,6 +82,11 @@ public:
   // align()'s guess -- only the voxels a solve looks up enter its cost (fast_vgicp_impl.hpp:73-116).  Every look-up is checked and a solve
   // that leaves the built part is repeated on the completed map: results are the full build's bit for bit.  0 switches it off.
   void setLazyTarget(int margin_cells) { chk(rgc_set_target_lazy(ctx_, margin_cells)); }
+  // What is kept between the targets setInputTargetReframed prepares (rgc_set_knn_reuse): RGC_REUSE_NONE / _SEEDS / _LISTS (default).  A frame
+  // body that keeps the reference's per-frame leaf filter of the sub-map (RGC_odometer.cpp:985-991) hands over a new point set every frame
+  // and gains nothing from seeds or lists; NONE then saves their 112 bytes per point.  Results never depend on the mode.
+  void setNeighbourReuse(int mode) { chk(rgc_set_knn_reuse(ctx_, mode)); }
+  int  getNeighbourReuse() const { int m = 0; rgc_get_knn_reuse(ctx_, &m); return m; }
   // two contexts taking turns on a dependent sequence: this context's scan preparation (enqueued now) is held back until `other`'s map
   // preparation has finished, so that it runs under other's solve instead of beside the launch other's frame is waiting for
   void holdSourceUntilTargetOf(FastVGICPHip& other) { chk(rgc_hold_source_until_target_of(ctx_, other.ctx_)); }

@@ -32,7 +32,8 @@ constexpr int kMaxK = 32;
 // system-scope one -- the L2s written back so that the HOST may read what came before; nobody's host does behind these).
 constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 // Build-time switches (RGC_EXTRA_FLAGS=-D...): alternative routes to the SAME results, kept for A/B measurements.  A caller's
-// process reads only RGC_LM_IMPL, RGC_SPEC_GRID, RGC_KNN_SEEDS and RGC_TRACE_ALLOC from the environment (rgc_create).
+// process reads RGC_LM_IMPL, RGC_SPEC_GRID, RGC_KNN_SEEDS, RGC_KNN_CACHE (a context's initial rgc_set_knn_reuse mode), RGC_TRACE_ALLOC, RGC_TRACE_CACHE and the
+// three scheduling switches RGC_JOIN_SPIN_US / RGC_PREP_EVENT_EXT / RGC_COOP_STREAM from the environment, once, in rgc_create.
 #ifndef RGC_LM_POST
 #define RGC_LM_POST 1          // 0: rgc_align_end always waits for the stream and its copy of the state (round 2)
 #endif
@@ -137,6 +138,7 @@ struct Cloud {
   const void* slots_seen = nullptr;  // ... of this allocation
   bool prepared_recorded = false;  // the preparation's last launch carried the context's tgt_prepared event (no record packet behind it)
   bool cache_searched_lists = false;  // the last preparation's search was the seeded launch that reads the lists (rgc_stats::searched_target)
+  int searched_known = -1;            // rgc_stats::searched_target of this preparation once it has been fetched (-1: not yet)
 };
 
 struct ProfRegion {
@@ -214,6 +216,8 @@ struct rgc_ctx {
   int join_spin_us = RGC_JOIN_SPIN_US;  // (build flag; RGC_JOIN_SPIN_US in the environment) how long the host waits for an almost-ready scan instead of putting a barrier into the map's stream (join_source)
   bool cache_on = RGC_KNN_CACHE != 0;  // (build flag; RGC_KNN_CACHE=0 in the environment) the neighbour lists of an unchanged map on top of the seeds
   bool seeds_on = RGC_KNN_SEEDS != 0;  // (build flag; RGC_KNN_SEEDS=0 in the environment) 0: every search of a re-framed map starts without a bound, as before round 5
+  bool cache_dropped = false;          // the lists' buffers did not fit on the device: the context went down to the seeds by itself (rgc_get_knn_reuse)
+  bool trace_cache = false;            // RGC_TRACE_CACHE in the environment (rgc_create): rgc_get_stats reports the lists' state on stderr
   double src_res = RGC_SRC_RES;  // (build flag) fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
   int map_wide_r = RGC_MAP_WIDE_R;          // (build flag; 0 = off, 2) block radius of the bulk kNN launch for a sparse map
   double map_wide_density = RGC_MAP_WIDE;   // (build flag) ... when the map has fewer points per grid cell than this
@@ -521,16 +525,30 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
       // way, so only that route has them; a lazy target searches a part of the map per frame and keeps none.
       const double qn = cl.rf.q.x * cl.rf.q.x + cl.rf.q.y * cl.rf.q.y + cl.rf.q.z * cl.rf.q.z + cl.rf.q.w * cl.rf.q.w;
       cl.cache_on = false;
-      if (c->cache_on && fuse_reframe && c->lazy_margin <= 0 && std::fabs(qn - 1.0) < 2.5e-7) {
+      // (the certificate's error budget is that of a RIGID motion: reframe_point applies v + 2w(u x v) + 2u x (u x v) as Eigen does, without
+      // normalising q, so |q|^2 - 1 shows up as a relative error of that order on every distance.  1e-9 is far inside the 4e-6 the
+      // certificate allows for and is met by any quaternion normalised in fp64; one normalised in fp32 gets seeds, not lists.)
+      bool lists = c->cache_on && fuse_reframe && c->lazy_margin <= 0 && std::fabs(qn - 1.0) < 1.0e-9;
+      const size_t cap = (size_t)std::max(256, n / (4 * rgck::kTodoLists) + 1);
+      if (lists) {
+        // The lists are an optimisation: if the device cannot hold them (112 B per point) the context goes down to the seeds and carries on.
+        const size_t want[7] = {sizeof(int) * (size_t)n * 20, sizeof(int) * (size_t)n, sizeof(int) * (size_t)n, sizeof(int) * (size_t)n,
+                                sizeof(float4) * (size_t)n, sizeof(int) * cap * rgck::kTodoLists, sizeof(int) * (rgck::kTodoLists + 16)};
+        DevBuf* bufs[7] = {&cl.nbr, &cl.pos_of, &cl.rank_of, &cl.qrank, &cl.map_copy, &cl.todo, &cl.cache_small};
+        for (int b = 0; b < 7 && lists; b++)
+          if (ensure(c, *bufs[b], want[b]) != RGC_OK) lists = false;
+        if (!lists) {
+          (void)hipGetLastError();
+          for (DevBuf* b : bufs) release(*b);
+          c->cache_on = false;
+          c->cache_dropped = true;
+          cl.cache_live = false;
+          static const bool trace = getenv("RGC_TRACE_ALLOC") != nullptr;
+          if (trace) fprintf(stderr, "[rgc] neighbour lists of %d points do not fit on the device: this context keeps seeds only from here on\n", n);
+        }
+      }
+      if (lists) {
         bool fresh = !cl.seed_warm || !cl.cache_live || !cl.nbr.p;
-        const size_t cap = (size_t)std::max(256, n / (4 * rgck::kTodoLists) + 1);
-        if ((rc = ensure(c, cl.nbr, sizeof(int) * (size_t)n * 20))) return rc;
-        if ((rc = ensure(c, cl.pos_of, sizeof(int) * (size_t)n))) return rc;
-        if ((rc = ensure(c, cl.rank_of, sizeof(int) * (size_t)n))) return rc;
-        if ((rc = ensure(c, cl.qrank, sizeof(int) * (size_t)n))) return rc;
-        if ((rc = ensure(c, cl.map_copy, sizeof(float4) * (size_t)n))) return rc;
-        if ((rc = ensure(c, cl.todo, sizeof(int) * cap * rgck::kTodoLists))) return rc;
-        if ((rc = ensure(c, cl.cache_small, sizeof(int) * (rgck::kTodoLists + 16)))) return rc;
         cl.todo_cap = (int)cap;
         int ce2;  // (a cell of margin around the box, as the grid has)
         (void)std::frexp(1.5 * maxabs + 2.0 * res, &ce2);
@@ -558,6 +576,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     }
     if (is_target && &cl == &c->tgt) {
       cl.cache_live = false;  // (set again by the search that attaches the lists, cloud_covariances)
+      cl.searched_known = -1;
       if (!cl.cache_on) { cl.rf.copy = nullptr; cl.rf.epoch = nullptr; }
     }
     cl.reframe_pending = false;
@@ -954,6 +973,7 @@ int join_source(rgc_ctx* c) {
         if (hipEventQuery(c->src_ready) == hipSuccess) { ready = true; break; }
         if (map_prep_finished(c)) break;
         if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > (double)c->join_spin_us) break;
+        __builtin_ia32_pause();  // (a sibling hyper-thread may be driving another sequence's context)
       }
     }
     if (!ready) {
@@ -1473,6 +1493,8 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   if (const char* e = getenv("RGC_SPEC_GRID")) c->spec_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_KNN_SEEDS")) c->seeds_on = atoi(e) != 0;
   if (const char* e = getenv("RGC_KNN_CACHE")) c->cache_on = atoi(e) != 0;
+  if (!c->seeds_on) c->cache_on = false;  // (the lists sit on top of the seeds)
+  c->trace_cache = getenv("RGC_TRACE_CACHE") != nullptr;
   if (const char* e = getenv("RGC_JOIN_SPIN_US")) c->join_spin_us = atoi(e);
   if (const char* e = getenv("RGC_PREP_EVENT_EXT")) c->prep_event_ext = atoi(e) != 0;
   if (const char* e = getenv("RGC_COOP_STREAM")) c->coop_stream_on = atoi(e) != 0;
@@ -1608,6 +1630,39 @@ int rgc_set_target_lazy(rgc_ctx* c, int margin_cells) {
   if (margin_cells < 0 || margin_cells > 16) return fail(c, RGC_ERR_INVALID, "rgc_set_target_lazy: margin_cells must be in [0, 16]");
   if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   c->lazy_margin = margin_cells;  // (takes effect with the next target; one already set keeps the state it is in)
+  return RGC_OK;
+}
+
+int rgc_set_knn_reuse(rgc_ctx* c, int mode) {
+  if (!c) return RGC_ERR_INVALID;
+  if (mode < RGC_REUSE_NONE || mode > RGC_REUSE_LISTS) return fail(c, RGC_ERR_INVALID, "rgc_set_knn_reuse: mode must be RGC_REUSE_NONE, _SEEDS or _LISTS");
+  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  const bool seeds = mode >= RGC_REUSE_SEEDS && RGC_KNN_SEEDS != 0, lists = seeds && mode >= RGC_REUSE_LISTS && RGC_KNN_CACHE != 0;
+  Cloud& cl = c->tgt;
+  if ((!lists && cl.nbr.p) || (!seeds && cl.seed.p)) {  // buffers this context no longer needs: nothing may still be reading them
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+  }
+  if (!lists) {
+    for (DevBuf* b : {&cl.nbr, &cl.pos_of, &cl.rank_of, &cl.qrank, &cl.map_copy, &cl.todo, &cl.cache_small}) release(*b);
+    cl.cache_on = cl.cache_live = cl.cache_searched_lists = false;
+    cl.rf.copy = nullptr; cl.rf.epoch = nullptr;
+  }
+  if (!seeds) {
+    release(cl.seed);
+    cl.seed_key = nullptr; cl.seed_n = 0;
+    cl.seed_on = cl.seed_warm = false;
+  }
+  c->seeds_on = seeds;
+  c->cache_on = lists;
+  c->cache_dropped = false;
+  return RGC_OK;
+}
+
+int rgc_get_knn_reuse(const rgc_ctx* c, int* mode) {
+  if (!c || !mode) return RGC_ERR_INVALID;
+  *mode = !c->seeds_on ? RGC_REUSE_NONE : (c->cache_on ? RGC_REUSE_LISTS : RGC_REUSE_SEEDS);
   return RGC_OK;
 }
 
@@ -2814,13 +2869,15 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   c->stats.searched_target = c->tgt.ready ? c->tgt.n : 0;
-  if (c->tgt.ready && c->tgt.cache_on && c->tgt.seed_warm && c->tgt.cache_small.p) {
+  if (c->tgt.ready && c->tgt.searched_known >= 0 && !c->trace_cache) {
+    c->stats.searched_target = c->tgt.searched_known;  // (fetched once per preparation)
+  } else if (c->tgt.ready && c->tgt.cache_on && c->tgt.seed_warm && c->tgt.cache_small.p) {
     // the neighbour-list cache's list lengths and its epoch word (== the frame: everything was searched)
     int h[rgck::kTodoLists + 3];
     HIPCHK(c, hipMemcpyAsync(h, c->tgt.cache_small.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const bool redo = h[rgck::kTodoLists] == c->tgt.cache_frame || h[rgck::kTodoLists + 1 + ((c->tgt.cache_frame - 1) & 1)] == c->tgt.cache_frame - 1;
-    if (getenv("RGC_TRACE_CACHE")) {
+    if (c->trace_cache) {
       int mx = 0; long long sm = 0;
       for (int l = 0; l < rgck::kTodoLists; l++) { mx = std::max(mx, h[l]); sm += h[l]; }
       fprintf(stderr, "[rgc] cache: frame %d epoch %d overflow %d %d lists sum %lld max %d cap %d e2 %d slack %g searched_lists %d\n", c->tgt.cache_frame, h[rgck::kTodoLists],
@@ -2831,6 +2888,7 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
       for (int l = 0; l < rgck::kTodoLists; l++) sum += std::min(h[l], c->tgt.todo_cap);
       c->stats.searched_target = sum;
     }
+    c->tgt.searched_known = c->stats.searched_target;
   }
   *out = c->stats;
   return RGC_OK;

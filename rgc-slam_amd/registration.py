@@ -163,6 +163,20 @@ class FastVGICP:
         at the solve's guess (0: everywhere, the default); results are the full build's bit for bit (a look-up outside repeats the solve)."""
         self._chk(self._L.rgc_set_target_lazy(self._h, int(margin_cells)))
 
+    REUSE_NONE, REUSE_SEEDS, REUSE_LISTS = 0, 1, 2
+
+    def setNeighbourReuse(self, mode: int):
+        """rgc_set_knn_reuse: what the context keeps between the targets setInputTargetReframed prepares -- REUSE_NONE (every target is
+        searched like a map the library has not seen: what a caller whose map's point set changes every frame pays anyway), REUSE_SEEDS
+        (the last search's k-th distances), REUSE_LISTS (seeds + neighbour lists of a verified-unchanged map; the default).  Results do
+        not depend on it, bit for bit."""
+        self._chk(self._L.rgc_set_knn_reuse(self._h, int(mode)))
+
+    def getNeighbourReuse(self) -> int:
+        m = C.c_int(0)
+        self._chk(self._L.rgc_get_knn_reuse(self._h, C.byref(m)))
+        return int(m.value)
+
     def holdSourceUntilTargetOf(self, other: "FastVGICP"):
         """the next setInputSource* here starts on the GPU when `other`'s target preparation (as enqueued so far) is done (rgc_hip.h)"""
         self._chk(self._L.rgc_hold_source_until_target_of(self._h, other._h))
@@ -404,6 +418,12 @@ class FastVGICP:
         a = np.ascontiguousarray(arr)
         self._chk(self._L.rgc_upload(self._h, C.c_void_p(ptr), a.ctypes.data, a.nbytes))
         self._chk(self._L.rgc_synchronize(self._h))
+
+    def upload_async(self, ptr: int, arr: np.ndarray):
+        """rgc_upload without the synchronisation: enqueued on the context's main stream; `arr` (C-contiguous, ideally page-locked) must
+        stay alive and unchanged until the stream has passed it"""
+        assert arr.flags["C_CONTIGUOUS"]
+        self._chk(self._L.rgc_upload(self._h, C.c_void_p(ptr), arr.ctypes.data, arr.nbytes))
 
 
 def odometer_vgicp(device: int = 0) -> FastVGICP:

@@ -30,6 +30,16 @@ def test_bench_line_direct_and_under_torchrun():
     assert a["one_frame_at_a_time"]["same_poses"] and a["scan_h2d_and_output"]["same_final_pose"]
     r = a["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    # `value` keeps nothing from one frame's target to the next: every query of every frame is searched
+    assert a["config"]["knn_reuse"] == "none" and a["config"]["queries_searched_per_frame"] == 150000 and r["queries_searched_per_launch"] == 150000
+    # the library's default beside it: the same poses, and on edited maps the poses of the same edits with nothing kept
+    ru = a["reuse_of_an_unchanged_map"]
+    assert ru["unchanged_map"]["same_poses_as_value"] and ru["seeds_only_unchanged_map"]["same_poses_as_value"]
+    assert ru["unchanged_map"]["queries_searched_per_launch"] < 0.2 * 150000
+    assert ru["one_point_edited_every_frame"]["same_poses_as_with_nothing_kept"] and ru["keyframe_every_3rd_frame"]["same_poses_as_with_nothing_kept"]
+    sp = a["sequences_per_gpu"]
+    assert "error" not in sp, sp
+    assert [x["S"] for x in sp["runs"]] == [1, 2, 4, 8] and all(x["poses_equal_each_sequence_alone"] for x in sp["runs"])
     b = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", "29611", "bench.py", "--gpus", "1"] + ARGS)
     assert b["n_gpus"] == 1

@@ -1,0 +1,184 @@
+"""What a context keeps between the targets rgc_set_target_reframed prepares (rgc_set_knn_reuse: nothing / seeds / seeds + neighbour
+lists) must never show in a result.  Parity here is HIP against HIP -- a context that keeps NOTHING (the plain exact search of every
+query, the route tests/test_gpu_parity.py pins to the CPU oracle) -- bit for bit, plus the oracle's covariances (<= 1e-9; the oracle is a
+restatement of impl/fast_gicp_impl.hpp:241-298, "parity unpinned": DESIGN.md section 3) on the frames named below."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reg_mod():
+    from rgc_slam_amd import registration
+    return registration
+
+
+def _pair(reg_mod):
+    """(a context with the library's default, a context that keeps nothing)"""
+    v = reg_mod.odometer_vgicp(0)
+    w = reg_mod.odometer_vgicp(0)
+    w.setNeighbourReuse(reg_mod.FastVGICP.REUSE_NONE)
+    assert v.getNeighbourReuse() == reg_mod.FastVGICP.REUSE_LISTS and w.getNeighbourReuse() == reg_mod.FastVGICP.REUSE_NONE
+    return v, w
+
+
+def _same_target(v, w, what):
+    cv, cw = v.getTargetCovariances(), w.getTargetCovariances()
+    assert np.array_equal(cv, cw), what
+    xv, xw = v.getVoxels(), w.getVoxels()
+    assert np.array_equal(xv["coords"], xw["coords"]) and np.array_equal(xv["cov"], xw["cov"]) and np.array_equal(xv["mean"], xw["mean"]), what
+    return cv
+
+
+def _pose(j):
+    import bench
+    import rgc_slam_amd.synth as synth
+    Tw = synth.se3(synth.rot_zyx(0.55 * j - 0.5, 0.03 * np.sin(j), -0.02 * np.cos(j)), [7.5 * np.cos(j), -11.0 * np.sin(1.3 * j), 0.3 * j])
+    return bench.world_to_body(Tw)
+
+
+def test_knn_reuse_modes(reg_mod, orc):
+    """rgc_set_knn_reuse on a live context: LISTS -> NONE -> SEEDS -> LISTS, the same map handed over throughout.  rgc_stats::searched_target
+    says which route ran; every covariance and the voxel table are those of the context that never kept anything."""
+    import rgc_slam_amd.synth as synth
+    n = 100000
+    _, tgt = synth.make_world_and_map(n, seed=synth.SEED)
+    a = np.zeros((n, 4), np.float32); a[:, :3] = tgt
+    v, w = _pair(reg_mod)
+    d_map, d_body = v.device_alloc(16 * n), v.device_alloc(16 * n)
+    d_map_w, d_body_w = w.device_alloc(16 * n), w.device_alloc(16 * n)
+    v.upload(d_map, a); w.upload(d_map_w, a)
+    F = reg_mod.FastVGICP
+    plan = [(None, "all"), (None, "few"), (None, "few"), (F.REUSE_NONE, "all"), (None, "all"), (F.REUSE_SEEDS, "all"), (None, "all"),
+            (F.REUSE_LISTS, "all"), (None, "few"), (None, "few")]
+    for j, (mode, searched) in enumerate(plan):
+        if mode is not None:
+            v.setNeighbourReuse(mode)
+            assert v.getNeighbourReuse() == mode
+        q, t = _pose(j)
+        v.setInputTargetReframed(d_map, n, 16, q, t, d_body)
+        w.setInputTargetReframed(d_map_w, n, 16, q, t, d_body_w)
+        cv = _same_target(v, w, (j, mode))
+        got = v.stats()["searched_target"]
+        assert (got == n) if searched == "all" else (got <= 0.15 * n), (j, mode, got)
+        assert w.stats()["searched_target"] == n
+    body = v.download(d_body, (n, 4))
+    ocov, _ = orc.covariances(body[:, :3].copy(), k=20)
+    assert np.abs(cv - ocov).max() <= 1e-9
+    with pytest.raises(reg_mod.RgcError):
+        v.setNeighbourReuse(3)
+    for p in (d_map, d_body):
+        v.device_free(p)
+    for p in (d_map_w, d_body_w):
+        w.device_free(p)
+    v.close(); w.close()
+
+
+def test_quaternion_next_to_the_unit_gate(reg_mod):
+    """The certificates' error budget is a rigid motion's; rgc_set_target_reframed applies q as Eigen does, without normalising it, so a
+    quaternion off the unit sphere scales every distance.  |q|^2 within 1e-9 of one (any fp64-normalised quaternion): lists serve, and must
+    give the search's bits on either side of one; |q|^2 = 1 +- 2e-7 (a quaternion normalised in fp32): no lists that frame, none trusted
+    after it, the same bits."""
+    import rgc_slam_amd.synth as synth
+    n = 100000
+    _, tgt = synth.make_world_and_map(n, seed=synth.SEED + 3)
+    a = np.zeros((n, 4), np.float32); a[:, :3] = tgt
+    v, w = _pair(reg_mod)
+    d_map, d_body = v.device_alloc(16 * n), v.device_alloc(16 * n)
+    d_map_w, d_body_w = w.device_alloc(16 * n), w.device_alloc(16 * n)
+    v.upload(d_map, a); w.upload(d_map_w, a)
+    scales = [(1.0, "all"), (1.0, "few"), (np.sqrt(1.0 + 4e-10), "few"), (np.sqrt(1.0 - 4e-10), "few"), (np.sqrt(1.0 + 2e-7), "all"),
+              (1.0, "all"), (1.0, "few"), (np.sqrt(1.0 - 2e-7), "all"), (1.0, "all"), (1.0, "few")]
+    for j, (sc, searched) in enumerate(scales):
+        q, t = _pose(j)
+        q = [x * sc for x in q]
+        v.setInputTargetReframed(d_map, n, 16, q, t, d_body)
+        w.setInputTargetReframed(d_map_w, n, 16, q, t, d_body_w)
+        _same_target(v, w, (j, sc))
+        got = v.stats()["searched_target"]
+        assert (got == n) if searched == "all" else (got <= 0.15 * n), (j, sc, got)
+    for p in (d_map, d_body):
+        v.device_free(p)
+    for p in (d_map_w, d_body_w):
+        w.device_free(p)
+    v.close(); w.close()
+
+
+def test_map_edited_every_frame_at_full_size(reg_mod, orc):
+    """The c-main map (1 M points) with 0.1 %, 1 % and 10 % of its rows overwritten before every frame -- what a rolling map does when
+    keyframes come and go (RGC_odometer.cpp:1236-1247) -- and frames in between where nothing changes: the default context (seeds + lists,
+    all-or-nothing invalidation) against one that keeps nothing, every covariance and the voxel table bit for bit; against the CPU
+    oracle's covariances (<= 1e-9) once per fraction."""
+    import os
+    import rgc_slam_amd.synth as synth
+    n = 1000000
+    world, tgt = synth.make_world_and_map(n, seed=synth.SEED)
+    a = np.zeros((n, 4), np.float32); a[:, :3] = tgt
+    rng = np.random.default_rng(41)
+    v, w = _pair(reg_mod)
+    d_map, d_body = v.device_alloc(16 * n), v.device_alloc(16 * n)
+    d_map_w, d_body_w = w.device_alloc(16 * n), w.device_alloc(16 * n)
+    v.upload(d_map, a); w.upload(d_map_w, a)
+    j = 0
+    o_threads = min(14, os.cpu_count() or 1)
+    for frac in (0.001, 0.01, 0.1):
+        m = int(n * frac)
+        for rep in range(3):
+            # rows [lo, lo + m) replaced by other points of the same surfaces (a keyframe's worth of new returns), then a frame; then one more
+            # frame with the buffer left alone
+            lo = int(rng.integers(0, n - m))
+            src = rng.integers(0, n, m)
+            a[lo:lo + m, :3] = tgt[src] + rng.normal(0.0, 0.02, (m, 3)).astype(np.float32)
+            v.upload(d_map + 16 * lo, a[lo:lo + m]); w.upload(d_map_w + 16 * lo, a[lo:lo + m])
+            for changed in (True, False):
+                q, t = _pose(j); j += 1
+                v.setInputTargetReframed(d_map, n, 16, q, t, d_body)
+                w.setInputTargetReframed(d_map_w, n, 16, q, t, d_body_w)
+                cv = _same_target(v, w, (frac, rep, changed))
+                got = v.stats()["searched_target"]
+                assert (got == n) if changed else (got < 0.1 * n), (frac, rep, changed, got)
+        body = v.download(d_body, (n, 4))
+        ocov, _ = orc.covariances(body[:, :3].copy(), k=20, threads=o_threads)
+        assert np.abs(cv - ocov).max() <= 1e-9, frac
+    for p in (d_map, d_body):
+        v.device_free(p)
+    for p in (d_map_w, d_body_w):
+        w.device_free(p)
+    v.close(); w.close()
+
+
+def test_soak_of_the_neighbour_lists(reg_mod):
+    """scripts/soak_lists.py as a test (it found the one real bug of the lists, a flag word overwritten by the launch that reads it): a 1 M-point
+    map under 30 random poses -- any yaw, +-30 m, every seventh frame +-400 m -- with a handful of points moved every thirteenth frame;
+    every frame's covariances and voxel table against a context that keeps nothing."""
+    import bench
+    import rgc_slam_amd.synth as synth
+    n = 1000000
+    _, tgt = synth.make_world_and_map(n, seed=synth.SEED)
+    a = np.zeros((n, 4), np.float32); a[:, :3] = tgt
+    v, w = _pair(reg_mod)
+    dm, db = v.device_alloc(a.nbytes), v.device_alloc(a.nbytes)
+    dmw, dbw = w.device_alloc(a.nbytes), w.device_alloc(a.nbytes)
+    v.upload(dm, a); w.upload(dmw, a)
+    rng = np.random.default_rng(5)
+    searched = []
+    for f in range(30):
+        if f and f % 13 == 0:
+            jj = rng.integers(0, n, 5)
+            a[jj, :3] += rng.normal(0, 0.2, (5, 3)).astype(np.float32)
+            v.upload(dm, a); w.upload(dmw, a)
+        ang = rng.uniform(-np.pi, np.pi, 3) * np.array([1.0, 0.02, 0.02])
+        scale = 400.0 if f % 7 == 6 else 30.0
+        Tw = synth.se3(synth.rot_zyx(*ang), rng.uniform(-scale, scale, 3) * np.array([1, 1, 0.05]))
+        q, t = bench.world_to_body(Tw)
+        v.setInputTargetReframed(dm, n, 16, q, t, db)
+        w.setInputTargetReframed(dmw, n, 16, q, t, dbw)
+        _same_target(v, w, f)
+        searched.append(int(v.stats()["searched_target"]))
+    assert min(searched) < 0.05 * n and searched[13] == n, searched
+    for p in (dm, db):
+        v.device_free(p)
+    for p in (dmw, dbw):
+        w.device_free(p)
+    v.close(); w.close()
