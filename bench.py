@@ -173,6 +173,38 @@ class DependentSequence:
         else:
             w.setInputSourceDevice(self.d_scans[i], self.n_scans[i], 16)
 
+    def run_cpp(self, first, count, Tw0, g0, overlap, stamps=None):
+        """run() with the frame loop in C++ (librgc_seq.so: rgc_seq_run_dependent, the calls of rgc::DependentSequence in the same order) --
+        the reference's host language, no interpreter between a frame's result and the next frame's first launch.  Scans from the device,
+        guess = the previous motion.  Same return value as run().  Falls back to run() when the frame-loop library is not available."""
+        import ctypes as C
+        import numpy as np
+        from rgc_slam_amd import _lib
+        S = _lib.load_seq()
+        if S is None:
+            return self.run(first, count, Tw0, g0, overlap, stamps=stamps)
+        a = self.v[0]
+        b = self.v[1] if (overlap and len(self.v) > 1) else None
+        Tw = np.array(Tw0, dtype=np.float64, order="C")
+        g0 = np.ascontiguousarray(g0, np.float32)
+        ptrs = (C.c_void_p * count)(*[int(self.d_scans[first + j]) for j in range(count)])
+        ns = (C.c_int * count)(*[int(self.n_scans[first + j]) for j in range(count)])
+        mot = np.empty((count, 4, 4), np.float32)
+        wor = np.empty((count, 4, 4), np.float64)
+        st = np.empty(count, np.float64)
+        fp, dp, ip = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)
+        t_call = time.perf_counter()
+        rc = S.rgc_seq_run_dependent(a._h, b._h if b is not None else None, C.c_void_p(self.d_map), int(self.n_map), 16, C.c_void_p(self.d_body[id(a)]),
+                                     C.c_void_p(self.d_body[id(b)]) if b is not None else None, ptrs, ns, 16, count, Tw.ctypes.data_as(dp),
+                                     g0.ctypes.data_as(fp), 1, mot.ctypes.data_as(fp), wor.ctypes.data_as(dp), None, None, st.ctypes.data_as(dp))
+        if rc != 0:
+            raise RuntimeError(f"rgc_seq_run_dependent: status {rc}: {a._L.rgc_last_error(a._h).decode()} / "
+                               f"{b._L.rgc_last_error(b._h).decode() if b is not None else ''}")
+        if stamps is not None:
+            stamps.extend((t_call + st).tolist())
+        motions = [mot[j].copy() for j in range(count)]
+        return motions, [wor[j].copy() for j in range(count)], [g0.reshape(4, 4)] + motions[:-1]
+
     def run(self, first, count, Tw0, g0, overlap, from_host=False, on_result=None, prior_world=None, stamps=None, edit_map=None):
         """frames first .. first + count - 1.  Tw0: world pose before frame `first` (4x4 fp64), g0: its guess (relative, 4x4 fp32).
         prior_world[i]: a world-frame guess of frame i (an IMU-like prior) instead of the previous motion.
@@ -698,8 +730,10 @@ def main():
         w.profile_enable(True)
         w.profile_select([DOMINANT])
     Tw_start, g_start = Tw_init, I4
+    from rgc_slam_amd import _lib as _rgc_lib
+    host_loop = "c++ (librgc_seq.so: rgc_seq_run_dependent)" if _rgc_lib.load_seq() is not None else "python (ctypes call per stage)"
     if W > 0:
-        m, wd, _ = seq.run(0, W, Tw_init, I4, True)
+        m, wd, _ = seq.run_cpp(0, W, Tw_init, I4, True)
         Tw_start, g_start = wd[-1], m[-1]
     pv.synchronize()
     for w in pv.v:
@@ -709,7 +743,7 @@ def main():
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     step_stamps = [t_start]
-    motions, worlds, guesses = seq.run(W, K, Tw_start, g_start, True, stamps=step_stamps)   # (per-frame counters are read in an untimed repetition below: 5 us of Python per frame)
+    motions, worlds, guesses = seq.run_cpp(W, K, Tw_start, g_start, True, stamps=step_stamps)   # (the K steps: one call into the C++ frame loop; per-frame counters are read in an untimed repetition below)
     pv.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
@@ -727,7 +761,7 @@ def main():
     # the same K steps one at a time on one context through the blocking calls (what a caller of align() gets: the frame's latency)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    seq_motions, _, _ = seq.run(W, K, Tw_start, g_start, False)
+    seq_motions, _, _ = seq.run_cpp(W, K, Tw_start, g_start, False)
     v.synchronize()
     elapsed_seq = time.perf_counter() - t1
     seq_same = bool(all(np.array_equal(a_, b_) for a_, b_ in zip(motions, seq_motions)))
@@ -763,12 +797,26 @@ def main():
         for r in range(REPS):
             pv.synchronize()
             tr = time.perf_counter()
-            mr, _, _ = seq.run(W, K, Tw_start, g_start, overlap, on_result=collect if (overlap and r == 0) else None)   # (repetition 0: the frames' counters; not in the median)
+            if r == 0:   # (repetition 0 through the Python loop: the frames' counters; not in the median)
+                mr, _, _ = seq.run(W, K, Tw_start, g_start, overlap, on_result=collect if overlap else None)
+            else:
+                mr, _, _ = seq.run_cpp(W, K, Tw_start, g_start, overlap)
             pv.synchronize()
             per.append(time.perf_counter() - tr)
             same = same and all(np.array_equal(a_, b_) for a_, b_ in zip(motions, mr))
         med = float(np.median(per[2:]))
         steady[mode] = {"scans_per_s": round(K / med, 3), "ms_per_step": round(1e3 * med / K, 4), "same_poses_every_repetition": bool(same)}
+    # ... and the same through the Python frame loop (a ctypes call per stage): what the interpreter costs a dependent sequence
+    per = []
+    for r in range(5):
+        pv.synchronize()
+        tr = time.perf_counter()
+        mr, _, _ = seq.run(W, K, Tw_start, g_start, True)
+        pv.synchronize()
+        per.append(time.perf_counter() - tr)
+    med = float(np.median(per[1:]))
+    steady["two_contexts_python_frame_loop"] = {"scans_per_s": round(K / med, 3), "ms_per_step": round(1e3 * med / K, 4),
+                                                "same_poses": bool(all(np.array_equal(a_, b_) for a_, b_ in zip(motions, mr)))}
     steady["what"] = (f"the K timed steps repeated {REPS} times back to back with no HIP events in the loop, median of the last {REPS - 2} repetitions: the "
                       f"rate of a sequence that keeps running, beside `value` (first pass behind W warm-up steps, dominant kernel bracketed by events)")
     # Lazy target (an extra key; `value` above stays the full rebuild, like the reference): covariances and voxels only where the solve can
@@ -842,11 +890,15 @@ def main():
     n_slots = max(1, n_map // kf_n)
     n_kf = (n_frames_all + 2) // 3
     kf_np = torch.zeros((n_kf, kf_n, 4), dtype=torch.float32).pin_memory().numpy()
+    map_lo, map_hi = maps[0].min(axis=0) + np.float32(0.5), maps[0].max(axis=0) - np.float32(0.5)
     for kk in range(n_kf):
         i = min(3 * kk, len(scans) - 1)
         P = np.asarray(poses[i + 1], np.float64)
         pts = scans[i][::max(1, scans[i].shape[0] // kf_n)][:kf_n].astype(np.float64)
         wpts = (pts @ P[:3, :3].T + P[:3, 3]).astype(np.float32)
+        # (returns beyond the map's own bounding box are left out: rgc_set_target_reframed derives the re-framed map's box from the buffer's,
+        # measured once per buffer -- "fixed between calls", rgc_hip.h; a rolling map that GROWS is the resident map's business, rgc_map_*)
+        wpts = wpts[np.all((wpts > map_lo) & (wpts < map_hi), axis=1)]
         kf_np[kk, :wpts.shape[0], :3] = wpts
         if wpts.shape[0] < kf_n:   # (a short sweep: the rest of the block keeps the map's own rows)
             slot = (kk % n_slots) * kf_n
@@ -1023,7 +1075,8 @@ def main():
                                f"a map whose point set changes every frame -- the reference's does; BASELINE.md c-main; RGC_odometer.cpp:976-1256; one "
                                f"independent sequence per GPU; only the next scan's preparation overlaps a solve)",
                    "n_source": args.n_source, "n_target": args.n_target, "voxel_res": 1.0, "k": 20, "max_iterations": 25,
-                   "knn_reuse": "none", "queries_searched_per_frame": searched_alone, "parallelism": f"sequences x{world_size}"},
+                   "knn_reuse": "none", "queries_searched_per_frame": searched_alone, "host_frame_loop": host_loop,
+                   "parallelism": f"sequences x{world_size}"},
         "algorithmic_bytes_per_scan": round(B), "hbm_gbps_algorithmic": round(B * scans_per_s / world_size / 1e9, 3),
         "hbm_frac_whole_frame": round(B * scans_per_s / world_size / 1e9 / HBM_PEAK_GBS, 6),
         "mean_outer_iterations": round(mean_outer, 2), "mean_linearize": round(mean_lin, 2), "mean_compute_error": round(mean_err, 2),

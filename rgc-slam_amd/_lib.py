@@ -16,7 +16,7 @@ DIRECT27, DIRECT7, DIRECT1 = 0, 1, 2
 K_GRID, K_KNN_COV, K_VOXEL, K_LINEARIZE, K_ERROR, K_FITNESS, K_KNN_COV_SRC, K_KNN_COOP, K_KNN_COOP_SRC, K_COUNT = range(10)
 
 OK = 0
-ERR_INVALID, ERR_HIP, ERR_TOO_FEW_POINTS, ERR_GRID_TOO_LARGE, ERR_NO_INPUT, ERR_NONFINITE = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_HIP, ERR_TOO_FEW_POINTS, ERR_GRID_TOO_LARGE, ERR_NO_INPUT, ERR_NONFINITE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 
 
 class Params(C.Structure):
@@ -112,7 +112,7 @@ class RgcError(RuntimeError):
 SYMBOLS = [
     "rgc_default_params", "rgc_create", "rgc_destroy", "rgc_set_params", "rgc_get_params", "rgc_last_error",
     "rgc_status_string", "rgc_version", "rgc_set_target", "rgc_set_source", "rgc_set_target_device",
-    "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align", "rgc_align_begin", "rgc_align_end", "rgc_align_end_reframe", "rgc_share_target", "rgc_hold_source_until_target_of", "rgc_set_target_lazy", "rgc_set_knn_reuse", "rgc_get_knn_reuse",
+    "rgc_set_source_device", "rgc_linearize", "rgc_compute_error", "rgc_num_correspondences", "rgc_align", "rgc_align_begin", "rgc_align_end", "rgc_align_end_reframe", "rgc_share_target", "rgc_hold_source_until_target_of", "rgc_set_target_lazy", "rgc_set_knn_reuse", "rgc_get_knn_reuse", "rgc_set_regularization_method", "rgc_set_voxel_accumulation_mode",
     "rgc_fitness", "rgc_get_aligned", "rgc_get_aligned_device", "rgc_get_source_covariances", "rgc_get_target_covariances", "rgc_set_source_covariances", "rgc_set_target_covariances",
     "rgc_clear_source", "rgc_clear_target", "rgc_swap_source_and_target", "rgc_get_voxels",
     "rgc_get_stats", "rgc_device_alloc", "rgc_device_free", "rgc_host_alloc", "rgc_host_free", "rgc_upload", "rgc_download", "rgc_synchronize",
@@ -147,6 +147,28 @@ class _PartialLibrary:
             return getattr(self._real, name)
         except AttributeError:
             return self._missing.setdefault(name, _PartialLibrary._Missing(name))
+
+
+_seq = None
+
+
+def load_seq():
+    """librgc_seq.so: the C++ host layer's dependent frame loop behind one call (cpp/dependent_sequence_c.cpp).  It is linked against the
+    in-tree librgc_hip.so; with RGC_HIP_LIB naming another build there is no frame loop for it (None): contexts of one library build
+    must not be driven through another's code."""
+    global _seq
+    if _seq is not None:
+        return _seq
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librgc_seq.so")
+    if os.path.abspath(LIB_PATH) != os.path.join(os.path.dirname(os.path.abspath(__file__)), "librgc_hip.so") or not os.path.exists(path):
+        return None
+    load()
+    S = C.CDLL(path)
+    vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)
+    S.rgc_seq_run_dependent.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp), ip, C.c_int, C.c_int, dp, fp, C.c_int, fp, dp, dp, ip, dp]
+    S.rgc_seq_run_dependent.restype = C.c_int
+    _seq = S
+    return S
 
 
 def load():
@@ -192,6 +214,8 @@ def load():
     L.rgc_hold_source_until_target_of.argtypes = [vp, vp]
     L.rgc_set_target_lazy.argtypes = [vp, C.c_int]
     L.rgc_set_knn_reuse.argtypes = [vp, C.c_int]
+    L.rgc_set_regularization_method.argtypes = [vp, C.c_int]
+    L.rgc_set_voxel_accumulation_mode.argtypes = [vp, C.c_int]
     L.rgc_get_knn_reuse.argtypes = [vp, ip]
     L.rgc_clear_source.argtypes = [vp]
     L.rgc_clear_target.argtypes = [vp]

@@ -1,4 +1,5 @@
-"""Builds librgc_hip.so (the product: HIP kernels + C-ABI) in-tree with hipcc for gfx950.
+"""Builds librgc_hip.so (the product: HIP kernels + C-ABI) in-tree with hipcc for gfx950, and beside it librgc_seq.so (the C++ host layer's
+dependent frame loop behind one extern "C" call, cpp/dependent_sequence_c.cpp: host code only, linked against librgc_hip.so).
 
     python rgc-slam_amd/build.py [--force]
     RGC_EXTRA_FLAGS="-DRGC_LM_POST=0" RGC_LIB_OUT=/tmp/librgc_alt.so python rgc-slam_amd/build.py   # an A/B build beside the product
@@ -22,7 +23,30 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fvisibility=hidden", "-DRGC_BUILD"] + os.environ.get("RGC_EXTRA_FLAGS", "").split()  # e.g. -DRGC_LAB: developer-only exports
 
 
+SEQ_LIB = os.path.join(os.path.dirname(LIB), "librgc_seq.so" if not os.environ.get("RGC_LIB_OUT") else os.path.splitext(os.path.basename(LIB))[0] + "_seq.so")
+SEQ_SRC = os.path.join(HERE, "cpp", "dependent_sequence_c.cpp")
+
+
+def build_seq(force: bool = False, verbose: bool = False) -> str:
+    """the host layer's frame loop (C++, no device code): g++-compatible, built with the same driver for one toolchain"""
+    deps = [SEQ_SRC, os.path.join(HERE, "cpp", "fast_vgicp_hip.hpp"), os.path.join(HERE, "..", "include", "rgc_hip.h"), LIB]
+    if not force and os.path.exists(SEQ_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(SEQ_LIB) for d in deps):
+        return SEQ_LIB
+    cmd = [HIPCC, "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fvisibility=hidden", SEQ_SRC, "-o", SEQ_LIB,
+           "-L", os.path.dirname(LIB), "-l:" + os.path.basename(LIB), "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SEQ_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    lib = build_hip(force, verbose)
+    build_seq(force, verbose)
+    return lib
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
     deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB

@@ -10,8 +10,11 @@
 //   vgicp.align(*aligned, T2);                                     // T2: anything with operator()(row, col) (Eigen::Matrix4f)
 //   double score = vgicp.getFitnessScore();  auto T = vgicp.getFinalTransformation<Eigen::Matrix4f>();
 //
-// Errors: like the reference, the solver itself never throws ("lm not converged" is lmFailed(), hasConverged() as in
-// PCL); API misuse and HIP failures throw std::runtime_error carrying rgc_last_error().  No CPU fallback exists.
+// Errors: like the reference, the solver itself never throws ("lm not converged" is lmFailed(), hasConverged() as in PCL) and NO SETTER
+// throws: the reference's setters return void and accept anything.  A setter the library refuses (an invalid parameter, a regularisation
+// method or voxel accumulation mode this path does not implement) leaves its status in lastSetterStatus() / lastSetterError() and the
+// requested value selected, so that the NEXT call that would compute something -- setInputTarget / setInputSource / align -- fails instead
+// of running under another setting's name: those, like HIP failures, throw std::runtime_error carrying rgc_last_error().  No CPU fallback.
 #pragma once
 #include <cmath>
 #include <cstddef>
@@ -52,29 +55,34 @@ public:
   void setInitialLambdaFactor(double f) { p_.lm_init_lambda_factor = f; push(); }  // lsq_registration_impl.hpp:32-34
   void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; push(); }    // fast_gicp_impl.hpp:41-43
   void setNeighborSearchMethod(NeighborSearchMethod m) { p_.neighbor_method = (int)m; push(); }
-  // the odometer leaves both at the constructor's values (PLANE, fast_gicp_impl.hpp:20; ADDITIVE, fast_vgicp_impl.hpp:24): the only ones built here
-  void setRegularizationMethod(RegularizationMethod m) { if (m != RegularizationMethod::PLANE) throw std::runtime_error("rgc: only RegularizationMethod::PLANE is implemented"); }
-  void setVoxelAccumulationMode(VoxelAccumulationMode m) { if (m != VoxelAccumulationMode::ADDITIVE) throw std::runtime_error("rgc: only VoxelAccumulationMode::ADDITIVE is implemented"); }
+  // the odometer leaves both at the constructor's values (PLANE, fast_gicp_impl.hpp:20; ADDITIVE, fast_vgicp_impl.hpp:24).  PLANE, ADDITIVE and
+  // ADDITIVE_WEIGHTED (the vendored FastVGICP's ADDITIVE: fast_vgicp_voxel.hpp:137-141) are implemented; any other value is remembered by the
+  // context and refused by the next call that would compute something (rgc_set_regularization_method in rgc_hip.h)
+  void setRegularizationMethod(RegularizationMethod m) { note(rgc_set_regularization_method(ctx_, (int)m)); }
+  void setVoxelAccumulationMode(VoxelAccumulationMode m) { note(rgc_set_voxel_accumulation_mode(ctx_, (int)m)); }
+  int lastSetterStatus() const { return setter_status_; }                 // RGC_OK, or why the last refused setter was refused
+  const std::string& lastSetterError() const { return setter_error_; }
   void setMaxCorrespondenceDistance(double) {}   // unused by FastVGICP
   void setEuclideanFitnessEpsilon(double) {}     // no-op in LsqRegistration
   void setRANSACIterations(int) {}               // no-op
   void setNumThreads(int) {}                     // CPU threads of the reference; nothing to set on the GPU
 
   // ---- clouds ----
-  void setInputTarget(const float* xyz, int n, int stride_bytes) { chk(rgc_set_target(ctx_, xyz, n, stride_bytes)); n_tgt_ = n; fit_valid_ = false; }
-  void setInputSource(const float* xyz, int n, int stride_bytes) { chk(rgc_set_source(ctx_, xyz, n, stride_bytes)); n_src_ = n; fit_valid_ = false; }
+  void setInputTarget(const float* xyz, int n, int stride_bytes) { params(); chk(rgc_set_target(ctx_, xyz, n, stride_bytes)); n_tgt_ = n; fit_valid_ = false; }
+  void setInputSource(const float* xyz, int n, int stride_bytes) { params(); chk(rgc_set_source(ctx_, xyz, n, stride_bytes)); n_src_ = n; fit_valid_ = false; }
   template <class CloudPtr>
   void setInputTarget(const CloudPtr& cloud) { setInputTarget(&cloud->points[0].x, (int)cloud->points.size(), (int)sizeof(cloud->points[0])); }
   template <class CloudPtr>
   void setInputSource(const CloudPtr& cloud) { setInputSource(&cloud->points[0].x, (int)cloud->points.size(), (int)sizeof(cloud->points[0])); }
-  void setInputTargetDevice(const float* d_xyz, int n, int stride_bytes) { chk(rgc_set_target_device(ctx_, d_xyz, n, stride_bytes)); n_tgt_ = n; fit_valid_ = false; }
-  void setInputSourceDevice(const float* d_xyz, int n, int stride_bytes) { chk(rgc_set_source_device(ctx_, d_xyz, n, stride_bytes)); n_src_ = n; fit_valid_ = false; }
+  void setInputTargetDevice(const float* d_xyz, int n, int stride_bytes) { params(); chk(rgc_set_target_device(ctx_, d_xyz, n, stride_bytes)); n_tgt_ = n; fit_valid_ = false; }
+  void setInputSourceDevice(const float* d_xyz, int n, int stride_bytes) { params(); chk(rgc_set_source_device(ctx_, d_xyz, n, stride_bytes)); n_src_ = n; fit_valid_ = false; }
 
   // The odometer's sub-map re-framing and setInputTarget in one call on device memory (RGC_odometer.cpp:1248-1256, 1007;
   // rgc_set_target_reframed): the map at d_map (x,y,z,intensity..., fixed between calls) re-expressed by q (x,y,z,w) and t into d_scratch
   // (n * 16 bytes) and prepared as the target.  A map handed over like this again and again is searched from what the last search found
   // (rgc_hip.h: seeds) -- same results, a shorter kNN launch.
   void setInputTargetReframed(const float* d_map, int n, int stride_bytes, const double q_xyzw[4], const double t[3], float* d_scratch) {
+    params();
     chk(rgc_set_target_reframed(ctx_, d_map, n, stride_bytes, q_xyzw, t, d_scratch));
     n_tgt_ = n; fit_valid_ = false;
   }
@@ -102,6 +110,7 @@ public:
   // guess: row-major float[16]
   void align(const float guess[16]) {
     int it = 0, conv = 0, fail = 0;
+    params();
     chk(rgc_align(ctx_, guess, final_, hessian_, nullptr, &it, &conv, &fail));
     iterations_ = it; converged_ = conv != 0; lm_failed_ = fail != 0; fit_valid_ = false;
   }
@@ -109,6 +118,7 @@ public:
   // align() in two halves (rgc_align_begin / rgc_align_end): between them the caller may prepare the next frame's clouds on ANOTHER
   // FastVGICPHip (rgc::PipelinedVGICP below); want_fitness chains getFitnessScore behind the solve
   void alignBegin(const float guess[16], bool want_fitness = false) {
+    params();
     chk(rgc_align_begin(ctx_, guess, want_fitness ? 1 : 0));
     pending_fitness_ = want_fitness;
   }
@@ -170,7 +180,14 @@ public:
 private:
   static void set_identity(float m[16]) { std::memset(m, 0, 16 * sizeof(float)); m[0] = m[5] = m[10] = m[15] = 1.f; }
   void chk(int rc) { if (rc != RGC_OK) throw std::runtime_error(std::string(rgc_status_string(rc)) + ": " + rgc_last_error(ctx_)); }
-  void push() { chk(rgc_set_params(ctx_, &p_)); }
+  // a parameter setter: the library takes the block or refuses it as a whole; refused, the requested values stay in p_ and the next
+  // call that computes something offers them again (params()) -- and throws if they are still refused
+  void note(int rc) { setter_status_ = rc; setter_error_ = rc == RGC_OK ? std::string() : std::string(rgc_status_string(rc)) + ": " + rgc_last_error(ctx_); }
+  void push() { const int rc = rgc_set_params(ctx_, &p_); params_dirty_ = rc != RGC_OK; note(rc); }
+  void params() { if (params_dirty_) { chk(rgc_set_params(ctx_, &p_)); params_dirty_ = false; } }
+  int setter_status_ = RGC_OK;
+  std::string setter_error_;
+  bool params_dirty_ = false;
   rgc_ctx* ctx_ = nullptr;
   rgc_params p_{};
   float final_[16];

@@ -216,6 +216,7 @@ struct rgc_ctx {
   int join_spin_us = RGC_JOIN_SPIN_US;  // (build flag; RGC_JOIN_SPIN_US in the environment) how long the host waits for an almost-ready scan instead of putting a barrier into the map's stream (join_source)
   bool cache_on = RGC_KNN_CACHE != 0;  // (build flag; RGC_KNN_CACHE=0 in the environment) the neighbour lists of an unchanged map on top of the seeds
   bool seeds_on = RGC_KNN_SEEDS != 0;  // (build flag; RGC_KNN_SEEDS=0 in the environment) 0: every search of a re-framed map starts without a bound, as before round 5
+  int reg_method = RGC_REG_PLANE, voxel_mode = RGC_VOXEL_ADDITIVE;  // as selected by the caller, implemented or not (rgc_set_regularization_method)
   bool cache_dropped = false;          // the lists' buffers did not fit on the device: the context went down to the seeds by itself (rgc_get_knn_reuse)
   bool trace_cache = false;            // RGC_TRACE_CACHE in the environment (rgc_create): rgc_get_stats reports the lists' state on stderr
   double src_res = RGC_SRC_RES;  // (build flag) fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
@@ -287,6 +288,15 @@ int fail(rgc_ctx* c, int code, const char* fmt, ...) {
     va_end(ap);
   }
   return code;
+}
+
+// a setting of the reference's interface that this path does not implement is selected: nothing is computed under another method's name
+int check_supported(rgc_ctx* c) {
+  if (c->reg_method != RGC_REG_PLANE)
+    return fail(c, RGC_ERR_UNSUPPORTED, "RegularizationMethod %d is selected; only PLANE (3) is implemented (rgc_set_regularization_method)", c->reg_method);
+  if (c->voxel_mode != RGC_VOXEL_ADDITIVE && c->voxel_mode != RGC_VOXEL_ADDITIVE_WEIGHTED)
+    return fail(c, RGC_ERR_UNSUPPORTED, "VoxelAccumulationMode %d is selected; only ADDITIVE (0) and ADDITIVE_WEIGHTED (1) are implemented (rgc_set_voxel_accumulation_mode)", c->voxel_mode);
+  return RGC_OK;
 }
 
 #define HIPCHK(c, expr)                                                                                    \
@@ -902,6 +912,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
   c->corr_valid = false;
   c->deferred_known = false;
   if (is_target) c->map_bound = false;
+  { const int rs = check_supported(c); if (rs) return rs; }
   if (!xyz || n < 0) return fail(c, RGC_ERR_INVALID, "null cloud");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
   if (n > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud has %d points, the limit is 2^27 (32-bit byte offsets into the sorted array)", n);
@@ -1050,6 +1061,7 @@ int validate_clouds(rgc_ctx* c, bool whole_target = true) {
 
 int need_inputs(rgc_ctx* c, bool validate = true) {
   if (!c) return RGC_ERR_INVALID;
+  { const int rs = check_supported(c); if (rs) return rs; }
   if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
   if (validate) {
     int rc = validate_clouds(c);
@@ -1445,6 +1457,7 @@ const char* rgc_status_string(int s) {
     case RGC_ERR_GRID_TOO_LARGE: return "grid too large";
     case RGC_ERR_NO_INPUT: return "no input cloud";
     case RGC_ERR_NONFINITE: return "non-finite input";
+    case RGC_ERR_UNSUPPORTED: return "unsupported setting selected";
   }
   return "unknown";
 }
@@ -1633,6 +1646,20 @@ int rgc_set_target_lazy(rgc_ctx* c, int margin_cells) {
   return RGC_OK;
 }
 
+int rgc_set_regularization_method(rgc_ctx* c, int method) {
+  if (!c) return RGC_ERR_INVALID;
+  if (method < RGC_REG_NONE || method > RGC_REG_FROBENIUS) return fail(c, RGC_ERR_INVALID, "rgc_set_regularization_method: %d is not a RegularizationMethod", method);
+  c->reg_method = method;
+  return check_supported(c);
+}
+
+int rgc_set_voxel_accumulation_mode(rgc_ctx* c, int mode) {
+  if (!c) return RGC_ERR_INVALID;
+  if (mode < RGC_VOXEL_ADDITIVE || mode > RGC_VOXEL_MULTIPLICATIVE) return fail(c, RGC_ERR_INVALID, "rgc_set_voxel_accumulation_mode: %d is not a VoxelAccumulationMode", mode);
+  c->voxel_mode = mode;
+  return check_supported(c);
+}
+
 int rgc_set_knn_reuse(rgc_ctx* c, int mode) {
   if (!c) return RGC_ERR_INVALID;
   if (mode < RGC_REUSE_NONE || mode > RGC_REUSE_LISTS) return fail(c, RGC_ERR_INVALID, "rgc_set_knn_reuse: mode must be RGC_REUSE_NONE, _SEEDS or _LISTS");
@@ -1765,6 +1792,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   if (c->lm_host) return fail(c, RGC_ERR_INVALID, "the host-driven LM loop (RGC_LM_IMPL=host) has no asynchronous form");
   HIPCHK(c, hipSetDevice(c->device));
   c->pend.active = false;
+  { const int rs = check_supported(c); if (rs) return rs; }
   // the guards of speculative grids come home with the LM state: no synchronisation here
   if (!c->src.ready || !c->tgt.ready) return fail(c, RGC_ERR_NO_INPUT, "source and target must be set first");
   { int rc = check_target_owner(c); if (rc) return rc; }

@@ -66,7 +66,29 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 16; i++) same &= vgicp.getFinalTransformation()[i] == T1[i];
     int refused = 0;
     try { std::vector<double> bad((size_t)source->points.size() * 9, 0.25); vgicp.setSourceCovariances(bad); } catch (const std::exception&) { refused++; }
-    try { vgicp.setRegularizationMethod(rgc::RegularizationMethod::FROBENIUS); } catch (const std::exception&) { refused++; }
+    // the reference's setters cannot fail: none throws here either.  A value this path does not implement is remembered and the next call
+    // that would compute something is refused (never PLANE's result under FROBENIUS' name); an invalid parameter likewise
+    int setters = 0;
+    vgicp.setRegularizationMethod(rgc::RegularizationMethod::FROBENIUS);
+    setters += vgicp.lastSetterStatus() == RGC_ERR_UNSUPPORTED;
+    try { vgicp.align(aligned, T2); } catch (const std::exception&) { setters++; }
+    vgicp.setRegularizationMethod(rgc::RegularizationMethod::PLANE);
+    setters += vgicp.lastSetterStatus() == RGC_OK;
+    vgicp.setVoxelAccumulationMode(rgc::VoxelAccumulationMode::MULTIPLICATIVE);
+    setters += vgicp.lastSetterStatus() == RGC_ERR_UNSUPPORTED;
+    try { vgicp.setInputTarget(target); } catch (const std::exception&) { setters++; }
+    vgicp.setVoxelAccumulationMode(rgc::VoxelAccumulationMode::ADDITIVE_WEIGHTED);   // = ADDITIVE in the vendored FastVGICP (fast_vgicp_voxel.hpp:137-141)
+    setters += vgicp.lastSetterStatus() == RGC_OK;
+    vgicp.setResolution(-1.0);
+    setters += vgicp.lastSetterStatus() == RGC_ERR_INVALID;
+    try { vgicp.setInputTarget(target); } catch (const std::exception&) { setters++; }
+    vgicp.setResolution(1.0);
+    setters += vgicp.lastSetterStatus() == RGC_OK;
+    vgicp.setInputTarget(target);
+    vgicp.setInputSource(source);
+    vgicp.align(aligned, T2);
+    for (int i = 0; i < 16; i++) same &= vgicp.getFinalTransformation()[i] == T1[i];
+    refused += setters == 9;
     vgicp.clearSource();
     try { vgicp.align(aligned, T2); } catch (const std::exception&) { refused++; }
     vgicp.setInputSource(source);

@@ -182,3 +182,73 @@ def test_soak_of_the_neighbour_lists(reg_mod):
     for p in (dmw, dbw):
         w.device_free(p)
     v.close(); w.close()
+
+
+def test_cpp_frame_loop_equals_the_python_one(reg_mod):
+    """librgc_seq.so (rgc_seq_run_dependent: the dependent frame loop of rgc::DependentSequence in C++, what bench.py's timed region runs)
+    against bench.DependentSequence.run, the same calls issued from Python: every motion and every world pose bit for bit, on two contexts
+    and one frame at a time."""
+    import bench
+    import rgc_slam_amd.synth as synth
+    from rgc_slam_amd import _lib
+    assert _lib.load_seq() is not None, "librgc_seq.so missing: python rgc-slam_amd/build.py"
+    world, tgt = synth.make_world_and_map(120000, seed=synth.SEED + 5)
+    poses = synth.make_trajectory(9, seed=synth.SEED + 5)
+    scans = [synth.make_scan_n(world, poses[i + 1], 15000, seed=synth.SEED + 900 + i)["xyz"] for i in range(8)]
+    pv = reg_mod.PipelinedVGICP(0, depth=2)
+    v = pv.v[0]
+    def to_dev(xyz):
+        a = np.zeros((xyz.shape[0], 4), np.float32); a[:, :3] = xyz
+        p = v.device_alloc(a.nbytes); v.upload(p, a); return p
+    d_map, d_scans = to_dev(tgt), [to_dev(s_) for s_ in scans]
+    seq = bench.DependentSequence(pv.v, d_map, len(tgt), d_scans, [len(s_) for s_ in scans])
+    Tw0, I4 = np.asarray(poses[0], np.float64), np.eye(4, dtype=np.float32)
+    for overlap in (True, False):
+        for mode in (reg_mod.FastVGICP.REUSE_NONE, reg_mod.FastVGICP.REUSE_LISTS):
+            for w in pv.v:
+                w.setNeighbourReuse(mode)
+            mp, wp, gp = seq.run(0, len(scans), Tw0, I4, overlap)
+            st = []
+            mc, wc, gc = seq.run_cpp(0, len(scans), Tw0, I4, overlap, stamps=st)
+            assert len(st) == len(scans) and all(b > a for a, b in zip(st, st[1:]))
+            for i in range(len(scans)):
+                assert np.array_equal(mp[i], mc[i]) and np.array_equal(gp[i], gc[i]), (overlap, mode, i)
+            for i in range(len(scans) - 1):   # (the last frame's world pose is composed by the caller: numpy's matmul there, a loop here)
+                assert np.array_equal(wp[i], wc[i]), (overlap, mode, i)
+            assert np.abs(wp[-1] - wc[-1]).max() <= 1e-12
+    seq.close(); pv.close()
+
+
+def test_unimplemented_settings_are_refused_not_replaced(reg_mod):
+    """rgc_set_regularization_method / rgc_set_voxel_accumulation_mode: the reference's setters cannot fail; here an unimplemented value
+    returns RGC_ERR_UNSUPPORTED without throwing across the boundary and is remembered -- the context computes nothing until an
+    implemented value is selected (never PLANE's result under MIN_EIG's name).  ADDITIVE_WEIGHTED is ADDITIVE in the vendored FastVGICP
+    (fast_vgicp_voxel.hpp:137-141): accepted, same bits."""
+    import rgc_slam_amd.synth as synth
+    from rgc_slam_amd import _lib
+    world, tgt = synth.make_world_and_map(30000, seed=synth.SEED + 6)
+    src = synth.make_scan_n(world, synth.se3(synth.rot_zyx(0.01, 0.0, 0.0), [0.1, 0.0, 0.0]), 8000, seed=synth.SEED + 6)["xyz"]
+    v = reg_mod.odometer_vgicp(0)
+    L = v._L
+    v.setInputTarget(tgt); v.setInputSource(src)
+    v.align(np.eye(4), want_output=False)
+    T0 = v.getFinalTransformation()
+    assert L.rgc_set_voxel_accumulation_mode(v._h, 1) == 0                      # ADDITIVE_WEIGHTED
+    v.setInputTarget(tgt); v.setInputSource(src)
+    v.align(np.eye(4), want_output=False)
+    assert np.array_equal(T0, v.getFinalTransformation())
+    for setter, bad, good in ((L.rgc_set_regularization_method, (0, 1, 2, 4), 3), (L.rgc_set_voxel_accumulation_mode, (2,), 0)):
+        for m in bad:
+            assert setter(v._h, m) == _lib.ERR_UNSUPPORTED
+            assert b"implemented" in L.rgc_last_error(v._h)
+            with pytest.raises(reg_mod.RgcError) as e:
+                v.setInputTarget(tgt)
+            assert e.value.status == _lib.ERR_UNSUPPORTED
+            with pytest.raises(reg_mod.RgcError):
+                v.align(np.eye(4), want_output=False)
+        assert setter(v._h, 99) == _lib.ERR_INVALID
+        assert setter(v._h, good) == 0
+    v.setInputTarget(tgt); v.setInputSource(src)
+    v.align(np.eye(4), want_output=False)
+    assert np.array_equal(T0, v.getFinalTransformation())
+    v.close()
