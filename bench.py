@@ -894,8 +894,10 @@ def main():
     for kk in range(n_kf):
         i = min(3 * kk, len(scans) - 1)
         P = np.asarray(poses[i + 1], np.float64)
-        pts = scans[i][::max(1, scans[i].shape[0] // kf_n)][:kf_n].astype(np.float64)
-        wpts = (pts @ P[:3, :3].T + P[:3, 3]).astype(np.float32)
+        # the sweep in the world frame (true pose) through the map's own 0.3 m leaf filter, like a keyframe that enters a sub-map
+        # (RGC_odometer.cpp:985-991, 1237): a RAW sweep would put hundreds of points into the cells next to the sensor
+        wall = synth.leaf_centroids(scans[i].astype(np.float64) @ P[:3, :3].T + P[:3, 3], 0.3).astype(np.float32)
+        wpts = wall[np.random.default_rng(seed + 500 + kk).permutation(len(wall))][:kf_n]
         # (returns beyond the map's own bounding box are left out: rgc_set_target_reframed derives the re-framed map's box from the buffer's,
         # measured once per buffer -- "fixed between calls", rgc_hip.h; a rolling map that GROWS is the resident map's business, rgc_map_*)
         wpts = wpts[np.all((wpts > map_lo) & (wpts < map_hi), axis=1)]

@@ -2,8 +2,8 @@
 (/root/reference/rgc_slam/src/scanRegistration.cpp), written from the reference text line by line in numpy float32 / Python
 scalars, to pin oracle/rgc_oracle_aux.c (orc_frontend): A3 range / incidence / near-intensity smoothing (:234-268), A4 curvature
 stencils (:270-306), A6 occlusion mask (:433-456), A7 per-sector sort and greedy selection (:469-644) and the intensity append of
-:645-656.  The ring bucket (A2) and the ground marking (A5) are inputs here (they are pinned by the sensor-model properties in
-tests/test_oracle_frontend.py).  Plain loops: use on small sweeps only.  Per-frame arrays start at zero and
+:645-656, and (round 6) A5, the ground marking and the weighted plane fit (:308-431, `ground` below).  The ring bucket (A2) is an
+input here (pinned by the sensor-model properties in tests/test_oracle_frontend.py).  Plain loops: use on small sweeps only.  Per-frame arrays start at zero and
 std::sort's unspecified tie order is fixed as ascending index (item 10), like every other implementation in this repository.
 """
 import numpy as np
@@ -163,3 +163,70 @@ def select(cloud, st, picked_in, ground_marked, scan_start, scan_end, use_intens
     arr = lambda v: np.array(v, np.float32).reshape(-1, 5)
     return dict(label=label, inten_label=ilabel, picked=picked, ipicked=ipicked, sharp=arr(sharp), flat=arr(flat), inten=arr(inten),
                 n_sharp_own=n_sharp_own)
+
+
+GROUND_SCAN_IND = 7            # groundScanInd, :34
+LADER_H = 0.56                 # laderH, :39
+GROUND_SCAN_RANGE = np.array([2.66, 3.04, 3.56, 4.30, 5.44, 7.41, 11.63, 27.12] + [0.0] * 8, np.float32)   # Ground_scan_range[16], :40
+
+
+def ground(cloud, ring_count, rng):
+    """:308-431 restated line by line.  cloud: (n, >=3) float32, ring-major; ring_count[i] = laserCloudScans[i].points.size(); rng =
+    range_vec (stencils()["range"]).  Returns (groundcloudMarked, GroundPoints indices in push order, groundparam[11] or None).
+    Reference quirks kept: `i / (groundScanInd - 1)` is an INTEGER division (:323, :325: threshold 0.8 and weight 1.5 for rings 0-5,
+    1.6 and 0.5 for ring 6); the neighbour growth runs n = -5 .. 4 (:333); a ring of fewer than 11 points is skipped (the reference's
+    size_t `size() - 5` would wrap: undefined there)."""
+    P = np.asarray(cloud, np.float32)
+    n = len(P)
+    mark = np.zeros(n, np.int32)
+    pushed, weights = [], []
+    center, gweights = np.zeros(3), 0.0
+    start = 0
+    for i in range(min(GROUND_SCAN_IND, len(ring_count))):
+        sz = int(ring_count[i])
+        if sz >= 11:
+            th = f32(0.8 * (1.0 + i // (GROUND_SCAN_IND - 1)))
+            w = 1.5 - i // (GROUND_SCAN_IND - 1)
+            for col in range(5, sz - 5):
+                ci = start + col
+                diff = f32(abs(f32(rng[ci] - GROUND_SCAN_RANGE[i])))
+                if diff < th and P[ci, 2] < 0.3:
+                    mark[ci] = 1
+                    for nn in range(-5, 5):
+                        if f32(abs(f32(rng[ci + nn] - rng[ci]))) < f32(th / f32(2)):
+                            mark[ci + nn] = 1
+                            pushed.append(ci + nn)
+                            weights.append(w)
+                            center = center + w * P[ci + nn, :3].astype(np.float64)
+                            gweights = gweights + w
+        start += sz
+    if not pushed:
+        return mark, np.zeros(0, np.int64), None
+    near = P[np.asarray(pushed), :3].astype(np.float64)
+    lw = np.asarray(weights)
+    center = center / gweights
+    cov = np.zeros((3, 3))
+    for j in range(len(near)):
+        d = near[j] - center
+        cov = cov + lw[j] * np.outer(d, d)
+    cov = cov / gweights
+    ev, V = np.linalg.eigh(cov)                      # ascending, like SelfAdjointEigenSolver
+    nrm = V[:, 0] / np.linalg.norm(V[:, 0])
+    if center @ nrm < 0:
+        nrm = -nrm
+    distance, src1 = 0.0, 0.0
+    for j in range(len(near)):
+        d = near[j] - center
+        dl = np.linalg.norm(d)
+        dw = 1.0 if dl == 0 else 1.0 - 100.0 * abs(nrm @ (d / dl))   # (Eigen's normalized() of a zero vector stays zero)
+        if dw < 0:
+            dw = 0.1
+        src1 += dw
+        distance += dw * (nrm @ near[j])
+    distance = distance / src1
+    src1 = src1 / len(near)
+    if distance / LADER_H > 1.1 or distance / LADER_H < 0.9:
+        distance = LADER_H
+    if src1 < 0.9:
+        distance = 0.9 * LADER_H + 0.1 * distance
+    return mark, np.asarray(pushed, np.int64), np.array([*nrm, *V[:, 1], *V[:, 2], distance, 1.0 - src1])

@@ -45,6 +45,15 @@ class World:
     cyls: np.ndarray   # (c, 4): cx, cy, radius, ztop   (base at GROUND_Z)
     ground_z: float = GROUND_Z
     seed: int = SEED
+    ramp: tuple | None = None   # (x0, x1, slope): the ground rises with `slope` between x0 and x1 and stays level behind (a ground CHANGE for
+                                # the odometer's ground-change detector, RGC_odometer.cpp:1034-1087); None: the flat ground every config uses
+
+    def ground_height(self, x):
+        """ground level at world x (scalar or array)"""
+        if self.ramp is None:
+            return np.full_like(np.asarray(x, np.float64), self.ground_z)
+        x0, x1, s = self.ramp
+        return self.ground_z + s * (np.clip(np.asarray(x, np.float64), x0, x1) - x0)
 
 
 def make_world(half_extent: float = 60.0, seed: int = SEED, pitch: float = 20.0) -> World:
@@ -175,10 +184,21 @@ def _cast(world: World, o: np.ndarray, d: np.ndarray, max_range: float) -> np.nd
     n = d.shape[0]
     t_best = np.full(n, np.inf)
     # ground
-    with np.errstate(divide="ignore", invalid="ignore"):
-        tg = (world.ground_z - o[:, 2]) / d[:, 2]
-    ok = (d[:, 2] < 0) & (tg > 0)
-    t_best = np.where(ok, np.minimum(t_best, tg), t_best)
+    if world.ramp is None:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = (world.ground_z - o[:, 2]) / d[:, 2]
+        ok = (d[:, 2] < 0) & (tg > 0)
+        t_best = np.where(ok, np.minimum(t_best, tg), t_best)
+    else:  # three planes -- level, ramp, level -- each valid where its hit falls into its own x range
+        x0, x1, sl = world.ramp
+        for (a, b, z_at_a, slope) in ((-np.inf, x0, world.ground_z, 0.0), (x0, x1, world.ground_z, sl), (x1, np.inf, world.ground_z + sl * (x1 - x0), 0.0)):
+            xa = x0 if not np.isfinite(a) else a
+            # plane: z = z_at_a + slope * (x - xa)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tg = (z_at_a + slope * (o[:, 0] - xa) - o[:, 2]) / (d[:, 2] - slope * d[:, 0])
+                xh = o[:, 0] + tg * d[:, 0]
+            ok = np.isfinite(tg) & (tg > 0) & (xh >= a) & (xh <= b)
+            t_best = np.where(ok, np.minimum(t_best, tg), t_best)
     # boxes near the sensor only
     oc = o.mean(axis=0)
     if len(world.boxes):

@@ -67,3 +67,22 @@ def test_two_ranks_with_real_hip_contexts_on_one_device():
     for r in (0, 1):
         one = _line([sys.executable, "bench.py", "--gpus", "1", "--sequence", str(r)] + args)
         assert one["final_pose_checksum"] == cs[r], (r, one["final_pose_checksum"], cs)
+
+
+def test_eight_ranks_on_one_device():
+    """BASELINE config 4's launch shape -- `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` -- at a reduced size with all eight
+    ranks on device 0 of a one-GPU box (RGC_BENCH_DEVICE, gloo for the barrier / MAX-reduce): eight different sequences, eight different
+    checksums, `value` = 8 K steps over the slowest rank's time, every rank's poses identical one frame at a time.  No scaling claim."""
+    args = ["--steps", "3", "--warmup", "1", "--n-target", "60000", "--n-source", "8000", "--no-cpu-baseline", "--configs", "none", "--no-two-sequences"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RGC_BENCH_DEVICE="0", RGC_BENCH_DIST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", "bench.py", "--gpus", "8"] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["steps"] == 3 and r["scaling"] == "weak" and r["config"]["parallelism"] == "sequences x8"
+    cs = r["final_pose_checksum_per_rank"]
+    assert len(cs) == 8 and len(set(cs)) == 8
+    assert abs(r["value"] - 8 * 3 / (r["ms_per_step"] * 3 * 1e-3)) <= 1e-2 * r["value"]
+    assert r["one_frame_at_a_time"]["same_poses"]

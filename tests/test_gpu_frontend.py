@@ -124,3 +124,13 @@ def test_sweeps_sized_from_the_previous_one(fe16):
             assert np.array_equal(a["groundparam"], b["groundparam"])
     finally:
         spec.close()
+
+
+def test_frontend_fixture(fe16):
+    """The HIP front-end on the committed sweep against the literal numpy restatement's arrays (tests/golden/fx_frontend.npz; the same
+    check tests/test_oracle_golden.py runs on the C oracle): labels, curvatures, ground marks / points / plane, feature clouds."""
+    import os
+    from conftest import GOLDEN
+    from test_oracle_golden import _check_frontend_against_fixture
+    fx = dict(np.load(os.path.join(GOLDEN, "fx_frontend.npz")))
+    _check_frontend_against_fixture(fe16.laserCloudHandler(fx["raw"]), fx)

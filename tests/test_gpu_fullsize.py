@@ -115,8 +115,17 @@ def test_c5_250k_vs_20M_with_prior(synth, map5m):
     # IMU stream of the motion through rgc_imu_preintegrate -- and no translation (the first frame of a sequence has no previous delta)
     from rgc_slam_amd import odometry
     guess = odometry.imu_rotation_priors([np.eye(4), T_true])[1]
-    # the CPU oracle on 20 M points needs a many-core host and a few GB; keep it where it finishes in seconds
-    _check_case(synth, world, tgt, src, T_true, guess, oracle_pose_check=(os.cpu_count() or 1) >= 64)
+    # the CPU oracle's pose on the same clouds, always: on all 20 M points where the host has the cores for it, otherwise on the ONE tile
+    # the scan can see -- the three translated copies lie a map's width away, no voxel the solve looks up and no neighbour of a point of
+    # the tile is in them, so the oracle's registration against the tile alone is its registration against the whole map
+    T = _check_case(synth, world, tgt, src, T_true, guess, oracle_pose_check=(os.cpu_count() or 1) >= 64)
+    if (os.cpu_count() or 1) < 64:
+        from oracle import oracle as orc
+        o = orc.Registration(num_threads=min(14, os.cpu_count() or 1))
+        o.set_target(tile)
+        o.set_source(src)
+        To = o.align(guess)
+        assert np.abs(T[:3, 3] - To[:3, 3]).max() <= 1e-4 and _rot_angle(T[:3, :3], To[:3, :3]) <= 1e-4
 
 
 def test_c_main_dependent_sequence_vs_oracle(synth):

@@ -126,3 +126,95 @@ def test_sequence_against_the_literal_frame_body():
     assert max(_angle(r[1], q) for r, q in zip(rows, fx["q"])) <= 5e-4 and max(np.abs(r[2] - t).max() for r, t in zip(rows, fx["t"])) <= 5e-4
     assert [r[3] for r in rows] == list(fx["gflag"]) and [r[4] for r in rows] == list(fx["keyframes"])
     assert [r[5] for r in rows] == list(fx["submap"])     # the leaf filters' output sizes: the same clouds went in
+
+
+def c2_standin(n_sweeps=200, slope=0.06, n_az=1200):
+    """BASELINE.md's c2 stand-in at its stated length: `n_sweeps` synthetic VLP-16 sweeps with motion distortion along a trajectory that
+    climbs a ramp (the ground CHANGES under the vehicle: the odometer's ground-change detector, RGC_odometer.cpp:1034-1087, trips there)
+    and a 200 Hz IMU stream.  -> (raw sweeps, stamps, (imu stamps, acc, gyr), true poses)"""
+    import math
+    import rgc_slam_amd.synth as synth
+    world = synth.make_world(half_extent=45.0, seed=synth.SEED)
+    base = synth.make_trajectory(n_sweeps + 1, seed=synth.SEED + 2)
+    x0 = base[min(25, n_sweeps // 2)][0, 3]
+    world.ramp = (x0, x0 + 4.0, slope)
+    poses = []
+    for P in base:
+        Q = P.copy()
+        Q[2, 3] += float(world.ground_height(Q[0, 3])) - world.ground_z
+        if world.ramp[0] <= Q[0, 3] <= world.ramp[1]:
+            Q[:3, :3] = Q[:3, :3] @ synth.rot_zyx(0.0, -math.atan(slope), 0.0)      # nose up by the ramp's angle
+        poses.append(Q)
+    imu = synth.make_imu(poses, seed=synth.SEED + 2)
+    raws = []
+    for k in range(n_sweeps):
+        sc = synth.make_scan(world, poses[k], n_az=n_az, seed=synth.SEED + 70 + k, T_ws_end=poses[k + 1])
+        raws.append(np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32))
+    return raws, [0.1 * (k + 1) for k in range(n_sweeps)], imu, poses
+
+
+def test_c2_standin_200_sweeps(tmp_path):
+    """BASELINE.md section 3, config 2 at its stated size: 200 sweeps through the whole frame body (front-end, IMU guess, de-skew, leaf
+    filters, 3-keyframe sub-map with turnover, FastVGICP, ground gate, fusion, composition), USE_IMU = 1 and USE_GROUND = 1 --
+      (a) the Python mirror on the HIP library against the SAME frame body on the CPU oracle, sweep by sweep: pose deltas within
+          1e-4 m / 1e-4 rad, the same ground flag every sweep (the gate trips on the ramp and recovers 25 sweeps later), the same keyframes;
+      (b) rgc::OdometryNode (C++: PointCloud2 bytes + IMU samples in, odometry out) on the same sweeps against (a)'s HIP poses to 1e-9."""
+    import os
+    import subprocess
+    from rgc_slam_amd import odometry
+    from oracle_backend import OracleBackend
+    raws, sweep_stamps, (stamps, acc, gyr), poses = c2_standin()
+    hb = odometry.HipBackend(0)
+    og = odometry.Odometer(hb, use_imu=True, first_frames=2)
+    oc = odometry.Odometer(OracleBackend(), use_imu=True, first_frames=2)
+    j = 0
+    prev_g = prev_c = None
+    worst_t = worst_r = 0.0
+    flags, turnover, ref = [], 0, []
+    newest = None
+    for k, raw in enumerate(raws):
+        t_k = sweep_stamps[k]
+        while j < len(stamps) and stamps[j] <= t_k + 0.011:
+            og.imu_callback(stamps[j], acc[j], gyr[j]); oc.imu_callback(stamps[j], acc[j], gyr[j]); j += 1
+        rg, rc = og.process(raw, t_k), oc.process(raw, t_k)
+        ref.append(np.concatenate([og.q_w_curr, og.t_w_curr]))
+        assert (rg is None) == (rc is None) == (k < 2)
+        if rg is None:
+            continue
+        (qg, tg), (qc, tc) = rg, rc
+        if prev_g is not None:
+            worst_t = max(worst_t, float(np.abs((tg - prev_g[1]) - (tc - prev_c[1])).max()))
+            worst_r = max(worst_r, abs(_angle(qg, prev_g[0]) - _angle(qc, prev_c[0])))
+        prev_g, prev_c = (qg, tg), (qc, tc)
+        assert og.gflag == oc.gflag and len(og.surrounding) == len(oc.surrounding), k
+        flags.append(og.gflag)
+        if og.surrounding_t and (newest is None or not np.array_equal(newest, og.surrounding_t[-1])):
+            turnover += newest is not None
+            newest = og.surrounding_t[-1].copy()
+    hb.close()
+    assert worst_t <= 1e-4 and worst_r <= 1e-4, (worst_t, worst_r)
+    assert 25 <= sum(flags) < 60 and flags[0] == 0 and flags[-1] == 0, "".join(map(str, flags))      # one trip of the gate, 25 sweeps off, back on
+    assert turnover >= 30 and len(og.surrounding) == 3                                                 # keyframes came and went the whole way
+    true = np.linalg.inv(poses[3]) @ poses[len(raws)]
+    assert np.linalg.norm(og.t_w_curr - true[:3, 3]) < 0.05 * np.linalg.norm(true[:3, 3]) + 0.5       # (coarse sanity, not parity)
+    # ---- (b) the C++ node on the same sweeps ----
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_odometry_node")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-pthread", os.path.join(root, "tests", "cpp", "test_odometry_node.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "rgc-slam_amd"), "-lrgc_hip", "-Wl,-rpath," + os.path.join(root, "rgc-slam_amd")])
+    path, ipath = str(tmp_path / "sweeps.bin"), str(tmp_path / "imu.bin")
+    dt = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4"), ("ring", "<u2"), ("time", "<f4")])
+    with open(path, "wb") as f:
+        f.write(np.int32(len(raws)).tobytes())
+        for r in raws:
+            rec = np.zeros(len(r), dt)
+            rec["x"], rec["y"], rec["z"], rec["intensity"] = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+            f.write(np.int32(len(r)).tobytes()); f.write(rec.tobytes())
+    with open(ipath, "wb") as f:
+        f.write(np.int32(len(stamps)).tobytes())
+        f.write(np.concatenate([stamps[:, None], acc, gyr], axis=1).astype("<f8").tobytes())
+    out = subprocess.run([exe, path, "0", "1", "50.0", "0", "0", ipath, "2"], capture_output=True, text=True, timeout=900).stdout
+    assert "EXCEPTION" not in out, out[-2000:]
+    cpp = np.array([[float(x) for x in l.split()[2:9]] for l in out.splitlines() if l.startswith("pose")])
+    ref = np.array(ref)
+    assert cpp.shape == ref.shape and np.abs(cpp - ref).max() < 1e-9, (cpp.shape, ref.shape, np.abs(cpp - ref).max() if cpp.shape == ref.shape else None)

@@ -138,3 +138,62 @@ def test_voxelgrid(orc, fx_vg):
         out = orc.voxelgrid_filter(fx_vg["xyzi"], leaf)
         assert out.shape == fx_vg[key].shape
         assert np.abs(out - fx_vg[key]).max() < 1e-4
+
+
+def _check_frontend_against_fixture(o, fx, rel_tol_intensity=3e-4):
+    """o: a front-end result (the C oracle's or the HIP path's dict); fx: tests/golden/fx_frontend.npz (the literal numpy restatement)"""
+    order = fx["ring_major_order"]
+    assert o["n_cloud"] == len(fx["raw"]) and np.array_equal(o["ring_count"][:16], fx["ring_count"])
+    assert np.array_equal(o["cloud"][:, :3], fx["raw"][order, :3])                                   # A1 / A2
+    for k in ("curvature", "curvature2", "inten_curvature"):                                         # A3 / A4, fp32 bit for bit
+        assert np.array_equal(o[k], fx[k]), k
+    assert np.array_equal(o["ground_marked"], fx["ground_marked"])                                   # A5 marks, ground points in push order
+    n_g = o["n_ground"] if "n_ground" in o else len(o["ground_pts"])
+    assert n_g == len(fx["ground_point_index"])
+    assert np.array_equal(o["ground_pts"][:n_g, :3], fx["raw"][order][fx["ground_point_index"], :3])
+    assert o["ground_valid"]
+    g, gf = np.asarray(o["groundparam"]), fx["groundparam"]                                          # A5 plane (fp64; eigenvector signs are arbitrary)
+    assert np.abs(g[0:3] - gf[0:3]).max() < 1e-8 and abs(g[9] - gf[9]) < 1e-9 and abs(g[10] - gf[10]) < 1e-9
+    for a in (3, 6):
+        assert min(np.abs(g[a:a + 3] - gf[a:a + 3]).max(), np.abs(g[a:a + 3] + gf[a:a + 3]).max()) < 1e-6
+    assert np.array_equal(o["label"], fx["label"]) and np.array_equal(o["picked"], fx["picked"])     # A6 / A7 decisions
+    for k in ("sharp", "flat", "inten"):                                                             # A8 clouds: x y z and the weight exactly;
+        assert o[k].shape == fx[k].shape, k                                                          # ring + 0.1 relTime to the azimuth reconstruction
+        assert np.array_equal(o[k][:, [0, 1, 2, 4]], fx[k][:, [0, 1, 2, 4]]), k
+        assert len(o[k]) == 0 or np.abs(o[k][:, 3] - fx[k][:, 3]).max() < rel_tol_intensity, k
+
+
+def test_frontend_fixture(orc):
+    """SURVEY 8c's fx_frontend: the C oracle's front-end on the committed sweep against the literal numpy restatement's labels, curvatures,
+    ground marks / points / plane and feature clouds (tests/golden/gen_frontend_fuse.py)."""
+    import os
+    from conftest import GOLDEN
+    fx = dict(np.load(os.path.join(GOLDEN, "fx_frontend.npz")))
+    _check_frontend_against_fixture(orc.frontend(fx["raw"]), fx)
+
+
+def test_fuse_fixture():
+    """SURVEY 8c's fx_fuse: the product's host-side pose fusion (rgc_fuse_pose: no GPU needed) against the committed scipy solutions of the
+    restated Ceres problem (src/RGC_odometer.cpp:1025-1119; oracle/py_fusion.py)."""
+    import ctypes as C
+    import json
+    import os
+    from conftest import GOLDEN
+    from rgc_slam_amd import _lib
+    h = _lib.load()
+    fx = json.load(open(os.path.join(GOLDEN, "fx_fuse.json")))
+    assert len(fx["cases"]) >= 10
+    for c in fx["cases"]:
+        fin = _lib.FuseIn()
+        h.rgc_default_fuse_in(C.byref(fin))
+        fin.q_lidar_xyzw[:] = c["q_lidar"]; fin.t_lidar[:] = c["t_lidar"]; fin.fitness = c["fitness"]
+        fin.use_ground = int(c["use_ground"]); fin.ground_last[:] = c["ground_last"]; fin.ground_cur[:] = c["ground_cur"]
+        fin.q_w_curr_f_xyzw[:] = c["q_w_curr_f"]; fin.ground_cov = c["ground_cov"]
+        fin.use_imu = int(c["use_imu"]); fin.q_imu_xyzw[:] = c["q_imu"]
+        q, t, it = np.empty(4), np.empty(3), C.c_int(0)
+        dp = C.POINTER(C.c_double)
+        assert h.rgc_fuse_pose(C.byref(fin), q.ctypes.data_as(dp), t.ctypes.data_as(dp), C.byref(it)) == 0
+        qo, to = np.asarray(c["q_fused_xyzw"]), np.asarray(c["t_fused"])
+        if np.dot(q, qo) < 0:
+            qo = -qo
+        assert np.abs(q - qo).max() < 1e-6 and np.abs(t - to).max() < 1e-6 and it.value <= 6
