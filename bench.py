@@ -630,7 +630,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=20)   # (a few milliseconds of the same steps in front of the timed ones: the first steps behind an idle GPU run at lower clocks)
     ap.add_argument("--n-target", type=int, default=N_TARGET)
     ap.add_argument("--n-source", type=int, default=N_SOURCE)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -4,8 +4,11 @@
 # dependent c-main sequence, one frame at a time on one context (scripts/prof_dependent.py), summed over EVERY kernel of a frame.
 # bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB -> bytes: the guide's gfx950 correction (FETCH_SIZE tallies 128-byte read requests at 64 bytes:
 # exact for wide coalesced reads, an upper estimate for narrow gathers).
-#   usage (GPU box): bash scripts/frame_traffic.sh [frames, default 20] [tag, default cmain]   -> gpurun_out/frame_traffic_<tag>.json
-K=${1:-20}; TAG=${2:-cmain}
+# Round 6: with nothing kept between frames (RGC_KNN_SEEDS=0 = rgc_set_knn_reuse(RGC_REUSE_NONE)), the workload bench.py's `value` times; a
+# third argument `lists` measures the library's default on the unchanged synthetic map instead (-> frame_traffic_<tag>_lists.json).
+#   usage (GPU box): bash scripts/frame_traffic.sh [frames, default 20] [tag, default cmain] [none|lists]   -> gpurun_out/frame_traffic_<tag>.json
+K=${1:-20}; TAG=${2:-cmain}; REUSE=${3:-none}
+if [ $REUSE = none ]; then export RGC_KNN_SEEDS=0; else unset RGC_KNN_SEEDS; fi
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/ft_$TAG
 rm -rf $O; mkdir -p $O
@@ -13,7 +16,7 @@ for set in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $set -d $O/$set -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prof_dependent.py $K 0 $TAG > $O/$set.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
-K=$K TAG=$TAG python3 - <<'PY'
+K=$K TAG=$TAG REUSE=$REUSE python3 - <<'PY'
 import csv, glob, json, collections, os, subprocess
 root = os.environ["GRAFT_REPO_ROOT"]; K = int(os.environ["K"]); tag = os.environ["TAG"]
 O = os.path.join(root, "gpurun_out", "ft_" + tag)
@@ -33,11 +36,14 @@ for name, m in per.items():
 rows.sort(key=lambda r: -r["MB_per_frame"])
 hc = os.path.join(root, ".head_commit")   # written beside the snapshot before the GPU call (there is no .git on the box)
 commit = open(hc).read().strip() if os.path.exists(hc) else None
-out = {"workload": tag + ": dependent sequence, one frame at a time, every kernel of a frame (scripts/prof_dependent.py)", "frames": frames,
+reuse = os.environ.get("REUSE", "none")
+out = {"workload": tag + ": dependent sequence, one frame at a time, every kernel of a frame (scripts/prof_dependent.py), "
+                   + ("nothing kept between frames (RGC_KNN_SEEDS=0)" if reuse == "none" else "the library's default: seeds + neighbour lists of the unchanged map"), "frames": frames,
        "bytes_per_frame_measured": int(tot), "formula": "(2 x FETCH_SIZE + WRITE_SIZE) KiB per kernel, summed (MI355X_MICROARCH.md: FETCH_SIZE x 2 on gfx950)",
        "commit": commit, "per_kernel": rows}
-json.dump(out, open(os.path.join(root, "gpurun_out", "frame_traffic_" + tag + ".json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "gpurun_out", "frame_traffic_" + tag + ("" if reuse == "none" else "_lists") + ".json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}))
 for r in rows[:14]: print(r)
 PY
 rm -rf $O
+unset RGC_KNN_SEEDS

@@ -5,32 +5,36 @@ cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc_seeded
 rm -rf $O; mkdir -p $O
 SETS=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "$@")
-# two sweeps: the product as it runs (neighbour lists on: launches 2..5 take certified queries' neighbours from their lists and search the
-# rest), and with RGC_KNN_CACHE=0 (every launch searches every query, seeded: what a frame runs after the map's buffer was written to)
-for mode in lists nolists; do
-  if [ $mode = nolists ]; then export RGC_KNN_CACHE=0; else unset RGC_KNN_CACHE; fi
+# three sweeps: RGC_KNN_SEEDS=0 (nothing kept between targets: every launch is the FULL search, what bench.py's `value` runs), the library's
+# default (neighbour lists on: launches 2..5 take certified queries' neighbours from their lists and search the rest), and RGC_KNN_CACHE=0
+# (every launch searches every query, seeded: what a frame runs after the map's buffer was written to)
+for mode in none lists nolists; do
+  unset RGC_KNN_CACHE RGC_KNN_SEEDS
+  if [ $mode = nolists ]; then export RGC_KNN_CACHE=0; fi
+  if [ $mode = none ]; then export RGC_KNN_SEEDS=0; fi
   for set in "${SETS[@]}"; do
     d=$O/$mode/$(echo $set | tr ' ' '_')
     mkdir -p $O/$mode
     rocprofv3 --pmc $set -d $d -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/prof_frame_reframed.py 1000000 5 > $d.log 2>&1 || tail -3 $d.log
   done
 done
-unset RGC_KNN_CACHE
+unset RGC_KNN_CACHE RGC_KNN_SEEDS
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, json, collections, os
 root = os.environ["GRAFT_REPO_ROOT"]
 O = os.path.join(root, "gpurun_out", "pmc_seeded")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for mode in ("lists", "nolists"):
+for mode in ("none", "lists", "nolists"):
     for f in glob.glob(os.path.join(O, mode, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
             if "k_knn_sp<20, true, true" in kn:
                 if "true, true, true" in kn:
-                    acc["lists" if mode == "lists" else "seeded"][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                elif mode == "lists":
-                    acc["unseeded"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    if mode != "none":
+                        acc["lists" if mode == "lists" else "seeded"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                elif mode == "none":
+                    acc["full_search"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 hc = os.path.join(root, ".head_commit")
 out = {"commit": open(hc).read().strip() if os.path.exists(hc) else None, "queries_per_launch": 1000000}
 for which, cs in acc.items():
@@ -43,13 +47,13 @@ for which, cs in acc.items():
                        ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "vmem_rd_per_valu"), ("SQ_INST_CYCLES_VMEM", "SQ_BUSY_CYCLES", "vmem_inst_cycles_per_busy_cycle")):
         if a in m and b in m and m[b]: o[name] = round(m[a] / m[b], 4)
     out[which] = o
-# the launch of the bench's timed region (a re-framed persistent map from its second frame on: neighbour lists + the search of the
-# uncertified queries) at the top level, in the layout bench.py / sync_docs.py read; beside it "seeded" (the same kernel with the lists
-# off: every query searched, what a frame runs after a write to the map) and "unseeded" (the full search: a map the library has not seen)
-if "lists" in out:
-    top = dict(out.pop("lists"))
-    top["launch"] = "lists"
-    top["kernel"] = "k_knn_sp<20, true, true, true> (1000000 queries per launch; scripts/prof_frame_reframed.py, launches 2..5: certified queries from their neighbour lists, the rest searched)"
+# the launch of the bench's timed region -- the full search of a re-framed map with nothing kept between frames (rgc_set_knn_reuse(RGC_REUSE_NONE)
+# = RGC_KNN_SEEDS=0) -- at the top level, in the layout bench.py reads; beside it "lists" (the library's default on an unchanged map:
+# certified queries from their neighbour lists, the rest searched) and "seeded" (the lists off: every query searched from its last k-th distance)
+if "full_search" in out:
+    top = dict(out.pop("full_search"))
+    top["launch"] = "full_search"
+    top["kernel"] = "k_knn_sp<20, true, true, false> (1000000 queries per launch; scripts/prof_frame_reframed.py under RGC_KNN_SEEDS=0: every query of every launch searched in full)"
     out = {**top, **out}
 json.dump(out, open(os.path.join(root, "gpurun_out", "pmc_seeded.json"), "w"), indent=1)
 print(json.dumps(out))
