@@ -732,6 +732,12 @@ def main():
     Tw_start, g_start = Tw_init, I4
     from rgc_slam_amd import _lib as _rgc_lib
     host_loop = "c++ (librgc_seq.so: rgc_seq_run_dependent)" if _rgc_lib.load_seq() is not None else "python (ctypes call per stage)"
+    # A device that has been idle (15 s of data generation, the collection above) starts at low clocks and takes a few milliseconds of work to
+    # leave them -- longer than the W warm-up steps a caller may ask for last.  The first frames of the sequence, PREWARM times over, untimed, in
+    # front of the W warm-up steps: the timed steps then run at the clocks a sequence that keeps running sees (steady_state below).
+    PREWARM = 8
+    for _ in range(PREWARM):
+        seq.run_cpp(0, min(4, K + W), Tw_init, I4, True)
     if W > 0:
         m, wd, _ = seq.run_cpp(0, W, Tw_init, I4, True)
         Tw_start, g_start = wd[-1], m[-1]
@@ -890,6 +896,7 @@ def main():
     n_slots = max(1, n_map // kf_n)
     n_kf = (n_frames_all + 2) // 3
     kf_np = torch.zeros((n_kf, kf_n, 4), dtype=torch.float32).pin_memory().numpy()
+    kf_short = []
     map_lo, map_hi = maps[0].min(axis=0) + np.float32(0.5), maps[0].max(axis=0) - np.float32(0.5)
     for kk in range(n_kf):
         i = min(3 * kk, len(scans) - 1)
@@ -902,26 +909,39 @@ def main():
         # measured once per buffer -- "fixed between calls", rgc_hip.h; a rolling map that GROWS is the resident map's business, rgc_map_*)
         wpts = wpts[np.all((wpts > map_lo) & (wpts < map_hi), axis=1)]
         kf_np[kk, :wpts.shape[0], :3] = wpts
-        if wpts.shape[0] < kf_n:   # (a short sweep: the rest of the block keeps the map's own rows)
-            slot = (kk % n_slots) * kf_n
-            kf_np[kk, wpts.shape[0]:, :] = map_host[slot + wpts.shape[0]:slot + kf_n]
+        kf_short.append(int(wpts.shape[0]))   # (a short keyframe: the rest of its block keeps the map's own rows, filled in below)
     def edit_one(i, w):
         w.upload_async(seq.d_map + 7 * 16, one_np[i:i + 1])
+    # the keyframe sequence runs on a copy of the map whose ROWS are shuffled: a keyframe then evicts a uniform 1 % of the map's points (an old
+    # keyframe's returns lie all over the local map), not a slab of it -- the generated map's rows are in leaf order, and a contiguous block of
+    # them is a hole in the ground
+    perm = np.random.default_rng(seed + 499).permutation(n_map)
+    map_perm = np.ascontiguousarray(map_host[perm])
+    d_map_perm = v.device_alloc(map_perm.nbytes)
+    v.upload(d_map_perm, map_perm)
+    seq_kf = DependentSequence(pv.v, d_map_perm, n_map, d_scans, [s_.shape[0] for s_ in scans])
+    for kk, got in enumerate(kf_short):
+        if got < kf_n:
+            slot = (kk % n_slots) * kf_n
+            kf_np[kk, got:, :] = map_perm[slot + got:slot + kf_n]
     def edit_kf(i, w):
         if i % 3 == 0:
-            w.upload_async(seq.d_map + ((i // 3) % n_slots) * kf_n * 16, kf_np[i // 3])
+            w.upload_async(d_map_perm + ((i // 3) % n_slots) * kf_n * 16, kf_np[i // 3])
     def timed_like_value(edit=None, overlap=True, reps=3):
         per, first, same = [], None, True
+        sq = seq_kf if edit is edit_kf else seq
         for _ in range(reps):
-            if edit is not None:
-                v.upload(seq.d_map, map_host)   # (synchronises) every pass starts from the map as generated
+            if edit is edit_kf:
+                v.upload(d_map_perm, map_perm)  # (synchronises) every pass starts from the map as generated
+            elif edit is not None:
+                v.upload(seq.d_map, map_host)
             Tw_s, g_s = Tw_init, I4
             if W > 0:
-                m, wd, _ = seq.run(0, W, Tw_init, I4, overlap, edit_map=edit)
+                m, wd, _ = sq.run(0, W, Tw_init, I4, overlap, edit_map=edit)
                 Tw_s, g_s = wd[-1], m[-1]
             pv.synchronize()
             tr = time.perf_counter()
-            m, _, _ = seq.run(W, K, Tw_s, g_s, overlap, edit_map=edit)
+            m, _, _ = sq.run(W, K, Tw_s, g_s, overlap, edit_map=edit)
             pv.synchronize()
             per.append(time.perf_counter() - tr)
             if first is None:
@@ -975,12 +995,14 @@ def main():
     v.upload(seq.d_map, map_host)
     reuse["map_knn_launch_alone_ms"] = {"unchanged_map_lists": round(dom_lists["total_ms"] / max(dom_lists["launches"], 1), 4),
                                         "after_a_write_seeded_search_and_lists_rebuilt": round(dom_rebuild["total_ms"] / max(dom_rebuild["launches"], 1), 4)}
+    seq_kf.close()
+    v.device_free(d_map_perm)
     reuse["what"] = ("rgc_set_knn_reuse(RGC_REUSE_LISTS), the library's default, instead of `value`'s RGC_REUSE_NONE; every entry W warm-up + K timed steps on two "
                      "contexts, median of 3 passes.  unchanged_map: this synthetic sequence as it is (the world-frame map handed over bit for bit every frame -- "
                      "a caller that has dropped the reference's per-frame body-frame leaf filter of the sub-map, RGC_odometer.cpp:985-991); "
                      "one_point_edited_every_frame: one coordinate moved by an ulp before every frame (all-or-nothing invalidation: everything searched, seeded, "
-                     "lists rebuilt); keyframe_every_3rd_frame: 1 % of the map's rows overwritten with that sweep's points in the world frame every third "
-                     "frame.  with_nothing_kept: the same edited sequence under RGC_REUSE_NONE (the edits' uploads included)")
+                     "lists rebuilt); keyframe_every_3rd_frame: every third frame a uniform 1 % of the map's points (a block of rows of a row-shuffled copy of the "
+                     "map) is overwritten with that sweep's leaf-filtered points in the world frame -- an insert and an evict, RGC_odometer.cpp:1236-1247.  with_nothing_kept: the same edited sequence under RGC_REUSE_NONE (the edits' uploads included)")
     for w in pv.v:
         w.setNeighbourReuse(REUSE_NONE)
 
@@ -1065,7 +1087,7 @@ def main():
 
     out = {
         "metric": "registered scans/sec (16-beam -> 1M-pt map)", "value": round(scans_per_s, 3), "unit": "scans/s",
-        "n_gpus": world_size, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
+        "n_gpus": world_size, "steps": K, "warmup": W, "prewarm_frames_before_the_warmup": 4 * PREWARM, "ms_per_step": round(1e3 * elapsed / K, 3),
         "timed_steps_ms": {"median": round(1e3 * float(np.median(np.diff(step_stamps))), 4), "max": round(1e3 * float(np.max(np.diff(step_stamps))), 4),
                            "slowest_step": int(np.argmax(np.diff(step_stamps))),
                            "what": "host time between consecutive results inside the timed region of rank 0 (a one-off stall -- an allocation, a speculative-grid miss -- shows here, not in the kernels)"},

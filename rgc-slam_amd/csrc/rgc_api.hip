@@ -67,6 +67,9 @@ constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 #ifndef RGC_JOIN_SPIN_US
 #define RGC_JOIN_SPIN_US 300
 #endif
+#ifndef RGC_EARLY_POSE
+#define RGC_EARLY_POSE 1       // 0: rgc_align_end_reframe waits for a solve's score before it enqueues the next frame's target (round 5)
+#endif
 #ifndef RGC_KNN_CACHE
 #define RGC_KNN_CACHE 1        // 0: no neighbour lists (rgck::KnnCache): every frame searches the whole map, seeded
 #endif
@@ -193,6 +196,7 @@ struct rgc_ctx {
   rgck::LmState* h_lm = nullptr;  // pinned mirror (the stream-ordered copy behind every batch of LM launches)
   rgck::LmState* h_post = nullptr; // mapped host memory the DEVICE writes a finished solve's state into, then the solve's number into its `gen`
   rgck::LmState* d_post = nullptr; // ... its device address
+  rgck::LmEarly* h_early = nullptr, *d_early = nullptr;  // mapped host memory / its device address: a solve's final pose, posted before its score (rgc_align_end_reframe)
   int lazy_margin = 0;             // rgc_set_target_lazy: > 0 = the target's covariances / voxels are built only where the solve can look (cells of margin)
   hipEvent_t src_in_ready = nullptr;  // recorded on stream2 behind a HOST scan's upload: the lazy target's footprint pass (main stream) reads the scan's input
   bool src_in_pending = false;
@@ -1497,6 +1501,10 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
     memset(c->h_post, 0, sizeof(rgck::LmState));
     if (hipHostGetDevicePointer((void**)&c->d_post, c->h_post, 0) != hipSuccess) c->d_post = nullptr;  // (no fast path then)
   }
+  if (ok && hipHostMalloc((void**)&c->h_early, sizeof(rgck::LmEarly), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+    memset(c->h_early, 0, sizeof(rgck::LmEarly));
+    if (hipHostGetDevicePointer((void**)&c->d_early, c->h_early, 0) != hipSuccess) c->d_early = nullptr;  // (no early pose then)
+  }
   c->uid = g_next_uid.fetch_add(1);
   ok = ok && hipEventCreateWithFlags(&c->src_read_done, kDevEvent) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->lm_tail, kDevEvent) == hipSuccess;
@@ -1544,6 +1552,7 @@ void rgc_destroy(rgc_ctx* c) {
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->h_lm) (void)hipHostFree(c->h_lm);
   if (c->h_post) (void)hipHostFree(c->h_post);
+  if (c->h_early) (void)hipHostFree(c->h_early);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   release(c->lm_state);
   release(c->fit_partials);
@@ -1744,7 +1753,8 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
                   (int*)c->corr_v2.p, (double*)c->corr_M2.p, (double*)c->partials.p, (rgck::LmState*)c->lm_state.p, c->lm_j++, op, c->d_small + 7,
                   c->tgt.segs.p, c->src.segs.p, post, seq, fit_in_steps ? (const float4*)c->tgt.P.p : nullptr,
                   fit_in_steps ? (const int*)c->tgt.start.p : nullptr, fit_in_steps ? (double*)c->fit_partials.p : nullptr, c->tgt.n,
-                  c->tgt.lazy == 2 ? (const int*)c->tgt.need.p : nullptr, c->tgt.need_stamp, c->tgt.lazy == 2 ? (const int*)c->tgt.segs.p + 1 : nullptr);
+                  c->tgt.lazy == 2 ? (const int*)c->tgt.need.p : nullptr, c->tgt.need_stamp, c->tgt.lazy == 2 ? (const int*)c->tgt.segs.p + 1 : nullptr,
+                  (fit_in_steps && post) ? c->d_early : nullptr);
   };
   auto score = [&]() {  // getFitnessScore at the final pose, chained blindly (on the image the last launch left)
     rgck::fitness_lm(s, (const float4*)c->src.P.p, n, rgck::lm_image((rgck::LmState*)c->lm_state.p, c->lm_j - 1), (const float4*)c->tgt.P.p,
@@ -2436,40 +2446,84 @@ int rgc_align_end_reframe(rgc_ctx* c, rgc_ctx* next, double Tw[16], const float*
     const int rc0 = reframe_args_ok(next, d_map, n, stride_bytes, d_scratch);
     if (rc0) { if (next != c) fail(c, rc0, "rgc_align_end_reframe: %s", next->err); return rc0; }
   }
+  // world_T * T in fp64, rows in ascending k (the composition of :1201-1203 on matrices), and world -> body of the new pose: R^T and
+  // -R^T t; the unit quaternion of R^T by Shepperd's branches (:1250-1255)
+  auto compose = [](const double* Tw_in, const float* T, double* W, double* q, double* t) {
+    for (int a = 0; a < 4; a++)
+      for (int b = 0; b < 4; b++) {
+        double v = 0.0;
+        for (int k = 0; k < 4; k++) v += Tw_in[a * 4 + k] * (double)T[k * 4 + b];
+        W[a * 4 + b] = v;
+      }
+    const double Rt[3][3] = {{W[0], W[4], W[8]}, {W[1], W[5], W[9]}, {W[2], W[6], W[10]}};
+    const double tr = Rt[0][0] + Rt[1][1] + Rt[2][2];
+    if (tr > 0) {
+      const double s4 = 2.0 * std::sqrt(tr + 1.0);
+      q[0] = (Rt[2][1] - Rt[1][2]) / s4; q[1] = (Rt[0][2] - Rt[2][0]) / s4; q[2] = (Rt[1][0] - Rt[0][1]) / s4; q[3] = 0.25 * s4;
+    } else {
+      const int i = (Rt[0][0] >= Rt[1][1] && Rt[0][0] >= Rt[2][2]) ? 0 : (Rt[1][1] >= Rt[2][2] ? 1 : 2);
+      const int j = (i + 1) % 3, k = (i + 2) % 3;
+      const double s4 = 2.0 * std::sqrt(1.0 + Rt[i][i] - Rt[j][j] - Rt[k][k]);
+      q[3] = (Rt[k][j] - Rt[j][k]) / s4;
+      q[i] = 0.25 * s4;
+      q[j] = (Rt[j][i] + Rt[i][j]) / s4;
+      q[k] = (Rt[k][i] + Rt[i][k]) / s4;
+    }
+    const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int a = 0; a < 4; a++) q[a] /= nrm;
+    const double tx = W[3], ty = W[7], tz = W[11];
+    t[0] = -(Rt[0][0] * tx + Rt[0][1] * ty + Rt[0][2] * tz);
+    t[1] = -(Rt[1][0] * tx + Rt[1][1] * ty + Rt[1][2] * tz);
+    t[2] = -(Rt[2][0] * tx + Rt[2][1] * ty + Rt[2][2] * tz);
+  };
+  // The POSE of a solve whose score is chained to it arrives before the score does (LmEarly: the deciding launch posts it, then scores it,
+  // ~25 us at the headline size).  On two contexts taking turns the next frame's target needs nothing else: it is enqueued on `next` while
+  // this context's last launch still computes the score, whose arrival the call then waits for like rgc_align_end.  Not on one context
+  // (the score reads the buffers the next preparation writes), not when a guard tripped or a lazy target missed (the solve is repeated).
+  float Te[16];
+  double We[16], qe[4], te[3];
+  bool early_done = false;
+  int rc_next = RGC_OK;
+  if (next != c && RGC_EARLY_POSE && c->post_on && c->d_post && c->d_early && c->pend.want_fitness && !c->lm_host) {
+    volatile int* eg = &c->h_early->gen;
+    volatile int* fg = &c->h_post->gen;
+    bool early = false;
+    for (unsigned spin = 0;; spin++) {
+      if (*eg == c->lm_seq) { early = true; break; }
+      if (*fg == c->lm_seq) break;
+      if (spin & 31u) continue;
+      const hipError_t qy = hipEventQuery(c->lm_tail);
+      if (qy == hipSuccess) { early = *eg == c->lm_seq; break; }
+      if (qy != hipErrorNotReady) break;   // (rgc_align_end below reports it)
+      (void)hipGetLastError();
+    }
+    if (early) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      rgck::LmEarly E;
+      memcpy(&E, c->h_early, sizeof(E));
+      if (E.pad == 0 && E.pad2 == 0) {
+        for (int i = 0; i < 16; i++) Te[i] = (float)E.x0[i];  // final_transformation_ = x0.cast<float>(), :77
+        compose(Tw, Te, We, qe, te);
+        rc_next = rgc_set_target_reframed(next, d_map, n, stride_bytes, qe, te, d_scratch);
+        if (rc_next) fail(c, rc_next, "rgc_align_end_reframe: %s", next->err);
+        early_done = true;
+      }
+    }
+  }
   float T[16];
+  char next_err[sizeof(c->err)];
+  if (rc_next) memcpy(next_err, c->err, sizeof(next_err));
   int rc = rgc_align_end(c, T, final_H, fitness, iterations, converged, lm_failed);
   if (rc) return rc;
   if (final_T) memcpy(final_T, T, sizeof(T));
-  // world_T <- world_T * T in fp64, rows in ascending k (the composition of :1201-1203 on matrices)
-  double W[16];
-  for (int a = 0; a < 4; a++)
-    for (int b = 0; b < 4; b++) {
-      double v = 0.0;
-      for (int k = 0; k < 4; k++) v += Tw[a * 4 + k] * (double)T[k * 4 + b];
-      W[a * 4 + b] = v;
-    }
-  memcpy(Tw, W, sizeof(W));
-  // world -> body of the new pose: R^T and -R^T t; the unit quaternion of R^T by Shepperd's branches (:1250-1255)
-  const double Rt[3][3] = {{W[0], W[4], W[8]}, {W[1], W[5], W[9]}, {W[2], W[6], W[10]}};
-  double q[4];
-  const double tr = Rt[0][0] + Rt[1][1] + Rt[2][2];
-  if (tr > 0) {
-    const double s4 = 2.0 * std::sqrt(tr + 1.0);
-    q[0] = (Rt[2][1] - Rt[1][2]) / s4; q[1] = (Rt[0][2] - Rt[2][0]) / s4; q[2] = (Rt[1][0] - Rt[0][1]) / s4; q[3] = 0.25 * s4;
-  } else {
-    const int i = (Rt[0][0] >= Rt[1][1] && Rt[0][0] >= Rt[2][2]) ? 0 : (Rt[1][1] >= Rt[2][2] ? 1 : 2);
-    const int j = (i + 1) % 3, k = (i + 2) % 3;
-    const double s4 = 2.0 * std::sqrt(1.0 + Rt[i][i] - Rt[j][j] - Rt[k][k]);
-    q[3] = (Rt[k][j] - Rt[j][k]) / s4;
-    q[i] = 0.25 * s4;
-    q[j] = (Rt[j][i] + Rt[i][j]) / s4;
-    q[k] = (Rt[k][i] + Rt[i][k]) / s4;
+  if (early_done && memcmp(T, Te, sizeof(T)) == 0) {  // (always, unless the solve had to be repeated behind the early pose's back)
+    memcpy(Tw, We, sizeof(We));
+    if (rc_next) memcpy(c->err, next_err, sizeof(next_err));
+    return rc_next;
   }
-  const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  for (int a = 0; a < 4; a++) q[a] /= nrm;
-  const double tx = W[3], ty = W[7], tz = W[11];
-  const double t[3] = {-(Rt[0][0] * tx + Rt[0][1] * ty + Rt[0][2] * tz), -(Rt[1][0] * tx + Rt[1][1] * ty + Rt[1][2] * tz),
-                       -(Rt[2][0] * tx + Rt[2][1] * ty + Rt[2][2] * tz)};
+  double W[16], q[4], t[3];
+  compose(Tw, T, W, q, t);
+  memcpy(Tw, W, sizeof(W));
   rc = rgc_set_target_reframed(next, d_map, n, stride_bytes, q, t, d_scratch);
   if (rc && next != c) fail(c, rc, "rgc_align_end_reframe: %s", next->err);
   return rc;

@@ -81,6 +81,10 @@ struct LmState {  // device-resident state of LsqRegistration::computeTransforma
   int lazy_nq, lazy_ncell;       // lazy target: listed queries / cells of this frame (size the next frame's launches)
 };
 struct LmInit { double x0[16], rot_eps, trans_eps, init_factor; int max_outer, max_inner; };
+// Mapped host memory: the final pose of a solve, posted by its deciding launch BEFORE that launch computes the score (C8) -- a caller that
+// needs only the pose to go on (the next frame's target of a dependent sequence, rgc_align_end_reframe) starts ~25 us earlier; pad / pad2:
+// the grid guards and the lazy target's miss flag as the finished state will carry them; gen: the solve's number, written last
+struct LmEarly { double x0[16]; int pad, pad2, outer, gen; };
 struct FeParams { int n_scans; double min_range, max_range; };
 struct LeafGrid { int minb[3]; int div[3]; };  // pcl::VoxelGrid leaf grid
 
@@ -175,7 +179,8 @@ void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny,
              const float4* TP = nullptr, const int* tstart = nullptr, double* fit_partials = nullptr, int nt = 0,
              // lazy target: the target is built for the cells stamped lazy_stamp in lazy_need[] only -- a look-up of any other occupied voxel
              // raises LmState::pad2; lazy_counts: the lists' sizes, carried home in LmState::lazy_nq / lazy_ncell
-             const int* lazy_need = nullptr, int lazy_stamp = 0, const int* lazy_counts = nullptr);
+             const int* lazy_need = nullptr, int lazy_stamp = 0, const int* lazy_counts = nullptr,
+             LmEarly* h_early = nullptr /* mapped host memory (nullable): the deciding launch posts the final pose there before it scores it */);
 // nt: the target's point count (a small map is scanned whole by the wave for a query its first cube does not settle; 0: never)
 void fitness_lm(hipStream_t s, const float4* SP, int ns, LmState* st, const float4* TP, const int* tstart, Grid g, double* partials,
                 LmState* h_post = nullptr, int seq = 0, int nt = 0);

@@ -3293,6 +3293,7 @@ struct FitArgs {
   const float4* TP; const int* tstart; double* partials; int n_all; int on;
   const int* need; int stamp;  // lazy target: the target is built only for the cells stamped `stamp` in need[]: every look-up is checked
   const int* counts;           // ... and its list sizes ([0] queries, [1] cells) ride home with the state
+  LmEarly* early;              // mapped host memory (nullable): the final pose goes there before the score is computed
 };
 
 // this wave's share of getFitnessScore at pose m16 (cast to float like final_transformation_, :77), as a write-through row
@@ -3414,6 +3415,19 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
       if (score) {
         // the solve ended with this launch's decision (or earlier, unscored: max_iterations <= 0): the score at the final pose, every
         // wave its row; the last arriver folds them
+        if (fa.early && blockIdx.x == 0 && !was_done) {
+          // ... the final POSE first (every linearisation of this solve ran in an earlier launch: the guards and the lazy target's miss flag
+          // are final too): whoever needs only the pose to go on does not wait for the score
+          int* hw = reinterpret_cast<int*>(fa.early);
+          const int* sw = reinterpret_cast<const int*>(ls.x0);
+          if (threadIdx.x < 32) __hip_atomic_store(&hw[threadIdx.x], sw[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (threadIdx.x == 32) __hip_atomic_store(&fa.early->pad, ls.pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (threadIdx.x == 33) __hip_atomic_store(&fa.early->pad2, __hip_atomic_load(miss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (threadIdx.x == 34) __hip_atomic_store(&fa.early->outer, ls.outer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          __syncthreads();
+          if (threadIdx.x == 0) __hip_atomic_store(&fa.early->gen, seq < 0 ? -seq : seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         step_fitness_rows(P, n, ls.x0, g, fa);
         if (!last_block_arrive(lm_area_ticket(st))) return;
         if (threadIdx.x < WAVE) {
@@ -4368,8 +4382,8 @@ static int fitness_scan_all(int nt) { return nt > 0 && nt <= 32768 ? nt : 0; }
 void lm_step(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Grid g, const int* cell_voxel,
              const double* vox, int noff, int* corr_v0, double* corr_M0, int* corr_v1, double* corr_M1, double* partials, LmState* st,
              int j, const LmInit* open, const int* nvox, const void* segs_t, const void* segs_s, LmState* h_post, int seq, const float4* TP,
-             const int* tstart, double* fit_partials, int nt, const int* lazy_need, int lazy_stamp, const int* lazy_counts) {
-  const FitArgs fa{TP, tstart, fit_partials, fitness_scan_all(nt), (TP && tstart && fit_partials) ? 1 : 0, lazy_need, lazy_stamp, lazy_counts};
+             const int* tstart, double* fit_partials, int nt, const int* lazy_need, int lazy_stamp, const int* lazy_counts, LmEarly* h_early) {
+  const FitArgs fa{TP, tstart, fit_partials, fitness_scan_all(nt), (TP && tstart && fit_partials) ? 1 : 0, lazy_need, lazy_stamp, lazy_counts, h_early};
   hipLaunchKernelGGL(k_lm_step, dim3(linearize_blocks(n)), dim3(LIN_T), 0, s, P, nx, ny, nz, n, g, cell_voxel, vox, noff, corr_v0, corr_M0, corr_v1,
                      corr_M1, partials, st, j, (j == 0 && open) ? *open : LmInit{}, nvox, (const int*)segs_t, (const int*)segs_s, h_post, seq, fa);
 }

@@ -41,7 +41,7 @@ def test_bench_line_direct_and_under_torchrun():
     assert "error" not in sp, sp
     assert [x["S"] for x in sp["runs"]] == [1, 2, 4, 8] and all(x["poses_equal_each_sequence_alone"] for x in sp["runs"])
     b = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-               "--master-port", "29611", "bench.py", "--gpus", "1"] + ARGS)
+               "--master-port", "29611", "bench.py", "--gpus", "1", "--no-two-sequences"] + ARGS)
     assert b["n_gpus"] == 1
     assert b["final_pose_checksum"] == a["final_pose_checksum"]
 
@@ -51,7 +51,7 @@ def test_two_ranks_with_real_hip_contexts_on_one_device():
     one-GPU box -- RGC_BENCH_DEVICE -- and the barrier / MAX-reduce go over gloo): each rank runs its own sequence (two different
     checksums), each equal to the `--gpus 1` run of that sequence, and `value` is the whole job's 2 K steps over the slower rank's time.
     No scaling claim: the two ranks share one GPU."""
-    args = ["--steps", "4", "--warmup", "2", "--n-target", "150000", "--no-cpu-baseline", "--configs", "none"]
+    args = ["--steps", "4", "--warmup", "2", "--n-target", "150000", "--no-cpu-baseline", "--configs", "none", "--no-two-sequences"]
     env2 = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RGC_BENCH_DEVICE="0", RGC_BENCH_DIST_BACKEND="gloo")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29613", "bench.py", "--gpus", "2"] + args, cwd=ROOT, env=env2, capture_output=True, text=True, timeout=1200)
