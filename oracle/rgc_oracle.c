@@ -36,7 +36,11 @@ void orc_default_params(orc_params* p) {
 static int clip_threads(int n) {
 #ifdef _OPENMP
   int m = omp_get_max_threads();
-  if (n <= 0 || n > m) n = m;
+  /* 0 = "the default": the host's threads, but no more than 16 -- the parallel loops of this restatement are short, and on a 256-thread
+   * host they run SEVEN TIMES SLOWER on all threads than on the reference's 14 (setNumThreads(14), src/RGC_odometer.cpp:1006).  An explicit
+   * count is honoured up to what the host has. */
+  if (n <= 0) n = m < 16 ? m : 16;
+  if (n > m) n = m;
   return n;
 #else
   (void)n;

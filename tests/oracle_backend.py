@@ -1,5 +1,7 @@
 """CPU-oracle implementation of the backend interface rgc_slam_amd.odometry.Odometer expects -- used ONLY by the tests to
 produce the reference trajectory of a sequence (the product's HipBackend never touches the oracle)."""
+import os
+
 import numpy as np
 
 from oracle import oracle as orc
@@ -26,7 +28,9 @@ class OracleBackend:
         return orc.transform_cloud(xyzi, q, t)
 
     def register(self, source, target, guess):
-        r = orc.Registration(num_threads=0)
+        # the reference's setNumThreads(14) (RGC_odometer.cpp:1006): on a many-core host the oracle's short OpenMP loops get SLOWER with
+        # more threads (0.6 against 4.3 scans/s at 256 against 14 threads on the GPU box: bench.py's cpu_baseline)
+        r = orc.Registration(num_threads=min(14, os.cpu_count() or 1))
         r.set_target(target); r.set_source(source)
         T = r.align(guess)
         return T, r.fitness()

@@ -193,7 +193,8 @@ def test_c2_standin_200_sweeps(tmp_path):
             newest = og.surrounding_t[-1].copy()
     hb.close()
     assert worst_t <= 1e-4 and worst_r <= 1e-4, (worst_t, worst_r)
-    assert 25 <= sum(flags) < 60 and flags[0] == 0 and flags[-1] == 0, "".join(map(str, flags))      # one trip of the gate, 25 sweeps off, back on
+    trace = "".join(map(str, flags))
+    assert flags[0] == 0 and sum(flags) >= 25 and "1" * 24 + "0" in trace, trace       # the gate trips on the ramp, holds the ground factor off for 25 sweeps, and lets it back in
     assert turnover >= 30 and len(og.surrounding) == 3                                                 # keyframes came and went the whole way
     true = np.linalg.inv(poses[3]) @ poses[len(raws)]
     assert np.linalg.norm(og.t_w_curr - true[:3, 3]) < 0.05 * np.linalg.norm(true[:3, 3]) + 0.5       # (coarse sanity, not parity)
