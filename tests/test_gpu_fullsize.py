@@ -170,3 +170,49 @@ def test_c_main_dependent_sequence_vs_oracle(synth):
     assert np.abs(worlds[-1][:3, 3] - poses[K + 1][:3, 3]).max() < 0.05      # the synthetic trajectory is recovered (metres travelled: ~1)
     seq.close()
     pv.close()
+
+
+def test_c_main_200_frames(synth):
+    """c-main at its stated length -- 200 frames of the dependent sequence (30 k-point scans against the 1 M-point map
+    re-expressed by the previous pose), through the C++ frame loop bench.py's timed region runs (librgc_seq.so):
+      * two contexts taking turns == one frame at a time, every motion bit for bit; the library's default reuse mode (seeds + lists) ==
+        nothing kept, bit for bit;
+      * every 40th frame against the CPU oracle started from the SAME previous pose and guess: <= 1e-4 m / 1e-4 rad;
+      * the accumulated world pose follows the known trajectory over its whole length."""
+    import bench
+    from oracle import oracle as orc
+    from rgc_slam_amd import registration
+    K = 200
+    world, tgt = synth.make_world_and_map(1_000_000, seed=synth.SEED)
+    poses = synth.make_trajectory(K + 1, seed=synth.SEED)
+    scans = [synth.make_scan_n(world, poses[i + 1], 30000, seed=synth.SEED + 100 + i)["xyz"] for i in range(K)]
+    pv = registration.PipelinedVGICP(0, depth=2)
+    v = pv.v[0]
+    def to_dev(xyz):
+        a = np.zeros((xyz.shape[0], 4), np.float32); a[:, :3] = xyz
+        p = v.device_alloc(a.nbytes); v.upload(p, a); return p, a
+    (d_map, map4), d_scans = to_dev(tgt), [to_dev(s)[0] for s in scans]
+    seq = bench.DependentSequence(pv.v, d_map, len(tgt), d_scans, [len(s) for s in scans])
+    I4, Tw0 = np.eye(4, dtype=np.float32), np.asarray(poses[0], np.float64)
+    for w in pv.v:
+        w.setNeighbourReuse(registration.FastVGICP.REUSE_NONE)
+    m2, worlds, guesses = seq.run_cpp(0, K, Tw0, I4, True)
+    m1, _, _ = seq.run_cpp(0, K, Tw0, I4, False)
+    assert all(np.array_equal(a, b) for a, b in zip(m1, m2))
+    for w in pv.v:
+        w.setNeighbourReuse(registration.FastVGICP.REUSE_LISTS)
+    ml, _, _ = seq.run_cpp(0, K, Tw0, I4, True)
+    assert all(np.array_equal(a, b) for a, b in zip(m2, ml))
+    assert v.stats()["searched_target"] < 0.05 * len(tgt) or pv.v[1].stats()["searched_target"] < 0.05 * len(tgt)
+    o = orc.Registration(num_threads=min(14, os.cpu_count() or 1))
+    for j in (0, 40, 80, 120, 160, K - 1):
+        q, t = bench.world_to_body(Tw0 if j == 0 else worlds[j - 1])
+        body = orc.transform_cloud(map4, q, t)
+        o.set_target(body[:, :3].copy()); o.set_source(scans[j])
+        To = o.align(guesses[j])
+        assert np.abs(m2[j][:3, 3] - To[:3, 3]).max() <= 1e-4 and _rot_angle(m2[j][:3, :3], To[:3, :3]) <= 1e-4, j
+    path = float(sum(np.linalg.norm(poses[i + 1][:3, 3] - poses[i][:3, 3]) for i in range(K)))
+    err = float(np.abs(worlds[-1][:3, 3] - poses[K][:3, 3]).max())
+    assert path > 10.0 and err < 0.005 * path + 0.1, (path, err)      # the synthetic trajectory is recovered over its whole length
+    seq.close()
+    pv.close()
