@@ -45,9 +45,9 @@ typedef enum rgc_status {
   RGC_ERR_GRID_TOO_LARGE = -4,  /* bounding box / resolution needs more cells than max_cells   */
   RGC_ERR_NO_INPUT = -5,        /* source or target not set                                    */
   RGC_ERR_NONFINITE = -6,       /* input contains NaN/Inf coordinates                          */
-  RGC_ERR_UNSUPPORTED = -7      /* a setting of the reference's interface that this path does not
-                                   implement is selected (rgc_set_regularization_method,
-                                   rgc_set_voxel_accumulation_mode)                            */
+  RGC_ERR_UNSUPPORTED = -7      /* the request has no meaning under the selected settings (e.g.
+                                   unit normals asked for under a RegularizationMethod other
+                                   than PLANE: rgc_set_regularization_method)                  */
 } rgc_status;
 
 /* enum order = fast_gicp::NeighborSearchMethod, include/fast_gicp/gicp/gicp_settings.hpp:8 */
@@ -73,14 +73,17 @@ RGC_API void rgc_default_params(rgc_params* p);
  * fast_gicp::RegularizationMethod, gicp_settings.hpp:6) and FastVGICP::setVoxelAccumulationMode (fast_vgicp.hpp:57,
  * impl/fast_vgicp_impl.hpp:41-43; enum order = VoxelAccumulationMode, gicp_settings.hpp:10).  The odometer calls neither
  * (src/RGC_odometer.cpp:998-1006 leaves PLANE, fast_gicp_impl.hpp:20, and ADDITIVE, fast_vgicp_impl.hpp:24).
- *   Implemented: RGC_REG_PLANE; RGC_VOXEL_ADDITIVE and RGC_VOXEL_ADDITIVE_WEIGHTED (the vendored FastVGICP builds the same
- *   AdditiveGaussianVoxel for both, fast_vgicp_voxel.hpp:137-141, and looks at the mode nowhere else: identical results).
- *   Not implemented: NONE, MIN_EIG, NORMALIZED_MIN_EIG, FROBENIUS (fast_gicp_impl.hpp:262-293: a full 3x3 per point; this path stores a
- *   plane-regularised covariance as its unit normal, 24 bytes, in every kernel) and MULTIPLICATIVE (fast_vgicp_voxel.hpp:76-99).
- * The reference's setters return void and cannot fail.  Here a setter never aborts or throws either: selecting an unimplemented value
- * returns RGC_ERR_UNSUPPORTED and is REMEMBERED -- every later rgc_set_target* / rgc_set_source* / rgc_align* / rgc_linearize on the
- * context fails with RGC_ERR_UNSUPPORTED (rgc_last_error names the setting) until an implemented value is selected: a caller that
- * ignores the status gets no result rather than the result of another method. */
+ * Every value is implemented.  PLANE with ADDITIVE / ADDITIVE_WEIGHTED (one and the same AdditiveGaussianVoxel in the vendored FastVGICP,
+ * fast_vgicp_voxel.hpp:137-141; the mode is looked at nowhere else) runs on the tuned kernels, which keep a point's covariance as the unit
+ * normal of I - 0.999 n n^T (24 bytes).  NONE, MIN_EIG, NORMALIZED_MIN_EIG, FROBENIUS (fast_gicp_impl.hpp:262-293) and
+ * VoxelAccumulationMode::MULTIPLICATIVE (fast_vgicp_voxel.hpp:76-99) run on a GENERAL route: a regularised 3x3 per point (48 bytes), every
+ * point's exact k-NN through the cooperative search, a plain voxel pass, and the LM loop driven from the host over a linearisation that takes
+ * the full source covariance -- the same entry points and the reference's arithmetic, an order of magnitude slower (it is not the odometer's
+ * path and has not been tuned).  On that route rgc_align_begin solves at once and rgc_align_end hands the result over; rgc_set_target_lazy and
+ * rgc_set_knn_reuse have no effect; rgc_get_*_covariances returns no normals (RGC_ERR_UNSUPPORTED if asked); rgc_set_*_covariances takes any
+ * symmetric 3x3.  RGC_ERR_UNSUPPORTED is otherwise unused by these calls; an out-of-range value is RGC_ERR_INVALID.
+ * The reference computes covariances at align() under the method selected THEN (fast_gicp_impl.hpp:103-112); this library computes them when
+ * a cloud is set, so changing the method (or additive <-> multiplicative) afterwards DROPS the clouds: set them again.  Select before setting. */
 typedef enum rgc_regularization_method { RGC_REG_NONE = 0, RGC_REG_MIN_EIG = 1, RGC_REG_NORMALIZED_MIN_EIG = 2, RGC_REG_PLANE = 3, RGC_REG_FROBENIUS = 4 } rgc_regularization_method;
 typedef enum rgc_voxel_accumulation_mode { RGC_VOXEL_ADDITIVE = 0, RGC_VOXEL_ADDITIVE_WEIGHTED = 1, RGC_VOXEL_MULTIPLICATIVE = 2 } rgc_voxel_accumulation_mode;
 RGC_API int rgc_set_regularization_method(rgc_ctx* ctx, int method);

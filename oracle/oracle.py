@@ -29,7 +29,12 @@ def build(force: bool = False) -> str:
 class Params(C.Structure):
     _fields_ = [("voxel_res", C.c_double), ("max_iterations", C.c_int), ("lm_max_iterations", C.c_int),
                 ("rotation_eps", C.c_double), ("translation_eps", C.c_double), ("lm_init_lambda_factor", C.c_double),
-                ("k_correspondences", C.c_int), ("neighbor_method", C.c_int), ("num_threads", C.c_int)]
+                ("k_correspondences", C.c_int), ("neighbor_method", C.c_int), ("num_threads", C.c_int),
+                ("regularization", C.c_int), ("voxel_mode", C.c_int)]
+
+
+REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = range(5)      # fast_gicp::RegularizationMethod, gicp_settings.hpp:6
+VOXEL_ADDITIVE, VOXEL_ADDITIVE_WEIGHTED, VOXEL_MULTIPLICATIVE = range(3)                # VoxelAccumulationMode, gicp_settings.hpp:10
 
 
 class FeParams(C.Structure):
@@ -126,6 +131,11 @@ def lib():
         L.orc_eig3.argtypes = [dp, dp, dp]
         L.orc_voxelmap_create.argtypes = [fp, C.c_int, C.c_int, dp, C.c_double]
         L.orc_voxelmap_create.restype = vp
+        L.orc_voxelmap_create_m.argtypes = [fp, C.c_int, C.c_int, dp, C.c_double, C.c_int]
+        L.orc_voxelmap_create_m.restype = vp
+        L.orc_covariances_m.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.c_int]
+        L.orc_regularize.argtypes = [dp, C.c_int, dp]
+        L.orc_regularize.restype = None
         L.orc_voxelmap_free.argtypes = [vp]
         L.orc_voxelmap_size.argtypes = [vp]
         L.orc_voxelmap_dump.argtypes = [vp, ip, ip, dp, dp]
@@ -219,6 +229,24 @@ def covariances(xyz, k=20, threads=0):
     return cov, nrm
 
 
+def covariances_m(xyz, method, k=20, threads=0):
+    """fast_gicp_impl.hpp:241-298 under any RegularizationMethod (REG_*): (n, 3, 3)"""
+    a, ap = _f32(xyz)
+    n = a.shape[0]
+    cov = np.empty((n, 3, 3), np.float64)
+    rc = lib().orc_covariances_m(ap, n, a.shape[1], k, int(method), cov.ctypes.data_as(C.POINTER(C.c_double)), threads)
+    if rc:
+        raise RuntimeError(f"orc_covariances_m rc={rc}")
+    return cov
+
+
+def regularize(S, method):
+    s, sp = _f64(np.asarray(S, np.float64).reshape(9))
+    out = np.empty((3, 3))
+    lib().orc_regularize(sp, int(method), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
 def eig3(A):
     a, ap = _f64(A)
     ev = np.empty(3)
@@ -239,10 +267,10 @@ def _dump_vm(handle):
     return dict(coords=coords, num=num, mean=mean, cov=cov)
 
 
-def voxelmap(xyz, cov, res=1.0):
+def voxelmap(xyz, cov, res=1.0, multiplicative=False):
     a, ap = _f32(xyz)
     c, cp = _f64(cov)
-    h = lib().orc_voxelmap_create(ap, a.shape[0], a.shape[1], cp, res)
+    h = lib().orc_voxelmap_create_m(ap, a.shape[0], a.shape[1], cp, res, 1 if multiplicative else 0)
     try:
         return _dump_vm(h)
     finally:

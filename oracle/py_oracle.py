@@ -26,8 +26,8 @@ def knn_indices(xyz: np.ndarray, k: int = K) -> np.ndarray:
     return idx
 
 
-def covariances(xyz: np.ndarray, k: int = K):
-    """fast_gicp_impl.hpp:241-298 with RegularizationMethod::PLANE: returns (n,4,4) Matrix4d-like covs."""
+def covariances(xyz: np.ndarray, k: int = K, regularization: str = "PLANE"):
+    """fast_gicp_impl.hpp:241-298 under RegularizationMethod `regularization` (the odometer's: PLANE): returns (n,4,4) Matrix4d-like covs."""
     idx = knn_indices(xyz, k)
     n = xyz.shape[0]
     covs = np.zeros((n, 4, 4))
@@ -36,8 +36,24 @@ def covariances(xyz: np.ndarray, k: int = K):
         nb[:3, :] = xyz[idx[i]].astype(np.float64).T          # :256-259 getVector4fMap().cast<double>()
         nb = nb - nb.mean(axis=1, keepdims=True)               # :261
         cov = nb @ nb.T / k                                    # :262
+        if regularization == "NONE":                           # :264-265
+            covs[i] = cov
+            continue
+        if regularization == "FROBENIUS":                      # :266-271
+            Cm = cov[:3, :3] + 1e-3 * np.eye(3)
+            Ci = np.linalg.inv(Cm)
+            covs[i, :3, :3] = np.linalg.inv(Ci / np.linalg.norm(Ci))
+            continue
         U, s, Vt = np.linalg.svd(cov[:3, :3])                  # :273 JacobiSVD
-        covs[i, :3, :3] = U @ np.diag([1.0, 1.0, 1e-3]) @ Vt   # :281,293
+        if regularization == "PLANE":
+            values = np.array([1.0, 1.0, 1e-3])                # :280-282
+        elif regularization == "MIN_EIG":
+            values = np.maximum(s, 1e-3)                       # :283-285
+        elif regularization == "NORMALIZED_MIN_EIG":
+            values = np.maximum(s / s.max(), 1e-3)             # :286-289
+        else:
+            raise ValueError(regularization)
+        covs[i, :3, :3] = U @ np.diag(values) @ Vt             # :293
     return covs, idx
 
 
@@ -46,9 +62,11 @@ def voxel_coord(x, res=1.0):
     return np.floor(np.asarray(x, dtype=np.float64)[:3] / res - 0.5).astype(np.int64)
 
 
-def build_voxelmap(xyz: np.ndarray, covs: np.ndarray, res: float = 1.0):
-    """fast_vgicp_voxel.hpp:129-156, AdditiveGaussianVoxel :105-122"""
+def build_voxelmap(xyz: np.ndarray, covs: np.ndarray, res: float = 1.0, voxel_mode: str = "ADDITIVE"):
+    """fast_vgicp_voxel.hpp:129-156; AdditiveGaussianVoxel :105-122 (ADDITIVE and ADDITIVE_WEIGHTED alike, :137-141),
+    MultiplicativeGaussianVoxel :76-99"""
     vox = {}
+    mult = voxel_mode == "MULTIPLICATIVE"
     for i in range(xyz.shape[0]):
         m = np.array([xyz[i, 0], xyz[i, 1], xyz[i, 2], 1.0], dtype=np.float64)
         c = tuple(voxel_coord(m, res))
@@ -56,11 +74,24 @@ def build_voxelmap(xyz: np.ndarray, covs: np.ndarray, res: float = 1.0):
         if v is None:
             v = vox[c] = dict(n=0, mean=np.zeros(4), cov=np.zeros((4, 4)))
         v["n"] += 1
-        v["mean"] += m
-        v["cov"] += covs[i]
+        if mult:                                               # :82-91
+            ci = covs[i].copy()
+            ci[3, 3] = 1.0
+            ci = np.linalg.inv(ci)
+            v["cov"] += ci
+            v["mean"] += ci @ m
+        else:
+            v["mean"] += m
+            v["cov"] += covs[i]
     for v in vox.values():
-        v["mean"] /= v["n"]
-        v["cov"] /= v["n"]
+        if mult:                                               # :93-99
+            v["cov"][3, 3] = 1.0
+            v["mean"][3] = 1.0
+            v["cov"] = np.linalg.inv(v["cov"])
+            v["mean"] = v["cov"] @ v["mean"]
+        else:
+            v["mean"] /= v["n"]
+            v["cov"] /= v["n"]
     return vox
 
 
@@ -98,20 +129,21 @@ OFFSETS = {
 class VGICP:
     """FastVGICP as driven at RGC_odometer.cpp:998-1009."""
 
-    def __init__(self, res=1.0, max_iterations=25, rot_eps=2e-3, trans_eps=1e-6, method="DIRECT1"):
+    def __init__(self, res=1.0, max_iterations=25, rot_eps=2e-3, trans_eps=1e-6, method="DIRECT1", regularization="PLANE", voxel_mode="ADDITIVE"):
         self.res, self.max_iterations, self.rot_eps, self.trans_eps = res, max_iterations, rot_eps, trans_eps
         self.lm_max_iterations, self.lm_init_lambda_factor = 10, 1e-9
         self.method = method
+        self.regularization, self.voxel_mode = regularization, voxel_mode
         self.trace = []
 
     def set_target(self, xyz):
         self.tgt = np.asarray(xyz, dtype=np.float32)
-        self.tgt_covs, self.tgt_knn = covariances(self.tgt)
-        self.vox = build_voxelmap(self.tgt, self.tgt_covs, self.res)
+        self.tgt_covs, self.tgt_knn = covariances(self.tgt, regularization=self.regularization)
+        self.vox = build_voxelmap(self.tgt, self.tgt_covs, self.res, self.voxel_mode)
 
     def set_source(self, xyz):
         self.src = np.asarray(xyz, dtype=np.float32)
-        self.src_covs, self.src_knn = covariances(self.src)
+        self.src_covs, self.src_knn = covariances(self.src, regularization=self.regularization)
 
     def update_correspondences(self, T):
         """fast_vgicp_impl.hpp:73-116"""

@@ -31,6 +31,8 @@ void orc_default_params(orc_params* p) {
   p->k_correspondences = 20;
   p->neighbor_method = ORC_DIRECT1;
   p->num_threads = 14;
+  p->regularization = ORC_REG_PLANE;
+  p->voxel_mode = ORC_VOXEL_ADDITIVE;
 }
 
 static int clip_threads(int n) {
@@ -357,6 +359,66 @@ void orc_cov_from_neighbors(const float* pts, int stride, const int* idx, int k,
   if (normal) { normal[0] = U[2]; normal[1] = U[5]; normal[2] = U[8]; }
 }
 
+static int inv3(const double A[9], double B[9]);
+/* fast_gicp_impl.hpp:262-293: what calculate_covariances makes of one neighbourhood's sample covariance under each RegularizationMethod.
+ * JacobiSVD of a symmetric positive semi-definite matrix is its eigen-decomposition (U = V, singular values = eigenvalues, descending). */
+void orc_regularize(const double S[9], int method, double cov9[9]) {
+  if (method == ORC_REG_NONE) { memcpy(cov9, S, sizeof(double) * 9); return; }                      /* :264-265 */
+  if (method == ORC_REG_FROBENIUS) {                                                                  /* :266-271 */
+    const double lambda = 1e-3;
+    double C[9], Ci[9], N[9];
+    memcpy(C, S, sizeof(C));
+    C[0] += lambda; C[4] += lambda; C[8] += lambda;
+    if (inv3(C, Ci)) memset(Ci, 0, sizeof(Ci));
+    double nrm = 0;
+    for (int a = 0; a < 9; a++) nrm += Ci[a] * Ci[a];
+    nrm = sqrt(nrm);                                                                                  /* Eigen's norm(): Frobenius */
+    for (int a = 0; a < 9; a++) N[a] = Ci[a] / nrm;
+    if (inv3(N, cov9)) memset(cov9, 0, sizeof(double) * 9);
+    return;
+  }
+  double ev[3], U[9], vals[3];
+  orc_eig3(S, ev, U);                                                                                 /* :273 */
+  if (method == ORC_REG_PLANE) { vals[0] = 1.0; vals[1] = 1.0; vals[2] = 1e-3; }                      /* :280-282 */
+  else if (method == ORC_REG_MIN_EIG) { for (int j = 0; j < 3; j++) vals[j] = ev[j] > 1e-3 ? ev[j] : 1e-3; }  /* :283-285 */
+  else { for (int j = 0; j < 3; j++) { const double t = ev[j] / ev[0]; vals[j] = t > 1e-3 ? t : 1e-3; } }     /* :286-289 */
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double s = 0;
+      for (int j = 0; j < 3; j++) s += U[a * 3 + j] * vals[j] * U[b * 3 + j];                         /* :293 */
+      cov9[a * 3 + b] = s;
+    }
+}
+
+int orc_covariances_m(const float* pts, int n, int stride, int k, int method, double* cov9_out, int num_threads) {
+  if (k > ORC_MAXK || k <= 0 || n < k) return -1;
+  grid_t g;
+  if (grid_build(&g, pts, n, stride, k) < 0) return -2;
+  int nt = clip_threads(num_threads);
+  (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    int idx[ORC_MAXK];
+    grid_knn(&g, pts + (size_t)i * stride, k, idx, NULL);
+    double mean[3] = {0, 0, 0}, S[9] = {0};
+    for (int j = 0; j < k; j++) {
+      const float* q = pts + (size_t)idx[j] * stride;
+      mean[0] += (double)q[0]; mean[1] += (double)q[1]; mean[2] += (double)q[2];
+    }
+    mean[0] /= k; mean[1] /= k; mean[2] /= k;
+    for (int j = 0; j < k; j++) {
+      const float* q = pts + (size_t)idx[j] * stride;
+      double d[3] = {(double)q[0] - mean[0], (double)q[1] - mean[1], (double)q[2] - mean[2]};
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) S[a * 3 + b] += d[a] * d[b];
+    }
+    for (int a = 0; a < 9; a++) S[a] /= k;
+    orc_regularize(S, method, cov9_out + (size_t)i * 9);
+  }
+  grid_free(&g);
+  return 0;
+}
+
 int orc_covariances(const float* pts, int n, int stride, int k, double* cov9_out, double* normal_out, int num_threads) {
   if (k > ORC_MAXK || k <= 0 || n < k) return -1;
   grid_t g;
@@ -434,6 +496,9 @@ static voxel_t* vm_find(const orc_voxelmap* vm, const int c[3], int insert) {
 }
 
 orc_voxelmap* orc_voxelmap_create(const float* pts, int n, int stride, const double* cov9, double res) {
+  return orc_voxelmap_create_m(pts, n, stride, cov9, res, 0);
+}
+orc_voxelmap* orc_voxelmap_create_m(const float* pts, int n, int stride, const double* cov9, double res, int multiplicative) {
   orc_voxelmap* vm = (orc_voxelmap*)calloc(1, sizeof(*vm));
   vm->res = res;
   size_t cap = 64;
@@ -450,11 +515,25 @@ orc_voxelmap* orc_voxelmap_create(const float* pts, int n, int stride, const dou
     orc_voxel_coord(x, res, c);
     voxel_t* v = vm_find(vm, c, 1);
     v->num++;                                        /* :112-116 append */
+    if (multiplicative) {                            /* MultiplicativeGaussianVoxel::append, :82-91: cov += C^-1, mean += C^-1 p (the 4x4's (3,3) = 1 trick is the 3x3 inverse) */
+      double Ci[9];
+      if (inv3(cov9 + (size_t)i * 9, Ci)) memset(Ci, 0, sizeof(Ci));
+      for (int a = 0; a < 9; a++) v->cov[a] += Ci[a];
+      for (int a = 0; a < 3; a++) v->mean[a] += Ci[a * 3] * x[0] + Ci[a * 3 + 1] * x[1] + Ci[a * 3 + 2] * x[2];
+      continue;
+    }
     for (int a = 0; a < 3; a++) v->mean[a] += x[a];
     for (int a = 0; a < 9; a++) v->cov[a] += cov9[(size_t)i * 9 + a];
   }
   for (int j = 0; j < vm->nvox; j++) {               /* :118-121 finalize */
     voxel_t* v = &vm->vox[j];
+    if (multiplicative) {                            /* :93-99: cov = (sum C^-1)^-1, mean = cov * sum C^-1 p */
+      double C[9], m[3] = {v->mean[0], v->mean[1], v->mean[2]};
+      if (inv3(v->cov, C)) memset(C, 0, sizeof(C));
+      memcpy(v->cov, C, sizeof(C));
+      for (int a = 0; a < 3; a++) v->mean[a] = C[a * 3] * m[0] + C[a * 3 + 1] * m[1] + C[a * 3 + 2] * m[2];
+      continue;
+    }
     for (int a = 0; a < 3; a++) v->mean[a] /= v->num;
     for (int a = 0; a < 9; a++) v->cov[a] /= v->num;
   }
@@ -570,15 +649,17 @@ int orc_reg_prepare(orc_reg* r) {
   if (r->n_src < k || r->n_tgt < k) return -2;
   if (!r->src_cov) {
     r->src_cov = (double*)malloc(sizeof(double) * 9 * (size_t)r->n_src);
-    int rc = orc_covariances(r->src, r->n_src, 3, k, r->src_cov, NULL, r->prm.num_threads);
+    int rc = r->prm.regularization == ORC_REG_PLANE ? orc_covariances(r->src, r->n_src, 3, k, r->src_cov, NULL, r->prm.num_threads)
+                                                    : orc_covariances_m(r->src, r->n_src, 3, k, r->prm.regularization, r->src_cov, r->prm.num_threads);
     if (rc) return rc;
   }
   if (!r->tgt_cov) {
     r->tgt_cov = (double*)malloc(sizeof(double) * 9 * (size_t)r->n_tgt);
-    int rc = orc_covariances(r->tgt, r->n_tgt, 3, k, r->tgt_cov, NULL, r->prm.num_threads);
+    int rc = r->prm.regularization == ORC_REG_PLANE ? orc_covariances(r->tgt, r->n_tgt, 3, k, r->tgt_cov, NULL, r->prm.num_threads)
+                                                    : orc_covariances_m(r->tgt, r->n_tgt, 3, k, r->prm.regularization, r->tgt_cov, r->prm.num_threads);
     if (rc) return rc;
   }
-  if (!r->vm) r->vm = orc_voxelmap_create(r->tgt, r->n_tgt, 3, r->tgt_cov, r->prm.voxel_res);
+  if (!r->vm) r->vm = orc_voxelmap_create_m(r->tgt, r->n_tgt, 3, r->tgt_cov, r->prm.voxel_res, r->prm.voxel_mode == ORC_VOXEL_MULTIPLICATIVE);
   return 0;
 }
 
@@ -604,7 +685,7 @@ static int neighbor_offsets(int method, int off[27][3]) {
   return 27;
 }
 
-static int inv3(const double A[9], double B[9]) {
+static int inv3(const double A[9], double B[9]) {  /* Eigen's Matrix3d::inverse(): cofactors over the determinant */
   double c00 = A[4] * A[8] - A[5] * A[7];
   double c01 = A[5] * A[6] - A[3] * A[8];
   double c02 = A[3] * A[7] - A[4] * A[6];

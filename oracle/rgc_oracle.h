@@ -36,7 +36,11 @@ typedef struct {
   int    k_correspondences;     /* fast_gicp_impl.hpp:16      (20)                   */
   int    neighbor_method;       /* fast_vgicp_impl.hpp:23     (ORC_DIRECT1)          */
   int    num_threads;           /* RGC_odometer.cpp:1006      (14; 0 = omp max)      */
+  int    regularization;        /* fast_gicp_impl.hpp:20      (ORC_REG_PLANE); enum order = gicp_settings.hpp:6  */
+  int    voxel_mode;            /* fast_vgicp_impl.hpp:24     (ORC_VOXEL_ADDITIVE); enum order = gicp_settings.hpp:10 */
 } orc_params;
+enum { ORC_REG_NONE = 0, ORC_REG_MIN_EIG = 1, ORC_REG_NORMALIZED_MIN_EIG = 2, ORC_REG_PLANE = 3, ORC_REG_FROBENIUS = 4 };
+enum { ORC_VOXEL_ADDITIVE = 0, ORC_VOXEL_ADDITIVE_WEIGHTED = 1, ORC_VOXEL_MULTIPLICATIVE = 2 };
 
 void orc_default_params(orc_params* p);
 
@@ -47,6 +51,10 @@ int orc_knn(const float* pts, int n, int stride, int k, int* idx_out, float* d2_
 /* cov9_out: n*9 doubles row-major 3x3 (the block<3,3>(0,0) of the reference's Matrix4d);
  * normal_out: n*3 unit eigenvector of the least eigenvalue (may be NULL). */
 int orc_covariances(const float* pts, int n, int stride, int k, double* cov9_out, double* normal_out, int num_threads);
+/* the same under any RegularizationMethod (fast_gicp_impl.hpp:262-293); orc_regularize: one neighbourhood's sample covariance S (row-major
+ * 3x3) -> the regularised covariance */
+int orc_covariances_m(const float* pts, int n, int stride, int k, int method, double* cov9_out, int num_threads);
+void orc_regularize(const double S[9], int method, double cov9[9]);
 /* covariance of ONE neighbourhood given explicit indices (for known-answer tests) */
 void orc_cov_from_neighbors(const float* pts, int stride, const int* idx, int k, double cov9[9], double normal[3]);
 /* symmetric 3x3 eigen decomposition (cyclic Jacobi); evals descending, evecs columns row-major */
@@ -55,6 +63,8 @@ void orc_eig3(const double A[9], double evals[3], double evecs[9]);
 /* ---- C3: Gaussian voxel map (fast_vgicp_voxel.hpp:105-182) ---- */
 typedef struct orc_voxelmap orc_voxelmap;
 orc_voxelmap* orc_voxelmap_create(const float* pts, int n, int stride, const double* cov9, double res);
+/* multiplicative != 0: MultiplicativeGaussianVoxel (fast_vgicp_voxel.hpp:76-99) instead of AdditiveGaussianVoxel (:105-122) */
+orc_voxelmap* orc_voxelmap_create_m(const float* pts, int n, int stride, const double* cov9, double res, int multiplicative);
 void orc_voxelmap_free(orc_voxelmap*);
 int  orc_voxelmap_size(const orc_voxelmap*);
 /* dump sorted by (cx,cy,cz): coords 3V ints, num V ints, mean 3V doubles, cov 9V doubles */

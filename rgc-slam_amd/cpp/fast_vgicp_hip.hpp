@@ -11,10 +11,10 @@
 //   double score = vgicp.getFitnessScore();  auto T = vgicp.getFinalTransformation<Eigen::Matrix4f>();
 //
 // Errors: like the reference, the solver itself never throws ("lm not converged" is lmFailed(), hasConverged() as in PCL) and NO SETTER
-// throws: the reference's setters return void and accept anything.  A setter the library refuses (an invalid parameter, a regularisation
-// method or voxel accumulation mode this path does not implement) leaves its status in lastSetterStatus() / lastSetterError() and the
-// requested value selected, so that the NEXT call that would compute something -- setInputTarget / setInputSource / align -- fails instead
-// of running under another setting's name: those, like HIP failures, throw std::runtime_error carrying rgc_last_error().  No CPU fallback.
+// throws: the reference's setters return void and accept anything.  A setter the library refuses (an invalid parameter) leaves its status
+// in lastSetterStatus() / lastSetterError() and the requested value pending, so that the NEXT call that would compute something --
+// setInputTarget / setInputSource / align -- fails instead of running under other settings: those, like HIP failures, throw
+// std::runtime_error carrying rgc_last_error().  No CPU fallback.
 #pragma once
 #include <cmath>
 #include <cstddef>
@@ -55,9 +55,9 @@ public:
   void setInitialLambdaFactor(double f) { p_.lm_init_lambda_factor = f; push(); }  // lsq_registration_impl.hpp:32-34
   void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; push(); }    // fast_gicp_impl.hpp:41-43
   void setNeighborSearchMethod(NeighborSearchMethod m) { p_.neighbor_method = (int)m; push(); }
-  // the odometer leaves both at the constructor's values (PLANE, fast_gicp_impl.hpp:20; ADDITIVE, fast_vgicp_impl.hpp:24).  PLANE, ADDITIVE and
-  // ADDITIVE_WEIGHTED (the vendored FastVGICP's ADDITIVE: fast_vgicp_voxel.hpp:137-141) are implemented; any other value is remembered by the
-  // context and refused by the next call that would compute something (rgc_set_regularization_method in rgc_hip.h)
+  // the odometer leaves both at the constructor's values (PLANE, fast_gicp_impl.hpp:20; ADDITIVE, fast_vgicp_impl.hpp:24), which run on the
+  // tuned kernels; every other value is implemented on the library's general route (rgc_set_regularization_method in rgc_hip.h: a 3x3 per
+  // point, unoptimised).  Select before setInputTarget / setInputSource: a change drops the clouds that were set under the other setting.
   void setRegularizationMethod(RegularizationMethod m) { note(rgc_set_regularization_method(ctx_, (int)m)); }
   void setVoxelAccumulationMode(VoxelAccumulationMode m) { note(rgc_set_voxel_accumulation_mode(ctx_, (int)m)); }
   int lastSetterStatus() const { return setter_status_; }                 // RGC_OK, or why the last refused setter was refused

@@ -32,7 +32,8 @@ constexpr int kMaxK = 32;
 // system-scope one -- the L2s written back so that the HOST may read what came before; nobody's host does behind these).
 constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 // Build-time switches (RGC_EXTRA_FLAGS=-D...): alternative routes to the SAME results, kept for A/B measurements.  A caller's
-// process reads RGC_LM_IMPL, RGC_SPEC_GRID, RGC_KNN_SEEDS, RGC_KNN_CACHE (a context's initial rgc_set_knn_reuse mode), RGC_TRACE_ALLOC, RGC_TRACE_CACHE and the
+// process reads RGC_LM_IMPL, RGC_SPEC_GRID, RGC_KNN_SEEDS, RGC_KNN_CACHE (a context's initial rgc_set_knn_reuse mode), RGC_TRACE_ALLOC, RGC_TRACE_CACHE,
+// RGC_FORCE_GENERAL (the odometer's settings on the general covariance route: a cross-check) and the
 // three scheduling switches RGC_JOIN_SPIN_US / RGC_PREP_EVENT_EXT / RGC_COOP_STREAM from the environment, once, in rgc_create.
 #ifndef RGC_LM_POST
 #define RGC_LM_POST 1          // 0: rgc_align_end always waits for the stream and its copy of the state (round 2)
@@ -99,6 +100,8 @@ struct Cloud {
   bool ready = false;  // grid + normals (+ voxels for the target) enqueued
   bool covs_user = false;  // the normals were given by the caller (rgc_set_source/target_covariances), not computed from the neighbours
   DevBuf in_copy, cell_of, slot_of, cnt, start, block_sums, order_tmp, P, nx, ny, nz;  // P: sorted float4 {x,y,z,orig idx}
+  DevBuf c6;            // the general covariance route only (general_route()): six doubles per point, SoA, instead of the normal
+  bool general = false; // this cloud was prepared on the general route (its covariances are in c6, nx / ny / nz hold nothing)
   DevBuf segs;  // deferred-query list of the bulk kNN kernel: [count, pad x15][query n][bound n]
   int deferred_seen = -1;  // deferred count of the last cloud whose count came home (sizes the next cooperative launch)
   rgck::Grid grid{};   // the search grid: sorted array P, start[]; for the target also the voxel grid cell_voxel[] is laid out on
@@ -208,6 +211,7 @@ struct rgc_ctx {
   hipStream_t lm_tail_stream = nullptr;  // ... that stream: a solve enqueued on the OTHER stream waits for lm_tail first
   bool post_on = RGC_LM_POST != 0; // (build flag) 0: always wait for the stream and its copy, as in round 2
   struct { bool active = false; bool want_fitness = false; float guess[16]; } pend;  // rgc_align_begin .. rgc_align_end
+  struct { bool on = false; int rc = 0; float T[16]; double H[36]; double fitness = 0; int iterations = 0, converged = 0, lm_failed = 0; bool has_fit = false; } gen_res;  // general route: rgc_align_begin solves at once, rgc_align_end hands this over
   int lm_last_outer = 0;      // outer iterations of the previous solve: sizes the next blind batch
   bool small_copy_always = RGC_SMALL_COPY != 0;  // (build flag) 1: the 32-byte copy in front of every preparation, as before
   bool small_clean[2] = {false, false};  // d_small block of the map / the scan holds its initial image (the last solve's first step restored it)
@@ -221,6 +225,7 @@ struct rgc_ctx {
   bool cache_on = RGC_KNN_CACHE != 0;  // (build flag; RGC_KNN_CACHE=0 in the environment) the neighbour lists of an unchanged map on top of the seeds
   bool seeds_on = RGC_KNN_SEEDS != 0;  // (build flag; RGC_KNN_SEEDS=0 in the environment) 0: every search of a re-framed map starts without a bound, as before round 5
   int reg_method = RGC_REG_PLANE, voxel_mode = RGC_VOXEL_ADDITIVE;  // as selected by the caller, implemented or not (rgc_set_regularization_method)
+  bool force_general = false;          // RGC_FORCE_GENERAL=1 in the environment (rgc_create): PLANE / ADDITIVE on the general route too (a test's cross-check of the two routes)
   bool cache_dropped = false;          // the lists' buffers did not fit on the device: the context went down to the seeds by itself (rgc_get_knn_reuse)
   bool trace_cache = false;            // RGC_TRACE_CACHE in the environment (rgc_create): rgc_get_stats reports the lists' state on stderr
   double src_res = RGC_SRC_RES;  // (build flag) fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
@@ -294,14 +299,13 @@ int fail(rgc_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
-// a setting of the reference's interface that this path does not implement is selected: nothing is computed under another method's name
-int check_supported(rgc_ctx* c) {
-  if (c->reg_method != RGC_REG_PLANE)
-    return fail(c, RGC_ERR_UNSUPPORTED, "RegularizationMethod %d is selected; only PLANE (3) is implemented (rgc_set_regularization_method)", c->reg_method);
-  if (c->voxel_mode != RGC_VOXEL_ADDITIVE && c->voxel_mode != RGC_VOXEL_ADDITIVE_WEIGHTED)
-    return fail(c, RGC_ERR_UNSUPPORTED, "VoxelAccumulationMode %d is selected; only ADDITIVE (0) and ADDITIVE_WEIGHTED (1) are implemented (rgc_set_voxel_accumulation_mode)", c->voxel_mode);
-  return RGC_OK;
-}
+// The odometer's settings (PLANE, ADDITIVE: fast_gicp_impl.hpp:20, fast_vgicp_impl.hpp:24) run on the tuned kernels, which keep a point's
+// covariance as the unit normal of I - 0.999 n n^T.  Every other RegularizationMethod, and VoxelAccumulationMode::MULTIPLICATIVE, runs on
+// the GENERAL route: every point through the cooperative search with a regularised 3x3 per point (rgck::knn_cov6), a plain voxel pass, and
+// the host-driven LM loop over a linearisation that takes the full source covariance.  Unoptimised; the same entry points, the same results
+// as the reference's arithmetic for those settings (fast_gicp_impl.hpp:262-293, fast_vgicp_voxel.hpp:76-99).
+bool general_route(const rgc_ctx* c) { return c->force_general || c->reg_method != RGC_REG_PLANE || c->voxel_mode == RGC_VOXEL_MULTIPLICATIVE; }
+int check_supported(rgc_ctx*) { return RGC_OK; }   // (every value of both enums is implemented since round 6)
 
 #define HIPCHK(c, expr)                                                                                    \
   do {                                                                                                     \
@@ -340,7 +344,7 @@ void release(DevBuf& b) {
 void release_cloud(Cloud& cl) {
   for (DevBuf* b : {&cl.in_copy, &cl.cell_of, &cl.slot_of, &cl.cnt, &cl.start, &cl.block_sums, &cl.order_tmp, &cl.P, &cl.nx, &cl.ny, &cl.nz, &cl.segs,
                     &cl.cell_voxel, &cl.vox, &cl.vox_cell, &cl.need, &cl.qlist, &cl.cell_list, &cl.seed, &cl.nbr, &cl.rank_of, &cl.pos_of, &cl.qrank,
-                    &cl.map_copy, &cl.todo, &cl.cache_small})
+                    &cl.map_copy, &cl.todo, &cl.cache_small, &cl.c6})
     release(*b);
 }
 
@@ -518,7 +522,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     // Seeds of the exact search: a re-framed map is the point set of cl.rf.src moved rigidly, so what the last search of that buffer found
     // bounds this one (rgck::KnnSeeds; exactness does not depend on it).  Any other target: no seeds.
     cl.seed_on = false;
-    if (is_target && &cl == &c->tgt && cl.reframe_pending && c->seeds_on && rgck::knn_seeds_apply(n, c->prm.k_correspondences)) {
+    if (is_target && &cl == &c->tgt && cl.reframe_pending && c->seeds_on && !general_route(c) && rgck::knn_seeds_apply(n, c->prm.k_correspondences)) {
       int rc;
       if (cl.seed_key != (const void*)cl.rf.src || cl.seed_n != n || !cl.seed.p) {
         if ((rc = ensure(c, cl.seed, sizeof(float) * (size_t)n))) return rc;
@@ -700,7 +704,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
                       (float4*)cl.P.p, (int*)cl.segs.p, hi, with_cache ? &sd.cache : nullptr);
   }
   cl.lazy = 0;
-  if (is_target && &cl == &c->tgt && c->lazy_margin > 0 && !c->lm_host && map_wide_r_of(c, cl) == 0) {
+  if (is_target && &cl == &c->tgt && c->lazy_margin > 0 && !c->lm_host && !general_route(c) && map_wide_r_of(c, cl) == 0) {
     // lazy target: which part of the map needs covariances and voxels is decided by the solve's guess (rgc_align_begin: lazy_build);
     // any other consumer completes the map first (validate_clouds)
     int rc;
@@ -758,6 +762,28 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
   const int n = cl.n, k = c->prm.k_correspondences;
   hipStream_t s = is_target ? c->stream : c->stream2;
   int* dsm = c->d_small + (is_target ? 0 : 16);
+  cl.general = general_route(c);
+  if (cl.general) {  // the general covariance route (general_route above): every point through the cooperative search, a 3x3 per point
+    int rc;
+    if ((rc = ensure(c, cl.c6, sizeof(double) * 6 * (size_t)n))) return rc;
+    const int* guard = cl.spec_used ? dsm + 6 : nullptr;
+    {
+      ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n, s);
+      rgck::knn_cov6(s, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, c->reg_method, (double*)cl.c6.p, guard);
+    }
+    if (is_target) {
+      const size_t vmax = (size_t)(n < cl.grid.ncell ? n : cl.grid.ncell);
+      if ((rc = ensure(c, cl.vox, sizeof(double) * rgck::kVoxRec * vmax))) return rc;
+      if ((rc = ensure(c, cl.vox_cell, sizeof(int) * vmax))) return rc;
+      ProfScope ps(c, RGC_K_VOXEL, n);
+      rgck::voxel_build_general(s, (const float4*)cl.P.p, (const double*)cl.c6.p, (const int*)cl.start.p, cl.grid, n, (const int*)cl.cell_voxel.p,
+                                (double*)cl.vox.p, (int*)cl.vox_cell.p, c->voxel_mode == RGC_VOXEL_MULTIPLICATIVE ? 1 : 0, guard);
+      cl.nvox = -1;
+      cl.cache_searched_lists = false;
+    }
+    // (the deferred-list counter is zeroed by the grid build and stays zero: no query is deferred on this route)
+    return RGC_OK;
+  }
   bool stream_coop = false;
   {
     // a sparse map (points per cell of its grid below map_wide_density): the wider block, see k_knn_sp_wide
@@ -1038,7 +1064,7 @@ int check_target_owner(rgc_ctx* c) {
   if (!alive) {  // its device buffers are gone with it
     c->tgt_owner = nullptr;
     for (DevBuf* b : {&c->tgt.in_copy, &c->tgt.cell_of, &c->tgt.slot_of, &c->tgt.cnt, &c->tgt.start, &c->tgt.block_sums, &c->tgt.order_tmp, &c->tgt.P,
-                      &c->tgt.nx, &c->tgt.ny, &c->tgt.nz, &c->tgt.segs, &c->tgt.cell_voxel, &c->tgt.vox, &c->tgt.vox_cell})
+                      &c->tgt.nx, &c->tgt.ny, &c->tgt.nz, &c->tgt.segs, &c->tgt.cell_voxel, &c->tgt.vox, &c->tgt.vox_cell, &c->tgt.c6})
       release(*b);
     c->tgt.ready = false;
     c->tgt.n = 0;
@@ -1087,6 +1113,11 @@ int do_linearize(rgc_ctx* c, const double T[16], double* H, double* b, double* c
   const int want = (H && b) ? 1 : 0;
   {
     ProfScope ps(c, RGC_K_LINEARIZE, n);
+    if (c->src.general)
+      rgck::linearize_general(c->stream, (const float4*)c->src.P.p, (const double*)c->src.c6.p, n, pose_from(T), c->tgt.grid, (const int*)c->tgt.cell_voxel.p,
+                              (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p, want, (double*)c->partials.p,
+                              (int*)c->ipartials.p, c->d_out, c->d_small + 8);
+    else
     rgck::linearize(c->stream, (const float4*)c->src.P.p,
                     (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n, pose_from(T), c->tgt.grid,
                     (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p, want,
@@ -1133,6 +1164,11 @@ int do_linearize_try(rgc_ctx* c, const double x0[16], double lambda, double H[36
   in.init_factor = c->prm.lm_init_lambda_factor;
   {
     ProfScope ps(c, RGC_K_LINEARIZE, n);
+    if (c->src.general)
+      rgck::linearize_general(c->stream, (const float4*)c->src.P.p, (const double*)c->src.c6.p, n, pose_from(x0), c->tgt.grid, (const int*)c->tgt.cell_voxel.p,
+                              (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p, (double*)c->corr_M.p, 1, (double*)c->partials.p,
+                              (int*)c->ipartials.p, c->d_out, c->d_small + 8);
+    else
     rgck::linearize(c->stream, (const float4*)c->src.P.p, (const double*)c->src.nx.p, (const double*)c->src.ny.p, (const double*)c->src.nz.p, n,
                     pose_from(x0), c->tgt.grid, (const int*)c->tgt.cell_voxel.p, (const double*)c->tgt.vox.p, noff, (int*)c->corr_v.p,
                     (double*)c->corr_M.p, 1, (double*)c->partials.p, (int*)c->ipartials.p, c->d_out, c->d_small + 8);
@@ -1516,6 +1552,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   if (const char* e = getenv("RGC_KNN_CACHE")) c->cache_on = atoi(e) != 0;
   if (!c->seeds_on) c->cache_on = false;  // (the lists sit on top of the seeds)
   c->trace_cache = getenv("RGC_TRACE_CACHE") != nullptr;
+  if (const char* e = getenv("RGC_FORCE_GENERAL")) c->force_general = atoi(e) != 0;
   if (const char* e = getenv("RGC_JOIN_SPIN_US")) c->join_spin_us = atoi(e);
   if (const char* e = getenv("RGC_PREP_EVENT_EXT")) c->prep_event_ext = atoi(e) != 0;
   if (const char* e = getenv("RGC_COOP_STREAM")) c->coop_stream_on = atoi(e) != 0;
@@ -1622,9 +1659,10 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
   const Cloud& o = owner->tgt;
   release_cloud(d);
   DevBuf* db[] = {&d.in_copy, &d.cell_of, &d.slot_of, &d.cnt, &d.start, &d.block_sums, &d.order_tmp, &d.P, &d.nx, &d.ny, &d.nz, &d.segs,
-                  &d.cell_voxel, &d.vox, &d.vox_cell};
+                  &d.cell_voxel, &d.vox, &d.vox_cell, &d.c6};
   const DevBuf* ob[] = {&o.in_copy, &o.cell_of, &o.slot_of, &o.cnt, &o.start, &o.block_sums, &o.order_tmp, &o.P, &o.nx, &o.ny, &o.nz, &o.segs,
-                        &o.cell_voxel, &o.vox, &o.vox_cell};
+                        &o.cell_voxel, &o.vox, &o.vox_cell, &o.c6};
+  d.general = o.general;
   for (size_t k = 0; k < sizeof(db) / sizeof(db[0]); k++) { db[k]->p = ob[k]->p; db[k]->cap = ob[k]->cap; db[k]->borrowed = ob[k]->p != nullptr; }
   d.in = o.in; d.stride_f = o.stride_f; d.n = o.n; d.grid = o.grid; d.grid = o.grid; d.nvox = o.nvox; d.deferred_seen = o.deferred_seen;
   d.spec_ok = false; d.spec_used = false; d.cnt_clean = 0; d.cnt_seen = nullptr; d.lazy = 0;
@@ -1658,15 +1696,24 @@ int rgc_set_target_lazy(rgc_ctx* c, int margin_cells) {
 int rgc_set_regularization_method(rgc_ctx* c, int method) {
   if (!c) return RGC_ERR_INVALID;
   if (method < RGC_REG_NONE || method > RGC_REG_FROBENIUS) return fail(c, RGC_ERR_INVALID, "rgc_set_regularization_method: %d is not a RegularizationMethod", method);
+  if (method != c->reg_method) {  // the covariances of the clouds set so far were computed under the other method (the reference computes them at align())
+    if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+    c->src.ready = c->tgt.ready = false; c->corr_valid = false; c->deferred_known = false; c->map_bound = false;
+  }
   c->reg_method = method;
-  return check_supported(c);
+  return RGC_OK;
 }
 
 int rgc_set_voxel_accumulation_mode(rgc_ctx* c, int mode) {
   if (!c) return RGC_ERR_INVALID;
   if (mode < RGC_VOXEL_ADDITIVE || mode > RGC_VOXEL_MULTIPLICATIVE) return fail(c, RGC_ERR_INVALID, "rgc_set_voxel_accumulation_mode: %d is not a VoxelAccumulationMode", mode);
+  const bool was = c->voxel_mode == RGC_VOXEL_MULTIPLICATIVE, is = mode == RGC_VOXEL_MULTIPLICATIVE;
+  if (was != is) {  // (ADDITIVE <-> ADDITIVE_WEIGHTED changes nothing: one voxel class in the vendored FastVGICP, fast_vgicp_voxel.hpp:137-141)
+    if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+    c->src.ready = c->tgt.ready = false; c->corr_valid = false; c->deferred_known = false; c->map_bound = false;
+  }
   c->voxel_mode = mode;
-  return check_supported(c);
+  return RGC_OK;
 }
 
 int rgc_set_knn_reuse(rgc_ctx* c, int mode) {
@@ -1799,6 +1846,15 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
 // rgc_align_end waits for it (and enqueues further batches if the solve needs more than six outer iterations).
 int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   if (!c || !guess) return RGC_ERR_INVALID;
+  if (general_route(c)) {  // no asynchronous form on the general route: the solve runs now, rgc_align_end hands its result over
+    auto& g = c->gen_res;
+    g.on = false;
+    g.rc = rgc_align(c, guess, g.T, g.H, want_fitness ? &g.fitness : nullptr, &g.iterations, &g.converged, &g.lm_failed);
+    if (g.rc) return g.rc;
+    g.has_fit = want_fitness != 0;
+    g.on = true;
+    return RGC_OK;
+  }
   if (c->lm_host) return fail(c, RGC_ERR_INVALID, "the host-driven LM loop (RGC_LM_IMPL=host) has no asynchronous form");
   HIPCHK(c, hipSetDevice(c->device));
   c->pend.active = false;
@@ -1876,6 +1932,17 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
 
 int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fitness, int* iterations, int* converged, int* lm_failed) {
   if (!c) return RGC_ERR_INVALID;
+  if (c->gen_res.on) {  // general route: solved in rgc_align_begin
+    auto& g = c->gen_res;
+    g.on = false;
+    if (final_T) memcpy(final_T, g.T, sizeof(g.T));
+    if (final_H) memcpy(final_H, g.H, sizeof(g.H));
+    if (iterations) *iterations = g.iterations;
+    if (converged) *converged = g.converged;
+    if (lm_failed) *lm_failed = g.lm_failed;
+    if (fitness) { if (g.has_fit) *fitness = g.fitness; else return do_fitness(c, g.T, fitness); }
+    return RGC_OK;
+  }
   if (!c->pend.active) return fail(c, RGC_ERR_INVALID, "rgc_align_end without rgc_align_begin");
   HIPCHK(c, hipSetDevice(c->device));
   c->pend.active = false;
@@ -1988,10 +2055,11 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
 int rgc_align(rgc_ctx* c, const float guess[16], float final_T[16], double final_H[36], double* fitness, int* iterations,
               int* converged, int* lm_failed) {
   if (!c || !guess) return RGC_ERR_INVALID;
-  if (!c->lm_host) {
+  if (!c->lm_host && !general_route(c)) {
     const int rc0 = rgc_align_begin(c, guess, fitness != nullptr);
     return rc0 ? rc0 : rgc_align_end(c, final_T, final_H, fitness, iterations, converged, lm_failed);
   }
+  // (the general covariance route solves here as well: the device-chained driver's step kernel takes the source's NORMAL)
   // ---- RGC_LM_IMPL=host: the loop on the host over the public fine-seam kernels (cross-check of the device-chained driver) ----
   HIPCHK(c, hipSetDevice(c->device));
   int rc = need_inputs(c, /*validate=*/true);
@@ -2106,6 +2174,15 @@ static int get_covs(rgc_ctx* c, Cloud& cl, double* cov9, double* normals) {
   if (!cl.ready) return fail(c, RGC_ERR_NO_INPUT, "cloud not set");
   const int n = cl.n;
   if ((rc = join_source(c))) return rc;
+  if (cl.general) {  // the general route keeps a 3x3 per point, no normal
+    if (normals) return fail(c, RGC_ERR_UNSUPPORTED, "normals exist only under RegularizationMethod PLANE with an additive voxel mode");
+    if (!cov9) return RGC_OK;
+    if ((rc = ensure(c, c->scratch, sizeof(double) * 9 * (size_t)n))) return rc;
+    rgck::unsort6(c->stream, (const double*)cl.c6.p, (const float4*)cl.P.p, n, (double*)c->scratch.p);
+    HIPCHK(c, hipMemcpyAsync(cov9, c->scratch.p, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RGC_OK;
+  }
   if ((rc = ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n))) return rc;
   rgck::unsort3(c->stream, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const float4*)cl.P.p, n, (double*)c->scratch.p);
   std::vector<double> tmp;
@@ -2140,6 +2217,22 @@ static int set_covs(rgc_ctx* c, Cloud& cl, bool is_target, const double* cov9, i
   if (!cl.ready) return fail(c, RGC_ERR_NO_INPUT, "cloud not set");
   if (is_target && c->tgt_owner) return fail(c, RGC_ERR_INVALID, "the target is borrowed (rgc_share_target): its covariances belong to the owner");
   if (n != cl.n) return fail(c, RGC_ERR_INVALID, "%d covariances for a cloud of %d points", n, cl.n);
+  if (cl.general) {  // the general route takes any symmetric 3x3 as it comes (fast_gicp_impl.hpp:93-100 does not look at them either)
+    if ((rc = join_source(c))) return rc;
+    if ((rc = ensure(c, c->scratch, sizeof(double) * 9 * (size_t)n))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->scratch.p, cov9, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    rgck::sort6(c->stream, (const double*)c->scratch.p, (const float4*)cl.P.p, n, (double*)cl.c6.p);
+    if (is_target) {
+      rgck::voxel_build_general(c->stream, (const float4*)cl.P.p, (const double*)cl.c6.p, (const int*)cl.start.p, cl.grid, n, (const int*)cl.cell_voxel.p,
+                                (double*)cl.vox.p, (int*)cl.vox_cell.p, c->voxel_mode == RGC_VOXEL_MULTIPLICATIVE ? 1 : 0, nullptr);
+      c->tgt_generation++;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (the caller's array is read until here)
+    HIPCHK(c, hipGetLastError());
+    c->corr_valid = false;
+    cl.covs_user = true;
+    return RGC_OK;
+  }
   std::vector<double> nrm((size_t)n * 3);
   for (int i = 0; i < n; i++) {
     const double* C9 = cov9 + (size_t)i * 9;
@@ -2211,7 +2304,9 @@ int rgc_swap_source_and_target(rgc_ctx* c) {
     for (int a = 0; a < 2; a++) {
       if (!from[a]->covs_user) continue;
       kept[a].on = true;
-      if (hipMalloc(&kept[a].p, sizeof(double) * 3 * (size_t)from[a]->n) != hipSuccess) { drop_kept(); return fail(c, RGC_ERR_HIP, "hipMalloc failed (swap)"); }
+      if (hipMalloc(&kept[a].p, sizeof(double) * (from[a]->general ? 9 : 3) * (size_t)from[a]->n) != hipSuccess) { drop_kept(); return fail(c, RGC_ERR_HIP, "hipMalloc failed (swap)"); }
+      if (from[a]->general) rgck::unsort6(c->stream, (const double*)from[a]->c6.p, (const float4*)from[a]->P.p, from[a]->n, (double*)kept[a].p);
+      else
       rgck::unsort3(c->stream, (const double*)from[a]->nx.p, (const double*)from[a]->ny.p, (const double*)from[a]->nz.p, (const float4*)from[a]->P.p,
                     from[a]->n, (double*)kept[a].p);
     }
@@ -2229,14 +2324,21 @@ int rgc_swap_source_and_target(rgc_ctx* c) {
     hipError_t e = hipStreamSynchronize(c->stream2);
     if (e == hipSuccess && kept[0].on) {  // the old source's covariances on the new target: normals, then its voxel map from them
       Cloud& cl = c->tgt;
+      if (cl.general) {
+        rgck::sort6(c->stream, (const double*)kept[0].p, (const float4*)cl.P.p, cl.n, (double*)cl.c6.p);
+        rgck::voxel_build_general(c->stream, (const float4*)cl.P.p, (const double*)cl.c6.p, (const int*)cl.start.p, cl.grid, cl.n, (const int*)cl.cell_voxel.p,
+                                  (double*)cl.vox.p, (int*)cl.vox_cell.p, c->voxel_mode == RGC_VOXEL_MULTIPLICATIVE ? 1 : 0, nullptr);
+      } else {
       rgck::sort3(c->stream, (const double*)kept[0].p, (const float4*)cl.P.p, cl.n, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
       rgck::voxel_build(c->stream, (const float4*)cl.P.p, (const double*)cl.nx.p, (const double*)cl.ny.p, (const double*)cl.nz.p, (const int*)cl.start.p,
                         cl.grid, cl.n, (const int*)cl.cell_voxel.p, (double*)cl.vox.p, (int*)cl.vox_cell.p);
+      }
       cl.covs_user = true;
     }
     if (e == hipSuccess && kept[1].on) {
       Cloud& cl = c->src;
-      rgck::sort3(c->stream, (const double*)kept[1].p, (const float4*)cl.P.p, cl.n, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
+      if (cl.general) rgck::sort6(c->stream, (const double*)kept[1].p, (const float4*)cl.P.p, cl.n, (double*)cl.c6.p);
+      else rgck::sort3(c->stream, (const double*)kept[1].p, (const float4*)cl.P.p, cl.n, (double*)cl.nx.p, (double*)cl.ny.p, (double*)cl.nz.p);
       cl.covs_user = true;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -2441,7 +2543,7 @@ int rgc_align_end_reframe(rgc_ctx* c, rgc_ctx* next, double Tw[16], const float*
     if (!ctx_alive(next)) return fail(c, RGC_ERR_INVALID, "rgc_align_end_reframe: the next context is not alive");
     if (next->pend.active) return fail(c, RGC_ERR_INVALID, "rgc_align_end_reframe: a solve is in flight on the next context");
   }
-  if (!c->pend.active) return fail(c, RGC_ERR_INVALID, "rgc_align_end without rgc_align_begin");
+  if (!c->pend.active && !c->gen_res.on) return fail(c, RGC_ERR_INVALID, "rgc_align_end without rgc_align_begin");
   {
     const int rc0 = reframe_args_ok(next, d_map, n, stride_bytes, d_scratch);
     if (rc0) { if (next != c) fail(c, rc0, "rgc_align_end_reframe: %s", next->err); return rc0; }

@@ -159,6 +159,16 @@ void voxel_patch(hipStream_t s, const float4* P, const double* nx, const double*
 void linearize(hipStream_t s, const float4* P, const double* nx, const double* ny, const double* nz, int n, Pose T, Grid g,
                const int* cell_voxel, const double* vox, int noff, int* corr_v, double* corr_M, int want_H, double* partials,
                int* ncorr_partials, double* out28, int* out_ncorr);
+// ---- the general covariance route (rgc_set_regularization_method other than PLANE, VoxelAccumulationMode::MULTIPLICATIVE): every point
+// through the cooperative search, a regularised 3x3 per point (c6: six doubles, SoA c6[a * n + i], sorted order) instead of a unit normal;
+// unoptimised by design.  method = rgc_regularization_method; guard (nullable): a tripped speculative-grid guard makes the kernels stand still
+void knn_cov6(hipStream_t s, const float4* P, const int* start, Grid g, int n, int k, int method, double* c6, const int* guard);
+void voxel_build_general(hipStream_t s, const float4* P, const double* c6, const int* start, Grid g, int n, const int* cell_voxel, double* vox,
+                         int* vox_cell, int multiplicative, const int* guard);
+void linearize_general(hipStream_t s, const float4* P, const double* c6, int n, Pose T, Grid g, const int* cell_voxel, const double* vox, int noff,
+                       int* corr_v, double* corr_M, int want_H, double* partials, int* ncorr_partials, double* out28, int* out_ncorr);
+void unsort6(hipStream_t s, const double* c6, const float4* P, int n, double* out9);
+void sort6(hipStream_t s, const double* in9, const float4* P, int n, double* c6);
 void compute_error(hipStream_t s, const float4* P, int n, Pose T, const double* vox, int noff, const int* corr_v,
                    const double* corr_M, double* partials, double* out1);
 void lm_try(hipStream_t s, double* out, const int* ncorr, LmIn in);

@@ -2189,15 +2189,22 @@ __device__ __forceinline__ unsigned coop_kth(const float4* __restrict__ P, const
   return T;
 }
 
+// The GENERAL covariance route (rgc_set_regularization_method other than PLANE, VoxelAccumulationMode::MULTIPLICATIVE): every point's
+// neighbourhood through the cooperative search below, its regularised 3x3 (six doubles, SoA) instead of a unit normal.  Unoptimised by
+// design: the odometer never selects it (src/RGC_odometer.cpp:998-1006), it exists so that the reference's setters mean what they say.
+struct GenOut { double* c6; int method; int n; };
+template <int KC>
+__device__ __forceinline__ void cov6_of(const float4* __restrict__ P, const int (&idx)[KC], int k, int i, const GenOut& go);
+
 // One-wave workgroups: the launch runs beside other kernels of the frame (the map's bulk launch fills every CU), and a single wave is
 // admitted wherever one SIMD has a slot; the grid is sized by the caller from the previous cloud's deferred count (idle workgroups
 // still have to be dispatched: 2048 four-wave workgroups cost 0.25 ms of the scan's critical path when 200 queries were waiting).
 // (the body: wave `wave` of `nwaves` takes every nwaves-th entry of the deferred list; sh: this wave's LDS scratch)
 // one deferred entry (enc: the query, or ~query when radius 1 is known to be insufficient; thr: the k-th distance seen so far), one wave
-template <int KC, bool kTarget>
+template <int KC, bool kTarget, bool kGeneral = false>
 __device__ __forceinline__ void coop_one(const float4* __restrict__ P, const int* __restrict__ start, const Grid& g, int k, const Deferred& df,
                                          double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz, CoopRows* sh, int lane,
-                                         int e, int enc, float thr) {
+                                         int e, int enc, float thr, const GenOut& go = GenOut{nullptr, 0, 0}) {
   {
 #ifdef RGC_LAB
     const long long lab_t0 = wall_clock64();
@@ -2296,8 +2303,12 @@ __device__ __forceinline__ void coop_one(const float4* __restrict__ P, const int
       int idx[KC];
 #pragma unroll
       for (int j = 0; j < KC; j++) idx[j] = j < k ? sh->nb[j] : 0;
-      if (k == KC) sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz);
-      else sp_normal_of<KC, false>(P, idx, px, py, pz, k, i, nx, ny, nz);
+      if constexpr (kGeneral) {
+        cov6_of<KC>(P, idx, k, i, go);
+      } else {
+        if (k == KC) sp_normal_of<KC, true>(P, idx, px, py, pz, k, i, nx, ny, nz);
+        else sp_normal_of<KC, false>(P, idx, px, py, pz, k, i, nx, ny, nz);
+      }
       if (kTarget && df.seed) df.seed[__float_as_int(pq.w)] = thr;  // the k-th squared distance itself: where this point's next search starts (knn_point_seeded)
 #ifdef RGC_LAB
       if (!kTarget && e < 8192) { g_lab_wave[2 * e] = lab_t0 | ((long long)r << 56) | ((long long)lab_rounds << 48); g_lab_wave[2 * e + 1] = wall_clock64(); }
@@ -3916,6 +3927,199 @@ __device__ __forceinline__ void eig3_sym(const double S[6], double ev[3], double
       if (ev[ord[j]] > ev[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
 }
 
+// ---- the general covariance route (see GenOut above) ----
+// fast_gicp_impl.hpp:256-293 for one point: mean and covariance of its k neighbours (fp64; neighbours in ascending position, the order every
+// route of this file sums in), then the selected regularisation.  JacobiSVD of a symmetric positive semi-definite matrix is its
+// eigen-decomposition (U = V), which is what is computed here; method = rgc_regularization_method (0 NONE, 1 MIN_EIG, 2 NORMALIZED_MIN_EIG,
+// 3 PLANE, 4 FROBENIUS).  c6 = {xx, xy, xz, yy, yz, zz}, SoA: c6[a * n + i].
+template <int KC>
+__device__ __forceinline__ void cov6_of(const float4* __restrict__ P, const int (&idx)[KC], int k, int i, const GenOut& go) {
+  double mx = 0.0, my = 0.0, mz = 0.0;
+  for (int j = 0; j < k; j++) { const float4 p = P[idx[j]]; mx += (double)p.x; my += (double)p.y; mz += (double)p.z; }
+  mx /= (double)k; my /= (double)k; mz /= (double)k;                         // neighbors.rowwise().mean(), :261
+  double S[6] = {0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < k; j++) {
+    const float4 p = P[idx[j]];
+    const double x = (double)p.x - mx, y = (double)p.y - my, z = (double)p.z - mz;
+    S[0] += x * x; S[1] += x * y; S[2] += x * z; S[3] += y * y; S[4] += y * z; S[5] += z * z;
+  }
+  for (int a = 0; a < 6; a++) S[a] /= (double)k;                             // :262
+  double C[6];
+  if (go.method == 0) {                                                       // NONE, :264-265
+    for (int a = 0; a < 6; a++) C[a] = S[a];
+  } else if (go.method == 4) {                                                // FROBENIUS, :266-271: (C_inv / |C_inv|_F)^-1 = |C_inv|_F (S + lambda I)
+    const double R[6] = {S[0] + 1e-3, S[1], S[2], S[3] + 1e-3, S[4], S[5] + 1e-3};
+    double Ci[6];
+    if (!inv_sym3(R, Ci)) { for (int a = 0; a < 6; a++) Ci[a] = 0.0; }
+    const double nrm = sqrt(Ci[0] * Ci[0] + Ci[3] * Ci[3] + Ci[5] * Ci[5] + 2.0 * (Ci[1] * Ci[1] + Ci[2] * Ci[2] + Ci[4] * Ci[4]));
+    for (int a = 0; a < 6; a++) C[a] = nrm * R[a];
+  } else {
+    double ev[3], V[3][3];
+    int ord[3];
+    eig3_sym(S, ev, V, ord);                                                  // :273, singular values in descending order
+    double val[3];
+    const double smax = ev[ord[0]];
+    for (int r = 0; r < 3; r++) {
+      const double sv = ev[ord[r]];
+      if (go.method == 3) val[r] = r < 2 ? 1.0 : 1e-3;                        // PLANE, :280-282
+      else if (go.method == 1) val[r] = sv > 1e-3 ? sv : 1e-3;                // MIN_EIG, :283-285
+      else { const double t = sv / smax; val[r] = t > 1e-3 ? t : 1e-3; }      // NORMALIZED_MIN_EIG, :286-289
+    }
+    for (int a = 0; a < 6; a++) C[a] = 0.0;
+    for (int r = 0; r < 3; r++) {                                             // U diag(values) V^T, :293
+      const int c = ord[r];
+      const double v0 = V[0][c], v1 = V[1][c], v2 = V[2][c], w = val[r];
+      C[0] += w * v0 * v0; C[1] += w * v0 * v1; C[2] += w * v0 * v2; C[3] += w * v1 * v1; C[4] += w * v1 * v2; C[5] += w * v2 * v2;
+    }
+  }
+  for (int a = 0; a < 6; a++) go.c6[(size_t)a * go.n + i] = C[a];
+}
+
+// every point of a cloud through the cooperative search (a wave per query; wave w takes queries w, w + nwaves, ...)
+template <int KC>
+__global__ void __launch_bounds__(WAVE)
+k_knn_cov6(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, GenOut go, const int* __restrict__ guard) {
+  __shared__ CoopRows shm[1];
+  if (guard && *guard) return;
+  Deferred df{};
+  for (int e = (int)blockIdx.x; e < n; e += (int)gridDim.x)
+    coop_one<KC, false, true>(P, start, g, k, df, nullptr, nullptr, nullptr, &shm[0], (int)threadIdx.x, e, e, INFINITY, go);
+}
+
+// fast_vgicp_voxel.hpp:129-156 for the general route, one thread per grid cell, a voxel's points in ascending position (= the cloud's order
+// inside a cell): ADDITIVE (:105-122) mean = sum p / n, cov = sum C / n; MULTIPLICATIVE (:76-99) cov = (sum C^-1)^-1, mean = cov * sum C^-1 p.
+__global__ void __launch_bounds__(256)
+k_voxel_build_general(const float4* __restrict__ P, const double* __restrict__ c6, const int* __restrict__ start, int ncell, int n,
+                      const int* __restrict__ cell_voxel, double* __restrict__ vox, int* __restrict__ vox_cell, int multiplicative,
+                      const int* __restrict__ guard) {
+  if (guard && *guard) return;
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= ncell) return;
+  const int a = start[cell], b = start[cell + 1];
+  if (b <= a) return;
+  const int v = cell_voxel[cell];
+  double m[3] = {0, 0, 0}, A[6] = {0, 0, 0, 0, 0, 0};
+  for (int u = a; u < b; u++) {
+    const float4 p = P[u];
+    double C[6];
+    for (int t = 0; t < 6; t++) C[t] = c6[(size_t)t * n + u];
+    if (multiplicative) {
+      double Ci[6];
+      if (!inv_sym3(C, Ci)) { for (int t = 0; t < 6; t++) Ci[t] = 0.0; }
+      for (int t = 0; t < 6; t++) A[t] += Ci[t];
+      m[0] += Ci[0] * (double)p.x + Ci[1] * (double)p.y + Ci[2] * (double)p.z;
+      m[1] += Ci[1] * (double)p.x + Ci[3] * (double)p.y + Ci[4] * (double)p.z;
+      m[2] += Ci[2] * (double)p.x + Ci[4] * (double)p.y + Ci[5] * (double)p.z;
+    } else {
+      for (int t = 0; t < 6; t++) A[t] += C[t];
+      m[0] += (double)p.x; m[1] += (double)p.y; m[2] += (double)p.z;
+    }
+  }
+  const double num = (double)(b - a);
+  double* rec = vox + (size_t)v * kVoxRec;
+  if (multiplicative) {
+    double Cv[6];
+    if (!inv_sym3(A, Cv)) { for (int t = 0; t < 6; t++) Cv[t] = 0.0; }
+    rec[0] = Cv[0] * m[0] + Cv[1] * m[1] + Cv[2] * m[2];
+    rec[1] = Cv[1] * m[0] + Cv[3] * m[1] + Cv[4] * m[2];
+    rec[2] = Cv[2] * m[0] + Cv[4] * m[1] + Cv[5] * m[2];
+    for (int t = 0; t < 6; t++) rec[3 + t] = Cv[t];
+  } else {
+    for (int t = 0; t < 3; t++) rec[t] = m[t] / num;
+    for (int t = 0; t < 6; t++) rec[3 + t] = A[t] / num;
+  }
+  rec[9] = num;
+  vox_cell[v] = cell;
+}
+
+// FastVGICP::update_correspondences + linearize (fast_vgicp_impl.hpp:73-180) for sorted source point i with a GENERAL source covariance:
+// linearize_point_pre above with R C_A R^T computed from the six entries instead of from the normal
+__device__ __forceinline__ void linearize_point_general(const float4 pp, const double* __restrict__ c6, int i, int n, const Pose& T, const Grid& g,
+                                                        const int* __restrict__ cell_voxel, const double* __restrict__ vox, int noff,
+                                                        int* __restrict__ corr_v, double* __restrict__ corr_M, int want_H, double (&acc)[kAccum],
+                                                        int& ncorr) {
+  const double p0 = (double)pp.x, p1 = (double)pp.y, p2 = (double)pp.z;
+  const double q0 = T.R[0] * p0 + T.R[1] * p1 + T.R[2] * p2 + T.t[0];
+  const double q1 = T.R[3] * p0 + T.R[4] * p1 + T.R[5] * p2 + T.t[1];
+  const double q2 = T.R[6] * p0 + T.R[7] * p1 + T.R[8] * p2 + T.t[2];
+  const double Cs[3][3] = {{c6[i], c6[(size_t)n + i], c6[2 * (size_t)n + i]},
+                           {c6[(size_t)n + i], c6[3 * (size_t)n + i], c6[4 * (size_t)n + i]},
+                           {c6[2 * (size_t)n + i], c6[4 * (size_t)n + i], c6[5 * (size_t)n + i]}};
+  double RC[3][3], RCR[3][3];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) RC[a][b] = T.R[3 * a] * Cs[0][b] + T.R[3 * a + 1] * Cs[1][b] + T.R[3 * a + 2] * Cs[2][b];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) RCR[a][b] = RC[a][0] * T.R[3 * b] + RC[a][1] * T.R[3 * b + 1] + RC[a][2] * T.R[3 * b + 2];
+  const double CA[6] = {RCR[0][0], RCR[0][1], RCR[0][2], RCR[1][1], RCR[1][2], RCR[2][2]};
+  const int cx = (int)floor(q0 / g.res - 0.5) - g.minc[0];
+  const int cy = (int)floor(q1 / g.res - 0.5) - g.minc[1];
+  const int cz = (int)floor(q2 / g.res - 0.5) - g.minc[2];
+  for (int o = 0; o < noff; o++) {
+    int ox, oy, oz;
+    neighbor_offset(noff, o, ox, oy, oz);
+    const int x = cx + ox, y = cy + oy, z = cz + oz;
+    int v = -1;
+    if (x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) v = cell_voxel[cell_index(g, x, y, z)];
+    const size_t slot = (size_t)o * n + i;
+    corr_v[slot] = v;
+    if (v < 0) continue;
+    const double* rec = vox + (size_t)v * kVoxRec;
+    double S[6], M[6];
+    for (int a = 0; a < 6; a++) S[a] = rec[3 + a] + CA[a];
+    if (!inv_sym3(S, M)) { for (int a = 0; a < 6; a++) M[a] = 0.0; }
+    for (int a = 0; a < 6; a++) corr_M[((size_t)a * noff + o) * n + i] = M[a];
+    ncorr++;
+    const double e0 = rec[0] - q0, e1 = rec[1] - q1, e2 = rec[2] - q2;
+    const double w = sqrt(rec[9]);
+    const double Me0 = M[0] * e0 + M[1] * e1 + M[2] * e2;
+    const double Me1 = M[1] * e0 + M[3] * e1 + M[4] * e2;
+    const double Me2 = M[2] * e0 + M[4] * e1 + M[5] * e2;
+    acc[27] += w * (e0 * Me0 + e1 * Me1 + e2 * Me2);
+    if (!want_H) continue;
+    const double J[3][6] = {{0.0, -q2, q1, -1.0, 0.0, 0.0}, {q2, 0.0, -q0, 0.0, -1.0, 0.0}, {-q1, q0, 0.0, 0.0, 0.0, -1.0}};
+    double MJ[3][6];
+    for (int c = 0; c < 6; c++) {
+      MJ[0][c] = M[0] * J[0][c] + M[1] * J[1][c] + M[2] * J[2][c];
+      MJ[1][c] = M[1] * J[0][c] + M[3] * J[1][c] + M[4] * J[2][c];
+      MJ[2][c] = M[2] * J[0][c] + M[4] * J[1][c] + M[5] * J[2][c];
+    }
+    int u = 0;
+    for (int a = 0; a < 6; a++)
+      for (int c = a; c < 6; c++) { acc[u] += w * (J[0][a] * MJ[0][c] + J[1][a] * MJ[1][c] + J[2][a] * MJ[2][c]); u++; }
+    for (int a = 0; a < 6; a++) acc[21 + a] += w * (J[0][a] * Me0 + J[1][a] * Me1 + J[2][a] * Me2);
+  }
+}
+__global__ void __launch_bounds__(LIN_T)
+k_linearize_general(const float4* __restrict__ P, const double* __restrict__ c6, int n, Pose T, Grid g, const int* __restrict__ cell_voxel,
+                    const double* __restrict__ vox, int noff, int* __restrict__ corr_v, double* __restrict__ corr_M, int want_H,
+                    double* __restrict__ partials, int* __restrict__ ncorr_partials) {
+  const int i = blockIdx.x * LIN_T + threadIdx.x;
+  double acc[kAccum];
+#pragma unroll
+  for (int a = 0; a < kAccum; a++) acc[a] = 0.0;
+  int ncorr = 0;
+  if (i < n) linearize_point_general(P[i], c6, i, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, want_H, acc, ncorr);
+  block_reduce_store<kAccum>(acc, partials + (size_t)blockIdx.x * kAccum);
+  block_count_store(ncorr, ncorr_partials + blockIdx.x);
+}
+// caller order <-> sorted order for the six entries (getters / setters of the general route): out9 / in9 = n x 9 doubles, row-major 3x3
+__global__ void k_unsort6(const double* __restrict__ c6, const float4* __restrict__ P, int n, double* __restrict__ out9) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = __float_as_int(P[i].w);
+  double C[6];
+  for (int a = 0; a < 6; a++) C[a] = c6[(size_t)a * n + i];
+  double* d = out9 + (size_t)o * 9;
+  d[0] = C[0]; d[1] = C[1]; d[2] = C[2]; d[3] = C[1]; d[4] = C[3]; d[5] = C[4]; d[6] = C[2]; d[7] = C[4]; d[8] = C[5];
+}
+__global__ void k_sort6(const double* __restrict__ in9, const float4* __restrict__ P, int n, double* __restrict__ c6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* s9 = in9 + (size_t)__float_as_int(P[i].w) * 9;
+  c6[i] = s9[0]; c6[(size_t)n + i] = s9[1]; c6[2 * (size_t)n + i] = s9[2]; c6[3 * (size_t)n + i] = s9[4]; c6[4 * (size_t)n + i] = s9[5];
+  c6[5 * (size_t)n + i] = s9[8];
+}
+
 // least-squares solution of the 5x3 system A x = b: Householder QR with column pivoting (Eigen::ColPivHouseholderQR)
 __device__ void lstsq_5x3_colpiv(double A[5][3], double b[5], double x[3]) {
   int perm[3] = {0, 1, 2};
@@ -4361,6 +4565,29 @@ void linearize(hipStream_t s, const float4* P, const double* nx, const double* n
   const int nb = linearize_blocks(n);
   hipLaunchKernelGGL(k_linearize, dim3(nb), dim3(LIN_T), 0, s, P, nx, ny, nz, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, want_H, partials, ncorr_partials);
   hipLaunchKernelGGL(k_fold<kAccum>, dim3(kAccum + 1), dim3(WAVE), 0, s, partials, nb, out28, ncorr_partials, out_ncorr);
+}
+// ---- the general covariance route ----
+void knn_cov6(hipStream_t s, const float4* P, const int* start, Grid g, int n, int k, int method, double* c6, const int* guard) {
+  const GenOut go{c6, method, n};
+  const int waves = n < 16384 ? n : 16384;
+  if (k <= 20) hipLaunchKernelGGL(k_knn_cov6<20>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard);
+  else hipLaunchKernelGGL(k_knn_cov6<32>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard);
+}
+void voxel_build_general(hipStream_t s, const float4* P, const double* c6, const int* start, Grid g, int n, const int* cell_voxel, double* vox,
+                         int* vox_cell, int multiplicative, const int* guard) {
+  hipLaunchKernelGGL(k_voxel_build_general, dim3(nblk(g.ncell, 256)), dim3(256), 0, s, P, c6, start, g.ncell, n, cell_voxel, vox, vox_cell, multiplicative, guard);
+}
+void linearize_general(hipStream_t s, const float4* P, const double* c6, int n, Pose T, Grid g, const int* cell_voxel, const double* vox, int noff,
+                       int* corr_v, double* corr_M, int want_H, double* partials, int* ncorr_partials, double* out28, int* out_ncorr) {
+  const int nb = linearize_blocks(n);
+  hipLaunchKernelGGL(k_linearize_general, dim3(nb), dim3(LIN_T), 0, s, P, c6, n, T, g, cell_voxel, vox, noff, corr_v, corr_M, want_H, partials, ncorr_partials);
+  hipLaunchKernelGGL(k_fold<kAccum>, dim3(kAccum + 1), dim3(WAVE), 0, s, partials, nb, out28, ncorr_partials, out_ncorr);
+}
+void unsort6(hipStream_t s, const double* c6, const float4* P, int n, double* out9) {
+  hipLaunchKernelGGL(k_unsort6, dim3(nblk(n, 256)), dim3(256), 0, s, c6, P, n, out9);
+}
+void sort6(hipStream_t s, const double* in9, const float4* P, int n, double* c6) {
+  hipLaunchKernelGGL(k_sort6, dim3(nblk(n, 256)), dim3(256), 0, s, in9, P, n, c6);
 }
 void compute_error(hipStream_t s, const float4* P, int n, Pose T, const double* vox, int noff, const int* corr_v,
                    const double* corr_M, double* partials, double* out1) {

@@ -164,6 +164,17 @@ class FastVGICP:
         self._chk(self._L.rgc_set_target_lazy(self._h, int(margin_cells)))
 
     REUSE_NONE, REUSE_SEEDS, REUSE_LISTS = 0, 1, 2
+    REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = range(5)     # fast_gicp::RegularizationMethod, gicp_settings.hpp:6
+    VOXEL_ADDITIVE, VOXEL_ADDITIVE_WEIGHTED, VOXEL_MULTIPLICATIVE = range(3)               # VoxelAccumulationMode, gicp_settings.hpp:10
+
+    def setRegularizationMethod(self, method: int):
+        """FastGICP::setRegularizationMethod (fast_gicp_impl.hpp:46-48).  PLANE (the odometer's) runs on the tuned kernels, every other
+        method on the general route (rgc_hip.h).  Select BEFORE setting the clouds: a change drops them."""
+        self._chk(self._L.rgc_set_regularization_method(self._h, int(method)))
+
+    def setVoxelAccumulationMode(self, mode: int):
+        """FastVGICP::setVoxelAccumulationMode (fast_vgicp_impl.hpp:41-43); MULTIPLICATIVE runs on the general route"""
+        self._chk(self._L.rgc_set_voxel_accumulation_mode(self._h, int(mode)))
 
     def setNeighbourReuse(self, mode: int):
         """rgc_set_knn_reuse: what the context keeps between the targets setInputTargetReframed prepares -- REUSE_NONE (every target is

@@ -219,36 +219,101 @@ def test_cpp_frame_loop_equals_the_python_one(reg_mod):
     seq.close(); pv.close()
 
 
-def test_unimplemented_settings_are_refused_not_replaced(reg_mod):
-    """rgc_set_regularization_method / rgc_set_voxel_accumulation_mode: the reference's setters cannot fail; here an unimplemented value
-    returns RGC_ERR_UNSUPPORTED without throwing across the boundary and is remembered -- the context computes nothing until an
-    implemented value is selected (never PLANE's result under MIN_EIG's name).  ADDITIVE_WEIGHTED is ADDITIVE in the vendored FastVGICP
-    (fast_vgicp_voxel.hpp:137-141): accepted, same bits."""
-    import rgc_slam_amd.synth as synth
-    from rgc_slam_amd import _lib
-    world, tgt = synth.make_world_and_map(30000, seed=synth.SEED + 6)
-    src = synth.make_scan_n(world, synth.se3(synth.rot_zyx(0.01, 0.0, 0.0), [0.1, 0.0, 0.0]), 8000, seed=synth.SEED + 6)["xyz"]
+def _general_case(reg_mod, orc, reg, vox, tgt, src, guess):
+    """one (RegularizationMethod, VoxelAccumulationMode) on the HIP library against the CPU oracle: covariances, voxel table, H / b / cost at
+    the guess, the registration itself"""
     v = reg_mod.odometer_vgicp(0)
-    L = v._L
+    v.setRegularizationMethod(reg)
+    v.setVoxelAccumulationMode(vox)
     v.setInputTarget(tgt); v.setInputSource(src)
-    v.align(np.eye(4), want_output=False)
-    T0 = v.getFinalTransformation()
-    assert L.rgc_set_voxel_accumulation_mode(v._h, 1) == 0                      # ADDITIVE_WEIGHTED
-    v.setInputTarget(tgt); v.setInputSource(src)
-    v.align(np.eye(4), want_output=False)
-    assert np.array_equal(T0, v.getFinalTransformation())
-    for setter, bad, good in ((L.rgc_set_regularization_method, (0, 1, 2, 4), 3), (L.rgc_set_voxel_accumulation_mode, (2,), 0)):
-        for m in bad:
-            assert setter(v._h, m) == _lib.ERR_UNSUPPORTED
-            assert b"implemented" in L.rgc_last_error(v._h)
-            with pytest.raises(reg_mod.RgcError) as e:
-                v.setInputTarget(tgt)
-            assert e.value.status == _lib.ERR_UNSUPPORTED
-            with pytest.raises(reg_mod.RgcError):
-                v.align(np.eye(4), want_output=False)
-        assert setter(v._h, 99) == _lib.ERR_INVALID
-        assert setter(v._h, good) == 0
-    v.setInputTarget(tgt); v.setInputSource(src)
-    v.align(np.eye(4), want_output=False)
-    assert np.array_equal(T0, v.getFinalTransformation())
+    o = orc.Registration(max_iterations=25, translation_eps=1e-6, regularization=reg, voxel_mode=vox, num_threads=min(14, __import__("os").cpu_count() or 1))
+    o.set_target(tgt); o.set_source(src); o.prepare()
+    ct, cs = v.getTargetCovariances(), v.getSourceCovariances()
+    ot, os_ = orc.covariances_m(tgt, reg), orc.covariances_m(src, reg)
+    scale = max(1.0, float(np.abs(ot).max()))
+    assert np.abs(ct - ot).max() <= 1e-9 * scale and np.abs(cs - os_).max() <= 1e-9 * scale, (reg, vox, np.abs(ct - ot).max(), np.abs(cs - os_).max())
+    xv, xo = v.getVoxels(), o.voxelmap()       # (both sorted by voxel coordinates)
+    assert np.array_equal(xv["coords"], xo["coords"]) and np.array_equal(xv["num"], xo["num"])
+    vs = max(1.0, float(np.abs(xo["cov"]).max()))
+    assert np.abs(xv["mean"] - xo["mean"]).max() <= 1e-8 and np.abs(xv["cov"] - xo["cov"]).max() <= 1e-8 * vs, (reg, vox)
+    cost, H, b = v.linearize(guess.astype(np.float64))
+    co, Ho, bo = o.linearize(guess.astype(np.float64))
+    assert abs(cost - co) <= 1e-8 * abs(co) and np.abs(H - Ho).max() <= 1e-8 * np.abs(Ho).max() and np.abs(b - bo).max() <= 1e-8 * np.abs(bo).max(), (reg, vox)
+    v.align(guess, want_output=False, want_fitness=True)
+    T, To = v.getFinalTransformation(), o.align(guess)
+    R = T[:3, :3].astype(np.float64) @ To[:3, :3].astype(np.float64).T
+    dth = float(np.arcsin(min(1.0, 0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]))))
+    assert np.abs(T[:3, 3] - To[:3, 3]).max() <= 1e-4 and dth <= 1e-4, (reg, vox, T, To)
+    assert abs(v.getFitnessScore() - o.fitness()) <= 1e-5 * o.fitness()
+    # the two halves (on this route the solve runs in the first) and a second solve give the same pose
+    v.align_begin(guess, want_fitness=True); T2 = v.align_end()
+    assert np.array_equal(T, T2)
     v.close()
+    return T
+
+
+def test_every_regularization_method_and_voxel_mode(reg_mod, orc):
+    """FastGICP::setRegularizationMethod x FastVGICP::setVoxelAccumulationMode (gicp_settings.hpp:6,10; fast_gicp_impl.hpp:262-293;
+    fast_vgicp_voxel.hpp:76-122): NONE, MIN_EIG, NORMALIZED_MIN_EIG, FROBENIUS and MULTIPLICATIVE run on the library's general route (a 3x3
+    per point), PLANE with an additive mode on the tuned kernels.  Each combination against the CPU oracle -- covariances and voxel table to
+    1e-9 / 1e-8 relative, H / b / cost to 1e-8, the pose to 1e-4 m / 1e-4 rad -- whose general methods tests/test_oracle_golden.py pins to
+    the literal numpy restatement."""
+    import rgc_slam_amd.synth as synth
+    F = reg_mod.FastVGICP
+    world, tgt = synth.make_world_and_map(40000, seed=synth.SEED + 8)
+    T_true = synth.se3(synth.rot_zyx(0.015, 0.002, -0.002), [0.12, -0.02, 0.003])
+    src = synth.make_scan_n(world, T_true, 9000, seed=synth.SEED + 8)["xyz"]
+    I4 = np.eye(4, dtype=np.float32)
+    poses = {}
+    for reg in (F.REG_MIN_EIG, F.REG_NORMALIZED_MIN_EIG, F.REG_FROBENIUS, F.REG_PLANE):
+        for vox in (F.VOXEL_ADDITIVE, F.VOXEL_MULTIPLICATIVE):
+            poses[(reg, vox)] = _general_case(reg_mod, orc, reg, vox, tgt, src, I4)
+    _general_case(reg_mod, orc, F.REG_NONE, F.VOXEL_ADDITIVE, tgt, src, I4)     # (NONE with MULTIPLICATIVE inverts rank-deficient covariances: undefined in the reference)
+    # every regularised variant recovers the known motion of the synthetic scan
+    for key, T in poses.items():
+        assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < 0.05, (key, T[:3, 3])
+    # ADDITIVE_WEIGHTED is ADDITIVE in the vendored FastVGICP (fast_vgicp_voxel.hpp:137-141): the tuned route, the same bits
+    v = reg_mod.odometer_vgicp(0)
+    v.setInputTarget(tgt); v.setInputSource(src); v.align(I4, want_output=False)
+    T0 = v.getFinalTransformation()
+    v.setVoxelAccumulationMode(F.VOXEL_ADDITIVE_WEIGHTED)
+    v.align(I4, want_output=False)                                               # (no change of route: the clouds stay)
+    assert np.array_equal(T0, v.getFinalTransformation())
+    assert np.array_equal(T0, poses[(F.REG_PLANE, F.VOXEL_ADDITIVE)])
+    # a change of route drops the clouds (the reference would compute covariances under the new method at align()): set them again
+    v.setRegularizationMethod(F.REG_MIN_EIG)
+    with pytest.raises(reg_mod.RgcError):
+        v.align(I4, want_output=False)
+    v.setInputTarget(tgt); v.setInputSource(src); v.align(I4, want_output=False)
+    assert np.array_equal(v.getFinalTransformation(), poses[(F.REG_MIN_EIG, F.VOXEL_ADDITIVE)])
+    with pytest.raises(reg_mod.RgcError):
+        v.setRegularizationMethod(7)
+    v.close()
+
+
+def test_the_two_routes_agree_on_the_odometers_settings(reg_mod, monkeypatch):
+    """PLANE / ADDITIVE through the general route (RGC_FORCE_GENERAL=1: every point through the cooperative search, a 3x3 per point, the
+    host-driven LM) against the tuned kernels: the same neighbour sets, covariances to 1e-9, the same voxels, the pose to 1e-6."""
+    import rgc_slam_amd.synth as synth
+    world, tgt = synth.make_world_and_map(60000, seed=synth.SEED + 9)
+    src = synth.make_scan_n(world, synth.se3(synth.rot_zyx(0.01, 0.0, 0.001), [0.1, 0.02, 0.0]), 12000, seed=synth.SEED + 9)["xyz"]
+    a = reg_mod.odometer_vgicp(0)
+    monkeypatch.setenv("RGC_FORCE_GENERAL", "1")
+    b = reg_mod.odometer_vgicp(0)
+    monkeypatch.delenv("RGC_FORCE_GENERAL")
+    I4 = np.eye(4, dtype=np.float32)
+    for v in (a, b):
+        v.setInputTarget(tgt); v.setInputSource(src)
+    assert np.abs(a.getTargetCovariances() - b.getTargetCovariances()).max() <= 1e-9
+    assert np.abs(a.getSourceCovariances() - b.getSourceCovariances()).max() <= 1e-9
+    xa, xb = a.getVoxels(), b.getVoxels()
+    assert np.array_equal(xa["coords"], xb["coords"]) and np.abs(xa["cov"] - xb["cov"]).max() <= 1e-9 and np.abs(xa["mean"] - xb["mean"]).max() <= 1e-9
+    a.align(I4, want_output=False); b.align(I4, want_output=False)
+    assert np.abs(a.getFinalTransformation() - b.getFinalTransformation()).max() <= 1e-6
+    # a general-route cloud has no normals to hand out
+    import ctypes as C
+    from rgc_slam_amd import _lib
+    nrm = np.empty((len(tgt), 3))
+    assert b._L.rgc_get_target_covariances(b._h, None, nrm.ctypes.data_as(C.POINTER(C.c_double))) == _lib.ERR_UNSUPPORTED
+    assert a._L.rgc_get_target_covariances(a._h, None, nrm.ctypes.data_as(C.POINTER(C.c_double))) == 0 and abs(np.linalg.norm(nrm[0]) - 1) < 1e-12
+    a.close(); b.close()

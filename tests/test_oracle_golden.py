@@ -197,3 +197,34 @@ def test_fuse_fixture():
         if np.dot(q, qo) < 0:
             qo = -qo
         assert np.abs(q - qo).max() < 1e-6 and np.abs(t - to).max() < 1e-6 and it.value <= 6
+
+
+def test_general_regularization_methods_and_multiplicative_voxels(orc, fx_reg):
+    """The C oracle's restatement of fast_gicp_impl.hpp:262-293 (NONE, MIN_EIG, NORMALIZED_MIN_EIG, FROBENIUS beside PLANE) and of
+    MultiplicativeGaussianVoxel (fast_vgicp_voxel.hpp:76-99) against the literal numpy restatement (oracle/py_oracle.py: np.linalg.svd /
+    inv as the reference's JacobiSVD / inverse()): covariances, H / b / cost, and the registration's pose.  CPU only."""
+    from oracle import py_oracle as po
+    tgt, src = fx_reg["tgt"][:2500], fx_reg["src"][:600]
+    names = {"NONE": orc.REG_NONE, "MIN_EIG": orc.REG_MIN_EIG, "NORMALIZED_MIN_EIG": orc.REG_NORMALIZED_MIN_EIG, "PLANE": orc.REG_PLANE,
+             "FROBENIUS": orc.REG_FROBENIUS}
+    for nm, m in names.items():
+        c_py, _ = po.covariances(src, regularization=nm)
+        c_c = orc.covariances_m(src, m)
+        assert np.abs(c_py[:, :3, :3] - c_c).max() <= 1e-9 * max(1.0, np.abs(c_c).max()), nm
+    S = np.array([[0.04, 0.01, 0.0], [0.01, 0.03, 0.002], [0.0, 0.002, 1e-5]])
+    ev = np.linalg.eigvalsh(S)[::-1]
+    assert np.allclose(np.linalg.eigvalsh(orc.regularize(S, orc.REG_MIN_EIG))[::-1], np.maximum(ev, 1e-3), atol=1e-12)
+    assert np.allclose(np.linalg.eigvalsh(orc.regularize(S, orc.REG_NORMALIZED_MIN_EIG))[::-1], np.maximum(ev / ev[0], 1e-3), atol=1e-12)
+    assert np.allclose(np.linalg.eigvalsh(orc.regularize(S, orc.REG_PLANE))[::-1], [1.0, 1.0, 1e-3], atol=1e-12)
+    Ci = np.linalg.inv(S + 1e-3 * np.eye(3))
+    assert np.allclose(orc.regularize(S, orc.REG_FROBENIUS), np.linalg.inv(Ci / np.linalg.norm(Ci)), rtol=1e-10)
+    I4 = np.eye(4)
+    for nm, vm in (("MIN_EIG", "ADDITIVE"), ("FROBENIUS", "MULTIPLICATIVE"), ("PLANE", "MULTIPLICATIVE")):
+        r_py = po.VGICP(regularization=nm, voxel_mode=vm); r_py.set_target(tgt); r_py.set_source(src)
+        r_c = orc.Registration(regularization=names[nm], voxel_mode=orc.VOXEL_MULTIPLICATIVE if vm == "MULTIPLICATIVE" else orc.VOXEL_ADDITIVE, num_threads=2)
+        r_c.set_target(tgt); r_c.set_source(src)
+        cost_py, H_py, b_py = r_py.linearize(I4)
+        cost_c, H_c, b_c = r_c.linearize(I4)
+        assert abs(cost_py - cost_c) <= 1e-10 * abs(cost_c) and np.abs(H_py - H_c).max() <= 1e-10 * np.abs(H_c).max() and np.abs(b_py - b_c).max() <= 1e-10 * np.abs(b_c).max(), (nm, vm)
+        Tp, Tc = r_py.align(np.eye(4, dtype=np.float32)), r_c.align(np.eye(4, dtype=np.float32))
+        assert np.abs(np.asarray(Tp, np.float64) - np.asarray(Tc, np.float64)).max() <= 1e-6, (nm, vm)
