@@ -156,6 +156,9 @@ RGC_API int rgc_align_end(rgc_ctx* ctx, float final_T[16], double final_H[36], d
  * n, stride_bytes, q, t, d_scratch).  The host's turn-around between a frame's result and the next frame's first launch is on the
  * critical path of a dependent sequence; here it is a few microseconds of C instead of the caller's pose arithmetic and a second call.
  * world_T: 16 doubles, row-major 4x4, in: the world pose before this frame, out: after it.  Outputs as rgc_align_end.
+ * On two contexts (next != solve) with the fitness chained to the solve, the next target is enqueued as soon as the solve's final POSE is
+ * known -- the deciding launch posts it before it computes the score -- and the call then waits for the score: same results, the score's
+ * ~25 us no longer in front of the next frame.
  * Failure is all or nothing for the caller's arguments: `next` (alive, no solve in flight), d_map / n / stride_bytes / d_scratch are
  * checked as rgc_set_target_reframed checks them BEFORE the solve is consumed -- such an error leaves the solve pending and world_T
  * untouched, and the call may be repeated with corrected arguments.  (A HIP or allocation failure inside the next target's preparation
