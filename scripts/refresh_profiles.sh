@@ -59,6 +59,7 @@ if [ "$1" != quick ]; then
   timeout 300 python scripts/bench_mapreg.py > $O/mapreg.json 2> /dev/null
   timeout 300 python scripts/bench_icp.py 2>/dev/null | tail -1 > $O/icp.json
   timeout 300 python scripts/bench_pre.py 2>/dev/null | tail -1 > $O/pre.json
+  timeout 300 python scripts/bench_general.py > $O/general_route.json 2> /dev/null
   cd /tmp
   timeout 400 rocprofv3 --kernel-trace --stats -d $O/fstats -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/bench_frontend.py > /dev/null 2>&1
   cd $GRAFT_REPO_ROOT
