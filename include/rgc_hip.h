@@ -78,7 +78,7 @@ RGC_API void rgc_default_params(rgc_params* p);
  * normal of I - 0.999 n n^T (24 bytes).  NONE, MIN_EIG, NORMALIZED_MIN_EIG, FROBENIUS (fast_gicp_impl.hpp:262-293) and
  * VoxelAccumulationMode::MULTIPLICATIVE (fast_vgicp_voxel.hpp:76-99) run on a GENERAL route: a regularised 3x3 per point (48 bytes), every
  * point's exact k-NN through the cooperative search, a plain voxel pass, and the LM loop driven from the host over a linearisation that takes
- * the full source covariance -- the same entry points and the reference's arithmetic, an order of magnitude slower (it is not the odometer's
+ * the full source covariance -- the same entry points and the reference's arithmetic, about four times slower at c1 size (it is not the odometer's
  * path and has not been tuned).  On that route rgc_align_begin solves at once and rgc_align_end hands the result over; rgc_set_target_lazy and
  * rgc_set_knn_reuse have no effect; rgc_get_*_covariances returns no normals (RGC_ERR_UNSUPPORTED if asked); rgc_set_*_covariances takes any
  * symmetric 3x3.  RGC_ERR_UNSUPPORTED is otherwise unused by these calls; an out-of-range value is RGC_ERR_INVALID.

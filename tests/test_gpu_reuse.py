@@ -1,7 +1,9 @@
 """What a context keeps between the targets rgc_set_target_reframed prepares (rgc_set_knn_reuse: nothing / seeds / seeds + neighbour
 lists) must never show in a result.  Parity here is HIP against HIP -- a context that keeps NOTHING (the plain exact search of every
 query, the route tests/test_gpu_parity.py pins to the CPU oracle) -- bit for bit, plus the oracle's covariances (<= 1e-9; the oracle is a
-restatement of impl/fast_gicp_impl.hpp:241-298, "parity unpinned": DESIGN.md section 3) on the frames named below."""
+restatement of impl/fast_gicp_impl.hpp:241-298, "parity unpinned": DESIGN.md section 3) on the frames named below.
+Also here (round 6's other API additions): the C++ frame loop against the Python one, and every RegularizationMethod / VoxelAccumulationMode
+-- the general covariance route -- against the oracle."""
 import numpy as np
 import pytest
 
