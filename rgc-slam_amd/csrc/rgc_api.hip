@@ -555,6 +555,8 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
         DevBuf* bufs[7] = {&cl.nbr, &cl.pos_of, &cl.rank_of, &cl.qrank, &cl.map_copy, &cl.todo, &cl.cache_small};
         for (int b = 0; b < 7 && lists; b++)
           if (ensure(c, *bufs[b], want[b]) != RGC_OK) lists = false;
+        static const bool test_fail = getenv("RGC_TEST_FAIL_CACHE_ALLOC") != nullptr;  // (a test's way to walk the path below: as if the device were full)
+        if (test_fail) lists = false;
         if (!lists) {
           (void)hipGetLastError();
           for (DevBuf* b : bufs) release(*b);
@@ -2586,7 +2588,7 @@ int rgc_align_end_reframe(rgc_ctx* c, rgc_ctx* next, double Tw[16], const float*
   double We[16], qe[4], te[3];
   bool early_done = false;
   int rc_next = RGC_OK;
-  if (next != c && RGC_EARLY_POSE && c->post_on && c->d_post && c->d_early && c->pend.want_fitness && !c->lm_host) {
+  if (next != c && RGC_EARLY_POSE && c->post_on && c->d_post && c->d_early && c->pend.active && c->pend.want_fitness && !c->lm_host && !c->gen_res.on) {
     volatile int* eg = &c->h_early->gen;
     volatile int* fg = &c->h_post->gen;
     bool early = false;

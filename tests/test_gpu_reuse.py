@@ -319,3 +319,33 @@ def test_the_two_routes_agree_on_the_odometers_settings(reg_mod, monkeypatch):
     assert b._L.rgc_get_target_covariances(b._h, None, nrm.ctypes.data_as(C.POINTER(C.c_double))) == _lib.ERR_UNSUPPORTED
     assert a._L.rgc_get_target_covariances(a._h, None, nrm.ctypes.data_as(C.POINTER(C.c_double))) == 0 and abs(np.linalg.norm(nrm[0]) - 1) < 1e-12
     a.close(); b.close()
+
+
+def test_lists_that_do_not_fit_drop_the_context_to_seeds(reg_mod, monkeypatch):
+    """The neighbour lists are an optimisation (112 bytes per map point): when their buffers cannot be had -- RGC_TEST_FAIL_CACHE_ALLOC walks
+    that path -- the call that wanted them succeeds all the same, the context reports RGC_REUSE_SEEDS from then on, and results stay those
+    of a context that keeps nothing."""
+    import rgc_slam_amd.synth as synth
+    n = 60000
+    _, tgt = synth.make_world_and_map(n, seed=synth.SEED + 4)
+    a = np.zeros((n, 4), np.float32); a[:, :3] = tgt
+    monkeypatch.setenv("RGC_TEST_FAIL_CACHE_ALLOC", "1")
+    v = reg_mod.odometer_vgicp(0)
+    w = reg_mod.odometer_vgicp(0)
+    w.setNeighbourReuse(reg_mod.FastVGICP.REUSE_NONE)
+    assert v.getNeighbourReuse() == reg_mod.FastVGICP.REUSE_LISTS
+    d_map, d_body = v.device_alloc(16 * n), v.device_alloc(16 * n)
+    d_map_w, d_body_w = w.device_alloc(16 * n), w.device_alloc(16 * n)
+    v.upload(d_map, a); w.upload(d_map_w, a)
+    for j in range(4):
+        q, t = _pose(j)
+        v.setInputTargetReframed(d_map, n, 16, q, t, d_body)
+        w.setInputTargetReframed(d_map_w, n, 16, q, t, d_body_w)
+        _same_target(v, w, j)
+        assert v.stats()["searched_target"] == n
+        assert v.getNeighbourReuse() == reg_mod.FastVGICP.REUSE_SEEDS
+    for p in (d_map, d_body):
+        v.device_free(p)
+    for p in (d_map_w, d_body_w):
+        w.device_free(p)
+    v.close(); w.close()
