@@ -225,6 +225,7 @@ struct rgc_ctx {
   bool cache_on = RGC_KNN_CACHE != 0;  // (build flag; RGC_KNN_CACHE=0 in the environment) the neighbour lists of an unchanged map on top of the seeds
   bool seeds_on = RGC_KNN_SEEDS != 0;  // (build flag; RGC_KNN_SEEDS=0 in the environment) 0: every search of a re-framed map starts without a bound, as before round 5
   int reg_method = RGC_REG_PLANE, voxel_mode = RGC_VOXEL_ADDITIVE;  // as selected by the caller, implemented or not (rgc_set_regularization_method)
+  bool test_fail_cache_alloc = false;  // RGC_TEST_FAIL_CACHE_ALLOC in the environment (rgc_create)
   bool force_general = false;          // RGC_FORCE_GENERAL=1 in the environment (rgc_create): PLANE / ADDITIVE on the general route too (a test's cross-check of the two routes)
   bool cache_dropped = false;          // the lists' buffers did not fit on the device: the context went down to the seeds by itself (rgc_get_knn_reuse)
   bool trace_cache = false;            // RGC_TRACE_CACHE in the environment (rgc_create): rgc_get_stats reports the lists' state on stderr
@@ -555,8 +556,7 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
         DevBuf* bufs[7] = {&cl.nbr, &cl.pos_of, &cl.rank_of, &cl.qrank, &cl.map_copy, &cl.todo, &cl.cache_small};
         for (int b = 0; b < 7 && lists; b++)
           if (ensure(c, *bufs[b], want[b]) != RGC_OK) lists = false;
-        static const bool test_fail = getenv("RGC_TEST_FAIL_CACHE_ALLOC") != nullptr;  // (a test's way to walk the path below: as if the device were full)
-        if (test_fail) lists = false;
+        if (c->test_fail_cache_alloc) lists = false;  // (RGC_TEST_FAIL_CACHE_ALLOC at rgc_create: a test's way to walk the path below, as if the device were full)
         if (!lists) {
           (void)hipGetLastError();
           for (DevBuf* b : bufs) release(*b);
@@ -1555,6 +1555,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   if (!c->seeds_on) c->cache_on = false;  // (the lists sit on top of the seeds)
   c->trace_cache = getenv("RGC_TRACE_CACHE") != nullptr;
   if (const char* e = getenv("RGC_FORCE_GENERAL")) c->force_general = atoi(e) != 0;
+  c->test_fail_cache_alloc = getenv("RGC_TEST_FAIL_CACHE_ALLOC") != nullptr;
   if (const char* e = getenv("RGC_JOIN_SPIN_US")) c->join_spin_us = atoi(e);
   if (const char* e = getenv("RGC_PREP_EVENT_EXT")) c->prep_event_ext = atoi(e) != 0;
   if (const char* e = getenv("RGC_COOP_STREAM")) c->coop_stream_on = atoi(e) != 0;

@@ -331,6 +331,7 @@ def test_lists_that_do_not_fit_drop_the_context_to_seeds(reg_mod, monkeypatch):
     a = np.zeros((n, 4), np.float32); a[:, :3] = tgt
     monkeypatch.setenv("RGC_TEST_FAIL_CACHE_ALLOC", "1")
     v = reg_mod.odometer_vgicp(0)
+    monkeypatch.delenv("RGC_TEST_FAIL_CACHE_ALLOC")
     w = reg_mod.odometer_vgicp(0)
     w.setNeighbourReuse(reg_mod.FastVGICP.REUSE_NONE)
     assert v.getNeighbourReuse() == reg_mod.FastVGICP.REUSE_LISTS
