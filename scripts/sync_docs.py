@@ -74,10 +74,19 @@ def traffic_line(name, f, alg):
     return f"{name} {f['bytes_per_frame_measured'] / 1e6:.0f} MB measured / {alg / 1e6:.0f} MB algorithmic = **{f['bytes_per_frame_measured'] / alg:.2f} ×** (largest, MB per frame: {top})"
 
 
+def grid_share(f):
+    """share of a frame's measured traffic that the grid build moves (the counting sort: SURVEY 8d's B has no term for it)"""
+    if not f:
+        return NAN
+    tot = sum(r["MB_per_frame"] for r in f["per_kernel"])
+    return sum(r["MB_per_frame"] for r in f["per_kernel"] if r["kernel"].startswith(("k_count", "k_rank_gather", "k_place", "k_cells_", "k_bbox"))) / tot
+
+
 tl = [traffic_line("c-main", ft, d["algorithmic_bytes_per_scan"]), traffic_line("c3", ft3, g(c, "c3", "algorithmic_bytes_per_scan", default=None)),
       traffic_line("c5", ft5, g(c, "c5", "algorithmic_bytes_per_scan", default=None))]
 traffic_txt = ("Frame-level HBM traffic, measured (`profiles/" + TAG + "_frame_traffic*.json`: `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over a dependent sequence with "
                "nothing kept between frames, every kernel of a frame; FETCH_SIZE × 2 as the guide prescribes for gfx950): " + "; ".join(x for x in tl if x) + "."
+               + f"  The grid build -- the counting sort that stands where the reference builds kd-trees, for which SURVEY §8d's B has no term -- moves {100 * grid_share(ft):.0f} % / {100 * grid_share(ft3):.0f} % / {100 * grid_share(ft5):.0f} % of that (c-main / c3 / c5); the kernels B does cover run at 1.3–2.0 × their algorithmic bytes (`roofline_by_kernel`)."
                + (f"  With the default reuse mode on the unchanged map the c-main frame moves {ftl['bytes_per_frame_measured'] / 1e6:.0f} MB (its lists: `{TAG}_frame_traffic_lists.json`).\n" if ftl else "\n")) if any(tl) else ""
 bk_rows = ""
 for r in BK.get("kernels", []):
