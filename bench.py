@@ -902,12 +902,12 @@ def main():
     for kk in range(n_kf):
         i = min(3 * kk, len(scans) - 1)
         P = np.asarray(poses[i + 1], np.float64)
-        # a keyframe's worth of NEW samples of the surfaces around the vehicle, at the map's own density: an independent sampling of the same
-        # world (other jitter, other noise) within 35 m of the pose.  (A raw sweep puts hundreds of points into the cells next to the
-        # sensor; a leaf-filtered sweep adds thousands of isolated far returns where the dense synthetic map has none -- either changes what
-        # the preparation costs by more than the turnover this key is about: EXPERIMENTS.md, round 6.)
-        near = alt[(np.abs(alt[:, 0] - P[0, 3]) < 35.0) & (np.abs(alt[:, 1] - P[1, 3]) < 35.0)]
-        wpts = near[np.random.default_rng(seed + 500 + kk).permutation(len(near))][:kf_n]
+        # a keyframe's worth of NEW samples of the map's surfaces at the map's own density, uniformly over the map like the rows they replace: an
+        # independent sampling of the same world (other jitter, other noise).  What was tried first, and why not (EXPERIMENTS.md, round 6): a raw
+        # sweep (hundreds of points per cell next to the sensor), a leaf-filtered sweep (isolated far returns where the dense synthetic map has
+        # none: thousands of deferred queries), new samples NEAR THE VEHICLE against rows evicted all over the map (the density around the vehicle
+        # grows by half over twenty keyframes) -- each changes what the preparation costs by more than the turnover this key is about.
+        wpts = alt[np.random.default_rng(seed + 500 + kk).permutation(len(alt))][:kf_n]
         # (returns beyond the map's own bounding box are left out: rgc_set_target_reframed derives the re-framed map's box from the buffer's,
         # measured once per buffer -- "fixed between calls", rgc_hip.h; a rolling map that GROWS is the resident map's business, rgc_map_*)
         wpts = wpts[np.all((wpts > map_lo) & (wpts < map_hi), axis=1)]
@@ -1005,7 +1005,7 @@ def main():
                      "a caller that has dropped the reference's per-frame body-frame leaf filter of the sub-map, RGC_odometer.cpp:985-991); "
                      "one_point_edited_every_frame: one coordinate moved by an ulp before every frame (all-or-nothing invalidation: everything searched, seeded, "
                      "lists rebuilt); keyframe_every_3rd_frame: every third frame a uniform 1 % of the map's points (a block of rows of a row-shuffled copy of the "
-                     "map) is overwritten with new samples of the surfaces within 35 m of the vehicle, at the map's density -- an insert and an evict, RGC_odometer.cpp:1236-1247.  with_nothing_kept: the same edited sequence under RGC_REUSE_NONE (the edits' uploads included)")
+                     "map) is overwritten with new samples of the same surfaces at the map's density, uniformly over the map -- an insert and an evict (RGC_odometer.cpp:1236-1247) at stationary statistics.  with_nothing_kept: the same edited sequence under RGC_REUSE_NONE (the edits' uploads included)")
     for w in pv.v:
         w.setNeighbourReuse(REUSE_NONE)
 
