@@ -902,12 +902,15 @@ def main():
     for kk in range(n_kf):
         i = min(3 * kk, len(scans) - 1)
         P = np.asarray(poses[i + 1], np.float64)
-        # a keyframe's worth of NEW samples of the map's surfaces at the map's own density, uniformly over the map like the rows they replace: an
-        # independent sampling of the same world (other jitter, other noise).  What was tried first, and why not (EXPERIMENTS.md, round 6): a raw
-        # sweep (hundreds of points per cell next to the sensor), a leaf-filtered sweep (isolated far returns where the dense synthetic map has
-        # none: thousands of deferred queries), new samples NEAR THE VEHICLE against rows evicted all over the map (the density around the vehicle
-        # grows by half over twenty keyframes) -- each changes what the preparation costs by more than the turnover this key is about.
-        wpts = alt[np.random.default_rng(seed + 500 + kk).permutation(len(alt))][:kf_n]
+        # a keyframe RE-OBSERVES a region: the block of map rows it overwrites -- the map's rows are in leaf order, a block of them is a slab of the
+        # world -- gets NEW samples of the same slab at the same density: the corresponding rows of an independent sampling of the same surfaces
+        # (other jitter, other noise; the same leaf order).  What was tried first, and why not (EXPERIMENTS.md, round 6): a raw sweep (hundreds
+        # of points per cell next to the sensor), a leaf-filtered sweep (isolated far returns: thousands of deferred queries), a sweep's points
+        # over a slab (a hole in the ground), new samples near the vehicle against rows evicted all over a row-shuffled map (density drift, and
+        # a shuffled map costs the counting sort its coherence) -- each changes what a frame costs by more than the turnover this key is about.
+        slot = (kk % n_slots) * kf_n
+        a_lo = min(int(slot * (len(alt) / float(n_map))), max(0, len(alt) - kf_n))
+        wpts = alt[a_lo:a_lo + kf_n]
         # (returns beyond the map's own bounding box are left out: rgc_set_target_reframed derives the re-framed map's box from the buffer's,
         # measured once per buffer -- "fixed between calls", rgc_hip.h; a rolling map that GROWS is the resident map's business, rgc_map_*)
         wpts = wpts[np.all((wpts > map_lo) & (wpts < map_hi), axis=1)]
@@ -915,29 +918,19 @@ def main():
         kf_short.append(int(wpts.shape[0]))   # (a short keyframe: the rest of its block keeps the map's own rows, filled in below)
     def edit_one(i, w):
         w.upload_async(seq.d_map + 7 * 16, one_np[i:i + 1])
-    # the keyframe sequence runs on a copy of the map whose ROWS are shuffled: a keyframe then evicts a uniform 1 % of the map's points (an old
-    # keyframe's returns lie all over the local map), not a slab of it -- the generated map's rows are in leaf order, and a contiguous block of
-    # them is a hole in the ground
-    perm = np.random.default_rng(seed + 499).permutation(n_map)
-    map_perm = np.ascontiguousarray(map_host[perm])
-    d_map_perm = v.device_alloc(map_perm.nbytes)
-    v.upload(d_map_perm, map_perm)
-    seq_kf = DependentSequence(pv.v, d_map_perm, n_map, d_scans, [s_.shape[0] for s_ in scans])
-    for kk, got in enumerate(kf_short):
+    for kk, got in enumerate(kf_short):   # (rows a short keyframe leaves alone keep the map's own points)
         if got < kf_n:
             slot = (kk % n_slots) * kf_n
-            kf_np[kk, got:, :] = map_perm[slot + got:slot + kf_n]
+            kf_np[kk, got:, :] = map_host[slot + got:slot + kf_n]
     def edit_kf(i, w):
         if i % 3 == 0:
-            w.upload_async(d_map_perm + ((i // 3) % n_slots) * kf_n * 16, kf_np[i // 3])
+            w.upload_async(seq.d_map + ((i // 3) % n_slots) * kf_n * 16, kf_np[i // 3])
     def timed_like_value(edit=None, overlap=True, reps=3):
         per, first, same = [], None, True
-        sq = seq_kf if edit is edit_kf else seq
+        sq = seq
         for _ in range(reps):
-            if edit is edit_kf:
-                v.upload(d_map_perm, map_perm)  # (synchronises) every pass starts from the map as generated
-            elif edit is not None:
-                v.upload(seq.d_map, map_host)
+            if edit is not None:
+                v.upload(seq.d_map, map_host)   # (synchronises) every pass starts from the map as generated
             Tw_s, g_s = Tw_init, I4
             if W > 0:
                 m, wd, _ = sq.run(0, W, Tw_init, I4, overlap, edit_map=edit)
@@ -998,14 +991,12 @@ def main():
     v.upload(seq.d_map, map_host)
     reuse["map_knn_launch_alone_ms"] = {"unchanged_map_lists": round(dom_lists["total_ms"] / max(dom_lists["launches"], 1), 4),
                                         "after_a_write_seeded_search_and_lists_rebuilt": round(dom_rebuild["total_ms"] / max(dom_rebuild["launches"], 1), 4)}
-    seq_kf.close()
-    v.device_free(d_map_perm)
     reuse["what"] = ("rgc_set_knn_reuse(RGC_REUSE_LISTS), the library's default, instead of `value`'s RGC_REUSE_NONE; every entry W warm-up + K timed steps on two "
                      "contexts, median of 3 passes.  unchanged_map: this synthetic sequence as it is (the world-frame map handed over bit for bit every frame -- "
                      "a caller that has dropped the reference's per-frame body-frame leaf filter of the sub-map, RGC_odometer.cpp:985-991); "
                      "one_point_edited_every_frame: one coordinate moved by an ulp before every frame (all-or-nothing invalidation: everything searched, seeded, "
-                     "lists rebuilt); keyframe_every_3rd_frame: every third frame a uniform 1 % of the map's points (a block of rows of a row-shuffled copy of the "
-                     "map) is overwritten with new samples of the same surfaces at the map's density, uniformly over the map -- an insert and an evict (RGC_odometer.cpp:1236-1247) at stationary statistics.  with_nothing_kept: the same edited sequence under RGC_REUSE_NONE (the edits' uploads included)")
+                     "lists rebuilt); keyframe_every_3rd_frame: every third frame 1 % of the map's points (a block of rows = a slab of the world) is overwritten with NEW samples "
+                     "of the same slab at the same density -- a keyframe that re-observes a region: an insert and an evict (RGC_odometer.cpp:1236-1247) at stationary statistics.  with_nothing_kept: the same edited sequence under RGC_REUSE_NONE (the edits' uploads included)")
     for w in pv.v:
         w.setNeighbourReuse(REUSE_NONE)
 
