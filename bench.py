@@ -899,6 +899,9 @@ def main():
     kf_short = []
     map_lo, map_hi = maps[0].min(axis=0) + np.float32(0.5), maps[0].max(axis=0) - np.float32(0.5)
     alt = synth.make_map(world, None, seed=seed + 77)   # the same surfaces sampled again
+    # (the blocks nearest to the vehicle first: the slabs the scans actually fall into, so that the edits reach the poses)
+    cen = map_host[:n_slots * kf_n, :3].reshape(n_slots, kf_n, 3).mean(axis=1)
+    slot_order = np.argsort(np.linalg.norm(cen - np.asarray(poses[0], np.float64)[:3, 3].astype(np.float32), axis=1))
     for kk in range(n_kf):
         i = min(3 * kk, len(scans) - 1)
         P = np.asarray(poses[i + 1], np.float64)
@@ -908,7 +911,7 @@ def main():
         # of points per cell next to the sensor), a leaf-filtered sweep (isolated far returns: thousands of deferred queries), a sweep's points
         # over a slab (a hole in the ground), new samples near the vehicle against rows evicted all over a row-shuffled map (density drift, and
         # a shuffled map costs the counting sort its coherence) -- each changes what a frame costs by more than the turnover this key is about.
-        slot = (kk % n_slots) * kf_n
+        slot = int(slot_order[kk % n_slots]) * kf_n
         a_lo = min(int(slot * (len(alt) / float(n_map))), max(0, len(alt) - kf_n))
         wpts = alt[a_lo:a_lo + kf_n]
         # (returns beyond the map's own bounding box are left out: rgc_set_target_reframed derives the re-framed map's box from the buffer's,
@@ -920,11 +923,11 @@ def main():
         w.upload_async(seq.d_map + 7 * 16, one_np[i:i + 1])
     for kk, got in enumerate(kf_short):   # (rows a short keyframe leaves alone keep the map's own points)
         if got < kf_n:
-            slot = (kk % n_slots) * kf_n
+            slot = int(slot_order[kk % n_slots]) * kf_n
             kf_np[kk, got:, :] = map_host[slot + got:slot + kf_n]
     def edit_kf(i, w):
         if i % 3 == 0:
-            w.upload_async(seq.d_map + ((i // 3) % n_slots) * kf_n * 16, kf_np[i // 3])
+            w.upload_async(seq.d_map + int(slot_order[(i // 3) % n_slots]) * kf_n * 16, kf_np[i // 3])
     def timed_like_value(edit=None, overlap=True, reps=3):
         per, first, same = [], None, True
         sq = seq
@@ -968,7 +971,8 @@ def main():
                                                  same_poses_as_with_nothing_kept=bool(sm and all(np.array_equal(a_, b_) for a_, b_ in zip(m_none_one, m_))))
     el, m_, sm = timed_like_value(edit_kf)
     reuse["keyframe_every_3rd_frame"] = dict(rate(el), with_nothing_kept=rate(el_none_kf), points_replaced_per_keyframe=int(kf_n),
-                                             same_poses_as_with_nothing_kept=bool(sm and all(np.array_equal(a_, b_) for a_, b_ in zip(m_none_kf, m_))))
+                                             same_poses_as_with_nothing_kept=bool(sm and all(np.array_equal(a_, b_) for a_, b_ in zip(m_none_kf, m_))),
+                                             poses_differ_from_the_unedited_sequence=bool(any(not np.array_equal(a_, b_) for a_, b_ in zip(motions, m_))))
     v.upload(seq.d_map, map_host)
     # the map's launch alone under the default: unchanged map (lists), and after a write to the buffer (everything searched, seeded, lists rebuilt)
     v.profile_enable(True)
