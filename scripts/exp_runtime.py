@@ -38,4 +38,5 @@ for name, overlap in (("two_contexts", True), ("one_frame_at_a_time", False)):
         seq.run_cpp(W, K, wd[-1], m[-1], overlap)
         pv.synchronize(); per.append(time.perf_counter() - t0)
     out[name] = round(K / float(np.median(per[2:])), 1)
+out["pose_checksum"] = float(np.asarray(wd).sum())
 print(json.dumps(out))
