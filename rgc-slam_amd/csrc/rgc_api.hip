@@ -3081,6 +3081,9 @@ int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   return RGC_OK;
 }
 
+#ifdef RGC_LAB_TURN
+extern "C" RGC_API int rgc_lab_turn(rgc_ctx*, unsigned long long* out8) { rgck::lab_turn(out8); return RGC_OK; }
+#endif
 #if defined(RGC_LAB) || defined(RGC_LAB_BLK)
 RGC_API int rgc_lab_blocks(rgc_ctx*, long long* out65536) { rgck::lab_blocks(out65536); return RGC_OK; }
 #endif

@@ -261,6 +261,9 @@ void fe_select(hipStream_t s, const float4* C, int NS, const int* meta, const fl
 void fe_emit(hipStream_t s, const float4* C, int NS, const int* slots, const float* dsrc, const float* osrc, float* sharp, float* flat, float* inten,
              int cap, int* counts);
 
+#ifdef RGC_LAB_TURN
+void lab_turn(unsigned long long* out8);
+#endif
 #if defined(RGC_LAB) || defined(RGC_LAB_BLK)
 void lab_blocks(long long* out65536);  // developer build: {start, end, XCC, first query} of every workgroup of the map's bulk kNN launch
 #endif

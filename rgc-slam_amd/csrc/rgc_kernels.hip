@@ -98,6 +98,18 @@ __device__ __forceinline__ void wave_prio(int hi) {
   else if (hi) __builtin_amdgcn_s_setprio(RGC_SCAN_PRIO);
 }
 
+// Developer build (-DRGC_LAB_TURN): the turn-around of a dependent sequence -- from the moment a solve's deciding launch posts its final pose to
+// the first wave of the next map's counting pass (k_count<true>) -- in ticks of the 100 MHz wall clock: [0] sum, [1] count, [2] max,
+// [3] the post's stamp, [4] the launch start's stamp (deciding launch entry -> post), [5] sum of that.  Printed by rgc_destroy's caller via lab_turn().
+#ifdef RGC_LAB_TURN
+__device__ unsigned long long g_lab_turn[8];
+void lab_turn(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lab_turn), sizeof(g_lab_turn));
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_turn), z, sizeof(z));
+}
+#endif
 // Developer build (-DRGC_LAB): how often the wave-level loops of the map's bulk kNN kernel run -- with the kernel's ISA that gives the
 // executed instruction mix (scripts/isa_mix.py).  One count per WAVE (its first active lane).  Compiled out of the product.
 #ifdef RGC_LAB
@@ -223,7 +235,13 @@ __global__ void k_count(const float* __restrict__ in, int stride_f, int n, Grid 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < n;
   const int lane = threadIdx.x & (WAVE - 1);
-  int c = -1 - lane;  // lanes past the end: distinct negative keys, so they never extend a neighbour's run
+  int c = -1 - lane;
+#ifdef RGC_LAB_TURN
+  if (kReframe && i == 0) {
+    const unsigned long long now = wall_clock64(), post = atomicExch(&g_lab_turn[3], 0ull);
+    if (post) { atomicAdd(&g_lab_turn[0], now - post); atomicAdd(&g_lab_turn[1], 1ull); atomicMax(&g_lab_turn[2], now - post); }
+  }
+#endif  // lanes past the end: distinct negative keys, so they never extend a neighbour's run
   if (valid) {
     float pt[3];
     if (kReframe) {  // the cloud is produced here (stride 4 floats) and counted from registers
@@ -3358,6 +3376,9 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
           LmInit in, const int* __restrict__ nvox, const int* __restrict__ def_t, const int* __restrict__ def_s, LmState* __restrict__ h_post,
           int seq, FitArgs fa) {
   wave_prio(2);  // a latency chain: issue ahead of whatever shares the CU (the other context's kNN, the next scan's preparation)
+#ifdef RGC_LAB_TURN
+  const unsigned long long lab_turn_t0 = wall_clock64();
+#endif
   constexpr int kStateWords = (int)(sizeof(LmState) / sizeof(int));
   __shared__ LmState ls;
   __shared__ double folded[kStepAcc];
@@ -3438,6 +3459,9 @@ k_lm_step(const float4* __restrict__ P, const double* __restrict__ nx, const dou
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
           __syncthreads();
           if (threadIdx.x == 0) __hip_atomic_store(&fa.early->gen, seq < 0 ? -seq : seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef RGC_LAB_TURN
+          if (threadIdx.x == 0) { const unsigned long long now = wall_clock64(); atomicExch(&g_lab_turn[3], now); atomicAdd(&g_lab_turn[5], now - lab_turn_t0); }
+#endif
         }
         step_fitness_rows(P, n, ls.x0, g, fa);
         if (!last_block_arrive(lm_area_ticket(st))) return;
