@@ -2081,9 +2081,12 @@ constexpr int kSeedT = RGC_SEED_T;
 #ifndef RGC_SEED_WAVES
 #define RGC_SEED_WAVES 1
 #endif
+#ifndef RGC_SP_WAVES
+#define RGC_SP_WAVES 1  // the map's full search: 86 VGPRs and 30 KB of LDS per 256 threads = five waves per SIMD either way
+#endif
 template <bool kTarget, bool kSeeded> struct SpLaunch : SpConfig<kTarget> {
   static constexpr int T = kSeeded ? kSeedT : SpConfig<kTarget>::T;
-  static constexpr int W = kSeeded ? RGC_SEED_WAVES : 1;  // waves per SIMD the register allocation must leave room for (1: whatever it takes)
+  static constexpr int W = kSeeded ? RGC_SEED_WAVES : (kTarget ? RGC_SP_WAVES : 1);  // waves per SIMD the register allocation must leave room for (1: whatever it takes)
 };
 struct CoopRows {  // per-wave LDS scratch of the cooperative search (coop_run)
   int pref[WAVE + 1];
