@@ -59,6 +59,11 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+__device__ __forceinline__ void wave_lds_fence() {  // LDS is in-order within a wave: only the compiler must not reorder
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // DPP quad permutes (registers only): lane l of every quad of lanes reads lane (CTRL >> 2 l) & 3 of its quad
 template <int CTRL>
 __device__ __forceinline__ int quad_perm_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
@@ -875,6 +880,10 @@ struct Deferred {
   int coop_blocks;
   int* done;
   unsigned long long* slots;
+  // The order a neighbourhood's moments are summed in.  0 (a map: its grid is the voxel grid, whatever route prepares it): ascending
+  // position in the sorted array.  1 (a scan: the cell size of ITS grid follows the crowding of the context's previous scan, so positions
+  // are not a property of the cloud): ascending ORIGINAL index.  Either way the covariance is a function of the neighbour set alone.
+  int by_index;
 };
 constexpr unsigned long long kSlotEnd = 0x8080808080808081ull;    // "no entry will ever appear here": written behind the list by the last bulk workgroup
 constexpr unsigned long long kSlotEmpty = 0x8080808080808080ull;  // (what hipMemset can write; its low word is no valid entry: |enc| <= 2^27)
@@ -961,6 +970,27 @@ __device__ constexpr unsigned short kSort24[kSort24N] = {1, 67, 2, 35, 34, 133, 
 // full search into ascending position in the sorted array: the order the moments are summed in (below).
 constexpr int kSort20N = 101;
 __device__ constexpr unsigned short kSort20[kSort20N] = {1, 67, 2, 35, 34, 133, 199, 134, 167, 166, 4, 70, 68, 37, 103, 101, 34, 100, 166, 265, 331, 266, 299, 298, 397, 463, 398, 431, 430, 268, 334, 332, 301, 367, 365, 298, 364, 430, 8, 140, 136, 74, 206, 202, 68, 200, 332, 41, 173, 169, 107, 239, 235, 101, 233, 365, 34, 100, 166, 232, 298, 364, 430, 529, 595, 530, 563, 562, 16, 272, 136, 400, 82, 338, 202, 466, 68, 200, 332, 464, 49, 305, 169, 433, 115, 371, 235, 499, 101, 233, 365, 497, 34, 100, 166, 232, 298, 364, 430, 496, 562};
+
+// The full 32-wire network (191 compare-exchanges) for the k > 20 instances (KC = 32).
+constexpr int kSort32N = 191;
+__device__ constexpr unsigned short kSort32[kSort32N] = {1, 67, 2, 35, 34, 133, 199, 134, 167, 166, 4, 70, 68, 37, 103, 101, 34, 100, 166, 265, 331, 266, 299, 298, 397, 463, 398, 431, 430, 268, 334, 332, 301, 367, 365, 298, 364, 430, 8, 140, 136, 74, 206, 202, 68, 200, 332, 41, 173, 169, 107, 239, 235, 101, 233, 365, 34, 100, 166, 232, 298, 364, 430, 529, 595, 530, 563, 562, 661, 727, 662, 695, 694, 532, 598, 596, 565, 631, 629, 562, 628, 694, 793, 859, 794, 827, 826, 925, 991, 926, 959, 958, 796, 862, 860, 829, 895, 893, 826, 892, 958, 536, 668, 664, 602, 734, 730, 596, 728, 860, 569, 701, 697, 635, 767, 763, 629, 761, 893, 562, 628, 694, 760, 826, 892, 958, 16, 280, 272, 148, 412, 404, 136, 400, 664, 82, 346, 338, 214, 478, 470, 202, 466, 730, 68, 200, 332, 464, 596, 728, 860, 49, 313, 305, 181, 445, 437, 169, 433, 697, 115, 379, 371, 247, 511, 503, 235, 499, 763, 101, 233, 365, 497, 629, 761, 893, 34, 100, 166, 232, 298, 364, 430, 496, 562, 628, 694, 760, 826, 892, 958};
+
+// idx[0 .. KC) into ascending order (entries that hold no neighbour: INT_MAX, they end up behind the others).  Neighbour positions in
+// ascending position in the sorted array are the order EVERY route sums a neighbourhood's moments in (sp_normal_of): the covariance is
+// then a function of the neighbour set alone -- whichever kernel found it, on whichever grid.
+template <int KC>
+__device__ __forceinline__ void sort_positions(int (&idx)[KC]) {
+  static_assert(KC == 20 || KC == 32, "a 20- or a 32-input network");
+  constexpr int N = KC == 20 ? kSort20N : kSort32N;
+#pragma unroll
+  for (int e = 0; e < N; e++) {
+    const int ce = KC == 20 ? kSort20[e] : kSort32[e];
+    const int a = ce >> 5, b = ce & 31;
+    const int lo_ = min(idx[a], idx[b]);
+    idx[b] = max(idx[a], idx[b]);
+    idx[a] = lo_;
+  }
+}
 
 // a = med3(below, a, x), IN PLACE: the chain's registers stay where they are across the loops they are carried through (with a
 // separate output operand the compiler shuffles all of them at every loop boundary)
@@ -1405,17 +1435,12 @@ __device__ __forceinline__ void knn_point_sp(const float4* __restrict__ P, const
 #pragma unroll
     for (int j = 0; j < KC; j++) idx[j] = index_of(top.a[j]);
     if (swap) idx[KC - 1] = index_of(a_k);
-#pragma unroll
-    for (int e = 0; e < kSort20N; e++) {
-      const int a = kSort20[e] >> 5, b = kSort20[e] & 31;
-      const int lo_ = min(idx[a], idx[b]);
-      idx[b] = max(idx[a], idx[b]);
-      idx[a] = lo_;
-    }
+    sort_positions<KC>(idx);
   } else {
     const int idx_k = swap ? index_of(a_k) : 0;
 #pragma unroll
-    for (int j = 0; j < KC; j++) idx[j] = j < k ? ((swap && j == k - 1) ? idx_k : index_of(top.a[j])) : 0;
+    for (int j = 0; j < KC; j++) idx[j] = j < k ? ((swap && j == k - 1) ? idx_k : index_of(top.a[j])) : INT_MAX;
+    sort_positions<KC>(idx);  // (any k: the same order as the cooperative kernel's and the four-lane search's)
   }
   const int orig = __float_as_int(pq.w);
   if constexpr (kExact && KC == 20) {
@@ -1986,51 +2011,67 @@ __device__ __forceinline__ bool knn_point_split(const float4* __restrict__ P, co
     defer(i, thr_up, 6);
     return false;
   }
-  // ---- moments of neighbours sub, sub + 4, ... in this lane, summed over the quad (one-pass form of knn_point_sp) ----
+  // ---- neighbour positions: every lane looks up its quarter (neighbours sub, sub + 4, ...), the quad exchanges them, and every lane holds
+  // all of them in ascending position -- then the bulk kernels' expression (sp_normal_of), so that a query's covariance is the same bits
+  // whether this search, the map's or the cooperative kernel ends up computing it (which one does depends on the grid's extent) ----
   const int idx_k = swap ? index_of(a_k) : 0;
-  double S6[6] = {0, 0, 0, 0, 0, 0}, m3[3] = {0, 0, 0};
   // this lane's pick of four registers by bit masks (a select chain on `sub` is turned into an indexed stack array by the compiler)
   const int m_lo = -(sub & 1), m_hi = -(sub >> 1);
   auto pick4 = [](int mlo, int mhi, int a0, int a1, int a2, int a3) {
     const int x = a0 ^ ((a0 ^ a1) & mlo), y = a2 ^ ((a2 ^ a3) & mlo);
     return x ^ ((x ^ y) & mhi);
   };
-  auto moments = [&](auto full_tag) {
+  int idx[KC];
+  auto positions = [&](auto full_tag) {
     constexpr bool kFull = decltype(full_tag)::value;
-    const double qx = (double)px, qy = (double)py, qz = (double)pz;
 #pragma unroll
     for (int t = 0; t < KC / S; t++) {  // positions replace the keys (slots 0 .. KC / S - 1: the keys there have been read by then)
       const int key = pick4(m_lo, m_hi, all.a[S * t], all.a[S * t + 1], all.a[S * t + 2], all.a[S * t + 3]);
       const int j = S * t + sub;
-      all.a[t] = (swap && j == k - 1) ? idx_k : ((kFull || j < k) ? index_of(key) : 0);
+      all.a[t] = (swap && j == k - 1) ? idx_k : ((kFull || j < k) ? index_of(key) : INT_MAX);
     }
 #pragma unroll
     for (int t = 0; t < KC / S; t++) {
-      const float4 cp = P[all.a[t]];  // (unconditional: position 0 is a valid point; its terms are masked below)
-      const bool use = kFull || S * t + sub < k;
-      const double dx = use ? (double)cp.x - qx : 0.0, dy = use ? (double)cp.y - qy : 0.0, dz = use ? (double)cp.z - qz : 0.0;
-      m3[0] += dx; m3[1] += dy; m3[2] += dz;
-      S6[0] = fma(dx, dx, S6[0]); S6[1] = fma(dx, dy, S6[1]); S6[2] = fma(dx, dz, S6[2]);
-      S6[3] = fma(dy, dy, S6[3]); S6[4] = fma(dy, dz, S6[4]); S6[5] = fma(dz, dz, S6[5]);
+      idx[S * t + 0] = quad_perm_i<0x00>(all.a[t]);
+      idx[S * t + 1] = quad_perm_i<0x55>(all.a[t]);
+      idx[S * t + 2] = quad_perm_i<0xAA>(all.a[t]);
+      idx[S * t + 3] = quad_perm_i<0xFF>(all.a[t]);
     }
+    if (!df.by_index) {
+      sort_positions<KC>(idx);
+    } else {
+      // a SCAN: ascending original index (Deferred::by_index).  Every lane ranks its quarter among the keys of all four -- original indices
+      // are distinct; an unused slot j >= k gets a key above every index, in slot order -- leaves each position at its rank in the quad's
+      // four LDS columns (the append buffers: empty by now) and reads the whole row back.
+      int ow[KC / S], key[KC];
+#pragma unroll
+      for (int t = 0; t < KC / S; t++) ow[t] = all.a[t] != INT_MAX ? __float_as_int(P[all.a[t]].w) : INT_MAX - KC + (S * t + sub);
+#pragma unroll
+      for (int t = 0; t < KC / S; t++) {
+        key[S * t + 0] = quad_perm_i<0x00>(ow[t]);
+        key[S * t + 1] = quad_perm_i<0x55>(ow[t]);
+        key[S * t + 2] = quad_perm_i<0xAA>(ow[t]);
+        key[S * t + 3] = quad_perm_i<0xFF>(ow[t]);
+      }
+      lds_int* const qb = buf - sub;  // the column of the quad's first lane
+      static_assert((KC + S - 1) / S <= kSpBuf, "a row of KC positions across the quad's four append buffers");
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < KC / S; t++) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < KC; j++) rank += key[j] < ow[t];
+        qb[(rank >> 2) * T + (rank & 3)] = all.a[t];
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int j = 0; j < KC; j++) idx[j] = qb[(j >> 2) * T + (j & 3)];
+      wave_lds_fence();
+    }
+    sp_normal_of<KC, kFull>(P, idx, px, py, pz, k, i, nx, ny, nz);  // (the four lanes store the same three values)
   };
-  if (kExact || k == KC) moments(std::true_type{});
-  else moments(std::false_type{});
-#pragma unroll
-  for (int a = 0; a < 3; a++) m3[a] = quad_sum_f64(m3[a]);
-#pragma unroll
-  for (int a = 0; a < 6; a++) S6[a] = quad_sum_f64(S6[a]);
-  const double inv_k = 1.0 / (double)k;
-  const double mx = m3[0] * inv_k, my = m3[1] * inv_k, mz = m3[2] * inv_k;
-  double Sc[6] = {S6[0] * inv_k - mx * mx, S6[1] * inv_k - mx * my, S6[2] * inv_k - mx * mz,
-                  S6[3] * inv_k - my * my, S6[4] * inv_k - my * mz, S6[5] * inv_k - mz * mz};
-  double nrm[3];
-  if (!min_eigenvector_direct(Sc, nrm)) min_eigenvector(Sc, nrm);
-  if (sub == 0) {
-    nx[i] = nrm[0];
-    ny[i] = nrm[1];
-    nz[i] = nrm[2];
-  }
+  if (kExact || k == KC) positions(std::true_type{});
+  else positions(std::false_type{});
   return false;
 }
 
@@ -2124,10 +2165,6 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 __device__ __forceinline__ int wave_min_i(int v) { return wave_min(v); }
 
 
-__device__ __forceinline__ void wave_lds_fence() {  // LDS is in-order within a wave: only the compiler must not reorder
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 __device__ __forceinline__ int coop_locate(const CoopRows* sh, int j) {  // sorted-array position of flattened candidate j
   int rr = 0;
@@ -2308,10 +2345,14 @@ __device__ __forceinline__ void coop_one(const float4* __restrict__ P, const int
     // The neighbour SET is what the search decides; the order it was collected in depends on the cube the search ended on, hence on the
     // hint (thr) the bulk kernel passed.  The neighbours are put into ascending position in the sorted array: the sums below are then a
     // function of the set alone, whichever route deferred the query (knn_point_seeded passes other hints than knn_point_sp).
+    // (a scan -- Deferred::by_index -- : ascending ORIGINAL index instead, as knn_point_split does: its positions depend on the cell size)
     {
       const int mine = lane < k ? sh->nb[lane] : INT_MAX;
+      const int mkey = (df.by_index && lane < k) ? __float_as_int(P[mine].w) : mine;
+      if (lane < k) sh->rowa[lane] = mkey;   // (the search's row table: free by now)
+      wave_lds_fence();
       int rank = 0;
-      for (int j = 0; j < k; j++) rank += sh->nb[j] < mine;
+      for (int j = 0; j < k; j++) rank += sh->rowa[j] < mkey;
       wave_lds_fence();
       if (lane < k) sh->nb[rank] = mine;
       wave_lds_fence();
@@ -4005,10 +4046,11 @@ __device__ __forceinline__ void cov6_of(const float4* __restrict__ P, const int 
 // every point of a cloud through the cooperative search (a wave per query; wave w takes queries w, w + nwaves, ...)
 template <int KC>
 __global__ void __launch_bounds__(WAVE)
-k_knn_cov6(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, GenOut go, const int* __restrict__ guard) {
+k_knn_cov6(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, GenOut go, const int* __restrict__ guard, int by_index) {
   __shared__ CoopRows shm[1];
   if (guard && *guard) return;
   Deferred df{};
+  df.by_index = by_index;
   for (int e = (int)blockIdx.x; e < n; e += (int)gridDim.x)
     coop_one<KC, false, true>(P, start, g, k, df, nullptr, nullptr, nullptr, &shm[0], (int)threadIdx.x, e, e, INFINITY, go);
 }
@@ -4460,7 +4502,7 @@ size_t deferred_bytes(int n) { return sizeof(int) * (2 * (size_t)n + 16); }
 static Deferred deferred_of(const void* buf, int n) {
   int* base = (int*)const_cast<void*>(buf);
   return Deferred{base + 16, (float*)(base + 16 + (size_t)n), base, nullptr, nullptr, nullptr, nullptr, 0.f, KnnCache{}, 0,
-                  0, base + 1, reinterpret_cast<unsigned long long*>(base + 16)};
+                  0, base + 1, reinterpret_cast<unsigned long long*>(base + 16), 0};
 }
 
 template <int KC, bool kExact>
@@ -4469,6 +4511,7 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
                         const int* qlist, const int* nq, int q_est, const KnnSeeds& seeds, int stream_coop_waves) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
+  df.by_index = is_target ? 0 : 1;
   df.qlist = qlist; df.nq = nq;
   // seeds: the map's dense search at k == KC only; `warm` = some search has written them (the seeded kernel is worth launching)
   const bool seeds_ok = is_target && kExact && wide_r != 2 && seeds.seed && n <= kSeedMaxPoints;
@@ -4524,6 +4567,7 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
                         double* nx, double* ny, double* nz, const int* guard, int waves, const KnnSeeds& seeds) {
   Deferred df = deferred_of(segs, n);
   df.guard = guard;
+  df.by_index = is_target ? 0 : 1;
   if (is_target) deferred_seeds(df, seeds, n, k);
   // the number of deferred queries is only known on the device: `waves` one-wave workgroups share the list (each takes every
   // waves-th entry); the caller sizes it from the previous cloud of the sequence
@@ -4594,11 +4638,11 @@ void linearize(hipStream_t s, const float4* P, const double* nx, const double* n
   hipLaunchKernelGGL(k_fold<kAccum>, dim3(kAccum + 1), dim3(WAVE), 0, s, partials, nb, out28, ncorr_partials, out_ncorr);
 }
 // ---- the general covariance route ----
-void knn_cov6(hipStream_t s, const float4* P, const int* start, Grid g, int n, int k, int method, double* c6, const int* guard) {
+void knn_cov6(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, int method, double* c6, const int* guard) {
   const GenOut go{c6, method, n};
   const int waves = n < 16384 ? n : 16384;
-  if (k <= 20) hipLaunchKernelGGL(k_knn_cov6<20>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard);
-  else hipLaunchKernelGGL(k_knn_cov6<32>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard);
+  if (k <= 20) hipLaunchKernelGGL(k_knn_cov6<20>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard, is_target ? 0 : 1);
+  else hipLaunchKernelGGL(k_knn_cov6<32>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard, is_target ? 0 : 1);
 }
 void voxel_build_general(hipStream_t s, const float4* P, const double* c6, const int* start, Grid g, int n, const int* cell_voxel, double* vox,
                          int* vox_cell, int multiplicative, const int* guard) {
