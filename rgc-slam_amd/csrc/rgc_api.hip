@@ -771,7 +771,7 @@ int cloud_covariances(rgc_ctx* c, Cloud& cl, bool is_target) {
     const int* guard = cl.spec_used ? dsm + 6 : nullptr;
     {
       ProfScope ps(c, is_target ? RGC_K_KNN_COV : RGC_K_KNN_COV_SRC, n, s);
-      rgck::knn_cov6(s, is_target, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, c->reg_method, (double*)cl.c6.p, guard);
+      rgck::knn_cov6(s, (const float4*)cl.P.p, (const int*)cl.start.p, cl.grid, n, k, c->reg_method, (double*)cl.c6.p, guard);
     }
     if (is_target) {
       const size_t vmax = (size_t)(n < cl.grid.ncell ? n : cl.grid.ncell);

@@ -162,7 +162,7 @@ void linearize(hipStream_t s, const float4* P, const double* nx, const double* n
 // ---- the general covariance route (rgc_set_regularization_method other than PLANE, VoxelAccumulationMode::MULTIPLICATIVE): every point
 // through the cooperative search, a regularised 3x3 per point (c6: six doubles, SoA c6[a * n + i], sorted order) instead of a unit normal;
 // unoptimised by design.  method = rgc_regularization_method; guard (nullable): a tripped speculative-grid guard makes the kernels stand still
-void knn_cov6(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, int method, double* c6, const int* guard);
+void knn_cov6(hipStream_t s, const float4* P, const int* start, Grid g, int n, int k, int method, double* c6, const int* guard);
 void voxel_build_general(hipStream_t s, const float4* P, const double* c6, const int* start, Grid g, int n, const int* cell_voxel, double* vox,
                          int* vox_cell, int multiplicative, const int* guard);
 void linearize_general(hipStream_t s, const float4* P, const double* c6, int n, Pose T, Grid g, const int* cell_voxel, const double* vox, int noff,

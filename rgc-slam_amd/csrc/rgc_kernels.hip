@@ -880,10 +880,12 @@ struct Deferred {
   int coop_blocks;
   int* done;
   unsigned long long* slots;
-  // The order a neighbourhood's moments are summed in.  0 (a map: its grid is the voxel grid, whatever route prepares it): ascending
-  // position in the sorted array.  1 (a scan: the cell size of ITS grid follows the crowding of the context's previous scan, so positions
-  // are not a property of the cloud): ascending ORIGINAL index.  Either way the covariance is a function of the neighbour set alone.
-  int by_index;
+  // knn_point_split only (the four-lane search).  1, a SCAN: every lane sums the moments of its quarter of the neighbours, in key order, and
+  // the quad adds up (the scan's sorted order follows ITS grid, whose cell size follows the crowding of the context's previous scan:
+  // no order of a scan's neighbours is a property of the cloud alone).  0, a MAP that takes this search (the sparse-map launch): ascending
+  // position in the sorted array, the dense kernels' expression -- a map's grid is the voxel grid whichever route prepares it, and its
+  // covariances are the same bits through every one of them.
+  int split_sums;
 };
 constexpr unsigned long long kSlotEnd = 0x8080808080808081ull;    // "no entry will ever appear here": written behind the list by the last bulk workgroup
 constexpr unsigned long long kSlotEmpty = 0x8080808080808080ull;  // (what hipMemset can write; its low word is no valid entry: |enc| <= 2^27)
@@ -1157,6 +1159,23 @@ __device__ __forceinline__ int sp_piece_table(const int* __restrict__ start, con
   return nr;
 }
 
+// sums -> mean / covariance (fast_gicp_impl.hpp:256-262) -> unit normal of the smallest eigenvalue, stored: the tail every route shares
+__device__ __forceinline__ void normal_from_moments(double (&S)[6], double mx, double my, double mz, int k, int i, double* __restrict__ nx,
+                                                    double* __restrict__ ny, double* __restrict__ nz) {
+  const double inv_k = 1.0 / (double)k;
+  mx *= inv_k; my *= inv_k; mz *= inv_k;
+  S[0] = S[0] * inv_k - mx * mx; S[1] = S[1] * inv_k - mx * my; S[2] = S[2] * inv_k - mx * mz;
+  S[3] = S[3] * inv_k - my * my; S[4] = S[4] * inv_k - my * mz; S[5] = S[5] * inv_k - mz * mz;
+  double nrm[3];
+  if (!min_eigenvector_direct(S, nrm)) {
+    LAB_COUNT(4);
+    min_eigenvector(S, nrm);
+  }
+  nx[i] = nrm[0];
+  ny[i] = nrm[1];
+  nz[i] = nrm[2];
+}
+
 // Mean / covariance (fast_gicp_impl.hpp:256-262) / normal of query (px, py, pz) from its neighbours' positions idx[0 .. k) in the sorted
 // array.  One pass: with u_j = p_j - q (exact in fp64: both are fp32 values), cov = sum u u^T / k - ubar ubar^T -- the reference's
 // centred sum up to rounding (|u| <= a few cells, so nothing cancels badly), half the gathers of the two-pass form.
@@ -1188,19 +1207,9 @@ __device__ __forceinline__ void sp_normal_of(const float4* __restrict__ P, const
       S[3] = fma(dy, dy, S[3]); S[4] = fma(dy, dz, S[4]); S[5] = fma(dz, dz, S[5]);
     }
   }
-  const double inv_k = 1.0 / (double)k;
-  mx *= inv_k; my *= inv_k; mz *= inv_k;
-  S[0] = S[0] * inv_k - mx * mx; S[1] = S[1] * inv_k - mx * my; S[2] = S[2] * inv_k - mx * mz;
-  S[3] = S[3] * inv_k - my * my; S[4] = S[4] * inv_k - my * mz; S[5] = S[5] * inv_k - mz * mz;
-  double nrm[3];
-  if (!min_eigenvector_direct(S, nrm)) {
-    LAB_COUNT(4);
-    min_eigenvector(S, nrm);
-  }
-  nx[i] = nrm[0];
-  ny[i] = nrm[1];
-  nz[i] = nrm[2];
+  normal_from_moments(S, mx, my, mz, k, i, nx, ny, nz);
 }
+
 
 // The certificate of a query's neighbour list (KnnCache): a_up = upper bound of the k-th squared distance as computed in this frame,
 // b_lo = lower bound of the (k+1)-th candidate's, bound = distance to the nearest face of the block that is not a grid border (what the
@@ -2030,45 +2039,38 @@ __device__ __forceinline__ bool knn_point_split(const float4* __restrict__ P, co
       const int j = S * t + sub;
       all.a[t] = (swap && j == k - 1) ? idx_k : ((kFull || j < k) ? index_of(key) : INT_MAX);
     }
+    if (!df.split_sums) {
+      // a MAP (the sparse-map launch): every lane holds all the positions, ascending, and evaluates the dense kernels' expression -- the
+      // covariance is the same bits whether this search, the dense one or the cooperative kernel finds the neighbours (which one does
+      // depends on the grid's box, i.e. on the route the map came by)
+#pragma unroll
+      for (int t = 0; t < KC / S; t++) {
+        idx[S * t + 0] = quad_perm_i<0x00>(all.a[t]);
+        idx[S * t + 1] = quad_perm_i<0x55>(all.a[t]);
+        idx[S * t + 2] = quad_perm_i<0xAA>(all.a[t]);
+        idx[S * t + 3] = quad_perm_i<0xFF>(all.a[t]);
+      }
+      sort_positions<KC>(idx);
+      sp_normal_of<KC, kFull>(P, idx, px, py, pz, k, i, nx, ny, nz);  // (the four lanes store the same three values)
+      return;
+    }
+    // a SCAN: moments of neighbours sub, sub + 4, ... (in key order) in this lane, summed over the quad
+    double S6[6] = {0, 0, 0, 0, 0, 0}, m3[3] = {0, 0, 0};
+    const double qx = (double)px, qy = (double)py, qz = (double)pz;
 #pragma unroll
     for (int t = 0; t < KC / S; t++) {
-      idx[S * t + 0] = quad_perm_i<0x00>(all.a[t]);
-      idx[S * t + 1] = quad_perm_i<0x55>(all.a[t]);
-      idx[S * t + 2] = quad_perm_i<0xAA>(all.a[t]);
-      idx[S * t + 3] = quad_perm_i<0xFF>(all.a[t]);
+      const bool use = kFull || S * t + sub < k;
+      const float4 cp = P[use ? all.a[t] : 0];  // (unconditional: position 0 is a valid point; its terms are masked)
+      const double dx = use ? (double)cp.x - qx : 0.0, dy = use ? (double)cp.y - qy : 0.0, dz = use ? (double)cp.z - qz : 0.0;
+      m3[0] += dx; m3[1] += dy; m3[2] += dz;
+      S6[0] = fma(dx, dx, S6[0]); S6[1] = fma(dx, dy, S6[1]); S6[2] = fma(dx, dz, S6[2]);
+      S6[3] = fma(dy, dy, S6[3]); S6[4] = fma(dy, dz, S6[4]); S6[5] = fma(dz, dz, S6[5]);
     }
-    if (!df.by_index) {
-      sort_positions<KC>(idx);
-    } else {
-      // a SCAN: ascending original index (Deferred::by_index).  Every lane ranks its quarter among the keys of all four -- original indices
-      // are distinct; an unused slot j >= k gets a key above every index, in slot order -- leaves each position at its rank in the quad's
-      // four LDS columns (the append buffers: empty by now) and reads the whole row back.
-      int ow[KC / S], key[KC];
 #pragma unroll
-      for (int t = 0; t < KC / S; t++) ow[t] = all.a[t] != INT_MAX ? __float_as_int(P[all.a[t]].w) : INT_MAX - KC + (S * t + sub);
+    for (int a = 0; a < 3; a++) m3[a] = quad_sum_f64(m3[a]);
 #pragma unroll
-      for (int t = 0; t < KC / S; t++) {
-        key[S * t + 0] = quad_perm_i<0x00>(ow[t]);
-        key[S * t + 1] = quad_perm_i<0x55>(ow[t]);
-        key[S * t + 2] = quad_perm_i<0xAA>(ow[t]);
-        key[S * t + 3] = quad_perm_i<0xFF>(ow[t]);
-      }
-      lds_int* const qb = buf - sub;  // the column of the quad's first lane
-      static_assert((KC + S - 1) / S <= kSpBuf, "a row of KC positions across the quad's four append buffers");
-      wave_lds_fence();
-#pragma unroll
-      for (int t = 0; t < KC / S; t++) {
-        int rank = 0;
-#pragma unroll
-        for (int j = 0; j < KC; j++) rank += key[j] < ow[t];
-        qb[(rank >> 2) * T + (rank & 3)] = all.a[t];
-      }
-      wave_lds_fence();
-#pragma unroll
-      for (int j = 0; j < KC; j++) idx[j] = qb[(j >> 2) * T + (j & 3)];
-      wave_lds_fence();
-    }
-    sp_normal_of<KC, kFull>(P, idx, px, py, pz, k, i, nx, ny, nz);  // (the four lanes store the same three values)
+    for (int a = 0; a < 6; a++) S6[a] = quad_sum_f64(S6[a]);
+    normal_from_moments(S6, m3[0], m3[1], m3[2], k, i, nx, ny, nz);  // (the four lanes store the same three values)
   };
   if (kExact || k == KC) positions(std::true_type{});
   else positions(std::false_type{});
@@ -2345,14 +2347,10 @@ __device__ __forceinline__ void coop_one(const float4* __restrict__ P, const int
     // The neighbour SET is what the search decides; the order it was collected in depends on the cube the search ended on, hence on the
     // hint (thr) the bulk kernel passed.  The neighbours are put into ascending position in the sorted array: the sums below are then a
     // function of the set alone, whichever route deferred the query (knn_point_seeded passes other hints than knn_point_sp).
-    // (a scan -- Deferred::by_index -- : ascending ORIGINAL index instead, as knn_point_split does: its positions depend on the cell size)
     {
       const int mine = lane < k ? sh->nb[lane] : INT_MAX;
-      const int mkey = (df.by_index && lane < k) ? __float_as_int(P[mine].w) : mine;
-      if (lane < k) sh->rowa[lane] = mkey;   // (the search's row table: free by now)
-      wave_lds_fence();
       int rank = 0;
-      for (int j = 0; j < k; j++) rank += sh->rowa[j] < mkey;
+      for (int j = 0; j < k; j++) rank += sh->nb[j] < mine;
       wave_lds_fence();
       if (lane < k) sh->nb[rank] = mine;
       wave_lds_fence();
@@ -4046,11 +4044,10 @@ __device__ __forceinline__ void cov6_of(const float4* __restrict__ P, const int 
 // every point of a cloud through the cooperative search (a wave per query; wave w takes queries w, w + nwaves, ...)
 template <int KC>
 __global__ void __launch_bounds__(WAVE)
-k_knn_cov6(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, GenOut go, const int* __restrict__ guard, int by_index) {
+k_knn_cov6(const float4* __restrict__ P, const int* __restrict__ start, Grid g, int n, int k, GenOut go, const int* __restrict__ guard) {
   __shared__ CoopRows shm[1];
   if (guard && *guard) return;
   Deferred df{};
-  df.by_index = by_index;
   for (int e = (int)blockIdx.x; e < n; e += (int)gridDim.x)
     coop_one<KC, false, true>(P, start, g, k, df, nullptr, nullptr, nullptr, &shm[0], (int)threadIdx.x, e, e, INFINITY, go);
 }
@@ -4511,7 +4508,7 @@ static void knn_bulk_kc(hipStream_t s, bool is_target, const float4* P, const in
                         const int* qlist, const int* nq, int q_est, const KnnSeeds& seeds, int stream_coop_waves) {
   Deferred df = deferred_of(deferred, n);  // df.cnt was zeroed by k_rank_gather
   df.guard = guard;
-  df.by_index = is_target ? 0 : 1;
+  df.split_sums = is_target ? 0 : 1;
   df.qlist = qlist; df.nq = nq;
   // seeds: the map's dense search at k == KC only; `warm` = some search has written them (the seeded kernel is worth launching)
   const bool seeds_ok = is_target && kExact && wide_r != 2 && seeds.seed && n <= kSeedMaxPoints;
@@ -4567,7 +4564,6 @@ static void knn_coop_kc(hipStream_t s, bool is_target, const float4* P, const in
                         double* nx, double* ny, double* nz, const int* guard, int waves, const KnnSeeds& seeds) {
   Deferred df = deferred_of(segs, n);
   df.guard = guard;
-  df.by_index = is_target ? 0 : 1;
   if (is_target) deferred_seeds(df, seeds, n, k);
   // the number of deferred queries is only known on the device: `waves` one-wave workgroups share the list (each takes every
   // waves-th entry); the caller sizes it from the previous cloud of the sequence
@@ -4638,11 +4634,11 @@ void linearize(hipStream_t s, const float4* P, const double* nx, const double* n
   hipLaunchKernelGGL(k_fold<kAccum>, dim3(kAccum + 1), dim3(WAVE), 0, s, partials, nb, out28, ncorr_partials, out_ncorr);
 }
 // ---- the general covariance route ----
-void knn_cov6(hipStream_t s, bool is_target, const float4* P, const int* start, Grid g, int n, int k, int method, double* c6, const int* guard) {
+void knn_cov6(hipStream_t s, const float4* P, const int* start, Grid g, int n, int k, int method, double* c6, const int* guard) {
   const GenOut go{c6, method, n};
   const int waves = n < 16384 ? n : 16384;
-  if (k <= 20) hipLaunchKernelGGL(k_knn_cov6<20>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard, is_target ? 0 : 1);
-  else hipLaunchKernelGGL(k_knn_cov6<32>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard, is_target ? 0 : 1);
+  if (k <= 20) hipLaunchKernelGGL(k_knn_cov6<20>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard);
+  else hipLaunchKernelGGL(k_knn_cov6<32>, dim3(waves), dim3(WAVE), 0, s, P, start, g, n, k, go, guard);
 }
 void voxel_build_general(hipStream_t s, const float4* P, const double* c6, const int* start, Grid g, int n, const int* cell_voxel, double* vox,
                          int* vox_cell, int multiplicative, const int* guard) {
