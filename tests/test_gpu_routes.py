@@ -81,3 +81,14 @@ def test_fuzz_campaign(reg_mod):
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 60 and rep["failures"] == [], rep["failures"][:5]
     assert rep["solves"] >= 180 and rep["oracle_checks"] >= 20
+
+
+def test_fuzz_against_the_oracle(reg_mod):
+    """scripts/fuzz_oracle.py, a short campaign: whole registrations -- both covariance sets, the voxel table, a linearisation at the guess, the
+    solve's pose, the fitness -- against the oracle, on random clouds, k = 10 / 20 / 25, leaf 0.5 / 1 / 2 m and every RegularizationMethod /
+    VoxelAccumulationMode of the reference's interface."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_oracle.py"), "80", "21", "30000"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["trials"] == 80 and rep["failures"] == [], rep["failures"][:5]
+    assert rep["general_route_trials"] >= 5 and rep["max"]["dt"] <= 1e-4
