@@ -274,8 +274,15 @@ int orc_frontend(const float* in, int n, int stride, const orc_fe_params* prm, o
       }
       for (int a = 0; a < 9; a++) cov[a] /= gw;
       double ev[3], V[9];
-      orc_eig3(cov, ev, V);                   /* descending; SelfAdjointEigenSolver is ascending: col(0) = smallest */
-      double nrm[3] = {V[2], V[5], V[8]}, v1[3] = {V[1], V[4], V[7]}, v2[3] = {V[0], V[3], V[6]};
+      orc_eig3(cov, ev, V);                   /* descending, equal eigenvalues in their original order */
+      /* SelfAdjointEigenSolver sorts ASCENDING by selection (the first minimum of what is left moves to the front).  Where eigenvalues are
+       * distinct that is the reverse of the descending order; where they tie exactly -- a single ground point: the zero matrix, whose
+       * eigenvectors come out as the identity -- the tied columns keep their original order: col(0) = (1, 0, 0), not (0, 0, 1). */
+      int asc[3] = {2, 1, 0};
+      if (ev[0] == ev[1] && ev[1] == ev[2]) { asc[0] = 0; asc[1] = 1; asc[2] = 2; }
+      else if (ev[1] == ev[2]) { asc[0] = 1; asc[1] = 2; asc[2] = 0; }
+      else if (ev[0] == ev[1]) { asc[0] = 2; asc[1] = 0; asc[2] = 1; }
+      double nrm[3] = {V[asc[0]], V[3 + asc[0]], V[6 + asc[0]]}, v1[3] = {V[asc[1]], V[3 + asc[1]], V[6 + asc[1]]}, v2[3] = {V[asc[2]], V[3 + asc[2]], V[6 + asc[2]]};
       double nl = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
       for (int a = 0; a < 3; a++) nrm[a] /= nl;
       if (center[0] * nrm[0] + center[1] * nrm[1] + center[2] * nrm[2] < 0) for (int a = 0; a < 3; a++) nrm[a] = -nrm[a];

@@ -14,19 +14,22 @@ def _raw(n_az=1800, beams=16, seed=0, half=60.0, pose=None):
     return np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32)
 
 
-def _compare(fe, orc, raw, n_scans):
+def _compare(fe, orc, raw, n_scans, time_outliers=0):
+    """time_outliers: how many points may carry another multiple of the sweep's period in their encoded time.  A sweep in firing order: none.
+    A SHUFFLED sweep has points at every azimuth on either side of the flag's flip, a few of them within an ulp of a wrap threshold
+    (:189-203), and atan2f is an ulp apart between the two libraries: one point in twenty thousand takes the other branch."""
     g = fe.laserCloudHandler(raw)
     o = orc.frontend(raw, n_scans=n_scans)
     assert g["n_cloud"] == o["n_cloud"] and np.array_equal(g["ring_count"], o["ring_count"])
     assert np.array_equal(g["cloud"][:, :3], o["cloud"][:, :3])                    # A1/A2: same points in the same ring-major order
-    assert g["n_cloud"] == 0 or np.abs(g["cloud"][:, 3] - o["cloud"][:, 3]).max() < 8e-6               # ring + 0.1*relTime (atan2f differs by an ulp)
+    assert g["n_cloud"] == 0 or int(np.sum(np.abs(g["cloud"][:, 3] - o["cloud"][:, 3]) >= 8e-6)) <= time_outliers   # ring + 0.1*relTime (atan2f differs by an ulp)
     for k in ("curvature", "curvature2", "inten_curvature"):                       # A3/A4: same fp32 stencils, bit for bit
         assert np.array_equal(g[k], o[k]), (k, np.abs(g[k] - o[k]).max())
     for k in ("ground_marked", "picked", "label", "inten_label"):                  # A5/A6/A7 decisions
         assert np.array_equal(g[k], o[k]), (k, int(np.sum(g[k] != o[k])))
     for k in ("sharp", "flat", "inten"):                                           # A8 feature clouds, reference order
         assert g[k].shape == o[k].shape, (k, g[k].shape, o[k].shape)
-        assert np.array_equal(g[k][:, :3], o[k][:, :3]) and (len(g[k]) == 0 or np.abs(g[k][:, 3:] - o[k][:, 3:]).max() < 8e-6)
+        assert np.array_equal(g[k][:, :3], o[k][:, :3]) and (len(g[k]) == 0 or int(np.sum(np.abs(g[k][:, 3:] - o[k][:, 3:]).max(axis=1) >= 8e-6)) <= time_outliers)
     assert g["n_sharp_own"] == o["n_sharp_own"]
     assert g["n_ground"] == len(o["ground_pts"]) and np.array_equal(g["ground_pts"][:, :3], o["ground_pts"][:, :3])
     assert g["ground_valid"] == o["ground_valid"]

@@ -92,3 +92,14 @@ def test_fuzz_against_the_oracle(reg_mod):
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 80 and rep["failures"] == [], rep["failures"][:5]
     assert rep["general_route_trials"] >= 5 and rep["max"]["dt"] <= 1e-4
+
+
+def test_fuzz_of_the_stages_in_front(reg_mod):
+    """scripts/fuzz_pre.py, a short campaign: the front-end (16 / 32 / 64 beams; points dropped, NaNs, shuffled firing order, truncated,
+    out of range), the leaf filter through one object (sweeps, noise, lattices on leaf boundaries, NaNs refused), de-skew and re-framing --
+    against the oracle, stage by stage."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_pre.py"), "60", "31"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["trials"] == 60 and rep["failures"] == [], rep["failures"][:5]
+    assert rep["frontend"] >= 55 and rep["voxelgrid"] == 60 and rep["max"]["deskew"] <= 4e-6
