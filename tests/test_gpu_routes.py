@@ -103,3 +103,14 @@ def test_fuzz_of_the_stages_in_front(reg_mod):
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 60 and rep["failures"] == [], rep["failures"][:5]
     assert rep["frontend"] >= 55 and rep["voxelgrid"] == 60 and rep["max"]["deskew"] <= 4e-6
+
+
+def test_fuzz_of_the_frame_body(reg_mod):
+    """scripts/fuzz_sequence.py, a short campaign: random worlds, trajectories (some up a ramp), azimuth counts, with and without the IMU path --
+    the frame body on the library against the same frame body on the oracle's stages, frame by frame: 1e-4 m / 1e-4 rad until a solve runs
+    out of iterations or stops an iteration apart on the two sides (a flat valley: both ends are as good), 2e-3 from there on."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_sequence.py"), "12", "41", "8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["trials"] == 12 and rep["failures"] == [], rep["failures"][:5]
+    assert rep["frames"] == 96 and rep["max"]["dt_strict"] <= 1e-4
