@@ -114,3 +114,16 @@ def test_fuzz_of_the_frame_body(reg_mod):
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 12 and rep["failures"] == [], rep["failures"][:5]
     assert rep["frames"] == 96 and rep["max"]["dt_strict"] <= 1e-4
+
+
+def test_fuzz_of_the_resident_map_and_the_next_rows(reg_mod):
+    """scripts/fuzz_map.py (f2: random insert / evict / rebase / commit sequences, stored points and committed target bit for bit with the
+    oracle's composition) and scripts/fuzz_next_rows.py (f4 loop-closure ICP, f1 mapping-node feature registration), short campaigns."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_map.py"), "25", "51", "25"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["trials"] == 25 and rep["failures"] == [] and rep["commits_compared"] >= 60, rep["failures"][:5]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_next_rows.py"), "40", "4", "61"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["icp_trials"] == 40 and rep["mapreg_trials"] == 4 and rep["failures"] == [], rep["failures"][:5]
