@@ -934,11 +934,15 @@ int complete_target(rgc_ctx* c) {
   return RGC_OK;
 }
 
+// between rgc_align_begin and rgc_align_end -- on the general route too, where the solve has already run and its result waits to be handed over:
+// the same calls are refused on both routes
+static inline bool solve_in_flight(const rgc_ctx* c) { return c->pend.active || c->gen_res.on; }
+
 // rf (nullable, device clouds only): xyz has not been written yet -- the preparation produces it from rf (rgc_set_target_reframed)
 int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, int stride_bytes, bool on_device, const rgck::Reframe* rf = nullptr) {
   if (!c) return RGC_ERR_INVALID;
   cl.reframe_pending = false;
-  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   cl.ready = false;
   cl.n = 0;
   c->corr_valid = false;
@@ -1037,6 +1041,7 @@ int resolve_guards(rgc_ctx* c, int guard_t, int guard_s) {
   for (int a = 0; a < 2; a++) {
     if (!cl[a]->spec_used) continue;
     cl[a]->spec_used = false;
+    if (!cl[a]->ready || cl[a]->n <= 0) continue;  // (a cloud cleared since -- rgc_clear_source / _target --: its guard word is the last cloud's, there is nothing to prepare again)
     if (!gd[a]) continue;
     cl[a]->ready = false;
     c->corr_valid = false;
@@ -1079,16 +1084,21 @@ int check_target_owner(rgc_ctx* c) {
 
 // for every consumer except rgc_align (which gets the guards with its state read-back): one synchronisation, once per cloud
 int validate_clouds(rgc_ctx* c, bool whole_target = true) {
-  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   { int rc = check_target_owner(c); if (rc) return rc; }
+  // The guards FIRST: a lazy target whose speculative grid did not hold must be prepared again on its own box BEFORE it is completed -- the
+  // completion's kernels leave at once on a tripped guard, and the re-preparation behind it would put back an unbuilt lazy target that
+  // nobody completes any more (a target replaced while a scan is set, then read through a getter: scripts/fuzz_api.py found it).
+  if ((c->tgt.ready && c->tgt.spec_used) || (c->src.ready && c->src.spec_used)) {
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    HIPCHK(c, hipMemcpyAsync(c->h_small + 6, c->d_small + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_small + 22, c->d_small + 22, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int r = resolve_guards(c, c->tgt.spec_used ? c->h_small[6] : 0, c->src.spec_used ? c->h_small[22] : 0);
+    if (r < 0) return r;
+  }
   if (whole_target) { int rc = complete_target(c); if (rc) return rc; }  // (lazy target: whoever comes this way reads covariances or voxels the solve may not have needed)
-  if (!((c->tgt.ready && c->tgt.spec_used) || (c->src.ready && c->src.spec_used))) return RGC_OK;
-  HIPCHK(c, hipStreamSynchronize(c->stream2));
-  HIPCHK(c, hipMemcpyAsync(c->h_small + 6, c->d_small + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_small + 22, c->d_small + 22, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  const int r = resolve_guards(c, c->tgt.spec_used ? c->h_small[6] : 0, c->src.spec_used ? c->h_small[22] : 0);
-  return r < 0 ? r : RGC_OK;
+  return RGC_OK;
 }
 
 int need_inputs(rgc_ctx* c, bool validate = true) {
@@ -1691,7 +1701,7 @@ int rgc_share_target(rgc_ctx* c, rgc_ctx* owner) {
 int rgc_set_target_lazy(rgc_ctx* c, int margin_cells) {
   if (!c) return RGC_ERR_INVALID;
   if (margin_cells < 0 || margin_cells > 16) return fail(c, RGC_ERR_INVALID, "rgc_set_target_lazy: margin_cells must be in [0, 16]");
-  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   c->lazy_margin = margin_cells;  // (takes effect with the next target; one already set keeps the state it is in)
   return RGC_OK;
 }
@@ -1700,7 +1710,7 @@ int rgc_set_regularization_method(rgc_ctx* c, int method) {
   if (!c) return RGC_ERR_INVALID;
   if (method < RGC_REG_NONE || method > RGC_REG_FROBENIUS) return fail(c, RGC_ERR_INVALID, "rgc_set_regularization_method: %d is not a RegularizationMethod", method);
   if (method != c->reg_method) {  // the covariances of the clouds set so far were computed under the other method (the reference computes them at align())
-    if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+    if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
     c->src.ready = c->tgt.ready = false; c->corr_valid = false; c->deferred_known = false; c->map_bound = false;
   }
   c->reg_method = method;
@@ -1712,7 +1722,7 @@ int rgc_set_voxel_accumulation_mode(rgc_ctx* c, int mode) {
   if (mode < RGC_VOXEL_ADDITIVE || mode > RGC_VOXEL_MULTIPLICATIVE) return fail(c, RGC_ERR_INVALID, "rgc_set_voxel_accumulation_mode: %d is not a VoxelAccumulationMode", mode);
   const bool was = c->voxel_mode == RGC_VOXEL_MULTIPLICATIVE, is = mode == RGC_VOXEL_MULTIPLICATIVE;
   if (was != is) {  // (ADDITIVE <-> ADDITIVE_WEIGHTED changes nothing: one voxel class in the vendored FastVGICP, fast_vgicp_voxel.hpp:137-141)
-    if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+    if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
     c->src.ready = c->tgt.ready = false; c->corr_valid = false; c->deferred_known = false; c->map_bound = false;
   }
   c->voxel_mode = mode;
@@ -1722,7 +1732,7 @@ int rgc_set_voxel_accumulation_mode(rgc_ctx* c, int mode) {
 int rgc_set_knn_reuse(rgc_ctx* c, int mode) {
   if (!c) return RGC_ERR_INVALID;
   if (mode < RGC_REUSE_NONE || mode > RGC_REUSE_LISTS) return fail(c, RGC_ERR_INVALID, "rgc_set_knn_reuse: mode must be RGC_REUSE_NONE, _SEEDS or _LISTS");
-  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   const bool seeds = mode >= RGC_REUSE_SEEDS && RGC_KNN_SEEDS != 0, lists = seeds && mode >= RGC_REUSE_LISTS && RGC_KNN_CACHE != 0;
   Cloud& cl = c->tgt;
   if ((!lists && cl.nbr.p) || (!seeds && cl.seed.p)) {  // buffers this context no longer needs: nothing may still be reading them
@@ -1849,6 +1859,7 @@ static int lm_enqueue_batch(rgc_ctx* c, int batch, const rgck::LmInit* open, boo
 // rgc_align_end waits for it (and enqueues further batches if the solve needs more than six outer iterations).
 int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
   if (!c || !guess) return RGC_ERR_INVALID;
+  if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   if (general_route(c)) {  // no asynchronous form on the general route: the solve runs now, rgc_align_end hands its result over
     auto& g = c->gen_res;
     g.on = false;
@@ -2275,14 +2286,14 @@ int rgc_set_target_covariances(rgc_ctx* c, const double* cov9, int n) { return c
 // pcl::Registration / FastGICP::clearSource, clearTarget (fast_gicp_impl.hpp:60-69): the cloud and its covariances are dropped
 int rgc_clear_source(rgc_ctx* c) {
   if (!c) return RGC_ERR_INVALID;
-  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
-  c->src.ready = false; c->src.n = 0; c->corr_valid = false; c->deferred_known = false;
+  if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  c->src.ready = false; c->src.n = 0; c->src.spec_used = false; c->corr_valid = false; c->deferred_known = false;
   return RGC_OK;
 }
 int rgc_clear_target(rgc_ctx* c) {
   if (!c) return RGC_ERR_INVALID;
-  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
-  c->tgt.ready = false; c->tgt.n = 0; c->corr_valid = false; c->deferred_known = false; c->map_bound = false;
+  if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  c->tgt.ready = false; c->tgt.n = 0; c->tgt.spec_used = false; c->corr_valid = false; c->deferred_known = false; c->map_bound = false;
   return RGC_OK;
 }
 
@@ -2482,7 +2493,7 @@ static int reframe_args_ok(rgc_ctx* c, const float* d_xyzi, int n, int stride_by
 
 int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, const double q[4], const double t[3], float* d_scratch) {
   if (!c || !q || !t) return RGC_ERR_INVALID;
-  if (c->pend.active) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
+  if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   {
     const int rc = reframe_args_ok(c, d_xyzi, n, stride_bytes, d_scratch);
     if (rc) return rc;
@@ -2544,7 +2555,7 @@ int rgc_align_end_reframe(rgc_ctx* c, rgc_ctx* next, double Tw[16], const float*
   // allocation failure inside the preparation, with the solve's outputs and Tw already valid (the message says which call failed).
   if (next != c) {
     if (!ctx_alive(next)) return fail(c, RGC_ERR_INVALID, "rgc_align_end_reframe: the next context is not alive");
-    if (next->pend.active) return fail(c, RGC_ERR_INVALID, "rgc_align_end_reframe: a solve is in flight on the next context");
+    if (solve_in_flight(next)) return fail(c, RGC_ERR_INVALID, "rgc_align_end_reframe: a solve is in flight on the next context");
   }
   if (!c->pend.active && !c->gen_res.on) return fail(c, RGC_ERR_INVALID, "rgc_align_end without rgc_align_begin");
   {

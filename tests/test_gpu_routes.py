@@ -127,3 +127,92 @@ def test_fuzz_of_the_resident_map_and_the_next_rows(reg_mod):
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["icp_trials"] == 40 and rep["mapreg_trials"] == 4 and rep["failures"] == [], rep["failures"][:5]
+
+
+def test_lazy_target_replaced_before_any_solve(reg_mod):
+    """Found by scripts/fuzz_api.py: a lazy target A, a scan, a lazy target B that leaves A's (speculative) grid, then a getter.  The getter
+    used to complete B first -- the completion's kernels leave at once on the tripped guard -- and resolve the guard second, which put an
+    UNBUILT lazy target back: every covariance it returned was stale.  Guards first now (validate_clouds)."""
+    import rgc_slam_amd.synth as synth
+    world, base = synth.make_world_and_map(20000, seed=5)
+    base = base.astype(np.float32)
+    A, B = base[:5245], base[3000:11368]
+    src = B[::3][:1500] + np.float32(0.02)
+    w = reg_mod.odometer_vgicp(0)
+    w.setInputTarget(B)
+    full, fullv = w.getTargetCovariances(), w.getVoxels()
+    w.setInputSource(src)
+    w.align(np.eye(4, dtype=np.float32), want_output=False, want_fitness=True)
+    for getter in ("covariances", "voxels", "solve"):
+        v = reg_mod.odometer_vgicp(0)
+        v.setLazyTarget(3)
+        v.setInputTarget(A); v.setInputSource(src); v.setInputTarget(B)
+        if getter == "covariances":
+            assert np.array_equal(v.getTargetCovariances(), full)
+        elif getter == "voxels":
+            x = v.getVoxels()
+            ka, kb = np.lexsort(x["coords"].T[::-1]), np.lexsort(fullv["coords"].T[::-1])
+            assert all(np.array_equal(x[k][ka], fullv[k][kb]) for k in ("coords", "num", "mean", "cov"))
+        else:
+            v.align(np.eye(4, dtype=np.float32), want_output=False, want_fitness=True)
+            assert np.array_equal(v.getFinalTransformation(), w.getFinalTransformation()) and v.getFitnessScore() == w.getFitnessScore()
+        v.close()
+    w.close()
+
+
+def test_a_solve_in_flight_is_one_on_either_route(reg_mod):
+    """rgc_align_begin on the general route runs the solve at once and keeps its result for rgc_align_end; until then the context refuses
+    what it refuses with a solve in flight on the tuned route (scripts/fuzz_api.py: it used to accept new clouds, and a later
+    rgc_align_end then found nothing)."""
+    import rgc_slam_amd.synth as synth
+    world, tgt = synth.make_world_and_map(15000, seed=9)
+    tgt = tgt.astype(np.float32)
+    src = tgt[::5][:2000] + np.float32(0.03)
+    for method in (reg_mod.FastVGICP.REG_PLANE, reg_mod.FastVGICP.REG_MIN_EIG):
+        v = reg_mod.odometer_vgicp(0)
+        v.setRegularizationMethod(method)
+        v.setInputTarget(tgt); v.setInputSource(src)
+        v.align_begin(np.eye(4, dtype=np.float32))
+        for refused in (lambda: v.setInputSource(src), lambda: v.setInputTarget(tgt), lambda: v.align_begin(np.eye(4, dtype=np.float32)),
+                        lambda: v.align(np.eye(4, dtype=np.float32), want_output=False), lambda: v.clearSource(), lambda: v.setLazyTarget(2),
+                        lambda: v.getTargetCovariances()):
+            with pytest.raises(reg_mod.RgcError):
+                refused()
+        T = v.align_end()
+        with pytest.raises(reg_mod.RgcError):
+            v.align_end()
+        v.align(np.eye(4, dtype=np.float32), want_output=False)
+        assert np.array_equal(T, v.getFinalTransformation())
+        v.close()
+
+
+def test_a_cleared_cloud_leaves_no_guard_behind(reg_mod):
+    """Found by scripts/fuzz_api.py: a scan prepared on a speculative grid, rgc_clear_source, then a getter of the target: the cleared scan's
+    stale guard made the library prepare it "again" -- zero points, a launch of zero workgroups, RGC_ERR_HIP out of a getter."""
+    import rgc_slam_amd.synth as synth
+    world, base = synth.make_world_and_map(30000, seed=5)
+    base = base.astype(np.float32)
+    v = reg_mod.odometer_vgicp(0)
+    v.setInputTarget(base[:20000])
+    v.setInputSource(base[100:3000])            # measures its box
+    v.setInputSource(base[20000:26000] + np.float32([40.0, 0, 0]))   # takes the previous grid speculatively -- and leaves it
+    v.clearSource()
+    v.setInputTarget(base[5000:21000])          # (the target's own grid is speculative too: the getter below goes through the guards)
+    c = v.getTargetCovariances()
+    w = reg_mod.odometer_vgicp(0)
+    w.setInputTarget(base[5000:21000])
+    assert np.array_equal(c, w.getTargetCovariances())
+    v.clearTarget()
+    v.setInputSource(base[100:3000])
+    assert len(v.getSourceCovariances()) == 2900
+    v.close(); w.close()
+
+
+def test_fuzz_of_the_call_sequences(reg_mod):
+    """scripts/fuzz_api.py, a short campaign: random sequences of the registration's calls against a model of what must work and what must be
+    refused, every solve against a fresh context's."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_api.py"), "40", "71", "40"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["trials"] == 40 and rep["failures"] == [], rep["failures"][:5]
+    assert rep["solves_compared"] >= 40 and rep["refusals_expected"] >= 200
