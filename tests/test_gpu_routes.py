@@ -216,3 +216,12 @@ def test_fuzz_of_the_call_sequences(reg_mod):
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 40 and rep["failures"] == [], rep["failures"][:5]
     assert rep["solves_compared"] >= 40 and rep["refusals_expected"] >= 200
+
+
+def test_fuzz_of_the_message_layouts(reg_mod):
+    """scripts/fuzz_wire.py: PointCloud2 unpacking against numpy's structured dtypes over random layouts (steps, offsets, every datatype for
+    every field, both byte orders, strict / converting), pack -> unpack round trips, bad layouts refused."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_wire.py"), "600", "81"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["trials"] == 600 and rep["failures"] == [] and rep["refused_as_expected"] == 3 and rep["round_trips"] == 120, rep["failures"][:5]
