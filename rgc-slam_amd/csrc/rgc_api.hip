@@ -3487,11 +3487,18 @@ int rgc_map_commit(rgc_ctx* c, float leaf, int* n_target) {
     if (n_target) *n_target = c->map_ntarget;
     return RGC_OK;
   }
+  // (before anything is written: the filter below writes the buffer the resident target was set from -- a commit refused behind it would
+  // leave a set target whose input has been overwritten, and rgc_map_download(1) returning another cloud; scripts/fuzz_api.py)
+  if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   if (!c->map_n) return fail(c, RGC_ERR_NO_INPUT, "the map holds no keyframe");
   int rc = ensure(c, c->map_target, c->map_n * 16);
   if (rc) return rc;
   int nt = 0;
   // downSizeFilter2.setInputCloud(laserCloudsubmap); filter (:985-991) -- on the resident store, nothing crosses PCIe
+  if (c->map_bound) {  // from here on the buffer no longer holds the cloud the bound target was set from: whatever fails below, that target goes
+    c->map_bound = false;
+    c->tgt.ready = false; c->tgt.n = 0; c->corr_valid = false;
+  }
   if ((rc = rgc_voxelgrid(c, (const float*)c->map_store[c->map_cur].p, (int)c->map_n, 16, leaf, (float*)c->map_target.p, &nt, 1))) return rc;
   // setInputTarget (:1007): grid, exact-kNN covariances, Gaussian voxel map
   if ((rc = set_cloud(c, c->tgt, true, (const float*)c->map_target.p, nt, 16, true))) return rc;

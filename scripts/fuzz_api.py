@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import rgc_slam_amd.synth as synth
-from rgc_slam_amd import registration as reg, _lib
+from rgc_slam_amd import registration as reg, local_map, _lib
 import bench
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
@@ -46,6 +46,9 @@ for trial in range(trials):
     v = reg.odometer_vgicp(0)
     other = reg.odometer_vgicp(0)
     m = Model()
+    lm = local_map.RollingLocalMap(v)   # f2: the map resident on the device commits its target INTO this context (rgc_map_commit)
+    lm.reset(None)
+    n_in_map = 0
     nmax = len(base)
     bufs = []   # a device cloud belongs to the caller and must stay as it is while it is set (the library re-reads it when a speculative grid did not
                 # hold, on a swap ...): every device cloud of the campaign gets a buffer of its own, freed at the trial's end
@@ -81,7 +84,7 @@ for trial in range(trials):
     try:
         for op_i in range(n_ops):
             op = str(rng.choice(["tgt_host", "tgt_dev", "tgt_reframed", "src_host", "src_dev", "align", "align", "begin", "end", "setting", "lazy", "reuse",
-                                 "getters", "swap", "clear_src", "clear_tgt", "share", "set_cov"]))
+                                 "getters", "swap", "clear_src", "clear_tgt", "share", "set_cov", "map_insert", "map_commit", "map_evict"]))
             tag.update(op=op, op_i=op_i)
             rep["operations"][op] = rep["operations"].get(op, 0) + 1
             if only is not None:
@@ -219,6 +222,36 @@ for trial in range(trials):
                             rep["solves_bit_equal"] += int(np.array_equal(other.getFinalTransformation(), exp[0]))
                             if not dT <= (1e-6 if other.nr_iterations == exp[1] else 2e-4):
                                 rep["failures"].append(dict(tag, error="solve on a shared target differs", dT=dT))
+            elif op == "map_insert":
+                c = new_cloud(lo=300)[: int(rng.integers(200, 6000))]
+                a = np.zeros((len(c), 4), np.float32); a[:, :3] = c
+                th = rng.normal(0, 0.05)
+                q = np.array([0, 0, np.sin(th / 2), np.cos(th / 2)])
+                _, ok = expect(True, lambda: lm.insert(a, q, rng.normal(0, 0.5, 3) * np.array([1, 1, 0.05])), op)   # (the store is not the target: allowed with a solve in flight)
+                n_in_map += int(ok)
+            elif op == "map_evict":
+                _, ok = expect(True, lambda: lm.evict(int(rng.integers(1, 4))), op)
+                if ok: n_in_map = min(n_in_map, 3)
+            elif op == "map_commit":
+                if n_in_map == 0 or m.stale_settings or m.lazy:
+                    continue
+                leaf = float(rng.choice([0.3, 0.5]))
+                if m.pending:   # (a commit of an unchanged, still bound map is a no-op and may pass; anything that would touch the target must be refused)
+                    try:
+                        lm.commit(leaf)
+                        if not np.array_equal(lm.target()[:, :3], m.tgt):
+                            rep["failures"].append(dict(tag, error="a commit changed the target under a solve in flight"))
+                            if only is not None:
+                                t_now = lm.target()
+                                print("commit in flight: leaf", leaf, "target now", t_now.shape, "model", m.tgt.shape, "same prefix", np.array_equal(t_now[:10, :3], m.tgt[:10]), file=sys.stderr)
+                                print("info", lm.info(), file=sys.stderr)
+                    except _lib.RgcError:
+                        rep["refusals_expected"] += 1
+                    continue
+                r, ok = expect(True, lambda: lm.commit(leaf), op)
+                if ok:
+                    m.tgt = lm.target()[:, :3].copy()
+                    if r != len(m.tgt): rep["failures"].append(dict(tag, error="commit's count and the target's differ"))
             elif op == "set_cov":
                 if m.pending or m.stale_settings or m.tgt is None:
                     continue

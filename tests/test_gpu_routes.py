@@ -208,10 +208,39 @@ def test_a_cleared_cloud_leaves_no_guard_behind(reg_mod):
     v.close(); w.close()
 
 
+def test_a_refused_commit_writes_nothing(reg_mod):
+    """Found by scripts/fuzz_api.py: rgc_map_commit with a solve in flight ran its leaf filter INTO the buffer the resident target had been set
+    from and was refused only behind it (by the target's setter): the bound target kept a rewritten input, rgc_map_download(1) returned
+    another cloud.  Refused before anything is written now."""
+    import rgc_slam_amd.synth as synth
+    from rgc_slam_amd import local_map
+    world, base = synth.make_world_and_map(20000, seed=5)
+    base = base.astype(np.float32)
+    v = reg_mod.odometer_vgicp(0)
+    lm = local_map.RollingLocalMap(v)
+    lm.reset(None)
+    for k in range(3):
+        a = np.zeros((3000, 4), np.float32); a[:, :3] = base[k * 3000:(k + 1) * 3000]
+        lm.insert(a, np.array([0, 0, 0, 1.0]), np.zeros(3))
+    n0 = lm.commit(0.3)
+    t0 = lm.target().copy()
+    v.setInputSource(base[:2000] + np.float32(0.02))
+    v.align_begin(np.eye(4, dtype=np.float32))
+    with pytest.raises(reg_mod.RgcError):
+        lm.commit(0.5)                                   # another leaf: a real commit -- refused, and nothing written
+    assert lm.commit(0.3) == n0                          # the unchanged map at the same leaf: a no-op, allowed
+    assert np.array_equal(lm.target(), t0)
+    T = v.align_end()
+    v.align(np.eye(4, dtype=np.float32), want_output=False)
+    assert np.array_equal(T, v.getFinalTransformation())
+    assert lm.commit(0.5) != n0 and not np.array_equal(lm.target()[:100], t0[:100])
+    v.close()
+
+
 def test_fuzz_of_the_call_sequences(reg_mod):
     """scripts/fuzz_api.py, a short campaign: random sequences of the registration's calls against a model of what must work and what must be
     refused, every solve against a fresh context's."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_api.py"), "40", "71", "40"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_api.py"), "40", "71", "45"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 40 and rep["failures"] == [], rep["failures"][:5]
