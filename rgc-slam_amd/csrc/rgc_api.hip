@@ -503,6 +503,9 @@ int prepare_cloud(rgc_ctx* c, Cloud& cl, bool is_target, bool force_bbox = false
     const double res = is_target ? c->prm.voxel_res : (c->src_res > 0.0 ? c->src_res : (c->src_res_auto > 0.0 ? c->src_res_auto : c->prm.voxel_res));
     bool spec = c->spec_on && !c->lm_host && cl.spec_ok && cl.spec_grid.res == res && !force_bbox;
     const rgc_ctx::BoxHint* hint = (is_target && c->spec_on && !c->lm_host && !force_bbox) ? find_hint(c, cl.in, n) : nullptr;
+    if (hint)  // (a box that is not one -- it was derived from a pose that was not finite -- is no hint: the float -> int conversions below are undefined on it)
+      for (int a = 0; a < 3; a++)
+        if (!(std::isfinite(hint->lo[a]) && std::isfinite(hint->hi[a]) && hint->hi[a] >= hint->lo[a] && std::fabs(hint->lo[a]) <= 1.0e8 && std::fabs(hint->hi[a]) <= 1.0e8)) { hint = nullptr; break; }
     rgck::Grid g{};
     if (hint) {  // the box is known (rgc_set_target_reframed / rgc_transform_cloud): its cells plus one on every side, guarded like a speculative grid
       int lo[3], dm[3];
@@ -2497,6 +2500,14 @@ int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_b
   {
     const int rc = reframe_args_ok(c, d_xyzi, n, stride_bytes, d_scratch);
     if (rc) return rc;
+  }
+  // a pose that is not a pose -- the NaN a diverged solve hands on through rgc_align_end_reframe, a zero quaternion -- has no box to derive a
+  // grid from (the float -> int conversions behind it are undefined: scripts/fuzz_api.py saw a 40-petabyte allocation request)
+  {
+    const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (!(std::isfinite(qq) && qq > 1.0e-12 && qq < 1.0e12 && std::isfinite(t[0]) && std::isfinite(t[1]) && std::isfinite(t[2]) &&
+          std::fabs(t[0]) <= 1.0e8 && std::fabs(t[1]) <= 1.0e8 && std::fabs(t[2]) <= 1.0e8))
+      return fail(c, RGC_ERR_NONFINITE, "rgc_set_target_reframed: the pose (q, t) is not finite");
   }
   HIPCHK(c, hipSetDevice(c->device));
   const float* xyzi = d_xyzi;

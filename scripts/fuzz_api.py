@@ -84,7 +84,7 @@ for trial in range(trials):
     try:
         for op_i in range(n_ops):
             op = str(rng.choice(["tgt_host", "tgt_dev", "tgt_reframed", "src_host", "src_dev", "align", "align", "begin", "end", "setting", "lazy", "reuse",
-                                 "getters", "swap", "clear_src", "clear_tgt", "share", "set_cov", "map_insert", "map_commit", "map_evict"]))
+                                 "getters", "swap", "clear_src", "clear_tgt", "share", "set_cov", "map_insert", "map_commit", "map_evict", "end_reframe"]))
             tag.update(op=op, op_i=op_i)
             rep["operations"][op] = rep["operations"].get(op, 0) + 1
             if only is not None:
@@ -169,7 +169,7 @@ for trial in range(trials):
                 elif which == 2: m.method = int(rng.integers(0, 5)); v.setRegularizationMethod(m.method)
                 else: m.mode = int(rng.integers(0, 3)); v.setVoxelAccumulationMode(m.mode)
                 m.stale_settings = True
-                m.lazy_off = True
+                other.setResolution(m.res); other.setCorrespondenceRandomness(m.k); other.setRegularizationMethod(m.method); other.setVoxelAccumulationMode(m.mode)
             elif op == "lazy":
                 if m.pending:
                     continue
@@ -252,6 +252,55 @@ for trial in range(trials):
                 if ok:
                     m.tgt = lm.target()[:, :3].copy()
                     if r != len(m.tgt): rep["failures"].append(dict(tag, error="commit's count and the target's differ"))
+            elif op == "end_reframe":
+                # rgc_align_end_reframe: collect v's solve, compose the world pose, and enqueue the NEXT target -- a world map re-expressed in the new
+                # body frame -- on `other`.  All or nothing for the caller's arguments: refused without a solve in flight (nothing happens).
+                wm = new_cloud(lo=2000)
+                aw = np.zeros((len(wm), 4), np.float32); aw[:, :3] = wm
+                d_w, d_s = dev(aw), dev(nbytes=aw.nbytes)
+                Tw = synth.se3(synth.rot_zyx(rng.uniform(-np.pi, np.pi), 0.01, -0.01), rng.uniform(-10, 10, 3) * np.array([1, 1, 0.02])).astype(np.float64).copy()
+                Tw0 = Tw.copy()
+                was_pending = m.pending
+                try:
+                    r = v.align_end_reframe(other, Tw, d_w, len(wm), 16, d_s); ok = True
+                    if not m.pending:
+                        rep["failures"].append(dict(tag, error="worked, should have been refused: end_reframe"))
+                except _lib.RgcError as e:
+                    ok = False
+                    if m.pending and "not finite" in str(e):   # the solve ended in NaN (a degenerate problem): its result has been handed over, the next
+                        m.pending = False                      # target -- a map re-framed by a pose that is none -- is refused
+                        rep["refusals_expected"] += 1
+                        rep["nan_poses_refused"] = rep.get("nan_poses_refused", 0) + 1
+                        if np.all(np.isfinite(v.getFinalTransformation() if hasattr(v, "_final") else np.zeros(1))):
+                            pass
+                    elif m.pending:
+                        rep["failures"].append(dict(tag, error="refused, should have worked: end_reframe: %s" % (str(e)[:160],)))
+                    else:
+                        rep["refusals_expected"] += 1
+                if ok:
+                    m.pending = False
+                    exp = fresh_solve(m, m.pending_guess)
+                    rep["solves_compared"] += 1
+                    if np.all(np.isfinite(exp[0])) and np.all(np.isfinite(r)):
+                        dT = float(np.abs(r - exp[0]).max())
+                        rep["max_dT"] = max(rep["max_dT"], dT)
+                        rep["solves_bit_equal"] += int(np.array_equal(r, exp[0]))
+                        if not dT <= (1e-6 if v.nr_iterations == exp[1] else 2e-4):
+                            rep["failures"].append(dict(tag, error="end_reframe's solve differs from a fresh context's", dT=dT))
+                        if not np.allclose(Tw, Tw0 @ r.astype(np.float64), rtol=0, atol=1e-9):
+                            rep["failures"].append(dict(tag, error="end_reframe: the composed world pose"))
+                        q, t = bench.world_to_body(Tw)
+                        body = other.download(d_s, (len(wm), 4))
+                        f = reg.odometer_vgicp(0); f.setResolution(m.res); f.setCorrespondenceRandomness(m.k); f.setRegularizationMethod(m.method); f.setVoxelAccumulationMode(m.mode)
+                        f.transformCloudDevice(d_w, len(wm), 16, q, t, d_s2 := dev(nbytes=aw.nbytes))
+                        same_body = np.array_equal(f.download(d_s2, (len(wm), 4)), body)
+                        f.setInputTarget(body[:, :3].copy())
+                        same_cov = np.array_equal(f.getTargetCovariances(), other.getTargetCovariances())
+                        f.close()
+                        if not (same_body and same_cov):
+                            rep["failures"].append(dict(tag, error="end_reframe: the next context's target", same_body=bool(same_body), same_covariances=bool(same_cov)))
+                elif not was_pending and not np.array_equal(Tw, Tw0):
+                    rep["failures"].append(dict(tag, error="a refused end_reframe touched the world pose"))
             elif op == "set_cov":
                 if m.pending or m.stale_settings or m.tgt is None:
                     continue

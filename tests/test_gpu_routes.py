@@ -237,6 +237,24 @@ def test_a_refused_commit_writes_nothing(reg_mod):
     v.close()
 
 
+def test_a_pose_that_is_none_is_refused(reg_mod):
+    """Found by scripts/fuzz_api.py: a solve that ends in NaN (a degenerate problem) handed its pose on through rgc_align_end_reframe; the
+    re-framed map's box came out NaN, the float -> int conversions behind it are undefined, and the preparation asked for 40 petabytes.
+    rgc_set_target_reframed refuses a pose that is not finite (and a zero quaternion); the solve's own outputs still come back."""
+    import rgc_slam_amd.synth as synth
+    world, base = synth.make_world_and_map(12000, seed=5)
+    a = np.zeros((len(base), 4), np.float32); a[:, :3] = base
+    v = reg_mod.odometer_vgicp(0)
+    d, s = v.device_alloc(a.nbytes), v.device_alloc(a.nbytes)
+    v.upload(d, a)
+    for q, t in (([0, 0, 0, 1.0], [np.nan, 0, 0]), ([np.nan, 0, 0, 1.0], [0, 0, 0]), ([0, 0, 0, 0.0], [0, 0, 0]), ([0, 0, 0, 1.0], [np.inf, 0, 0])):
+        with pytest.raises(reg_mod.RgcError):
+            v.setInputTargetReframed(d, len(a), 16, np.array(q, float), np.array(t, float), s)
+    v.setInputTargetReframed(d, len(a), 16, np.array([0, 0, 0, 1.0]), np.zeros(3), s)      # the context is none the worse for it
+    assert len(v.getTargetCovariances()) == len(a)
+    v.device_free(d); v.device_free(s); v.close()
+
+
 def test_fuzz_of_the_call_sequences(reg_mod):
     """scripts/fuzz_api.py, a short campaign: random sequences of the registration's calls against a model of what must work and what must be
     refused, every solve against a fresh context's."""
