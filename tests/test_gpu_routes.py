@@ -272,3 +272,15 @@ def test_fuzz_of_the_message_layouts(reg_mod):
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 600 and rep["failures"] == [] and rep["refused_as_expected"] == 3 and rep["round_trips"] == 120, rep["failures"][:5]
+
+
+def test_degenerate_clouds(reg_mod):
+    """scripts/fuzz_degenerate.py: every point the same, a line, a lattice sheet, clumps 100 km apart, coordinates of 1e6 m, exactly k / k + 1 /
+    k - 1 points, a NaN, an inf, an outlier, an empty cloud -- as target, as scan, registered to themselves: a clean refusal or a finite
+    result, the oracle's covariances where they are defined."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_degenerate.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout)
+    assert rep["failures"] == [] and len(rep["cases"]) >= 15, rep["failures"]
+    assert rep["cases"]["one NaN"]["target"].startswith("refused") and rep["cases"]["k - 1 points"]["source"].startswith("refused")
+    assert "vs oracle" in rep["cases"]["coordinates of 1e6 m"]["target"]
