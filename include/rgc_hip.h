@@ -145,7 +145,11 @@ RGC_API int rgc_align(rgc_ctx* ctx, const float guess[16], float final_T[16], do
  * anything that does not touch THIS context -- in particular prepare the next frame's clouds on a second context, so that
  * the preparation of frame i + 1 runs on the GPU while frame i is being solved (rgc_slam_amd.registration.PipelinedVGICP,
  * rgc::OdometryNode's replay).  want_fitness != 0 chains getFitnessScore behind the solve (rgc_align_end's `fitness` then costs
- * nothing extra).  Errors that a speculative grid defers (rgc_set_* above) may surface in rgc_align_end. */
+ * nothing extra).  Errors that a speculative grid defers (rgc_set_* above) may surface in rgc_align_end.
+ * BETWEEN the two halves the context refuses (RGC_ERR_INVALID, "a solve is in flight") everything that would touch the solve's inputs:
+ * new clouds, clearing or swapping them, another begin or a blocking rgc_align, the settings that re-route a cloud, the getters,
+ * rgc_map_commit (but for the no-op commit of an unchanged map).  The same on the general covariance route, where rgc_align_begin runs the
+ * solve at once and keeps its result for rgc_align_end. */
 RGC_API int rgc_align_begin(rgc_ctx* ctx, const float guess[16], int want_fitness);
 RGC_API int rgc_align_end(rgc_ctx* ctx, float final_T[16], double final_H[36], double* fitness, int* iterations, int* converged,
                           int* lm_failed);
@@ -275,7 +279,9 @@ RGC_API int rgc_transform_cloud(rgc_ctx* ctx, const float* xyzi, int n, int stri
  * that cost for any map, and is what bench.py's `value` is timed with.
  * Preconditions: d_scratch must not overlap d_xyzi (RGC_ERR_INVALID: the input is read while the output is written, and a buffer has
  * one bounding-box hint); a d_scratch that is 16-byte aligned (anything hipMalloc / rgc_device_alloc returns) takes the fused path
- * -- re-framing inside the preparation's counting pass -- any other 4-byte aligned address the re-framing runs as its own launch. */
+ * -- re-framing inside the preparation's counting pass -- any other 4-byte aligned address the re-framing runs as its own launch.
+ * A pose that is none -- a non-finite q or t (the NaN a diverged solve hands on through rgc_align_end_reframe), a zero quaternion -- is refused
+ * with RGC_ERR_NONFINITE before anything is touched. */
 RGC_API int rgc_set_target_reframed(rgc_ctx* ctx, const float* d_xyzi, int n, int stride_bytes, const double q_xyzw[4], const double t[3],
                                     float* d_scratch);
 /* What a context keeps between the targets rgc_set_target_reframed prepares (no reference counterpart: the reference keeps nothing, it
@@ -551,7 +557,10 @@ RGC_API int rgc_map_evict(rgc_ctx* ctx, int max_keyframes, const double center[3
 RGC_API int rgc_map_rebase(rgc_ctx* ctx, const double new_origin[3]);
 /* makes the map the registration target: pcl::VoxelGrid(leaf) over the keyframes in insertion order (:985-991) + setInputTarget
  * (:1007), all on the device.  A no-op when nothing changed since the last commit and the target is still bound (rgc_set_target*
- * unbinds it).  Poses passed to rgc_align / rgc_linearize are then map-frame poses (world translation minus origin). */
+ * unbinds it).  Poses passed to rgc_align / rgc_linearize are then map-frame poses (world translation minus origin).
+ * With a solve in flight on the context anything but that no-op is refused before a byte is written (the filter's output buffer is the one
+ * the bound target was set from); a commit that fails further down leaves the context WITHOUT a target rather than with one whose input
+ * has been overwritten. */
 RGC_API int rgc_map_commit(rgc_ctx* ctx, float leaf, int* n_target);
 RGC_API int rgc_map_get_info(rgc_ctx* ctx, rgc_map_info* out);
 /* which = 0: the stored keyframe points, 1: the committed target; up to cap points (x,y,z,intensity) to the host, *n = total */
