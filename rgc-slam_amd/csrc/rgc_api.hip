@@ -1091,7 +1091,7 @@ int validate_clouds(rgc_ctx* c, bool whole_target = true) {
   { int rc = check_target_owner(c); if (rc) return rc; }
   // The guards FIRST: a lazy target whose speculative grid did not hold must be prepared again on its own box BEFORE it is completed -- the
   // completion's kernels leave at once on a tripped guard, and the re-preparation behind it would put back an unbuilt lazy target that
-  // nobody completes any more (a target replaced while a scan is set, then read through a getter: scripts/fuzz_api.py found it).
+  // nobody completes any more (a target replaced while a scan is set, then read through a getter: tests/fuzz/fuzz_api.py found it).
   if ((c->tgt.ready && c->tgt.spec_used) || (c->src.ready && c->src.spec_used)) {
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     HIPCHK(c, hipMemcpyAsync(c->h_small + 6, c->d_small + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2502,7 +2502,7 @@ int rgc_set_target_reframed(rgc_ctx* c, const float* d_xyzi, int n, int stride_b
     if (rc) return rc;
   }
   // a pose that is not a pose -- the NaN a diverged solve hands on through rgc_align_end_reframe, a zero quaternion -- has no box to derive a
-  // grid from (the float -> int conversions behind it are undefined: scripts/fuzz_api.py saw a 40-petabyte allocation request)
+  // grid from (the float -> int conversions behind it are undefined: tests/fuzz/fuzz_api.py saw a 40-petabyte allocation request)
   {
     const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
     if (!(std::isfinite(qq) && qq > 1.0e-12 && qq < 1.0e12 && std::isfinite(t[0]) && std::isfinite(t[1]) && std::isfinite(t[2]) &&
@@ -3499,7 +3499,7 @@ int rgc_map_commit(rgc_ctx* c, float leaf, int* n_target) {
     return RGC_OK;
   }
   // (before anything is written: the filter below writes the buffer the resident target was set from -- a commit refused behind it would
-  // leave a set target whose input has been overwritten, and rgc_map_download(1) returning another cloud; scripts/fuzz_api.py)
+  // leave a set target whose input has been overwritten, and rgc_map_download(1) returning another cloud; tests/fuzz/fuzz_api.py)
   if (solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");
   if (!c->map_n) return fail(c, RGC_ERR_NO_INPUT, "the map holds no keyframe");
   int rc = ensure(c, c->map_target, c->map_n * 16);

@@ -1,4 +1,4 @@
-"""A lazy target replaced while a scan is set, then read through the getters (found by scripts/fuzz_api.py)."""
+"""A lazy target replaced while a scan is set, then read through the getters (found by tests/fuzz/fuzz_api.py)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

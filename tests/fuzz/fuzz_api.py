@@ -3,9 +3,9 @@ from the host / the device / re-framed on the device, settings, the lazy target,
 a shared target -- against a small model of what must succeed and what must be refused, and every successful solve against a FRESH context
 given the same clouds and settings through the plain calls (pose to 1e-6: the routes' bits agree, a scan's grid may not).
 A call that should be refused and is not, one that should work and is refused, any crash: a failure.
-    python scripts/fuzz_api.py [trials] [seed] [operations per trial]"""
+    python tests/fuzz/fuzz_api.py [trials] [seed] [operations per trial]"""
 import sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import rgc_slam_amd.synth as synth

@@ -1,9 +1,9 @@
 """Degenerate clouds through the registration's calls: every point the same, points on a line, an exact lattice sheet, two clumps a hundred
 kilometres apart, coordinates of 1e6 m, exactly k points, k + 1, one NaN / inf among good points, a single far outlier -- as the target, as
 the scan, registered to themselves.  What must hold: a clean refusal or a result, never a crash or a hang; where the oracle's answer is
-defined (covariances of non-degenerate neighbourhoods), it is the library's.      python scripts/fuzz_degenerate.py [seed]"""
+defined (covariances of non-degenerate neighbourhoods), it is the library's.      python tests/fuzz/fuzz_degenerate.py [seed]"""
 import sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import rgc_slam_amd.synth as synth

@@ -1,9 +1,9 @@
 """Randomised campaign of the local map resident on the device (rgc_map_*, f2) against the ORACLE's composition of transformPointCloud and
 VoxelGrid: random sequences of insert (random keyframe poses and sizes, sweeps and noise clouds) / evict by count / evict by distance /
 rebase / commit with a random leaf / an unrelated setInputTarget in between -- the stored points and the committed target bit for bit
-after every operation.      python scripts/fuzz_map.py [trials] [seed] [operations per trial]"""
+after every operation.      python tests/fuzz/fuzz_map.py [trials] [seed] [operations per trial]"""
 import sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -3,14 +3,14 @@ seeds / neighbour lists / a lazy target, and rgc_transform_cloud + rgc_set_targe
 whose distances tie exactly, repeated points, sheets and lines, a dense clump in a sparse field, uniform noise), random sizes, leaf sizes, k,
 poses (any yaw, +-60 m) and edits of the buffer between frames.  Per frame: every covariance and the voxel table bit for bit across the routes,
 the oracle's covariances (1e-9) on the smaller clouds, then one solve per route from the same guess: final transformation, iteration count and
-fitness bit for bit (where the routes' contexts chose the same grid for the scan).      python scripts/fuzz_modes.py [trials] [seed] [max_points]"""
+fitness bit for bit (where the routes' contexts chose the same grid for the scan).      python tests/fuzz/fuzz_modes.py [trials] [seed] [max_points]"""
 import sys, os, json, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rgc_slam_amd.synth as synth
 from rgc_slam_amd import registration
 import bench
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
 import oracle as orc
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100

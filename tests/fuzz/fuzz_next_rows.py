@@ -1,9 +1,9 @@
 """Randomised campaign of two of SURVEY 8f's "next" rows against the ORACLE: f4, the loop-closure ICP (random maps, drifts up to 1 m / 5 degrees,
 source sizes, correspondence distances), and f1, the mapping node's feature registration (random worlds / trajectories / perturbations:
 association flags and factors, the two-pass solve's iteration counts, costs and poses).
-    python scripts/fuzz_next_rows.py [icp trials] [mapreg trials] [seed]"""
+    python tests/fuzz/fuzz_next_rows.py [icp trials] [mapreg trials] [seed]"""
 import sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -2,9 +2,9 @@
 do not hold -- both covariance sets, the voxel table, a linearisation at the guess, the solve's pose, the fitness.  Clouds: the synthetic world
 with a raw sweep as the scan, uniform noise, sheets and a pole, a clump in a sparse field; k = 10 / 20 / 25, leaf 0.5 / 1 / 2 m, every
 RegularizationMethod and VoxelAccumulationMode of the reference's interface, guesses on and off the truth.
-    python scripts/fuzz_oracle.py [trials] [seed] [max target points]"""
+    python tests/fuzz/fuzz_oracle.py [trials] [seed] [max target points]"""
 import sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np

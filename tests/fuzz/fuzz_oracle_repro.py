@@ -1,13 +1,13 @@
-"""One trial of scripts/fuzz_oracle.py in detail: python scripts/fuzz_oracle_repro.py <trial> <seed> <nmax>"""
+"""One trial of tests/fuzz/fuzz_oracle.py in detail: python tests/fuzz/fuzz_oracle_repro.py <trial> <seed> <nmax>"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import rgc_slam_amd.synth as synth
 from rgc_slam_amd import registration as reg
 import oracle as orc
 trial, seed0, nmax = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-src_txt = open(os.path.join(ROOT, "scripts", "fuzz_oracle.py")).read()
+src_txt = open(os.path.join(ROOT, "tests", "fuzz", "fuzz_oracle.py")).read()
 ns_ = {"np": np, "synth": synth}
 exec("def problem" + src_txt.split("def problem")[1].split("KINDS = ")[0], ns_)
 KINDS = ["synth", "synth", "synth", "uniform", "sheets", "clump"]

@@ -2,9 +2,9 @@
 (ring-major sweep, stencils, ground marking + plane, occlusion mask, feature selection), the leaf filter B3, de-skew B2 and re-framing B9.
 Sweeps of 16 / 32 / 64 beams from random worlds, poses (tilted, moving), azimuth counts, with points dropped, NaNs, shuffled firing order,
 truncated; leaf sizes 0.1-1 m on sweeps, noise, lattices whose points sit on leaf boundaries, through ONE filter object (its kept box).
-    python scripts/fuzz_pre.py [trials] [seed]"""
+    python tests/fuzz/fuzz_pre.py [trials] [seed]"""
 import sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

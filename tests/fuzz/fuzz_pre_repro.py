@@ -1,6 +1,6 @@
-"""The front-end half of one trial of scripts/fuzz_pre.py, with the sweep's encoded time compared point by point.  python scripts/fuzz_pre_repro.py <trial> <seed>"""
+"""The front-end half of one trial of tests/fuzz/fuzz_pre.py, with the sweep's encoded time compared point by point.  python tests/fuzz/fuzz_pre_repro.py <trial> <seed>"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import rgc_slam_amd.synth as synth

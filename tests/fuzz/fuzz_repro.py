@@ -1,6 +1,6 @@
-"""Reproduce one trial of scripts/fuzz_modes.py and say where two routes differ.   python scripts/fuzz_repro.py <trial> [seed]"""
+"""Reproduce one trial of tests/fuzz/fuzz_modes.py and say where two routes differ.   python tests/fuzz/fuzz_repro.py <trial> [seed]"""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rgc_slam_amd.synth as synth
 from rgc_slam_amd import registration
@@ -36,7 +36,7 @@ ca, cb = A.getTargetCovariances().reshape(n, -1), B.getTargetCovariances().resha
 d = np.nonzero(np.any(ca != cb, axis=1))[0]
 print("points that differ:", len(d), "max |diff|", float(np.abs(ca - cb).max()))
 print("stats A", A.stats()); print("stats B", B.stats())
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
 import oracle as orc
 oc, _ = orc.covariances(ba[:, :3].copy(), k=k, threads=14); oc = oc.reshape(n, -1)
 print("A vs oracle max", float(np.abs(ca - oc).max()), " B vs oracle max", float(np.abs(cb - oc).max()))

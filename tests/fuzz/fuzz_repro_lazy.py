@@ -1,6 +1,6 @@
-"""Trial of scripts/fuzz_modes.py where the lazy route's solve differs: which inputs of the solve differ?   FUZZ_ONLY-style: python scripts/fuzz_repro_lazy.py <trial> <seed> <nmax> <frame>"""
+"""Trial of tests/fuzz/fuzz_modes.py where the lazy route's solve differs: which inputs of the solve differ?   FUZZ_ONLY-style: python tests/fuzz/fuzz_repro_lazy.py <trial> <seed> <nmax> <frame>"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rgc_slam_amd.synth as synth
 from rgc_slam_amd import registration

@@ -2,9 +2,9 @@
 re-framing; with and without the IMU path) on the HIP library against the same frame body driven by the ORACLE's stages (tests/oracle_backend.py):
 short synthetic VLP-16 sequences over random worlds, trajectories (some climbing a ramp: the ground-change detector trips), azimuth counts.
 Per-frame pose deltas within 1e-4 m / 1e-4 rad, the same ground flag, keyframe window and sub-map size on every frame.
-    python scripts/fuzz_sequence.py [trials] [seed] [sweeps per trial]"""
+    python tests/fuzz/fuzz_sequence.py [trials] [seed] [sweeps per trial]"""
 import sys, os, json, time, math
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

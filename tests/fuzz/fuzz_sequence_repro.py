@@ -1,6 +1,6 @@
-"""One trial of scripts/fuzz_sequence.py with the registrations' iteration counts per frame.   python scripts/fuzz_sequence_repro.py <trial> <seed> <sweeps>"""
+"""One trial of tests/fuzz/fuzz_sequence.py with the registrations' iteration counts per frame.   python tests/fuzz/fuzz_sequence_repro.py <trial> <seed> <sweeps>"""
 import sys, os, math
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import rgc_slam_amd.synth as synth

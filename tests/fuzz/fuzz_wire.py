@@ -1,8 +1,8 @@
 """Randomised campaign of the PointCloud2 unpacking (f3) against numpy's structured dtypes: random point steps, field orders and offsets (packed,
 padded, unaligned), every PointField datatype for every field, both byte orders, fields missing, strict (pcl::fromROSMsg: only FLOAT32 maps)
-or converting; and pack -> unpack round trips.      python scripts/fuzz_wire.py [trials] [seed]"""
+or converting; and pack -> unpack round trips.      python tests/fuzz/fuzz_wire.py [trials] [seed]"""
 import sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from rgc_slam_amd import wire, _lib

@@ -1,6 +1,6 @@
 """A map's covariances are a function of the cloud alone: whichever route it comes by (rgc_set_target_reframed, rgc_transform_cloud +
 rgc_set_target_device), whichever kernel ends up searching a query (the dense search, the sparse map's four-lane search, the cooperative
-kernel -- that depends on the grid's box, which the routes derive differently) and for any k.  Found by scripts/fuzz_modes.py: the four-lane
+kernel -- that depends on the grid's box, which the routes derive differently) and for any k.  Found by tests/fuzz/fuzz_modes.py: the four-lane
 search and the general-k branch of the dense one used to sum a neighbourhood in key order, the cooperative kernel in ascending position."""
 import json
 import os
@@ -73,10 +73,10 @@ def test_two_routes_same_bits(reg_mod, orc, k, kind):
 
 
 def test_fuzz_campaign(reg_mod):
-    """scripts/fuzz_modes.py, a short campaign: lattices with exact ties, repeated points, sheets, a clump in a sparse field, uniform noise;
+    """tests/fuzz/fuzz_modes.py, a short campaign: lattices with exact ties, repeated points, sheets, a clump in a sparse field, uniform noise;
     nothing kept / seeds / lists / lazy / transform + device; k = 10, 20, 25; leaf 0.5, 1, 2 m; edits between frames -- covariances, voxel
     tables and solves bit for bit across the routes, covariances against the oracle."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_modes.py"), "60", "11", "40000"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_modes.py"), "60", "11", "40000"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 60 and rep["failures"] == [], rep["failures"][:5]
@@ -84,10 +84,10 @@ def test_fuzz_campaign(reg_mod):
 
 
 def test_fuzz_against_the_oracle(reg_mod):
-    """scripts/fuzz_oracle.py, a short campaign: whole registrations -- both covariance sets, the voxel table, a linearisation at the guess, the
+    """tests/fuzz/fuzz_oracle.py, a short campaign: whole registrations -- both covariance sets, the voxel table, a linearisation at the guess, the
     solve's pose, the fitness -- against the oracle, on random clouds, k = 10 / 20 / 25, leaf 0.5 / 1 / 2 m and every RegularizationMethod /
     VoxelAccumulationMode of the reference's interface."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_oracle.py"), "80", "21", "30000"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_oracle.py"), "80", "21", "30000"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 80 and rep["failures"] == [], rep["failures"][:5]
@@ -95,10 +95,10 @@ def test_fuzz_against_the_oracle(reg_mod):
 
 
 def test_fuzz_of_the_stages_in_front(reg_mod):
-    """scripts/fuzz_pre.py, a short campaign: the front-end (16 / 32 / 64 beams; points dropped, NaNs, shuffled firing order, truncated,
+    """tests/fuzz/fuzz_pre.py, a short campaign: the front-end (16 / 32 / 64 beams; points dropped, NaNs, shuffled firing order, truncated,
     out of range), the leaf filter through one object (sweeps, noise, lattices on leaf boundaries, NaNs refused), de-skew and re-framing --
     against the oracle, stage by stage."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_pre.py"), "60", "31"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_pre.py"), "60", "31"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 60 and rep["failures"] == [], rep["failures"][:5]
@@ -106,10 +106,10 @@ def test_fuzz_of_the_stages_in_front(reg_mod):
 
 
 def test_fuzz_of_the_frame_body(reg_mod):
-    """scripts/fuzz_sequence.py, a short campaign: random worlds, trajectories (some up a ramp), azimuth counts, with and without the IMU path --
+    """tests/fuzz/fuzz_sequence.py, a short campaign: random worlds, trajectories (some up a ramp), azimuth counts, with and without the IMU path --
     the frame body on the library against the same frame body on the oracle's stages, frame by frame: 1e-4 m / 1e-4 rad until a solve runs
     out of iterations or stops an iteration apart on the two sides (a flat valley: both ends are as good), 2e-3 from there on."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_sequence.py"), "12", "41", "8"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_sequence.py"), "12", "41", "8"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 12 and rep["failures"] == [], rep["failures"][:5]
@@ -117,20 +117,20 @@ def test_fuzz_of_the_frame_body(reg_mod):
 
 
 def test_fuzz_of_the_resident_map_and_the_next_rows(reg_mod):
-    """scripts/fuzz_map.py (f2: random insert / evict / rebase / commit sequences, stored points and committed target bit for bit with the
-    oracle's composition) and scripts/fuzz_next_rows.py (f4 loop-closure ICP, f1 mapping-node feature registration), short campaigns."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_map.py"), "25", "51", "25"], capture_output=True, text=True, timeout=900)
+    """tests/fuzz/fuzz_map.py (f2: random insert / evict / rebase / commit sequences, stored points and committed target bit for bit with the
+    oracle's composition) and tests/fuzz/fuzz_next_rows.py (f4 loop-closure ICP, f1 mapping-node feature registration), short campaigns."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_map.py"), "25", "51", "25"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 25 and rep["failures"] == [] and rep["commits_compared"] >= 60, rep["failures"][:5]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_next_rows.py"), "40", "4", "61"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_next_rows.py"), "40", "4", "61"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["icp_trials"] == 40 and rep["mapreg_trials"] == 4 and rep["failures"] == [], rep["failures"][:5]
 
 
 def test_lazy_target_replaced_before_any_solve(reg_mod):
-    """Found by scripts/fuzz_api.py: a lazy target A, a scan, a lazy target B that leaves A's (speculative) grid, then a getter.  The getter
+    """Found by tests/fuzz/fuzz_api.py: a lazy target A, a scan, a lazy target B that leaves A's (speculative) grid, then a getter.  The getter
     used to complete B first -- the completion's kernels leave at once on the tripped guard -- and resolve the guard second, which put an
     UNBUILT lazy target back: every covariance it returned was stale.  Guards first now (validate_clouds)."""
     import rgc_slam_amd.synth as synth
@@ -162,7 +162,7 @@ def test_lazy_target_replaced_before_any_solve(reg_mod):
 
 def test_a_solve_in_flight_is_one_on_either_route(reg_mod):
     """rgc_align_begin on the general route runs the solve at once and keeps its result for rgc_align_end; until then the context refuses
-    what it refuses with a solve in flight on the tuned route (scripts/fuzz_api.py: it used to accept new clouds, and a later
+    what it refuses with a solve in flight on the tuned route (tests/fuzz/fuzz_api.py: it used to accept new clouds, and a later
     rgc_align_end then found nothing)."""
     import rgc_slam_amd.synth as synth
     world, tgt = synth.make_world_and_map(15000, seed=9)
@@ -187,7 +187,7 @@ def test_a_solve_in_flight_is_one_on_either_route(reg_mod):
 
 
 def test_a_cleared_cloud_leaves_no_guard_behind(reg_mod):
-    """Found by scripts/fuzz_api.py: a scan prepared on a speculative grid, rgc_clear_source, then a getter of the target: the cleared scan's
+    """Found by tests/fuzz/fuzz_api.py: a scan prepared on a speculative grid, rgc_clear_source, then a getter of the target: the cleared scan's
     stale guard made the library prepare it "again" -- zero points, a launch of zero workgroups, RGC_ERR_HIP out of a getter."""
     import rgc_slam_amd.synth as synth
     world, base = synth.make_world_and_map(30000, seed=5)
@@ -209,7 +209,7 @@ def test_a_cleared_cloud_leaves_no_guard_behind(reg_mod):
 
 
 def test_a_refused_commit_writes_nothing(reg_mod):
-    """Found by scripts/fuzz_api.py: rgc_map_commit with a solve in flight ran its leaf filter INTO the buffer the resident target had been set
+    """Found by tests/fuzz/fuzz_api.py: rgc_map_commit with a solve in flight ran its leaf filter INTO the buffer the resident target had been set
     from and was refused only behind it (by the target's setter): the bound target kept a rewritten input, rgc_map_download(1) returned
     another cloud.  Refused before anything is written now."""
     import rgc_slam_amd.synth as synth
@@ -238,7 +238,7 @@ def test_a_refused_commit_writes_nothing(reg_mod):
 
 
 def test_a_pose_that_is_none_is_refused(reg_mod):
-    """Found by scripts/fuzz_api.py: a solve that ends in NaN (a degenerate problem) handed its pose on through rgc_align_end_reframe; the
+    """Found by tests/fuzz/fuzz_api.py: a solve that ends in NaN (a degenerate problem) handed its pose on through rgc_align_end_reframe; the
     re-framed map's box came out NaN, the float -> int conversions behind it are undefined, and the preparation asked for 40 petabytes.
     rgc_set_target_reframed refuses a pose that is not finite (and a zero quaternion); the solve's own outputs still come back."""
     import rgc_slam_amd.synth as synth
@@ -256,9 +256,9 @@ def test_a_pose_that_is_none_is_refused(reg_mod):
 
 
 def test_fuzz_of_the_call_sequences(reg_mod):
-    """scripts/fuzz_api.py, a short campaign: random sequences of the registration's calls against a model of what must work and what must be
+    """tests/fuzz/fuzz_api.py, a short campaign: random sequences of the registration's calls against a model of what must work and what must be
     refused, every solve against a fresh context's."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_api.py"), "40", "71", "45"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_api.py"), "40", "71", "45"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 40 and rep["failures"] == [], rep["failures"][:5]
@@ -266,19 +266,19 @@ def test_fuzz_of_the_call_sequences(reg_mod):
 
 
 def test_fuzz_of_the_message_layouts(reg_mod):
-    """scripts/fuzz_wire.py: PointCloud2 unpacking against numpy's structured dtypes over random layouts (steps, offsets, every datatype for
+    """tests/fuzz/fuzz_wire.py: PointCloud2 unpacking against numpy's structured dtypes over random layouts (steps, offsets, every datatype for
     every field, both byte orders, strict / converting), pack -> unpack round trips, bad layouts refused."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_wire.py"), "600", "81"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_wire.py"), "600", "81"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 600 and rep["failures"] == [] and rep["refused_as_expected"] == 3 and rep["round_trips"] == 120, rep["failures"][:5]
 
 
 def test_degenerate_clouds(reg_mod):
-    """scripts/fuzz_degenerate.py: every point the same, a line, a lattice sheet, clumps 100 km apart, coordinates of 1e6 m, exactly k / k + 1 /
+    """tests/fuzz/fuzz_degenerate.py: every point the same, a line, a lattice sheet, clumps 100 km apart, coordinates of 1e6 m, exactly k / k + 1 /
     k - 1 points, a NaN, an inf, an outlier, an empty cloud -- as target, as scan, registered to themselves: a clean refusal or a finite
     result, the oracle's covariances where they are defined."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_degenerate.py")], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_degenerate.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout)
     assert rep["failures"] == [] and len(rep["cases"]) >= 15, rep["failures"]
