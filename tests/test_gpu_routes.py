@@ -284,3 +284,12 @@ def test_degenerate_clouds(reg_mod):
     assert rep["failures"] == [] and len(rep["cases"]) >= 15, rep["failures"]
     assert rep["cases"]["one NaN"]["target"].startswith("refused") and rep["cases"]["k - 1 points"]["source"].startswith("refused")
     assert "vs oracle" in rep["cases"]["coordinates of 1e6 m"]["target"]
+
+
+def test_everything_on_one_context(reg_mod):
+    """tests/fuzz/fuzz_one_context.py, a short campaign: the front-end, the leaf filter (blocking and in two halves), de-skew, re-framing, the
+    registration and the wire unpacking interleaved at random on ONE context, each result against the same call on a context of its own."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_one_context.py"), "8", "91", "40"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["trials"] == 8 and rep["failures"] == [] and rep["compared"] >= 150, rep["failures"][:5]
