@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import rgc_slam_amd.synth as synth
-from rgc_slam_amd import frontend, odometry
+from rgc_slam_amd import frontend, odometry, wire
 import oracle as orc
 from test_gpu_frontend import _compare      # the front-end's stage-by-stage comparison (tests/test_gpu_frontend.py)
 
@@ -18,6 +18,8 @@ trials = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rep = {"trials": 0, "frontend": 0, "voxelgrid": 0, "deskew": 0, "transform": 0, "failures": [], "max": {"deskew": 0.0, "transform": 0.0}}
 fe = {b: frontend.ScanRegistration(b) for b in (16, 32, 64)}
+spec = {b: frontend.ScanRegistration(b) for b in (16, 32, 64)}   # the sweep left on the device: launches sized from the PREVIOUS sweep (whose size is random here)
+msgfe = {b: frontend.ScanRegistration(b) for b in (16, 32, 64)}  # the callback on the message's bytes
 pre = odometry.Preprocessor(0)
 t0 = time.time()
 
@@ -57,8 +59,20 @@ for trial in range(trials):
             raw = raw.copy(); raw[:, :3] *= np.float32(rng.choice([0.01, 3.0]))
         tag.update(stage="frontend", beams=beams, n=len(raw), what=what)
         if len(raw) > 0:
-            _compare(fe[beams], orc, raw, beams, time_outliers=3 if what == "shuffled" else 0)
+            g, _o = _compare(fe[beams], orc, raw, beams, time_outliers=3 if what == "shuffled" else 0)
             rep["frontend"] += 1
+            keys = ("curvature", "curvature2", "inten_curvature", "ground_marked", "picked", "label", "inten_label", "sharp", "flat", "inten", "ground_pts", "ring_count", "groundparam")
+            a = spec[beams].laserCloudHandler(raw, cloud=False)
+            bad = [k for k in keys if not np.array_equal(a[k], g[k])] + [k for k in ("n_cloud", "n_sharp_own", "n_ground", "ground_valid") if a[k] != g[k]]
+            if bad:
+                rep["failures"].append(dict(tag, error="the sweep left on the device differs from the synchronous path", keys=bad))
+            m = np.zeros((len(raw), 8), np.float32); m[:, :3] = raw[:, :3]; m[:, 4] = raw[:, 3]
+            lay = wire.layout(32, dict(x=(0, 7), y=(4, 7), z=(8, 7), intensity=(16, 7)))
+            b = msgfe[beams].laserCloudHandlerMsg(m.tobytes(), len(raw), lay)
+            bad = [k for k in keys + ("cloud",) if not np.array_equal(b[k], g[k])] + [k for k in ("n_cloud", "n_sharp_own", "n_ground", "ground_valid") if b[k] != g[k]]
+            if bad:
+                rep["failures"].append(dict(tag, error="the callback on the message bytes differs from the host path", keys=bad))
+            rep["frontend_device_and_message"] = rep.get("frontend_device_and_message", 0) + 1
         # ---- leaf filter, on one object (the box kept from the previous cloud of the same leaf) ----
         leaf = float(rng.choice([0.1, 0.2, 0.3, 0.5, 1.0]))
         kind = str(rng.choice(["sweep", "sweep", "noise", "lattice", "shifted", "nan"]))
