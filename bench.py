@@ -148,6 +148,21 @@ def world_to_body(Tw):
                         -(Rt[2][0] * tx + Rt[2][1] * ty + Rt[2][2] * tz)]
 
 
+def compose_world(Tw, T):
+    """world_T * T in fp64 with every entry summed in ascending k -- rgc_align_end_reframe's composition (RGC_odometer.cpp:1201-1203 on
+    matrices), so that the last frame of a sequence, which has no next target to enqueue, ends on the same bits as the others (a BLAS
+    matmul sums in another order)."""
+    import numpy as np
+    W = np.zeros((4, 4))
+    for a in range(4):
+        for b in range(4):
+            acc = 0.0
+            for k in range(4):
+                acc += float(Tw[a, k]) * float(T[k, b])
+            W[a, b] = acc
+    return W
+
+
 class DependentSequence:
     """The odometer's frame loop on device-resident clouds (RGC_odometer.cpp:976-1023, 1201-1203, 1248-1256):
     frame i: target = the local map re-expressed in the body frame of world pose i - 1 and rebuilt in full (rgc_set_target_reframed,
@@ -240,7 +255,7 @@ class DependentSequence:
                 T = cur.align_end_reframe(nxt, Tw, self.d_map, self.n_map, 16, self.d_body[id(nxt)])
             else:
                 T = cur.align_end()
-                Tw[:] = Tw @ T.astype(np.float64)
+                Tw[:] = compose_world(Tw, T)
             if from_host and self.d_aligned is not None:
                 cur.alignedToDevice(self.d_aligned[id(cur)], 16)              # pcl::transformPointCloud(*input_, output, final), left on the device
             if on_result is not None:

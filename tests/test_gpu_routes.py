@@ -293,3 +293,13 @@ def test_everything_on_one_context(reg_mod):
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 8 and rep["failures"] == [] and rep["compared"] >= 150, rep["failures"][:5]
+
+
+def test_fuzz_of_the_dependent_sequence(reg_mod):
+    """tests/fuzz/fuzz_dependent.py, a short campaign: the headline's path -- rgc_set_target_reframed / rgc_align_end_reframe on one and two
+    contexts, the Python and the C++ frame loop, random maps, scans, lengths, reuse modes and lazy margins -- against the plain calls
+    (rgc_transform_cloud, rgc_set_target_device, rgc_set_source_device, rgc_align, the world pose composed by hand): bit for bit."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_dependent.py"), "12", "101"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["trials"] == 12 and rep["failures"] == [] and rep["variants_compared"] == 48, rep["failures"][:5]
