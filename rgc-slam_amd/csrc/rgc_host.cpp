@@ -149,8 +149,8 @@ bool solve_sym(double* A, double* b, int n) {  // Gaussian elimination with part
 
 extern "C" {
 
-void rgc_R2ypr(const double R[9], double ypr_deg[3]) { R2ypr(R, ypr_deg); }
-void rgc_ypr2R(const double ypr_deg[3], double R[9]) { ypr2R(ypr_deg, R); }
+void rgc_R2ypr(const double R[9], double ypr_deg[3]) { if (R && ypr_deg) R2ypr(R, ypr_deg); }
+void rgc_ypr2R(const double ypr_deg[3], double R[9]) { if (ypr_deg && R) ypr2R(ypr_deg, R); }
 
 // B1  vg_ICP::IMU_preintegration / IMU_preintegration2 over the samples of one sweep
 // (src/RGC_odometer.cpp:883-931, 1418-1438).  stamps/gyr/acc: the vectors getIMUInterval returns (:1376-1416).

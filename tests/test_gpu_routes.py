@@ -303,3 +303,12 @@ def test_fuzz_of_the_dependent_sequence(reg_mod):
     assert r.returncode == 0, r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 12 and rep["failures"] == [] and rep["variants_compared"] == 48, rep["failures"][:5]
+
+
+def test_every_entry_point_with_nothing(reg_mod):
+    """tests/fuzz/fuzz_null_args.py: every prototype of include/rgc_hip.h called with NULL for every pointer and 0 for every number -- without a
+    context, with a fresh one, with one that holds clouds: statuses, no crash (rgc_R2ypr / rgc_ypr2R used to dereference)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_null_args.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["functions"] >= 80 and rep["failures"] == [] and rep["context_still_works"] and rep["create_with_null_out"] != 0
