@@ -311,7 +311,11 @@ int check_supported(rgc_ctx*) { return RGC_OK; }   // (every value of both enums
 #define HIPCHK(c, expr)                                                                                    \
   do {                                                                                                     \
     hipError_t _e = (expr);                                                                                \
-    if (_e != hipSuccess) return fail((c), RGC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    if (_e != hipSuccess) {                                                                                \
+      (void)hipGetLastError(); /* the runtime keeps a failed call's error until it is read: reported HERE, it must not surface again   \
+                                  from the hipGetLastError() of the next, unrelated call (tests/fuzz/fuzz_bad_args.py) */             \
+      return fail((c), RGC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);                       \
+    }                                                                                                      \
   } while (0)
 
 int ensure(rgc_ctx* c, DevBuf& b, size_t bytes) {
@@ -953,7 +957,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
   if (is_target) c->map_bound = false;
   { const int rs = check_supported(c); if (rs) return rs; }
   if (!xyz || n < 0) return fail(c, RGC_ERR_INVALID, "null cloud");
-  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
   if (n > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud has %d points, the limit is 2^27 (32-bit byte offsets into the sorted array)", n);
   if (n < c->prm.k_correspondences)
     return fail(c, RGC_ERR_TOO_FEW_POINTS, "%s cloud has %d points, need >= k = %d", is_target ? "target" : "source", n, c->prm.k_correspondences);
@@ -2151,7 +2155,7 @@ int rgc_fitness(rgc_ctx* c, const float T[16], double* fitness) {
 int rgc_get_aligned_device(rgc_ctx* c, const float T[16], float* d_out, int stride_bytes) {
   if (!c || !T || !d_out) return RGC_ERR_INVALID;
   if (!c->src.ready) return fail(c, RGC_ERR_NO_INPUT, "source not set");
-  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
+  if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "bad stride");
   HIPCHK(c, hipSetDevice(c->device));
   int rc = join_source(c);
   if (rc) return rc;
@@ -2167,7 +2171,7 @@ int rgc_get_aligned_device(rgc_ctx* c, const float T[16], float* d_out, int stri
 int rgc_get_aligned(rgc_ctx* c, const float T[16], float* out, int stride_bytes) {
   if (!c || !T || !out) return RGC_ERR_INVALID;
   if (!c->src.ready) return fail(c, RGC_ERR_NO_INPUT, "source not set");
-  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
+  if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "bad stride");
   HIPCHK(c, hipSetDevice(c->device));
   const int n = c->src.n;
   int rc = join_source(c);
@@ -2422,6 +2426,7 @@ int rgc_get_voxels(rgc_ctx* c, int cap, int* coords, int* num, double* mean, dou
 
 // ---- B2 / B3 / B9: the stages either side of the operator in the odometer's frame body ----
 static int stage_in(rgc_ctx* c, const float* p, int n, int stride_bytes, int on_device, const float** d_in) {
+  if (n > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud has %d points, the limit is 2^27", n);  // (every entry point that takes a cloud: one limit)
   if (on_device) { *d_in = p; return RGC_OK; }
   const size_t bytes = (size_t)n * stride_bytes;
   int rc = ensure(c, c->pre_in, bytes);
@@ -2433,7 +2438,7 @@ static int stage_in(rgc_ctx* c, const float* p, int n, int stride_bytes, int on_
 
 int rgc_deskew(rgc_ctx* c, float* xyzi, int n, int stride_bytes, const double q[4], const double t[3], int on_device) {
   if (!c || !xyzi || !q || !t || n < 0) return RGC_ERR_INVALID;
-  if (stride_bytes < 16 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "de-skew needs x,y,z,intensity: stride_bytes >= 16");
+  if (stride_bytes < 16 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "de-skew needs x,y,z,intensity: stride_bytes >= 16");
   if (n == 0) return RGC_OK;
   HIPCHK(c, hipSetDevice(c->device));
   const float* d_in;
@@ -2457,7 +2462,7 @@ int rgc_deskew(rgc_ctx* c, float* xyzi, int n, int stride_bytes, const double q[
 int rgc_transform_cloud(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const double q[4], const double t[3], float* out_xyzi,
                         int on_device) {
   if (!c || !xyzi || !q || !t || !out_xyzi || n < 0) return RGC_ERR_INVALID;
-  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
+  if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "bad stride");
   if (n == 0) return RGC_OK;
   HIPCHK(c, hipSetDevice(c->device));
   const float* d_in;
@@ -2484,7 +2489,7 @@ int rgc_transform_cloud(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, 
 // the argument checks of rgc_set_target_reframed (also made by rgc_align_end_reframe BEFORE it consumes the solve)
 static int reframe_args_ok(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, const float* d_scratch) {
   if (!d_xyzi || !d_scratch || n <= 0) return fail(c, RGC_ERR_INVALID, "rgc_set_target_reframed: null buffer or no points");
-  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "bad stride");
+  if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "bad stride");
   if (n > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud has %d points, the limit is 2^27 (32-bit byte offsets into the sorted array)", n);
   if (n < c->prm.k_correspondences) return fail(c, RGC_ERR_TOO_FEW_POINTS, "target cloud has %d points, need >= k = %d", n, c->prm.k_correspondences);
   // the re-framed cloud is WRITTEN to d_scratch while d_xyzi is read: they must not overlap (and one buffer has one bounding-box hint)
@@ -2719,7 +2724,7 @@ static bool vg_rows_fit(const rgck::LeafGrid& g, int n) {  // sparse enough for 
 
 int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float leaf, float* out_xyzi, int* n_out, int on_device) {
   if (!c || !xyzi || !out_xyzi || !n_out || n < 0) return RGC_ERR_INVALID;
-  if (stride_bytes < 12 || (stride_bytes & 3) || !(leaf > 0.f)) return fail(c, RGC_ERR_INVALID, "bad stride or leaf size");
+  if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096 || !(leaf > 0.f) || !std::isfinite(leaf)) return fail(c, RGC_ERR_INVALID, "bad stride or leaf size");
   *n_out = 0;
   if (n == 0) return RGC_OK;
   HIPCHK(c, hipSetDevice(c->device));
@@ -2813,8 +2818,8 @@ int rgc_voxelgrid(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, float 
 // of its count are off the frame's critical path.  Other rgc_voxelgrid calls may run in between (they come later in stream order and
 // use other result words); only ONE begin may be open per context.
 int rgc_voxelgrid_begin(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes, float leaf, float* d_out) {
-  if (!c || !d_xyzi || !d_out || n < 0) return RGC_ERR_INVALID;
-  if (stride_bytes < 12 || (stride_bytes & 3) || !(leaf > 0.f)) return fail(c, RGC_ERR_INVALID, "bad stride or leaf size");
+  if (!c || !d_xyzi || !d_out || n < 0 || n > (1 << 27)) return RGC_ERR_INVALID;
+  if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096 || !(leaf > 0.f) || !std::isfinite(leaf)) return fail(c, RGC_ERR_INVALID, "bad stride or leaf size");
   if (c->vg_pend.active) return fail(c, RGC_ERR_INVALID, "rgc_voxelgrid_begin: the previous one has not been ended");
   HIPCHK(c, hipSetDevice(c->device));
   rgc_ctx::VgPending& pd_ = c->vg_pend;
@@ -2904,7 +2909,7 @@ int rgc_frontend_device(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes
 static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out, int on_device, bool allow_spec) {
   if (!c || !xyzi || !prm || !out || n < 0) return RGC_ERR_INVALID;
   if (n > (1 << 24)) return fail(c, RGC_ERR_INVALID, "sweep has %d points, the front-end's limit is 2^24", n);  // 32-bit sizes and candidate lists below
-  if (stride_bytes < 16 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "front-end needs x,y,z,intensity: stride_bytes >= 16");
+  if (stride_bytes < 16 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "front-end needs x,y,z,intensity: stride_bytes >= 16");
   const int NS = prm->n_scans;
   if (NS != 16 && NS != 32 && NS != 64) return fail(c, RGC_ERR_INVALID, "only 16, 32 or 64 scan lines (scanRegistration.cpp:69-72)");
   out->n_cloud = out->n_sharp = out->n_sharp_own = out->n_flat = out->n_inten = out->n_ground = 0;
@@ -3217,7 +3222,7 @@ const char* rgc_profile_name(int kind) {
 // ---- f1: scan-to-map FEATURE registration of the mapping node (RGC_mapping.cpp:1069-1358) --------------------------------
 int rgc_mapreg_set_maps(rgc_ctx* c, const float* corner_map, int n_corner, const float* surf_map, int n_surf, int stride_bytes) {
   if (!c || !corner_map || !surf_map) return RGC_ERR_INVALID;
-  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
   if (n_corner < 5 || n_surf < 5) return fail(c, RGC_ERR_TOO_FEW_POINTS, "feature maps need at least 5 points each (5-NN)");
   if (n_corner > (1 << 27) || n_surf > (1 << 27)) return fail(c, RGC_ERR_INVALID, "feature map larger than 2^27 points");
   HIPCHK(c, hipSetDevice(c->device));
@@ -3405,7 +3410,7 @@ int rgc_map_reset(rgc_ctx* c, const double origin[3]) {
 
 int rgc_map_insert(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const double q[4], const double t[3], int on_device, int* keyframe_id) {
   if (!c || !xyzi || !q || !t || n <= 0) return RGC_ERR_INVALID;
-  if (stride_bytes < 16 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "a keyframe is x,y,z,intensity: stride_bytes >= 16");
+  if (stride_bytes < 16 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "a keyframe is x,y,z,intensity: stride_bytes >= 16");
   if (c->map_n + (size_t)n > ((size_t)1 << 27)) return fail(c, RGC_ERR_INVALID, "the map would exceed 2^27 points");
   HIPCHK(c, hipSetDevice(c->device));
   const float* d_in;
@@ -3675,7 +3680,7 @@ void rgc_default_icp_params(rgc_icp_params* p) {
 int rgc_icp_align(rgc_ctx* c, const float* source, int ns, const float* target, int nt, int stride_bytes, const rgc_icp_params* prm,
                   float final_T[16], rgc_icp_result* res) {
   if (!c || !source || !target || !prm || !final_T || !res) return RGC_ERR_INVALID;
-  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
   if (ns < 1 || nt < 1) return fail(c, RGC_ERR_TOO_FEW_POINTS, "ICP needs a non-empty source and target");
   if (ns > (1 << 27) || nt > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud larger than 2^27 points");
   if (!(prm->max_correspondence_distance > 0) || prm->max_iterations < 1) return fail(c, RGC_ERR_INVALID, "bad ICP parameters");
