@@ -2907,7 +2907,7 @@ int rgc_frontend_device(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes
   return frontend_impl(c, d_xyzi, n, stride_bytes, prm, out, 1);
 }
 static int frontend_impl(rgc_ctx* c, const float* xyzi, int n, int stride_bytes, const rgc_fe_params* prm, rgc_fe_out* out, int on_device, bool allow_spec) {
-  if (!c || !xyzi || !prm || !out || n < 0) return RGC_ERR_INVALID;
+  if (!c || !xyzi || !prm || !out || n < 0 || n > (1 << 27)) return RGC_ERR_INVALID;
   if (n > (1 << 24)) return fail(c, RGC_ERR_INVALID, "sweep has %d points, the front-end's limit is 2^24", n);  // 32-bit sizes and candidate lists below
   if (stride_bytes < 16 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "front-end needs x,y,z,intensity: stride_bytes >= 16");
   const int NS = prm->n_scans;
@@ -3253,7 +3253,7 @@ static int mapreg_upload_features(rgc_ctx* c, int slot, const float* feat, int n
 
 int rgc_mapreg_associate(rgc_ctx* c, int kind, const float* feat_xyzw, int n, const double q_xyzw[4], const double t[3], double* factors8,
                          int* n_valid) {
-  if (!c || !feat_xyzw || !q_xyzw || !t || n < 0 || (kind != 0 && kind != 1)) return RGC_ERR_INVALID;
+  if (!c || !feat_xyzw || !q_xyzw || !t || n < 0 || n > (1 << 27) || (kind != 0 && kind != 1)) return RGC_ERR_INVALID;
   if (!c->mr_map[kind].ready) return fail(c, RGC_ERR_NO_INPUT, "rgc_mapreg_set_maps first");
   HIPCHK(c, hipSetDevice(c->device));
   int rc = mapreg_upload_features(c, kind, feat_xyzw, n);
@@ -3280,6 +3280,7 @@ int rgc_mapreg_optimize(rgc_ctx* c, const float* corner_cur, int n_ccur, const f
                         int n_clast, const float* surf_last, int n_slast, const rgc_mapreg_ground* ground_cur, const rgc_mapreg_ground* ground_last,
                         const rgc_mapreg_imu* imu, double poses[14], rgc_mapreg_report report[2], int* gate_failed) {
   if (!c || !poses || n_ccur < 0 || n_scur < 0 || n_clast < 0 || n_slast < 0) return RGC_ERR_INVALID;
+  if (n_ccur > (1 << 27) || n_scur > (1 << 27) || n_clast > (1 << 27) || n_slast > (1 << 27)) return fail(c, RGC_ERR_INVALID, "feature cloud larger than 2^27 points");
   if ((n_ccur && !corner_cur) || (n_scur && !surf_cur) || (n_clast && !corner_last) || (n_slast && !surf_last)) return RGC_ERR_INVALID;
   if (!c->mr_map[0].ready || !c->mr_map[1].ready) return fail(c, RGC_ERR_NO_INPUT, "rgc_mapreg_set_maps first");
   if (report) memset(report, 0, sizeof(rgc_mapreg_report) * 2);
@@ -3608,7 +3609,7 @@ int rgc_pc2_unpack(rgc_ctx* c, const void* data, int n, const rgc_pc2_layout* L,
 }
 
 int rgc_pc2_pack(rgc_ctx* c, int kind, const float* in, int n, int in_on_device, void* data_out) {
-  if (!c || !in || !data_out || n < 0 || (kind != 0 && kind != 1)) return RGC_ERR_INVALID;
+  if (!c || !in || !data_out || n < 0 || n > (1 << 24) || (kind != 0 && kind != 1)) return RGC_ERR_INVALID;   // (a message of more than 2^24 points: rgc_pc2_unpack's limit)
   if (n == 0) return RGC_OK;
   HIPCHK(c, hipSetDevice(c->device));
   const int cols = kind == 0 ? 4 : 5, step = kind == 0 ? 32 : 48;

@@ -33,6 +33,31 @@ deskew_buf = xyzi.copy()
 cap = 4096
 vx_c, vx_n, vx_m, vx_v, vx_cnt = np.zeros(cap * 3, np.int32), np.zeros(cap, np.int32), np.zeros(cap * 3), np.zeros(cap * 9), np.zeros(1, np.int32)
 d_buf = v.device_alloc(xyzi.nbytes); v.upload(d_buf, xyzi)
+msg = np.zeros((nt, 8), np.float32); msg[:, :3] = tgt
+lay = _lib.Pc2Layout(); lay.point_step = 32
+for i_, (o_, t_) in enumerate(((0, 7), (4, 7), (8, 7), (16, 7), (-1, 0), (-1, 0))):
+    lay.offset[i_], lay.datatype[i_] = o_, t_
+ring_out, time_out = np.zeros(nt, np.int32), np.zeros(nt, np.float32)
+msg_out = np.zeros(nt * 48, np.uint8)
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_iterations", ci), ("max_correspondence_distance", cd), ("transformation_epsilon", cd), ("euclidean_fitness_epsilon", cd)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("iterations", ci), ("converged", ci), ("state", ci), ("n_correspondences", ci), ("fitness", cd)]
+
+
+icp_p, icp_r = IcpParams(20, 2.0, 1e-6, 1e-6), IcpResult()
+feat = np.zeros((500, 4), np.float32); feat[:, :3] = tgt[:500]
+fac8, n_valid, kid, n_ev = np.zeros(500 * 8), np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32)
+big_out = np.zeros((4 * nt + 64, 4), np.float32)
+fe_p = _lib.FeParams(16, 0.5, 80.0, 1)
+fe_o = _lib.FeOut()      # (the optional per-point outputs NULL; the feature clouds need room)
+fe_sharp, fe_flat, fe_inten = (np.zeros((nt, 5), np.float32) for _ in range(3))
+fp_ = C.POINTER(C.c_float)
+fe_o.sharp, fe_o.flat, fe_o.inten, fe_o.feat_cap = fe_sharp.ctypes.data_as(fp_), fe_flat.ctypes.data_as(fp_), fe_inten.ctypes.data_as(fp_), nt
 d_out = v.device_alloc(xyzi.nbytes)
 P = lambda a: a.ctypes.data
 
@@ -58,6 +83,19 @@ def cases():
     yield "rgc_voxelgrid", [vp, vp, ci, ci, cf, vp, vp, ci], [h, P(xyzi), nt, 16, 0.3, P(vg_out), P(n_out), 0], (7,)
     yield "rgc_deskew", [vp, vp, ci, ci, vp, vp, ci], [h, P(deskew_buf), nt, 16, P(q4), P(t3), 0], (6,)
     yield "rgc_transform_cloud", [vp, vp, ci, ci, vp, vp, vp, ci], [h, P(xyzi), nt, 16, P(q4), P(t3), P(vg_out), 0], (7,)
+    # ---- the rows either side: wire, loop-closure ICP, the mapping node's registration, the resident map ----
+    yield "rgc_pc2_unpack", [vp, vp, ci, vp, vp, vp, vp, ci], [h, P(msg), nt, C.addressof(lay), P(vg_out), P(ring_out), P(time_out), 0], (7,)
+    yield "rgc_pc2_pack", [vp, ci, vp, ci, ci, vp], [h, 0, P(xyzi), nt, 0, P(msg_out)], (4,)
+    yield "rgc_icp_align", [vp, vp, ci, vp, ci, ci, vp, vp, vp], [h, P(src), ns, P(tgt), nt, 12, C.addressof(icp_p), P(np.zeros(16, np.float32)), C.addressof(icp_r)]
+    yield "rgc_mapreg_set_maps", [vp, vp, ci, vp, ci, ci], [h, P(xyzi), nt, P(xyzi), nt, 16]
+    yield "rgc_mapreg_associate", [vp, ci, vp, ci, vp, vp, vp, vp], [h, 1, P(feat), len(feat), P(q4), P(t3), P(fac8), P(n_valid)]
+    yield "rgc_map_reset", [vp, vp], [h, P(t3)]
+    yield "rgc_map_insert", [vp, vp, ci, ci, vp, vp, ci, vp], [h, P(xyzi), nt, 16, P(q4), P(t3), 0, P(kid)], (6,)
+    yield "rgc_map_evict", [vp, ci, vp, cd, vp], [h, 2, P(t3), 5.0, P(n_ev)]
+    yield "rgc_map_rebase", [vp, vp], [h, P(t3)]
+    yield "rgc_map_commit", [vp, cf, vp], [h, 0.3, P(n_out)]
+    yield "rgc_map_download", [vp, ci, vp, ci, vp], [h, 0, P(big_out), len(big_out), P(n_out)]
+    yield "rgc_frontend", [vp, vp, ci, ci, vp, vp], [h, P(xyzi), nt, 16, C.addressof(fe_p), C.addressof(fe_o)]
     yield "rgc_set_target_lazy", [vp, ci], [h, 2]
     yield "rgc_set_knn_reuse", [vp, ci], [h, 1]
     yield "rgc_set_regularization_method", [vp, ci], [h, 3]
