@@ -49,6 +49,12 @@ typedef enum rgc_status {
                                    unit normals asked for under a RegularizationMethod other
                                    than PLANE: rgc_set_regularization_method)                  */
 } rgc_status;
+/* What every entry point checks of its arguments before it touches anything (tests/fuzz/fuzz_null_args.py, fuzz_bad_args.py call each of them
+ * with nothing, and with one bad argument at a time): a required pointer that is NULL, a negative count, a count above 2^27 points (2^24
+ * for a PointCloud2 message), a stride that is not a multiple of 4 between the point type's minimum and 4096 bytes, a leaf size or a pose
+ * that is not finite -- RGC_ERR_INVALID / RGC_ERR_NONFINITE, and the context is as it was.  What it cannot check and takes the caller's
+ * word for: that a buffer holds as many points as the count says, and that a pointer called "device" (on_device != 0, the *_device
+ * entries) is one.  A HIP error is reported once, by the call it happened in (RGC_ERR_HIP, rgc_last_error); it does not surface again. */
 
 /* enum order = fast_gicp::NeighborSearchMethod, include/fast_gicp/gicp/gicp_settings.hpp:8 */
 typedef enum rgc_neighbor_method { RGC_DIRECT27 = 0, RGC_DIRECT7 = 1, RGC_DIRECT1 = 2 } rgc_neighbor_method;
