@@ -54,7 +54,9 @@ typedef enum rgc_status {
  * for a PointCloud2 message), a stride that is not a multiple of 4 between the point type's minimum and 4096 bytes, a leaf size or a pose
  * that is not finite -- RGC_ERR_INVALID / RGC_ERR_NONFINITE, and the context is as it was.  What it cannot check and takes the caller's
  * word for: that a buffer holds as many points as the count says, and that a pointer called "device" (on_device != 0, the *_device
- * entries) is one.  A HIP error is reported once, by the call it happened in (RGC_ERR_HIP, rgc_last_error); it does not surface again. */
+ * entries) is one -- unless RGC_CHECK_POINTERS=1 is in the environment when the context is created: then every such pointer is looked up first
+ * (device memory of the context's GPU, an allocation with room for the count) and a host pointer or a short buffer is RGC_ERR_INVALID.
+ * A HIP error is reported once, by the call it happened in (RGC_ERR_HIP, rgc_last_error); it does not surface again. */
 
 /* enum order = fast_gicp::NeighborSearchMethod, include/fast_gicp/gicp/gicp_settings.hpp:8 */
 typedef enum rgc_neighbor_method { RGC_DIRECT27 = 0, RGC_DIRECT7 = 1, RGC_DIRECT1 = 2 } rgc_neighbor_method;

@@ -32,7 +32,7 @@ constexpr int kMaxK = 32;
 // system-scope one -- the L2s written back so that the HOST may read what came before; nobody's host does behind these).
 constexpr unsigned kDevEvent = hipEventDisableTiming | hipEventReleaseToDevice;
 // Build-time switches (RGC_EXTRA_FLAGS=-D...): alternative routes to the SAME results, kept for A/B measurements.  A caller's
-// process reads RGC_LM_IMPL, RGC_SPEC_GRID, RGC_KNN_SEEDS, RGC_KNN_CACHE (a context's initial rgc_set_knn_reuse mode), RGC_TRACE_ALLOC, RGC_TRACE_CACHE,
+// process reads RGC_LM_IMPL, RGC_SPEC_GRID, RGC_KNN_SEEDS, RGC_KNN_CACHE (a context's initial rgc_set_knn_reuse mode), RGC_TRACE_ALLOC, RGC_TRACE_CACHE, RGC_CHECK_POINTERS,
 // RGC_FORCE_GENERAL (the odometer's settings on the general covariance route: a cross-check) and the
 // three scheduling switches RGC_JOIN_SPIN_US / RGC_PREP_EVENT_EXT / RGC_COOP_STREAM from the environment, once, in rgc_create.
 #ifndef RGC_LM_POST
@@ -228,6 +228,7 @@ struct rgc_ctx {
   bool test_fail_cache_alloc = false;  // RGC_TEST_FAIL_CACHE_ALLOC in the environment (rgc_create)
   bool force_general = false;          // RGC_FORCE_GENERAL=1 in the environment (rgc_create): PLANE / ADDITIVE on the general route too (a test's cross-check of the two routes)
   bool cache_dropped = false;          // the lists' buffers did not fit on the device: the context went down to the seeds by itself (rgc_get_knn_reuse)
+  bool check_ptrs = false;             // RGC_CHECK_POINTERS in the environment (rgc_create): every pointer a caller calls "device" is looked up before it is used (check_device_range)
   bool trace_cache = false;            // RGC_TRACE_CACHE in the environment (rgc_create): rgc_get_stats reports the lists' state on stderr
   double src_res = RGC_SRC_RES;  // (build flag) fixed cell size of the SCAN's kNN grid (only the map's grid must be the voxel grid); 0 = adaptive
   int map_wide_r = RGC_MAP_WIDE_R;          // (build flag; 0 = off, 2) block radius of the bulk kNN launch for a sparse map
@@ -336,6 +337,27 @@ int ensure(rgc_ctx* c, DevBuf& b, size_t bytes) {
   b.cap = want;
   static const bool trace = getenv("RGC_TRACE_ALLOC") != nullptr;  // developer aid: which buffer grew, and when
   if (trace) fprintf(stderr, "[rgc] buffer at ctx+%ld grew to %zu bytes (asked %zu)\n", (long)((char*)&b - (char*)c), want, bytes);
+  return RGC_OK;
+}
+
+// An integrator's aid (RGC_CHECK_POINTERS=1; off by default: a look-up per pointer per call, microseconds on a frame's critical path): is what
+// the caller calls a device buffer one -- device memory of THIS context's device, with room for `bytes` behind p?  A host pointer handed to
+// a *_device entry, a buffer of another GPU, a count larger than the allocation: RGC_ERR_INVALID instead of a memory fault on the device.
+static int check_device_range(rgc_ctx* c, const void* p, size_t bytes, const char* what) {
+  if (!c->check_ptrs || !p) return RGC_OK;
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(c, RGC_ERR_INVALID, "%s: %p is not memory the HIP runtime knows (a host pointer passed as a device pointer?)", what, p);
+  }
+  if (at.type != hipMemoryTypeDevice) return fail(c, RGC_ERR_INVALID, "%s: %p is not device memory", what, p);
+  if (at.device != c->device) return fail(c, RGC_ERR_INVALID, "%s: %p lives on device %d, the context on device %d", what, p, at.device, c->device);
+  void* base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)const_cast<void*>(p)) != hipSuccess) { (void)hipGetLastError(); return RGC_OK; }
+  const size_t off = (size_t)((const char*)p - (const char*)base);
+  if (off + bytes > size) return fail(c, RGC_ERR_INVALID, "%s: %zu bytes asked of an allocation that has %zu behind %p", what, bytes, size - off, p);
   return RGC_OK;
 }
 
@@ -963,6 +985,7 @@ int set_cloud(rgc_ctx* c, Cloud& cl, bool is_target, const float* xyz, int n, in
     return fail(c, RGC_ERR_TOO_FEW_POINTS, "%s cloud has %d points, need >= k = %d", is_target ? "target" : "source", n, c->prm.k_correspondences);
   HIPCHK(c, hipSetDevice(c->device));
   const int stride_f = stride_bytes / 4;
+  if (on_device) { const int rk = check_device_range(c, xyz, (size_t)n * stride_bytes - (stride_bytes - 12), is_target ? "target cloud" : "source cloud"); if (rk) return rk; }
   if (on_device) {
     cl.in = xyz;
     if (!is_target) c->src_in_pending = false;  // (no upload of this scan to wait for)
@@ -1571,6 +1594,7 @@ int rgc_create(int hip_device, const rgc_params* params, rgc_ctx** out) {
   if (const char* e = getenv("RGC_KNN_CACHE")) c->cache_on = atoi(e) != 0;
   if (!c->seeds_on) c->cache_on = false;  // (the lists sit on top of the seeds)
   c->trace_cache = getenv("RGC_TRACE_CACHE") != nullptr;
+  if (const char* e = getenv("RGC_CHECK_POINTERS")) c->check_ptrs = atoi(e) != 0;
   if (const char* e = getenv("RGC_FORCE_GENERAL")) c->force_general = atoi(e) != 0;
   c->test_fail_cache_alloc = getenv("RGC_TEST_FAIL_CACHE_ALLOC") != nullptr;
   if (const char* e = getenv("RGC_JOIN_SPIN_US")) c->join_spin_us = atoi(e);
@@ -2156,6 +2180,7 @@ int rgc_get_aligned_device(rgc_ctx* c, const float T[16], float* d_out, int stri
   if (!c || !T || !d_out) return RGC_ERR_INVALID;
   if (!c->src.ready) return fail(c, RGC_ERR_NO_INPUT, "source not set");
   if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096) return fail(c, RGC_ERR_INVALID, "bad stride");
+  { int rk = check_device_range(c, d_out, (size_t)c->src.n * stride_bytes - (stride_bytes - 12), "rgc_get_aligned_device: d_out"); if (rk) return rk; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = join_source(c);
   if (rc) return rc;
@@ -2427,7 +2452,11 @@ int rgc_get_voxels(rgc_ctx* c, int cap, int* coords, int* num, double* mean, dou
 // ---- B2 / B3 / B9: the stages either side of the operator in the odometer's frame body ----
 static int stage_in(rgc_ctx* c, const float* p, int n, int stride_bytes, int on_device, const float** d_in) {
   if (n > (1 << 27)) return fail(c, RGC_ERR_INVALID, "cloud has %d points, the limit is 2^27", n);  // (every entry point that takes a cloud: one limit)
-  if (on_device) { *d_in = p; return RGC_OK; }
+  if (on_device) {
+    if (n > 0) { const int rk = check_device_range(c, p, (size_t)n * stride_bytes - (stride_bytes - 12), "input cloud"); if (rk) return rk; }
+    *d_in = p;
+    return RGC_OK;
+  }
   const size_t bytes = (size_t)n * stride_bytes;
   int rc = ensure(c, c->pre_in, bytes);
   if (rc) return rc;
@@ -2496,6 +2525,8 @@ static int reframe_args_ok(rgc_ctx* c, const float* d_xyzi, int n, int stride_by
   const char* a0 = (const char*)d_xyzi; const char* a1 = a0 + (size_t)n * stride_bytes;
   const char* b0 = (const char*)d_scratch; const char* b1 = b0 + (size_t)n * 16;
   if (a0 < b1 && b0 < a1) return fail(c, RGC_ERR_INVALID, "rgc_set_target_reframed: d_scratch overlaps d_xyzi");
+  { int rk = check_device_range(c, d_xyzi, (size_t)n * stride_bytes - (stride_bytes - 12), "rgc_set_target_reframed: d_xyzi"); if (rk) return rk; }
+  { int rk = check_device_range(c, d_scratch, (size_t)n * 16, "rgc_set_target_reframed: d_scratch"); if (rk) return rk; }
   return RGC_OK;
 }
 
@@ -2821,6 +2852,7 @@ int rgc_voxelgrid_begin(rgc_ctx* c, const float* d_xyzi, int n, int stride_bytes
   if (!c || !d_xyzi || !d_out || n < 0 || n > (1 << 27)) return RGC_ERR_INVALID;
   if (stride_bytes < 12 || (stride_bytes & 3) || stride_bytes > 4096 || !(leaf > 0.f) || !std::isfinite(leaf)) return fail(c, RGC_ERR_INVALID, "bad stride or leaf size");
   if (c->vg_pend.active) return fail(c, RGC_ERR_INVALID, "rgc_voxelgrid_begin: the previous one has not been ended");
+  if (n > 0) { int rk = check_device_range(c, d_xyzi, (size_t)n * stride_bytes - (stride_bytes - 12), "rgc_voxelgrid_begin: d_xyzi"); if (rk) return rk; rk = check_device_range(c, d_out, (size_t)n * 16, "rgc_voxelgrid_begin: d_out"); if (rk) return rk; }
   HIPCHK(c, hipSetDevice(c->device));
   rgc_ctx::VgPending& pd_ = c->vg_pend;
   pd_ = rgc_ctx::VgPending{};

@@ -322,3 +322,32 @@ def test_one_bad_argument_at_a_time(reg_mod):
     assert r.returncode == 0, r.stderr[-1500:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["functions"] >= 33 and rep["calls"] >= 300 and rep["failures"] == [] and rep["same_result_afterwards"], rep["failures"]
+
+
+def test_the_pointer_checker(reg_mod, monkeypatch):
+    """RGC_CHECK_POINTERS=1 (an integrator's aid, off by default): what a caller calls a device buffer is looked up first -- a host pointer, a
+    count larger than the allocation: RGC_ERR_INVALID where there would be a memory fault on the device; correct calls are untouched."""
+    import rgc_slam_amd.synth as synth
+    monkeypatch.setenv("RGC_CHECK_POINTERS", "1")
+    world, base = synth.make_world_and_map(6000, seed=5)
+    a = np.zeros((len(base), 4), np.float32); a[:, :3] = base
+    v = reg_mod.odometer_vgicp(0)
+    d, s = v.device_alloc(a.nbytes), v.device_alloc(a.nbytes)
+    small = v.device_alloc(16 * 100)
+    v.upload(d, a)
+    v.setInputTargetDevice(d, len(a), 16)                                          # correct: works
+    ref = v.getTargetCovariances()
+    for bad in (lambda: v.setInputTargetDevice(a.ctypes.data, len(a), 16),         # a host pointer called "device"
+                lambda: v.setInputSourceDevice(a.ctypes.data, len(a), 16),
+                lambda: v.setInputTargetDevice(small, len(a), 16),                 # 100 points allocated, 6 000 claimed
+                lambda: v.setInputTargetDevice(d + 16 * 10, len(a), 16),           # an offset into the allocation: ten points short
+                lambda: v.setInputTargetReframed(d, len(a), 16, np.array([0, 0, 0, 1.0]), np.zeros(3), small),
+                lambda: v.setInputTargetReframed(a.ctypes.data, len(a), 16, np.array([0, 0, 0, 1.0]), np.zeros(3), s)):
+        with pytest.raises(reg_mod.RgcError):
+            bad()
+    v.setInputTargetDevice(d + 16 * 10, len(a) - 10, 16)                           # the same offset with the right count: fine
+    v.setInputTargetReframed(d, len(a), 16, np.array([0, 0, 0, 1.0]), np.zeros(3), s)
+    assert np.array_equal(v.getTargetCovariances(), ref)
+    for p_ in (d, s, small):
+        v.device_free(p_)
+    v.close()
