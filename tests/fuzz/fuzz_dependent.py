@@ -2,7 +2,7 @@
 rgc_align_end_reframe) on random maps, scans, lengths, reuse modes and lazy margins -- one context, two contexts, the Python frame loop, the C++
 frame loop (librgc_seq.so) -- all against the plain calls a caller without any of it would make on one context: rgc_transform_cloud,
 rgc_set_target_device, rgc_set_source_device, rgc_align, the world pose composed in numpy.  Motions and world poses bit for bit.
-    python tests/fuzz/fuzz_dependent.py [trials] [seed]"""
+    python tests/fuzz/fuzz_dependent.py [trials] [seed] [max map points]"""
 import sys, os, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -13,11 +13,12 @@ from rgc_slam_amd import registration
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 250000
 rep = {"trials": 0, "frames": 0, "variants_compared": 0, "failures": [], "max_d": 0.0}
 t0 = time.time()
 for trial in range(trials):
     rng = np.random.default_rng(seed0 * 122949829 + trial)
-    nt, ns, K = int(np.exp(rng.uniform(np.log(20000), np.log(250000)))), int(rng.integers(2000, 30000)), int(rng.integers(5, 12))
+    nt, ns, K = int(np.exp(rng.uniform(np.log(20000), np.log(nmax)))), int(rng.integers(2000, 30000)), int(rng.integers(5, 12))
     reuse, lazy = int(rng.integers(0, 3)), int(rng.choice([0, 0, 2]))
     tag = {"trial": trial, "n_target": nt, "n_source": ns, "frames": K, "reuse": reuse, "lazy": lazy}
     try:
