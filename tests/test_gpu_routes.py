@@ -351,3 +351,12 @@ def test_the_pointer_checker(reg_mod, monkeypatch):
     for p_ in (d, s, small):
         v.device_free(p_)
     v.close()
+
+
+def test_threads_on_contexts_of_their_own(reg_mod):
+    """tests/fuzz/fuzz_threads.py: eight host threads, each with contexts of its own, run random registrations, leaf filters and front-ends at
+    the same time; every result is the one of the same call made alone."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_threads.py"), "8", "20", "111"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["jobs"] == 160 and rep["failures"] == [], rep["failures"][:5]
