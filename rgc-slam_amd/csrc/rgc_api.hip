@@ -1657,10 +1657,19 @@ int rgc_set_params(rgc_ctx* c, const rgc_params* p) {
   int rc = check_params(c, p);
   if (rc) return rc;
   const bool redo = p->voxel_res != c->prm.voxel_res || p->k_correspondences != c->prm.k_correspondences;
+  if (redo && solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");  // (the clouds are prepared again below)
   if (p->voxel_res != c->prm.voxel_res) c->src_res_auto = 0.0;
   c->prm = *p;
   c->corr_valid = false;
   if (redo) {  // covariances / voxel map depend on these: recompute from the resident inputs
+    if (c->tgt_owner) {
+      // a BORROWED target (rgc_share_target) is the owner's, prepared under the owner's settings, and its input buffer is the owner's to
+      // keep or free: nothing to recompute from here (tests/fuzz/fuzz_api.py: the re-preparation read an input the owner had long replaced --
+      // a memory fault on the device).  The alias goes; share again once the owner holds a target under these settings.
+      release_cloud(c->tgt);
+      c->tgt.ready = false; c->tgt.n = 0; c->tgt.in = nullptr;
+      c->tgt_owner = nullptr;
+    }
     if (c->src.ready) { c->src.ready = false; if ((rc = prepare_cloud(c, c->src, false))) return rc; }
     if (c->tgt.ready) { c->tgt.ready = false; if ((rc = prepare_cloud(c, c->tgt, true))) return rc; }
   }
@@ -2357,6 +2366,16 @@ int rgc_swap_source_and_target(rgc_ctx* c) {
                     from[a]->n, (double*)kept[a].p);
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess) { drop_kept(); return fail(c, RGC_ERR_HIP, "hipStreamSynchronize failed (swap)"); }
+  }
+  // A target bound to the resident map (rgc_map_commit) was set from the map's own filter output buffer, which the NEXT commit overwrites:
+  // as the scan it would keep pointing there (tests/fuzz/fuzz_api.py: swapped back later, it was prepared from another cloud's
+  // points).  It takes a copy of its own with it.
+  if (c->map_target.p && c->tgt.in == (const float*)c->map_target.p) {
+    const size_t bytes = (size_t)c->tgt.n * 16;
+    if ((rc = ensure(c, c->tgt.in_copy, bytes))) { drop_kept(); return rc; }
+    if (hipMemcpyAsync(c->tgt.in_copy.p, c->map_target.p, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); drop_kept(); return fail(c, RGC_ERR_HIP, "swap: copy of the map's target failed"); }
+    c->tgt.in = (const float*)c->tgt.in_copy.p;
+    c->tgt.stride_f = 4;
   }
   std::swap(c->src.in_copy, c->tgt.in_copy);
   std::swap(c->src.in, c->tgt.in);

@@ -40,6 +40,8 @@ only = os.environ.get("FUZZ_ONLY")
 for trial in range(trials):
     if only is not None and trial != int(only):
         continue
+    if os.environ.get("FUZZ_PROGRESS"):
+        print("trial", trial, file=sys.stderr, flush=True)
     rng = np.random.default_rng(seed0 * 86028121 + trial)
     world, base = synth.make_world_and_map(int(rng.integers(3000, 40000)), seed=int(rng.integers(1, 1 << 30)))
     base = base.astype(np.float32)
@@ -222,6 +224,14 @@ for trial in range(trials):
                             rep["solves_bit_equal"] += int(np.array_equal(other.getFinalTransformation(), exp[0]))
                             if not dT <= (1e-6 if other.nr_iterations == exp[1] else 2e-4):
                                 rep["failures"].append(dict(tag, error="solve on a shared target differs", dT=dT))
+                                if only is not None:
+                                    f = reg.odometer_vgicp(0); f.setResolution(m.res); f.setCorrespondenceRandomness(m.k); f.setInputTarget(m.tgt); f.setInputSource(m.src)
+                                    ct, cs = f.getTargetCovariances(), f.getSourceCovariances()
+                                    vt, vs = v.getTargetCovariances(), v.getSourceCovariances()
+                                    print("owner: target covariances equal a fresh context's:", np.array_equal(ct, vt), float(np.abs(ct - vt).max()), " source:", np.array_equal(cs, vs), float(np.abs(cs - vs).max()),
+                                          "\n voxels:", v.stats()["n_voxels"], f.stats()["n_voxels"], file=sys.stderr)
+                                    v.align(g, want_output=False); print(" owner's own solve vs fresh:", float(np.abs(v.getFinalTransformation() - exp[0]).max()), file=sys.stderr)
+                                    f.close()
             elif op == "map_insert":
                 c = new_cloud(lo=300)[: int(rng.integers(200, 6000))]
                 a = np.zeros((len(c), 4), np.float32); a[:, :3] = c
@@ -312,6 +322,12 @@ for trial in range(trials):
                     print("covariances that differ from a full build's:", len(bad), bad[:10], "\n", c[bad[0]] if len(bad) else "", "\n", full[bad[0]] if len(bad) else "", v.stats(), file=sys.stderr)
             if len(rep["failures"]) > 12:
                 break
+        if os.environ.get("FUZZ_DEBUG_END"):
+            print("state at the end:", v.stats(), "lazy", m.lazy, file=sys.stderr, flush=True)
+            v.setResolution(float(os.environ["FUZZ_DEBUG_END"]))
+            print("after the setting (enqueued)", file=sys.stderr, flush=True)
+            v.synchronize()
+            print("synchronised:", v.stats(), file=sys.stderr, flush=True)
         if m.pending:
             v.align_end()
     except Exception as e:

@@ -27,28 +27,43 @@ for trial in range(trials):
         scans = [synth.make_scan_n(world, poses[i + 1], ns, seed=int(rng.integers(1, 1 << 30)))["xyz"] for i in range(K)]
         Tw0 = np.asarray(poses[0], np.float64)
         I4 = np.eye(4, dtype=np.float32)
-        # ---- the plain calls, one context, nothing kept ----
+        # ---- the plain calls, nothing kept: on one context, and on two taking turns (a scan's grid follows the previous scan of ITS context --
+        #      DESIGN.md 5.1 -- so the two-context variants below are compared with the plain calls made on two contexts the same way) ----
         p = registration.odometer_vgicp(0)
         p.setNeighbourReuse(0)
+        p2 = registration.odometer_vgicp(0)
+        p2.setNeighbourReuse(0)
 
         def to_dev(v, xyz):
             a = np.zeros((xyz.shape[0], 4), np.float32); a[:, :3] = xyz
             d = v.device_alloc(a.nbytes); v.upload(d, a); return d
         dm, db = to_dev(p, tgt), p.device_alloc(16 * len(tgt))
         ds = [to_dev(p, s) for s in scans]
-        ref_m, ref_w = [], []
-        Tw, g = Tw0.copy(), I4.copy()
-        for i in range(K):
-            q, t = bench.world_to_body(Tw)
-            p.transformCloudDevice(dm, len(tgt), 16, q, t, db)
-            p.setInputTargetDevice(db, len(tgt), 16)
-            p.setInputSourceDevice(ds[i], len(scans[i]), 16)
-            p.align(g, want_output=False, want_fitness=True)
-            T = p.getFinalTransformation()
-            W = bench.compose_world(Tw, T)   # world_T * T in fp64, rows in ascending k (rgc_align_end_reframe's composition)
-            Tw = W
-            g = T
-            ref_m.append(T.copy()); ref_w.append(Tw.copy())
+        refs = {}
+        for two in (False, True):
+            ref_m, ref_w = [], []
+            Tw, g = Tw0.copy(), I4.copy()
+            for i in range(K):
+                c_ = p2 if (two and i % 2 == 1) else p
+                q, t = bench.world_to_body(Tw)
+                c_.transformCloudDevice(dm, len(tgt), 16, q, t, db)
+                c_.setInputTargetDevice(db, len(tgt), 16)
+                c_.setInputSourceDevice(ds[i], len(scans[i]), 16)
+                c_.align(g, want_output=False, want_fitness=True)
+                T = c_.getFinalTransformation()
+                Tw = bench.compose_world(Tw, T)   # world_T * T in fp64, rows in ascending k (rgc_align_end_reframe's composition)
+                g = T
+                ref_m.append(T.copy()); ref_w.append(Tw.copy())
+            refs[two] = (ref_m, ref_w)
+            if two:
+                p2.close()
+                p.close()
+                p = None
+            else:   # (the one-context reference is done: a fresh pair for the two-context one)
+                p.close()
+                p = registration.odometer_vgicp(0); p.setNeighbourReuse(0)
+                dm, db = to_dev(p, tgt), p.device_alloc(16 * len(tgt))
+                ds = [to_dev(p, s_) for s_ in scans]
         rep["frames"] += K
         # ---- the sequence's own entry points, each variant on contexts of its own (a scan's grid follows its context's previous scan: the
         #      plain calls above start from a fresh context, so must these) ----
@@ -64,6 +79,7 @@ for trial in range(trials):
             seq = bench.DependentSequence(pv.v, d_map, len(tgt), d_scans, [len(s) for s in scans])
             m, wd, _ = (seq.run_cpp if cpp else seq.run)(0, K, Tw0, I4, overlap)
             rep["variants_compared"] += 1
+            ref_m, ref_w = refs[overlap]
             same = all(np.array_equal(a_, b_) for a_, b_ in zip(m, ref_m)) and all(np.array_equal(a_, b_) for a_, b_ in zip(wd, ref_w))
             if not same:
                 d = max(float(np.abs(a_ - b_).max()) for a_, b_ in zip(m, ref_m))
@@ -73,7 +89,6 @@ for trial in range(trials):
             seq.close()
             for w in pv.v:
                 w.close()
-        p.close()
     except Exception as e:
         import traceback
         rep["failures"].append(dict(tag, error="exception: %r" % (e,), where=traceback.format_exc()[-500:]))

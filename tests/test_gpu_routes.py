@@ -255,6 +255,69 @@ def test_a_pose_that_is_none_is_refused(reg_mod):
     v.device_free(d); v.device_free(s); v.close()
 
 
+def test_settings_and_a_borrowed_target(reg_mod):
+    """Found by tests/fuzz/fuzz_api.py (2 000 trials in): rgc_set_params with another leaf size or k prepares the context's clouds again from
+    their inputs -- including a BORROWED target (rgc_share_target), whose input is the owner's and may be long gone: a memory fault on the
+    device.  The alias is dropped instead (share again); and the same settings are refused with a solve in flight."""
+    import rgc_slam_amd.synth as synth
+    world, base = synth.make_world_and_map(20000, seed=5)
+    base = base.astype(np.float32)
+    a, b = reg_mod.odometer_vgicp(0), reg_mod.odometer_vgicp(0)
+    a.setInputTarget(base[:8000])
+    b.shareTargetFrom(a)
+    for k in range(4):                       # the owner moves on: its old input buffer is re-used
+        a.setInputTarget(base[2000 * k: 2000 * k + 6000])
+    b.setInputSource(base[:3000])
+    b.setResolution(2.0)                     # used to fault; now: the alias is gone
+    b.synchronize()
+    with pytest.raises(reg_mod.RgcError):
+        b.align(np.eye(4, dtype=np.float32), want_output=False)
+    a.setResolution(2.0)
+    b.shareTargetFrom(a)
+    b.align(np.eye(4, dtype=np.float32), want_output=False)
+    a.setInputSource(base[:3000])
+    a.align(np.eye(4, dtype=np.float32), want_output=False)
+    assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())
+    a.align_begin(np.eye(4, dtype=np.float32))
+    with pytest.raises(reg_mod.RgcError):
+        a.setResolution(1.0)                 # the clouds would be prepared again under the running solve
+    a.align_end()
+    a.close(); b.close()
+
+
+def test_a_map_bound_target_swapped_away(reg_mod):
+    """Found by tests/fuzz/fuzz_api.py: a target committed from the resident map is set from the map's own filter output buffer; swapped into
+    the scan it kept pointing there, the next commit overwrote the buffer, and swapped back it was prepared from another cloud's points
+    (its voxel table missed voxels).  The swap gives it a copy of its own."""
+    import rgc_slam_amd.synth as synth
+    from rgc_slam_amd import local_map
+    world, base = synth.make_world_and_map(20000, seed=5)
+    base = base.astype(np.float32)
+    rng = np.random.default_rng(2)
+
+    def vox(v):
+        x = v.getVoxels()
+        o = np.lexsort(x["coords"].T[::-1])
+        return {k: x[k][o] for k in ("coords", "num", "mean", "cov")}
+    v = reg_mod.odometer_vgicp(0)
+    lm = local_map.RollingLocalMap(v)
+    lm.reset(None)
+    kf = np.zeros((4000, 4), np.float32); kf[:, :3] = base[rng.choice(len(base), 4000, replace=False)]
+    lm.insert(kf, np.array([0, 0, 0, 1.0]), np.zeros(3))
+    lm.commit(0.5)
+    T1 = lm.target()[:, :3].copy()
+    v.setInputSource(T1 + np.float32(0.01))
+    v.swapSourceAndTarget()                  # the map's target is the scan now
+    lm.commit(0.3)                           # ... and the map writes its buffer again
+    v.swapSourceAndTarget()                  # back: must still be T1
+    f = reg_mod.odometer_vgicp(0)
+    f.setInputTarget(T1)
+    x, r = vox(v), vox(f)
+    assert all(np.array_equal(x[k], r[k]) for k in ("coords", "num", "mean", "cov"))
+    assert np.array_equal(v.getTargetCovariances(), f.getTargetCovariances())
+    v.close(); f.close()
+
+
 def test_fuzz_of_the_call_sequences(reg_mod):
     """tests/fuzz/fuzz_api.py, a short campaign: random sequences of the registration's calls against a model of what must work and what must be
     refused, every solve against a fresh context's."""
