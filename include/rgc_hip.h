@@ -101,6 +101,8 @@ RGC_API int rgc_set_voxel_accumulation_mode(rgc_ctx* ctx, int mode);
  * here the context is long-lived and re-used, device buffers grow on demand). */
 RGC_API int  rgc_create(int hip_device, const rgc_params* params /* NULL = defaults */, rgc_ctx** out);
 RGC_API void rgc_destroy(rgc_ctx* ctx);
+/* setResolution / setCorrespondenceRandomness / setMaximumIterations ... in one struct.  A new voxel_res or k_correspondences prepares the
+ * clouds the context holds again, from their inputs (a device cloud must still be where it was set from); refused with a solve in flight. */
 RGC_API int  rgc_set_params(rgc_ctx* ctx, const rgc_params* params);
 RGC_API int  rgc_get_params(const rgc_ctx* ctx, rgc_params* params);
 RGC_API const char* rgc_last_error(const rgc_ctx* ctx);
@@ -183,7 +185,10 @@ RGC_API int rgc_align_end_reframe(rgc_ctx* solve, rgc_ctx* next, double world_T[
  * on a sequence whose map does not change every frame (the next scan is prepared on one while the current one is solved on the
  * other).  The owner must stay alive and must not be destroyed while ctx uses the target; when the owner prepares a new target
  * (rgc_set_target*, a commit that rebuilds) ctx's next rgc_align* fails with RGC_ERR_INVALID until the target is shared again.
- * Synchronises both contexts.  No reference counterpart (the reference builds one FastVGICP per frame). */
+ * Synchronises both contexts.  No reference counterpart (the reference builds one FastVGICP per frame).
+ * A borrowed target is the OWNER's, prepared under the owner's settings: rgc_set_params on ctx with another voxel_res or k (which prepares a
+ * context's own clouds again) drops the alias -- share again once the owner holds a target under those settings; swapping, clearing or
+ * setting covariances on a borrowed target is refused or drops it likewise. */
 RGC_API int rgc_share_target(rgc_ctx* ctx, rgc_ctx* owner);
 /* pcl::Registration::getFitnessScore() for an arbitrary pose */
 RGC_API int rgc_fitness(rgc_ctx* ctx, const float T[16], double* fitness);
