@@ -1,0 +1,123 @@
+"""Randomised pinning of the C ORACLE's front-end (oracle/rgc_oracle_aux.c: orc_frontend, scanRegistration.cpp:98-660) against the literal numpy
+restatement it was first checked with on one committed sweep (oracle/py_frontend.py -> tests/golden/fx_frontend.npz): random synthetic sweeps --
+16 / 32 / 64 beams, tilted and displaced sensor poses, near grazing returns (the intensity-smoothing branch), painted intensity stripes (the
+intensity corners), junk returns the A1 filter must drop -- ring bucket, the three curvature arrays bit for bit, occlusion / suppression flags,
+ground marks, ground points in push order, the ground plane, labels, and the three feature clouds (points, order, weights).  No GPU.
+    python tests/fuzz/fuzz_oracle_pin_frontend.py [trials] [seed]"""
+import sys, os, json, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import rgc_slam_amd.synth as synth
+from oracle import oracle as orc, py_frontend as pf
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rep = {"trials": 0, "failures": [], "by_beams": {}, "with_ground_plane": 0, "with_intensity_corners": 0, "smoothing_branch_ran": 0,
+       "max": {"ground_normal": 0.0, "ground_distance": 0.0, "ground_src": 0.0}}
+worlds = {}
+t0 = time.time()
+for trial in range(trials):
+    rng = np.random.default_rng(seed0 * 2654435761 % (1 << 32) + trial)
+    beams = int(rng.choice([16, 16, 16, 32, 64]))
+    n_az = int(rng.integers(120, 520)) if beams == 16 else int(rng.integers(100, 260)) if beams == 32 else int(rng.integers(80, 150))
+    wseed = int(rng.integers(0, 6))
+    tag = {"trial": trial, "beams": beams, "n_az": n_az, "world": wseed}
+    try:
+        if wseed not in worlds:
+            worlds[wseed] = synth.make_world(half_extent=50.0, seed=synth.SEED + wseed)
+        w = worlds[wseed]
+        T = synth.se3(synth.rot_zyx(rng.uniform(-3.1, 3.1), rng.normal(0, 0.03), rng.normal(0, 0.03)), [rng.uniform(-8, 8), rng.uniform(-8, 8), rng.normal(0, 0.05)])
+        elev = synth.VLP16_ELEV if beams == 16 else synth.hdl32_elev() if beams == 32 else synth.hdl64_elev()
+        sc = synth.make_scan(w, T, elev_deg=elev, n_az=n_az, seed=int(rng.integers(1, 1 << 30)))
+        raw = np.concatenate([sc["xyz"], sc["intensity"][:, None]], axis=1).astype(np.float32)
+        ring = sc["ring"].copy()
+        near = rng.random() < 0.4
+        if near:       # a stretch of returns pulled close to the sensor: grazing incidence at short range
+            lo = int(rng.integers(2, beams // 2))
+            m = (ring >= lo) & (ring <= lo + 1)
+            raw[m, :3] *= np.float32(rng.uniform(0.08, 0.25))
+        if rng.random() < 0.5:   # painted intensity stripes
+            per = int(rng.integers(3, 15))
+            raw[:, 3] = np.where((np.arange(len(raw)) // per) % 2 == 0, 20.0, 200.0).astype(np.float32) + rng.integers(0, 5, len(raw)).astype(np.float32)
+        # the reference's A1 filter restated (scanRegistration.cpp:112-113, :732-763: squared range in float against thresholds 0.5 / 80, and the
+        # strip behind the sensor `x < 0 && |y| < 0.5`); the generator applies it to what it casts, the near stretch moves points inside
+        x, y, z = raw[:, 0], raw[:, 1], raw[:, 2]
+        dis = (x * x + y * y) + z * z
+        keep = ~(dis < np.float32(0.5) * np.float32(0.5)) & ~(dis > np.float32(80.0) * np.float32(80.0)) & ~((x < 0) & (np.abs(y) < np.float32(0.5)))
+        raw, ring = raw[keep], ring[keep]
+        feed = raw
+        if rng.random() < 0.3:   # junk the filter must drop, in the middle of the stream
+            junk = np.array([[0.1, 0.1, 0.0, 5], [100.0, 0, 0, 5], [np.nan, 1, 1, 5], [0.2, -0.1, 0.1, 9]], np.float32)
+            at = int(rng.integers(0, len(raw)))
+            feed = np.concatenate([raw[:at], junk, raw[at:]])
+        o = orc.frontend(feed, n_scans=beams)
+        if beams != 64:
+            order = np.argsort(ring, kind="stable")
+            if o["n_cloud"] != len(raw) or not np.array_equal(o["cloud"][:, :3], raw[order, :3]):
+                rep["failures"].append(dict(tag, error="ring bucket / filter", c=int(o["n_cloud"]), expected=int(len(raw))))
+                rep["trials"] += 1
+                continue
+            ring_count = np.bincount(ring, minlength=beams).astype(np.int32)
+            if not np.array_equal(o["ring_count"][:beams], ring_count):
+                rep["failures"].append(dict(tag, error="ring counts"))
+        else:
+            # 64 beams: the reference's ring formula (scanRegistration.cpp:163-176) drops what it maps outside [0, 50) and does not follow the
+            # generator's elevation ranks: the bucket is checked for being one (rings ascending, firing order kept inside a ring, every point
+            # one of the sweep's), and the stages behind it are pinned on the oracle's own bucket
+            where = {raw[j, :3].tobytes(): j for j in range(len(raw))}
+            order = np.array([where.get(o["cloud"][j, :3].tobytes(), -1) for j in range(o["n_cloud"])], np.int64)
+            oring = np.floor(o["cloud"][:, 3]).astype(np.int64)
+            ring_count = np.asarray(o["ring_count"][:beams], np.int32)
+            ok = order.min() >= 0 and len(set(order.tolist())) == len(order) and np.all(np.diff(oring) >= 0) and np.all((np.diff(order) > 0) | (np.diff(oring) > 0)) \
+                and np.array_equal(np.bincount(oring, minlength=beams)[:beams], ring_count)
+            if not ok:
+                rep["failures"].append(dict(tag, error="ring bucket (64 beams)"))
+                rep["trials"] += 1
+                continue
+        st = pf.stencils(o["cloud"][:, :3], raw[order, 3].astype(np.int64))
+        for k in ("curvature", "curvature2", "inten_curvature"):
+            if not np.array_equal(st[k], o[k]):
+                rep["failures"].append(dict(tag, error=k, differing=int(np.sum(st[k] != o[k]))))
+        if np.any((st["angle"] < 0.07) & (st["range"] < 2) & (st["angle"] > 0)):
+            rep["smoothing_branch_ran"] += 1
+        mark, pushed, g = pf.ground(o["cloud"], ring_count, st["range"])
+        if not np.array_equal(mark, o["ground_marked"]):
+            rep["failures"].append(dict(tag, error="ground marks", differing=int(np.sum(mark != o["ground_marked"]))))
+        elif len(pushed) != len(o["ground_pts"]) or not np.array_equal(o["ground_pts"][:, :3], o["cloud"][pushed, :3]):
+            rep["failures"].append(dict(tag, error="ground points", c=len(o["ground_pts"]), py=len(pushed)))
+        elif (g is not None) != bool(o["ground_valid"]) and len(pushed) >= 3:
+            rep["failures"].append(dict(tag, error="ground plane validity", c=bool(o["ground_valid"]), py=g is not None))
+        elif g is not None and o["ground_valid"]:
+            go = np.asarray(o["groundparam"])
+            e_n, e_d, e_s = float(np.abs(go[0:3] - g[0:3]).max()), float(abs(go[9] - g[9])), float(abs(go[10] - g[10]))
+            # (a plane through few, nearly collinear points has no stable smallest eigenvector: compared where the restatement's own two
+            #  smallest eigenvalues are apart)
+            near_pts = o["cloud"][pushed, :3].astype(np.float64)
+            ev = np.linalg.eigvalsh(np.cov(near_pts.T)) if len(near_pts) > 3 else np.zeros(3)
+            if len(near_pts) > 30 and ev[1] > 1e3 * max(ev[0], 1e-12):
+                rep["with_ground_plane"] += 1
+                for kk, vv in (("ground_normal", e_n), ("ground_distance", e_d), ("ground_src", e_s)):
+                    rep["max"][kk] = max(rep["max"][kk], vv)
+                if not (e_n < 1e-7 and e_d < 1e-8 and e_s < 1e-8):
+                    rep["failures"].append(dict(tag, error="ground plane", normal=e_n, distance=e_d, src=e_s))
+        sel = pf.select(o["cloud"], st, pf.occlusion(st["range"]), o["ground_marked"], o["scan_start"], o["scan_end"])
+        for k in ("label", "inten_label", "picked"):
+            if not np.array_equal(sel[k], o[k]):
+                rep["failures"].append(dict(tag, error=k, differing=int(np.sum(sel[k] != o[k]))))
+        if sel["n_sharp_own"] != o["n_sharp_own"]:
+            rep["failures"].append(dict(tag, error="own sharp count", c=int(o["n_sharp_own"]), py=int(sel["n_sharp_own"])))
+        for k in ("sharp", "flat", "inten"):
+            if sel[k].shape != o[k].shape or not np.array_equal(sel[k], o[k]):
+                rep["failures"].append(dict(tag, error="feature cloud " + k, c=list(o[k].shape), py=list(sel[k].shape)))
+        if len(o["inten"]):
+            rep["with_intensity_corners"] += 1
+        rep["by_beams"][str(beams)] = rep["by_beams"].get(str(beams), 0) + 1
+    except Exception as e:
+        import traceback
+        rep["failures"].append(dict(tag, error="exception: %r" % (e,), where=traceback.format_exc()[-600:]))
+    rep["trials"] += 1
+    if len(rep["failures"]) > 12:
+        break
+rep["wall_s"] = round(time.time() - t0, 1)
+print(json.dumps(rep))
