@@ -5,6 +5,7 @@ stencils (:270-306), A6 occlusion mask (:433-456), A7 per-sector sort and greedy
 :645-656, and (round 6) A5, the ground marking and the weighted plane fit (:308-431, `ground` below).  The ring bucket (A2) is an
 input here (pinned by the sensor-model properties in tests/test_oracle_frontend.py).  Plain loops: use on small sweeps only.  Per-frame arrays start at zero and
 std::sort's unspecified tie order is fixed as ascending index (item 10), like every other implementation in this repository.
+PARITY UNPINNED: the reference holds no vectors for this stage and cannot be built here; this is the builder's second restatement.
 """
 import numpy as np
 

@@ -1,6 +1,8 @@
 """Independent numpy/scipy restatement of the loop-closure ICP (pcl::IterativeClosestPoint as configured
 at RGC_mapping.cpp:2050-2069).  TEST INFRASTRUCTURE ONLY: it pins the C oracle's orc_icp_align.  cKDTree for the nearest
-neighbours, numpy SVD for the rigid fit -- different machinery from the C code's grid and Jacobi."""
+neighbours, numpy SVD for the rigid fit -- different machinery from the C code's grid and Jacobi.
+PARITY UNPINNED: PCL is absent from /root/reference and from this image; pcl::IterativeClosestPoint's behaviour is restated from its published
+algorithm; this is the builder's second restatement, not the reference's binary."""
 import numpy as np
 from scipy.spatial import cKDTree
 

@@ -2,7 +2,9 @@
 RGC_mapping.cpp:1069-1358, lidarFactor.hpp:9-51,91-121).  TEST INFRASTRUCTURE ONLY: it pins oracle/rgc_oracle_map.c.
 
 Deliberately different machinery from the C oracle: cKDTree for the 5-NN, numpy eigh / lstsq for the line test and the
-plane fit, finite-difference Jacobians for the normal equations, scipy BFGS on the robust cost for the optimum."""
+plane fit, finite-difference Jacobians for the normal equations, scipy BFGS on the robust cost for the optimum.
+PARITY UNPINNED: the reference holds no vectors for this path and cannot be built here (Ceres, PCL absent); this is the builder's second
+restatement, not the reference's binary."""
 import numpy as np
 from scipy.spatial import cKDTree
 

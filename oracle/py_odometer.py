@@ -1,4 +1,6 @@
 """vg_ICP::ICP_thread's per-frame body (src/RGC_odometer.cpp:848-1256, 1319-1322), restated line by line in numpy -- TEST INFRASTRUCTURE.
+PARITY UNPINNED: the reference holds no recorded sequence and cannot be built here; this restatement is checked against nothing but itself
+(tests/golden/fx_sequence.npz is its own output) and pins the product's mirrors, not the other way round.
 
 This is the independent pin of the frame body's ORCHESTRATION: it keeps the reference's variable names and statement order (first_flag,
 submapflag, surroundingCloud, histoary_pose, gflag / changegroundflag, q_w_curr_delta, t_last_curr_l, ...) and shares no code with the
