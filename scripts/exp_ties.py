@@ -1,3 +1,6 @@
+"""Lattices of exact distance ties (regular and stretched spacing, with repeated points): how many of the map's queries the bulk kNN defers to the
+cooperative kernel, and whether every covariance still agrees with the oracle's (the tie rule: ascending original index).  GPU.
+    python scripts/exp_ties.py"""
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np
 from rgc_slam_amd import registration

@@ -1,3 +1,4 @@
+# one batch of every differential campaign (tests/fuzz/*.py) with new seeds, on the GPU box: reports under gpurun_out/big/ (profiles/r06_fuzz_big_batch.json)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/big
 timeout 900 python3 tests/fuzz/fuzz_api.py 2000 21 45 > gpurun_out/big/api.json 2> gpurun_out/big/api.err

@@ -1,3 +1,5 @@
+# the three campaigns that found bugs in round 6 (call sequences, target routes, everything on one context) once more with new seeds: gpurun_out/big2/
+# (profiles/r06_fuzz_second_batch.json)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/big2
 timeout 330 python3 tests/fuzz/fuzz_api.py 2500 41 45 > gpurun_out/big2/api.json 2> gpurun_out/big2/api.err

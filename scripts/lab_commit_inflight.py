@@ -1,3 +1,6 @@
+"""Repro behind a fix (round 6): rgc_map_commit with a solve in flight on the map's context must be refused BEFORE it writes anything -- commits with
+changing leaf sizes between rgc_align_begin and rgc_align_end, under PLANE and FROBENIUS; regression test: tests/test_gpu_routes.py::test_a_refused_commit_writes_nothing.  GPU.
+    python scripts/lab_commit_inflight.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

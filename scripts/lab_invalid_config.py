@@ -1,3 +1,6 @@
+"""Repro behind a fix (round 6, found by tests/fuzz/fuzz_api.py): a sequence of re-framed / device / host targets, cleared clouds and user covariances that
+left a context with a stale guard ('invalid configuration'); the sequence is cut down step by step to the calls that matter.  GPU.
+    python scripts/lab_invalid_config.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,6 @@
+"""When do the neighbour lists of an unchanged map engage?  A map handed over five times by rgc_set_target_reframed at random poses: queries searched,
+deferred, and cells per frame (VAR=align / vox: with a solve or a voxel read-back between the frames).  GPU.
+    VAR=align python scripts/lab_lists_engage.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
