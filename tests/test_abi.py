@@ -67,3 +67,17 @@ def test_null_arguments_are_rejected_without_a_gpu(lib):
     assert L.rgc_align_end(None, None, None, None, None, None, None) == -1
     assert L.rgc_share_target(None, None) == -1
     assert L.rgc_align(None, g, None, None, None, None, None, None) == -1
+
+
+def test_knob_inventory_is_current():
+    """rgc-slam_amd/csrc/KNOBS.md lists every build flag (#ifndef RGC_X / #define RGC_X default) and every environment variable of the library as the
+    sources define them now (scripts/make_knobs.py regenerates it), and README.md names every environment variable."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "make_knobs.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr or r.stdout
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import make_knobs
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    assert [n for n, _ in make_knobs.env_vars() if n not in readme] == []
+    assert len(make_knobs.build_flags()) >= 30
