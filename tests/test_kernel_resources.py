@@ -37,3 +37,18 @@ def test_register_allocation_admits_the_launched_occupancy():
     assert m.waves_per_simd(ks["k_lm_step"]) >= 3 and ks["k_lm_step"]["lds"] <= 64 * 1024
     for n in ("k_count<true>", "k_place", "k_rank_gather", "k_cells_reduce", "k_transform_q"):    # the streaming passes: full occupancy
         assert m.waves_per_simd(ks[n]) == 8, n
+
+
+def test_the_in_tree_library_is_what_the_sources_build_to(tmp_path):
+    """A from-scratch build of the committed sources (RGC_LIB_OUT: beside the product, about a minute of hipcc) holds the same gfx950 device code as the
+    in-tree librgc_hip.so the GPU tests, smoke() and bench.py load: .text of every code object by SHA-256, every kernel's registers / LDS / scratch
+    (scripts/same_device_code.py).  A library left over from other sources, or from a build with RGC_EXTRA_FLAGS, fails here and not on the GPU box."""
+    import subprocess
+    import sys
+    out = tmp_path / "librgc_rebuild.so"
+    env = dict(os.environ, RGC_LIB_OUT=str(out))
+    env.pop("RGC_EXTRA_FLAGS", None)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "rgc-slam_amd", "build.py"), "--force"], env=env, stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "same_device_code.py"), os.path.join(ROOT, "rgc-slam_amd", "librgc_hip.so"), str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
