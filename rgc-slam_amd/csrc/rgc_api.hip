@@ -1658,6 +1658,7 @@ int rgc_set_params(rgc_ctx* c, const rgc_params* p) {
   if (rc) return rc;
   const bool redo = p->voxel_res != c->prm.voxel_res || p->k_correspondences != c->prm.k_correspondences;
   if (redo && solve_in_flight(c)) return fail(c, RGC_ERR_INVALID, "a solve is in flight on this context: call rgc_align_end first");  // (the clouds are prepared again below)
+  if (redo) HIPCHK(c, hipSetDevice(c->device));  // (the re-preparation launches kernels: like every entry point that does, whatever device the calling thread had current)
   if (p->voxel_res != c->prm.voxel_res) c->src_res_auto = 0.0;
   c->prm = *p;
   c->corr_valid = false;
@@ -3123,6 +3124,7 @@ int rgc_frontend_cloud_device(rgc_ctx* c, float** d_cloud, int* n) {
 
 int rgc_get_stats(rgc_ctx* c, rgc_stats* out) {
   if (!c || !out) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));  // (a tripped guard or a lazy target is resolved below: kernels)
   { int rc = validate_clouds(c, /*whole_target=*/false); if (rc) return rc; }
   if (c->tgt.ready) { int rc = fetch_nvox(c); if (rc) return rc; }
   // queries the bulk kNN kernel handed to the cooperative kernel (first int of the deferred-list buffer)
@@ -3248,6 +3250,7 @@ int rgc_profile_select(rgc_ctx* c, unsigned kind_mask) {
 }
 int rgc_profile_reset(rgc_ctx* c) {
   if (!c) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   prof_collect(c);
@@ -3256,6 +3259,7 @@ int rgc_profile_reset(rgc_ctx* c) {
 }
 int rgc_profile_get(rgc_ctx* c, int kind, long long* launches, double* total_ms, long long* total_points) {
   if (!c || kind < 0 || kind >= kProfKinds) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   prof_collect(c);

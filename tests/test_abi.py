@@ -81,3 +81,41 @@ def test_knob_inventory_is_current():
     readme = open(os.path.join(ROOT, "README.md")).read()
     assert [n for n, _ in make_knobs.env_vars() if n not in readme] == []
     assert len(make_knobs.build_flags()) >= 30
+
+
+def test_every_entry_point_selects_its_device():
+    """One process may hold contexts on several GPUs and call them from threads whose current device is another one (a new thread starts on device 0).
+    A static audit of csrc/rgc_api.hip, where every entry point lives: each exported rgc_* function from which a HIP runtime call or a kernel launch can
+    be reached calls hipSetDevice(c->device) itself or in a function it calls directly.  (A one-GPU box cannot show the difference; round 6 found
+    rgc_set_params and rgc_get_stats re-preparing clouds -- kernel launches -- on whatever device the caller's thread had current.)"""
+    import re
+    src = open(os.path.join(ROOT, "rgc-slam_amd", "csrc", "rgc_api.hip")).read()
+    funcs = {}
+    for m in re.finditer(r'^(?:extern "C" )?(?:RGC_API |static |inline )*[\w:<>\*& ]+?\b(\w+)\s*\(([^;{}]*?)\)\s*(?:const\s*)?\{', src, re.M):
+        if m.group(1) in ("for", "if", "while", "switch", "catch"):
+            continue
+        i, depth = m.end(), 1
+        while depth and i < len(src):
+            depth += (src[i] == "{") - (src[i] == "}")
+            i += 1
+        funcs.setdefault(m.group(1), src[m.end():i])
+    hip_call = re.compile(r"\bhip(?!SetDevice|Success|Error|GetErrorString|GetLastError|Stream_t|Event_t)[A-Z]\w*\s*\(|<<<|hipLaunchKernelGGL|hipExtLaunch")
+
+    def reaches_hip(name, seen=frozenset()):
+        body = funcs.get(name)
+        if body is None or name in seen:
+            return False
+        return bool(hip_call.search(body)) or any(reaches_hip(c, seen | {name}) for c in set(re.findall(r"\b(\w+)\s*\(", body)) if c in funcs and c != name)
+
+    exported = [n for n in funcs if n.startswith("rgc_")]
+    assert len(exported) >= 75
+    no_context = {"rgc_host_alloc", "rgc_host_free"}                    # pinned host memory, hipHostMallocPortable: no context in the signature
+    bad = []
+    for n in exported:
+        if n in no_context or n.startswith("rgc_lab_") or not reaches_hip(n):
+            continue
+        body = funcs[n]
+        if "hipSetDevice" in body or any("hipSetDevice" in funcs[c] for c in set(re.findall(r"\b(\w+)\s*\(", body)) if c in funcs and c != n):
+            continue
+        bad.append(n)
+    assert bad == [], bad
