@@ -9,7 +9,9 @@
  *   the device before the call returns); the context owns all device memory, its HIP stream and events.
  * Threading: a context is NOT thread-safe and is bound to one HIP device; use one context per
  *   sequence / GPU, driven by one host thread (the reference drives registration from the single
- *   ICP_thread, src/RGC_odometer.cpp:408).
+ *   ICP_thread, src/RGC_odometer.cpp:408).  Every entry point that reaches the HIP runtime selects the context's
+ *   device first (hipSetDevice) and leaves it current on return: a process may hold contexts on several GPUs and
+ *   call each from a thread of its own, whatever device that thread had current (tests/test_abi.py audits it).
  * Errors: 0 = OK, negative = rgc_status; nothing aborts or throws across this boundary (the reference
  *   prints "lm not converged!!" and carries on, lsq_registration_impl.hpp:69-72; here that is the
  *   `lm_failed` output).  rgc_last_error() returns a human-readable message for the last failure.
