@@ -119,3 +119,15 @@ def test_every_entry_point_selects_its_device():
             continue
         bad.append(n)
     assert bad == [], bad
+
+
+def test_integration_names_every_entry_point():
+    """INTEGRATION.md's appendix (scripts/make_abi_index.py, generated from include/rgc_hip.h) is current and names every symbol the header declares."""
+    import re
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "make_abi_index.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr or r.stdout
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    syms = set(re.findall(r"\b(rgc_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "rgc_hip.h")).read()))
+    assert len(syms) >= 85 and [s for s in sorted(syms) if "`" + s + "`" not in doc] == []
