@@ -1987,6 +1987,7 @@ int rgc_align_begin(rgc_ctx* c, const float guess[16], int want_fitness) {
 
 int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fitness, int* iterations, int* converged, int* lm_failed) {
   if (!c) return RGC_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));  // (before the general route's score below, too)
   if (c->gen_res.on) {  // general route: solved in rgc_align_begin
     auto& g = c->gen_res;
     g.on = false;
@@ -1999,7 +2000,6 @@ int rgc_align_end(rgc_ctx* c, float final_T[16], double final_H[36], double* fit
     return RGC_OK;
   }
   if (!c->pend.active) return fail(c, RGC_ERR_INVALID, "rgc_align_end without rgc_align_begin");
-  HIPCHK(c, hipSetDevice(c->device));
   c->pend.active = false;
   int rc;
   const bool want_fitness = c->pend.want_fitness;

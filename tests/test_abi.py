@@ -119,6 +119,30 @@ def test_every_entry_point_selects_its_device():
             continue
         bad.append(n)
     assert bad == [], bad
+    # ... and selects it BEFORE the first launch or allocation it can reach, in the order of the text (rgc_align_end scored the general route's pose first)
+    device_work = re.compile(r"<<<|hipLaunchKernelGGL|hipExtLaunch|hipMalloc\b|hipMallocAsync|hipFree\b|hipEventCreate|hipStreamCreate|hipMemset")
+
+    def launches(name, seen=frozenset()):
+        body = funcs.get(name)
+        if body is None or name in seen:
+            return False
+        return bool(device_work.search(body)) or any(launches(c, seen | {name}) for c in set(re.findall(r"\b(\w+)\s*\(", body)) if c in funcs and c != name)
+
+    late = []
+    for n in exported:
+        if n in no_context or n.startswith("rgc_lab_"):
+            continue
+        first_set = first_work = None
+        for m in re.finditer(r"\b(\w+)\s*\(|<<<", funcs[n]):
+            tok = m.group(1) or "<<<"
+            sets_it = tok == "hipSetDevice" or (tok in funcs and "hipSetDevice" in funcs[tok])
+            if sets_it and first_set is None:
+                first_set = m.start()
+            if first_work is None and not sets_it and (tok == "<<<" or device_work.match(tok) or (tok in funcs and tok != n and launches(tok))):
+                first_work = m.start()
+        if first_work is not None and (first_set is None or first_work < first_set):
+            late.append(n)
+    assert late == [], late
 
 
 def test_integration_names_every_entry_point():
