@@ -155,3 +155,114 @@ def test_integration_names_every_entry_point():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     syms = set(re.findall(r"\b(rgc_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "rgc_hip.h")).read()))
     assert len(syms) >= 85 and [s for s in sorted(syms) if "`" + s + "`" not in doc] == []
+
+
+def test_python_mirror_prototypes_match_the_header(lib):
+    """The ctypes prototypes the tests and bench.py call through (rgc_slam_amd/_lib.py) against include/rgc_hip.h: every declared function has argtypes,
+    as many as the header's parameters, pointer where the header has a pointer or an array and scalar where it has a scalar (a mismatch is silent in ctypes)."""
+    L = lib.load()
+    h = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rgc_hip.h")).read(), flags=re.S)
+    checked = 0
+    for m in re.finditer(r"RGC_API\s+[\w\s\*]+?\b(rgc_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", h, re.S):
+        name, args = m.group(1), m.group(2).strip()
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        f = getattr(L, name)
+        if not params:
+            assert not f.argtypes, name
+            continue
+        assert f.argtypes is not None and len(f.argtypes) == len(params), (name, len(params), f.argtypes)
+        for p, t in zip(params, f.argtypes):
+            is_ptr = "*" in p or "[" in p
+            t_ptr = t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or issubclass(t, (C._Pointer, C.Array)) or (hasattr(t, "_type_") and not isinstance(t._type_, str))
+            assert is_ptr == bool(t_ptr), (name, p, t)
+            if not is_ptr and re.match(r"(const\s+)?(double|float)\b", p):
+                assert t in (C.c_double, C.c_float) and (t is C.c_double) == ("double" in p), (name, p, t)
+        checked += 1
+    assert checked >= 80
+
+
+def test_python_mirror_struct_layouts_match_the_header(lib, tmp_path):
+    """sizeof and every field's offset of the ctypes Structures (rgc_slam_amd/_lib.py) against the C compiler's view of include/rgc_hip.h's structs
+    (a generated C program prints offsetof for each field, in the header's order)."""
+    import subprocess
+    pairs = {"rgc_params": lib.Params, "rgc_stats": lib.Stats, "rgc_fuse_in": lib.FuseIn, "rgc_imu_filter": lib.ImuFilter, "rgc_ground_gate": lib.GroundGate,
+             "rgc_fe_params": lib.FeParams, "rgc_fe_out": lib.FeOut, "rgc_mapreg_report": lib.MapregReport, "rgc_icp_params": lib.IcpParams,
+             "rgc_icp_result": lib.IcpResult, "rgc_pc2_layout": lib.Pc2Layout, "rgc_pc2_field": lib.Pc2Field, "rgc_mapreg_ground": lib.MapregGround,
+             "rgc_mapreg_imu": lib.MapregImu, "rgc_map_info": lib.MapInfo}
+    h = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rgc_hip.h")).read(), flags=re.S)
+    fields = {}
+    for m in re.finditer(r"typedef struct (rgc_\w+)\s*\{(.*?)\}\s*\1\s*;", h, re.S):
+        names = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if decl:
+                for part in decl.split(","):          # `double a, b[3]` declares two fields
+                    names.append(re.sub(r"\[.*", "", part.strip().split()[-1].lstrip("*")))
+        fields[m.group(1)] = names
+    assert set(pairs) <= set(fields), sorted(set(pairs) - set(fields))
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "rgc_hip.h"', "int main(void) {"]
+    for s, names in fields.items():
+        if s in pairs:
+            src.append(f'  printf("{s} %zu", sizeof({s}));')
+            src += [f'  printf(" %zu", offsetof({s}, {n}));' for n in names]
+            src.append('  printf("\\n");')
+    src += ["  return 0;", "}"]
+    (tmp_path / "layout.c").write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(tmp_path / "layout.c"), "-o", str(tmp_path / "layout")])
+    out = subprocess.run([str(tmp_path / "layout")], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        s, size, *offs = line.split()
+        cls = pairs[s]
+        assert C.sizeof(cls) == int(size), (s, C.sizeof(cls), size)
+        assert [getattr(cls, f[0]).offset for f in cls._fields_] == [int(o) for o in offs], (s, [f[0] for f in cls._fields_], fields[s])
+        seen += 1
+    assert seen == len(pairs)
+
+
+def test_oracle_mirror_matches_its_header(tmp_path):
+    """The checker's own binding (oracle/oracle.py over oracle/rgc_oracle.h) held to the same two checks: a ctypes mismatch in the ORACLE would corrupt what
+    every parity test compares against.  Prototypes: count, pointer / scalar, float / double.  Structs: sizeof and every field's offset."""
+    import subprocess
+    from oracle import oracle as orc
+    L = orc.lib()
+    h = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "oracle", "rgc_oracle.h")).read(), flags=re.S)
+    checked = 0
+    for m in re.finditer(r"^\s*([\w\s\*]+?)\b(orc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h, re.S | re.M):
+        name, args = m.group(2), m.group(3).strip()
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        f = getattr(L, name)
+        assert f.argtypes is not None and len(f.argtypes) == len(params), (name, len(params), f.argtypes)
+        for p, t in zip(params, f.argtypes):
+            is_ptr = "*" in p or "[" in p
+            t_ptr = t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or (hasattr(t, "_type_") and not isinstance(t._type_, str))
+            assert is_ptr == bool(t_ptr), (name, p, t)
+            if not is_ptr and re.match(r"(const\s+)?(double|float)\b", p):
+                assert (t is C.c_double) == ("double" in p) and t in (C.c_double, C.c_float), (name, p, t)
+        checked += 1
+    assert checked >= 40
+    pairs = {"orc_params": orc.Params, "orc_lm_trace": orc.LmTrace, "orc_fe_params": orc.FeParams, "orc_fe_out": orc.FeOut, "orc_edge_factor": orc.EdgeFactor,
+             "orc_plane_factor": orc.PlaneFactor, "orc_mapreg_trace": orc.MapregTrace, "orc_mapreg_ground": orc.MapregGround, "orc_mapreg_imu": orc.MapregImu,
+             "orc_icp_params": orc.IcpParams, "orc_icp_result": orc.IcpResult}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "rgc_oracle.h"', "int main(void) {"]
+    for m in re.finditer(r"typedef struct\s*\{(.*?)\}\s*(orc_\w+)\s*;", h, re.S):
+        if m.group(2) not in pairs:
+            continue
+        names = []
+        for decl in m.group(1).split(";"):
+            if decl.strip():
+                for part in decl.strip().split(","):
+                    names.append(re.sub(r"\[.*", "", part.strip().split()[-1].lstrip("*")))
+        src.append(f'  printf("{m.group(2)} %zu", sizeof({m.group(2)}));')
+        src += [f'  printf(" %zu", offsetof({m.group(2)}, {n}));' for n in names]
+        src.append('  printf("\\n");')
+    src += ["  return 0;", "}"]
+    (tmp_path / "layout.c").write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "oracle"), str(tmp_path / "layout.c"), "-o", str(tmp_path / "layout")])
+    out = subprocess.run([str(tmp_path / "layout")], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(out) == len(pairs)
+    for line in out:
+        s, size, *offs = line.split()
+        cls = pairs[s]
+        assert C.sizeof(cls) == int(size), (s, C.sizeof(cls), size)
+        assert [getattr(cls, f[0]).offset for f in cls._fields_] == [int(o) for o in offs], (s, [f[0] for f in cls._fields_])
