@@ -66,6 +66,7 @@ public:
   void setEuclideanFitnessEpsilon(double) {}     // no-op in LsqRegistration
   void setRANSACIterations(int) {}               // no-op
   void setNumThreads(int) {}                     // CPU threads of the reference; nothing to set on the GPU
+  void setDebugPrint(bool) {}                    // LsqRegistration::setDebugPrint (lsq_registration.hpp:53, impl :38-40): the LM trace on stdout (:59, :147); accepted, nothing is printed
 
   // ---- clouds ----
   void setInputTarget(const float* xyz, int n, int stride_bytes) { params(); chk(rgc_set_target(ctx_, xyz, n, stride_bytes)); n_tgt_ = n; fit_valid_ = false; }

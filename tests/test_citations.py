@@ -16,3 +16,20 @@ def test_reference_citations_resolve():
     assert r.returncode == 0, r.stdout[-3000:]
     n = int(r.stdout.split()[0])
     assert n >= 600, r.stdout[:300]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only present in the build container")
+def test_the_adaptor_has_every_public_method_of_the_reference_classes():
+    """rgc::FastVGICPHip (rgc-slam_amd/cpp/fast_vgicp_hip.hpp) against the public setters / getters / actions of the classes it stands in for
+    (fast_gicp::FastVGICP, FastGICP, LsqRegistration: the names read from the reference's headers) and the pcl::Registration calls of the odometer's
+    call site (RGC_odometer.cpp:1000-1011): a user of the reference finds every method name."""
+    import glob
+    import re
+    mine = set(re.findall(r"\b(set\w+|get\w+|clear\w+|swap\w+|align\w*|hasConverged)\s*\(", open(os.path.join(ROOT, "rgc-slam_amd", "cpp", "fast_vgicp_hip.hpp")).read()))
+    wanted = {"setMaximumIterations", "setMaxCorrespondenceDistance", "setTransformationEpsilon", "setEuclideanFitnessEpsilon", "setRANSACIterations", "setInputTarget",
+              "setInputSource", "align", "getFitnessScore", "getFinalTransformation", "hasConverged"}
+    for f in ("fast_vgicp.hpp", "fast_gicp.hpp", "lsq_registration.hpp"):
+        paths = [p for p in glob.glob("/root/reference/**/" + f, recursive=True) if "cuda" not in p]
+        assert paths, f
+        wanted |= set(re.findall(r"\b(set\w+|get\w+|clear\w+|swap\w+)\s*\(", open(paths[0]).read()))
+    assert sorted(wanted - mine) == []
