@@ -103,6 +103,9 @@ class FastVGICP:
     def setNumThreads(self, n):                      # fast_gicp_impl.hpp:29-37: CPU threads; nothing to set on the GPU
         self._num_threads = int(n)
 
+    def setDebugPrint(self, on):                     # lsq_registration.hpp:53 (the LM trace on stdout, impl :59, :147): accepted, nothing is printed
+        self._debug_print = bool(on)
+
     # -- clouds ----------------------------------------------------------------------------------
     def setInputTarget(self, cloud):                 # fast_vgicp_impl.hpp:56-63
         a = _f32c(cloud)

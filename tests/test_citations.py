@@ -33,3 +33,5 @@ def test_the_adaptor_has_every_public_method_of_the_reference_classes():
         assert paths, f
         wanted |= set(re.findall(r"\b(set\w+|get\w+|clear\w+|swap\w+)\s*\(", open(paths[0]).read()))
     assert sorted(wanted - mine) == []
+    python_mirror = set(re.findall(r"def (\w+)\(", open(os.path.join(ROOT, "rgc-slam_amd", "registration.py")).read()))     # the same names in the Python mirror
+    assert sorted(wanted - python_mirror) == []
