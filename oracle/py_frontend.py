@@ -2,8 +2,8 @@
 (/root/reference/rgc_slam/src/scanRegistration.cpp), written from the reference text line by line in numpy float32 / Python
 scalars, to pin oracle/rgc_oracle_aux.c (orc_frontend): A3 range / incidence / near-intensity smoothing (:234-268), A4 curvature
 stencils (:270-306), A6 occlusion mask (:433-456), A7 per-sector sort and greedy selection (:469-644) and the intensity append of
-:645-656, and (round 6) A5, the ground marking and the weighted plane fit (:308-431, `ground` below).  The ring bucket (A2) is an
-input here (pinned by the sensor-model properties in tests/test_oracle_frontend.py).  Plain loops: use on small sweeps only.  Per-frame arrays start at zero and
+:645-656, and (round 6) A5, the ground marking and the weighted plane fit (:308-431, `ground` below) and A2, the ring bucket (:116-230,
+`ring_bucket` below; also pinned by the sensor-model properties in tests/test_oracle_frontend.py).  Plain loops: use on small sweeps only.  Per-frame arrays start at zero and
 std::sort's unspecified tie order is fixed as ascending index (item 10), like every other implementation in this repository.
 PARITY UNPINNED: the reference holds no vectors for this stage and cannot be built here; this is the builder's second restatement.
 """
@@ -164,6 +164,88 @@ def select(cloud, st, picked_in, ground_marked, scan_start, scan_end, use_intens
     arr = lambda v: np.array(v, np.float32).reshape(-1, 5)
     return dict(label=label, inten_label=ilabel, picked=picked, ipicked=ipicked, sharp=arr(sharp), flat=arr(flat), inten=arr(inten),
                 n_sharp_own=n_sharp_own)
+
+
+def _libm():
+    """glibc's single-precision atan2f / atanf / sqrtf: what `atan2(float, float)`, `atan(float)` and `sqrt(float)` resolve to in the reference's C++
+    (libstdc++'s <cmath> float overloads) on its x86-64 build -- numpy's float32 arctan2 is another implementation and may differ in the last bit"""
+    import ctypes as C
+    m = C.CDLL("libm.so.6")
+    for f in (m.atan2f, m.atanf, m.sqrtf):
+        f.restype = C.c_float
+    m.atan2f.argtypes = [C.c_float, C.c_float]
+    m.atanf.argtypes = [C.c_float]
+    m.sqrtf.argtypes = [C.c_float]
+    return m
+
+
+def ring_bucket(raw_xyzi, n_scans=16, scan_period=0.1):
+    """A2, :116-230 restated statement by statement: start / end orientation, per point the vertical angle -> scanID (the three N_SCANS formulas,
+    their mixed float / double arithmetic as C++ promotes it), the orientation with the halfPassed logic, relTime, intensity = scanID + scanPeriod *
+    relTime, the push into laserCloudScans[scanID] / intensityScans[scanID]; then the concatenation in ring order with scanStartInd / scanEndInd.
+    raw_xyzi: (n, 4) float32 AFTER the A1 filter (removeNaN + removeClosedPointCloud).  Returns dict(cloud (m, 4) float32, intensity_num (m,) int64 --
+    `int point_intensity = ...intensity` truncates --, ring_count, scan_start, scan_end).  Plain loop: small sweeps."""
+    import math
+    m = _libm()
+    P = np.asarray(raw_xyzi, np.float32)
+    n = len(P)
+    PI = math.pi
+    startOri = f32(-m.atan2f(float(P[0, 1]), float(P[0, 0])))                                   # :117
+    endOri = f32(float(f32(-m.atan2f(float(P[n - 1, 1]), float(P[n - 1, 0])))) + 2 * PI)        # :118 (float + double -> float)
+    if float(f32(endOri - startOri)) > 3 * PI:                                                   # :120-127
+        endOri = f32(float(endOri) - 2 * PI)
+    elif float(f32(endOri - startOri)) < PI:
+        endOri = f32(float(endOri) + 2 * PI)
+    halfPassed = False
+    scans = [[] for _ in range(n_scans)]
+    inten = [[] for _ in range(n_scans)]
+    for i in range(n):
+        x, y, z = P[i, 0], P[i, 1], P[i, 2]
+        point_intensity = int(P[i, 3])                                                           # :140 (float -> int truncates)
+        hyp = f32(m.sqrtf(float(f32(f32(x * x) + f32(y * y)))))                                  # :142: sqrt(x * x + y * y) in float
+        va = f32(float(f32(m.atanf(float(f32(z / hyp))))) * 180 / PI)                            #       atan(float) in float, * 180 / M_PI in double, stored float
+        if n_scans == 16:
+            scanID = int(float(f32(f32(va + f32(15)) / f32(2))) + 0.5)                           # :147 (float, float, then + 0.5 in double)
+            if scanID > n_scans - 1 or scanID < 0:
+                continue
+        elif n_scans == 32:
+            scanID = int((float(va) + 92.0 / 3.0) * 3.0 / 4.0)                                   # :156 (all double)
+            if scanID > n_scans - 1 or scanID < 0:
+                continue
+        elif n_scans == 64:
+            if float(va) >= -8.83:                                                               # :165-172
+                scanID = int(float(f32(f32(2) - va)) * 3.0 + 0.5)
+            else:
+                scanID = n_scans // 2 + int((-8.83 - float(va)) * 2.0 + 0.5)
+            if float(va) > 2 or float(va) < -24.33 or scanID > 50 or scanID < 0:
+                continue
+        else:
+            raise ValueError("wrong scan number")
+        ori = f32(-m.atan2f(float(y), float(x)))                                                 # :187
+        if not halfPassed:
+            if float(ori) < float(startOri) - PI / 2:
+                ori = f32(float(ori) + 2 * PI)
+            elif float(ori) > float(startOri) + PI * 3 / 2:
+                ori = f32(float(ori) - 2 * PI)
+            if float(f32(ori - startOri)) > PI:
+                halfPassed = True
+        else:
+            ori = f32(float(ori) + 2 * PI)
+            if float(ori) < float(endOri) - PI * 3 / 2:
+                ori = f32(float(ori) + 2 * PI)
+            elif float(ori) > float(endOri) + PI / 2:
+                ori = f32(float(ori) - 2 * PI)
+        relTime = f32(f32(ori - startOri) / f32(endOri - startOri))                              # :207
+        scans[scanID].append((x, y, z, f32(scanID + scan_period * float(relTime))))              # :210 (int + double * float -> float)
+        inten[scanID].append(point_intensity)
+    cloud, inum, scan_start, scan_end = [], [], [], []
+    for r in range(n_scans):                                                                     # :222-230
+        scan_start.append(len(cloud) + 5)
+        cloud += scans[r]
+        inum += inten[r]
+        scan_end.append(len(cloud) - 5)
+    return dict(cloud=np.array(cloud, np.float32).reshape(-1, 4), intensity_num=np.array(inum, np.int64), ring_count=np.array([len(q) for q in scans], np.int32),
+                scan_start=np.array(scan_start, np.int32), scan_end=np.array(scan_end, np.int32))
 
 
 GROUND_SCAN_IND = 7            # groundScanInd, :34

@@ -1,7 +1,7 @@
 """Randomised pinning of the C ORACLE's front-end (oracle/rgc_oracle_aux.c: orc_frontend, scanRegistration.cpp:98-660) against the literal numpy
 restatement it was first checked with on one committed sweep (oracle/py_frontend.py -> tests/golden/fx_frontend.npz): random synthetic sweeps --
 16 / 32 / 64 beams, tilted and displaced sensor poses, near grazing returns (the intensity-smoothing branch), painted intensity stripes (the
-intensity corners), junk returns the A1 filter must drop -- ring bucket, the three curvature arrays bit for bit, occlusion / suppression flags,
+intensity corners), junk returns the A1 filter must drop -- the ring bucket with its encoded ring + relTime (A2, bit for bit), the three curvature arrays bit for bit, occlusion / suppression flags,
 ground marks, ground points in push order, the ground plane, labels, and the three feature clouds (points, order, weights).  No GPU.
     python tests/fuzz/fuzz_oracle_pin_frontend.py [trials] [seed]"""
 import sys, os, json, time
@@ -75,6 +75,16 @@ for trial in range(trials):
                 rep["failures"].append(dict(tag, error="ring bucket (64 beams)"))
                 rep["trials"] += 1
                 continue
+        # A2 by the literal restatement (:116-230, glibc's float libm like the reference's build): the bucket, the encoded ring + relTime, the int intensities
+        rb = pf.ring_bucket(raw, beams)
+        if rb["cloud"].shape != o["cloud"].shape or not np.array_equal(rb["cloud"], o["cloud"]):
+            rep["failures"].append(dict(tag, error="A2 cloud (x, y, z, ring + 0.1 relTime)", c=list(o["cloud"].shape), py=list(rb["cloud"].shape)))
+        elif not (np.array_equal(rb["ring_count"], o["ring_count"][:beams]) and np.array_equal(rb["scan_start"], o["scan_start"][:beams]) and np.array_equal(rb["scan_end"], o["scan_end"][:beams])):
+            rep["failures"].append(dict(tag, error="A2 ring counts / scanStartInd / scanEndInd"))
+        elif not np.array_equal(rb["intensity_num"], raw[order, 3].astype(np.int64)):
+            rep["failures"].append(dict(tag, error="A2 intensity_num"))
+        else:
+            rep["ring_buckets_bit_for_bit"] = rep.get("ring_buckets_bit_for_bit", 0) + 1
         st = pf.stencils(o["cloud"][:, :3], raw[order, 3].astype(np.int64))
         for k in ("curvature", "curvature2", "inten_curvature"):
             if not np.array_equal(st[k], o[k]):

@@ -28,6 +28,7 @@ def test_fuzz_of_the_oracle_front_end_against_its_literal_restatement():
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["trials"] == 40 and rep["failures"] == [], rep["failures"][:5]
     assert set(rep["by_beams"]) == {"16", "32", "64"} and rep["with_ground_plane"] >= 10 and rep["smoothing_branch_ran"] >= 5
+    assert rep["ring_buckets_bit_for_bit"] == 40          # A2 against oracle/py_frontend.ring_bucket, glibc's float libm on both sides
     assert rep["max"]["ground_normal"] < 1e-7 and rep["max"]["ground_distance"] < 1e-8
 
 
