@@ -1,7 +1,7 @@
 """Randomised pinning of the C ORACLE itself (oracle/rgc_oracle*.c) against the literal numpy / scipy restatements it was first checked with on
 fixed fixtures (oracle/py_oracle.py: cKDTree kNN, numpy SVD, 4x4 homogeneous matrices as the reference writes them): random small clouds --
 the synthetic world, uniform noise, sheets -- k, leaf sizes, every regularisation and accumulation mode, DIRECT1 / DIRECT7 / DIRECT27:
-neighbour sets, covariances, voxel tables, a linearisation, the LM trajectory's end and the fitness; and the leaf filter.  No GPU.
+neighbour sets, covariances, voxel tables, a linearisation, the LM trajectory's end and the fitness; the leaf filter; de-skew and re-framing against scipy.  No GPU.
     python tests/fuzz/fuzz_oracle_pin.py [trials] [seed]"""
 import sys, os, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 REG = ["NONE", "MIN_EIG", "NORMALIZED_MIN_EIG", "PLANE", "FROBENIUS"]
 MODE = ["ADDITIVE", "ADDITIVE_WEIGHTED", "MULTIPLICATIVE"]
 METH = ["DIRECT27", "DIRECT7", "DIRECT1"]     # enum order of gicp_settings.hpp:8
-rep = {"trials": 0, "failures": [], "max": {"cov": 0.0, "vox_mean": 0.0, "vox_cov": 0.0, "H_rel": 0.0, "b_rel": 0.0, "cost_rel": 0.0, "pose": 0.0, "fitness_rel": 0.0, "leaf_filter": 0.0}}
+rep = {"trials": 0, "failures": [], "max": {"cov": 0.0, "vox_mean": 0.0, "vox_cov": 0.0, "H_rel": 0.0, "b_rel": 0.0, "cost_rel": 0.0, "pose": 0.0, "fitness_rel": 0.0, "leaf_filter": 0.0, "deskew": 0.0, "transform": 0.0}}
 
 
 def note(k, v):
@@ -99,6 +99,24 @@ for trial in range(trials):
                 note("fitness_rel", fr)
                 if not fr <= 1e-4:
                     rep["failures"].append(dict(tag, error="fitness", c=float(fo), py=float(fp_)))
+        # ---- B2 adjustDistortion (RGC_odometer.cpp:1441-1481) and B9 transformPointCloud (:1495-1514) against scipy's Rotation / Slerp ----
+        from scipy.spatial.transform import Rotation as Rot, Slerp
+        m_pts = min(n, 600)
+        pts = tgt[:m_pts]
+        ring, rel = rng.integers(0, 16, m_pts), rng.uniform(0, 1, m_pts)
+        inten = (ring + 0.1 * rel).astype(np.float32)
+        cloud = np.ascontiguousarray(np.c_[pts, inten], np.float32)
+        qd = Rot.from_rotvec(rng.normal(0, 0.03, 3))
+        td = rng.normal(0, 0.1, 3)
+        out = orc.deskew(cloud, qd.as_quat(), td)
+        sfrac = 1.0 - (inten.astype(np.float64) - np.floor(inten.astype(np.float64))) / 0.1
+        qs = Slerp([0.0, 1.0], Rot.from_quat(np.stack([[0, 0, 0, 1.0], qd.inv().as_quat()])))(np.clip(sfrac, 0.0, 1.0))
+        e_ds = float(np.abs(out[:, :3] - qs.apply(pts.astype(np.float64) - sfrac[:, None] * td).astype(np.float32)).max())
+        tw = orc.transform_cloud(cloud, qd.as_quat(), td)
+        e_tf = float(np.abs(tw[:, :3] - (qd.apply(pts.astype(np.float64)) + td).astype(np.float32)).max())
+        note("deskew", e_ds); note("transform", e_tf)
+        if not (e_ds < 4e-6 and e_tf < 4e-6 and np.array_equal(out[:, 3], inten) and np.array_equal(tw[:, 3], inten)):     # (fp32 results of points up to ~20 m: an ulp is 2e-6)
+            rep["failures"].append(dict(tag, error="de-skew / transform", deskew=e_ds, transform=e_tf))
         # ---- the leaf filter ----
         xyzi = np.c_[tgt, rng.uniform(0, 16, n)].astype(np.float32)
         leaf = float(rng.choice([0.2, 0.3, 0.5, 1.0]))
